@@ -1,0 +1,49 @@
+"""CPU: the oracle (our restatement) reproduces the golden vectors produced by running the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_mel_oracle_matches_reference_golden(golden_dir):
+    from oracle import mel as omel
+    g = np.load(os.path.join(golden_dir, "mel.npz"))
+    y = torch.from_numpy(g["wav"])
+    assert torch.equal(omel.mel_m1(y), torch.from_numpy(g["m1"]))
+    ys = torch.from_numpy(g["wav_seg"])
+    assert torch.equal(omel.mel_m2(ys, fmax=8000), torch.from_numpy(g["m2_fmax8000"]))
+    assert torch.equal(omel.mel_m2(ys, fmax=None), torch.from_numpy(g["m2_fmaxNone"]))
+
+
+def test_slaney_filterbank_known_answers(golden_dir):
+    """librosa filters.mel is un-vendored (parity unpinned): check the published algorithm's invariants."""
+    from oracle import mel as omel
+    w = omel.slaney_mel_filterbank(22050, 1024, 80, 0.0, 8000.0)
+    assert w.shape == (80, 513) and w.dtype == np.float32 and (w >= 0).all()
+    for row in w:
+        nz = np.nonzero(row)[0]
+        assert len(nz) > 0 and (np.diff(nz) == 1).all()          # contiguous triangular support
+    peaks = w.argmax(1)
+    assert (np.diff(peaks) > 0).all()                              # centre frequencies increase
+    assert w[:, 372:].sum() == 0                                   # nothing above fmax=8000 Hz (bin 371.5)
+    g = np.load(os.path.join(golden_dir, "mel.npz"))
+    assert np.array_equal(w, g["mel_basis_8000"])
+
+
+def test_host_mel_constants_match_oracle():
+    """The product's own filterbank / DFT basis builders (xva-trainer_amd/mel.py) equal the oracle's."""
+    from oracle import mel as omel
+    from xva_trainer_amd import mel as pmel
+    assert np.array_equal(pmel.librosa_mel_fn(22050, 1024, 80, 0.0, 8000.0), omel.slaney_mel_filterbank(22050, 1024, 80, 0.0, 8000.0))
+    assert np.array_equal(pmel.librosa_mel_fn(22050, 1024, 80, 0, None), omel.slaney_mel_filterbank(22050, 1024, 80, 0, None))
+    b = pmel._dft_basis(1024, pmel._hann_periodic(1024))
+    assert torch.equal(b, omel.stft_forward_basis(1024, 1024)[:, 0, :])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/python"), reason="reference tree only exists in the build container")
+def test_mel_oracle_matches_live_reference():
+    from oracle import mel as omel, ref_import
+    ns = ref_import.import_reference()
+    y = torch.from_numpy(np.stack([omel.synth_wave(9000, 77), omel.synth_wave(9000, 78)]))
+    assert torch.equal(ns.TacotronSTFT().mel_spectrogram(y), omel.mel_m1(y))

@@ -1,0 +1,144 @@
+// mel.hip — mel-spectrogram front end (STFT + mel filterbank + dynamic-range compression).
+//
+// Reference (three variants of one pipeline, see include/xva_hip.h for the knobs):
+//   M1 TacotronSTFT.mel_spectrogram   python/fastpitch1_1/common/layers.py:121-138,
+//      STFT.transform                 python/fastpitch1_1/common/stft.py:86-114,
+//      dynamic_range_compression      python/fastpitch1_1/common/audio_processing.py:105-111
+//   M2 mel_spectrogram                python/hifigan/meldataset.py:217-240
+//   M3 TorchSTFT.__call__             python/xvapitch/audio.py:138-181
+//
+// MI355X mapping: the reference's own formulation (a strided conv1d with a windowed DFT
+// basis) is a GEMM whose A operand is the reflect-padded waveform read with OVERLAPPING rows
+// (lda = hop, K = n_fft), so frames are never materialised: each sample is read from HBM
+// once per K-tile pass and lives in L2/LDS for its 4 overlapping frames.  The product runs
+// on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32); bf16 would not hold the 1e-3 log-mel
+// tolerance.  Pipeline:  reflect-pad -> DFT GEMM (re | im) -> magnitude -> mel GEMM with
+// the log-clamp fused in its epilogue, written directly in the reference's (B, n_mel, T)
+// layout (the mel GEMM is batched per clip with the filterbank as its A operand).
+#include "xva_common.h"
+#include "../../include/xva_gemm.h"
+#include "../../include/xva_hip.h"
+
+// y[b][i] = x[b][reflect(i - pad)]   (torch 'reflect': no edge repeat)
+__global__ void xva_reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int N, int pad,
+                                       int64_t ldx, int64_t ldy, int Np) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)B * ldy;
+    if (idx >= total) return;
+    int b = (int)(idx / ldy);
+    int i = (int)(idx - (int64_t)b * ldy);
+    float v = 0.f;
+    if (i < Np) {
+        int s = i - pad;
+        if (s < 0) s = -s;
+        if (s >= N) s = 2 * (N - 1) - s;
+        v = x[(int64_t)b * ldx + s];
+    }
+    y[idx] = v;
+}
+
+// spec: rows of [re(0..nb-1) | im(0..nb-1)] with leading dim lds -> mag rows with leading
+// dim ldm, columns >= nb zeroed (K padding for the mel GEMM).
+__global__ void xva_magnitude_kernel(const float* __restrict__ spec, float* __restrict__ mag, int64_t rows, int nb,
+                                     int64_t lds, int64_t ldm, float eps_add, float clamp_min) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * ldm) return;
+    int64_t r = idx / ldm;
+    int j = (int)(idx - r * ldm);
+    float v = 0.f;
+    if (j < nb) {
+        float re = spec[r * lds + j], im = spec[r * lds + nb + j];
+        float p = re * re + im * im + eps_add;
+        if (clamp_min > 0.f) p = fmaxf(p, clamp_min);
+        v = sqrtf(p);
+    }
+    mag[idx] = v;
+}
+
+static inline int64_t al4(int64_t x) { return (x + 3) & ~(int64_t)3; }
+static inline int64_t al32(int64_t x) { return (x + 31) & ~(int64_t)31; }
+
+struct MelPlan {
+    int T, Np, nb;
+    int64_t ldy, lds, ldm;
+    int64_t off_pad, off_spec, off_mag, total;  // in floats
+};
+
+static int mel_plan(const xva_mel_config* c, int B, int N, MelPlan* pl) {
+    XVA_CHECK_ARG(c->n_fft > 0 && c->n_fft % 4 == 0 && c->hop > 0 && c->hop % 4 == 0, "mel: n_fft and hop must be multiples of 4");
+    XVA_CHECK_ARG(c->pad >= 0 && c->pad < N, "mel: reflect pad %d needs N > pad (N=%d)", c->pad, N);
+    pl->Np = N + 2 * c->pad;
+    XVA_CHECK_ARG(pl->Np >= c->n_fft, "mel: clip shorter than one frame");
+    pl->T = (pl->Np - c->n_fft) / c->hop + 1;
+    pl->nb = c->n_fft / 2 + 1;
+    pl->ldy = al4(pl->Np);
+    pl->lds = al4(2 * pl->nb);
+    pl->ldm = al32(pl->nb);
+    pl->off_pad = 0;
+    pl->off_spec = al4((int64_t)B * pl->ldy + c->n_fft);  // slack: last frame row never over-reads
+    pl->off_mag = pl->off_spec + (int64_t)B * pl->T * pl->lds;
+    pl->total = pl->off_mag + (int64_t)B * pl->T * pl->ldm;
+    return XVA_OK;
+}
+
+extern "C" int xva_mel_num_frames(const xva_mel_config* c, int N) {
+    MelPlan pl;
+    if (!c || mel_plan(c, 1, N, &pl) != XVA_OK) return -1;
+    return pl.T;
+}
+
+extern "C" int64_t xva_mel_workspace_bytes(const xva_mel_config* c, int B, int N) {
+    MelPlan pl;
+    if (!c || mel_plan(c, B, N, &pl) != XVA_OK) return -1;
+    return pl.total * (int64_t)sizeof(float);
+}
+
+extern "C" int xva_mel_spectrogram(const xva_mel_config* c, const float* wav, int B, int N, int64_t ld_wav,
+                                   const float* dft_basis, const float* mel_basis_padded, float* mel_out,
+                                   float* workspace, int64_t workspace_bytes, void* stream) {
+    XVA_CHECK_ARG(c && wav && dft_basis && mel_basis_padded && mel_out && workspace, "mel: null pointer");
+    MelPlan pl;
+    XVA_TRY(mel_plan(c, B, N, &pl));
+    XVA_CHECK_ARG(workspace_bytes >= pl.total * (int64_t)sizeof(float), "mel: workspace too small (%ld < %ld)",
+                  (long)workspace_bytes, (long)(pl.total * sizeof(float)));
+    XVA_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "mel: workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    float* ypad = workspace + pl.off_pad;
+    float* spec = workspace + pl.off_spec;
+    float* mag = workspace + pl.off_mag;
+
+    {   // 1. reflect pad (plus zero the slack so over-reads of tail vectors are benign)
+        int64_t total = (int64_t)B * pl.ldy;
+        hipLaunchKernelGGL(xva_reflect_pad_kernel, dim3(xva_cdiv(total, 256)), dim3(256), 0, st, wav, ypad, B, N, c->pad,
+                           ld_wav, pl.ldy, pl.Np);
+        XVA_LAUNCH_CHECK();
+    }
+    {   // 2. windowed DFT as an overlapping-row GEMM: spec[b][t][:] = frames[b][t][:] . basis^T
+        xva_gemm_params g;
+        memset(&g, 0, sizeof(g));
+        g.A = ypad; g.B = dft_basis; g.C = spec;
+        g.M = pl.T; g.N = 2 * pl.nb; g.K = c->n_fft;
+        g.lda = c->hop; g.ldb = c->n_fft; g.ldc = pl.lds;
+        g.batch = B; g.sA = pl.ldy; g.sB = 0; g.sC = (int64_t)pl.T * pl.lds;
+        g.alpha = 1.f; g.splitk = 1; g.compute = 0; g.layout = XVA_GEMM_NT;
+        XVA_TRY(xva_gemm(&g, stream));
+    }
+    {   // 3. magnitude
+        int64_t rows = (int64_t)B * pl.T;
+        int64_t total = rows * pl.ldm;
+        hipLaunchKernelGGL(xva_magnitude_kernel, dim3(xva_cdiv(total, 256)), dim3(256), 0, st, spec, mag, rows, pl.nb,
+                           pl.lds, pl.ldm, c->mag_eps_add, c->mag_clamp_min);
+        XVA_LAUNCH_CHECK();
+    }
+    {   // 4. mel filterbank with fused log(clamp(.)), output (B, n_mel, T)
+        xva_gemm_params g;
+        memset(&g, 0, sizeof(g));
+        g.A = mel_basis_padded; g.B = mag; g.C = mel_out;
+        g.M = c->n_mel; g.N = pl.T; g.K = (int)pl.ldm;
+        g.lda = pl.ldm; g.ldb = pl.ldm; g.ldc = pl.T;
+        g.batch = B; g.sA = 0; g.sB = (int64_t)pl.T * pl.ldm; g.sC = (int64_t)c->n_mel * pl.T;
+        g.alpha = 1.f; g.log_clamp = c->log_clamp; g.splitk = 1; g.compute = 0; g.layout = XVA_GEMM_NT;
+        XVA_TRY(xva_gemm(&g, stream));
+    }
+    return XVA_OK;
+}

@@ -1,0 +1,111 @@
+// xva_common.h — shared device/host helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Wave = 64 lanes everywhere in this tree; nothing here is written for 32-wide warps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define XVA_OK 0
+#define XVA_ERR_ARG -1
+#define XVA_ERR_HIP -2
+#define XVA_ERR_WS -3
+
+// last-error string (thread-local), exported through xva_last_error()
+void xva_set_error(const char* fmt, ...);
+
+#define XVA_CHECK_ARG(cond, ...)                                                      \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            xva_set_error(__VA_ARGS__);                                                \
+            return XVA_ERR_ARG;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define XVA_LAUNCH_CHECK()                                                            \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) {                                                       \
+            xva_set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__,           \
+                          hipGetErrorString(e__));                                     \
+            return XVA_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define XVA_TRY(expr)                                                                 \
+    do {                                                                               \
+        int rc__ = (expr);                                                             \
+        if (rc__ != XVA_OK) return rc__;                                               \
+    } while (0)
+
+static inline int xva_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Row-mask modes for sequence tensors stored in the padded token-major layout
+// (B, Tp = T + 2, C): row 0 and row T+1 of every item are structural zero rows (the
+// zero padding of the k=3 convolutions), rows 1..len are live, rows len+1..T are the
+// batch padding the reference multiplies away with `mask`.
+#define XVA_MASK_NONE 0
+#define XVA_MASK_PAD 1  // zero only the two structural rows  (1 <= t' <= Tp-2 kept)
+#define XVA_MASK_LEN 2  // zero everything outside 1 <= t' <= len[b]
+
+#ifdef __HIPCC__
+__device__ __forceinline__ bool xva_row_live(int mode, const int* __restrict__ lens, int Tp, long r) {
+    if (mode == XVA_MASK_NONE) return true;
+    int t = (int)(r % Tp);
+    if (t == 0 || t == Tp - 1) return false;
+    if (mode == XVA_MASK_PAD) return true;
+    int b = (int)(r / Tp);
+    return t <= lens[b];
+}
+
+__device__ __forceinline__ float xva_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float xva_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64). `sh` needs 16 floats.
+__device__ __forceinline__ float xva_block_sum(float v, float* sh) {
+    v = xva_wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += sh[i];
+    return r;
+}
+__device__ __forceinline__ float xva_block_max(float v, float* sh) {
+    v = xva_wave_max(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int i = 0; i < nw; ++i) r = fmaxf(r, sh[i]);
+    return r;
+}
+
+// Stateless counter-based RNG for dropout: the keep-mask of element `idx` of stream
+// `stream_id` under `seed` is a pure function, so backward regenerates it instead of
+// storing it.  (murmur3-style 64->32 finaliser; quality is ample for Bernoulli masks.)
+__device__ __forceinline__ uint32_t xva_hash(uint64_t seed, uint32_t stream_id, uint64_t idx) {
+    uint64_t x = idx + 0x9E3779B97F4A7C15ull * (uint64_t)(stream_id + 1) + seed;
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return (uint32_t)x;
+}
+// returns the multiplier to apply: 0 or 1/(1-p).  p<=0 -> 1.
+__device__ __forceinline__ float xva_dropout_scale(float p, uint64_t seed, uint32_t stream_id, uint64_t idx) {
+    if (p <= 0.f) return 1.f;
+    uint32_t h = xva_hash(seed, stream_id, idx);
+    float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    return u < p ? 0.f : 1.f / (1.f - p);
+}
+#endif
