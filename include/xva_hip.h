@@ -58,6 +58,120 @@ int xva_mel_spectrogram(const xva_mel_config* cfg, const float* wav, int B, int 
                         const float* dft_basis, const float* mel_basis_padded, float* mel_out,
                         float* workspace, int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------- FastPitch 1.1 engine ---- */
+/* Replaces, for training stages 2-4, the PyTorch graph behind
+ *   y_pred = FastPitch.forward(x)          python/fastpitch1_1/fastpitch/model.py:325-423
+ *   loss   = FastPitchLoss.forward(...)    python/fastpitch1_1/fastpitch/loss_function.py:63-154
+ *   loss.backward()                        python/fastpitch1_1/xva_train.py:810-813
+ * called from FastPitchTrainer.iteration (xva_train.py:757-911).
+ *
+ * Sequence tensors are "padded token-major": (B, T+2, C) fp32, row 0 and row T+1 of each item structurally
+ * zero, rows 1..len live.  Parameters / gradients are ONE flat fp32 buffer laid out by xva_fp_tensor_info
+ * (conv k=3 weights stored tap-major [Cout][3][Cin]; `kind` = 1 marks them — the host permutes to/from the
+ * checkpoint layout [Cout][Cin][3]).  The workspace must be zero-filled ONCE when allocated (guard rows). */
+typedef struct xva_fp_dims {
+    int32_t B;        /* items in the micro-batch */
+    int32_t Tt;       /* padded text length  (max_inp_lengths[0]) */
+    int32_t Tm;       /* padded mel length   (max_mel_lengths[0]) */
+    int32_t stage;    /* training stage 2, 3 or 4 (model.training_stage) */
+    int32_t compute;  /* 0: exact fp32 MFMA (parity mode), 1: bf16-input MFMA with fp32 accumulation */
+} xva_fp_dims;
+
+typedef struct xva_fp_batch {
+    const int32_t* text;      /* (B, Tt) symbol ids, 0 = padding            (TTSCollate text_padded)  */
+    const int32_t* in_lens;   /* (B)                                                                   */
+    const int32_t* durs;      /* (B, Tt) integer durations, 0 on padding    (durs_padded)              */
+    const float* pitch;       /* (B, Tm) frame-level pitch, 0 = unvoiced    (pitch_padded[:, 0])       */
+    const float* energy;      /* (B, Tm) frame-level energy                 (energy_padded)            */
+    const float* pos_table;   /* (>= max(Tt, Tm), 384) sinusoid table cat(sin, cos) (transformer.py:21-35) */
+} xva_fp_batch;
+
+enum {
+    XVA_FP_SLOT_MEL_OUT = 0,   /* (B, Tm+2, 80)  */
+    XVA_FP_SLOT_PITCH_PRED,    /* (B, Tt+2)      */
+    XVA_FP_SLOT_ENERGY_PRED,   /* (B, Tt+2)      */
+    XVA_FP_SLOT_LOG_DUR_PRED,  /* (B, Tt+2)      */
+    XVA_FP_SLOT_DUR_PRED,      /* (B, Tt+2)      */
+    XVA_FP_SLOT_PITCH_TGT,     /* (B, Tt+2)      */
+    XVA_FP_SLOT_ENERGY_TGT,    /* (B, Tt+2)      */
+    XVA_FP_SLOT_DEC_LENS,      /* (B) int32      */
+    XVA_FP_SLOT_LOSS_ACC,      /* 8 floats: mel_num, mel_den, pitch_num, tok_den, energy_num, dur_num, -, - */
+    XVA_FP_SLOT_LOSSES,        /* 8 floats: total, mel, dur, pitch, energy, -, -, - */
+    XVA_FP_SLOT_D_MEL,         /* (B, Tm+2, 80)  */
+    XVA_FP_SLOT_D_PITCH,       /* (B, Tt+2)      */
+    XVA_FP_SLOT_D_ENERGY,      /* (B, Tt+2)      */
+    XVA_FP_SLOT_D_LOGDUR,      /* (B, Tt+2)      */
+    XVA_FP_SLOT_ENC_OUT,       /* (B, Tt+2, 384) */
+    XVA_FP_SLOT_DEC_OUT,       /* (B, Tm+2, 384) */
+    XVA_FP_SLOT_ENC_COND,      /* (B, Tt+2, 384) */
+    XVA_FP_SLOT_COUNT
+};
+
+int64_t xva_fp_param_floats(void);
+int xva_fp_num_tensors(void);
+int xva_fp_tensor_info(int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int32_t* ndim, int64_t* shape4,
+                       int32_t* kind);
+int xva_fp_trainable_ranges(int stage, int64_t* begins, int64_t* ends, int cap);
+int64_t xva_fp_workspace_bytes(const xva_fp_dims* d);
+int xva_fp_slot_offset(const xva_fp_dims* d, int slot, int64_t* off_floats);
+int xva_fp_forward(const xva_fp_dims* d, const float* params, const xva_fp_batch* batch, float* workspace,
+                   int64_t workspace_bytes, void* stream);
+int xva_fp_backward(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* batch, float* workspace,
+                    int64_t workspace_bytes, void* stream);
+
+/* FastPitchLoss in two phases (so data-parallel ranks can all-reduce `acc` in between: global normalisation). */
+int xva_fp_loss_partials(int stage, const float* mel_out, const float* mel_tgt, const float* pitch_pred, const float* pitch_tgt,
+                         const float* energy_pred, const float* energy_tgt, const float* log_dur_pred, const int32_t* durs,
+                         const int32_t* in_lens, float* acc, int B, int Tt, int Tm, void* stream);
+int xva_fp_loss_grads(int stage, const float* mel_out, const float* mel_tgt, const float* pitch_pred, const float* pitch_tgt,
+                      const float* energy_pred, const float* energy_tgt, const float* log_dur_pred, const int32_t* durs,
+                      const int32_t* in_lens, const float* acc, float* losses_out, float* d_mel, float* d_pitch, float* d_energy,
+                      float* d_logdur, int B, int Tt, int Tm, float grad_scale, float dur_w, float pitch_w, float energy_w,
+                      void* stream);
+
+/* Individual kernels of the path (each is also used on its own by the parity tests). */
+int xva_fp_embed_fwd(const int32_t* ids, const float* emb, const float* pos, float* out, int B, int T, int C, void* stream);
+int xva_fp_embed_bwd(const int32_t* ids, const float* dX, float* dEmb, int B, int T, int C, void* stream);
+int xva_fp_softmax_fwd(float* S, const int32_t* lens, int B, int Tp, int64_t Ts, float p_drop, uint64_t seed, uint32_t stream_id,
+                       void* stream);
+int xva_fp_softmax_bwd(const float* P, float* dP, int B, int Tp, int64_t Ts, float scale, float p_drop, uint64_t seed,
+                       uint32_t stream_id, void* stream);
+int xva_fp_layernorm_fwd(const float* X, const float* gamma, const float* beta, float* Y, float* mean, float* rstd, int64_t rows,
+                         int C, int mask_mode, const int32_t* lens, int Tp, void* stream);
+int xva_fp_layernorm_bwd(const float* dY, const float* X, const float* mean, const float* rstd, const float* gamma, float* dX,
+                         float* dgamma, float* dbeta, int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp,
+                         int relu_gate, void* stream);
+int xva_fp_colsum(const float* X, float* out, int64_t rows, int C, int64_t ld, void* stream);
+int xva_fp_avg_pitch(const float* dense, const int32_t* durs, float* avg_out, int B, int Tt, int Tm, int log1p_, void* stream);
+int xva_fp_lenreg_map(const int32_t* durs, int32_t* tok, int32_t* tstart, int32_t* dec_lens, int B, int Tt, int Tm, float pace,
+                      void* stream);
+int xva_fp_cond_add_fwd(const float* in, const float* s, const float* w, const float* bias, float* out, const int32_t* lens,
+                        int B, int Tp, int C, void* stream);
+int xva_fp_cond_add_bwd(const float* dOut, const float* s, float* dw, float* db, const int32_t* lens, int B, int Tp, int C,
+                        void* stream);
+int xva_fp_lenreg_fwd(const float* enc, const int32_t* tok, const int32_t* dec_lens, const float* pos, float* out, int B, int Tt,
+                      int Tm, int C, void* stream);
+int xva_fp_lenreg_bwd(const float* dOut, const int32_t* tstart, const int32_t* dec_lens, float* dEnc, int B, int Tt, int Tm, int C,
+                      int accumulate, void* stream);
+int xva_fp_outer(const float* s, const float* w, float* out, int64_t rows, int C, void* stream);
+int xva_fp_rowscale_colsum(const float* X, const float* s, float* out, int64_t rows, int C, void* stream);
+int xva_fp_dur_from_log(const float* logd, float* out, int n, float max_dur, void* stream);
+
+/* ------------------------------------------------------------------------ optimizers ---- */
+/* Fused multi-tensor LAMB over the flat buffers = torch.nn.utils.clip_grad_norm_(.., max_grad_norm) followed by
+ * Lamb.step (python/fastpitch1_1/lamb.py:40-106; call site xva_train.py:853-862).  Chunk descriptors come from
+ * xva_opt_build_chunks (host) and list only the tensors that received a gradient this stage (Lamb skips
+ * p.grad is None). */
+int xva_opt_chunk_size(void);
+int64_t xva_opt_build_chunks(const int64_t* offsets, const int64_t* numels, const int32_t* active, int n, int32_t* ctid,
+                             int64_t* cstart, int32_t* clen, int64_t cap);
+int xva_lamb_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t total_floats, const int32_t* ctid,
+                  const int64_t* cstart, const int32_t* clen, int64_t n_chunks, int n_tensors, float* scal, float* norms, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, float inv_scale, void* stream);
+/* torch.optim.AdamW step over a flat buffer (python/hifigan/xva_train.py:298-300,498,515). */
+int xva_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,356 @@
+"""CPU oracle for the FastPitch1.1 training step (floating point: torch fp32/fp64 on CPU, autograd for grads).
+
+A functional restatement driven by a state_dict with the REFERENCE's keys and layouts, so the same
+checkpoint feeds the reference, this oracle and the HIP path.  Restates:
+  FFTransformer / TransformerLayer / MultiHeadAttn / PositionwiseConvFF / PositionalEmbedding
+                                      python/fastpitch1_1/fastpitch/transformer.py:21-243
+  TemporalPredictor, ConvReLUNorm     python/fastpitch1_1/fastpitch/model.py:103-122, common/layers.py:85-97
+  regulate_len, average_pitch         python/fastpitch1_1/fastpitch/model.py:59-100
+  FastPitch.forward (stages 2, 3, 4)  python/fastpitch1_1/fastpitch/model.py:325-423
+  FastPitchLoss.forward               python/fastpitch1_1/fastpitch/loss_function.py:63-154
+  Lamb.step                           python/fastpitch1_1/lamb.py:40-106
+  adjust_learning_rate                python/fastpitch1_1/xva_train.py:1252-1261
+Dropout is omitted (goldens are taken with model.eval(); see SURVEY.md §7 "hard parts").
+Stage 1 (ConvAttention + MAS) is a "next" row and is not restated yet.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+N_LAYERS = 6
+D_MODEL = 384
+D_HEAD = 64
+N_MEL = 80
+N_SYMBOLS = 148
+
+
+def mask_from_lens(lens, max_len):
+    ids = torch.arange(0, max_len, device=lens.device, dtype=lens.dtype)
+    return torch.lt(ids, lens.unsqueeze(1))
+
+
+def positional_embedding(T, demb, dtype):
+    inv_freq = 1 / (10000 ** (torch.arange(0.0, demb, 2.0) / demb))
+    pos_seq = torch.arange(T).to(dtype)
+    sinusoid = torch.matmul(pos_seq.unsqueeze(-1), inv_freq.to(dtype).unsqueeze(0))
+    return torch.cat([sinusoid.sin(), sinusoid.cos()], dim=1)[None]
+
+
+def _mha(sd, pre, inp, key_pad_mask):
+    qkv = F.linear(inp, sd[pre + "qkv_net.weight"], sd[pre + "qkv_net.bias"])
+    q, k, v = torch.chunk(qkv, 3, dim=2)
+    score = torch.bmm(q, k.transpose(1, 2)) * (1 / (D_HEAD ** 0.5))
+    score = score.masked_fill(key_pad_mask.unsqueeze(1), -float("inf"))
+    prob = F.softmax(score, dim=2)
+    vec = torch.bmm(prob, v)
+    out = F.linear(vec, sd[pre + "o_net.weight"])
+    return F.layer_norm(inp + out, (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"])
+
+
+def _conv_ff(sd, pre, inp):
+    core = inp.transpose(1, 2)
+    core = F.conv1d(core, sd[pre + "CoreNet.0.weight"], sd[pre + "CoreNet.0.bias"], padding=1)
+    core = F.relu(core)
+    core = F.conv1d(core, sd[pre + "CoreNet.2.weight"], sd[pre + "CoreNet.2.bias"], padding=1)
+    core = core.transpose(1, 2)
+    return F.layer_norm(inp + core, (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"])
+
+
+def fft_transformer(sd, pre, dec_inp, seq_lens=None, embed=False, taps=None):
+    if embed:
+        inp = F.embedding(dec_inp, sd[pre + "word_emb.weight"], padding_idx=0)
+        mask = (dec_inp != 0).unsqueeze(2)
+    else:
+        inp = dec_inp
+        mask = mask_from_lens(seq_lens, inp.size(1)).unsqueeze(2)
+    pos = positional_embedding(inp.size(1), D_MODEL, inp.dtype) * mask
+    out = inp + pos
+    if taps is not None:
+        taps[pre + "in"] = out
+    for i in range(N_LAYERS):
+        lp = "%slayers.%d." % (pre, i)
+        out = _mha(sd, lp + "dec_attn.", out, ~mask.squeeze(2))
+        out = out * mask
+        out = _conv_ff(sd, lp + "pos_ff.", out)
+        out = out * mask
+        if taps is not None:
+            taps[lp + "out"] = out
+    return out, mask
+
+
+def temporal_predictor(sd, pre, enc_out, enc_mask):
+    out = (enc_out * enc_mask).transpose(1, 2)
+    for i in range(2):
+        lp = "%slayers.%d." % (pre, i)
+        out = F.relu(F.conv1d(out, sd[lp + "conv.weight"], sd[lp + "conv.bias"], padding=1))
+        C = out.size(1)
+        out = F.layer_norm(out.transpose(1, 2), (C,), sd[lp + "norm.weight"], sd[lp + "norm.bias"]).transpose(1, 2)
+    out = out.transpose(1, 2)
+    return F.linear(out, sd[pre + "fc.weight"], sd[pre + "fc.bias"]) * enc_mask
+
+
+def regulate_len(durations, enc_out, pace=1.0, mel_max_len=None):
+    reps = (durations.float() * pace + 0.5).long()
+    dec_lens = reps.sum(dim=1)
+    max_len = int(dec_lens.max())
+    cum = torch.cumsum(F.pad(reps, (1, 0, 0, 0), value=0), dim=1)[:, None, :].to(enc_out.dtype)
+    rng = torch.arange(max_len)[None, :, None]
+    mult = ((cum[:, :, :-1] <= rng) & (cum[:, :, 1:] > rng)).to(enc_out.dtype)
+    enc_rep = torch.matmul(mult, enc_out)
+    if mel_max_len is not None:
+        enc_rep = enc_rep[:, :mel_max_len]
+        dec_lens = torch.clamp_max(dec_lens, mel_max_len)
+    return enc_rep, dec_lens
+
+
+def average_pitch(pitch, durs):
+    ends = torch.cumsum(durs, dim=1).long()
+    starts = F.pad(ends[:, :-1], (1, 0))
+    nz_cums = F.pad(torch.cumsum(pitch != 0.0, dim=2), (1, 0))
+    p_cums = F.pad(torch.cumsum(pitch, dim=2), (1, 0))
+    bs, l = ends.size()
+    nf = pitch.size(1)
+    dcs = starts[:, None, :].expand(bs, nf, l)
+    dce = ends[:, None, :].expand(bs, nf, l)
+    sums = (torch.gather(p_cums, 2, dce) - torch.gather(p_cums, 2, dcs)).float()
+    nel = (torch.gather(nz_cums, 2, dce) - torch.gather(nz_cums, 2, dcs)).float()
+    return torch.where(nel == 0.0, nel, sums / nel).to(pitch.dtype)
+
+
+def forward(sd, batch, stage, taps=None):
+    """batch: dict(text (B,Tt) int64, in_lens, mel_tgt (B,80,Tm), mel_lens, pitch (B,1,Tm), energy (B,Tm),
+    durs (B,Tt) int).  Returns the reference's 13-slot output list (model.py:388-390)."""
+    text, mel_lens = batch["text"], batch["mel_lens"]
+    mel_max_len = int(mel_lens.max())
+    enc_out, enc_mask = fft_transformer(sd, "encoder.", text, embed=True, taps=taps)
+    dur_tgt = batch["durs"]
+    if stage == 2:
+        log_dur_pred = temporal_predictor(sd, "duration_predictor.", enc_out, enc_mask).squeeze(-1)
+        dur_pred = torch.clamp(torch.exp(log_dur_pred) - 1, 0, 75)
+        return [None, None, dur_pred, log_dur_pred, None, None, None, None, None, None, dur_tgt, None, batch["in_lens"]]
+    pitch_pred = temporal_predictor(sd, "pitch_predictor.", enc_out, enc_mask).permute(0, 2, 1)
+    pitch_tgt = average_pitch(batch["pitch"], dur_tgt)
+    pitch_emb = F.conv1d(pitch_tgt, sd["pitch_emb.weight"], sd["pitch_emb.bias"], padding=1)
+    enc_out = enc_out + pitch_emb.transpose(1, 2)
+    energy_pred = temporal_predictor(sd, "energy_predictor.", enc_out, enc_mask).squeeze(-1)
+    energy_tgt = torch.log(1.0 + average_pitch(batch["energy"].unsqueeze(1), dur_tgt))
+    energy_emb = F.conv1d(energy_tgt, sd["energy_emb.weight"], sd["energy_emb.bias"], padding=1)
+    energy_tgt = energy_tgt.squeeze(1)
+    enc_out = enc_out + energy_emb.transpose(1, 2)
+    if taps is not None:
+        taps["enc_cond"] = enc_out
+    len_regulated, dec_lens = regulate_len(dur_tgt, enc_out, 1.0, mel_max_len)
+    dec_out, dec_mask = fft_transformer(sd, "decoder.", len_regulated, seq_lens=dec_lens, taps=taps)
+    mel_out = F.linear(dec_out, sd["proj.weight"], sd["proj.bias"])
+    return [mel_out, dec_mask, None, None, pitch_pred, pitch_tgt, energy_pred, energy_tgt, None, None, dur_tgt, None,
+            batch["in_lens"]]
+
+
+def loss(model_out, batch, stage, dur_scale=0.1, pitch_scale=0.1, energy_scale=0.1):
+    """FastPitchLoss.forward with the trainer's scales (xva_train.py:702-704; energy default loss_function.py:54).
+    Returns (loss, dict of component losses)."""
+    (mel_out, _, _, log_dur_pred, pitch_pred, pitch_tgt, energy_pred, energy_tgt, _, _, dur_tgt, _, in_lens) = model_out
+    mel_tgt = batch["mel_tgt"]
+    max_inp = int(batch["text"].size(1))
+    dur_mask = mask_from_lens(in_lens, max_inp)
+    z = torch.zeros((), dtype=mel_tgt.dtype)
+    dur_l = mel_l = pitch_l = energy_l = z
+    if stage == 2:
+        log_dur_tgt = torch.log(dur_tgt.to(mel_tgt.dtype) + 1)
+        dl = F.mse_loss(log_dur_pred, log_dur_tgt, reduction="none")
+        dur_l = (dl * dur_mask).sum() / dur_mask.sum()
+    if stage in (3, 4):
+        mt = mel_tgt.transpose(1, 2)
+        ldiff = mt.size(1) - mel_out.size(1)
+        mo = F.pad(mel_out, (0, 0, 0, ldiff, 0, 0), value=0.0)
+        mm = mt.ne(0).to(mt.dtype)
+        mel_l = (F.mse_loss(mo, mt, reduction="none") * mm).sum() / mm.sum()
+        if stage == 3:
+            pl = F.mse_loss(pitch_tgt, pitch_pred, reduction="none")
+            pitch_l = (pl * dur_mask.unsqueeze(1)).sum() / dur_mask.sum()
+            el = F.mse_loss(energy_tgt, energy_pred, reduction="none")
+            energy_l = (el * dur_mask).sum() / dur_mask.sum()
+    total = mel_l + dur_l * dur_scale + pitch_l * pitch_scale + energy_l * energy_scale
+    return total, {"mel": mel_l, "dur": dur_l, "pitch": pitch_l, "energy": energy_l}
+
+
+def trainable_names(sd_keys, stage):
+    """Which parameters train in each stage (freezing in xva_train.py:589-672, summarised SURVEY.md Appendix A)."""
+    def frozen(k):
+        grp = k.split(".")[0]
+        if stage == 2:
+            return grp in ("attention", "decoder", "pitch_predictor", "pitch_emb", "energy_predictor", "proj")
+        if stage == 3:
+            return grp in ("attention", "duration_predictor")
+        if stage == 4:
+            return grp in ("attention", "duration_predictor", "pitch_predictor", "pitch_emb", "energy_predictor")
+        return False
+    buffers = ("pitch_mean", "pitch_std")
+    return [k for k in sd_keys if k not in buffers and not k.endswith("inv_freq") and not frozen(k)]
+
+
+def adjust_learning_rate(total_iter, learning_rate=0.1, warmup_iters=1000):
+    if warmup_iters == 0:
+        scale = 1.0
+    elif total_iter > warmup_iters:
+        scale = 1.0 / (total_iter ** 0.5)
+    else:
+        scale = total_iter / (warmup_iters ** 1.5)
+    return learning_rate * scale
+
+
+def clip_grad_norm_(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (xva_train.py:857,861): global L2 norm, coef = max_norm/(norm+1e-6) clamped to 1."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return total
+
+
+def lamb_step(params, grads, state, lr, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6):
+    """Lamb.step (lamb.py:40-106): no bias correction, weight-norm clamp 10, trust ratio 1 when either norm is 0.
+    params/grads/state are dicts keyed by name; state[name] = dict(exp_avg, exp_avg_sq, step)."""
+    b1, b2 = betas
+    for k, p in params.items():
+        g = grads.get(k)
+        if g is None:
+            continue
+        st = state.setdefault(k, {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)})
+        st["step"] += 1
+        st["exp_avg"].mul_(b1).add_(g, alpha=1 - b1)
+        st["exp_avg_sq"].mul_(b2).addcmul_(g, g, value=1 - b2)
+        weight_norm = p.pow(2).sum().sqrt().clamp(0, 10)
+        adam_step = st["exp_avg"] / st["exp_avg_sq"].sqrt().add(eps)
+        if weight_decay != 0:
+            adam_step.add_(p, alpha=weight_decay)
+        adam_norm = adam_step.pow(2).sum().sqrt()
+        trust = 1.0 if (weight_norm == 0 or adam_norm == 0) else (weight_norm / adam_norm).item()
+        st["weight_norm"], st["adam_norm"], st["trust_ratio"] = weight_norm, adam_norm, trust
+        p.add_(adam_step, alpha=-lr * trust)
+
+
+# ---------------------------------------------------------------- synthetic inputs ----
+def synth_batch(B, T_text, T_mel, seed, ragged=True, dtype=torch.float32):
+    """Seeded FastPitch batch shaped like TTSCollate's output (data_function.py:565-695): text sorted by length desc,
+    zero padding, durations summing to each item's mel length, pitch with unvoiced zeros, energy = ||mel||_2."""
+    g = torch.Generator().manual_seed(seed)
+    if ragged and B > 1:
+        in_lens = torch.sort(torch.randint(max(2, T_text // 3), T_text + 1, (B,), generator=g), descending=True).values
+        in_lens[0] = T_text
+    else:
+        in_lens = torch.full((B,), T_text, dtype=torch.long)
+    text = torch.zeros(B, T_text, dtype=torch.long)
+    durs = torch.zeros(B, T_text, dtype=torch.long)
+    mel_lens = torch.zeros(B, dtype=torch.long)
+    for b in range(B):
+        L = int(in_lens[b])
+        text[b, :L] = torch.randint(1, N_SYMBOLS, (L,), generator=g)
+        tm = T_mel if b == 0 else max(L, int(T_mel * L / T_text))
+        tm = max(tm, L)
+        extra = torch.multinomial(torch.ones(L), tm - L, replacement=True, generator=g) if tm > L else torch.zeros(0, dtype=torch.long)
+        d = torch.ones(L, dtype=torch.long)
+        d.scatter_add_(0, extra, torch.ones_like(extra))
+        durs[b, :L] = d
+        mel_lens[b] = tm
+    Tm = int(mel_lens.max())
+    mel = torch.zeros(B, N_MEL, Tm, dtype=dtype)
+    pitch = torch.zeros(B, 1, Tm, dtype=dtype)
+    for b in range(B):
+        tm = int(mel_lens[b])
+        mel[b, :, :tm] = torch.clamp(torch.randn(N_MEL, tm, generator=g) * 2 - 5, math.log(1e-5), 2.0).to(dtype)
+        p = torch.randn(tm, generator=g)
+        p[torch.rand(tm, generator=g) < 0.3] = 0.0
+        pitch[b, 0, :tm] = p.to(dtype)
+    energy = torch.norm(mel.float(), dim=1, p=2).to(dtype)
+    for b in range(B):
+        energy[b, int(mel_lens[b]):] = 0
+    return {"text": text, "in_lens": in_lens, "mel_tgt": mel, "mel_lens": mel_lens, "pitch": pitch, "energy": energy,
+            "durs": durs}
+
+
+def init_state_dict(seed, dtype=torch.float32):
+    """Random-init state_dict with the reference's 185 keys/shapes (FastPitch.__init__, model.py:125-265), using torch's
+    default initialisers' scale (values only need to be plausible: there are no checkpoints offline)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def U(shape, fan_in):
+        bound = 1.0 / math.sqrt(fan_in)
+        return ((torch.rand(shape, generator=g) * 2 - 1) * bound).to(dtype)
+
+    sd = {"pitch_mean": torch.zeros(1, dtype=dtype), "pitch_std": torch.zeros(1, dtype=dtype)}
+    emb = torch.randn(N_SYMBOLS, D_MODEL, generator=g).to(dtype)
+    emb[0] = 0
+    for name in ("encoder", "decoder"):
+        if name == "encoder":
+            sd["encoder.word_emb.weight"] = emb
+        sd[name + ".pos_emb.inv_freq"] = (1 / (10000 ** (torch.arange(0.0, D_MODEL, 2.0) / D_MODEL))).to(dtype)
+        for i in range(N_LAYERS):
+            p = "%s.layers.%d." % (name, i)
+            sd[p + "dec_attn.qkv_net.weight"] = U((192, 384), 384)
+            sd[p + "dec_attn.qkv_net.bias"] = U((192,), 384)
+            sd[p + "dec_attn.o_net.weight"] = U((384, 64), 64)
+            sd[p + "dec_attn.layer_norm.weight"] = (1 + 0.1 * torch.randn(384, generator=g)).to(dtype)
+            sd[p + "dec_attn.layer_norm.bias"] = (0.1 * torch.randn(384, generator=g)).to(dtype)
+            sd[p + "pos_ff.CoreNet.0.weight"] = U((1536, 384, 3), 384 * 3)
+            sd[p + "pos_ff.CoreNet.0.bias"] = U((1536,), 384 * 3)
+            sd[p + "pos_ff.CoreNet.2.weight"] = U((384, 1536, 3), 1536 * 3)
+            sd[p + "pos_ff.CoreNet.2.bias"] = U((384,), 1536 * 3)
+            sd[p + "pos_ff.layer_norm.weight"] = (1 + 0.1 * torch.randn(384, generator=g)).to(dtype)
+            sd[p + "pos_ff.layer_norm.bias"] = (0.1 * torch.randn(384, generator=g)).to(dtype)
+        if name == "encoder":
+            _init_predictor(sd, "duration_predictor.", U, g, dtype)
+    _init_predictor(sd, "pitch_predictor.", U, g, dtype)
+    sd["pitch_emb.weight"] = U((384, 1, 3), 3)
+    sd["pitch_emb.bias"] = U((384,), 3)
+    _init_predictor(sd, "energy_predictor.", U, g, dtype)
+    sd["energy_emb.weight"] = U((384, 1, 3), 3)
+    sd["energy_emb.bias"] = U((384,), 3)
+    sd["proj.weight"] = U((80, 384), 384)
+    sd["proj.bias"] = U((80,), 384)
+    sd["attention.query_proj.0.conv.weight"] = U((160, 80, 3), 240)
+    sd["attention.query_proj.0.conv.bias"] = U((160,), 240)
+    sd["attention.query_proj.2.conv.weight"] = U((80, 160, 1), 160)
+    sd["attention.query_proj.2.conv.bias"] = U((80,), 160)
+    sd["attention.query_proj.4.conv.weight"] = U((80, 80, 1), 80)
+    sd["attention.query_proj.4.conv.bias"] = U((80,), 80)
+    sd["attention.attn_proj.weight"] = U((1, 80, 1, 1), 80)
+    sd["attention.attn_proj.bias"] = U((1,), 80)
+    sd["attention.key_proj.0.conv.weight"] = U((768, 384, 3), 1152)
+    sd["attention.key_proj.0.conv.bias"] = U((768,), 1152)
+    sd["attention.key_proj.2.conv.weight"] = U((80, 768, 1), 768)
+    sd["attention.key_proj.2.conv.bias"] = U((80,), 768)
+    return sd
+
+
+def _init_predictor(sd, p, U, g, dtype):
+    sd[p + "layers.0.conv.weight"] = U((256, 384, 3), 1152)
+    sd[p + "layers.0.conv.bias"] = U((256,), 1152)
+    sd[p + "layers.0.norm.weight"] = (1 + 0.1 * torch.randn(256, generator=g)).to(dtype)
+    sd[p + "layers.0.norm.bias"] = (0.1 * torch.randn(256, generator=g)).to(dtype)
+    sd[p + "layers.1.conv.weight"] = U((256, 256, 3), 768)
+    sd[p + "layers.1.conv.bias"] = U((256,), 768)
+    sd[p + "layers.1.norm.weight"] = (1 + 0.1 * torch.randn(256, generator=g)).to(dtype)
+    sd[p + "layers.1.norm.bias"] = (0.1 * torch.randn(256, generator=g)).to(dtype)
+    sd[p + "fc.weight"] = U((1, 256), 256)
+    sd[p + "fc.bias"] = U((1,), 256)
+
+
+def train_step(sd, batch, stage, opt_state, total_iter, grad_clip=1000.0, gam=1):
+    """One reference optimizer step (xva_train.py:780-862, AMP off): fwd, loss/gam, bwd, clip 1000, LAMB.
+    Mutates sd (trainable tensors) and opt_state in place.  Returns (loss value, components, grads dict)."""
+    names = trainable_names(sd.keys(), stage)
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in names}
+    work = dict(sd)
+    work.update(leaves)
+    out = forward(work, batch, stage)
+    total, comps = loss(out, batch, stage)
+    (total / gam).backward()
+    grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    clip_grad_norm_(list(grads.values()), grad_clip)
+    lr = adjust_learning_rate(total_iter)
+    with torch.no_grad():
+        params = {k: sd[k] for k in grads}
+        lamb_step(params, grads, opt_state, lr)
+    return float(total), {k: float(v) for k, v in comps.items()}, grads

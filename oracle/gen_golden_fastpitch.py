@@ -1,0 +1,104 @@
+"""FastPitch golden vectors: run the REFERENCE FastPitch / FastPitchLoss / Lamb (imported from /root/reference)
+on a seeded state_dict + synthetic batch, and record inputs, outputs, losses, gradient and post-step summaries.
+
+The 46 M-parameter state_dict is not stored: it is regenerated from `seed` by oracle.fastpitch.init_state_dict
+(torch CPU generator, deterministic for the pinned torch build); the fixture stores per-tensor checksums so a
+generator drift would be detected rather than silently shifting the goldens.
+"""
+import os
+
+import numpy as np
+import torch
+
+from oracle import fastpitch as ofp
+
+CASES = [
+    # name, stage, B, T_text, T_mel, seed
+    ("fp_stage3_small", 3, 3, 14, 45, 1234),
+    ("fp_stage4_small", 4, 2, 9, 30, 1235),
+    ("fp_stage2_small", 2, 3, 14, 45, 1236),
+]
+
+
+def _ref_inputs(batch):
+    B = batch["text"].size(0)
+    max_inp = torch.full((B,), batch["text"].size(1), dtype=torch.long)
+    max_mel = torch.full((B,), int(batch["mel_lens"].max()), dtype=torch.long)
+    x = (batch["text"], batch["in_lens"], batch["mel_tgt"], batch["mel_lens"], batch["pitch"], batch["energy"], None,
+         None, batch["durs"], max_inp, max_mel, None)
+    y = [batch["mel_tgt"], batch["in_lens"], batch["mel_lens"], max_inp]
+    return x, y
+
+
+def run_reference(ns, sd, batch, stage, total_iter):
+    model = ns.FastPitch()
+    model.load_state_dict(sd)
+    model.eval()  # dropout off
+    model.training_stage = torch.tensor(stage)
+    train = set(ofp.trainable_names(sd.keys(), stage))
+    for n, p in model.named_parameters():
+        p.requires_grad = n in train
+    crit = ns.loss_function.FastPitchLoss(dur_predictor_loss_scale=0.1, pitch_predictor_loss_scale=0.1, attn_loss_scale=1.0)
+    opt = ns.Lamb(model.parameters(), lr=0.1, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6)
+    x, y = _ref_inputs(batch)
+    y_pred = model(x)
+    loss, meta, comps = crit(y_pred, y, training_stage=stage)
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1000)
+    for g in opt.param_groups:
+        g["lr"] = ofp.adjust_learning_rate(total_iter)
+    opt.step()
+    new_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return y_pred, float(loss), comps, grads, float(gnorm), new_sd, opt
+
+
+def generate(ns, out_dir):
+    for name, stage, B, Tt, Tm, seed in CASES:
+        sd = ofp.init_state_dict(seed)
+        batch = ofp.synth_batch(B, Tt, Tm, seed + 1)
+        total_iter = 50000
+        y_pred, loss, comps, grads, gnorm, new_sd, opt = run_reference(ns, {k: v.clone() for k, v in sd.items()}, batch, stage, total_iter)
+
+        # cross-check the oracle restatement against the live reference before writing anything
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        o_loss, o_comps, o_grads = ofp.train_step(sd2, batch, stage, {}, total_iter)
+        assert abs(o_loss - loss) <= 1e-6 * max(1, abs(loss)), (o_loss, loss)
+        assert set(o_grads) == set(grads), set(o_grads) ^ set(grads)
+        for k in grads:
+            assert torch.allclose(o_grads[k] * 1.0, grads[k], rtol=1e-4, atol=1e-7), k
+        for k in new_sd:
+            assert torch.allclose(sd2[k], new_sd[k], rtol=1e-5, atol=1e-7), k
+
+        keys = sorted(grads)
+        rec = {
+            "seed": np.int64(seed), "stage": np.int64(stage), "total_iter": np.int64(total_iter),
+            "loss": np.float64(loss), "comps": np.array([float(c) for c in comps], dtype=np.float64),
+            "grad_norm": np.float64(gnorm),
+            "grad_keys": np.array(keys),
+            "grad_l2": np.array([float(grads[k].double().norm()) for k in keys]),
+            "grad_sum": np.array([float(grads[k].double().sum()) for k in keys]),
+            "param_l2_before": np.array([float(sd[k].double().norm()) for k in keys]),
+            "param_l2_after": np.array([float(new_sd[k].double().norm()) for k in keys]),
+            "delta_l2": np.array([float((new_sd[k].double() - sd[k].double()).norm()) for k in keys]),
+            "sd_checksum": np.array([float(sd[k].double().sum()) for k in sorted(sd)]),
+        }
+        for k, v in batch.items():
+            rec["in_" + k] = v.numpy()
+        if stage == 2:
+            rec["log_dur_pred"] = y_pred[3].detach().numpy()
+            rec["dur_pred"] = y_pred[2].detach().numpy()
+        else:
+            rec["mel_out"] = y_pred[0].detach().numpy()
+            rec["pitch_pred"] = y_pred[4].detach().numpy()
+            rec["pitch_tgt"] = y_pred[5].detach().numpy()
+            rec["energy_pred"] = y_pred[6].detach().numpy()
+            rec["energy_tgt"] = y_pred[7].detach().numpy()
+            # a few raw gradient slices (layout = reference layout)
+            rec["g_proj_weight"] = grads["proj.weight"].numpy()
+            rec["g_enc0_ffn0_w_slice"] = grads["encoder.layers.0.pos_ff.CoreNet.0.weight"][:8].numpy()
+            rec["g_dec5_qkv_w_slice"] = grads["decoder.layers.5.dec_attn.qkv_net.weight"][:8].numpy()
+            rec["g_word_emb"] = grads["encoder.word_emb.weight"].numpy()
+            rec["new_proj_weight"] = new_sd["proj.weight"].numpy()
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+        print(name, "loss", loss, "comps", comps, "gnorm", gnorm, "ngrads", len(keys))

@@ -1,0 +1,583 @@
+// fastpitch_engine.hip — the FastPitch1.1 forward / backward schedule as ONE host call each.
+//
+// Reference: FastPitch.forward (python/fastpitch1_1/fastpitch/model.py:325-423), FFTransformer /
+// TransformerLayer / MultiHeadAttn / PositionwiseConvFF (fastpitch/transformer.py:59-243), TemporalPredictor
+// (model.py:103-122), regulate_len / average_pitch (model.py:59-100) and the autograd backward PyTorch derives
+// for them.  The reference issues ~1.5k tiny ATen kernels per step from Python; here the whole step is a fixed
+// C++ launch schedule over a caller-owned workspace (no allocation, no sync, graph-capturable), every dense
+// contraction on the MFMA GEMM (gemm.hip) with bias / ReLU / residual / mask fused in its epilogue.
+//
+// Memory model: parameters live in ONE flat fp32 buffer (table below; conv-k3 weights are stored tap-major
+// [Cout][3][Cin] — the host converts to/from the checkpoint layout [Cout][Cin][3]); gradients mirror it.
+// Activations use the padded token-major layout described in fp_ops.hip.
+#include "xva_common.h"
+#include "../../include/xva_hip.h"
+#include <string>
+#include <vector>
+
+// ---- per-op launchers from fp_ops.hip ----
+extern "C" {
+int xva_fp_embed_fwd(const int32_t*, const float*, const float*, float*, int, int, int, void*);
+int xva_fp_embed_bwd(const int32_t*, const float*, float*, int, int, int, void*);
+int xva_fp_softmax_fwd(float*, const int32_t*, int, int, int64_t, float, uint64_t, uint32_t, void*);
+int xva_fp_softmax_bwd(const float*, float*, int, int, int64_t, float, float, uint64_t, uint32_t, void*);
+int xva_fp_layernorm_fwd(const float*, const float*, const float*, float*, float*, float*, int64_t, int, int, const int32_t*, int, void*);
+int xva_fp_layernorm_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int64_t, int, int, const int32_t*, int, int, void*);
+int xva_fp_colsum(const float*, float*, int64_t, int, int64_t, void*);
+int xva_fp_avg_pitch(const float*, const int32_t*, float*, int, int, int, int, void*);
+int xva_fp_lenreg_map(const int32_t*, int32_t*, int32_t*, int32_t*, int, int, int, float, void*);
+int xva_fp_cond_add_fwd(const float*, const float*, const float*, const float*, float*, const int32_t*, int, int, int, void*);
+int xva_fp_cond_add_bwd(const float*, const float*, float*, float*, const int32_t*, int, int, int, void*);
+int xva_fp_lenreg_fwd(const float*, const int32_t*, const int32_t*, const float*, float*, int, int, int, int, void*);
+int xva_fp_lenreg_bwd(const float*, const int32_t*, const int32_t*, float*, int, int, int, int, int, void*);
+int xva_fp_outer(const float*, const float*, float*, int64_t, int, void*);
+int xva_fp_rowscale_colsum(const float*, const float*, float*, int64_t, int, void*);
+int xva_fp_dur_from_log(const float*, float*, int, float, void*);
+}
+
+namespace {
+
+constexpr int NL = 6, DM = 384, DI = 1536, DH = 64, DQKV = 192, DP = 256, NMEL = 80, NSYM = 148;
+
+// ------------------------------------------------------------------ parameter table ----
+struct TensorInfo {
+    std::string name;
+    int64_t offset, numel;
+    int ndim;
+    int64_t shape[4];  // checkpoint (reference) shape
+    int kind;          // 0 plain, 1 conv-k3 stored tap-major
+};
+
+struct LayerP { int64_t qkv_w, qkv_b, o_w, ln1_g, ln1_b, c1_w, c1_b, c2_w, c2_b, ln2_g, ln2_b; };
+struct PredP { int64_t c1_w, c1_b, n1_g, n1_b, c2_w, c2_b, n2_g, n2_b, fc_w, fc_b; };
+struct ParamTable {
+    std::vector<TensorInfo> t;
+    int64_t total = 0;
+    int64_t word_emb;
+    LayerP enc[NL], dec[NL];
+    PredP dur, pitch, energy;
+    int64_t pitch_emb_w, pitch_emb_b, energy_emb_w, energy_emb_b, proj_w, proj_b;
+    // contiguous [begin, end) ranges of the flat buffer by module group (used for stage freezing)
+    int64_t enc_begin, enc_end, dur_begin, dur_end, pitch_begin, pitch_end, pemb_begin, pemb_end, energy_begin, energy_end,
+        eemb_begin, eemb_end, dec_begin, dec_end, proj_begin, proj_end, attn_begin, attn_end;
+
+    int64_t add(const std::string& name, std::initializer_list<int64_t> shape, int kind = 0) {
+        TensorInfo ti;
+        ti.name = name; ti.kind = kind; ti.ndim = (int)shape.size();
+        ti.numel = 1; int i = 0;
+        for (auto s : shape) { ti.shape[i++] = s; ti.numel *= s; }
+        for (; i < 4; ++i) ti.shape[i] = 1;
+        ti.offset = total;
+        total += (ti.numel + 3) & ~(int64_t)3;  // keep every tensor 16-byte aligned
+        t.push_back(ti);
+        return ti.offset;
+    }
+    void add_layer(const std::string& p, LayerP& L) {
+        L.qkv_w = add(p + "dec_attn.qkv_net.weight", {DQKV, DM});
+        L.qkv_b = add(p + "dec_attn.qkv_net.bias", {DQKV});
+        L.o_w = add(p + "dec_attn.o_net.weight", {DM, DH});
+        L.ln1_g = add(p + "dec_attn.layer_norm.weight", {DM});
+        L.ln1_b = add(p + "dec_attn.layer_norm.bias", {DM});
+        L.c1_w = add(p + "pos_ff.CoreNet.0.weight", {DI, DM, 3}, 1);
+        L.c1_b = add(p + "pos_ff.CoreNet.0.bias", {DI});
+        L.c2_w = add(p + "pos_ff.CoreNet.2.weight", {DM, DI, 3}, 1);
+        L.c2_b = add(p + "pos_ff.CoreNet.2.bias", {DM});
+        L.ln2_g = add(p + "pos_ff.layer_norm.weight", {DM});
+        L.ln2_b = add(p + "pos_ff.layer_norm.bias", {DM});
+    }
+    void add_pred(const std::string& p, PredP& P) {
+        P.c1_w = add(p + "layers.0.conv.weight", {DP, DM, 3}, 1);
+        P.c1_b = add(p + "layers.0.conv.bias", {DP});
+        P.n1_g = add(p + "layers.0.norm.weight", {DP});
+        P.n1_b = add(p + "layers.0.norm.bias", {DP});
+        P.c2_w = add(p + "layers.1.conv.weight", {DP, DP, 3}, 1);
+        P.c2_b = add(p + "layers.1.conv.bias", {DP});
+        P.n2_g = add(p + "layers.1.norm.weight", {DP});
+        P.n2_b = add(p + "layers.1.norm.bias", {DP});
+        P.fc_w = add(p + "fc.weight", {1, DP});
+        P.fc_b = add(p + "fc.bias", {1});
+    }
+    ParamTable() {
+        enc_begin = total;
+        word_emb = add("encoder.word_emb.weight", {NSYM, DM});
+        for (int i = 0; i < NL; ++i) add_layer("encoder.layers." + std::to_string(i) + ".", enc[i]);
+        enc_end = dur_begin = total;
+        add_pred("duration_predictor.", dur);
+        dur_end = pitch_begin = total;
+        add_pred("pitch_predictor.", pitch);
+        pitch_end = pemb_begin = total;
+        pitch_emb_w = add("pitch_emb.weight", {DM, 1, 3});
+        pitch_emb_b = add("pitch_emb.bias", {DM});
+        pemb_end = energy_begin = total;
+        add_pred("energy_predictor.", energy);
+        energy_end = eemb_begin = total;
+        energy_emb_w = add("energy_emb.weight", {DM, 1, 3});
+        energy_emb_b = add("energy_emb.bias", {DM});
+        eemb_end = dec_begin = total;
+        for (int i = 0; i < NL; ++i) add_layer("decoder.layers." + std::to_string(i) + ".", dec[i]);
+        dec_end = proj_begin = total;
+        proj_w = add("proj.weight", {NMEL, DM});
+        proj_b = add("proj.bias", {NMEL});
+        proj_end = attn_begin = total;
+        // Stage-1 aligner (ConvAttention, attention.py:171-220): carried for checkpoint compatibility; its
+        // compute is a "next" row and no kernel touches it yet.
+        add("attention.query_proj.0.conv.weight", {160, 80, 3}, 1);
+        add("attention.query_proj.0.conv.bias", {160});
+        add("attention.query_proj.2.conv.weight", {80, 160, 1});
+        add("attention.query_proj.2.conv.bias", {80});
+        add("attention.query_proj.4.conv.weight", {80, 80, 1});
+        add("attention.query_proj.4.conv.bias", {80});
+        add("attention.attn_proj.weight", {1, 80, 1, 1});
+        add("attention.attn_proj.bias", {1});
+        add("attention.key_proj.0.conv.weight", {768, 384, 3}, 1);
+        add("attention.key_proj.0.conv.bias", {768});
+        add("attention.key_proj.2.conv.weight", {80, 768, 1});
+        add("attention.key_proj.2.conv.bias", {80});
+        attn_end = total;
+    }
+};
+const ParamTable& table() { static ParamTable T; return T; }
+
+// ------------------------------------------------------------------ workspace plan ----
+struct Bump {
+    int64_t cur = 0;
+    int64_t take(int64_t n) { int64_t o = cur; cur += (n + 3) & ~(int64_t)3; return o; }
+    // sequence buffer of `rows` x C with one guard row before and after; returns offset of row 0
+    int64_t seq(int64_t rows, int C) { int64_t o = take((rows + 2) * (int64_t)C); return o + C; }
+};
+
+struct LayerA { int64_t qkv, P, av, sum1, mean1, rstd1, y1, h, sum2, mean2, rstd2; };
+struct PredA { int64_t c1, m1, r1, n1, c2, m2, r2, n2, out; };
+struct Plan {
+    int B, Tt, Tm, Ttp, Tmp;
+    int64_t Re, Rd, Tse, Tsd;
+    // forward
+    int64_t enc_x[NL + 1], dec_x[NL + 1];
+    LayerA enc[NL], dec[NL];
+    PredA dur, pitch, energy;
+    int64_t ptgt, etgt, enc_c1, enc_c2, tok, tstart, dec_lens, mel_out, dur_pred;
+    // loss / grads of outputs
+    int64_t acc, losses, d_mel, d_pitch, d_energy, d_logdur;
+    // backward scratch, sized for the decoder (Rd rows); the encoder reuses it
+    int64_t gA, gB, gC, gD, gH, gAV, gP, gQKV, gE, pa, pb;
+    int64_t total;
+};
+
+int make_plan(const xva_fp_dims* d, Plan* p) {
+    XVA_CHECK_ARG(d && d->B > 0 && d->Tt > 0 && d->Tm > 0, "fastpitch: bad dims");
+    XVA_CHECK_ARG(d->stage >= 2 && d->stage <= 4, "fastpitch: stage must be 2, 3 or 4 (stage 1 aligner is not built yet)");
+    XVA_CHECK_ARG(d->Tm + 2 <= 2048 && d->Tt + 2 <= 2048, "fastpitch: sequence longer than 2046 unsupported");
+    p->B = d->B; p->Tt = d->Tt; p->Tm = d->Tm; p->Ttp = d->Tt + 2; p->Tmp = d->Tm + 2;
+    p->Re = (int64_t)d->B * p->Ttp; p->Rd = (int64_t)d->B * p->Tmp;
+    p->Tse = (p->Ttp + 3) & ~3; p->Tsd = (p->Tmp + 3) & ~3;
+    Bump b;
+    auto plan_layers = [&](int64_t R, int Tp, int64_t Ts, int64_t* x, LayerA* L) {
+        x[0] = b.seq(R, DM);
+        for (int i = 0; i < NL; ++i) {
+            L[i].qkv = b.seq(R, DQKV);
+            L[i].P = b.take((int64_t)p->B * Tp * Ts);
+            L[i].av = b.seq(R, DH);
+            L[i].sum1 = b.seq(R, DM);
+            L[i].mean1 = b.take(R); L[i].rstd1 = b.take(R);
+            L[i].y1 = b.seq(R, DM);
+            L[i].h = b.seq(R, DI);
+            L[i].sum2 = b.seq(R, DM);
+            L[i].mean2 = b.take(R); L[i].rstd2 = b.take(R);
+            x[i + 1] = b.seq(R, DM);
+        }
+    };
+    auto plan_pred = [&](PredA& A) {
+        A.c1 = b.seq(p->Re, DP); A.m1 = b.take(p->Re); A.r1 = b.take(p->Re); A.n1 = b.seq(p->Re, DP);
+        A.c2 = b.seq(p->Re, DP); A.m2 = b.take(p->Re); A.r2 = b.take(p->Re); A.n2 = b.seq(p->Re, DP);
+        A.out = b.take(p->Re + 8) + 4;
+    };
+    plan_layers(p->Re, p->Ttp, p->Tse, p->enc_x, p->enc);
+    plan_pred(p->dur); plan_pred(p->pitch); plan_pred(p->energy);
+    p->ptgt = b.take(p->Re + 8) + 4; p->etgt = b.take(p->Re + 8) + 4;
+    p->enc_c1 = b.seq(p->Re, DM); p->enc_c2 = b.seq(p->Re, DM);
+    p->tok = b.take((int64_t)p->B * p->Tm); p->tstart = b.take((int64_t)p->B * (p->Tt + 1)); p->dec_lens = b.take(p->B);
+    plan_layers(p->Rd, p->Tmp, p->Tsd, p->dec_x, p->dec);
+    p->mel_out = b.seq(p->Rd, NMEL);
+    p->dur_pred = b.take(p->Re + 8) + 4;
+    p->acc = b.take(8); p->losses = b.take(8);
+    p->d_mel = b.seq(p->Rd, NMEL);
+    p->d_pitch = b.take(p->Re + 8) + 4; p->d_energy = b.take(p->Re + 8) + 4; p->d_logdur = b.take(p->Re + 8) + 4;
+    int64_t Rm = p->Rd > p->Re ? p->Rd : p->Re;
+    int64_t Tsm = p->Tsd > p->Tse ? p->Tsd : p->Tse;
+    int Tpm = p->Tmp > p->Ttp ? p->Tmp : p->Ttp;
+    p->gA = b.seq(Rm, DM); p->gB = b.seq(Rm, DM); p->gC = b.seq(Rm, DM); p->gD = b.seq(Rm, DM);
+    p->gH = b.seq(Rm, DI); p->gAV = b.seq(Rm, DH); p->gP = b.take((int64_t)p->B * Tpm * Tsm); p->gQKV = b.seq(Rm, DQKV);
+    p->gE = b.seq(p->Re, DM); p->pa = b.seq(p->Re, DP); p->pb = b.seq(p->Re, DP);
+    p->total = b.cur;
+    return XVA_OK;
+}
+
+// ------------------------------------------------------------------ GEMM helpers ----
+struct Ctx {
+    const xva_fp_dims* d;
+    Plan pl;
+    const float* P;  // params
+    float* G;        // grads (may be null in forward)
+    float* W;        // workspace
+    void* st;
+    int compute;
+};
+
+static xva_gemm_params gp0(int compute) {
+    xva_gemm_params g;
+    memset(&g, 0, sizeof(g));
+    g.batch = 1; g.alpha = 1.f; g.splitk = 1; g.compute = compute;
+    return g;
+}
+static int splitk_for(int M, int N, int K) {
+    long tiles = (long)xva_cdiv(M, 128) * xva_cdiv(N, 128);
+    int sk = (int)((768 + tiles - 1) / tiles);
+    int nkt = xva_cdiv(K, 32);
+    int maxsk = nkt / 8; if (maxsk < 1) maxsk = 1;   // at least 8 K-tiles per split
+    if (sk > maxsk) sk = maxsk;
+    if (sk < 1) sk = 1;
+    return sk;
+}
+// Y[rows, N] = X[rows, K] W[N, K]^T (+bias) (+R) ...   (nn.Linear)
+static int linear_fwd(Ctx& c, const float* X, int64_t rows, int K, int64_t ldx, const float* Wm, const float* bias, float* Y,
+                      int N, int64_t ldy, const float* R, int64_t ldr, int mask, const int32_t* lens, int Tp) {
+    xva_gemm_params g = gp0(c.compute);
+    g.layout = XVA_GEMM_NT; g.A = X; g.B = Wm; g.C = Y; g.M = (int)rows; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy;
+    g.bias = bias; g.R = R; g.ldr = ldr; g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
+    return xva_gemm(&g, c.st);
+}
+// dX[rows, K] = dY[rows, N] W[N, K] (+R)
+static int linear_bwd_data(Ctx& c, const float* dY, int64_t rows, int N, int64_t ldy, const float* Wm, int K, float* dX,
+                           int64_t ldx, const float* R, int64_t ldr, int mask, const int32_t* lens, int Tp) {
+    xva_gemm_params g = gp0(c.compute);
+    g.layout = XVA_GEMM_NN; g.A = dY; g.B = Wm; g.C = dX; g.M = (int)rows; g.N = K; g.K = N; g.lda = ldy; g.ldb = K; g.ldc = ldx;
+    g.R = R; g.ldr = ldr; g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
+    return xva_gemm(&g, c.st);
+}
+// dW[N, K] += dY[rows, N]^T X[rows, K]
+static int linear_bwd_weight(Ctx& c, const float* dY, int64_t rows, int N, int64_t ldy, const float* X, int K, int64_t ldx,
+                             float* dW) {
+    xva_gemm_params g = gp0(c.compute);
+    g.layout = XVA_GEMM_TN; g.A = dY; g.B = X; g.C = dW; g.M = N; g.N = K; g.K = (int)rows; g.lda = ldy; g.ldb = ldx; g.ldc = K;
+    g.accumulate = 1; g.splitk = splitk_for(N, K, (int)rows);
+    return xva_gemm(&g, c.st);
+}
+// Conv1d(k=3, pad=1) over a padded token-major sequence: Y = act(Xcat Wt^T + b) (+R), Wt tap-major [Cout][3*Cin]
+static int conv3_fwd(Ctx& c, const float* X, int64_t rows, int Cin, const float* Wt, const float* bias, float* Y, int Cout,
+                     int relu, const float* R, int mask, const int32_t* lens, int Tp) {
+    xva_gemm_params g = gp0(c.compute);
+    g.layout = XVA_GEMM_NT; g.A = X - Cin; g.B = Wt; g.C = Y; g.M = (int)rows; g.N = Cout; g.K = 3 * Cin;
+    g.lda = Cin; g.ldb = 3 * Cin; g.ldc = Cout; g.bias = bias; g.relu = relu; g.R = R; g.ldr = Cout;
+    g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
+    return xva_gemm(&g, c.st);
+}
+// dX[r] = sum_j dY[r-1+j] W[:, tap 2-j, :]  (+R) (gated by Gate > 0)
+static int conv3_bwd_data(Ctx& c, const float* dY, int64_t rows, int Cout, const float* Wt, int Cin, float* dX, const float* R,
+                          const float* Gate, int mask, const int32_t* lens, int Tp, int accumulate) {
+    xva_gemm_params g = gp0(c.compute);
+    g.layout = XVA_GEMM_NN; g.A = dY - Cout; g.B = Wt; g.C = dX; g.M = (int)rows; g.N = Cin; g.K = 3 * Cout;
+    g.lda = Cout; g.ldb = 3 * Cin; g.ldc = Cin; g.seglen = Cout; g.seg0 = 2 * Cin; g.segstride = -Cin;
+    g.R = R; g.ldr = Cin; g.G = Gate; g.ldg = Cin; g.mask_mode = mask; g.lens = lens; g.Tp = Tp; g.accumulate = accumulate;
+    return xva_gemm(&g, c.st);
+}
+// dWt[Cout][3*Cin] += dY^T Xcat
+static int conv3_bwd_weight(Ctx& c, const float* dY, int64_t rows, int Cout, const float* X, int Cin, float* dWt) {
+    xva_gemm_params g = gp0(c.compute);
+    g.layout = XVA_GEMM_TN; g.A = dY; g.B = X - Cin; g.C = dWt; g.M = Cout; g.N = 3 * Cin; g.K = (int)rows;
+    g.lda = Cout; g.ldb = Cin; g.ldc = 3 * Cin; g.accumulate = 1; g.splitk = splitk_for(Cout, 3 * Cin, (int)rows);
+    return xva_gemm(&g, c.st);
+}
+
+// ------------------------------------------------------------------ transformer stack ----
+static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t* xo, int64_t R, int Tp, int64_t Ts,
+                      const int32_t* lens) {
+    const int B = c.pl.B;
+    for (int l = 0; l < NL; ++l) {
+        const LayerP& p = LP[l];
+        const LayerA& a = LA[l];
+        float* x = c.W + xo[l];
+        float* qkv = c.W + a.qkv; float* Pm = c.W + a.P; float* av = c.W + a.av;
+        // qkv = x Wqkv^T + b                                             (transformer.py:109)
+        XVA_TRY(linear_fwd(c, x, R, DM, DM, c.P + p.qkv_w, c.P + p.qkv_b, qkv, DQKV, DQKV, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
+        {   // S = scale * Q K^T per item                                  (transformer.py:118-119)
+            xva_gemm_params g = gp0(c.compute);
+            g.layout = XVA_GEMM_NT; g.A = qkv; g.B = qkv + DH; g.C = Pm; g.M = Tp; g.N = Tp; g.K = DH;
+            g.lda = DQKV; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DQKV; g.sB = g.sA; g.sC = (int64_t)Tp * Ts;
+            g.alpha = 0.125f;
+            XVA_TRY(xva_gemm(&g, c.st));
+        }
+        XVA_TRY(xva_fp_softmax_fwd(Pm, lens, B, Tp, Ts, 0.f, 0, 0, c.st));          // :121-127
+        {   // AV = P V                                                     (transformer.py:130)
+            xva_gemm_params g = gp0(c.compute);
+            g.layout = XVA_GEMM_NN; g.A = Pm; g.B = qkv + 2 * DH; g.C = av; g.M = Tp; g.N = DH; g.K = Tp;
+            g.lda = Ts; g.ldb = DQKV; g.ldc = DH; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DH;
+            XVA_TRY(xva_gemm(&g, c.st));
+        }
+        // sum1 = x + AV Wo^T ; y1 = LN(sum1) * mask                        (transformer.py:137-146,166-167)
+        XVA_TRY(linear_fwd(c, av, R, DH, DH, c.P + p.o_w, nullptr, c.W + a.sum1, DM, DM, x, DM, XVA_MASK_NONE, nullptr, 0));
+        XVA_TRY(xva_fp_layernorm_fwd(c.W + a.sum1, c.P + p.ln1_g, c.P + p.ln1_b, c.W + a.y1, c.W + a.mean1, c.W + a.rstd1, R, DM,
+                                     XVA_MASK_LEN, lens, Tp, c.st));
+        // h = relu(conv1(y1)) ; sum2 = y1 + conv2(h) ; x' = LN(sum2) * mask  (transformer.py:59-77,168-170)
+        XVA_TRY(conv3_fwd(c, c.W + a.y1, R, DM, c.P + p.c1_w, c.P + p.c1_b, c.W + a.h, DI, 1, nullptr, XVA_MASK_PAD, lens, Tp));
+        XVA_TRY(conv3_fwd(c, c.W + a.h, R, DI, c.P + p.c2_w, c.P + p.c2_b, c.W + a.sum2, DM, 0, c.W + a.y1, XVA_MASK_NONE, nullptr, 0));
+        XVA_TRY(xva_fp_layernorm_fwd(c.W + a.sum2, c.P + p.ln2_g, c.P + p.ln2_b, c.W + xo[l + 1], c.W + a.mean2, c.W + a.rstd2, R, DM,
+                                     XVA_MASK_LEN, lens, Tp, c.st));
+    }
+    return XVA_OK;
+}
+
+// Backward through the 6 layers.  On entry gA holds dL/d(x_out) ; on exit gA holds dL/d(x_in) (LEN-masked).
+static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t* xo, int64_t R, int Tp, int64_t Ts,
+                      const int32_t* lens, bool want_grads) {
+    const int B = c.pl.B;
+    float *gA = c.W + c.pl.gA, *gB = c.W + c.pl.gB, *gC = c.W + c.pl.gC, *gD = c.W + c.pl.gD, *gH = c.W + c.pl.gH,
+          *gAV = c.W + c.pl.gAV, *gP = c.W + c.pl.gP, *gQKV = c.W + c.pl.gQKV;
+    for (int l = NL - 1; l >= 0; --l) {
+        const LayerP& p = LP[l];
+        const LayerA& a = LA[l];
+        float* x = c.W + xo[l];
+        float* qkv = c.W + a.qkv; float* Pm = c.W + a.P; float* av = c.W + a.av;
+        float* Gg = want_grads ? c.G : nullptr;
+        // LN2 backward -> gB = d sum2 (zero on dead rows)
+        XVA_TRY(xva_fp_layernorm_bwd(gA, c.W + a.sum2, c.W + a.mean2, c.W + a.rstd2, c.P + p.ln2_g, gB, Gg ? Gg + p.ln2_g : nullptr,
+                                     Gg ? Gg + p.ln2_b : nullptr, R, DM, XVA_MASK_LEN, lens, Tp, 0, c.st));
+        // conv2 backward: gH = (gB (*) W2) * [h > 0], structural rows zero
+        XVA_TRY(conv3_bwd_data(c, gB, R, DM, c.P + p.c2_w, DI, gH, nullptr, c.W + a.h, XVA_MASK_PAD, lens, Tp, 0));
+        if (Gg) {
+            XVA_TRY(conv3_bwd_weight(c, gB, R, DM, c.W + a.h, DI, Gg + p.c2_w));
+            XVA_TRY(xva_fp_colsum(gB, Gg + p.c2_b, R, DM, DM, c.st));
+        }
+        // conv1 backward + residual: gC = gB + gH (*) W1, LEN-masked (y1 was multiplied by mask)
+        XVA_TRY(conv3_bwd_data(c, gH, R, DI, c.P + p.c1_w, DM, gC, gB, nullptr, XVA_MASK_LEN, lens, Tp, 0));
+        if (Gg) {
+            XVA_TRY(conv3_bwd_weight(c, gH, R, DI, c.W + a.y1, DM, Gg + p.c1_w));
+            XVA_TRY(xva_fp_colsum(gH, Gg + p.c1_b, R, DI, DI, c.st));
+        }
+        // LN1 backward -> gD = d sum1
+        XVA_TRY(xva_fp_layernorm_bwd(gC, c.W + a.sum1, c.W + a.mean1, c.W + a.rstd1, c.P + p.ln1_g, gD, Gg ? Gg + p.ln1_g : nullptr,
+                                     Gg ? Gg + p.ln1_b : nullptr, R, DM, XVA_MASK_LEN, lens, Tp, 0, c.st));
+        // o_net backward
+        XVA_TRY(linear_bwd_data(c, gD, R, DM, DM, c.P + p.o_w, DH, gAV, DH, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
+        if (Gg) XVA_TRY(linear_bwd_weight(c, gD, R, DM, DM, av, DH, DH, Gg + p.o_w));
+        {   // dP = dAV V^T
+            xva_gemm_params g = gp0(c.compute);
+            g.layout = XVA_GEMM_NT; g.A = gAV; g.B = qkv + 2 * DH; g.C = gP; g.M = Tp; g.N = Tp; g.K = DH;
+            g.lda = DH; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DH; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * Ts;
+            XVA_TRY(xva_gemm(&g, c.st));
+        }
+        {   // dV = P^T dAV  -> gQKV[:, 128:192]
+            xva_gemm_params g = gp0(c.compute);
+            g.layout = XVA_GEMM_TN; g.A = Pm; g.B = gAV; g.C = gQKV + 2 * DH; g.M = Tp; g.N = DH; g.K = Tp;
+            g.lda = Ts; g.ldb = DH; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DH; g.sC = (int64_t)Tp * DQKV;
+            XVA_TRY(xva_gemm(&g, c.st));
+        }
+        XVA_TRY(xva_fp_softmax_bwd(Pm, gP, B, Tp, Ts, 0.125f, 0.f, 0, 0, c.st));    // gP = dS (incl. 1/sqrt(d))
+        {   // dQ = dS K -> gQKV[:, 0:64]
+            xva_gemm_params g = gp0(c.compute);
+            g.layout = XVA_GEMM_NN; g.A = gP; g.B = qkv + DH; g.C = gQKV; g.M = Tp; g.N = DH; g.K = Tp;
+            g.lda = Ts; g.ldb = DQKV; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DQKV;
+            XVA_TRY(xva_gemm(&g, c.st));
+        }
+        {   // dK = dS^T Q -> gQKV[:, 64:128]
+            xva_gemm_params g = gp0(c.compute);
+            g.layout = XVA_GEMM_TN; g.A = gP; g.B = qkv; g.C = gQKV + DH; g.M = Tp; g.N = DH; g.K = Tp;
+            g.lda = Ts; g.ldb = DQKV; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DQKV;
+            XVA_TRY(xva_gemm(&g, c.st));
+        }
+        // d x = gD + gQKV Wqkv, LEN-masked -> gA
+        XVA_TRY(linear_bwd_data(c, gQKV, R, DQKV, DQKV, c.P + p.qkv_w, DM, gA, DM, gD, DM, XVA_MASK_LEN, lens, Tp));
+        if (Gg) {
+            XVA_TRY(linear_bwd_weight(c, gQKV, R, DQKV, DQKV, x, DM, DM, Gg + p.qkv_w));
+            XVA_TRY(xva_fp_colsum(gQKV, Gg + p.qkv_b, R, DQKV, DQKV, c.st));
+        }
+    }
+    return XVA_OK;
+}
+
+// ------------------------------------------------------------------ temporal predictors ----
+static int pred_fwd(Ctx& c, const PredP& p, const PredA& a, const float* xin, const int32_t* lens) {
+    const int64_t R = c.pl.Re; const int Tp = c.pl.Ttp;
+    XVA_TRY(conv3_fwd(c, xin, R, DM, c.P + p.c1_w, c.P + p.c1_b, c.W + a.c1, DP, 1, nullptr, XVA_MASK_PAD, lens, Tp));
+    XVA_TRY(xva_fp_layernorm_fwd(c.W + a.c1, c.P + p.n1_g, c.P + p.n1_b, c.W + a.n1, c.W + a.m1, c.W + a.r1, R, DP, XVA_MASK_PAD, lens, Tp, c.st));
+    XVA_TRY(conv3_fwd(c, c.W + a.n1, R, DP, c.P + p.c2_w, c.P + p.c2_b, c.W + a.c2, DP, 1, nullptr, XVA_MASK_PAD, lens, Tp));
+    XVA_TRY(xva_fp_layernorm_fwd(c.W + a.c2, c.P + p.n2_g, c.P + p.n2_b, c.W + a.n2, c.W + a.m2, c.W + a.r2, R, DP, XVA_MASK_PAD, lens, Tp, c.st));
+    XVA_TRY(linear_fwd(c, c.W + a.n2, R, DP, DP, c.P + p.fc_w, c.P + p.fc_b, c.W + a.out, 1, 1, nullptr, 0, XVA_MASK_LEN, lens, Tp));
+    return XVA_OK;
+}
+// d_out: (Re) gradient of the predictor output (zero on dead rows).  Accumulates (or writes) dL/d xin into gX.
+static int pred_bwd(Ctx& c, const PredP& p, const PredA& a, const float* xin, const float* d_out, float* gX, int accumulate,
+                    const int32_t* lens) {
+    const int64_t R = c.pl.Re; const int Tp = c.pl.Ttp;
+    float *pa = c.W + c.pl.pa, *pb = c.W + c.pl.pb;
+    XVA_TRY(xva_fp_outer(d_out, c.P + p.fc_w, pa, R, DP, c.st));                                   // pa = d n2
+    XVA_TRY(xva_fp_rowscale_colsum(c.W + a.n2, d_out, c.G + p.fc_w, R, DP, c.st));
+    XVA_TRY(xva_fp_colsum(d_out, c.G + p.fc_b, R, 1, 1, c.st));
+    XVA_TRY(xva_fp_layernorm_bwd(pa, c.W + a.c2, c.W + a.m2, c.W + a.r2, c.P + p.n2_g, pb, c.G + p.n2_g, c.G + p.n2_b, R, DP,
+                                 XVA_MASK_PAD, lens, Tp, 1, c.st));                                // pb = d conv2-preact
+    XVA_TRY(conv3_bwd_data(c, pb, R, DP, c.P + p.c2_w, DP, pa, nullptr, nullptr, XVA_MASK_PAD, lens, Tp, 0));   // pa = d n1
+    XVA_TRY(conv3_bwd_weight(c, pb, R, DP, c.W + a.n1, DP, c.G + p.c2_w));
+    XVA_TRY(xva_fp_colsum(pb, c.G + p.c2_b, R, DP, DP, c.st));
+    XVA_TRY(xva_fp_layernorm_bwd(pa, c.W + a.c1, c.W + a.m1, c.W + a.r1, c.P + p.n1_g, pb, c.G + p.n1_g, c.G + p.n1_b, R, DP,
+                                 XVA_MASK_PAD, lens, Tp, 1, c.st));                                // pb = d conv1-preact
+    XVA_TRY(conv3_bwd_data(c, pb, R, DP, c.P + p.c1_w, DM, gX, nullptr, nullptr, XVA_MASK_LEN, lens, Tp, accumulate));
+    XVA_TRY(conv3_bwd_weight(c, pb, R, DP, xin, DM, c.G + p.c1_w));
+    XVA_TRY(xva_fp_colsum(pb, c.G + p.c1_b, R, DP, DP, c.st));
+    return XVA_OK;
+}
+
+static int make_ctx(Ctx& c, const xva_fp_dims* d, const float* params, float* grads, float* ws, int64_t ws_bytes, void* st) {
+    XVA_TRY(make_plan(d, &c.pl));
+    XVA_CHECK_ARG(params && ws, "fastpitch: null params/workspace");
+    XVA_CHECK_ARG(((uintptr_t)params % 16) == 0 && ((uintptr_t)ws % 16) == 0, "fastpitch: params/workspace must be 16-byte aligned");
+    XVA_CHECK_ARG(ws_bytes >= c.pl.total * (int64_t)sizeof(float), "fastpitch: workspace too small (%ld < %ld bytes)", (long)ws_bytes,
+                  (long)(c.pl.total * sizeof(float)));
+    c.d = d; c.P = params; c.G = grads; c.W = ws; c.st = st; c.compute = d->compute;
+    return XVA_OK;
+}
+
+}  // namespace
+
+// =========================================================================== C ABI ====
+extern "C" int64_t xva_fp_param_floats(void) { return table().total; }
+extern "C" int xva_fp_num_tensors(void) { return (int)table().t.size(); }
+extern "C" int xva_fp_tensor_info(int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int32_t* ndim, int64_t* shape4,
+                                  int32_t* kind) {
+    const ParamTable& T = table();
+    XVA_CHECK_ARG(i >= 0 && i < (int)T.t.size() && name && name_cap > 0, "tensor_info: bad index");
+    const TensorInfo& ti = T.t[i];
+    snprintf(name, name_cap, "%s", ti.name.c_str());
+    if (offset) *offset = ti.offset;
+    if (numel) *numel = ti.numel;
+    if (ndim) *ndim = ti.ndim;
+    if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = ti.shape[k];
+    if (kind) *kind = ti.kind;
+    return XVA_OK;
+}
+// Trainable [begin, end) ranges of the flat buffer for a stage (freezing of xva_train.py:589-672). Returns count.
+extern "C" int xva_fp_trainable_ranges(int stage, int64_t* begins, int64_t* ends, int cap) {
+    const ParamTable& T = table();
+    int n = 0;
+    auto push = [&](int64_t b, int64_t e) { if (n < cap) { begins[n] = b; ends[n] = e; } ++n; };
+    push(T.enc_begin, T.enc_end);
+    if (stage == 1 || stage == 2) push(T.dur_begin, T.dur_end);
+    if (stage == 3) { push(T.pitch_begin, T.pitch_end); push(T.pemb_begin, T.pemb_end); push(T.energy_begin, T.energy_end); }
+    if (stage == 2 || stage == 3 || stage == 4) push(T.eemb_begin, T.eemb_end);
+    if (stage == 3 || stage == 4) { push(T.dec_begin, T.dec_end); push(T.proj_begin, T.proj_end); }
+    if (stage == 1) push(T.attn_begin, T.attn_end);
+    return n;
+}
+
+extern "C" int64_t xva_fp_workspace_bytes(const xva_fp_dims* d) {
+    Plan p;
+    if (make_plan(d, &p) != XVA_OK) return -1;
+    return p.total * (int64_t)sizeof(float);
+}
+
+extern "C" int xva_fp_slot_offset(const xva_fp_dims* d, int slot, int64_t* off_floats) {
+    Plan p;
+    XVA_TRY(make_plan(d, &p));
+    XVA_CHECK_ARG(off_floats, "slot_offset: null");
+    switch (slot) {
+        case XVA_FP_SLOT_MEL_OUT: *off_floats = p.mel_out; break;
+        case XVA_FP_SLOT_PITCH_PRED: *off_floats = p.pitch.out; break;
+        case XVA_FP_SLOT_ENERGY_PRED: *off_floats = p.energy.out; break;
+        case XVA_FP_SLOT_LOG_DUR_PRED: *off_floats = p.dur.out; break;
+        case XVA_FP_SLOT_DUR_PRED: *off_floats = p.dur_pred; break;
+        case XVA_FP_SLOT_PITCH_TGT: *off_floats = p.ptgt; break;
+        case XVA_FP_SLOT_ENERGY_TGT: *off_floats = p.etgt; break;
+        case XVA_FP_SLOT_DEC_LENS: *off_floats = p.dec_lens; break;
+        case XVA_FP_SLOT_LOSS_ACC: *off_floats = p.acc; break;
+        case XVA_FP_SLOT_LOSSES: *off_floats = p.losses; break;
+        case XVA_FP_SLOT_D_MEL: *off_floats = p.d_mel; break;
+        case XVA_FP_SLOT_D_PITCH: *off_floats = p.d_pitch; break;
+        case XVA_FP_SLOT_D_ENERGY: *off_floats = p.d_energy; break;
+        case XVA_FP_SLOT_D_LOGDUR: *off_floats = p.d_logdur; break;
+        case XVA_FP_SLOT_ENC_OUT: *off_floats = p.enc_x[NL]; break;
+        case XVA_FP_SLOT_DEC_OUT: *off_floats = p.dec_x[NL]; break;
+        case XVA_FP_SLOT_ENC_COND: *off_floats = p.enc_c2; break;
+        default: xva_set_error("slot_offset: unknown slot %d", slot); return XVA_ERR_ARG;
+    }
+    return XVA_OK;
+}
+
+extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const xva_fp_batch* bt, float* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    Ctx c;
+    XVA_TRY(make_ctx(c, d, params, nullptr, workspace, workspace_bytes, stream));
+    XVA_CHECK_ARG(bt && bt->text && bt->in_lens && bt->pos_table, "fastpitch_forward: null batch field");
+    const Plan& pl = c.pl;
+    const ParamTable& T = table();
+    const int B = pl.B;
+    // encoder                                                              (model.py:346)
+    XVA_TRY(xva_fp_embed_fwd(bt->text, c.P + T.word_emb, bt->pos_table, c.W + pl.enc_x[0], B, pl.Tt, DM, c.st));
+    XVA_TRY(layers_fwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens));
+    float* enc_out = c.W + pl.enc_x[NL];
+    if (d->stage == 2) {                                                    // model.py:367-373
+        XVA_TRY(pred_fwd(c, T.dur, pl.dur, enc_out, bt->in_lens));
+        XVA_TRY(xva_fp_dur_from_log(c.W + pl.dur.out, c.W + pl.dur_pred, (int)pl.Re, 75.f, c.st));
+        return XVA_OK;
+    }
+    XVA_CHECK_ARG(bt->durs && bt->pitch && bt->energy, "fastpitch_forward: stage 3/4 needs durations, pitch and energy");
+    int32_t* dec_lens = (int32_t*)(c.W + pl.dec_lens);
+    // pitch / energy conditioning                                          (model.py:394-423)
+    XVA_TRY(pred_fwd(c, T.pitch, pl.pitch, enc_out, bt->in_lens));
+    XVA_TRY(xva_fp_avg_pitch(bt->pitch, bt->durs, c.W + pl.ptgt, B, pl.Tt, pl.Tm, 0, c.st));
+    XVA_TRY(xva_fp_cond_add_fwd(enc_out, c.W + pl.ptgt, c.P + T.pitch_emb_w, c.P + T.pitch_emb_b, c.W + pl.enc_c1, bt->in_lens, B,
+                                pl.Ttp, DM, c.st));
+    XVA_TRY(pred_fwd(c, T.energy, pl.energy, c.W + pl.enc_c1, bt->in_lens));
+    XVA_TRY(xva_fp_avg_pitch(bt->energy, bt->durs, c.W + pl.etgt, B, pl.Tt, pl.Tm, 1, c.st));
+    XVA_TRY(xva_fp_cond_add_fwd(c.W + pl.enc_c1, c.W + pl.etgt, c.P + T.energy_emb_w, c.P + T.energy_emb_b, c.W + pl.enc_c2,
+                                bt->in_lens, B, pl.Ttp, DM, c.st));
+    // length regulation + decoder + projection                             (model.py:381-386)
+    XVA_TRY(xva_fp_lenreg_map(bt->durs, (int32_t*)(c.W + pl.tok), (int32_t*)(c.W + pl.tstart), dec_lens, B, pl.Tt, pl.Tm, 1.0f, c.st));
+    XVA_TRY(xva_fp_lenreg_fwd(c.W + pl.enc_c2, (int32_t*)(c.W + pl.tok), dec_lens, bt->pos_table, c.W + pl.dec_x[0], B, pl.Tt, pl.Tm,
+                              DM, c.st));
+    XVA_TRY(layers_fwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens));
+    XVA_TRY(linear_fwd(c, c.W + pl.dec_x[NL], pl.Rd, DM, DM, c.P + T.proj_w, c.P + T.proj_b, c.W + pl.mel_out, NMEL, NMEL, nullptr, 0,
+                       XVA_MASK_PAD, dec_lens, pl.Tmp));
+    return XVA_OK;
+}
+
+// Gradients of the loss w.r.t. the model outputs must already sit in the workspace slots D_MEL / D_PITCH /
+// D_ENERGY / D_LOGDUR (xva_fp_loss_grads writes them there).  Accumulates into `grads` (caller zeroes it when
+// a new optimizer step starts: gradient accumulation across micro-batches is the reference's "GAM").
+extern "C" int xva_fp_backward(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* bt, float* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    Ctx c;
+    XVA_TRY(make_ctx(c, d, params, grads, workspace, workspace_bytes, stream));
+    XVA_CHECK_ARG(grads && ((uintptr_t)grads % 16) == 0, "fastpitch_backward: grads null or misaligned");
+    XVA_CHECK_ARG(bt && bt->text && bt->in_lens, "fastpitch_backward: null batch field");
+    const Plan& pl = c.pl;
+    const ParamTable& T = table();
+    const int B = pl.B;
+    float* gA = c.W + pl.gA;
+    float* gE = c.W + pl.gE;
+    float* enc_out = c.W + pl.enc_x[NL];
+    if (d->stage == 2) {
+        XVA_TRY(pred_bwd(c, T.dur, pl.dur, enc_out, c.W + pl.d_logdur, gA, 0, bt->in_lens));
+    } else {
+        int32_t* dec_lens = (int32_t*)(c.W + pl.dec_lens);
+        float* d_mel = c.W + pl.d_mel;
+        // proj backward                                                    (model.py:386)
+        XVA_TRY(linear_bwd_data(c, d_mel, pl.Rd, NMEL, NMEL, c.P + T.proj_w, DM, gA, DM, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
+        XVA_TRY(linear_bwd_weight(c, d_mel, pl.Rd, NMEL, NMEL, c.W + pl.dec_x[NL], DM, DM, c.G + T.proj_w));
+        XVA_TRY(xva_fp_colsum(d_mel, c.G + T.proj_b, pl.Rd, NMEL, NMEL, c.st));
+        XVA_TRY(layers_bwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens, true));
+        // regulate_len backward: segmented sum of frame grads per token -> gE = d enc_c2 = d enc_c1
+        XVA_TRY(xva_fp_lenreg_bwd(gA, (int32_t*)(c.W + pl.tstart), dec_lens, gE, B, pl.Tt, pl.Tm, DM, 0, c.st));
+        XVA_TRY(xva_fp_cond_add_bwd(gE, c.W + pl.etgt, c.G + T.energy_emb_w, c.G + T.energy_emb_b, bt->in_lens, B, pl.Ttp, DM, c.st));
+        if (d->stage == 3) {
+            XVA_TRY(pred_bwd(c, T.energy, pl.energy, c.W + pl.enc_c1, c.W + pl.d_energy, gE, 1, bt->in_lens));
+            XVA_TRY(xva_fp_cond_add_bwd(gE, c.W + pl.ptgt, c.G + T.pitch_emb_w, c.G + T.pitch_emb_b, bt->in_lens, B, pl.Ttp, DM, c.st));
+            XVA_TRY(pred_bwd(c, T.pitch, pl.pitch, enc_out, c.W + pl.d_pitch, gE, 1, bt->in_lens));
+        }
+        // hand over to the encoder stack: gA <- gE
+        if (hipMemcpyAsync(gA, gE, pl.Re * DM * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)c.st) != hipSuccess) {
+            xva_set_error("fastpitch_backward: memcpy failed");
+            return XVA_ERR_HIP;
+        }
+    }
+    XVA_TRY(layers_bwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, true));
+    XVA_TRY(xva_fp_embed_bwd(bt->text, gA, c.G + T.word_emb, B, pl.Tt, DM, c.st));
+    return XVA_OK;
+}

@@ -1,0 +1,710 @@
+// fp_ops.hip — the non-GEMM kernels of the FastPitch forward/backward hot loop (gfx950).
+//
+// All sequence tensors use the padded token-major layout (B, Tp = T + 2, C), fp32: row 0 and
+// row Tp-1 of every item are structural zero rows (they ARE the zero padding of the k=3
+// convolutions, so a conv is a plain overlapping-row GEMM), rows 1..len are live.  Every
+// kernel here is HBM-bound: one pass over its operands, float4 / wave-per-row accesses,
+// reductions by wave64 shuffles.  Reference call sites are cited per kernel.
+#include "xva_common.h"
+#include "../../include/xva_hip.h"
+
+#define WAVES_PER_BLOCK 4
+
+// =====================================================================================
+// Embedding + positional embedding  (transformer.py:212-227: word_emb(ids) + pos_emb * mask)
+// out[b, t', :] = emb[id] + (id != 0 ? pos[t'-1] : 0) for 1 <= t' <= T ; structural rows = 0
+// =====================================================================================
+__global__ void embed_fwd_kernel(const int* __restrict__ ids, const float* __restrict__ emb, const float* __restrict__ pos,
+                                 float* __restrict__ out, int B, int T, int C) {
+    int Tp = T + 2;
+    int64_t r = blockIdx.x;
+    int b = (int)(r / Tp), tp = (int)(r % Tp);
+    float4* o = reinterpret_cast<float4*>(out + r * C);
+    if (tp == 0 || tp == Tp - 1) {
+        for (int c = threadIdx.x; c < C / 4; c += blockDim.x) o[c] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    int id = ids[b * T + tp - 1];
+    const float4* e = reinterpret_cast<const float4*>(emb + (int64_t)id * C);
+    const float4* p = reinterpret_cast<const float4*>(pos + (int64_t)(tp - 1) * C);
+    for (int c = threadIdx.x; c < C / 4; c += blockDim.x) {
+        float4 v = e[c];
+        if (id != 0) { float4 q = p[c]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        o[c] = v;
+    }
+}
+// dEmb[id] += dX[row] for id != 0 (padding_idx = 0 receives no gradient: nn.Embedding(padding_idx=0))
+__global__ void embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dX, float* __restrict__ dEmb, int B,
+                                 int T, int C) {
+    int Tp = T + 2;
+    int64_t r = blockIdx.x;
+    int b = (int)(r / Tp), tp = (int)(r % Tp);
+    if (tp == 0 || tp == Tp - 1) return;
+    int id = ids[b * T + tp - 1];
+    if (id == 0) return;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(dEmb + (int64_t)id * C + c, dX[r * C + c]);
+}
+
+extern "C" int xva_fp_embed_fwd(const int32_t* ids, const float* emb, const float* pos, float* out, int B, int T, int C,
+                                void* stream) {
+    XVA_CHECK_ARG(ids && emb && pos && out && C % 4 == 0, "embed_fwd: bad args");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(B * (T + 2)), dim3(128), 0, (hipStream_t)stream, ids, emb, pos, out, B, T, C);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_fp_embed_bwd(const int32_t* ids, const float* dX, float* dEmb, int B, int T, int C, void* stream) {
+    XVA_CHECK_ARG(ids && dX && dEmb, "embed_bwd: bad args");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * (T + 2)), dim3(128), 0, (hipStream_t)stream, ids, dX, dEmb, B, T, C);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// =====================================================================================
+// Masked softmax over keys, in place  (transformer.py:118-127: masked_fill(-inf) + softmax)
+// S: (B, Tp, Ts) rows of Tp scores (Ts = padded row stride). Key j is valid iff 1 <= j <= len[b].
+// One wave64 per query row.  Optional dropout on the probabilities (dropatt).
+// =====================================================================================
+#define SM_MAXPL 32  // up to 64*32 = 2048 keys per row
+__global__ void softmax_fwd_kernel(float* __restrict__ S, const int* __restrict__ lens, int B, int Tp, int64_t Ts,
+                                   float p_drop, uint64_t seed, uint32_t stream_id) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (row >= (int64_t)B * Tp) return;
+    int b = (int)(row / Tp);
+    int len = lens[b];
+    float* s = S + row * Ts;
+    float v[SM_MAXPL];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SM_MAXPL; ++i) {
+        int j = lane + 64 * i;
+        v[i] = (j >= 1 && j <= len) ? s[j] : -INFINITY;
+        m = fmaxf(m, v[i]);
+    }
+    m = xva_wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXPL; ++i) {
+        v[i] = (v[i] == -INFINITY) ? 0.f : expf(v[i] - m);
+        sum += v[i];
+    }
+    sum = xva_wave_sum(sum);
+    float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXPL; ++i) {
+        int j = lane + 64 * i;
+        if (j < Ts) {
+            float pv = v[i] * inv;
+            if (p_drop > 0.f) pv *= xva_dropout_scale(p_drop, seed, stream_id, (uint64_t)row * Tp + j);
+            s[j] = pv;
+        }
+    }
+}
+// dS = scale * P * (dP - sum_k dP_k P_k) in place over dP.
+__global__ void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int B, int Tp, int64_t Ts, float scale,
+                                   float p_drop, uint64_t seed, uint32_t stream_id) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (row >= (int64_t)B * Tp) return;
+    const float* p = P + row * Ts;
+    float* d = dP + row * Ts;
+    float pv[SM_MAXPL], dv[SM_MAXPL];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXPL; ++i) {
+        int j = lane + 64 * i;
+        pv[i] = 0.f; dv[i] = 0.f;
+        if (j < Tp) {
+            float a = p[j], g = d[j];
+            pv[i] = a; dv[i] = g;
+            dot += pv[i] * dv[i];
+        }
+    }
+    dot = xva_wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < SM_MAXPL; ++i) {
+        int j = lane + 64 * i;
+        if (j < Ts) d[j] = (j < Tp) ? scale * pv[i] * (dv[i] - dot) : 0.f;
+    }
+}
+
+extern "C" int xva_fp_softmax_fwd(float* S, const int32_t* lens, int B, int Tp, int64_t Ts, float p_drop, uint64_t seed,
+                                  uint32_t stream_id, void* stream) {
+    XVA_CHECK_ARG(S && lens && Ts >= Tp && Ts <= 64 * SM_MAXPL, "softmax_fwd: row length %ld unsupported (max %d)", (long)Ts,
+                  64 * SM_MAXPL);
+    XVA_CHECK_ARG(p_drop == 0.f, "softmax: attention dropout is not supported by the backward yet");
+    int64_t rows = (int64_t)B * Tp;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(xva_cdiv(rows, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
+                       (hipStream_t)stream, S, lens, B, Tp, Ts, p_drop, seed, stream_id);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_fp_softmax_bwd(const float* P, float* dP, int B, int Tp, int64_t Ts, float scale, float p_drop,
+                                  uint64_t seed, uint32_t stream_id, void* stream) {
+    XVA_CHECK_ARG(P && dP && Ts >= Tp && Ts <= 64 * SM_MAXPL, "softmax_bwd: bad args");
+    XVA_CHECK_ARG(p_drop == 0.f, "softmax: attention dropout is not supported by the backward yet");
+    int64_t rows = (int64_t)B * Tp;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(xva_cdiv(rows, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
+                       (hipStream_t)stream, P, dP, B, Tp, Ts, scale, p_drop, seed, stream_id);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// =====================================================================================
+// LayerNorm over channels, one wave64 per row  (transformer.py:75,146 post-LN; common/layers.py:96)
+// Y = (LN(X) * gamma + beta) * rowmask ; saves mean / rstd.  C = 64 * CPL.
+// =====================================================================================
+template <int CPL>
+__global__ void layernorm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ Y, float* __restrict__ mean,
+                                     float* __restrict__ rstd, int64_t rows, int mask_mode, const int* __restrict__ lens,
+                                     int Tp, float eps) {
+    constexpr int C = 64 * CPL;
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (row >= rows) return;
+    const float* x = X + row * C;
+    float v[CPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { v[i] = x[lane + 64 * i]; s += v[i]; }
+    float mu = xva_wave_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { float d = v[i] - mu; q += d * d; }
+    float var = xva_wave_sum(q) * (1.f / C);
+    float rs = rsqrtf(var + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    bool live = xva_row_live(mask_mode, lens, Tp, row);
+    float* y = Y + row * C;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        int c = lane + 64 * i;
+        y[c] = live ? (v[i] - mu) * rs * gamma[c] + beta[c] : 0.f;
+    }
+}
+
+// dX = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),  dxhat = dY * gamma; dead rows -> 0.
+// relu_gate: additionally zero dX where X <= 0 (X is a post-ReLU activation: ConvReLUNorm).
+// dgamma += sum_r dY * xhat, dbeta += sum_r dY  (per-block partials, then one atomicAdd per column per block).
+template <int CPL>
+__global__ void layernorm_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, const float* __restrict__ gamma, float* __restrict__ dX,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int rows_per_block,
+                                     int mask_mode, const int* __restrict__ lens, int Tp, int relu_gate) {
+    constexpr int C = 64 * CPL;
+    __shared__ float sh_g[WAVES_PER_BLOCK][C];
+    __shared__ float sh_b[WAVES_PER_BLOCK][C];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float ag[CPL], ab[CPL], gm[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; gm[i] = gamma[lane + 64 * i]; }
+    for (int64_t row = r0 + wave; row < r1; row += WAVES_PER_BLOCK) {
+        float* dx = dX + row * C;
+        if (!xva_row_live(mask_mode, lens, Tp, row)) {
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) dx[lane + 64 * i] = 0.f;
+            continue;
+        }
+        const float* x = X + row * C;
+        const float* dy = dY + row * C;
+        float mu = mean[row], rs = rstd[row];
+        float xh[CPL], dh[CPL], xr[CPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            int c = lane + 64 * i;
+            xr[i] = x[c];
+            float g = dy[c];
+            xh[i] = (xr[i] - mu) * rs;
+            dh[i] = g * gm[i];
+            s1 += dh[i];
+            s2 += dh[i] * xh[i];
+            ag[i] += g * xh[i];
+            ab[i] += g;
+        }
+        s1 = xva_wave_sum(s1) * (1.f / C);
+        s2 = xva_wave_sum(s2) * (1.f / C);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            float v = rs * (dh[i] - s1 - xh[i] * s2);
+            if (relu_gate && !(xr[i] > 0.f)) v = 0.f;
+            dx[lane + 64 * i] = v;
+        }
+    }
+    if (dgamma) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { sh_g[wave][lane + 64 * i] = ag[i]; sh_b[wave][lane + 64 * i] = ab[i]; }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float g = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_PER_BLOCK; ++w) { g += sh_g[w][c]; b += sh_b[w][c]; }
+            atomicAdd(dgamma + c, g);
+            atomicAdd(dbeta + c, b);
+        }
+    }
+}
+
+extern "C" int xva_fp_layernorm_fwd(const float* X, const float* gamma, const float* beta, float* Y, float* mean, float* rstd,
+                                    int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp, void* stream) {
+    XVA_CHECK_ARG(X && gamma && beta && Y && mean && rstd, "layernorm_fwd: null");
+    XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
+    dim3 grid(xva_cdiv(rows, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
+    if (C == 384)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<6>), grid, block, 0, (hipStream_t)stream, X, gamma, beta, Y, mean, rstd, rows,
+                           mask_mode, lens, Tp, 1e-5f);
+    else
+        hipLaunchKernelGGL((layernorm_fwd_kernel<4>), grid, block, 0, (hipStream_t)stream, X, gamma, beta, Y, mean, rstd, rows,
+                           mask_mode, lens, Tp, 1e-5f);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_fp_layernorm_bwd(const float* dY, const float* X, const float* mean, const float* rstd, const float* gamma,
+                                    float* dX, float* dgamma, float* dbeta, int64_t rows, int C, int mask_mode,
+                                    const int32_t* lens, int Tp, int relu_gate, void* stream) {
+    XVA_CHECK_ARG(dY && X && mean && rstd && gamma && dX, "layernorm_bwd: null");
+    XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
+    XVA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both null");
+    const int rpb = 32;
+    dim3 grid(xva_cdiv(rows, rpb)), block(64 * WAVES_PER_BLOCK);
+    if (C == 384)
+        hipLaunchKernelGGL((layernorm_bwd_kernel<6>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dgamma,
+                           dbeta, rows, rpb, mask_mode, lens, Tp, relu_gate);
+    else
+        hipLaunchKernelGGL((layernorm_bwd_kernel<4>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dgamma,
+                           dbeta, rows, rpb, mask_mode, lens, Tp, relu_gate);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// =====================================================================================
+// Column sum (bias gradients): out[c] += sum_r X[r][c].  Block = 64 columns x 4 row lanes.
+// =====================================================================================
+__global__ void colsum_kernel(const float* __restrict__ X, float* __restrict__ out, int64_t rows, int C, int64_t ld,
+                              int rows_per_block) {
+    __shared__ float sh[4][64];
+    int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    int c = blockIdx.x * 64 + cl;
+    int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float acc = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + rl; r < r1; r += 4) acc += X[r * ld + c];
+    sh[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) atomicAdd(out + c, sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]);
+}
+extern "C" int xva_fp_colsum(const float* X, float* out, int64_t rows, int C, int64_t ld, void* stream) {
+    XVA_CHECK_ARG(X && out && C > 0, "colsum: bad args");
+    if (rows <= 0) return XVA_OK;
+    const int rpb = 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, X, out, rows,
+                       C, ld, rpb);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// =====================================================================================
+// average_pitch (model.py:82-100) and the frame->token map of regulate_len (model.py:59-79).
+// One block per batch item; thread j owns token j.
+//  avg_out: (B, Tt+2) padded 1-channel sequence: mean of the NON-ZERO frames of token j's span (0 if none),
+//           optionally log(1 + .)   (energy: model.py:413-414)
+// =====================================================================================
+__global__ void avg_pitch_kernel(const float* __restrict__ dense, const int* __restrict__ durs, float* __restrict__ avg_out,
+                                 int Tt, int Tm, int log1p_) {
+    int b = blockIdx.x;
+    const int* d = durs + b * Tt;
+    const float* x = dense + (int64_t)b * Tm;
+    float* o = avg_out + (int64_t)b * (Tt + 2);
+    if (threadIdx.x == 0) { o[0] = 0.f; o[Tt + 1] = 0.f; }
+    for (int j = threadIdx.x; j < Tt; j += blockDim.x) {
+        int start = 0;
+        for (int i = 0; i < j; ++i) start += d[i];
+        int end = start + d[j];
+        if (start > Tm) start = Tm;   // torch.gather would raise; synthetic/real batches never exceed Tm
+        if (end > Tm) end = Tm;
+        float s = 0.f; int n = 0;
+        for (int t = start; t < end; ++t) { float v = x[t]; if (v != 0.f) { s += v; ++n; } }
+        float a = n > 0 ? s / (float)n : 0.f;
+        if (log1p_) a = logf(1.0f + a);
+        o[j + 1] = a;
+    }
+}
+// tok[b][t] = token owning frame t (or -1), tstart[b][j] = first frame of token j, dec_lens[b] = min(sum reps, Tm)
+__global__ void lenreg_map_kernel(const int* __restrict__ durs, int* __restrict__ tok, int* __restrict__ tstart,
+                                  int* __restrict__ dec_lens, int Tt, int Tm, float pace) {
+    int b = blockIdx.x;
+    const int* d = durs + b * Tt;
+    int* tk = tok + (int64_t)b * Tm;
+    for (int t = threadIdx.x; t < Tm; t += blockDim.x) tk[t] = -1;
+    __syncthreads();
+    for (int j = threadIdx.x; j < Tt; j += blockDim.x) {
+        int start = 0;
+        for (int i = 0; i < j; ++i) start += (int)((float)d[i] * pace + 0.5f);
+        int rep = (int)((float)d[j] * pace + 0.5f);
+        tstart[b * (Tt + 1) + j] = start;
+        for (int t = start; t < start + rep && t < Tm; ++t) tk[t] = j;
+        if (j == Tt - 1) {
+            int tot = start + rep;
+            tstart[b * (Tt + 1) + Tt] = tot;
+            dec_lens[b] = tot < Tm ? tot : Tm;
+        }
+    }
+}
+extern "C" int xva_fp_avg_pitch(const float* dense, const int32_t* durs, float* avg_out, int B, int Tt, int Tm, int log1p_,
+                                void* stream) {
+    XVA_CHECK_ARG(dense && durs && avg_out, "avg_pitch: null");
+    hipLaunchKernelGGL(avg_pitch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dense, durs, avg_out, Tt, Tm, log1p_);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_fp_lenreg_map(const int32_t* durs, int32_t* tok, int32_t* tstart, int32_t* dec_lens, int B, int Tt, int Tm,
+                                 float pace, void* stream) {
+    XVA_CHECK_ARG(durs && tok && tstart && dec_lens, "lenreg_map: null");
+    hipLaunchKernelGGL(lenreg_map_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, durs, tok, tstart, dec_lens, Tt, Tm, pace);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// =====================================================================================
+// Conditioning add: out = (in + Conv1d(1 -> C, k=3, pad=1)(s) + bias) * lenmask    (model.py:234-237,403,418)
+// s: (B, Tp) padded 1-channel sequence; w: (C, 3) ; rows live iff 1 <= t' <= lens[b].
+// =====================================================================================
+__global__ void cond_add_fwd_kernel(const float* __restrict__ in, const float* __restrict__ s, const float* __restrict__ w,
+                                    const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ lens, int Tp,
+                                    int C) {
+    int64_t r = blockIdx.x;
+    int b = (int)(r / Tp), tp = (int)(r % Tp);
+    bool live = tp >= 1 && tp <= lens[b];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (live) { const float* sp = s + (int64_t)b * Tp + tp; s0 = sp[-1]; s1 = sp[0]; s2 = sp[1]; }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float v = 0.f;
+        if (live) v = in[r * C + c] + w[c * 3 + 0] * s0 + w[c * 3 + 1] * s1 + w[c * 3 + 2] * s2 + bias[c];
+        out[r * C + c] = v;
+    }
+}
+// dw[c][k] += sum_r dOut[r][c] * s[b][t'-1+k], db[c] += sum_r dOut[r][c]   (dOut is zero on dead rows)
+__global__ void cond_add_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ s, float* __restrict__ dw,
+                                    float* __restrict__ db, const int* __restrict__ lens, int64_t rows, int Tp, int C,
+                                    int rows_per_block) {
+    __shared__ float sh[4][4][64];
+    int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    int c = blockIdx.x * 64 + cl;
+    int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ab = 0.f;
+    if (c < C) {
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            int b = (int)(r / Tp), tp = (int)(r % Tp);
+            if (tp < 1 || tp > lens[b]) continue;
+            float g = dOut[r * C + c];
+            const float* sp = s + (int64_t)b * Tp + tp;
+            a0 += g * sp[-1]; a1 += g * sp[0]; a2 += g * sp[1]; ab += g;
+        }
+    }
+    sh[0][rl][cl] = a0; sh[1][rl][cl] = a1; sh[2][rl][cl] = a2; sh[3][rl][cl] = ab;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = sh[k][0][cl] + sh[k][1][cl] + sh[k][2][cl] + sh[k][3][cl];
+        if (dw) { atomicAdd(dw + c * 3 + 0, t[0]); atomicAdd(dw + c * 3 + 1, t[1]); atomicAdd(dw + c * 3 + 2, t[2]); }
+        if (db) atomicAdd(db + c, t[3]);
+    }
+}
+extern "C" int xva_fp_cond_add_fwd(const float* in, const float* s, const float* w, const float* bias, float* out,
+                                   const int32_t* lens, int B, int Tp, int C, void* stream) {
+    XVA_CHECK_ARG(in && s && w && bias && out && lens, "cond_add_fwd: null");
+    hipLaunchKernelGGL(cond_add_fwd_kernel, dim3(B * Tp), dim3(128), 0, (hipStream_t)stream, in, s, w, bias, out, lens, Tp, C);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_fp_cond_add_bwd(const float* dOut, const float* s, float* dw, float* db, const int32_t* lens, int B, int Tp,
+                                   int C, void* stream) {
+    XVA_CHECK_ARG(dOut && s && lens, "cond_add_bwd: null");
+    int64_t rows = (int64_t)B * Tp;
+    const int rpb = 128;
+    hipLaunchKernelGGL(cond_add_bwd_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, dOut, s,
+                       dw, db, lens, rows, Tp, C, rpb);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// =====================================================================================
+// regulate_len (model.py:59-79) as a gather + the decoder's positional embedding (transformer.py:224-227).
+//   out[b, t', :] = enc[b, tok[b][t'-1] + 1, :] + pos[t'-1]   for 1 <= t' <= dec_lens[b], else 0
+// backward = segmented sum (no atomics): dEnc[b, j+1, :] (+)= sum_{t in span j} dOut[b, t+1, :]
+// =====================================================================================
+__global__ void lenreg_fwd_kernel(const float* __restrict__ enc, const int* __restrict__ tok, const int* __restrict__ dec_lens,
+                                  const float* __restrict__ pos, float* __restrict__ out, int Tt, int Tm, int C) {
+    int Tmp = Tm + 2, Ttp = Tt + 2;
+    int64_t r = blockIdx.x;
+    int b = (int)(r / Tmp), tp = (int)(r % Tmp);
+    float4* o = reinterpret_cast<float4*>(out + r * C);
+    int j = -1;
+    if (tp >= 1 && tp <= dec_lens[b]) j = tok[(int64_t)b * Tm + tp - 1];
+    if (j < 0) {
+        for (int c = threadIdx.x; c < C / 4; c += blockDim.x) o[c] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const float4* e = reinterpret_cast<const float4*>(enc + ((int64_t)b * Ttp + j + 1) * C);
+    const float4* p = reinterpret_cast<const float4*>(pos + (int64_t)(tp - 1) * C);
+    for (int c = threadIdx.x; c < C / 4; c += blockDim.x) {
+        float4 v = e[c], q = p[c];
+        o[c] = make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w);
+    }
+}
+__global__ void lenreg_bwd_kernel(const float* __restrict__ dOut, const int* __restrict__ tstart, const int* __restrict__ dec_lens,
+                                  float* __restrict__ dEnc, int Tt, int Tm, int C, int accumulate) {
+    int Tmp = Tm + 2, Ttp = Tt + 2;
+    int64_t r = blockIdx.x;  // row of dEnc
+    int b = (int)(r / Ttp), tp = (int)(r % Ttp);
+    float4* o = reinterpret_cast<float4*>(dEnc + r * C);
+    int t0 = 0, t1 = 0;
+    if (tp >= 1 && tp <= Tt) {
+        t0 = tstart[b * (Tt + 1) + tp - 1];
+        t1 = tstart[b * (Tt + 1) + tp];
+        int dl = dec_lens[b];
+        if (t0 > dl) t0 = dl;
+        if (t1 > dl) t1 = dl;
+    }
+    for (int c = threadIdx.x; c < C / 4; c += blockDim.x) {
+        float4 a = make_float4(0, 0, 0, 0);
+        for (int t = t0; t < t1; ++t) {
+            float4 g = reinterpret_cast<const float4*>(dOut + ((int64_t)b * Tmp + t + 1) * C)[c];
+            a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+        }
+        if (accumulate) { float4 q = o[c]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
+        o[c] = a;
+    }
+}
+extern "C" int xva_fp_lenreg_fwd(const float* enc, const int32_t* tok, const int32_t* dec_lens, const float* pos, float* out,
+                                 int B, int Tt, int Tm, int C, void* stream) {
+    XVA_CHECK_ARG(enc && tok && dec_lens && pos && out && C % 4 == 0, "lenreg_fwd: bad args");
+    hipLaunchKernelGGL(lenreg_fwd_kernel, dim3(B * (Tm + 2)), dim3(128), 0, (hipStream_t)stream, enc, tok, dec_lens, pos, out, Tt,
+                       Tm, C);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_fp_lenreg_bwd(const float* dOut, const int32_t* tstart, const int32_t* dec_lens, float* dEnc, int B, int Tt,
+                                 int Tm, int C, int accumulate, void* stream) {
+    XVA_CHECK_ARG(dOut && tstart && dec_lens && dEnc && C % 4 == 0, "lenreg_bwd: bad args");
+    hipLaunchKernelGGL(lenreg_bwd_kernel, dim3(B * (Tt + 2)), dim3(128), 0, (hipStream_t)stream, dOut, tstart, dec_lens, dEnc, Tt,
+                       Tm, C, accumulate);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// =====================================================================================
+// FastPitchLoss (loss_function.py:63-154).  Two phases so that data-parallel ranks can all-reduce the
+// numerators / denominators in between (global normalisation = the reference's DataParallel semantics):
+//   partials:  acc[0..7] += {mel_num, mel_den, pitch_num, tok_den, energy_num, dur_num, 0, 0}
+//   grads:     d_pred = grad_scale * w * 2 * (pred - tgt) * mask / den
+// mel_out: (B, Tm+2, 80) padded token-major ; mel_tgt: (B, 80, Tm) reference layout ; mask = (tgt != 0).
+// =====================================================================================
+__global__ void mel_loss_partial_kernel(const float* __restrict__ mel_out, const float* __restrict__ mel_tgt,
+                                        float* __restrict__ acc, int B, int Tm, int NM) {
+    __shared__ float sh[16];
+    int64_t total = (int64_t)B * NM * Tm;
+    float num = 0.f, den = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int t = (int)(i % Tm);
+        int c = (int)((i / Tm) % NM);
+        int b = (int)(i / ((int64_t)Tm * NM));
+        float tg = mel_tgt[i];
+        if (tg != 0.f) {
+            float o = mel_out[((int64_t)b * (Tm + 2) + t + 1) * NM + c];
+            float d = o - tg;
+            num += d * d;
+            den += 1.f;
+        }
+    }
+    num = xva_block_sum(num, sh);
+    den = xva_block_sum(den, sh);
+    if (threadIdx.x == 0) { atomicAdd(acc + 0, num); atomicAdd(acc + 1, den); }
+}
+__global__ void mel_loss_grad_kernel(const float* __restrict__ mel_out, const float* __restrict__ mel_tgt,
+                                     const float* __restrict__ acc, float* __restrict__ d_mel, int B, int Tm, int NM,
+                                     float grad_scale) {
+    int Tmp = Tm + 2;
+    int64_t total = (int64_t)B * Tmp * NM;
+    float den = acc[1];
+    float k = den > 0.f ? 2.f * grad_scale / den : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % NM);
+        int tp = (int)((i / NM) % Tmp);
+        int b = (int)(i / ((int64_t)NM * Tmp));
+        float g = 0.f;
+        if (tp >= 1 && tp <= Tm) {
+            float tg = mel_tgt[((int64_t)b * NM + c) * Tm + tp - 1];
+            if (tg != 0.f) g = k * (mel_out[i] - tg);
+        }
+        d_mel[i] = g;
+    }
+}
+// token-level masked MSE between pred (B, Tp) padded sequence [ld 1] and tgt (B, Tp) padded sequence.
+// mode 0: tgt as is ; mode 1: tgt = log(dur + 1) from integer durations (B, Tt) (stage 2, loss_function.py:87-90)
+__global__ void tok_loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                        const int* __restrict__ durs, const int* __restrict__ lens, float* __restrict__ acc,
+                                        int slot_num, int slot_den, int B, int Tt, int mode) {
+    __shared__ float sh[16];
+    int Tp = Tt + 2;
+    float num = 0.f, den = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * Tp; i += gridDim.x * blockDim.x) {
+        int b = i / Tp, tp = i % Tp;
+        if (tp >= 1 && tp <= lens[b]) {
+            float tg = mode == 1 ? logf((float)durs[b * Tt + tp - 1] + 1.0f) : tgt[i];
+            float d = pred[i] - tg;
+            num += d * d;
+            den += 1.f;
+        }
+    }
+    num = xva_block_sum(num, sh);
+    den = xva_block_sum(den, sh);
+    if (threadIdx.x == 0) { atomicAdd(acc + slot_num, num); if (slot_den >= 0) atomicAdd(acc + slot_den, den); }
+}
+__global__ void tok_loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const int* __restrict__ durs,
+                                     const int* __restrict__ lens, const float* __restrict__ acc, int slot_den,
+                                     float* __restrict__ d_pred, int B, int Tt, int mode, float weight) {
+    int Tp = Tt + 2;
+    float den = acc[slot_den];
+    float k = den > 0.f ? 2.f * weight / den : 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * Tp; i += gridDim.x * blockDim.x) {
+        int b = i / Tp, tp = i % Tp;
+        float g = 0.f;
+        if (tp >= 1 && tp <= lens[b]) {
+            float tg = mode == 1 ? logf((float)durs[b * Tt + tp - 1] + 1.0f) : tgt[i];
+            g = k * (pred[i] - tg);
+        }
+        d_pred[i] = g;
+    }
+}
+// out[0] = total, out[1] = mel, out[2] = dur, out[3] = pitch, out[4] = energy  (unscaled component means)
+__global__ void loss_finalize_kernel(const float* __restrict__ acc, float* __restrict__ out, int stage, float dur_w, float pitch_w,
+                                     float energy_w) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float mel = (stage >= 3 && acc[1] > 0.f) ? acc[0] / acc[1] : 0.f;
+    float tden = acc[3];
+    float pitch = (stage == 3 && tden > 0.f) ? acc[2] / tden : 0.f;
+    float energy = (stage == 3 && tden > 0.f) ? acc[4] / tden : 0.f;
+    float dur = (stage == 2 && tden > 0.f) ? acc[5] / tden : 0.f;
+    out[0] = mel + dur_w * dur + pitch_w * pitch + energy_w * energy;
+    out[1] = mel; out[2] = dur; out[3] = pitch; out[4] = energy;
+}
+
+extern "C" int xva_fp_loss_partials(int stage, const float* mel_out, const float* mel_tgt, const float* pitch_pred,
+                                    const float* pitch_tgt, const float* energy_pred, const float* energy_tgt,
+                                    const float* log_dur_pred, const int32_t* durs, const int32_t* in_lens, float* acc, int B,
+                                    int Tt, int Tm, void* stream) {
+    XVA_CHECK_ARG(acc && in_lens, "loss_partials: null");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(acc, 0, 8 * sizeof(float), st) != hipSuccess) { xva_set_error("loss_partials: memset failed"); return XVA_ERR_HIP; }
+    int gtok = xva_cdiv((int64_t)B * (Tt + 2), 256);
+    if (stage == 3 || stage == 4) {
+        XVA_CHECK_ARG(mel_out && mel_tgt, "loss_partials: null mel");
+        int64_t total = (int64_t)B * 80 * Tm;
+        int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(mel_loss_partial_kernel, dim3(grid), dim3(256), 0, st, mel_out, mel_tgt, acc, B, Tm, 80);
+    }
+    if (stage == 3) {
+        XVA_CHECK_ARG(pitch_pred && pitch_tgt && energy_pred && energy_tgt, "loss_partials: null pitch/energy");
+        hipLaunchKernelGGL(tok_loss_partial_kernel, dim3(gtok), dim3(256), 0, st, pitch_pred, pitch_tgt, (const int*)nullptr, in_lens,
+                           acc, 2, 3, B, Tt, 0);
+        hipLaunchKernelGGL(tok_loss_partial_kernel, dim3(gtok), dim3(256), 0, st, energy_pred, energy_tgt, (const int*)nullptr,
+                           in_lens, acc, 4, -1, B, Tt, 0);
+    }
+    if (stage == 2) {
+        XVA_CHECK_ARG(log_dur_pred && durs, "loss_partials: null durations");
+        hipLaunchKernelGGL(tok_loss_partial_kernel, dim3(gtok), dim3(256), 0, st, log_dur_pred, (const float*)nullptr, durs, in_lens,
+                           acc, 5, 3, B, Tt, 1);
+    }
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+extern "C" int xva_fp_loss_grads(int stage, const float* mel_out, const float* mel_tgt, const float* pitch_pred,
+                                 const float* pitch_tgt, const float* energy_pred, const float* energy_tgt,
+                                 const float* log_dur_pred, const int32_t* durs, const int32_t* in_lens, const float* acc,
+                                 float* losses_out, float* d_mel, float* d_pitch, float* d_energy, float* d_logdur, int B, int Tt,
+                                 int Tm, float grad_scale, float dur_w, float pitch_w, float energy_w, void* stream) {
+    XVA_CHECK_ARG(acc && losses_out && in_lens, "loss_grads: null");
+    hipStream_t st = (hipStream_t)stream;
+    int gtok = xva_cdiv((int64_t)B * (Tt + 2), 256);
+    if (stage == 3 || stage == 4) {
+        XVA_CHECK_ARG(mel_out && mel_tgt && d_mel, "loss_grads: null mel");
+        int64_t total = (int64_t)B * (Tm + 2) * 80;
+        int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(mel_loss_grad_kernel, dim3(grid), dim3(256), 0, st, mel_out, mel_tgt, acc, d_mel, B, Tm, 80, grad_scale);
+    }
+    if (stage == 3) {
+        XVA_CHECK_ARG(d_pitch && d_energy, "loss_grads: null pitch/energy grads");
+        hipLaunchKernelGGL(tok_loss_grad_kernel, dim3(gtok), dim3(256), 0, st, pitch_pred, pitch_tgt, (const int*)nullptr, in_lens, acc,
+                           3, d_pitch, B, Tt, 0, grad_scale * pitch_w);
+        hipLaunchKernelGGL(tok_loss_grad_kernel, dim3(gtok), dim3(256), 0, st, energy_pred, energy_tgt, (const int*)nullptr, in_lens,
+                           acc, 3, d_energy, B, Tt, 0, grad_scale * energy_w);
+    }
+    if (stage == 2) {
+        XVA_CHECK_ARG(d_logdur, "loss_grads: null duration grad");
+        hipLaunchKernelGGL(tok_loss_grad_kernel, dim3(gtok), dim3(256), 0, st, log_dur_pred, (const float*)nullptr, durs, in_lens, acc,
+                           3, d_logdur, B, Tt, 1, grad_scale * dur_w);
+    }
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, acc, losses_out, stage, dur_w, pitch_w, energy_w);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// dur_pred = clamp(exp(log_dur_pred) - 1, 0, max_duration)   (model.py:370)
+__global__ void dur_from_log_kernel(const float* __restrict__ logd, float* __restrict__ out, int n, float max_dur) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fminf(fmaxf(expf(logd[i]) - 1.f, 0.f), max_dur);
+}
+extern "C" int xva_fp_dur_from_log(const float* logd, float* out, int n, float max_dur, void* stream) {
+    XVA_CHECK_ARG(logd && out, "dur_from_log: null");
+    hipLaunchKernelGGL(dur_from_log_kernel, dim3(xva_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, logd, out, n, max_dur);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// =====================================================================================
+// Final 256 -> 1 projection of a TemporalPredictor, backward (model.py:116,121): the GEMM's 16-byte
+// operand alignment cannot hold for a 1-wide operand, so its two backward products are vector kernels.
+//   outer:          out[r][c]  = s[r] * w[c]
+//   rowscale_colsum out[c]    += sum_r s[r] * X[r][c]
+// =====================================================================================
+__global__ void outer_kernel(const float* __restrict__ s, const float* __restrict__ w, float* __restrict__ out, int64_t rows, int C) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    out[i] = s[i / C] * w[i % C];
+}
+__global__ void rowscale_colsum_kernel(const float* __restrict__ X, const float* __restrict__ s, float* __restrict__ out,
+                                       int64_t rows, int C, int rows_per_block) {
+    __shared__ float sh[4][64];
+    int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    int c = blockIdx.x * 64 + cl;
+    int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float acc = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + rl; r < r1; r += 4) acc += s[r] * X[r * C + c];
+    sh[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) atomicAdd(out + c, sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]);
+}
+extern "C" int xva_fp_outer(const float* s, const float* w, float* out, int64_t rows, int C, void* stream) {
+    XVA_CHECK_ARG(s && w && out, "outer: null");
+    hipLaunchKernelGGL(outer_kernel, dim3(xva_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, s, w, out, rows, C);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_fp_rowscale_colsum(const float* X, const float* s, float* out, int64_t rows, int C, void* stream) {
+    XVA_CHECK_ARG(X && s && out, "rowscale_colsum: null");
+    const int rpb = 256;
+    hipLaunchKernelGGL(rowscale_colsum_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, X, s,
+                       out, rows, C, rpb);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}

@@ -1,0 +1,202 @@
+"""FastPitchEngine — thin host driver of the C-ABI FastPitch engine (xva_fp_* in include/xva_hip.h).
+
+Owns no numerics: it allocates the flat parameter / gradient buffers and the workspace as torch tensors
+(device memory is the caller's, per the ABI), converts the reference's batch format to the ABI's plain int32 /
+fp32 arrays, and issues forward / loss / backward as three C calls on torch's current stream.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+lib = _lib.lib
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class FpDims(C.Structure):
+    _fields_ = [("B", i32), ("Tt", i32), ("Tm", i32), ("stage", i32), ("compute", i32)]
+
+
+class FpBatch(C.Structure):
+    _fields_ = [("text", vp), ("in_lens", vp), ("durs", vp), ("pitch", vp), ("energy", vp), ("pos_table", vp)]
+
+
+SLOTS = ["MEL_OUT", "PITCH_PRED", "ENERGY_PRED", "LOG_DUR_PRED", "DUR_PRED", "PITCH_TGT", "ENERGY_TGT", "DEC_LENS", "LOSS_ACC",
+         "LOSSES", "D_MEL", "D_PITCH", "D_ENERGY", "D_LOGDUR", "ENC_OUT", "DEC_OUT", "ENC_COND"]
+SLOT = {n: i for i, n in enumerate(SLOTS)}
+
+lib.xva_fp_param_floats.restype = i64
+lib.xva_fp_num_tensors.restype = i32
+lib.xva_fp_tensor_info.restype = i32
+lib.xva_fp_tensor_info.argtypes = [i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i64 * 4), C.POINTER(i32)]
+lib.xva_fp_trainable_ranges.restype = i32
+lib.xva_fp_trainable_ranges.argtypes = [i32, C.POINTER(i64), C.POINTER(i64), i32]
+lib.xva_fp_workspace_bytes.restype = i64
+lib.xva_fp_workspace_bytes.argtypes = [C.POINTER(FpDims)]
+lib.xva_fp_slot_offset.restype = i32
+lib.xva_fp_slot_offset.argtypes = [C.POINTER(FpDims), i32, C.POINTER(i64)]
+lib.xva_fp_forward.restype = i32
+lib.xva_fp_forward.argtypes = [C.POINTER(FpDims), vp, C.POINTER(FpBatch), vp, i64, vp]
+lib.xva_fp_backward.restype = i32
+lib.xva_fp_backward.argtypes = [C.POINTER(FpDims), vp, vp, C.POINTER(FpBatch), vp, i64, vp]
+lib.xva_fp_loss_partials.restype = i32
+lib.xva_fp_loss_partials.argtypes = [i32] + [vp] * 10 + [i32, i32, i32, vp]
+lib.xva_fp_loss_grads.restype = i32
+lib.xva_fp_loss_grads.argtypes = [i32] + [vp] * 15 + [i32, i32, i32, f32, f32, f32, f32, vp]
+
+COMPUTE = {"fp32": 0, "bf16": 1, 0: 0, 1: 1}
+
+
+def tensor_table():
+    """[(name, offset, numel, reference_shape, kind)] straight from the library (single source of truth)."""
+    out = []
+    buf = C.create_string_buffer(128)
+    for i in range(lib.xva_fp_num_tensors()):
+        off, n, nd, kind = i64(), i64(), i32(), i32()
+        shape = (i64 * 4)()
+        _lib.check(lib.xva_fp_tensor_info(i, buf, 128, C.byref(off), C.byref(n), C.byref(nd), C.byref(shape), C.byref(kind)))
+        out.append((buf.value.decode(), off.value, n.value, tuple(shape[k] for k in range(nd.value)), kind.value))
+    return out
+
+
+def trainable_ranges(stage):
+    b, e = (i64 * 16)(), (i64 * 16)()
+    n = lib.xva_fp_trainable_ranges(int(stage), b, e, 16)
+    return [(b[k], e[k]) for k in range(n)]
+
+
+def positional_table(T, d_model=384, device="cpu", dtype=torch.float32):
+    """PositionalEmbedding (transformer.py:21-35), computed with the same torch ops as the reference module buffer."""
+    inv_freq = 1 / (10000 ** (torch.arange(0.0, d_model, 2.0, device=device) / d_model))
+    pos_seq = torch.arange(T, device=device).to(dtype)
+    sinusoid = torch.matmul(pos_seq.unsqueeze(-1), inv_freq.unsqueeze(0))
+    return torch.cat([sinusoid.sin(), sinusoid.cos()], dim=1).contiguous()
+
+
+class DeviceBatch:
+    """ABI-shaped batch living on the device (contiguous int32 / fp32)."""
+
+    def __init__(self, text, in_lens, mel_tgt=None, mel_lens=None, pitch=None, energy=None, durs=None):
+        dev = text.device
+        self.text = text.to(torch.int32).contiguous()
+        self.in_lens = in_lens.to(device=dev, dtype=torch.int32).contiguous()
+        self.B, self.Tt = self.text.shape
+        self.mel_tgt = mel_tgt.float().contiguous() if mel_tgt is not None else None
+        self.mel_lens = mel_lens.to(device=dev, dtype=torch.int32).contiguous() if mel_lens is not None else None
+        self.Tm = int(self.mel_tgt.size(2)) if mel_tgt is not None else 1
+        self.pitch = pitch.float().reshape(self.B, -1).contiguous() if pitch is not None else None
+        self.energy = energy.float().contiguous() if energy is not None else None
+        self.durs = durs.to(torch.int32).contiguous() if durs is not None else None
+        self.num_frames = None
+
+    @staticmethod
+    def from_dict(b, device):
+        g = lambda k: b[k].to(device, non_blocking=True) if b.get(k) is not None else None
+        return DeviceBatch(g("text"), g("in_lens"), g("mel_tgt"), g("mel_lens"), g("pitch"), g("energy"), g("durs"))
+
+
+class FastPitchEngine:
+    def __init__(self, device, compute="bf16"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.XvaError("FastPitchEngine needs a GPU device; the hot path has no CPU implementation")
+        self.compute = COMPUTE[compute]
+        self.table = tensor_table()
+        self.total = int(lib.xva_fp_param_floats())
+        self._ws = None
+        self._ws_key = None
+        self._dims = None
+        self._pos = None
+        self._slot_off = {}
+
+    # -- workspace ---------------------------------------------------------------------
+    def _prepare(self, B, Tt, Tm, stage):
+        key = (B, Tt, Tm, int(stage), self.compute)
+        if key != self._ws_key:
+            d = FpDims(B, Tt, Tm, int(stage), self.compute)
+            need = int(lib.xva_fp_workspace_bytes(C.byref(d)))
+            if need < 0:
+                raise _lib.XvaError("xva_fp_workspace_bytes: " + lib.xva_last_error().decode())
+            if self._ws is None or self._ws.numel() * 4 < need:
+                self._ws = torch.zeros((need + 3) // 4, device=self.device, dtype=torch.float32)  # zero ONCE: guard rows
+            self._dims = d
+            self._ws_key = key
+            self._slot_off = {}
+            for name, sid in SLOT.items():
+                off = i64()
+                _lib.check(lib.xva_fp_slot_offset(C.byref(d), sid, C.byref(off)), "xva_fp_slot_offset")
+                self._slot_off[name] = off.value
+            tmax = max(Tt, Tm)
+            if self._pos is None or self._pos.size(0) < tmax:
+                self._pos = positional_table(max(tmax, 1024), device=self.device)
+        return self._dims
+
+    def slot(self, name, shape, dtype=torch.float32):
+        off = self._slot_off[name]
+        n = 1
+        for s in shape:
+            n *= s
+        v = self._ws[off:off + n]
+        if dtype != torch.float32:
+            v = v.view(dtype)
+        return v.view(*shape)
+
+    def _abi_batch(self, b):
+        return FpBatch(_lib.ptr(b.text), _lib.ptr(b.in_lens), _lib.ptr(b.durs), _lib.ptr(b.pitch), _lib.ptr(b.energy), _lib.ptr(self._pos))
+
+    # -- the three calls ---------------------------------------------------------------
+    def forward(self, flat_params, b, stage):
+        d = self._prepare(b.B, b.Tt, b.Tm, stage)
+        self._abi = self._abi_batch(b)
+        _lib.check(lib.xva_fp_forward(C.byref(d), _lib.ptr(flat_params), C.byref(self._abi), _lib.ptr(self._ws), self._ws.numel() * 4,
+                                      _lib.stream_ptr()), "xva_fp_forward")
+
+    def _loss_args(self, b):
+        sp = lambda n: C.c_void_p(self._ws.data_ptr() + 4 * self._slot_off[n])
+        return [sp("MEL_OUT"), _lib.ptr(b.mel_tgt), sp("PITCH_PRED"), sp("PITCH_TGT"), sp("ENERGY_PRED"), sp("ENERGY_TGT"),
+                sp("LOG_DUR_PRED"), _lib.ptr(b.durs), _lib.ptr(b.in_lens)], sp
+
+    def loss_partials(self, b, stage):
+        args, sp = self._loss_args(b)
+        _lib.check(lib.xva_fp_loss_partials(int(stage), *args, sp("LOSS_ACC"), b.B, b.Tt, b.Tm, _lib.stream_ptr()), "xva_fp_loss_partials")
+        return self.slot("LOSS_ACC", (8,))
+
+    def loss_grads(self, b, stage, grad_scale=1.0, dur_w=0.1, pitch_w=0.1, energy_w=0.1):
+        args, sp = self._loss_args(b)
+        _lib.check(lib.xva_fp_loss_grads(int(stage), *args, sp("LOSS_ACC"), sp("LOSSES"), sp("D_MEL"), sp("D_PITCH"), sp("D_ENERGY"),
+                                         sp("D_LOGDUR"), b.B, b.Tt, b.Tm, grad_scale, dur_w, pitch_w, energy_w, _lib.stream_ptr()),
+                   "xva_fp_loss_grads")
+        return self.slot("LOSSES", (8,))
+
+    def backward(self, flat_params, flat_grads, b, stage):
+        d = self._prepare(b.B, b.Tt, b.Tm, stage)
+        _lib.check(lib.xva_fp_backward(C.byref(d), _lib.ptr(flat_params), _lib.ptr(flat_grads), C.byref(self._abi), _lib.ptr(self._ws),
+                                       self._ws.numel() * 4, _lib.stream_ptr()), "xva_fp_backward")
+
+    def fwd_loss_bwd(self, flat_params, flat_grads, b, stage, grad_scale=1.0, reduce_acc=None):
+        """One micro-batch: forward, loss (optionally all-reducing the loss numerators/denominators across DP ranks through
+        `reduce_acc(acc_tensor)`), backward accumulating into flat_grads. Returns the 8-float device tensor of losses."""
+        self.forward(flat_params, b, stage)
+        acc = self.loss_partials(b, stage)
+        if reduce_acc is not None:
+            reduce_acc(acc)
+        losses = self.loss_grads(b, stage, grad_scale)
+        self.backward(flat_params, flat_grads, b, stage)
+        return losses
+
+    # -- views of outputs in the reference's shapes --------------------------------------
+    def outputs(self, b, stage):
+        B, Tt, Tm = b.B, b.Tt, b.Tm
+        o = {}
+        if stage == 2:
+            o["log_dur_pred"] = self.slot("LOG_DUR_PRED", (B, Tt + 2))[:, 1:Tt + 1]
+            o["dur_pred"] = self.slot("DUR_PRED", (B, Tt + 2))[:, 1:Tt + 1]
+            return o
+        o["mel_out"] = self.slot("MEL_OUT", (B, Tm + 2, 80))[:, 1:Tm + 1]
+        o["pitch_pred"] = self.slot("PITCH_PRED", (B, Tt + 2))[:, 1:Tt + 1].unsqueeze(1)
+        o["pitch_tgt"] = self.slot("PITCH_TGT", (B, Tt + 2))[:, 1:Tt + 1].unsqueeze(1)
+        o["energy_pred"] = self.slot("ENERGY_PRED", (B, Tt + 2))[:, 1:Tt + 1]
+        o["energy_tgt"] = self.slot("ENERGY_TGT", (B, Tt + 2))[:, 1:Tt + 1]
+        o["dec_lens"] = self.slot("DEC_LENS", (B,), torch.int32)
+        return o
