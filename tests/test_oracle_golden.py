@@ -47,3 +47,31 @@ def test_mel_oracle_matches_live_reference():
     ns = ref_import.import_reference()
     y = torch.from_numpy(np.stack([omel.synth_wave(9000, 77), omel.synth_wave(9000, 78)]))
     assert torch.equal(ns.TacotronSTFT().mel_spectrogram(y), omel.mel_m1(y))
+
+
+@pytest.mark.parametrize("case", ["fp_stage3_small", "fp_stage4_small", "fp_stage2_small"])
+def test_fastpitch_oracle_matches_reference_golden(golden_dir, case):
+    """oracle/fastpitch.py (forward, loss, autograd grads, clip + LAMB) vs vectors recorded from the reference classes."""
+    from oracle import fastpitch as ofp
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    stage, seed = int(g["stage"]), int(g["seed"])
+    sd = ofp.init_state_dict(seed)
+    assert np.allclose(np.array([float(sd[k].double().sum()) for k in sorted(sd)]), g["sd_checksum"], rtol=1e-6, atol=1e-6)
+    batch = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+    before = {k: v.clone() for k, v in sd.items()}
+    out = ofp.forward(sd, batch, stage)
+    if stage == 2:
+        assert torch.allclose(out[3], torch.from_numpy(g["log_dur_pred"]), rtol=1e-4, atol=1e-6)
+    else:
+        assert torch.allclose(out[0], torch.from_numpy(g["mel_out"]), rtol=1e-4, atol=1e-5)
+        assert torch.allclose(out[4], torch.from_numpy(g["pitch_pred"]), rtol=1e-4, atol=1e-6)
+        assert torch.allclose(out[5], torch.from_numpy(g["pitch_tgt"]), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(out[7], torch.from_numpy(g["energy_tgt"]), rtol=1e-5, atol=1e-6)
+    loss, comps, grads = ofp.train_step(sd, batch, stage, {}, int(g["total_iter"]))
+    assert abs(loss - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    keys = [str(k) for k in g["grad_keys"]]
+    assert sorted(grads) == keys
+    for k, l2, d_ref in zip(keys, g["grad_l2"], g["delta_l2"]):
+        assert abs(float(grads[k].double().norm()) - l2) <= 1e-4 * max(l2, 1e-12), k
+        d = float((sd[k].double() - before[k].double()).norm())
+        assert abs(d - d_ref) <= 1e-3 * max(d_ref, 1e-12), k
