@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json metric on MI355X: FastPitch1.1 training throughput in mel-frames/s.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full optimizer step of the hot path on one synthetic micro-batch per GPU (weak scaling):
+forward + FastPitchLoss + backward + gradient all-reduce (N > 1) + grad-norm clip + fused LAMB.
+Workload = BASELINE.json configs[1]: FastPitch1.1, bf16-input MFMA, batch 32/GPU, 150 tokens x 860 mel frames per clip,
+training stage 3 (all heads active).  Inputs are resident in HBM before the timed region.
+value = sum over ranks of true mel frames per step * K / max-over-ranks time.
+Extra objects: "roofline" (MFMA GEMM, per-launch average from HIP events in an extra profiled pass of the same step) and
+"cpu_baseline" (the CPU oracle = our port of the reference step, timed on a bounded sample on this host's cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--t-text", type=int, default=150)
+    ap.add_argument("--t-mel", type=int, default=860)
+    ap.add_argument("--stage", type=int, default=3)
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(stage):
+    """Reference-equivalent CPU step (oracle/fastpitch.py: fwd + loss + autograd bwd + clip + LAMB, fp32, torch CPU ops),
+    on a bounded sample: B=2 clips of 150 tokens x 860 frames, 1 warm-up + 2 timed steps (~10-20 s)."""
+    from oracle import fastpitch as ofp
+    sd = ofp.init_state_dict(1234)
+    batch = ofp.synth_batch(2, 150, 860, 1235, ragged=False)
+    frames = int(batch["mel_lens"].sum())
+    state = {}
+    ofp.train_step(sd, batch, stage, state, 50000)
+    t0 = time.perf_counter()
+    n = 2
+    for i in range(n):
+        ofp.train_step(sd, batch, stage, state, 50001 + i)
+    dt = time.perf_counter() - t0
+    return {"value": frames * n / dt, "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "B=2 x (150 tok, 860 frames) stage-%d full train step (fwd+loss+bwd+clip+LAMB), fp32 torch-CPU, %d timed steps"
+                      % (stage, n), "host_cpu_count": os.cpu_count()}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from xva_trainer_amd import _lib, synthetic
+    from xva_trainer_amd.fastpitch import engine as E, params as P
+    from xva_trainer_amd.fastpitch.lamb import Lamb
+    from xva_trainer_amd.fastpitch.dp import GradSync
+
+    torch.manual_seed(1234 + rank)
+    eng = E.FastPitchEngine(dev, a.compute)
+    flat = torch.zeros(eng.total, device=dev)
+    P.default_init_(flat, eng.table, seed=1234)          # identical replicas on every rank
+    grads = torch.zeros_like(flat)
+    opt = Lamb(flat, eng.table, lr=0.1, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6)
+    stage = a.stage
+    ranges = E.trainable_ranges(stage)
+    active = {t[0] for t in eng.table if any(b <= t[1] < e for b, e in ranges)}
+    if stage == 2:
+        active = {n for n in active if not n.startswith("energy_emb")}
+    batch = E.DeviceBatch.from_dict(synthetic.fastpitch_batch(a.batch, a.t_text, a.t_mel, 1234 + rank), dev)
+    frames_per_step = int(batch.mel_lens.sum().item())
+    sync = GradSync(eng, flat, grads, world) if world > 1 else None
+    total_iter = [50000]
+
+    def step():
+        total_iter[0] += 1
+        it = total_iter[0]
+        opt.param_groups[0]["lr"] = 0.1 * (1.0 / it ** 0.5 if it > 1000 else it / 1000 ** 1.5)   # xva_train.py:1252-1261
+        grads.zero_()
+        if sync is None:
+            eng.fwd_loss_bwd(flat, grads, batch, stage, grad_scale=1.0)
+        else:
+            sync.fwd_loss_bwd(batch, stage, grad_scale=1.0)
+        opt.step(grads, active, max_grad_norm=1000.0)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt, float(frames_per_step)], device=dev, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt = tmax[0].item()
+        total_frames = t[1].item()
+    else:
+        total_frames = float(frames_per_step)
+    loss = eng.slot("LOSSES", (8,)).cpu()[0].item()
+
+    out = {
+        "metric": "mel-frames/sec (FastPitch1.1 train step; BASELINE.json: mel-frames/sec/GPU (FastPitch) + audio-samples/sec/GPU (HiFi-GAN))",
+        "value": total_frames * a.steps / dt, "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.compute, "data": "synthetic",
+        "config": {"workload": "FastPitch1.1 stage-%d full train step (fwd+loss+bwd%s+clip+fused LAMB), batch %d/GPU, %d tokens x %d mel frames, dropout off"
+                               % (stage, "+RCCL grad all-reduce" if world > 1 else "", a.batch, a.t_text, a.t_mel),
+                   "global_batch": a.batch * world, "per_gpu_frames_per_step": frames_per_step, "parallelism": "dp%d" % world,
+                   "final_loss": loss},
+    }
+    if rank == 0 and not a.no_roofline:
+        lib = _lib.lib
+        lib.xva_prof_collect.argtypes = [C.POINTER(C.c_double), C.c_int]
+        lib.xva_prof_enable(1)
+        nprof = 3
+        for _ in range(nprof):
+            grads.zero_()
+            eng.fwd_loss_bwd(flat, grads, batch, stage)
+        torch.cuda.synchronize()
+        lib.xva_prof_enable(0)
+        buf = (C.c_double * 32)()
+        lib.xva_prof_collect(buf, 32)
+        launches, ms, flops = buf[0], buf[1], buf[2]
+        peak = 2500.0 if a.compute == "bf16" else 157.3
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        names = ["NT", "NN", "TN"]
+        per = {}
+        for v in range(6):
+            n_, ms_, fl_ = buf[3 + 3 * v], buf[4 + 3 * v], buf[5 + 3 * v]
+            if n_ > 0:
+                per["%s_%s" % (names[v // 2], "bf16" if v % 2 else "fp32")] = {"launches_per_step": n_ / nprof, "avg_us": 1e3 * ms_ / n_,
+                                                                                "tflops": fl_ / (ms_ * 1e-3) / 1e12}
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                           "kernel": "xva_gemm_kernel<layout, %s> (all GEMM launches of one fwd+bwd)" % a.compute,
+                           "launches_per_step": launches / nprof, "avg_launch_us": 1e3 * ms / launches if launches else None,
+                           "gemm_ms_per_step": ms / nprof, "algorithmic_gflop_per_step": flops / nprof / 1e9, "by_variant": per,
+                           "method": "hipEvent pair around every xva_gemm launch on the launch stream, %d extra profiled fwd+bwd passes after the timed region" % nprof}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(stage)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,6 +25,9 @@ extern "C" {
 const char* xva_last_error(void);
 int xva_abi_version(void);
 const char* xva_target_arch(void);
+/* Optional per-launch GEMM timing with HIP events (used by bench.py's roofline leg only). */
+void xva_prof_enable(int on);
+int xva_prof_collect(double* out, int cap);
 
 /* ------------------------------------------------------------------ mel front end ---- */
 /* One config covers the reference's three mel variants:
@@ -118,6 +121,18 @@ int xva_fp_forward(const xva_fp_dims* d, const float* params, const xva_fp_batch
                    int64_t workspace_bytes, void* stream);
 int xva_fp_backward(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* batch, float* workspace,
                     int64_t workspace_bytes, void* stream);
+
+/* Data-parallel overlap: gradient buckets (contiguous flat ranges, in backward completion order) and a backward
+ * that records one hipEvent_t per bucket as it completes; the host starts that bucket's RCCL all-reduce on a side
+ * stream (replaces nn.DataParallel's reduce_add_coalesced, python/fastpitch1_1/xva_train.py:48-53,465-466). */
+int xva_fp_num_buckets(void);
+int xva_fp_bucket_range(int i, int64_t* begin, int64_t* end);
+int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* batch, float* workspace,
+                       int64_t workspace_bytes, void* const* bucket_events, void* stream);
+void* xva_event_create(void);
+int xva_event_destroy(void* event);
+int xva_event_record(void* event, void* stream);
+int xva_stream_wait_event(void* stream, void* event);
 
 /* FastPitchLoss in two phases (so data-parallel ranks can all-reduce `acc` in between: global normalisation). */
 int xva_fp_loss_partials(int stage, const float* mel_out, const float* mel_tgt, const float* pitch_pred, const float* pitch_tgt,

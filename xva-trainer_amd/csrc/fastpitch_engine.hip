@@ -221,6 +221,12 @@ struct Ctx {
     float* W;        // workspace
     void* st;
     int compute;
+    void* const* events = nullptr;  // optional hipEvent_t per gradient bucket (data-parallel overlap)
+    int ev_base = 0;
+    int record(int i) {
+        if (events && events[i] && hipEventRecord((hipEvent_t)events[i], (hipStream_t)st) != hipSuccess) { xva_set_error("bucket event record failed"); return XVA_ERR_HIP; }
+        return XVA_OK;
+    }
 };
 
 static xva_gemm_params gp0(int compute) {
@@ -328,7 +334,7 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
 
 // Backward through the 6 layers.  On entry gA holds dL/d(x_out) ; on exit gA holds dL/d(x_in) (LEN-masked).
 static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t* xo, int64_t R, int Tp, int64_t Ts,
-                      const int32_t* lens, bool want_grads) {
+                      const int32_t* lens, bool want_grads, bool last_bucket_deferred) {
     const int B = c.pl.B;
     float *gA = c.W + c.pl.gA, *gB = c.W + c.pl.gB, *gC = c.W + c.pl.gC, *gD = c.W + c.pl.gD, *gH = c.W + c.pl.gH,
           *gAV = c.W + c.pl.gAV, *gP = c.W + c.pl.gP, *gQKV = c.W + c.pl.gQKV;
@@ -390,6 +396,7 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
             XVA_TRY(linear_bwd_weight(c, gQKV, R, DQKV, DQKV, x, DM, DM, Gg + p.qkv_w));
             XVA_TRY(xva_fp_colsum(gQKV, Gg + p.qkv_b, R, DQKV, DQKV, c.st));
         }
+        if (l > 0 || !last_bucket_deferred) XVA_TRY(c.record(c.ev_base + (NL - 1 - l)));
     }
     return XVA_OK;
 }
@@ -541,10 +548,40 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
 // Gradients of the loss w.r.t. the model outputs must already sit in the workspace slots D_MEL / D_PITCH /
 // D_ENERGY / D_LOGDUR (xva_fp_loss_grads writes them there).  Accumulates into `grads` (caller zeroes it when
 // a new optimizer step starts: gradient accumulation across micro-batches is the reference's "GAM").
+// Gradient buckets in the order backward completes them (each a contiguous [begin, end) range of the flat buffer):
+//   0..5   decoder layers 5..0 (bucket 0 also holds proj)      6   predictors + pitch/energy embeddings
+//   7..12  encoder layers 5..0 (bucket 12 also holds word_emb)
+extern "C" int xva_fp_num_buckets(void) { return 2 * NL + 1; }
+extern "C" int xva_fp_bucket_range(int i, int64_t* begin, int64_t* end) {
+    const ParamTable& T = table();
+    XVA_CHECK_ARG(i >= 0 && i < 2 * NL + 1 && begin && end, "bucket_range: bad index");
+    if (i < NL) {
+        int l = NL - 1 - i;
+        *begin = T.dec[l].qkv_w;
+        *end = (l == NL - 1) ? T.proj_end : T.dec[l + 1].qkv_w;
+    } else if (i == NL) {
+        *begin = T.dur_begin; *end = T.dec_begin;
+    } else {
+        int l = NL - 1 - (i - NL - 1);
+        *begin = (l == 0) ? T.enc_begin : T.enc[l].qkv_w;
+        *end = (l == NL - 1) ? T.enc_end : T.enc[l + 1].qkv_w;
+    }
+    return XVA_OK;
+}
+
+extern "C" int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* bt, float* workspace,
+                                  int64_t workspace_bytes, void* const* bucket_events, void* stream);
 extern "C" int xva_fp_backward(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* bt, float* workspace,
                                int64_t workspace_bytes, void* stream) {
+    return xva_fp_backward_ex(d, params, grads, bt, workspace, workspace_bytes, nullptr, stream);
+}
+// Same, recording bucket_events[i] (hipEvent_t, xva_fp_num_buckets() of them, entries may be null) on `stream` as soon as
+// bucket i's gradients are complete, so the caller can start that bucket's all-reduce on another stream.
+extern "C" int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* bt, float* workspace,
+                                  int64_t workspace_bytes, void* const* bucket_events, void* stream) {
     Ctx c;
     XVA_TRY(make_ctx(c, d, params, grads, workspace, workspace_bytes, stream));
+    c.events = bucket_events;
     XVA_CHECK_ARG(grads && ((uintptr_t)grads % 16) == 0, "fastpitch_backward: grads null or misaligned");
     XVA_CHECK_ARG(bt && bt->text && bt->in_lens, "fastpitch_backward: null batch field");
     const Plan& pl = c.pl;
@@ -554,6 +591,7 @@ extern "C" int xva_fp_backward(const xva_fp_dims* d, const float* params, float*
     float* gE = c.W + pl.gE;
     float* enc_out = c.W + pl.enc_x[NL];
     if (d->stage == 2) {
+        for (int i = 0; i < NL; ++i) XVA_TRY(c.record(i));   // decoder buckets carry no gradient in stage 2
         XVA_TRY(pred_bwd(c, T.dur, pl.dur, enc_out, c.W + pl.d_logdur, gA, 0, bt->in_lens));
     } else {
         int32_t* dec_lens = (int32_t*)(c.W + pl.dec_lens);
@@ -562,7 +600,8 @@ extern "C" int xva_fp_backward(const xva_fp_dims* d, const float* params, float*
         XVA_TRY(linear_bwd_data(c, d_mel, pl.Rd, NMEL, NMEL, c.P + T.proj_w, DM, gA, DM, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
         XVA_TRY(linear_bwd_weight(c, d_mel, pl.Rd, NMEL, NMEL, c.W + pl.dec_x[NL], DM, DM, c.G + T.proj_w));
         XVA_TRY(xva_fp_colsum(d_mel, c.G + T.proj_b, pl.Rd, NMEL, NMEL, c.st));
-        XVA_TRY(layers_bwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens, true));
+        c.ev_base = 0;
+        XVA_TRY(layers_bwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens, true, false));
         // regulate_len backward: segmented sum of frame grads per token -> gE = d enc_c2 = d enc_c1
         XVA_TRY(xva_fp_lenreg_bwd(gA, (int32_t*)(c.W + pl.tstart), dec_lens, gE, B, pl.Tt, pl.Tm, DM, 0, c.st));
         XVA_TRY(xva_fp_cond_add_bwd(gE, c.W + pl.etgt, c.G + T.energy_emb_w, c.G + T.energy_emb_b, bt->in_lens, B, pl.Ttp, DM, c.st));
@@ -577,7 +616,10 @@ extern "C" int xva_fp_backward(const xva_fp_dims* d, const float* params, float*
             return XVA_ERR_HIP;
         }
     }
-    XVA_TRY(layers_bwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, true));
+    XVA_TRY(c.record(NL));          // predictors + conditioning embeddings bucket
+    c.ev_base = NL + 1;
+    XVA_TRY(layers_bwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, true, true));
     XVA_TRY(xva_fp_embed_bwd(bt->text, gA, c.G + T.word_emb, B, pl.Tt, DM, c.st));
+    XVA_TRY(c.record(2 * NL));      // encoder layer 0 + word embedding bucket
     return XVA_OK;
 }

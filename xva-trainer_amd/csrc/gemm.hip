@@ -228,8 +228,15 @@ __global__ __launch_bounds__(NTHREADS) void xva_gemm_kernel(xva_gemm_params p) {
     }
 }
 
+bool xva_prof_is_on();
+void xva_prof_begin(hipStream_t st, double flops, int variant);
+void xva_prof_end(hipStream_t st);
+
 template <int LAYOUT>
 static int launch_layout(const xva_gemm_params& p, dim3 grid, hipStream_t st) {
+    const bool prof = xva_prof_is_on();
+    if (prof) xva_prof_begin(st, 2.0 * p.M * (double)p.N * p.K * p.batch, LAYOUT * 2 + (p.compute ? 1 : 0));
+    struct End { bool on; hipStream_t s; ~End() { if (on) xva_prof_end(s); } } end_{prof, st};
     if (p.compute) hipLaunchKernelGGL((xva_gemm_kernel<LAYOUT, true>), grid, dim3(NTHREADS), 0, st, p);
     else hipLaunchKernelGGL((xva_gemm_kernel<LAYOUT, false>), grid, dim3(NTHREADS), 0, st, p);
     XVA_LAUNCH_CHECK();

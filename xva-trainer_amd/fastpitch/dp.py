@@ -1,0 +1,100 @@
+"""Data-parallel FastPitch step: one process per GPU, RCCL over xGMI through torch.distributed.
+
+Replaces the reference's single-process nn.DataParallel (python/fastpitch1_1/xva_train.py:48-53,465-466): replicate /
+scatter / gather / reduce-to-GPU0 every step under the GIL.  Here every rank owns a full replica and a disjoint shard of
+the minibatch; per optimizer step there are exactly two exchanges:
+  1. an 8-float all-reduce of the loss numerators / denominators, so the masked-mean losses are normalised GLOBALLY —
+     the semantics of the reference, which computes the loss on the gathered outputs (xva_train.py:788-790);
+  2. a SUM all-reduce of the gradients, bucketed per transformer layer in backward-completion order.  The engine records
+     a HIP event per bucket while backward is still running; each bucket's all-reduce is enqueued on a side stream that
+     waits on its event, so communication overlaps the rest of backward.  xGMI is point-to-point (per-link bound), so
+     buckets are whole layers (~14.6 MB fp32) rather than NVSwitch-style tiny buckets.
+With gradient accumulation only the last micro-batch synchronises (pass sync=False for the others).
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+from . import engine as E
+
+lib = _lib.lib
+lib.xva_fp_num_buckets.restype = C.c_int32
+lib.xva_fp_bucket_range.restype = C.c_int32
+lib.xva_fp_bucket_range.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+lib.xva_fp_backward_ex.restype = C.c_int32
+lib.xva_fp_backward_ex.argtypes = [C.POINTER(E.FpDims), C.c_void_p, C.c_void_p, C.POINTER(E.FpBatch), C.c_void_p, C.c_int64,
+                                   C.POINTER(C.c_void_p), C.c_void_p]
+lib.xva_event_create.restype = C.c_void_p
+lib.xva_event_destroy.argtypes = [C.c_void_p]
+lib.xva_stream_wait_event.restype = C.c_int32
+lib.xva_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
+
+
+def bucket_ranges():
+    out = []
+    for i in range(lib.xva_fp_num_buckets()):
+        b, e = C.c_int64(), C.c_int64()
+        _lib.check(lib.xva_fp_bucket_range(i, C.byref(b), C.byref(e)), "xva_fp_bucket_range")
+        out.append((b.value, e.value))
+    return out
+
+
+def buckets_for_stage(stage):
+    """Indices of the buckets that carry gradients in `stage` (decoder buckets are empty in stage 2)."""
+    tr = E.trainable_ranges(stage)
+    keep = []
+    for i, (b, e) in enumerate(bucket_ranges()):
+        if any(b < te and tb < e for tb, te in tr):
+            if stage == 2 and i < lib.xva_fp_num_buckets() // 2:
+                continue
+            keep.append(i)
+    return keep
+
+
+class GradSync:
+    def __init__(self, eng, flat, grads, world, group=None):
+        self.eng, self.flat, self.grads, self.world, self.group = eng, flat, grads, world, group
+        self.ranges = bucket_ranges()
+        n = len(self.ranges)
+        self.events = (C.c_void_p * n)(*[lib.xva_event_create() for _ in range(n)])
+        self.comm = torch.cuda.Stream(device=flat.device)
+        self._works = []
+
+    def __del__(self):
+        try:
+            for e in self.events:
+                lib.xva_event_destroy(e)
+        except Exception:
+            pass
+
+    def fwd_loss_bwd(self, batch, stage, grad_scale=1.0, sync=True):
+        eng = self.eng
+        eng.forward(self.flat, batch, stage)
+        acc = eng.loss_partials(batch, stage)
+        dist.all_reduce(acc, group=self.group)                     # global loss normalisation (8 floats)
+        losses = eng.loss_grads(batch, stage, grad_scale)
+        d = eng._prepare(batch.B, batch.Tt, batch.Tm, stage)
+        rc = lib.xva_fp_backward_ex(C.byref(d), _lib.ptr(self.flat), _lib.ptr(self.grads), C.byref(eng._abi), _lib.ptr(eng._ws),
+                                    eng._ws.numel() * 4, self.events if sync else None, _lib.stream_ptr())
+        _lib.check(rc, "xva_fp_backward_ex")
+        if sync:
+            comm_ptr = C.c_void_p(self.comm.cuda_stream)
+            self._works = []
+            for i in buckets_for_stage(stage):
+                b, e = self.ranges[i]
+                _lib.check(lib.xva_stream_wait_event(comm_ptr, self.events[i]), "xva_stream_wait_event")
+                with torch.cuda.stream(self.comm):
+                    self._works.append(dist.all_reduce(self.grads[b:e], group=self.group, async_op=True))
+            for w in self._works:
+                w.wait()                                            # the compute stream waits for the reduced buckets
+        return losses
+
+
+def allreduce_flat_buckets(grads, ranges, group=None):
+    """Backend-agnostic bucketed SUM all-reduce of a flat gradient buffer (used by the CPU/gloo tests and as the plain
+    fallback when no event overlap is wanted)."""
+    works = [dist.all_reduce(grads[b:e], group=group, async_op=True) for b, e in ranges if e > b]
+    for w in works:
+        w.wait()
