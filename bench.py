@@ -155,11 +155,12 @@ def main():
         peak = 2500.0 if a.compute == "bf16" else 157.3
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         names = ["NT", "NN", "TN"]
+        modes = ["fp32", "bf16", "mixed(fp32->bf16)"]
         per = {}
-        for v in range(6):
+        for v in range(9):
             n_, ms_, fl_ = buf[3 + 3 * v], buf[4 + 3 * v], buf[5 + 3 * v]
             if n_ > 0:
-                per["%s_%s" % (names[v // 2], "bf16" if v % 2 else "fp32")] = {"launches_per_step": n_ / nprof, "avg_us": 1e3 * ms_ / n_,
+                per["%s_%s" % (names[v // 3], modes[v % 3])] = {"launches_per_step": n_ / nprof, "avg_us": 1e3 * ms_ / n_,
                                                                                 "tflops": fl_ / (ms_ * 1e-3) / 1e12}
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                            "kernel": "xva_gemm_kernel<layout, %s> (all GEMM launches of one fwd+bwd)" % a.compute,

@@ -1,14 +1,19 @@
-/* xva_gemm.h — C-ABI descriptor of the MFMA GEMM that carries every dense contraction of
- * the FastPitch hot path (reference: the cuBLAS/cuDNN calls behind nn.Linear / nn.Conv1d(k=3)
- * / torch.bmm in python/fastpitch1_1/fastpitch/transformer.py:59-152 and model.py:103-122,261).
+/* xva_gemm.h — C-ABI descriptor of the MFMA "implicit-convolution GEMM" that carries every dense contraction of the
+ * path: nn.Linear / nn.Conv1d(k=3) / torch.bmm of FastPitch (python/fastpitch1_1/fastpitch/transformer.py:59-152,
+ * model.py:103-122,261), the DFT / mel-filterbank products of the mel front end (common/stft.py:86-103), and the
+ * Conv1d / ConvTranspose1d / Conv2d(k,1) / grouped Conv1d stacks of HiFi-GAN (python/hifigan/models.py:17-260)
+ * in forward, backward-data and backward-weight form.
  *
- * All operands are fp32 in HBM, 16-byte aligned, leading dimensions multiples of 4 elements.
- * `compute` selects the MFMA path: 0 = exact fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 inputs
- * with fp32 accumulation (v_mfma_f32_16x16x32_bf16; operands are rounded to bf16 while they
- * are staged into LDS).
+ * Operands live in HBM as fp32 or bf16 (`a_dtype`, `b_dtype`, `c_dtype`; 0 = fp32, 1 = bf16), 16-byte aligned, leading
+ * dimensions in ELEMENTS and multiples of 4 (fp32) / 8 (bf16).  `compute` selects the matrix pipe:
+ *   0 = exact fp32 (v_mfma_f32_16x16x4_f32; operands must be stored fp32) — the parity mode;
+ *   1 = bf16 inputs, fp32 accumulation (v_mfma_f32_16x16x32_bf16; fp32-stored operands are rounded while staged).
  *
- * A k=3 "same" Conv1d over a (B, T+2, C) padded token-major tensor is expressed with an
- * OVERLAPPING-row A operand: lda = C, K = 3*C, A = x - C  (row r reads rows r-1, r, r+1).
+ * Convolution over a time-major (rows = time, columns = channels) activation is expressed by K SEGMENTS: the reduction
+ * index kk = j * seglen + c (tap j, channel c) reads the A row shifted by tap j:
+ *      A(r, kk) = A[r * lda + kk + (kk / a_seglen) * a_segadj]                 (NT, NN)
+ * so a conv with dilation d over C channels has a_seglen = C_in, a_segadj = d * row_stride - C_in and a strided conv
+ * simply has lda = stride * row_stride.  (k = 3, d = 1, lda = C is the plain overlapping-row case: a_segadj = 0.)
  */
 #ifndef XVA_GEMM_H
 #define XVA_GEMM_H
@@ -17,38 +22,62 @@
 extern "C" {
 #endif
 
-#define XVA_GEMM_NT 0 /* C[M,N] = A[M,K] * B[N,K]^T   (A, B k-contiguous)            */
-#define XVA_GEMM_NN 1 /* C[M,N] = A[M,K] * B[K,N]     (B n-contiguous, optional segs) */
-#define XVA_GEMM_TN 2 /* C[M,N] = A[K,M]^T * B[K,N]   (A m-contiguous, B n-contiguous)*/
+#define XVA_GEMM_NT 0 /* C[M,N] = A[M,K] * B[N,K]^T   (A, B k-contiguous)                          */
+#define XVA_GEMM_NN 1 /* C[M,N] = A[M,K] * B[K,N]     (B n-contiguous; row kk may be segment-mapped) */
+#define XVA_GEMM_TN 2 /* C[M,N] = A[K,M]^T * B[K,N]   (A m-contiguous, B n-contiguous, col-segmented)*/
+
+#define XVA_F32 0
+#define XVA_BF16 1
+
+#define XVA_ACT_NONE 0
+#define XVA_ACT_RELU 1
+#define XVA_ACT_LRELU 2   /* slope = act_slope */
+#define XVA_ACT_TANH 3
+#define XVA_ACT_LOGCLAMP 4 /* log(max(v, act_slope)) */
 
 typedef struct xva_gemm_params {
-    const float* A;
-    const float* B;
-    float* C;
+    const void* A;
+    const void* B;
+    void* C;
     int32_t M, N, K;
     int64_t lda, ldb, ldc;
-    int32_t batch;          /* >= 1 */
+    int32_t batch;          /* >= 1 (blockIdx batch); optional second level: z = z1 * batch2 + z2 */
     int64_t sA, sB, sC;     /* batch strides (elements) */
-    /* NN only: B row kk lives at B + seg0 + (kk / seglen) * segstride + (kk % seglen) * ldb.
-     * seglen == 0 disables segmentation (row kk at B + kk * ldb). */
+    int32_t batch2;         /* 0/1 = none */
+    int64_t sA2, sB2, sC2;
+    /* A tap segments (NT / NN): see header comment. a_seglen == 0 disables. */
+    int32_t a_seglen;
+    int64_t a_segadj;
+    /* B segments.  NN: row kk lives at B + seg0 + (kk / seglen) * segstride + (kk % seglen) * ldb.
+     *              TN: column n lives at B + seg0 + k * ldb + n + (n / seglen) * segstride.
+     * seglen == 0 disables. */
     int32_t seglen;
     int64_t seg0, segstride;
-    /* epilogue: v = alpha*acc (+bias[col]) ; relu ; (+R) ; (*[G>0]) ; row-mask ; store */
-    float alpha;
-    const float* bias;      /* [N] or NULL */
-    int32_t relu;
-    float log_clamp;        /* > 0: v = logf(max(v, log_clamp)) after bias/relu (mel dynamic-range compression) */
-    const float* R;         /* residual, same batch index, or NULL */
-    int64_t ldr, sR;
-    const float* G;         /* gate tensor (ReLU backward: keep where G > 0) or NULL */
-    int64_t ldg, sG;
-    int32_t mask_mode;      /* XVA_MASK_* applied on global row index (batch must be 1) */
-    const int32_t* lens;    /* [rows / Tp] */
-    int32_t Tp;
-    int32_t accumulate;     /* 0: C = v ; 1: C += v (atomic when splitk > 1) */
-    int32_t splitk;         /* >= 1; > 1 requires accumulate = 1 */
+    /* operand transforms applied while staging (LeakyReLU fused into the consumer): x -> x > 0 ? x : slope * x */
+    int32_t a_lrelu, b_lrelu;
+    float a_slope, b_slope;
+    /* epilogue: v = alpha * (acc + bias[col]) + beta * R ; act ; v *= (G > 0 ? 1 : gate_slope) ; row-mask ; store */
+    float alpha, beta;
+    const float* bias;      /* [N] fp32 or NULL */
+    int32_t act;            /* XVA_ACT_* */
+    float act_slope;
+    const void* R;          /* residual (dtype r_dtype), or NULL */
+    int64_t ldr, sR, sR2;
+    int32_t r_dtype;
+    const void* G;          /* gate tensor (dtype g_dtype): backward of ReLU / LeakyReLU, or NULL */
+    int64_t ldg, sG, sG2;
+    int32_t g_dtype;
+    float gate_slope;
+    /* row mask on the global row index r (batch must be 1): item b = r / Tp, t' = r % Tp; rows with t' < mask_pad or
+     * t' >= Tp - mask_pad are structural zeros; XVA_MASK_LEN additionally zeroes t' - mask_pad >= lens[b]. */
+    int32_t mask_mode;
+    const int32_t* lens;
+    int32_t Tp, mask_pad;
+    int32_t accumulate;     /* 0: C = v ; 1: C += v (atomic when splitk > 1; fp32 C only) */
+    int32_t splitk;         /* >= 1; > 1 requires accumulate = 1 and a linear epilogue */
     int32_t compute;        /* 0 fp32, 1 bf16 */
     int32_t layout;         /* XVA_GEMM_* */
+    int32_t a_dtype, b_dtype, c_dtype;
 } xva_gemm_params;
 
 /* Launches on `stream` (a hipStream_t); returns 0 or a negative XVA_ERR_* code. */

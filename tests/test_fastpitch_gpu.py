@@ -131,3 +131,49 @@ def test_gradient_accumulation_and_grad_scale():
     torch.cuda.synchronize()
     ref = 0.5 * (g1.double() + g2.double())
     assert ((grads.double() - ref).norm() / ref.norm()).item() < 1e-5
+
+
+@pytest.mark.parametrize("stage", [3, 2])
+def test_reference_api_path(stage):
+    """The drop-in modules: model(x) -> criterion(y_pred, y) -> loss.backward() exactly as FastPitchTrainer.iteration does
+    (xva_train.py:784-813), checked against the oracle's loss and autograd gradients."""
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd.fastpitch import params as P
+    from xva_trainer_amd.fastpitch.loss_function import FastPitchLoss
+    from xva_trainer_amd.fastpitch.model import FastPitch
+    sd = ofp.init_state_dict(11)
+    batch = ofp.synth_batch(3, 13, 50, 12)
+    names = ofp.trainable_names(sd.keys(), stage)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd); work.update(leaves)
+    out_ref = ofp.forward(work, batch, stage)
+    loss_ref, comps = ofp.loss(out_ref, batch, stage)
+    (loss_ref / 4).backward()                                     # gam = 4
+    model = FastPitch(compute="fp32").cuda()
+    model.load_state_dict(sd)
+    model.training_stage = torch.tensor(stage)
+    crit = FastPitchLoss(dur_predictor_loss_scale=0.1, pitch_predictor_loss_scale=0.1, attn_loss_scale=1.0)
+    B = batch["text"].size(0)
+    dev = "cuda"
+    x = (batch["text"].to(dev), batch["in_lens"].to(dev), batch["mel_tgt"].to(dev), batch["mel_lens"].to(dev), batch["pitch"].to(dev),
+         batch["energy"].to(dev), None, None, batch["durs"].to(dev), torch.full((B,), batch["text"].size(1)),
+         torch.full((B,), int(batch["mel_lens"].max())), None)
+    y = [batch["mel_tgt"].to(dev), batch["in_lens"].to(dev), batch["mel_lens"].to(dev), x[9]]
+    y_pred = model(x)
+    loss, meta, comps_mine = crit(y_pred, y, training_stage=model.training_stage)
+    (loss / 4).backward()
+    assert abs(loss.item() - loss_ref.item()) < RTOL * abs(loss_ref.item())
+    if stage == 3:
+        assert y_pred[0].shape == out_ref[0].shape and y_pred[4].shape == out_ref[4].shape and y_pred[6].shape == out_ref[6].shape
+        assert torch.equal(y_pred[1].cpu(), out_ref[1])
+        assert abs(comps_mine[0] - comps["mel"].item()) < RTOL * comps["mel"].item()
+    mine = P.from_flat(model.flat.grad, model._table)
+    for k, v in leaves.items():
+        if v.grad is None:
+            continue
+        r = ((mine[k].double().cpu() - v.grad.double()).norm() / v.grad.double().norm().clamp_min(1e-30)).item()
+        assert r < 2e-3, (k, r)
+    # checkpoint written by us loads back bit-exactly
+    sd2 = model.state_dict()
+    for k in sd:
+        assert torch.equal(sd2[k].cpu(), sd[k]), k

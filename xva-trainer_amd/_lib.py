@@ -35,21 +35,24 @@ class GemmParams(C.Structure):
         ("lda", i64), ("ldb", i64), ("ldc", i64),
         ("batch", i32),
         ("sA", i64), ("sB", i64), ("sC", i64),
-        ("seglen", i32),
-        ("seg0", i64), ("segstride", i64),
-        ("alpha", f32),
+        ("batch2", i32),
+        ("sA2", i64), ("sB2", i64), ("sC2", i64),
+        ("a_seglen", i32), ("a_segadj", i64),
+        ("seglen", i32), ("seg0", i64), ("segstride", i64),
+        ("a_lrelu", i32), ("b_lrelu", i32), ("a_slope", f32), ("b_slope", f32),
+        ("alpha", f32), ("beta", f32),
         ("bias", vp),
-        ("relu", i32),
-        ("log_clamp", f32),
-        ("R", vp), ("ldr", i64), ("sR", i64),
-        ("G", vp), ("ldg", i64), ("sG", i64),
+        ("act", i32), ("act_slope", f32),
+        ("R", vp), ("ldr", i64), ("sR", i64), ("sR2", i64), ("r_dtype", i32),
+        ("G", vp), ("ldg", i64), ("sG", i64), ("sG2", i64), ("g_dtype", i32), ("gate_slope", f32),
         ("mask_mode", i32),
         ("lens", vp),
-        ("Tp", i32),
+        ("Tp", i32), ("mask_pad", i32),
         ("accumulate", i32),
         ("splitk", i32),
         ("compute", i32),
         ("layout", i32),
+        ("a_dtype", i32), ("b_dtype", i32), ("c_dtype", i32),
     ]
 
 
@@ -94,33 +97,53 @@ def require_cuda(*tensors):
             raise XvaError("libxvahip ops need device tensors; got a %s tensor (no CPU fallback exists)" % t.device)
 
 
-def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batch=1, sA=0, sB=0, sC=0, alpha=1.0,
-         bias=None, relu=False, log_clamp=0.0, R=None, ldr=0, sR=0, G=None, ldg=0, sG=0, mask_mode=MASK_NONE,
-         lens=None, Tp=0, accumulate=False, splitk=1, seglen=0, seg0=0, segstride=0, a_offset=0):
-    """Thin test/utility wrapper over xva_gemm. `a_offset` (elements) shifts the A base pointer
-    (negative for the overlapping-row conv form)."""
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP = 0, 1, 2, 3, 4
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise XvaError("unsupported dtype %s" % t.dtype)
+
+
+def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batch=1, sA=0, sB=0, sC=0, alpha=1.0, beta=1.0,
+         bias=None, relu=False, act=ACT_NONE, act_slope=0.0, R=None, ldr=0, sR=0, G=None, ldg=0, sG=0, gate_slope=0.0,
+         mask_mode=MASK_NONE, lens=None, Tp=0, mask_pad=1, accumulate=False, splitk=1, seglen=0, seg0=0, segstride=0,
+         a_seglen=0, a_segadj=0, a_lrelu=None, b_lrelu=None, a_offset=0, b_offset=0, batch2=1, sA2=0, sB2=0, sC2=0, sR2=0, sG2=0):
+    """Thin test/utility wrapper over xva_gemm. `a_offset` / `b_offset` (elements) shift the base pointers (negative for
+    the overlapping-row conv forms).  Storage dtypes are taken from the tensors."""
     require_cuda(A, B, Cm, bias, R, G, lens)
     p = GemmParams()
-    p.A = A.data_ptr() + 4 * a_offset
-    p.B = B.data_ptr()
+    p.A = A.data_ptr() + A.element_size() * a_offset
+    p.B = B.data_ptr() + B.element_size() * b_offset
     p.C = Cm.data_ptr()
     p.M, p.N, p.K = M, N, K
     p.lda, p.ldb, p.ldc = lda, ldb, ldc
     p.batch, p.sA, p.sB, p.sC = batch, sA, sB, sC
+    p.batch2, p.sA2, p.sB2, p.sC2 = batch2, sA2, sB2, sC2
+    p.a_seglen, p.a_segadj = a_seglen, a_segadj
     p.seglen, p.seg0, p.segstride = seglen, seg0, segstride
-    p.alpha = alpha
+    p.a_lrelu, p.a_slope = (1, a_lrelu) if a_lrelu is not None else (0, 0.0)
+    p.b_lrelu, p.b_slope = (1, b_lrelu) if b_lrelu is not None else (0, 0.0)
+    p.alpha, p.beta = alpha, beta
     p.bias = bias.data_ptr() if bias is not None else None
-    p.relu = int(relu)
-    p.log_clamp = log_clamp
+    p.act = ACT_RELU if relu else act
+    p.act_slope = act_slope
     p.R = R.data_ptr() if R is not None else None
-    p.ldr, p.sR = ldr, sR
+    p.ldr, p.sR, p.sR2 = ldr, sR, sR2
+    p.r_dtype = _dt(R) if R is not None else 0
     p.G = G.data_ptr() if G is not None else None
-    p.ldg, p.sG = ldg, sG
+    p.ldg, p.sG, p.sG2 = ldg, sG, sG2
+    p.g_dtype = _dt(G) if G is not None else 0
+    p.gate_slope = gate_slope
     p.mask_mode = mask_mode
     p.lens = lens.data_ptr() if lens is not None else None
-    p.Tp = Tp
+    p.Tp, p.mask_pad = Tp, mask_pad
     p.accumulate = int(accumulate)
     p.splitk = splitk
     p.compute = compute
     p.layout = layout
+    p.a_dtype, p.b_dtype, p.c_dtype = _dt(A), _dt(B), _dt(Cm)
     check(lib.xva_gemm(C.byref(p), stream_ptr()), "xva_gemm")

@@ -232,7 +232,7 @@ struct Ctx {
 static xva_gemm_params gp0(int compute) {
     xva_gemm_params g;
     memset(&g, 0, sizeof(g));
-    g.batch = 1; g.alpha = 1.f; g.splitk = 1; g.compute = compute;
+    g.batch = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.compute = compute; g.mask_pad = 1;
     return g;
 }
 static int splitk_for(int M, int N, int K) {
@@ -273,7 +273,7 @@ static int conv3_fwd(Ctx& c, const float* X, int64_t rows, int Cin, const float*
                      int relu, const float* R, int mask, const int32_t* lens, int Tp) {
     xva_gemm_params g = gp0(c.compute);
     g.layout = XVA_GEMM_NT; g.A = X - Cin; g.B = Wt; g.C = Y; g.M = (int)rows; g.N = Cout; g.K = 3 * Cin;
-    g.lda = Cin; g.ldb = 3 * Cin; g.ldc = Cout; g.bias = bias; g.relu = relu; g.R = R; g.ldr = Cout;
+    g.lda = Cin; g.ldb = 3 * Cin; g.ldc = Cout; g.bias = bias; g.act = relu ? XVA_ACT_RELU : XVA_ACT_NONE; g.R = R; g.ldr = Cout;
     g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
     return xva_gemm(&g, c.st);
 }

@@ -137,7 +137,7 @@ extern "C" int xva_mel_spectrogram(const xva_mel_config* c, const float* wav, in
         g.M = c->n_mel; g.N = pl.T; g.K = (int)pl.ldm;
         g.lda = pl.ldm; g.ldb = pl.ldm; g.ldc = pl.T;
         g.batch = B; g.sA = 0; g.sB = (int64_t)pl.T * pl.ldm; g.sC = (int64_t)c->n_mel * pl.T;
-        g.alpha = 1.f; g.log_clamp = c->log_clamp; g.splitk = 1; g.compute = 0; g.layout = XVA_GEMM_NT;
+        g.alpha = 1.f; g.act = XVA_ACT_LOGCLAMP; g.act_slope = c->log_clamp; g.splitk = 1; g.compute = 0; g.layout = XVA_GEMM_NT;
         XVA_TRY(xva_gemm(&g, stream));
     }
     return XVA_OK;

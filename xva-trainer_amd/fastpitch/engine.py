@@ -68,7 +68,7 @@ def trainable_ranges(stage):
 
 def positional_table(T, d_model=384, device="cpu", dtype=torch.float32):
     """PositionalEmbedding (transformer.py:21-35), computed with the same torch ops as the reference module buffer."""
-    inv_freq = 1 / (10000 ** (torch.arange(0.0, d_model, 2.0, device=device) / d_model))
+    inv_freq = (1 / (10000 ** (torch.arange(0.0, d_model, 2.0) / d_model))).to(device)   # module buffer: built on the CPU, moved
     pos_seq = torch.arange(T, device=device).to(dtype)
     sinusoid = torch.matmul(pos_seq.unsqueeze(-1), inv_freq.unsqueeze(0))
     return torch.cat([sinusoid.sin(), sinusoid.cos()], dim=1).contiguous()
