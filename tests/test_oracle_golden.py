@@ -75,3 +75,23 @@ def test_fastpitch_oracle_matches_reference_golden(golden_dir, case):
         assert abs(float(grads[k].double().norm()) - l2) <= 1e-4 * max(l2, 1e-12), k
         d = float((sd[k].double() - before[k].double()).norm())
         assert abs(d - d_ref) <= 1e-3 * max(d_ref, 1e-12), k
+
+
+def test_hifigan_oracle_matches_reference_golden(golden_dir):
+    """oracle/hifigan.py full D+G iteration vs vectors recorded from the reference Generator/MPD/MSD + torch AdamW."""
+    from oracle import hifigan as ohg
+    g = np.load(os.path.join(golden_dir, "hg_step_b2.npz"))
+    seed = int(g["seed"])
+    g_sd, mpd_sd, msd_sd = ohg.init_generator_sd(seed), ohg.init_mpd_sd(seed + 1), ohg.init_msd_sd(seed + 2)
+    chk = np.array([float(sd[k].double().sum()) for sd in (g_sd, mpd_sd, msd_sd) for k in sorted(sd)])
+    assert np.allclose(chk, g["sd_checksum"], rtol=1e-6, atol=1e-6)
+    x, y_wav, y_mel = torch.from_numpy(g["x_mel"]), torch.from_numpy(g["y_wav"]), torch.from_numpy(g["y_mel"])
+    out, g_grads, d_grads, y_hat = ohg.train_step(g_sd, mpd_sd, msd_sd, x, y_wav, y_mel, {}, {})
+    for name, ref in zip(g["loss_names"], g["losses"]):
+        assert abs(out[str(name)] - ref) <= 5e-5 * max(1.0, abs(ref)), name
+    assert torch.allclose(y_hat, torch.from_numpy(g["y_g_hat"]), rtol=1e-4, atol=5e-5)
+    for k, l2 in zip(g["g_grad_keys"], g["g_grad_l2"]):
+        assert abs(float(g_grads[str(k)].double().norm()) - l2) <= 2e-3 * max(l2, 1e-12), k
+    for k, l2 in zip(g["d_grad_keys"], g["d_grad_l2"]):
+        assert abs(float(d_grads[str(k)].double().norm()) - l2) <= 2e-3 * max(l2, 1e-12), k
+    assert torch.allclose(msd_sd["discriminators.0.convs.0.weight_u"], torch.from_numpy(g["msd_u0_after"]), rtol=1e-4, atol=1e-6)
