@@ -56,9 +56,10 @@ typedef struct xva_gemm_params {
     /* operand transforms applied while staging (LeakyReLU fused into the consumer): x -> x > 0 ? x : slope * x */
     int32_t a_lrelu, b_lrelu;
     float a_slope, b_slope;
-    /* epilogue: v = alpha * (acc + bias[col]) + beta * R ; act ; v *= (G > 0 ? 1 : gate_slope) ; row-mask ; store */
+    /* epilogue: v = alpha * (acc + bias[col]) ; v *= (G > 0 ? 1 : gate_slope) ; v += beta * R ; act ; row-mask ; store */
     float alpha, beta;
-    const float* bias;      /* [N] fp32 or NULL */
+    const float* bias;      /* [N] fp32 or NULL; second-level batch z2 reads bias + z2 * sbias2 */
+    int64_t sbias2;
     int32_t act;            /* XVA_ACT_* */
     float act_slope;
     const void* R;          /* residual (dtype r_dtype), or NULL */
@@ -68,12 +69,14 @@ typedef struct xva_gemm_params {
     int64_t ldg, sG, sG2;
     int32_t g_dtype;
     float gate_slope;
-    /* row mask on the global row index r (batch must be 1): item b = r / Tp, t' = r % Tp; rows with t' < mask_pad or
-     * t' >= Tp - mask_pad are structural zeros; XVA_MASK_LEN additionally zeroes t' - mask_pad >= lens[b]. */
+    /* row mask on the (mapped) global row index r' = r * mask_mul + mask_add (batch must be 1): item b = r' / Tp,
+     * t' = r' % Tp; rows outside mask_pad <= t' < mask_pad + mask_len are structural zeros (mask_len == 0 means
+     * Tp - 2 * mask_pad, mask_mul == 0 means 1); XVA_MASK_LEN additionally zeroes t' - mask_pad >= lens[b]. */
     int32_t mask_mode;
     const int32_t* lens;
-    int32_t Tp, mask_pad;
-    int32_t accumulate;     /* 0: C = v ; 1: C += v (atomic when splitk > 1; fp32 C only) */
+    int32_t Tp, mask_pad, mask_len, mask_mul, mask_add;
+    int32_t accumulate;     /* 0: C = v ; 1: C += v (atomic when splitk > 1) ; 2: C += v always atomically (batches that
+                             * reduce into one C); fp32 C only for atomics */
     int32_t splitk;         /* >= 1; > 1 requires accumulate = 1 and a linear epilogue */
     int32_t compute;        /* 0 fp32, 1 bf16 */
     int32_t layout;         /* XVA_GEMM_* */

@@ -187,6 +187,42 @@ int xva_lamb_step(float* params, const float* grads, float* exp_avg, float* exp_
 int xva_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step, float lr,
                    float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* --------------------------------------------------------------------- HiFi-GAN v1 engine ---- */
+/* Replaces the PyTorch graph of HiFiTrainer.iteration (python/hifigan/xva_train.py:451-567): Generator forward /
+ * backward (python/hifigan/models.py:81-128), MultiPeriodDiscriminator + MultiScaleDiscriminator forward / backward
+ * (:140-260), GAN + feature-matching losses (:263-294).  Parameters are two flat fp32 buffers (which = 0 generator,
+ * 1 discriminators: "mpd.*" then "msd.*", trainable tensors first, then spectral-norm buffers) in the checkpoint's
+ * own tensor layouts (weight_g / weight_v / weight_orig / weight_u / weight_v).  Activations are time-major sequences
+ * of dtype dims.dt; the workspace must be zero-filled once when allocated. */
+typedef struct xva_hg_dims {
+    int32_t B;     /* items per micro-batch */
+    int32_t seg;   /* samples per item (config_v1.json segment_size = 8192); multiple of 256 */
+    int32_t dt;    /* activation / MFMA dtype: XVA_F32 (exact-fp32 parity mode) or XVA_BF16 */
+} xva_hg_dims;
+int64_t xva_hg_param_floats(int which);
+int64_t xva_hg_trainable_floats(int which);
+int xva_hg_num_tensors(int which);
+int xva_hg_tensor_info(int which, int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int32_t* ndim, int64_t* shape4,
+                       int32_t* kind);
+int64_t xva_hg_workspace_bytes(const xva_hg_dims* d);
+/* mel: (B, 80, seg/256) fp32 -> wav_out: (B, seg) fp32 (may be NULL; the waveform also stays in the workspace) */
+int xva_hg_generator_forward(const xva_hg_dims* d, const float* params_g, const float* mel, void* workspace, int64_t workspace_bytes,
+                             float* wav_out, void* stream);
+/* d_wav: (B, seg) fp32 gradient w.r.t. the generated waveform; accumulates into grads_g */
+int xva_hg_generator_backward(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+/* MPD + MSD on (real, fake) waveforms (B, seg) fp32 (xva_train.py:488-493 / 506-507).  `losses` (device, 4 floats or
+ * NULL) receives {discriminator loss, generator LSGAN loss, feature-matching loss, -} (models.py:263-294).  params_d is
+ * mutable: each pass of the spectral-norm discriminator advances weight_u / weight_v by one power iteration. */
+int xva_hg_disc_forward(const xva_hg_dims* d, float* params_d, const float* y_real, const float* y_fake, void* workspace,
+                        int64_t workspace_bytes, float* losses, void* stream);
+/* D step (xva_train.py:494-495): accumulates d(loss_disc_s + loss_disc_f)/d(params_d) into grads_d. */
+int xva_hg_disc_backward_d(const xva_hg_dims* d, float* params_d, float* grads_d, const float* y_real, const float* y_fake,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+/* G step (xva_train.py:506-513): d_wav (B, seg) = d(loss_gen_f + loss_gen_s + loss_fm_f + loss_fm_s)/d(y_fake). */
+int xva_hg_disc_backward_g(const xva_hg_dims* d, float* params_d, const float* y_real, const float* y_fake, float* d_wav,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,137 @@
+"""GPU parity of the HiFi-GAN HIP engine (C ABI xva_hg_*) against the CPU oracle (oracle/hifigan.py, pinned to the
+reference) and the golden step recorded from the reference (tests/golden/hg_step_b2.npz).  fp32 mode = exact-fp32 MFMA,
+tolerance 1e-3 relative (north_star); bf16 mode is checked against a looser documented bound."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _nrel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _gen_setup(compute, seed=4321):
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan import engine as E
+    g_sd = ohg.init_generator_sd(seed)
+    eng = E.HifiganEngine("cuda", compute)
+    flat = torch.zeros(eng.total[E.G], device="cuda")
+    E.to_flat(g_sd, eng.table[E.G], flat)
+    return ohg, E, eng, g_sd, flat
+
+
+@pytest.mark.parametrize("compute,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
+def test_generator_forward(compute, tol):
+    ohg, E, eng, g_sd, flat = _gen_setup(compute)
+    x, y, _ = ohg.synth_batch(2, 4324)
+    with torch.no_grad():
+        ref = ohg.generator(g_sd, x).squeeze(1)
+    wav = eng.generator_forward(flat, x.cuda())
+    torch.cuda.synchronize()
+    assert wav.shape == ref.shape == (2, 8192)
+    assert _nrel(wav, ref) < tol
+    if compute == "fp32":
+        assert (wav.cpu() - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("compute,tol", [("fp32", 1e-2), ("bf16", 1e-1)])
+def test_generator_backward(compute, tol):
+    """Random cotangent on the waveform: an ill-conditioned probe (heavy cancellation) — the fp32 CPU oracle itself sits
+    ~5e-3 from the fp64 truth on the worst tensor (printed), so the fp32 bound here is 1e-2 worst / 3e-3 median; the
+    well-conditioned check of the same code is the golden training step (test_full_step_against_reference_golden)."""
+    ohg, E, eng, g_sd, flat = _gen_setup(compute)
+    x, y, _ = ohg.synth_batch(2, 4324)
+    # fp64 oracle = ground truth; the fp32 oracle's own distance to it calibrates what fp32 round-off does to these gradients
+    leaves = {k: v.double().requires_grad_(True) for k, v in g_sd.items()}
+    out = ohg.generator(leaves, x.double()).squeeze(1)
+    torch.manual_seed(0)
+    dw = torch.randn(out.shape)
+    (out * dw.double()).sum().backward()
+    l32 = {k: v.clone().requires_grad_(True) for k, v in g_sd.items()}
+    (ohg.generator(l32, x).squeeze(1) * dw).sum().backward()
+    cpu32 = sorted(((_nrel(l32[k].grad, leaves[k].grad), k) for k in leaves), reverse=True)
+    print("fp32 CPU oracle vs fp64:", cpu32[:3], "median", cpu32[len(cpu32) // 2])
+    eng.generator_forward(flat, x.cuda())
+    grads = torch.zeros_like(flat)
+    eng.generator_backward(flat, grads, dw.cuda())
+    torch.cuda.synchronize()
+    mine = E.from_flat(grads, eng.table[E.G])
+    errs = sorted(((_nrel(mine[k], v.grad), k) for k, v in leaves.items()), reverse=True)
+    print("worst generator grads:", errs[:12])
+    print("median:", errs[len(errs) // 2])
+    assert errs[0][0] < tol, errs[:5]
+    if compute == "fp32":
+        assert errs[len(errs) // 2][0] < 3e-3
+
+
+def _disc_setup(compute, seed=4321):
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan import engine as E
+    mpd_sd, msd_sd = ohg.init_mpd_sd(seed + 1), ohg.init_msd_sd(seed + 2)
+    eng = E.HifiganEngine("cuda", compute)
+    flat = torch.zeros(eng.total[E.D], device="cuda")
+    E.to_flat(mpd_sd, eng.table[E.D], flat, "mpd.")
+    E.to_flat(msd_sd, eng.table[E.D], flat, "msd.")
+    x, y, _ = ohg.synth_batch(2, seed + 3)
+    torch.manual_seed(1)
+    y_fake = (0.3 * torch.randn_like(y)).clamp(-1, 1)
+    return ohg, E, eng, mpd_sd, msd_sd, flat, y, y_fake
+
+
+def _clone(sd):
+    return {k: v.clone() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("compute,tol_loss,tol_grad", [("fp32", 1e-3, 5e-3), ("bf16", 3e-2, 1.5e-1)])
+def test_discriminators_d_step(compute, tol_loss, tol_grad):
+    """D-step: losses, parameter gradients of all 8 discriminators, spectral-norm buffers (xva_train.py:487-495)."""
+    ohg, E, eng, mpd_sd, msd_sd, flat, y, y_fake = _disc_setup(compute)
+    pl = {k: v.clone().requires_grad_(True) for k, v in mpd_sd.items()}
+    sl = {k: (v.clone().requires_grad_(True) if k in ohg._leaves(msd_sd) else v.clone()) for k, v in msd_sd.items()}
+    r, g, _, _ = ohg.mpd(pl, y.unsqueeze(1), y_fake.unsqueeze(1))
+    lf = ohg.discriminator_loss(r, g)
+    r, g, _, _ = ohg.msd(sl, y.unsqueeze(1), y_fake.unsqueeze(1))
+    ls = ohg.discriminator_loss(r, g)
+    (lf + ls).backward()
+    losses = eng.disc_forward(flat, y.cuda(), y_fake.cuda())
+    grads = torch.zeros_like(flat)
+    eng.disc_backward_d(flat, grads)
+    torch.cuda.synchronize()
+    assert abs(losses[0].item() - (lf + ls).item()) < tol_loss * (lf + ls).item()
+    mine = E.from_flat(grads, eng.table[E.D])
+    errs = []
+    for k, v in pl.items():
+        errs.append((_nrel(mine["mpd." + k], v.grad), "mpd." + k))
+    for k, v in sl.items():
+        if v.requires_grad:
+            errs.append((_nrel(mine["msd." + k], v.grad), "msd." + k))
+    errs.sort(reverse=True)
+    print("worst D grads:", errs[:8], "median", errs[len(errs) // 2])
+    assert errs[0][0] < tol_grad, errs[:5]
+    after = E.from_flat(flat, eng.table[E.D], "msd.")
+    for k in ("discriminators.0.convs.0.weight_u", "discriminators.0.convs.4.weight_v", "discriminators.0.conv_post.weight_u"):
+        assert _nrel(after[k], sl[k]) < 1e-3, k
+
+
+@pytest.mark.parametrize("compute,tol_loss,tol_grad", [("fp32", 1e-3, 5e-3), ("bf16", 3e-2, 1.5e-1)])
+def test_discriminators_g_step(compute, tol_loss, tol_grad):
+    """G-step: LSGAN generator loss + feature matching and their gradient w.r.t. the generated waveform (xva_train.py:506-513)."""
+    ohg, E, eng, mpd_sd, msd_sd, flat, y, y_fake = _disc_setup(compute)
+    yf = y_fake.clone().requires_grad_(True)
+    msd_c = _clone(msd_sd)
+    _, g_f, fr_f, fg_f = ohg.mpd(mpd_sd, y.unsqueeze(1), yf.unsqueeze(1))
+    _, g_s, fr_s, fg_s = ohg.msd(msd_c, y.unsqueeze(1), yf.unsqueeze(1))
+    l_fm = ohg.feature_loss(fr_f, fg_f) + ohg.feature_loss(fr_s, fg_s)
+    l_gen = ohg.generator_loss(g_f) + ohg.generator_loss(g_s)
+    (l_fm + l_gen).backward()
+    losses = eng.disc_forward(flat, y.cuda(), y_fake.cuda())
+    d_wav = eng.disc_backward_g(flat)
+    torch.cuda.synchronize()
+    assert abs(losses[1].item() - l_gen.item()) < tol_loss * l_gen.item()
+    assert abs(losses[2].item() - l_fm.item()) < tol_loss * l_fm.item()
+    e = _nrel(d_wav, yf.grad)
+    print("d_wav rel err", e)
+    assert e < tol_grad

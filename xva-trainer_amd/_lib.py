@@ -41,13 +41,13 @@ class GemmParams(C.Structure):
         ("seglen", i32), ("seg0", i64), ("segstride", i64),
         ("a_lrelu", i32), ("b_lrelu", i32), ("a_slope", f32), ("b_slope", f32),
         ("alpha", f32), ("beta", f32),
-        ("bias", vp),
+        ("bias", vp), ("sbias2", i64),
         ("act", i32), ("act_slope", f32),
         ("R", vp), ("ldr", i64), ("sR", i64), ("sR2", i64), ("r_dtype", i32),
         ("G", vp), ("ldg", i64), ("sG", i64), ("sG2", i64), ("g_dtype", i32), ("gate_slope", f32),
         ("mask_mode", i32),
         ("lens", vp),
-        ("Tp", i32), ("mask_pad", i32),
+        ("Tp", i32), ("mask_pad", i32), ("mask_len", i32), ("mask_mul", i32), ("mask_add", i32),
         ("accumulate", i32),
         ("splitk", i32),
         ("compute", i32),
@@ -110,7 +110,7 @@ def _dt(t):
 
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batch=1, sA=0, sB=0, sC=0, alpha=1.0, beta=1.0,
          bias=None, relu=False, act=ACT_NONE, act_slope=0.0, R=None, ldr=0, sR=0, G=None, ldg=0, sG=0, gate_slope=0.0,
-         mask_mode=MASK_NONE, lens=None, Tp=0, mask_pad=1, accumulate=False, splitk=1, seglen=0, seg0=0, segstride=0,
+         mask_mode=MASK_NONE, lens=None, Tp=0, mask_pad=1, mask_len=0, mask_mul=1, mask_add=0, accumulate=False, splitk=1, seglen=0, seg0=0, segstride=0,
          a_seglen=0, a_segadj=0, a_lrelu=None, b_lrelu=None, a_offset=0, b_offset=0, batch2=1, sA2=0, sB2=0, sC2=0, sR2=0, sG2=0):
     """Thin test/utility wrapper over xva_gemm. `a_offset` / `b_offset` (elements) shift the base pointers (negative for
     the overlapping-row conv forms).  Storage dtypes are taken from the tensors."""
@@ -140,7 +140,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batch=1, s
     p.gate_slope = gate_slope
     p.mask_mode = mask_mode
     p.lens = lens.data_ptr() if lens is not None else None
-    p.Tp, p.mask_pad = Tp, mask_pad
+    p.Tp, p.mask_pad, p.mask_len, p.mask_mul, p.mask_add = Tp, mask_pad, mask_len, mask_mul, mask_add
     p.accumulate = int(accumulate)
     p.splitk = splitk
     p.compute = compute

@@ -30,15 +30,19 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     XVA_CHECK_ARG(p.sA % ve == 0 && p.sB % ve == 0 && p.sA2 % ve == 0 && p.sB2 % ve == 0, "xva_gemm: batch strides must be multiples of %d", ve);
     XVA_CHECK_ARG(p.seg0 % ve == 0 && p.segstride % ve == 0 && p.a_segadj % ve == 0, "xva_gemm: segment offsets must be multiples of %d", ve);
     XVA_CHECK_ARG(p.a_seglen % ve == 0, "xva_gemm: a_seglen must be a multiple of %d", ve);
-    XVA_CHECK_ARG(p.layout != XVA_GEMM_NN || p.seglen % 32 == 0, "xva_gemm: NN seglen must be a multiple of 32");
+    XVA_CHECK_ARG(p.layout != XVA_GEMM_NN || p.seglen % 4 == 0, "xva_gemm: NN seglen must be a multiple of 4");
     XVA_CHECK_ARG(p.layout != XVA_GEMM_TN || p.seglen % ve == 0, "xva_gemm: TN seglen must be a multiple of %d", ve);
     XVA_CHECK_ARG(p.layout != XVA_GEMM_TN || p.a_seglen == 0, "xva_gemm: A segments are not defined for TN");
     XVA_CHECK_ARG(p.splitk == 1 || (p.accumulate && p.c_dtype == XVA_F32), "xva_gemm: splitk > 1 requires accumulate into fp32 C");
     XVA_CHECK_ARG(p.splitk == 1 || (p.act == XVA_ACT_NONE && !p.G && p.mask_mode == XVA_MASK_NONE),
                   "xva_gemm: splitk > 1 cannot carry a non-linear epilogue");
+    if (p.mask_mul == 0) p.mask_mul = 1;
+    if (p.mask_len == 0) p.mask_len = p.Tp - 2 * p.mask_pad;
     XVA_CHECK_ARG(p.mask_mode == XVA_MASK_NONE ||
-                      (p.batch == 1 && p.batch2 == 1 && p.mask_pad >= 0 && p.Tp > 2 * p.mask_pad && (p.mask_mode == XVA_MASK_PAD || p.lens)),
+                      (p.batch == 1 && p.mask_pad >= 0 && p.mask_len > 0 && p.mask_pad + p.mask_len <= p.Tp &&
+                       p.mask_add >= 0 && (p.mask_mode == XVA_MASK_PAD || p.lens)),
                   "xva_gemm: bad row-mask arguments");
+    XVA_CHECK_ARG(p.accumulate != 2 || p.c_dtype == XVA_F32, "xva_gemm: atomic accumulation needs an fp32 C");
     if (p.K == 0) p.splitk = 1;
     int nkt = xva_cdiv(p.K, 32);
     if (p.splitk > nkt && nkt > 0) p.splitk = nkt;

@@ -287,6 +287,15 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
         }
     }
 
+    int bj = 0, brem = 0;
+    if constexpr (LAYOUT == XVA_GEMM_NN) {
+        if (p.seglen > 0) {
+            int kg, ic; ib.coords(kg, ic);
+            const int kk = kt_begin * BK + kg * 4;
+            bj = kk / p.seglen; brem = kk - bj * p.seglen;
+        }
+    }
+
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
         const bool tail = (k0 + BK > p.K);
@@ -300,9 +309,10 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
         }
         const ST* bbase = B;
         if constexpr (LAYOUT == XVA_GEMM_NN) {
-            if (p.seglen > 0) {   // B row segments never straddle a K-tile (seglen % BK == 0, checked on the host)
-                const int sidx = k0 / p.seglen;
-                bbase = B + p.seg0 + (int64_t)sidx * p.segstride - (int64_t)sidx * p.seglen * p.ldb;
+            if (p.seglen > 0) {   // this thread's 4 k-rows share one segment (seglen % 4 == 0, checked on the host)
+                bbase = B + p.seg0 + (int64_t)bj * p.segstride - (int64_t)bj * p.seglen * p.ldb;
+                brem += BK;
+                while (brem >= p.seglen) { brem -= p.seglen; ++bj; }
             }
         }
         if (!tail) {
@@ -372,22 +382,20 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
             if (row >= p.M) continue;
             bool live = true;
             if (p.mask_mode != XVA_MASK_NONE) {
-                const int t = row % p.Tp;
-                live = t >= p.mask_pad && t < p.Tp - p.mask_pad;
-                if (live && p.mask_mode == XVA_MASK_LEN) live = (t - p.mask_pad) < p.lens[row / p.Tp];
+                const int64_t rr = (int64_t)row * p.mask_mul + p.mask_add;
+                const int t = (int)(rr % p.Tp);
+                live = t >= p.mask_pad && t < p.mask_pad + p.mask_len;
+                if (live && p.mask_mode == XVA_MASK_LEN) live = (t - p.mask_pad) < p.lens[rr / p.Tp];
             }
 #pragma unroll
             for (int j = 0; j < NTN; ++j) {
                 const int col = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
                 if (col >= p.N) continue;
                 float v = acc[i][j][r];
-                if (p.splitk == 1 || first_split) {
-                    if (p.bias) v += p.bias[col];
-                    v *= p.alpha;
-                    if (p.R) v += p.beta * ld_elem(p.R, roff + (int64_t)row * p.ldr + col, p.r_dtype);
-                } else {
-                    v *= p.alpha;
-                }
+                if ((p.splitk == 1 || first_split) && p.bias) v += p.bias[(int64_t)z2 * p.sbias2 + col];
+                v *= p.alpha;
+                if (p.G) v = (ld_elem(p.G, goff + (int64_t)row * p.ldg + col, p.g_dtype) > 0.f) ? v : v * p.gate_slope;
+                if ((p.splitk == 1 || first_split) && p.R) v += p.beta * ld_elem(p.R, roff + (int64_t)row * p.ldr + col, p.r_dtype);
                 switch (p.act) {
                     case XVA_ACT_RELU: v = fmaxf(v, 0.f); break;
                     case XVA_ACT_LRELU: v = lrelu(v, p.act_slope); break;
@@ -395,7 +403,6 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
                     case XVA_ACT_LOGCLAMP: v = logf(fmaxf(v, p.act_slope)); break;
                     default: break;
                 }
-                if (p.G) v = (ld_elem(p.G, goff + (int64_t)row * p.ldg + col, p.g_dtype) > 0.f) ? v : v * p.gate_slope;
                 if (!live) v = 0.f;
                 const int64_t ci = coff + (int64_t)row * p.ldc + col;
                 if (p.c_dtype == XVA_BF16) {
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
                     *dst = f2bf(v);
                 } else {
                     float* dst = reinterpret_cast<float*>(p.C) + ci;
-                    if (p.splitk > 1) atomicAdd(dst, v);
+                    if (p.splitk > 1 || p.accumulate == 2) atomicAdd(dst, v);
                     else if (p.accumulate) *dst += v;
                     else *dst = v;
                 }

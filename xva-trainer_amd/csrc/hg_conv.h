@@ -1,0 +1,235 @@
+// hg_conv.h — 1-D convolutions over time-major sequence tensors expressed as implicit-convolution GEMMs (xva_gemm):
+// forward, backward-data and backward-weight for Conv1d with stride / dilation / groups and for ConvTranspose1d.
+// Used by the HiFi-GAN engine (python/hifigan/models.py:17-260); see include/xva_gemm.h for the operand model.
+//
+// A sequence tensor (Seq) holds nseq items of Hp = padF + T + padB rows x C channels (fp32 or bf16), pad rows zero.
+// Two launch modes:
+//   merged   — one GEMM over ALL rows of all items (pad rows are computed and masked back to zero).  Needs an affine
+//              row map between input and output rows: same geometry for stride 1; Hp_in = s * Hp_out and
+//              padF_in = s * padF_out for stride s.  Best when T is small (discriminator tails).
+//   per-item — batch = nseq GEMMs of T_out rows each; any geometry; nothing is masked because only valid rows are written.
+#pragma once
+#include "xva_common.h"
+#include "../../include/xva_gemm.h"
+
+struct Seq {
+    char* base = nullptr;   // workspace base (bytes)
+    int64_t off = 0;        // byte offset of item 0, row 0
+    int nseq = 0, T = 0, C = 0, padF = 0, padB = 0, dt = 0;
+    int es() const { return dt == XVA_BF16 ? 2 : 4; }
+    int Hp() const { return padF + T + padB; }
+    int64_t item() const { return (int64_t)Hp() * C; }            // elements
+    int64_t rows() const { return (int64_t)nseq * Hp(); }
+    void* ptr(int64_t elem = 0) const { return base + off + elem * es(); }
+    void* valid(int64_t elem = 0) const { return ptr((int64_t)padF * C + elem); }
+    // view of items [i0, i0 + n)
+    Seq slice(int i0, int n) const { Seq s = *this; s.off += (int64_t)i0 * item() * es(); s.nseq = n; return s; }
+    bool same_geom(const Seq& o) const { return nseq == o.nseq && T == o.T && padF == o.padF && padB == o.padB; }
+};
+
+struct ConvW {                 // effective (reparametrised) weights of one conv layer, tap-major [G][Cout_g][k][Cin_g]
+    const void* eff = nullptr; // activation dtype
+    const float* bias = nullptr;
+    float* dweff = nullptr;    // fp32 gradient of eff (same layout)
+    float* dbias = nullptr;
+    int Cin = 0, Cout = 0, k = 1, s = 1, d = 1, P = 0, groups = 1;
+};
+
+struct ConvEpi {
+    int a_lrelu = 0; float a_slope = 0.f;          // LeakyReLU applied to the conv INPUT while staging
+    int act = XVA_ACT_NONE; float act_slope = 0.f;  // activation on the output
+    const Seq* R = nullptr; float alpha = 1.f, beta = 1.f;   // y = alpha * (conv + bias) + beta * R
+    int accumulate = 0;
+};
+
+inline xva_gemm_params hg_gp(int compute, int dt) {
+    xva_gemm_params g;
+    memset(&g, 0, sizeof(g));
+    g.batch = 1; g.batch2 = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.compute = compute; g.mask_mul = 1;
+    g.a_dtype = g.b_dtype = g.c_dtype = dt;
+    return g;
+}
+inline int hg_splitk(int M, int N, int64_t K, int batches) {
+    long tiles = (long)xva_cdiv(M, 128) * xva_cdiv(N, N <= 32 ? 32 : (N <= 64 ? 64 : 128)) * batches;
+    int sk = (int)((768 + tiles - 1) / tiles);
+    int nkt = xva_cdiv(K, 32);
+    int maxsk = nkt / 8; if (maxsk < 1) maxsk = 1;
+    if (sk > maxsk) sk = maxsk;
+    return sk < 1 ? 1 : sk;
+}
+inline int hg_conv_out_len(int T, const ConvW& w) { return (T + 2 * w.P - w.d * (w.k - 1) - 1) / w.s + 1; }
+
+enum { HG_MERGED = 0, HG_PERITEM = 1 };
+inline int hg_mode(const Seq& X, const Seq& Y, const ConvW& w) {
+    if (X.nseq == Y.nseq && X.Hp() == w.s * Y.Hp() && X.padF == w.s * Y.padF) return HG_MERGED;
+    return HG_PERITEM;
+}
+
+// ---- forward: Y = act(alpha * (conv(lrelu?(X)) + bias) + beta * R) ------------------------------------------------
+inline int hg_conv_fwd(const Seq& X, const Seq& Y, const ConvW& w, const ConvEpi& e, int compute, void* st) {
+    XVA_CHECK_ARG(X.C == w.Cin && Y.C == w.Cout && X.nseq == Y.nseq, "conv_fwd: channel/batch mismatch");
+    XVA_CHECK_ARG(Y.T == hg_conv_out_len(X.T, w), "conv_fwd: output length %d != %d", Y.T, hg_conv_out_len(X.T, w));
+    const int Cig = w.Cin / w.groups, Cog = w.Cout / w.groups;
+    xva_gemm_params g = hg_gp(compute, X.dt);
+    g.layout = XVA_GEMM_NT;
+    g.N = Cog; g.K = w.k * Cig;
+    g.lda = (int64_t)w.s * X.C; g.ldb = g.K; g.ldc = Y.C;
+    g.a_seglen = Cig; g.a_segadj = (int64_t)w.d * X.C - Cig;
+    g.B = w.eff; g.bias = w.bias;
+    g.a_lrelu = e.a_lrelu; g.a_slope = e.a_slope; g.act = e.act; g.act_slope = e.act_slope;
+    g.alpha = e.alpha; g.beta = e.beta; g.accumulate = e.accumulate;
+    g.batch2 = w.groups; g.sA2 = Cig; g.sB2 = (int64_t)Cog * g.K; g.sC2 = Cog; g.sR2 = Cog;
+    if (e.R) { XVA_CHECK_ARG(e.R->same_geom(Y) && e.R->C == Y.C, "conv_fwd: residual geometry"); g.ldr = Y.C; g.r_dtype = e.R->dt; }
+    if (hg_mode(X, Y, w) == HG_MERGED) {
+        g.A = (const char*)X.ptr() - (int64_t)w.P * X.C * X.es();
+        g.C = Y.ptr(); g.M = (int)Y.rows();
+        if (e.R) g.R = e.R->ptr();
+        g.mask_mode = XVA_MASK_PAD; g.Tp = Y.Hp(); g.mask_pad = Y.padF; g.mask_len = Y.T;
+    } else {
+        g.batch = X.nseq; g.sA = X.item(); g.sC = Y.item(); g.sR = Y.item();
+        g.A = (const char*)X.valid() - (int64_t)w.P * X.C * X.es();
+        g.C = Y.valid(); g.M = Y.T;
+        if (e.R) g.R = e.R->valid();
+    }
+    g.sbias2 = Cog;
+    return xva_gemm(&g, st);
+}
+
+// ---- backward-data: dX = gate(X) * sum_taps dY (*) W  (+ beta * R) -----------------------------------------------
+// stride 1: one GEMM.  stride s: one GEMM per input phase psi (polyphase), each using the taps j = j0 + m*s.
+struct BwdEpi {
+    const Seq* gate = nullptr; float gate_slope = 0.f;   // multiply by lrelu'(gate) (gate has dX's geometry)
+    const Seq* R = nullptr; float alpha = 1.f, beta = 1.f;
+    int accumulate = 0;
+};
+inline int hg_conv_bwd_data(const Seq& dY, const Seq& dX, const ConvW& w, const BwdEpi& e, int compute, void* st) {
+    XVA_CHECK_ARG(dX.C == w.Cin && dY.C == w.Cout && dX.nseq == dY.nseq, "conv_bwd_data: channel/batch mismatch");
+    XVA_CHECK_ARG(w.s == 1 || w.d == 1, "conv_bwd_data: strided + dilated is not used by the path");
+    const int Cig = w.Cin / w.groups, Cog = w.Cout / w.groups;
+    const int mode = hg_mode(dX, dY, w);
+    for (int psi = 0; psi < w.s; ++psi) {
+        const int j0 = (psi + w.P) % w.s, c0 = (psi + w.P) / w.s;
+        const int ntap = (w.k - j0 + w.s - 1) / w.s;
+        if (ntap <= 0) continue;   // (cannot happen for k >= s)
+        xva_gemm_params g = hg_gp(compute, dY.dt);
+        g.layout = XVA_GEMM_NN;
+        g.N = Cig; g.K = ntap * Cog;
+        g.lda = dY.C; g.ldb = (int64_t)w.k * Cig; g.ldc = (int64_t)w.s * dX.C;
+        // A(q, (m, co)) = dY[(q + c0 - m * d') * C + co], d' = dilation (stride-1 case) or 1
+        const int64_t step = (w.s == 1) ? (int64_t)w.d : 1;
+        g.a_seglen = Cog; g.a_segadj = -step * dY.C - Cog;
+        // B row (m, co) -> eff[co][j0 + m*s][:]
+        g.seglen = Cog; g.seg0 = (int64_t)j0 * Cig; g.segstride = (int64_t)w.s * Cig;
+        g.B = w.eff;
+        g.alpha = e.alpha; g.beta = e.beta; g.accumulate = e.accumulate;
+        g.batch2 = w.groups; g.sA2 = Cog; g.sB2 = (int64_t)Cog * w.k * Cig; g.sC2 = Cig; g.sR2 = Cig; g.sG2 = Cig;
+        if (e.R) { g.ldr = (int64_t)w.s * dX.C; g.r_dtype = e.R->dt; }
+        if (e.gate) { g.ldg = (int64_t)w.s * dX.C; g.g_dtype = e.gate->dt; g.gate_slope = e.gate_slope; }
+        // stride 1: dX[t] = sum_j dY[t + P - j*d] W_j  -> c0 = P (row offset), taps step by d
+        const int64_t a_row0 = (w.s == 1) ? (int64_t)w.P : (int64_t)c0;
+        if (mode == HG_MERGED) {
+            g.A = (const char*)dY.ptr() + a_row0 * dY.C * dY.es();
+            g.C = (char*)dX.ptr() + (int64_t)psi * dX.C * dX.es();
+            g.M = (int)dY.rows();
+            if (e.R) g.R = (const char*)e.R->ptr() + (int64_t)psi * dX.C * e.R->es();
+            if (e.gate) g.G = (const char*)e.gate->ptr() + (int64_t)psi * dX.C * e.gate->es();
+            g.mask_mode = XVA_MASK_PAD; g.Tp = dX.Hp(); g.mask_pad = dX.padF; g.mask_len = dX.T; g.mask_mul = w.s; g.mask_add = psi;
+        } else {
+            const int Q = (dX.T - psi + w.s - 1) / w.s;
+            if (Q <= 0) continue;
+            g.batch = dX.nseq; g.sA = dY.item(); g.sC = dX.item(); g.sR = dX.item(); g.sG = dX.item();
+            g.A = (const char*)dY.valid() + a_row0 * dY.C * dY.es();
+            g.C = (char*)dX.valid() + (int64_t)psi * dX.C * dX.es();
+            g.M = Q;
+            if (e.R) g.R = (const char*)e.R->valid() + (int64_t)psi * dX.C * e.R->es();
+            if (e.gate) g.G = (const char*)e.gate->valid() + (int64_t)psi * dX.C * e.gate->es();
+        }
+        XVA_TRY(xva_gemm(&g, st));
+    }
+    return XVA_OK;
+}
+
+// ---- backward-weight: dWeff[g][co][(j, ci)] += alpha * sum_rows dY[r][co] * lrelu?(X)[s*r + j*d - P][ci] ----------
+inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x_lrelu, float x_slope, float alpha, int compute, void* st) {
+    XVA_CHECK_ARG(X.C == w.Cin && dY.C == w.Cout && X.nseq == dY.nseq && w.dweff, "conv_bwd_weight: mismatch");
+    const int Cig = w.Cin / w.groups, Cog = w.Cout / w.groups;
+    xva_gemm_params g = hg_gp(compute, dY.dt);
+    g.layout = XVA_GEMM_TN;
+    g.M = Cog; g.N = w.k * Cig;
+    g.lda = dY.C; g.ldb = (int64_t)w.s * X.C; g.ldc = g.N;
+    g.seglen = Cig; g.segstride = (int64_t)w.d * X.C - Cig; g.seg0 = 0;
+    g.C = w.dweff; g.c_dtype = XVA_F32;
+    g.b_lrelu = x_lrelu; g.b_slope = x_slope; g.alpha = alpha;
+    g.batch2 = w.groups; g.sA2 = Cog; g.sB2 = Cig; g.sC2 = (int64_t)Cog * g.N;
+    if (hg_mode(X, dY, w) == HG_MERGED) {
+        g.A = dY.ptr();
+        g.B = (const char*)X.ptr() - (int64_t)w.P * X.C * X.es();
+        g.K = (int)dY.rows();
+        g.accumulate = 1; g.splitk = hg_splitk(g.M, g.N, g.K, w.groups);
+    } else {
+        g.batch = X.nseq; g.sA = dY.item(); g.sB = X.item(); g.sC = 0;
+        g.A = dY.valid();
+        g.B = (const char*)X.valid() - (int64_t)w.P * X.C * X.es();
+        g.K = dY.T;
+        g.accumulate = 2;
+    }
+    return xva_gemm(&g, st);
+}
+
+// ---- ConvTranspose1d(Cin -> Cout, k, stride s, padding p = (k - s) / 2), k % s == 0 -------------------------------
+struct ConvTW {
+    const void* effF = nullptr;   // [phase][Cout][ntap * Cin]   (forward, per output phase)
+    const void* effB = nullptr;   // [Cin][k * Cout]             (backward-data = strided conv of dY)
+    const float* bias = nullptr;
+    float* dweff = nullptr;       // fp32 [Cin][k * Cout]
+    float* dbias = nullptr;
+    int Cin = 0, Cout = 0, k = 0, s = 0, p = 0;
+};
+// Y[s*q + phi] = bias + sum_m lrelu(X)[q + c0(phi) - m] * W[:, :, j0(phi) + m*s]      (per item; any geometry)
+inline int hg_convT_fwd(const Seq& X, const Seq& Y, const ConvTW& w, int a_lrelu, float a_slope, int compute, void* st) {
+    XVA_CHECK_ARG(X.C == w.Cin && Y.C == w.Cout && X.nseq == Y.nseq && Y.T == X.T * w.s, "convT_fwd: geometry mismatch");
+    const int ntap = w.k / w.s;
+    XVA_CHECK_ARG(X.padF >= ntap && X.padB >= ntap, "convT_fwd: input pads too small");
+    for (int phi = 0; phi < w.s; ++phi) {
+        const int c0 = (phi + w.p) / w.s;
+        xva_gemm_params g = hg_gp(compute, X.dt);
+        g.layout = XVA_GEMM_NT;
+        g.M = X.T; g.N = w.Cout; g.K = ntap * w.Cin;
+        g.lda = X.C; g.ldb = g.K; g.ldc = (int64_t)w.s * Y.C;
+        g.a_seglen = w.Cin; g.a_segadj = -(int64_t)X.C - w.Cin;
+        g.A = (const char*)X.valid() + (int64_t)c0 * X.C * X.es();
+        g.B = (const char*)w.effF + (int64_t)phi * w.Cout * g.K * X.es();
+        g.C = (char*)Y.valid() + (int64_t)phi * Y.C * Y.es();
+        g.bias = w.bias; g.a_lrelu = a_lrelu; g.a_slope = a_slope;
+        g.batch = X.nseq; g.sA = X.item(); g.sC = Y.item();
+        XVA_TRY(xva_gemm(&g, st));
+    }
+    return XVA_OK;
+}
+// dX[t][ci] = lrelu'(X) * sum_{j, co} dY[s*t + j - p][co] * W[ci][co][j]   (a strided conv of dY; per item)
+inline int hg_convT_bwd_data(const Seq& dY, const Seq& dX, const ConvTW& w, const Seq* gate, float gate_slope, int compute, void* st) {
+    XVA_CHECK_ARG(dX.C == w.Cin && dY.C == w.Cout && dX.nseq == dY.nseq && dY.T == dX.T * w.s, "convT_bwd_data: geometry mismatch");
+    XVA_CHECK_ARG(dY.padF >= w.p && dY.padB >= w.k, "convT_bwd_data: dY pads too small");
+    xva_gemm_params g = hg_gp(compute, dY.dt);
+    g.layout = XVA_GEMM_NT;
+    g.M = dX.T; g.N = w.Cin; g.K = w.k * w.Cout;
+    g.lda = (int64_t)w.s * dY.C; g.ldb = g.K; g.ldc = dX.C;      // taps are consecutive rows of dY: no segment adjustment
+    g.A = (const char*)dY.valid() - (int64_t)w.p * dY.C * dY.es();
+    g.B = w.effB; g.C = dX.valid();
+    g.batch = dX.nseq; g.sA = dY.item(); g.sC = dX.item();
+    if (gate) { g.G = gate->valid(); g.ldg = dX.C; g.sG = gate->item(); g.g_dtype = gate->dt; g.gate_slope = gate_slope; }
+    return xva_gemm(&g, st);
+}
+// dW[ci][(j, co)] += sum_t lrelu(X)[t][ci] * dY[s*t + j - p][co]
+inline int hg_convT_bwd_weight(const Seq& dY, const Seq& X, const ConvTW& w, int x_lrelu, float x_slope, int compute, void* st) {
+    xva_gemm_params g = hg_gp(compute, dY.dt);
+    g.layout = XVA_GEMM_TN;
+    g.M = w.Cin; g.N = w.k * w.Cout; g.K = X.T;
+    g.lda = X.C; g.ldb = (int64_t)w.s * dY.C; g.ldc = g.N;
+    g.A = X.valid();
+    g.B = (const char*)dY.valid() - (int64_t)w.p * dY.C * dY.es();
+    g.C = w.dweff; g.c_dtype = XVA_F32;
+    g.a_lrelu = x_lrelu; g.a_slope = x_slope;
+    g.batch = X.nseq; g.sA = X.item(); g.sB = dY.item(); g.sC = 0; g.accumulate = 2;
+    return xva_gemm(&g, st);
+}

@@ -1,0 +1,540 @@
+// hg_ops.hip — the non-GEMM kernels of the HiFi-GAN hot loop (gfx950): single-channel convolutions at the waveform
+// boundary, period folding, pooling, reparametrisations (weight_norm / spectral_norm), GAN / feature / L1 losses.
+// Reference: python/hifigan/models.py:17-294, python/hifigan/xva_train.py:479-515.
+//
+// Activations are "time-major sequences": nseq items, each Hp = padF + T + padB rows of C channels, element type
+// fp32 or bf16 (dt = XVA_F32 / XVA_BF16), pad rows structurally zero.  All kernels here are HBM-bound single passes.
+#include "xva_common.h"
+#include "../../include/xva_gemm.h"
+#include "../../include/xva_hip.h"
+
+__device__ __forceinline__ float hg_ld(const void* p, int64_t i, int dt) {
+    return dt == XVA_BF16 ? __uint_as_float(((uint32_t) reinterpret_cast<const uint16_t*>(p)[i]) << 16)
+                          : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void hg_st(void* p, int64_t i, int dt, float v) {
+    if (dt == XVA_BF16) {
+        uint32_t u = __float_as_uint(v);
+        u += 0x7fffu + ((u >> 16) & 1u);   // round to nearest even
+        reinterpret_cast<uint16_t*>(p)[i] = (uint16_t)(u >> 16);
+    } else {
+        reinterpret_cast<float*>(p)[i] = v;
+    }
+}
+__device__ __forceinline__ float hg_lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// mel (B, C, T) fp32  ->  time-major sequence rows (B, Hp, C) at valid rows          (Generator input, models.py:110)
+__global__ void hg_mel_to_tm_kernel(const float* __restrict__ mel, void* __restrict__ out, int dt, int B, int C, int T, int Hp,
+                                    int padF) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T * C) return;
+    int c = (int)(i % C);
+    int t = (int)((i / C) % T);
+    int b = (int)(i / ((int64_t)C * T));
+    hg_st(out, ((int64_t)b * Hp + padF + t) * C + c, dt, mel[((int64_t)b * C + c) * T + t]);
+}
+extern "C" int xva_hg_mel_to_tm(const float* mel, void* out, int dt, int B, int C, int T, int Hp, int padF, void* stream) {
+    XVA_CHECK_ARG(mel && out, "mel_to_tm: null");
+    int64_t n = (int64_t)B * T * C;
+    hipLaunchKernelGGL(hg_mel_to_tm_kernel, dim3(xva_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, mel, out, dt, B, C, T, Hp, padF);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Single-input-channel convolution at the waveform boundary (DiscriminatorS conv0: Conv1d(1,128,15,1,pad 7) models.py:207;
+// DiscriminatorP conv0: Conv2d(1,32,(5,1),(3,1),pad (2,0)) on the wave folded to (T/p, p) with right reflect padding,
+// models.py:154-163).  Sequence (b, w) of a period-p discriminator holds samples wav[b, h * p + w]; p = 1 is the plain case.
+//   out[(b,w)][padF + h'][co] = lrelu(bias[co] + sum_j W[co][j] * x(b, w, s*h' + j - P))
+// wav: (nb, Tw) fp32 ; reflect: samples Tw <= i < Hfold * p map to wav[2*(Tw-1) - i]; x = 0 outside [0, Hfold).
+struct Cin1Geom { int nb, Tw, p, Hfold, k, s, P, Cout, Tout, Hp, padF; };
+
+__device__ __forceinline__ float cin1_sample(const float* __restrict__ wav, const Cin1Geom& g, int b, int w, int h) {
+    if (h < 0 || h >= g.Hfold) return 0.f;
+    int i = h * g.p + w;
+    if (i >= g.Tw) i = 2 * (g.Tw - 1) - i;
+    return wav[(int64_t)b * g.Tw + i];
+}
+__global__ void hg_cin1_fwd_kernel(const float* __restrict__ wav, const float* __restrict__ W, const float* __restrict__ bias,
+                                   void* __restrict__ out, int dt, Cin1Geom g, float slope) {
+    // one block per (sequence, chunk of 64 output rows); threads over (row, co)
+    const int seq = blockIdx.y, b = seq / g.p, w = seq % g.p;
+    const int h0 = blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < 64 * g.Cout; idx += blockDim.x) {
+        int hl = idx / g.Cout, co = idx % g.Cout;
+        int h = h0 + hl;
+        if (h >= g.Tout) continue;
+        float acc = bias[co];
+        for (int j = 0; j < g.k; ++j) acc += W[co * g.k + j] * cin1_sample(wav, g, b, w, g.s * h + j - g.P);
+        hg_st(out, ((int64_t)seq * g.Hp + g.padF + h) * g.Cout + co, dt, hg_lrelu(acc, slope));
+    }
+}
+// dW[co][j] += sum dY[seq][h][co] * x(seq, s*h + j - P) ; db[co] += sum dY   (dY = gradient w.r.t. the pre-activation)
+__global__ void hg_cin1_bwd_weight_kernel(const float* __restrict__ wav, const void* __restrict__ dY, int dt, float* __restrict__ dW,
+                                          float* __restrict__ db, Cin1Geom g) {
+    const int seq = blockIdx.y, b = seq / g.p, w = seq % g.p;
+    const int h0 = blockIdx.x * 256, h1 = min(h0 + 256, g.Tout);
+    for (int idx = threadIdx.x; idx < g.Cout * (g.k + 1); idx += blockDim.x) {
+        int co = idx / (g.k + 1), j = idx % (g.k + 1);
+        float acc = 0.f;
+        for (int h = h0; h < h1; ++h) {
+            float d = hg_ld(dY, ((int64_t)seq * g.Hp + g.padF + h) * g.Cout + co, dt);
+            acc += (j == g.k) ? d : d * cin1_sample(wav, g, b, w, g.s * h + j - g.P);
+        }
+        if (j == g.k) atomicAdd(db + co, acc); else atomicAdd(dW + co * g.k + j, acc);
+    }
+}
+// d_wav[b][i] (+)= sum over folded positions aliasing sample i of sum_{j, co} dY[(b,w)][h'][co] W[co][j], s*h' + j - P = h
+__global__ void hg_cin1_bwd_data_kernel(const void* __restrict__ dY, int dt, const float* __restrict__ W, float* __restrict__ dwav,
+                                        Cin1Geom g, int accumulate) {
+    extern __shared__ float sW[];   // Cout * k
+    for (int i = threadIdx.x; i < g.Cout * g.k; i += blockDim.x) sW[i] = W[i];
+    __syncthreads();
+    int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= (int64_t)g.nb * g.Tw) return;
+    int b = (int)(gi / g.Tw), i = (int)(gi % g.Tw);
+    float total = 0.f;
+    for (int alias = 0; alias < 2; ++alias) {
+        int ii = i;
+        if (alias == 1) { ii = 2 * (g.Tw - 1) - i; if (ii < g.Tw || ii >= g.Hfold * g.p) break; }
+        int h = ii / g.p, w = ii % g.p;
+        int seq = b * g.p + w;
+        for (int j = 0; j < g.k; ++j) {
+            int num = h + g.P - j;
+            if (num < 0 || num % g.s != 0) continue;
+            int hp = num / g.s;
+            if (hp >= g.Tout) continue;
+            int64_t base = ((int64_t)seq * g.Hp + g.padF + hp) * g.Cout;
+            float acc = 0.f;
+            for (int co = 0; co < g.Cout; ++co) acc += hg_ld(dY, base + co, dt) * sW[co * g.k + j];
+            total += acc;
+        }
+    }
+    if (accumulate) dwav[gi] += total; else dwav[gi] = total;
+}
+static int cin1_geom(Cin1Geom* g, int nb, int Tw, int p, int k, int s, int P, int Cout, int Hp, int padF) {
+    XVA_CHECK_ARG(nb > 0 && Tw > 1 && p >= 1 && k >= 1 && s >= 1 && Cout >= 1, "cin1: bad geometry");
+    g->nb = nb; g->Tw = Tw; g->p = p; g->k = k; g->s = s; g->P = P; g->Cout = Cout; g->Hp = Hp; g->padF = padF;
+    g->Hfold = (Tw + p - 1) / p;
+    g->Tout = (g->Hfold + 2 * P - k) / s + 1;
+    XVA_CHECK_ARG(padF + g->Tout <= Hp, "cin1: output rows do not fit Hp");
+    return XVA_OK;
+}
+extern "C" int xva_hg_cin1_out_len(int Tw, int p, int k, int s, int P) { return ((Tw + p - 1) / p + 2 * P - k) / s + 1; }
+extern "C" int xva_hg_cin1_fwd(const float* wav, const float* W, const float* bias, void* out, int dt, int nb, int Tw, int p, int k,
+                               int s, int P, int Cout, int Hp, int padF, float slope, void* stream) {
+    Cin1Geom g;
+    XVA_TRY(cin1_geom(&g, nb, Tw, p, k, s, P, Cout, Hp, padF));
+    XVA_CHECK_ARG(wav && W && bias && out, "cin1_fwd: null");
+    hipLaunchKernelGGL(hg_cin1_fwd_kernel, dim3(xva_cdiv(g.Tout, 64), nb * p), dim3(256), 0, (hipStream_t)stream, wav, W, bias, out, dt, g, slope);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_hg_cin1_bwd_weight(const float* wav, const void* dY, int dt, float* dW, float* db, int nb, int Tw, int p, int k, int s,
+                                      int P, int Cout, int Hp, int padF, void* stream) {
+    Cin1Geom g;
+    XVA_TRY(cin1_geom(&g, nb, Tw, p, k, s, P, Cout, Hp, padF));
+    XVA_CHECK_ARG(wav && dY && dW && db, "cin1_bwd_weight: null");
+    hipLaunchKernelGGL(hg_cin1_bwd_weight_kernel, dim3(xva_cdiv(g.Tout, 256), nb * p), dim3(256), 0, (hipStream_t)stream, wav, dY, dt, dW, db, g);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_hg_cin1_bwd_data(const void* dY, int dt, const float* W, float* dwav, int nb, int Tw, int p, int k, int s, int P,
+                                    int Cout, int Hp, int padF, int accumulate, void* stream) {
+    Cin1Geom g;
+    XVA_TRY(cin1_geom(&g, nb, Tw, p, k, s, P, Cout, Hp, padF));
+    XVA_CHECK_ARG(dY && W && dwav, "cin1_bwd_data: null");
+    int64_t n = (int64_t)nb * Tw;
+    hipLaunchKernelGGL(hg_cin1_bwd_data_kernel, dim3(xva_cdiv(n, 256)), dim3(256), Cout * k * sizeof(float), (hipStream_t)stream, dY, dt, W,
+                       dwav, g, accumulate);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Single-OUTPUT-channel convolution backward (conv_post layers: models.py:108,152,216).  Forward runs on the GEMM (N = 1).
+// Rows are the merged row index of the input sequence tensor x (rows = nseq * Hp, C channels); d is the gradient of the
+// 1-channel output on the same row grid.
+//   dX[r][c] = gate(x[r][c]) * sum_j d[r + P - j*dil] * w[j*C + c]      (valid rows only, pads -> 0)
+//   dw[j*C + c] += sum_r d[r] * act(x[r + j*dil - P][c]) ; db += sum_r d[r]
+__global__ void hg_cout1_bwd_data_kernel(const void* __restrict__ d, const float* __restrict__ w, const void* __restrict__ x,
+                                         void* __restrict__ dX, int dt, int64_t rows, int C, int k, int dil, int P, int Hp, int padF,
+                                         int T, int gate, float slope) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    int64_t r = i / C;
+    int c = (int)(i % C);
+    int t = (int)(r % Hp);
+    float v = 0.f;
+    if (t >= padF && t < padF + T) {
+        for (int j = 0; j < k; ++j) {
+            int64_t rr = r + P - (int64_t)j * dil;
+            if (rr < 0 || rr >= rows) continue;
+            v += hg_ld(d, rr, dt) * w[j * C + c];
+        }
+        if (gate && !(hg_ld(x, i, dt) > 0.f)) v *= slope;
+    }
+    hg_st(dX, i, dt, v);
+}
+__global__ void hg_cout1_bwd_weight_kernel(const void* __restrict__ d, const void* __restrict__ x, float* __restrict__ dw,
+                                           float* __restrict__ db, int dt, int64_t rows, int C, int k, int dil, int P, int act,
+                                           float slope, int rows_per_block) {
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (int idx = threadIdx.x; idx < k * C + 1; idx += blockDim.x) {
+        float acc = 0.f;
+        if (idx == k * C) {
+            for (int64_t r = r0; r < r1; ++r) acc += hg_ld(d, r, dt);
+            if (acc != 0.f) atomicAdd(db, acc);
+        } else {
+            int j = idx / C, c = idx % C;
+            for (int64_t r = r0; r < r1; ++r) {
+                float dv = hg_ld(d, r, dt);
+                if (dv == 0.f) continue;
+                int64_t rr = r + (int64_t)j * dil - P;
+                if (rr < 0 || rr >= rows) continue;
+                float xv = hg_ld(x, rr * C + c, dt);
+                if (act) xv = hg_lrelu(xv, slope);
+                acc += dv * xv;
+            }
+            if (acc != 0.f) atomicAdd(dw + idx, acc);
+        }
+    }
+}
+extern "C" int xva_hg_cout1_bwd_data(const void* d, const float* w, const void* x, void* dX, int dt, int64_t rows, int C, int k, int dil,
+                                     int P, int Hp, int padF, int T, int gate, float slope, void* stream) {
+    XVA_CHECK_ARG(d && w && x && dX, "cout1_bwd_data: null");
+    hipLaunchKernelGGL(hg_cout1_bwd_data_kernel, dim3(xva_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, d, w, x, dX, dt, rows, C, k,
+                       dil, P, Hp, padF, T, gate, slope);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_hg_cout1_bwd_weight(const void* d, const void* x, float* dw, float* db, int dt, int64_t rows, int C, int k, int dil, int P,
+                                       int act, float slope, void* stream) {
+    XVA_CHECK_ARG(d && x && dw && db, "cout1_bwd_weight: null");
+    const int rpb = 128;
+    hipLaunchKernelGGL(hg_cout1_bwd_weight_kernel, dim3(xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, d, x, dw, db, dt, rows, C, k,
+                       dil, P, act, slope, rpb);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// AvgPool1d(4, 2, padding=2) on waveforms (count_include_pad) and its backward   (MultiScaleDiscriminator, models.py:240-249)
+__global__ void hg_avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int nb, int T, int To) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nb * To) return;
+    int b = (int)(i / To), t = (int)(i % To);
+    float s = 0.f;
+    for (int j = 0; j < 4; ++j) { int k = 2 * t - 2 + j; if (k >= 0 && k < T) s += x[(int64_t)b * T + k]; }
+    y[i] = 0.25f * s;
+}
+__global__ void hg_avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int nb, int T, int To, int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nb * T) return;
+    int b = (int)(i / T), k = (int)(i % T);
+    float s = 0.f;
+    for (int j = 0; j < 4; ++j) { int num = k + 2 - j; if (num >= 0 && num % 2 == 0 && num / 2 < To) s += dy[(int64_t)b * To + num / 2]; }
+    s *= 0.25f;
+    if (accumulate) dx[i] += s; else dx[i] = s;
+}
+extern "C" int xva_hg_avgpool_fwd(const float* x, float* y, int nb, int T, void* stream) {
+    int To = T / 2 + 1;
+    hipLaunchKernelGGL(hg_avgpool_fwd_kernel, dim3(xva_cdiv((int64_t)nb * To, 256)), dim3(256), 0, (hipStream_t)stream, x, y, nb, T, To);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_hg_avgpool_bwd(const float* dy, float* dx, int nb, int T, int accumulate, void* stream) {
+    int To = T / 2 + 1;
+    hipLaunchKernelGGL(hg_avgpool_bwd_kernel, dim3(xva_cdiv((int64_t)nb * T, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, nb, T, To, accumulate);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Reductions over the valid region of sequence tensors (losses, models.py:263-294; xva_train.py:504).
+// mode 0: sum |a - b|   mode 1: sum (1 - a)^2   mode 2: sum a^2        (b unused for 1, 2)
+__global__ void hg_reduce_kernel(const void* __restrict__ a, const void* __restrict__ b, int dt, int nseq, int Hp, int padF, int T, int C,
+                                 int mode, float scale, float* __restrict__ out) {
+    __shared__ float sh[16];
+    int64_t total = (int64_t)nseq * T * C;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        int t = (int)((i / C) % T);
+        int64_t s = i / ((int64_t)C * T);
+        int64_t idx = (s * Hp + padF + t) * C + c;
+        float av = hg_ld(a, idx, dt);
+        if (mode == 0) acc += fabsf(av - hg_ld(b, idx, dt));
+        else if (mode == 1) acc += (1.f - av) * (1.f - av);
+        else acc += av * av;
+    }
+    acc = xva_block_sum(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(out, acc * scale);
+}
+extern "C" int xva_hg_reduce(const void* a, const void* b, int dt, int nseq, int Hp, int padF, int T, int C, int mode, float scale, float* out, void* stream) {
+    XVA_CHECK_ARG(a && out && (mode != 0 || b), "hg_reduce: null");
+    int64_t total = (int64_t)nseq * T * C;
+    int grid = (int)((total + 255) / 256); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(hg_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, dt, nseq, Hp, padF, T, C, mode, scale, out);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+// Gradient seeds / additions on the valid region of the FAKE half of a discriminator tensor:
+//   dY (+)= c_fm * sign(g - r) [* lrelu'(g) if gated] + (mode 1: c_gan * 2 (g - 1) ; mode 2: c_gan * 2 g ; mode 3 (real): c_gan * 2 (r - 1))
+// r, g: real / fake tensors (same geometry); dY: gradient tensor of the same geometry.  init: 0 -> accumulate, 1 -> overwrite.
+__global__ void hg_seed_grad_kernel(const void* __restrict__ r, const void* __restrict__ g, void* __restrict__ dY, int dt, int nseq, int Hp,
+                                    int padF, int T, int C, float c_fm, float c_gan, int gan_mode, int gated, float slope, int init) {
+    int64_t total = (int64_t)nseq * T * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        int t = (int)((i / C) % T);
+        int64_t s = i / ((int64_t)C * T);
+        int64_t idx = (s * Hp + padF + t) * C + c;
+        float gv = g ? hg_ld(g, idx, dt) : 0.f;
+        float rv = r ? hg_ld(r, idx, dt) : 0.f;
+        float v = 0.f;
+        if (c_fm != 0.f) { float df = gv - rv; v += c_fm * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)); }
+        if (gan_mode == 1) v += c_gan * 2.f * (gv - 1.f);
+        else if (gan_mode == 2) v += c_gan * 2.f * gv;
+        else if (gan_mode == 3) v += c_gan * 2.f * (rv - 1.f);
+        if (!init) v += hg_ld(dY, idx, dt);
+        if (gated) { float ref = (gan_mode == 3) ? rv : gv; if (!(ref > 0.f)) v *= slope; }
+        hg_st(dY, idx, dt, v);
+    }
+}
+extern "C" int xva_hg_seed_grad(const void* r, const void* g, void* dY, int dt, int nseq, int Hp, int padF, int T, int C, float c_fm,
+                                float c_gan, int gan_mode, int gated, float slope, int init, void* stream) {
+    XVA_CHECK_ARG(dY, "hg_seed_grad: null");
+    int64_t total = (int64_t)nseq * T * C;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(hg_seed_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, r, g, dY, dt, nseq, Hp, padF, T, C, c_fm, c_gan,
+                       gan_mode, gated, slope, init);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// wav (nb, T) fp32 <-> 1-channel sequence tensor ; tanh backward
+__global__ void hg_seq1_to_wav_kernel(const void* __restrict__ s, int dt, float* __restrict__ wav, int nb, int T, int Hp, int padF) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nb * T) return;
+    int b = (int)(i / T), t = (int)(i % T);
+    wav[i] = hg_ld(s, (int64_t)b * Hp + padF + t, dt);
+}
+// d_pre[seq rows] = d_wav * (1 - y^2), y = tanh output (1-channel sequence tensor)
+__global__ void hg_tanh_bwd_kernel(const float* __restrict__ dwav, const void* __restrict__ y, void* __restrict__ dpre, int dt, int nb, int T,
+                                   int Hp, int padF) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nb * T) return;
+    int b = (int)(i / T), t = (int)(i % T);
+    int64_t idx = (int64_t)b * Hp + padF + t;
+    float yv = hg_ld(y, idx, dt);
+    hg_st(dpre, idx, dt, dwav[i] * (1.f - yv * yv));
+}
+extern "C" int xva_hg_seq1_to_wav(const void* s, int dt, float* wav, int nb, int T, int Hp, int padF, void* stream) {
+    hipLaunchKernelGGL(hg_seq1_to_wav_kernel, dim3(xva_cdiv((int64_t)nb * T, 256)), dim3(256), 0, (hipStream_t)stream, s, dt, wav, nb, T, Hp, padF);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_hg_tanh_bwd(const float* dwav, const void* y, void* dpre, int dt, int nb, int T, int Hp, int padF, void* stream) {
+    hipLaunchKernelGGL(hg_tanh_bwd_kernel, dim3(xva_cdiv((int64_t)nb * T, 256)), dim3(256), 0, (hipStream_t)stream, dwav, y, dpre, dt, nb, T, Hp, padF);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// column sums over ALL rows of a sequence tensor (bias gradients; pad rows are zero): out[c] += sum_r X[r][c]
+__global__ void hg_colsum_kernel(const void* __restrict__ X, int dt, float* __restrict__ out, int64_t rows, int C, int rows_per_block, float scale) {
+    __shared__ float sh[4][64];
+    int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    int c = blockIdx.x * 64 + cl;
+    int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float acc = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + rl; r < r1; r += 4) acc += hg_ld(X, r * C + c, dt);
+    sh[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) atomicAdd(out + c, scale * (sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]));
+}
+extern "C" int xva_hg_colsum(const void* X, int dt, float* out, int64_t rows, int C, float scale, void* stream) {
+    XVA_CHECK_ARG(X && out, "hg_colsum: null");
+    const int rpb = 512;
+    hipLaunchKernelGGL(hg_colsum_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, X, dt, out, rows, C, rpb, scale);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight_norm (old API, dim 0): w = g * v / ||v||  (torch.nn.utils.weight_norm; models.py:21-108)
+// v: (D0, inner) fp32 in the checkpoint layout; writes the effective weight in a GEMM layout given by an index map:
+//   kind 0 (Conv, v = (Cout, Cin_g, k)):       eff[o][j*Cin_g + i]              = w[o][i][j]         (tap-major)
+//   kind 1 (ConvTranspose, v = (Cin, Cout, k)): effF[phase][co][m*Cin + ci]      = w[ci][co][j0(phase) + m*s]   (forward, per phase)
+//                                               effB[ci][j*Cout + co]            = w[ci][co][j]                  (backward-data conv)
+// One block per dim-0 index.  norm[o] saved for the backward.
+__global__ void hg_weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ gparam, void* __restrict__ eff,
+                                          void* __restrict__ effB, float* __restrict__ norm, int dt, int kind, int D0, int D1, int k, int s,
+                                          int pconv) {
+    __shared__ float sh[16];
+    const int o = blockIdx.x;
+    const int inner = D1 * k;
+    const float* vo = v + (int64_t)o * inner;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < inner; i += blockDim.x) acc += vo[i] * vo[i];
+    acc = xva_block_sum(acc, sh);
+    float n = sqrtf(acc);
+    if (threadIdx.x == 0) norm[o] = n;
+    float sc = gparam[o] / n;
+    for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) {
+        int i1 = idx / k, j = idx % k;
+        float w = vo[idx] * sc;
+        if (kind == 0) {
+            hg_st(eff, (int64_t)o * inner + (int64_t)j * D1 + i1, dt, w);
+        } else {
+            // o = ci, i1 = co ; forward phases: t_out = s*q + phi uses taps j = j0 + m*s with j0 = (phi + pconv) % s
+            int ntap = k / s;
+            int Cin = D0, Cout = D1;
+            int j0 = j % s, m = j / s;
+            int phi = ((j0 - pconv) % s + s) % s;
+            hg_st(eff, (((int64_t)phi * Cout + i1) * ntap + m) * Cin + o, dt, w);
+            hg_st(effB, (int64_t)o * k * Cout + (int64_t)j * Cout + i1, dt, w);
+        }
+    }
+}
+// dW: fp32 gradient of the effective weight in the layout: kind 0 tap-major [o][j*D1 + i] ; kind 1 [ci][j*Cout + co].
+// dg[o] = sum dW * v / ||v|| ; dv = (g/||v||) * (dW - (dg/||v||) * v)
+__global__ void hg_weight_norm_bwd_kernel(const float* __restrict__ dW, const float* __restrict__ v, const float* __restrict__ gparam,
+                                          const float* __restrict__ norm, float* __restrict__ dv, float* __restrict__ dg, int kind, int D0,
+                                          int D1, int k) {
+    __shared__ float sh[16];
+    const int o = blockIdx.x;
+    const int inner = D1 * k;
+    const float* vo = v + (int64_t)o * inner;
+    const float* dwo = dW + (int64_t)o * inner;
+    float acc = 0.f;
+    for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) {
+        int i1 = idx / k, j = idx % k;
+        acc += dwo[(int64_t)j * D1 + i1] * vo[idx];
+    }
+    acc = xva_block_sum(acc, sh);
+    float n = norm[o], g = gparam[o];
+    float dgo = acc / n;
+    if (threadIdx.x == 0) dg[o] += dgo;
+    for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) {
+        int i1 = idx / k, j = idx % k;
+        dv[(int64_t)o * inner + idx] += (g / n) * (dwo[(int64_t)j * D1 + i1] - (dgo / n) * vo[idx]);
+    }
+}
+extern "C" int xva_hg_weight_norm_fwd(const float* v, const float* g, void* eff, void* effB, float* norm, int dt, int kind, int D0, int D1, int k,
+                                      int s, int pconv, void* stream) {
+    XVA_CHECK_ARG(v && g && eff && norm && (kind == 0 || effB), "weight_norm_fwd: null");
+    XVA_CHECK_ARG(kind == 0 || (k % s == 0), "weight_norm_fwd: transposed conv needs k %% s == 0");
+    hipLaunchKernelGGL(hg_weight_norm_fwd_kernel, dim3(D0), dim3(256), 0, (hipStream_t)stream, v, g, eff, effB, norm, dt, kind, D0, D1, k, s, pconv);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_hg_weight_norm_bwd(const float* dW, const float* v, const float* g, const float* norm, float* dv, float* dg, int kind, int D0,
+                                      int D1, int k, void* stream) {
+    XVA_CHECK_ARG(dW && v && g && norm && dv && dg, "weight_norm_bwd: null");
+    hipLaunchKernelGGL(hg_weight_norm_bwd_kernel, dim3(D0), dim3(256), 0, (hipStream_t)stream, dW, v, g, norm, dv, dg, kind, D0, D1, k);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// spectral_norm (torch.nn.utils.spectral_norm, 1 power iteration per training forward, eps 1e-12; MSD discriminator 0,
+// models.py:205,233).  W = weight_orig viewed (D0, inner = D1*k):
+//   v <- normalize(W^T u) ; u <- normalize(W v) ; sigma = u . (W v) ; eff (tap-major) = W / sigma
+// tmp: inner + D0 + 2 floats of scratch.
+__global__ void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ t, int D0, int inner) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= inner) return;
+    float a = 0.f;
+    for (int o = 0; o < D0; ++o) a += W[(int64_t)o * inner + i] * u[o];
+    t[i] = a;
+}
+// out = in / max(||in||, eps); optionally dot_out = out . in  (single block)
+__global__ void sn_normalize_kernel(const float* __restrict__ in, float* __restrict__ out, int n, float* __restrict__ dot_out) {
+    __shared__ float sh[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) a += in[i] * in[i];
+    a = xva_block_sum(a, sh);
+    float inv = 1.f / fmaxf(sqrtf(a), 1e-12f);
+    float d = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { float o = in[i] * inv; out[i] = o; d += o * in[i]; }
+    if (dot_out) { d = xva_block_sum(d, sh); if (threadIdx.x == 0) dot_out[0] = d; }
+}
+__global__ void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v, float* __restrict__ sres, int D0, int inner) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int o = blockIdx.x * 4 + wave;
+    if (o >= D0) return;
+    float a = 0.f;
+    for (int i = lane; i < inner; i += 64) a += W[(int64_t)o * inner + i] * v[i];
+    a = xva_wave_sum(a);
+    if (lane == 0) sres[o] = a;
+}
+__global__ void sn_scale_kernel(const float* __restrict__ W, const float* __restrict__ sigma, void* __restrict__ eff, int dt, int D0, int D1, int k) {
+    const int inner = D1 * k;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)D0 * inner) return;
+    int o = (int)(idx / inner), rem = (int)(idx % inner);
+    int i1 = rem / k, j = rem % k;
+    hg_st(eff, (int64_t)o * inner + (int64_t)j * D1 + i1, dt, W[idx] / sigma[0]);
+}
+// dW_orig += dW_eff / sigma - (sum dW_eff * W_orig) / sigma^2 * u v^T    (u, v = the buffers AFTER this pass's power iteration)
+__global__ void sn_bwd_dot_kernel(const float* __restrict__ dWeff, const float* __restrict__ W, float* __restrict__ dot, int D0, int D1, int k) {
+    __shared__ float sh[16];
+    const int inner = D1 * k;
+    float acc = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)D0 * inner; idx += (int64_t)gridDim.x * blockDim.x) {
+        int o = (int)(idx / inner), rem = (int)(idx % inner);
+        int i1 = rem / k, j = rem % k;
+        acc += dWeff[(int64_t)o * inner + (int64_t)j * D1 + i1] * W[idx];
+    }
+    acc = xva_block_sum(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(dot, acc);
+}
+__global__ void sn_bwd_apply_kernel(const float* __restrict__ dWeff, const float* __restrict__ u, const float* __restrict__ vv,
+                                    const float* __restrict__ sigma, const float* __restrict__ dot, float* __restrict__ dWorig, int D0, int D1,
+                                    int k) {
+    const int inner = D1 * k;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)D0 * inner) return;
+    int o = (int)(idx / inner), rem = (int)(idx % inner);
+    int i1 = rem / k, j = rem % k;
+    float sg = sigma[0];
+    dWorig[idx] += dWeff[(int64_t)o * inner + (int64_t)j * D1 + i1] / sg - (dot[0] / (sg * sg)) * u[o] * vv[rem];
+}
+extern "C" int xva_hg_spectral_norm_fwd(const float* W, float* u, float* v, void* eff, float* sigma, int dt, int D0, int D1, int k, float* tmp,
+                                        void* stream) {
+    XVA_CHECK_ARG(W && u && v && eff && sigma && tmp, "spectral_norm_fwd: null");
+    hipStream_t st = (hipStream_t)stream;
+    const int inner = D1 * k;
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(xva_cdiv(inner, 256)), dim3(256), 0, st, W, u, tmp, D0, inner);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, tmp, v, inner, (float*)nullptr);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(xva_cdiv(D0, 4)), dim3(256), 0, st, W, v, tmp + inner, D0, inner);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, tmp + inner, u, D0, sigma);
+    hipLaunchKernelGGL(sn_scale_kernel, dim3(xva_cdiv((int64_t)D0 * inner, 256)), dim3(256), 0, st, W, sigma, eff, dt, D0, D1, k);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+// eff = W / sigma in another dtype (fp32 copy for the 1-channel direct kernels), no power iteration
+extern "C" int xva_hg_sn_scale(const float* W, const float* sigma, void* eff, int dt, int D0, int D1, int k, void* stream) {
+    XVA_CHECK_ARG(W && sigma && eff, "sn_scale: null");
+    hipLaunchKernelGGL(sn_scale_kernel, dim3(xva_cdiv((int64_t)D0 * D1 * k, 256)), dim3(256), 0, (hipStream_t)stream, W, sigma, eff, dt, D0, D1, k);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+// tmp: 1 float of scratch (zeroed here)
+extern "C" int xva_hg_spectral_norm_bwd(const float* dWeff, const float* W, const float* u, const float* v, const float* sigma, float* dWorig, int D0,
+                                        int D1, int k, float* tmp, void* stream) {
+    XVA_CHECK_ARG(dWeff && W && u && v && sigma && dWorig && tmp, "spectral_norm_bwd: null");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(tmp, 0, sizeof(float), st) != hipSuccess) { xva_set_error("spectral_norm_bwd: memset failed"); return XVA_ERR_HIP; }
+    int64_t n = (int64_t)D0 * D1 * k;
+    int grid = (int)((n + 255) / 256); if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(grid), dim3(256), 0, st, dWeff, W, tmp, D0, D1, k);
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(xva_cdiv(n, 256)), dim3(256), 0, st, dWeff, u, v, sigma, tmp, dWorig, D0, D1, k);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}

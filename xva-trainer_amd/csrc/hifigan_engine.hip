@@ -1,0 +1,755 @@
+// hifigan_engine.hip — HiFi-GAN v1 generator + MPD + MSD forward / backward as fixed C++ launch schedules.
+//
+// Reference: Generator / ResBlock1 (python/hifigan/models.py:17-128), DiscriminatorP / MultiPeriodDiscriminator
+// (:140-200), DiscriminatorS / MultiScaleDiscriminator (:203-260), losses (:263-294) and the D + G step of
+// python/hifigan/xva_train.py:479-515.  Every convolution with C_in, C_out > 1 runs on the MFMA implicit-conv GEMM
+// (hg_conv.h) over time-major sequence tensors, with LeakyReLU fused into the consumer's operand staging, bias /
+// residual / (sum of resblocks)/3 / tanh fused into epilogues and LeakyReLU backward fused as an epilogue gate.
+// The 1-channel layers at the waveform boundary, the reparametrisations and the losses are the kernels of hg_ops.hip.
+//
+// Parameters: two flat fp32 buffers in the checkpoint's own tensor layouts — G (generator) and D (mpd.* then msd.*,
+// trainable tensors first, then the spectral-norm power-iteration buffers).  Gradients mirror them.
+#include "hg_conv.h"
+#include "../../include/xva_hip.h"
+#include <string>
+#include <vector>
+
+extern "C" {
+int xva_hg_mel_to_tm(const float*, void*, int, int, int, int, int, int, void*);
+int xva_hg_cin1_fwd(const float*, const float*, const float*, void*, int, int, int, int, int, int, int, int, int, int, float, void*);
+int xva_hg_cin1_bwd_weight(const float*, const void*, int, float*, float*, int, int, int, int, int, int, int, int, int, void*);
+int xva_hg_cin1_bwd_data(const void*, int, const float*, float*, int, int, int, int, int, int, int, int, int, int, void*);
+int xva_hg_cout1_bwd_data(const void*, const float*, const void*, void*, int, int64_t, int, int, int, int, int, int, int, int, float, void*);
+int xva_hg_cout1_bwd_weight(const void*, const void*, float*, float*, int, int64_t, int, int, int, int, int, float, void*);
+int xva_hg_avgpool_fwd(const float*, float*, int, int, void*);
+int xva_hg_avgpool_bwd(const float*, float*, int, int, int, void*);
+int xva_hg_reduce(const void*, const void*, int, int, int, int, int, int, int, float, float*, void*);
+int xva_hg_seed_grad(const void*, const void*, void*, int, int, int, int, int, int, float, float, int, int, float, int, void*);
+int xva_hg_seq1_to_wav(const void*, int, float*, int, int, int, int, void*);
+int xva_hg_tanh_bwd(const float*, const void*, void*, int, int, int, int, int, void*);
+int xva_hg_colsum(const void*, int, float*, int64_t, int, float, void*);
+int xva_hg_weight_norm_fwd(const float*, const float*, void*, void*, float*, int, int, int, int, int, int, int, void*);
+int xva_hg_weight_norm_bwd(const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, void*);
+int xva_hg_spectral_norm_fwd(const float*, float*, float*, void*, float*, int, int, int, int, float*, void*);
+int xva_hg_spectral_norm_bwd(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, float*, void*);
+int xva_hg_sn_scale(const float*, const float*, void*, int, int, int, int, void*);
+}
+
+namespace {
+
+constexpr float SLOPE = 0.1f;
+constexpr int GUARD = 32;           // guard rows before / after every sequence tensor
+constexpr int NPER = 5;
+const int PERIODS[NPER] = {2, 3, 5, 7, 11};
+const int UPS_RATE[4] = {8, 8, 2, 2}, UPS_K[4] = {16, 16, 4, 4};
+const int RES_K[3] = {3, 7, 11}, RES_D[3] = {1, 3, 5};
+enum { LK_WN = 0, LK_WNT = 1, LK_SN = 2 };
+
+struct TInfo { std::string name; int64_t off, numel; int ndim; int64_t shape[4]; int kind; };   // kind 0 trainable, 2 buffer
+
+struct Layer {
+    int kind = LK_WN;
+    int Cin = 0, Cout = 0, k = 1, s = 1, d = 1, P = 0, groups = 1;
+    int64_t bias = -1, wg = -1, wv = -1, bu = -1, bv = -1;   // offsets (floats) in the flat parameter buffer
+    // workspace byte offsets
+    int64_t eff[2] = {-1, -1}, effB = -1, eff32[2] = {-1, -1}, norm[2] = {-1, -1}, su[2] = {-1, -1}, sv[2] = {-1, -1}, dweff[2] = {-1, -1};
+    int D0() const { return kind == LK_WNT ? Cin : Cout; }
+    int D1() const { return kind == LK_WNT ? Cout : Cin / groups; }
+    int64_t wnumel() const { return (int64_t)D0() * D1() * k; }
+};
+
+struct Net {
+    std::vector<TInfo> t;
+    std::vector<Layer> L;
+    int64_t total = 0, trainable = 0;
+    int add_layer(const std::string& pre, Layer l, std::vector<TInfo>* buffers) {
+        auto add = [&](const std::string& n, std::initializer_list<int64_t> shape, int kind, std::vector<TInfo>* dst) {
+            TInfo ti; ti.name = n; ti.kind = kind; ti.ndim = (int)shape.size(); ti.numel = 1;
+            int i = 0; for (auto s : shape) { ti.shape[i++] = s; ti.numel *= s; }
+            for (; i < 4; ++i) ti.shape[i] = 1;
+            ti.off = -1; dst->push_back(ti); return (int)dst->size() - 1;
+        };
+        const int64_t d0 = l.D0(), d1 = l.D1();
+        int ib = add(pre + "bias", {l.kind == LK_WNT ? l.Cout : l.Cout}, 0, &t);
+        l.bias = ib;   // temporarily the tensor index; resolved to offsets in finalize()
+        if (l.kind == LK_SN) {
+            l.wv = add(pre + "weight_orig", {d0, d1, l.k}, 0, &t);
+            l.bu = add(pre + "weight_u", {d0}, 2, buffers);
+            l.bv = add(pre + "weight_v", {d1 * l.k}, 2, buffers);
+        } else {
+            if (conv2d) { l.wg = add(pre + "weight_g", {d0, 1, 1, 1}, 0, &t); l.wv = add(pre + "weight_v", {d0, d1, l.k, 1}, 0, &t); }
+            else { l.wg = add(pre + "weight_g", {d0, 1, 1}, 0, &t); l.wv = add(pre + "weight_v", {d0, d1, l.k}, 0, &t); }
+        }
+        L.push_back(l);
+        return (int)L.size() - 1;
+    }
+    bool conv2d = false;
+    void finalize(std::vector<TInfo>& buffers) {
+        for (auto& ti : t) { ti.off = total; total += (ti.numel + 3) & ~(int64_t)3; }
+        trainable = total;
+        int nb0 = (int)t.size();
+        for (auto& ti : buffers) { ti.off = total; total += (ti.numel + 3) & ~(int64_t)3; t.push_back(ti); }
+        for (auto& l : L) {
+            l.bias = t[l.bias].off;
+            if (l.wg >= 0) l.wg = t[l.wg].off;
+            l.wv = t[l.wv].off;
+            if (l.bu >= 0) { l.bu = t[nb0 + l.bu].off; l.bv = t[nb0 + l.bv].off; }
+        }
+    }
+};
+
+// ---- generator layer indices ----
+struct GenNet : Net {
+    int pre, ups[4], rc1[12][3], rc2[12][3], post;
+    GenNet() {
+        std::vector<TInfo> buf;
+        Layer l; l.Cin = 80; l.Cout = 512; l.k = 7; l.P = 3; pre = add_layer("conv_pre.", l, &buf);
+        int ch = 512;
+        for (int i = 0; i < 4; ++i) {
+            Layer u; u.kind = LK_WNT; u.Cin = ch; u.Cout = ch / 2; u.k = UPS_K[i]; u.s = UPS_RATE[i]; u.P = (UPS_K[i] - UPS_RATE[i]) / 2;
+            ups[i] = add_layer("ups." + std::to_string(i) + ".", u, &buf);
+            ch /= 2;
+        }
+        ch = 512;
+        for (int i = 0; i < 4; ++i) {
+            ch /= 2;
+            for (int j = 0; j < 3; ++j) {
+                int rb = i * 3 + j;
+                for (int m = 0; m < 3; ++m) {
+                    Layer c; c.Cin = c.Cout = ch; c.k = RES_K[j]; c.d = RES_D[m]; c.P = (RES_K[j] * RES_D[m] - RES_D[m]) / 2;
+                    rc1[rb][m] = add_layer("resblocks." + std::to_string(rb) + ".convs1." + std::to_string(m) + ".", c, &buf);
+                }
+                for (int m = 0; m < 3; ++m) {
+                    Layer c; c.Cin = c.Cout = ch; c.k = RES_K[j]; c.d = 1; c.P = (RES_K[j] - 1) / 2;
+                    rc2[rb][m] = add_layer("resblocks." + std::to_string(rb) + ".convs2." + std::to_string(m) + ".", c, &buf);
+                }
+            }
+        }
+        Layer p; p.Cin = 32; p.Cout = 1; p.k = 7; p.P = 3; post = add_layer("conv_post.", p, &buf);
+        finalize(buf);
+    }
+};
+struct DiscNet : Net {
+    int mpd[NPER][6], msd[3][8];
+    DiscNet() {
+        std::vector<TInfo> buf;
+        const int pc[5][2] = {{1, 32}, {32, 128}, {128, 512}, {512, 1024}, {1024, 1024}};
+        conv2d = true;
+        for (int d = 0; d < NPER; ++d) {
+            std::string pre = "mpd.discriminators." + std::to_string(d) + ".";
+            for (int i = 0; i < 5; ++i) {
+                Layer l; l.Cin = pc[i][0]; l.Cout = pc[i][1]; l.k = 5; l.s = i < 4 ? 3 : 1; l.P = 2;
+                mpd[d][i] = add_layer(pre + "convs." + std::to_string(i) + ".", l, &buf);
+            }
+            Layer p; p.Cin = 1024; p.Cout = 1; p.k = 3; p.P = 1; mpd[d][5] = add_layer(pre + "conv_post.", p, &buf);
+        }
+        conv2d = false;
+        const int sc[8][6] = {{1, 128, 15, 1, 1, 7}, {128, 128, 41, 2, 4, 20}, {128, 256, 41, 2, 16, 20}, {256, 512, 41, 4, 16, 20},
+                              {512, 1024, 41, 4, 16, 20}, {1024, 1024, 41, 1, 16, 20}, {1024, 1024, 5, 1, 1, 2}, {1024, 1, 3, 1, 1, 1}};
+        for (int d = 0; d < 3; ++d) {
+            std::string pre = "msd.discriminators." + std::to_string(d) + ".";
+            for (int i = 0; i < 8; ++i) {
+                Layer l; l.kind = d == 0 ? LK_SN : LK_WN;
+                l.Cin = sc[i][0]; l.Cout = sc[i][1]; l.k = sc[i][2]; l.s = sc[i][3]; l.groups = sc[i][4]; l.P = sc[i][5];
+                msd[d][i] = add_layer(pre + (i < 7 ? "convs." + std::to_string(i) + "." : std::string("conv_post.")), l, &buf);
+            }
+        }
+        finalize(buf);
+    }
+};
+const GenNet& gnet() { static GenNet n; return n; }
+const DiscNet& dnet() { static DiscNet n; return n; }
+
+// ------------------------------------------------------------------ workspace plan ----
+struct Bump {
+    int64_t cur = 0;
+    int64_t take(int64_t bytes) { int64_t o = cur; cur += (bytes + 255) & ~(int64_t)255; return o; }
+};
+struct SeqSpec { int64_t off; int nseq, T, C, padF, padB; };
+struct Plan {
+    int B, seg, dt, es, T[5], Cst[5];
+    std::vector<Layer> gl, dl;          // layers with workspace offsets resolved
+    // generator activations
+    SeqSpec xin, h0, u[4], xt1[12][3], xr[12][2], xs[4], y;
+    // generator backward scratch
+    SeqSpec g_dxs, g_da, g_db, g_dt1, g_du, g_dy;
+    // discriminators: per MPD period: t1..t6 ; per MSD scale: t1..t8 (real+fake stacked: nseq = 2B*p / 2B; SN scale 0: two sets)
+    SeqSpec pt[NPER][7], st[3][2][9];
+    SeqSpec pd[NPER][7], sd[3][2][9];   // gradient tensors (same geometry)
+    int64_t wav_s[3][2];                // pooled waveforms (fp32): [scale][real/fake] ; scale 0 = the inputs themselves
+    int64_t dwav_s[3];                  // gradient w.r.t. the (pooled) fake waveforms
+    int Tw[3];
+    int64_t sn_tmp, losses, total;
+};
+
+SeqSpec mk(Bump& b, int es, int nseq, int T, int C, int padF, int padB) {
+    SeqSpec s; s.nseq = nseq; s.T = T; s.C = C; s.padF = padF; s.padB = padB;
+    int64_t rows = (int64_t)nseq * (padF + T + padB) + 2 * GUARD;
+    int64_t o = b.take(rows * C * es);
+    s.off = o + (int64_t)GUARD * C * es;
+    return s;
+}
+Seq seq(const SeqSpec& s, char* base, int dt) {
+    Seq q; q.base = base; q.off = s.off; q.nseq = s.nseq; q.T = s.T; q.C = s.C; q.padF = s.padF; q.padB = s.padB; q.dt = dt;
+    return q;
+}
+
+void plan_layer_ws(Layer& l, Bump& b, int es, bool grads) {
+    const int64_t n = l.wnumel();
+    const int passes = l.kind == LK_SN ? 2 : 1;
+    for (int p = 0; p < passes; ++p) {
+        l.eff[p] = b.take(n * es + 64);
+        if (l.Cin == 1 || l.Cout == 1) l.eff32[p] = b.take(n * 4);
+        l.norm[p] = b.take((l.kind == LK_SN ? 4 : l.D0()) * 4);
+        if (l.kind == LK_SN) { l.su[p] = b.take(l.D0() * 4); l.sv[p] = b.take((int64_t)l.D1() * l.k * 4); }
+        if (grads) l.dweff[p] = b.take(n * 4);
+    }
+    if (l.kind == LK_WNT) l.effB = b.take(n * es + 64);
+}
+
+int make_plan(const xva_hg_dims* d, Plan* p) {
+    XVA_CHECK_ARG(d && d->B > 0 && d->seg >= 2048 && d->seg % 256 == 0, "hifigan: bad dims (segment must be a multiple of 256, >= 2048)");
+    XVA_CHECK_ARG(d->dt == XVA_F32 || d->dt == XVA_BF16, "hifigan: bad dtype");
+    p->B = d->B; p->seg = d->seg; p->dt = d->dt; p->es = d->dt == XVA_BF16 ? 2 : 4;
+    const int es = p->es, B = d->B;
+    p->T[0] = d->seg / 256; p->T[1] = p->T[0] * 8; p->T[2] = p->T[1] * 8; p->T[3] = p->T[2] * 2; p->T[4] = p->T[3] * 2;
+    p->Cst[0] = 512; p->Cst[1] = 256; p->Cst[2] = 128; p->Cst[3] = 64; p->Cst[4] = 32;
+    Bump b;
+    p->gl = gnet().L; p->dl = dnet().L;
+    for (auto& l : p->gl) plan_layer_ws(l, b, es, true);
+    for (auto& l : p->dl) plan_layer_ws(l, b, es, true);
+    const int PG = 32;   // generator pad rows (>= max dilation * (k - 1) / 2 = 25)
+    p->xin = mk(b, es, B, p->T[0], 80, PG, PG);
+    p->h0 = mk(b, es, B, p->T[0], 512, PG, PG);
+    for (int i = 0; i < 4; ++i) {
+        const int T = p->T[i + 1], C = p->Cst[i + 1];
+        p->u[i] = mk(b, es, B, T, C, PG, PG);
+        for (int j = 0; j < 3; ++j) {
+            for (int m = 0; m < 3; ++m) p->xt1[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG);
+            for (int m = 0; m < 2; ++m) p->xr[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG);
+        }
+        p->xs[i] = mk(b, es, B, T, C, PG, PG);
+    }
+    p->y = mk(b, es, B, p->T[4], 1, PG, PG);
+    {   // backward scratch sized for the largest stage (C * T is constant from stage 2 on)
+        int64_t best = 0; int bi = 0;
+        for (int i = 0; i < 4; ++i) { int64_t v = (int64_t)p->Cst[i + 1] * (p->T[i + 1] + 2 * PG); if (v > best) { best = v; bi = i; } }
+        const int T = p->T[bi + 1], C = p->Cst[bi + 1];
+        p->g_dxs = mk(b, es, B, T, C, PG, PG); p->g_da = mk(b, es, B, T, C, PG, PG); p->g_db = mk(b, es, B, T, C, PG, PG);
+        p->g_dt1 = mk(b, es, B, T, C, PG, PG); p->g_du = mk(b, es, B, T, C, PG, PG);
+        p->g_dy = mk(b, es, B, p->T[4], 1, PG, PG);
+    }
+    // ---- MPD: sequences (b, w); real items first, then fake
+    for (int d5 = 0; d5 < NPER; ++d5) {
+        const int pp = PERIODS[d5], ns = 2 * B * pp;
+        int H[7];
+        H[0] = (d->seg + pp - 1) / pp;
+        for (int i = 1; i <= 4; ++i) H[i] = (H[i - 1] + 4 - 5) / 3 + 1;
+        H[5] = H[4]; H[6] = H[4];
+        const int pf4 = 4, hp4 = H[4] + 8;
+        for (int which = 0; which < 2; ++which) {
+            SeqSpec* t = which == 0 ? p->pt[d5] : p->pd[d5];
+            t[1] = mk(b, es, ns, H[1], 32, 4, 4);
+            t[2] = mk(b, es, ns, H[2], 128, 4, 4);
+            t[3] = mk(b, es, ns, H[3], 512, 3 * pf4, 3 * hp4 - H[3] - 3 * pf4);    // aligned 3:1 with t4 (merged strided conv3)
+            t[4] = mk(b, es, ns, H[4], 1024, pf4, hp4 - H[4] - pf4);
+            t[5] = mk(b, es, ns, H[5], 1024, pf4, hp4 - H[4] - pf4);
+            t[6] = mk(b, es, ns, H[6], 1, pf4, hp4 - H[4] - pf4);
+        }
+    }
+    // ---- MSD
+    p->Tw[0] = d->seg; p->Tw[1] = p->Tw[0] / 2 + 1; p->Tw[2] = p->Tw[1] / 2 + 1;
+    for (int sc = 0; sc < 3; ++sc) {
+        int T[9];
+        T[0] = p->Tw[sc]; T[1] = T[0];
+        const int str[8] = {1, 2, 2, 4, 4, 1, 1, 1};
+        for (int i = 2; i <= 8; ++i) T[i] = (i <= 5) ? (T[i - 1] - 1) / str[i - 1] + 1 : T[i - 1];
+        const int ch[9] = {1, 128, 128, 256, 512, 1024, 1024, 1024, 1};
+        const int sets = sc == 0 ? 2 : 1, ns = sc == 0 ? B : 2 * B;
+        for (int set = 0; set < sets; ++set)
+            for (int which = 0; which < 2; ++which) {
+                SeqSpec* t = which == 0 ? p->st[sc][set] : p->sd[sc][set];
+                for (int i = 1; i <= 8; ++i) t[i] = mk(b, es, ns, T[i], ch[i], 24, 24);
+            }
+        for (int rf = 0; rf < 2; ++rf) p->wav_s[sc][rf] = sc == 0 ? -1 : b.take((int64_t)B * p->Tw[sc] * 4);
+        p->dwav_s[sc] = b.take((int64_t)B * p->Tw[sc] * 4);
+    }
+    p->sn_tmp = b.take((1024 * 41 * 64 + 1024 + 64) * 4);
+    p->losses = b.take(64 * 4);
+    p->total = b.cur;
+    return XVA_OK;
+}
+
+struct Ctx {
+    Plan pl;
+    char* W;          // workspace
+    void* st;
+    int compute, dt;
+    Seq S(const SeqSpec& s) const { return seq(s, W, dt); }
+    float* F(int64_t off) const { return (float*)(W + off); }
+};
+int make_ctx(Ctx& c, const xva_hg_dims* d, void* ws, int64_t ws_bytes, void* st) {
+    XVA_TRY(make_plan(d, &c.pl));
+    XVA_CHECK_ARG(ws && ((uintptr_t)ws % 256) == 0, "hifigan: workspace null or not 256-byte aligned");
+    XVA_CHECK_ARG(ws_bytes >= c.pl.total, "hifigan: workspace too small (%ld < %ld bytes)", (long)ws_bytes, (long)c.pl.total);
+    c.W = (char*)ws; c.st = st; c.dt = d->dt; c.compute = d->dt == XVA_BF16 ? 1 : 0;
+    return XVA_OK;
+}
+
+ConvW cw(const Ctx& c, const Layer& l, const float* params, int pass = 0) {
+    ConvW w; w.eff = c.W + l.eff[pass]; w.bias = params + l.bias; w.dweff = l.dweff[pass] >= 0 ? c.F(l.dweff[pass]) : nullptr;
+    w.Cin = l.Cin; w.Cout = l.Cout; w.k = l.k; w.s = l.s; w.d = l.d; w.P = l.P; w.groups = l.groups;
+    return w;
+}
+ConvTW ctw(const Ctx& c, const Layer& l, const float* params) {
+    ConvTW w; w.effF = c.W + l.eff[0]; w.effB = c.W + l.effB; w.bias = params + l.bias; w.dweff = c.F(l.dweff[0]);
+    w.Cin = l.Cin; w.Cout = l.Cout; w.k = l.k; w.s = l.s; w.p = l.P;
+    return w;
+}
+
+// effective weights of weight-norm layers (and fp32 copies for the 1-channel direct kernels)
+int prep_wn(const Ctx& c, const std::vector<Layer>& L, const float* params) {
+    for (const Layer& l : L) {
+        if (l.kind == LK_SN) continue;
+        const int kind = l.kind == LK_WNT ? 1 : 0;
+        XVA_TRY(xva_hg_weight_norm_fwd(params + l.wv, params + l.wg, c.W + l.eff[0], l.effB >= 0 ? c.W + l.effB : nullptr, c.F(l.norm[0]), c.dt, kind,
+                                       l.D0(), l.D1(), l.k, l.s, l.P, c.st));
+        if (l.eff32[0] >= 0 && c.dt != XVA_F32)
+            XVA_TRY(xva_hg_weight_norm_fwd(params + l.wv, params + l.wg, c.W + l.eff32[0], nullptr, c.F(l.norm[0]), XVA_F32, 0, l.D0(), l.D1(), l.k,
+                                           l.s, l.P, c.st));
+    }
+    return XVA_OK;
+}
+const float* eff32(const Ctx& c, const Layer& l, int pass) { return c.dt == XVA_F32 ? (const float*)(c.W + l.eff[pass]) : c.F(l.eff32[pass]); }
+
+int zero(const Ctx& c, void* p, int64_t bytes) {
+    if (hipMemsetAsync(p, 0, bytes, (hipStream_t)c.st) != hipSuccess) { xva_set_error("hifigan: memset failed"); return XVA_ERR_HIP; }
+    return XVA_OK;
+}
+
+// ================================================================== generator ====
+int gen_forward(Ctx& c, const float* P, const float* mel, float* wav_out) {
+    const Plan& pl = c.pl; const GenNet& N = gnet(); const auto& L = pl.gl;
+    XVA_TRY(prep_wn(c, L, P));
+    Seq xin = c.S(pl.xin), h0 = c.S(pl.h0);
+    XVA_TRY(xva_hg_mel_to_tm(mel, xin.ptr(), c.dt, pl.B, 80, pl.T[0], xin.Hp(), xin.padF, c.st));
+    ConvEpi e0;
+    XVA_TRY(hg_conv_fwd(xin, h0, cw(c, L[N.pre], P), e0, c.compute, c.st));                         // conv_pre        (models.py:111)
+    Seq prev = h0;
+    for (int i = 0; i < 4; ++i) {
+        Seq u = c.S(pl.u[i]), xs = c.S(pl.xs[i]);
+        XVA_TRY(hg_convT_fwd(prev, u, ctw(c, L[N.ups[i]], P), 1, SLOPE, c.compute, c.st));         // lrelu + ups[i]  (:115-116)
+        for (int j = 0; j < 3; ++j) {
+            const int rb = i * 3 + j;
+            Seq xcur = u;
+            for (int m = 0; m < 3; ++m) {                                                          // ResBlock1.forward (:41-48)
+                Seq xt1 = c.S(pl.xt1[rb][m]);
+                ConvEpi e1; e1.a_lrelu = 1; e1.a_slope = SLOPE;
+                XVA_TRY(hg_conv_fwd(xcur, xt1, cw(c, L[N.rc1[rb][m]], P), e1, c.compute, c.st));
+                ConvEpi e2; e2.a_lrelu = 1; e2.a_slope = SLOPE; e2.R = &xcur;
+                if (m < 2) {
+                    Seq xn = c.S(pl.xr[rb][m]);
+                    XVA_TRY(hg_conv_fwd(xt1, xn, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, c.st));
+                    xcur = xn;
+                } else {                                                                           // xs = sum_j resblock_j / 3  (:118-123)
+                    e2.alpha = 1.f / 3; e2.beta = 1.f / 3; e2.accumulate = j > 0;
+                    XVA_TRY(hg_conv_fwd(xt1, xs, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, c.st));
+                }
+            }
+        }
+        prev = xs;
+    }
+    Seq y = c.S(pl.y);
+    ConvEpi ep; ep.a_lrelu = 1; ep.a_slope = 0.01f; ep.act = XVA_ACT_TANH;                            // leaky_relu(0.01), conv_post, tanh (:124-126)
+    XVA_TRY(hg_conv_fwd(prev, y, cw(c, L[N.post], P), ep, c.compute, c.st));
+    if (wav_out) XVA_TRY(xva_hg_seq1_to_wav(y.ptr(), c.dt, wav_out, pl.B, pl.T[4], y.Hp(), y.padF, c.st));
+    return XVA_OK;
+}
+
+int wn_backward(Ctx& c, const std::vector<Layer>& L, const float* P, float* G) {
+    for (const Layer& l : L) {
+        if (l.kind == LK_SN) continue;
+        XVA_TRY(xva_hg_weight_norm_bwd(c.F(l.dweff[0]), P + l.wv, P + l.wg, c.F(l.norm[0]), G + l.wv, G + l.wg, l.kind == LK_WNT ? 1 : 0, l.D0(),
+                                       l.D1(), l.k, c.st));
+    }
+    return XVA_OK;
+}
+int zero_dweff(Ctx& c, const std::vector<Layer>& L) {
+    for (const Layer& l : L)
+        for (int p = 0; p < 2; ++p)
+            if (l.dweff[p] >= 0) XVA_TRY(zero(c, c.W + l.dweff[p], l.wnumel() * 4));
+    return XVA_OK;
+}
+
+// view of a scratch spec with another stage's geometry (scratch buffers are sized for the largest stage)
+Seq as_stage(const Ctx& c, const SeqSpec& s, int T, int C) {
+    SeqSpec v = s; v.T = T; v.C = C;
+    int64_t shift = (int64_t)GUARD * (s.C - C) * c.pl.es;   // keep GUARD rows of the NEW width in front
+    v.off = s.off - shift;
+    return c.S(v);
+}
+
+int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav) {
+    const Plan& pl = c.pl; const GenNet& N = gnet(); const auto& L = pl.gl;
+    XVA_TRY(zero_dweff(c, L));
+    Seq y = c.S(pl.y), dy = c.S(pl.g_dy);
+    XVA_TRY(xva_hg_tanh_bwd(d_wav, y.ptr(), dy.ptr(), c.dt, pl.B, pl.T[4], y.Hp(), y.padF, c.st));
+    // conv_post backward (single output channel: direct kernels)
+    {
+        const Layer& l = L[N.post];
+        Seq xs = c.S(pl.xs[3]);
+        Seq dxs = as_stage(c, pl.g_dxs, pl.T[4], pl.Cst[4]);
+        XVA_TRY(xva_hg_cout1_bwd_weight(dy.ptr(), xs.ptr(), c.F(l.dweff[0]), G + l.bias, c.dt, xs.rows(), xs.C, l.k, 1, l.P, 1, 0.01f, c.st));
+        XVA_TRY(xva_hg_cout1_bwd_data(dy.ptr(), eff32(c, l, 0), xs.ptr(), dxs.ptr(), c.dt, xs.rows(), xs.C, l.k, 1, l.P, xs.Hp(), xs.padF, xs.T, 1,
+                                      0.01f, c.st));
+    }
+    for (int i = 3; i >= 0; --i) {
+        const int T = pl.T[i + 1], C = pl.Cst[i + 1];
+        Seq dxs = as_stage(c, pl.g_dxs, T, C), da = as_stage(c, pl.g_da, T, C), db = as_stage(c, pl.g_db, T, C),
+            dt1 = as_stage(c, pl.g_dt1, T, C), du = as_stage(c, pl.g_du, T, C);
+        Seq u = c.S(pl.u[i]);
+        for (int j = 0; j < 3; ++j) {
+            const int rb = i * 3 + j;
+            // d(pair output) for m = 2 is dxs / 3; the 1/3 is folded into the first GEMMs' alpha / beta
+            Seq dcur = dxs; float sc = 1.f / 3;
+            for (int m = 2; m >= 0; --m) {
+                Seq xin = m == 0 ? u : c.S(pl.xr[rb][m - 1]);
+                Seq xt1 = c.S(pl.xt1[rb][m]);
+                ConvW w2 = cw(c, L[N.rc2[rb][m]], P), w1 = cw(c, L[N.rc1[rb][m]], P);
+                XVA_TRY(hg_conv_bwd_weight(dcur, xt1, w2, 1, SLOPE, sc, c.compute, c.st));
+                XVA_TRY(xva_hg_colsum(dcur.ptr(), c.dt, G + L[N.rc2[rb][m]].bias, dcur.rows(), C, sc, c.st));
+                BwdEpi b2; b2.gate = &xt1; b2.gate_slope = SLOPE; b2.alpha = sc;
+                XVA_TRY(hg_conv_bwd_data(dcur, dt1, w2, b2, c.compute, c.st));                    // dt1 = d(conv1 output)
+                XVA_TRY(hg_conv_bwd_weight(dt1, xin, w1, 1, SLOPE, 1.f, c.compute, c.st));
+                XVA_TRY(xva_hg_colsum(dt1.ptr(), c.dt, G + L[N.rc1[rb][m]].bias, dt1.rows(), C, 1.f, c.st));
+                BwdEpi b1; b1.gate = &xin; b1.gate_slope = SLOPE; b1.R = &dcur; b1.beta = sc;
+                Seq dst = (m == 0) ? du : ((m == 2) ? da : db);
+                if (m == 0) b1.accumulate = 0;
+                // m == 0 writes the resblock's contribution to d(u): first resblock overwrites, the others accumulate
+                if (m == 0 && j > 0) {
+                    // residual (beta * dcur) and conv term both accumulate into du
+                    b1.accumulate = 1;
+                }
+                XVA_TRY(hg_conv_bwd_data(dt1, dst, w1, b1, c.compute, c.st));
+                dcur = dst; sc = 1.f;
+            }
+        }
+        // ups[i] backward: d(prev) = lrelu'(prev) * strided-conv(du) ; dW, db
+        Seq prev = i == 0 ? c.S(pl.h0) : c.S(pl.xs[i - 1]);
+        Seq dprev = as_stage(c, pl.g_dxs, pl.T[i], pl.Cst[i]);
+        ConvTW wt = ctw(c, L[N.ups[i]], P);
+        XVA_TRY(hg_convT_bwd_weight(du, prev, wt, 1, SLOPE, c.compute, c.st));
+        XVA_TRY(xva_hg_colsum(du.ptr(), c.dt, G + L[N.ups[i]].bias, du.rows(), C, 1.f, c.st));
+        XVA_TRY(zero(c, dprev.ptr(), dprev.rows() * dprev.C * dprev.es()));     // per-item GEMM writes valid rows only: pads must be zero
+        XVA_TRY(hg_convT_bwd_data(du, dprev, wt, &prev, SLOPE, c.compute, c.st));
+    }
+    {   // conv_pre backward (weights only)
+        Seq dh0 = as_stage(c, pl.g_dxs, pl.T[0], 512), xin = c.S(pl.xin);
+        XVA_TRY(hg_conv_bwd_weight(dh0, xin, cw(c, L[N.pre], P), 0, 0.f, 1.f, c.compute, c.st));
+        XVA_TRY(xva_hg_colsum(dh0.ptr(), c.dt, G + L[N.pre].bias, dh0.rows(), 512, 1.f, c.st));
+    }
+    return wn_backward(c, L, P, G);
+}
+
+// ================================================================== discriminators ====
+// One discriminator = conv0 (1 input channel, direct kernel) + GEMM layers + conv_post (1 output channel).
+struct DiscRun {
+    const int* li; int n;            // layer indices into pl.dl (n layers incl. conv_post): MPD 6, MSD 8
+    const SeqSpec* t; const SeqSpec* d;   // activations / gradients t[1..n]
+    int p;                           // period (MSD: 1)
+    int Tw;                          // input waveform length
+    int pass;                        // effective-weight set (spectral norm: 0 real pass, 1 fake pass)
+};
+
+int sn_prepare(Ctx& c, float* Pd, const DiscRun& r) {
+    for (int i = 0; i < r.n; ++i) {
+        const Layer& l = c.pl.dl[r.li[i]];
+        if (l.kind != LK_SN) continue;
+        XVA_TRY(xva_hg_spectral_norm_fwd(Pd + l.wv, Pd + l.bu, Pd + l.bv, c.W + l.eff[r.pass], c.F(l.norm[r.pass]), c.dt, l.D0(), l.D1(), l.k,
+                                         c.F(c.pl.sn_tmp), c.st));
+        if (hipMemcpyAsync(c.W + l.su[r.pass], Pd + l.bu, l.D0() * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.st) != hipSuccess ||
+            hipMemcpyAsync(c.W + l.sv[r.pass], Pd + l.bv, (int64_t)l.D1() * l.k * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.st) != hipSuccess) {
+            xva_set_error("sn_prepare: memcpy failed");
+            return XVA_ERR_HIP;
+        }
+        if (l.eff32[r.pass] >= 0 && c.dt != XVA_F32)
+            XVA_TRY(xva_hg_sn_scale(Pd + l.wv, c.F(l.norm[r.pass]), c.W + l.eff32[r.pass], XVA_F32, l.D0(), l.D1(), l.k, c.st));
+    }
+    return XVA_OK;
+}
+
+// forward of sequences [i0, i0 + ni) (ni = nb * p) fed from waveform `wav` (nb items)
+int disc_forward(Ctx& c, const float* Pd, const DiscRun& r, const float* wav, int i0, int ni) {
+    const auto& L = c.pl.dl;
+    {
+        const Layer& l0 = L[r.li[0]];
+        Seq t1 = c.S(r.t[1]).slice(i0, ni);
+        XVA_TRY(xva_hg_cin1_fwd(wav, eff32(c, l0, r.pass), Pd + l0.bias, t1.ptr(), c.dt, ni / r.p, r.Tw, r.p, l0.k, l0.s, l0.P, l0.Cout, t1.Hp(), t1.padF,
+                                SLOPE, c.st));
+    }
+    for (int i = 1; i < r.n; ++i) {
+        Seq x = c.S(r.t[i]).slice(i0, ni), y = c.S(r.t[i + 1]).slice(i0, ni);
+        ConvEpi e;
+        if (i < r.n - 1) { e.act = XVA_ACT_LRELU; e.act_slope = SLOPE; }
+        XVA_TRY(hg_conv_fwd(x, y, cw(c, L[r.li[i]], Pd, r.pass), e, c.compute, c.st));
+    }
+    return XVA_OK;
+}
+
+// D-step backward over sequences [i0, i0+ni): d[n] (score gradient) must be seeded.  Accumulates dweff / bias grads.
+// wav_a / wav_b: the waveforms feeding the first / second half of the slice (nb_a + nb_b items); wav_b may be null.
+int disc_backward_params(Ctx& c, const float* Pd, float* Gd, const DiscRun& r, int i0, int ni, const float* wav_a, int nb_a, const float* wav_b) {
+    const auto& L = c.pl.dl;
+    for (int i = r.n - 1; i >= 1; --i) {
+        const Layer& l = L[r.li[i]];
+        Seq x = c.S(r.t[i]).slice(i0, ni), dy = c.S(r.d[i + 1]).slice(i0, ni), dx = c.S(r.d[i]).slice(i0, ni);
+        if (i == r.n - 1) {       // conv_post: single output channel
+            XVA_TRY(xva_hg_cout1_bwd_weight(dy.ptr(), x.ptr(), c.F(l.dweff[r.pass]), Gd + l.bias, c.dt, x.rows(), x.C, l.k, 1, l.P, 0, 0.f, c.st));
+            XVA_TRY(xva_hg_cout1_bwd_data(dy.ptr(), eff32(c, l, r.pass), x.ptr(), dx.ptr(), c.dt, x.rows(), x.C, l.k, 1, l.P, x.Hp(), x.padF, x.T, 1, SLOPE,
+                                          c.st));
+        } else {
+            ConvW w = cw(c, l, Pd, r.pass);
+            XVA_TRY(hg_conv_bwd_weight(dy, x, w, 0, 0.f, 1.f, c.compute, c.st));
+            XVA_TRY(xva_hg_colsum(dy.ptr(), c.dt, Gd + l.bias, dy.rows(), dy.C, 1.f, c.st));
+            BwdEpi b; b.gate = &x; b.gate_slope = SLOPE;
+            XVA_TRY(hg_conv_bwd_data(dy, dx, w, b, c.compute, c.st));
+        }
+    }
+    const Layer& l0 = L[r.li[0]];
+    Seq d1 = c.S(r.d[1]).slice(i0, ni);
+    const int ni_a = nb_a * r.p;
+    XVA_TRY(xva_hg_cin1_bwd_weight(wav_a, d1.ptr(), c.dt, c.F(l0.dweff[r.pass]), Gd + l0.bias, nb_a, r.Tw, r.p, l0.k, l0.s, l0.P, l0.Cout, d1.Hp(), d1.padF, c.st));
+    if (wav_b && ni > ni_a) {
+        Seq d1b = d1.slice(ni_a, ni - ni_a);
+        XVA_TRY(xva_hg_cin1_bwd_weight(wav_b, d1b.ptr(), c.dt, c.F(l0.dweff[r.pass]), Gd + l0.bias, (ni - ni_a) / r.p, r.Tw, r.p, l0.k, l0.s, l0.P, l0.Cout,
+                                       d1b.Hp(), d1b.padF, c.st));
+    }
+    return XVA_OK;
+}
+
+// G-step backward of the FAKE sequences [f0, f0+nf) against the REAL sequences [r0, r0+nf) (feature matching + LSGAN):
+// data gradients only, down to d(wave).  rt = tensors holding the real fmaps (may be another set for spectral norm).
+int disc_backward_wave(Ctx& c, const float* Pd, const DiscRun& r, const SeqSpec* rt, int r0, int f0, int nf, float* dwav, int accumulate) {
+    const auto& L = c.pl.dl;
+    auto numel = [&](int i) { const SeqSpec& s = r.t[i]; return (float)((int64_t)nf * s.T * s.C); };
+    {   // score: LSGAN generator loss mean((1 - g)^2) + feature term of the last fmap
+        Seq g = c.S(r.t[r.n]).slice(f0, nf), rr = c.S(rt[r.n]).slice(r0, nf), d = c.S(r.d[r.n]).slice(f0, nf);
+        XVA_TRY(xva_hg_seed_grad(rr.ptr(), g.ptr(), d.ptr(), c.dt, nf, g.Hp(), g.padF, g.T, g.C, 2.f / numel(r.n), 1.f / numel(r.n), 1, 0, 0.f, 1, c.st));
+    }
+    for (int i = r.n - 1; i >= 1; --i) {
+        const Layer& l = L[r.li[i]];
+        Seq x = c.S(r.t[i]).slice(f0, nf), xr = c.S(rt[i]).slice(r0, nf), dy = c.S(r.d[i + 1]).slice(f0, nf), dx = c.S(r.d[i]).slice(f0, nf);
+        if (i == r.n - 1) {
+            XVA_TRY(xva_hg_cout1_bwd_data(dy.ptr(), eff32(c, l, r.pass), x.ptr(), dx.ptr(), c.dt, x.rows(), x.C, l.k, 1, l.P, x.Hp(), x.padF, x.T, 0, 0.f, c.st));
+        } else {
+            BwdEpi b;
+            XVA_TRY(hg_conv_bwd_data(dy, dx, cw(c, l, Pd, r.pass), b, c.compute, c.st));
+        }
+        // + feature-matching gradient of this fmap, then LeakyReLU backward on the total
+        XVA_TRY(xva_hg_seed_grad(xr.ptr(), x.ptr(), dx.ptr(), c.dt, nf, x.Hp(), x.padF, x.T, x.C, 2.f / numel(i), 0.f, 0, 1, SLOPE, 0, c.st));
+    }
+    const Layer& l0 = L[r.li[0]];
+    Seq d1 = c.S(r.d[1]).slice(f0, nf);
+    return xva_hg_cin1_bwd_data(d1.ptr(), c.dt, eff32(c, l0, r.pass), dwav, nf / r.p, r.Tw, r.p, l0.k, l0.s, l0.P, l0.Cout, d1.Hp(), d1.padF, accumulate, c.st);
+}
+
+// loss sums: out[0] += mean((1-r)^2) + mean(g^2) (discriminator loss), out[1] += mean((1-g)^2) (generator loss),
+// out[2] += 2 * sum_l mean|r_l - g_l| (feature loss)
+int disc_losses(Ctx& c, const DiscRun& r, const SeqSpec* rt, int r0, int f0, int nf, float* out) {
+    for (int i = 1; i <= r.n; ++i) {
+        Seq g = c.S(r.t[i]).slice(f0, nf), rr = c.S(rt[i]).slice(r0, nf);
+        const float inv = 1.f / (float)((int64_t)nf * g.T * g.C);
+        XVA_TRY(xva_hg_reduce(rr.ptr(), g.ptr(), c.dt, nf, g.Hp(), g.padF, g.T, g.C, 0, 2.f * inv, out + 2, c.st));
+        if (i == r.n) {
+            XVA_TRY(xva_hg_reduce(rr.ptr(), nullptr, c.dt, nf, g.Hp(), g.padF, g.T, g.C, 1, inv, out + 0, c.st));
+            XVA_TRY(xva_hg_reduce(g.ptr(), nullptr, c.dt, nf, g.Hp(), g.padF, g.T, g.C, 2, inv, out + 0, c.st));
+            XVA_TRY(xva_hg_reduce(g.ptr(), nullptr, c.dt, nf, g.Hp(), g.padF, g.T, g.C, 1, inv, out + 1, c.st));
+        }
+    }
+    return XVA_OK;
+}
+
+struct DiscSet { DiscRun run; const SeqSpec* rt; int r0, f0, nf; bool sn; const float* wr; const float* wg; int nb; };
+
+// enumerate the 8 discriminators: (MPD x 5, then MSD x 3).  For spectral-norm scale 0 the real / fake passes are separate sets.
+void build_sets(Ctx& c, const float* yr, const float* yg, std::vector<DiscSet>& out, std::vector<DiscRun>& sn_real) {
+    const Plan& pl = c.pl; const DiscNet& N = dnet();
+    for (int d5 = 0; d5 < NPER; ++d5) {
+        DiscSet s; s.run.li = N.mpd[d5]; s.run.n = 6; s.run.t = pl.pt[d5]; s.run.d = pl.pd[d5]; s.run.p = PERIODS[d5]; s.run.Tw = pl.seg; s.run.pass = 0;
+        s.rt = pl.pt[d5]; s.nf = pl.B * PERIODS[d5]; s.r0 = 0; s.f0 = s.nf; s.sn = false; s.wr = yr; s.wg = yg; s.nb = pl.B;
+        out.push_back(s);
+    }
+    for (int sc = 0; sc < 3; ++sc) {
+        const float* wr = sc == 0 ? yr : c.F(pl.wav_s[sc][0]);
+        const float* wg = sc == 0 ? yg : c.F(pl.wav_s[sc][1]);
+        DiscSet s; s.run.li = N.msd[sc]; s.run.n = 8; s.run.p = 1; s.run.Tw = pl.Tw[sc]; s.nf = pl.B; s.wr = wr; s.wg = wg; s.nb = pl.B;
+        if (sc == 0) {
+            s.run.t = pl.st[0][1]; s.run.d = pl.sd[0][1]; s.run.pass = 1; s.rt = pl.st[0][0]; s.r0 = 0; s.f0 = 0; s.sn = true;
+            DiscRun rr = s.run; rr.t = pl.st[0][0]; rr.d = pl.sd[0][0]; rr.pass = 0; sn_real.push_back(rr);
+        } else {
+            s.run.t = pl.st[sc][0]; s.run.d = pl.sd[sc][0]; s.run.pass = 0; s.rt = pl.st[sc][0]; s.r0 = 0; s.f0 = pl.B; s.sn = false;
+        }
+        out.push_back(s);
+    }
+}
+
+int pool_waves(Ctx& c, const float* yr, const float* yg) {
+    const Plan& pl = c.pl;
+    XVA_TRY(xva_hg_avgpool_fwd(yr, c.F(pl.wav_s[1][0]), pl.B, pl.Tw[0], c.st));
+    XVA_TRY(xva_hg_avgpool_fwd(yg, c.F(pl.wav_s[1][1]), pl.B, pl.Tw[0], c.st));
+    XVA_TRY(xva_hg_avgpool_fwd(c.F(pl.wav_s[1][0]), c.F(pl.wav_s[2][0]), pl.B, pl.Tw[1], c.st));
+    XVA_TRY(xva_hg_avgpool_fwd(c.F(pl.wav_s[1][1]), c.F(pl.wav_s[2][1]), pl.B, pl.Tw[1], c.st));
+    return XVA_OK;
+}
+
+// forward of all 8 discriminators on (real, fake); losses[0..2] = {disc loss, gen loss, feature loss}
+int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* losses) {
+    XVA_TRY(prep_wn(c, c.pl.dl, Pd));
+    XVA_TRY(pool_waves(c, yr, yg));
+    std::vector<DiscSet> sets; std::vector<DiscRun> snr;
+    build_sets(c, yr, yg, sets, snr);
+    if (losses) XVA_TRY(zero(c, losses, 4 * sizeof(float)));
+    for (auto& s : sets) {
+        if (s.sn) {   // models.py:244-253: d(y) then d(y_hat), one power iteration each
+            DiscRun rr = snr[0];
+            XVA_TRY(sn_prepare(c, Pd, rr));
+            XVA_TRY(disc_forward(c, Pd, rr, s.wr, 0, s.nb));
+            XVA_TRY(sn_prepare(c, Pd, s.run));
+            XVA_TRY(disc_forward(c, Pd, s.run, s.wg, 0, s.nb));
+        } else {
+            // conv0 per half (different waveforms), the GEMM layers jointly over real + fake
+            const auto& L = c.pl.dl; const Layer& l0 = L[s.run.li[0]];
+            Seq t1 = c.S(s.run.t[1]);
+            XVA_TRY(xva_hg_cin1_fwd(s.wr, eff32(c, l0, 0), Pd + l0.bias, t1.slice(0, s.nf).ptr(), c.dt, s.nb, s.run.Tw, s.run.p, l0.k, l0.s, l0.P, l0.Cout,
+                                    t1.Hp(), t1.padF, SLOPE, c.st));
+            XVA_TRY(xva_hg_cin1_fwd(s.wg, eff32(c, l0, 0), Pd + l0.bias, t1.slice(s.nf, s.nf).ptr(), c.dt, s.nb, s.run.Tw, s.run.p, l0.k, l0.s, l0.P, l0.Cout,
+                                    t1.Hp(), t1.padF, SLOPE, c.st));
+            for (int i = 1; i < s.run.n; ++i) {
+                Seq x = c.S(s.run.t[i]), y = c.S(s.run.t[i + 1]);
+                ConvEpi e;
+                if (i < s.run.n - 1) { e.act = XVA_ACT_LRELU; e.act_slope = SLOPE; }
+                XVA_TRY(hg_conv_fwd(x, y, cw(c, L[s.run.li[i]], Pd, 0), e, c.compute, c.st));
+            }
+        }
+        if (losses) XVA_TRY(disc_losses(c, s.run, s.rt, s.r0, s.f0, s.nf, losses));
+    }
+    return XVA_OK;
+}
+
+// D-step backward: gradients of sum_d [mean((1 - D(y))^2) + mean(D(G(x))^2)] w.r.t. all discriminator parameters
+int discs_backward_d(Ctx& c, float* Pd, float* Gd, const float* yr, const float* yg) {
+    std::vector<DiscSet> sets; std::vector<DiscRun> snr;
+    build_sets(c, yr, yg, sets, snr);
+    XVA_TRY(zero_dweff(c, c.pl.dl));
+    for (auto& s : sets) {
+        const int n = s.run.n;
+        const float inv = 1.f / (float)((int64_t)s.nf * s.run.t[n].T);
+        Seq g = c.S(s.run.t[n]).slice(s.f0, s.nf), dg = c.S(s.run.d[n]).slice(s.f0, s.nf);
+        XVA_TRY(xva_hg_seed_grad(nullptr, g.ptr(), dg.ptr(), c.dt, s.nf, g.Hp(), g.padF, g.T, 1, 0.f, inv, 2, 0, 0.f, 1, c.st));
+        if (s.sn) {
+            DiscRun rr = snr[0];
+            Seq r = c.S(rr.t[n]), dr = c.S(rr.d[n]);
+            XVA_TRY(xva_hg_seed_grad(r.ptr(), nullptr, dr.ptr(), c.dt, s.nf, r.Hp(), r.padF, r.T, 1, 0.f, inv, 3, 0, 0.f, 1, c.st));
+            XVA_TRY(disc_backward_params(c, Pd, Gd, rr, 0, s.nf, s.wr, s.nb, nullptr));
+            XVA_TRY(disc_backward_params(c, Pd, Gd, s.run, 0, s.nf, s.wg, s.nb, nullptr));
+        } else {
+            Seq r = c.S(s.run.t[n]).slice(s.r0, s.nf), dr = c.S(s.run.d[n]).slice(s.r0, s.nf);
+            XVA_TRY(xva_hg_seed_grad(r.ptr(), nullptr, dr.ptr(), c.dt, s.nf, r.Hp(), r.padF, r.T, 1, 0.f, inv, 3, 0, 0.f, 1, c.st));
+            XVA_TRY(disc_backward_params(c, Pd, Gd, s.run, 0, 2 * s.nf, s.wr, s.nb, s.wg));
+        }
+    }
+    XVA_TRY(wn_backward(c, c.pl.dl, Pd, Gd));
+    for (const Layer& l : c.pl.dl) {
+        if (l.kind != LK_SN) continue;
+        for (int pass = 0; pass < 2; ++pass)
+            XVA_TRY(xva_hg_spectral_norm_bwd(c.F(l.dweff[pass]), Pd + l.wv, c.F(l.su[pass]), c.F(l.sv[pass]), c.F(l.norm[pass]), Gd + l.wv, l.D0(), l.D1(), l.k,
+                                             c.F(c.pl.sn_tmp), c.st));
+    }
+    return XVA_OK;
+}
+
+// G-step backward: d/d(fake wave) of sum_d [mean((1 - D(G))^2) + 2 * sum_l mean|fmap_l(y) - fmap_l(G)|]
+int discs_backward_g(Ctx& c, float* Pd, const float* yr, const float* yg, float* d_wav) {
+    const Plan& pl = c.pl;
+    std::vector<DiscSet> sets; std::vector<DiscRun> snr;
+    build_sets(c, yr, yg, sets, snr);
+    bool first[3] = {true, true, true};
+    int di = 0;
+    for (auto& s : sets) {
+        const int sc = di < NPER ? 0 : di - NPER;
+        float* dst = sc == 0 ? d_wav : c.F(pl.dwav_s[sc]);
+        const bool acc = sc == 0 ? !first[0] : false;
+        XVA_TRY(disc_backward_wave(c, Pd, s.run, s.rt, s.r0, s.f0, s.nf, dst, acc ? 1 : 0));
+        if (sc == 0) first[0] = false;
+        ++di;
+    }
+    // pooled scales: d(y) += pool_bwd(d(pool(y))) ; scale 2 goes through scale 1
+    XVA_TRY(xva_hg_avgpool_bwd(c.F(pl.dwav_s[2]), c.F(pl.dwav_s[1]), pl.B, pl.Tw[1], 1, c.st));
+    XVA_TRY(xva_hg_avgpool_bwd(c.F(pl.dwav_s[1]), d_wav, pl.B, pl.Tw[0], 1, c.st));
+    return XVA_OK;
+}
+
+}  // namespace
+
+// =========================================================================== C ABI ====
+static const Net& net_of(int which) { return which == 0 ? (const Net&)gnet() : (const Net&)dnet(); }
+extern "C" int64_t xva_hg_param_floats(int which) { return net_of(which).total; }
+extern "C" int64_t xva_hg_trainable_floats(int which) { return net_of(which).trainable; }
+extern "C" int xva_hg_num_tensors(int which) { return (int)net_of(which).t.size(); }
+extern "C" int xva_hg_tensor_info(int which, int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int32_t* ndim, int64_t* shape4,
+                                  int32_t* kind) {
+    const Net& n = net_of(which);
+    XVA_CHECK_ARG(i >= 0 && i < (int)n.t.size() && name && name_cap > 0, "hg_tensor_info: bad index");
+    const TInfo& ti = n.t[i];
+    snprintf(name, name_cap, "%s", ti.name.c_str());
+    if (offset) *offset = ti.off;
+    if (numel) *numel = ti.numel;
+    if (ndim) *ndim = ti.ndim;
+    if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = ti.shape[k];
+    if (kind) *kind = ti.kind;
+    return XVA_OK;
+}
+extern "C" int64_t xva_hg_workspace_bytes(const xva_hg_dims* d) {
+    Plan p;
+    if (make_plan(d, &p) != XVA_OK) return -1;
+    return p.total;
+}
+extern "C" int xva_hg_generator_forward(const xva_hg_dims* d, const float* params_g, const float* mel, void* ws, int64_t ws_bytes, float* wav_out,
+                                        void* stream) {
+    Ctx c;
+    XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream));
+    XVA_CHECK_ARG(params_g && mel, "generator_forward: null");
+    return gen_forward(c, params_g, mel, wav_out);
+}
+extern "C" int xva_hg_generator_backward(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* ws, int64_t ws_bytes,
+                                         void* stream) {
+    Ctx c;
+    XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream));
+    XVA_CHECK_ARG(params_g && grads_g && d_wav, "generator_backward: null");
+    return gen_backward(c, params_g, grads_g, d_wav);
+}
+
+/* yr / yg: real / generated waveforms (B, seg) fp32.  losses (device, 4 floats, may be NULL): {discriminator loss,
+ * generator LSGAN loss, feature-matching loss, -}.  params_d is non-const: the spectral-norm power iteration advances
+ * weight_u / weight_v (one iteration per pass, python/hifigan/models.py:244-253). */
+extern "C" int xva_hg_disc_forward(const xva_hg_dims* d, float* params_d, const float* yr, const float* yg, void* ws, int64_t ws_bytes, float* losses,
+                                   void* stream) {
+    Ctx c;
+    XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream));
+    XVA_CHECK_ARG(params_d && yr && yg, "disc_forward: null");
+    return discs_forward(c, params_d, yr, yg, losses);
+}
+extern "C" int xva_hg_disc_backward_d(const xva_hg_dims* d, float* params_d, float* grads_d, const float* yr, const float* yg, void* ws, int64_t ws_bytes,
+                                      void* stream) {
+    Ctx c;
+    XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream));
+    XVA_CHECK_ARG(params_d && grads_d && yr && yg, "disc_backward_d: null");
+    return discs_backward_d(c, params_d, grads_d, yr, yg);
+}
+extern "C" int xva_hg_disc_backward_g(const xva_hg_dims* d, float* params_d, const float* yr, const float* yg, float* d_wav, void* ws, int64_t ws_bytes,
+                                      void* stream) {
+    Ctx c;
+    XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream));
+    XVA_CHECK_ARG(params_d && yr && yg && d_wav, "disc_backward_g: null");
+    return discs_backward_g(c, params_d, yr, yg, d_wav);
+}

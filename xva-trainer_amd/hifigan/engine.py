@@ -1,0 +1,146 @@
+"""HifiganEngine — host driver of the C-ABI HiFi-GAN engine (xva_hg_* in include/xva_hip.h).
+
+Owns no numerics: allocates the two flat parameter buffers (generator; mpd + msd), their gradient buffers and the
+workspace as torch tensors, converts reference state_dicts (python/hifigan/models.py; checkpoint keys of
+python/hifigan/xva_train.py:570-601) to / from the flat buffers, and issues the engine calls on torch's current stream.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+lib = _lib.lib
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class HgDims(C.Structure):
+    _fields_ = [("B", i32), ("seg", i32), ("dt", i32)]
+
+
+lib.xva_hg_param_floats.restype = i64
+lib.xva_hg_param_floats.argtypes = [i32]
+lib.xva_hg_trainable_floats.restype = i64
+lib.xva_hg_trainable_floats.argtypes = [i32]
+lib.xva_hg_num_tensors.restype = i32
+lib.xva_hg_num_tensors.argtypes = [i32]
+lib.xva_hg_tensor_info.restype = i32
+lib.xva_hg_tensor_info.argtypes = [i32, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i64 * 4), C.POINTER(i32)]
+lib.xva_hg_workspace_bytes.restype = i64
+lib.xva_hg_workspace_bytes.argtypes = [C.POINTER(HgDims)]
+lib.xva_hg_generator_forward.restype = i32
+lib.xva_hg_generator_forward.argtypes = [C.POINTER(HgDims), vp, vp, vp, i64, vp, vp]
+lib.xva_hg_generator_backward.restype = i32
+lib.xva_hg_generator_backward.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, i64, vp]
+
+DT = {"fp32": 0, "bf16": 1, 0: 0, 1: 1}
+G, D = 0, 1
+
+
+def tensor_table(which):
+    out = []
+    buf = C.create_string_buffer(160)
+    for i in range(lib.xva_hg_num_tensors(which)):
+        off, n, nd, kind = i64(), i64(), i32(), i32()
+        shape = (i64 * 4)()
+        _lib.check(lib.xva_hg_tensor_info(which, i, buf, 160, C.byref(off), C.byref(n), C.byref(nd), C.byref(shape), C.byref(kind)))
+        out.append((buf.value.decode(), off.value, n.value, tuple(shape[k] for k in range(nd.value)), kind.value))
+    return out
+
+
+def to_flat(sd, table, flat, prefix=""):
+    with torch.no_grad():
+        for name, off, n, shape, kind in table:
+            if not name.startswith(prefix):
+                continue
+            t = sd[name[len(prefix):]]
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError("%s: checkpoint shape %s != %s" % (name, tuple(t.shape), shape))
+            flat[off:off + n].copy_(t.reshape(-1).to(device=flat.device, dtype=torch.float32))
+
+
+def from_flat(flat, table, prefix=""):
+    out = {}
+    for name, off, n, shape, kind in table:
+        if name.startswith(prefix):
+            out[name[len(prefix):]] = flat[off:off + n].view(shape).clone()
+    return out
+
+
+class HifiganEngine:
+    def __init__(self, device, compute="bf16"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.XvaError("HifiganEngine needs a GPU device; the hot path has no CPU implementation")
+        self.dt = DT[compute]
+        self.table = {G: tensor_table(G), D: tensor_table(D)}
+        self.total = {G: int(lib.xva_hg_param_floats(G)), D: int(lib.xva_hg_param_floats(D))}
+        self.trainable = {G: int(lib.xva_hg_trainable_floats(G)), D: int(lib.xva_hg_trainable_floats(D))}
+        self._ws, self._key, self._dims = None, None, None
+
+    def _prepare(self, B, seg):
+        key = (B, seg, self.dt)
+        if key != self._key:
+            d = HgDims(B, seg, self.dt)
+            need = int(lib.xva_hg_workspace_bytes(C.byref(d)))
+            if need < 0:
+                raise _lib.XvaError("xva_hg_workspace_bytes: " + lib.xva_last_error().decode())
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.zeros(need, device=self.device, dtype=torch.uint8)   # zero ONCE: pad / guard rows
+            else:
+                self._ws.zero_()
+            self._dims, self._key = d, key
+        return self._dims
+
+    def generator_forward(self, flat_g, mel):
+        """mel: (B, 80, T) fp32 -> waveform (B, T * 256) fp32."""
+        _lib.require_cuda(flat_g, mel)
+        B, _, T = mel.shape
+        d = self._prepare(B, T * 256)
+        mel = mel.float().contiguous()
+        wav = torch.empty(B, T * 256, device=self.device, dtype=torch.float32)
+        _lib.check(lib.xva_hg_generator_forward(C.byref(d), _lib.ptr(flat_g), _lib.ptr(mel), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(wav),
+                                                _lib.stream_ptr()), "xva_hg_generator_forward")
+        return wav
+
+    def generator_backward(self, flat_g, grads_g, d_wav):
+        d = self._dims
+        d_wav = d_wav.float().contiguous()
+        _lib.check(lib.xva_hg_generator_backward(C.byref(d), _lib.ptr(flat_g), _lib.ptr(grads_g), _lib.ptr(d_wav), _lib.ptr(self._ws),
+                                                 self._ws.numel(), _lib.stream_ptr()), "xva_hg_generator_backward")
+
+
+lib.xva_hg_disc_forward.restype = i32
+lib.xva_hg_disc_forward.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, i64, vp, vp]
+lib.xva_hg_disc_backward_d.restype = i32
+lib.xva_hg_disc_backward_d.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, vp, i64, vp]
+lib.xva_hg_disc_backward_g.restype = i32
+lib.xva_hg_disc_backward_g.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, vp, i64, vp]
+
+
+def _disc_forward(self, flat_d, y_real, y_fake):
+    """MPD + MSD on (real, fake) (B, seg) fp32.  Returns a 4-float device tensor {loss_disc, loss_gen, loss_fm, -}."""
+    _lib.require_cuda(flat_d, y_real, y_fake)
+    d = self._prepare(y_real.size(0), y_real.size(1))
+    self._yr, self._yg = y_real.float().contiguous(), y_fake.float().contiguous()
+    losses = torch.zeros(4, device=self.device)
+    _lib.check(lib.xva_hg_disc_forward(C.byref(d), _lib.ptr(flat_d), _lib.ptr(self._yr), _lib.ptr(self._yg), _lib.ptr(self._ws), self._ws.numel(),
+                                       _lib.ptr(losses), _lib.stream_ptr()), "xva_hg_disc_forward")
+    return losses
+
+
+def _disc_backward_d(self, flat_d, grads_d):
+    _lib.check(lib.xva_hg_disc_backward_d(C.byref(self._dims), _lib.ptr(flat_d), _lib.ptr(grads_d), _lib.ptr(self._yr), _lib.ptr(self._yg),
+                                          _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "xva_hg_disc_backward_d")
+
+
+def _disc_backward_g(self, flat_d):
+    d_wav = torch.empty_like(self._yg)
+    _lib.check(lib.xva_hg_disc_backward_g(C.byref(self._dims), _lib.ptr(flat_d), _lib.ptr(self._yr), _lib.ptr(self._yg), _lib.ptr(d_wav),
+                                          _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "xva_hg_disc_backward_g")
+    return d_wav
+
+
+HifiganEngine.disc_forward = _disc_forward
+HifiganEngine.disc_backward_d = _disc_backward_d
+HifiganEngine.disc_backward_g = _disc_backward_g
