@@ -61,6 +61,14 @@ int xva_mel_spectrogram(const xva_mel_config* cfg, const float* wav, int B, int 
                         const float* dft_basis, const float* mel_basis_padded, float* mel_out,
                         float* workspace, int64_t workspace_bytes, void* stream);
 
+/* Differentiable mel for the generator's L1 mel loss (python/hifigan/xva_train.py:480,504):
+ *   *loss_out += scale * mean|mel_tgt - mel(wav)| ; d_wav (+)= d loss / d wav ; mel_out = mel(wav).
+ * Same config / basis arguments as xva_mel_spectrogram; T = frames must be a multiple of 4. */
+int64_t xva_mel_backward_workspace_bytes(const xva_mel_config* cfg, int B, int N);
+int xva_mel_l1_loss_backward(const xva_mel_config* cfg, const float* wav, int B, int N, int64_t ld_wav, const float* mel_tgt,
+                             const float* dft_basis, const float* mel_basis_padded, float scale, float* mel_out, float* loss_out,
+                             float* d_wav, int64_t ld_dwav, int accumulate, float* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------- FastPitch 1.1 engine ---- */
 /* Replaces, for training stages 2-4, the PyTorch graph behind
  *   y_pred = FastPitch.forward(x)          python/fastpitch1_1/fastpitch/model.py:325-423

@@ -37,7 +37,7 @@ def test_generator_forward(compute, tol):
         assert (wav.cpu() - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("compute,tol", [("fp32", 1e-2), ("bf16", 1e-1)])
+@pytest.mark.parametrize("compute,tol", [("fp32", 1e-2), ("bf16", 5e-1)])
 def test_generator_backward(compute, tol):
     """Random cotangent on the waveform: an ill-conditioned probe (heavy cancellation) — the fp32 CPU oracle itself sits
     ~5e-3 from the fp64 truth on the worst tensor (printed), so the fp32 bound here is 1e-2 worst / 3e-3 median; the
@@ -135,3 +135,95 @@ def test_discriminators_g_step(compute, tol_loss, tol_grad):
     e = _nrel(d_wav, yf.grad)
     print("d_wav rel err", e)
     assert e < tol_grad
+
+
+def test_mel_l1_loss_backward():
+    """Differentiable mel (xva_train.py:480,504): loss value and d loss / d wav vs torch autograd through the oracle mel."""
+    from oracle import hifigan as ohg, mel as omel
+    from xva_trainer_amd.mel import mel_l1_loss_backward
+    _, y, y_mel = ohg.synth_batch(3, 99)
+    torch.manual_seed(3)
+    yh = (y + 0.05 * torch.randn_like(y)).clamp(-1, 1).requires_grad_(True)
+    loss_ref = torch.nn.functional.l1_loss(y_mel, omel.mel_m2(yh, fmax=None)) * 45
+    loss_ref.backward()
+    d_wav = torch.full_like(y, 0.25).cuda()
+    loss, mel = mel_l1_loss_backward(yh.detach().cuda(), y_mel.cuda(), d_wav, scale=45.0, accumulate=True)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) < 1e-3 * loss_ref.item()
+    assert _nrel(d_wav.cpu() - 0.25, yh.grad) < 5e-3
+
+
+def test_full_step_bf16_close_to_reference_golden(golden_dir):
+    """The bf16 training path (bf16 activations + bf16-input MFMA, fp32 master weights / accumulation) on the same golden
+    iteration: documented looser bound (losses 3 %, gradient norms 15 % worst / 5 % median)."""
+    import os
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan import engine as E
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    g = np.load(os.path.join(golden_dir, "hg_step_b2.npz"))
+    seed = int(g["seed"])
+    st = HifiganStep("cuda", "bf16")
+    st.load_state_dicts(ohg.init_generator_sd(seed), ohg.init_mpd_sd(seed + 1), ohg.init_msd_sd(seed + 2))
+    out = st.train_step(torch.from_numpy(g["x_mel"]).cuda(), torch.from_numpy(g["y_wav"]).cuda(), torch.from_numpy(g["y_mel"]).cuda())
+    torch.cuda.synchronize()
+    ref = dict(zip([str(k) for k in g["loss_names"]], g["losses"]))
+    assert _nrel(out["y_g_hat"], torch.from_numpy(g["y_g_hat"]).squeeze(1)) < 5e-2
+    assert abs(out["loss_disc_all"].item() - ref["loss_disc_all"]) < 3e-2 * ref["loss_disc_all"]
+    assert abs(out["loss_gen_all"].item() - ref["loss_gen_all"]) < 3e-2 * ref["loss_gen_all"]
+    gg = E.from_flat(st.grads_g, st.eng.table[E.G])
+    errs = sorted(((abs(gg[str(k)].double().norm().item() - l2) / max(l2, 1e-12), str(k)) for k, l2 in zip(g["g_grad_keys"], g["g_grad_l2"])), reverse=True)
+    print("bf16 worst G grad-norm errors:", errs[:5], "median", errs[len(errs) // 2])
+    assert errs[0][0] < 0.15 and errs[len(errs) // 2][0] < 0.05
+    dg = E.from_flat(st.grads_d, st.eng.table[E.D])
+    errs = sorted(((abs(dg[str(k)].double().norm().item() - l2) / max(l2, 1e-12), str(k)) for k, l2 in zip(g["d_grad_keys"], g["d_grad_l2"])), reverse=True)
+    print("bf16 worst D grad-norm errors:", errs[:5], "median", errs[len(errs) // 2])
+    assert errs[0][0] < 0.15 and errs[len(errs) // 2][0] < 0.05
+
+
+def test_full_step_against_reference_golden(golden_dir):
+    """One full D + G iteration (xva_train.py:479-515) in fp32 vs the vectors recorded from the REFERENCE classes:
+    losses, generated waveform, every parameter-gradient norm of G / MPD / MSD, spectral-norm buffer."""
+    import os
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan import engine as E
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    g = np.load(os.path.join(golden_dir, "hg_step_b2.npz"))
+    seed = int(g["seed"])
+    st = HifiganStep("cuda", "fp32")
+    st.load_state_dicts(ohg.init_generator_sd(seed), ohg.init_mpd_sd(seed + 1), ohg.init_msd_sd(seed + 2))
+    out = st.train_step(torch.from_numpy(g["x_mel"]).cuda(), torch.from_numpy(g["y_wav"]).cuda(), torch.from_numpy(g["y_mel"]).cuda())
+    torch.cuda.synchronize()
+    ref = dict(zip([str(k) for k in g["loss_names"]], g["losses"]))
+    assert _nrel(out["y_g_hat"], torch.from_numpy(g["y_g_hat"]).squeeze(1)) < 1e-3
+    assert abs(out["loss_disc_all"].item() - ref["loss_disc_all"]) < 1e-3 * ref["loss_disc_all"]
+    assert abs(out["loss_mel"].item() - ref["loss_mel"]) < 1e-3 * ref["loss_mel"]
+    assert abs(out["loss_gen"].item() - (ref["loss_gen_f"] + ref["loss_gen_s"])) < 1e-3 * (ref["loss_gen_f"] + ref["loss_gen_s"])
+    assert abs(out["loss_fm"].item() - (ref["loss_fm_f"] + ref["loss_fm_s"])) < 2e-3 * (ref["loss_fm_f"] + ref["loss_fm_s"])
+    assert abs(out["loss_gen_all"].item() - ref["loss_gen_all"]) < 1e-3 * ref["loss_gen_all"]
+    gg = E.from_flat(st.grads_g, st.eng.table[E.G])
+    errs = sorted(((abs(gg[str(k)].double().norm().item() - l2) / max(l2, 1e-12), str(k)) for k, l2 in zip(g["g_grad_keys"], g["g_grad_l2"])), reverse=True)
+    print("worst G grad-norm errors:", errs[:5])
+    assert errs[0][0] < 1e-2 and errs[len(errs) // 2][0] < 2e-3
+    dg = E.from_flat(st.grads_d, st.eng.table[E.D])
+    errs = sorted(((abs(dg[str(k)].double().norm().item() - l2) / max(l2, 1e-12), str(k)) for k, l2 in zip(g["d_grad_keys"], g["d_grad_l2"])), reverse=True)
+    print("worst D grad-norm errors:", errs[:5])
+    assert errs[0][0] < 5e-3
+    assert _nrel(gg["conv_post.weight_v"], torch.from_numpy(g["g_conv_post_v_grad"])) < 1e-2
+    assert _nrel(gg["ups.3.weight_v"], torch.from_numpy(g["g_ups3_v_grad"])) < 1e-2
+    sd = st.state_dicts()
+    assert _nrel(sd["msd"]["discriminators.0.convs.0.weight_u"], torch.from_numpy(g["msd_u0_after"])) < 1e-3
+
+
+def test_adamw_kernel_matches_oracle():
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan.step import FlatAdamW
+    torch.manual_seed(5)
+    p = torch.randn(10000); grads = [torch.randn(10000) * 0.01 for _ in range(3)]
+    ref = {"p": p.clone()}; state = {}
+    flat = p.clone().cuda()
+    opt = FlatAdamW(flat, flat.numel())
+    for gsd in grads:
+        ohg.adamw_step(ref, {"p": gsd}, state)
+        opt.step(gsd.cuda())
+    torch.cuda.synchronize()
+    assert torch.allclose(flat.cpu(), ref["p"], rtol=1e-5, atol=1e-7)

@@ -142,3 +142,128 @@ extern "C" int xva_mel_spectrogram(const xva_mel_config* c, const float* wav, in
     }
     return XVA_OK;
 }
+
+
+// ====================================================================================================================
+// Differentiable mel: L1 mel loss of a generated waveform and its gradient w.r.t. the waveform
+//   loss = scale * mean |mel_tgt - mel(wav)|        (F.l1_loss(y_mel, y_g_hat_mel) * 45, python/hifigan/xva_train.py:480,504)
+// Backward of the same pipeline, transposed: d(log-clamp) -> mel^T GEMM -> magnitude -> DFT^T GEMM -> overlap-add -> reflect fold.
+// ====================================================================================================================
+struct MelBwdPlan { MelPlan f; int64_t off_dM, off_dmag, off_dfr, total; };
+static int mel_bwd_plan(const xva_mel_config* c, int B, int N, MelBwdPlan* p) {
+    XVA_TRY(mel_plan(c, B, N, &p->f));
+    XVA_CHECK_ARG(p->f.T % 4 == 0, "mel backward: number of frames must be a multiple of 4 (got %d)", p->f.T);
+    p->off_dM = al4(p->f.total);
+    p->off_dmag = p->off_dM + al4((int64_t)B * c->n_mel * p->f.T);
+    p->off_dfr = p->off_dmag + (int64_t)B * p->f.T * p->f.ldm;
+    p->total = p->off_dfr + (int64_t)B * p->f.T * c->n_fft + 16;
+    return XVA_OK;
+}
+// dM = -(scale / numel) * sign(tgt - mel) * exp(-mel) * [mel > log(clamp)] ; loss += (scale / numel) * sum |tgt - mel|
+__global__ void mel_l1_kernel(const float* __restrict__ mel, const float* __restrict__ tgt, float* __restrict__ dM, float* __restrict__ loss,
+                              int64_t n, float k, float log_clamp) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float m = mel[i], d = tgt[i] - m;
+        acc += fabsf(d);
+        float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        dM[i] = (m > log_clamp) ? -k * sg * expf(-m) : 0.f;
+    }
+    acc = xva_block_sum(acc, sh);
+    if (threadIdx.x == 0 && loss) atomicAdd(loss, acc * k);
+}
+// spec rows [re | im] (in place) <- dmag * re / mag , dmag * im / mag
+__global__ void mel_dspec_kernel(float* __restrict__ spec, const float* __restrict__ mag, const float* __restrict__ dmag, int64_t rows, int nb,
+                                 int64_t lds, int64_t ldm) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * nb) return;
+    int64_t r = idx / nb;
+    int j = (int)(idx - r * nb);
+    float mg = mag[r * ldm + j], g = dmag[r * ldm + j];
+    float sc = mg > 0.f ? g / mg : 0.f;
+    spec[r * lds + j] *= sc;
+    spec[r * lds + nb + j] *= sc;
+}
+// d_wav[b][n] (+)= sum over padded positions aliasing sample n (direct + reflect images) of the overlap-add of frame gradients
+__global__ void mel_fold_kernel(const float* __restrict__ dfr, float* __restrict__ dwav, int B, int N, int pad, int T, int n_fft, int hop,
+                                int64_t ld_dwav, int accumulate) {
+    int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= (int64_t)B * N) return;
+    int b = (int)(gi / N), n = (int)(gi % N);
+    int cand[3] = {n + pad, pad - n, pad + 2 * (N - 1) - n};
+    bool ok[3] = {true, n >= 1 && n <= pad, n <= N - 2 && n >= N - 1 - pad};
+    float acc = 0.f;
+    const int Np = N + 2 * pad;
+    for (int q = 0; q < 3; ++q) {
+        if (!ok[q]) continue;
+        int i = cand[q];
+        if (i < 0 || i >= Np) continue;
+        int t1 = i / hop; if (t1 > T - 1) t1 = T - 1;
+        int t0 = (i - n_fft + hop) / hop; if (i - n_fft + 1 <= 0) t0 = 0;
+        if (t0 < 0) t0 = 0;
+        for (int t = t0; t <= t1; ++t) {
+            int off = i - t * hop;
+            if (off >= 0 && off < n_fft) acc += dfr[((int64_t)b * T + t) * n_fft + off];
+        }
+    }
+    float* dst = dwav + (int64_t)b * ld_dwav + n;
+    if (accumulate) *dst += acc; else *dst = acc;
+}
+
+extern "C" int64_t xva_mel_backward_workspace_bytes(const xva_mel_config* c, int B, int N) {
+    MelBwdPlan p;
+    if (!c || mel_bwd_plan(c, B, N, &p) != XVA_OK) return -1;
+    return p.total * (int64_t)sizeof(float);
+}
+
+extern "C" int xva_mel_l1_loss_backward(const xva_mel_config* c, const float* wav, int B, int N, int64_t ld_wav, const float* mel_tgt,
+                                        const float* dft_basis, const float* mel_basis_padded, float scale, float* mel_out, float* loss_out,
+                                        float* d_wav, int64_t ld_dwav, int accumulate, float* workspace, int64_t workspace_bytes, void* stream) {
+    XVA_CHECK_ARG(c && wav && mel_tgt && dft_basis && mel_basis_padded && mel_out && d_wav && workspace, "mel_l1_loss_backward: null pointer");
+    MelBwdPlan p;
+    XVA_TRY(mel_bwd_plan(c, B, N, &p));
+    XVA_CHECK_ARG(workspace_bytes >= p.total * (int64_t)sizeof(float), "mel backward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    XVA_TRY(xva_mel_spectrogram(c, wav, B, N, ld_wav, dft_basis, mel_basis_padded, mel_out, workspace, workspace_bytes, stream));
+    const MelPlan& f = p.f;
+    float* spec = workspace + f.off_spec;
+    float* mag = workspace + f.off_mag;
+    float* dM = workspace + p.off_dM;
+    float* dmag = workspace + p.off_dmag;
+    float* dfr = workspace + p.off_dfr;
+    const int64_t nmel = (int64_t)B * c->n_mel * f.T;
+    {
+        int grid = (int)((nmel + 255) / 256); if (grid > 1024) grid = 1024;
+        hipLaunchKernelGGL(mel_l1_kernel, dim3(grid), dim3(256), 0, st, mel_out, mel_tgt, dM, loss_out, nmel, scale / (float)nmel, logf(c->log_clamp));
+        XVA_LAUNCH_CHECK();
+    }
+    {   // dmag[b] (T x ldm) = dM[b]^T (T x n_mel) * melW (n_mel x ldm)
+        xva_gemm_params g;
+        memset(&g, 0, sizeof(g));
+        g.layout = XVA_GEMM_TN; g.A = dM; g.B = mel_basis_padded; g.C = dmag;
+        g.M = f.T; g.N = (int)f.ldm; g.K = c->n_mel;
+        g.lda = f.T; g.ldb = f.ldm; g.ldc = f.ldm;
+        g.batch = B; g.sA = (int64_t)c->n_mel * f.T; g.sB = 0; g.sC = (int64_t)f.T * f.ldm;
+        g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.compute = 0; g.mask_mul = 1;
+        XVA_TRY(xva_gemm(&g, stream));
+    }
+    {
+        const int64_t rows = (int64_t)B * f.T;
+        hipLaunchKernelGGL(mel_dspec_kernel, dim3(xva_cdiv(rows * f.nb, 256)), dim3(256), 0, st, spec, mag, dmag, rows, f.nb, f.lds, f.ldm);
+        XVA_LAUNCH_CHECK();
+    }
+    {   // dframes (rows x n_fft) = dspec (rows x 2 nb) * basis (2 nb x n_fft)
+        xva_gemm_params g;
+        memset(&g, 0, sizeof(g));
+        g.layout = XVA_GEMM_NN; g.A = spec; g.B = dft_basis; g.C = dfr;
+        g.M = (int)((int64_t)B * f.T); g.N = c->n_fft; g.K = 2 * f.nb;
+        g.lda = f.lds; g.ldb = c->n_fft; g.ldc = c->n_fft;
+        g.batch = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.compute = 0; g.mask_mul = 1;
+        XVA_TRY(xva_gemm(&g, stream));
+    }
+    hipLaunchKernelGGL(mel_fold_kernel, dim3(xva_cdiv((int64_t)B * N, 256)), dim3(256), 0, st, dfr, d_wav, B, N, c->pad, f.T, c->n_fft, c->hop,
+                       ld_dwav, accumulate);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}

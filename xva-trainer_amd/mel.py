@@ -172,3 +172,44 @@ class TorchSTFTMel(torch.nn.Module):
         if x.ndim == 3:
             x = x.squeeze(1)
         return self.engine(x)
+
+
+# ---- differentiable mel for the HiFi-GAN generator loss (python/hifigan/xva_train.py:480,504) ----
+_lib.lib.xva_mel_backward_workspace_bytes.restype = C.c_int64
+_lib.lib.xva_mel_backward_workspace_bytes.argtypes = [C.POINTER(_lib.MelConfig), C.c_int32, C.c_int32]
+_lib.lib.xva_mel_l1_loss_backward.restype = C.c_int32
+_lib.lib.xva_mel_l1_loss_backward.argtypes = [C.POINTER(_lib.MelConfig), C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                              C.c_int64, C.c_void_p]
+_bwd_ws = {}
+
+
+def mel_l1_loss_backward(y_hat, y_mel, d_wav, scale=45.0, accumulate=True, n_fft=1024, num_mels=80, sampling_rate=22050, hop_size=256,
+                         win_size=1024, fmin=0, fmax=None):
+    """loss = scale * F.l1_loss(y_mel, mel_spectrogram(y_hat, ..., fmax)) and d_wav (+)= d loss / d y_hat, fused on the HIP mel
+    pipeline.  y_hat, d_wav: (B, N) fp32 contiguous; y_mel: (B, num_mels, N // hop).  Returns (loss 1-elem tensor, mel(y_hat))."""
+    _lib.require_cuda(y_hat, y_mel, d_wav)
+    key = (n_fft, num_mels, sampling_rate, hop_size, fmin, fmax, str(y_hat.device))
+    eng = _hifi_engines.get(key)
+    if eng is None:
+        mel_basis = librosa_mel_fn(sampling_rate, n_fft, num_mels, fmin, fmax)
+        eng = _MelEngine(n_fft, hop_size, num_mels, int((n_fft - hop_size) / 2), 1e-9, 0.0, torch.hann_window(win_size), mel_basis).to(y_hat.device)
+        _hifi_engines[key] = eng
+    B, N = y_hat.shape
+    y_hat = y_hat.float().contiguous()
+    y_mel = y_mel.float().contiguous()
+    need = int(_lib.lib.xva_mel_backward_workspace_bytes(C.byref(eng.cfg), B, N))
+    if need < 0:
+        raise _lib.XvaError("mel backward: " + _lib.lib.xva_last_error().decode())
+    ws = _bwd_ws.get(str(y_hat.device))
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, device=y_hat.device, dtype=torch.float32)
+        _bwd_ws[str(y_hat.device)] = ws
+    T = eng.num_frames(N)
+    mel_out = torch.empty(B, num_mels, T, device=y_hat.device, dtype=torch.float32)
+    loss = torch.zeros(1, device=y_hat.device)
+    rc = _lib.lib.xva_mel_l1_loss_backward(C.byref(eng.cfg), _lib.ptr(y_hat), B, N, y_hat.stride(0), _lib.ptr(y_mel), _lib.ptr(eng.forward_basis),
+                                           _lib.ptr(eng._mel_basis_padded), float(scale), _lib.ptr(mel_out), _lib.ptr(loss), _lib.ptr(d_wav),
+                                           d_wav.stride(0), int(bool(accumulate)), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "xva_mel_l1_loss_backward")
+    return loss, mel_out
