@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-hifigan", action="store_true", help="skip the HiFi-GAN audio-samples/s leg")
+    ap.add_argument("--hg-batch", type=int, default=64)
+    ap.add_argument("--hg-steps", type=int, default=0, help="timed HiFi-GAN steps (default: min(steps, 10))")
     return ap.parse_args()
 
 
@@ -56,6 +59,83 @@ def cpu_baseline(stage):
     return {"value": frames * n / dt, "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "B=2 x (150 tok, 860 frames) stage-%d full train step (fwd+loss+bwd+clip+LAMB), fp32 torch-CPU, %d timed steps"
                       % (stage, n), "host_cpu_count": os.cpu_count()}
+
+
+def hifigan_cpu_baseline():
+    """Reference-equivalent CPU iteration (oracle/hifigan.py: G fwd, D step, G step, 2 x AdamW; fp32 torch-CPU) on B=2 x 8192."""
+    from oracle import hifigan as ohg
+    g_sd, mpd_sd, msd_sd = ohg.init_generator_sd(1), ohg.init_mpd_sd(2), ohg.init_msd_sd(3)
+    x, y, ym = ohg.synth_batch(2, 4)
+    og, od = {}, {}
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        ohg.train_step(g_sd, mpd_sd, msd_sd, x, y, ym, og, od)
+    dt = time.perf_counter() - t0
+    return {"value": 2 * 8192 * n / dt, "unit": "audio-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "B=2 x 8192-sample segments, full D+G iteration (G fwd, MPD+MSD x2, losses, bwd, 2 x AdamW), fp32 torch-CPU, %d timed steps" % n}
+
+
+def hifigan_leg(a, dev, rank, world):
+    """audio-samples/s of the full HiFi-GAN v1 D+G iteration (BASELINE.json configs[2]: batch 64, 8192-sample segments)."""
+    import numpy as np
+    from xva_trainer_amd import synthetic
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    from xva_trainer_amd.mel import mel_spectrogram
+    st = HifiganStep(dev, a.compute)
+    torch.manual_seed(1234)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    # random-init weights of the v1 architecture (no checkpoints offline): weight_v ~ N(0, 0.02), weight_g = ||v||, spectral-norm u/v unit vectors
+    for which, flat in ((0, st.flat_g), (1, st.flat_d)):
+        for name, off, n, shape, kind in st.eng.table[which]:
+            if name.endswith("weight_g"):
+                continue
+            if name.endswith("bias"):
+                t = torch.zeros(shape)
+            elif name.endswith("weight_u") or (name.endswith("weight_v") and kind == 2):
+                t = torch.nn.functional.normalize(torch.randn(shape, generator=g), dim=0)
+            else:
+                fan_in = 1
+                for s_ in shape[1:]:
+                    fan_in *= s_
+                t = torch.randn(shape, generator=g) * (0.5 / max(fan_in, 1) ** 0.5)
+            flat[off:off + n].copy_(t.reshape(-1))
+        for name, off, n, shape, kind in st.eng.table[which]:
+            if name.endswith("weight_g"):
+                vname = name[:-1] + "v"
+                voff, vn, vshape = next((o, nn, sh) for nm, o, nn, sh, kd in st.eng.table[which] if nm == vname)
+                v = flat[voff:voff + vn].view(vshape)
+                flat[off:off + n].copy_(v.reshape(vshape[0], -1).norm(dim=1))
+    B, seg = a.hg_batch, 8192
+    wav = np.stack([synthetic.synth_wave(seg, 5000 + rank * 1000 + i) for i in range(B)])
+    wav = wav / np.abs(wav).max(axis=1, keepdims=True) * 0.95
+    y = torch.from_numpy(wav.astype(np.float32)).to(dev)
+    x = mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0, 8000)
+    y_mel = mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0, None)
+    steps = a.hg_steps or min(a.steps, 10)
+    for _ in range(2):
+        out = st.train_step(x, y, y_mel)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = st.train_step(x, y, y_mel)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    res = {"metric": "audio-samples/sec (HiFi-GAN v1 full D+G iteration)", "value": B * seg * world * steps / dt, "unit": "audio-samples/s",
+           "ms_per_step": 1000.0 * dt / steps, "steps": steps, "dtype": a.compute,
+           "config": {"workload": "HiFi-GAN v1 generator + MPD + MSD, batch %d/GPU x %d samples, D step + G step + 2 x fused AdamW" % (B, seg)},
+           "loss_mel": float(out["loss_mel"].item()), "loss_disc_all": float(out["loss_disc_all"].item())}
+    del st
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -167,6 +247,14 @@ def main():
                            "launches_per_step": launches / nprof, "avg_launch_us": 1e3 * ms / launches if launches else None,
                            "gemm_ms_per_step": ms / nprof, "algorithmic_gflop_per_step": flops / nprof / 1e9, "by_variant": per,
                            "method": "hipEvent pair around every xva_gemm launch on the launch stream, %d extra profiled fwd+bwd passes after the timed region" % nprof}
+    if not a.no_hifigan:
+        del opt, grads
+        eng._ws = None
+        torch.cuda.empty_cache()
+        hg = hifigan_leg(a, dev, rank, world)
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            hg["cpu_baseline"] = hifigan_cpu_baseline()
+        out["hifigan"] = hg
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(stage)
     if rank == 0:
