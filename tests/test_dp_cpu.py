@@ -35,8 +35,9 @@ def _worker(rank, world, port, tmp):
     sd = ofp.init_state_dict(21)
     full = ofp.synth_batch(4, 10, 36, 22)
     shard = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
-    Tm = int(shard["mel_lens"].max())                      # per-rank padding differs from the global batch: must not matter
-    shard["mel_tgt"] = shard["mel_tgt"][:, :, :Tm]; shard["pitch"] = shard["pitch"][:, :, :Tm]; shard["energy"] = shard["energy"][:, :Tm]
+    # Shards keep the GLOBAL padding, exactly as nn.DataParallel scatters an already-collated batch (xva_train.py:465-466):
+    # the reference's conv-FFN does not mask its inner activation, so an item's output depends (slightly) on how far it is
+    # padded (transformer.py:59-77) — re-padding per rank would change the math, not just the layout.
     names = ofp.trainable_names(sd.keys(), 3)
     leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
     out = ofp.forward({**sd, **leaves}, shard, 3)
