@@ -25,6 +25,14 @@ def _global_loss_parts(ofp, out, batch):
     return nums, dens
 
 
+def _full_batch(ofp):
+    """Global batch of 4 = two ragged pairs that each contain a full-length item, so every shard pads to the same lengths
+    as the global batch.  (The reference's conv-FFN does not mask its inner activation — transformer.py:59-77 — so an item's
+    output depends slightly on how far it is padded: re-padding per rank would change the math, not only the layout.)"""
+    a, b = ofp.synth_batch(2, 10, 36, 22), ofp.synth_batch(2, 10, 36, 23)
+    return {k: torch.cat([a[k], b[k]]) for k in a}
+
+
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -33,11 +41,8 @@ def _worker(rank, world, port, tmp):
     from xva_trainer_amd.fastpitch import dp
     torch.manual_seed(0)
     sd = ofp.init_state_dict(21)
-    full = ofp.synth_batch(4, 10, 36, 22)
+    full = _full_batch(ofp)
     shard = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
-    # Shards keep the GLOBAL padding, exactly as nn.DataParallel scatters an already-collated batch (xva_train.py:465-466):
-    # the reference's conv-FFN does not mask its inner activation, so an item's output depends (slightly) on how far it is
-    # padded (transformer.py:59-77) — re-padding per rank would change the math, not just the layout.
     names = ofp.trainable_names(sd.keys(), 3)
     leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
     out = ofp.forward({**sd, **leaves}, shard, 3)
@@ -67,7 +72,7 @@ def test_dp_world2_equals_full_batch(tmp_path):
     mp.spawn(_worker, args=(2, port, out_file), nprocs=2, join=True)
     res = torch.load(out_file, weights_only=False)
     sd = ofp.init_state_dict(21)
-    full = ofp.synth_batch(4, 10, 36, 22)
+    full = _full_batch(ofp)
     names = ofp.trainable_names(sd.keys(), 3)
     leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
     loss, _ = ofp.loss(ofp.forward({**sd, **leaves}, full, 3), full, 3)
