@@ -168,7 +168,8 @@ def test_epilogue_residual_gate_accumulate():
     Cm = torch.randn(M, N, device="cuda")
     C0 = Cm.clone()
     L.gemm(A, B, Cm, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=0, R=R, ldr=N, G=G, ldg=N, accumulate=True, alpha=0.5)
-    ref = C0.double() + torch.where(G > 0, 0.5 * (A[:, :K].double() @ B[:, :K].double().t()) + R.double(), torch.zeros((), device="cuda", dtype=torch.float64))
+    # epilogue order: alpha * acc -> gate -> + beta * R  (the residual path is not gated)
+    ref = C0.double() + torch.where(G > 0, 0.5 * (A[:, :K].double() @ B[:, :K].double().t()), torch.zeros((), device="cuda", dtype=torch.float64)) + R.double()
     assert _relerr(Cm, ref) < 2e-5
 
 

@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libxvahip.so")
+LIB_PATH = os.environ.get("XVA_LIB_PATH", os.path.join(_HERE, "csrc", "libxvahip.so"))   # override: A/B builds of the kernel library
 
 
 class XvaError(RuntimeError):

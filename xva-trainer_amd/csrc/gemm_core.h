@@ -26,7 +26,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int BM = 128, BK = 32, NTHREADS = 256;
+#ifndef XVA_BK
+#define XVA_BK 32
+#endif
+constexpr int BM = 128, BK = XVA_BK, NTHREADS = 256;
+constexpr int KH = BK / 32;   // 32-deep K halves per tile
 
 template <int MODE> struct Cfg;
 template <> struct Cfg<0> { typedef float S; typedef float L; static constexpr int VE = 4, LD = BK + 4; static constexpr bool BF = false; };
@@ -153,7 +157,7 @@ struct KcStage {
 template <int ROWS, int MODE, int T0>
 struct IcStage {
     typedef Cfg<MODE> C;
-    uint4 v[4];
+    uint4 v[4 * KH];
 
     __device__ __forceinline__ static bool active() {
         if constexpr (MODE == 1) return (int)threadIdx.x >= T0 && (int)threadIdx.x < T0 + ROWS;
@@ -166,17 +170,21 @@ struct IcStage {
     }
     // rowptr(k) = rowbase + k * ld ; column offset `coloff` (segment adjusted, per thread constant)
     template <bool TAIL>
-    __device__ __forceinline__ void load(const typename C::S* __restrict__ rowbase, int64_t ld, int64_t col, int k0, int Kbound) {
+    __device__ __forceinline__ void load(const typename C::S* const (&rowbases)[KH], int64_t ld, int64_t col, int k0, int Kbound) {
         if (!active()) return;
         int kg, icol;
         coords(kg, icol);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + kg * 4 + j;
-            if constexpr (TAIL) {
-                v[j] = (k < Kbound) ? *reinterpret_cast<const uint4*>(rowbase + (int64_t)k * ld + col) : make_uint4(0u, 0u, 0u, 0u);
-            } else {
-                v[j] = *reinterpret_cast<const uint4*>(rowbase + (int64_t)k * ld + col);
+        for (int kh = 0; kh < KH; ++kh) {
+            const typename C::S* rowbase = rowbases[kh];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + kh * 32 + kg * 4 + j;
+                if constexpr (TAIL) {
+                    v[kh * 4 + j] = (k < Kbound) ? *reinterpret_cast<const uint4*>(rowbase + (int64_t)k * ld + col) : make_uint4(0u, 0u, 0u, 0u);
+                } else {
+                    v[kh * 4 + j] = *reinterpret_cast<const uint4*>(rowbase + (int64_t)k * ld + col);
+                }
             }
         }
     }
@@ -185,32 +193,36 @@ struct IcStage {
         if (!active()) return;
         int kg, icol;
         coords(kg, icol);
-        typename C::L* d = Xs + icol * C::LD + kg * 4;
-        if constexpr (MODE == 1) {
-            const uint32_t w[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
-                                      {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {   // column e of the micro-tile -> 4 k-consecutive bf16
-                uint16_t h[4];
+        for (int kh = 0; kh < KH; ++kh) {
+            typename C::L* d = Xs + icol * C::LD + kh * 32 + kg * 4;
+            const uint4* vv = v + kh * 4;
+            if constexpr (MODE == 1) {
+                const uint32_t w[4][4] = {{vv[0].x, vv[0].y, vv[0].z, vv[0].w}, {vv[1].x, vv[1].y, vv[1].z, vv[1].w},
+                                          {vv[2].x, vv[2].y, vv[2].z, vv[2].w}, {vv[3].x, vv[3].y, vv[3].z, vv[3].w}};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t word = w[j][e >> 1];
-                    h[j] = (e & 1) ? (uint16_t)(word >> 16) : (uint16_t)(word & 0xffffu);
-                    if constexpr (ACT) h[j] = f2bf(lrelu(bf2f(h[j]), slope));
+                for (int e = 0; e < 8; ++e) {   // column e of the micro-tile -> 4 k-consecutive bf16
+                    uint16_t h[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        uint32_t word = w[j][e >> 1];
+                        h[j] = (e & 1) ? (uint16_t)(word >> 16) : (uint16_t)(word & 0xffffu);
+                        if constexpr (ACT) h[j] = f2bf(lrelu(bf2f(h[j]), slope));
+                    }
+                    uint2 o = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                    *reinterpret_cast<uint2*>(d + e * C::LD) = o;
                 }
-                uint2 o = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-                *reinterpret_cast<uint2*>(d + e * C::LD) = o;
-            }
-        } else {
-            const float f[4][4] = {{__uint_as_float(v[0].x), __uint_as_float(v[0].y), __uint_as_float(v[0].z), __uint_as_float(v[0].w)},
-                                   {__uint_as_float(v[1].x), __uint_as_float(v[1].y), __uint_as_float(v[1].z), __uint_as_float(v[1].w)},
-                                   {__uint_as_float(v[2].x), __uint_as_float(v[2].y), __uint_as_float(v[2].z), __uint_as_float(v[2].w)},
-                                   {__uint_as_float(v[3].x), __uint_as_float(v[3].y), __uint_as_float(v[3].z), __uint_as_float(v[3].w)}};
+            } else {
+                const float f[4][4] = {{__uint_as_float(vv[0].x), __uint_as_float(vv[0].y), __uint_as_float(vv[0].z), __uint_as_float(vv[0].w)},
+                                       {__uint_as_float(vv[1].x), __uint_as_float(vv[1].y), __uint_as_float(vv[1].z), __uint_as_float(vv[1].w)},
+                                       {__uint_as_float(vv[2].x), __uint_as_float(vv[2].y), __uint_as_float(vv[2].z), __uint_as_float(vv[2].w)},
+                                       {__uint_as_float(vv[3].x), __uint_as_float(vv[3].y), __uint_as_float(vv[3].z), __uint_as_float(vv[3].w)}};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float a = f[0][e], b = f[1][e], c = f[2][e], dd = f[3][e];
-                if constexpr (ACT) { a = lrelu(a, slope); b = lrelu(b, slope); c = lrelu(c, slope); dd = lrelu(dd, slope); }
-                st_quad<MODE>(d + e * C::LD, a, b, c, dd);
+                for (int e = 0; e < 4; ++e) {
+                    float a = f[0][e], b = f[1][e], c = f[2][e], dd = f[3][e];
+                    if constexpr (ACT) { a = lrelu(a, slope); b = lrelu(b, slope); c = lrelu(c, slope); dd = lrelu(dd, slope); }
+                    st_quad<MODE>(d + e * C::LD, a, b, c, dd);
+                }
             }
         }
     }
@@ -287,12 +299,17 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
         }
     }
 
-    int bj = 0, brem = 0;
+    int bj[KH], brem[KH];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) { bj[kh] = 0; brem[kh] = 0; }
     if constexpr (LAYOUT == XVA_GEMM_NN) {
         if (p.seglen > 0) {
             int kg, ic; ib.coords(kg, ic);
-            const int kk = kt_begin * BK + kg * 4;
-            bj = kk / p.seglen; brem = kk - bj * p.seglen;
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                const int kk = kt_begin * BK + kh * 32 + kg * 4;
+                bj[kh] = kk / p.seglen; brem[kh] = kk - bj[kh] * p.seglen;
+            }
         }
     }
 
@@ -307,21 +324,27 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
                 while (arem >= p.a_seglen) { arem -= p.a_seglen; ++aj; }
             }
         }
-        const ST* bbase = B;
+        const ST* bbase[KH];
+        const ST* abase[KH];
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) { bbase[kh] = B; abase[kh] = A; }
         if constexpr (LAYOUT == XVA_GEMM_NN) {
-            if (p.seglen > 0) {   // this thread's 4 k-rows share one segment (seglen % 4 == 0, checked on the host)
-                bbase = B + p.seg0 + (int64_t)bj * p.segstride - (int64_t)bj * p.seglen * p.ldb;
-                brem += BK;
-                while (brem >= p.seglen) { brem -= p.seglen; ++bj; }
+            if (p.seglen > 0) {   // a thread's 4 consecutive k-rows share one segment (seglen % 4 == 0, checked on the host)
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh) {
+                    bbase[kh] = B + p.seg0 + (int64_t)bj[kh] * p.segstride - (int64_t)bj[kh] * p.seglen * p.ldb;
+                    brem[kh] += BK;
+                    while (brem[kh] >= p.seglen) { brem[kh] -= p.seglen; ++bj[kh]; }
+                }
             }
         }
         if (!tail) {
-            if constexpr (LAYOUT == XVA_GEMM_TN) ia.template load<false>(A, p.lda, ia_col, k0, p.K);
+            if constexpr (LAYOUT == XVA_GEMM_TN) ia.template load<false>(abase, p.lda, ia_col, k0, p.K);
             else ka.template load<false>(A, p.lda, m0, p.M, k0, p.K, aoff);
             if constexpr (LAYOUT == XVA_GEMM_NT) kb.template load<false>(B, p.ldb, n0, p.N, k0, p.K, 0);
             else ib.template load<false>(bbase, p.ldb, ib_col, k0, p.K);
         } else {
-            if constexpr (LAYOUT == XVA_GEMM_TN) ia.template load<true>(A, p.lda, ia_col, k0, p.K);
+            if constexpr (LAYOUT == XVA_GEMM_TN) ia.template load<true>(abase, p.lda, ia_col, k0, p.K);
             else ka.template load<true>(A, p.lda, m0, p.M, k0, p.K, aoff);
             if constexpr (LAYOUT == XVA_GEMM_NT) kb.template load<true>(B, p.ldb, n0, p.N, k0, p.K, 0);
             else ib.template load<true>(bbase, p.ldb, ib_col, k0, p.K);
@@ -341,16 +364,19 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
         const LT* Aw = As + (wm * 64 + (lane & 15)) * LD;
         const LT* Bw = Bs + (wn * (BN / 2) + (lane & 15)) * LD;
         if constexpr (C::BF) {
-            bf16x8 af[4], bfr[NTN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Aw + i * 16 * LD + (lane >> 4) * 8);
+            for (int kh = 0; kh < KH; ++kh) {
+                bf16x8 af[4], bfr[NTN];
 #pragma unroll
-            for (int j = 0; j < NTN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bw + j * 16 * LD + (lane >> 4) * 8);
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Aw + i * 16 * LD + kh * 32 + (lane >> 4) * 8);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < NTN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bw + j * 16 * LD + kh * 32 + (lane >> 4) * 8);
 #pragma unroll
-                for (int j = 0; j < NTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
         } else {
 #pragma unroll
             for (int s = 0; s < BK / 4; ++s) {
