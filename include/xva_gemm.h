@@ -45,7 +45,8 @@ typedef struct xva_gemm_params {
     int64_t sA, sB, sC;     /* batch strides (elements) */
     int32_t batch2;         /* 0/1 = none */
     int64_t sA2, sB2, sC2;
-    /* A tap segments (NT / NN): see header comment. a_seglen == 0 disables. */
+    /* A tap segments (NT / NN): see header comment. a_seglen == 0 disables.
+     * TN: A column m lives at A + k * lda + m + (m / a_seglen) * a_segadj (column segments, like B's). */
     int32_t a_seglen;
     int64_t a_segadj;
     /* B segments.  NN: row kk lives at B + seg0 + (kk / seglen) * segstride + (kk % seglen) * ldb.
@@ -81,6 +82,7 @@ typedef struct xva_gemm_params {
     int32_t compute;        /* 0 fp32, 1 bf16 */
     int32_t layout;         /* XVA_GEMM_* */
     int32_t a_dtype, b_dtype, c_dtype;
+    int32_t c_trans;        /* 1: store C transposed: element (row, col) at C[col * ldc + row] */
 } xva_gemm_params;
 
 /* Launches on `stream` (a hipStream_t); returns 0 or a negative XVA_ERR_* code. */

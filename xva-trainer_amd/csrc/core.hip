@@ -21,14 +21,18 @@ extern "C" const char* xva_target_arch(void) { return "gfx950"; }
 // the timed throughput region never runs with it on.
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int variant; };
+struct ProfRec { hipEvent_t a, b; double flops; int variant; int M, N, K, batch, splitk, bn; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }
 extern "C" void xva_prof_enable(int on) { g_prof_on = on != 0; }
 bool xva_prof_is_on() { return g_prof_on; }
+void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn) {
+    if (g_prof.empty()) return;
+    ProfRec& r = g_prof.back(); r.M = M; r.N = N; r.K = K; r.batch = batch; r.splitk = splitk; r.bn = bn;
+}
 void xva_prof_begin(hipStream_t st, double flops, int variant) {
-    ProfRec r; r.flops = flops; r.variant = variant;
+    ProfRec r; r.flops = flops; r.variant = variant; r.M = r.N = r.K = r.batch = r.splitk = r.bn = 0;
     hipEventCreate(&r.a); hipEventCreate(&r.b);
     hipEventRecord(r.a, st);
     g_prof.push_back(r);
@@ -65,4 +69,22 @@ extern "C" int xva_event_record(void* e, void* stream) {
 extern "C" int xva_stream_wait_event(void* stream, void* e) {
     if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e, 0) != hipSuccess) { xva_set_error("hipStreamWaitEvent failed"); return XVA_ERR_HIP; }
     return XVA_OK;
+}
+
+// Dump one CSV line per recorded GEMM launch (variant = layout*3 + mode) and clear the records.
+extern "C" int xva_prof_dump(const char* path) {
+    FILE* f = fopen(path, "w");
+    if (!f) return XVA_ERR_ARG;
+    fprintf(f, "variant,M,N,K,batch,splitk,bn,ms,gflop\n");
+    for (auto& r : g_prof) {
+        hipEventSynchronize(r.b);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.5f,%.4f\n", r.variant, r.M, r.N, r.K, r.batch, r.splitk, r.bn, ms, r.flops * 1e-9);
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    fclose(f);
+    int n = (int)g_prof.size();
+    g_prof.clear();
+    return n;
 }

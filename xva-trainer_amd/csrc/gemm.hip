@@ -9,6 +9,7 @@ void xva_gemm_launch_mixed(const xva_gemm_params& p, int bn, unsigned nblocks, h
 bool xva_prof_is_on();
 void xva_prof_begin(hipStream_t st, double flops, int variant);
 void xva_prof_end(hipStream_t st);
+void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn);
 
 extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     XVA_CHECK_ARG(pp != nullptr, "xva_gemm: null params");
@@ -32,7 +33,6 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     XVA_CHECK_ARG(p.a_seglen % ve == 0, "xva_gemm: a_seglen must be a multiple of %d", ve);
     XVA_CHECK_ARG(p.layout != XVA_GEMM_NN || p.seglen % 4 == 0, "xva_gemm: NN seglen must be a multiple of 4");
     XVA_CHECK_ARG(p.layout != XVA_GEMM_TN || p.seglen % ve == 0, "xva_gemm: TN seglen must be a multiple of %d", ve);
-    XVA_CHECK_ARG(p.layout != XVA_GEMM_TN || p.a_seglen == 0, "xva_gemm: A segments are not defined for TN");
     XVA_CHECK_ARG(p.splitk == 1 || (p.accumulate && p.c_dtype == XVA_F32), "xva_gemm: splitk > 1 requires accumulate into fp32 C");
     XVA_CHECK_ARG(p.splitk == 1 || (p.act == XVA_ACT_NONE && !p.G && p.mask_mode == XVA_MASK_NONE),
                   "xva_gemm: splitk > 1 cannot carry a non-linear epilogue");
@@ -52,7 +52,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int mode = p.compute == 0 ? 0 : (p.a_dtype == XVA_BF16 ? 1 : 2);
     const bool prof = xva_prof_is_on();
-    if (prof) xva_prof_begin(st, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + mode);
+    if (prof) { xva_prof_begin(st, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + mode); xva_prof_shape(p.M, p.N, p.K, p.batch * p.batch2, p.splitk, bn); }
     if (mode == 0) xva_gemm_launch_fp32(p, bn, (unsigned)nblocks, st);
     else if (mode == 1) xva_gemm_launch_bf16(p, bn, (unsigned)nblocks, st);
     else xva_gemm_launch_mixed(p, bn, (unsigned)nblocks, st);

@@ -281,7 +281,9 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
     if constexpr (LAYOUT == XVA_GEMM_TN) {
         int kg, ic; ia.coords(kg, ic);
         const int MV = (p.M + C::VE - 1) / C::VE * C::VE;
-        ia_col = min(m0 + ic, MV - C::VE);
+        const int m = min(m0 + ic, MV - C::VE);
+        ia_col = m;
+        if (p.a_seglen > 0) ia_col = m + (int64_t)(m / p.a_seglen) * p.a_segadj;
     }
     if constexpr (LAYOUT != XVA_GEMM_NT) {
         int kg, ic; ib.coords(kg, ic);
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
                     default: break;
                 }
                 if (!live) v = 0.f;
-                const int64_t ci = coff + (int64_t)row * p.ldc + col;
+                const int64_t ci = coff + (p.c_trans ? (int64_t)col * p.ldc + row : (int64_t)row * p.ldc + col);
                 if (p.c_dtype == XVA_BF16) {
                     uint16_t* dst = reinterpret_cast<uint16_t*>(p.C) + ci;
                     if (p.accumulate) v += bf2f(*dst);

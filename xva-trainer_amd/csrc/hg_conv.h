@@ -155,23 +155,35 @@ inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x
     const int Cig = w.Cin / w.groups, Cog = w.Cout / w.groups;
     xva_gemm_params g = hg_gp(compute, dY.dt);
     g.layout = XVA_GEMM_TN;
-    g.M = Cog; g.N = w.k * Cig;
-    g.lda = dY.C; g.ldb = (int64_t)w.s * X.C; g.ldc = g.N;
-    g.seglen = Cig; g.segstride = (int64_t)w.d * X.C - Cig; g.seg0 = 0;
-    g.C = w.dweff; g.c_dtype = XVA_F32;
-    g.b_lrelu = x_lrelu; g.b_slope = x_slope; g.alpha = alpha;
-    g.batch2 = w.groups; g.sA2 = Cog; g.sB2 = Cig; g.sC2 = (int64_t)Cog * g.N;
-    if (hg_mode(X, dY, w) == HG_MERGED) {
-        g.A = dY.ptr();
-        g.B = (const char*)X.ptr() - (int64_t)w.P * X.C * X.es();
+    g.C = w.dweff; g.c_dtype = XVA_F32; g.alpha = alpha;
+    g.batch2 = w.groups; g.sC2 = (int64_t)Cog * w.k * Cig;
+    const bool merged = hg_mode(X, dY, w) == HG_MERGED;
+    const void* dy0 = merged ? dY.ptr() : dY.valid();
+    const void* x0 = (const char*)(merged ? X.ptr() : X.valid()) - (int64_t)w.P * X.C * X.es();
+    // The 128-row M tile wants the LARGER of (Cout_g, k*Cin_g) on M: for narrow layers (Cout_g <= 64) compute dW^T = Xcat^T dY
+    // (M = k*Cin_g taps x channels as segmented columns of A, N = Cout_g on the narrow N tile) and store it transposed.
+    const bool swap = Cog <= 64 && w.k * Cig > Cog;
+    if (!swap) {
+        g.M = Cog; g.N = w.k * Cig;
+        g.lda = dY.C; g.ldb = (int64_t)w.s * X.C; g.ldc = g.N;
+        g.seglen = Cig; g.segstride = (int64_t)w.d * X.C - Cig; g.seg0 = 0;
+        g.b_lrelu = x_lrelu; g.b_slope = x_slope;
+        g.sA2 = Cog; g.sB2 = Cig;
+        g.A = dy0; g.B = x0;
+    } else {
+        g.M = w.k * Cig; g.N = Cog;
+        g.lda = (int64_t)w.s * X.C; g.ldb = dY.C; g.ldc = w.k * Cig; g.c_trans = 1;
+        g.a_seglen = Cig; g.a_segadj = (int64_t)w.d * X.C - Cig;
+        g.a_lrelu = x_lrelu; g.a_slope = x_slope;
+        g.sA2 = Cig; g.sB2 = Cog;
+        g.A = x0; g.B = dy0;
+    }
+    if (merged) {
         g.K = (int)dY.rows();
         g.accumulate = 1; g.splitk = hg_splitk(g.M, g.N, g.K, w.groups);
     } else {
-        g.batch = X.nseq; g.sA = dY.item(); g.sB = X.item(); g.sC = 0;
-        g.A = dY.valid();
-        g.B = (const char*)X.valid() - (int64_t)w.P * X.C * X.es();
-        g.K = dY.T;
-        g.accumulate = 2;
+        g.batch = X.nseq; g.sC = 0; g.K = dY.T; g.accumulate = 2;
+        if (!swap) { g.sA = dY.item(); g.sB = X.item(); } else { g.sA = X.item(); g.sB = dY.item(); }
     }
     return xva_gemm(&g, st);
 }

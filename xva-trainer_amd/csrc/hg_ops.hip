@@ -177,29 +177,46 @@ __global__ void hg_cout1_bwd_data_kernel(const void* __restrict__ d, const float
     }
     hg_st(dX, i, dt, v);
 }
+#define COUT1_MAXK 8
 __global__ void hg_cout1_bwd_weight_kernel(const void* __restrict__ d, const void* __restrict__ x, float* __restrict__ dw,
                                            float* __restrict__ db, int dt, int64_t rows, int C, int k, int dil, int P, int act,
                                            float slope, int rows_per_block) {
-    int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (int idx = threadIdx.x; idx < k * C + 1; idx += blockDim.x) {
-        float acc = 0.f;
-        if (idx == k * C) {
-            for (int64_t r = r0; r < r1; ++r) acc += hg_ld(d, r, dt);
-            if (acc != 0.f) atomicAdd(db, acc);
-        } else {
-            int j = idx / C, c = idx % C;
-            for (int64_t r = r0; r < r1; ++r) {
-                float dv = hg_ld(d, r, dt);
-                if (dv == 0.f) continue;
-                int64_t rr = r + (int64_t)j * dil - P;
-                if (rr < 0 || rr >= rows) continue;
-                float xv = hg_ld(x, rr * C + c, dt);
-                if (act) xv = hg_lrelu(xv, slope);
-                acc += dv * xv;
-            }
-            if (acc != 0.f) atomicAdd(dw + idx, acc);
+    // dw[j*C + c] = sum_r x[r][c] * d[r - j*dil + P] : each thread owns channel c, reads x[r][c] ONCE and k shifted d values
+    __shared__ float sd[1024 + 64];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const int span = (k - 1) * dil;
+    // stage d[r0 - span + P .. r1 - 1 + P] (rows referenced by this chunk)
+    const int64_t dlo = r0 - span + P;
+    const int nd = (int)(r1 - r0) + span;
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) {
+        int64_t rr = dlo + i;
+        sd[i] = (rr >= 0 && rr < rows) ? hg_ld(d, rr, dt) : 0.f;
+    }
+    __syncthreads();
+    float acc[COUT1_MAXK];
+#pragma unroll
+    for (int j = 0; j < COUT1_MAXK; ++j) acc[j] = 0.f;
+    float accb = 0.f;
+    if (c < C) {
+        for (int64_t r = r0; r < r1; ++r) {
+            float xv = hg_ld(x, r * C + c, dt);
+            if (act) xv = hg_lrelu(xv, slope);
+            const int base = (int)(r - r0) + span;   // index of d[r + P] in sd
+#pragma unroll
+            for (int j = 0; j < COUT1_MAXK; ++j)
+                if (j < k) acc[j] += xv * sd[base - j * dil];
         }
+#pragma unroll
+        for (int j = 0; j < COUT1_MAXK; ++j)
+            if (j < k && acc[j] != 0.f) atomicAdd(dw + j * C + c, acc[j]);
+    }
+    if (blockIdx.x == 0) {   // db += sum_r d[r] ; d[r] = sd[(r - r0) + span - P]
+        __shared__ float shb[16];
+        for (int i = threadIdx.x; i < (int)(r1 - r0); i += blockDim.x) accb += sd[i + span - P];
+        accb = xva_block_sum(accb, shb);
+        if (threadIdx.x == 0 && accb != 0.f) atomicAdd(db, accb);
     }
 }
 extern "C" int xva_hg_cout1_bwd_data(const void* d, const float* w, const void* x, void* dX, int dt, int64_t rows, int C, int k, int dil,
@@ -213,9 +230,10 @@ extern "C" int xva_hg_cout1_bwd_data(const void* d, const float* w, const void* 
 extern "C" int xva_hg_cout1_bwd_weight(const void* d, const void* x, float* dw, float* db, int dt, int64_t rows, int C, int k, int dil, int P,
                                        int act, float slope, void* stream) {
     XVA_CHECK_ARG(d && x && dw && db, "cout1_bwd_weight: null");
-    const int rpb = 128;
-    hipLaunchKernelGGL(hg_cout1_bwd_weight_kernel, dim3(xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, d, x, dw, db, dt, rows, C, k,
-                       dil, P, act, slope, rpb);
+    XVA_CHECK_ARG(k <= COUT1_MAXK && (k - 1) * dil <= 64, "cout1_bwd_weight: kernel size unsupported");
+    const int rpb = 1024;
+    hipLaunchKernelGGL(hg_cout1_bwd_weight_kernel, dim3(xva_cdiv(C, 256), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, d, x, dw, db, dt,
+                       rows, C, k, dil, P, act, slope, rpb);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
@@ -449,9 +467,10 @@ extern "C" int xva_hg_weight_norm_bwd(const float* dW, const float* v, const flo
 __global__ void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ t, int D0, int inner) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= inner) return;
+    const int o0 = blockIdx.y * 64, o1 = min(o0 + 64, D0);
     float a = 0.f;
-    for (int o = 0; o < D0; ++o) a += W[(int64_t)o * inner + i] * u[o];
-    t[i] = a;
+    for (int o = o0; o < o1; ++o) a += W[(int64_t)o * inner + i] * u[o];
+    atomicAdd(t + i, a);
 }
 // out = in / max(||in||, eps); optionally dot_out = out . in  (single block)
 __global__ void sn_normalize_kernel(const float* __restrict__ in, float* __restrict__ out, int n, float* __restrict__ dot_out) {
@@ -510,7 +529,8 @@ extern "C" int xva_hg_spectral_norm_fwd(const float* W, float* u, float* v, void
     XVA_CHECK_ARG(W && u && v && eff && sigma && tmp, "spectral_norm_fwd: null");
     hipStream_t st = (hipStream_t)stream;
     const int inner = D1 * k;
-    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(xva_cdiv(inner, 256)), dim3(256), 0, st, W, u, tmp, D0, inner);
+    if (hipMemsetAsync(tmp, 0, inner * sizeof(float), st) != hipSuccess) { xva_set_error("spectral_norm_fwd: memset failed"); return XVA_ERR_HIP; }
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(xva_cdiv(inner, 256), xva_cdiv(D0, 64)), dim3(256), 0, st, W, u, tmp, D0, inner);
     hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, tmp, v, inner, (float*)nullptr);
     hipLaunchKernelGGL(sn_w_v_kernel, dim3(xva_cdiv(D0, 4)), dim3(256), 0, st, W, v, tmp + inner, D0, inner);
     hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, tmp + inner, u, D0, sigma);
@@ -535,6 +555,85 @@ extern "C" int xva_hg_spectral_norm_bwd(const float* dWeff, const float* W, cons
     int grid = (int)((n + 255) / 256); if (grid > 512) grid = 512;
     hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(grid), dim3(256), 0, st, dWeff, W, tmp, D0, D1, k);
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(xva_cdiv(n, 256)), dim3(256), 0, st, dWeff, u, v, sigma, tmp, dWorig, D0, D1, k);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Waveform-boundary convs as GEMMs: explicit im2col of the 1-channel input (k taps padded to kp columns) so that the
+// first discriminator layer's forward / backward-weight / backward-data all run on the MFMA GEMM.
+//   xcol[(b,w)][padF + h'][j] = x(b, w, s*h' + j - P)  (j < k), 0 for k <= j < kp
+__global__ void hg_im2col1_kernel(const float* __restrict__ wav, void* __restrict__ xcol, int dt, Cin1Geom g, int kp) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)g.nb * g.p * g.Tout * kp;
+    if (i >= total) return;
+    int j = (int)(i % kp);
+    int h = (int)((i / kp) % g.Tout);
+    int seq = (int)(i / ((int64_t)kp * g.Tout));
+    int b = seq / g.p, w = seq % g.p;
+    float v = j < g.k ? cin1_sample(wav, g, b, w, g.s * h + j - g.P) : 0.f;
+    hg_st(xcol, ((int64_t)seq * g.Hp + g.padF + h) * kp + j, dt, v);
+}
+// d_wav[b][i] (+)= sum over folded positions aliasing sample i, sum_j [ (h + P - j) % s == 0 ] dxcol[(b,w)][(h + P - j)/s][j]
+__global__ void hg_col2im1_kernel(const void* __restrict__ dxcol, int dt, float* __restrict__ dwav, Cin1Geom g, int kp, int accumulate) {
+    int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= (int64_t)g.nb * g.Tw) return;
+    int b = (int)(gi / g.Tw), i = (int)(gi % g.Tw);
+    float total = 0.f;
+    for (int alias = 0; alias < 2; ++alias) {
+        int ii = i;
+        if (alias == 1) { ii = 2 * (g.Tw - 1) - i; if (ii < g.Tw || ii >= g.Hfold * g.p) break; }
+        int h = ii / g.p, w = ii % g.p;
+        int seq = b * g.p + w;
+        for (int j = 0; j < g.k; ++j) {
+            int num = h + g.P - j;
+            if (num < 0 || num % g.s != 0) continue;
+            int hp = num / g.s;
+            if (hp >= g.Tout) continue;
+            total += hg_ld(dxcol, ((int64_t)seq * g.Hp + g.padF + hp) * kp + j, dt);
+        }
+    }
+    if (accumulate) dwav[gi] += total; else dwav[gi] = total;
+}
+// zero-padded copy of a (rows, k) fp32 matrix into (rows, kp) of dtype dt ; and the reverse accumulation (fp32 -> fp32)
+__global__ void hg_pad_cols_kernel(const float* __restrict__ src, void* __restrict__ dst, int dt, int rows, int k, int kp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * kp) return;
+    int r = i / kp, j = i % kp;
+    hg_st(dst, i, dt, j < k ? src[r * k + j] : 0.f);
+}
+__global__ void hg_unpad_cols_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int k, int kp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * k) return;
+    int r = i / k, j = i % k;
+    dst[i] += src[r * kp + j];
+}
+extern "C" int xva_hg_im2col1(const float* wav, void* xcol, int dt, int nb, int Tw, int p, int k, int s, int P, int kp, int Hp, int padF, void* stream) {
+    Cin1Geom g;
+    XVA_TRY(cin1_geom(&g, nb, Tw, p, k, s, P, 1, Hp, padF));
+    XVA_CHECK_ARG(wav && xcol && kp >= k, "im2col1: bad args");
+    int64_t total = (int64_t)nb * p * g.Tout * kp;
+    hipLaunchKernelGGL(hg_im2col1_kernel, dim3(xva_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, wav, xcol, dt, g, kp);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_hg_col2im1(const void* dxcol, int dt, float* dwav, int nb, int Tw, int p, int k, int s, int P, int kp, int Hp, int padF,
+                              int accumulate, void* stream) {
+    Cin1Geom g;
+    XVA_TRY(cin1_geom(&g, nb, Tw, p, k, s, P, 1, Hp, padF));
+    XVA_CHECK_ARG(dxcol && dwav, "col2im1: null");
+    hipLaunchKernelGGL(hg_col2im1_kernel, dim3(xva_cdiv((int64_t)nb * Tw, 256)), dim3(256), 0, (hipStream_t)stream, dxcol, dt, dwav, g, kp, accumulate);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_hg_pad_cols(const float* src, void* dst, int dt, int rows, int k, int kp, void* stream) {
+    hipLaunchKernelGGL(hg_pad_cols_kernel, dim3(xva_cdiv(rows * kp, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, dt, rows, k, kp);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_hg_unpad_cols_add(const float* src, float* dst, int rows, int k, int kp, void* stream) {
+    hipLaunchKernelGGL(hg_unpad_cols_add_kernel, dim3(xva_cdiv(rows * k, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, k, kp);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }

@@ -33,6 +33,10 @@ int xva_hg_weight_norm_bwd(const float*, const float*, const float*, const float
 int xva_hg_spectral_norm_fwd(const float*, float*, float*, void*, float*, int, int, int, int, float*, void*);
 int xva_hg_spectral_norm_bwd(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, float*, void*);
 int xva_hg_sn_scale(const float*, const float*, void*, int, int, int, int, void*);
+int xva_hg_im2col1(const float*, void*, int, int, int, int, int, int, int, int, int, int, void*);
+int xva_hg_col2im1(const void*, int, float*, int, int, int, int, int, int, int, int, int, int, void*);
+int xva_hg_pad_cols(const float*, void*, int, int, int, int, void*);
+int xva_hg_unpad_cols_add(const float*, float*, int, int, int, void*);
 }
 
 namespace {
@@ -53,6 +57,8 @@ struct Layer {
     int64_t bias = -1, wg = -1, wv = -1, bu = -1, bv = -1;   // offsets (floats) in the flat parameter buffer
     // workspace byte offsets
     int64_t eff[2] = {-1, -1}, effB = -1, eff32[2] = {-1, -1}, norm[2] = {-1, -1}, su[2] = {-1, -1}, sv[2] = {-1, -1}, dweff[2] = {-1, -1};
+    int64_t wp[2] = {-1, -1}, dwp[2] = {-1, -1};   // Cin == 1 layers: taps padded to kp columns (GEMM form of the boundary conv)
+    int kp() const { return k <= 8 ? 8 : 16; }
     int D0() const { return kind == LK_WNT ? Cin : Cout; }
     int D1() const { return kind == LK_WNT ? Cout : Cin / groups; }
     int64_t wnumel() const { return (int64_t)D0() * D1() * k; }
@@ -176,6 +182,7 @@ struct Plan {
     // discriminators: per MPD period: t1..t6 ; per MSD scale: t1..t8 (real+fake stacked: nseq = 2B*p / 2B; SN scale 0: two sets)
     SeqSpec pt[NPER][7], st[3][2][9];
     SeqSpec pd[NPER][7], sd[3][2][9];   // gradient tensors (same geometry)
+    SeqSpec pxc[NPER][2], sxc[3][2][2];  // im2col of the waveform for conv0 [.][0] and its gradient [.][1]
     int64_t wav_s[3][2];                // pooled waveforms (fp32): [scale][real/fake] ; scale 0 = the inputs themselves
     int64_t dwav_s[3];                  // gradient w.r.t. the (pooled) fake waveforms
     int Tw[3];
@@ -203,6 +210,7 @@ void plan_layer_ws(Layer& l, Bump& b, int es, bool grads) {
         l.norm[p] = b.take((l.kind == LK_SN ? 4 : l.D0()) * 4);
         if (l.kind == LK_SN) { l.su[p] = b.take(l.D0() * 4); l.sv[p] = b.take((int64_t)l.D1() * l.k * 4); }
         if (grads) l.dweff[p] = b.take(n * 4);
+        if (l.Cin == 1) { l.wp[p] = b.take((int64_t)l.Cout * l.kp() * es + 64); l.dwp[p] = b.take((int64_t)l.Cout * l.kp() * 4); }
     }
     if (l.kind == LK_WNT) l.effB = b.take(n * es + 64);
 }
@@ -255,6 +263,7 @@ int make_plan(const xva_hg_dims* d, Plan* p) {
             t[4] = mk(b, es, ns, H[4], 1024, pf4, hp4 - H[4] - pf4);
             t[5] = mk(b, es, ns, H[5], 1024, pf4, hp4 - H[4] - pf4);
             t[6] = mk(b, es, ns, H[6], 1, pf4, hp4 - H[4] - pf4);
+            p->pxc[d5][which] = mk(b, es, ns, H[1], 8, 4, 4);
         }
     }
     // ---- MSD
@@ -270,6 +279,7 @@ int make_plan(const xva_hg_dims* d, Plan* p) {
             for (int which = 0; which < 2; ++which) {
                 SeqSpec* t = which == 0 ? p->st[sc][set] : p->sd[sc][set];
                 for (int i = 1; i <= 8; ++i) t[i] = mk(b, es, ns, T[i], ch[i], 24, 24);
+                p->sxc[sc][set][which] = mk(b, es, ns, T[1], 16, 24, 24);
             }
         for (int rf = 0; rf < 2; ++rf) p->wav_s[sc][rf] = sc == 0 ? -1 : b.take((int64_t)B * p->Tw[sc] * 4);
         p->dwav_s[sc] = b.take((int64_t)B * p->Tw[sc] * 4);
@@ -307,6 +317,7 @@ ConvTW ctw(const Ctx& c, const Layer& l, const float* params) {
     return w;
 }
 
+const float* eff32(const Ctx& c, const Layer& l, int pass) { return c.dt == XVA_F32 ? (const float*)(c.W + l.eff[pass]) : c.F(l.eff32[pass]); }
 // effective weights of weight-norm layers (and fp32 copies for the 1-channel direct kernels)
 int prep_wn(const Ctx& c, const std::vector<Layer>& L, const float* params) {
     for (const Layer& l : L) {
@@ -317,10 +328,10 @@ int prep_wn(const Ctx& c, const std::vector<Layer>& L, const float* params) {
         if (l.eff32[0] >= 0 && c.dt != XVA_F32)
             XVA_TRY(xva_hg_weight_norm_fwd(params + l.wv, params + l.wg, c.W + l.eff32[0], nullptr, c.F(l.norm[0]), XVA_F32, 0, l.D0(), l.D1(), l.k,
                                            l.s, l.P, c.st));
+        if (l.Cin == 1) XVA_TRY(xva_hg_pad_cols(eff32(c, l, 0), c.W + l.wp[0], c.dt, l.Cout, l.k, l.kp(), c.st));
     }
     return XVA_OK;
 }
-const float* eff32(const Ctx& c, const Layer& l, int pass) { return c.dt == XVA_F32 ? (const float*)(c.W + l.eff[pass]) : c.F(l.eff32[pass]); }
 
 int zero(const Ctx& c, void* p, int64_t bytes) {
     if (hipMemsetAsync(p, 0, bytes, (hipStream_t)c.st) != hipSuccess) { xva_set_error("hifigan: memset failed"); return XVA_ERR_HIP; }
@@ -376,8 +387,17 @@ int wn_backward(Ctx& c, const std::vector<Layer>& L, const float* P, float* G) {
 }
 int zero_dweff(Ctx& c, const std::vector<Layer>& L) {
     for (const Layer& l : L)
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < 2; ++p) {
             if (l.dweff[p] >= 0) XVA_TRY(zero(c, c.W + l.dweff[p], l.wnumel() * 4));
+            if (l.dwp[p] >= 0) XVA_TRY(zero(c, c.W + l.dwp[p], (int64_t)l.Cout * l.kp() * 4));
+        }
+    return XVA_OK;
+}
+// gradients of the padded first-layer weights -> the layer's dweff ([Cout][k], tap-major with Cin = 1)
+int fold_dwp(Ctx& c, const std::vector<Layer>& L) {
+    for (const Layer& l : L)
+        for (int p = 0; p < 2; ++p)
+            if (l.dwp[p] >= 0 && l.dweff[p] >= 0) XVA_TRY(xva_hg_unpad_cols_add(c.F(l.dwp[p]), c.F(l.dweff[p]), l.Cout, l.k, l.kp(), c.st));
     return XVA_OK;
 }
 
@@ -456,10 +476,30 @@ int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav) {
 struct DiscRun {
     const int* li; int n;            // layer indices into pl.dl (n layers incl. conv_post): MPD 6, MSD 8
     const SeqSpec* t; const SeqSpec* d;   // activations / gradients t[1..n]
+    const SeqSpec* xc;                    // xc[0] im2col of the waveform, xc[1] its gradient
     int p;                           // period (MSD: 1)
     int Tw;                          // input waveform length
     int pass;                        // effective-weight set (spectral norm: 0 real pass, 1 fake pass)
 };
+
+
+// conv0 (1 input channel) in GEMM form: W padded to kp taps, input = im2col of the waveform
+ConvW cw0(const Ctx& c, const Layer& l, const float* P, int pass) {
+    ConvW w; w.eff = c.W + l.wp[pass]; w.bias = P + l.bias; w.dweff = c.F(l.dwp[pass]);
+    w.Cin = l.kp(); w.Cout = l.Cout; w.k = 1; w.s = 1; w.d = 1; w.P = 0; w.groups = 1;
+    return w;
+}
+int conv0_im2col(Ctx& c, const DiscRun& r, const float* wav, int i0, int ni) {
+    const Layer& l0 = c.pl.dl[r.li[0]];
+    Seq xc = c.S(r.xc[0]).slice(i0, ni);
+    return xva_hg_im2col1(wav, xc.ptr(), c.dt, ni / r.p, r.Tw, r.p, l0.k, l0.s, l0.P, l0.kp(), xc.Hp(), xc.padF, c.st);
+}
+int conv0_fwd(Ctx& c, const float* Pd, const DiscRun& r, int i0, int ni) {
+    const Layer& l0 = c.pl.dl[r.li[0]];
+    Seq xc = c.S(r.xc[0]).slice(i0, ni), t1 = c.S(r.t[1]).slice(i0, ni);
+    ConvEpi e; e.act = XVA_ACT_LRELU; e.act_slope = SLOPE;
+    return hg_conv_fwd(xc, t1, cw0(c, l0, Pd, r.pass), e, c.compute, c.st);
+}
 
 int sn_prepare(Ctx& c, float* Pd, const DiscRun& r) {
     for (int i = 0; i < r.n; ++i) {
@@ -474,6 +514,7 @@ int sn_prepare(Ctx& c, float* Pd, const DiscRun& r) {
         }
         if (l.eff32[r.pass] >= 0 && c.dt != XVA_F32)
             XVA_TRY(xva_hg_sn_scale(Pd + l.wv, c.F(l.norm[r.pass]), c.W + l.eff32[r.pass], XVA_F32, l.D0(), l.D1(), l.k, c.st));
+        if (l.Cin == 1) XVA_TRY(xva_hg_pad_cols(eff32(c, l, r.pass), c.W + l.wp[r.pass], c.dt, l.Cout, l.k, l.kp(), c.st));
     }
     return XVA_OK;
 }
@@ -481,12 +522,8 @@ int sn_prepare(Ctx& c, float* Pd, const DiscRun& r) {
 // forward of sequences [i0, i0 + ni) (ni = nb * p) fed from waveform `wav` (nb items)
 int disc_forward(Ctx& c, const float* Pd, const DiscRun& r, const float* wav, int i0, int ni) {
     const auto& L = c.pl.dl;
-    {
-        const Layer& l0 = L[r.li[0]];
-        Seq t1 = c.S(r.t[1]).slice(i0, ni);
-        XVA_TRY(xva_hg_cin1_fwd(wav, eff32(c, l0, r.pass), Pd + l0.bias, t1.ptr(), c.dt, ni / r.p, r.Tw, r.p, l0.k, l0.s, l0.P, l0.Cout, t1.Hp(), t1.padF,
-                                SLOPE, c.st));
-    }
+    XVA_TRY(conv0_im2col(c, r, wav, i0, ni));
+    XVA_TRY(conv0_fwd(c, Pd, r, i0, ni));
     for (int i = 1; i < r.n; ++i) {
         Seq x = c.S(r.t[i]).slice(i0, ni), y = c.S(r.t[i + 1]).slice(i0, ni);
         ConvEpi e;
@@ -516,14 +553,10 @@ int disc_backward_params(Ctx& c, const float* Pd, float* Gd, const DiscRun& r, i
         }
     }
     const Layer& l0 = L[r.li[0]];
-    Seq d1 = c.S(r.d[1]).slice(i0, ni);
-    const int ni_a = nb_a * r.p;
-    XVA_TRY(xva_hg_cin1_bwd_weight(wav_a, d1.ptr(), c.dt, c.F(l0.dweff[r.pass]), Gd + l0.bias, nb_a, r.Tw, r.p, l0.k, l0.s, l0.P, l0.Cout, d1.Hp(), d1.padF, c.st));
-    if (wav_b && ni > ni_a) {
-        Seq d1b = d1.slice(ni_a, ni - ni_a);
-        XVA_TRY(xva_hg_cin1_bwd_weight(wav_b, d1b.ptr(), c.dt, c.F(l0.dweff[r.pass]), Gd + l0.bias, (ni - ni_a) / r.p, r.Tw, r.p, l0.k, l0.s, l0.P, l0.Cout,
-                                       d1b.Hp(), d1b.padF, c.st));
-    }
+    Seq d1 = c.S(r.d[1]).slice(i0, ni), xc = c.S(r.xc[0]).slice(i0, ni);
+    (void)wav_a; (void)nb_a; (void)wav_b;   // the im2col of both waveforms is already in xc (forward)
+    XVA_TRY(hg_conv_bwd_weight(d1, xc, cw0(c, l0, Pd, r.pass), 0, 0.f, 1.f, c.compute, c.st));
+    XVA_TRY(xva_hg_colsum(d1.ptr(), c.dt, Gd + l0.bias, d1.rows(), d1.C, 1.f, c.st));
     return XVA_OK;
 }
 
@@ -549,8 +582,10 @@ int disc_backward_wave(Ctx& c, const float* Pd, const DiscRun& r, const SeqSpec*
         XVA_TRY(xva_hg_seed_grad(xr.ptr(), x.ptr(), dx.ptr(), c.dt, nf, x.Hp(), x.padF, x.T, x.C, 2.f / numel(i), 0.f, 0, 1, SLOPE, 0, c.st));
     }
     const Layer& l0 = L[r.li[0]];
-    Seq d1 = c.S(r.d[1]).slice(f0, nf);
-    return xva_hg_cin1_bwd_data(d1.ptr(), c.dt, eff32(c, l0, r.pass), dwav, nf / r.p, r.Tw, r.p, l0.k, l0.s, l0.P, l0.Cout, d1.Hp(), d1.padF, accumulate, c.st);
+    Seq d1 = c.S(r.d[1]).slice(f0, nf), dxc = c.S(r.xc[1]).slice(f0, nf);
+    BwdEpi b0;
+    XVA_TRY(hg_conv_bwd_data(d1, dxc, cw0(c, l0, Pd, r.pass), b0, c.compute, c.st));
+    return xva_hg_col2im1(dxc.ptr(), c.dt, dwav, nf / r.p, r.Tw, r.p, l0.k, l0.s, l0.P, l0.kp(), dxc.Hp(), dxc.padF, accumulate, c.st);
 }
 
 // loss sums: out[0] += mean((1-r)^2) + mean(g^2) (discriminator loss), out[1] += mean((1-g)^2) (generator loss),
@@ -575,7 +610,7 @@ struct DiscSet { DiscRun run; const SeqSpec* rt; int r0, f0, nf; bool sn; const 
 void build_sets(Ctx& c, const float* yr, const float* yg, std::vector<DiscSet>& out, std::vector<DiscRun>& sn_real) {
     const Plan& pl = c.pl; const DiscNet& N = dnet();
     for (int d5 = 0; d5 < NPER; ++d5) {
-        DiscSet s; s.run.li = N.mpd[d5]; s.run.n = 6; s.run.t = pl.pt[d5]; s.run.d = pl.pd[d5]; s.run.p = PERIODS[d5]; s.run.Tw = pl.seg; s.run.pass = 0;
+        DiscSet s; s.run.li = N.mpd[d5]; s.run.n = 6; s.run.t = pl.pt[d5]; s.run.d = pl.pd[d5]; s.run.xc = pl.pxc[d5]; s.run.p = PERIODS[d5]; s.run.Tw = pl.seg; s.run.pass = 0;
         s.rt = pl.pt[d5]; s.nf = pl.B * PERIODS[d5]; s.r0 = 0; s.f0 = s.nf; s.sn = false; s.wr = yr; s.wg = yg; s.nb = pl.B;
         out.push_back(s);
     }
@@ -584,10 +619,10 @@ void build_sets(Ctx& c, const float* yr, const float* yg, std::vector<DiscSet>& 
         const float* wg = sc == 0 ? yg : c.F(pl.wav_s[sc][1]);
         DiscSet s; s.run.li = N.msd[sc]; s.run.n = 8; s.run.p = 1; s.run.Tw = pl.Tw[sc]; s.nf = pl.B; s.wr = wr; s.wg = wg; s.nb = pl.B;
         if (sc == 0) {
-            s.run.t = pl.st[0][1]; s.run.d = pl.sd[0][1]; s.run.pass = 1; s.rt = pl.st[0][0]; s.r0 = 0; s.f0 = 0; s.sn = true;
-            DiscRun rr = s.run; rr.t = pl.st[0][0]; rr.d = pl.sd[0][0]; rr.pass = 0; sn_real.push_back(rr);
+            s.run.t = pl.st[0][1]; s.run.d = pl.sd[0][1]; s.run.xc = pl.sxc[0][1]; s.run.pass = 1; s.rt = pl.st[0][0]; s.r0 = 0; s.f0 = 0; s.sn = true;
+            DiscRun rr = s.run; rr.t = pl.st[0][0]; rr.d = pl.sd[0][0]; rr.xc = pl.sxc[0][0]; rr.pass = 0; sn_real.push_back(rr);
         } else {
-            s.run.t = pl.st[sc][0]; s.run.d = pl.sd[sc][0]; s.run.pass = 0; s.rt = pl.st[sc][0]; s.r0 = 0; s.f0 = pl.B; s.sn = false;
+            s.run.t = pl.st[sc][0]; s.run.d = pl.sd[sc][0]; s.run.xc = pl.sxc[sc][0]; s.run.pass = 0; s.rt = pl.st[sc][0]; s.r0 = 0; s.f0 = pl.B; s.sn = false;
         }
         out.push_back(s);
     }
@@ -617,13 +652,11 @@ int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* lo
             XVA_TRY(sn_prepare(c, Pd, s.run));
             XVA_TRY(disc_forward(c, Pd, s.run, s.wg, 0, s.nb));
         } else {
-            // conv0 per half (different waveforms), the GEMM layers jointly over real + fake
-            const auto& L = c.pl.dl; const Layer& l0 = L[s.run.li[0]];
-            Seq t1 = c.S(s.run.t[1]);
-            XVA_TRY(xva_hg_cin1_fwd(s.wr, eff32(c, l0, 0), Pd + l0.bias, t1.slice(0, s.nf).ptr(), c.dt, s.nb, s.run.Tw, s.run.p, l0.k, l0.s, l0.P, l0.Cout,
-                                    t1.Hp(), t1.padF, SLOPE, c.st));
-            XVA_TRY(xva_hg_cin1_fwd(s.wg, eff32(c, l0, 0), Pd + l0.bias, t1.slice(s.nf, s.nf).ptr(), c.dt, s.nb, s.run.Tw, s.run.p, l0.k, l0.s, l0.P, l0.Cout,
-                                    t1.Hp(), t1.padF, SLOPE, c.st));
+            // im2col per half (different waveforms), then every layer jointly over real + fake
+            const auto& L = c.pl.dl;
+            XVA_TRY(conv0_im2col(c, s.run, s.wr, 0, s.nf));
+            XVA_TRY(conv0_im2col(c, s.run, s.wg, s.nf, s.nf));
+            XVA_TRY(conv0_fwd(c, Pd, s.run, 0, 2 * s.nf));
             for (int i = 1; i < s.run.n; ++i) {
                 Seq x = c.S(s.run.t[i]), y = c.S(s.run.t[i + 1]);
                 ConvEpi e;
@@ -658,6 +691,7 @@ int discs_backward_d(Ctx& c, float* Pd, float* Gd, const float* yr, const float*
             XVA_TRY(disc_backward_params(c, Pd, Gd, s.run, 0, 2 * s.nf, s.wr, s.nb, s.wg));
         }
     }
+    XVA_TRY(fold_dwp(c, c.pl.dl));
     XVA_TRY(wn_backward(c, c.pl.dl, Pd, Gd));
     for (const Layer& l : c.pl.dl) {
         if (l.kind != LK_SN) continue;
