@@ -83,6 +83,10 @@ typedef struct xva_gemm_params {
     int32_t layout;         /* XVA_GEMM_* */
     int32_t a_dtype, b_dtype, c_dtype;
     int32_t c_trans;        /* 1: store C transposed: element (row, col) at C[col * ldc + row] */
+    /* TN only: the reduction index runs over `K / kb_len` blocks of kb_len rows (e.g. the items of a batch): row k of A / B
+     * lives at base + (k / kb_len) * kb_sA|kb_sB + (k % kb_len) * lda|ldb.  kb_len == 0 disables. */
+    int32_t kb_len;
+    int64_t kb_sA, kb_sB;
 } xva_gemm_params;
 
 /* Launches on `stream` (a hipStream_t); returns 0 or a negative XVA_ERR_* code. */

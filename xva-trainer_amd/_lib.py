@@ -52,7 +52,7 @@ class GemmParams(C.Structure):
         ("splitk", i32),
         ("compute", i32),
         ("layout", i32),
-        ("a_dtype", i32), ("b_dtype", i32), ("c_dtype", i32), ("c_trans", i32),
+        ("a_dtype", i32), ("b_dtype", i32), ("c_dtype", i32), ("c_trans", i32), ("kb_len", i32), ("kb_sA", i64), ("kb_sB", i64),
     ]
 
 

@@ -43,6 +43,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
                        p.mask_add >= 0 && (p.mask_mode == XVA_MASK_PAD || p.lens)),
                   "xva_gemm: bad row-mask arguments");
     XVA_CHECK_ARG(p.accumulate != 2 || p.c_dtype == XVA_F32, "xva_gemm: atomic accumulation needs an fp32 C");
+    XVA_CHECK_ARG(p.kb_len == 0 || (p.layout == XVA_GEMM_TN && p.kb_len > 0 && p.kb_sA % ve == 0 && p.kb_sB % ve == 0), "xva_gemm: bad K-block arguments");
     if (p.K == 0) p.splitk = 1;
     int nkt = xva_cdiv(p.K, 32);
     if (p.splitk > nkt && nkt > 0) p.splitk = nkt;

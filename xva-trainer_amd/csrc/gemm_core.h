@@ -170,7 +170,8 @@ struct IcStage {
     }
     // rowptr(k) = rowbase + k * ld ; column offset `coloff` (segment adjusted, per thread constant)
     template <bool TAIL>
-    __device__ __forceinline__ void load(const typename C::S* const (&rowbases)[KH], int64_t ld, int64_t col, int k0, int Kbound) {
+    __device__ __forceinline__ void load(const typename C::S* const (&rowbases)[KH], int64_t ld, int64_t col, int k0, int Kbound,
+                                         int kb_len = 0, int64_t kb_stride = 0) {
         if (!active()) return;
         int kg, icol;
         coords(kg, icol);
@@ -180,10 +181,18 @@ struct IcStage {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = k0 + kh * 32 + kg * 4 + j;
+                int64_t roff = (int64_t)k * ld;
+                if (kb_len > 0) {   // K runs over blocks of kb_len rows (batch items): k -> (block, row in block)
+                    const int kc = k < Kbound ? k : Kbound - 1;
+                    int blk = (int)(((float)kc + 0.5f) / (float)kb_len);
+                    if ((int64_t)blk * kb_len > kc) --blk;
+                    if ((int64_t)(blk + 1) * kb_len <= kc) ++blk;
+                    roff = (int64_t)blk * kb_stride + (int64_t)(kc - blk * kb_len) * ld;
+                }
                 if constexpr (TAIL) {
-                    v[kh * 4 + j] = (k < Kbound) ? *reinterpret_cast<const uint4*>(rowbase + (int64_t)k * ld + col) : make_uint4(0u, 0u, 0u, 0u);
+                    v[kh * 4 + j] = (k < Kbound) ? *reinterpret_cast<const uint4*>(rowbase + roff + col) : make_uint4(0u, 0u, 0u, 0u);
                 } else {
-                    v[kh * 4 + j] = *reinterpret_cast<const uint4*>(rowbase + (int64_t)k * ld + col);
+                    v[kh * 4 + j] = *reinterpret_cast<const uint4*>(rowbase + roff + col);
                 }
             }
         }
@@ -341,15 +350,15 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
             }
         }
         if (!tail) {
-            if constexpr (LAYOUT == XVA_GEMM_TN) ia.template load<false>(abase, p.lda, ia_col, k0, p.K);
+            if constexpr (LAYOUT == XVA_GEMM_TN) ia.template load<false>(abase, p.lda, ia_col, k0, p.K, p.kb_len, p.kb_sA);
             else ka.template load<false>(A, p.lda, m0, p.M, k0, p.K, aoff);
             if constexpr (LAYOUT == XVA_GEMM_NT) kb.template load<false>(B, p.ldb, n0, p.N, k0, p.K, 0);
-            else ib.template load<false>(bbase, p.ldb, ib_col, k0, p.K);
+            else ib.template load<false>(bbase, p.ldb, ib_col, k0, p.K, LAYOUT == XVA_GEMM_TN ? p.kb_len : 0, p.kb_sB);
         } else {
-            if constexpr (LAYOUT == XVA_GEMM_TN) ia.template load<true>(abase, p.lda, ia_col, k0, p.K);
+            if constexpr (LAYOUT == XVA_GEMM_TN) ia.template load<true>(abase, p.lda, ia_col, k0, p.K, p.kb_len, p.kb_sA);
             else ka.template load<true>(A, p.lda, m0, p.M, k0, p.K, aoff);
             if constexpr (LAYOUT == XVA_GEMM_NT) kb.template load<true>(B, p.ldb, n0, p.N, k0, p.K, 0);
-            else ib.template load<true>(bbase, p.ldb, ib_col, k0, p.K);
+            else ib.template load<true>(bbase, p.ldb, ib_col, k0, p.K, LAYOUT == XVA_GEMM_TN ? p.kb_len : 0, p.kb_sB);
         }
     };
     const bool a_act = p.a_lrelu != 0, b_act = p.b_lrelu != 0;

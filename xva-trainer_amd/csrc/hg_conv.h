@@ -182,8 +182,10 @@ inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x
         g.K = (int)dY.rows();
         g.accumulate = 1; g.splitk = hg_splitk(g.M, g.N, g.K, w.groups);
     } else {
-        g.batch = X.nseq; g.sC = 0; g.K = dY.T; g.accumulate = 2;
-        if (!swap) { g.sA = dY.item(); g.sB = X.item(); } else { g.sA = X.item(); g.sB = dY.item(); }
+        // per-item geometry: the reduction still runs over ALL items in one split-K GEMM (K blocks of T_out rows)
+        g.K = (int)((int64_t)X.nseq * dY.T); g.kb_len = dY.T;
+        if (!swap) { g.kb_sA = dY.item(); g.kb_sB = X.item(); } else { g.kb_sA = X.item(); g.kb_sB = dY.item(); }
+        g.accumulate = 1; g.splitk = hg_splitk(g.M, g.N, g.K, w.groups);
     }
     return xva_gemm(&g, st);
 }
@@ -242,6 +244,7 @@ inline int hg_convT_bwd_weight(const Seq& dY, const Seq& X, const ConvTW& w, int
     g.B = (const char*)dY.valid() - (int64_t)w.p * dY.C * dY.es();
     g.C = w.dweff; g.c_dtype = XVA_F32;
     g.a_lrelu = x_lrelu; g.a_slope = x_slope;
-    g.batch = X.nseq; g.sA = X.item(); g.sB = dY.item(); g.sC = 0; g.accumulate = 2;
+    g.K = (int)((int64_t)X.nseq * X.T); g.kb_len = X.T; g.kb_sA = X.item(); g.kb_sB = dY.item();
+    g.accumulate = 1; g.splitk = hg_splitk(g.M, g.N, g.K, 1);
     return xva_gemm(&g, st);
 }
