@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--t-mel", type=int, default=860)
     ap.add_argument("--stage", type=int, default=3)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dropout", type=float, default=0.1, help="FastPitch dropout probability (reference trains with 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hifigan", action="store_true", help="skip the HiFi-GAN audio-samples/s leg")
@@ -157,7 +158,7 @@ def main():
     from xva_trainer_amd.fastpitch.dp import GradSync
 
     torch.manual_seed(1234 + rank)
-    eng = E.FastPitchEngine(dev, a.compute)
+    eng = E.FastPitchEngine(dev, a.compute, p_dropout=a.dropout, seed=1234 + rank)
     flat = torch.zeros(eng.total, device=dev)
     P.default_init_(flat, eng.table, seed=1234)          # identical replicas on every rank
     grads = torch.zeros_like(flat)
@@ -214,8 +215,9 @@ def main():
         "value": total_frames * a.steps / dt, "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.compute, "data": "synthetic",
-        "config": {"workload": "FastPitch1.1 stage-%d full train step (fwd+loss+bwd%s+clip+fused LAMB), batch %d/GPU, %d tokens x %d mel frames, dropout off"
-                               % (stage, "+RCCL grad all-reduce" if world > 1 else "", a.batch, a.t_text, a.t_mel),
+        "config": {"workload": "FastPitch1.1 stage-%d full train step (fwd+loss+bwd%s+clip+fused LAMB), batch %d/GPU, %d tokens x %d mel frames, dropout p=%g, %s activations"
+                               % (stage, "+RCCL grad all-reduce" if world > 1 else "", a.batch, a.t_text, a.t_mel, a.dropout,
+                                  "bf16" if a.compute == "bf16" else "fp32"),
                    "global_batch": a.batch * world, "per_gpu_frames_per_step": frames_per_step, "parallelism": "dp%d" % world,
                    "final_loss": loss},
     }

@@ -57,7 +57,7 @@ typedef struct xva_gemm_params {
     /* operand transforms applied while staging (LeakyReLU fused into the consumer): x -> x > 0 ? x : slope * x */
     int32_t a_lrelu, b_lrelu;
     float a_slope, b_slope;
-    /* epilogue: v = alpha * (acc + bias[col]) ; v *= (G > 0 ? 1 : gate_slope) ; v += beta * R ; act ; row-mask ; store */
+    /* epilogue: v = alpha * (acc + bias[col]) ; dropout ; v *= (G > 0 ? 1 : gate_slope) ; v += beta * R ; act ; row-mask ; store */
     float alpha, beta;
     const float* bias;      /* [N] fp32 or NULL; second-level batch z2 reads bias + z2 * sbias2 */
     int64_t sbias2;
@@ -87,6 +87,10 @@ typedef struct xva_gemm_params {
      * lives at base + (k / kb_len) * kb_sA|kb_sB + (k % kb_len) * lda|ldb.  kb_len == 0 disables. */
     int32_t kb_len;
     int64_t kb_sA, kb_sB;
+    /* epilogue dropout (nn.Dropout on the GEMM output before the residual add): v *= 0 or 1/(1-p), mask = hash(seed, stream, row*N+col) */
+    float drop_p;
+    uint64_t drop_seed;
+    uint32_t drop_stream;
 } xva_gemm_params;
 
 /* Launches on `stream` (a hipStream_t); returns 0 or a negative XVA_ERR_* code. */

@@ -79,13 +79,16 @@ int xva_mel_l1_loss_backward(const xva_mel_config* cfg, const float* wav, int B,
  * Sequence tensors are "padded token-major": (B, T+2, C) fp32, row 0 and row T+1 of each item structurally
  * zero, rows 1..len live.  Parameters / gradients are ONE flat fp32 buffer laid out by xva_fp_tensor_info
  * (conv k=3 weights stored tap-major [Cout][3][Cin]; `kind` = 1 marks them — the host permutes to/from the
- * checkpoint layout [Cout][Cin][3]).  The workspace must be zero-filled ONCE when allocated (guard rows). */
+ * checkpoint layout [Cout][Cin][3]).  The workspace must be zero-filled ONCE when allocated (guard rows).  Activation
+ * slots are dtype-dependent (fp32 or bf16 per dims.compute): xva_fp_slot_offset returns BYTE offsets. */
 typedef struct xva_fp_dims {
     int32_t B;        /* items in the micro-batch */
     int32_t Tt;       /* padded text length  (max_inp_lengths[0]) */
     int32_t Tm;       /* padded mel length   (max_mel_lengths[0]) */
     int32_t stage;    /* training stage 2, 3 or 4 (model.training_stage) */
-    int32_t compute;  /* 0: exact fp32 MFMA (parity mode), 1: bf16-input MFMA with fp32 accumulation */
+    int32_t compute;  /* 0: fp32 activations + exact fp32 MFMA (parity mode); 1: bf16 activations + bf16-input MFMA (fp32 accumulate) */
+    float p_dropout;  /* 0.1 in the reference's training mode (model.py:149-174: dropout, dropatt, predictor dropout); 0 = eval */
+    uint64_t seed;    /* dropout seed of this micro-batch (forward and backward must pass the same value) */
 } xva_fp_dims;
 
 typedef struct xva_fp_batch {
@@ -124,10 +127,10 @@ int xva_fp_tensor_info(int i, char* name, int name_cap, int64_t* offset, int64_t
                        int32_t* kind);
 int xva_fp_trainable_ranges(int stage, int64_t* begins, int64_t* ends, int cap);
 int64_t xva_fp_workspace_bytes(const xva_fp_dims* d);
-int xva_fp_slot_offset(const xva_fp_dims* d, int slot, int64_t* off_floats);
-int xva_fp_forward(const xva_fp_dims* d, const float* params, const xva_fp_batch* batch, float* workspace,
+int xva_fp_slot_offset(const xva_fp_dims* d, int slot, int64_t* off_bytes);
+int xva_fp_forward(const xva_fp_dims* d, const float* params, const xva_fp_batch* batch, void* workspace,
                    int64_t workspace_bytes, void* stream);
-int xva_fp_backward(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* batch, float* workspace,
+int xva_fp_backward(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* batch, void* workspace,
                     int64_t workspace_bytes, void* stream);
 
 /* Data-parallel overlap: gradient buckets (contiguous flat ranges, in backward completion order) and a backward
@@ -135,50 +138,55 @@ int xva_fp_backward(const xva_fp_dims* d, const float* params, float* grads, con
  * stream (replaces nn.DataParallel's reduce_add_coalesced, python/fastpitch1_1/xva_train.py:48-53,465-466). */
 int xva_fp_num_buckets(void);
 int xva_fp_bucket_range(int i, int64_t* begin, int64_t* end);
-int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* batch, float* workspace,
+int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* batch, void* workspace,
                        int64_t workspace_bytes, void* const* bucket_events, void* stream);
 void* xva_event_create(void);
 int xva_event_destroy(void* event);
 int xva_event_record(void* event, void* stream);
 int xva_stream_wait_event(void* stream, void* event);
 
-/* FastPitchLoss in two phases (so data-parallel ranks can all-reduce `acc` in between: global normalisation). */
-int xva_fp_loss_partials(int stage, const float* mel_out, const float* mel_tgt, const float* pitch_pred, const float* pitch_tgt,
+/* FastPitchLoss in two phases (so data-parallel ranks can all-reduce `acc` in between: global normalisation).
+ * mel_out / d_mel are activation-dtype tensors (dt); the token-level predictions and targets are fp32. */
+int xva_fp_loss_partials(int stage, int dt, const void* mel_out, const float* mel_tgt, const float* pitch_pred, const float* pitch_tgt,
                          const float* energy_pred, const float* energy_tgt, const float* log_dur_pred, const int32_t* durs,
                          const int32_t* in_lens, float* acc, int B, int Tt, int Tm, void* stream);
-int xva_fp_loss_grads(int stage, const float* mel_out, const float* mel_tgt, const float* pitch_pred, const float* pitch_tgt,
+int xva_fp_loss_grads(int stage, int dt, const void* mel_out, const float* mel_tgt, const float* pitch_pred, const float* pitch_tgt,
                       const float* energy_pred, const float* energy_tgt, const float* log_dur_pred, const int32_t* durs,
-                      const int32_t* in_lens, const float* acc, float* losses_out, float* d_mel, float* d_pitch, float* d_energy,
+                      const int32_t* in_lens, const float* acc, float* losses_out, void* d_mel, float* d_pitch, float* d_energy,
                       float* d_logdur, int B, int Tt, int Tm, float grad_scale, float dur_w, float pitch_w, float energy_w,
                       void* stream);
 
-/* Individual kernels of the path (each is also used on its own by the parity tests). */
-int xva_fp_embed_fwd(const int32_t* ids, const float* emb, const float* pos, float* out, int B, int T, int C, void* stream);
-int xva_fp_embed_bwd(const int32_t* ids, const float* dX, float* dEmb, int B, int T, int C, void* stream);
-int xva_fp_softmax_fwd(float* S, const int32_t* lens, int B, int Tp, int64_t Ts, float p_drop, uint64_t seed, uint32_t stream_id,
-                       void* stream);
-int xva_fp_softmax_bwd(const float* P, float* dP, int B, int Tp, int64_t Ts, float scale, float p_drop, uint64_t seed,
+/* Individual kernels of the path.  Activation tensors are `void*` of dtype dt (XVA_F32 / XVA_BF16); parameters, statistics
+ * and token-level scalars are fp32.  Dropout masks are a pure function of (seed, stream_id, element index). */
+int xva_fp_embed_fwd(const int32_t* ids, const float* emb, const float* pos, void* out, int dt, int B, int T, int C, void* stream);
+int xva_fp_embed_bwd(const int32_t* ids, const void* dX, int dt, float* dEmb, int B, int T, int C, void* stream);
+int xva_fp_softmax_fwd(void* S, void* P_dropped, int dt, const int32_t* lens, int B, int Tp, int64_t Ts, float p_drop, uint64_t seed,
                        uint32_t stream_id, void* stream);
-int xva_fp_layernorm_fwd(const float* X, const float* gamma, const float* beta, float* Y, float* mean, float* rstd, int64_t rows,
-                         int C, int mask_mode, const int32_t* lens, int Tp, void* stream);
-int xva_fp_layernorm_bwd(const float* dY, const float* X, const float* mean, const float* rstd, const float* gamma, float* dX,
-                         float* dgamma, float* dbeta, int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp,
-                         int relu_gate, void* stream);
-int xva_fp_colsum(const float* X, float* out, int64_t rows, int C, int64_t ld, void* stream);
+int xva_fp_softmax_bwd(const void* P, void* dP, int dt, int B, int Tp, int64_t Ts, float scale, float p_drop, uint64_t seed,
+                       uint32_t stream_id, void* stream);
+int xva_fp_layernorm_fwd(const void* X, const float* gamma, const float* beta, void* Y, int dt, float* mean, float* rstd, int64_t rows,
+                         int C, int mask_mode, const int32_t* lens, int Tp, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+int xva_fp_layernorm_bwd(const void* dY, const void* X, const float* mean, const float* rstd, const float* gamma, void* dX, void* dX_masked,
+                         int dt, float* dgamma, float* dbeta, int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp, int relu_gate,
+                         float p_in, uint64_t seed_in, uint32_t stream_in, float p_out, uint64_t seed_out, uint32_t stream_out,
+                         const float* outer_d, const float* outer_w, void* stream);  /* outer_*: dY[r][c] = outer_d[r] * outer_w[c] (fp32), dY ignored */
+int xva_fp_colsum(const void* X, int dt, float* out, int64_t rows, int C, int64_t ld, void* stream);
 int xva_fp_avg_pitch(const float* dense, const int32_t* durs, float* avg_out, int B, int Tt, int Tm, int log1p_, void* stream);
 int xva_fp_lenreg_map(const int32_t* durs, int32_t* tok, int32_t* tstart, int32_t* dec_lens, int B, int Tt, int Tm, float pace,
                       void* stream);
-int xva_fp_cond_add_fwd(const float* in, const float* s, const float* w, const float* bias, float* out, const int32_t* lens,
+int xva_fp_cond_add_fwd(const void* in, const float* s, const float* w, const float* bias, void* out, int dt, const int32_t* lens,
                         int B, int Tp, int C, void* stream);
-int xva_fp_cond_add_bwd(const float* dOut, const float* s, float* dw, float* db, const int32_t* lens, int B, int Tp, int C,
+int xva_fp_cond_add_bwd(const void* dOut, int dt, const float* s, float* dw, float* db, const int32_t* lens, int B, int Tp, int C,
                         void* stream);
-int xva_fp_lenreg_fwd(const float* enc, const int32_t* tok, const int32_t* dec_lens, const float* pos, float* out, int B, int Tt,
+int xva_fp_lenreg_fwd(const void* enc, const int32_t* tok, const int32_t* dec_lens, const float* pos, void* out, int dt, int B, int Tt,
                       int Tm, int C, void* stream);
-int xva_fp_lenreg_bwd(const float* dOut, const int32_t* tstart, const int32_t* dec_lens, float* dEnc, int B, int Tt, int Tm, int C,
+int xva_fp_lenreg_bwd(const void* dOut, const int32_t* tstart, const int32_t* dec_lens, void* dEnc, int dt, int B, int Tt, int Tm, int C,
                       int accumulate, void* stream);
-int xva_fp_outer(const float* s, const float* w, float* out, int64_t rows, int C, void* stream);
-int xva_fp_rowscale_colsum(const float* X, const float* s, float* out, int64_t rows, int C, void* stream);
+int xva_fp_outer(const float* s, const float* w, void* out, int dt, int64_t rows, int C, void* stream);
+int xva_fp_rowscale_colsum(const void* X, int dt, const float* s, float* out, int64_t rows, int C, void* stream);
 int xva_fp_dur_from_log(const float* logd, float* out, int n, float max_dur, void* stream);
+int xva_cast_f32(const float* src, void* dst, int dt, int64_t n, void* stream);
+int xva_cast_to_f32(const void* src, int dt, float* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------ optimizers ---- */
 /* Fused multi-tensor LAMB over the flat buffers = torch.nn.utils.clip_grad_norm_(.., max_grad_norm) followed by

@@ -10,7 +10,10 @@ checkpoint feeds the reference, this oracle and the HIP path.  Restates:
   FastPitchLoss.forward               python/fastpitch1_1/fastpitch/loss_function.py:63-154
   Lamb.step                           python/fastpitch1_1/lamb.py:40-106
   adjust_learning_rate                python/fastpitch1_1/xva_train.py:1252-1261
-Dropout is omitted (goldens are taken with model.eval(); see SURVEY.md §7 "hard parts").
+Dropout: the goldens are taken with model.eval() (torch's dropout RNG stream cannot be reproduced by another implementation;
+SURVEY.md §7 "hard parts").  For the training-mode check the oracle applies nn.Dropout's arithmetic (x * m / (1 - p)) at the
+reference's sites (transformer.py:51,127,139; common/layers.py:97) with the masks supplied by a callable — HashDropout below
+restates the HIP path's stateless mask function, so both sides drop the same elements.
 Stage 1 (ConvAttention + MAS) is a "next" row and is not restated yet.
 """
 import math
@@ -37,27 +40,78 @@ def positional_embedding(T, demb, dtype):
     return torch.cat([sinusoid.sin(), sinusoid.cos()], dim=1)[None]
 
 
-def _mha(sd, pre, inp, key_pad_mask):
+class HashDropout:
+    """Mask source equal to xva_dropout_scale (xva-trainer_amd/csrc/xva_common.h): element idx of dropout site `stream` is dropped
+    iff (murmur-style hash(seed, stream, idx) >> 8) * 2^-24 < p; kept elements are scaled by 1/(1-p).  Indices follow the HIP
+    path's padded layouts: activations (B, T+2, C) row-major, attention probabilities rows of T+2 columns."""
+
+    def __init__(self, p, seed):
+        import numpy as np
+        self.np = np
+        self.p = np.float32(p)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+
+    def _mult(self, stream, idx):
+        np = self.np
+        with np.errstate(over="ignore"):
+            x = idx.astype(np.uint64) + np.uint64((0x9E3779B97F4A7C15 * (stream + 1) + self.seed) & 0xFFFFFFFFFFFFFFFF)
+            x ^= x >> np.uint64(33); x *= np.uint64(0xff51afd7ed558ccd)
+            x ^= x >> np.uint64(33); x *= np.uint64(0xc4ceb9fe1a85ec53)
+            x ^= x >> np.uint64(33)
+        h = (x & np.uint64(0xFFFFFFFF)) >> np.uint64(8)
+        u = h.astype(np.float32) * np.float32(1.0 / 16777216.0)
+        keep = np.float32(1.0) / (np.float32(1.0) - self.p)
+        return np.where(u < self.p, np.float32(0.0), keep).astype(np.float32)
+
+    def act(self, stream, x):
+        """x: (B, T, C) activation; padded row index = b * (T + 2) + t + 1."""
+        if self.p <= 0:
+            return x
+        np = self.np
+        B, T, C = x.shape
+        rows = (np.arange(B, dtype=np.uint64)[:, None] * np.uint64(T + 2) + np.arange(1, T + 1, dtype=np.uint64)[None, :])
+        idx = rows[:, :, None] * np.uint64(C) + np.arange(C, dtype=np.uint64)[None, None, :]
+        return x * torch.from_numpy(self._mult(stream, idx)).to(x.dtype)
+
+    def prob(self, stream, pr):
+        """pr: (B, T, T) attention probabilities; index = (b * Tp + i + 1) * Tp + j + 1 with Tp = T + 2."""
+        if self.p <= 0:
+            return pr
+        np = self.np
+        B, T, _ = pr.shape
+        Tp = np.uint64(T + 2)
+        rows = (np.arange(B, dtype=np.uint64)[:, None] * Tp + np.arange(1, T + 1, dtype=np.uint64)[None, :])
+        idx = rows[:, :, None] * Tp + np.arange(1, T + 1, dtype=np.uint64)[None, None, :]
+        return pr * torch.from_numpy(self._mult(stream, idx)).to(pr.dtype)
+
+
+def _mha(sd, pre, inp, key_pad_mask, drop=None, site=0):
     qkv = F.linear(inp, sd[pre + "qkv_net.weight"], sd[pre + "qkv_net.bias"])
     q, k, v = torch.chunk(qkv, 3, dim=2)
     score = torch.bmm(q, k.transpose(1, 2)) * (1 / (D_HEAD ** 0.5))
     score = score.masked_fill(key_pad_mask.unsqueeze(1), -float("inf"))
     prob = F.softmax(score, dim=2)
+    if drop is not None:
+        prob = drop.prob(site + 0, prob)                      # dropatt, transformer.py:127
     vec = torch.bmm(prob, v)
     out = F.linear(vec, sd[pre + "o_net.weight"])
+    if drop is not None:
+        out = drop.act(site + 1, out)                         # drop, transformer.py:139
     return F.layer_norm(inp + out, (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"])
 
 
-def _conv_ff(sd, pre, inp):
+def _conv_ff(sd, pre, inp, drop=None, site=0):
     core = inp.transpose(1, 2)
     core = F.conv1d(core, sd[pre + "CoreNet.0.weight"], sd[pre + "CoreNet.0.bias"], padding=1)
     core = F.relu(core)
     core = F.conv1d(core, sd[pre + "CoreNet.2.weight"], sd[pre + "CoreNet.2.bias"], padding=1)
     core = core.transpose(1, 2)
+    if drop is not None:
+        core = drop.act(site + 2, core)                       # CoreNet's trailing nn.Dropout, transformer.py:51
     return F.layer_norm(inp + core, (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"])
 
 
-def fft_transformer(sd, pre, dec_inp, seq_lens=None, embed=False, taps=None):
+def fft_transformer(sd, pre, dec_inp, seq_lens=None, embed=False, taps=None, drop=None, site=0):
     if embed:
         inp = F.embedding(dec_inp, sd[pre + "word_emb.weight"], padding_idx=0)
         mask = (dec_inp != 0).unsqueeze(2)
@@ -70,22 +124,25 @@ def fft_transformer(sd, pre, dec_inp, seq_lens=None, embed=False, taps=None):
         taps[pre + "in"] = out
     for i in range(N_LAYERS):
         lp = "%slayers.%d." % (pre, i)
-        out = _mha(sd, lp + "dec_attn.", out, ~mask.squeeze(2))
+        out = _mha(sd, lp + "dec_attn.", out, ~mask.squeeze(2), drop, site + 4 * i)
         out = out * mask
-        out = _conv_ff(sd, lp + "pos_ff.", out)
+        out = _conv_ff(sd, lp + "pos_ff.", out, drop, site + 4 * i)
         out = out * mask
         if taps is not None:
             taps[lp + "out"] = out
     return out, mask
 
 
-def temporal_predictor(sd, pre, enc_out, enc_mask):
+def temporal_predictor(sd, pre, enc_out, enc_mask, drop=None, site=0):
     out = (enc_out * enc_mask).transpose(1, 2)
     for i in range(2):
         lp = "%slayers.%d." % (pre, i)
         out = F.relu(F.conv1d(out, sd[lp + "conv.weight"], sd[lp + "conv.bias"], padding=1))
         C = out.size(1)
-        out = F.layer_norm(out.transpose(1, 2), (C,), sd[lp + "norm.weight"], sd[lp + "norm.bias"]).transpose(1, 2)
+        out = F.layer_norm(out.transpose(1, 2), (C,), sd[lp + "norm.weight"], sd[lp + "norm.bias"])
+        if drop is not None:
+            out = drop.act(site + i, out)                     # ConvReLUNorm dropout, common/layers.py:97
+        out = out.transpose(1, 2)
     out = out.transpose(1, 2)
     return F.linear(out, sd[pre + "fc.weight"], sd[pre + "fc.bias"]) * enc_mask
 
@@ -118,22 +175,25 @@ def average_pitch(pitch, durs):
     return torch.where(nel == 0.0, nel, sums / nel).to(pitch.dtype)
 
 
-def forward(sd, batch, stage, taps=None):
+DS_ENC, DS_DEC, DS_PRED = 0, 100, 200      # dropout site (stream) numbering shared with fastpitch_engine.hip
+
+
+def forward(sd, batch, stage, taps=None, drop=None):
     """batch: dict(text (B,Tt) int64, in_lens, mel_tgt (B,80,Tm), mel_lens, pitch (B,1,Tm), energy (B,Tm),
     durs (B,Tt) int).  Returns the reference's 13-slot output list (model.py:388-390)."""
     text, mel_lens = batch["text"], batch["mel_lens"]
     mel_max_len = int(mel_lens.max())
-    enc_out, enc_mask = fft_transformer(sd, "encoder.", text, embed=True, taps=taps)
+    enc_out, enc_mask = fft_transformer(sd, "encoder.", text, embed=True, taps=taps, drop=drop, site=DS_ENC)
     dur_tgt = batch["durs"]
     if stage == 2:
-        log_dur_pred = temporal_predictor(sd, "duration_predictor.", enc_out, enc_mask).squeeze(-1)
+        log_dur_pred = temporal_predictor(sd, "duration_predictor.", enc_out, enc_mask, drop, DS_PRED + 0).squeeze(-1)
         dur_pred = torch.clamp(torch.exp(log_dur_pred) - 1, 0, 75)
         return [None, None, dur_pred, log_dur_pred, None, None, None, None, None, None, dur_tgt, None, batch["in_lens"]]
-    pitch_pred = temporal_predictor(sd, "pitch_predictor.", enc_out, enc_mask).permute(0, 2, 1)
+    pitch_pred = temporal_predictor(sd, "pitch_predictor.", enc_out, enc_mask, drop, DS_PRED + 2).permute(0, 2, 1)
     pitch_tgt = average_pitch(batch["pitch"], dur_tgt)
     pitch_emb = F.conv1d(pitch_tgt, sd["pitch_emb.weight"], sd["pitch_emb.bias"], padding=1)
     enc_out = enc_out + pitch_emb.transpose(1, 2)
-    energy_pred = temporal_predictor(sd, "energy_predictor.", enc_out, enc_mask).squeeze(-1)
+    energy_pred = temporal_predictor(sd, "energy_predictor.", enc_out, enc_mask, drop, DS_PRED + 4).squeeze(-1)
     energy_tgt = torch.log(1.0 + average_pitch(batch["energy"].unsqueeze(1), dur_tgt))
     energy_emb = F.conv1d(energy_tgt, sd["energy_emb.weight"], sd["energy_emb.bias"], padding=1)
     energy_tgt = energy_tgt.squeeze(1)
@@ -141,7 +201,7 @@ def forward(sd, batch, stage, taps=None):
     if taps is not None:
         taps["enc_cond"] = enc_out
     len_regulated, dec_lens = regulate_len(dur_tgt, enc_out, 1.0, mel_max_len)
-    dec_out, dec_mask = fft_transformer(sd, "decoder.", len_regulated, seq_lens=dec_lens, taps=taps)
+    dec_out, dec_mask = fft_transformer(sd, "decoder.", len_regulated, seq_lens=dec_lens, taps=taps, drop=drop, site=DS_DEC)
     mel_out = F.linear(dec_out, sd["proj.weight"], sd["proj.bias"])
     return [mel_out, dec_mask, None, None, pitch_pred, pitch_tgt, energy_pred, energy_tgt, None, None, dur_tgt, None,
             batch["in_lens"]]

@@ -83,10 +83,13 @@ def test_against_reference_golden(golden_dir, case):
         assert rel(after["proj.weight"], torch.from_numpy(g["new_proj_weight"])) < 1e-5
 
 
-@pytest.mark.parametrize("compute,tol_out,tol_grad", [("fp32", 1e-3, 2e-3), ("bf16", 5e-2, 1e-1)])
+@pytest.mark.parametrize("compute,tol_out,tol_grad", [("fp32", 1e-3, 2e-3), ("bf16", 5e-2, 1.5e-1)])
 @pytest.mark.parametrize("stage", [3, 4, 2])
 def test_against_oracle_ragged(compute, tol_out, tol_grad, stage):
-    """Larger ragged batch (different text/mel lengths per item, several MFMA tiles per GEMM) vs the CPU oracle."""
+    """Larger ragged batch (different text/mel lengths per item, several MFMA tiles per GEMM) vs the CPU oracle.
+    fp32 is the parity mode (north_star: 1e-3 relative).  bf16 is the throughput mode (bf16-stored activations, fp32 master
+    weights / statistics / gradients): its per-tensor bound is loose because the random-init pitch predictor's gradient is a
+    sum of near-cancelling terms (sum(pred - tgt) ~ 3 % of sum|pred - tgt|), so the whole-gradient direction is checked too."""
     from oracle import fastpitch as ofp
     torch.manual_seed(0)
     sd = ofp.init_state_dict(77)
@@ -112,6 +115,55 @@ def test_against_oracle_ragged(compute, tol_out, tol_grad, stage):
     bad, worst = grad_report(eng, grads, ref_grads, tol_grad)
     print("worst grad tensor:", worst)
     assert not bad, bad[:10]
+    from xva_trainer_amd.fastpitch import params as P
+    mine = P.from_flat(grads, eng.table)
+    a = torch.cat([mine[k].double().cpu().flatten() for k in ref_grads])
+    r = torch.cat([ref_grads[k].double().flatten() for k in ref_grads])
+    cos = (a @ r / (a.norm() * r.norm())).item()
+    assert cos > (1 - 1e-6 if compute == "fp32" else 0.9995), cos
+
+
+@pytest.mark.parametrize("compute,tol_out,tol_grad", [("fp32", 1e-3, 2e-3), ("bf16", 5e-2, 1.5e-1)])
+@pytest.mark.parametrize("stage", [3, 2])
+def test_training_dropout_against_oracle(compute, tol_out, tol_grad, stage):
+    """Training mode (p = 0.1 at every dropout site of transformer.py:51,127,139 and common/layers.py:97): the HIP path's masks
+    are a pure function of (seed, site, index); the oracle applies nn.Dropout's arithmetic with the same masks, so outputs,
+    loss and every gradient must agree as tightly as without dropout.  Step 2 of the same engine draws different masks."""
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd.fastpitch import engine as E, params as P
+    sd = ofp.init_state_dict(31)
+    batch = ofp.synth_batch(3, 29, 150, 32)
+    names = ofp.trainable_names(sd.keys(), stage)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd); work.update(leaves)
+    seed = 987654321
+    out_ref = ofp.forward(work, batch, stage, drop=ofp.HashDropout(0.1, seed))
+    out_nodrop = ofp.forward(sd, batch, stage)
+    loss_ref, comps = ofp.loss(out_ref, batch, stage)
+    loss_ref.backward()
+    ref_grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    eng = E.FastPitchEngine("cuda", compute, p_dropout=0.1, seed=seed)
+    flat = torch.zeros(eng.total, device="cuda")
+    P.to_flat(sd, eng.table, flat)
+    grads = torch.zeros_like(flat)
+    b, losses = _run(eng, flat, grads, batch, stage)
+    out = eng.outputs(b, stage)
+    if stage == 2:
+        assert rel(out["log_dur_pred"], out_ref[3]) < tol_out
+        assert rel(out_nodrop[3], out_ref[3]) > 0.05            # dropout really changed the network
+    else:
+        assert rel(out["mel_out"], out_ref[0]) < tol_out
+        assert rel(out["pitch_pred"], out_ref[4]) < tol_out
+        assert rel(out["energy_pred"], out_ref[6]) < tol_out
+        assert rel(out_nodrop[0], out_ref[0]) > 0.05
+    assert abs(losses[0].item() - loss_ref.item()) < tol_out * abs(loss_ref.item())
+    bad, worst = grad_report(eng, grads, ref_grads, tol_grad)
+    print("worst grad tensor:", worst)
+    assert not bad, bad[:10]
+    first = (out["log_dur_pred"] if stage == 2 else out["mel_out"]).float().clone()
+    _run(eng, flat, grads, batch, stage)                         # next step: new masks
+    second = (eng.outputs(b, stage)["log_dur_pred"] if stage == 2 else eng.outputs(b, stage)["mel_out"]).float()
+    assert rel(second, first) > 0.02
 
 
 def test_gradient_accumulation_and_grad_scale():
@@ -149,7 +201,7 @@ def test_reference_api_path(stage):
     out_ref = ofp.forward(work, batch, stage)
     loss_ref, comps = ofp.loss(out_ref, batch, stage)
     (loss_ref / 4).backward()                                     # gam = 4
-    model = FastPitch(compute="fp32").cuda()
+    model = FastPitch(compute="fp32", p_dropout=0.0).cuda()
     model.load_state_dict(sd)
     model.training_stage = torch.tensor(stage)
     crit = FastPitchLoss(dur_predictor_loss_scale=0.1, pitch_predictor_loss_scale=0.1, attn_loss_scale=1.0)

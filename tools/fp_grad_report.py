@@ -1,0 +1,34 @@
+"""Diagnostic: per-tensor relative gradient error of the HIP FastPitch engine vs the CPU oracle (run on the GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+from oracle import fastpitch as ofp
+from fp_util import build_engine
+from xva_trainer_amd.fastpitch import params as P
+from xva_trainer_amd.fastpitch.engine import DeviceBatch
+
+stage = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+compute = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+sd = ofp.init_state_dict(77)
+batch = ofp.synth_batch(4, 37, 210, 78)
+names = ofp.trainable_names(sd.keys(), stage)
+leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+work = dict(sd); work.update(leaves)
+out_ref = ofp.forward(work, batch, stage)
+loss_ref, comps = ofp.loss(out_ref, batch, stage)
+loss_ref.backward()
+eng, flat, grads = build_engine(sd, compute)
+b = DeviceBatch.from_dict(batch, "cuda")
+eng.fwd_loss_bwd(flat, grads, b, stage)
+mine = P.from_flat(grads, eng.table)
+rows = []
+for k, v in leaves.items():
+    if v.grad is None:
+        continue
+    g = v.grad.double()
+    r = ((mine[k].double().cpu() - g).norm() / g.norm().clamp_min(1e-30)).item()
+    rows.append((r, k, g.norm().item()))
+rows.sort(reverse=True)
+for r, k, n in rows[:25]:
+    print("%.4f  %-60s |g|=%.3e" % (r, k, n))

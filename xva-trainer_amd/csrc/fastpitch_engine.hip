@@ -9,31 +9,16 @@
 //
 // Memory model: parameters live in ONE flat fp32 buffer (table below; conv-k3 weights are stored tap-major
 // [Cout][3][Cin] — the host converts to/from the checkpoint layout [Cout][Cin][3]); gradients mirror it.
-// Activations use the padded token-major layout described in fp_ops.hip.
+// Activations use the padded token-major layout described in fp_ops.hip, stored in fp32 (parity mode) or bf16
+// (training mode: every GEMM operand is read as bf16, halving operand traffic; a bf16 shadow of the parameters
+// is refreshed by one cast kernel per forward).  Dropout (p = 0.1 in the reference's training mode) uses stateless
+// hash masks regenerated in backward: nothing is stored for it except the dropped attention probabilities.
 #include "xva_common.h"
 #include "../../include/xva_hip.h"
 #include <string>
 #include <vector>
 
-// ---- per-op launchers from fp_ops.hip ----
-extern "C" {
-int xva_fp_embed_fwd(const int32_t*, const float*, const float*, float*, int, int, int, void*);
-int xva_fp_embed_bwd(const int32_t*, const float*, float*, int, int, int, void*);
-int xva_fp_softmax_fwd(float*, const int32_t*, int, int, int64_t, float, uint64_t, uint32_t, void*);
-int xva_fp_softmax_bwd(const float*, float*, int, int, int64_t, float, float, uint64_t, uint32_t, void*);
-int xva_fp_layernorm_fwd(const float*, const float*, const float*, float*, float*, float*, int64_t, int, int, const int32_t*, int, void*);
-int xva_fp_layernorm_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int64_t, int, int, const int32_t*, int, int, void*);
-int xva_fp_colsum(const float*, float*, int64_t, int, int64_t, void*);
-int xva_fp_avg_pitch(const float*, const int32_t*, float*, int, int, int, int, void*);
-int xva_fp_lenreg_map(const int32_t*, int32_t*, int32_t*, int32_t*, int, int, int, float, void*);
-int xva_fp_cond_add_fwd(const float*, const float*, const float*, const float*, float*, const int32_t*, int, int, int, void*);
-int xva_fp_cond_add_bwd(const float*, const float*, float*, float*, const int32_t*, int, int, int, void*);
-int xva_fp_lenreg_fwd(const float*, const int32_t*, const int32_t*, const float*, float*, int, int, int, int, void*);
-int xva_fp_lenreg_bwd(const float*, const int32_t*, const int32_t*, float*, int, int, int, int, int, void*);
-int xva_fp_outer(const float*, const float*, float*, int64_t, int, void*);
-int xva_fp_rowscale_colsum(const float*, const float*, float*, int64_t, int, void*);
-int xva_fp_dur_from_log(const float*, float*, int, float, void*);
-}
+// per-op launchers (fp_ops.hip) are declared in include/xva_hip.h
 
 namespace {
 
@@ -68,7 +53,7 @@ struct ParamTable {
         for (auto s : shape) { ti.shape[i++] = s; ti.numel *= s; }
         for (; i < 4; ++i) ti.shape[i] = 1;
         ti.offset = total;
-        total += (ti.numel + 3) & ~(int64_t)3;  // keep every tensor 16-byte aligned
+        total += (ti.numel + 7) & ~(int64_t)7;  // keep every tensor 32-byte aligned (16 bytes in the bf16 shadow)
         t.push_back(ti);
         return ti.offset;
     }
@@ -139,27 +124,28 @@ struct ParamTable {
 const ParamTable& table() { static ParamTable T; return T; }
 
 // ------------------------------------------------------------------ workspace plan ----
+// All offsets are BYTES.  Activation tensors have element size es (4 or 2); statistics / token scalars are fp32.
 struct Bump {
     int64_t cur = 0;
-    int64_t take(int64_t n) { int64_t o = cur; cur += (n + 3) & ~(int64_t)3; return o; }
-    // sequence buffer of `rows` x C with one guard row before and after; returns offset of row 0
-    int64_t seq(int64_t rows, int C) { int64_t o = take((rows + 2) * (int64_t)C); return o + C; }
+    int64_t take(int64_t bytes) { int64_t o = cur; cur += (bytes + 255) & ~(int64_t)255; return o; }
+    // sequence buffer of `rows` x C elements of size es with one guard row before and after; returns the offset of row 0
+    int64_t seq(int64_t rows, int C, int es) { int64_t o = take((rows + 2) * (int64_t)C * es); return o + (int64_t)C * es; }
 };
 
-struct LayerA { int64_t qkv, P, av, sum1, mean1, rstd1, y1, h, sum2, mean2, rstd2; };
+struct LayerA { int64_t qkv, P, Pd, av, sum1, mean1, rstd1, y1, h, sum2, mean2, rstd2; };
 struct PredA { int64_t c1, m1, r1, n1, c2, m2, r2, n2, out; };
 struct Plan {
-    int B, Tt, Tm, Ttp, Tmp;
+    int B, Tt, Tm, Ttp, Tmp, es, dt;
     int64_t Re, Rd, Tse, Tsd;
-    // forward
     int64_t enc_x[NL + 1], dec_x[NL + 1];
     LayerA enc[NL], dec[NL];
     PredA dur, pitch, energy;
+    int64_t pin_a, pin_b;   // fp32 copies of the predictor inputs (enc_out, enc_c1) in bf16 mode; -1 in fp32 mode
     int64_t ptgt, etgt, enc_c1, enc_c2, tok, tstart, dec_lens, mel_out, dur_pred;
-    // loss / grads of outputs
     int64_t acc, losses, d_mel, d_pitch, d_energy, d_logdur;
-    // backward scratch, sized for the decoder (Rd rows); the encoder reuses it
-    int64_t gA, gB, gC, gD, gH, gAV, gP, gQKV, gE, pa, pb;
+    // backward scratch, sized for the decoder; the encoder reuses it.  gBm / gDm: dropout-masked copies for the branches.
+    int64_t gA, gB, gBm, gC, gD, gDm, gH, gAV, gP, gQKV, gE, pa, pb;
+    int64_t wshadow;    // activation-dtype copy of the flat parameters (bf16 mode); unused in fp32 mode
     int64_t total;
 };
 
@@ -167,47 +153,56 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     XVA_CHECK_ARG(d && d->B > 0 && d->Tt > 0 && d->Tm > 0, "fastpitch: bad dims");
     XVA_CHECK_ARG(d->stage >= 2 && d->stage <= 4, "fastpitch: stage must be 2, 3 or 4 (stage 1 aligner is not built yet)");
     XVA_CHECK_ARG(d->Tm + 2 <= 2048 && d->Tt + 2 <= 2048, "fastpitch: sequence longer than 2046 unsupported");
+    XVA_CHECK_ARG(d->p_dropout >= 0.f && d->p_dropout < 1.f, "fastpitch: bad dropout probability");
     p->B = d->B; p->Tt = d->Tt; p->Tm = d->Tm; p->Ttp = d->Tt + 2; p->Tmp = d->Tm + 2;
+    p->dt = d->compute ? XVA_BF16 : XVA_F32; p->es = d->compute ? 2 : 4;
+    const int es = p->es;
+    const bool drop = d->p_dropout > 0.f;
     p->Re = (int64_t)d->B * p->Ttp; p->Rd = (int64_t)d->B * p->Tmp;
-    p->Tse = (p->Ttp + 3) & ~3; p->Tsd = (p->Tmp + 3) & ~3;
+    p->Tse = (p->Ttp + 7) & ~7; p->Tsd = (p->Tmp + 7) & ~7;
     Bump b;
     auto plan_layers = [&](int64_t R, int Tp, int64_t Ts, int64_t* x, LayerA* L) {
-        x[0] = b.seq(R, DM);
+        x[0] = b.seq(R, DM, es);
         for (int i = 0; i < NL; ++i) {
-            L[i].qkv = b.seq(R, DQKV);
-            L[i].P = b.take((int64_t)p->B * Tp * Ts);
-            L[i].av = b.seq(R, DH);
-            L[i].sum1 = b.seq(R, DM);
-            L[i].mean1 = b.take(R); L[i].rstd1 = b.take(R);
-            L[i].y1 = b.seq(R, DM);
-            L[i].h = b.seq(R, DI);
-            L[i].sum2 = b.seq(R, DM);
-            L[i].mean2 = b.take(R); L[i].rstd2 = b.take(R);
-            x[i + 1] = b.seq(R, DM);
+            L[i].qkv = b.seq(R, DQKV, es);
+            L[i].P = b.take((int64_t)p->B * Tp * Ts * es + 64);
+            L[i].Pd = drop ? b.take((int64_t)p->B * Tp * Ts * es + 64) : L[i].P;
+            L[i].av = b.seq(R, DH, es);
+            L[i].sum1 = b.seq(R, DM, es);
+            L[i].mean1 = b.take(R * 4); L[i].rstd1 = b.take(R * 4);
+            L[i].y1 = b.seq(R, DM, es);
+            L[i].h = b.seq(R, DI, es);
+            L[i].sum2 = b.seq(R, DM, es);
+            L[i].mean2 = b.take(R * 4); L[i].rstd2 = b.take(R * 4);
+            x[i + 1] = b.seq(R, DM, es);
         }
     };
     auto plan_pred = [&](PredA& A) {
-        A.c1 = b.seq(p->Re, DP); A.m1 = b.take(p->Re); A.r1 = b.take(p->Re); A.n1 = b.seq(p->Re, DP);
-        A.c2 = b.seq(p->Re, DP); A.m2 = b.take(p->Re); A.r2 = b.take(p->Re); A.n2 = b.seq(p->Re, DP);
-        A.out = b.take(p->Re + 8) + 4;
+        // predictors are stored fp32 in both modes (see pred_fwd)
+        A.c1 = b.seq(p->Re, DP, 4); A.m1 = b.take(p->Re * 4); A.r1 = b.take(p->Re * 4); A.n1 = b.seq(p->Re, DP, 4);
+        A.c2 = b.seq(p->Re, DP, 4); A.m2 = b.take(p->Re * 4); A.r2 = b.take(p->Re * 4); A.n2 = b.seq(p->Re, DP, 4);
+        A.out = b.take((p->Re + 8) * 4) + 16;
     };
     plan_layers(p->Re, p->Ttp, p->Tse, p->enc_x, p->enc);
     plan_pred(p->dur); plan_pred(p->pitch); plan_pred(p->energy);
-    p->ptgt = b.take(p->Re + 8) + 4; p->etgt = b.take(p->Re + 8) + 4;
-    p->enc_c1 = b.seq(p->Re, DM); p->enc_c2 = b.seq(p->Re, DM);
-    p->tok = b.take((int64_t)p->B * p->Tm); p->tstart = b.take((int64_t)p->B * (p->Tt + 1)); p->dec_lens = b.take(p->B);
+    p->pin_a = d->compute ? b.seq(p->Re, DM, 4) : -1; p->pin_b = d->compute ? b.seq(p->Re, DM, 4) : -1;
+    p->ptgt = b.take((p->Re + 8) * 4) + 16; p->etgt = b.take((p->Re + 8) * 4) + 16;
+    p->enc_c1 = b.seq(p->Re, DM, es); p->enc_c2 = b.seq(p->Re, DM, es);
+    p->tok = b.take((int64_t)p->B * p->Tm * 4); p->tstart = b.take((int64_t)p->B * (p->Tt + 1) * 4); p->dec_lens = b.take(p->B * 4);
     plan_layers(p->Rd, p->Tmp, p->Tsd, p->dec_x, p->dec);
-    p->mel_out = b.seq(p->Rd, NMEL);
-    p->dur_pred = b.take(p->Re + 8) + 4;
-    p->acc = b.take(8); p->losses = b.take(8);
-    p->d_mel = b.seq(p->Rd, NMEL);
-    p->d_pitch = b.take(p->Re + 8) + 4; p->d_energy = b.take(p->Re + 8) + 4; p->d_logdur = b.take(p->Re + 8) + 4;
+    p->mel_out = b.seq(p->Rd, NMEL, es);
+    p->dur_pred = b.take((p->Re + 8) * 4) + 16;
+    p->acc = b.take(8 * 4); p->losses = b.take(8 * 4);
+    p->d_mel = b.seq(p->Rd, NMEL, es);
+    p->d_pitch = b.take((p->Re + 8) * 4) + 16; p->d_energy = b.take((p->Re + 8) * 4) + 16; p->d_logdur = b.take((p->Re + 8) * 4) + 16;
     int64_t Rm = p->Rd > p->Re ? p->Rd : p->Re;
     int64_t Tsm = p->Tsd > p->Tse ? p->Tsd : p->Tse;
     int Tpm = p->Tmp > p->Ttp ? p->Tmp : p->Ttp;
-    p->gA = b.seq(Rm, DM); p->gB = b.seq(Rm, DM); p->gC = b.seq(Rm, DM); p->gD = b.seq(Rm, DM);
-    p->gH = b.seq(Rm, DI); p->gAV = b.seq(Rm, DH); p->gP = b.take((int64_t)p->B * Tpm * Tsm); p->gQKV = b.seq(Rm, DQKV);
-    p->gE = b.seq(p->Re, DM); p->pa = b.seq(p->Re, DP); p->pb = b.seq(p->Re, DP);
+    p->gA = b.seq(Rm, DM, es); p->gB = b.seq(Rm, DM, es); p->gC = b.seq(Rm, DM, es); p->gD = b.seq(Rm, DM, es);
+    p->gBm = drop ? b.seq(Rm, DM, es) : p->gB; p->gDm = drop ? b.seq(Rm, DM, es) : p->gD;
+    p->gH = b.seq(Rm, DI, es); p->gAV = b.seq(Rm, DH, es); p->gP = b.take((int64_t)p->B * Tpm * Tsm * es + 64); p->gQKV = b.seq(Rm, DQKV, es);
+    p->gE = b.seq(p->Re, DM, es); p->pa = b.seq(p->Re, DP, 4); p->pb = b.seq(p->Re, DP, 4);
+    p->wshadow = d->compute ? b.take(table().total * es) : -1;
     p->total = b.cur;
     return XVA_OK;
 }
@@ -216,23 +211,31 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
 struct Ctx {
     const xva_fp_dims* d;
     Plan pl;
-    const float* P;  // params
-    float* G;        // grads (may be null in forward)
-    float* W;        // workspace
+    const float* P;   // fp32 parameters
+    const char* Pw;   // GEMM-operand view of the parameters (activation dtype): the shadow in bf16 mode, P itself in fp32 mode
+    float* G;         // grads (may be null in forward)
+    char* W;          // workspace
     void* st;
-    int compute;
+    int compute, dt, es;
+    float pd;         // dropout probability
+    uint64_t seed;
     void* const* events = nullptr;  // optional hipEvent_t per gradient bucket (data-parallel overlap)
     int ev_base = 0;
     int record(int i) {
         if (events && events[i] && hipEventRecord((hipEvent_t)events[i], (hipStream_t)st) != hipSuccess) { xva_set_error("bucket event record failed"); return XVA_ERR_HIP; }
         return XVA_OK;
     }
+    char* A(int64_t off) const { return W + off; }                       // activation tensor at byte offset
+    float* F(int64_t off) const { return (float*)(W + off); }            // fp32 tensor at byte offset
+    const void* wt(int64_t elem_off) const { return Pw + elem_off * es; } // parameter tensor as a GEMM operand
+    char* sh(char* p, int64_t elems) const { return p + elems * es; }     // shift an activation pointer by elements
 };
 
-static xva_gemm_params gp0(int compute) {
+static xva_gemm_params gp0(const Ctx& c) {
     xva_gemm_params g;
     memset(&g, 0, sizeof(g));
-    g.batch = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.compute = compute; g.mask_pad = 1;
+    g.batch = 1; g.batch2 = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.compute = c.compute; g.mask_pad = 1; g.mask_mul = 1;
+    g.a_dtype = g.b_dtype = g.c_dtype = c.dt; g.r_dtype = g.g_dtype = c.dt;
     return g;
 }
 static int splitk_for(int M, int N, int K) {
@@ -244,201 +247,225 @@ static int splitk_for(int M, int N, int K) {
     if (sk < 1) sk = 1;
     return sk;
 }
-// Y[rows, N] = X[rows, K] W[N, K]^T (+bias) (+R) ...   (nn.Linear)
-static int linear_fwd(Ctx& c, const float* X, int64_t rows, int K, int64_t ldx, const float* Wm, const float* bias, float* Y,
-                      int N, int64_t ldy, const float* R, int64_t ldr, int mask, const int32_t* lens, int Tp) {
-    xva_gemm_params g = gp0(c.compute);
-    g.layout = XVA_GEMM_NT; g.A = X; g.B = Wm; g.C = Y; g.M = (int)rows; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy;
+// dropout descriptor of a GEMM epilogue / kernel site
+struct Drop { float p; uint32_t stream; };
+
+// Y[rows, N] = X[rows, K] W[N, K]^T (+bias) [dropout] (+R) ...   (nn.Linear)
+static int linear_fwd(Ctx& c, const void* X, int64_t rows, int K, int64_t ldx, int64_t w_off, const float* bias, void* Y,
+                      int N, int64_t ldy, const void* R, int64_t ldr, int mask, const int32_t* lens, int Tp, Drop dr = {0.f, 0}, int c_f32 = 0) {
+    xva_gemm_params g = gp0(c);
+    g.layout = XVA_GEMM_NT; g.A = X; g.B = c.wt(w_off); g.C = Y; g.M = (int)rows; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy;
     g.bias = bias; g.R = R; g.ldr = ldr; g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
+    g.drop_p = dr.p; g.drop_seed = c.seed; g.drop_stream = dr.stream;
+    if (c_f32) g.c_dtype = XVA_F32;
     return xva_gemm(&g, c.st);
 }
 // dX[rows, K] = dY[rows, N] W[N, K] (+R)
-static int linear_bwd_data(Ctx& c, const float* dY, int64_t rows, int N, int64_t ldy, const float* Wm, int K, float* dX,
-                           int64_t ldx, const float* R, int64_t ldr, int mask, const int32_t* lens, int Tp) {
-    xva_gemm_params g = gp0(c.compute);
-    g.layout = XVA_GEMM_NN; g.A = dY; g.B = Wm; g.C = dX; g.M = (int)rows; g.N = K; g.K = N; g.lda = ldy; g.ldb = K; g.ldc = ldx;
+static int linear_bwd_data(Ctx& c, const void* dY, int64_t rows, int N, int64_t ldy, int64_t w_off, int K, void* dX,
+                           int64_t ldx, const void* R, int64_t ldr, int mask, const int32_t* lens, int Tp) {
+    xva_gemm_params g = gp0(c);
+    g.layout = XVA_GEMM_NN; g.A = dY; g.B = c.wt(w_off); g.C = dX; g.M = (int)rows; g.N = K; g.K = N; g.lda = ldy; g.ldb = K; g.ldc = ldx;
     g.R = R; g.ldr = ldr; g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
     return xva_gemm(&g, c.st);
 }
-// dW[N, K] += dY[rows, N]^T X[rows, K]
-static int linear_bwd_weight(Ctx& c, const float* dY, int64_t rows, int N, int64_t ldy, const float* X, int K, int64_t ldx,
-                             float* dW) {
-    xva_gemm_params g = gp0(c.compute);
-    g.layout = XVA_GEMM_TN; g.A = dY; g.B = X; g.C = dW; g.M = N; g.N = K; g.K = (int)rows; g.lda = ldy; g.ldb = ldx; g.ldc = K;
+// dW[N, K] += dY[rows, N]^T X[rows, K]      (fp32 gradient)
+static int linear_bwd_weight(Ctx& c, const void* dY, int64_t rows, int N, int64_t ldy, const void* X, int K, int64_t ldx, float* dW) {
+    xva_gemm_params g = gp0(c);
+    g.layout = XVA_GEMM_TN; g.A = dY; g.B = X; g.C = dW; g.c_dtype = XVA_F32; g.M = N; g.N = K; g.K = (int)rows; g.lda = ldy; g.ldb = ldx; g.ldc = K;
     g.accumulate = 1; g.splitk = splitk_for(N, K, (int)rows);
     return xva_gemm(&g, c.st);
 }
-// Conv1d(k=3, pad=1) over a padded token-major sequence: Y = act(Xcat Wt^T + b) (+R), Wt tap-major [Cout][3*Cin]
-static int conv3_fwd(Ctx& c, const float* X, int64_t rows, int Cin, const float* Wt, const float* bias, float* Y, int Cout,
-                     int relu, const float* R, int mask, const int32_t* lens, int Tp) {
-    xva_gemm_params g = gp0(c.compute);
-    g.layout = XVA_GEMM_NT; g.A = X - Cin; g.B = Wt; g.C = Y; g.M = (int)rows; g.N = Cout; g.K = 3 * Cin;
+// Conv1d(k=3, pad=1) over a padded token-major sequence: Y = act(Xcat Wt^T + b) [dropout] (+R), Wt tap-major [Cout][3*Cin]
+static int conv3_fwd(Ctx& c, const char* X, int64_t rows, int Cin, int64_t w_off, const float* bias, void* Y, int Cout,
+                     int relu, const void* R, int mask, const int32_t* lens, int Tp, Drop dr = {0.f, 0}) {
+    xva_gemm_params g = gp0(c);
+    g.layout = XVA_GEMM_NT; g.A = X - (int64_t)Cin * c.es; g.B = c.wt(w_off); g.C = Y; g.M = (int)rows; g.N = Cout; g.K = 3 * Cin;
     g.lda = Cin; g.ldb = 3 * Cin; g.ldc = Cout; g.bias = bias; g.act = relu ? XVA_ACT_RELU : XVA_ACT_NONE; g.R = R; g.ldr = Cout;
     g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
+    g.drop_p = dr.p; g.drop_seed = c.seed; g.drop_stream = dr.stream;
     return xva_gemm(&g, c.st);
 }
-// dX[r] = sum_j dY[r-1+j] W[:, tap 2-j, :]  (+R) (gated by Gate > 0)
-static int conv3_bwd_data(Ctx& c, const float* dY, int64_t rows, int Cout, const float* Wt, int Cin, float* dX, const float* R,
-                          const float* Gate, int mask, const int32_t* lens, int Tp, int accumulate) {
-    xva_gemm_params g = gp0(c.compute);
-    g.layout = XVA_GEMM_NN; g.A = dY - Cout; g.B = Wt; g.C = dX; g.M = (int)rows; g.N = Cin; g.K = 3 * Cout;
+// dX[r] = sum_j dY[r-1+j] W[:, tap 2-j, :]  (gated by Gate > 0) (+R)
+static int conv3_bwd_data(Ctx& c, const char* dY, int64_t rows, int Cout, int64_t w_off, int Cin, void* dX, const void* R,
+                          const void* Gate, int mask, const int32_t* lens, int Tp, int accumulate, int c_dt = -1) {
+    xva_gemm_params g = gp0(c);
+    if (c_dt >= 0) g.c_dtype = c_dt;
+    g.layout = XVA_GEMM_NN; g.A = dY - (int64_t)Cout * c.es; g.B = c.wt(w_off); g.C = dX; g.M = (int)rows; g.N = Cin; g.K = 3 * Cout;
     g.lda = Cout; g.ldb = 3 * Cin; g.ldc = Cin; g.seglen = Cout; g.seg0 = 2 * Cin; g.segstride = -Cin;
     g.R = R; g.ldr = Cin; g.G = Gate; g.ldg = Cin; g.mask_mode = mask; g.lens = lens; g.Tp = Tp; g.accumulate = accumulate;
     return xva_gemm(&g, c.st);
 }
 // dWt[Cout][3*Cin] += dY^T Xcat
-static int conv3_bwd_weight(Ctx& c, const float* dY, int64_t rows, int Cout, const float* X, int Cin, float* dWt) {
-    xva_gemm_params g = gp0(c.compute);
-    g.layout = XVA_GEMM_TN; g.A = dY; g.B = X - Cin; g.C = dWt; g.M = Cout; g.N = 3 * Cin; g.K = (int)rows;
+static int conv3_bwd_weight(Ctx& c, const void* dY, int64_t rows, int Cout, const char* X, int Cin, float* dWt) {
+    xva_gemm_params g = gp0(c);
+    g.layout = XVA_GEMM_TN; g.A = dY; g.B = X - (int64_t)Cin * c.es; g.C = dWt; g.c_dtype = XVA_F32; g.M = Cout; g.N = 3 * Cin; g.K = (int)rows;
     g.lda = Cout; g.ldb = Cin; g.ldc = 3 * Cin; g.accumulate = 1; g.splitk = splitk_for(Cout, 3 * Cin, (int)rows);
     return xva_gemm(&g, c.st);
 }
 
+// dropout sites: stream id = site_base + layer * 4 + {0 attention probs, 1 o_net output, 2 conv2 output}
+enum { DS_ENC = 0, DS_DEC = 100, DS_PRED = 200 };
+
 // ------------------------------------------------------------------ transformer stack ----
 static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t* xo, int64_t R, int Tp, int64_t Ts,
-                      const int32_t* lens) {
+                      const int32_t* lens, int site) {
     const int B = c.pl.B;
     for (int l = 0; l < NL; ++l) {
         const LayerP& p = LP[l];
         const LayerA& a = LA[l];
-        float* x = c.W + xo[l];
-        float* qkv = c.W + a.qkv; float* Pm = c.W + a.P; float* av = c.W + a.av;
+        char* x = c.A(xo[l]);
+        char* qkv = c.A(a.qkv); char* Pm = c.A(a.P); char* Pdm = c.A(a.Pd); char* av = c.A(a.av);
+        const uint32_t s0 = site + l * 4;
         // qkv = x Wqkv^T + b                                             (transformer.py:109)
-        XVA_TRY(linear_fwd(c, x, R, DM, DM, c.P + p.qkv_w, c.P + p.qkv_b, qkv, DQKV, DQKV, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
+        XVA_TRY(linear_fwd(c, x, R, DM, DM, p.qkv_w, c.P + p.qkv_b, qkv, DQKV, DQKV, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
         {   // S = scale * Q K^T per item                                  (transformer.py:118-119)
-            xva_gemm_params g = gp0(c.compute);
-            g.layout = XVA_GEMM_NT; g.A = qkv; g.B = qkv + DH; g.C = Pm; g.M = Tp; g.N = Tp; g.K = DH;
+            xva_gemm_params g = gp0(c);
+            g.layout = XVA_GEMM_NT; g.A = qkv; g.B = c.sh(qkv, DH); g.C = Pm; g.M = Tp; g.N = Tp; g.K = DH;
             g.lda = DQKV; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DQKV; g.sB = g.sA; g.sC = (int64_t)Tp * Ts;
             g.alpha = 0.125f;
             XVA_TRY(xva_gemm(&g, c.st));
         }
-        XVA_TRY(xva_fp_softmax_fwd(Pm, lens, B, Tp, Ts, 0.f, 0, 0, c.st));          // :121-127
-        {   // AV = P V                                                     (transformer.py:130)
-            xva_gemm_params g = gp0(c.compute);
-            g.layout = XVA_GEMM_NN; g.A = Pm; g.B = qkv + 2 * DH; g.C = av; g.M = Tp; g.N = DH; g.K = Tp;
+        XVA_TRY(xva_fp_softmax_fwd(Pm, Pdm, c.dt, lens, B, Tp, Ts, c.pd, c.seed, s0 + 0, c.st));      // :121-128 (softmax, dropatt)
+        {   // AV = dropatt(P) V                                            (transformer.py:130)
+            xva_gemm_params g = gp0(c);
+            g.layout = XVA_GEMM_NN; g.A = Pdm; g.B = c.sh(qkv, 2 * DH); g.C = av; g.M = Tp; g.N = DH; g.K = Tp;
             g.lda = Ts; g.ldb = DQKV; g.ldc = DH; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DH;
             XVA_TRY(xva_gemm(&g, c.st));
         }
-        // sum1 = x + AV Wo^T ; y1 = LN(sum1) * mask                        (transformer.py:137-146,166-167)
-        XVA_TRY(linear_fwd(c, av, R, DH, DH, c.P + p.o_w, nullptr, c.W + a.sum1, DM, DM, x, DM, XVA_MASK_NONE, nullptr, 0));
-        XVA_TRY(xva_fp_layernorm_fwd(c.W + a.sum1, c.P + p.ln1_g, c.P + p.ln1_b, c.W + a.y1, c.W + a.mean1, c.W + a.rstd1, R, DM,
-                                     XVA_MASK_LEN, lens, Tp, c.st));
-        // h = relu(conv1(y1)) ; sum2 = y1 + conv2(h) ; x' = LN(sum2) * mask  (transformer.py:59-77,168-170)
-        XVA_TRY(conv3_fwd(c, c.W + a.y1, R, DM, c.P + p.c1_w, c.P + p.c1_b, c.W + a.h, DI, 1, nullptr, XVA_MASK_PAD, lens, Tp));
-        XVA_TRY(conv3_fwd(c, c.W + a.h, R, DI, c.P + p.c2_w, c.P + p.c2_b, c.W + a.sum2, DM, 0, c.W + a.y1, XVA_MASK_NONE, nullptr, 0));
-        XVA_TRY(xva_fp_layernorm_fwd(c.W + a.sum2, c.P + p.ln2_g, c.P + p.ln2_b, c.W + xo[l + 1], c.W + a.mean2, c.W + a.rstd2, R, DM,
-                                     XVA_MASK_LEN, lens, Tp, c.st));
+        // sum1 = x + drop(AV Wo^T) ; y1 = LN(sum1) * mask                  (transformer.py:137-146,166-167)
+        XVA_TRY(linear_fwd(c, av, R, DH, DH, p.o_w, nullptr, c.A(a.sum1), DM, DM, x, DM, XVA_MASK_NONE, nullptr, 0, Drop{c.pd, s0 + 1}));
+        XVA_TRY(xva_fp_layernorm_fwd(c.A(a.sum1), c.P + p.ln1_g, c.P + p.ln1_b, c.A(a.y1), c.dt, c.F(a.mean1), c.F(a.rstd1), R, DM,
+                                     XVA_MASK_LEN, lens, Tp, 0.f, 0, 0, c.st));
+        // h = relu(conv1(y1)) ; sum2 = y1 + drop(conv2(h)) ; x' = LN(sum2) * mask  (transformer.py:59-77,168-170)
+        XVA_TRY(conv3_fwd(c, c.A(a.y1), R, DM, p.c1_w, c.P + p.c1_b, c.A(a.h), DI, 1, nullptr, XVA_MASK_PAD, lens, Tp));
+        XVA_TRY(conv3_fwd(c, c.A(a.h), R, DI, p.c2_w, c.P + p.c2_b, c.A(a.sum2), DM, 0, c.A(a.y1), XVA_MASK_NONE, nullptr, 0, Drop{c.pd, s0 + 2}));
+        XVA_TRY(xva_fp_layernorm_fwd(c.A(a.sum2), c.P + p.ln2_g, c.P + p.ln2_b, c.A(xo[l + 1]), c.dt, c.F(a.mean2), c.F(a.rstd2), R, DM,
+                                     XVA_MASK_LEN, lens, Tp, 0.f, 0, 0, c.st));
     }
     return XVA_OK;
 }
 
 // Backward through the 6 layers.  On entry gA holds dL/d(x_out) ; on exit gA holds dL/d(x_in) (LEN-masked).
 static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t* xo, int64_t R, int Tp, int64_t Ts,
-                      const int32_t* lens, bool want_grads, bool last_bucket_deferred) {
+                      const int32_t* lens, bool last_bucket_deferred, int site) {
     const int B = c.pl.B;
-    float *gA = c.W + c.pl.gA, *gB = c.W + c.pl.gB, *gC = c.W + c.pl.gC, *gD = c.W + c.pl.gD, *gH = c.W + c.pl.gH,
-          *gAV = c.W + c.pl.gAV, *gP = c.W + c.pl.gP, *gQKV = c.W + c.pl.gQKV;
+    char *gA = c.A(c.pl.gA), *gB = c.A(c.pl.gB), *gBm = c.A(c.pl.gBm), *gC = c.A(c.pl.gC), *gD = c.A(c.pl.gD), *gDm = c.A(c.pl.gDm),
+         *gH = c.A(c.pl.gH), *gAV = c.A(c.pl.gAV), *gP = c.A(c.pl.gP), *gQKV = c.A(c.pl.gQKV);
+    const bool drop = c.pd > 0.f;
+    float* Gg = c.G;
     for (int l = NL - 1; l >= 0; --l) {
         const LayerP& p = LP[l];
         const LayerA& a = LA[l];
-        float* x = c.W + xo[l];
-        float* qkv = c.W + a.qkv; float* Pm = c.W + a.P; float* av = c.W + a.av;
-        float* Gg = want_grads ? c.G : nullptr;
-        // LN2 backward -> gB = d sum2 (zero on dead rows)
-        XVA_TRY(xva_fp_layernorm_bwd(gA, c.W + a.sum2, c.W + a.mean2, c.W + a.rstd2, c.P + p.ln2_g, gB, Gg ? Gg + p.ln2_g : nullptr,
-                                     Gg ? Gg + p.ln2_b : nullptr, R, DM, XVA_MASK_LEN, lens, Tp, 0, c.st));
-        // conv2 backward: gH = (gB (*) W2) * [h > 0], structural rows zero
-        XVA_TRY(conv3_bwd_data(c, gB, R, DM, c.P + p.c2_w, DI, gH, nullptr, c.W + a.h, XVA_MASK_PAD, lens, Tp, 0));
-        if (Gg) {
-            XVA_TRY(conv3_bwd_weight(c, gB, R, DM, c.W + a.h, DI, Gg + p.c2_w));
-            XVA_TRY(xva_fp_colsum(gB, Gg + p.c2_b, R, DM, DM, c.st));
-        }
+        char* x = c.A(xo[l]);
+        char* qkv = c.A(a.qkv); char* Pm = c.A(a.P); char* Pdm = c.A(a.Pd); char* av = c.A(a.av);
+        const uint32_t s0 = site + l * 4;
+        // LN2 backward -> gB = d sum2 (residual path) ; gBm = gB * dropmask (conv2 branch)
+        XVA_TRY(xva_fp_layernorm_bwd(gA, c.A(a.sum2), c.F(a.mean2), c.F(a.rstd2), c.P + p.ln2_g, gB, drop ? gBm : nullptr, c.dt, Gg + p.ln2_g,
+                                     Gg + p.ln2_b, R, DM, XVA_MASK_LEN, lens, Tp, 0, 0.f, 0, 0, c.pd, c.seed, s0 + 2, nullptr, nullptr, c.st));
+        // conv2 backward: gH = (gBm (*) W2) * [h > 0], structural rows zero
+        XVA_TRY(conv3_bwd_data(c, gBm, R, DM, p.c2_w, DI, gH, nullptr, c.A(a.h), XVA_MASK_PAD, lens, Tp, 0));
+        XVA_TRY(conv3_bwd_weight(c, gBm, R, DM, c.A(a.h), DI, Gg + p.c2_w));
+        XVA_TRY(xva_fp_colsum(gBm, c.dt, Gg + p.c2_b, R, DM, DM, c.st));
         // conv1 backward + residual: gC = gB + gH (*) W1, LEN-masked (y1 was multiplied by mask)
-        XVA_TRY(conv3_bwd_data(c, gH, R, DI, c.P + p.c1_w, DM, gC, gB, nullptr, XVA_MASK_LEN, lens, Tp, 0));
-        if (Gg) {
-            XVA_TRY(conv3_bwd_weight(c, gH, R, DI, c.W + a.y1, DM, Gg + p.c1_w));
-            XVA_TRY(xva_fp_colsum(gH, Gg + p.c1_b, R, DI, DI, c.st));
-        }
-        // LN1 backward -> gD = d sum1
-        XVA_TRY(xva_fp_layernorm_bwd(gC, c.W + a.sum1, c.W + a.mean1, c.W + a.rstd1, c.P + p.ln1_g, gD, Gg ? Gg + p.ln1_g : nullptr,
-                                     Gg ? Gg + p.ln1_b : nullptr, R, DM, XVA_MASK_LEN, lens, Tp, 0, c.st));
+        XVA_TRY(conv3_bwd_data(c, gH, R, DI, p.c1_w, DM, gC, gB, nullptr, XVA_MASK_LEN, lens, Tp, 0));
+        XVA_TRY(conv3_bwd_weight(c, gH, R, DI, c.A(a.y1), DM, Gg + p.c1_w));
+        XVA_TRY(xva_fp_colsum(gH, c.dt, Gg + p.c1_b, R, DI, DI, c.st));
+        // LN1 backward -> gD = d sum1 ; gDm = gD * dropmask (o_net branch)
+        XVA_TRY(xva_fp_layernorm_bwd(gC, c.A(a.sum1), c.F(a.mean1), c.F(a.rstd1), c.P + p.ln1_g, gD, drop ? gDm : nullptr, c.dt, Gg + p.ln1_g,
+                                     Gg + p.ln1_b, R, DM, XVA_MASK_LEN, lens, Tp, 0, 0.f, 0, 0, c.pd, c.seed, s0 + 1, nullptr, nullptr, c.st));
         // o_net backward
-        XVA_TRY(linear_bwd_data(c, gD, R, DM, DM, c.P + p.o_w, DH, gAV, DH, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
-        if (Gg) XVA_TRY(linear_bwd_weight(c, gD, R, DM, DM, av, DH, DH, Gg + p.o_w));
-        {   // dP = dAV V^T
-            xva_gemm_params g = gp0(c.compute);
-            g.layout = XVA_GEMM_NT; g.A = gAV; g.B = qkv + 2 * DH; g.C = gP; g.M = Tp; g.N = Tp; g.K = DH;
+        XVA_TRY(linear_bwd_data(c, gDm, R, DM, DM, p.o_w, DH, gAV, DH, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
+        XVA_TRY(linear_bwd_weight(c, gDm, R, DM, DM, av, DH, DH, Gg + p.o_w));
+        {   // dPd = dAV V^T
+            xva_gemm_params g = gp0(c);
+            g.layout = XVA_GEMM_NT; g.A = gAV; g.B = c.sh(qkv, 2 * DH); g.C = gP; g.M = Tp; g.N = Tp; g.K = DH;
             g.lda = DH; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DH; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * Ts;
             XVA_TRY(xva_gemm(&g, c.st));
         }
-        {   // dV = P^T dAV  -> gQKV[:, 128:192]
-            xva_gemm_params g = gp0(c.compute);
-            g.layout = XVA_GEMM_TN; g.A = Pm; g.B = gAV; g.C = gQKV + 2 * DH; g.M = Tp; g.N = DH; g.K = Tp;
+        {   // dV = Pd^T dAV  -> gQKV[:, 128:192]
+            xva_gemm_params g = gp0(c);
+            g.layout = XVA_GEMM_TN; g.A = Pdm; g.B = gAV; g.C = c.sh(gQKV, 2 * DH); g.M = Tp; g.N = DH; g.K = Tp;
             g.lda = Ts; g.ldb = DH; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DH; g.sC = (int64_t)Tp * DQKV;
             XVA_TRY(xva_gemm(&g, c.st));
         }
-        XVA_TRY(xva_fp_softmax_bwd(Pm, gP, B, Tp, Ts, 0.125f, 0.f, 0, 0, c.st));    // gP = dS (incl. 1/sqrt(d))
+        XVA_TRY(xva_fp_softmax_bwd(Pm, gP, c.dt, B, Tp, Ts, 0.125f, c.pd, c.seed, s0 + 0, c.st));    // gP = dS (incl. 1/sqrt(d))
         {   // dQ = dS K -> gQKV[:, 0:64]
-            xva_gemm_params g = gp0(c.compute);
-            g.layout = XVA_GEMM_NN; g.A = gP; g.B = qkv + DH; g.C = gQKV; g.M = Tp; g.N = DH; g.K = Tp;
+            xva_gemm_params g = gp0(c);
+            g.layout = XVA_GEMM_NN; g.A = gP; g.B = c.sh(qkv, DH); g.C = gQKV; g.M = Tp; g.N = DH; g.K = Tp;
             g.lda = Ts; g.ldb = DQKV; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DQKV;
             XVA_TRY(xva_gemm(&g, c.st));
         }
         {   // dK = dS^T Q -> gQKV[:, 64:128]
-            xva_gemm_params g = gp0(c.compute);
-            g.layout = XVA_GEMM_TN; g.A = gP; g.B = qkv; g.C = gQKV + DH; g.M = Tp; g.N = DH; g.K = Tp;
+            xva_gemm_params g = gp0(c);
+            g.layout = XVA_GEMM_TN; g.A = gP; g.B = qkv; g.C = c.sh(gQKV, DH); g.M = Tp; g.N = DH; g.K = Tp;
             g.lda = Ts; g.ldb = DQKV; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DQKV;
             XVA_TRY(xva_gemm(&g, c.st));
         }
         // d x = gD + gQKV Wqkv, LEN-masked -> gA
-        XVA_TRY(linear_bwd_data(c, gQKV, R, DQKV, DQKV, c.P + p.qkv_w, DM, gA, DM, gD, DM, XVA_MASK_LEN, lens, Tp));
-        if (Gg) {
-            XVA_TRY(linear_bwd_weight(c, gQKV, R, DQKV, DQKV, x, DM, DM, Gg + p.qkv_w));
-            XVA_TRY(xva_fp_colsum(gQKV, Gg + p.qkv_b, R, DQKV, DQKV, c.st));
-        }
+        XVA_TRY(linear_bwd_data(c, gQKV, R, DQKV, DQKV, p.qkv_w, DM, gA, DM, gD, DM, XVA_MASK_LEN, lens, Tp));
+        XVA_TRY(linear_bwd_weight(c, gQKV, R, DQKV, DQKV, x, DM, DM, Gg + p.qkv_w));
+        XVA_TRY(xva_fp_colsum(gQKV, c.dt, Gg + p.qkv_b, R, DQKV, DQKV, c.st));
         if (l > 0 || !last_bucket_deferred) XVA_TRY(c.record(c.ev_base + (NL - 1 - l)));
     }
     return XVA_OK;
 }
 
 // ------------------------------------------------------------------ temporal predictors ----
-static int pred_fwd(Ctx& c, const PredP& p, const PredA& a, const float* xin, const int32_t* lens) {
+// The predictors (model.py:103-122) run on fp32-STORED tensors in both modes (bf16 MFMA with operands rounded while staged in
+// bf16 mode): their gradients are sums of near-cancelling terms, which amplifies bf16 storage noise ~10x, and they are < 2 % of
+// the step.  `xin` is the activation-dtype input; `pin` the workspace offset of its fp32 copy (bf16 mode).
+static Ctx pred_ctx(const Ctx& c) {
+    Ctx p = c;
+    p.dt = XVA_F32; p.es = 4; p.Pw = (const char*)c.P;
+    return p;
+}
+static int pred_fwd(Ctx& c0, const PredP& p, const PredA& a, const char* xin, int64_t pin, const int32_t* lens, int site) {
+    Ctx c = pred_ctx(c0);
     const int64_t R = c.pl.Re; const int Tp = c.pl.Ttp;
-    XVA_TRY(conv3_fwd(c, xin, R, DM, c.P + p.c1_w, c.P + p.c1_b, c.W + a.c1, DP, 1, nullptr, XVA_MASK_PAD, lens, Tp));
-    XVA_TRY(xva_fp_layernorm_fwd(c.W + a.c1, c.P + p.n1_g, c.P + p.n1_b, c.W + a.n1, c.W + a.m1, c.W + a.r1, R, DP, XVA_MASK_PAD, lens, Tp, c.st));
-    XVA_TRY(conv3_fwd(c, c.W + a.n1, R, DP, c.P + p.c2_w, c.P + p.c2_b, c.W + a.c2, DP, 1, nullptr, XVA_MASK_PAD, lens, Tp));
-    XVA_TRY(xva_fp_layernorm_fwd(c.W + a.c2, c.P + p.n2_g, c.P + p.n2_b, c.W + a.n2, c.W + a.m2, c.W + a.r2, R, DP, XVA_MASK_PAD, lens, Tp, c.st));
-    XVA_TRY(linear_fwd(c, c.W + a.n2, R, DP, DP, c.P + p.fc_w, c.P + p.fc_b, c.W + a.out, 1, 1, nullptr, 0, XVA_MASK_LEN, lens, Tp));
+    if (c0.dt != XVA_F32) {
+        XVA_TRY(xva_cast_to_f32(xin, c0.dt, c.F(pin), R * DM, c.st));
+        xin = c.A(pin);
+    }
+    XVA_TRY(conv3_fwd(c, xin, R, DM, p.c1_w, c.P + p.c1_b, c.A(a.c1), DP, 1, nullptr, XVA_MASK_PAD, lens, Tp));
+    XVA_TRY(xva_fp_layernorm_fwd(c.A(a.c1), c.P + p.n1_g, c.P + p.n1_b, c.A(a.n1), c.dt, c.F(a.m1), c.F(a.r1), R, DP, XVA_MASK_PAD, lens, Tp,
+                                 c.pd, c.seed, site + 0, c.st));
+    XVA_TRY(conv3_fwd(c, c.A(a.n1), R, DP, p.c2_w, c.P + p.c2_b, c.A(a.c2), DP, 1, nullptr, XVA_MASK_PAD, lens, Tp));
+    XVA_TRY(xva_fp_layernorm_fwd(c.A(a.c2), c.P + p.n2_g, c.P + p.n2_b, c.A(a.n2), c.dt, c.F(a.m2), c.F(a.r2), R, DP, XVA_MASK_PAD, lens, Tp,
+                                 c.pd, c.seed, site + 1, c.st));
+    XVA_TRY(linear_fwd(c, c.A(a.n2), R, DP, DP, p.fc_w, c.P + p.fc_b, c.F(a.out), 1, 1, nullptr, 0, XVA_MASK_LEN, lens, Tp, Drop{0.f, 0}, 1));
     return XVA_OK;
 }
-// d_out: (Re) gradient of the predictor output (zero on dead rows).  Accumulates (or writes) dL/d xin into gX.
-static int pred_bwd(Ctx& c, const PredP& p, const PredA& a, const float* xin, const float* d_out, float* gX, int accumulate,
-                    const int32_t* lens) {
+// d_out: (Re) fp32 gradient of the predictor output (zero on dead rows).  Accumulates (or writes) dL/d xin into gX (act dtype).
+static int pred_bwd(Ctx& c0, const PredP& p, const PredA& a, const char* xin, int64_t pin, const float* d_out, char* gX, int accumulate,
+                    const int32_t* lens, int site) {
+    Ctx c = pred_ctx(c0);
     const int64_t R = c.pl.Re; const int Tp = c.pl.Ttp;
-    float *pa = c.W + c.pl.pa, *pb = c.W + c.pl.pb;
-    XVA_TRY(xva_fp_outer(d_out, c.P + p.fc_w, pa, R, DP, c.st));                                   // pa = d n2
-    XVA_TRY(xva_fp_rowscale_colsum(c.W + a.n2, d_out, c.G + p.fc_w, R, DP, c.st));
-    XVA_TRY(xva_fp_colsum(d_out, c.G + p.fc_b, R, 1, 1, c.st));
-    XVA_TRY(xva_fp_layernorm_bwd(pa, c.W + a.c2, c.W + a.m2, c.W + a.r2, c.P + p.n2_g, pb, c.G + p.n2_g, c.G + p.n2_b, R, DP,
-                                 XVA_MASK_PAD, lens, Tp, 1, c.st));                                // pb = d conv2-preact
-    XVA_TRY(conv3_bwd_data(c, pb, R, DP, c.P + p.c2_w, DP, pa, nullptr, nullptr, XVA_MASK_PAD, lens, Tp, 0));   // pa = d n1
-    XVA_TRY(conv3_bwd_weight(c, pb, R, DP, c.W + a.n1, DP, c.G + p.c2_w));
-    XVA_TRY(xva_fp_colsum(pb, c.G + p.c2_b, R, DP, DP, c.st));
-    XVA_TRY(xva_fp_layernorm_bwd(pa, c.W + a.c1, c.W + a.m1, c.W + a.r1, c.P + p.n1_g, pb, c.G + p.n1_g, c.G + p.n1_b, R, DP,
-                                 XVA_MASK_PAD, lens, Tp, 1, c.st));                                // pb = d conv1-preact
-    XVA_TRY(conv3_bwd_data(c, pb, R, DP, c.P + p.c1_w, DM, gX, nullptr, nullptr, XVA_MASK_LEN, lens, Tp, accumulate));
+    if (c0.dt != XVA_F32) xin = c.A(pin);          // the fp32 copy made by pred_fwd
+    char *pa = c.A(c.pl.pa), *pb = c.A(c.pl.pb);
+    XVA_TRY(xva_fp_rowscale_colsum(c.A(a.n2), c.dt, d_out, c.G + p.fc_w, R, DP, c.st));
+    XVA_TRY(xva_fp_colsum(d_out, XVA_F32, c.G + p.fc_b, R, 1, 1, c.st));
+    // d (dropped n2) = d_out (x) fc_w is rank 1: the LayerNorm backward forms it on the fly                     (model.py:121)
+    XVA_TRY(xva_fp_layernorm_bwd(nullptr, c.A(a.c2), c.F(a.m2), c.F(a.r2), c.P + p.n2_g, pb, nullptr, c.dt, c.G + p.n2_g, c.G + p.n2_b, R, DP,
+                                 XVA_MASK_PAD, lens, Tp, 1, c.pd, c.seed, site + 1, 0.f, 0, 0, d_out, c.P + p.fc_w, c.st));   // pb = d conv2-preact
+    XVA_TRY(conv3_bwd_data(c, pb, R, DP, p.c2_w, DP, pa, nullptr, nullptr, XVA_MASK_PAD, lens, Tp, 0));   // pa = d (dropped n1)
+    XVA_TRY(conv3_bwd_weight(c, pb, R, DP, c.A(a.n1), DP, c.G + p.c2_w));
+    XVA_TRY(xva_fp_colsum(pb, c.dt, c.G + p.c2_b, R, DP, DP, c.st));
+    XVA_TRY(xva_fp_layernorm_bwd(pa, c.A(a.c1), c.F(a.m1), c.F(a.r1), c.P + p.n1_g, pb, nullptr, c.dt, c.G + p.n1_g, c.G + p.n1_b, R, DP,
+                                 XVA_MASK_PAD, lens, Tp, 1, c.pd, c.seed, site + 0, 0.f, 0, 0, nullptr, nullptr, c.st));   // pb = d conv1-preact
+    XVA_TRY(conv3_bwd_data(c, pb, R, DP, p.c1_w, DM, gX, nullptr, nullptr, XVA_MASK_LEN, lens, Tp, accumulate, c0.dt));
     XVA_TRY(conv3_bwd_weight(c, pb, R, DP, xin, DM, c.G + p.c1_w));
-    XVA_TRY(xva_fp_colsum(pb, c.G + p.c1_b, R, DP, DP, c.st));
+    XVA_TRY(xva_fp_colsum(pb, c.dt, c.G + p.c1_b, R, DP, DP, c.st));
     return XVA_OK;
 }
 
-static int make_ctx(Ctx& c, const xva_fp_dims* d, const float* params, float* grads, float* ws, int64_t ws_bytes, void* st) {
+static int make_ctx(Ctx& c, const xva_fp_dims* d, const float* params, float* grads, void* ws, int64_t ws_bytes, void* st) {
     XVA_TRY(make_plan(d, &c.pl));
     XVA_CHECK_ARG(params && ws, "fastpitch: null params/workspace");
-    XVA_CHECK_ARG(((uintptr_t)params % 16) == 0 && ((uintptr_t)ws % 16) == 0, "fastpitch: params/workspace must be 16-byte aligned");
-    XVA_CHECK_ARG(ws_bytes >= c.pl.total * (int64_t)sizeof(float), "fastpitch: workspace too small (%ld < %ld bytes)", (long)ws_bytes,
-                  (long)(c.pl.total * sizeof(float)));
-    c.d = d; c.P = params; c.G = grads; c.W = ws; c.st = st; c.compute = d->compute;
+    XVA_CHECK_ARG(((uintptr_t)params % 16) == 0 && ((uintptr_t)ws % 256) == 0, "fastpitch: params must be 16-byte and workspace 256-byte aligned");
+    XVA_CHECK_ARG(ws_bytes >= c.pl.total, "fastpitch: workspace too small (%ld < %ld bytes)", (long)ws_bytes, (long)c.pl.total);
+    c.d = d; c.P = params; c.G = grads; c.W = (char*)ws; c.st = st; c.compute = d->compute ? 1 : 0; c.dt = c.pl.dt; c.es = c.pl.es;
+    c.pd = d->p_dropout; c.seed = d->seed;
+    c.Pw = d->compute ? c.W + c.pl.wshadow : (const char*)params;
     return XVA_OK;
 }
 
@@ -477,37 +504,37 @@ extern "C" int xva_fp_trainable_ranges(int stage, int64_t* begins, int64_t* ends
 extern "C" int64_t xva_fp_workspace_bytes(const xva_fp_dims* d) {
     Plan p;
     if (make_plan(d, &p) != XVA_OK) return -1;
-    return p.total * (int64_t)sizeof(float);
+    return p.total;
 }
 
-extern "C" int xva_fp_slot_offset(const xva_fp_dims* d, int slot, int64_t* off_floats) {
+extern "C" int xva_fp_slot_offset(const xva_fp_dims* d, int slot, int64_t* off_bytes) {
     Plan p;
     XVA_TRY(make_plan(d, &p));
-    XVA_CHECK_ARG(off_floats, "slot_offset: null");
+    XVA_CHECK_ARG(off_bytes, "slot_offset: null");
     switch (slot) {
-        case XVA_FP_SLOT_MEL_OUT: *off_floats = p.mel_out; break;
-        case XVA_FP_SLOT_PITCH_PRED: *off_floats = p.pitch.out; break;
-        case XVA_FP_SLOT_ENERGY_PRED: *off_floats = p.energy.out; break;
-        case XVA_FP_SLOT_LOG_DUR_PRED: *off_floats = p.dur.out; break;
-        case XVA_FP_SLOT_DUR_PRED: *off_floats = p.dur_pred; break;
-        case XVA_FP_SLOT_PITCH_TGT: *off_floats = p.ptgt; break;
-        case XVA_FP_SLOT_ENERGY_TGT: *off_floats = p.etgt; break;
-        case XVA_FP_SLOT_DEC_LENS: *off_floats = p.dec_lens; break;
-        case XVA_FP_SLOT_LOSS_ACC: *off_floats = p.acc; break;
-        case XVA_FP_SLOT_LOSSES: *off_floats = p.losses; break;
-        case XVA_FP_SLOT_D_MEL: *off_floats = p.d_mel; break;
-        case XVA_FP_SLOT_D_PITCH: *off_floats = p.d_pitch; break;
-        case XVA_FP_SLOT_D_ENERGY: *off_floats = p.d_energy; break;
-        case XVA_FP_SLOT_D_LOGDUR: *off_floats = p.d_logdur; break;
-        case XVA_FP_SLOT_ENC_OUT: *off_floats = p.enc_x[NL]; break;
-        case XVA_FP_SLOT_DEC_OUT: *off_floats = p.dec_x[NL]; break;
-        case XVA_FP_SLOT_ENC_COND: *off_floats = p.enc_c2; break;
+        case XVA_FP_SLOT_MEL_OUT: *off_bytes = p.mel_out; break;
+        case XVA_FP_SLOT_PITCH_PRED: *off_bytes = p.pitch.out; break;
+        case XVA_FP_SLOT_ENERGY_PRED: *off_bytes = p.energy.out; break;
+        case XVA_FP_SLOT_LOG_DUR_PRED: *off_bytes = p.dur.out; break;
+        case XVA_FP_SLOT_DUR_PRED: *off_bytes = p.dur_pred; break;
+        case XVA_FP_SLOT_PITCH_TGT: *off_bytes = p.ptgt; break;
+        case XVA_FP_SLOT_ENERGY_TGT: *off_bytes = p.etgt; break;
+        case XVA_FP_SLOT_DEC_LENS: *off_bytes = p.dec_lens; break;
+        case XVA_FP_SLOT_LOSS_ACC: *off_bytes = p.acc; break;
+        case XVA_FP_SLOT_LOSSES: *off_bytes = p.losses; break;
+        case XVA_FP_SLOT_D_MEL: *off_bytes = p.d_mel; break;
+        case XVA_FP_SLOT_D_PITCH: *off_bytes = p.d_pitch; break;
+        case XVA_FP_SLOT_D_ENERGY: *off_bytes = p.d_energy; break;
+        case XVA_FP_SLOT_D_LOGDUR: *off_bytes = p.d_logdur; break;
+        case XVA_FP_SLOT_ENC_OUT: *off_bytes = p.enc_x[NL]; break;
+        case XVA_FP_SLOT_DEC_OUT: *off_bytes = p.dec_x[NL]; break;
+        case XVA_FP_SLOT_ENC_COND: *off_bytes = p.enc_c2; break;
         default: xva_set_error("slot_offset: unknown slot %d", slot); return XVA_ERR_ARG;
     }
     return XVA_OK;
 }
 
-extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const xva_fp_batch* bt, float* workspace,
+extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const xva_fp_batch* bt, void* workspace,
                               int64_t workspace_bytes, void* stream) {
     Ctx c;
     XVA_TRY(make_ctx(c, d, params, nullptr, workspace, workspace_bytes, stream));
@@ -515,39 +542,37 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
     const Plan& pl = c.pl;
     const ParamTable& T = table();
     const int B = pl.B;
+    if (d->compute) XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));   // bf16 shadow of the parameters
     // encoder                                                              (model.py:346)
-    XVA_TRY(xva_fp_embed_fwd(bt->text, c.P + T.word_emb, bt->pos_table, c.W + pl.enc_x[0], B, pl.Tt, DM, c.st));
-    XVA_TRY(layers_fwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens));
-    float* enc_out = c.W + pl.enc_x[NL];
+    XVA_TRY(xva_fp_embed_fwd(bt->text, c.P + T.word_emb, bt->pos_table, c.A(pl.enc_x[0]), c.dt, B, pl.Tt, DM, c.st));
+    XVA_TRY(layers_fwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, DS_ENC));
+    char* enc_out = c.A(pl.enc_x[NL]);
     if (d->stage == 2) {                                                    // model.py:367-373
-        XVA_TRY(pred_fwd(c, T.dur, pl.dur, enc_out, bt->in_lens));
-        XVA_TRY(xva_fp_dur_from_log(c.W + pl.dur.out, c.W + pl.dur_pred, (int)pl.Re, 75.f, c.st));
+        XVA_TRY(pred_fwd(c, T.dur, pl.dur, enc_out, pl.pin_a, bt->in_lens, DS_PRED + 0));
+        XVA_TRY(xva_fp_dur_from_log(c.F(pl.dur.out), c.F(pl.dur_pred), (int)pl.Re, 75.f, c.st));
         return XVA_OK;
     }
     XVA_CHECK_ARG(bt->durs && bt->pitch && bt->energy, "fastpitch_forward: stage 3/4 needs durations, pitch and energy");
-    int32_t* dec_lens = (int32_t*)(c.W + pl.dec_lens);
+    int32_t* dec_lens = (int32_t*)c.A(pl.dec_lens);
     // pitch / energy conditioning                                          (model.py:394-423)
-    XVA_TRY(pred_fwd(c, T.pitch, pl.pitch, enc_out, bt->in_lens));
-    XVA_TRY(xva_fp_avg_pitch(bt->pitch, bt->durs, c.W + pl.ptgt, B, pl.Tt, pl.Tm, 0, c.st));
-    XVA_TRY(xva_fp_cond_add_fwd(enc_out, c.W + pl.ptgt, c.P + T.pitch_emb_w, c.P + T.pitch_emb_b, c.W + pl.enc_c1, bt->in_lens, B,
+    XVA_TRY(pred_fwd(c, T.pitch, pl.pitch, enc_out, pl.pin_a, bt->in_lens, DS_PRED + 2));
+    XVA_TRY(xva_fp_avg_pitch(bt->pitch, bt->durs, c.F(pl.ptgt), B, pl.Tt, pl.Tm, 0, c.st));
+    XVA_TRY(xva_fp_cond_add_fwd(enc_out, c.F(pl.ptgt), c.P + T.pitch_emb_w, c.P + T.pitch_emb_b, c.A(pl.enc_c1), c.dt, bt->in_lens, B,
                                 pl.Ttp, DM, c.st));
-    XVA_TRY(pred_fwd(c, T.energy, pl.energy, c.W + pl.enc_c1, bt->in_lens));
-    XVA_TRY(xva_fp_avg_pitch(bt->energy, bt->durs, c.W + pl.etgt, B, pl.Tt, pl.Tm, 1, c.st));
-    XVA_TRY(xva_fp_cond_add_fwd(c.W + pl.enc_c1, c.W + pl.etgt, c.P + T.energy_emb_w, c.P + T.energy_emb_b, c.W + pl.enc_c2,
+    XVA_TRY(pred_fwd(c, T.energy, pl.energy, c.A(pl.enc_c1), pl.pin_b, bt->in_lens, DS_PRED + 4));
+    XVA_TRY(xva_fp_avg_pitch(bt->energy, bt->durs, c.F(pl.etgt), B, pl.Tt, pl.Tm, 1, c.st));
+    XVA_TRY(xva_fp_cond_add_fwd(c.A(pl.enc_c1), c.F(pl.etgt), c.P + T.energy_emb_w, c.P + T.energy_emb_b, c.A(pl.enc_c2), c.dt,
                                 bt->in_lens, B, pl.Ttp, DM, c.st));
     // length regulation + decoder + projection                             (model.py:381-386)
-    XVA_TRY(xva_fp_lenreg_map(bt->durs, (int32_t*)(c.W + pl.tok), (int32_t*)(c.W + pl.tstart), dec_lens, B, pl.Tt, pl.Tm, 1.0f, c.st));
-    XVA_TRY(xva_fp_lenreg_fwd(c.W + pl.enc_c2, (int32_t*)(c.W + pl.tok), dec_lens, bt->pos_table, c.W + pl.dec_x[0], B, pl.Tt, pl.Tm,
+    XVA_TRY(xva_fp_lenreg_map(bt->durs, (int32_t*)c.A(pl.tok), (int32_t*)c.A(pl.tstart), dec_lens, B, pl.Tt, pl.Tm, 1.0f, c.st));
+    XVA_TRY(xva_fp_lenreg_fwd(c.A(pl.enc_c2), (int32_t*)c.A(pl.tok), dec_lens, bt->pos_table, c.A(pl.dec_x[0]), c.dt, B, pl.Tt, pl.Tm,
                               DM, c.st));
-    XVA_TRY(layers_fwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens));
-    XVA_TRY(linear_fwd(c, c.W + pl.dec_x[NL], pl.Rd, DM, DM, c.P + T.proj_w, c.P + T.proj_b, c.W + pl.mel_out, NMEL, NMEL, nullptr, 0,
+    XVA_TRY(layers_fwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens, DS_DEC));
+    XVA_TRY(linear_fwd(c, c.A(pl.dec_x[NL]), pl.Rd, DM, DM, T.proj_w, c.P + T.proj_b, c.A(pl.mel_out), NMEL, NMEL, nullptr, 0,
                        XVA_MASK_PAD, dec_lens, pl.Tmp));
     return XVA_OK;
 }
 
-// Gradients of the loss w.r.t. the model outputs must already sit in the workspace slots D_MEL / D_PITCH /
-// D_ENERGY / D_LOGDUR (xva_fp_loss_grads writes them there).  Accumulates into `grads` (caller zeroes it when
-// a new optimizer step starts: gradient accumulation across micro-batches is the reference's "GAM").
 // Gradient buckets in the order backward completes them (each a contiguous [begin, end) range of the flat buffer):
 //   0..5   decoder layers 5..0 (bucket 0 also holds proj)      6   predictors + pitch/energy embeddings
 //   7..12  encoder layers 5..0 (bucket 12 also holds word_emb)
@@ -569,15 +594,17 @@ extern "C" int xva_fp_bucket_range(int i, int64_t* begin, int64_t* end) {
     return XVA_OK;
 }
 
-extern "C" int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* bt, float* workspace,
+extern "C" int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* bt, void* workspace,
                                   int64_t workspace_bytes, void* const* bucket_events, void* stream);
-extern "C" int xva_fp_backward(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* bt, float* workspace,
+extern "C" int xva_fp_backward(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* bt, void* workspace,
                                int64_t workspace_bytes, void* stream) {
     return xva_fp_backward_ex(d, params, grads, bt, workspace, workspace_bytes, nullptr, stream);
 }
-// Same, recording bucket_events[i] (hipEvent_t, xva_fp_num_buckets() of them, entries may be null) on `stream` as soon as
-// bucket i's gradients are complete, so the caller can start that bucket's all-reduce on another stream.
-extern "C" int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* bt, float* workspace,
+// Gradients of the loss w.r.t. the model outputs must already sit in the workspace slots D_MEL / D_PITCH / D_ENERGY /
+// D_LOGDUR (xva_fp_loss_grads writes them there).  Accumulates into `grads` (the caller zeroes it when a new optimizer step
+// starts: gradient accumulation across micro-batches is the reference's "GAM").  Records bucket_events[i] (hipEvent_t,
+// xva_fp_num_buckets() of them, entries may be null) on `stream` as soon as bucket i's gradients are complete.
+extern "C" int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* bt, void* workspace,
                                   int64_t workspace_bytes, void* const* bucket_events, void* stream) {
     Ctx c;
     XVA_TRY(make_ctx(c, d, params, grads, workspace, workspace_bytes, stream));
@@ -587,39 +614,39 @@ extern "C" int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, flo
     const Plan& pl = c.pl;
     const ParamTable& T = table();
     const int B = pl.B;
-    float* gA = c.W + pl.gA;
-    float* gE = c.W + pl.gE;
-    float* enc_out = c.W + pl.enc_x[NL];
+    char* gA = c.A(pl.gA);
+    char* gE = c.A(pl.gE);
+    char* enc_out = c.A(pl.enc_x[NL]);
     if (d->stage == 2) {
         for (int i = 0; i < NL; ++i) XVA_TRY(c.record(i));   // decoder buckets carry no gradient in stage 2
-        XVA_TRY(pred_bwd(c, T.dur, pl.dur, enc_out, c.W + pl.d_logdur, gA, 0, bt->in_lens));
+        XVA_TRY(pred_bwd(c, T.dur, pl.dur, enc_out, pl.pin_a, c.F(pl.d_logdur), gA, 0, bt->in_lens, DS_PRED + 0));
     } else {
-        int32_t* dec_lens = (int32_t*)(c.W + pl.dec_lens);
-        float* d_mel = c.W + pl.d_mel;
+        int32_t* dec_lens = (int32_t*)c.A(pl.dec_lens);
+        char* d_mel = c.A(pl.d_mel);
         // proj backward                                                    (model.py:386)
-        XVA_TRY(linear_bwd_data(c, d_mel, pl.Rd, NMEL, NMEL, c.P + T.proj_w, DM, gA, DM, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
-        XVA_TRY(linear_bwd_weight(c, d_mel, pl.Rd, NMEL, NMEL, c.W + pl.dec_x[NL], DM, DM, c.G + T.proj_w));
-        XVA_TRY(xva_fp_colsum(d_mel, c.G + T.proj_b, pl.Rd, NMEL, NMEL, c.st));
+        XVA_TRY(linear_bwd_data(c, d_mel, pl.Rd, NMEL, NMEL, T.proj_w, DM, gA, DM, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
+        XVA_TRY(linear_bwd_weight(c, d_mel, pl.Rd, NMEL, NMEL, c.A(pl.dec_x[NL]), DM, DM, c.G + T.proj_w));
+        XVA_TRY(xva_fp_colsum(d_mel, c.dt, c.G + T.proj_b, pl.Rd, NMEL, NMEL, c.st));
         c.ev_base = 0;
-        XVA_TRY(layers_bwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens, true, false));
+        XVA_TRY(layers_bwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens, false, DS_DEC));
         // regulate_len backward: segmented sum of frame grads per token -> gE = d enc_c2 = d enc_c1
-        XVA_TRY(xva_fp_lenreg_bwd(gA, (int32_t*)(c.W + pl.tstart), dec_lens, gE, B, pl.Tt, pl.Tm, DM, 0, c.st));
-        XVA_TRY(xva_fp_cond_add_bwd(gE, c.W + pl.etgt, c.G + T.energy_emb_w, c.G + T.energy_emb_b, bt->in_lens, B, pl.Ttp, DM, c.st));
+        XVA_TRY(xva_fp_lenreg_bwd(gA, (int32_t*)c.A(pl.tstart), dec_lens, gE, c.dt, B, pl.Tt, pl.Tm, DM, 0, c.st));
+        XVA_TRY(xva_fp_cond_add_bwd(gE, c.dt, c.F(pl.etgt), c.G + T.energy_emb_w, c.G + T.energy_emb_b, bt->in_lens, B, pl.Ttp, DM, c.st));
         if (d->stage == 3) {
-            XVA_TRY(pred_bwd(c, T.energy, pl.energy, c.W + pl.enc_c1, c.W + pl.d_energy, gE, 1, bt->in_lens));
-            XVA_TRY(xva_fp_cond_add_bwd(gE, c.W + pl.ptgt, c.G + T.pitch_emb_w, c.G + T.pitch_emb_b, bt->in_lens, B, pl.Ttp, DM, c.st));
-            XVA_TRY(pred_bwd(c, T.pitch, pl.pitch, enc_out, c.W + pl.d_pitch, gE, 1, bt->in_lens));
+            XVA_TRY(pred_bwd(c, T.energy, pl.energy, c.A(pl.enc_c1), pl.pin_b, c.F(pl.d_energy), gE, 1, bt->in_lens, DS_PRED + 4));
+            XVA_TRY(xva_fp_cond_add_bwd(gE, c.dt, c.F(pl.ptgt), c.G + T.pitch_emb_w, c.G + T.pitch_emb_b, bt->in_lens, B, pl.Ttp, DM, c.st));
+            XVA_TRY(pred_bwd(c, T.pitch, pl.pitch, enc_out, pl.pin_a, c.F(pl.d_pitch), gE, 1, bt->in_lens, DS_PRED + 2));
         }
         // hand over to the encoder stack: gA <- gE
-        if (hipMemcpyAsync(gA, gE, pl.Re * DM * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)c.st) != hipSuccess) {
+        if (hipMemcpyAsync(gA, gE, pl.Re * DM * c.es, hipMemcpyDeviceToDevice, (hipStream_t)c.st) != hipSuccess) {
             xva_set_error("fastpitch_backward: memcpy failed");
             return XVA_ERR_HIP;
         }
     }
     XVA_TRY(c.record(NL));          // predictors + conditioning embeddings bucket
     c.ev_base = NL + 1;
-    XVA_TRY(layers_bwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, true, true));
-    XVA_TRY(xva_fp_embed_bwd(bt->text, gA, c.G + T.word_emb, B, pl.Tt, DM, c.st));
+    XVA_TRY(layers_bwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, true, DS_ENC));
+    XVA_TRY(xva_fp_embed_bwd(bt->text, gA, c.dt, c.G + T.word_emb, B, pl.Tt, DM, c.st));
     XVA_TRY(c.record(2 * NL));      // encoder layer 0 + word embedding bucket
     return XVA_OK;
 }

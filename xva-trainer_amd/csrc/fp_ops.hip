@@ -6,35 +6,46 @@
 // kernel here is HBM-bound: one pass over its operands, float4 / wave-per-row accesses,
 // reductions by wave64 shuffles.  Reference call sites are cited per kernel.
 #include "xva_common.h"
+#include "../../include/xva_gemm.h"
 #include "../../include/xva_hip.h"
 
 #define WAVES_PER_BLOCK 4
+
+// activation element access: dt = XVA_F32 (parity mode) or XVA_BF16 (bf16 training mode); arithmetic is always fp32
+__device__ __forceinline__ float a_ld(const void* p, int64_t i, int dt) {
+    return dt == XVA_BF16 ? __uint_as_float(((uint32_t) reinterpret_cast<const uint16_t*>(p)[i]) << 16)
+                          : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void a_st(void* p, int64_t i, int dt, float v) {
+    if (dt == XVA_BF16) {
+        uint32_t u = __float_as_uint(v);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        reinterpret_cast<uint16_t*>(p)[i] = (uint16_t)(u >> 16);
+    } else {
+        reinterpret_cast<float*>(p)[i] = v;
+    }
+}
 
 // =====================================================================================
 // Embedding + positional embedding  (transformer.py:212-227: word_emb(ids) + pos_emb * mask)
 // out[b, t', :] = emb[id] + (id != 0 ? pos[t'-1] : 0) for 1 <= t' <= T ; structural rows = 0
 // =====================================================================================
 __global__ void embed_fwd_kernel(const int* __restrict__ ids, const float* __restrict__ emb, const float* __restrict__ pos,
-                                 float* __restrict__ out, int B, int T, int C) {
+                                 void* __restrict__ out, int dt, int B, int T, int C) {
     int Tp = T + 2;
     int64_t r = blockIdx.x;
     int b = (int)(r / Tp), tp = (int)(r % Tp);
-    float4* o = reinterpret_cast<float4*>(out + r * C);
     if (tp == 0 || tp == Tp - 1) {
-        for (int c = threadIdx.x; c < C / 4; c += blockDim.x) o[c] = make_float4(0, 0, 0, 0);
+        for (int c = threadIdx.x; c < C; c += blockDim.x) a_st(out, r * C + c, dt, 0.f);
         return;
     }
     int id = ids[b * T + tp - 1];
-    const float4* e = reinterpret_cast<const float4*>(emb + (int64_t)id * C);
-    const float4* p = reinterpret_cast<const float4*>(pos + (int64_t)(tp - 1) * C);
-    for (int c = threadIdx.x; c < C / 4; c += blockDim.x) {
-        float4 v = e[c];
-        if (id != 0) { float4 q = p[c]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-        o[c] = v;
-    }
+    const float* e = emb + (int64_t)id * C;
+    const float* p = pos + (int64_t)(tp - 1) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) a_st(out, r * C + c, dt, e[c] + (id != 0 ? p[c] : 0.f));
 }
 // dEmb[id] += dX[row] for id != 0 (padding_idx = 0 receives no gradient: nn.Embedding(padding_idx=0))
-__global__ void embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dX, float* __restrict__ dEmb, int B,
+__global__ void embed_bwd_kernel(const int* __restrict__ ids, const void* __restrict__ dX, int dt, float* __restrict__ dEmb, int B,
                                  int T, int C) {
     int Tp = T + 2;
     int64_t r = blockIdx.x;
@@ -42,19 +53,19 @@ __global__ void embed_bwd_kernel(const int* __restrict__ ids, const float* __res
     if (tp == 0 || tp == Tp - 1) return;
     int id = ids[b * T + tp - 1];
     if (id == 0) return;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(dEmb + (int64_t)id * C + c, dX[r * C + c]);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(dEmb + (int64_t)id * C + c, a_ld(dX, r * C + c, dt));
 }
 
-extern "C" int xva_fp_embed_fwd(const int32_t* ids, const float* emb, const float* pos, float* out, int B, int T, int C,
+extern "C" int xva_fp_embed_fwd(const int32_t* ids, const float* emb, const float* pos, void* out, int dt, int B, int T, int C,
                                 void* stream) {
     XVA_CHECK_ARG(ids && emb && pos && out && C % 4 == 0, "embed_fwd: bad args");
-    hipLaunchKernelGGL(embed_fwd_kernel, dim3(B * (T + 2)), dim3(128), 0, (hipStream_t)stream, ids, emb, pos, out, B, T, C);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(B * (T + 2)), dim3(128), 0, (hipStream_t)stream, ids, emb, pos, out, dt, B, T, C);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
-extern "C" int xva_fp_embed_bwd(const int32_t* ids, const float* dX, float* dEmb, int B, int T, int C, void* stream) {
+extern "C" int xva_fp_embed_bwd(const int32_t* ids, const void* dX, int dt, float* dEmb, int B, int T, int C, void* stream) {
     XVA_CHECK_ARG(ids && dX && dEmb, "embed_bwd: bad args");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * (T + 2)), dim3(128), 0, (hipStream_t)stream, ids, dX, dEmb, B, T, C);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * (T + 2)), dim3(128), 0, (hipStream_t)stream, ids, dX, dt, dEmb, B, T, C);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
@@ -65,20 +76,22 @@ extern "C" int xva_fp_embed_bwd(const int32_t* ids, const float* dX, float* dEmb
 // One wave64 per query row.  Optional dropout on the probabilities (dropatt).
 // =====================================================================================
 #define SM_MAXPL 32  // up to 64*32 = 2048 keys per row
-__global__ void softmax_fwd_kernel(float* __restrict__ S, const int* __restrict__ lens, int B, int Tp, int64_t Ts,
-                                   float p_drop, uint64_t seed, uint32_t stream_id) {
+// Writes the probabilities P in place over S; with attention dropout (dropatt, transformer.py:128) ALSO writes the dropped
+// copy Pd = P * m / (1 - p) that the P.V product consumes (backward needs the undropped P for the softmax Jacobian).
+__global__ void softmax_fwd_kernel(void* __restrict__ S, void* __restrict__ Pd, int dt, const int* __restrict__ lens, int B, int Tp,
+                                   int64_t Ts, float p_drop, uint64_t seed, uint32_t stream_id) {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     if (row >= (int64_t)B * Tp) return;
     int b = (int)(row / Tp);
     int len = lens[b];
-    float* s = S + row * Ts;
+    const int64_t base = row * Ts;
     float v[SM_MAXPL];
     float m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < SM_MAXPL; ++i) {
         int j = lane + 64 * i;
-        v[i] = (j >= 1 && j <= len) ? s[j] : -INFINITY;
+        v[i] = (j >= 1 && j <= len) ? a_ld(S, base + j, dt) : -INFINITY;
         m = fmaxf(m, v[i]);
     }
     m = xva_wave_max(m);
@@ -95,19 +108,18 @@ __global__ void softmax_fwd_kernel(float* __restrict__ S, const int* __restrict_
         int j = lane + 64 * i;
         if (j < Ts) {
             float pv = v[i] * inv;
-            if (p_drop > 0.f) pv *= xva_dropout_scale(p_drop, seed, stream_id, (uint64_t)row * Tp + j);
-            s[j] = pv;
+            a_st(S, base + j, dt, pv);
+            if (Pd) a_st(Pd, base + j, dt, pv * xva_dropout_scale(p_drop, seed, stream_id, (uint64_t)row * Tp + j));
         }
     }
 }
-// dS = scale * P * (dP - sum_k dP_k P_k) in place over dP.
-__global__ void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int B, int Tp, int64_t Ts, float scale,
+// dS = scale * P * (dP - sum_k dP_k P_k) in place over dP, where dP = dPd * m (attention-dropout mask regenerated).
+__global__ void softmax_bwd_kernel(const void* __restrict__ P, void* __restrict__ dP, int dt, int B, int Tp, int64_t Ts, float scale,
                                    float p_drop, uint64_t seed, uint32_t stream_id) {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     if (row >= (int64_t)B * Tp) return;
-    const float* p = P + row * Ts;
-    float* d = dP + row * Ts;
+    const int64_t base = row * Ts;
     float pv[SM_MAXPL], dv[SM_MAXPL];
     float dot = 0.f;
 #pragma unroll
@@ -115,8 +127,8 @@ __global__ void softmax_bwd_kernel(const float* __restrict__ P, float* __restric
         int j = lane + 64 * i;
         pv[i] = 0.f; dv[i] = 0.f;
         if (j < Tp) {
-            float a = p[j], g = d[j];
-            pv[i] = a; dv[i] = g;
+            pv[i] = a_ld(P, base + j, dt);
+            dv[i] = a_ld(dP, base + j, dt) * xva_dropout_scale(p_drop, seed, stream_id, (uint64_t)row * Tp + j);
             dot += pv[i] * dv[i];
         }
     }
@@ -124,50 +136,49 @@ __global__ void softmax_bwd_kernel(const float* __restrict__ P, float* __restric
 #pragma unroll
     for (int i = 0; i < SM_MAXPL; ++i) {
         int j = lane + 64 * i;
-        if (j < Ts) d[j] = (j < Tp) ? scale * pv[i] * (dv[i] - dot) : 0.f;
+        if (j < Ts) a_st(dP, base + j, dt, (j < Tp) ? scale * pv[i] * (dv[i] - dot) : 0.f);
     }
 }
 
-extern "C" int xva_fp_softmax_fwd(float* S, const int32_t* lens, int B, int Tp, int64_t Ts, float p_drop, uint64_t seed,
+extern "C" int xva_fp_softmax_fwd(void* S, void* Pd, int dt, const int32_t* lens, int B, int Tp, int64_t Ts, float p_drop, uint64_t seed,
                                   uint32_t stream_id, void* stream) {
     XVA_CHECK_ARG(S && lens && Ts >= Tp && Ts <= 64 * SM_MAXPL, "softmax_fwd: row length %ld unsupported (max %d)", (long)Ts,
                   64 * SM_MAXPL);
-    XVA_CHECK_ARG(p_drop == 0.f, "softmax: attention dropout is not supported by the backward yet");
+    XVA_CHECK_ARG(p_drop == 0.f || Pd, "softmax_fwd: attention dropout needs the dropped-copy buffer");
     int64_t rows = (int64_t)B * Tp;
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3(xva_cdiv(rows, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
-                       (hipStream_t)stream, S, lens, B, Tp, Ts, p_drop, seed, stream_id);
+                       (hipStream_t)stream, S, p_drop > 0.f ? Pd : (void*)nullptr, dt, lens, B, Tp, Ts, p_drop, seed, stream_id);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
-extern "C" int xva_fp_softmax_bwd(const float* P, float* dP, int B, int Tp, int64_t Ts, float scale, float p_drop,
+extern "C" int xva_fp_softmax_bwd(const void* P, void* dP, int dt, int B, int Tp, int64_t Ts, float scale, float p_drop,
                                   uint64_t seed, uint32_t stream_id, void* stream) {
     XVA_CHECK_ARG(P && dP && Ts >= Tp && Ts <= 64 * SM_MAXPL, "softmax_bwd: bad args");
-    XVA_CHECK_ARG(p_drop == 0.f, "softmax: attention dropout is not supported by the backward yet");
     int64_t rows = (int64_t)B * Tp;
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(xva_cdiv(rows, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
-                       (hipStream_t)stream, P, dP, B, Tp, Ts, scale, p_drop, seed, stream_id);
+                       (hipStream_t)stream, P, dP, dt, B, Tp, Ts, scale, p_drop, seed, stream_id);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
 
 // =====================================================================================
 // LayerNorm over channels, one wave64 per row  (transformer.py:75,146 post-LN; common/layers.py:96)
-// Y = (LN(X) * gamma + beta) * rowmask ; saves mean / rstd.  C = 64 * CPL.
+// Y = (LN(X) * gamma + beta) * rowmask [* dropout]; saves mean / rstd.  C = 64 * CPL.
+// The optional dropout on the OUTPUT is ConvReLUNorm's (common/layers.py:97); transformer LayerNorms pass p_drop = 0.
 // =====================================================================================
 template <int CPL>
-__global__ void layernorm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, float* __restrict__ Y, float* __restrict__ mean,
+__global__ void layernorm_fwd_kernel(const void* __restrict__ X, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, void* __restrict__ Y, int dt, float* __restrict__ mean,
                                      float* __restrict__ rstd, int64_t rows, int mask_mode, const int* __restrict__ lens,
-                                     int Tp, float eps) {
+                                     int Tp, float eps, float p_drop, uint64_t seed, uint32_t stream_id) {
     constexpr int C = 64 * CPL;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     if (row >= rows) return;
-    const float* x = X + row * C;
     float v[CPL];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) { v[i] = x[lane + 64 * i]; s += v[i]; }
+    for (int i = 0; i < CPL; ++i) { v[i] = a_ld(X, row * C + lane + 64 * i, dt); s += v[i]; }
     float mu = xva_wave_sum(s) * (1.f / C);
     float q = 0.f;
 #pragma unroll
@@ -176,22 +187,26 @@ __global__ void layernorm_fwd_kernel(const float* __restrict__ X, const float* _
     float rs = rsqrtf(var + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     bool live = xva_row_live(mask_mode, lens, Tp, row);
-    float* y = Y + row * C;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         int c = lane + 64 * i;
-        y[c] = live ? (v[i] - mu) * rs * gamma[c] + beta[c] : 0.f;
+        float y = live ? (v[i] - mu) * rs * gamma[c] + beta[c] : 0.f;
+        if (p_drop > 0.f) y *= xva_dropout_scale(p_drop, seed, stream_id, (uint64_t)row * C + c);
+        a_st(Y, row * C + c, dt, y);
     }
 }
 
-// dX = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),  dxhat = dY * gamma; dead rows -> 0.
-// relu_gate: additionally zero dX where X <= 0 (X is a post-ReLU activation: ConvReLUNorm).
-// dgamma += sum_r dY * xhat, dbeta += sum_r dY  (per-block partials, then one atomicAdd per column per block).
+// dX = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),  dxhat = dY' * gamma, dY' = dY * m_in (dropout applied on
+// the LN output in forward); dead rows -> 0.  relu_gate: zero dX where X <= 0 (X is a post-ReLU activation).
+// Second output dXm = dX * m_out: the gradient entering a dropout-ed branch (residual + dropout(branch): the residual path
+// takes dX, the branch takes dXm); dXm may be null.  dgamma += sum_r dY' * xhat, dbeta += sum_r dY'.
 template <int CPL>
-__global__ void layernorm_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
-                                     const float* __restrict__ rstd, const float* __restrict__ gamma, float* __restrict__ dX,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int rows_per_block,
-                                     int mask_mode, const int* __restrict__ lens, int Tp, int relu_gate) {
+__global__ void layernorm_bwd_kernel(const void* __restrict__ dY, const void* __restrict__ X, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, const float* __restrict__ gamma, void* __restrict__ dX,
+                                     void* __restrict__ dXm, int dt, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
+                                     int rows_per_block, int mask_mode, const int* __restrict__ lens, int Tp, int relu_gate, float p_in,
+                                     uint64_t seed_in, uint32_t stream_in, float p_out, uint64_t seed_out, uint32_t stream_out,
+                                     const float* __restrict__ outer_d, const float* __restrict__ outer_w) {
     constexpr int C = 64 * CPL;
     __shared__ float sh_g[WAVES_PER_BLOCK][C];
     __shared__ float sh_b[WAVES_PER_BLOCK][C];
@@ -202,22 +217,20 @@ __global__ void layernorm_bwd_kernel(const float* __restrict__ dY, const float* 
 #pragma unroll
     for (int i = 0; i < CPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; gm[i] = gamma[lane + 64 * i]; }
     for (int64_t row = r0 + wave; row < r1; row += WAVES_PER_BLOCK) {
-        float* dx = dX + row * C;
         if (!xva_row_live(mask_mode, lens, Tp, row)) {
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) dx[lane + 64 * i] = 0.f;
+            for (int i = 0; i < CPL; ++i) { a_st(dX, row * C + lane + 64 * i, dt, 0.f); if (dXm) a_st(dXm, row * C + lane + 64 * i, dt, 0.f); }
             continue;
         }
-        const float* x = X + row * C;
-        const float* dy = dY + row * C;
         float mu = mean[row], rs = rstd[row];
         float xh[CPL], dh[CPL], xr[CPL];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             int c = lane + 64 * i;
-            xr[i] = x[c];
-            float g = dy[c];
+            xr[i] = a_ld(X, row * C + c, dt);
+            float g = outer_d ? outer_d[row] * outer_w[c] : a_ld(dY, row * C + c, dt);   // rank-1 dY of a 1-output Linear, kept fp32
+            if (p_in > 0.f) g *= xva_dropout_scale(p_in, seed_in, stream_in, (uint64_t)row * C + c);
             xh[i] = (xr[i] - mu) * rs;
             dh[i] = g * gm[i];
             s1 += dh[i];
@@ -229,9 +242,11 @@ __global__ void layernorm_bwd_kernel(const float* __restrict__ dY, const float* 
         s2 = xva_wave_sum(s2) * (1.f / C);
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
+            int c = lane + 64 * i;
             float v = rs * (dh[i] - s1 - xh[i] * s2);
             if (relu_gate && !(xr[i] > 0.f)) v = 0.f;
-            dx[lane + 64 * i] = v;
+            a_st(dX, row * C + c, dt, v);
+            if (dXm) a_st(dXm, row * C + c, dt, v * xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c));
         }
     }
     if (dgamma) {
@@ -248,34 +263,39 @@ __global__ void layernorm_bwd_kernel(const float* __restrict__ dY, const float* 
     }
 }
 
-extern "C" int xva_fp_layernorm_fwd(const float* X, const float* gamma, const float* beta, float* Y, float* mean, float* rstd,
-                                    int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp, void* stream) {
+extern "C" int xva_fp_layernorm_fwd(const void* X, const float* gamma, const float* beta, void* Y, int dt, float* mean, float* rstd,
+                                    int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp, float p_drop, uint64_t seed,
+                                    uint32_t stream_id, void* stream) {
     XVA_CHECK_ARG(X && gamma && beta && Y && mean && rstd, "layernorm_fwd: null");
     XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
     dim3 grid(xva_cdiv(rows, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
     if (C == 384)
-        hipLaunchKernelGGL((layernorm_fwd_kernel<6>), grid, block, 0, (hipStream_t)stream, X, gamma, beta, Y, mean, rstd, rows,
-                           mask_mode, lens, Tp, 1e-5f);
+        hipLaunchKernelGGL((layernorm_fwd_kernel<6>), grid, block, 0, (hipStream_t)stream, X, gamma, beta, Y, dt, mean, rstd, rows,
+                           mask_mode, lens, Tp, 1e-5f, p_drop, seed, stream_id);
     else
-        hipLaunchKernelGGL((layernorm_fwd_kernel<4>), grid, block, 0, (hipStream_t)stream, X, gamma, beta, Y, mean, rstd, rows,
-                           mask_mode, lens, Tp, 1e-5f);
+        hipLaunchKernelGGL((layernorm_fwd_kernel<4>), grid, block, 0, (hipStream_t)stream, X, gamma, beta, Y, dt, mean, rstd, rows,
+                           mask_mode, lens, Tp, 1e-5f, p_drop, seed, stream_id);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
-extern "C" int xva_fp_layernorm_bwd(const float* dY, const float* X, const float* mean, const float* rstd, const float* gamma,
-                                    float* dX, float* dgamma, float* dbeta, int64_t rows, int C, int mask_mode,
-                                    const int32_t* lens, int Tp, int relu_gate, void* stream) {
-    XVA_CHECK_ARG(dY && X && mean && rstd && gamma && dX, "layernorm_bwd: null");
+extern "C" int xva_fp_layernorm_bwd(const void* dY, const void* X, const float* mean, const float* rstd, const float* gamma,
+                                    void* dX, void* dXm, int dt, float* dgamma, float* dbeta, int64_t rows, int C, int mask_mode,
+                                    const int32_t* lens, int Tp, int relu_gate, float p_in, uint64_t seed_in, uint32_t stream_in,
+                                    float p_out, uint64_t seed_out, uint32_t stream_out, const float* outer_d, const float* outer_w,
+                                    void* stream) {
+    XVA_CHECK_ARG((dY || (outer_d && outer_w)) && X && mean && rstd && gamma && dX, "layernorm_bwd: null");
     XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
     XVA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both null");
     const int rpb = 32;
     dim3 grid(xva_cdiv(rows, rpb)), block(64 * WAVES_PER_BLOCK);
     if (C == 384)
-        hipLaunchKernelGGL((layernorm_bwd_kernel<6>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dgamma,
-                           dbeta, rows, rpb, mask_mode, lens, Tp, relu_gate);
+        hipLaunchKernelGGL((layernorm_bwd_kernel<6>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma,
+                           dbeta, rows, rpb, mask_mode, lens, Tp, relu_gate, p_in, seed_in, stream_in, p_out, seed_out, stream_out,
+                           outer_d, outer_w);
     else
-        hipLaunchKernelGGL((layernorm_bwd_kernel<4>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dgamma,
-                           dbeta, rows, rpb, mask_mode, lens, Tp, relu_gate);
+        hipLaunchKernelGGL((layernorm_bwd_kernel<4>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma,
+                           dbeta, rows, rpb, mask_mode, lens, Tp, relu_gate, p_in, seed_in, stream_in, p_out, seed_out, stream_out,
+                           outer_d, outer_w);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
@@ -283,7 +303,7 @@ extern "C" int xva_fp_layernorm_bwd(const float* dY, const float* X, const float
 // =====================================================================================
 // Column sum (bias gradients): out[c] += sum_r X[r][c].  Block = 64 columns x 4 row lanes.
 // =====================================================================================
-__global__ void colsum_kernel(const float* __restrict__ X, float* __restrict__ out, int64_t rows, int C, int64_t ld,
+__global__ void colsum_kernel(const void* __restrict__ X, int dt, float* __restrict__ out, int64_t rows, int C, int64_t ld,
                               int rows_per_block) {
     __shared__ float sh[4][64];
     int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -292,16 +312,16 @@ __global__ void colsum_kernel(const float* __restrict__ X, float* __restrict__ o
     int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float acc = 0.f;
     if (c < C)
-        for (int64_t r = r0 + rl; r < r1; r += 4) acc += X[r * ld + c];
+        for (int64_t r = r0 + rl; r < r1; r += 4) acc += a_ld(X, r * ld + c, dt);
     sh[rl][cl] = acc;
     __syncthreads();
     if (rl == 0 && c < C) atomicAdd(out + c, sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]);
 }
-extern "C" int xva_fp_colsum(const float* X, float* out, int64_t rows, int C, int64_t ld, void* stream) {
+extern "C" int xva_fp_colsum(const void* X, int dt, float* out, int64_t rows, int C, int64_t ld, void* stream) {
     XVA_CHECK_ARG(X && out && C > 0, "colsum: bad args");
     if (rows <= 0) return XVA_OK;
     const int rpb = 256;
-    hipLaunchKernelGGL(colsum_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, X, out, rows,
+    hipLaunchKernelGGL(colsum_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, X, dt, out, rows,
                        C, ld, rpb);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
@@ -373,8 +393,8 @@ extern "C" int xva_fp_lenreg_map(const int32_t* durs, int32_t* tok, int32_t* tst
 // Conditioning add: out = (in + Conv1d(1 -> C, k=3, pad=1)(s) + bias) * lenmask    (model.py:234-237,403,418)
 // s: (B, Tp) padded 1-channel sequence; w: (C, 3) ; rows live iff 1 <= t' <= lens[b].
 // =====================================================================================
-__global__ void cond_add_fwd_kernel(const float* __restrict__ in, const float* __restrict__ s, const float* __restrict__ w,
-                                    const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ lens, int Tp,
+__global__ void cond_add_fwd_kernel(const void* __restrict__ in, const float* __restrict__ s, const float* __restrict__ w,
+                                    const float* __restrict__ bias, void* __restrict__ out, int dt, const int* __restrict__ lens, int Tp,
                                     int C) {
     int64_t r = blockIdx.x;
     int b = (int)(r / Tp), tp = (int)(r % Tp);
@@ -383,12 +403,12 @@ __global__ void cond_add_fwd_kernel(const float* __restrict__ in, const float* _
     if (live) { const float* sp = s + (int64_t)b * Tp + tp; s0 = sp[-1]; s1 = sp[0]; s2 = sp[1]; }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float v = 0.f;
-        if (live) v = in[r * C + c] + w[c * 3 + 0] * s0 + w[c * 3 + 1] * s1 + w[c * 3 + 2] * s2 + bias[c];
-        out[r * C + c] = v;
+        if (live) v = a_ld(in, r * C + c, dt) + w[c * 3 + 0] * s0 + w[c * 3 + 1] * s1 + w[c * 3 + 2] * s2 + bias[c];
+        a_st(out, r * C + c, dt, v);
     }
 }
 // dw[c][k] += sum_r dOut[r][c] * s[b][t'-1+k], db[c] += sum_r dOut[r][c]   (dOut is zero on dead rows)
-__global__ void cond_add_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ s, float* __restrict__ dw,
+__global__ void cond_add_bwd_kernel(const void* __restrict__ dOut, int dt, const float* __restrict__ s, float* __restrict__ dw,
                                     float* __restrict__ db, const int* __restrict__ lens, int64_t rows, int Tp, int C,
                                     int rows_per_block) {
     __shared__ float sh[4][4][64];
@@ -401,7 +421,7 @@ __global__ void cond_add_bwd_kernel(const float* __restrict__ dOut, const float*
         for (int64_t r = r0 + rl; r < r1; r += 4) {
             int b = (int)(r / Tp), tp = (int)(r % Tp);
             if (tp < 1 || tp > lens[b]) continue;
-            float g = dOut[r * C + c];
+            float g = a_ld(dOut, r * C + c, dt);
             const float* sp = s + (int64_t)b * Tp + tp;
             a0 += g * sp[-1]; a1 += g * sp[0]; a2 += g * sp[1]; ab += g;
         }
@@ -416,19 +436,19 @@ __global__ void cond_add_bwd_kernel(const float* __restrict__ dOut, const float*
         if (db) atomicAdd(db + c, t[3]);
     }
 }
-extern "C" int xva_fp_cond_add_fwd(const float* in, const float* s, const float* w, const float* bias, float* out,
+extern "C" int xva_fp_cond_add_fwd(const void* in, const float* s, const float* w, const float* bias, void* out, int dt,
                                    const int32_t* lens, int B, int Tp, int C, void* stream) {
     XVA_CHECK_ARG(in && s && w && bias && out && lens, "cond_add_fwd: null");
-    hipLaunchKernelGGL(cond_add_fwd_kernel, dim3(B * Tp), dim3(128), 0, (hipStream_t)stream, in, s, w, bias, out, lens, Tp, C);
+    hipLaunchKernelGGL(cond_add_fwd_kernel, dim3(B * Tp), dim3(128), 0, (hipStream_t)stream, in, s, w, bias, out, dt, lens, Tp, C);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
-extern "C" int xva_fp_cond_add_bwd(const float* dOut, const float* s, float* dw, float* db, const int32_t* lens, int B, int Tp,
+extern "C" int xva_fp_cond_add_bwd(const void* dOut, int dt, const float* s, float* dw, float* db, const int32_t* lens, int B, int Tp,
                                    int C, void* stream) {
     XVA_CHECK_ARG(dOut && s && lens, "cond_add_bwd: null");
     int64_t rows = (int64_t)B * Tp;
     const int rpb = 128;
-    hipLaunchKernelGGL(cond_add_bwd_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, dOut, s,
+    hipLaunchKernelGGL(cond_add_bwd_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, dOut, dt, s,
                        dw, db, lens, rows, Tp, C, rpb);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
@@ -439,31 +459,26 @@ extern "C" int xva_fp_cond_add_bwd(const float* dOut, const float* s, float* dw,
 //   out[b, t', :] = enc[b, tok[b][t'-1] + 1, :] + pos[t'-1]   for 1 <= t' <= dec_lens[b], else 0
 // backward = segmented sum (no atomics): dEnc[b, j+1, :] (+)= sum_{t in span j} dOut[b, t+1, :]
 // =====================================================================================
-__global__ void lenreg_fwd_kernel(const float* __restrict__ enc, const int* __restrict__ tok, const int* __restrict__ dec_lens,
-                                  const float* __restrict__ pos, float* __restrict__ out, int Tt, int Tm, int C) {
+__global__ void lenreg_fwd_kernel(const void* __restrict__ enc, const int* __restrict__ tok, const int* __restrict__ dec_lens,
+                                  const float* __restrict__ pos, void* __restrict__ out, int dt, int Tt, int Tm, int C) {
     int Tmp = Tm + 2, Ttp = Tt + 2;
     int64_t r = blockIdx.x;
     int b = (int)(r / Tmp), tp = (int)(r % Tmp);
-    float4* o = reinterpret_cast<float4*>(out + r * C);
     int j = -1;
     if (tp >= 1 && tp <= dec_lens[b]) j = tok[(int64_t)b * Tm + tp - 1];
     if (j < 0) {
-        for (int c = threadIdx.x; c < C / 4; c += blockDim.x) o[c] = make_float4(0, 0, 0, 0);
+        for (int c = threadIdx.x; c < C; c += blockDim.x) a_st(out, r * C + c, dt, 0.f);
         return;
     }
-    const float4* e = reinterpret_cast<const float4*>(enc + ((int64_t)b * Ttp + j + 1) * C);
-    const float4* p = reinterpret_cast<const float4*>(pos + (int64_t)(tp - 1) * C);
-    for (int c = threadIdx.x; c < C / 4; c += blockDim.x) {
-        float4 v = e[c], q = p[c];
-        o[c] = make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w);
-    }
+    const int64_t eb = ((int64_t)b * Ttp + j + 1) * C;
+    const float* p = pos + (int64_t)(tp - 1) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) a_st(out, r * C + c, dt, a_ld(enc, eb + c, dt) + p[c]);
 }
-__global__ void lenreg_bwd_kernel(const float* __restrict__ dOut, const int* __restrict__ tstart, const int* __restrict__ dec_lens,
-                                  float* __restrict__ dEnc, int Tt, int Tm, int C, int accumulate) {
+__global__ void lenreg_bwd_kernel(const void* __restrict__ dOut, const int* __restrict__ tstart, const int* __restrict__ dec_lens,
+                                  void* __restrict__ dEnc, int dt, int Tt, int Tm, int C, int accumulate) {
     int Tmp = Tm + 2, Ttp = Tt + 2;
     int64_t r = blockIdx.x;  // row of dEnc
     int b = (int)(r / Ttp), tp = (int)(r % Ttp);
-    float4* o = reinterpret_cast<float4*>(dEnc + r * C);
     int t0 = 0, t1 = 0;
     if (tp >= 1 && tp <= Tt) {
         t0 = tstart[b * (Tt + 1) + tp - 1];
@@ -472,28 +487,25 @@ __global__ void lenreg_bwd_kernel(const float* __restrict__ dOut, const int* __r
         if (t0 > dl) t0 = dl;
         if (t1 > dl) t1 = dl;
     }
-    for (int c = threadIdx.x; c < C / 4; c += blockDim.x) {
-        float4 a = make_float4(0, 0, 0, 0);
-        for (int t = t0; t < t1; ++t) {
-            float4 g = reinterpret_cast<const float4*>(dOut + ((int64_t)b * Tmp + t + 1) * C)[c];
-            a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
-        }
-        if (accumulate) { float4 q = o[c]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
-        o[c] = a;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f;
+        for (int t = t0; t < t1; ++t) a += a_ld(dOut, ((int64_t)b * Tmp + t + 1) * C + c, dt);
+        if (accumulate) a += a_ld(dEnc, r * C + c, dt);
+        a_st(dEnc, r * C + c, dt, a);
     }
 }
-extern "C" int xva_fp_lenreg_fwd(const float* enc, const int32_t* tok, const int32_t* dec_lens, const float* pos, float* out,
+extern "C" int xva_fp_lenreg_fwd(const void* enc, const int32_t* tok, const int32_t* dec_lens, const float* pos, void* out, int dt,
                                  int B, int Tt, int Tm, int C, void* stream) {
     XVA_CHECK_ARG(enc && tok && dec_lens && pos && out && C % 4 == 0, "lenreg_fwd: bad args");
-    hipLaunchKernelGGL(lenreg_fwd_kernel, dim3(B * (Tm + 2)), dim3(128), 0, (hipStream_t)stream, enc, tok, dec_lens, pos, out, Tt,
+    hipLaunchKernelGGL(lenreg_fwd_kernel, dim3(B * (Tm + 2)), dim3(128), 0, (hipStream_t)stream, enc, tok, dec_lens, pos, out, dt, Tt,
                        Tm, C);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
-extern "C" int xva_fp_lenreg_bwd(const float* dOut, const int32_t* tstart, const int32_t* dec_lens, float* dEnc, int B, int Tt,
+extern "C" int xva_fp_lenreg_bwd(const void* dOut, const int32_t* tstart, const int32_t* dec_lens, void* dEnc, int dt, int B, int Tt,
                                  int Tm, int C, int accumulate, void* stream) {
     XVA_CHECK_ARG(dOut && tstart && dec_lens && dEnc && C % 4 == 0, "lenreg_bwd: bad args");
-    hipLaunchKernelGGL(lenreg_bwd_kernel, dim3(B * (Tt + 2)), dim3(128), 0, (hipStream_t)stream, dOut, tstart, dec_lens, dEnc, Tt,
+    hipLaunchKernelGGL(lenreg_bwd_kernel, dim3(B * (Tt + 2)), dim3(128), 0, (hipStream_t)stream, dOut, tstart, dec_lens, dEnc, dt, Tt,
                        Tm, C, accumulate);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
@@ -506,7 +518,7 @@ extern "C" int xva_fp_lenreg_bwd(const float* dOut, const int32_t* tstart, const
 //   grads:     d_pred = grad_scale * w * 2 * (pred - tgt) * mask / den
 // mel_out: (B, Tm+2, 80) padded token-major ; mel_tgt: (B, 80, Tm) reference layout ; mask = (tgt != 0).
 // =====================================================================================
-__global__ void mel_loss_partial_kernel(const float* __restrict__ mel_out, const float* __restrict__ mel_tgt,
+__global__ void mel_loss_partial_kernel(const void* __restrict__ mel_out, int dt, const float* __restrict__ mel_tgt,
                                         float* __restrict__ acc, int B, int Tm, int NM) {
     __shared__ float sh[16];
     int64_t total = (int64_t)B * NM * Tm;
@@ -517,7 +529,7 @@ __global__ void mel_loss_partial_kernel(const float* __restrict__ mel_out, const
         int b = (int)(i / ((int64_t)Tm * NM));
         float tg = mel_tgt[i];
         if (tg != 0.f) {
-            float o = mel_out[((int64_t)b * (Tm + 2) + t + 1) * NM + c];
+            float o = a_ld(mel_out, ((int64_t)b * (Tm + 2) + t + 1) * NM + c, dt);
             float d = o - tg;
             num += d * d;
             den += 1.f;
@@ -527,8 +539,8 @@ __global__ void mel_loss_partial_kernel(const float* __restrict__ mel_out, const
     den = xva_block_sum(den, sh);
     if (threadIdx.x == 0) { atomicAdd(acc + 0, num); atomicAdd(acc + 1, den); }
 }
-__global__ void mel_loss_grad_kernel(const float* __restrict__ mel_out, const float* __restrict__ mel_tgt,
-                                     const float* __restrict__ acc, float* __restrict__ d_mel, int B, int Tm, int NM,
+__global__ void mel_loss_grad_kernel(const void* __restrict__ mel_out, int dt, const float* __restrict__ mel_tgt,
+                                     const float* __restrict__ acc, void* __restrict__ d_mel, int B, int Tm, int NM,
                                      float grad_scale) {
     int Tmp = Tm + 2;
     int64_t total = (int64_t)B * Tmp * NM;
@@ -541,9 +553,9 @@ __global__ void mel_loss_grad_kernel(const float* __restrict__ mel_out, const fl
         float g = 0.f;
         if (tp >= 1 && tp <= Tm) {
             float tg = mel_tgt[((int64_t)b * NM + c) * Tm + tp - 1];
-            if (tg != 0.f) g = k * (mel_out[i] - tg);
+            if (tg != 0.f) g = k * (a_ld(mel_out, i, dt) - tg);
         }
-        d_mel[i] = g;
+        a_st(d_mel, i, dt, g);
     }
 }
 // token-level masked MSE between pred (B, Tp) padded sequence [ld 1] and tgt (B, Tp) padded sequence.
@@ -596,7 +608,7 @@ __global__ void loss_finalize_kernel(const float* __restrict__ acc, float* __res
     out[1] = mel; out[2] = dur; out[3] = pitch; out[4] = energy;
 }
 
-extern "C" int xva_fp_loss_partials(int stage, const float* mel_out, const float* mel_tgt, const float* pitch_pred,
+extern "C" int xva_fp_loss_partials(int stage, int dt, const void* mel_out, const float* mel_tgt, const float* pitch_pred,
                                     const float* pitch_tgt, const float* energy_pred, const float* energy_tgt,
                                     const float* log_dur_pred, const int32_t* durs, const int32_t* in_lens, float* acc, int B,
                                     int Tt, int Tm, void* stream) {
@@ -608,7 +620,7 @@ extern "C" int xva_fp_loss_partials(int stage, const float* mel_out, const float
         XVA_CHECK_ARG(mel_out && mel_tgt, "loss_partials: null mel");
         int64_t total = (int64_t)B * 80 * Tm;
         int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(mel_loss_partial_kernel, dim3(grid), dim3(256), 0, st, mel_out, mel_tgt, acc, B, Tm, 80);
+        hipLaunchKernelGGL(mel_loss_partial_kernel, dim3(grid), dim3(256), 0, st, mel_out, dt, mel_tgt, acc, B, Tm, 80);
     }
     if (stage == 3) {
         XVA_CHECK_ARG(pitch_pred && pitch_tgt && energy_pred && energy_tgt, "loss_partials: null pitch/energy");
@@ -626,10 +638,10 @@ extern "C" int xva_fp_loss_partials(int stage, const float* mel_out, const float
     return XVA_OK;
 }
 
-extern "C" int xva_fp_loss_grads(int stage, const float* mel_out, const float* mel_tgt, const float* pitch_pred,
+extern "C" int xva_fp_loss_grads(int stage, int dt, const void* mel_out, const float* mel_tgt, const float* pitch_pred,
                                  const float* pitch_tgt, const float* energy_pred, const float* energy_tgt,
                                  const float* log_dur_pred, const int32_t* durs, const int32_t* in_lens, const float* acc,
-                                 float* losses_out, float* d_mel, float* d_pitch, float* d_energy, float* d_logdur, int B, int Tt,
+                                 float* losses_out, void* d_mel, float* d_pitch, float* d_energy, float* d_logdur, int B, int Tt,
                                  int Tm, float grad_scale, float dur_w, float pitch_w, float energy_w, void* stream) {
     XVA_CHECK_ARG(acc && losses_out && in_lens, "loss_grads: null");
     hipStream_t st = (hipStream_t)stream;
@@ -638,7 +650,7 @@ extern "C" int xva_fp_loss_grads(int stage, const float* mel_out, const float* m
         XVA_CHECK_ARG(mel_out && mel_tgt && d_mel, "loss_grads: null mel");
         int64_t total = (int64_t)B * (Tm + 2) * 80;
         int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(mel_loss_grad_kernel, dim3(grid), dim3(256), 0, st, mel_out, mel_tgt, acc, d_mel, B, Tm, 80, grad_scale);
+        hipLaunchKernelGGL(mel_loss_grad_kernel, dim3(grid), dim3(256), 0, st, mel_out, dt, mel_tgt, acc, d_mel, B, Tm, 80, grad_scale);
     }
     if (stage == 3) {
         XVA_CHECK_ARG(d_pitch && d_energy, "loss_grads: null pitch/energy grads");
@@ -675,12 +687,12 @@ extern "C" int xva_fp_dur_from_log(const float* logd, float* out, int n, float m
 //   outer:          out[r][c]  = s[r] * w[c]
 //   rowscale_colsum out[c]    += sum_r s[r] * X[r][c]
 // =====================================================================================
-__global__ void outer_kernel(const float* __restrict__ s, const float* __restrict__ w, float* __restrict__ out, int64_t rows, int C) {
+__global__ void outer_kernel(const float* __restrict__ s, const float* __restrict__ w, void* __restrict__ out, int dt, int64_t rows, int C) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * C) return;
-    out[i] = s[i / C] * w[i % C];
+    a_st(out, i, dt, s[i / C] * w[i % C]);
 }
-__global__ void rowscale_colsum_kernel(const float* __restrict__ X, const float* __restrict__ s, float* __restrict__ out,
+__global__ void rowscale_colsum_kernel(const void* __restrict__ X, int dt, const float* __restrict__ s, float* __restrict__ out,
                                        int64_t rows, int C, int rows_per_block) {
     __shared__ float sh[4][64];
     int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -689,22 +701,47 @@ __global__ void rowscale_colsum_kernel(const float* __restrict__ X, const float*
     int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float acc = 0.f;
     if (c < C)
-        for (int64_t r = r0 + rl; r < r1; r += 4) acc += s[r] * X[r * C + c];
+        for (int64_t r = r0 + rl; r < r1; r += 4) acc += s[r] * a_ld(X, r * C + c, dt);
     sh[rl][cl] = acc;
     __syncthreads();
     if (rl == 0 && c < C) atomicAdd(out + c, sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]);
 }
-extern "C" int xva_fp_outer(const float* s, const float* w, float* out, int64_t rows, int C, void* stream) {
+extern "C" int xva_fp_outer(const float* s, const float* w, void* out, int dt, int64_t rows, int C, void* stream) {
     XVA_CHECK_ARG(s && w && out, "outer: null");
-    hipLaunchKernelGGL(outer_kernel, dim3(xva_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, s, w, out, rows, C);
+    hipLaunchKernelGGL(outer_kernel, dim3(xva_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, s, w, out, dt, rows, C);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
-extern "C" int xva_fp_rowscale_colsum(const float* X, const float* s, float* out, int64_t rows, int C, void* stream) {
+extern "C" int xva_fp_rowscale_colsum(const void* X, int dt, const float* s, float* out, int64_t rows, int C, void* stream) {
     XVA_CHECK_ARG(X && s && out, "rowscale_colsum: null");
     const int rpb = 256;
-    hipLaunchKernelGGL(rowscale_colsum_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, X, s,
+    hipLaunchKernelGGL(rowscale_colsum_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, X, dt, s,
                        out, rows, C, rpb);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// fp32 master parameters -> activation-dtype shadow used as GEMM operands (bf16 mode), once per step
+__global__ void cast_kernel(const float* __restrict__ src, void* __restrict__ dst, int dt, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a_st(dst, i, dt, src[i]);
+}
+extern "C" int xva_cast_f32(const float* src, void* dst, int dt, int64_t n, void* stream) {
+    XVA_CHECK_ARG(src && dst, "cast: null");
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, dt, n);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// activation-dtype tensor -> fp32 copy (the temporal predictors run on fp32-stored tensors: their gradients are sums of
+// near-cancelling terms and bf16 storage noise is amplified ~10x there; they are < 2 % of the step's bytes)
+__global__ void cast_to_f32_kernel(const void* __restrict__ src, int dt, float* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = a_ld(src, i, dt);
+}
+extern "C" int xva_cast_to_f32(const void* src, int dt, float* dst, int64_t n, void* stream) {
+    XVA_CHECK_ARG(src && dst, "cast: null");
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(cast_to_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dt, dst, n);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }

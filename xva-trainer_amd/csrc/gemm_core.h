@@ -431,6 +431,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
                 float v = acc[i][j][r];
                 if ((p.splitk == 1 || first_split) && p.bias) v += p.bias[(int64_t)z2 * p.sbias2 + col];
                 v *= p.alpha;
+                if (p.drop_p > 0.f) v *= xva_dropout_scale(p.drop_p, p.drop_seed, p.drop_stream, (uint64_t)row * p.N + col);
                 if (p.G) v = (ld_elem(p.G, goff + (int64_t)row * p.ldg + col, p.g_dtype) > 0.f) ? v : v * p.gate_slope;
                 if ((p.splitk == 1 || first_split) && p.R) v += p.beta * ld_elem(p.R, roff + (int64_t)row * p.ldr + col, p.r_dtype);
                 switch (p.act) {

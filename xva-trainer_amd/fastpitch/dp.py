@@ -77,7 +77,7 @@ class GradSync:
         losses = eng.loss_grads(batch, stage, grad_scale)
         d = eng._prepare(batch.B, batch.Tt, batch.Tm, stage)
         rc = lib.xva_fp_backward_ex(C.byref(d), _lib.ptr(self.flat), _lib.ptr(self.grads), C.byref(eng._abi), _lib.ptr(eng._ws),
-                                    eng._ws.numel() * 4, self.events if sync else None, _lib.stream_ptr())
+                                    eng._ws.numel(), self.events if sync else None, _lib.stream_ptr())
         _lib.check(rc, "xva_fp_backward_ex")
         if sync:
             comm_ptr = C.c_void_p(self.comm.cuda_stream)

@@ -15,7 +15,7 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 
 class FpDims(C.Structure):
-    _fields_ = [("B", i32), ("Tt", i32), ("Tm", i32), ("stage", i32), ("compute", i32)]
+    _fields_ = [("B", i32), ("Tt", i32), ("Tm", i32), ("stage", i32), ("compute", i32), ("p_dropout", f32), ("seed", C.c_uint64)]
 
 
 class FpBatch(C.Structure):
@@ -41,11 +41,12 @@ lib.xva_fp_forward.argtypes = [C.POINTER(FpDims), vp, C.POINTER(FpBatch), vp, i6
 lib.xva_fp_backward.restype = i32
 lib.xva_fp_backward.argtypes = [C.POINTER(FpDims), vp, vp, C.POINTER(FpBatch), vp, i64, vp]
 lib.xva_fp_loss_partials.restype = i32
-lib.xva_fp_loss_partials.argtypes = [i32] + [vp] * 10 + [i32, i32, i32, vp]
+lib.xva_fp_loss_partials.argtypes = [i32, i32] + [vp] * 10 + [i32, i32, i32, vp]
 lib.xva_fp_loss_grads.restype = i32
-lib.xva_fp_loss_grads.argtypes = [i32] + [vp] * 15 + [i32, i32, i32, f32, f32, f32, f32, vp]
+lib.xva_fp_loss_grads.argtypes = [i32, i32] + [vp] * 15 + [i32, i32, i32, f32, f32, f32, f32, vp]
 
 COMPUTE = {"fp32": 0, "bf16": 1, 0: 0, 1: 1}
+ACT_SLOTS = {"MEL_OUT", "D_MEL", "ENC_OUT", "DEC_OUT", "ENC_COND"}   # stored in the activation dtype (bf16 when compute == bf16)
 
 
 def tensor_table():
@@ -97,11 +98,17 @@ class DeviceBatch:
 
 
 class FastPitchEngine:
-    def __init__(self, device, compute="bf16"):
+    def __init__(self, device, compute="bf16", p_dropout=0.0, seed=1234):
+        """p_dropout: the reference trains with 0.1 on every dropout site (model.py:248-263 defaults; nn.Module.train()); 0
+        gives the deterministic network the parity tests pin.  Masks are a pure function of (seed + step, site, index)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.XvaError("FastPitchEngine needs a GPU device; the hot path has no CPU implementation")
         self.compute = COMPUTE[compute]
+        self.act_dtype = torch.bfloat16 if self.compute else torch.float32
+        self.p_dropout = float(p_dropout)
+        self.seed = int(seed)
+        self.step = 0
         self.table = tensor_table()
         self.total = int(lib.xva_fp_param_floats())
         self._ws = None
@@ -112,14 +119,16 @@ class FastPitchEngine:
 
     # -- workspace ---------------------------------------------------------------------
     def _prepare(self, B, Tt, Tm, stage):
-        key = (B, Tt, Tm, int(stage), self.compute)
+        key = (B, Tt, Tm, int(stage), self.compute, self.p_dropout)
         if key != self._ws_key:
-            d = FpDims(B, Tt, Tm, int(stage), self.compute)
+            d = FpDims(B, Tt, Tm, int(stage), self.compute, self.p_dropout, self.seed)
             need = int(lib.xva_fp_workspace_bytes(C.byref(d)))
             if need < 0:
                 raise _lib.XvaError("xva_fp_workspace_bytes: " + lib.xva_last_error().decode())
-            if self._ws is None or self._ws.numel() * 4 < need:
-                self._ws = torch.zeros((need + 3) // 4, device=self.device, dtype=torch.float32)  # zero ONCE: guard rows
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.zeros(need, device=self.device, dtype=torch.uint8)  # zero ONCE: guard rows
+            else:
+                self._ws.zero_()   # a new geometry moves the structural-zero rows
             self._dims = d
             self._ws_key = key
             self._slot_off = {}
@@ -132,15 +141,16 @@ class FastPitchEngine:
                 self._pos = positional_table(max(tmax, 1024), device=self.device)
         return self._dims
 
-    def slot(self, name, shape, dtype=torch.float32):
+    def slot(self, name, shape, dtype=None):
+        """View of a workspace slot (no copy).  Activation slots carry the engine's activation dtype."""
+        if dtype is None:
+            dtype = self.act_dtype if name in ACT_SLOTS else torch.float32
         off = self._slot_off[name]
         n = 1
         for s in shape:
             n *= s
-        v = self._ws[off:off + n]
-        if dtype != torch.float32:
-            v = v.view(dtype)
-        return v.view(*shape)
+        nb = n * torch.empty((), dtype=dtype).element_size()
+        return self._ws[off:off + nb].view(dtype).view(*shape)
 
     def _abi_batch(self, b):
         return FpBatch(_lib.ptr(b.text), _lib.ptr(b.in_lens), _lib.ptr(b.durs), _lib.ptr(b.pitch), _lib.ptr(b.energy), _lib.ptr(self._pos))
@@ -148,23 +158,25 @@ class FastPitchEngine:
     # -- the three calls ---------------------------------------------------------------
     def forward(self, flat_params, b, stage):
         d = self._prepare(b.B, b.Tt, b.Tm, stage)
+        d.seed = (self.seed + 0x9E3779B97F4A7C15 * self.step) & 0xFFFFFFFFFFFFFFFF   # backward regenerates the same masks
+        self.step += 1
         self._abi = self._abi_batch(b)
-        _lib.check(lib.xva_fp_forward(C.byref(d), _lib.ptr(flat_params), C.byref(self._abi), _lib.ptr(self._ws), self._ws.numel() * 4,
+        _lib.check(lib.xva_fp_forward(C.byref(d), _lib.ptr(flat_params), C.byref(self._abi), _lib.ptr(self._ws), self._ws.numel(),
                                       _lib.stream_ptr()), "xva_fp_forward")
 
     def _loss_args(self, b):
-        sp = lambda n: C.c_void_p(self._ws.data_ptr() + 4 * self._slot_off[n])
+        sp = lambda n: C.c_void_p(self._ws.data_ptr() + self._slot_off[n])
         return [sp("MEL_OUT"), _lib.ptr(b.mel_tgt), sp("PITCH_PRED"), sp("PITCH_TGT"), sp("ENERGY_PRED"), sp("ENERGY_TGT"),
                 sp("LOG_DUR_PRED"), _lib.ptr(b.durs), _lib.ptr(b.in_lens)], sp
 
     def loss_partials(self, b, stage):
         args, sp = self._loss_args(b)
-        _lib.check(lib.xva_fp_loss_partials(int(stage), *args, sp("LOSS_ACC"), b.B, b.Tt, b.Tm, _lib.stream_ptr()), "xva_fp_loss_partials")
+        _lib.check(lib.xva_fp_loss_partials(int(stage), self.compute, *args, sp("LOSS_ACC"), b.B, b.Tt, b.Tm, _lib.stream_ptr()), "xva_fp_loss_partials")
         return self.slot("LOSS_ACC", (8,))
 
     def loss_grads(self, b, stage, grad_scale=1.0, dur_w=0.1, pitch_w=0.1, energy_w=0.1):
         args, sp = self._loss_args(b)
-        _lib.check(lib.xva_fp_loss_grads(int(stage), *args, sp("LOSS_ACC"), sp("LOSSES"), sp("D_MEL"), sp("D_PITCH"), sp("D_ENERGY"),
+        _lib.check(lib.xva_fp_loss_grads(int(stage), self.compute, *args, sp("LOSS_ACC"), sp("LOSSES"), sp("D_MEL"), sp("D_PITCH"), sp("D_ENERGY"),
                                          sp("D_LOGDUR"), b.B, b.Tt, b.Tm, grad_scale, dur_w, pitch_w, energy_w, _lib.stream_ptr()),
                    "xva_fp_loss_grads")
         return self.slot("LOSSES", (8,))
@@ -172,7 +184,7 @@ class FastPitchEngine:
     def backward(self, flat_params, flat_grads, b, stage):
         d = self._prepare(b.B, b.Tt, b.Tm, stage)
         _lib.check(lib.xva_fp_backward(C.byref(d), _lib.ptr(flat_params), _lib.ptr(flat_grads), C.byref(self._abi), _lib.ptr(self._ws),
-                                       self._ws.numel() * 4, _lib.stream_ptr()), "xva_fp_backward")
+                                       self._ws.numel(), _lib.stream_ptr()), "xva_fp_backward")
 
     def fwd_loss_bwd(self, flat_params, flat_grads, b, stage, grad_scale=1.0, reduce_acc=None):
         """One micro-batch: forward, loss (optionally all-reducing the loss numerators/denominators across DP ranks through

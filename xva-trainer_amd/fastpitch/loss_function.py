@@ -27,7 +27,7 @@ class _LossFn(torch.autograd.Function):
         if stage == 2:
             d = eng.slot("D_LOGDUR", (b.B, b.Tt + 2))[:, 1:b.Tt + 1]
             return None, None, d * s
-        dm = eng.slot("D_MEL", (b.B, b.Tm + 2, 80))[:, 1:b.Tm + 1]
+        dm = eng.slot("D_MEL", (b.B, b.Tm + 2, 80))[:, 1:b.Tm + 1].float()
         dp = eng.slot("D_PITCH", (b.B, b.Tt + 2))[:, 1:b.Tt + 1].unsqueeze(1)
         de = eng.slot("D_ENERGY", (b.B, b.Tt + 2))[:, 1:b.Tt + 1]
         if stage == 4:

@@ -31,7 +31,7 @@ class _FastPitchFn(torch.autograd.Function):
         o = eng.outputs(batch, stage)
         if stage == 2:
             return o["log_dur_pred"].clone(), o["dur_pred"].clone()
-        return o["mel_out"].clone(), o["pitch_pred"].clone(), o["energy_pred"].clone()
+        return o["mel_out"].to(torch.float32, copy=True), o["pitch_pred"].clone(), o["energy_pred"].clone()
 
     @staticmethod
     def backward(ctx, *gouts):
@@ -57,10 +57,13 @@ class _FastPitchFn(torch.autograd.Function):
 
 
 class FastPitch(nn.Module):
-    def __init__(self, logger=None, compute="bf16"):
+    def __init__(self, logger=None, compute="bf16", p_dropout=0.1):
+        """p_dropout: every dropout site of the reference model (p_in_fft_dropout, p_in_fft_dropatt, dur/pitch/energy predictor
+        dropout, ... model.py:248-263) is 0.1; it is applied in train() mode and off in eval() mode like nn.Dropout."""
         super().__init__()
         self.logger = logger
         self.compute = compute
+        self.p_dropout = float(p_dropout)
         self._table = E.tensor_table()
         total = int(_lib.lib.xva_fp_param_floats())
         self.flat = nn.Parameter(torch.zeros(total))
@@ -77,6 +80,7 @@ class FastPitch(nn.Module):
     def _get_engine(self):
         if self._engine is None or self._engine.device != self.flat.device:
             self._engine = E.FastPitchEngine(self.flat.device, self.compute)
+        self._engine.p_dropout = self.p_dropout if self.training else 0.0
         return self._engine
 
     def named_tensors(self):
