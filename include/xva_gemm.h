@@ -91,10 +91,20 @@ typedef struct xva_gemm_params {
     float drop_p;
     uint64_t drop_seed;
     uint32_t drop_stream;
+    /* optional split-K scratch (device, 16-byte aligned): when splitk > 1 and sk_ws holds >= splitk * batch * batch2 * M * N floats
+     * each K split writes its partial tile there and a second launch reduces them into C (no atomics; deterministic order).
+     * Without it split-K accumulates with fp32 atomics. */
+    void* sk_ws;
+    int64_t sk_ws_bytes;
 } xva_gemm_params;
 
 /* Launches on `stream` (a hipStream_t); returns 0 or a negative XVA_ERR_* code. */
 int xva_gemm(const xva_gemm_params* p, void* stream);
+
+/* Diagnostics / test knob: main-loop selection for bf16-stored operands. -1 automatic (default), 0 general register-staged kernel,
+ * 1 direct-to-LDS 128x128 tiles, 2 direct-to-LDS 256x256 tiles wherever eligible. Returns the previous mode. Results are the
+ * same up to fp32 summation order. */
+int xva_gemm_set_mainloop(int mode);
 
 #ifdef __cplusplus
 }

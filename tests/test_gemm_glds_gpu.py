@@ -1,0 +1,190 @@
+"""GPU parity of the direct-to-LDS GEMM main loop (csrc/gemm_glds.h: global_load_lds staging, LDS transpose reads, 64-deep
+K tiles, 128x128 and 256x256 tiles) against fp64 references built from the same bf16-rounded operands.  With an fp32 C the
+only difference to the reference is fp32 accumulation order, so the bound is tight; bf16 C adds one rounding."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from xva_trainer_amd import _lib
+    _lib.lib.xva_gemm_set_mainloop.restype = int
+    return _lib
+
+
+@pytest.fixture(params=[1, 2], ids=["tile128", "tile256"])
+def mainloop(request):
+    L = _lib()
+    old = L.lib.xva_gemm_set_mainloop(request.param)
+    yield request.param
+    L.lib.xva_gemm_set_mainloop(old)
+
+
+def _bf(rows, cols, ld=None, scale=1.0):
+    ld = ld or (cols + 7) // 8 * 8
+    return (torch.randn(rows, ld, device="cuda") * scale).bfloat16(), ld
+
+
+def _rel(out, ref):
+    return ((out.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 256), (257, 136, 1000), (1000, 520, 328), (64, 72, 192), (129, 1000, 4608)])
+def test_nt_ragged(mainloop, M, N, K):
+    L = _lib()
+    torch.manual_seed(M + N + K)
+    A, lda = _bf(M, K, K + 8)
+    B, ldb = _bf(N, K)
+    C32 = torch.full((M, N), 3.0, device="cuda")
+    L.gemm(A, B, C32, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=1)
+    ref = A[:, :K].double() @ B[:, :K].double().t()
+    assert _rel(C32, ref) < 2e-6
+    C16 = torch.zeros(M, N + 8, device="cuda", dtype=torch.bfloat16)
+    L.gemm(A, B, C16, M, N, K, lda, ldb, N + 8, layout=L.GEMM_NT, compute=1)
+    assert _rel(C16[:, :N], ref) < 5e-3
+    assert C16[:, N:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 256), (130, 136, 864), (1000, 520, 328), (257, 72, 1000)])
+def test_nn_and_tn_ragged(mainloop, M, N, K):
+    L = _lib()
+    torch.manual_seed(M * 3 + N + K)
+    A, lda = _bf(M, K)
+    B, ldb = _bf(K, N, N + 16)
+    C32 = torch.zeros(M, N, device="cuda")
+    L.gemm(A, B, C32, M, N, K, lda, ldb, N, layout=L.GEMM_NN, compute=1)
+    assert _rel(C32, A[:, :K].double() @ B[:, :N].double()) < 2e-6
+    # TN: both operands k-major
+    Mt = (M + 7) // 8 * 8
+    At, ldat = _bf(K, Mt)
+    C0 = torch.randn(Mt, N, device="cuda")
+    Ct = C0.clone()
+    L.gemm(At, B, Ct, Mt, N, K, ldat, ldb, N, layout=L.GEMM_TN, compute=1, accumulate=True)
+    ref = C0.double() + At[:, :Mt].double().t() @ B[:, :N].double()
+    assert _rel(Ct, ref) < 2e-6
+
+
+@pytest.mark.parametrize("splitk,slabs", [(3, False), (5, True), (16, True)])
+def test_tn_splitk_atomics_and_slabs(mainloop, splitk, slabs):
+    """Weight-gradient form: huge K, fp32 accumulate into C; split-K through fp32 atomics or through scratch slabs + reduce."""
+    L = _lib()
+    torch.manual_seed(5)
+    M, N, K = 384, 1152, 6000
+    A, lda = _bf(K, M, scale=0.3)
+    B, ldb = _bf(K, N, scale=0.3)
+    C0 = torch.randn(M, N, device="cuda")
+    Cm = C0.clone()
+    ws = torch.empty(splitk * M * N, device="cuda") if slabs else None
+    L.gemm(A, B, Cm, M, N, K, lda, ldb, N, layout=L.GEMM_TN, compute=1, accumulate=True, splitk=splitk, sk_ws=ws)
+    ref = C0.double() + A[:, :M].double().t() @ B[:, :N].double()
+    assert _rel(Cm, ref) < 3e-6
+    if slabs:   # the slab path is deterministic
+        C2 = C0.clone()
+        L.gemm(A, B, C2, M, N, K, lda, ldb, N, layout=L.GEMM_TN, compute=1, accumulate=True, splitk=splitk, sk_ws=ws)
+        assert torch.equal(C2, Cm)
+
+
+def test_tn_kblocks_and_column_segments(mainloop):
+    """K-block addressing (per-item weight gradients merged into one launch) + TN column segments (dilated taps)."""
+    L = _lib()
+    torch.manual_seed(6)
+    items, T, Cout, Cin, k, d = 3, 256, 136, 64, 3, 2
+    PAD = 4
+    x = torch.zeros(items, T + 2 * PAD, Cin, device="cuda", dtype=torch.bfloat16)
+    x[:, PAD:PAD + T] = torch.randn(items, T, Cin, device="cuda").bfloat16()
+    dy = torch.randn(items, T, Cout, device="cuda").bfloat16()
+    dW = torch.zeros(Cout, k * Cin, device="cuda")
+    # dW[co][j*Cin + ci] = sum_{b,t} dy[b,t,co] * x[b, t + (j-1)*d, ci]
+    L.gemm(dy, x, dW, Cout, k * Cin, items * T, Cout, Cin, k * Cin, layout=L.GEMM_TN, compute=1, accumulate=True,
+           b_offset=(PAD - d) * Cin, seglen=Cin, seg0=0, segstride=d * Cin - Cin,
+           kb_len=T, kb_sA=T * Cout, kb_sB=(T + 2 * PAD) * Cin)
+    xr = x[:, PAD:PAD + T].double().transpose(1, 2)
+    w = torch.zeros(Cout, Cin, k, dtype=torch.float64, device="cuda", requires_grad=True)
+    y = F.conv1d(xr, w, padding=d, dilation=d)
+    (y * dy.double().transpose(1, 2)).sum().backward()
+    ref = w.grad.permute(0, 2, 1).reshape(Cout, k * Cin)
+    assert _rel(dW, ref) < 3e-6
+
+
+@pytest.mark.parametrize("Cin,Cout,d", [(64, 136, 1), (128, 72, 3)])
+def test_conv_tap_segments_fwd_bwd_data(mainloop, Cin, Cout, d):
+    """Dilated k=3 conv as implicit GEMM: A tap segments (NT forward) and B row segments (NN backward-data)."""
+    L = _lib()
+    torch.manual_seed(7)
+    T, k, PAD = 700, 3, 4
+    xs = torch.zeros(T + 2 * PAD, Cin, device="cuda", dtype=torch.bfloat16)
+    xs[PAD:PAD + T] = torch.randn(T, Cin, device="cuda").bfloat16()
+    W = (torch.randn(Cout, Cin, k, device="cuda") * 0.1).bfloat16()
+    Wt = W.permute(0, 2, 1).contiguous().view(Cout, k * Cin)            # tap-major
+    bias = torch.randn(Cout, device="cuda")
+    y = torch.zeros(T, Cout, device="cuda")
+    L.gemm(xs, Wt, y, T, Cout, k * Cin, Cin, k * Cin, Cout, layout=L.GEMM_NT, compute=1, bias=bias,
+           a_offset=(PAD - d) * Cin, a_seglen=Cin, a_segadj=d * Cin - Cin)
+    ref = F.conv1d(xs[PAD:PAD + T].double().t()[None], W.double(), bias.double(), padding=d, dilation=d)[0].t()
+    assert _rel(y, ref) < 3e-6
+    dys = torch.zeros(T + 2 * PAD, Cout, device="cuda", dtype=torch.bfloat16)
+    dys[PAD:PAD + T] = torch.randn(T, Cout, device="cuda").bfloat16()
+    dx = torch.zeros(T, Cin, device="cuda")
+    L.gemm(dys, Wt, dx, T, Cin, k * Cout, Cout, k * Cin, Cin, layout=L.GEMM_NN, compute=1, a_offset=(PAD - d) * Cout,
+           a_seglen=Cout, a_segadj=d * Cout - Cout, seglen=Cout, seg0=(k - 1) * Cin, segstride=-Cin)
+    xr = xs[PAD:PAD + T].double().t()[None].requires_grad_(True)
+    F.conv1d(xr, W.double(), padding=d, dilation=d).backward(dys[PAD:PAD + T].double().t()[None])
+    assert _rel(dx, xr.grad[0].t()) < 3e-6
+
+
+def test_epilogue_options(mainloop):
+    """bias, alpha, dropout, gate, residual, ReLU, row mask, accumulate, bf16 / fp32 / transposed C — the documented order."""
+    L = _lib()
+    torch.manual_seed(8)
+    Bn, T, N, K = 3, 100, 264, 320
+    Tp = T + 2
+    M = Bn * Tp
+    A, lda = _bf(M, K)
+    Bw, ldb = _bf(N, K)
+    bias = torch.randn(N, device="cuda")
+    R = torch.randn(M, N, device="cuda").bfloat16()
+    G = torch.randn(M, N, device="cuda").bfloat16()
+    lens = torch.tensor([100, 37, 64], device="cuda", dtype=torch.int32)
+    acc = A.double() @ Bw.double().t()
+    v = 0.5 * (acc + bias.double())
+    v = torch.where(G.double() > 0, v, v * 0.1)
+    v = v + 2.0 * R.double()
+    v = torch.relu(v)
+    t = torch.arange(M, device="cuda") % Tp
+    b = torch.arange(M, device="cuda") // Tp
+    live = (t >= 1) & (t < Tp - 1) & ((t - 1) < lens[b])
+    ref = v * live[:, None]
+    for cdt in (torch.float32, torch.bfloat16):
+        Cm = torch.full((M, N), 5.0, device="cuda", dtype=cdt)
+        L.gemm(A, Bw, Cm, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=1, bias=bias, alpha=0.5, beta=2.0, R=R, ldr=N, G=G, ldg=N,
+               gate_slope=0.1, relu=True, mask_mode=L.MASK_LEN, lens=lens, Tp=Tp)
+        assert _rel(Cm, ref) < (3e-6 if cdt == torch.float32 else 5e-3)
+    # accumulate + transposed store
+    Ct = torch.ones(N, M, device="cuda")
+    L.gemm(A, Bw, Ct, M, N, K, lda, ldb, M, layout=L.GEMM_NT, compute=1, accumulate=True, c_trans=1)
+    assert _rel(Ct, 1.0 + acc.t()) < 3e-6
+    # dropout in the epilogue: kept elements scaled by 1/(1-p), dropped exactly 0, before the residual
+    Cd = torch.zeros(M, N, device="cuda")
+    L.gemm(A, Bw, Cd, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=1, drop_p=0.25, drop_seed=99, drop_stream=3)
+    Cg = torch.zeros(M, N, device="cuda")
+    old = L.lib.xva_gemm_set_mainloop(0)
+    L.gemm(A, Bw, Cg, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=1, drop_p=0.25, drop_seed=99, drop_stream=3)
+    L.lib.xva_gemm_set_mainloop(old)
+    kept = Cd != 0
+    assert abs(kept.float().mean().item() - 0.75) < 0.01
+    assert torch.equal(kept, Cg != 0)                                  # same mask as the general kernel
+    assert _rel(Cd[kept], (acc / 0.75)[kept]) < 3e-6
+
+
+def test_batched_two_level(mainloop):
+    L = _lib()
+    torch.manual_seed(9)
+    b1, b2, M, N, K = 2, 3, 140, 96, 256
+    A = torch.randn(b1, b2, M, K, device="cuda").bfloat16()
+    Bw = torch.randn(b1, b2, N, K, device="cuda").bfloat16()
+    Cm = torch.zeros(b1, b2, M, N, device="cuda")
+    L.gemm(A, Bw, Cm, M, N, K, K, K, N, layout=L.GEMM_NT, compute=1, batch=b1, sA=b2 * M * K, sB=b2 * N * K, sC=b2 * M * N,
+           batch2=b2, sA2=M * K, sB2=N * K, sC2=M * N)
+    assert _rel(Cm, A.double() @ Bw.double().transpose(-1, -2)) < 2e-6

@@ -54,6 +54,7 @@ class GemmParams(C.Structure):
         ("layout", i32),
         ("a_dtype", i32), ("b_dtype", i32), ("c_dtype", i32), ("c_trans", i32), ("kb_len", i32), ("kb_sA", i64), ("kb_sB", i64),
         ("drop_p", f32), ("drop_seed", C.c_uint64), ("drop_stream", C.c_uint32),
+        ("sk_ws", C.c_void_p), ("sk_ws_bytes", i64),
     ]
 
 
@@ -112,7 +113,8 @@ def _dt(t):
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batch=1, sA=0, sB=0, sC=0, alpha=1.0, beta=1.0,
          bias=None, relu=False, act=ACT_NONE, act_slope=0.0, R=None, ldr=0, sR=0, G=None, ldg=0, sG=0, gate_slope=0.0,
          mask_mode=MASK_NONE, lens=None, Tp=0, mask_pad=1, mask_len=0, mask_mul=1, mask_add=0, accumulate=False, splitk=1, seglen=0, seg0=0, segstride=0,
-         a_seglen=0, a_segadj=0, a_lrelu=None, b_lrelu=None, a_offset=0, b_offset=0, batch2=1, sA2=0, sB2=0, sC2=0, sR2=0, sG2=0):
+         a_seglen=0, a_segadj=0, a_lrelu=None, b_lrelu=None, a_offset=0, b_offset=0, batch2=1, sA2=0, sB2=0, sC2=0, sR2=0, sG2=0,
+         sk_ws=None, **extra):
     """Thin test/utility wrapper over xva_gemm. `a_offset` / `b_offset` (elements) shift the base pointers (negative for
     the overlapping-row conv forms).  Storage dtypes are taken from the tensors."""
     require_cuda(A, B, Cm, bias, R, G, lens)
@@ -147,4 +149,8 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batch=1, s
     p.compute = compute
     p.layout = layout
     p.a_dtype, p.b_dtype, p.c_dtype = _dt(A), _dt(B), _dt(Cm)
+    if sk_ws is not None:
+        p.sk_ws, p.sk_ws_bytes = sk_ws.data_ptr(), sk_ws.numel() * sk_ws.element_size()
+    for k, v in extra.items():          # any further xva_gemm_params field by name (c_trans, kb_len, drop_p, ...)
+        setattr(p, k, v)
     check(lib.xva_gemm(C.byref(p), stream_ptr()), "xva_gemm")

@@ -145,6 +145,7 @@ struct Plan {
     int64_t acc, losses, d_mel, d_pitch, d_energy, d_logdur;
     // backward scratch, sized for the decoder; the encoder reuses it.  gBm / gDm: dropout-masked copies for the branches.
     int64_t gA, gB, gBm, gC, gD, gDm, gH, gAV, gP, gQKV, gE, pa, pb;
+    int64_t skws, skws_bytes;   // split-K slab scratch of the weight-gradient GEMMs
     int64_t wshadow;    // activation-dtype copy of the flat parameters (bf16 mode); unused in fp32 mode
     int64_t total;
 };
@@ -202,6 +203,8 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     p->gBm = drop ? b.seq(Rm, DM, es) : p->gB; p->gDm = drop ? b.seq(Rm, DM, es) : p->gD;
     p->gH = b.seq(Rm, DI, es); p->gAV = b.seq(Rm, DH, es); p->gP = b.take((int64_t)p->B * Tpm * Tsm * es + 64); p->gQKV = b.seq(Rm, DQKV, es);
     p->gE = b.seq(p->Re, DM, es); p->pa = b.seq(p->Re, DP, 4); p->pb = b.seq(p->Re, DP, 4);
+    p->skws_bytes = (int64_t)8 * DI * 3 * DM * 4;   // 8 splits of the largest weight gradient (1536 x 1152 fp32)
+    p->skws = b.take(p->skws_bytes);
     p->wshadow = d->compute ? b.take(table().total * es) : -1;
     p->total = b.cur;
     return XVA_OK;
@@ -273,6 +276,7 @@ static int linear_bwd_weight(Ctx& c, const void* dY, int64_t rows, int N, int64_
     xva_gemm_params g = gp0(c);
     g.layout = XVA_GEMM_TN; g.A = dY; g.B = X; g.C = dW; g.c_dtype = XVA_F32; g.M = N; g.N = K; g.K = (int)rows; g.lda = ldy; g.ldb = ldx; g.ldc = K;
     g.accumulate = 1; g.splitk = splitk_for(N, K, (int)rows);
+    g.sk_ws = c.W + c.pl.skws; g.sk_ws_bytes = c.pl.skws_bytes;
     return xva_gemm(&g, c.st);
 }
 // Conv1d(k=3, pad=1) over a padded token-major sequence: Y = act(Xcat Wt^T + b) [dropout] (+R), Wt tap-major [Cout][3*Cin]
@@ -300,6 +304,7 @@ static int conv3_bwd_weight(Ctx& c, const void* dY, int64_t rows, int Cout, cons
     xva_gemm_params g = gp0(c);
     g.layout = XVA_GEMM_TN; g.A = dY; g.B = X - (int64_t)Cin * c.es; g.C = dWt; g.c_dtype = XVA_F32; g.M = Cout; g.N = 3 * Cin; g.K = (int)rows;
     g.lda = Cout; g.ldb = Cin; g.ldc = 3 * Cin; g.accumulate = 1; g.splitk = splitk_for(Cout, 3 * Cin, (int)rows);
+    g.sk_ws = c.W + c.pl.skws; g.sk_ws_bytes = c.pl.skws_bytes;
     return xva_gemm(&g, c.st);
 }
 

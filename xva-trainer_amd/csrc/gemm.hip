@@ -6,10 +6,17 @@
 void xva_gemm_launch_fp32(const xva_gemm_params& p, int bn, unsigned nblocks, hipStream_t st);
 void xva_gemm_launch_bf16(const xva_gemm_params& p, int bn, unsigned nblocks, hipStream_t st);
 void xva_gemm_launch_mixed(const xva_gemm_params& p, int bn, unsigned nblocks, hipStream_t st);
+bool xva_gemm_glds_eligible(const xva_gemm_params& p);
+int xva_gemm_launch_glds(const xva_gemm_params& p, int tile, hipStream_t st);
 bool xva_prof_is_on();
 void xva_prof_begin(hipStream_t st, double flops, int variant);
 void xva_prof_end(hipStream_t st);
 void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn);
+
+// Main-loop selection: -1 automatic (default; env XVA_GEMM_GLDS overrides), 0 general kernel only, 1 direct-to-LDS 128x128,
+// 2 direct-to-LDS 256x256 wherever eligible.  A diagnostics / test knob, not part of the numerical contract.
+static int g_glds_mode = [] { const char* e = getenv("XVA_GEMM_GLDS"); return e ? atoi(e) : -1; }();
+extern "C" int xva_gemm_set_mainloop(int mode) { int old = g_glds_mode; g_glds_mode = mode; return old; }
 
 extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     XVA_CHECK_ARG(pp != nullptr, "xva_gemm: null params");
@@ -47,14 +54,29 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     if (p.K == 0) p.splitk = 1;
     int nkt = xva_cdiv(p.K, 32);
     if (p.splitk > nkt && nkt > 0) p.splitk = nkt;
-    const int bn = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
+    int bn = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
+    // direct-to-LDS main loop (gemm_glds.h) for bf16-stored operands; XVA_GEMM_GLDS=0 keeps everything on the general kernel,
+    // =1 forces the 128x128 tile, =2 forces 256x256 (A/B switches for profiling)
+    const int glds_env = g_glds_mode;
+    int glds_tile = -1;
+    if (glds_env != 0 && p.N > 64 && p.K >= 192 && xva_gemm_glds_eligible(p)) {
+        const long t256 = (long)xva_cdiv(p.N, 256) * xva_cdiv(p.M, 256) * p.batch * p.batch2 * p.splitk;
+        const double eff256 = (double)p.M * p.N / ((double)xva_cdiv(p.N, 256) * xva_cdiv(p.M, 256) * 65536.0);
+        glds_tile = (t256 >= 192 && eff256 >= 0.8) ? 1 : 0;
+        if (glds_env == 1) glds_tile = 0;
+        if (glds_env == 2) glds_tile = 1;
+        bn = glds_tile ? 256 : 129;
+        nkt = xva_cdiv(p.K, 64);
+        if (p.splitk > nkt) p.splitk = nkt;
+    }
     long nblocks = (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2 * p.splitk;
     XVA_CHECK_ARG(nblocks < (1L << 31), "xva_gemm: grid too large");
     hipStream_t st = (hipStream_t)stream;
     const int mode = p.compute == 0 ? 0 : (p.a_dtype == XVA_BF16 ? 1 : 2);
     const bool prof = xva_prof_is_on();
     if (prof) { xva_prof_begin(st, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + mode); xva_prof_shape(p.M, p.N, p.K, p.batch * p.batch2, p.splitk, bn); }
-    if (mode == 0) xva_gemm_launch_fp32(p, bn, (unsigned)nblocks, st);
+    if (glds_tile >= 0) { if (xva_gemm_launch_glds(p, glds_tile, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; } }
+    else if (mode == 0) xva_gemm_launch_fp32(p, bn, (unsigned)nblocks, st);
     else if (mode == 1) xva_gemm_launch_bf16(p, bn, (unsigned)nblocks, st);
     else xva_gemm_launch_mixed(p, bn, (unsigned)nblocks, st);
     if (prof) xva_prof_end(st);

@@ -1,0 +1,437 @@
+// gemm_glds.h — second-generation main loop of the implicit-convolution GEMM for bf16-STORED operands (gfx950).
+//
+// What changes against gemm_core.h (which stays the general path: fp32 / mixed storage, fused LeakyReLU staging, ragged
+// segment lengths):
+//   * operand tiles travel HBM -> LDS directly (global_load_lds_dwordx4, 16 B per lane): no staging VGPRs, no ds_write pass;
+//     the LDS image is lane-linear per wave instruction, so the bank swizzle is applied to the per-lane SOURCE address;
+//   * operands whose contiguous dimension is not k (NN's B, TN's A and B) keep their natural [k][idx] image and the MFMA
+//     fragments are gathered by the LDS transpose read (ds_read_b64_tr_b16); k-rows are stored with bits 2/3 of k swapped
+//     and their 32-byte windows XOR-ed with the row position, which makes both the DMA writes and the transpose reads
+//     conflict-free (measured: 3.2 cycles per wave read vs 16 for the plain image);
+//   * K tile 64, two LDS buffers, ONE barrier per K tile: the DMA of tile t+1 is in flight while tile t feeds the MFMAs;
+//   * tiles 256x256 (8 waves, 128x64 each, 128 KiB LDS, one workgroup per CU) and 128x128 (4 waves, 64x64 each);
+//   * the MFMA operands are swapped (D = B-frag x A-frag) so each lane ends up with 4 CONSECUTIVE COLUMNS of one output row:
+//     the epilogue loads residual / gate and stores C with 8- or 16-byte vectors.
+// M / N edges clamp onto valid memory (their products reach only never-stored rows / columns); k >= K lanes read a zero page.
+#pragma once
+#include <type_traits>
+#include "gemm_core.h"
+
+namespace xva_glds {
+using xva_gemm_impl::bf16x8;
+using xva_gemm_impl::bf2f;
+using xva_gemm_impl::f2bf;
+using xva_gemm_impl::f32x4;
+using xva_gemm_impl::ld_elem;
+using xva_gemm_impl::lrelu;
+using xva_gemm_impl::pack_bf2;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define XVA_LDS __attribute__((address_space(3)))
+#define XVA_GLB __attribute__((address_space(1)))
+
+constexpr int GK = 64;            // K tile
+enum { KC = 0, IC = 1 };          // operand kinds: k-contiguous rows / index-contiguous k-rows
+
+static __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<N, I + 1>(f); }
+}
+
+__device__ __forceinline__ int swap23(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
+
+// ---- DMA descriptors of one operand tile ([ROWS idx] x [64 k]) for one thread ---------------------------------------------
+// The tile is 8 * ROWS 16-byte chunks; wave instruction Q (0 .. ROWS/8 - 1) fills LDS bytes [Q * 1024, Q * 1024 + 1024).
+template <int KIND, int ROWS, int NW>
+struct Loader {
+    static constexpr int NI = ROWS / (8 * NW);   // wave instructions per wave per tile
+    int64_t off[NI];                              // element offset of this lane's chunk from the tile's scalar base
+    int kk[NI];                                   // k index inside the tile of the chunk's first element
+
+    // i0: first row / column of the tile; bound: number of valid rows / columns; ld: leading dimension (elements);
+    // KIND == IC: column c is remapped to colmap(c) = cseg0 + c + (c / cseglen) * csegstride when cseglen > 0 (TN column segments)
+    __device__ __forceinline__ void init(int lane, int wave, int i0, int bound, int64_t ld, int cseglen, int64_t cseg0, int64_t csegstride) {
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int Q = q * NW + wave;
+            if constexpr (KIND == KC) {
+                const int r = Q * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (lane >> 3);             // chunk held by LDS position (lane & 7) of row r: c ^ (r & 7)
+                off[q] = (int64_t)min(i0 + r, bound - 1) * ld + c * 8;
+                kk[q] = c * 8;
+            } else {
+                constexpr int CPR = ROWS / 8;                       // chunks per k-row: 16 or 32
+                constexpr int RPI = 64 / CPR;                       // k-rows per wave instruction: 4 or 2
+                const int pos = Q * RPI + lane / CPR;
+                const int p = lane % CPR;
+                const int c = p ^ ((pos & 7) << 1);
+                const int k = swap23(pos);
+                int col = min(i0 + c * 8, bound - 8);
+                int64_t cm = col;
+                if (cseglen > 0) cm = cseg0 + col + (int64_t)(col / cseglen) * csegstride;
+                off[q] = (int64_t)k * ld + cm;
+                kk[q] = k;
+            }
+        }
+    }
+    // base: operand pointer advanced to this K tile (scalar); k0: first k of the tile; K: reduction length
+    __device__ __forceinline__ void issue(const uint16_t* base, int k0, int K, XVA_LDS uint8_t* tile, int wave) const {
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const uint16_t* src = (k0 + kk[q] < K) ? base + off[q] : reinterpret_cast<const uint16_t*>(g_zero_page);
+            __builtin_amdgcn_global_load_lds((const XVA_GLB void*)src, (XVA_LDS void*)(tile + (q * NW + wave) * 1024), 16, 0, 0);
+        }
+    }
+};
+
+// ---- MFMA fragment readers ------------------------------------------------------------------------------------------------
+// KC image: [ROWS][64 k] bf16, 128-byte rows, chunk c of row r at position c ^ (r & 7).
+// lane -> row (l & 15) of the 16-row tile, k = kh * 32 + (l >> 4) * 8 + j
+struct KcReader {
+    uint32_t o0, o1;   // byte offsets of this lane inside a 16-row tile for kh = 0 / 1
+    __device__ __forceinline__ void init(int lane) {
+        o0 = (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) * 16);
+        o1 = o0 ^ 64;
+    }
+    __device__ __forceinline__ bf16x8 read(const XVA_LDS uint8_t* tile, int row0, int kh) const {
+        return *reinterpret_cast<const XVA_LDS bf16x8*>(tile + row0 * 128 + (kh ? o1 : o0));
+    }
+};
+// IC image: [64 kpos][ROWS idx] bf16, kpos = k with bits 2/3 swapped, 16-byte chunk c of a row at position c ^ ((kpos & 7) << 1).
+template <int ROWS, int TILES>
+struct IcReader {
+    uint32_t o[TILES];   // byte offset of this lane for idx tile t (16 columns), kh = 0, half 0
+    __device__ __forceinline__ void init(int lane, int w0) {
+        const int g = lane >> 4, i = lane & 15;
+        const int X = (g & 1) * 4 + (i >> 2);                                  // kpos & 7
+        const int posl = (g >> 1) * 16 + (g & 1) * 4 + (i >> 2);               // kpos without the (kh, half) bits
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+            o[t] = posl * (ROWS * 2) + ((w0 / 8 + t * 2 + ((i >> 1) & 1)) ^ (X << 1)) * 16 + (i & 1) * 8;
+    }
+    __device__ __forceinline__ bf16x8 read(const XVA_LDS uint8_t* tile, int t, int kh) const {
+        const XVA_LDS uint8_t* a = tile + o[t] + kh * (32 * ROWS * 2);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((XVA_LDS s16x4*)a);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((XVA_LDS s16x4*)(a + 8 * ROWS * 2));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    }
+};
+
+// ---- epilogue -------------------------------------------------------------------------------------------------------------
+// v[0..3]: columns col .. col + 3 of row `row` (all inside N when VEC).  Order (include/xva_gemm.h):
+// v = alpha * (acc + bias) ; dropout ; gate ; + beta * R ; act ; row mask ; store / accumulate.
+template <bool VEC>
+__device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int row, int col, bool live, bool lin_first, int z2,
+                                          int64_t coff, int64_t roff, int64_t goff) {
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    const int nv = VEC ? 4 : min(4, p.N - col);
+    if (lin_first && p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) v[e] += p.bias[(int64_t)z2 * p.sbias2 + col + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+    if (p.drop_p > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= xva_dropout_scale(p.drop_p, p.drop_seed, p.drop_stream, (uint64_t)row * p.N + col + e);
+    }
+    if (p.G) {
+        float g[4] = {1.f, 1.f, 1.f, 1.f};
+        const int64_t gi = goff + (int64_t)row * p.ldg + col;
+        if (VEC) {
+            if (p.g_dtype == XVA_BF16) {
+                uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.G) + gi);
+                g[0] = __uint_as_float(r.x << 16); g[1] = __uint_as_float(r.x & 0xffff0000u);
+                g[2] = __uint_as_float(r.y << 16); g[3] = __uint_as_float(r.y & 0xffff0000u);
+            } else {
+                float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.G) + gi);
+                g[0] = r.x; g[1] = r.y; g[2] = r.z; g[3] = r.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nv) g[e] = ld_elem(p.G, gi + e, p.g_dtype);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = g[e] > 0.f ? v[e] : v[e] * p.gate_slope;
+    }
+    if (lin_first && p.R) {
+        const int64_t ri = roff + (int64_t)row * p.ldr + col;
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (VEC) {
+            if (p.r_dtype == XVA_BF16) {
+                uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.R) + ri);
+                r4[0] = __uint_as_float(r.x << 16); r4[1] = __uint_as_float(r.x & 0xffff0000u);
+                r4[2] = __uint_as_float(r.y << 16); r4[3] = __uint_as_float(r.y & 0xffff0000u);
+            } else {
+                float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.R) + ri);
+                r4[0] = r.x; r4[1] = r.y; r4[2] = r.z; r4[3] = r.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nv) r4[e] = ld_elem(p.R, ri + e, p.r_dtype);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p.beta * r4[e];
+    }
+    if (p.act != XVA_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            switch (p.act) {
+                case XVA_ACT_RELU: v[e] = fmaxf(v[e], 0.f); break;
+                case XVA_ACT_LRELU: v[e] = lrelu(v[e], p.act_slope); break;
+                case XVA_ACT_TANH: v[e] = tanhf(v[e]); break;
+                case XVA_ACT_LOGCLAMP: v[e] = logf(fmaxf(v[e], p.act_slope)); break;
+                default: break;
+            }
+        }
+    }
+    if (!live) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+    if (VEC && !p.c_trans) {
+        const int64_t ci = coff + (int64_t)row * p.ldc + col;
+        if (p.c_dtype == XVA_BF16) {
+            uint2* dst = reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + ci);
+            if (p.accumulate) {
+                uint2 o = *dst;
+                v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
+                v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
+            }
+            *dst = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        } else {
+            float* dst = reinterpret_cast<float*>(p.C) + ci;
+            if (p.splitk > 1 || p.accumulate == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(dst + e, v[e]);
+            } else {
+                float4* d4 = reinterpret_cast<float4*>(dst);
+                if (p.accumulate) { float4 o = *d4; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                *d4 = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e >= nv) break;
+            const int64_t ci = coff + (p.c_trans ? (int64_t)(col + e) * p.ldc + row : (int64_t)row * p.ldc + col + e);
+            if (p.c_dtype == XVA_BF16) {
+                uint16_t* dst = reinterpret_cast<uint16_t*>(p.C) + ci;
+                float x = v[e];
+                if (p.accumulate) x += bf2f(*dst);
+                *dst = f2bf(x);
+            } else {
+                float* dst = reinterpret_cast<float*>(p.C) + ci;
+                if (p.splitk > 1 || p.accumulate == 2) atomicAdd(dst, v[e]);
+                else if (p.accumulate) *dst += v[e];
+                else *dst = v[e];
+            }
+        }
+    }
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------------------------------
+// vec_epi: host-verified that N % 4 == 0 and C / R / G rows are 4-element aligned (vector epilogue allowed)
+template <int LAYOUT, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) ? 1 : 2) void xva_gemm_glds_kernel(xva_gemm_params p, int vec_epi) {
+    constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
+    constexpr int MI = WM / 16, NJ = WN / 16;
+    constexpr int AK = LAYOUT == XVA_GEMM_TN ? IC : KC;
+    constexpr int BKD = LAYOUT == XVA_GEMM_NT ? KC : IC;
+    constexpr int A_BYTES = BM * GK * 2, B_BYTES = BN * GK * 2, BUF = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem_raw[];
+    XVA_LDS uint8_t* smem = (XVA_LDS uint8_t*)smem_raw;
+
+    const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
+    int Lg;
+    {
+        const unsigned total = gridDim.x, id = blockIdx.x;
+        const unsigned xcd = id & 7u, slot = id >> 3, q = total >> 3, r = total & 7u;
+        Lg = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot);
+    }
+    const int tn = Lg % nbx, tm = (Lg / nbx) % nby, z = Lg / (nbx * nby);
+    const int bz = z / p.splitk, ks = z - bz * p.splitk;
+    const int b2n = p.batch2 > 1 ? p.batch2 : 1;
+    const int z1 = bz / b2n, z2 = bz - z1 * b2n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + (int64_t)z1 * p.sA + (int64_t)z2 * p.sA2;
+    const uint16_t* B = reinterpret_cast<const uint16_t*>(p.B) + (int64_t)z1 * p.sB + (int64_t)z2 * p.sB2;
+
+    const int nkt_total = (p.K + GK - 1) / GK;
+    const int per = (nkt_total + p.splitk - 1) / p.splitk;
+    const int kt_begin = ks * per;
+    const int kt_end = min(nkt_total, kt_begin + per);
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+
+    Loader<AK, BM, NW> la;
+    Loader<BKD, BN, NW> lb;
+    if constexpr (AK == KC) la.init(lane, wave, m0, p.M, p.lda, 0, 0, 0);
+    else la.init(lane, wave, m0, p.M, p.lda, p.a_seglen, 0, p.a_segadj);          // TN: A column m -> m + (m / a_seglen) * a_segadj
+    if constexpr (BKD == KC) lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0);
+    else if constexpr (LAYOUT == XVA_GEMM_TN) lb.init(lane, wave, n0, p.N, p.ldb, p.seglen, p.seg0, p.segstride);
+    else lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0);                             // NN: row segments are folded into the tile base
+
+    auto a_base = [&](int k0) -> const uint16_t* {
+        if constexpr (AK == KC) return A + k0 + (p.a_seglen > 0 ? (int64_t)(k0 / p.a_seglen) * p.a_segadj : 0);
+        else return p.kb_len > 0 ? A + (int64_t)(k0 / p.kb_len) * p.kb_sA + (int64_t)(k0 % p.kb_len) * p.lda : A + (int64_t)k0 * p.lda;
+    };
+    auto b_base = [&](int k0) -> const uint16_t* {
+        if constexpr (BKD == KC) return B + k0;
+        else if constexpr (LAYOUT == XVA_GEMM_NN)
+            return p.seglen > 0 ? B + p.seg0 + (int64_t)(k0 / p.seglen) * p.segstride + (int64_t)(k0 % p.seglen) * p.ldb : B + (int64_t)k0 * p.ldb;
+        else return p.kb_len > 0 ? B + (int64_t)(k0 / p.kb_len) * p.kb_sB + (int64_t)(k0 % p.kb_len) * p.ldb : B + (int64_t)k0 * p.ldb;
+    };
+    auto issue = [&](int kt, int buf) {
+        const int k0 = kt * GK;
+        la.issue(a_base(k0), k0, p.K, smem + buf * BUF, wave);
+        lb.issue(b_base(k0), k0, p.K, smem + buf * BUF + A_BYTES, wave);
+    };
+
+    KcReader kra, krb;
+    IcReader<BM, MI> ira;
+    IcReader<BN, NJ> irb;
+    if constexpr (AK == KC) kra.init(lane); else ira.init(lane, wm * WM);
+    if constexpr (BKD == KC) krb.init(lane); else irb.init(lane, wn * WN);
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (kt_begin < kt_end) issue(kt_begin, 0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
+        const XVA_LDS uint8_t* At = smem + cur * BUF;
+        const XVA_LDS uint8_t* Bt = At + A_BYTES;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            bf16x8 af[MI], bfr[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (BKD == KC) bfr[j] = krb.read(Bt, wn * WN + j * 16, kh);
+                else bfr[j] = irb.read(Bt, j, kh);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if constexpr (AK == KC) af[i] = kra.read(At, wm * WM + i * 16, kh);
+                else af[i] = ira.read(At, i, kh);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // swapped: lane = 4 columns of a row
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[i][j][e] = C[m0 + wm*WM + i*16 + (lane & 15)][n0 + wn*WN + j*16 + (lane >> 4)*4 + e]
+    // (compile-time indices: a rolled loop would index `acc` dynamically and push the accumulators to scratch)
+    const int64_t coff = (int64_t)z1 * p.sC + (int64_t)z2 * p.sC2;
+    const int64_t roff = (int64_t)z1 * p.sR + (int64_t)z2 * p.sR2;
+    const int64_t goff = (int64_t)z1 * p.sG + (int64_t)z2 * p.sG2;
+    const bool lin_first = (p.splitk == 1) || (ks == 0);
+    const int rbase = m0 + wm * WM + (lane & 15), cbase = n0 + wn * WN + (lane >> 4) * 4;
+    auto run = [&](auto vec_tag) {
+        constexpr bool VEC = decltype(vec_tag)::value;
+        static_for<MI>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int row = rbase + i * 16;
+            if (row < p.M) {
+                bool live = true;
+                if (p.mask_mode != XVA_MASK_NONE) {
+                    const int64_t rr = (int64_t)row * p.mask_mul + p.mask_add;
+                    const int t = (int)(rr % p.Tp);
+                    live = t >= p.mask_pad && t < p.mask_pad + p.mask_len;
+                    if (live && p.mask_mode == XVA_MASK_LEN) live = (t - p.mask_pad) < p.lens[rr / p.Tp];
+                }
+                static_for<NJ>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const int col = cbase + j * 16;
+                    if (col < p.N) epilogue4<VEC>(p, acc[i][j], row, col, live, lin_first, z2, coff, roff, goff);
+                });
+            }
+        });
+    };
+    if (p.splitk > 1 && p.sk_ws) {
+        // split-K slab: raw partial sums of this K range, [split][M][N] fp32; xva_gemm_splitk_reduce applies the epilogue
+        float* slab = reinterpret_cast<float*>(p.sk_ws) + ((int64_t)bz * p.splitk + ks) * (int64_t)p.M * p.N;
+        static_for<MI>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int row = rbase + i * 16;
+            if (row < p.M) {
+                static_for<NJ>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const int col = cbase + j * 16;
+                    if (col < p.N) {
+                        float* dst = slab + (int64_t)row * p.N + col;
+                        if (vec_epi) *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                        else for (int e = 0; e < 4 && col + e < p.N; ++e) dst[e] = acc[i][j][e];
+                    }
+                });
+            }
+        });
+        return;
+    }
+    if (vec_epi) run(std::true_type{}); else run(std::false_type{});
+}
+
+// C (+)= alpha * (sum_s slab[s] + bias) + beta * R  for one batch item per blockIdx.y; thread = one column, rows strided by gridDim.x.
+__global__ __launch_bounds__(256) void xva_gemm_splitk_reduce_kernel(xva_gemm_params p) {
+    const int b2n = p.batch2 > 1 ? p.batch2 : 1;
+    const int bz = blockIdx.y, z1 = bz / b2n, z2 = bz - z1 * b2n;
+    const int64_t MN = (int64_t)p.M * p.N;
+    const float* slab = reinterpret_cast<const float*>(p.sk_ws) + (int64_t)bz * p.splitk * MN;
+    const int64_t coff = (int64_t)z1 * p.sC + (int64_t)z2 * p.sC2;
+    const int64_t roff = (int64_t)z1 * p.sR + (int64_t)z2 * p.sR2;
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < MN; e += (int64_t)gridDim.x * 1024) {
+        float4 s = *reinterpret_cast<const float4*>(slab + e);
+        for (int k = 1; k < p.splitk; ++k) {
+            float4 t = *reinterpret_cast<const float4*>(slab + k * MN + e);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        float v[4] = {s.x, s.y, s.z, s.w};
+        const int row = (int)(e / p.N), col = (int)(e - (int64_t)row * p.N);   // N % 4 == 0: the 4 values share a row
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = v[q];
+            if (p.bias) x += p.bias[(int64_t)z2 * p.sbias2 + col + q];
+            x *= p.alpha;
+            if (p.R) x += p.beta * ld_elem(p.R, roff + (int64_t)row * p.ldr + col + q, p.r_dtype);
+            const int64_t ci = coff + (p.c_trans ? (int64_t)(col + q) * p.ldc + row : (int64_t)row * p.ldc + col + q);
+            if (p.c_dtype == XVA_BF16) {
+                uint16_t* dst = reinterpret_cast<uint16_t*>(p.C) + ci;
+                if (p.accumulate) x += bf2f(*dst);
+                *dst = f2bf(x);
+            } else {
+                float* dst = reinterpret_cast<float*>(p.C) + ci;
+                if (p.accumulate == 2) atomicAdd(dst, x);
+                else if (p.accumulate) *dst += x;
+                else *dst = x;
+            }
+        }
+    }
+}
+
+template <int LAYOUT, int BM, int BN, int WM, int WN>
+inline int launch_tile(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    constexpr int LDS = 2 * (BM + BN) * GK * 2;
+    auto kern = xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+        attr_set = true;
+    }
+    long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, BM) * p.batch * p.batch2 * p.splitk;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT), LDS, st, p, vec_epi);
+    return 0;
+}
+
+}  // namespace xva_glds
