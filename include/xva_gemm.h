@@ -78,7 +78,8 @@ typedef struct xva_gemm_params {
     int32_t Tp, mask_pad, mask_len, mask_mul, mask_add;
     int32_t accumulate;     /* 0: C = v ; 1: C += v (atomic when splitk > 1) ; 2: C += v always atomically (batches that
                              * reduce into one C); fp32 C only for atomics */
-    int32_t splitk;         /* >= 1; > 1 requires accumulate = 1 and a linear epilogue */
+    int32_t splitk;         /* >= 1; > 1 requires accumulate = 1 and a linear epilogue; 0 = let xva_gemm choose (it splits only
+                             * when accumulate != 0, C is fp32 and the epilogue is linear) */
     int32_t compute;        /* 0 fp32, 1 bf16 */
     int32_t layout;         /* XVA_GEMM_* */
     int32_t a_dtype, b_dtype, c_dtype;

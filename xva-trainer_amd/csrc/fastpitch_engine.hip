@@ -241,15 +241,6 @@ static xva_gemm_params gp0(const Ctx& c) {
     g.a_dtype = g.b_dtype = g.c_dtype = c.dt; g.r_dtype = g.g_dtype = c.dt;
     return g;
 }
-static int splitk_for(int M, int N, int K) {
-    long tiles = (long)xva_cdiv(M, 128) * xva_cdiv(N, 128);
-    int sk = (int)((768 + tiles - 1) / tiles);
-    int nkt = xva_cdiv(K, 32);
-    int maxsk = nkt / 8; if (maxsk < 1) maxsk = 1;   // at least 8 K-tiles per split
-    if (sk > maxsk) sk = maxsk;
-    if (sk < 1) sk = 1;
-    return sk;
-}
 // dropout descriptor of a GEMM epilogue / kernel site
 struct Drop { float p; uint32_t stream; };
 
@@ -275,7 +266,7 @@ static int linear_bwd_data(Ctx& c, const void* dY, int64_t rows, int N, int64_t 
 static int linear_bwd_weight(Ctx& c, const void* dY, int64_t rows, int N, int64_t ldy, const void* X, int K, int64_t ldx, float* dW) {
     xva_gemm_params g = gp0(c);
     g.layout = XVA_GEMM_TN; g.A = dY; g.B = X; g.C = dW; g.c_dtype = XVA_F32; g.M = N; g.N = K; g.K = (int)rows; g.lda = ldy; g.ldb = ldx; g.ldc = K;
-    g.accumulate = 1; g.splitk = splitk_for(N, K, (int)rows);
+    g.accumulate = 1; g.splitk = 0;
     g.sk_ws = c.W + c.pl.skws; g.sk_ws_bytes = c.pl.skws_bytes;
     return xva_gemm(&g, c.st);
 }
@@ -303,7 +294,7 @@ static int conv3_bwd_data(Ctx& c, const char* dY, int64_t rows, int Cout, int64_
 static int conv3_bwd_weight(Ctx& c, const void* dY, int64_t rows, int Cout, const char* X, int Cin, float* dWt) {
     xva_gemm_params g = gp0(c);
     g.layout = XVA_GEMM_TN; g.A = dY; g.B = X - (int64_t)Cin * c.es; g.C = dWt; g.c_dtype = XVA_F32; g.M = Cout; g.N = 3 * Cin; g.K = (int)rows;
-    g.lda = Cout; g.ldb = Cin; g.ldc = 3 * Cin; g.accumulate = 1; g.splitk = splitk_for(Cout, 3 * Cin, (int)rows);
+    g.lda = Cout; g.ldb = Cin; g.ldc = 3 * Cin; g.accumulate = 1; g.splitk = 0;
     g.sk_ws = c.W + c.pl.skws; g.sk_ws_bytes = c.pl.skws_bytes;
     return xva_gemm(&g, c.st);
 }

@@ -26,6 +26,26 @@ __device__ __forceinline__ void a_st(void* p, int64_t i, int dt, float v) {
     }
 }
 
+// two adjacent elements (i even): one 4-byte (bf16) or 8-byte (fp32) access
+__device__ __forceinline__ void a_ld2(const void* p, int64_t i, int dt, float& x, float& y) {
+    if (dt == XVA_BF16) {
+        uint32_t u = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(p) + i);
+        x = __uint_as_float(u << 16); y = __uint_as_float(u & 0xffff0000u);
+    } else {
+        float2 f = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(p) + i);
+        x = f.x; y = f.y;
+    }
+}
+__device__ __forceinline__ void a_st2(void* p, int64_t i, int dt, float x, float y) {
+    if (dt == XVA_BF16) {
+        uint32_t a = __float_as_uint(x), b = __float_as_uint(y);
+        a += 0x7fffu + ((a >> 16) & 1u); b += 0x7fffu + ((b >> 16) & 1u);
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(p) + i) = (a >> 16) | (b & 0xffff0000u);
+    } else {
+        *reinterpret_cast<float2*>(reinterpret_cast<float*>(p) + i) = make_float2(x, y);
+    }
+}
+
 // =====================================================================================
 // Embedding + positional embedding  (transformer.py:212-227: word_emb(ids) + pos_emb * mask)
 // out[b, t', :] = emb[id] + (id != 0 ? pos[t'-1] : 0) for 1 <= t' <= T ; structural rows = 0
@@ -175,10 +195,11 @@ __global__ void layernorm_fwd_kernel(const void* __restrict__ X, const float* __
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     if (row >= rows) return;
+    // lane owns the column pairs c = 2 * lane + 128 * h + {0, 1}, h < CPL / 2 (paired loads / stores)
     float v[CPL];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) { v[i] = a_ld(X, row * C + lane + 64 * i, dt); s += v[i]; }
+    for (int h = 0; h < CPL / 2; ++h) { a_ld2(X, row * C + 2 * lane + 128 * h, dt, v[2 * h], v[2 * h + 1]); s += v[2 * h] + v[2 * h + 1]; }
     float mu = xva_wave_sum(s) * (1.f / C);
     float q = 0.f;
 #pragma unroll
@@ -188,11 +209,15 @@ __global__ void layernorm_fwd_kernel(const void* __restrict__ X, const float* __
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     bool live = xva_row_live(mask_mode, lens, Tp, row);
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        int c = lane + 64 * i;
-        float y = live ? (v[i] - mu) * rs * gamma[c] + beta[c] : 0.f;
-        if (p_drop > 0.f) y *= xva_dropout_scale(p_drop, seed, stream_id, (uint64_t)row * C + c);
-        a_st(Y, row * C + c, dt, y);
+    for (int h = 0; h < CPL / 2; ++h) {
+        const int c = 2 * lane + 128 * h;
+        float y[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            y[e] = live ? (v[2 * h + e] - mu) * rs * gamma[c + e] + beta[c + e] : 0.f;
+            if (p_drop > 0.f) y[e] *= xva_dropout_scale(p_drop, seed, stream_id, (uint64_t)row * C + c + e);
+        }
+        a_st2(Y, row * C + c, dt, y[0], y[1]);
     }
 }
 
@@ -215,21 +240,31 @@ __global__ void layernorm_bwd_kernel(const void* __restrict__ dY, const void* __
     int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float ag[CPL], ab[CPL], gm[CPL];
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; gm[i] = gamma[lane + 64 * i]; }
+    for (int i = 0; i < CPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; gm[i] = gamma[2 * lane + 128 * (i >> 1) + (i & 1)]; }   // column pairs
     for (int64_t row = r0 + wave; row < r1; row += WAVES_PER_BLOCK) {
         if (!xva_row_live(mask_mode, lens, Tp, row)) {
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) { a_st(dX, row * C + lane + 64 * i, dt, 0.f); if (dXm) a_st(dXm, row * C + lane + 64 * i, dt, 0.f); }
+            for (int h = 0; h < CPL / 2; ++h) {
+                a_st2(dX, row * C + 2 * lane + 128 * h, dt, 0.f, 0.f);
+                if (dXm) a_st2(dXm, row * C + 2 * lane + 128 * h, dt, 0.f, 0.f);
+            }
             continue;
         }
         float mu = mean[row], rs = rstd[row];
         float xh[CPL], dh[CPL], xr[CPL];
         float s1 = 0.f, s2 = 0.f;
+        float gr[CPL];
+#pragma unroll
+        for (int h = 0; h < CPL / 2; ++h) {
+            const int c = 2 * lane + 128 * h;
+            a_ld2(X, row * C + c, dt, xr[2 * h], xr[2 * h + 1]);
+            if (outer_d) { gr[2 * h] = outer_d[row] * outer_w[c]; gr[2 * h + 1] = outer_d[row] * outer_w[c + 1]; }   // rank-1 dY of a 1-output Linear, kept fp32
+            else a_ld2(dY, row * C + c, dt, gr[2 * h], gr[2 * h + 1]);
+        }
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            int c = lane + 64 * i;
-            xr[i] = a_ld(X, row * C + c, dt);
-            float g = outer_d ? outer_d[row] * outer_w[c] : a_ld(dY, row * C + c, dt);   // rank-1 dY of a 1-output Linear, kept fp32
+            const int c = 2 * lane + 128 * (i >> 1) + (i & 1);
+            float g = gr[i];
             if (p_in > 0.f) g *= xva_dropout_scale(p_in, seed_in, stream_in, (uint64_t)row * C + c);
             xh[i] = (xr[i] - mu) * rs;
             dh[i] = g * gm[i];
@@ -241,17 +276,22 @@ __global__ void layernorm_bwd_kernel(const void* __restrict__ dY, const void* __
         s1 = xva_wave_sum(s1) * (1.f / C);
         s2 = xva_wave_sum(s2) * (1.f / C);
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            int c = lane + 64 * i;
-            float v = rs * (dh[i] - s1 - xh[i] * s2);
-            if (relu_gate && !(xr[i] > 0.f)) v = 0.f;
-            a_st(dX, row * C + c, dt, v);
-            if (dXm) a_st(dXm, row * C + c, dt, v * xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c));
+        for (int h = 0; h < CPL / 2; ++h) {
+            const int c = 2 * lane + 128 * h;
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                v[e] = rs * (dh[2 * h + e] - s1 - xh[2 * h + e] * s2);
+                if (relu_gate && !(xr[2 * h + e] > 0.f)) v[e] = 0.f;
+            }
+            a_st2(dX, row * C + c, dt, v[0], v[1]);
+            if (dXm) a_st2(dXm, row * C + c, dt, v[0] * xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c),
+                           v[1] * xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c + 1));
         }
     }
     if (dgamma) {
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) { sh_g[wave][lane + 64 * i] = ag[i]; sh_b[wave][lane + 64 * i] = ab[i]; }
+        for (int i = 0; i < CPL; ++i) { const int c = 2 * lane + 128 * (i >> 1) + (i & 1); sh_g[wave][c] = ag[i]; sh_b[wave][c] = ab[i]; }
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float g = 0.f, b = 0.f;
@@ -286,7 +326,7 @@ extern "C" int xva_fp_layernorm_bwd(const void* dY, const void* X, const float* 
     XVA_CHECK_ARG((dY || (outer_d && outer_w)) && X && mean && rstd && gamma && dX, "layernorm_bwd: null");
     XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
     XVA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both null");
-    const int rpb = 32;
+    const int rpb = 16;
     dim3 grid(xva_cdiv(rows, rpb)), block(64 * WAVES_PER_BLOCK);
     if (C == 384)
         hipLaunchKernelGGL((layernorm_bwd_kernel<6>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma,
@@ -317,9 +357,42 @@ __global__ void colsum_kernel(const void* __restrict__ X, int dt, float* __restr
     __syncthreads();
     if (rl == 0 && c < C) atomicAdd(out + c, sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]);
 }
+// paired-column version (C and ld even): a wave reads 128 adjacent columns of a row per load
+__global__ void colsum2_kernel(const void* __restrict__ X, int dt, float* __restrict__ out, int64_t rows, int C, int64_t ld,
+                               int rows_per_block) {
+    __shared__ float sh[4][128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 128 + 2 * lane;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        int64_t r = r0 + w;
+        for (; r + 4 < r1; r += 8) {       // two rows in flight
+            float x0, y0, x1, y1;
+            a_ld2(X, r * ld + c, dt, x0, y0);
+            a_ld2(X, (r + 4) * ld + c, dt, x1, y1);
+            a0 += x0 + x1; a1 += y0 + y1;
+        }
+        for (; r < r1; r += 4) { float x, y; a_ld2(X, r * ld + c, dt, x, y); a0 += x; a1 += y; }
+    }
+    sh[w][2 * lane] = a0; sh[w][2 * lane + 1] = a1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int cc = blockIdx.x * 128 + threadIdx.x;
+        if (cc < C) atomicAdd(out + cc, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    }
+}
 extern "C" int xva_fp_colsum(const void* X, int dt, float* out, int64_t rows, int C, int64_t ld, void* stream) {
     XVA_CHECK_ARG(X && out && C > 0, "colsum: bad args");
     if (rows <= 0) return XVA_OK;
+    if (C % 2 == 0 && ld % 2 == 0 && ((uintptr_t)X % 8) == 0) {
+        const int rpb2 = 128;
+        hipLaunchKernelGGL(colsum2_kernel, dim3(xva_cdiv(C, 128), xva_cdiv(rows, rpb2)), dim3(256), 0, (hipStream_t)stream, X, dt, out,
+                           rows, C, ld, rpb2);
+        XVA_LAUNCH_CHECK();
+        return XVA_OK;
+    }
     const int rpb = 256;
     hipLaunchKernelGGL(colsum_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, X, dt, out, rows,
                        C, ld, rpb);

@@ -26,6 +26,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     if (p.M == 0 || p.N == 0) return XVA_OK;
     if (p.batch < 1) p.batch = 1;
     if (p.batch2 < 1) p.batch2 = 1;
+    const bool auto_sk = (p.splitk == 0);     // 0: choose the split count here (needs accumulate into fp32 C, linear epilogue)
     if (p.splitk < 1) p.splitk = 1;
     XVA_CHECK_ARG(p.layout >= 0 && p.layout <= 2, "xva_gemm: bad layout");
     XVA_CHECK_ARG(p.a_dtype == p.b_dtype, "xva_gemm: A and B must share a storage dtype");
@@ -59,15 +60,34 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     // =1 forces the 128x128 tile, =2 forces 256x256 (A/B switches for profiling)
     const int glds_env = g_glds_mode;
     int glds_tile = -1;
+    const bool can_split = auto_sk && p.accumulate && p.c_dtype == XVA_F32 && p.act == XVA_ACT_NONE && !p.G && p.mask_mode == XVA_MASK_NONE;
     if (glds_env != 0 && p.N > 64 && p.K >= 192 && xva_gemm_glds_eligible(p)) {
-        const long t256 = (long)xva_cdiv(p.N, 256) * xva_cdiv(p.M, 256) * p.batch * p.batch2 * p.splitk;
+        const long nb = (long)p.batch * p.batch2;
+        const long t256 = (long)xva_cdiv(p.N, 256) * xva_cdiv(p.M, 256) * nb;
         const double eff256 = (double)p.M * p.N / ((double)xva_cdiv(p.N, 256) * xva_cdiv(p.M, 256) * 65536.0);
-        glds_tile = (t256 >= 192 && eff256 >= 0.8) ? 1 : 0;
+        nkt = xva_cdiv(p.K, 64);
+        // 256x256 tiles (one workgroup per CU) when they fill the chip — by themselves or through split-K — without much padding
+        const bool fills = can_split ? (t256 * (nkt / 8) >= 192) : (t256 * p.splitk >= 192);
+        glds_tile = (fills && eff256 >= 0.8) ? 1 : 0;
         if (glds_env == 1) glds_tile = 0;
         if (glds_env == 2) glds_tile = 1;
         bn = glds_tile ? 256 : 129;
-        nkt = xva_cdiv(p.K, 64);
+        if (can_split) {   // 256x256 tiles: at most one round of 256 workgroups; 128x128 tiles (two per CU): ~1.7 rounds; >= 8 K tiles per split
+            const long tiles = glds_tile ? t256 : (long)xva_cdiv(p.N, 128) * xva_cdiv(p.M, 128) * nb;
+            long sk = glds_tile ? 256 / tiles : (864 + tiles / 2) / tiles;
+            if (sk > nkt / 8) sk = nkt / 8;
+            if (p.sk_ws && p.N % 4 == 0) {   // stay inside the caller's slab scratch (atomics are much slower)
+                const long fit = (long)(p.sk_ws_bytes / ((int64_t)p.M * p.N * 4 * nb));
+                if (fit >= 2 && sk > fit) sk = fit;
+            }
+            p.splitk = sk < 1 ? 1 : (int)sk;
+        }
         if (p.splitk > nkt) p.splitk = nkt;
+    } else if (can_split) {
+        const long tiles = (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2;
+        long sk = (768 + tiles - 1) / tiles;
+        if (sk > nkt / 8) sk = nkt / 8;
+        p.splitk = sk < 1 ? 1 : (int)sk;
     }
     long nblocks = (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2 * p.splitk;
     XVA_CHECK_ARG(nblocks < (1L << 31), "xva_gemm: grid too large");
