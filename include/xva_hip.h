@@ -164,6 +164,13 @@ int xva_fp_softmax_fwd(void* S, void* P_dropped, int dt, const int32_t* lens, in
                        uint32_t stream_id, void* stream);
 int xva_fp_softmax_bwd(const void* P, void* dP, int dt, int B, int Tp, int64_t Ts, float scale, float p_drop, uint64_t seed,
                        uint32_t stream_id, void* stream);
+/* Fused single-head attention (d_head = 64) on bf16 tensors: qkv (B, Tp, 192) = [Q | K | V], keys 1..lens[b] valid.
+ * Forward writes av (B, Tp, 64) and the per-row logsumexp; backward writes d_qkv (B, Tp, 192) (dscratch: B * Tp floats).
+ * Same mathematics and dropout masks as the unfused xva_gemm + xva_fp_softmax_* chain (transformer.py:109-130). */
+int xva_fp_attention_fwd(const void* qkv, const int32_t* lens, void* av, float* lse, int B, int Tp, float scale, float p_drop,
+                         uint64_t seed, uint32_t stream_id, void* stream);
+int xva_fp_attention_bwd(const void* qkv, const void* av, const void* d_av, const float* lse, float* dscratch, const int32_t* lens,
+                         void* d_qkv, int B, int Tp, float scale, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
 int xva_fp_layernorm_fwd(const void* X, const float* gamma, const float* beta, void* Y, int dt, float* mean, float* rstd, int64_t rows,
                          int C, int mask_mode, const int32_t* lens, int Tp, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
 int xva_fp_layernorm_bwd(const void* dY, const void* X, const float* mean, const float* rstd, const float* gamma, void* dX, void* dX_masked,

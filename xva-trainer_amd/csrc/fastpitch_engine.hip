@@ -132,7 +132,7 @@ struct Bump {
     int64_t seq(int64_t rows, int C, int es) { int64_t o = take((rows + 2) * (int64_t)C * es); return o + (int64_t)C * es; }
 };
 
-struct LayerA { int64_t qkv, P, Pd, av, sum1, mean1, rstd1, y1, h, sum2, mean2, rstd2; };
+struct LayerA { int64_t qkv, P, Pd, lse, av, sum1, mean1, rstd1, y1, h, sum2, mean2, rstd2; };
 struct PredA { int64_t c1, m1, r1, n1, c2, m2, r2, n2, out; };
 struct Plan {
     int B, Tt, Tm, Ttp, Tmp, es, dt;
@@ -159,6 +159,7 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     p->dt = d->compute ? XVA_BF16 : XVA_F32; p->es = d->compute ? 2 : 4;
     const int es = p->es;
     const bool drop = d->p_dropout > 0.f;
+    const bool fused = d->compute != 0;
     p->Re = (int64_t)d->B * p->Ttp; p->Rd = (int64_t)d->B * p->Tmp;
     p->Tse = (p->Ttp + 7) & ~7; p->Tsd = (p->Tmp + 7) & ~7;
     Bump b;
@@ -166,8 +167,10 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
         x[0] = b.seq(R, DM, es);
         for (int i = 0; i < NL; ++i) {
             L[i].qkv = b.seq(R, DQKV, es);
-            L[i].P = b.take((int64_t)p->B * Tp * Ts * es + 64);
-            L[i].Pd = drop ? b.take((int64_t)p->B * Tp * Ts * es + 64) : L[i].P;
+            // bf16 mode runs the fused attention kernels (attention.hip): no (T x T) probability matrices, one logsumexp per row
+            L[i].P = fused ? -1 : b.take((int64_t)p->B * Tp * Ts * es + 64);
+            L[i].Pd = fused ? -1 : (drop ? b.take((int64_t)p->B * Tp * Ts * es + 64) : L[i].P);
+            L[i].lse = fused ? b.take(R * 4) : -1;
             L[i].av = b.seq(R, DH, es);
             L[i].sum1 = b.seq(R, DM, es);
             L[i].mean1 = b.take(R * 4); L[i].rstd1 = b.take(R * 4);
@@ -201,7 +204,7 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     int Tpm = p->Tmp > p->Ttp ? p->Tmp : p->Ttp;
     p->gA = b.seq(Rm, DM, es); p->gB = b.seq(Rm, DM, es); p->gC = b.seq(Rm, DM, es); p->gD = b.seq(Rm, DM, es);
     p->gBm = drop ? b.seq(Rm, DM, es) : p->gB; p->gDm = drop ? b.seq(Rm, DM, es) : p->gD;
-    p->gH = b.seq(Rm, DI, es); p->gAV = b.seq(Rm, DH, es); p->gP = b.take((int64_t)p->B * Tpm * Tsm * es + 64); p->gQKV = b.seq(Rm, DQKV, es);
+    p->gH = b.seq(Rm, DI, es); p->gAV = b.seq(Rm, DH, es); p->gP = fused ? b.take(Rm * 4) : b.take((int64_t)p->B * Tpm * Tsm * es + 64); p->gQKV = b.seq(Rm, DQKV, es);
     p->gE = b.seq(p->Re, DM, es); p->pa = b.seq(p->Re, DP, 4); p->pb = b.seq(p->Re, DP, 4);
     p->skws_bytes = (int64_t)8 * DI * 3 * DM * 4;   // 8 splits of the largest weight gradient (1536 x 1152 fp32)
     p->skws = b.take(p->skws_bytes);
@@ -310,23 +313,28 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         const LayerP& p = LP[l];
         const LayerA& a = LA[l];
         char* x = c.A(xo[l]);
-        char* qkv = c.A(a.qkv); char* Pm = c.A(a.P); char* Pdm = c.A(a.Pd); char* av = c.A(a.av);
+        char* qkv = c.A(a.qkv); char* av = c.A(a.av);
         const uint32_t s0 = site + l * 4;
         // qkv = x Wqkv^T + b                                             (transformer.py:109)
         XVA_TRY(linear_fwd(c, x, R, DM, DM, p.qkv_w, c.P + p.qkv_b, qkv, DQKV, DQKV, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
-        {   // S = scale * Q K^T per item                                  (transformer.py:118-119)
-            xva_gemm_params g = gp0(c);
-            g.layout = XVA_GEMM_NT; g.A = qkv; g.B = c.sh(qkv, DH); g.C = Pm; g.M = Tp; g.N = Tp; g.K = DH;
-            g.lda = DQKV; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DQKV; g.sB = g.sA; g.sC = (int64_t)Tp * Ts;
-            g.alpha = 0.125f;
-            XVA_TRY(xva_gemm(&g, c.st));
-        }
-        XVA_TRY(xva_fp_softmax_fwd(Pm, Pdm, c.dt, lens, B, Tp, Ts, c.pd, c.seed, s0 + 0, c.st));      // :121-128 (softmax, dropatt)
-        {   // AV = dropatt(P) V                                            (transformer.py:130)
-            xva_gemm_params g = gp0(c);
-            g.layout = XVA_GEMM_NN; g.A = Pdm; g.B = c.sh(qkv, 2 * DH); g.C = av; g.M = Tp; g.N = DH; g.K = Tp;
-            g.lda = Ts; g.ldb = DQKV; g.ldc = DH; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DH;
-            XVA_TRY(xva_gemm(&g, c.st));
+        if (c.compute) {
+            XVA_TRY(xva_fp_attention_fwd(qkv, lens, av, c.F(a.lse), B, Tp, 0.125f, c.pd, c.seed, s0 + 0, c.st));   // transformer.py:118-130
+        } else {
+            char* Pm = c.A(a.P); char* Pdm = c.A(a.Pd);
+            {   // S = scale * Q K^T per item                                  (transformer.py:118-119)
+                xva_gemm_params g = gp0(c);
+                g.layout = XVA_GEMM_NT; g.A = qkv; g.B = c.sh(qkv, DH); g.C = Pm; g.M = Tp; g.N = Tp; g.K = DH;
+                g.lda = DQKV; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DQKV; g.sB = g.sA; g.sC = (int64_t)Tp * Ts;
+                g.alpha = 0.125f;
+                XVA_TRY(xva_gemm(&g, c.st));
+            }
+            XVA_TRY(xva_fp_softmax_fwd(Pm, Pdm, c.dt, lens, B, Tp, Ts, c.pd, c.seed, s0 + 0, c.st));      // :121-128 (softmax, dropatt)
+            {   // AV = dropatt(P) V                                            (transformer.py:130)
+                xva_gemm_params g = gp0(c);
+                g.layout = XVA_GEMM_NN; g.A = Pdm; g.B = c.sh(qkv, 2 * DH); g.C = av; g.M = Tp; g.N = DH; g.K = Tp;
+                g.lda = Ts; g.ldb = DQKV; g.ldc = DH; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DH;
+                XVA_TRY(xva_gemm(&g, c.st));
+            }
         }
         // sum1 = x + drop(AV Wo^T) ; y1 = LN(sum1) * mask                  (transformer.py:137-146,166-167)
         XVA_TRY(linear_fwd(c, av, R, DH, DH, p.o_w, nullptr, c.A(a.sum1), DM, DM, x, DM, XVA_MASK_NONE, nullptr, 0, Drop{c.pd, s0 + 1}));
@@ -353,7 +361,7 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         const LayerP& p = LP[l];
         const LayerA& a = LA[l];
         char* x = c.A(xo[l]);
-        char* qkv = c.A(a.qkv); char* Pm = c.A(a.P); char* Pdm = c.A(a.Pd); char* av = c.A(a.av);
+        char* qkv = c.A(a.qkv); char* av = c.A(a.av);
         const uint32_t s0 = site + l * 4;
         // LN2 backward -> gB = d sum2 (residual path) ; gBm = gB * dropmask (conv2 branch)
         XVA_TRY(xva_fp_layernorm_bwd(gA, c.A(a.sum2), c.F(a.mean2), c.F(a.rstd2), c.P + p.ln2_g, gB, drop ? gBm : nullptr, c.dt, Gg + p.ln2_g,
@@ -372,30 +380,35 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         // o_net backward
         XVA_TRY(linear_bwd_data(c, gDm, R, DM, DM, p.o_w, DH, gAV, DH, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
         XVA_TRY(linear_bwd_weight(c, gDm, R, DM, DM, av, DH, DH, Gg + p.o_w));
-        {   // dPd = dAV V^T
-            xva_gemm_params g = gp0(c);
-            g.layout = XVA_GEMM_NT; g.A = gAV; g.B = c.sh(qkv, 2 * DH); g.C = gP; g.M = Tp; g.N = Tp; g.K = DH;
-            g.lda = DH; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DH; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * Ts;
-            XVA_TRY(xva_gemm(&g, c.st));
-        }
-        {   // dV = Pd^T dAV  -> gQKV[:, 128:192]
-            xva_gemm_params g = gp0(c);
-            g.layout = XVA_GEMM_TN; g.A = Pdm; g.B = gAV; g.C = c.sh(gQKV, 2 * DH); g.M = Tp; g.N = DH; g.K = Tp;
-            g.lda = Ts; g.ldb = DH; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DH; g.sC = (int64_t)Tp * DQKV;
-            XVA_TRY(xva_gemm(&g, c.st));
-        }
-        XVA_TRY(xva_fp_softmax_bwd(Pm, gP, c.dt, B, Tp, Ts, 0.125f, c.pd, c.seed, s0 + 0, c.st));    // gP = dS (incl. 1/sqrt(d))
-        {   // dQ = dS K -> gQKV[:, 0:64]
-            xva_gemm_params g = gp0(c);
-            g.layout = XVA_GEMM_NN; g.A = gP; g.B = c.sh(qkv, DH); g.C = gQKV; g.M = Tp; g.N = DH; g.K = Tp;
-            g.lda = Ts; g.ldb = DQKV; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DQKV;
-            XVA_TRY(xva_gemm(&g, c.st));
-        }
-        {   // dK = dS^T Q -> gQKV[:, 64:128]
-            xva_gemm_params g = gp0(c);
-            g.layout = XVA_GEMM_TN; g.A = gP; g.B = qkv; g.C = c.sh(gQKV, DH); g.M = Tp; g.N = DH; g.K = Tp;
-            g.lda = Ts; g.ldb = DQKV; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DQKV;
-            XVA_TRY(xva_gemm(&g, c.st));
+        if (c.compute) {
+            XVA_TRY(xva_fp_attention_bwd(qkv, av, gAV, c.F(a.lse), (float*)gP, lens, gQKV, B, Tp, 0.125f, c.pd, c.seed, s0 + 0, c.st));
+        } else {
+            char* Pm = c.A(a.P); char* Pdm = c.A(a.Pd);
+            {   // dPd = dAV V^T
+                xva_gemm_params g = gp0(c);
+                g.layout = XVA_GEMM_NT; g.A = gAV; g.B = c.sh(qkv, 2 * DH); g.C = gP; g.M = Tp; g.N = Tp; g.K = DH;
+                g.lda = DH; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DH; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * Ts;
+                XVA_TRY(xva_gemm(&g, c.st));
+            }
+            {   // dV = Pd^T dAV  -> gQKV[:, 128:192]
+                xva_gemm_params g = gp0(c);
+                g.layout = XVA_GEMM_TN; g.A = Pdm; g.B = gAV; g.C = c.sh(gQKV, 2 * DH); g.M = Tp; g.N = DH; g.K = Tp;
+                g.lda = Ts; g.ldb = DH; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DH; g.sC = (int64_t)Tp * DQKV;
+                XVA_TRY(xva_gemm(&g, c.st));
+            }
+            XVA_TRY(xva_fp_softmax_bwd(Pm, gP, c.dt, B, Tp, Ts, 0.125f, c.pd, c.seed, s0 + 0, c.st));    // gP = dS (incl. 1/sqrt(d))
+            {   // dQ = dS K -> gQKV[:, 0:64]
+                xva_gemm_params g = gp0(c);
+                g.layout = XVA_GEMM_NN; g.A = gP; g.B = c.sh(qkv, DH); g.C = gQKV; g.M = Tp; g.N = DH; g.K = Tp;
+                g.lda = Ts; g.ldb = DQKV; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DQKV;
+                XVA_TRY(xva_gemm(&g, c.st));
+            }
+            {   // dK = dS^T Q -> gQKV[:, 64:128]
+                xva_gemm_params g = gp0(c);
+                g.layout = XVA_GEMM_TN; g.A = gP; g.B = qkv; g.C = c.sh(gQKV, DH); g.M = Tp; g.N = DH; g.K = Tp;
+                g.lda = Ts; g.ldb = DQKV; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DQKV;
+                XVA_TRY(xva_gemm(&g, c.st));
+            }
         }
         // d x = gD + gQKV Wqkv, LEN-masked -> gA
         XVA_TRY(linear_bwd_data(c, gQKV, R, DQKV, DQKV, p.qkv_w, DM, gA, DM, gD, DM, XVA_MASK_LEN, lens, Tp));

@@ -1,6 +1,46 @@
 // gemm_glds.hip — instantiations of the direct-to-LDS GEMM main loop (gemm_glds.h) and its eligibility test.
 #include "gemm_glds.h"
 
+namespace xva_glds {
+// C (+)= alpha * (sum_s slab[s] + bias) + beta * R  for one batch item per blockIdx.y; thread = one column, rows strided by gridDim.x.
+__global__ __launch_bounds__(256) void xva_gemm_splitk_reduce_kernel(xva_gemm_params p) {
+    const int b2n = p.batch2 > 1 ? p.batch2 : 1;
+    const int bz = blockIdx.y, z1 = bz / b2n, z2 = bz - z1 * b2n;
+    const int64_t MN = (int64_t)p.M * p.N;
+    const float* slab = reinterpret_cast<const float*>(p.sk_ws) + (int64_t)bz * p.splitk * MN;
+    const int64_t coff = (int64_t)z1 * p.sC + (int64_t)z2 * p.sC2;
+    const int64_t roff = (int64_t)z1 * p.sR + (int64_t)z2 * p.sR2;
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < MN; e += (int64_t)gridDim.x * 1024) {
+        float4 s = *reinterpret_cast<const float4*>(slab + e);
+        for (int k = 1; k < p.splitk; ++k) {
+            float4 t = *reinterpret_cast<const float4*>(slab + k * MN + e);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        float v[4] = {s.x, s.y, s.z, s.w};
+        const int row = (int)(e / p.N), col = (int)(e - (int64_t)row * p.N);   // N % 4 == 0: the 4 values share a row
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = v[q];
+            if (p.bias) x += p.bias[(int64_t)z2 * p.sbias2 + col + q];
+            x *= p.alpha;
+            if (p.R) x += p.beta * ld_elem(p.R, roff + (int64_t)row * p.ldr + col + q, p.r_dtype);
+            const int64_t ci = coff + (p.c_trans ? (int64_t)(col + q) * p.ldc + row : (int64_t)row * p.ldc + col + q);
+            if (p.c_dtype == XVA_BF16) {
+                uint16_t* dst = reinterpret_cast<uint16_t*>(p.C) + ci;
+                if (p.accumulate) x += bf2f(*dst);
+                *dst = f2bf(x);
+            } else {
+                float* dst = reinterpret_cast<float*>(p.C) + ci;
+                if (p.accumulate == 2) atomicAdd(dst, x);
+                else if (p.accumulate) *dst += x;
+                else *dst = x;
+            }
+        }
+    }
+}
+
+}  // namespace xva_glds
+
 // Can this problem take the direct-to-LDS path?  (bf16-stored operands, bf16 MFMA, segment / K-block lengths that keep a
 // 64-deep K tile inside one segment, 8-element granularity of every index-contiguous dimension.)
 bool xva_gemm_glds_eligible(const xva_gemm_params& p) {
