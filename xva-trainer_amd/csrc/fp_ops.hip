@@ -225,23 +225,26 @@ __global__ void layernorm_fwd_kernel(const void* __restrict__ X, const float* __
 // the LN output in forward); dead rows -> 0.  relu_gate: zero dX where X <= 0 (X is a post-ReLU activation).
 // Second output dXm = dX * m_out: the gradient entering a dropout-ed branch (residual + dropout(branch): the residual path
 // takes dX, the branch takes dXm); dXm may be null.  dgamma += sum_r dY' * xhat, dbeta += sum_r dY'.
+// 16 waves per workgroup and at most ~2 workgroups per CU: each gamma / beta address receives a few hundred atomics per launch
+// (one per workgroup) instead of one per 16 rows — same-address L2 atomics serialise.
+#define LNB_WAVES 16
 template <int CPL>
-__global__ void layernorm_bwd_kernel(const void* __restrict__ dY, const void* __restrict__ X, const float* __restrict__ mean,
+__global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const void* __restrict__ dY, const void* __restrict__ X, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const float* __restrict__ gamma, void* __restrict__ dX,
                                      void* __restrict__ dXm, int dt, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
                                      int rows_per_block, int mask_mode, const int* __restrict__ lens, int Tp, int relu_gate, float p_in,
                                      uint64_t seed_in, uint32_t stream_in, float p_out, uint64_t seed_out, uint32_t stream_out,
                                      const float* __restrict__ outer_d, const float* __restrict__ outer_w) {
     constexpr int C = 64 * CPL;
-    __shared__ float sh_g[WAVES_PER_BLOCK][C];
-    __shared__ float sh_b[WAVES_PER_BLOCK][C];
+    __shared__ float sh_g[LNB_WAVES][C];
+    __shared__ float sh_b[LNB_WAVES][C];
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float ag[CPL], ab[CPL], gm[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; gm[i] = gamma[2 * lane + 128 * (i >> 1) + (i & 1)]; }   // column pairs
-    for (int64_t row = r0 + wave; row < r1; row += WAVES_PER_BLOCK) {
+    for (int64_t row = r0 + wave; row < r1; row += LNB_WAVES) {
         if (!xva_row_live(mask_mode, lens, Tp, row)) {
 #pragma unroll
             for (int h = 0; h < CPL / 2; ++h) {
@@ -296,7 +299,7 @@ __global__ void layernorm_bwd_kernel(const void* __restrict__ dY, const void* __
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float g = 0.f, b = 0.f;
 #pragma unroll
-            for (int w = 0; w < WAVES_PER_BLOCK; ++w) { g += sh_g[w][c]; b += sh_b[w][c]; }
+            for (int w = 0; w < LNB_WAVES; ++w) { g += sh_g[w][c]; b += sh_b[w][c]; }
             atomicAdd(dgamma + c, g);
             atomicAdd(dbeta + c, b);
         }
@@ -326,8 +329,9 @@ extern "C" int xva_fp_layernorm_bwd(const void* dY, const void* X, const float* 
     XVA_CHECK_ARG((dY || (outer_d && outer_w)) && X && mean && rstd && gamma && dX, "layernorm_bwd: null");
     XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
     XVA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both null");
-    const int rpb = 16;
-    dim3 grid(xva_cdiv(rows, rpb)), block(64 * WAVES_PER_BLOCK);
+    int rpb = (int)xva_cdiv(rows, 512);          // <= 512 workgroups
+    rpb = (rpb + LNB_WAVES - 1) / LNB_WAVES * LNB_WAVES;
+    dim3 grid(xva_cdiv(rows, rpb)), block(64 * LNB_WAVES);
     if (C == 384)
         hipLaunchKernelGGL((layernorm_bwd_kernel<6>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma,
                            dbeta, rows, rpb, mask_mode, lens, Tp, relu_gate, p_in, seed_in, stream_in, p_out, seed_out, stream_out,

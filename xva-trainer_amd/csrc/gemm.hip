@@ -8,13 +8,14 @@ void xva_gemm_launch_bf16(const xva_gemm_params& p, int bn, unsigned nblocks, hi
 void xva_gemm_launch_mixed(const xva_gemm_params& p, int bn, unsigned nblocks, hipStream_t st);
 bool xva_gemm_glds_eligible(const xva_gemm_params& p);
 int xva_gemm_launch_glds(const xva_gemm_params& p, int tile, hipStream_t st);
+void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn);
 bool xva_prof_is_on();
 void xva_prof_begin(hipStream_t st, double flops, int variant);
 void xva_prof_end(hipStream_t st);
 void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn);
 
-// Main-loop selection: -1 automatic (default; env XVA_GEMM_GLDS overrides), 0 general kernel only, 1 direct-to-LDS 128x128,
-// 2 direct-to-LDS 256x256 wherever eligible.  A diagnostics / test knob, not part of the numerical contract.
+// Main-loop selection: -1 automatic (default; env XVA_GEMM_GLDS overrides), 0 general kernel only, 1..4 force the direct-to-LDS tile
+// 128x128 / 256x256 / 128x64 / 64x64 wherever eligible.  A diagnostics / test knob, not part of the numerical contract.
 static int g_glds_mode = [] { const char* e = getenv("XVA_GEMM_GLDS"); return e ? atoi(e) : -1; }();
 extern "C" int xva_gemm_set_mainloop(int mode) { int old = g_glds_mode; g_glds_mode = mode; return old; }
 
@@ -61,20 +62,25 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     const int glds_env = g_glds_mode;
     int glds_tile = -1;
     const bool can_split = auto_sk && p.accumulate && p.c_dtype == XVA_F32 && p.act == XVA_ACT_NONE && !p.G && p.mask_mode == XVA_MASK_NONE;
-    if (glds_env != 0 && p.N > 64 && p.K >= 192 && xva_gemm_glds_eligible(p)) {
+    if (glds_env != 0 && p.K >= 192 && xva_gemm_glds_eligible(p)) {
         const long nb = (long)p.batch * p.batch2;
-        const long t256 = (long)xva_cdiv(p.N, 256) * xva_cdiv(p.M, 256) * nb;
-        const double eff256 = (double)p.M * p.N / ((double)xva_cdiv(p.N, 256) * xva_cdiv(p.M, 256) * 65536.0);
         nkt = xva_cdiv(p.K, 64);
-        // 256x256 tiles (one workgroup per CU) when they fill the chip — by themselves or through split-K — without much padding
-        const bool fills = can_split ? (t256 * (nkt / 8) >= 192) : (t256 * p.splitk >= 192);
-        glds_tile = (fills && eff256 >= 0.8) ? 1 : 0;
-        if (glds_env == 1) glds_tile = 0;
-        if (glds_env == 2) glds_tile = 1;
-        bn = glds_tile ? 256 : 129;
-        if (can_split) {   // 256x256 tiles: at most one round of 256 workgroups; 128x128 tiles (two per CU): ~1.7 rounds; >= 8 K tiles per split
-            const long tiles = glds_tile ? t256 : (long)xva_cdiv(p.N, 128) * xva_cdiv(p.M, 128) * nb;
-            long sk = glds_tile ? 256 / tiles : (864 + tiles / 2) / tiles;
+        auto ntiles = [&](int t) { int bm, bnn; xva_gemm_glds_tile_dims(t, &bm, &bnn); return (long)xva_cdiv(p.N, bnn) * xva_cdiv(p.M, bm) * nb; };
+        const long t256 = ntiles(1);
+        const double eff256 = (double)p.M * p.N * nb / ((double)t256 * 65536.0);
+        // 256x256 tiles (one workgroup per CU) when they fill the chip — by themselves or through split-K — without much padding;
+        // narrow outputs take 64-column tiles; grids that would leave most CUs idle take 64x64 tiles
+        const long maxsk = can_split ? (nkt / 8 > 1 ? nkt / 8 : 1) : p.splitk;
+        if (p.N <= 64) glds_tile = 2;
+        else if (t256 * maxsk >= 192 && eff256 >= 0.7) glds_tile = 1;
+        else if (ntiles(0) * maxsk >= 256) glds_tile = 0;
+        else glds_tile = 3;
+        if (glds_env >= 1 && glds_env <= 4) glds_tile = glds_env - 1;   // forced: 1 -> 128x128, 2 -> 256x256, 3 -> 128x64, 4 -> 64x64
+        int bm; xva_gemm_glds_tile_dims(glds_tile, &bm, &bn);
+        bn = bn * 1000 + bm;   // profile tag
+        if (can_split) {   // 256x256 tiles: at most one round of 256 workgroups; smaller tiles (2-3 per CU): ~1.7 rounds; >= 8 K tiles per split
+            const long tiles = ntiles(glds_tile);
+            long sk = glds_tile == 1 ? 256 / tiles : (864 + tiles / 2) / tiles;
             if (sk > nkt / 8) sk = nkt / 8;
             if (p.sk_ws && p.N % 4 == 0) {   // stay inside the caller's slab scratch (atomics are much slower)
                 const long fit = (long)(p.sk_ws_bytes / ((int64_t)p.M * p.N * 4 * nb));
@@ -89,7 +95,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (sk > nkt / 8) sk = nkt / 8;
         p.splitk = sk < 1 ? 1 : (int)sk;
     }
-    long nblocks = (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2 * p.splitk;
+    long nblocks = glds_tile >= 0 ? 1 : (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2 * p.splitk;
     XVA_CHECK_ARG(nblocks < (1L << 31), "xva_gemm: grid too large");
     hipStream_t st = (hipStream_t)stream;
     const int mode = p.compute == 0 ? 0 : (p.a_dtype == XVA_BF16 ? 1 : 2);

@@ -42,6 +42,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 __device__ __forceinline__ int swap23(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
+// position of 16-byte chunk c inside k-row `pos` of an IC image with ROWS index columns (an involution in c):
+// rows of >= 256 bytes XOR the 32-byte window with pos & 7, 128-byte rows (ROWS = 64) with (pos >> 1) & 3 — either way the 8
+// k-rows a half-wave transpose read touches land on 8 distinct 32-byte bank windows.
+template <int ROWS>
+__device__ __forceinline__ int ic_chunk(int pos, int c) { return ROWS >= 128 ? (c ^ ((pos & 7) << 1)) : (c ^ (((pos >> 1) & 3) << 1)); }
 
 // ---- DMA descriptors of one operand tile ([ROWS idx] x [64 k]) for one thread ---------------------------------------------
 // The tile is 8 * ROWS 16-byte chunks; wave instruction Q (0 .. ROWS/8 - 1) fills LDS bytes [Q * 1024, Q * 1024 + 1024).
@@ -67,7 +72,7 @@ struct Loader {
                 constexpr int RPI = 64 / CPR;                       // k-rows per wave instruction: 4 or 2
                 const int pos = Q * RPI + lane / CPR;
                 const int p = lane % CPR;
-                const int c = p ^ ((pos & 7) << 1);
+                const int c = ic_chunk<ROWS>(pos, p);
                 const int k = swap23(pos);
                 int col = min(i0 + c * 8, bound - 8);
                 int64_t cm = col;
@@ -100,17 +105,16 @@ struct KcReader {
         return *reinterpret_cast<const XVA_LDS bf16x8*>(tile + row0 * 128 + (kh ? o1 : o0));
     }
 };
-// IC image: [64 kpos][ROWS idx] bf16, kpos = k with bits 2/3 swapped, 16-byte chunk c of a row at position c ^ ((kpos & 7) << 1).
+// IC image: [64 kpos][ROWS idx] bf16, kpos = k with bits 2/3 swapped, 16-byte chunk c of a row at position ic_chunk(kpos, c).
 template <int ROWS, int TILES>
 struct IcReader {
     uint32_t o[TILES];   // byte offset of this lane for idx tile t (16 columns), kh = 0, half 0
     __device__ __forceinline__ void init(int lane, int w0) {
         const int g = lane >> 4, i = lane & 15;
-        const int X = (g & 1) * 4 + (i >> 2);                                  // kpos & 7
-        const int posl = (g >> 1) * 16 + (g & 1) * 4 + (i >> 2);               // kpos without the (kh, half) bits
+        const int posl = (g >> 1) * 16 + (g & 1) * 4 + (i >> 2);               // kpos without the (kh, half) bits (they do not enter the swizzle)
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
-            o[t] = posl * (ROWS * 2) + ((w0 / 8 + t * 2 + ((i >> 1) & 1)) ^ (X << 1)) * 16 + (i & 1) * 8;
+            o[t] = posl * (ROWS * 2) + ic_chunk<ROWS>(posl, w0 / 8 + t * 2 + ((i >> 1) & 1)) * 16 + (i & 1) * 8;
     }
     __device__ __forceinline__ bf16x8 read(const XVA_LDS uint8_t* tile, int t, int kh) const {
         const XVA_LDS uint8_t* a = tile + o[t] + kh * (32 * ROWS * 2);
@@ -234,7 +238,7 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
 // vec_epi: host-verified that N % 4 == 0 and C / R / G rows are 4-element aligned (vector epilogue allowed)
 template <int LAYOUT, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) ? 1 : 2) void xva_gemm_glds_kernel(xva_gemm_params p, int vec_epi) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) ? 1 : (BM * BN >= 128 * 128 ? 2 : 3)) void xva_gemm_glds_kernel(xva_gemm_params p, int vec_epi) {
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
     constexpr int MI = WM / 16, NJ = WN / 16;
     constexpr int AK = LAYOUT == XVA_GEMM_TN ? IC : KC;

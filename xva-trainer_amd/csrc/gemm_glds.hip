@@ -62,7 +62,7 @@ bool xva_gemm_glds_eligible(const xva_gemm_params& p) {
 
 static int launch_tiles(const xva_gemm_params& p, int tile, int vec, hipStream_t st);
 
-// tile: 0 = 128 x 128 (4 waves), 1 = 256 x 256 (8 waves)
+// tile: see launch_tiles
 int xva_gemm_launch_glds(const xva_gemm_params& pin, int tile, hipStream_t st) {
     using namespace xva_glds;
     xva_gemm_params p = pin;
@@ -82,18 +82,25 @@ int xva_gemm_launch_glds(const xva_gemm_params& pin, int tile, hipStream_t st) {
     return rc;
 }
 
-static int launch_tiles(const xva_gemm_params& p, int tile, int vec, hipStream_t st) {
+template <int BM, int BN, int WM, int WN>
+static int launch_layout(const xva_gemm_params& p, int vec, hipStream_t st) {
     using namespace xva_glds;
-    if (tile == 1) {
-        switch (p.layout) {
-            case XVA_GEMM_NT: return launch_tile<XVA_GEMM_NT, 256, 256, 128, 64>(p, vec, st);
-            case XVA_GEMM_NN: return launch_tile<XVA_GEMM_NN, 256, 256, 128, 64>(p, vec, st);
-            default: return launch_tile<XVA_GEMM_TN, 256, 256, 128, 64>(p, vec, st);
-        }
-    }
     switch (p.layout) {
-        case XVA_GEMM_NT: return launch_tile<XVA_GEMM_NT, 128, 128, 64, 64>(p, vec, st);
-        case XVA_GEMM_NN: return launch_tile<XVA_GEMM_NN, 128, 128, 64, 64>(p, vec, st);
-        default: return launch_tile<XVA_GEMM_TN, 128, 128, 64, 64>(p, vec, st);
+        case XVA_GEMM_NT: return launch_tile<XVA_GEMM_NT, BM, BN, WM, WN>(p, vec, st);
+        case XVA_GEMM_NN: return launch_tile<XVA_GEMM_NN, BM, BN, WM, WN>(p, vec, st);
+        default: return launch_tile<XVA_GEMM_TN, BM, BN, WM, WN>(p, vec, st);
     }
+}
+// tile: 0 = 128x128 (4 waves of 64x64), 1 = 256x256 (8 waves of 128x64), 2 = 128x64 (4 waves of 32x64), 3 = 64x64 (4 waves of 32x32)
+static int launch_tiles(const xva_gemm_params& p, int tile, int vec, hipStream_t st) {
+    switch (tile) {
+        case 1: return launch_layout<256, 256, 128, 64>(p, vec, st);
+        case 2: return launch_layout<128, 64, 32, 64>(p, vec, st);
+        case 3: return launch_layout<64, 64, 32, 32>(p, vec, st);
+        default: return launch_layout<128, 128, 64, 64>(p, vec, st);
+    }
+}
+void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn) {
+    static const int d[4][2] = {{128, 128}, {256, 256}, {128, 64}, {64, 64}};
+    *bm = d[tile & 3][0]; *bn = d[tile & 3][1];
 }
