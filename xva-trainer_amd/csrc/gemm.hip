@@ -62,7 +62,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     const int glds_env = g_glds_mode;
     int glds_tile = -1;
     const bool can_split = auto_sk && p.accumulate && p.c_dtype == XVA_F32 && p.act == XVA_ACT_NONE && !p.G && p.mask_mode == XVA_MASK_NONE;
-    if (glds_env != 0 && p.K >= 192 && xva_gemm_glds_eligible(p)) {
+    if (glds_env != 0 && p.K >= 64 && xva_gemm_glds_eligible(p)) {
         const long nb = (long)p.batch * p.batch2;
         nkt = xva_cdiv(p.K, 64);
         auto ntiles = [&](int t) { int bm, bnn; xva_gemm_glds_tile_dims(t, &bm, &bnn); return (long)xva_cdiv(p.N, bnn) * xva_cdiv(p.M, bm) * nb; };
@@ -72,6 +72,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         // narrow outputs take 64-column tiles; grids that would leave most CUs idle take 64x64 tiles
         const long maxsk = can_split ? (nkt / 8 > 1 ? nkt / 8 : 1) : p.splitk;
         if (p.N <= 64) glds_tile = 2;
+        else if (nkt < 4) glds_tile = ntiles(0) >= 1024 ? 0 : 3;     // short reductions are prologue / epilogue bound: many small workgroups
         else if (t256 * maxsk >= 192 && eff256 >= 0.7) glds_tile = 1;
         else if (ntiles(0) * maxsk >= 256) glds_tile = 0;
         else glds_tile = 3;
