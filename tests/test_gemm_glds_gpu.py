@@ -108,12 +108,12 @@ def test_tn_kblocks_and_column_segments(mainloop):
     assert _rel(dW, ref) < 3e-6
 
 
-@pytest.mark.parametrize("Cin,Cout,d", [(64, 136, 1), (128, 72, 3)])
+@pytest.mark.parametrize("Cin,Cout,d", [(64, 136, 1), (128, 72, 3), (32, 32, 5), (16, 64, 2)])
 def test_conv_tap_segments_fwd_bwd_data(mainloop, Cin, Cout, d):
     """Dilated k=3 conv as implicit GEMM: A tap segments (NT forward) and B row segments (NN backward-data)."""
     L = _lib()
     torch.manual_seed(7)
-    T, k, PAD = 700, 3, 4
+    T, k, PAD = 700, 3, 8
     xs = torch.zeros(T + 2 * PAD, Cin, device="cuda", dtype=torch.bfloat16)
     xs[PAD:PAD + T] = torch.randn(T, Cin, device="cuda").bfloat16()
     W = (torch.randn(Cout, Cin, k, device="cuda") * 0.1).bfloat16()
@@ -176,6 +176,27 @@ def test_epilogue_options(mainloop):
     assert abs(kept.float().mean().item() - 0.75) < 0.01
     assert torch.equal(kept, Cg != 0)                                  # same mask as the general kernel
     assert _rel(Cd[kept], (acc / 0.75)[kept]) < 3e-6
+
+
+def test_leaky_relu_fused_into_operands(mainloop):
+    """HiFi-GAN's generator feeds lrelu(x) to its convolutions and their weight gradients: the activation is applied to the MFMA
+    fragments (models.py:62-66).  x * slope is re-rounded to bf16 exactly like the reference rounds lrelu(x) stored in bf16."""
+    L = _lib()
+    torch.manual_seed(10)
+    M, N, K = 520, 136, 448
+    A, lda = _bf(M, K)
+    Bw, ldb = _bf(N, K)
+    lr = lambda t, s: torch.where(t > 0, t, (t.float() * s).bfloat16())
+    Cm = torch.zeros(M, N, device="cuda")
+    L.gemm(A, Bw, Cm, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=1, a_lrelu=0.1)
+    assert _rel(Cm, lr(A, 0.1).double() @ Bw.double().t()) < 3e-6
+    Bn, ldbn = _bf(K, N)
+    L.gemm(A, Bn, Cm, M, N, K, lda, ldbn, N, layout=L.GEMM_NN, compute=1, a_lrelu=0.2, b_lrelu=0.01)
+    assert _rel(Cm, lr(A, 0.2).double() @ lr(Bn, 0.01)[:, :N].double()) < 3e-6
+    At, ldat = _bf(K, M)
+    Ct = torch.zeros(M, N, device="cuda")
+    L.gemm(At, Bn, Ct, M, N, K, ldat, ldbn, N, layout=L.GEMM_TN, compute=1, accumulate=True, b_lrelu=0.1)
+    assert _rel(Ct, At[:, :M].double().t() @ lr(Bn, 0.1)[:, :N].double()) < 3e-6
 
 
 def test_batched_two_level(mainloop):

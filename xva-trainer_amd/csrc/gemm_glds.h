@@ -58,14 +58,17 @@ struct Loader {
 
     // i0: first row / column of the tile; bound: number of valid rows / columns; ld: leading dimension (elements);
     // KIND == IC: column c is remapped to colmap(c) = cseg0 + c + (c / cseglen) * csegstride when cseglen > 0 (TN column segments)
-    __device__ __forceinline__ void init(int lane, int wave, int i0, int bound, int64_t ld, int cseglen, int64_t cseg0, int64_t csegstride) {
+    // KIND == KC: k segments (conv taps): chunk k-offset kc adds (kc / kseglen) * ksegadj (kseglen divides 64 or is a multiple of it)
+    // KIND == IC: k-row kr lives at (kr / kseglen) * ksegadj + (kr % kseglen) * ld (NN row segments)
+    __device__ __forceinline__ void init(int lane, int wave, int i0, int bound, int64_t ld, int cseglen, int64_t cseg0, int64_t csegstride,
+                                         int kseglen = 0, int64_t ksegadj = 0) {
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             const int Q = q * NW + wave;
             if constexpr (KIND == KC) {
                 const int r = Q * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ (lane >> 3);             // chunk held by LDS position (lane & 7) of row r: c ^ (r & 7)
-                off[q] = (int64_t)min(i0 + r, bound - 1) * ld + c * 8;
+                off[q] = (int64_t)min(i0 + r, bound - 1) * ld + c * 8 + (kseglen > 0 ? (int64_t)((c * 8) / kseglen) * ksegadj : 0);
                 kk[q] = c * 8;
             } else {
                 constexpr int CPR = ROWS / 8;                       // chunks per k-row: 16 or 32
@@ -77,7 +80,7 @@ struct Loader {
                 int col = min(i0 + c * 8, bound - 8);
                 int64_t cm = col;
                 if (cseglen > 0) cm = cseg0 + col + (int64_t)(col / cseglen) * csegstride;
-                off[q] = (int64_t)k * ld + cm;
+                off[q] = (kseglen > 0 ? (int64_t)(k / kseglen) * ksegadj + (int64_t)(k % kseglen) * ld : (int64_t)k * ld) + cm;
                 kk[q] = k;
             }
         }
@@ -124,6 +127,21 @@ struct IcReader {
         return __builtin_bit_cast(bf16x8, v);
     }
 };
+
+// LeakyReLU of an operand fragment (x -> x > 0 ? x : slope * x), the "activation fused into the consumer" of HiFi-GAN's
+// generator (models.py:62-66,115-126): applied to the 8 bf16 values a lane feeds to one MFMA
+__device__ __forceinline__ bf16x8 lrelu_frag(bf16x8 f, float slope) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w = __builtin_bit_cast(u32x4, f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (w[e] & 0x80008000u) {   // at least one negative value in the pair
+            const float lo = lrelu(__uint_as_float(w[e] << 16), slope), hi = lrelu(__uint_as_float(w[e] & 0xffff0000u), slope);
+            w[e] = pack_bf2(lo, hi);
+        }
+    }
+    return __builtin_bit_cast(bf16x8, w);
+}
 
 // ---- epilogue -------------------------------------------------------------------------------------------------------------
 // v[0..3]: columns col .. col + 3 of row `row` (all inside N when VEC).  Order (include/xva_gemm.h):
@@ -272,11 +290,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) 
 
     Loader<AK, BM, NW> la;
     Loader<BKD, BN, NW> lb;
-    if constexpr (AK == KC) la.init(lane, wave, m0, p.M, p.lda, 0, 0, 0);
+    if constexpr (AK == KC) la.init(lane, wave, m0, p.M, p.lda, 0, 0, 0, p.a_seglen, p.a_segadj);
     else la.init(lane, wave, m0, p.M, p.lda, p.a_seglen, 0, p.a_segadj);          // TN: A column m -> m + (m / a_seglen) * a_segadj
     if constexpr (BKD == KC) lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0);
     else if constexpr (LAYOUT == XVA_GEMM_TN) lb.init(lane, wave, n0, p.N, p.ldb, p.seglen, p.seg0, p.segstride);
-    else lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0);                             // NN: row segments are folded into the tile base
+    else lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0, p.seglen, p.segstride);      // NN: row segments (tile base carries the tile's first segment)
 
     auto a_base = [&](int k0) -> const uint16_t* {
         if constexpr (AK == KC) return A + k0 + (p.a_seglen > 0 ? (int64_t)(k0 / p.a_seglen) * p.a_segadj : 0);
@@ -325,6 +343,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) 
             for (int i = 0; i < MI; ++i) {
                 if constexpr (AK == KC) af[i] = kra.read(At, wm * WM + i * 16, kh);
                 else af[i] = ira.read(At, i, kh);
+            }
+            if (p.a_lrelu) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
+            }
+            if (p.b_lrelu) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag(bfr[j], p.b_slope);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)

@@ -41,20 +41,20 @@ __global__ __launch_bounds__(256) void xva_gemm_splitk_reduce_kernel(xva_gemm_pa
 
 }  // namespace xva_glds
 
-// Can this problem take the direct-to-LDS path?  (bf16-stored operands, bf16 MFMA, segment / K-block lengths that keep a
-// 64-deep K tile inside one segment, 8-element granularity of every index-contiguous dimension.)
+// Can this problem take the direct-to-LDS path?  (bf16-stored operands, bf16 MFMA, tap-segment lengths that divide or are divided
+// by the 64-deep K tile, K-block lengths that are multiples of it, 8-element granularity of every index-contiguous dimension.)
 bool xva_gemm_glds_eligible(const xva_gemm_params& p) {
     if (p.compute != 1 || p.a_dtype != XVA_BF16 || p.b_dtype != XVA_BF16) return false;
-    if (p.a_lrelu || p.b_lrelu) return false;
     if (p.K % 8 != 0 || p.K < 8) return false;
     if (p.layout == XVA_GEMM_TN) {
         if (p.M % 8 != 0 || p.N % 8 != 0 || p.M < 8 || p.N < 8) return false;
         if (p.kb_len > 0 && p.kb_len % xva_glds::GK != 0) return false;
     } else {
-        if (p.a_seglen > 0 && p.a_segadj != 0 && p.a_seglen % xva_glds::GK != 0) return false;
+        auto seg_ok = [](int len) { return len <= 0 || len % xva_glds::GK == 0 || xva_glds::GK % len == 0; };   // a K tile maps onto whole segments
+        if (p.a_segadj != 0 && !seg_ok(p.a_seglen)) return false;
         if (p.layout == XVA_GEMM_NN) {
             if (p.N % 8 != 0 || p.N < 8) return false;
-            if (p.seglen > 0 && p.seglen % xva_glds::GK != 0) return false;
+            if (!seg_ok(p.seglen)) return false;
         }
     }
     return true;

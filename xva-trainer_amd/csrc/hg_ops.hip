@@ -22,6 +22,33 @@ __device__ __forceinline__ void hg_st(void* p, int64_t i, int dt, float v) {
     }
 }
 __device__ __forceinline__ float hg_lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+// 8 consecutive elements (16-byte aligned for bf16, 32-byte for fp32)
+__device__ __forceinline__ void hg_ld8(const void* p, int64_t i, int dt, float (&v)[8]) {
+    if (dt == XVA_BF16) {
+        const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p) + i);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    } else {
+        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+}
+__device__ __forceinline__ uint32_t hg_pack2(float a, float b) {
+    uint32_t x = __float_as_uint(a), y = __float_as_uint(b);
+    x += 0x7fffu + ((x >> 16) & 1u); y += 0x7fffu + ((y >> 16) & 1u);
+    return (x >> 16) | (y & 0xffff0000u);
+}
+__device__ __forceinline__ void hg_st8(void* p, int64_t i, int dt, const float (&v)[8]) {
+    if (dt == XVA_BF16) {
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p) + i) =
+            make_uint4(hg_pack2(v[0], v[1]), hg_pack2(v[2], v[3]), hg_pack2(v[4], v[5]), hg_pack2(v[6], v[7]));
+    } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // mel (B, C, T) fp32  ->  time-major sequence rows (B, Hp, C) at valid rows          (Generator input, models.py:110)
@@ -180,14 +207,17 @@ __global__ void hg_cout1_bwd_data_kernel(const void* __restrict__ d, const float
 #define COUT1_MAXK 8
 __global__ void hg_cout1_bwd_weight_kernel(const void* __restrict__ d, const void* __restrict__ x, float* __restrict__ dw,
                                            float* __restrict__ db, int dt, int64_t rows, int C, int k, int dil, int P, int act,
-                                           float slope, int rows_per_block) {
-    // dw[j*C + c] = sum_r x[r][c] * d[r - j*dil + P] : each thread owns channel c, reads x[r][c] ONCE and k shifted d values
+                                           float slope, int rows_per_block, int cpb) {
+    // dw[j*C + c] = sum_r x[r][c] * d[r - j*dil + P].  A workgroup covers cpb (power of two <= 256) channels x 256 / cpb row lanes:
+    // thread (c, rl) reads x[r][c] ONCE per row r = r0 + rl + i * (256 / cpb) and the k shifted d values from LDS; the row lanes
+    // are combined through LDS before one global atomic per (tap, channel).
     __shared__ float sd[1024 + 64];
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float sacc[COUT1_MAXK][256];
+    const int cl = threadIdx.x & (cpb - 1), rl = threadIdx.x / cpb, nrl = blockDim.x / cpb;
+    const int c = blockIdx.x * cpb + cl;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     const int span = (k - 1) * dil;
-    // stage d[r0 - span + P .. r1 - 1 + P] (rows referenced by this chunk)
     const int64_t dlo = r0 - span + P;
     const int nd = (int)(r1 - r0) + span;
     for (int i = threadIdx.x; i < nd; i += blockDim.x) {
@@ -198,9 +228,8 @@ __global__ void hg_cout1_bwd_weight_kernel(const void* __restrict__ d, const voi
     float acc[COUT1_MAXK];
 #pragma unroll
     for (int j = 0; j < COUT1_MAXK; ++j) acc[j] = 0.f;
-    float accb = 0.f;
     if (c < C) {
-        for (int64_t r = r0; r < r1; ++r) {
+        for (int64_t r = r0 + rl; r < r1; r += nrl) {
             float xv = hg_ld(x, r * C + c, dt);
             if (act) xv = hg_lrelu(xv, slope);
             const int base = (int)(r - r0) + span;   // index of d[r + P] in sd
@@ -208,12 +237,19 @@ __global__ void hg_cout1_bwd_weight_kernel(const void* __restrict__ d, const voi
             for (int j = 0; j < COUT1_MAXK; ++j)
                 if (j < k) acc[j] += xv * sd[base - j * dil];
         }
+    }
 #pragma unroll
-        for (int j = 0; j < COUT1_MAXK; ++j)
-            if (j < k && acc[j] != 0.f) atomicAdd(dw + j * C + c, acc[j]);
+    for (int j = 0; j < COUT1_MAXK; ++j) sacc[j][threadIdx.x] = acc[j];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < k * cpb; idx += blockDim.x) {
+        const int j = idx / cpb, cc = idx - j * cpb;
+        float v = 0.f;
+        for (int q = 0; q < nrl; ++q) v += sacc[j][q * cpb + cc];
+        if (blockIdx.x * cpb + cc < C && v != 0.f) atomicAdd(dw + j * C + blockIdx.x * cpb + cc, v);
     }
     if (blockIdx.x == 0) {   // db += sum_r d[r] ; d[r] = sd[(r - r0) + span - P]
         __shared__ float shb[16];
+        float accb = 0.f;
         for (int i = threadIdx.x; i < (int)(r1 - r0); i += blockDim.x) accb += sd[i + span - P];
         accb = xva_block_sum(accb, shb);
         if (threadIdx.x == 0 && accb != 0.f) atomicAdd(db, accb);
@@ -232,8 +268,10 @@ extern "C" int xva_hg_cout1_bwd_weight(const void* d, const void* x, float* dw, 
     XVA_CHECK_ARG(d && x && dw && db, "cout1_bwd_weight: null");
     XVA_CHECK_ARG(k <= COUT1_MAXK && (k - 1) * dil <= 64, "cout1_bwd_weight: kernel size unsupported");
     const int rpb = 1024;
-    hipLaunchKernelGGL(hg_cout1_bwd_weight_kernel, dim3(xva_cdiv(C, 256), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, d, x, dw, db, dt,
-                       rows, C, k, dil, P, act, slope, rpb);
+    int cpb = 256;
+    while (cpb > 1 && cpb / 2 >= C) cpb /= 2;
+    hipLaunchKernelGGL(hg_cout1_bwd_weight_kernel, dim3(xva_cdiv(C, cpb), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, d, x, dw, db, dt,
+                       rows, C, k, dil, P, act, slope, rpb, cpb);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
@@ -273,62 +311,105 @@ extern "C" int xva_hg_avgpool_bwd(const float* dy, float* dx, int nb, int T, int
 // ---------------------------------------------------------------------------------------------------------------
 // Reductions over the valid region of sequence tensors (losses, models.py:263-294; xva_train.py:504).
 // mode 0: sum |a - b|   mode 1: sum (1 - a)^2   mode 2: sum a^2        (b unused for 1, 2)
-__global__ void hg_reduce_kernel(const void* __restrict__ a, const void* __restrict__ b, int dt, int nseq, int Hp, int padF, int T, int C,
-                                 int mode, float scale, float* __restrict__ out) {
+// The valid region of sequence s is ONE contiguous span of T * C elements starting at (s * Hp + padF) * C: blockIdx.y walks the
+// sequences, blockIdx.x the span in 8-element vectors (VEC) or single elements — no per-element index arithmetic.
+__device__ __forceinline__ float hg_red_term(float av, float bv, int mode) {
+    if (mode == 0) return fabsf(av - bv);
+    if (mode == 1) return (1.f - av) * (1.f - av);
+    return av * av;
+}
+template <bool VEC>
+__global__ void hg_reduce_kernel(const void* __restrict__ a, const void* __restrict__ b, int dt, int Hp, int padF, int T, int C, int mode,
+                                 float scale, float* __restrict__ out) {
     __shared__ float sh[16];
-    int64_t total = (int64_t)nseq * T * C;
+    const int64_t base = ((int64_t)blockIdx.y * Hp + padF) * C;
+    const int64_t L = (int64_t)T * C;
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % C);
-        int t = (int)((i / C) % T);
-        int64_t s = i / ((int64_t)C * T);
-        int64_t idx = (s * Hp + padF + t) * C + c;
-        float av = hg_ld(a, idx, dt);
-        if (mode == 0) acc += fabsf(av - hg_ld(b, idx, dt));
-        else if (mode == 1) acc += (1.f - av) * (1.f - av);
-        else acc += av * av;
+    if (VEC) {
+        for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < L; i += (int64_t)gridDim.x * blockDim.x * 8) {
+            float av[8], bv[8];
+            hg_ld8(a, base + i, dt, av);
+            if (mode == 0) hg_ld8(b, base + i, dt, bv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += hg_red_term(av[e], mode == 0 ? bv[e] : 0.f, mode);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x)
+            acc += hg_red_term(hg_ld(a, base + i, dt), mode == 0 ? hg_ld(b, base + i, dt) : 0.f, mode);
     }
     acc = xva_block_sum(acc, sh);
-    if (threadIdx.x == 0) atomicAdd(out, acc * scale);
+    if (threadIdx.x == 0 && acc != 0.f) atomicAdd(out, acc * scale);
+}
+static inline bool hg_vec8_ok(const void* p, int dt, int C, int T, int Hp, int padF) {
+    const int es = dt == XVA_BF16 ? 2 : 4;
+    return p == nullptr || (((uintptr_t)p % (8 * es)) == 0 && ((int64_t)T * C) % 8 == 0 && ((int64_t)Hp * C) % 8 == 0 && ((int64_t)padF * C) % 8 == 0);
 }
 extern "C" int xva_hg_reduce(const void* a, const void* b, int dt, int nseq, int Hp, int padF, int T, int C, int mode, float scale, float* out, void* stream) {
     XVA_CHECK_ARG(a && out && (mode != 0 || b), "hg_reduce: null");
-    int64_t total = (int64_t)nseq * T * C;
-    int grid = (int)((total + 255) / 256); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(hg_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, dt, nseq, Hp, padF, T, C, mode, scale, out);
+    XVA_CHECK_ARG(nseq <= 65535, "hg_reduce: too many sequences");
+    if (nseq <= 0 || T <= 0) return XVA_OK;
+    const int64_t L = (int64_t)T * C;
+    const bool vec = hg_vec8_ok(a, dt, C, T, Hp, padF) && hg_vec8_ok(b, dt, C, T, Hp, padF);
+    int gx = (int)((L / (vec ? 8 : 1) + 255) / 256);
+    const int cap = 2048 / nseq > 1 ? 2048 / nseq : 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    if (vec) hipLaunchKernelGGL((hg_reduce_kernel<true>), dim3(gx, nseq), dim3(256), 0, (hipStream_t)stream, a, b, dt, Hp, padF, T, C, mode, scale, out);
+    else hipLaunchKernelGGL((hg_reduce_kernel<false>), dim3(gx, nseq), dim3(256), 0, (hipStream_t)stream, a, b, dt, Hp, padF, T, C, mode, scale, out);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
 // Gradient seeds / additions on the valid region of the FAKE half of a discriminator tensor:
 //   dY (+)= c_fm * sign(g - r) [* lrelu'(g) if gated] + (mode 1: c_gan * 2 (g - 1) ; mode 2: c_gan * 2 g ; mode 3 (real): c_gan * 2 (r - 1))
 // r, g: real / fake tensors (same geometry); dY: gradient tensor of the same geometry.  init: 0 -> accumulate, 1 -> overwrite.
-__global__ void hg_seed_grad_kernel(const void* __restrict__ r, const void* __restrict__ g, void* __restrict__ dY, int dt, int nseq, int Hp,
-                                    int padF, int T, int C, float c_fm, float c_gan, int gan_mode, int gated, float slope, int init) {
-    int64_t total = (int64_t)nseq * T * C;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % C);
-        int t = (int)((i / C) % T);
-        int64_t s = i / ((int64_t)C * T);
-        int64_t idx = (s * Hp + padF + t) * C + c;
-        float gv = g ? hg_ld(g, idx, dt) : 0.f;
-        float rv = r ? hg_ld(r, idx, dt) : 0.f;
-        float v = 0.f;
-        if (c_fm != 0.f) { float df = gv - rv; v += c_fm * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)); }
-        if (gan_mode == 1) v += c_gan * 2.f * (gv - 1.f);
-        else if (gan_mode == 2) v += c_gan * 2.f * gv;
-        else if (gan_mode == 3) v += c_gan * 2.f * (rv - 1.f);
-        if (!init) v += hg_ld(dY, idx, dt);
-        if (gated) { float ref = (gan_mode == 3) ? rv : gv; if (!(ref > 0.f)) v *= slope; }
-        hg_st(dY, idx, dt, v);
+__device__ __forceinline__ float hg_seed_term(float rv, float gv, float old, float c_fm, float c_gan, int gan_mode, int gated, float slope, int init) {
+    float v = 0.f;
+    if (c_fm != 0.f) { float df = gv - rv; v += c_fm * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)); }
+    if (gan_mode == 1) v += c_gan * 2.f * (gv - 1.f);
+    else if (gan_mode == 2) v += c_gan * 2.f * gv;
+    else if (gan_mode == 3) v += c_gan * 2.f * (rv - 1.f);
+    if (!init) v += old;
+    if (gated) { float ref = (gan_mode == 3) ? rv : gv; if (!(ref > 0.f)) v *= slope; }
+    return v;
+}
+template <bool VEC>
+__global__ void hg_seed_grad_kernel(const void* __restrict__ r, const void* __restrict__ g, void* __restrict__ dY, int dt, int Hp, int padF,
+                                    int T, int C, float c_fm, float c_gan, int gan_mode, int gated, float slope, int init) {
+    const int64_t base = ((int64_t)blockIdx.y * Hp + padF) * C;
+    const int64_t L = (int64_t)T * C;
+    if (VEC) {
+        for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < L; i += (int64_t)gridDim.x * blockDim.x * 8) {
+            float gv[8], rv[8], ov[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gv[e] = 0.f; rv[e] = 0.f; ov[e] = 0.f; }
+            if (g) hg_ld8(g, base + i, dt, gv);
+            if (r) hg_ld8(r, base + i, dt, rv);
+            if (!init) hg_ld8(dY, base + i, dt, ov);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = hg_seed_term(rv[e], gv[e], ov[e], c_fm, c_gan, gan_mode, gated, slope, init);
+            hg_st8(dY, base + i, dt, ov);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t idx = base + i;
+            const float gv = g ? hg_ld(g, idx, dt) : 0.f, rv = r ? hg_ld(r, idx, dt) : 0.f;
+            hg_st(dY, idx, dt, hg_seed_term(rv, gv, init ? 0.f : hg_ld(dY, idx, dt), c_fm, c_gan, gan_mode, gated, slope, init));
+        }
     }
 }
 extern "C" int xva_hg_seed_grad(const void* r, const void* g, void* dY, int dt, int nseq, int Hp, int padF, int T, int C, float c_fm,
                                 float c_gan, int gan_mode, int gated, float slope, int init, void* stream) {
     XVA_CHECK_ARG(dY, "hg_seed_grad: null");
-    int64_t total = (int64_t)nseq * T * C;
-    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(hg_seed_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, r, g, dY, dt, nseq, Hp, padF, T, C, c_fm, c_gan,
-                       gan_mode, gated, slope, init);
+    XVA_CHECK_ARG(nseq <= 65535, "hg_seed_grad: too many sequences");
+    if (nseq <= 0 || T <= 0) return XVA_OK;
+    const int64_t L = (int64_t)T * C;
+    const bool vec = hg_vec8_ok(r, dt, C, T, Hp, padF) && hg_vec8_ok(g, dt, C, T, Hp, padF) && hg_vec8_ok(dY, dt, C, T, Hp, padF);
+    int gx = (int)((L / (vec ? 8 : 1) + 255) / 256);
+    const int cap = 8192 / nseq > 1 ? 8192 / nseq : 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    if (vec) hipLaunchKernelGGL((hg_seed_grad_kernel<true>), dim3(gx, nseq), dim3(256), 0, (hipStream_t)stream, r, g, dY, dt, Hp, padF, T, C, c_fm, c_gan, gan_mode, gated, slope, init);
+    else hipLaunchKernelGGL((hg_seed_grad_kernel<false>), dim3(gx, nseq), dim3(256), 0, (hipStream_t)stream, r, g, dY, dt, Hp, padF, T, C, c_fm, c_gan, gan_mode, gated, slope, init);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
@@ -375,8 +456,48 @@ __global__ void hg_colsum_kernel(const void* __restrict__ X, int dt, float* __re
     __syncthreads();
     if (rl == 0 && c < C) atomicAdd(out + c, scale * (sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]));
 }
+// column pairs: a wave reads 128 adjacent columns (4-byte / 8-byte accesses), two rows in flight
+__global__ void hg_colsum2_kernel(const void* __restrict__ X, int dt, float* __restrict__ out, int64_t rows, int C, int rows_per_block, float scale) {
+    __shared__ float sh[4][128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 128 + 2 * lane;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        if (dt == XVA_BF16) {
+            const uint16_t* xp = reinterpret_cast<const uint16_t*>(X);
+            int64_t r = r0 + w;
+            for (; r + 4 < r1; r += 8) {
+                const uint32_t u = *reinterpret_cast<const uint32_t*>(xp + r * C + c), v = *reinterpret_cast<const uint32_t*>(xp + (r + 4) * C + c);
+                a0 += __uint_as_float(u << 16) + __uint_as_float(v << 16);
+                a1 += __uint_as_float(u & 0xffff0000u) + __uint_as_float(v & 0xffff0000u);
+            }
+            for (; r < r1; r += 4) { const uint32_t u = *reinterpret_cast<const uint32_t*>(xp + r * C + c); a0 += __uint_as_float(u << 16); a1 += __uint_as_float(u & 0xffff0000u); }
+        } else {
+            const float* xp = reinterpret_cast<const float*>(X);
+            for (int64_t r = r0 + w; r < r1; r += 4) { const float2 f = *reinterpret_cast<const float2*>(xp + r * C + c); a0 += f.x; a1 += f.y; }
+        }
+    }
+    sh[w][2 * lane] = a0; sh[w][2 * lane + 1] = a1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int cc = blockIdx.x * 128 + threadIdx.x;
+        if (cc < C) atomicAdd(out + cc, scale * (sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]));
+    }
+}
 extern "C" int xva_hg_colsum(const void* X, int dt, float* out, int64_t rows, int C, float scale, void* stream) {
     XVA_CHECK_ARG(X && out, "hg_colsum: null");
+    if (rows <= 0) return XVA_OK;
+    if (C % 2 == 0 && ((uintptr_t)X % 8) == 0) {
+        // enough row blocks to fill the chip even for narrow tensors, few enough to keep the atomics per column low
+        const int cb = xva_cdiv(C, 128);
+        int rpb2 = (int)xva_cdiv(rows, xva_cdiv(1024, cb));
+        if (rpb2 < 64) rpb2 = 64;
+        hipLaunchKernelGGL(hg_colsum2_kernel, dim3(cb, (unsigned)xva_cdiv(rows, rpb2)), dim3(256), 0, (hipStream_t)stream, X, dt, out, rows, C, rpb2, scale);
+        XVA_LAUNCH_CHECK();
+        return XVA_OK;
+    }
     const int rpb = 512;
     hipLaunchKernelGGL(hg_colsum_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, X, dt, out, rows, C, rpb, scale);
     XVA_LAUNCH_CHECK();
