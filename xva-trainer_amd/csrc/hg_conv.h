@@ -42,20 +42,17 @@ struct ConvEpi {
     int accumulate = 0;
 };
 
+// split-K slab scratch of the weight-gradient GEMMs: set by the engine entry points from their workspace plan
+struct HgSplitKScratch { void* ptr = nullptr; int64_t bytes = 0; };
+inline HgSplitKScratch& hg_skws() { static thread_local HgSplitKScratch s; return s; }
+
 inline xva_gemm_params hg_gp(int compute, int dt) {
     xva_gemm_params g;
     memset(&g, 0, sizeof(g));
     g.batch = 1; g.batch2 = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.compute = compute; g.mask_mul = 1;
     g.a_dtype = g.b_dtype = g.c_dtype = dt;
+    g.sk_ws = hg_skws().ptr; g.sk_ws_bytes = hg_skws().bytes;
     return g;
-}
-inline int hg_splitk(int M, int N, int64_t K, int batches) {
-    long tiles = (long)xva_cdiv(M, 128) * xva_cdiv(N, N <= 32 ? 32 : (N <= 64 ? 64 : 128)) * batches;
-    int sk = (int)((768 + tiles - 1) / tiles);
-    int nkt = xva_cdiv(K, 32);
-    int maxsk = nkt / 8; if (maxsk < 1) maxsk = 1;
-    if (sk > maxsk) sk = maxsk;
-    return sk < 1 ? 1 : sk;
 }
 inline int hg_conv_out_len(int T, const ConvW& w) { return (T + 2 * w.P - w.d * (w.k - 1) - 1) / w.s + 1; }
 
@@ -180,12 +177,12 @@ inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x
     }
     if (merged) {
         g.K = (int)dY.rows();
-        g.accumulate = 1; g.splitk = hg_splitk(g.M, g.N, g.K, w.groups);
+        g.accumulate = 1; g.splitk = 0;   // xva_gemm sizes the split to its tile grid and the slab scratch
     } else {
         // per-item geometry: the reduction still runs over ALL items in one split-K GEMM (K blocks of T_out rows)
         g.K = (int)((int64_t)X.nseq * dY.T); g.kb_len = dY.T;
         if (!swap) { g.kb_sA = dY.item(); g.kb_sB = X.item(); } else { g.kb_sA = X.item(); g.kb_sB = dY.item(); }
-        g.accumulate = 1; g.splitk = hg_splitk(g.M, g.N, g.K, w.groups);
+        g.accumulate = 1; g.splitk = 0;   // xva_gemm sizes the split to its tile grid and the slab scratch
     }
     return xva_gemm(&g, st);
 }
@@ -245,6 +242,6 @@ inline int hg_convT_bwd_weight(const Seq& dY, const Seq& X, const ConvTW& w, int
     g.C = w.dweff; g.c_dtype = XVA_F32;
     g.a_lrelu = x_lrelu; g.a_slope = x_slope;
     g.K = (int)((int64_t)X.nseq * X.T); g.kb_len = X.T; g.kb_sA = X.item(); g.kb_sB = dY.item();
-    g.accumulate = 1; g.splitk = hg_splitk(g.M, g.N, g.K, 1);
+    g.accumulate = 1; g.splitk = 0;
     return xva_gemm(&g, st);
 }

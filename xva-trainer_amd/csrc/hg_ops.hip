@@ -267,9 +267,11 @@ extern "C" int xva_hg_cout1_bwd_weight(const void* d, const void* x, float* dw, 
                                        int act, float slope, void* stream) {
     XVA_CHECK_ARG(d && x && dw && db, "cout1_bwd_weight: null");
     XVA_CHECK_ARG(k <= COUT1_MAXK && (k - 1) * dil <= 64, "cout1_bwd_weight: kernel size unsupported");
-    const int rpb = 1024;
     int cpb = 256;
     while (cpb > 1 && cpb / 2 >= C) cpb /= 2;
+    // ~1024 workgroups whatever the tensor shape (rows may be a few thousand with C = 1024, or half a million with C = 32)
+    int64_t rpb64 = xva_cdiv(rows, xva_cdiv(1024, xva_cdiv(C, cpb)));
+    int rpb = rpb64 < 32 ? 32 : (rpb64 > 1024 ? 1024 : (int)rpb64);
     hipLaunchKernelGGL(hg_cout1_bwd_weight_kernel, dim3(xva_cdiv(C, cpb), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, d, x, dw, db, dt,
                        rows, C, k, dil, P, act, slope, rpb, cpb);
     XVA_LAUNCH_CHECK();
@@ -351,7 +353,7 @@ extern "C" int xva_hg_reduce(const void* a, const void* b, int dt, int nseq, int
     const int64_t L = (int64_t)T * C;
     const bool vec = hg_vec8_ok(a, dt, C, T, Hp, padF) && hg_vec8_ok(b, dt, C, T, Hp, padF);
     int gx = (int)((L / (vec ? 8 : 1) + 255) / 256);
-    const int cap = 2048 / nseq > 1 ? 2048 / nseq : 1;
+    const int cap = 512 / nseq > 1 ? 512 / nseq : 1;    // every workgroup ends in ONE atomic on the same address: keep them few
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     if (vec) hipLaunchKernelGGL((hg_reduce_kernel<true>), dim3(gx, nseq), dim3(256), 0, (hipStream_t)stream, a, b, dt, Hp, padF, T, C, mode, scale, out);
@@ -492,7 +494,7 @@ extern "C" int xva_hg_colsum(const void* X, int dt, float* out, int64_t rows, in
     if (C % 2 == 0 && ((uintptr_t)X % 8) == 0) {
         // enough row blocks to fill the chip even for narrow tensors, few enough to keep the atomics per column low
         const int cb = xva_cdiv(C, 128);
-        int rpb2 = (int)xva_cdiv(rows, xva_cdiv(1024, cb));
+        int rpb2 = (int)xva_cdiv(rows, xva_cdiv(256, cb) > 16 ? xva_cdiv(256, cb) : 16);
         if (rpb2 < 64) rpb2 = 64;
         hipLaunchKernelGGL(hg_colsum2_kernel, dim3(cb, (unsigned)xva_cdiv(rows, rpb2)), dim3(256), 0, (hipStream_t)stream, X, dt, out, rows, C, rpb2, scale);
         XVA_LAUNCH_CHECK();

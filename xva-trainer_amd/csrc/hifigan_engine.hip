@@ -186,7 +186,7 @@ struct Plan {
     int64_t wav_s[3][2];                // pooled waveforms (fp32): [scale][real/fake] ; scale 0 = the inputs themselves
     int64_t dwav_s[3];                  // gradient w.r.t. the (pooled) fake waveforms
     int Tw[3];
-    int64_t sn_tmp, losses, total;
+    int64_t sn_tmp, losses, skws, skws_bytes, total;
 };
 
 SeqSpec mk(Bump& b, int es, int nseq, int T, int C, int padF, int padB) {
@@ -286,6 +286,8 @@ int make_plan(const xva_hg_dims* d, Plan* p) {
     }
     p->sn_tmp = b.take((1024 * 41 * 64 + 1024 + 64) * 4);
     p->losses = b.take(64 * 4);
+    p->skws_bytes = (int64_t)96 << 20;      // split-K slabs of the weight-gradient GEMMs (largest: 3 x 1024 x 5120 fp32)
+    p->skws = b.take(p->skws_bytes);
     p->total = b.cur;
     return XVA_OK;
 }
@@ -303,6 +305,7 @@ int make_ctx(Ctx& c, const xva_hg_dims* d, void* ws, int64_t ws_bytes, void* st)
     XVA_CHECK_ARG(ws && ((uintptr_t)ws % 256) == 0, "hifigan: workspace null or not 256-byte aligned");
     XVA_CHECK_ARG(ws_bytes >= c.pl.total, "hifigan: workspace too small (%ld < %ld bytes)", (long)ws_bytes, (long)c.pl.total);
     c.W = (char*)ws; c.st = st; c.dt = d->dt; c.compute = d->dt == XVA_BF16 ? 1 : 0;
+    hg_skws().ptr = c.W + c.pl.skws; hg_skws().bytes = c.pl.skws_bytes;
     return XVA_OK;
 }
 
