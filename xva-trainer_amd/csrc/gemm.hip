@@ -83,6 +83,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
             const long tiles = ntiles(glds_tile);
             long sk = glds_tile == 1 ? 256 / tiles : (864 + tiles / 2) / tiles;
             if (sk > nkt / 8) sk = nkt / 8;
+            if (sk > 128) sk = 128;          // the reduce pass reads every slab: beyond this it costs more than the idle CUs
             if (p.sk_ws && p.N % 4 == 0) {   // stay inside the caller's slab scratch (atomics are much slower)
                 const long fit = (long)(p.sk_ws_bytes / ((int64_t)p.M * p.N * 4 * nb));
                 if (fit >= 2 && sk > fit) sk = fit;

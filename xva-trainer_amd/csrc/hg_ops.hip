@@ -459,7 +459,8 @@ __global__ void hg_colsum_kernel(const void* __restrict__ X, int dt, float* __re
     if (rl == 0 && c < C) atomicAdd(out + c, scale * (sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]));
 }
 // column pairs: a wave reads 128 adjacent columns (4-byte / 8-byte accesses), two rows in flight
-__global__ void hg_colsum2_kernel(const void* __restrict__ X, int dt, float* __restrict__ out, int64_t rows, int C, int rows_per_block, float scale) {
+// Narrow tensors are FOLDED by the host: f consecutive rows of Creal channels are read as one row of C = f * Creal columns.
+__global__ void hg_colsum2_kernel(const void* __restrict__ X, int dt, float* __restrict__ out, int64_t rows, int C, int rows_per_block, float scale, int Creal) {
     __shared__ float sh[4][128];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 128 + 2 * lane;
@@ -485,18 +486,20 @@ __global__ void hg_colsum2_kernel(const void* __restrict__ X, int dt, float* __r
     __syncthreads();
     if (threadIdx.x < 128) {
         const int cc = blockIdx.x * 128 + threadIdx.x;
-        if (cc < C) atomicAdd(out + cc, scale * (sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]));
+        if (cc < C) atomicAdd(out + (cc % Creal), scale * (sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]));
     }
 }
 extern "C" int xva_hg_colsum(const void* X, int dt, float* out, int64_t rows, int C, float scale, void* stream) {
     XVA_CHECK_ARG(X && out, "hg_colsum: null");
     if (rows <= 0) return XVA_OK;
     if (C % 2 == 0 && ((uintptr_t)X % 8) == 0) {
+        const int Creal = C;
+        while (C * 2 <= 128 && rows % 2 == 0) { C *= 2; rows /= 2; }   // fold rows of narrow tensors so every lane of a wave has a column pair
         // enough row blocks to fill the chip even for narrow tensors, few enough to keep the atomics per column low
         const int cb = xva_cdiv(C, 128);
         int rpb2 = (int)xva_cdiv(rows, xva_cdiv(256, cb) > 16 ? xva_cdiv(256, cb) : 16);
         if (rpb2 < 64) rpb2 = 64;
-        hipLaunchKernelGGL(hg_colsum2_kernel, dim3(cb, (unsigned)xva_cdiv(rows, rpb2)), dim3(256), 0, (hipStream_t)stream, X, dt, out, rows, C, rpb2, scale);
+        hipLaunchKernelGGL(hg_colsum2_kernel, dim3(cb, (unsigned)xva_cdiv(rows, rpb2)), dim3(256), 0, (hipStream_t)stream, X, dt, out, rows, C, rpb2, scale, Creal);
         XVA_LAUNCH_CHECK();
         return XVA_OK;
     }
