@@ -77,6 +77,55 @@ def hifigan_cpu_baseline():
             "sample": "B=2 x 8192-sample segments, full D+G iteration (G fwd, MPD+MSD x2, losses, bwd, 2 x AdamW), fp32 torch-CPU, %d timed steps" % n}
 
 
+TILE_NAMES = {"128128": "128x128", "256256": "256x256", "64128": "128x64", "64064": "64x64"}
+
+
+def gemm_roofline(run, nprof, bound, peak, note):
+    """Live per-launch timing of the GEMM kernels (HIP event pair around every xva_gemm launch, on the launch stream, recorded by the
+    library itself: xva_prof_* in csrc/core.hip).  The DOMINANT kernel = the (main loop, tile) family with the largest total time;
+    `achieved` = its algorithmic FLOPs (2MNK) or bytes (every distinct operand / result element once) / its summed launch time."""
+    import collections
+    import csv
+    import tempfile
+    from xva_trainer_amd import _lib
+    lib = _lib.lib
+    lib.xva_prof_enable(1)
+    for _ in range(nprof):
+        run()
+    torch.cuda.synchronize()
+    lib.xva_prof_enable(0)
+    path = os.path.join(tempfile.gettempdir(), "xva_gemm_launches_%d.csv" % os.getpid())
+    lib.xva_prof_dump(path.encode())
+    rows = list(csv.DictReader(open(path)))
+    os.remove(path)
+    fam = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+    lay = ["NT", "NN", "TN"]
+    for r in rows:
+        glds = int(r["bn"]) > 1000
+        key = ("xva_gemm_glds_kernel<%s>" % TILE_NAMES.get(r["bn"], r["bn"])) if glds else ("xva_gemm_kernel<BN=%s>" % r["bn"])
+        f = fam[key]
+        f[0] += 1; f[1] += float(r["ms"]); f[2] += float(r["gflop"]); f[3] += float(r["mbytes"])
+    tot_ms = sum(f[1] for f in fam.values())
+    name, f = max(fam.items(), key=lambda kv: kv[1][1])
+    if bound == "mfma":
+        ach, unit = f[2] / f[1], "TFLOP/s"                   # GFLOP / ms = TFLOP/s
+    else:
+        ach, unit = f[3] / f[1], "GB/s"                       # MB / ms = GB/s
+    res = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+           "kernel": name + " (direct-to-LDS MFMA implicit-convolution GEMM, all layouts)" if "glds" in name else name,
+           "launches_per_step": f[0] / nprof, "avg_launch_us": 1e3 * f[1] / f[0], "kernel_ms_per_step": f[1] / nprof,
+           "share_of_gemm_time": f[1] / tot_ms if tot_ms else None,
+           "algorithmic_gflop_per_launch": f[2] / f[0], "algorithmic_mbytes_per_launch": f[3] / f[0],
+           "all_gemm": {"launches_per_step": len(rows) / nprof, "ms_per_step": tot_ms / nprof,
+                        "tflops": sum(x[2] for x in fam.values()) / tot_ms if tot_ms else None,
+                        "algorithmic_gbytes_per_s": sum(x[3] for x in fam.values()) / tot_ms if tot_ms else None,
+                        "by_kernel": {k: {"launches_per_step": v[0] / nprof, "ms_per_step": v[1] / nprof, "tflops": v[2] / v[1],
+                                          "algorithmic_gbytes_per_s": v[3] / v[1]} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}},
+           "method": "hipEvent pair around every xva_gemm launch on the launch stream (csrc/core.hip xva_prof_*); " + note +
+                     "; PMC HBM traffic not collected in-process (see profiles/)"}
+    return res
+
+
 def hifigan_leg(a, dev, rank, world):
     """audio-samples/s of the full HiFi-GAN v1 D+G iteration (BASELINE.json configs[2]: batch 64, 8192-sample segments)."""
     import numpy as np
@@ -134,6 +183,9 @@ def hifigan_leg(a, dev, rank, world):
            "ms_per_step": 1000.0 * dt / steps, "steps": steps, "dtype": a.compute,
            "config": {"workload": "HiFi-GAN v1 generator + MPD + MSD, batch %d/GPU x %d samples, D step + G step + 2 x fused AdamW" % (B, seg)},
            "loss_mel": float(out["loss_mel"].item()), "loss_disc_all": float(out["loss_disc_all"].item())}
+    if rank == 0 and not a.no_roofline:
+        # the conv stack is priced against the HBM roofline (north_star): algorithmic bytes of every conv-as-GEMM launch / its time
+        res["roofline"] = gemm_roofline(lambda: st.train_step(x, y, y_mel), 1, "hbm", 8000.0, "one extra profiled D+G iteration")
     del st
     torch.cuda.empty_cache()
     return res
@@ -222,33 +274,12 @@ def main():
                    "final_loss": loss},
     }
     if rank == 0 and not a.no_roofline:
-        lib = _lib.lib
-        lib.xva_prof_collect.argtypes = [C.POINTER(C.c_double), C.c_int]
-        lib.xva_prof_enable(1)
-        nprof = 3
-        for _ in range(nprof):
+        def run_profiled():
             grads.zero_()
             eng.fwd_loss_bwd(flat, grads, batch, stage)
-        torch.cuda.synchronize()
-        lib.xva_prof_enable(0)
-        buf = (C.c_double * 32)()
-        lib.xva_prof_collect(buf, 32)
-        launches, ms, flops = buf[0], buf[1], buf[2]
         peak = 2500.0 if a.compute == "bf16" else 157.3
-        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        names = ["NT", "NN", "TN"]
-        modes = ["fp32", "bf16", "mixed(fp32->bf16)"]
-        per = {}
-        for v in range(9):
-            n_, ms_, fl_ = buf[3 + 3 * v], buf[4 + 3 * v], buf[5 + 3 * v]
-            if n_ > 0:
-                per["%s_%s" % (names[v // 3], modes[v % 3])] = {"launches_per_step": n_ / nprof, "avg_us": 1e3 * ms_ / n_,
-                                                                                "tflops": fl_ / (ms_ * 1e-3) / 1e12}
-        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                           "kernel": "xva_gemm_kernel<layout, %s> (all GEMM launches of one fwd+bwd)" % a.compute,
-                           "launches_per_step": launches / nprof, "avg_launch_us": 1e3 * ms / launches if launches else None,
-                           "gemm_ms_per_step": ms / nprof, "algorithmic_gflop_per_step": flops / nprof / 1e9, "by_variant": per,
-                           "method": "hipEvent pair around every xva_gemm launch on the launch stream, %d extra profiled fwd+bwd passes after the timed region" % nprof}
+        out["roofline"] = gemm_roofline(run_profiled, 3, "mfma", peak,
+                                        "FastPitch fwd+bwd: %d extra profiled passes after the timed region" % 3)
     if not a.no_hifigan:
         del opt, grads
         eng._ws = None

@@ -21,18 +21,18 @@ extern "C" const char* xva_target_arch(void) { return "gfx950"; }
 // the timed throughput region never runs with it on.
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int variant; int M, N, K, batch, splitk, bn; };
+struct ProfRec { hipEvent_t a, b; double flops, bytes; int variant; int M, N, K, batch, splitk, bn; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }
 extern "C" void xva_prof_enable(int on) { g_prof_on = on != 0; }
 bool xva_prof_is_on() { return g_prof_on; }
-void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn) {
+void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn, double bytes) {
     if (g_prof.empty()) return;
-    ProfRec& r = g_prof.back(); r.M = M; r.N = N; r.K = K; r.batch = batch; r.splitk = splitk; r.bn = bn;
+    ProfRec& r = g_prof.back(); r.M = M; r.N = N; r.K = K; r.batch = batch; r.splitk = splitk; r.bn = bn; r.bytes = bytes;
 }
 void xva_prof_begin(hipStream_t st, double flops, int variant) {
-    ProfRec r; r.flops = flops; r.variant = variant; r.M = r.N = r.K = r.batch = r.splitk = r.bn = 0;
+    ProfRec r; r.flops = flops; r.bytes = 0.0; r.variant = variant; r.M = r.N = r.K = r.batch = r.splitk = r.bn = 0;
     hipEventCreate(&r.a); hipEventCreate(&r.b);
     hipEventRecord(r.a, st);
     g_prof.push_back(r);
@@ -71,16 +71,17 @@ extern "C" int xva_stream_wait_event(void* stream, void* e) {
     return XVA_OK;
 }
 
-// Dump one CSV line per recorded GEMM launch (variant = layout*3 + mode) and clear the records.
+// Dump one CSV line per recorded GEMM launch (variant = layout*3 + mode; bn = tile tag: BN * 1000 + BM for the direct-to-LDS
+// kernel, BN for the general one; mbytes = ALGORITHMIC bytes: every distinct operand / result element once) and clear the records.
 extern "C" int xva_prof_dump(const char* path) {
     FILE* f = fopen(path, "w");
     if (!f) return XVA_ERR_ARG;
-    fprintf(f, "variant,M,N,K,batch,splitk,bn,ms,gflop\n");
+    fprintf(f, "variant,M,N,K,batch,splitk,bn,ms,gflop,mbytes\n");
     for (auto& r : g_prof) {
         hipEventSynchronize(r.b);
         float ms = 0.f;
         hipEventElapsedTime(&ms, r.a, r.b);
-        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.5f,%.4f\n", r.variant, r.M, r.N, r.K, r.batch, r.splitk, r.bn, ms, r.flops * 1e-9);
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.5f,%.4f,%.4f\n", r.variant, r.M, r.N, r.K, r.batch, r.splitk, r.bn, ms, r.flops * 1e-9, r.bytes * 1e-6);
         hipEventDestroy(r.a); hipEventDestroy(r.b);
     }
     fclose(f);

@@ -12,7 +12,7 @@ void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn);
 bool xva_prof_is_on();
 void xva_prof_begin(hipStream_t st, double flops, int variant);
 void xva_prof_end(hipStream_t st);
-void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn);
+void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn, double bytes);
 
 // Main-loop selection: -1 automatic (default; env XVA_GEMM_GLDS overrides), 0 general kernel only, 1..4 force the direct-to-LDS tile
 // 128x128 / 256x256 / 128x64 / 64x64 wherever eligible.  A diagnostics / test knob, not part of the numerical contract.
@@ -102,7 +102,17 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int mode = p.compute == 0 ? 0 : (p.a_dtype == XVA_BF16 ? 1 : 2);
     const bool prof = xva_prof_is_on();
-    if (prof) { xva_prof_begin(st, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + mode); xva_prof_shape(p.M, p.N, p.K, p.batch * p.batch2, p.splitk, bn); }
+    if (prof) { xva_prof_begin(st, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + mode); 
+        // algorithmic bytes: each distinct element of A, B once (tap segments re-address the SAME rows/columns), C written (read too when
+        // accumulating), residual and gate read
+        const double es_ab = p.a_dtype == XVA_BF16 ? 2.0 : 4.0, es_c = p.c_dtype == XVA_BF16 ? 2.0 : 4.0, nbz = (double)p.batch * p.batch2;
+        double ua, ub;
+        if (p.layout == XVA_GEMM_TN) { ua = (double)p.K * (p.a_seglen > 0 ? p.a_seglen : p.M); ub = (double)p.K * (p.seglen > 0 ? p.seglen : p.N); }
+        else { ua = (double)p.M * (p.a_seglen > 0 ? p.a_seglen : p.K); ub = (double)p.N * p.K; }
+        double by = (ua + ub) * es_ab + (double)p.M * p.N * es_c * (p.accumulate ? 2.0 : 1.0);
+        if (p.R) by += (double)p.M * p.N * (p.r_dtype == XVA_BF16 ? 2.0 : 4.0);
+        if (p.G) by += (double)p.M * p.N * (p.g_dtype == XVA_BF16 ? 2.0 : 4.0);
+        xva_prof_shape(p.M, p.N, p.K, p.batch * p.batch2, p.splitk, bn, by * nbz); }
     if (glds_tile >= 0) { if (xva_gemm_launch_glds(p, glds_tile, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; } }
     else if (mode == 0) xva_gemm_launch_fp32(p, bn, (unsigned)nblocks, st);
     else if (mode == 1) xva_gemm_launch_bf16(p, bn, (unsigned)nblocks, st);
