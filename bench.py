@@ -102,7 +102,10 @@ def gemm_roofline(run, nprof, bound, peak, note):
     lay = ["NT", "NN", "TN"]
     for r in rows:
         glds = int(r["bn"]) > 1000
-        key = ("xva_gemm_glds_kernel<%s>" % TILE_NAMES.get(r["bn"], r["bn"])) if glds else ("xva_gemm_kernel<BN=%s>" % r["bn"])
+        if int(r["bn"]) >= 900000:
+            key = "xva_conv_res_kernel<CIN=%d>" % (int(r["bn"]) - 900000)
+        else:
+            key = ("xva_gemm_glds_kernel<%s>" % TILE_NAMES.get(r["bn"], r["bn"])) if glds else ("xva_gemm_kernel<BN=%s>" % r["bn"])
         f = fam[key]
         f[0] += 1; f[1] += float(r["ms"]); f[2] += float(r["gflop"]); f[3] += float(r["mbytes"])
     tot_ms = sum(f[1] for f in fam.values())
@@ -112,7 +115,8 @@ def gemm_roofline(run, nprof, bound, peak, note):
     else:
         ach, unit = f[3] / f[1], "GB/s"                       # MB / ms = GB/s
     res = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
-           "kernel": name + " (direct-to-LDS MFMA implicit-convolution GEMM, all layouts)" if "glds" in name else name,
+           "kernel": name + (" (direct-to-LDS MFMA implicit-convolution GEMM, all layouts)" if "glds" in name else
+                             (" (resident-input MFMA convolution, forward + backward-data)" if "conv_res" in name else "")),
            "launches_per_step": f[0] / nprof, "avg_launch_us": 1e3 * f[1] / f[0], "kernel_ms_per_step": f[1] / nprof,
            "share_of_gemm_time": f[1] / tot_ms if tot_ms else None,
            "algorithmic_gflop_per_launch": f[2] / f[0], "algorithmic_mbytes_per_launch": f[3] / f[0],

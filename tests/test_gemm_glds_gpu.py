@@ -14,7 +14,7 @@ def _lib():
     return _lib
 
 
-@pytest.fixture(params=[1, 2, 3, 4], ids=["tile128", "tile256", "tile128x64", "tile64"])
+@pytest.fixture(params=[1, 2, 3, 4, -1, 6], ids=["tile128", "tile256", "tile128x64", "tile64", "auto", "auto_no_resident_conv"])
 def mainloop(request):
     L = _lib()
     old = L.lib.xva_gemm_set_mainloop(request.param)
@@ -108,7 +108,7 @@ def test_tn_kblocks_and_column_segments(mainloop):
     assert _rel(dW, ref) < 3e-6
 
 
-@pytest.mark.parametrize("Cin,Cout,d", [(64, 136, 1), (128, 72, 3), (32, 32, 5), (16, 64, 2)])
+@pytest.mark.parametrize("Cin,Cout,d", [(64, 136, 1), (128, 72, 3), (32, 32, 5), (16, 64, 2), (64, 64, 5), (128, 128, 1), (32, 64, 3)])
 def test_conv_tap_segments_fwd_bwd_data(mainloop, Cin, Cout, d):
     """Dilated k=3 conv as implicit GEMM: A tap segments (NT forward) and B row segments (NN backward-data)."""
     L = _lib()
@@ -132,6 +132,49 @@ def test_conv_tap_segments_fwd_bwd_data(mainloop, Cin, Cout, d):
     xr = xs[PAD:PAD + T].double().t()[None].requires_grad_(True)
     F.conv1d(xr, W.double(), padding=d, dilation=d).backward(dys[PAD:PAD + T].double().t()[None])
     assert _rel(dx, xr.grad[0].t()) < 3e-6
+
+
+@pytest.mark.parametrize("C,k,d", [(32, 11, 5), (64, 7, 3), (128, 3, 1)])
+def test_resblock_conv_resident_input(mainloop, C, k, d):
+    """HiFi-GAN ResBlock1 convolution (models.py:62-66): y = conv_k,d(lrelu(x)) + bias + residual on 32/64/128 channels — the shape the
+    resident-input kernel serves (input rows loaded once, taps read shifted LDS rows), and its backward-data with the lrelu gate."""
+    L = _lib()
+    torch.manual_seed(C + k)
+    nseq, T, PAD = 3, 500, 32
+    Hp = T + 2 * PAD
+    P_ = d * (k - 1) // 2
+    xs = torch.zeros(nseq * Hp + 2 * PAD, C, device="cuda", dtype=torch.bfloat16)      # guard rows before / after
+    xv = xs[PAD:PAD + nseq * Hp].view(nseq, Hp, C)
+    xv[:, PAD:PAD + T] = torch.randn(nseq, T, C, device="cuda").bfloat16()
+    W = (torch.randn(C, C, k, device="cuda") * 0.05).bfloat16()
+    Wt = W.permute(0, 2, 1).contiguous().view(C, k * C)
+    bias = torch.randn(C, device="cuda")
+    R = torch.randn(nseq * Hp, C, device="cuda").bfloat16()
+    y = torch.zeros(nseq * Hp, C, device="cuda", dtype=torch.bfloat16)
+    rows = nseq * Hp
+    L.gemm(xs, Wt, y, rows, C, k * C, C, k * C, C, layout=L.GEMM_NT, compute=1, bias=bias, R=R, ldr=C, a_lrelu=0.1,
+           a_offset=(PAD - P_) * C, a_seglen=C, a_segadj=d * C - C, mask_mode=L.MASK_PAD, Tp=Hp, mask_pad=PAD, mask_len=T)
+    lr = lambda t: torch.where(t > 0, t, (t.float() * 0.1).bfloat16())
+    xin = lr(xv[:, PAD:PAD + T]).double().transpose(1, 2)
+    ref = torch.nn.functional.conv1d(xin, W.double(), bias.double(), padding=P_, dilation=d).transpose(1, 2) + R.view(nseq, Hp, C)[:, PAD:PAD + T].double()
+    out = y.view(nseq, Hp, C)
+    assert _rel(out[:, PAD:PAD + T], ref) < 6e-3
+    assert out[:, :PAD].abs().max().item() == 0.0 and out[:, PAD + T:].abs().max().item() == 0.0
+    # backward-data: dx = lrelu'(x) * conv^T(dy)
+    dys = torch.zeros_like(xs)
+    dys[PAD:PAD + rows].view(nseq, Hp, C)[:, PAD:PAD + T] = torch.randn(nseq, T, C, device="cuda").bfloat16()
+    dx = torch.zeros(rows, C, device="cuda")
+    L.gemm(dys, Wt, dx, rows, C, k * C, C, k * C, C, layout=L.GEMM_NN, compute=1, a_offset=(PAD - P_) * C, a_seglen=C, a_segadj=d * C - C,
+           seglen=C, seg0=(k - 1) * C, segstride=-C, G=xs[PAD:], ldg=C, gate_slope=0.1, mask_mode=L.MASK_PAD, Tp=Hp, mask_pad=PAD, mask_len=T)
+    xr = xv[:, PAD:PAD + T].double().transpose(1, 2).requires_grad_(True)
+    xa = torch.where(xr > 0, xr, xr * 0.1)
+    torch.nn.functional.conv1d(xa, W.double(), padding=P_, dilation=d).backward(dys[PAD:PAD + rows].view(nseq, Hp, C)[:, PAD:PAD + T].double().transpose(1, 2))
+    assert _rel(dx.view(nseq, Hp, C)[:, PAD:PAD + T], xr.grad.transpose(1, 2)) < 3e-6
+    # the engine's form of the same product: taps walk BACKWARDS over dY (a_segadj < -C), weights in natural tap order
+    dx2 = torch.zeros(rows, C, device="cuda")
+    L.gemm(dys, Wt, dx2, rows, C, k * C, C, k * C, C, layout=L.GEMM_NN, compute=1, a_offset=(PAD + P_) * C, a_seglen=C, a_segadj=-d * C - C,
+           seglen=C, seg0=0, segstride=C, G=xs[PAD:], ldg=C, gate_slope=0.1, mask_mode=L.MASK_PAD, Tp=Hp, mask_pad=PAD, mask_len=T)
+    assert _rel(dx2.view(nseq, Hp, C)[:, PAD:PAD + T], xr.grad.transpose(1, 2)) < 3e-6
 
 
 def test_epilogue_options(mainloop):

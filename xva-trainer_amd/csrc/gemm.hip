@@ -9,6 +9,8 @@ void xva_gemm_launch_mixed(const xva_gemm_params& p, int bn, unsigned nblocks, h
 bool xva_gemm_glds_eligible(const xva_gemm_params& p);
 int xva_gemm_launch_glds(const xva_gemm_params& p, int tile, hipStream_t st);
 void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn);
+int xva_gemm_conv_res_plan(const xva_gemm_params& p);
+int xva_gemm_launch_conv_res(const xva_gemm_params& p, int dstep, hipStream_t st);
 bool xva_prof_is_on();
 void xva_prof_begin(hipStream_t st, double flops, int variant);
 void xva_prof_end(hipStream_t st);
@@ -97,6 +99,8 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (sk > nkt / 8) sk = nkt / 8;
         p.splitk = sk < 1 ? 1 : (int)sk;
     }
+    const int res_dstep = (glds_tile >= 0 && glds_env != 6) ? xva_gemm_conv_res_plan(p) : 0;   // mode 6: resident-input kernel off
+    if (res_dstep != 0) bn = 900000 + p.a_seglen;
     long nblocks = glds_tile >= 0 ? 1 : (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2 * p.splitk;
     XVA_CHECK_ARG(nblocks < (1L << 31), "xva_gemm: grid too large");
     hipStream_t st = (hipStream_t)stream;
@@ -113,7 +117,9 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (p.R) by += (double)p.M * p.N * (p.r_dtype == XVA_BF16 ? 2.0 : 4.0);
         if (p.G) by += (double)p.M * p.N * (p.g_dtype == XVA_BF16 ? 2.0 : 4.0);
         xva_prof_shape(p.M, p.N, p.K, p.batch * p.batch2, p.splitk, bn, by * nbz); }
-    if (glds_tile >= 0) { if (xva_gemm_launch_glds(p, glds_tile, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; } }
+    if (res_dstep != 0) {   // stride-1 conv over 32 / 64 / 128 channels: resident input tile
+        if (xva_gemm_launch_conv_res(p, res_dstep, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; }
+    } else if (glds_tile >= 0) { if (xva_gemm_launch_glds(p, glds_tile, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; } }
     else if (mode == 0) xva_gemm_launch_fp32(p, bn, (unsigned)nblocks, st);
     else if (mode == 1) xva_gemm_launch_bf16(p, bn, (unsigned)nblocks, st);
     else xva_gemm_launch_mixed(p, bn, (unsigned)nblocks, st);

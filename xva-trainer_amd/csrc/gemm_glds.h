@@ -46,7 +46,9 @@ __device__ __forceinline__ int swap23(int k) { return (k & ~12) | ((k & 4) << 1)
 // rows of >= 256 bytes XOR the 32-byte window with pos & 7, 128-byte rows (ROWS = 64) with (pos >> 1) & 3 — either way the 8
 // k-rows a half-wave transpose read touches land on 8 distinct 32-byte bank windows.
 template <int ROWS>
-__device__ __forceinline__ int ic_chunk(int pos, int c) { return ROWS >= 128 ? (c ^ ((pos & 7) << 1)) : (c ^ (((pos >> 1) & 3) << 1)); }
+__device__ __forceinline__ int ic_chunk(int pos, int c) {
+    return ROWS >= 128 ? (c ^ ((pos & 7) << 1)) : (ROWS == 64 ? (c ^ (((pos >> 1) & 3) << 1)) : (c ^ (((pos >> 2) & 1) << 1)));
+}
 
 // ---- DMA descriptors of one operand tile ([ROWS idx] x [64 k]) for one thread ---------------------------------------------
 // The tile is 8 * ROWS 16-byte chunks; wave instruction Q (0 .. ROWS/8 - 1) fills LDS bytes [Q * 1024, Q * 1024 + 1024).
@@ -253,6 +255,59 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
     }
 }
 
+// ---- epilogue of one wave tile: acc[i][j][e] = C[rbase + i*16][cbase + j*16 + e]  (rbase includes lane & 15, cbase (lane >> 4) * 4)
+// (compile-time indices: a rolled loop would index `acc` dynamically and push the accumulators to scratch)
+template <int MI, int NJ>
+__device__ __forceinline__ void tile_epilogue(const xva_gemm_params& p, f32x4 (&acc)[MI][NJ], int vec_epi, int rbase, int cbase, int z1, int z2,
+                                              int bz, int ks) {
+    const int64_t coff = (int64_t)z1 * p.sC + (int64_t)z2 * p.sC2;
+    const int64_t roff = (int64_t)z1 * p.sR + (int64_t)z2 * p.sR2;
+    const int64_t goff = (int64_t)z1 * p.sG + (int64_t)z2 * p.sG2;
+    const bool lin_first = (p.splitk == 1) || (ks == 0);
+    auto run = [&](auto vec_tag) {
+        constexpr bool VEC = decltype(vec_tag)::value;
+        static_for<MI>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int row = rbase + i * 16;
+            if (row < p.M) {
+                bool live = true;
+                if (p.mask_mode != XVA_MASK_NONE) {
+                    const int64_t rr = (int64_t)row * p.mask_mul + p.mask_add;
+                    const int t = (int)(rr % p.Tp);
+                    live = t >= p.mask_pad && t < p.mask_pad + p.mask_len;
+                    if (live && p.mask_mode == XVA_MASK_LEN) live = (t - p.mask_pad) < p.lens[rr / p.Tp];
+                }
+                static_for<NJ>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const int col = cbase + j * 16;
+                    if (col < p.N) epilogue4<VEC>(p, acc[i][j], row, col, live, lin_first, z2, coff, roff, goff);
+                });
+            }
+        });
+    };
+    if (p.splitk > 1 && p.sk_ws) {
+        // split-K slab: raw partial sums of this K range, [split][M][N] fp32; xva_gemm_splitk_reduce applies the epilogue
+        float* slab = reinterpret_cast<float*>(p.sk_ws) + ((int64_t)bz * p.splitk + ks) * (int64_t)p.M * p.N;
+        static_for<MI>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int row = rbase + i * 16;
+            if (row < p.M) {
+                static_for<NJ>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const int col = cbase + j * 16;
+                    if (col < p.N) {
+                        float* dst = slab + (int64_t)row * p.N + col;
+                        if (vec_epi) *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                        else for (int e = 0; e < 4 && col + e < p.N; ++e) dst[e] = acc[i][j][e];
+                    }
+                });
+            }
+        });
+        return;
+    }
+    if (vec_epi) run(std::true_type{}); else run(std::false_type{});
+}
+
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
 // vec_epi: host-verified that N % 4 == 0 and C / R / G rows are 4-element aligned (vector epilogue allowed)
 template <int LAYOUT, int BM, int BN, int WM, int WN>
@@ -361,55 +416,131 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) 
         __syncthreads();
     }
 
-    // ---- epilogue: acc[i][j][e] = C[m0 + wm*WM + i*16 + (lane & 15)][n0 + wn*WN + j*16 + (lane >> 4)*4 + e]
-    // (compile-time indices: a rolled loop would index `acc` dynamically and push the accumulators to scratch)
-    const int64_t coff = (int64_t)z1 * p.sC + (int64_t)z2 * p.sC2;
-    const int64_t roff = (int64_t)z1 * p.sR + (int64_t)z2 * p.sR2;
-    const int64_t goff = (int64_t)z1 * p.sG + (int64_t)z2 * p.sG2;
-    const bool lin_first = (p.splitk == 1) || (ks == 0);
-    const int rbase = m0 + wm * WM + (lane & 15), cbase = n0 + wn * WN + (lane >> 4) * 4;
-    auto run = [&](auto vec_tag) {
-        constexpr bool VEC = decltype(vec_tag)::value;
-        static_for<MI>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const int row = rbase + i * 16;
-            if (row < p.M) {
-                bool live = true;
-                if (p.mask_mode != XVA_MASK_NONE) {
-                    const int64_t rr = (int64_t)row * p.mask_mul + p.mask_add;
-                    const int t = (int)(rr % p.Tp);
-                    live = t >= p.mask_pad && t < p.mask_pad + p.mask_len;
-                    if (live && p.mask_mode == XVA_MASK_LEN) live = (t - p.mask_pad) < p.lens[rr / p.Tp];
-                }
-                static_for<NJ>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    const int col = cbase + j * 16;
-                    if (col < p.N) epilogue4<VEC>(p, acc[i][j], row, col, live, lin_first, z2, coff, roff, goff);
-                });
-            }
-        });
-    };
-    if (p.splitk > 1 && p.sk_ws) {
-        // split-K slab: raw partial sums of this K range, [split][M][N] fp32; xva_gemm_splitk_reduce applies the epilogue
-        float* slab = reinterpret_cast<float*>(p.sk_ws) + ((int64_t)bz * p.splitk + ks) * (int64_t)p.M * p.N;
-        static_for<MI>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const int row = rbase + i * 16;
-            if (row < p.M) {
-                static_for<NJ>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    const int col = cbase + j * 16;
-                    if (col < p.N) {
-                        float* dst = slab + (int64_t)row * p.N + col;
-                        if (vec_epi) *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                        else for (int e = 0; e < 4 && col + e < p.N; ++e) dst[e] = acc[i][j][e];
-                    }
-                });
-            }
-        });
-        return;
+    tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
+}
+
+// ---- stride-1 convolution with a RESIDENT input tile ------------------------------------------------------------------------
+// A k-tap (dilation d) convolution over CIN channels is the GEMM above with K = k * CIN in tap segments; there every 64-deep K tile
+// re-fetches its 128 input rows shifted by the tap, i.e. the input is streamed k times through L2 -> LDS (the measured bound of
+// HiFi-GAN's 32/64/128-channel stages: 6.7 TB/s of L2 traffic for 47 MB of input).  Here the workgroup's 128 output rows load
+// their 128 + (k-1) d input rows ONCE (global_load_lds, 16-byte chunks XOR-swizzled by the row so that the shifted 16-row MFMA
+// fragments stay (nearly) conflict-free); only the small weight tiles stream through the usual double buffer.
+// NT: forward (weights [Cout][k * CIN]).  NN: backward-data (weights read through the B row segments, tap-reversed).
+constexpr int RES_HALO = 64;
+template <int CIN> __device__ __forceinline__ int res_swz(int row) { return CIN == 128 ? (row & 15) : (CIN == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3)); }
+
+template <int LAYOUT, int CIN, int BN, int WM, int WN>
+__global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_kernel(xva_gemm_params p, int vec_epi, int dstep) {
+    constexpr int BM = 128;
+    constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
+    static_assert(NW == 4, "resident-input conv: 4 waves");
+    constexpr int MI = WM / 16, NJ = WN / 16;
+    constexpr int BKD = LAYOUT == XVA_GEMM_NT ? KC : IC;
+    constexpr int A_BYTES = (BM + RES_HALO) * CIN * 2, B_BYTES = BN * GK * 2;
+    constexpr int CPR = CIN / 8, RPI = 64 / CPR;            // 16-byte chunks per input row, rows per DMA instruction
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem_raw[];
+    XVA_LDS uint8_t* smem = (XVA_LDS uint8_t*)smem_raw;
+
+    const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
+    int Lg;
+    {
+        const unsigned total = gridDim.x, id = blockIdx.x;
+        const unsigned xcd = id & 7u, slot = id >> 3, q = total >> 3, r = total & 7u;
+        Lg = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot);
     }
-    if (vec_epi) run(std::true_type{}); else run(std::false_type{});
+    const int tn = Lg % nbx, tm = (Lg / nbx) % nby, z = Lg / (nbx * nby);
+    const int b2n = p.batch2 > 1 ? p.batch2 : 1;
+    const int z1 = z / b2n, z2 = z - z1 * b2n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + (int64_t)z1 * p.sA + (int64_t)z2 * p.sA2;
+    const uint16_t* B = reinterpret_cast<const uint16_t*>(p.B) + (int64_t)z1 * p.sB + (int64_t)z2 * p.sB2;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int ntaps = p.K / CIN;
+    const int halo = (ntaps - 1) * (dstep < 0 ? -dstep : dstep);
+    const int lo = dstep < 0 ? -halo : 0;                     // taps step forwards (forward conv) or backwards (backward-data)
+    const int nkt = (p.K + GK - 1) / GK;
+
+    // resident input rows m0 + lo .. m0 + lo + BM + halo - 1 (valid input rows: lo .. M - 1 + lo + halo)
+    {
+        const int nrows = BM + halo, rmax = p.M - 1 + lo + halo;
+        const int ninstr = (nrows + RPI - 1) / RPI;
+        for (int q = wave; q < ninstr; q += NW) {
+            const int r = q * RPI + lane / CPR, pch = lane % CPR;
+            const int c = pch ^ res_swz<CIN>(r);
+            const uint16_t* src = A + (int64_t)min(m0 + lo + r, rmax) * p.lda + c * 8;
+            __builtin_amdgcn_global_load_lds((const XVA_GLB void*)src, (XVA_LDS void*)(smem + q * 1024), 16, 0, 0);
+        }
+    }
+    Loader<BKD, BN, NW> lb;
+    if constexpr (BKD == KC) lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0);
+    else lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0, p.seglen, p.segstride);
+    auto b_base = [&](int k0) -> const uint16_t* {
+        if constexpr (BKD == KC) return B + k0;
+        else return p.seglen > 0 ? B + p.seg0 + (int64_t)(k0 / p.seglen) * p.segstride + (int64_t)(k0 % p.seglen) * p.ldb : B + (int64_t)k0 * p.ldb;
+    };
+    KcReader krb;
+    IcReader<BN, NJ> irb;
+    if constexpr (BKD == KC) krb.init(lane); else irb.init(lane, wn * WN);
+    const int g = lane >> 4;
+    const int arow = wm * WM + (lane & 15) - lo;
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    lb.issue(b_base(0), 0, p.K, smem + A_BYTES, wave);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) lb.issue(b_base((kt + 1) * GK), (kt + 1) * GK, p.K, smem + A_BYTES + (cur ^ 1) * B_BYTES, wave);
+        const XVA_LDS uint8_t* Bt = smem + A_BYTES + cur * B_BYTES;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const int kk0 = kt * GK + kh * 32;
+            const int tap = min(kk0 / CIN, ntaps - 1);          // a ragged last K tile multiplies zero weights: stay inside the tile
+            const int ch = (kk0 % CIN) / 8 + g;
+            const int shift = tap * dstep;
+            bf16x8 af[MI], bfr[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (BKD == KC) bfr[j] = krb.read(Bt, wn * WN + j * 16, kh);
+                else bfr[j] = irb.read(Bt, j, kh);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int r = arow + i * 16 + shift;
+                af[i] = *reinterpret_cast<const XVA_LDS bf16x8*>(smem + r * (CIN * 2) + ((ch ^ res_swz<CIN>(r)) << 4));
+            }
+            if (p.a_lrelu) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, z, 0);
+}
+
+template <int LAYOUT, int CIN, int BN, int WM, int WN>
+inline int launch_conv_res(const xva_gemm_params& p, int vec_epi, int dstep, hipStream_t st) {
+    constexpr int LDS = (128 + RES_HALO) * CIN * 2 + 2 * BN * GK * 2;
+    auto kern = xva_conv_res_kernel<LAYOUT, CIN, BN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+        attr_set = true;
+    }
+    long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, 128) * p.batch * p.batch2;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, st, p, vec_epi, dstep);
+    return 0;
 }
 
 template <int LAYOUT, int BM, int BN, int WM, int WN>

@@ -61,6 +61,7 @@ bool xva_gemm_glds_eligible(const xva_gemm_params& p) {
 }
 
 static int launch_tiles(const xva_gemm_params& p, int tile, int vec, hipStream_t st);
+static int vec_epilogue_ok(const xva_gemm_params& p);
 
 // tile: see launch_tiles
 int xva_gemm_launch_glds(const xva_gemm_params& pin, int tile, hipStream_t st) {
@@ -69,10 +70,7 @@ int xva_gemm_launch_glds(const xva_gemm_params& pin, int tile, hipStream_t st) {
     // split-K through slabs needs N % 4 == 0 and enough scratch; otherwise fall back to fp32 atomics
     const int64_t need = (int64_t)p.splitk * p.batch * p.batch2 * (int64_t)p.M * p.N * 4;
     if (p.splitk <= 1 || !p.sk_ws || p.sk_ws_bytes < need || p.N % 4 != 0 || ((uintptr_t)p.sk_ws % 16) != 0) p.sk_ws = nullptr;
-    auto al = [](const void* q, int b) { return ((uintptr_t)q % b) == 0; };
-    int vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.sC % 4 == 0) && (p.sC2 % 4 == 0) && al(p.C, p.c_dtype == XVA_BF16 ? 8 : 16);
-    if (p.R) vec = vec && (p.ldr % 4 == 0) && (p.sR % 4 == 0) && (p.sR2 % 4 == 0) && al(p.R, p.r_dtype == XVA_BF16 ? 8 : 16);
-    if (p.G) vec = vec && (p.ldg % 4 == 0) && (p.sG % 4 == 0) && (p.sG2 % 4 == 0) && al(p.G, p.g_dtype == XVA_BF16 ? 8 : 16);
+    const int vec = vec_epilogue_ok(p);
     int rc = launch_tiles(p, tile, vec, st);
     if (rc == 0 && p.sk_ws) {
         const int64_t quads = (int64_t)p.M * p.N / 4;
@@ -103,4 +101,41 @@ static int launch_tiles(const xva_gemm_params& p, int tile, int vec, hipStream_t
 void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn) {
     static const int d[4][2] = {{128, 128}, {256, 256}, {128, 64}, {64, 64}};
     *bm = d[tile & 3][0]; *bn = d[tile & 3][1];
+}
+
+static int vec_epilogue_ok(const xva_gemm_params& p) {
+    auto al = [](const void* q, int b) { return ((uintptr_t)q % b) == 0; };
+    int vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.sC % 4 == 0) && (p.sC2 % 4 == 0) && al(p.C, p.c_dtype == XVA_BF16 ? 8 : 16);
+    if (p.R) vec = vec && (p.ldr % 4 == 0) && (p.sR % 4 == 0) && (p.sR2 % 4 == 0) && al(p.R, p.r_dtype == XVA_BF16 ? 8 : 16);
+    if (p.G) vec = vec && (p.ldg % 4 == 0) && (p.sG % 4 == 0) && (p.sG2 % 4 == 0) && al(p.G, p.g_dtype == XVA_BF16 ? 8 : 16);
+    return vec;
+}
+
+// ---- stride-1 convolutions over 32 / 64 / 128 input channels: resident-input kernel (gemm_glds.h) --------------------------------
+template <int LAYOUT, int CIN>
+static int conv_res_bn(const xva_gemm_params& p, int vec, int dstep, hipStream_t st) {
+    using namespace xva_glds;
+    if (p.N > 64) return launch_conv_res<LAYOUT, CIN, 128, 64, 64>(p, vec, dstep, st);
+    if (p.N > 32 || LAYOUT == XVA_GEMM_NN) return launch_conv_res<LAYOUT, CIN, 64, 32, 64>(p, vec, dstep, st);
+    return launch_conv_res<LAYOUT, CIN, 32, 32, 32>(p, vec, dstep, st);
+}
+// signed rows between consecutive taps when the problem qualifies for the resident-input kernel, 0 otherwise
+int xva_gemm_conv_res_plan(const xva_gemm_params& p) {
+    if (!xva_gemm_glds_eligible(p) || p.layout == XVA_GEMM_TN || p.splitk != 1) return 0;
+    const int cin = p.a_seglen;
+    if (!(cin == 32 || cin == 64 || cin == 128) || p.lda != cin || p.K % cin != 0 || p.K / cin < 2) return 0;
+    const int64_t step = (int64_t)p.a_seglen + p.a_segadj;          // elements between consecutive taps of one output row
+    if (step == 0 || step % p.lda != 0) return 0;
+    const int dstep = (int)(step / p.lda);                          // > 0: forward convolution, < 0: backward-data (taps walk backwards)
+    if ((int64_t)(p.K / cin - 1) * (dstep < 0 ? -dstep : dstep) > xva_glds::RES_HALO) return 0;
+    if (p.layout == XVA_GEMM_NN && (p.N % 8 != 0)) return 0;
+    return dstep;
+}
+int xva_gemm_launch_conv_res(const xva_gemm_params& p, int dstep, hipStream_t st) {
+    const int cin = p.a_seglen;
+    const int vec = vec_epilogue_ok(p);
+    int rc;
+    if (p.layout == XVA_GEMM_NT) rc = cin == 32 ? conv_res_bn<XVA_GEMM_NT, 32>(p, vec, dstep, st) : (cin == 64 ? conv_res_bn<XVA_GEMM_NT, 64>(p, vec, dstep, st) : conv_res_bn<XVA_GEMM_NT, 128>(p, vec, dstep, st));
+    else rc = cin == 32 ? conv_res_bn<XVA_GEMM_NN, 32>(p, vec, dstep, st) : (cin == 64 ? conv_res_bn<XVA_GEMM_NN, 64>(p, vec, dstep, st) : conv_res_bn<XVA_GEMM_NN, 128>(p, vec, dstep, st));
+    return rc;
 }
