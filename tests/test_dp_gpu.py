@@ -1,0 +1,55 @@
+"""GPU: the data-parallel step (fastpitch/dp.py: per-bucket HIP events, side-stream RCCL all-reduce) on a 1-rank RCCL group
+reproduces the plain step (up to the summation order of fp32 atomics); world-size-2 semantics are covered on CPU/gloo in tests/test_dp_cpu.py."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("stage", [3, 2])
+def test_gradsync_single_rank_rccl_matches_plain_step(stage):
+    import torch.distributed as dist
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd.fastpitch import engine as E, params as P
+    from xva_trainer_amd.fastpitch.dp import GradSync
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sd = ofp.init_state_dict(21)
+        batch = E.DeviceBatch.from_dict(ofp.synth_batch(3, 17, 70, 22), "cuda")
+        eng = E.FastPitchEngine("cuda", "bf16", p_dropout=0.1, seed=5)
+        flat = torch.zeros(eng.total, device="cuda")
+        P.to_flat(sd, eng.table, flat)
+        g_plain = torch.zeros_like(flat)
+        l_plain = eng.fwd_loss_bwd(flat, g_plain, batch, stage).clone()
+        eng.step = 0                                                  # same dropout masks for the second pass
+        g_dp = torch.zeros_like(flat)
+        sync = GradSync(eng, flat, g_dp, 1)
+        l_dp = sync.fwd_loss_bwd(batch, stage)
+        torch.cuda.synchronize()
+        assert torch.allclose(l_dp, l_plain, rtol=1e-5, atol=1e-7)
+        assert ((g_dp - g_plain).norm() / g_plain.norm()).item() < 1e-5          # fp32 atomics (bias / LayerNorm gradients) reorder between runs
+        # gradient accumulation: only the last micro-batch synchronises
+        eng.step = 0
+        g2 = torch.zeros_like(flat)
+        sync2 = GradSync(eng, flat, g2, 1)
+        sync2.fwd_loss_bwd(batch, stage, grad_scale=0.5, sync=False)
+        eng.step = 0
+        sync2.fwd_loss_bwd(batch, stage, grad_scale=0.5, sync=True)
+        torch.cuda.synchronize()
+        rel = ((g2 - g_plain).norm() / g_plain.norm()).item()
+        assert rel < 2e-2, rel                                        # two half-scaled bf16 passes vs one full pass
+    finally:
+        dist.destroy_process_group()
