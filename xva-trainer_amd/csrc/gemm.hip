@@ -83,9 +83,10 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         bn = bn * 1000 + bm;   // profile tag
         if (can_split) {   // 256x256 tiles: at most one round of 256 workgroups; smaller tiles (2-3 per CU): ~1.7 rounds; >= 8 K tiles per split
             const long tiles = ntiles(glds_tile);
-            long sk = glds_tile == 1 ? 256 / tiles : (864 + tiles / 2) / tiles;
+            // small tiles are latency-bound per K tile (one DMA stage in flight): fill the chip with ~6 workgroups per CU
+            long sk = glds_tile == 1 ? 256 / tiles : ((glds_tile == 0 ? 864 : 1536) + tiles / 2) / tiles;
             if (sk > nkt / 8) sk = nkt / 8;
-            if (sk > 128) sk = 128;          // the reduce pass reads every slab: beyond this it costs more than the idle CUs
+            if (sk > 1024) sk = 1024;
             if (p.sk_ws && p.N % 4 == 0) {   // stay inside the caller's slab scratch (atomics are much slower)
                 const long fit = (long)(p.sk_ws_bytes / ((int64_t)p.M * p.N * 4 * nb));
                 if (fit >= 2 && sk > fit) sk = fit;

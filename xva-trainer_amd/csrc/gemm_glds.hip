@@ -2,7 +2,9 @@
 #include "gemm_glds.h"
 
 namespace xva_glds {
-// C (+)= alpha * (sum_s slab[s] + bias) + beta * R  for one batch item per blockIdx.y; thread = one column, rows strided by gridDim.x.
+// C (+)= alpha * (sum_s slab[s] + bias) + beta * R  for one batch item per blockIdx.y.
+// gridDim.z == 1: one pass with the full (linear) epilogue.  gridDim.z > 1 (many slabs of a small output; host-checked: pure fp32
+// accumulation, no bias / residual): each z sums its share of the slabs and adds alpha * partial atomically.
 __global__ __launch_bounds__(256) void xva_gemm_splitk_reduce_kernel(xva_gemm_params p) {
     const int b2n = p.batch2 > 1 ? p.batch2 : 1;
     const int bz = blockIdx.y, z1 = bz / b2n, z2 = bz - z1 * b2n;
@@ -10,13 +12,25 @@ __global__ __launch_bounds__(256) void xva_gemm_splitk_reduce_kernel(xva_gemm_pa
     const float* slab = reinterpret_cast<const float*>(p.sk_ws) + (int64_t)bz * p.splitk * MN;
     const int64_t coff = (int64_t)z1 * p.sC + (int64_t)z2 * p.sC2;
     const int64_t roff = (int64_t)z1 * p.sR + (int64_t)z2 * p.sR2;
+    const int per = (p.splitk + gridDim.z - 1) / gridDim.z;
+    const int k0 = blockIdx.z * per, k1 = min(p.splitk, k0 + per);
+    if (k0 >= k1) return;
     for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < MN; e += (int64_t)gridDim.x * 1024) {
-        float4 s = *reinterpret_cast<const float4*>(slab + e);
-        for (int k = 1; k < p.splitk; ++k) {
+        float4 s = *reinterpret_cast<const float4*>(slab + k0 * MN + e);
+        for (int k = k0 + 1; k < k1; ++k) {
             float4 t = *reinterpret_cast<const float4*>(slab + k * MN + e);
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
         float v[4] = {s.x, s.y, s.z, s.w};
+        if (gridDim.z > 1) {
+            const int row = (int)(e / p.N), col = (int)(e - (int64_t)row * p.N);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t ci = coff + (p.c_trans ? (int64_t)(col + q) * p.ldc + row : (int64_t)row * p.ldc + col + q);
+                atomicAdd(reinterpret_cast<float*>(p.C) + ci, p.alpha * v[q]);
+            }
+            continue;
+        }
         const int row = (int)(e / p.N), col = (int)(e - (int64_t)row * p.N);   // N % 4 == 0: the 4 values share a row
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -75,7 +89,14 @@ int xva_gemm_launch_glds(const xva_gemm_params& pin, int tile, hipStream_t st) {
     if (rc == 0 && p.sk_ws) {
         const int64_t quads = (int64_t)p.M * p.N / 4;
         int gx = (int)((quads + 255) / 256); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
-        hipLaunchKernelGGL(xva_gemm_splitk_reduce_kernel, dim3(gx, p.batch * p.batch2), dim3(256), 0, st, p);
+        // few output elements, many slabs: spread the slabs over gridDim.z (needs a purely additive fp32 epilogue)
+        int gz = 1;
+        if (p.splitk > 32 && gx * p.batch * p.batch2 < 256 && p.accumulate && p.c_dtype == XVA_F32 && !p.bias && !p.R) {
+            gz = 256 / (gx * p.batch * p.batch2);
+            if (gz > p.splitk / 8) gz = p.splitk / 8;
+            if (gz < 1) gz = 1;
+        }
+        hipLaunchKernelGGL(xva_gemm_splitk_reduce_kernel, dim3(gx, p.batch * p.batch2, gz), dim3(256), 0, st, p);
     }
     return rc;
 }
