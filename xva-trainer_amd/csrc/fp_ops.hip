@@ -329,7 +329,7 @@ extern "C" int xva_fp_layernorm_bwd(const void* dY, const void* X, const float* 
     XVA_CHECK_ARG((dY || (outer_d && outer_w)) && X && mean && rstd && gamma && dX, "layernorm_bwd: null");
     XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
     XVA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both null");
-    int rpb = (int)xva_cdiv(rows, 512);          // <= 512 workgroups
+    int rpb = (int)xva_cdiv(rows, 256);          // <= 256 workgroups (one per CU)
     rpb = (rpb + LNB_WAVES - 1) / LNB_WAVES * LNB_WAVES;
     dim3 grid(xva_cdiv(rows, rpb)), block(64 * LNB_WAVES);
     if (C == 384)
