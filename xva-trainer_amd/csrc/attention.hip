@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                                                               const float* __restrict__ lse, const float* __restrict__ Dv,
                                                               const int* __restrict__ lens, uint16_t* __restrict__ dqkv, int Tp,
                                                               float scale, float pdrop, uint64_t seed, uint32_t stream_id) {
-    __shared__ __attribute__((aligned(1024))) uint8_t smem_raw[4 * TILE];   // Q0 dO0 Q1 dO1
+    __shared__ __attribute__((aligned(1024))) uint8_t smem_raw[4 * TILE + 1024];   // Q0 dO0 Q1 dO1 | logsumexp / D of the two query blocks
     XVA_LDS uint8_t* smem = (XVA_LDS uint8_t*)smem_raw;
     const int b = blockIdx.y, k0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -218,15 +218,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     const int nqb = (min(len + 1, Tp) + 63) / 64;   // rows above len carry dO = 0: no contribution
     const float* Lb = lse + (int64_t)b * Tp;
     const float* Db = Dv + (int64_t)b * Tp;
+    // per-row statistics of a query block travel with its tiles: wave 0 DMAs 64 logsumexp values, wave 1 the 64 D values (4 bytes per lane)
+    XVA_LDS uint8_t* stat = smem + 4 * TILE;
+    auto stat_dma = [&](int ib, int buf) {
+        if (wave < 2) {
+            const float* src = (wave == 0 ? Lb : Db) + min(ib * 64 + lane, Tp - 1);
+            __builtin_amdgcn_global_load_lds((const XVA_GLB void*)src, (XVA_LDS void*)(stat + buf * 512 + wave * 256), 4, 0, 0);
+        }
+    };
 
     tile_dma(base, 192, 0, Tp - 1, smem, lane, wave);
     tile_dma(dob, 64, 0, Tp - 1, smem + TILE, lane, wave);
+    stat_dma(0, 0);
     __syncthreads();
     for (int ib = 0; ib < nqb; ++ib) {
         const int cur = ib & 1;
         if (ib + 1 < nqb) {
             tile_dma(base, 192, (ib + 1) * 64, Tp - 1, smem + (cur ^ 1) * 2 * TILE, lane, wave);
             tile_dma(dob, 64, (ib + 1) * 64, Tp - 1, smem + (cur ^ 1) * 2 * TILE + TILE, lane, wave);
+            stat_dma(ib + 1, cur ^ 1);
         }
         const XVA_LDS uint8_t* Qt = smem + cur * 2 * TILE;
         const XVA_LDS uint8_t* Ot = Qt + TILE;
@@ -241,17 +251,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
             }
         }
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < 4; ++rt) {
+            const f32x4 L4 = *reinterpret_cast<const XVA_LDS f32x4*>(stat + cur * 512 + (rt * 16 + g * 4) * 4);
+            const f32x4 D4 = *reinterpret_cast<const XVA_LDS f32x4*>(stat + cur * 512 + 256 + (rt * 16 + g * 4) * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ir = ib * 64 + rt * 16 + g * 4 + r, irc = min(ir, Tp - 1);
+                const int ir = ib * 64 + rt * 16 + g * 4 + r;
                 const bool ok = key_ok && ir < Tp;
-                const float p = ok ? __expf(s[rt][r] * scale - Lb[irc]) : 0.f;
+                const float p = ok ? __expf(s[rt][r] * scale - L4[r]) : 0.f;
                 float dr = 1.f;
                 if (DROP) dr = xva_dropout_scale(pdrop, seed, stream_id, ((uint64_t)b * Tp + ir) * Tp + key);
                 s[rt][r] = p * dr;                                           // dropped probabilities
-                dp[rt][r] = p * (dp[rt][r] * dr - Db[irc]) * scale;          // dS (scale of S folded in)
+                dp[rt][r] = p * (dp[rt][r] * dr - D4[r]) * scale;            // dS (scale of S folded in)
             }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const bf16x8 pf = pack_rows(s[2 * t], s[2 * t + 1]);
