@@ -133,6 +133,23 @@ int xva_fp_forward(const xva_fp_dims* d, const float* params, const xva_fp_batch
 int xva_fp_backward(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_batch* batch, void* workspace,
                     int64_t workspace_bytes, void* stream);
 
+/* Inference (FastPitch.infer, python/fastpitch1_1/fastpitch/model.py:426-481: predicted durations, pitch and energy; no speaker
+ * embedding, no pitch transform).  Two calls because the mel length is data dependent: the host reads dec_lens, sizes the
+ * decoder workspace for Tm = max(dec_lens) and calls the second half.
+ *   encode: dims {B, Tt, Tm ignored, stage ignored, compute, dropout ignored}; batch needs text, in_lens, pos_table.
+ *           enc_cond_out (B, Tt+2, 384) activation dtype; durs_out (B, Tt) int32 = (long)(dur_pred * pace + 0.5);
+ *           dec_lens_out (B) int32; dur_pred / pitch_pred / energy_pred (B, Tt) fp32.
+ *   decode: dims {B, Tt, Tm, ., compute, .}; mel_out (B, 80, Tm) fp32 (the reference's permuted layout; frames >= dec_lens hold proj(0) = bias
+ *           exactly like the reference's masked decoder output). */
+int xva_fp_infer_encode(const xva_fp_dims* d, const float* params, const xva_fp_batch* batch, float pace, float max_duration, void* workspace,
+                        int64_t workspace_bytes, void* enc_cond_out, int32_t* durs_out, int32_t* dec_lens_out, float* dur_pred_out,
+                        float* pitch_pred_out, float* energy_pred_out, void* stream);
+int xva_fp_infer_decode(const xva_fp_dims* d, const float* params, const void* enc_cond, const int32_t* durs, const float* pos_table,
+                        void* workspace, int64_t workspace_bytes, float* mel_out, void* stream);
+int xva_fp_infer_finish(const float* dur_pad, const float* pitch_pad, const float* energy_pad, const int32_t* lens, float pace, int B, int Tt,
+                        int32_t* durs, int32_t* dec_lens, float* dur_out, float* pitch_out, float* energy_out, void* stream);
+int xva_fp_mel_to_bct(const void* in, int dt, float* out, int B, int Tm, int C, void* stream);
+
 /* Data-parallel overlap: gradient buckets (contiguous flat ranges, in backward completion order) and a backward
  * that records one hipEvent_t per bucket as it completes; the host starts that bucket's RCCL all-reduce on a side
  * stream (replaces nn.DataParallel's reduce_add_coalesced, python/fastpitch1_1/xva_train.py:48-53,465-466). */

@@ -207,6 +207,22 @@ def forward(sd, batch, stage, taps=None, drop=None):
             batch["in_lens"]]
 
 
+def infer(sd, text, pace=1.0, max_duration=75):
+    """FastPitch.infer (model.py:426-481) with predicted durations / pitch / energy, no speaker embedding, no pitch transform.
+    text: (B, Tt) int64, zero-padded.  Returns (mel_out (B, 80, Tm), dec_lens, dur_pred, pitch_pred (B, 1, Tt), energy_pred)."""
+    enc_out, enc_mask = fft_transformer(sd, "encoder.", text, embed=True)
+    log_dur_pred = temporal_predictor(sd, "duration_predictor.", enc_out, enc_mask).squeeze(-1)
+    dur_pred = torch.clamp(torch.exp(log_dur_pred) - 1, 0, max_duration)
+    pitch_pred = temporal_predictor(sd, "pitch_predictor.", enc_out, enc_mask).permute(0, 2, 1)
+    enc_out = enc_out + F.conv1d(pitch_pred, sd["pitch_emb.weight"], sd["pitch_emb.bias"], padding=1).transpose(1, 2)
+    energy_pred = temporal_predictor(sd, "energy_predictor.", enc_out, enc_mask).squeeze(-1)
+    enc_out = enc_out + F.conv1d(energy_pred.unsqueeze(1), sd["energy_emb.weight"], sd["energy_emb.bias"], padding=1).transpose(1, 2)
+    len_regulated, dec_lens = regulate_len(dur_pred, enc_out, pace, None)
+    dec_out, dec_mask = fft_transformer(sd, "decoder.", len_regulated, seq_lens=dec_lens)
+    mel_out = F.linear(dec_out, sd["proj.weight"], sd["proj.bias"]).permute(0, 2, 1)
+    return mel_out, dec_lens, dur_pred, pitch_pred, energy_pred
+
+
 def loss(model_out, batch, stage, dur_scale=0.1, pitch_scale=0.1, energy_scale=0.1):
     """FastPitchLoss.forward with the trainer's scales (xva_train.py:702-704; energy default loss_function.py:54).
     Returns (loss, dict of component losses)."""

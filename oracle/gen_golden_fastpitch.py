@@ -102,3 +102,25 @@ def generate(ns, out_dir):
             rec["new_proj_weight"] = new_sd["proj.weight"].numpy()
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
         print(name, "loss", loss, "comps", comps, "gnorm", gnorm, "ngrads", len(keys))
+
+
+def generate_infer(ns, out_dir):
+    """Inference path: reference FastPitch.infer in eval() on a seeded state_dict whose duration head is biased
+    towards ~4 frames per token (a random-init head predicts ~0 frames)."""
+    seed, B, Tt = 4321, 3, 17
+    sd = ofp.init_state_dict(seed)
+    sd["duration_predictor.fc.bias"] = sd["duration_predictor.fc.bias"] + 1.6
+    batch = ofp.synth_batch(B, Tt, 40, seed + 1)
+    text = batch["text"]
+    model = ns.FastPitch()
+    model.load_state_dict(sd)
+    model.eval()
+    with torch.no_grad():
+        mel, dec_lens, dur, pitch, energy = model.infer(text, pace=1.0)
+        o_mel, o_dec, o_dur, o_pitch, o_energy = ofp.infer(sd, text, 1.0)
+    assert torch.equal(o_dec, dec_lens)
+    for a, b in ((o_mel, mel), (o_dur, dur), (o_pitch, pitch), (o_energy, energy)):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    np.savez_compressed(os.path.join(out_dir, "fp_infer_small.npz"), seed=np.int64(seed), dur_bias_shift=np.float64(1.6), text=text.numpy(),
+                        mel_out=mel.numpy(), dec_lens=dec_lens.numpy(), dur_pred=dur.numpy(), pitch_pred=pitch.numpy(), energy_pred=energy.numpy())
+    print("fp_infer_small: mel", tuple(mel.shape), "dec_lens", dec_lens.tolist())

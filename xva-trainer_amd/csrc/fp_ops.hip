@@ -822,3 +822,49 @@ extern "C" int xva_cast_to_f32(const void* src, int dt, float* dst, int64_t n, v
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
+
+// =====================================================================================
+// Inference helpers (FastPitch.infer, model.py:426-481)
+// infer_finish: per item, reps[t] = (long)(dur_pred[t] * pace + 0.5) (regulate_len, model.py:62-64; 0 on padding tokens),
+// dec_lens = sum reps, and the token-level predictions unpadded to (B, Tt).
+// =====================================================================================
+__global__ void infer_finish_kernel(const float* __restrict__ dur_pad, const float* __restrict__ pitch_pad, const float* __restrict__ energy_pad,
+                                    const int* __restrict__ lens, float pace, int Tt, int* __restrict__ durs, int* __restrict__ dec_lens,
+                                    float* __restrict__ dur_out, float* __restrict__ pitch_out, float* __restrict__ energy_out) {
+    __shared__ float sh[16];
+    const int b = blockIdx.x, Tp = Tt + 2;
+    float tot = 0.f;
+    for (int t = threadIdx.x; t < Tt; t += blockDim.x) {
+        const bool live = t < lens[b];
+        const float d = live ? dur_pad[b * Tp + t + 1] : 0.f;
+        const int rep = (int)(d * pace + 0.5f);
+        durs[b * Tt + t] = rep;
+        tot += (float)rep;
+        dur_out[b * Tt + t] = d;
+        pitch_out[b * Tt + t] = live ? pitch_pad[b * Tp + t + 1] : 0.f;
+        energy_out[b * Tt + t] = live ? energy_pad[b * Tp + t + 1] : 0.f;
+    }
+    tot = xva_block_sum(tot, sh);
+    if (threadIdx.x == 0) dec_lens[b] = (int)(tot + 0.5f);
+}
+extern "C" int xva_fp_infer_finish(const float* dur_pad, const float* pitch_pad, const float* energy_pad, const int32_t* lens, float pace, int B,
+                                   int Tt, int32_t* durs, int32_t* dec_lens, float* dur_out, float* pitch_out, float* energy_out, void* stream) {
+    XVA_CHECK_ARG(dur_pad && pitch_pad && energy_pad && lens && durs && dec_lens && dur_out && pitch_out && energy_out, "infer_finish: null");
+    hipLaunchKernelGGL(infer_finish_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dur_pad, pitch_pad, energy_pad, lens, pace, Tt, durs,
+                       dec_lens, dur_out, pitch_out, energy_out);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+// padded time-major mel (B, Tm + 2, C) in the activation dtype -> (B, C, Tm) fp32 (the layout inference hands to the vocoder)
+__global__ void mel_tm_to_bct_kernel(const void* __restrict__ in, int dt, float* __restrict__ out, int B, int Tm, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * C * Tm) return;
+    const int t = (int)(i % Tm), c = (int)((i / Tm) % C), b = (int)(i / ((int64_t)Tm * C));
+    out[i] = a_ld(in, ((int64_t)b * (Tm + 2) + t + 1) * C + c, dt);
+}
+extern "C" int xva_fp_mel_to_bct(const void* in, int dt, float* out, int B, int Tm, int C, void* stream) {
+    XVA_CHECK_ARG(in && out, "mel_to_bct: null");
+    hipLaunchKernelGGL(mel_tm_to_bct_kernel, dim3((unsigned)xva_cdiv((int64_t)B * C * Tm, 256)), dim3(256), 0, (hipStream_t)stream, in, dt, out, B, Tm, C);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}

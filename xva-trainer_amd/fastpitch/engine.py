@@ -45,6 +45,11 @@ lib.xva_fp_loss_partials.argtypes = [i32, i32] + [vp] * 10 + [i32, i32, i32, vp]
 lib.xva_fp_loss_grads.restype = i32
 lib.xva_fp_loss_grads.argtypes = [i32, i32] + [vp] * 15 + [i32, i32, i32, f32, f32, f32, f32, vp]
 
+lib.xva_fp_infer_encode.restype = i32
+lib.xva_fp_infer_encode.argtypes = [C.POINTER(FpDims), vp, C.POINTER(FpBatch), f32, f32, vp, i64, vp, vp, vp, vp, vp, vp, vp]
+lib.xva_fp_infer_decode.restype = i32
+lib.xva_fp_infer_decode.argtypes = [C.POINTER(FpDims), vp, vp, vp, vp, vp, i64, vp, vp]
+
 COMPUTE = {"fp32": 0, "bf16": 1, 0: 0, 1: 1}
 ACT_SLOTS = {"MEL_OUT", "D_MEL", "ENC_OUT", "DEC_OUT", "ENC_COND"}   # stored in the activation dtype (bf16 when compute == bf16)
 
@@ -196,6 +201,35 @@ class FastPitchEngine:
         losses = self.loss_grads(b, stage, grad_scale)
         self.backward(flat_params, flat_grads, b, stage)
         return losses
+
+    # -- inference (FastPitch.infer, model.py:426-481) -----------------------------------
+    def infer(self, flat_params, text, in_lens, pace=1.0, max_duration=75.0):
+        """text (B, Tt) int, in_lens (B).  Returns mel_out (B, 80, Tm) fp32, dec_lens (B) int64, dur_pred, pitch_pred (B, 1, Tt),
+        energy_pred (B, Tt).  Two C calls: the mel length is data dependent, so dec_lens crosses to the host in between."""
+        keep = self.p_dropout
+        self.p_dropout = 0.0
+        try:
+            text = text.to(torch.int32).contiguous()
+            in_lens = in_lens.to(device=self.device, dtype=torch.int32).contiguous()
+            B, Tt = text.shape
+            d = self._prepare(B, Tt, 1, 3)
+            dev = self.device
+            enc_cond = torch.empty(B, Tt + 2, 384, device=dev, dtype=self.act_dtype)
+            durs = torch.empty(B, Tt, device=dev, dtype=torch.int32)
+            dec_lens = torch.empty(B, device=dev, dtype=torch.int32)
+            dur, pitch, energy = (torch.empty(B, Tt, device=dev) for _ in range(3))
+            bt = FpBatch(_lib.ptr(text), _lib.ptr(in_lens), None, None, None, _lib.ptr(self._pos))
+            _lib.check(lib.xva_fp_infer_encode(C.byref(d), _lib.ptr(flat_params), C.byref(bt), float(pace), float(max_duration), _lib.ptr(self._ws),
+                                               self._ws.numel(), _lib.ptr(enc_cond), _lib.ptr(durs), _lib.ptr(dec_lens), _lib.ptr(dur), _lib.ptr(pitch),
+                                               _lib.ptr(energy), _lib.stream_ptr()), "xva_fp_infer_encode")
+            Tm = max(int(dec_lens.max().item()), 1)            # host sync: sizes the decoder pass
+            d = self._prepare(B, Tt, Tm, 3)
+            mel = torch.empty(B, 80, Tm, device=dev)
+            _lib.check(lib.xva_fp_infer_decode(C.byref(d), _lib.ptr(flat_params), _lib.ptr(enc_cond), _lib.ptr(durs), _lib.ptr(self._pos),
+                                               _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(mel), _lib.stream_ptr()), "xva_fp_infer_decode")
+            return mel, dec_lens.long(), dur, pitch.unsqueeze(1), energy
+        finally:
+            self.p_dropout = keep
 
     # -- views of outputs in the reference's shapes --------------------------------------
     def outputs(self, b, stage):

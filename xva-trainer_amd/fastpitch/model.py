@@ -120,6 +120,16 @@ class FastPitch(nn.Module):
                     getattr(self, k).copy_(sd[k].to(getattr(self, k)))
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
+    # ---- inference (model.py:426-481) ----
+    def infer(self, inputs, pace=1.0, dur_tgt=None, pitch_tgt=None, energy_tgt=None, pitch_transform=None, max_duration=75, speaker=0):
+        """Same signature and return tuple as the reference: (mel_out (B, 80, T), dec_lens, dur_pred, pitch_pred, energy_pred)."""
+        if dur_tgt is not None or pitch_tgt is not None or energy_tgt is not None or pitch_transform is not None or self.speaker_emb is not None:
+            raise NotImplementedError("infer supports predicted durations / pitch / energy, single speaker, no pitch transform")
+        _lib.require_cuda(inputs, self.flat)
+        in_lens = (inputs != 0).sum(dim=1)                     # encoder mask = non-padding symbols (transformer.py:216)
+        with torch.no_grad():
+            return self._get_engine().infer(self.flat.detach(), inputs, in_lens, pace, float(max_duration))
+
     # ---- forward (model.py:325-390) ----
     def forward(self, inputs_x, use_gt_pitch=True, use_dur_tgt=False, pace=1.0, max_duration=75):
         (inputs, input_lens, mel_tgt, mel_lens, pitch_dense, energy_dense, speaker, attn_prior, durs_padded, max_inp_lengths,
@@ -147,5 +157,3 @@ class FastPitch(nn.Module):
                     durs_padded, None, input_lens])
         return res
 
-    def infer(self, *args, **kwargs):
-        raise NotImplementedError("inference/export path is a 'next' row (SURVEY.md §8f N4)")
