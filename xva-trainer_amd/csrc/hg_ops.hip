@@ -7,6 +7,7 @@
 #include "xva_common.h"
 #include "../../include/xva_gemm.h"
 #include "../../include/xva_hip.h"
+#include "hg_wn.h"
 
 __device__ __forceinline__ float hg_ld(const void* p, int64_t i, int dt) {
     return dt == XVA_BF16 ? __uint_as_float(((uint32_t) reinterpret_cast<const uint16_t*>(p)[i]) << 16)
@@ -516,11 +517,10 @@ extern "C" int xva_hg_colsum(const void* X, int dt, float* out, int64_t rows, in
 //   kind 1 (ConvTranspose, v = (Cin, Cout, k)): effF[phase][co][m*Cin + ci]      = w[ci][co][j0(phase) + m*s]   (forward, per phase)
 //                                               effB[ci][j*Cout + co]            = w[ci][co][j]                  (backward-data conv)
 // One block per dim-0 index.  norm[o] saved for the backward.
-__global__ void hg_weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ gparam, void* __restrict__ eff,
-                                          void* __restrict__ effB, float* __restrict__ norm, int dt, int kind, int D0, int D1, int k, int s,
-                                          int pconv) {
+__device__ __forceinline__ void hg_weight_norm_fwd_body(const float* __restrict__ v, const float* __restrict__ gparam, void* __restrict__ eff,
+                                                        void* __restrict__ effB, float* __restrict__ norm, int dt, int kind, int D0, int D1, int k, int s,
+                                                        int pconv, int o) {
     __shared__ float sh[16];
-    const int o = blockIdx.x;
     const int inner = D1 * k;
     const float* vo = v + (int64_t)o * inner;
     float acc = 0.f;
@@ -545,13 +545,24 @@ __global__ void hg_weight_norm_fwd_kernel(const float* __restrict__ v, const flo
         }
     }
 }
+__global__ void hg_weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ gparam, void* __restrict__ eff,
+                                          void* __restrict__ effB, float* __restrict__ norm, int dt, int kind, int D0, int D1, int k, int s,
+                                          int pconv) {
+    hg_weight_norm_fwd_body(v, gparam, eff, effB, norm, dt, kind, D0, D1, k, s, pconv, blockIdx.x);
+}
+// Batched form: up to XVA_WN_BATCH layers per launch, one workgroup per (layer, dim-0 index); the descriptors travel as kernel arguments.
+__global__ void hg_weight_norm_fwd_batch_kernel(xva_wn_batch b) {
+    int l = 0;
+    while (l + 1 < b.n && (int)blockIdx.x >= b.d[l + 1].block0) ++l;
+    const xva_wn_desc& d = b.d[l];
+    hg_weight_norm_fwd_body(d.v, d.g, d.eff, d.effB, d.norm, d.dt, d.kind, d.D0, d.D1, d.k, d.s, d.pconv, (int)blockIdx.x - d.block0);
+}
 // dW: fp32 gradient of the effective weight in the layout: kind 0 tap-major [o][j*D1 + i] ; kind 1 [ci][j*Cout + co].
 // dg[o] = sum dW * v / ||v|| ; dv = (g/||v||) * (dW - (dg/||v||) * v)
-__global__ void hg_weight_norm_bwd_kernel(const float* __restrict__ dW, const float* __restrict__ v, const float* __restrict__ gparam,
-                                          const float* __restrict__ norm, float* __restrict__ dv, float* __restrict__ dg, int kind, int D0,
-                                          int D1, int k) {
+__device__ __forceinline__ void hg_weight_norm_bwd_body(const float* __restrict__ dW, const float* __restrict__ v, const float* __restrict__ gparam,
+                                                        const float* __restrict__ norm, float* __restrict__ dv, float* __restrict__ dg, int kind, int D0,
+                                                        int D1, int k, int o) {
     __shared__ float sh[16];
-    const int o = blockIdx.x;
     const int inner = D1 * k;
     const float* vo = v + (int64_t)o * inner;
     const float* dwo = dW + (int64_t)o * inner;
@@ -568,6 +579,39 @@ __global__ void hg_weight_norm_bwd_kernel(const float* __restrict__ dW, const fl
         int i1 = idx / k, j = idx % k;
         dv[(int64_t)o * inner + idx] += (g / n) * (dwo[(int64_t)j * D1 + i1] - (dgo / n) * vo[idx]);
     }
+}
+__global__ void hg_weight_norm_bwd_kernel(const float* __restrict__ dW, const float* __restrict__ v, const float* __restrict__ gparam,
+                                          const float* __restrict__ norm, float* __restrict__ dv, float* __restrict__ dg, int kind, int D0,
+                                          int D1, int k) {
+    hg_weight_norm_bwd_body(dW, v, gparam, norm, dv, dg, kind, D0, D1, k, blockIdx.x);
+}
+__global__ void hg_weight_norm_bwd_batch_kernel(xva_wn_batch b) {
+    int l = 0;
+    while (l + 1 < b.n && (int)blockIdx.x >= b.d[l + 1].block0) ++l;
+    const xva_wn_desc& d = b.d[l];
+    hg_weight_norm_bwd_body(d.dW, d.v, d.g, d.norm, d.dv, d.dg, d.kind, d.D0, d.D1, d.k, (int)blockIdx.x - d.block0);
+}
+// launches: `n` layers in chunks of XVA_WN_BATCH
+extern "C" int xva_hg_weight_norm_batch(const xva_wn_desc* descs, int n, int backward, void* stream) {
+    XVA_CHECK_ARG(descs || n == 0, "weight_norm_batch: null");
+    for (int i0 = 0; i0 < n; i0 += XVA_WN_BATCH) {
+        xva_wn_batch b;
+        b.n = n - i0 < XVA_WN_BATCH ? n - i0 : XVA_WN_BATCH;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.d[i] = descs[i0 + i];
+            XVA_CHECK_ARG(b.d[i].v && b.d[i].g && b.d[i].norm && (backward ? (b.d[i].dW && b.d[i].dv && b.d[i].dg) : (b.d[i].eff && (b.d[i].kind == 0 || b.d[i].effB))),
+                          "weight_norm_batch: null tensor in layer %d", i0 + i);
+            XVA_CHECK_ARG(backward || b.d[i].kind == 0 || (b.d[i].k % b.d[i].s == 0), "weight_norm_batch: transposed conv needs k %% s == 0");
+            b.d[i].block0 = blocks;
+            blocks += b.d[i].D0;
+        }
+        if (blocks == 0) continue;
+        if (backward) hipLaunchKernelGGL(hg_weight_norm_bwd_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+        else hipLaunchKernelGGL(hg_weight_norm_fwd_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
 }
 extern "C" int xva_hg_weight_norm_fwd(const float* v, const float* g, void* eff, void* effB, float* norm, int dt, int kind, int D0, int D1, int k,
                                       int s, int pconv, void* stream) {

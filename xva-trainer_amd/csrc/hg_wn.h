@@ -1,0 +1,14 @@
+// hg_wn.h — descriptors of the batched weight-norm launches (hg_ops.hip <-> hifigan_engine.hip; internal).
+// HiFi-GAN re-parametrises ~130 conv weights per forward (torch.nn.utils.weight_norm, models.py:21-108): one launch per tensor is
+// launch-latency bound (~8 us each), so the engine hands the kernel up to XVA_WN_BATCH layer descriptors as kernel arguments.
+#pragma once
+#include <stdint.h>
+#define XVA_WN_BATCH 40
+struct xva_wn_desc {
+    const float* v; const float* g; float* norm;
+    void* eff; void* effB;                 // forward outputs
+    const float* dW; float* dv; float* dg;  // backward
+    int32_t dt, kind, D0, D1, k, s, pconv, block0;
+};
+struct xva_wn_batch { int32_t n; xva_wn_desc d[XVA_WN_BATCH]; };
+extern "C" int xva_hg_weight_norm_batch(const xva_wn_desc* descs, int n, int backward, void* stream);

@@ -10,6 +10,7 @@
 // Parameters: two flat fp32 buffers in the checkpoint's own tensor layouts — G (generator) and D (mpd.* then msd.*,
 // trainable tensors first, then the spectral-norm power-iteration buffers).  Gradients mirror them.
 #include "hg_conv.h"
+#include "hg_wn.h"
 #include "../../include/xva_hip.h"
 #include <string>
 #include <vector>
@@ -186,6 +187,7 @@ struct Plan {
     int64_t wav_s[3][2];                // pooled waveforms (fp32): [scale][real/fake] ; scale 0 = the inputs themselves
     int64_t dwav_s[3];                  // gradient w.r.t. the (pooled) fake waveforms
     int Tw[3];
+    int64_t dw_g[2], dw_d[2];           // [begin, end) of the generator / discriminator effective-weight gradient regions
     int64_t sn_tmp, losses, skws, skws_bytes, total;
 };
 
@@ -209,10 +211,21 @@ void plan_layer_ws(Layer& l, Bump& b, int es, bool grads) {
         if (l.Cin == 1 || l.Cout == 1) l.eff32[p] = b.take(n * 4);
         l.norm[p] = b.take((l.kind == LK_SN ? 4 : l.D0()) * 4);
         if (l.kind == LK_SN) { l.su[p] = b.take(l.D0() * 4); l.sv[p] = b.take((int64_t)l.D1() * l.k * 4); }
-        if (grads) l.dweff[p] = b.take(n * 4);
-        if (l.Cin == 1) { l.wp[p] = b.take((int64_t)l.Cout * l.kp() * es + 64); l.dwp[p] = b.take((int64_t)l.Cout * l.kp() * 4); }
+        if (l.Cin == 1) l.wp[p] = b.take((int64_t)l.Cout * l.kp() * es + 64);
     }
     if (l.kind == LK_WNT) l.effB = b.take(n * es + 64);
+}
+// effective-weight gradients of one network in ONE contiguous region (zeroed by a single memset per backward)
+void plan_layer_grads(std::vector<Layer>& L, Bump& b, int64_t* begin, int64_t* end) {
+    *begin = b.cur;
+    for (auto& l : L) {
+        const int passes = l.kind == LK_SN ? 2 : 1;
+        for (int p = 0; p < passes; ++p) {
+            l.dweff[p] = b.take(l.wnumel() * 4);
+            if (l.Cin == 1) l.dwp[p] = b.take((int64_t)l.Cout * l.kp() * 4);
+        }
+    }
+    *end = b.cur;
 }
 
 int make_plan(const xva_hg_dims* d, Plan* p) {
@@ -226,6 +239,8 @@ int make_plan(const xva_hg_dims* d, Plan* p) {
     p->gl = gnet().L; p->dl = dnet().L;
     for (auto& l : p->gl) plan_layer_ws(l, b, es, true);
     for (auto& l : p->dl) plan_layer_ws(l, b, es, true);
+    plan_layer_grads(p->gl, b, &p->dw_g[0], &p->dw_g[1]);
+    plan_layer_grads(p->dl, b, &p->dw_d[0], &p->dw_d[1]);
     const int PG = 32;   // generator pad rows (>= max dilation * (k - 1) / 2 = 25)
     p->xin = mk(b, es, B, p->T[0], 80, PG, PG);
     p->h0 = mk(b, es, B, p->T[0], 512, PG, PG);
@@ -323,14 +338,24 @@ ConvTW ctw(const Ctx& c, const Layer& l, const float* params) {
 const float* eff32(const Ctx& c, const Layer& l, int pass) { return c.dt == XVA_F32 ? (const float*)(c.W + l.eff[pass]) : c.F(l.eff32[pass]); }
 // effective weights of weight-norm layers (and fp32 copies for the 1-channel direct kernels)
 int prep_wn(const Ctx& c, const std::vector<Layer>& L, const float* params) {
+    std::vector<xva_wn_desc> ds;
+    ds.reserve(L.size() + 8);
     for (const Layer& l : L) {
         if (l.kind == LK_SN) continue;
-        const int kind = l.kind == LK_WNT ? 1 : 0;
-        XVA_TRY(xva_hg_weight_norm_fwd(params + l.wv, params + l.wg, c.W + l.eff[0], l.effB >= 0 ? c.W + l.effB : nullptr, c.F(l.norm[0]), c.dt, kind,
-                                       l.D0(), l.D1(), l.k, l.s, l.P, c.st));
-        if (l.eff32[0] >= 0 && c.dt != XVA_F32)
-            XVA_TRY(xva_hg_weight_norm_fwd(params + l.wv, params + l.wg, c.W + l.eff32[0], nullptr, c.F(l.norm[0]), XVA_F32, 0, l.D0(), l.D1(), l.k,
-                                           l.s, l.P, c.st));
+        xva_wn_desc d;
+        memset(&d, 0, sizeof(d));
+        d.v = params + l.wv; d.g = params + l.wg; d.norm = c.F(l.norm[0]);
+        d.eff = c.W + l.eff[0]; d.effB = l.effB >= 0 ? c.W + l.effB : nullptr;
+        d.dt = c.dt; d.kind = l.kind == LK_WNT ? 1 : 0; d.D0 = l.D0(); d.D1 = l.D1(); d.k = l.k; d.s = l.s; d.pconv = l.P;
+        ds.push_back(d);
+        if (l.eff32[0] >= 0 && c.dt != XVA_F32) {   // fp32 copy for the 1-channel direct kernels
+            d.eff = c.W + l.eff32[0]; d.effB = nullptr; d.dt = XVA_F32; d.kind = 0;
+            ds.push_back(d);
+        }
+    }
+    XVA_TRY(xva_hg_weight_norm_batch(ds.data(), (int)ds.size(), 0, c.st));
+    for (const Layer& l : L) {
+        if (l.kind == LK_SN) continue;
         if (l.Cin == 1) XVA_TRY(xva_hg_pad_cols(eff32(c, l, 0), c.W + l.wp[0], c.dt, l.Cout, l.k, l.kp(), c.st));
     }
     return XVA_OK;
@@ -381,20 +406,21 @@ int gen_forward(Ctx& c, const float* P, const float* mel, float* wav_out) {
 }
 
 int wn_backward(Ctx& c, const std::vector<Layer>& L, const float* P, float* G) {
+    std::vector<xva_wn_desc> ds;
+    ds.reserve(L.size());
     for (const Layer& l : L) {
         if (l.kind == LK_SN) continue;
-        XVA_TRY(xva_hg_weight_norm_bwd(c.F(l.dweff[0]), P + l.wv, P + l.wg, c.F(l.norm[0]), G + l.wv, G + l.wg, l.kind == LK_WNT ? 1 : 0, l.D0(),
-                                       l.D1(), l.k, c.st));
+        xva_wn_desc d;
+        memset(&d, 0, sizeof(d));
+        d.dW = c.F(l.dweff[0]); d.v = P + l.wv; d.g = P + l.wg; d.norm = c.F(l.norm[0]); d.dv = G + l.wv; d.dg = G + l.wg;
+        d.kind = l.kind == LK_WNT ? 1 : 0; d.D0 = l.D0(); d.D1 = l.D1(); d.k = l.k;
+        ds.push_back(d);
     }
-    return XVA_OK;
+    return xva_hg_weight_norm_batch(ds.data(), (int)ds.size(), 1, c.st);
 }
 int zero_dweff(Ctx& c, const std::vector<Layer>& L) {
-    for (const Layer& l : L)
-        for (int p = 0; p < 2; ++p) {
-            if (l.dweff[p] >= 0) XVA_TRY(zero(c, c.W + l.dweff[p], l.wnumel() * 4));
-            if (l.dwp[p] >= 0) XVA_TRY(zero(c, c.W + l.dwp[p], (int64_t)l.Cout * l.kp() * 4));
-        }
-    return XVA_OK;
+    const int64_t* r = (&L == &c.pl.gl) ? c.pl.dw_g : c.pl.dw_d;
+    return zero(c, c.W + r[0], r[1] - r[0]);
 }
 // gradients of the padded first-layer weights -> the layer's dweff ([Cout][k], tap-major with Cin = 1)
 int fold_dwp(Ctx& c, const std::vector<Layer>& L) {
