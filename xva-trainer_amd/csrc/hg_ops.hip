@@ -322,14 +322,14 @@ __device__ __forceinline__ float hg_red_term(float av, float bv, int mode) {
     return av * av;
 }
 template <bool VEC>
-__global__ void hg_reduce_kernel(const void* __restrict__ a, const void* __restrict__ b, int dt, int Hp, int padF, int T, int C, int mode,
-                                 float scale, float* __restrict__ out) {
+__device__ __forceinline__ void hg_reduce_body(const void* __restrict__ a, const void* __restrict__ b, int dt, int Hp, int padF, int T, int C, int mode,
+                                               float scale, float* __restrict__ out, int bx, int by, int gx) {
     __shared__ float sh[16];
-    const int64_t base = ((int64_t)blockIdx.y * Hp + padF) * C;
+    const int64_t base = ((int64_t)by * Hp + padF) * C;
     const int64_t L = (int64_t)T * C;
     float acc = 0.f;
     if (VEC) {
-        for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < L; i += (int64_t)gridDim.x * blockDim.x * 8) {
+        for (int64_t i = ((int64_t)bx * blockDim.x + threadIdx.x) * 8; i < L; i += (int64_t)gx * blockDim.x * 8) {
             float av[8], bv[8];
             hg_ld8(a, base + i, dt, av);
             if (mode == 0) hg_ld8(b, base + i, dt, bv);
@@ -337,11 +337,26 @@ __global__ void hg_reduce_kernel(const void* __restrict__ a, const void* __restr
             for (int e = 0; e < 8; ++e) acc += hg_red_term(av[e], mode == 0 ? bv[e] : 0.f, mode);
         }
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x)
+        for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < L; i += (int64_t)gx * blockDim.x)
             acc += hg_red_term(hg_ld(a, base + i, dt), mode == 0 ? hg_ld(b, base + i, dt) : 0.f, mode);
     }
     acc = xva_block_sum(acc, sh);
     if (threadIdx.x == 0 && acc != 0.f) atomicAdd(out, acc * scale);
+}
+template <bool VEC>
+__global__ void hg_reduce_kernel(const void* __restrict__ a, const void* __restrict__ b, int dt, int Hp, int padF, int T, int C, int mode,
+                                 float scale, float* __restrict__ out) {
+    hg_reduce_body<VEC>(a, b, dt, Hp, padF, T, C, mode, scale, out, blockIdx.x, blockIdx.y, gridDim.x);
+}
+// many tensors, one launch: workgroup id -> (tensor, x, sequence)
+__global__ void hg_reduce_batch_kernel(xva_red_batch bt) {
+    int l = 0;
+    while (l + 1 < bt.n && (int)blockIdx.x >= bt.d[l + 1].block0) ++l;
+    const xva_red_desc& d = bt.d[l];
+    const int local = (int)blockIdx.x - d.block0;
+    const int bx = local % d.gx, by = local / d.gx;
+    if (d.vec) hg_reduce_body<true>(d.a, d.b, d.dt, d.Hp, d.padF, d.T, d.C, d.mode, d.scale, d.out, bx, by, d.gx);
+    else hg_reduce_body<false>(d.a, d.b, d.dt, d.Hp, d.padF, d.T, d.C, d.mode, d.scale, d.out, bx, by, d.gx);
 }
 static inline bool hg_vec8_ok(const void* p, int dt, int C, int T, int Hp, int padF) {
     const int es = dt == XVA_BF16 ? 2 : 4;
@@ -359,6 +374,30 @@ extern "C" int xva_hg_reduce(const void* a, const void* b, int dt, int nseq, int
     if (gx < 1) gx = 1;
     if (vec) hipLaunchKernelGGL((hg_reduce_kernel<true>), dim3(gx, nseq), dim3(256), 0, (hipStream_t)stream, a, b, dt, Hp, padF, T, C, mode, scale, out);
     else hipLaunchKernelGGL((hg_reduce_kernel<false>), dim3(gx, nseq), dim3(256), 0, (hipStream_t)stream, a, b, dt, Hp, padF, T, C, mode, scale, out);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_hg_reduce_batch(const xva_red_desc* descs, int n, void* stream) {
+    XVA_CHECK_ARG(descs || n == 0, "hg_reduce_batch: null");
+    for (int i0 = 0; i0 < n; i0 += XVA_RED_BATCH) {
+        xva_red_batch bt;
+        bt.n = n - i0 < XVA_RED_BATCH ? n - i0 : XVA_RED_BATCH;
+        int blocks = 0;
+        for (int i = 0; i < bt.n; ++i) {
+            xva_red_desc& d = bt.d[i];
+            d = descs[i0 + i];
+            XVA_CHECK_ARG(d.a && d.out && (d.mode != 0 || d.b) && d.nseq > 0 && d.T > 0, "hg_reduce_batch: bad descriptor %d", i0 + i);
+            const int64_t L = (int64_t)d.T * d.C;
+            d.vec = hg_vec8_ok(d.a, d.dt, d.C, d.T, d.Hp, d.padF) && hg_vec8_ok(d.b, d.dt, d.C, d.T, d.Hp, d.padF);
+            int gx = (int)((L / (d.vec ? 8 : 1) + 255) / 256);
+            const int cap = 512 / d.nseq > 1 ? 512 / d.nseq : 1;
+            if (gx > cap) gx = cap;
+            if (gx < 1) gx = 1;
+            d.gx = gx; d.block0 = blocks;
+            blocks += gx * d.nseq;
+        }
+        hipLaunchKernelGGL(hg_reduce_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt);
+    }
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }

@@ -12,3 +12,13 @@ struct xva_wn_desc {
 };
 struct xva_wn_batch { int32_t n; xva_wn_desc d[XVA_WN_BATCH]; };
 extern "C" int xva_hg_weight_norm_batch(const xva_wn_desc* descs, int n, int backward, void* stream);
+
+// Batched loss reductions (hg_reduce): one launch for all feature maps of a discriminator pass.
+#define XVA_RED_BATCH 48
+struct xva_red_desc {
+    const void* a; const void* b; float* out;
+    float scale;
+    int32_t dt, nseq, Hp, padF, T, C, mode, gx, vec, block0;
+};
+struct xva_red_batch { int32_t n; xva_red_desc d[XVA_RED_BATCH]; };
+extern "C" int xva_hg_reduce_batch(const xva_red_desc* descs, int n, void* stream);

@@ -619,18 +619,25 @@ int disc_backward_wave(Ctx& c, const float* Pd, const DiscRun& r, const SeqSpec*
 
 // loss sums: out[0] += mean((1-r)^2) + mean(g^2) (discriminator loss), out[1] += mean((1-g)^2) (generator loss),
 // out[2] += 2 * sum_l mean|r_l - g_l| (feature loss)
-int disc_losses(Ctx& c, const DiscRun& r, const SeqSpec* rt, int r0, int f0, int nf, float* out) {
+// (the reductions of all discriminators are collected and issued as one batched launch by the caller)
+void disc_losses(Ctx& c, const DiscRun& r, const SeqSpec* rt, int r0, int f0, int nf, float* out, std::vector<xva_red_desc>& reds) {
+    auto add = [&](const Seq& a, const Seq* b, const Seq& geo, int mode, float scale, float* dst) {
+        xva_red_desc d;
+        memset(&d, 0, sizeof(d));
+        d.a = a.ptr(); d.b = b ? b->ptr() : nullptr; d.out = dst; d.scale = scale;
+        d.dt = c.dt; d.nseq = nf; d.Hp = geo.Hp(); d.padF = geo.padF; d.T = geo.T; d.C = geo.C; d.mode = mode;
+        reds.push_back(d);
+    };
     for (int i = 1; i <= r.n; ++i) {
         Seq g = c.S(r.t[i]).slice(f0, nf), rr = c.S(rt[i]).slice(r0, nf);
         const float inv = 1.f / (float)((int64_t)nf * g.T * g.C);
-        XVA_TRY(xva_hg_reduce(rr.ptr(), g.ptr(), c.dt, nf, g.Hp(), g.padF, g.T, g.C, 0, 2.f * inv, out + 2, c.st));
+        add(rr, &g, g, 0, 2.f * inv, out + 2);
         if (i == r.n) {
-            XVA_TRY(xva_hg_reduce(rr.ptr(), nullptr, c.dt, nf, g.Hp(), g.padF, g.T, g.C, 1, inv, out + 0, c.st));
-            XVA_TRY(xva_hg_reduce(g.ptr(), nullptr, c.dt, nf, g.Hp(), g.padF, g.T, g.C, 2, inv, out + 0, c.st));
-            XVA_TRY(xva_hg_reduce(g.ptr(), nullptr, c.dt, nf, g.Hp(), g.padF, g.T, g.C, 1, inv, out + 1, c.st));
+            add(rr, nullptr, g, 1, inv, out + 0);
+            add(g, nullptr, g, 2, inv, out + 0);
+            add(g, nullptr, g, 1, inv, out + 1);
         }
     }
-    return XVA_OK;
 }
 
 struct DiscSet { DiscRun run; const SeqSpec* rt; int r0, f0, nf; bool sn; const float* wr; const float* wg; int nb; };
@@ -671,6 +678,7 @@ int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* lo
     XVA_TRY(prep_wn(c, c.pl.dl, Pd));
     XVA_TRY(pool_waves(c, yr, yg));
     std::vector<DiscSet> sets; std::vector<DiscRun> snr;
+    std::vector<xva_red_desc> reds;
     build_sets(c, yr, yg, sets, snr);
     if (losses) XVA_TRY(zero(c, losses, 4 * sizeof(float)));
     for (auto& s : sets) {
@@ -693,8 +701,9 @@ int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* lo
                 XVA_TRY(hg_conv_fwd(x, y, cw(c, L[s.run.li[i]], Pd, 0), e, c.compute, c.st));
             }
         }
-        if (losses) XVA_TRY(disc_losses(c, s.run, s.rt, s.r0, s.f0, s.nf, losses));
+        if (losses) disc_losses(c, s.run, s.rt, s.r0, s.f0, s.nf, losses, reds);
     }
+    if (!reds.empty()) XVA_TRY(xva_hg_reduce_batch(reds.data(), (int)reds.size(), c.st));
     return XVA_OK;
 }
 
