@@ -500,11 +500,12 @@ __global__ void hg_colsum_kernel(const void* __restrict__ X, int dt, float* __re
 }
 // column pairs: a wave reads 128 adjacent columns (4-byte / 8-byte accesses), two rows in flight
 // Narrow tensors are FOLDED by the host: f consecutive rows of Creal channels are read as one row of C = f * Creal columns.
-__global__ void hg_colsum2_kernel(const void* __restrict__ X, int dt, float* __restrict__ out, int64_t rows, int C, int rows_per_block, float scale, int Creal) {
+__device__ __forceinline__ void hg_colsum2_body(const void* __restrict__ X, int dt, float* __restrict__ out, int64_t rows, int C, int rows_per_block, float scale, int Creal,
+                                                int bx, int by) {
     __shared__ float sh[4][128];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = blockIdx.x * 128 + 2 * lane;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int c = bx * 128 + 2 * lane;
+    const int64_t r0 = (int64_t)by * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float a0 = 0.f, a1 = 0.f;
     if (c < C) {
@@ -525,9 +526,19 @@ __global__ void hg_colsum2_kernel(const void* __restrict__ X, int dt, float* __r
     sh[w][2 * lane] = a0; sh[w][2 * lane + 1] = a1;
     __syncthreads();
     if (threadIdx.x < 128) {
-        const int cc = blockIdx.x * 128 + threadIdx.x;
+        const int cc = bx * 128 + threadIdx.x;
         if (cc < C) atomicAdd(out + (cc % Creal), scale * (sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]));
     }
+}
+__global__ void hg_colsum2_kernel(const void* __restrict__ X, int dt, float* __restrict__ out, int64_t rows, int C, int rows_per_block, float scale, int Creal) {
+    hg_colsum2_body(X, dt, out, rows, C, rows_per_block, scale, Creal, blockIdx.x, blockIdx.y);
+}
+__global__ void hg_colsum2_batch_kernel(xva_cs_batch bt) {
+    int l = 0;
+    while (l + 1 < bt.n && (int)blockIdx.x >= bt.d[l + 1].block0) ++l;
+    const xva_cs_desc& d = bt.d[l];
+    const int local = (int)blockIdx.x - d.block0;
+    hg_colsum2_body(d.X, d.dt, d.out, d.rows, d.C, d.rpb, d.scale, d.Creal, local % d.cb, local / d.cb);
 }
 extern "C" int xva_hg_colsum(const void* X, int dt, float* out, int64_t rows, int C, float scale, void* stream) {
     XVA_CHECK_ARG(X && out, "hg_colsum: null");
@@ -545,6 +556,37 @@ extern "C" int xva_hg_colsum(const void* X, int dt, float* out, int64_t rows, in
     }
     const int rpb = 512;
     hipLaunchKernelGGL(hg_colsum_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, X, dt, out, rows, C, rpb, scale);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// several tensors, one launch (tensors that do not fit the paired-column form go through the single-tensor entry point)
+extern "C" int xva_hg_colsum_batch(const xva_cs_desc* descs, int n, void* stream) {
+    XVA_CHECK_ARG(descs || n == 0, "hg_colsum_batch: null");
+    xva_cs_batch bt;
+    bt.n = 0;
+    int blocks = 0;
+    auto flush = [&]() {
+        if (bt.n > 0) hipLaunchKernelGGL(hg_colsum2_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt);
+        bt.n = 0; blocks = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+        xva_cs_desc d = descs[i];
+        XVA_CHECK_ARG(d.X && d.out, "hg_colsum_batch: null tensor %d", i);
+        if (d.rows <= 0) continue;
+        if (!(d.C % 2 == 0 && ((uintptr_t)d.X % 8) == 0)) { XVA_TRY(xva_hg_colsum(d.X, d.dt, d.out, d.rows, d.C, d.scale, stream)); continue; }
+        d.Creal = d.C;
+        while (d.C * 2 <= 128 && d.rows % 2 == 0) { d.C *= 2; d.rows /= 2; }
+        d.cb = xva_cdiv(d.C, 128);
+        int rpb = (int)xva_cdiv(d.rows, xva_cdiv(256, d.cb) > 16 ? xva_cdiv(256, d.cb) : 16);
+        if (rpb < 64) rpb = 64;
+        d.rpb = rpb;
+        d.block0 = blocks;
+        blocks += d.cb * (int)xva_cdiv(d.rows, rpb);
+        bt.d[bt.n++] = d;
+        if (bt.n == XVA_CS_BATCH) flush();
+    }
+    flush();
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }

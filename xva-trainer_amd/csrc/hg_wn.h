@@ -22,3 +22,9 @@ struct xva_red_desc {
 };
 struct xva_red_batch { int32_t n; xva_red_desc d[XVA_RED_BATCH]; };
 extern "C" int xva_hg_reduce_batch(const xva_red_desc* descs, int n, void* stream);
+
+// Batched bias-gradient column sums (hg_colsum2): all layers of a discriminator backward in one launch.
+#define XVA_CS_BATCH 64
+struct xva_cs_desc { const void* X; float* out; int64_t rows; float scale; int32_t dt, C, Creal, rpb, cb, block0; };
+struct xva_cs_batch { int32_t n; xva_cs_desc d[XVA_CS_BATCH]; };
+extern "C" int xva_hg_colsum_batch(const xva_cs_desc* descs, int n, void* stream);

@@ -564,7 +564,13 @@ int disc_forward(Ctx& c, const float* Pd, const DiscRun& r, const float* wav, in
 
 // D-step backward over sequences [i0, i0+ni): d[n] (score gradient) must be seeded.  Accumulates dweff / bias grads.
 // wav_a / wav_b: the waveforms feeding the first / second half of the slice (nb_a + nb_b items); wav_b may be null.
-int disc_backward_params(Ctx& c, const float* Pd, float* Gd, const DiscRun& r, int i0, int ni, const float* wav_a, int nb_a, const float* wav_b) {
+int disc_backward_params(Ctx& c, const float* Pd, float* Gd, const DiscRun& r, int i0, int ni, const float* wav_a, int nb_a, const float* wav_b,
+                         std::vector<xva_cs_desc>& colsums) {
+    auto defer_colsum = [&](const Seq& t, float* out) {   // the gradient tensors persist: bias gradients are summed in one batched launch later
+        xva_cs_desc d; memset(&d, 0, sizeof(d));
+        d.X = t.ptr(); d.out = out; d.rows = t.rows(); d.scale = 1.f; d.dt = c.dt; d.C = t.C;
+        colsums.push_back(d);
+    };
     const auto& L = c.pl.dl;
     for (int i = r.n - 1; i >= 1; --i) {
         const Layer& l = L[r.li[i]];
@@ -576,7 +582,7 @@ int disc_backward_params(Ctx& c, const float* Pd, float* Gd, const DiscRun& r, i
         } else {
             ConvW w = cw(c, l, Pd, r.pass);
             XVA_TRY(hg_conv_bwd_weight(dy, x, w, 0, 0.f, 1.f, c.compute, c.st));
-            XVA_TRY(xva_hg_colsum(dy.ptr(), c.dt, Gd + l.bias, dy.rows(), dy.C, 1.f, c.st));
+            defer_colsum(dy, Gd + l.bias);
             BwdEpi b; b.gate = &x; b.gate_slope = SLOPE;
             XVA_TRY(hg_conv_bwd_data(dy, dx, w, b, c.compute, c.st));
         }
@@ -585,7 +591,7 @@ int disc_backward_params(Ctx& c, const float* Pd, float* Gd, const DiscRun& r, i
     Seq d1 = c.S(r.d[1]).slice(i0, ni), xc = c.S(r.xc[0]).slice(i0, ni);
     (void)wav_a; (void)nb_a; (void)wav_b;   // the im2col of both waveforms is already in xc (forward)
     XVA_TRY(hg_conv_bwd_weight(d1, xc, cw0(c, l0, Pd, r.pass), 0, 0.f, 1.f, c.compute, c.st));
-    XVA_TRY(xva_hg_colsum(d1.ptr(), c.dt, Gd + l0.bias, d1.rows(), d1.C, 1.f, c.st));
+    defer_colsum(d1, Gd + l0.bias);
     return XVA_OK;
 }
 
@@ -711,6 +717,7 @@ int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* lo
 int discs_backward_d(Ctx& c, float* Pd, float* Gd, const float* yr, const float* yg) {
     std::vector<DiscSet> sets; std::vector<DiscRun> snr;
     build_sets(c, yr, yg, sets, snr);
+    std::vector<xva_cs_desc> colsums;
     XVA_TRY(zero_dweff(c, c.pl.dl));
     for (auto& s : sets) {
         const int n = s.run.n;
@@ -721,14 +728,15 @@ int discs_backward_d(Ctx& c, float* Pd, float* Gd, const float* yr, const float*
             DiscRun rr = snr[0];
             Seq r = c.S(rr.t[n]), dr = c.S(rr.d[n]);
             XVA_TRY(xva_hg_seed_grad(r.ptr(), nullptr, dr.ptr(), c.dt, s.nf, r.Hp(), r.padF, r.T, 1, 0.f, inv, 3, 0, 0.f, 1, c.st));
-            XVA_TRY(disc_backward_params(c, Pd, Gd, rr, 0, s.nf, s.wr, s.nb, nullptr));
-            XVA_TRY(disc_backward_params(c, Pd, Gd, s.run, 0, s.nf, s.wg, s.nb, nullptr));
+            XVA_TRY(disc_backward_params(c, Pd, Gd, rr, 0, s.nf, s.wr, s.nb, nullptr, colsums));
+            XVA_TRY(disc_backward_params(c, Pd, Gd, s.run, 0, s.nf, s.wg, s.nb, nullptr, colsums));
         } else {
             Seq r = c.S(s.run.t[n]).slice(s.r0, s.nf), dr = c.S(s.run.d[n]).slice(s.r0, s.nf);
             XVA_TRY(xva_hg_seed_grad(r.ptr(), nullptr, dr.ptr(), c.dt, s.nf, r.Hp(), r.padF, r.T, 1, 0.f, inv, 3, 0, 0.f, 1, c.st));
-            XVA_TRY(disc_backward_params(c, Pd, Gd, s.run, 0, 2 * s.nf, s.wr, s.nb, s.wg));
+            XVA_TRY(disc_backward_params(c, Pd, Gd, s.run, 0, 2 * s.nf, s.wr, s.nb, s.wg, colsums));
         }
     }
+    XVA_TRY(xva_hg_colsum_batch(colsums.data(), (int)colsums.size(), c.st));
     XVA_TRY(fold_dwp(c, c.pl.dl));
     XVA_TRY(wn_backward(c, c.pl.dl, Pd, Gd));
     for (const Layer& l : c.pl.dl) {
