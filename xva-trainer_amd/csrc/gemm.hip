@@ -59,7 +59,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     int nkt = xva_cdiv(p.K, 32);
     if (p.splitk > nkt && nkt > 0) p.splitk = nkt;
     int bn = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
-    {   // general kernel: narrower column tiles when the grid would leave most of the 256 CUs idle
+    if (!auto_sk) {   // general kernel: narrower column tiles when the grid would leave most of the 256 CUs idle (split-K fills it otherwise)
         const long nb = (long)p.batch * p.batch2 * p.splitk;
         while (bn > 32 && (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * nb < 256) bn >>= 1;
     }
