@@ -14,7 +14,7 @@ def _lib():
     return _lib
 
 
-@pytest.fixture(params=[1, 2, 3, 4, -1, 6], ids=["tile128", "tile256", "tile128x64", "tile64", "auto", "auto_no_resident_conv"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, -1, 6], ids=["tile128", "tile256", "tile128x64", "tile64", "tile128x32", "auto", "auto_no_resident_conv"])
 def mainloop(request):
     L = _lib()
     old = L.lib.xva_gemm_set_mainloop(request.param)
@@ -47,7 +47,7 @@ def test_nt_ragged(mainloop, M, N, K):
     assert C16[:, N:].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 200, 256), (130, 136, 864), (1000, 520, 328), (257, 72, 1000), (700, 64, 384), (96, 40, 640)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 256), (130, 136, 864), (1000, 520, 328), (257, 72, 1000), (700, 64, 384), (96, 40, 640), (1000, 32, 448), (520, 16, 192)])
 def test_nn_and_tn_ragged(mainloop, M, N, K):
     L = _lib()
     torch.manual_seed(M * 3 + N + K)
