@@ -207,6 +207,108 @@ def forward(sd, batch, stage, taps=None, drop=None):
             batch["in_lens"]]
 
 
+# ---- stage 1: the aligner (ConvAttention + monotonic alignment search + forward-sum / CTC loss) -------------------------------
+def beta_binomial_prior(phoneme_count, mel_count, scaling=1.0):
+    """data_function.py:84-94: the (mel_count, phoneme_count) beta-binomial attention prior of one utterance."""
+    import numpy as np
+    from scipy.stats import betabinom
+    x = np.arange(0, phoneme_count)
+    rows = [betabinom(phoneme_count, scaling * i, scaling * (mel_count + 1 - i)).pmf(x) for i in range(1, mel_count + 1)]
+    return torch.tensor(np.array(rows))
+
+
+def attn_prior_batch(in_lens, mel_lens, dtype=torch.float32):
+    """TTSCollate (data_function.py:600-609): zero-padded (B, max_mel, max_text) stack of the per-item priors."""
+    B = in_lens.numel()
+    out = torch.zeros(B, int(mel_lens.max()), int(in_lens.max()), dtype=dtype)
+    for b in range(B):
+        L, M = int(in_lens[b]), int(mel_lens[b])
+        out[b, :M, :L] = beta_binomial_prior(L, M).to(dtype)
+    return out
+
+
+def conv_attention(sd, queries, keys, key_pad_mask, attn_prior, pre="attention."):
+    """ConvAttention.forward (attention.py:171-220), align_query_enc_type '3xconv'.  queries (B, 80, T1) mel, keys (B, 384, T2)
+    text embeddings, key_pad_mask (B, T2) True on padding.  Returns attn (B, 1, T1, T2) and attn_logprob."""
+    k = F.conv1d(keys, sd[pre + "key_proj.0.conv.weight"], sd[pre + "key_proj.0.conv.bias"], padding=1)
+    k = F.conv1d(F.relu(k), sd[pre + "key_proj.2.conv.weight"], sd[pre + "key_proj.2.conv.bias"])
+    q = F.conv1d(queries, sd[pre + "query_proj.0.conv.weight"], sd[pre + "query_proj.0.conv.bias"], padding=1)
+    q = F.conv1d(F.relu(q), sd[pre + "query_proj.2.conv.weight"], sd[pre + "query_proj.2.conv.bias"])
+    q = F.conv1d(F.relu(q), sd[pre + "query_proj.4.conv.weight"], sd[pre + "query_proj.4.conv.bias"])
+    attn = (q[:, :, :, None] - k[:, :, None]) ** 2
+    attn = -0.0005 * attn.sum(1, keepdim=True)
+    attn = F.log_softmax(attn, dim=3) + torch.log(attn_prior[:, None] + 1e-8)
+    attn_logprob = attn.clone()
+    attn = attn.masked_fill(key_pad_mask[:, None, None, :], -float("inf"))
+    return F.softmax(attn, dim=3), attn_logprob
+
+
+def mas_width1(attn_map):
+    """alignment.py:76-104 (numpy): monotonic alignment search over a (mel, text) probability map; ties prefer the diagonal."""
+    import numpy as np
+    opt = np.zeros_like(attn_map)
+    with np.errstate(divide="ignore"):
+        lm = np.log(attn_map)
+    lm[0, 1:] = -np.inf
+    log_p = np.zeros_like(lm)
+    log_p[0, :] = lm[0, :]
+    prev_ind = np.zeros(lm.shape, dtype=np.int64)
+    for i in range(1, lm.shape[0]):
+        prev = log_p[i - 1]
+        shifted = np.concatenate([[-np.inf], prev[:-1]])
+        take_diag = shifted >= prev
+        take_diag[0] = False
+        log_p[i] = lm[i] + np.where(take_diag, shifted, prev)
+        prev_ind[i] = np.arange(lm.shape[1]) - take_diag.astype(np.int64)
+    cur = lm.shape[1] - 1
+    for i in range(lm.shape[0] - 1, -1, -1):
+        opt[i, cur] = 1
+        cur = prev_ind[i, cur]
+    opt[0, cur] = 1
+    return opt
+
+
+def binarize_attention(attn, in_lens, out_lens):
+    """model.py:283-295 (b_mas): hard alignment of every item, zero outside its (out_len, in_len) block."""
+    a = attn.detach().cpu().numpy()
+    import numpy as np
+    out = np.zeros_like(a)
+    for b in range(a.shape[0]):
+        L, M = int(in_lens[b]), int(out_lens[b])
+        out[b, 0, :M, :L] = mas_width1(a[b, 0, :M, :L])
+    return torch.from_numpy(out)
+
+
+def attention_ctc_loss(attn_logprob, in_lens, out_lens, blank_logprob=-1.0):
+    """AttentionCTCLoss (attn_loss_function.py:20-44): per item, log-softmax over [blank, keys 1..L] and nn.CTCLoss(mean) against the
+    identity target 1..L; averaged over the batch."""
+    padded = F.pad(attn_logprob, (1, 0, 0, 0, 0, 0, 0, 0), value=blank_logprob)
+    total = 0.0
+    for b in range(attn_logprob.shape[0]):
+        L, M = int(in_lens[b]), int(out_lens[b])
+        target = torch.arange(1, L + 1).unsqueeze(0)
+        lp = padded[b].permute(1, 0, 2)[:M, :, :L + 1]
+        lp = F.log_softmax(lp[None], dim=3)[0]
+        total = total + F.ctc_loss(lp, target, input_lengths=torch.tensor([M]), target_lengths=torch.tensor([L]), zero_infinity=True)
+    return total / attn_logprob.shape[0]
+
+
+def forward_stage1(sd, batch):
+    """FastPitch.forward with training_stage == 1 (model.py:346-360) -> (attn_hard_dur, attn_soft, attn_hard, attn_logprob)."""
+    text = batch["text"]
+    text_emb = F.embedding(text, sd["encoder.word_emb.weight"], padding_idx=0)
+    key_pad = ~mask_from_lens(batch["in_lens"], text.size(1))
+    attn_soft, attn_logprob = conv_attention(sd, batch["mel_tgt"], text_emb.permute(0, 2, 1), key_pad, batch["attn_prior"])
+    attn_hard = binarize_attention(attn_soft, batch["in_lens"], batch["mel_lens"])
+    attn_hard_dur = attn_hard.sum(2)[:, 0, :]
+    return attn_hard_dur, attn_soft, attn_hard, attn_logprob
+
+
+def loss_stage1(attn_logprob, batch, attn_loss_scale=1.0):
+    """FastPitchLoss.forward, training_stage == 1 (loss_function.py:73-81)."""
+    return attention_ctc_loss(attn_logprob, batch["in_lens"], batch["mel_lens"]) * attn_loss_scale
+
+
 def infer(sd, text, pace=1.0, max_duration=75):
     """FastPitch.infer (model.py:426-481) with predicted durations / pitch / energy, no speaker embedding, no pitch transform.
     text: (B, Tt) int64, zero-padded.  Returns (mel_out (B, 80, Tm), dec_lens, dur_pred, pitch_pred (B, 1, Tt), energy_pred)."""

@@ -49,6 +49,9 @@ def main():
     if "fastpitch_infer" in which or "fastpitch" in which:
         from oracle import gen_golden_fastpitch
         gen_golden_fastpitch.generate_infer(ns, OUT)
+    if "fastpitch_stage1" in which or "fastpitch" in which:
+        from oracle import gen_golden_fastpitch
+        gen_golden_fastpitch.generate_stage1(ns, OUT)
     if "hifigan" in which:
         from oracle import gen_golden_hifigan
         gen_golden_hifigan.generate(ns, OUT)

@@ -124,3 +124,69 @@ def generate_infer(ns, out_dir):
     np.savez_compressed(os.path.join(out_dir, "fp_infer_small.npz"), seed=np.int64(seed), dur_bias_shift=np.float64(1.6), text=text.numpy(),
                         mel_out=mel.numpy(), dec_lens=dec_lens.numpy(), dur_pred=dur.numpy(), pitch_pred=pitch.numpy(), energy_pred=energy.numpy())
     print("fp_infer_small: mel", tuple(mel.shape), "dec_lens", dec_lens.tolist())
+
+
+def generate_stage1(ns, out_dir):
+    """Stage 1: reference FastPitch(training_stage = 1) + FastPitchLoss on a seeded batch with the reference's own
+    beta-binomial prior; records attention maps, MAS durations, the CTC loss and the gradients it sends into the aligner."""
+    import importlib
+    seed, B, Tt, Tm = 777, 3, 12, 40
+    sd = ofp.init_state_dict(seed)
+    batch = ofp.synth_batch(B, Tt, Tm, seed + 1)
+    try:   # the reference's own prior (data_function.py:84-94) when its module imports here; else the oracle's restatement of it
+        df = importlib.import_module("python.fastpitch1_1.fastpitch.data_function")
+        prior_fn, prior_src = df.beta_binomial_prior_distribution, "reference"
+    except Exception as e:
+        print("data_function not importable (%s): using the oracle's scipy.stats.betabinom restatement" % type(e).__name__)
+        prior_fn, prior_src = ofp.beta_binomial_prior, "oracle"
+    prior = torch.zeros(B, int(batch["mel_lens"].max()), Tt)
+    for b in range(B):
+        L, M = int(batch["in_lens"][b]), int(batch["mel_lens"][b])
+        prior[b, :M, :L] = prior_fn(L, M).float()
+    batch["attn_prior"] = prior
+    assert torch.allclose(ofp.attn_prior_batch(batch["in_lens"], batch["mel_lens"]), prior, atol=1e-7)
+    model = ns.FastPitch()
+    model.load_state_dict(sd)
+    model.eval()
+    model.training_stage = torch.tensor(1)
+    # binarize_attention_parallel (model.py:283-295) ends in `.to(attn.get_device())`, which is -1 on CPU: same two lines around the
+    # reference's own b_mas, minus the device move
+    import types
+    ref_alignment = importlib.import_module("python.fastpitch1_1.fastpitch.alignment")
+
+    def _binarize(self, attn, in_lens, out_lens):
+        with torch.no_grad():
+            out = ref_alignment.b_mas(attn.data.cpu().numpy(), in_lens.cpu().numpy(), out_lens.cpu().numpy(), width=1)
+            return torch.from_numpy(out)
+    model.binarize_attention_parallel = types.MethodType(_binarize, model)
+    crit = ns.loss_function.FastPitchLoss(dur_predictor_loss_scale=0.1, pitch_predictor_loss_scale=0.1, attn_loss_scale=1.0)
+    x = (batch["text"], batch["in_lens"], batch["mel_tgt"], batch["mel_lens"], batch["pitch"], batch["energy"], None, prior, batch["durs"],
+         torch.full((B,), Tt, dtype=torch.long), torch.full((B,), int(batch["mel_lens"].max()), dtype=torch.long), None)
+    y = [batch["mel_tgt"], batch["in_lens"], batch["mel_lens"], x[9]]
+    y_pred = model(x)
+    loss, meta, _ = crit(y_pred, y, training_stage=1)
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None and p.grad.abs().max() > 0}
+    # the oracle restatement against the live reference
+    names = [k for k in sd if k.startswith("attention.") or k == "encoder.word_emb.weight"]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd); work.update(leaves)
+    dur, soft, hard, logprob = ofp.forward_stage1(work, batch)
+    o_loss = ofp.loss_stage1(logprob, batch)
+    o_loss.backward()
+    assert abs(float(o_loss) - float(loss)) < 1e-5 * abs(float(loss)), (float(o_loss), float(loss))
+    assert torch.allclose(soft, y_pred[8], rtol=1e-5, atol=1e-7) and torch.equal(hard, y_pred[9]) and torch.equal(dur, y_pred[10])
+    assert torch.allclose(logprob, y_pred[11], rtol=1e-5, atol=1e-6)
+    for k, g in grads.items():
+        assert torch.allclose(leaves[k].grad, g, rtol=1e-4, atol=1e-8), k
+    keys = sorted(grads)
+    rec = {"seed": np.int64(seed), "loss": np.float64(float(loss)), "attn_soft": y_pred[8].detach().numpy(), "attn_hard_dur": y_pred[10].numpy(),
+           "attn_logprob": y_pred[11].detach().numpy(), "grad_keys": np.array(keys),
+           "grad_l2": np.array([float(grads[k].double().norm()) for k in keys]),
+           "g_key_proj2_w": grads["attention.key_proj.2.conv.weight"].numpy(), "g_query_proj4_w": grads["attention.query_proj.4.conv.weight"].numpy(),
+           "g_word_emb": grads["encoder.word_emb.weight"].numpy(), "attn_prior": prior.numpy(), "prior_source": np.array(prior_src)}
+    for k, v in batch.items():
+        if k != "attn_prior":
+            rec["in_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(out_dir, "fp_stage1_small.npz"), **rec)
+    print("fp_stage1_small: loss", float(loss), "durs", y_pred[10].sum(1).tolist(), "grads", keys)

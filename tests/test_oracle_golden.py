@@ -95,3 +95,28 @@ def test_hifigan_oracle_matches_reference_golden(golden_dir):
     for k, l2 in zip(g["d_grad_keys"], g["d_grad_l2"]):
         assert abs(float(d_grads[str(k)].double().norm()) - l2) <= 2e-3 * max(l2, 1e-12), k
     assert torch.allclose(msd_sd["discriminators.0.convs.0.weight_u"], torch.from_numpy(g["msd_u0_after"]), rtol=1e-4, atol=1e-6)
+
+
+def test_fastpitch_stage1_oracle_matches_reference_golden(golden_dir):
+    """Stage-1 aligner (ConvAttention + MAS + forward-sum / CTC loss): the oracle against vectors recorded from the reference classes."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import fastpitch as ofp
+    g = np.load(os.path.join(golden_dir, "fp_stage1_small.npz"))
+    sd = ofp.init_state_dict(int(g["seed"]))
+    batch = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+    batch["attn_prior"] = torch.from_numpy(g["attn_prior"])
+    assert torch.allclose(ofp.attn_prior_batch(batch["in_lens"], batch["mel_lens"]), batch["attn_prior"], atol=1e-7)
+    names = [k for k in sd if k.startswith("attention.") or k == "encoder.word_emb.weight"]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd); work.update(leaves)
+    dur, soft, hard, logprob = ofp.forward_stage1(work, batch)
+    loss = ofp.loss_stage1(logprob, batch)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    assert torch.allclose(soft, torch.from_numpy(g["attn_soft"]), rtol=1e-5, atol=1e-7)
+    assert torch.equal(dur, torch.from_numpy(g["attn_hard_dur"]))
+    for k, l2 in zip(g["grad_keys"], g["grad_l2"]):
+        assert abs(leaves[str(k)].grad.double().norm().item() - l2) < 1e-4 * l2, k
+    assert torch.allclose(leaves["encoder.word_emb.weight"].grad, torch.from_numpy(g["g_word_emb"]), rtol=1e-4, atol=1e-8)
