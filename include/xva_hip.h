@@ -150,6 +150,40 @@ int xva_fp_infer_finish(const float* dur_pad, const float* pitch_pad, const floa
                         int32_t* durs, int32_t* dec_lens, float* dur_out, float* pitch_out, float* energy_out, void* stream);
 int xva_fp_mel_to_bct(const void* in, int dt, float* out, int B, int Tm, int C, void* stream);
 
+/* Training stage 1 — the aligner (python/fastpitch1_1/fastpitch/model.py:296-323,346-360; attention.py:171-220; alignment.py:76-118;
+ * attn_loss_function.py:20-44; loss_function.py:73-81): text embeddings and the target mel go through ConvAttention's key / query
+ * projections, attn = log_softmax(-0.0005 ||q - k||^2) + log(prior + 1e-8); soft = softmax over the valid keys; monotonic
+ * alignment search gives the hard durations; loss = forward-sum (CTC, blank log-prob -1) / B.  fp32 storage; `compute` picks the
+ * MFMA pipe of the GEMMs.  Gradients reach attention.* and encoder.word_emb only. */
+typedef struct xva_fp_align_batch {
+    const int32_t* text;      /* (B, Tt) */
+    const int32_t* in_lens;   /* (B) */
+    const float* mel;         /* (B, 80, Tm) zero padded */
+    const int32_t* mel_lens;  /* (B) */
+    const float* attn_prior;  /* (B, Tm, Tt) beta-binomial prior, zero padded (data_function.py:84-94,600-609) */
+} xva_fp_align_batch;
+int64_t xva_fp_align_workspace_bytes(const xva_fp_dims* d);
+/* attn_soft_out / attn_logprob_out: (B, Tm, Tt) fp32 or NULL; durs_out (B, Tt) int32 hard durations; loss_out: 1 float (overwritten) */
+int xva_fp_align_forward(const xva_fp_dims* d, const float* params, const xva_fp_align_batch* batch, void* workspace, int64_t workspace_bytes,
+                         float* attn_soft_out, float* attn_logprob_out, int32_t* durs_out, float* loss_out, void* stream);
+/* accumulates grad_scale * d(loss)/d(params) into grads; consumes the state xva_fp_align_forward left in the workspace (call once
+ * per forward) */
+int xva_fp_align_backward(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_align_batch* batch, void* workspace,
+                          int64_t workspace_bytes, float grad_scale, void* stream);
+/* single kernels of the aligner (align_ops.hip) */
+int xva_al_embed(const int32_t* ids, const float* emb, float* out, int B, int T, int C, void* stream);
+int xva_al_mel_to_tm(const float* mel, float* out, int B, int C, int Tm, void* stream);
+int xva_al_sqnorm(const float* X, float* out, int64_t rows, int C, void* stream);
+int xva_al_attn_rows(const float* S, const float* qn, const float* kn, const float* prior, const int32_t* in_lens, float* logprob, float* soft,
+                     float* lse1, float* lse2, int B, int Tm, int Tt, int ld, void* stream);
+int xva_al_mas(const float* soft, const int32_t* in_lens, const int32_t* mel_lens, uint8_t* choice, int32_t* durs, int B, int Tm, int Tt, int ld,
+               void* stream);
+int xva_al_ctc(const float* logprob, const float* lse2, const int32_t* in_lens, const int32_t* mel_lens, float* alpha, float* beta,
+               float* dlogprob, float* loss, int B, int Tm, int Tt, int ld, float gscale, void* stream);
+int xva_al_logsoftmax_bwd(const float* S, const float* qn, const float* kn, const float* lse1, float* G, float* colsum, int B, int Tm, int Tt,
+                          int ld, void* stream);
+int xva_al_dk_fix(float* dk, const float* k, const float* colsum, int B, int Tt, int C, float scale, void* stream);
+
 /* Data-parallel overlap: gradient buckets (contiguous flat ranges, in backward completion order) and a backward
  * that records one hipEvent_t per bucket as it completes; the host starts that bucket's RCCL all-reduce on a side
  * stream (replaces nn.DataParallel's reduce_add_coalesced, python/fastpitch1_1/xva_train.py:48-53,465-466). */

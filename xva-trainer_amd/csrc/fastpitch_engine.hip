@@ -35,8 +35,10 @@ struct TensorInfo {
 
 struct LayerP { int64_t qkv_w, qkv_b, o_w, ln1_g, ln1_b, c1_w, c1_b, c2_w, c2_b, ln2_g, ln2_b; };
 struct PredP { int64_t c1_w, c1_b, n1_g, n1_b, c2_w, c2_b, n2_g, n2_b, fc_w, fc_b; };
+struct AttnP { int64_t q0_w, q0_b, q2_w, q2_b, q4_w, q4_b, k0_w, k0_b, k2_w, k2_b; };
 struct ParamTable {
     std::vector<TensorInfo> t;
+    AttnP at;
     int64_t total = 0;
     int64_t word_emb;
     LayerP enc[NL], dec[NL];
@@ -104,20 +106,20 @@ struct ParamTable {
         proj_w = add("proj.weight", {NMEL, DM});
         proj_b = add("proj.bias", {NMEL});
         proj_end = attn_begin = total;
-        // Stage-1 aligner (ConvAttention, attention.py:171-220): carried for checkpoint compatibility; its
-        // compute is a "next" row and no kernel touches it yet.
-        add("attention.query_proj.0.conv.weight", {160, 80, 3}, 1);
-        add("attention.query_proj.0.conv.bias", {160});
-        add("attention.query_proj.2.conv.weight", {80, 160, 1});
-        add("attention.query_proj.2.conv.bias", {80});
-        add("attention.query_proj.4.conv.weight", {80, 80, 1});
-        add("attention.query_proj.4.conv.bias", {80});
+        // Stage-1 aligner (ConvAttention, attention.py:82-133): query_proj = conv3(80->160) ReLU conv1(160->80) ReLU conv1(80->80),
+        // key_proj = conv3(384->768) ReLU conv1(768->80); attn_proj is an unused member of the reference module (checkpoint only)
+        at.q0_w = add("attention.query_proj.0.conv.weight", {160, 80, 3}, 1);
+        at.q0_b = add("attention.query_proj.0.conv.bias", {160});
+        at.q2_w = add("attention.query_proj.2.conv.weight", {80, 160, 1});
+        at.q2_b = add("attention.query_proj.2.conv.bias", {80});
+        at.q4_w = add("attention.query_proj.4.conv.weight", {80, 80, 1});
+        at.q4_b = add("attention.query_proj.4.conv.bias", {80});
         add("attention.attn_proj.weight", {1, 80, 1, 1});
         add("attention.attn_proj.bias", {1});
-        add("attention.key_proj.0.conv.weight", {768, 384, 3}, 1);
-        add("attention.key_proj.0.conv.bias", {768});
-        add("attention.key_proj.2.conv.weight", {80, 768, 1});
-        add("attention.key_proj.2.conv.bias", {80});
+        at.k0_w = add("attention.key_proj.0.conv.weight", {768, 384, 3}, 1);
+        at.k0_b = add("attention.key_proj.0.conv.bias", {768});
+        at.k2_w = add("attention.key_proj.2.conv.weight", {80, 768, 1});
+        at.k2_b = add("attention.key_proj.2.conv.bias", {80});
         attn_end = total;
     }
 };
@@ -579,6 +581,169 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
     XVA_TRY(layers_fwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens, DS_DEC));
     XVA_TRY(linear_fwd(c, c.A(pl.dec_x[NL]), pl.Rd, DM, DM, T.proj_w, c.P + T.proj_b, c.A(pl.mel_out), NMEL, NMEL, nullptr, 0,
                        XVA_MASK_PAD, dec_lens, pl.Tmp));
+    return XVA_OK;
+}
+
+// ---- training stage 1: the aligner ------------------------------------------------------------------------------------------
+namespace {
+constexpr int NATT = 80, NKH = 2 * DM, NQH = 2 * NMEL;   // attention dim, key / query hidden widths (768, 160)
+struct AlignPlan {
+    int B, Tt, Tm, Ttp, Tmp, ld;
+    int64_t Rt, Rm;
+    int64_t temb, k1, kenc, melT, q1, q2, qenc, qn, kn, S, logprob, soft, lse1, lse2, alpha, beta, G, colsum, choice, durs, loss;
+    int64_t dqenc, dq2, dq1, dkenc, dk1, dtemb;
+    int64_t total;
+};
+int make_align_plan(const xva_fp_dims* d, AlignPlan* p) {
+    XVA_CHECK_ARG(d && d->B > 0 && d->Tt > 0 && d->Tm > 0 && d->Tt <= 2046 && d->Tm <= 8190, "align: bad dims");
+    p->B = d->B; p->Tt = d->Tt; p->Tm = d->Tm; p->Ttp = d->Tt + 2; p->Tmp = d->Tm + 2; p->ld = (d->Tt + 3) & ~3;
+    p->Rt = (int64_t)d->B * p->Ttp; p->Rm = (int64_t)d->B * p->Tmp;
+    Bump b;
+    const int64_t map = (int64_t)d->B * d->Tm * p->ld * 4;
+    p->temb = b.seq(p->Rt, DM, 4); p->k1 = b.seq(p->Rt, NKH, 4); p->kenc = b.seq(p->Rt, NATT, 4);
+    p->melT = b.seq(p->Rm, NMEL, 4); p->q1 = b.seq(p->Rm, NQH, 4); p->q2 = b.seq(p->Rm, NMEL, 4); p->qenc = b.seq(p->Rm, NATT, 4);
+    p->qn = b.take(p->Rm * 4); p->kn = b.take(p->Rt * 4);
+    p->S = b.take(map); p->logprob = b.take(map); p->soft = b.take(map);
+    p->lse1 = b.take((int64_t)d->B * d->Tm * 4); p->lse2 = b.take((int64_t)d->B * d->Tm * 4);
+    p->alpha = b.take((int64_t)d->B * d->Tm * (2 * d->Tt + 1) * 4); p->beta = b.take((int64_t)d->B * d->Tm * (2 * d->Tt + 1) * 4);
+    p->G = b.take(map); p->colsum = b.take((int64_t)d->B * d->Tt * 4);
+    p->choice = b.take((int64_t)d->B * d->Tm * d->Tt); p->durs = b.take((int64_t)d->B * d->Tt * 4); p->loss = b.take(16);
+    p->dqenc = b.seq(p->Rm, NATT, 4); p->dq2 = b.seq(p->Rm, NMEL, 4); p->dq1 = b.seq(p->Rm, NQH, 4);
+    p->dkenc = b.seq(p->Rt, NATT, 4); p->dk1 = b.seq(p->Rt, NKH, 4); p->dtemb = b.seq(p->Rt, DM, 4);
+    p->total = b.cur;
+    return XVA_OK;
+}
+struct ACtx {
+    AlignPlan pl; const float* P; float* G; char* W; void* st; int compute;
+    float* F(int64_t off) const { return (float*)(W + off); }
+};
+xva_gemm_params agp(const ACtx& c) {
+    xva_gemm_params g;
+    memset(&g, 0, sizeof(g));
+    g.batch = 1; g.batch2 = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.compute = c.compute; g.mask_pad = 1; g.mask_mul = 1;
+    g.a_dtype = g.b_dtype = g.c_dtype = XVA_F32; g.r_dtype = g.g_dtype = XVA_F32;
+    return g;
+}
+// Y[rows, N] = act(Xcat W^T + b): conv k (1 or 3) over a padded token-major fp32 sequence; W tap-major [N][k*Cin]
+int a_conv_fwd(ACtx& c, const float* X, int64_t rows, int Cin, int k, int64_t w_off, int64_t b_off, float* Y, int N, int relu) {
+    xva_gemm_params g = agp(c);
+    g.layout = XVA_GEMM_NT; g.A = X - (k == 3 ? Cin : 0); g.B = c.P + w_off; g.C = Y; g.M = (int)rows; g.N = N; g.K = k * Cin;
+    g.lda = Cin; g.ldb = k * Cin; g.ldc = N; g.bias = c.P + b_off; g.act = relu ? XVA_ACT_RELU : XVA_ACT_NONE;
+    return xva_gemm(&g, c.st);
+}
+// dX = (dY (*) W^T-conv) gated by Gate > 0 (ReLU backward) — k = 1: dX = dY W ; k = 3: tap-reversed segments
+int a_conv_bwd_data(ACtx& c, const float* dY, int64_t rows, int N, int k, int64_t w_off, int Cin, float* dX, const float* Gate) {
+    xva_gemm_params g = agp(c);
+    g.layout = XVA_GEMM_NN; g.A = dY - (k == 3 ? N : 0); g.B = c.P + w_off; g.C = dX; g.M = (int)rows; g.N = Cin; g.K = k * N;
+    g.lda = N; g.ldb = k * Cin; g.ldc = Cin;
+    if (k == 3) { g.seglen = N; g.seg0 = 2 * Cin; g.segstride = -Cin; }
+    g.G = Gate; g.ldg = Cin;
+    return xva_gemm(&g, c.st);
+}
+// dW[N][k*Cin] += scale-free dY^T Xcat ; db[N] += colsum(dY)
+int a_conv_bwd_weight(ACtx& c, const float* dY, int64_t rows, int N, int k, const float* X, int Cin, int64_t w_off, int64_t b_off) {
+    xva_gemm_params g = agp(c);
+    g.layout = XVA_GEMM_TN; g.A = dY; g.B = X - (k == 3 ? Cin : 0); g.C = c.G + w_off; g.M = N; g.N = k * Cin; g.K = (int)rows;
+    g.lda = N; g.ldb = Cin; g.ldc = k * Cin; g.accumulate = 1; g.splitk = 0;
+    XVA_TRY(xva_gemm(&g, c.st));
+    return xva_fp_colsum(dY, XVA_F32, c.G + b_off, rows, N, N, c.st);
+}
+int make_actx(ACtx& c, const xva_fp_dims* d, const float* params, float* grads, void* ws, int64_t ws_bytes, void* st) {
+    XVA_TRY(make_align_plan(d, &c.pl));
+    XVA_CHECK_ARG(params && ws && ((uintptr_t)ws % 256) == 0 && ((uintptr_t)params % 16) == 0, "align: null / misaligned params or workspace");
+    XVA_CHECK_ARG(ws_bytes >= c.pl.total, "align: workspace too small (%ld < %ld bytes)", (long)ws_bytes, (long)c.pl.total);
+    c.P = params; c.G = grads; c.W = (char*)ws; c.st = st; c.compute = d->compute ? 1 : 0;
+    return XVA_OK;
+}
+}  // namespace
+
+extern "C" int64_t xva_fp_align_workspace_bytes(const xva_fp_dims* d) {
+    AlignPlan p;
+    if (make_align_plan(d, &p) != XVA_OK) return -1;
+    return p.total;
+}
+
+extern "C" int xva_fp_align_forward(const xva_fp_dims* d, const float* params, const xva_fp_align_batch* bt, void* workspace, int64_t workspace_bytes,
+                                    float* attn_soft_out, float* attn_logprob_out, int32_t* durs_out, float* loss_out, void* stream) {
+    ACtx c;
+    XVA_TRY(make_actx(c, d, params, nullptr, workspace, workspace_bytes, stream));
+    XVA_CHECK_ARG(bt && bt->text && bt->in_lens && bt->mel && bt->mel_lens && bt->attn_prior && durs_out && loss_out, "align_forward: null");
+    const AlignPlan& pl = c.pl;
+    const ParamTable& T = table();
+    const int B = pl.B, Tt = pl.Tt, Tm = pl.Tm, ld = pl.ld;
+    hipStream_t hs = (hipStream_t)stream;
+    // keys: word embeddings -> key_proj                                                          (model.py:300; attention.py:189)
+    XVA_TRY(xva_al_embed(bt->text, c.P + T.word_emb, c.F(pl.temb), B, Tt, DM, stream));
+    XVA_TRY(a_conv_fwd(c, c.F(pl.temb), pl.Rt, DM, 3, T.at.k0_w, T.at.k0_b, c.F(pl.k1), NKH, 1));
+    XVA_TRY(a_conv_fwd(c, c.F(pl.k1), pl.Rt, NKH, 1, T.at.k2_w, T.at.k2_b, c.F(pl.kenc), NATT, 0));
+    // queries: target mel -> query_proj                                                          (attention.py:192-196)
+    XVA_TRY(xva_al_mel_to_tm(bt->mel, c.F(pl.melT), B, NMEL, Tm, stream));
+    XVA_TRY(a_conv_fwd(c, c.F(pl.melT), pl.Rm, NMEL, 3, T.at.q0_w, T.at.q0_b, c.F(pl.q1), NQH, 1));
+    XVA_TRY(a_conv_fwd(c, c.F(pl.q1), pl.Rm, NQH, 1, T.at.q2_w, T.at.q2_b, c.F(pl.q2), NMEL, 1));
+    XVA_TRY(a_conv_fwd(c, c.F(pl.q2), pl.Rm, NMEL, 1, T.at.q4_w, T.at.q4_b, c.F(pl.qenc), NATT, 0));
+    XVA_TRY(xva_al_sqnorm(c.F(pl.qenc), c.F(pl.qn), pl.Rm, NATT, stream));
+    XVA_TRY(xva_al_sqnorm(c.F(pl.kenc), c.F(pl.kn), pl.Rt, NATT, stream));
+    {   // S = 0.001 q.k per item: -0.0005 ||q - k||^2 = S - 0.0005 (|q|^2 + |k|^2)                (attention.py:206-208)
+        xva_gemm_params g = agp(c);
+        g.layout = XVA_GEMM_NT; g.A = c.F(pl.qenc) + NATT; g.B = c.F(pl.kenc) + NATT; g.C = c.F(pl.S); g.M = Tm; g.N = Tt; g.K = NATT;
+        g.lda = NATT; g.ldb = NATT; g.ldc = ld; g.batch = B; g.sA = (int64_t)pl.Tmp * NATT; g.sB = (int64_t)pl.Ttp * NATT; g.sC = (int64_t)Tm * ld;
+        g.alpha = 0.001f;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    XVA_TRY(xva_al_attn_rows(c.F(pl.S), c.F(pl.qn), c.F(pl.kn), bt->attn_prior, bt->in_lens, c.F(pl.logprob), c.F(pl.soft), c.F(pl.lse1),
+                             c.F(pl.lse2), B, Tm, Tt, ld, stream));                                                  // :209-219
+    XVA_TRY(xva_al_mas(c.F(pl.soft), bt->in_lens, bt->mel_lens, (uint8_t*)(c.W + pl.choice), (int32_t*)(c.W + pl.durs), B, Tm, Tt, ld, stream));   // model.py:315-318
+    // forward-sum loss; its gradient w.r.t. attn_logprob is produced in the same pass (scaled in backward)   (attn_loss_function.py:27-44)
+    if (hipMemsetAsync(c.W + pl.loss, 0, 16, hs) != hipSuccess) { xva_set_error("align_forward: memset failed"); return XVA_ERR_HIP; }
+    XVA_TRY(xva_al_ctc(c.F(pl.logprob), c.F(pl.lse2), bt->in_lens, bt->mel_lens, c.F(pl.alpha), c.F(pl.beta), c.F(pl.G), c.F(pl.loss), B, Tm, Tt, ld,
+                       1.f, stream));
+    bool ok = hipMemcpyAsync(loss_out, c.W + pl.loss, 4, hipMemcpyDeviceToDevice, hs) == hipSuccess &&
+              hipMemcpyAsync(durs_out, c.W + pl.durs, (size_t)B * Tt * 4, hipMemcpyDeviceToDevice, hs) == hipSuccess;
+    if (attn_soft_out) ok = ok && hipMemcpy2DAsync(attn_soft_out, (size_t)Tt * 4, c.W + pl.soft, (size_t)ld * 4, (size_t)Tt * 4, (size_t)B * Tm, hipMemcpyDeviceToDevice, hs) == hipSuccess;
+    if (attn_logprob_out) ok = ok && hipMemcpy2DAsync(attn_logprob_out, (size_t)Tt * 4, c.W + pl.logprob, (size_t)ld * 4, (size_t)Tt * 4, (size_t)B * Tm, hipMemcpyDeviceToDevice, hs) == hipSuccess;
+    if (!ok) { xva_set_error("align_forward: output copy failed"); return XVA_ERR_HIP; }
+    return XVA_OK;
+}
+
+extern "C" int xva_fp_align_backward(const xva_fp_dims* d, const float* params, float* grads, const xva_fp_align_batch* bt, void* workspace,
+                                     int64_t workspace_bytes, float grad_scale, void* stream) {
+    ACtx c;
+    XVA_TRY(make_actx(c, d, params, grads, workspace, workspace_bytes, stream));
+    XVA_CHECK_ARG(grads && bt && bt->text && bt->in_lens, "align_backward: null");
+    const AlignPlan& pl = c.pl;
+    const ParamTable& T = table();
+    const int B = pl.B, Tt = pl.Tt, Tm = pl.Tm, ld = pl.ld;
+    hipStream_t hs = (hipStream_t)stream;
+    // G holds d(loss)/d(attn_logprob) from the forward (unit scale): through the first log-softmax -> d/d(-0.0005 ||q-k||^2)
+    if (hipMemsetAsync(c.W + pl.colsum, 0, (size_t)B * Tt * 4, hs) != hipSuccess) { xva_set_error("align_backward: memset failed"); return XVA_ERR_HIP; }
+    XVA_TRY(xva_al_logsoftmax_bwd(c.F(pl.S), c.F(pl.qn), c.F(pl.kn), c.F(pl.lse1), c.F(pl.G), c.F(pl.colsum), B, Tm, Tt, ld, stream));
+    {   // d q = 0.001 G K   (the -|q|^2 term cancels: every row of G sums to zero)
+        xva_gemm_params g = agp(c);
+        g.layout = XVA_GEMM_NN; g.A = c.F(pl.G); g.B = c.F(pl.kenc) + NATT; g.C = c.F(pl.dqenc) + NATT; g.M = Tm; g.N = NATT; g.K = Tt;
+        g.lda = ld; g.ldb = NATT; g.ldc = NATT; g.batch = B; g.sA = (int64_t)Tm * ld; g.sB = (int64_t)pl.Ttp * NATT; g.sC = (int64_t)pl.Tmp * NATT;
+        g.alpha = 0.001f * grad_scale;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    {   // d k = 0.001 (G^T Q - colsum(G) o k)
+        xva_gemm_params g = agp(c);
+        g.layout = XVA_GEMM_TN; g.A = c.F(pl.G); g.B = c.F(pl.qenc) + NATT; g.C = c.F(pl.dkenc) + NATT; g.M = Tt; g.N = NATT; g.K = Tm;
+        g.lda = ld; g.ldb = NATT; g.ldc = NATT; g.batch = B; g.sA = (int64_t)Tm * ld; g.sB = (int64_t)pl.Tmp * NATT; g.sC = (int64_t)pl.Ttp * NATT;
+        g.alpha = 0.001f * grad_scale;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    XVA_TRY(xva_al_dk_fix(c.F(pl.dkenc), c.F(pl.kenc), c.F(pl.colsum), B, Tt, NATT, grad_scale, stream));
+    // query projections (weights only: the mel is data)                                          (attention.py:118-133)
+    XVA_TRY(a_conv_bwd_weight(c, c.F(pl.dqenc), pl.Rm, NATT, 1, c.F(pl.q2), NMEL, T.at.q4_w, T.at.q4_b));
+    XVA_TRY(a_conv_bwd_data(c, c.F(pl.dqenc), pl.Rm, NATT, 1, T.at.q4_w, NMEL, c.F(pl.dq2), c.F(pl.q2)));
+    XVA_TRY(a_conv_bwd_weight(c, c.F(pl.dq2), pl.Rm, NMEL, 1, c.F(pl.q1), NQH, T.at.q2_w, T.at.q2_b));
+    XVA_TRY(a_conv_bwd_data(c, c.F(pl.dq2), pl.Rm, NMEL, 1, T.at.q2_w, NQH, c.F(pl.dq1), c.F(pl.q1)));
+    XVA_TRY(a_conv_bwd_weight(c, c.F(pl.dq1), pl.Rm, NQH, 3, c.F(pl.melT), NMEL, T.at.q0_w, T.at.q0_b));
+    // key projections and the word embedding                                                     (attention.py:103-113; model.py:300)
+    XVA_TRY(a_conv_bwd_weight(c, c.F(pl.dkenc), pl.Rt, NATT, 1, c.F(pl.k1), NKH, T.at.k2_w, T.at.k2_b));
+    XVA_TRY(a_conv_bwd_data(c, c.F(pl.dkenc), pl.Rt, NATT, 1, T.at.k2_w, NKH, c.F(pl.dk1), c.F(pl.k1)));
+    XVA_TRY(a_conv_bwd_weight(c, c.F(pl.dk1), pl.Rt, NKH, 3, c.F(pl.temb), DM, T.at.k0_w, T.at.k0_b));
+    XVA_TRY(a_conv_bwd_data(c, c.F(pl.dk1), pl.Rt, NKH, 3, T.at.k0_w, DM, c.F(pl.dtemb), nullptr));
+    XVA_TRY(xva_fp_embed_bwd(bt->text, c.F(pl.dtemb), XVA_F32, c.G + T.word_emb, B, Tt, DM, stream));
     return XVA_OK;
 }
 

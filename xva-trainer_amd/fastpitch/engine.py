@@ -45,6 +45,16 @@ lib.xva_fp_loss_partials.argtypes = [i32, i32] + [vp] * 10 + [i32, i32, i32, vp]
 lib.xva_fp_loss_grads.restype = i32
 lib.xva_fp_loss_grads.argtypes = [i32, i32] + [vp] * 15 + [i32, i32, i32, f32, f32, f32, f32, vp]
 
+class FpAlignBatch(C.Structure):
+    _fields_ = [("text", vp), ("in_lens", vp), ("mel", vp), ("mel_lens", vp), ("attn_prior", vp)]
+
+
+lib.xva_fp_align_workspace_bytes.restype = i64
+lib.xva_fp_align_workspace_bytes.argtypes = [C.POINTER(FpDims)]
+lib.xva_fp_align_forward.restype = i32
+lib.xva_fp_align_forward.argtypes = [C.POINTER(FpDims), vp, C.POINTER(FpAlignBatch), vp, i64, vp, vp, vp, vp, vp]
+lib.xva_fp_align_backward.restype = i32
+lib.xva_fp_align_backward.argtypes = [C.POINTER(FpDims), vp, vp, C.POINTER(FpAlignBatch), vp, i64, f32, vp]
 lib.xva_fp_infer_encode.restype = i32
 lib.xva_fp_infer_encode.argtypes = [C.POINTER(FpDims), vp, C.POINTER(FpBatch), f32, f32, vp, i64, vp, vp, vp, vp, vp, vp, vp]
 lib.xva_fp_infer_decode.restype = i32
@@ -201,6 +211,38 @@ class FastPitchEngine:
         losses = self.loss_grads(b, stage, grad_scale)
         self.backward(flat_params, flat_grads, b, stage)
         return losses
+
+    # -- training stage 1: the aligner (model.py:296-323,346-360) --------------------------
+    def align_forward(self, flat_params, text, in_lens, mel_tgt, mel_lens, attn_prior, want_maps=True):
+        """Returns (loss (1,), attn_hard_dur (B, Tt) int32, attn_soft, attn_logprob (B, 1, Tm, Tt) or None).  The workspace keeps what
+        align_backward needs."""
+        dev = self.device
+        text = text.to(torch.int32).contiguous()
+        B, Tt = text.shape
+        mel = mel_tgt.float().contiguous()
+        Tm = mel.size(2)
+        self._al = dict(text=text, in_lens=in_lens.to(device=dev, dtype=torch.int32).contiguous(), mel=mel,
+                        mel_lens=mel_lens.to(device=dev, dtype=torch.int32).contiguous(), prior=attn_prior.float().contiguous())
+        a = self._al
+        d = FpDims(B, Tt, Tm, 1, self.compute, 0.0, 0)
+        need = int(lib.xva_fp_align_workspace_bytes(C.byref(d)))
+        if need < 0:
+            raise _lib.XvaError("xva_fp_align_workspace_bytes: " + lib.xva_last_error().decode())
+        if getattr(self, "_al_ws", None) is None or self._al_ws.numel() < need:
+            self._al_ws = torch.zeros(need, device=dev, dtype=torch.uint8)
+        self._al_dims = d
+        self._al_bt = FpAlignBatch(_lib.ptr(a["text"]), _lib.ptr(a["in_lens"]), _lib.ptr(a["mel"]), _lib.ptr(a["mel_lens"]), _lib.ptr(a["prior"]))
+        loss = torch.zeros(1, device=dev)
+        durs = torch.zeros(B, Tt, device=dev, dtype=torch.int32)
+        soft = torch.empty(B, 1, Tm, Tt, device=dev) if want_maps else None
+        logp = torch.empty(B, 1, Tm, Tt, device=dev) if want_maps else None
+        _lib.check(lib.xva_fp_align_forward(C.byref(d), _lib.ptr(flat_params), C.byref(self._al_bt), _lib.ptr(self._al_ws), self._al_ws.numel(),
+                                            _lib.ptr(soft), _lib.ptr(logp), _lib.ptr(durs), _lib.ptr(loss), _lib.stream_ptr()), "xva_fp_align_forward")
+        return loss, durs, soft, logp
+
+    def align_backward(self, flat_params, flat_grads, grad_scale=1.0):
+        _lib.check(lib.xva_fp_align_backward(C.byref(self._al_dims), _lib.ptr(flat_params), _lib.ptr(flat_grads), C.byref(self._al_bt),
+                                             _lib.ptr(self._al_ws), self._al_ws.numel(), float(grad_scale), _lib.stream_ptr()), "xva_fp_align_backward")
 
     # -- inference (FastPitch.infer, model.py:426-481) -----------------------------------
     def infer(self, flat_params, text, in_lens, pace=1.0, max_duration=75.0):
