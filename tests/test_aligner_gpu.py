@@ -78,3 +78,32 @@ def test_stage1_against_oracle_ragged_and_grad_scale():
             continue
         r = ((mine[k].double().cpu() - v.grad.double()).norm() / v.grad.double().norm()).item()
         assert r < 2e-3, (k, r)
+
+
+def test_stage1_through_the_reference_interface(golden_dir):
+    """FastPitch(training_stage = 1)(inputs_x) + FastPitchLoss(..., training_stage=1) + backward, as xva_train.py drives them."""
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd.fastpitch import params as P
+    from xva_trainer_amd.fastpitch.loss_function import FastPitchLoss
+    from xva_trainer_amd.fastpitch.model import FastPitch
+    g = np.load(os.path.join(golden_dir, "fp_stage1_small.npz"))
+    sd = ofp.init_state_dict(int(g["seed"]))
+    batch = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+    prior = torch.from_numpy(g["attn_prior"])
+    model = FastPitch(compute="fp32").cuda()
+    model.load_state_dict(sd)
+    model.training_stage = torch.tensor(1)
+    B, Tt = batch["text"].shape
+    x = (batch["text"].cuda(), batch["in_lens"].cuda(), batch["mel_tgt"].cuda(), batch["mel_lens"].cuda(), batch["pitch"].cuda(), batch["energy"].cuda(),
+         None, prior.cuda(), batch["durs"].cuda(), torch.full((B,), Tt), torch.full((B,), int(batch["mel_lens"].max())), None)
+    y = [batch["mel_tgt"].cuda(), batch["in_lens"].cuda(), batch["mel_lens"].cuda(), x[9]]
+    crit = FastPitchLoss(dur_predictor_loss_scale=0.1, pitch_predictor_loss_scale=0.1, attn_loss_scale=1.0)
+    y_pred = model(x)
+    loss, meta, comps = crit(y_pred, y, training_stage=model.training_stage)
+    (loss / 4).backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * float(g["loss"]) and comps == [None, None, None, None]
+    assert torch.equal(y_pred[10].cpu().long(), torch.from_numpy(g["attn_hard_dur"]).long())
+    assert rel(y_pred[8], torch.from_numpy(g["attn_soft"])) < 1e-3
+    mine = P.from_flat(model.flat.grad, model._table)
+    for k, l2 in zip(g["grad_keys"], g["grad_l2"]):
+        assert abs(mine[str(k)].double().norm().item() - l2 / 4) < 2e-3 * l2 / 4, k

@@ -1,4 +1,4 @@
-"""FastPitchLoss — drop-in for python/fastpitch1_1/fastpitch/loss_function.py:52-154 (stages 2-4) on libxvahip.
+"""FastPitchLoss — drop-in for python/fastpitch1_1/fastpitch/loss_function.py:52-154 (stages 1-4) on libxvahip.
 
 Same constructor and `forward(model_out, targets, is_training, meta_agg, training_stage)` -> (loss, meta, [mel, dur, pitch,
 energy]) contract.  The masked-MSE terms and their gradients are two fused HIP kernels per term reading the engine's
@@ -47,10 +47,13 @@ class FastPitchLoss(nn.Module):
 
     def forward(self, model_out, targets, is_training=True, meta_agg="mean", training_stage=1):
         stage = int(training_stage)
-        if stage == 1:
-            raise NotImplementedError("stage-1 attention CTC loss is a 'next' row (SURVEY.md §8f N1)")
         if not isinstance(model_out, M.FpOutputs):
             raise TypeError("FastPitchLoss needs the output list of xva_trainer_amd FastPitch.forward (it reads the engine workspace)")
+        if stage == 1:   # loss_function.py:73-81: the forward-sum loss was evaluated with the alignment (one fused pass)
+            attn_loss = model_out.align_loss.reshape(())
+            loss = attn_loss * self.attn_loss_scale
+            meta = {"loss": loss.clone().detach(), "attn_loss": attn_loss.clone().detach()}
+            return loss, meta, [None, None, None, None]
         w = (self.dur_predictor_loss_scale, self.pitch_predictor_loss_scale, self.energy_predictor_loss_scale)
         if stage == 2:
             preds = (model_out[3],)

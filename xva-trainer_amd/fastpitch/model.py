@@ -56,6 +56,26 @@ class _FastPitchFn(torch.autograd.Function):
         return g, None, None, None
 
 
+class _AlignFn(torch.autograd.Function):
+    """Training stage 1 (model.py:346-360): forward = ConvAttention + MAS + the forward-sum loss in one C call; backward = one C call that
+    accumulates d(loss)/d(attention.*, encoder.word_emb) into the flat gradient."""
+
+    @staticmethod
+    def forward(ctx, flat, module, inputs, input_lens, mel_tgt, mel_lens, attn_prior):
+        eng = module._get_engine()
+        loss, durs, soft, logp = eng.align_forward(flat.detach(), inputs, input_lens, mel_tgt, mel_lens, attn_prior)
+        ctx.module = module
+        ctx.mark_non_differentiable(durs, soft, logp)
+        return loss, durs, soft, logp
+
+    @staticmethod
+    def backward(ctx, g_loss, *unused):
+        module = ctx.module
+        g = torch.zeros_like(module.flat)
+        module._get_engine().align_backward(module.flat.detach(), g, float(g_loss.reshape(-1)[0].item()))
+        return g, None, None, None, None, None, None
+
+
 class FastPitch(nn.Module):
     def __init__(self, logger=None, compute="bf16", p_dropout=0.1):
         """p_dropout: every dropout site of the reference model (p_in_fft_dropout, p_in_fft_dropatt, dur/pitch/energy predictor
@@ -135,11 +155,22 @@ class FastPitch(nn.Module):
         (inputs, input_lens, mel_tgt, mel_lens, pitch_dense, energy_dense, speaker, attn_prior, durs_padded, max_inp_lengths,
          max_mel_lengths, audiopaths) = inputs_x
         stage = int(self.training_stage)
-        if stage not in (2, 3, 4):
-            raise NotImplementedError("training_stage %d: the stage-1 aligner (ConvAttention + MAS) is not built on the HIP path yet" % stage)
+        if stage not in (1, 2, 3, 4):
+            raise NotImplementedError("training_stage %d is not built on the HIP path (stages 1-4 are)" % stage)
         if not use_gt_pitch or pace != 1.0 or speaker is not None:
             raise NotImplementedError("training forward supports use_gt_pitch=True, pace=1.0, single speaker (the trainer's settings)")
         _lib.require_cuda(inputs, self.flat)
+        if stage == 1:   # the aligner: [.., attn_soft, attn_hard, attn_hard_dur, attn_logprob, input_lens] (model.py:357-360)
+            if attn_prior is None:
+                raise ValueError("training stage 1 needs the beta-binomial attn_prior of the batch (data_function.py:84-94)")
+            text = inputs.text if isinstance(inputs, E.DeviceBatch) else inputs
+            loss, durs, soft, logp = _AlignFn.apply(self.flat, self, text, input_lens, mel_tgt, mel_lens, attn_prior.to(self.flat.device))
+            res = FpOutputs()
+            res.engine, res.batch, res.stage = self._get_engine(), None, 1
+            res.align_loss = loss
+            # attn_hard (the (B, 1, Tm, Tt) 0/1 map) is not materialised: every consumer on the training path uses its column sums
+            res.extend([None, None, None, None, None, None, None, None, soft, None, durs.float(), logp, input_lens])
+            return res
         b = inputs if isinstance(inputs, E.DeviceBatch) else E.DeviceBatch(inputs, input_lens, mel_tgt, mel_lens, pitch_dense, energy_dense, durs_padded)
         outs = _FastPitchFn.apply(self.flat, self, b, stage)
         eng = self._get_engine()
