@@ -61,6 +61,38 @@ def test_fastpitch_trainer_protocol(tmp_path):
     assert torch.equal(tr2.model.state_dict()["pitch_mean"].cpu(), ck["state_dict"]["pitch_mean"].cpu())
 
 
+def test_fastpitch_trainer_stage1_aligner(tmp_path):
+    """A fresh run starts at training stage 1 (the aligner): the trainer drives ConvAttention + MAS + the forward-sum loss, LAMB only
+    moves attention.* and the symbol embedding, and the loss goes down."""
+    import re
+    from xva_trainer_amd.data import SyntheticFastPitchLoader
+    from xva_trainer_amd.fastpitch.model import FastPitch
+    from xva_trainer_amd.models_manager import ModelsManager
+    mm = ModelsManager(logging.getLogger("t"), False, "cuda:0")
+    ws = _WS()
+    data = {"dataset_path": str(tmp_path / "in" / "voice_c"), "output_path": str(tmp_path / "out"), "checkpoint": None, "num_workers": 0,
+            "batch_size": 32, "epochs_per_checkpoint": 1, "max_iterations": 8}
+    mm.sync_init_model("fastpitch1_1", websocket=ws, gpus=[0])
+    tr = mm.models_bank["fastpitch1_1"]
+    tr.compute = "fp32"
+    tr.loader_factory = lambda t: SyntheticFastPitchLoader(32, n_batches=8, t_text=12, t_mel=50, seed=3, with_prior=True)
+    tr.init_logs(data["output_path"] + "/voice_c")
+    try:
+        asyncio.run(tr.start(data, gpus=[0]))
+    except RuntimeError as e:     # the loss-delta criterion may end the stage early; the reference signals that by raising (xva_train.py:970)
+        assert "stage 1 finished" in str(e)
+    assert int(tr.model.training_stage) == 1 and any(m.startswith("Set stage to: 1") for m in ws.sent)
+    assert tr.gam == 8 and 3 <= tr.total_iter <= 8
+    log = open(data["output_path"] + "/voice_c/training.log").read()
+    losses = [float(x) for x in re.findall(r"Stage: 1 .*?loss: ([0-9.]+)", log)]
+    assert len(losses) >= 3 and losses[-1] < losses[0], losses
+    fresh = FastPitch(compute="fp32").state_dict()
+    sd = tr.model.state_dict()
+    moved = {k for k in sd if not torch.equal(sd[k].cpu(), fresh[k].cpu())}
+    assert moved and all(k.startswith("attention.") or k == "encoder.word_emb.weight" for k in moved), moved
+    assert tr._last_durs.sum(1).tolist() == [int(v) for v in tr.train_loader.batches[-1]["mel_lens"]]
+
+
 def test_hifigan_trainer_protocol(tmp_path):
     from xva_trainer_amd.data import SyntheticHifiLoader
     from xva_trainer_amd.models_manager import ModelsManager

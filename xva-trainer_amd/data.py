@@ -12,11 +12,32 @@ import torch
 from . import synthetic
 
 
-class SyntheticFastPitchLoader:
-    """Yields (x, y, num_frames)-ready dict batches shaped like TTSCollate's output (data_function.py:565-695)."""
+def beta_binomial_prior_distribution(phoneme_count, mel_count, scaling=1.0):
+    """The (mel_count, phoneme_count) beta-binomial attention prior of one utterance — same call and formula as
+    python/fastpitch1_1/fastpitch/data_function.py:84-94 (scipy.stats.betabinom)."""
+    from scipy.stats import betabinom
+    x = np.arange(0, phoneme_count)
+    rows = [betabinom(phoneme_count, scaling * i, scaling * (mel_count + 1 - i)).pmf(x) for i in range(1, mel_count + 1)]
+    return torch.tensor(np.array(rows))
 
-    def __init__(self, batch_size, n_batches=8, t_text=150, t_mel=860, seed=1234, ragged=True):
+
+def collate_attn_prior(in_lens, mel_lens):
+    """TTSCollate's zero-padded (B, max_mel, max_text) stack of the per-item priors (data_function.py:600-609)."""
+    out = torch.zeros(len(in_lens), int(max(mel_lens)), int(max(in_lens)))
+    for b, (L, M) in enumerate(zip(in_lens, mel_lens)):
+        out[b, :int(M), :int(L)] = beta_binomial_prior_distribution(int(L), int(M)).float()
+    return out
+
+
+class SyntheticFastPitchLoader:
+    """Yields (x, y, num_frames)-ready dict batches shaped like TTSCollate's output (data_function.py:565-695).
+    with_prior adds the beta-binomial `attn_prior` training stage 1 consumes."""
+
+    def __init__(self, batch_size, n_batches=8, t_text=150, t_mel=860, seed=1234, ragged=True, with_prior=False):
         self.batches = [synthetic.fastpitch_batch(batch_size, t_text, t_mel, seed + i, ragged=ragged) for i in range(n_batches)]
+        if with_prior:
+            for b in self.batches:
+                b["attn_prior"] = collate_attn_prior(b["in_lens"].tolist(), b["mel_lens"].tolist())
 
     def __len__(self):
         return len(self.batches)

@@ -105,11 +105,14 @@ class DeviceBatch:
         self.energy = energy.float().contiguous() if energy is not None else None
         self.durs = durs.to(torch.int32).contiguous() if durs is not None else None
         self.num_frames = None
+        self.attn_prior = None
 
     @staticmethod
     def from_dict(b, device):
         g = lambda k: b[k].to(device, non_blocking=True) if b.get(k) is not None else None
-        return DeviceBatch(g("text"), g("in_lens"), g("mel_tgt"), g("mel_lens"), g("pitch"), g("energy"), g("durs"))
+        db = DeviceBatch(g("text"), g("in_lens"), g("mel_tgt"), g("mel_lens"), g("pitch"), g("energy"), g("durs"))
+        db.attn_prior = g("attn_prior")          # (B, Tm, Tt) beta-binomial prior: training stage 1 only
+        return db
 
 
 class FastPitchEngine:

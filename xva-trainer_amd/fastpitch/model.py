@@ -1,9 +1,9 @@
-"""FastPitch — drop-in for python/fastpitch1_1/fastpitch/model.py:125-482 (class FastPitch), stages 2-4, on libxvahip.
+"""FastPitch — drop-in for python/fastpitch1_1/fastpitch/model.py:125-482 (class FastPitch), stages 1-4, on libxvahip.
 
 Same constructor, same `forward(inputs_x)` 12-tuple in / 13-slot list out, same `training_stage` attribute, same 185-entry
 state_dict (keys, shapes, dtypes) — so reference checkpoints load and our checkpoints load into the reference.  Inside,
 all 181 parameters are views of ONE flat nn.Parameter (`flat`) that the HIP engine consumes directly; `forward` and
-`backward` are one C call each.  Stage 1 (ConvAttention aligner + MAS) is not built yet: forward raises.
+`backward` are one C call each (training stages 1-4 and `infer`).
 """
 from collections import OrderedDict
 

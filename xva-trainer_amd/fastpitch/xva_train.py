@@ -1,5 +1,5 @@
 """FastPitchTrainer / handleTrainer — the trainer protocol of python/fastpitch1_1/xva_train.py:57-176,185-1081 on the HIP
-engine (stages 2-4; the stage-1 aligner is a "next" row).
+engine (training stages 1-4).
 
 Kept from the reference, because the Electron UI / server.py consume them: module-level `async handleTrainer(models_manager,
 data, websocket, gpus, resume)` returning None | "move to hifi"; class `FastPitchTrainer(logger, PROD, gpus, models_manager,
@@ -135,12 +135,17 @@ class FastPitchTrainer(object):
             self.max_iterations = data.get("max_iterations")          # benchmark / test hook (not in the reference)
             self.learning_rate, self.weight_decay = 0.1, 1e-6
             self.dur_predictor_loss_scale = self.pitch_predictor_loss_scale = 0.1
+            self.attn_loss_scale = 1.0                                 # xva_train.py:704
             self.warmup_steps, self.grad_clip_thresh = 1000, 1000
         while self.running and not self.JUST_FINISHED_STAGE:
             await self.iteration()
 
     def get_target_delta(self, num_data_lines, stage):
         """xva_train.py:589-672 (target deltas; freezing is implemented by the engine's per-stage trainable ranges)."""
+        if stage == 1:
+            if num_data_lines > 4000: return 2e-5
+            if num_data_lines > 2000: return 15e-5
+            return 4e-4
         if stage == 2:
             td = 5e-4
             if num_data_lines > 4000: td = 5e-5
@@ -170,13 +175,13 @@ class FastPitchTrainer(object):
                               weight_decay=self.weight_decay)
         self.grads = torch.zeros_like(self.model.flat.data)
         self.epoch, self.total_iter, self.avg_loss_per_epoch = 1, 0, []
-        stage = 2
+        stage = 1                                             # a fresh model starts with the aligner (model.py:176: training_stage = 1)
         ckpt = self.last_checkpoint(self.dataset_output) or self.checkpoint
         if ckpt and os.path.exists(str(ckpt)):
             stage, self.epoch, self.total_iter, self.avg_loss_per_epoch = self.load_checkpoint(ckpt)
         if self.force_stage:
             stage = self.force_stage
-        stage = max(2, int(stage))
+        stage = max(1, int(stage))
         self.model.training_stage = torch.tensor(stage)
         if self.websocket is not None:
             await self.websocket.send("Set stage to: %d " % stage)
@@ -193,6 +198,8 @@ class FastPitchTrainer(object):
         self.active = {t[0] for t in self.model._table if any(b <= t[1] < e for b, e in ranges)}
         if stage == 2:
             self.active = {n for n in self.active if not n.startswith("energy_emb")}
+        if stage == 1:   # only the aligner and the symbol embedding are in the stage-1 graph (every other grad is None in the reference)
+            self.active = {t[0] for t in self.model._table if (t[0].startswith("attention.") and "attn_proj" not in t[0]) or t[0] == "encoder.word_emb.weight"}
         self.sync = None
         if self.world > 1:
             from .dp import GradSync
@@ -226,7 +233,16 @@ class FastPitchTrainer(object):
         b = E.DeviceBatch.from_dict(batch, self.model.flat.device)
         flat = self.model.flat.data
         last = (self.accumulated_steps + 1) % self.gam == 0
-        if self.sync is None:
+        if stage == 1:
+            if b.attn_prior is None:
+                raise ValueError("training stage 1 needs `attn_prior` in the batch (TTSCollate, data_function.py:600-609)")
+            al_loss, self._last_durs, _, _ = self.eng.align_forward(flat, b.text, b.in_lens, b.mel_tgt, b.mel_lens, b.attn_prior, want_maps=False)
+            self.eng.align_backward(flat, self.grads, 1.0 / (self.gam * self.world))
+            if self.world > 1 and last:   # the aligner's gradients are a few MB: one plain all-reduce at the end of the accumulation
+                import torch.distributed as dist
+                dist.all_reduce(self.grads)
+            losses = torch.cat([al_loss * self.attn_loss_scale, torch.zeros(7, device=flat.device)])
+        elif self.sync is None:
             losses = self.eng.fwd_loss_bwd(flat, self.grads, b, stage, grad_scale=1.0 / self.gam)
         else:
             losses = self.sync.fwd_loss_bwd(b, stage, grad_scale=1.0 / self.gam, sync=last)
@@ -234,7 +250,7 @@ class FastPitchTrainer(object):
         self._pending = (losses, b.mel_lens if b.mel_lens is not None else None)
         host = losses.detach().cpu()                      # the one host sync per micro-batch (reference: 5 x .item())
         mel_loss, dur_loss, pitch_loss = float(host[1]), float(host[2]), float(host[3])
-        reduced = {2: float(host[0]), 3: pitch_loss * self.pitch_predictor_loss_scale, 4: mel_loss}[stage]
+        reduced = {1: float(host[0]), 2: float(host[0]), 3: pitch_loss * self.pitch_predictor_loss_scale, 4: mel_loss}[stage]
         if np.isnan(reduced):
             self.print_and_log("loss is NaN", save_to_file=self.dataset_output)
             self.grads.zero_()
