@@ -36,6 +36,14 @@ enum { KC = 0, IC = 1 };          // operand kinds: k-contiguous rows / index-co
 
 static __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
 
+// phase timestamps of every workgroup (tools/glds_timing.hip builds this header with XVA_GLDS_TIMING; the product never does)
+#ifdef XVA_GLDS_TIMING
+static __device__ unsigned long long* g_glds_timing;
+#define XVA_T(i) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0) g_glds_timing[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define XVA_T(i) do { } while (0)
+#endif
+
 template <int N, int I = 0, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<N, I + 1>(f); }
@@ -308,8 +316,144 @@ __device__ __forceinline__ void tile_epilogue(const xva_gemm_params& p, f32x4 (&
     if (vec_epi) run(std::true_type{}); else run(std::false_type{});
 }
 
+
+// ---- row-contiguous epilogue (vec_epi == 2) ---------------------------------------------------------------------------------
+// The MFMA result layout gives a lane 4 columns of a row, i.e. 8-byte (bf16) pieces: a wave store touches 16 rows x 32 bytes, and
+// every residual / gate load sits behind the previous piece's store (C, R and G may alias, so the compiler keeps the order) —
+// measured 17 us of a 25 us HiFi-GAN resblock workgroup.  Here each 16-row block of the wave tile is transposed through a private
+// LDS scratch (pitch WN + 4 floats: conflict-free b128 writes and reads) so that a lane owns 8 CONSECUTIVE columns of a row:
+// 16-byte bf16 loads / stores, full 128-byte row segments per wave, and all loads of a group of row blocks issued before its
+// first store.  Same operation order as epilogue4.  Host-verified (vec_epi == 2): N % 8 == 0, 8-element row alignment of C / R / G.
+// (residual / gate / accumulated-into tensors are bf16 here: 8 values = one 16-byte load; fp32 ones take the 4-column epilogue)
+__device__ __forceinline__ void unpack8(const uint4& raw, float (&o)[8]) {
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(w[e] << 16); o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 load8(const void* base, int64_t idx) { return *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + idx); }
+
+template <int MI, int NJ>
+__device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32x4 (&acc)[MI][NJ], XVA_LDS float* scr, int r0, int c0, int lane,
+                                                   int z1, int z2, int bz, int ks) {
+    constexpr int WN = NJ * 16, PITCH = WN + 4, LPR = WN / 8, RPP = 64 / LPR, NPASS = 16 / RPP;
+    constexpr int CH = MI < 2 ? MI : 2;                                   // 16-row blocks whose loads are in flight together
+    const int rr = lane / LPR, col = c0 + (lane % LPR) * 8;
+    const bool col_ok = col < p.N;
+    const bool slab = p.splitk > 1 && p.sk_ws;
+    const int64_t coff = (int64_t)z1 * p.sC + (int64_t)z2 * p.sC2;
+    const int64_t roff = (int64_t)z1 * p.sR + (int64_t)z2 * p.sR2;
+    const int64_t goff = (int64_t)z1 * p.sG + (int64_t)z2 * p.sG2;
+    float* slab_base = slab ? reinterpret_cast<float*>(p.sk_ws) + ((int64_t)bz * p.splitk + ks) * (int64_t)p.M * p.N : nullptr;
+    float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!slab && p.bias && col_ok) {
+        const float4* bq = reinterpret_cast<const float4*>(p.bias + (int64_t)z2 * p.sbias2 + col);
+        const float4 b0 = bq[0], b1 = bq[1];
+        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+    }
+    const bool want_r = !slab && p.R, want_g = !slab && p.G, want_c = !slab && p.accumulate;
+    static_for<MI / CH>([&](auto cc) {
+        constexpr int i0 = decltype(cc)::value * CH;
+        uint4 rraw[CH * NPASS], graw[CH * NPASS], craw[CH * NPASS];
+        static_for<CH * NPASS>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const int row = r0 + (i0 + q / NPASS) * 16 + (q % NPASS) * RPP + rr;
+            if (row < p.M && col_ok) {
+                if (want_r) rraw[q] = load8(p.R, roff + (int64_t)row * p.ldr + col);
+                if (want_g) graw[q] = load8(p.G, goff + (int64_t)row * p.ldg + col);
+                if (want_c) craw[q] = load8(p.C, coff + (int64_t)row * p.ldc + col);
+            }
+        });
+        static_for<CH>([&](auto ic) {
+            constexpr int ii = decltype(ic)::value, i = i0 + ii;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            static_for<NJ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                *reinterpret_cast<XVA_LDS f32x4*>(scr + (lane & 15) * PITCH + j * 16 + (lane >> 4) * 4) = acc[i][j];
+            });
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            static_for<NPASS>([&](auto pc) {
+                constexpr int ps = decltype(pc)::value, q = ii * NPASS + ps;
+                const int row = r0 + i * 16 + ps * RPP + rr;
+                const XVA_LDS f32x4* src = reinterpret_cast<const XVA_LDS f32x4*>(scr + (ps * RPP + rr) * PITCH + (lane % LPR) * 8);
+                const f32x4 lo = src[0], hi = src[1];
+                if (!(row < p.M && col_ok)) return;
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (slab) {
+                    float4* dst = reinterpret_cast<float4*>(slab_base + (int64_t)row * p.N + col);
+                    dst[0] = make_float4(v[0], v[1], v[2], v[3]); dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+                    return;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias[e]) * p.alpha;
+                if (p.drop_p > 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= xva_dropout_scale(p.drop_p, p.drop_seed, p.drop_stream, (uint64_t)row * p.N + col + e);
+                }
+                if (want_g) {
+                    float g[8]; unpack8(graw[q], g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = g[e] > 0.f ? v[e] : v[e] * p.gate_slope;
+                }
+                if (want_r) {
+                    float r8[8]; unpack8(rraw[q], r8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += p.beta * r8[e];
+                }
+                if (p.act != XVA_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        switch (p.act) {
+                            case XVA_ACT_RELU: v[e] = fmaxf(v[e], 0.f); break;
+                            case XVA_ACT_LRELU: v[e] = lrelu(v[e], p.act_slope); break;
+                            case XVA_ACT_TANH: v[e] = tanhf(v[e]); break;
+                            case XVA_ACT_LOGCLAMP: v[e] = logf(fmaxf(v[e], p.act_slope)); break;
+                            default: break;
+                        }
+                    }
+                }
+                if (p.mask_mode != XVA_MASK_NONE) {
+                    const int64_t rm = (int64_t)row * p.mask_mul + p.mask_add;
+                    const int t = (int)(rm % p.Tp);
+                    bool live = t >= p.mask_pad && t < p.mask_pad + p.mask_len;
+                    if (live && p.mask_mode == XVA_MASK_LEN) live = (t - p.mask_pad) < p.lens[rm / p.Tp];
+                    if (!live) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                    }
+                }
+                if (want_c) {
+                    float o[8]; unpack8(craw[q], o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += o[e];
+                }
+                const int64_t ci = coff + (int64_t)row * p.ldc + col;
+                if (p.c_dtype == XVA_BF16) {
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + ci) =
+                        make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                } else {
+                    float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + ci);
+                    dst[0] = make_float4(v[0], v[1], v[2], v[3]); dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            });
+        });
+    });
+}
+// can the row-contiguous epilogue serve this problem? (no transposed / atomic stores)
+__device__ __forceinline__ bool rows_epilogue_ok(const xva_gemm_params& p, int vec_epi) {
+    if (vec_epi != 2 || p.c_trans) return false;
+    const bool slab = p.splitk > 1 && p.sk_ws;
+    if (!slab && p.c_dtype == XVA_F32 && (p.splitk > 1 || p.accumulate == 2)) return false;
+    if (!slab && p.splitk > 1) return false;
+    if (!slab && ((p.R && p.r_dtype != XVA_BF16) || (p.G && p.g_dtype != XVA_BF16) || (p.accumulate && p.c_dtype != XVA_BF16))) return false;
+    return true;
+}
+constexpr int epi_scratch_bytes(int WN) { return 16 * (WN + 4) * 4; }
+
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
-// vec_epi: host-verified that N % 4 == 0 and C / R / G rows are 4-element aligned (vector epilogue allowed)
+// vec_epi: 1 = host-verified that N % 4 == 0 and C / R / G rows are 4-element aligned (vector epilogue allowed); 2 = 8-element
+// granularity as well (row-contiguous epilogue through LDS)
 template <int LAYOUT, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) ? 1 : (BM * BN >= 128 * 128 ? 2 : 3)) void xva_gemm_glds_kernel(xva_gemm_params p, int vec_epi) {
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
@@ -342,6 +486,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) 
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
+    XVA_T(0);
 
     Loader<AK, BM, NW> la;
     Loader<BKD, BN, NW> lb;
@@ -381,6 +526,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) 
 
     if (kt_begin < kt_end) issue(kt_begin, 0);
     __syncthreads();
+    XVA_T(1);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
         if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
@@ -415,8 +561,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) 
         }
         __syncthreads();
     }
-
-    tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
+    XVA_T(2);
+    if (rows_epilogue_ok(p, vec_epi))
+        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks);
+    else
+        tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
+    XVA_T(3);
 }
 
 // ---- stride-1 convolution with a RESIDENT input tile ------------------------------------------------------------------------
@@ -456,6 +606,7 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
     const uint16_t* B = reinterpret_cast<const uint16_t*>(p.B) + (int64_t)z1 * p.sB + (int64_t)z2 * p.sB2;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
+    XVA_T(0);
     const int ntaps = p.K / CIN;
     const int halo = (ntaps - 1) * (dstep < 0 ? -dstep : dstep);
     const int lo = dstep < 0 ? -halo : 0;                     // taps step forwards (forward conv) or backwards (backward-data)
@@ -493,6 +644,7 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
 
     lb.issue(b_base(0), 0, p.K, smem + A_BYTES, wave);
     __syncthreads();
+    XVA_T(1);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) lb.issue(b_base((kt + 1) * GK), (kt + 1) * GK, p.K, smem + A_BYTES + (cur ^ 1) * B_BYTES, wave);
@@ -526,7 +678,12 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
         }
         __syncthreads();
     }
-    tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, z, 0);
+    XVA_T(2);
+    if (rows_epilogue_ok(p, vec_epi))
+        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, z, 0);
+    else
+        tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, z, 0);
+    XVA_T(3);
 }
 
 template <int LAYOUT, int CIN, int BN, int WM, int WN>

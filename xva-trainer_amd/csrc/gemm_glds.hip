@@ -128,10 +128,16 @@ void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn) {
 
 static int vec_epilogue_ok(const xva_gemm_params& p) {
     auto al = [](const void* q, int b) { return ((uintptr_t)q % b) == 0; };
-    int vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.sC % 4 == 0) && (p.sC2 % 4 == 0) && al(p.C, p.c_dtype == XVA_BF16 ? 8 : 16);
-    if (p.R) vec = vec && (p.ldr % 4 == 0) && (p.sR % 4 == 0) && (p.sR2 % 4 == 0) && al(p.R, p.r_dtype == XVA_BF16 ? 8 : 16);
-    if (p.G) vec = vec && (p.ldg % 4 == 0) && (p.sG % 4 == 0) && (p.sG2 % 4 == 0) && al(p.G, p.g_dtype == XVA_BF16 ? 8 : 16);
-    return vec;
+    auto level = [&](int n) {   // n-element granularity of every row the epilogue touches
+        const int ab = n == 4 ? 8 : 16;                                     // bf16 rows: 8 / 16 bytes; fp32 rows: 16 bytes either way
+        int ok = (p.N % n == 0) && (p.ldc % n == 0) && (p.sC % n == 0) && (p.sC2 % n == 0) && al(p.C, p.c_dtype == XVA_BF16 ? ab : 16);
+        if (p.R) ok = ok && (p.ldr % n == 0) && (p.sR % n == 0) && (p.sR2 % n == 0) && al(p.R, p.r_dtype == XVA_BF16 ? ab : 16);
+        if (p.G) ok = ok && (p.ldg % n == 0) && (p.sG % n == 0) && (p.sG2 % n == 0) && al(p.G, p.g_dtype == XVA_BF16 ? ab : 16);
+        return ok;
+    };
+    if (!level(4)) return 0;
+    if (level(8) && (!p.bias || (al(p.bias, 16) && p.sbias2 % 4 == 0))) return 2;
+    return 1;
 }
 
 // ---- stride-1 convolutions over 32 / 64 / 128 input channels: resident-input kernel (gemm_glds.h) --------------------------------
