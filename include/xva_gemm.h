@@ -97,6 +97,12 @@ typedef struct xva_gemm_params {
      * Without it split-K accumulates with fp32 atomics. */
     void* sk_ws;
     int64_t sk_ws_bytes;
+    /* optional second output with C's dtype and indexing (C2[i] next to every C[i] written): the LeakyReLU of the stored value,
+     * lrelu(C[i], c2_slope) — the producer writes the activated copy its consumers would otherwise recompute per tap
+     * (HiFi-GAN ResBlock1: the residual stream stays raw, the convolutions read the activated copy; models.py:41-48).
+     * Needs splitk == 1 and accumulate == 0. */
+    void* C2;
+    float c2_slope;
 } xva_gemm_params;
 
 /* Launches on `stream` (a hipStream_t); returns 0 or a negative XVA_ERR_* code. */

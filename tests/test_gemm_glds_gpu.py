@@ -252,3 +252,26 @@ def test_batched_two_level(mainloop):
     L.gemm(A, Bw, Cm, M, N, K, K, K, N, layout=L.GEMM_NT, compute=1, batch=b1, sA=b2 * M * K, sB=b2 * N * K, sC=b2 * M * N,
            batch2=b2, sA2=M * K, sB2=N * K, sC2=M * N)
     assert _rel(Cm, A.double() @ Bw.double().transpose(-1, -2)) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,cdt", [(300, 200, 256, torch.bfloat16), (257, 136, 320, torch.bfloat16), (1000, 64, 384, torch.float32), (130, 92, 128, torch.bfloat16)])
+def test_second_output_activated_copy(mainloop, M, N, K, cdt):
+    """C2 = lrelu(C): the activated copy a producer stores next to its raw output (HiFi-GAN residual stream, models.py:41-48) —
+    through the row-contiguous epilogue (N % 8 == 0) and the 4-column one (N % 4 == 0); the general kernel refuses it loudly."""
+    L = _lib()
+    torch.manual_seed(M + N)
+    A, lda = _bf(M, K)
+    B, ldb = _bf(N, K)
+    bias = torch.randn(N, device="cuda")
+    R = torch.randn(M, N, device="cuda").to(cdt)
+    Cm = torch.zeros(M, N, device="cuda", dtype=cdt)
+    C2 = torch.full((M, N), 7.0, device="cuda", dtype=cdt)
+    L.gemm(A, B, Cm, M, N, K, lda, ldb, N, compute=1, bias=bias, R=R, ldr=N, C2=C2.data_ptr(), c2_slope=0.1)
+    ref = A[:, :K].double() @ B[:, :K].double().t() + bias.double() + R.double()
+    assert _rel(Cm, ref) < (6e-3 if cdt == torch.bfloat16 else 1e-5)
+    act = torch.where(Cm.double() > 0, Cm.double(), Cm.double() * 0.1)      # C2 is the LeakyReLU of the value C holds (before C's rounding)
+    assert _rel(C2, act) < (8e-3 if cdt == torch.bfloat16 else 1e-6)
+    assert bool(((C2.double() > 0) == (Cm.double() > 0)).all())
+    L.lib.xva_gemm_set_mainloop(0)
+    with pytest.raises(L.XvaError):
+        L.gemm(A, B, Cm, M, N, K, lda, ldb, N, compute=1, C2=C2.data_ptr(), c2_slope=0.1)

@@ -55,6 +55,7 @@ class GemmParams(C.Structure):
         ("a_dtype", i32), ("b_dtype", i32), ("c_dtype", i32), ("c_trans", i32), ("kb_len", i32), ("kb_sA", i64), ("kb_sB", i64),
         ("drop_p", f32), ("drop_seed", C.c_uint64), ("drop_stream", C.c_uint32),
         ("sk_ws", C.c_void_p), ("sk_ws_bytes", i64),
+        ("C2", vp), ("c2_slope", f32),
     ]
 
 

@@ -54,6 +54,8 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
                        p.mask_add >= 0 && (p.mask_mode == XVA_MASK_PAD || p.lens)),
                   "xva_gemm: bad row-mask arguments");
     XVA_CHECK_ARG(p.accumulate != 2 || p.c_dtype == XVA_F32, "xva_gemm: atomic accumulation needs an fp32 C");
+    XVA_CHECK_ARG(!p.C2 || (p.splitk == 1 && !p.accumulate && !p.c_trans && ((uintptr_t)p.C2 % 16) == ((uintptr_t)p.C % 16)),
+                  "xva_gemm: a second output needs splitk == 1, plain (non-accumulating, non-transposed) stores and C's alignment");
     XVA_CHECK_ARG(p.kb_len == 0 || (p.layout == XVA_GEMM_TN && p.kb_len > 0 && p.kb_sA % ve == 0 && p.kb_sB % ve == 0), "xva_gemm: bad K-block arguments");
     if (p.K == 0) p.splitk = 1;
     int nkt = xva_cdiv(p.K, 32);
@@ -123,6 +125,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (p.R) by += (double)p.M * p.N * (p.r_dtype == XVA_BF16 ? 2.0 : 4.0);
         if (p.G) by += (double)p.M * p.N * (p.g_dtype == XVA_BF16 ? 2.0 : 4.0);
         xva_prof_shape(p.M, p.N, p.K, p.batch * p.batch2, p.splitk, bn, by * nbz); }
+    XVA_CHECK_ARG(!p.C2 || glds_tile >= 0, "xva_gemm: the second output is written by the direct-to-LDS kernels only (bf16 operands, K >= 64)");
     if (res_dstep != 0) {   // stride-1 conv over 32 / 64 / 128 channels: resident input tile
         if (xva_gemm_launch_conv_res(p, res_dstep, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; }
     } else if (glds_tile >= 0) { if (xva_gemm_launch_glds(p, glds_tile, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; } }

@@ -232,6 +232,8 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
                 v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
             }
             *dst = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (p.C2) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C2) + ci) =
+                make_uint2(pack_bf2(lrelu(v[0], p.c2_slope), lrelu(v[1], p.c2_slope)), pack_bf2(lrelu(v[2], p.c2_slope), lrelu(v[3], p.c2_slope)));
         } else {
             float* dst = reinterpret_cast<float*>(p.C) + ci;
             if (p.splitk > 1 || p.accumulate == 2) {
@@ -241,6 +243,8 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
                 float4* d4 = reinterpret_cast<float4*>(dst);
                 if (p.accumulate) { float4 o = *d4; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
                 *d4 = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.C2) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C2) + ci) =
+                    make_float4(lrelu(v[0], p.c2_slope), lrelu(v[1], p.c2_slope), lrelu(v[2], p.c2_slope), lrelu(v[3], p.c2_slope));
             }
         }
     } else {
@@ -253,11 +257,16 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
                 float x = v[e];
                 if (p.accumulate) x += bf2f(*dst);
                 *dst = f2bf(x);
+                if (p.C2) reinterpret_cast<uint16_t*>(p.C2)[ci] = f2bf(lrelu(x, p.c2_slope));
             } else {
                 float* dst = reinterpret_cast<float*>(p.C) + ci;
                 if (p.splitk > 1 || p.accumulate == 2) atomicAdd(dst, v[e]);
-                else if (p.accumulate) *dst += v[e];
-                else *dst = v[e];
+                else {
+                    float x = v[e];
+                    if (p.accumulate) x += *dst;
+                    *dst = x;
+                    if (p.C2) reinterpret_cast<float*>(p.C2)[ci] = lrelu(x, p.c2_slope);
+                }
             }
         }
     }
@@ -435,6 +444,17 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                 } else {
                     float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + ci);
                     dst[0] = make_float4(v[0], v[1], v[2], v[3]); dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                if (p.C2) {   // the activated copy next to the raw one
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = lrelu(v[e], p.c2_slope);
+                    if (p.c_dtype == XVA_BF16) {
+                        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C2) + ci) =
+                            make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                    } else {
+                        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C2) + ci);
+                        dst[0] = make_float4(v[0], v[1], v[2], v[3]); dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+                    }
                 }
             });
         });

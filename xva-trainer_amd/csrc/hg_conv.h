@@ -40,6 +40,7 @@ struct ConvEpi {
     int act = XVA_ACT_NONE; float act_slope = 0.f;  // activation on the output
     const Seq* R = nullptr; float alpha = 1.f, beta = 1.f;   // y = alpha * (conv + bias) + beta * R
     int accumulate = 0;
+    const Seq* Y2 = nullptr; float y2_slope = 0.f;  // also store lrelu(y, y2_slope) there (Y's geometry)
 };
 
 // split-K slab scratch of the weight-gradient GEMMs: set by the engine entry points from their workspace plan
@@ -77,16 +78,19 @@ inline int hg_conv_fwd(const Seq& X, const Seq& Y, const ConvW& w, const ConvEpi
     g.alpha = e.alpha; g.beta = e.beta; g.accumulate = e.accumulate;
     g.batch2 = w.groups; g.sA2 = Cig; g.sB2 = (int64_t)Cog * g.K; g.sC2 = Cog; g.sR2 = Cog;
     if (e.R) { XVA_CHECK_ARG(e.R->same_geom(Y) && e.R->C == Y.C, "conv_fwd: residual geometry"); g.ldr = Y.C; g.r_dtype = e.R->dt; }
+    if (e.Y2) { XVA_CHECK_ARG(e.Y2->same_geom(Y) && e.Y2->C == Y.C && e.Y2->dt == Y.dt, "conv_fwd: second output geometry"); g.c2_slope = e.y2_slope; }
     if (hg_mode(X, Y, w) == HG_MERGED) {
         g.A = (const char*)X.ptr() - (int64_t)w.P * X.C * X.es();
         g.C = Y.ptr(); g.M = (int)Y.rows();
         if (e.R) g.R = e.R->ptr();
+        if (e.Y2) g.C2 = e.Y2->ptr();
         g.mask_mode = XVA_MASK_PAD; g.Tp = Y.Hp(); g.mask_pad = Y.padF; g.mask_len = Y.T;
     } else {
         g.batch = X.nseq; g.sA = X.item(); g.sC = Y.item(); g.sR = Y.item();
         g.A = (const char*)X.valid() - (int64_t)w.P * X.C * X.es();
         g.C = Y.valid(); g.M = Y.T;
         if (e.R) g.R = e.R->valid();
+        if (e.Y2) g.C2 = e.Y2->valid();
     }
     g.sbias2 = Cog;
     return xva_gemm(&g, st);
@@ -197,8 +201,10 @@ struct ConvTW {
     int Cin = 0, Cout = 0, k = 0, s = 0, p = 0;
 };
 // Y[s*q + phi] = bias + sum_m lrelu(X)[q + c0(phi) - m] * W[:, :, j0(phi) + m*s]      (per item; any geometry)
-inline int hg_convT_fwd(const Seq& X, const Seq& Y, const ConvTW& w, int a_lrelu, float a_slope, int compute, void* st) {
+inline int hg_convT_fwd(const Seq& X, const Seq& Y, const ConvTW& w, int a_lrelu, float a_slope, int compute, void* st,
+                        const Seq* Y2 = nullptr, float y2_slope = 0.f) {   // Y2: also store lrelu(Y, y2_slope) (Y's geometry)
     XVA_CHECK_ARG(X.C == w.Cin && Y.C == w.Cout && X.nseq == Y.nseq && Y.T == X.T * w.s, "convT_fwd: geometry mismatch");
+    XVA_CHECK_ARG(!Y2 || (Y2->same_geom(Y) && Y2->C == Y.C && Y2->dt == Y.dt), "convT_fwd: second output geometry");
     const int ntap = w.k / w.s;
     XVA_CHECK_ARG(X.padF >= ntap && X.padB >= ntap, "convT_fwd: input pads too small");
     for (int phi = 0; phi < w.s; ++phi) {
@@ -211,6 +217,7 @@ inline int hg_convT_fwd(const Seq& X, const Seq& Y, const ConvTW& w, int a_lrelu
         g.A = (const char*)X.valid() + (int64_t)c0 * X.C * X.es();
         g.B = (const char*)w.effF + (int64_t)phi * w.Cout * g.K * X.es();
         g.C = (char*)Y.valid() + (int64_t)phi * Y.C * Y.es();
+        if (Y2) { g.C2 = (char*)Y2->valid() + (int64_t)phi * Y.C * Y.es(); g.c2_slope = y2_slope; }
         g.bias = w.bias; g.a_lrelu = a_lrelu; g.a_slope = a_slope;
         g.batch = X.nseq; g.sA = X.item(); g.sC = Y.item();
         XVA_TRY(xva_gemm(&g, st));

@@ -484,6 +484,25 @@ extern "C" int xva_hg_tanh_bwd(const float* dwav, const void* y, void* dpre, int
     return XVA_OK;
 }
 
+// dst = lrelu(src, slope) over a whole sequence tensor (n % 8 == 0): the activated copy of a residual-stream tensor where the producing
+// GEMM cannot store it itself (exact-fp32 parity mode; the direct-to-LDS kernels write it from their epilogue, xva_gemm_params.C2)
+__global__ void hg_lrelu_copy_kernel(const void* __restrict__ src, void* __restrict__ dst, int dt, int64_t n, float slope) {
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 2048) {
+        float v[8];
+        hg_ld8(src, i, dt, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        hg_st8(dst, i, dt, v);
+    }
+}
+extern "C" int xva_hg_lrelu_copy(const void* src, void* dst, int dt, int64_t n, float slope, void* stream) {
+    XVA_CHECK_ARG(n % 8 == 0, "lrelu_copy: n must be a multiple of 8");
+    int64_t nb = xva_cdiv(n / 8, 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(hg_lrelu_copy_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, dst, dt, n, slope);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
 // column sums over ALL rows of a sequence tensor (bias gradients; pad rows are zero): out[c] += sum_r X[r][c]
 __global__ void hg_colsum_kernel(const void* __restrict__ X, int dt, float* __restrict__ out, int64_t rows, int C, int rows_per_block, float scale) {
     __shared__ float sh[4][64];

@@ -27,6 +27,7 @@ int xva_hg_avgpool_bwd(const float*, float*, int, int, int, void*);
 int xva_hg_reduce(const void*, const void*, int, int, int, int, int, int, int, float, float*, void*);
 int xva_hg_seed_grad(const void*, const void*, void*, int, int, int, int, int, int, float, float, int, int, float, int, void*);
 int xva_hg_seq1_to_wav(const void*, int, float*, int, int, int, int, void*);
+int xva_hg_lrelu_copy(const void* src, void* dst, int dt, int64_t n, float slope, void* stream);
 int xva_hg_tanh_bwd(const float*, const void*, void*, int, int, int, int, int, void*);
 int xva_hg_colsum(const void*, int, float*, int64_t, int, float, void*);
 int xva_hg_weight_norm_fwd(const float*, const float*, void*, void*, float*, int, int, int, int, int, int, int, void*);
@@ -178,6 +179,7 @@ struct Plan {
     std::vector<Layer> gl, dl;          // layers with workspace offsets resolved
     // generator activations
     SeqSpec xin, h0, u[4], xt1[12][3], xr[12][2], xs[4], y;
+    SeqSpec ua[4], xra[12][2];          // lrelu(u), lrelu(xr): what the resblock convolutions (and their weight gradients) read
     // generator backward scratch
     SeqSpec g_dxs, g_da, g_db, g_dt1, g_du, g_dy;
     // discriminators: per MPD period: t1..t6 ; per MSD scale: t1..t8 (real+fake stacked: nseq = 2B*p / 2B; SN scale 0: two sets)
@@ -247,9 +249,10 @@ int make_plan(const xva_hg_dims* d, Plan* p) {
     for (int i = 0; i < 4; ++i) {
         const int T = p->T[i + 1], C = p->Cst[i + 1];
         p->u[i] = mk(b, es, B, T, C, PG, PG);
+        p->ua[i] = mk(b, es, B, T, C, PG, PG);
         for (int j = 0; j < 3; ++j) {
             for (int m = 0; m < 3; ++m) p->xt1[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG);
-            for (int m = 0; m < 2; ++m) p->xr[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG);
+            for (int m = 0; m < 2; ++m) { p->xr[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG); p->xra[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG); }
         }
         p->xs[i] = mk(b, es, B, T, C, PG, PG);
     }
@@ -376,20 +379,30 @@ int gen_forward(Ctx& c, const float* P, const float* mel, float* wav_out) {
     XVA_TRY(hg_conv_fwd(xin, h0, cw(c, L[N.pre], P), e0, c.compute, c.st));                         // conv_pre        (models.py:111)
     Seq prev = h0;
     for (int i = 0; i < 4; ++i) {
-        Seq u = c.S(pl.u[i]), xs = c.S(pl.xs[i]);
-        XVA_TRY(hg_convT_fwd(prev, u, ctw(c, L[N.ups[i]], P), 1, SLOPE, c.compute, c.st));         // lrelu + ups[i]  (:115-116)
+        Seq u = c.S(pl.u[i]), ua = c.S(pl.ua[i]), xs = c.S(pl.xs[i]);
+        // lrelu + ups[i] (:115-116).  Every producer on the residual stream also stores the LeakyReLU of its output (u -> ua,
+        // xr -> xra): the resblock convolutions read the activated copy instead of re-activating their operand once per tap, and
+        // xt1 (only ever consumed through a LeakyReLU) is stored activated.
+        const bool dual = c.compute != 0;   // bf16 GEMM epilogues write the activated copy; the exact-fp32 mode makes it with one more pass
+        auto act_copy = [&](const Seq& raw, const Seq& actv) {
+            return xva_hg_lrelu_copy(raw.ptr(), actv.ptr(), c.dt, raw.rows() * raw.C, SLOPE, c.st);
+        };
+        XVA_TRY(hg_convT_fwd(prev, u, ctw(c, L[N.ups[i]], P), 1, SLOPE, c.compute, c.st, dual ? &ua : nullptr, SLOPE));
+        if (!dual) XVA_TRY(act_copy(u, ua));
         for (int j = 0; j < 3; ++j) {
             const int rb = i * 3 + j;
-            Seq xcur = u;
+            Seq xcur = u, xact = ua;
             for (int m = 0; m < 3; ++m) {                                                          // ResBlock1.forward (:41-48)
                 Seq xt1 = c.S(pl.xt1[rb][m]);
-                ConvEpi e1; e1.a_lrelu = 1; e1.a_slope = SLOPE;
-                XVA_TRY(hg_conv_fwd(xcur, xt1, cw(c, L[N.rc1[rb][m]], P), e1, c.compute, c.st));
-                ConvEpi e2; e2.a_lrelu = 1; e2.a_slope = SLOPE; e2.R = &xcur;
+                ConvEpi e1; e1.act = XVA_ACT_LRELU; e1.act_slope = SLOPE;                           // xt1 = lrelu(c1(lrelu(x)))
+                XVA_TRY(hg_conv_fwd(xact, xt1, cw(c, L[N.rc1[rb][m]], P), e1, c.compute, c.st));
+                ConvEpi e2; e2.R = &xcur;
                 if (m < 2) {
-                    Seq xn = c.S(pl.xr[rb][m]);
+                    Seq xn = c.S(pl.xr[rb][m]), xna = c.S(pl.xra[rb][m]);
+                    if (dual) { e2.Y2 = &xna; e2.y2_slope = SLOPE; }
                     XVA_TRY(hg_conv_fwd(xt1, xn, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, c.st));
-                    xcur = xn;
+                    if (!dual) XVA_TRY(act_copy(xn, xna));
+                    xcur = xn; xact = xna;
                 } else {                                                                           // xs = sum_j resblock_j / 3  (:118-123)
                     e2.alpha = 1.f / 3; e2.beta = 1.f / 3; e2.accumulate = j > 0;
                     XVA_TRY(hg_conv_fwd(xt1, xs, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, c.st));
@@ -456,20 +469,21 @@ int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav) {
         const int T = pl.T[i + 1], C = pl.Cst[i + 1];
         Seq dxs = as_stage(c, pl.g_dxs, T, C), da = as_stage(c, pl.g_da, T, C), db = as_stage(c, pl.g_db, T, C),
             dt1 = as_stage(c, pl.g_dt1, T, C), du = as_stage(c, pl.g_du, T, C);
-        Seq u = c.S(pl.u[i]);
+        Seq ua = c.S(pl.ua[i]);
         for (int j = 0; j < 3; ++j) {
             const int rb = i * 3 + j;
             // d(pair output) for m = 2 is dxs / 3; the 1/3 is folded into the first GEMMs' alpha / beta
             Seq dcur = dxs; float sc = 1.f / 3;
             for (int m = 2; m >= 0; --m) {
-                Seq xin = m == 0 ? u : c.S(pl.xr[rb][m - 1]);
+                // the ACTIVATED conv inputs: they are the weight-gradient operands, and (LeakyReLU keeps the sign) the gates
+                Seq xin = m == 0 ? ua : c.S(pl.xra[rb][m - 1]);
                 Seq xt1 = c.S(pl.xt1[rb][m]);
                 ConvW w2 = cw(c, L[N.rc2[rb][m]], P), w1 = cw(c, L[N.rc1[rb][m]], P);
-                XVA_TRY(hg_conv_bwd_weight(dcur, xt1, w2, 1, SLOPE, sc, c.compute, c.st));
+                XVA_TRY(hg_conv_bwd_weight(dcur, xt1, w2, 0, 0.f, sc, c.compute, c.st));
                 XVA_TRY(xva_hg_colsum(dcur.ptr(), c.dt, G + L[N.rc2[rb][m]].bias, dcur.rows(), C, sc, c.st));
                 BwdEpi b2; b2.gate = &xt1; b2.gate_slope = SLOPE; b2.alpha = sc;
                 XVA_TRY(hg_conv_bwd_data(dcur, dt1, w2, b2, c.compute, c.st));                    // dt1 = d(conv1 output)
-                XVA_TRY(hg_conv_bwd_weight(dt1, xin, w1, 1, SLOPE, 1.f, c.compute, c.st));
+                XVA_TRY(hg_conv_bwd_weight(dt1, xin, w1, 0, 0.f, 1.f, c.compute, c.st));
                 XVA_TRY(xva_hg_colsum(dt1.ptr(), c.dt, G + L[N.rc1[rb][m]].bias, dt1.rows(), C, 1.f, c.st));
                 BwdEpi b1; b1.gate = &xin; b1.gate_slope = SLOPE; b1.R = &dcur; b1.beta = sc;
                 Seq dst = (m == 0) ? du : ((m == 2) ? da : db);
