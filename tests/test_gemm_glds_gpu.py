@@ -86,18 +86,21 @@ def test_tn_splitk_atomics_and_slabs(mainloop, splitk, slabs):
         assert torch.equal(C2, Cm)
 
 
-def test_tn_kblocks_and_column_segments(mainloop):
-    """K-block addressing (per-item weight gradients merged into one launch) + TN column segments (dilated taps)."""
+@pytest.mark.parametrize("T,splitk", [(256, 1), (200, 1), (98, 3), (130, 0)])
+def test_tn_kblocks_and_column_segments(mainloop, T, splitk):
+    """K-block addressing (per-item weight gradients merged into one launch; block lengths need not be multiples of the 64-row K
+    tile: the tail tile of each block is zero-filled) + TN column segments (dilated taps)."""
     L = _lib()
     torch.manual_seed(6)
-    items, T, Cout, Cin, k, d = 3, 256, 136, 64, 3, 2
+    items, Cout, Cin, k, d = 3, 136, 64, 3, 2
     PAD = 4
     x = torch.zeros(items, T + 2 * PAD, Cin, device="cuda", dtype=torch.bfloat16)
     x[:, PAD:PAD + T] = torch.randn(items, T, Cin, device="cuda").bfloat16()
     dy = torch.randn(items, T, Cout, device="cuda").bfloat16()
     dW = torch.zeros(Cout, k * Cin, device="cuda")
     # dW[co][j*Cin + ci] = sum_{b,t} dy[b,t,co] * x[b, t + (j-1)*d, ci]
-    L.gemm(dy, x, dW, Cout, k * Cin, items * T, Cout, Cin, k * Cin, layout=L.GEMM_TN, compute=1, accumulate=True,
+    ws = torch.zeros(8 * Cout * k * Cin, device="cuda")
+    L.gemm(dy, x, dW, Cout, k * Cin, items * T, Cout, Cin, k * Cin, layout=L.GEMM_TN, compute=1, accumulate=True, splitk=splitk, sk_ws=ws,
            b_offset=(PAD - d) * Cin, seglen=Cin, seg0=0, segstride=d * Cin - Cin,
            kb_len=T, kb_sA=T * Cout, kb_sB=(T + 2 * PAD) * Cin)
     xr = x[:, PAD:PAD + T].double().transpose(1, 2)

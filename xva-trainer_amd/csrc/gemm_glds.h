@@ -499,7 +499,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) 
     const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + (int64_t)z1 * p.sA + (int64_t)z2 * p.sA2;
     const uint16_t* B = reinterpret_cast<const uint16_t*>(p.B) + (int64_t)z1 * p.sB + (int64_t)z2 * p.sB2;
 
-    const int nkt_total = (p.K + GK - 1) / GK;
+    const int tpb = p.kb_len > 0 ? (p.kb_len + GK - 1) / GK : 1;                                  // K tiles per K block (TN)
+    const int nkt_total = p.kb_len > 0 ? (p.K / p.kb_len) * tpb : (p.K + GK - 1) / GK;
     const int per = (nkt_total + p.splitk - 1) / p.splitk;
     const int kt_begin = ks * per;
     const int kt_end = min(nkt_total, kt_begin + per);
@@ -518,15 +519,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) 
 
     auto a_base = [&](int k0) -> const uint16_t* {
         if constexpr (AK == KC) return A + k0 + (p.a_seglen > 0 ? (int64_t)(k0 / p.a_seglen) * p.a_segadj : 0);
-        else return p.kb_len > 0 ? A + (int64_t)(k0 / p.kb_len) * p.kb_sA + (int64_t)(k0 % p.kb_len) * p.lda : A + (int64_t)k0 * p.lda;
+        else return A + (int64_t)k0 * p.lda;
     };
     auto b_base = [&](int k0) -> const uint16_t* {
         if constexpr (BKD == KC) return B + k0;
         else if constexpr (LAYOUT == XVA_GEMM_NN)
             return p.seglen > 0 ? B + p.seg0 + (int64_t)(k0 / p.seglen) * p.segstride + (int64_t)(k0 % p.seglen) * p.ldb : B + (int64_t)k0 * p.ldb;
-        else return p.kb_len > 0 ? B + (int64_t)(k0 / p.kb_len) * p.kb_sB + (int64_t)(k0 % p.kb_len) * p.ldb : B + (int64_t)k0 * p.ldb;
+        else return B + (int64_t)k0 * p.ldb;
     };
     auto issue = [&](int kt, int buf) {
+        if constexpr (LAYOUT == XVA_GEMM_TN) {
+            if (p.kb_len > 0) {   // K blocks (one per item, any length): tile kt = (block, 64-row piece of it); rows past the block end are zero
+                const int blk = kt / tpb, kl = (kt - blk * tpb) * GK;
+                la.issue(A + (int64_t)blk * p.kb_sA + (int64_t)kl * p.lda, kl, p.kb_len, smem + buf * BUF, wave);
+                lb.issue(B + (int64_t)blk * p.kb_sB + (int64_t)kl * p.ldb, kl, p.kb_len, smem + buf * BUF + A_BYTES, wave);
+                return;
+            }
+        }
         const int k0 = kt * GK;
         la.issue(a_base(k0), k0, p.K, smem + buf * BUF, wave);
         lb.issue(b_base(k0), k0, p.K, smem + buf * BUF + A_BYTES, wave);

@@ -62,7 +62,7 @@ bool xva_gemm_glds_eligible(const xva_gemm_params& p) {
     if (p.K % 8 != 0 || p.K < 8) return false;
     if (p.layout == XVA_GEMM_TN) {
         if (p.M % 8 != 0 || p.N % 8 != 0 || p.M < 8 || p.N < 8) return false;
-        if (p.kb_len > 0 && p.kb_len % xva_glds::GK != 0) return false;
+        if (p.kb_len > 0 && p.K % p.kb_len != 0) return false;
     } else {
         auto seg_ok = [](int len) { return len <= 0 || len % xva_glds::GK == 0 || xva_glds::GK % len == 0; };   // a K tile maps onto whole segments
         if (p.a_segadj != 0 && !seg_ok(p.a_seglen)) return false;
