@@ -25,6 +25,8 @@ def main():
     o1 = torch.zeros(R, 1536, device="cuda", dtype=dt); o2 = torch.zeros(R, 384, device="cuda", dtype=dt)
     dW1 = torch.zeros(1536, 1152, device="cuda"); dW2 = torch.zeros(384, 4608, device="cuda")
     ws = torch.zeros(8 * 1536 * 1152, device="cuda")
+    b1 = torch.randn(1536, device="cuda"); b2 = torch.randn(384, device="cuda"); r2 = torch.randn(R, 384, device="cuda").to(dt)
+    lens = torch.full((32,), 860, device="cuda", dtype=torch.int32)
     A = torch.randn(8192, 4096, device="cuda").to(dt); B = torch.randn(8192, 4096, device="cuda").to(dt); Cm = torch.zeros(8192, 8192, device="cuda", dtype=dt)
     A0 = torch.zeros_like(A); B0 = torch.zeros_like(B)
     cases = [
@@ -33,6 +35,15 @@ def main():
         ("square NN", lambda: L.gemm(A, B, Cm, 8192, 8192, 4096, 4096, 8192, 8192, layout=L.GEMM_NN, compute=1), 2 * 8192 * 8192 * 4096),
         ("square TN", lambda: L.gemm(A, B, Cm, 8192, 8192, 4096, 8192, 8192, 8192, layout=L.GEMM_TN, compute=1), 2 * 8192 * 8192 * 4096),
         ("conv1 fwd NT", lambda: L.gemm(x[1:], W1, o1, R, 1536, 1152, 384, 1152, 1536, compute=1, a_offset=-384), 2 * R * 1536 * 1152),
+        ("conv1 fwd +bias+relu", lambda: L.gemm(x[1:], W1, o1, R, 1536, 1152, 384, 1152, 1536, compute=1, a_offset=-384, bias=b1, relu=True), 2 * R * 1536 * 1152),
+        ("conv1 fwd +bias+relu+mask", lambda: L.gemm(x[1:], W1, o1, R, 1536, 1152, 384, 1152, 1536, compute=1, a_offset=-384, bias=b1, relu=True,
+                                                  mask_mode=L.MASK_LEN, lens=lens, Tp=862, mask_pad=1, mask_len=860), 2 * R * 1536 * 1152),
+        ("conv2 fwd +bias+R+mask", lambda: L.gemm(h[1:], W2, o2, R, 384, 4608, 1536, 4608, 384, compute=1, a_offset=-1536, bias=b2, R=r2, ldr=384,
+                                               mask_mode=L.MASK_LEN, lens=lens, Tp=862, mask_pad=1, mask_len=860), 2 * R * 384 * 4608),
+        ("conv2 fwd +bias+drop+R+mask", lambda: L.gemm(h[1:], W2, o2, R, 384, 4608, 1536, 4608, 384, compute=1, a_offset=-1536, bias=b2, R=r2, ldr=384,
+                                                    mask_mode=L.MASK_LEN, lens=lens, Tp=862, mask_pad=1, mask_len=860, drop_p=0.1, drop_seed=5, drop_stream=3), 2 * R * 384 * 4608),
+        ("conv2 bwd-data NN +gate+mask", lambda: L.gemm(x[1:], W2, o1, R, 1536, 1152, 384, 4608, 1536, layout=L.GEMM_NN, compute=1, seglen=384, seg0=2 * 1536, segstride=-1536, a_offset=-384,
+                                                     G=h, ldg=1536, mask_mode=L.MASK_LEN, lens=lens, Tp=862, mask_pad=1, mask_len=860), 2 * R * 1536 * 1152),
         ("conv2 fwd NT", lambda: L.gemm(h[1:], W2, o2, R, 384, 4608, 1536, 4608, 384, compute=1, a_offset=-1536), 2 * R * 384 * 4608),
         ("conv2 bwd-data NN", lambda: L.gemm(x[1:], W2, o1, R, 1536, 1152, 384, 4608, 1536, layout=L.GEMM_NN, compute=1, seglen=384, seg0=2 * 1536, segstride=-1536, a_offset=-384), 2 * R * 1536 * 1152),
         ("conv1 bwd-data NN", lambda: L.gemm(h[1:], W1, o2, R, 384, 4608, 1536, 1152, 384, layout=L.GEMM_NN, compute=1, seglen=1536, seg0=2 * 384, segstride=-384, a_offset=-1536), 2 * R * 384 * 4608),
