@@ -44,7 +44,36 @@ static void run(const char* name, long nblocks, F launch) {
     hipFree(dt);
 }
 
+static void fastpitch_shapes() {
+    const int R = 32 * 862;
+    void* x = dev_bf16((size_t)(R + 4) * 384, 1.f); void* h = dev_bf16((size_t)(R + 4) * 1536, 1.f);
+    void* W1 = dev_bf16((size_t)1536 * 1152, 0.05f); void* W2 = dev_bf16((size_t)384 * 4608, 0.05f);
+    void* o1 = dev_bf16((size_t)R * 1536, 0.f, true); void* o2 = dev_bf16((size_t)R * 384, 0.f, true);
+    std::vector<float> hb(1536, 0.1f); float* bias; hipMalloc(&bias, 1536 * 4); hipMemcpy(bias, hb.data(), 1536 * 4, hipMemcpyHostToDevice);
+    auto base = [&]() { xva_gemm_params p; memset(&p, 0, sizeof(p)); p.batch = 1; p.batch2 = 1; p.alpha = 1.f; p.beta = 1.f; p.splitk = 1; p.compute = 1;
+                        p.mask_mul = 1; p.a_dtype = p.b_dtype = p.c_dtype = XVA_BF16; return p; };
+    {   // conv1 forward: [R x 1152] (overlapping rows of x) x W1^T -> [R x 1536], bias + ReLU
+        xva_gemm_params p = base(); p.layout = XVA_GEMM_NT; p.A = x; p.B = W1; p.C = o1; p.M = R; p.N = 1536; p.K = 1152; p.lda = 384; p.ldb = 1152; p.ldc = 1536;
+        p.bias = bias; p.act = XVA_ACT_RELU;
+        run("FastPitch conv1 fwd 256x256", (long)((R + 255) / 256) * 6, [&] { launch_tile<XVA_GEMM_NT, 256, 256, 128, 64>(p, 2, 0); });
+        run("FastPitch conv1 fwd 128x128", (long)((R + 127) / 128) * 12, [&] { launch_tile<XVA_GEMM_NT, 128, 128, 64, 64>(p, 2, 0); });
+        xva_gemm_params q = p; q.M = 256 * 10;      // 60 workgroups: a quarter of the CUs busy
+        run("  same, 60 workgroups only", 60, [&] { launch_tile<XVA_GEMM_NT, 256, 256, 128, 64>(q, 2, 0); });
+        q.M = 256 * 42;                             // 252 workgroups: one round
+        run("  same, 252 workgroups", 252, [&] { launch_tile<XVA_GEMM_NT, 256, 256, 128, 64>(q, 2, 0); });
+        q = p; q.c_dtype = XVA_F32; q.M = 256 * 42; q.C = h;   // fp32 output (twice the bytes), 252 workgroups
+        run("  252 workgroups, fp32 C", 252, [&] { launch_tile<XVA_GEMM_NT, 256, 256, 128, 64>(q, 2, 0); });
+    }
+    {   // conv2 forward: [R x 4608] x W2^T -> [R x 384]
+        xva_gemm_params p = base(); p.layout = XVA_GEMM_NT; p.A = h; p.B = W2; p.C = o2; p.M = R; p.N = 384; p.K = 4608; p.lda = 1536; p.ldb = 4608; p.ldc = 384;
+        p.bias = bias;
+        run("FastPitch conv2 fwd 256x256", (long)((R + 255) / 256) * 2, [&] { launch_tile<XVA_GEMM_NT, 256, 256, 128, 64>(p, 2, 0); });
+        run("FastPitch conv2 fwd 128x128", (long)((R + 127) / 128) * 3, [&] { launch_tile<XVA_GEMM_NT, 128, 128, 64, 64>(p, 2, 0); });
+    }
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && atoi(argv[1]) == 0) { fastpitch_shapes(); return 0; }
     const int nseq = argc > 1 ? atoi(argv[1]) : 64;
     const int PAD = 32;
     for (int C : {128, 64, 32}) {
