@@ -244,32 +244,44 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const voi
     float ag[CPL], ab[CPL], gm[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; gm[i] = gamma[2 * lane + 128 * (i >> 1) + (i & 1)]; }   // column pairs
+    // Each wave walks its rows with the NEXT row's operands already in flight: a row is a load -> two wave reductions -> store
+    // chain of a few microseconds, and 7 of them back to back per wave made this kernel latency-bound (30 us for 64 MB).
+    struct RowIn { float xr[CPL], gr[CPL], mu, rs; bool live; };
+    auto fetch = [&](int64_t row, RowIn& in) {
+        in.live = row < r1 && xva_row_live(mask_mode, lens, Tp, row);
+        if (!in.live) return;
+        in.mu = mean[row]; in.rs = rstd[row];
+        const float od = outer_d ? outer_d[row] : 0.f;
+#pragma unroll
+        for (int h = 0; h < CPL / 2; ++h) {
+            const int c = 2 * lane + 128 * h;
+            a_ld2(X, row * C + c, dt, in.xr[2 * h], in.xr[2 * h + 1]);
+            if (outer_d) { in.gr[2 * h] = od * outer_w[c]; in.gr[2 * h + 1] = od * outer_w[c + 1]; }   // rank-1 dY of a 1-output Linear, kept fp32
+            else a_ld2(dY, row * C + c, dt, in.gr[2 * h], in.gr[2 * h + 1]);
+        }
+    };
+    RowIn cur, nxt;
+    fetch(r0 + wave, cur);
     for (int64_t row = r0 + wave; row < r1; row += LNB_WAVES) {
-        if (!xva_row_live(mask_mode, lens, Tp, row)) {
+        fetch(row + LNB_WAVES, nxt);
+        if (!cur.live) {
 #pragma unroll
             for (int h = 0; h < CPL / 2; ++h) {
                 a_st2(dX, row * C + 2 * lane + 128 * h, dt, 0.f, 0.f);
                 if (dXm) a_st2(dXm, row * C + 2 * lane + 128 * h, dt, 0.f, 0.f);
             }
+            cur = nxt;
             continue;
         }
-        float mu = mean[row], rs = rstd[row];
-        float xh[CPL], dh[CPL], xr[CPL];
+        const float rs = cur.rs, mu = cur.mu;
+        float xh[CPL], dh[CPL];
         float s1 = 0.f, s2 = 0.f;
-        float gr[CPL];
-#pragma unroll
-        for (int h = 0; h < CPL / 2; ++h) {
-            const int c = 2 * lane + 128 * h;
-            a_ld2(X, row * C + c, dt, xr[2 * h], xr[2 * h + 1]);
-            if (outer_d) { gr[2 * h] = outer_d[row] * outer_w[c]; gr[2 * h + 1] = outer_d[row] * outer_w[c + 1]; }   // rank-1 dY of a 1-output Linear, kept fp32
-            else a_ld2(dY, row * C + c, dt, gr[2 * h], gr[2 * h + 1]);
-        }
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int c = 2 * lane + 128 * (i >> 1) + (i & 1);
-            float g = gr[i];
+            float g = cur.gr[i];
             if (p_in > 0.f) g *= xva_dropout_scale(p_in, seed_in, stream_in, (uint64_t)row * C + c);
-            xh[i] = (xr[i] - mu) * rs;
+            xh[i] = (cur.xr[i] - mu) * rs;
             dh[i] = g * gm[i];
             s1 += dh[i];
             s2 += dh[i] * xh[i];
@@ -285,12 +297,13 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const voi
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 v[e] = rs * (dh[2 * h + e] - s1 - xh[2 * h + e] * s2);
-                if (relu_gate && !(xr[2 * h + e] > 0.f)) v[e] = 0.f;
+                if (relu_gate && !(cur.xr[2 * h + e] > 0.f)) v[e] = 0.f;
             }
             a_st2(dX, row * C + c, dt, v[0], v[1]);
             if (dXm) a_st2(dXm, row * C + c, dt, v[0] * xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c),
                            v[1] * xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c + 1));
         }
+        cur = nxt;
     }
     if (dgamma) {
 #pragma unroll

@@ -480,8 +480,10 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
 }
 // can the row-contiguous epilogue serve this problem? (no transposed / atomic stores)
 __device__ __forceinline__ bool rows_epilogue_ok(const xva_gemm_params& p, int vec_epi) {
-    if (vec_epi != 2 || p.c_trans) return false;
+    if (vec_epi != 2) return false;
     const bool slab = p.splitk > 1 && p.sk_ws;
+    if (slab) return true;                       // raw partial sums [split][M][N]: C's own layout (c_trans, strides) is the reduce kernel's business
+    if (p.c_trans) return false;
     if (!slab && p.c_dtype == XVA_F32 && (p.splitk > 1 || p.accumulate == 2)) return false;
     if (!slab && p.splitk > 1) return false;
     if (!slab && ((p.R && p.r_dtype != XVA_BF16) || (p.G && p.g_dtype != XVA_BF16) || (p.accumulate && p.c_dtype != XVA_BF16))) return false;

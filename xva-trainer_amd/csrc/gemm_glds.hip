@@ -84,7 +84,8 @@ int xva_gemm_launch_glds(const xva_gemm_params& pin, int tile, hipStream_t st) {
     // split-K through slabs needs N % 4 == 0 and enough scratch; otherwise fall back to fp32 atomics
     const int64_t need = (int64_t)p.splitk * p.batch * p.batch2 * (int64_t)p.M * p.N * 4;
     if (p.splitk <= 1 || !p.sk_ws || p.sk_ws_bytes < need || p.N % 4 != 0 || ((uintptr_t)p.sk_ws % 16) != 0) p.sk_ws = nullptr;
-    const int vec = vec_epilogue_ok(p);
+    int vec = vec_epilogue_ok(p);
+    if (p.sk_ws && p.N % 8 == 0) vec = 2;        // slab stores are [M][N] fp32 rows whatever C looks like
     int rc = launch_tiles(p, tile, vec, st);
     if (rc == 0 && p.sk_ws) {
         const int64_t quads = (int64_t)p.M * p.N / 4;
