@@ -523,28 +523,70 @@ __device__ __forceinline__ void hg_colsum2_body(const void* __restrict__ X, int 
                                                 int bx, int by) {
     __shared__ float sh[4][128];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = bx * 128 + 2 * lane;
     const int64_t r0 = (int64_t)by * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    float a0 = 0.f, a1 = 0.f;
-    if (c < C) {
-        if (dt == XVA_BF16) {
-            const uint16_t* xp = reinterpret_cast<const uint16_t*>(X);
-            int64_t r = r0 + w;
-            for (; r + 4 < r1; r += 8) {
-                const uint32_t u = *reinterpret_cast<const uint32_t*>(xp + r * C + c), v = *reinterpret_cast<const uint32_t*>(xp + (r + 4) * C + c);
-                a0 += __uint_as_float(u << 16) + __uint_as_float(v << 16);
-                a1 += __uint_as_float(u & 0xffff0000u) + __uint_as_float(v & 0xffff0000u);
+    if (dt == XVA_BF16 && C % 8 == 0 && ((uintptr_t)X % 16) == 0) {
+        // 16-byte loads: a lane owns 8 columns, 16 lanes cover the 128-column tile, a wave instruction covers 4 rows; 4 rows x 4
+        // instructions in flight per wave (4-byte loads, two in flight, measured 1.3 TB/s)
+        const int c = bx * 128 + (lane & 15) * 8;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c < C) {
+            const uint16_t* xp = reinterpret_cast<const uint16_t*>(X) + c;
+            auto add = [&](const uint4& q) {
+                const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[2 * e] += __uint_as_float(u[e] << 16); a[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+            };
+            int64_t r = r0 + w * 4 + (lane >> 4);
+            for (; r + 112 < r1; r += 128) {
+                uint4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = *reinterpret_cast<const uint4*>(xp + (r + 16 * u) * C);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) add(q[u]);
             }
-            for (; r < r1; r += 4) { const uint32_t u = *reinterpret_cast<const uint32_t*>(xp + r * C + c); a0 += __uint_as_float(u << 16); a1 += __uint_as_float(u & 0xffff0000u); }
-        } else {
-            const float* xp = reinterpret_cast<const float*>(X);
-            for (int64_t r = r0 + w; r < r1; r += 4) { const float2 f = *reinterpret_cast<const float2*>(xp + r * C + c); a0 += f.x; a1 += f.y; }
+            for (; r < r1; r += 16) add(*reinterpret_cast<const uint4*>(xp + r * C));
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {   // the 4 row-lanes of a column group
+            a[e] += __shfl_xor(a[e], 16);
+            a[e] += __shfl_xor(a[e], 32);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sh[w][lane * 8 + e] = a[e];
+        }
+    } else {
+        const int c = bx * 128 + 2 * lane;
+        float a0 = 0.f, a1 = 0.f;
+        if (c < C) {
+            if (dt == XVA_BF16) {
+                const uint16_t* xp = reinterpret_cast<const uint16_t*>(X);
+                int64_t r = r0 + w;
+                for (; r + 4 < r1; r += 8) {
+                    const uint32_t u = *reinterpret_cast<const uint32_t*>(xp + r * C + c), v = *reinterpret_cast<const uint32_t*>(xp + (r + 4) * C + c);
+                    a0 += __uint_as_float(u << 16) + __uint_as_float(v << 16);
+                    a1 += __uint_as_float(u & 0xffff0000u) + __uint_as_float(v & 0xffff0000u);
+                }
+                for (; r < r1; r += 4) { const uint32_t u = *reinterpret_cast<const uint32_t*>(xp + r * C + c); a0 += __uint_as_float(u << 16); a1 += __uint_as_float(u & 0xffff0000u); }
+            } else {
+                const float* xp = reinterpret_cast<const float*>(X);
+                for (int64_t r = r0 + w; r < r1; r += 4) { const float2 f = *reinterpret_cast<const float2*>(xp + r * C + c); a0 += f.x; a1 += f.y; }
+            }
+        }
+        sh[w][2 * lane] = a0; sh[w][2 * lane + 1] = a1;
     }
-    sh[w][2 * lane] = a0; sh[w][2 * lane + 1] = a1;
     __syncthreads();
-    if (threadIdx.x < 128) {
+    // folded narrow tensors (Creal < 128 | 128): the 128 / Creal replicas of a column are summed here, ONE atomic per real column and
+    // workgroup (same-address atomics serialise in L2)
+    const int wtile = C < 128 ? C : 128;
+    if (Creal < wtile && wtile % Creal == 0) {
+        if ((int)threadIdx.x < Creal) {
+            float t = 0.f;
+            for (int m = threadIdx.x; m < wtile; m += Creal) t += sh[0][m] + sh[1][m] + sh[2][m] + sh[3][m];
+            atomicAdd(out + threadIdx.x, scale * t);
+        }
+    } else if (threadIdx.x < 128) {
         const int cc = bx * 128 + threadIdx.x;
         if (cc < C) atomicAdd(out + (cc % Creal), scale * (sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]));
     }
