@@ -382,18 +382,47 @@ __global__ void colsum2_kernel(const void* __restrict__ X, int dt, float* __rest
     const int c = blockIdx.x * 128 + 2 * lane;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    float a0 = 0.f, a1 = 0.f;
-    if (c < C) {
-        int64_t r = r0 + w;
-        for (; r + 4 < r1; r += 8) {       // two rows in flight
-            float x0, y0, x1, y1;
-            a_ld2(X, r * ld + c, dt, x0, y0);
-            a_ld2(X, (r + 4) * ld + c, dt, x1, y1);
-            a0 += x0 + x1; a1 += y0 + y1;
+    if (dt == XVA_BF16 && C % 8 == 0 && ld % 8 == 0 && ((uintptr_t)X % 16) == 0) {
+        // 16-byte loads: a lane owns 8 columns, 16 lanes the 128-column tile, a wave instruction 4 rows, 8 instructions in flight
+        const int c8 = blockIdx.x * 128 + (lane & 15) * 8;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c8 < C) {
+            const uint16_t* xp = reinterpret_cast<const uint16_t*>(X) + c8;
+            auto add = [&](const uint4& q) {
+                const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[2 * e] += __uint_as_float(u[e] << 16); a[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+            };
+            int64_t r = r0 + w * 4 + (lane >> 4);
+            for (; r + 112 < r1; r += 128) {
+                uint4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = *reinterpret_cast<const uint4*>(xp + (r + 16 * u) * ld);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) add(q[u]);
+            }
+            for (; r < r1; r += 16) add(*reinterpret_cast<const uint4*>(xp + r * ld));
         }
-        for (; r < r1; r += 4) { float x, y; a_ld2(X, r * ld + c, dt, x, y); a0 += x; a1 += y; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] += __shfl_xor(a[e], 16); a[e] += __shfl_xor(a[e], 32); }
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sh[w][lane * 8 + e] = a[e];
+        }
+    } else {
+        float a0 = 0.f, a1 = 0.f;
+        if (c < C) {
+            int64_t r = r0 + w;
+            for (; r + 4 < r1; r += 8) {       // two rows in flight
+                float x0, y0, x1, y1;
+                a_ld2(X, r * ld + c, dt, x0, y0);
+                a_ld2(X, (r + 4) * ld + c, dt, x1, y1);
+                a0 += x0 + x1; a1 += y0 + y1;
+            }
+            for (; r < r1; r += 4) { float x, y; a_ld2(X, r * ld + c, dt, x, y); a0 += x; a1 += y; }
+        }
+        sh[w][2 * lane] = a0; sh[w][2 * lane + 1] = a1;
     }
-    sh[w][2 * lane] = a0; sh[w][2 * lane + 1] = a1;
     __syncthreads();
     if (threadIdx.x < 128) {
         const int cc = blockIdx.x * 128 + threadIdx.x;
