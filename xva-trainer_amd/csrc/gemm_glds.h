@@ -290,10 +290,16 @@ __device__ __forceinline__ void tile_epilogue(const xva_gemm_params& p, f32x4 (&
     const int64_t roff = (int64_t)z1 * p.sR + (int64_t)z2 * p.sR2;
     const int64_t goff = (int64_t)z1 * p.sG + (int64_t)z2 * p.sG2;
     const bool lin_first = (p.splitk == 1) || (ks == 0);
+    // runtime loops over the row blocks (code size: see tile_epilogue_rows); the accumulators keep compile-time indices behind a compare
     auto run = [&](auto vec_tag) {
         constexpr bool VEC = decltype(vec_tag)::value;
-        static_for<MI>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
+#pragma unroll 1
+        for (int i = 0; i < MI; ++i) {
+            f32x4 a[NJ];
+            static_for<MI>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if (i == g) static_for<NJ>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = acc[g][j]; });
+            });
             const int row = rbase + i * 16;
             if (row < p.M) {
                 bool live = true;
@@ -306,16 +312,21 @@ __device__ __forceinline__ void tile_epilogue(const xva_gemm_params& p, f32x4 (&
                 static_for<NJ>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     const int col = cbase + j * 16;
-                    if (col < p.N) epilogue4<VEC>(p, acc[i][j], row, col, live, lin_first, z2, coff, roff, goff);
+                    if (col < p.N) epilogue4<VEC>(p, a[j], row, col, live, lin_first, z2, coff, roff, goff);
                 });
             }
-        });
+        }
     };
     if (p.splitk > 1 && p.sk_ws) {
         // split-K slab: raw partial sums of this K range, [split][M][N] fp32; xva_gemm_splitk_reduce applies the epilogue
         float* slab = reinterpret_cast<float*>(p.sk_ws) + ((int64_t)bz * p.splitk + ks) * (int64_t)p.M * p.N;
-        static_for<MI>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
+#pragma unroll 1
+        for (int i = 0; i < MI; ++i) {
+            f32x4 a[NJ];
+            static_for<MI>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if (i == g) static_for<NJ>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = acc[g][j]; });
+            });
             const int row = rbase + i * 16;
             if (row < p.M) {
                 static_for<NJ>([&](auto jc) {
@@ -323,12 +334,12 @@ __device__ __forceinline__ void tile_epilogue(const xva_gemm_params& p, f32x4 (&
                     const int col = cbase + j * 16;
                     if (col < p.N) {
                         float* dst = slab + (int64_t)row * p.N + col;
-                        if (vec_epi) *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                        else for (int e = 0; e < 4 && col + e < p.N; ++e) dst[e] = acc[i][j][e];
+                        if (vec_epi) *reinterpret_cast<float4*>(dst) = make_float4(a[j][0], a[j][1], a[j][2], a[j][3]);
+                        else for (int e = 0; e < 4 && col + e < p.N; ++e) dst[e] = a[j][e];
                     }
                 });
             }
-        });
+        }
         return;
     }
     if (vec_epi) run(std::true_type{}); else run(std::false_type{});
