@@ -411,8 +411,18 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
     const int64_t roff = (int64_t)z1 * p.sR + (int64_t)z2 * p.sR2;
     const int64_t goff = (int64_t)z1 * p.sG + (int64_t)z2 * p.sG2;
     const bool first_split = (ks == 0);
-#pragma unroll
+    // runtime loop over the four 16-row blocks (the fully unrolled epilogue was most of this kernel's code); the accumulators keep
+    // compile-time indices: block i is selected by compares
+#pragma unroll 1
     for (int i = 0; i < 4; ++i) {
+        f32x4 ai[NTN];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (i == g) {
+#pragma unroll
+                for (int j = 0; j < NTN; ++j) ai[j] = acc[g][j];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
             for (int j = 0; j < NTN; ++j) {
                 const int col = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
                 if (col >= p.N) continue;
-                float v = acc[i][j][r];
+                float v = ai[j][r];
                 if ((p.splitk == 1 || first_split) && p.bias) v += p.bias[(int64_t)z2 * p.sbias2 + col];
                 v *= p.alpha;
                 if (p.drop_p > 0.f) v *= xva_dropout_scale(p.drop_p, p.drop_seed, p.drop_stream, (uint64_t)row * p.N + col);
