@@ -42,7 +42,7 @@ def positional_embedding(T, demb, dtype):
 
 class HashDropout:
     """Mask source equal to xva_dropout_scale (xva-trainer_amd/csrc/xva_common.h): element idx of dropout site `stream` is dropped
-    iff (murmur-style hash(seed, stream, idx) >> 8) * 2^-24 < p; kept elements are scaled by 1/(1-p).  Indices follow the HIP
+    iff (keyed 32-bit xorshift-multiply hash(seed, stream, idx) >> 8) * 2^-24 < p; kept elements are scaled by 1/(1-p).  Indices follow the HIP
     path's padded layouts: activations (B, T+2, C) row-major, attention probabilities rows of T+2 columns."""
 
     def __init__(self, p, seed):
@@ -51,14 +51,29 @@ class HashDropout:
         self.p = np.float32(p)
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
 
+    @staticmethod
+    def _mix32(x):
+        import numpy as np
+        x = np.asarray(x, dtype=np.uint32).copy()
+        with np.errstate(over="ignore"):
+            x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
+            x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+            x ^= x >> np.uint32(16)
+        return x
+
     def _mult(self, stream, idx):
         np = self.np
         with np.errstate(over="ignore"):
-            x = idx.astype(np.uint64) + np.uint64((0x9E3779B97F4A7C15 * (stream + 1) + self.seed) & 0xFFFFFFFFFFFFFFFF)
-            x ^= x >> np.uint64(33); x *= np.uint64(0xff51afd7ed558ccd)
-            x ^= x >> np.uint64(33); x *= np.uint64(0xc4ceb9fe1a85ec53)
-            x ^= x >> np.uint64(33)
-        h = (x & np.uint64(0xFFFFFFFF)) >> np.uint64(8)
+            inner = self._mix32(np.uint32(((self.seed >> 32) + 0x9E3779B9 * (stream + 1)) & 0xFFFFFFFF))
+            k1 = self._mix32(np.uint32(self.seed & 0xFFFFFFFF) ^ inner)
+            k2 = self._mix32(k1 + np.uint32(0x85ebca6b))
+            idx = idx.astype(np.uint64)
+            x = ((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32) + (idx >> np.uint64(32)).astype(np.uint32)) ^ k1
+            x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
+            x ^= k2
+            x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+            x ^= x >> np.uint32(16)
+        h = x >> np.uint32(8)
         u = h.astype(np.float32) * np.float32(1.0 / 16777216.0)
         keep = np.float32(1.0) / (np.float32(1.0) - self.p)
         return np.where(u < self.p, np.float32(0.0), keep).astype(np.float32)

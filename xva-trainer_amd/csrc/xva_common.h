@@ -91,15 +91,26 @@ __device__ __forceinline__ float xva_block_max(float v, float* sh) {
     return r;
 }
 
-// Stateless counter-based RNG for dropout: the keep-mask of element `idx` of stream
-// `stream_id` under `seed` is a pure function, so backward regenerates it instead of
-// storing it.  (murmur3-style 64->32 finaliser; quality is ample for Bernoulli masks.)
+// Stateless counter-based RNG for dropout: the keep-mask of element `idx` of stream `stream_id` under `seed` is a pure function,
+// so backward regenerates it instead of storing it.  A keyed 32-bit mixer (two rounds of xorshift-multiply, the "lowbias32"
+// constants) on the element counter: 2 integer multiplies per element.  (The first version ran a 64-bit murmur finaliser per
+// element — 8 quarter-rate 32-bit multiplies — and made LayerNorm backward and the dropout epilogues VALU-bound.)  The two keys
+// are functions of (seed, stream) only: uniform, computed on the scalar unit.
+__device__ __forceinline__ uint32_t xva_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
 __device__ __forceinline__ uint32_t xva_hash(uint64_t seed, uint32_t stream_id, uint64_t idx) {
-    uint64_t x = idx + 0x9E3779B97F4A7C15ull * (uint64_t)(stream_id + 1) + seed;
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
-    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
-    x ^= x >> 33;
-    return (uint32_t)x;
+    const uint32_t k1 = xva_mix32((uint32_t)seed ^ xva_mix32((uint32_t)(seed >> 32) + 0x9E3779B9u * (stream_id + 1u)));
+    const uint32_t k2 = xva_mix32(k1 + 0x85ebca6bu);
+    uint32_t x = ((uint32_t)idx + (uint32_t)(idx >> 32)) ^ k1;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= k2;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
 }
 // returns the multiplier to apply: 0 or 1/(1-p).  p<=0 -> 1.
 __device__ __forceinline__ float xva_dropout_scale(float p, uint64_t seed, uint32_t stream_id, uint64_t idx) {
