@@ -80,7 +80,33 @@ def hifigan_cpu_baseline():
 TILE_NAMES = {"128128": "128x128", "256256": "256x256", "64128": "128x64", "64064": "64x64", "32128": "128x32"}
 
 
-def gemm_roofline(run, nprof, bound, peak, note):
+def pmc_traffic(family, pmc_csv):
+    """HBM bytes per launch of one kernel family from the committed PMC summary (profiles/*_pmc_hbm_bytes.csv: separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes over this same workload, FETCH_SIZE in KB and x2 per the gfx950 calibration of
+    MI355X_MICROARCH.md, WRITE_SIZE in KB; tools/profile_round.sh).  Counters cannot be read in-process, so this is the last
+    committed measurement, or None when the file is missing."""
+    import csv
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_csv)
+    if not os.path.exists(path):
+        return None, None
+    m = re.match(r"xva_gemm_glds_kernel<(\d+)x(\d+)>", family)
+    if m:
+        pat = re.compile(r"xva_gemm_glds_kernel<\d, %s, %s," % (m.group(1), m.group(2)))
+    elif family.startswith("xva_conv_res_kernel<CIN="):
+        pat = re.compile(r"xva_conv_res_kernel<\d, %s," % family[len("xva_conv_res_kernel<CIN="):-1])
+    else:
+        pat = re.compile(r"xva_gemm_kernel<\d, \d, %s>" % family[len("xva_gemm_kernel<BN="):-1])
+    n, by = 0, 0.0
+    for r in csv.DictReader(open(path)):
+        if pat.search(r["Kernel"]):
+            d = int(r["Dispatches"])
+            n += d
+            by += d * (float(r["FETCH_SIZE_KB_mean_raw"]) * 2.0 + float(r["WRITE_SIZE_KB_mean_raw"])) * 1000.0
+    return (by / n if n else None), "profiles/" + pmc_csv
+
+
+def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
     """Live per-launch timing of the GEMM kernels (HIP event pair around every xva_gemm launch, on the launch stream, recorded by the
     library itself: xva_prof_* in csrc/core.hip).  The DOMINANT kernel = the (main loop, tile) family with the largest total time;
     `achieved` = its algorithmic FLOPs (2MNK) or bytes (every distinct operand / result element once) / its summed launch time."""
@@ -114,7 +140,9 @@ def gemm_roofline(run, nprof, bound, peak, note):
         ach, unit = f[2] / f[1], "TFLOP/s"                   # GFLOP / ms = TFLOP/s
     else:
         ach, unit = f[3] / f[1], "GB/s"                       # MB / ms = GB/s
-    res = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+    traffic, traffic_src = pmc_traffic(name, pmc_csv) if pmc_csv else (None, None)
+    res = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
+           "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE; offline passes over this workload: %s)" % traffic_src if traffic else None,
            "kernel": name + (" (direct-to-LDS MFMA implicit-convolution GEMM, all layouts)" if "glds" in name else
                              (" (resident-input MFMA convolution, forward + backward-data)" if "conv_res" in name else "")),
            "launches_per_step": f[0] / nprof, "avg_launch_us": 1e3 * f[1] / f[0], "kernel_ms_per_step": f[1] / nprof,
@@ -126,7 +154,7 @@ def gemm_roofline(run, nprof, bound, peak, note):
                         "by_kernel": {k: {"launches_per_step": v[0] / nprof, "ms_per_step": v[1] / nprof, "tflops": v[2] / v[1],
                                           "algorithmic_gbytes_per_s": v[3] / v[1]} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}},
            "method": "hipEvent pair around every xva_gemm launch on the launch stream (csrc/core.hip xva_prof_*); " + note +
-                     "; PMC HBM traffic not collected in-process (see profiles/)"}
+                     "; PMC counters cannot be read in-process: `traffic` is the committed rocprofv3 --pmc measurement of this workload (profiles/)"}
     return res
 
 
@@ -189,7 +217,8 @@ def hifigan_leg(a, dev, rank, world):
            "loss_mel": float(out["loss_mel"].item()), "loss_disc_all": float(out["loss_disc_all"].item())}
     if rank == 0 and not a.no_roofline:
         # the conv stack is priced against the HBM roofline (north_star): algorithmic bytes of every conv-as-GEMM launch / its time
-        res["roofline"] = gemm_roofline(lambda: st.train_step(x, y, y_mel), 1, "hbm", 8000.0, "one extra profiled D+G iteration")
+        res["roofline"] = gemm_roofline(lambda: st.train_step(x, y, y_mel), 1, "hbm", 8000.0, "one extra profiled D+G iteration",
+                                        pmc_csv="r01_hifigan_pmc_hbm_bytes.csv")
     del st
     torch.cuda.empty_cache()
     return res
@@ -283,7 +312,8 @@ def main():
             eng.fwd_loss_bwd(flat, grads, batch, stage)
         peak = 2500.0 if a.compute == "bf16" else 157.3
         out["roofline"] = gemm_roofline(run_profiled, 3, "mfma", peak,
-                                        "FastPitch fwd+bwd: %d extra profiled passes after the timed region" % 3)
+                                        "FastPitch fwd+bwd: %d extra profiled passes after the timed region" % 3,
+                                        pmc_csv="r01_fastpitch_pmc_hbm_bytes.csv" if a.compute == "bf16" else None)
     if not a.no_hifigan:
         del opt, grads
         eng._ws = None
