@@ -1,0 +1,148 @@
+"""Parity at BASELINE.json's FULL sizes (configs[1]: FastPitch B = 32 x 150 tokens x 860 frames; configs[2]: HiFi-GAN B = 64 x 8192
+samples) through size-independent properties — the CPU oracle pins the same code paths at sizes it finishes in seconds
+(test_fastpitch_gpu.py, test_hifigan_gpu.py); here the full-size launches (other tile choices, split-K factors, grid remaps) must
+be CONSISTENT with them:
+  * batch-composition invariance: an item's outputs do not depend on what else is in the batch (the small batch is the
+    oracle-pinned regime);
+  * the analytic gradient is the derivative of the loss: central finite difference along a random parameter direction;
+  * throughput mode (bf16) vs parity mode (fp32) at the full size stay inside the documented bf16 bound."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _fp_setup(compute, B, Tt, Tm, seed=11):
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd.fastpitch import engine as E
+    from fp_util import build_engine
+    sd = ofp.init_state_dict(3)
+    batch = ofp.synth_batch(B, Tt, Tm, seed)
+    eng, flat, grads = build_engine(sd, compute)
+    return ofp, E, eng, flat, grads, batch
+
+
+def _sub_batch(batch, idx):
+    """Items `idx` of a collated batch, re-padded to their own maxima (TTSCollate layout: sorted by text length desc)."""
+    idx = sorted(idx)
+    tt = int(batch["in_lens"][idx].max()); tm = int(batch["mel_lens"][idx].max())
+    out = {}
+    for k, v in batch.items():
+        if not torch.is_tensor(v):
+            out[k] = v
+            continue
+        w = v[idx]
+        if k in ("text", "durs"):
+            w = w[:, :tt]
+        elif k in ("mel_tgt", "pitch"):
+            w = w[..., :tm]
+        elif k == "energy":
+            w = w[:, :tm]
+        out[k] = w.contiguous()
+    return out
+
+
+def test_fastpitch_full_size_batch_invariance_and_modes():
+    ofp, E, eng, flat, grads, batch = _fp_setup("fp32", 32, 150, 860)
+    b = E.DeviceBatch.from_dict(batch, "cuda")
+    assert (b.B, b.Tt, b.Tm) == (32, 150, 860)
+    losses = eng.fwd_loss_bwd(flat, grads, b, 3).clone()
+    out = {k: v.clone() for k, v in eng.outputs(b, 3).items() if torch.is_tensor(v)}
+    assert torch.equal(out["dec_lens"].cpu().long(), batch["mel_lens"])
+    # the same items in a batch of three (the regime the oracle pins): identical predictions up to fp32 summation order
+    idx = [0, 13, 31]
+    sb = _sub_batch(batch, idx)
+    b3 = E.DeviceBatch.from_dict(sb, "cuda")
+    eng.forward(flat, b3, 3)
+    o3 = eng.outputs(b3, 3)
+    for j, i in enumerate(idx):
+        tm, tt = int(batch["mel_lens"][i]), int(batch["in_lens"][i])
+        a, r = out["mel_out"][i, :tm].float(), o3["mel_out"][j, :tm].float()
+        assert ((a - r).abs().max() / r.abs().max()).item() < 2e-5
+        for key in ("pitch_pred", "energy_pred"):
+            a, r = out[key][i][..., :tt], o3[key][j][..., :tt]
+            assert ((a - r).abs().max() / r.abs().max().clamp_min(1e-6)).item() < 2e-5
+    # throughput mode at the full size vs the parity mode
+    from fp_util import build_engine
+    sd = ofp.init_state_dict(3)
+    eng16, flat16, grads16 = build_engine(sd, "bf16")
+    l16 = eng16.fwd_loss_bwd(flat16, grads16, b, 3)
+    mel16 = eng16.outputs(b, 3)["mel_out"].float()
+    assert abs(l16[0].item() - losses[0].item()) < 2e-2 * abs(losses[0].item())
+    assert ((mel16 - out["mel_out"].float()).norm() / out["mel_out"].float().norm()).item() < 3e-2
+    cos = torch.nn.functional.cosine_similarity(grads16.double(), grads.double(), dim=0).item()
+    assert cos > 0.99, cos
+
+
+@pytest.mark.parametrize("stage", [2, 3])
+def test_fastpitch_full_size_gradient_is_the_loss_derivative(stage):
+    """(L(theta + eps v) - L(theta - eps v)) / (2 eps) = <grad, v> at B = 32 x 860 in the exact-fp32 mode."""
+    ofp, E, eng, flat, grads, batch = _fp_setup("fp32", 32, 150, 860, seed=12)
+    b = E.DeviceBatch.from_dict(batch, "cuda")
+    eng.fwd_loss_bwd(flat, grads, b, stage)
+    def loss_at(t):
+        eng.forward(t, b, stage)
+        eng.loss_partials(b, stage)
+        return eng.loss_grads(b, stage)[0].item()
+    torch.manual_seed(5)
+    # directions with a derivative far above the fp32 noise of the loss: the gradient restricted to a random half of the parameters
+    for trial in range(2):
+        m = (torch.rand_like(flat) < 0.5).float() if trial else torch.ones_like(flat)
+        v = grads * m
+        v /= v.norm()
+        gv = (grads.double() * v.double()).sum().item()
+        eps = 2e-3
+        fd = (loss_at(flat + eps * v) - loss_at(flat - eps * v)) / (2 * eps)
+        assert abs(fd - gv) < 2e-2 * abs(gv), (trial, fd, gv)
+
+
+def test_hifigan_full_size_generator_batch_invariance():
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan import engine as HE
+    g_sd = ohg.init_generator_sd(4321)
+    eng = HE.HifiganEngine("cuda", "fp32")
+    flat = torch.zeros(eng.total[HE.G], device="cuda")
+    HE.to_flat(g_sd, eng.table[HE.G], flat)
+    torch.manual_seed(3)
+    mel = (torch.randn(64, 80, 32) * 2 - 5).clamp(-11.5, 2.0).cuda()
+    wav = eng.generator_forward(flat, mel).clone()
+    assert wav.shape == (64, 8192)
+    idx = [0, 29, 63]
+    w3 = eng.generator_forward(flat, mel[idx].contiguous())
+    assert ((wav[idx] - w3).abs().max() / w3.abs().max()).item() < 2e-5
+    # bf16 throughput mode at the full size vs the parity mode
+    e16 = HE.HifiganEngine("cuda", "bf16")
+    w16 = e16.generator_forward(flat, mel)
+    assert ((w16 - wav).norm() / wav.norm()).item() < 5e-2
+
+
+def test_hifigan_full_size_discriminator_gradient_is_the_loss_derivative():
+    """d(loss_disc)/d(theta_D) at B = 64 x 8192 against a central finite difference along a random direction (fp32 mode)."""
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan import engine as HE
+    eng = HE.HifiganEngine("cuda", "fp32")
+    flat = torch.zeros(eng.total[HE.D], device="cuda")
+    HE.to_flat(ohg.init_mpd_sd(78), eng.table[HE.D], flat, "mpd.")
+    HE.to_flat(ohg.init_msd_sd(79), eng.table[HE.D], flat, "msd.")
+    torch.manual_seed(9)
+    y = (torch.rand(64, 8192, device="cuda") * 2 - 1) * 0.5
+    yh = (torch.rand(64, 8192, device="cuda") * 2 - 1) * 0.5
+    grads = torch.zeros_like(flat)
+    eng.disc_forward(flat.clone(), y, yh)        # (the forward advances the spectral-norm power-iteration buffers held in the parameter buffer)
+    eng.disc_backward_d(flat.clone(), grads)
+    # direction over the weight-normed discriminators (5 MPD periods, MSD scales 1 and 2); the spectral-normed scale 0 treats its
+    # power-iteration vectors as constants in backward (like torch), which a finite difference would not
+    keep = torch.zeros_like(flat)
+    for name, off, n, shape, kind in eng.table[HE.D]:
+        if not name.startswith("msd.discriminators.0."):
+            keep[off:off + n] = 1.0
+    for trial in range(2):
+        m = keep * ((torch.rand_like(flat) < 0.5).float() if trial else 1.0)
+        v = grads * m
+        v /= v.norm()
+        gv = (grads.double() * v.double()).sum().item()
+        eps = 2e-3
+        lp = eng.disc_forward(flat + eps * v, y, yh)[0].item()
+        lm = eng.disc_forward(flat - eps * v, y, yh)[0].item()
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - gv) < 2e-2 * abs(gv), (trial, fd, gv)
