@@ -77,7 +77,7 @@ def hifigan_cpu_baseline():
             "sample": "B=2 x 8192-sample segments, full D+G iteration (G fwd, MPD+MSD x2, losses, bwd, 2 x AdamW), fp32 torch-CPU, %d timed steps" % n}
 
 
-TILE_NAMES = {"128128": "128x128", "256256": "256x256", "64128": "128x64", "64064": "64x64", "32128": "128x32"}
+TILE_NAMES = {"128128": "128x128", "256256": "256x256", "64128": "128x64", "64064": "64x64", "32128": "128x32", "128384": "384x128"}
 
 
 def pmc_traffic(family, pmc_csv):

@@ -109,8 +109,8 @@ typedef struct xva_gemm_params {
 int xva_gemm(const xva_gemm_params* p, void* stream);
 
 /* Diagnostics / test knob: main-loop selection for bf16-stored operands. -1 automatic (default), 0 general register-staged kernel,
- * 1..4 direct-to-LDS 128x128 / 256x256 / 128x64 / 64x64 tiles wherever eligible. Returns the previous mode. Results are the
- * same up to fp32 summation order. */
+ * 1..5 direct-to-LDS 128x128 / 256x256 / 128x64 / 64x64 / 128x32 tiles wherever eligible, 6 automatic without the resident-input
+ * convolution kernel, 7 the 384x128 tile (NT / NN). Returns the previous mode. Results are the same up to fp32 summation order. */
 int xva_gemm_set_mainloop(int mode);
 
 #ifdef __cplusplus

@@ -14,7 +14,7 @@ def _lib():
     return _lib
 
 
-@pytest.fixture(params=[1, 2, 3, 4, 5, -1, 6], ids=["tile128", "tile256", "tile128x64", "tile64", "tile128x32", "auto", "auto_no_resident_conv"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, -1, 6, 7], ids=["tile128", "tile256", "tile128x64", "tile64", "tile128x32", "auto", "auto_no_resident_conv", "tile384x128"])
 def mainloop(request):
     L = _lib()
     old = L.lib.xva_gemm_set_mainloop(request.param)

@@ -1,5 +1,5 @@
 """A/B of the direct-to-LDS GEMM tiles on the FastPitch decoder shapes: python tools/gemm_tile_ab.py [mode ...]
-(modes of xva_gemm_set_mainloop: -1 auto, 2 = 256x256 / 8 waves, 7 = 256x256 / 4 waves of 128x128, 1 = 128x128)."""
+(modes of xva_gemm_set_mainloop: -1 auto, 2 = 256x256, 1 = 128x128, 7 = 384x128 for NT / NN)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

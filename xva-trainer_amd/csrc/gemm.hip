@@ -82,10 +82,12 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (p.N <= 32) glds_tile = 4;
         else if (p.N <= 64) glds_tile = 2;
         else if (nkt < 4) glds_tile = ntiles(0) >= 1024 ? 0 : 3;     // short reductions are prologue / epilogue bound: many small workgroups
+        else if (p.layout != XVA_GEMM_TN && p.N > 256 && p.N <= 384 && ntiles(5) >= 160 && !can_split) glds_tile = 5;   // 384 x 128 tiles: no padded columns
         else if (t256 * maxsk >= 192 && eff256 >= 0.7) glds_tile = 1;
         else if (ntiles(0) * maxsk >= 256) glds_tile = 0;
         else glds_tile = 3;
-        if (glds_env >= 1 && glds_env <= 5) glds_tile = glds_env - 1;   // forced: 1 -> 128x128, 2 -> 256x256, 3 -> 128x64, 4 -> 64x64, 5 -> 128x32
+        if (glds_env >= 1 && glds_env <= 5) glds_tile = glds_env - 1;
+        if (glds_env == 7 && p.layout != XVA_GEMM_TN) glds_tile = 5;     // forced 384x128 (NT / NN)   // forced: 1 -> 128x128, 2 -> 256x256, 3 -> 128x64, 4 -> 64x64, 5 -> 128x32
         int bm; xva_gemm_glds_tile_dims(glds_tile, &bm, &bn);
         bn = bn * 1000 + bm;   // profile tag
         if (can_split) {   // 256x256 tiles: at most one round of 256 workgroups; smaller tiles (2-3 per CU): ~1.7 rounds; >= 8 K tiles per split

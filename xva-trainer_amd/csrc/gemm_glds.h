@@ -506,7 +506,7 @@ constexpr int epi_scratch_bytes(int WN) { return 16 * (WN + 4) * 4; }
 // vec_epi: 1 = host-verified that N % 4 == 0 and C / R / G rows are 4-element aligned (vector epilogue allowed); 2 = 8-element
 // granularity as well (row-contiguous epilogue through LDS)
 template <int LAYOUT, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 256 * 256) ? 1 : (BM * BN >= 128 * 128 ? 2 : 3)) void xva_gemm_glds_kernel(xva_gemm_params p, int vec_epi) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2 > 80 * 1024) ? 1 : (BM * BN >= 128 * 128 ? 2 : 3)) void xva_gemm_glds_kernel(xva_gemm_params p, int vec_epi) {
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
     constexpr int MI = WM / 16, NJ = WN / 16;
     constexpr int AK = LAYOUT == XVA_GEMM_TN ? IC : KC;

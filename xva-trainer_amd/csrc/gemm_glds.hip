@@ -112,19 +112,20 @@ static int launch_layout(const xva_gemm_params& p, int vec, hipStream_t st) {
     }
 }
 // tile: 0 = 128x128 (4 waves of 64x64), 1 = 256x256 (8 waves of 128x64), 2 = 128x64 (4 waves of 32x64), 3 = 64x64 (4 waves of 32x32),
-//       4 = 128x32 (4 waves of 32x32)
+//       4 = 128x32 (4 waves of 32x32), 5 = 384x128 (8 waves of 96x64; NT / NN only: a 384-wide index-contiguous operand image is not laid out)
 static int launch_tiles(const xva_gemm_params& p, int tile, int vec, hipStream_t st) {
     switch (tile) {
         case 1: return launch_layout<256, 256, 128, 64>(p, vec, st);
         case 2: return launch_layout<128, 64, 32, 64>(p, vec, st);
         case 3: return launch_layout<64, 64, 32, 32>(p, vec, st);
         case 4: return launch_layout<128, 32, 32, 32>(p, vec, st);       // N <= 32: no padded columns through the matrix pipe
+        case 5: return launch_layout<384, 128, 96, 64>(p, vec, st);      // 256 < N <= 384 (FastPitch d_model): no padded columns, one workgroup per CU
         default: return launch_layout<128, 128, 64, 64>(p, vec, st);
     }
 }
 void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn) {
-    static const int d[5][2] = {{128, 128}, {256, 256}, {128, 64}, {64, 64}, {128, 32}};
-    *bm = d[tile % 5][0]; *bn = d[tile % 5][1];
+    static const int d[6][2] = {{128, 128}, {256, 256}, {128, 64}, {64, 64}, {128, 32}, {384, 128}};
+    *bm = d[tile % 6][0]; *bn = d[tile % 6][1];
 }
 
 static int vec_epilogue_ok(const xva_gemm_params& p) {
