@@ -84,6 +84,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         else if (nkt < 4) glds_tile = ntiles(0) >= 1024 ? 0 : 3;     // short reductions are prologue / epilogue bound: many small workgroups
         else if (p.layout != XVA_GEMM_TN && p.N > 256 && p.N <= 384 && ntiles(5) >= 160 && !can_split) glds_tile = 5;   // 384 x 128 tiles: no padded columns
         else if (t256 * maxsk >= 192 && eff256 >= 0.7) glds_tile = 1;
+        else if (p.layout != XVA_GEMM_TN && p.N % 128 == 0 && !can_split && ntiles(5) >= 176 && ntiles(5) <= 256) glds_tile = 5;   // one round of 384x128 tiles beats 1.x rounds of 128x128
         else if (ntiles(0) * maxsk >= 256) glds_tile = 0;
         else glds_tile = 3;
         if (glds_env >= 1 && glds_env <= 5) glds_tile = glds_env - 1;
