@@ -51,10 +51,12 @@ static inline int xva_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 #ifdef __HIPCC__
 __device__ __forceinline__ bool xva_row_live(int mode, const int* __restrict__ lens, int Tp, long r) {
     if (mode == XVA_MASK_NONE) return true;
-    int t = (int)(r % Tp);
+    int t, b;
+    if (r >= 0 && r < (1l << 31)) {   // 32-bit division (a 64-bit one is ~100 VALU instructions per row: LayerNorm rows are issue-bound)
+        b = (int)((unsigned)r / (unsigned)Tp); t = (int)((unsigned)r - (unsigned)b * (unsigned)Tp);
+    } else { b = (int)(r / Tp); t = (int)(r - (long)b * Tp); }
     if (t == 0 || t == Tp - 1) return false;
     if (mode == XVA_MASK_PAD) return true;
-    int b = (int)(r / Tp);
     return t <= lens[b];
 }
 
