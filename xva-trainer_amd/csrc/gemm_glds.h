@@ -584,42 +584,59 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // K loop, two LDS stages, ONE AND A HALF tiles in flight: the DMA of tile kt + 2 is issued in the middle of tile kt — as soon as every
+    // wave has read the second half of tile kt out of its buffer (barrier A) — and only tile kt + 1 has to have landed at the end of the
+    // iteration (`vmcnt(LOADS)` leaves the youngest tile's loads outstanding; barrier B).  Inside a training step the operands come from
+    // HBM (the producer's writes do not stay in the Infinity Cache) and one tile of prefetch distance did not cover that latency.
+    constexpr int LOADS = Loader<AK, BM, NW>::NI + Loader<BKD, BN, NW>::NI;          // DMA instructions per wave per tile
+    constexpr int WAIT_YOUNGEST = 0x0F70 | (LOADS & 15) | ((LOADS >> 4) << 14);       // s_waitcnt vmcnt(LOADS)
+    auto read_frags = [&](const XVA_LDS uint8_t* At, const XVA_LDS uint8_t* Bt, int kh, bf16x8 (&af)[MI], bf16x8 (&bfr)[NJ]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if constexpr (BKD == KC) bfr[j] = krb.read(Bt, wn * WN + j * 16, kh);
+            else bfr[j] = irb.read(Bt, j, kh);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if constexpr (AK == KC) af[i] = kra.read(At, wm * WM + i * 16, kh);
+            else af[i] = ira.read(At, i, kh);
+        }
+        if (p.a_lrelu) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
+        }
+        if (p.b_lrelu) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag(bfr[j], p.b_slope);
+        }
+    };
+    auto mfma_all = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[NJ]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // swapped: lane = 4 columns of a row
+    };
     if (kt_begin < kt_end) issue(kt_begin, 0);
-    __syncthreads();
+    if (kt_begin + 1 < kt_end) { issue(kt_begin + 1, 1); __builtin_amdgcn_s_waitcnt(WAIT_YOUNGEST); }
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
     XVA_T(1);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
         const XVA_LDS uint8_t* At = smem + cur * BUF;
         const XVA_LDS uint8_t* Bt = At + A_BYTES;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            bf16x8 af[MI], bfr[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if constexpr (BKD == KC) bfr[j] = krb.read(Bt, wn * WN + j * 16, kh);
-                else bfr[j] = irb.read(Bt, j, kh);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                if constexpr (AK == KC) af[i] = kra.read(At, wm * WM + i * 16, kh);
-                else af[i] = ira.read(At, i, kh);
-            }
-            if (p.a_lrelu) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
-            }
-            if (p.b_lrelu) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag(bfr[j], p.b_slope);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // swapped: lane = 4 columns of a row
-        }
-        __syncthreads();
+        bf16x8 af[MI], bfr[NJ];
+        read_frags(At, Bt, 0, af, bfr);
+        mfma_all(af, bfr);
+        read_frags(At, Bt, 1, af, bfr);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): this wave's reads of the buffer are in registers
+        __builtin_amdgcn_s_barrier();                            // A: the buffer of tile kt is free
+        const bool more = kt + 2 < kt_end;
+        if (more) issue(kt + 2, cur);
+        mfma_all(af, bfr);
+        if (more) __builtin_amdgcn_s_waitcnt(WAIT_YOUNGEST); else __builtin_amdgcn_s_waitcnt(0x0F70);   // tile kt + 1 has landed (tile kt + 2 may be in flight)
+        __builtin_amdgcn_s_barrier();                            // B
     }
     XVA_T(2);
     if (rows_epilogue_ok(p, vec_epi))
