@@ -719,41 +719,55 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // weight tiles: two LDS stages, one and a half tiles in flight (see xva_gemm_glds_kernel)
+    constexpr int LOADS = Loader<BKD, BN, NW>::NI;
+    constexpr int WAIT_YOUNGEST = 0x0F70 | (LOADS & 15) | ((LOADS >> 4) << 14);       // s_waitcnt vmcnt(LOADS)
+    auto read_frags = [&](const XVA_LDS uint8_t* Bt, int kt, int kh, bf16x8 (&af)[MI], bf16x8 (&bfr)[NJ]) {
+        const int kk0 = kt * GK + kh * 32;
+        const int tap = min(kk0 / CIN, ntaps - 1);          // a ragged last K tile multiplies zero weights: stay inside the tile
+        const int ch = (kk0 % CIN) / 8 + g;
+        const int shift = tap * dstep;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if constexpr (BKD == KC) bfr[j] = krb.read(Bt, wn * WN + j * 16, kh);
+            else bfr[j] = irb.read(Bt, j, kh);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = arow + i * 16 + shift;
+            af[i] = *reinterpret_cast<const XVA_LDS bf16x8*>(smem + r * (CIN * 2) + ((ch ^ res_swz<CIN>(r)) << 4));
+        }
+        if (p.a_lrelu) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
+        }
+    };
+    auto mfma_all = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[NJ]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    };
     lb.issue(b_base(0), 0, p.K, smem + A_BYTES, wave);
-    __syncthreads();
+    if (nkt > 1) { lb.issue(b_base(GK), GK, p.K, smem + A_BYTES + B_BYTES, wave); __builtin_amdgcn_s_waitcnt(WAIT_YOUNGEST); }
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
     XVA_T(1);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) lb.issue(b_base((kt + 1) * GK), (kt + 1) * GK, p.K, smem + A_BYTES + (cur ^ 1) * B_BYTES, wave);
         const XVA_LDS uint8_t* Bt = smem + A_BYTES + cur * B_BYTES;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            const int kk0 = kt * GK + kh * 32;
-            const int tap = min(kk0 / CIN, ntaps - 1);          // a ragged last K tile multiplies zero weights: stay inside the tile
-            const int ch = (kk0 % CIN) / 8 + g;
-            const int shift = tap * dstep;
-            bf16x8 af[MI], bfr[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if constexpr (BKD == KC) bfr[j] = krb.read(Bt, wn * WN + j * 16, kh);
-                else bfr[j] = irb.read(Bt, j, kh);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int r = arow + i * 16 + shift;
-                af[i] = *reinterpret_cast<const XVA_LDS bf16x8*>(smem + r * (CIN * 2) + ((ch ^ res_swz<CIN>(r)) << 4));
-            }
-            if (p.a_lrelu) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
+        bf16x8 af[MI], bfr[NJ];
+        read_frags(Bt, kt, 0, af, bfr);
+        mfma_all(af, bfr);
+        read_frags(Bt, kt, 1, af, bfr);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();                            // A: the weight buffer of tile kt is free
+        const bool more = kt + 2 < nkt;
+        if (more) lb.issue(b_base((kt + 2) * GK), (kt + 2) * GK, p.K, smem + A_BYTES + cur * B_BYTES, wave);
+        mfma_all(af, bfr);
+        if (more) __builtin_amdgcn_s_waitcnt(WAIT_YOUNGEST); else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();                            // B: tile kt + 1 has landed
     }
     XVA_T(2);
     if (rows_epilogue_ok(p, vec_epi))
