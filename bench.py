@@ -224,18 +224,39 @@ def hifigan_leg(a, dev, rank, world):
     return res
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run, one rank per GPU
+    (the reference's DP entry is single-process nn.DataParallel, python/fastpitch1_1/xva_train.py:465-466; here N processes
+    over RCCL).  Fails loudly when the node has fewer than N devices."""
+    import socket
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.exit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (n, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a.gpus)                              # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world and world > 1:
-        a.gpus = world
+    if a.gpus != world:
+        sys.exit("bench.py: --gpus %d does not match the launcher's WORLD_SIZE %d" % (a.gpus, world))
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit("bench.py: rank %d needs cuda:%d but only %d GPU(s) are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == world
 
     from xva_trainer_amd import _lib, synthetic
     from xva_trainer_amd.fastpitch import engine as E, params as P

@@ -69,6 +69,42 @@ int xva_mel_l1_loss_backward(const xva_mel_config* cfg, const float* wav, int B,
                              const float* dft_basis, const float* mel_basis_padded, float scale, float* mel_out, float* loss_out,
                              float* d_wav, int64_t ld_dwav, int accumulate, float* workspace, int64_t workspace_bytes, void* stream);
 
+/* --------------------------------------------------------- on-device batch preparation ---- */
+/* What the reference does on the CPU in DataLoader workers, moved next to the mel kernels: the host hands over RAGGED
+ * data as it comes off disk (int16 clips, symbol ids, cached pitch / durations) concatenated into flat buffers with an
+ * offsets array (int64, elements, B entries) and per-item lengths (int32); everything below is one coalesced pass. */
+#define XVA_DATA_I16 0
+#define XVA_DATA_I32 1
+#define XVA_DATA_I64 2
+#define XVA_DATA_F32 3
+#define XVA_DATA_F64 4
+/* TTSCollate's descending sort by text length (python/fastpitch1_1/fastpitch/data_function.py:569-572):
+ * order[r] = index of the r-th longest item, ties in ascending item order (stable).  B <= 4096. */
+int xva_data_rank_desc(const int32_t* lens, int B, int32_t* order, void* stream);
+/* TTSCollate's right zero-padding (data_function.py:574-660) of text ids / pitch / durations: item i is an
+ * (inner, lens[i]) row-major slab at flat[offsets[i] * inner]; dst (B, inner, max_len) row r = item order[r] (order may be
+ * NULL), truncated / zero-padded to max_len, converted src_dtype -> dst_dtype.  lens_out (B, may be NULL) = min(len, max_len). */
+int xva_data_pad_gather(const void* flat, int src_dtype, const int64_t* offsets, const int32_t* lens, const int32_t* order, void* dst,
+                        int dst_dtype, int B, int inner, int max_len, int32_t* lens_out, void* stream);
+/* TTSDataset.get_mel + the mel part of TTSCollate (data_function.py:385-429,574-590) + energy (:327): clips are int16,
+ * y = x / 32768, each reflect-padded by its own length; mel_out (B, n_mel, T(Nmax)) with frames past a clip's own
+ * n_frames_out[r] zeroed; energy_out (B, T) = ||mel[:, t]||_2 (may be NULL).  Row r = clip order[r] (order may be NULL).
+ * Workspace: xva_mel_workspace_bytes(cfg, B, Nmax). */
+int xva_mel_spectrogram_ragged(const xva_mel_config* cfg, const int16_t* flat, const int64_t* offsets, const int32_t* n_samples,
+                               const int32_t* order, int B, int Nmax, const float* dft_basis, const float* mel_basis_padded,
+                               float* mel_out, float* energy_out, int32_t* n_frames_out, float* workspace, int64_t workspace_bytes,
+                               void* stream);
+int xva_mel_finish_ragged(float* mel, const int32_t* n_frames, float* energy, int B, int n_mel, int T, void* stream);
+/* beta_binomial_prior_distribution + its collate (data_function.py:84-94,640-660): out (B, Tm, Tt) fp32,
+ * out[r][m][k] = betabinom(n = P, a = m + 1, b = M - m).pmf(k) for m < M = mel_lens[r], k < P = text_lens[r], else 0. */
+int xva_data_betabinom_prior(const int32_t* text_lens, const int32_t* mel_lens, float* out, int B, int Tm, int Tt, void* stream);
+/* MelDataset.__getitem__ (python/hifigan/meldataset.py:340-373): peak[i] = max|x| of clip i (int16 magnitudes);
+ * out (B, seg) fp32 = (x / 32768) / (peak / 32768) * gain over [starts[r], starts[r] + seg) of clip r, zero past its end
+ * (normalize = 0: plain x / 32768).  Arithmetic in fp64 then rounded to fp32, as numpy + torch.FloatTensor do. */
+int xva_wav_peak_i16(const int16_t* flat, const int64_t* offsets, const int32_t* lens, int B, int32_t* peak, void* stream);
+int xva_wav_crop_norm(const int16_t* flat, const int64_t* offsets, const int32_t* lens, const int32_t* starts, const int32_t* peak,
+                      float* out, int B, int seg, double gain, int normalize, void* stream);
+
 /* ------------------------------------------------------------- FastPitch 1.1 engine ---- */
 /* Replaces, for training stages 2-4, the PyTorch graph behind
  *   y_pred = FastPitch.forward(x)          python/fastpitch1_1/fastpitch/model.py:325-423
@@ -285,6 +321,17 @@ int xva_hg_generator_forward(const xva_hg_dims* d, const float* params_g, const 
 /* d_wav: (B, seg) fp32 gradient w.r.t. the generated waveform; accumulates into grads_g */
 int xva_hg_generator_backward(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* workspace,
                               int64_t workspace_bytes, void* stream);
+/* Data-parallel variants (the reference's nn.DataParallel reduce step, python/fastpitch1_1/xva_train.py:48-53; HiFi-GAN's
+ * unused dist_config in python/hifigan/config_v1.json:32-36): the flat gradient buffer `which` splits into
+ * xva_hg_num_buckets(which) contiguous buckets listed in backward-completion order; the *_ex backward records
+ * bucket_events[i] (xva_event_create handles, entries or the array may be NULL) on `stream` as soon as bucket i's
+ * gradients are final, so the caller can all-reduce it on a side stream under the rest of backward. */
+int xva_hg_num_buckets(int which);
+int xva_hg_bucket_range(int which, int i, int64_t* begin, int64_t* end);
+int xva_hg_generator_backward_ex(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* workspace,
+                                 int64_t workspace_bytes, void* const* bucket_events, void* stream);
+int xva_hg_disc_backward_d_ex(const xva_hg_dims* d, float* params_d, float* grads_d, const float* y_real, const float* y_fake,
+                              void* workspace, int64_t workspace_bytes, void* const* bucket_events, void* stream);
 /* MPD + MSD on (real, fake) waveforms (B, seg) fp32 (xva_train.py:488-493 / 506-507).  `losses` (device, 4 floats or
  * NULL) receives {discriminator loss, generator LSGAN loss, feature-matching loss, -} (models.py:263-294).  params_d is
  * mutable: each pass of the spectral-norm discriminator advances weight_u / weight_v by one power iteration. */

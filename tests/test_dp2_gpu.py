@@ -1,0 +1,163 @@
+"""GPU, world size 2, PRODUCT data-parallel paths (the counterpart of tests/test_dp_cpu.py, which checks the semantics with oracle math):
+fastpitch/dp.py:GradSync and hifigan/step.py:BucketSync — per-bucket HIP events recorded by the engine's backward, side-stream
+all-reduce — on two ranks against the single-process full-batch gradient of the same engine.
+
+Two launch modes:
+  * `nccl`  — one rank per GPU over RCCL; needs >= 2 GPUs (skipped otherwise).  This is what bench.py --gpus N runs.
+  * `gloo`  — both ranks on cuda:0 with torch's gloo backend on device tensors: the same product code (events, side stream,
+              bucket ranges, global loss normalisation) on a 1-GPU box; only the transport differs.
+Replaces the reference's nn.DataParallel (python/fastpitch1_1/xva_train.py:48-53,465-466)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _full_batch(ofp):
+    # two ragged pairs that each contain a full-length item: every shard pads to the same lengths as the global batch
+    a, b = ofp.synth_batch(2, 12, 44, 22), ofp.synth_batch(2, 12, 44, 23)
+    return {k: torch.cat([a[k], b[k]]) for k in a}
+
+
+def _init(rank, world, port, backend):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist, dev
+
+
+def _fp_worker(rank, world, port, backend, stage, out_file):
+    dist, dev = _init(rank, world, port, backend)
+    try:
+        from oracle import fastpitch as ofp
+        from xva_trainer_amd.fastpitch import engine as E, params as P
+        from xva_trainer_amd.fastpitch.dp import GradSync
+        sd = ofp.init_state_dict(21)
+        full = _full_batch(ofp)
+        shard = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
+        eng = E.FastPitchEngine(dev, "fp32", p_dropout=0.0, seed=5)
+        flat = torch.zeros(eng.total, device=dev)
+        P.to_flat(sd, eng.table, flat)
+        grads = torch.zeros_like(flat)
+        sync = GradSync(eng, flat, grads, world)
+        losses = sync.fwd_loss_bwd(E.DeviceBatch.from_dict(shard, dev), stage)
+        # gradient accumulation over two micro-batches, only the second one synchronises
+        grads2 = torch.zeros_like(flat)
+        sync2 = GradSync(eng, flat, grads2, world)
+        sync2.fwd_loss_bwd(E.DeviceBatch.from_dict(shard, dev), stage, grad_scale=0.5, sync=False)
+        sync2.fwd_loss_bwd(E.DeviceBatch.from_dict(shard, dev), stage, grad_scale=0.5, sync=True)
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({"grads": grads.cpu(), "grads2": grads2.cpu(), "losses": losses.cpu()}, out_file)
+    finally:
+        dist.destroy_process_group()
+
+
+def _hg_worker(rank, world, port, backend, out_file):
+    dist, dev = _init(rank, world, port, backend)
+    try:
+        from oracle import hifigan as ohg
+        from xva_trainer_amd.hifigan.step import HifiganStep
+        st = HifiganStep(dev, "fp32")
+        assert st.world == world and st.sync_d is not None and st.sync_g is not None
+        st.load_state_dicts(ohg.init_generator_sd(1), ohg.init_mpd_sd(2), ohg.init_msd_sd(3))
+        x, y, ym = ohg.synth_batch(2, 4)
+        sl = slice(rank, rank + 1)
+        out = st.train_step(x[sl].to(dev), y[sl].to(dev), ym[sl].to(dev))
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({"gd": st.grads_d.cpu(), "gg": st.grads_g.cpu(), "fd": st.flat_d.cpu(), "fg": st.flat_g.cpu(),
+                        "loss_mel": out["loss_mel"].cpu()}, out_file)
+    finally:
+        dist.destroy_process_group()
+
+
+def _backends():
+    return [pytest.param("nccl", marks=pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL refuses two ranks on one device)")),
+            pytest.param("gloo")]
+
+
+def _spawn(fn, args):
+    try:
+        mp.spawn(fn, args=args, nprocs=2, join=True)
+    except Exception as e:                                           # a gloo build without device-tensor support is an environment gap, not a product failure
+        if args[2] == "gloo" and ("gloo" in str(e).lower() and "cuda" in str(e).lower() and "support" in str(e).lower()):
+            pytest.skip("this torch build's gloo has no device-tensor all-reduce: %s" % str(e).splitlines()[-1])
+        raise
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("backend", _backends())
+@pytest.mark.parametrize("stage", [3, 2])
+def test_gradsync_world2_equals_full_batch(tmp_path, backend, stage):
+    sys.path.insert(0, ROOT)
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd.fastpitch import engine as E, params as P
+    out_file = str(tmp_path / "fp.pt")
+    _spawn(_fp_worker, (2, _free_port(), backend, stage, out_file))
+    res = torch.load(out_file, weights_only=False)
+    sd = ofp.init_state_dict(21)
+    eng = E.FastPitchEngine("cuda:0", "fp32", p_dropout=0.0, seed=5)
+    flat = torch.zeros(eng.total, device="cuda:0")
+    P.to_flat(sd, eng.table, flat)
+    ref = torch.zeros_like(flat)
+    l_ref = eng.fwd_loss_bwd(flat, ref, E.DeviceBatch.from_dict(_full_batch(ofp), "cuda:0"), stage).cpu()
+    ref = ref.cpu()
+    assert torch.allclose(res["losses"][:5], l_ref[:5], rtol=1e-5, atol=1e-6), (res["losses"], l_ref)     # globally normalised loss
+    for key in ("grads", "grads2"):
+        rel = ((res[key] - ref).norm() / ref.norm()).item()
+        assert rel < 1e-4, (key, rel)
+        # every bucket individually (a bucket that was never reduced would be off by 2x, one reduced twice as well)
+        from xva_trainer_amd.fastpitch import dp
+        for i in dp.buckets_for_stage(stage):
+            b, e = dp.bucket_ranges()[i]
+            n = ref[b:e].norm().item()
+            if n > 0:
+                assert ((res[key][b:e] - ref[b:e]).norm().item() / n) < 1e-3, (key, i)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("backend", _backends())
+def test_hifigan_bucketsync_world2_equals_full_batch(tmp_path, backend):
+    sys.path.insert(0, ROOT)
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan import engine as HE
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    out_file = str(tmp_path / "hg.pt")
+    _spawn(_hg_worker, (2, _free_port(), backend, out_file))
+    res = torch.load(out_file, weights_only=False)
+    st = HifiganStep("cuda:0", "fp32")
+    st.load_state_dicts(ohg.init_generator_sd(1), ohg.init_mpd_sd(2), ohg.init_msd_sd(3))
+    x, y, ym = ohg.synth_batch(2, 4)
+    out = st.train_step(x.cuda(), y.cuda(), ym.cuda())
+    torch.cuda.synchronize()
+    # the mel loss is a per-rank mean here (rank 0 holds item 0 only): compare gradients and updated parameters, which are global
+    for which, key, ref in ((HE.D, "gd", st.grads_d.cpu()), (HE.G, "gg", st.grads_g.cpu())):
+        n = st.eng.trainable[which]
+        rel = ((res[key][:n] - ref[:n]).norm() / ref[:n].norm()).item()
+        assert rel < (1e-4 if which == HE.D else 2e-3), (key, rel)    # G gradients pass through the D update (AdamW of nearly equal gradients)
+        for i, (b, e) in enumerate(HE.bucket_ranges(which)):
+            nb = ref[b:e].norm().item()
+            assert nb > 0 and ((res[key][b:e] - ref[b:e]).norm().item() / nb) < (1e-3 if which == HE.D else 2e-2), (key, i)
+    assert ((res["fd"] - st.flat_d.cpu()).abs().max().item()) < 5e-4      # one AdamW step moves a weight by <= lr = 2e-4
+    assert ((res["fg"] - st.flat_g.cpu()).abs().max().item()) < 5e-4

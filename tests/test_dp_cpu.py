@@ -95,3 +95,19 @@ def test_bucket_ranges_cover_trainable_params():
     assert dp.buckets_for_stage(3) == list(range(13))
     assert dp.buckets_for_stage(2) == [6, 7, 8, 9, 10, 11, 12]
     assert rng[0][1] > rng[5][0] and rng[12][0] == 0       # decoder buckets come first, the embedding bucket last
+
+
+def test_hifigan_bucket_ranges_tile_the_trainable_prefix():
+    """hifigan/step.py:BucketSync exchanges each flat gradient buffer in the engine's buckets: 8 discriminators / 6 generator
+    ranges that tile [0, trainable) without overlap (the spectral-norm buffers behind it are never exchanged)."""
+    from xva_trainer_amd.hifigan import engine as HE
+    for which, nb in ((HE.G, 6), (HE.D, 8)):
+        rng = HE.bucket_ranges(which)
+        assert len(rng) == nb
+        srt = sorted(rng)
+        assert srt[0][0] == 0 and srt[-1][1] == int(HE.lib.xva_hg_trainable_floats(which))
+        assert all(a[1] == b[0] for a, b in zip(srt, srt[1:]))
+    d = HE.bucket_ranges(HE.D)
+    assert d == sorted(d)                                   # discriminators finish in buffer order (MPD 0..4, MSD 0..2)
+    g = HE.bucket_ranges(HE.G)
+    assert g[0][0] > g[3][0] and g[4][0] == 0               # generator: last stage's resblocks first, conv_pre + ups last

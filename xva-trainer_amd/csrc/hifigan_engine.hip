@@ -418,10 +418,13 @@ int gen_forward(Ctx& c, const float* P, const float* mel, float* wav_out) {
     return XVA_OK;
 }
 
-int wn_backward(Ctx& c, const std::vector<Layer>& L, const float* P, float* G) {
+// weight-norm backward of layers li[0..n) of L (li == nullptr: all of L)
+int wn_backward(Ctx& c, const std::vector<Layer>& L, const float* P, float* G, const int* li = nullptr, int n = 0) {
     std::vector<xva_wn_desc> ds;
     ds.reserve(L.size());
-    for (const Layer& l : L) {
+    const int cnt = li ? n : (int)L.size();
+    for (int q = 0; q < cnt; ++q) {
+        const Layer& l = L[li ? li[q] : q];
         if (l.kind == LK_SN) continue;
         xva_wn_desc d;
         memset(&d, 0, sizeof(d));
@@ -429,17 +432,25 @@ int wn_backward(Ctx& c, const std::vector<Layer>& L, const float* P, float* G) {
         d.kind = l.kind == LK_WNT ? 1 : 0; d.D0 = l.D0(); d.D1 = l.D1(); d.k = l.k;
         ds.push_back(d);
     }
+    if (ds.empty()) return XVA_OK;
     return xva_hg_weight_norm_batch(ds.data(), (int)ds.size(), 1, c.st);
+}
+int record(const Ctx& c, void* const* events, int i) {
+    if (!events || !events[i]) return XVA_OK;
+    if (hipEventRecord((hipEvent_t)events[i], (hipStream_t)c.st) != hipSuccess) { xva_set_error("hifigan: hipEventRecord failed"); return XVA_ERR_HIP; }
+    return XVA_OK;
 }
 int zero_dweff(Ctx& c, const std::vector<Layer>& L) {
     const int64_t* r = (&L == &c.pl.gl) ? c.pl.dw_g : c.pl.dw_d;
     return zero(c, c.W + r[0], r[1] - r[0]);
 }
 // gradients of the padded first-layer weights -> the layer's dweff ([Cout][k], tap-major with Cin = 1)
-int fold_dwp(Ctx& c, const std::vector<Layer>& L) {
-    for (const Layer& l : L)
+int fold_dwp(Ctx& c, const std::vector<Layer>& L, const int* li, int n) {
+    for (int q = 0; q < n; ++q) {
+        const Layer& l = L[li[q]];
         for (int p = 0; p < 2; ++p)
             if (l.dwp[p] >= 0 && l.dweff[p] >= 0) XVA_TRY(xva_hg_unpad_cols_add(c.F(l.dwp[p]), c.F(l.dweff[p]), l.Cout, l.k, l.kp(), c.st));
+    }
     return XVA_OK;
 }
 
@@ -451,7 +462,10 @@ Seq as_stage(const Ctx& c, const SeqSpec& s, int T, int C) {
     return c.S(v);
 }
 
-int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav) {
+// Gradient buckets of the generator in backward-completion order (each a contiguous range of the flat buffer):
+// 0..3 = the resblocks of stages 3..0, 4 = conv_pre + ups.0-3, 5 = conv_post.
+constexpr int G_BUCKETS = 6;
+int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav, void* const* events) {
     const Plan& pl = c.pl; const GenNet& N = gnet(); const auto& L = pl.gl;
     XVA_TRY(zero_dweff(c, L));
     Seq y = c.S(pl.y), dy = c.S(pl.g_dy);
@@ -505,13 +519,22 @@ int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav) {
         XVA_TRY(xva_hg_colsum(du.ptr(), c.dt, G + L[N.ups[i]].bias, du.rows(), C, 1.f, c.st));
         XVA_TRY(zero(c, dprev.ptr(), dprev.rows() * dprev.C * dprev.es()));     // per-item GEMM writes valid rows only: pads must be zero
         XVA_TRY(hg_convT_bwd_data(du, dprev, wt, &prev, SLOPE, c.compute, c.st));
+        {   // this stage's resblock gradients are final: reparametrisation backward, then the bucket's event
+            int li[18], n = 0;
+            for (int j = 0; j < 3; ++j) for (int m = 0; m < 3; ++m) { li[n++] = N.rc1[i * 3 + j][m]; li[n++] = N.rc2[i * 3 + j][m]; }
+            XVA_TRY(wn_backward(c, L, P, G, li, n));
+            XVA_TRY(record(c, events, 3 - i));
+        }
     }
     {   // conv_pre backward (weights only)
         Seq dh0 = as_stage(c, pl.g_dxs, pl.T[0], 512), xin = c.S(pl.xin);
         XVA_TRY(hg_conv_bwd_weight(dh0, xin, cw(c, L[N.pre], P), 0, 0.f, 1.f, c.compute, c.st));
         XVA_TRY(xva_hg_colsum(dh0.ptr(), c.dt, G + L[N.pre].bias, dh0.rows(), 512, 1.f, c.st));
     }
-    return wn_backward(c, L, P, G);
+    const int rest[6] = {N.pre, N.ups[0], N.ups[1], N.ups[2], N.ups[3], N.post};
+    XVA_TRY(wn_backward(c, L, P, G, rest, 6));
+    XVA_TRY(record(c, events, 4));
+    return record(c, events, 5);
 }
 
 // ================================================================== discriminators ====
@@ -728,12 +751,17 @@ int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* lo
 }
 
 // D-step backward: gradients of sum_d [mean((1 - D(y))^2) + mean(D(G(x))^2)] w.r.t. all discriminator parameters
-int discs_backward_d(Ctx& c, float* Pd, float* Gd, const float* yr, const float* yg) {
+// Gradient buckets of the discriminators = the 8 discriminators in backward order (MPD 0..4, MSD 0..2); each owns one
+// contiguous range of the flat buffer and is finalised (bias sums, reparametrisation backward) as soon as its backward is done.
+constexpr int D_BUCKETS = NPER + 3;
+int discs_backward_d(Ctx& c, float* Pd, float* Gd, const float* yr, const float* yg, void* const* events) {
     std::vector<DiscSet> sets; std::vector<DiscRun> snr;
     build_sets(c, yr, yg, sets, snr);
     std::vector<xva_cs_desc> colsums;
     XVA_TRY(zero_dweff(c, c.pl.dl));
+    int di = 0;
     for (auto& s : sets) {
+        colsums.clear();
         const int n = s.run.n;
         const float inv = 1.f / (float)((int64_t)s.nf * s.run.t[n].T);
         Seq g = c.S(s.run.t[n]).slice(s.f0, s.nf), dg = c.S(s.run.d[n]).slice(s.f0, s.nf);
@@ -749,15 +777,18 @@ int discs_backward_d(Ctx& c, float* Pd, float* Gd, const float* yr, const float*
             XVA_TRY(xva_hg_seed_grad(r.ptr(), nullptr, dr.ptr(), c.dt, s.nf, r.Hp(), r.padF, r.T, 1, 0.f, inv, 3, 0, 0.f, 1, c.st));
             XVA_TRY(disc_backward_params(c, Pd, Gd, s.run, 0, 2 * s.nf, s.wr, s.nb, s.wg, colsums));
         }
-    }
-    XVA_TRY(xva_hg_colsum_batch(colsums.data(), (int)colsums.size(), c.st));
-    XVA_TRY(fold_dwp(c, c.pl.dl));
-    XVA_TRY(wn_backward(c, c.pl.dl, Pd, Gd));
-    for (const Layer& l : c.pl.dl) {
-        if (l.kind != LK_SN) continue;
-        for (int pass = 0; pass < 2; ++pass)
-            XVA_TRY(xva_hg_spectral_norm_bwd(c.F(l.dweff[pass]), Pd + l.wv, c.F(l.su[pass]), c.F(l.sv[pass]), c.F(l.norm[pass]), Gd + l.wv, l.D0(), l.D1(), l.k,
-                                             c.F(c.pl.sn_tmp), c.st));
+        XVA_TRY(xva_hg_colsum_batch(colsums.data(), (int)colsums.size(), c.st));
+        XVA_TRY(fold_dwp(c, c.pl.dl, s.run.li, s.run.n));
+        XVA_TRY(wn_backward(c, c.pl.dl, Pd, Gd, s.run.li, s.run.n));
+        for (int q = 0; q < s.run.n; ++q) {
+            const Layer& l = c.pl.dl[s.run.li[q]];
+            if (l.kind != LK_SN) continue;
+            for (int pass = 0; pass < 2; ++pass)
+                XVA_TRY(xva_hg_spectral_norm_bwd(c.F(l.dweff[pass]), Pd + l.wv, c.F(l.su[pass]), c.F(l.sv[pass]), c.F(l.norm[pass]), Gd + l.wv, l.D0(), l.D1(),
+                                                 l.k, c.F(c.pl.sn_tmp), c.st));
+        }
+        XVA_TRY(record(c, events, di));
+        ++di;
     }
     return XVA_OK;
 }
@@ -815,12 +846,42 @@ extern "C" int xva_hg_generator_forward(const xva_hg_dims* d, const float* param
     XVA_CHECK_ARG(params_g && mel, "generator_forward: null");
     return gen_forward(c, params_g, mel, wav_out);
 }
-extern "C" int xva_hg_generator_backward(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* ws, int64_t ws_bytes,
-                                         void* stream) {
+extern "C" int xva_hg_generator_backward_ex(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* ws, int64_t ws_bytes,
+                                            void* const* bucket_events, void* stream) {
     Ctx c;
     XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream));
     XVA_CHECK_ARG(params_g && grads_g && d_wav, "generator_backward: null");
-    return gen_backward(c, params_g, grads_g, d_wav);
+    return gen_backward(c, params_g, grads_g, d_wav, bucket_events);
+}
+extern "C" int xva_hg_generator_backward(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* ws, int64_t ws_bytes,
+                                         void* stream) {
+    return xva_hg_generator_backward_ex(d, params_g, grads_g, d_wav, ws, ws_bytes, nullptr, stream);
+}
+extern "C" int xva_hg_num_buckets(int which) { return which == 0 ? G_BUCKETS : D_BUCKETS; }
+// [begin, end) in floats of bucket i of the flat gradient buffer `which`, in backward-completion order
+extern "C" int xva_hg_bucket_range(int which, int i, int64_t* begin, int64_t* end) {
+    XVA_CHECK_ARG((which == 0 || which == 1) && i >= 0 && i < xva_hg_num_buckets(which) && begin && end, "hg_bucket_range: bad index");
+    const Net& n = net_of(which);
+    auto span = [&](const std::string& first, const std::string& last_prefix, int64_t* b, int64_t* e) {
+        *b = -1; *e = -1;
+        for (const TInfo& ti : n.t) {
+            if (ti.kind != 0) continue;
+            if (*b < 0 && ti.name.rfind(first, 0) == 0) *b = ti.off;
+            if (ti.name.rfind(last_prefix, 0) == 0) *e = ti.off + ((ti.numel + 3) & ~(int64_t)3);
+        }
+    };
+    if (which == 0) {
+        if (i < 4) {
+            const int st = 3 - i;
+            span("resblocks." + std::to_string(st * 3) + ".", "resblocks." + std::to_string(st * 3 + 2) + ".", begin, end);
+        } else if (i == 4) span("conv_pre.", "ups.3.", begin, end);
+        else span("conv_post.", "conv_post.", begin, end);
+    } else {
+        const std::string pre = i < NPER ? "mpd.discriminators." + std::to_string(i) + "." : "msd.discriminators." + std::to_string(i - NPER) + ".";
+        span(pre, pre, begin, end);
+    }
+    XVA_CHECK_ARG(*begin >= 0 && *end > *begin, "hg_bucket_range: empty bucket");
+    return XVA_OK;
 }
 
 /* yr / yg: real / generated waveforms (B, seg) fp32.  losses (device, 4 floats, may be NULL): {discriminator loss,
@@ -833,12 +894,16 @@ extern "C" int xva_hg_disc_forward(const xva_hg_dims* d, float* params_d, const 
     XVA_CHECK_ARG(params_d && yr && yg, "disc_forward: null");
     return discs_forward(c, params_d, yr, yg, losses);
 }
-extern "C" int xva_hg_disc_backward_d(const xva_hg_dims* d, float* params_d, float* grads_d, const float* yr, const float* yg, void* ws, int64_t ws_bytes,
-                                      void* stream) {
+extern "C" int xva_hg_disc_backward_d_ex(const xva_hg_dims* d, float* params_d, float* grads_d, const float* yr, const float* yg, void* ws,
+                                         int64_t ws_bytes, void* const* bucket_events, void* stream) {
     Ctx c;
     XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream));
     XVA_CHECK_ARG(params_d && grads_d && yr && yg, "disc_backward_d: null");
-    return discs_backward_d(c, params_d, grads_d, yr, yg);
+    return discs_backward_d(c, params_d, grads_d, yr, yg, bucket_events);
+}
+extern "C" int xva_hg_disc_backward_d(const xva_hg_dims* d, float* params_d, float* grads_d, const float* yr, const float* yg, void* ws, int64_t ws_bytes,
+                                      void* stream) {
+    return xva_hg_disc_backward_d_ex(d, params_d, grads_d, yr, yg, ws, ws_bytes, nullptr, stream);
 }
 extern "C" int xva_hg_disc_backward_g(const xva_hg_dims* d, float* params_d, const float* yr, const float* yg, float* d_wav, void* ws, int64_t ws_bytes,
                                       void* stream) {

@@ -93,6 +93,9 @@ extern "C" int64_t xva_mel_workspace_bytes(const xva_mel_config* c, int B, int N
     return pl.total * (int64_t)sizeof(float);
 }
 
+static int mel_core(const xva_mel_config* c, const MelPlan& pl, int B, const float* dft_basis, const float* mel_basis_padded, float* mel_out,
+                    float* workspace, void* stream);
+
 extern "C" int xva_mel_spectrogram(const xva_mel_config* c, const float* wav, int B, int N, int64_t ld_wav,
                                    const float* dft_basis, const float* mel_basis_padded, float* mel_out,
                                    float* workspace, int64_t workspace_bytes, void* stream) {
@@ -104,15 +107,59 @@ extern "C" int xva_mel_spectrogram(const xva_mel_config* c, const float* wav, in
     XVA_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "mel: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     float* ypad = workspace + pl.off_pad;
-    float* spec = workspace + pl.off_spec;
-    float* mag = workspace + pl.off_mag;
-
     {   // 1. reflect pad (plus zero the slack so over-reads of tail vectors are benign)
         int64_t total = (int64_t)B * pl.ldy;
         hipLaunchKernelGGL(xva_reflect_pad_kernel, dim3(xva_cdiv(total, 256)), dim3(256), 0, st, wav, ypad, B, N, c->pad,
                            ld_wav, pl.ldy, pl.Np);
         XVA_LAUNCH_CHECK();
     }
+    return mel_core(c, pl, B, dft_basis, mel_basis_padded, mel_out, workspace, stream);
+}
+
+// Ragged int16 clips straight off disk -> zero-padded batch mel (+ per-frame energy), the device side of TTSDataset.get_mel +
+// TTSCollate (python/fastpitch1_1/fastpitch/data_function.py:385-429,565-600): row r of the batch is clip order[r] (or r),
+// y = int16 / 32768 reflect-padded by ITS OWN length; frames past the clip's own count are zeroed by the finishing pass.
+__global__ void xva_reflect_pad_i16_ragged_kernel(const int16_t* __restrict__ flat, const int64_t* __restrict__ offsets, const int32_t* __restrict__ lens,
+                                                  const int32_t* __restrict__ order, float* __restrict__ y, int pad, int64_t ldy,
+                                                  int32_t* __restrict__ n_frames, int n_fft, int hop) {
+    const int r = blockIdx.y, i0 = order ? order[r] : r;
+    const int N = lens[i0], Np = N + 2 * pad;
+    const int16_t* x = flat + offsets[i0];
+    if (n_frames && blockIdx.x == 0 && threadIdx.x == 0) n_frames[r] = (Np - n_fft) / hop + 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ldy; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < Np) {
+            int s = (int)i - pad;
+            if (s < 0) s = -s;
+            if (s >= N) s = 2 * (N - 1) - s;
+            v = (float)x[s] * (1.0f / 32768.0f);      // exact: audio / max_wav_value with max_wav_value = 2^15 (data_function.py:408-416)
+        }
+        y[(int64_t)r * ldy + i] = v;
+    }
+}
+extern "C" int xva_mel_finish_ragged(float* mel, const int32_t* n_frames, float* energy, int B, int n_mel, int T, void* stream);
+extern "C" int xva_mel_spectrogram_ragged(const xva_mel_config* c, const int16_t* flat, const int64_t* offsets, const int32_t* n_samples,
+                                          const int32_t* order, int B, int Nmax, const float* dft_basis, const float* mel_basis_padded,
+                                          float* mel_out, float* energy_out, int32_t* n_frames_out, float* workspace, int64_t workspace_bytes,
+                                          void* stream) {
+    XVA_CHECK_ARG(c && flat && offsets && n_samples && dft_basis && mel_basis_padded && mel_out && n_frames_out && workspace, "mel_ragged: null pointer");
+    MelPlan pl;
+    XVA_TRY(mel_plan(c, B, Nmax, &pl));
+    XVA_CHECK_ARG(workspace_bytes >= pl.total * (int64_t)sizeof(float), "mel_ragged: workspace too small");
+    XVA_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "mel_ragged: workspace must be 16-byte aligned");
+    hipLaunchKernelGGL(xva_reflect_pad_i16_ragged_kernel, dim3((unsigned)(pl.ldy / 256 < 1 ? 1 : (pl.ldy / 256 > 128 ? 128 : pl.ldy / 256)), B), dim3(256), 0,
+                       (hipStream_t)stream, flat, offsets, n_samples, order, workspace + pl.off_pad, c->pad, pl.ldy, n_frames_out, c->n_fft, c->hop);
+    XVA_LAUNCH_CHECK();
+    XVA_TRY(mel_core(c, pl, B, dft_basis, mel_basis_padded, mel_out, workspace, stream));
+    return xva_mel_finish_ragged(mel_out, n_frames_out, energy_out, B, c->n_mel, pl.T, stream);
+}
+
+static int mel_core(const xva_mel_config* c, const MelPlan& pl, int B, const float* dft_basis, const float* mel_basis_padded, float* mel_out,
+                    float* workspace, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    float* ypad = workspace + pl.off_pad;
+    float* spec = workspace + pl.off_spec;
+    float* mag = workspace + pl.off_mag;
     {   // 2. windowed DFT as an overlapping-row GEMM: spec[b][t][:] = frames[b][t][:] . basis^T
         xva_gemm_params g;
         memset(&g, 0, sizeof(g));

@@ -30,8 +30,12 @@ lib.xva_hg_workspace_bytes.restype = i64
 lib.xva_hg_workspace_bytes.argtypes = [C.POINTER(HgDims)]
 lib.xva_hg_generator_forward.restype = i32
 lib.xva_hg_generator_forward.argtypes = [C.POINTER(HgDims), vp, vp, vp, i64, vp, vp]
-lib.xva_hg_generator_backward.restype = i32
-lib.xva_hg_generator_backward.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, i64, vp]
+lib.xva_hg_generator_backward_ex.restype = i32
+lib.xva_hg_generator_backward_ex.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, i64, C.POINTER(vp), vp]
+lib.xva_hg_num_buckets.restype = i32
+lib.xva_hg_num_buckets.argtypes = [i32]
+lib.xva_hg_bucket_range.restype = i32
+lib.xva_hg_bucket_range.argtypes = [i32, i32, C.POINTER(i64), C.POINTER(i64)]
 
 DT = {"fp32": 0, "bf16": 1, 0: 0, 1: 1}
 G, D = 0, 1
@@ -103,17 +107,28 @@ class HifiganEngine:
                                                 _lib.stream_ptr()), "xva_hg_generator_forward")
         return wav
 
-    def generator_backward(self, flat_g, grads_g, d_wav):
+    def generator_backward(self, flat_g, grads_g, d_wav, events=None):
+        """events: ctypes array of xva_hg_num_buckets(G) event handles recorded as each gradient bucket completes (DP overlap)."""
         d = self._dims
         d_wav = d_wav.float().contiguous()
-        _lib.check(lib.xva_hg_generator_backward(C.byref(d), _lib.ptr(flat_g), _lib.ptr(grads_g), _lib.ptr(d_wav), _lib.ptr(self._ws),
-                                                 self._ws.numel(), _lib.stream_ptr()), "xva_hg_generator_backward")
+        _lib.check(lib.xva_hg_generator_backward_ex(C.byref(d), _lib.ptr(flat_g), _lib.ptr(grads_g), _lib.ptr(d_wav), _lib.ptr(self._ws),
+                                                    self._ws.numel(), events, _lib.stream_ptr()), "xva_hg_generator_backward_ex")
+
+
+def bucket_ranges(which):
+    """[begin, end) float ranges of the gradient buckets of flat buffer `which`, in backward-completion order."""
+    out = []
+    for i in range(lib.xva_hg_num_buckets(which)):
+        b, e = i64(), i64()
+        _lib.check(lib.xva_hg_bucket_range(which, i, C.byref(b), C.byref(e)), "xva_hg_bucket_range")
+        out.append((b.value, e.value))
+    return out
 
 
 lib.xva_hg_disc_forward.restype = i32
 lib.xva_hg_disc_forward.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, i64, vp, vp]
-lib.xva_hg_disc_backward_d.restype = i32
-lib.xva_hg_disc_backward_d.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, vp, i64, vp]
+lib.xva_hg_disc_backward_d_ex.restype = i32
+lib.xva_hg_disc_backward_d_ex.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, vp, i64, C.POINTER(vp), vp]
 lib.xva_hg_disc_backward_g.restype = i32
 lib.xva_hg_disc_backward_g.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, vp, i64, vp]
 
@@ -129,9 +144,9 @@ def _disc_forward(self, flat_d, y_real, y_fake):
     return losses
 
 
-def _disc_backward_d(self, flat_d, grads_d):
-    _lib.check(lib.xva_hg_disc_backward_d(C.byref(self._dims), _lib.ptr(flat_d), _lib.ptr(grads_d), _lib.ptr(self._yr), _lib.ptr(self._yg),
-                                          _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "xva_hg_disc_backward_d")
+def _disc_backward_d(self, flat_d, grads_d, events=None):
+    _lib.check(lib.xva_hg_disc_backward_d_ex(C.byref(self._dims), _lib.ptr(flat_d), _lib.ptr(grads_d), _lib.ptr(self._yr), _lib.ptr(self._yg),
+                                             _lib.ptr(self._ws), self._ws.numel(), events, _lib.stream_ptr()), "xva_hg_disc_backward_d_ex")
 
 
 def _disc_backward_g(self, flat_d):
