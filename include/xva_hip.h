@@ -61,9 +61,15 @@ int xva_mel_spectrogram(const xva_mel_config* cfg, const float* wav, int B, int 
                         const float* dft_basis, const float* mel_basis_padded, float* mel_out,
                         float* workspace, int64_t workspace_bytes, void* stream);
 
-/* Differentiable mel for the generator's L1 mel loss (python/hifigan/xva_train.py:480,504):
+/* Linear magnitude spectrogram (B, n_fft/2+1, T) fp32: TorchSTFT with use_mel=False (python/xvapitch/audio.py:138-171), the
+ * 513-bin posterior-encoder input of xVAPitch (dataset side: AudioProcessor.spectrogram :632-652).  Workspace as above. */
+int xva_linear_spectrogram(const xva_mel_config* cfg, const float* wav, int B, int N, int64_t ld_wav, const float* dft_basis,
+                           float* lin_out, float* workspace, int64_t workspace_bytes, void* stream);
+
+/* Differentiable mel for the generator's L1 mel loss (python/hifigan/xva_train.py:480,504; xVAPitch: VitsGeneratorLoss,
+ * python/xvapitch/losses.py:187-193 with the M3 config):
  *   *loss_out += scale * mean|mel_tgt - mel(wav)| ; d_wav (+)= d loss / d wav ; mel_out = mel(wav).
- * Same config / basis arguments as xva_mel_spectrogram; T = frames must be a multiple of 4. */
+ * Same config / basis arguments as xva_mel_spectrogram; any frame count. */
 int64_t xva_mel_backward_workspace_bytes(const xva_mel_config* cfg, int B, int N);
 int xva_mel_l1_loss_backward(const xva_mel_config* cfg, const float* wav, int B, int N, int64_t ld_wav, const float* mel_tgt,
                              const float* dft_basis, const float* mel_basis_padded, float scale, float* mel_out, float* loss_out,
@@ -78,12 +84,16 @@ int xva_mel_l1_loss_backward(const xva_mel_config* cfg, const float* wav, int B,
 #define XVA_DATA_I64 2
 #define XVA_DATA_F32 3
 #define XVA_DATA_F64 4
+#define XVA_DATA_F32_TRUNC 5   /* destination only: fp32 holding trunc(x) — a value that passed through a LongTensor (see below) */
 /* TTSCollate's descending sort by text length (python/fastpitch1_1/fastpitch/data_function.py:569-572):
  * order[r] = index of the r-th longest item, ties in ascending item order (stable).  B <= 4096. */
 int xva_data_rank_desc(const int32_t* lens, int B, int32_t* order, void* stream);
 /* TTSCollate's right zero-padding (data_function.py:574-660) of text ids / pitch / durations: item i is an
  * (inner, lens[i]) row-major slab at flat[offsets[i] * inner]; dst (B, inner, max_len) row r = item order[r] (order may be
- * NULL), truncated / zero-padded to max_len, converted src_dtype -> dst_dtype.  lens_out (B, may be NULL) = min(len, max_len). */
+ * NULL), truncated / zero-padded to max_len, converted src_dtype -> dst_dtype.  lens_out (B, may be NULL) = min(len, max_len).
+ * Reference quirk kept for parity: TTSCollate allocates pitch_padded / energy_padded / durs_padded with the TEXT's dtype
+ * (`dtype=batch[0][0].dtype`, :594-606,629-636), so pitch, energy and durations are truncated toward zero on the way into
+ * the batch; XVA_DATA_F32_TRUNC / XVA_DATA_I32 destinations and `energy_trunc` below reproduce that. */
 int xva_data_pad_gather(const void* flat, int src_dtype, const int64_t* offsets, const int32_t* lens, const int32_t* order, void* dst,
                         int dst_dtype, int B, int inner, int max_len, int32_t* lens_out, void* stream);
 /* TTSDataset.get_mel + the mel part of TTSCollate (data_function.py:385-429,574-590) + energy (:327): clips are int16,
@@ -92,9 +102,9 @@ int xva_data_pad_gather(const void* flat, int src_dtype, const int64_t* offsets,
  * Workspace: xva_mel_workspace_bytes(cfg, B, Nmax). */
 int xva_mel_spectrogram_ragged(const xva_mel_config* cfg, const int16_t* flat, const int64_t* offsets, const int32_t* n_samples,
                                const int32_t* order, int B, int Nmax, const float* dft_basis, const float* mel_basis_padded,
-                               float* mel_out, float* energy_out, int32_t* n_frames_out, float* workspace, int64_t workspace_bytes,
-                               void* stream);
-int xva_mel_finish_ragged(float* mel, const int32_t* n_frames, float* energy, int B, int n_mel, int T, void* stream);
+                               float* mel_out, float* energy_out, int energy_trunc, int32_t* n_frames_out, float* workspace,
+                               int64_t workspace_bytes, void* stream);
+int xva_mel_finish_ragged(float* mel, const int32_t* n_frames, float* energy, int B, int n_mel, int T, int energy_trunc, void* stream);
 /* beta_binomial_prior_distribution + its collate (data_function.py:84-94,640-660): out (B, Tm, Tt) fp32,
  * out[r][m][k] = betabinom(n = P, a = m + 1, b = M - m).pmf(k) for m < M = mel_lens[r], k < P = text_lens[r], else 0. */
 int xva_data_betabinom_prior(const int32_t* text_lens, const int32_t* mel_lens, float* out, int B, int Tm, int Tt, void* stream);

@@ -74,3 +74,33 @@ def test_golden_fixture(golden_dir):
     y8 = torch.from_numpy(g["wav_seg"]).cuda()
     assert (mel_spectrogram(y8, 1024, 80, 22050, 256, 1024, 0, 8000).cpu() - torch.from_numpy(g["m2_fmax8000"])).abs().max().item() < ATOL
     assert (mel_spectrogram(y8, 1024, 80, 22050, 256, 1024, 0, None).cpu() - torch.from_numpy(g["m2_fmaxNone"])).abs().max().item() < ATOL
+
+
+def test_m3_reference_golden_forward_linear_and_gradient(golden_dir):
+    """xVAPitch TorchSTFT (python/xvapitch/audio.py:138-181) recorded from the reference: log-mel, the 513-bin linear magnitudes and the
+    gradient of VitsGeneratorLoss's mel term (45 * l1_loss, python/xvapitch/losses.py:187-193) w.r.t. the waveform."""
+    import os
+    from xva_trainer_amd.mel import TorchSTFTMel
+    g = np.load(os.path.join(golden_dir, "mel_m3.npz"))
+    y = torch.from_numpy(g["wav"]).cuda()
+    m = TorchSTFTMel().cuda()
+    assert (m(y).cpu() - torch.from_numpy(g["m3"])).abs().max().item() < ATOL
+    lin, ref = m.linear(y).cpu(), torch.from_numpy(g["linear"])
+    assert lin.shape == ref.shape == (3, 513, 33)
+    assert ((lin - ref).abs().max() / ref.abs().max()).item() < 1e-4
+    d_wav = torch.zeros_like(y)
+    loss, mel = m.l1_loss_backward(y, torch.from_numpy(g["tgt"]).cuda(), d_wav, scale=45.0, accumulate=False)
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
+    ref_g = torch.from_numpy(g["d_wav"])
+    assert ((d_wav.cpu() - ref_g).norm() / ref_g.norm()).item() < 1e-3
+    assert ((d_wav.cpu() - ref_g).abs().max() / ref_g.abs().max()).item() < 5e-3
+
+
+def test_m3_clamp_passes_no_gradient_on_silence():
+    """sqrt(clamp(re^2 + im^2, 1e-8)): bins under the clamp are constants — an all-zero clip gets an all-zero waveform gradient."""
+    from xva_trainer_amd.mel import TorchSTFTMel
+    m = TorchSTFTMel().cuda()
+    y = torch.zeros(2, 8192, device="cuda")
+    d = torch.ones_like(y)
+    loss, mel = m.l1_loss_backward(y, torch.zeros(2, 80, 33, device="cuda"), d, accumulate=False)
+    assert torch.isfinite(loss).all() and float(d.abs().max()) == 0.0

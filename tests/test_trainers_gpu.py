@@ -1,10 +1,14 @@
-"""GPU: the trainer protocol mirrors (handleTrainer / FastPitchTrainer / HiFiTrainer) drive the HIP engines end to end on
-synthetic loaders: logs, graphs.json, checkpoint files and formats, resume."""
+"""GPU: the trainer protocol mirrors (handleTrainer / FastPitchTrainer / HiFiTrainer / ModelsManager.load_model) drive the HIP engines
+end to end: from a reference-layout dataset directory (metadata.csv + wavs/ + pitch/, durations extracted after stage 1), through
+stage transitions, checkpoints in the reference's formats (incl. files rebuilt from the layouts recorded from the reference's own
+classes), resume with optimizer state, the out-of-memory back-off and the inference wrappers."""
 import asyncio
 import json
 import logging
 import os
+import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -19,107 +23,338 @@ class _WS:
         self.sent.append(msg)
 
 
-def test_fastpitch_trainer_protocol(tmp_path):
-    from xva_trainer_amd.data import SyntheticFastPitchLoader
-    from xva_trainer_amd.fastpitch import xva_train as T
+def _mm():
     from xva_trainer_amd.models_manager import ModelsManager
-    mm = ModelsManager(logging.getLogger("t"), False, "cuda:0")
-    ws = _WS()
-    data = {"dataset_path": str(tmp_path / "in" / "voice_a"), "output_path": str(tmp_path / "out"), "checkpoint": None, "num_workers": 0,
-            "batch_size": 4, "epochs_per_checkpoint": 1, "force_stage": 3, "max_iterations": 3}
+    return ModelsManager(logging.getLogger("t"), False, "cuda:0")
+
+
+def _fp_trainer(mm, ws, out, name, compute="fp32", factory=None):
     mm.sync_init_model("fastpitch1_1", websocket=ws, gpus=[0])
     tr = mm.models_bank["fastpitch1_1"]
-    tr.compute = "fp32"
-    tr.loader_factory = lambda t: SyntheticFastPitchLoader(4, n_batches=128, t_text=20, t_mel=90, seed=7)
-    tr.init_logs(data["output_path"] + "/voice_a")
+    tr.compute = compute
+    tr.loader_factory = factory
+    tr.init_logs(out + "/" + name)
+    return tr
+
+
+def test_fastpitch_trainer_protocol(tmp_path):
+    from xva_trainer_amd.data import SyntheticFastPitchLoader
+    mm, ws = _mm(), _WS()
+    data = {"dataset_path": str(tmp_path / "in" / "voice_a"), "output_path": str(tmp_path / "out"), "checkpoint": None, "num_workers": 0,
+            "batch_size": 4, "epochs_per_checkpoint": 1, "force_stage": 3, "max_iterations": 50003}
+    factory = lambda t: SyntheticFastPitchLoader(t.per_rank_batch, n_batches=64, t_text=20, t_mel=90, seed=7)
+    tr = _fp_trainer(mm, ws, data["output_path"], "voice_a", factory=factory)
     asyncio.run(tr.start(data, gpus=[0]))
-    assert tr.gam == 64 and tr.total_iter == 3 and not tr.running
+    # stage 3: batch = int(4 * 3.5 * 1 GPU * 10 / max_len) with no wavs -> 14, gam = round(256 / 14) (xva_train.py:387-407)
+    assert tr.global_batch == tr.per_rank_batch == 14 and tr.gam == 18 and tr.EPOCH_AVG_SPAN == 6
+    assert tr.total_iter == tr.start_iterations + 3 == 50003 and not tr.running                # a new voice starts at start_iterations (:380-385)
     assert any(m.startswith("Set stage to: 3") for m in ws.sent)
     log = open(data["output_path"] + "/voice_a/training.log").read()
-    assert "Stage: 3 | Epoch: 1" in log and "frames/s" in log
+    assert "Stage: 3 | Epoch: 1" in log and "frames/s" in log and "Batch size: 14 (Base: 4, Stage mult: 3.5" in log and "New voice" in log
     # checkpoint round trip in the reference's format
-    tr.save_checkpoint(force_save=True, total_iter=tr.total_iter, avg_loss_per_epoch=[1.0], fpath=data["output_path"] + "/voice_a/FastPitch_checkpoint_1_3.pt")
-    ck = torch.load(data["output_path"] + "/voice_a/FastPitch_checkpoint_1_3.pt", weights_only=False)
-    assert set(ck) >= {"epoch", "iteration", "avg_loss_per_epoch", "training_stage", "state_dict", "optimizer"}
+    ck_path = data["output_path"] + "/voice_a/FastPitch_checkpoint_1_50003.pt"
+    tr.save_checkpoint(force_save=True, total_iter=tr.total_iter, avg_loss_per_epoch=[1.0], fpath=ck_path)
+    ck = torch.load(ck_path, weights_only=False)
+    assert list(ck) == ["epoch", "iteration", "avg_loss_per_epoch", "training_stage", "state_dict", "optimizer"]
     assert len(ck["state_dict"]) == 185 and ck["state_dict"]["proj.weight"].shape == (80, 384)
-    st = ck["optimizer"]["state"]
-    some = next(iter(st.values()))
+    some = next(iter(ck["optimizer"]["state"].values()))
     assert set(some) >= {"step", "exp_avg", "exp_avg_sq", "weight_norm", "adam_norm", "trust_ratio"}
     half = torch.load(data["output_path"] + "/voice_a/voice_a.pt", weights_only=False)
     assert half["proj.weight"].dtype == torch.float16
     assert json.load(open(data["output_path"] + "/voice_a/voice_a.json"))["modelType"] == "FastPitch1.1"
-    # resume picks the newest checkpoint up
-    mm2 = ModelsManager(logging.getLogger("t"), False, "cuda:0")
-    mm2.sync_init_model("fastpitch1_1", websocket=_WS(), gpus=[0])
-    tr2 = mm2.models_bank["fastpitch1_1"]
-    tr2.compute = "fp32"
-    tr2.loader_factory = tr.loader_factory
-    tr2.init_logs(data["output_path"] + "/voice_a")
-    d2 = dict(data); d2["max_iterations"] = 4
+    # resume picks the newest checkpoint of this voice up (not a new voice any more: iteration continues)
+    mm2 = _mm()
+    tr2 = _fp_trainer(mm2, _WS(), data["output_path"], "voice_a", factory=factory)
+    d2 = dict(data); d2["max_iterations"] = 50004
     asyncio.run(tr2.start(d2, gpus=[0]))
-    assert tr2.total_iter == 4
+    assert tr2.total_iter == 50004 and "New voice" not in "\n".join(tr2.training_log)
     assert torch.equal(tr2.model.state_dict()["pitch_mean"].cpu(), ck["state_dict"]["pitch_mean"].cpu())
+    # a real run never falls back to synthetic data silently
+    mm3 = _mm()
+    tr3 = _fp_trainer(mm3, _WS(), data["output_path"], "voice_z")
+    with pytest.raises(FileNotFoundError):
+        asyncio.run(tr3.start(dict(data, dataset_path=str(tmp_path / "in" / "voice_z")), gpus=[0]))
+    with pytest.raises(NotImplementedError):                                                   # multi-GPU = one process per GPU, never DataParallel
+        asyncio.run(_fp_trainer(_mm(), _WS(), data["output_path"], "voice_y").start(dict(data, synthetic_data=True), gpus=[0, 1]))
 
 
-def test_fastpitch_trainer_stage1_aligner(tmp_path):
-    """A fresh run starts at training stage 1 (the aligner): the trainer drives ConvAttention + MAS + the forward-sum loss, LAMB only
-    moves attention.* and the symbol embedding, and the loss goes down."""
-    import re
-    from xva_trainer_amd.data import SyntheticFastPitchLoader
+def test_fastpitch_trainer_from_dataset_directory(tmp_path):
+    """metadata.csv + wavs/ + pitch/: stage 1 (aligner) on device-built batches -> durations written in the reference's durs_text/*.npy
+    layout -> stages 2 and 3 train from those files."""
+    from xva_trainer_amd import data as D
     from xva_trainer_amd.fastpitch.model import FastPitch
-    from xva_trainer_amd.models_manager import ModelsManager
-    mm = ModelsManager(logging.getLogger("t"), False, "cuda:0")
-    ws = _WS()
-    data = {"dataset_path": str(tmp_path / "in" / "voice_c"), "output_path": str(tmp_path / "out"), "checkpoint": None, "num_workers": 0,
-            "batch_size": 32, "epochs_per_checkpoint": 1, "max_iterations": 8}
-    mm.sync_init_model("fastpitch1_1", websocket=ws, gpus=[0])
-    tr = mm.models_bank["fastpitch1_1"]
-    tr.compute = "fp32"
-    tr.loader_factory = lambda t: SyntheticFastPitchLoader(32, n_batches=8, t_text=12, t_mel=50, seed=3, with_prior=True)
-    tr.init_logs(data["output_path"] + "/voice_c")
-    try:
-        asyncio.run(tr.start(data, gpus=[0]))
-    except RuntimeError as e:     # the loss-delta criterion may end the stage early; the reference signals that by raising (xva_train.py:970)
-        assert "stage 1 finished" in str(e)
+    ds = D.write_synthetic_dataset(str(tmp_path / "in" / "voice_c"), n_items=12, seed=4, min_s=0.5, max_s=1.0)
+    json.dump({"mean": 180.5, "std": 41.25}, open(ds + "/pitch_stats.json", "w"))
+    out = str(tmp_path / "out")
+    base = {"dataset_path": ds, "output_path": out, "checkpoint": None, "num_workers": 0, "batch_size": 1, "epochs_per_checkpoint": 1000}
+    mm, ws = _mm(), _WS()
+    tr = _fp_trainer(mm, ws, out, "voice_c")
+    asyncio.run(tr.start(dict(base, max_iterations=50006), gpus=[0]))
     assert int(tr.model.training_stage) == 1 and any(m.startswith("Set stage to: 1") for m in ws.sent)
-    assert tr.gam == 8 and 3 <= tr.total_iter <= 8
-    log = open(data["output_path"] + "/voice_c/training.log").read()
+    assert tr.global_batch == int(1 * 1.5 * 10 / max(tr._dataset_file_lengths())) and tr.gam == max(1, round(256 / tr.global_batch))
+    assert float(tr.model.pitch_mean[0]) == 180.5 and float(tr.model.pitch_std[0]) == 41.25     # pitch_stats.json -> model buffers (:344-346)
+    log = open(out + "/voice_c/training.log").read()
     losses = [float(x) for x in re.findall(r"Stage: 1 .*?loss: ([0-9.]+)", log)]
-    assert len(losses) >= 3 and losses[-1] < losses[0], losses
+    assert len(losses) == 6 and losses[-1] < losses[0], losses
     fresh = FastPitch(compute="fp32").state_dict()
     sd = tr.model.state_dict()
-    moved = {k for k in sd if not torch.equal(sd[k].cpu(), fresh[k].cpu())}
+    moved = {k for k in sd if not torch.equal(sd[k].cpu(), fresh[k].cpu()) and k not in ("pitch_mean", "pitch_std")}
     assert moved and all(k.startswith("attention.") or k == "encoder.word_emb.weight" for k in moved), moved
-    assert tr._last_durs.sum(1).tolist() == [int(v) for v in tr.train_loader.batches[-1]["mel_lens"]]
+    tr.save_checkpoint(force_save=True, total_iter=tr.total_iter, avg_loss_per_epoch=[], fpath=out + "/voice_c/FastPitch_checkpoint_1_%d.pt" % tr.total_iter)
+    # stage 2: the trainer extracts the durations first (no durs_text/ yet)
+    mm2 = _mm()
+    tr2 = _fp_trainer(mm2, _WS(), out, "voice_c")
+    asyncio.run(tr2.start(dict(base, force_stage=2, max_iterations=50002), gpus=[0]))     # forcing a later stage restarts at start_iterations (:366-367)
+    meta = D.read_metadata(ds)
+    enc = D.BasicTextEncoder()
+    for name, path, text in meta:
+        d = np.load("%s/durs_text/%s.npy" % (ds, name))
+        wav, _ = D.read_wav_int16(path)
+        assert d.dtype == np.float32 and d.shape == (len(enc.encode(text)),) and int(d.sum()) == 1 + len(wav) // 256 and (d >= 0).all()
+    assert "Extracting durations from alignments" in open(out + "/voice_c/training.log").read()
+    assert int(tr2.model.training_stage) == 2 and tr2.epochs_per_checkpoint == 3000 and tr2.total_iter == 50002
+    assert tr2.per_rank_batch == 48 and "Capping batch size" in open(out + "/voice_c/training.log").read()      # 12 clips x dm 4 < 1 * 12 * 10 / 1.0
+    # stage 3 from the same files (pitch cache + durations)
+    mm3 = _mm()
+    tr3 = _fp_trainer(mm3, _WS(), out, "voice_c", compute="bf16")
+    asyncio.run(tr3.start(dict(base, force_stage=3, max_iterations=50002), gpus=[0]))
+    assert int(tr3.model.training_stage) == 3
+    l3 = [float(x) for x in re.findall(r"Stage: 3 .*?loss: ([0-9.]+)", open(out + "/voice_c/training.log").read())]
+    assert len(l3) >= 2 and all(np.isfinite(l3))
 
 
-def test_hifigan_trainer_protocol(tmp_path):
-    from xva_trainer_amd.data import SyntheticHifiLoader
-    from xva_trainer_amd.models_manager import ModelsManager
-    mm = ModelsManager(logging.getLogger("t"), False, "cuda:0")
-    ws = _WS()
-    data = {"dataset_path": str(tmp_path / "in" / "voice_b"), "output_path": str(tmp_path / "out"), "hifigan_checkpoint": None, "num_workers": 0,
-            "batch_size": 2, "epochs_per_checkpoint": 1, "max_iterations": 3}
+def test_stage_completion_rewrites_checkpoint_for_the_next_stage(tmp_path):
+    """xva_train.py:954-970: patience of 3 on the avg-delta criterion; on completion training_stage + 1 and an EMPTY loss history go into
+    the regular FastPitch_checkpoint_* (and Stage_N_DONE_*), so the next trainer starts stage N + 1 with a clean stopping history."""
+    from xva_trainer_amd.data import SyntheticFastPitchLoader
+    from xva_trainer_amd.fastpitch import xva_train as T
+    out = str(tmp_path / "out")
+    data = {"dataset_path": str(tmp_path / "in" / "voice_s"), "output_path": out, "checkpoint": None, "num_workers": 0,
+            "batch_size": 64, "epochs_per_checkpoint": 1, "force_stage": 3}
+    factory = lambda t: SyntheticFastPitchLoader(2, n_batches=2, t_text=12, t_mel=40, seed=11)
+    mm, ws = _mm(), _WS()
+
+    async def run():
+        # first call: trains stage 3 until the criterion fires, then recurses into stage 4 (bounded by max_iterations)
+        real = T.FastPitchTrainer.get_target_delta
+        T.FastPitchTrainer.get_target_delta = lambda self, n, stage: 1e9 if stage == 3 else -1e9      # stage 3 converges at once, stage 4 never
+        try:
+            mm.sync_init_model("fastpitch1_1", websocket=ws, gpus=[0])
+            mm.models_bank["fastpitch1_1"].compute = "fp32"
+            mm.models_bank["fastpitch1_1"].loader_factory = factory
+            orig_sync = mm.sync_init_model
+
+            def sync(key, websocket=None, gpus=[0]):
+                orig_sync(key, websocket=websocket, gpus=gpus)
+                t = mm.models_bank[key]
+                t.compute, t.loader_factory = "fp32", factory
+            mm.sync_init_model = sync
+            return await T.handleTrainer(mm, dict(data, max_iterations=50030), ws, [0])
+        finally:
+            T.FastPitchTrainer.get_target_delta = real
+
+    asyncio.run(run())
+    log = open(out + "/voice_s/training.log").read()
+    assert "Finished training stage 3..." in log
+    done = [f for f in os.listdir(out + "/voice_s") if f.startswith("Stage_3_DONE_FastPitch_checkpoint_")]
+    assert len(done) == 1
+    ck = torch.load(out + "/voice_s/" + done[0], weights_only=False)
+    assert int(ck["training_stage"]) == 4 and ck["avg_loss_per_epoch"] == []
+    # stage 3 needs len(deltas) >= 2 and three consecutive qualifying epochs: it cannot finish before its 5th epoch
+    e3 = [int(x) for x in re.findall(r"Stage: 3 \| Epoch: (\d+) \| iter", log)]
+    assert max(e3) >= 4
+    # the recursion started stage 4 from the re-written checkpoint (no force_stage) and kept training past one epoch
+    assert [m for m in ws.sent if m.startswith("Set stage to:")] == ["Set stage to: 3 ", "Set stage to: 4 "]
+    e4 = [int(x) for x in re.findall(r"Stage: 4 \| Epoch: (\d+) \| iter", log)]
+    assert e4 and max(e4) - min(e4) >= 2 and "Finished training stage 4" not in log
+
+
+def test_out_of_memory_backoff(tmp_path):
+    """xva_train.py:131-145: an out-of-memory RuntimeError restarts the trainer with the base batch size reduced by 3."""
+    from xva_trainer_amd.data import SyntheticFastPitchLoader
+    from xva_trainer_amd.fastpitch import xva_train as T
+    mm = _mm()
+    seen = []
+    factory = lambda t: SyntheticFastPitchLoader(2, n_batches=4, t_text=10, t_mel=30, seed=1)
+    orig_sync = mm.sync_init_model
+
+    def sync(key, websocket=None, gpus=[0]):
+        orig_sync(key, websocket=websocket, gpus=gpus)
+        t = mm.models_bank[key]
+        t.compute, t.loader_factory = "fp32", factory
+        real_init = t.init
+
+        async def init():
+            seen.append(t.batch_size)
+            if len(seen) < 3:
+                raise RuntimeError("HIP out of memory. Tried to allocate 20.00 GiB")
+            await real_init()
+        t.init = init
+    mm.sync_init_model = sync
+    data = {"dataset_path": str(tmp_path / "in" / "voice_o"), "output_path": str(tmp_path / "out"), "checkpoint": None, "num_workers": 0,
+            "batch_size": 10, "epochs_per_checkpoint": 1, "force_stage": 2, "max_iterations": 50001}
+    asyncio.run(T.handleTrainer(mm, data, _WS(), [0]))
+    assert seen == [10, 7, 4]
+    assert "Reducing base batch size from 10 to 7" in open(data["output_path"] + "/voice_o/training.log").read()
+
+
+def _rand_like(shape, gen, scale=0.05):
+    return torch.randn(tuple(shape), generator=gen) * scale
+
+
+def test_checkpoints_in_the_reference_layout_load_into_the_trainers(tmp_path, golden_dir):
+    """Files rebuilt from the layouts recorded from the reference's own classes (tests/golden/checkpoint_layouts.json, written by
+    oracle/gen_checkpoint_layouts.py): a full FastPitch checkpoint with its Lamb state, and a HiFi-GAN g_ / do_ pair whose optimizer
+    states come out of torch.optim.AdamW itself in the reference's parameter order."""
+    from xva_trainer_amd.data import SyntheticFastPitchLoader, SyntheticHifiLoader
+    lay = json.load(open(os.path.join(golden_dir, "checkpoint_layouts.json")))
+    gen = torch.Generator().manual_seed(5)
+    out = str(tmp_path / "out")
+    # ---- FastPitch
+    os.makedirs(out + "/voice_r")
+    sd = {k: (_rand_like(sh, gen) if "inv_freq" not in k else torch.zeros(sh)) for k, sh, dt in [(a, b, c) for a, b, c in lay["fastpitch"]["state_dict"]]}
+    order = lay["fastpitch"]["optimizer"]["param_order"]
+    state = {i: {"step": 12, "exp_avg": _rand_like(sd[n].shape, gen), "exp_avg_sq": _rand_like(sd[n].shape, gen).abs(), "weight_norm": torch.tensor(1.0),
+                 "adam_norm": torch.tensor(2.0), "trust_ratio": torch.tensor(0.5)} for i, n in enumerate(order)}
+    torch.save({"epoch": 7, "iteration": 51234, "avg_loss_per_epoch": [0.5, 0.4], "training_stage": torch.tensor(3), "state_dict": sd,
+                "optimizer": {"state": state, "param_groups": [{"lr": 4.4e-4, "betas": (0.9, 0.98), "eps": 1e-9, "weight_decay": 1e-6, "adam": False,
+                                                                "params": list(range(len(order)))}]}},
+               out + "/voice_r/FastPitch_checkpoint_7_51234.pt")
+    data = {"dataset_path": str(tmp_path / "in" / "voice_r"), "output_path": out, "checkpoint": None, "num_workers": 0, "batch_size": 4,
+            "epochs_per_checkpoint": 1, "max_iterations": 51235}
+    tr = _fp_trainer(_mm(), _WS(), out, "voice_r", factory=lambda t: SyntheticFastPitchLoader(2, n_batches=40, t_text=10, t_mel=30, seed=2))
+
+    asyncio.run(tr.start(dict(data, max_iterations=1), gpus=[0]))      # init() from the checkpoint, then exactly one optimizer step
+    assert int(tr.model.training_stage) == 3 and tr.epoch == 8 and tr.avg_loss_per_epoch[:2] == [0.5, 0.4]
+    from xva_trainer_amd.fastpitch import params as P
+    m = P.from_flat(tr.optimizer.exp_avg, tr.model._table)
+    frozen = [n for n in order if n.startswith("duration_predictor.")]    # stage 3 freezes these: parameters and moments stay as loaded
+    for n in frozen[:3]:
+        assert torch.equal(tr.model.state_dict()[n].cpu(), sd[n]) and torch.equal(m[n].cpu(), state[order.index(n)]["exp_avg"])
+    assert tr.optimizer.steps[[t[0] for t in tr.model._table].index("proj.weight")] == 13
+    # ---- HiFi-GAN: AdamW states produced by torch.optim.AdamW over the reference parameter order
+    hifi = out + "/voice_h/hifi"
+    os.makedirs(hifi)
+    hl = lay["hifigan"]
+    sds = {part: {k: _rand_like(sh, gen) + (1.0 if k.endswith("weight_g") else 0.0) for k, sh, dt in hl[part]} for part in ("generator", "mpd", "msd")}
+    for k in list(sds["msd"]):
+        if k.endswith("weight_u") or (k.endswith("weight_v") and "discriminators.0." in k):
+            sds["msd"][k] = torch.nn.functional.normalize(sds["msd"][k], dim=0)
+    opt_sd = {}
+    for key, named in (("optim_g", [("", sds["generator"])]), ("optim_d", [("msd.", sds["msd"]), ("mpd.", sds["mpd"])])):
+        flat_named = {pre + k: v for pre, d in named for k, v in d.items()}
+        params = [torch.nn.Parameter(flat_named[n].clone()) for n in hl[key]["param_order"]]
+        opt = torch.optim.AdamW(params, 2e-4, betas=[0.8, 0.99])
+        sch = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.999)
+        for p in params:
+            p.grad = _rand_like(p.shape, gen, 1e-3)
+        opt.step(); sch.step(); sch.step()
+        opt_sd[key] = opt.state_dict()
+    torch.save({"generator": sds["generator"]}, hifi + "/g_00000040")
+    torch.save({"mpd": sds["mpd"], "msd": sds["msd"], "optim_g": opt_sd["optim_g"], "optim_d": opt_sd["optim_d"], "steps": 40, "epoch": 2,
+                "avg_loss_per_epoch": [], "ckpts_finetuned": 3}, hifi + "/do_00000040")
+    mm = _mm()
+    mm.sync_init_model("hifigan", websocket=_WS(), gpus=[0])
+    th = mm.models_bank["hifigan"]
+    th.compute = "fp32"
+    th.loader_factory = lambda t: SyntheticHifiLoader(1, n_batches=2)
+    th.init_logs(out + "/voice_h")
+    hd = {"dataset_path": str(tmp_path / "in" / "voice_h"), "output_path": out, "hifigan_checkpoint": None, "num_workers": 0, "batch_size": 1,
+          "epochs_per_checkpoint": 1, "max_iterations": 41}
+
+    async def hg_init():                                              # init() only (no training step: the loaded optimizer state is compared as is)
+        th.dataset_input, th.dataset_id, th.dataset_output = hd["dataset_path"], "voice_h", out + "/voice_h"
+        th.hifigan_checkpoint, th.workers, th.batch_size, th.epochs_per_checkpoint, th.max_iterations, th.synthetic_data = None, 0, 1, 1, 41, False
+        await th.init()
+    asyncio.run(hg_init())
+    assert th.training_steps == 41 and th.training_epoch == 2 and th.ckpts_finetuned == 3
+    got = th.core.state_dicts()
+    for part in ("generator", "mpd", "msd"):
+        for k, v in sds[part].items():
+            assert torch.equal(got[part][k].cpu(), v), (part, k)
+    og = th.core.optim_g
+    assert og.step_count == 1 and abs(og.param_groups[0]["lr"] - 2e-4 * 0.999 ** 3) < 1e-12      # saved lr (two decays) x the scheduler's initial step
+    name, off, n, shape = og.order[5]
+    assert torch.equal(og.exp_avg[off:off + n].view(shape).cpu(), opt_sd["optim_g"]["state"][5]["exp_avg"])
+    od = th.core.optim_d
+    name, off, n, shape = od.order[1]
+    assert name == "msd.discriminators.0.convs.0.weight_orig"
+    assert torch.equal(od.exp_avg_sq[off:off + n].view(shape).cpu(), opt_sd["optim_d"]["state"][1]["exp_avg_sq"])
+
+
+def test_hifigan_trainer_protocol_resume_and_inference_wrappers(tmp_path):
+    from oracle import hifigan as ohg
+    from xva_trainer_amd import data as D
+    ds = D.write_synthetic_dataset(str(tmp_path / "in" / "voice_b"), n_items=6, seed=2, min_s=0.3, max_s=0.8, with_pitch=False)
+    out = str(tmp_path / "out")
+    data = {"dataset_path": ds, "output_path": out, "hifigan_checkpoint": None, "num_workers": 0, "batch_size": 2, "epochs_per_checkpoint": 1}
+    mm, ws = _mm(), _WS()
     mm.sync_init_model("hifigan", websocket=ws, gpus=[0])
     tr = mm.models_bank["hifigan"]
-    tr.loader_factory = lambda t: SyntheticHifiLoader(2, n_batches=2)
-    tr.init_logs(data["output_path"] + "/voice_b")
-    # random-init weights (the reference never trains from scratch; here there is no checkpoint offline)
-    from oracle import hifigan as ohg
-    async def run():
-        await tr.init()
-        tr.core.load_state_dicts(ohg.init_generator_sd(1), ohg.init_mpd_sd(2), ohg.init_msd_sd(3))
-        tr.running = False
-        await tr.start(data, gpus=[0], resume=False)
-    tr.dataset_output = data["output_path"] + "/voice_b"; tr.hifigan_checkpoint = None; tr.batch_size = 2; tr.epochs_per_checkpoint = 1; tr.max_iterations = 3
-    asyncio.run(run())
-    assert tr.training_steps == 3
-    hifi = data["output_path"] + "/voice_b/hifi"
+    tr.init_logs(out + "/voice_b")
+    with pytest.raises(RuntimeError, match="never trains from scratch"):                       # xva_train.py:276-277
+        asyncio.run(tr.start(dict(data, max_iterations=1), gpus=[0]))
+    # a "pretrained" pair to fine-tune from (random-init weights of the v1 architecture: there are no checkpoints offline)
+    pre = str(tmp_path / "pretrained")
+    os.makedirs(pre)
+    torch.save({"generator": ohg.init_generator_sd(1)}, pre + "/g_00000000")
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    st = HifiganStep("cuda:0", "fp32")
+    st.load_state_dicts(ohg.init_generator_sd(1), ohg.init_mpd_sd(2), ohg.init_msd_sd(3))
+    sds = st.state_dicts()
+    torch.save({"mpd": {k: v.cpu() for k, v in sds["mpd"].items()}, "msd": {k: v.cpu() for k, v in sds["msd"].items()}, "optim_g": st.optim_g.state_dict(),
+                "optim_d": st.optim_d.state_dict(), "steps": -1, "epoch": -1, "avg_loss_per_epoch": [], "ckpts_finetuned": 0}, pre + "/do_00000000")
+    del st
+    mm, ws = _mm(), _WS()
+    mm.sync_init_model("hifigan", websocket=ws, gpus=[0])
+    tr = mm.models_bank["hifigan"]
+    tr.init_logs(out + "/voice_b")
+
+    async def run(max_it):
+        await tr.start(dict(data, hifigan_checkpoint=pre, max_iterations=max_it), gpus=[0])
+    # dm = round(1000 / 6) = 167 repetitions of 6 files / batch int(2 * 1.4) = 2 -> 501 iterations per epoch: run one full epoch + 1
+    asyncio.run(run(502))
+    assert len(tr.train_loader) == 501 and tr.training_steps == 502 and tr.training_epoch == 0
+    assert "Set stage to: 5 " in ws.sent
+    hifi = out + "/voice_b/hifi"
     files = sorted(os.listdir(hifi))
-    assert any(f.startswith("g_") for f in files) and any(f.startswith("do_") for f in files)
-    g = torch.load(hifi + "/" + [f for f in files if f.startswith("g_")][-1], weights_only=False)
-    assert "generator" in g and g["generator"]["conv_pre.weight_v"].shape == (512, 80, 7)
-    do = torch.load(hifi + "/" + [f for f in files if f.startswith("do_")][-1], weights_only=False)
-    assert set(do) >= {"mpd", "msd", "optim_g", "optim_d", "steps", "epoch", "avg_loss_per_epoch", "ckpts_finetuned"}
+    assert "g_00000501" in files and "do_00000501" in files
+    g = torch.load(hifi + "/g_00000501", weights_only=False)
+    assert list(g) == ["generator"] and g["generator"]["conv_pre.weight_v"].shape == (512, 80, 7)
+    do = torch.load(hifi + "/do_00000501", weights_only=False)
+    assert list(do) == ["mpd", "msd", "optim_g", "optim_d", "steps", "epoch", "avg_loss_per_epoch", "ckpts_finetuned"]
     assert "discriminators.0.convs.0.weight_orig" in do["msd"] and "discriminators.0.convs.0.weight_u" in do["msd"]
-    assert "Stage 5 | Epoch" in open(data["output_path"] + "/voice_b/training.log").read()
+    assert len(do["optim_d"]["state"]) == 154 and float(do["optim_d"]["state"][0]["step"]) == 501.0
+    assert abs(do["optim_g"]["param_groups"][0]["lr"] - 2e-4 * 0.999) < 1e-12
+    log = open(out + "/voice_b/training.log").read()
+    assert "Stage 5 | Epoch: 1 | It: 1/501" in log and "Stage 5 |Epoch: 0 | It: 501 | g_00000501 | Mel loss:" in log
+    mel_line = float(re.search(r"g_00000501 \| Mel loss: ([0-9.e-]+)", log).group(1))
+    assert 0.05 < mel_line < 5.0                                                            # a per-iteration mean, not a mean divided twice
+    # resume: parameters, both AdamW states, the step counter and the decayed learning rate come back
+    mm2 = _mm()
+    mm2.sync_init_model("hifigan", websocket=_WS(), gpus=[0])
+    tr2 = mm2.models_bank["hifigan"]
+    tr2.init_logs(out + "/voice_b")
+    asyncio.run(tr2.start(dict(data, max_iterations=503), gpus=[0]))
+    assert tr2.training_steps >= 503 and tr2.core.optim_d.step_count >= 502
+    assert abs(tr2.core.optim_g.param_groups[0]["lr"] - 2e-4 * 0.999 * 0.999) < 1e-12
+    # ---- inference wrappers (python/models_manager.py:130-150) on the checkpoints the trainers wrote
+    from xva_trainer_amd.fastpitch.model import FastPitch
+    fp_dir = str(tmp_path / "fp")
+    os.makedirs(fp_dir)
+    fp_sd = FastPitch(compute="fp32").state_dict()
+    fp_sd["duration_predictor.fc.bias"] = torch.tensor([1.5])                              # ~3-4 frames per symbol from a random-init model
+    torch.save({k: (v.half() if v.is_floating_point() else v) for k, v in fp_sd.items()}, fp_dir + "/voice.pt")
+    json.dump({"version": "2.0", "modelType": "FastPitch1.1"}, open(fp_dir + "/voice.json", "w"))
+    mm3 = _mm()
+    assert mm3.load_model("infer_hifigan", out + "/voice_b/nope.hg.pt") == "ENOENT"
+    mm3.load_model("infer_hifigan", out + "/voice_b/voice_b.hg.pt")
+    mm3.load_model("infer_fastpitch1_1", fp_dir + "/voice.pt")
+    assert mm3.models("infer_hifigan").ckpt_path.endswith("voice_b.hg.pt") and mm3.models("infer_fastpitch1_1").isReady
+    wav_path = str(tmp_path / "preview.wav")
+    mm3.models("infer_fastpitch1_1").infer(None, "Hello there, general alpha bravo charlie.", wav_path, None, 0)
+    wav, sr = D.read_wav_int16(wav_path)
+    assert sr == 22050 and len(wav) % 256 == 0 and len(wav) >= 2048
+    mm3.set_device("gpu")
+    with pytest.raises(RuntimeError):
+        mm3.set_device("cpu")

@@ -34,6 +34,11 @@ extern "C" int xva_data_rank_desc(const int32_t* lens, int B, int32_t* order, vo
     return XVA_OK;
 }
 
+struct TruncF {                      // fp32 storage of a value that went through a LongTensor
+    float v;
+    __device__ TruncF(float x) : v(truncf(x)) {}
+    __device__ TruncF(int x) : v((float)x) {}
+};
 // dst[r][c][j] = j < lens[i] ? src[offsets[i] * inner + c * lens[i] + j] : 0   with i = order[r] (or r)
 // Items are (inner, len) row-major slabs of a flat buffer (pitch is (n_formants, T); ids / durations have inner = 1).
 template <typename S, typename D>
@@ -62,6 +67,8 @@ extern "C" int xva_data_pad_gather(const void* flat, int src_dtype, const int64_
     else if (src_dtype == XVA_DATA_F64 && dst_dtype == XVA_DATA_F32) XVA_PG(double, float);
     else if (src_dtype == XVA_DATA_I16 && dst_dtype == XVA_DATA_F32) XVA_PG(int16_t, float);
     else if (src_dtype == XVA_DATA_I64 && dst_dtype == XVA_DATA_F32) XVA_PG(int64_t, float);
+    else if (src_dtype == XVA_DATA_F32 && dst_dtype == XVA_DATA_I32) XVA_PG(float, int32_t);     // durations: float .npy into a LongTensor (truncation)
+    else if (src_dtype == XVA_DATA_F32 && dst_dtype == XVA_DATA_F32_TRUNC) XVA_PG(float, TruncF);  // pitch: same LongTensor quirk, kept as fp32
     else { xva_set_error("data_pad_gather: unsupported dtype pair %d -> %d", src_dtype, dst_dtype); return XVA_ERR_ARG; }
 #undef XVA_PG
     XVA_LAUNCH_CHECK();
@@ -145,8 +152,11 @@ extern "C" int xva_data_betabinom_prior(const int32_t* text_lens, const int32_t*
 
 // ---- ragged mel: finishing pass -------------------------------------------------------------------------------------------------
 // mel (B, n_mel, T): frames t >= n_frames[b] are zeroed (TTSCollate's zero padding); energy[b][t] = ||mel[b, :, t]||_2 for live
-// frames (data_function.py:327), 0 beyond.
-__global__ void mel_finish_ragged_kernel(float* __restrict__ mel, const int32_t* __restrict__ n_frames, float* __restrict__ energy, int n_mel, int T) {
+// frames (data_function.py:327), 0 beyond.  energy_trunc: TTSCollate accumulates pitch and energy into tensors created with the TEXT's
+// dtype (`dtype=batch[0][0].dtype`, `zeros_like(pitch_padded[:, 0, :])`, data_function.py:594-606), i.e. LongTensors: the values a
+// reference batch carries are truncated toward zero before batch_to_gpu's .float().  Set for bit-parity with the reference batch.
+__global__ void mel_finish_ragged_kernel(float* __restrict__ mel, const int32_t* __restrict__ n_frames, float* __restrict__ energy, int n_mel, int T,
+                                         int energy_trunc) {
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -159,12 +169,13 @@ __global__ void mel_finish_ragged_kernel(float* __restrict__ mel, const int32_t*
     if (energy) {
         float acc = 0.f;
         for (int c = 0; c < n_mel; ++c) { const float v = m[(int64_t)c * T]; acc += v * v; }
-        energy[(int64_t)b * T + t] = sqrtf(acc);
+        const float e = sqrtf(acc);
+        energy[(int64_t)b * T + t] = energy_trunc ? truncf(e) : e;
     }
 }
-extern "C" int xva_mel_finish_ragged(float* mel, const int32_t* n_frames, float* energy, int B, int n_mel, int T, void* stream) {
+extern "C" int xva_mel_finish_ragged(float* mel, const int32_t* n_frames, float* energy, int B, int n_mel, int T, int energy_trunc, void* stream) {
     XVA_CHECK_ARG(mel && n_frames && B > 0 && n_mel > 0 && T > 0, "mel_finish_ragged: bad arguments");
-    hipLaunchKernelGGL(mel_finish_ragged_kernel, dim3(xva_cdiv(T, 64), B), dim3(64), 0, (hipStream_t)stream, mel, n_frames, energy, n_mel, T);
+    hipLaunchKernelGGL(mel_finish_ragged_kernel, dim3(xva_cdiv(T, 64), B), dim3(64), 0, (hipStream_t)stream, mel, n_frames, energy, n_mel, T, energy_trunc);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }

@@ -137,11 +137,11 @@ __global__ void xva_reflect_pad_i16_ragged_kernel(const int16_t* __restrict__ fl
         y[(int64_t)r * ldy + i] = v;
     }
 }
-extern "C" int xva_mel_finish_ragged(float* mel, const int32_t* n_frames, float* energy, int B, int n_mel, int T, void* stream);
+extern "C" int xva_mel_finish_ragged(float* mel, const int32_t* n_frames, float* energy, int B, int n_mel, int T, int energy_trunc, void* stream);
 extern "C" int xva_mel_spectrogram_ragged(const xva_mel_config* c, const int16_t* flat, const int64_t* offsets, const int32_t* n_samples,
                                           const int32_t* order, int B, int Nmax, const float* dft_basis, const float* mel_basis_padded,
-                                          float* mel_out, float* energy_out, int32_t* n_frames_out, float* workspace, int64_t workspace_bytes,
-                                          void* stream) {
+                                          float* mel_out, float* energy_out, int energy_trunc, int32_t* n_frames_out, float* workspace,
+                                          int64_t workspace_bytes, void* stream) {
     XVA_CHECK_ARG(c && flat && offsets && n_samples && dft_basis && mel_basis_padded && mel_out && n_frames_out && workspace, "mel_ragged: null pointer");
     MelPlan pl;
     XVA_TRY(mel_plan(c, B, Nmax, &pl));
@@ -151,7 +151,7 @@ extern "C" int xva_mel_spectrogram_ragged(const xva_mel_config* c, const int16_t
                        (hipStream_t)stream, flat, offsets, n_samples, order, workspace + pl.off_pad, c->pad, pl.ldy, n_frames_out, c->n_fft, c->hop);
     XVA_LAUNCH_CHECK();
     XVA_TRY(mel_core(c, pl, B, dft_basis, mel_basis_padded, mel_out, workspace, stream));
-    return xva_mel_finish_ragged(mel_out, n_frames_out, energy_out, B, c->n_mel, pl.T, stream);
+    return xva_mel_finish_ragged(mel_out, n_frames_out, energy_out, B, c->n_mel, pl.T, energy_trunc, stream);
 }
 
 static int mel_core(const xva_mel_config* c, const MelPlan& pl, int B, const float* dft_basis, const float* mel_basis_padded, float* mel_out,
@@ -191,44 +191,101 @@ static int mel_core(const xva_mel_config* c, const MelPlan& pl, int B, const flo
 }
 
 
+// Linear magnitude spectrogram in the reference's (B, n_fft/2+1, T) layout: the 513-bin posterior-encoder input of xVAPitch
+// (TorchSTFT with use_mel=False, python/xvapitch/audio.py:138-171; the dataset-side AudioProcessor.spectrogram :632-652 is the same
+// |STFT| without the 1e-8 clamp).  Same reflect pad + DFT GEMM; the magnitude pass transposes 32 x 32 tiles through LDS so both
+// the [frame][bin] reads and the [bin][frame] writes are coalesced.
+__global__ void xva_magnitude_t_kernel(const float* __restrict__ spec, float* __restrict__ out, int T, int nb, int64_t lds, float eps_add,
+                                       float clamp_min) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads = 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, j = j0 + tx;
+        float v = 0.f;
+        if (t < T && j < nb) {
+            const float* row = spec + ((int64_t)b * T + t) * lds;
+            float p = row[j] * row[j] + row[nb + j] * row[nb + j] + eps_add;
+            if (clamp_min > 0.f) p = fmaxf(p, clamp_min);
+            v = sqrtf(p);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r, t = t0 + tx;
+        if (j < nb && t < T) out[((int64_t)b * nb + j) * T + t] = tile[tx][r];
+    }
+}
+extern "C" int xva_linear_spectrogram(const xva_mel_config* c, const float* wav, int B, int N, int64_t ld_wav, const float* dft_basis,
+                                      float* lin_out, float* workspace, int64_t workspace_bytes, void* stream) {
+    XVA_CHECK_ARG(c && wav && dft_basis && lin_out && workspace, "linear_spectrogram: null pointer");
+    MelPlan pl;
+    XVA_TRY(mel_plan(c, B, N, &pl));
+    XVA_CHECK_ARG(workspace_bytes >= pl.total * (int64_t)sizeof(float), "linear_spectrogram: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* ypad = workspace + pl.off_pad;
+    float* spec = workspace + pl.off_spec;
+    hipLaunchKernelGGL(xva_reflect_pad_kernel, dim3(xva_cdiv((int64_t)B * pl.ldy, 256)), dim3(256), 0, st, wav, ypad, B, N, c->pad, ld_wav, pl.ldy, pl.Np);
+    XVA_LAUNCH_CHECK();
+    xva_gemm_params g;
+    memset(&g, 0, sizeof(g));
+    g.A = ypad; g.B = dft_basis; g.C = spec;
+    g.M = pl.T; g.N = 2 * pl.nb; g.K = c->n_fft;
+    g.lda = c->hop; g.ldb = c->n_fft; g.ldc = pl.lds;
+    g.batch = B; g.sA = pl.ldy; g.sB = 0; g.sC = (int64_t)pl.T * pl.lds;
+    g.alpha = 1.f; g.splitk = 1; g.compute = 0; g.layout = XVA_GEMM_NT;
+    XVA_TRY(xva_gemm(&g, stream));
+    hipLaunchKernelGGL(xva_magnitude_t_kernel, dim3(xva_cdiv(pl.T, 32), xva_cdiv(pl.nb, 32), B), dim3(256), 0, st, spec, lin_out, pl.T, pl.nb, pl.lds,
+                       c->mag_eps_add, c->mag_clamp_min);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
 // ====================================================================================================================
 // Differentiable mel: L1 mel loss of a generated waveform and its gradient w.r.t. the waveform
 //   loss = scale * mean |mel_tgt - mel(wav)|        (F.l1_loss(y_mel, y_g_hat_mel) * 45, python/hifigan/xva_train.py:480,504)
 // Backward of the same pipeline, transposed: d(log-clamp) -> mel^T GEMM -> magnitude -> DFT^T GEMM -> overlap-add -> reflect fold.
 // ====================================================================================================================
-struct MelBwdPlan { MelPlan f; int64_t off_dM, off_dmag, off_dfr, total; };
+struct MelBwdPlan { MelPlan f; int64_t off_dM, off_dmag, off_dfr, total, ldT; };
 static int mel_bwd_plan(const xva_mel_config* c, int B, int N, MelBwdPlan* p) {
     XVA_TRY(mel_plan(c, B, N, &p->f));
-    XVA_CHECK_ARG(p->f.T % 4 == 0, "mel backward: number of frames must be a multiple of 4 (got %d)", p->f.T);
+    p->ldT = al4(p->f.T);        // dM rows are padded to a multiple of 4 frames (M3: 33 frames per 8192-sample segment)
     p->off_dM = al4(p->f.total);
-    p->off_dmag = p->off_dM + al4((int64_t)B * c->n_mel * p->f.T);
+    p->off_dmag = p->off_dM + al4((int64_t)B * c->n_mel * p->ldT);
     p->off_dfr = p->off_dmag + (int64_t)B * p->f.T * p->f.ldm;
     p->total = p->off_dfr + (int64_t)B * p->f.T * c->n_fft + 16;
     return XVA_OK;
 }
 // dM = -(scale / numel) * sign(tgt - mel) * exp(-mel) * [mel > log(clamp)] ; loss += (scale / numel) * sum |tgt - mel|
 __global__ void mel_l1_kernel(const float* __restrict__ mel, const float* __restrict__ tgt, float* __restrict__ dM, float* __restrict__ loss,
-                              int64_t n, float k, float log_clamp) {
+                              int64_t n, float k, float log_clamp, int T, int ldT) {
     __shared__ float sh[16];
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float m = mel[i], d = tgt[i] - m;
         acc += fabsf(d);
         float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        dM[i] = (m > log_clamp) ? -k * sg * expf(-m) : 0.f;
+        const int64_t row = i / T;
+        dM[row * ldT + (i - row * T)] = (m > log_clamp) ? -k * sg * expf(-m) : 0.f;
     }
     acc = xva_block_sum(acc, sh);
     if (threadIdx.x == 0 && loss) atomicAdd(loss, acc * k);
 }
 // spec rows [re | im] (in place) <- dmag * re / mag , dmag * im / mag
+// (M3: magnitude = sqrt(clamp(re^2 + im^2, clamp_min)) passes no gradient below the clamp)
 __global__ void mel_dspec_kernel(float* __restrict__ spec, const float* __restrict__ mag, const float* __restrict__ dmag, int64_t rows, int nb,
-                                 int64_t lds, int64_t ldm) {
+                                 int64_t lds, int64_t ldm, float eps_add, float clamp_min) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * nb) return;
     int64_t r = idx / nb;
     int j = (int)(idx - r * nb);
     float mg = mag[r * ldm + j], g = dmag[r * ldm + j];
     float sc = mg > 0.f ? g / mg : 0.f;
+    if (clamp_min > 0.f) {
+        const float re = spec[r * lds + j], im = spec[r * lds + nb + j];
+        if (re * re + im * im + eps_add < clamp_min) sc = 0.f;
+    }
     spec[r * lds + j] *= sc;
     spec[r * lds + nb + j] *= sc;
 }
@@ -282,7 +339,11 @@ extern "C" int xva_mel_l1_loss_backward(const xva_mel_config* c, const float* wa
     const int64_t nmel = (int64_t)B * c->n_mel * f.T;
     {
         int grid = (int)((nmel + 255) / 256); if (grid > 1024) grid = 1024;
-        hipLaunchKernelGGL(mel_l1_kernel, dim3(grid), dim3(256), 0, st, mel_out, mel_tgt, dM, loss_out, nmel, scale / (float)nmel, logf(c->log_clamp));
+        if (p.ldT != f.T && hipMemsetAsync(dM, 0, (size_t)B * c->n_mel * p.ldT * sizeof(float), st) != hipSuccess) {
+            xva_set_error("mel backward: memset failed"); return XVA_ERR_HIP;
+        }
+        hipLaunchKernelGGL(mel_l1_kernel, dim3(grid), dim3(256), 0, st, mel_out, mel_tgt, dM, loss_out, nmel, scale / (float)nmel, logf(c->log_clamp),
+                           f.T, (int)p.ldT);
         XVA_LAUNCH_CHECK();
     }
     {   // dmag[b] (T x ldm) = dM[b]^T (T x n_mel) * melW (n_mel x ldm)
@@ -290,14 +351,14 @@ extern "C" int xva_mel_l1_loss_backward(const xva_mel_config* c, const float* wa
         memset(&g, 0, sizeof(g));
         g.layout = XVA_GEMM_TN; g.A = dM; g.B = mel_basis_padded; g.C = dmag;
         g.M = f.T; g.N = (int)f.ldm; g.K = c->n_mel;
-        g.lda = f.T; g.ldb = f.ldm; g.ldc = f.ldm;
-        g.batch = B; g.sA = (int64_t)c->n_mel * f.T; g.sB = 0; g.sC = (int64_t)f.T * f.ldm;
+        g.lda = p.ldT; g.ldb = f.ldm; g.ldc = f.ldm;
+        g.batch = B; g.sA = (int64_t)c->n_mel * p.ldT; g.sB = 0; g.sC = (int64_t)f.T * f.ldm;
         g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.compute = 0; g.mask_mul = 1;
         XVA_TRY(xva_gemm(&g, stream));
     }
     {
         const int64_t rows = (int64_t)B * f.T;
-        hipLaunchKernelGGL(mel_dspec_kernel, dim3(xva_cdiv(rows * f.nb, 256)), dim3(256), 0, st, spec, mag, dmag, rows, f.nb, f.lds, f.ldm);
+        hipLaunchKernelGGL(mel_dspec_kernel, dim3(xva_cdiv(rows * f.nb, 256)), dim3(256), 0, st, spec, mag, dmag, rows, f.nb, f.lds, f.ldm, c->mag_eps_add, c->mag_clamp_min);
         XVA_LAUNCH_CHECK();
     }
     {   // dframes (rows x n_fft) = dspec (rows x 2 nb) * basis (2 nb x n_fft)

@@ -95,11 +95,12 @@ class FastPitch(nn.Module):
         self.energy_conditioning = True
         self.speaker_emb = None
         self._engine = None
+        self.seed = 1234                 # dropout-mask seed of the engine (the trainer sets 1234 + rank, xva_train.py:294-295)
 
     # ---- engine plumbing ----
     def _get_engine(self):
         if self._engine is None or self._engine.device != self.flat.device:
-            self._engine = E.FastPitchEngine(self.flat.device, self.compute)
+            self._engine = E.FastPitchEngine(self.flat.device, self.compute, seed=self.seed)
         self._engine.p_dropout = self.p_dropout if self.training else 0.0
         return self._engine
 

@@ -2,19 +2,28 @@
 engine (training stages 1-4).
 
 Kept from the reference, because the Electron UI / server.py consume them: module-level `async handleTrainer(models_manager,
-data, websocket, gpus, resume)` returning None | "move to hifi"; class `FastPitchTrainer(logger, PROD, gpus, models_manager,
-websocket)` with `async start / init / iteration`, `pause`, `finish_epoch`, `save_checkpoint`, `load_checkpoint` and the flags
+data, websocket, gpus, resume)` returning None | "move to hifi" (checkpoint resolution incl. "[male]" / "[female]", the
+out-of-memory back-off, the stage-to-stage recursion); class `FastPitchTrainer(logger, PROD, gpus, models_manager, websocket)` with
+`async start / init / iteration`, `pause`, `finish_epoch`, `save_checkpoint`, `load_checkpoint`, `extract_durations` and the flags
 `running / is_init / JUST_FINISHED_STAGE / END_OF_TRAINING`; the `data` dict keys; `training.log` + `graphs.json`; ws strings
-"Set stage to: N "; checkpoint files `FastPitch_checkpoint_{epoch}_{iter}.pt` (keep last 2), `{dataset_id}.pt` (fp16
-state_dict) and `{dataset_id}.json`; LAMB(lr 0.1, betas (0.9, 0.98), eps 1e-9, wd 1e-6), clip 1000, warm-up 1000,
-gam = max(1, round(256 / batch)); stage freezing; loss-delta early stopping.
+"Set stage to: N "; checkpoint files `FastPitch_checkpoint_{epoch}_{iter}.pt` (keep last 2), `Stage_{n}_DONE_...pt`,
+`{dataset_id}.pt` (fp16 state_dict) and `{dataset_id}.json`; LAMB(lr 0.1, betas (0.9, 0.98), eps 1e-9, wd 1e-6), clip 1000,
+warm-up 1000; the per-stage batch multipliers {1: 1.5, 2: 12, 3: 3.5, 4: 4} x GPUs x 10 / max clip seconds and
+gam = max(1, round(256 / batch)); stage freezing; the loss-delta stopping rule (mean of the last EPOCH_AVG_SPAN relative
+epoch-loss deltas <= target for 3 consecutive epochs, at least 20 epochs in stage 2); on stage completion the checkpoint is
+re-written with training_stage + 1 and an empty loss history before the bare raise.
 Changed on purpose: the step is 3 C calls (no autograd graph, no GradScaler: bf16 needs no loss scaling); training.log is
-appended, not rewritten, each step; multi-GPU is one process per GPU (dp.GradSync) instead of nn.DataParallel.
+appended, not rewritten, each step; batches are built on the device from the dataset directory (xva-trainer_amd/data.py);
+multi-GPU is one process per GPU (dp.GradSync over RCCL) instead of single-process nn.DataParallel — launch the server /
+trainer under `python -m torch.distributed.run --nproc-per-node N`; rank 0 keeps the ws / log / checkpoint duties.
 """
+import contextlib
+import gc
 import json
 import os
 import time
 import traceback
+import wave
 
 import numpy as np
 import torch
@@ -24,6 +33,8 @@ from . import params as P
 from .lamb import Lamb
 from .loss_function import FastPitchLoss  # noqa: F401  (re-exported like the reference module)
 from .model import FastPitch
+
+STAGE_BS_MULT = {1: 1.5, 2: 12, 3: 3.5, 4: 4}          # xva_train.py:387-398
 
 
 def sort_fp(x):
@@ -41,32 +52,93 @@ def adjust_learning_rate(total_iter, opt, learning_rate, warmup_iters=None):
         param_group["lr"] = learning_rate * scale
 
 
+def _is_oom(e):
+    s = str(e)
+    return "out of memory" in s.lower() or "PYTORCH_CUDA_ALLOC_CONF" in s or "PYTORCH_HIP_ALLOC_CONF" in s
+
+
+def resolve_checkpoint(trainer, ckpt_fname, dataset_output):
+    """xva_train.py:73-102: newest checkpoint in the output directory, else "[male]" / "[female]" pretrained, else the newest in a
+    given directory, else the given file."""
+    final = None
+    if ckpt_fname is None:
+        return None
+    if os.path.exists(dataset_output):
+        ckpts = sorted([c for c in os.listdir(dataset_output) if c.startswith("FastPitch_checkpoint_")], key=sort_fp)
+        if ckpts:
+            final = "%s/%s" % (dataset_output, ckpts[-1])
+    if ckpt_fname == "[male]":
+        final = trainer.pretrained_ckpt_male
+    elif ckpt_fname == "[female]":
+        final = trainer.pretrained_ckpt_female
+    else:
+        if final is None and os.path.isdir(ckpt_fname):
+            ckpts = sorted([c for c in os.listdir(ckpt_fname) if c.startswith("FastPitch_checkpoint_")], key=sort_fp)
+            if ckpts:
+                final = "%s/%s" % (ckpt_fname, ckpts[-1])
+        if final is None:
+            final = ckpt_fname
+    return final
+
+
 async def handleTrainer(models_manager, data, websocket, gpus, resume=False):
     """python/fastpitch1_1/xva_train.py:57-176."""
+    gc.collect()
+    torch.cuda.empty_cache()
     if not resume:
         models_manager.sync_init_model("fastpitch1_1", websocket=websocket, gpus=gpus)
-    trainer = models_manager.models_bank["fastpitch1_1"]
-    if not resume:
+        trainer = models_manager.models_bank["fastpitch1_1"]
         dataset_id = data["dataset_path"].split("/")[-1]
-        trainer.init_logs(dataset_output=data["output_path"] + "/" + dataset_id)
+        dataset_output = data["output_path"] + "/" + dataset_id
+        trainer.init_logs(dataset_output=dataset_output)
+        data["checkpoint"] = resolve_checkpoint(trainer, data.get("checkpoint"), dataset_output)
+    else:
+        trainer = models_manager.models_bank["fastpitch1_1"]
     try:
         return await trainer.start(data, gpus=gpus, resume=resume)
     except KeyboardInterrupt:
         trainer.running = False
         raise
-    except RuntimeError:
+    except RuntimeError as e:
+        running = trainer.running
+        trainer.running = False
+        stage_finished = trainer.stage_finished
+        for attr in ("train_loader", "dataloader_iterator", "optimizer", "grads", "sync"):
+            if hasattr(trainer, attr):
+                try:
+                    delattr(trainer, attr)
+                except Exception:
+                    pass
+        gc.collect()
+        torch.cuda.empty_cache()
+        if _is_oom(e):                                                       # xva_train.py:131-145: retry with the base batch size - 3
+            trainer.print_and_log("Out of VRAM")
+            if running and int(data["batch_size"]) > 3:
+                trainer.print_and_log("============= Reducing base batch size from %s to %s" % (data["batch_size"], int(data["batch_size"]) - 3),
+                                      save_to_file=trainer.dataset_output)
+                data["batch_size"] = int(data["batch_size"]) - 3
+                models_manager.models_bank.pop("fastpitch1_1", None)
+                del trainer
+                gc.collect()
+                torch.cuda.empty_cache()
+                return await handleTrainer(models_manager, data, websocket, gpus)
+            models_manager.models_bank.pop("fastpitch1_1", None)
+            raise
         if trainer.JUST_FINISHED_STAGE:
+            trainer.print_and_log("Finished training stage %d...\n" % stage_finished if stage_finished < 4 else "Moving to HiFi-GAN...\n",
+                                  save_to_file=trainer.dataset_output)
             trainer.JUST_FINISHED_STAGE = False
             trainer.is_init = False
-            finished = int(trainer.model.training_stage)
-            if finished >= 4:
-                trainer.print_and_log("Finished training FastPitch", save_to_file=trainer.dataset_output)
-                del models_manager.models_bank["fastpitch1_1"]
+            models_manager.models_bank.pop("fastpitch1_1", None)
+            del trainer
+            gc.collect()
+            if stage_finished >= 4:
+                models_manager.models_bank["fastpitch1_1"] = "move to hifi"
                 return "move to hifi"
             data = dict(data)
-            data["force_stage"] = finished + 1
-            del models_manager.models_bank["fastpitch1_1"]
+            data.pop("force_stage", None)       # the re-written checkpoint carries the next stage (xva_train.py:958-966)
             return await handleTrainer(models_manager, data, websocket, gpus)
+        models_manager.models_bank.pop("fastpitch1_1", None)
         raise
 
 
@@ -81,9 +153,14 @@ class FastPitchTrainer(object):
         self.JUST_FINISHED_STAGE = self.END_OF_TRAINING = False
         self.training_log, self.training_log_live_line, self.graphs_json = [], "", None
         self.dataset_input = self.dataset_output = self.dataset_id = None
+        self.force_stage = None
+        self.stage_finished = 0
         self.EPOCH_AVG_SPAN, self.target_delta = 20, 0.0
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        root = "./resources/app" if PROD else "."
+        self.pretrained_ckpt_male = root + "/python/fastpitch1_1/pretrained_models/f4_nate_FastPitch_checkpoint_5760_67000.pt"
+        self.pretrained_ckpt_female = root + "/python/fastpitch1_1/pretrained_models/f4_nora_FastPitch_checkpoint_4520_65550.pt"
 
     # ---- logs the UI reads from disk (xva_train.py:226-238,546-569) ----
     def print_and_log(self, line=None, end="\n", flush=False, save_to_file=None):
@@ -91,7 +168,7 @@ class FastPitchTrainer(object):
             line = self.training_log_live_line
         else:
             self.training_log.append(line)
-        if self.rank == 0 and save_to_file is not None:
+        if self.rank == 0 and save_to_file:
             os.makedirs(save_to_file, exist_ok=True)
             with open(save_to_file + "/training.log", "a") as f:
                 f.write(line.rstrip() + "\n")
@@ -133,11 +210,12 @@ class FastPitchTrainer(object):
             self.batch_size = int(data["batch_size"])
             self.epochs_per_checkpoint = int(data.get("epochs_per_checkpoint", 1))
             self.max_iterations = data.get("max_iterations")          # benchmark / test hook (not in the reference)
+            self.synthetic_data = bool(data.get("synthetic_data", False))   # explicit opt-in (bench / tests); never a silent fallback
             self.learning_rate, self.weight_decay = 0.1, 1e-6
             self.dur_predictor_loss_scale = self.pitch_predictor_loss_scale = 0.1
             self.attn_loss_scale = 1.0                                 # xva_train.py:704
             self.warmup_steps, self.grad_clip_thresh = 1000, 1000
-        while self.running and not self.JUST_FINISHED_STAGE:
+        while self.running and not self.JUST_FINISHED_STAGE and not self.END_OF_TRAINING:
             await self.iteration()
 
     def get_target_delta(self, num_data_lines, stage):
@@ -164,35 +242,155 @@ class FastPitchTrainer(object):
         if num_data_lines < 500: td = 15e-4 if num_data_lines < 250 else 45e-5
         return td * 3.0
 
+    # ---- dataset statistics (xva_train.py:304-335,493-536) ----
+    def _dataset_file_lengths(self):
+        lengths = []
+        meta = os.path.join(self.dataset_input, "metadata.csv")
+        if not os.path.exists(meta):
+            return lengths
+        with open(meta, encoding="utf-8") as f:
+            for line in f.read().split("\n"):
+                if not line.strip():
+                    continue
+                fname = line.split("|")[0]
+                fname = "%s/wavs/%s" % (self.dataset_input, fname + ("" if fname.endswith(".wav") else ".wav"))
+                if os.path.exists(fname):
+                    with contextlib.closing(wave.open(fname, "r")) as w:
+                        lengths.append(w.getnframes() / float(w.getframerate()))
+        return lengths
+
+    def get_or_calculate_pitch_stats(self):
+        """pitch_stats.json {mean, std} in Hz (xva_train.py:493-536) -> the model's pitch_mean / pitch_std buffers.  Computing them needs
+        librosa.pyin over the whole set: CPU preprocessing of the reference, outside this path — a missing file is reported, not guessed."""
+        path = os.path.join(self.dataset_input, "pitch_stats.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f)
+            self.print_and_log("pitch_mean: %s | pitch_std: %s" % (d["mean"], d["std"]), save_to_file=self.dataset_output)
+            return float(d["mean"]), float(d["std"])
+        self.print_and_log("No existing pitch mean/std stats (pitch_stats.json is written by the reference's pyin preprocessing); "
+                           "keeping the checkpoint's pitch_mean / pitch_std.", save_to_file=self.dataset_output)
+        return None, None
+
+    def _init_distributed(self):
+        """One process per GPU.  WORLD_SIZE > 1 without a process group is initialised here from the launcher's env (RANK,
+        LOCAL_RANK, MASTER_ADDR, MASTER_PORT); a multi-GPU request inside ONE process is refused (the reference would wrap the model
+        in nn.DataParallel, xva_train.py:465-466 — that single-process mode does not exist here)."""
+        import torch.distributed as dist
+        if self.world > 1:
+            if not dist.is_available():
+                raise RuntimeError("WORLD_SIZE=%d but torch.distributed is not available" % self.world)
+            if not dist.is_initialized():
+                for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                    if k not in os.environ:
+                        raise RuntimeError("WORLD_SIZE=%d but %s is not set: launch under `python -m torch.distributed.run`" % (self.world, k))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+            if dist.get_world_size() != self.world:
+                raise RuntimeError("process group size %d != WORLD_SIZE %d" % (dist.get_world_size(), self.world))
+            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        if self.gpus is not None and len(self.gpus) > 1:
+            raise NotImplementedError("gpus=%s in one process: the MI355X path is one process per GPU — start the trainer under "
+                                      "`python -m torch.distributed.run --nproc-per-node %d` instead of nn.DataParallel" % (self.gpus, len(self.gpus)))
+        return torch.device("cuda", int(self.gpus[0]) if self.gpus else 0)
+
+    def _make_loader(self, stage, dm):
+        if self.loader_factory:
+            loader = self.loader_factory(self)
+            if loader is not None:
+                return loader
+        if self.synthetic_data:
+            from ..data import SyntheticFastPitchLoader
+            return SyntheticFastPitchLoader(self.per_rank_batch, seed=1234 + self.rank, with_prior=stage == 1)
+        if not os.path.exists(os.path.join(self.dataset_input, "metadata.csv")):
+            raise FileNotFoundError("%s/metadata.csv not found: the trainer reads the reference's dataset layout (metadata.csv + wavs/); "
+                                    "synthetic data needs the explicit `synthetic_data` opt-in" % self.dataset_input)
+        from ..data import FastPitchFileLoader, read_metadata
+        n_items = len(read_metadata(self.dataset_input)) * max(1, dm) // self.world
+        if 0 < n_items < self.per_rank_batch:       # a batch larger than the (repeated) dataset would leave drop_last with nothing to train on
+            self.print_and_log("Capping batch size to %d (dataset size x data multiplier)" % n_items, save_to_file=self.dataset_output)
+            self.per_rank_batch = n_items
+            self.global_batch = n_items * self.world
+            self.gam = max(1, round(256 / self.global_batch))
+        return FastPitchFileLoader(self.dataset_input, self.per_rank_batch, stage, self.device, seed=1234, rank=self.rank, world=self.world, dm=dm)
+
     async def init(self):
-        dev = torch.device("cuda", self.gpus[0] if self.world == 1 else int(os.environ.get("LOCAL_RANK", "0")))
+        self.device = dev = self._init_distributed()
         torch.cuda.set_device(dev)
         torch.manual_seed(1234 + self.rank)
         np.random.seed(1234 + self.rank)
+        self.print_and_log("Dataset: %s" % self.dataset_input, save_to_file=self.dataset_output)
+        ckpt_path = self.last_checkpoint(self.dataset_output)
+        if ckpt_path is None:
+            ckpt_path = self.checkpoint
+            self.print_and_log("Checkpoint: %s" % ckpt_path, save_to_file=self.dataset_output)
+        self.ckpt_path = str(ckpt_path)
+        self.start_iterations = 50000
+        lengths = self._dataset_file_lengths()
+        num_data_lines = len(lengths)
+        for lim, it in ((1000, 47500), (2000, 45000), (4000, 42500), (8000, 40000)):
+            if num_data_lines > lim:
+                self.start_iterations = it
+        pitch_mean, pitch_std = self.get_or_calculate_pitch_stats()
+
         self.model = FastPitch(logger=self.logger, compute=self.compute).to(dev)
+        self.model.seed = 1234 + self.rank                    # dropout masks differ across DP ranks (xva_train.py:294-295 seeds per rank)
+        self.model.train()
         self.eng = self.model._get_engine()
         self.optimizer = Lamb(self.model.flat.data, self.model._table, lr=self.learning_rate, betas=(0.9, 0.98), eps=1e-9,
                               weight_decay=self.weight_decay)
         self.grads = torch.zeros_like(self.model.flat.data)
-        self.epoch, self.total_iter, self.avg_loss_per_epoch = 1, 0, []
-        stage = 1                                             # a fresh model starts with the aligner (model.py:176: training_stage = 1)
-        ckpt = self.last_checkpoint(self.dataset_output) or self.checkpoint
-        if ckpt and os.path.exists(str(ckpt)):
-            stage, self.epoch, self.total_iter, self.avg_loss_per_epoch = self.load_checkpoint(ckpt)
+        stage, start_epoch, start_iter, self.avg_loss_per_epoch = 1, 1, 0, []
+        if ckpt_path and os.path.exists(str(ckpt_path)):
+            stage, start_epoch, start_iter, self.avg_loss_per_epoch = self.load_checkpoint(ckpt_path)
+        if pitch_mean is not None:                            # xva_train.py:344-346 (the reference sets them before load_checkpoint; the file wins)
+            self.model.pitch_mean[0], self.model.pitch_std[0] = pitch_mean, pitch_std
+        if (stage == 5 and self.force_stage is None) or self.force_stage == 5:
+            self.END_OF_TRAINING = self.JUST_FINISHED_STAGE = True
+            self.stage_finished = 4
+            raise RuntimeError("FastPitch training already finished")
         if self.force_stage:
+            self.print_and_log("Forcing stage: %d" % self.force_stage, save_to_file=self.dataset_output)
+            if stage < self.force_stage and stage != 3:
+                start_iter = self.start_iterations
+            self.avg_loss_per_epoch = []
             stage = self.force_stage
-        stage = max(1, int(stage))
+        self.total_iter = start_iter
+        if ckpt_path is None or self.dataset_id not in str(ckpt_path):            # IS_NEW (xva_train.py:380-385)
+            self.print_and_log("New voice", save_to_file=self.dataset_output)
+            stage = self.force_stage or 1
+            self.total_iter = self.start_iterations
+            self.avg_loss_per_epoch = []
+        stage = max(1, min(4, int(stage)))
         self.model.training_stage = torch.tensor(stage)
         if self.websocket is not None:
             await self.websocket.send("Set stage to: %d " % stage)
-        self.gam = max(1, round(256 / (self.batch_size * self.world)))
-        loader = self.loader_factory(self) if self.loader_factory else None
-        if loader is None:
-            from ..data import SyntheticFastPitchLoader
-            loader = SyntheticFastPitchLoader(self.batch_size, seed=1234 + self.rank)
-        self.train_loader = loader
-        self.num_iters = max(1, len(loader) // self.gam)
-        self.target_delta = self.get_target_delta(len(loader) * self.batch_size, stage)
+
+        # ---- batch size per stage (xva_train.py:387-407).  batch_size is the GLOBAL batch, split over the ranks.
+        if stage == 2:
+            self.epochs_per_checkpoint = self.epochs_per_checkpoint * 3
+        mult = STAGE_BS_MULT[stage]
+        file_lengths_bs_mult = 10 / max(lengths) if lengths else 1.0
+        base = self.batch_size
+        self.global_batch = max(1, int(base * mult * self.world * file_lengths_bs_mult))
+        self.per_rank_batch = max(1, self.global_batch // self.world)
+        self.global_batch = self.per_rank_batch * self.world
+        self.gam = max(1, round(256 / self.global_batch))
+        self.print_and_log(["", "Stage 1: Pre-training only the alignment.", "Stage 2: Pre-training durations predictor",
+                            "Stage 3: Fine-tuning pitch/energy/mel", "Stage 4: Fine-tuning mel"][stage], save_to_file=self.dataset_output)
+        self.print_and_log("Batch size: %d (Base: %d, Stage mult: %s, File lengths mult: %s, GPUs mult: %d) | GAM: %d -> (%d)" % (
+            self.global_batch, base, mult, int(file_lengths_bs_mult * 100) / 100, self.world, self.gam, self.global_batch * self.gam),
+            save_to_file=self.dataset_output)
+        data_mult = max(1, min(4, int(self.global_batch / base)))
+        self.EPOCH_AVG_SPAN = max(1, int(20 / data_mult))
+        self.print_and_log("Data multiplier: %d" % data_mult, save_to_file=self.dataset_output)
+
+        if stage >= 2 and not self.synthetic_data and not self.loader_factory and not os.path.exists(self.dataset_input + "/durs_text"):
+            self.extract_durations()                                              # xva_train.py:473-474
+        self.train_loader = self._make_loader(stage, data_mult)
+        n_lines = getattr(self.train_loader, "actual_num_lines", None) or len(self.train_loader) * self.global_batch
+        self.num_iters = max(1, len(self.train_loader) // self.gam)
+        self.target_delta = self.get_target_delta(n_lines, stage)
+        self.target_patience, self.target_patience_count = 3, 0
         self.graphs_json["stages"][str(stage)]["target_delta"] = self.target_delta
         ranges = E.trainable_ranges(stage)
         self.active = {t[0] for t in self.model._table if any(b <= t[1] < e for b, e in ranges)}
@@ -200,17 +398,34 @@ class FastPitchTrainer(object):
             self.active = {n for n in self.active if not n.startswith("energy_emb")}
         if stage == 1:   # only the aligner and the symbol embedding are in the stage-1 graph (every other grad is None in the reference)
             self.active = {t[0] for t in self.model._table if (t[0].startswith("attention.") and "attn_proj" not in t[0]) or t[0] == "encoder.word_emb.weight"}
+        self.active_ranges = sorted((t[1], t[1] + t[2]) for t in self.model._table if t[0] in self.active)
         self.sync = None
         if self.world > 1:
             from .dp import GradSync
             self.sync = GradSync(self.eng, self.model.flat.data, self.grads, self.world)
+        self.epoch = start_epoch
         self.dataloader_iterator = iter(self.train_loader)
-        self.accumulated_steps, self.iter_loss, self.iter_num_frames, self.epoch_iter = 0, 0.0, 0, 0
-        self.iter_start_time = None
-        self.avg_loss_per_epoch.append(0.0)
-        self.epoch_frames_per_sec = [0.0]
-        self.avg_frames_s = []
+        self.epoch_frames_per_sec, self.avg_frames_s, self.last_loss = [], [], None
+        self.start_new_epoch()
+        self.print_and_log("Starting training.")
         self.is_init = True
+
+    def start_new_epoch(self):
+        self.avg_loss_per_epoch += [0.0]
+        self.epoch_frames_per_sec += [0.0]
+        self.accumulated_steps, self.iter_loss, self.iter_num_frames = 0, 0.0, 0
+        self.iter_start_time = None
+        self.iter_losses = []
+        self.epoch_iter = 0
+
+    def _global_mean(self, value):
+        """mean over the DP ranks of a host scalar (keeps every rank's stopping / NaN decisions identical)."""
+        if self.world == 1:
+            return value
+        import torch.distributed as dist
+        t = torch.tensor([value], device=self.device, dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item()) / self.world
 
     # ---- xva_train.py:757-911 ----
     async def iteration(self):
@@ -220,6 +435,7 @@ class FastPitchTrainer(object):
             batch = next(self.dataloader_iterator)
         except StopIteration:
             self.finish_epoch()
+            self.start_new_epoch()
             self.dataloader_iterator = iter(self.train_loader)
             batch = next(self.dataloader_iterator)
         stage = int(self.model.training_stage)
@@ -230,7 +446,7 @@ class FastPitchTrainer(object):
                 self.iter_start_time = time.perf_counter()
             adjust_learning_rate(self.total_iter, self.optimizer, self.learning_rate, self.warmup_steps)
             self.grads.zero_()
-        b = E.DeviceBatch.from_dict(batch, self.model.flat.device)
+        b = batch if isinstance(batch, E.DeviceBatch) else E.DeviceBatch.from_dict(batch, self.model.flat.device)
         flat = self.model.flat.data
         last = (self.accumulated_steps + 1) % self.gam == 0
         if stage == 1:
@@ -238,23 +454,26 @@ class FastPitchTrainer(object):
                 raise ValueError("training stage 1 needs `attn_prior` in the batch (TTSCollate, data_function.py:600-609)")
             al_loss, self._last_durs, _, _ = self.eng.align_forward(flat, b.text, b.in_lens, b.mel_tgt, b.mel_lens, b.attn_prior, want_maps=False)
             self.eng.align_backward(flat, self.grads, 1.0 / (self.gam * self.world))
-            if self.world > 1 and last:   # the aligner's gradients are a few MB: one plain all-reduce at the end of the accumulation
+            if self.world > 1:
                 import torch.distributed as dist
-                dist.all_reduce(self.grads)
+                dist.all_reduce(al_loss)
+                al_loss = al_loss / self.world
+                if last:                                   # only the aligner + symbol embedding carry gradients in stage 1: a few MB
+                    for rb, re_ in self.active_ranges:
+                        dist.all_reduce(self.grads[rb:re_])
             losses = torch.cat([al_loss * self.attn_loss_scale, torch.zeros(7, device=flat.device)])
         elif self.sync is None:
             losses = self.eng.fwd_loss_bwd(flat, self.grads, b, stage, grad_scale=1.0 / self.gam)
         else:
             losses = self.sync.fwd_loss_bwd(b, stage, grad_scale=1.0 / self.gam, sync=last)
         self.accumulated_steps += 1
-        self._pending = (losses, b.mel_lens if b.mel_lens is not None else None)
         host = losses.detach().cpu()                      # the one host sync per micro-batch (reference: 5 x .item())
         mel_loss, dur_loss, pitch_loss = float(host[1]), float(host[2]), float(host[3])
         reduced = {1: float(host[0]), 2: float(host[0]), 3: pitch_loss * self.pitch_predictor_loss_scale, 4: mel_loss}[stage]
-        if np.isnan(reduced):
+        if np.isnan(reduced):                             # xva_train.py:825-832 (the loss is global: every rank takes this branch together)
             self.print_and_log("loss is NaN", save_to_file=self.dataset_output)
             self.grads.zero_()
-            self.accumulated_steps = 0
+            self.accumulated_steps, self.iter_loss, self.iter_num_frames = 0, 0.0, 0
             return
         self.iter_loss += reduced / self.gam
         self.iter_num_frames += int(b.mel_lens.sum().item()) if b.mel_lens is not None else 0
@@ -265,6 +484,7 @@ class FastPitchTrainer(object):
             self.epoch_frames_per_sec[-1] += fps
             self.avg_frames_s.append(fps)
             self.avg_loss_per_epoch[-1] += self.iter_loss
+            self.iter_losses.append(self.iter_loss)
             self.training_log_live_line = "Stage: %d | Epoch: %d | iter: %d/%d -> %d | loss: %.6f | frames/s %d | Target: %.6f    " % (
                 stage, self.epoch, (self.total_iter + 1) % self.num_iters, self.num_iters, self.total_iter, self.iter_loss, int(fps), self.target_delta)
             self.print_and_log(save_to_file=self.dataset_output)
@@ -276,29 +496,51 @@ class FastPitchTrainer(object):
     # ---- xva_train.py:915-977 ----
     def finish_epoch(self):
         stage = int(self.model.training_stage)
-        avg = self.avg_loss_per_epoch[-1] / max(1, self.epoch_iter)
-        self.avg_loss_per_epoch[-1] = avg
-        deltas = [(a - b) / a for a, b in zip(self.avg_loss_per_epoch[:-1], self.avg_loss_per_epoch[1:]) if a]
-        delta = float(np.mean(deltas[-self.EPOCH_AVG_SPAN:])) if deltas else None
-        g = self.graphs_json["stages"][str(stage)]
-        g["loss"].append([self.total_iter, avg])
-        if delta is not None:
-            g["loss_delta"].append([self.total_iter, delta])
-        self._save_graphs()
-        fpath = "%s/FastPitch_checkpoint_%d_%d.pt" % (self.dataset_output, self.epoch, self.total_iter)
-        self.save_checkpoint(frames_s=self.epoch_frames_per_sec[-1] / max(1, self.epoch_iter), total_iter=self.total_iter, avg_loss=avg,
-                             loss_delta=delta, avg_loss_per_epoch=self.avg_loss_per_epoch, fpath=fpath)
-        finished = len(deltas) >= 3 and all(d <= self.target_delta for d in deltas[-3:]) and delta is not None and delta <= self.target_delta
         self.epoch += 1
-        self.epoch_iter = 0
-        self.avg_loss_per_epoch.append(0.0)
-        self.epoch_frames_per_sec.append(0.0)
-        if finished:
-            self.save_checkpoint(force_save=True, total_iter=self.total_iter, avg_loss_per_epoch=self.avg_loss_per_epoch,
-                                 fpath="%s/Stage_%d_DONE_%d_%d.pt" % (self.dataset_output, stage, self.epoch, self.total_iter))
-            self.JUST_FINISHED_STAGE = True
-            self.running = False
-            raise RuntimeError("stage %d finished" % stage)     # the reference signals stage completion by raising (xva_train.py:970)
+        self.avg_loss_per_epoch[-1] = self._global_mean(self.avg_loss_per_epoch[-1] / max(1, self.epoch_iter))
+        self.iter_start_time = None
+        losses = self.avg_loss_per_epoch
+        deltas = [(losses[i - 1] - losses[i]) / losses[i - 1] for i in range(1, len(losses)) if losses[i - 1]]
+        avg_loss = float(np.mean(self.iter_losses)) if self.iter_losses else None
+        delta_avg = float(np.mean(deltas[-self.EPOCH_AVG_SPAN:])) if len(deltas) >= 2 else None
+        frames_s = float(np.mean(self.avg_frames_s)) if self.avg_frames_s else 0.0
+        fpath = "%s/FastPitch_checkpoint_%d_%d.pt" % (self.dataset_output, self.epoch, self.total_iter)
+        self.save_checkpoint(force_save=False, frames_s=frames_s, total_iter=self.total_iter, avg_loss=avg_loss, loss_delta=delta_avg,
+                             avg_loss_per_epoch=self.avg_loss_per_epoch, fpath=fpath)
+        g = self.graphs_json["stages"][str(stage)]
+        g["loss"].append([self.total_iter, losses[-1]])
+        self._save_graphs()
+        if self.iter_losses:
+            if self.last_loss and delta_avg is not None:
+                g["loss_delta"].append([self.total_iter, delta_avg])
+                self._save_graphs()
+                min_epochs = 20 if stage == 2 else 1                              # xva_train.py:954
+                if len(deltas) >= min_epochs and delta_avg <= self.target_delta:
+                    self.target_patience_count += 1
+                    if self.target_patience_count >= self.target_patience:
+                        self._finish_stage(stage, frames_s, avg_loss, delta_avg, fpath)
+                else:
+                    self.target_patience_count = 0
+            self.last_loss = avg_loss
+        self.avg_frames_s = []
+
+    def _finish_stage(self, stage, frames_s, avg_loss, delta_avg, fpath):
+        """xva_train.py:956-970: the NEXT stage and an empty loss history go into the regular checkpoint (so the next trainer starts
+        there with a clean stopping history) and into Stage_{n}_DONE_*, then the bare raise handleTrainer turns into the next stage."""
+        fpath_stage = "%s/Stage_%d_DONE_FastPitch_checkpoint_%d_%d.pt" % (self.dataset_output, stage, self.epoch, self.total_iter)
+        if stage == 4:
+            self.END_OF_TRAINING = True
+        self.JUST_FINISHED_STAGE = True
+        self.stage_finished = stage
+        self.model.training_stage = torch.tensor(stage + 1)
+        self.avg_loss_per_epoch = []
+        it = self.total_iter if stage + 1 == 4 else self.start_iterations
+        self.save_checkpoint(force_save=True, frames_s=frames_s, total_iter=it, avg_loss=avg_loss, loss_delta=delta_avg,
+                             avg_loss_per_epoch=self.avg_loss_per_epoch, fpath=fpath)
+        self.save_checkpoint(force_save=True, frames_s=frames_s, total_iter=it, avg_loss=avg_loss, loss_delta=delta_avg,
+                             avg_loss_per_epoch=self.avg_loss_per_epoch, fpath=fpath_stage, doPrintLog=False)
+        self.running = False
+        raise RuntimeError("stage %d finished" % stage)     # the reference signals stage completion by raising (xva_train.py:970)
 
     # ---- xva_train.py:979-1052 ----
     def save_checkpoint(self, force_save=False, frames_s=0, total_iter=0, avg_loss=None, loss_delta=None, avg_loss_per_epoch=[], fpath="out.pt",
@@ -312,7 +554,7 @@ class FastPitchTrainer(object):
         for ck in old[:-2] if len(old) > 2 else []:
             os.remove(self.dataset_output + "/" + ck)
         sd = self.model.state_dict()
-        checkpoint = {"epoch": self.epoch, "iteration": total_iter, "avg_loss_per_epoch": avg_loss_per_epoch,
+        checkpoint = {"epoch": self.epoch, "iteration": total_iter, "avg_loss_per_epoch": list(avg_loss_per_epoch),
                       "training_stage": self.model.training_stage, "state_dict": sd, "optimizer": self.optimizer.state_dict()}
         torch.save(checkpoint, fpath)
         torch.save({k: (v.half() if v.is_floating_point() else v) for k, v in sd.items()}, "%s/%s.pt" % (self.dataset_output, self.dataset_id))
@@ -344,10 +586,11 @@ class FastPitchTrainer(object):
             self.optimizer.load_state_dict(checkpoint["optimizer"])
         except Exception:
             self.print_and_log("========== OPTIM NOT LOADED ==========", save_to_file=self.dataset_output)
-        epoch = checkpoint.get("epoch", 0) + 1 if isinstance(checkpoint, dict) else 1
-        total_iter = checkpoint.get("iteration", 0) if isinstance(checkpoint, dict) else 0
-        stage = checkpoint.get("training_stage", 1) if isinstance(checkpoint, dict) else 1
-        return int(stage), epoch, total_iter, list(checkpoint.get("avg_loss_per_epoch", [])) if isinstance(checkpoint, dict) else []
+        full = isinstance(checkpoint, dict) and "state_dict" in checkpoint
+        epoch = checkpoint.get("epoch", 0) + 1 if full else 1
+        total_iter = checkpoint.get("iteration", 0) if full else 0
+        stage = checkpoint.get("training_stage", 1) if full else 1
+        return int(stage), epoch, total_iter, list(checkpoint.get("avg_loss_per_epoch", [])) if full else []
 
     @staticmethod
     def last_checkpoint(output):
@@ -356,3 +599,37 @@ class FastPitchTrainer(object):
             return None
         saved = sorted([f for f in os.listdir(output) if f.startswith("FastPitch_checkpoint_")], key=sort_fp)
         return output + "/" + saved[-1] if saved else None
+
+    # ---- xva_train.py:1120-1168 ----
+    def extract_durations(self, batch_size=8):
+        """Run the aligner (training stage 1 graph: ConvAttention + monotonic alignment search, all on the GPU) over the whole dataset
+        and write each clip's hard durations to `{dataset}/durs_text/{name}.npy` (and `durs_arpabet/` when the text encoder provides an
+        ARPAbet mode), the files `TTSDataset.get_durs` (data_function.py:371-382) loads in stages 2-4.  The reference does this with
+        batch size 1 and a CPU MAS; the durations of an item do not depend on its batch."""
+        from ..data import FastPitchFileLoader
+        self.print_and_log("Extracting durations from alignments (text)...", save_to_file=self.dataset_output)
+        out_dirs = [self.dataset_input + "/durs_text"]
+        os.makedirs(out_dirs[0], exist_ok=True)
+        if self.rank != 0:
+            if self.world > 1:
+                torch.distributed.barrier()
+            return
+        ld = FastPitchFileLoader(self.dataset_input, batch_size, 1, self.device, shuffle=False)
+        flat = self.model.flat.data
+        n = len(ld.items)
+        with torch.no_grad():
+            for s in range(0, n, batch_size):
+                idx = list(range(s, min(n, s + batch_size)))
+                b = ld.collate([ld.item(i) for i in idx], 1)
+                _, durs, _, _ = self.eng.align_forward(flat, b.text, b.in_lens, b.mel_tgt, b.mel_lens, b.attn_prior, want_maps=False)
+                durs, order, lens = durs.cpu().numpy(), b.order.cpu().numpy(), b.in_lens.cpu().numpy()
+                for r, i in enumerate(order):
+                    name = ld.items[idx[i]][0]
+                    for d in out_dirs:
+                        np.save("%s/%s.npy" % (d, name), durs[r, :lens[r]].astype(np.float32))
+                self.training_log_live_line = "\r%d/%d " % (min(n, s + batch_size), n)
+                self.print_and_log(save_to_file=self.dataset_output)
+        self.training_log_live_line = ""
+        if self.world > 1:
+            torch.distributed.barrier()
+        torch.cuda.empty_cache()

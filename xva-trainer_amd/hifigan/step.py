@@ -25,14 +25,18 @@ lib.xva_adamw_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C
 
 
 class FlatAdamW:
-    """torch.optim.AdamW over the trainable prefix of a flat buffer (python/hifigan/xva_train.py:298-300)."""
+    """torch.optim.AdamW over the trainable prefix of a flat buffer (python/hifigan/xva_train.py:298-300).
+    `order` = [(name, offset, numel, shape)] in the REFERENCE optimizer's parameter order (generator.parameters(); for the
+    discriminators itertools.chain(msd.parameters(), mpd.parameters())): state_dict() / load_state_dict() speak torch's own
+    format over it, so `do_########` checkpoints are interchangeable with the reference's optim.load_state_dict (:583,303-304)."""
 
-    def __init__(self, flat, n_trainable, lr=2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01):
+    def __init__(self, flat, n_trainable, lr=2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01, order=None):
         self.flat, self.n = flat, int(n_trainable)
-        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, initial_lr=lr)]
         self.exp_avg = torch.zeros(self.n, device=flat.device)
         self.exp_avg_sq = torch.zeros(self.n, device=flat.device)
         self.step_count = 0
+        self.order = order
 
     def step(self, grads):
         g = self.param_groups[0]
@@ -40,6 +44,46 @@ class FlatAdamW:
         _lib.check(lib.xva_adamw_step(_lib.ptr(self.flat), _lib.ptr(grads), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.n,
                                       self.step_count, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], _lib.stream_ptr()),
                    "xva_adamw_step")
+
+    def state_dict(self):
+        g = self.param_groups[0]
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"], "amsgrad": False, "foreach": None,
+                 "maximize": False, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": True,
+                 "initial_lr": g["initial_lr"],
+                 "params": list(range(len(self.order)))}
+        state = {}
+        if self.step_count > 0:
+            for i, (name, off, n, shape) in enumerate(self.order):
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[off:off + n].view(shape).cpu().clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shape).cpu().clone()}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.order):
+            raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+        g = groups[0]
+        self.param_groups[0].update(lr=float(g["lr"]), betas=tuple(g["betas"]), eps=float(g["eps"]), weight_decay=float(g["weight_decay"]),
+                                    initial_lr=float(g.get("initial_lr", g["lr"])))
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step_count = 0
+        for idx, st in sd["state"].items():
+            name, off, n, shape = self.order[g["params"].index(idx) if idx in g["params"] else int(idx)]
+            if tuple(st["exp_avg"].shape) != tuple(shape):
+                raise ValueError("optimizer state %d (%s): shape %s != %s" % (idx, name, tuple(st["exp_avg"].shape), tuple(shape)))
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1).to(self.exp_avg))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(self.exp_avg_sq))
+            self.step_count = max(self.step_count, int(float(st["step"])))
+
+
+def optimizer_orders(table=None):
+    """[(name, offset, numel, shape)] of the trainable tensors in the reference optimizers' parameter order:
+    optim_g = AdamW(generator.parameters()), optim_d = AdamW(chain(msd.parameters(), mpd.parameters())) (python/hifigan/xva_train.py:298-300)."""
+    table = table or {E.G: E.tensor_table(E.G), E.D: E.tensor_table(E.D)}
+    tg = [(n_, o, c, sh) for n_, o, c, sh, k in table[E.G] if k == 0]
+    td = [(n_, o, c, sh) for n_, o, c, sh, k in table[E.D] if k == 0]
+    return tg, [t for t in td if t[0].startswith("msd.")] + [t for t in td if t[0].startswith("mpd.")]
 
 
 class BucketSync:
@@ -91,8 +135,9 @@ class HifiganStep:
         self.flat_d = torch.zeros(self.eng.total[E.D], device=dev)
         self.grads_g = torch.zeros_like(self.flat_g)
         self.grads_d = torch.zeros_like(self.flat_d)
-        self.optim_g = FlatAdamW(self.flat_g, self.eng.trainable[E.G], lr, betas)
-        self.optim_d = FlatAdamW(self.flat_d, self.eng.trainable[E.D], lr, betas)
+        order_g, order_d = optimizer_orders(self.eng.table)
+        self.optim_g = FlatAdamW(self.flat_g, self.eng.trainable[E.G], lr, betas, order=order_g)
+        self.optim_d = FlatAdamW(self.flat_d, self.eng.trainable[E.D], lr, betas, order=order_d)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
         self.sync_d = BucketSync(E.D, self.grads_d, group) if self.world > 1 else None

@@ -8,8 +8,12 @@ ExponentialLR(0.999) per epoch; checkpoints `hifi/g_{steps:08d}` = {'generator':
 'optim_g', 'optim_d', 'steps', 'epoch', 'avg_loss_per_epoch', 'ckpts_finetuned'} (keep last 2) and `{name}.hg.pt`; the
 "Stage 5 | Epoch ... | Mel loss ... | its/s" log line; early stop when the mean of the last 25 epoch mel-error deltas is
 <= 1e-4 after >= 25 epochs; ws string "Finished training HiFi-GAN\\n".
-Changed on purpose: mels are computed on the GPU (HIP mel) instead of on the CPU in the dataset; one iteration is a fixed
-sequence of C calls (hifigan/step.py)."""
+Resume restores both AdamW states (torch's own state_dict format over the reference parameter order) and applies
+ExponentialLR(last_epoch=epoch)'s initial step; like the reference the trainer never trains from scratch (raises without a
+g_ / do_ pair; "[male]" / "[female]" resolve to the pretrained directories).
+Changed on purpose: crops, peak normalisation and both mels are computed on the GPU (xva-trainer_amd/data.py, HIP mel) instead of on
+the CPU in the dataset; one iteration is a fixed sequence of C calls (hifigan/step.py); multi-GPU is one process per GPU with
+bucketed, overlapped RCCL gradient exchange (the reference defines DataParallel here but never wraps, xva_train.py:40)."""
 import glob
 import json
 import os
@@ -75,13 +79,17 @@ class HiFiTrainer(object):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dataset_output = None
+        self.allow_random_init = False              # tests / benchmarks only: the reference refuses to train from scratch (xva_train.py:276-277)
+        root = "./resources/app" if PROD else "."
+        self.pretrained_ckpt_male = root + "/python/hifigan/pretrained_models/male"
+        self.pretrained_ckpt_female = root + "/python/hifigan/pretrained_models/female"
 
     def print_and_log(self, line=None, end="\n", flush=False, save_to_file=None):
         if line is None:
             line = self.training_log_live_line
         else:
             self.training_log.append(line)
-        if self.rank == 0 and save_to_file is not None:
+        if self.rank == 0 and save_to_file:
             os.makedirs(save_to_file, exist_ok=True)
             with open(save_to_file + "/training.log", "a") as f:
                 f.write(line.rstrip() + "\n")
@@ -112,36 +120,87 @@ class HiFiTrainer(object):
             self.batch_size = int(data["batch_size"])
             self.epochs_per_checkpoint = int(data.get("epochs_per_checkpoint", 1))
             self.max_iterations = data.get("max_iterations")
+            self.synthetic_data = bool(data.get("synthetic_data", False))      # explicit opt-in (bench / tests); never a silent fallback
         while self.running and not self.END_OF_TRAINING:
             await self.iteration()
 
+    def _init_distributed(self):
+        import torch.distributed as dist
+        if self.world > 1:
+            if not dist.is_initialized():
+                for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                    if k not in os.environ:
+                        raise RuntimeError("WORLD_SIZE=%d but %s is not set: launch under `python -m torch.distributed.run`" % (self.world, k))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+            if dist.get_world_size() != self.world:
+                raise RuntimeError("process group size %d != WORLD_SIZE %d" % (dist.get_world_size(), self.world))
+            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        if self.gpus is not None and len(self.gpus) > 1:
+            raise NotImplementedError("gpus=%s in one process: the MI355X path is one process per GPU — start the trainer under "
+                                      "`python -m torch.distributed.run --nproc-per-node %d`" % (self.gpus, len(self.gpus)))
+        return torch.device("cuda", int(self.gpus[0]) if self.gpus else 0)
+
     async def init(self):
-        dev = torch.device("cuda", self.gpus[0] if self.world == 1 else int(os.environ.get("LOCAL_RANK", "0")))
+        dev = self._init_distributed()
         torch.cuda.set_device(dev)
         torch.manual_seed(self.h["seed"] + self.rank)
         self.device = dev
         self.h["batch_size"] = int(self.batch_size * 1.4)                                   # xva_train.py:228
         self.core = HifiganStep(dev, self.compute, lr=self.h["learning_rate"], betas=(self.h["adam_b1"], self.h["adam_b2"]))
-        self.training_steps, self.training_epoch, self.ckpts_finetuned = 0, 0, 0
+        checkpoint_path = self.dataset_output + "/hifi"
+        self.print_and_log("Output checkpoints directory: %s" % checkpoint_path, save_to_file=self.dataset_output)
+        self.print_and_log("Stage 5: HiFi-GAN fine-tuning", save_to_file=self.dataset_output)
+        self.print_and_log("Batch size: %d (Base: %d, Stage mult: 1.5)" % (self.h["batch_size"], self.batch_size), save_to_file=self.dataset_output)
+        if self.websocket is not None:
+            await self.websocket.send("Set stage to: 5 ")
+        self.training_steps, self.training_epoch, self.ckpts_finetuned = 0, -1, 0
         self.avg_loss_per_epoch = []
-        cp_g = scan_checkpoint(self.dataset_output + "/hifi", "g_") or self.hifigan_checkpoint
-        cp_do = scan_checkpoint(self.dataset_output + "/hifi", "do_")
-        if cp_g and os.path.exists(str(cp_g)):
-            sd = torch.load(cp_g, map_location="cpu", weights_only=False)
-            self.core.load_state_dicts(generator=sd["generator"])
-        if cp_do:
-            sd = torch.load(cp_do, map_location="cpu", weights_only=False)
-            self.core.load_state_dicts(mpd=sd["mpd"], msd=sd["msd"])
-            self.training_steps, self.training_epoch = sd["steps"] + 1, sd["epoch"]
-            self.ckpts_finetuned = sd.get("ckpts_finetuned", 0)
-        loader = self.loader_factory(self) if self.loader_factory else None
-        if loader is None:
-            from ..data import SyntheticHifiLoader
-            loader = SyntheticHifiLoader(self.h["batch_size"], segment=self.h["segment_size"], seed=self.h["seed"] + 100 * self.rank)
-        self.train_loader = loader
-        self.dataloader_iterator = iter(loader)
+        self.target_patience, self.target_patience_count = 3, 0
+        self.graphs_json["stages"]["5"]["target_delta"] = self.target_delta
+        cp_g, cp_do = scan_checkpoint(checkpoint_path, "g_"), scan_checkpoint(checkpoint_path, "do_")
+        if cp_g is None:                                                                    # xva_train.py:255-264
+            self.print_and_log("No existing HiFi-GAN checkpoints for this voice.", save_to_file=self.dataset_output)
+            src = {"[male]": self.pretrained_ckpt_male, "[female]": self.pretrained_ckpt_female}.get(self.hifigan_checkpoint, self.hifigan_checkpoint)
+            if src and os.path.isdir(str(src)):
+                cp_g, cp_do = scan_checkpoint(src, "g_"), scan_checkpoint(src, "do_")
+        if cp_g is None or cp_do is None:
+            if not self.allow_random_init:
+                raise RuntimeError("HiFi-GAN: no g_ / do_ checkpoint pair to fine-tune from (hifigan_checkpoint=%r) — the trainer never trains "
+                                   "from scratch (python/hifigan/xva_train.py:276-277)" % (self.hifigan_checkpoint,))
+        else:
+            self.print_and_log("Loading checkpoint from: %s" % cp_g, save_to_file=self.dataset_output)
+            sd_g = torch.load(cp_g, map_location="cpu", weights_only=False)
+            sd_do = torch.load(cp_do, map_location="cpu", weights_only=False)
+            self.core.load_state_dicts(generator=sd_g["generator"], mpd=sd_do["mpd"], msd=sd_do["msd"])
+            self.training_steps, self.training_epoch = sd_do["steps"] + 1, sd_do["epoch"]
+            self.ckpts_finetuned = sd_do.get("ckpts_finetuned", 0)
+            self.core.optim_g.load_state_dict(sd_do["optim_g"])                             # xva_train.py:302-304
+            self.core.optim_d.load_state_dict(sd_do["optim_d"])
+            self.ckpt_path = cp_g
+        if self.training_epoch >= 0:       # ExponentialLR(optimizer, gamma, last_epoch=epoch): its initial step() decays the restored lr once (:306-307)
+            for opt in (self.core.optim_g, self.core.optim_d):
+                opt.param_groups[0]["lr"] *= self.h["lr_decay"]
+        self.train_loader = self._make_loader()
+        self.dataloader_iterator = iter(self.train_loader)
         self.start_new_epoch()
         self.is_init = True
+
+    def _make_loader(self):
+        if self.loader_factory:
+            loader = self.loader_factory(self)
+            if loader is not None:
+                return loader
+        if self.synthetic_data:
+            from ..data import SyntheticHifiLoader
+            return SyntheticHifiLoader(self.h["batch_size"], segment=self.h["segment_size"], seed=self.h["seed"] + 100 * self.rank)
+        if not os.path.exists(os.path.join(self.dataset_input, "metadata.csv")):
+            raise FileNotFoundError("%s/metadata.csv not found: the trainer reads the reference's dataset layout (metadata.csv + wavs/); "
+                                    "synthetic data needs the explicit `synthetic_data` opt-in" % self.dataset_input)
+        from ..data import HifiFileLoader
+        ld = HifiFileLoader(self.dataset_input, self.h["batch_size"], self.device, segment=self.h["segment_size"], seed=self.h["seed"],
+                            rank=self.rank, world=self.world)
+        self.print_and_log("Training items: %d" % len(ld.files), save_to_file=self.dataset_output)
+        return ld
 
     def start_new_epoch(self):
         self.epoch_start_time = time.time()
@@ -178,34 +237,53 @@ class HiFiTrainer(object):
             self.running = False
 
     def output_checkpoint(self):
+        """xva_train.py:570-601.  Called BEFORE the epoch loss is normalised, like the reference: the log line divides the running sum."""
         if self.rank != 0 or self.training_epoch % self.epochs_per_checkpoint != 0:
             return
         sds = self.core.state_dicts()
         cpu = lambda sd: {k: v.cpu() for k, v in sd.items()}
         hifi = self.dataset_output + "/hifi"
         torch.save({"generator": cpu(sds["generator"])}, "%s/g_%08d" % (hifi, self.training_steps))
+        self.print_and_log("Stage 5 |Epoch: %d | It: %d | g_%08d | Mel loss: %s" % (self.training_epoch, self.training_steps, self.training_steps,
+                                                                                   self.avg_loss_per_epoch[-1] / max(1, self.epoch_iter)),
+                           save_to_file=self.dataset_output)
         self.ckpts_finetuned += 1
-        torch.save({"mpd": cpu(sds["mpd"]), "msd": cpu(sds["msd"]), "optim_g": self.core.optim_g.param_groups, "optim_d": self.core.optim_d.param_groups,
+        torch.save({"mpd": cpu(sds["mpd"]), "msd": cpu(sds["msd"]), "optim_g": self.core.optim_g.state_dict(), "optim_d": self.core.optim_d.state_dict(),
                     "steps": self.training_steps, "epoch": self.training_epoch, "avg_loss_per_epoch": [], "ckpts_finetuned": self.ckpts_finetuned},
                    "%s/do_%08d" % (hifi, self.training_steps))
         for prefix in ("do_", "g_"):
             for ck in sorted([f for f in os.listdir(hifi) if f.startswith(prefix)], key=sort_ckpt)[:-2]:
                 os.remove(hifi + "/" + ck)
         torch.save({"generator": cpu(sds["generator"])}, "%s/%s.hg.pt" % (self.dataset_output, self.dataset_output.split("/")[-1]))
-        self.print_and_log("Stage 5 |Epoch: %d | It: %d | g_%08d | Mel loss: %s" % (self.training_epoch, self.training_steps, self.training_steps,
-                                                                                   self.avg_loss_per_epoch[-1] / max(1, self.epoch_iter)),
-                           save_to_file=self.dataset_output)
 
     def finish_epoch(self):
-        for opt in (self.core.optim_g, self.core.optim_d):                                # ExponentialLR(gamma=lr_decay) per epoch
+        """xva_train.py:607-650."""
+        for opt in (self.core.optim_g, self.core.optim_d):                                # scheduler_g / scheduler_d .step(): ExponentialLR(gamma=lr_decay)
             opt.param_groups[0]["lr"] *= self.h["lr_decay"]
         self.training_epoch += 1
-        self.avg_loss_per_epoch[-1] /= max(1, self.epoch_iter)
         self.output_checkpoint()
+        self.avg_loss_per_epoch[-1] /= max(1, self.epoch_iter)
+        if self.world > 1:                                                                # identical stopping decisions on every rank
+            import torch.distributed as dist
+            t = torch.tensor([self.avg_loss_per_epoch[-1]], device=self.device, dtype=torch.float64)
+            dist.all_reduce(t)
+            self.avg_loss_per_epoch[-1] = float(t.item()) / self.world
         losses = self.avg_loss_per_epoch
-        deltas = [(a - b) / a for a, b in zip(losses[:-1], losses[1:]) if a]
-        if len(deltas) >= self.EPOCH_AVG_SPAN and len(losses) >= 25:
-            if all(float(np.mean(deltas[max(0, i - self.EPOCH_AVG_SPAN):i])) <= self.target_delta for i in range(len(deltas) - 2, len(deltas) + 1)):
-                self.END_OF_TRAINING = True
-                self.running = False
-                raise RuntimeError("HiFi-GAN training finished")
+        deltas = [(losses[i - 1] - losses[i]) / losses[i - 1] for i in range(1, len(losses)) if losses[i - 1]]
+        self.graphs_json["stages"]["5"]["loss"].append([self.training_steps, losses[-1]])
+        if len(deltas) >= 2:
+            avg = float(np.mean(deltas[-self.EPOCH_AVG_SPAN:]))
+            self.graphs_json["stages"]["5"]["loss_delta"].append([self.training_steps, avg])
+            if self.rank == 0:
+                with open(self.dataset_output + "/graphs.json", "w") as f:
+                    json.dump(self.graphs_json, f)
+            if avg <= self.target_delta and len(deltas) >= 25:
+                self.target_patience_count += 1
+                if self.target_patience_count >= self.target_patience:
+                    self.training_log_live_line = ""
+                    self.print_and_log("HiFi-GAN training finished", save_to_file=self.dataset_output)
+                    self.END_OF_TRAINING = True
+                    self.running = False
+                    raise RuntimeError("HiFi-GAN training finished")
+            else:
+                self.target_patience_count = 0

@@ -114,6 +114,33 @@ class _MelEngine(torch.nn.Module):
         return out
 
 
+def _engine_linear(self, y):
+    _lib.require_cuda(y)
+    if self.forward_basis.device != y.device:
+        self.to(y.device)
+    y = y.float().contiguous()
+    B, N = y.shape
+    if y.stride(0) % 4 != 0 or y.data_ptr() % 16 != 0:
+        ld = (N + 3) // 4 * 4
+        buf = torch.zeros(B, ld, device=y.device, dtype=torch.float32)
+        buf[:, :N] = y
+        y = buf
+    T = self.num_frames(N)
+    need = int(_lib.lib.xva_mel_workspace_bytes(C.byref(self.cfg), B, N))
+    if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != y.device:
+        self._ws = torch.empty((need + 3) // 4, device=y.device, dtype=torch.float32)
+    out = torch.empty(B, self.cfg.n_fft // 2 + 1, T, device=y.device, dtype=torch.float32)
+    _lib.check(_lib.lib.xva_linear_spectrogram(C.byref(self.cfg), _lib.ptr(y), B, N, y.stride(0), _lib.ptr(self.forward_basis), _lib.ptr(out),
+                                               _lib.ptr(self._ws), self._ws.numel() * 4, _lib.stream_ptr()), "xva_linear_spectrogram")
+    return out
+
+
+_lib.lib.xva_linear_spectrogram.restype = C.c_int32
+_lib.lib.xva_linear_spectrogram.argtypes = [C.POINTER(_lib.MelConfig), C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int64, C.c_void_p]
+_MelEngine.linear = _engine_linear
+
+
 def _hann_periodic(n):
     return torch.from_numpy(0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n))
 
@@ -173,6 +200,19 @@ class TorchSTFTMel(torch.nn.Module):
             x = x.squeeze(1)
         return self.engine(x)
 
+    def linear(self, x):
+        """TorchSTFT(use_mel=False): (B, 513, 1 + N // hop) magnitudes sqrt(clamp(re^2 + im^2, 1e-8)) (audio.py:155-171)."""
+        if x.ndim == 3:
+            x = x.squeeze(1)
+        return self.engine.linear(x)
+
+    def l1_loss_backward(self, y_hat, mel_tgt, d_wav, scale=45.0, accumulate=True):
+        """VitsGeneratorLoss's mel term (python/xvapitch/losses.py:187-193): loss = scale * l1_loss(mel_tgt, self(y_hat)) and
+        d_wav (+)= d loss / d y_hat.  Returns (loss 1-elem tensor, mel(y_hat))."""
+        if y_hat.ndim == 3:
+            y_hat = y_hat.squeeze(1)
+        return _l1_loss_backward(self.engine.to(y_hat.device), y_hat, mel_tgt, d_wav, scale, accumulate)
+
 
 # ---- differentiable mel for the HiFi-GAN generator loss (python/hifigan/xva_train.py:480,504) ----
 _lib.lib.xva_mel_backward_workspace_bytes.restype = C.c_int64
@@ -195,6 +235,11 @@ def mel_l1_loss_backward(y_hat, y_mel, d_wav, scale=45.0, accumulate=True, n_fft
         mel_basis = librosa_mel_fn(sampling_rate, n_fft, num_mels, fmin, fmax)
         eng = _MelEngine(n_fft, hop_size, num_mels, int((n_fft - hop_size) / 2), 1e-9, 0.0, torch.hann_window(win_size), mel_basis).to(y_hat.device)
         _hifi_engines[key] = eng
+    return _l1_loss_backward(eng, y_hat, y_mel, d_wav, scale, accumulate)
+
+
+def _l1_loss_backward(eng, y_hat, y_mel, d_wav, scale, accumulate):
+    num_mels = eng.cfg.n_mel
     B, N = y_hat.shape
     y_hat = y_hat.float().contiguous()
     y_mel = y_mel.float().contiguous()

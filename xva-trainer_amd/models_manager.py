@@ -1,7 +1,10 @@
 """ModelsManager — the registry entry points server.py uses for the trainers (python/models_manager.py:115-128,152-163).
 
-Only the trainer keys of the accelerated path are served ("fastpitch1_1", "hifigan"); the 16 dataset tools, the inference
-wrappers and the xVAPitch trainer stay with the reference (`init_model` / `load_model` raise NotImplementedError here)."""
+Served here: the trainer keys of the accelerated path ("fastpitch1_1", "hifigan") and their inference wrappers
+("infer_fastpitch1_1", "infer_hifigan", python/models_manager.py:130-150); the 16 dataset tools and the xVAPitch trainer stay with
+the reference (`init_model` raises NotImplementedError here)."""
+import os
+
 import torch
 
 
@@ -34,13 +37,37 @@ class ModelsManager(object):
             pass
 
     def load_model(self, model_key, ckpt_path, **kwargs):
-        raise NotImplementedError("inference wrappers (infer_fastpitch1_1 / infer_hifigan) are a 'next' row (SURVEY.md §8f N4)")
+        """python/models_manager.py:130-150: lazily build the inference wrapper, return "ENOENT" for a missing file, (re)load the
+        checkpoint when the path changed."""
+        if model_key not in self.models_bank:
+            dev = self.device if self.device.type == "cuda" else torch.device("cuda", 0)
+            if model_key == "infer_fastpitch1_1":
+                from .infer import FastPitch1_1
+                self.models_bank[model_key] = FastPitch1_1(self.logger, self.PROD, dev, self)
+            elif model_key == "infer_hifigan":
+                from .infer import HiFi_GAN
+                self.models_bank[model_key] = HiFi_GAN(self.logger, self.PROD, dev, self)
+            else:
+                raise NotImplementedError("inference model '%s' is not part of the accelerated path" % model_key)
+        if not os.path.exists(ckpt_path):
+            return "ENOENT"
+        if self.models_bank[model_key].ckpt_path != ckpt_path:
+            ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+            self.models_bank[model_key].load_state_dict(ckpt_path, ckpt, **kwargs)
 
     def set_device(self, device):
+        """python/models_manager.py:152-161 ("gpu" -> "cuda"); the MI355X-native path has no CPU implementation."""
+        if device == "gpu":
+            device = "cuda"
         if device == "cpu":
-            raise RuntimeError("the MI355X-native training path has no CPU implementation")
+            raise RuntimeError("the MI355X-native path has no CPU implementation")
+        if self.device_label == device:
+            return
         self.device_label = device
         self.device = torch.device(device)
+        for key, m in list(self.models_bank.items()):
+            if hasattr(m, "set_device"):
+                m.set_device(self.device)
 
     def models(self, key):
         return self.models_bank[key.lower()]
