@@ -43,38 +43,160 @@ def parse():
     return ap.parse_args()
 
 
+def _thread_candidates():
+    n = os.cpu_count() or 1
+    return sorted({t for t in (8, 32, 128) if t <= n} or {n})
+
+
+def _best_of_threads(step, n_timed=3):
+    """Time `step()` (one full CPU training step) honestly: for each thread count in {8, 32, 128} (those the host has) one warm-up +
+    one timed step picks the best count (more threads is NOT faster for these small GEMMs), then n_timed steps are timed at it."""
+    probe = {}
+    for t in _thread_candidates():
+        torch.set_num_threads(t)
+        step()
+        t0 = time.perf_counter()
+        step()
+        probe[t] = time.perf_counter() - t0
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
+    t0 = time.perf_counter()
+    for _ in range(n_timed):
+        step()
+    return (time.perf_counter() - t0) / n_timed, best, {str(k): round(v, 3) for k, v in probe.items()}
+
+
+def c1_batch(seed=1234):
+    """BASELINE.json configs[0]: batch 4, 22050 Hz clips of U[2, 10] s -> T_mel = 1 + N // 256 frames, T_text = round(15 * seconds)
+    (SURVEY.md §8d), collated like TTSCollate (sorted by text length, zero padded)."""
+    import numpy as np
+    from oracle import fastpitch as ofp
+    rng = np.random.RandomState(seed)
+    secs = sorted(rng.uniform(2.0, 10.0, size=4), reverse=True)
+    items = [ofp.synth_batch(1, int(round(15 * s)), 1 + int(s * 22050) // 256, seed + i, ragged=False) for i, s in enumerate(secs)]
+    Tt, Tm = items[0]["text"].size(1), max(it["mel_tgt"].size(2) for it in items)
+    pad = lambda t, n: torch.nn.functional.pad(t, (0, n - t.size(-1)))
+    batch = {"text": torch.cat([pad(it["text"], Tt) for it in items]), "in_lens": torch.cat([it["in_lens"] for it in items]),
+             "mel_tgt": torch.cat([pad(it["mel_tgt"], Tm) for it in items]), "mel_lens": torch.cat([it["mel_lens"] for it in items]),
+             "pitch": torch.cat([pad(it["pitch"], Tm) for it in items]), "energy": torch.cat([pad(it["energy"], Tm) for it in items]),
+             "durs": torch.cat([pad(it["durs"], Tt) for it in items])}
+    return batch, [round(float(s), 2) for s in secs]
+
+
 def cpu_baseline(stage):
-    """Reference-equivalent CPU step (oracle/fastpitch.py: fwd + loss + autograd bwd + clip + LAMB, fp32, torch CPU ops),
-    on a bounded sample: B=2 clips of 150 tokens x 860 frames, 1 warm-up + 2 timed steps (~10-20 s)."""
+    """Reference-equivalent CPU step (oracle/fastpitch.py: fwd + loss + autograd bwd + clip + LAMB, fp32, torch CPU ops arranged as the
+    reference's graph) at BASELINE.json configs[0] (C1): batch 4, clips U[2, 10] s."""
     from oracle import fastpitch as ofp
     sd = ofp.init_state_dict(1234)
-    batch = ofp.synth_batch(2, 150, 860, 1235, ragged=False)
+    batch, secs = c1_batch()
     frames = int(batch["mel_lens"].sum())
-    state = {}
-    ofp.train_step(sd, batch, stage, state, 50000)
-    t0 = time.perf_counter()
-    n = 2
-    for i in range(n):
-        ofp.train_step(sd, batch, stage, state, 50001 + i)
-    dt = time.perf_counter() - t0
-    return {"value": frames * n / dt, "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "B=2 x (150 tok, 860 frames) stage-%d full train step (fwd+loss+bwd+clip+LAMB), fp32 torch-CPU, %d timed steps"
-                      % (stage, n), "host_cpu_count": os.cpu_count()}
+    state, it = {}, [50000]
+
+    def step():
+        it[0] += 1
+        ofp.train_step(sd, batch, stage, state, it[0])
+    dt, threads, probe = _best_of_threads(step)
+    return {"value": frames / dt, "unit": "mel-frames/s", "cores": threads, "kind": "port", "s_per_step": dt, "host_cpu_count": os.cpu_count(),
+            "thread_probe_s_per_step": probe,
+            "sample": "C1: B=4 clips of %s s (%d true mel frames, T_text %s) stage-%d full train step (fwd+loss+bwd+clip+LAMB), fp32 torch-CPU; "
+                      "per thread count 1 warm-up + 1 timed step, then 3 timed steps at the best count (%d threads)"
+                      % (secs, frames, batch["in_lens"].tolist(), stage, threads)}
 
 
 def hifigan_cpu_baseline():
-    """Reference-equivalent CPU iteration (oracle/hifigan.py: G fwd, D step, G step, 2 x AdamW; fp32 torch-CPU) on B=2 x 8192."""
+    """Reference-equivalent CPU iteration (oracle/hifigan.py: G fwd, D step, G step, 2 x AdamW; fp32 torch-CPU) on B=2 x 8192 samples (a
+    bounded sample of configs[2]'s workload: the per-item cost of the D+G iteration does not depend on the batch)."""
     from oracle import hifigan as ohg
     g_sd, mpd_sd, msd_sd = ohg.init_generator_sd(1), ohg.init_mpd_sd(2), ohg.init_msd_sd(3)
     x, y, ym = ohg.synth_batch(2, 4)
     og, od = {}, {}
-    t0 = time.perf_counter()
-    n = 2
-    for _ in range(n):
-        ohg.train_step(g_sd, mpd_sd, msd_sd, x, y, ym, og, od)
-    dt = time.perf_counter() - t0
-    return {"value": 2 * 8192 * n / dt, "unit": "audio-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "B=2 x 8192-sample segments, full D+G iteration (G fwd, MPD+MSD x2, losses, bwd, 2 x AdamW), fp32 torch-CPU, %d timed steps" % n}
+    dt, threads, probe = _best_of_threads(lambda: ohg.train_step(g_sd, mpd_sd, msd_sd, x, y, ym, og, od))
+    return {"value": 2 * 8192 / dt, "unit": "audio-samples/s", "cores": threads, "kind": "port", "s_per_step": dt, "host_cpu_count": os.cpu_count(),
+            "thread_probe_s_per_step": probe,
+            "sample": "B=2 x 8192-sample segments, full D+G iteration (G fwd, MPD+MSD x2, losses, bwd, 2 x AdamW), fp32 torch-CPU; per thread "
+                      "count 1 warm-up + 1 timed step, then 3 timed steps at the best count (%d threads)" % threads}
+
+
+def csrc_fingerprint():
+    """sha256 over the kernel sources: a PMC summary is only quoted while it still describes the kernels that ran."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "xva-trainer_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def timed_us(fn, iters=10, warm=2):
+    """Average duration of fn() in microseconds by a HIP event pair on torch's current stream (the stream every libxvahip launch of
+    this process goes to) around `iters` back-to-back calls."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1000.0 * e0.elapsed_time(e1) / iters
+
+
+def hbm_kernel_rooflines(dev, opt, grads, active, compute):
+    """Roofline lines of the HBM-bound kernels SURVEY.md §8(d) lists next to the GEMMs, each timed live at the C2 shapes:
+    algorithmic bytes (one read + one write of each operand) / measured duration against 8 TB/s."""
+    import ctypes as C
+    from xva_trainer_amd import _lib
+    from xva_trainer_amd.mel import TacotronSTFT
+    lib = _lib.lib
+    out = {}
+    def line(name, us, nbytes, note, flops=None, mfma_peak=None):
+        gbs = nbytes / us / 1e3
+        d = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None, "avg_launch_us": us,
+             "algorithmic_mbytes_per_launch": nbytes / 1e6, "note": note}
+        if flops:
+            d["tflops"] = flops / us / 1e6
+            d["mfma_frac"] = d["tflops"] / mfma_peak
+        out[name] = d
+    # ---- LAMB (3 launches over the flat buffers): pass 1 reads p, g, m, v (16 B) and writes m, v (8 B); pass 2 reads p, m, v (12 B), writes p (4 B)
+    n_active = sum(t[2] for t in opt.table if t[0] in active)
+    us = timed_us(lambda: opt.step(grads, active, max_grad_norm=1000.0))
+    line("lamb_step", us, 44.0 * n_active, "clip + LAMB over %d active parameters: grad-norm pass (4 B) + moments pass (16 B read, 8 B written) + "
+         "update pass (12 B read, 4 B written) per parameter" % n_active)
+    # ---- LayerNorm forward / backward at the decoder shape: 32 x (860 + 2) rows of 384 channels in the activation dtype
+    rows, Cc = 32 * 862, 384
+    es = 2 if compute == "bf16" else 4
+    adt = torch.bfloat16 if compute == "bf16" else torch.float32
+    X = torch.randn(rows, Cc, device=dev).to(adt)
+    Y, dY, dX = torch.empty_like(X), torch.randn(rows, Cc, device=dev).to(adt), torch.empty_like(X)
+    gam, bet = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    dg, db = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    lib.xva_fp_layernorm_fwd.restype = C.c_int32
+    lib.xva_fp_layernorm_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                         C.c_float, C.c_uint64, C.c_uint32, C.c_void_p]
+    lib.xva_fp_layernorm_bwd.restype = C.c_int32
+    lib.xva_fp_layernorm_bwd.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                         C.c_int32, C.c_float, C.c_uint64, C.c_uint32, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    dtc = 1 if compute == "bf16" else 0
+    P = _lib.ptr
+    fwd = lambda: _lib.check(lib.xva_fp_layernorm_fwd(P(X), P(gam), P(bet), P(Y), dtc, P(mean), P(rstd), rows, Cc, 0, None, 862, 0.0, 0, 0,
+                                                      _lib.stream_ptr()), "layernorm_fwd")
+    bwd = lambda: _lib.check(lib.xva_fp_layernorm_bwd(P(dY), P(X), P(mean), P(rstd), P(gam), P(dX), None, dtc, P(dg), P(db), rows, Cc, 0, None, 862, 0,
+                                                      0.0, 0, 0, 0.0, 0, 0, None, None, _lib.stream_ptr()), "layernorm_bwd")
+    line("layernorm_fwd", timed_us(fwd), rows * Cc * 2.0 * es + rows * 8.0, "decoder shape %d rows x %d, %s: read X, write Y (+ mean, rstd)" % (rows, Cc, compute))
+    line("layernorm_bwd", timed_us(bwd), rows * Cc * 3.0 * es + rows * 8.0, "same shape: read dY, X (+ mean, rstd), write dX; dgamma / dbeta by atomics")
+    del X, Y, dY, dX
+    # ---- mel-STFT (M1) on the C2 clips: the windowed DFT runs as an exact-fp32 MFMA GEMM, so it is priced against both roofs
+    stft = TacotronSTFT().to(dev)
+    wav = torch.rand(32, 219904, device=dev) * 1.6 - 0.8
+    us = timed_us(lambda: stft.mel_spectrogram(wav), iters=5, warm=1)
+    frames = 32 * 860
+    line("mel_stft_m1", us, frames * (256 * 4.0 + 80 * 4.0), "32 clips x 219 904 samples -> 27 520 frames (reflect pad, DFT GEMM, magnitude, mel GEMM + log): "
+         "algorithmic 256 new samples read + 80 log-mels written per frame; the dense DFT makes it MFMA work (2.1 MFLOP/frame, exact-fp32 MFMA)",
+         flops=frames * (2.0 * 1026 * 1024 + 2.0 * 80 * 513), mfma_peak=157.3)
+    return out
 
 
 TILE_NAMES = {"128128": "128x128", "256256": "256x256", "64128": "128x64", "64064": "64x64", "32128": "128x32", "128384": "384x128"}
@@ -90,6 +212,9 @@ def pmc_traffic(family, pmc_csv):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_csv)
     if not os.path.exists(path):
         return None, None
+    meta = path[:-4] + ".meta.json"                       # {"csrc": fingerprint of the kernel sources the PMC pass ran, "commit": ...}
+    if not os.path.exists(meta) or json.load(open(meta)).get("csrc") != csrc_fingerprint():
+        return None, "profiles/%s is stale (kernel sources changed since that PMC pass): not quoted" % pmc_csv
     m = re.match(r"xva_gemm_glds_kernel<(\d+)x(\d+)>", family)
     if m:
         pat = re.compile(r"xva_gemm_glds_kernel<\d, %s, %s," % (m.group(1), m.group(2)))
@@ -103,7 +228,7 @@ def pmc_traffic(family, pmc_csv):
             d = int(r["Dispatches"])
             n += d
             by += d * (float(r["FETCH_SIZE_KB_mean_raw"]) * 2.0 + float(r["WRITE_SIZE_KB_mean_raw"])) * 1000.0
-    return (by / n if n else None), "profiles/" + pmc_csv
+    return (by / n if n else None), "profiles/%s @ %s" % (pmc_csv, json.load(open(meta)).get("commit", "?"))
 
 
 def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
@@ -142,7 +267,8 @@ def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
         ach, unit = f[3] / f[1], "GB/s"                       # MB / ms = GB/s
     traffic, traffic_src = pmc_traffic(name, pmc_csv) if pmc_csv else (None, None)
     res = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
-           "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE; offline passes over this workload: %s)" % traffic_src if traffic else None,
+           "traffic_unit": ("HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE; offline passes over this workload: %s)" % traffic_src) if traffic
+                           else traffic_src,
            "kernel": name + (" (direct-to-LDS MFMA implicit-convolution GEMM, all layouts)" if "glds" in name else
                              (" (resident-input MFMA convolution, forward + backward-data)" if "conv_res" in name else "")),
            "launches_per_step": f[0] / nprof, "avg_launch_us": 1e3 * f[1] / f[0], "kernel_ms_per_step": f[1] / nprof,
@@ -158,16 +284,10 @@ def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
     return res
 
 
-def hifigan_leg(a, dev, rank, world):
-    """audio-samples/s of the full HiFi-GAN v1 D+G iteration (BASELINE.json configs[2]: batch 64, 8192-sample segments)."""
-    import numpy as np
-    from xva_trainer_amd import synthetic
-    from xva_trainer_amd.hifigan.step import HifiganStep
-    from xva_trainer_amd.mel import mel_spectrogram
-    st = HifiganStep(dev, a.compute)
-    torch.manual_seed(1234)
-    g = torch.Generator(device="cpu").manual_seed(1234)
-    # random-init weights of the v1 architecture (no checkpoints offline): weight_v ~ N(0, 0.02), weight_g = ||v||, spectral-norm u/v unit vectors
+def init_hifigan_weights(st, seed=1234):
+    """random-init weights of the v1 architecture (no checkpoints offline): weight_v ~ N(0, 0.5 / sqrt(fan_in)), weight_g = ||v||,
+    spectral-norm u / v unit vectors, zero biases."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
     for which, flat in ((0, st.flat_g), (1, st.flat_d)):
         for name, off, n, shape, kind in st.eng.table[which]:
             if name.endswith("weight_g"):
@@ -188,12 +308,26 @@ def hifigan_leg(a, dev, rank, world):
                 voff, vn, vshape = next((o, nn, sh) for nm, o, nn, sh, kd in st.eng.table[which] if nm == vname)
                 v = flat[voff:voff + vn].view(vshape)
                 flat[off:off + n].copy_(v.reshape(vshape[0], -1).norm(dim=1))
-    B, seg = a.hg_batch, 8192
+
+
+def hifigan_inputs(B, rank, dev, seg=8192):
+    """B synthetic 22050 Hz crops, peak-normalised x 0.95 (MelDataset.__getitem__), with the input mel (fmax 8000) and the loss mel (fmax None)."""
+    import numpy as np
+    from xva_trainer_amd import synthetic
+    from xva_trainer_amd.mel import mel_spectrogram
     wav = np.stack([synthetic.synth_wave(seg, 5000 + rank * 1000 + i) for i in range(B)])
     wav = wav / np.abs(wav).max(axis=1, keepdims=True) * 0.95
     y = torch.from_numpy(wav.astype(np.float32)).to(dev)
-    x = mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0, 8000)
-    y_mel = mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0, None)
+    return mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0, 8000), y, mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0, None)
+
+
+def hifigan_leg(a, dev, rank, world):
+    """audio-samples/s of the full HiFi-GAN v1 D+G iteration (BASELINE.json configs[2]: batch 64, 8192-sample segments)."""
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    st = HifiganStep(dev, a.compute)
+    init_hifigan_weights(st)
+    B, seg = a.hg_batch, 8192
+    x, y, y_mel = hifigan_inputs(B, rank, dev, seg)
     steps = a.hg_steps or min(a.steps, 10)
     for _ in range(2):
         out = st.train_step(x, y, y_mel)
@@ -218,7 +352,7 @@ def hifigan_leg(a, dev, rank, world):
     if rank == 0 and not a.no_roofline:
         # the conv stack is priced against the HBM roofline (north_star): algorithmic bytes of every conv-as-GEMM launch / its time
         res["roofline"] = gemm_roofline(lambda: st.train_step(x, y, y_mel), 1, "hbm", 8000.0, "one extra profiled D+G iteration",
-                                        pmc_csv="r01_hifigan_pmc_hbm_bytes.csv")
+                                        pmc_csv="r02_hifigan_pmc_hbm_bytes.csv")
     del st
     torch.cuda.empty_cache()
     return res
@@ -334,7 +468,9 @@ def main():
         peak = 2500.0 if a.compute == "bf16" else 157.3
         out["roofline"] = gemm_roofline(run_profiled, 3, "mfma", peak,
                                         "FastPitch fwd+bwd: %d extra profiled passes after the timed region" % 3,
-                                        pmc_csv="r01_fastpitch_pmc_hbm_bytes.csv" if a.compute == "bf16" else None)
+                                        pmc_csv="r02_fastpitch_pmc_hbm_bytes.csv" if a.compute == "bf16" else None)
+    if rank == 0 and not a.no_roofline:
+        out["hbm_kernels"] = hbm_kernel_rooflines(dev, opt, grads, active, a.compute)
     if not a.no_hifigan:
         del opt, grads
         eng._ws = None

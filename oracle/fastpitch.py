@@ -28,6 +28,47 @@ N_MEL = 80
 N_SYMBOLS = 148
 
 
+# ---- storage="bf16": the throughput mode's rounding points --------------------------------------------------------------------
+# The HIP engine's bf16 mode (csrc/fastpitch_engine.hip: make_plan / layers_fwd / layers_bwd) STORES sequence activations and their
+# gradients in bf16, feeds the MFMAs a bf16 shadow of the fp32 master weights, accumulates in fp32 and runs every epilogue
+# (bias, residual, dropout, ReLU, LayerNorm statistics, softmax, losses, LAMB) in fp32.  The three temporal predictors keep fp32
+# storage but their GEMM operands are rounded to bf16 in flight.  Restating exactly those roundings on top of the fp32 graph gives
+# an oracle the bf16 engine can be held to tightly (tests/test_fastpitch_gpu.py: 2e-3 outputs / loss, 1e-2 per-tensor gradients)
+# instead of the loose bf16-vs-fp32 bounds:
+#   s(x)   a STORED tensor: value rounded in forward, its gradient rounded in backward (both live in bf16 buffers)
+#   q(x)   a GEMM OPERAND rounded on its way into the MFMA (weight shadow, fp32-stored predictor tensors): forward only
+#   gq(x)  the upstream gradient rounded on ITS way into the backward GEMMs of an fp32-stored tensor: backward only
+class _Round(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return x.to(torch.bfloat16).to(x.dtype) if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(torch.bfloat16).to(g.dtype) if ctx.bwd else g), None, None
+
+
+class Fp32Storage:
+    name = "fp32"
+    s = q = gq = staticmethod(lambda x: x)
+
+
+class Bf16Storage:
+    name = "bf16"
+    s = staticmethod(lambda x: _Round.apply(x, True, True))
+    q = staticmethod(lambda x: _Round.apply(x, True, False))
+    gq = staticmethod(lambda x: _Round.apply(x, False, True))
+
+
+def _storage(storage):
+    if storage is None or storage == "fp32":
+        return Fp32Storage
+    if storage == "bf16":
+        return Bf16Storage
+    return storage
+
+
 def mask_from_lens(lens, max_len):
     ids = torch.arange(0, max_len, device=lens.device, dtype=lens.dtype)
     return torch.lt(ids, lens.unsqueeze(1))
@@ -100,33 +141,33 @@ class HashDropout:
         return pr * torch.from_numpy(self._mult(stream, idx)).to(pr.dtype)
 
 
-def _mha(sd, pre, inp, key_pad_mask, drop=None, site=0):
-    qkv = F.linear(inp, sd[pre + "qkv_net.weight"], sd[pre + "qkv_net.bias"])
+def _mha(sd, pre, inp, key_pad_mask, drop=None, site=0, st=Fp32Storage):
+    qkv = st.s(F.linear(inp, st.q(sd[pre + "qkv_net.weight"]), sd[pre + "qkv_net.bias"]))
     q, k, v = torch.chunk(qkv, 3, dim=2)
-    score = torch.bmm(q, k.transpose(1, 2)) * (1 / (D_HEAD ** 0.5))
+    score = st.gq(torch.bmm(q, k.transpose(1, 2)) * (1 / (D_HEAD ** 0.5)))   # dS is rounded on its way into the dQ / dK products
     score = score.masked_fill(key_pad_mask.unsqueeze(1), -float("inf"))
     prob = F.softmax(score, dim=2)
     if drop is not None:
         prob = drop.prob(site + 0, prob)                      # dropatt, transformer.py:127
-    vec = torch.bmm(prob, v)
-    out = F.linear(vec, sd[pre + "o_net.weight"])
+    vec = st.s(torch.bmm(st.q(prob), v))                      # the probabilities enter the P V product as bf16 operands
+    out = F.linear(vec, st.q(sd[pre + "o_net.weight"]))
     if drop is not None:
         out = drop.act(site + 1, out)                         # drop, transformer.py:139
-    return F.layer_norm(inp + out, (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"])
+    return st.s(F.layer_norm(st.s(inp + out), (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"]))
 
 
-def _conv_ff(sd, pre, inp, drop=None, site=0):
+def _conv_ff(sd, pre, inp, drop=None, site=0, st=Fp32Storage):
     core = inp.transpose(1, 2)
-    core = F.conv1d(core, sd[pre + "CoreNet.0.weight"], sd[pre + "CoreNet.0.bias"], padding=1)
-    core = F.relu(core)
-    core = F.conv1d(core, sd[pre + "CoreNet.2.weight"], sd[pre + "CoreNet.2.bias"], padding=1)
+    core = F.conv1d(core, st.q(sd[pre + "CoreNet.0.weight"]), sd[pre + "CoreNet.0.bias"], padding=1)
+    core = st.s(F.relu(core))
+    core = F.conv1d(core, st.q(sd[pre + "CoreNet.2.weight"]), sd[pre + "CoreNet.2.bias"], padding=1)
     core = core.transpose(1, 2)
     if drop is not None:
         core = drop.act(site + 2, core)                       # CoreNet's trailing nn.Dropout, transformer.py:51
-    return F.layer_norm(inp + core, (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"])
+    return st.s(F.layer_norm(st.s(inp + core), (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"]))
 
 
-def fft_transformer(sd, pre, dec_inp, seq_lens=None, embed=False, taps=None, drop=None, site=0):
+def fft_transformer(sd, pre, dec_inp, seq_lens=None, embed=False, taps=None, drop=None, site=0, st=Fp32Storage):
     if embed:
         inp = F.embedding(dec_inp, sd[pre + "word_emb.weight"], padding_idx=0)
         mask = (dec_inp != 0).unsqueeze(2)
@@ -134,32 +175,33 @@ def fft_transformer(sd, pre, dec_inp, seq_lens=None, embed=False, taps=None, dro
         inp = dec_inp
         mask = mask_from_lens(seq_lens, inp.size(1)).unsqueeze(2)
     pos = positional_embedding(inp.size(1), D_MODEL, inp.dtype) * mask
-    out = inp + pos
+    out = st.s(inp + pos)
     if taps is not None:
         taps[pre + "in"] = out
     for i in range(N_LAYERS):
         lp = "%slayers.%d." % (pre, i)
-        out = _mha(sd, lp + "dec_attn.", out, ~mask.squeeze(2), drop, site + 4 * i)
+        out = _mha(sd, lp + "dec_attn.", out, ~mask.squeeze(2), drop, site + 4 * i, st)
         out = out * mask
-        out = _conv_ff(sd, lp + "pos_ff.", out, drop, site + 4 * i)
+        out = _conv_ff(sd, lp + "pos_ff.", out, drop, site + 4 * i, st)
         out = out * mask
         if taps is not None:
             taps[lp + "out"] = out
     return out, mask
 
 
-def temporal_predictor(sd, pre, enc_out, enc_mask, drop=None, site=0):
+def temporal_predictor(sd, pre, enc_out, enc_mask, drop=None, site=0, st=Fp32Storage):
     out = (enc_out * enc_mask).transpose(1, 2)
     for i in range(2):
         lp = "%slayers.%d." % (pre, i)
-        out = F.relu(F.conv1d(out, sd[lp + "conv.weight"], sd[lp + "conv.bias"], padding=1))
+        # fp32-stored in both modes; in bf16 mode the conv operands (and, in backward, the pre-activation gradient) are rounded in flight
+        out = F.relu(st.gq(F.conv1d(st.q(out), st.q(sd[lp + "conv.weight"]), sd[lp + "conv.bias"], padding=1)))
         C = out.size(1)
         out = F.layer_norm(out.transpose(1, 2), (C,), sd[lp + "norm.weight"], sd[lp + "norm.bias"])
         if drop is not None:
             out = drop.act(site + i, out)                     # ConvReLUNorm dropout, common/layers.py:97
         out = out.transpose(1, 2)
     out = out.transpose(1, 2)
-    return F.linear(out, sd[pre + "fc.weight"], sd[pre + "fc.bias"]) * enc_mask
+    return F.linear(st.q(out), st.q(sd[pre + "fc.weight"]), sd[pre + "fc.bias"]) * enc_mask
 
 
 def regulate_len(durations, enc_out, pace=1.0, mel_max_len=None):
@@ -193,31 +235,33 @@ def average_pitch(pitch, durs):
 DS_ENC, DS_DEC, DS_PRED = 0, 100, 200      # dropout site (stream) numbering shared with fastpitch_engine.hip
 
 
-def forward(sd, batch, stage, taps=None, drop=None):
+def forward(sd, batch, stage, taps=None, drop=None, storage=None):
     """batch: dict(text (B,Tt) int64, in_lens, mel_tgt (B,80,Tm), mel_lens, pitch (B,1,Tm), energy (B,Tm),
-    durs (B,Tt) int).  Returns the reference's 13-slot output list (model.py:388-390)."""
+    durs (B,Tt) int).  Returns the reference's 13-slot output list (model.py:388-390).
+    storage: None / "fp32" = the reference's arithmetic; "bf16" = the same graph with the HIP throughput mode's rounding points."""
+    st = _storage(storage)
     text, mel_lens = batch["text"], batch["mel_lens"]
     mel_max_len = int(mel_lens.max())
-    enc_out, enc_mask = fft_transformer(sd, "encoder.", text, embed=True, taps=taps, drop=drop, site=DS_ENC)
+    enc_out, enc_mask = fft_transformer(sd, "encoder.", text, embed=True, taps=taps, drop=drop, site=DS_ENC, st=st)
     dur_tgt = batch["durs"]
     if stage == 2:
-        log_dur_pred = temporal_predictor(sd, "duration_predictor.", enc_out, enc_mask, drop, DS_PRED + 0).squeeze(-1)
+        log_dur_pred = temporal_predictor(sd, "duration_predictor.", enc_out, enc_mask, drop, DS_PRED + 0, st).squeeze(-1)
         dur_pred = torch.clamp(torch.exp(log_dur_pred) - 1, 0, 75)
         return [None, None, dur_pred, log_dur_pred, None, None, None, None, None, None, dur_tgt, None, batch["in_lens"]]
-    pitch_pred = temporal_predictor(sd, "pitch_predictor.", enc_out, enc_mask, drop, DS_PRED + 2).permute(0, 2, 1)
+    pitch_pred = temporal_predictor(sd, "pitch_predictor.", enc_out, enc_mask, drop, DS_PRED + 2, st).permute(0, 2, 1)
     pitch_tgt = average_pitch(batch["pitch"], dur_tgt)
     pitch_emb = F.conv1d(pitch_tgt, sd["pitch_emb.weight"], sd["pitch_emb.bias"], padding=1)
-    enc_out = enc_out + pitch_emb.transpose(1, 2)
-    energy_pred = temporal_predictor(sd, "energy_predictor.", enc_out, enc_mask, drop, DS_PRED + 4).squeeze(-1)
+    enc_out = st.s(enc_out + pitch_emb.transpose(1, 2))
+    energy_pred = temporal_predictor(sd, "energy_predictor.", enc_out, enc_mask, drop, DS_PRED + 4, st).squeeze(-1)
     energy_tgt = torch.log(1.0 + average_pitch(batch["energy"].unsqueeze(1), dur_tgt))
     energy_emb = F.conv1d(energy_tgt, sd["energy_emb.weight"], sd["energy_emb.bias"], padding=1)
     energy_tgt = energy_tgt.squeeze(1)
-    enc_out = enc_out + energy_emb.transpose(1, 2)
+    enc_out = st.s(enc_out + energy_emb.transpose(1, 2))
     if taps is not None:
         taps["enc_cond"] = enc_out
     len_regulated, dec_lens = regulate_len(dur_tgt, enc_out, 1.0, mel_max_len)
-    dec_out, dec_mask = fft_transformer(sd, "decoder.", len_regulated, seq_lens=dec_lens, taps=taps, drop=drop, site=DS_DEC)
-    mel_out = F.linear(dec_out, sd["proj.weight"], sd["proj.bias"])
+    dec_out, dec_mask = fft_transformer(sd, "decoder.", len_regulated, seq_lens=dec_lens, taps=taps, drop=drop, site=DS_DEC, st=st)
+    mel_out = st.s(F.linear(dec_out, st.q(sd["proj.weight"]), sd["proj.bias"]))
     return [mel_out, dec_mask, None, None, pitch_pred, pitch_tgt, energy_pred, energy_tgt, None, None, dur_tgt, None,
             batch["in_lens"]]
 

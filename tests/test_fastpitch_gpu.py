@@ -258,3 +258,121 @@ def test_infer_against_reference_golden(golden_dir, compute, tol):
         assert (dec_lens.cpu() - ref_dec).abs().max().item() <= text.size(1)
         T = min(mel.size(2), g["mel_out"].shape[2])
         assert mel.shape[:2] == tuple(g["mel_out"].shape[:2]) and T > 0
+
+
+def _oracle_step(ofp, sd, batch, stage, storage, drop=None):
+    names = ofp.trainable_names(sd.keys(), stage)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd); work.update(leaves)
+    out = ofp.forward(work, batch, stage, drop=drop, storage=storage)
+    loss, comps = ofp.loss(out, batch, stage)
+    loss.backward()
+    return out, loss, {k: v.grad for k, v in leaves.items() if v.grad is not None}
+
+
+# ---- the throughput (bf16) schedule: direct-to-LDS GEMMs, the resident conv, fused attention, bf16 activation / gradient storage ----------
+# The oracle's storage="bf16" mode rounds at the engine's own storage points (oracle/fastpitch.py: s / q / gq).  Two facts shape the tests:
+#  (1) bf16 storage is CHAOTIC end to end: the bf16-storage oracle evaluated with fp32 and with fp64 accumulation differs from ITSELF by
+#      ~7e-3 (L2) at the mel output of this 12-layer network — an element that lands on the other side of a rounding boundary moves by one
+#      bf16 ulp (4e-3) and the next LayerNorm spreads it; the distance grows ~3e-4 per layer.  No implementation can be held to 2e-3 there.
+#  (2) Layer by layer that noise has no room to grow: fed the ENGINE's own stored layer input, the oracle layer must reproduce the engine's
+#      stored layer output tightly.  That is the tight check of every fused kernel in the schedule (teacher forcing), at 2e-3.
+# End to end the engine is then held to the arithmetic's own noise floor: its distance to the bf16 oracle may not exceed 1.5 x the oracle's
+# self-distance (fp32 vs fp64 accumulation), output by output and gradient tensor by gradient tensor.
+BF16_LAYER = 2e-3
+
+
+def _l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _oracle_layer(ofp, sd, pre, l, x, mask, drop=None, site=0):
+    """One TransformerLayer (transformer.py:164-171) on a given input with the bf16 storage model."""
+    lp = "%slayers.%d." % (pre, l)
+    st = ofp.Bf16Storage
+    out = ofp._mha(sd, lp + "dec_attn.", x, ~mask.squeeze(2), drop, site + 4 * l, st) * mask
+    return ofp._conv_ff(sd, lp + "pos_ff.", out, drop, site + 4 * l, st) * mask
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("case", ["golden", "ragged"])
+def test_bf16_schedule_layer_by_layer_against_bf16_storage_oracle(golden_dir, case, p_drop):
+    """Teacher-forced: every encoder / decoder layer of the bf16 engine (qkv GEMM, fused attention, o_net + residual, LayerNorm, conv-k3
+    FFN on the direct-to-LDS / resident-input kernels, LayerNorm; with and without dropout) against the oracle layer on the SAME stored input."""
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd.fastpitch import engine as E, params as P
+    if case == "golden":
+        g, batch = load_case(golden_dir, "fp_stage3_small")
+        sd = ofp.init_state_dict(int(g["seed"]))
+    else:
+        sd, batch = ofp.init_state_dict(77), ofp.synth_batch(4, 37, 210, 78)
+    eng = E.FastPitchEngine("cuda", "bf16", p_dropout=p_drop, seed=4242)
+    flat = torch.zeros(eng.total, device="cuda")
+    P.to_flat(sd, eng.table, flat)
+    b = E.DeviceBatch.from_dict(batch, "cuda")
+    drop = ofp.HashDropout(p_drop, 4242 + eng.step) if p_drop > 0 else None
+    eng.forward(flat, b, 3)
+    torch.cuda.synchronize()
+    B, Tt, Tm = b.B, b.Tt, b.Tm
+    dec_lens = eng.outputs(b, 3)["dec_lens"].cpu().long()
+    worst = 0.0
+    with torch.no_grad():
+        for stack, T, lens, site in (("encoder", Tt, batch["in_lens"], ofp.DS_ENC), ("decoder", Tm, dec_lens, ofp.DS_DEC)):
+            mask = ofp.mask_from_lens(lens, T).unsqueeze(2)
+            for l in range(6):
+                x_in = eng.layer_input(stack, l, B, T).float().cpu()
+                x_out = eng.layer_input(stack, l + 1, B, T).float().cpu()
+                ref = _oracle_layer(ofp, sd, stack + ".", l, x_in, mask, drop, site)
+                e = _l2(x_out, ref)
+                worst = max(worst, e)
+                assert e < BF16_LAYER, (stack, l, e)
+                # element-wise: nothing further than 2 bf16 ulps of the tensor's scale (a flipped rounding upstream of the last LayerNorm)
+                assert ((x_out - ref).abs().max() / ref.abs().max()).item() < 2.5 * 2 ** -8, (stack, l)
+        # the input side: embedding + positional table, and the conditioning + length regulation feeding the decoder
+        emb = torch.nn.functional.embedding(batch["text"], sd["encoder.word_emb.weight"], padding_idx=0)
+        m = (batch["text"] != 0).unsqueeze(2)
+        ref0 = ofp.Bf16Storage.s(emb + ofp.positional_embedding(Tt, 384, torch.float32) * m)
+        assert _l2(eng.layer_input("encoder", 0, B, Tt).float().cpu(), ref0) < 1e-6
+    print("worst layer L2 error %.2e" % worst)
+
+
+def _self_distance(ofp, sd, batch, stage):
+    """The bf16-storage oracle with fp64 instead of fp32 accumulation: what the arithmetic itself leaves undetermined."""
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    return _oracle_step(ofp, sd64, b64, stage, "bf16")
+
+
+@pytest.mark.parametrize("stage", [3, 4, 2])
+def test_bf16_engine_end_to_end_within_the_noise_floor_of_bf16_storage(stage):
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd.fastpitch import params as P
+    sd = ofp.init_state_dict(77)
+    batch = ofp.synth_batch(4, 37, 210, 78)
+    out_ref, loss_ref, ref_grads = _oracle_step(ofp, sd, batch, stage, "bf16")
+    out_64, loss_64, grads_64 = _self_distance(ofp, sd, batch, stage)
+    eng, flat, grads = build_engine(sd, "bf16")
+    b, losses = _run(eng, flat, grads, batch, stage)
+    out = eng.outputs(b, stage)
+    pairs = [("log_dur_pred", 3)] if stage == 2 else [("mel_out", 0), ("pitch_pred", 4), ("energy_pred", 6)]
+    for name, idx in pairs:
+        floor = _l2(out_ref[idx], out_64[idx])
+        mine = _l2(out[name].float(), out_ref[idx])
+        print("%s: engine vs bf16 oracle %.2e, oracle self-distance %.2e" % (name, mine, floor))
+        assert mine < 1.5 * floor + 1e-3, (name, mine, floor)
+    assert abs(losses[0].item() - loss_ref.item()) < 2e-3 * abs(loss_ref.item())            # the loss averages the noise out
+    mineg = P.from_flat(grads, eng.table)
+    bad = []
+    for k, gr in ref_grads.items():
+        floor = _l2(gr, grads_64[k])
+        e = _l2(mineg[k], gr)
+        if not e < 1.5 * floor + 2e-3:
+            bad.append((k, e, floor))
+    assert not bad, bad[:8]
+    a = torch.cat([mineg[k].double().cpu().flatten() for k in ref_grads])
+    r = torch.cat([ref_grads[k].double().flatten() for k in ref_grads])
+    r64 = torch.cat([grads_64[k].double().flatten() for k in ref_grads])
+    cos = (a @ r / (a.norm() * r.norm())).item()
+    cos_floor = (r64 @ r / (r64.norm() * r.norm())).item()
+    assert 1 - cos < 1.5 * (1 - cos_floor) + 1e-5, (cos, cos_floor)

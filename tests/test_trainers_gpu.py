@@ -91,7 +91,8 @@ def test_fastpitch_trainer_from_dataset_directory(tmp_path):
     tr = _fp_trainer(mm, ws, out, "voice_c")
     asyncio.run(tr.start(dict(base, max_iterations=50006), gpus=[0]))
     assert int(tr.model.training_stage) == 1 and any(m.startswith("Set stage to: 1") for m in ws.sent)
-    assert tr.global_batch == int(1 * 1.5 * 10 / max(tr._dataset_file_lengths())) and tr.gam == max(1, round(256 / tr.global_batch))
+    assert tr.global_batch == int(1 * 1.5 * 10 / max(tr._dataset_file_lengths())) == 15
+    assert len(tr.train_loader) == 3 and tr.gam == 3          # 12 clips x data multiplier 4 = 48 items; round(256 / 15) = 17 capped to one epoch
     assert float(tr.model.pitch_mean[0]) == 180.5 and float(tr.model.pitch_std[0]) == 41.25     # pitch_stats.json -> model buffers (:344-346)
     log = open(out + "/voice_c/training.log").read()
     losses = [float(x) for x in re.findall(r"Stage: 1 .*?loss: ([0-9.]+)", log)]

@@ -540,7 +540,12 @@ extern "C" int xva_fp_slot_offset(const xva_fp_dims* d, int slot, int64_t* off_b
         case XVA_FP_SLOT_ENC_OUT: *off_bytes = p.enc_x[NL]; break;
         case XVA_FP_SLOT_DEC_OUT: *off_bytes = p.dec_x[NL]; break;
         case XVA_FP_SLOT_ENC_COND: *off_bytes = p.enc_c2; break;
-        default: xva_set_error("slot_offset: unknown slot %d", slot); return XVA_ERR_ARG;
+        default:
+            // 100 + l / 200 + l: input of encoder / decoder layer l (l = NL: the stack's output), (B, T + 2, 384) in the activation dtype —
+            // what the layer-by-layer (teacher-forced) parity check of the bf16 schedule reads
+            if (slot >= 100 && slot <= 100 + NL) { *off_bytes = p.enc_x[slot - 100]; break; }
+            if (slot >= 200 && slot <= 200 + NL) { *off_bytes = p.dec_x[slot - 200]; break; }
+            xva_set_error("slot_offset: unknown slot %d", slot); return XVA_ERR_ARG;
     }
     return XVA_OK;
 }

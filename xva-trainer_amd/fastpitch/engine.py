@@ -170,6 +170,14 @@ class FastPitchEngine:
         nb = n * torch.empty((), dtype=dtype).element_size()
         return self._ws[off:off + nb].view(dtype).view(*shape)
 
+    def layer_input(self, stack, l, B, T):
+        """Stored input of layer l (l = 6: the stack output) of the "encoder" / "decoder" stack after a forward: (B, T, 384) view in the
+        activation dtype without the two structural pad rows (slots 100 + l / 200 + l of xva_fp_slot_offset)."""
+        off = i64()
+        _lib.check(lib.xva_fp_slot_offset(C.byref(self._dims), (100 if stack == "encoder" else 200) + int(l), C.byref(off)), "xva_fp_slot_offset")
+        nb = B * (T + 2) * 384 * (2 if self.compute else 4)
+        return self._ws[off.value:off.value + nb].view(self.act_dtype).view(B, T + 2, 384)[:, 1:T + 1]
+
     def _abi_batch(self, b):
         return FpBatch(_lib.ptr(b.text), _lib.ptr(b.in_lens), _lib.ptr(b.durs), _lib.ptr(b.pitch), _lib.ptr(b.energy), _lib.ptr(self._pos))
 

@@ -387,6 +387,11 @@ class FastPitchTrainer(object):
         if stage >= 2 and not self.synthetic_data and not self.loader_factory and not os.path.exists(self.dataset_input + "/durs_text"):
             self.extract_durations()                                              # xva_train.py:473-474
         self.train_loader = self._make_loader(stage, data_mult)
+        if len(self.train_loader) < self.gam:
+            # start_new_epoch() drops a partial accumulation like the reference (xva_train.py:737-741): with fewer batches per epoch than
+            # GAM no optimizer step would ever happen (the reference livelocks there) — accumulate over one whole epoch instead
+            self.gam = max(1, len(self.train_loader))
+            self.print_and_log("GAM capped to %d (batches per epoch)" % self.gam, save_to_file=self.dataset_output)
         n_lines = getattr(self.train_loader, "actual_num_lines", None) or len(self.train_loader) * self.global_batch
         self.num_iters = max(1, len(self.train_loader) // self.gam)
         self.target_delta = self.get_target_delta(n_lines, stage)
@@ -474,7 +479,11 @@ class FastPitchTrainer(object):
             self.print_and_log("loss is NaN", save_to_file=self.dataset_output)
             self.grads.zero_()
             self.accumulated_steps, self.iter_loss, self.iter_num_frames = 0, 0.0, 0
+            self.nan_streak = getattr(self, "nan_streak", 0) + 1
+            if self.nan_streak >= 100:              # the reference would skip micro-batches forever; a diverged model is reported instead
+                raise FloatingPointError("FastPitch stage %d: the loss was NaN for 100 consecutive micro-batches" % stage)
             return
+        self.nan_streak = 0
         self.iter_loss += reduced / self.gam
         self.iter_num_frames += int(b.mel_lens.sum().item()) if b.mel_lens is not None else 0
         if last:
