@@ -141,15 +141,45 @@ class HashDropout:
         return pr * torch.from_numpy(self._mult(stream, idx)).to(pr.dtype)
 
 
+def _flash_pv(score, v, mult, st):
+    """softmax(score) @ v the way csrc/attention.hip:attn_fwd_kernel evaluates it: keys in blocks of 64 PADDED positions (key k sits at
+    padded index k + 1), a running row maximum, UNNORMALISED probabilities p = exp(s - m) (times the dropout multiplier) rounded to bf16 as
+    the MFMA operand, the fp32 accumulator rescaled when the maximum moves, one division by the unrounded row sum at the end.
+    Mathematically softmax(score) @ v; numerically the roundings land where the kernel's do."""
+    B, Tq, Tk = score.shape
+    m = torch.full((B, Tq, 1), -float("inf"), dtype=score.dtype)
+    lsum = torch.zeros(B, Tq, 1, dtype=score.dtype)
+    o = torch.zeros(B, Tq, v.size(2), dtype=score.dtype)
+    for j0 in range(0, Tk + 1, 64):
+        k0, k1 = max(j0 - 1, 0), min(j0 + 63, Tk)             # keys whose padded index lies in [j0, j0 + 63]
+        if k1 <= k0:
+            continue
+        sb = score[:, :, k0:k1]
+        m_new = torch.maximum(m, sb.max(dim=2, keepdim=True).values)
+        m_use = torch.where(torch.isinf(m_new), torch.zeros_like(m_new), m_new)
+        alpha = torch.exp(m - m_use)
+        pb = torch.exp(sb - m_use)
+        lsum = lsum * alpha + pb.sum(dim=2, keepdim=True)
+        if mult is not None:
+            pb = pb * mult[:, :, k0:k1]
+        o = o * alpha + torch.bmm(st.q(pb), v[:, k0:k1])
+        m = m_new
+    return o / torch.where(lsum > 0, lsum, torch.ones_like(lsum)) * (lsum > 0)
+
+
 def _mha(sd, pre, inp, key_pad_mask, drop=None, site=0, st=Fp32Storage):
     qkv = st.s(F.linear(inp, st.q(sd[pre + "qkv_net.weight"]), sd[pre + "qkv_net.bias"]))
     q, k, v = torch.chunk(qkv, 3, dim=2)
     score = st.gq(torch.bmm(q, k.transpose(1, 2)) * (1 / (D_HEAD ** 0.5)))   # dS is rounded on its way into the dQ / dK products
     score = score.masked_fill(key_pad_mask.unsqueeze(1), -float("inf"))
-    prob = F.softmax(score, dim=2)
-    if drop is not None:
-        prob = drop.prob(site + 0, prob)                      # dropatt, transformer.py:127
-    vec = st.s(torch.bmm(st.q(prob), v))                      # the probabilities enter the P V product as bf16 operands
+    if st is Bf16Storage:                                     # the fused flash-style attention of the throughput mode
+        mult = drop.prob(site + 0, torch.ones_like(score)) if drop is not None else None
+        vec = st.s(_flash_pv(score, v, mult, st))
+    else:
+        prob = F.softmax(score, dim=2)
+        if drop is not None:
+            prob = drop.prob(site + 0, prob)                  # dropatt, transformer.py:127
+        vec = torch.bmm(prob, v)
     out = F.linear(vec, st.q(sd[pre + "o_net.weight"]))
     if drop is not None:
         out = drop.act(site + 1, out)                         # drop, transformer.py:139
