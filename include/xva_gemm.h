@@ -103,6 +103,10 @@ typedef struct xva_gemm_params {
      * Needs splitk == 1 and accumulate == 0. */
     void* C2;
     float c2_slope;
+    /* convolution hint (NT / NN with A tap segments): elements between consecutive INPUT rows of A (the tensor's channel count).  A
+     * strided convolution has lda = stride * a_rowpitch, a grouped one a_seglen < a_rowpitch.  0 = lda.  Only used to recognise
+     * problems the resident-input kernel can take; the product it describes is the same. */
+    int64_t a_rowpitch;
 } xva_gemm_params;
 
 /* Launches on `stream` (a hipStream_t); returns 0 or a negative XVA_ERR_* code. */

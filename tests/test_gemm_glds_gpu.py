@@ -278,3 +278,47 @@ def test_second_output_activated_copy(mainloop, M, N, K, cdt):
     L.lib.xva_gemm_set_mainloop(0)
     with pytest.raises(L.XvaError):
         L.gemm(A, B, Cm, M, N, K, lda, ldb, N, compute=1, C2=C2.data_ptr(), c2_slope=0.1)
+
+
+@pytest.mark.parametrize("C,Cout,groups,k,s", [(128, 128, 4, 41, 2), (128, 256, 16, 41, 2), (256, 512, 16, 41, 4), (512, 1024, 16, 41, 4), (1024, 1024, 16, 41, 1),
+                                               (64, 64, 1, 5, 2), (256, 128, 2, 7, 4), (32, 48, 2, 3, 1)])
+def test_grouped_strided_conv_resident_input(mainloop, C, Cout, groups, k, s):
+    """HiFi-GAN MultiScaleDiscriminator convolutions (models.py:203-216: k = 41, stride 2 / 4, groups 4 / 16) in the form hg_conv.h issues
+    them — per-item batches, the group index as the second batch level, lda = stride * C (a_rowpitch = C) — forward and the polyphase
+    backward-data (one stride-1 problem per input phase), against fp64 F.conv1d.  With 32 / 64 channels per group these take the
+    resident-input kernel (input rows of a group loaded once, strided MFMA fragments)."""
+    L = _lib()
+    torch.manual_seed(C + k + s)
+    nseq, T, PAD = 3, 1000, 24
+    P_ = (k - 1) // 2
+    Cig, Cog = C // groups, Cout // groups
+    To = (T + 2 * P_ - (k - 1) - 1) // s + 1
+    Hp, Hpo = T + 2 * PAD, To + 2 * PAD
+    xs = torch.zeros(nseq * Hp + 2 * PAD, C, device="cuda", dtype=torch.bfloat16)
+    xv = xs[PAD:PAD + nseq * Hp].view(nseq, Hp, C)
+    xv[:, PAD:PAD + T] = torch.randn(nseq, T, C, device="cuda").bfloat16()
+    W = (torch.randn(Cout, Cig, k, device="cuda") * 0.05).bfloat16()
+    Wt = W.permute(0, 2, 1).contiguous().view(Cout, k * Cig)                       # [G][Cog][k * Cig] tap-major
+    bias = torch.randn(Cout, device="cuda")
+    y = torch.zeros(nseq * Hpo, Cout, device="cuda", dtype=torch.bfloat16)
+    L.gemm(xs, Wt, y, To, Cog, k * Cig, s * C, k * Cig, Cout, layout=L.GEMM_NT, compute=1, bias=bias, act=L.ACT_LRELU, act_slope=0.1,
+           a_offset=(PAD + PAD - P_) * C, a_seglen=Cig, a_segadj=C - Cig, a_rowpitch=C, batch=nseq, sA=Hp * C, sC=Hpo * Cout,
+           batch2=groups, sA2=Cig, sB2=Cog * k * Cig, sC2=Cog, sbias2=Cog, b_offset=0)
+    ref = F.leaky_relu(F.conv1d(xv[:, PAD:PAD + T].double().transpose(1, 2), W.double(), bias.double(), stride=s, padding=P_, groups=groups), 0.1)
+    out = y.view(nseq, Hpo, Cout)[:, :To]                                          # the per-item GEMM writes rows [0, To) of each item's slab
+    assert _rel(out, ref.transpose(1, 2)) < 6e-3
+    # backward-data, phase by phase (hg_conv_bwd_data): dX[s q + psi] = sum_m dY[q + c0 - m] W[:, :, j0 + m s]
+    dys = torch.zeros(nseq * Hpo + 2 * PAD, Cout, device="cuda", dtype=torch.bfloat16)
+    dyv = dys[PAD:PAD + nseq * Hpo].view(nseq, Hpo, Cout)
+    dyv[:, PAD:PAD + To] = torch.randn(nseq, To, Cout, device="cuda").bfloat16()
+    dx = torch.zeros(nseq * Hp, C, device="cuda")
+    for psi in range(s):
+        j0, c0 = (psi + P_) % s, (psi + P_) // s
+        ntap = (k - j0 + s - 1) // s
+        Q = (T - psi + s - 1) // s
+        L.gemm(dys, Wt, dx, Q, Cig, ntap * Cog, Cout, k * Cig, s * C, layout=L.GEMM_NN, compute=1,
+               a_offset=(PAD + PAD + c0) * Cout, a_seglen=Cog, a_segadj=-Cout - Cog, seglen=Cog, seg0=j0 * Cig, segstride=s * Cig,
+               batch=nseq, sA=Hpo * Cout, sC=Hp * C, batch2=groups, sA2=Cog, sB2=Cog * k * Cig, sC2=Cig, c_offset=(PAD + psi) * C)
+    xr = xv[:, PAD:PAD + T].double().transpose(1, 2).requires_grad_(True)
+    F.conv1d(xr, W.double(), stride=s, padding=P_, groups=groups).backward(dyv[:, PAD:PAD + To].double().transpose(1, 2))
+    assert _rel(dx.view(nseq, Hp, C)[:, PAD:PAD + T], xr.grad.transpose(1, 2)) < 3e-6

@@ -56,6 +56,7 @@ class GemmParams(C.Structure):
         ("drop_p", f32), ("drop_seed", C.c_uint64), ("drop_stream", C.c_uint32),
         ("sk_ws", C.c_void_p), ("sk_ws_bytes", i64),
         ("C2", vp), ("c2_slope", f32),
+        ("a_rowpitch", i64),
     ]
 
 
@@ -114,7 +115,7 @@ def _dt(t):
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batch=1, sA=0, sB=0, sC=0, alpha=1.0, beta=1.0,
          bias=None, relu=False, act=ACT_NONE, act_slope=0.0, R=None, ldr=0, sR=0, G=None, ldg=0, sG=0, gate_slope=0.0,
          mask_mode=MASK_NONE, lens=None, Tp=0, mask_pad=1, mask_len=0, mask_mul=1, mask_add=0, accumulate=False, splitk=1, seglen=0, seg0=0, segstride=0,
-         a_seglen=0, a_segadj=0, a_lrelu=None, b_lrelu=None, a_offset=0, b_offset=0, batch2=1, sA2=0, sB2=0, sC2=0, sR2=0, sG2=0,
+         a_seglen=0, a_segadj=0, a_lrelu=None, b_lrelu=None, a_offset=0, b_offset=0, c_offset=0, batch2=1, sA2=0, sB2=0, sC2=0, sR2=0, sG2=0,
          sk_ws=None, **extra):
     """Thin test/utility wrapper over xva_gemm. `a_offset` / `b_offset` (elements) shift the base pointers (negative for
     the overlapping-row conv forms).  Storage dtypes are taken from the tensors."""
@@ -122,7 +123,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batch=1, s
     p = GemmParams()
     p.A = A.data_ptr() + A.element_size() * a_offset
     p.B = B.data_ptr() + B.element_size() * b_offset
-    p.C = Cm.data_ptr()
+    p.C = Cm.data_ptr() + Cm.element_size() * c_offset
     p.M, p.N, p.K = M, N, K
     p.lda, p.ldb, p.ldc = lda, ldb, ldc
     p.batch, p.sA, p.sB, p.sC = batch, sA, sB, sC

@@ -9,7 +9,7 @@ void xva_gemm_launch_mixed(const xva_gemm_params& p, int bn, unsigned nblocks, h
 bool xva_gemm_glds_eligible(const xva_gemm_params& p);
 int xva_gemm_launch_glds(const xva_gemm_params& p, int tile, hipStream_t st);
 void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn);
-int xva_gemm_conv_res_plan(const xva_gemm_params& p);
+int xva_gemm_conv_res_plan(const xva_gemm_params& p, int* stride_out = nullptr, int64_t* rowpitch_out = nullptr);
 int xva_gemm_launch_conv_res(const xva_gemm_params& p, int dstep, hipStream_t st);
 bool xva_prof_is_on();
 void xva_prof_begin(hipStream_t st, double flops, int variant);
@@ -129,7 +129,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (p.G) by += (double)p.M * p.N * (p.g_dtype == XVA_BF16 ? 2.0 : 4.0);
         xva_prof_shape(p.M, p.N, p.K, p.batch * p.batch2, p.splitk, bn, by * nbz); }
     XVA_CHECK_ARG(!p.C2 || glds_tile >= 0, "xva_gemm: the second output is written by the direct-to-LDS kernels only (bf16 operands, K >= 64)");
-    if (res_dstep != 0) {   // stride-1 conv over 32 / 64 / 128 channels: resident input tile
+    if (res_dstep != 0) {   // conv over 32 / 64 / 128 channels (per group), stride 1 / 2 / 4: resident input tile
         if (xva_gemm_launch_conv_res(p, res_dstep, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; }
     } else if (glds_tile >= 0) { if (xva_gemm_launch_glds(p, glds_tile, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; } }
     else if (mode == 0) xva_gemm_launch_fp32(p, bn, (unsigned)nblocks, st);

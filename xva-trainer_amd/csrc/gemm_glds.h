@@ -654,16 +654,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
 // fragments stay (nearly) conflict-free); only the small weight tiles stream through the usual double buffer.
 // NT: forward (weights [Cout][k * CIN]).  NN: backward-data (weights read through the B row segments, tap-reversed).
 constexpr int RES_HALO = 64;
-template <int CIN> __device__ __forceinline__ int res_swz(int row) { return CIN == 128 ? (row & 15) : (CIN == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3)); }
+template <int CIN> __device__ __forceinline__ int res_swz(int row) {
+    return CIN == 128 ? (row & 15) : (CIN == 64 ? ((row >> 1) & 7) : (CIN == 32 ? ((row >> 2) & 3) : (CIN == 16 ? ((row >> 3) & 1) : 0)));
+}
 
+// stride (1, 2, 4: HiFi-GAN's strided discriminator convs) = input rows per output row; rowpitch = elements between consecutive input
+// rows (> CIN for a grouped conv: the tile holds one group's channels); the problem's group index is the second batch level (z2).
+constexpr int res_a_bytes(int cin, int stride) { return (((stride * 128 + RES_HALO) * cin * 2) + 1023) & ~1023; }
 template <int LAYOUT, int CIN, int BN, int WM, int WN>
-__global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_kernel(xva_gemm_params p, int vec_epi, int dstep) {
+__global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_kernel(xva_gemm_params p, int vec_epi, int dstep, int stride,
+                                                                                       int64_t rowpitch) {
     constexpr int BM = 128;
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
     static_assert(NW == 4, "resident-input conv: 4 waves");
     constexpr int MI = WM / 16, NJ = WN / 16;
     constexpr int BKD = LAYOUT == XVA_GEMM_NT ? KC : IC;
-    constexpr int A_BYTES = (BM + RES_HALO) * CIN * 2, B_BYTES = BN * GK * 2;
+    constexpr int B_BYTES = BN * GK * 2;
+    const int A_BYTES = res_a_bytes(CIN, stride);
     constexpr int CPR = CIN / 8, RPI = 64 / CPR;            // 16-byte chunks per input row, rows per DMA instruction
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem_raw[];
     XVA_LDS uint8_t* smem = (XVA_LDS uint8_t*)smem_raw;
@@ -689,14 +696,14 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
     const int lo = dstep < 0 ? -halo : 0;                     // taps step forwards (forward conv) or backwards (backward-data)
     const int nkt = (p.K + GK - 1) / GK;
 
-    // resident input rows m0 + lo .. m0 + lo + BM + halo - 1 (valid input rows: lo .. M - 1 + lo + halo)
+    // resident input rows stride * m0 + lo .. stride * (m0 + BM - 1) + lo + halo (valid input rows: lo .. stride * (M - 1) + lo + halo)
     {
-        const int nrows = BM + halo, rmax = p.M - 1 + lo + halo;
+        const int nrows = stride * (BM - 1) + 1 + halo, rmax = stride * (p.M - 1) + lo + halo;
         const int ninstr = (nrows + RPI - 1) / RPI;
         for (int q = wave; q < ninstr; q += NW) {
             const int r = q * RPI + lane / CPR, pch = lane % CPR;
             const int c = pch ^ res_swz<CIN>(r);
-            const uint16_t* src = A + (int64_t)min(m0 + lo + r, rmax) * p.lda + c * 8;
+            const uint16_t* src = A + (int64_t)min(stride * m0 + lo + r, rmax) * rowpitch + c * 8;
             __builtin_amdgcn_global_load_lds((const XVA_GLB void*)src, (XVA_LDS void*)(smem + q * 1024), 16, 0, 0);
         }
     }
@@ -711,7 +718,7 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
     IcReader<BN, NJ> irb;
     if constexpr (BKD == KC) krb.init(lane); else irb.init(lane, wn * WN);
     const int g = lane >> 4;
-    const int arow = wm * WM + (lane & 15) - lo;
+    const int arow = stride * (wm * WM + (lane & 15)) - lo;
 
     f32x4 acc[MI][NJ];
 #pragma unroll
@@ -723,9 +730,9 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
     constexpr int LOADS = Loader<BKD, BN, NW>::NI;
     constexpr int WAIT_YOUNGEST = 0x0F70 | (LOADS & 15) | ((LOADS >> 4) << 14);       // s_waitcnt vmcnt(LOADS)
     auto read_frags = [&](const XVA_LDS uint8_t* Bt, int kt, int kh, bf16x8 (&af)[MI], bf16x8 (&bfr)[NJ]) {
-        const int kk0 = kt * GK + kh * 32;
-        const int tap = min(kk0 / CIN, ntaps - 1);          // a ragged last K tile multiplies zero weights: stay inside the tile
-        const int ch = (kk0 % CIN) / 8 + g;
+        const int kl = kt * GK + kh * 32 + g * 8;           // this lane's first k: one MFMA k-step spans 32 / CIN taps when CIN < 32
+        const int tap = min(kl / CIN, ntaps - 1);           // a ragged last K tile multiplies zero weights: stay inside the tile
+        const int ch = (kl % CIN) / 8;
         const int shift = tap * dstep;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -734,7 +741,7 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int r = arow + i * 16 + shift;
+            const int r = arow + stride * (i * 16) + shift;
             af[i] = *reinterpret_cast<const XVA_LDS bf16x8*>(smem + r * (CIN * 2) + ((ch ^ res_swz<CIN>(r)) << 4));
         }
         if (p.a_lrelu) {
@@ -778,16 +785,19 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
 }
 
 template <int LAYOUT, int CIN, int BN, int WM, int WN>
-inline int launch_conv_res(const xva_gemm_params& p, int vec_epi, int dstep, hipStream_t st) {
-    constexpr int LDS = (128 + RES_HALO) * CIN * 2 + 2 * BN * GK * 2;
+inline int launch_conv_res(const xva_gemm_params& p, int vec_epi, int dstep, int stride, int64_t rowpitch, hipStream_t st) {
+    constexpr int LDS_FULL = res_a_bytes(CIN, 4) + 2 * BN * GK * 2;
+    constexpr int LDS_MAX = LDS_FULL > 160 * 1024 ? 160 * 1024 : LDS_FULL;      // the plan never admits a (CIN, stride) pair beyond the 160 KiB of a CU
+    if (res_a_bytes(CIN, stride) + 2 * BN * GK * 2 > LDS_MAX) return -1;
+    const int LDS = res_a_bytes(CIN, stride) + 2 * BN * GK * 2;
     auto kern = xva_conv_res_kernel<LAYOUT, CIN, BN, WM, WN>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess) return -1;
         attr_set = true;
     }
     long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, 128) * p.batch * p.batch2;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, st, p, vec_epi, dstep);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, st, p, vec_epi, dstep, stride, rowpitch);
     return 0;
 }
 

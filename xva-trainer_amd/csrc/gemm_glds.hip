@@ -142,31 +142,53 @@ static int vec_epilogue_ok(const xva_gemm_params& p) {
     return 1;
 }
 
-// ---- stride-1 convolutions over 32 / 64 / 128 input channels: resident-input kernel (gemm_glds.h) --------------------------------
+// ---- convolutions over 8 / 16 / 32 / 64 / 128 input channels (per group), stride 1 / 2 / 4: resident-input kernel (gemm_glds.h) ----------
 template <int LAYOUT, int CIN>
-static int conv_res_bn(const xva_gemm_params& p, int vec, int dstep, hipStream_t st) {
+static int conv_res_bn(const xva_gemm_params& p, int vec, int dstep, int stride, int64_t rp, hipStream_t st) {
     using namespace xva_glds;
-    if (p.N > 64) return launch_conv_res<LAYOUT, CIN, 128, 64, 64>(p, vec, dstep, st);
-    if (p.N > 32 || LAYOUT == XVA_GEMM_NN) return launch_conv_res<LAYOUT, CIN, 64, 32, 64>(p, vec, dstep, st);
-    return launch_conv_res<LAYOUT, CIN, 32, 32, 32>(p, vec, dstep, st);
+    if (p.N > 64) return launch_conv_res<LAYOUT, CIN, 128, 64, 64>(p, vec, dstep, stride, rp, st);
+    if (p.N > 32) return launch_conv_res<LAYOUT, CIN, 64, 32, 64>(p, vec, dstep, stride, rp, st);
+    return launch_conv_res<LAYOUT, CIN, 32, 32, 32>(p, vec, dstep, stride, rp, st);
 }
-// signed rows between consecutive taps when the problem qualifies for the resident-input kernel, 0 otherwise
-int xva_gemm_conv_res_plan(const xva_gemm_params& p) {
+// The resident-input plan of a problem: signed rows between consecutive taps (0 = does not qualify), input rows per output row, row pitch.
+//   forward (NT): A(r, tap j, c) = X[(stride * r + j * d) * rowpitch + c]  ->  lda = stride * rowpitch, a_seglen + a_segadj = d * rowpitch
+//   backward-data (NN): the same over dY, taps walking backwards; one polyphase component of a strided conv is a stride-1 problem
+//   grouped: a_seglen = channels per group < rowpitch, the group index is the second batch level
+int xva_gemm_conv_res_plan(const xva_gemm_params& p, int* stride_out, int64_t* rowpitch_out) {
     if (!xva_gemm_glds_eligible(p) || p.layout == XVA_GEMM_TN || p.splitk != 1) return 0;
     const int cin = p.a_seglen;
-    if (!(cin == 32 || cin == 64 || cin == 128) || p.lda != cin || p.K % cin != 0 || p.K / cin < 2) return 0;
+    const int64_t rp = p.a_rowpitch > 0 ? p.a_rowpitch : p.lda;
+    if (!(cin == 8 || cin == 16 || cin == 32 || cin == 64 || cin == 128) || rp < cin || rp % 8 != 0 || p.lda % rp != 0 || p.K % cin != 0 || p.K / cin < 2) return 0;
+    const int stride = (int)(p.lda / rp);
+    if (!(stride == 1 || stride == 2 || stride == 4)) return 0;
+    if (p.batch2 > 1 && p.sA2 % 8 != 0) return 0;                    // a group's channels start on a 16-byte boundary
+    {   // resident tile + two weight stages inside the 160 KiB of a CU
+        const int bn = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
+        if (xva_glds::res_a_bytes(cin, stride) + 2 * bn * xva_glds::GK * 2 > 160 * 1024) return 0;
+    }
     const int64_t step = (int64_t)p.a_seglen + p.a_segadj;          // elements between consecutive taps of one output row
-    if (step == 0 || step % p.lda != 0) return 0;
-    const int dstep = (int)(step / p.lda);                          // > 0: forward convolution, < 0: backward-data (taps walk backwards)
+    if (step == 0 || step % rp != 0) return 0;
+    const int dstep = (int)(step / rp);                             // > 0: forward convolution, < 0: backward-data (taps walk backwards)
     if ((int64_t)(p.K / cin - 1) * (dstep < 0 ? -dstep : dstep) > xva_glds::RES_HALO) return 0;
     if (p.layout == XVA_GEMM_NN && (p.N % 8 != 0)) return 0;
+    if (stride_out) *stride_out = stride;
+    if (rowpitch_out) *rowpitch_out = rp;
     return dstep;
 }
+template <int LAYOUT>
+static int conv_res_cin(const xva_gemm_params& p, int cin, int vec, int dstep, int stride, int64_t rp, hipStream_t st) {
+    switch (cin) {
+        case 8: return conv_res_bn<LAYOUT, 8>(p, vec, dstep, stride, rp, st);
+        case 16: return conv_res_bn<LAYOUT, 16>(p, vec, dstep, stride, rp, st);
+        case 32: return conv_res_bn<LAYOUT, 32>(p, vec, dstep, stride, rp, st);
+        case 64: return conv_res_bn<LAYOUT, 64>(p, vec, dstep, stride, rp, st);
+        default: return conv_res_bn<LAYOUT, 128>(p, vec, dstep, stride, rp, st);
+    }
+}
 int xva_gemm_launch_conv_res(const xva_gemm_params& p, int dstep, hipStream_t st) {
-    const int cin = p.a_seglen;
     const int vec = vec_epilogue_ok(p);
-    int rc;
-    if (p.layout == XVA_GEMM_NT) rc = cin == 32 ? conv_res_bn<XVA_GEMM_NT, 32>(p, vec, dstep, st) : (cin == 64 ? conv_res_bn<XVA_GEMM_NT, 64>(p, vec, dstep, st) : conv_res_bn<XVA_GEMM_NT, 128>(p, vec, dstep, st));
-    else rc = cin == 32 ? conv_res_bn<XVA_GEMM_NN, 32>(p, vec, dstep, st) : (cin == 64 ? conv_res_bn<XVA_GEMM_NN, 64>(p, vec, dstep, st) : conv_res_bn<XVA_GEMM_NN, 128>(p, vec, dstep, st));
-    return rc;
+    int stride = 1; int64_t rp = p.lda;
+    if (xva_gemm_conv_res_plan(p, &stride, &rp) == 0) return -1;
+    if (p.layout == XVA_GEMM_NT) return conv_res_cin<XVA_GEMM_NT>(p, p.a_seglen, vec, dstep, stride, rp, st);
+    return conv_res_cin<XVA_GEMM_NN>(p, p.a_seglen, vec, dstep, stride, rp, st);
 }

@@ -72,7 +72,7 @@ inline int hg_conv_fwd(const Seq& X, const Seq& Y, const ConvW& w, const ConvEpi
     g.layout = XVA_GEMM_NT;
     g.N = Cog; g.K = w.k * Cig;
     g.lda = (int64_t)w.s * X.C; g.ldb = g.K; g.ldc = Y.C;
-    g.a_seglen = Cig; g.a_segadj = (int64_t)w.d * X.C - Cig;
+    g.a_seglen = Cig; g.a_segadj = (int64_t)w.d * X.C - Cig; g.a_rowpitch = X.C;
     g.B = w.eff; g.bias = w.bias;
     g.a_lrelu = e.a_lrelu; g.a_slope = e.a_slope; g.act = e.act; g.act_slope = e.act_slope;
     g.alpha = e.alpha; g.beta = e.beta; g.accumulate = e.accumulate;
