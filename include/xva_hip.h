@@ -347,6 +347,10 @@ int xva_hg_disc_backward_d_ex(const xva_hg_dims* d, float* params_d, float* grad
  * mutable: each pass of the spectral-norm discriminator advances weight_u / weight_v by one power iteration. */
 int xva_hg_disc_forward(const xva_hg_dims* d, float* params_d, const float* y_real, const float* y_fake, void* workspace,
                         int64_t workspace_bytes, float* losses, void* stream);
+/* Same with a loss selection: bit 0 = discriminator loss (all the D step needs, xva_train.py:488-493), bit 1 = generator LSGAN +
+ * feature-matching losses (the G step, :506-512; the only part that reads every feature map).  Unselected entries stay 0. */
+int xva_hg_disc_forward_ex(const xva_hg_dims* d, float* params_d, const float* y_real, const float* y_fake, void* workspace,
+                           int64_t workspace_bytes, float* losses, int loss_mask, void* stream);
 /* D step (xva_train.py:494-495): accumulates d(loss_disc_s + loss_disc_f)/d(params_d) into grads_d. */
 int xva_hg_disc_backward_d(const xva_hg_dims* d, float* params_d, float* grads_d, const float* y_real, const float* y_fake,
                            void* workspace, int64_t workspace_bytes, void* stream);

@@ -850,6 +850,97 @@ extern "C" int xva_hg_spectral_norm_fwd(const float* W, float* u, float* v, void
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
+// ---- the same, every phase one launch over up to XVA_SN_BATCH layers (descriptors travel as kernel arguments) ----
+template <int PHASE>
+__device__ __forceinline__ int sn_layer_of(const xva_sn_batch& bt, int blk) {
+    int l = 0;
+    for (int i = 1; i < bt.n; ++i) {
+        const int b0 = PHASE == 0 ? bt.d[i].b_wtu : (PHASE == 1 ? bt.d[i].b_wv : bt.d[i].b_scale);
+        if (blk >= b0) l = i;
+    }
+    return l;
+}
+// phase 0: t[i] = sum_o W[o][i] u[o]: a thread per column i and 64-row chunk (coalesced across i), partial sums by atomics
+__global__ void sn_b_wtu_kernel(xva_sn_batch bt) {
+    const int l = sn_layer_of<0>(bt, blockIdx.x);
+    const xva_sn_desc& d = bt.d[l];
+    const int inner = d.D1 * d.k;
+    const int cb = (inner + 255) / 256;                       // column blocks of this layer; the rest of its blocks split D0 in chunks of 64 rows
+    const int local = blockIdx.x - d.b_wtu;
+    const int i = (local % cb) * 256 + threadIdx.x;
+    if (i >= inner) return;
+    const int o0 = (local / cb) * 64, o1 = min(o0 + 64, d.D0);
+    float a = 0.f;
+    for (int o = o0; o < o1; ++o) a += d.W[(int64_t)o * inner + i] * d.u[o];
+    atomicAdd(d.tmp + i, a);                                  // tmp[0 .. inner) is zeroed by the host before the launch
+}
+// phases 1 / 3: one workgroup per layer: out = in / max(||in||, eps) (+ saved copy, + sigma = out . in)
+__global__ void sn_b_normalize_kernel(xva_sn_batch bt, int second) {
+    __shared__ float sh[16];
+    const xva_sn_desc& d = bt.d[blockIdx.x];
+    const int inner = d.D1 * d.k;
+    const float* in = second ? d.tmp + inner : d.tmp;
+    float* out = second ? d.u : d.v;
+    float* keep = second ? d.su : d.sv;
+    const int n = second ? d.D0 : inner;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) a += in[i] * in[i];
+    a = xva_block_sum(a, sh);
+    const float inv = 1.f / fmaxf(sqrtf(a), 1e-12f);
+    float dt = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const float o = in[i] * inv; out[i] = o; if (keep) keep[i] = o; dt += o * in[i]; }
+    if (second) { dt = xva_block_sum(dt, sh); if (threadIdx.x == 0) d.sigma[0] = dt; }
+}
+// phase 2: s[o] = W[o] . v, one wave per row
+__global__ void sn_b_wv_kernel(xva_sn_batch bt) {
+    const int l = sn_layer_of<1>(bt, blockIdx.x);
+    const xva_sn_desc& d = bt.d[l];
+    const int inner = d.D1 * d.k;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o = (blockIdx.x - d.b_wv) * 4 + wave;
+    if (o >= d.D0) return;
+    float a = 0.f;
+    for (int i = lane; i < inner; i += 64) a += d.W[(int64_t)o * inner + i] * d.v[i];
+    a = xva_wave_sum(a);
+    if (lane == 0) d.tmp[inner + o] = a;
+}
+// phase 4: eff (tap-major, dt) = W / sigma (+ fp32 copy)
+__global__ void sn_b_scale_kernel(xva_sn_batch bt) {
+    const int l = sn_layer_of<2>(bt, blockIdx.x);
+    const xva_sn_desc& d = bt.d[l];
+    const int inner = d.D1 * d.k;
+    const int64_t idx = (int64_t)(blockIdx.x - d.b_scale) * 256 + threadIdx.x;
+    if (idx >= (int64_t)d.D0 * inner) return;
+    const int o = (int)(idx / inner), rem = (int)(idx % inner);
+    const int i1 = rem / d.k, j = rem % d.k;
+    const float w = d.W[idx] / d.sigma[0];
+    const int64_t at = (int64_t)o * inner + (int64_t)j * d.D1 + i1;
+    hg_st(d.eff, at, d.dt, w);
+    if (d.eff2) reinterpret_cast<float*>(d.eff2)[at] = w;
+}
+extern "C" int xva_hg_spectral_norm_fwd_batch(xva_sn_desc* descs, int n, void* stream) {
+    XVA_CHECK_ARG(descs && n > 0 && n <= XVA_SN_BATCH, "spectral_norm_fwd_batch: 1..%d layers", XVA_SN_BATCH);
+    hipStream_t st = (hipStream_t)stream;
+    xva_sn_batch bt;
+    bt.n = n; bt.nb_wtu = bt.nb_wv = bt.nb_scale = 0;
+    for (int i = 0; i < n; ++i) {
+        xva_sn_desc d = descs[i];
+        XVA_CHECK_ARG(d.W && d.u && d.v && d.eff && d.sigma && d.tmp, "spectral_norm_fwd_batch: null in layer %d", i);
+        const int inner = d.D1 * d.k;
+        d.b_wtu = bt.nb_wtu; bt.nb_wtu += xva_cdiv(inner, 256) * xva_cdiv(d.D0, 64);
+        if (hipMemsetAsync(d.tmp, 0, inner * sizeof(float), st) != hipSuccess) { xva_set_error("spectral_norm_fwd_batch: memset failed"); return XVA_ERR_HIP; }
+        d.b_wv = bt.nb_wv; bt.nb_wv += xva_cdiv(d.D0, 4);
+        d.b_scale = bt.nb_scale; bt.nb_scale += xva_cdiv((int64_t)d.D0 * inner, 256);
+        bt.d[i] = d;
+    }
+    hipLaunchKernelGGL(sn_b_wtu_kernel, dim3(bt.nb_wtu), dim3(256), 0, st, bt);
+    hipLaunchKernelGGL(sn_b_normalize_kernel, dim3(n), dim3(1024), 0, st, bt, 0);
+    hipLaunchKernelGGL(sn_b_wv_kernel, dim3(bt.nb_wv), dim3(256), 0, st, bt);
+    hipLaunchKernelGGL(sn_b_normalize_kernel, dim3(n), dim3(1024), 0, st, bt, 1);
+    hipLaunchKernelGGL(sn_b_scale_kernel, dim3(bt.nb_scale), dim3(256), 0, st, bt);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
 // eff = W / sigma in another dtype (fp32 copy for the 1-channel direct kernels), no power iteration
 extern "C" int xva_hg_sn_scale(const float* W, const float* sigma, void* eff, int dt, int D0, int D1, int k, void* stream) {
     XVA_CHECK_ARG(W && sigma && eff, "sn_scale: null");

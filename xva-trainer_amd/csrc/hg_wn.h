@@ -28,3 +28,17 @@ extern "C" int xva_hg_reduce_batch(const xva_red_desc* descs, int n, void* strea
 struct xva_cs_desc { const void* X; float* out; int64_t rows; float scale; int32_t dt, C, Creal, rpb, cb, block0; };
 struct xva_cs_batch { int32_t n; xva_cs_desc d[XVA_CS_BATCH]; };
 extern "C" int xva_hg_colsum_batch(const xva_cs_desc* descs, int n, void* stream);
+
+// Batched spectral norm (the 8 layers of MSD discriminator 0, one power iteration each per pass): every phase of the iteration is ONE
+// launch over all layers instead of one per layer (7 tiny launches x 8 layers x 4 passes per iteration were launch-latency bound).
+#define XVA_SN_BATCH 8
+struct xva_sn_desc {
+    const float* W; float* u; float* v;      // weight_orig (D0, inner), buffers weight_u (D0) / weight_v (inner): advanced in place
+    float* su; float* sv;                    // copies of the advanced buffers kept for this pass's backward
+    void* eff; void* eff2;                   // effective weight W / sigma, tap-major, dtype dt (and an optional fp32 copy)
+    float* sigma; float* tmp;                // sigma (1 float) and inner + D0 floats of scratch
+    int32_t dt, D0, D1, k;
+    int32_t b_wtu, b_wv, b_scale;            // first block of this layer in the three multi-block phases
+};
+struct xva_sn_batch { int32_t n; int32_t nb_wtu, nb_wv, nb_scale; xva_sn_desc d[XVA_SN_BATCH]; };
+extern "C" int xva_hg_spectral_norm_fwd_batch(xva_sn_desc* descs, int n, void* stream);

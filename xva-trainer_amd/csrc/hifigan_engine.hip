@@ -568,19 +568,30 @@ int conv0_fwd(Ctx& c, const float* Pd, const DiscRun& r, int i0, int ni) {
 }
 
 int sn_prepare(Ctx& c, float* Pd, const DiscRun& r) {
+    // one power iteration for every spectral-norm layer of the discriminator: 5 launches for all 8 layers (hg_wn.h: xva_sn_desc)
+    xva_sn_desc ds[XVA_SN_BATCH];
+    int n = 0;
+    int64_t toff = 0;
     for (int i = 0; i < r.n; ++i) {
         const Layer& l = c.pl.dl[r.li[i]];
         if (l.kind != LK_SN) continue;
-        XVA_TRY(xva_hg_spectral_norm_fwd(Pd + l.wv, Pd + l.bu, Pd + l.bv, c.W + l.eff[r.pass], c.F(l.norm[r.pass]), c.dt, l.D0(), l.D1(), l.k,
-                                         c.F(c.pl.sn_tmp), c.st));
-        if (hipMemcpyAsync(c.W + l.su[r.pass], Pd + l.bu, l.D0() * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.st) != hipSuccess ||
-            hipMemcpyAsync(c.W + l.sv[r.pass], Pd + l.bv, (int64_t)l.D1() * l.k * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.st) != hipSuccess) {
-            xva_set_error("sn_prepare: memcpy failed");
-            return XVA_ERR_HIP;
-        }
-        if (l.eff32[r.pass] >= 0 && c.dt != XVA_F32)
-            XVA_TRY(xva_hg_sn_scale(Pd + l.wv, c.F(l.norm[r.pass]), c.W + l.eff32[r.pass], XVA_F32, l.D0(), l.D1(), l.k, c.st));
-        if (l.Cin == 1) XVA_TRY(xva_hg_pad_cols(eff32(c, l, r.pass), c.W + l.wp[r.pass], c.dt, l.Cout, l.k, l.kp(), c.st));
+        xva_sn_desc d;
+        memset(&d, 0, sizeof(d));
+        d.W = Pd + l.wv; d.u = Pd + l.bu; d.v = Pd + l.bv;
+        d.su = c.F(l.su[r.pass]); d.sv = c.F(l.sv[r.pass]);
+        d.eff = c.W + l.eff[r.pass]; d.eff2 = (l.eff32[r.pass] >= 0 && c.dt != XVA_F32) ? c.W + l.eff32[r.pass] : nullptr;
+        d.sigma = c.F(l.norm[r.pass]); d.tmp = c.F(c.pl.sn_tmp) + toff;
+        d.dt = c.dt; d.D0 = l.D0(); d.D1 = l.D1(); d.k = l.k;
+        toff += ((int64_t)l.D1() * l.k + l.D0() + 7) & ~(int64_t)3;
+        XVA_CHECK_ARG(n < XVA_SN_BATCH, "sn_prepare: more than %d spectral-norm layers", XVA_SN_BATCH);
+        ds[n++] = d;
+    }
+    if (n == 0) return XVA_OK;
+    XVA_CHECK_ARG(toff * 4 <= (1024 * 41 * 64 + 1024 + 64) * 4, "sn_prepare: scratch too small");
+    XVA_TRY(xva_hg_spectral_norm_fwd_batch(ds, n, c.st));
+    for (int i = 0; i < r.n; ++i) {
+        const Layer& l = c.pl.dl[r.li[i]];
+        if (l.kind == LK_SN && l.Cin == 1) XVA_TRY(xva_hg_pad_cols(eff32(c, l, r.pass), c.W + l.wp[r.pass], c.dt, l.Cout, l.k, l.kp(), c.st));
     }
     return XVA_OK;
 }
@@ -663,7 +674,8 @@ int disc_backward_wave(Ctx& c, const float* Pd, const DiscRun& r, const SeqSpec*
 // loss sums: out[0] += mean((1-r)^2) + mean(g^2) (discriminator loss), out[1] += mean((1-g)^2) (generator loss),
 // out[2] += 2 * sum_l mean|r_l - g_l| (feature loss)
 // (the reductions of all discriminators are collected and issued as one batched launch by the caller)
-void disc_losses(Ctx& c, const DiscRun& r, const SeqSpec* rt, int r0, int f0, int nf, float* out, std::vector<xva_red_desc>& reds) {
+// loss_mask: bit 0 = the discriminator loss (D step), bit 1 = generator + feature-matching losses (G step: these read every fmap)
+void disc_losses(Ctx& c, const DiscRun& r, const SeqSpec* rt, int r0, int f0, int nf, float* out, std::vector<xva_red_desc>& reds, int loss_mask) {
     auto add = [&](const Seq& a, const Seq* b, const Seq& geo, int mode, float scale, float* dst) {
         xva_red_desc d;
         memset(&d, 0, sizeof(d));
@@ -674,11 +686,10 @@ void disc_losses(Ctx& c, const DiscRun& r, const SeqSpec* rt, int r0, int f0, in
     for (int i = 1; i <= r.n; ++i) {
         Seq g = c.S(r.t[i]).slice(f0, nf), rr = c.S(rt[i]).slice(r0, nf);
         const float inv = 1.f / (float)((int64_t)nf * g.T * g.C);
-        add(rr, &g, g, 0, 2.f * inv, out + 2);
+        if (loss_mask & 2) add(rr, &g, g, 0, 2.f * inv, out + 2);
         if (i == r.n) {
-            add(rr, nullptr, g, 1, inv, out + 0);
-            add(g, nullptr, g, 2, inv, out + 0);
-            add(g, nullptr, g, 1, inv, out + 1);
+            if (loss_mask & 1) { add(rr, nullptr, g, 1, inv, out + 0); add(g, nullptr, g, 2, inv, out + 0); }
+            if (loss_mask & 2) add(g, nullptr, g, 1, inv, out + 1);
         }
     }
 }
@@ -717,7 +728,7 @@ int pool_waves(Ctx& c, const float* yr, const float* yg) {
 }
 
 // forward of all 8 discriminators on (real, fake); losses[0..2] = {disc loss, gen loss, feature loss}
-int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* losses) {
+int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* losses, int loss_mask) {
     XVA_TRY(prep_wn(c, c.pl.dl, Pd));
     XVA_TRY(pool_waves(c, yr, yg));
     std::vector<DiscSet> sets; std::vector<DiscRun> snr;
@@ -744,7 +755,7 @@ int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* lo
                 XVA_TRY(hg_conv_fwd(x, y, cw(c, L[s.run.li[i]], Pd, 0), e, c.compute, c.st));
             }
         }
-        if (losses) disc_losses(c, s.run, s.rt, s.r0, s.f0, s.nf, losses, reds);
+        if (losses) disc_losses(c, s.run, s.rt, s.r0, s.f0, s.nf, losses, reds, loss_mask);
     }
     if (!reds.empty()) XVA_TRY(xva_hg_reduce_batch(reds.data(), (int)reds.size(), c.st));
     return XVA_OK;
@@ -887,12 +898,16 @@ extern "C" int xva_hg_bucket_range(int which, int i, int64_t* begin, int64_t* en
 /* yr / yg: real / generated waveforms (B, seg) fp32.  losses (device, 4 floats, may be NULL): {discriminator loss,
  * generator LSGAN loss, feature-matching loss, -}.  params_d is non-const: the spectral-norm power iteration advances
  * weight_u / weight_v (one iteration per pass, python/hifigan/models.py:244-253). */
-extern "C" int xva_hg_disc_forward(const xva_hg_dims* d, float* params_d, const float* yr, const float* yg, void* ws, int64_t ws_bytes, float* losses,
-                                   void* stream) {
+extern "C" int xva_hg_disc_forward_ex(const xva_hg_dims* d, float* params_d, const float* yr, const float* yg, void* ws, int64_t ws_bytes, float* losses,
+                                      int loss_mask, void* stream) {
     Ctx c;
     XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream));
     XVA_CHECK_ARG(params_d && yr && yg, "disc_forward: null");
-    return discs_forward(c, params_d, yr, yg, losses);
+    return discs_forward(c, params_d, yr, yg, losses, loss_mask);
+}
+extern "C" int xva_hg_disc_forward(const xva_hg_dims* d, float* params_d, const float* yr, const float* yg, void* ws, int64_t ws_bytes, float* losses,
+                                   void* stream) {
+    return xva_hg_disc_forward_ex(d, params_d, yr, yg, ws, ws_bytes, losses, 3, stream);
 }
 extern "C" int xva_hg_disc_backward_d_ex(const xva_hg_dims* d, float* params_d, float* grads_d, const float* yr, const float* yg, void* ws,
                                          int64_t ws_bytes, void* const* bucket_events, void* stream) {

@@ -125,23 +125,25 @@ def bucket_ranges(which):
     return out
 
 
-lib.xva_hg_disc_forward.restype = i32
-lib.xva_hg_disc_forward.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, i64, vp, vp]
+lib.xva_hg_disc_forward_ex.restype = i32
+lib.xva_hg_disc_forward_ex.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, i64, vp, i32, vp]
 lib.xva_hg_disc_backward_d_ex.restype = i32
 lib.xva_hg_disc_backward_d_ex.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, vp, i64, C.POINTER(vp), vp]
 lib.xva_hg_disc_backward_g.restype = i32
 lib.xva_hg_disc_backward_g.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, vp, i64, vp]
 
 
-def _disc_forward(self, flat_d, y_real, y_fake):
-    """MPD + MSD on (real, fake) (B, seg) fp32.  Returns a 4-float device tensor {loss_disc, loss_gen, loss_fm, -}."""
+def _disc_forward(self, flat_d, y_real, y_fake, losses="all"):
+    """MPD + MSD on (real, fake) (B, seg) fp32.  Returns a 4-float device tensor {loss_disc, loss_gen, loss_fm, -}.
+    losses: "all", "d" (discriminator loss only: the D step) or "g" (generator + feature-matching losses: the G step)."""
     _lib.require_cuda(flat_d, y_real, y_fake)
     d = self._prepare(y_real.size(0), y_real.size(1))
     self._yr, self._yg = y_real.float().contiguous(), y_fake.float().contiguous()
-    losses = torch.zeros(4, device=self.device)
-    _lib.check(lib.xva_hg_disc_forward(C.byref(d), _lib.ptr(flat_d), _lib.ptr(self._yr), _lib.ptr(self._yg), _lib.ptr(self._ws), self._ws.numel(),
-                                       _lib.ptr(losses), _lib.stream_ptr()), "xva_hg_disc_forward")
-    return losses
+    mask = {"all": 3, "d": 1, "g": 2}[losses]
+    out = torch.zeros(4, device=self.device)
+    _lib.check(lib.xva_hg_disc_forward_ex(C.byref(d), _lib.ptr(flat_d), _lib.ptr(self._yr), _lib.ptr(self._yg), _lib.ptr(self._ws), self._ws.numel(),
+                                          _lib.ptr(out), mask, _lib.stream_ptr()), "xva_hg_disc_forward_ex")
+    return out
 
 
 def _disc_backward_d(self, flat_d, grads_d, events=None):

@@ -162,14 +162,14 @@ class HifiganStep:
         eng = self.eng
         y_g_hat = eng.generator_forward(self.flat_g, x_mel)
         # ---- discriminator step
-        ld = eng.disc_forward(self.flat_d, y_wav, y_g_hat)
+        ld = eng.disc_forward(self.flat_d, y_wav, y_g_hat, losses="d")
         self.grads_d.zero_()
         eng.disc_backward_d(self.flat_d, self.grads_d, self.sync_d.events if self.sync_d else None)
         if self.sync_d:
             self.sync_d.reduce()
         self.optim_d.step(self.grads_d)
         # ---- generator step (updated discriminators)
-        lg = eng.disc_forward(self.flat_d, y_wav, y_g_hat)
+        lg = eng.disc_forward(self.flat_d, y_wav, y_g_hat, losses="g")
         d_wav = eng.disc_backward_g(self.flat_d)
         loss_mel, _ = pmel.mel_l1_loss_backward(y_g_hat, y_mel, d_wav, scale=45.0, accumulate=True)
         self.grads_g.zero_()
