@@ -358,6 +358,58 @@ int xva_hg_disc_backward_d(const xva_hg_dims* d, float* params_d, float* grads_d
 int xva_hg_disc_backward_g(const xva_hg_dims* d, float* params_d, const float* y_real, const float* y_fake, float* d_wav,
                            void* workspace, int64_t workspace_bytes, void* stream);
 
+/* torch.nn.utils.weight_norm (old API, dim 0) of ONE conv weight: eff (tap-major [D0][k * D1], dtype dt) = g * v / ||v||, norm[D0] saved;
+ * kind 0 = Conv1d v (Cout, Cin_g, k), kind 1 = ConvTranspose1d (also writes effB).  bwd: dv / dg += from the fp32 gradient of eff.
+ * (HiFi-GAN python/hifigan/models.py:21-108, WaveNet python/xvapitch/wavenet.py:62-82.) */
+int xva_hg_weight_norm_fwd(const float* v, const float* g, void* eff, void* effB, float* norm, int dt, int kind, int D0, int D1, int k, int s,
+                           int pconv, void* stream);
+int xva_hg_weight_norm_bwd(const float* dW, const float* v, const float* g, const float* norm, float* dv, float* dg, int kind, int D0, int D1,
+                           int k, void* stream);
+/* out[c] += scale * sum_r X[r][c] (bias gradients; X (rows, C) in dtype dt). */
+int xva_hg_colsum(const void* X, int dt, float* out, int64_t rows, int C, float scale, void* stream);
+
+/* ------------------------------------------------------------ xVAPitch-only blocks (first set) ---- */
+/* Kernels of the VITS-style xVAPitch model that FastPitch / HiFi-GAN do not share.  Sequence tensors are
+ * time-major (B, Tp = pad + T + pad, C) in dtype dt (XVA_F32 / XVA_BF16) with structurally zero pad rows; the WaveNet
+ * convolutions themselves run on xva_gemm (host: xva-trainer_amd/xvapitch/wn.py). */
+/* fused_add_tanh_sigmoid_multiply (python/xvapitch/wavenet.py:5-12): acts (B*Tp, H) = tanh(a[:, :H] + g) * sigmoid(a[:, H:] + g);
+ * a (B*Tp, 2H); g (B, 2H; row stride g_ld) fp32 per-item conditioning broadcast over time, or NULL.  bwd: d_a from d_acts. */
+int xva_wn_gate_fwd(const void* a, const float* g, int64_t g_ld, void* acts, int dt, int B, int Tp, int H, void* stream);
+int xva_wn_gate_bwd(const void* a, const float* g, int64_t g_ld, const void* d_acts, void* d_a, int dt, int B, int Tp, int H, void* stream);
+/* WN.forward's residual / skip split (wavenet.py:103-108): x_next = (x + rs[:, :H]) * mask, out += rs[:, H:] (last layer: out += rs, rs
+ * (rows, H)); mask = rows pad <= t' < pad + lens[b].  bwd: d_rs from (d_x, d_out). */
+int xva_wn_res_skip_fwd(const void* rs, const void* x, void* x_next, void* out, int dt, int B, int Tp, int pad, int H, int last, const int32_t* lens,
+                        void* stream);
+int xva_wn_res_skip_bwd(const void* d_x, const void* d_out, void* d_rs, int dt, int B, int Tp, int pad, int H, int last, const int32_t* lens,
+                        void* stream);
+/* maximum_path (python/xvapitch/util.py:14-53): value (B, t_x, t_y) fp32, x_lens / y_lens (B) -> path (B, t_x, t_y) fp32 of 0 / 1,
+ * on the device (the reference runs it in numpy on the CPU each step).  workspace: xva_maximum_path_workspace_bytes. */
+int64_t xva_maximum_path_workspace_bytes(int B, int t_x, int t_y);
+int xva_maximum_path(const float* value, const int32_t* x_lens, const int32_t* y_lens, float* path, void* workspace, int64_t workspace_bytes,
+                     int B, int t_x, int t_y, void* stream);
+/* segment (util.py:166-178): out (B, C, S) = x[b, :, idx[b] : idx[b] + S] of x (B, C, T); bwd scatters d_out back (zero elsewhere). */
+int xva_segment_fwd(const float* x, const int64_t* idx, float* out, int B, int C, int T, int S, void* stream);
+int xva_segment_bwd(const float* d_out, const int64_t* idx, float* d_x, int B, int C, int T, int S, void* stream);
+/* VitsGeneratorLoss.kl_loss (python/xvapitch/losses.py:87-104) on (B, H, T) fp32 tensors, mask (B, 1, T): acc2[0] += sum(kl * mask),
+ * acc2[1] += sum(mask) (zero acc2 first; loss = acc2[0] / acc2[1]); kl_sample_wise (B, H, T) optional.  bwd: gradients of
+ * gscale * loss (any output may be NULL). */
+int xva_kl_loss_fwd(const float* z_p, const float* logs_q, const float* m_p, const float* logs_p, const float* mask, float* kl_sample_wise,
+                    float* acc2, int B, int H, int T, void* stream);
+int xva_kl_loss_bwd(const float* z_p, const float* m_p, const float* logs_p, const float* mask, const float* acc2, float gscale, float* d_z_p,
+                    float* d_logs_q, float* d_m_p, float* d_logs_p, int B, int H, int T, void* stream);
+/* Zero the rows of a time-major sequence outside [pad, pad + lens[b]) (`* x_mask` after a biased convolution). */
+int xva_seq_mask(void* x, int dt, int B, int Tp, int pad, int C, const int32_t* lens, void* stream);
+/* ResidualCouplingBlock with mean_only=True (python/xvapitch/model.py:1519-1535): out (B, Ch, T) = stats + x1 * mask (forward) or
+ * (x1 - stats) * mask (reverse); stats = the masked `post` output as a time-major sequence (B, pad + T + pad, Ch). */
+int xva_coupling_mean_only(const void* stats, const float* x1, float* out, int dt, int B, int Ch, int T, int pad, const int32_t* lens, int reverse,
+                           void* stream);
+int xva_coupling_mean_only_bwd(const float* d_out, float* d_x1, void* d_stats, int dt, int B, int Ch, int T, int pad, const int32_t* lens, int reverse,
+                               void* stream);
+/* (B, C, T) fp32 <-> time-major sequence (B, pad + T + pad, C) in dt; to_seq zeroes pads and positions t >= lens[b] (lens may be NULL);
+ * to_bct overwrites or (accumulate) adds into x. */
+int xva_bct_to_seq(const float* x, void* seq, int dt, int B, int C, int T, int pad, const int32_t* lens, void* stream);
+int xva_seq_to_bct(const void* seq, float* x, int dt, int B, int C, int T, int pad, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

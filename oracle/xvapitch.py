@@ -1,0 +1,82 @@
+"""CPU oracle for the xVAPitch-only blocks built so far (TEST INFRASTRUCTURE ONLY — never imported by the package).
+
+Functional torch / numpy restatements driven by state_dicts with the REFERENCE's keys; oracle/gen_golden_xvapitch.py asserts them equal
+to the reference's own modules and records tests/golden/xvapitch_blocks.npz.
+  wn()                WN.forward + fused_add_tanh_sigmoid_multiply   python/xvapitch/wavenet.py:5-12,92-109
+  coupling()          ResidualCouplingBlock.forward (mean_only)      python/xvapitch/model.py:1519-1535
+  maximum_path()      monotonic alignment search                     python/xvapitch/util.py:14-53
+  segment()           util.py:166-178 ;  kl_loss()  VitsGeneratorLoss.kl_loss  python/xvapitch/losses.py:87-104
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _wn_weight(sd, pre):
+    v, g = sd[pre + "weight_v"], sd[pre + "weight_g"]
+    return g * v / v.reshape(v.size(0), -1).norm(dim=1).reshape(-1, 1, 1)          # torch.nn.utils.weight_norm (old API, dim 0)
+
+
+def wn(sd, x, x_mask, g=None, hidden=None, kernel_size=5, dilation_rate=1, num_layers=4, pre=""):
+    """x (B, H, T), x_mask (B, 1, T), g (B, c_in, 1) or None -> (B, H, T)."""
+    H = hidden or x.size(1)
+    output = torch.zeros_like(x)
+    if g is not None:
+        g = F.conv1d(g, _wn_weight(sd, pre + "cond_layer."), sd[pre + "cond_layer.bias"])
+    for i in range(num_layers):
+        d = dilation_rate ** i
+        x_in = F.conv1d(x, _wn_weight(sd, pre + "in_layers.%d." % i), sd[pre + "in_layers.%d.bias" % i], dilation=d, padding=(kernel_size * d - d) // 2)
+        g_l = g[:, i * 2 * H:(i + 1) * 2 * H, :] if g is not None else torch.zeros_like(x_in)
+        in_act = x_in + g_l
+        acts = torch.tanh(in_act[:, :H]) * torch.sigmoid(in_act[:, H:])
+        rs = F.conv1d(acts, _wn_weight(sd, pre + "res_skip_layers.%d." % i), sd[pre + "res_skip_layers.%d.bias" % i])
+        if i < num_layers - 1:
+            x = (x + rs[:, :H]) * x_mask
+            output = output + rs[:, H:]
+        else:
+            output = output + rs
+    return output * x_mask
+
+
+def coupling(sd, x, x_mask, g=None, reverse=False, **wn_args):
+    half = x.size(1) // 2
+    x0, x1 = x[:, :half], x[:, half:]
+    h = F.conv1d(x0, sd["pre.weight"], sd["pre.bias"]) * x_mask
+    h = wn(sd, h, x_mask, g, pre="enc.", **wn_args)
+    m = F.conv1d(h, sd["post.weight"], sd["post.bias"]) * x_mask
+    x1 = (x1 - m) * x_mask if reverse else m + x1 * x_mask
+    return torch.cat([x0, x1], 1)
+
+
+def maximum_path(value, mask):
+    """value, mask (B, t_x, t_y) numpy -> 0/1 path, the reference's loop."""
+    value = value * mask
+    mask = mask.astype(bool)
+    b, t_x, t_y = value.shape
+    direction = np.zeros(value.shape, dtype=np.int64)
+    v = np.zeros((b, t_x), dtype=np.float32)
+    x_range = np.arange(t_x, dtype=np.float32).reshape(1, -1)
+    for j in range(t_y):
+        v0 = np.pad(v, [[0, 0], [1, 0]], mode="constant", constant_values=-np.inf)[:, :-1]
+        max_mask = v >= v0
+        v_max = np.where(max_mask, v, v0)
+        direction[:, :, j] = max_mask
+        v = np.where(x_range <= j, v_max + value[:, :, j], -np.inf)
+    direction = np.where(mask, direction, 1)
+    path = np.zeros(value.shape, dtype=np.float32)
+    index = mask[:, :, 0].sum(1).astype(np.int64) - 1
+    rng = np.arange(b)
+    for j in reversed(range(t_y)):
+        path[rng, index, j] = 1
+        index = index + direction[rng, index, j] - 1
+    return path * mask.astype(np.float32)
+
+
+def segment(x, idx, S):
+    return torch.stack([x[i, :, int(idx[i]):int(idx[i]) + S] for i in range(x.size(0))])
+
+
+def kl_loss(z_p, logs_q, m_p, logs_p, z_mask):
+    kl = logs_p - logs_q - 0.5 + 0.5 * ((z_p - m_p) ** 2) * torch.exp(-2.0 * logs_p)
+    kl_sw = kl * z_mask
+    return kl_sw.sum() / z_mask.sum(), kl_sw

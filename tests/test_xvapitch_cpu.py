@@ -1,0 +1,74 @@
+"""CPU: oracle/xvapitch.py against the vectors recorded from the reference's xVAPitch modules (tests/golden/xvapitch_blocks.npz,
+written by oracle/gen_golden_xvapitch.py): WN with conditioning, the mean-only ResidualCouplingBlock (forward, reverse), maximum_path,
+segment, kl_loss — values and autograd gradients."""
+import os
+
+import numpy as np
+import torch
+
+
+def _g(golden_dir):
+    return np.load(os.path.join(golden_dir, "xvapitch_blocks.npz"))
+
+
+def _sd(g, pre):
+    return {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+
+
+def _mask(lens, T):
+    return (torch.arange(T)[None, :] < torch.as_tensor(lens)[:, None]).float().unsqueeze(1)
+
+
+def test_wn_oracle_matches_reference(golden_dir):
+    from oracle import xvapitch as oxv
+    g = _g(golden_dir)
+    B, H, T, CIN, L, K = [int(v) for v in g["wn_cfg"]]
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd(g, "wn_sd/").items()}
+    x = torch.from_numpy(g["wn_x"]).requires_grad_(True)
+    cond = torch.from_numpy(g["wn_g"]).requires_grad_(True)
+    y = oxv.wn(sd, x, _mask(g["wn_lens"], T), cond, hidden=H, kernel_size=K, dilation_rate=1, num_layers=L)
+    assert torch.allclose(y, torch.from_numpy(g["wn_y"]), rtol=1e-5, atol=1e-6)
+    (y * torch.from_numpy(g["wn_r"])).sum().backward()
+    assert torch.allclose(x.grad, torch.from_numpy(g["wn_dx"]), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(cond.grad, torch.from_numpy(g["wn_dg"]), rtol=1e-4, atol=1e-5)
+    for k, ref in _sd(g, "wn_grad/").items():
+        assert torch.allclose(sd[k].grad, ref, rtol=1e-3, atol=1e-5), k
+
+
+def test_coupling_oracle_matches_reference(golden_dir):
+    from oracle import xvapitch as oxv
+    g = _g(golden_dir)
+    B, CH, H, T, L, K = [int(v) for v in g["cp_cfg"]]
+    sd = _sd(g, "cp_sd/")
+    x = torch.from_numpy(g["cp_x"])
+    m = _mask(g["wn_lens"], T)
+    kw = dict(hidden=H, kernel_size=K, dilation_rate=1, num_layers=L)
+    assert torch.allclose(oxv.coupling(sd, x, m, **kw), torch.from_numpy(g["cp_y"]), rtol=1e-5, atol=1e-6)
+    rev = oxv.coupling(sd, x, m, reverse=True, **kw)
+    assert torch.allclose(rev, torch.from_numpy(g["cp_yrev"]), rtol=1e-5, atol=1e-6)
+    # the flow is invertible on the live positions: reverse(forward(x)) == x there (x1 is masked by both directions)
+    back = oxv.coupling(sd, oxv.coupling(sd, x, m, **kw), m, reverse=True, **kw)
+    half = CH // 2
+    assert torch.allclose(back[:, half:], x[:, half:] * m, rtol=1e-4, atol=1e-5) and torch.equal(back[:, :half], x[:, :half])
+
+
+def test_maximum_path_segment_kl_oracles(golden_dir):
+    from oracle import xvapitch as oxv
+    g = _g(golden_dir)
+    path = oxv.maximum_path(g["mp_value"], g["mp_mask"])
+    assert np.array_equal(path, g["mp_path"])
+    xl, yl = g["mp_mask"][:, :, 0].sum(1), g["mp_mask"][:, 0, :].sum(1)
+    for b in range(path.shape[0]):                       # a monotonic path: one text position per live frame, never moving back, ending on the last symbol
+        if xl[b] > yl[b]:
+            continue                                     # more symbols than frames (item 2: 12 x 12 is fine, item 3: 1 symbol): the DP cannot cover them all
+        cols = path[b, :, :int(yl[b])]
+        assert np.all(cols.sum(0) == 1)
+        pos = cols.argmax(0)
+        assert np.all(np.diff(pos) >= 0) and np.all(np.diff(pos) <= 1) and pos[-1] == xl[b] - 1
+    assert torch.equal(oxv.segment(torch.from_numpy(g["sg_x"]), g["sg_idx"], 4), torch.from_numpy(g["sg_out"]))
+    t4 = [torch.from_numpy(a).requires_grad_(True) for a in g["kl_in"]]
+    l, sw = oxv.kl_loss(*t4, torch.from_numpy(g["kl_mask"]))
+    assert abs(l.item() - float(g["kl_loss"])) < 1e-5 and torch.allclose(sw, torch.from_numpy(g["kl_sw"]), rtol=1e-5, atol=1e-6)
+    (l * 1.7).backward()
+    for t, ref in zip(t4, g["kl_grads"]):
+        assert torch.allclose(t.grad, torch.from_numpy(ref), rtol=1e-5, atol=1e-7)

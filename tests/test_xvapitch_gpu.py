@@ -1,0 +1,153 @@
+"""GPU: the xVAPitch-only blocks on libxvahip (xva-trainer_amd/xvapitch: WN gated stack, mean-only ResidualCouplingBlock, maximum_path,
+segment, kl_loss) against the vectors recorded from the reference's own modules (tests/golden/xvapitch_blocks.npz) — outputs and every
+gradient at 1e-3 in the exact-fp32 mode, index work bit-exact — and against the CPU oracle on other sizes; bf16 mode at a looser bound."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+
+
+def _g(golden_dir):
+    return np.load(os.path.join(golden_dir, "xvapitch_blocks.npz"))
+
+
+def _sd(g, pre):
+    return {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+
+
+def _mask(lens, T, device="cpu"):
+    return (torch.arange(T, device=device)[None, :] < torch.as_tensor(lens, device=device)[:, None]).float().unsqueeze(1)
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("compute,tol", [("fp32", RTOL), ("bf16", 3e-2)])
+def test_wn_against_reference_golden(golden_dir, compute, tol):
+    from xva_trainer_amd.xvapitch.wn import WN
+    g = _g(golden_dir)
+    B, H, T, CIN, L, K = [int(v) for v in g["wn_cfg"]]
+    wn = WN(H, H, K, 1, L, c_in_channels=CIN, compute=compute)
+    sd = _sd(g, "wn_sd/")
+    assert set(wn.state_dict()) == set(sd) and all(tuple(wn.state_dict()[k].shape) == tuple(v.shape) for k, v in sd.items())
+    wn.load_state_dict(sd)
+    x = torch.from_numpy(g["wn_x"]).cuda().requires_grad_(True)
+    cond = torch.from_numpy(g["wn_g"]).cuda().requires_grad_(True)
+    y = wn(x, _mask(g["wn_lens"], T, "cuda"), g=cond)
+    assert _rel(y, torch.from_numpy(g["wn_y"])) < tol
+    wn.zero_grad()
+    (y * torch.from_numpy(g["wn_r"]).cuda()).sum().backward()
+    assert _rel(x.grad, torch.from_numpy(g["wn_dx"])) < tol
+    assert _rel(cond.grad, torch.from_numpy(g["wn_dg"])) < tol
+    mine = wn.grads()
+    for k, ref in _sd(g, "wn_grad/").items():
+        assert _rel(mine[k], ref) < (tol if compute == "fp32" else 6e-2), k
+    if compute == "fp32":
+        dead = y[1, :, int(g["wn_lens"][1]):]
+        assert float(dead.abs().max()) == 0.0                       # output * x_mask
+
+
+def test_coupling_against_reference_golden(golden_dir):
+    from xva_trainer_amd.xvapitch.wn import ResidualCouplingBlock
+    g = _g(golden_dir)
+    B, CH, H, T, L, K = [int(v) for v in g["cp_cfg"]]
+    blk = ResidualCouplingBlock(CH, H, K, 1, L, mean_only=True, compute="fp32")
+    sd = _sd(g, "cp_sd/")
+    assert set(blk.state_dict()) == set(sd)
+    blk.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    m = _mask(g["wn_lens"], T, "cuda")
+    x = torch.from_numpy(g["cp_x"]).cuda().requires_grad_(True)
+    y, logdet = blk(x, m)
+    assert _rel(y, torch.from_numpy(g["cp_y"])) < RTOL and float(logdet.abs().max()) == 0.0
+    blk.zero_grad()
+    (y * torch.from_numpy(g["cp_r"]).cuda()).sum().backward()
+    assert _rel(x.grad, torch.from_numpy(g["cp_dx"])) < RTOL
+    mine = blk.grads()
+    for k, ref in _sd(g, "cp_grad/").items():
+        assert _rel(mine[k], ref) < RTOL, k
+    with torch.no_grad():
+        rev = blk(torch.from_numpy(g["cp_x"]).cuda(), m, reverse=True)
+    assert _rel(rev, torch.from_numpy(g["cp_yrev"])) < RTOL
+    with pytest.raises(NotImplementedError):
+        ResidualCouplingBlock(CH, H, K, 1, L, mean_only=False)
+
+
+def test_wn_against_oracle_xvapitch_shapes():
+    """The posterior-encoder / flow shape of xVAPitch (hidden 192, kernel 5, 4 layers) on a ragged batch, no conditioning."""
+    from oracle import xvapitch as oxv
+    from xva_trainer_amd.xvapitch.wn import WN
+    torch.manual_seed(3)
+    B, H, T, L, K = 3, 192, 210, 4, 5
+    wn = WN(H, H, K, 1, L, compute="fp32", seed=5)
+    sd = {k: v.cpu() for k, v in wn.state_dict().items()}
+    lens = [210, 151, 64]
+    x = torch.randn(B, H, T)
+    r = torch.randn(B, H, T)
+    xo = x.clone().requires_grad_(True)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = oxv.wn(sdo, xo, _mask(lens, T), None, hidden=H, kernel_size=K, dilation_rate=1, num_layers=L)
+    (yo * r).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = wn(xg, _mask(lens, T, "cuda"))
+    wn.zero_grad()
+    (y * r.cuda()).sum().backward()
+    assert _rel(y, yo) < RTOL and _rel(xg.grad, xo.grad) < RTOL
+    mine = wn.grads()
+    for k in sdo:
+        assert _rel(mine[k], sdo[k].grad) < 2e-3, k
+
+
+def test_maximum_path_segment_kl_against_reference_golden(golden_dir):
+    from xva_trainer_amd.xvapitch import ops
+    g = _g(golden_dir)
+    path = ops.maximum_path(torch.from_numpy(g["mp_value"]).cuda(), torch.from_numpy(g["mp_mask"]).cuda())
+    assert np.array_equal(path.cpu().numpy(), g["mp_path"])                                    # index work: bit-exact, ties included
+    x = torch.from_numpy(g["sg_x"]).cuda().requires_grad_(True)
+    seg = ops.segment(x, torch.from_numpy(g["sg_idx"]).cuda(), 4)
+    assert torch.equal(seg.cpu(), torch.from_numpy(g["sg_out"]))
+    w = torch.arange(seg.numel(), device="cuda", dtype=torch.float32).reshape(seg.shape)
+    (seg * w).sum().backward()
+    ref = torch.zeros_like(x)
+    for i, s in enumerate(g["sg_idx"]):
+        ref[i, :, int(s):int(s) + 4] = w[i]
+    assert torch.equal(x.grad, ref)
+    t4 = [torch.from_numpy(a).cuda().requires_grad_(True) for a in g["kl_in"]]
+    l, sw = ops.kl_loss(*t4, torch.from_numpy(g["kl_mask"]).cuda())
+    assert abs(l.item() - float(g["kl_loss"])) < RTOL * abs(float(g["kl_loss"])) and _rel(sw, torch.from_numpy(g["kl_sw"])) < 1e-5
+    (l * 1.7).backward()
+    for t, ref in zip(t4, g["kl_grads"]):
+        assert _rel(t.grad, torch.from_numpy(ref)) < 1e-5
+
+
+@pytest.mark.parametrize("B,tx,ty", [(1, 1, 1), (5, 64, 300), (8, 150, 860)])
+def test_maximum_path_against_oracle(B, tx, ty):
+    """Up to the C2 / C5 sizes (150 symbols x 860 frames), ragged lengths, quantised values so that ties occur."""
+    from oracle import xvapitch as oxv
+    from xva_trainer_amd.xvapitch import ops
+    rng = np.random.RandomState(B + tx)
+    xl = np.maximum(1, rng.randint(1, tx + 1, size=B)); xl[0] = tx
+    yl = np.array([max(int(x), int(rng.randint(1, ty + 1))) for x in xl]); yl = np.minimum(yl, ty); yl[0] = ty
+    xl = np.minimum(xl, yl)
+    mask = ((np.arange(tx)[None, :, None] < xl[:, None, None]) & (np.arange(ty)[None, None, :] < yl[:, None, None])).astype(np.float32)
+    value = (np.round(rng.randn(B, tx, ty) * 4) / 4).astype(np.float32)
+    ref = oxv.maximum_path(value, mask)
+    out = ops.maximum_path(torch.from_numpy(value).cuda(), torch.from_numpy(mask).cuda()).cpu().numpy()
+    assert np.array_equal(out, ref)
+    assert np.array_equal(out.sum(1)[mask[:, 0, :] > 0], np.ones(int(mask[:, 0, :].sum())))   # one symbol per live frame
+
+
+def test_rand_segments_draws_inside_the_clips():
+    from xva_trainer_amd.xvapitch import ops
+    torch.manual_seed(0)
+    x = torch.arange(4 * 3 * 50, dtype=torch.float32).reshape(4, 3, 50).cuda()
+    lens = torch.tensor([50, 32, 40, 33], device="cuda")
+    seg, idx = ops.rand_segments(x, lens, segment_size=32)
+    assert seg.shape == (4, 3, 32) and bool((idx >= 0).all()) and bool((idx + 32 <= lens).all())
+    for i in range(4):
+        assert torch.equal(seg[i], x[i, :, int(idx[i]):int(idx[i]) + 32])

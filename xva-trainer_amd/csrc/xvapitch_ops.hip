@@ -1,0 +1,388 @@
+// xvapitch_ops.hip — kernels of the xVAPitch-only blocks, first set: the WaveNet gate, the residual / skip
+// split, monotonic alignment search, segment gather / scatter and the KL term.
+//
+// Reference:
+//   fused_add_tanh_sigmoid_multiply, WN.forward       python/xvapitch/wavenet.py:5-12,92-109
+//   maximum_path                                      python/xvapitch/util.py:14-53   (numpy on the CPU, one D2H + H2D round trip per step)
+//   rand_segments / segment                           python/xvapitch/util.py:145-178
+//   VitsGeneratorLoss.kl_loss                         python/xvapitch/losses.py:87-104
+//
+// Sequence tensors follow the HiFi-GAN engine's convention: time-major (B, Tp = pad + T + pad, C), rows = time, channels
+// contiguous, pad rows structurally zero (they ARE the zero padding of the convolutions, which run on xva_gemm).  Everything
+// here is HBM-bound: one coalesced pass, 16-byte vectors where the element type allows.
+#include "xva_common.h"
+#include "../../include/xva_hip.h"
+#include <math.h>
+
+namespace {
+__device__ __forceinline__ float ld(const void* p, int64_t i, int dt) {
+    return dt == XVA_BF16 ? __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(p)[i] << 16) : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st(void* p, int64_t i, int dt, float v) {
+    if (dt == XVA_BF16) {
+        uint32_t u = __float_as_uint(v);
+        u += 0x7fffu + ((u >> 16) & 1u);                       // round to nearest even
+        reinterpret_cast<uint16_t*>(p)[i] = (uint16_t)(u >> 16);
+    } else reinterpret_cast<float*>(p)[i] = v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+}  // namespace
+
+// ---- WaveNet gate -----------------------------------------------------------------------------------------------------------------
+// acts[r][c] = tanh(a[r][c] + g[b][c]) * sigmoid(a[r][H + c] + g[b][H + c])      (wavenet.py:5-12)
+// a: (rows, 2H) the dilated conv's output; g: per-item conditioning (B, 2H; row stride g_ld) broadcast over time (the reference's cond_layer(g) has a
+// singleton time axis) or NULL; pad rows (outside [pad, pad + len)) produce 0.
+__global__ void wn_gate_fwd_kernel(const void* __restrict__ a, const float* __restrict__ g, void* __restrict__ acts, int dt, int64_t rows, int H,
+                                   int Tp, int64_t g_ld) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * H) return;
+    const int64_t r = idx / H;
+    const int c = (int)(idx - r * H);
+    const int b = (int)(r / Tp);
+    float ta = ld(a, r * 2 * H + c, dt), sa = ld(a, r * 2 * H + H + c, dt);
+    if (g) { ta += g[(int64_t)b * g_ld + c]; sa += g[(int64_t)b * g_ld + H + c]; }
+    st(acts, idx, dt, tanhf(ta) * sigmoidf_(sa));
+}
+// d_a[r][c] = d * s * (1 - t^2) ; d_a[r][H + c] = d * t * s * (1 - s) ; d_g[b][.] += the same summed over the item's rows (optional)
+__global__ void wn_gate_bwd_kernel(const void* __restrict__ a, const float* __restrict__ g, const void* __restrict__ d_acts, void* __restrict__ d_a,
+                                   int dt, int64_t rows, int H, int Tp, int64_t g_ld) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * H) return;
+    const int64_t r = idx / H;
+    const int c = (int)(idx - r * H);
+    const int b = (int)(r / Tp);
+    float ta = ld(a, r * 2 * H + c, dt), sa = ld(a, r * 2 * H + H + c, dt);
+    if (g) { ta += g[(int64_t)b * g_ld + c]; sa += g[(int64_t)b * g_ld + H + c]; }
+    const float t = tanhf(ta), s = sigmoidf_(sa), d = ld(d_acts, idx, dt);
+    st(d_a, r * 2 * H + c, dt, d * s * (1.f - t * t));
+    st(d_a, r * 2 * H + H + c, dt, d * t * s * (1.f - s));
+}
+extern "C" int xva_wn_gate_fwd(const void* a, const float* g, int64_t g_ld, void* acts, int dt, int B, int Tp, int H, void* stream) {
+    XVA_CHECK_ARG(a && acts && B > 0 && Tp > 0 && H > 0, "wn_gate_fwd: bad arguments");
+    const int64_t rows = (int64_t)B * Tp;
+    hipLaunchKernelGGL(wn_gate_fwd_kernel, dim3((unsigned)xva_cdiv(rows * H, 256)), dim3(256), 0, (hipStream_t)stream, a, g, acts, dt, rows, H, Tp, g_ld);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_wn_gate_bwd(const void* a, const float* g, int64_t g_ld, const void* d_acts, void* d_a, int dt, int B, int Tp, int H, void* stream) {
+    XVA_CHECK_ARG(a && d_acts && d_a && B > 0 && Tp > 0 && H > 0, "wn_gate_bwd: bad arguments");
+    const int64_t rows = (int64_t)B * Tp;
+    hipLaunchKernelGGL(wn_gate_bwd_kernel, dim3((unsigned)xva_cdiv(rows * H, 256)), dim3(256), 0, (hipStream_t)stream, a, g, d_acts, d_a, dt, rows, H, Tp, g_ld);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---- residual / skip split (wavenet.py:103-108) -------------------------------------------------------------------------------------
+// rs: (rows, 2H) (last layer: (rows, H)).  x_next = (x + rs[:, :H]) * mask (a new tensor: the layer's input is kept for its backward) ;
+// out += rs[:, H:]   (last: out += rs).  mask = live rows.
+__global__ void wn_res_skip_fwd_kernel(const void* __restrict__ rs, const void* __restrict__ x, void* __restrict__ x_next, void* __restrict__ out, int dt,
+                                       int64_t rows, int H, int last, const int32_t* __restrict__ lens, int Tp, int pad) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * H) return;
+    const int64_t r = idx / H;
+    const int c = (int)(idx - r * H);
+    const int b = (int)(r / Tp), t = (int)(r - (int64_t)b * Tp) - pad;
+    const bool live = t >= 0 && t < lens[b];
+    if (last) { st(out, idx, dt, ld(out, idx, dt) + (live ? ld(rs, r * H + c, dt) : 0.f)); return; }
+    st(x_next, idx, dt, live ? ld(x, idx, dt) + ld(rs, r * 2 * H + c, dt) : 0.f);
+    st(out, idx, dt, ld(out, idx, dt) + (live ? ld(rs, r * 2 * H + H + c, dt) : 0.f));
+}
+// d_rs[:, :H] = d_x * mask ; d_rs[:, H:] = d_out   (last: d_rs = d_out) ; d_x (the residual path) stays d_x * mask and receives the
+// in_layer's backward-data on top (done by the caller's GEMM with beta = 1).
+__global__ void wn_res_skip_bwd_kernel(const void* __restrict__ d_x, const void* __restrict__ d_out, void* __restrict__ d_rs, int dt, int64_t rows, int H,
+                                       int last, const int32_t* __restrict__ lens, int Tp, int pad) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * H) return;
+    const int64_t r = idx / H;
+    const int c = (int)(idx - r * H);
+    const int b = (int)(r / Tp), t = (int)(r - (int64_t)b * Tp) - pad;
+    const bool live = t >= 0 && t < lens[b];
+    const float dout = live ? ld(d_out, idx, dt) : 0.f;
+    if (last) { st(d_rs, r * H + c, dt, dout); return; }
+    st(d_rs, r * 2 * H + c, dt, live ? ld(d_x, idx, dt) : 0.f);
+    st(d_rs, r * 2 * H + H + c, dt, dout);
+}
+extern "C" int xva_wn_res_skip_fwd(const void* rs, const void* x, void* x_next, void* out, int dt, int B, int Tp, int pad, int H, int last, const int32_t* lens,
+                                   void* stream) {
+    XVA_CHECK_ARG(rs && out && lens && (last || (x && x_next)), "wn_res_skip_fwd: null");
+    const int64_t rows = (int64_t)B * Tp;
+    hipLaunchKernelGGL(wn_res_skip_fwd_kernel, dim3((unsigned)xva_cdiv(rows * H, 256)), dim3(256), 0, (hipStream_t)stream, rs, x, x_next, out, dt, rows, H, last,
+                       lens, Tp, pad);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_wn_res_skip_bwd(const void* d_x, const void* d_out, void* d_rs, int dt, int B, int Tp, int pad, int H, int last, const int32_t* lens,
+                                   void* stream) {
+    XVA_CHECK_ARG(d_out && d_rs && lens && (last || d_x), "wn_res_skip_bwd: null");
+    const int64_t rows = (int64_t)B * Tp;
+    hipLaunchKernelGGL(wn_res_skip_bwd_kernel, dim3((unsigned)xva_cdiv(rows * H, 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_out, d_rs, dt, rows, H, last,
+                       lens, Tp, pad);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---- monotonic alignment search (util.py:14-53) --------------------------------------------------------------------------------------
+// value (B, t_x, t_y) fp32, x_lens / y_lens (B): path (B, t_x, t_y) fp32 of 0 / 1 — the reference's numpy loop, all on the device
+// (no D2H / H2D round trip).  One workgroup per item, one thread per text position x; per mel frame j:
+//   v0[x] = v[x - 1] (-inf at x = 0), direction[x][j] = v[x] >= v0[x], v[x] <- (x <= j) ? max(v[x], v0[x]) + value[x][j] * mask : -inf
+// then one thread walks back from (x_len - 1, y_len - 1).  `dirs`: B * t_x * t_y bytes of scratch.  Ties resolve like the reference (>=).
+__global__ void maximum_path_kernel(const float* __restrict__ value, const int32_t* __restrict__ x_lens, const int32_t* __restrict__ y_lens,
+                                    float* __restrict__ path, uint8_t* __restrict__ dirs, int t_x, int t_y) {
+    extern __shared__ float v_sh[];                              // 2 * t_x floats (double buffer)
+    const int b = blockIdx.x;
+    const int xl = x_lens[b], yl = y_lens[b];
+    const float* val = value + (int64_t)b * t_x * t_y;
+    uint8_t* dir = dirs + (int64_t)b * t_x * t_y;
+    float* pth = path + (int64_t)b * t_x * t_y;
+    for (int64_t i = threadIdx.x; i < (int64_t)t_x * t_y; i += blockDim.x) pth[i] = 0.f;
+    for (int x = threadIdx.x; x < t_x; x += blockDim.x) v_sh[x] = 0.f;
+    __syncthreads();
+    int cur = 0;
+    for (int j = 0; j < t_y; ++j) {
+        float* vin = v_sh + cur * t_x;
+        float* vout = v_sh + (cur ^ 1) * t_x;
+        for (int x = threadIdx.x; x < t_x; x += blockDim.x) {
+            const float v1 = vin[x], v0 = x > 0 ? vin[x - 1] : -INFINITY;
+            const bool mm = v1 >= v0;
+            const bool m = x < xl && j < yl;
+            dir[(int64_t)x * t_y + j] = m ? (mm ? 1 : 0) : 1;     // direction = where(mask, direction, 1)
+            const float vm = mm ? v1 : v0;
+            vout[x] = x <= j ? vm + (m ? val[(int64_t)x * t_y + j] : 0.f) : -INFINITY;
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && xl > 0 && yl > 0) {
+        int index = xl - 1;
+        for (int j = t_y - 1; j >= 0; --j) {
+            if (index >= 0 && index < t_x) {
+                if (j < yl) pth[(int64_t)index * t_y + j] = 1.f;                           // path * mask
+                index = index + (int)dir[(int64_t)index * t_y + j] - 1;
+            }
+        }
+    }
+}
+extern "C" int64_t xva_maximum_path_workspace_bytes(int B, int t_x, int t_y) { return (int64_t)B * t_x * t_y; }
+extern "C" int xva_maximum_path(const float* value, const int32_t* x_lens, const int32_t* y_lens, float* path, void* workspace, int64_t workspace_bytes,
+                                int B, int t_x, int t_y, void* stream) {
+    XVA_CHECK_ARG(value && x_lens && y_lens && path && workspace && B > 0 && t_x > 0 && t_y > 0, "maximum_path: bad arguments");
+    XVA_CHECK_ARG(workspace_bytes >= (int64_t)B * t_x * t_y, "maximum_path: workspace too small");
+    XVA_CHECK_ARG(t_x <= 8192, "maximum_path: t_x %d > 8192", t_x);
+    hipLaunchKernelGGL(maximum_path_kernel, dim3(B), dim3(256), 2 * t_x * sizeof(float), (hipStream_t)stream, value, x_lens, y_lens, path,
+                       (uint8_t*)workspace, t_x, t_y);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---- segment gather / scatter (util.py:145-178) --------------------------------------------------------------------------------------
+// x (B, C, T) -> out (B, C, S): out[b, c, s] = x[b, c, idx[b] + s] (0 past T, like the zeros_like initialisation when a slice runs short)
+__global__ void segment_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, float* __restrict__ out, int C, int T, int S) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= C * S) return;
+    const int c = e / S, s = e - c * S;
+    const int64_t t = idx[b] + s;
+    out[((int64_t)b * C + c) * S + s] = (t >= 0 && t < T) ? x[((int64_t)b * C + c) * T + t] : 0.f;
+}
+// d_x (B, C, T) = 0 except d_x[b, c, idx[b] + s] = d_out[b, c, s]
+__global__ void segment_bwd_kernel(const float* __restrict__ d_out, const int64_t* __restrict__ idx, float* __restrict__ d_x, int C, int T, int S) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= C * T) return;
+    const int c = e / T, t = e - c * T;
+    const int64_t s = t - idx[b];
+    d_x[((int64_t)b * C + c) * T + t] = (s >= 0 && s < S) ? d_out[((int64_t)b * C + c) * S + s] : 0.f;
+}
+extern "C" int xva_segment_fwd(const float* x, const int64_t* idx, float* out, int B, int C, int T, int S, void* stream) {
+    XVA_CHECK_ARG(x && idx && out && B > 0 && C > 0 && T > 0 && S > 0, "segment_fwd: bad arguments");
+    hipLaunchKernelGGL(segment_fwd_kernel, dim3(xva_cdiv((long)C * S, 256), B), dim3(256), 0, (hipStream_t)stream, x, idx, out, C, T, S);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_segment_bwd(const float* d_out, const int64_t* idx, float* d_x, int B, int C, int T, int S, void* stream) {
+    XVA_CHECK_ARG(d_out && idx && d_x && B > 0 && C > 0 && T > 0 && S > 0, "segment_bwd: bad arguments");
+    hipLaunchKernelGGL(segment_bwd_kernel, dim3(xva_cdiv((long)C * T, 256), B), dim3(256), 0, (hipStream_t)stream, d_out, idx, d_x, C, T, S);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---- KL term of VitsGeneratorLoss (losses.py:87-104) -----------------------------------------------------------------------------------
+// kl = logs_p - logs_q - 0.5 + 0.5 (z_p - m_p)^2 exp(-2 logs_p) ; loss = sum(kl * mask) / sum(mask).  Tensors (B, H, T) fp32, mask (B, 1, T).
+// acc[0] += sum(kl * mask), acc[1] += sum(mask) (acc zeroed by the caller); kl_sample_wise written when non-null.
+__global__ void kl_fwd_kernel(const float* __restrict__ z_p, const float* __restrict__ logs_q, const float* __restrict__ m_p, const float* __restrict__ logs_p,
+                              const float* __restrict__ mask, float* __restrict__ kl_out, float* __restrict__ acc, int H, int T, int64_t n) {
+    __shared__ float sh[16];
+    float a = 0.f, ms = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t bt = i / ((int64_t)H * T);
+        const int t = (int)(i % T);
+        const float m = mask[bt * T + t];
+        const float d = z_p[i] - m_p[i];
+        const float kl = (logs_p[i] - logs_q[i] - 0.5f + 0.5f * d * d * __expf(-2.f * logs_p[i])) * m;
+        if (kl_out) kl_out[i] = kl;
+        a += kl;
+        ms += m;
+    }
+    a = xva_block_sum(a, sh);
+    ms = xva_block_sum(ms, sh);
+    if (threadIdx.x == 0) { atomicAdd(acc, a); atomicAdd(acc + 1, ms); }
+}
+// gradients of loss = acc[0] / acc[1] scaled by `gscale` (the upstream gradient x the loss weight)
+__global__ void kl_bwd_kernel(const float* __restrict__ z_p, const float* __restrict__ m_p, const float* __restrict__ logs_p, const float* __restrict__ mask,
+                              const float* __restrict__ acc, float gscale, float* __restrict__ d_z_p, float* __restrict__ d_logs_q, float* __restrict__ d_m_p,
+                              float* __restrict__ d_logs_p, int H, int T, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t bt = i / ((int64_t)H * T);
+    const int t = (int)(i % T);
+    const float k = gscale * mask[bt * T + t] / acc[1];
+    const float d = z_p[i] - m_p[i], e = __expf(-2.f * logs_p[i]);
+    if (d_z_p) d_z_p[i] = k * d * e;
+    if (d_m_p) d_m_p[i] = -k * d * e;
+    if (d_logs_q) d_logs_q[i] = -k;
+    if (d_logs_p) d_logs_p[i] = k * (1.f - d * d * e);
+}
+extern "C" int xva_kl_loss_fwd(const float* z_p, const float* logs_q, const float* m_p, const float* logs_p, const float* mask, float* kl_sample_wise,
+                               float* acc2, int B, int H, int T, void* stream) {
+    XVA_CHECK_ARG(z_p && logs_q && m_p && logs_p && mask && acc2, "kl_loss_fwd: null");
+    const int64_t n = (int64_t)B * H * T;
+    int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(kl_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z_p, logs_q, m_p, logs_p, mask, kl_sample_wise, acc2, H, T, n);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_kl_loss_bwd(const float* z_p, const float* m_p, const float* logs_p, const float* mask, const float* acc2, float gscale, float* d_z_p,
+                               float* d_logs_q, float* d_m_p, float* d_logs_p, int B, int H, int T, void* stream) {
+    XVA_CHECK_ARG(z_p && m_p && logs_p && mask && acc2, "kl_loss_bwd: null");
+    const int64_t n = (int64_t)B * H * T;
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3((unsigned)xva_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, z_p, m_p, logs_p, mask, acc2, gscale, d_z_p, d_logs_q,
+                       d_m_p, d_logs_p, H, T, n);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---- layout changes between the reference's (B, C, T) tensors and the time-major sequences the convolutions run on -----------------------
+// seq[b][pad + t][c] = x[b][c][t] * (t < lens[b]) ; pad rows are written as zeros too (the tensor needs no prior clearing)
+__global__ void bct_to_seq_kernel(const float* __restrict__ x, void* __restrict__ seq, int dt, int C, int T, int Tp, int pad, const int32_t* __restrict__ lens) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32 - pad, c0 = blockIdx.y * 32;   // tile rows (time incl. pads) x channels
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int len = lens ? lens[b] : T;
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, t = t0 + tx;
+        tile[r][tx] = (c < C && t >= 0 && t < T && t < len) ? x[((int64_t)b * C + c) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int tp = blockIdx.x * 32 + r, c = c0 + tx;
+        if (tp < Tp && c < C) st(seq, ((int64_t)b * Tp + tp) * C + c, dt, tile[tx][r]);
+    }
+}
+__global__ void seq_to_bct_kernel(const void* __restrict__ seq, float* __restrict__ x, int dt, int C, int T, int Tp, int pad, int accumulate) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, c = c0 + tx;
+        tile[r][tx] = (t < T && c < C) ? ld(seq, ((int64_t)b * Tp + pad + t) * C + c, dt) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, t = t0 + tx;
+        if (c < C && t < T) { float* d = x + ((int64_t)b * C + c) * T + t; *d = accumulate ? *d + tile[tx][r] : tile[tx][r]; }
+    }
+}
+extern "C" int xva_bct_to_seq(const float* x, void* seq, int dt, int B, int C, int T, int pad, const int32_t* lens, void* stream) {
+    XVA_CHECK_ARG(x && seq && B > 0 && C > 0 && T > 0 && pad >= 0, "bct_to_seq: bad arguments");
+    const int Tp = T + 2 * pad;
+    hipLaunchKernelGGL(bct_to_seq_kernel, dim3(xva_cdiv(Tp, 32), xva_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, seq, dt, C, T, Tp, pad, lens);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_seq_to_bct(const void* seq, float* x, int dt, int B, int C, int T, int pad, int accumulate, void* stream) {
+    XVA_CHECK_ARG(x && seq && B > 0 && C > 0 && T > 0 && pad >= 0, "seq_to_bct: bad arguments");
+    hipLaunchKernelGGL(seq_to_bct_kernel, dim3(xva_cdiv(T, 32), xva_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, seq, x, dt, C, T, T + 2 * pad, pad, accumulate);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---- sequence mask: zero every row outside [pad, pad + lens[b]) (the reference's `* x_mask` after a biased conv) -----------------------------
+__global__ void seq_mask_kernel(void* __restrict__ x, int dt, int64_t rows, int C, int Tp, int pad, const int32_t* __restrict__ lens) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * C) return;
+    const int64_t r = idx / C;
+    const int b = (int)(r / Tp), t = (int)(r - (int64_t)b * Tp) - pad;
+    if (!(t >= 0 && t < lens[b])) st(x, idx, dt, 0.f);
+}
+extern "C" int xva_seq_mask(void* x, int dt, int B, int Tp, int pad, int C, const int32_t* lens, void* stream) {
+    XVA_CHECK_ARG(x && lens && B > 0 && Tp > 0 && C > 0, "seq_mask: bad arguments");
+    const int64_t rows = (int64_t)B * Tp;
+    hipLaunchKernelGGL(seq_mask_kernel, dim3((unsigned)xva_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, dt, rows, C, Tp, pad, lens);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---- mean-only affine coupling (python/xvapitch/model.py:1519-1535, mean_only=True: log_scale = 0, logdet = 0) ------------------------------
+// forward: out[b][c][t] = stats[b][pad + t][c] + x1[b][c][t] * mask   (stats is the masked `post` conv output, time-major; x1 / out (B, Ch, T))
+// reverse: out = (x1 - m) * mask.   backward of forward: d_x1 = d_out * mask, d_stats[b][pad + t][c] = d_out[b][c][t] * mask (pads zero).
+__global__ void coupling_kernel(const void* __restrict__ stats, const float* __restrict__ x1, float* __restrict__ out, int dt, int Ch, int T, int Tp, int pad,
+                                const int32_t* __restrict__ lens, int reverse) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, c = c0 + tx;
+        tile[r][tx] = (t < T && c < Ch) ? ld(stats, ((int64_t)b * Tp + pad + t) * Ch + c, dt) : 0.f;
+    }
+    __syncthreads();
+    const int len = lens[b];
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, t = t0 + tx;
+        if (c < Ch && t < T) {
+            const int64_t i = ((int64_t)b * Ch + c) * T + t;
+            const float m = tile[tx][r], live = t < len ? 1.f : 0.f;
+            out[i] = reverse ? (x1[i] - m) * live : m + x1[i] * live;
+        }
+    }
+}
+extern "C" int xva_coupling_mean_only(const void* stats, const float* x1, float* out, int dt, int B, int Ch, int T, int pad, const int32_t* lens, int reverse,
+                                      void* stream) {
+    XVA_CHECK_ARG(stats && x1 && out && lens, "coupling: null");
+    hipLaunchKernelGGL(coupling_kernel, dim3(xva_cdiv(T, 32), xva_cdiv(Ch, 32), B), dim3(256), 0, (hipStream_t)stream, stats, x1, out, dt, Ch, T, T + 2 * pad,
+                       pad, lens, reverse);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// backward of the mean-only coupling: d_x1 (B, Ch, T) = d_out * mask ; d_stats[b][pad + t][c] = (reverse ? -1 : 1) * d_out[b][c][t] * mask (pads zero)
+__global__ void coupling_bwd_kernel(const float* __restrict__ d_out, float* __restrict__ d_x1, void* __restrict__ d_stats, int dt, int Ch, int T, int Tp, int pad,
+                                    const int32_t* __restrict__ lens, int reverse) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32 - pad, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int len = lens[b];
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, t = t0 + tx;
+        float v = 0.f;
+        if (c < Ch && t >= 0 && t < T) {
+            const int64_t i = ((int64_t)b * Ch + c) * T + t;
+            v = t < len ? d_out[i] : 0.f;
+            d_x1[i] = v;
+        }
+        tile[r][tx] = reverse ? -v : v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int tp = blockIdx.x * 32 + r, c = c0 + tx;
+        if (tp < Tp && c < Ch) st(d_stats, ((int64_t)b * Tp + tp) * Ch + c, dt, tile[tx][r]);
+    }
+}
+extern "C" int xva_coupling_mean_only_bwd(const float* d_out, float* d_x1, void* d_stats, int dt, int B, int Ch, int T, int pad, const int32_t* lens, int reverse,
+                                          void* stream) {
+    XVA_CHECK_ARG(d_out && d_x1 && d_stats && lens, "coupling_bwd: null");
+    const int Tp = T + 2 * pad;
+    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(xva_cdiv(Tp, 32), xva_cdiv(Ch, 32), B), dim3(256), 0, (hipStream_t)stream, d_out, d_x1, d_stats, dt, Ch, T, Tp, pad,
+                       lens, reverse);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
