@@ -221,7 +221,7 @@ __global__ void kl_fwd_kernel(const float* __restrict__ z_p, const float* __rest
         const float kl = (logs_p[i] - logs_q[i] - 0.5f + 0.5f * d * d * __expf(-2.f * logs_p[i])) * m;
         if (kl_out) kl_out[i] = kl;
         a += kl;
-        ms += m;
+        if ((i / T) % H == 0) ms += m;                         // sum(z_mask): the mask is (B, 1, T) — counted once per (b, t), not per channel
     }
     a = xva_block_sum(a, sh);
     ms = xva_block_sum(ms, sh);
