@@ -405,6 +405,13 @@ int xva_coupling_mean_only(const void* stats, const float* x1, float* out, int d
                            void* stream);
 int xva_coupling_mean_only_bwd(const float* d_out, float* d_x1, void* d_stats, int dt, int B, int Ch, int T, int pad, const int32_t* lens, int reverse,
                                void* stream);
+/* PosteriorEncoder's sampling (python/xvapitch/model.py:1470-1475): stats = masked `proj` output (B, pad + T + pad, 2 Co) = [mean | log_scale];
+ * z = (mean + eps * exp(log_scale)) * mask with eps (B, Co, T) the caller's N(0, 1) draw; mean / logs (B, Co, T).  bwd: d_stats from
+ * d_z / d_mean / d_logs (each may be NULL); pad rows of d_stats must already be zero. */
+int xva_posterior_sample(const void* stats, const float* eps, float* z, float* mean, float* logs, int dt, int B, int Co, int T, int pad,
+                         const int32_t* lens, void* stream);
+int xva_posterior_sample_bwd(const void* stats, const float* eps, const float* d_z, const float* d_mean, const float* d_logs, void* d_stats, int dt, int B,
+                             int Co, int T, int pad, const int32_t* lens, void* stream);
 /* (B, C, T) fp32 <-> time-major sequence (B, pad + T + pad, C) in dt; to_seq zeroes pads and positions t >= lens[b] (lens may be NULL);
  * to_bct overwrites or (accumulate) adds into x. */
 int xva_bct_to_seq(const float* x, void* seq, int dt, int B, int C, int T, int pad, const int32_t* lens, void* stream);

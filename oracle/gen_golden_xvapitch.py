@@ -42,6 +42,13 @@ def import_ref():
         ns = {"torch": torch, "nn": torch.nn, "WN": wavenet.WN}
         exec(compile(src[a:b], "model.py:ResidualCouplingBlock", "exec"), ns)          # executed in memory only; nothing of it is stored
         RCB = ns["ResidualCouplingBlock"]
+    src = open(os.path.join(ref_import.REF_ROOT, "python", "xvapitch", "model.py")).read()
+    a = src.index("class PosteriorEncoder(nn.Module):")
+    b = src.index("class ResidualCouplingBlock(nn.Module):")
+    ns3 = {"torch": torch, "nn": torch.nn, "WN": wavenet.WN, "sequence_mask": util.sequence_mask}
+    exec(compile(src[a:b], "model.py:PosteriorEncoder", "exec"), ns3)
+    global PosteriorEncoderRef
+    PosteriorEncoderRef = ns3["PosteriorEncoder"]
     # losses.py imports the whole model (text front end, espeak, ...) at module level: take VitsGeneratorLoss.kl_loss — a pure staticmethod —
     # from its source lines, again in memory only
     import textwrap
@@ -107,6 +114,29 @@ def main():
         out["cp_sd/" + k] = v.numpy()
     for k, v in pgc.items():
         out["cp_grad/" + k] = v.numpy()
+    # ---- PosteriorEncoder (linear-spectrogram bins -> z, m, logs): conditioned WN inside, the N(0, 1) draw pinned by the seed
+    CSP, CO = 40, 12
+    pe = PosteriorEncoderRef(CSP, CO, H, K, 1, 3, cond_channels=CIN)
+    for p in pe.parameters():
+        p.data += 0.05 * torch.randn_like(p)
+    xp = torch.rand(B, CSP, T, requires_grad=True)
+    gp = torch.randn(B, CIN, 1, requires_grad=True)
+    torch.manual_seed(77)
+    z, mean, logs, pm = pe(xp * 1.0, lens, g=gp)
+    torch.manual_seed(77)
+    eps = torch.randn(B, CO, T)
+    sdp = {k: v.detach().clone() for k, v in pe.state_dict().items()}
+    zo, mo, lo2, _ = oxv.posterior_encoder(sdp, xp, lens, gp, eps, CO, hidden=H, kernel_size=K, dilation_rate=1, num_layers=3)
+    assert torch.allclose(z, zo, rtol=1e-5, atol=1e-6) and torch.allclose(mean, mo, rtol=1e-5, atol=1e-6) and torch.allclose(logs, lo2, rtol=1e-5, atol=1e-6)
+    rz, rm, rl = torch.randn(B, CO, T), torch.randn(B, CO, T), torch.randn(B, CO, T)
+    pgp = grads_of(pe, (z * rz).sum() + (mean * rm).sum() + 0.5 * (logs * rl).sum())
+    out.update({"pe_cfg": np.array([B, CSP, CO, H, T, 3, K, CIN]), "pe_x": xp.detach().numpy(), "pe_g": gp.detach().numpy(), "pe_eps": eps.numpy(),
+                "pe_z": z.detach().numpy(), "pe_mean": mean.detach().numpy(), "pe_logs": logs.detach().numpy(), "pe_rz": rz.numpy(), "pe_rm": rm.numpy(),
+                "pe_rl": rl.numpy(), "pe_dx": xp.grad.numpy(), "pe_dg": gp.grad.numpy()})
+    for k, v in sdp.items():
+        out["pe_sd/" + k] = v.numpy()
+    for k, v in pgp.items():
+        out["pe_grad/" + k] = v.numpy()
     # ---- maximum_path
     b, tx, ty = 4, 17, 40
     xl, yl = torch.tensor([17, 9, 12, 1]), torch.tensor([40, 31, 12, 20])

@@ -4,6 +4,7 @@ Functional torch / numpy restatements driven by state_dicts with the REFERENCE's
 to the reference's own modules and records tests/golden/xvapitch_blocks.npz.
   wn()                WN.forward + fused_add_tanh_sigmoid_multiply   python/xvapitch/wavenet.py:5-12,92-109
   coupling()          ResidualCouplingBlock.forward (mean_only)      python/xvapitch/model.py:1519-1535
+  posterior_encoder() PosteriorEncoder.forward                       python/xvapitch/model.py:1462-1475
   maximum_path()      monotonic alignment search                     python/xvapitch/util.py:14-53
   segment()           util.py:166-178 ;  kl_loss()  VitsGeneratorLoss.kl_loss  python/xvapitch/losses.py:87-104
 """
@@ -46,6 +47,16 @@ def coupling(sd, x, x_mask, g=None, reverse=False, **wn_args):
     m = F.conv1d(h, sd["post.weight"], sd["post.bias"]) * x_mask
     x1 = (x1 - m) * x_mask if reverse else m + x1 * x_mask
     return torch.cat([x0, x1], 1)
+
+
+def posterior_encoder(sd, x, x_lengths, g, eps, out_channels, **wn_args):
+    """PosteriorEncoder.forward (model.py:1462-1475) with the N(0, 1) draw passed in.  Returns z, mean, log_scale, x_mask."""
+    x_mask = (torch.arange(x.size(2))[None, :] < x_lengths[:, None]).to(x.dtype).unsqueeze(1)
+    h = F.conv1d(x, sd["pre.weight"], sd["pre.bias"]) * x_mask
+    h = wn(sd, h, x_mask, g, pre="enc.", **wn_args)
+    stats = F.conv1d(h, sd["proj.weight"], sd["proj.bias"]) * x_mask
+    mean, log_scale = torch.split(stats, out_channels, dim=1)
+    return (mean + eps * torch.exp(log_scale)) * x_mask, mean, log_scale, x_mask
 
 
 def maximum_path(value, mask):

@@ -72,3 +72,13 @@ def test_maximum_path_segment_kl_oracles(golden_dir):
     (l * 1.7).backward()
     for t, ref in zip(t4, g["kl_grads"]):
         assert torch.allclose(t.grad, torch.from_numpy(ref), rtol=1e-5, atol=1e-7)
+
+
+def test_posterior_encoder_oracle_matches_reference(golden_dir):
+    from oracle import xvapitch as oxv
+    g = _g(golden_dir)
+    B, CSP, CO, H, T, L, K, CIN = [int(v) for v in g["pe_cfg"]]
+    z, mean, logs, _ = oxv.posterior_encoder(_sd(g, "pe_sd/"), torch.from_numpy(g["pe_x"]), torch.from_numpy(g["wn_lens"]), torch.from_numpy(g["pe_g"]),
+                                            torch.from_numpy(g["pe_eps"]), CO, hidden=H, kernel_size=K, dilation_rate=1, num_layers=L)
+    for a, k in ((z, "pe_z"), (mean, "pe_mean"), (logs, "pe_logs")):
+        assert torch.allclose(a, torch.from_numpy(g[k]), rtol=1e-5, atol=1e-6), k

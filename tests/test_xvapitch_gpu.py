@@ -151,3 +151,27 @@ def test_rand_segments_draws_inside_the_clips():
     assert seg.shape == (4, 3, 32) and bool((idx >= 0).all()) and bool((idx + 32 <= lens).all())
     for i in range(4):
         assert torch.equal(seg[i], x[i, :, int(idx[i]):int(idx[i]) + 32])
+
+
+def test_posterior_encoder_against_reference_golden(golden_dir):
+    """PosteriorEncoder (model.py:1427-1475): conv1x1 -> conditioned WN -> conv1x1 -> z = (m + eps * exp(logs)) * mask with the reference's own
+    N(0, 1) draw; z / m / logs and every gradient of a scalar over all three outputs."""
+    from xva_trainer_amd.xvapitch.wn import PosteriorEncoder
+    g = _g(golden_dir)
+    B, CSP, CO, H, T, L, K, CIN = [int(v) for v in g["pe_cfg"]]
+    pe = PosteriorEncoder(CSP, CO, H, K, 1, L, cond_channels=CIN, compute="fp32")
+    sd = _sd(g, "pe_sd/")
+    assert set(pe.state_dict()) == set(sd)
+    pe.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    x = torch.from_numpy(g["pe_x"]).cuda().requires_grad_(True)
+    cond = torch.from_numpy(g["pe_g"]).cuda().requires_grad_(True)
+    z, mean, logs, x_mask = pe(x, torch.from_numpy(g["wn_lens"]).cuda(), g=cond, eps=torch.from_numpy(g["pe_eps"]).cuda())
+    assert _rel(z, torch.from_numpy(g["pe_z"])) < RTOL and _rel(mean, torch.from_numpy(g["pe_mean"])) < RTOL and _rel(logs, torch.from_numpy(g["pe_logs"])) < RTOL
+    assert x_mask.shape == (B, 1, T) and int(x_mask.sum()) == int(g["wn_lens"].sum())
+    pe.zero_grad()
+    loss = (z * torch.from_numpy(g["pe_rz"]).cuda()).sum() + (mean * torch.from_numpy(g["pe_rm"]).cuda()).sum() + 0.5 * (logs * torch.from_numpy(g["pe_rl"]).cuda()).sum()
+    loss.backward()
+    assert _rel(x.grad, torch.from_numpy(g["pe_dx"])) < RTOL and _rel(cond.grad, torch.from_numpy(g["pe_dg"])) < RTOL
+    mine = pe.grads()
+    for k, ref in _sd(g, "pe_grad/").items():
+        assert _rel(mine[k], ref) < RTOL, k

@@ -386,3 +386,56 @@ extern "C" int xva_coupling_mean_only_bwd(const float* d_out, float* d_x1, void*
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
+
+// ---- posterior sampling (PosteriorEncoder.forward, python/xvapitch/model.py:1470-1475) ----------------------------------------------------
+// stats: masked `proj` output, time-major (B, pad + T + pad, 2 * Co) = [mean | log_scale]; eps (B, Co, T) the N(0, 1) draw (torch.randn_like in
+// the reference: supplied by the caller).  z = (mean + eps * exp(log_scale)) * mask ; mean / log_scale returned in (B, Co, T).
+__global__ void posterior_sample_kernel(const void* __restrict__ stats, const float* __restrict__ eps, float* __restrict__ z, float* __restrict__ mean,
+                                        float* __restrict__ logs, int dt, int Co, int T, int Tp, int pad, const int32_t* __restrict__ lens) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Co * T) return;
+    const int c = e / T, t = e - c * T;
+    const int64_t row = ((int64_t)b * Tp + pad + t) * 2 * Co;
+    const float m = ld(stats, row + c, dt), s = ld(stats, row + Co + c, dt);
+    const int64_t i = ((int64_t)b * Co + c) * T + t;
+    mean[i] = m; logs[i] = s;
+    z[i] = t < lens[b] ? m + eps[i] * __expf(s) : 0.f;
+}
+// d_stats[b][pad + t][c] = (d_mean + d_z) * mask' ; d_stats[..][Co + c] = d_logs + d_z * eps * exp(log_scale)   (d_z only on live positions; the
+// direct d_mean / d_logs terms are masked too: stats = proj(x) * mask)
+__global__ void posterior_sample_bwd_kernel(const void* __restrict__ stats, const float* __restrict__ eps, const float* __restrict__ d_z,
+                                            const float* __restrict__ d_mean, const float* __restrict__ d_logs, void* __restrict__ d_stats, int dt, int Co, int T,
+                                            int Tp, int pad, const int32_t* __restrict__ lens) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Co * T) return;
+    const int t = e / Co, c = e - t * Co;                      // channel-fastest: coalesced stores into the time-major gradient
+    const int64_t row = ((int64_t)b * Tp + pad + t) * 2 * Co;
+    const int64_t i = ((int64_t)b * Co + c) * T + t;
+    float gm = 0.f, gs = 0.f;
+    if (t < lens[b]) {
+        const float s = ld(stats, row + Co + c, dt);
+        const float dz = d_z ? d_z[i] : 0.f;
+        gm = dz + (d_mean ? d_mean[i] : 0.f);
+        gs = dz * eps[i] * __expf(s) + (d_logs ? d_logs[i] : 0.f);
+    }
+    st(d_stats, row + c, dt, gm);
+    st(d_stats, row + Co + c, dt, gs);
+}
+extern "C" int xva_posterior_sample(const void* stats, const float* eps, float* z, float* mean, float* logs, int dt, int B, int Co, int T, int pad,
+                                    const int32_t* lens, void* stream) {
+    XVA_CHECK_ARG(stats && eps && z && mean && logs && lens, "posterior_sample: null");
+    hipLaunchKernelGGL(posterior_sample_kernel, dim3(xva_cdiv((long)Co * T, 256), B), dim3(256), 0, (hipStream_t)stream, stats, eps, z, mean, logs, dt, Co, T,
+                       T + 2 * pad, pad, lens);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_posterior_sample_bwd(const void* stats, const float* eps, const float* d_z, const float* d_mean, const float* d_logs, void* d_stats, int dt,
+                                        int B, int Co, int T, int pad, const int32_t* lens, void* stream) {
+    XVA_CHECK_ARG(stats && eps && d_stats && lens, "posterior_sample_bwd: null");
+    hipLaunchKernelGGL(posterior_sample_bwd_kernel, dim3(xva_cdiv((long)Co * T, 256), B), dim3(256), 0, (hipStream_t)stream, stats, eps, d_z, d_mean, d_logs,
+                       d_stats, dt, Co, T, T + 2 * pad, pad, lens);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}

@@ -32,6 +32,10 @@ lib.xva_coupling_mean_only.restype = i32
 lib.xva_coupling_mean_only.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]
 lib.xva_coupling_mean_only_bwd.restype = i32
 lib.xva_coupling_mean_only_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]
+lib.xva_posterior_sample.restype = i32
+lib.xva_posterior_sample.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+lib.xva_posterior_sample_bwd.restype = i32
+lib.xva_posterior_sample_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
 lib.xva_hg_weight_norm_fwd.restype = i32
 lib.xva_hg_weight_norm_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
 lib.xva_hg_weight_norm_bwd.restype = i32
@@ -372,17 +376,107 @@ class _CouplingFn(torch.autograd.Function):
         d_stats = Seq(B, T, half, wn.device, wn.dtype)
         _lib.check(lib.xva_coupling_mean_only_bwd(_lib.ptr(d1), _lib.ptr(d_x1), C.c_void_p(d_stats.view.data_ptr()), d_stats.dt, B, half, T, PAD, _lib.ptr(lens),
                                                   int(reverse), _lib.stream_ptr()), "xva_coupling_mean_only_bwd")
-        dw_post = torch.zeros(half, hid, device=wn.device)
-        conv_bwd_weight(d_stats, hw, dw_post, blk.post.g["bias"], 1, 1, wn.compute)
-        blk.post.g["weight"] += dw_post.reshape(half, hid, 1)
+        conv_bwd_weight(d_stats, hw, blk.post.g["weight"].view(half, hid), blk.post.g["bias"], 1, 1, wn.compute)      # accumulates into the gradient
         d_hw = Seq(B, T, hid, wn.device, wn.dtype)
         conv_bwd_data(d_stats, blk.post.eff(), d_hw, 1, 1, wn.compute, accumulate=False)
         d_h, d_g = wn.backward_seq(d_hw)
         _lib.check(lib.xva_seq_mask(C.c_void_p(d_h.view.data_ptr()), d_h.dt, B, d_h.Tp, PAD, hid, _lib.ptr(lens), _lib.stream_ptr()), "xva_seq_mask")
-        dw_pre = torch.zeros(hid, half, device=wn.device)
-        conv_bwd_weight(d_h, x0s, dw_pre, blk.pre.g["bias"], 1, 1, wn.compute)
-        blk.pre.g["weight"] += dw_pre.reshape(hid, half, 1)
+        conv_bwd_weight(d_h, x0s, blk.pre.g["weight"].view(hid, half), blk.pre.g["bias"], 1, 1, wn.compute)
         d_x0s = Seq(B, T, half, wn.device, wn.dtype)
         conv_bwd_data(d_h, blk.pre.eff(), d_x0s, 1, 1, wn.compute, accumulate=False)
         d_x0 = ops.seq_to_bct(d_x0s.view, T, PAD, into=d_out[:, :half].float().contiguous())
         return torch.cat([d_x0, d_x1], 1), (d_g.reshape(B, -1, 1) if ctx.has_g else None), None, None, None
+
+
+class PosteriorEncoder:
+    """model.py:1427-1475: x -> conv1x1 `pre` -> WN (non-causal, conditioned) -> conv1x1 `proj` -> [m | log_scale] -> z = (m + eps * exp(log_scale)) * mask.
+    The input is the 513-bin linear spectrogram (xva-trainer_amd/mel.py:TorchSTFTMel.linear).  eps: the N(0, 1) draw (the reference calls
+    torch.randn_like inside forward; pass it for reproducibility, else it is drawn here)."""
+
+    def __init__(self, in_channels, out_channels, hidden_channels, kernel_size, dilation_rate, num_layers, cond_channels=0, device="cuda", compute="fp32", seed=0):
+        self.Cin, self.Co, self.hidden = in_channels, out_channels, hidden_channels
+        self.device = torch.device(device)
+        gen = torch.Generator().manual_seed(seed)
+        self.enc = WN(hidden_channels, hidden_channels, kernel_size, dilation_rate, num_layers, c_in_channels=cond_channels, device=device, compute=compute,
+                      seed=seed + 1)
+        self.pre = _PlainConv1x1(in_channels, hidden_channels, self.device, self.enc.dtype, gen)
+        self.proj = _PlainConv1x1(hidden_channels, 2 * out_channels, self.device, self.enc.dtype, gen)
+
+    def state_dict(self):
+        sd = {"pre." + n: t.clone() for n, t in self.pre.p.items()}
+        sd.update({"enc." + k: v for k, v in self.enc.state_dict().items()})
+        sd.update({"proj." + n: t.clone() for n, t in self.proj.p.items()})
+        return sd
+
+    def load_state_dict(self, sd):
+        for n in self.pre.p:
+            self.pre.p[n].copy_(sd["pre." + n])
+            self.proj.p[n].copy_(sd["proj." + n])
+        self.enc.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("enc.")})
+
+    def grads(self):
+        g = {"pre." + n: t for n, t in self.pre.g.items()}
+        g.update({"enc." + k: v for k, v in self.enc.grads().items()})
+        g.update({"proj." + n: t for n, t in self.proj.g.items()})
+        return g
+
+    def zero_grad(self):
+        self.enc.zero_grad()
+        for c in (self.pre, self.proj):
+            for t in c.g.values():
+                t.zero_()
+
+    def __call__(self, x, x_lengths, g=None, eps=None):
+        B, _, T = x.shape
+        lens = x_lengths.reshape(B).to(device=x.device, dtype=torch.int32).contiguous()
+        if eps is None:
+            eps = torch.randn(B, self.Co, T, device=x.device)
+        z, mean, logs = _PosteriorFn.apply(x, g, eps, self, lens)
+        x_mask = (torch.arange(T, device=x.device)[None, :] < lens[:, None]).to(x.dtype).unsqueeze(1)     # sequence_mask(x_lengths) as returned by the reference
+        return z, mean, logs, x_mask
+
+
+class _PosteriorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, eps, enc, lens):
+        _lib.require_cuda(x, eps)
+        B, Cin, T = x.shape
+        wn, Co, hid = enc.enc, enc.Co, enc.hidden
+        xs = Seq(B, T, Cin, wn.device, wn.dtype)
+        _lib.check(ops.lib.xva_bct_to_seq(_lib.ptr(x.float().contiguous()), C.c_void_p(xs.view.data_ptr()), xs.dt, B, Cin, T, PAD, None, _lib.stream_ptr()),
+                   "xva_bct_to_seq")
+        h = Seq(B, T, hid, wn.device, wn.dtype)
+        conv_fwd(xs, enc.pre.eff(), enc.pre.p["bias"], h, 1, 1, wn.compute)
+        _lib.check(lib.xva_seq_mask(C.c_void_p(h.view.data_ptr()), h.dt, B, h.Tp, PAD, hid, _lib.ptr(lens), _lib.stream_ptr()), "xva_seq_mask")
+        hw = wn.forward_seq(h, lens, g.reshape(B, -1) if g is not None else None)
+        stats = Seq(B, T, 2 * Co, wn.device, wn.dtype)
+        conv_fwd(hw, enc.proj.eff(), enc.proj.p["bias"], stats, 1, 1, wn.compute)
+        _lib.check(lib.xva_seq_mask(C.c_void_p(stats.view.data_ptr()), stats.dt, B, stats.Tp, PAD, 2 * Co, _lib.ptr(lens), _lib.stream_ptr()), "xva_seq_mask")
+        eps = eps.float().contiguous()
+        z, mean, logs = (torch.empty(B, Co, T, device=x.device) for _ in range(3))
+        _lib.check(lib.xva_posterior_sample(C.c_void_p(stats.view.data_ptr()), _lib.ptr(eps), _lib.ptr(z), _lib.ptr(mean), _lib.ptr(logs), stats.dt, B, Co, T, PAD,
+                                            _lib.ptr(lens), _lib.stream_ptr()), "xva_posterior_sample")
+        ctx.enc, ctx.lens, ctx.dims, ctx.has_g = enc, lens, (B, Cin, T), g is not None
+        ctx.saved = (xs, h, hw, stats, eps)
+        return z, mean, logs
+
+    @staticmethod
+    def backward(ctx, d_z, d_mean, d_logs):
+        enc, lens = ctx.enc, ctx.lens
+        B, Cin, T = ctx.dims
+        wn, Co, hid = enc.enc, enc.Co, enc.hidden
+        xs, h, hw, stats, eps = ctx.saved
+        d_stats = Seq(B, T, 2 * Co, wn.device, wn.dtype)
+        dz, dm, dl = (t.float().contiguous() if t is not None else None for t in (d_z, d_mean, d_logs))
+        _lib.check(lib.xva_posterior_sample_bwd(C.c_void_p(stats.view.data_ptr()), _lib.ptr(eps), _lib.ptr(dz), _lib.ptr(dm), _lib.ptr(dl),
+                                                C.c_void_p(d_stats.view.data_ptr()), d_stats.dt, B, Co, T, PAD, _lib.ptr(lens), _lib.stream_ptr()),
+                   "xva_posterior_sample_bwd")
+        conv_bwd_weight(d_stats, hw, enc.proj.g["weight"].view(2 * Co, hid), enc.proj.g["bias"], 1, 1, wn.compute)
+        d_hw = Seq(B, T, hid, wn.device, wn.dtype)
+        conv_bwd_data(d_stats, enc.proj.eff(), d_hw, 1, 1, wn.compute, accumulate=False)
+        d_h, d_g = wn.backward_seq(d_hw)
+        _lib.check(lib.xva_seq_mask(C.c_void_p(d_h.view.data_ptr()), d_h.dt, B, d_h.Tp, PAD, hid, _lib.ptr(lens), _lib.stream_ptr()), "xva_seq_mask")
+        conv_bwd_weight(d_h, xs, enc.pre.g["weight"].view(hid, Cin), enc.pre.g["bias"], 1, 1, wn.compute)
+        d_xs = Seq(B, T, Cin, wn.device, wn.dtype)
+        conv_bwd_data(d_h, enc.pre.eff(), d_xs, 1, 1, wn.compute, accumulate=False)
+        return ops.seq_to_bct(d_xs.view, T, PAD), (d_g.reshape(B, -1, 1) if ctx.has_g else None), None, None, None
