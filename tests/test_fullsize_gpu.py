@@ -146,3 +146,63 @@ def test_hifigan_full_size_discriminator_gradient_is_the_loss_derivative():
         lm = eng.disc_forward(flat - eps * v, y, yh)[0].item()
         fd = (lp - lm) / (2 * eps)
         assert abs(fd - gv) < 2e-2 * abs(gv), (trial, fd, gv)
+
+
+def test_hifigan_full_size_bf16_step_is_the_weighted_sum_of_its_items():
+    """The BENCHMARKED schedule — bf16, B = 64 x 8192, every engine call of the D + G iteration (generator forward / backward, the 8
+    discriminators' forward, D-step backward, G-step backward-data, the mel L1 gradient) — must be consistent with the regime the oracle
+    pins: every loss is a batch mean of per-item terms, so with a batch of 22 / 21 / 21 copies of three clips every gradient equals the
+    same weighted mean of the three single-clip (B = 1) gradients.  Tile shapes, split-K factors and resident-conv grids differ between B = 1 and
+    B = 64, i.e. the fp32 summation order inside a product differs, and an element that rounds to the other bf16 neighbour moves by 4e-3: through ~50
+    conv layers that leaves a few 1e-3 of L2 noise (the same effect tests/test_fastpitch_gpu.py quantifies), which is the bound used here."""
+    from oracle import hifigan as ohg
+    from xva_trainer_amd import mel as pmel
+    from xva_trainer_amd.hifigan import engine as HE
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    st = HifiganStep("cuda", "bf16")
+    st.load_state_dicts(ohg.init_generator_sd(1), ohg.init_mpd_sd(2), ohg.init_msd_sd(3))
+    u0 = st.flat_d.clone()                                   # the spectral-norm buffers advance with every forward: restore them per run
+    x3, y3, ym3 = [t.cuda() for t in ohg.synth_batch(3, 4)]
+    counts = [22, 21, 21]
+    rep = torch.tensor(sum(([i] * c for i, c in enumerate(counts)), []), device="cuda")
+
+    def run(x, y, ym):
+        eng = st.eng
+        st.flat_d.copy_(u0)
+        yg = eng.generator_forward(st.flat_g, x)
+        ld = eng.disc_forward(st.flat_d, y, yg, losses="d")
+        gd = torch.zeros_like(st.flat_d)
+        eng.disc_backward_d(st.flat_d, gd)
+        st.flat_d.copy_(u0)
+        lg = eng.disc_forward(st.flat_d, y, yg, losses="g")
+        d_wav = eng.disc_backward_g(st.flat_d)
+        lm, _ = pmel.mel_l1_loss_backward(yg, ym, d_wav, scale=45.0, accumulate=True)
+        gg = torch.zeros_like(st.flat_g)
+        eng.generator_backward(st.flat_g, gg, d_wav)
+        torch.cuda.synchronize()
+        return {"yg": yg.clone(), "ld": ld[0].item(), "lgen": lg[1].item(), "lfm": lg[2].item(), "lmel": lm[0].item(), "gd": gd, "gg": gg,
+                "d_wav": d_wav.clone()}
+
+    full = run(x3[rep].contiguous(), y3[rep].contiguous(), ym3[rep].contiguous())
+    assert full["yg"].shape == (64, 8192)
+    singles = [run(x3[i:i + 1].contiguous(), y3[i:i + 1].contiguous(), ym3[i:i + 1].contiguous()) for i in range(3)]
+    w = [c / 64.0 for c in counts]
+    for i, c in enumerate(counts):                            # per-item tensors: identical rows whatever the batch
+        j = sum(counts[:i])
+        assert ((full["yg"][j] - singles[i]["yg"][0]).norm() / singles[i]["yg"][0].norm()).item() < 5e-3
+        a, r = full["d_wav"][j] * 64.0, singles[i]["d_wav"][0]
+        assert ((a - r).norm() / r.norm()).item() < 5e-3, i
+    for k in ("ld", "lgen", "lfm", "lmel"):
+        ref = sum(wi * s[k] for wi, s in zip(w, singles))
+        assert abs(full[k] - ref) < 1e-3 * abs(ref), (k, full[k], ref)
+    nd, ng = st.eng.trainable[HE.D], st.eng.trainable[HE.G]
+    for key, n in (("gd", nd), ("gg", ng)):
+        ref = sum(wi * s[key][:n].double() for wi, s in zip(w, singles))
+        rel = ((full[key][:n].double() - ref).norm() / ref.norm()).item()
+        assert rel < 5e-3, (key, rel)
+        for which, tbl in ((HE.D, "gd"), (HE.G, "gg")):
+            if tbl != key:
+                continue
+            for b, e in HE.bucket_ranges(which):
+                nb = ref[b:e].norm().item()
+                assert ((full[key][b:e].double() - ref[b:e]).norm().item() / nb) < 1e-2, (key, b)
