@@ -99,9 +99,9 @@ int main(int argc, char** argv) {
                 if (variant == 1) { q.R = nullptr; q.mask_mode = XVA_MASK_NONE; q.bias = nullptr; }
                 if (variant == 2) { q.a_lrelu = 1; q.a_slope = 0.1f; }
                 snprintf(name, sizeof(name), "conv_res C=%d k=%d %s", C, k, variant == 0 ? "bias+R+mask" : (variant == 1 ? "bare epilogue" : "a_lrelu"));
-                if (C == 128) run(name, nb, [&] { launch_conv_res<XVA_GEMM_NT, 128, 128, 64, 64>(q, 2, d, 0); });
-                else if (C == 64) run(name, nb, [&] { launch_conv_res<XVA_GEMM_NT, 64, 64, 32, 64>(q, 2, d, 0); });
-                else run(name, nb, [&] { launch_conv_res<XVA_GEMM_NT, 32, 32, 32, 32>(q, 2, d, 0); });
+                if (C == 128) run(name, nb, [&] { launch_conv_res<XVA_GEMM_NT, 128, 128, 64, 64>(q, 2, d, 1, q.lda, 0); });
+                else if (C == 64) run(name, nb, [&] { launch_conv_res<XVA_GEMM_NT, 64, 64, 32, 64>(q, 2, d, 1, q.lda, 0); });
+                else run(name, nb, [&] { launch_conv_res<XVA_GEMM_NT, 32, 32, 32, 32>(q, 2, d, 1, q.lda, 0); });
             }
             hipFree(W);
         }
