@@ -112,10 +112,15 @@ typedef struct xva_gemm_params {
 /* Launches on `stream` (a hipStream_t); returns 0 or a negative XVA_ERR_* code. */
 int xva_gemm(const xva_gemm_params* p, void* stream);
 
-/* Diagnostics / test knob: main-loop selection for bf16-stored operands. -1 automatic (default), 0 general register-staged kernel,
+/* Diagnostics / test knob: main-loop selection for bf16-stored operands. -1 automatic (default), 0 general register-staged kernel, 8 the
+ * 256x128 tile with a 32-deep K tile (two workgroups per CU),
  * 1..5 direct-to-LDS 128x128 / 256x256 / 128x64 / 64x64 / 128x32 tiles wherever eligible, 6 automatic without the resident-input
  * convolution kernel, 7 the 384x128 tile (NT / NN). Returns the previous mode. Results are the same up to fp32 summation order. */
 int xva_gemm_set_mainloop(int mode);
+/* Diagnostics / test knob: K loop of the 256x256 direct-to-LDS tile. 0 = all waves in one phase (two barriers per 64-deep K tile),
+ * 1 = two wave groups one barrier apart over a ring of four 32-deep K tiles ({12 LDS reads + DMA | 32 MFMAs} phases), 2 (default) = 1 for
+ * the NT layout, 0 for NN / TN. Returns the previous mode. Same results up to fp32 summation order. */
+int xva_gemm_set_kloop(int mode);
 
 #ifdef __cplusplus
 }

@@ -31,18 +31,7 @@ SECONDS = [1.10, 0.30, 0.86, 0.52, 0.71]          # clip 1 is shorter than one H
 
 
 def import_data_modules():
-    ref_import._install_stubs()
-    for name in ("unidecode", "inflect"):
-        if name not in sys.modules:
-            m = types.ModuleType(name)
-            if name == "unidecode":
-                m.unidecode = lambda s: s
-            else:
-                m.engine = type("engine", (), {"number_to_words": lambda self, *a, **k: ""})
-            sys.modules[name] = m
-    if ref_import.REF_ROOT not in sys.path:
-        sys.path.insert(0, ref_import.REF_ROOT)
-    from python.fastpitch1_1.fastpitch import data_function as df
+    df = ref_import.import_data_function()
     from python.fastpitch1_1.common.text.text_processing import TextProcessing
     from python.fastpitch1_1.common.layers import TacotronSTFT
     from python.hifigan import meldataset as hm

@@ -11,6 +11,16 @@ import numpy as np
 import torch
 
 from oracle import fastpitch as ofp
+from oracle import golden_util as gu
+
+# gradient tensors stored in full (reference layout) next to the evenly spaced samples of ALL of them
+FULL_GRADS = [
+    "encoder.word_emb.weight", "encoder.layers.0.dec_attn.qkv_net.weight", "encoder.layers.0.dec_attn.o_net.weight",
+    "encoder.layers.5.dec_attn.qkv_net.weight", "encoder.layers.3.dec_attn.layer_norm.weight", "encoder.layers.3.pos_ff.layer_norm.bias",
+    "decoder.layers.0.dec_attn.qkv_net.weight", "decoder.layers.5.dec_attn.o_net.weight", "decoder.layers.2.pos_ff.CoreNet.0.bias",
+    "decoder.layers.2.pos_ff.CoreNet.2.bias", "pitch_emb.weight", "energy_emb.weight", "proj.weight", "proj.bias",
+    "duration_predictor.layers.0.conv.bias", "duration_predictor.fc.weight", "pitch_predictor.layers.1.norm.weight", "energy_predictor.fc.weight",
+]
 
 CASES = [
     # name, stage, B, T_text, T_mel, seed
@@ -83,6 +93,11 @@ def generate(ns, out_dir):
             "delta_l2": np.array([float((new_sd[k].double() - sd[k].double()).norm()) for k in keys]),
             "sd_checksum": np.array([float(sd[k].double().sum()) for k in sorted(sd)]),
         }
+        rec["grad_samples"], rec["grad_sample_off"] = gu.pack_samples(grads, keys)
+        full = [k for k in FULL_GRADS if k in grads]
+        rec["grad_full_keys"] = np.array(full)
+        for i, k in enumerate(full):
+            rec["grad_full_%d" % i] = grads[k].numpy()
         for k, v in batch.items():
             rec["in_" + k] = v.numpy()
         if stage == 2:
@@ -133,12 +148,8 @@ def generate_stage1(ns, out_dir):
     seed, B, Tt, Tm = 777, 3, 12, 40
     sd = ofp.init_state_dict(seed)
     batch = ofp.synth_batch(B, Tt, Tm, seed + 1)
-    try:   # the reference's own prior (data_function.py:84-94) when its module imports here; else the oracle's restatement of it
-        df = importlib.import_module("python.fastpitch1_1.fastpitch.data_function")
-        prior_fn, prior_src = df.beta_binomial_prior_distribution, "reference"
-    except Exception as e:
-        print("data_function not importable (%s): using the oracle's scipy.stats.betabinom restatement" % type(e).__name__)
-        prior_fn, prior_src = ofp.beta_binomial_prior, "oracle"
+    from oracle import ref_import
+    prior_fn, prior_src = ref_import.import_data_function().beta_binomial_prior_distribution, "reference"   # data_function.py:84-94
     prior = torch.zeros(B, int(batch["mel_lens"].max()), Tt)
     for b in range(B):
         L, M = int(batch["in_lens"][b]), int(batch["mel_lens"][b])

@@ -10,7 +10,19 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from oracle import golden_util as gu
 from oracle import hifigan as ohg
+
+# gradient tensors stored in full (checkpoint layout; "g." = generator, "mpd." / "msd." = discriminators), next to the samples of all 404
+FULL_GRADS = [
+    "g.ups.3.weight_v", "g.ups.2.weight_v", "g.resblocks.3.convs1.1.weight_v", "g.resblocks.8.convs2.2.weight_v",
+    "g.resblocks.11.convs1.0.weight_v", "g.resblocks.6.convs1.0.weight_v", "g.conv_post.weight_v", "g.conv_pre.bias",
+    "g.resblocks.0.convs1.0.weight_g",
+    "mpd.discriminators.0.convs.1.weight_v", "mpd.discriminators.3.convs.0.weight_v", "mpd.discriminators.4.conv_post.weight_v",
+    "mpd.discriminators.2.convs.4.bias", "mpd.discriminators.1.convs.3.weight_g",
+    "msd.discriminators.0.convs.0.weight_orig", "msd.discriminators.0.convs.2.weight_orig", "msd.discriminators.0.conv_post.weight_orig",
+    "msd.discriminators.1.convs.2.weight_v", "msd.discriminators.2.conv_post.weight_v", "msd.discriminators.2.convs.5.weight_g",
+]
 
 CASES = [("hg_step_b2", 2, 4321)]
 
@@ -102,5 +114,14 @@ def generate(ns, out_dir):
             "g_ups3_v_grad": ref_gg["ups.3.weight_v"].numpy(),
             "sd_checksum": np.array([float(sd[k].double().sum()) for sd in (g_sd, mpd_sd, msd_sd) for k in sorted(sd)]),
         }
+        rec["g_grad_samples"], rec["g_grad_sample_off"] = gu.pack_samples(ref_gg, gk, 1024)
+        rec["d_grad_samples"], rec["d_grad_sample_off"] = gu.pack_samples(ref_dg, dk, 1024)
+        both = dict(ref_dg)
+        both.update({"g." + k: v for k, v in ref_gg.items()})
+        full = [k for k in FULL_GRADS if k in both]
+        assert len(full) == len(FULL_GRADS), set(FULL_GRADS) - set(full)
+        rec["grad_full_keys"] = np.array(full)
+        for i, k in enumerate(full):
+            rec["grad_full_%d" % i] = both[k].numpy()
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
         print(name, ref_out)

@@ -80,6 +80,24 @@ def _install_stubs():
                 sys.modules[name] = m
 
 
+def import_data_function():
+    """The reference's fastpitch/data_function.py (TTSDataset, TTSCollate, batch_to_gpu, beta_binomial_prior_distribution): its text
+    front end additionally imports unidecode / inflect, absent from this image; neither is reached by the functions the generators call."""
+    import importlib
+    _install_stubs()
+    for name in ("unidecode", "inflect"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            if name == "unidecode":
+                m.unidecode = lambda s: s
+            else:
+                m.engine = type("engine", (), {"number_to_words": lambda self, *a, **k: ""})
+            sys.modules[name] = m
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    return importlib.import_module("python.fastpitch1_1.fastpitch.data_function")
+
+
 def import_reference():
     """Returns a namespace of the reference classes/functions the oracle is pinned against."""
     if not reference_available():

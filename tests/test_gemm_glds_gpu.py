@@ -14,12 +14,16 @@ def _lib():
     return _lib
 
 
-@pytest.fixture(params=[1, 2, 3, 4, 5, -1, 6, 7], ids=["tile128", "tile256", "tile128x64", "tile64", "tile128x32", "auto", "auto_no_resident_conv", "tile384x128"])
+# (mainloop mode, K loop of the 256x256 tile): 2/0 = two barriers per K tile, 2/1 = staggered wave groups; 8 = 256x128 tile with a 32-deep K tile
+@pytest.fixture(params=[(1, 1), (2, 1), (2, 0), (3, 1), (4, 1), (5, 1), (-1, 1), (6, 1), (7, 1), (8, 1)],
+                ids=["tile128", "tile256", "tile256_lockstep", "tile128x64", "tile64", "tile128x32", "auto", "auto_no_resident_conv", "tile384x128", "tile256x128k32"])
 def mainloop(request):
     L = _lib()
-    old = L.lib.xva_gemm_set_mainloop(request.param)
-    yield request.param
+    old = L.lib.xva_gemm_set_mainloop(request.param[0])
+    oldk = L.lib.xva_gemm_set_kloop(request.param[1])
+    yield request.param[0]
     L.lib.xva_gemm_set_mainloop(old)
+    L.lib.xva_gemm_set_kloop(oldk)
 
 
 def _bf(rows, cols, ld=None, scale=1.0):

@@ -17,7 +17,8 @@ def bench(fn, iters=20):
 
 
 def main():
-    modes = [int(a) for a in sys.argv[1:]] or [2, 7]
+    # "2:0" = mainloop mode 2 with K loop 0 (xva_gemm_set_kloop); a bare "2" keeps the default K loop (1)
+    modes = [tuple(int(v) for v in (a.split(":") + ["1"])[:2]) for a in sys.argv[1:]] or [(2, 0), (2, 1), (7, 1)]
     dt = torch.bfloat16
     R = 32 * 862
     x = torch.randn(R + 2, 384, device="cuda").to(dt); h = torch.randn(R + 2, 1536, device="cuda").to(dt)
@@ -50,15 +51,15 @@ def main():
         ("conv1 dW TN auto-sk", lambda: L.gemm(h[1:], x, dW1, 1536, 1152, R, 1536, 384, 1152, layout=L.GEMM_TN, compute=1, accumulate=True, splitk=0, sk_ws=ws), 2 * R * 1536 * 1152),
         ("conv2 dW TN auto-sk", lambda: L.gemm(x[1:], h, dW2, 384, 4608, R, 384, 1536, 4608, layout=L.GEMM_TN, compute=1, accumulate=True, splitk=0, sk_ws=ws), 2 * R * 384 * 4608),
     ]
-    print("%-24s" % "shape" + "".join("  mode %2d us / TF   " % m for m in modes))
+    print("%-24s" % "shape" + "".join("  mode %2d:%d us / TF " % m for m in modes))
     for name, fn, fl in cases:
         row = "%-24s" % name
         for m in modes:
-            L.lib.xva_gemm_set_mainloop(m)
+            L.lib.xva_gemm_set_mainloop(m[0]); L.lib.xva_gemm_set_kloop(m[1])
             ms = bench(fn)
             row += "  %8.1f / %6.1f " % (ms * 1e3, fl / ms / 1e9)
         print(row, flush=True)
-    L.lib.xva_gemm_set_mainloop(-1)
+    L.lib.xva_gemm_set_mainloop(-1); L.lib.xva_gemm_set_kloop(1)
 
 
 main()

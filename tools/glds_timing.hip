@@ -56,6 +56,13 @@ static void fastpitch_shapes() {
         xva_gemm_params p = base(); p.layout = XVA_GEMM_NT; p.A = x; p.B = W1; p.C = o1; p.M = R; p.N = 1536; p.K = 1152; p.lda = 384; p.ldb = 1152; p.ldc = 1536;
         p.bias = bias; p.act = XVA_ACT_RELU;
         run("FastPitch conv1 fwd 256x256", (long)((R + 255) / 256) * 6, [&] { launch_tile<XVA_GEMM_NT, 256, 256, 128, 64>(p, 2, 0); });
+        run("FastPitch conv1 fwd 256x256 staggered", (long)((R + 255) / 256) * 6, [&] { launch_tile8<XVA_GEMM_NT>(p, 2, 0); });
+        if (XVA_GLDS_ABLATE) {   // ablation builds: the full grid and one round only
+            xva_gemm_params q1 = p; q1.M = 256 * 42;
+            run("  staggered, 252 workgroups", 252, [&] { launch_tile8<XVA_GEMM_NT>(q1, 2, 0); });
+            run("  same, 252 workgroups", 252, [&] { launch_tile<XVA_GEMM_NT, 256, 256, 128, 64>(q1, 2, 0); });
+            return;
+        }
         run("FastPitch conv1 fwd 128x128", (long)((R + 127) / 128) * 12, [&] { launch_tile<XVA_GEMM_NT, 128, 128, 64, 64>(p, 2, 0); });
         xva_gemm_params q = p; q.M = 256 * 10;      // 60 workgroups: a quarter of the CUs busy
         run("  same, 60 workgroups only", 60, [&] { launch_tile<XVA_GEMM_NT, 256, 256, 128, 64>(q, 2, 0); });

@@ -5,7 +5,6 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 RD=${XVA_ROUND:-r02}
 O=$R/gpurun_out/final; mkdir -p $O
-cd $R && python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/${RD}_final_bench.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o b -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_final_bench_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_stats -name "*.db" | head -1) $O/${RD}_final_bench_kernel_stats.csv
@@ -28,4 +27,7 @@ json.dump({"csrc": bench.csrc_fingerprint(), "commit": "${XVA_COMMIT:-unknown}",
           open("$O/${RD}_${leg}_pmc_hbm_bytes.meta.json", "w"))
 PY
 done
+# the plain bench line last: its roofline.traffic reads the PMC tables just measured (same sources: fingerprint checked)
+cp $O/${RD}_*_pmc_hbm_bytes.csv $O/${RD}_*_pmc_hbm_bytes.meta.json $R/profiles/
+cd $R && python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/${RD}_final_bench.json
 ls -la $O

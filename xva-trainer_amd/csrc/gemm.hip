@@ -88,6 +88,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         else if (ntiles(0) * maxsk >= 256) glds_tile = 0;
         else glds_tile = 3;
         if (glds_env >= 1 && glds_env <= 5) glds_tile = glds_env - 1;
+        if (glds_env == 8) glds_tile = 6;                                // forced 256x128 (K tile 32, two workgroups per CU)
         if (glds_env == 7 && p.layout != XVA_GEMM_TN) glds_tile = 5;     // forced 384x128 (NT / NN)   // forced: 1 -> 128x128, 2 -> 256x256, 3 -> 128x64, 4 -> 64x64, 5 -> 128x32
         int bm; xva_gemm_glds_tile_dims(glds_tile, &bm, &bn);
         bn = bn * 1000 + bm;   // profile tag

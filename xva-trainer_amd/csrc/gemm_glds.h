@@ -43,6 +43,11 @@ static __device__ unsigned long long* g_glds_timing;
 #else
 #define XVA_T(i) do { } while (0)
 #endif
+// ablation of the 256x256 K loop for tools/glds_timing.hip (bit 0: no MFMAs, 1: no DMA inside the loop, 2: no fragment reads inside the
+// loop, 3: no epilogue); the product never defines it
+#ifndef XVA_GLDS_ABLATE
+#define XVA_GLDS_ABLATE 0
+#endif
 
 template <int N, int I = 0, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -611,6 +616,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
         }
     };
     auto mfma_all = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[NJ]) {
+        if constexpr (XVA_GLDS_ABLATE & 1) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(af[i]));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(bfr[j]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -627,23 +639,379 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
         const XVA_LDS uint8_t* At = smem + cur * BUF;
         const XVA_LDS uint8_t* Bt = At + A_BYTES;
         bf16x8 af[MI], bfr[NJ];
-        read_frags(At, Bt, 0, af, bfr);
+        if constexpr (XVA_GLDS_ABLATE & 4) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = __builtin_bit_cast(bf16x8, (f32x4){1.f * lane, 2.f, 3.f, 4.f * kt});
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8, (f32x4){1.f, 2.f * lane, 3.f, 4.f});
+        } else read_frags(At, Bt, 0, af, bfr);
         mfma_all(af, bfr);
-        read_frags(At, Bt, 1, af, bfr);
+        if constexpr (!(XVA_GLDS_ABLATE & 4)) read_frags(At, Bt, 1, af, bfr);
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): this wave's reads of the buffer are in registers
         __builtin_amdgcn_s_barrier();                            // A: the buffer of tile kt is free
-        const bool more = kt + 2 < kt_end;
+        const bool more = (XVA_GLDS_ABLATE & 2) ? false : kt + 2 < kt_end;
         if (more) issue(kt + 2, cur);
         mfma_all(af, bfr);
         if (more) __builtin_amdgcn_s_waitcnt(WAIT_YOUNGEST); else __builtin_amdgcn_s_waitcnt(0x0F70);   // tile kt + 1 has landed (tile kt + 2 may be in flight)
         __builtin_amdgcn_s_barrier();                            // B
     }
     XVA_T(2);
+    if constexpr (XVA_GLDS_ABLATE & 8) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else if (rows_epilogue_ok(p, vec_epi))
+        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks);
+    else
+        tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
+    XVA_T(3);
+}
+
+// ---- 32-deep K tiles -------------------------------------------------------------------------------------------------------------
+constexpr int GK3 = 32;
+__device__ __forceinline__ int kc32_f(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+template <int KIND, int ROWS, int NW>
+struct Loader32 {
+    static constexpr int NI = ROWS * GK3 * 2 / 1024 / NW;   // wave instructions (1024 bytes each) per wave per tile
+    int64_t off[NI];
+    int kk[NI];
+    __device__ __forceinline__ void init(int lane, int wave, int i0, int bound, int64_t ld, int cseglen, int64_t cseg0, int64_t csegstride,
+                                         int kseglen = 0, int64_t ksegadj = 0) {
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int Q = q * NW + wave;
+            if constexpr (KIND == KC) {
+                const int r = Q * 16 + (lane >> 2);
+                const int c = (lane & 3) ^ kc32_f(lane >> 2);
+                off[q] = (int64_t)min(i0 + r, bound - 1) * ld + c * 8 + (kseglen > 0 ? (int64_t)((c * 8) / kseglen) * ksegadj : 0);
+                kk[q] = c * 8;
+            } else {
+                constexpr int CPR = ROWS / 8;
+                constexpr int RPI = 64 / CPR;
+                const int pos = Q * RPI + lane / CPR;
+                const int pch = lane % CPR;
+                const int c = ic_chunk<ROWS>(pos, pch);
+                const int k = swap23(pos);
+                int col = min(i0 + c * 8, bound - 8);
+                int64_t cm = col;
+                if (cseglen > 0) cm = cseg0 + col + (int64_t)(col / cseglen) * csegstride;
+                off[q] = (kseglen > 0 ? (int64_t)(k / kseglen) * ksegadj + (int64_t)(k % kseglen) * ld : (int64_t)k * ld) + cm;
+                kk[q] = k;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(const uint16_t* base, int k0, int K, XVA_LDS uint8_t* tile, int wave) const {
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const uint16_t* src = (k0 + kk[q] < K) ? base + off[q] : reinterpret_cast<const uint16_t*>(g_zero_page);
+            __builtin_amdgcn_global_load_lds((const XVA_GLB void*)src, (XVA_LDS void*)(tile + (q * NW + wave) * 1024), 16, 0, 0);
+        }
+    }
+};
+struct KcReader32 {
+    uint32_t o;
+    __device__ __forceinline__ void init(int lane) { o = (lane & 15) * 64 + (((lane >> 4) ^ kc32_f(lane & 15)) * 16); }
+    __device__ __forceinline__ bf16x8 read(const XVA_LDS uint8_t* tile, int row0) const {
+        return *reinterpret_cast<const XVA_LDS bf16x8*>(tile + row0 * 64 + o);
+    }
+};
+
+
+// ---- 256 x 256 tile, staggered wave groups -----------------------------------------------------------------------------------------
+// Same operands and epilogues as xva_gemm_glds_kernel<256, 256, 128, 64>; a different K loop.  There, the barriers keep all 8 waves in
+// the same phase: every SIMD first waits for its two waves' LDS fragment reads (measured 0.5 us per 64-deep K tile) and then runs their
+// MFMAs (0.97 us) — the sum, not the maximum (tools/glds_timing.hip ablations: MFMAs alone 17.5 us per 18 tiles, reads + DMA + barriers
+// alone 16.7, everything 30.8).  Here the two row halves of the tile (wave groups wm = 0 / 1; each SIMD holds one wave of either) run ONE
+// BARRIER APART: a phase is {read the 12 fragments of a 32-deep K tile, issue the DMA of tile kt + 3 | barrier | 32 MFMAs | barrier},
+// and group 1 enters the loop through one extra barrier, so that between any two barriers one group computes while the other reads LDS
+// and issues DMA — the matrix pipe of a SIMD alternates between its two waves instead of idling through the reads.
+// LDS: a ring of four 32-deep tiles (4 x 32 KiB): three tiles = 96 k in flight.  Hazards (interval I(2t+1): group 0 reads tile t, group 1
+// computes tile t - 1; I(2t+2): group 1 reads tile t, group 0 computes it):
+//   * tile t - 1 is last read in I(2t) and every read slot ends with lgkmcnt(0) before its barrier; tile t + 3 is written to its slot
+//     from I(2t+1) on: after a barrier every reader has passed;
+//   * tile t + 1 is first read in I(2t+3); every wave waits for its own tile t + 1 loads (vmcnt leaves tiles t + 2, t + 3 outstanding) in
+//     its read slot of tile t (I(2t+1) / I(2t+2)), i.e. before a barrier the first reader passes.
+template <int LAYOUT>
+__global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params p, int vec_epi) {
+    constexpr int BM = 256, BN = 256, WM = 128, WN = 64;
+    constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
+    constexpr int MI = WM / 16, NJ = WN / 16;
+    constexpr int AK = LAYOUT == XVA_GEMM_TN ? IC : KC;
+    constexpr int BKD = LAYOUT == XVA_GEMM_NT ? KC : IC;
+    constexpr int A_BYTES = BM * GK3 * 2, B_BYTES = BN * GK3 * 2, BUF = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem_raw[];
+    XVA_LDS uint8_t* smem = (XVA_LDS uint8_t*)smem_raw;
+
+    const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
+    int Lg;
+    {
+        const unsigned total = gridDim.x, id = blockIdx.x;
+        const unsigned xcd = id & 7u, slot = id >> 3, q = total >> 3, r = total & 7u;
+        Lg = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot);
+    }
+    const int tn = Lg % nbx, tm = (Lg / nbx) % nby, z = Lg / (nbx * nby);
+    const int bz = z / p.splitk, ks = z - bz * p.splitk;
+    const int b2n = p.batch2 > 1 ? p.batch2 : 1;
+    const int z1 = bz / b2n, z2 = bz - z1 * b2n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + (int64_t)z1 * p.sA + (int64_t)z2 * p.sA2;
+    const uint16_t* B = reinterpret_cast<const uint16_t*>(p.B) + (int64_t)z1 * p.sB + (int64_t)z2 * p.sB2;
+
+    const int tpb = p.kb_len > 0 ? (p.kb_len + GK3 - 1) / GK3 : 1;
+    const int nkt_total = p.kb_len > 0 ? (p.K / p.kb_len) * tpb : (p.K + GK3 - 1) / GK3;
+    const int per = (nkt_total + p.splitk - 1) / p.splitk;
+    const int kt_begin = ks * per;
+    const int kt_end = min(nkt_total, kt_begin + per);
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    XVA_T(0);
+
+    Loader32<AK, BM, NW> la;
+    Loader32<BKD, BN, NW> lb;
+    if constexpr (AK == KC) la.init(lane, wave, m0, p.M, p.lda, 0, 0, 0, p.a_seglen, p.a_segadj);
+    else la.init(lane, wave, m0, p.M, p.lda, p.a_seglen, 0, p.a_segadj);
+    if constexpr (BKD == KC) lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0);
+    else if constexpr (LAYOUT == XVA_GEMM_TN) lb.init(lane, wave, n0, p.N, p.ldb, p.seglen, p.seg0, p.segstride);
+    else lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0, p.seglen, p.segstride);
+
+    auto issue = [&](int kt, int slot) {
+        XVA_LDS uint8_t* st = smem + slot * BUF;
+        if constexpr (LAYOUT == XVA_GEMM_TN) {
+            if (p.kb_len > 0) {
+                const int blk = kt / tpb, kl = (kt - blk * tpb) * GK3;
+                la.issue(A + (int64_t)blk * p.kb_sA + (int64_t)kl * p.lda, kl, p.kb_len, st, wave);
+                lb.issue(B + (int64_t)blk * p.kb_sB + (int64_t)kl * p.ldb, kl, p.kb_len, st + A_BYTES, wave);
+                return;
+            }
+        }
+        const int k0 = kt * GK3;
+        if constexpr (AK == KC) la.issue(A + k0 + (p.a_seglen > 0 ? (int64_t)(k0 / p.a_seglen) * p.a_segadj : 0), k0, p.K, st, wave);
+        else la.issue(A + (int64_t)k0 * p.lda, k0, p.K, st, wave);
+        const uint16_t* bb;
+        if constexpr (BKD == KC) bb = B + k0;
+        else if constexpr (LAYOUT == XVA_GEMM_NN)
+            bb = p.seglen > 0 ? B + p.seg0 + (int64_t)(k0 / p.seglen) * p.segstride + (int64_t)(k0 % p.seglen) * p.ldb : B + (int64_t)k0 * p.ldb;
+        else bb = B + (int64_t)k0 * p.ldb;
+        lb.issue(bb, k0, p.K, st + A_BYTES, wave);
+    };
+
+    KcReader32 kra, krb;
+    IcReader<BM, MI> ira;
+    IcReader<BN, NJ> irb;
+    if constexpr (AK == KC) kra.init(lane); else ira.init(lane, wm * WM);
+    if constexpr (BKD == KC) krb.init(lane); else irb.init(lane, wn * WN);
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int LOADS = Loader32<AK, BM, NW>::NI + Loader32<BKD, BN, NW>::NI;      // DMA instructions per wave per 32-deep tile (4)
+    static_assert(2 * LOADS < 16, "vmcnt immediates below");
+    constexpr int WAIT_VM2 = 0x0F70 | (2 * LOADS), WAIT_VM1 = 0x0F70 | LOADS, WAIT_VM0 = 0x0F70;
+#define XVA_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    const int ntl = kt_end - kt_begin;
+    if (ntl > 0) issue(kt_begin, 0);
+    if (ntl > 1) issue(kt_begin + 1, 1);
+    if (ntl > 2) issue(kt_begin + 2, 2);
+    if (ntl > 2) __builtin_amdgcn_s_waitcnt(WAIT_VM2); else if (ntl > 1) __builtin_amdgcn_s_waitcnt(WAIT_VM1); else __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+    XVA_BAR();
+    if (wm == 1) XVA_BAR();                                      // group 1 runs one barrier behind group 0
+    XVA_T(1);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int slot = (kt - kt_begin) & 3;
+        const XVA_LDS uint8_t* At = smem + slot * BUF;
+        const XVA_LDS uint8_t* Bt = At + A_BYTES;
+        bf16x8 af[MI], bfr[NJ];
+        if constexpr (XVA_GLDS_ABLATE & 4) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = __builtin_bit_cast(bf16x8, (f32x4){1.f * lane, 2.f, 3.f, 4.f * kt});
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8, (f32x4){1.f, 2.f * lane, 3.f, 4.f});
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (BKD == KC) bfr[j] = krb.read(Bt, wn * WN + j * 16);
+                else bfr[j] = irb.read(Bt, j, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if constexpr (AK == KC) af[i] = kra.read(At, wm * WM + i * 16);
+                else af[i] = ira.read(At, i, 0);
+            }
+        }
+        const int ahead = (XVA_GLDS_ABLATE & 2) ? 0 : kt_end - kt;     // tiles left including this one
+        if (ahead > 3) { issue(kt + 3, (slot + 3) & 3); __builtin_amdgcn_s_waitcnt(WAIT_VM2); }
+        else if (ahead > 2) __builtin_amdgcn_s_waitcnt(WAIT_VM1);
+        else __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+        if (p.a_lrelu) {                                         // one uniform branch per read slot
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
+        }
+        if (p.b_lrelu) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag(bfr[j], p.b_slope);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+        XVA_BAR();
+        if constexpr (XVA_GLDS_ABLATE & 1) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(af[i]));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(bfr[j]));
+        } else {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        XVA_BAR();
+    }
+    if (wm == 0) XVA_BAR();
+#undef XVA_BAR
+    XVA_T(2);
     if (rows_epilogue_ok(p, vec_epi))
         tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks);
     else
         tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
     XVA_T(3);
+}
+
+// ---- 256 x 128 tile, K tile 32, three LDS stages, TWO workgroups per CU ------------------------------------------------------------
+// The 256 x 256 kernels hold one workgroup per CU: nothing runs under its 9 us epilogue (all 256 workgroups of a round store their
+// 128 KiB at the same time), under its prologue, or while its waves sit at a barrier.  Here a workgroup is 4 waves (one per SIMD) with
+// the same 128 x 64 wave tile (same LDS bytes per flop), a 32-deep K tile of (256 + 128) rows = 24 KiB and a ring of three of them
+// (72 KiB), so that TWO independent workgroups share a CU: each SIMD holds one wave of either, their barriers and epilogues are not
+// synchronised, and whatever one workgroup waits for, the other's MFMAs fill.  Two K tiles (64 k) are in flight, one barrier per tile.
+// KC image: [ROWS][32 k] bf16 = 64-byte rows, 16-byte chunk c of row r at position c ^ f(r), f(r) = (4 - ((r >> 2) & 3)) & 3: the four
+// 16-lane groups of a ds_read_b128 fragment read ({rows v, 12 + v: chunk c}, {rows 4 + v, 8 + v: chunk c ^ 1}) each cover the 64 banks once.
+// IC image: the first 32 k-rows of the 64-deep image above (same swizzles, same transpose reads).
+template <int LAYOUT, int BM, int BN>
+__global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void xva_gemm_glds3_kernel(xva_gemm_params p, int vec_epi) {
+    constexpr int WM = 128, WN = 64;
+    constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
+    static_assert(NW == 4, "4 waves");
+    constexpr int MI = WM / 16, NJ = WN / 16;
+    constexpr int AK = LAYOUT == XVA_GEMM_TN ? IC : KC;
+    constexpr int BKD = LAYOUT == XVA_GEMM_NT ? KC : IC;
+    constexpr int A_BYTES = BM * GK3 * 2, B_BYTES = BN * GK3 * 2, BUF = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem_raw[];
+    XVA_LDS uint8_t* smem = (XVA_LDS uint8_t*)smem_raw;
+
+    const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
+    int Lg;
+    {
+        const unsigned total = gridDim.x, id = blockIdx.x;
+        const unsigned xcd = id & 7u, slot = id >> 3, q = total >> 3, r = total & 7u;
+        Lg = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot);
+    }
+    const int tn = Lg % nbx, tm = (Lg / nbx) % nby, z = Lg / (nbx * nby);
+    const int bz = z / p.splitk, ks = z - bz * p.splitk;
+    const int b2n = p.batch2 > 1 ? p.batch2 : 1;
+    const int z1 = bz / b2n, z2 = bz - z1 * b2n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + (int64_t)z1 * p.sA + (int64_t)z2 * p.sA2;
+    const uint16_t* B = reinterpret_cast<const uint16_t*>(p.B) + (int64_t)z1 * p.sB + (int64_t)z2 * p.sB2;
+
+    const int tpb = p.kb_len > 0 ? (p.kb_len + GK3 - 1) / GK3 : 1;
+    const int nkt_total = p.kb_len > 0 ? (p.K / p.kb_len) * tpb : (p.K + GK3 - 1) / GK3;
+    const int per = (nkt_total + p.splitk - 1) / p.splitk;
+    const int kt_begin = ks * per;
+    const int kt_end = min(nkt_total, kt_begin + per);
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+
+    Loader32<AK, BM, NW> la;
+    Loader32<BKD, BN, NW> lb;
+    if constexpr (AK == KC) la.init(lane, wave, m0, p.M, p.lda, 0, 0, 0, p.a_seglen, p.a_segadj);
+    else la.init(lane, wave, m0, p.M, p.lda, p.a_seglen, 0, p.a_segadj);
+    if constexpr (BKD == KC) lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0);
+    else if constexpr (LAYOUT == XVA_GEMM_TN) lb.init(lane, wave, n0, p.N, p.ldb, p.seglen, p.seg0, p.segstride);
+    else lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0, p.seglen, p.segstride);
+
+    auto issue = [&](int kt, int slot) {
+        XVA_LDS uint8_t* st = smem + slot * BUF;
+        if constexpr (LAYOUT == XVA_GEMM_TN) {
+            if (p.kb_len > 0) {
+                const int blk = kt / tpb, kl = (kt - blk * tpb) * GK3;
+                la.issue(A + (int64_t)blk * p.kb_sA + (int64_t)kl * p.lda, kl, p.kb_len, st, wave);
+                lb.issue(B + (int64_t)blk * p.kb_sB + (int64_t)kl * p.ldb, kl, p.kb_len, st + A_BYTES, wave);
+                return;
+            }
+        }
+        const int k0 = kt * GK3;
+        if constexpr (AK == KC) la.issue(A + k0 + (p.a_seglen > 0 ? (int64_t)(k0 / p.a_seglen) * p.a_segadj : 0), k0, p.K, st, wave);
+        else la.issue(A + (int64_t)k0 * p.lda, k0, p.K, st, wave);
+        const uint16_t* bb;
+        if constexpr (BKD == KC) bb = B + k0;
+        else if constexpr (LAYOUT == XVA_GEMM_NN)
+            bb = p.seglen > 0 ? B + p.seg0 + (int64_t)(k0 / p.seglen) * p.segstride + (int64_t)(k0 % p.seglen) * p.ldb : B + (int64_t)k0 * p.ldb;
+        else bb = B + (int64_t)k0 * p.ldb;
+        lb.issue(bb, k0, p.K, st + A_BYTES, wave);
+    };
+
+    KcReader32 kra, krb;
+    IcReader<BM, MI> ira;
+    IcReader<BN, NJ> irb;
+    if constexpr (AK == KC) kra.init(lane); else ira.init(lane, wm * WM);
+    if constexpr (BKD == KC) krb.init(lane); else irb.init(lane, wn * WN);
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int LOADS = Loader32<AK, BM, NW>::NI + Loader32<BKD, BN, NW>::NI;
+    constexpr int WAIT_YOUNGEST = 0x0F70 | (LOADS & 15) | ((LOADS >> 4) << 14);
+    if (kt_begin < kt_end) issue(kt_begin, 0);
+    if (kt_begin + 1 < kt_end) issue(kt_begin + 1, 1);
+    int slot = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        if (kt + 1 < kt_end) __builtin_amdgcn_s_waitcnt(WAIT_YOUNGEST); else __builtin_amdgcn_s_waitcnt(0x0F70);   // tile kt has landed (this wave's part)
+        __builtin_amdgcn_s_barrier();           // ... every wave's part; and every wave has read tile kt - 1 out of its slot
+        if (kt + 2 < kt_end) issue(kt + 2, slot >= 1 ? slot - 1 : 2);
+        const XVA_LDS uint8_t* At = smem + slot * BUF;
+        const XVA_LDS uint8_t* Bt = At + A_BYTES;
+        bf16x8 af[MI], bfr[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if constexpr (BKD == KC) bfr[j] = krb.read(Bt, wn * WN + j * 16);
+            else bfr[j] = irb.read(Bt, j, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if constexpr (AK == KC) af[i] = kra.read(At, wm * WM + i * 16);
+            else af[i] = ira.read(At, i, 0);
+        }
+        if (p.a_lrelu) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
+        }
+        if (p.b_lrelu) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag(bfr[j], p.b_slope);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): the slot's fragments are in registers before this wave reaches the next barrier
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    __builtin_amdgcn_s_barrier();               // the epilogue scratch overlays the ring
+    if (rows_epilogue_ok(p, vec_epi))
+        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks);
+    else
+        tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
 }
 
 // ---- stride-1 convolution with a RESIDENT input tile ------------------------------------------------------------------------
@@ -798,6 +1166,34 @@ inline int launch_conv_res(const xva_gemm_params& p, int vec_epi, int dstep, int
     }
     long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, 128) * p.batch * p.batch2;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, st, p, vec_epi, dstep, stride, rowpitch);
+    return 0;
+}
+
+template <int LAYOUT, int BM, int BN>
+inline int launch_tile3(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
+    constexpr int LDS = 3 * (BM + BN) * GK3 * 2;
+    auto kern = xva_gemm_glds3_kernel<LAYOUT, BM, BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+        attr_set = true;
+    }
+    long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, BM) * p.batch * p.batch2 * p.splitk;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, st, p, vec_epi);
+    return 0;
+}
+
+template <int LAYOUT>
+inline int launch_tile8(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
+    constexpr int LDS = 4 * (256 + 256) * GK3 * 2;
+    auto kern = xva_gemm_glds8_kernel<LAYOUT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+        attr_set = true;
+    }
+    long nblocks = (long)xva_cdiv(p.N, 256) * xva_cdiv(p.M, 256) * p.batch * p.batch2 * p.splitk;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(512), LDS, st, p, vec_epi);
     return 0;
 }
 

@@ -75,6 +75,12 @@ bool xva_gemm_glds_eligible(const xva_gemm_params& p) {
 }
 
 static int launch_tiles(const xva_gemm_params& p, int tile, int vec, hipStream_t st);
+// K loop of the 256 x 256 tile: 0 = all waves in one phase (two barriers per 64-deep K tile), 1 = two wave groups one barrier apart
+// (xva_gemm_glds8_kernel), 2 (default) = the latter for NT only.  Measured (tools/gemm_tile_ab.py, tools/glds_timing.hip): NT +2 % (K = 1152)
+// ... +18 % (8192^2 x 4096), NN / TN -7 ... -15 % (their transpose reads make the read slot longer than the other group's 32 MFMAs);
+// in the training steps mode 2 is worth 0.5 - 0.7 %.  env XVA_GEMM_KLOOP8
+static int g_kloop8 = [] { const char* e = getenv("XVA_GEMM_KLOOP8"); return e ? atoi(e) : 2; }();
+extern "C" int xva_gemm_set_kloop(int mode) { int old = g_kloop8; g_kloop8 = mode; return old; }
 static int vec_epilogue_ok(const xva_gemm_params& p);
 
 // tile: see launch_tiles
@@ -115,17 +121,31 @@ static int launch_layout(const xva_gemm_params& p, int vec, hipStream_t st) {
 //       4 = 128x32 (4 waves of 32x32), 5 = 384x128 (8 waves of 96x64; NT / NN only: a 384-wide index-contiguous operand image is not laid out)
 static int launch_tiles(const xva_gemm_params& p, int tile, int vec, hipStream_t st) {
     switch (tile) {
-        case 1: return launch_layout<256, 256, 128, 64>(p, vec, st);
+        case 1:
+            if (g_kloop8 == 1 || (g_kloop8 == 2 && p.layout == XVA_GEMM_NT)) {
+                switch (p.layout) {
+                    case XVA_GEMM_NT: return xva_glds::launch_tile8<XVA_GEMM_NT>(p, vec, st);
+                    case XVA_GEMM_NN: return xva_glds::launch_tile8<XVA_GEMM_NN>(p, vec, st);
+                    default: return xva_glds::launch_tile8<XVA_GEMM_TN>(p, vec, st);
+                }
+            }
+            return launch_layout<256, 256, 128, 64>(p, vec, st);
         case 2: return launch_layout<128, 64, 32, 64>(p, vec, st);
         case 3: return launch_layout<64, 64, 32, 32>(p, vec, st);
         case 4: return launch_layout<128, 32, 32, 32>(p, vec, st);       // N <= 32: no padded columns through the matrix pipe
         case 5: return launch_layout<384, 128, 96, 64>(p, vec, st);      // 256 < N <= 384 (FastPitch d_model): no padded columns, one workgroup per CU
+        case 6:                                                          // 256x128, K tile 32, two workgroups per CU
+            switch (p.layout) {
+                case XVA_GEMM_NT: return xva_glds::launch_tile3<XVA_GEMM_NT, 256, 128>(p, vec, st);
+                case XVA_GEMM_NN: return xva_glds::launch_tile3<XVA_GEMM_NN, 256, 128>(p, vec, st);
+                default: return xva_glds::launch_tile3<XVA_GEMM_TN, 256, 128>(p, vec, st);
+            }
         default: return launch_layout<128, 128, 64, 64>(p, vec, st);
     }
 }
 void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn) {
-    static const int d[6][2] = {{128, 128}, {256, 256}, {128, 64}, {64, 64}, {128, 32}, {384, 128}};
-    *bm = d[tile % 6][0]; *bn = d[tile % 6][1];
+    static const int d[7][2] = {{128, 128}, {256, 256}, {128, 64}, {64, 64}, {128, 32}, {384, 128}, {256, 128}};
+    *bm = d[tile % 7][0]; *bn = d[tile % 7][1];
 }
 
 static int vec_epilogue_ok(const xva_gemm_params& p) {
