@@ -331,6 +331,12 @@ int xva_hg_generator_forward(const xva_hg_dims* d, const float* params_g, const 
 /* d_wav: (B, seg) fp32 gradient w.r.t. the generated waveform; accumulates into grads_g */
 int xva_hg_generator_backward(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* workspace,
                               int64_t workspace_bytes, void* stream);
+/* Test / diagnostics: byte offset (into the caller's workspace) and geometry {nseq, T, C, padF, padB} of an activation tensor the last
+ * forward stored, time-major (nseq, padF + T + padB, C) in the activation dtype.  kind: 0 mel input, 1 conv_pre output, 2 u[i0] (ups
+ * output), 3 lrelu(u[i0]), 4 xt1[resblock i0][m i1] (= lrelu(c1(lrelu(x))), models.py:43-45), 5 / 6 x after block m and its lrelu copy,
+ * 7 xs[i0] (mean of the three resblocks, :118-123), 8 the waveform, 9 MPD period i0 tensor i1 (0 = folded input), 10 MSD scale i0 set i1
+ * tensor i2. */
+int xva_hg_slot(const xva_hg_dims* d, int kind, int i0, int i1, int i2, int64_t* off_bytes, int32_t* geom5);
 /* Data-parallel variants (the reference's nn.DataParallel reduce step, python/fastpitch1_1/xva_train.py:48-53; HiFi-GAN's
  * unused dist_config in python/hifigan/config_v1.json:32-36): the flat gradient buffer `which` splits into
  * xva_hg_num_buckets(which) contiguous buckets listed in backward-completion order; the *_ex backward records

@@ -60,6 +60,18 @@ def test_against_reference_golden(golden_dir, case):
     for name in mine:
         if name not in have:
             assert mine[name].abs().max().item() == 0.0, name + " must not receive a gradient in stage %d" % stage
+    # ... an evenly spaced sample of up to 2048 elements of EVERY gradient tensor, and a list of tensors in full (element-wise)
+    from oracle import golden_util as gu
+    errs = gu.check_samples(mine, keys, g["grad_samples"], g["grad_sample_off"])
+    assert errs[0][0] < 2e-3, errs[:5]
+    full = [str(k) for k in g["grad_full_keys"]]
+    assert len(full) >= (10 if stage != 2 else 3)
+    for i, k in enumerate(full):
+        ref = torch.from_numpy(g["grad_full_%d" % i])
+        got = mine[k].cpu()
+        assert got.shape == ref.shape, k
+        assert rel(got, ref) < 2e-3, (k, rel(got, ref))
+        assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-9, k
     if stage != 2:
         assert rel(mine["proj.weight"], torch.from_numpy(g["g_proj_weight"])) < RTOL
         assert rel(mine["encoder.layers.0.pos_ff.CoreNet.0.weight"][:8], torch.from_numpy(g["g_enc0_ffn0_w_slice"])) < 2e-3

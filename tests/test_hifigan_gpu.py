@@ -210,6 +210,22 @@ def test_full_step_against_reference_golden(golden_dir):
     assert errs[0][0] < 5e-3
     assert _nrel(gg["conv_post.weight_v"], torch.from_numpy(g["g_conv_post_v_grad"])) < 1e-2
     assert _nrel(gg["ups.3.weight_v"], torch.from_numpy(g["g_ups3_v_grad"])) < 1e-2
+    # an evenly spaced sample of up to 1024 elements of EVERY gradient tensor (404 of them), and 20 tensors in full, element-wise
+    from oracle import golden_util as gu
+    errs = gu.check_samples(gg, g["g_grad_keys"], g["g_grad_samples"], g["g_grad_sample_off"], 1024)
+    print("worst sampled G gradients:", errs[:3])
+    assert errs[0][0] < 1e-2 and errs[len(errs) // 2][0] < 2e-3
+    errs = gu.check_samples(dg, g["d_grad_keys"], g["d_grad_samples"], g["d_grad_sample_off"], 1024)
+    print("worst sampled D gradients:", errs[:3])
+    assert errs[0][0] < 5e-3
+    full = [str(k) for k in g["grad_full_keys"]]
+    assert len(full) >= 20
+    for i, k in enumerate(full):
+        ref = torch.from_numpy(g["grad_full_%d" % i])
+        got = (gg[k[2:]] if k.startswith("g.") else dg[k]).cpu()
+        assert got.shape == ref.shape, k
+        assert _nrel(got, ref) < 1e-2, (k, _nrel(got, ref))
+        assert (got - ref).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-9, k
     sd = st.state_dicts()
     assert _nrel(sd["msd"]["discriminators.0.convs.0.weight_u"], torch.from_numpy(g["msd_u0_after"])) < 1e-3
 
@@ -227,3 +243,121 @@ def test_adamw_kernel_matches_oracle():
         opt.step(gsd.cuda())
     torch.cuda.synchronize()
     assert torch.allclose(flat.cpu(), ref["p"], rtol=1e-5, atol=1e-7)
+
+
+BF16_LAYER = 1e-3     # teacher-forced: one layer, one rounding; what is left is fp32-vs-fp64 summation order (rare 1-ulp flips)
+
+
+def _tm(x):
+    """engine slot (nseq, T, C) -> (nseq, C, T) fp64 on the CPU"""
+    return x.float().cpu().double().permute(0, 2, 1).contiguous()
+
+
+def test_bf16_generator_layer_by_layer_against_the_storage_oracle(golden_dir):
+    """Throughput mode (bf16-stored activations and effective weights) of the whole generator, checked TEACHER-FORCED: every one of its
+    78 layers (conv_pre, 4 ConvTranspose1d, 72 resblock convolutions, conv_post — models.py:95-128) is restated on the CPU
+    (oracle/hifigan.py `layer_*`: fp64 products of the same bf16 operands, one rounding where the engine stores) from the engine's own
+    stored input of that layer and compared with the engine's stored output."""
+    import os
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    g = np.load(os.path.join(golden_dir, "hg_step_b2.npz"))
+    seed = int(g["seed"])
+    sd = ohg.init_generator_sd(seed)
+    st = HifiganStep("cuda", "bf16")
+    st.load_state_dicts(sd, ohg.init_mpd_sd(seed + 1), ohg.init_msd_sd(seed + 2))
+    eng = st.eng
+    x_mel = torch.from_numpy(g["x_mel"])
+    wav = eng.generator_forward(st.flat_g, x_mel.cuda())
+    torch.cuda.synchronize()
+    worst = []
+
+    def chk(name, got, ref):
+        r = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+        worst.append((r, name))
+        assert r < BF16_LAYER, (name, r)
+
+    xin = _tm(eng.slot("mel"))
+    assert torch.equal(xin, ohg.bf16r(x_mel))                                                   # the input is stored rounded
+    chk("conv_pre", _tm(eng.slot("h0")), ohg.bf16r(ohg.layer_conv(xin, ohg.wn_weight(sd, "conv_pre."), sd["conv_pre.bias"], padding=3)))
+    prev = _tm(eng.slot("h0"))
+    for i in range(4):
+        u, ua = _tm(eng.slot("u", i)), _tm(eng.slot("ua", i))
+        ru, rua = ohg.layer_ups(sd, i, prev)
+        chk("ups.%d" % i, u, ru)
+        chk("ups.%d (activated copy)" % i, ua, rua)
+        acc = None
+        for j in range(3):
+            rb = i * 3 + j
+            xcur, xact = u, ua
+            for m in range(3):
+                xt1 = _tm(eng.slot("xt1", rb, m))
+                chk("resblocks.%d.convs1.%d" % (rb, m), xt1, ohg.layer_res_c1(sd, rb, m, xact))
+                v = ohg.layer_res_c2(sd, rb, m, xt1, xcur)
+                if m < 2:
+                    xn, xna = _tm(eng.slot("xr", rb, m)), _tm(eng.slot("xra", rb, m))
+                    chk("resblocks.%d.convs2.%d" % (rb, m), xn, ohg.bf16r(v))
+                    chk("resblocks.%d.convs2.%d (activated copy)" % (rb, m), xna, ohg.bf16r(ohg.lrelu64(v)))
+                    xcur, xact = xn, xna
+                else:   # xs = sum_j resblock_j / 3 (:118-123): the stage tensor accumulates in its stored dtype
+                    acc = ohg.bf16r(v / 3) if acc is None else ohg.bf16r(acc + v / 3)
+        xs = _tm(eng.slot("xs", i))
+        chk("stage %d mean of the resblocks" % i, xs, acc)
+        prev = xs
+    a = ohg.bf16r(ohg.lrelu64(prev, float(torch.tensor(0.01, dtype=torch.float32))))
+    y = torch.tanh(ohg.layer_conv(a, ohg.wn_weight(sd, "conv_post."), sd["conv_post.bias"], padding=3))
+    chk("conv_post + tanh", wav.cpu().double().unsqueeze(1), ohg.bf16r(y))                      # the waveform tensor is an activation: stored bf16
+    worst.sort(reverse=True)
+    print("bf16 generator, teacher-forced: worst layers", worst[:4], "of", len(worst))
+    assert len(worst) >= 1 + 8 + 36 + 24 + 24 + 4 + 1
+
+
+def test_bf16_discriminator_layers_against_the_storage_oracle(golden_dir):
+    """Same for the discriminators: every GEMM-path layer of the five period discriminators (convs.1-4 + conv_post, models.py:146-166) and of
+    the three scale discriminators (convs.1-6 + conv_post, :210-231; scale 0 spectral-normed: its two passes see the weights after
+    one / two power iterations, :244-253) from the engine's stored layer inputs."""
+    import os
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    g = np.load(os.path.join(golden_dir, "hg_step_b2.npz"))
+    seed = int(g["seed"])
+    mpd_sd, msd_sd = ohg.init_mpd_sd(seed + 1), ohg.init_msd_sd(seed + 2)
+    st = HifiganStep("cuda", "bf16")
+    st.load_state_dicts(ohg.init_generator_sd(seed), mpd_sd, msd_sd)
+    eng = st.eng
+    y = torch.from_numpy(g["y_wav"]).cuda()
+    y_g = torch.from_numpy(g["y_g_hat"]).squeeze(1).cuda()
+    eng.disc_forward(st.flat_d, y, y_g)
+    torch.cuda.synchronize()
+    worst = []
+
+    def chk(name, got, ref):
+        r = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+        worst.append((r, name))
+        assert r < BF16_LAYER, (name, r)
+
+    for d in range(5):
+        pre = "discriminators.%d." % d
+        for i in range(1, 6):
+            x, out = _tm(eng.slot("mpd", d, i)), _tm(eng.slot("mpd", d, i + 1))
+            name = pre + ("convs.%d." % i if i < 5 else "conv_post.")
+            w = ohg.wn_weight(mpd_sd, name).squeeze(-1)
+            v = ohg.layer_conv(x, w, mpd_sd[name + "bias"], stride=3 if i < 4 else 1, padding=2 if i < 5 else 1)
+            chk("mpd." + name, out, ohg.bf16r(ohg.lrelu64(v) if i < 5 else v))
+    sn_sd = {k: v.clone() for k, v in msd_sd.items()}
+    for sc in range(3):
+        pre = "discriminators.%d." % sc
+        for s in range(2 if sc == 0 else 1):
+            for i in range(1, 8):
+                name = pre + ("convs.%d." % i if i < 7 else "conv_post.")
+                w = ohg.sn_weight(sn_sd, name, True) if sc == 0 else ohg.wn_weight(msd_sd, name)     # scale 0: pass s sees s + 1 power iterations
+                x, out = _tm(eng.slot("msd", sc, s, i)), _tm(eng.slot("msd", sc, s, i + 1))
+                if i < 7:
+                    cin, cout, k, stride, groups, pad = ohg.MSD_CFG[i]
+                    v = ohg.lrelu64(ohg.layer_conv(x, w, msd_sd[name + "bias"], stride=stride, padding=pad, groups=groups))
+                else:
+                    v = ohg.layer_conv(x, w, msd_sd[name + "bias"], padding=1)
+                chk("msd.%s pass %d" % (name, s), out, ohg.bf16r(v))
+    worst.sort(reverse=True)
+    print("bf16 discriminators, teacher-forced: worst layers", worst[:4], "of", len(worst))
+    assert len(worst) == 5 * 5 + 4 * 7

@@ -75,6 +75,12 @@ def test_fastpitch_oracle_matches_reference_golden(golden_dir, case):
         assert abs(float(grads[k].double().norm()) - l2) <= 1e-4 * max(l2, 1e-12), k
         d = float((sd[k].double() - before[k].double()).norm())
         assert abs(d - d_ref) <= 1e-3 * max(d_ref, 1e-12), k
+    # every gradient tensor, sampled element-wise, and the fully stored ones
+    from oracle import golden_util as gu
+    errs = gu.check_samples(grads, keys, g["grad_samples"], g["grad_sample_off"])
+    assert errs[0][0] < 1e-4, errs[:3]
+    for i, k in enumerate(g["grad_full_keys"]):
+        assert torch.allclose(grads[str(k)] * 1.0, torch.from_numpy(g["grad_full_%d" % i]), rtol=1e-4, atol=1e-7), k
 
 
 def test_hifigan_oracle_matches_reference_golden(golden_dir):
@@ -95,6 +101,16 @@ def test_hifigan_oracle_matches_reference_golden(golden_dir):
     for k, l2 in zip(g["d_grad_keys"], g["d_grad_l2"]):
         assert abs(float(d_grads[str(k)].double().norm()) - l2) <= 2e-3 * max(l2, 1e-12), k
     assert torch.allclose(msd_sd["discriminators.0.convs.0.weight_u"], torch.from_numpy(g["msd_u0_after"]), rtol=1e-4, atol=1e-6)
+    from oracle import golden_util as gu
+    errs = gu.check_samples(g_grads, g["g_grad_keys"], g["g_grad_samples"], g["g_grad_sample_off"], 1024)
+    assert errs[0][0] < 2e-3, errs[:3]
+    errs = gu.check_samples(d_grads, g["d_grad_keys"], g["d_grad_samples"], g["d_grad_sample_off"], 1024)
+    assert errs[0][0] < 2e-3, errs[:3]
+    both = dict(d_grads)
+    both.update({"g." + k: v for k, v in g_grads.items()})
+    for i, k in enumerate(g["grad_full_keys"]):
+        ref = torch.from_numpy(g["grad_full_%d" % i]).double()
+        assert float((both[str(k)].double() - ref).norm() / ref.norm()) < 2e-3, k
 
 
 def test_fastpitch_stage1_oracle_matches_reference_golden(golden_dir):

@@ -868,6 +868,33 @@ extern "C" int xva_hg_generator_backward(const xva_hg_dims* d, const float* para
                                          void* stream) {
     return xva_hg_generator_backward_ex(d, params_g, grads_g, d_wav, ws, ws_bytes, nullptr, stream);
 }
+// Where an activation tensor of the last forward lives in the caller's workspace (parity tests feed a CPU restatement of ONE layer with
+// the engine's own input and compare outputs: storage-dtype rounding is then checked layer by layer instead of through ~50 layers).
+extern "C" int xva_hg_slot(const xva_hg_dims* d, int kind, int i0, int i1, int i2, int64_t* off_bytes, int32_t* geom5) {
+    Plan pl;
+    XVA_TRY(make_plan(d, &pl));
+    XVA_CHECK_ARG(off_bytes && geom5, "hg_slot: null output");
+    const SeqSpec* s = nullptr;
+    auto in = [](int v, int n) { return v >= 0 && v < n; };
+    switch (kind) {
+        case 0: s = &pl.xin; break;
+        case 1: s = &pl.h0; break;
+        case 2: if (in(i0, 4)) s = &pl.u[i0]; break;
+        case 3: if (in(i0, 4)) s = &pl.ua[i0]; break;
+        case 4: if (in(i0, 12) && in(i1, 3)) s = &pl.xt1[i0][i1]; break;
+        case 5: if (in(i0, 12) && in(i1, 2)) s = &pl.xr[i0][i1]; break;
+        case 6: if (in(i0, 12) && in(i1, 2)) s = &pl.xra[i0][i1]; break;
+        case 7: if (in(i0, 4)) s = &pl.xs[i0]; break;
+        case 8: s = &pl.y; break;
+        case 9: if (in(i0, NPER) && in(i1, 7)) s = &pl.pt[i0][i1]; break;
+        case 10: if (in(i0, 3) && in(i1, 2) && in(i2, 9)) s = &pl.st[i0][i1][i2]; break;
+        default: break;
+    }
+    XVA_CHECK_ARG(s != nullptr, "hg_slot: unknown slot (%d, %d, %d, %d)", kind, i0, i1, i2);
+    *off_bytes = s->off;
+    geom5[0] = s->nseq; geom5[1] = s->T; geom5[2] = s->C; geom5[3] = s->padF; geom5[4] = s->padB;
+    return XVA_OK;
+}
 extern "C" int xva_hg_num_buckets(int which) { return which == 0 ? G_BUCKETS : D_BUCKETS; }
 // [begin, end) in floats of bucket i of the flat gradient buffer `which`, in backward-completion order
 extern "C" int xva_hg_bucket_range(int which, int i, int64_t* begin, int64_t* end) {

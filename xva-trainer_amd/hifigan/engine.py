@@ -115,6 +115,27 @@ class HifiganEngine:
                                                     self._ws.numel(), events, _lib.stream_ptr()), "xva_hg_generator_backward_ex")
 
 
+SLOT_KINDS = {"mel": 0, "h0": 1, "u": 2, "ua": 3, "xt1": 4, "xr": 5, "xra": 6, "xs": 7, "y": 8, "mpd": 9, "msd": 10}
+lib.xva_hg_slot.restype = i32
+lib.xva_hg_slot.argtypes = [C.POINTER(HgDims), i32, i32, i32, i32, C.POINTER(i64), C.POINTER(i32)]
+
+
+def _slot(self, kind, i0=0, i1=0, i2=0):
+    """View of an activation tensor the last forward stored: (nseq, T, C) in the activation dtype, structural pad rows cut off
+    (test / diagnostics accessor, include/xva_hip.h:xva_hg_slot)."""
+    off, geom = i64(), (i32 * 5)()
+    _lib.check(lib.xva_hg_slot(C.byref(self._dims), SLOT_KINDS[kind], int(i0), int(i1), int(i2), C.byref(off), geom), "xva_hg_slot")
+    nseq, T, Cc, padF, padB = (int(v) for v in geom)
+    tdt = torch.bfloat16 if self.dt == DT["bf16"] else torch.float32
+    es = 2 if tdt == torch.bfloat16 else 4
+    Hp = padF + T + padB
+    flat = self._ws[off.value:off.value + nseq * Hp * Cc * es].view(tdt)
+    return flat.view(nseq, Hp, Cc)[:, padF:padF + T]
+
+
+HifiganEngine.slot = _slot
+
+
 def bucket_ranges(which):
     """[begin, end) float ranges of the gradient buckets of flat buffer `which`, in backward-completion order."""
     out = []
