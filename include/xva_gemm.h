@@ -118,7 +118,7 @@ int xva_gemm(const xva_gemm_params* p, void* stream);
  * convolution kernel, 7 the 384x128 tile (NT / NN). Returns the previous mode. Results are the same up to fp32 summation order. */
 int xva_gemm_set_mainloop(int mode);
 /* Diagnostics / test knob: K loop of the 256x256 direct-to-LDS tile. 0 = all waves in one phase (two barriers per 64-deep K tile),
- * 1 = two wave groups one barrier apart over a ring of four 32-deep K tiles ({12 LDS reads + DMA | 32 MFMAs} phases), 2 (default) = 1 for
+ * 1 (default) = two wave groups one barrier apart over a ring of four 32-deep K tiles ({12 LDS reads + DMA | 32 MFMAs} phases), 2 = 1 for
  * the NT layout, 0 for NN / TN. Returns the previous mode. Same results up to fp32 summation order. */
 int xva_gemm_set_kloop(int mode);
 

@@ -670,6 +670,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
 
 // ---- 32-deep K tiles -------------------------------------------------------------------------------------------------------------
 constexpr int GK3 = 32;
+#ifndef XVA_GLDS8_SLOTS
+#define XVA_GLDS8_SLOTS 4          // ring slots of the staggered 256x256 K loop (4 or 5): 4 x 32 KiB, three tiles (96 k) in flight; 5 slots (all 160 KiB)
+                                   // measured +2 % warm, nothing inside the training steps
+#endif
 __device__ __forceinline__ int kc32_f(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 template <int KIND, int ROWS, int NW>
 struct Loader32 {
@@ -707,6 +711,12 @@ struct Loader32 {
             const uint16_t* src = (k0 + kk[q] < K) ? base + off[q] : reinterpret_cast<const uint16_t*>(g_zero_page);
             __builtin_amdgcn_global_load_lds((const XVA_GLB void*)src, (XVA_LDS void*)(tile + (q * NW + wave) * 1024), 16, 0, 0);
         }
+    }
+    // the whole 32-deep tile lies inside K: no zero-page select
+    __device__ __forceinline__ void issue_full(const uint16_t* base, XVA_LDS uint8_t* tile, int wave) const {
+#pragma unroll
+        for (int q = 0; q < NI; ++q)
+            __builtin_amdgcn_global_load_lds((const XVA_GLB void*)(base + off[q]), (XVA_LDS void*)(tile + (q * NW + wave) * 1024), 16, 0, 0);
     }
 };
 struct KcReader32 {
@@ -776,25 +786,59 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
     else if constexpr (LAYOUT == XVA_GEMM_TN) lb.init(lane, wave, n0, p.N, p.ldb, p.seglen, p.seg0, p.segstride);
     else lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0, p.seglen, p.segstride);
 
-    auto issue = [&](int kt, int slot) {
-        XVA_LDS uint8_t* st = smem + slot * BUF;
-        if constexpr (LAYOUT == XVA_GEMM_TN) {
-            if (p.kb_len > 0) {
-                const int blk = kt / tpb, kl = (kt - blk * tpb) * GK3;
-                la.issue(A + (int64_t)blk * p.kb_sA + (int64_t)kl * p.lda, kl, p.kb_len, st, wave);
-                lb.issue(B + (int64_t)blk * p.kb_sB + (int64_t)kl * p.ldb, kl, p.kb_len, st + A_BYTES, wave);
-                return;
-            }
+    // Tiles are issued strictly in order (kt_begin, kt_begin + 1, ...): the operand bases of the NEXT tile are kept incrementally — the
+    // divisions by the segment / K-block lengths cost ~60 scalar instructions per tile in the read slot, which has to fit under the
+    // other wave group's 32 MFMAs (512 cycles).
+    const uint16_t* nA; const uint16_t* nB;      // bases of the next tile to issue
+    int n_k0, n_akin = 0, n_bkin = 0;            // its first k (inside its K block for TN K blocks); position inside the A / B segment
+    const bool kblocks = LAYOUT == XVA_GEMM_TN && p.kb_len > 0;
+    const int Kb = kblocks ? p.kb_len : p.K;     // bound of the k index the loaders compare against
+    {
+        if (kblocks) {
+            const int blk = kt_begin / tpb, kl = (kt_begin - blk * tpb) * GK3;
+            n_k0 = kl;
+            nA = A + (int64_t)blk * p.kb_sA + (int64_t)kl * p.lda;
+            nB = B + (int64_t)blk * p.kb_sB + (int64_t)kl * p.ldb;
+        } else {
+            const int k0 = kt_begin * GK3;
+            n_k0 = k0;
+            if constexpr (AK == KC) {
+                nA = A + k0 + (p.a_seglen > 0 ? (int64_t)(k0 / p.a_seglen) * p.a_segadj : 0);
+                n_akin = p.a_seglen > 0 ? k0 % p.a_seglen : 0;
+            } else nA = A + (int64_t)k0 * p.lda;
+            if constexpr (BKD == KC) nB = B + k0;
+            else if constexpr (LAYOUT == XVA_GEMM_NN) {
+                if (p.seglen > 0) { nB = B + p.seg0 + (int64_t)(k0 / p.seglen) * p.segstride; n_bkin = k0 % p.seglen; nB += (int64_t)n_bkin * p.ldb; }
+                else nB = B + (int64_t)k0 * p.ldb;
+            } else nB = B + (int64_t)k0 * p.ldb;
         }
-        const int k0 = kt * GK3;
-        if constexpr (AK == KC) la.issue(A + k0 + (p.a_seglen > 0 ? (int64_t)(k0 / p.a_seglen) * p.a_segadj : 0), k0, p.K, st, wave);
-        else la.issue(A + (int64_t)k0 * p.lda, k0, p.K, st, wave);
-        const uint16_t* bb;
-        if constexpr (BKD == KC) bb = B + k0;
-        else if constexpr (LAYOUT == XVA_GEMM_NN)
-            bb = p.seglen > 0 ? B + p.seg0 + (int64_t)(k0 / p.seglen) * p.segstride + (int64_t)(k0 % p.seglen) * p.ldb : B + (int64_t)k0 * p.ldb;
-        else bb = B + (int64_t)k0 * p.ldb;
-        lb.issue(bb, k0, p.K, st + A_BYTES, wave);
+    }
+    const int64_t a_small = (AK == KC && p.a_seglen > 0 && p.a_seglen < GK3) ? (int64_t)(GK3 / p.a_seglen) * p.a_segadj : 0;   // segments shorter than a tile
+    auto issue_next = [&](int slot) {
+        XVA_LDS uint8_t* st = smem + slot * BUF;
+        if (n_k0 + GK3 <= Kb) { la.issue_full(nA, st, wave); lb.issue_full(nB, st + A_BYTES, wave); }
+        else { la.issue(nA, n_k0, Kb, st, wave); lb.issue(nB, n_k0, Kb, st + A_BYTES, wave); }
+        // advance to the next tile
+        n_k0 += GK3;
+        if (kblocks) {
+            if (n_k0 >= tpb * GK3) {              // next K block
+                nA += p.kb_sA - (int64_t)(n_k0 - GK3) * p.lda; nB += p.kb_sB - (int64_t)(n_k0 - GK3) * p.ldb; n_k0 = 0;
+            } else { nA += (int64_t)GK3 * p.lda; nB += (int64_t)GK3 * p.ldb; }
+            return;
+        }
+        if constexpr (AK == KC) {
+            nA += GK3 + a_small;
+            if (p.a_seglen >= GK3) { n_akin += GK3; if (n_akin >= p.a_seglen) { n_akin -= p.a_seglen; nA += p.a_segadj; } }
+        } else nA += (int64_t)GK3 * p.lda;
+        if constexpr (BKD == KC) nB += GK3;
+        else if constexpr (LAYOUT == XVA_GEMM_NN) {
+            if (p.seglen >= GK3) {
+                n_bkin += GK3;
+                if (n_bkin >= p.seglen) { n_bkin -= p.seglen; nB += p.segstride - (int64_t)(p.seglen - GK3) * p.ldb; }
+                else nB += (int64_t)GK3 * p.ldb;
+            } else if (p.seglen > 0) nB += (int64_t)(GK3 / p.seglen) * p.segstride;
+            else nB += (int64_t)GK3 * p.ldb;
+        } else nB += (int64_t)GK3 * p.ldb;
     };
 
     KcReader32 kra, krb;
@@ -810,19 +854,22 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     constexpr int LOADS = Loader32<AK, BM, NW>::NI + Loader32<BKD, BN, NW>::NI;      // DMA instructions per wave per 32-deep tile (4)
-    static_assert(2 * LOADS < 16, "vmcnt immediates below");
-    constexpr int WAIT_VM2 = 0x0F70 | (2 * LOADS), WAIT_VM1 = 0x0F70 | LOADS, WAIT_VM0 = 0x0F70;
+    constexpr int NS = XVA_GLDS8_SLOTS;                                               // ring slots; NS - 1 tiles in flight
+    static_assert((NS - 2) * LOADS < 16, "vmcnt immediates below");
+    constexpr int WAIT_VM3 = 0x0F70 | (3 * LOADS), WAIT_VM2 = 0x0F70 | (2 * LOADS), WAIT_VM1 = 0x0F70 | LOADS, WAIT_VM0 = 0x0F70;
 #define XVA_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
     const int ntl = kt_end - kt_begin;
-    if (ntl > 0) issue(kt_begin, 0);
-    if (ntl > 1) issue(kt_begin + 1, 1);
-    if (ntl > 2) issue(kt_begin + 2, 2);
-    if (ntl > 2) __builtin_amdgcn_s_waitcnt(WAIT_VM2); else if (ntl > 1) __builtin_amdgcn_s_waitcnt(WAIT_VM1); else __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+    if (ntl > 0) issue_next(0);
+    if (ntl > 1) issue_next(1);
+    if (ntl > 2) issue_next(2);
+    if (NS > 4 && ntl > 3) issue_next(3);
+    if (NS > 4 && ntl > 3) __builtin_amdgcn_s_waitcnt(WAIT_VM3);
+    else if (ntl > 2) __builtin_amdgcn_s_waitcnt(WAIT_VM2); else if (ntl > 1) __builtin_amdgcn_s_waitcnt(WAIT_VM1); else __builtin_amdgcn_s_waitcnt(WAIT_VM0);
     XVA_BAR();
     if (wm == 1) XVA_BAR();                                      // group 1 runs one barrier behind group 0
     XVA_T(1);
+    int slot = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int slot = (kt - kt_begin) & 3;
         const XVA_LDS uint8_t* At = smem + slot * BUF;
         const XVA_LDS uint8_t* Bt = At + A_BYTES;
         bf16x8 af[MI], bfr[NJ];
@@ -844,7 +891,9 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
             }
         }
         const int ahead = (XVA_GLDS_ABLATE & 2) ? 0 : kt_end - kt;     // tiles left including this one
-        if (ahead > 3) { issue(kt + 3, (slot + 3) & 3); __builtin_amdgcn_s_waitcnt(WAIT_VM2); }
+        // tile kt + NS - 1 goes into the slot of tile kt - 1; then this wave's part of tile kt + 1 must have landed
+        if (ahead > NS - 1) { issue_next(slot == 0 ? NS - 1 : slot - 1); __builtin_amdgcn_s_waitcnt(NS > 4 ? WAIT_VM3 : WAIT_VM2); }
+        else if (NS > 4 && ahead > 3) __builtin_amdgcn_s_waitcnt(WAIT_VM2);
         else if (ahead > 2) __builtin_amdgcn_s_waitcnt(WAIT_VM1);
         else __builtin_amdgcn_s_waitcnt(WAIT_VM0);
         if (p.a_lrelu) {                                         // one uniform branch per read slot
@@ -872,6 +921,7 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
             __builtin_amdgcn_s_setprio(0);
         }
         XVA_BAR();
+        slot = slot == NS - 1 ? 0 : slot + 1;
     }
     if (wm == 0) XVA_BAR();
 #undef XVA_BAR
@@ -1185,7 +1235,7 @@ inline int launch_tile3(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
 
 template <int LAYOUT>
 inline int launch_tile8(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
-    constexpr int LDS = 4 * (256 + 256) * GK3 * 2;
+    constexpr int LDS = XVA_GLDS8_SLOTS * (256 + 256) * GK3 * 2;
     auto kern = xva_gemm_glds8_kernel<LAYOUT>;
     static bool attr_set = false;
     if (!attr_set) {

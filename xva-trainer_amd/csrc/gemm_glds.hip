@@ -75,11 +75,10 @@ bool xva_gemm_glds_eligible(const xva_gemm_params& p) {
 }
 
 static int launch_tiles(const xva_gemm_params& p, int tile, int vec, hipStream_t st);
-// K loop of the 256 x 256 tile: 0 = all waves in one phase (two barriers per 64-deep K tile), 1 = two wave groups one barrier apart
-// (xva_gemm_glds8_kernel), 2 (default) = the latter for NT only.  Measured (tools/gemm_tile_ab.py, tools/glds_timing.hip): NT +2 % (K = 1152)
-// ... +18 % (8192^2 x 4096), NN / TN -7 ... -15 % (their transpose reads make the read slot longer than the other group's 32 MFMAs);
-// in the training steps mode 2 is worth 0.5 - 0.7 %.  env XVA_GEMM_KLOOP8
-static int g_kloop8 = [] { const char* e = getenv("XVA_GEMM_KLOOP8"); return e ? atoi(e) : 2; }();
+// K loop of the 256 x 256 tile: 0 = all waves in one phase (two barriers per 64-deep K tile), 1 (default) = two wave groups one barrier
+// apart (xva_gemm_glds8_kernel), 2 = the latter for NT only.  Measured (tools/gemm_tile_ab.py): NT +5 ... +18 %, NN +2 ... +6 %, TN +-1 % on
+// warm operands; inside the training steps (operands from HBM) FastPitch -0.8 %, HiFi-GAN -1.0 % step time.  env XVA_GEMM_KLOOP8
+static int g_kloop8 = [] { const char* e = getenv("XVA_GEMM_KLOOP8"); return e ? atoi(e) : 1; }();
 extern "C" int xva_gemm_set_kloop(int mode) { int old = g_kloop8; g_kloop8 = mode; return old; }
 static int vec_epilogue_ok(const xva_gemm_params& p);
 
