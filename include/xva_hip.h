@@ -291,6 +291,9 @@ int xva_fp_rowscale_colsum(const void* X, int dt, const float* s, float* out, in
 int xva_fp_dur_from_log(const float* logd, float* out, int n, float max_dur, void* stream);
 int xva_cast_f32(const float* src, void* dst, int dt, int64_t n, void* stream);
 int xva_cast_to_f32(const void* src, int dt, float* dst, int64_t n, void* stream);
+/* dst += src over n (even) elements of the activation dtype: joins the gradient contributions that the temporal predictors' backward
+ * (python/fastpitch1_1/fastpitch/model.py:394-418) produces on its own stream into d(encoder output) */
+int xva_fp_add_act(void* dst, const void* src, int dt, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------ optimizers ---- */
 /* Fused multi-tensor LAMB over the flat buffers = torch.nn.utils.clip_grad_norm_(.., max_grad_norm) followed by

@@ -147,7 +147,10 @@ struct Plan {
     int64_t acc, losses, d_mel, d_pitch, d_energy, d_logdur;
     // backward scratch, sized for the decoder; the encoder reuses it.  gBm / gDm: dropout-masked copies for the branches.
     int64_t gA, gB, gBm, gC, gD, gDm, gH, gAV, gP, gQKV, gE, pa, pb;
-    int64_t skws, skws_bytes;   // split-K slab scratch of the weight-gradient GEMMs
+    // second copies of the tensors the weight-gradient lane reads (layers alternate between the two sets: see layers_bwd)
+    int64_t gB2, gBm2, gD2, gDm2, gH2, gQKV2;
+    int64_t skws, skws2, skws3, skws_bytes;   // split-K slab scratch of the weight-gradient GEMMs (main stream / weight-gradient lane / predictor lane)
+    int64_t gX1, gX2;   // d(encoder output) contributions of the energy / pitch predictors (predictor lane)
     int64_t wshadow;    // activation-dtype copy of the flat parameters (bf16 mode); unused in fp32 mode
     int64_t total;
 };
@@ -210,6 +213,11 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     p->gE = b.seq(p->Re, DM, es); p->pa = b.seq(p->Re, DP, 4); p->pb = b.seq(p->Re, DP, 4);
     p->skws_bytes = (int64_t)8 * DI * 3 * DM * 4;   // 8 splits of the largest weight gradient (1536 x 1152 fp32)
     p->skws = b.take(p->skws_bytes);
+    p->skws2 = b.take(p->skws_bytes); p->skws3 = b.take(p->skws_bytes);
+    p->gX1 = b.seq(p->Re, DM, es); p->gX2 = b.seq(p->Re, DM, es);
+    p->gB2 = b.seq(Rm, DM, es); p->gD2 = b.seq(Rm, DM, es);
+    p->gBm2 = drop ? b.seq(Rm, DM, es) : p->gB2; p->gDm2 = drop ? b.seq(Rm, DM, es) : p->gD2;
+    p->gH2 = b.seq(Rm, DI, es); p->gQKV2 = b.seq(Rm, DQKV, es);
     p->wshadow = d->compute ? b.take(table().total * es) : -1;
     p->total = b.cur;
     return XVA_OK;
@@ -227,6 +235,7 @@ struct Ctx {
     int compute, dt, es;
     float pd;         // dropout probability
     uint64_t seed;
+    int lane = 0;     // 0: the caller's stream, 1: the weight-gradient side stream, 2: the predictor side stream (own split-K slabs each)
     void* const* events = nullptr;  // optional hipEvent_t per gradient bucket (data-parallel overlap)
     int ev_base = 0;
     int record(int i) {
@@ -272,7 +281,7 @@ static int linear_bwd_weight(Ctx& c, const void* dY, int64_t rows, int N, int64_
     xva_gemm_params g = gp0(c);
     g.layout = XVA_GEMM_TN; g.A = dY; g.B = X; g.C = dW; g.c_dtype = XVA_F32; g.M = N; g.N = K; g.K = (int)rows; g.lda = ldy; g.ldb = ldx; g.ldc = K;
     g.accumulate = 1; g.splitk = 0;
-    g.sk_ws = c.W + c.pl.skws; g.sk_ws_bytes = c.pl.skws_bytes;
+    g.sk_ws = c.W + (c.lane == 2 ? c.pl.skws3 : (c.lane ? c.pl.skws2 : c.pl.skws)); g.sk_ws_bytes = c.pl.skws_bytes;
     return xva_gemm(&g, c.st);
 }
 // Conv1d(k=3, pad=1) over a padded token-major sequence: Y = act(Xcat Wt^T + b) [dropout] (+R), Wt tap-major [Cout][3*Cin]
@@ -300,7 +309,7 @@ static int conv3_bwd_weight(Ctx& c, const void* dY, int64_t rows, int Cout, cons
     xva_gemm_params g = gp0(c);
     g.layout = XVA_GEMM_TN; g.A = dY; g.B = X - (int64_t)Cin * c.es; g.C = dWt; g.c_dtype = XVA_F32; g.M = Cout; g.N = 3 * Cin; g.K = (int)rows;
     g.lda = Cout; g.ldb = Cin; g.ldc = 3 * Cin; g.accumulate = 1; g.splitk = 0;
-    g.sk_ws = c.W + c.pl.skws; g.sk_ws_bytes = c.pl.skws_bytes;
+    g.sk_ws = c.W + (c.lane == 2 ? c.pl.skws3 : (c.lane ? c.pl.skws2 : c.pl.skws)); g.sk_ws_bytes = c.pl.skws_bytes;
     return xva_gemm(&g, c.st);
 }
 
@@ -352,6 +361,36 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
 }
 
 // Backward through the 6 layers.  On entry gA holds dL/d(x_out) ; on exit gA holds dL/d(x_in) (LEN-masked).
+// ---- weight-gradient lane ----------------------------------------------------------------------------------------------------------
+// Inside a layer's backward the four weight gradients (and three bias column sums) depend on the data-gradient chain but nothing
+// depends on them until the optimizer.  Issued on the same stream they sit between the chain's kernels: every GEMM's last, partly
+// filled round of workgroups and every small kernel's latency leaves CUs idle.  Here the chain stays on the caller's stream and the
+// weight gradients of layer l go to a side stream behind an event recorded at the end of the chain's layer l; the tensors they read
+// (gB / gBm, gD / gDm, gH, gQKV) alternate between two sets by layer parity, and the chain waits for the side stream's layer l + 2
+// before it overwrites a set.  The side stream and its events are created once per host thread; every call joins before returning,
+// and a gradient bucket's event (DP overlap) is recorded on the side stream, i.e. after both lanes finished the layer.
+// A second side stream carries the temporal predictors (model.py:394-418): in training the decoder is conditioned on the TARGET pitch /
+// energy, so neither its forward nor its backward depends on them; their small, latency-bound kernels run under the decoder's GEMMs.
+// env XVA_FP_STREAMS=1 keeps everything on the caller's stream.
+struct WgLane { hipStream_t s = nullptr, sp = nullptr; hipEvent_t fork = nullptr, chain[NL] = {}, done[NL] = {}, pfork = nullptr, pmid = nullptr, pjoin = nullptr;
+                bool init = false, ok = false; };
+static WgLane& wg_lane() {
+    static thread_local WgLane r;
+    if (!r.init) {
+        r.init = true;
+        const char* e = getenv("XVA_FP_STREAMS");
+        bool ok = !(e && atoi(e) == 1) && hipStreamCreateWithFlags(&r.s, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&r.sp, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&r.pfork, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&r.pmid, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&r.pjoin, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < NL; ++i)
+            ok = hipEventCreateWithFlags(&r.chain[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming) == hipSuccess;
+        r.ok = ok;
+    }
+    return r;
+}
+#define XVA_HIP_TRY(x) do { if ((x) != hipSuccess) { xva_set_error("fastpitch: stream / event call failed: " #x); return XVA_ERR_HIP; } } while (0)
+
 static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t* xo, int64_t R, int Tp, int64_t Ts,
                       const int32_t* lens, bool last_bucket_deferred, int site) {
     const int B = c.pl.B;
@@ -359,29 +398,37 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
          *gH = c.A(c.pl.gH), *gAV = c.A(c.pl.gAV), *gP = c.A(c.pl.gP), *gQKV = c.A(c.pl.gQKV);
     const bool drop = c.pd > 0.f;
     float* Gg = c.G;
+    WgLane& wl = wg_lane();
+    const bool two = wl.ok;
+    Ctx cw = c;                                   // the weight-gradient lane
+    if (two) {
+        cw.st = wl.s; cw.lane = 1;
+        XVA_HIP_TRY(hipEventRecord(wl.fork, (hipStream_t)c.st));
+        XVA_HIP_TRY(hipStreamWaitEvent(wl.s, wl.fork, 0));
+    }
+    char* const setB[2] = {gB, c.A(c.pl.gB2)}; char* const setBm[2] = {gBm, c.A(c.pl.gBm2)}; char* const setD[2] = {gD, c.A(c.pl.gD2)};
+    char* const setDm[2] = {gDm, c.A(c.pl.gDm2)}; char* const setH[2] = {gH, c.A(c.pl.gH2)}; char* const setQ[2] = {gQKV, c.A(c.pl.gQKV2)};
     for (int l = NL - 1; l >= 0; --l) {
         const LayerP& p = LP[l];
         const LayerA& a = LA[l];
         char* x = c.A(xo[l]);
         char* qkv = c.A(a.qkv); char* av = c.A(a.av);
         const uint32_t s0 = site + l * 4;
+        const int par = two ? (l & 1) : 0;
+        gB = setB[par]; gBm = setBm[par]; gD = setD[par]; gDm = setDm[par]; gH = setH[par]; gQKV = setQ[par];
+        if (two && l + 2 < NL) XVA_HIP_TRY(hipStreamWaitEvent((hipStream_t)c.st, wl.done[l + 2], 0));   // this set's last readers
         // LN2 backward -> gB = d sum2 (residual path) ; gBm = gB * dropmask (conv2 branch)
         XVA_TRY(xva_fp_layernorm_bwd(gA, c.A(a.sum2), c.F(a.mean2), c.F(a.rstd2), c.P + p.ln2_g, gB, drop ? gBm : nullptr, c.dt, Gg + p.ln2_g,
                                      Gg + p.ln2_b, R, DM, XVA_MASK_LEN, lens, Tp, 0, 0.f, 0, 0, c.pd, c.seed, s0 + 2, nullptr, nullptr, c.st));
         // conv2 backward: gH = (gBm (*) W2) * [h > 0], structural rows zero
         XVA_TRY(conv3_bwd_data(c, gBm, R, DM, p.c2_w, DI, gH, nullptr, c.A(a.h), XVA_MASK_PAD, lens, Tp, 0));
-        XVA_TRY(conv3_bwd_weight(c, gBm, R, DM, c.A(a.h), DI, Gg + p.c2_w));
-        XVA_TRY(xva_fp_colsum(gBm, c.dt, Gg + p.c2_b, R, DM, DM, c.st));
         // conv1 backward + residual: gC = gB + gH (*) W1, LEN-masked (y1 was multiplied by mask)
         XVA_TRY(conv3_bwd_data(c, gH, R, DI, p.c1_w, DM, gC, gB, nullptr, XVA_MASK_LEN, lens, Tp, 0));
-        XVA_TRY(conv3_bwd_weight(c, gH, R, DI, c.A(a.y1), DM, Gg + p.c1_w));
-        XVA_TRY(xva_fp_colsum(gH, c.dt, Gg + p.c1_b, R, DI, DI, c.st));
         // LN1 backward -> gD = d sum1 ; gDm = gD * dropmask (o_net branch)
         XVA_TRY(xva_fp_layernorm_bwd(gC, c.A(a.sum1), c.F(a.mean1), c.F(a.rstd1), c.P + p.ln1_g, gD, drop ? gDm : nullptr, c.dt, Gg + p.ln1_g,
                                      Gg + p.ln1_b, R, DM, XVA_MASK_LEN, lens, Tp, 0, 0.f, 0, 0, c.pd, c.seed, s0 + 1, nullptr, nullptr, c.st));
         // o_net backward
         XVA_TRY(linear_bwd_data(c, gDm, R, DM, DM, p.o_w, DH, gAV, DH, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
-        XVA_TRY(linear_bwd_weight(c, gDm, R, DM, DM, av, DH, DH, Gg + p.o_w));
         if (c.compute) {
             XVA_TRY(xva_fp_attention_bwd(qkv, av, gAV, c.F(a.lse), (float*)gP, lens, gQKV, B, Tp, 0.125f, c.pd, c.seed, s0 + 0, c.st));
         } else {
@@ -414,10 +461,22 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         }
         // d x = gD + gQKV Wqkv, LEN-masked -> gA
         XVA_TRY(linear_bwd_data(c, gQKV, R, DQKV, DQKV, p.qkv_w, DM, gA, DM, gD, DM, XVA_MASK_LEN, lens, Tp));
-        XVA_TRY(linear_bwd_weight(c, gQKV, R, DQKV, DQKV, x, DM, DM, Gg + p.qkv_w));
-        XVA_TRY(xva_fp_colsum(gQKV, c.dt, Gg + p.qkv_b, R, DQKV, DQKV, c.st));
-        if (l > 0 || !last_bucket_deferred) XVA_TRY(c.record(c.ev_base + (NL - 1 - l)));
+        // weight gradients and bias sums of this layer (models' transformer.py:21-147 parameters), on the side lane when there is one
+        if (two) {
+            XVA_HIP_TRY(hipEventRecord(wl.chain[l], (hipStream_t)c.st));
+            XVA_HIP_TRY(hipStreamWaitEvent(wl.s, wl.chain[l], 0));
+        }
+        XVA_TRY(conv3_bwd_weight(cw, gBm, R, DM, c.A(a.h), DI, Gg + p.c2_w));
+        XVA_TRY(xva_fp_colsum(gBm, c.dt, Gg + p.c2_b, R, DM, DM, cw.st));
+        XVA_TRY(conv3_bwd_weight(cw, gH, R, DI, c.A(a.y1), DM, Gg + p.c1_w));
+        XVA_TRY(xva_fp_colsum(gH, c.dt, Gg + p.c1_b, R, DI, DI, cw.st));
+        XVA_TRY(linear_bwd_weight(cw, gDm, R, DM, DM, av, DH, DH, Gg + p.o_w));
+        XVA_TRY(linear_bwd_weight(cw, gQKV, R, DQKV, DQKV, x, DM, DM, Gg + p.qkv_w));
+        XVA_TRY(xva_fp_colsum(gQKV, c.dt, Gg + p.qkv_b, R, DQKV, DQKV, cw.st));
+        if (two) XVA_HIP_TRY(hipEventRecord(wl.done[l], wl.s));
+        if (l > 0 || !last_bucket_deferred) XVA_TRY(cw.record(c.ev_base + (NL - 1 - l)));
     }
+    if (two) XVA_HIP_TRY(hipStreamWaitEvent((hipStream_t)c.st, wl.done[0], 0));     // join (the side stream runs in order: layer 0 is its last)
     return XVA_OK;
 }
 
@@ -571,11 +630,24 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
     XVA_CHECK_ARG(bt->durs && bt->pitch && bt->energy, "fastpitch_forward: stage 3/4 needs durations, pitch and energy");
     int32_t* dec_lens = (int32_t*)c.A(pl.dec_lens);
     // pitch / energy conditioning                                          (model.py:394-423)
-    XVA_TRY(pred_fwd(c, T.pitch, pl.pitch, enc_out, pl.pin_a, bt->in_lens, DS_PRED + 2));
+    // The decoder input uses the TARGET pitch / energy (training): the two predictors only feed the loss, and run on the predictor lane.
+    WgLane& wl = wg_lane();
+    Ctx cp = c;
+    if (wl.ok) {
+        cp.st = wl.sp; cp.lane = 2;
+        XVA_HIP_TRY(hipEventRecord(wl.pfork, (hipStream_t)c.st));
+        XVA_HIP_TRY(hipStreamWaitEvent(wl.sp, wl.pfork, 0));
+    }
+    XVA_TRY(pred_fwd(cp, T.pitch, pl.pitch, enc_out, pl.pin_a, bt->in_lens, DS_PRED + 2));
     XVA_TRY(xva_fp_avg_pitch(bt->pitch, bt->durs, c.F(pl.ptgt), B, pl.Tt, pl.Tm, 0, c.st));
     XVA_TRY(xva_fp_cond_add_fwd(enc_out, c.F(pl.ptgt), c.P + T.pitch_emb_w, c.P + T.pitch_emb_b, c.A(pl.enc_c1), c.dt, bt->in_lens, B,
                                 pl.Ttp, DM, c.st));
-    XVA_TRY(pred_fwd(c, T.energy, pl.energy, c.A(pl.enc_c1), pl.pin_b, bt->in_lens, DS_PRED + 4));
+    if (wl.ok) {   // the energy predictor reads enc_c1
+        XVA_HIP_TRY(hipEventRecord(wl.pmid, (hipStream_t)c.st));
+        XVA_HIP_TRY(hipStreamWaitEvent(wl.sp, wl.pmid, 0));
+    }
+    XVA_TRY(pred_fwd(cp, T.energy, pl.energy, c.A(pl.enc_c1), pl.pin_b, bt->in_lens, DS_PRED + 4));
+    if (wl.ok) XVA_HIP_TRY(hipEventRecord(wl.pjoin, wl.sp));
     XVA_TRY(xva_fp_avg_pitch(bt->energy, bt->durs, c.F(pl.etgt), B, pl.Tt, pl.Tm, 1, c.st));
     XVA_TRY(xva_fp_cond_add_fwd(c.A(pl.enc_c1), c.F(pl.etgt), c.P + T.energy_emb_w, c.P + T.energy_emb_b, c.A(pl.enc_c2), c.dt,
                                 bt->in_lens, B, pl.Ttp, DM, c.st));
@@ -586,6 +658,7 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
     XVA_TRY(layers_fwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens, DS_DEC));
     XVA_TRY(linear_fwd(c, c.A(pl.dec_x[NL]), pl.Rd, DM, DM, T.proj_w, c.P + T.proj_b, c.A(pl.mel_out), NMEL, NMEL, nullptr, 0,
                        XVA_MASK_PAD, dec_lens, pl.Tmp));
+    if (wl.ok) XVA_HIP_TRY(hipStreamWaitEvent((hipStream_t)c.st, wl.pjoin, 0));     // join the predictor lane
     return XVA_OK;
 }
 
@@ -856,6 +929,18 @@ extern "C" int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, flo
     } else {
         int32_t* dec_lens = (int32_t*)c.A(pl.dec_lens);
         char* d_mel = c.A(pl.d_mel);
+        // stage 3: the predictors' backward (their inputs are the loss gradients and stored activations) on the predictor lane, under the
+        // decoder's; each writes its d(encoder output) contribution to its own buffer, added into gE below
+        WgLane& wl = wg_lane();
+        const bool plane = wl.ok && d->stage == 3;
+        if (plane) {
+            Ctx cp = c; cp.st = wl.sp; cp.lane = 2;
+            XVA_HIP_TRY(hipEventRecord(wl.pfork, (hipStream_t)c.st));
+            XVA_HIP_TRY(hipStreamWaitEvent(wl.sp, wl.pfork, 0));
+            XVA_TRY(pred_bwd(cp, T.energy, pl.energy, c.A(pl.enc_c1), pl.pin_b, c.F(pl.d_energy), c.A(pl.gX1), 0, bt->in_lens, DS_PRED + 4));
+            XVA_TRY(pred_bwd(cp, T.pitch, pl.pitch, enc_out, pl.pin_a, c.F(pl.d_pitch), c.A(pl.gX2), 0, bt->in_lens, DS_PRED + 2));
+            XVA_HIP_TRY(hipEventRecord(wl.pjoin, wl.sp));
+        }
         // proj backward                                                    (model.py:386)
         XVA_TRY(linear_bwd_data(c, d_mel, pl.Rd, NMEL, NMEL, T.proj_w, DM, gA, DM, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
         XVA_TRY(linear_bwd_weight(c, d_mel, pl.Rd, NMEL, NMEL, c.A(pl.dec_x[NL]), DM, DM, c.G + T.proj_w));
@@ -866,9 +951,13 @@ extern "C" int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, flo
         XVA_TRY(xva_fp_lenreg_bwd(gA, (int32_t*)c.A(pl.tstart), dec_lens, gE, c.dt, B, pl.Tt, pl.Tm, DM, 0, c.st));
         XVA_TRY(xva_fp_cond_add_bwd(gE, c.dt, c.F(pl.etgt), c.G + T.energy_emb_w, c.G + T.energy_emb_b, bt->in_lens, B, pl.Ttp, DM, c.st));
         if (d->stage == 3) {
-            XVA_TRY(pred_bwd(c, T.energy, pl.energy, c.A(pl.enc_c1), pl.pin_b, c.F(pl.d_energy), gE, 1, bt->in_lens, DS_PRED + 4));
+            if (plane) {
+                XVA_HIP_TRY(hipStreamWaitEvent((hipStream_t)c.st, wl.pjoin, 0));
+                XVA_TRY(xva_fp_add_act(gE, c.A(pl.gX1), c.dt, pl.Re * DM, c.st));
+            } else XVA_TRY(pred_bwd(c, T.energy, pl.energy, c.A(pl.enc_c1), pl.pin_b, c.F(pl.d_energy), gE, 1, bt->in_lens, DS_PRED + 4));
             XVA_TRY(xva_fp_cond_add_bwd(gE, c.dt, c.F(pl.ptgt), c.G + T.pitch_emb_w, c.G + T.pitch_emb_b, bt->in_lens, B, pl.Ttp, DM, c.st));
-            XVA_TRY(pred_bwd(c, T.pitch, pl.pitch, enc_out, pl.pin_a, c.F(pl.d_pitch), gE, 1, bt->in_lens, DS_PRED + 2));
+            if (plane) XVA_TRY(xva_fp_add_act(gE, c.A(pl.gX2), c.dt, pl.Re * DM, c.st));
+            else XVA_TRY(pred_bwd(c, T.pitch, pl.pitch, enc_out, pl.pin_a, c.F(pl.d_pitch), gE, 1, bt->in_lens, DS_PRED + 2));
         }
         // hand over to the encoder stack: gA <- gE
         if (hipMemcpyAsync(gA, gE, pl.Re * DM * c.es, hipMemcpyDeviceToDevice, (hipStream_t)c.st) != hipSuccess) {

@@ -844,6 +844,22 @@ extern "C" int xva_fp_rowscale_colsum(const void* X, int dt, const float* s, flo
 __global__ void cast_kernel(const float* __restrict__ src, void* __restrict__ dst, int dt, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a_st(dst, i, dt, src[i]);
 }
+// dst += src (activation dtype, element pairs; n even)
+__global__ void add_act_kernel(void* __restrict__ dst, const void* __restrict__ src, int dt, int64_t npairs) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * blockDim.x) {
+        float a, b, x, y;
+        a_ld2(dst, 2 * i, dt, a, b); a_ld2(src, 2 * i, dt, x, y);
+        a_st2(dst, 2 * i, dt, a + x, b + y);
+    }
+}
+extern "C" int xva_fp_add_act(void* dst, const void* src, int dt, int64_t n, void* stream) {
+    XVA_CHECK_ARG(dst && src && n % 2 == 0, "add_act: null or odd length");
+    if (n == 0) return XVA_OK;
+    int g = (int)((n / 2 + 255) / 256); if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(add_act_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, dst, src, dt, n / 2);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
 extern "C" int xva_cast_f32(const float* src, void* dst, int dt, int64_t n, void* stream) {
     XVA_CHECK_ARG(src && dst, "cast: null");
     int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;

@@ -1035,6 +1035,16 @@ extern "C" int xva_hg_pad_cols(const float* src, void* dst, int dt, int rows, in
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
+__global__ void hg_add_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+extern "C" int xva_hg_add_f32(float* dst, const float* src, int64_t n, void* stream) {
+    if (n <= 0) return XVA_OK;
+    int g = (int)((n + 255) / 256); if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(hg_add_f32_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
 extern "C" int xva_hg_unpad_cols_add(const float* src, float* dst, int rows, int k, int kp, void* stream) {
     hipLaunchKernelGGL(hg_unpad_cols_add_kernel, dim3(xva_cdiv(rows * k, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, k, kp);
     XVA_LAUNCH_CHECK();

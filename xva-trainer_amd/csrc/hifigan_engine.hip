@@ -39,6 +39,7 @@ int xva_hg_im2col1(const float*, void*, int, int, int, int, int, int, int, int, 
 int xva_hg_col2im1(const void*, int, float*, int, int, int, int, int, int, int, int, int, int, void*);
 int xva_hg_pad_cols(const float*, void*, int, int, int, int, void*);
 int xva_hg_unpad_cols_add(const float*, float*, int, int, int, void*);
+int xva_hg_add_f32(float* dst, const float* src, int64_t n, void* stream);
 }
 
 namespace {
@@ -190,7 +191,7 @@ struct Plan {
     int64_t dwav_s[3];                  // gradient w.r.t. the (pooled) fake waveforms
     int Tw[3];
     int64_t dw_g[2], dw_d[2];           // [begin, end) of the generator / discriminator effective-weight gradient regions
-    int64_t sn_tmp, losses, skws, skws_bytes, total;
+    int64_t sn_tmp, losses, skws[4], skws_bytes, dwav_lane[4], total;   // per stream lane: split-K slabs, partial d(waveform)
 };
 
 SeqSpec mk(Bump& b, int es, int nseq, int T, int C, int padF, int padB) {
@@ -305,7 +306,7 @@ int make_plan(const xva_hg_dims* d, Plan* p) {
     p->sn_tmp = b.take((1024 * 41 * 64 + 1024 + 64) * 4);
     p->losses = b.take(64 * 4);
     p->skws_bytes = (int64_t)96 << 20;      // split-K slabs of the weight-gradient GEMMs (largest: 3 x 1024 x 5120 fp32)
-    p->skws = b.take(p->skws_bytes);
+    for (int l = 0; l < 4; ++l) { p->skws[l] = b.take(p->skws_bytes); p->dwav_lane[l] = b.take((int64_t)B * d->seg * 4); }
     p->total = b.cur;
     return XVA_OK;
 }
@@ -315,15 +316,81 @@ struct Ctx {
     char* W;          // workspace
     void* st;
     int compute, dt;
+    int lane = 0;     // 0: the caller's stream, 1: the side stream
     Seq S(const SeqSpec& s) const { return seq(s, W, dt); }
     float* F(int64_t off) const { return (float*)(W + off); }
 };
+// ---- two streams for the discriminators ---------------------------------------------------------------------------------------------
+// The five period discriminators and the three scale discriminators are independent networks (models.py:169-200, 234-260).  Issued on
+// one stream, every kernel's last, partly filled round of workgroups and every dependent launch's latency is dead time on the other
+// CUs; issued on two streams (MPD on the caller's, MSD on a side stream forked and joined with events inside the call), the two
+// chains fill each other's gaps.  The side stream and its two events are created once per host thread; nothing else is hidden: the
+// call still returns with all work ordered on the caller's stream.  env XVA_HG_STREAMS=n: number of lanes (1 = everything on the caller's
+// stream; default 2).
+constexpr int MAXL = 4;                      // lanes: 0 = the caller's stream, 1 .. MAXL-1 side streams
+struct SideStreams { hipStream_t s[MAXL] = {}; hipEvent_t fork = nullptr, join[MAXL] = {}; int n = 0; bool init = false; };
+static SideStreams& side_streams() {
+    static thread_local SideStreams r;
+    if (!r.init) {
+        r.init = true;
+        const char* e = getenv("XVA_HG_STREAMS");
+        int want = e ? atoi(e) : 2;                 // measured: 2 lanes (MPD | MSD) 45.8 -> 41.3 ms per iteration, 3 and 4 lanes 41.7 - 42.0
+        if (want > MAXL) want = MAXL;
+        bool ok = want > 1 && hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 1; ok && i < want; ++i)
+            ok = hipStreamCreateWithFlags(&r.s[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&r.join[i], hipEventDisableTiming) == hipSuccess;
+        r.n = ok ? want : 1;
+    }
+    return r;
+}
+// which lane runs discriminator di (MPD 0..4, MSD 0..2), for 2 / 3 / 4 lanes: the two families alternate so that neighbours in time are
+// kernels of different shapes; env XVA_HG_LANES="a,b,c,d,e,f,g,h" overrides
+static int disc_lane(int di, int nl) {
+    static int tab[8] = {-1};
+    static bool init = false;
+    if (!init) {
+        init = true;
+        const char* e = getenv("XVA_HG_LANES");
+        if (e) { int i = 0; for (const char* q = e; *q && i < 8; ++q) if (*q >= '0' && *q <= '9') tab[i++] = *q - '0'; if (i < 8) tab[0] = -1; }
+    }
+    if (tab[0] >= 0) return tab[di] % nl;
+    static const int l2[8] = {0, 0, 0, 0, 0, 1, 1, 1}, l3[8] = {0, 1, 0, 1, 0, 2, 2, 2}, l4[8] = {0, 1, 0, 1, 0, 2, 3, 3};
+    return nl >= 4 ? l4[di] : (nl == 3 ? l3[di] : (nl == 2 ? l2[di] : 0));
+}
+struct Ctx;
+struct Lanes { Ctx* c[MAXL]; int n; };
+static void use_slabs(const Ctx& c);
+
 int make_ctx(Ctx& c, const xva_hg_dims* d, void* ws, int64_t ws_bytes, void* st) {
     XVA_TRY(make_plan(d, &c.pl));
     XVA_CHECK_ARG(ws && ((uintptr_t)ws % 256) == 0, "hifigan: workspace null or not 256-byte aligned");
     XVA_CHECK_ARG(ws_bytes >= c.pl.total, "hifigan: workspace too small (%ld < %ld bytes)", (long)ws_bytes, (long)c.pl.total);
     c.W = (char*)ws; c.st = st; c.dt = d->dt; c.compute = d->dt == XVA_BF16 ? 1 : 0;
-    hg_skws().ptr = c.W + c.pl.skws; hg_skws().bytes = c.pl.skws_bytes;
+    use_slabs(c);
+    return XVA_OK;
+}
+
+static void use_slabs(const Ctx& c) { hg_skws().ptr = c.W + c.pl.skws[c.lane]; hg_skws().bytes = c.pl.skws_bytes; }
+// cs[1 .. n-1] = c0 on the side streams (own split-K slabs), ordered after everything issued on c0's stream so far; returns the lane count
+static int fork_lanes(const Ctx& c0, Ctx* cs) {
+    SideStreams& ss = side_streams();
+    cs[0] = c0;
+    if (ss.n <= 1) return 1;
+    if (hipEventRecord(ss.fork, (hipStream_t)c0.st) != hipSuccess) return 1;
+    for (int i = 1; i < ss.n; ++i) {
+        if (hipStreamWaitEvent(ss.s[i], ss.fork, 0) != hipSuccess) return 1;
+        cs[i] = c0; cs[i].st = ss.s[i]; cs[i].lane = i;
+    }
+    return ss.n;
+}
+static int join_lanes(const Ctx* cs, int n) {
+    SideStreams& ss = side_streams();
+    for (int i = 1; i < n; ++i)
+        if (hipEventRecord(ss.join[i], (hipStream_t)cs[i].st) != hipSuccess || hipStreamWaitEvent((hipStream_t)cs[0].st, ss.join[i], 0) != hipSuccess) {
+            xva_set_error("hifigan: joining a side stream failed"); return XVA_ERR_HIP;
+        }
+    use_slabs(cs[0]);
     return XVA_OK;
 }
 
@@ -728,14 +795,18 @@ int pool_waves(Ctx& c, const float* yr, const float* yg) {
 }
 
 // forward of all 8 discriminators on (real, fake); losses[0..2] = {disc loss, gen loss, feature loss}
-int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* losses, int loss_mask) {
-    XVA_TRY(prep_wn(c, c.pl.dl, Pd));
-    XVA_TRY(pool_waves(c, yr, yg));
+int discs_forward(Ctx& c0, float* Pd, const float* yr, const float* yg, float* losses, int loss_mask) {
+    XVA_TRY(prep_wn(c0, c0.pl.dl, Pd));
+    XVA_TRY(pool_waves(c0, yr, yg));
     std::vector<DiscSet> sets; std::vector<DiscRun> snr;
     std::vector<xva_red_desc> reds;
-    build_sets(c, yr, yg, sets, snr);
-    if (losses) XVA_TRY(zero(c, losses, 4 * sizeof(float)));
+    build_sets(c0, yr, yg, sets, snr);
+    if (losses) XVA_TRY(zero(c0, losses, 4 * sizeof(float)));
+    Ctx cs[MAXL]; const int nl = fork_lanes(c0, cs);
+    int di = 0;
     for (auto& s : sets) {
+        Ctx& c = cs[disc_lane(di, nl)];
+        ++di;
         if (s.sn) {   // models.py:244-253: d(y) then d(y_hat), one power iteration each
             DiscRun rr = snr[0];
             XVA_TRY(sn_prepare(c, Pd, rr));
@@ -757,7 +828,8 @@ int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* lo
         }
         if (losses) disc_losses(c, s.run, s.rt, s.r0, s.f0, s.nf, losses, reds, loss_mask);
     }
-    if (!reds.empty()) XVA_TRY(xva_hg_reduce_batch(reds.data(), (int)reds.size(), c.st));
+    XVA_TRY(join_lanes(cs, nl));
+    if (!reds.empty()) XVA_TRY(xva_hg_reduce_batch(reds.data(), (int)reds.size(), c0.st));
     return XVA_OK;
 }
 
@@ -765,13 +837,16 @@ int discs_forward(Ctx& c, float* Pd, const float* yr, const float* yg, float* lo
 // Gradient buckets of the discriminators = the 8 discriminators in backward order (MPD 0..4, MSD 0..2); each owns one
 // contiguous range of the flat buffer and is finalised (bias sums, reparametrisation backward) as soon as its backward is done.
 constexpr int D_BUCKETS = NPER + 3;
-int discs_backward_d(Ctx& c, float* Pd, float* Gd, const float* yr, const float* yg, void* const* events) {
+int discs_backward_d(Ctx& c0, float* Pd, float* Gd, const float* yr, const float* yg, void* const* events) {
     std::vector<DiscSet> sets; std::vector<DiscRun> snr;
-    build_sets(c, yr, yg, sets, snr);
+    build_sets(c0, yr, yg, sets, snr);
     std::vector<xva_cs_desc> colsums;
-    XVA_TRY(zero_dweff(c, c.pl.dl));
+    XVA_TRY(zero_dweff(c0, c0.pl.dl));
+    Ctx cs[MAXL]; const int nl = fork_lanes(c0, cs);
     int di = 0;
     for (auto& s : sets) {
+        Ctx& c = cs[disc_lane(di, nl)];                      // each lane has its own split-K slabs
+        use_slabs(c);
         colsums.clear();
         const int n = s.run.n;
         const float inv = 1.f / (float)((int64_t)s.nf * s.run.t[n].T);
@@ -801,27 +876,37 @@ int discs_backward_d(Ctx& c, float* Pd, float* Gd, const float* yr, const float*
         XVA_TRY(record(c, events, di));
         ++di;
     }
+    XVA_TRY(join_lanes(cs, nl));
     return XVA_OK;
 }
 
 // G-step backward: d/d(fake wave) of sum_d [mean((1 - D(G))^2) + 2 * sum_l mean|fmap_l(y) - fmap_l(G)|]
-int discs_backward_g(Ctx& c, float* Pd, const float* yr, const float* yg, float* d_wav) {
-    const Plan& pl = c.pl;
+int discs_backward_g(Ctx& c0, float* Pd, const float* yr, const float* yg, float* d_wav) {
+    const Plan& pl = c0.pl;
     std::vector<DiscSet> sets; std::vector<DiscRun> snr;
-    build_sets(c, yr, yg, sets, snr);
-    bool first[3] = {true, true, true};
+    build_sets(c0, yr, yg, sets, snr);
+    Ctx cs[MAXL]; const int nl = fork_lanes(c0, cs);
+    bool first[MAXL] = {true, true, true, true};
     int di = 0;
     for (auto& s : sets) {
-        const int sc = di < NPER ? 0 : di - NPER;
-        float* dst = sc == 0 ? d_wav : c.F(pl.dwav_s[sc]);
-        const bool acc = sc == 0 ? !first[0] : false;
+        const int ln = disc_lane(di, nl);
+        Ctx& c = cs[ln];
+        use_slabs(c);
+        const int sc = di >= NPER ? di - NPER : 0;
+        // the full-rate discriminators all add into d(waveform): lane 0 into d_wav itself, every other lane into its own partial buffer
+        float* dst = sc != 0 ? c.F(pl.dwav_s[sc]) : (ln == 0 ? d_wav : c.F(pl.dwav_lane[ln]));
+        const bool acc = sc == 0 ? !first[ln] : false;
         XVA_TRY(disc_backward_wave(c, Pd, s.run, s.rt, s.r0, s.f0, s.nf, dst, acc ? 1 : 0));
-        if (sc == 0) first[0] = false;
+        if (sc == 0) first[ln] = false;
         ++di;
     }
+    XVA_TRY(join_lanes(cs, nl));
+    if (first[0]) XVA_TRY(zero(c0, d_wav, (int64_t)pl.B * pl.Tw[0] * 4));
+    for (int ln = 1; ln < nl; ++ln)
+        if (!first[ln]) XVA_TRY(xva_hg_add_f32(d_wav, c0.F(pl.dwav_lane[ln]), (int64_t)pl.B * pl.Tw[0], c0.st));
     // pooled scales: d(y) += pool_bwd(d(pool(y))) ; scale 2 goes through scale 1
-    XVA_TRY(xva_hg_avgpool_bwd(c.F(pl.dwav_s[2]), c.F(pl.dwav_s[1]), pl.B, pl.Tw[1], 1, c.st));
-    XVA_TRY(xva_hg_avgpool_bwd(c.F(pl.dwav_s[1]), d_wav, pl.B, pl.Tw[0], 1, c.st));
+    XVA_TRY(xva_hg_avgpool_bwd(c0.F(pl.dwav_s[2]), c0.F(pl.dwav_s[1]), pl.B, pl.Tw[1], 1, c0.st));
+    XVA_TRY(xva_hg_avgpool_bwd(c0.F(pl.dwav_s[1]), d_wav, pl.B, pl.Tw[0], 1, c0.st));
     return XVA_OK;
 }
 
