@@ -183,6 +183,7 @@ struct Plan {
     SeqSpec ua[4], xra[12][2];          // lrelu(u), lrelu(xr): what the resblock convolutions (and their weight gradients) read
     // generator backward scratch
     SeqSpec g_dxs, g_da, g_db, g_dt1, g_du, g_dy;
+    SeqSpec g_daj[3], g_dbj[3], g_dt1jm[3][3];   // per-resblock copies: the weight-gradient lane reads them while the chain moves on
     // discriminators: per MPD period: t1..t6 ; per MSD scale: t1..t8 (real+fake stacked: nseq = 2B*p / 2B; SN scale 0: two sets)
     SeqSpec pt[NPER][7], st[3][2][9];
     SeqSpec pd[NPER][7], sd[3][2][9];   // gradient tensors (same geometry)
@@ -265,6 +266,11 @@ int make_plan(const xva_hg_dims* d, Plan* p) {
         p->g_dxs = mk(b, es, B, T, C, PG, PG); p->g_da = mk(b, es, B, T, C, PG, PG); p->g_db = mk(b, es, B, T, C, PG, PG);
         p->g_dt1 = mk(b, es, B, T, C, PG, PG); p->g_du = mk(b, es, B, T, C, PG, PG);
         p->g_dy = mk(b, es, B, p->T[4], 1, PG, PG);
+        for (int j = 0; j < 3; ++j) {
+            p->g_daj[j] = j == 0 ? p->g_da : mk(b, es, B, T, C, PG, PG);
+            p->g_dbj[j] = j == 0 ? p->g_db : mk(b, es, B, T, C, PG, PG);
+            for (int m = 0; m < 3; ++m) p->g_dt1jm[j][m] = (j == 0 && m == 0) ? p->g_dt1 : mk(b, es, B, T, C, PG, PG);
+        }
     }
     // ---- MPD: sequences (b, w); real items first, then fake
     for (int d5 = 0; d5 < NPER; ++d5) {
@@ -328,18 +334,19 @@ struct Ctx {
 // call still returns with all work ordered on the caller's stream.  env XVA_HG_STREAMS=n: number of lanes (1 = everything on the caller's
 // stream; default 2).
 constexpr int MAXL = 4;                      // lanes: 0 = the caller's stream, 1 .. MAXL-1 side streams
-struct SideStreams { hipStream_t s[MAXL] = {}; hipEvent_t fork = nullptr, join[MAXL] = {}; int n = 0; bool init = false; };
+struct SideStreams { hipStream_t s[MAXL] = {}; hipEvent_t fork = nullptr, join[MAXL] = {}, pool[10] = {}; int n = 0; bool init = false; };
 static SideStreams& side_streams() {
     static thread_local SideStreams r;
     if (!r.init) {
         r.init = true;
         const char* e = getenv("XVA_HG_STREAMS");
-        int want = e ? atoi(e) : 2;                 // measured: 2 lanes (MPD | MSD) 45.8 -> 41.3 ms per iteration, 3 and 4 lanes 41.7 - 42.0
+        int want = e ? atoi(e) : 3;                 // 3 streams: one per parallel resblock of a generator stage; the discriminators use two
         if (want > MAXL) want = MAXL;
         bool ok = want > 1 && hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess;
         for (int i = 1; ok && i < want; ++i)
             ok = hipStreamCreateWithFlags(&r.s[i], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&r.join[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < 10; ++i) ok = hipEventCreateWithFlags(&r.pool[i], hipEventDisableTiming) == hipSuccess;
         r.n = ok ? want : 1;
     }
     return r;
@@ -355,8 +362,8 @@ static int disc_lane(int di, int nl) {
         if (e) { int i = 0; for (const char* q = e; *q && i < 8; ++q) if (*q >= '0' && *q <= '9') tab[i++] = *q - '0'; if (i < 8) tab[0] = -1; }
     }
     if (tab[0] >= 0) return tab[di] % nl;
-    static const int l2[8] = {0, 0, 0, 0, 0, 1, 1, 1}, l3[8] = {0, 1, 0, 1, 0, 2, 2, 2}, l4[8] = {0, 1, 0, 1, 0, 2, 3, 3};
-    return nl >= 4 ? l4[di] : (nl == 3 ? l3[di] : (nl == 2 ? l2[di] : 0));
+    // measured: 2 lanes (MPD | MSD) 45.8 -> 41.3 ms per iteration; 3 and 4 lanes 41.7 - 42.0
+    return nl >= 2 ? (di >= NPER ? 1 : 0) : 0;
 }
 struct Ctx;
 struct Lanes { Ctx* c[MAXL]; int n; };
@@ -456,26 +463,40 @@ int gen_forward(Ctx& c, const float* P, const float* mel, float* wav_out) {
         };
         XVA_TRY(hg_convT_fwd(prev, u, ctw(c, L[N.ups[i]], P), 1, SLOPE, c.compute, c.st, dual ? &ua : nullptr, SLOPE));
         if (!dual) XVA_TRY(act_copy(u, ua));
+        // The three resblocks of a stage (:118-121) are independent chains of six convolutions: one stream lane each (when there are
+        // three).  Only the last convolution of a chain touches the shared stage tensor xs (it accumulates the running mean), and it waits
+        // for the previous resblock's, so the accumulation order — and every bit of xs — is what one stream produces.
+        SideStreams& ss = side_streams();
+        const bool lanes = ss.n >= 3;
+        auto fail = [&]() { xva_set_error("hifigan: event record / wait failed"); return XVA_ERR_HIP; };
+        if (lanes) {
+            if (hipEventRecord(ss.fork, (hipStream_t)c.st) != hipSuccess) return fail();
+            for (int j = 1; j < 3; ++j) if (hipStreamWaitEvent(ss.s[j], ss.fork, 0) != hipSuccess) return fail();
+        }
         for (int j = 0; j < 3; ++j) {
             const int rb = i * 3 + j;
+            void* st = (lanes && j > 0) ? (void*)ss.s[j] : c.st;
             Seq xcur = u, xact = ua;
             for (int m = 0; m < 3; ++m) {                                                          // ResBlock1.forward (:41-48)
                 Seq xt1 = c.S(pl.xt1[rb][m]);
                 ConvEpi e1; e1.act = XVA_ACT_LRELU; e1.act_slope = SLOPE;                           // xt1 = lrelu(c1(lrelu(x)))
-                XVA_TRY(hg_conv_fwd(xact, xt1, cw(c, L[N.rc1[rb][m]], P), e1, c.compute, c.st));
+                XVA_TRY(hg_conv_fwd(xact, xt1, cw(c, L[N.rc1[rb][m]], P), e1, c.compute, st));
                 ConvEpi e2; e2.R = &xcur;
                 if (m < 2) {
                     Seq xn = c.S(pl.xr[rb][m]), xna = c.S(pl.xra[rb][m]);
                     if (dual) { e2.Y2 = &xna; e2.y2_slope = SLOPE; }
-                    XVA_TRY(hg_conv_fwd(xt1, xn, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, c.st));
-                    if (!dual) XVA_TRY(act_copy(xn, xna));
+                    XVA_TRY(hg_conv_fwd(xt1, xn, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, st));
+                    if (!dual) XVA_TRY(xva_hg_lrelu_copy(xn.ptr(), xna.ptr(), c.dt, xn.rows() * xn.C, SLOPE, st));
                     xcur = xn; xact = xna;
                 } else {                                                                           // xs = sum_j resblock_j / 3  (:118-123)
                     e2.alpha = 1.f / 3; e2.beta = 1.f / 3; e2.accumulate = j > 0;
-                    XVA_TRY(hg_conv_fwd(xt1, xs, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, c.st));
+                    if (lanes && j > 0 && hipStreamWaitEvent((hipStream_t)st, ss.pool[j - 1], 0) != hipSuccess) return fail();
+                    XVA_TRY(hg_conv_fwd(xt1, xs, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, st));
+                    if (lanes && hipEventRecord(ss.pool[j], (hipStream_t)st) != hipSuccess) return fail();
                 }
             }
         }
+        if (lanes && hipStreamWaitEvent((hipStream_t)c.st, ss.pool[2], 0) != hipSuccess) return fail();   // join: lane 2 finished after lanes 0 and 1
         prev = xs;
     }
     Seq y = c.S(pl.y);
@@ -546,26 +567,44 @@ int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav, void* con
         XVA_TRY(xva_hg_cout1_bwd_data(dy.ptr(), eff32(c, l, 0), xs.ptr(), dxs.ptr(), c.dt, xs.rows(), xs.C, l.k, 1, l.P, xs.Hp(), xs.padF, xs.T, 1,
                                       0.01f, c.st));
     }
+    // Two lanes (see "two streams for the discriminators"): the data-gradient chain on the caller's stream, the weight gradients and bias
+    // sums of each convolution pair on a side stream behind an event recorded once the pair's d(conv1 output) exists.  The tensors the
+    // side lane reads (d of each block's output, d of each conv1 output) have their own buffer per (resblock, block) within a stage;
+    // the stage's buffers are reused by the next stage, so the chain joins the side lane before a stage's ups backward.
+    SideStreams& ss = side_streams();
+    const bool two = ss.n > 1;
+    Ctx cw_ = c;
+    if (two) { cw_.st = ss.s[1]; cw_.lane = 1; }
     for (int i = 3; i >= 0; --i) {
         const int T = pl.T[i + 1], C = pl.Cst[i + 1];
-        Seq dxs = as_stage(c, pl.g_dxs, T, C), da = as_stage(c, pl.g_da, T, C), db = as_stage(c, pl.g_db, T, C),
-            dt1 = as_stage(c, pl.g_dt1, T, C), du = as_stage(c, pl.g_du, T, C);
+        Seq dxs = as_stage(c, pl.g_dxs, T, C), du = as_stage(c, pl.g_du, T, C);
         Seq ua = c.S(pl.ua[i]);
         for (int j = 0; j < 3; ++j) {
             const int rb = i * 3 + j;
+            const int jj = two ? j : 0;
+            Seq da = as_stage(c, pl.g_daj[jj], T, C), db = as_stage(c, pl.g_dbj[jj], T, C);
             // d(pair output) for m = 2 is dxs / 3; the 1/3 is folded into the first GEMMs' alpha / beta
             Seq dcur = dxs; float sc = 1.f / 3;
             for (int m = 2; m >= 0; --m) {
                 // the ACTIVATED conv inputs: they are the weight-gradient operands, and (LeakyReLU keeps the sign) the gates
                 Seq xin = m == 0 ? ua : c.S(pl.xra[rb][m - 1]);
                 Seq xt1 = c.S(pl.xt1[rb][m]);
+                Seq dt1 = as_stage(c, pl.g_dt1jm[jj][two ? m : 0], T, C);
                 ConvW w2 = cw(c, L[N.rc2[rb][m]], P), w1 = cw(c, L[N.rc1[rb][m]], P);
-                XVA_TRY(hg_conv_bwd_weight(dcur, xt1, w2, 0, 0.f, sc, c.compute, c.st));
-                XVA_TRY(xva_hg_colsum(dcur.ptr(), c.dt, G + L[N.rc2[rb][m]].bias, dcur.rows(), C, sc, c.st));
                 BwdEpi b2; b2.gate = &xt1; b2.gate_slope = SLOPE; b2.alpha = sc;
                 XVA_TRY(hg_conv_bwd_data(dcur, dt1, w2, b2, c.compute, c.st));                    // dt1 = d(conv1 output)
-                XVA_TRY(hg_conv_bwd_weight(dt1, xin, w1, 0, 0.f, 1.f, c.compute, c.st));
-                XVA_TRY(xva_hg_colsum(dt1.ptr(), c.dt, G + L[N.rc1[rb][m]].bias, dt1.rows(), C, 1.f, c.st));
+                if (two) {
+                    hipEvent_t ev = ss.pool[j * 3 + m];
+                    if (hipEventRecord(ev, (hipStream_t)c.st) != hipSuccess || hipStreamWaitEvent(ss.s[1], ev, 0) != hipSuccess) {
+                        xva_set_error("hifigan: event record / wait failed"); return XVA_ERR_HIP;
+                    }
+                }
+                use_slabs(cw_);
+                XVA_TRY(hg_conv_bwd_weight(dcur, xt1, w2, 0, 0.f, sc, c.compute, cw_.st));
+                XVA_TRY(xva_hg_colsum(dcur.ptr(), c.dt, G + L[N.rc2[rb][m]].bias, dcur.rows(), C, sc, cw_.st));
+                XVA_TRY(hg_conv_bwd_weight(dt1, xin, w1, 0, 0.f, 1.f, c.compute, cw_.st));
+                XVA_TRY(xva_hg_colsum(dt1.ptr(), c.dt, G + L[N.rc1[rb][m]].bias, dt1.rows(), C, 1.f, cw_.st));
+                use_slabs(c);
                 BwdEpi b1; b1.gate = &xin; b1.gate_slope = SLOPE; b1.R = &dcur; b1.beta = sc;
                 Seq dst = (m == 0) ? du : ((m == 2) ? da : db);
                 if (m == 0) b1.accumulate = 0;
@@ -576,6 +615,11 @@ int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav, void* con
                 }
                 XVA_TRY(hg_conv_bwd_data(dt1, dst, w1, b1, c.compute, c.st));
                 dcur = dst; sc = 1.f;
+            }
+        }
+        if (two) {   // join: the next kernels overwrite what the side lane reads (d xs), and the stage's weight gradients must be final
+            if (hipEventRecord(ss.pool[9], ss.s[1]) != hipSuccess || hipStreamWaitEvent((hipStream_t)c.st, ss.pool[9], 0) != hipSuccess) {
+                xva_set_error("hifigan: joining the weight-gradient lane failed"); return XVA_ERR_HIP;
             }
         }
         // ups[i] backward: d(prev) = lrelu'(prev) * strided-conv(du) ; dW, db
