@@ -240,11 +240,15 @@ def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
     import tempfile
     from xva_trainer_amd import _lib
     lib = _lib.lib
+    # per-kernel durations: the engines' stream lanes are put back on one stream for these passes (concurrent kernels share the CUs, a
+    # launch's event pair would time its neighbours too); the timed region above runs with the lanes on
+    old_hg, old_fp = lib.xva_hg_set_streams(1), lib.xva_fp_set_streams(1)
     lib.xva_prof_enable(1)
     for _ in range(nprof):
         run()
     torch.cuda.synchronize()
     lib.xva_prof_enable(0)
+    lib.xva_hg_set_streams(old_hg); lib.xva_fp_set_streams(old_fp)
     path = os.path.join(tempfile.gettempdir(), "xva_gemm_launches_%d.csv" % os.getpid())
     lib.xva_prof_dump(path.encode())
     rows = list(csv.DictReader(open(path)))
@@ -261,6 +265,9 @@ def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
         f[0] += 1; f[1] += float(r["ms"]); f[2] += float(r["gflop"]); f[3] += float(r["mbytes"])
     tot_ms = sum(f[1] for f in fam.values())
     name, f = max(fam.items(), key=lambda kv: kv[1][1])
+    if bound == "auto":   # the dominant family's own side of the ridge (2.5 PFLOP/s : 8 TB/s = 312 flop per algorithmic byte)
+        bound = "mfma" if f[2] * 1e9 / max(f[3] * 1e6, 1.0) > 2500.0e12 / 8000.0e9 else "hbm"
+        peak = 2500.0 if bound == "mfma" else 8000.0
     if bound == "mfma":
         ach, unit = f[2] / f[1], "TFLOP/s"                   # GFLOP / ms = TFLOP/s
     else:
@@ -351,7 +358,7 @@ def hifigan_leg(a, dev, rank, world):
            "loss_mel": float(out["loss_mel"].item()), "loss_disc_all": float(out["loss_disc_all"].item())}
     if rank == 0 and not a.no_roofline:
         # the conv stack is priced against the HBM roofline (north_star): algorithmic bytes of every conv-as-GEMM launch / its time
-        res["roofline"] = gemm_roofline(lambda: st.train_step(x, y, y_mel), 1, "hbm", 8000.0, "one extra profiled D+G iteration",
+        res["roofline"] = gemm_roofline(lambda: st.train_step(x, y, y_mel), 1, "auto", 8000.0, "one extra profiled D+G iteration (stream lanes off)",
                                         pmc_csv="r02_hifigan_pmc_hbm_bytes.csv")
     del st
     torch.cuda.empty_cache()

@@ -334,6 +334,14 @@ int xva_hg_generator_forward(const xva_hg_dims* d, const float* params_g, const 
 /* d_wav: (B, seg) fp32 gradient w.r.t. the generated waveform; accumulates into grads_g */
 int xva_hg_generator_backward(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* workspace,
                               int64_t workspace_bytes, void* stream);
+/* Stream lanes.  Inside one call the engines issue independent chains on side streams they own (created once per host thread, forked
+ * from and joined to the caller's stream with events inside the call): HiFi-GAN — period | scale discriminators, the generator's
+ * weight gradients, the three parallel resblocks of a stage; FastPitch — the weight gradients of a layer and the temporal predictors.
+ * n <= 1 puts everything back on the caller's stream (per-kernel measurements, debugging); returns the previous lane count.  Results do
+ * not depend on it, bit for bit, except FastPitch's d(encoder output), where the predictors' contributions are then added by a separate
+ * kernel (one more bf16 rounding in the throughput mode).  env XVA_HG_STREAMS / XVA_FP_STREAMS = 1 do the same at start-up. */
+int xva_hg_set_streams(int n);
+int xva_fp_set_streams(int n);
 /* Test / diagnostics: byte offset (into the caller's workspace) and geometry {nseq, T, C, padF, padB} of an activation tensor the last
  * forward stored, time-major (nseq, padF + T + padB, C) in the activation dtype.  kind: 0 mel input, 1 conv_pre output, 2 u[i0] (ups
  * output), 3 lrelu(u[i0]), 4 xt1[resblock i0][m i1] (= lrelu(c1(lrelu(x))), models.py:43-45), 5 / 6 x after block m and its lrelu copy,

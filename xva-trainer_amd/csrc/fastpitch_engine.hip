@@ -389,6 +389,7 @@ static WgLane& wg_lane() {
     }
     return r;
 }
+static int g_fp_serial = 0;     // xva_fp_set_streams(1): everything on the caller's stream (per-kernel measurements)
 #define XVA_HIP_TRY(x) do { if ((x) != hipSuccess) { xva_set_error("fastpitch: stream / event call failed: " #x); return XVA_ERR_HIP; } } while (0)
 
 static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t* xo, int64_t R, int Tp, int64_t Ts,
@@ -399,7 +400,7 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
     const bool drop = c.pd > 0.f;
     float* Gg = c.G;
     WgLane& wl = wg_lane();
-    const bool two = wl.ok;
+    const bool two = wl.ok && !g_fp_serial;
     Ctx cw = c;                                   // the weight-gradient lane
     if (two) {
         cw.st = wl.s; cw.lane = 1;
@@ -542,6 +543,7 @@ static int make_ctx(Ctx& c, const xva_fp_dims* d, const float* params, float* gr
 }  // namespace
 
 // =========================================================================== C ABI ====
+extern "C" int xva_fp_set_streams(int n) { int old = g_fp_serial ? 1 : 3; g_fp_serial = n <= 1; return old; }
 extern "C" int64_t xva_fp_param_floats(void) { return table().total; }
 extern "C" int xva_fp_num_tensors(void) { return (int)table().t.size(); }
 extern "C" int xva_fp_tensor_info(int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int32_t* ndim, int64_t* shape4,
@@ -633,7 +635,8 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
     // The decoder input uses the TARGET pitch / energy (training): the two predictors only feed the loss, and run on the predictor lane.
     WgLane& wl = wg_lane();
     Ctx cp = c;
-    if (wl.ok) {
+    const bool pl_on = wl.ok && !g_fp_serial;
+    if (pl_on) {
         cp.st = wl.sp; cp.lane = 2;
         XVA_HIP_TRY(hipEventRecord(wl.pfork, (hipStream_t)c.st));
         XVA_HIP_TRY(hipStreamWaitEvent(wl.sp, wl.pfork, 0));
@@ -642,12 +645,12 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
     XVA_TRY(xva_fp_avg_pitch(bt->pitch, bt->durs, c.F(pl.ptgt), B, pl.Tt, pl.Tm, 0, c.st));
     XVA_TRY(xva_fp_cond_add_fwd(enc_out, c.F(pl.ptgt), c.P + T.pitch_emb_w, c.P + T.pitch_emb_b, c.A(pl.enc_c1), c.dt, bt->in_lens, B,
                                 pl.Ttp, DM, c.st));
-    if (wl.ok) {   // the energy predictor reads enc_c1
+    if (pl_on) {   // the energy predictor reads enc_c1
         XVA_HIP_TRY(hipEventRecord(wl.pmid, (hipStream_t)c.st));
         XVA_HIP_TRY(hipStreamWaitEvent(wl.sp, wl.pmid, 0));
     }
     XVA_TRY(pred_fwd(cp, T.energy, pl.energy, c.A(pl.enc_c1), pl.pin_b, bt->in_lens, DS_PRED + 4));
-    if (wl.ok) XVA_HIP_TRY(hipEventRecord(wl.pjoin, wl.sp));
+    if (pl_on) XVA_HIP_TRY(hipEventRecord(wl.pjoin, wl.sp));
     XVA_TRY(xva_fp_avg_pitch(bt->energy, bt->durs, c.F(pl.etgt), B, pl.Tt, pl.Tm, 1, c.st));
     XVA_TRY(xva_fp_cond_add_fwd(c.A(pl.enc_c1), c.F(pl.etgt), c.P + T.energy_emb_w, c.P + T.energy_emb_b, c.A(pl.enc_c2), c.dt,
                                 bt->in_lens, B, pl.Ttp, DM, c.st));
@@ -658,7 +661,7 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
     XVA_TRY(layers_fwd(c, T.dec, pl.dec, pl.dec_x, pl.Rd, pl.Tmp, pl.Tsd, dec_lens, DS_DEC));
     XVA_TRY(linear_fwd(c, c.A(pl.dec_x[NL]), pl.Rd, DM, DM, T.proj_w, c.P + T.proj_b, c.A(pl.mel_out), NMEL, NMEL, nullptr, 0,
                        XVA_MASK_PAD, dec_lens, pl.Tmp));
-    if (wl.ok) XVA_HIP_TRY(hipStreamWaitEvent((hipStream_t)c.st, wl.pjoin, 0));     // join the predictor lane
+    if (pl_on) XVA_HIP_TRY(hipStreamWaitEvent((hipStream_t)c.st, wl.pjoin, 0));     // join the predictor lane
     return XVA_OK;
 }
 
@@ -932,7 +935,7 @@ extern "C" int xva_fp_backward_ex(const xva_fp_dims* d, const float* params, flo
         // stage 3: the predictors' backward (their inputs are the loss gradients and stored activations) on the predictor lane, under the
         // decoder's; each writes its d(encoder output) contribution to its own buffer, added into gE below
         WgLane& wl = wg_lane();
-        const bool plane = wl.ok && d->stage == 3;
+        const bool plane = wl.ok && !g_fp_serial && d->stage == 3;
         if (plane) {
             Ctx cp = c; cp.st = wl.sp; cp.lane = 2;
             XVA_HIP_TRY(hipEventRecord(wl.pfork, (hipStream_t)c.st));

@@ -335,8 +335,11 @@ struct Ctx {
 // stream; default 2).
 constexpr int MAXL = 4;                      // lanes: 0 = the caller's stream, 1 .. MAXL-1 side streams
 struct SideStreams { hipStream_t s[MAXL] = {}; hipEvent_t fork = nullptr, join[MAXL] = {}, pool[10] = {}; int n = 0; bool init = false; };
+static int g_hg_serial = 0;     // xva_hg_set_streams(1): everything on the caller's stream (per-kernel measurements)
 static SideStreams& side_streams() {
     static thread_local SideStreams r;
+    static thread_local SideStreams serial;   // n == 1
+    serial.n = 1; serial.init = true;
     if (!r.init) {
         r.init = true;
         const char* e = getenv("XVA_HG_STREAMS");
@@ -349,7 +352,7 @@ static SideStreams& side_streams() {
         for (int i = 0; ok && i < 10; ++i) ok = hipEventCreateWithFlags(&r.pool[i], hipEventDisableTiming) == hipSuccess;
         r.n = ok ? want : 1;
     }
-    return r;
+    return g_hg_serial ? serial : r;
 }
 // which lane runs discriminator di (MPD 0..4, MSD 0..2), for 2 / 3 / 4 lanes: the two families alternate so that neighbours in time are
 // kernels of different shapes; env XVA_HG_LANES="a,b,c,d,e,f,g,h" overrides
@@ -1024,6 +1027,7 @@ extern "C" int xva_hg_slot(const xva_hg_dims* d, int kind, int i0, int i1, int i
     geom5[0] = s->nseq; geom5[1] = s->T; geom5[2] = s->C; geom5[3] = s->padF; geom5[4] = s->padB;
     return XVA_OK;
 }
+extern "C" int xva_hg_set_streams(int n) { int old = g_hg_serial ? 1 : side_streams().n; g_hg_serial = n <= 1; return old; }
 extern "C" int xva_hg_num_buckets(int which) { return which == 0 ? G_BUCKETS : D_BUCKETS; }
 // [begin, end) in floats of bucket i of the flat gradient buffer `which`, in backward-completion order
 extern "C" int xva_hg_bucket_range(int which, int i, int64_t* begin, int64_t* end) {
