@@ -218,6 +218,8 @@ def pmc_traffic(family, pmc_csv):
     m = re.match(r"xva_gemm_glds_kernel<(\d+)x(\d+)>", family)
     if m:
         pat = re.compile(r"xva_gemm_glds_kernel<\d, %s, %s," % (m.group(1), m.group(2)))
+        if m.group(1) == "256" and m.group(2) == "256":     # both K loops of the 256x256 tile (the staggered one is its own kernel)
+            pat = re.compile(r"xva_gemm_glds_kernel<\d, 256, 256,|xva_gemm_glds8_kernel<\d>")
     elif family.startswith("xva_conv_res_kernel<CIN="):
         pat = re.compile(r"xva_conv_res_kernel<\d, %s," % family[len("xva_conv_res_kernel<CIN="):-1])
     else:
@@ -276,7 +278,7 @@ def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
     res = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
            "traffic_unit": ("HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE; offline passes over this workload: %s)" % traffic_src) if traffic
                            else traffic_src,
-           "kernel": name + (" (direct-to-LDS MFMA implicit-convolution GEMM, all layouts)" if "glds" in name else
+           "kernel": name + (" (direct-to-LDS MFMA implicit-convolution GEMM, all layouts; 256x256: xva_gemm_glds8_kernel, the staggered K loop)" if "glds" in name else
                              (" (resident-input MFMA convolution, forward + backward-data)" if "conv_res" in name else "")),
            "launches_per_step": f[0] / nprof, "avg_launch_us": 1e3 * f[1] / f[0], "kernel_ms_per_step": f[1] / nprof,
            "share_of_gemm_time": f[1] / tot_ms if tot_ms else None,

@@ -337,9 +337,12 @@ int xva_hg_generator_backward(const xva_hg_dims* d, const float* params_g, float
 /* Stream lanes.  Inside one call the engines issue independent chains on side streams they own (created once per host thread, forked
  * from and joined to the caller's stream with events inside the call): HiFi-GAN — period | scale discriminators, the generator's
  * weight gradients, the three parallel resblocks of a stage; FastPitch — the weight gradients of a layer and the temporal predictors.
- * n <= 1 puts everything back on the caller's stream (per-kernel measurements, debugging); returns the previous lane count.  Results do
- * not depend on it, bit for bit, except FastPitch's d(encoder output), where the predictors' contributions are then added by a separate
- * kernel (one more bf16 rounding in the throughput mode).  env XVA_HG_STREAMS / XVA_FP_STREAMS = 1 do the same at start-up. */
+ * n <= 1 puts everything back on the caller's stream (per-kernel measurements, debugging); returns the previous lane count.  Every
+ * tensor is still produced by the same kernels in the same order, so activations do not depend on it; sums that end in fp32 atomics
+ * (losses, bias / LayerNorm-parameter gradients, the spectral-norm power iteration) differ by the order of those atomics exactly as two
+ * runs on one stream do (tests/test_stream_lanes_gpu.py), and FastPitch's d(encoder output) receives the predictors' contributions
+ * from a separate add kernel instead of a GEMM epilogue (one more bf16 rounding in the throughput mode).
+ * env XVA_HG_STREAMS / XVA_FP_STREAMS = 1 do the same at start-up. */
 int xva_hg_set_streams(int n);
 int xva_fp_set_streams(int n);
 /* Test / diagnostics: byte offset (into the caller's workspace) and geometry {nseq, T, C, padF, padB} of an activation tensor the last
