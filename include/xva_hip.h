@@ -437,6 +437,21 @@ int xva_posterior_sample_bwd(const void* stats, const float* eps, const float* d
 int xva_bct_to_seq(const float* x, void* seq, int dt, int B, int C, int T, int pad, const int32_t* lens, void* stream);
 int xva_seq_to_bct(const void* seq, float* x, int dt, int B, int C, int T, int pad, int accumulate, void* stream);
 
+/* RelativePositionMultiHeadAttention.attention of the xVAPitch text encoder (python/xvapitch/glow_tts.py:173-292): scaled dot-product
+ * scores + the relative-key term (window w), masked_fill(-1e4) outside the item's length, softmax, P V + the relative-value term.
+ * q / k / v / out: fp32 activation matrices, item b's token t in row b * Tp + pad + t, head h at columns h*dk ..; emb_*: (Hr, 2w + 1, dk) with
+ * Hr = 1 (heads share) or H; P: (B, H, T, T) kept for the backward.  Dropout on the attention weights is not built (p = 0). */
+int xva_relattn_fwd(const float* q, const float* k, const float* v, int64_t ld, const float* emb_k, const float* emb_v, const int32_t* lens, float* P,
+                    float* out, int64_t ld_out, int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, void* stream);
+/* dS: (B, H, T, T) scratch; dq / dk / dv are written, d_emb_k / d_emb_v accumulated into */
+int xva_relattn_bwd(const float* dO, int64_t ld_do, const float* q, const float* k, const float* v, int64_t ld, const float* emb_k, const float* emb_v,
+                    const int32_t* lens, const float* P, float* dS, float* dq, float* dk_out, float* dv_out, int64_t ld_d, float* d_emb_k, float* d_emb_v,
+                    int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, void* stream);
+/* LayerNorm2 (glow_tts.py:34-56): layer_norm over the C channels of each row, any C; the backward accumulates into dgamma / dbeta */
+int xva_ln_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int C, float eps, void* stream);
+int xva_ln_rows_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                    int64_t rows, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,3 +91,40 @@ def kl_loss(z_p, logs_q, m_p, logs_p, z_mask):
     kl = logs_p - logs_q - 0.5 + 0.5 * ((z_p - m_p) ** 2) * torch.exp(-2.0 * logs_p)
     kl_sw = kl * z_mask
     return kl_sw.sum() / z_mask.sum(), kl_sw
+
+
+def rel_transformer(sd, x, x_mask, num_heads, num_layers, kernel_size, window):
+    """RelativePositionTransformer.forward (python/xvapitch/glow_tts.py:463-484; layer_norm_type "2", heads sharing the relative
+    embeddings, in = hidden = out, dropout off) with the attention's relative terms (:173-292) written directly: for r = j - i in
+    [-window, window] the scores get q_i . emb_rel_k[r + window] / sqrt(dk) and the output gets p[i][j] emb_rel_v[r + window]; the
+    reference reaches the same numbers through zero-padded embeddings and two pad / reshape index shifts."""
+    B, Cc, T = x.shape
+    H, dk = num_heads, Cc // num_heads
+    attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)                                   # (B, 1, T, T)
+    idx = torch.arange(T)
+    rel = idx[None, :] - idx[:, None]                                                        # j - i
+    inwin = (rel.abs() <= window)
+    ridx = (rel + window).clamp(0, 2 * window)
+    pad_l, pad_r = (kernel_size - 1) // 2, kernel_size // 2
+    for i in range(num_layers):
+        a, f = "attn_layers.%d." % i, "ffn_layers.%d." % i
+        x = x * x_mask
+        q = F.conv1d(x, sd[a + "conv_q.weight"], sd[a + "conv_q.bias"]).view(B, H, dk, T).transpose(2, 3)
+        k = F.conv1d(x, sd[a + "conv_k.weight"], sd[a + "conv_k.bias"]).view(B, H, dk, T).transpose(2, 3)
+        v = F.conv1d(x, sd[a + "conv_v.weight"], sd[a + "conv_v.bias"]).view(B, H, dk, T).transpose(2, 3)
+        ek, ev = sd[a + "emb_rel_k"][0], sd[a + "emb_rel_v"][0]                              # (2w + 1, dk)
+        scores = q @ k.transpose(-2, -1)
+        qe = q @ ek.t()                                                                      # (B, H, T, 2w + 1)
+        scores = scores + torch.where(inwin, qe.gather(-1, ridx.expand(B, H, T, T)), torch.zeros(()))
+        scores = (scores / dk ** 0.5).masked_fill(attn_mask == 0, -1e4)
+        p = torch.softmax(scores, dim=-1)
+        o = p @ v
+        pw = torch.zeros(B, H, T, 2 * window + 1).scatter_add(-1, ridx.expand(B, H, T, T), p * inwin)
+        o = o + pw @ ev
+        o = o.transpose(2, 3).contiguous().view(B, Cc, T)
+        y = F.conv1d(o, sd[a + "conv_o.weight"], sd[a + "conv_o.bias"])
+        x = F.layer_norm((x + y).transpose(1, -1), (Cc,), sd["norm_layers_1.%d.gamma" % i], sd["norm_layers_1.%d.beta" % i], 1e-5).transpose(1, -1)
+        h = torch.relu(F.conv1d(F.pad(x * x_mask, (pad_l, pad_r)), sd[f + "conv_1.weight"], sd[f + "conv_1.bias"]))
+        y = F.conv1d(F.pad(h * x_mask, (pad_l, pad_r)), sd[f + "conv_2.weight"], sd[f + "conv_2.bias"]) * x_mask
+        x = F.layer_norm((x + y).transpose(1, -1), (Cc,), sd["norm_layers_2.%d.gamma" % i], sd["norm_layers_2.%d.beta" % i], 1e-5).transpose(1, -1)
+    return x * x_mask

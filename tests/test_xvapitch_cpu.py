@@ -82,3 +82,24 @@ def test_posterior_encoder_oracle_matches_reference(golden_dir):
                                             torch.from_numpy(g["pe_eps"]), CO, hidden=H, kernel_size=K, dilation_rate=1, num_layers=L)
     for a, k in ((z, "pe_z"), (mean, "pe_mean"), (logs, "pe_logs")):
         assert torch.allclose(a, torch.from_numpy(g[k]), rtol=1e-5, atol=1e-6), k
+
+
+def test_rel_transformer_oracle_matches_reference_golden():
+    """oracle/xvapitch.py:rel_transformer vs the vectors recorded from the reference RelativePositionTransformer (glow_tts.py:373-485)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import xvapitch as oxv
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xvapitch_transformer.npz"))
+    B, Cc, Fh, H, L, K, W, T = (int(v) for v in g["cfg"])
+    lens = torch.from_numpy(g["lens"])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1)
+    sd = {k[3:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("sd/")}
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = oxv.rel_transformer(sd, x, x_mask, H, L, K, W)
+    assert torch.allclose(y, torch.from_numpy(g["y"]), rtol=1e-5, atol=1e-5)
+    (y * torch.from_numpy(g["r"])).sum().backward()
+    assert torch.allclose(x.grad, torch.from_numpy(g["dx"]), rtol=1e-4, atol=1e-5)
+    for k in g.files:
+        if k.startswith("grad/"):
+            assert torch.allclose(sd[k[5:]].grad, torch.from_numpy(g[k]), rtol=1e-4, atol=1e-5), k

@@ -175,3 +175,69 @@ def test_posterior_encoder_against_reference_golden(golden_dir):
     mine = pe.grads()
     for k, ref in _sd(g, "pe_grad/").items():
         assert _rel(mine[k], ref) < RTOL, k
+
+
+def _rel(a, b):
+    return float((a.detach().double().cpu() - b.detach().double()).norm() / b.detach().double().norm().clamp_min(1e-30))
+
+
+def test_rel_transformer_against_reference_golden(golden_dir):
+    """xvapitch/transformer.py:RelativePositionTransformer (the text encoder's stack: relative-position attention, LayerNorm2, k = 3
+    feed-forward convolutions; glow_tts.py:59-485) vs the vectors recorded from the REFERENCE module: output, input gradient and all
+    36 parameter gradients (incl. the relative key / value embeddings) at 1e-3, masked positions exactly zero."""
+    from xva_trainer_amd.xvapitch.transformer import RelativePositionTransformer
+    g = np.load(os.path.join(golden_dir, "xvapitch_transformer.npz"))
+    B, Cc, Fh, H, L, K, W, T = (int(v) for v in g["cfg"])
+    lens = torch.from_numpy(g["lens"])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1).cuda()
+    tr = RelativePositionTransformer(Cc, Cc, Cc, Fh, H, L, kernel_size=K, dropout_p=0.0, rel_attn_window_size=W, layer_norm_type="2")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    assert set(tr.state_dict()) == set(sd)
+    tr.load_state_dict(sd)
+    tr.zero_grad()
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = tr(x, x_mask)
+    assert _rel(y, torch.from_numpy(g["y"])) < 1e-3
+    dead = y.detach() * (1 - x_mask)
+    assert float(dead.abs().max()) == 0.0
+    (y * torch.from_numpy(g["r"]).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert _rel(x.grad, torch.from_numpy(g["dx"])) < 1e-3
+    grads = tr.grads()
+    # conv_k's bias adds the same q_i . b to every score of a row: softmax does not see it, its gradient is zero up to rounding (1e-8 in the
+    # reference as well) and has no relative error to speak of
+    names = [k[5:] for k in g.files if k.startswith("grad/")]
+    for n in names:
+        if n.endswith("conv_k.bias"):
+            assert float(grads[n].abs().max()) < 1e-5 and float(np.abs(g["grad/" + n]).max()) < 1e-5
+    worst = sorted(((_rel(grads[n], torch.from_numpy(g["grad/" + n])), n) for n in names if not n.endswith("conv_k.bias")), reverse=True)
+    print("rel transformer worst gradients:", worst[:4])
+    assert len(names) == 18 * L and worst[0][0] < 1e-3, worst[:4]
+
+
+@pytest.mark.parametrize("B,T,Cc,H", [(2, 64, 192, 2), (1, 150, 196, 2), (3, 9, 8, 1)])
+def test_rel_transformer_against_oracle(B, T, Cc, H):
+    """Other shapes (text-encoder width 192 / 196, a sequence shorter than the attention window, one head) against the CPU oracle."""
+    from oracle import xvapitch as oxv
+    from xva_trainer_amd.xvapitch.transformer import RelativePositionTransformer
+    gen = torch.Generator().manual_seed(5)
+    tr = RelativePositionTransformer(Cc, Cc, Cc, 64, H, 2, kernel_size=3, rel_attn_window_size=4, layer_norm_type="2", seed=3)
+    sd = tr.state_dict()
+    lens = torch.tensor([T] + [max(1, T // (i + 2)) for i in range(B - 1)])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1)
+    x = torch.randn(B, Cc, T, generator=gen)
+    r = torch.randn(B, Cc, T, generator=gen)
+    xo = x.clone().requires_grad_(True)
+    leaves = {k: v.cpu().clone().requires_grad_(True) for k, v in sd.items()}
+    yo = oxv.rel_transformer(leaves, xo, x_mask, H, 2, 3, 4)
+    (yo * r).sum().backward()
+    tr.zero_grad()
+    xg = x.cuda().requires_grad_(True)
+    y = tr(xg, x_mask.cuda())
+    (y * r.cuda()).sum().backward()
+    assert _rel(y, yo.detach()) < 1e-3 and _rel(xg.grad, xo.grad) < 1e-3
+    for k, gr in tr.grads().items():
+        if k.endswith("conv_k.bias"):
+            assert float(gr.abs().max()) < 1e-4                  # mathematically zero (see above)
+        else:
+            assert _rel(gr, leaves[k].grad) < 2e-3, k

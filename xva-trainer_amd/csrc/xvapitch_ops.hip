@@ -439,3 +439,278 @@ extern "C" int xva_posterior_sample_bwd(const void* stats, const float* eps, con
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
+
+// ---- relative-position multi-head self-attention ----------------------------------------------------------------------------------
+// RelativePositionMultiHeadAttention.attention (python/xvapitch/glow_tts.py:173-214) with its relative-key / relative-value terms
+// (:216-292) written as what they compute: for r = j - i in [-w, w]
+//     scores[i][j] = (q_i . k_j + q_i . emb_k[r + w]) / sqrt(dk);   masked_fill(mask == 0, -1e4) for i or j >= len;   p = softmax_j
+//     out_i = sum_j p[i][j] v_j + sum_{|r| <= w} p[i][i + r] emb_v[r + w]
+// (the reference pads the embeddings to 2T - 1 relative positions with zeros and runs two pad / reshape tricks to shift between
+// relative and absolute indexing; outside the window the padded embeddings are zero, so nothing else contributes).
+// Text-encoder sizes (T <= a few hundred tokens, dk ~ 100, 2 heads): a latency-bound VALU problem, not MFMA work; one workgroup per
+// (item, head, query row).  q / k / v: fp32 rows of an activation matrix (row stride ld, head h at columns h*dk ..), item b's token t in row
+// b*Tp + pad + t.  P (B, H, T, T) is kept for the backward.  emb: (Hr, 2w + 1, dk), Hr = 1 (heads share) or H.
+namespace {
+constexpr int RA_THREADS = 128;
+__device__ __forceinline__ float ra_block_sum(float v, float* sh) {
+    v = xva_wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1];
+}
+__device__ __forceinline__ float ra_block_max(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return fmaxf(sh[0], sh[1]);
+}
+}  // namespace
+
+__global__ __launch_bounds__(RA_THREADS) void relattn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                                 int64_t ld, const float* __restrict__ emb_k, const float* __restrict__ emb_v,
+                                                                 const int32_t* __restrict__ lens, float* __restrict__ P, float* __restrict__ out,
+                                                                 int64_t ld_out, int T, int H, int dk, int w, int Hr, int Tp, int pad) {
+    extern __shared__ float sm[];                 // scores / probabilities of this row [T] + q_i [dk] + reduction scratch [2]
+    float* s = sm; float* qi = sm + T; float* red = qi + dk;
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = lens[b];
+    const int64_t row0 = (int64_t)b * Tp + pad;
+    const float scale = rsqrtf((float)dk);
+    for (int d = threadIdx.x; d < dk; d += RA_THREADS) qi[d] = q[(row0 + i) * ld + h * dk + d];
+    __syncthreads();
+    const float* ek = emb_k + (int64_t)(Hr == 1 ? 0 : h) * (2 * w + 1) * dk;
+    const float* ev = emb_v + (int64_t)(Hr == 1 ? 0 : h) * (2 * w + 1) * dk;
+    float mx = -3.0e38f;
+    for (int j = threadIdx.x; j < T; j += RA_THREADS) {
+        const float* kj = k + (row0 + j) * ld + h * dk;
+        float acc = 0.f;
+        for (int d = 0; d < dk; ++d) acc += qi[d] * kj[d];
+        const int r = j - i;
+        if (r >= -w && r <= w) {
+            const float* e = ek + (int64_t)(r + w) * dk;
+            float a2 = 0.f;
+            for (int d = 0; d < dk; ++d) a2 += qi[d] * e[d];
+            acc += a2;
+        }
+        acc *= scale;
+        if (i >= len || j >= len) acc = -1e4f;
+        s[j] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = ra_block_max(mx, red);
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < T; j += RA_THREADS) { const float e = __expf(s[j] - mx); s[j] = e; sum += e; }
+    sum = ra_block_sum(sum, red);
+    const float inv = 1.f / sum;
+    float* Pi = P + (((int64_t)b * H + h) * T + i) * T;
+    for (int j = threadIdx.x; j < T; j += RA_THREADS) { const float p = s[j] * inv; s[j] = p; Pi[j] = p; }
+    __syncthreads();
+    for (int d = threadIdx.x; d < dk; d += RA_THREADS) {
+        float acc = 0.f;
+        for (int j = 0; j < T; ++j) acc += s[j] * v[(row0 + j) * ld + h * dk + d];
+        for (int r = -w; r <= w; ++r) {
+            const int j = i + r;
+            if (j >= 0 && j < T) acc += s[j] * ev[(int64_t)(r + w) * dk + d];
+        }
+        out[(row0 + i) * ld_out + h * dk + d] = acc;
+    }
+}
+
+// backward, per query row: dP[j] = dO_i . v_j + [|r| <= w] dO_i . emb_v[r + w];  dS = P * (dP - sum_j P dP) / sqrt(dk)  (stored over P's twin dS);
+// dq_i = sum_j dS[j] k_j + sum_r dS[i + r] emb_k[r + w]
+__global__ __launch_bounds__(RA_THREADS) void relattn_bwd_row_kernel(const float* __restrict__ dO, int64_t ld_do, const float* __restrict__ k,
+                                                                     const float* __restrict__ v, int64_t ld, const float* __restrict__ emb_k,
+                                                                     const float* __restrict__ emb_v, const int32_t* __restrict__ lens,
+                                                                     const float* __restrict__ P, float* __restrict__ dS, float* __restrict__ dq,
+                                                                     int64_t ld_dq, int T, int H, int dk, int w, int Hr, int Tp, int pad) {
+    extern __shared__ float sm[];
+    float* s = sm; float* doi = sm + T; float* red = doi + dk;
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = lens[b];
+    const int64_t row0 = (int64_t)b * Tp + pad;
+    const float scale = rsqrtf((float)dk);
+    for (int d = threadIdx.x; d < dk; d += RA_THREADS) doi[d] = dO[(row0 + i) * ld_do + h * dk + d];
+    __syncthreads();
+    const float* ek = emb_k + (int64_t)(Hr == 1 ? 0 : h) * (2 * w + 1) * dk;
+    const float* ev = emb_v + (int64_t)(Hr == 1 ? 0 : h) * (2 * w + 1) * dk;
+    const float* Pi = P + (((int64_t)b * H + h) * T + i) * T;
+    float dot = 0.f;
+    for (int j = threadIdx.x; j < T; j += RA_THREADS) {
+        const float* vj = v + (row0 + j) * ld + h * dk;
+        float acc = 0.f;
+        for (int d = 0; d < dk; ++d) acc += doi[d] * vj[d];
+        const int r = j - i;
+        if (r >= -w && r <= w) {
+            const float* e = ev + (int64_t)(r + w) * dk;
+            for (int d = 0; d < dk; ++d) acc += doi[d] * e[d];
+        }
+        s[j] = acc;
+        dot += Pi[j] * acc;
+    }
+    dot = ra_block_sum(dot, red);
+    float* dSi = dS + (((int64_t)b * H + h) * T + i) * T;
+    for (int j = threadIdx.x; j < T; j += RA_THREADS) {
+        float g = Pi[j] * (s[j] - dot) * scale;
+        if (i >= len || j >= len) g = 0.f;                    // masked_fill: no gradient into the replaced scores
+        s[j] = g; dSi[j] = g;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < dk; d += RA_THREADS) {
+        float acc = 0.f;
+        for (int j = 0; j < T; ++j) acc += s[j] * k[(row0 + j) * ld + h * dk + d];
+        for (int r = -w; r <= w; ++r) {
+            const int j = i + r;
+            if (j >= 0 && j < T) acc += s[j] * ek[(int64_t)(r + w) * dk + d];
+        }
+        dq[(row0 + i) * ld_dq + h * dk + d] = acc;
+    }
+}
+// backward, per key row j: dk_j = sum_i dS[i][j] q_i ; dv_j = sum_i P[i][j] dO_i
+__global__ __launch_bounds__(RA_THREADS) void relattn_bwd_col_kernel(const float* __restrict__ dO, int64_t ld_do, const float* __restrict__ q, int64_t ld,
+                                                                     const float* __restrict__ P, const float* __restrict__ dS, float* __restrict__ dk_out,
+                                                                     float* __restrict__ dv_out, int64_t ld_d, int T, int H, int dk, int Tp, int pad) {
+    extern __shared__ float sm[];
+    float* ps = sm; float* ds = sm + T;
+    const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int64_t row0 = (int64_t)b * Tp + pad;
+    const float* Pb = P + ((int64_t)b * H + h) * T * T;
+    const float* Sb = dS + ((int64_t)b * H + h) * T * T;
+    for (int i = threadIdx.x; i < T; i += RA_THREADS) { ps[i] = Pb[(int64_t)i * T + j]; ds[i] = Sb[(int64_t)i * T + j]; }
+    __syncthreads();
+    for (int d = threadIdx.x; d < dk; d += RA_THREADS) {
+        float ak = 0.f, av = 0.f;
+        for (int i = 0; i < T; ++i) {
+            ak += ds[i] * q[(row0 + i) * ld + h * dk + d];
+            av += ps[i] * dO[(row0 + i) * ld_do + h * dk + d];
+        }
+        dk_out[(row0 + j) * ld_d + h * dk + d] = ak;
+        dv_out[(row0 + j) * ld_d + h * dk + d] = av;
+    }
+}
+// gradients of the relative embeddings: d emb_k[r][d] += sum_{b, h, i} dS[i][i + r] q_i[d] ; d emb_v[r][d] += sum P[i][i + r] dO_i[d]
+// grid (2w + 1, H, B): one relative position of one (item, head); atomics over (b, h) — Hr * (2w + 1) * dk addresses, B * H adders each
+__global__ __launch_bounds__(RA_THREADS) void relattn_bwd_emb_kernel(const float* __restrict__ dO, int64_t ld_do, const float* __restrict__ q, int64_t ld,
+                                                                     const float* __restrict__ P, const float* __restrict__ dS, float* __restrict__ d_emb_k,
+                                                                     float* __restrict__ d_emb_v, int T, int H, int dk, int w, int Hr, int Tp, int pad) {
+    const int r = (int)blockIdx.x - w, h = blockIdx.y, b = blockIdx.z;
+    const int64_t row0 = (int64_t)b * Tp + pad;
+    const float* Pb = P + ((int64_t)b * H + h) * T * T;
+    const float* Sb = dS + ((int64_t)b * H + h) * T * T;
+    for (int d = threadIdx.x; d < dk; d += RA_THREADS) {
+        float ak = 0.f, av = 0.f;
+        for (int i = 0; i < T; ++i) {
+            const int j = i + r;
+            if (j < 0 || j >= T) continue;
+            ak += Sb[(int64_t)i * T + j] * q[(row0 + i) * ld + h * dk + d];
+            av += Pb[(int64_t)i * T + j] * dO[(row0 + i) * ld_do + h * dk + d];
+        }
+        const int64_t o = ((int64_t)(Hr == 1 ? 0 : h) * (2 * w + 1) + (r + w)) * dk + d;
+        atomicAdd(d_emb_k + o, ak);
+        atomicAdd(d_emb_v + o, av);
+    }
+}
+
+extern "C" int xva_relattn_fwd(const float* q, const float* k, const float* v, int64_t ld, const float* emb_k, const float* emb_v, const int32_t* lens,
+                               float* P, float* out, int64_t ld_out, int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, void* stream) {
+    XVA_CHECK_ARG(q && k && v && emb_k && emb_v && lens && P && out, "relattn_fwd: null");
+    XVA_CHECK_ARG(B > 0 && T > 0 && H > 0 && dk > 0 && w >= 0 && (Hr == 1 || Hr == H) && T <= 8192, "relattn_fwd: bad dims");
+    const size_t shm = (size_t)(T + dk + 4) * 4;
+    hipLaunchKernelGGL(relattn_fwd_kernel, dim3(T, H, B), dim3(RA_THREADS), shm, (hipStream_t)stream, q, k, v, ld, emb_k, emb_v, lens, P, out, ld_out, T, H, dk, w,
+                       Hr, Tp, pad);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+/* dS: scratch (B, H, T, T); d_emb_k / d_emb_v are ACCUMULATED into (parameter gradients), dq / dk / dv written */
+extern "C" int xva_relattn_bwd(const float* dO, int64_t ld_do, const float* q, const float* k, const float* v, int64_t ld, const float* emb_k,
+                               const float* emb_v, const int32_t* lens, const float* P, float* dS, float* dq, float* dk_out, float* dv_out, int64_t ld_d,
+                               float* d_emb_k, float* d_emb_v, int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, void* stream) {
+    XVA_CHECK_ARG(dO && q && k && v && emb_k && emb_v && lens && P && dS && dq && dk_out && dv_out && d_emb_k && d_emb_v, "relattn_bwd: null");
+    XVA_CHECK_ARG(B > 0 && T > 0 && H > 0 && dk > 0 && w >= 0 && (Hr == 1 || Hr == H) && T <= 8192, "relattn_bwd: bad dims");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(relattn_bwd_row_kernel, dim3(T, H, B), dim3(RA_THREADS), (size_t)(T + dk + 4) * 4, st, dO, ld_do, k, v, ld, emb_k, emb_v, lens, P, dS, dq,
+                       ld_d, T, H, dk, w, Hr, Tp, pad);
+    hipLaunchKernelGGL(relattn_bwd_col_kernel, dim3(T, H, B), dim3(RA_THREADS), (size_t)(2 * T) * 4, st, dO, ld_do, q, ld, P, dS, dk_out, dv_out, ld_d, T, H, dk,
+                       Tp, pad);
+    hipLaunchKernelGGL(relattn_bwd_emb_kernel, dim3(2 * w + 1, H, B), dim3(RA_THREADS), 0, st, dO, ld_do, q, ld, P, dS, d_emb_k, d_emb_v, T, H, dk, w, Hr, Tp,
+                       pad);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+// ---- LayerNorm over the channels of each row (any C) ------------------------------------------------------------------------------
+// LayerNorm2 (python/xvapitch/glow_tts.py:34-56): torch layer_norm over C with gamma / beta (C,), eps 1e-5.  One wave per row.
+__global__ void ln_rows_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                                   float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int C, float eps) {
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mu = xva_wave_sum(s) / C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mu; q += d * d; }
+    const float rs = rsqrtf(xva_wave_sum(q) / C + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    for (int c = lane; c < C; c += 64) y[row * C + c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+}
+// dX = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dY * gamma ; dgamma += sum_r dY * xhat ; dbeta += sum_r dY   (row blocks + atomics)
+__global__ void ln_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                   const float* __restrict__ gamma, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
+                                   int C, int rows_per_wave) {
+    const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = wv * rows_per_wave, r1 = r0 + rows_per_wave < rows ? r0 + rows_per_wave : rows;
+    if (r0 >= rows) return;
+    for (int c0 = 0; c0 < C; c0 += 64 * 4) {              // gamma / beta partial sums for up to 4 columns per lane at a time
+        float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t r = r0; r < r1; ++r) {
+            const float mu = mean[r], rs = rstd[r];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 64 + lane;
+                if (c < C) { const float g = dy[r * C + c]; ag[u] += g * (x[r * C + c] - mu) * rs; ab[u] += g; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * 64 + lane;
+            if (c < C) { atomicAdd(dgamma + c, ag[u]); atomicAdd(dbeta + c, ab[u]); }
+        }
+    }
+    for (int64_t r = r0; r < r1; ++r) {
+        const float mu = mean[r], rs = rstd[r];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < C; c += 64) { const float g = dy[r * C + c] * gamma[c]; s1 += g; s2 += g * (x[r * C + c] - mu) * rs; }
+        s1 = xva_wave_sum(s1) / C; s2 = xva_wave_sum(s2) / C;
+        for (int c = lane; c < C; c += 64) {
+            const float g = dy[r * C + c] * gamma[c], xh = (x[r * C + c] - mu) * rs;
+            dx[r * C + c] = rs * (g - s1 - xh * s2);
+        }
+    }
+}
+extern "C" int xva_ln_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int C, float eps,
+                               void* stream) {
+    XVA_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows >= 0 && C > 0, "ln_rows_fwd: bad args");
+    if (rows == 0) return XVA_OK;
+    hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3((unsigned)xva_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+/* dgamma / dbeta are accumulated into */
+extern "C" int xva_ln_rows_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma,
+                               float* dbeta, int64_t rows, int C, void* stream) {
+    XVA_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && rows >= 0 && C > 0, "ln_rows_bwd: bad args");
+    if (rows == 0) return XVA_OK;
+    const int rpw = 16;
+    const int64_t waves = xva_cdiv(rows, rpw);
+    hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)xva_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C,
+                       rpw);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}

@@ -1,0 +1,250 @@
+"""RelativePositionTransformer of xVAPitch's text encoder on libxvahip — python/xvapitch/glow_tts.py:59-485 as TextEncoder builds it
+(python/xvapitch/model.py:1125-1136: layer_norm_type "2", rel_attn_window_size 4, heads share the relative embeddings, in = hidden = out).
+
+Same constructor arguments, state_dict keys and layouts as the reference module (`attn_layers.i.conv_{q,k,v,o}.{weight,bias}`,
+`attn_layers.i.emb_rel_{k,v}`, `norm_layers_{1,2}.i.{gamma,beta}`, `ffn_layers.i.conv_{1,2}.{weight,bias}`), same (B, C, T) tensors and
+(B, 1, T) mask at the interface.  Inside, activations are fp32 time-major sequences with structurally zero pad rows (xvapitch/wn.py:Seq);
+the q / k / v projections are ONE xva_gemm against the stacked weights, conv_o and the k-tap feed-forward convolutions are xva_gemm calls in
+implicit-conv form (ReLU and the residual in the epilogue, the ReLU gate in the backward epilogue), the attention core and LayerNorm are
+csrc/xvapitch_ops.hip kernels.  Host code only sequences C calls; the module is one autograd Function, checked against the reference by
+output and by every parameter / input gradient (tests/test_xvapitch_gpu.py).  Not built: dropout_p > 0 (masks cannot match torch's RNG; the
+reference evaluates with dropout off), out_channels != hidden_channels (the `proj` of the pitch / energy encoders), input_length, layer_norm
+type "1".
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from . import ops
+from .wn import PAD, Seq, conv_bwd_data, conv_bwd_weight, conv_fwd, _lens_of
+
+lib = _lib.lib
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+lib.xva_relattn_fwd.restype = i32
+lib.xva_relattn_fwd.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, i64] + [i32] * 8 + [vp]
+lib.xva_relattn_bwd.restype = i32
+lib.xva_relattn_bwd.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp] + [i32] * 8 + [vp]
+lib.xva_ln_rows_fwd.restype = i32
+lib.xva_ln_rows_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]
+lib.xva_ln_rows_bwd.restype = i32
+lib.xva_ln_rows_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+
+
+def _p(t, elem_off=0):
+    return C.c_void_p(t.data_ptr() + 4 * elem_off)
+
+
+def _mask(s, lens):
+    _lib.check(lib.xva_seq_mask(C.c_void_p(s.view.data_ptr()), s.dt, s.B, s.Tp, PAD, s.C, _lib.ptr(lens), _lib.stream_ptr()), "xva_seq_mask")
+
+
+def _tapmajor(w):
+    """nn.Conv1d weight (Cout, Cin, k) -> (Cout, k * Cin)"""
+    return w.permute(0, 2, 1).reshape(w.size(0), -1).contiguous()
+
+
+class _Layer:
+    def __init__(self, Cc, F, H, k, w, device, gen):
+        dk = Cc // H
+
+        def conv(co, ci, kk):
+            bound = (1.0 / (ci * kk)) ** 0.5
+            return {"weight": ((torch.rand(co, ci, kk, generator=gen) * 2 - 1) * bound).to(device), "bias": ((torch.rand(co, generator=gen) * 2 - 1) * bound).to(device)}
+        self.p = {}
+        for n in ("q", "k", "v", "o"):
+            for a, t in conv(Cc, Cc, 1).items():
+                self.p["attn.conv_%s.%s" % (n, a)] = t
+        self.p["attn.emb_rel_k"] = (torch.randn(1, 2 * w + 1, dk, generator=gen) * dk ** -0.5).to(device)
+        self.p["attn.emb_rel_v"] = (torch.randn(1, 2 * w + 1, dk, generator=gen) * dk ** -0.5).to(device)
+        for a, t in conv(F, Cc, k).items():
+            self.p["ffn.conv_1." + a] = t
+        for a, t in conv(Cc, F, k).items():
+            self.p["ffn.conv_2." + a] = t
+        for n in ("norm1", "norm2"):
+            self.p[n + ".gamma"] = torch.ones(Cc, device=device)
+            self.p[n + ".beta"] = torch.zeros(Cc, device=device)
+        self.g = {n: torch.zeros_like(t) for n, t in self.p.items()}
+
+
+_KEYMAP = (("attn.", "attn_layers.%d."), ("ffn.", "ffn_layers.%d."), ("norm1.", "norm_layers_1.%d."), ("norm2.", "norm_layers_2.%d."))
+
+
+class RelativePositionTransformer:
+    def __init__(self, in_channels, out_channels, hidden_channels, hidden_channels_ffn, num_heads, num_layers, kernel_size=1, dropout_p=0.0,
+                 rel_attn_window_size=None, input_length=None, layer_norm_type="1", device="cuda", seed=0):
+        if dropout_p:
+            raise NotImplementedError("RelativePositionTransformer: dropout_p > 0 is not built")
+        if not (in_channels == hidden_channels == out_channels):
+            raise NotImplementedError("RelativePositionTransformer: in / hidden / out channels must agree (the text encoder's configuration)")
+        if rel_attn_window_size is None or input_length is not None or layer_norm_type != "2":
+            raise NotImplementedError("RelativePositionTransformer: built for rel_attn_window_size set, input_length None, layer_norm_type '2'")
+        if hidden_channels % num_heads or hidden_channels % 4 or hidden_channels_ffn % 4 or kernel_size % 2 != 1 or kernel_size // 2 > PAD:
+            raise NotImplementedError("RelativePositionTransformer: channels must be multiples of 4 and of num_heads, kernel_size odd")
+        self.C, self.F, self.H, self.L, self.k, self.w = hidden_channels, hidden_channels_ffn, num_heads, num_layers, kernel_size, rel_attn_window_size
+        self.device = torch.device(device)
+        gen = torch.Generator().manual_seed(seed)
+        self.layers = [_Layer(self.C, self.F, self.H, self.k, self.w, self.device, gen) for _ in range(num_layers)]
+
+    # ---- reference state_dict ----
+    def _named(self, which):
+        for i, l in enumerate(self.layers):
+            for n, t in getattr(l, which).items():
+                for a, b in _KEYMAP:
+                    if n.startswith(a):
+                        yield (b % i) + n[len(a):], t
+                        break
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self._named("p")}
+
+    def load_state_dict(self, sd):
+        mine = dict(self._named("p"))
+        if set(mine) != set(sd):
+            raise KeyError("RelativePositionTransformer.load_state_dict: key mismatch %s" % sorted(set(mine) ^ set(sd))[:6])
+        for k, t in mine.items():
+            if tuple(t.shape) != tuple(sd[k].shape):
+                raise ValueError("%s: shape %s != %s" % (k, tuple(sd[k].shape), tuple(t.shape)))
+            t.copy_(sd[k].to(device=self.device, dtype=torch.float32))
+
+    def grads(self):
+        return {k: v for k, v in self._named("g")}
+
+    def zero_grad(self):
+        for l in self.layers:
+            for t in l.g.values():
+                t.zero_()
+
+    def __call__(self, x, x_mask):
+        return _TransformerFn.apply(x, self, _lens_of(x, x_mask))
+
+    # ---- sequences ----
+    def _ln(self, x, gamma, beta):
+        y = Seq(x.B, x.T, x.C, self.device, torch.float32)
+        mean = torch.empty(x.rows, device=self.device); rstd = torch.empty(x.rows, device=self.device)
+        _lib.check(lib.xva_ln_rows_fwd(_p(x.view), _lib.ptr(gamma), _lib.ptr(beta), _p(y.view), _lib.ptr(mean), _lib.ptr(rstd), x.rows, x.C, 1e-5,
+                                       _lib.stream_ptr()), "xva_ln_rows_fwd")
+        return y, mean, rstd
+
+    def forward_seq(self, x, lens):
+        B, T, Cc, F, H, k = x.B, x.T, self.C, self.F, self.H, self.k
+        dk = Cc // H
+        self.saved = []
+        mk = lambda ch: Seq(B, T, ch, self.device, torch.float32)
+        for l in self.layers:
+            p = l.p
+            xm = mk(Cc); xm.store.copy_(x.store); _mask(xm, lens)                               # x = x * x_mask            (glow_tts.py:471)
+            wqkv = torch.cat([p["attn.conv_%s.weight" % n].reshape(Cc, Cc) for n in "qkv"], 0).contiguous()
+            bqkv = torch.cat([p["attn.conv_%s.bias" % n] for n in "qkv"]).contiguous()
+            qkv = mk(3 * Cc)
+            conv_fwd(xm, wqkv, bqkv, qkv, 1, 1, 0)                                              # conv_q / conv_k / conv_v  (:166-168)
+            P = torch.empty(B, H, T, T, device=self.device)
+            att = mk(Cc)
+            base = PAD * 3 * Cc
+            _lib.check(lib.xva_relattn_fwd(_p(qkv.view), _p(qkv.view, Cc), _p(qkv.view, 2 * Cc), 3 * Cc, _lib.ptr(p["attn.emb_rel_k"]),
+                                           _lib.ptr(p["attn.emb_rel_v"]), _lib.ptr(lens), _lib.ptr(P), _p(att.view), Cc, B, T, H, dk, self.w, 1, x.Tp, PAD,
+                                           _lib.stream_ptr()), "xva_relattn_fwd")                # attention                 (:173-214)
+            s1 = mk(Cc)
+            wo = p["attn.conv_o.weight"].reshape(Cc, Cc).contiguous()
+            _lib.gemm(att.store, wo, s1.store, att.rows, Cc, Cc, Cc, Cc, Cc, layout=_lib.GEMM_NT, compute=0, bias=p["attn.conv_o.bias"], a_offset=att.off(),
+                      c_offset=s1.off(), R=xm.view, ldr=Cc, mask_mode=_lib.MASK_PAD, Tp=x.Tp, mask_pad=PAD, mask_len=T)   # x + conv_o(..)  (:170,474)
+            x1, m1, r1 = self._ln(s1, p["norm1.gamma"], p["norm1.beta"])                        # norm_layers_1             (:474)
+            x1m = mk(Cc); x1m.store.copy_(x1.store); _mask(x1m, lens)                           # FFN: conv_1(pad(x * x_mask)), relu  (:342-343)
+            h = mk(F)
+            P_ = (k - 1) // 2
+            w1 = _tapmajor(p["ffn.conv_1.weight"]); w2 = _tapmajor(p["ffn.conv_2.weight"])
+            _lib.gemm(x1m.store, w1, h.store, x1m.rows, F, k * Cc, Cc, k * Cc, F, layout=_lib.GEMM_NT, compute=0, bias=p["ffn.conv_1.bias"], relu=True,
+                      a_offset=x1m.off(-P_), c_offset=h.off(), a_seglen=Cc if k > 1 else 0, a_segadj=0, mask_mode=_lib.MASK_PAD, Tp=x.Tp, mask_pad=PAD,
+                      mask_len=T)
+            _mask(h, lens)                                                                      # conv_2(pad(x * x_mask)) * x_mask    (:345-346)
+            y2 = mk(Cc)
+            conv_fwd(h, w2, p["ffn.conv_2.bias"], y2, k, 1, 0)
+            _mask(y2, lens)
+            s2 = mk(Cc)
+            torch.add(x1.store, y2.store, out=s2.store)                                         # norm_layers_2(x + y)     (:482)
+            x2, m2, r2 = self._ln(s2, p["norm2.gamma"], p["norm2.beta"])
+            self.saved.append((xm, wqkv, qkv, P, att, wo, s1, m1, r1, x1m, w1, w2, h, s2, m2, r2))
+            x = x2
+        out = mk(Cc); out.store.copy_(x.store); _mask(out, lens)                                # x * x_mask               (:483)
+        self.lens = lens
+        return out
+
+    def backward_seq(self, d_out):
+        B, T, Cc, F, H, k = d_out.B, d_out.T, self.C, self.F, self.H, self.k
+        dk = Cc // H
+        lens = self.lens
+        mk = lambda ch: Seq(B, T, ch, self.device, torch.float32)
+        dx = mk(Cc); dx.store.copy_(d_out.store); _mask(dx, lens)
+        for l, sv in zip(reversed(self.layers), reversed(self.saved)):
+            xm, wqkv, qkv, P, att, wo, s1, m1, r1, x1m, w1, w2, h, s2, m2, r2 = sv
+            p, g = l.p, l.g
+            ds2 = mk(Cc)
+            _lib.check(lib.xva_ln_rows_bwd(_p(dx.view), _p(s2.view), _lib.ptr(m2), _lib.ptr(r2), _lib.ptr(p["norm2.gamma"]), _p(ds2.view), _lib.ptr(g["norm2.gamma"]),
+                                           _lib.ptr(g["norm2.beta"]), dx.rows, Cc, _lib.stream_ptr()), "xva_ln_rows_bwd")
+            dy2 = mk(Cc); dy2.store.copy_(ds2.store); _mask(dy2, lens)                           # y2 = conv_2(..) * x_mask
+            dW2 = torch.zeros(Cc, k * F, device=self.device)
+            conv_bwd_weight(dy2, h, dW2, g["ffn.conv_2.bias"], k, 1, 0)
+            g["ffn.conv_2.weight"] += dW2.view(Cc, k, F).permute(0, 2, 1)
+            dh = mk(F)
+            P_ = (k - 1) // 2
+            # d(conv_1 output) = (dy2 (*) W2) gated by relu (h is stored masked and post-ReLU: h > 0 is both the gate and the mask)
+            _lib.gemm(dy2.store, w2, dh.store, dy2.rows, F, k * Cc, Cc, k * F, F, layout=_lib.GEMM_NN, compute=0, a_offset=dy2.off(P_), c_offset=dh.off(),
+                      a_seglen=Cc if k > 1 else 0, a_segadj=-2 * Cc if k > 1 else 0, seglen=Cc if k > 1 else 0, seg0=0, segstride=F if k > 1 else 0,
+                      G=h.view, ldg=F, gate_slope=0.0, mask_mode=_lib.MASK_PAD, Tp=dy2.Tp, mask_pad=PAD, mask_len=T)
+            dW1 = torch.zeros(F, k * Cc, device=self.device)
+            conv_bwd_weight(dh, x1m, dW1, g["ffn.conv_1.bias"], k, 1, 0)
+            g["ffn.conv_1.weight"] += dW1.view(F, k, Cc).permute(0, 2, 1)
+            dx1m = mk(Cc)
+            conv_bwd_data(dh, w1, dx1m, k, 1, 0, False)
+            _mask(dx1m, lens)                                                                    # x1m = x1 * x_mask
+            dx1 = mk(Cc)
+            torch.add(ds2.store, dx1m.store, out=dx1.store)                                      # residual x + y
+            ds1 = mk(Cc)
+            _lib.check(lib.xva_ln_rows_bwd(_p(dx1.view), _p(s1.view), _lib.ptr(m1), _lib.ptr(r1), _lib.ptr(p["norm1.gamma"]), _p(ds1.view), _lib.ptr(g["norm1.gamma"]),
+                                           _lib.ptr(g["norm1.beta"]), dx1.rows, Cc, _lib.stream_ptr()), "xva_ln_rows_bwd")
+            dWo = torch.zeros(Cc, Cc, device=self.device)
+            conv_bwd_weight(ds1, att, dWo, g["attn.conv_o.bias"], 1, 1, 0)
+            g["attn.conv_o.weight"] += dWo.view(Cc, Cc, 1)
+            datt = mk(Cc)
+            conv_bwd_data(ds1, wo, datt, 1, 1, 0, False)
+            dqkv = mk(3 * Cc)
+            dS = torch.empty_like(P)
+            demb_k = g["attn.emb_rel_k"]; demb_v = g["attn.emb_rel_v"]
+            _lib.check(lib.xva_relattn_bwd(_p(datt.view), Cc, _p(qkv.view), _p(qkv.view, Cc), _p(qkv.view, 2 * Cc), 3 * Cc, _lib.ptr(p["attn.emb_rel_k"]),
+                                           _lib.ptr(p["attn.emb_rel_v"]), _lib.ptr(lens), _lib.ptr(P), _lib.ptr(dS), _p(dqkv.view), _p(dqkv.view, Cc),
+                                           _p(dqkv.view, 2 * Cc), 3 * Cc, _lib.ptr(demb_k), _lib.ptr(demb_v), B, T, H, dk, self.w, 1, dx.Tp, PAD,
+                                           _lib.stream_ptr()), "xva_relattn_bwd")
+            dWqkv = torch.zeros(3 * Cc, Cc, device=self.device); dbqkv = torch.zeros(3 * Cc, device=self.device)
+            conv_bwd_weight(dqkv, xm, dWqkv, dbqkv, 1, 1, 0)
+            for j, n in enumerate("qkv"):
+                g["attn.conv_%s.weight" % n] += dWqkv[j * Cc:(j + 1) * Cc].view(Cc, Cc, 1)
+                g["attn.conv_%s.bias" % n] += dbqkv[j * Cc:(j + 1) * Cc]
+            dxm = mk(Cc)
+            conv_bwd_data(dqkv, wqkv, dxm, 1, 1, 0, False)
+            dxm.store += ds1.store                                                               # residual x + y
+            _mask(dxm, lens)                                                                     # xm = x * x_mask
+            dx = dxm
+        return dx
+
+
+class _TransformerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tr, lens):
+        _lib.require_cuda(x)
+        B, Cc, T = x.shape
+        xs = Seq(B, T, Cc, tr.device, torch.float32)
+        _lib.check(ops.lib.xva_bct_to_seq(_lib.ptr(x.float().contiguous()), C.c_void_p(xs.view.data_ptr()), 0, B, Cc, T, PAD, None, _lib.stream_ptr()),
+                   "xva_bct_to_seq")
+        out = tr.forward_seq(xs, lens)
+        ctx.tr, ctx.dims = tr, (B, Cc, T)
+        return ops.seq_to_bct(out.view, T, PAD)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        tr = ctx.tr
+        B, Cc, T = ctx.dims
+        ds = Seq(B, T, Cc, tr.device, torch.float32)
+        _lib.check(ops.lib.xva_bct_to_seq(_lib.ptr(d_out.float().contiguous()), C.c_void_p(ds.view.data_ptr()), 0, B, Cc, T, PAD, None, _lib.stream_ptr()),
+                   "xva_bct_to_seq")
+        d_x = tr.backward_seq(ds)
+        return ops.seq_to_bct(d_x.view, T, PAD), None, None
