@@ -619,10 +619,23 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
     const Plan& pl = c.pl;
     const ParamTable& T = table();
     const int B = pl.B;
-    if (d->compute) XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));   // bf16 shadow of the parameters
+    // bf16 shadow of the parameters: the encoder's slice first; the rest (predictors, embeddings, decoder, aligner: 5/6 of the bytes) on the
+    // predictor lane under the encoder's forward
+    WgLane& wl0 = wg_lane();
+    const bool split_cast = d->compute && wl0.ok && !g_fp_serial && d->stage != 2 && T.enc_begin == 0 && T.enc_end % 8 == 0;
+    if (d->compute) {
+        if (split_cast) {
+            XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.enc_end, c.st));
+            XVA_HIP_TRY(hipEventRecord(wl0.pfork, (hipStream_t)c.st));      // orders the side lane after whatever wrote `params` on the caller's stream
+            XVA_HIP_TRY(hipStreamWaitEvent(wl0.sp, wl0.pfork, 0));
+            XVA_TRY(xva_cast_f32(params + T.enc_end, c.W + pl.wshadow + T.enc_end * c.es, c.dt, T.total - T.enc_end, wl0.sp));
+            XVA_HIP_TRY(hipEventRecord(wl0.pmid, wl0.sp));
+        } else XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
+    }
     // encoder                                                              (model.py:346)
     XVA_TRY(xva_fp_embed_fwd(bt->text, c.P + T.word_emb, bt->pos_table, c.A(pl.enc_x[0]), c.dt, B, pl.Tt, DM, c.st));
     XVA_TRY(layers_fwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, DS_ENC));
+    if (split_cast) XVA_HIP_TRY(hipStreamWaitEvent((hipStream_t)c.st, wl0.pmid, 0));          // the rest of the shadow is in place
     char* enc_out = c.A(pl.enc_x[NL]);
     if (d->stage == 2) {                                                    // model.py:367-373
         XVA_TRY(pred_fwd(c, T.dur, pl.dur, enc_out, pl.pin_a, bt->in_lens, DS_PRED + 0));
