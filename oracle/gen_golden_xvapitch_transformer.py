@@ -51,6 +51,30 @@ def main():
         out["sd/" + k] = v.numpy()
     for k, v in grads.items():
         out["grad/" + k] = v.numpy()
+    # ---- the pitch / energy encoders' form (model.py:1292-1305): out_channels = 1, so `proj` exists and the stack returns proj(x)
+    C2, F2 = 36, 32
+    m2 = glow.RelativePositionTransformer(in_channels=C2, out_channels=1, hidden_channels=C2, hidden_channels_ffn=F2, num_heads=H, num_layers=2, kernel_size=K,
+                                          dropout_p=0.0, layer_norm_type="2", rel_attn_window_size=W)
+    m2.eval()
+    x2 = torch.randn(B, C2, T, requires_grad=True)
+    r2 = torch.randn(B, 1, T)
+    y2 = m2(x2 * 1.0, x_mask)
+    sd2 = {k: v.detach().clone() for k, v in m2.state_dict().items()}
+    x2o = x2.detach().clone().requires_grad_(True)
+    leaves2 = {k: v.clone().requires_grad_(True) for k, v in sd2.items()}
+    y2o = oxv.rel_transformer(leaves2, x2o, x_mask, H, 2, K, W)
+    assert y2.shape == (B, 1, T) and torch.allclose(y2, y2o, rtol=1e-5, atol=1e-5)
+    (y2 * r2).sum().backward()
+    (y2o * r2).sum().backward()
+    out.update({"p_cfg": np.array([B, C2, F2, H, 2, K, W, T]), "p_x": x2.detach().numpy(), "p_r": r2.numpy(), "p_y": y2.detach().numpy(), "p_dx": x2.grad.numpy()})
+    for k, v in sd2.items():
+        out["p_sd/" + k] = v.numpy()
+    for n, p in m2.named_parameters():
+        if p.grad is not None:                                  # the last layer's feed-forward network and second norm do not reach the output
+            assert torch.allclose(leaves2[n].grad, p.grad, rtol=1e-4, atol=1e-5), n
+            out["p_grad/" + n] = p.grad.numpy()
+        else:
+            assert leaves2[n].grad is None or float(leaves2[n].grad.abs().max()) == 0.0, n
     path = os.path.join(ROOT, "tests", "golden", "xvapitch_transformer.npz")
     np.savez_compressed(path, **out)
     print("xvapitch_transformer.npz", len(out), "arrays", os.path.getsize(path), "bytes; |y|", float(y.abs().mean()))

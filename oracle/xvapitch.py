@@ -124,7 +124,12 @@ def rel_transformer(sd, x, x_mask, num_heads, num_layers, kernel_size, window):
         o = o.transpose(2, 3).contiguous().view(B, Cc, T)
         y = F.conv1d(o, sd[a + "conv_o.weight"], sd[a + "conv_o.bias"])
         x = F.layer_norm((x + y).transpose(1, -1), (Cc,), sd["norm_layers_1.%d.gamma" % i], sd["norm_layers_1.%d.beta" % i], 1e-5).transpose(1, -1)
+        last = i == num_layers - 1
         h = torch.relu(F.conv1d(F.pad(x * x_mask, (pad_l, pad_r)), sd[f + "conv_1.weight"], sd[f + "conv_1.bias"]))
         y = F.conv1d(F.pad(h * x_mask, (pad_l, pad_r)), sd[f + "conv_2.weight"], sd[f + "conv_2.bias"]) * x_mask
-        x = F.layer_norm((x + y).transpose(1, -1), (Cc,), sd["norm_layers_2.%d.gamma" % i], sd["norm_layers_2.%d.beta" % i], 1e-5).transpose(1, -1)
+        if last and "proj.weight" in sd:                                                     # hidden != out (:479-480)
+            x = F.conv1d(x, sd["proj.weight"], sd["proj.bias"])
+        Co = x.size(1)
+        if Co != 1 or not last:                                                              # out_channels == 1: the stack returns proj(x) (:482)
+            x = F.layer_norm((x + y).transpose(1, -1), (Co,), sd["norm_layers_2.%d.gamma" % i], sd["norm_layers_2.%d.beta" % i], 1e-5).transpose(1, -1)
     return x * x_mask

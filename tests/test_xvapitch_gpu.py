@@ -241,3 +241,35 @@ def test_rel_transformer_against_oracle(B, T, Cc, H):
             assert float(gr.abs().max()) < 1e-4                  # mathematically zero (see above)
         else:
             assert _rel(gr, leaves[k].grad) < 2e-3, k
+
+
+def test_rel_transformer_pitch_encoder_form_against_reference_golden(golden_dir):
+    """The pitch / energy encoders' stack (model.py:1292-1305): out_channels = 1, so `proj` maps the last layer's attention block to one
+    channel and the stack returns it (glow_tts.py:479-482); the last layer's feed-forward network and second norm do not reach the output and
+    receive no gradient, in the reference as here."""
+    from xva_trainer_amd.xvapitch.transformer import RelativePositionTransformer
+    g = np.load(os.path.join(golden_dir, "xvapitch_transformer.npz"))
+    B, Cc, Fh, H, L, K, W, T = (int(v) for v in g["p_cfg"])
+    lens = torch.from_numpy(g["lens"])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1).cuda()
+    tr = RelativePositionTransformer(Cc, 1, Cc, Fh, H, L, kernel_size=K, dropout_p=0.0, rel_attn_window_size=W, layer_norm_type="2")
+    sd = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("p_sd/")}
+    assert set(tr.state_dict()) == set(sd) and "proj.weight" in sd
+    tr.load_state_dict(sd)
+    tr.zero_grad()
+    x = torch.from_numpy(g["p_x"]).cuda().requires_grad_(True)
+    y = tr(x, x_mask)
+    assert tuple(y.shape) == (B, 1, T) and _rel(y, torch.from_numpy(g["p_y"])) < 1e-3
+    (y * torch.from_numpy(g["p_r"]).cuda()).sum().backward()
+    assert _rel(x.grad, torch.from_numpy(g["p_dx"])) < 1e-3
+    grads = tr.grads()
+    have = {k[7:] for k in g.files if k.startswith("p_grad/")}
+    for n, gr in grads.items():
+        if n in have:
+            if n.endswith("conv_k.bias"):
+                assert float(gr.abs().max()) < 1e-5
+            else:
+                assert _rel(gr, torch.from_numpy(g["p_grad/" + n])) < 1e-3, n
+        else:
+            assert float(gr.abs().max()) == 0.0, n + " does not reach the output"
+    assert {"proj.weight", "proj.bias"} <= have and "ffn_layers.1.conv_2.weight" not in have

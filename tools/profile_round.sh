@@ -12,6 +12,8 @@ python $R/tools/rocpd_summary.py $(find /tmp/p_stats -name "*.db" | head -1) $O/
 # kernels' own — the numbers bench.py's roofline passes (lanes off as well) have to agree with
 XVA_FP_STREAMS=1 XVA_HG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/p_ser -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_serial_lanes_bench_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_ser -name "*.db" | head -1) $O/${RD}_serial_lanes_kernel_stats.csv
+XVA_FP_STREAMS=1 XVA_HG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/p_fps -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hifigan 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_fastpitch_only_serial_lanes_under_rocprof.json
+python $R/tools/rocpd_summary.py $(find /tmp/p_fps -name "*.db" | head -1) $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d /tmp/p_fp -o f -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hifigan 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_fastpitch_only_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_fp -name "*.db" | head -1) $O/${RD}_fastpitch_only_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d /tmp/p_hg -o h -- python $R/tools/hg_phase_timing.py > $O/${RD}_hifigan_phase_timing.txt 2>/dev/null

@@ -8,7 +8,7 @@ the q / k / v projections are ONE xva_gemm against the stacked weights, conv_o a
 implicit-conv form (ReLU and the residual in the epilogue, the ReLU gate in the backward epilogue), the attention core and LayerNorm are
 csrc/xvapitch_ops.hip kernels.  Host code only sequences C calls; the module is one autograd Function, checked against the reference by
 output and by every parameter / input gradient (tests/test_xvapitch_gpu.py).  Not built: dropout_p > 0 (masks cannot match torch's RNG; the
-reference evaluates with dropout off), out_channels != hidden_channels (the `proj` of the pitch / energy encoders), input_length, layer_norm
+reference evaluates with dropout off), in_channels != hidden_channels, input_length, layer_norm
 type "1".
 """
 import ctypes as C
@@ -45,8 +45,10 @@ def _tapmajor(w):
 
 
 class _Layer:
-    def __init__(self, Cc, F, H, k, w, device, gen):
+    def __init__(self, Cc, F, H, k, w, device, gen, Co=None):
+        """Co: output width of conv_2 / norm2 (the last layer of a stack with out_channels != hidden_channels)"""
         dk = Cc // H
+        Co = Cc if Co is None else Co
 
         def conv(co, ci, kk):
             bound = (1.0 / (ci * kk)) ** 0.5
@@ -59,11 +61,11 @@ class _Layer:
         self.p["attn.emb_rel_v"] = (torch.randn(1, 2 * w + 1, dk, generator=gen) * dk ** -0.5).to(device)
         for a, t in conv(F, Cc, k).items():
             self.p["ffn.conv_1." + a] = t
-        for a, t in conv(Cc, F, k).items():
+        for a, t in conv(Co, F, k).items():
             self.p["ffn.conv_2." + a] = t
-        for n in ("norm1", "norm2"):
-            self.p[n + ".gamma"] = torch.ones(Cc, device=device)
-            self.p[n + ".beta"] = torch.zeros(Cc, device=device)
+        for n, ch in (("norm1", Cc), ("norm2", Co)):
+            self.p[n + ".gamma"] = torch.ones(ch, device=device)
+            self.p[n + ".beta"] = torch.zeros(ch, device=device)
         self.g = {n: torch.zeros_like(t) for n, t in self.p.items()}
 
 
@@ -75,16 +77,27 @@ class RelativePositionTransformer:
                  rel_attn_window_size=None, input_length=None, layer_norm_type="1", device="cuda", seed=0):
         if dropout_p:
             raise NotImplementedError("RelativePositionTransformer: dropout_p > 0 is not built")
-        if not (in_channels == hidden_channels == out_channels):
-            raise NotImplementedError("RelativePositionTransformer: in / hidden / out channels must agree (the text encoder's configuration)")
+        if in_channels != hidden_channels or not (out_channels == 1 or out_channels % 4 == 0):
+            raise NotImplementedError("RelativePositionTransformer: in_channels must equal hidden_channels, out_channels 1 or a multiple of 4")
         if rel_attn_window_size is None or input_length is not None or layer_norm_type != "2":
             raise NotImplementedError("RelativePositionTransformer: built for rel_attn_window_size set, input_length None, layer_norm_type '2'")
         if hidden_channels % num_heads or hidden_channels % 4 or hidden_channels_ffn % 4 or kernel_size % 2 != 1 or kernel_size // 2 > PAD:
             raise NotImplementedError("RelativePositionTransformer: channels must be multiples of 4 and of num_heads, kernel_size odd")
         self.C, self.F, self.H, self.L, self.k, self.w = hidden_channels, hidden_channels_ffn, num_heads, num_layers, kernel_size, rel_attn_window_size
+        self.Co = out_channels
         self.device = torch.device(device)
         gen = torch.Generator().manual_seed(seed)
-        self.layers = [_Layer(self.C, self.F, self.H, self.k, self.w, self.device, gen) for _ in range(num_layers)]
+        self.layers = [_Layer(self.C, self.F, self.H, self.k, self.w, self.device, gen, Co=out_channels if i == num_layers - 1 else None)
+                       for i in range(num_layers)]
+        # hidden != out: `proj` maps the last layer's attention block output to the output width (glow_tts.py:440-441,479-480); with
+        # out_channels == 1 (the pitch / energy encoders, model.py:1292-1305) the stack RETURNS proj(x) and the last layer's feed-forward
+        # network and second LayerNorm do not reach the output (:482): they are not evaluated here and receive no gradient.
+        self.proj = None
+        if out_channels != hidden_channels:
+            bound = (1.0 / hidden_channels) ** 0.5
+            self.proj = {"weight": ((torch.rand(out_channels, hidden_channels, 1, generator=gen) * 2 - 1) * bound).to(self.device),
+                         "bias": ((torch.rand(out_channels, generator=gen) * 2 - 1) * bound).to(self.device)}
+            self.proj_g = {n: torch.zeros_like(t) for n, t in self.proj.items()}
 
     # ---- reference state_dict ----
     def _named(self, which):
@@ -94,6 +107,9 @@ class RelativePositionTransformer:
                     if n.startswith(a):
                         yield (b % i) + n[len(a):], t
                         break
+        if self.proj is not None:
+            for n, t in (self.proj if which == "p" else self.proj_g).items():
+                yield "proj." + n, t
 
     def state_dict(self):
         return {k: v.detach().clone() for k, v in self._named("p")}
@@ -114,11 +130,22 @@ class RelativePositionTransformer:
         for l in self.layers:
             for t in l.g.values():
                 t.zero_()
+        if self.proj is not None:
+            for t in self.proj_g.values():
+                t.zero_()
 
     def __call__(self, x, x_mask):
         return _TransformerFn.apply(x, self, _lens_of(x, x_mask))
 
     # ---- sequences ----
+    def _proj_padded(self):
+        """proj weight (rows padded with zeros to a multiple of 4: out_channels == 1) and bias, as GEMM operands"""
+        Co, Cc = self.Co, self.C
+        Cp = (Co + 3) // 4 * 4
+        w = torch.zeros(Cp, Cc, device=self.device); w[:Co] = self.proj["weight"].reshape(Co, Cc)
+        b = torch.zeros(Cp, device=self.device); b[:Co] = self.proj["bias"]
+        return w, b
+
     def _ln(self, x, gamma, beta):
         y = Seq(x.B, x.T, x.C, self.device, torch.float32)
         mean = torch.empty(x.rows, device=self.device); rstd = torch.empty(x.rows, device=self.device)
@@ -131,8 +158,10 @@ class RelativePositionTransformer:
         dk = Cc // H
         self.saved = []
         mk = lambda ch: Seq(B, T, ch, self.device, torch.float32)
-        for l in self.layers:
+        for li, l in enumerate(self.layers):
             p = l.p
+            last = li == self.L - 1
+            Co = self.Co if last else Cc
             xm = mk(Cc); xm.store.copy_(x.store); _mask(xm, lens)                               # x = x * x_mask            (glow_tts.py:471)
             wqkv = torch.cat([p["attn.conv_%s.weight" % n].reshape(Cc, Cc) for n in "qkv"], 0).contiguous()
             bqkv = torch.cat([p["attn.conv_%s.bias" % n] for n in "qkv"]).contiguous()
@@ -149,6 +178,15 @@ class RelativePositionTransformer:
             _lib.gemm(att.store, wo, s1.store, att.rows, Cc, Cc, Cc, Cc, Cc, layout=_lib.GEMM_NT, compute=0, bias=p["attn.conv_o.bias"], a_offset=att.off(),
                       c_offset=s1.off(), R=xm.view, ldr=Cc, mask_mode=_lib.MASK_PAD, Tp=x.Tp, mask_pad=PAD, mask_len=T)   # x + conv_o(..)  (:170,474)
             x1, m1, r1 = self._ln(s1, p["norm1.gamma"], p["norm1.beta"])                        # norm_layers_1             (:474)
+            res = x1                                                                            # the residual branch of the second sub-layer
+            if last and self.proj is not None:                                                  # x = proj(x)               (:479-480)
+                wp, bp = self._proj_padded()
+                res = mk(wp.size(0))
+                conv_fwd(x1, wp, bp, res, 1, 1, 0)
+            if last and Co == 1:                                                                # the stack returns proj(x) (:482)
+                self.saved.append((xm, wqkv, qkv, P, att, wo, s1, m1, r1, x1))
+                x = res
+                continue
             x1m = mk(Cc); x1m.store.copy_(x1.store); _mask(x1m, lens)                           # FFN: conv_1(pad(x * x_mask)), relu  (:342-343)
             h = mk(F)
             P_ = (k - 1) // 2
@@ -157,15 +195,15 @@ class RelativePositionTransformer:
                       a_offset=x1m.off(-P_), c_offset=h.off(), a_seglen=Cc if k > 1 else 0, a_segadj=0, mask_mode=_lib.MASK_PAD, Tp=x.Tp, mask_pad=PAD,
                       mask_len=T)
             _mask(h, lens)                                                                      # conv_2(pad(x * x_mask)) * x_mask    (:345-346)
-            y2 = mk(Cc)
+            y2 = mk(Co)
             conv_fwd(h, w2, p["ffn.conv_2.bias"], y2, k, 1, 0)
             _mask(y2, lens)
-            s2 = mk(Cc)
-            torch.add(x1.store, y2.store, out=s2.store)                                         # norm_layers_2(x + y)     (:482)
+            s2 = mk(Co)
+            torch.add(res.store, y2.store, out=s2.store)                                        # norm_layers_2(x + y)     (:482)
             x2, m2, r2 = self._ln(s2, p["norm2.gamma"], p["norm2.beta"])
-            self.saved.append((xm, wqkv, qkv, P, att, wo, s1, m1, r1, x1m, w1, w2, h, s2, m2, r2))
+            self.saved.append((xm, wqkv, qkv, P, att, wo, s1, m1, r1, x1, x1m, w1, w2, h, s2, m2, r2))
             x = x2
-        out = mk(Cc); out.store.copy_(x.store); _mask(out, lens)                                # x * x_mask               (:483)
+        out = mk(self.Co); out.store.copy_(x.store[:, :self.Co]); _mask(out, lens)              # x * x_mask               (:483)
         self.lens = lens
         return out
 
@@ -174,31 +212,55 @@ class RelativePositionTransformer:
         dk = Cc // H
         lens = self.lens
         mk = lambda ch: Seq(B, T, ch, self.device, torch.float32)
-        dx = mk(Cc); dx.store.copy_(d_out.store); _mask(dx, lens)
-        for l, sv in zip(reversed(self.layers), reversed(self.saved)):
-            xm, wqkv, qkv, P, att, wo, s1, m1, r1, x1m, w1, w2, h, s2, m2, r2 = sv
+        dx = mk(self.Co); dx.store.copy_(d_out.store); _mask(dx, lens)
+
+        def proj_bwd(dres, x1):
+            """dres = d proj(x1): accumulates the proj gradients, returns d x1"""
+            Co = self.Co
+            wp, _ = self._proj_padded()
+            Cp = wp.size(0)
+            if Cp != Co:                                           # one output channel rides in a 4-wide sequence (GEMM leading dimensions)
+                wide = mk(Cp); wide.store[:, :Co] = dres.store; dres = wide
+            dWp = torch.zeros(Cp, Cc, device=self.device); dbp = torch.zeros(Cp, device=self.device)
+            conv_bwd_weight(dres, x1, dWp, dbp, 1, 1, 0)
+            self.proj_g["weight"] += dWp[:Co].view(Co, Cc, 1)
+            self.proj_g["bias"] += dbp[:Co]
+            d = mk(Cc)
+            conv_bwd_data(dres, wp, d, 1, 1, 0, False)
+            return d
+        for li, l, sv in zip(reversed(range(self.L)), reversed(self.layers), reversed(self.saved)):
             p, g = l.p, l.g
-            ds2 = mk(Cc)
-            _lib.check(lib.xva_ln_rows_bwd(_p(dx.view), _p(s2.view), _lib.ptr(m2), _lib.ptr(r2), _lib.ptr(p["norm2.gamma"]), _p(ds2.view), _lib.ptr(g["norm2.gamma"]),
-                                           _lib.ptr(g["norm2.beta"]), dx.rows, Cc, _lib.stream_ptr()), "xva_ln_rows_bwd")
-            dy2 = mk(Cc); dy2.store.copy_(ds2.store); _mask(dy2, lens)                           # y2 = conv_2(..) * x_mask
-            dW2 = torch.zeros(Cc, k * F, device=self.device)
-            conv_bwd_weight(dy2, h, dW2, g["ffn.conv_2.bias"], k, 1, 0)
-            g["ffn.conv_2.weight"] += dW2.view(Cc, k, F).permute(0, 2, 1)
-            dh = mk(F)
-            P_ = (k - 1) // 2
-            # d(conv_1 output) = (dy2 (*) W2) gated by relu (h is stored masked and post-ReLU: h > 0 is both the gate and the mask)
-            _lib.gemm(dy2.store, w2, dh.store, dy2.rows, F, k * Cc, Cc, k * F, F, layout=_lib.GEMM_NN, compute=0, a_offset=dy2.off(P_), c_offset=dh.off(),
-                      a_seglen=Cc if k > 1 else 0, a_segadj=-2 * Cc if k > 1 else 0, seglen=Cc if k > 1 else 0, seg0=0, segstride=F if k > 1 else 0,
-                      G=h.view, ldg=F, gate_slope=0.0, mask_mode=_lib.MASK_PAD, Tp=dy2.Tp, mask_pad=PAD, mask_len=T)
-            dW1 = torch.zeros(F, k * Cc, device=self.device)
-            conv_bwd_weight(dh, x1m, dW1, g["ffn.conv_1.bias"], k, 1, 0)
-            g["ffn.conv_1.weight"] += dW1.view(F, k, Cc).permute(0, 2, 1)
-            dx1m = mk(Cc)
-            conv_bwd_data(dh, w1, dx1m, k, 1, 0, False)
-            _mask(dx1m, lens)                                                                    # x1m = x1 * x_mask
-            dx1 = mk(Cc)
-            torch.add(ds2.store, dx1m.store, out=dx1.store)                                      # residual x + y
+            last = li == self.L - 1
+            Co = self.Co if last else Cc
+            if last and Co == 1:
+                xm, wqkv, qkv, P, att, wo, s1, m1, r1, x1 = sv
+                dx1 = proj_bwd(dx, x1)
+            else:
+                xm, wqkv, qkv, P, att, wo, s1, m1, r1, x1, x1m, w1, w2, h, s2, m2, r2 = sv
+            ds2 = None
+            if not (last and Co == 1):
+                ds2 = mk(Co)
+                _lib.check(lib.xva_ln_rows_bwd(_p(dx.view), _p(s2.view), _lib.ptr(m2), _lib.ptr(r2), _lib.ptr(p["norm2.gamma"]), _p(ds2.view), _lib.ptr(g["norm2.gamma"]),
+                                               _lib.ptr(g["norm2.beta"]), dx.rows, Co, _lib.stream_ptr()), "xva_ln_rows_bwd")
+                dy2 = mk(Co); dy2.store.copy_(ds2.store); _mask(dy2, lens)                       # y2 = conv_2(..) * x_mask
+                dW2 = torch.zeros(Co, k * F, device=self.device)
+                conv_bwd_weight(dy2, h, dW2, g["ffn.conv_2.bias"], k, 1, 0)
+                g["ffn.conv_2.weight"] += dW2.view(Co, k, F).permute(0, 2, 1)
+                dh = mk(F)
+                P_ = (k - 1) // 2
+                # d(conv_1 output) = (dy2 (*) W2) gated by relu (h is stored masked and post-ReLU: h > 0 is both the gate and the mask)
+                _lib.gemm(dy2.store, w2, dh.store, dy2.rows, F, k * Co, Co, k * F, F, layout=_lib.GEMM_NN, compute=0, a_offset=dy2.off(P_), c_offset=dh.off(),
+                          a_seglen=Co if k > 1 else 0, a_segadj=-2 * Co if k > 1 else 0, seglen=Co if k > 1 else 0, seg0=0, segstride=F if k > 1 else 0,
+                          G=h.view, ldg=F, gate_slope=0.0, mask_mode=_lib.MASK_PAD, Tp=dy2.Tp, mask_pad=PAD, mask_len=T)
+                dW1 = torch.zeros(F, k * Cc, device=self.device)
+                conv_bwd_weight(dh, x1m, dW1, g["ffn.conv_1.bias"], k, 1, 0)
+                g["ffn.conv_1.weight"] += dW1.view(F, k, Cc).permute(0, 2, 1)
+                dx1m = mk(Cc)
+                conv_bwd_data(dh, w1, dx1m, k, 1, 0, False)
+                _mask(dx1m, lens)                                                                # x1m = x1 * x_mask
+                dres = proj_bwd(ds2, x1) if (last and self.proj is not None) else ds2            # residual branch: x or proj(x)
+                dx1 = mk(Cc)
+                torch.add(dres.store, dx1m.store, out=dx1.store)
             ds1 = mk(Cc)
             _lib.check(lib.xva_ln_rows_bwd(_p(dx1.view), _p(s1.view), _lib.ptr(m1), _lib.ptr(r1), _lib.ptr(p["norm1.gamma"]), _p(ds1.view), _lib.ptr(g["norm1.gamma"]),
                                            _lib.ptr(g["norm1.beta"]), dx1.rows, Cc, _lib.stream_ptr()), "xva_ln_rows_bwd")
@@ -243,8 +305,8 @@ class _TransformerFn(torch.autograd.Function):
     def backward(ctx, d_out):
         tr = ctx.tr
         B, Cc, T = ctx.dims
-        ds = Seq(B, T, Cc, tr.device, torch.float32)
-        _lib.check(ops.lib.xva_bct_to_seq(_lib.ptr(d_out.float().contiguous()), C.c_void_p(ds.view.data_ptr()), 0, B, Cc, T, PAD, None, _lib.stream_ptr()),
+        ds = Seq(B, T, tr.Co, tr.device, torch.float32)
+        _lib.check(ops.lib.xva_bct_to_seq(_lib.ptr(d_out.float().contiguous()), C.c_void_p(ds.view.data_ptr()), 0, B, tr.Co, T, PAD, None, _lib.stream_ptr()),
                    "xva_bct_to_seq")
         d_x = tr.backward_seq(ds)
         return ops.seq_to_bct(d_x.view, T, PAD), None, None
