@@ -27,7 +27,7 @@ cases = [
  ("qkv dW TN 192x384x27584", lambda: L.gemm(q, x, dWq, 192, 384, R, 192, 384, 384, layout=L.GEMM_TN, compute=1, accumulate=True, splitk=0, sk_ws=ws)),
  ("o_net dW TN 384x64x27584", lambda: L.gemm(x, a64, dWo, 384, 64, R, 384, 64, 64, layout=L.GEMM_TN, compute=1, accumulate=True, splitk=0, sk_ws=ws)),
 ]
-modes = [-1, 1, 3, 4, 5]
+modes = [-1, 1, 2, 3, 4, 5, 8, 0]
 print("%-36s" % "shape" + "".join("  mode %2d us " % m for m in modes))
 for name, fn in cases:
     row = "%-36s" % name
