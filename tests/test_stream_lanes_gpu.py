@@ -46,13 +46,16 @@ def test_hifigan_iteration_with_and_without_stream_lanes(golden_dir, compute):
 
     def rel(x, y):
         return float((x - y).norm() / y.norm().clamp_min(1e-30))
+    # one pair of identical runs is a small sample of that spread (it has come out as exactly 0 for a loss): the floors are the spread seen
+    # over many pairs — bf16: a flipped rounding moves a loss by ~1e-4 and the generator gradients by ~3e-3; fp32: atomic order only
+    gfloor, lfloor = (1e-2, 1e-3) if compute == "bf16" else (1e-5, 1e-5)
     for i, name in ((2, "discriminator gradients"), (1, "generator gradients")):
         noise, diff = rel(a[i], a2[i]), rel(a[i], b[i])
         print(name, "one stream twice", noise, "lanes vs one stream", diff)
-        assert diff <= 3 * noise + 1e-5, (name, diff, noise)
+        assert diff <= max(3 * noise, gfloor), (name, diff, noise)
     for k in ("loss_disc_all", "loss_gen", "loss_fm", "loss_mel"):
         noise, diff = abs(float(a[0][k]) - float(a2[0][k])), abs(float(a[0][k]) - float(b[0][k]))
-        assert diff <= 3 * noise + 1e-5 * abs(float(a[0][k])), (k, diff, noise)
+        assert diff <= max(3 * noise, lfloor * abs(float(a[0][k]))), (k, diff, noise)
 
 
 def _fastpitch_step(lanes, compute):

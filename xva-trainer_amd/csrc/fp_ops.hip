@@ -602,7 +602,7 @@ extern "C" int xva_fp_cond_add_bwd(const void* dOut, int dt, const float* s, flo
                                    int C, void* stream) {
     XVA_CHECK_ARG(dOut && s && lens, "cond_add_bwd: null");
     int64_t rows = (int64_t)B * Tp;
-    const int rpb = 128;
+    const int rpb = 32;   // 8 dependent row iterations per thread (was 32: 25 us for 3.7 MB, latency-bound); ~150 atomics per address
     hipLaunchKernelGGL(cond_add_bwd_kernel, dim3(xva_cdiv(C, 64), xva_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, dOut, dt, s,
                        dw, db, lens, rows, Tp, C, rpb);
     XVA_LAUNCH_CHECK();
@@ -673,26 +673,30 @@ extern "C" int xva_fp_lenreg_bwd(const void* dOut, const int32_t* tstart, const 
 //   grads:     d_pred = grad_scale * w * 2 * (pred - tgt) * mask / den
 // mel_out: (B, Tm+2, 80) padded token-major ; mel_tgt: (B, 80, Tm) reference layout ; mask = (tgt != 0).
 // =====================================================================================
-__global__ void mel_loss_partial_kernel(const void* __restrict__ mel_out, int dt, const float* __restrict__ mel_tgt,
-                                        float* __restrict__ acc, int B, int Tm, int NM) {
+// One workgroup = one item x 64 frames x all NM mel channels: the target (B, NM, Tm) is read along t, the prediction (B, Tm + 2, NM) along c,
+// through a [64][NM + 1] LDS tile (read in the target's order, the prediction was fetched 2 bytes per 160-byte row: 65 us for 13 MB).
+__global__ __launch_bounds__(256) void mel_loss_partial_kernel(const void* __restrict__ mel_out, int dt, const float* __restrict__ mel_tgt,
+                                                               float* __restrict__ acc, int B, int Tm, int NM) {
     __shared__ float sh[16];
-    int64_t total = (int64_t)B * NM * Tm;
+    __shared__ float tile[64][81];
+    const int tb = blockIdx.x * 64, b = blockIdx.y;
+    const int nt = min(64, Tm - tb);
+    for (int i = threadIdx.x; i < nt * NM; i += 256) {                 // prediction: consecutive threads = consecutive channels of a frame
+        const int t = i / NM, c = i - t * NM;
+        tile[t][c] = a_ld(mel_out, ((int64_t)b * (Tm + 2) + tb + t + 1) * NM + c, dt);
+    }
+    __syncthreads();
     float num = 0.f, den = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int t = (int)(i % Tm);
-        int c = (int)((i / Tm) % NM);
-        int b = (int)(i / ((int64_t)Tm * NM));
-        float tg = mel_tgt[i];
-        if (tg != 0.f) {
-            float o = a_ld(mel_out, ((int64_t)b * (Tm + 2) + t + 1) * NM + c, dt);
-            float d = o - tg;
-            num += d * d;
-            den += 1.f;
+    for (int i = threadIdx.x; i < NM * 64; i += 256) {                 // target: consecutive threads = consecutive frames of a channel
+        const int c = i >> 6, t = i & 63;
+        if (t < nt) {
+            const float tg = mel_tgt[((int64_t)b * NM + c) * Tm + tb + t];
+            if (tg != 0.f) { const float d = tile[t][c] - tg; num += d * d; den += 1.f; }
         }
     }
     num = xva_block_sum(num, sh);
     den = xva_block_sum(den, sh);
-    if (threadIdx.x == 0) { atomicAdd(acc + 0, num); atomicAdd(acc + 1, den); }
+    if (threadIdx.x == 0 && den > 0.f) { atomicAdd(acc + 0, num); atomicAdd(acc + 1, den); }
 }
 __global__ void mel_loss_grad_kernel(const void* __restrict__ mel_out, int dt, const float* __restrict__ mel_tgt,
                                      const float* __restrict__ acc, void* __restrict__ d_mel, int B, int Tm, int NM,
@@ -773,9 +777,7 @@ extern "C" int xva_fp_loss_partials(int stage, int dt, const void* mel_out, cons
     int gtok = xva_cdiv((int64_t)B * (Tt + 2), 256);
     if (stage == 3 || stage == 4) {
         XVA_CHECK_ARG(mel_out && mel_tgt, "loss_partials: null mel");
-        int64_t total = (int64_t)B * 80 * Tm;
-        int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(mel_loss_partial_kernel, dim3(grid), dim3(256), 0, st, mel_out, dt, mel_tgt, acc, B, Tm, 80);
+        hipLaunchKernelGGL(mel_loss_partial_kernel, dim3(xva_cdiv(Tm, 64), B), dim3(256), 0, st, mel_out, dt, mel_tgt, acc, B, Tm, 80);
     }
     if (stage == 3) {
         XVA_CHECK_ARG(pitch_pred && pitch_tgt && energy_pred && energy_tgt, "loss_partials: null pitch/energy");
@@ -880,6 +882,19 @@ extern "C" int xva_fp_rowscale_colsum(const void* X, int dt, const float* s, flo
 __global__ void cast_kernel(const float* __restrict__ src, void* __restrict__ dst, int dt, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a_st(dst, i, dt, src[i]);
 }
+// fp32 -> bf16, 8 elements per thread and iteration: two 16-byte loads, one 16-byte store (the scalar form stored 2 bytes per lane: 122 us
+// for the 46 M parameters of the FastPitch shadow = 2.3 TB/s)
+__global__ void cast_bf16x8_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = src[2 * i], b = src[2 * i + 1];
+        uint4 o;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(a.x), "v"(a.y));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(a.z), "v"(a.w));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.z) : "v"(b.x), "v"(b.y));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.w) : "v"(b.z), "v"(b.w));
+        dst[i] = o;
+    }
+}
 // dst += src (activation dtype, element pairs; n even)
 __global__ void add_act_kernel(void* __restrict__ dst, const void* __restrict__ src, int dt, int64_t npairs) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * blockDim.x) {
@@ -898,6 +913,13 @@ extern "C" int xva_fp_add_act(void* dst, const void* src, int dt, int64_t n, voi
 }
 extern "C" int xva_cast_f32(const float* src, void* dst, int dt, int64_t n, void* stream) {
     XVA_CHECK_ARG(src && dst, "cast: null");
+    if (dt == XVA_BF16 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 && n >= 8) {
+        const int64_t n8 = n / 8;
+        int g8 = (int)((n8 + 255) / 256); if (g8 > 8192) g8 = 8192;
+        hipLaunchKernelGGL(cast_bf16x8_kernel, dim3(g8), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst), n8);
+        if (n % 8 == 0) { XVA_LAUNCH_CHECK(); return XVA_OK; }
+        src += n8 * 8; dst = reinterpret_cast<uint16_t*>(dst) + n8 * 8; n -= n8 * 8;
+    }
     int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
     hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, dt, n);
     XVA_LAUNCH_CHECK();
