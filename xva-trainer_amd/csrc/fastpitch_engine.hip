@@ -372,6 +372,15 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
 // A second side stream carries the temporal predictors (model.py:394-418): in training the decoder is conditioned on the TARGET pitch /
 // energy, so neither its forward nor its backward depends on them; their small, latency-bound kernels run under the decoder's GEMMs.
 // env XVA_FP_STREAMS=1 keeps everything on the caller's stream.
+// Side-lane stream priority: env XVA_LANE_PRIO = 0 default priority (the default), 1 lowest, 2 highest.  Measured (FastPitch / HiFi-GAN ms
+// per step): default 10.38 / 38.4, lowest 10.49 / 45.9 (the lanes starve: HiFi-GAN falls back to its one-stream time), highest 10.47 / 55.0 (the caller's chain starves).
+static hipError_t xva_create_lane_stream(hipStream_t* s) {
+    static const int mode = [] { const char* e = getenv("XVA_LANE_PRIO"); return e ? atoi(e) : 0; }();
+    int least = 0, greatest = 0;
+    if (mode != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, mode == 1 ? least : greatest);
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
 struct WgLane { hipStream_t s = nullptr, sp = nullptr; hipEvent_t fork = nullptr, chain[NL] = {}, done[NL] = {}, pfork = nullptr, pmid = nullptr, pjoin = nullptr;
                 bool init = false, ok = false; };
 static WgLane& wg_lane() {
@@ -379,8 +388,8 @@ static WgLane& wg_lane() {
     if (!r.init) {
         r.init = true;
         const char* e = getenv("XVA_FP_STREAMS");
-        bool ok = !(e && atoi(e) == 1) && hipStreamCreateWithFlags(&r.s, hipStreamNonBlocking) == hipSuccess &&
-                  hipStreamCreateWithFlags(&r.sp, hipStreamNonBlocking) == hipSuccess &&
+        bool ok = !(e && atoi(e) == 1) && xva_create_lane_stream(&r.s) == hipSuccess &&
+                  xva_create_lane_stream(&r.sp) == hipSuccess &&
                   hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&r.pfork, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&r.pmid, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&r.pjoin, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; ok && i < NL; ++i)

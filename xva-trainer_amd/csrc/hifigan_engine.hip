@@ -333,6 +333,15 @@ struct Ctx {
 // chains fill each other's gaps.  The side stream and its two events are created once per host thread; nothing else is hidden: the
 // call still returns with all work ordered on the caller's stream.  env XVA_HG_STREAMS=n: number of lanes (1 = everything on the caller's
 // stream; default 2).
+// Side-lane stream priority: env XVA_LANE_PRIO = 0 default priority (the default), 1 lowest, 2 highest.  Measured (FastPitch / HiFi-GAN ms
+// per step): default 10.38 / 38.4, lowest 10.49 / 45.9 (the lanes starve: HiFi-GAN falls back to its one-stream time), highest 10.47 / 55.0 (the caller's chain starves).
+static hipError_t xva_create_lane_stream(hipStream_t* s) {
+    static const int mode = [] { const char* e = getenv("XVA_LANE_PRIO"); return e ? atoi(e) : 0; }();
+    int least = 0, greatest = 0;
+    if (mode != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, mode == 1 ? least : greatest);
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
 constexpr int MAXL = 4;                      // lanes: 0 = the caller's stream, 1 .. MAXL-1 side streams
 struct SideStreams { hipStream_t s[MAXL] = {}; hipEvent_t fork = nullptr, join[MAXL] = {}, pool[10] = {}; int n = 0; bool init = false; };
 static int g_hg_serial = 0;     // xva_hg_set_streams(1): everything on the caller's stream (per-kernel measurements)
@@ -347,7 +356,7 @@ static SideStreams& side_streams() {
         if (want > MAXL) want = MAXL;
         bool ok = want > 1 && hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess;
         for (int i = 1; ok && i < want; ++i)
-            ok = hipStreamCreateWithFlags(&r.s[i], hipStreamNonBlocking) == hipSuccess &&
+            ok = xva_create_lane_stream(&r.s[i]) == hipSuccess &&
                  hipEventCreateWithFlags(&r.join[i], hipEventDisableTiming) == hipSuccess;
         for (int i = 0; ok && i < 10; ++i) ok = hipEventCreateWithFlags(&r.pool[i], hipEventDisableTiming) == hipSuccess;
         r.n = ok ? want : 1;
