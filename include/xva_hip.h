@@ -452,6 +452,15 @@ int xva_ln_rows_fwd(const float* x, const float* gamma, const float* beta, float
 int xva_ln_rows_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
                     int64_t rows, int C, void* stream);
 
+/* Pieces of the stochastic duration predictor (python/xvapitch/sdp.py).  fp32, time-major (B, T, C) tensors without pad rows; `lens` = x_mask.
+ * xva_dwconv_*: the depthwise dilated Conv1d of DilatedDepthSeparableConv (sdp.py:66-69,85) on x * x_mask with zero padding (k odd <= 7);
+ * the backward writes dx and accumulates into dw (C, k) / db (C).  xva_gelu_*: torch's exact (erf) F.gelu (sdp.py:87,90). */
+int xva_dwconv_fwd(const float* x, const float* w, const float* bias, float* y, const int32_t* lens, int B, int T, int C, int k, int d, void* stream);
+int xva_dwconv_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, const int32_t* lens, int B, int T, int C, int k, int d,
+                   void* stream);
+int xva_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int xva_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,3 +133,19 @@ def rel_transformer(sd, x, x_mask, num_heads, num_layers, kernel_size, window):
         if Co != 1 or not last:                                                              # out_channels == 1: the stack returns proj(x) (:482)
             x = F.layer_norm((x + y).transpose(1, -1), (Co,), sd["norm_layers_2.%d.gamma" % i], sd["norm_layers_2.%d.beta" % i], 1e-5).transpose(1, -1)
     return x * x_mask
+
+
+def dds_conv(sd, x, x_mask, g=None, kernel_size=3, num_layers=3, pre=""):
+    """DilatedDepthSeparableConv.forward (python/xvapitch/sdp.py:76-93), dropout off."""
+    Cc = x.size(1)
+    if g is not None:
+        x = x + g
+    for i in range(num_layers):
+        d = kernel_size ** i
+        y = F.conv1d(x * x_mask, sd["%sconvs_sep.%d.weight" % (pre, i)], sd["%sconvs_sep.%d.bias" % (pre, i)], groups=Cc, dilation=d,
+                     padding=(kernel_size * d - d) // 2)
+        y = F.gelu(F.layer_norm(y.transpose(1, -1), (Cc,), sd["%snorms_1.%d.gamma" % (pre, i)], sd["%snorms_1.%d.beta" % (pre, i)], 1e-5).transpose(1, -1))
+        y = F.conv1d(y, sd["%sconvs_1x1.%d.weight" % (pre, i)], sd["%sconvs_1x1.%d.bias" % (pre, i)])
+        y = F.gelu(F.layer_norm(y.transpose(1, -1), (Cc,), sd["%snorms_2.%d.gamma" % (pre, i)], sd["%snorms_2.%d.beta" % (pre, i)], 1e-5).transpose(1, -1))
+        x = x + y
+    return x * x_mask

@@ -103,3 +103,24 @@ def test_rel_transformer_oracle_matches_reference_golden():
     for k in g.files:
         if k.startswith("grad/"):
             assert torch.allclose(sd[k[5:]].grad, torch.from_numpy(g[k]), rtol=1e-4, atol=1e-5), k
+
+
+def test_dds_conv_oracle_matches_reference_golden():
+    """oracle/xvapitch.py:dds_conv vs the vectors recorded from the reference DilatedDepthSeparableConv (sdp.py:40-93)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import xvapitch as oxv
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xvapitch_sdp.npz"))
+    B, Cc, T, K, L = (int(v) for v in g["dds_cfg"])
+    lens = torch.from_numpy(g["lens"])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1)
+    sd = {k[7:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("dds_sd/")}
+    x = torch.from_numpy(g["dds_x"]).requires_grad_(True); gg = torch.from_numpy(g["dds_g"]).requires_grad_(True)
+    y = oxv.dds_conv(sd, x, x_mask, gg, K, L)
+    assert torch.allclose(y, torch.from_numpy(g["dds_y"]), rtol=1e-5, atol=1e-6)
+    (y * torch.from_numpy(g["dds_r"])).sum().backward()
+    assert torch.allclose(x.grad, torch.from_numpy(g["dds_dx"]), rtol=1e-4, atol=1e-5) and torch.allclose(gg.grad, torch.from_numpy(g["dds_dg"]), rtol=1e-4, atol=1e-5)
+    for k in g.files:
+        if k.startswith("dds_grad/"):
+            assert torch.allclose(sd[k[9:]].grad, torch.from_numpy(g[k]), rtol=1e-4, atol=1e-5), k

@@ -273,3 +273,28 @@ def test_rel_transformer_pitch_encoder_form_against_reference_golden(golden_dir)
         else:
             assert float(gr.abs().max()) == 0.0, n + " does not reach the output"
     assert {"proj.weight", "proj.bias"} <= have and "ffn_layers.1.conv_2.weight" not in have
+
+
+def test_dds_conv_against_reference_golden(golden_dir):
+    """xvapitch/sdp.py:DilatedDepthSeparableConv (depthwise dilated conv, LayerNorm2, exact GELU, 1x1 conv: every step a HIP primitive under
+    torch autograd; python/xvapitch/sdp.py:40-93) vs the REFERENCE module: output, d x, d g and all 24 parameter gradients at 1e-3."""
+    from xva_trainer_amd.xvapitch.sdp import DilatedDepthSeparableConv
+    g = np.load(os.path.join(golden_dir, "xvapitch_sdp.npz"))
+    B, Cc, T, K, L = (int(v) for v in g["dds_cfg"])
+    lens = torch.from_numpy(g["lens"])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1).cuda()
+    m = DilatedDepthSeparableConv(Cc, K, L)
+    sd = {k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("dds_sd/")}
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict(sd)
+    x = torch.from_numpy(g["dds_x"]).cuda().requires_grad_(True)
+    cond = torch.from_numpy(g["dds_g"]).cuda().requires_grad_(True)
+    y = m(x, x_mask, g=cond)
+    assert _rel(y, torch.from_numpy(g["dds_y"])) < 1e-3
+    assert float((y.detach() * (1 - x_mask)).abs().max()) == 0.0
+    (y * torch.from_numpy(g["dds_r"]).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert _rel(x.grad, torch.from_numpy(g["dds_dx"])) < 1e-3 and _rel(cond.grad, torch.from_numpy(g["dds_dg"])) < 1e-3
+    worst = sorted(((_rel(m.p[k[9:]].grad, torch.from_numpy(g[k])), k[9:]) for k in g.files if k.startswith("dds_grad/")), reverse=True)
+    print("DDSConv worst gradients:", worst[:3])
+    assert len(worst) == 8 * L and worst[0][0] < 1e-3, worst[:3]

@@ -714,3 +714,114 @@ extern "C" int xva_ln_rows_bwd(const float* dy, const float* x, const float* mea
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
+
+// ---- stochastic duration predictor pieces (python/xvapitch/sdp.py) ----------------------------------------------------------------------
+// Tensors are fp32, time-major (B, T, C) without pad rows (token-level sizes: a few hundred rows, 192 channels); `lens` carries x_mask.
+// Depthwise dilated Conv1d (groups = channels; DilatedDepthSeparableConv.convs_sep, sdp.py:66-69 on x * x_mask, :85):
+//   y[b][t][c] = bias[c] + sum_j w[c][j] * xm[b][t + (j - (k-1)/2) * d][c],   xm = x inside [0, len_b), 0 outside (x * x_mask and the zero padding)
+__global__ void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                                  const int32_t* __restrict__ lens, int B, int T, int C, int k, int d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T * C) return;
+    const int c = (int)(i % C);
+    const int64_t bt = i / C;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    const int len = lens[b], P = (k - 1) / 2;
+    float acc = bias[c];
+    for (int j = 0; j < k; ++j) {
+        const int tt = t + (j - P) * d;
+        if (tt >= 0 && tt < len) acc += w[c * k + j] * x[((int64_t)b * T + tt) * C + c];
+    }
+    y[i] = acc;
+}
+// dx[b][t][c] = [t < len] * sum_j w[c][j] * dy[b][t - (j - P) * d][c]
+__global__ void dwconv_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, const int32_t* __restrict__ lens,
+                                       int B, int T, int C, int k, int d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T * C) return;
+    const int c = (int)(i % C);
+    const int64_t bt = i / C;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    const int P = (k - 1) / 2;
+    float acc = 0.f;
+    if (t < lens[b]) {
+        for (int j = 0; j < k; ++j) {
+            const int tt = t - (j - P) * d;
+            if (tt >= 0 && tt < T) acc += w[c * k + j] * dy[((int64_t)b * T + tt) * C + c];
+        }
+    }
+    dx[i] = acc;
+}
+// dw[c][j] += sum_{b,t} dy[b][t][c] * xm[b][t + (j - P) d][c] ; db[c] += sum dy   — grid (ceil(C / 64), row chunks), one atomic per (chunk, c, j)
+__global__ void dwconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db,
+                                         const int32_t* __restrict__ lens, int B, int T, int C, int k, int d, int rows_per_block) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;                        // 4 row lanes
+    __shared__ float sh[4][9][64];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ab = 0.f;
+    const int P = (k - 1) / 2;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min((int64_t)B * T, r0 + rows_per_block);
+    if (c < C) {
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            const int b = (int)(r / T), t = (int)(r % T);
+            const float g = dy[r * C + c];
+            ab += g;
+            const int len = lens[b];
+            for (int j = 0; j < k; ++j) {
+                const int tt = t + (j - P) * d;
+                if (tt >= 0 && tt < len) acc[j] += g * x[((int64_t)b * T + tt) * C + c];
+            }
+        }
+    }
+    for (int j = 0; j < 8; ++j) sh[rl][j][threadIdx.x & 63] = acc[j];
+    sh[rl][8][threadIdx.x & 63] = ab;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int j = 0; j < k; ++j) atomicAdd(dw + c * k + j, sh[0][j][threadIdx.x] + sh[1][j][threadIdx.x] + sh[2][j][threadIdx.x] + sh[3][j][threadIdx.x]);
+        atomicAdd(db + c, sh[0][8][threadIdx.x] + sh[1][8][threadIdx.x] + sh[2][8][threadIdx.x] + sh[3][8][threadIdx.x]);
+    }
+}
+// exact (erf) GELU, torch's F.gelu default (sdp.py:87,90)
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = x[i]; y[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = x[i];
+        dx[i] = dy[i] * (0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v));
+    }
+}
+extern "C" int xva_dwconv_fwd(const float* x, const float* w, const float* bias, float* y, const int32_t* lens, int B, int T, int C, int k, int d, void* stream) {
+    XVA_CHECK_ARG(x && w && bias && y && lens && B > 0 && T > 0 && C > 0 && k >= 1 && k <= 8 && (k & 1) && d >= 1, "dwconv_fwd: bad args");
+    const int64_t n = (int64_t)B * T * C;
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3((unsigned)xva_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, lens, B, T, C, k, d);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+/* dx written; dw (C, k) and db (C) accumulated into */
+extern "C" int xva_dwconv_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, const int32_t* lens, int B, int T, int C, int k,
+                              int d, void* stream) {
+    XVA_CHECK_ARG(dy && x && w && dx && dw && db && lens && B > 0 && T > 0 && C > 0 && k >= 1 && k <= 8 && (k & 1) && d >= 1, "dwconv_bwd: bad args");
+    const int64_t n = (int64_t)B * T * C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3((unsigned)xva_cdiv(n, 256)), dim3(256), 0, st, dy, w, dx, lens, B, T, C, k, d);
+    const int rpb = 64;
+    hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(xva_cdiv(C, 64), (unsigned)xva_cdiv((int64_t)B * T, rpb)), dim3(256), 0, st, dy, x, dw, db, lens, B, T, C, k, d,
+                       rpb);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    XVA_CHECK_ARG(x && y && n >= 0, "gelu_fwd: bad args");
+    if (n) hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)xva_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+    XVA_CHECK_ARG(x && dy && dx && n >= 0, "gelu_bwd: bad args");
+    if (n) hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)xva_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}

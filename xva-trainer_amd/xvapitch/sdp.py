@@ -1,0 +1,205 @@
+"""Building blocks of xVAPitch's stochastic duration predictor on libxvahip — python/xvapitch/sdp.py:
+DilatedDepthSeparableConv (:40-93), ElementwiseAffine (:95-114).
+
+Same constructor arguments and state_dict keys / layouts as the reference modules, same (B, C, T) tensors and (B, 1, T) mask at the interface.
+Every arithmetic step is a C call wrapped as ONE autograd primitive (depthwise dilated convolution, LayerNorm2, exact GELU, 1x1 convolution =
+xva_gemm, mask, add), so the blocks compose with torch autograd like the reference's; parameters are leaf tensors whose `.grad` autograd fills.
+Inside, tensors are fp32 time-major (B, T, C).  Not built here: the spline ConvFlow and the predictor's likelihood assembly.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .wn import _lens_of
+
+lib = _lib.lib
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+lib.xva_dwconv_fwd.restype = i32
+lib.xva_dwconv_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+lib.xva_dwconv_bwd.restype = i32
+lib.xva_dwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+lib.xva_gelu_fwd.restype = i32
+lib.xva_gelu_fwd.argtypes = [vp, vp, i64, vp]
+lib.xva_gelu_bwd.restype = i32
+lib.xva_gelu_bwd.argtypes = [vp, vp, vp, i64, vp]
+lib.xva_ln_rows_fwd.restype = i32
+lib.xva_ln_rows_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]
+lib.xva_ln_rows_bwd.restype = i32
+lib.xva_ln_rows_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+lib.xva_seq_mask.restype = i32
+lib.xva_seq_mask.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+lib.xva_fp_add_act.restype = i32
+lib.xva_fp_add_act.argtypes = [vp, vp, i32, i64, vp]
+lib.xva_hg_colsum.restype = i32
+lib.xva_hg_colsum.argtypes = [vp, i32, vp, i64, i32, f32, vp]
+P = _lib.ptr
+ST = _lib.stream_ptr
+
+
+class DwConv(torch.autograd.Function):
+    """y = depthwise dilated Conv1d(x * x_mask) ('same' zero padding); x (B, T, C), w (C, 1, k), b (C)."""
+    @staticmethod
+    def forward(ctx, x, w, b, lens, d):
+        x = x.contiguous(); B, T, Cc = x.shape; k = w.size(-1)
+        y = torch.empty_like(x)
+        _lib.check(lib.xva_dwconv_fwd(P(x), P(w.contiguous()), P(b), P(y), P(lens), B, T, Cc, k, d, ST()), "xva_dwconv_fwd")
+        ctx.save_for_backward(x, w, lens); ctx.d = d
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, lens = ctx.saved_tensors
+        B, T, Cc = x.shape; k = w.size(-1)
+        dx = torch.empty_like(x); dw = torch.zeros_like(w); db = torch.zeros(Cc, device=x.device)
+        _lib.check(lib.xva_dwconv_bwd(P(dy.contiguous()), P(x), P(w.contiguous()), P(dx), P(dw), P(db), P(lens), B, T, Cc, k, ctx.d, ST()), "xva_dwconv_bwd")
+        return dx, dw, db, None, None
+
+
+class Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous(); y = torch.empty_like(x)
+        _lib.check(lib.xva_gelu_fwd(P(x), P(y), x.numel(), ST()), "xva_gelu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        _lib.check(lib.xva_gelu_bwd(P(x), P(dy.contiguous()), P(dx), x.numel(), ST()), "xva_gelu_bwd")
+        return dx
+
+
+class LayerNormRows(torch.autograd.Function):
+    """LayerNorm2 (sdp.py:13-37): layer_norm over the last (channel) dimension of (B, T, C), eps 1e-5."""
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        x = x.contiguous(); rows, Cc = x.numel() // x.size(-1), x.size(-1)
+        y = torch.empty_like(x); mean = torch.empty(rows, device=x.device); rstd = torch.empty(rows, device=x.device)
+        _lib.check(lib.xva_ln_rows_fwd(P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), rows, Cc, 1e-5, ST()), "xva_ln_rows_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        rows, Cc = x.numel() // x.size(-1), x.size(-1)
+        dx = torch.empty_like(x); dg = torch.zeros_like(gamma); db = torch.zeros_like(gamma)
+        _lib.check(lib.xva_ln_rows_bwd(P(dy.contiguous()), P(x), P(mean), P(rstd), P(gamma), P(dx), P(dg), P(db), rows, Cc, ST()), "xva_ln_rows_bwd")
+        return dx, dg, db
+
+
+class Conv1x1(torch.autograd.Function):
+    """nn.Conv1d(Cin, Cout, 1) on (B, T, Cin): one xva_gemm each for y, dx and dw (Cin, Cout multiples of 4)."""
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous(); Cin = x.size(-1); rows = x.numel() // Cin; Cout = w.size(0)
+        w2 = w.reshape(Cout, Cin).contiguous()
+        y = torch.empty(*x.shape[:-1], Cout, device=x.device)
+        _lib.gemm(x, w2, y, rows, Cout, Cin, Cin, Cin, Cout, layout=_lib.GEMM_NT, compute=0, bias=b)
+        ctx.save_for_backward(x, w2); ctx.wshape = tuple(w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        dy = dy.contiguous(); Cin = x.size(-1); rows = x.numel() // Cin; Cout = w2.size(0)
+        dx = torch.empty_like(x)
+        _lib.gemm(dy, w2, dx, rows, Cin, Cout, Cout, Cin, Cin, layout=_lib.GEMM_NN, compute=0)
+        dw = torch.zeros(Cout, Cin, device=x.device); db = torch.zeros(Cout, device=x.device)
+        _lib.gemm(dy, x, dw, Cout, Cin, rows, Cout, Cin, Cin, layout=_lib.GEMM_TN, compute=0, accumulate=True, splitk=0)
+        _lib.check(lib.xva_hg_colsum(P(dy), 0, P(db), rows, Cout, 1.0, ST()), "xva_hg_colsum")
+        return dx, dw.view(ctx.wshape), db
+
+
+class Mask(torch.autograd.Function):
+    """x * x_mask on (B, T, C) (lens = the mask)"""
+    @staticmethod
+    def forward(ctx, x, lens):
+        y = x.contiguous().clone(); B, T, Cc = y.shape
+        _lib.check(lib.xva_seq_mask(P(y), 0, B, T, 0, Cc, P(lens), ST()), "xva_seq_mask")
+        ctx.save_for_backward(lens)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (lens,) = ctx.saved_tensors
+        d = dy.contiguous().clone(); B, T, Cc = d.shape
+        _lib.check(lib.xva_seq_mask(P(d), 0, B, T, 0, Cc, P(lens), ST()), "xva_seq_mask")
+        return d, None
+
+
+class Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        y = a.contiguous().clone()
+        _lib.check(lib.xva_fp_add_act(P(y), P(b.contiguous()), 0, y.numel(), ST()), "xva_fp_add_act")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def _param(t, device):
+    return t.to(device=device, dtype=torch.float32).requires_grad_(True)
+
+
+class DilatedDepthSeparableConv:
+    """sdp.py:40-93: per layer  y = GELU(LN(dwconv_{d = k^i}(x * x_mask))); y = GELU(LN(conv1x1(y))); x = x + y;  output x * x_mask."""
+
+    def __init__(self, channels, kernel_size, num_layers, dropout_p=0.0, device="cuda", seed=0):
+        if dropout_p:
+            raise NotImplementedError("DilatedDepthSeparableConv: dropout_p > 0 is not built")
+        if channels % 4 or kernel_size % 2 != 1 or kernel_size > 7:
+            raise NotImplementedError("DilatedDepthSeparableConv: channels must be a multiple of 4, kernel_size odd <= 7")
+        self.C, self.k, self.L = channels, kernel_size, num_layers
+        self.device = torch.device(device)
+        gen = torch.Generator().manual_seed(seed)
+        u = lambda shape, fan: (torch.rand(*shape, generator=gen) * 2 - 1) * (1.0 / fan) ** 0.5
+        self.p = {}
+        for i in range(num_layers):
+            self.p["convs_sep.%d.weight" % i] = _param(u((channels, 1, kernel_size), kernel_size), self.device)
+            self.p["convs_sep.%d.bias" % i] = _param(u((channels,), kernel_size), self.device)
+            self.p["convs_1x1.%d.weight" % i] = _param(u((channels, channels, 1), channels), self.device)
+            self.p["convs_1x1.%d.bias" % i] = _param(u((channels,), channels), self.device)
+            for n in ("norms_1", "norms_2"):
+                self.p["%s.%d.gamma" % (n, i)] = _param(torch.ones(channels), self.device)
+                self.p["%s.%d.beta" % (n, i)] = _param(torch.zeros(channels), self.device)
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.p.items()}
+
+    def load_state_dict(self, sd):
+        if set(sd) != set(self.p):
+            raise KeyError("DilatedDepthSeparableConv.load_state_dict: key mismatch %s" % sorted(set(sd) ^ set(self.p))[:6])
+        for k, t in self.p.items():
+            if tuple(t.shape) != tuple(sd[k].shape):
+                raise ValueError("%s: shape %s != %s" % (k, tuple(sd[k].shape), tuple(t.shape)))
+            with torch.no_grad():
+                t.copy_(sd[k])
+
+    def parameters(self):
+        return list(self.p.values())
+
+    def forward_btc(self, x, lens, g=None):
+        """x, g: (B, T, C)"""
+        p = self.p
+        if g is not None:
+            x = Add.apply(x, g)
+        for i in range(self.L):
+            y = DwConv.apply(x, p["convs_sep.%d.weight" % i], p["convs_sep.%d.bias" % i], lens, self.k ** i)
+            y = Gelu.apply(LayerNormRows.apply(y, p["norms_1.%d.gamma" % i], p["norms_1.%d.beta" % i]))
+            y = Conv1x1.apply(y, p["convs_1x1.%d.weight" % i], p["convs_1x1.%d.bias" % i])
+            y = Gelu.apply(LayerNormRows.apply(y, p["norms_2.%d.gamma" % i], p["norms_2.%d.beta" % i]))
+            x = Add.apply(x, y)
+        return Mask.apply(x, lens)
+
+    def __call__(self, x, x_mask, g=None):
+        """(B, C, T) in and out, like the reference"""
+        _lib.require_cuda(x)
+        lens = _lens_of(x, x_mask)
+        y = self.forward_btc(x.float().transpose(1, 2).contiguous(), lens, g.float().transpose(1, 2).contiguous() if g is not None else None)
+        return y.transpose(1, 2)
