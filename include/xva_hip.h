@@ -461,6 +461,14 @@ int xva_dwconv_bwd(const float* dy, const float* x, const float* w, float* dx, f
 int xva_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int xva_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
 
+/* Rational-quadratic spline with linear tails, forward direction: piecewise_rational_quadratic_transform(inverse=False, tails="linear") of
+ * python/xvapitch/util.py:203-391 as ConvFlow uses it (sdp.py:151-167).  x, y, logdet: n elements; h: (n, 3K - 1) raw parameters
+ * [K widths | K heights | K - 1 derivatives], widths / heights multiplied by wh_scale (= 1 / sqrt(hidden)) before their softmax.  K <= 16.
+ * The backward returns d x and d h from the gradients of y and of log|det|. */
+int xva_rq_spline_fwd(const float* x, const float* h, float* y, float* logdet, int64_t n, int K, float wh_scale, float bound, void* stream);
+int xva_rq_spline_bwd(const float* x, const float* h, const float* dy, const float* dlogdet, float* dx, float* dh, int64_t n, int K, float wh_scale,
+                      float bound, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,32 @@ def main():
                 "dds_y": y.detach().numpy(), "dds_dx": x.grad.numpy(), "dds_dg": g.grad.numpy()})
     for k, v in sd.items():
         out["dds_sd/" + k] = v.numpy()
+    # ---- ConvFlow (2-channel flow variable; the reference zero-initialises `proj`: give it values so that the spline is exercised), inputs
+    # reaching into the linear tails (|x| > 5) as well
+    Hh = 32
+    cf = sdp.ConvFlow(2, Hh, K, num_layers=3)
+    cf.proj.weight.data = 0.8 * torch.randn_like(cf.proj.weight)
+    cf.proj.bias.data = 0.3 * torch.randn_like(cf.proj.bias)
+    z = (torch.randn(B, 2, T) * 3.0).requires_grad_(True)
+    gc = torch.randn(B, Hh, T, requires_grad=True)
+    rz = torch.randn(B, 2, T); rl = torch.randn(B)
+    zy, zld = cf(z * 1.0, x_mask, g=gc * 1.0)
+    sdc = {k: v.detach().clone() for k, v in cf.state_dict().items()}
+    zo, gco = z.detach().clone().requires_grad_(True), gc.detach().clone().requires_grad_(True)
+    lv = {k: v.clone().requires_grad_(True) for k, v in sdc.items()}
+    zyo, zldo = oxv.conv_flow(lv, zo, x_mask, gco, Hh, K, 3)
+    assert torch.allclose(zy, zyo, rtol=1e-5, atol=1e-5) and torch.allclose(zld, zldo, rtol=1e-5, atol=1e-4), (float((zy - zyo).abs().max()), float((zld - zldo).abs().max()))
+    ((zy * rz).sum() + (zld * rl).sum()).backward()
+    ((zyo * rz).sum() + (zldo * rl).sum()).backward()
+    for n, p in cf.named_parameters():
+        assert torch.allclose(lv[n].grad, p.grad, rtol=1e-4, atol=1e-4), (n, float((lv[n].grad - p.grad).abs().max()))
+        out["cf_grad/" + n] = p.grad.numpy()
+    assert torch.allclose(zo.grad, z.grad, rtol=1e-4, atol=1e-5) and torch.allclose(gco.grad, gc.grad, rtol=1e-4, atol=1e-5)
+    assert float((z.detach().abs() > 5).float().mean()) > 0.02          # some inputs are in the tails
+    out.update({"cf_cfg": np.array([B, Hh, T, K, 3, 10]), "cf_z": z.detach().numpy(), "cf_g": gc.detach().numpy(), "cf_rz": rz.numpy(), "cf_rl": rl.numpy(),
+                "cf_y": zy.detach().numpy(), "cf_logdet": zld.detach().numpy(), "cf_dz": z.grad.numpy(), "cf_dg": gc.grad.numpy()})
+    for k, v in sdc.items():
+        out["cf_sd/" + k] = v.numpy()
     path = os.path.join(ROOT, "tests", "golden", "xvapitch_sdp.npz")
     np.savez_compressed(path, **out)
     print("xvapitch_sdp.npz", len(out), "arrays", os.path.getsize(path), "bytes")

@@ -149,3 +149,46 @@ def dds_conv(sd, x, x_mask, g=None, kernel_size=3, num_layers=3, pre=""):
         y = F.gelu(F.layer_norm(y.transpose(1, -1), (Cc,), sd["%snorms_2.%d.gamma" % (pre, i)], sd["%snorms_2.%d.beta" % (pre, i)], 1e-5).transpose(1, -1))
         x = x + y
     return x * x_mask
+
+
+def rq_spline(x, uw, uh, ud, bound=5.0, min_w=1e-3, min_h=1e-3, min_d=1e-3):
+    """piecewise_rational_quadratic_transform(inverse=False, tails="linear") (python/xvapitch/util.py:203-391): x (...), uw / uh (..., K),
+    ud (..., K - 1) -> y, log|det|.  Outside [-bound, bound]: identity; inside: the rational-quadratic map of the bin that holds x, with knot
+    derivatives softplus(ud) + min_d inside and exactly 1 at the two boundary knots."""
+    K = uw.size(-1)
+    inside = (x >= -bound) & (x <= bound)
+
+    def edges(u, m):
+        w = m + (1 - m * K) * torch.softmax(u, -1)
+        c = F.pad(torch.cumsum(w, -1), (1, 0)) * (2 * bound) - bound
+        c = torch.cat([torch.full_like(c[..., :1], -bound), c[..., 1:-1], torch.full_like(c[..., :1], bound)], -1)
+        return c, c[..., 1:] - c[..., :-1]
+    cw, w = edges(uw, min_w)
+    ch, hh = edges(uh, min_h)
+    const = float(np.log(np.exp(1 - min_d) - 1))
+    d = min_d + F.softplus(torch.cat([torch.full_like(ud[..., :1], const), ud, torch.full_like(ud[..., :1], const)], -1))
+    loc = cw.clone()
+    loc[..., -1] = loc[..., -1] + 1e-6
+    xc = x.clamp(-bound, bound)
+    k = ((xc[..., None] >= loc).sum(-1) - 1).clamp(0, K - 1)[..., None]
+    g = lambda t: t.gather(-1, k)[..., 0]
+    cwk, wk, chk, hk, dk, dk1 = g(cw), g(w), g(ch), g(hh), g(d), g(d[..., 1:])
+    th = (xc - cwk) / wk
+    om = th * (1 - th)
+    dl = hk / wk
+    den = dl + (dk + dk1 - 2 * dl) * om
+    y = chk + hk * (dl * th ** 2 + dk * om) / den
+    ld = torch.log(dl ** 2 * (dk1 * th ** 2 + 2 * dl * om + dk * (1 - th) ** 2)) - 2 * torch.log(den)
+    return torch.where(inside, y, x), torch.where(inside, ld, torch.zeros_like(ld))
+
+
+def conv_flow(sd, x, x_mask, g, hidden, kernel_size=3, num_layers=3, num_bins=10, tail_bound=5.0, pre=""):
+    """ConvFlow.forward (python/xvapitch/sdp.py:144-176), forward direction, 2-channel input."""
+    x0, x1 = x[:, :1], x[:, 1:]
+    h = F.conv1d(x0, sd[pre + "pre.weight"], sd[pre + "pre.bias"])
+    h = dds_conv(sd, h, x_mask, g, kernel_size, num_layers, pre=pre + "convs.")
+    h = F.conv1d(h, sd[pre + "proj.weight"], sd[pre + "proj.bias"]) * x_mask
+    b, c, t = x0.shape
+    h = h.reshape(b, c, -1, t).permute(0, 1, 3, 2)
+    y1, ld = rq_spline(x1, h[..., :num_bins] / hidden ** 0.5, h[..., num_bins:2 * num_bins] / hidden ** 0.5, h[..., 2 * num_bins:], tail_bound)
+    return torch.cat([x0, y1], 1) * x_mask, (ld * x_mask).sum((1, 2))

@@ -124,3 +124,24 @@ def test_dds_conv_oracle_matches_reference_golden():
     for k in g.files:
         if k.startswith("dds_grad/"):
             assert torch.allclose(sd[k[9:]].grad, torch.from_numpy(g[k]), rtol=1e-4, atol=1e-5), k
+
+
+def test_conv_flow_oracle_matches_reference_golden():
+    """oracle/xvapitch.py:conv_flow + rq_spline vs the vectors recorded from the reference ConvFlow (sdp.py:116-176, util.py:203-391)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import xvapitch as oxv
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xvapitch_sdp.npz"))
+    B, Hh, T, K, L, NB = (int(v) for v in g["cf_cfg"])
+    lens = torch.from_numpy(g["lens"])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1)
+    sd = {k[6:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("cf_sd/")}
+    z = torch.from_numpy(g["cf_z"]).requires_grad_(True); cond = torch.from_numpy(g["cf_g"]).requires_grad_(True)
+    y, ld = oxv.conv_flow(sd, z, x_mask, cond, Hh, K, L, NB)
+    assert torch.allclose(y, torch.from_numpy(g["cf_y"]), rtol=1e-5, atol=1e-5) and torch.allclose(ld, torch.from_numpy(g["cf_logdet"]), rtol=1e-5, atol=1e-4)
+    ((y * torch.from_numpy(g["cf_rz"])).sum() + (ld * torch.from_numpy(g["cf_rl"])).sum()).backward()
+    assert torch.allclose(z.grad, torch.from_numpy(g["cf_dz"]), rtol=1e-4, atol=1e-5)
+    for k in g.files:
+        if k.startswith("cf_grad/"):
+            assert torch.allclose(sd[k[8:]].grad, torch.from_numpy(g[k]), rtol=1e-4, atol=1e-4), k

@@ -298,3 +298,28 @@ def test_dds_conv_against_reference_golden(golden_dir):
     worst = sorted(((_rel(m.p[k[9:]].grad, torch.from_numpy(g[k])), k[9:]) for k in g.files if k.startswith("dds_grad/")), reverse=True)
     print("DDSConv worst gradients:", worst[:3])
     assert len(worst) == 8 * L and worst[0][0] < 1e-3, worst[:3]
+
+
+def test_conv_flow_against_reference_golden(golden_dir):
+    """xvapitch/sdp.py:ConvFlow (pre, DDSConv with conditioning, proj, the rational-quadratic spline with linear tails — xva_rq_spline_fwd/bwd;
+    python/xvapitch/sdp.py:116-176, util.py:203-391) vs the REFERENCE module on inputs that reach into the tails: transformed variable, per-item
+    log-determinant, d z, d g and all 28 parameter gradients at 1e-3."""
+    from xva_trainer_amd.xvapitch.sdp import ConvFlow
+    g = np.load(os.path.join(golden_dir, "xvapitch_sdp.npz"))
+    B, Hh, T, K, L, NB = (int(v) for v in g["cf_cfg"])
+    lens = torch.from_numpy(g["lens"])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1).cuda()
+    m = ConvFlow(2, Hh, K, L, num_bins=NB)
+    sd = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cf_sd/")}
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict(sd)
+    z = torch.from_numpy(g["cf_z"]).cuda().requires_grad_(True)
+    cond = torch.from_numpy(g["cf_g"]).cuda().requires_grad_(True)
+    y, ld = m(z, x_mask, g=cond)
+    assert _rel(y, torch.from_numpy(g["cf_y"])) < 1e-3 and _rel(ld, torch.from_numpy(g["cf_logdet"])) < 1e-3
+    ((y * torch.from_numpy(g["cf_rz"]).cuda()).sum() + (ld * torch.from_numpy(g["cf_rl"]).cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    assert _rel(z.grad, torch.from_numpy(g["cf_dz"])) < 1e-3 and _rel(cond.grad, torch.from_numpy(g["cf_dg"])) < 1e-3
+    worst = sorted(((_rel(m.p[k[8:]].grad, torch.from_numpy(g[k])), k[8:]) for k in g.files if k.startswith("cf_grad/")), reverse=True)
+    print("ConvFlow worst gradients:", worst[:3])
+    assert len(worst) == 4 + 8 * L and worst[0][0] < 1e-3, worst[:3]

@@ -825,3 +825,130 @@ extern "C" int xva_gelu_bwd(const float* x, const float* dy, float* dx, int64_t 
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
+
+// ---- rational-quadratic spline with linear tails (forward direction) ----------------------------------------------------------------
+// piecewise_rational_quadratic_transform(..., inverse=False, tails="linear") of python/xvapitch/util.py:203-391 as ConvFlow calls it
+// (sdp.py:151-167): per element x and its 3K - 1 raw parameters h = [K widths | K heights | K - 1 derivatives] (the first two blocks scaled by
+// `wh_scale` = 1 / sqrt(hidden) by the caller's convention, sdp.py:155-156): outside [-bound, bound] identity with log|det| 0; inside, the
+// monotone rational-quadratic map of the bin that holds x.  One thread per element; K <= 16.
+namespace {
+constexpr int RQ_MAXK = 16;
+constexpr float RQ_MIN_W = 1e-3f, RQ_MIN_H = 1e-3f, RQ_MIN_D = 1e-3f;
+struct RqBins { float cw[RQ_MAXK + 1], ch[RQ_MAXK + 1], sw[RQ_MAXK], shh[RQ_MAXK], dv[RQ_MAXK + 1]; };
+__device__ __forceinline__ void rq_softmax(const float* u, float scale, int K, float* s) {
+    float mx = -3.0e38f;
+    for (int i = 0; i < K; ++i) mx = fmaxf(mx, u[i] * scale);
+    float sum = 0.f;
+    for (int i = 0; i < K; ++i) { s[i] = __expf(u[i] * scale - mx); sum += s[i]; }
+    const float inv = 1.f / sum;
+    for (int i = 0; i < K; ++i) s[i] *= inv;
+}
+__device__ __forceinline__ float rq_softplus(float v) { return v > 20.f ? v : log1pf(__expf(v)); }
+// cumulative bin edges cw / ch (K + 1), softmaxes and knot derivatives dv (K + 1; the two boundary ones are 1: linear tails)
+__device__ __forceinline__ void rq_bins(const float* h, int K, float wh_scale, float bound, RqBins& b) {
+    rq_softmax(h, wh_scale, K, b.sw);
+    rq_softmax(h + K, wh_scale, K, b.shh);
+    float aw = 0.f, ah = 0.f;
+    b.cw[0] = -bound; b.ch[0] = -bound;
+    for (int i = 0; i < K; ++i) {
+        aw += RQ_MIN_W + (1.f - RQ_MIN_W * K) * b.sw[i];
+        ah += RQ_MIN_H + (1.f - RQ_MIN_H * K) * b.shh[i];
+        b.cw[i + 1] = 2.f * bound * aw - bound;
+        b.ch[i + 1] = 2.f * bound * ah - bound;
+    }
+    b.cw[K] = bound; b.ch[K] = bound;
+    const float edge = RQ_MIN_D + rq_softplus(logf(__expf(1.f - RQ_MIN_D) - 1.f));
+    b.dv[0] = edge; b.dv[K] = edge;
+    for (int j = 1; j < K; ++j) b.dv[j] = RQ_MIN_D + rq_softplus(h[2 * K + j - 1]);
+}
+__device__ __forceinline__ int rq_find(const RqBins& b, int K, float x) {
+    int idx = -1;
+    for (int j = 0; j <= K; ++j) idx += (x >= (j == K ? b.cw[j] + 1e-6f : b.cw[j])) ? 1 : 0;     // searchsorted (util.py:235-237)
+    return min(max(idx, 0), K - 1);
+}
+}  // namespace
+
+__global__ void rq_spline_fwd_kernel(const float* __restrict__ x, const float* __restrict__ h, float* __restrict__ y, float* __restrict__ logdet, int64_t n, int K,
+                                     float wh_scale, float bound) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xv = x[i];
+    if (!(xv >= -bound && xv <= bound)) { y[i] = xv; logdet[i] = 0.f; return; }
+    RqBins b;
+    rq_bins(h + i * (3 * K - 1), K, wh_scale, bound, b);
+    const int k = rq_find(b, K, xv);
+    const float wk = b.cw[k + 1] - b.cw[k], hk = b.ch[k + 1] - b.ch[k], dk = b.dv[k], dk1 = b.dv[k + 1];
+    const float th = (xv - b.cw[k]) / wk, om = th * (1.f - th), dl = hk / wk;
+    const float num = hk * (dl * th * th + dk * om), den = dl + (dk + dk1 - 2.f * dl) * om;
+    y[i] = b.ch[k] + num / den;
+    const float D = dl * dl * (dk1 * th * th + 2.f * dl * om + dk * (1.f - th) * (1.f - th));
+    logdet[i] = logf(D) - 2.f * logf(den);
+}
+// dx and dh (n, 3K - 1) from dy (gradient of y) and dl (gradient of log|det|)
+__global__ void rq_spline_bwd_kernel(const float* __restrict__ x, const float* __restrict__ h, const float* __restrict__ gy_, const float* __restrict__ gl_,
+                                     float* __restrict__ dx, float* __restrict__ dh, int64_t n, int K, float wh_scale, float bound) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int NP = 3 * K - 1;
+    float* dhi = dh + i * NP;
+    const float xv = x[i], gy = gy_[i], gL = gl_[i];
+    if (!(xv >= -bound && xv <= bound)) {
+        dx[i] = gy;
+        for (int j = 0; j < NP; ++j) dhi[j] = 0.f;
+        return;
+    }
+    const float* hi = h + i * NP;
+    RqBins b;
+    rq_bins(hi, K, wh_scale, bound, b);
+    const int k = rq_find(b, K, xv);
+    const float wk = b.cw[k + 1] - b.cw[k], hk = b.ch[k + 1] - b.ch[k], dk = b.dv[k], dk1 = b.dv[k + 1];
+    const float th = (xv - b.cw[k]) / wk, om = th * (1.f - th), om_t = 1.f - 2.f * th, dl = hk / wk, A = dk + dk1 - 2.f * dl;
+    const float num = hk * (dl * th * th + dk * om), den = dl + A * om;
+    const float E = dk1 * th * th + 2.f * dl * om + dk * (1.f - th) * (1.f - th), D = dl * dl * E;
+    // reverse mode through y = ch_k + num / den and L = log D - 2 log den
+    const float g_num = gy / den, g_den = -gy * num / (den * den) - 2.f * gL / den, g_D = gL / D;
+    const float E_t = 2.f * dk1 * th + 2.f * dl * om_t - 2.f * dk * (1.f - th);
+    const float g_th = g_num * hk * (2.f * dl * th + dk * om_t) + g_den * A * om_t + g_D * dl * dl * E_t;
+    const float g_dl = g_num * hk * th * th + g_den * (1.f - 2.f * om) + g_D * (2.f * dl * E + dl * dl * 2.f * om);
+    float g_hk = g_num * (dl * th * th + dk * om) + g_dl / wk;
+    const float g_dk = g_num * hk * om + g_den * om + g_D * dl * dl * (1.f - th) * (1.f - th);
+    const float g_dk1 = g_den * om + g_D * dl * dl * th * th;
+    dx[i] = g_th / wk;
+    const float g_cwk = -g_th / wk, g_wk = -g_th * th / wk - g_dl * dl / wk, g_chk = gy;
+    // bin k's width / height / edges -> the normalised widths / heights -> softmax inputs
+    float gcw[RQ_MAXK + 1], gch[RQ_MAXK + 1];
+    for (int j = 0; j <= K; ++j) { gcw[j] = 0.f; gch[j] = 0.f; }
+    gcw[k + 1] += g_wk; gcw[k] += g_cwk - g_wk;
+    gch[k + 1] += g_hk; gch[k] += g_chk - g_hk;
+    float tw = 0.f, thh = 0.f, gsw[RQ_MAXK], gsh[RQ_MAXK], dotw = 0.f, doth = 0.f;
+    for (int ii = K - 1; ii >= 0; --ii) {                    // g w_i = 2 bound * sum_{j > i, j <= K - 1} g cw_j   (cw_0 and cw_K are constants)
+        gsw[ii] = 2.f * bound * tw * (1.f - RQ_MIN_W * K);
+        gsh[ii] = 2.f * bound * thh * (1.f - RQ_MIN_H * K);
+        if (ii >= 1) { tw += gcw[ii]; thh += gch[ii]; }
+    }
+    // note: the loop above adds edge ii AFTER using the running sum, so bin ii sees edges ii + 1 .. K - 1
+    for (int ii = 0; ii < K; ++ii) { dotw += b.sw[ii] * gsw[ii]; doth += b.shh[ii] * gsh[ii]; }
+    for (int ii = 0; ii < K; ++ii) {
+        dhi[ii] = b.sw[ii] * (gsw[ii] - dotw) * wh_scale;
+        dhi[K + ii] = b.shh[ii] * (gsh[ii] - doth) * wh_scale;
+    }
+    for (int j = 1; j < K; ++j) {
+        const float g = (j == k ? g_dk : 0.f) + (j == k + 1 ? g_dk1 : 0.f);
+        const float u = hi[2 * K + j - 1];
+        dhi[2 * K + j - 1] = g / (1.f + __expf(-u));          // softplus' = sigmoid
+    }
+}
+extern "C" int xva_rq_spline_fwd(const float* x, const float* h, float* y, float* logdet, int64_t n, int K, float wh_scale, float bound, void* stream) {
+    XVA_CHECK_ARG(x && h && y && logdet && n >= 0 && K >= 2 && K <= RQ_MAXK && bound > 0.f, "rq_spline_fwd: bad args");
+    if (n) hipLaunchKernelGGL(rq_spline_fwd_kernel, dim3((unsigned)xva_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, x, h, y, logdet, n, K, wh_scale, bound);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_rq_spline_bwd(const float* x, const float* h, const float* dy, const float* dlogdet, float* dx, float* dh, int64_t n, int K, float wh_scale,
+                                 float bound, void* stream) {
+    XVA_CHECK_ARG(x && h && dy && dlogdet && dx && dh && n >= 0 && K >= 2 && K <= RQ_MAXK && bound > 0.f, "rq_spline_bwd: bad args");
+    if (n) hipLaunchKernelGGL(rq_spline_bwd_kernel, dim3((unsigned)xva_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, x, h, dy, dlogdet, dx, dh, n, K, wh_scale,
+                              bound);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}

@@ -1,10 +1,11 @@
 """Building blocks of xVAPitch's stochastic duration predictor on libxvahip — python/xvapitch/sdp.py:
-DilatedDepthSeparableConv (:40-93), ElementwiseAffine (:95-114).
+DilatedDepthSeparableConv (:40-93), ElementwiseAffine (:95-114), ConvFlow with its rational-quadratic spline (:116-176, util.py:203-391).
 
 Same constructor arguments and state_dict keys / layouts as the reference modules, same (B, C, T) tensors and (B, 1, T) mask at the interface.
 Every arithmetic step is a C call wrapped as ONE autograd primitive (depthwise dilated convolution, LayerNorm2, exact GELU, 1x1 convolution =
 xva_gemm, mask, add), so the blocks compose with torch autograd like the reference's; parameters are leaf tensors whose `.grad` autograd fills.
-Inside, tensors are fp32 time-major (B, T, C).  Not built here: the spline ConvFlow and the predictor's likelihood assembly.
+Inside, tensors are fp32 time-major (B, T, C); splits / concatenations / flips of the 2-channel flow variable and the per-item sums of
+log-determinants are torch view / reduction glue.  Not built here: the predictor's likelihood assembly (StochasticDurationPredictor.forward).
 """
 import ctypes as C
 
@@ -33,6 +34,10 @@ lib.xva_fp_add_act.restype = i32
 lib.xva_fp_add_act.argtypes = [vp, vp, i32, i64, vp]
 lib.xva_hg_colsum.restype = i32
 lib.xva_hg_colsum.argtypes = [vp, i32, vp, i64, i32, f32, vp]
+lib.xva_rq_spline_fwd.restype = i32
+lib.xva_rq_spline_fwd.argtypes = [vp, vp, vp, vp, i64, i32, f32, f32, vp]
+lib.xva_rq_spline_bwd.restype = i32
+lib.xva_rq_spline_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp]
 P = _lib.ptr
 ST = _lib.stream_ptr
 
@@ -203,3 +208,82 @@ class DilatedDepthSeparableConv:
         lens = _lens_of(x, x_mask)
         y = self.forward_btc(x.float().transpose(1, 2).contiguous(), lens, g.float().transpose(1, 2).contiguous() if g is not None else None)
         return y.transpose(1, 2)
+
+
+class RqSpline(torch.autograd.Function):
+    """x (...), h (..., 3K - 1) -> y, log|det| : the forward rational-quadratic transform with linear tails (util.py:203-391)."""
+    @staticmethod
+    def forward(ctx, x, h, K, wh_scale, bound):
+        x = x.contiguous(); h = h.contiguous()
+        y = torch.empty_like(x); ld = torch.empty_like(x)
+        _lib.check(lib.xva_rq_spline_fwd(P(x), P(h), P(y), P(ld), x.numel(), K, wh_scale, bound, ST()), "xva_rq_spline_fwd")
+        ctx.save_for_backward(x, h); ctx.cfg = (K, wh_scale, bound)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, dy, dld):
+        x, h = ctx.saved_tensors
+        K, wh_scale, bound = ctx.cfg
+        dx = torch.empty_like(x); dh = torch.empty_like(h)
+        _lib.check(lib.xva_rq_spline_bwd(P(x), P(h), P(dy.contiguous()), P(dld.contiguous()), P(dx), P(dh), x.numel(), K, wh_scale, bound, ST()), "xva_rq_spline_bwd")
+        return dx, dh, None, None, None
+
+
+class _Module:
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.p.items()}
+
+    def load_state_dict(self, sd):
+        if set(sd) != set(self.p):
+            raise KeyError("%s.load_state_dict: key mismatch %s" % (type(self).__name__, sorted(set(sd) ^ set(self.p))[:6]))
+        for k, t in self.p.items():
+            if tuple(t.shape) != tuple(sd[k].shape):
+                raise ValueError("%s: shape %s != %s" % (k, tuple(sd[k].shape), tuple(t.shape)))
+            with torch.no_grad():
+                t.copy_(sd[k])
+
+    def parameters(self):
+        return list(self.p.values())
+
+
+class ConvFlow(_Module):
+    """sdp.py:116-176 (in_channels = 2, the predictor's case; forward direction): x0 conditions a spline over x1.
+    h = proj(DDSConv(pre(x0), g)) * x_mask -> [10 widths | 10 heights | 9 derivatives] per token; y1, log|det| = spline(x1, h)."""
+
+    def __init__(self, in_channels, hidden_channels, kernel_size, num_layers, num_bins=10, tail_bound=5.0, device="cuda", seed=0):
+        if in_channels != 2:
+            raise NotImplementedError("ConvFlow: built for the 2-channel flow variable of the duration predictor")
+        self.H, self.K, self.bound = hidden_channels, num_bins, float(tail_bound)
+        self.device = torch.device(device)
+        gen = torch.Generator().manual_seed(seed)
+        self.convs = DilatedDepthSeparableConv(hidden_channels, kernel_size, num_layers, device=device, seed=seed + 1)
+        NP = 3 * num_bins - 1
+        u = lambda shape, fan: (torch.rand(*shape, generator=gen) * 2 - 1) * (1.0 / fan) ** 0.5
+        self.p = {"pre.weight": _param(u((hidden_channels, 1, 1), 1), self.device), "pre.bias": _param(u((hidden_channels,), 1), self.device),
+                  "proj.weight": _param(torch.zeros(NP, hidden_channels, 1), self.device), "proj.bias": _param(torch.zeros(NP), self.device)}
+        for k, v in self.convs.p.items():
+            self.p["convs." + k] = v
+
+    def forward_btc(self, z, lens, g=None):
+        """z (B, T, 2), g (B, T, H) -> (B, T, 2), logdet (B)"""
+        p, H, NP = self.p, self.H, 3 * self.K - 1
+        x0, x1 = z[..., 0:1], z[..., 1]
+        # pre: Conv1d(1, H, 1) and proj: Conv1d(H, 3K - 1, 1) ride in GEMMs whose narrow dimension is zero-padded to a multiple of 4
+        x0p = torch.cat([x0, torch.zeros(*x0.shape[:-1], 3, device=z.device)], -1)
+        wpre = torch.cat([p["pre.weight"].reshape(H, 1), torch.zeros(H, 3, device=z.device)], 1).reshape(H, 4, 1)
+        h = Conv1x1.apply(x0p, wpre, p["pre.bias"])
+        h = self.convs.forward_btc(h, lens, g)
+        NPp = (NP + 3) // 4 * 4
+        wproj = torch.cat([p["proj.weight"].reshape(NP, H), torch.zeros(NPp - NP, H, device=z.device)], 0).reshape(NPp, H, 1)
+        bproj = torch.cat([p["proj.bias"], torch.zeros(NPp - NP, device=z.device)])
+        h = Mask.apply(Conv1x1.apply(h, wproj, bproj), lens)[..., :NP]
+        y1, ld = RqSpline.apply(x1, h, self.K, 1.0 / H ** 0.5, self.bound)
+        out = Mask.apply(torch.stack([x0[..., 0], y1], -1), lens)
+        ldm = Mask.apply(ld.unsqueeze(-1), lens)
+        return out, ldm.sum((1, 2))
+
+    def __call__(self, x, x_mask, g=None):
+        _lib.require_cuda(x)
+        lens = _lens_of(x, x_mask)
+        y, logdet = self.forward_btc(x.float().transpose(1, 2).contiguous(), lens, g.float().transpose(1, 2).contiguous() if g is not None else None)
+        return y.transpose(1, 2), logdet
