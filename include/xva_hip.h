@@ -469,6 +469,16 @@ int xva_rq_spline_fwd(const float* x, const float* h, float* y, float* logdet, i
 int xva_rq_spline_bwd(const float* x, const float* h, const float* dy, const float* dlogdet, float* dx, float* dh, int64_t n, int K, float wh_scale,
                       float bound, void* stream);
 
+/* ElementwiseAffine (sdp.py:95-114) on (B, T, C): y = (x * exp(log_scale) + translation) * mask, logdet[b] = len_b * sum(log_scale); the backward
+ * accumulates into d_log_scale / d_translation.  xva_sdp_dequant_*: the variational-dequantisation step of StochasticDurationPredictor.forward
+ * (sdp.py:283-296) per token: z0_log = log(max(dr - sigmoid(z_u), 1e-5)) * mask, logsig = (logsigmoid(z_u) + logsigmoid(-z_u)) * mask. */
+int xva_affine_fwd(const float* x, const float* log_scale, const float* translation, float* y, float* logdet, const int32_t* lens, int B, int T, int C, void* stream);
+int xva_affine_bwd(const float* x, const float* log_scale, const float* dy, const float* dlogdet, float* dx, float* d_log_scale, float* d_translation,
+                   const int32_t* lens, int B, int T, int C, void* stream);
+int xva_sdp_dequant_fwd(const float* z_u, const float* dr, float* z0_log, float* logsig, const int32_t* lens, int B, int T, void* stream);
+int xva_sdp_dequant_bwd(const float* z_u, const float* dr, const float* d_z0_log, const float* d_logsig, float* d_z_u, const int32_t* lens, int B, int T,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

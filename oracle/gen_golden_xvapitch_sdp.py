@@ -77,6 +77,45 @@ def main():
                 "cf_y": zy.detach().numpy(), "cf_logdet": zld.detach().numpy(), "cf_dz": z.grad.numpy(), "cf_dg": gc.grad.numpy()})
     for k, v in sdc.items():
         out["cf_sd/" + k] = v.numpy()
+    # ---- StochasticDurationPredictor, training direction, with speaker (cond) and language conditioning; dropout off; the N(0, 1) draw of
+    # sdp.py:281 is the first use of torch's generator inside forward(), so the same seed reproduces it outside
+    Cin, Hs, Cg, Cl = 24, 32, 8, 4
+    pr = sdp.StochasticDurationPredictor(Cin, Hs, K, 0.0, 4, cond_channels=Cg, language_emb_dim=Cl)
+    pr.eval()
+    for n, p in pr.named_parameters():
+        if n.endswith("proj.weight") and "flows" in n:
+            p.data = 0.5 * torch.randn_like(p)
+        elif n.endswith("proj.bias") and "flows" in n:
+            p.data = 0.2 * torch.randn_like(p)
+        elif "log_scale" in n or "translation" in n:
+            p.data = 0.3 * torch.randn_like(p)
+    xs = torch.randn(B, Cin + Cl, T, requires_grad=True)
+    dr = (torch.randint(1, 9, (B, 1, T)).float() * x_mask)
+    gs = torch.randn(B, Cg, 1, requires_grad=True)
+    le = torch.randn(B, Cl, 1, requires_grad=True)
+    rn = torch.randn(B)
+    torch.manual_seed(99)
+    nll = pr(xs * 1.0, x_mask, dr=dr, g=gs * 1.0, lang_emb=le * 1.0)
+    torch.manual_seed(99)
+    noise = torch.randn(B, 2, T)
+    sds = {k: v.detach().clone() for k, v in pr.state_dict().items()}
+    xso, gso, leo = (t.detach().clone().requires_grad_(True) for t in (xs, gs, le))
+    lvs = {k: v.clone().requires_grad_(True) for k, v in sds.items()}
+    nllo = oxv.sdp_forward(lvs, xso, x_mask, dr, noise, Hs, K, 4, g=gso, lang_emb=leo)
+    assert torch.allclose(nll, nllo, rtol=1e-5, atol=1e-3), (nll, nllo)
+    (nll * rn).sum().backward()
+    (nllo * rn).sum().backward()
+    for n, p in pr.named_parameters():
+        # ten flows deep in fp32: compared by relative L2 norm (element-wise the two fp32 evaluation orders differ by ~1e-3 of the tensor's scale)
+        rel = float((lvs[n].grad - p.grad).norm() / p.grad.norm().clamp_min(1e-12))
+        assert rel < 2e-4, (n, rel)
+        out["sdp_grad/" + n] = p.grad.numpy()
+    assert torch.allclose(xso.grad, xs.grad, rtol=1e-3, atol=1e-5) and torch.allclose(gso.grad, gs.grad, rtol=1e-3, atol=1e-4)
+    out.update({"sdp_cfg": np.array([B, Cin, Hs, Cg, Cl, T, K]), "sdp_x": xs.detach().numpy(), "sdp_dr": dr.numpy(), "sdp_g": gs.detach().numpy(), "sdp_lang": le.detach().numpy(),
+                "sdp_noise": noise.numpy(), "sdp_r": rn.numpy(), "sdp_nll": nll.detach().numpy(), "sdp_dx": xs.grad.numpy(), "sdp_dg": gs.grad.numpy(),
+                "sdp_dlang": le.grad.numpy()})
+    for k, v in sds.items():
+        out["sdp_sd/" + k] = v.numpy()
     path = os.path.join(ROOT, "tests", "golden", "xvapitch_sdp.npz")
     np.savez_compressed(path, **out)
     print("xvapitch_sdp.npz", len(out), "arrays", os.path.getsize(path), "bytes")

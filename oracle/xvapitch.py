@@ -192,3 +192,48 @@ def conv_flow(sd, x, x_mask, g, hidden, kernel_size=3, num_layers=3, num_bins=10
     h = h.reshape(b, c, -1, t).permute(0, 1, 3, 2)
     y1, ld = rq_spline(x1, h[..., :num_bins] / hidden ** 0.5, h[..., num_bins:2 * num_bins] / hidden ** 0.5, h[..., 2 * num_bins:], tail_bound)
     return torch.cat([x0, y1], 1) * x_mask, (ld * x_mask).sum((1, 2))
+
+
+def sdp_forward(sd, x, x_mask, dr, noise, hidden, kernel_size=3, num_flows=4, g=None, lang_emb=None):
+    """StochasticDurationPredictor.forward, training direction (python/xvapitch/sdp.py:247-310): negative log-likelihood (B,) of the durations
+    `dr` with variational dequantisation; `noise` is the N(0, 1) draw of :281."""
+    import math
+    x = F.conv1d(x, sd["pre.weight"], sd["pre.bias"])
+    if g is not None:
+        x = x + F.conv1d(g, sd["cond.weight"], sd["cond.bias"])
+    if lang_emb is not None:
+        x = x + F.conv1d(lang_emb, sd["cond_lang.weight"], sd["cond_lang.bias"])
+    x = dds_conv(sd, x, x_mask, None, kernel_size, 3, pre="convs.")
+    x = F.conv1d(x, sd["proj.weight"], sd["proj.bias"]) * x_mask
+    h = F.conv1d(dr, sd["post_pre.weight"], sd["post_pre.bias"])
+    h = dds_conv(sd, h, x_mask, None, kernel_size, 3, pre="post_convs.")
+    h = F.conv1d(h, sd["post_proj.weight"], sd["post_proj.bias"]) * x_mask
+
+    def affine(pre, z):
+        return (z * torch.exp(sd[pre + "log_scale"]) + sd[pre + "translation"]) * x_mask, (sd[pre + "log_scale"] * x_mask).sum((1, 2))
+    noise = noise * x_mask
+    z_q, ld_q = noise, 0.0
+    for idx in range(num_flows + 1):
+        if idx == 0:
+            z_q, ld = affine("post_flows.0.", z_q)
+        else:
+            z_q, ld = conv_flow(sd, z_q, x_mask, x + h, hidden, kernel_size, 3, pre="post_flows.%d." % idx)
+            z_q = torch.flip(z_q, [1])
+        ld_q = ld_q + ld
+    z_u, z_v = z_q[:, :1], z_q[:, 1:]
+    u = torch.sigmoid(z_u) * x_mask
+    z0 = (dr - u) * x_mask
+    ld_q = ld_q + ((F.logsigmoid(z_u) + F.logsigmoid(-z_u)) * x_mask).sum((1, 2))
+    nll_post = (-0.5 * (math.log(2 * math.pi) + noise ** 2) * x_mask).sum((1, 2)) - ld_q
+    z0 = torch.log(torch.clamp_min(z0, 1e-5)) * x_mask
+    ld_tot = (-z0).sum((1, 2))
+    z = torch.cat([z0, z_v], 1)
+    for idx in range(num_flows + 1):
+        if idx == 0:
+            z, ld = affine("flows.0.", z)
+        else:
+            z, ld = conv_flow(sd, z, x_mask, x, hidden, kernel_size, 3, pre="flows.%d." % idx)
+            z = torch.flip(z, [1])
+        ld_tot = ld_tot + ld
+    nll_flow = (0.5 * (math.log(2 * math.pi) + z ** 2) * x_mask).sum((1, 2)) - ld_tot
+    return nll_flow + nll_post

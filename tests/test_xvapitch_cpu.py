@@ -145,3 +145,27 @@ def test_conv_flow_oracle_matches_reference_golden():
     for k in g.files:
         if k.startswith("cf_grad/"):
             assert torch.allclose(sd[k[8:]].grad, torch.from_numpy(g[k]), rtol=1e-4, atol=1e-4), k
+
+
+def test_sdp_oracle_matches_reference_golden():
+    """oracle/xvapitch.py:sdp_forward vs the vectors recorded from the reference StochasticDurationPredictor (sdp.py:179-310, training direction)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import xvapitch as oxv
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xvapitch_sdp.npz"))
+    B, Cin, Hs, Cg, Cl, T, K = (int(v) for v in g["sdp_cfg"])
+    lens = torch.from_numpy(g["lens"])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1)
+    sd = {k[7:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("sdp_sd/")}
+    x = torch.from_numpy(g["sdp_x"]).requires_grad_(True)
+    nll = oxv.sdp_forward(sd, x, x_mask, torch.from_numpy(g["sdp_dr"]), torch.from_numpy(g["sdp_noise"]), Hs, K, 4, g=torch.from_numpy(g["sdp_g"]),
+                          lang_emb=torch.from_numpy(g["sdp_lang"]))
+    assert torch.allclose(nll, torch.from_numpy(g["sdp_nll"]), rtol=1e-5, atol=1e-3)
+    (nll * torch.from_numpy(g["sdp_r"])).sum().backward()
+    ref = torch.from_numpy(g["sdp_dx"])
+    assert float((x.grad - ref).norm() / ref.norm()) < 2e-4
+    for k in g.files:
+        if k.startswith("sdp_grad/"):
+            r = torch.from_numpy(g[k])
+            assert float((sd[k[9:]].grad - r).norm() / r.norm().clamp_min(1e-12)) < 2e-4, k

@@ -323,3 +323,30 @@ def test_conv_flow_against_reference_golden(golden_dir):
     worst = sorted(((_rel(m.p[k[8:]].grad, torch.from_numpy(g[k])), k[8:]) for k in g.files if k.startswith("cf_grad/")), reverse=True)
     print("ConvFlow worst gradients:", worst[:3])
     assert len(worst) == 4 + 8 * L and worst[0][0] < 1e-3, worst[:3]
+
+
+def test_stochastic_duration_predictor_against_reference_golden(golden_dir):
+    """xvapitch/sdp.py:StochasticDurationPredictor, training direction (negative log-likelihood of the durations through 2 x (ElementwiseAffine + 4
+    ConvFlows), variational dequantisation, speaker and language conditioning; python/xvapitch/sdp.py:179-310) vs the REFERENCE module with the same
+    N(0, 1) draw: nll per item, d x, d g, d lang and all 290 parameter gradients at 1e-3."""
+    from xva_trainer_amd.xvapitch.sdp import StochasticDurationPredictor
+    g = np.load(os.path.join(golden_dir, "xvapitch_sdp.npz"))
+    B, Cin, Hs, Cg, Cl, T, K = (int(v) for v in g["sdp_cfg"])
+    lens = torch.from_numpy(g["lens"])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1).cuda()
+    m = StochasticDurationPredictor(Cin, Hs, K, 0.0, 4, cond_channels=Cg, language_emb_dim=Cl)
+    sd = {k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sdp_sd/")}
+    assert set(m.state_dict()) == set(sd), sorted(set(m.state_dict()) ^ set(sd))[:8]
+    m.load_state_dict(sd)
+    x = torch.from_numpy(g["sdp_x"]).cuda().requires_grad_(True)
+    gs = torch.from_numpy(g["sdp_g"]).cuda().requires_grad_(True)
+    le = torch.from_numpy(g["sdp_lang"]).cuda().requires_grad_(True)
+    nll = m(x, x_mask, torch.from_numpy(g["sdp_dr"]).cuda(), g=gs, lang_emb=le, noise=torch.from_numpy(g["sdp_noise"]).cuda())
+    assert _rel(nll, torch.from_numpy(g["sdp_nll"])) < 1e-3, (nll, g["sdp_nll"])
+    (nll * torch.from_numpy(g["sdp_r"]).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert _rel(x.grad, torch.from_numpy(g["sdp_dx"])) < 1e-3 and _rel(gs.grad, torch.from_numpy(g["sdp_dg"])) < 1e-3
+    assert _rel(le.grad, torch.from_numpy(g["sdp_dlang"])) < 1e-3
+    worst = sorted(((_rel(m.p[k[9:]].grad, torch.from_numpy(g[k])), k[9:]) for k in g.files if k.startswith("sdp_grad/")), reverse=True)
+    print("SDP worst gradients:", worst[:4], "of", len(worst))
+    assert len(worst) == len(sd) and worst[0][0] < 1e-3, worst[:4]

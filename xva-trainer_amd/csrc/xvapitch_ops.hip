@@ -952,3 +952,85 @@ extern "C" int xva_rq_spline_bwd(const float* x, const float* h, const float* dy
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
+
+// ---- ElementwiseAffine (sdp.py:95-114) and the dequantisation step of the duration predictor (sdp.py:283-296), (B, T, C) fp32 -------------------
+// y = (x * exp(log_scale[c]) + translation[c]) * mask ; logdet[b] = len_b * sum_c log_scale[c]
+__global__ void affine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ls, const float* __restrict__ tr, float* __restrict__ y,
+                                  float* __restrict__ logdet, const int32_t* __restrict__ lens, int B, int T, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T * C) return;
+    const int c = (int)(i % C);
+    const int64_t bt = i / C;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    y[i] = t < lens[b] ? x[i] * __expf(ls[c]) + tr[c] : 0.f;
+    if (t == 0 && c == 0) { float s = 0.f; for (int k = 0; k < C; ++k) s += ls[k]; logdet[b] = s * (float)lens[b]; }
+}
+// dx = dy * exp(ls) * mask ; d ls[c] += sum dy * x * exp(ls) * mask + sum_b dlogdet[b] * len_b ; d tr[c] += sum dy * mask     (tiny tensors: atomics)
+__global__ void affine_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ls, const float* __restrict__ dy, const float* __restrict__ dlogdet,
+                                  float* __restrict__ dx, float* __restrict__ dls, float* __restrict__ dtr, const int32_t* __restrict__ lens, int B, int T, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T * C) return;
+    const int c = (int)(i % C);
+    const int64_t bt = i / C;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    const bool live = t < lens[b];
+    const float e = __expf(ls[c]), g = live ? dy[i] : 0.f;
+    dx[i] = g * e;
+    if (live) { atomicAdd(dls + c, g * x[i] * e); atomicAdd(dtr + c, g); }
+    if (t == 0) atomicAdd(dls + c, dlogdet[b] * (float)lens[b]);
+}
+// u = sigmoid(z_u) * m ; z0 = (dr - u) * m ; out0 = log(max(z0, 1e-5)) * m ; out1 = (logsigmoid(z_u) + logsigmoid(-z_u)) * m          (per token)
+__global__ void sdp_dequant_fwd_kernel(const float* __restrict__ zu, const float* __restrict__ dr, float* __restrict__ z0log, float* __restrict__ lsig,
+                                       const int32_t* __restrict__ lens, int B, int T) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T) return;
+    const int t = (int)(i % T), b = (int)(i / T);
+    if (t >= lens[b]) { z0log[i] = 0.f; lsig[i] = 0.f; return; }
+    const float v = zu[i];
+    const float sp = fmaxf(v, 0.f) + log1pf(__expf(-fabsf(v)));      // softplus(v): logsigmoid(v) = v - sp, logsigmoid(-v) = -sp
+    const float s = 1.f / (1.f + __expf(-v));
+    z0log[i] = logf(fmaxf(dr[i] - s, 1e-5f));
+    lsig[i] = v - 2.f * sp;
+}
+__global__ void sdp_dequant_bwd_kernel(const float* __restrict__ zu, const float* __restrict__ dr, const float* __restrict__ d_z0log, const float* __restrict__ d_lsig,
+                                       float* __restrict__ d_zu, const int32_t* __restrict__ lens, int B, int T) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T) return;
+    const int t = (int)(i % T), b = (int)(i / T);
+    if (t >= lens[b]) { d_zu[i] = 0.f; return; }
+    const float v = zu[i], s = 1.f / (1.f + __expf(-v)), z0 = dr[i] - s;
+    float g = d_lsig[i] * (1.f - 2.f * s);
+    if (z0 > 1e-5f) g += d_z0log[i] * (-s * (1.f - s)) / z0;
+    d_zu[i] = g;
+}
+extern "C" int xva_affine_fwd(const float* x, const float* log_scale, const float* translation, float* y, float* logdet, const int32_t* lens, int B, int T, int C,
+                              void* stream) {
+    XVA_CHECK_ARG(x && log_scale && translation && y && logdet && lens && B > 0 && T > 0 && C > 0, "affine_fwd: bad args");
+    hipLaunchKernelGGL(affine_fwd_kernel, dim3((unsigned)xva_cdiv((int64_t)B * T * C, 256)), dim3(256), 0, (hipStream_t)stream, x, log_scale, translation, y, logdet, lens,
+                       B, T, C);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+/* d_log_scale / d_translation (C) are accumulated into */
+extern "C" int xva_affine_bwd(const float* x, const float* log_scale, const float* dy, const float* dlogdet, float* dx, float* d_log_scale, float* d_translation,
+                              const int32_t* lens, int B, int T, int C, void* stream) {
+    XVA_CHECK_ARG(x && log_scale && dy && dlogdet && dx && d_log_scale && d_translation && lens && B > 0 && T > 0 && C > 0, "affine_bwd: bad args");
+    hipLaunchKernelGGL(affine_bwd_kernel, dim3((unsigned)xva_cdiv((int64_t)B * T * C, 256)), dim3(256), 0, (hipStream_t)stream, x, log_scale, dy, dlogdet, dx, d_log_scale,
+                       d_translation, lens, B, T, C);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_sdp_dequant_fwd(const float* z_u, const float* dr, float* z0_log, float* logsig, const int32_t* lens, int B, int T, void* stream) {
+    XVA_CHECK_ARG(z_u && dr && z0_log && logsig && lens && B > 0 && T > 0, "sdp_dequant_fwd: bad args");
+    hipLaunchKernelGGL(sdp_dequant_fwd_kernel, dim3((unsigned)xva_cdiv((int64_t)B * T, 256)), dim3(256), 0, (hipStream_t)stream, z_u, dr, z0_log, logsig, lens, B, T);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_sdp_dequant_bwd(const float* z_u, const float* dr, const float* d_z0_log, const float* d_logsig, float* d_z_u, const int32_t* lens, int B, int T,
+                                   void* stream) {
+    XVA_CHECK_ARG(z_u && dr && d_z0_log && d_logsig && d_z_u && lens && B > 0 && T > 0, "sdp_dequant_bwd: bad args");
+    hipLaunchKernelGGL(sdp_dequant_bwd_kernel, dim3((unsigned)xva_cdiv((int64_t)B * T, 256)), dim3(256), 0, (hipStream_t)stream, z_u, dr, d_z0_log, d_logsig, d_z_u, lens,
+                       B, T);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}

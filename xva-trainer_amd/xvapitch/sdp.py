@@ -1,11 +1,12 @@
 """Building blocks of xVAPitch's stochastic duration predictor on libxvahip — python/xvapitch/sdp.py:
-DilatedDepthSeparableConv (:40-93), ElementwiseAffine (:95-114), ConvFlow with its rational-quadratic spline (:116-176, util.py:203-391).
+DilatedDepthSeparableConv (:40-93), ElementwiseAffine (:95-114), ConvFlow with its rational-quadratic spline (:116-176, util.py:203-391),
+StochasticDurationPredictor (:179-310, forward / training direction).
 
 Same constructor arguments and state_dict keys / layouts as the reference modules, same (B, C, T) tensors and (B, 1, T) mask at the interface.
 Every arithmetic step is a C call wrapped as ONE autograd primitive (depthwise dilated convolution, LayerNorm2, exact GELU, 1x1 convolution =
 xva_gemm, mask, add), so the blocks compose with torch autograd like the reference's; parameters are leaf tensors whose `.grad` autograd fills.
 Inside, tensors are fp32 time-major (B, T, C); splits / concatenations / flips of the 2-channel flow variable and the per-item sums of
-log-determinants are torch view / reduction glue.  Not built here: the predictor's likelihood assembly (StochasticDurationPredictor.forward).
+log-determinants are torch view / reduction glue.  StochasticDurationPredictor.forward (the training likelihood, :247-310) is assembled from these primitives; its reverse (sampling) direction is not built.
 """
 import ctypes as C
 
@@ -38,6 +39,14 @@ lib.xva_rq_spline_fwd.restype = i32
 lib.xva_rq_spline_fwd.argtypes = [vp, vp, vp, vp, i64, i32, f32, f32, vp]
 lib.xva_rq_spline_bwd.restype = i32
 lib.xva_rq_spline_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp]
+lib.xva_affine_fwd.restype = i32
+lib.xva_affine_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+lib.xva_affine_bwd.restype = i32
+lib.xva_affine_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+lib.xva_sdp_dequant_fwd.restype = i32
+lib.xva_sdp_dequant_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
+lib.xva_sdp_dequant_bwd.restype = i32
+lib.xva_sdp_dequant_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
 P = _lib.ptr
 ST = _lib.stream_ptr
 
@@ -287,3 +296,139 @@ class ConvFlow(_Module):
         lens = _lens_of(x, x_mask)
         y, logdet = self.forward_btc(x.float().transpose(1, 2).contiguous(), lens, g.float().transpose(1, 2).contiguous() if g is not None else None)
         return y.transpose(1, 2), logdet
+
+
+class Affine(torch.autograd.Function):
+    """ElementwiseAffine.forward (sdp.py:107-111) on (B, T, C): y, logdet (B)"""
+    @staticmethod
+    def forward(ctx, x, log_scale, translation, lens):
+        x = x.contiguous(); B, T, Cc = x.shape
+        ls, tr = log_scale.reshape(-1).contiguous(), translation.reshape(-1).contiguous()
+        y = torch.empty_like(x); ld = torch.empty(B, device=x.device)
+        _lib.check(lib.xva_affine_fwd(P(x), P(ls), P(tr), P(y), P(ld), P(lens), B, T, Cc, ST()), "xva_affine_fwd")
+        ctx.save_for_backward(x, ls, lens); ctx.shapes = (tuple(log_scale.shape), tuple(translation.shape))
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, dy, dld):
+        x, ls, lens = ctx.saved_tensors
+        B, T, Cc = x.shape
+        dx = torch.empty_like(x); dls = torch.zeros_like(ls); dtr = torch.zeros_like(ls)
+        _lib.check(lib.xva_affine_bwd(P(x), P(ls), P(dy.contiguous()), P(dld.contiguous()), P(dx), P(dls), P(dtr), P(lens), B, T, Cc, ST()), "xva_affine_bwd")
+        return dx, dls.view(ctx.shapes[0]), dtr.view(ctx.shapes[1]), None
+
+
+class Dequant(torch.autograd.Function):
+    """z_u, dr (B, T) -> log(max(dr - sigmoid(z_u), 1e-5)) * mask, (logsigmoid(z_u) + logsigmoid(-z_u)) * mask   (sdp.py:283-296)"""
+    @staticmethod
+    def forward(ctx, zu, dr, lens):
+        zu = zu.contiguous(); dr = dr.contiguous(); B, T = zu.shape
+        z0 = torch.empty_like(zu); ls = torch.empty_like(zu)
+        _lib.check(lib.xva_sdp_dequant_fwd(P(zu), P(dr), P(z0), P(ls), P(lens), B, T, ST()), "xva_sdp_dequant_fwd")
+        ctx.save_for_backward(zu, dr, lens)
+        return z0, ls
+
+    @staticmethod
+    def backward(ctx, dz0, dls):
+        zu, dr, lens = ctx.saved_tensors
+        B, T = zu.shape
+        d = torch.empty_like(zu)
+        _lib.check(lib.xva_sdp_dequant_bwd(P(zu), P(dr), P(dz0.contiguous()), P(dls.contiguous()), P(d), P(lens), B, T, ST()), "xva_sdp_dequant_bwd")
+        return d, None, None
+
+
+class ElementwiseAffine(_Module):
+    def __init__(self, channels, device="cuda"):
+        self.p = {"translation": _param(torch.zeros(channels, 1), device), "log_scale": _param(torch.zeros(channels, 1), device)}
+
+    def forward_btc(self, x, lens, g=None):
+        return Affine.apply(x, self.p["log_scale"], self.p["translation"], lens)
+
+
+class StochasticDurationPredictor(_Module):
+    """sdp.py:179-310, training direction: the negative log-likelihood (B,) of the durations dr under the flow, with variational dequantisation
+    (posterior flows conditioned on text + duration encodings).  `noise` (B, 2, T): the N(0, 1) draw of :281 (drawn with torch when None)."""
+
+    def __init__(self, in_channels, hidden_channels, kernel_size, dropout_p, num_flows=4, cond_channels=0, language_emb_dim=0, device="cuda", seed=0):
+        if dropout_p:
+            raise NotImplementedError("StochasticDurationPredictor: dropout_p > 0 is not built")
+        if language_emb_dim:
+            in_channels += language_emb_dim
+        if in_channels % 4 or hidden_channels % 4 or (cond_channels or 0) % 4 or (language_emb_dim or 0) % 4:
+            raise NotImplementedError("StochasticDurationPredictor: channel counts must be multiples of 4")
+        self.H = hidden_channels
+        self.device = torch.device(device)
+        gen = torch.Generator().manual_seed(seed)
+        u = lambda shape, fan: (torch.rand(*shape, generator=gen) * 2 - 1) * (1.0 / fan) ** 0.5
+        H = hidden_channels
+        self.p = {}
+
+        def conv(name, co, ci):
+            self.p[name + ".weight"] = _param(u((co, ci, 1), ci), self.device)
+            self.p[name + ".bias"] = _param(u((co,), ci), self.device)
+
+        def sub(name, m):
+            for k, v in m.p.items():
+                self.p[name + "." + k] = v
+            return m
+        conv("pre", H, in_channels)
+        self.convs = sub("convs", DilatedDepthSeparableConv(H, kernel_size, 3, device=device, seed=seed + 1))
+        conv("proj", H, H)
+        self.flows = [sub("flows.0", ElementwiseAffine(2, device))] + [sub("flows.%d" % (i + 1), ConvFlow(2, H, kernel_size, 3, device=device, seed=seed + 10 + i))
+                                                                       for i in range(num_flows)]
+        conv("post_pre", H, 1)
+        self.post_convs = sub("post_convs", DilatedDepthSeparableConv(H, kernel_size, 3, device=device, seed=seed + 2))
+        conv("post_proj", H, H)
+        self.post_flows = [sub("post_flows.0", ElementwiseAffine(2, device))] + [sub("post_flows.%d" % (i + 1), ConvFlow(2, H, kernel_size, 3, device=device,
+                                                                                                                      seed=seed + 20 + i)) for i in range(num_flows)]
+        self.has_cond = bool(cond_channels)
+        if self.has_cond:
+            conv("cond", H, cond_channels)
+        self.has_lang = bool(language_emb_dim)
+        if self.has_lang:
+            conv("cond_lang", H, language_emb_dim)
+
+    def __call__(self, x, x_mask, dr, g=None, lang_emb=None, noise=None):
+        """x (B, C, T), x_mask (B, 1, T), dr (B, 1, T), g (B, Cg, 1), lang_emb (B, Cl, 1 or T), noise (B, 2, T) -> nll (B,)"""
+        _lib.require_cuda(x, dr)
+        import math
+        p, H = self.p, self.H
+        lens = _lens_of(x, x_mask)
+        B, _, T = x.shape
+        tm = lambda t: t.float().transpose(1, 2).contiguous()
+        xs = Conv1x1.apply(tm(x), p["pre.weight"], p["pre.bias"])
+        if g is not None:
+            xs = Add.apply(xs, Conv1x1.apply(tm(g), p["cond.weight"], p["cond.bias"]).expand(B, T, H).contiguous())
+        if lang_emb is not None:
+            xs = Add.apply(xs, Conv1x1.apply(tm(lang_emb), p["cond_lang.weight"], p["cond_lang.bias"]).expand(B, T, H).contiguous())
+        xs = self.convs.forward_btc(xs, lens)
+        xs = Mask.apply(Conv1x1.apply(xs, p["proj.weight"], p["proj.bias"]), lens)
+        # condition encoder of the durations: Conv1d(1, H, 1) as a GEMM over a 4-wide zero-padded input
+        drs = tm(dr)
+        wpp = torch.cat([p["post_pre.weight"].reshape(H, 1), torch.zeros(H, 3, device=x.device)], 1).reshape(H, 4, 1)
+        h = Conv1x1.apply(torch.cat([drs, torch.zeros(B, T, 3, device=x.device)], -1), wpp, p["post_pre.bias"])
+        h = self.post_convs.forward_btc(h, lens)
+        h = Mask.apply(Conv1x1.apply(h, p["post_proj.weight"], p["post_proj.bias"]), lens)
+        if noise is None:
+            noise = torch.randn(B, 2, T, device=x.device)
+        nz = Mask.apply(tm(noise), lens)
+        cond_q = Add.apply(xs, h)
+        z_q, ld_q = nz, 0.0
+        for idx, flow in enumerate(self.post_flows):
+            z_q, ld = flow.forward_btc(z_q, lens, cond_q)
+            ld_q = ld_q + ld
+            if idx > 0:
+                z_q = torch.flip(z_q, [2])
+        z_u, z_v = z_q[..., 0], z_q[..., 1]
+        z0, lsig = Dequant.apply(z_u, drs[..., 0], lens)
+        ld_q = ld_q + lsig.sum(1)
+        nll_post = (-0.5 * (math.log(2 * math.pi) * 2 * lens.float() + (nz ** 2).sum((1, 2)))) - ld_q
+        ld_tot = -z0.sum(1)
+        z = torch.stack([z0, z_v], -1)
+        for idx, flow in enumerate(self.flows):
+            z, ld = flow.forward_btc(z, lens, xs)
+            ld_tot = ld_tot + ld
+            if idx > 0:
+                z = torch.flip(z, [2])
+        nll_flow = 0.5 * (math.log(2 * math.pi) * 2 * lens.float() + (z ** 2).sum((1, 2))) - ld_tot
+        return nll_flow + nll_post
