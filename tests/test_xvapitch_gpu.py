@@ -350,3 +350,35 @@ def test_stochastic_duration_predictor_against_reference_golden(golden_dir):
     worst = sorted(((_rel(m.p[k[9:]].grad, torch.from_numpy(g[k])), k[9:]) for k in g.files if k.startswith("sdp_grad/")), reverse=True)
     print("SDP worst gradients:", worst[:4], "of", len(worst))
     assert len(worst) == len(sd) and worst[0][0] < 1e-3, worst[:4]
+
+
+def test_residual_coupling_blocks_flow_and_its_inverse():
+    """The flow stack (model.py:1358-1422): four mean-only coupling blocks with channel flips, against the block-wise pinned oracle composed
+    the same way — output, d x, d g, parameter gradients — and reverse(forward(x)) = x on the unmasked positions (a flow is a bijection)."""
+    from oracle import xvapitch as oxv
+    from xva_trainer_amd.xvapitch.wn import ResidualCouplingBlocks
+    B, CH, H, T, K, L, CIN = 2, 16, 32, 33, 5, 2, 8
+    gen = torch.Generator().manual_seed(2)
+    fl = ResidualCouplingBlocks(CH, H, K, 1, L, num_flows=4, cond_channels=CIN, seed=11)
+    sd = {k: v.cpu() for k, v in fl.state_dict().items()}
+    lens = torch.tensor([33, 20])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1)
+    x = torch.randn(B, CH, T, generator=gen); g = torch.randn(B, CIN, 1, generator=gen); r = torch.randn(B, CH, T, generator=gen)
+    xo, go = x.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y = xo
+    for i in range(4):
+        sub = {k[len("flows.%d." % i):]: v for k, v in leaves.items() if k.startswith("flows.%d." % i)}
+        y = torch.flip(oxv.coupling(sub, y, x_mask, g=go, hidden=H, kernel_size=K, dilation_rate=1, num_layers=L), [1])
+    (y * r).sum().backward()
+    fl.zero_grad()
+    xg, gg = x.cuda().requires_grad_(True), g.cuda().requires_grad_(True)
+    out = fl(xg, x_mask.cuda(), g=gg)
+    (out * r.cuda()).sum().backward()
+    assert _rel(out, y.detach()) < 1e-3 and _rel(xg.grad, xo.grad) < 1e-3 and _rel(gg.grad, go.grad) < 1e-3
+    for k, gr in fl.grads().items():
+        if leaves[k].grad is not None and float(leaves[k].grad.abs().max()) > 0:
+            assert _rel(gr, leaves[k].grad) < 2e-3, k
+    with torch.no_grad():
+        back = fl(out.detach(), x_mask.cuda(), g=gg.detach(), reverse=True)
+    assert _rel(back * x_mask.cuda(), x * x_mask) < 1e-4

@@ -341,6 +341,40 @@ class ResidualCouplingBlock:
         return out, torch.zeros(x.size(0), device=x.device, dtype=x.dtype)          # logdet = sum(log_scale) = 0 for mean_only
 
 
+class ResidualCouplingBlocks:
+    """The flow of xVAPitch (model.py:1358-1422, expanded_flow off): num_flows mean-only coupling blocks, the channel halves flipped after each
+    (forward) / before each, last block first (reverse).  state_dict keys `flows.i.*`."""
+
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, num_layers, num_flows=4, cond_channels=0, device="cuda", compute="fp32", seed=0):
+        self.flows = [ResidualCouplingBlock(channels, hidden_channels, kernel_size, dilation_rate, num_layers, cond_channels=cond_channels, mean_only=True,
+                                            device=device, compute=compute, seed=seed + 7 * i) for i in range(num_flows)]
+
+    def state_dict(self):
+        return {"flows.%d.%s" % (i, k): v for i, f in enumerate(self.flows) for k, v in f.state_dict().items()}
+
+    def load_state_dict(self, sd):
+        for i, f in enumerate(self.flows):
+            pre = "flows.%d." % i
+            f.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+
+    def grads(self):
+        return {"flows.%d.%s" % (i, k): v for i, f in enumerate(self.flows) for k, v in f.grads().items()}
+
+    def zero_grad(self):
+        for f in self.flows:
+            f.zero_grad()
+
+    def __call__(self, x, x_mask, g=None, reverse=False):
+        if not reverse:
+            for f in self.flows:
+                x, _ = f(x, x_mask, g=g)
+                x = torch.flip(x, [1])
+        else:
+            for f in reversed(self.flows):
+                x = f(torch.flip(x, [1]), x_mask, g=g, reverse=True)
+        return x
+
+
 class _CouplingFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, blk, lens, reverse):
