@@ -237,3 +237,50 @@ def sdp_forward(sd, x, x_mask, dr, noise, hidden, kernel_size=3, num_flows=4, g=
         ld_tot = ld_tot + ld
     nll_flow = (0.5 * (math.log(2 * math.pi) + z ** 2) * x_mask).sum((1, 2)) - ld_tot
     return nll_flow + nll_post
+
+
+def acoustic_losses(sd, tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps, noise, cfg):
+    """xVAPitch.train_step (python/xvapitch/model.py:681-870) followed by the KL and duration terms of VitsGeneratorLoss.forward
+    (losses.py:213-220), on the reference's default switches (--pitch / --energy / --flc / --ow_flow / --mltts_rc 0, detach_dp_input True,
+    lang_w 1; dropout off) and WITHOUT the waveform decoder / discriminator branch (:852-853 — that branch is the HiFi-GAN path).
+    sd: state_dict with the reference's keys (emb_l.*, text_encoder.*, posterior_encoder.*, flow.flows.i.*, duration_predictor.*).
+    cfg: latent, lang_dim, heads, te_layers, pe_layers, flow_layers, num_flows.  Returns a dict of the intermediate tensors and losses."""
+    import math
+    Cc = cfg["latent"]
+
+    def sub(pre):
+        return {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    B, Tt = tokens.shape
+    g = F.normalize(d_vectors).unsqueeze(-1)                                                              # _set_cond_input :918
+    lang_emb = sd["emb_l.weight"][language_ids].unsqueeze(-1)                                              # :695-696 (lang_w = 1)
+    z, m_q, logs_q, y_mask = posterior_encoder(sub("posterior_encoder."), y, y_lengths, g, eps, Cc, hidden=Cc, kernel_size=5, dilation_rate=1,
+                                               num_layers=cfg["pe_layers"])                                # :698
+    te = sub("text_encoder.")
+    x_emb = te["emb.weight"][tokens] * math.sqrt(Cc)                                                       # TextEncoder.forward :1152
+    x = torch.cat([x_emb, lang_emb.transpose(2, 1).expand(B, Tt, -1)], -1).transpose(1, 2)                 # :1158-1163
+    x_mask = (torch.arange(Tt)[None, :] < x_lengths[:, None]).to(x.dtype).unsqueeze(1)
+    x = rel_transformer(sub("text_encoder.encoder."), x * x_mask, x_mask, cfg["heads"], cfg["te_layers"], 3, 4)
+    stats = F.conv1d(x, te["proj.weight"], te["proj.bias"]) * x_mask                                       # stats=True branch :1148-1150
+    m_p, logs_p = torch.split(stats, Cc, dim=1)
+    lang_emb = lang_emb.detach()                                                                           # :722
+    z_p = z
+    for i in range(cfg["num_flows"]):                                                                      # ResidualCouplingBlocks.forward :1406-1420
+        z_p = torch.flip(coupling(sub("flow.flows.%d." % i), z_p, y_mask, g, hidden=Cc, kernel_size=5, dilation_rate=1, num_layers=cfg["flow_layers"]), [1])
+    attn_mask = x_mask.detach().unsqueeze(-1) * y_mask.unsqueeze(2)                                        # :763
+    with torch.no_grad():                                                                                  # :765-776
+        o_scale = torch.exp(-2 * logs_p)
+        logp1 = torch.sum(-0.5 * math.log(2 * math.pi) - logs_p, [1]).unsqueeze(-1)
+        logp2 = torch.einsum("klm, kln -> kmn", [o_scale, -0.5 * (z_p ** 2)])
+        logp3 = torch.einsum("klm, kln -> kmn", [m_p * o_scale, z_p])
+        logp4 = torch.sum(-0.5 * (m_p ** 2) * o_scale, [1]).unsqueeze(-1)
+        logp = logp2 + logp3 + logp1 + logp4
+        attn = torch.from_numpy(maximum_path(logp.numpy(), attn_mask.squeeze(1).numpy())).to(logp.dtype).unsqueeze(1)
+    attn_durations = attn.sum(3)                                                                           # :792
+    nll = sdp_forward(sub("duration_predictor."), x.detach(), x_mask, attn_durations, noise, Cc, 3, 4, g=g.detach(), lang_emb=lang_emb)   # :795-803
+    loss_duration = nll / torch.sum(x_mask)                                                                # :814
+    m_p_e = torch.einsum("klmn, kjm -> kjn", [attn, m_p])                                                  # :846-847
+    logs_p_e = torch.einsum("klmn, kjm -> kjn", [attn, logs_p])
+    loss_kl, _ = kl_loss(z_p, logs_q, m_p_e, logs_p_e, y_mask)                                             # losses.py:213
+    loss_dur = torch.sum(loss_duration.float())                                                            # losses.py:220
+    return {"z": z, "m_q": m_q, "logs_q": logs_q, "x": x, "m_p": m_p_e, "logs_p": logs_p_e, "z_p": z_p, "attn": attn.squeeze(1), "logp": logp,
+            "loss_kl": loss_kl, "loss_duration": loss_dur, "loss": loss_kl + loss_dur}

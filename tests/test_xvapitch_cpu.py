@@ -169,3 +169,32 @@ def test_sdp_oracle_matches_reference_golden():
         if k.startswith("sdp_grad/"):
             r = torch.from_numpy(g[k])
             assert float((sd[k[9:]].grad - r).norm() / r.norm().clamp_min(1e-12)) < 2e-4, k
+
+
+def test_acoustic_losses_oracle_matches_reference_train_step_golden():
+    """oracle/xvapitch.py:acoustic_losses vs the vectors recorded from the reference's own xVAPitch.train_step (model.py:681-870; the generator
+    oracle/gen_golden_xvapitch_acoustic.py compiled the method from its source lines in memory and ran it): outputs, MAS path, both losses and all
+    429 parameter gradients."""
+    from oracle import xvapitch as oxv
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xvapitch_acoustic.npz"))
+    cfg = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    t = lambda k: torch.from_numpy(g[k])
+    o = oxv.acoustic_losses(leaves, t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("dvec"), t("lids"), t("eps"), t("noise"), cfg)
+    for k in ("z", "z_p", "m_p", "logs_p", "m_q", "logs_q"):
+        assert torch.allclose(o[k].detach(), t("out/" + k), rtol=1e-4, atol=1e-5), k
+    assert np.array_equal(o["attn"].numpy().astype(np.uint8), g["attn"])
+    assert abs(float(o["loss_kl"].detach()) - float(g["loss_kl"])) < 1e-3 and abs(float(o["loss_duration"].detach()) - float(g["loss_duration"])) < 1e-3
+    o["loss"].backward()
+    n = 0
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref = t(k)
+            got = leaves[k[5:]].grad if leaves[k[5:]].grad is not None else torch.zeros_like(ref)
+            if float(ref.norm()) < 1e-5 * ref.numel() ** 0.5:                      # mathematically zero (conv_k.bias)
+                assert float(got.norm()) < 1e-4, k
+                continue
+            assert float((got - ref).norm() / ref.norm()) < 2e-4, k
+            n += 1
+    assert n > 400

@@ -382,3 +382,40 @@ def test_residual_coupling_blocks_flow_and_its_inverse():
     with torch.no_grad():
         back = fl(out.detach(), x_mask.cuda(), g=gg.detach(), reverse=True)
     assert _rel(back * x_mask.cuda(), x * x_mask) < 1e-4
+
+
+def test_acoustic_train_path_against_reference_train_step_golden(golden_dir):
+    """xvapitch/acoustic.py:AcousticTrainPath — embeddings, TextEncoder, PosteriorEncoder (41 spectrogram bins: a channel count that is no multiple
+    of 4, like the model's 513), flow, MAS, StochasticDurationPredictor, prior expansion, KL + duration losses — against the vectors recorded from
+    the REFERENCE's own xVAPitch.train_step (model.py:681-870) with the same two N(0, 1) draws: outputs and losses at 1e-3, the MAS path bit-exact,
+    all 429 parameter gradients at 2e-3 (relative L2)."""
+    from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
+    g = np.load(os.path.join(golden_dir, "xvapitch_acoustic.npz"))
+    c = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    m = AcousticTrainPath(c["vocab"], c["langs"], latent_size=c["latent"], embedded_language_dim=c["lang_dim"], d_vector_dim=c["dvec"],
+                          hidden_channels_ffn=c["ffn"], num_heads=c["heads"], text_layers=c["te_layers"], posterior_layers=c["pe_layers"],
+                          flow_layers=c["flow_layers"], num_flows=c["num_flows"], spec_bins=c["spec_bins"])
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    grads_ref = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad/")}
+    assert set(m.state_dict()) == set(grads_ref), sorted(set(m.state_dict()) ^ set(grads_ref))[:8]
+    m.load_state_dict(sd)
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    m.zero_grad()
+    o = m(t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("dvec"), t("lids"), eps=t("eps"), noise=t("noise"))
+    for k in ("z", "z_p", "m_q", "logs_q", "m_p", "logs_p"):
+        assert _rel(o[k], torch.from_numpy(g["out/" + k])) < 1e-3, (k, _rel(o[k], torch.from_numpy(g["out/" + k])))
+    assert np.array_equal(o["attn"].cpu().numpy().astype(np.uint8), g["attn"])
+    assert abs(float(o["loss_kl"]) - float(g["loss_kl"])) < 1e-3 * abs(float(g["loss_kl"])), (float(o["loss_kl"]), float(g["loss_kl"]))
+    assert abs(float(o["loss_duration"]) - float(g["loss_duration"])) < 1e-3 * abs(float(g["loss_duration"]))
+    o["loss"].backward()
+    torch.cuda.synchronize()
+    mine = m.grads()
+    worst = []
+    for k, ref in grads_ref.items():
+        if float(ref.norm()) < 1e-5 * ref.numel() ** 0.5:                          # mathematically zero (conv_k.bias): rounding noise on both sides
+            assert float(mine[k].norm()) < 1e-3, k
+            continue
+        worst.append((_rel(mine[k].reshape(ref.shape), ref), k))
+    worst.sort(reverse=True)
+    print("acoustic path worst gradients:", worst[:5], "of", len(worst))
+    assert len(worst) > 400 and worst[0][0] < 2e-3, worst[:5]

@@ -1,0 +1,167 @@
+"""The acoustic half of xVAPitch's generator step on libxvahip — `xVAPitch.train_step` (python/xvapitch/model.py:681-870) up to, and without,
+the waveform decoder, followed by the KL and duration terms of VitsGeneratorLoss.forward (python/xvapitch/losses.py:213-220):
+
+    language / symbol embeddings -> TextEncoder (RelativePositionTransformer + `proj` statistics, model.py:1140-1170)
+    linear spectrogram -> PosteriorEncoder -> z ; ResidualCouplingBlocks: z -> z_p
+    monotonic alignment search over the prior log-likelihoods (:763-776) -> durations -> StochasticDurationPredictor NLL (:792-814)
+    prior expansion along the path (:846-847) ; kl_loss(z_p, logs_q, m_p, logs_p)
+
+Built for the reference's default switches (xva_train.py:1098-1120: --pitch / --energy / --flc / --ow_flow / --mltts_rc 0; detach_dp_input True,
+model.py:52; lang_w 1) and with dropout off (the text encoder's 0.1 and the duration predictor's 0.5 are not built — wn.py / sdp.py raise on
+dropout_p > 0).  The waveform decoder + discriminator branch (:852-853) is the HiFi-GAN path (xva-trainer_amd/hifigan); its speaker-conditioned
+generator variant is not built, so this class returns z / slice inputs and the two acoustic losses, not the full generator loss.
+
+state_dict keys are the reference's (`emb_l.weight`, `text_encoder.*`, `posterior_encoder.*`, `flow.flows.i.*`, `duration_predictor.*`).
+Every matrix product, convolution, normalisation, spline, MAS and KL step is a libxvahip call (through the block classes of wn.py /
+transformer.py / sdp.py / ops.py, plus the two batched GEMM forms below); torch supplies the embedding gathers, the speaker-vector
+normalisation, concatenations / transposes and the elementwise preparation of the MAS operands."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+from . import ops
+from .sdp import Conv1x1, Mask, StochasticDurationPredictor, _param
+from .transformer import RelativePositionTransformer
+from .wn import PosteriorEncoder, ResidualCouplingBlocks
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def prior_logp(stats, z_p, Cc):
+    """The four log-likelihood terms of model.py:765-771 as ONE batched xva_gemm: with s = exp(-2 logs_p),
+    logp[b, i, j] = [s | m s](b, i, :) . [-z^2 / 2 | z](b, j, :) + sum_c(-log(2 pi) / 2 - logs_p - m^2 s / 2)(b, i).
+    stats (B, Tt, 2C) = [m_p | logs_p] time-major, z_p (B, C, Ty).  Returns (B, Tt, Ty)."""
+    B, Tt, _ = stats.shape
+    Ty = z_p.size(2)
+    Typ = _pad4(Ty)
+    m_p, logs_p = stats[..., :Cc], stats[..., Cc:]
+    s = torch.exp(-2.0 * logs_p)
+    A = torch.cat([s, m_p * s], -1).contiguous()
+    zt = z_p.transpose(1, 2)
+    Bm = torch.zeros(B, Typ, 2 * Cc, device=stats.device)
+    Bm[:, :Ty, :Cc] = -0.5 * zt * zt
+    Bm[:, :Ty, Cc:] = zt
+    row = (-0.5 * math.log(2 * math.pi) - logs_p - 0.5 * m_p * m_p * s).sum(-1)
+    logp = torch.empty(B, Tt, Typ, device=stats.device)
+    _lib.gemm(A, Bm, logp, Tt, Typ, 2 * Cc, 2 * Cc, 2 * Cc, Typ, layout=_lib.GEMM_NT, compute=0, batch=B, sA=Tt * 2 * Cc, sB=Typ * 2 * Cc, sC=Tt * Typ)
+    return logp[..., :Ty] + row.unsqueeze(-1)
+
+
+class _Expand(torch.autograd.Function):
+    """model.py:846-847, both einsums at once: out[b, j, :] = sum_i attn[b, i, j] stats[b, i, :] (the path is constant).  attn (B, Tt, Typ) with
+    zero columns past Ty; stats (B, Tt, 2C); out (B, Typ, 2C)."""
+    @staticmethod
+    def forward(ctx, stats, attn):
+        B, Tt, W = stats.shape
+        Typ = attn.size(2)
+        stats = stats.contiguous()
+        out = torch.empty(B, Typ, W, device=stats.device)
+        _lib.gemm(attn, stats, out, Typ, W, Tt, Typ, W, W, layout=_lib.GEMM_TN, compute=0, batch=B, sA=Tt * Typ, sB=Tt * W, sC=Typ * W)
+        ctx.save_for_backward(attn)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (attn,) = ctx.saved_tensors
+        B, Tt, Typ = attn.shape
+        d_out = d_out.contiguous()
+        W = d_out.size(2)
+        d_stats = torch.empty(B, Tt, W, device=d_out.device)
+        _lib.gemm(attn, d_out, d_stats, Tt, W, Typ, Typ, W, W, layout=_lib.GEMM_NN, compute=0, batch=B, sA=Tt * Typ, sB=Typ * W, sC=Tt * W)
+        return d_stats, None
+
+
+class AcousticTrainPath:
+    """Constructor arguments follow model.py:55-135 (defaults = the reference's non-`big` model)."""
+
+    def __init__(self, n_vocab, num_languages, latent_size=192, embedded_language_dim=4, d_vector_dim=512, hidden_channels_ffn=768, num_heads=2,
+                 text_layers=10, posterior_layers=16, flow_layers=4, num_flows=4, spec_bins=513, device="cuda", compute="fp32", seed=0):
+        Cc, L = latent_size, embedded_language_dim
+        self.C, self.L = Cc, L
+        self.device = torch.device(device)
+        gen = torch.Generator().manual_seed(seed)
+        self.p = {"emb_l.weight": _param(torch.randn(num_languages, L, generator=gen), self.device),
+                  "text_encoder.emb.weight": _param(torch.randn(n_vocab, Cc, generator=gen) * Cc ** -0.5, self.device),                 # model.py:1120
+                  "text_encoder.proj.weight": _param((torch.rand(2 * Cc, Cc + L, 1, generator=gen) * 2 - 1) * (Cc + L) ** -0.5, self.device),
+                  "text_encoder.proj.bias": _param((torch.rand(2 * Cc, generator=gen) * 2 - 1) * (Cc + L) ** -0.5, self.device)}
+        self.encoder = RelativePositionTransformer(Cc + L, Cc + L, Cc + L, hidden_channels_ffn, num_heads, text_layers, kernel_size=3, dropout_p=0.0,
+                                                   layer_norm_type="2", rel_attn_window_size=4, device=device, seed=seed + 1)
+        self.posterior_encoder = PosteriorEncoder(spec_bins, Cc, Cc, 5, 1, posterior_layers, cond_channels=d_vector_dim, device=device, compute=compute,
+                                                  seed=seed + 2)
+        self.flow = ResidualCouplingBlocks(Cc, Cc, 5, 1, flow_layers, num_flows=num_flows, cond_channels=d_vector_dim, device=device, compute=compute,
+                                           seed=seed + 3)
+        self.duration_predictor = StochasticDurationPredictor(Cc, Cc, 3, 0.0, 4, cond_channels=d_vector_dim, language_emb_dim=L, device=device, seed=seed + 4)
+        self._subs = (("text_encoder.encoder.", self.encoder), ("posterior_encoder.", self.posterior_encoder), ("flow.", self.flow),
+                      ("duration_predictor.", self.duration_predictor))
+
+    # ---- reference state_dict ----
+    def state_dict(self):
+        sd = {k: v.detach().clone() for k, v in self.p.items()}
+        for pre, m in self._subs:
+            sd.update({pre + k: v for k, v in m.state_dict().items()})
+        return sd
+
+    def load_state_dict(self, sd):
+        """Reference keys; buffers the reference registers beside the parameters (none are read by this path) are ignored."""
+        with torch.no_grad():
+            for k, t in self.p.items():
+                t.copy_(sd[k].to(device=self.device, dtype=torch.float32))
+        for pre, m in self._subs:
+            own = set(m.state_dict())
+            m.load_state_dict({k[len(pre):]: v.to(self.device) for k, v in sd.items() if k.startswith(pre) and k[len(pre):] in own})
+
+    def grads(self):
+        g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in self.p.items()}
+        for pre, m in self._subs:
+            if hasattr(m, "grads"):
+                g.update({pre + k: v for k, v in m.grads().items()})
+            else:
+                g.update({pre + k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in m.p.items()})
+        return g
+
+    def zero_grad(self):
+        for v in self.p.values():
+            v.grad = None
+        for _, m in self._subs:
+            if hasattr(m, "zero_grad"):
+                m.zero_grad()
+            else:
+                for v in m.p.values():
+                    v.grad = None
+
+    # ---- model.py:681-870 ----
+    def __call__(self, tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps=None, noise=None):
+        """tokens (B, Tt) int64, y (B, spec_bins, Ty) linear spectrogram, d_vectors (B, d_vector_dim), language_ids (B,).  eps (B, C, Ty) / noise
+        (B, 2, Tt): the N(0, 1) draws of the posterior encoder (model.py:1472) and the duration predictor (sdp.py:281), drawn here when None.
+        Returns the tensors train_step hands to the loss plus `attn`, `loss_kl`, `loss_duration`, `loss` (their sum)."""
+        _lib.require_cuda(y, d_vectors)
+        p, Cc, L = self.p, self.C, self.L
+        B, Tt = tokens.shape
+        Ty = y.size(2)
+        g = F.normalize(d_vectors.float()).unsqueeze(-1)                                                  # _set_cond_input, model.py:918
+        lang = F.embedding(language_ids, p["emb_l.weight"])                                               # (B, L) :695-696
+        z, m_q, logs_q, y_mask = self.posterior_encoder(y, y_lengths, g=g, eps=eps)                        # :698
+        x_emb = F.embedding(tokens, p["text_encoder.emb.weight"]) * math.sqrt(Cc)                          # :1152
+        x_in = torch.cat([x_emb, lang.unsqueeze(1).expand(B, Tt, L)], -1).transpose(1, 2)                  # :1158-1163
+        x_lens = x_lengths.to(device=y.device, dtype=torch.int32).contiguous()
+        x_mask = (torch.arange(Tt, device=y.device)[None, :] < x_lens[:, None]).float().unsqueeze(1)
+        x = self.encoder(x_in * x_mask, x_mask)                                                            # (B, C + L, Tt) :1166
+        stats = Mask.apply(Conv1x1.apply(x.transpose(1, 2).contiguous(), p["text_encoder.proj.weight"], p["text_encoder.proj.bias"]), x_lens)   # :1148
+        z_p = self.flow(z, y_mask, g=g)                                                                    # :723
+        with torch.no_grad():                                                                              # :763-776
+            logp = prior_logp(stats.detach(), z_p.detach(), Cc)
+            attn_mask = x_mask.squeeze(1).unsqueeze(-1) * y_mask.squeeze(1).unsqueeze(1)
+            attn = ops.maximum_path(logp, attn_mask)
+            attn_pad = F.pad(attn, (0, _pad4(Ty) - Ty)).contiguous()
+        dr = attn.sum(2).unsqueeze(1)                                                                      # :792
+        nll = self.duration_predictor(x.detach(), x_mask, dr, g=g, lang_emb=lang.detach().unsqueeze(-1), noise=noise)     # :795-803, :722
+        loss_duration = (nll / x_mask.sum()).sum()                                                         # :814, losses.py:220
+        ex = _Expand.apply(stats, attn_pad)[:, :Ty].transpose(1, 2)                                        # (B, 2C, Ty) :846-847
+        m_p, logs_p = ex[:, :Cc].contiguous(), ex[:, Cc:].contiguous()
+        loss_kl, _ = ops.kl_loss(z_p, logs_q, m_p, logs_p, y_mask)                                          # losses.py:213
+        return {"z": z, "m_q": m_q, "logs_q": logs_q, "x": x, "x_mask": x_mask, "y_mask": y_mask, "z_p": z_p, "m_p": m_p, "logs_p": logs_p, "attn": attn,
+                "loss_kl": loss_kl, "loss_duration": loss_duration, "loss": loss_kl + loss_duration}

@@ -17,7 +17,7 @@ import torch
 
 from .. import _lib
 from . import ops
-from .wn import PAD, Seq, conv_bwd_data, conv_bwd_weight, conv_fwd, _lens_of
+from .wn import PAD, Seq, conv_bwd_data, conv_bwd_weight, conv_fwd, _grad_hook, _lens_of
 
 lib = _lib.lib
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -135,7 +135,7 @@ class RelativePositionTransformer:
                 t.zero_()
 
     def __call__(self, x, x_mask):
-        return _TransformerFn.apply(x, self, _lens_of(x, x_mask))
+        return _TransformerFn.apply(x, self, _lens_of(x, x_mask), _grad_hook(x.device))
 
     # ---- sequences ----
     def _proj_padded(self):
@@ -291,7 +291,7 @@ class RelativePositionTransformer:
 
 class _TransformerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, tr, lens):
+    def forward(ctx, x, tr, lens, hook=None):
         _lib.require_cuda(x)
         B, Cc, T = x.shape
         xs = Seq(B, T, Cc, tr.device, torch.float32)
@@ -309,4 +309,4 @@ class _TransformerFn(torch.autograd.Function):
         _lib.check(ops.lib.xva_bct_to_seq(_lib.ptr(d_out.float().contiguous()), C.c_void_p(ds.view.data_ptr()), 0, B, tr.Co, T, PAD, None, _lib.stream_ptr()),
                    "xva_bct_to_seq")
         d_x = tr.backward_seq(ds)
-        return ops.seq_to_bct(d_x.view, T, PAD), None, None
+        return ops.seq_to_bct(d_x.view, T, PAD), None, None, None

@@ -247,7 +247,13 @@ class WN:
 
     # ---- reference interface: x (B, H, T), x_mask (B, 1, T) from lengths, g (B, c_in, 1) ----
     def __call__(self, x, x_mask=None, g=None):
-        return _WNFn.apply(x, g, self, _lens_of(x, x_mask))
+        return _WNFn.apply(x, g, self, _lens_of(x, x_mask), _grad_hook(x.device))
+
+
+def _grad_hook(device):
+    """A requires-grad scalar handed to every block-level autograd.Function: their backward accumulates the PARAMETER gradients into the block's
+    own buffers, so it has to run even when no tensor input requires grad (the posterior encoder's inputs are data)."""
+    return torch.zeros(1, device=device, requires_grad=True)
 
 
 def _lens_of(x, x_mask):
@@ -258,7 +264,7 @@ def _lens_of(x, x_mask):
 
 class _WNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g, wn, lens):
+    def forward(ctx, x, g, wn, lens, hook=None):
         _lib.require_cuda(x)
         B, H, T = x.shape
         xs = Seq(B, T, H, wn.device, wn.dtype)
@@ -276,7 +282,7 @@ class _WNFn(torch.autograd.Function):
         _lib.check(ops.lib.xva_bct_to_seq(_lib.ptr(d_out.float().contiguous()), C.c_void_p(ds.view.data_ptr()), ds.dt, B, H, T, PAD, None, _lib.stream_ptr()),
                    "xva_bct_to_seq")
         d_x, d_g = wn.backward_seq(ds)
-        return ops.seq_to_bct(d_x.view, T, PAD), (d_g.reshape(B, -1, 1) if ctx.has_g else None), None, None
+        return ops.seq_to_bct(d_x.view, T, PAD), (d_g.reshape(B, -1, 1) if ctx.has_g else None), None, None, None
 
 
 class _PlainConv1x1:
@@ -335,7 +341,7 @@ class ResidualCouplingBlock:
                 t.zero_()
 
     def __call__(self, x, x_mask, g=None, reverse=False):
-        out = _CouplingFn.apply(x, g, self, _lens_of(x, x_mask), bool(reverse))
+        out = _CouplingFn.apply(x, g, self, _lens_of(x, x_mask), bool(reverse), _grad_hook(x.device))
         if reverse:
             return out
         return out, torch.zeros(x.size(0), device=x.device, dtype=x.dtype)          # logdet = sum(log_scale) = 0 for mean_only
@@ -377,7 +383,7 @@ class ResidualCouplingBlocks:
 
 class _CouplingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g, blk, lens, reverse):
+    def forward(ctx, x, g, blk, lens, reverse, hook=None):
         _lib.require_cuda(x)
         B, Cc, T = x.shape
         half, hid, wn = blk.half, blk.hidden, blk.enc
@@ -419,7 +425,7 @@ class _CouplingFn(torch.autograd.Function):
         d_x0s = Seq(B, T, half, wn.device, wn.dtype)
         conv_bwd_data(d_h, blk.pre.eff(), d_x0s, 1, 1, wn.compute, accumulate=False)
         d_x0 = ops.seq_to_bct(d_x0s.view, T, PAD, into=d_out[:, :half].float().contiguous())
-        return torch.cat([d_x0, d_x1], 1), (d_g.reshape(B, -1, 1) if ctx.has_g else None), None, None, None
+        return torch.cat([d_x0, d_x1], 1), (d_g.reshape(B, -1, 1) if ctx.has_g else None), None, None, None, None
 
 
 class PosteriorEncoder:
@@ -429,27 +435,32 @@ class PosteriorEncoder:
 
     def __init__(self, in_channels, out_channels, hidden_channels, kernel_size, dilation_rate, num_layers, cond_channels=0, device="cuda", compute="fp32", seed=0):
         self.Cin, self.Co, self.hidden = in_channels, out_channels, hidden_channels
+        # the GEMM operands want rows of a multiple of 4 elements: the 513 spectrogram bins are carried as 516 channels, the 3 extra input
+        # channels and weight columns zero (they stay zero: their gradient is dy^T times a zero column)
+        self.Cp = (in_channels + 3) // 4 * 4
         self.device = torch.device(device)
         gen = torch.Generator().manual_seed(seed)
         self.enc = WN(hidden_channels, hidden_channels, kernel_size, dilation_rate, num_layers, c_in_channels=cond_channels, device=device, compute=compute,
                       seed=seed + 1)
-        self.pre = _PlainConv1x1(in_channels, hidden_channels, self.device, self.enc.dtype, gen)
+        self.pre = _PlainConv1x1(self.Cp, hidden_channels, self.device, self.enc.dtype, gen)
+        self.pre.p["weight"][:, in_channels:] = 0
         self.proj = _PlainConv1x1(hidden_channels, 2 * out_channels, self.device, self.enc.dtype, gen)
 
     def state_dict(self):
-        sd = {"pre." + n: t.clone() for n, t in self.pre.p.items()}
+        sd = {"pre.weight": self.pre.p["weight"][:, :self.Cin].clone(), "pre.bias": self.pre.p["bias"].clone()}
         sd.update({"enc." + k: v for k, v in self.enc.state_dict().items()})
         sd.update({"proj." + n: t.clone() for n, t in self.proj.p.items()})
         return sd
 
     def load_state_dict(self, sd):
-        for n in self.pre.p:
-            self.pre.p[n].copy_(sd["pre." + n])
+        self.pre.p["weight"][:, :self.Cin].copy_(sd["pre.weight"])
+        self.pre.p["bias"].copy_(sd["pre.bias"])
+        for n in self.proj.p:
             self.proj.p[n].copy_(sd["proj." + n])
         self.enc.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("enc.")})
 
     def grads(self):
-        g = {"pre." + n: t for n, t in self.pre.g.items()}
+        g = {"pre.weight": self.pre.g["weight"][:, :self.Cin], "pre.bias": self.pre.g["bias"]}
         g.update({"enc." + k: v for k, v in self.enc.grads().items()})
         g.update({"proj." + n: t for n, t in self.proj.g.items()})
         return g
@@ -465,14 +476,16 @@ class PosteriorEncoder:
         lens = x_lengths.reshape(B).to(device=x.device, dtype=torch.int32).contiguous()
         if eps is None:
             eps = torch.randn(B, self.Co, T, device=x.device)
-        z, mean, logs = _PosteriorFn.apply(x, g, eps, self, lens)
+        if self.Cp != self.Cin:
+            x = torch.nn.functional.pad(x, (0, 0, 0, self.Cp - self.Cin))
+        z, mean, logs = _PosteriorFn.apply(x, g, eps, self, lens, _grad_hook(x.device))
         x_mask = (torch.arange(T, device=x.device)[None, :] < lens[:, None]).to(x.dtype).unsqueeze(1)     # sequence_mask(x_lengths) as returned by the reference
         return z, mean, logs, x_mask
 
 
 class _PosteriorFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g, eps, enc, lens):
+    def forward(ctx, x, g, eps, enc, lens, hook=None):
         _lib.require_cuda(x, eps)
         B, Cin, T = x.shape
         wn, Co, hid = enc.enc, enc.Co, enc.hidden
@@ -513,4 +526,4 @@ class _PosteriorFn(torch.autograd.Function):
         conv_bwd_weight(d_h, xs, enc.pre.g["weight"].view(hid, Cin), enc.pre.g["bias"], 1, 1, wn.compute)
         d_xs = Seq(B, T, Cin, wn.device, wn.dtype)
         conv_bwd_data(d_h, enc.pre.eff(), d_xs, 1, 1, wn.compute, accumulate=False)
-        return ops.seq_to_bct(d_xs.view, T, PAD), (d_g.reshape(B, -1, 1) if ctx.has_g else None), None, None, None
+        return ops.seq_to_bct(d_xs.view, T, PAD), (d_g.reshape(B, -1, 1) if ctx.has_g else None), None, None, None, None
