@@ -11,8 +11,13 @@ StochasticDurationPredictor at a reduced width, nn.Embedding for the language, t
 (--pitch / --energy / --flc / --ow_flow / --mltts_rc 0; detach_dp_input True, model.py:52; dropout 0), and a waveform decoder stand-in
 that returns zeros (the decoder / discriminator branch is the HiFi-GAN path and takes no part in the losses recorded here).
 
-The script asserts oracle/xvapitch.py:acoustic_losses equal to that run (outputs, losses and every parameter gradient), then writes
-tests/golden/xvapitch_acoustic.npz: state_dict, batch, the two N(0, 1) draws, outputs, losses, gradients.  Data only."""
+Two runs of train_step on the same weights and batch: the argparse defaults (--pitch 0), and --pitch 1 with pe_scaling 0.1 — what the shipped
+trainer sets (xva_train.py:1421-1425): pitch_emb subtracted from z_p, average_pitch targets, the pitch predictor and the pitch loss term
+(losses.py:224-241, restated here on the reference's outputs because VitsGeneratorLoss needs the discriminator branch).
+
+The script asserts oracle/xvapitch.py:acoustic_losses equal to each run (outputs, losses and every parameter gradient), then writes
+tests/golden/xvapitch_acoustic.npz: state_dict, batch, the two N(0, 1) draws, outputs, losses; gradients in full for the first run, for the
+second run the pitch tensors in full and every tensor by norm + 256 evenly spaced samples (oracle/golden_util.py).  Data only."""
 import importlib
 import math
 import os
@@ -48,7 +53,8 @@ def load_reference():
 
     def cut(a, b):
         return src[src.index(a):src.index(b)]
-    exec(compile(cut("class TextEncoder(nn.Module):", "class RelativePositioningPitchEnergyEncoder(nn.Module):"), "model.py:TextEncoder", "exec"), ns)
+    exec(compile(cut("class TextEncoder(nn.Module):", "class ResidualCouplingBlocks(nn.Module):"), "model.py:TextEncoder+pitch encoder", "exec"), ns)
+    exec(compile(cut("def average_pitch(pitch, durs):", "class GradientReversalFunction(torch.autograd.Function):"), "model.py:average_pitch", "exec"), ns)
     exec(compile(cut("class ResidualCouplingBlocks(nn.Module):", "class DiscriminatorS(torch.nn.Module):"), "model.py:flow+posterior", "exec"), ns)
     methods = textwrap.dedent(cut("    def train_step(self,", "    # Opposite of average_pitch"))
     exec(compile(methods, "model.py:train_step", "exec"), ns)
@@ -75,6 +81,11 @@ class Holder(torch.nn.Module):
         self.flow = ns["ResidualCouplingBlocks"](Cc, Cc, kernel_size=5, dilation_rate=1, num_layers=c["flow_layers"], cond_channels=c["dvec"], args=self.args)
         self.duration_predictor = ns["StochasticDurationPredictor"](Cc, Cc, 3, 0.0, 4, cond_channels=c["dvec"], language_emb_dim=c["lang_dim"])
         self.waveform_decoder = lambda z_slice, g=None: torch.zeros(z_slice.size(0), 1, z_slice.size(2) * 256)
+        # --pitch 1 (what the shipped trainer sets, xva_train.py:1421-1425): model.py:153-176 at CFG's width
+        self.pitch_predictor = ns["RelativePositioningPitchEnergyEncoder"](out_channels=1, hidden_channels=Cc + c["lang_dim"], hidden_channels_ffn=c["ffn"],
+                                                                          num_heads=c["heads"], num_layers=3, kernel_size=3, dropout_p=0.0,
+                                                                          conditioning_emb_dim=c["dvec"])
+        self.pitch_emb = torch.nn.Conv1d(1, Cc, kernel_size=3, padding=1)
 
 
 def main():
@@ -99,50 +110,72 @@ def main():
     lids = torch.tensor([0, 3, 1])
     zeros_t, zeros_y = torch.zeros(B, 1, Tt), torch.zeros(B, 1, Ty * 256)
     SEED = 97
-    torch.manual_seed(SEED)
-    out = m.train_step(tokens, x_lens, y, y_lens, zeros_t, zeros_t, zeros_y, aux_input={"d_vectors": dvec, "language_ids": lids})
-    torch.manual_seed(SEED)
-    eps = torch.randn(B, c["latent"], Ty)                                # PosteriorEncoder's randn_like (model.py:1472), first draw of the step
-    noise = torch.randn(B, 2, Tt)                                        # sdp.py:281, second draw
+    pitch = (torch.rand(B, 1, Ty) * 3 - 1.2).clamp_min(0) * (torch.arange(Ty)[None, None, :] < y_lens[:, None, None])      # zeros = unvoiced frames
     y_mask = (torch.arange(Ty)[None, :] < y_lens[:, None]).float()
-    loss_kl, _ = ns["kl_loss"](out["z_p"], out["logs_q"], out["m_p"], out["logs_p"], y_mask.unsqueeze(1))          # losses.py:213
-    loss_dur = torch.sum(out["loss_duration"].float())                                                          # losses.py:220
-    loss = loss_kl + loss_dur
-    m.zero_grad()
-    loss.backward()
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    grads = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()}
-    # ---- the restatement must agree with the reference run before anything is recorded
-    leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
-    o = oxv.acoustic_losses(leaves, tokens, x_lens, y, y_lens, dvec, lids, eps, noise, c)
-    for k in ("z", "m_q", "logs_q", "z_p", "m_p", "logs_p"):
-        assert torch.allclose(o[k], out[k], rtol=1e-4, atol=1e-5), (k, float((o[k] - out[k]).abs().max()))
-    assert abs(float(o["loss_kl"].detach()) - float(loss_kl)) < 1e-4 * max(1.0, abs(float(loss_kl))), (float(o["loss_kl"].detach()), float(loss_kl))
-    assert abs(float(o["loss_duration"].detach()) - float(loss_dur)) < 1e-4 * max(1.0, abs(float(loss_dur))), (float(o["loss_duration"].detach()), float(loss_dur))
-    o["loss"].backward()
-    worst = 0.0
-    for n, gr in grads.items():
-        go = leaves[n].grad if leaves[n].grad is not None else torch.zeros_like(gr)
-        if float(gr.norm()) < 1e-5 * gr.numel() ** 0.5:                   # mathematically zero (conv_k.bias: softmax is shift invariant): rounding noise only
-            assert float(go.norm()) < 1e-4, (n, float(go.norm()))
-            continue
-        err = float((go - gr).norm() / gr.norm())
-        worst = max(worst, err)
-        assert err < 2e-4, (n, err)
     res = {"cfg_keys": np.array(sorted(c)), "cfg_vals": np.array([c[k] for k in sorted(c)]), "tokens": tokens.numpy(), "x_lens": x_lens.numpy(),
-           "y": y.numpy(), "y_lens": y_lens.numpy(), "dvec": dvec.numpy(), "lids": lids.numpy(), "eps": eps.numpy(), "noise": noise.numpy(),
-           "loss_kl": np.float32(loss_kl.item()), "loss_duration": np.float32(loss_dur.item()), "attn": o["attn"].numpy().astype(np.uint8)}
-    for k in ("z", "z_p", "m_p", "logs_p", "m_q", "logs_q"):
-        res["out/" + k] = out[k].detach().numpy()
+           "y": y.numpy(), "y_lens": y_lens.numpy(), "dvec": dvec.numpy(), "lids": lids.numpy(), "pitch": pitch.numpy()}
     for k, v in sd.items():
         res["sd/" + k] = v.numpy()
-    for k, v in grads.items():
-        res["grad/" + k] = v.numpy()
+    from oracle import golden_util
+    for tag, use_pitch in (("", 0), ("p_", 1)):
+        m.args.pitch = use_pitch
+        torch.manual_seed(SEED)
+        out = m.train_step(tokens, x_lens, y, y_lens, pitch if use_pitch else zeros_t, zeros_t, zeros_y, aux_input={"d_vectors": dvec, "language_ids": lids})
+        torch.manual_seed(SEED)
+        eps = torch.randn(B, c["latent"], Ty)                            # PosteriorEncoder's randn_like (model.py:1472), first draw of the step
+        noise = torch.randn(B, 2, Tt)                                    # sdp.py:281, second draw
+        loss_kl, _ = ns["kl_loss"](out["z_p"], out["logs_q"], out["m_p"], out["logs_p"], y_mask.unsqueeze(1))      # losses.py:213
+        loss_dur = torch.sum(out["loss_duration"].float())                                                      # losses.py:220
+        loss = loss_kl + loss_dur
+        loss_pitch = torch.zeros(())
+        if use_pitch:                                                    # losses.py:224-241, its lines restated on the reference's outputs
+            lp = F.mse_loss(out["pitch_tgt"], out["pitch_pred"], reduction="none") * out["mask"].unsqueeze(1)
+            loss_pitch = lp.sum() / out["mask"].sum() / out["pitch_pred"].shape[0] * 0.1
+            loss = loss + loss_pitch
+        m.zero_grad()
+        loss.backward()
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()}
+        # ---- the restatement must agree with the reference run before anything is recorded
+        leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        o = oxv.acoustic_losses(leaves, tokens, x_lens, y, y_lens, dvec, lids, eps, noise, c, pitch_padded=pitch if use_pitch else None, pe_scaling=m.args.pe_scaling)
+        keys = ("z", "m_q", "logs_q", "z_p", "m_p", "logs_p") + (("pitch_tgt", "pitch_pred") if use_pitch else ())
+        for k in keys:
+            assert torch.allclose(o[k], out[k], rtol=1e-4, atol=1e-5), (tag, k, float((o[k] - out[k]).abs().max()))
+        for a, b in ((o["loss_kl"], loss_kl), (o["loss_duration"], loss_dur)) + (((o["loss_pitch"], loss_pitch),) if use_pitch else ()):
+            assert abs(float(a.detach()) - float(b)) < 1e-4 * max(1.0, abs(float(b))), (tag, float(a.detach()), float(b))
+        o["loss"].backward()
+        worst = 0.0
+        for n, gr in grads.items():
+            go = leaves[n].grad if leaves[n].grad is not None else torch.zeros_like(gr)
+            if float(gr.norm()) < 1e-5 * gr.numel() ** 0.5:               # mathematically zero (conv_k.bias: softmax is shift invariant; unused branch): rounding noise only
+                assert float(go.norm()) < 1e-4, (n, float(go.norm()))
+                continue
+            err = float((go - gr).norm() / gr.norm())
+            worst = max(worst, err)
+            assert err < 2e-4, (tag, n, err)
+        res.update({tag + "eps": eps.numpy(), tag + "noise": noise.numpy(), tag + "loss_kl": np.float32(loss_kl.item()),
+                    tag + "loss_duration": np.float32(loss_dur.item()), tag + "loss_pitch": np.float32(float(loss_pitch)),
+                    tag + "attn": o["attn"].numpy().astype(np.uint8)})
+        for k in keys:
+            res[tag + "out/" + k] = out[k].detach().numpy()
+        if not use_pitch:
+            for k, v in grads.items():
+                res["grad/" + k] = v.numpy()
+        else:                                                            # second scenario: pitch tensors in full, the rest as norms + evenly spaced samples
+            gkeys = sorted(grads)
+            flat, off = golden_util.pack_samples(grads, gkeys, 256)
+            res.update({"p_grad_keys": np.array(gkeys), "p_grad_samples": flat, "p_grad_offsets": off,
+                        "p_grad_norms": np.array([float(grads[k].norm()) for k in gkeys], dtype=np.float32)})
+            for k, v in grads.items():
+                if k.startswith("pitch_"):
+                    res["p_grad/" + k] = v.numpy()
+        nz = sum(1 for v in grads.values() if float(v.norm()) >= 1e-5 * v.numel() ** 0.5)
+        print("scenario pitch=%d: loss_kl %.5f loss_duration %.5f loss_pitch %.5f; %d / %d gradient tensors non-zero; oracle vs reference worst rel %.2e"
+              % (use_pitch, loss_kl.item(), loss_dur.item(), float(loss_pitch), nz, len(grads), worst))
     path = os.path.join(OUT, "xvapitch_acoustic.npz")
     np.savez_compressed(path, **res)
-    nz = sum(1 for v in grads.values() if float(v.abs().max()) > 0)
-    print("xvapitch_acoustic.npz: %d arrays, %.2f MB; loss_kl %.5f loss_duration %.5f; %d / %d gradient tensors non-zero; oracle vs reference worst rel %.2e"
-          % (len(res), os.path.getsize(path) / 1e6, loss_kl.item(), loss_dur.item(), nz, len(grads), worst))
+    print("xvapitch_acoustic.npz: %d arrays, %.2f MB" % (len(res), os.path.getsize(path) / 1e6))
 
 
 if __name__ == "__main__":

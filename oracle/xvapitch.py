@@ -239,12 +239,28 @@ def sdp_forward(sd, x, x_mask, dr, noise, hidden, kernel_size=3, num_flows=4, g=
     return nll_flow + nll_post
 
 
-def acoustic_losses(sd, tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps, noise, cfg):
+def average_pitch(pitch, durs):
+    """model.py:1005-1023: mean of the non-zero frame values under each symbol's duration span.  pitch (B, 1, Ty), durs (B, Tt) -> (B, 1, Tt)."""
+    ends = torch.cumsum(durs, dim=1).long()
+    starts = F.pad(ends[:, :-1], (1, 0))
+    nz = F.pad(torch.cumsum(pitch != 0.0, dim=2), (1, 0))
+    cs = F.pad(torch.cumsum(pitch, dim=2), (1, 0))
+    dcs, dce = starts[:, None, :], ends[:, None, :]
+    sums = (torch.gather(cs, 2, dce) - torch.gather(cs, 2, dcs)).float()
+    n = (torch.gather(nz, 2, dce) - torch.gather(nz, 2, dcs)).float()
+    return torch.where(n == 0.0, n, sums / n)
+
+
+def acoustic_losses(sd, tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps, noise, cfg, pitch_padded=None, pe_scaling=0.1):
     """xVAPitch.train_step (python/xvapitch/model.py:681-870) followed by the KL and duration terms of VitsGeneratorLoss.forward
     (losses.py:213-220), on the reference's default switches (--pitch / --energy / --flc / --ow_flow / --mltts_rc 0, detach_dp_input True,
     lang_w 1; dropout off) and WITHOUT the waveform decoder / discriminator branch (:852-853 — that branch is the HiFi-GAN path).
     sd: state_dict with the reference's keys (emb_l.*, text_encoder.*, posterior_encoder.*, flow.flows.i.*, duration_predictor.*).
-    cfg: latent, lang_dim, heads, te_layers, pe_layers, flow_layers, num_flows.  Returns a dict of the intermediate tensors and losses."""
+    cfg: latent, lang_dim, heads, te_layers, pe_layers, flow_layers, num_flows.  Returns a dict of the intermediate tensors and losses.
+    pitch_padded (B, 1, Ty): the --pitch 1 branch the shipped trainer runs (xva_train.py:1421-1425, pe_scaling 0.1): z_p -= pitch_emb(pitch) *
+    pe_scaling (:752-755), per-symbol pitch targets by average_pitch over ceil(durations) (:817-834), the pitch predictor on the detached text
+    encoding + speaker vector (:836), and the pitch term of losses.py:224-241 with its broadcast (mask (B, Tt, 1) -> unsqueeze(1) against a
+    (B, 1, Tt) error: the product is (B, B, Tt, Tt), so sum / mask.sum() is the UNMASKED sum of squared errors)."""
     import math
     Cc = cfg["latent"]
 
@@ -266,6 +282,8 @@ def acoustic_losses(sd, tokens, x_lengths, y, y_lengths, d_vectors, language_ids
     z_p = z
     for i in range(cfg["num_flows"]):                                                                      # ResidualCouplingBlocks.forward :1406-1420
         z_p = torch.flip(coupling(sub("flow.flows.%d." % i), z_p, y_mask, g, hidden=Cc, kernel_size=5, dilation_rate=1, num_layers=cfg["flow_layers"]), [1])
+    if pitch_padded is not None:
+        z_p = z_p - F.conv1d(pitch_padded, sd["pitch_emb.weight"], sd["pitch_emb.bias"], padding=1) * pe_scaling   # :752-755
     attn_mask = x_mask.detach().unsqueeze(-1) * y_mask.unsqueeze(2)                                        # :763
     with torch.no_grad():                                                                                  # :765-776
         o_scale = torch.exp(-2 * logs_p)
@@ -282,5 +300,17 @@ def acoustic_losses(sd, tokens, x_lengths, y, y_lengths, d_vectors, language_ids
     logs_p_e = torch.einsum("klmn, kjm -> kjn", [attn, logs_p])
     loss_kl, _ = kl_loss(z_p, logs_q, m_p_e, logs_p_e, y_mask)                                             # losses.py:213
     loss_dur = torch.sum(loss_duration.float())                                                            # losses.py:220
-    return {"z": z, "m_q": m_q, "logs_q": logs_q, "x": x, "m_p": m_p_e, "logs_p": logs_p_e, "z_p": z_p, "attn": attn.squeeze(1), "logp": logp,
-            "loss_kl": loss_kl, "loss_duration": loss_dur, "loss": loss_kl + loss_dur}
+    extra = {}
+    loss_pitch = 0.0
+    if pitch_padded is not None:
+        w_ceil = torch.ceil(attn_durations * x_mask).squeeze(1)                                            # :817-819
+        mask = (torch.arange(Tt)[None, :] < x_lengths[:, None])[..., None]                                 # :824
+        with torch.no_grad():
+            pitch_tgt = average_pitch(pitch_padded, w_ceil)                                                # :829
+        pin = torch.cat([x.permute(0, 2, 1).detach(), g.transpose(2, 1).expand(B, Tt, -1)], -1).transpose(1, -1)   # :836, model.py:1338-1340
+        pitch_pred = rel_transformer(sub("pitch_predictor.encoder."), pin * x_mask, x_mask, cfg["heads"], 3, 3, 4)
+        lp = F.mse_loss(pitch_tgt, pitch_pred, reduction="none") * mask.unsqueeze(1)                       # losses.py:227-228
+        loss_pitch = lp.sum() / mask.sum() / pitch_pred.shape[0] * 0.1                                     # :236-241 (pitch_predictor_loss_scale 0.1, :55)
+        extra = {"pitch_tgt": pitch_tgt, "pitch_pred": pitch_pred, "loss_pitch": loss_pitch}
+    return {**extra, "z": z, "m_q": m_q, "logs_q": logs_q, "x": x, "m_p": m_p_e, "logs_p": logs_p_e, "z_p": z_p, "attn": attn.squeeze(1), "logp": logp,
+            "loss_kl": loss_kl, "loss_duration": loss_dur, "loss": loss_kl + loss_dur + loss_pitch}

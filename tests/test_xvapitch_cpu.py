@@ -4,6 +4,7 @@ segment, kl_loss — values and autograd gradients."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 
@@ -171,30 +172,41 @@ def test_sdp_oracle_matches_reference_golden():
             assert float((sd[k[9:]].grad - r).norm() / r.norm().clamp_min(1e-12)) < 2e-4, k
 
 
-def test_acoustic_losses_oracle_matches_reference_train_step_golden():
+@pytest.mark.parametrize("tag", ["", "p_"])
+def test_acoustic_losses_oracle_matches_reference_train_step_golden(tag):
     """oracle/xvapitch.py:acoustic_losses vs the vectors recorded from the reference's own xVAPitch.train_step (model.py:681-870; the generator
-    oracle/gen_golden_xvapitch_acoustic.py compiled the method from its source lines in memory and ran it): outputs, MAS path, both losses and all
-    429 parameter gradients."""
-    from oracle import xvapitch as oxv
+    oracle/gen_golden_xvapitch_acoustic.py compiled the method from its source lines in memory and ran it) — with --pitch 0 and with --pitch 1
+    (tag p_): outputs, MAS path, the losses and the parameter gradients (first run: all in full; second: norms + samples, pitch tensors in full)."""
+    from oracle import golden_util, xvapitch as oxv
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xvapitch_acoustic.npz"))
     cfg = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
     sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
     leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
     t = lambda k: torch.from_numpy(g[k])
-    o = oxv.acoustic_losses(leaves, t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("dvec"), t("lids"), t("eps"), t("noise"), cfg)
-    for k in ("z", "z_p", "m_p", "logs_p", "m_q", "logs_q"):
-        assert torch.allclose(o[k].detach(), t("out/" + k), rtol=1e-4, atol=1e-5), k
-    assert np.array_equal(o["attn"].numpy().astype(np.uint8), g["attn"])
-    assert abs(float(o["loss_kl"].detach()) - float(g["loss_kl"])) < 1e-3 and abs(float(o["loss_duration"].detach()) - float(g["loss_duration"])) < 1e-3
+    o = oxv.acoustic_losses(leaves, t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("dvec"), t("lids"), t(tag + "eps"), t(tag + "noise"), cfg,
+                            pitch_padded=t("pitch") if tag else None)
+    for k in [f[len(tag) + 4:] for f in g.files if f.startswith(tag + "out/")]:
+        assert torch.allclose(o[k].detach(), t(tag + "out/" + k), rtol=1e-4, atol=1e-5), k
+    assert np.array_equal(o["attn"].numpy().astype(np.uint8), g[tag + "attn"])
+    for k in ("loss_kl", "loss_duration") + (("loss_pitch",) if tag else ()):
+        assert abs(float(o[k].detach()) - float(g[tag + k])) < 1e-3, k
     o["loss"].backward()
+    mine = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items() if v.requires_grad}
     n = 0
     for k in g.files:
-        if k.startswith("grad/"):
+        if k.startswith(tag + "grad/"):
             ref = t(k)
-            got = leaves[k[5:]].grad if leaves[k[5:]].grad is not None else torch.zeros_like(ref)
-            if float(ref.norm()) < 1e-5 * ref.numel() ** 0.5:                      # mathematically zero (conv_k.bias)
+            got = mine[k[len(tag) + 5:]]
+            if float(ref.norm()) < 1e-5 * ref.numel() ** 0.5:                      # mathematically zero (conv_k.bias, an unused branch)
                 assert float(got.norm()) < 1e-4, k
                 continue
             assert float((got - ref).norm() / ref.norm()) < 2e-4, k
             n += 1
-    assert n > 400
+    assert n > (30 if tag else 400)
+    if tag:
+        keys = [str(k) for k in g["p_grad_keys"]]
+        live = [k for k, nr in zip(keys, g["p_grad_norms"]) if nr >= 1e-5 * mine[k].numel() ** 0.5]
+        errs = [e for e in golden_util.check_samples(mine, keys, g["p_grad_samples"], g["p_grad_offsets"], 256) if e[1] in live]
+        assert len(errs) > 450 and errs[0][0] < 2e-4, errs[:4]
+        for k, nr in zip(keys, g["p_grad_norms"]):
+            assert abs(float(mine[k].norm()) - float(nr)) < 2e-4 * float(nr) + 1e-5, k

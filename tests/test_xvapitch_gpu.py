@@ -384,38 +384,54 @@ def test_residual_coupling_blocks_flow_and_its_inverse():
     assert _rel(back * x_mask.cuda(), x * x_mask) < 1e-4
 
 
-def test_acoustic_train_path_against_reference_train_step_golden(golden_dir):
+@pytest.mark.parametrize("tag", ["", "p_"])
+def test_acoustic_train_path_against_reference_train_step_golden(golden_dir, tag):
     """xvapitch/acoustic.py:AcousticTrainPath — embeddings, TextEncoder, PosteriorEncoder (41 spectrogram bins: a channel count that is no multiple
-    of 4, like the model's 513), flow, MAS, StochasticDurationPredictor, prior expansion, KL + duration losses — against the vectors recorded from
-    the REFERENCE's own xVAPitch.train_step (model.py:681-870) with the same two N(0, 1) draws: outputs and losses at 1e-3, the MAS path bit-exact,
-    all 429 parameter gradients at 2e-3 (relative L2)."""
+    of 4, like the model's 513), flow, MAS, StochasticDurationPredictor, prior expansion, KL + duration losses; with tag p_ also the --pitch 1
+    branch the shipped trainer runs (pitch_emb on z_p, average_pitch targets, pitch predictor, pitch loss) — against the vectors recorded from
+    the REFERENCE's own xVAPitch.train_step (model.py:681-870) with the same two N(0, 1) draws: outputs and losses at 1e-3, the MAS path
+    bit-exact, every parameter gradient at 2e-3 (relative L2; the second run's non-pitch tensors by their norms and 256 samples each)."""
+    from oracle import golden_util
     from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
     g = np.load(os.path.join(golden_dir, "xvapitch_acoustic.npz"))
     c = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
     m = AcousticTrainPath(c["vocab"], c["langs"], latent_size=c["latent"], embedded_language_dim=c["lang_dim"], d_vector_dim=c["dvec"],
                           hidden_channels_ffn=c["ffn"], num_heads=c["heads"], text_layers=c["te_layers"], posterior_layers=c["pe_layers"],
-                          flow_layers=c["flow_layers"], num_flows=c["num_flows"], spec_bins=c["spec_bins"])
+                          flow_layers=c["flow_layers"], num_flows=c["num_flows"], spec_bins=c["spec_bins"], pitch=bool(tag))
     sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
-    grads_ref = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad/")}
-    assert set(m.state_dict()) == set(grads_ref), sorted(set(m.state_dict()) ^ set(grads_ref))[:8]
+    grads_all = [k[5:] for k in g.files if k.startswith("grad/")]
+    want = set(k for k in grads_all if tag or not k.startswith("pitch_"))
+    assert set(m.state_dict()) == want, sorted(set(m.state_dict()) ^ want)[:8]
     m.load_state_dict(sd)
     t = lambda k: torch.from_numpy(g[k]).cuda()
     m.zero_grad()
-    o = m(t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("dvec"), t("lids"), eps=t("eps"), noise=t("noise"))
-    for k in ("z", "z_p", "m_q", "logs_q", "m_p", "logs_p"):
-        assert _rel(o[k], torch.from_numpy(g["out/" + k])) < 1e-3, (k, _rel(o[k], torch.from_numpy(g["out/" + k])))
-    assert np.array_equal(o["attn"].cpu().numpy().astype(np.uint8), g["attn"])
-    assert abs(float(o["loss_kl"]) - float(g["loss_kl"])) < 1e-3 * abs(float(g["loss_kl"])), (float(o["loss_kl"]), float(g["loss_kl"]))
-    assert abs(float(o["loss_duration"]) - float(g["loss_duration"])) < 1e-3 * abs(float(g["loss_duration"]))
+    o = m(t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("dvec"), t("lids"), eps=t(tag + "eps"), noise=t(tag + "noise"),
+          pitch_padded=t("pitch") if tag else None)
+    for k in [f[len(tag) + 4:] for f in g.files if f.startswith(tag + "out/")]:
+        assert _rel(o[k], torch.from_numpy(g[tag + "out/" + k])) < 1e-3, (k, _rel(o[k], torch.from_numpy(g[tag + "out/" + k])))
+    assert np.array_equal(o["attn"].cpu().numpy().astype(np.uint8), g[tag + "attn"])
+    for k in ("loss_kl", "loss_duration") + (("loss_pitch",) if tag else ()):
+        assert abs(float(o[k]) - float(g[tag + k])) < 1e-3 * abs(float(g[tag + k])), (k, float(o[k]), float(g[tag + k]))
     o["loss"].backward()
     torch.cuda.synchronize()
-    mine = m.grads()
+    mine = {k: v.detach().cpu() for k, v in m.grads().items()}
     worst = []
-    for k, ref in grads_ref.items():
-        if float(ref.norm()) < 1e-5 * ref.numel() ** 0.5:                          # mathematically zero (conv_k.bias): rounding noise on both sides
+    for k in [f[len(tag) + 5:] for f in g.files if f.startswith(tag + "grad/")]:
+        ref = torch.from_numpy(g[tag + "grad/" + k])
+        if k not in mine:
+            continue
+        if float(ref.norm()) < 1e-5 * ref.numel() ** 0.5:                          # mathematically zero (conv_k.bias, unused last FFN): rounding noise on both sides
             assert float(mine[k].norm()) < 1e-3, k
             continue
         worst.append((_rel(mine[k].reshape(ref.shape), ref), k))
     worst.sort(reverse=True)
-    print("acoustic path worst gradients:", worst[:5], "of", len(worst))
-    assert len(worst) > 400 and worst[0][0] < 2e-3, worst[:5]
+    print("acoustic path%s worst gradients:" % (" (pitch)" if tag else ""), worst[:5], "of", len(worst))
+    assert len(worst) > (30 if tag else 400) and worst[0][0] < 2e-3, worst[:5]
+    if tag:
+        keys = [str(k) for k in g["p_grad_keys"]]
+        live = set(k for k, nr in zip(keys, g["p_grad_norms"]) if nr >= 1e-5 * mine[k].numel() ** 0.5)
+        errs = [e for e in golden_util.check_samples(mine, keys, g["p_grad_samples"], g["p_grad_offsets"], 256) if e[1] in live]
+        print("sampled:", errs[:3], "of", len(errs))
+        assert len(errs) > 450 and errs[0][0] < 2e-3, errs[:4]
+        for k, nr in zip(keys, g["p_grad_norms"]):
+            assert abs(float(mine[k].norm()) - float(nr)) < 2e-3 * float(nr) + 1e-4, k

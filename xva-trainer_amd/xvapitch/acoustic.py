@@ -6,10 +6,11 @@ the waveform decoder, followed by the KL and duration terms of VitsGeneratorLoss
     monotonic alignment search over the prior log-likelihoods (:763-776) -> durations -> StochasticDurationPredictor NLL (:792-814)
     prior expansion along the path (:846-847) ; kl_loss(z_p, logs_q, m_p, logs_p)
 
-Built for the reference's default switches (xva_train.py:1098-1120: --pitch / --energy / --flc / --ow_flow / --mltts_rc 0; detach_dp_input True,
-model.py:52; lang_w 1) and with dropout off (the text encoder's 0.1 and the duration predictor's 0.5 are not built — wn.py / sdp.py raise on
-dropout_p > 0).  The waveform decoder + discriminator branch (:852-853) is the HiFi-GAN path (xva-trainer_amd/hifigan); its speaker-conditioned
-generator variant is not built, so this class returns z / slice inputs and the two acoustic losses, not the full generator loss.
+Built for the reference's default switches (xva_train.py:1098-1120: --energy / --flc / --ow_flow / --mltts_rc 0; detach_dp_input True,
+model.py:52; lang_w 1), with --pitch 0 (the argparse default) or 1 (what the shipped trainer sets, xva_train.py:1421-1425: pitch_emb subtracted
+from z_p :752-755, average_pitch targets :817-829, the pitch predictor :836, the pitch term of losses.py:224-241), and with dropout off (the
+text encoder's 0.1 and the duration predictor's 0.5 are not built — wn.py / sdp.py raise on dropout_p > 0).  The waveform decoder + discriminator branch (:852-853) is the HiFi-GAN path (xva-trainer_amd/hifigan); its speaker-conditioned
+generator variant is not built, so this class returns z and the acoustic losses, not the full generator loss.
 
 state_dict keys are the reference's (`emb_l.weight`, `text_encoder.*`, `posterior_encoder.*`, `flow.flows.i.*`, `duration_predictor.*`).
 Every matrix product, convolution, normalisation, spline, MAS and KL step is a libxvahip call (through the block classes of wn.py /
@@ -25,6 +26,10 @@ from . import ops
 from .sdp import Conv1x1, Mask, StochasticDurationPredictor, _param
 from .transformer import RelativePositionTransformer
 from .wn import PosteriorEncoder, ResidualCouplingBlocks
+
+
+_lib.lib.xva_fp_avg_pitch.restype = __import__("ctypes").c_int32
+_lib.lib.xva_fp_avg_pitch.argtypes = [__import__("ctypes").c_void_p] * 3 + [__import__("ctypes").c_int32] * 4 + [__import__("ctypes").c_void_p]
 
 
 def _pad4(n):
@@ -79,7 +84,8 @@ class AcousticTrainPath:
     """Constructor arguments follow model.py:55-135 (defaults = the reference's non-`big` model)."""
 
     def __init__(self, n_vocab, num_languages, latent_size=192, embedded_language_dim=4, d_vector_dim=512, hidden_channels_ffn=768, num_heads=2,
-                 text_layers=10, posterior_layers=16, flow_layers=4, num_flows=4, spec_bins=513, device="cuda", compute="fp32", seed=0):
+                 text_layers=10, posterior_layers=16, flow_layers=4, num_flows=4, spec_bins=513, pitch=False, pe_scaling=0.1, device="cuda", compute="fp32",
+                 seed=0):
         Cc, L = latent_size, embedded_language_dim
         self.C, self.L = Cc, L
         self.device = torch.device(device)
@@ -95,8 +101,17 @@ class AcousticTrainPath:
         self.flow = ResidualCouplingBlocks(Cc, Cc, 5, 1, flow_layers, num_flows=num_flows, cond_channels=d_vector_dim, device=device, compute=compute,
                                            seed=seed + 3)
         self.duration_predictor = StochasticDurationPredictor(Cc, Cc, 3, 0.0, 4, cond_channels=d_vector_dim, language_emb_dim=L, device=device, seed=seed + 4)
-        self._subs = (("text_encoder.encoder.", self.encoder), ("posterior_encoder.", self.posterior_encoder), ("flow.", self.flow),
-                      ("duration_predictor.", self.duration_predictor))
+        self._subs = [("text_encoder.encoder.", self.encoder), ("posterior_encoder.", self.posterior_encoder), ("flow.", self.flow),
+                      ("duration_predictor.", self.duration_predictor)]
+        # --pitch 1, what the shipped trainer sets (xva_train.py:1421-1425): model.py:153-176
+        self.pitch, self.pe_scaling, self.Dv = bool(pitch), float(pe_scaling), d_vector_dim
+        if self.pitch:
+            hid = Cc + L + d_vector_dim                                                                                                   # model.py:1283-1284
+            self.pitch_predictor = RelativePositionTransformer(hid, 1, hid, hidden_channels_ffn, num_heads, 3, kernel_size=3, dropout_p=0.0,
+                                                               layer_norm_type="2", rel_attn_window_size=4, device=device, seed=seed + 5)
+            self._subs.append(("pitch_predictor.encoder.", self.pitch_predictor))
+            self.p["pitch_emb.weight"] = _param((torch.rand(Cc, 1, 3, generator=gen) * 2 - 1) * 3 ** -0.5, self.device)
+            self.p["pitch_emb.bias"] = _param((torch.rand(Cc, generator=gen) * 2 - 1) * 3 ** -0.5, self.device)
 
     # ---- reference state_dict ----
     def state_dict(self):
@@ -134,10 +149,13 @@ class AcousticTrainPath:
                     v.grad = None
 
     # ---- model.py:681-870 ----
-    def __call__(self, tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps=None, noise=None):
+    def __call__(self, tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps=None, noise=None, pitch_padded=None):
         """tokens (B, Tt) int64, y (B, spec_bins, Ty) linear spectrogram, d_vectors (B, d_vector_dim), language_ids (B,).  eps (B, C, Ty) / noise
         (B, 2, Tt): the N(0, 1) draws of the posterior encoder (model.py:1472) and the duration predictor (sdp.py:281), drawn here when None.
-        Returns the tensors train_step hands to the loss plus `attn`, `loss_kl`, `loss_duration`, `loss` (their sum)."""
+        pitch_padded (B, 1, Ty): frame-level pitch (0 = unvoiced), required when built with pitch=True.
+        Returns the tensors train_step hands to the loss plus `attn`, `loss_kl`, `loss_duration` (`loss_pitch`, `pitch_tgt`, `pitch_pred`), `loss`."""
+        if self.pitch and pitch_padded is None:
+            raise ValueError("AcousticTrainPath(pitch=True): pitch_padded is required")
         _lib.require_cuda(y, d_vectors)
         p, Cc, L = self.p, self.C, self.L
         B, Tt = tokens.shape
@@ -152,6 +170,12 @@ class AcousticTrainPath:
         x = self.encoder(x_in * x_mask, x_mask)                                                            # (B, C + L, Tt) :1166
         stats = Mask.apply(Conv1x1.apply(x.transpose(1, 2).contiguous(), p["text_encoder.proj.weight"], p["text_encoder.proj.bias"]), x_lens)   # :1148
         z_p = self.flow(z, y_mask, g=g)                                                                    # :723
+        if self.pitch:                                                                                     # :752-755  z_p -= pitch_emb(pitch) * pe_scaling
+            # Conv1d(1, C, 3, padding 1) as a GEMM over the three taps of each frame (a 4th zero column keeps rows 16 bytes wide)
+            pp = F.pad(pitch_padded.float().reshape(B, Ty), (1, 1))
+            cols = torch.stack([pp[:, 0:Ty], pp[:, 1:Ty + 1], pp[:, 2:Ty + 2], torch.zeros(B, Ty, device=y.device)], -1).contiguous()
+            w4 = torch.cat([p["pitch_emb.weight"].reshape(Cc, 3), torch.zeros(Cc, 1, device=y.device)], 1).reshape(Cc, 4, 1)
+            z_p = z_p - Conv1x1.apply(cols, w4, p["pitch_emb.bias"]).transpose(1, 2) * self.pe_scaling
         with torch.no_grad():                                                                              # :763-776
             logp = prior_logp(stats.detach(), z_p.detach(), Cc)
             attn_mask = x_mask.squeeze(1).unsqueeze(-1) * y_mask.squeeze(1).unsqueeze(1)
@@ -163,5 +187,19 @@ class AcousticTrainPath:
         ex = _Expand.apply(stats, attn_pad)[:, :Ty].transpose(1, 2)                                        # (B, 2C, Ty) :846-847
         m_p, logs_p = ex[:, :Cc].contiguous(), ex[:, Cc:].contiguous()
         loss_kl, _ = ops.kl_loss(z_p, logs_q, m_p, logs_p, y_mask)                                          # losses.py:213
-        return {"z": z, "m_q": m_q, "logs_q": logs_q, "x": x, "x_mask": x_mask, "y_mask": y_mask, "z_p": z_p, "m_p": m_p, "logs_p": logs_p, "attn": attn,
-                "loss_kl": loss_kl, "loss_duration": loss_duration, "loss": loss_kl + loss_duration}
+        out = {"z": z, "m_q": m_q, "logs_q": logs_q, "x": x, "x_mask": x_mask, "y_mask": y_mask, "z_p": z_p, "m_p": m_p, "logs_p": logs_p, "attn": attn,
+               "loss_kl": loss_kl, "loss_duration": loss_duration, "loss": loss_kl + loss_duration}
+        if self.pitch:
+            with torch.no_grad():                                                                          # :817-829 (ceil of a 0 / 1 path sum = the sum)
+                durs = (dr.squeeze(1) * x_mask.squeeze(1)).ceil().to(torch.int32).contiguous()
+                tgt_pad = torch.empty(B, Tt + 2, device=y.device)                                         # the kernel writes FastPitch's padded token rows: [0 | Tt values | 0]
+                _lib.check(_lib.lib.xva_fp_avg_pitch(_lib.ptr(pitch_padded.float().reshape(B, Ty).contiguous()), _lib.ptr(durs), _lib.ptr(tgt_pad), B, Tt, Ty, 0,
+                                                     _lib.stream_ptr()), "xva_fp_avg_pitch")
+                pitch_tgt = tgt_pad[:, 1:Tt + 1].contiguous()
+            pin = torch.cat([x.detach(), g.expand(B, self.Dv, Tt)], 1)                                     # :836, model.py:1338-1340
+            pitch_pred = self.pitch_predictor(pin * x_mask, x_mask)                                        # (B, 1, Tt)
+            # losses.py:224-241: the reference's mask broadcast makes the "masked mean" the plain sum of squared errors; / B, x 0.1 (:55)
+            err = pitch_pred.reshape(B, Tt) - pitch_tgt
+            loss_pitch = (err * err).sum() / B * 0.1
+            out.update({"pitch_tgt": pitch_tgt.unsqueeze(1), "pitch_pred": pitch_pred, "loss_pitch": loss_pitch, "loss": out["loss"] + loss_pitch})
+        return out
