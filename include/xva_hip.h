@@ -334,6 +334,27 @@ int xva_hg_generator_forward(const xva_hg_dims* d, const float* params_g, const 
 /* d_wav: (B, seg) fp32 gradient w.r.t. the generated waveform; accumulates into grads_g */
 int xva_hg_generator_backward(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* workspace,
                               int64_t workspace_bytes, void* stream);
+/* The VITS waveform decoder of xVAPitch — python/xvapitch/hifigan.py:156-262 (HifiganGenerator) as python/xvapitch/model.py:134-149 builds it:
+ * the HiFi-GAN v1 generator above with `in_channels` latent channels in (192; 256 for the `big` model), conv_pre / conv_post WITHOUT weight norm
+ * (tensors conv_pre.weight / .bias, conv_post.weight — no bias), and cond_layer = Conv1d(cond_channels, 512, 1) on the speaker vector added to
+ * conv_pre's output (hifigan.py:247-248).  Parameters: one flat fp32 buffer, tensors named and shaped as in the reference state_dict
+ * (xva_vits_dec_tensor_info).  z: (B, in_channels, seg / 256) fp32; g: (B, cond_channels) fp32 (NULL when cond_channels == 0);
+ * wav_out: (B, seg) fp32.  backward accumulates into `grads` and writes d_z (B, in_channels, seg / 256) fp32 (may be NULL).
+ * The workspace (zero-filled once when allocated) holds the activations between forward and backward. */
+typedef struct xva_vits_dec_dims {
+    int32_t B, seg, dt;               /* as xva_hg_dims */
+    int32_t in_channels;              /* multiple of 8 */
+    int32_t cond_channels;            /* multiple of 4; 0: no cond_layer */
+} xva_vits_dec_dims;
+int64_t xva_vits_dec_param_floats(const xva_vits_dec_dims* d);
+int xva_vits_dec_num_tensors(const xva_vits_dec_dims* d);
+int xva_vits_dec_tensor_info(const xva_vits_dec_dims* d, int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int32_t* ndim,
+                             int64_t* shape4);
+int64_t xva_vits_dec_workspace_bytes(const xva_vits_dec_dims* d);
+int xva_vits_dec_forward(const xva_vits_dec_dims* d, const float* params, const float* z, const float* g, void* workspace, int64_t workspace_bytes,
+                         float* wav_out, void* stream);
+int xva_vits_dec_backward(const xva_vits_dec_dims* d, const float* params, float* grads, const float* g, const float* d_wav, float* d_z,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 /* Stream lanes.  Inside one call the engines issue independent chains on side streams they own (created once per host thread, forked
  * from and joined to the caller's stream with events inside the call): HiFi-GAN — period | scale discriminators, the generator's
  * weight gradients, the three parallel resblocks of a stage; FastPitch — the weight gradients of a layer and the temporal predictors.

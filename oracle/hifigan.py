@@ -360,3 +360,50 @@ def layer_res_c2(sd, rb, m, xt1, xcur):
     k = RES_KERNELS[rb % 3]
     pre = "resblocks.%d.convs2.%d." % (rb, m)
     return layer_conv(xt1, wn_weight(sd, pre), sd[pre + "bias"], padding=get_padding(k, 1)) + xcur.double()
+
+
+# ------------------------------------------------------------------ the VITS waveform decoder (xVAPitch) ----
+def vits_decoder(sd, x, g=None):
+    """HifiganGenerator.forward (python/xvapitch/hifigan.py:233-262) as xVAPitch builds it (python/xvapitch/model.py:134-149): the v1
+    generator above on `in_channels` latent channels, conv_pre / conv_post WITHOUT weight norm, conv_post without bias, and
+    o = conv_pre(x) + cond_layer(g) with g (B, cond, 1) the speaker vector.  x: (B, in, T) -> (B, 1, T * 256)."""
+    x = F.conv1d(x, sd["conv_pre.weight"], sd["conv_pre.bias"], padding=3)
+    if g is not None:
+        x = x + F.conv1d(g, sd["cond_layer.weight"], sd["cond_layer.bias"])
+    nk = len(RES_KERNELS)
+    for i, (u, k) in enumerate(zip(UPSAMPLE_RATES, UPSAMPLE_KERNELS)):
+        x = F.leaky_relu(x, LRELU_SLOPE)
+        x = F.conv_transpose1d(x, wn_weight(sd, "ups.%d." % i), sd["ups.%d.bias" % i], stride=u, padding=(k - u) // 2)
+        xs = None
+        for j in range(nk):
+            r = _resblock1(sd, "resblocks.%d." % (i * nk + j), x, RES_KERNELS[j], RES_DILATIONS[j])
+            xs = r if xs is None else xs + r
+        x = xs / nk
+    x = F.leaky_relu(x)
+    x = F.conv1d(x, sd["conv_post.weight"], None, padding=3)
+    return torch.tanh(x)
+
+
+def init_vits_decoder_sd(seed, in_channels=192, cond_channels=512):
+    """Seeded state_dict in the reference key order (HifiganGenerator.state_dict() after the two remove_weight_norm calls of
+    hifigan.py:226-230: conv_pre.bias / .weight, ups.*, resblocks.*, conv_post.weight, cond_layer.weight / .bias)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    sd["conv_pre.bias"] = (torch.rand(UPSAMPLE_INITIAL, generator=g) * 2 - 1) / math.sqrt(in_channels * 7)
+    sd["conv_pre.weight"] = (torch.rand(UPSAMPLE_INITIAL, in_channels, 7, generator=g) * 2 - 1) / math.sqrt(in_channels * 7)
+    ch = UPSAMPLE_INITIAL
+    for i, (u, k) in enumerate(zip(UPSAMPLE_RATES, UPSAMPLE_KERNELS)):
+        _wn(sd, "ups.%d." % i, (ch, ch // 2, k), g, std=0.04, transpose=True)
+        ch //= 2
+    ch = UPSAMPLE_INITIAL
+    for i in range(4):
+        ch //= 2
+        for j, k in enumerate(RES_KERNELS):
+            for name in ("convs1", "convs2"):
+                for m in range(3):
+                    _wn(sd, "resblocks.%d.%s.%d." % (i * 3 + j, name, m), (ch, ch, k), g, std=0.04)
+    sd["conv_post.weight"] = torch.randn(1, 32, 7, generator=g) * 0.04
+    if cond_channels:
+        sd["cond_layer.weight"] = (torch.rand(UPSAMPLE_INITIAL, cond_channels, 1, generator=g) * 2 - 1) / math.sqrt(cond_channels)
+        sd["cond_layer.bias"] = (torch.rand(UPSAMPLE_INITIAL, generator=g) * 2 - 1) / math.sqrt(cond_channels)
+    return sd

@@ -210,3 +210,22 @@ def test_acoustic_losses_oracle_matches_reference_train_step_golden(tag):
         assert len(errs) > 450 and errs[0][0] < 2e-4, errs[:4]
         for k, nr in zip(keys, g["p_grad_norms"]):
             assert abs(float(mine[k].norm()) - float(nr)) < 2e-4 * float(nr) + 1e-5, k
+
+
+def test_vits_decoder_oracle_matches_reference_golden():
+    """oracle/hifigan.py:vits_decoder vs the vectors recorded from the reference HifiganGenerator (python/xvapitch/hifigan.py:156-262 built as
+    model.py:134-149): waveform 1e-5, gradients at the fixture's LeakyReLU-gate bound (1e-2, see oracle/gen_golden_vits_decoder.py)."""
+    from oracle import golden_util, hifigan as ohg
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vits_decoder.npz"))
+    seed, B, Cin, Cc, T = (int(v) for v in g["cfg"])
+    sd = ohg.init_vits_decoder_sd(seed, Cin, Cc)
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(g["sd_checksum"])) < 1e-3
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    z = torch.from_numpy(g["z"]).requires_grad_(True)
+    y = ohg.vits_decoder(leaves, z, torch.from_numpy(g["g"]).unsqueeze(-1))
+    assert torch.allclose(y.detach(), torch.from_numpy(g["y"]), rtol=1e-5, atol=1e-6)
+    (y * torch.from_numpy(g["r"])).sum().backward()
+    mine = {k: v.grad for k, v in leaves.items()}
+    errs = golden_util.check_samples(mine, [str(k) for k in g["grad_keys"]], g["grad_samples"], g["grad_offsets"], 512)
+    assert len(errs) == 233 and errs[0][0] < 1e-2, errs[:4]
+    assert float((z.grad - torch.from_numpy(g["dz"])).norm() / torch.from_numpy(g["dz"]).norm()) < 1e-2

@@ -435,3 +435,64 @@ def test_acoustic_train_path_against_reference_train_step_golden(golden_dir, tag
         assert len(errs) > 450 and errs[0][0] < 2e-3, errs[:4]
         for k, nr in zip(keys, g["p_grad_norms"]):
             assert abs(float(mine[k].norm()) - float(nr)) < 2e-3 * float(nr) + 1e-4, k
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_vits_decoder_against_reference_golden(golden_dir, compute):
+    """xvapitch/decoder.py:VitsDecoder (xva_vits_dec_forward / _backward: the HiFi-GAN v1 generator engine with a 192-channel latent input, plain
+    conv_pre / conv_post, no conv_post bias, cond_layer on the speaker vector) against the vectors recorded from the REFERENCE HifiganGenerator
+    (python/xvapitch/hifigan.py:156-262 built as model.py:134-149).  fp32: waveform 1e-4; d z and all 233 parameter gradients 1e-2 — the bound the
+    fixture's generator derives (LeakyReLU gates within rounding of zero flip between any two fp32 evaluations; the same CPU restatement in fp64
+    moves its own gradients by 2-4e-3).  bf16 storage: the waveform at 3e-2, gradient norms at 15 %, d z at 0.35 relative L2 (measured 9e-3 / 7 % / 0.20: end-to-end
+    through ~50 bf16-stored layers against a random cotangent; the tight, teacher-forced per-layer bound of the shared engine is in test_hifigan_gpu.py)."""
+    from oracle import golden_util, hifigan as ohg
+    from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+    g = np.load(os.path.join(golden_dir, "vits_decoder.npz"))
+    seed, B, Cin, Cc, T = (int(v) for v in g["cfg"])
+    sd = ohg.init_vits_decoder_sd(seed, Cin, Cc)
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(g["sd_checksum"])) < 1e-3
+    dec = VitsDecoder(Cin, Cc, compute=compute)
+    assert set(dec.state_dict()) == set(sd), sorted(set(dec.state_dict()) ^ set(sd))[:8]
+    dec.load_state_dict(sd)
+    z = torch.from_numpy(g["z"]).cuda().requires_grad_(True)
+    gv = torch.from_numpy(g["g"]).cuda().unsqueeze(-1)
+    y = dec(z, gv)
+    ey = _rel(y, torch.from_numpy(g["y"]))
+    dec.zero_grad()
+    (y * torch.from_numpy(g["r"]).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    mine = {k: v.detach().cpu() for k, v in dec.grads().items()}
+    keys = [str(k) for k in g["grad_keys"]]
+    edz = _rel(z.grad, torch.from_numpy(g["dz"]))
+    if compute == "fp32":
+        errs = golden_util.check_samples(mine, keys, g["grad_samples"], g["grad_offsets"], 512)
+        full = sorted(((_rel(mine[k[5:]], torch.from_numpy(g[k])), k[5:]) for k in g.files if k.startswith("grad/")), reverse=True)
+        print("vits decoder fp32: y %.2e dz %.2e sampled worst %s full worst %s" % (ey, edz, errs[:3], full[:3]))
+        assert ey < 1e-4 and edz < 1e-2
+        assert len(errs) == 233 and errs[0][0] < 1e-2, errs[:4]
+        assert full[0][0] < 1e-2, full[:4]
+    else:
+        nerr = sorted(((abs(float(mine[k].norm()) - float(n)) / float(n), k) for k, n in zip(keys, g["grad_norms"])), reverse=True)
+        print("vits decoder bf16: y %.2e dz %.2e worst norm errors %s" % (ey, edz, nerr[:3]))
+        assert ey < 3e-2 and edz < 0.35 and nerr[0][0] < 0.15, (ey, edz, nerr[:3])
+
+
+def test_vits_decoder_without_conditioning_and_data_only_input():
+    """cond_channels = 0 (no cond_layer tensors), a 256-channel latent (the `big` model), an input that does not require grad: the parameter
+    gradients are still produced; against the CPU oracle."""
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+    sd = ohg.init_vits_decoder_sd(5, 256, 0)
+    dec = VitsDecoder(256, 0)
+    dec.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(6)
+    z = torch.randn(1, 256, 8, generator=gen); r = torch.randn(1, 1, 2048, generator=gen)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = ohg.vits_decoder(leaves, z, None)
+    (yo * r).sum().backward()
+    dec.zero_grad()
+    y = dec(z.cuda(), None)
+    (y * r.cuda()).sum().backward()
+    assert _rel(y, yo.detach()) < 1e-4
+    worst = sorted(((_rel(v, leaves[k].grad), k) for k, v in dec.grads().items()), reverse=True)
+    assert worst[0][0] < 1e-2, worst[:4]

@@ -715,6 +715,28 @@ extern "C" int xva_hg_colsum_batch(const xva_cs_desc* descs, int n, void* stream
     return XVA_OK;
 }
 
+// seq[b][padF + t][c] += vec[b][c] on the T valid rows of each item (pad rows stay zero): the VITS decoder's o + cond_layer(g)
+// (python/xvapitch/hifigan.py:247-248).  One thread per 4 channels.
+__global__ void hg_add_item_vec_kernel(void* __restrict__ seq, int dt, const float* __restrict__ vec, int Hp, int padF, int T, int C, int64_t total4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int c4 = C >> 2;
+    const int64_t row = i / c4;                       // over B * T valid rows
+    const int c = (int)(i % c4) * 4;
+    const int b = (int)(row / T), t = (int)(row % T);
+    const int64_t e = ((int64_t)b * Hp + padF + t) * C + c;
+    const float4 v = *reinterpret_cast<const float4*>(vec + (int64_t)b * C + c);
+    hg_st(seq, e, dt, hg_ld(seq, e, dt) + v.x); hg_st(seq, e + 1, dt, hg_ld(seq, e + 1, dt) + v.y);
+    hg_st(seq, e + 2, dt, hg_ld(seq, e + 2, dt) + v.z); hg_st(seq, e + 3, dt, hg_ld(seq, e + 3, dt) + v.w);
+}
+extern "C" int xva_hg_add_item_vec(void* seq, int dt, const float* vec, int B, int Hp, int padF, int T, int C, void* stream) {
+    XVA_CHECK_ARG(seq && vec && C % 4 == 0, "add_item_vec: null or C %% 4 != 0");
+    const int64_t total4 = (int64_t)B * T * (C / 4);
+    hipLaunchKernelGGL(hg_add_item_vec_kernel, dim3((unsigned)xva_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, seq, dt, vec, Hp, padF, T, C, total4);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // weight_norm (old API, dim 0): w = g * v / ||v||  (torch.nn.utils.weight_norm; models.py:21-108)
 // v: (D0, inner) fp32 in the checkpoint layout; writes the effective weight in a GEMM layout given by an index map:
@@ -733,7 +755,7 @@ __device__ __forceinline__ void hg_weight_norm_fwd_body(const float* __restrict_
     acc = xva_block_sum(acc, sh);
     float n = sqrtf(acc);
     if (threadIdx.x == 0) norm[o] = n;
-    float sc = gparam[o] / n;
+    float sc = gparam ? gparam[o] / n : 1.f;          // gparam == null: a plain (not reparametrised) weight, re-laid out only
     for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) {
         int i1 = idx / k, j = idx % k;
         float w = vo[idx] * sc;
@@ -771,6 +793,10 @@ __device__ __forceinline__ void hg_weight_norm_bwd_body(const float* __restrict_
     const int inner = D1 * k;
     const float* vo = v + (int64_t)o * inner;
     const float* dwo = dW + (int64_t)o * inner;
+    if (!gparam) {                                    // plain weight: dv += dW in the checkpoint layout
+        for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) dv[(int64_t)o * inner + idx] += dwo[(int64_t)(idx % k) * D1 + idx / k];
+        return;
+    }
     float acc = 0.f;
     for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) {
         int i1 = idx / k, j = idx % k;
@@ -805,7 +831,8 @@ extern "C" int xva_hg_weight_norm_batch(const xva_wn_desc* descs, int n, int bac
         int blocks = 0;
         for (int i = 0; i < b.n; ++i) {
             b.d[i] = descs[i0 + i];
-            XVA_CHECK_ARG(b.d[i].v && b.d[i].g && b.d[i].norm && (backward ? (b.d[i].dW && b.d[i].dv && b.d[i].dg) : (b.d[i].eff && (b.d[i].kind == 0 || b.d[i].effB))),
+            XVA_CHECK_ARG(b.d[i].v && b.d[i].norm && (b.d[i].g || b.d[i].kind == 0) &&
+                          (backward ? (b.d[i].dW && b.d[i].dv && (b.d[i].dg || !b.d[i].g)) : (b.d[i].eff && (b.d[i].kind == 0 || b.d[i].effB))),
                           "weight_norm_batch: null tensor in layer %d", i0 + i);
             XVA_CHECK_ARG(backward || b.d[i].kind == 0 || (b.d[i].k % b.d[i].s == 0), "weight_norm_batch: transposed conv needs k %% s == 0");
             b.d[i].block0 = blocks;

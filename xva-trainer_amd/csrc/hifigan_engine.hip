@@ -12,6 +12,8 @@
 #include "hg_conv.h"
 #include "hg_wn.h"
 #include "../../include/xva_hip.h"
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -40,6 +42,7 @@ int xva_hg_col2im1(const void*, int, float*, int, int, int, int, int, int, int, 
 int xva_hg_pad_cols(const float*, void*, int, int, int, int, void*);
 int xva_hg_unpad_cols_add(const float*, float*, int, int, int, void*);
 int xva_hg_add_f32(float* dst, const float* src, int64_t n, void* stream);
+int xva_hg_add_item_vec(void* seq, int dt, const float* vec, int B, int Hp, int padF, int T, int C, void* stream);
 }
 
 namespace {
@@ -50,13 +53,15 @@ constexpr int NPER = 5;
 const int PERIODS[NPER] = {2, 3, 5, 7, 11};
 const int UPS_RATE[4] = {8, 8, 2, 2}, UPS_K[4] = {16, 16, 4, 4};
 const int RES_K[3] = {3, 7, 11}, RES_D[3] = {1, 3, 5};
-enum { LK_WN = 0, LK_WNT = 1, LK_SN = 2 };
+enum { LK_WN = 0, LK_WNT = 1, LK_SN = 2, LK_PLAIN = 3 };   // LK_PLAIN: nn.Conv1d without a reparametrisation (the VITS decoder's conv_pre / conv_post / cond_layer)
 
 struct TInfo { std::string name; int64_t off, numel; int ndim; int64_t shape[4]; int kind; };   // kind 0 trainable, 2 buffer
 
 struct Layer {
     int kind = LK_WN;
     int Cin = 0, Cout = 0, k = 1, s = 1, d = 1, P = 0, groups = 1;
+    bool has_bias = true;   // LK_PLAIN only: conv_post of the VITS decoder has none
+    bool aux = false;       // not a sequence convolution (cond_layer: a (B, cond) x (cond, C) product): no effective-weight copy
     int64_t bias = -1, wg = -1, wv = -1, bu = -1, bv = -1;   // offsets (floats) in the flat parameter buffer
     // workspace byte offsets
     int64_t eff[2] = {-1, -1}, effB = -1, eff32[2] = {-1, -1}, norm[2] = {-1, -1}, su[2] = {-1, -1}, sv[2] = {-1, -1}, dweff[2] = {-1, -1};
@@ -79,6 +84,12 @@ struct Net {
             ti.off = -1; dst->push_back(ti); return (int)dst->size() - 1;
         };
         const int64_t d0 = l.D0(), d1 = l.D1();
+        if (l.kind == LK_PLAIN) {   // torch order: weight, bias
+            l.wv = add(pre + "weight", {d0, d1, l.k}, 0, &t);
+            l.bias = l.has_bias ? add(pre + "bias", {l.Cout}, 0, &t) : -1;
+            L.push_back(l);
+            return (int)L.size() - 1;
+        }
         int ib = add(pre + "bias", {l.kind == LK_WNT ? l.Cout : l.Cout}, 0, &t);
         l.bias = ib;   // temporarily the tensor index; resolved to offsets in finalize()
         if (l.kind == LK_SN) {
@@ -99,7 +110,7 @@ struct Net {
         int nb0 = (int)t.size();
         for (auto& ti : buffers) { ti.off = total; total += (ti.numel + 3) & ~(int64_t)3; t.push_back(ti); }
         for (auto& l : L) {
-            l.bias = t[l.bias].off;
+            if (l.bias >= 0) l.bias = t[l.bias].off;
             if (l.wg >= 0) l.wg = t[l.wg].off;
             l.wv = t[l.wv].off;
             if (l.bu >= 0) { l.bu = t[nb0 + l.bu].off; l.bv = t[nb0 + l.bv].off; }
@@ -108,11 +119,15 @@ struct Net {
 };
 
 // ---- generator layer indices ----
+// gin = 80, gcond = 0, vits = false: HiFi-GAN v1 (python/hifigan/models.py:75-128).  vits: xVAPitch's waveform decoder
+// (python/xvapitch/hifigan.py:156-262 as built at model.py:134-149): `gin` latent channels in, conv_pre / conv_post WITHOUT weight norm,
+// conv_post without bias, cond_layer = Conv1d(gcond, 512, 1) on the speaker vector added to conv_pre's output; same ups / resblocks.
 struct GenNet : Net {
-    int pre, ups[4], rc1[12][3], rc2[12][3], post;
-    GenNet() {
+    int pre, ups[4], rc1[12][3], rc2[12][3], post, cond = -1;
+    int gin, gcond; bool vits;
+    GenNet(int gin_ = 80, int gcond_ = 0, bool vits_ = false) : gin(gin_), gcond(gcond_), vits(vits_) {
         std::vector<TInfo> buf;
-        Layer l; l.Cin = 80; l.Cout = 512; l.k = 7; l.P = 3; pre = add_layer("conv_pre.", l, &buf);
+        Layer l; l.Cin = gin; l.Cout = 512; l.k = 7; l.P = 3; if (vits) l.kind = LK_PLAIN; pre = add_layer("conv_pre.", l, &buf);
         int ch = 512;
         for (int i = 0; i < 4; ++i) {
             Layer u; u.kind = LK_WNT; u.Cin = ch; u.Cout = ch / 2; u.k = UPS_K[i]; u.s = UPS_RATE[i]; u.P = (UPS_K[i] - UPS_RATE[i]) / 2;
@@ -134,7 +149,8 @@ struct GenNet : Net {
                 }
             }
         }
-        Layer p; p.Cin = 32; p.Cout = 1; p.k = 7; p.P = 3; post = add_layer("conv_post.", p, &buf);
+        Layer p; p.Cin = 32; p.Cout = 1; p.k = 7; p.P = 3; if (vits) { p.kind = LK_PLAIN; p.has_bias = false; } post = add_layer("conv_post.", p, &buf);
+        if (gcond > 0) { Layer cl; cl.kind = LK_PLAIN; cl.aux = true; cl.Cin = gcond; cl.Cout = 512; cl.k = 1; cond = add_layer("cond_layer.", cl, &buf); }
         finalize(buf);
     }
 };
@@ -167,6 +183,15 @@ struct DiscNet : Net {
     }
 };
 const GenNet& gnet() { static GenNet n; return n; }
+// the VITS decoder variants met so far (latent 192 / 256 x speaker-vector width): built once each, never freed
+const GenNet& vits_gnet(int gin, int gcond) {
+    static std::mutex mu;
+    static std::vector<std::unique_ptr<GenNet>> nets;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& n : nets) if (n->gin == gin && n->gcond == gcond) return *n;
+    nets.emplace_back(new GenNet(gin, gcond, true));
+    return *nets.back();
+}
 const DiscNet& dnet() { static DiscNet n; return n; }
 
 // ------------------------------------------------------------------ workspace plan ----
@@ -193,6 +218,10 @@ struct Plan {
     int Tw[3];
     int64_t dw_g[2], dw_d[2];           // [begin, end) of the generator / discriminator effective-weight gradient regions
     int64_t sn_tmp, losses, skws[4], skws_bytes, dwav_lane[4], total;   // per stream lane: split-K slabs, partial d(waveform)
+    // VITS decoder variant (gnetp != &gnet()): d(input), the speaker projection and its gradient, a zero bias / dummy bias gradient for conv_post
+    const GenNet* gnetp = nullptr;
+    SeqSpec g_dxin;
+    int64_t cvec = -1, dcvec = -1, zbias = -1, dumdb = -1;
 };
 
 SeqSpec mk(Bump& b, int es, int nseq, int T, int C, int padF, int padB) {
@@ -208,6 +237,7 @@ Seq seq(const SeqSpec& s, char* base, int dt) {
 }
 
 void plan_layer_ws(Layer& l, Bump& b, int es, bool grads) {
+    if (l.aux) return;
     const int64_t n = l.wnumel();
     const int passes = l.kind == LK_SN ? 2 : 1;
     for (int p = 0; p < passes; ++p) {
@@ -223,6 +253,7 @@ void plan_layer_ws(Layer& l, Bump& b, int es, bool grads) {
 void plan_layer_grads(std::vector<Layer>& L, Bump& b, int64_t* begin, int64_t* end) {
     *begin = b.cur;
     for (auto& l : L) {
+        if (l.aux) continue;
         const int passes = l.kind == LK_SN ? 2 : 1;
         for (int p = 0; p < passes; ++p) {
             l.dweff[p] = b.take(l.wnumel() * 4);
@@ -232,7 +263,7 @@ void plan_layer_grads(std::vector<Layer>& L, Bump& b, int64_t* begin, int64_t* e
     *end = b.cur;
 }
 
-int make_plan(const xva_hg_dims* d, Plan* p) {
+int make_plan(const xva_hg_dims* d, Plan* p, const GenNet* gn = nullptr) {
     XVA_CHECK_ARG(d && d->B > 0 && d->seg >= 2048 && d->seg % 256 == 0, "hifigan: bad dims (segment must be a multiple of 256, >= 2048)");
     XVA_CHECK_ARG(d->dt == XVA_F32 || d->dt == XVA_BF16, "hifigan: bad dtype");
     p->B = d->B; p->seg = d->seg; p->dt = d->dt; p->es = d->dt == XVA_BF16 ? 2 : 4;
@@ -240,13 +271,21 @@ int make_plan(const xva_hg_dims* d, Plan* p) {
     p->T[0] = d->seg / 256; p->T[1] = p->T[0] * 8; p->T[2] = p->T[1] * 8; p->T[3] = p->T[2] * 2; p->T[4] = p->T[3] * 2;
     p->Cst[0] = 512; p->Cst[1] = 256; p->Cst[2] = 128; p->Cst[3] = 64; p->Cst[4] = 32;
     Bump b;
-    p->gl = gnet().L; p->dl = dnet().L;
+    const bool vits = gn != nullptr;                 // decoder only: no discriminator tensors in the workspace
+    p->gnetp = vits ? gn : &gnet();
+    p->gl = p->gnetp->L;
+    if (!vits) p->dl = dnet().L;
     for (auto& l : p->gl) plan_layer_ws(l, b, es, true);
     for (auto& l : p->dl) plan_layer_ws(l, b, es, true);
     plan_layer_grads(p->gl, b, &p->dw_g[0], &p->dw_g[1]);
     plan_layer_grads(p->dl, b, &p->dw_d[0], &p->dw_d[1]);
     const int PG = 32;   // generator pad rows (>= max dilation * (k - 1) / 2 = 25)
-    p->xin = mk(b, es, B, p->T[0], 80, PG, PG);
+    p->xin = mk(b, es, B, p->T[0], p->gnetp->gin, PG, PG);
+    if (vits) {
+        p->g_dxin = mk(b, es, B, p->T[0], p->gnetp->gin, PG, PG);
+        p->cvec = b.take((int64_t)B * 512 * 4); p->dcvec = b.take((int64_t)B * 512 * 4);
+        p->zbias = b.take(256); p->dumdb = b.take(256);
+    }
     p->h0 = mk(b, es, B, p->T[0], 512, PG, PG);
     for (int i = 0; i < 4; ++i) {
         const int T = p->T[i + 1], C = p->Cst[i + 1];
@@ -273,7 +312,7 @@ int make_plan(const xva_hg_dims* d, Plan* p) {
         }
     }
     // ---- MPD: sequences (b, w); real items first, then fake
-    for (int d5 = 0; d5 < NPER; ++d5) {
+    for (int d5 = 0; d5 < NPER && !vits; ++d5) {
         const int pp = PERIODS[d5], ns = 2 * B * pp;
         int H[7];
         H[0] = (d->seg + pp - 1) / pp;
@@ -293,7 +332,7 @@ int make_plan(const xva_hg_dims* d, Plan* p) {
     }
     // ---- MSD
     p->Tw[0] = d->seg; p->Tw[1] = p->Tw[0] / 2 + 1; p->Tw[2] = p->Tw[1] / 2 + 1;
-    for (int sc = 0; sc < 3; ++sc) {
+    for (int sc = 0; sc < 3 && !vits; ++sc) {
         int T[9];
         T[0] = p->Tw[sc]; T[1] = T[0];
         const int str[8] = {1, 2, 2, 4, 4, 1, 1, 1};
@@ -309,7 +348,7 @@ int make_plan(const xva_hg_dims* d, Plan* p) {
         for (int rf = 0; rf < 2; ++rf) p->wav_s[sc][rf] = sc == 0 ? -1 : b.take((int64_t)B * p->Tw[sc] * 4);
         p->dwav_s[sc] = b.take((int64_t)B * p->Tw[sc] * 4);
     }
-    p->sn_tmp = b.take((1024 * 41 * 64 + 1024 + 64) * 4);
+    p->sn_tmp = vits ? -1 : b.take((1024 * 41 * 64 + 1024 + 64) * 4);
     p->losses = b.take(64 * 4);
     p->skws_bytes = (int64_t)96 << 20;      // split-K slabs of the weight-gradient GEMMs (largest: 3 x 1024 x 5120 fp32)
     for (int l = 0; l < 4; ++l) { p->skws[l] = b.take(p->skws_bytes); p->dwav_lane[l] = b.take((int64_t)B * d->seg * 4); }
@@ -381,8 +420,8 @@ struct Ctx;
 struct Lanes { Ctx* c[MAXL]; int n; };
 static void use_slabs(const Ctx& c);
 
-int make_ctx(Ctx& c, const xva_hg_dims* d, void* ws, int64_t ws_bytes, void* st) {
-    XVA_TRY(make_plan(d, &c.pl));
+int make_ctx(Ctx& c, const xva_hg_dims* d, void* ws, int64_t ws_bytes, void* st, const GenNet* gn = nullptr) {
+    XVA_TRY(make_plan(d, &c.pl, gn));
     XVA_CHECK_ARG(ws && ((uintptr_t)ws % 256) == 0, "hifigan: workspace null or not 256-byte aligned");
     XVA_CHECK_ARG(ws_bytes >= c.pl.total, "hifigan: workspace too small (%ld < %ld bytes)", (long)ws_bytes, (long)c.pl.total);
     c.W = (char*)ws; c.st = st; c.dt = d->dt; c.compute = d->dt == XVA_BF16 ? 1 : 0;
@@ -414,7 +453,7 @@ static int join_lanes(const Ctx* cs, int n) {
 }
 
 ConvW cw(const Ctx& c, const Layer& l, const float* params, int pass = 0) {
-    ConvW w; w.eff = c.W + l.eff[pass]; w.bias = params + l.bias; w.dweff = l.dweff[pass] >= 0 ? c.F(l.dweff[pass]) : nullptr;
+    ConvW w; w.eff = c.W + l.eff[pass]; w.bias = l.bias >= 0 ? params + l.bias : c.F(c.pl.zbias); w.dweff = l.dweff[pass] >= 0 ? c.F(l.dweff[pass]) : nullptr;
     w.Cin = l.Cin; w.Cout = l.Cout; w.k = l.k; w.s = l.s; w.d = l.d; w.P = l.P; w.groups = l.groups;
     return w;
 }
@@ -430,10 +469,10 @@ int prep_wn(const Ctx& c, const std::vector<Layer>& L, const float* params) {
     std::vector<xva_wn_desc> ds;
     ds.reserve(L.size() + 8);
     for (const Layer& l : L) {
-        if (l.kind == LK_SN) continue;
+        if (l.kind == LK_SN || l.aux) continue;
         xva_wn_desc d;
         memset(&d, 0, sizeof(d));
-        d.v = params + l.wv; d.g = params + l.wg; d.norm = c.F(l.norm[0]);
+        d.v = params + l.wv; d.g = l.kind == LK_PLAIN ? nullptr : params + l.wg; d.norm = c.F(l.norm[0]);   // g == null: effective weight = v
         d.eff = c.W + l.eff[0]; d.effB = l.effB >= 0 ? c.W + l.effB : nullptr;
         d.dt = c.dt; d.kind = l.kind == LK_WNT ? 1 : 0; d.D0 = l.D0(); d.D1 = l.D1(); d.k = l.k; d.s = l.s; d.pconv = l.P;
         ds.push_back(d);
@@ -444,7 +483,7 @@ int prep_wn(const Ctx& c, const std::vector<Layer>& L, const float* params) {
     }
     XVA_TRY(xva_hg_weight_norm_batch(ds.data(), (int)ds.size(), 0, c.st));
     for (const Layer& l : L) {
-        if (l.kind == LK_SN) continue;
+        if (l.kind == LK_SN || l.aux) continue;
         if (l.Cin == 1) XVA_TRY(xva_hg_pad_cols(eff32(c, l, 0), c.W + l.wp[0], c.dt, l.Cout, l.k, l.kp(), c.st));
     }
     return XVA_OK;
@@ -456,13 +495,24 @@ int zero(const Ctx& c, void* p, int64_t bytes) {
 }
 
 // ================================================================== generator ====
-int gen_forward(Ctx& c, const float* P, const float* mel, float* wav_out) {
-    const Plan& pl = c.pl; const GenNet& N = gnet(); const auto& L = pl.gl;
+// gvec (B, gcond) fp32: the VITS decoder's speaker vector (null: no conditioning term)
+int gen_forward(Ctx& c, const float* P, const float* mel, float* wav_out, const float* gvec = nullptr) {
+    const Plan& pl = c.pl; const GenNet& N = *pl.gnetp; const auto& L = pl.gl;
     XVA_TRY(prep_wn(c, L, P));
     Seq xin = c.S(pl.xin), h0 = c.S(pl.h0);
-    XVA_TRY(xva_hg_mel_to_tm(mel, xin.ptr(), c.dt, pl.B, 80, pl.T[0], xin.Hp(), xin.padF, c.st));
+    XVA_TRY(xva_hg_mel_to_tm(mel, xin.ptr(), c.dt, pl.B, N.gin, pl.T[0], xin.Hp(), xin.padF, c.st));
     ConvEpi e0;
     XVA_TRY(hg_conv_fwd(xin, h0, cw(c, L[N.pre], P), e0, c.compute, c.st));                         // conv_pre        (models.py:111)
+    if (N.cond >= 0 && gvec) {                                                                     // o = o + cond_layer(g)   (xvapitch/hifigan.py:247-248)
+        const Layer& cl = L[N.cond];
+        xva_gemm_params gp;
+        memset(&gp, 0, sizeof(gp));
+        gp.A = gvec; gp.B = P + cl.wv; gp.C = c.F(pl.cvec); gp.M = pl.B; gp.N = 512; gp.K = N.gcond; gp.lda = N.gcond; gp.ldb = N.gcond; gp.ldc = 512;
+        gp.batch = 1; gp.batch2 = 1; gp.layout = XVA_GEMM_NT; gp.alpha = 1.f; gp.beta = 1.f; gp.bias = P + cl.bias; gp.splitk = 1; gp.compute = 0;
+        gp.a_dtype = gp.b_dtype = gp.c_dtype = XVA_F32;
+        XVA_TRY(xva_gemm(&gp, c.st));
+        XVA_TRY(xva_hg_add_item_vec(h0.ptr(), c.dt, c.F(pl.cvec), pl.B, h0.Hp(), h0.padF, h0.T, 512, c.st));
+    }
     Seq prev = h0;
     for (int i = 0; i < 4; ++i) {
         Seq u = c.S(pl.u[i]), ua = c.S(pl.ua[i]), xs = c.S(pl.xs[i]);
@@ -525,10 +575,11 @@ int wn_backward(Ctx& c, const std::vector<Layer>& L, const float* P, float* G, c
     const int cnt = li ? n : (int)L.size();
     for (int q = 0; q < cnt; ++q) {
         const Layer& l = L[li ? li[q] : q];
-        if (l.kind == LK_SN) continue;
+        if (l.kind == LK_SN || l.aux) continue;
         xva_wn_desc d;
         memset(&d, 0, sizeof(d));
-        d.dW = c.F(l.dweff[0]); d.v = P + l.wv; d.g = P + l.wg; d.norm = c.F(l.norm[0]); d.dv = G + l.wv; d.dg = G + l.wg;
+        const bool plain = l.kind == LK_PLAIN;           // dv += dW re-laid out; no g
+        d.dW = c.F(l.dweff[0]); d.v = P + l.wv; d.g = plain ? nullptr : P + l.wg; d.norm = c.F(l.norm[0]); d.dv = G + l.wv; d.dg = plain ? nullptr : G + l.wg;
         d.kind = l.kind == LK_WNT ? 1 : 0; d.D0 = l.D0(); d.D1 = l.D1(); d.k = l.k;
         ds.push_back(d);
     }
@@ -565,8 +616,9 @@ Seq as_stage(const Ctx& c, const SeqSpec& s, int T, int C) {
 // Gradient buckets of the generator in backward-completion order (each a contiguous range of the flat buffer):
 // 0..3 = the resblocks of stages 3..0, 4 = conv_pre + ups.0-3, 5 = conv_post.
 constexpr int G_BUCKETS = 6;
-int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav, void* const* events) {
-    const Plan& pl = c.pl; const GenNet& N = gnet(); const auto& L = pl.gl;
+// VITS decoder: gvec as in gen_forward; d_in (B, gin, T0) fp32 (may be null) receives the gradient w.r.t. the input features
+int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav, void* const* events, const float* gvec = nullptr, float* d_in = nullptr) {
+    const Plan& pl = c.pl; const GenNet& N = *pl.gnetp; const auto& L = pl.gl;
     XVA_TRY(zero_dweff(c, L));
     Seq y = c.S(pl.y), dy = c.S(pl.g_dy);
     XVA_TRY(xva_hg_tanh_bwd(d_wav, y.ptr(), dy.ptr(), c.dt, pl.B, pl.T[4], y.Hp(), y.padF, c.st));
@@ -575,7 +627,8 @@ int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav, void* con
         const Layer& l = L[N.post];
         Seq xs = c.S(pl.xs[3]);
         Seq dxs = as_stage(c, pl.g_dxs, pl.T[4], pl.Cst[4]);
-        XVA_TRY(xva_hg_cout1_bwd_weight(dy.ptr(), xs.ptr(), c.F(l.dweff[0]), G + l.bias, c.dt, xs.rows(), xs.C, l.k, 1, l.P, 1, 0.01f, c.st));
+        XVA_TRY(xva_hg_cout1_bwd_weight(dy.ptr(), xs.ptr(), c.F(l.dweff[0]), l.bias >= 0 ? G + l.bias : c.F(pl.dumdb), c.dt, xs.rows(), xs.C, l.k, 1, l.P, 1,
+                                        0.01f, c.st));
         XVA_TRY(xva_hg_cout1_bwd_data(dy.ptr(), eff32(c, l, 0), xs.ptr(), dxs.ptr(), c.dt, xs.rows(), xs.C, l.k, 1, l.P, xs.Hp(), xs.padF, xs.T, 1,
                                       0.01f, c.st));
     }
@@ -649,10 +702,30 @@ int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav, void* con
             XVA_TRY(record(c, events, 3 - i));
         }
     }
-    {   // conv_pre backward (weights only)
+    {   // conv_pre backward (weights; the VITS decoder also wants d(input) and the cond_layer gradients)
         Seq dh0 = as_stage(c, pl.g_dxs, pl.T[0], 512), xin = c.S(pl.xin);
         XVA_TRY(hg_conv_bwd_weight(dh0, xin, cw(c, L[N.pre], P), 0, 0.f, 1.f, c.compute, c.st));
         XVA_TRY(xva_hg_colsum(dh0.ptr(), c.dt, G + L[N.pre].bias, dh0.rows(), 512, 1.f, c.st));
+        if (N.cond >= 0 && gvec) {   // d cvec[b] = sum_t d h0[b][t] (pad rows are zero) ; dW_c += d cvec^T g ; db_c += sum_b d cvec
+            const Layer& cl = L[N.cond];
+            float* dcv = c.F(pl.dcvec);
+            XVA_TRY(zero(c, dcv, (int64_t)pl.B * 512 * 4));
+            const int64_t item = (int64_t)dh0.Hp() * 512 * dh0.es();
+            for (int b = 0; b < pl.B; ++b) XVA_TRY(xva_hg_colsum((const char*)dh0.ptr() + b * item, c.dt, dcv + (int64_t)b * 512, dh0.Hp(), 512, 1.f, c.st));
+            xva_gemm_params gp;
+            memset(&gp, 0, sizeof(gp));
+            gp.A = dcv; gp.B = gvec; gp.C = G + cl.wv; gp.M = 512; gp.N = N.gcond; gp.K = pl.B; gp.lda = 512; gp.ldb = N.gcond; gp.ldc = N.gcond;
+            gp.batch = 1; gp.batch2 = 1; gp.layout = XVA_GEMM_TN; gp.alpha = 1.f; gp.beta = 1.f; gp.accumulate = 1; gp.splitk = 1; gp.compute = 0;
+            gp.a_dtype = gp.b_dtype = gp.c_dtype = XVA_F32;
+            XVA_TRY(xva_gemm(&gp, c.st));
+            XVA_TRY(xva_hg_colsum(dcv, XVA_F32, G + cl.bias, pl.B, 512, 1.f, c.st));
+        }
+        if (d_in) {
+            Seq dxin = c.S(pl.g_dxin);
+            BwdEpi b0;
+            XVA_TRY(hg_conv_bwd_data(dh0, dxin, cw(c, L[N.pre], P), b0, c.compute, c.st));
+            XVA_TRY(xva_seq_to_bct(dxin.ptr(), d_in, c.dt == XVA_BF16 ? 1 : 0, pl.B, N.gin, pl.T[0], dxin.padF, 0, c.st));
+        }
     }
     const int rest[6] = {N.pre, N.ups[0], N.ups[1], N.ups[2], N.ups[3], N.post};
     XVA_TRY(wn_backward(c, L, P, G, rest, 6));
@@ -1008,6 +1081,50 @@ extern "C" int xva_hg_generator_backward_ex(const xva_hg_dims* d, const float* p
 extern "C" int xva_hg_generator_backward(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* ws, int64_t ws_bytes,
                                          void* stream) {
     return xva_hg_generator_backward_ex(d, params_g, grads_g, d_wav, ws, ws_bytes, nullptr, stream);
+}
+// ---- the VITS waveform decoder (xVAPitch): the same generator with a latent input, plain conv_pre / conv_post and the speaker projection ----
+static int vits_dims(const xva_vits_dec_dims* d, xva_hg_dims* hd, const GenNet** gn) {
+    XVA_CHECK_ARG(d && d->in_channels > 0 && d->in_channels % 8 == 0 && d->cond_channels >= 0 && d->cond_channels % 4 == 0,
+                  "vits_dec: in_channels must be a positive multiple of 8, cond_channels a multiple of 4");
+    hd->B = d->B; hd->seg = d->seg; hd->dt = d->dt;
+    *gn = &vits_gnet(d->in_channels, d->cond_channels);
+    return XVA_OK;
+}
+extern "C" int64_t xva_vits_dec_param_floats(const xva_vits_dec_dims* d) { xva_hg_dims hd; const GenNet* gn; return vits_dims(d, &hd, &gn) == XVA_OK ? gn->total : -1; }
+extern "C" int xva_vits_dec_num_tensors(const xva_vits_dec_dims* d) { xva_hg_dims hd; const GenNet* gn; return vits_dims(d, &hd, &gn) == XVA_OK ? (int)gn->t.size() : -1; }
+extern "C" int xva_vits_dec_tensor_info(const xva_vits_dec_dims* d, int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int32_t* ndim,
+                                        int64_t* shape4) {
+    xva_hg_dims hd; const GenNet* gn;
+    XVA_TRY(vits_dims(d, &hd, &gn));
+    XVA_CHECK_ARG(i >= 0 && i < (int)gn->t.size() && name && name_cap > 0, "vits_dec_tensor_info: bad index");
+    const TInfo& ti = gn->t[i];
+    snprintf(name, name_cap, "%s", ti.name.c_str());
+    if (offset) *offset = ti.off;
+    if (numel) *numel = ti.numel;
+    if (ndim) *ndim = ti.ndim;
+    if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = ti.shape[k];
+    return XVA_OK;
+}
+extern "C" int64_t xva_vits_dec_workspace_bytes(const xva_vits_dec_dims* d) {
+    xva_hg_dims hd; const GenNet* gn; Plan p;
+    if (vits_dims(d, &hd, &gn) != XVA_OK || make_plan(&hd, &p, gn) != XVA_OK) return -1;
+    return p.total;
+}
+extern "C" int xva_vits_dec_forward(const xva_vits_dec_dims* d, const float* params, const float* z, const float* g, void* ws, int64_t ws_bytes,
+                                    float* wav_out, void* stream) {
+    xva_hg_dims hd; const GenNet* gn; Ctx c;
+    XVA_TRY(vits_dims(d, &hd, &gn));
+    XVA_TRY(make_ctx(c, &hd, ws, ws_bytes, stream, gn));
+    XVA_CHECK_ARG(params && z && (g || d->cond_channels == 0), "vits_dec_forward: null");
+    return gen_forward(c, params, z, wav_out, g);
+}
+extern "C" int xva_vits_dec_backward(const xva_vits_dec_dims* d, const float* params, float* grads, const float* g, const float* d_wav, float* d_z,
+                                     void* ws, int64_t ws_bytes, void* stream) {
+    xva_hg_dims hd; const GenNet* gn; Ctx c;
+    XVA_TRY(vits_dims(d, &hd, &gn));
+    XVA_TRY(make_ctx(c, &hd, ws, ws_bytes, stream, gn));
+    XVA_CHECK_ARG(params && grads && d_wav && (g || d->cond_channels == 0), "vits_dec_backward: null");
+    return gen_backward(c, params, grads, d_wav, nullptr, g, d_z);
 }
 // Where an activation tensor of the last forward lives in the caller's workspace (parity tests feed a CPU restatement of ONE layer with
 // the engine's own input and compare outputs: storage-dtype rounding is then checked layer by layer instead of through ~50 layers).
