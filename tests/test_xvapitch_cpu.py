@@ -229,3 +229,30 @@ def test_vits_decoder_oracle_matches_reference_golden():
     errs = golden_util.check_samples(mine, [str(k) for k in g["grad_keys"]], g["grad_samples"], g["grad_offsets"], 512)
     assert len(errs) == 233 and errs[0][0] < 1e-2, errs[:4]
     assert float((z.grad - torch.from_numpy(g["dz"])).norm() / torch.from_numpy(g["dz"]).norm()) < 1e-2
+
+
+def test_generator_pass_oracle_matches_reference_train_step_golden():
+    """The CPU restatement of the generator pass (oracle.xvapitch.acoustic_losses + oracle.hifigan.vits_decoder + oracle.mel.mel_m3) vs the vectors
+    recorded from the reference's own train_step with the reference HifiganGenerator as decoder (oracle/gen_golden_xvapitch_genpass.py)."""
+    import torch.nn.functional as F
+    from oracle import golden_util, hifigan as ohg, mel as omel, xvapitch as oxv
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xvapitch_genpass.npz"))
+    cfg = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    t = lambda k: torch.from_numpy(g[k])
+    leaves = {k[3:]: t(k).clone().requires_grad_(t(k).is_floating_point()) for k in g.files if k.startswith("sd/")}
+    dl = {k: v.requires_grad_(True) for k, v in ohg.init_vits_decoder_sd(int(g["dec_seed"]), cfg["latent"], cfg["dvec"]).items()}
+    o = oxv.acoustic_losses(leaves, t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("dvec"), t("lids"), t("eps"), t("noise"), cfg, pitch_padded=t("pitch"))
+    S = int(g["seg"])
+    wav_hat = ohg.vits_decoder(dl, oxv.segment(o["z"], t("slice_ids"), S), F.normalize(t("dvec")).unsqueeze(-1))
+    assert torch.allclose(wav_hat.detach(), t("model_outputs"), rtol=1e-4, atol=1e-5)
+    seg = oxv.segment(t("wav"), t("slice_ids") * 256, S * 256)
+    loss_mel = F.l1_loss(omel.mel_m3(seg.squeeze(1)), omel.mel_m3(wav_hat.squeeze(1)), reduction="none").mean() * 45
+    for k, v in (("loss_mel", loss_mel), ("loss_kl", o["loss_kl"]), ("loss_duration", o["loss_duration"]), ("loss_pitch", o["loss_pitch"])):
+        assert abs(float(v.detach()) - float(g[k])) < 1e-3 * abs(float(g[k])), k
+    (o["loss"] + loss_mel).backward()
+    mine = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items() if v.requires_grad}
+    mine.update({"waveform_decoder." + k: v.grad for k, v in dl.items()})
+    keys = [str(k) for k in g["grad_keys"]]
+    live = set(k for k, nr in zip(keys, g["grad_norms"]) if nr >= 1e-5 * mine[k].numel() ** 0.5)
+    errs = [e for e in golden_util.check_samples(mine, keys, g["grad_samples"], g["grad_offsets"], 256) if e[1] in live]
+    assert len(errs) > 690 and errs[0][0] < 1e-2, errs[:4]

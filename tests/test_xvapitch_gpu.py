@@ -496,3 +496,49 @@ def test_vits_decoder_without_conditioning_and_data_only_input():
     assert _rel(y, yo.detach()) < 1e-4
     worst = sorted(((_rel(v, leaves[k].grad), k) for k, v in dec.grads().items()), reverse=True)
     assert worst[0][0] < 1e-2, worst[:4]
+
+
+def test_generator_pass_against_reference_train_step_golden(golden_dir):
+    """xvapitch/generator_pass.py:GeneratorPass — AcousticTrainPath (--pitch 1) + rand_segments + VitsDecoder + segment + TorchSTFT-mel L1 x 45 —
+    against the vectors recorded from the REFERENCE's own train_step (model.py:681-870) with the reference HifiganGenerator as waveform decoder and
+    the non-adversarial terms of VitsGeneratorLoss (losses.py:187-241), same three random draws: the generated segment 1e-3, the four losses
+    1e-3, and d(loss)/d(every parameter) of the acoustic modules AND the decoder (709 tensors, norms + 256 samples each; 7 in full) at 1e-2 — the
+    LeakyReLU-gate bound of the decoder's backward (oracle/gen_golden_vits_decoder.py); the decoder gradient reaches the posterior encoder through d z."""
+    from oracle import golden_util, hifigan as ohg
+    from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
+    from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+    from xva_trainer_amd.xvapitch.generator_pass import GeneratorPass
+    g = np.load(os.path.join(golden_dir, "xvapitch_genpass.npz"))
+    c = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    ac = AcousticTrainPath(c["vocab"], c["langs"], latent_size=c["latent"], embedded_language_dim=c["lang_dim"], d_vector_dim=c["dvec"],
+                           hidden_channels_ffn=c["ffn"], num_heads=c["heads"], text_layers=c["te_layers"], posterior_layers=c["pe_layers"],
+                           flow_layers=c["flow_layers"], num_flows=c["num_flows"], spec_bins=c["spec_bins"], pitch=True)
+    ac.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")})
+    dec = VitsDecoder(c["latent"], c["dvec"])
+    dsd = ohg.init_vits_decoder_sd(int(g["dec_seed"]), c["latent"], c["dvec"])
+    assert abs(sum(float(v.double().sum()) for v in dsd.values()) - float(g["dec_checksum"])) < 1e-3
+    dec.load_state_dict(dsd)
+    gp = GeneratorPass(ac, dec, spec_segment_size=int(g["seg"]))
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    gp.zero_grad()
+    o = gp(t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("wav"), t("dvec"), t("lids"), pitch_padded=t("pitch"), eps=t("eps"), noise=t("noise"),
+           slice_ids=t("slice_ids"))
+    assert _rel(o["model_outputs"], torch.from_numpy(g["model_outputs"])) < 1e-3 and _rel(o["z_p"], torch.from_numpy(g["z_p"])) < 1e-3
+    for k in ("loss_mel", "loss_kl", "loss_duration", "loss_pitch"):
+        assert abs(float(o[k]) - float(g[k])) < 1e-3 * abs(float(g[k])), (k, float(o[k]), float(g[k]))
+    o["loss"].backward()
+    torch.cuda.synchronize()
+    mine = {k: v.detach().cpu() for k, v in ac.grads().items()}
+    mine.update({"waveform_decoder." + k: v.detach().cpu() for k, v in dec.grads().items()})
+    keys = [str(k) for k in g["grad_keys"]]
+    assert set(keys) == set(mine), sorted(set(keys) ^ set(mine))[:8]
+    live = set(k for k, nr in zip(keys, g["grad_norms"]) if nr >= 1e-5 * mine[k].numel() ** 0.5)
+    errs = [e for e in golden_util.check_samples(mine, keys, g["grad_samples"], g["grad_offsets"], 256) if e[1] in live]
+    full = sorted(((_rel(mine[k[5:]], torch.from_numpy(g[k])), k[5:]) for k in g.files if k.startswith("grad/")), reverse=True)
+    print("generator pass: sampled worst", errs[:4], "of", len(errs), "full worst", full[:3])
+    assert len(errs) > 690 and errs[0][0] < 1e-2, errs[:4]
+    assert full[0][0] < 1e-2, full[:3]
+    # the draw path: without slice_ids the starts are drawn like the reference's rand_segments and stay inside the clips
+    o2 = gp(t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("wav"), t("dvec"), t("lids"), pitch_padded=t("pitch"))
+    ids = o2["slice_ids"].cpu()
+    assert bool((ids >= 0).all()) and bool((ids + int(g["seg"]) <= torch.from_numpy(g["y_lens"])).all())
