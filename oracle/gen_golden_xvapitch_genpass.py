@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import gen_golden_xvapitch_acoustic as ga, golden_util as gu, hifigan as ohg, mel as omel, ref_import, xvapitch as oxv  # noqa: E402
 
-DEC_SEED, SEG = 909, 4
+DEC_SEED, SEG = 909, 8          # the engine wants segments of >= 2048 samples (8 frames); the model trains on 32
 
 
 def main():
