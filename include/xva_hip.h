@@ -355,6 +355,22 @@ int xva_vits_dec_forward(const xva_vits_dec_dims* d, const float* params, const 
                          float* wav_out, void* stream);
 int xva_vits_dec_backward(const xva_vits_dec_dims* d, const float* params, float* grads, const float* g, const float* d_wav, float* d_z,
                           void* workspace, int64_t workspace_bytes, void* stream);
+/* VitsDiscriminator of xVAPitch — python/xvapitch/model.py:1590-1640: nets.0 = the scale discriminator of :1548-1587 (weight norm; grouped k = 41
+ * convolutions with four input channels per group, run as dense products over block-diagonal effective weights), nets.1-5 = the period
+ * discriminators of python/xvapitch/hifigan.py:301-367.  One flat fp32 parameter buffer with the reference's tensor names / shapes
+ * (xva_vits_disc_tensor_info).  The three passes, their loss definitions (python/xvapitch/losses.py:62-84,306-351: LSGAN discriminator / generator
+ * losses, feature loss x 2) and argument conventions are those of xva_hg_disc_forward_ex / _backward_d / _backward_g below; the workspace is its own
+ * (xva_vits_disc_workspace_bytes, zero-filled once when allocated). */
+int64_t xva_vits_disc_param_floats(void);
+int xva_vits_disc_num_tensors(void);
+int xva_vits_disc_tensor_info(int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int32_t* ndim, int64_t* shape4);
+int64_t xva_vits_disc_workspace_bytes(const xva_hg_dims* d);
+int xva_vits_disc_forward(const xva_hg_dims* d, float* params_d, const float* y_real, const float* y_fake, void* workspace, int64_t workspace_bytes,
+                          float* losses, int loss_mask, void* stream);
+int xva_vits_disc_backward_d(const xva_hg_dims* d, float* params_d, float* grads_d, const float* y_real, const float* y_fake, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+int xva_vits_disc_backward_g(const xva_hg_dims* d, float* params_d, const float* y_real, const float* y_fake, float* d_wav, void* workspace,
+                             int64_t workspace_bytes, void* stream);
 /* Stream lanes.  Inside one call the engines issue independent chains on side streams they own (created once per host thread, forked
  * from and joined to the caller's stream with events inside the call): HiFi-GAN — period | scale discriminators, the generator's
  * weight gradients, the three parallel resblocks of a stage; FastPitch — the weight gradients of a layer and the temporal predictors.

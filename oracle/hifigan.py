@@ -407,3 +407,47 @@ def init_vits_decoder_sd(seed, in_channels=192, cond_channels=512):
         sd["cond_layer.weight"] = (torch.rand(UPSAMPLE_INITIAL, cond_channels, 1, generator=g) * 2 - 1) / math.sqrt(cond_channels)
         sd["cond_layer.bias"] = (torch.rand(UPSAMPLE_INITIAL, generator=g) * 2 - 1) / math.sqrt(cond_channels)
     return sd
+
+
+# ------------------------------------------------------------------ VitsDiscriminator (xVAPitch) ----
+VITS_S_CFG = [(1, 16, 15, 1, 1, 7), (16, 64, 41, 4, 4, 20), (64, 256, 41, 4, 16, 20), (256, 1024, 41, 4, 64, 20), (1024, 1024, 41, 4, 256, 20),
+              (1024, 1024, 5, 1, 1, 2)]
+
+
+def vits_disc_s(sd, pre, x):
+    """DiscriminatorS.forward of python/xvapitch/model.py:1548-1587 (weight norm)."""
+    fmap = []
+    for i, (cin, cout, k, s, g, p) in enumerate(VITS_S_CFG):
+        x = F.conv1d(x, wn_weight(sd, "%sconvs.%d." % (pre, i)), sd["%sconvs.%d.bias" % (pre, i)], stride=s, padding=p, groups=g)
+        x = F.leaky_relu(x, LRELU_SLOPE)
+        fmap.append(x)
+    x = F.conv1d(x, wn_weight(sd, pre + "conv_post."), sd[pre + "conv_post.bias"], padding=1)
+    fmap.append(x)
+    return torch.flatten(x, 1, -1), fmap
+
+
+def vits_disc(sd, y, y_hat):
+    """VitsDiscriminator.forward (python/xvapitch/model.py:1609-1640): nets.0 the scale discriminator, nets.1-5 periods 2, 3, 5, 7, 11.
+    Returns (scores real, feats real, scores fake, feats fake)."""
+    rs, fr, gs, fg = [], [], [], []
+    for n in range(6):
+        pre = "nets.%d." % n
+        f = (lambda t: vits_disc_s(sd, pre, t)) if n == 0 else (lambda t: disc_p(sd, pre, t, PERIODS[n - 1]))
+        r, f1 = f(y)
+        g, f2 = f(y_hat)
+        rs.append(r); fr.append(f1); gs.append(g); fg.append(f2)
+    return rs, fr, gs, fg
+
+
+def init_vits_disc_sd(seed):
+    """Seeded state_dict in the reference key order (VitsDiscriminator.state_dict())."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for i, (ci, co, k, s, gr, p) in enumerate(VITS_S_CFG + [(1024, 1, 3, 1, 1, 1)]):
+        _wn(sd, "nets.0.%s" % ("convs.%d." % i if i < 6 else "conv_post."), (co, ci // gr, k), g)
+    chans = [(1, 32), (32, 128), (128, 512), (512, 1024), (1024, 1024)]
+    for d in range(5):
+        for i, (ci, co) in enumerate(chans):
+            _wn(sd, "nets.%d.convs.%d." % (d + 1, i), (co, ci, 5, 1), g)
+        _wn(sd, "nets.%d.conv_post." % (d + 1), (1, 1024, 3, 1), g)
+    return sd

@@ -256,3 +256,25 @@ def test_generator_pass_oracle_matches_reference_train_step_golden():
     live = set(k for k, nr in zip(keys, g["grad_norms"]) if nr >= 1e-5 * mine[k].numel() ** 0.5)
     errs = [e for e in golden_util.check_samples(mine, keys, g["grad_samples"], g["grad_offsets"], 256) if e[1] in live]
     assert len(errs) > 690 and errs[0][0] < 1e-2, errs[:4]
+
+
+def test_vits_discriminator_oracle_matches_reference_golden():
+    """oracle/hifigan.py:vits_disc + the loss restatements vs the vectors recorded from the reference VitsDiscriminator / loss functions."""
+    from oracle import golden_util, hifigan as ohg
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vits_disc.npz"))
+    seed, B, seg = (int(v) for v in g["cfg"])
+    leaves = {k: v.requires_grad_(True) for k, v in ohg.init_vits_disc_sd(seed).items()}
+    y = torch.from_numpy(g["y"]).unsqueeze(1)
+    yh = torch.from_numpy(g["y_hat"]).unsqueeze(1).requires_grad_(True)
+    rs, fr, gs, fg = ohg.vits_disc(leaves, y, yh.detach())
+    ld = ohg.discriminator_loss(rs, gs)
+    assert abs(float(ld.detach()) - float(g["loss_disc"])) < 1e-4 * float(g["loss_disc"])
+    ld.backward()
+    errs = golden_util.check_samples({k: v.grad for k, v in leaves.items()}, [str(k) for k in g["grad_keys"]], g["grad_samples"], g["grad_offsets"], 512)
+    assert len(errs) == 111 and errs[0][0] < 1e-4, errs[:4]
+    rs, fr, gs, fg = ohg.vits_disc({k: v.detach() for k, v in leaves.items()}, y, yh)
+    lg, lf = ohg.generator_loss(gs), ohg.feature_loss([[t.detach() for t in f] for f in fr], fg)
+    assert abs(float(lg.detach()) - float(g["loss_gen"])) < 1e-4 * float(g["loss_gen"]) and abs(float(lf.detach()) - float(g["loss_feat"])) < 1e-4 * float(g["loss_feat"])
+    (lg + lf).backward()
+    ref = torch.from_numpy(g["d_wav"]).unsqueeze(1)
+    assert float((yh.grad - ref).norm() / ref.norm()) < 1e-3

@@ -542,3 +542,42 @@ def test_generator_pass_against_reference_train_step_golden(golden_dir):
     o2 = gp(t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("wav"), t("dvec"), t("lids"), pitch_padded=t("pitch"))
     ids = o2["slice_ids"].cpu()
     assert bool((ids >= 0).all()) and bool((ids + int(g["seg"]) <= torch.from_numpy(g["y_lens"])).all())
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_vits_discriminator_against_reference_golden(golden_dir, compute):
+    """xvapitch/discriminator.py:VitsDiscriminator (xva_vits_disc_*: five period discriminators + the scale discriminator whose grouped k = 41
+    convolutions — four input channels per group — run as dense products over block-diagonal weights) against the vectors recorded from the
+    REFERENCE VitsDiscriminator and loss functions (model.py:1548-1640, losses.py:64-84,331-343).  fp32: the three losses 1e-4, d(loss_gen + loss_feat)/d y_hat of the G pass 1e-3, the 111 parameter
+    gradients of the D pass 1e-3 except a handful of the first period discriminator's (≤ 5e-3 on 512 samples: LeakyReLU gates within rounding
+    of zero, as for the decoder; the scale discriminator's land at 5e-7).  bf16: losses 2e-2, gradient norms 10 %."""
+    from oracle import golden_util, hifigan as ohg
+    from xva_trainer_amd.xvapitch.discriminator import VitsDiscriminator
+    g = np.load(os.path.join(golden_dir, "vits_disc.npz"))
+    seed, B, seg = (int(v) for v in g["cfg"])
+    sd = ohg.init_vits_disc_sd(seed)
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(g["sd_checksum"])) < 1e-3
+    D = VitsDiscriminator(compute=compute)
+    assert list(D.state_dict()) == list(sd)                     # same tensors in the reference's order
+    D.load_state_dict(sd)
+    y, yh = torch.from_numpy(g["y"]).cuda(), torch.from_numpy(g["y_hat"]).cuda()
+    D.zero_grad()
+    loss_disc = float(D.d_pass(y, yh))
+    loss_gen, loss_feat, d_wav = D.g_pass(y, yh)
+    torch.cuda.synchronize()
+    mine = {k: v.detach().cpu() for k, v in D.grads().items()}
+    keys = [str(k) for k in g["grad_keys"]]
+    rel = lambda a, b: abs(a - b) / abs(b)
+    el = max(rel(loss_disc, float(g["loss_disc"])), rel(float(loss_gen), float(g["loss_gen"])), rel(float(loss_feat), float(g["loss_feat"])))
+    edw = _rel(d_wav, torch.from_numpy(g["d_wav"]))
+    if compute == "fp32":
+        errs = golden_util.check_samples(mine, keys, g["grad_samples"], g["grad_offsets"], 512)
+        full = sorted(((_rel(mine[k[5:]], torch.from_numpy(g[k])), k[5:]) for k in g.files if k.startswith("grad/")), reverse=True)
+        print("vits disc fp32: losses %.2e d_wav %.2e sampled worst %s full worst %s" % (el, edw, errs[:3], full[:3]))
+        assert el < 1e-4 and edw < 1e-3
+        assert len(errs) == 111 and errs[0][0] < 5e-3 and errs[4][0] < 1e-3, errs[:6]
+        assert full[0][0] < 2e-3, full[:4]
+    else:
+        nerr = sorted(((abs(float(mine[k].norm()) - float(n)) / float(n), k) for k, n in zip(keys, g["grad_norms"])), reverse=True)
+        print("vits disc bf16: losses %.2e d_wav %.2e worst norm errors %s" % (el, edw, nerr[:3]))
+        assert el < 2e-2 and edw < 0.1 and nerr[0][0] < 0.1, (el, edw, nerr[:3])

@@ -741,6 +741,7 @@ extern "C" int xva_hg_add_item_vec(void* seq, int dt, const float* vec, int B, i
 // weight_norm (old API, dim 0): w = g * v / ||v||  (torch.nn.utils.weight_norm; models.py:21-108)
 // v: (D0, inner) fp32 in the checkpoint layout; writes the effective weight in a GEMM layout given by an index map:
 //   kind 0 (Conv, v = (Cout, Cin_g, k)):       eff[o][j*Cin_g + i]              = w[o][i][j]         (tap-major)
+//   kind 2 (grouped Conv as dense, v = (Cout, Cin_g, k)): eff[o][j*Cin + (o / Cout_g)*Cin_g + i] = w[o][i][j], zero elsewhere (s = Cin, pconv = Cout_g)
 //   kind 1 (ConvTranspose, v = (Cin, Cout, k)): effF[phase][co][m*Cin + ci]      = w[ci][co][j0(phase) + m*s]   (forward, per phase)
 //                                               effB[ci][j*Cout + co]            = w[ci][co][j]                  (backward-data conv)
 // One block per dim-0 index.  norm[o] saved for the backward.
@@ -761,6 +762,8 @@ __device__ __forceinline__ void hg_weight_norm_fwd_body(const float* __restrict_
         float w = vo[idx] * sc;
         if (kind == 0) {
             hg_st(eff, (int64_t)o * inner + (int64_t)j * D1 + i1, dt, w);
+        } else if (kind == 2) {   // grouped conv as a dense block-diagonal weight: s = Cin (all groups), pconv = Cout per group; the rest stays zero
+            hg_st(eff, ((int64_t)o * k + j) * s + (int64_t)(o / pconv) * D1 + i1, dt, w);
         } else {
             // o = ci, i1 = co ; forward phases: t_out = s*q + phi uses taps j = j0 + m*s with j0 = (phi + pconv) % s
             int ntap = k / s;
@@ -788,19 +791,21 @@ __global__ void hg_weight_norm_fwd_batch_kernel(xva_wn_batch b) {
 // dg[o] = sum dW * v / ||v|| ; dv = (g/||v||) * (dW - (dg/||v||) * v)
 __device__ __forceinline__ void hg_weight_norm_bwd_body(const float* __restrict__ dW, const float* __restrict__ v, const float* __restrict__ gparam,
                                                         const float* __restrict__ norm, float* __restrict__ dv, float* __restrict__ dg, int kind, int D0,
-                                                        int D1, int k, int o) {
+                                                        int D1, int k, int o, int s = 0, int pconv = 1) {
     __shared__ float sh[16];
     const int inner = D1 * k;
     const float* vo = v + (int64_t)o * inner;
-    const float* dwo = dW + (int64_t)o * inner;
+    // kind 2: dW is the gradient of the dense block-diagonal weight; only this row's own block is read (tap pitch s = Cin)
+    const int tp = kind == 2 ? s : D1;
+    const float* dwo = kind == 2 ? dW + (int64_t)o * k * s + (int64_t)(o / pconv) * D1 : dW + (int64_t)o * inner;
     if (!gparam) {                                    // plain weight: dv += dW in the checkpoint layout
-        for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) dv[(int64_t)o * inner + idx] += dwo[(int64_t)(idx % k) * D1 + idx / k];
+        for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) dv[(int64_t)o * inner + idx] += dwo[(int64_t)(idx % k) * tp + idx / k];
         return;
     }
     float acc = 0.f;
     for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) {
         int i1 = idx / k, j = idx % k;
-        acc += dwo[(int64_t)j * D1 + i1] * vo[idx];
+        acc += dwo[(int64_t)j * tp + i1] * vo[idx];
     }
     acc = xva_block_sum(acc, sh);
     float n = norm[o], g = gparam[o];
@@ -808,7 +813,7 @@ __device__ __forceinline__ void hg_weight_norm_bwd_body(const float* __restrict_
     if (threadIdx.x == 0) dg[o] += dgo;
     for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) {
         int i1 = idx / k, j = idx % k;
-        dv[(int64_t)o * inner + idx] += (g / n) * (dwo[(int64_t)j * D1 + i1] - (dgo / n) * vo[idx]);
+        dv[(int64_t)o * inner + idx] += (g / n) * (dwo[(int64_t)j * tp + i1] - (dgo / n) * vo[idx]);
     }
 }
 __global__ void hg_weight_norm_bwd_kernel(const float* __restrict__ dW, const float* __restrict__ v, const float* __restrict__ gparam,
@@ -820,7 +825,7 @@ __global__ void hg_weight_norm_bwd_batch_kernel(xva_wn_batch b) {
     int l = 0;
     while (l + 1 < b.n && (int)blockIdx.x >= b.d[l + 1].block0) ++l;
     const xva_wn_desc& d = b.d[l];
-    hg_weight_norm_bwd_body(d.dW, d.v, d.g, d.norm, d.dv, d.dg, d.kind, d.D0, d.D1, d.k, (int)blockIdx.x - d.block0);
+    hg_weight_norm_bwd_body(d.dW, d.v, d.g, d.norm, d.dv, d.dg, d.kind, d.D0, d.D1, d.k, (int)blockIdx.x - d.block0, d.s, d.pconv);
 }
 // launches: `n` layers in chunks of XVA_WN_BATCH
 extern "C" int xva_hg_weight_norm_batch(const xva_wn_desc* descs, int n, int backward, void* stream) {
@@ -831,10 +836,10 @@ extern "C" int xva_hg_weight_norm_batch(const xva_wn_desc* descs, int n, int bac
         int blocks = 0;
         for (int i = 0; i < b.n; ++i) {
             b.d[i] = descs[i0 + i];
-            XVA_CHECK_ARG(b.d[i].v && b.d[i].norm && (b.d[i].g || b.d[i].kind == 0) &&
-                          (backward ? (b.d[i].dW && b.d[i].dv && (b.d[i].dg || !b.d[i].g)) : (b.d[i].eff && (b.d[i].kind == 0 || b.d[i].effB))),
+            XVA_CHECK_ARG(b.d[i].v && b.d[i].norm && (b.d[i].g || b.d[i].kind != 1) &&
+                          (backward ? (b.d[i].dW && b.d[i].dv && (b.d[i].dg || !b.d[i].g)) : (b.d[i].eff && (b.d[i].kind != 1 || b.d[i].effB))),
                           "weight_norm_batch: null tensor in layer %d", i0 + i);
-            XVA_CHECK_ARG(backward || b.d[i].kind == 0 || (b.d[i].k % b.d[i].s == 0), "weight_norm_batch: transposed conv needs k %% s == 0");
+            XVA_CHECK_ARG(backward || b.d[i].kind != 1 || (b.d[i].k % b.d[i].s == 0), "weight_norm_batch: transposed conv needs k %% s == 0");
             b.d[i].block0 = blocks;
             blocks += b.d[i].D0;
         }

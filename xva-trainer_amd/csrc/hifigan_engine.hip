@@ -61,6 +61,7 @@ struct Layer {
     int kind = LK_WN;
     int Cin = 0, Cout = 0, k = 1, s = 1, d = 1, P = 0, groups = 1;
     bool has_bias = true;   // LK_PLAIN only: conv_post of the VITS decoder has none
+    bool dense = false;     // grouped convolution run as ONE dense product over a block-diagonal effective weight (groups of 4 channels: VITS scale discriminator)
     bool aux = false;       // not a sequence convolution (cond_layer: a (B, cond) x (cond, C) product): no effective-weight copy
     int64_t bias = -1, wg = -1, wv = -1, bu = -1, bv = -1;   // offsets (floats) in the flat parameter buffer
     // workspace byte offsets
@@ -70,6 +71,7 @@ struct Layer {
     int D0() const { return kind == LK_WNT ? Cin : Cout; }
     int D1() const { return kind == LK_WNT ? Cout : Cin / groups; }
     int64_t wnumel() const { return (int64_t)D0() * D1() * k; }
+    int64_t effnumel() const { return dense ? (int64_t)Cout * Cin * k : wnumel(); }
 };
 
 struct Net {
@@ -154,14 +156,27 @@ struct GenNet : Net {
         finalize(buf);
     }
 };
+// vits: xVAPitch's VitsDiscriminator (python/xvapitch/model.py:1548-1640): nets.0 = ONE scale discriminator (weight norm; Conv1d 1->16 k15,
+// 16->64 / 64->256 / 256->1024 / 1024->1024 k41 s4 in groups of FOUR input channels, 1024->1024 k5, post 1024->1 k3), nets.1-5 = the period
+// discriminators of python/xvapitch/hifigan.py:301-367 (same as HiFi-GAN's).  The grouped layers run dense (Layer::dense).
 struct DiscNet : Net {
     int mpd[NPER][6], msd[3][8];
-    DiscNet() {
+    bool vits;
+    DiscNet(bool vits_ = false) : vits(vits_) {
         std::vector<TInfo> buf;
         const int pc[5][2] = {{1, 32}, {32, 128}, {128, 512}, {512, 1024}, {1024, 1024}};
+        if (vits) {   // reference key order: nets.0 (scale) first
+            const int vc[7][6] = {{1, 16, 15, 1, 1, 7}, {16, 64, 41, 4, 4, 20}, {64, 256, 41, 4, 16, 20}, {256, 1024, 41, 4, 64, 20},
+                                  {1024, 1024, 41, 4, 256, 20}, {1024, 1024, 5, 1, 1, 2}, {1024, 1, 3, 1, 1, 1}};
+            for (int i = 0; i < 7; ++i) {
+                Layer l; l.kind = LK_WN;
+                l.Cin = vc[i][0]; l.Cout = vc[i][1]; l.k = vc[i][2]; l.s = vc[i][3]; l.groups = vc[i][4]; l.P = vc[i][5]; l.dense = l.groups > 1;
+                msd[0][i] = add_layer(std::string("nets.0.") + (i < 6 ? "convs." + std::to_string(i) + "." : std::string("conv_post.")), l, &buf);
+            }
+        }
         conv2d = true;
         for (int d = 0; d < NPER; ++d) {
-            std::string pre = "mpd.discriminators." + std::to_string(d) + ".";
+            std::string pre = vits ? "nets." + std::to_string(d + 1) + "." : "mpd.discriminators." + std::to_string(d) + ".";
             for (int i = 0; i < 5; ++i) {
                 Layer l; l.Cin = pc[i][0]; l.Cout = pc[i][1]; l.k = 5; l.s = i < 4 ? 3 : 1; l.P = 2;
                 mpd[d][i] = add_layer(pre + "convs." + std::to_string(i) + ".", l, &buf);
@@ -171,7 +186,7 @@ struct DiscNet : Net {
         conv2d = false;
         const int sc[8][6] = {{1, 128, 15, 1, 1, 7}, {128, 128, 41, 2, 4, 20}, {128, 256, 41, 2, 16, 20}, {256, 512, 41, 4, 16, 20},
                               {512, 1024, 41, 4, 16, 20}, {1024, 1024, 41, 1, 16, 20}, {1024, 1024, 5, 1, 1, 2}, {1024, 1, 3, 1, 1, 1}};
-        for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < 3 && !vits; ++d) {
             std::string pre = "msd.discriminators." + std::to_string(d) + ".";
             for (int i = 0; i < 8; ++i) {
                 Layer l; l.kind = d == 0 ? LK_SN : LK_WN;
@@ -193,6 +208,7 @@ const GenNet& vits_gnet(int gin, int gcond) {
     return *nets.back();
 }
 const DiscNet& dnet() { static DiscNet n; return n; }
+const DiscNet& vits_dnet() { static DiscNet n(true); return n; }
 
 // ------------------------------------------------------------------ workspace plan ----
 struct Bump {
@@ -220,6 +236,7 @@ struct Plan {
     int64_t sn_tmp, losses, skws[4], skws_bytes, dwav_lane[4], total;   // per stream lane: split-K slabs, partial d(waveform)
     // VITS decoder variant (gnetp != &gnet()): d(input), the speaker projection and its gradient, a zero bias / dummy bias gradient for conv_post
     const GenNet* gnetp = nullptr;
+    const DiscNet* dnetp = nullptr;     // null: no discriminators in this plan
     SeqSpec g_dxin;
     int64_t cvec = -1, dcvec = -1, zbias = -1, dumdb = -1;
 };
@@ -238,7 +255,7 @@ Seq seq(const SeqSpec& s, char* base, int dt) {
 
 void plan_layer_ws(Layer& l, Bump& b, int es, bool grads) {
     if (l.aux) return;
-    const int64_t n = l.wnumel();
+    const int64_t n = l.effnumel();
     const int passes = l.kind == LK_SN ? 2 : 1;
     for (int p = 0; p < passes; ++p) {
         l.eff[p] = b.take(n * es + 64);
@@ -256,14 +273,16 @@ void plan_layer_grads(std::vector<Layer>& L, Bump& b, int64_t* begin, int64_t* e
         if (l.aux) continue;
         const int passes = l.kind == LK_SN ? 2 : 1;
         for (int p = 0; p < passes; ++p) {
-            l.dweff[p] = b.take(l.wnumel() * 4);
+            l.dweff[p] = b.take(l.effnumel() * 4);
             if (l.Cin == 1) l.dwp[p] = b.take((int64_t)l.Cout * l.kp() * 4);
         }
     }
     *end = b.cur;
 }
 
-int make_plan(const xva_hg_dims* d, Plan* p, const GenNet* gn = nullptr) {
+// gn / dn: the networks this plan serves — (null, null) = HiFi-GAN v1 generator + MPD + MSD; (vits decoder, null) = the decoder alone;
+// (null, vits discriminator) = VitsDiscriminator alone
+int make_plan(const xva_hg_dims* d, Plan* p, const GenNet* gn = nullptr, const DiscNet* dn = nullptr) {
     XVA_CHECK_ARG(d && d->B > 0 && d->seg >= 2048 && d->seg % 256 == 0, "hifigan: bad dims (segment must be a multiple of 256, >= 2048)");
     XVA_CHECK_ARG(d->dt == XVA_F32 || d->dt == XVA_BF16, "hifigan: bad dtype");
     p->B = d->B; p->seg = d->seg; p->dt = d->dt; p->es = d->dt == XVA_BF16 ? 2 : 4;
@@ -272,43 +291,47 @@ int make_plan(const xva_hg_dims* d, Plan* p, const GenNet* gn = nullptr) {
     p->Cst[0] = 512; p->Cst[1] = 256; p->Cst[2] = 128; p->Cst[3] = 64; p->Cst[4] = 32;
     Bump b;
     const bool vits = gn != nullptr;                 // decoder only: no discriminator tensors in the workspace
+    const bool vd = dn != nullptr;                   // VitsDiscriminator only: no generator tensors
     p->gnetp = vits ? gn : &gnet();
-    p->gl = p->gnetp->L;
-    if (!vits) p->dl = dnet().L;
+    p->dnetp = vits ? nullptr : (vd ? dn : &dnet());
+    if (!vd) p->gl = p->gnetp->L;
+    if (!vits) p->dl = p->dnetp->L;
     for (auto& l : p->gl) plan_layer_ws(l, b, es, true);
     for (auto& l : p->dl) plan_layer_ws(l, b, es, true);
     plan_layer_grads(p->gl, b, &p->dw_g[0], &p->dw_g[1]);
     plan_layer_grads(p->dl, b, &p->dw_d[0], &p->dw_d[1]);
     const int PG = 32;   // generator pad rows (>= max dilation * (k - 1) / 2 = 25)
-    p->xin = mk(b, es, B, p->T[0], p->gnetp->gin, PG, PG);
-    if (vits) {
-        p->g_dxin = mk(b, es, B, p->T[0], p->gnetp->gin, PG, PG);
-        p->cvec = b.take((int64_t)B * 512 * 4); p->dcvec = b.take((int64_t)B * 512 * 4);
-        p->zbias = b.take(256); p->dumdb = b.take(256);
-    }
-    p->h0 = mk(b, es, B, p->T[0], 512, PG, PG);
-    for (int i = 0; i < 4; ++i) {
-        const int T = p->T[i + 1], C = p->Cst[i + 1];
-        p->u[i] = mk(b, es, B, T, C, PG, PG);
-        p->ua[i] = mk(b, es, B, T, C, PG, PG);
-        for (int j = 0; j < 3; ++j) {
-            for (int m = 0; m < 3; ++m) p->xt1[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG);
-            for (int m = 0; m < 2; ++m) { p->xr[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG); p->xra[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG); }
+    if (!vd) {
+        p->xin = mk(b, es, B, p->T[0], p->gnetp->gin, PG, PG);
+        if (vits) {
+            p->g_dxin = mk(b, es, B, p->T[0], p->gnetp->gin, PG, PG);
+            p->cvec = b.take((int64_t)B * 512 * 4); p->dcvec = b.take((int64_t)B * 512 * 4);
+            p->zbias = b.take(256); p->dumdb = b.take(256);
         }
-        p->xs[i] = mk(b, es, B, T, C, PG, PG);
-    }
-    p->y = mk(b, es, B, p->T[4], 1, PG, PG);
-    {   // backward scratch sized for the largest stage (C * T is constant from stage 2 on)
-        int64_t best = 0; int bi = 0;
-        for (int i = 0; i < 4; ++i) { int64_t v = (int64_t)p->Cst[i + 1] * (p->T[i + 1] + 2 * PG); if (v > best) { best = v; bi = i; } }
-        const int T = p->T[bi + 1], C = p->Cst[bi + 1];
-        p->g_dxs = mk(b, es, B, T, C, PG, PG); p->g_da = mk(b, es, B, T, C, PG, PG); p->g_db = mk(b, es, B, T, C, PG, PG);
-        p->g_dt1 = mk(b, es, B, T, C, PG, PG); p->g_du = mk(b, es, B, T, C, PG, PG);
-        p->g_dy = mk(b, es, B, p->T[4], 1, PG, PG);
-        for (int j = 0; j < 3; ++j) {
-            p->g_daj[j] = j == 0 ? p->g_da : mk(b, es, B, T, C, PG, PG);
-            p->g_dbj[j] = j == 0 ? p->g_db : mk(b, es, B, T, C, PG, PG);
-            for (int m = 0; m < 3; ++m) p->g_dt1jm[j][m] = (j == 0 && m == 0) ? p->g_dt1 : mk(b, es, B, T, C, PG, PG);
+        p->h0 = mk(b, es, B, p->T[0], 512, PG, PG);
+        for (int i = 0; i < 4; ++i) {
+            const int T = p->T[i + 1], C = p->Cst[i + 1];
+            p->u[i] = mk(b, es, B, T, C, PG, PG);
+            p->ua[i] = mk(b, es, B, T, C, PG, PG);
+            for (int j = 0; j < 3; ++j) {
+                for (int m = 0; m < 3; ++m) p->xt1[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG);
+                for (int m = 0; m < 2; ++m) { p->xr[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG); p->xra[i * 3 + j][m] = mk(b, es, B, T, C, PG, PG); }
+            }
+            p->xs[i] = mk(b, es, B, T, C, PG, PG);
+        }
+        p->y = mk(b, es, B, p->T[4], 1, PG, PG);
+        {   // backward scratch sized for the largest stage (C * T is constant from stage 2 on)
+            int64_t best = 0; int bi = 0;
+            for (int i = 0; i < 4; ++i) { int64_t v = (int64_t)p->Cst[i + 1] * (p->T[i + 1] + 2 * PG); if (v > best) { best = v; bi = i; } }
+            const int T = p->T[bi + 1], C = p->Cst[bi + 1];
+            p->g_dxs = mk(b, es, B, T, C, PG, PG); p->g_da = mk(b, es, B, T, C, PG, PG); p->g_db = mk(b, es, B, T, C, PG, PG);
+            p->g_dt1 = mk(b, es, B, T, C, PG, PG); p->g_du = mk(b, es, B, T, C, PG, PG);
+            p->g_dy = mk(b, es, B, p->T[4], 1, PG, PG);
+            for (int j = 0; j < 3; ++j) {
+                p->g_daj[j] = j == 0 ? p->g_da : mk(b, es, B, T, C, PG, PG);
+                p->g_dbj[j] = j == 0 ? p->g_db : mk(b, es, B, T, C, PG, PG);
+                for (int m = 0; m < 3; ++m) p->g_dt1jm[j][m] = (j == 0 && m == 0) ? p->g_dt1 : mk(b, es, B, T, C, PG, PG);
+            }
         }
     }
     // ---- MPD: sequences (b, w); real items first, then fake
@@ -332,7 +355,20 @@ int make_plan(const xva_hg_dims* d, Plan* p, const GenNet* gn = nullptr) {
     }
     // ---- MSD
     p->Tw[0] = d->seg; p->Tw[1] = p->Tw[0] / 2 + 1; p->Tw[2] = p->Tw[1] / 2 + 1;
-    for (int sc = 0; sc < 3 && !vits; ++sc) {
+    if (vd) {   // the one scale discriminator of VitsDiscriminator: real + fake stacked, 7 layers
+        int T[8];
+        T[0] = d->seg; T[1] = T[0];
+        const int str[7] = {1, 4, 4, 4, 4, 1, 1};
+        for (int i = 2; i <= 7; ++i) T[i] = (T[i - 1] - 1) / str[i - 1] + 1;
+        const int ch[8] = {1, 16, 64, 256, 1024, 1024, 1024, 1};
+        for (int which = 0; which < 2; ++which) {
+            SeqSpec* t = which == 0 ? p->st[0][0] : p->sd[0][0];
+            for (int i = 1; i <= 7; ++i) t[i] = mk(b, es, 2 * B, T[i], ch[i], 24, 24);
+            p->sxc[0][0][which] = mk(b, es, 2 * B, T[1], 16, 24, 24);
+        }
+        for (int sc = 0; sc < 3; ++sc) p->dwav_s[sc] = -1;
+    }
+    for (int sc = 0; sc < 3 && !vits && !vd; ++sc) {
         int T[9];
         T[0] = p->Tw[sc]; T[1] = T[0];
         const int str[8] = {1, 2, 2, 4, 4, 1, 1, 1};
@@ -348,7 +384,7 @@ int make_plan(const xva_hg_dims* d, Plan* p, const GenNet* gn = nullptr) {
         for (int rf = 0; rf < 2; ++rf) p->wav_s[sc][rf] = sc == 0 ? -1 : b.take((int64_t)B * p->Tw[sc] * 4);
         p->dwav_s[sc] = b.take((int64_t)B * p->Tw[sc] * 4);
     }
-    p->sn_tmp = vits ? -1 : b.take((1024 * 41 * 64 + 1024 + 64) * 4);
+    p->sn_tmp = (vits || vd) ? -1 : b.take((1024 * 41 * 64 + 1024 + 64) * 4);
     p->losses = b.take(64 * 4);
     p->skws_bytes = (int64_t)96 << 20;      // split-K slabs of the weight-gradient GEMMs (largest: 3 x 1024 x 5120 fp32)
     for (int l = 0; l < 4; ++l) { p->skws[l] = b.take(p->skws_bytes); p->dwav_lane[l] = b.take((int64_t)B * d->seg * 4); }
@@ -420,8 +456,8 @@ struct Ctx;
 struct Lanes { Ctx* c[MAXL]; int n; };
 static void use_slabs(const Ctx& c);
 
-int make_ctx(Ctx& c, const xva_hg_dims* d, void* ws, int64_t ws_bytes, void* st, const GenNet* gn = nullptr) {
-    XVA_TRY(make_plan(d, &c.pl, gn));
+int make_ctx(Ctx& c, const xva_hg_dims* d, void* ws, int64_t ws_bytes, void* st, const GenNet* gn = nullptr, const DiscNet* dn = nullptr) {
+    XVA_TRY(make_plan(d, &c.pl, gn, dn));
     XVA_CHECK_ARG(ws && ((uintptr_t)ws % 256) == 0, "hifigan: workspace null or not 256-byte aligned");
     XVA_CHECK_ARG(ws_bytes >= c.pl.total, "hifigan: workspace too small (%ld < %ld bytes)", (long)ws_bytes, (long)c.pl.total);
     c.W = (char*)ws; c.st = st; c.dt = d->dt; c.compute = d->dt == XVA_BF16 ? 1 : 0;
@@ -454,7 +490,7 @@ static int join_lanes(const Ctx* cs, int n) {
 
 ConvW cw(const Ctx& c, const Layer& l, const float* params, int pass = 0) {
     ConvW w; w.eff = c.W + l.eff[pass]; w.bias = l.bias >= 0 ? params + l.bias : c.F(c.pl.zbias); w.dweff = l.dweff[pass] >= 0 ? c.F(l.dweff[pass]) : nullptr;
-    w.Cin = l.Cin; w.Cout = l.Cout; w.k = l.k; w.s = l.s; w.d = l.d; w.P = l.P; w.groups = l.groups;
+    w.Cin = l.Cin; w.Cout = l.Cout; w.k = l.k; w.s = l.s; w.d = l.d; w.P = l.P; w.groups = l.dense ? 1 : l.groups;
     return w;
 }
 ConvTW ctw(const Ctx& c, const Layer& l, const float* params) {
@@ -475,6 +511,7 @@ int prep_wn(const Ctx& c, const std::vector<Layer>& L, const float* params) {
         d.v = params + l.wv; d.g = l.kind == LK_PLAIN ? nullptr : params + l.wg; d.norm = c.F(l.norm[0]);   // g == null: effective weight = v
         d.eff = c.W + l.eff[0]; d.effB = l.effB >= 0 ? c.W + l.effB : nullptr;
         d.dt = c.dt; d.kind = l.kind == LK_WNT ? 1 : 0; d.D0 = l.D0(); d.D1 = l.D1(); d.k = l.k; d.s = l.s; d.pconv = l.P;
+        if (l.dense) { d.kind = 2; d.s = l.Cin; d.pconv = l.Cout / l.groups; }
         ds.push_back(d);
         if (l.eff32[0] >= 0 && c.dt != XVA_F32) {   // fp32 copy for the 1-channel direct kernels
             d.eff = c.W + l.eff32[0]; d.effB = nullptr; d.dt = XVA_F32; d.kind = 0;
@@ -581,6 +618,7 @@ int wn_backward(Ctx& c, const std::vector<Layer>& L, const float* P, float* G, c
         const bool plain = l.kind == LK_PLAIN;           // dv += dW re-laid out; no g
         d.dW = c.F(l.dweff[0]); d.v = P + l.wv; d.g = plain ? nullptr : P + l.wg; d.norm = c.F(l.norm[0]); d.dv = G + l.wv; d.dg = plain ? nullptr : G + l.wg;
         d.kind = l.kind == LK_WNT ? 1 : 0; d.D0 = l.D0(); d.D1 = l.D1(); d.k = l.k;
+        if (l.dense) { d.kind = 2; d.s = l.Cin; d.pconv = l.Cout / l.groups; }
         ds.push_back(d);
     }
     if (ds.empty()) return XVA_OK;
@@ -894,11 +932,17 @@ struct DiscSet { DiscRun run; const SeqSpec* rt; int r0, f0, nf; bool sn; const 
 
 // enumerate the 8 discriminators: (MPD x 5, then MSD x 3).  For spectral-norm scale 0 the real / fake passes are separate sets.
 void build_sets(Ctx& c, const float* yr, const float* yg, std::vector<DiscSet>& out, std::vector<DiscRun>& sn_real) {
-    const Plan& pl = c.pl; const DiscNet& N = dnet();
+    const Plan& pl = c.pl; const DiscNet& N = *pl.dnetp;
     for (int d5 = 0; d5 < NPER; ++d5) {
         DiscSet s; s.run.li = N.mpd[d5]; s.run.n = 6; s.run.t = pl.pt[d5]; s.run.d = pl.pd[d5]; s.run.xc = pl.pxc[d5]; s.run.p = PERIODS[d5]; s.run.Tw = pl.seg; s.run.pass = 0;
         s.rt = pl.pt[d5]; s.nf = pl.B * PERIODS[d5]; s.r0 = 0; s.f0 = s.nf; s.sn = false; s.wr = yr; s.wg = yg; s.nb = pl.B;
         out.push_back(s);
+    }
+    if (N.vits) {   // one full-rate scale discriminator, weight norm, real + fake stacked
+        DiscSet s; s.run.li = N.msd[0]; s.run.n = 7; s.run.p = 1; s.run.Tw = pl.seg; s.nf = pl.B; s.wr = yr; s.wg = yg; s.nb = pl.B;
+        s.run.t = pl.st[0][0]; s.run.d = pl.sd[0][0]; s.run.xc = pl.sxc[0][0]; s.run.pass = 0; s.rt = pl.st[0][0]; s.r0 = 0; s.f0 = pl.B; s.sn = false;
+        out.push_back(s);
+        return;
     }
     for (int sc = 0; sc < 3; ++sc) {
         const float* wr = sc == 0 ? yr : c.F(pl.wav_s[sc][0]);
@@ -926,7 +970,7 @@ int pool_waves(Ctx& c, const float* yr, const float* yg) {
 // forward of all 8 discriminators on (real, fake); losses[0..2] = {disc loss, gen loss, feature loss}
 int discs_forward(Ctx& c0, float* Pd, const float* yr, const float* yg, float* losses, int loss_mask) {
     XVA_TRY(prep_wn(c0, c0.pl.dl, Pd));
-    XVA_TRY(pool_waves(c0, yr, yg));
+    if (!c0.pl.dnetp->vits) XVA_TRY(pool_waves(c0, yr, yg));
     std::vector<DiscSet> sets; std::vector<DiscRun> snr;
     std::vector<xva_red_desc> reds;
     build_sets(c0, yr, yg, sets, snr);
@@ -1033,6 +1077,7 @@ int discs_backward_g(Ctx& c0, float* Pd, const float* yr, const float* yg, float
     if (first[0]) XVA_TRY(zero(c0, d_wav, (int64_t)pl.B * pl.Tw[0] * 4));
     for (int ln = 1; ln < nl; ++ln)
         if (!first[ln]) XVA_TRY(xva_hg_add_f32(d_wav, c0.F(pl.dwav_lane[ln]), (int64_t)pl.B * pl.Tw[0], c0.st));
+    if (pl.dnetp->vits) return XVA_OK;
     // pooled scales: d(y) += pool_bwd(d(pool(y))) ; scale 2 goes through scale 1
     XVA_TRY(xva_hg_avgpool_bwd(c0.F(pl.dwav_s[2]), c0.F(pl.dwav_s[1]), pl.B, pl.Tw[1], 1, c0.st));
     XVA_TRY(xva_hg_avgpool_bwd(c0.F(pl.dwav_s[1]), d_wav, pl.B, pl.Tw[0], 1, c0.st));
@@ -1125,6 +1170,46 @@ extern "C" int xva_vits_dec_backward(const xva_vits_dec_dims* d, const float* pa
     XVA_TRY(make_ctx(c, &hd, ws, ws_bytes, stream, gn));
     XVA_CHECK_ARG(params && grads && d_wav && (g || d->cond_channels == 0), "vits_dec_backward: null");
     return gen_backward(c, params, grads, d_wav, nullptr, g, d_z);
+}
+// ---- VitsDiscriminator (xVAPitch): five period discriminators + one scale discriminator, the same three passes as xva_hg_disc_* ----
+extern "C" int64_t xva_vits_disc_param_floats(void) { return vits_dnet().total; }
+extern "C" int xva_vits_disc_num_tensors(void) { return (int)vits_dnet().t.size(); }
+extern "C" int xva_vits_disc_tensor_info(int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int32_t* ndim, int64_t* shape4) {
+    const Net& n = vits_dnet();
+    XVA_CHECK_ARG(i >= 0 && i < (int)n.t.size() && name && name_cap > 0, "vits_disc_tensor_info: bad index");
+    const TInfo& ti = n.t[i];
+    snprintf(name, name_cap, "%s", ti.name.c_str());
+    if (offset) *offset = ti.off;
+    if (numel) *numel = ti.numel;
+    if (ndim) *ndim = ti.ndim;
+    if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = ti.shape[k];
+    return XVA_OK;
+}
+extern "C" int64_t xva_vits_disc_workspace_bytes(const xva_hg_dims* d) {
+    Plan p;
+    if (make_plan(d, &p, nullptr, &vits_dnet()) != XVA_OK) return -1;
+    return p.total;
+}
+extern "C" int xva_vits_disc_forward(const xva_hg_dims* d, float* params_d, const float* yr, const float* yg, void* ws, int64_t ws_bytes, float* losses,
+                                     int loss_mask, void* stream) {
+    Ctx c;
+    XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream, nullptr, &vits_dnet()));
+    XVA_CHECK_ARG(params_d && yr && yg, "vits_disc_forward: null");
+    return discs_forward(c, params_d, yr, yg, losses, loss_mask);
+}
+extern "C" int xva_vits_disc_backward_d(const xva_hg_dims* d, float* params_d, float* grads_d, const float* yr, const float* yg, void* ws, int64_t ws_bytes,
+                                        void* stream) {
+    Ctx c;
+    XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream, nullptr, &vits_dnet()));
+    XVA_CHECK_ARG(params_d && grads_d && yr && yg, "vits_disc_backward_d: null");
+    return discs_backward_d(c, params_d, grads_d, yr, yg, nullptr);
+}
+extern "C" int xva_vits_disc_backward_g(const xva_hg_dims* d, float* params_d, const float* yr, const float* yg, float* d_wav, void* ws, int64_t ws_bytes,
+                                        void* stream) {
+    Ctx c;
+    XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream, nullptr, &vits_dnet()));
+    XVA_CHECK_ARG(params_d && yr && yg && d_wav, "vits_disc_backward_g: null");
+    return discs_backward_g(c, params_d, yr, yg, d_wav);
 }
 // Where an activation tensor of the last forward lives in the caller's workspace (parity tests feed a CPU restatement of ONE layer with
 // the engine's own input and compare outputs: storage-dtype rounding is then checked layer by layer instead of through ~50 layers).
