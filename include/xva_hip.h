@@ -369,8 +369,11 @@ int xva_vits_disc_forward(const xva_hg_dims* d, float* params_d, const float* y_
                           float* losses, int loss_mask, void* stream);
 int xva_vits_disc_backward_d(const xva_hg_dims* d, float* params_d, float* grads_d, const float* y_real, const float* y_fake, void* workspace,
                              int64_t workspace_bytes, void* stream);
-int xva_vits_disc_backward_g(const xva_hg_dims* d, float* params_d, const float* y_real, const float* y_fake, float* d_wav, void* workspace,
-                             int64_t workspace_bytes, void* stream);
+/* feature_grad: 1 = d(generator loss + feature loss) / d y_fake ; 0 = d(generator loss) / d y_fake only — what xVAPitch's trainer back-propagates:
+ * python/xvapitch/model.py:345-347 passes (fake, real) features to feature_loss(feats_real, feats_generated) (python/xvapitch/losses.py:64-72),
+ * whose .detach() therefore lands on the GENERATED features, so the feature term reaches no generator parameter. */
+int xva_vits_disc_backward_g(const xva_hg_dims* d, float* params_d, const float* y_real, const float* y_fake, float* d_wav, int feature_grad,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 /* Stream lanes.  Inside one call the engines issue independent chains on side streams they own (created once per host thread, forked
  * from and joined to the caller's stream with events inside the call): HiFi-GAN — period | scale discriminators, the generator's
  * weight gradients, the three parallel resblocks of a stage; FastPitch — the weight gradients of a layer and the temporal predictors.

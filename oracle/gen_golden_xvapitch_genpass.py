@@ -25,7 +25,8 @@ from oracle import gen_golden_xvapitch_acoustic as ga, golden_util as gu, hifiga
 DEC_SEED, SEG = 909, 8          # the engine wants segments of >= 2048 samples (8 frames); the model trains on 32
 
 
-def main():
+def build():
+    """The reference objects and the seeded batch shared with gen_golden_xvapitch_c5.py."""
     ns = ga.load_reference()
     hg = importlib.import_module("python.xvapitch.hifigan")
     xa = importlib.import_module("python.xvapitch.audio")
@@ -58,6 +59,30 @@ def main():
     pitch = (torch.rand(B, 1, Ty) * 3 - 1.2).clamp_min(0) * (torch.arange(Ty)[None, None, :] < y_lens[:, None, None])
     wav = torch.from_numpy(np.stack([omel.synth_wave(Ty * 256, 70 + i) for i in range(B)]).astype(np.float32)).unsqueeze(1) * 0.9
     zeros_t = torch.zeros(B, 1, Tt)
+    return {"ns": ns, "xa": xa, "m": m, "c": c, "dec_sd": dec_sd, "B": B, "Tt": Tt, "Ty": Ty, "x_lens": x_lens, "y_lens": y_lens, "tokens": tokens, "y": y,
+            "dvec": dvec, "lids": lids, "pitch": pitch, "wav": wav, "zeros_t": zeros_t}
+
+
+def reference_mel(xa, a, b):
+    """TorchSTFT mels of two waveforms (losses.py:29-46,187-188) through the reference class."""
+    real_stft = torch.stft
+
+    def stft_compat(*args, **k):                                         # torch >= 2 refuses return_complex=False on real input
+        k["return_complex"] = True
+        return torch.view_as_real(real_stft(*args, **k))
+    xa.torch.stft = stft_compat
+    try:
+        stft = xa.TorchSTFT(1024, 256, 1024, sample_rate=22050, mel_fmin=0, mel_fmax=8000, n_mels=80, use_mel=True, do_amp_to_db=True)
+        return stft(a.float()), stft(b.float())
+    finally:
+        xa.torch.stft = real_stft
+
+
+def main():
+    bd = build()
+    ns, xa, m, c, dec_sd = bd["ns"], bd["xa"], bd["m"], bd["c"], bd["dec_sd"]
+    B, Tt, Ty, x_lens, y_lens, tokens, y, dvec, lids, pitch, wav, zeros_t = (bd[k] for k in ("B", "Tt", "Ty", "x_lens", "y_lens", "tokens", "y", "dvec", "lids",
+                                                                                             "pitch", "wav", "zeros_t"))
     SEED = 123
     torch.manual_seed(SEED)
     out = m.train_step(tokens, x_lens, y, y_lens, pitch, zeros_t, wav, aux_input={"d_vectors": dvec, "language_ids": lids})
@@ -66,17 +91,7 @@ def main():
     noise = torch.randn(B, 2, Tt)                                        # sdp.py:281
     slice_ids = (torch.rand([B]) * (y_lens - SEG + 1)).long()            # util.py:160-162, the step's third draw
     assert torch.equal(ns["segment"](wav, slice_ids * 256, SEG * 256), out["waveform_seg"])
-    real_stft = torch.stft
-
-    def stft_compat(*a, **k):                                            # torch >= 2 refuses return_complex=False on real input
-        k["return_complex"] = True
-        return torch.view_as_real(real_stft(*a, **k))
-    xa.torch.stft = stft_compat
-    try:
-        stft = xa.TorchSTFT(1024, 256, 1024, sample_rate=22050, mel_fmin=0, mel_fmax=8000, n_mels=80, use_mel=True, do_amp_to_db=True)   # losses.py:29-46
-        mel, mel_hat = stft(out["waveform_seg"].float()), stft(out["model_outputs"].float())
-    finally:
-        xa.torch.stft = real_stft
+    mel, mel_hat = reference_mel(xa, out["waveform_seg"], out["model_outputs"])
     y_mask = (torch.arange(Ty)[None, :] < y_lens[:, None]).float()
     loss_mel = F.l1_loss(mel, mel_hat, reduction="none").mean() * 45                                             # losses.py:189-193
     loss_kl, _ = ns["kl_loss"](out["z_p"], out["logs_q"], out["m_p"], out["logs_p"], y_mask.unsqueeze(1))

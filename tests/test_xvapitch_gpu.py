@@ -581,3 +581,55 @@ def test_vits_discriminator_against_reference_golden(golden_dir, compute):
         nerr = sorted(((abs(float(mine[k].norm()) - float(n)) / float(n), k) for k, n in zip(keys, g["grad_norms"])), reverse=True)
         print("vits disc bf16: losses %.2e d_wav %.2e worst norm errors %s" % (el, edw, nerr[:3]))
         assert el < 2e-2 and edw < 0.1 and nerr[0][0] < 0.1, (el, edw, nerr[:3])
+
+
+def test_c5_generator_and_discriminator_passes_against_reference_golden(golden_dir):
+    """xvapitch/train_step.py:XVAPitchStep — BOTH passes of one xVAPitch iteration (BASELINE config C5) — against the vectors recorded from the
+    reference's own code (oracle/gen_golden_xvapitch_c5.py: train_step + HifiganGenerator + VitsDiscriminator + the loss functions, assembled as
+    model.py:272-384 / losses.py:187-300 do): the six generator-side losses, their total and loss_disc at 1e-3; d(total)/d(every generator
+    parameter) (709 tensors: text encoder, posterior encoder, flow, duration + pitch predictors, embeddings, decoder) and d(loss_disc)/d(every
+    discriminator parameter) (111) at 1e-2 on norms and 256 samples each (the LeakyReLU-gate bound of the decoder / discriminators)."""
+    from oracle import golden_util, hifigan as ohg
+    from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
+    from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+    from xva_trainer_amd.xvapitch.discriminator import VitsDiscriminator
+    from xva_trainer_amd.xvapitch.generator_pass import GeneratorPass
+    from xva_trainer_amd.xvapitch.train_step import XVAPitchStep
+    g = np.load(os.path.join(golden_dir, "xvapitch_genpass.npz"))
+    g5 = np.load(os.path.join(golden_dir, "xvapitch_c5.npz"))
+    c = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    ac = AcousticTrainPath(c["vocab"], c["langs"], latent_size=c["latent"], embedded_language_dim=c["lang_dim"], d_vector_dim=c["dvec"],
+                           hidden_channels_ffn=c["ffn"], num_heads=c["heads"], text_layers=c["te_layers"], posterior_layers=c["pe_layers"],
+                           flow_layers=c["flow_layers"], num_flows=c["num_flows"], spec_bins=c["spec_bins"], pitch=True)
+    ac.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")})
+    dec = VitsDecoder(c["latent"], c["dvec"])
+    dec.load_state_dict(ohg.init_vits_decoder_sd(int(g["dec_seed"]), c["latent"], c["dvec"]))
+    D = VitsDiscriminator()
+    dsd = ohg.init_vits_disc_sd(int(g5["disc_seed"]))
+    assert abs(sum(float(v.double().sum()) for v in dsd.values()) - float(g5["disc_checksum"])) < 1e-3
+    D.load_state_dict(dsd)
+    step = XVAPitchStep(GeneratorPass(ac, dec, spec_segment_size=int(g["seg"])), D)
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    step.gen.zero_grad(); D.zero_grad()
+    o = step.generator_pass(t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("wav"), t("dvec"), t("lids"), pitch_padded=t("pitch"), eps=t("eps"),
+                            noise=t("noise"), slice_ids=t("slice_ids"))
+    assert _rel(o["model_outputs"], torch.from_numpy(g5["model_outputs"])) < 1e-3
+    for k in ("loss_mel", "loss_kl", "loss_duration", "loss_pitch", "loss_gen", "loss_feat", "loss"):
+        assert abs(float(o[k]) - float(g5[k])) < 1e-3 * abs(float(g5[k])), (k, float(o[k]), float(g5[k]))
+    o["loss"].backward()
+    loss_disc = step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
+    torch.cuda.synchronize()
+    assert abs(float(loss_disc) - float(g5["loss_disc"])) < 1e-3 * float(g5["loss_disc"]), (float(loss_disc), float(g5["loss_disc"]))
+
+    def check(mine, tag, nmin):
+        keys = [str(k) for k in g5[tag + "_keys"]]
+        assert set(keys) == set(mine), sorted(set(keys) ^ set(mine))[:8]
+        live = set(k for k, nr in zip(keys, g5[tag + "_norms"]) if nr >= 1e-5 * mine[k].numel() ** 0.5)
+        errs = [e for e in golden_util.check_samples(mine, keys, g5[tag + "_samples"], g5[tag + "_offsets"], 256) if e[1] in live]
+        nerr = sorted(((abs(float(mine[k].norm()) - float(nr)) / float(nr), k) for k, nr in zip(keys, g5[tag + "_norms"]) if k in live), reverse=True)
+        print("C5 %s-pass gradients: sampled worst %s ; norm worst %s ; %d tensors" % (tag, errs[:3], nerr[:2], len(errs)))
+        assert len(errs) >= nmin and errs[0][0] < 1e-2 and nerr[0][0] < 1e-2, (errs[:4], nerr[:4])
+    mine = {k: v.detach().cpu() for k, v in ac.grads().items()}
+    mine.update({"waveform_decoder." + k: v.detach().cpu() for k, v in dec.grads().items()})
+    check(mine, "g", 690)
+    check({k: v.detach().cpu() for k, v in D.grads().items()}, "d", 111)

@@ -879,12 +879,14 @@ int disc_backward_params(Ctx& c, const float* Pd, float* Gd, const DiscRun& r, i
 
 // G-step backward of the FAKE sequences [f0, f0+nf) against the REAL sequences [r0, r0+nf) (feature matching + LSGAN):
 // data gradients only, down to d(wave).  rt = tensors holding the real fmaps (may be another set for spectral norm).
-int disc_backward_wave(Ctx& c, const float* Pd, const DiscRun& r, const SeqSpec* rt, int r0, int f0, int nf, float* dwav, int accumulate) {
+// feat: weight of the feature-matching term in the gradient (1; 0 for xVAPitch, whose feature loss detaches the GENERATED features —
+// python/xvapitch/model.py:345-347 hands (fake, real) to feature_loss(feats_real, feats_generated), python/xvapitch/losses.py:64-72)
+int disc_backward_wave(Ctx& c, const float* Pd, const DiscRun& r, const SeqSpec* rt, int r0, int f0, int nf, float* dwav, int accumulate, float feat = 1.f) {
     const auto& L = c.pl.dl;
     auto numel = [&](int i) { const SeqSpec& s = r.t[i]; return (float)((int64_t)nf * s.T * s.C); };
     {   // score: LSGAN generator loss mean((1 - g)^2) + feature term of the last fmap
         Seq g = c.S(r.t[r.n]).slice(f0, nf), rr = c.S(rt[r.n]).slice(r0, nf), d = c.S(r.d[r.n]).slice(f0, nf);
-        XVA_TRY(xva_hg_seed_grad(rr.ptr(), g.ptr(), d.ptr(), c.dt, nf, g.Hp(), g.padF, g.T, g.C, 2.f / numel(r.n), 1.f / numel(r.n), 1, 0, 0.f, 1, c.st));
+        XVA_TRY(xva_hg_seed_grad(rr.ptr(), g.ptr(), d.ptr(), c.dt, nf, g.Hp(), g.padF, g.T, g.C, feat * 2.f / numel(r.n), 1.f / numel(r.n), 1, 0, 0.f, 1, c.st));
     }
     for (int i = r.n - 1; i >= 1; --i) {
         const Layer& l = L[r.li[i]];
@@ -896,7 +898,7 @@ int disc_backward_wave(Ctx& c, const float* Pd, const DiscRun& r, const SeqSpec*
             XVA_TRY(hg_conv_bwd_data(dy, dx, cw(c, l, Pd, r.pass), b, c.compute, c.st));
         }
         // + feature-matching gradient of this fmap, then LeakyReLU backward on the total
-        XVA_TRY(xva_hg_seed_grad(xr.ptr(), x.ptr(), dx.ptr(), c.dt, nf, x.Hp(), x.padF, x.T, x.C, 2.f / numel(i), 0.f, 0, 1, SLOPE, 0, c.st));
+        XVA_TRY(xva_hg_seed_grad(xr.ptr(), x.ptr(), dx.ptr(), c.dt, nf, x.Hp(), x.padF, x.T, x.C, feat * 2.f / numel(i), 0.f, 0, 1, SLOPE, 0, c.st));
     }
     const Layer& l0 = L[r.li[0]];
     Seq d1 = c.S(r.d[1]).slice(f0, nf), dxc = c.S(r.xc[1]).slice(f0, nf);
@@ -1054,7 +1056,7 @@ int discs_backward_d(Ctx& c0, float* Pd, float* Gd, const float* yr, const float
 }
 
 // G-step backward: d/d(fake wave) of sum_d [mean((1 - D(G))^2) + 2 * sum_l mean|fmap_l(y) - fmap_l(G)|]
-int discs_backward_g(Ctx& c0, float* Pd, const float* yr, const float* yg, float* d_wav) {
+int discs_backward_g(Ctx& c0, float* Pd, const float* yr, const float* yg, float* d_wav, float feat = 1.f) {
     const Plan& pl = c0.pl;
     std::vector<DiscSet> sets; std::vector<DiscRun> snr;
     build_sets(c0, yr, yg, sets, snr);
@@ -1069,7 +1071,7 @@ int discs_backward_g(Ctx& c0, float* Pd, const float* yr, const float* yg, float
         // the full-rate discriminators all add into d(waveform): lane 0 into d_wav itself, every other lane into its own partial buffer
         float* dst = sc != 0 ? c.F(pl.dwav_s[sc]) : (ln == 0 ? d_wav : c.F(pl.dwav_lane[ln]));
         const bool acc = sc == 0 ? !first[ln] : false;
-        XVA_TRY(disc_backward_wave(c, Pd, s.run, s.rt, s.r0, s.f0, s.nf, dst, acc ? 1 : 0));
+        XVA_TRY(disc_backward_wave(c, Pd, s.run, s.rt, s.r0, s.f0, s.nf, dst, acc ? 1 : 0, feat));
         if (sc == 0) first[ln] = false;
         ++di;
     }
@@ -1204,12 +1206,12 @@ extern "C" int xva_vits_disc_backward_d(const xva_hg_dims* d, float* params_d, f
     XVA_CHECK_ARG(params_d && grads_d && yr && yg, "vits_disc_backward_d: null");
     return discs_backward_d(c, params_d, grads_d, yr, yg, nullptr);
 }
-extern "C" int xva_vits_disc_backward_g(const xva_hg_dims* d, float* params_d, const float* yr, const float* yg, float* d_wav, void* ws, int64_t ws_bytes,
-                                        void* stream) {
+extern "C" int xva_vits_disc_backward_g(const xva_hg_dims* d, float* params_d, const float* yr, const float* yg, float* d_wav, int feature_grad, void* ws,
+                                        int64_t ws_bytes, void* stream) {
     Ctx c;
     XVA_TRY(make_ctx(c, d, ws, ws_bytes, stream, nullptr, &vits_dnet()));
     XVA_CHECK_ARG(params_d && yr && yg && d_wav, "vits_disc_backward_g: null");
-    return discs_backward_g(c, params_d, yr, yg, d_wav);
+    return discs_backward_g(c, params_d, yr, yg, d_wav, feature_grad ? 1.f : 0.f);
 }
 // Where an activation tensor of the last forward lives in the caller's workspace (parity tests feed a CPU restatement of ONE layer with
 // the engine's own input and compare outputs: storage-dtype rounding is then checked layer by layer instead of through ~50 layers).

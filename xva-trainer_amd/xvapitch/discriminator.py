@@ -33,7 +33,7 @@ lib.xva_vits_disc_forward.argtypes = [C.POINTER(_Dims), vp, vp, vp, vp, i64, vp,
 lib.xva_vits_disc_backward_d.restype = i32
 lib.xva_vits_disc_backward_d.argtypes = [C.POINTER(_Dims), vp, vp, vp, vp, vp, i64, vp]
 lib.xva_vits_disc_backward_g.restype = i32
-lib.xva_vits_disc_backward_g.argtypes = [C.POINTER(_Dims), vp, vp, vp, vp, vp, i64, vp]
+lib.xva_vits_disc_backward_g.argtypes = [C.POINTER(_Dims), vp, vp, vp, vp, i32, vp, i64, vp]
 
 
 class VitsDiscriminator:
@@ -99,10 +99,12 @@ class VitsDiscriminator:
                                                 self._ws.numel(), _lib.stream_ptr()), "xva_vits_disc_backward_d")
         return self._losses[0].clone()
 
-    def g_pass(self, y, y_hat):
+    def g_pass(self, y, y_hat, feature_grad=True):
+        """feature_grad=False: d_wav = d loss_gen / d y_hat only — what the reference trainer back-propagates (its feature loss detaches the
+        generated features: python/xvapitch/model.py:345-347 with losses.py:64-72); the returned loss values are the same either way."""
         y, yh, d = self._prep(y, y_hat)
         self._forward(y, yh, d, 2)
         d_wav = torch.empty_like(yh)
-        _lib.check(lib.xva_vits_disc_backward_g(C.byref(d), _lib.ptr(self.params), _lib.ptr(y), _lib.ptr(yh), _lib.ptr(d_wav), _lib.ptr(self._ws),
-                                                self._ws.numel(), _lib.stream_ptr()), "xva_vits_disc_backward_g")
+        _lib.check(lib.xva_vits_disc_backward_g(C.byref(d), _lib.ptr(self.params), _lib.ptr(y), _lib.ptr(yh), _lib.ptr(d_wav), int(bool(feature_grad)),
+                                                _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "xva_vits_disc_backward_g")
         return self._losses[1].clone(), self._losses[2].clone(), d_wav
