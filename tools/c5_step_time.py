@@ -1,0 +1,74 @@
+"""One xVAPitch iteration (BASELINE config C5: generator pass fwd + bwd, discriminator pass fwd + bwd; no optimiser) at the reference's model size —
+python/xvapitch/model.py:55-149: latent 192, language embedding 4, speaker vector 512, text encoder 10 layers x 196 channels (ffn 768, 2 heads),
+posterior encoder 16 WN layers on 513 spectrogram bins, flow 4 x 4 WN layers, pitch predictor 3 layers x 708 channels, decoder 512 -> 32 channels,
+spec_segment_size 32 (8192 samples) — on a synthetic batch (random weights; sizes from argv).
+
+    python tools/c5_step_time.py [B=16] [T_text=100] [T_spec=400] [decoder/discriminator dtype: bf16|fp32]
+Prints ms per pass and waveform-segment samples / s; under `rocprofv3 --kernel-trace --stats` gives the per-kernel table of profiles/."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
+from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+from xva_trainer_amd.xvapitch.discriminator import VitsDiscriminator
+from xva_trainer_amd.xvapitch.generator_pass import GeneratorPass
+from xva_trainer_amd.xvapitch.train_step import XVAPitchStep
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+Tt = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+Ty = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+dt = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+VOCAB, LANGS, SEG = 256, 31, 32
+torch.manual_seed(0)
+ac = AcousticTrainPath(VOCAB, LANGS, pitch=True)                      # the reference's defaults (model.py:55-135)
+dec = VitsDecoder(192, 512, compute=dt)
+D = VitsDiscriminator(compute=dt)
+gen = torch.Generator().manual_seed(1)
+for eng, std in ((dec, 0.02), (D, 0.02)):                              # random weights: weight_v ~ N, weight_g = row norms (unit-gain weight norm)
+    sd = {}
+    for k, (off, numel, shape) in eng.table.items():
+        sd[k] = torch.randn(shape, generator=gen) * std
+    for k in list(sd):
+        if k.endswith("weight_g"):
+            v = sd[k[:-1] + "v"]
+            sd[k] = v.reshape(v.size(0), -1).norm(dim=1).reshape(sd[k].shape)
+    eng.load_state_dict(sd)
+step = XVAPitchStep(GeneratorPass(ac, dec, SEG), D)
+dev = "cuda"
+x_lens = torch.randint(Tt // 2, Tt + 1, (B,), generator=gen); x_lens[0] = Tt
+y_lens = torch.randint(max(Ty // 2, SEG + 1), Ty + 1, (B,), generator=gen); y_lens[0] = Ty
+tokens = (torch.randint(1, VOCAB, (B, Tt), generator=gen) * (torch.arange(Tt)[None, :] < x_lens[:, None])).to(dev)
+y = (torch.rand(B, 513, Ty, generator=gen) * (torch.arange(Ty)[None, None, :] < y_lens[:, None, None])).to(dev)
+wav = (torch.rand(B, 1, Ty * 256, generator=gen) * 1.6 - 0.8).to(dev)
+dvec = torch.randn(B, 512, generator=gen).to(dev)
+lids = torch.randint(0, LANGS, (B,), generator=gen).to(dev)
+pitch = ((torch.rand(B, 1, Ty, generator=gen) * 3 - 1.2).clamp_min(0) * (torch.arange(Ty)[None, None, :] < y_lens[:, None, None])).to(dev)
+x_lens, y_lens = x_lens.to(dev), y_lens.to(dev)
+
+
+def iteration():
+    step.gen.zero_grad(); D.zero_grad()
+    t0 = time.perf_counter()
+    o = step.generator_pass(tokens, x_lens, y, y_lens, wav, dvec, lids, pitch_padded=pitch)
+    o["loss"].backward()
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    ld = step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    return (t1 - t0) * 1e3, (t2 - t1) * 1e3, float(o["loss"]), float(ld)
+
+
+for _ in range(2):
+    iteration()
+N = 5
+acc = [0.0, 0.0]
+for _ in range(N):
+    a, b, lg, ld = iteration()
+    acc[0] += a / N; acc[1] += b / N
+tot = acc[0] + acc[1]
+print("xVAPitch C5 iteration, B=%d x (%d symbols, %d spectrogram frames), segment %d samples, decoder / discriminator %s, acoustic path fp32:" % (B, Tt, Ty, SEG * 256, dt))
+print("  generator pass fwd + bwd %.1f ms | discriminator pass fwd + bwd %.1f ms | iteration %.1f ms = %.0f k segment-samples / s, %.0f spectrogram frames / s (losses %.3f / %.3f)"
+      % (acc[0], acc[1], tot, B * SEG * 256 / tot, float(y_lens.sum()) / tot * 1e3, lg, ld))
