@@ -72,3 +72,39 @@ tot = acc[0] + acc[1]
 print("xVAPitch C5 iteration, B=%d x (%d symbols, %d spectrogram frames), segment %d samples, decoder / discriminator %s, acoustic path fp32:" % (B, Tt, Ty, SEG * 256, dt))
 print("  generator pass fwd + bwd %.1f ms | discriminator pass fwd + bwd %.1f ms | iteration %.1f ms = %.0f k segment-samples / s, %.0f spectrogram frames / s (losses %.3f / %.3f)"
       % (acc[0], acc[1], tot, B * SEG * 256 / tot, float(y_lens.sum()) / tot * 1e3, lg, ld))
+
+if os.environ.get("XVA_C5_CPU_BASELINE", "0") != "0":
+    # The CPU restatement (oracle/: the checker of tests/, timed here as the reference-algorithm baseline on this host's cores) on the first
+    # Bc items of the same batch, same weights: generator pass + discriminator pass, forward + backward, fp32 torch-CPU.
+    import torch.nn.functional as F
+    from oracle import hifigan as ohg, mel as omel, xvapitch as oxv
+    Bc, threads = min(B, 4), 8
+    torch.set_num_threads(threads)
+    cfg = {"latent": 192, "lang_dim": 4, "dvec": 512, "heads": 2, "te_layers": 10, "pe_layers": 16, "flow_layers": 4, "num_flows": 4}
+    cpu = lambda t: t[:Bc].detach().cpu()
+    leaves = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in ac.state_dict().items()}
+    dl = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    ddl = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in D.state_dict().items()}
+    tk, xl, yy, yl, ww, dv, li, pp = (cpu(t) for t in (tokens, x_lens, y, y_lens, wav, dvec, lids, pitch))
+    Tyc, Ttc = int(yl.max()), int(xl.max())
+    tk, yy, ww, pp = tk[:, :Ttc], yy[:, :, :Tyc], ww[:, :, :Tyc * 256], pp[:, :, :Tyc]
+    eps, noise = torch.randn(Bc, 192, Tyc), torch.randn(Bc, 2, Ttc)
+    ids = (torch.rand(Bc) * (yl - SEG + 1)).long()
+
+    def cpu_iteration():
+        t0 = time.perf_counter()
+        o = oxv.acoustic_losses(leaves, tk, xl, yy, yl, dv, li, eps, noise, cfg, pitch_padded=pp)
+        g = F.normalize(dv).unsqueeze(-1)
+        wav_hat = ohg.vits_decoder(dl, oxv.segment(o["z"], ids, SEG), g)
+        seg = oxv.segment(ww, ids * 256, SEG * 256)
+        loss_mel = F.l1_loss(omel.mel_m3(seg.squeeze(1)), omel.mel_m3(wav_hat.squeeze(1)), reduction="none").mean() * 45
+        rs, fr, gs, fg = ohg.vits_disc({k: v.detach() for k, v in ddl.items()}, seg, wav_hat)
+        loss = o["loss"] + loss_mel + ohg.generator_loss(gs) + ohg.feature_loss(fr, [[t.detach() for t in f] for f in fg])
+        loss.backward()
+        rs, fr, gs, fg = ohg.vits_disc(ddl, seg, wav_hat.detach())
+        ohg.discriminator_loss(rs, gs).backward()
+        return time.perf_counter() - t0
+    cpu_iteration()
+    s = min(cpu_iteration() for _ in range(2))
+    print("  CPU baseline (oracle port, %d threads of %d host CPUs, first %d items, 1 warm-up + best of 2): %.2f s / iteration = %.1f k segment-samples / s"
+          % (threads, os.cpu_count(), Bc, s, Bc * SEG * 256 / s / 1e3))
