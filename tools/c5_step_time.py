@@ -3,7 +3,7 @@ python/xvapitch/model.py:55-149: latent 192, language embedding 4, speaker vecto
 posterior encoder 16 WN layers on 513 spectrogram bins, flow 4 x 4 WN layers, pitch predictor 3 layers x 708 channels, decoder 512 -> 32 channels,
 spec_segment_size 32 (8192 samples) — on a synthetic batch (random weights; sizes from argv).
 
-    python tools/c5_step_time.py [B=16] [T_text=100] [T_spec=400] [decoder/discriminator dtype: bf16|fp32]
+    python tools/c5_step_time.py [B=16] [T_text=100] [T_spec=400] [decoder/discriminator dtype: bf16|fp32] [WaveNet stacks: fp32|bf16]
 Prints ms per pass and waveform-segment samples / s; under `rocprofv3 --kernel-trace --stats` gives the per-kernel table of profiles/."""
 import os
 import sys
@@ -22,9 +22,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 Tt = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 Ty = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 dt = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+adt = sys.argv[5] if len(sys.argv) > 5 else "fp32"        # storage / MFMA dtype of the WaveNet stacks (posterior encoder, flow); transformer / SDP are fp32
 VOCAB, LANGS, SEG = 256, 31, 32
 torch.manual_seed(0)
-ac = AcousticTrainPath(VOCAB, LANGS, pitch=True)                      # the reference's defaults (model.py:55-135)
+ac = AcousticTrainPath(VOCAB, LANGS, pitch=True, compute=adt)                      # the reference's defaults (model.py:55-135)
 dec = VitsDecoder(192, 512, compute=dt)
 D = VitsDiscriminator(compute=dt)
 gen = torch.Generator().manual_seed(1)
@@ -69,7 +70,7 @@ for _ in range(N):
     a, b, lg, ld = iteration()
     acc[0] += a / N; acc[1] += b / N
 tot = acc[0] + acc[1]
-print("xVAPitch C5 iteration, B=%d x (%d symbols, %d spectrogram frames), segment %d samples, decoder / discriminator %s, acoustic path fp32:" % (B, Tt, Ty, SEG * 256, dt))
+print("xVAPitch C5 iteration, B=%d x (%d symbols, %d spectrogram frames), segment %d samples, decoder / discriminator %s, WaveNet stacks %s, transformer / SDP fp32:" % (B, Tt, Ty, SEG * 256, dt, adt))
 print("  generator pass fwd + bwd %.1f ms | discriminator pass fwd + bwd %.1f ms | iteration %.1f ms = %.0f k segment-samples / s, %.0f spectrogram frames / s (losses %.3f / %.3f)"
       % (acc[0], acc[1], tot, B * SEG * 256 / tot, float(y_lens.sum()) / tot * 1e3, lg, ld))
 

@@ -435,9 +435,9 @@ class PosteriorEncoder:
 
     def __init__(self, in_channels, out_channels, hidden_channels, kernel_size, dilation_rate, num_layers, cond_channels=0, device="cuda", compute="fp32", seed=0):
         self.Cin, self.Co, self.hidden = in_channels, out_channels, hidden_channels
-        # the GEMM operands want rows of a multiple of 4 elements: the 513 spectrogram bins are carried as 516 channels, the 3 extra input
-        # channels and weight columns zero (they stay zero: their gradient is dy^T times a zero column)
-        self.Cp = (in_channels + 3) // 4 * 4
+        # the GEMM operands want rows of a multiple of 4 (fp32) / 8 (bf16) elements: the 513 spectrogram bins are carried as 520 channels, the
+        # extra input channels and weight columns zero (they stay zero: their gradient is dy^T times a zero column)
+        self.Cp = (in_channels + 7) // 8 * 8
         self.device = torch.device(device)
         gen = torch.Generator().manual_seed(seed)
         self.enc = WN(hidden_channels, hidden_channels, kernel_size, dilation_rate, num_layers, c_in_channels=cond_channels, device=device, compute=compute,
