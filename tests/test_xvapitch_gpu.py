@@ -633,3 +633,27 @@ def test_c5_generator_and_discriminator_passes_against_reference_golden(golden_d
     mine.update({"waveform_decoder." + k: v.detach().cpu() for k, v in dec.grads().items()})
     check(mine, "g", 690)
     check({k: v.detach().cpu() for k, v in D.grads().items()}, "d", 111)
+
+
+def test_rel_transformer_mixed_mode_against_reference_golden(golden_dir):
+    """compute="mixed" (the throughput mode of the two transformers: bf16 MFMA on the fp32-stored operands of the projections and feed-forward
+    convolutions; attention and LayerNorm fp32) against the same reference vectors: output 2e-2 (measured 1.6e-3), input gradient 5e-2 (1.2e-2), parameter gradients 0.1 (worst 5.9e-2: a feed-forward bias, a sum of
+    near-cancelling bf16-rounded products)."""
+    from xva_trainer_amd.xvapitch.transformer import RelativePositionTransformer
+    g = np.load(os.path.join(golden_dir, "xvapitch_transformer.npz"))
+    B, Cc, Fh, H, L, K, W, T = (int(v) for v in g["cfg"])
+    lens = torch.from_numpy(g["lens"])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1).cuda()
+    tr = RelativePositionTransformer(Cc, Cc, Cc, Fh, H, L, kernel_size=K, dropout_p=0.0, rel_attn_window_size=W, layer_norm_type="2", compute="mixed")
+    tr.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")})
+    tr.zero_grad()
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = tr(x, x_mask)
+    (y * torch.from_numpy(g["r"]).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    grads = tr.grads()
+    names = [k[5:] for k in g.files if k.startswith("grad/") and not k.endswith("conv_k.bias")]
+    worst = sorted(((_rel(grads[n], torch.from_numpy(g["grad/" + n])), n) for n in names), reverse=True)
+    ey, edx = _rel(y, torch.from_numpy(g["y"])), _rel(x.grad, torch.from_numpy(g["dx"]))
+    print("rel transformer (mixed): y %.2e dx %.2e worst gradients %s" % (ey, edx, worst[:3]))
+    assert 1e-6 < ey < 2e-2 and edx < 5e-2 and worst[0][0] < 0.1, (ey, edx, worst[:4])      # > 1e-6: the bf16 products really ran

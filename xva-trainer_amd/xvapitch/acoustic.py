@@ -81,7 +81,9 @@ class _Expand(torch.autograd.Function):
 
 
 class AcousticTrainPath:
-    """Constructor arguments follow model.py:55-135 (defaults = the reference's non-`big` model)."""
+    """Constructor arguments follow model.py:55-135 (defaults = the reference's non-`big` model).  compute: "fp32" = exact-fp32 products everywhere
+    (the parity mode) ; "bf16" = the throughput mode: WaveNet stacks (posterior encoder, flow) bf16-stored with bf16 MFMA, the two transformers' projections
+    and feed-forward convolutions bf16 MFMA on fp32-stored tensors; attention, LayerNorm, the duration predictor, MAS and the losses stay fp32."""
 
     def __init__(self, n_vocab, num_languages, latent_size=192, embedded_language_dim=4, d_vector_dim=512, hidden_channels_ffn=768, num_heads=2,
                  text_layers=10, posterior_layers=16, flow_layers=4, num_flows=4, spec_bins=513, pitch=False, pe_scaling=0.1, device="cuda", compute="fp32",
@@ -95,7 +97,8 @@ class AcousticTrainPath:
                   "text_encoder.proj.weight": _param((torch.rand(2 * Cc, Cc + L, 1, generator=gen) * 2 - 1) * (Cc + L) ** -0.5, self.device),
                   "text_encoder.proj.bias": _param((torch.rand(2 * Cc, generator=gen) * 2 - 1) * (Cc + L) ** -0.5, self.device)}
         self.encoder = RelativePositionTransformer(Cc + L, Cc + L, Cc + L, hidden_channels_ffn, num_heads, text_layers, kernel_size=3, dropout_p=0.0,
-                                                   layer_norm_type="2", rel_attn_window_size=4, device=device, seed=seed + 1)
+                                                   layer_norm_type="2", rel_attn_window_size=4, device=device, seed=seed + 1,
+                                                   compute="mixed" if compute == "bf16" else "fp32")
         self.posterior_encoder = PosteriorEncoder(spec_bins, Cc, Cc, 5, 1, posterior_layers, cond_channels=d_vector_dim, device=device, compute=compute,
                                                   seed=seed + 2)
         self.flow = ResidualCouplingBlocks(Cc, Cc, 5, 1, flow_layers, num_flows=num_flows, cond_channels=d_vector_dim, device=device, compute=compute,
@@ -108,7 +111,8 @@ class AcousticTrainPath:
         if self.pitch:
             hid = Cc + L + d_vector_dim                                                                                                   # model.py:1283-1284
             self.pitch_predictor = RelativePositionTransformer(hid, 1, hid, hidden_channels_ffn, num_heads, 3, kernel_size=3, dropout_p=0.0,
-                                                               layer_norm_type="2", rel_attn_window_size=4, device=device, seed=seed + 5)
+                                                               layer_norm_type="2", rel_attn_window_size=4, device=device, seed=seed + 5,
+                                                               compute="mixed" if compute == "bf16" else "fp32")
             self._subs.append(("pitch_predictor.encoder.", self.pitch_predictor))
             self.p["pitch_emb.weight"] = _param((torch.rand(Cc, 1, 3, generator=gen) * 2 - 1) * 3 ** -0.5, self.device)
             self.p["pitch_emb.bias"] = _param((torch.rand(Cc, generator=gen) * 2 - 1) * 3 ** -0.5, self.device)

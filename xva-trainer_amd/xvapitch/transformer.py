@@ -74,7 +74,7 @@ _KEYMAP = (("attn.", "attn_layers.%d."), ("ffn.", "ffn_layers.%d."), ("norm1.", 
 
 class RelativePositionTransformer:
     def __init__(self, in_channels, out_channels, hidden_channels, hidden_channels_ffn, num_heads, num_layers, kernel_size=1, dropout_p=0.0,
-                 rel_attn_window_size=None, input_length=None, layer_norm_type="1", device="cuda", seed=0):
+                 rel_attn_window_size=None, input_length=None, layer_norm_type="1", device="cuda", seed=0, compute="fp32"):
         if dropout_p:
             raise NotImplementedError("RelativePositionTransformer: dropout_p > 0 is not built")
         if in_channels != hidden_channels or not (out_channels == 1 or out_channels % 4 == 0):
@@ -85,6 +85,11 @@ class RelativePositionTransformer:
             raise NotImplementedError("RelativePositionTransformer: channels must be multiples of 4 and of num_heads, kernel_size odd")
         self.C, self.F, self.H, self.L, self.k, self.w = hidden_channels, hidden_channels_ffn, num_heads, num_layers, kernel_size, rel_attn_window_size
         self.Co = out_channels
+        # "fp32": exact-fp32 MFMA products (the parity mode) ; "mixed": the same fp32-stored tensors, operands rounded to bf16 while staged
+        # (bf16 MFMA, fp32 accumulation) — the throughput mode of the projections and feed-forward convolutions; attention / LayerNorm stay fp32
+        if compute not in ("fp32", "mixed"):
+            raise ValueError("RelativePositionTransformer: compute must be 'fp32' or 'mixed'")
+        self.cmp = 1 if compute == "mixed" else 0
         self.device = torch.device(device)
         gen = torch.Generator().manual_seed(seed)
         self.layers = [_Layer(self.C, self.F, self.H, self.k, self.w, self.device, gen, Co=out_channels if i == num_layers - 1 else None)
@@ -166,7 +171,7 @@ class RelativePositionTransformer:
             wqkv = torch.cat([p["attn.conv_%s.weight" % n].reshape(Cc, Cc) for n in "qkv"], 0).contiguous()
             bqkv = torch.cat([p["attn.conv_%s.bias" % n] for n in "qkv"]).contiguous()
             qkv = mk(3 * Cc)
-            conv_fwd(xm, wqkv, bqkv, qkv, 1, 1, 0)                                              # conv_q / conv_k / conv_v  (:166-168)
+            conv_fwd(xm, wqkv, bqkv, qkv, 1, 1, self.cmp)                                              # conv_q / conv_k / conv_v  (:166-168)
             P = torch.empty(B, H, T, T, device=self.device)
             att = mk(Cc)
             base = PAD * 3 * Cc
@@ -175,14 +180,14 @@ class RelativePositionTransformer:
                                            _lib.stream_ptr()), "xva_relattn_fwd")                # attention                 (:173-214)
             s1 = mk(Cc)
             wo = p["attn.conv_o.weight"].reshape(Cc, Cc).contiguous()
-            _lib.gemm(att.store, wo, s1.store, att.rows, Cc, Cc, Cc, Cc, Cc, layout=_lib.GEMM_NT, compute=0, bias=p["attn.conv_o.bias"], a_offset=att.off(),
+            _lib.gemm(att.store, wo, s1.store, att.rows, Cc, Cc, Cc, Cc, Cc, layout=_lib.GEMM_NT, compute=self.cmp, bias=p["attn.conv_o.bias"], a_offset=att.off(),
                       c_offset=s1.off(), R=xm.view, ldr=Cc, mask_mode=_lib.MASK_PAD, Tp=x.Tp, mask_pad=PAD, mask_len=T)   # x + conv_o(..)  (:170,474)
             x1, m1, r1 = self._ln(s1, p["norm1.gamma"], p["norm1.beta"])                        # norm_layers_1             (:474)
             res = x1                                                                            # the residual branch of the second sub-layer
             if last and self.proj is not None:                                                  # x = proj(x)               (:479-480)
                 wp, bp = self._proj_padded()
                 res = mk(wp.size(0))
-                conv_fwd(x1, wp, bp, res, 1, 1, 0)
+                conv_fwd(x1, wp, bp, res, 1, 1, self.cmp)
             if last and Co == 1:                                                                # the stack returns proj(x) (:482)
                 self.saved.append((xm, wqkv, qkv, P, att, wo, s1, m1, r1, x1))
                 x = res
@@ -191,12 +196,12 @@ class RelativePositionTransformer:
             h = mk(F)
             P_ = (k - 1) // 2
             w1 = _tapmajor(p["ffn.conv_1.weight"]); w2 = _tapmajor(p["ffn.conv_2.weight"])
-            _lib.gemm(x1m.store, w1, h.store, x1m.rows, F, k * Cc, Cc, k * Cc, F, layout=_lib.GEMM_NT, compute=0, bias=p["ffn.conv_1.bias"], relu=True,
+            _lib.gemm(x1m.store, w1, h.store, x1m.rows, F, k * Cc, Cc, k * Cc, F, layout=_lib.GEMM_NT, compute=self.cmp, bias=p["ffn.conv_1.bias"], relu=True,
                       a_offset=x1m.off(-P_), c_offset=h.off(), a_seglen=Cc if k > 1 else 0, a_segadj=0, mask_mode=_lib.MASK_PAD, Tp=x.Tp, mask_pad=PAD,
                       mask_len=T)
             _mask(h, lens)                                                                      # conv_2(pad(x * x_mask)) * x_mask    (:345-346)
             y2 = mk(Co)
-            conv_fwd(h, w2, p["ffn.conv_2.bias"], y2, k, 1, 0)
+            conv_fwd(h, w2, p["ffn.conv_2.bias"], y2, k, 1, self.cmp)
             _mask(y2, lens)
             s2 = mk(Co)
             torch.add(res.store, y2.store, out=s2.store)                                        # norm_layers_2(x + y)     (:482)
@@ -222,11 +227,11 @@ class RelativePositionTransformer:
             if Cp != Co:                                           # one output channel rides in a 4-wide sequence (GEMM leading dimensions)
                 wide = mk(Cp); wide.store[:, :Co] = dres.store; dres = wide
             dWp = torch.zeros(Cp, Cc, device=self.device); dbp = torch.zeros(Cp, device=self.device)
-            conv_bwd_weight(dres, x1, dWp, dbp, 1, 1, 0)
+            conv_bwd_weight(dres, x1, dWp, dbp, 1, 1, self.cmp)
             self.proj_g["weight"] += dWp[:Co].view(Co, Cc, 1)
             self.proj_g["bias"] += dbp[:Co]
             d = mk(Cc)
-            conv_bwd_data(dres, wp, d, 1, 1, 0, False)
+            conv_bwd_data(dres, wp, d, 1, 1, self.cmp, False)
             return d
         for li, l, sv in zip(reversed(range(self.L)), reversed(self.layers), reversed(self.saved)):
             p, g = l.p, l.g
@@ -244,19 +249,19 @@ class RelativePositionTransformer:
                                                _lib.ptr(g["norm2.beta"]), dx.rows, Co, _lib.stream_ptr()), "xva_ln_rows_bwd")
                 dy2 = mk(Co); dy2.store.copy_(ds2.store); _mask(dy2, lens)                       # y2 = conv_2(..) * x_mask
                 dW2 = torch.zeros(Co, k * F, device=self.device)
-                conv_bwd_weight(dy2, h, dW2, g["ffn.conv_2.bias"], k, 1, 0)
+                conv_bwd_weight(dy2, h, dW2, g["ffn.conv_2.bias"], k, 1, self.cmp)
                 g["ffn.conv_2.weight"] += dW2.view(Co, k, F).permute(0, 2, 1)
                 dh = mk(F)
                 P_ = (k - 1) // 2
                 # d(conv_1 output) = (dy2 (*) W2) gated by relu (h is stored masked and post-ReLU: h > 0 is both the gate and the mask)
-                _lib.gemm(dy2.store, w2, dh.store, dy2.rows, F, k * Co, Co, k * F, F, layout=_lib.GEMM_NN, compute=0, a_offset=dy2.off(P_), c_offset=dh.off(),
+                _lib.gemm(dy2.store, w2, dh.store, dy2.rows, F, k * Co, Co, k * F, F, layout=_lib.GEMM_NN, compute=self.cmp, a_offset=dy2.off(P_), c_offset=dh.off(),
                           a_seglen=Co if k > 1 else 0, a_segadj=-2 * Co if k > 1 else 0, seglen=Co if k > 1 else 0, seg0=0, segstride=F if k > 1 else 0,
                           G=h.view, ldg=F, gate_slope=0.0, mask_mode=_lib.MASK_PAD, Tp=dy2.Tp, mask_pad=PAD, mask_len=T)
                 dW1 = torch.zeros(F, k * Cc, device=self.device)
-                conv_bwd_weight(dh, x1m, dW1, g["ffn.conv_1.bias"], k, 1, 0)
+                conv_bwd_weight(dh, x1m, dW1, g["ffn.conv_1.bias"], k, 1, self.cmp)
                 g["ffn.conv_1.weight"] += dW1.view(F, k, Cc).permute(0, 2, 1)
                 dx1m = mk(Cc)
-                conv_bwd_data(dh, w1, dx1m, k, 1, 0, False)
+                conv_bwd_data(dh, w1, dx1m, k, 1, self.cmp, False)
                 _mask(dx1m, lens)                                                                # x1m = x1 * x_mask
                 dres = proj_bwd(ds2, x1) if (last and self.proj is not None) else ds2            # residual branch: x or proj(x)
                 dx1 = mk(Cc)
@@ -265,10 +270,10 @@ class RelativePositionTransformer:
             _lib.check(lib.xva_ln_rows_bwd(_p(dx1.view), _p(s1.view), _lib.ptr(m1), _lib.ptr(r1), _lib.ptr(p["norm1.gamma"]), _p(ds1.view), _lib.ptr(g["norm1.gamma"]),
                                            _lib.ptr(g["norm1.beta"]), dx1.rows, Cc, _lib.stream_ptr()), "xva_ln_rows_bwd")
             dWo = torch.zeros(Cc, Cc, device=self.device)
-            conv_bwd_weight(ds1, att, dWo, g["attn.conv_o.bias"], 1, 1, 0)
+            conv_bwd_weight(ds1, att, dWo, g["attn.conv_o.bias"], 1, 1, self.cmp)
             g["attn.conv_o.weight"] += dWo.view(Cc, Cc, 1)
             datt = mk(Cc)
-            conv_bwd_data(ds1, wo, datt, 1, 1, 0, False)
+            conv_bwd_data(ds1, wo, datt, 1, 1, self.cmp, False)
             dqkv = mk(3 * Cc)
             dS = torch.empty_like(P)
             demb_k = g["attn.emb_rel_k"]; demb_v = g["attn.emb_rel_v"]
@@ -277,12 +282,12 @@ class RelativePositionTransformer:
                                            _p(dqkv.view, 2 * Cc), 3 * Cc, _lib.ptr(demb_k), _lib.ptr(demb_v), B, T, H, dk, self.w, 1, dx.Tp, PAD,
                                            _lib.stream_ptr()), "xva_relattn_bwd")
             dWqkv = torch.zeros(3 * Cc, Cc, device=self.device); dbqkv = torch.zeros(3 * Cc, device=self.device)
-            conv_bwd_weight(dqkv, xm, dWqkv, dbqkv, 1, 1, 0)
+            conv_bwd_weight(dqkv, xm, dWqkv, dbqkv, 1, 1, self.cmp)
             for j, n in enumerate("qkv"):
                 g["attn.conv_%s.weight" % n] += dWqkv[j * Cc:(j + 1) * Cc].view(Cc, Cc, 1)
                 g["attn.conv_%s.bias" % n] += dbqkv[j * Cc:(j + 1) * Cc]
             dxm = mk(Cc)
-            conv_bwd_data(dqkv, wqkv, dxm, 1, 1, 0, False)
+            conv_bwd_data(dqkv, wqkv, dxm, 1, 1, self.cmp, False)
             dxm.store += ds1.store                                                               # residual x + y
             _mask(dxm, lens)                                                                     # xm = x * x_mask
             dx = dxm
