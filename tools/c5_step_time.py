@@ -1,4 +1,4 @@
-"""One xVAPitch iteration (BASELINE config C5: generator pass fwd + bwd, discriminator pass fwd + bwd; no optimiser) at the reference's model size —
+"""One xVAPitch iteration (BASELINE config C5: generator pass fwd + bwd, discriminator pass fwd + bwd, the two AdamW updates) at the reference's model size —
 python/xvapitch/model.py:55-149: latent 192, language embedding 4, speaker vector 512, text encoder 10 layers x 196 channels (ffn 768, 2 heads),
 posterior encoder 16 WN layers on 513 spectrogram bins, flow 4 x 4 WN layers, pitch predictor 3 layers x 708 channels, decoder 512 -> 32 channels,
 spec_segment_size 32 (8192 samples) — on a synthetic batch (random weights; sizes from argv).
@@ -59,20 +59,22 @@ def iteration():
     torch.cuda.synchronize(); t1 = time.perf_counter()
     ld = step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    return (t1 - t0) * 1e3, (t2 - t1) * 1e3, float(o["loss"]), float(ld)
+    step.optimizer_step(lr=1e-6, lr_disc=1e-6)
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    return (t1 - t0) * 1e3, (t2 - t1) * 1e3, float(o["loss"]), float(ld), (t3 - t2) * 1e3
 
 
 for _ in range(2):
     iteration()
 N = 5
-acc = [0.0, 0.0]
+acc = [0.0, 0.0, 0.0]
 for _ in range(N):
-    a, b, lg, ld = iteration()
-    acc[0] += a / N; acc[1] += b / N
-tot = acc[0] + acc[1]
+    a, b, lg, ld, c_ = iteration()
+    acc[0] += a / N; acc[1] += b / N; acc[2] += c_ / N
+tot = acc[0] + acc[1] + acc[2]
 print("xVAPitch C5 iteration, B=%d x (%d symbols, %d spectrogram frames), segment %d samples, decoder / discriminator %s, WaveNet stacks %s, transformer / SDP fp32:" % (B, Tt, Ty, SEG * 256, dt, adt))
-print("  generator pass fwd + bwd %.1f ms | discriminator pass fwd + bwd %.1f ms | iteration %.1f ms = %.0f k segment-samples / s, %.0f spectrogram frames / s (losses %.3f / %.3f)"
-      % (acc[0], acc[1], tot, B * SEG * 256 / tot, float(y_lens.sum()) / tot * 1e3, lg, ld))
+print("  generator pass fwd + bwd %.1f ms | discriminator pass fwd + bwd %.1f ms | 2 x AdamW %.1f ms | iteration %.1f ms = %.0f k segment-samples / s, %.0f spectrogram frames / s (losses %.3f / %.3f)"
+      % (acc[0], acc[1], acc[2], tot, B * SEG * 256 / tot, float(y_lens.sum()) / tot * 1e3, lg, ld))
 
 if os.environ.get("XVA_C5_CPU_BASELINE", "0") != "0":
     # The CPU restatement (oracle/: the checker of tests/, timed here as the reference-algorithm baseline on this host's cores) on the first

@@ -142,6 +142,31 @@ class AcousticTrainPath:
                 g.update({pre + k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in m.p.items()})
         return g
 
+    def param_grad_pairs(self):
+        """[(parameter tensor, its gradient tensor)] over the tensors the modules actually hold (not the clones of state_dict()): what an in-place
+        optimiser steps.  Leaf parameters without a gradient yet are paired with None."""
+        def conv(c):
+            return [(c.p[n], c.g[n]) for n in c.p]
+
+        def wn(w):
+            return [pg for _, c in w._named() for pg in conv(c)]
+        out = [(v, v.grad) for v in self.p.values()]
+        for _, m in self._subs:
+            if isinstance(m, RelativePositionTransformer):
+                pd, gd = dict(m._named("p")), dict(m._named("g"))
+                # out_channels == 1: the last layer's feed-forward network and second LayerNorm never reach the output (transformer.py): no gradient, like
+                # the reference's p.grad None
+                dead = ("ffn_layers.%d." % (m.L - 1), "norm_layers_2.%d." % (m.L - 1)) if m.Co == 1 else ()
+                out += [(pd[k], None if k.startswith(dead) and dead else gd[k]) for k in pd]
+            elif isinstance(m, PosteriorEncoder):
+                out += conv(m.pre) + wn(m.enc) + conv(m.proj)
+            elif isinstance(m, ResidualCouplingBlocks):
+                for f in m.flows:
+                    out += conv(f.pre) + wn(f.enc) + conv(f.post)
+            else:
+                out += [(v, v.grad) for v in m.p.values()]
+        return out
+
     def zero_grad(self):
         for v in self.p.values():
             v.grad = None

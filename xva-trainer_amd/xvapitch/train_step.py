@@ -15,7 +15,15 @@ gradient to the generator; only loss_gen sends a gradient through the discrimina
     out["loss"].backward()                               # generator gradients: step.gen.acoustic.grads(), step.gen.decoder.grads()
     loss_disc = step.discriminator_pass(out["model_outputs"].detach(), out["waveform_seg"])      # discriminator gradients: step.disc.grads()
 """
+import ctypes as C
+
 import torch
+
+from .. import _lib
+
+_lib.lib.xva_adamw_step.restype = C.c_int32
+_lib.lib.xva_adamw_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_void_p]
 
 
 class _Adversarial(torch.autograd.Function):
@@ -42,6 +50,36 @@ class XVAPitchStep:
         loss_gen, loss_feat = _Adversarial.apply(out["model_outputs"], out["waveform_seg"], self.disc)          # model.py:313-315, losses.py:195-196
         out.update({"loss_gen": loss_gen, "loss_feat": loss_feat, "loss": out["loss"] + loss_gen + loss_feat})  # losses.py:300
         return out
+
+    # ---- the two torch.optim.AdamW of python/xvapitch/training_util.py:56-57 (betas 0.8 / 0.99, eps 1e-9, weight decay 0.01; lr args.lr / 2e-4) ----
+    def _adamw(self, key, flat_p, flat_g, lr, betas, eps, weight_decay):
+        st = self._opt.setdefault(key, {"m": torch.zeros_like(flat_p), "v": torch.zeros_like(flat_p)})
+        _lib.check(_lib.lib.xva_adamw_step(_lib.ptr(flat_p), _lib.ptr(flat_g), _lib.ptr(st["m"]), _lib.ptr(st["v"]), flat_p.numel(), self._opt_step, lr,
+                                           betas[0], betas[1], eps, weight_decay, _lib.stream_ptr()), "xva_adamw_step")
+
+    def optimizer_step(self, lr=2e-4, lr_disc=2e-4, betas=(0.8, 0.99), eps=1e-9, weight_decay=0.01):
+        """One step of both optimisers on the gradients the two passes left (xva_train.py:722-735: both step after the iteration's backward
+        passes).  Generator group = every module make_optim chains (emb_l, text encoder, duration predictor, flow, posterior encoder, waveform
+        decoder, pitch predictor, pitch_emb): one AdamW, so the acoustic parameters are stepped as one flat vector (gathered from / scattered
+        back to the modules' tensors), the decoder and the discriminator in their own flat buffers — one xva_adamw_step each."""
+        if not hasattr(self, "_opt"):
+            self._opt, self._opt_step = {}, 0
+        self._opt_step += 1
+        ac, dec, D = self.gen.acoustic, self.gen.decoder, self.disc
+        pairs = [(p_, g_) for p_, g_ in ac.param_grad_pairs() if g_ is not None]          # parameters no loss term reached are not stepped (torch skips p.grad is None)
+        ps = [p_.detach() for p_, _ in pairs]
+        key = "acoustic:%d" % len(ps)
+        flat_p = torch.cat([t.reshape(-1) for t in ps])                                    # gather -> ONE xva_adamw_step -> scatter (torch copies: plumbing)
+        flat_g = torch.cat([g_.detach().reshape(-1) for _, g_ in pairs])
+        self._adamw(key, flat_p, flat_g, lr, betas, eps, weight_decay)
+        views, off = [], 0
+        for t in ps:
+            views.append(flat_p[off:off + t.numel()].view(t.shape))
+            off += t.numel()
+        with torch.no_grad():
+            torch._foreach_copy_(ps, views)
+        self._adamw("decoder", dec.params, dec.grad, lr, betas, eps, weight_decay)
+        self._adamw("disc", D.params, D.grad, lr_disc, betas, eps, weight_decay)
 
     def discriminator_pass(self, y_disc_cache, wav_seg_disc_cache):
         """model.py:366-384 + VitsDiscriminatorLoss (losses.py:331-351); the parameter gradients accumulate in self.disc.grads()."""
