@@ -111,3 +111,31 @@ def test_hifigan_bucket_ranges_tile_the_trainable_prefix():
     assert d == sorted(d)                                   # discriminators finish in buffer order (MPD 0..4, MSD 0..2)
     g = HE.bucket_ranges(HE.G)
     assert g[0][0] > g[3][0] and g[4][0] == 0               # generator: last stage's resblocks first, conv_pre + ups last
+
+
+def _mean_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xva_trainer_amd.xvapitch.train_step import allreduce_mean_
+    g = torch.Generator().manual_seed(100 + rank)
+    a, b, c = torch.randn(3, 4, generator=g), torch.randn(5, generator=g), torch.randn(2, 1, 3, generator=g)
+    keep = [t.clone() for t in (a, b, c)]
+    allreduce_mean_([a, None, b, c[:, :, :2]])                        # a None entry and a non-contiguous view (the padded posterior weight's gradient)
+    torch.save({"after": [a, b, c], "before": keep}, os.path.join(tmp, "mean_%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_xvapitch_gradient_mean_world2(tmp_path):
+    """xvapitch/train_step.py:allreduce_mean_ (the C5 iteration's data-parallel gradient reduction) on 2 gloo ranks: every listed tensor ends as
+    the mean over ranks, in place, including a non-contiguous view; tensors outside the list (the last column of c) keep their values."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_mean_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "mean_%d.pt" % r)) for r in (0, 1))
+    for i in range(2):
+        want = (r0["before"][i] + r1["before"][i]) / 2
+        assert torch.allclose(r0["after"][i], want) and torch.allclose(r1["after"][i], want)
+    want = (r0["before"][2] + r1["before"][2]) / 2
+    for r in (r0, r1):
+        assert torch.allclose(r["after"][2][:, :, :2], want[:, :, :2]) and torch.equal(r["after"][2][:, :, 2], r["before"][2][:, :, 2])

@@ -53,3 +53,42 @@ def test_gradsync_single_rank_rccl_matches_plain_step(stage):
         assert rel < 2e-2, rel                                        # two half-scaled bf16 passes vs one full pass
     finally:
         dist.destroy_process_group()
+
+
+def test_xvapitch_c5_sync_gradients_single_rank_rccl(golden_dir):
+    """xvapitch/train_step.py:XVAPitchStep.sync_gradients on a 1-rank RCCL group: the flat gather / all-reduce / scatter over the acoustic modules'
+    own gradient tensors (incl. the non-contiguous view of the padded posterior-encoder weight), the decoder's and the discriminator's flat
+    buffers returns every gradient unchanged (mean over one rank); world-size-2 arithmetic is covered on gloo in tests/test_dp_cpu.py."""
+    import numpy as np
+    import torch.distributed as dist
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
+    from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+    from xva_trainer_amd.xvapitch.discriminator import VitsDiscriminator
+    from xva_trainer_amd.xvapitch.generator_pass import GeneratorPass
+    from xva_trainer_amd.xvapitch.train_step import XVAPitchStep
+    g = np.load(os.path.join(golden_dir, "xvapitch_genpass.npz"))
+    c = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    ac = AcousticTrainPath(c["vocab"], c["langs"], latent_size=c["latent"], embedded_language_dim=c["lang_dim"], d_vector_dim=c["dvec"],
+                           hidden_channels_ffn=c["ffn"], num_heads=c["heads"], text_layers=c["te_layers"], posterior_layers=c["pe_layers"],
+                           flow_layers=c["flow_layers"], num_flows=c["num_flows"], spec_bins=c["spec_bins"], pitch=True)
+    ac.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")})
+    dec = VitsDecoder(c["latent"], c["dvec"]); dec.load_state_dict(ohg.init_vits_decoder_sd(int(g["dec_seed"]), c["latent"], c["dvec"]))
+    D = VitsDiscriminator(); D.load_state_dict(ohg.init_vits_disc_sd(3))
+    step = XVAPitchStep(GeneratorPass(ac, dec, spec_segment_size=int(g["seg"])), D)
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    o = step.generator_pass(t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("wav"), t("dvec"), t("lids"), pitch_padded=t("pitch"), eps=t("eps"),
+                            noise=t("noise"), slice_ids=t("slice_ids"))
+    o["loss"].backward()
+    step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
+    before = {n + k: v.detach().clone() for n, m in (("ac/", ac), ("dec/", dec), ("D/", D)) for k, v in m.grads().items()}
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        step.sync_gradients()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    after = {n + k: v for n, m in (("ac/", ac), ("dec/", dec), ("D/", D)) for k, v in m.grads().items()}
+    assert len(before) > 800 and all(torch.equal(before[k], after[k]) for k in before)

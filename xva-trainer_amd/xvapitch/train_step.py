@@ -26,6 +26,26 @@ _lib.lib.xva_adamw_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void
                                     C.c_float, C.c_void_p]
 
 
+def allreduce_mean_(tensors, group=None):
+    """Data-parallel gradient reduction of a list of tensors: ONE flat SUM all-reduce (RCCL on GPU ranks, gloo in the CPU tests) and a division by
+    the world size, written back in place.  The mean is nn.DataParallel's semantics in the reference trainer (python/xvapitch/xva_train.py:77-82,
+    427-428 wrap the model; each replica normalises its losses over its own sub-batch and `loss_dict["loss"].mean()` averages the replicas, :664-668)."""
+    import torch.distributed as dist
+    ts = [t for t in tensors if t is not None]
+    if not ts or not dist.is_available() or not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    flat = torch.cat([t.detach().reshape(-1) for t in ts])
+    dist.all_reduce(flat, group=group)
+    flat.mul_(1.0 / world)
+    views, off = [], 0
+    for t in ts:
+        views.append(flat[off:off + t.numel()].view(t.shape))
+        off += t.numel()
+    with torch.no_grad():
+        torch._foreach_copy_([t.detach() for t in ts], views)
+
+
 class _Adversarial(torch.autograd.Function):
     """(generated segment, real segment) -> (loss_gen, loss_feat); backward: d loss_gen / d generated (see the module docstring for loss_feat)."""
     @staticmethod
@@ -80,6 +100,13 @@ class XVAPitchStep:
             torch._foreach_copy_(ps, views)
         self._adamw("decoder", dec.params, dec.grad, lr, betas, eps, weight_decay)
         self._adamw("disc", D.params, D.grad, lr_disc, betas, eps, weight_decay)
+
+    def sync_gradients(self, group=None):
+        """One process per GPU (torch.distributed over RCCL): average the iteration's gradients across the ranks — the generator group (acoustic
+        modules + decoder) and the discriminator — before optimizer_step.  No-op without an initialised process group."""
+        ac, dec, D = self.gen.acoustic, self.gen.decoder, self.disc
+        allreduce_mean_([g_ for _, g_ in ac.param_grad_pairs() if g_ is not None] + [dec.grad], group)
+        allreduce_mean_([D.grad], group)
 
     def discriminator_pass(self, y_disc_cache, wav_seg_disc_cache):
         """model.py:366-384 + VitsDiscriminatorLoss (losses.py:331-351); the parameter gradients accumulate in self.disc.grads()."""
