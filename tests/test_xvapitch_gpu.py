@@ -178,7 +178,8 @@ def test_posterior_encoder_against_reference_golden(golden_dir):
 
 
 def _rel(a, b):
-    return float((a.detach().double().cpu() - b.detach().double()).norm() / b.detach().double().norm().clamp_min(1e-30))
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
 def test_rel_transformer_against_reference_golden(golden_dir):
@@ -702,3 +703,52 @@ def test_c5_optimizer_step_matches_torch_adamw(golden_dir):
                     for n, m in mods for k, v in m.state_dict().items()), reverse=True)
     print("C5 AdamW: worst max-abs error relative to the tensor's max after 2 steps:", worst[:3], "of", len(worst))
     assert len(worst) > 800 and worst[0][0] < 1e-5, worst[:4]
+
+
+def test_c5_properties_at_reference_model_size():
+    """Size-independent properties at the reference's model size (latent 192, speaker vector 512, 513 spectrogram bins, B = 4 x 100 symbols x 400
+    frames): the flow is a bijection (reverse(forward(z)) = z on the unmasked frames), the alignment the acoustic path searches is a monotonic
+    path (one symbol per frame, non-decreasing, every symbol visited, durations summing to the frame count), and the decoder's backward is
+    linear in the cotangent (gradients for 2 r = 2 x gradients for r)."""
+    from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
+    from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+    B, Tt, Ty = 4, 100, 400
+    gen = torch.Generator().manual_seed(3)
+    ac = AcousticTrainPath(256, 31, pitch=True, text_layers=2, posterior_layers=4)            # full widths; fewer layers keep the test short
+    x_lens = torch.tensor([100, 77, 60, 31]); y_lens = torch.tensor([400, 333, 251, 140])
+    tokens = (torch.randint(1, 256, (B, Tt), generator=gen) * (torch.arange(Tt)[None, :] < x_lens[:, None])).cuda()
+    y = (torch.rand(B, 513, Ty, generator=gen) * (torch.arange(Ty)[None, None, :] < y_lens[:, None, None])).cuda()
+    dvec = torch.randn(B, 512, generator=gen).cuda(); lids = torch.randint(0, 31, (B,), generator=gen).cuda()
+    pitch = ((torch.rand(B, 1, Ty, generator=gen) * 3 - 1.2).clamp_min(0) * (torch.arange(Ty)[None, None, :] < y_lens[:, None, None])).cuda()
+    o = ac(tokens, x_lens.cuda(), y, y_lens.cuda(), dvec, lids, pitch_padded=pitch)
+    assert all(torch.isfinite(o[k]).all() for k in ("loss_kl", "loss_duration", "loss_pitch", "z_p"))
+    attn = o["attn"].cpu()                                                                      # (B, Tt, Ty)
+    for b in range(B):
+        a = attn[b, :x_lens[b], :y_lens[b]]
+        assert bool((a.sum(0) == 1).all()) and bool((a.sum(1) >= 1).all())                      # one symbol per frame, every symbol used
+        idx = a.argmax(0)
+        assert bool((idx[1:] - idx[:-1] >= 0).all()) and bool((idx[1:] - idx[:-1] <= 1).all()) and int(idx[0]) == 0 and int(idx[-1]) == int(x_lens[b]) - 1
+        assert float(attn[b].sum()) == float(y_lens[b])
+    g = torch.nn.functional.normalize(dvec).unsqueeze(-1)
+    with torch.no_grad():
+        zf = ac.flow(o["z"].detach(), o["y_mask"], g=g)
+        back = ac.flow(zf, o["y_mask"], g=g, reverse=True)
+    assert _rel(back * o["y_mask"], o["z"].detach() * o["y_mask"]) < 1e-4
+    dec = VitsDecoder(192, 512)
+    sd = {}
+    for k, (off, numel, shape) in dec.table.items():
+        sd[k] = torch.randn(shape, generator=gen) * 0.03
+    for k in list(sd):
+        if k.endswith("weight_g"):
+            v = sd[k[:-1] + "v"]
+            sd[k] = v.reshape(v.size(0), -1).norm(dim=1).reshape(sd[k].shape)
+    dec.load_state_dict(sd)
+    z = torch.randn(B, 192, 32, generator=gen).cuda()
+    r = torch.randn(B, 1, 8192, generator=gen).cuda()
+    res = []
+    for scale in (1.0, 2.0):
+        dec.zero_grad()
+        zz = z.clone().requires_grad_(True)
+        (dec(zz, g) * (r * scale)).sum().backward()
+        res.append((zz.grad.clone(), dec.grad.clone()))
+    assert _rel(res[1][0], 2 * res[0][0]) < 1e-5 and _rel(res[1][1], 2 * res[0][1]) < 1e-5
