@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hifigan", action="store_true", help="skip the HiFi-GAN audio-samples/s leg")
+    ap.add_argument("--no-xvapitch", action="store_true", help="skip the xVAPitch (BASELINE configs[4]) iteration timing")
     ap.add_argument("--hg-batch", type=int, default=64)
     ap.add_argument("--hg-steps", type=int, default=0, help="timed HiFi-GAN steps (default: min(steps, 10))")
     return ap.parse_args()
@@ -383,6 +384,60 @@ def spawn_ranks(n):
     os.execv(sys.executable, cmd)
 
 
+def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2):
+    """One xVAPitch training iteration (BASELINE configs[4] on one GPU: generator pass fwd + bwd, discriminator pass fwd + bwd, the two AdamW updates;
+    xva-trainer_amd/xvapitch/train_step.py) at the reference's model size (python/xvapitch/model.py:55-149) on a synthetic batch with random weights,
+    throughput mode (decoder / discriminator / WaveNet stacks bf16, transformer products bf16 MFMA on fp32 storage).  An extra measurement beside
+    the two legs of `metric`: the path is parity-first (pinned to the reference's own train_step, tests/test_xvapitch_gpu.py), not tuned."""
+    from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
+    from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+    from xva_trainer_amd.xvapitch.discriminator import VitsDiscriminator
+    from xva_trainer_amd.xvapitch.generator_pass import GeneratorPass
+    from xva_trainer_amd.xvapitch.train_step import XVAPitchStep
+    VOCAB, LANGS, SEG = 256, 31, 32
+    gen = torch.Generator().manual_seed(1)
+    ac = AcousticTrainPath(VOCAB, LANGS, pitch=True, compute="bf16", device=dev)
+    dec, D = VitsDecoder(192, 512, compute="bf16", device=dev), VitsDiscriminator(compute="bf16", device=dev)
+    for eng in (dec, D):                                    # random weights: weight_v ~ N(0, 0.02), weight_g = the row norms
+        sd = {k: torch.randn(shape, generator=gen) * 0.02 for k, (off, numel, shape) in eng.table.items()}
+        for k in list(sd):
+            if k.endswith("weight_g"):
+                v = sd[k[:-1] + "v"]
+                sd[k] = v.reshape(v.size(0), -1).norm(dim=1).reshape(sd[k].shape)
+        eng.load_state_dict(sd)
+    step = XVAPitchStep(GeneratorPass(ac, dec, SEG), D)
+    x_lens = torch.randint(Tt // 2, Tt + 1, (B,), generator=gen); x_lens[0] = Tt
+    y_lens = torch.randint(max(Ty // 2, SEG + 1), Ty + 1, (B,), generator=gen); y_lens[0] = Ty
+    tokens = (torch.randint(1, VOCAB, (B, Tt), generator=gen) * (torch.arange(Tt)[None, :] < x_lens[:, None])).to(dev)
+    frame_mask = torch.arange(Ty)[None, None, :] < y_lens[:, None, None]
+    y = (torch.rand(B, 513, Ty, generator=gen) * frame_mask).to(dev)
+    wav = (torch.rand(B, 1, Ty * 256, generator=gen) * 1.6 - 0.8).to(dev)
+    dvec, lids = torch.randn(B, 512, generator=gen).to(dev), torch.randint(0, LANGS, (B,), generator=gen).to(dev)
+    pitch = ((torch.rand(B, 1, Ty, generator=gen) * 3 - 1.2).clamp_min(0) * frame_mask).to(dev)
+    xl, yl = x_lens.to(dev), y_lens.to(dev)
+
+    def iteration():
+        step.gen.zero_grad(); D.zero_grad()
+        o = step.generator_pass(tokens, xl, y, yl, wav, dvec, lids, pitch_padded=pitch)
+        o["loss"].backward()
+        ld = step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
+        step.optimizer_step(lr=1e-6, lr_disc=1e-6)
+        return o, ld
+    for _ in range(warm):
+        iteration()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        o, ld = iteration()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"metric": "segment audio-samples/sec (xVAPitch iteration: generator pass + discriminator pass + 2 x AdamW)", "value": B * SEG * 256 / ms * 1e3,
+            "unit": "audio-samples/s", "ms_per_step": ms, "steps": iters, "dtype": "bf16 (duration predictor, attention, LayerNorm, MAS, losses fp32)",
+            "config": {"workload": "xVAPitch (python/xvapitch/model.py:55-149 sizes) B=%d x %d symbols x %d spectrogram frames (513 bins), 8192-sample segments, --pitch 1"
+                                   % (B, Tt, Ty), "spectrogram_frames_per_s": float(y_lens.sum()) / ms * 1e3},
+            "loss": float(o["loss"]), "loss_disc": float(ld), "note": "parity-first path (tests/test_xvapitch_gpu.py), launch bound, not tuned; random weights"}
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -488,6 +543,12 @@ def main():
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             hg["cpu_baseline"] = hifigan_cpu_baseline()
         out["hifigan"] = hg
+    if rank == 0 and world == 1 and not a.no_xvapitch:
+        try:
+            torch.cuda.empty_cache()
+            out["xvapitch_c5"] = xvapitch_c5_leg(dev)
+        except Exception as e:                               # an extra measurement: never at the price of the contract line
+            out["xvapitch_c5"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(stage)
     if rank == 0:
