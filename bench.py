@@ -385,7 +385,8 @@ def spawn_ranks(n):
 
 
 def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2):
-    """One xVAPitch training iteration (BASELINE configs[4] on one GPU: generator pass fwd + bwd, discriminator pass fwd + bwd, the two AdamW updates;
+    """One xVAPitch training iteration (BASELINE configs[4] on one GPU: linear spectrograms from the raw clips, generator pass fwd + bwd,
+    discriminator pass fwd + bwd, the two AdamW updates;
     xva-trainer_amd/xvapitch/train_step.py) at the reference's model size (python/xvapitch/model.py:55-149) on a synthetic batch with random weights,
     throughput mode (decoder / discriminator / WaveNet stacks bf16, transformer products bf16 MFMA on fp32 storage).  An extra measurement beside
     the two legs of `metric`: the path is parity-first (pinned to the reference's own train_step, tests/test_xvapitch_gpu.py), not tuned."""
@@ -410,14 +411,16 @@ def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2):
     y_lens = torch.randint(max(Ty // 2, SEG + 1), Ty + 1, (B,), generator=gen); y_lens[0] = Ty
     tokens = (torch.randint(1, VOCAB, (B, Tt), generator=gen) * (torch.arange(Tt)[None, :] < x_lens[:, None])).to(dev)
     frame_mask = torch.arange(Ty)[None, None, :] < y_lens[:, None, None]
-    y = (torch.rand(B, 513, Ty, generator=gen) * frame_mask).to(dev)
-    wav = (torch.rand(B, 1, Ty * 256, generator=gen) * 1.6 - 0.8).to(dev)
+    wav_lens = ((y_lens - 1) * 256 + torch.randint(0, 256, (B,), generator=gen)).to(dev)          # raw clips of y_lens frames each (1 + N // 256)
+    wavs = (torch.rand(B, (Ty - 1) * 256 + 255, generator=gen) * 1.6 - 0.8).to(dev)
+    wavs = wavs * (torch.arange(wavs.size(1), device=dev)[None, :] < wav_lens[:, None])
     dvec, lids = torch.randn(B, 512, generator=gen).to(dev), torch.randint(0, LANGS, (B,), generator=gen).to(dev)
     pitch = ((torch.rand(B, 1, Ty, generator=gen) * 3 - 1.2).clamp_min(0) * frame_mask).to(dev)
-    xl, yl = x_lens.to(dev), y_lens.to(dev)
+    xl = x_lens.to(dev)
 
     def iteration():
         step.gen.zero_grad(); D.zero_grad()
+        y, yl, wav = step.gen.batch_from_wav(wavs, wav_lens)        # the posterior encoder's linear spectrograms from the raw clips, on the fly
         o = step.generator_pass(tokens, xl, y, yl, wav, dvec, lids, pitch_padded=pitch)
         o["loss"].backward()
         ld = step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
@@ -431,7 +434,7 @@ def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2):
         o, ld = iteration()
     torch.cuda.synchronize(dev)
     ms = (time.perf_counter() - t0) / iters * 1e3
-    return {"metric": "segment audio-samples/sec (xVAPitch iteration: generator pass + discriminator pass + 2 x AdamW)", "value": B * SEG * 256 / ms * 1e3,
+    return {"metric": "segment audio-samples/sec (xVAPitch iteration from raw clips: spectrograms + generator pass + discriminator pass + 2 x AdamW)", "value": B * SEG * 256 / ms * 1e3,
             "unit": "audio-samples/s", "ms_per_step": ms, "steps": iters, "dtype": "bf16 (duration predictor, attention, LayerNorm, MAS, losses fp32)",
             "config": {"workload": "xVAPitch (python/xvapitch/model.py:55-149 sizes) B=%d x %d symbols x %d spectrogram frames (513 bins), 8192-sample segments, --pitch 1"
                                    % (B, Tt, Ty), "spectrogram_frames_per_s": float(y_lens.sum()) / ms * 1e3},

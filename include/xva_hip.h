@@ -65,6 +65,12 @@ int xva_mel_spectrogram(const xva_mel_config* cfg, const float* wav, int B, int 
  * 513-bin posterior-encoder input of xVAPitch (dataset side: AudioProcessor.spectrogram :632-652).  Workspace as above. */
 int xva_linear_spectrogram(const xva_mel_config* cfg, const float* wav, int B, int N, int64_t ld_wav, const float* dft_basis,
                            float* lin_out, float* workspace, int64_t workspace_bytes, void* stream);
+/* The same for a ragged batch of float clips (xVAPitch: python/xvapitch/dataset.py:251 computes AudioProcessor.spectrogram per clip — librosa.stft,
+ * center, reflect padding at the clip's own ends — and the collate zero-pads, :470-475): row r of wav (B, ld_wav) holds n_samples[r] valid samples;
+ * lin_out (B, n_fft / 2 + 1, 1 + Nmax / hop) gets the clip's own 1 + n_samples[r] / hop frames (written to n_frames_out[r]) and zeros after.
+ * Every n_samples[r] must exceed n_fft / 2 (reflect padding, as torch.stft / librosa require); the values live on the device and are not checked. */
+int xva_linear_spectrogram_ragged(const xva_mel_config* cfg, const float* wav, const int32_t* n_samples, int B, int Nmax, int64_t ld_wav,
+                                  const float* dft_basis, float* lin_out, int32_t* n_frames_out, float* workspace, int64_t workspace_bytes, void* stream);
 
 /* Differentiable mel for the generator's L1 mel loss (python/hifigan/xva_train.py:480,504; xVAPitch: VitsGeneratorLoss,
  * python/xvapitch/losses.py:187-193 with the M3 config):

@@ -104,3 +104,26 @@ def test_m3_clamp_passes_no_gradient_on_silence():
     d = torch.ones_like(y)
     loss, mel = m.l1_loss_backward(y, torch.zeros(2, 80, 33, device="cuda"), d, accumulate=False)
     assert torch.isfinite(loss).all() and float(d.abs().max()) == 0.0
+
+
+def test_linear_spectrogram_ragged_equals_per_clip_spectrograms():
+    """xva_linear_spectrogram_ragged (xVAPitch's posterior-encoder input from a zero-padded ragged batch of raw clips) equals the dense-batch
+    kernel run on each clip alone — the per-clip reflect padding of the reference's dataset (python/xvapitch/dataset.py:251) — bit for bit on the
+    clip's own 1 + N // 256 frames, and is zero after them (the collate's zero padding, :470-475); frame counts exact."""
+    from xva_trainer_amd.mel import TorchSTFTMel
+    from xva_trainer_amd.xvapitch.generator_pass import GeneratorPass
+    stft = TorchSTFTMel()
+    lens = [22050, 9001, 600, 17000, 2047]               # every clip longer than n_fft / 2 (reflect padding, as torch.stft / librosa require)
+    gen = torch.Generator().manual_seed(0)
+    wavs = torch.zeros(len(lens), max(lens))
+    for i, n in enumerate(lens):
+        wavs[i, :n] = torch.rand(n, generator=gen) * 1.8 - 0.9
+    lin, frames = stft.linear_ragged(wavs.cuda(), torch.tensor(lens).cuda())
+    assert frames.cpu().tolist() == [1 + n // 256 for n in lens] and lin.shape == (len(lens), 513, 1 + max(lens) // 256)
+    for i, n in enumerate(lens):
+        one = stft.linear(wavs[i:i + 1, :n].cuda())[0]
+        assert torch.equal(lin[i, :, :one.size(1)], one), i
+        assert float(lin[i, :, one.size(1):].abs().max()) == 0.0 if one.size(1) < lin.size(2) else True
+    gp = GeneratorPass.__new__(GeneratorPass); gp.stft = stft
+    y, yl, wf = gp.batch_from_wav(wavs.cuda(), torch.tensor(lens).cuda())
+    assert torch.equal(y, lin) and wf.shape == (len(lens), 1, y.size(2) * 256) and torch.equal(wf[:, 0, :max(lens)].cpu(), wavs) and float(wf[:, 0, max(lens):].abs().max()) == 0.0

@@ -242,6 +242,59 @@ extern "C" int xva_linear_spectrogram(const xva_mel_config* c, const float* wav,
     return XVA_OK;
 }
 
+// Ragged batch of float clips (xVAPitch: python/xvapitch/dataset.py:251 computes `self.ap.spectrogram(wav)` per clip — librosa.stft, center,
+// reflect padding at the clip's OWN ends — and the collate zero-pads the spectrograms, :470-475): row r of a dense (B, ld_wav) batch holds
+// n_samples[r] valid samples; its 1 + n_samples[r] / hop frames are those of the clip alone, later frames are zero.
+__global__ void xva_reflect_pad_f32_ragged_kernel(const float* __restrict__ wav, int64_t ld_wav, const int32_t* __restrict__ lens, float* __restrict__ y, int pad,
+                                                  int64_t ldy, int32_t* __restrict__ n_frames, int n_fft, int hop) {
+    const int r = blockIdx.y;
+    const int N = lens[r], Np = N + 2 * pad;
+    const float* x = wav + (int64_t)r * ld_wav;
+    if (n_frames && blockIdx.x == 0 && threadIdx.x == 0) n_frames[r] = (Np - n_fft) / hop + 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ldy; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < Np) {
+            int s = (int)i - pad;
+            if (s < 0) s = -s;
+            if (s >= N) s = 2 * (N - 1) - s;
+            v = x[s];
+        }
+        y[(int64_t)r * ldy + i] = v;
+    }
+}
+__global__ void xva_zero_frames_kernel(float* __restrict__ out, const int32_t* __restrict__ n_frames, int C, int T) {
+    const int b = blockIdx.z, c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T && t >= n_frames[b]) out[((int64_t)b * C + c) * T + t] = 0.f;
+}
+extern "C" int xva_linear_spectrogram_ragged(const xva_mel_config* c, const float* wav, const int32_t* n_samples, int B, int Nmax, int64_t ld_wav,
+                                             const float* dft_basis, float* lin_out, int32_t* n_frames_out, float* workspace, int64_t workspace_bytes,
+                                             void* stream) {
+    XVA_CHECK_ARG(c && wav && n_samples && dft_basis && lin_out && n_frames_out && workspace, "linear_spectrogram_ragged: null pointer");
+    MelPlan pl;
+    XVA_TRY(mel_plan(c, B, Nmax, &pl));
+    XVA_CHECK_ARG(workspace_bytes >= pl.total * (int64_t)sizeof(float), "linear_spectrogram_ragged: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* ypad = workspace + pl.off_pad;
+    float* spec = workspace + pl.off_spec;
+    hipLaunchKernelGGL(xva_reflect_pad_f32_ragged_kernel, dim3((unsigned)(pl.ldy / 256 < 1 ? 1 : (pl.ldy / 256 > 128 ? 128 : pl.ldy / 256)), B), dim3(256), 0, st,
+                       wav, ld_wav, n_samples, ypad, c->pad, pl.ldy, n_frames_out, c->n_fft, c->hop);
+    XVA_LAUNCH_CHECK();
+    xva_gemm_params g;
+    memset(&g, 0, sizeof(g));
+    g.A = ypad; g.B = dft_basis; g.C = spec;
+    g.M = pl.T; g.N = 2 * pl.nb; g.K = c->n_fft;
+    g.lda = c->hop; g.ldb = c->n_fft; g.ldc = pl.lds;
+    g.batch = B; g.sA = pl.ldy; g.sB = 0; g.sC = (int64_t)pl.T * pl.lds;
+    g.alpha = 1.f; g.splitk = 1; g.compute = 0; g.layout = XVA_GEMM_NT;
+    XVA_TRY(xva_gemm(&g, stream));
+    hipLaunchKernelGGL(xva_magnitude_t_kernel, dim3(xva_cdiv(pl.T, 32), xva_cdiv(pl.nb, 32), B), dim3(256), 0, st, spec, lin_out, pl.T, pl.nb, pl.lds,
+                       c->mag_eps_add, c->mag_clamp_min);
+    XVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(xva_zero_frames_kernel, dim3(xva_cdiv(pl.T, 256), pl.nb, B), dim3(256), 0, st, lin_out, n_frames_out, pl.nb, pl.T);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
 // ====================================================================================================================
 // Differentiable mel: L1 mel loss of a generated waveform and its gradient w.r.t. the waveform
 //   loss = scale * mean |mel_tgt - mel(wav)|        (F.l1_loss(y_mel, y_g_hat_mel) * 45, python/hifigan/xva_train.py:480,504)

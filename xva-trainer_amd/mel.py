@@ -141,6 +141,38 @@ _lib.lib.xva_linear_spectrogram.argtypes = [C.POINTER(_lib.MelConfig), C.c_void_
 _MelEngine.linear = _engine_linear
 
 
+def _engine_linear_ragged(self, y, lens):
+    """y (B, Nmax) float clips, zero-padded; lens (B,) valid samples.  -> ((B, n_fft / 2 + 1, 1 + Nmax // hop) each clip's OWN spectrogram, zeros
+    after its 1 + lens // hop frames, n_frames (B,) int32)."""
+    _lib.require_cuda(y, lens)
+    if self.forward_basis.device != y.device:
+        self.to(y.device)
+    y = y.float().contiguous()
+    B, N = y.shape
+    if y.stride(0) % 4 != 0 or y.data_ptr() % 16 != 0:
+        ld = (N + 3) // 4 * 4
+        buf = torch.zeros(B, ld, device=y.device, dtype=torch.float32)
+        buf[:, :N] = y
+        y = buf
+    lens = lens.to(device=y.device, dtype=torch.int32).contiguous()
+    T = self.num_frames(N)
+    need = int(_lib.lib.xva_mel_workspace_bytes(C.byref(self.cfg), B, N))
+    if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != y.device:
+        self._ws = torch.empty((need + 3) // 4, device=y.device, dtype=torch.float32)
+    out = torch.empty(B, self.cfg.n_fft // 2 + 1, T, device=y.device, dtype=torch.float32)
+    n_frames = torch.empty(B, device=y.device, dtype=torch.int32)
+    _lib.check(_lib.lib.xva_linear_spectrogram_ragged(C.byref(self.cfg), _lib.ptr(y), _lib.ptr(lens), B, N, y.stride(0), _lib.ptr(self.forward_basis),
+                                                      _lib.ptr(out), _lib.ptr(n_frames), _lib.ptr(self._ws), self._ws.numel() * 4, _lib.stream_ptr()),
+               "xva_linear_spectrogram_ragged")
+    return out, n_frames
+
+
+_lib.lib.xva_linear_spectrogram_ragged.restype = C.c_int32
+_lib.lib.xva_linear_spectrogram_ragged.argtypes = [C.POINTER(_lib.MelConfig), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+_MelEngine.linear_ragged = _engine_linear_ragged
+
+
 def _hann_periodic(n):
     return torch.from_numpy(0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n))
 
@@ -205,6 +237,13 @@ class TorchSTFTMel(torch.nn.Module):
         if x.ndim == 3:
             x = x.squeeze(1)
         return self.engine.linear(x)
+
+    def linear_ragged(self, x, lengths):
+        """Per-clip linear spectrograms of a zero-padded ragged batch: x (B, Nmax) / (B, 1, Nmax), lengths (B,) samples -> ((B, 513, 1 + Nmax // hop),
+        frames (B,)) — what the reference's dataset + collate hand the posterior encoder (python/xvapitch/dataset.py:251,470-475)."""
+        if x.ndim == 3:
+            x = x.squeeze(1)
+        return self.engine.linear_ragged(x, lengths)
 
     def l1_loss_backward(self, y_hat, mel_tgt, d_wav, scale=45.0, accumulate=True):
         """VitsGeneratorLoss's mel term (python/xvapitch/losses.py:187-193): loss = scale * l1_loss(mel_tgt, self(y_hat)) and

@@ -43,6 +43,15 @@ class GeneratorPass:
         self.acoustic.zero_grad()
         self.decoder.zero_grad()
 
+    def batch_from_wav(self, wavs, wav_lengths):
+        """On-device counterpart of the reference's dataset + collate for the two audio tensors of a batch (python/xvapitch/dataset.py:251,470-490):
+        wavs (B, Nmax) zero-padded float clips, wav_lengths (B,) -> y (B, 513, Ty) per-clip linear spectrograms (zeros after each clip's frames),
+        y_lengths (B,) = 1 + wav_lengths // 256, waveform (B, 1, Ty * 256) zero-padded to the frame grid (`max(mel_lengths) * hop_length`)."""
+        y, y_lengths = self.stft.linear_ragged(wavs, wav_lengths)
+        Ty = y.size(2)
+        waveform = F.pad(wavs.float(), (0, Ty * 256 - wavs.size(1))).unsqueeze(1)
+        return y, y_lengths, waveform
+
     def __call__(self, tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=None, eps=None, noise=None, slice_ids=None):
         """waveform (B, 1, Ty * 256).  slice_ids (B,): the segment starts (drawn like the reference's rand_segments when None)."""
         out = self.acoustic(tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps=eps, noise=noise, pitch_padded=pitch_padded)
