@@ -412,7 +412,7 @@ def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2):
     tokens = (torch.randint(1, VOCAB, (B, Tt), generator=gen) * (torch.arange(Tt)[None, :] < x_lens[:, None])).to(dev)
     frame_mask = torch.arange(Ty)[None, None, :] < y_lens[:, None, None]
     wav_lens = ((y_lens - 1) * 256 + torch.randint(0, 256, (B,), generator=gen)).to(dev)          # raw clips of y_lens frames each (1 + N // 256)
-    wavs = (torch.rand(B, (Ty - 1) * 256 + 255, generator=gen) * 1.6 - 0.8).to(dev)
+    wavs = (torch.rand(B, (Ty - 1) * 256 + 255, generator=gen) * 0.1 - 0.05).to(dev)              # quiet noise: spectrogram magnitudes O(1), like speech
     wavs = wavs * (torch.arange(wavs.size(1), device=dev)[None, :] < wav_lens[:, None])
     dvec, lids = torch.randn(B, 512, generator=gen).to(dev), torch.randint(0, LANGS, (B,), generator=gen).to(dev)
     pitch = ((torch.rand(B, 1, Ty, generator=gen) * 3 - 1.2).clamp_min(0) * frame_mask).to(dev)
