@@ -121,6 +121,14 @@ int xva_gemm_set_mainloop(int mode);
  * 1 (default) = two wave groups one barrier apart over a ring of four 32-deep K tiles ({12 LDS reads + DMA | 32 MFMAs} phases), 2 = 1 for
  * the NT layout, 0 for NN / TN. Returns the previous mode. Same results up to fp32 summation order. */
 int xva_gemm_set_kloop(int mode);
+/* Diagnostics / test knob: 1 (default) = convolution weight gradients (TN, column segments, fp32 C accumulated through the caller's
+ * split-K slabs) run on the resident-operand kernel (csrc/wgrad_res.h: the chunk's dY and X rows loaded once, all taps from LDS);
+ * 0 = they stay on the general TN tiles.  Returns the previous mode.  Same results up to fp32 summation order. */
+int xva_gemm_set_wgrad(int mode);
+/* Tuning overrides of that kernel's plan (tools/wgrad_bench.py): rows per chunk (0 = automatic), DMA instructions per wave per chunk
+ * (2 / 4 / 6: 16 / 32 / 48 KiB stages; 0 = automatic), workgroups in flight (0 = automatic).  xva_gemm_set_wgrad(2) additionally skips the
+ * slab reduction (kernel timing only: C is NOT updated). */
+void xva_gemm_wgrad_tune(int rows_per_chunk, int dma_per_wave, int workgroups);
 
 #ifdef __cplusplus
 }

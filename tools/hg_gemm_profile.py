@@ -19,6 +19,8 @@ wav = np.stack([synthetic.synth_wave(8192, 5000 + i) for i in range(B)]); wav = 
 y = torch.from_numpy(wav.astype(np.float32)).cuda()
 x = mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0, 8000); ym = mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0, None)
 st.train_step(x, y, ym); torch.cuda.synchronize()
+_lib.lib.xva_hg_set_streams(1)     # serial: a launch's event pair times that launch alone
+st.train_step(x, y, ym); torch.cuda.synchronize()
 _lib.lib.xva_prof_enable(1)
 st.train_step(x, y, ym); torch.cuda.synchronize()
 _lib.lib.xva_prof_enable(0)
@@ -34,3 +36,13 @@ print("total GEMM ms", tot, "launches", len(rows))
 names = ["NT", "NN", "TN"]
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print("%s m%d M=%-6s N=%-5s K=%-7s batch=%-5s sk=%-3s bn=%-3s n=%-3d ms=%8.3f  TF=%7.1f" % (names[int(k[0]) // 3], int(k[0]) % 3, k[1], k[2], k[3], k[4], k[5], k[6], v[0], v[1], v[2] / v[1] if v[1] else 0))
+
+# by section tag (hifigan_engine.hip: phase * 1000 + network * 10; phases 1 generator fwd, 2 D fwd (both), 3 D-step bwd, 4 G-step bwd through D, 5 generator bwd)
+sec = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+for r in rows:
+    t = int(r.get("tag", 0)); k = (t // 1000, (t % 1000) // 10)
+    sec[k][0] += 1; sec[k][1] += float(r["ms"]); sec[k][2] += float(r["gflop"]); sec[k][3] += float(r["mbytes"])
+print("phase net   launches   ms      TF/s   TB/s(alg)")
+for k in sorted(sec):
+    v = sec[k]
+    print("%5d %3d   %6d %8.3f %8.1f %7.2f" % (k[0], k[1], v[0], v[1], v[2] / v[1] if v[1] else 0, v[3] / v[1] / 1e3 if v[1] else 0))

@@ -21,23 +21,27 @@ extern "C" const char* xva_target_arch(void) { return "gfx950"; }
 // the timed throughput region never runs with it on.
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops, bytes; int variant; int M, N, K, batch, splitk, bn; };
+struct ProfRec { hipEvent_t a, b; double flops, bytes; int variant; int M, N, K, batch, splitk, bn, tag; };
 bool g_prof_on = false;
+int g_prof_tag = 0;
 std::vector<ProfRec> g_prof;
 }
 extern "C" void xva_prof_enable(int on) { g_prof_on = on != 0; }
+// free-form section tag the engines attach to the launches that follow (phase / network / layer: see tools/hg_gemm_profile.py)
+void xva_prof_tag(int tag) { g_prof_tag = tag; }
 bool xva_prof_is_on() { return g_prof_on; }
 void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn, double bytes) {
     if (g_prof.empty()) return;
     ProfRec& r = g_prof.back(); r.M = M; r.N = N; r.K = K; r.batch = batch; r.splitk = splitk; r.bn = bn; r.bytes = bytes;
 }
 void xva_prof_begin(hipStream_t st, double flops, int variant) {
-    ProfRec r; r.flops = flops; r.bytes = 0.0; r.variant = variant; r.M = r.N = r.K = r.batch = r.splitk = r.bn = 0;
+    ProfRec r; r.flops = flops; r.bytes = 0.0; r.variant = variant; r.M = r.N = r.K = r.batch = r.splitk = r.bn = 0; r.tag = g_prof_tag;
     hipEventCreate(&r.a); hipEventCreate(&r.b);
     hipEventRecord(r.a, st);
     g_prof.push_back(r);
 }
 void xva_prof_end(hipStream_t st) { hipEventRecord(g_prof.back().b, st); }
+void xva_prof_cancel() { if (!g_prof.empty()) { hipEventDestroy(g_prof.back().a); hipEventDestroy(g_prof.back().b); g_prof.pop_back(); } }
 // out[0] = launches, out[1] = total ms, out[2] = total flops ; per-variant (layout*2+compute) in out[3 + 3*v ..]
 extern "C" int xva_prof_collect(double* out, int cap) {
     for (int i = 0; i < cap; ++i) out[i] = 0.0;
@@ -76,12 +80,12 @@ extern "C" int xva_stream_wait_event(void* stream, void* e) {
 extern "C" int xva_prof_dump(const char* path) {
     FILE* f = fopen(path, "w");
     if (!f) return XVA_ERR_ARG;
-    fprintf(f, "variant,M,N,K,batch,splitk,bn,ms,gflop,mbytes\n");
+    fprintf(f, "variant,M,N,K,batch,splitk,bn,ms,gflop,mbytes,tag\n");
     for (auto& r : g_prof) {
         hipEventSynchronize(r.b);
         float ms = 0.f;
         hipEventElapsedTime(&ms, r.a, r.b);
-        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.5f,%.4f,%.4f\n", r.variant, r.M, r.N, r.K, r.batch, r.splitk, r.bn, ms, r.flops * 1e-9, r.bytes * 1e-6);
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.5f,%.4f,%.4f,%d\n", r.variant, r.M, r.N, r.K, r.batch, r.splitk, r.bn, ms, r.flops * 1e-9, r.bytes * 1e-6, r.tag);
         hipEventDestroy(r.a); hipEventDestroy(r.b);
     }
     fclose(f);

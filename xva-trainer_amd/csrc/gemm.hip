@@ -11,9 +11,11 @@ int xva_gemm_launch_glds(const xva_gemm_params& p, int tile, hipStream_t st);
 void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn);
 int xva_gemm_conv_res_plan(const xva_gemm_params& p, int* stride_out = nullptr, int64_t* rowpitch_out = nullptr);
 int xva_gemm_launch_conv_res(const xva_gemm_params& p, int dstep, hipStream_t st);
+int xva_gemm_launch_wgrad_res(const xva_gemm_params& p, hipStream_t st, int* splits_out);
 bool xva_prof_is_on();
 void xva_prof_begin(hipStream_t st, double flops, int variant);
 void xva_prof_end(hipStream_t st);
+void xva_prof_cancel();
 void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn, double bytes);
 
 // Main-loop selection: -1 automatic (default; env XVA_GEMM_GLDS overrides), 0 general kernel only, 1..4 force the direct-to-LDS tile
@@ -58,6 +60,23 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
                   "xva_gemm: a second output needs splitk == 1, plain (non-accumulating, non-transposed) stores and C's alignment");
     XVA_CHECK_ARG(p.kb_len == 0 || (p.layout == XVA_GEMM_TN && p.kb_len > 0 && p.kb_sA % ve == 0 && p.kb_sB % ve == 0), "xva_gemm: bad K-block arguments");
     if (p.K == 0) p.splitk = 1;
+    if (auto_sk && p.layout == XVA_GEMM_TN && p.seglen > 0 && p.sk_ws) {   // convolution weight gradient: resident-operand kernel (wgrad_res.h)
+        const bool prof = xva_prof_is_on();
+        if (prof) xva_prof_begin((hipStream_t)stream, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + 1);
+        int splits = 1;
+        const int rc = xva_gemm_launch_wgrad_res(p, (hipStream_t)stream, &splits);
+        if (rc < 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; }
+        if (rc == 0) {
+            if (prof) {
+                const double nbz = (double)p.batch * p.batch2;
+                xva_prof_shape(p.M, p.N, p.K, p.batch * p.batch2, splits, 800000 + p.seglen, ((double)p.K * (p.M + p.seglen) * 2.0 + (double)p.M * p.N * 8.0) * nbz);
+                xva_prof_end((hipStream_t)stream);
+            }
+            XVA_LAUNCH_CHECK();
+            return XVA_OK;
+        }
+        if (prof) xva_prof_cancel();
+    }
     int nkt = xva_cdiv(p.K, 32);
     if (p.splitk > nkt && nkt > 0) p.splitk = nkt;
     int bn = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);

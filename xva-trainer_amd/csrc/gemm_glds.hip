@@ -75,6 +75,21 @@ bool xva_gemm_glds_eligible(const xva_gemm_params& p) {
 }
 
 static int launch_tiles(const xva_gemm_params& p, int tile, int vec, hipStream_t st);
+// C (+)= alpha * sum of the p.splitk slabs in p.sk_ws (written by a split-K launch of any of the kernels)
+int xva_gemm_launch_splitk_reduce(const xva_gemm_params& p, hipStream_t st) {
+    using namespace xva_glds;
+    const int64_t quads = (int64_t)p.M * p.N / 4;
+    int gx = (int)((quads + 255) / 256); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
+    // few output elements, many slabs: spread the slabs over gridDim.z (needs a purely additive fp32 epilogue)
+    int gz = 1;
+    if (p.splitk > 32 && gx * p.batch * p.batch2 < 256 && p.accumulate && p.c_dtype == XVA_F32 && !p.bias && !p.R) {
+        gz = 256 / (gx * p.batch * p.batch2);
+        if (gz > p.splitk / 8) gz = p.splitk / 8;
+        if (gz < 1) gz = 1;
+    }
+    hipLaunchKernelGGL(xva_gemm_splitk_reduce_kernel, dim3(gx, p.batch * p.batch2, gz), dim3(256), 0, st, p);
+    return 0;
+}
 // K loop of the 256 x 256 tile: 0 = all waves in one phase (two barriers per 64-deep K tile), 1 (default) = two wave groups one barrier
 // apart (xva_gemm_glds8_kernel), 2 = the latter for NT only.  Measured (tools/gemm_tile_ab.py): NT +5 ... +18 %, NN +2 ... +6 %, TN +-1 % on
 // warm operands; inside the training steps (operands from HBM) FastPitch -0.8 %, HiFi-GAN -1.0 % step time.  env XVA_GEMM_KLOOP8
@@ -92,18 +107,7 @@ int xva_gemm_launch_glds(const xva_gemm_params& pin, int tile, hipStream_t st) {
     int vec = vec_epilogue_ok(p);
     if (p.sk_ws && p.N % 8 == 0) vec = 2;        // slab stores are [M][N] fp32 rows whatever C looks like
     int rc = launch_tiles(p, tile, vec, st);
-    if (rc == 0 && p.sk_ws) {
-        const int64_t quads = (int64_t)p.M * p.N / 4;
-        int gx = (int)((quads + 255) / 256); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
-        // few output elements, many slabs: spread the slabs over gridDim.z (needs a purely additive fp32 epilogue)
-        int gz = 1;
-        if (p.splitk > 32 && gx * p.batch * p.batch2 < 256 && p.accumulate && p.c_dtype == XVA_F32 && !p.bias && !p.R) {
-            gz = 256 / (gx * p.batch * p.batch2);
-            if (gz > p.splitk / 8) gz = p.splitk / 8;
-            if (gz < 1) gz = 1;
-        }
-        hipLaunchKernelGGL(xva_gemm_splitk_reduce_kernel, dim3(gx, p.batch * p.batch2, gz), dim3(256), 0, st, p);
-    }
+    if (rc == 0 && p.sk_ws) rc = xva_gemm_launch_splitk_reduce(p, st);
     return rc;
 }
 

@@ -55,6 +55,7 @@ inline xva_gemm_params hg_gp(int compute, int dt) {
     g.sk_ws = hg_skws().ptr; g.sk_ws_bytes = hg_skws().bytes;
     return g;
 }
+bool xva_gemm_wgrad_res_ok(const xva_gemm_params& p);   // wgrad_res.hip: does the resident-operand weight-gradient kernel take this TN problem?
 inline int hg_conv_out_len(int T, const ConvW& w) { return (T + 2 * w.P - w.d * (w.k - 1) - 1) / w.s + 1; }
 
 enum { HG_MERGED = 0, HG_PERITEM = 1 };
@@ -163,10 +164,19 @@ inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x
     const void* x0 = (const char*)(merged ? X.ptr() : X.valid()) - (int64_t)w.P * X.C * X.es();
     // The 128-row M tile wants the LARGER of (Cout_g, k*Cin_g) on M: for narrow layers (Cout_g <= 64) compute dW^T = Xcat^T dY
     // (M = k*Cin_g taps x channels as segmented columns of A, N = Cout_g on the narrow N tile) and store it transposed.
-    const bool swap = Cog <= 64 && w.k * Cig > Cog;
+    bool swap = Cog <= 64 && w.k * Cig > Cog;
+    if (swap) {   // the resident-operand kernel (wgrad_res.h) wants the natural form: dY on M, (tap, channel) column segments on N
+        xva_gemm_params t = g;
+        t.M = Cog; t.N = w.k * Cig; t.lda = dY.C; t.ldb = (int64_t)w.s * X.C; t.ldc = t.N; t.a_rowpitch = X.C;
+        t.seglen = Cig; t.segstride = (int64_t)w.d * X.C - Cig; t.b_lrelu = x_lrelu; t.sA2 = Cog; t.sB2 = Cig;
+        t.A = dy0; t.B = x0; t.accumulate = 1; t.splitk = 0;
+        if (merged) t.K = (int)dY.rows();
+        else { t.K = (int)((int64_t)X.nseq * dY.T); t.kb_len = dY.T; t.kb_sA = dY.item(); t.kb_sB = X.item(); }
+        if (xva_gemm_wgrad_res_ok(t)) swap = false;
+    }
     if (!swap) {
         g.M = Cog; g.N = w.k * Cig;
-        g.lda = dY.C; g.ldb = (int64_t)w.s * X.C; g.ldc = g.N;
+        g.lda = dY.C; g.ldb = (int64_t)w.s * X.C; g.ldc = g.N; g.a_rowpitch = X.C;
         g.seglen = Cig; g.segstride = (int64_t)w.d * X.C - Cig; g.seg0 = 0;
         g.b_lrelu = x_lrelu; g.b_slope = x_slope;
         g.sA2 = Cog; g.sB2 = Cig;

@@ -45,7 +45,13 @@ int xva_hg_add_f32(float* dst, const float* src, int64_t n, void* stream);
 int xva_hg_add_item_vec(void* seq, int dt, const float* vec, int B, int Hp, int padF, int T, int C, void* stream);
 }
 
+void xva_prof_tag(int tag);
+
 namespace {
+
+// profiling knob (tools/hg_disc_split.py): bit di set = discriminator di (MPD 0..4, MSD 5..7) runs; results are meaningless with bits cleared
+static int g_disc_mask = [] { const char* e = getenv("XVA_HG_DISC_MASK"); return e ? (int)strtol(e, nullptr, 0) : 0xff; }();
+static int disc_mask() { return g_disc_mask; }
 
 constexpr float SLOPE = 0.1f;
 constexpr int GUARD = 32;           // guard rows before / after every sequence tensor
@@ -535,6 +541,7 @@ int zero(const Ctx& c, void* p, int64_t bytes) {
 // gvec (B, gcond) fp32: the VITS decoder's speaker vector (null: no conditioning term)
 int gen_forward(Ctx& c, const float* P, const float* mel, float* wav_out, const float* gvec = nullptr) {
     const Plan& pl = c.pl; const GenNet& N = *pl.gnetp; const auto& L = pl.gl;
+    xva_prof_tag(1000);
     XVA_TRY(prep_wn(c, L, P));
     Seq xin = c.S(pl.xin), h0 = c.S(pl.h0);
     XVA_TRY(xva_hg_mel_to_tm(mel, xin.ptr(), c.dt, pl.B, N.gin, pl.T[0], xin.Hp(), xin.padF, c.st));
@@ -553,6 +560,7 @@ int gen_forward(Ctx& c, const float* P, const float* mel, float* wav_out, const 
     Seq prev = h0;
     for (int i = 0; i < 4; ++i) {
         Seq u = c.S(pl.u[i]), ua = c.S(pl.ua[i]), xs = c.S(pl.xs[i]);
+        xva_prof_tag(1000 + (i + 1) * 10);
         // lrelu + ups[i] (:115-116).  Every producer on the residual stream also stores the LeakyReLU of its output (u -> ua,
         // xr -> xra): the resblock convolutions read the activated copy instead of re-activating their operand once per tap, and
         // xt1 (only ever consumed through a LeakyReLU) is stored activated.
@@ -657,6 +665,7 @@ constexpr int G_BUCKETS = 6;
 // VITS decoder: gvec as in gen_forward; d_in (B, gin, T0) fp32 (may be null) receives the gradient w.r.t. the input features
 int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav, void* const* events, const float* gvec = nullptr, float* d_in = nullptr) {
     const Plan& pl = c.pl; const GenNet& N = *pl.gnetp; const auto& L = pl.gl;
+    xva_prof_tag(5000);
     XVA_TRY(zero_dweff(c, L));
     Seq y = c.S(pl.y), dy = c.S(pl.g_dy);
     XVA_TRY(xva_hg_tanh_bwd(d_wav, y.ptr(), dy.ptr(), c.dt, pl.B, pl.T[4], y.Hp(), y.padF, c.st));
@@ -680,6 +689,7 @@ int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav, void* con
     if (two) { cw_.st = ss.s[1]; cw_.lane = 1; }
     for (int i = 3; i >= 0; --i) {
         const int T = pl.T[i + 1], C = pl.Cst[i + 1];
+        xva_prof_tag(5000 + (i + 1) * 10);
         Seq dxs = as_stage(c, pl.g_dxs, T, C), du = as_stage(c, pl.g_du, T, C);
         Seq ua = c.S(pl.ua[i]);
         for (int j = 0; j < 3; ++j) {
@@ -981,7 +991,9 @@ int discs_forward(Ctx& c0, float* Pd, const float* yr, const float* yg, float* l
     int di = 0;
     for (auto& s : sets) {
         Ctx& c = cs[disc_lane(di, nl)];
+        xva_prof_tag(2000 + di * 10);
         ++di;
+        if (!((disc_mask() >> (di - 1)) & 1)) continue;
         if (s.sn) {   // models.py:244-253: d(y) then d(y_hat), one power iteration each
             DiscRun rr = snr[0];
             XVA_TRY(sn_prepare(c, Pd, rr));
@@ -1021,6 +1033,8 @@ int discs_backward_d(Ctx& c0, float* Pd, float* Gd, const float* yr, const float
     int di = 0;
     for (auto& s : sets) {
         Ctx& c = cs[disc_lane(di, nl)];                      // each lane has its own split-K slabs
+        xva_prof_tag(3000 + di * 10);
+        if (!((disc_mask() >> di) & 1)) { XVA_TRY(record(c, events, di)); ++di; continue; }
         use_slabs(c);
         colsums.clear();
         const int n = s.run.n;
@@ -1066,6 +1080,8 @@ int discs_backward_g(Ctx& c0, float* Pd, const float* yr, const float* yg, float
     for (auto& s : sets) {
         const int ln = disc_lane(di, nl);
         Ctx& c = cs[ln];
+        xva_prof_tag(4000 + di * 10);
+        if (!((disc_mask() >> di) & 1)) { ++di; continue; }
         use_slabs(c);
         const int sc = di >= NPER ? di - NPER : 0;
         // the full-rate discriminators all add into d(waveform): lane 0 into d_wav itself, every other lane into its own partial buffer
@@ -1240,6 +1256,7 @@ extern "C" int xva_hg_slot(const xva_hg_dims* d, int kind, int i0, int i1, int i
     geom5[0] = s->nseq; geom5[1] = s->T; geom5[2] = s->C; geom5[3] = s->padF; geom5[4] = s->padB;
     return XVA_OK;
 }
+extern "C" int xva_hg_set_disc_mask(int m) { int old = g_disc_mask; g_disc_mask = m; return old; }   // profiling only (tools/hg_disc_split.py)
 extern "C" int xva_hg_set_streams(int n) { int old = g_hg_serial ? 1 : side_streams().n; g_hg_serial = n <= 1; return old; }
 extern "C" int xva_hg_num_buckets(int which) { return which == 0 ? G_BUCKETS : D_BUCKETS; }
 // [begin, end) in floats of bucket i of the flat gradient buffer `which`, in backward-completion order

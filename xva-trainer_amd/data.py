@@ -226,6 +226,20 @@ class DeviceCollate:
         return b
 
 
+class _BoundedCache(dict):
+    """Decoded clips kept in host memory up to `cap` items, oldest first out (the reference caps its caches the same way: 3000 items in
+    TTSDataset, 5000 in MelDataset — multi-hour datasets times N ranks must not exhaust host RAM)."""
+
+    def __init__(self, cap):
+        super().__init__()
+        self.cap = int(cap)
+
+    def __setitem__(self, k, v):
+        if k not in self and len(self) >= self.cap:
+            del self[next(iter(self))]
+        super().__setitem__(k, v)
+
+
 # ------------------------------------------------------------------------------------------------ FastPitch loader
 class FastPitchFileLoader:
     """DataLoader(TTSDataset, TTSCollate, shuffle=True, drop_last=True) (python/fastpitch1_1/xva_train.py:437-452) with the batch
@@ -243,7 +257,7 @@ class FastPitchFileLoader:
         self.seed, self.rank, self.world, self.shuffle, self.epoch = seed, rank, world, shuffle, 0
         self.durs_kind = durs_kind
         self.collate = DeviceCollate(self.device)
-        self._cache = {}
+        self._cache = _BoundedCache(3000)
 
     def __len__(self):
         return (len(self.index) // self.world) // self.batch_size
@@ -310,13 +324,17 @@ class HifiFileLoader:
             raise FileNotFoundError("no usable lines in %s/metadata.csv (wavs/ missing?)" % dataset_path)
         if dm is None:
             dm = max(1, round(1000 / len(files)))                                       # get_dataset_filelist (:298-300)
-        self.rng = random.Random(seed)
+        rng = random.Random(seed)
         self.files = []
         for _ in range(dm):
-            self.rng.shuffle(files)
+            rng.shuffle(files)
             self.files += files
         self.batch_size, self.segment, self.device, self.rank, self.world = int(batch_size), int(segment), torch.device(device), rank, world
-        self._cache = {}
+        # Two streams: the epoch shuffle must be IDENTICAL on every rank (order[rank::world] is then a disjoint shard), so it gets its own
+        # Random(seed + epoch) like FastPitchFileLoader; the crop starts are per-rank draws and never touch it.
+        self.seed, self.epoch = seed, 0
+        self.crop_rng = random.Random(seed * 7919 + 1 + rank)
+        self._cache = _BoundedCache(5000)
 
     def __len__(self):
         return (len(self.files) // self.world) // self.batch_size
@@ -330,11 +348,12 @@ class HifiFileLoader:
 
     def __iter__(self):
         order = list(self.files)
-        self.rng.shuffle(order)
+        random.Random(self.seed + 1 + self.epoch).shuffle(order)
+        self.epoch += 1
         order = order[self.rank::self.world]
         for b in range(len(self)):
             clips = [self.clip(p) for p in order[b * self.batch_size:(b + 1) * self.batch_size]]
-            starts = [self.rng.randint(0, len(c) - self.segment) if len(c) >= self.segment else 0 for c in clips]   # meldataset.py:354-358
+            starts = [self.crop_rng.randint(0, len(c) - self.segment) if len(c) >= self.segment else 0 for c in clips]   # meldataset.py:354-358
             yield prepare_segments(clips, starts, self.segment, self.device)
 
 

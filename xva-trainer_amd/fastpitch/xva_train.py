@@ -52,6 +52,14 @@ def adjust_learning_rate(total_iter, opt, learning_rate, warmup_iters=None):
         param_group["lr"] = learning_rate * scale
 
 
+def _atomic_save(obj, path):
+    """torch.save under a temporary name, then os.replace: a reader (another rank after a stage change, a resumed run) sees the old file
+    or the new one, never a partial write."""
+    tmp = "%s.tmp.%d" % (path, os.getpid())
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
+
+
 def _is_oom(e):
     s = str(e)
     return "out of memory" in s.lower() or "PYTORCH_CUDA_ALLOC_CONF" in s or "PYTORCH_HIP_ALLOC_CONF" in s
@@ -319,7 +327,8 @@ class FastPitchTrainer(object):
         torch.manual_seed(1234 + self.rank)
         np.random.seed(1234 + self.rank)
         self.print_and_log("Dataset: %s" % self.dataset_input, save_to_file=self.dataset_output)
-        ckpt_path = self.last_checkpoint(self.dataset_output)
+        self._barrier()                                       # every rank's writes to the output directory so far are done
+        ckpt_path = self._from_rank0(self.last_checkpoint(self.dataset_output) if self.rank == 0 else None)   # one view of "newest": the ranks must load the SAME stage
         if ckpt_path is None:
             ckpt_path = self.checkpoint
             self.print_and_log("Checkpoint: %s" % ckpt_path, save_to_file=self.dataset_output)
@@ -384,8 +393,11 @@ class FastPitchTrainer(object):
         self.EPOCH_AVG_SPAN = max(1, int(20 / data_mult))
         self.print_and_log("Data multiplier: %d" % data_mult, save_to_file=self.dataset_output)
 
-        if stage >= 2 and not self.synthetic_data and not self.loader_factory and not os.path.exists(self.dataset_input + "/durs_text"):
-            self.extract_durations()                                              # xva_train.py:473-474
+        if stage >= 2 and not self.synthetic_data and not self.loader_factory:
+            # xva_train.py:473-474.  Rank 0 decides (one answer for all ranks: a rank that saw the directory appear must not skip the
+            # barriers inside); extract_durations publishes the directory only when it is complete.
+            if self._from_rank0(not os.path.exists(self.dataset_input + "/durs_text") if self.rank == 0 else None):
+                self.extract_durations()
         self.train_loader = self._make_loader(stage, data_mult)
         if len(self.train_loader) < self.gam:
             # start_new_epoch() drops a partial accumulation like the reference (xva_train.py:737-741): with fewer batches per epoch than
@@ -422,6 +434,22 @@ class FastPitchTrainer(object):
         self.iter_start_time = None
         self.iter_losses = []
         self.epoch_iter = 0
+
+    def _barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier()
+
+    def _from_rank0(self, obj):
+        """rank 0's value of a small host object on every rank (decisions that must not differ between ranks: which checkpoint is the
+        newest, whether the durations still have to be extracted)."""
+        if self.world == 1:
+            return obj
+        import torch.distributed as dist
+        box = [obj]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
 
     def _global_mean(self, value):
         """mean over the DP ranks of a host scalar (keeps every rank's stopping / NaN decisions identical)."""
@@ -549,6 +577,7 @@ class FastPitchTrainer(object):
         self.save_checkpoint(force_save=True, frames_s=frames_s, total_iter=it, avg_loss=avg_loss, loss_delta=delta_avg,
                              avg_loss_per_epoch=self.avg_loss_per_epoch, fpath=fpath_stage, doPrintLog=False)
         self.running = False
+        self._barrier()      # rank 0's re-written checkpoint (next stage) is complete before any rank's next trainer looks for it
         raise RuntimeError("stage %d finished" % stage)     # the reference signals stage completion by raising (xva_train.py:970)
 
     # ---- xva_train.py:979-1052 ----
@@ -565,8 +594,8 @@ class FastPitchTrainer(object):
         sd = self.model.state_dict()
         checkpoint = {"epoch": self.epoch, "iteration": total_iter, "avg_loss_per_epoch": list(avg_loss_per_epoch),
                       "training_stage": self.model.training_stage, "state_dict": sd, "optimizer": self.optimizer.state_dict()}
-        torch.save(checkpoint, fpath)
-        torch.save({k: (v.half() if v.is_floating_point() else v) for k, v in sd.items()}, "%s/%s.pt" % (self.dataset_output, self.dataset_id))
+        _atomic_save(checkpoint, fpath)      # never a half-written file under the final name (other ranks / a resumed run read it)
+        _atomic_save({k: (v.half() if v.is_floating_point() else v) for k, v in sd.items()}, "%s/%s.pt" % (self.dataset_output, self.dataset_id))
         with open("%s/%s.json" % (self.dataset_output, self.dataset_id), "w+") as f:
             json.dump({"version": "2.0", "modelVersion": "2.0", "modelType": "FastPitch1.1", "author": "", "lang": "en",
                        "games": [{"gameId": "other", "voiceId": self.dataset_id, "voiceName": self.dataset_output.split("/")[-1],
@@ -617,12 +646,16 @@ class FastPitchTrainer(object):
         batch size 1 and a CPU MAS; the durations of an item do not depend on its batch."""
         from ..data import FastPitchFileLoader
         self.print_and_log("Extracting durations from alignments (text)...", save_to_file=self.dataset_output)
-        out_dirs = [self.dataset_input + "/durs_text"]
-        os.makedirs(out_dirs[0], exist_ok=True)
-        if self.rank != 0:
-            if self.world > 1:
-                torch.distributed.barrier()
+        final_dir = self.dataset_input + "/durs_text"
+        if self.rank != 0:            # rank 0 extracts; the others wait until the directory has been published
+            self._barrier()
             return
+        # written under a temporary name and renamed when every file is there: the directory's existence is the reference's (and this
+        # trainer's) "durations are extracted" test, so it must never exist half-filled
+        out_dirs = [final_dir + ".partial"]
+        import shutil
+        shutil.rmtree(out_dirs[0], ignore_errors=True)
+        os.makedirs(out_dirs[0])
         ld = FastPitchFileLoader(self.dataset_input, batch_size, 1, self.device, shuffle=False)
         flat = self.model.flat.data
         n = len(ld.items)
@@ -639,6 +672,7 @@ class FastPitchTrainer(object):
                 self.training_log_live_line = "\r%d/%d " % (min(n, s + batch_size), n)
                 self.print_and_log(save_to_file=self.dataset_output)
         self.training_log_live_line = ""
-        if self.world > 1:
-            torch.distributed.barrier()
+        del ld                       # its clip cache is not the training loader's
+        os.replace(out_dirs[0], final_dir)
+        self._barrier()
         torch.cuda.empty_cache()
