@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hifigan", action="store_true", help="skip the HiFi-GAN audio-samples/s leg")
     ap.add_argument("--no-xvapitch", action="store_true", help="skip the xVAPitch (BASELINE configs[4]) iteration timing")
+    ap.add_argument("--no-fp32-parity", action="store_true", help="skip the fp32 parity-mode FastPitch timing")
     ap.add_argument("--hg-batch", type=int, default=64)
     ap.add_argument("--hg-steps", type=int, default=0, help="timed HiFi-GAN steps (default: min(steps, 10))")
     return ap.parse_args()
@@ -223,6 +224,8 @@ def pmc_traffic(family, pmc_csv):
             pat = re.compile(r"xva_gemm_glds_kernel<\d, 256, 256,|xva_gemm_glds8_kernel<\d>")
     elif family.startswith("xva_conv_res_kernel<CIN="):
         pat = re.compile(r"xva_conv_res_kernel<\d, %s," % family[len("xva_conv_res_kernel<CIN="):-1])
+    elif family.startswith("xva_wgrad_res_kernel"):
+        pat = re.compile(r"xva_wgrad_res_kernel<")
     else:
         pat = re.compile(r"xva_gemm_kernel<\d, \d, %s>" % family[len("xva_gemm_kernel<BN="):-1])
     n, by = 0, 0.0
@@ -262,6 +265,8 @@ def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
         glds = int(r["bn"]) > 1000
         if int(r["bn"]) >= 900000:
             key = "xva_conv_res_kernel<CIN=%d>" % (int(r["bn"]) - 900000)
+        elif int(r["bn"]) >= 800000:
+            key = "xva_wgrad_res_kernel<CIN=%d>" % (int(r["bn"]) - 800000)
         else:
             key = ("xva_gemm_glds_kernel<%s>" % TILE_NAMES.get(r["bn"], r["bn"])) if glds else ("xva_gemm_kernel<BN=%s>" % r["bn"])
         f = fam[key]
@@ -280,7 +285,8 @@ def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
            "traffic_unit": ("HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE; offline passes over this workload: %s)" % traffic_src) if traffic
                            else traffic_src,
            "kernel": name + (" (direct-to-LDS MFMA implicit-convolution GEMM, all layouts; 256x256: xva_gemm_glds8_kernel, the staggered K loop)" if "glds" in name else
-                             (" (resident-input MFMA convolution, forward + backward-data)" if "conv_res" in name else "")),
+                             (" (resident-input MFMA convolution, forward + backward-data)" if "conv_res" in name else
+                              (" (resident-operand MFMA convolution weight gradient)" if "wgrad_res" in name else ""))),
            "launches_per_step": f[0] / nprof, "avg_launch_us": 1e3 * f[1] / f[0], "kernel_ms_per_step": f[1] / nprof,
            "share_of_gemm_time": f[1] / tot_ms if tot_ms else None,
            "algorithmic_gflop_per_launch": f[2] / f[0], "algorithmic_mbytes_per_launch": f[3] / f[0],
@@ -362,8 +368,68 @@ def hifigan_leg(a, dev, rank, world):
     if rank == 0 and not a.no_roofline:
         # the conv stack is priced against the HBM roofline (north_star): algorithmic bytes of every conv-as-GEMM launch / its time
         res["roofline"] = gemm_roofline(lambda: st.train_step(x, y, y_mel), 1, "auto", 8000.0, "one extra profiled D+G iteration (stream lanes off)",
-                                        pmc_csv="r02_hifigan_pmc_hbm_bytes.csv")
+                                        pmc_csv="r03_hifigan_pmc_hbm_bytes.csv")
+        # the HiFi-GAN conv stack is priced on HBM — ALGORITHMIC bytes of the whole iteration (every distinct operand /
+        # result element of every convolution launch once, forward + both backward products: the sum the profiled pass above recorded
+        # per launch) over the TIMED iteration (stream lanes on, everything included: losses, reparametrisations, AdamW)
+        ag = res["roofline"]["all_gemm"]
+        alg_gb = ag["algorithmic_gbytes_per_s"] * ag["ms_per_step"] / 1e3
+        alg_tf = ag["tflops"] * ag["ms_per_step"] / 1e3
+        res["roofline_stack"] = {"bound": "hbm", "achieved": alg_gb / res["ms_per_step"] * 1e3, "peak": 8000.0, "unit": "GB/s",
+                                 "frac": alg_gb / res["ms_per_step"] * 1e3 / 8000.0, "algorithmic_gbytes_per_step": alg_gb,
+                                 "algorithmic_tflop_per_step": alg_tf, "mfma_tflops": alg_tf / res["ms_per_step"] * 1e3,
+                                 "mfma_frac": alg_tf / res["ms_per_step"] * 1e3 / 2500.0,
+                                 "note": "whole D+G iteration: algorithmic bytes of all convolution launches (B=%d) / timed ms_per_step; the workload sits on the "
+                                         "ridge (17 TFLOP : 55 GB = 313 flop/B), so the MFMA fraction of the same time is given beside it" % B}
     del st
+    torch.cuda.empty_cache()
+    return res
+
+
+def fastpitch_fp32_leg(a, dev, steps=5, warm=2):
+    """The same FastPitch step (B x tokens x frames of the headline line) in the PARITY mode: fp32 storage, exact-fp32 MFMA
+    (v_mfma_f32_16x16x4_f32) — the mode that meets north_star's 1e-3 against the reference end to end (tests/test_fastpitch_gpu.py,
+    tests/test_fullsize_gpu.py).  Dropout 0.1, LAMB, same batch; its roofline is priced against the 157.3 TFLOP/s fp32 matrix peak."""
+    from xva_trainer_amd import synthetic
+    from xva_trainer_amd.fastpitch import engine as E, params as P
+    from xva_trainer_amd.fastpitch.lamb import Lamb
+    eng = E.FastPitchEngine(dev, "fp32", p_dropout=a.dropout, seed=1234)
+    flat = torch.zeros(eng.total, device=dev)
+    P.default_init_(flat, eng.table, seed=1234)
+    grads = torch.zeros_like(flat)
+    opt = Lamb(flat, eng.table, lr=0.1, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6)
+    ranges = E.trainable_ranges(a.stage)
+    active = {t[0] for t in eng.table if any(b <= t[1] < e for b, e in ranges)}
+    batch = E.DeviceBatch.from_dict(synthetic.fastpitch_batch(a.batch, a.t_text, a.t_mel, 1234), dev)
+    frames = int(batch.mel_lens.sum().item())
+    it = [50000]
+
+    def step():
+        it[0] += 1
+        opt.param_groups[0]["lr"] = 0.1 / it[0] ** 0.5
+        grads.zero_()
+        eng.fwd_loss_bwd(flat, grads, batch, a.stage, grad_scale=1.0)
+        opt.step(grads, active, max_grad_norm=1000.0)
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"metric": "mel-frames/sec (FastPitch1.1 train step, fp32 parity mode)", "value": frames * steps / dt, "unit": "mel-frames/s",
+           "ms_per_step": 1000.0 * dt / steps, "steps": steps, "dtype": "fp32", "final_loss": eng.slot("LOSSES", (8,)).cpu()[0].item(),
+           "config": {"workload": "FastPitch1.1 stage-%d full train step, batch %d, %d tokens x %d mel frames, dropout p=%g, fp32 storage + exact-fp32 MFMA"
+                                  % (a.stage, a.batch, a.t_text, a.t_mel, a.dropout)},
+           "tolerance": "outputs / losses / gradients within 1e-3 of the reference goldens (tests/test_fastpitch_gpu.py) and of the oracle at full length "
+                        "(tests/test_fullsize_gpu.py::test_fastpitch_full_length_against_the_oracle)"}
+    if not a.no_roofline:
+        def run_profiled():
+            grads.zero_()
+            eng.fwd_loss_bwd(flat, grads, batch, a.stage)
+        res["roofline"] = gemm_roofline(run_profiled, 1, "mfma", 157.3, "FastPitch fwd+bwd in the fp32 parity mode: 1 extra profiled pass")
+    del eng, opt, grads, flat
     torch.cuda.empty_cache()
     return res
 
@@ -535,9 +601,14 @@ def main():
         peak = 2500.0 if a.compute == "bf16" else 157.3
         out["roofline"] = gemm_roofline(run_profiled, 3, "mfma", peak,
                                         "FastPitch fwd+bwd: %d extra profiled passes after the timed region" % 3,
-                                        pmc_csv="r02_fastpitch_pmc_hbm_bytes.csv" if a.compute == "bf16" else None)
+                                        pmc_csv="r03_fastpitch_pmc_hbm_bytes.csv" if a.compute == "bf16" else None)
     if rank == 0 and not a.no_roofline:
         out["hbm_kernels"] = hbm_kernel_rooflines(dev, opt, grads, active, a.compute)
+    if rank == 0 and world == 1 and a.compute == "bf16" and not a.no_fp32_parity:
+        try:
+            out["fastpitch_fp32_parity"] = fastpitch_fp32_leg(a, dev)
+        except Exception as e:                               # an extra measurement: never at the price of the contract line
+            out["fastpitch_fp32_parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if not a.no_hifigan:
         del opt, grads
         eng._ws = None

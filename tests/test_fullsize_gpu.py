@@ -206,3 +206,37 @@ def test_hifigan_full_size_bf16_step_is_the_weighted_sum_of_its_items():
             for b, e in HE.bucket_ranges(which):
                 nb = ref[b:e].norm().item()
                 assert ((full[key][b:e].double() - ref[b:e]).norm().item() / nb) < 1e-2, (key, b)
+
+
+def test_fastpitch_full_length_against_the_oracle():
+    """The CPU oracle AT FULL LENGTH: B = 2 clips of 150 tokens x 860 frames (BASELINE configs[1]'s sequence lengths: 14 key blocks in
+    the attention, the 27 584-row GEMM grids' tile shapes per item, 862-row LayerNorm / loss reductions), parity mode (fp32, north_star's
+    1e-3): mel / pitch / energy predictions, the loss and every parameter gradient against oracle/fastpitch.py's forward + autograd — the
+    full-size tests above are properties only, test_against_oracle_ragged stops at 210 frames."""
+    from oracle import fastpitch as ofp
+    from fp_util import build_engine, grad_report, rel
+    from xva_trainer_amd.fastpitch.engine import DeviceBatch
+    torch.manual_seed(0)
+    stage = 3
+    sd = ofp.init_state_dict(5)
+    batch = ofp.synth_batch(2, 150, 860, 21)
+    assert int(batch["mel_lens"].max()) == 860 and int(batch["in_lens"].max()) == 150
+    names = ofp.trainable_names(sd.keys(), stage)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd); work.update(leaves)
+    out_ref = ofp.forward(work, batch, stage)
+    loss_ref, _ = ofp.loss(out_ref, batch, stage)
+    loss_ref.backward()
+    ref_grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    eng, flat, grads = build_engine(sd, "fp32")
+    b = DeviceBatch.from_dict(batch, "cuda")
+    grads.zero_()
+    losses = eng.fwd_loss_bwd(flat, grads, b, stage).cpu()
+    out = eng.outputs(b, stage)
+    assert rel(out["mel_out"], out_ref[0]) < 1e-3
+    assert rel(out["pitch_pred"], out_ref[4]) < 1e-3
+    assert rel(out["energy_pred"], out_ref[6]) < 1e-3
+    assert torch.equal(out["dec_lens"].cpu().long(), batch["mel_lens"])
+    assert abs(losses[0].item() - loss_ref.item()) < 1e-3 * abs(loss_ref.item())
+    bad, worst = grad_report(eng, grads, ref_grads, 2e-3)
+    assert not bad, bad[:10]

@@ -12,14 +12,14 @@ python $R/tools/rocpd_summary.py $(find /tmp/p_stats -name "*.db" | head -1) $O/
 # kernels' own — the numbers bench.py's roofline passes (lanes off as well) have to agree with
 XVA_FP_STREAMS=1 XVA_HG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/p_ser -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_serial_lanes_bench_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_ser -name "*.db" | head -1) $O/${RD}_serial_lanes_kernel_stats.csv
-XVA_FP_STREAMS=1 XVA_HG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/p_fps -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hifigan --no-xvapitch 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_fastpitch_only_serial_lanes_under_rocprof.json
+XVA_FP_STREAMS=1 XVA_HG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/p_fps -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hifigan --no-xvapitch --no-fp32-parity 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_fastpitch_only_serial_lanes_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_fps -name "*.db" | head -1) $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.csv
-rocprofv3 --kernel-trace --stats -d /tmp/p_fp -o f -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hifigan --no-xvapitch 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_fastpitch_only_under_rocprof.json
+rocprofv3 --kernel-trace --stats -d /tmp/p_fp -o f -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hifigan --no-xvapitch --no-fp32-parity 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_fastpitch_only_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_fp -name "*.db" | head -1) $O/${RD}_fastpitch_only_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d /tmp/p_hg -o h -- python $R/tools/hg_phase_timing.py > $O/${RD}_hifigan_phase_timing.txt 2>/dev/null
 python $R/tools/rocpd_summary.py $(find /tmp/p_hg -name "*.db" | head -1) $O/${RD}_hifigan_only_kernel_stats.csv
 for leg in fastpitch hifigan; do
-  if [ $leg = fastpitch ]; then CMD="python $R/bench.py --steps 2 --warmup 1 --no-hifigan --no-cpu-baseline --no-roofline --no-xvapitch"; else CMD="python $R/tools/hg_gemm_profile.py 64"; fi
+  if [ $leg = fastpitch ]; then CMD="python $R/bench.py --steps 2 --warmup 1 --no-hifigan --no-cpu-baseline --no-roofline --no-xvapitch --no-fp32-parity"; else CMD="python $R/tools/hg_gemm_profile.py 64"; fi
   for ctr in FETCH_SIZE WRITE_SIZE; do
     XVA_FP_STREAMS=1 XVA_HG_STREAMS=1 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/p_${leg}_$ctr -o c -- $CMD > /dev/null 2>&1
     python $R/tools/pmc_summary.py $(find /tmp/p_${leg}_$ctr -name "*.db" | head -1) /tmp/${leg}_$ctr.csv

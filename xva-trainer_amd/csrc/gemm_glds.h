@@ -110,6 +110,23 @@ struct Loader {
     }
 };
 
+// ---- MFMA operand fragments -----------------------------------------------------------------------------------------------------
+// KC operands are read by plain ds_read_b128 (the compiler tracks them).  IC operands come from LDS transpose reads, and those are issued
+// as INLINE ASM: through the builtin the compiler cannot tell the read from the LDS bytes an in-flight global_load_lds is still writing
+// and puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 — in the NN / TN K loops that drained the whole DMA ring once per K
+// tile (found in the ISA of the first resident weight-gradient kernel, wgrad_res.h; the NT loops never had it).  The compiler then no
+// longer tracks lgkmcnt for these reads: frags_wait() is the explicit wait (lgkmcnt(0) only — scalar loads share the counter and return
+// out of order, so counted waits are not safe), and frag_value() ties the registers to it before anything may read them.
+template <int KIND> struct Frag { bf16x8 v; };
+template <> struct Frag<1> { s16x4 lo, hi; };
+template <bool ANY_IC> __device__ __forceinline__ void frags_wait() { if constexpr (ANY_IC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ bf16x8 frag_value(Frag<0>& f) { return f.v; }
+__device__ __forceinline__ bf16x8 frag_value(Frag<1>& f) {
+    asm volatile("" : "+v"(f.lo), "+v"(f.hi));                     // ordered after the preceding frags_wait
+    s16x8 v = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 // ---- MFMA fragment readers ------------------------------------------------------------------------------------------------
 // KC image: [ROWS][64 k] bf16, 128-byte rows, chunk c of row r at position c ^ (r & 7).
 // lane -> row (l & 15) of the 16-row tile, k = kh * 32 + (l >> 4) * 8 + j
@@ -119,8 +136,8 @@ struct KcReader {
         o0 = (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) * 16);
         o1 = o0 ^ 64;
     }
-    __device__ __forceinline__ bf16x8 read(const XVA_LDS uint8_t* tile, int row0, int kh) const {
-        return *reinterpret_cast<const XVA_LDS bf16x8*>(tile + row0 * 128 + (kh ? o1 : o0));
+    __device__ __forceinline__ Frag<KC> read(const XVA_LDS uint8_t* tile, int row0, int kh) const {
+        Frag<KC> f; f.v = *reinterpret_cast<const XVA_LDS bf16x8*>(tile + row0 * 128 + (kh ? o1 : o0)); return f;
     }
 };
 // IC image: [64 kpos][ROWS idx] bf16, kpos = k with bits 2/3 swapped, 16-byte chunk c of a row at position ic_chunk(kpos, c).
@@ -134,12 +151,13 @@ struct IcReader {
         for (int t = 0; t < TILES; ++t)
             o[t] = posl * (ROWS * 2) + ic_chunk<ROWS>(posl, w0 / 8 + t * 2 + ((i >> 1) & 1)) * 16 + (i & 1) * 8;
     }
-    __device__ __forceinline__ bf16x8 read(const XVA_LDS uint8_t* tile, int t, int kh) const {
+    // The two transpose reads of one MFMA operand, as inline asm: see Frag below
+    __device__ __forceinline__ Frag<IC> read(const XVA_LDS uint8_t* tile, int t, int kh) const {
         const XVA_LDS uint8_t* a = tile + o[t] + kh * (32 * ROWS * 2);
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((XVA_LDS s16x4*)a);
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((XVA_LDS s16x4*)(a + 8 * ROWS * 2));
-        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(bf16x8, v);
+        Frag<IC> f;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"((uint32_t)(uintptr_t)a));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"((uint32_t)(uintptr_t)a), "n"(8 * ROWS * 2));
+        return f;
     }
 };
 
@@ -595,7 +613,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
     // HBM (the producer's writes do not stay in the Infinity Cache) and one tile of prefetch distance did not cover that latency.
     constexpr int LOADS = Loader<AK, BM, NW>::NI + Loader<BKD, BN, NW>::NI;          // DMA instructions per wave per tile
     constexpr int WAIT_YOUNGEST = 0x0F70 | (LOADS & 15) | ((LOADS >> 4) << 14);       // s_waitcnt vmcnt(LOADS)
-    auto read_frags = [&](const XVA_LDS uint8_t* At, const XVA_LDS uint8_t* Bt, int kh, bf16x8 (&af)[MI], bf16x8 (&bfr)[NJ]) {
+    constexpr bool ANY_IC = AK == IC || BKD == IC;
+    auto read_frags = [&](const XVA_LDS uint8_t* At, const XVA_LDS uint8_t* Bt, int kh, Frag<AK> (&af)[MI], Frag<BKD> (&bfr)[NJ]) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if constexpr (BKD == KC) bfr[j] = krb.read(Bt, wn * WN + j * 16, kh);
@@ -606,6 +625,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
             if constexpr (AK == KC) af[i] = kra.read(At, wm * WM + i * 16, kh);
             else af[i] = ira.read(At, i, kh);
         }
+    };
+    // wait for the transpose reads (if any), take the operand values (LeakyReLU of an operand applied here), multiply
+    auto mfma_all = [&](Frag<AK> (&afr)[MI], Frag<BKD> (&bfrr)[NJ]) {
+        frags_wait<ANY_IC>();
+        bf16x8 af[MI], bfr[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = frag_value(afr[i]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = frag_value(bfrr[j]);
         if (p.a_lrelu) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
@@ -614,8 +642,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
 #pragma unroll
             for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag(bfr[j], p.b_slope);
         }
-    };
-    auto mfma_all = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[NJ]) {
         if constexpr (XVA_GLDS_ABLATE & 1) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(af[i]));
@@ -638,15 +664,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
         const int cur = (kt - kt_begin) & 1;
         const XVA_LDS uint8_t* At = smem + cur * BUF;
         const XVA_LDS uint8_t* Bt = At + A_BYTES;
-        bf16x8 af[MI], bfr[NJ];
-        if constexpr (XVA_GLDS_ABLATE & 4) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = __builtin_bit_cast(bf16x8, (f32x4){1.f * lane, 2.f, 3.f, 4.f * kt});
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8, (f32x4){1.f, 2.f * lane, 3.f, 4.f});
-        } else read_frags(At, Bt, 0, af, bfr);
+        Frag<AK> af[MI];
+        Frag<BKD> bfr[NJ];
+        read_frags(At, Bt, 0, af, bfr);
         mfma_all(af, bfr);
-        if constexpr (!(XVA_GLDS_ABLATE & 4)) read_frags(At, Bt, 1, af, bfr);
+        read_frags(At, Bt, 1, af, bfr);
+        frags_wait<ANY_IC>();
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): this wave's reads of the buffer are in registers
         __builtin_amdgcn_s_barrier();                            // A: the buffer of tile kt is free
         const bool more = (XVA_GLDS_ABLATE & 2) ? false : kt + 2 < kt_end;
@@ -722,8 +745,8 @@ struct Loader32 {
 struct KcReader32 {
     uint32_t o;
     __device__ __forceinline__ void init(int lane) { o = (lane & 15) * 64 + (((lane >> 4) ^ kc32_f(lane & 15)) * 16); }
-    __device__ __forceinline__ bf16x8 read(const XVA_LDS uint8_t* tile, int row0) const {
-        return *reinterpret_cast<const XVA_LDS bf16x8*>(tile + row0 * 64 + o);
+    __device__ __forceinline__ Frag<KC> read(const XVA_LDS uint8_t* tile, int row0) const {
+        Frag<KC> f; f.v = *reinterpret_cast<const XVA_LDS bf16x8*>(tile + row0 * 64 + o); return f;
     }
 };
 
@@ -872,23 +895,17 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const XVA_LDS uint8_t* At = smem + slot * BUF;
         const XVA_LDS uint8_t* Bt = At + A_BYTES;
-        bf16x8 af[MI], bfr[NJ];
-        if constexpr (XVA_GLDS_ABLATE & 4) {
+        Frag<AK> afr[MI];
+        Frag<BKD> bfrr[NJ];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = __builtin_bit_cast(bf16x8, (f32x4){1.f * lane, 2.f, 3.f, 4.f * kt});
+        for (int j = 0; j < NJ; ++j) {
+            if constexpr (BKD == KC) bfrr[j] = krb.read(Bt, wn * WN + j * 16);
+            else bfrr[j] = irb.read(Bt, j, 0);
+        }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8, (f32x4){1.f, 2.f * lane, 3.f, 4.f});
-        } else {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if constexpr (BKD == KC) bfr[j] = krb.read(Bt, wn * WN + j * 16);
-                else bfr[j] = irb.read(Bt, j, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                if constexpr (AK == KC) af[i] = kra.read(At, wm * WM + i * 16);
-                else af[i] = ira.read(At, i, 0);
-            }
+        for (int i = 0; i < MI; ++i) {
+            if constexpr (AK == KC) afr[i] = kra.read(At, wm * WM + i * 16);
+            else afr[i] = ira.read(At, i, 0);
         }
         const int ahead = (XVA_GLDS_ABLATE & 2) ? 0 : kt_end - kt;     // tiles left including this one
         // tile kt + NS - 1 goes into the slot of tile kt - 1; then this wave's part of tile kt + 1 must have landed
@@ -896,6 +913,12 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
         else if (NS > 4 && ahead > 3) __builtin_amdgcn_s_waitcnt(WAIT_VM2);
         else if (ahead > 2) __builtin_amdgcn_s_waitcnt(WAIT_VM1);
         else __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+        frags_wait<AK == IC || BKD == IC>();                     // the transpose reads (inline asm: see Frag)
+        bf16x8 af[MI], bfr[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = frag_value(afr[i]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = frag_value(bfrr[j]);
         if (p.a_lrelu) {                                         // one uniform branch per read slot
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
@@ -1030,17 +1053,24 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void xva_gemm_glds3
         if (kt + 2 < kt_end) issue(kt + 2, slot >= 1 ? slot - 1 : 2);
         const XVA_LDS uint8_t* At = smem + slot * BUF;
         const XVA_LDS uint8_t* Bt = At + A_BYTES;
-        bf16x8 af[MI], bfr[NJ];
+        Frag<AK> afr[MI];
+        Frag<BKD> bfrr[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            if constexpr (BKD == KC) bfr[j] = krb.read(Bt, wn * WN + j * 16);
-            else bfr[j] = irb.read(Bt, j, 0);
+            if constexpr (BKD == KC) bfrr[j] = krb.read(Bt, wn * WN + j * 16);
+            else bfrr[j] = irb.read(Bt, j, 0);
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            if constexpr (AK == KC) af[i] = kra.read(At, wm * WM + i * 16);
-            else af[i] = ira.read(At, i, 0);
+            if constexpr (AK == KC) afr[i] = kra.read(At, wm * WM + i * 16);
+            else afr[i] = ira.read(At, i, 0);
         }
+        frags_wait<AK == IC || BKD == IC>();
+        bf16x8 af[MI], bfr[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = frag_value(afr[i]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = frag_value(bfrr[j]);
         if (p.a_lrelu) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
@@ -1147,7 +1177,7 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
     // weight tiles: two LDS stages, one and a half tiles in flight (see xva_gemm_glds_kernel)
     constexpr int LOADS = Loader<BKD, BN, NW>::NI;
     constexpr int WAIT_YOUNGEST = 0x0F70 | (LOADS & 15) | ((LOADS >> 4) << 14);       // s_waitcnt vmcnt(LOADS)
-    auto read_frags = [&](const XVA_LDS uint8_t* Bt, int kt, int kh, bf16x8 (&af)[MI], bf16x8 (&bfr)[NJ]) {
+    auto read_frags = [&](const XVA_LDS uint8_t* Bt, int kt, int kh, bf16x8 (&af)[MI], Frag<BKD> (&bfr)[NJ]) {
         const int kl = kt * GK + kh * 32 + g * 8;           // this lane's first k: one MFMA k-step spans 32 / CIN taps when CIN < 32
         const int tap = min(kl / CIN, ntaps - 1);           // a ragged last K tile multiplies zero weights: stay inside the tile
         const int ch = (kl % CIN) / 8;
@@ -1167,7 +1197,11 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
             for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
         }
     };
-    auto mfma_all = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[NJ]) {
+    auto mfma_all = [&](const bf16x8 (&af)[MI], Frag<BKD> (&bfrr)[NJ]) {
+        frags_wait<BKD == IC>();                            // the weight fragments of backward-data are transpose reads (inline asm: see Frag)
+        bf16x8 bfr[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = frag_value(bfrr[j]);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1182,10 +1216,12 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_k
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const XVA_LDS uint8_t* Bt = smem + A_BYTES + cur * B_BYTES;
-        bf16x8 af[MI], bfr[NJ];
+        bf16x8 af[MI];
+        Frag<BKD> bfr[NJ];
         read_frags(Bt, kt, 0, af, bfr);
         mfma_all(af, bfr);
         read_frags(Bt, kt, 1, af, bfr);
+        frags_wait<BKD == IC>();
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();                            // A: the weight buffer of tile kt is free
         const bool more = kt + 2 < nkt;

@@ -217,6 +217,8 @@ const DiscNet& dnet() { static DiscNet n; return n; }
 const DiscNet& vits_dnet() { static DiscNet n(true); return n; }
 
 // ------------------------------------------------------------------ workspace plan ----
+// env XVA_HG_WIDE_PADS=1: the round-2 geometry of the merged discriminator tails (A/B switch)
+static const int g_hg_wide_pads = [] { const char* e = getenv("XVA_HG_WIDE_PADS"); return e ? atoi(e) : 0; }();
 struct Bump {
     int64_t cur = 0;
     int64_t take(int64_t bytes) { int64_t o = cur; cur += (bytes + 255) & ~(int64_t)255; return o; }
@@ -347,7 +349,11 @@ int make_plan(const xva_hg_dims* d, Plan* p, const GenNet* gn = nullptr, const D
         H[0] = (d->seg + pp - 1) / pp;
         for (int i = 1; i <= 4; ++i) H[i] = (H[i - 1] + 4 - 5) / 3 + 1;
         H[5] = H[4]; H[6] = H[4];
-        const int pf4 = 4, hp4 = H[4] + 8;
+        // conv3 (k 5, stride 3) and conv4 (k 5, stride 1) run MERGED over all rows of all sequences, pad rows included: the 1024-channel
+        // layers are 85 % of a period discriminator's FLOPs and H[4] is only 10 .. 51 rows, so every pad row counts (4 + 4 pad rows: 43 % more
+        // rows than valid ones over the five periods; 1 + 1: 11 %).  Two zero rows between consecutive sequences is what a k = 5 convolution
+        // needs; the first / last sequence borrow their second row from the guard rows around the tensor.
+        const int pf4 = g_hg_wide_pads ? 4 : 1, hp4 = H[4] + (g_hg_wide_pads ? 8 : 2);
         for (int which = 0; which < 2; ++which) {
             SeqSpec* t = which == 0 ? p->pt[d5] : p->pd[d5];
             t[1] = mk(b, es, ns, H[1], 32, 4, 4);
@@ -384,7 +390,9 @@ int make_plan(const xva_hg_dims* d, Plan* p, const GenNet* gn = nullptr, const D
         for (int set = 0; set < sets; ++set)
             for (int which = 0; which < 2; ++which) {
                 SeqSpec* t = which == 0 ? p->st[sc][set] : p->sd[sc][set];
-                for (int i = 1; i <= 8; ++i) t[i] = mk(b, es, ns, T[i], ch[i], 24, 24);
+                // t5 .. t8 (conv5 k 41, conv6 k 5, conv_post k 3: stride 1, merged over all rows) share one geometry: 20 zero rows in FRONT of
+                // every sequence serve as the back pad of the previous one (the last sequence's are the guard rows): T + 20 rows instead of T + 48
+                for (int i = 1; i <= 8; ++i) t[i] = (i >= 5 && !g_hg_wide_pads) ? mk(b, es, ns, T[i], ch[i], 20, 0) : mk(b, es, ns, T[i], ch[i], 24, 24);
                 p->sxc[sc][set][which] = mk(b, es, ns, T[1], 16, 24, 24);
             }
         for (int rf = 0; rf < 2; ++rf) p->wav_s[sc][rf] = sc == 0 ? -1 : b.take((int64_t)B * p->Tw[sc] * 4);
