@@ -615,6 +615,8 @@ extern "C" int xva_fp_slot_offset(const xva_fp_dims* d, int slot, int64_t* off_b
             // what the layer-by-layer (teacher-forced) parity check of the bf16 schedule reads
             if (slot >= 100 && slot <= 100 + NL) { *off_bytes = p.enc_x[slot - 100]; break; }
             if (slot >= 200 && slot <= 200 + NL) { *off_bytes = p.dec_x[slot - 200]; break; }
+            if (slot == 300) { *off_bytes = p.pa; break; }     // diagnostics: the temporal predictors' backward scratch (Re x 256 fp32)
+            if (slot == 301) { *off_bytes = p.pb; break; }
             xva_set_error("slot_offset: unknown slot %d", slot); return XVA_ERR_ARG;
     }
     return XVA_OK;
