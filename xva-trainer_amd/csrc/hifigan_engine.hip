@@ -357,7 +357,10 @@ int make_plan(const xva_hg_dims* d, Plan* p, const GenNet* gn = nullptr, const D
         for (int which = 0; which < 2; ++which) {
             SeqSpec* t = which == 0 ? p->pt[d5] : p->pd[d5];
             t[1] = mk(b, es, ns, H[1], 32, 4, 4);
-            t[2] = mk(b, es, ns, H[2], 128, 4, 4);
+            // t2 is aligned 3 : 1 with t3 (as t3 is with t4) so that conv2 (128 -> 512, k 5, stride 3) is ONE merged GEMM over all rows too: per
+            // sequence it has only H[3] = 28 .. 152 output rows, a fifth to a full 128-row tile (measured per-sequence: 56 .. 161 us per launch)
+            if (g_hg_wide_pads) t[2] = mk(b, es, ns, H[2], 128, 4, 4);
+            else t[2] = mk(b, es, ns, H[2], 128, 9 * pf4, 9 * hp4 - H[2] - 9 * pf4);
             t[3] = mk(b, es, ns, H[3], 512, 3 * pf4, 3 * hp4 - H[3] - 3 * pf4);    // aligned 3:1 with t4 (merged strided conv3)
             t[4] = mk(b, es, ns, H[4], 1024, pf4, hp4 - H[4] - pf4);
             t[5] = mk(b, es, ns, H[5], 1024, pf4, hp4 - H[4] - pf4);
