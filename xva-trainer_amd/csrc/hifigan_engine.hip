@@ -444,7 +444,7 @@ static SideStreams& side_streams() {
     if (!r.init) {
         r.init = true;
         const char* e = getenv("XVA_HG_STREAMS");
-        int want = e ? atoi(e) : 3;                 // 3 streams: one per parallel resblock of a generator stage; the discriminators use two
+        int want = e ? atoi(e) : 4;                 // the discriminators use four lanes (disc_lane), a generator stage's parallel resblocks three
         if (want > MAXL) want = MAXL;
         bool ok = want > 1 && hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess;
         for (int i = 1; ok && i < want; ++i)
@@ -466,7 +466,13 @@ static int disc_lane(int di, int nl) {
         if (e) { int i = 0; for (const char* q = e; *q && i < 8; ++q) if (*q >= '0' && *q <= '9') tab[i++] = *q - '0'; if (i < 8) tab[0] = -1; }
     }
     if (tab[0] >= 0) return tab[di] % nl;
-    // measured: 2 lanes (MPD | MSD) 45.8 -> 41.3 ms per iteration; 3 and 4 lanes 41.7 - 42.0
+    // Round 2 (before the merged tails were tightened): 2 lanes (MPD | MSD) 45.8 -> 41.3 ms per iteration, 3 and 4 lanes 41.7 - 42.0.
+    // Round 3: the scale discriminators are the longer chain now — full-rate scale 0 (spectral norm: real and fake passes apart) alone on
+    // lane 1, the two pooled scales on lane 2, the period discriminators over lanes 0 and 3: 34.3 -> 33.1 ms (sweep of ten assignments:
+    // 33.1 - 33.7 for every split that keeps scale 0 alone; 34.1 - 35.0 for 2 / 3 lanes).
+    static const int four[8] = {0, 0, 0, 3, 3, 1, 2, 2}, three[8] = {0, 0, 0, 0, 0, 1, 2, 1};
+    if (nl >= 4) return four[di];
+    if (nl == 3) return three[di];
     return nl >= 2 ? (di >= NPER ? 1 : 0) : 0;
 }
 struct Ctx;

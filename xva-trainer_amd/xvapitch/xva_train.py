@@ -1,0 +1,682 @@
+"""xVAPitchTrainer / handleTrainer — the trainer protocol of python/xvapitch/xva_train.py:86-215 (handleTrainer), :218-600 (init / start / logs),
+:601-900 (iteration), :903-918 (finish_epoch), :924-1010 (save_checkpoint), :1017-1067 (load_checkpoint) around the iteration of
+xva-trainer_amd/xvapitch/train_step.py (generator pass + discriminator pass on libxvahip).
+
+Kept from the reference, because server.py / the Electron UI / existing checkpoints depend on them: module-level `async handleTrainer(models_manager,
+data, websocket, gpus, resume)` (checkpoint resolution incl. "[base]", the bare-raise stage protocol, "Finished training\\n" on the websocket); class
+`xVAPitchTrainer(logger, PROD, gpus, models_manager, websocket, amp, cmd_training)` with `async start / init / iteration`, `pause`, `start_new_epoch`,
+`finish_epoch`, `save_checkpoint`, `load_checkpoint`, `get_target_delta`, `init_logs`, `print_and_log`, the flags `running / is_init /
+JUST_FINISHED_STAGE / END_OF_TRAINING`; the `data` keys (dataset_path, output_path, checkpoint, num_workers, batch_size, lang, bkp_every_x,
+[force_stage], [use_amp]); gam = ceil(400 / batch) (target_bs 400, :1135-1145) with the reference's own accumulation semantics (below); two AdamW
+(lr 1.75e-4 generator group / 2e-4 discriminator, betas (0.8, 0.99), eps 1e-9, wd 0.01; training_util.py:56-57) and two ExponentialLR(0.999875) stepped
+once per finished epoch (:919-920); the finetune / priors alternation (FINETUNE_WEIGHT 20, :889-893) with the posterior encoder's and waveform
+decoder's gradients dropped on priors iterations (:724-726); save_step 50; the checkpoint-time stopping rule on the discriminator loss (:796-851) and the
+stage 1 -> 2 -> finished transitions; `xVAPitch_{steps}.pt` = {"model", "optimizer": [sd0, sd1], "scaler", "step", "epoch", "lr", "date",
+"avg_disc_loss_per_epoch", "avg_disc_loss_per_epoch_deltas", "training_stage"} (keep the last two), `{dataset_id}.pt` (fp16 state_dict) and
+`{dataset_id}.json`; training.log + graphs.json; ws strings "Set stage to: N ".
+
+Gradient accumulation, as the reference has it (:652-653): `optimizer.zero_grad()` runs at the start of EVERY pass of every iteration, so an optimiser
+step after `gam` iterations applies the LAST micro-batch's gradients only; mirrored here (parity with the reference's training dynamics), not "fixed".
+
+Changed on purpose: no GradScaler (bf16 needs none; the checkpoint's "scaler" entry is an empty dict); spectrograms are computed on the GPU from the raw
+clips (GeneratorPass.batch_from_wav) instead of in DataLoader workers; multi-GPU is one process per GPU (train_step.BucketedSync over RCCL) instead of
+nn.DataParallel.  The text front end (g2p -> ALL_SYMBOLS ids), speaker-embedding extraction and pitch extraction are the reference's CPU preprocessing:
+this trainer reads their caches (`tokens/{name}.npy` int ids, `se_embs/{name}.npy` 512-d, `pitch/{name}.npy`), and says so when one is missing.
+"""
+import datetime
+import json
+import math
+import os
+import time
+import traceback
+import types
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..data import BasicTextEncoder, read_metadata, read_wav_int16
+from .acoustic import AcousticTrainPath
+from .decoder import VitsDecoder
+from .discriminator import VitsDiscriminator
+from .generator_pass import GeneratorPass
+from .train_step import FlatGroupAdamW, XVAPitchStep
+
+N_SYMBOLS = 524          # len(ALL_SYMBOLS), python/xvapitch/text/ipa_to_xvaarpabet.py:103 (oracle/gen_xvapitch_checkpoint_layout.py evaluates it)
+N_LANGUAGES = 31         # len(lang_names), python/xvapitch/model.py:57
+LANGS = ["de", "en", "it", "fr", "ro", "jp", "es", "ru", "ar", "da", "el", "fi", "ha", "hi", "hu", "ko", "la", "nl", "pl", "pt", "sw", "sv", "tr", "uk",
+         "vi", "wo", "yo", "zh"]                                                       # xva_train.py:1163 (the language id is the index into lang_names' keys)
+
+
+def sort_xvap(x):
+    return int(x.split("xVAPitch_")[-1].split(".")[0].split("_")[0])
+
+
+def last_checkpoint(output):
+    """Newest xVAPitch_{steps}.pt by its step count (xva_train.py:1447-1458)."""
+    if not output or not os.path.isdir(output):
+        return None
+    saved = sorted([f for f in os.listdir(output) if f.startswith("xVAPitch_") and f.endswith(".pt") and " - " not in f], key=sort_xvap)
+    return output + "/" + saved[-1] if saved else None
+
+
+def format_time(seconds):
+    """training_util.py:71-89."""
+    out = ""
+    for unit, name in ((86400, "d"), (3600, "h"), (60, "m")):
+        if seconds > unit:
+            n = int(seconds / unit)
+            out += "%d%s " % (n, name)
+            seconds -= n * unit
+    if seconds > 0:
+        out += "%ds " % int(seconds)
+    return out
+
+
+def _now():
+    return str(datetime.datetime.now().time()).split(".")[0]
+
+
+async def handleTrainer(models_manager, data, websocket, gpus, resume=False):
+    """python/xvapitch/xva_train.py:86-215."""
+    torch.cuda.empty_cache()
+    if not resume:
+        models_manager.sync_init_model("xvapitch", websocket=websocket, gpus=[0] if gpus is None else gpus)
+        trainer = models_manager.models_bank["xvapitch"]
+        dataset_id = data["dataset_path"].split("/")[-1]
+        dataset_output = data["output_path"] + "/" + dataset_id
+        trainer.init_logs(dataset_output=dataset_output)
+        ckpt_fname, final = data.get("checkpoint"), None
+        if ckpt_fname is not None:                                                   # :101-127
+            final = last_checkpoint(dataset_output)
+            if final is None:
+                if ckpt_fname == "[base]":
+                    final = trainer.pretrained_ckpt
+                else:
+                    if os.path.isdir(ckpt_fname):
+                        final = last_checkpoint(ckpt_fname)
+                    if final is None:
+                        final = ckpt_fname
+        data["checkpoint"] = final
+    else:
+        trainer = models_manager.models_bank["xvapitch"]
+    try:
+        await trainer.start(data, gpus=gpus, resume=resume)
+    except KeyboardInterrupt:
+        trainer.running = False
+        raise
+    except RuntimeError as e:
+        trainer.running = False
+        for attr in ("train_loader", "finetune_loader", "priors_iterator", "finetune_iterator", "step", "optimizer"):
+            if hasattr(trainer, attr):
+                try:
+                    delattr(trainer, attr)
+                except Exception:
+                    pass
+        torch.cuda.empty_cache()
+        if "out of memory" in str(e).lower() or "ALLOC_CONF" in str(e):
+            trainer.print_and_log("Out of VRAM", save_to_file=trainer.dataset_output)
+            raise                                                                    # DO_LOWER_BATCHSIZE_REATTEMPT is False in the reference (:172)
+        if trainer.JUST_FINISHED_STAGE:
+            stage_finished = trainer.force_stage or trainer.training_stage - 1
+            trainer.print_and_log("Finished training stage %d...\n" % stage_finished, save_to_file=trainer.dataset_output)
+            trainer.JUST_FINISHED_STAGE = False
+            trainer.is_init = False
+            models_manager.models_bank.pop("xvapitch", None)
+            if trainer.websocket is not None:
+                await trainer.websocket.send("Finished training\n")
+            return None
+        models_manager.models_bank.pop("xvapitch", None)
+        raise
+    return None
+
+
+class XVAPitchFileLoader:
+    """DataLoader(TTSDataset(read_datasets([dataset]))) of the reference (xva_train.py:1162-1260, dataset.py:223-527) for ONE dataset directory, the batch
+    built on the device.  Per item: wavs/{name}.wav (22050 Hz int16), the symbol ids (`tokens/{name}.npy` written by the reference's g2p front end, else
+    the basic character table of data.py — only meaningful for smoke tests), `se_embs/{name}.npy` (the 512-d speaker embedding; the dataset mean when an
+    item has none), `pitch/{name}.npy` ((1, frames) or (frames,), 0 = unvoiced; zeros when absent).  Yields dicts with xVAPitch.format_batch's keys
+    (model.py:221-269); `linear_input` / `waveform` come from GeneratorPass.batch_from_wav in the trainer (raw clips go to the device, not spectrograms).
+    Data-parallel: every rank shuffles the same epoch order and takes a disjoint stride of it."""
+
+    def __init__(self, dataset_path, batch_size, device, lang="en", seed=1234, rank=0, world=1, data_mult=1, min_seq_len=15, log=None):
+        self.path, self.batch_size, self.device = dataset_path, int(batch_size), torch.device(device)
+        self.items = read_metadata(dataset_path)
+        if not self.items:
+            raise FileNotFoundError("no usable lines in %s/metadata.csv (wavs/ missing?)" % dataset_path)
+        self.lang_id = LANGS.index(lang) if lang in LANGS else 1
+        self.enc = BasicTextEncoder()
+        self.seed, self.rank, self.world, self.epoch = seed, rank, world, 0
+        self.index = list(range(len(self.items))) * max(1, int(data_mult))
+        self.actual_num_lines = len(self.items)
+        self._cache = {}
+        embs = [np.load(os.path.join(dataset_path, "se_embs", n + ".npy")).reshape(-1).astype(np.float32) for n, _, _ in self.items
+                if os.path.exists(os.path.join(dataset_path, "se_embs", n + ".npy"))]
+        if not embs:
+            raise FileNotFoundError("%s/se_embs/*.npy not found: the speaker embeddings are extracted by the reference's preprocessing "
+                                    "(python/xvapitch/get_dataset_emb.py), outside the accelerated path" % dataset_path)
+        self.mean_emb = np.mean(np.stack(embs), 0)
+        self.missing = {"tokens": 0, "pitch": 0}
+        self.log = log
+
+    def __len__(self):
+        return (len(self.index) // self.world) // self.batch_size
+
+    def item(self, i):
+        it = self._cache.get(i)
+        if it is None:
+            name, path, text = self.items[i]
+            wav, sr = read_wav_int16(path)
+            if sr != 22050:
+                raise ValueError("%s SR doesn't match target 22050 SR" % path)
+            tpath = os.path.join(self.path, "tokens", name + ".npy")
+            if os.path.exists(tpath):
+                tok = np.load(tpath).astype(np.int64).reshape(-1)
+            else:
+                self.missing["tokens"] += 1
+                tok = np.asarray(self.enc.encode(text), dtype=np.int64) + 1           # character ids (smoke tests): never the pad id 0
+            epath = os.path.join(self.path, "se_embs", name + ".npy")
+            emb = np.load(epath).reshape(-1).astype(np.float32) if os.path.exists(epath) else self.mean_emb
+            frames = 1 + wav.shape[0] // 256
+            ppath = os.path.join(self.path, "pitch", name + ".npy")
+            if os.path.exists(ppath):
+                pitch = np.load(ppath).astype(np.float32).reshape(-1)[:frames]
+                pitch = np.pad(pitch, (0, frames - pitch.shape[0]))
+            else:
+                self.missing["pitch"] += 1
+                pitch = np.zeros(frames, dtype=np.float32)
+            it = {"name": path, "wav": wav.astype(np.float32) / 32768.0, "tokens": tok, "emb": emb, "pitch": pitch}
+            if len(self._cache) < 5000:
+                self._cache[i] = it
+        return it
+
+    def __iter__(self):
+        import random
+        order = list(self.index)
+        random.Random(self.seed + self.epoch).shuffle(order)
+        self.epoch += 1
+        order = order[self.rank::self.world]
+        for b in range(len(self)):
+            its = [self.item(i) for i in order[b * self.batch_size:(b + 1) * self.batch_size]]
+            B = len(its)
+            Tt, N = max(len(it["tokens"]) for it in its), max(len(it["wav"]) for it in its)
+            Ty = 1 + N // 256
+            text = torch.zeros(B, Tt, dtype=torch.int64)
+            wavs = torch.zeros(B, N)
+            pitch = torch.zeros(B, 1, Ty)
+            for j, it in enumerate(its):
+                text[j, :len(it["tokens"])] = torch.from_numpy(it["tokens"])
+                wavs[j, :len(it["wav"])] = torch.from_numpy(it["wav"])
+                pitch[j, 0, :len(it["pitch"])] = torch.from_numpy(it["pitch"])
+            dev = self.device
+            yield {"text_input": text.to(dev), "text_lengths": torch.tensor([len(it["tokens"]) for it in its], device=dev),
+                   "wavs": wavs.to(dev), "wav_lengths": torch.tensor([len(it["wav"]) for it in its], device=dev), "pitch_padded": pitch.to(dev),
+                   "d_vectors": torch.from_numpy(np.stack([it["emb"] for it in its])).to(dev),
+                   "language_ids": torch.full((B,), self.lang_id, dtype=torch.int64, device=dev), "wav_file_name": [it["name"] for it in its]}
+
+
+class xVAPitchTrainer(object):
+    def __init__(self, logger, PROD, gpus, models_manager, websocket=None, amp=None, cmd_training=False, compute="bf16", loader_factory=None, model_kwargs=None):
+        self.logger, self.PROD, self.gpus, self.models_manager, self.websocket = logger, PROD, gpus, models_manager, websocket
+        self.amp, self.cmd_training, self.compute, self.loader_factory = amp, cmd_training, compute, loader_factory
+        self.model_kwargs = dict(model_kwargs or {})            # tests shrink the model; default = the reference's `--big 1 --pitch 1`
+        self.ckpt_path, self.isReady, self.model = None, True, None
+        self.epoch, self.running, self.is_init, self.logs_are_init = None, False, False, False
+        self.training_log, self.training_log_live_line = [], ""
+        self.dataset_id = self.dataset_input = self.dataset_output = None
+        self.batch_size = self.force_stage = self.workers = None
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.pretrained_ckpt = ("./pretrained_models/xVAPitch_5820651.pt" if cmd_training else
+                                ("./resources/app" if PROD else ".") + "/python/xvapitch/pretrained_models/xVAPitch_5820651.pt")
+        self.priors_languages_loaded = []
+        self.JUST_FINISHED_STAGE = self.END_OF_TRAINING = False
+        self.training_stage = 1
+        self.allow_random_init = False          # tests / benchmarks only
+
+    # ---- logs the UI reads from disk (xva_train.py:259-271,469-510) ----
+    def print_and_log(self, line=None, end="\n", flush=False, save_to_file=None):
+        if line is not None:
+            self.training_log.append("%s | %s" % (_now(), line))
+        if self.rank == 0 and save_to_file:
+            os.makedirs(save_to_file, exist_ok=True)
+            with open(save_to_file + "/training.log", "w+", encoding="utf8") as f:
+                f.write("\n".join(self.training_log + [self.training_log_live_line]))
+
+    def init_logs(self, dataset_output):
+        if self.logs_are_init:
+            return
+        os.makedirs(dataset_output, exist_ok=True)
+        self.training_log, self.training_log_live_line = [], ""
+        self.graphs_json = {"stages": {str(s): {"loss": [], "loss_delta": []} for s in (1, 2, 3)}}
+        if os.path.exists(dataset_output + "/training.log"):
+            with open(dataset_output + "/training.log", encoding="utf8") as f:
+                self.training_log = f.read().split("\n")
+            self.training_log.append("\n%s | New Session" % _now())
+        else:
+            self.training_log.append("No %s/training.log file found. Starting anew." % dataset_output)
+        if os.path.exists(dataset_output + "/graphs.json"):
+            with open(dataset_output + "/graphs.json", encoding="utf8") as f:
+                self.graphs_json = json.load(f)
+        else:
+            self.print_and_log("No graphs.json file found. Starting anew.", save_to_file=dataset_output)
+        self.logs_are_init = True
+
+    def _save_graphs(self):
+        if self.rank == 0:
+            with open(self.dataset_output + "/graphs.json", "w+", encoding="utf8") as f:
+                f.write(json.dumps(self.graphs_json))
+
+    def load_state_dict(self, ckpt_path, sd):
+        pass
+
+    def set_device(self, device):
+        pass
+
+    def get_target_delta(self, num_data_lines):
+        """xva_train.py:512-531."""
+        NATE_DELTA, NATE_NUMFILES = 0.0002, 8000
+        mult = NATE_NUMFILES / (max(1, num_data_lines) * 1.25)
+        td = NATE_DELTA * math.sqrt(mult if (mult - 1) < 1 else (mult - 1)) / 1.5
+        return [0.04, td * 0.2]
+
+    def pause(self, websocket=None):
+        self.running = False
+        torch.cuda.empty_cache()
+
+    # ---- xva_train.py:534-577 ----
+    async def start(self, data, gpus=None, resume=False):
+        if self.running:
+            return
+        self.running = True
+        if not resume:
+            if gpus is not None:
+                self.gpus = gpus
+            self.force_stage = int(data["force_stage"]) if "force_stage" in data else None
+            self.dataset_input = data["dataset_path"]
+            self.dataset_id = self.dataset_input.split("/")[-1]
+            self.dataset_output = data["output_path"] + "/" + self.dataset_id
+            os.makedirs(self.dataset_output, exist_ok=True)
+            self.checkpoint = data.get("checkpoint")
+            self.workers = data.get("num_workers", 0)
+            self.batch_size = int(data["batch_size"])
+            self.lang = data.get("lang", "en")
+            self.backup_model_every_x_ckpt = int(data.get("bkp_every_x", 2))
+            self.backup_model_counter = 0
+            self.learning_rate = 0.000175
+            self.max_iterations = data.get("max_iterations")            # benchmark / test hook (not in the reference)
+            self.save_step = int(data.get("save_step", 50))              # the reference's constant (:310); tests shorten it
+            self.priors_path = data.get("priors_path")
+        torch.cuda.empty_cache()
+        while self.running and not self.JUST_FINISHED_STAGE and not self.END_OF_TRAINING:
+            await self.iteration()
+
+    def start_new_epoch(self):
+        self.keep_avg_train = {k: [] for k in ("step_time", "loss", "loss_gen", "loss_kl", "loss_feat", "loss_mel", "loss_mel_pred", "loss_duration",
+                                               "loss_disc", "frames_per_second")}
+        self.steps_since_log = 0
+        self.epoch_steps = 0
+        self.finetune_it = True
+
+    def _device(self):
+        import torch.distributed as dist
+        if self.world > 1:
+            if not dist.is_initialized():
+                for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                    if k not in os.environ:
+                        raise RuntimeError("WORLD_SIZE=%d but %s is not set: launch under `python -m torch.distributed.run`" % (self.world, k))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        if self.gpus is not None and len(self.gpus) > 1:
+            raise NotImplementedError("gpus=%s in one process: the MI355X path is one process per GPU — start the trainer under "
+                                      "`python -m torch.distributed.run --nproc-per-node %d` instead of nn.DataParallel" % (self.gpus, len(self.gpus)))
+        return torch.device("cuda", int(self.gpus[0]) if self.gpus else 0)
+
+    def init_model(self, device):
+        """xVAPitch(args) at the trainer's switches (`--big 1 --pitch 1 --pe_scaling 0.2`, xva_train.py:1098-1132,1421-1425; model.py:40-215)."""
+        kw = dict(n_vocab=N_SYMBOLS, num_languages=N_LANGUAGES, latent_size=256, embedded_language_dim=12, d_vector_dim=512, pitch=True, pe_scaling=0.2,
+                  dropout_p=0.1, sdp_dropout_p=0.5)
+        kw.update(self.model_kwargs)
+        seg = kw.pop("spec_segment_size", 32)
+        ac = AcousticTrainPath(device=device, compute=self.compute, **kw)
+        dec = VitsDecoder(ac.C, ac.Dv, compute=self.compute, device=device)
+        disc = VitsDiscriminator(compute=self.compute, device=device)
+        return XVAPitchStep(GeneratorPass(ac, dec, seg), disc)
+
+    def model_state_dict(self):
+        """The reference model's state_dict keys: acoustic modules as they are, `waveform_decoder.*`, `disc.*` (model.py:40-215)."""
+        sd = dict(self.step.gen.acoustic.state_dict())
+        sd.update({"waveform_decoder." + k: v for k, v in self.step.gen.decoder.state_dict().items()})
+        sd.update({"disc." + k: v for k, v in self.step.disc.state_dict().items()})
+        return sd
+
+    def load_model_state_dict(self, sd):
+        """strict=False like the reference (:1038): keys this model does not hold are ignored, missing ones keep their values."""
+        ac, dec, disc = self.step.gen.acoustic, self.step.gen.decoder, self.step.disc
+        own = ac.state_dict()
+        ac.load_state_dict({k: sd[k] if k in sd and tuple(sd[k].shape) == tuple(v.shape) else v for k, v in own.items()})
+        for pre, eng in (("waveform_decoder.", dec), ("disc.", disc)):
+            cur = eng.state_dict()
+            eng.load_state_dict({k: (sd[pre + k] if pre + k in sd and tuple(sd[pre + k].shape) == tuple(v.shape) else v) for k, v in cur.items()})
+
+    # ---- xva_train.py:277-466 ----
+    async def init(self):
+        self.FINETUNE_WEIGHT = 20
+        self.device = dev = self._device()
+        torch.cuda.set_device(dev)
+        np.random.seed(1234 + self.rank)
+        torch.manual_seed(1234 + self.rank)
+        os.makedirs(self.dataset_output, exist_ok=True)
+        self.init_logs(dataset_output=self.dataset_output)
+        self.print_and_log("Dataset: %s" % self.dataset_input, save_to_file=self.dataset_output)
+        self.print_and_log("Language: %s" % self.lang, save_to_file=self.dataset_output)
+        ckpt_path = last_checkpoint(self.dataset_output)
+        if ckpt_path is None:
+            ckpt_path = self.checkpoint or self.pretrained_ckpt
+            self.print_and_log("Checkpoint: %s" % ckpt_path, save_to_file=self.dataset_output)
+        self.target_bs = 400
+        base_batch_size = self.batch_size
+        self.batch_size = max(1, int(self.batch_size * self.world))                                    # :327-329 (global batch; one process per GPU)
+        self.per_rank_batch = max(1, self.batch_size // self.world)
+        self.gam = max(1, math.ceil(self.target_bs / self.batch_size))                                 # :1142
+        self.print_and_log("CUDA device IDs: %s" % ",".join(str(v) for v in (self.gpus or [0])), save_to_file=self.dataset_output)
+        self.print_and_log("Batch size: %d (Base: %d, GPUs mult: %d) | GAM: %d -> (%d) | Target: %d" % (
+            self.batch_size, base_batch_size, self.world, self.gam, self.batch_size * self.gam, self.target_bs), save_to_file=self.dataset_output)
+        self.print_and_log("Outputting model backups every %d checkpoint%s  " % (self.backup_model_every_x_ckpt, "s" if self.backup_model_every_x_ckpt > 1 else ""),
+                           save_to_file=self.dataset_output)
+        self.step = self.init_model(dev)
+        self.model = self.step
+        ac, dec, disc = self.step.gen.acoustic, self.step.gen.decoder, self.step.disc
+        self.optimizer = [FlatGroupAdamW.for_generator(ac, dec, lr=self.learning_rate), FlatGroupAdamW.for_discriminator(disc, lr=0.0002)]
+        if ckpt_path and os.path.exists(str(ckpt_path)):
+            epoch, total_steps_done, adl, adld = self.load_checkpoint(ckpt_path)
+        elif self.allow_random_init:
+            epoch, total_steps_done, adl, adld = 0, 0, [[], []], [[], []]
+        else:
+            raise FileNotFoundError("xVAPitch checkpoint %s not found (the reference fine-tunes from its pretrained model, xva_train.py:247-250,321-324)" % ckpt_path)
+        self.ckpt_path = str(ckpt_path)
+        if ckpt_path is None or self.dataset_id not in str(ckpt_path):                                # IS_NEW, :351-354
+            self.print_and_log("New voice", save_to_file=self.dataset_output)
+            self.training_stage = 1
+        if self.force_stage:
+            self.training_stage = self.force_stage
+            self.print_and_log("Forcing stage: %d " % self.force_stage, save_to_file=self.dataset_output)
+        self.epoch, self.total_steps_done = epoch, total_steps_done
+        self.avg_disc_loss_per_epoch, self.avg_disc_loss_per_epoch_deltas = adl, adld
+        # dataloaders (:1162-1260): the fine-tune set, and the priors sets when they are installed
+        self.print_and_log("Workers: %s" % self.workers, save_to_file=self.dataset_output)
+        self.finetune_loader, self.train_loader = self.setup_dataloaders(dev)
+        ft_files = getattr(self.finetune_loader, "actual_num_lines", None) or len(self.finetune_loader) * self.batch_size
+        self.target_deltas = self.get_target_delta(ft_files)
+        self.ft_dataset_emb = [float(v) for v in getattr(self.finetune_loader, "mean_emb", np.zeros(512))]
+        # ExponentialLR(gamma 0.999875), stepped per finished epoch (training_util.py:59-69, xva_train.py:919-920)
+        self.gamma = 0.999875
+        if self.websocket is not None:
+            await self.websocket.send("Set stage to: %d " % self.training_stage)
+        self.print_and_log({1: "Stage 1: Warming up the training via text processing training.", 2: "Stage 2: Full training",
+                            3: "Stage 3: [Training finished] Extra training time with no auto-stop"}.get(self.training_stage, ""), save_to_file=self.dataset_output)
+        self.target_patience, self.target_patience_count = 3, 0
+        self.graphs_json["stages"]["1"]["target_delta"] = round(self.target_deltas[0] * 100, 3)
+        self.graphs_json["stages"]["2"]["target_delta"] = round(self.target_deltas[1] * 100, 3)
+        self.sync = None
+        if self.world > 1:
+            from .train_step import BucketedSync
+            self.sync = BucketedSync(self.step)
+        torch.cuda.synchronize()
+        self.print_and_log("Starting training.")
+        self.finetune_iterator = iter(self.finetune_loader)
+        self.priors_iterator = iter(self.train_loader) if self.train_loader is not None else None
+        self.ckpt_start_time = self.step_start_time = None
+        self.accumulated_steps, self.gam_num_frames, self.finetune_counter, self.training_iters = 0, 0, 0, 0
+        self.start_new_epoch()
+        self.is_init = True
+
+    def setup_dataloaders(self, dev):
+        if self.loader_factory:
+            pair = self.loader_factory(self)
+            if pair is not None:
+                return pair
+        ft = XVAPitchFileLoader(self.dataset_input, self.per_rank_batch, dev, lang=self.lang, seed=1234, rank=self.rank, world=self.world, data_mult=10)
+        if 0 < len(ft.index) // self.world < self.per_rank_batch:
+            ft.batch_size = max(1, len(ft.index) // self.world)
+        self.print_and_log("Fine-tune dataset files: %d" % ft.actual_num_lines, save_to_file=self.dataset_output)
+        root = self.priors_path or ("./PRIORS" if self.cmd_training else ("./resources/app" if self.PROD else ".") + "/python/xvapitch/PRIORS")
+        priors = None
+        if os.path.isdir(root) and os.path.exists(os.path.join(root, "metadata.csv")):
+            priors = XVAPitchFileLoader(root, self.per_rank_batch, dev, lang=self.lang, seed=4321, rank=self.rank, world=self.world)
+            self.print_and_log("Priors datasets files: %d" % priors.actual_num_lines, save_to_file=self.dataset_output)
+        else:
+            # the reference refuses to start without its PRIORS download (:372-374); here the fine-tune set alone trains (every iteration is a
+            # fine-tune iteration) and the log says so
+            self.print_and_log("No priors dataset at %s: fine-tuning without priors reinforcement iterations" % root, save_to_file=self.dataset_output)
+        return ft, priors
+
+    # ---- xva_train.py:601-900 ----
+    async def iteration(self):
+        if not self.is_init:
+            await self.init()
+        use_ft = self.finetune_it or self.priors_iterator is None
+        try:
+            batch = next(self.finetune_iterator if use_ft else self.priors_iterator)
+        except StopIteration:
+            if len(self.keep_avg_train["step_time"]) > 0:
+                self.finish_epoch()
+            self.start_new_epoch()
+            self.epoch += 1
+            use_ft = True if self.priors_iterator is None else self.finetune_it
+            if use_ft:
+                self.finetune_iterator = iter(self.finetune_loader)
+            else:
+                self.priors_iterator = iter(self.train_loader)
+            batch = next(self.finetune_iterator if use_ft else self.priors_iterator)
+        self.epoch_steps += 1
+        if self.ckpt_start_time is None:
+            self.ckpt_start_time = time.time()
+        if self.step_start_time is None:
+            self.step_start_time = time.time()
+        step = self.step
+        gp = step.gen
+        y, y_lengths, waveform = gp.batch_from_wav(batch["wavs"], batch["wav_lengths"])
+        Ty = y.size(2)
+        pitch = torch.nn.functional.pad(batch["pitch_padded"], (0, max(0, Ty - batch["pitch_padded"].size(2))))[..., :Ty].contiguous()
+        self.gam_num_frames += int(y_lengths.sum().item())
+        # ---- pass 0: generator (zero_grad at the start of each pass: :652-653) ----
+        gp.zero_grad()
+        out = step.generator_pass(batch["text_input"], batch["text_lengths"], y, y_lengths, waveform, batch["d_vectors"], batch["language_ids"],
+                                  pitch_padded=pitch, train=True)
+        out["loss"].backward()
+        loss_dict = {k: float(out[k].detach()) for k in ("loss", "loss_gen", "loss_kl", "loss_feat", "loss_mel", "loss_duration")}
+        if "loss_pitch" in out:
+            loss_dict["loss_pitch"] = float(out["loss_pitch"].detach())
+        # ---- pass 1: discriminator on the cached (generated.detach(), real) segments ----
+        step.disc.zero_grad()
+        loss_disc = step.discriminator_pass(out["model_outputs"].detach(), out["waveform_seg"])
+        loss_dict["loss_disc"] = float(loss_disc)
+        del out
+        self.accumulated_steps += 1
+        if self.accumulated_steps % self.gam == 0:
+            self.accumulated_steps = 0
+            if not use_ft:                                                             # priors iteration: the vocoder and posterior are not trained (:724-726)
+                gp.acoustic.posterior_encoder.zero_grad()
+                gp.decoder.zero_grad()
+            if self.sync is not None:
+                self.sync.reduce()
+            for opt in self.optimizer:
+                opt.step()
+            step_time = time.time() - self.step_start_time
+            self.step_start_time = time.time()
+            k = self.keep_avg_train
+            k["step_time"].append(step_time)
+            for name in ("loss", "loss_gen", "loss_kl", "loss_feat", "loss_mel", "loss_duration", "loss_disc"):
+                k[name].append(loss_dict[name])
+            k["current_lr"] = self.optimizer[0].param_groups[0]["lr"]
+            frames_per_second = int(self.gam_num_frames * self.world / step_time)
+            self.gam_num_frames = 0
+            k["frames_per_second"].append(frames_per_second)
+            self.training_iters += 1
+            stage = self.training_stage
+            loss_delta = 0
+            avg_loss = round(float(np.mean(k["loss"][-10:])), 4)
+            frames_per_second = int(np.mean(k["frames_per_second"]))
+            self.graphs_json["stages"][str(stage)]["loss"].append([self.total_steps_done, avg_loss])
+            if (self.training_iters % self.save_step) % 10 == 0:
+                self._save_graphs()
+            if stage <= 2 and len(self.avg_disc_loss_per_epoch[stage - 1]) > 1:       # :787-793
+                adlpe = self.avg_disc_loss_per_epoch[stage - 1]
+                self.avg_disc_loss_per_epoch_deltas[stage - 1].append((adlpe[-2] - adlpe[-1]) / adlpe[-2])
+                adlped = self.avg_disc_loss_per_epoch_deltas[stage - 1]
+                loss_delta = float(np.mean(adlped if len(adlped) < 10 else adlped[-10:]))
+            if self.training_iters % self.save_step == 0 and self.training_iters != 0:
+                await self._checkpoint_time(loss_delta, avg_loss, frames_per_second)
+            if loss_delta:
+                txt = " | Avg loss %% delta: %s " % round(loss_delta * 100, 3)
+                if self.training_stage <= 2:
+                    txt += "| Target: %s " % round(self.target_deltas[self.training_stage - 1] * 100, 3)
+                if self.target_patience_count > 0:
+                    txt += "| Hit: %d/%d " % (self.target_patience_count, self.target_patience)
+            else:
+                txt = " " * 67
+            iter_loss = round(float(np.mean(k["loss_disc"][-10:])), 4)
+            self.training_log_live_line = "Stage: %d | Steps: %d | Ckpt: %d/%d | Loss: %s | frames/s %d%s   " % (
+                self.training_stage, self.total_steps_done, self.training_iters % self.save_step, self.save_step, iter_loss, frames_per_second, txt)
+            self.print_and_log(save_to_file=self.dataset_output)
+            self.finetune_counter += 1
+            self.finetune_it = True
+            if self.finetune_counter >= self.FINETUNE_WEIGHT:
+                self.finetune_it = False
+                self.finetune_counter = 0
+            self.total_steps_done += self.gam
+            if self.max_iterations and self.training_iters >= self.max_iterations:
+                self.running = False
+
+    async def _checkpoint_time(self, loss_delta, avg_loss, frames_per_second):
+        """xva_train.py:796-865: every save_step optimiser steps — the stopping rule on the mean discriminator loss, then the checkpoint."""
+        stage = self.training_stage
+        ckpt_time = time.time() - self.ckpt_start_time
+        ckpt_avg_loss_disc = self._global_mean(float(np.mean(self.keep_avg_train["loss_disc"])))
+        if stage <= 2:
+            self.avg_disc_loss_per_epoch[stage - 1].append(ckpt_avg_loss_disc)
+        has_saved = False
+        output_path = "%s/xVAPitch_%d.pt" % (self.dataset_output, self.total_steps_done)
+        if loss_delta:
+            self.graphs_json["stages"][str(stage)]["loss_delta"].append([self.total_steps_done, round(loss_delta * 100, 3)])
+            self._save_graphs()
+            if loss_delta < self.target_deltas[stage - 1] if stage <= 2 else False:
+                self.target_patience_count += 1
+                if stage < 3 and self.target_patience_count >= self.target_patience:
+                    if stage == 1:
+                        has_saved = True
+                        self.save_checkpoint(frames_s=frames_per_second, avg_loss=avg_loss, loss_delta=loss_delta, fpath=output_path, ckpt_time=ckpt_time)
+                        self.print_and_log("Finished Stage 1. Moving on.. \n\n", save_to_file=self.dataset_output)
+                        self.print_and_log("\nStage 2: Full training", save_to_file=self.dataset_output)
+                        self.training_stage = 2
+                        self.target_patience_count = 0
+                        if self.websocket is not None:
+                            await self.websocket.send("Set stage to: %d " % self.training_stage)
+                    else:
+                        self.END_OF_TRAINING = self.JUST_FINISHED_STAGE = True
+                        self.training_stage += 1
+                        self.save_checkpoint(frames_s=frames_per_second, avg_loss=avg_loss, loss_delta=loss_delta, fpath=output_path, ckpt_time=ckpt_time)
+                        self.print_and_log("Finished Stage 2. Stopping training. \n\n", save_to_file=self.dataset_output)
+                        self.running = False
+                        raise RuntimeError("stage 2 finished")          # the reference signals completion by a bare raise (:838)
+            else:
+                self.target_patience_count = 0
+        else:
+            self.target_patience_count = 0
+        if not has_saved:
+            self.save_checkpoint(frames_s=frames_per_second, avg_loss=avg_loss, loss_delta=loss_delta, fpath=output_path, ckpt_time=ckpt_time)
+
+    def _global_mean(self, value):
+        if self.world == 1:
+            return value
+        import torch.distributed as dist
+        t = torch.tensor([value], device=self.device, dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item()) / self.world
+
+    def finish_epoch(self):
+        """xva_train.py:903-920: both schedulers step (ExponentialLR: lr *= gamma)."""
+        for opt in self.optimizer:
+            for g in opt.param_groups:
+                g["lr"] *= self.gamma
+
+    # ---- xva_train.py:924-1010 ----
+    def save_checkpoint(self, frames_s=0, avg_loss=None, loss_delta=None, fpath="out.pt", ckpt_time=None, doPrintLog=True):
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.rank != 0:
+                dist.barrier()
+                return
+        old = sorted([f for f in os.listdir(self.dataset_output) if f.startswith("xVAPitch_") and f.endswith(".pt") and " - " not in f], key=sort_xvap)
+        for ck in old[:-2] if len(old) > 2 else []:
+            os.remove(self.dataset_output + "/" + ck)
+        line = "Stage: %d | %s~%d.pt | Time: %s | frames/s: %d" % (self.training_stage, self.dataset_output.split("/")[-1], self.total_steps_done,
+                                                                  format_time(ckpt_time or 0), int(frames_s))
+        sd = {k: v.detach().cpu() for k, v in self.model_state_dict().items()}
+        model_entry = dict(sd)
+        model_entry["avg_disc_loss_per_epoch"] = self.avg_disc_loss_per_epoch
+        model_entry["avg_disc_loss_per_epoch_deltas"] = self.avg_disc_loss_per_epoch_deltas
+        checkpoint = {"model": model_entry, "optimizer": [o.state_dict() for o in self.optimizer], "scaler": {}, "step": self.total_steps_done,
+                      "epoch": self.epoch, "lr": self.optimizer[0].param_groups[0]["lr"], "date": datetime.date.today().strftime("%B %d, %Y"),
+                      "avg_disc_loss_per_epoch": self.avg_disc_loss_per_epoch, "avg_disc_loss_per_epoch_deltas": self.avg_disc_loss_per_epoch_deltas,
+                      "training_stage": self.training_stage}
+        if avg_loss is not None:
+            line += " | Loss: %.5f" % (int(avg_loss * 100000) / 100000)
+        if loss_delta is not None:
+            line += " | Delta: %s" % round(loss_delta * 100, 3)
+        if self.training_stage <= 2 and loss_delta is not None and loss_delta > 0:
+            line += " | Target: %s" % round(self.target_deltas[self.training_stage - 1] * 100, 3)
+            if self.target_patience_count > 0:
+                line += " | Hit: %d/%d " % (self.target_patience_count, self.target_patience)
+        tmp = "%s.tmp.%d" % (fpath, os.getpid())
+        torch.save(checkpoint, tmp)
+        os.replace(tmp, fpath)
+        half = {k: (v.half() if v.is_floating_point() else v) for k, v in sd.items()}
+        torch.save(half, "%s/%s.pt" % (self.dataset_output, self.dataset_id))
+        self.backup_model_counter += 1
+        if self.backup_model_counter >= self.backup_model_every_x_ckpt:
+            os.makedirs("%s/viz/%d" % (self.dataset_output, self.total_steps_done), exist_ok=True)
+            torch.save(half, "%s/viz/%d/%s.pt" % (self.dataset_output, self.total_steps_done, self.dataset_id))
+            self.backup_model_counter = 0
+        with open("%s/%s.json" % (self.dataset_output, self.dataset_id), "w+", encoding="utf8") as f:
+            json.dump({"version": "3.0", "modelVersion": "3.0", "modelType": "xVAPitch", "author": "", "lang": "en",
+                       "lang_capabilities": list(self.priors_languages_loaded),
+                       "games": [{"gameId": "other", "voiceId": self.dataset_id, "voiceName": self.dataset_output.split("/")[-1],
+                                  "base_speaker_emb": list(self.ft_dataset_emb), "gender": "male"}]}, f, indent=4)
+        self.training_log_live_line = ""
+        if doPrintLog:
+            self.print_and_log(line + "      ", save_to_file=self.dataset_output)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    # ---- xva_train.py:1017-1067 ----
+    def load_checkpoint(self, filepath):
+        self.print_and_log("Loading model and optimizer state from %s" % filepath, save_to_file=self.dataset_output)
+        try:
+            checkpoint = torch.load(filepath, map_location="cpu", weights_only=False)
+        except Exception:
+            self.print_and_log("Failed to load the checkpoint! Maybe try the second-last checkpoint (delete the last one). Full error message: %s"
+                               % traceback.format_exc(), save_to_file=self.dataset_output)
+            raise
+        total_steps_done = 0
+        if "step" in checkpoint:
+            total_steps_done = checkpoint["step"] if str(filepath).split("/")[-1] != self.pretrained_ckpt.split("/")[-1] else 0
+        src = checkpoint["model"] if "model" in checkpoint else checkpoint
+        sd = {k.replace("module.", ""): v for k, v in src.items() if torch.is_tensor(v)}
+        self.load_model_state_dict({k: v.float() if v.is_floating_point() else v for k, v in sd.items()})
+        if "optimizer" in checkpoint:
+            for idx, state in enumerate(checkpoint["optimizer"]):
+                try:
+                    self.optimizer[idx].load_state_dict(state)
+                except Exception:
+                    self.print_and_log("=== OPTIM NOT LOADED ===", save_to_file=self.dataset_output)
+        lr = checkpoint.get("lr", self.learning_rate)
+        for opt in self.optimizer:                                                    # both groups get the checkpoint's lr (:1056-1061)
+            for g in opt.param_groups:
+                g["lr"] = lr
+        adl = checkpoint.get("avg_disc_loss_per_epoch", [[], []])
+        adld = checkpoint.get("avg_disc_loss_per_epoch_deltas", [[], []])
+        self.training_stage = int(checkpoint.get("training_stage", 1))
+        return 0, total_steps_done, adl, adld
