@@ -93,6 +93,27 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "xvapitch_checkpoint_layout.json")
     with open(path, "w") as f:
         json.dump(out, f)
+    # the registration order of sibling modules / parameters (what fixes parameters() order for ANY layer count): parent pattern -> child -> rank,
+    # digits in ModuleList positions replaced by "#"; written as data into the package (xvapitch/param_order.py)
+    ranks = {}
+    for k in out["optimizer0_param_order"] + out["optimizer1_param_order"]:
+        toks = k.split(".")
+        for i, t in enumerate(toks):
+            if t.isdigit():
+                continue
+            parent = ".".join("#" if x.isdigit() else x for x in toks[:i])
+            d = ranks.setdefault(parent, {})
+            d.setdefault(t, len(d))
+    with open(os.path.join(ROOT, "xva-trainer_amd", "xvapitch", "param_order.py"), "w") as f:
+        f.write('"""Registration order of sibling sub-modules / parameters in the reference xVAPitch model (python/xvapitch/model.py:40-215 and the classes it\n'
+                'builds): parent key pattern ("#" = a ModuleList index) -> {child name: rank}.  torch\'s `parameters()` walks a module\'s own parameters, then its\n'
+                'children, in this order, which fixes the parameter order of the two AdamW state_dicts inside `xVAPitch_*.pt` checkpoints whatever the layer\n'
+                'counts.  DATA generated by oracle/gen_xvapitch_checkpoint_layout.py from the reference\'s own classes; do not edit."""\n')
+        f.write("SIBLING_RANK = " + json.dumps(ranks, indent=0).replace("\n", "") + "\n\n\n")
+        f.write('def order_key(name):\n    """sort key reproducing parameters() order for a reference state_dict key"""\n'
+                '    toks, key = name.split("."), []\n    for i, t in enumerate(toks):\n        if t.isdigit():\n            key.append(int(t))\n'
+                '        else:\n            parent = ".".join("#" if x.isdigit() else x for x in toks[:i])\n'
+                '            key.append(SIBLING_RANK.get(parent, {}).get(t, 1 << 20))\n    return key\n')
     n = sum(v.numel() for v in sd.values())
     print("wrote %s: %d tensors, %.1f M elements; optimizer0 %d params, optimizer1 %d params; n_symbols %s"
           % (path, len(sd), n / 1e6, len(out["optimizer0_param_order"]), len(out["optimizer1_param_order"]), n_symbols))

@@ -359,3 +359,117 @@ def test_hifigan_trainer_protocol_resume_and_inference_wrappers(tmp_path):
     mm3.set_device("gpu")
     with pytest.raises(RuntimeError):
         mm3.set_device("cpu")
+
+
+# ------------------------------------------------------------------------------------------------ xVAPitch (BASELINE configs[4])
+_XV_SMALL = dict(n_vocab=160, num_languages=31, latent_size=32, embedded_language_dim=4, d_vector_dim=512, hidden_channels_ffn=64, text_layers=2,
+                 posterior_layers=3, flow_layers=2, spec_segment_size=8)
+
+
+def _xv_trainer(mm, ws, out, name):
+    mm.sync_init_model("xvapitch", websocket=ws, gpus=[0])
+    tr = mm.models_bank["xvapitch"]
+    tr.compute, tr.model_kwargs, tr.allow_random_init = "fp32", dict(_XV_SMALL), True
+    tr.init_logs(out + "/" + name)
+    return tr
+
+
+def test_xvapitch_trainer_runs_checkpoints_and_resumes(tmp_path):
+    """python/xvapitch/xva_train.py's protocol on a synthetic dataset directory (metadata.csv + wavs/ + pitch/ + se_embs/): epochs roll over, the
+    schedulers step per epoch, a checkpoint in the reference's keys is written every save_step optimiser steps, a second trainer resumes from it
+    (model, both AdamW states, step count, stage), and handleTrainer drives the same thing through ModelsManager."""
+    from xva_trainer_amd.data import write_synthetic_dataset
+    from xva_trainer_amd.xvapitch import xva_train as XT
+    ds = write_synthetic_dataset(str(tmp_path / "in" / "voice_x"), n_items=6, seed=3, min_s=0.6, max_s=1.2, with_se_embs=True)
+    data = {"dataset_path": ds, "output_path": str(tmp_path / "out"), "checkpoint": None, "num_workers": 0, "batch_size": 400, "lang": "en",
+            "bkp_every_x": 2, "save_step": 4, "max_iterations": 9}
+    mm, ws = _mm(), _WS()
+    tr = _xv_trainer(mm, ws, data["output_path"], "voice_x")
+    asyncio.run(tr.start(data, gpus=[0]))
+    out = data["output_path"] + "/voice_x"
+    assert tr.gam == 1 and tr.training_iters == 9 and tr.total_steps_done == 9 and not tr.running
+    assert tr.epoch >= 2                                                    # 6 clips x data_mult 10 in batches of 6 (capped): 10 iterations an epoch... at least two roll-overs with the cap
+    assert any(m.startswith("Set stage to: 1") for m in ws.sent)
+    log = open(out + "/training.log").read()
+    assert "New voice" in log and "Stage: 1 | Steps:" in log and "frames/s" in log and "Fine-tune dataset files: 6" in log
+    cks = sorted(f for f in os.listdir(out) if f.startswith("xVAPitch_"))
+    assert cks == ["xVAPitch_3.pt", "xVAPitch_7.pt"], cks                   # named by the steps done BEFORE the saving step is counted (xva_train.py:853,894)
+    ck = torch.load(out + "/xVAPitch_7.pt", weights_only=False)
+    assert list(ck) == ["model", "optimizer", "scaler", "step", "epoch", "lr", "date", "avg_disc_loss_per_epoch", "avg_disc_loss_per_epoch_deltas",
+                        "training_stage"]
+    assert ck["step"] == 7 and ck["training_stage"] == 1 and len(ck["optimizer"]) == 2
+    assert ck["lr"] < 0.000175                                              # ExponentialLR stepped at the epoch roll-overs
+    assert any(k.startswith("waveform_decoder.") for k in ck["model"]) and any(k.startswith("disc.nets.0.") for k in ck["model"])
+    st0 = ck["optimizer"][0]["state"]
+    assert len(st0) > 100 and set(next(iter(st0.values()))) == {"step", "exp_avg", "exp_avg_sq"}
+    assert torch.load(out + "/voice_x.pt", weights_only=False)["emb_l.weight"].dtype == torch.float16
+    meta = json.load(open(out + "/voice_x.json"))
+    assert meta["modelType"] == "xVAPitch" and len(meta["games"][0]["base_speaker_emb"]) == 512
+    assert json.load(open(out + "/graphs.json"))["stages"]["1"]["loss"]
+    # ---- resume: not a new voice, steps continue, weights and moments are the checkpoint's
+    tr2 = _xv_trainer(_mm(), _WS(), data["output_path"], "voice_x")
+    asyncio.run(tr2.start(dict(data, max_iterations=1), gpus=[0]))
+    assert tr2.total_steps_done == 8 and "New voice" not in "\n".join(tr2.training_log[-12:])
+    assert tr2.optimizer[0].step_count == ck["optimizer"][0]["state"][0]["step"] + 1
+    tr3 = _xv_trainer(_mm(), _WS(), data["output_path"], "voice_x")
+    tr3.dataset_input, tr3.dataset_id, tr3.dataset_output, tr3.batch_size, tr3.lang = ds, "voice_x", out, 400, "en"
+    tr3.backup_model_every_x_ckpt, tr3.backup_model_counter, tr3.checkpoint, tr3.workers, tr3.learning_rate = 2, 0, None, 0, 0.000175
+    tr3.save_step, tr3.max_iterations, tr3.priors_path, tr3.force_stage = 4, None, None, None
+    asyncio.run(tr3.init())
+    sd = tr3.model_state_dict()
+    for k in ("emb_l.weight", "flow.flows.1.enc.in_layers.0.weight_v", "waveform_decoder.ups.1.weight_v", "disc.nets.2.convs.1.weight_g"):
+        assert torch.equal(sd[k].cpu(), ck["model"][k]), k
+    i_dec = [k for k, _ in tr3.optimizer[0].order()].index("waveform_decoder.ups.1.weight_v")
+    m_view = tr3.optimizer[0]._state_views()["waveform_decoder.ups.1.weight_v"][0]
+    assert torch.equal(m_view.cpu(), ck["optimizer"][0]["state"][i_dec]["exp_avg"])
+    # ---- handleTrainer + ModelsManager (server.py's entry, python/xvapitch/xva_train.py:86-215)
+    mm4, ws4 = _mm(), _WS()
+    mm4.sync_init_model("xvapitch", websocket=ws4, gpus=[0])
+    t4 = mm4.models_bank["xvapitch"]
+    t4.compute, t4.model_kwargs, t4.allow_random_init = "fp32", dict(_XV_SMALL), True
+    asyncio.run(XT.handleTrainer(mm4, dict(data, max_iterations=1, checkpoint="[base]"), ws4, [0]))
+    assert t4.total_steps_done == 8 and t4.ckpt_path.endswith("xVAPitch_7.pt")      # the output directory's newest checkpoint wins over "[base]"
+
+
+def test_xvapitch_checkpoint_layout_is_the_references():
+    """Keys, shapes and the two optimisers' parameter orders of the trainer's model at the reference's own switches (--big 1 --pitch 1) against the
+    layout recorded from the reference's classes (tests/golden/xvapitch_checkpoint_layout.json, oracle/gen_xvapitch_checkpoint_layout.py); a
+    checkpoint rebuilt in that layout (seeded values) loads into the trainer and comes back out bit for bit."""
+    import tempfile
+    from xva_trainer_amd.xvapitch import xva_train as XT
+    lay = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "xvapitch_checkpoint_layout.json")))
+    tr = XT.xVAPitchTrainer(logging.getLogger("t"), False, [0], None)
+    tr.compute = "bf16"
+    tr.step = tr.init_model(torch.device("cuda:0"))
+    ac, dec, disc = tr.step.gen.acoustic, tr.step.gen.decoder, tr.step.disc
+    tr.optimizer = [XT.FlatGroupAdamW.for_generator(ac, dec, lr=0.000175), XT.FlatGroupAdamW.for_discriminator(disc, lr=0.0002)]
+    mine = tr.model_state_dict()
+    ref = {k: tuple(shape) for k, shape, _ in lay["state_dict"]}
+    assert set(mine) == set(ref), sorted(set(mine) ^ set(ref))[:10]
+    assert all(tuple(mine[k].shape) == ref[k] for k in ref), [k for k in ref if tuple(mine[k].shape) != ref[k]][:5]
+    assert [k for k, _ in tr.optimizer[0].order()] == lay["optimizer0_param_order"]
+    assert [k for k, _ in tr.optimizer[1].order()] == lay["optimizer1_param_order"]
+    gen = torch.Generator().manual_seed(5)
+    sd = {k: torch.randn(shape, generator=gen) * 0.01 for k, shape, _ in lay["state_dict"]}
+    for k in list(sd):
+        if k.endswith("weight_g"):
+            sd[k] = sd[k].abs() + 0.5
+    opt_sd = []
+    for order, lr in ((lay["optimizer0_param_order"], 0.00016), (lay["optimizer1_param_order"], 0.00016)):
+        state = {i: {"step": torch.tensor(7.0), "exp_avg": torch.randn(ref[k], generator=gen) * 1e-3, "exp_avg_sq": torch.rand(ref[k], generator=gen) * 1e-6}
+                 for i, k in enumerate(order)}
+        opt_sd.append({"state": state, "param_groups": [{"lr": lr, "betas": (0.8, 0.99), "eps": 1e-9, "weight_decay": 0.01, "params": list(range(len(order)))}]})
+    ck = {"model": dict(sd, avg_disc_loss_per_epoch=[[0.5], []], avg_disc_loss_per_epoch_deltas=[[], []]), "optimizer": opt_sd, "scaler": {}, "step": 1234,
+          "epoch": 3, "lr": 0.00016, "date": "x", "avg_disc_loss_per_epoch": [[0.5], []], "avg_disc_loss_per_epoch_deltas": [[], []], "training_stage": 2}
+    with tempfile.TemporaryDirectory() as d:
+        path = d + "/xVAPitch_1234.pt"
+        torch.save(ck, path)
+        tr.dataset_output = d
+        tr.training_log, tr.training_log_live_line = [], ""
+        epoch, steps, adl, _ = tr.load_checkpoint(path)
+    assert steps == 1234 and tr.training_stage == 2 and adl == [[0.5], []] and tr.optimizer[0].param_groups[0]["lr"] == 0.00016
+    back = tr.model_state_dict()
+    assert all(torch.equal(back[k].cpu(), sd[k]) for k in sd)
+    osd = tr.optimizer[0].state_dict()
+    i = lay["optimizer0_param_order"].index("posterior_encoder.pre.weight")          # held zero-padded to 520 bins, stored at the checkpoint's 513
+    assert torch.equal(osd["state"][i]["exp_avg"], opt_sd[0]["state"][i]["exp_avg"]) and tr.optimizer[0].step_count == 7

@@ -410,7 +410,7 @@ class SyntheticHifiLoader:
         return iter(self.items)
 
 
-def write_synthetic_dataset(path, n_items=8, seed=0, min_s=1.0, max_s=3.0, with_pitch=True, sr=22050):
+def write_synthetic_dataset(path, n_items=8, seed=0, min_s=1.0, max_s=3.0, with_pitch=True, sr=22050, with_se_embs=False):
     """A reference-layout dataset directory of synthetic clips (tests / smoke): metadata.csv, wavs/*.wav (int16) and, with_pitch,
     the `pitch/*.npy` cache in the reference's format ((1, n_frames) float32, zeros = unvoiced; data_function.py:525-560)."""
     rng = np.random.RandomState(seed)
@@ -431,6 +431,9 @@ def write_synthetic_dataset(path, n_items=8, seed=0, min_s=1.0, max_s=3.0, with_
             p = rng.randn(1, T).astype(np.float32)
             p[0, rng.rand(T) < 0.3] = 0.0
             np.save(os.path.join(path, "pitch", name + ".npy"), p)
+        if with_se_embs:                  # xVAPitch: the 512-d speaker embedding of each clip (python/xvapitch/get_dataset_emb.py reads se_embs/*.npy)
+            os.makedirs(os.path.join(path, "se_embs"), exist_ok=True)
+            np.save(os.path.join(path, "se_embs", name + ".npy"), (rng.randn(512) * 0.05 + np.linspace(-1, 1, 512)).astype(np.float32))
     with open(os.path.join(path, "metadata.csv"), "w", encoding="utf-8") as f:
         f.write("\n".join(lines) + "\n")
     return path

@@ -1,8 +1,8 @@
 """ModelsManager — the registry entry points server.py uses for the trainers (python/models_manager.py:115-128,152-163).
 
-Served here: the trainer keys of the accelerated path ("fastpitch1_1", "hifigan") and their inference wrappers
-("infer_fastpitch1_1", "infer_hifigan", python/models_manager.py:130-150); the 16 dataset tools and the xVAPitch trainer stay with
-the reference (`init_model` raises NotImplementedError here)."""
+Served here: the trainer keys of the accelerated path ("fastpitch1_1", "hifigan", "xvapitch": python/models_manager.py:105-128) and the
+FastPitch / HiFi-GAN inference wrappers ("infer_fastpitch1_1", "infer_hifigan", :130-150); the 16 dataset tools and xVAPitch inference
+("infer_xvapitch") stay with the reference (`init_model` / `load_model` raise NotImplementedError for them here)."""
 import os
 
 import torch
@@ -29,6 +29,9 @@ class ModelsManager(object):
         elif model_key == "hifigan":
             from .hifigan.xva_train import HiFiTrainer
             self.models_bank[model_key] = HiFiTrainer(self.logger, self.PROD, gpus, self, websocket=websocket)
+        elif model_key == "xvapitch":
+            from .xvapitch.xva_train import xVAPitchTrainer
+            self.models_bank[model_key] = xVAPitchTrainer(self.logger, self.PROD, gpus, self, websocket=websocket)
         else:
             raise NotImplementedError("trainer '%s' is not part of the accelerated path" % model_key)
         try:

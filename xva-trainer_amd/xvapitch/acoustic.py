@@ -167,6 +167,30 @@ class AcousticTrainPath:
                 out += [(v, v.grad) for v in m.p.values()]
         return out
 
+    def named_param_grads(self):
+        """[(reference state_dict key, parameter tensor as the module holds it, callable -> its current gradient or None)] in module order: what
+        an optimiser with per-parameter state and a torch-format state_dict needs (train_step.FlatGroupAdamW).  The posterior encoder's input
+        convolution is held zero-padded to a multiple of 4 bins (its key's checkpoint shape is narrower; see state_dict())."""
+        def conv(pre, c):
+            return [(pre + n, c.p[n], (lambda g=c.g[n]: g)) for n in c.p]
+
+        def wn(pre, w):
+            return [e for sub, c in w._named() for e in conv(pre + sub, c)]
+        out = [(k, v, (lambda v=v: v.grad)) for k, v in self.p.items()]
+        for pre, m in self._subs:
+            if isinstance(m, RelativePositionTransformer):
+                pd, gd = dict(m._named("p")), dict(m._named("g"))
+                dead = ("ffn_layers.%d." % (m.L - 1), "norm_layers_2.%d." % (m.L - 1)) if m.Co == 1 else ()
+                out += [(pre + k, pd[k], ((lambda: None) if (dead and k.startswith(dead)) else (lambda g=gd[k]: g))) for k in pd]
+            elif isinstance(m, PosteriorEncoder):
+                out += conv(pre + "pre.", m.pre) + wn(pre + "enc.", m.enc) + conv(pre + "proj.", m.proj)
+            elif isinstance(m, ResidualCouplingBlocks):
+                for i, f in enumerate(m.flows):
+                    out += conv("%sflows.%d.pre." % (pre, i), f.pre) + wn("%sflows.%d.enc." % (pre, i), f.enc) + conv("%sflows.%d.post." % (pre, i), f.post)
+            else:
+                out += [(pre + k, v, (lambda v=v: v.grad)) for k, v in m.p.items()]
+        return out
+
     def zero_grad(self):
         for v in self.p.values():
             v.grad = None

@@ -29,7 +29,6 @@ import math
 import os
 import time
 import traceback
-import types
 
 import numpy as np
 import torch
@@ -233,6 +232,7 @@ class xVAPitchTrainer(object):
         self.JUST_FINISHED_STAGE = self.END_OF_TRAINING = False
         self.training_stage = 1
         self.allow_random_init = False          # tests / benchmarks only
+        self.learning_rate = 0.000175
 
     # ---- logs the UI reads from disk (xva_train.py:259-271,469-510) ----
     def print_and_log(self, line=None, end="\n", flush=False, save_to_file=None):
@@ -334,8 +334,7 @@ class xVAPitchTrainer(object):
 
     def init_model(self, device):
         """xVAPitch(args) at the trainer's switches (`--big 1 --pitch 1 --pe_scaling 0.2`, xva_train.py:1098-1132,1421-1425; model.py:40-215)."""
-        kw = dict(n_vocab=N_SYMBOLS, num_languages=N_LANGUAGES, latent_size=256, embedded_language_dim=12, d_vector_dim=512, pitch=True, pe_scaling=0.2,
-                  dropout_p=0.1, sdp_dropout_p=0.5)
+        kw = dict(n_vocab=N_SYMBOLS, num_languages=N_LANGUAGES, latent_size=256, embedded_language_dim=12, d_vector_dim=512, pitch=True, pe_scaling=0.2)
         kw.update(self.model_kwargs)
         seg = kw.pop("spec_segment_size", 32)
         ac = AcousticTrainPath(device=device, compute=self.compute, **kw)
@@ -392,6 +391,14 @@ class xVAPitchTrainer(object):
             epoch, total_steps_done, adl, adld = self.load_checkpoint(ckpt_path)
         elif self.allow_random_init:
             epoch, total_steps_done, adl, adld = 0, 0, [[], []], [[], []]
+            gen = torch.Generator().manual_seed(1234)
+            for eng in (dec, disc):                      # tests / benchmarks: weight_v ~ N(0, 0.02), weight_g = the row norms (the engines start at zero)
+                sd = {k: torch.randn(shape, generator=gen) * 0.02 for k, (off, numel, shape) in eng.table.items()}
+                for k in list(sd):
+                    if k.endswith("weight_g"):
+                        v = sd[k[:-1] + "v"]
+                        sd[k] = v.reshape(v.size(0), -1).norm(dim=1).reshape(sd[k].shape)
+                eng.load_state_dict(sd)
         else:
             raise FileNotFoundError("xVAPitch checkpoint %s not found (the reference fine-tunes from its pretrained model, xva_train.py:247-250,321-324)" % ckpt_path)
         self.ckpt_path = str(ckpt_path)
@@ -480,28 +487,33 @@ class xVAPitchTrainer(object):
         Ty = y.size(2)
         pitch = torch.nn.functional.pad(batch["pitch_padded"], (0, max(0, Ty - batch["pitch_padded"].size(2))))[..., :Ty].contiguous()
         self.gam_num_frames += int(y_lengths.sum().item())
+        stepping = (self.accumulated_steps + 1) % self.gam == 0
         # ---- pass 0: generator (zero_grad at the start of each pass: :652-653) ----
         gp.zero_grad()
         out = step.generator_pass(batch["text_input"], batch["text_lengths"], y, y_lengths, waveform, batch["d_vectors"], batch["language_ids"],
-                                  pitch_padded=pitch, train=True)
+                                  pitch_padded=pitch)
         out["loss"].backward()
+        if stepping and not use_ft:                                                    # priors iteration: the vocoder and posterior are not trained (:724-726)
+            gp.acoustic.posterior_encoder.zero_grad()
+            gp.decoder.zero_grad()
+        if stepping and self.sync is not None:
+            self.sync.start_generator()                                                # the exchange runs under the discriminator pass
         loss_dict = {k: float(out[k].detach()) for k in ("loss", "loss_gen", "loss_kl", "loss_feat", "loss_mel", "loss_duration")}
         if "loss_pitch" in out:
             loss_dict["loss_pitch"] = float(out["loss_pitch"].detach())
         # ---- pass 1: discriminator on the cached (generated.detach(), real) segments ----
         step.disc.zero_grad()
         loss_disc = step.discriminator_pass(out["model_outputs"].detach(), out["waveform_seg"])
+        if stepping and self.sync is not None:
+            self.sync.start_discriminator()                                            # ... and this one under the generator group's update
         loss_dict["loss_disc"] = float(loss_disc)
         del out
         self.accumulated_steps += 1
         if self.accumulated_steps % self.gam == 0:
             self.accumulated_steps = 0
-            if not use_ft:                                                             # priors iteration: the vocoder and posterior are not trained (:724-726)
-                gp.acoustic.posterior_encoder.zero_grad()
-                gp.decoder.zero_grad()
-            if self.sync is not None:
-                self.sync.reduce()
-            for opt in self.optimizer:
+            for which, opt in zip(("gen", "disc"), self.optimizer):
+                if self.sync is not None:
+                    self.sync.finish(which)
                 opt.step()
             step_time = time.time() - self.step_start_time
             self.step_start_time = time.time()
