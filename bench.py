@@ -450,7 +450,7 @@ def spawn_ranks(n):
     os.execv(sys.executable, cmd)
 
 
-def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2):
+def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2, roofline=True, cpu_base=True):
     """One xVAPitch training iteration (BASELINE configs[4] on one GPU: linear spectrograms from the raw clips, generator pass fwd + bwd,
     discriminator pass fwd + bwd, the two AdamW updates;
     xva-trainer_amd/xvapitch/train_step.py) at the reference's model size (python/xvapitch/model.py:55-149) on a synthetic batch with random weights,
@@ -500,11 +500,68 @@ def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2):
         o, ld = iteration()
     torch.cuda.synchronize(dev)
     ms = (time.perf_counter() - t0) / iters * 1e3
-    return {"metric": "segment audio-samples/sec (xVAPitch iteration from raw clips: spectrograms + generator pass + discriminator pass + 2 x AdamW)", "value": B * SEG * 256 / ms * 1e3,
-            "unit": "audio-samples/s", "ms_per_step": ms, "steps": iters, "dtype": "bf16 (duration predictor, attention, LayerNorm, MAS, losses fp32)",
-            "config": {"workload": "xVAPitch (python/xvapitch/model.py:55-149 sizes) B=%d x %d symbols x %d spectrogram frames (513 bins), 8192-sample segments, --pitch 1"
-                                   % (B, Tt, Ty), "spectrogram_frames_per_s": float(y_lens.sum()) / ms * 1e3},
-            "loss": float(o["loss"]), "loss_disc": float(ld), "note": "parity-first path (tests/test_xvapitch_gpu.py), launch bound, not tuned; random weights"}
+    res = {"metric": "segment audio-samples/sec (xVAPitch iteration from raw clips: spectrograms + generator pass + discriminator pass + 2 x AdamW)", "value": B * SEG * 256 / ms * 1e3,
+           "unit": "audio-samples/s", "ms_per_step": ms, "steps": iters, "dtype": "bf16 (duration predictor, attention, LayerNorm, MAS, losses fp32)",
+           "config": {"workload": "xVAPitch (python/xvapitch/model.py:55-149 sizes) B=%d x %d symbols x %d spectrogram frames (513 bins), 8192-sample segments, --pitch 1"
+                                  % (B, Tt, Ty), "spectrogram_frames_per_s": float(y_lens.sum()) / ms * 1e3},
+           "loss": float(o["loss"]), "loss_disc": float(ld), "note": "parity-first path (tests/test_xvapitch_gpu.py), launch bound, not tuned; random weights"}
+    if roofline:
+        # dominant convolution / GEMM kernel family of one extra profiled iteration (every xva_gemm launch of the acoustic modules, the decoder and
+        # the discriminator; stream lanes off) against its own roof, and the whole iteration's algorithmic FLOPs / bytes over the timed iteration
+        r = gemm_roofline(lambda: iteration(), 1, "auto", 8000.0, "one extra profiled xVAPitch iteration (stream lanes off)")
+        ag = r["all_gemm"]
+        r["iteration"] = {"algorithmic_tflop_per_step": ag["tflops"] * ag["ms_per_step"] / 1e3, "algorithmic_gbytes_per_step": ag["algorithmic_gbytes_per_s"] * ag["ms_per_step"] / 1e3,
+                          "gemm_ms_per_step": ag["ms_per_step"], "mfma_frac_of_step": ag["tflops"] * ag["ms_per_step"] / ms / 2500.0,
+                          "hbm_frac_of_step": ag["algorithmic_gbytes_per_s"] * ag["ms_per_step"] / ms / 8000.0,
+                          "note": "GEMM launches are %.0f %% of the timed iteration: the rest is launch latency / torch glue (the path is launch bound)" % (100.0 * ag["ms_per_step"] / ms)}
+        res["roofline"] = r
+    if cpu_base:
+        res["cpu_baseline"] = xvapitch_cpu_baseline(ac, dec, D, tokens, x_lens, y_lens, wavs, wav_lens, dvec, lids, pitch, SEG)
+    return res
+
+
+def xvapitch_cpu_baseline(ac, dec, D, tokens, x_lens, y_lens, wavs, wav_lens, dvec, lids, pitch, SEG, Bc=4, threads=8):
+    """The CPU restatement of the same iteration (oracle/xvapitch.py + oracle/hifigan.py + oracle/mel.py: the checker of tests/, timed here as the
+    reference-algorithm baseline on this host's cores) on the first Bc items of the bench batch with the same weights: linear spectrograms, generator
+    pass + discriminator pass, forward + backward, fp32 torch-CPU (no optimiser: < 1 % of the CPU iteration)."""
+    import torch.nn.functional as F
+    from oracle import hifigan as ohg, mel as omel, xvapitch as oxv
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        cfg = {"latent": 192, "lang_dim": 4, "dvec": 512, "heads": 2, "te_layers": 10, "pe_layers": 16, "flow_layers": 4, "num_flows": 4}
+        cpu = lambda t: t[:Bc].detach().cpu()
+        leaves = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in ac.state_dict().items()}
+        dl = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+        ddl = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in D.state_dict().items()}
+        tk, xl, yl, ww, wl, dv, li, pp = (cpu(t) for t in (tokens, x_lens.cpu(), y_lens, wavs, wav_lens, dvec, lids, pitch))
+        Tyc, Ttc = int(yl.max()), int(xl.max())
+        tk, pp = tk[:, :Ttc], pp[:, :, :Tyc]
+        ww = F.pad(ww, (0, max(0, Tyc * 256 - ww.size(1))))[:, :Tyc * 256]
+        eps, noise = torch.randn(Bc, 192, Tyc), torch.randn(Bc, 2, Ttc)
+        ids = (torch.rand(Bc) * (yl - SEG + 1)).long()
+
+        def cpu_iteration():
+            t0 = time.perf_counter()
+            yy = torch.stack([F.pad(omel.linear_m3(ww[i, :int(wl[i])].unsqueeze(0))[0], (0, Tyc - (1 + int(wl[i]) // 256))) for i in range(Bc)])
+            o = oxv.acoustic_losses(leaves, tk, xl, yy, yl, dv, li, eps, noise, cfg, pitch_padded=pp)
+            g = F.normalize(dv).unsqueeze(-1)
+            wav_hat = ohg.vits_decoder(dl, oxv.segment(o["z"], ids, SEG), g)
+            seg = oxv.segment(ww.unsqueeze(1), ids * 256, SEG * 256)
+            loss_mel = F.l1_loss(omel.mel_m3(seg.squeeze(1)), omel.mel_m3(wav_hat.squeeze(1)), reduction="none").mean() * 45
+            rs, fr, gs, fg = ohg.vits_disc({k: v.detach() for k, v in ddl.items()}, seg, wav_hat)
+            loss = o["loss"] + loss_mel + ohg.generator_loss(gs) + ohg.feature_loss(fr, [[t.detach() for t in f] for f in fg])
+            loss.backward()
+            rs, fr, gs, fg = ohg.vits_disc(ddl, seg, wav_hat.detach())
+            ohg.discriminator_loss(rs, gs).backward()
+            return time.perf_counter() - t0
+        cpu_iteration()
+        s_ = min(cpu_iteration() for _ in range(2))
+    finally:
+        torch.set_num_threads(old_threads)
+    return {"value": Bc * SEG * 256 / s_, "unit": "audio-samples/s", "cores": threads, "kind": "port", "s_per_step": s_, "host_cpu_count": os.cpu_count(),
+            "sample": "first %d items of the bench batch (same weights): spectrograms + generator pass + discriminator pass, forward + backward, fp32 torch-CPU "
+                      "oracle; 1 warm-up + best of 2 at %d threads" % (Bc, threads)}
 
 
 def main():
@@ -620,7 +677,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_xvapitch:
         try:
             torch.cuda.empty_cache()
-            out["xvapitch_c5"] = xvapitch_c5_leg(dev)
+            out["xvapitch_c5"] = xvapitch_c5_leg(dev, roofline=not a.no_roofline, cpu_base=not a.no_cpu_baseline)
         except Exception as e:                               # an extra measurement: never at the price of the contract line
             out["xvapitch_c5"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

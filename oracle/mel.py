@@ -118,6 +118,14 @@ def mel_m3(y, sr=22050, n_fft=1024, hop=256, win=1024, n_mel=80, fmin=0.0, fmax=
     return torch.log(torch.clamp(torch.matmul(melb.to(S), S), min=1e-5))
 
 
+def linear_m3(y, n_fft=1024, hop=256, win=1024):
+    """xVAPitch's linear spectrogram, the posterior encoder's input (python/xvapitch/audio.py:138-181 TorchSTFT with use_mel=False: the same centred
+    STFT and clamp as mel_m3, no filterbank, no log).  y: (B, N) -> (B, 513, 1 + N // hop)."""
+    o = torch.stft(y, n_fft, hop, win, torch.hann_window(win), center=True, pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+    o = torch.view_as_real(o)
+    return torch.sqrt(torch.clamp(o[..., 0] ** 2 + o[..., 1] ** 2, min=1e-8))
+
+
 def synth_wave(n_samples, seed, sr=22050):
     """SURVEY.md §8d synthetic clip: gliding f0 100->300 Hz + 3 harmonics (-6 dB/oct) + noise, int16-quantised."""
     rng = np.random.RandomState(seed)

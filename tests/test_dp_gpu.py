@@ -88,7 +88,17 @@ def test_xvapitch_c5_sync_gradients_single_rank_rccl(golden_dir):
     try:
         step.sync_gradients()
         torch.cuda.synchronize()
+        after = {n + k: v.clone() for n, m in (("ac/", ac), ("dec/", dec), ("D/", D)) for k, v in m.grads().items()}
+        # the trainer's form: buckets on a side stream (decoder, then the acoustic modules group by group; the discriminator after its pass),
+        # the compute stream waiting for a group's buckets right before that group's optimiser step
+        from xva_trainer_amd.xvapitch.train_step import BucketedSync
+        bs = BucketedSync(step)
+        bs.start_generator(); bs.start_discriminator()
+        assert len(bs.pending["gen"]) >= 5 and len(bs.pending["disc"]) == 1
+        bs.finish("gen"); bs.finish("disc")
+        torch.cuda.synchronize()
+        after2 = {n + k: v for n, m in (("ac/", ac), ("dec/", dec), ("D/", D)) for k, v in m.grads().items()}
     finally:
         dist.destroy_process_group()
-    after = {n + k: v for n, m in (("ac/", ac), ("dec/", dec), ("D/", D)) for k, v in m.grads().items()}
     assert len(before) > 800 and all(torch.equal(before[k], after[k]) for k in before)
+    assert all(torch.equal(before[k], after2[k]) for k in before)
