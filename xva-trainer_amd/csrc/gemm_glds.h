@@ -1108,9 +1108,13 @@ template <int CIN> __device__ __forceinline__ int res_swz(int row) {
 
 // stride (1, 2, 4: HiFi-GAN's strided discriminator convs) = input rows per output row; rowpitch = elements between consecutive input
 // rows (> CIN for a grouped conv: the tile holds one group's channels); the problem's group index is the second batch level (z2).
+// minimum waves per SIMD the register allocation has to leave room for (narrow outputs: small accumulators, latency-bound workgroups)
+#ifndef XVA_CONV_RES_WAVES
+#define XVA_CONV_RES_WAVES(BN) ((BN) <= 32 ? 5 : ((BN) <= 64 ? 3 : 2))
+#endif
 constexpr int res_a_bytes(int cin, int stride) { return (((stride * 128 + RES_HALO) * cin * 2) + 1023) & ~1023; }
 template <int LAYOUT, int CIN, int BN, int WM, int WN>
-__global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, 2) void xva_conv_res_kernel(xva_gemm_params p, int vec_epi, int dstep, int stride,
+__global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, XVA_CONV_RES_WAVES(BN)) void xva_conv_res_kernel(xva_gemm_params p, int vec_epi, int dstep, int stride,
                                                                                        int64_t rowpitch) {
     constexpr int BM = 128;
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
