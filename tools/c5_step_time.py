@@ -76,6 +76,25 @@ print("xVAPitch C5 iteration, B=%d x (%d symbols, %d spectrogram frames), segmen
 print("  generator pass fwd + bwd %.1f ms | discriminator pass fwd + bwd %.1f ms | 2 x AdamW %.1f ms | iteration %.1f ms = %.0f k segment-samples / s, %.0f spectrogram frames / s (losses %.3f / %.3f)"
       % (acc[0], acc[1], acc[2], tot, B * SEG * 256 / tot, float(y_lens.sum()) / tot * 1e3, lg, ld))
 
+if os.environ.get("XVA_C5_GEMM_PROFILE", "0") != "0":
+    # every xva_gemm launch of one iteration with its own HIP event pair (csrc/core.hip xva_prof_*), by shape
+    import collections, csv
+    from xva_trainer_amd import _lib
+    _lib.lib.xva_prof_enable(1)
+    iteration(); torch.cuda.synchronize()
+    _lib.lib.xva_prof_enable(0)
+    os.makedirs("gpurun_out", exist_ok=True)
+    _lib.lib.xva_prof_dump(b"gpurun_out/c5_gemm_launches.csv")
+    rows = list(csv.DictReader(open("gpurun_out/c5_gemm_launches.csv")))
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for r in rows:
+        k = (r["variant"], r["M"], r["N"], r["K"], r["batch"], r["splitk"], r["bn"])
+        agg[k][0] += 1; agg[k][1] += float(r["ms"]); agg[k][2] += float(r["gflop"])
+    print("  xva_gemm: %d launches, %.2f ms" % (len(rows), sum(v[1] for v in agg.values())))
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+        print("  %s m%d M=%-6s N=%-5s K=%-6s batch=%-4s sk=%-3s bn=%-6s n=%-4d ms=%7.3f us/launch=%6.1f TF=%6.1f"
+              % (["NT", "NN", "TN"][int(k[0]) // 3], int(k[0]) % 3, k[1], k[2], k[3], k[4], k[5], k[6], v[0], v[1], v[1] / v[0] * 1e3, v[2] / v[1] if v[1] else 0))
+
 if os.environ.get("XVA_C5_CPU_BASELINE", "0") != "0":
     # The CPU restatement (oracle/: the checker of tests/, timed here as the reference-algorithm baseline on this host's cores) on the first
     # Bc items of the same batch, same weights: generator pass + discriminator pass, forward + backward, fp32 torch-CPU.

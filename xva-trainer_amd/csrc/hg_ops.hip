@@ -741,7 +741,9 @@ extern "C" int xva_hg_add_item_vec(void* seq, int dt, const float* vec, int B, i
 // weight_norm (old API, dim 0): w = g * v / ||v||  (torch.nn.utils.weight_norm; models.py:21-108)
 // v: (D0, inner) fp32 in the checkpoint layout; writes the effective weight in a GEMM layout given by an index map:
 //   kind 0 (Conv, v = (Cout, Cin_g, k)):       eff[o][j*Cin_g + i]              = w[o][i][j]         (tap-major)
-//   kind 2 (grouped Conv as dense, v = (Cout, Cin_g, k)): eff[o][j*Cin + (o / Cout_g)*Cin_g + i] = w[o][i][j], zero elsewhere (s = Cin, pconv = Cout_g)
+//   kind 2 (grouped Conv with few channels per group, v = (Cout, Cin_g, k)): the groups are taken S / Cin_g at a time as SUPER-GROUPS of S input
+//           channels, each a dense product over a block-diagonal weight: eff[o][j*S + ((o / Cout_g) % (S / Cin_g))*Cin_g + i] = w[o][i][j], zero
+//           elsewhere (s = S, pconv = Cout_g; S = Cin: one dense product over all groups)
 //   kind 1 (ConvTranspose, v = (Cin, Cout, k)): effF[phase][co][m*Cin + ci]      = w[ci][co][j0(phase) + m*s]   (forward, per phase)
 //                                               effB[ci][j*Cout + co]            = w[ci][co][j]                  (backward-data conv)
 // One block per dim-0 index.  norm[o] saved for the backward.
@@ -762,8 +764,8 @@ __device__ __forceinline__ void hg_weight_norm_fwd_body(const float* __restrict_
         float w = vo[idx] * sc;
         if (kind == 0) {
             hg_st(eff, (int64_t)o * inner + (int64_t)j * D1 + i1, dt, w);
-        } else if (kind == 2) {   // grouped conv as a dense block-diagonal weight: s = Cin (all groups), pconv = Cout per group; the rest stays zero
-            hg_st(eff, ((int64_t)o * k + j) * s + (int64_t)(o / pconv) * D1 + i1, dt, w);
+        } else if (kind == 2) {   // block-diagonal weight of a super-group of s input channels, pconv = Cout per group; the rest stays zero
+            hg_st(eff, ((int64_t)o * k + j) * s + (int64_t)((o / pconv) % (s / D1)) * D1 + i1, dt, w);
         } else {
             // o = ci, i1 = co ; forward phases: t_out = s*q + phi uses taps j = j0 + m*s with j0 = (phi + pconv) % s
             int ntap = k / s;
@@ -795,9 +797,9 @@ __device__ __forceinline__ void hg_weight_norm_bwd_body(const float* __restrict_
     __shared__ float sh[16];
     const int inner = D1 * k;
     const float* vo = v + (int64_t)o * inner;
-    // kind 2: dW is the gradient of the dense block-diagonal weight; only this row's own block is read (tap pitch s = Cin)
+    // kind 2: dW is the gradient of the block-diagonal super-group weight; only this row's own block is read (tap pitch s)
     const int tp = kind == 2 ? s : D1;
-    const float* dwo = kind == 2 ? dW + (int64_t)o * k * s + (int64_t)(o / pconv) * D1 : dW + (int64_t)o * inner;
+    const float* dwo = kind == 2 ? dW + (int64_t)o * k * s + (int64_t)((o / pconv) % (s / D1)) * D1 : dW + (int64_t)o * inner;
     if (!gparam) {                                    // plain weight: dv += dW in the checkpoint layout
         for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) dv[(int64_t)o * inner + idx] += dwo[(int64_t)(idx % k) * tp + idx / k];
         return;

@@ -67,7 +67,11 @@ struct Layer {
     int kind = LK_WN;
     int Cin = 0, Cout = 0, k = 1, s = 1, d = 1, P = 0, groups = 1;
     bool has_bias = true;   // LK_PLAIN only: conv_post of the VITS decoder has none
-    bool dense = false;     // grouped convolution run as ONE dense product over a block-diagonal effective weight (groups of 4 channels: VITS scale discriminator)
+    bool dense = false;     // grouped convolution with few channels per group (4: VITS scale discriminator) run in SUPER-GROUPS of dense_cin() input channels,
+                            // each a dense product over a block-diagonal effective weight (hg_ops.hip weight norm kind 2): MFMA-sized K segments at 16x
+                            // the group's flops instead of Cin / 4 x
+    int dense_cin() const { return Cin < 64 ? Cin : 64; }
+    int conv_groups() const { return dense ? Cin / dense_cin() : groups; }
     bool aux = false;       // not a sequence convolution (cond_layer: a (B, cond) x (cond, C) product): no effective-weight copy
     int64_t bias = -1, wg = -1, wv = -1, bu = -1, bv = -1;   // offsets (floats) in the flat parameter buffer
     // workspace byte offsets
@@ -77,7 +81,7 @@ struct Layer {
     int D0() const { return kind == LK_WNT ? Cin : Cout; }
     int D1() const { return kind == LK_WNT ? Cout : Cin / groups; }
     int64_t wnumel() const { return (int64_t)D0() * D1() * k; }
-    int64_t effnumel() const { return dense ? (int64_t)Cout * Cin * k : wnumel(); }
+    int64_t effnumel() const { return dense ? (int64_t)Cout * dense_cin() * k : wnumel(); }
 };
 
 struct Net {
@@ -164,7 +168,7 @@ struct GenNet : Net {
 };
 // vits: xVAPitch's VitsDiscriminator (python/xvapitch/model.py:1548-1640): nets.0 = ONE scale discriminator (weight norm; Conv1d 1->16 k15,
 // 16->64 / 64->256 / 256->1024 / 1024->1024 k41 s4 in groups of FOUR input channels, 1024->1024 k5, post 1024->1 k3), nets.1-5 = the period
-// discriminators of python/xvapitch/hifigan.py:301-367 (same as HiFi-GAN's).  The grouped layers run dense (Layer::dense).
+// discriminators of python/xvapitch/hifigan.py:301-367 (same as HiFi-GAN's).  The grouped layers run as dense super-groups (Layer::dense).
 struct DiscNet : Net {
     int mpd[NPER][6], msd[3][8];
     bool vits;
@@ -513,7 +517,7 @@ static int join_lanes(const Ctx* cs, int n) {
 
 ConvW cw(const Ctx& c, const Layer& l, const float* params, int pass = 0) {
     ConvW w; w.eff = c.W + l.eff[pass]; w.bias = l.bias >= 0 ? params + l.bias : c.F(c.pl.zbias); w.dweff = l.dweff[pass] >= 0 ? c.F(l.dweff[pass]) : nullptr;
-    w.Cin = l.Cin; w.Cout = l.Cout; w.k = l.k; w.s = l.s; w.d = l.d; w.P = l.P; w.groups = l.dense ? 1 : l.groups;
+    w.Cin = l.Cin; w.Cout = l.Cout; w.k = l.k; w.s = l.s; w.d = l.d; w.P = l.P; w.groups = l.conv_groups();
     return w;
 }
 ConvTW ctw(const Ctx& c, const Layer& l, const float* params) {
@@ -534,7 +538,7 @@ int prep_wn(const Ctx& c, const std::vector<Layer>& L, const float* params) {
         d.v = params + l.wv; d.g = l.kind == LK_PLAIN ? nullptr : params + l.wg; d.norm = c.F(l.norm[0]);   // g == null: effective weight = v
         d.eff = c.W + l.eff[0]; d.effB = l.effB >= 0 ? c.W + l.effB : nullptr;
         d.dt = c.dt; d.kind = l.kind == LK_WNT ? 1 : 0; d.D0 = l.D0(); d.D1 = l.D1(); d.k = l.k; d.s = l.s; d.pconv = l.P;
-        if (l.dense) { d.kind = 2; d.s = l.Cin; d.pconv = l.Cout / l.groups; }
+        if (l.dense) { d.kind = 2; d.s = l.dense_cin(); d.pconv = l.Cout / l.groups; }
         ds.push_back(d);
         if (l.eff32[0] >= 0 && c.dt != XVA_F32) {   // fp32 copy for the 1-channel direct kernels
             d.eff = c.W + l.eff32[0]; d.effB = nullptr; d.dt = XVA_F32; d.kind = 0;
@@ -643,7 +647,7 @@ int wn_backward(Ctx& c, const std::vector<Layer>& L, const float* P, float* G, c
         const bool plain = l.kind == LK_PLAIN;           // dv += dW re-laid out; no g
         d.dW = c.F(l.dweff[0]); d.v = P + l.wv; d.g = plain ? nullptr : P + l.wg; d.norm = c.F(l.norm[0]); d.dv = G + l.wv; d.dg = plain ? nullptr : G + l.wg;
         d.kind = l.kind == LK_WNT ? 1 : 0; d.D0 = l.D0(); d.D1 = l.D1(); d.k = l.k;
-        if (l.dense) { d.kind = 2; d.s = l.Cin; d.pconv = l.Cout / l.groups; }
+        if (l.dense) { d.kind = 2; d.s = l.dense_cin(); d.pconv = l.Cout / l.groups; }
         ds.push_back(d);
     }
     if (ds.empty()) return XVA_OK;
