@@ -465,6 +465,9 @@ int xva_kl_loss_bwd(const float* z_p, const float* m_p, const float* logs_p, con
                     float* d_logs_q, float* d_m_p, float* d_logs_p, int B, int H, int T, void* stream);
 /* Zero the rows of a time-major sequence outside [pad, pad + lens[b]) (`* x_mask` after a biased convolution). */
 int xva_seq_mask(void* x, int dt, int B, int Tp, int pad, int C, const int32_t* lens, void* stream);
+/* Per-item column sums of a time-major sequence (B, Tp, C): out[b * out_stride + c] += sum_t x[b][t][c] — the gradient of WN's conditioning
+ * term (python/xvapitch/wavenet.py:91-97), one launch for the batch. */
+int xva_seq_item_colsum(const void* x, int dt, float* out, int B, int Tp, int C, int64_t out_stride, void* stream);
 /* ResidualCouplingBlock with mean_only=True (python/xvapitch/model.py:1519-1535): out (B, Ch, T) = stats + x1 * mask (forward) or
  * (x1 - stats) * mask (reverse); stats = the masked `post` output as a time-major sequence (B, pad + T + pad, Ch). */
 int xva_coupling_mean_only(const void* stats, const float* x1, float* out, int dt, int B, int Ch, int T, int pad, const int32_t* lens, int reverse,

@@ -192,6 +192,9 @@ class AcousticTrainPath:
         return out
 
     def zero_grad(self):
+        if getattr(self, "_flat_g", None) is not None:                 # train_step.FlatGroupAdamW moved every gradient into one arena: one memset, and the
+            self._flat_g.zero_()                                       # leaf parameters keep their .grad views (autograd accumulates into them in place)
+            return
         for v in self.p.values():
             v.grad = None
         for _, m in self._subs:

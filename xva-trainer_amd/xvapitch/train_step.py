@@ -61,6 +61,7 @@ class _Adversarial(torch.autograd.Function):
         return (d_wav * g_gen).view(ctx.shape), None, None
 
 
+BACKWARD_BUCKETS = ("posterior_encoder", "flow", "duration_predictor", "pitch_predictor", "text_encoder", "pitch_emb", "emb_l")   # order the backward pass finishes them
 GEN_GROUP_ORDER = ("emb_l.", "text_encoder.", "duration_predictor.", "flow.", "posterior_encoder.", "waveform_decoder.", "pitch_predictor.", "pitch_emb.")
 
 
@@ -69,9 +70,9 @@ class FlatGroupAdamW:
     xVAPitch trainer, stepped by xva_adamw_step and (de)serialised in torch's own state_dict format over the REFERENCE's parameter order
     (make_optim chains emb_l, text_encoder, duration_predictor, flow, posterior_encoder, waveform_decoder, pitch_predictor, pitch_emb; the
     discriminator group is model.disc.parameters()), so `xVAPitch_*.pt` checkpoints carry optimiser states either trainer can resume from.
-    Entries are either named tensors of the acoustic modules (moments in ONE flat buffer with fixed offsets — a parameter keeps its moments
-    whatever the other parameters' gradients do; parameters without a gradient are not stepped, like torch) or a whole engine's flat parameter
-    buffer (waveform decoder, discriminator: one launch).  One step counter for the group (torch's per-parameter counters only differ for
+    Entries are either named tensors of the acoustic modules — moved, at the first step, with their gradients and moments into flat arenas
+    (_flatten): one launch over the parameters that have a gradient; the ones the loss never reaches sit in a tail that is not stepped, like
+    torch skips p.grad None — or a whole engine's flat parameter buffer (waveform decoder, discriminator: one launch each).  One step counter for the group (torch's per-parameter counters only differ for
     parameters that are never reached, and those have no state)."""
 
     def __init__(self, named, flats, lr, betas=(0.8, 0.99), eps=1e-9, weight_decay=0.01):
@@ -86,6 +87,8 @@ class FlatGroupAdamW:
             n += t.numel()
         self.m = torch.zeros(max(n, 1), device=dev)
         self.v = torch.zeros(max(n, 1), device=dev)
+        self.flat_p = self.flat_g = self.owner = None
+        self.n_live, self.bucket_slices = 0, {}
         self.fm = [torch.zeros_like(e.params) for _, e, _ in self.flats]
         self.fv = [torch.zeros_like(e.params) for _, e, _ in self.flats]
 
@@ -95,7 +98,9 @@ class FlatGroupAdamW:
         ent = [(k, t, g, ref_shapes[k]) for k, t, g in acoustic.named_param_grads()]
         rank = lambda k: next(i for i, pre in enumerate(GEN_GROUP_ORDER) if k.startswith(pre))
         ent.sort(key=lambda e: rank(e[0]))              # stable: module order inside a group
-        return cls(ent, [("waveform_decoder.", decoder, GEN_GROUP_ORDER.index("waveform_decoder."))], lr)
+        opt = cls(ent, [("waveform_decoder.", decoder, GEN_GROUP_ORDER.index("waveform_decoder."))], lr)
+        opt.owner = acoustic
+        return opt
 
     @classmethod
     def for_discriminator(cls, disc, lr):
@@ -116,28 +121,48 @@ class FlatGroupAdamW:
         _lib.check(_lib.lib.xva_adamw_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), self.step_count, h["lr"], h["betas"][0],
                                            h["betas"][1], h["eps"], h["weight_decay"], _lib.stream_ptr()), "xva_adamw_step")
 
+    def _flatten(self):
+        """First step: move the named parameters, their gradients and their moments into flat arenas — live parameters (the ones that have a
+        gradient now: the set is structural) first, bucket by bucket in the backward order BucketedSync sends them, the never-reached ones in a
+        tail the update does not cover — and re-point the modules' own tensors (`.data`) at the arena.  From here on the group is ONE
+        xva_adamw_step launch over [0, n_live), zero_grad is one memset, and a data-parallel bucket is a contiguous slice: no gather / scatter."""
+        ent = [(k, t, g, shp, g()) for k, t, g, shp in self.named]
+        bucket = lambda k: BACKWARD_BUCKETS.index(k.split(".")[0]) if k.split(".")[0] in BACKWARD_BUCKETS else len(BACKWARD_BUCKETS)
+        ent.sort(key=lambda e: (e[4] is None, bucket(e[0])))                     # stable inside a bucket
+        al = lambda c: (c + 15) // 16 * 16                                       # every tensor on a 64-byte boundary (GEMM operands want 16; the gaps stay zero)
+        n = sum(al(e[1].numel()) for e in ent)
+        dev = self.m.device
+        P, G = torch.empty(max(n, 1), device=dev), torch.zeros(max(n, 1), device=dev)
+        m, v = torch.zeros(max(n, 1), device=dev), torch.zeros(max(n, 1), device=dev)
+        old = {k: o for (k, _, _, _), o in zip(self.named, self.offs)}
+        offs, off, slices = [], 0, {}
+        with torch.no_grad():
+            for k, t, _, _, g in ent:
+                c = t.numel()
+                P[off:off + c].copy_(t.detach().reshape(-1))
+                m[off:off + c].copy_(self.m[old[k]:old[k] + c]); v[off:off + c].copy_(self.v[old[k]:old[k] + c])
+                t.data = P[off:off + c].view(t.shape)
+                if g is not None:
+                    G[off:off + c].copy_(g.detach().reshape(-1))
+                    g.data = G[off:off + c].view(g.shape)
+                    b = k.split(".")[0]
+                    slices[b] = (slices.get(b, (off, off))[0], off + c)
+                    self.n_live = off + c
+                offs.append(off)
+                off += al(c)
+        self.named = [e[:4] for e in ent]
+        self.offs, self.m, self.v, self.flat_p, self.flat_g, self.bucket_slices = offs, m, v, P, G, slices
+        if self.owner is not None:
+            self.owner._flat_g, self.owner._flat_buckets = G, slices
+
     def step(self):
         self.step_count += 1
-        live = [(i, t, g()) for i, (_, t, g, _) in enumerate(self.named)]
-        live = [(i, t, g) for i, t, g in live if g is not None]
-        if live:
-            ps = [t.detach() for _, t, _ in live]
-            sl = [slice(self.offs[i], self.offs[i] + t.numel()) for i, t, _ in live]
-            flat_p = torch.cat([t.reshape(-1) for t in ps])                      # gather -> ONE xva_adamw_step -> scatter (torch copies: plumbing)
-            flat_g = torch.cat([g.detach().reshape(-1) for _, _, g in live])
-            flat_m = torch.cat([self.m[s_] for s_ in sl])
-            flat_v = torch.cat([self.v[s_] for s_ in sl])
-            self._launch(flat_p, flat_g, flat_m, flat_v)
-            off = 0
-            views = []
-            for (i, t, _), s_ in zip(live, sl):
-                n = t.numel()
-                views.append(flat_p[off:off + n].view(t.shape))
-                self.m[s_] = flat_m[off:off + n]
-                self.v[s_] = flat_v[off:off + n]
-                off += n
-            with torch.no_grad():
-                torch._foreach_copy_(ps, views)
+        if self.named:
+            if self.flat_p is None:
+                self._flatten()
+            if self.n_live:
+                n = self.n_live
+                self._launch(self.flat_p[:n], self.flat_g[:n], self.m[:n], self.v[:n])
         for (pre, e, _), m, v in zip(self.flats, self.fm, self.fv):
             self._launch(e.params, e.grad, m, v)
 
@@ -231,10 +256,16 @@ class BucketedSync:
     def start_generator(self):
         ac, dec = self.step.gen.acoustic, self.step.gen.decoder
         self._launch("gen", [dec.grad])                                          # final first (the decoder is the head of the backward pass)
+        flat, slices = getattr(ac, "_flat_g", None), getattr(ac, "_flat_buckets", None)
+        if flat is not None:                                                     # after the first optimiser step: a bucket is a slice of the gradient arena
+            for name in list(BACKWARD_BUCKETS) + [n for n in slices if n not in BACKWARD_BUCKETS]:
+                if name in slices:
+                    self._launch("gen", [flat[slices[name][0]:slices[name][1]]])
+            return
         buckets = {}
         for k, _, g in ac.named_param_grads():
             buckets.setdefault(k.split(".")[0], []).append(g())
-        for name in ("posterior_encoder", "flow", "duration_predictor", "pitch_predictor", "text_encoder", "pitch_emb", "emb_l"):   # backward order
+        for name in BACKWARD_BUCKETS:
             if name in buckets:
                 self._launch("gen", buckets.pop(name))
         for rest in buckets.values():

@@ -28,6 +28,8 @@ lib.xva_wn_res_skip_bwd.restype = i32
 lib.xva_wn_res_skip_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
 lib.xva_seq_mask.restype = i32
 lib.xva_seq_mask.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+lib.xva_seq_item_colsum.restype = i32
+lib.xva_seq_item_colsum.argtypes = [vp, i32, vp, i32, i32, i32, i64, vp]
 lib.xva_coupling_mean_only.restype = i32
 lib.xva_coupling_mean_only.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]
 lib.xva_coupling_mean_only_bwd.restype = i32
@@ -225,9 +227,8 @@ class WN:
             _lib.check(lib.xva_wn_gate_bwd(C.c_void_p(self._a[i].view.data_ptr()), gl, 2 * H * self.L, C.c_void_p(d_acts.view.data_ptr()),
                                            C.c_void_p(d_a.view.data_ptr()), dt, B, d_out.Tp, H, _lib.stream_ptr()), "xva_wn_gate_bwd")
             if d_gc is not None:                                   # d(cond)[b] = sum over the item's rows of d_a (pad / dead rows carry zeros)
-                for b in range(B):
-                    _lib.check(lib.xva_hg_colsum(C.c_void_p(d_a.view[b].data_ptr()), dt, C.c_void_p(d_gc.data_ptr() + 4 * (b * 2 * H * self.L + i * 2 * H)),
-                                                 d_a.Tp, 2 * H, 1.0, _lib.stream_ptr()), "xva_hg_colsum")
+                _lib.check(lib.xva_seq_item_colsum(C.c_void_p(d_a.view.data_ptr()), dt, C.c_void_p(d_gc.data_ptr() + 4 * i * 2 * H), B, d_a.Tp, 2 * H,
+                                                   2 * H * self.L, _lib.stream_ptr()), "xva_seq_item_colsum")
             conv_bwd_weight(d_a, self._x[i], inl.dweff, inl.g["bias"], self.k, self.rate ** i, self.compute)
             # d_x (residual path, already masked by res_skip_bwd's first half when not last) += conv^T(d_a)
             if not last:
