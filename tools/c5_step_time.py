@@ -56,7 +56,10 @@ def iteration():
     t0 = time.perf_counter()
     o = step.generator_pass(tokens, x_lens, y, y_lens, wav, dvec, lids, pitch_padded=pitch)
     o["loss"].backward()
+    t1a = time.perf_counter()
     torch.cuda.synchronize(); t1 = time.perf_counter()
+    global host_wait
+    host_wait = (t1 - t1a) * 1e3                                  # how long the host waits for the GPU after issuing the pass: ~0 = issue-bound
     ld = step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
     torch.cuda.synchronize(); t2 = time.perf_counter()
     step.optimizer_step(lr=1e-6, lr_disc=1e-6)
@@ -72,6 +75,7 @@ for _ in range(N):
     a, b, lg, ld, c_ = iteration()
     acc[0] += a / N; acc[1] += b / N; acc[2] += c_ / N
 tot = acc[0] + acc[1] + acc[2]
+print("  (generator pass: the host waited %.1f ms for the GPU after issuing the last launch)" % host_wait)
 print("xVAPitch C5 iteration, B=%d x (%d symbols, %d spectrogram frames), segment %d samples, decoder / discriminator %s, WaveNet stacks %s, transformer / SDP fp32:" % (B, Tt, Ty, SEG * 256, dt, adt))
 print("  generator pass fwd + bwd %.1f ms | discriminator pass fwd + bwd %.1f ms | 2 x AdamW %.1f ms | iteration %.1f ms = %.0f k segment-samples / s, %.0f spectrogram frames / s (losses %.3f / %.3f)"
       % (acc[0], acc[1], acc[2], tot, B * SEG * 256 / tot, float(y_lens.sum()) / tot * 1e3, lg, ld))

@@ -51,6 +51,19 @@ P = _lib.ptr
 ST = _lib.stream_ptr
 
 
+
+def _gbuf(p):
+    """Where a backward accumulates parameter p's gradient: (buffer the kernel adds into, what autograd is handed).  A leaf parameter that
+    already has a contiguous .grad — always, once train_step.FlatGroupAdamW has moved the gradients into its flat arena (zero_grad zeroes the
+    arena, the .grad views stay) — takes the sum directly and autograd gets None: no zero-filled temporary, no add launch per parameter.
+    Otherwise (first iteration, computed weights, torch.autograd.grad) a fresh zero tensor that autograd accumulates as usual."""
+    g = p.grad if p.is_leaf else None
+    if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+        return g, None
+    z = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+    return z, z
+
+
 class DwConv(torch.autograd.Function):
     """y = depthwise dilated Conv1d(x * x_mask) ('same' zero padding); x (B, T, C), w (C, 1, k), b (C)."""
     @staticmethod
@@ -58,16 +71,17 @@ class DwConv(torch.autograd.Function):
         x = x.contiguous(); B, T, Cc = x.shape; k = w.size(-1)
         y = torch.empty_like(x)
         _lib.check(lib.xva_dwconv_fwd(P(x), P(w.contiguous()), P(b), P(y), P(lens), B, T, Cc, k, d, ST()), "xva_dwconv_fwd")
-        ctx.save_for_backward(x, w, lens); ctx.d = d
+        ctx.save_for_backward(x, w, lens); ctx.d = d; ctx.params = (w, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, lens = ctx.saved_tensors
         B, T, Cc = x.shape; k = w.size(-1)
-        dx = torch.empty_like(x); dw = torch.zeros_like(w); db = torch.zeros(Cc, device=x.device)
+        dx = torch.empty_like(x)
+        (dw, rw), (db, rb) = _gbuf(ctx.params[0]), _gbuf(ctx.params[1])
         _lib.check(lib.xva_dwconv_bwd(P(dy.contiguous()), P(x), P(w.contiguous()), P(dx), P(dw), P(db), P(lens), B, T, Cc, k, ctx.d, ST()), "xva_dwconv_bwd")
-        return dx, dw, db, None, None
+        return dx, rw, rb, None, None
 
 
 class Gelu(torch.autograd.Function):
@@ -93,16 +107,17 @@ class LayerNormRows(torch.autograd.Function):
         x = x.contiguous(); rows, Cc = x.numel() // x.size(-1), x.size(-1)
         y = torch.empty_like(x); mean = torch.empty(rows, device=x.device); rstd = torch.empty(rows, device=x.device)
         _lib.check(lib.xva_ln_rows_fwd(P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), rows, Cc, 1e-5, ST()), "xva_ln_rows_fwd")
-        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.save_for_backward(x, gamma, mean, rstd); ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         rows, Cc = x.numel() // x.size(-1), x.size(-1)
-        dx = torch.empty_like(x); dg = torch.zeros_like(gamma); db = torch.zeros_like(gamma)
+        dx = torch.empty_like(x)
+        (dg, rg), (db, rb) = _gbuf(ctx.params[0]), _gbuf(ctx.params[1])
         _lib.check(lib.xva_ln_rows_bwd(P(dy.contiguous()), P(x), P(mean), P(rstd), P(gamma), P(dx), P(dg), P(db), rows, Cc, ST()), "xva_ln_rows_bwd")
-        return dx, dg, db
+        return dx, rg, rb
 
 
 class Conv1x1(torch.autograd.Function):
@@ -113,7 +128,7 @@ class Conv1x1(torch.autograd.Function):
         w2 = w.reshape(Cout, Cin).contiguous()
         y = torch.empty(*x.shape[:-1], Cout, device=x.device)
         _lib.gemm(x, w2, y, rows, Cout, Cin, Cin, Cin, Cout, layout=_lib.GEMM_NT, compute=0, bias=b)
-        ctx.save_for_backward(x, w2); ctx.wshape = tuple(w.shape)
+        ctx.save_for_backward(x, w2); ctx.wshape = tuple(w.shape); ctx.params = (w, b)
         return y
 
     @staticmethod
@@ -122,10 +137,10 @@ class Conv1x1(torch.autograd.Function):
         dy = dy.contiguous(); Cin = x.size(-1); rows = x.numel() // Cin; Cout = w2.size(0)
         dx = torch.empty_like(x)
         _lib.gemm(dy, w2, dx, rows, Cin, Cout, Cout, Cin, Cin, layout=_lib.GEMM_NN, compute=0)
-        dw = torch.zeros(Cout, Cin, device=x.device); db = torch.zeros(Cout, device=x.device)
+        (dw, rw), (db, rb) = _gbuf(ctx.params[0]), _gbuf(ctx.params[1])
         _lib.gemm(dy, x, dw, Cout, Cin, rows, Cout, Cin, Cin, layout=_lib.GEMM_TN, compute=0, accumulate=True, splitk=0)
         _lib.check(lib.xva_hg_colsum(P(dy), 0, P(db), rows, Cout, 1.0, ST()), "xva_hg_colsum")
-        return dx, dw.view(ctx.wshape), db
+        return dx, (rw.view(ctx.wshape) if rw is not None else None), rb
 
 
 class Mask(torch.autograd.Function):

@@ -290,6 +290,8 @@ class XVAPitchStep:
 
     def generator_pass(self, tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=None, eps=None, noise=None, slice_ids=None,
                        train=False):
+        from .wn import seq_arena_begin
+        seq_arena_begin(y.device)          # a new iteration: the previous one's sequences are dead, their slab is zeroed in one memset and reused
         out = self.gen(tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=pitch_padded, eps=eps, noise=noise, slice_ids=slice_ids)
         loss_gen, loss_feat = _Adversarial.apply(out["model_outputs"], out["waveform_seg"], self.disc)          # model.py:313-315, losses.py:195-196
         out.update({"loss_gen": loss_gen, "loss_feat": loss_feat, "loss": out["loss"] + loss_gen + loss_feat})  # losses.py:300

@@ -42,10 +42,65 @@ lib.xva_hg_weight_norm_fwd.restype = i32
 lib.xva_hg_weight_norm_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
 lib.xva_hg_weight_norm_bwd.restype = i32
 lib.xva_hg_weight_norm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+
+
+class _WnDesc(C.Structure):
+    """csrc/hg_wn.h xva_wn_desc: one weight-normed tensor of a batched xva_hg_weight_norm_batch launch"""
+    _fields_ = [("v", vp), ("g", vp), ("norm", vp), ("eff", vp), ("effB", vp), ("dW", vp), ("dv", vp), ("dg", vp),
+                ("dt", i32), ("kind", i32), ("D0", i32), ("D1", i32), ("k", i32), ("s", i32), ("pconv", i32), ("block0", i32)]
+
+
+lib.xva_hg_weight_norm_batch.restype = i32
+lib.xva_hg_weight_norm_batch.argtypes = [C.POINTER(_WnDesc), i32, i32, vp]
 lib.xva_hg_colsum.restype = i32
 lib.xva_hg_colsum.argtypes = [vp, i32, vp, i64, i32, f32, vp]
 
 PAD, GUARD = 8, 32
+
+
+class _SeqArena:
+    """One zeroed slab the sequences of a training iteration are carved from.  A Seq is born all-zero (structural pad rows, guard rows, the
+    accumulators of the residual / skip paths rely on it); as torch.zeros each costs an allocation and a fill launch, ~500 per xVAPitch iteration.
+    seq_arena_begin() — called by XVAPitchStep.generator_pass at the start of an iteration, when every sequence of the previous one is dead
+    (its autograd graph has been consumed) — zeroes the part of the slab the last iteration used in ONE memset and starts handing it out
+    again.  Without that call (module-level use, the tests) every Seq is its own torch.zeros, as before."""
+    slab, cap, used, want, active = None, 0, 0, 0, False
+
+
+_ARENA = _SeqArena()
+
+
+def _dev(device):
+    d = torch.device(device)
+    return torch.device(d.type, torch.cuda.current_device()) if d.type == "cuda" and d.index is None else d
+
+
+def seq_arena_begin(device):
+    a = _ARENA
+    need = max(a.want, a.used)
+    device = _dev(device)
+    if a.slab is None or need > a.cap or a.slab.device != device:
+        a.cap = int(need * 1.25) + (64 << 20)
+        a.slab = torch.zeros(a.cap, device=device, dtype=torch.uint8)
+    elif a.used:
+        a.slab[:a.used].zero_()
+    a.used, a.want, a.active = 0, 0, True
+
+
+def seq_arena_end():
+    """stop carving (sequences created from here on own their storage; the ones handed out stay valid until the next seq_arena_begin)"""
+    _ARENA.active = False
+
+
+def _zeros(rows, Cc, device, dtype):
+    a = _ARENA
+    n = (rows * Cc * (2 if dtype == torch.bfloat16 else 4) + 255) // 256 * 256
+    a.want += n
+    if a.active and a.used + n <= a.cap and a.slab.device == _dev(device):
+        t = a.slab[a.used:a.used + n].view(dtype)[:rows * Cc].view(rows, Cc)
+        a.used += n
+        return t
+    return torch.zeros(rows, Cc, device=device, dtype=dtype)
 
 
 class Seq:
@@ -53,7 +108,7 @@ class Seq:
 
     def __init__(self, B, T, Cc, device, dtype):
         self.B, self.T, self.C, self.Tp = B, T, Cc, T + 2 * PAD
-        self.store = torch.zeros(2 * GUARD + B * self.Tp, Cc, device=device, dtype=dtype)
+        self.store = _zeros(2 * GUARD + B * self.Tp, Cc, device, dtype)
         self.view = self.store[GUARD:GUARD + B * self.Tp].view(B, self.Tp, Cc)
         self.dt = 1 if dtype == torch.bfloat16 else 0
 
@@ -132,6 +187,27 @@ class WN:
         self.in_layers = [_WNConv(H, 2 * H, kernel_size, dilation_rate ** i, self.device, self.dtype, gen) for i in range(num_layers)]
         self.res_skip_layers = [_WNConv(H, 2 * H if i < num_layers - 1 else H, 1, 1, self.device, self.dtype, gen) for i in range(num_layers)]
         self.cond_layer = _WNConv(c_in_channels, 2 * H * num_layers, 1, 1, self.device, torch.float32, gen) if c_in_channels > 0 else None
+        # the effective-weight gradients of all the stack's convolutions in ONE buffer (one memset per backward), and the weight-norm
+        # reparametrisations (forward and backward) as one batched launch over the stack (csrc/hg_ops.hip xva_hg_weight_norm_batch)
+        convs = [c for _, c in self._named()]
+        self._dweff = torch.zeros(sum((c.dweff.numel() + 63) // 64 * 64 for c in convs), device=self.device)
+        off = 0
+        for c in convs:
+            c.dweff = self._dweff[off:off + c.dweff.numel()].view(c.dweff.shape)
+            off += (c.dweff.numel() + 63) // 64 * 64
+        self._descs = None
+
+    def _wn_batch(self, backward):
+        convs = [c for _, c in self._named()]
+        key = tuple(t.data_ptr() for c in (convs[0], convs[-1]) for t in (c.p["weight_v"], c.g["weight_v"]))
+        if self._descs is None or self._descs[0] != key:                      # the parameters move once (FlatGroupAdamW's arenas): rebuild then
+            arr = (_WnDesc * len(convs))()
+            for d, c in zip(arr, convs):
+                d.v, d.g, d.norm, d.eff, d.effB = c.p["weight_v"].data_ptr(), c.p["weight_g"].data_ptr(), c.norm.data_ptr(), c.eff.data_ptr(), None
+                d.dW, d.dv, d.dg = c.dweff.data_ptr(), c.g["weight_v"].data_ptr(), c.g["weight_g"].data_ptr()
+                d.dt, d.kind, d.D0, d.D1, d.k, d.s, d.pconv, d.block0 = c.dt, 0, c.Cout, c.Cin, c.k, 1, 0, 0
+            self._descs = (key, arr, len(convs))
+        _lib.check(lib.xva_hg_weight_norm_batch(self._descs[1], self._descs[2], int(backward), _lib.stream_ptr()), "xva_hg_weight_norm_batch")
 
     # ---- reference state_dict (wavenet.py:62-82) ----
     def _named(self):
@@ -167,8 +243,7 @@ class WN:
     def forward_seq(self, x, lens, g=None):
         """x: Seq (B, Tp, H) already masked; lens (B) int32; g (B, c_in) fp32 or None.  Returns the output Seq; keeps what backward needs."""
         B, H = x.B, self.H
-        for _, c in self._named():
-            c.reparam()
+        self._wn_batch(False)
         gc = None
         if self.cond_layer is not None:
             if g is None:
@@ -241,9 +316,8 @@ class WN:
             _lib.check(lib.xva_hg_colsum(_lib.ptr(d_gc), 0, _lib.ptr(cl.g["bias"]), B, 2 * H * self.L, 1.0, _lib.stream_ptr()), "xva_hg_colsum")
             d_g = torch.empty(B, self.c_in, device=self.device)
             _lib.gemm(d_gc, cl.eff, d_g, B, self.c_in, 2 * H * self.L, 2 * H * self.L, self.c_in, self.c_in, layout=_lib.GEMM_NN, compute=0)
-        for _, c in self._named():
-            c.reparam_bwd()
-            c.dweff.zero_()
+        self._wn_batch(True)
+        self._dweff.zero_()
         return d_x, d_g
 
     # ---- reference interface: x (B, H, T), x_mask (B, 1, T) from lengths, g (B, c_in, 1) ----
