@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--no-hifigan", action="store_true", help="skip the HiFi-GAN audio-samples/s leg")
     ap.add_argument("--no-xvapitch", action="store_true", help="skip the xVAPitch (BASELINE configs[4]) iteration timing")
     ap.add_argument("--no-fp32-parity", action="store_true", help="skip the fp32 parity-mode FastPitch timing")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="no GPU: run the multi-rank plumbing of this script (rank environment, process group, per-rank shards, the bucketed gradient "
+                         "all-reduce over the engine's real bucket ranges, barrier + max-over-ranks timing, whole-job aggregation, the JSON line) on "
+                         "CPU over gloo with a stand-in for the compute; the line carries \"dry_run\": true and is NOT a measurement")
     ap.add_argument("--hg-batch", type=int, default=64)
     ap.add_argument("--hg-steps", type=int, default=0, help="timed HiFi-GAN steps (default: min(steps, 10))")
     return ap.parse_args()
@@ -440,7 +444,7 @@ def spawn_ranks(n):
     over RCCL).  Fails loudly when the node has fewer than N devices."""
     import socket
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and "--dry-run-gloo" not in sys.argv:
         sys.exit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (n, have))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -564,6 +568,62 @@ def xvapitch_cpu_baseline(ac, dec, D, tokens, x_lens, y_lens, wavs, wav_lens, dv
                       "oracle; 1 warm-up + best of 2 at %d threads" % (Bc, threads)}
 
 
+def dry_run_gloo(a, rank, world):
+    """--dry-run-gloo: the N-rank skeleton of main() on CPU — same shards (seed 1234 + rank), same bucket ranges (csrc xva_fp_bucket_range),
+    same barrier / MAX-over-ranks / SUM-of-units arithmetic and the same JSON contract — with gloo for RCCL and `grads = rank + 1` standing in
+    for forward + backward.  Every rank checks the reduced gradient (sum over ranks of rank + 1 in every trainable bucket)."""
+    import torch.distributed as dist
+    from xva_trainer_amd import synthetic
+    from xva_trainer_amd.fastpitch import engine as E
+    from xva_trainer_amd.fastpitch.dp import allreduce_flat_buckets, bucket_ranges, buckets_for_stage
+    if world > 1:
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == world
+    shard = synthetic.fastpitch_batch(a.batch, a.t_text, a.t_mel, 1234 + rank)
+    frames_per_step = int(torch.as_tensor(shard["mel_lens"]).sum())
+    ranges = [bucket_ranges()[i] for i in buckets_for_stage(a.stage)]
+    total = max(e for _, e in bucket_ranges())
+    grads = torch.zeros(total)
+    expect = float(sum(r + 1 for r in range(world)))
+
+    def step():
+        grads.zero_()
+        for b, e in ranges:
+            grads[b:e] = rank + 1.0
+        if world > 1:
+            allreduce_flat_buckets(grads, ranges)
+        for b, e in ranges:
+            if e > b and not (grads[b].item() == expect and grads[e - 1].item() == expect):
+                sys.exit("bench.py --dry-run-gloo: rank %d bucket [%d, %d) reduced to %g / %g, expected %g" % (rank, b, e, grads[b], grads[e - 1], expect))
+
+    barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    total_frames = float(frames_per_step)
+    if world > 1:
+        t = torch.tensor([dt, float(frames_per_step)], dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, total_frames = tmax[0].item(), t[1].item()
+    if rank == 0:
+        print(json.dumps({"metric": "mel-frames/sec (FastPitch1.1 train step) — DRY RUN of the multi-rank plumbing on CPU / gloo, no compute",
+                          "value": total_frames * a.steps / dt, "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "stand-in step: bucketed gloo all-reduce of the stage-%d gradient ranges" % a.stage,
+                                     "global_batch": a.batch * world, "per_gpu_frames_per_step": frames_per_step, "parallelism": "dp%d" % world,
+                                     "buckets": len(ranges), "bucket_floats": int(sum(e - b for b, e in ranges))}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -573,6 +633,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
         sys.exit("bench.py: --gpus %d does not match the launcher's WORLD_SIZE %d" % (a.gpus, world))
+    if a.dry_run_gloo:
+        return dry_run_gloo(a, rank, world)
     if torch.cuda.device_count() <= local_rank:
         sys.exit("bench.py: rank %d needs cuda:%d but only %d GPU(s) are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)

@@ -248,6 +248,11 @@ int xva_event_destroy(void* event);
 int xva_event_record(void* event, void* stream);
 int xva_stream_wait_event(void* stream, void* event);
 
+/* The denominators of FastPitchLoss's masked means (python/fastpitch1_1/loss_function.py:70-73,98-100) from the targets alone: den2[0] =
+ * #(mel_tgt != 0) (stages 3 / 4, else 0), den2[1] = sum of the token lengths.  Data-parallel ranks all-reduce these two floats UNDER the forward
+ * pass and overwrite acc[1] / acc[3] of xva_fp_loss_partials with the global values before xva_fp_loss_grads: the losses a rank then reports are
+ * its share of the global means (their SUM over ranks is the global loss — a reduction that is off the critical path). */
+int xva_fp_loss_denominators(int stage, const float* mel_tgt, const int32_t* in_lens, float* den2, int B, int Tt, int Tm, void* stream);
 /* FastPitchLoss in two phases (so data-parallel ranks can all-reduce `acc` in between: global normalisation).
  * mel_out / d_mel are activation-dtype tensors (dt); the token-level predictions and targets are fp32. */
 int xva_fp_loss_partials(int stage, int dt, const void* mel_out, const float* mel_tgt, const float* pitch_pred, const float* pitch_tgt,

@@ -139,3 +139,28 @@ def test_xvapitch_gradient_mean_world2(tmp_path):
     want = (r0["before"][2] + r1["before"][2]) / 2
     for r in (r0, r1):
         assert torch.allclose(r["after"][2][:, :, :2], want[:, :, :2]) and torch.equal(r["after"][2][:, :, 2], r["before"][2][:, :, 2])
+
+
+def test_bench_two_rank_dry_run_over_gloo():
+    """`python bench.py --gpus 2 --dry-run-gloo`: the script re-executes itself under torch.distributed.run (127.0.0.1 rendezvous), two CPU ranks
+    build their own shard (seed 1234 + rank), all-reduce the stage-3 gradient bucket ranges of the engine over gloo (each rank checks the sum),
+    and rank 0 prints ONE contract line whose `value` is the whole job's frames (both shards) over the slowest rank's time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-gloo", "--steps", "2", "--warmup", "1"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 64 and out["config"]["buckets"] >= 12
+    per_rank = out["config"]["per_gpu_frames_per_step"]
+    # whole-job aggregate: both ranks' frames (their shards differ by seed, so within a few percent of 2 x rank 0's) over the max-over-ranks time
+    total = out["value"] * out["ms_per_step"] / 1e3
+    assert 1.8 * per_rank < total < 2.2 * per_rank, (total, per_rank)

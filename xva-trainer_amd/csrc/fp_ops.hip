@@ -795,6 +795,34 @@ extern "C" int xva_fp_loss_partials(int stage, int dt, const void* mel_out, cons
     return XVA_OK;
 }
 
+// The two DENOMINATORS of the masked means from the targets alone — den[0] = #(mel_tgt != 0), den[1] = sum of the token lengths — so that
+// data-parallel ranks can all-reduce them while the forward pass runs: the gradients need only the global denominators (the numerators are
+// reporting), which takes the 8-float exchange of xva_fp_loss_partials off the forward -> backward critical path.
+__global__ __launch_bounds__(256) void loss_den_kernel(const float* __restrict__ mel_tgt, const int* __restrict__ lens, float* __restrict__ den, int64_t nmel,
+                                                       int B, int Tt) {
+    __shared__ float sh[16];
+    float c = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nmel; i += (int64_t)gridDim.x * blockDim.x) c += mel_tgt[i] != 0.f ? 1.f : 0.f;
+    c = xva_block_sum(c, sh);
+    if (threadIdx.x == 0 && c > 0.f) atomicAdd(den + 0, c);
+    if (blockIdx.x == 0) {
+        float t = 0.f;
+        for (int b = threadIdx.x; b < B; b += blockDim.x) t += (float)min(max(lens[b], 0), Tt + 1);
+        t = xva_block_sum(t, sh);
+        if (threadIdx.x == 0) atomicAdd(den + 1, t);
+    }
+}
+extern "C" int xva_fp_loss_denominators(int stage, const float* mel_tgt, const int32_t* in_lens, float* den2, int B, int Tt, int Tm, void* stream) {
+    XVA_CHECK_ARG(den2 && in_lens && (mel_tgt || stage == 2), "loss_denominators: null");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(den2, 0, 2 * sizeof(float), st) != hipSuccess) { xva_set_error("loss_denominators: memset failed"); return XVA_ERR_HIP; }
+    const int64_t nmel = (stage == 3 || stage == 4) ? (int64_t)B * 80 * Tm : 0;
+    int grid = (int)((nmel + 256 * 16 - 1) / (256 * 16)); if (grid < 1) grid = 1; if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(loss_den_kernel, dim3(grid), dim3(256), 0, st, mel_tgt, in_lens, den2, nmel, B, Tt);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
 extern "C" int xva_fp_loss_grads(int stage, int dt, const void* mel_out, const float* mel_tgt, const float* pitch_pred,
                                  const float* pitch_tgt, const float* energy_pred, const float* energy_tgt,
                                  const float* log_dur_pred, const int32_t* durs, const int32_t* in_lens, const float* acc,

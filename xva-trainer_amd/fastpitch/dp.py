@@ -3,8 +3,10 @@
 Replaces the reference's single-process nn.DataParallel (python/fastpitch1_1/xva_train.py:48-53,465-466): replicate /
 scatter / gather / reduce-to-GPU0 every step under the GIL.  Here every rank owns a full replica and a disjoint shard of
 the minibatch; per optimizer step there are exactly two exchanges:
-  1. an 8-float all-reduce of the loss numerators / denominators, so the masked-mean losses are normalised GLOBALLY —
-     the semantics of the reference, which computes the loss on the gathered outputs (xva_train.py:788-790);
+  1. a 2-float all-reduce of the masked-mean DENOMINATORS (valid mel bins, tokens: functions of the batch alone), issued before the
+     forward and travelling under it, so the losses are normalised GLOBALLY — the semantics of the reference, which computes the loss
+     on the gathered outputs (xva_train.py:788-790) — without an exchange between forward and backward; the numerators are reporting
+     only: each rank's losses are its share of the global means, SUM-reduced on the side stream while backward runs;
   2. a SUM all-reduce of the gradients, bucketed per transformer layer in backward-completion order.  The engine records
      a HIP event per bucket while backward is still running; each bucket's all-reduce is enqueued on a side stream that
      waits on its event, so communication overlaps the rest of backward.  xGMI is point-to-point (per-link bound), so
@@ -71,10 +73,19 @@ class GradSync:
 
     def fwd_loss_bwd(self, batch, stage, grad_scale=1.0, sync=True):
         eng = self.eng
+        cur = torch.cuda.current_stream()
+        den = eng.loss_denominators(batch, stage)
+        self.comm.wait_stream(cur)
+        with torch.cuda.stream(self.comm):
+            wden = dist.all_reduce(den, group=self.group, async_op=True)      # 2 floats, under the forward pass
         eng.forward(self.flat, batch, stage)
         acc = eng.loss_partials(batch, stage)
-        dist.all_reduce(acc, group=self.group)                     # global loss normalisation (8 floats)
-        losses = eng.loss_grads(batch, stage, grad_scale)
+        wden.wait()
+        acc[1:4:2].copy_(den)                                                  # acc[1], acc[3]: the GLOBAL denominators
+        losses = eng.loss_grads(batch, stage, grad_scale)                      # this rank's share of the global means
+        self.comm.wait_stream(cur)
+        with torch.cuda.stream(self.comm):
+            wloss = dist.all_reduce(losses, group=self.group, async_op=True)   # reporting: SUM of the shares, under backward
         d = eng._prepare(batch.B, batch.Tt, batch.Tm, stage)
         rc = lib.xva_fp_backward_ex(C.byref(d), _lib.ptr(self.flat), _lib.ptr(self.grads), C.byref(eng._abi), _lib.ptr(eng._ws),
                                     eng._ws.numel(), self.events if sync else None, _lib.stream_ptr())
@@ -89,6 +100,7 @@ class GradSync:
                     self._works.append(dist.all_reduce(self.grads[b:e], group=self.group, async_op=True))
             for w in self._works:
                 w.wait()                                            # the compute stream waits for the reduced buckets
+        wloss.wait()
         return losses
 
 

@@ -40,6 +40,8 @@ lib.xva_fp_forward.restype = i32
 lib.xva_fp_forward.argtypes = [C.POINTER(FpDims), vp, C.POINTER(FpBatch), vp, i64, vp]
 lib.xva_fp_backward.restype = i32
 lib.xva_fp_backward.argtypes = [C.POINTER(FpDims), vp, vp, C.POINTER(FpBatch), vp, i64, vp]
+lib.xva_fp_loss_denominators.restype = i32
+lib.xva_fp_loss_denominators.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
 lib.xva_fp_loss_partials.restype = i32
 lib.xva_fp_loss_partials.argtypes = [i32, i32] + [vp] * 10 + [i32, i32, i32, vp]
 lib.xva_fp_loss_grads.restype = i32
@@ -194,6 +196,13 @@ class FastPitchEngine:
         sp = lambda n: C.c_void_p(self._ws.data_ptr() + self._slot_off[n])
         return [sp("MEL_OUT"), _lib.ptr(b.mel_tgt), sp("PITCH_PRED"), sp("PITCH_TGT"), sp("ENERGY_PRED"), sp("ENERGY_TGT"),
                 sp("LOG_DUR_PRED"), _lib.ptr(b.durs), _lib.ptr(b.in_lens)], sp
+
+    def loss_denominators(self, b, stage):
+        """(2,) fp32: the masked means' denominators [#(mel_tgt != 0), sum(in_lens)] from the batch alone (before / beside the forward)."""
+        den = torch.empty(2, device=self.device)
+        _lib.check(lib.xva_fp_loss_denominators(int(stage), _lib.ptr(b.mel_tgt), _lib.ptr(b.in_lens), _lib.ptr(den), b.B, b.Tt, b.Tm, _lib.stream_ptr()),
+                   "xva_fp_loss_denominators")
+        return den
 
     def loss_partials(self, b, stage):
         args, sp = self._loss_args(b)
