@@ -467,7 +467,7 @@ def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2, roofline=True, c
     from xva_trainer_amd.xvapitch.train_step import XVAPitchStep
     VOCAB, LANGS, SEG = 256, 31, 32
     gen = torch.Generator().manual_seed(1)
-    ac = AcousticTrainPath(VOCAB, LANGS, pitch=True, compute="bf16", device=dev)
+    ac = AcousticTrainPath(VOCAB, LANGS, pitch=True, compute="bf16", device=dev, dropout_p=0.1, sdp_dropout_p=0.5)     # train mode: the reference's dropout (model.py:88,128,166)
     dec, D = VitsDecoder(192, 512, compute="bf16", device=dev), VitsDiscriminator(compute="bf16", device=dev)
     for eng in (dec, D):                                    # random weights: weight_v ~ N(0, 0.02), weight_g = the row norms
         sd = {k: torch.randn(shape, generator=gen) * 0.02 for k, (off, numel, shape) in eng.table.items()}

@@ -494,13 +494,19 @@ int xva_seq_to_bct(const void* seq, float* x, int dt, int B, int C, int T, int p
 /* RelativePositionMultiHeadAttention.attention of the xVAPitch text encoder (python/xvapitch/glow_tts.py:173-292): scaled dot-product
  * scores + the relative-key term (window w), masked_fill(-1e4) outside the item's length, softmax, P V + the relative-value term.
  * q / k / v / out: fp32 activation matrices, item b's token t in row b * Tp + pad + t, head h at columns h*dk ..; emb_*: (Hr, 2w + 1, dk) with
- * Hr = 1 (heads share) or H; P: (B, H, T, T) kept for the backward.  Dropout on the attention weights is not built (p = 0). */
+ * Hr = 1 (heads share) or H; P: (B, H, T, T), the softmax, kept for the backward.  drop_p > 0: nn.Dropout on the attention weights (:204) —
+ * both products use dropout(P); element (b, h, i, j) is index ((b H + h) T + i) T + j of dropout site drop_stream under drop_seed (the keyed
+ * hash of csrc/xva_common.h xva_dropout_scale; the backward is given the same three values). */
 int xva_relattn_fwd(const float* q, const float* k, const float* v, int64_t ld, const float* emb_k, const float* emb_v, const int32_t* lens, float* P,
-                    float* out, int64_t ld_out, int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, void* stream);
+                    float* out, int64_t ld_out, int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, float drop_p, uint64_t drop_seed,
+                    uint32_t drop_stream, void* stream);
+/* nn.Dropout on a contiguous tensor of n elements (dt: 0 fp32, 1 bf16): y[i] = x[i] * (0 | 1 / (1 - p)), decided by the keyed hash of
+ * (seed, site, i); applying it to a gradient with the same (p, seed, site) is the backward.  y == x allowed. */
+int xva_dropout_apply(const void* x, void* y, int dt, int64_t n, float p, uint64_t seed, uint32_t site, void* stream);
 /* dS: (B, H, T, T) scratch; dq / dk / dv are written, d_emb_k / d_emb_v accumulated into */
 int xva_relattn_bwd(const float* dO, int64_t ld_do, const float* q, const float* k, const float* v, int64_t ld, const float* emb_k, const float* emb_v,
                     const int32_t* lens, const float* P, float* dS, float* dq, float* dk_out, float* dv_out, int64_t ld_d, float* d_emb_k, float* d_emb_v,
-                    int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, void* stream);
+                    int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, float drop_p, uint64_t drop_seed, uint32_t drop_stream, void* stream);
 /* LayerNorm2 (glow_tts.py:34-56): layer_norm over the C channels of each row, any C; the backward accumulates into dgamma / dbeta */
 int xva_ln_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int C, float eps, void* stream);
 int xva_ln_rows_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta,

@@ -93,9 +93,11 @@ def kl_loss(z_p, logs_q, m_p, logs_p, z_mask):
     return kl_sw.sum() / z_mask.sum(), kl_sw
 
 
-def rel_transformer(sd, x, x_mask, num_heads, num_layers, kernel_size, window):
+def rel_transformer(sd, x, x_mask, num_heads, num_layers, kernel_size, window, drop=None, site0=0):
     """RelativePositionTransformer.forward (python/xvapitch/glow_tts.py:463-484; layer_norm_type "2", heads sharing the relative
-    embeddings, in = hidden = out, dropout off) with the attention's relative terms (:173-292) written directly: for r = j - i in
+    embeddings, in = hidden = out) — `drop(site, tensor) -> tensor`, when given, stands for nn.Dropout at the module's four calls per layer, in
+    the reference's order: site0 + 4 i + 0 the attention weights (:204), + 1 the attention block's output (:473), + 2 the feed-forward hidden
+    activation (:344), + 3 the feed-forward output (:477); None = eval mode — with the attention's relative terms (:173-292) written directly: for r = j - i in
     [-window, window] the scores get q_i . emb_rel_k[r + window] / sqrt(dk) and the output gets p[i][j] emb_rel_v[r + window]; the
     reference reaches the same numbers through zero-padded embeddings and two pad / reshape index shifts."""
     B, Cc, T = x.shape
@@ -118,15 +120,23 @@ def rel_transformer(sd, x, x_mask, num_heads, num_layers, kernel_size, window):
         scores = scores + torch.where(inwin, qe.gather(-1, ridx.expand(B, H, T, T)), torch.zeros(()))
         scores = (scores / dk ** 0.5).masked_fill(attn_mask == 0, -1e4)
         p = torch.softmax(scores, dim=-1)
+        if drop is not None:
+            p = drop(site0 + 4 * i, p)
         o = p @ v
         pw = torch.zeros(B, H, T, 2 * window + 1).scatter_add(-1, ridx.expand(B, H, T, T), p * inwin)
         o = o + pw @ ev
         o = o.transpose(2, 3).contiguous().view(B, Cc, T)
         y = F.conv1d(o, sd[a + "conv_o.weight"], sd[a + "conv_o.bias"])
+        if drop is not None:
+            y = drop(site0 + 4 * i + 1, y)
         x = F.layer_norm((x + y).transpose(1, -1), (Cc,), sd["norm_layers_1.%d.gamma" % i], sd["norm_layers_1.%d.beta" % i], 1e-5).transpose(1, -1)
         last = i == num_layers - 1
         h = torch.relu(F.conv1d(F.pad(x * x_mask, (pad_l, pad_r)), sd[f + "conv_1.weight"], sd[f + "conv_1.bias"]))
+        if drop is not None:
+            h = drop(site0 + 4 * i + 2, h)
         y = F.conv1d(F.pad(h * x_mask, (pad_l, pad_r)), sd[f + "conv_2.weight"], sd[f + "conv_2.bias"]) * x_mask
+        if drop is not None:
+            y = drop(site0 + 4 * i + 3, y)
         if last and "proj.weight" in sd:                                                     # hidden != out (:479-480)
             x = F.conv1d(x, sd["proj.weight"], sd["proj.bias"])
         Co = x.size(1)
@@ -135,8 +145,8 @@ def rel_transformer(sd, x, x_mask, num_heads, num_layers, kernel_size, window):
     return x * x_mask
 
 
-def dds_conv(sd, x, x_mask, g=None, kernel_size=3, num_layers=3, pre=""):
-    """DilatedDepthSeparableConv.forward (python/xvapitch/sdp.py:76-93), dropout off."""
+def dds_conv(sd, x, x_mask, g=None, kernel_size=3, num_layers=3, pre="", drop=None, site0=0):
+    """DilatedDepthSeparableConv.forward (python/xvapitch/sdp.py:76-93); `drop(site0 + layer, y)` stands for nn.Dropout (:90), None = off."""
     Cc = x.size(1)
     if g is not None:
         x = x + g
@@ -147,6 +157,8 @@ def dds_conv(sd, x, x_mask, g=None, kernel_size=3, num_layers=3, pre=""):
         y = F.gelu(F.layer_norm(y.transpose(1, -1), (Cc,), sd["%snorms_1.%d.gamma" % (pre, i)], sd["%snorms_1.%d.beta" % (pre, i)], 1e-5).transpose(1, -1))
         y = F.conv1d(y, sd["%sconvs_1x1.%d.weight" % (pre, i)], sd["%sconvs_1x1.%d.bias" % (pre, i)])
         y = F.gelu(F.layer_norm(y.transpose(1, -1), (Cc,), sd["%snorms_2.%d.gamma" % (pre, i)], sd["%snorms_2.%d.beta" % (pre, i)], 1e-5).transpose(1, -1))
+        if drop is not None:
+            y = drop(site0 + i, y)
         x = x + y
     return x * x_mask
 
@@ -194,19 +206,20 @@ def conv_flow(sd, x, x_mask, g, hidden, kernel_size=3, num_layers=3, num_bins=10
     return torch.cat([x0, y1], 1) * x_mask, (ld * x_mask).sum((1, 2))
 
 
-def sdp_forward(sd, x, x_mask, dr, noise, hidden, kernel_size=3, num_flows=4, g=None, lang_emb=None):
+def sdp_forward(sd, x, x_mask, dr, noise, hidden, kernel_size=3, num_flows=4, g=None, lang_emb=None, drop=None, site0=0):
     """StochasticDurationPredictor.forward, training direction (python/xvapitch/sdp.py:247-310): negative log-likelihood (B,) of the durations
-    `dr` with variational dequantisation; `noise` is the N(0, 1) draw of :281."""
+    `dr` with variational dequantisation; `noise` is the N(0, 1) draw of :281.  `drop`: nn.Dropout of `convs` (sites site0 + 0..2) and
+    `post_convs` (site0 + 3..5), the two DilatedDepthSeparableConv built with dropout_p (:227,237); the flows' have none (:144)."""
     import math
     x = F.conv1d(x, sd["pre.weight"], sd["pre.bias"])
     if g is not None:
         x = x + F.conv1d(g, sd["cond.weight"], sd["cond.bias"])
     if lang_emb is not None:
         x = x + F.conv1d(lang_emb, sd["cond_lang.weight"], sd["cond_lang.bias"])
-    x = dds_conv(sd, x, x_mask, None, kernel_size, 3, pre="convs.")
+    x = dds_conv(sd, x, x_mask, None, kernel_size, 3, pre="convs.", drop=drop, site0=site0)
     x = F.conv1d(x, sd["proj.weight"], sd["proj.bias"]) * x_mask
     h = F.conv1d(dr, sd["post_pre.weight"], sd["post_pre.bias"])
-    h = dds_conv(sd, h, x_mask, None, kernel_size, 3, pre="post_convs.")
+    h = dds_conv(sd, h, x_mask, None, kernel_size, 3, pre="post_convs.", drop=drop, site0=site0 + 3)
     h = F.conv1d(h, sd["post_proj.weight"], sd["post_proj.bias"]) * x_mask
 
     def affine(pre, z):
@@ -251,10 +264,11 @@ def average_pitch(pitch, durs):
     return torch.where(n == 0.0, n, sums / n)
 
 
-def acoustic_losses(sd, tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps, noise, cfg, pitch_padded=None, pe_scaling=0.1):
+def acoustic_losses(sd, tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps, noise, cfg, pitch_padded=None, pe_scaling=0.1, drop=None):
     """xVAPitch.train_step (python/xvapitch/model.py:681-870) followed by the KL and duration terms of VitsGeneratorLoss.forward
     (losses.py:213-220), on the reference's default switches (--pitch / --energy / --flc / --ow_flow / --mltts_rc 0, detach_dp_input True,
-    lang_w 1; dropout off) and WITHOUT the waveform decoder / discriminator branch (:852-853 — that branch is the HiFi-GAN path).
+    lang_w 1; `drop(site, tensor)` = nn.Dropout of the text encoder (sites 1000 + 4 layer + k), the pitch predictor (2000 + ...) and the duration
+    predictor (3000 + 0..5), None = eval mode) and WITHOUT the waveform decoder / discriminator branch (:852-853 — that branch is the HiFi-GAN path).
     sd: state_dict with the reference's keys (emb_l.*, text_encoder.*, posterior_encoder.*, flow.flows.i.*, duration_predictor.*).
     cfg: latent, lang_dim, heads, te_layers, pe_layers, flow_layers, num_flows.  Returns a dict of the intermediate tensors and losses.
     pitch_padded (B, 1, Ty): the --pitch 1 branch the shipped trainer runs (xva_train.py:1421-1425, pe_scaling 0.1): z_p -= pitch_emb(pitch) *
@@ -275,7 +289,7 @@ def acoustic_losses(sd, tokens, x_lengths, y, y_lengths, d_vectors, language_ids
     x_emb = te["emb.weight"][tokens] * math.sqrt(Cc)                                                       # TextEncoder.forward :1152
     x = torch.cat([x_emb, lang_emb.transpose(2, 1).expand(B, Tt, -1)], -1).transpose(1, 2)                 # :1158-1163
     x_mask = (torch.arange(Tt)[None, :] < x_lengths[:, None]).to(x.dtype).unsqueeze(1)
-    x = rel_transformer(sub("text_encoder.encoder."), x * x_mask, x_mask, cfg["heads"], cfg["te_layers"], 3, 4)
+    x = rel_transformer(sub("text_encoder.encoder."), x * x_mask, x_mask, cfg["heads"], cfg["te_layers"], 3, 4, drop=drop, site0=1000)
     stats = F.conv1d(x, te["proj.weight"], te["proj.bias"]) * x_mask                                       # stats=True branch :1148-1150
     m_p, logs_p = torch.split(stats, Cc, dim=1)
     lang_emb = lang_emb.detach()                                                                           # :722
@@ -294,7 +308,8 @@ def acoustic_losses(sd, tokens, x_lengths, y, y_lengths, d_vectors, language_ids
         logp = logp2 + logp3 + logp1 + logp4
         attn = torch.from_numpy(maximum_path(logp.numpy(), attn_mask.squeeze(1).numpy())).to(logp.dtype).unsqueeze(1)
     attn_durations = attn.sum(3)                                                                           # :792
-    nll = sdp_forward(sub("duration_predictor."), x.detach(), x_mask, attn_durations, noise, Cc, 3, 4, g=g.detach(), lang_emb=lang_emb)   # :795-803
+    nll = sdp_forward(sub("duration_predictor."), x.detach(), x_mask, attn_durations, noise, Cc, 3, 4, g=g.detach(), lang_emb=lang_emb, drop=drop,
+                      site0=3000)                                                                          # :795-803
     loss_duration = nll / torch.sum(x_mask)                                                                # :814
     m_p_e = torch.einsum("klmn, kjm -> kjn", [attn, m_p])                                                  # :846-847
     logs_p_e = torch.einsum("klmn, kjm -> kjn", [attn, logs_p])
@@ -308,9 +323,40 @@ def acoustic_losses(sd, tokens, x_lengths, y, y_lengths, d_vectors, language_ids
         with torch.no_grad():
             pitch_tgt = average_pitch(pitch_padded, w_ceil)                                                # :829
         pin = torch.cat([x.permute(0, 2, 1).detach(), g.transpose(2, 1).expand(B, Tt, -1)], -1).transpose(1, -1)   # :836, model.py:1338-1340
-        pitch_pred = rel_transformer(sub("pitch_predictor.encoder."), pin * x_mask, x_mask, cfg["heads"], 3, 3, 4)
+        pitch_pred = rel_transformer(sub("pitch_predictor.encoder."), pin * x_mask, x_mask, cfg["heads"], 3, 3, 4, drop=drop, site0=2000)
         lp = F.mse_loss(pitch_tgt, pitch_pred, reduction="none") * mask.unsqueeze(1)                       # losses.py:227-228
         loss_pitch = lp.sum() / mask.sum() / pitch_pred.shape[0] * 0.1                                     # :236-241 (pitch_predictor_loss_scale 0.1, :55)
         extra = {"pitch_tgt": pitch_tgt, "pitch_pred": pitch_pred, "loss_pitch": loss_pitch}
     return {**extra, "z": z, "m_q": m_q, "logs_q": logs_q, "x": x, "m_p": m_p_e, "logs_p": logs_p_e, "z_p": z_p, "attn": attn.squeeze(1), "logp": logp,
             "loss_kl": loss_kl, "loss_duration": loss_dur, "loss": loss_kl + loss_dur + loss_pitch}
+
+
+class HashDrop:
+    """The `drop` hooks of this module over the keyed hash of xva-trainer_amd/csrc/xva_common.h (oracle/fastpitch.py HashDropout restates it in
+    numpy): drop(site, x) = x * (0 | 1 / (1 - p(site))).  layout "flat": element index = position in x's own contiguous order (the stand-in the
+    reference's nn.Dropout is patched with when the goldens are made: oracle/gen_golden_xvapitch_dropout.py); layout "hip": the index the HIP path
+    uses for the same element — attention weights (B, H, T, T): flat; a (B, C, T) activation of the transformers: (row of the time-major
+    sequence = b * (T + 2 pad) + pad + t) * C + c; a (B, C, T) activation of the duration predictor, held (B, T, C) there: (b * T + t) * C + c."""
+
+    def __init__(self, p_of_site, seed, layout="flat", pad=8, btc_sites=range(3000, 4000)):
+        from oracle.fastpitch import HashDropout
+        self.p_of_site, self.seed, self.layout, self.pad, self.btc = p_of_site, seed, layout, pad, btc_sites
+        self._h = {}
+        self._HD = HashDropout
+
+    def __call__(self, site, x):
+        import numpy as np
+        p = self.p_of_site(site) if callable(self.p_of_site) else self.p_of_site
+        if p <= 0:
+            return x
+        h = self._h.setdefault(p, self._HD(p, self.seed))
+        if self.layout == "flat" or x.dim() == 4:
+            idx = np.arange(x.numel(), dtype=np.uint64).reshape(tuple(x.shape))
+        else:
+            B, Cc, T = x.shape
+            b, c, t = np.meshgrid(np.arange(B, dtype=np.uint64), np.arange(Cc, dtype=np.uint64), np.arange(T, dtype=np.uint64), indexing="ij")
+            if site in self.btc:
+                idx = (b * np.uint64(T) + t) * np.uint64(Cc) + c
+            else:
+                idx = (b * np.uint64(T + 2 * self.pad) + np.uint64(self.pad) + t) * np.uint64(Cc) + c
+        return x * torch.from_numpy(h._mult(site, idx)).to(x.dtype)

@@ -278,3 +278,47 @@ def test_vits_discriminator_oracle_matches_reference_golden():
     (lg + lf).backward()
     ref = torch.from_numpy(g["d_wav"]).unsqueeze(1)
     assert float((yh.grad - ref).norm() / ref.norm()) < 1e-3
+
+
+def test_oracle_dropout_sites_against_reference_train_mode_golden():
+    """tests/golden/xvapitch_dropout.npz was recorded from the REFERENCE modules in train mode with nn.Dropout.forward replaced by the
+    keyed-hash mask of the call's site over the tensor's flat order (oracle/gen_golden_xvapitch_dropout.py).  The oracle with the same hook at
+    its sites — attention weights, attention output, feed-forward hidden, feed-forward output per transformer layer (glow_tts.py:204,473,344,477);
+    after the second GELU of each layer of the duration predictor's `convs` / `post_convs` (sdp.py:90,227,237) — must reproduce outputs and
+    gradients: this pins WHERE the oracle (and through it the HIP path, tests/test_xvapitch_gpu.py) drops to where the reference does."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import xvapitch as oxv
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xvapitch_dropout.npz"))
+    seed = int(g["seed"][0])
+    lens = torch.from_numpy(g["lens"])
+    for tag in ("te", "pp"):
+        B, Cc, Co, Fh, H, L, K, W, T = (int(v) for v in g[tag + "_cfg"])
+        x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1)
+        sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith(tag + "_sd/")}
+        x = torch.from_numpy(g[tag + "_x"]).requires_grad_(True)
+        hook = oxv.HashDrop(float(g[tag + "_p"][0]), seed, layout="flat")
+        y = oxv.rel_transformer(sd, x, x_mask, H, L, K, W, drop=hook)
+        assert torch.allclose(y, torch.from_numpy(g[tag + "_y"]), rtol=1e-5, atol=1e-5)
+        y0 = oxv.rel_transformer(sd, x, x_mask, H, L, K, W)
+        assert float((y0 - y).abs().max()) > 1e-2                                     # and it is not the eval-mode output
+        (y * torch.from_numpy(g[tag + "_r"])).sum().backward()
+        assert torch.allclose(x.grad, torch.from_numpy(g[tag + "_dx"]), rtol=1e-4, atol=1e-5)
+        names = [k[len(tag) + 6:] for k in g.files if k.startswith(tag + "_grad/")]
+        assert len(names) >= 18 * L - 6
+        for n in names:
+            assert torch.allclose(sd[n].grad, torch.from_numpy(g["%s_grad/%s" % (tag, n)]), rtol=1e-4, atol=1e-5), (tag, n)
+    B, Cin, Hh, Cg, Cl, Ts = (int(v) for v in g["sdp_cfg"])
+    lens2 = torch.from_numpy(g["sdp_lens"])
+    m_ = (torch.arange(Ts)[None, :] < lens2[:, None]).float().unsqueeze(1)
+    sd = {k[7:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("sdp_sd/")}
+    x = torch.from_numpy(g["sdp_x"]).requires_grad_(True)
+    t = lambda k: torch.from_numpy(g[k])
+    nll = oxv.sdp_forward(sd, x, m_, t("sdp_dr"), t("sdp_noise"), Hh, 3, 4, g=t("sdp_g"), lang_emb=t("sdp_le"), drop=oxv.HashDrop(0.5, seed + 1, layout="flat"))
+    assert torch.allclose(nll, t("sdp_nll"), rtol=1e-4, atol=1e-3)
+    nll.sum().backward()
+    assert torch.allclose(x.grad, t("sdp_dx"), rtol=1e-3, atol=1e-4)
+    for k in g.files:
+        if k.startswith("sdp_grad/"):
+            assert torch.allclose(sd[k[9:]].grad, t(k), rtol=1e-3, atol=1e-4), k

@@ -752,3 +752,80 @@ def test_c5_properties_at_reference_model_size():
         (dec(zz, g) * (r * scale)).sum().backward()
         res.append((zz.grad.clone(), dec.grad.clone()))
     assert _rel(res[1][0], 2 * res[0][0]) < 1e-5 and _rel(res[1][1], 2 * res[0][1]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["te", "pp"])
+def test_rel_transformer_dropout_against_oracle_with_the_same_masks(golden_dir, tag):
+    """Train-mode RelativePositionTransformer (dropout 0.1 at the reference's four sites per layer: inside the attention kernels, in the conv_o /
+    conv_1 GEMM epilogues, on the feed-forward output) against the CPU oracle given THE SAME masks — oracle.xvapitch.HashDrop in the HIP
+    path's element order — on the reference modules' weights and inputs of tests/golden/xvapitch_dropout.npz (whose own vectors pin the
+    oracle's sites to the reference's train mode, tests/test_xvapitch_cpu.py): output, input gradient and every parameter gradient at 1e-3;
+    eval mode returns the dropout-free output; a second seed gives different masks."""
+    from oracle import xvapitch as oxv
+    from xva_trainer_amd.xvapitch.transformer import RelativePositionTransformer
+    g = np.load(os.path.join(golden_dir, "xvapitch_dropout.npz"))
+    B, Cc, Co, Fh, H, L, K, W, T = (int(v) for v in g[tag + "_cfg"])
+    p = float(g[tag + "_p"][0])
+    lens = torch.from_numpy(g["lens"])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1)
+    sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_sd/")}
+    tr = RelativePositionTransformer(Cc, Co, Cc, Fh, H, L, kernel_size=K, dropout_p=p, rel_attn_window_size=W, layer_norm_type="2", dropout_site_base=1000)
+    tr.load_state_dict(sd)
+    seed = 987654321012345
+    tr.set_dropout_seed(seed)
+    tr.zero_grad()
+    x = torch.from_numpy(g[tag + "_x"]).cuda().requires_grad_(True)
+    r = torch.from_numpy(g[tag + "_r"])
+    y = tr(x, x_mask.cuda())
+    (y * r.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = torch.from_numpy(g[tag + "_x"]).requires_grad_(True)
+    yo = oxv.rel_transformer(leaves, xo, x_mask, H, L, K, W, drop=oxv.HashDrop(p, seed, layout="hip"), site0=1000)
+    (yo * r).sum().backward()
+    assert _rel(y, yo.detach()) < 1e-3 and _rel(x.grad, xo.grad) < 1e-3
+    grads = tr.grads()
+    worst = sorted(((_rel(grads[n], v.grad), n) for n, v in leaves.items() if v.grad is not None and not n.endswith("conv_k.bias") and float(v.grad.abs().max()) > 0),
+                   reverse=True)
+    print("transformer dropout (%s): worst gradients %s" % (tag, worst[:3]))
+    assert len(worst) >= 18 * L - 8 and worst[0][0] < 1e-3, worst[:4]
+    y_eval_ref = oxv.rel_transformer(sd, torch.from_numpy(g[tag + "_x"]), x_mask, H, L, K, W)
+    assert _rel(y, y_eval_ref) > 1e-2                                   # dropout really ran
+    tr.eval()
+    assert _rel(tr(x.detach(), x_mask.cuda()), y_eval_ref) < 1e-3
+    tr.train(); tr.set_dropout_seed(seed + 1)
+    assert _rel(tr(x.detach(), x_mask.cuda()), yo.detach()) > 1e-2       # another seed, other masks
+
+
+def test_duration_predictor_dropout_against_oracle_with_the_same_masks(golden_dir):
+    """StochasticDurationPredictor in train mode, dropout 0.5 in `convs` / `post_convs` (python/xvapitch/sdp.py:90,227,237), against the oracle
+    given the same keyed-hash masks in the HIP path's (B, T, C) element order: the NLL and every gradient."""
+    from oracle import xvapitch as oxv
+    from xva_trainer_amd.xvapitch.sdp import StochasticDurationPredictor
+    g = np.load(os.path.join(golden_dir, "xvapitch_dropout.npz"))
+    B, Cin, Hh, Cg, Cl, Ts = (int(v) for v in g["sdp_cfg"])
+    lens2 = torch.from_numpy(g["sdp_lens"])
+    m_ = (torch.arange(Ts)[None, :] < lens2[:, None]).float().unsqueeze(1)
+    sd = {k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sdp_sd/")}
+    t = lambda k: torch.from_numpy(g[k])
+    dp = StochasticDurationPredictor(Cin, Hh, 3, 0.5, 4, cond_channels=Cg, language_emb_dim=Cl, dropout_site_base=3000)
+    assert set(dp.state_dict()) == set(sd)
+    dp.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    seed = 424242424242
+    dp.set_dropout_seed(seed)
+    x = t("sdp_x").cuda().requires_grad_(True)
+    nll = dp(x, m_.cuda(), t("sdp_dr").cuda(), g=t("sdp_g").cuda(), lang_emb=t("sdp_le").cuda(), noise=t("sdp_noise").cuda())
+    nll.sum().backward()
+    torch.cuda.synchronize()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = t("sdp_x").requires_grad_(True)
+    nllo = oxv.sdp_forward(leaves, xo, m_, t("sdp_dr"), t("sdp_noise"), Hh, 3, 4, g=t("sdp_g"), lang_emb=t("sdp_le"), drop=oxv.HashDrop(0.5, seed, layout="hip"), site0=3000)
+    nllo.sum().backward()
+    assert _rel(nll, nllo.detach()) < 1e-3 and _rel(x.grad, xo.grad) < 2e-3
+    worst = sorted(((_rel(v.grad, leaves[k].grad), k) for k, v in dp.p.items() if leaves[k].grad is not None and float(leaves[k].grad.abs().max()) > 0), reverse=True)
+    print("sdp dropout: worst gradients", worst[:3])
+    assert len(worst) > 100 and worst[0][0] < 5e-3, worst[:4]
+    nll_eval = oxv.sdp_forward(sd, t("sdp_x"), m_, t("sdp_dr"), t("sdp_noise"), Hh, 3, 4, g=t("sdp_g"), lang_emb=t("sdp_le"))
+    assert _rel(nll, nll_eval) > 1e-3
+    dp.eval()
+    assert _rel(dp(x.detach(), m_.cuda(), t("sdp_dr").cuda(), g=t("sdp_g").cuda(), lang_emb=t("sdp_le").cuda(), noise=t("sdp_noise").cuda()), nll_eval) < 1e-3

@@ -25,7 +25,7 @@ dt = sys.argv[4] if len(sys.argv) > 4 else "bf16"
 adt = sys.argv[5] if len(sys.argv) > 5 else "fp32"        # storage / MFMA dtype of the WaveNet stacks (posterior encoder, flow); transformer / SDP are fp32
 VOCAB, LANGS, SEG = 256, 31, 32
 torch.manual_seed(0)
-ac = AcousticTrainPath(VOCAB, LANGS, pitch=True, compute=adt)                      # the reference's defaults (model.py:55-135)
+ac = AcousticTrainPath(VOCAB, LANGS, pitch=True, compute=adt, dropout_p=0.1, sdp_dropout_p=0.5)      # the reference's defaults, train mode (model.py:55-135; dropout :88,128,166)
 dec = VitsDecoder(192, 512, compute=dt)
 D = VitsDiscriminator(compute=dt)
 gen = torch.Generator().manual_seed(1)

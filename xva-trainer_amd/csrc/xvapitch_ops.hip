@@ -322,6 +322,23 @@ extern "C" int xva_seq_mask(void* x, int dt, int B, int Tp, int pad, int C, cons
     return XVA_OK;
 }
 
+// ---- nn.Dropout on a contiguous tensor: y[i] = x[i] * (0 or 1 / (1 - p)), the decision a keyed hash of (seed, site, i) (xva_common.h) ------------
+// The same call on a gradient is the backward (same mask).  In place allowed.  Sites of python/xvapitch: glow_tts.py:473,477 (the
+// sub-layer outputs of RelativePositionTransformer), sdp.py:90 (DilatedDepthSeparableConv).
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const void* __restrict__ x, void* __restrict__ y, int dt, int64_t n, float p, uint64_t seed,
+                                                            uint32_t site) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        st(y, i, dt, ld(x, i, dt) * xva_dropout_scale(p, seed, site, (uint64_t)i));
+}
+extern "C" int xva_dropout_apply(const void* x, void* y, int dt, int64_t n, float p, uint64_t seed, uint32_t site, void* stream) {
+    XVA_CHECK_ARG(x && y && n >= 0 && p >= 0.f && p < 1.f, "dropout_apply: bad arguments");
+    if (n == 0) return XVA_OK;
+    int64_t grid = (n + 255) / 256; if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, y, dt, n, p, seed, site);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
 // ---- per-item column sums of a time-major sequence: out[b * out_stride + c] += sum over the item's Tp rows of x[b][.][c] --------------------------
 // (the gradient of WN's conditioning term, python/xvapitch/wavenet.py:91-97: g_l is broadcast over time, so d g_l[b] = sum_t d(in_act)[b, t])
 // One workgroup per (item, 64 columns): 4 row phases x 64 columns, LDS tree over the phases; rows outside the item's length hold zeros.
@@ -494,7 +511,8 @@ __device__ __forceinline__ float ra_block_max(float v, float* sh) {
 __global__ __launch_bounds__(RA_THREADS) void relattn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                                  int64_t ld, const float* __restrict__ emb_k, const float* __restrict__ emb_v,
                                                                  const int32_t* __restrict__ lens, float* __restrict__ P, float* __restrict__ out,
-                                                                 int64_t ld_out, int T, int H, int dk, int w, int Hr, int Tp, int pad) {
+                                                                 int64_t ld_out, int T, int H, int dk, int w, int Hr, int Tp, int pad, float drop_p,
+                                                                 uint64_t drop_seed, uint32_t drop_stream) {
     extern __shared__ float sm[];                 // scores / probabilities of this row [T] + q_i [dk] + reduction scratch [2]
     float* s = sm; float* qi = sm + T; float* red = qi + dk;
     const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -528,7 +546,14 @@ __global__ __launch_bounds__(RA_THREADS) void relattn_fwd_kernel(const float* __
     sum = ra_block_sum(sum, red);
     const float inv = 1.f / sum;
     float* Pi = P + (((int64_t)b * H + h) * T + i) * T;
-    for (int j = threadIdx.x; j < T; j += RA_THREADS) { const float p = s[j] * inv; s[j] = p; Pi[j] = p; }
+    // P keeps the softmax itself (its backward needs it); the products below use dropout(P) (glow_tts.py:204): element (b, h, i, j) of the
+    // (B, H, T, T) weights is dropout index ((b H + h) T + i) T + j of site `drop_stream`
+    const uint64_t drow = (((uint64_t)b * H + h) * T + i) * T;
+    for (int j = threadIdx.x; j < T; j += RA_THREADS) {
+        const float p = s[j] * inv;
+        Pi[j] = p;
+        s[j] = p * xva_dropout_scale(drop_p, drop_seed, drop_stream, drow + j);
+    }
     __syncthreads();
     for (int d = threadIdx.x; d < dk; d += RA_THREADS) {
         float acc = 0.f;
@@ -547,7 +572,8 @@ __global__ __launch_bounds__(RA_THREADS) void relattn_bwd_row_kernel(const float
                                                                      const float* __restrict__ v, int64_t ld, const float* __restrict__ emb_k,
                                                                      const float* __restrict__ emb_v, const int32_t* __restrict__ lens,
                                                                      const float* __restrict__ P, float* __restrict__ dS, float* __restrict__ dq,
-                                                                     int64_t ld_dq, int T, int H, int dk, int w, int Hr, int Tp, int pad) {
+                                                                     int64_t ld_dq, int T, int H, int dk, int w, int Hr, int Tp, int pad, float drop_p,
+                                                                     uint64_t drop_seed, uint32_t drop_stream) {
     extern __shared__ float sm[];
     float* s = sm; float* doi = sm + T; float* red = doi + dk;
     const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -569,6 +595,7 @@ __global__ __launch_bounds__(RA_THREADS) void relattn_bwd_row_kernel(const float
             const float* e = ev + (int64_t)(r + w) * dk;
             for (int d = 0; d < dk; ++d) acc += doi[d] * e[d];
         }
+        acc *= xva_dropout_scale(drop_p, drop_seed, drop_stream, (((uint64_t)b * H + h) * T + i) * T + j);   // d dropout(P) -> d P
         s[j] = acc;
         dot += Pi[j] * acc;
     }
@@ -593,14 +620,19 @@ __global__ __launch_bounds__(RA_THREADS) void relattn_bwd_row_kernel(const float
 // backward, per key row j: dk_j = sum_i dS[i][j] q_i ; dv_j = sum_i P[i][j] dO_i
 __global__ __launch_bounds__(RA_THREADS) void relattn_bwd_col_kernel(const float* __restrict__ dO, int64_t ld_do, const float* __restrict__ q, int64_t ld,
                                                                      const float* __restrict__ P, const float* __restrict__ dS, float* __restrict__ dk_out,
-                                                                     float* __restrict__ dv_out, int64_t ld_d, int T, int H, int dk, int Tp, int pad) {
+                                                                     float* __restrict__ dv_out, int64_t ld_d, int T, int H, int dk, int Tp, int pad, float drop_p,
+                                                                     uint64_t drop_seed, uint32_t drop_stream) {
     extern __shared__ float sm[];
     float* ps = sm; float* ds = sm + T;
     const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int64_t row0 = (int64_t)b * Tp + pad;
     const float* Pb = P + ((int64_t)b * H + h) * T * T;
     const float* Sb = dS + ((int64_t)b * H + h) * T * T;
-    for (int i = threadIdx.x; i < T; i += RA_THREADS) { ps[i] = Pb[(int64_t)i * T + j]; ds[i] = Sb[(int64_t)i * T + j]; }
+    const uint64_t d0 = ((uint64_t)b * H + h) * T * T;
+    for (int i = threadIdx.x; i < T; i += RA_THREADS) {
+        ps[i] = Pb[(int64_t)i * T + j] * xva_dropout_scale(drop_p, drop_seed, drop_stream, d0 + (uint64_t)i * T + j);   // dv sees dropout(P)
+        ds[i] = Sb[(int64_t)i * T + j];
+    }
     __syncthreads();
     for (int d = threadIdx.x; d < dk; d += RA_THREADS) {
         float ak = 0.f, av = 0.f;
@@ -616,18 +648,20 @@ __global__ __launch_bounds__(RA_THREADS) void relattn_bwd_col_kernel(const float
 // grid (2w + 1, H, B): one relative position of one (item, head); atomics over (b, h) — Hr * (2w + 1) * dk addresses, B * H adders each
 __global__ __launch_bounds__(RA_THREADS) void relattn_bwd_emb_kernel(const float* __restrict__ dO, int64_t ld_do, const float* __restrict__ q, int64_t ld,
                                                                      const float* __restrict__ P, const float* __restrict__ dS, float* __restrict__ d_emb_k,
-                                                                     float* __restrict__ d_emb_v, int T, int H, int dk, int w, int Hr, int Tp, int pad) {
+                                                                     float* __restrict__ d_emb_v, int T, int H, int dk, int w, int Hr, int Tp, int pad, float drop_p,
+                                                                     uint64_t drop_seed, uint32_t drop_stream) {
     const int r = (int)blockIdx.x - w, h = blockIdx.y, b = blockIdx.z;
     const int64_t row0 = (int64_t)b * Tp + pad;
     const float* Pb = P + ((int64_t)b * H + h) * T * T;
     const float* Sb = dS + ((int64_t)b * H + h) * T * T;
+    const uint64_t d0 = ((uint64_t)b * H + h) * T * T;
     for (int d = threadIdx.x; d < dk; d += RA_THREADS) {
         float ak = 0.f, av = 0.f;
         for (int i = 0; i < T; ++i) {
             const int j = i + r;
             if (j < 0 || j >= T) continue;
             ak += Sb[(int64_t)i * T + j] * q[(row0 + i) * ld + h * dk + d];
-            av += Pb[(int64_t)i * T + j] * dO[(row0 + i) * ld_do + h * dk + d];
+            av += Pb[(int64_t)i * T + j] * xva_dropout_scale(drop_p, drop_seed, drop_stream, d0 + (uint64_t)i * T + j) * dO[(row0 + i) * ld_do + h * dk + d];
         }
         const int64_t o = ((int64_t)(Hr == 1 ? 0 : h) * (2 * w + 1) + (r + w)) * dk + d;
         atomicAdd(d_emb_k + o, ak);
@@ -636,28 +670,31 @@ __global__ __launch_bounds__(RA_THREADS) void relattn_bwd_emb_kernel(const float
 }
 
 extern "C" int xva_relattn_fwd(const float* q, const float* k, const float* v, int64_t ld, const float* emb_k, const float* emb_v, const int32_t* lens,
-                               float* P, float* out, int64_t ld_out, int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, void* stream) {
+                               float* P, float* out, int64_t ld_out, int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, float drop_p,
+                               uint64_t drop_seed, uint32_t drop_stream, void* stream) {
     XVA_CHECK_ARG(q && k && v && emb_k && emb_v && lens && P && out, "relattn_fwd: null");
+    XVA_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "relattn_fwd: dropout probability outside [0, 1)");
     XVA_CHECK_ARG(B > 0 && T > 0 && H > 0 && dk > 0 && w >= 0 && (Hr == 1 || Hr == H) && T <= 8192, "relattn_fwd: bad dims");
     const size_t shm = (size_t)(T + dk + 4) * 4;
     hipLaunchKernelGGL(relattn_fwd_kernel, dim3(T, H, B), dim3(RA_THREADS), shm, (hipStream_t)stream, q, k, v, ld, emb_k, emb_v, lens, P, out, ld_out, T, H, dk, w,
-                       Hr, Tp, pad);
+                       Hr, Tp, pad, drop_p, drop_seed, drop_stream);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
 /* dS: scratch (B, H, T, T); d_emb_k / d_emb_v are ACCUMULATED into (parameter gradients), dq / dk / dv written */
 extern "C" int xva_relattn_bwd(const float* dO, int64_t ld_do, const float* q, const float* k, const float* v, int64_t ld, const float* emb_k,
                                const float* emb_v, const int32_t* lens, const float* P, float* dS, float* dq, float* dk_out, float* dv_out, int64_t ld_d,
-                               float* d_emb_k, float* d_emb_v, int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, void* stream) {
+                               float* d_emb_k, float* d_emb_v, int B, int T, int H, int dk, int w, int Hr, int Tp, int pad, float drop_p,
+                               uint64_t drop_seed, uint32_t drop_stream, void* stream) {
     XVA_CHECK_ARG(dO && q && k && v && emb_k && emb_v && lens && P && dS && dq && dk_out && dv_out && d_emb_k && d_emb_v, "relattn_bwd: null");
     XVA_CHECK_ARG(B > 0 && T > 0 && H > 0 && dk > 0 && w >= 0 && (Hr == 1 || Hr == H) && T <= 8192, "relattn_bwd: bad dims");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(relattn_bwd_row_kernel, dim3(T, H, B), dim3(RA_THREADS), (size_t)(T + dk + 4) * 4, st, dO, ld_do, k, v, ld, emb_k, emb_v, lens, P, dS, dq,
-                       ld_d, T, H, dk, w, Hr, Tp, pad);
+                       ld_d, T, H, dk, w, Hr, Tp, pad, drop_p, drop_seed, drop_stream);
     hipLaunchKernelGGL(relattn_bwd_col_kernel, dim3(T, H, B), dim3(RA_THREADS), (size_t)(2 * T) * 4, st, dO, ld_do, q, ld, P, dS, dk_out, dv_out, ld_d, T, H, dk,
-                       Tp, pad);
+                       Tp, pad, drop_p, drop_seed, drop_stream);
     hipLaunchKernelGGL(relattn_bwd_emb_kernel, dim3(2 * w + 1, H, B), dim3(RA_THREADS), 0, st, dO, ld_do, q, ld, P, dS, d_emb_k, d_emb_v, T, H, dk, w, Hr, Tp,
-                       pad);
+                       pad, drop_p, drop_seed, drop_stream);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }

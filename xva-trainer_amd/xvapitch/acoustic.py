@@ -8,8 +8,10 @@ the waveform decoder, followed by the KL and duration terms of VitsGeneratorLoss
 
 Built for the reference's default switches (xva_train.py:1098-1120: --energy / --flc / --ow_flow / --mltts_rc 0; detach_dp_input True,
 model.py:52; lang_w 1), with --pitch 0 (the argparse default) or 1 (what the shipped trainer sets, xva_train.py:1421-1425: pitch_emb subtracted
-from z_p :752-755, average_pitch targets :817-829, the pitch predictor :836, the pitch term of losses.py:224-241), and with dropout off (the
-text encoder's 0.1 and the duration predictor's 0.5 are not built — wn.py / sdp.py raise on dropout_p > 0).  The waveform decoder + discriminator branch (:852-853) is the HiFi-GAN path (xva-trainer_amd/hifigan); its speaker-conditioned
+from z_p :752-755, average_pitch targets :817-829, the pitch predictor :836, the pitch term of losses.py:224-241).  Dropout: `dropout_p` is the
+text encoder's and the pitch predictor's (0.1: model.py:88,166), `sdp_dropout_p` the duration predictor's (0.5: model.py:128) — at the
+reference's sites (transformer.py / sdp.py), masks from a keyed hash under a seed that advances with every training forward; both default to 0
+(the parity goldens run the reference in eval mode), the trainer passes the reference's values.  The waveform decoder + discriminator branch (:852-853) is the HiFi-GAN path (xva-trainer_amd/hifigan); its speaker-conditioned
 generator variant is not built, so this class returns z and the acoustic losses, not the full generator loss.
 
 state_dict keys are the reference's (`emb_l.weight`, `text_encoder.*`, `posterior_encoder.*`, `flow.flows.i.*`, `duration_predictor.*`).
@@ -87,8 +89,9 @@ class AcousticTrainPath:
 
     def __init__(self, n_vocab, num_languages, latent_size=192, embedded_language_dim=4, d_vector_dim=512, hidden_channels_ffn=768, num_heads=2,
                  text_layers=10, posterior_layers=16, flow_layers=4, num_flows=4, spec_bins=513, pitch=False, pe_scaling=0.1, device="cuda", compute="fp32",
-                 seed=0):
+                 seed=0, dropout_p=0.0, sdp_dropout_p=0.0):
         Cc, L = latent_size, embedded_language_dim
+        self.training, self.drop_seed, self._drop_calls = True, (int(seed) * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF, 0
         self.C, self.L = Cc, L
         self.device = torch.device(device)
         gen = torch.Generator().manual_seed(seed)
@@ -96,26 +99,45 @@ class AcousticTrainPath:
                   "text_encoder.emb.weight": _param(torch.randn(n_vocab, Cc, generator=gen) * Cc ** -0.5, self.device),                 # model.py:1120
                   "text_encoder.proj.weight": _param((torch.rand(2 * Cc, Cc + L, 1, generator=gen) * 2 - 1) * (Cc + L) ** -0.5, self.device),
                   "text_encoder.proj.bias": _param((torch.rand(2 * Cc, generator=gen) * 2 - 1) * (Cc + L) ** -0.5, self.device)}
-        self.encoder = RelativePositionTransformer(Cc + L, Cc + L, Cc + L, hidden_channels_ffn, num_heads, text_layers, kernel_size=3, dropout_p=0.0,
+        self.encoder = RelativePositionTransformer(Cc + L, Cc + L, Cc + L, hidden_channels_ffn, num_heads, text_layers, kernel_size=3, dropout_p=dropout_p,
                                                    layer_norm_type="2", rel_attn_window_size=4, device=device, seed=seed + 1,
-                                                   compute="mixed" if compute == "bf16" else "fp32")
+                                                   compute="mixed" if compute == "bf16" else "fp32", dropout_site_base=1000)
         self.posterior_encoder = PosteriorEncoder(spec_bins, Cc, Cc, 5, 1, posterior_layers, cond_channels=d_vector_dim, device=device, compute=compute,
                                                   seed=seed + 2)
         self.flow = ResidualCouplingBlocks(Cc, Cc, 5, 1, flow_layers, num_flows=num_flows, cond_channels=d_vector_dim, device=device, compute=compute,
                                            seed=seed + 3)
-        self.duration_predictor = StochasticDurationPredictor(Cc, Cc, 3, 0.0, 4, cond_channels=d_vector_dim, language_emb_dim=L, device=device, seed=seed + 4)
+        self.duration_predictor = StochasticDurationPredictor(Cc, Cc, 3, sdp_dropout_p, 4, cond_channels=d_vector_dim, language_emb_dim=L, device=device,
+                                                              seed=seed + 4, dropout_site_base=3000)
         self._subs = [("text_encoder.encoder.", self.encoder), ("posterior_encoder.", self.posterior_encoder), ("flow.", self.flow),
                       ("duration_predictor.", self.duration_predictor)]
         # --pitch 1, what the shipped trainer sets (xva_train.py:1421-1425): model.py:153-176
         self.pitch, self.pe_scaling, self.Dv = bool(pitch), float(pe_scaling), d_vector_dim
         if self.pitch:
             hid = Cc + L + d_vector_dim                                                                                                   # model.py:1283-1284
-            self.pitch_predictor = RelativePositionTransformer(hid, 1, hid, hidden_channels_ffn, num_heads, 3, kernel_size=3, dropout_p=0.0,
+            self.pitch_predictor = RelativePositionTransformer(hid, 1, hid, hidden_channels_ffn, num_heads, 3, kernel_size=3, dropout_p=dropout_p,
                                                                layer_norm_type="2", rel_attn_window_size=4, device=device, seed=seed + 5,
-                                                               compute="mixed" if compute == "bf16" else "fp32")
+                                                               compute="mixed" if compute == "bf16" else "fp32", dropout_site_base=2000)
             self._subs.append(("pitch_predictor.encoder.", self.pitch_predictor))
             self.p["pitch_emb.weight"] = _param((torch.rand(Cc, 1, 3, generator=gen) * 2 - 1) * 3 ** -0.5, self.device)
             self.p["pitch_emb.bias"] = _param((torch.rand(Cc, generator=gen) * 2 - 1) * 3 ** -0.5, self.device)
+
+    # ---- dropout (nn.Module.train / eval; the masks' seed) ----
+    def _droppers(self):
+        return [self.encoder, self.duration_predictor] + ([self.pitch_predictor] if self.pitch else [])
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        for m in self._droppers():
+            m.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def set_dropout_seed(self, seed):
+        """Base seed of the dropout masks (the trainer derives it from its run seed); every training forward uses base + its call count, so
+        iterations differ and a resumed run can be replayed."""
+        self.drop_seed, self._drop_calls = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
 
     # ---- reference state_dict ----
     def state_dict(self):
@@ -213,6 +235,10 @@ class AcousticTrainPath:
         if self.pitch and pitch_padded is None:
             raise ValueError("AcousticTrainPath(pitch=True): pitch_padded is required")
         _lib.require_cuda(y, d_vectors)
+        if self.training:
+            self._drop_calls += 1
+            for m in self._droppers():
+                m.set_dropout_seed(self.drop_seed + 0x9E3779B97F4A7C15 * self._drop_calls)
         p, Cc, L = self.p, self.C, self.L
         B, Tt = tokens.shape
         Ty = y.size(2)

@@ -21,6 +21,8 @@ lib.xva_dwconv_fwd.restype = i32
 lib.xva_dwconv_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
 lib.xva_dwconv_bwd.restype = i32
 lib.xva_dwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+lib.xva_dropout_apply.restype = i32
+lib.xva_dropout_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p]
 lib.xva_gelu_fwd.restype = i32
 lib.xva_gelu_fwd.argtypes = [vp, vp, i64, vp]
 lib.xva_gelu_bwd.restype = i32
@@ -160,6 +162,23 @@ class Mask(torch.autograd.Function):
         return d, None
 
 
+class Dropout(torch.autograd.Function):
+    """nn.Dropout on a contiguous tensor (sdp.py:90): y = x * (0 | 1 / (1 - p)) by the keyed hash of (seed, site, flat index)
+    (csrc/xva_common.h xva_dropout_scale); the backward applies the same mask to the gradient."""
+    @staticmethod
+    def forward(ctx, x, p, seed, site):
+        x = x.contiguous(); y = torch.empty_like(x)
+        _lib.check(lib.xva_dropout_apply(P(x), P(y), 0, x.numel(), p, seed, site, ST()), "xva_dropout_apply")
+        ctx.cfg = (p, seed, site)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous(); dx = torch.empty_like(dy)
+        _lib.check(lib.xva_dropout_apply(P(dy), P(dx), 0, dy.numel(), *ctx.cfg, ST()), "xva_dropout_apply")
+        return dx, None, None, None
+
+
 class Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -179,9 +198,12 @@ def _param(t, device):
 class DilatedDepthSeparableConv:
     """sdp.py:40-93: per layer  y = GELU(LN(dwconv_{d = k^i}(x * x_mask))); y = GELU(LN(conv1x1(y))); x = x + y;  output x * x_mask."""
 
-    def __init__(self, channels, kernel_size, num_layers, dropout_p=0.0, device="cuda", seed=0):
-        if dropout_p:
-            raise NotImplementedError("DilatedDepthSeparableConv: dropout_p > 0 is not built")
+    def __init__(self, channels, kernel_size, num_layers, dropout_p=0.0, device="cuda", seed=0, dropout_site_base=0):
+        """dropout_p > 0: nn.Dropout after the second GELU of every layer (sdp.py:90), site dropout_site_base + layer, flat index of the (B, T, C)
+        activation, under the seed of `drop_seed` (set per iteration by the owner); `training = False` switches it off."""
+        if not 0.0 <= dropout_p < 1.0:
+            raise ValueError("DilatedDepthSeparableConv: dropout_p must be in [0, 1)")
+        self.dropout_p, self.site0, self.training, self.drop_seed = float(dropout_p), int(dropout_site_base), True, int(seed) + 0x5EED
         if channels % 4 or kernel_size % 2 != 1 or kernel_size > 7:
             raise NotImplementedError("DilatedDepthSeparableConv: channels must be a multiple of 4, kernel_size odd <= 7")
         self.C, self.k, self.L = channels, kernel_size, num_layers
@@ -223,6 +245,8 @@ class DilatedDepthSeparableConv:
             y = Gelu.apply(LayerNormRows.apply(y, p["norms_1.%d.gamma" % i], p["norms_1.%d.beta" % i]))
             y = Conv1x1.apply(y, p["convs_1x1.%d.weight" % i], p["convs_1x1.%d.bias" % i])
             y = Gelu.apply(LayerNormRows.apply(y, p["norms_2.%d.gamma" % i], p["norms_2.%d.beta" % i]))
+            if self.dropout_p > 0 and self.training:
+                y = Dropout.apply(y, self.dropout_p, self.drop_seed, self.site0 + i)
             x = Add.apply(x, y)
         return Mask.apply(x, lens)
 
@@ -364,9 +388,10 @@ class StochasticDurationPredictor(_Module):
     """sdp.py:179-310, training direction: the negative log-likelihood (B,) of the durations dr under the flow, with variational dequantisation
     (posterior flows conditioned on text + duration encodings).  `noise` (B, 2, T): the N(0, 1) draw of :281 (drawn with torch when None)."""
 
-    def __init__(self, in_channels, hidden_channels, kernel_size, dropout_p, num_flows=4, cond_channels=0, language_emb_dim=0, device="cuda", seed=0):
-        if dropout_p:
-            raise NotImplementedError("StochasticDurationPredictor: dropout_p > 0 is not built")
+    def __init__(self, in_channels, hidden_channels, kernel_size, dropout_p, num_flows=4, cond_channels=0, language_emb_dim=0, device="cuda", seed=0,
+                 dropout_site_base=0):
+        """dropout_p: nn.Dropout inside `convs` and `post_convs` (sdp.py:227,237; the flows' own DilatedDepthSeparableConv have none, :144) — sites
+        dropout_site_base + {0, 1, 2} and + {3, 4, 5}."""
         if language_emb_dim:
             in_channels += language_emb_dim
         if in_channels % 4 or hidden_channels % 4 or (cond_channels or 0) % 4 or (language_emb_dim or 0) % 4:
@@ -387,12 +412,13 @@ class StochasticDurationPredictor(_Module):
                 self.p[name + "." + k] = v
             return m
         conv("pre", H, in_channels)
-        self.convs = sub("convs", DilatedDepthSeparableConv(H, kernel_size, 3, device=device, seed=seed + 1))
+        self.convs = sub("convs", DilatedDepthSeparableConv(H, kernel_size, 3, dropout_p=dropout_p, device=device, seed=seed + 1, dropout_site_base=dropout_site_base))
         conv("proj", H, H)
         self.flows = [sub("flows.0", ElementwiseAffine(2, device))] + [sub("flows.%d" % (i + 1), ConvFlow(2, H, kernel_size, 3, device=device, seed=seed + 10 + i))
                                                                        for i in range(num_flows)]
         conv("post_pre", H, 1)
-        self.post_convs = sub("post_convs", DilatedDepthSeparableConv(H, kernel_size, 3, device=device, seed=seed + 2))
+        self.post_convs = sub("post_convs", DilatedDepthSeparableConv(H, kernel_size, 3, dropout_p=dropout_p, device=device, seed=seed + 2,
+                                                                       dropout_site_base=dropout_site_base + 3))
         conv("post_proj", H, H)
         self.post_flows = [sub("post_flows.0", ElementwiseAffine(2, device))] + [sub("post_flows.%d" % (i + 1), ConvFlow(2, H, kernel_size, 3, device=device,
                                                                                                                       seed=seed + 20 + i)) for i in range(num_flows)]
@@ -402,6 +428,16 @@ class StochasticDurationPredictor(_Module):
         self.has_lang = bool(language_emb_dim)
         if self.has_lang:
             conv("cond_lang", H, language_emb_dim)
+
+    def set_dropout_seed(self, seed):
+        self.convs.drop_seed = self.post_convs.drop_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+
+    def train(self, mode=True):
+        self.convs.training = self.post_convs.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
 
     def __call__(self, x, x_mask, dr, g=None, lang_emb=None, noise=None):
         """x (B, C, T), x_mask (B, 1, T), dr (B, 1, T), g (B, Cg, 1), lang_emb (B, Cl, 1 or T), noise (B, 2, T) -> nll (B,)"""

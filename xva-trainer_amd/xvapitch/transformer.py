@@ -7,9 +7,12 @@ Same constructor arguments, state_dict keys and layouts as the reference module 
 the q / k / v projections are ONE xva_gemm against the stacked weights, conv_o and the k-tap feed-forward convolutions are xva_gemm calls in
 implicit-conv form (ReLU and the residual in the epilogue, the ReLU gate in the backward epilogue), the attention core and LayerNorm are
 csrc/xvapitch_ops.hip kernels.  Host code only sequences C calls; the module is one autograd Function, checked against the reference by
-output and by every parameter / input gradient (tests/test_xvapitch_gpu.py).  Not built: dropout_p > 0 (masks cannot match torch's RNG; the
-reference evaluates with dropout off), in_channels != hidden_channels, input_length, layer_norm
-type "1".
+output and by every parameter / input gradient (tests/test_xvapitch_gpu.py).  dropout_p > 0: nn.Dropout at the reference's four sites per
+layer — the attention weights (glow_tts.py:204, inside the attention kernels), the attention block's output (:473, the conv_o epilogue),
+the feed-forward hidden activation (:344, the conv_1 epilogue) and the feed-forward output (:477) — with masks from the keyed hash of
+csrc/xva_common.h: site `dropout_site_base + 4 * layer + {0, 1, 2, 3}` under the seed of set_dropout_seed() (a new one per training
+iteration), element index = position in the (B, H, T, T) weights / (row of the time-major sequence) * channels + channel; `training =
+False` switches it off (eval).  Not built: in_channels != hidden_channels, input_length, layer_norm type "1".
 """
 import ctypes as C
 
@@ -22,9 +25,11 @@ from .wn import PAD, Seq, conv_bwd_data, conv_bwd_weight, conv_fwd, _grad_hook, 
 lib = _lib.lib
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 lib.xva_relattn_fwd.restype = i32
-lib.xva_relattn_fwd.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, i64] + [i32] * 8 + [vp]
+lib.xva_relattn_fwd.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, i64] + [i32] * 8 + [f32, C.c_uint64, C.c_uint32, vp]
 lib.xva_relattn_bwd.restype = i32
-lib.xva_relattn_bwd.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp] + [i32] * 8 + [vp]
+lib.xva_relattn_bwd.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp] + [i32] * 8 + [f32, C.c_uint64, C.c_uint32, vp]
+lib.xva_dropout_apply.restype = i32
+lib.xva_dropout_apply.argtypes = [vp, vp, i32, i64, f32, C.c_uint64, C.c_uint32, vp]
 lib.xva_ln_rows_fwd.restype = i32
 lib.xva_ln_rows_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]
 lib.xva_ln_rows_bwd.restype = i32
@@ -37,6 +42,12 @@ def _p(t, elem_off=0):
 
 def _mask(s, lens):
     _lib.check(lib.xva_seq_mask(C.c_void_p(s.view.data_ptr()), s.dt, s.B, s.Tp, PAD, s.C, _lib.ptr(lens), _lib.stream_ptr()), "xva_seq_mask")
+
+
+def _drop(src, dst, p, seed, site):
+    """dst = nn.Dropout(src) over the rows of a sequence's view (element index = row * C + channel); the same call on a gradient is the backward"""
+    _lib.check(lib.xva_dropout_apply(C.c_void_p(src.view.data_ptr()), C.c_void_p(dst.view.data_ptr()), src.dt, src.rows * src.C, p, seed, site,
+                                     _lib.stream_ptr()), "xva_dropout_apply")
 
 
 def _tapmajor(w):
@@ -74,9 +85,10 @@ _KEYMAP = (("attn.", "attn_layers.%d."), ("ffn.", "ffn_layers.%d."), ("norm1.", 
 
 class RelativePositionTransformer:
     def __init__(self, in_channels, out_channels, hidden_channels, hidden_channels_ffn, num_heads, num_layers, kernel_size=1, dropout_p=0.0,
-                 rel_attn_window_size=None, input_length=None, layer_norm_type="1", device="cuda", seed=0, compute="fp32"):
-        if dropout_p:
-            raise NotImplementedError("RelativePositionTransformer: dropout_p > 0 is not built")
+                 rel_attn_window_size=None, input_length=None, layer_norm_type="1", device="cuda", seed=0, compute="fp32", dropout_site_base=0):
+        if not 0.0 <= dropout_p < 1.0:
+            raise ValueError("RelativePositionTransformer: dropout_p must be in [0, 1)")
+        self.dropout_p, self.site0, self.training, self.drop_seed = float(dropout_p), int(dropout_site_base), True, int(seed) + 0x5EED
         if in_channels != hidden_channels or not (out_channels == 1 or out_channels % 4 == 0):
             raise NotImplementedError("RelativePositionTransformer: in_channels must equal hidden_channels, out_channels 1 or a multiple of 4")
         if rel_attn_window_size is None or input_length is not None or layer_norm_type != "2":
@@ -139,6 +151,17 @@ class RelativePositionTransformer:
             for t in self.proj_g.values():
                 t.zero_()
 
+    def set_dropout_seed(self, seed):
+        """the seed of the NEXT forward's dropout masks (its backward reuses it); the trainer passes a new one every iteration"""
+        self.drop_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
     def __call__(self, x, x_mask):
         return _TransformerFn.apply(x, self, _lens_of(x, x_mask), _grad_hook(x.device))
 
@@ -163,8 +186,12 @@ class RelativePositionTransformer:
         dk = Cc // H
         self.saved = []
         mk = lambda ch: Seq(B, T, ch, self.device, torch.float32)
+        pd, seed = (self.dropout_p if self.training else 0.0), self.drop_seed
+        self.saved_drop = (pd, seed)
         for li, l in enumerate(self.layers):
             p = l.p
+            site = self.site0 + 4 * li
+            dkw = lambda s_: dict(drop_p=pd, drop_seed=seed, drop_stream=site + s_) if pd > 0 else {}
             last = li == self.L - 1
             Co = self.Co if last else Cc
             xm = mk(Cc); xm.store.copy_(x.store); _mask(xm, lens)                               # x = x * x_mask            (glow_tts.py:471)
@@ -177,11 +204,11 @@ class RelativePositionTransformer:
             base = PAD * 3 * Cc
             _lib.check(lib.xva_relattn_fwd(_p(qkv.view), _p(qkv.view, Cc), _p(qkv.view, 2 * Cc), 3 * Cc, _lib.ptr(p["attn.emb_rel_k"]),
                                            _lib.ptr(p["attn.emb_rel_v"]), _lib.ptr(lens), _lib.ptr(P), _p(att.view), Cc, B, T, H, dk, self.w, 1, x.Tp, PAD,
-                                           _lib.stream_ptr()), "xva_relattn_fwd")                # attention                 (:173-214)
+                                           pd, seed, site, _lib.stream_ptr()), "xva_relattn_fwd")   # attention, dropout(p_attn)  (:173-214)
             s1 = mk(Cc)
             wo = p["attn.conv_o.weight"].reshape(Cc, Cc).contiguous()
             _lib.gemm(att.store, wo, s1.store, att.rows, Cc, Cc, Cc, Cc, Cc, layout=_lib.GEMM_NT, compute=self.cmp, bias=p["attn.conv_o.bias"], a_offset=att.off(),
-                      c_offset=s1.off(), R=xm.view, ldr=Cc, mask_mode=_lib.MASK_PAD, Tp=x.Tp, mask_pad=PAD, mask_len=T)   # x + conv_o(..)  (:170,474)
+                      c_offset=s1.off(), R=xm.view, ldr=Cc, mask_mode=_lib.MASK_PAD, Tp=x.Tp, mask_pad=PAD, mask_len=T, **dkw(1))   # x + dropout(conv_o(..))  (:170,473-474)
             x1, m1, r1 = self._ln(s1, p["norm1.gamma"], p["norm1.beta"])                        # norm_layers_1             (:474)
             res = x1                                                                            # the residual branch of the second sub-layer
             if last and self.proj is not None:                                                  # x = proj(x)               (:479-480)
@@ -198,11 +225,13 @@ class RelativePositionTransformer:
             w1 = _tapmajor(p["ffn.conv_1.weight"]); w2 = _tapmajor(p["ffn.conv_2.weight"])
             _lib.gemm(x1m.store, w1, h.store, x1m.rows, F, k * Cc, Cc, k * Cc, F, layout=_lib.GEMM_NT, compute=self.cmp, bias=p["ffn.conv_1.bias"], relu=True,
                       a_offset=x1m.off(-P_), c_offset=h.off(), a_seglen=Cc if k > 1 else 0, a_segadj=0, mask_mode=_lib.MASK_PAD, Tp=x.Tp, mask_pad=PAD,
-                      mask_len=T)
+                      mask_len=T, **dkw(2))                                                     # dropout(relu(.)) = relu(dropout(.)): the scale is >= 0  (:343-344)
             _mask(h, lens)                                                                      # conv_2(pad(x * x_mask)) * x_mask    (:345-346)
             y2 = mk(Co)
             conv_fwd(h, w2, p["ffn.conv_2.bias"], y2, k, 1, self.cmp)
             _mask(y2, lens)
+            if pd > 0:
+                _drop(y2, y2, pd, seed, site + 3)                                               # y = dropout(ffn(x))      (:477)
             s2 = mk(Co)
             torch.add(res.store, y2.store, out=s2.store)                                        # norm_layers_2(x + y)     (:482)
             x2, m2, r2 = self._ln(s2, p["norm2.gamma"], p["norm2.beta"])
@@ -217,6 +246,7 @@ class RelativePositionTransformer:
         dk = Cc // H
         lens = self.lens
         mk = lambda ch: Seq(B, T, ch, self.device, torch.float32)
+        pd, seed = self.saved_drop
         dx = mk(self.Co); dx.store.copy_(d_out.store); _mask(dx, lens)
 
         def proj_bwd(dres, x1):
@@ -237,6 +267,8 @@ class RelativePositionTransformer:
             p, g = l.p, l.g
             last = li == self.L - 1
             Co = self.Co if last else Cc
+            site = self.site0 + 4 * li
+            dkw = lambda s_: dict(drop_p=pd, drop_seed=seed, drop_stream=site + s_) if pd > 0 else {}
             if last and Co == 1:
                 xm, wqkv, qkv, P, att, wo, s1, m1, r1, x1 = sv
                 dx1 = proj_bwd(dx, x1)
@@ -247,7 +279,9 @@ class RelativePositionTransformer:
                 ds2 = mk(Co)
                 _lib.check(lib.xva_ln_rows_bwd(_p(dx.view), _p(s2.view), _lib.ptr(m2), _lib.ptr(r2), _lib.ptr(p["norm2.gamma"]), _p(ds2.view), _lib.ptr(g["norm2.gamma"]),
                                                _lib.ptr(g["norm2.beta"]), dx.rows, Co, _lib.stream_ptr()), "xva_ln_rows_bwd")
-                dy2 = mk(Co); dy2.store.copy_(ds2.store); _mask(dy2, lens)                       # y2 = conv_2(..) * x_mask
+                dy2 = mk(Co); dy2.store.copy_(ds2.store); _mask(dy2, lens)                       # y2 = dropout(conv_2(..) * x_mask)
+                if pd > 0:
+                    _drop(dy2, dy2, pd, seed, site + 3)
                 dW2 = torch.zeros(Co, k * F, device=self.device)
                 conv_bwd_weight(dy2, h, dW2, g["ffn.conv_2.bias"], k, 1, self.cmp)
                 g["ffn.conv_2.weight"] += dW2.view(Co, k, F).permute(0, 2, 1)
@@ -256,7 +290,7 @@ class RelativePositionTransformer:
                 # d(conv_1 output) = (dy2 (*) W2) gated by relu (h is stored masked and post-ReLU: h > 0 is both the gate and the mask)
                 _lib.gemm(dy2.store, w2, dh.store, dy2.rows, F, k * Co, Co, k * F, F, layout=_lib.GEMM_NN, compute=self.cmp, a_offset=dy2.off(P_), c_offset=dh.off(),
                           a_seglen=Co if k > 1 else 0, a_segadj=-2 * Co if k > 1 else 0, seglen=Co if k > 1 else 0, seg0=0, segstride=F if k > 1 else 0,
-                          G=h.view, ldg=F, gate_slope=0.0, mask_mode=_lib.MASK_PAD, Tp=dy2.Tp, mask_pad=PAD, mask_len=T)
+                          G=h.view, ldg=F, gate_slope=0.0, mask_mode=_lib.MASK_PAD, Tp=dy2.Tp, mask_pad=PAD, mask_len=T, **dkw(2))
                 dW1 = torch.zeros(F, k * Cc, device=self.device)
                 conv_bwd_weight(dh, x1m, dW1, g["ffn.conv_1.bias"], k, 1, self.cmp)
                 g["ffn.conv_1.weight"] += dW1.view(F, k, Cc).permute(0, 2, 1)
@@ -269,18 +303,21 @@ class RelativePositionTransformer:
             ds1 = mk(Cc)
             _lib.check(lib.xva_ln_rows_bwd(_p(dx1.view), _p(s1.view), _lib.ptr(m1), _lib.ptr(r1), _lib.ptr(p["norm1.gamma"]), _p(ds1.view), _lib.ptr(g["norm1.gamma"]),
                                            _lib.ptr(g["norm1.beta"]), dx1.rows, Cc, _lib.stream_ptr()), "xva_ln_rows_bwd")
+            dyo = ds1                                                                            # s1 = x + dropout(conv_o(att))
+            if pd > 0:
+                dyo = mk(Cc); _drop(ds1, dyo, pd, seed, site + 1)
             dWo = torch.zeros(Cc, Cc, device=self.device)
-            conv_bwd_weight(ds1, att, dWo, g["attn.conv_o.bias"], 1, 1, self.cmp)
+            conv_bwd_weight(dyo, att, dWo, g["attn.conv_o.bias"], 1, 1, self.cmp)
             g["attn.conv_o.weight"] += dWo.view(Cc, Cc, 1)
             datt = mk(Cc)
-            conv_bwd_data(ds1, wo, datt, 1, 1, self.cmp, False)
+            conv_bwd_data(dyo, wo, datt, 1, 1, self.cmp, False)
             dqkv = mk(3 * Cc)
             dS = torch.empty_like(P)
             demb_k = g["attn.emb_rel_k"]; demb_v = g["attn.emb_rel_v"]
             _lib.check(lib.xva_relattn_bwd(_p(datt.view), Cc, _p(qkv.view), _p(qkv.view, Cc), _p(qkv.view, 2 * Cc), 3 * Cc, _lib.ptr(p["attn.emb_rel_k"]),
                                            _lib.ptr(p["attn.emb_rel_v"]), _lib.ptr(lens), _lib.ptr(P), _lib.ptr(dS), _p(dqkv.view), _p(dqkv.view, Cc),
                                            _p(dqkv.view, 2 * Cc), 3 * Cc, _lib.ptr(demb_k), _lib.ptr(demb_v), B, T, H, dk, self.w, 1, dx.Tp, PAD,
-                                           _lib.stream_ptr()), "xva_relattn_bwd")
+                                           pd, seed, site, _lib.stream_ptr()), "xva_relattn_bwd")
             dWqkv = torch.zeros(3 * Cc, Cc, device=self.device); dbqkv = torch.zeros(3 * Cc, device=self.device)
             conv_bwd_weight(dqkv, xm, dWqkv, dbqkv, 1, 1, self.cmp)
             for j, n in enumerate("qkv"):

@@ -334,7 +334,8 @@ class xVAPitchTrainer(object):
 
     def init_model(self, device):
         """xVAPitch(args) at the trainer's switches (`--big 1 --pitch 1 --pe_scaling 0.2`, xva_train.py:1098-1132,1421-1425; model.py:40-215)."""
-        kw = dict(n_vocab=N_SYMBOLS, num_languages=N_LANGUAGES, latent_size=256, embedded_language_dim=12, d_vector_dim=512, pitch=True, pe_scaling=0.2)
+        kw = dict(n_vocab=N_SYMBOLS, num_languages=N_LANGUAGES, latent_size=256, embedded_language_dim=12, d_vector_dim=512, pitch=True, pe_scaling=0.2,
+                  dropout_p=0.1, sdp_dropout_p=0.5)                 # text encoder / pitch predictor 0.1, duration predictor 0.5 (model.py:88,166,128)
         kw.update(self.model_kwargs)
         seg = kw.pop("spec_segment_size", 32)
         ac = AcousticTrainPath(device=device, compute=self.compute, **kw)
@@ -409,6 +410,8 @@ class xVAPitchTrainer(object):
             self.training_stage = self.force_stage
             self.print_and_log("Forcing stage: %d " % self.force_stage, save_to_file=self.dataset_output)
         self.epoch, self.total_steps_done = epoch, total_steps_done
+        # dropout masks: seeded like the other draws (1234 + rank, :367-368), offset by the steps already done so a resumed run does not replay masks
+        self.step.gen.acoustic.train().set_dropout_seed((1234 + self.rank) * 1000003 + total_steps_done)
         self.avg_disc_loss_per_epoch, self.avg_disc_loss_per_epoch_deltas = adl, adld
         # dataloaders (:1162-1260): the fine-tune set, and the priors sets when they are installed
         self.print_and_log("Workers: %s" % self.workers, save_to_file=self.dataset_output)
