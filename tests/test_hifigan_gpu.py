@@ -361,3 +361,62 @@ def test_bf16_discriminator_layers_against_the_storage_oracle(golden_dir):
     worst.sort(reverse=True)
     print("bf16 discriminators, teacher-forced: worst layers", worst[:4], "of", len(worst))
     assert len(worst) == 5 * 5 + 4 * 7
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 7])
+def test_generator_short_inputs(T):
+    """Fewer than 8 mel frames (the reference's Generator is a plain conv stack: any length runs, models.py:110-128): the engine against the
+    oracle on 1 - 7 frames, forward and parameter gradients."""
+    ohg, E, eng, g_sd, flat = _gen_setup("fp32")
+    x, _, _ = ohg.synth_batch(2, 4324)
+    x = x[:, :, :T].contiguous()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in g_sd.items()}
+    ref = ohg.generator(leaves, x).squeeze(1)
+    torch.manual_seed(0)
+    dw = torch.randn(ref.shape)
+    (ref * dw).sum().backward()
+    wav = eng.generator_forward(flat, x.cuda())
+    assert wav.shape == ref.shape == (2, T * 256)
+    assert (wav.cpu() - ref.detach()).abs().max().item() < 1e-3 * ref.abs().max().item()
+    grads = torch.zeros_like(flat)
+    eng.generator_backward(flat, grads, dw.cuda())
+    torch.cuda.synchronize()
+    mine = E.from_flat(grads, eng.table[E.G])
+    errs = sorted(((_nrel(mine[k], v.grad), k) for k, v in leaves.items()), reverse=True)
+    assert errs[0][0] < 2e-2 and errs[len(errs) // 2][0] < 3e-3, errs[:4]
+
+
+@pytest.mark.parametrize("seg", [256, 512, 1024, 1792])
+def test_discriminators_short_segments(seg):
+    """Segments shorter than 2048 samples through all eight discriminators (period 11 folds 256 samples into 24 rows; the scale discriminators'
+    pooled inputs shrink to 65 samples): D-step loss + gradients, G-step losses + the waveform gradient, against the oracle."""
+    ohg, E, eng, mpd_sd, msd_sd, flat, y, y_fake = _disc_setup("fp32")
+    y, y_fake = y[:, :seg].contiguous(), y_fake[:, :seg].contiguous()
+    pl = {k: v.clone().requires_grad_(True) for k, v in mpd_sd.items()}
+    sl = {k: (v.clone().requires_grad_(True) if k in ohg._leaves(msd_sd) else v.clone()) for k, v in msd_sd.items()}
+    r, g, _, _ = ohg.mpd(pl, y.unsqueeze(1), y_fake.unsqueeze(1))
+    lf = ohg.discriminator_loss(r, g)
+    r, g, _, _ = ohg.msd(sl, y.unsqueeze(1), y_fake.unsqueeze(1))
+    ls = ohg.discriminator_loss(r, g)
+    (lf + ls).backward()
+    flat_d = flat.clone()
+    losses = eng.disc_forward(flat_d, y.cuda(), y_fake.cuda())
+    grads = torch.zeros_like(flat_d)
+    eng.disc_backward_d(flat_d, grads)
+    torch.cuda.synchronize()
+    assert abs(losses[0].item() - (lf + ls).item()) < 1e-3 * (lf + ls).item()
+    mine = E.from_flat(grads, eng.table[E.D])
+    errs = sorted([(_nrel(mine["mpd." + k], v.grad), "mpd." + k) for k, v in pl.items()] +
+                  [(_nrel(mine["msd." + k], v.grad), "msd." + k) for k, v in sl.items() if v.requires_grad], reverse=True)
+    assert errs[0][0] < 5e-3, errs[:5]
+    yf = y_fake.clone().requires_grad_(True)
+    _, g_f, fr_f, fg_f = ohg.mpd(mpd_sd, y.unsqueeze(1), yf.unsqueeze(1))
+    _, g_s, fr_s, fg_s = ohg.msd(_clone(msd_sd), y.unsqueeze(1), yf.unsqueeze(1))
+    l_fm = ohg.feature_loss(fr_f, fg_f) + ohg.feature_loss(fr_s, fg_s)
+    l_gen = ohg.generator_loss(g_f) + ohg.generator_loss(g_s)
+    (l_fm + l_gen).backward()
+    losses = eng.disc_forward(flat.clone(), y.cuda(), y_fake.cuda())
+    d_wav = eng.disc_backward_g(flat)
+    torch.cuda.synchronize()
+    assert abs(losses[1].item() - l_gen.item()) < 1e-3 * l_gen.item() and abs(losses[2].item() - l_fm.item()) < 1e-3 * l_fm.item()
+    assert _nrel(d_wav, yf.grad) < 5e-3

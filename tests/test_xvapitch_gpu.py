@@ -829,3 +829,56 @@ def test_duration_predictor_dropout_against_oracle_with_the_same_masks(golden_di
     assert _rel(nll, nll_eval) > 1e-3
     dp.eval()
     assert _rel(dp(x.detach(), m_.cuda(), t("sdp_dr").cuda(), g=t("sdp_g").cuda(), lang_emb=t("sdp_le").cuda(), noise=t("sdp_noise").cuda()), nll_eval) < 1e-3
+
+
+@pytest.mark.parametrize("T", [1, 3, 7])
+def test_vits_decoder_short_latents(T):
+    """Fewer than 8 latent frames (< 2048 samples) through the waveform decoder — what inference on a short utterance needs — against the oracle:
+    waveform and parameter gradients."""
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+    sd = ohg.init_vits_decoder_sd(5, 192, 512)
+    dec = VitsDecoder(192, 512)
+    dec.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(6 + T)
+    z = torch.randn(2, 192, T, generator=gen); gv = torch.randn(2, 512, 1, generator=gen); r = torch.randn(2, 1, T * 256, generator=gen)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = ohg.vits_decoder(leaves, z, gv)
+    (yo * r).sum().backward()
+    dec.zero_grad()
+    y = dec(z.cuda(), gv.cuda())
+    assert tuple(y.shape) == (2, 1, T * 256)
+    (y * r.cuda()).sum().backward()
+    assert _rel(y, yo.detach()) < 1e-4
+    worst = sorted(((_rel(v, leaves[k].grad), k) for k, v in dec.grads().items()), reverse=True)
+    assert worst[0][0] < 2e-2 and worst[len(worst) // 2][0] < 1e-3, worst[:4]
+
+
+@pytest.mark.parametrize("seg", [256, 768, 1792])
+def test_vits_discriminator_short_segments(seg):
+    """Segments under 2048 samples through VitsDiscriminator (five period discriminators + the scale discriminator): the three losses and the
+    waveform gradient of the G pass against the oracle."""
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.xvapitch.discriminator import VitsDiscriminator
+    sd = ohg.init_vits_disc_sd(3)
+    D = VitsDiscriminator()
+    D.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(seg)
+    y = (torch.rand(2, 1, seg, generator=gen) * 1.6 - 0.8); yh = (0.3 * torch.randn(2, 1, seg, generator=gen)).clamp(-1, 1)
+    D.zero_grad()
+    loss_disc = float(D.d_pass(y.cuda(), yh.cuda()))
+    loss_gen, loss_feat, d_wav = D.g_pass(y.cuda(), yh.cuda())
+    torch.cuda.synchronize()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rs, fr, gs, fg = ohg.vits_disc(leaves, y, yh)
+    ld = ohg.discriminator_loss(rs, gs)
+    ld.backward()
+    yhg = yh.clone().requires_grad_(True)
+    rs, fr, gs, fg = ohg.vits_disc(sd, y, yhg)
+    lg, lf = ohg.generator_loss(gs), ohg.feature_loss(fr, fg)
+    (lg + lf).backward()
+    rel = lambda a, b: abs(float(a) - float(b)) / abs(float(b))
+    assert rel(loss_disc, ld) < 1e-4 and rel(loss_gen, lg) < 1e-4 and rel(loss_feat, lf) < 1e-4
+    assert _rel(d_wav.reshape(yhg.grad.shape), yhg.grad) < 2e-3
+    worst = sorted(((_rel(v, leaves[k].grad), k) for k, v in D.grads().items()), reverse=True)
+    assert worst[0][0] < 1e-2 and worst[len(worst) // 2][0] < 1e-3, worst[:4]

@@ -295,7 +295,7 @@ void plan_layer_grads(std::vector<Layer>& L, Bump& b, int64_t* begin, int64_t* e
 // gn / dn: the networks this plan serves — (null, null) = HiFi-GAN v1 generator + MPD + MSD; (vits decoder, null) = the decoder alone;
 // (null, vits discriminator) = VitsDiscriminator alone
 int make_plan(const xva_hg_dims* d, Plan* p, const GenNet* gn = nullptr, const DiscNet* dn = nullptr) {
-    XVA_CHECK_ARG(d && d->B > 0 && d->seg >= 2048 && d->seg % 256 == 0, "hifigan: bad dims (segment must be a multiple of 256, >= 2048)");
+    XVA_CHECK_ARG(d && d->B > 0 && d->seg >= 256 && d->seg % 256 == 0, "hifigan: bad dims (segment must be a positive multiple of 256)");
     XVA_CHECK_ARG(d->dt == XVA_F32 || d->dt == XVA_BF16, "hifigan: bad dtype");
     p->B = d->B; p->seg = d->seg; p->dt = d->dt; p->es = d->dt == XVA_BF16 ? 2 : 4;
     const int es = p->es, B = d->B;

@@ -42,9 +42,7 @@ class Generator:
         return self
 
     def __call__(self, mel):
-        """mel (B, 80, T) -> waveform (B, 1, T * 256) (models.py:110-128).  T >= 8 frames (one engine tile)."""
-        if mel.size(2) < 8:
-            raise NotImplementedError("generator inference needs >= 8 mel frames (got %d)" % mel.size(2))
+        """mel (B, 80, T) -> waveform (B, 1, T * 256) (models.py:110-128), any T >= 1."""
         with torch.no_grad():
             return self.eng.generator_forward(self.flat, mel.to(self.device)).unsqueeze(1)
 

@@ -6,7 +6,7 @@ the trainer runs (python/xvapitch/model.py:313-315 generator side, :366-384 disc
     loss_disc = D.d_pass(y, y_hat)                    # discriminator_loss(D(y), D(y_hat)); parameter gradients accumulate in D.grads()
     loss_gen, loss_feat, d_wav = D.g_pass(y, y_hat)   # generator_loss + feature_loss x 2 and their gradient w.r.t. y_hat
 
-y, y_hat: (B, seg) or (B, 1, seg) fp32 device tensors, seg a multiple of 256 (>= 2048).  One C call per forward / backward
+y, y_hat: (B, seg) or (B, 1, seg) fp32 device tensors, seg a positive multiple of 256.  One C call per forward / backward
 (xva_vits_disc_forward / _backward_d / _backward_g); no CPU fallback."""
 import ctypes as C
 
