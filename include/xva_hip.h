@@ -50,6 +50,10 @@ typedef struct xva_mel_config {
 
 /* Number of frames T for clips of N samples, or -1 on bad arguments. */
 int xva_mel_num_frames(const xva_mel_config* cfg, int N);
+/* Diagnostics / test knob: 0 (default) = the windowed DFT of every frame is a 1024-point real FFT wherever n_fft == 1024 (all three reference
+ * configurations); 1 = always the dense GEMM against the windowed DFT basis (the reference's own formulation; also env XVA_MEL_DFT=1).  Returns
+ * the previous mode. */
+int xva_mel_set_dft(int mode);
 int64_t xva_mel_workspace_bytes(const xva_mel_config* cfg, int B, int N);
 /* wav:  (B, N) fp32 in [-1, 1], row stride ld_wav.
  * dft_basis: (2*(n_fft/2+1), n_fft) fp32 = [real rows | imag rows] of the windowed DFT, the

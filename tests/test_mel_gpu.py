@@ -127,3 +127,47 @@ def test_linear_spectrogram_ragged_equals_per_clip_spectrograms():
     gp = GeneratorPass.__new__(GeneratorPass); gp.stft = stft
     y, yl, wf = gp.batch_from_wav(wavs.cuda(), torch.tensor(lens).cuda())
     assert torch.equal(y, lin) and wf.shape == (len(lens), 1, y.size(2) * 256) and torch.equal(wf[:, 0, :max(lens)].cpu(), wavs) and float(wf[:, 0, max(lens):].abs().max()) == 0.0
+
+
+def test_fft_front_end_against_the_dense_dft_and_the_oracle():
+    """The windowed DFT runs as a 1024-point real FFT per frame (csrc/mel.hip xva_stft_fft1024_kernel); xva_mel_set_dft(1) switches back to the
+    reference's own formulation, the GEMM against the windowed DFT basis.  Both against the oracle (TacotronSTFT log-mels at 1e-3; measured 7e-6 /
+    2e-6), against each other on the log-mels and on the 513-bin linear
+    spectrogram (|X| relative 2e-5 of the clip's peak bin), and timed on FastPitch's bench batch (32 clips x 219 904 samples)."""
+    from oracle import mel as omel
+    from xva_trainer_amd import _lib
+    from xva_trainer_amd.mel import TacotronSTFT, TorchSTFTMel
+    _lib.lib.xva_mel_set_dft.restype = int
+    y = _waves([44032, 30000, 9000])
+    ref = omel.mel_m1(y)
+    st = TacotronSTFT().cuda()
+    m3 = TorchSTFTMel(1024, 256, 1024, sample_rate=22050, mel_fmin=0.0, mel_fmax=8000.0, n_mels=80)
+    out, lin = {}, {}
+    for mode in (0, 1):
+        old = _lib.lib.xva_mel_set_dft(mode)
+        try:
+            out[mode] = st.mel_spectrogram(y.cuda()).cpu()
+            lin[mode] = m3.linear(y.cuda()).cpu()
+        finally:
+            _lib.lib.xva_mel_set_dft(old)
+    e_fft, e_dft = (out[0] - ref).abs().max().item(), (out[1] - ref).abs().max().item()
+    print("log-mel max error vs the oracle: FFT %.2e, dense DFT %.2e" % (e_fft, e_dft))
+    assert e_fft < ATOL and e_dft < ATOL and not torch.equal(out[0], out[1])
+    assert (out[0] - out[1]).abs().max().item() < ATOL
+    assert ((lin[0] - lin[1]).abs().amax((1, 2)) / lin[1].amax((1, 2))).max().item() < 2e-5
+    big = torch.from_numpy(np.stack([omel.synth_wave(219904, 50 + i) for i in range(4)])).cuda().repeat(8, 1)
+    t = {}
+    for mode in (0, 1):
+        old = _lib.lib.xva_mel_set_dft(mode)
+        try:
+            st.mel_spectrogram(big); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                st.mel_spectrogram(big)
+            e1.record(); torch.cuda.synchronize()
+            t[mode] = e0.elapsed_time(e1) / 10 * 1e3
+        finally:
+            _lib.lib.xva_mel_set_dft(old)
+    print("mel front end, 32 x 219 904 samples -> 27 520 frames: FFT %.0f us, dense DFT %.0f us" % (t[0], t[1]))
+    assert t[0] < 0.5 * t[1]

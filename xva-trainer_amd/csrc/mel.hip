@@ -7,12 +7,11 @@
 //   M2 mel_spectrogram                python/hifigan/meldataset.py:217-240
 //   M3 TorchSTFT.__call__             python/xvapitch/audio.py:138-181
 //
-// MI355X mapping: the reference's own formulation (a strided conv1d with a windowed DFT
-// basis) is a GEMM whose A operand is the reflect-padded waveform read with OVERLAPPING rows
-// (lda = hop, K = n_fft), so frames are never materialised: each sample is read from HBM
-// once per K-tile pass and lives in L2/LDS for its 4 overlapping frames.  The product runs
-// on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32); bf16 would not hold the 1e-3 log-mel
-// tolerance.  Pipeline:  reflect-pad -> DFT GEMM (re | im) -> magnitude -> mel GEMM with
+// MI355X mapping: frames are never materialised — the reflect-padded waveform is read with OVERLAPPING rows (row pitch = hop), each sample
+// from HBM once, from L2 for its 4 overlapping frames.  The windowed DFT is a 1024-point real FFT, one wavefront per frame
+// (xva_stft_fft1024_kernel below: HBM-bound on the spectrum it writes); n_fft != 1024 or XVA_MEL_DFT=1 take the reference's own formulation,
+// a GEMM against the windowed DFT basis on the exact-fp32 MFMA (bf16 would not hold the 1e-3 log-mel tolerance) — that GEMM is also what the
+// differentiable mel's backward uses.  Pipeline:  reflect-pad -> DFT (re | im) -> magnitude -> mel GEMM with
 // the log-clamp fused in its epilogue, written directly in the reference's (B, n_mel, T)
 // layout (the mel GEMM is batched per clip with the filterbank as its A operand).
 #include "xva_common.h"
@@ -55,6 +54,97 @@ __global__ void xva_magnitude_kernel(const float* __restrict__ spec, float* __re
     mag[idx] = v;
 }
 
+
+// ---- the windowed DFT of every frame as a 1024-point real FFT (one wavefront per frame) ------------------------------------------------------
+// The reference's STFT is torch.stft / a conv1d with a windowed DFT basis; as a dense GEMM it costs 2 * 1024 * 1026 flops per frame on the
+// exact-fp32 MFMA (0.95 ms for FastPitch's 27 520-frame batch, the whole front end's time).  The same 513 bins from an FFT are ~30 kflop per
+// frame and the kernel is bound by the spectrum it writes.  Per frame: z[n] = (w x)[2n] + i (w x)[2n + 1], n < 512; Z = FFT_512(z) as three
+// radix-8 passes (512 = 8 * 8 * 8; lane l of the wave owns 8 points per pass, the two regroupings go through LDS); then
+// X[k] = (Z[k] + conj Z[512 - k]) / 2 - i W_1024^k (Z[k] - conj Z[512 - k]) / 2, k = 0 .. 512.  The window is row 0 of the caller's basis
+// (cos(0) * w[n]); twiddles W_1024^m are computed once per workgroup into LDS (sincospif: 1 ulp).  Output: the DFT GEMM's layout,
+// spec[frame][re(0 .. nb - 1) | im(0 .. nb - 1)] with the GEMM's sign (im = -sum x w sin), so every consumer is unchanged.
+#define FFT_WAVES 4
+struct cf { float x, y; };
+__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cf cmni(cf a) { return {a.y, -a.x}; }                 // a * (-i)
+__device__ __forceinline__ void dft8(cf* a) {                                     // in place, natural order in and out, forward (e^{-2 pi i nk / 8})
+    const float h = 0.70710678118654752440f;
+    cf t0 = cadd(a[0], a[4]), t1 = csub(a[0], a[4]), t2 = cadd(a[2], a[6]), t3 = cmni(csub(a[2], a[6]));
+    cf t4 = cadd(a[1], a[5]), t5 = csub(a[1], a[5]), t6 = cadd(a[3], a[7]), t7 = cmni(csub(a[3], a[7]));
+    cf u0 = cadd(t0, t2), u2 = csub(t0, t2), u1 = cadd(t1, t3), u3 = csub(t1, t3);
+    cf v0 = cadd(t4, t6), v2 = cmni(csub(t4, t6)), v1 = cadd(t5, t7), v3 = csub(t5, t7);
+    v1 = {h * (v1.x + v1.y), h * (v1.y - v1.x)};                                  // * W8   = (1 - i) / sqrt 2
+    v3 = {h * (v3.y - v3.x), -h * (v3.x + v3.y)};                                 // * W8^3 = (-1 - i) / sqrt 2
+    a[0] = cadd(u0, v0); a[4] = csub(u0, v0); a[1] = cadd(u1, v1); a[5] = csub(u1, v1);
+    a[2] = cadd(u2, v2); a[6] = csub(u2, v2); a[3] = cadd(u3, v3); a[7] = csub(u3, v3);
+}
+__global__ __launch_bounds__(64 * FFT_WAVES) void xva_stft_fft1024_kernel(const float* __restrict__ ypad, const float* __restrict__ window, float* __restrict__ spec,
+                                                                          int B, int T, int hop, int64_t ldy, int64_t lds, int nb) {
+    __shared__ cf tw[1024];                                                       // W_1024^m = e^{-2 pi i m / 1024}
+    __shared__ cf buf[FFT_WAVES][584];                                            // per-wave exchange (8 x 72 / 64 x 9 padded) and the 513-point spectrum
+    for (int m = threadIdx.x; m < 1024; m += 64 * FFT_WAVES) { float sn, cs; sincospif(-(float)m * (1.0f / 512.0f), &sn, &cs); tw[m] = {cs, sn}; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    cf* sb = buf[wave];
+    const int n2 = lane >> 3, n3 = lane & 7;                                      // pass 1: lane = (n2, n3); pass 2: lane = (k1, n3) ; pass 3: lane = k1 + 8 k2
+    float2 w2[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) w2[n1] = *reinterpret_cast<const float2*>(window + 2 * (64 * n1 + lane));
+    __syncthreads();
+    const int64_t nframes = (int64_t)B * T;
+    const int64_t per = (int64_t)gridDim.x * FFT_WAVES;
+    const int64_t iters = (nframes + per - 1) / per;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t f = it * per + (int64_t)blockIdx.x * FFT_WAVES + wave;
+        const bool live = f < nframes;
+        const int b = live ? (int)(f / T) : 0, t = live ? (int)(f - (int64_t)b * T) : 0;
+        const float* x = ypad + (int64_t)b * ldy + (int64_t)t * hop;
+        cf a[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {                                          // hop % 4 == 0 and ldy % 4 == 0: 8-byte aligned
+            const float2 v = *reinterpret_cast<const float2*>(x + 2 * (64 * n1 + lane));
+            a[n1] = {v.x * w2[n1].x, v.y * w2[n1].y};
+        }
+        dft8(a);                                                                  // over n1: A[k1; n2, n3]
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) sb[72 * k1 + lane] = k1 ? cmul(a[k1], tw[(16 * n2 * k1) & 1023]) : a[0];     // * W_64^{n2 k1}
+        __syncthreads();
+        const int k1 = lane >> 3;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = sb[72 * k1 + 8 * q + n3];              // over n2
+        dft8(a);                                                                  // B[k1, k2; n3]
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) sb[9 * (k1 + 8 * k2) + n3] = cmul(a[k2], tw[(2 * n3 * (k1 + 8 * k2)) & 1023]);   // * W_512^{n3 (k1 + 8 k2)}
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = sb[9 * lane + q];                      // over n3
+        dft8(a);                                                                  // Z[lane + 64 k3]
+        __syncthreads();
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) sb[lane + 64 * k3] = a[k3];
+        if (lane == 0) sb[512] = a[0];                                            // Z[512] = Z[0]
+        __syncthreads();
+        if (live) {
+            float* row = spec + f * lds;
+#pragma unroll
+            for (int k3 = 0; k3 <= 8; ++k3) {
+                const int k = lane + 64 * k3;
+                if (k3 == 8 && lane != 0) break;
+                const cf zk = sb[k], zc = sb[512 - k];
+                const cf e = {0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y)};        // (Z[k] + conj Z[512 - k]) / 2
+                const cf d = {0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y)};        // (Z[k] - conj Z[512 - k]) / 2
+                const cf o = cmul(cmni(d), tw[k]);                                // -i W^k (.)
+                if (k < nb) { row[k] = e.x + o.x; row[nb + k] = e.y + o.y; }
+            }
+        }
+        __syncthreads();
+    }
+}
+// g_mel_dft: 1 = always the dense DFT GEMM (XVA_MEL_DFT=1 / xva_mel_set_dft); default the FFT wherever n_fft == 1024 (all three variants)
+static int g_mel_dft = [] { const char* e = getenv("XVA_MEL_DFT"); return e ? atoi(e) : 0; }();
+extern "C" int xva_mel_set_dft(int mode) { int old = g_mel_dft; g_mel_dft = mode; return old; }
 static inline int64_t al4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 static inline int64_t al32(int64_t x) { return (x + 31) & ~(int64_t)31; }
 
@@ -79,6 +169,27 @@ static int mel_plan(const xva_mel_config* c, int B, int N, MelPlan* pl) {
     pl->off_mag = pl->off_spec + (int64_t)B * pl->T * pl->lds;
     pl->total = pl->off_mag + (int64_t)B * pl->T * pl->ldm;
     return XVA_OK;
+}
+
+// spec[b][t][re | im] = windowed DFT of frame t of clip b: the 1024-point FFT kernel, or (other sizes, XVA_MEL_DFT=1) the overlapping-row GEMM
+static int stft_spec(const xva_mel_config* c, const MelPlan& pl, int B, const float* ypad, const float* dft_basis, float* spec, void* stream) {
+    if (c->n_fft == 1024 && !g_mel_dft && c->hop % 4 == 0) {
+        const int64_t nframes = (int64_t)B * pl.T;
+        int64_t grid = (nframes + FFT_WAVES - 1) / FFT_WAVES;
+        if (grid > 256 * 8) grid = 256 * 8;
+        hipLaunchKernelGGL(xva_stft_fft1024_kernel, dim3((unsigned)grid), dim3(64 * FFT_WAVES), 0, (hipStream_t)stream, ypad, dft_basis, spec, B, pl.T, c->hop,
+                           pl.ldy, pl.lds, pl.nb);
+        XVA_LAUNCH_CHECK();
+        return XVA_OK;
+    }
+    xva_gemm_params g;
+    memset(&g, 0, sizeof(g));
+    g.A = ypad; g.B = dft_basis; g.C = spec;
+    g.M = pl.T; g.N = 2 * pl.nb; g.K = c->n_fft;
+    g.lda = c->hop; g.ldb = c->n_fft; g.ldc = pl.lds;
+    g.batch = B; g.sA = pl.ldy; g.sB = 0; g.sC = (int64_t)pl.T * pl.lds;
+    g.alpha = 1.f; g.splitk = 1; g.compute = 0; g.layout = XVA_GEMM_NT;
+    return xva_gemm(&g, stream);
 }
 
 extern "C" int xva_mel_num_frames(const xva_mel_config* c, int N) {
@@ -160,16 +271,7 @@ static int mel_core(const xva_mel_config* c, const MelPlan& pl, int B, const flo
     float* ypad = workspace + pl.off_pad;
     float* spec = workspace + pl.off_spec;
     float* mag = workspace + pl.off_mag;
-    {   // 2. windowed DFT as an overlapping-row GEMM: spec[b][t][:] = frames[b][t][:] . basis^T
-        xva_gemm_params g;
-        memset(&g, 0, sizeof(g));
-        g.A = ypad; g.B = dft_basis; g.C = spec;
-        g.M = pl.T; g.N = 2 * pl.nb; g.K = c->n_fft;
-        g.lda = c->hop; g.ldb = c->n_fft; g.ldc = pl.lds;
-        g.batch = B; g.sA = pl.ldy; g.sB = 0; g.sC = (int64_t)pl.T * pl.lds;
-        g.alpha = 1.f; g.splitk = 1; g.compute = 0; g.layout = XVA_GEMM_NT;
-        XVA_TRY(xva_gemm(&g, stream));
-    }
+    XVA_TRY(stft_spec(c, pl, B, ypad, dft_basis, spec, stream));   // 2. windowed DFT of every frame: spec[b][t][re | im]
     {   // 3. magnitude
         int64_t rows = (int64_t)B * pl.T;
         int64_t total = rows * pl.ldm;
@@ -228,14 +330,7 @@ extern "C" int xva_linear_spectrogram(const xva_mel_config* c, const float* wav,
     float* spec = workspace + pl.off_spec;
     hipLaunchKernelGGL(xva_reflect_pad_kernel, dim3(xva_cdiv((int64_t)B * pl.ldy, 256)), dim3(256), 0, st, wav, ypad, B, N, c->pad, ld_wav, pl.ldy, pl.Np);
     XVA_LAUNCH_CHECK();
-    xva_gemm_params g;
-    memset(&g, 0, sizeof(g));
-    g.A = ypad; g.B = dft_basis; g.C = spec;
-    g.M = pl.T; g.N = 2 * pl.nb; g.K = c->n_fft;
-    g.lda = c->hop; g.ldb = c->n_fft; g.ldc = pl.lds;
-    g.batch = B; g.sA = pl.ldy; g.sB = 0; g.sC = (int64_t)pl.T * pl.lds;
-    g.alpha = 1.f; g.splitk = 1; g.compute = 0; g.layout = XVA_GEMM_NT;
-    XVA_TRY(xva_gemm(&g, stream));
+    XVA_TRY(stft_spec(c, pl, B, ypad, dft_basis, spec, stream));
     hipLaunchKernelGGL(xva_magnitude_t_kernel, dim3(xva_cdiv(pl.T, 32), xva_cdiv(pl.nb, 32), B), dim3(256), 0, st, spec, lin_out, pl.T, pl.nb, pl.lds,
                        c->mag_eps_add, c->mag_clamp_min);
     XVA_LAUNCH_CHECK();
@@ -279,14 +374,7 @@ extern "C" int xva_linear_spectrogram_ragged(const xva_mel_config* c, const floa
     hipLaunchKernelGGL(xva_reflect_pad_f32_ragged_kernel, dim3((unsigned)(pl.ldy / 256 < 1 ? 1 : (pl.ldy / 256 > 128 ? 128 : pl.ldy / 256)), B), dim3(256), 0, st,
                        wav, ld_wav, n_samples, ypad, c->pad, pl.ldy, n_frames_out, c->n_fft, c->hop);
     XVA_LAUNCH_CHECK();
-    xva_gemm_params g;
-    memset(&g, 0, sizeof(g));
-    g.A = ypad; g.B = dft_basis; g.C = spec;
-    g.M = pl.T; g.N = 2 * pl.nb; g.K = c->n_fft;
-    g.lda = c->hop; g.ldb = c->n_fft; g.ldc = pl.lds;
-    g.batch = B; g.sA = pl.ldy; g.sB = 0; g.sC = (int64_t)pl.T * pl.lds;
-    g.alpha = 1.f; g.splitk = 1; g.compute = 0; g.layout = XVA_GEMM_NT;
-    XVA_TRY(xva_gemm(&g, stream));
+    XVA_TRY(stft_spec(c, pl, B, ypad, dft_basis, spec, stream));
     hipLaunchKernelGGL(xva_magnitude_t_kernel, dim3(xva_cdiv(pl.T, 32), xva_cdiv(pl.nb, 32), B), dim3(256), 0, st, spec, lin_out, pl.T, pl.nb, pl.lds,
                        c->mag_eps_add, c->mag_clamp_min);
     XVA_LAUNCH_CHECK();
