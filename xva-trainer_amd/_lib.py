@@ -112,13 +112,11 @@ def _dt(t):
     raise XvaError("unsupported dtype %s" % t.dtype)
 
 
-def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batch=1, sA=0, sB=0, sC=0, alpha=1.0, beta=1.0,
-         bias=None, relu=False, act=ACT_NONE, act_slope=0.0, R=None, ldr=0, sR=0, G=None, ldg=0, sG=0, gate_slope=0.0,
-         mask_mode=MASK_NONE, lens=None, Tp=0, mask_pad=1, mask_len=0, mask_mul=1, mask_add=0, accumulate=False, splitk=1, seglen=0, seg0=0, segstride=0,
-         a_seglen=0, a_segadj=0, a_lrelu=None, b_lrelu=None, a_offset=0, b_offset=0, c_offset=0, batch2=1, sA2=0, sB2=0, sC2=0, sR2=0, sG2=0,
-         sk_ws=None, **extra):
-    """Thin test/utility wrapper over xva_gemm. `a_offset` / `b_offset` (elements) shift the base pointers (negative for
-    the overlapping-row conv forms).  Storage dtypes are taken from the tensors."""
+def _fill_gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batch=1, sA=0, sB=0, sC=0, alpha=1.0, beta=1.0,
+               bias=None, relu=False, act=ACT_NONE, act_slope=0.0, R=None, ldr=0, sR=0, G=None, ldg=0, sG=0, gate_slope=0.0,
+               mask_mode=MASK_NONE, lens=None, Tp=0, mask_pad=1, mask_len=0, mask_mul=1, mask_add=0, accumulate=False, splitk=1, seglen=0, seg0=0, segstride=0,
+               a_seglen=0, a_segadj=0, a_lrelu=None, b_lrelu=None, a_offset=0, b_offset=0, c_offset=0, batch2=1, sA2=0, sB2=0, sC2=0, sR2=0, sG2=0,
+               sk_ws=None, **extra):
     require_cuda(A, B, Cm, bias, R, G, lens)
     p = GemmParams()
     p.A = A.data_ptr() + A.element_size() * a_offset
@@ -155,4 +153,35 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batch=1, s
         p.sk_ws, p.sk_ws_bytes = sk_ws.data_ptr(), sk_ws.numel() * sk_ws.element_size()
     for k, v in extra.items():          # any further xva_gemm_params field by name (c_trans, kb_len, drop_p, ...)
         setattr(p, k, v)
-    check(lib.xva_gemm(C.byref(p), stream_ptr()), "xva_gemm")
+    return p
+
+
+def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, **kw):
+    """Thin test/utility wrapper over xva_gemm (keywords: see _fill_gemm). `a_offset` / `b_offset` / `c_offset` (elements) shift the base
+    pointers (negative for the overlapping-row conv forms).  Storage dtypes are taken from the tensors."""
+    check(lib.xva_gemm(C.byref(_fill_gemm(A, B, Cm, M, N, K, lda, ldb, ldc, **kw)), stream_ptr()), "xva_gemm")
+
+
+class PreparedGemm:
+    """One xva_gemm call site with everything but the operand addresses fixed: the parameter block is filled once (from exemplar tensors) and
+    run() patches the pointers — the Python-sequenced paths (xvapitch/wn.py, transformer.py) issue ~1 000 GEMMs per iteration and filling the
+    60-field block through ctypes dominated their host time."""
+    __slots__ = ("p", "ref", "oa", "ob", "oc")
+
+    def __init__(self, A, B, Cm, *args, a_offset=0, b_offset=0, c_offset=0, **kw):
+        self.p = _fill_gemm(A, B, Cm, *args, a_offset=a_offset, b_offset=b_offset, c_offset=c_offset, **kw)
+        self.ref = C.byref(self.p)
+        self.oa, self.ob, self.oc = A.element_size() * a_offset, B.element_size() * b_offset, Cm.element_size() * c_offset
+
+    def run(self, A, B, Cm, bias=None, R=None, G=None):
+        """same dtypes / shapes as the exemplars; bias / R / G only if the call was prepared with them"""
+        p = self.p
+        p.A, p.B, p.C = A.data_ptr() + self.oa, B.data_ptr() + self.ob, Cm.data_ptr() + self.oc
+        if bias is not None:
+            p.bias = bias.data_ptr()
+        if R is not None:
+            p.R = R.data_ptr()
+        if G is not None:
+            p.G = G.data_ptr()
+        if lib.xva_gemm(self.ref, stream_ptr()) != 0:
+            check(-1, "xva_gemm")

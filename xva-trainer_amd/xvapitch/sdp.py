@@ -122,14 +122,27 @@ class LayerNormRows(torch.autograd.Function):
         return dx, rg, rb
 
 
+_PREP = {}
+
+
+def _prep(key, make):
+    pg = _PREP.get(key)
+    if pg is None:
+        if len(_PREP) > 1024:
+            _PREP.clear()
+        pg = _PREP[key] = make()
+    return pg
+
+
 class Conv1x1(torch.autograd.Function):
-    """nn.Conv1d(Cin, Cout, 1) on (B, T, Cin): one xva_gemm each for y, dx and dw (Cin, Cout multiples of 4)."""
+    """nn.Conv1d(Cin, Cout, 1) on (B, T, Cin): one xva_gemm each for y, dx and dw (Cin, Cout multiples of 4); the three call sites are prepared
+    once per (rows, Cin, Cout) (_lib.PreparedGemm)."""
     @staticmethod
     def forward(ctx, x, w, b):
         x = x.contiguous(); Cin = x.size(-1); rows = x.numel() // Cin; Cout = w.size(0)
         w2 = w.reshape(Cout, Cin).contiguous()
         y = torch.empty(*x.shape[:-1], Cout, device=x.device)
-        _lib.gemm(x, w2, y, rows, Cout, Cin, Cin, Cin, Cout, layout=_lib.GEMM_NT, compute=0, bias=b)
+        _prep((0, rows, Cin, Cout, b is not None), lambda: _lib.PreparedGemm(x, w2, y, rows, Cout, Cin, Cin, Cin, Cout, layout=_lib.GEMM_NT, compute=0, bias=b)).run(x, w2, y, bias=b)
         ctx.save_for_backward(x, w2); ctx.wshape = tuple(w.shape); ctx.params = (w, b)
         return y
 
@@ -138,9 +151,10 @@ class Conv1x1(torch.autograd.Function):
         x, w2 = ctx.saved_tensors
         dy = dy.contiguous(); Cin = x.size(-1); rows = x.numel() // Cin; Cout = w2.size(0)
         dx = torch.empty_like(x)
-        _lib.gemm(dy, w2, dx, rows, Cin, Cout, Cout, Cin, Cin, layout=_lib.GEMM_NN, compute=0)
+        _prep((1, rows, Cin, Cout), lambda: _lib.PreparedGemm(dy, w2, dx, rows, Cin, Cout, Cout, Cin, Cin, layout=_lib.GEMM_NN, compute=0)).run(dy, w2, dx)
         (dw, rw), (db, rb) = _gbuf(ctx.params[0]), _gbuf(ctx.params[1])
-        _lib.gemm(dy, x, dw, Cout, Cin, rows, Cout, Cin, Cin, layout=_lib.GEMM_TN, compute=0, accumulate=True, splitk=0)
+        _prep((2, rows, Cin, Cout), lambda: _lib.PreparedGemm(dy, x, dw, Cout, Cin, rows, Cout, Cin, Cin, layout=_lib.GEMM_TN, compute=0, accumulate=True,
+                                                             splitk=0)).run(dy, x, dw)
         _lib.check(lib.xva_hg_colsum(P(dy), 0, P(db), rows, Cout, 1.0, ST()), "xva_hg_colsum")
         return dx, (rw.view(ctx.wshape) if rw is not None else None), rb
 

@@ -120,29 +120,51 @@ class Seq:
         return (GUARD + row) * self.C
 
 
+_PREP = {}
+
+
+def _prepared(key, make):
+    """xva_gemm call sites of the sequence convolutions, prepared once per geometry (_lib.PreparedGemm)"""
+    pg = _PREP.get(key)
+    if pg is None:
+        if len(_PREP) > 4096:
+            _PREP.clear()
+        pg = _PREP[key] = make()
+    return pg
+
+
 def conv_fwd(x, w_eff, bias, y, k, d, compute):
     """y = conv1d(x; k taps, dilation d, 'same' padding) + bias on all rows (pad rows of y are zeroed by the epilogue mask)."""
-    P = d * (k - 1) // 2
     Cin, Cout = x.C, y.C
-    _lib.gemm(x.store, w_eff, y.store, x.rows, Cout, k * Cin, Cin, k * Cin, Cout, layout=_lib.GEMM_NT, compute=compute, bias=bias,
-              a_offset=x.off(-P), c_offset=y.off(), a_seglen=Cin if k > 1 else 0, a_segadj=d * Cin - Cin if k > 1 else 0,
-              mask_mode=_lib.MASK_PAD, Tp=x.Tp, mask_pad=PAD, mask_len=x.T)
+    key = (0, x.B, x.T, Cin, Cout, k, d, compute, x.dt, y.dt, w_eff.dtype)
+    def make():
+        P = d * (k - 1) // 2
+        return _lib.PreparedGemm(x.store, w_eff, y.store, x.rows, Cout, k * Cin, Cin, k * Cin, Cout, layout=_lib.GEMM_NT, compute=compute, bias=bias,
+                                 a_offset=x.off(-P), c_offset=y.off(), a_seglen=Cin if k > 1 else 0, a_segadj=d * Cin - Cin if k > 1 else 0,
+                                 mask_mode=_lib.MASK_PAD, Tp=x.Tp, mask_pad=PAD, mask_len=x.T)
+    _prepared(key, make).run(x.store, w_eff, y.store, bias=bias)
 
 
 def conv_bwd_data(dy, w_eff, dx, k, d, compute, accumulate):
-    P = d * (k - 1) // 2
     Cout, Cin = dy.C, dx.C
-    _lib.gemm(dy.store, w_eff, dx.store, dy.rows, Cin, k * Cout, Cout, k * Cin, Cin, layout=_lib.GEMM_NN, compute=compute, a_offset=dy.off(P),
-              c_offset=dx.off(), a_seglen=Cout if k > 1 else 0, a_segadj=-d * Cout - Cout if k > 1 else 0, seglen=Cout if k > 1 else 0, seg0=0,
-              segstride=Cin if k > 1 else 0, accumulate=accumulate, mask_mode=_lib.MASK_PAD, Tp=dy.Tp, mask_pad=PAD, mask_len=dy.T)
+    key = (1, dy.B, dy.T, Cin, Cout, k, d, compute, dy.dt, dx.dt, w_eff.dtype, bool(accumulate))
+    def make():
+        P = d * (k - 1) // 2
+        return _lib.PreparedGemm(dy.store, w_eff, dx.store, dy.rows, Cin, k * Cout, Cout, k * Cin, Cin, layout=_lib.GEMM_NN, compute=compute, a_offset=dy.off(P),
+                                 c_offset=dx.off(), a_seglen=Cout if k > 1 else 0, a_segadj=-d * Cout - Cout if k > 1 else 0, seglen=Cout if k > 1 else 0,
+                                 seg0=0, segstride=Cin if k > 1 else 0, accumulate=accumulate, mask_mode=_lib.MASK_PAD, Tp=dy.Tp, mask_pad=PAD, mask_len=dy.T)
+    _prepared(key, make).run(dy.store, w_eff, dx.store)
 
 
 def conv_bwd_weight(dy, x, dw, db, k, d, compute):
     """dw (Cout, k * Cin) fp32 += dy^T xcat ; db (Cout) += column sums of dy."""
-    P = d * (k - 1) // 2
     Cout, Cin = dy.C, x.C
-    _lib.gemm(dy.store, x.store, dw, Cout, k * Cin, dy.rows, Cout, Cin, k * Cin, layout=_lib.GEMM_TN, compute=compute, accumulate=True, splitk=0,
-              a_offset=dy.off(), b_offset=x.off(-P), seglen=Cin if k > 1 else 0, seg0=0, segstride=d * Cin - Cin if k > 1 else 0)
+    key = (2, dy.B, dy.T, Cin, Cout, k, d, compute, dy.dt, x.dt)
+    def make():
+        P = d * (k - 1) // 2
+        return _lib.PreparedGemm(dy.store, x.store, dw, Cout, k * Cin, dy.rows, Cout, Cin, k * Cin, layout=_lib.GEMM_TN, compute=compute, accumulate=True, splitk=0,
+                                 a_offset=dy.off(), b_offset=x.off(-P), seglen=Cin if k > 1 else 0, seg0=0, segstride=d * Cin - Cin if k > 1 else 0)
+    _prepared(key, make).run(dy.store, x.store, dw)
     _lib.check(lib.xva_hg_colsum(C.c_void_p(dy.view.data_ptr()), dy.dt, _lib.ptr(db), dy.rows, Cout, 1.0, _lib.stream_ptr()), "xva_hg_colsum")
 
 
