@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-end evidence on the GPU box: plain bench line, rocprofv3 kernel stats of the same command, and the two PMC passes
 # (FETCH_SIZE / WRITE_SIZE, separate runs as MI355X_MICROARCH.md prescribes) per leg.  Everything lands in gpurun_out/final/.
-# usage (from the build container):  gpurun -- 'XVA_COMMIT=<short sha> XVA_ROUND=r02 bash tools/profile_round.sh'
+# usage (from the build container):  gpurun -- 'XVA_COMMIT=<short sha> XVA_ROUND=r03 bash tools/profile_round.sh'
 R=${GRAFT_REPO_ROOT:-$PWD}
-RD=${XVA_ROUND:-r02}
+RD=${XVA_ROUND:-r03}
 O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o b -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_final_bench_under_rocprof.json
@@ -18,6 +18,10 @@ rocprofv3 --kernel-trace --stats -d /tmp/p_fp -o f -- python $R/bench.py --steps
 python $R/tools/rocpd_summary.py $(find /tmp/p_fp -name "*.db" | head -1) $O/${RD}_fastpitch_only_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d /tmp/p_hg -o h -- python $R/tools/hg_phase_timing.py > $O/${RD}_hifigan_phase_timing.txt 2>/dev/null
 python $R/tools/rocpd_summary.py $(find /tmp/p_hg -name "*.db" | head -1) $O/${RD}_hifigan_only_kernel_stats.csv
+# the xVAPitch C5 iteration: per-pass timing + per-shape xva_gemm table (plain run), kernel stats of the same command under rocprofv3
+XVA_C5_GEMM_PROFILE=1 python $R/tools/c5_step_time.py 16 100 400 bf16 bf16 2>/dev/null | grep -v Warning > $O/${RD}_xvapitch_c5_timing.txt
+rocprofv3 --kernel-trace --stats -d /tmp/p_c5 -o c -- python $R/tools/c5_step_time.py 16 100 400 bf16 bf16 > /dev/null 2>&1
+python $R/tools/rocpd_summary.py $(find /tmp/p_c5 -name "*.db" | head -1) $O/${RD}_xvapitch_c5_kernel_stats.csv
 for leg in fastpitch hifigan; do
   if [ $leg = fastpitch ]; then CMD="python $R/bench.py --steps 2 --warmup 1 --no-hifigan --no-cpu-baseline --no-roofline --no-xvapitch --no-fp32-parity"; else CMD="python $R/tools/hg_gemm_profile.py 64"; fi
   for ctr in FETCH_SIZE WRITE_SIZE; do
