@@ -714,7 +714,7 @@ def test_c5_properties_at_reference_model_size():
     from xva_trainer_amd.xvapitch.decoder import VitsDecoder
     B, Tt, Ty = 4, 100, 400
     gen = torch.Generator().manual_seed(3)
-    ac = AcousticTrainPath(256, 31, pitch=True, text_layers=2, posterior_layers=4)            # full widths; fewer layers keep the test short
+    ac = AcousticTrainPath(256, 31, pitch=True)                                                # the reference's layer counts (10 text-encoder / 16 posterior-encoder layers)
     x_lens = torch.tensor([100, 77, 60, 31]); y_lens = torch.tensor([400, 333, 251, 140])
     tokens = (torch.randint(1, 256, (B, Tt), generator=gen) * (torch.arange(Tt)[None, :] < x_lens[:, None])).cuda()
     y = (torch.rand(B, 513, Ty, generator=gen) * (torch.arange(Ty)[None, None, :] < y_lens[:, None, None])).cuda()

@@ -156,6 +156,20 @@ def _fill_gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batc
     return p
 
 
+_SK_SCRATCH = {}
+
+
+def sk_scratch(device, nbytes=64 << 20):
+    """Split-K slab scratch of the Python-sequenced GEMM call sites (xvapitch/wn.py, ...): one buffer per (device, stream) — launches of one
+    stream are ordered, so the slabs of a product are reduced before the next product on that stream overwrites them.  Without a scratch
+    xva_gemm's split-K falls back to fp32 atomics (measured 4x slower on the WaveNet weight gradients)."""
+    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream)
+    t = _SK_SCRATCH.get(key)
+    if t is None:                          # never re-allocated: prepared call sites keep its address
+        t = _SK_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return t
+
+
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, **kw):
     """Thin test/utility wrapper over xva_gemm (keywords: see _fill_gemm). `a_offset` / `b_offset` / `c_offset` (elements) shift the base
     pointers (negative for the overlapping-row conv forms).  Storage dtypes are taken from the tensors."""

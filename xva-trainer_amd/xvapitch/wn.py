@@ -159,11 +159,12 @@ def conv_bwd_data(dy, w_eff, dx, k, d, compute, accumulate):
 def conv_bwd_weight(dy, x, dw, db, k, d, compute):
     """dw (Cout, k * Cin) fp32 += dy^T xcat ; db (Cout) += column sums of dy."""
     Cout, Cin = dy.C, x.C
-    key = (2, dy.B, dy.T, Cin, Cout, k, d, compute, dy.dt, x.dt)
+    key = (2, dy.B, dy.T, Cin, Cout, k, d, compute, dy.dt, x.dt, torch.cuda.current_stream(dw.device).cuda_stream)
     def make():
         P = d * (k - 1) // 2
         return _lib.PreparedGemm(dy.store, x.store, dw, Cout, k * Cin, dy.rows, Cout, Cin, k * Cin, layout=_lib.GEMM_TN, compute=compute, accumulate=True, splitk=0,
-                                 a_offset=dy.off(), b_offset=x.off(-P), seglen=Cin if k > 1 else 0, seg0=0, segstride=d * Cin - Cin if k > 1 else 0)
+                                 a_offset=dy.off(), b_offset=x.off(-P), seglen=Cin if k > 1 else 0, seg0=0, segstride=d * Cin - Cin if k > 1 else 0,
+                                 sk_ws=_lib.sk_scratch(dw.device))
     _prepared(key, make).run(dy.store, x.store, dw)
     _lib.check(lib.xva_hg_colsum(C.c_void_p(dy.view.data_ptr()), dy.dt, _lib.ptr(db), dy.rows, Cout, 1.0, _lib.stream_ptr()), "xva_hg_colsum")
 
