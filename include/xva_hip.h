@@ -533,6 +533,10 @@ int xva_rq_spline_fwd(const float* x, const float* h, float* y, float* logdet, i
 int xva_rq_spline_bwd(const float* x, const float* h, const float* dy, const float* dlogdet, float* dx, float* dh, int64_t n, int K, float wh_scale,
                       float bound, void* stream);
 
+/* The inverse direction of the same spline (util.py:322-350; ConvFlow with reverse=True, the duration predictor's sampling path sdp.py:311-321):
+ * x = spline^-1(y) per element; outside [-bound, bound] the identity.  The sampling path discards log|det|, so none is returned. */
+int xva_rq_spline_inv(const float* y, const float* h, float* x, int64_t n, int K, float wh_scale, float bound, void* stream);
+
 /* ElementwiseAffine (sdp.py:95-114) on (B, T, C): y = (x * exp(log_scale) + translation) * mask, logdet[b] = len_b * sum(log_scale); the backward
  * accumulates into d_log_scale / d_translation.  xva_sdp_dequant_*: the variational-dequantisation step of StochasticDurationPredictor.forward
  * (sdp.py:283-296) per token: z0_log = log(max(dr - sigmoid(z_u), 1e-5)) * mask, logsig = (logsigmoid(z_u) + logsigmoid(-z_u)) * mask. */

@@ -252,6 +252,123 @@ def sdp_forward(sd, x, x_mask, dr, noise, hidden, kernel_size=3, num_flows=4, g=
     return nll_flow + nll_post
 
 
+def rq_spline_inverse(y, uw, uh, ud, bound=5.0, min_w=1e-3, min_h=1e-3, min_d=1e-3):
+    """piecewise_rational_quadratic_transform(inverse=True, tails="linear") (python/xvapitch/util.py:203-350): the bin is searched over the
+    cumulative heights (:322), x is the root 2c / (-b - sqrt(b^2 - 4ac)) of the bin's quadratic (:325-340).  Returns x only (the sampling
+    direction of ConvFlow discards log|det|, sdp.py:174-176)."""
+    K = uw.size(-1)
+    inside = (y >= -bound) & (y <= bound)
+
+    def edges(u, m):
+        w = m + (1 - m * K) * torch.softmax(u, -1)
+        c = F.pad(torch.cumsum(w, -1), (1, 0)) * (2 * bound) - bound
+        c = torch.cat([torch.full_like(c[..., :1], -bound), c[..., 1:-1], torch.full_like(c[..., :1], bound)], -1)
+        return c, c[..., 1:] - c[..., :-1]
+    cw, w = edges(uw, min_w)
+    ch, hh = edges(uh, min_h)
+    const = float(np.log(np.exp(1 - min_d) - 1))
+    d = min_d + F.softplus(torch.cat([torch.full_like(ud[..., :1], const), ud, torch.full_like(ud[..., :1], const)], -1))
+    loc = ch.clone()
+    loc[..., -1] = loc[..., -1] + 1e-6
+    yc = y.clamp(-bound, bound)
+    k = ((yc[..., None] >= loc).sum(-1) - 1).clamp(0, K - 1)[..., None]
+    g = lambda t: t.gather(-1, k)[..., 0]
+    cwk, wk, chk, hk, dk, dk1 = g(cw), g(w), g(ch), g(hh), g(d), g(d[..., 1:])
+    dl = hk / wk
+    dy = yc - chk
+    a = dy * (dk + dk1 - 2 * dl) + hk * (dl - dk)
+    b = hk * dk - dy * (dk + dk1 - 2 * dl)
+    c = -dl * dy
+    root = (2 * c) / (-b - torch.sqrt((b * b - 4 * a * c).clamp_min(0)))
+    return torch.where(inside, root * wk + cwk, y)
+
+
+def conv_flow_reverse(sd, x, x_mask, g, hidden, kernel_size=3, num_layers=3, num_bins=10, tail_bound=5.0, pre=""):
+    """ConvFlow.forward(reverse=True) (python/xvapitch/sdp.py:144-176)."""
+    x0, x1 = x[:, :1], x[:, 1:]
+    h = F.conv1d(x0, sd[pre + "pre.weight"], sd[pre + "pre.bias"])
+    h = dds_conv(sd, h, x_mask, g, kernel_size, num_layers, pre=pre + "convs.")
+    h = F.conv1d(h, sd[pre + "proj.weight"], sd[pre + "proj.bias"]) * x_mask
+    b, c, t = x0.shape
+    h = h.reshape(b, c, -1, t).permute(0, 1, 3, 2)
+    x1 = rq_spline_inverse(x1, h[..., :num_bins] / hidden ** 0.5, h[..., num_bins:2 * num_bins] / hidden ** 0.5, h[..., 2 * num_bins:], tail_bound)
+    return torch.cat([x0, x1], 1) * x_mask
+
+
+def sdp_reverse(sd, x, x_mask, noise, hidden, kernel_size=3, num_flows=4, g=None, lang_emb=None, noise_scale=1.0):
+    """StochasticDurationPredictor.forward(reverse=True) (python/xvapitch/sdp.py:247-276,311-321): log w (B, 1, T) sampled by running
+    z = noise * noise_scale backwards through the flows (list reversed, its second-to-last entry dropped, a channel flip BEFORE each flow).
+    `noise` (B, 2, T) is the N(0, 1) draw of :313."""
+    x = F.conv1d(x, sd["pre.weight"], sd["pre.bias"])
+    if g is not None:
+        x = x + F.conv1d(g, sd["cond.weight"], sd["cond.bias"])
+    if lang_emb is not None:
+        x = x + F.conv1d(lang_emb, sd["cond_lang.weight"], sd["cond_lang.bias"])
+    x = dds_conv(sd, x, x_mask, None, kernel_size, 3, pre="convs.")
+    x = F.conv1d(x, sd["proj.weight"], sd["proj.bias"]) * x_mask
+    order = list(reversed(range(num_flows + 1)))                     # flows[4], [3], [2], [1], [0] (= ElementwiseAffine)
+    order = order[:-2] + [order[-1]]                                 # :312 "remove a useless vflow"
+    z = noise * noise_scale
+    for idx in order:
+        z = torch.flip(z, [1])
+        if idx == 0:
+            z = (z - sd["flows.0.translation"]) * torch.exp(-sd["flows.0.log_scale"]) * x_mask       # ElementwiseAffine reverse :112-113
+        else:
+            z = conv_flow_reverse(sd, z, x_mask, x, hidden, kernel_size, 3, pre="flows.%d." % idx)
+    return z[:, :1]
+
+
+def generate_path(duration, mask):
+    """util.py:849-864: duration (B, Tt) whole frames per symbol, mask (B, Tt, Ty) -> the 0 / 1 monotonic path."""
+    b, t_x, t_y = mask.shape
+    cum = torch.cumsum(duration, 1).reshape(b * t_x)
+    path = (torch.arange(t_y)[None, :] < cum[:, None]).to(mask.dtype).reshape(b, t_x, t_y)
+    path = path - F.pad(path, (0, 0, 1, 0))[:, :-1]
+    return path * mask
+
+
+def infer(sd, tokens, d_vector, language_id, noise, cfg, decoder, pacing=1.0, pe_scaling=0.1, noise_scale_dp=0.333, length_scale=1.0):
+    """xVAPitch.infer (python/xvapitch/model.py:417-599) on the switches xVAPitchModel sets (xva_train.py:1424-1428: --pitch 1, pe_scaling 0.1,
+    --energy / --ow_flow / --expanded_flow 0; flc 0, lang_w 1): text encoder -> duration predictor sampled in reverse (noise_scale_dp 0.333,
+    model.py:73) -> w = ceil(exp(logw) * mask * length_scale * pacing) -> path -> prior statistics expanded along it -> m_p += pitch_emb(expanded
+    pitch prediction) * pe_scaling (:498-515) -> z_p = m_p (inference_noise_scale is set to 0, :549) -> flow in reverse -> waveform decoder.
+    tokens (1, Tt) int64, d_vector (dvec,), language_id scalar, noise (1, 2, Tt); decoder(z (1, C, Ty), g (1, dvec, 1)) -> (1, 1, Ty * 256).
+    Returns dict(w_ceil, y_lengths, m_p, z, wav)."""
+    import math
+    Cc = cfg["latent"]
+
+    def sub(pre):
+        return {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    B, Tt = tokens.shape
+    g = F.normalize(d_vector.unsqueeze(0)).unsqueeze(-1)                                                   # _set_cond_input :918
+    lang_emb = sd["emb_l.weight"][language_id.reshape(1)].unsqueeze(-1)                                    # :431-432 (lang_w 1)
+    te = sub("text_encoder.")
+    x_emb = te["emb.weight"][tokens] * math.sqrt(Cc)
+    x = torch.cat([x_emb, lang_emb.transpose(2, 1).expand(B, Tt, -1)], -1).transpose(1, 2)
+    x_mask = torch.ones(B, 1, Tt)
+    x = rel_transformer(sub("text_encoder.encoder."), x * x_mask, x_mask, cfg["heads"], cfg["te_layers"], 3, 4)          # :438
+    stats = F.conv1d(x, te["proj.weight"], te["proj.bias"]) * x_mask                                                   # :439
+    m_p, logs_p = torch.split(stats, Cc, dim=1)
+    logw = sdp_reverse(sub("duration_predictor."), x, x_mask, noise, Cc, 3, 4, g=g, lang_emb=lang_emb, noise_scale=noise_scale_dp)   # :443
+    w_ceil = torch.ceil(torch.exp(logw) * x_mask * length_scale * pacing)                                              # :445-447
+    y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()                                                   # :452
+    Ty = int(y_lengths.max())
+    y_mask = torch.ones(B, 1, Ty)
+    attn = generate_path(w_ceil.squeeze(1), torch.ones(B, Tt, Ty))                                                     # :455-456
+    m_p = torch.matmul(attn.transpose(1, 2), m_p.transpose(1, 2)).transpose(1, 2)                                      # :458
+    pin = torch.cat([x.permute(0, 2, 1), g.transpose(2, 1).expand(B, Tt, -1)], -1).transpose(1, -1)                    # :498, model.py:1338-1340
+    pitch_pred = rel_transformer(sub("pitch_predictor.encoder."), pin * x_mask, x_mask, cfg["heads"], 3, 3, 4)         # (1, 1, Tt)
+    reps = w_ceil.reshape(Tt).long()
+    pitch_exp = torch.repeat_interleave(pitch_pred.reshape(Tt), reps).reshape(1, 1, Ty)                                # expand_pitch_energy :935-958
+    m_p = m_p + F.conv1d(pitch_exp, sd["pitch_emb.weight"], sd["pitch_emb.bias"], padding=1) * pe_scaling              # :511-515
+    z = m_p                                                                                                            # :549-550 (noise scale 0)
+    for i in reversed(range(cfg["num_flows"])):                                                                        # ResidualCouplingBlocks reverse :1415-1419
+        z = torch.flip(z, [1])
+        z = coupling(sub("flow.flows.%d." % i), z, y_mask, g, reverse=True, hidden=Cc, kernel_size=5, dilation_rate=1, num_layers=cfg["flow_layers"])
+    wav = decoder(z * y_mask, g)                                                                                       # :593-597
+    return {"w_ceil": w_ceil, "y_lengths": y_lengths, "m_p": m_p, "z": z * y_mask, "wav": wav, "logw": logw, "pitch_pred": pitch_pred}
+
+
 def average_pitch(pitch, durs):
     """model.py:1005-1023: mean of the non-zero frame values under each symbol's duration span.  pitch (B, 1, Ty), durs (B, Tt) -> (B, 1, Tt)."""
     ends = torch.cumsum(durs, dim=1).long()

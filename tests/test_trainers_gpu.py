@@ -429,6 +429,23 @@ def test_xvapitch_trainer_runs_checkpoints_and_resumes(tmp_path):
     t4.compute, t4.model_kwargs, t4.allow_random_init = "fp32", dict(_XV_SMALL), True
     asyncio.run(XT.handleTrainer(mm4, dict(data, max_iterations=1, checkpoint="[base]"), ws4, [0]))
     assert t4.total_steps_done == 8 and t4.ckpt_path.endswith("xVAPitch_7.pt")      # the output directory's newest checkpoint wins over "[base]"
+    # ---- the inference wrapper server.py loads for the exported voice (python/models_manager.py:141-143, xva_train.py:1396-1467)
+    from xva_trainer_amd.xvapitch.xva_train import xVAPitchModel, LANG_CODES
+    assert LANG_CODES.index("en") == 5 and len(LANG_CODES) == 31                   # index into the sorted lang_names keys (dataset.py:123)
+    mm5 = _mm()
+    assert mm5.load_model("infer_xvapitch", out + "/nope.pt") == "ENOENT"
+    mm5.models_bank["infer_xvapitch"] = xVAPitchModel(None, False, "cuda:0", mm5, model_kwargs={k: v for k, v in _XV_SMALL.items() if k != "spec_segment_size"},
+                                                      text_to_sequence=lambda text: ([1 + (ord(ch) % 20) for ch in text], None))
+    mm5.load_model("infer_xvapitch", out + "/voice_x.pt")
+    inf = mm5.models_bank["infer_xvapitch"]
+    assert inf.ckpt_path == out + "/voice_x.pt"
+    assert torch.equal(inf.model.state_dict()["emb_l.weight"].cpu(), torch.load(out + "/voice_x.pt", weights_only=False)["emb_l.weight"].float())
+    assert inf.infer("hello there", str(tmp_path / "o.wav"), meta["games"][0]["base_speaker_emb"]) == ""
+    import scipy.io.wavfile
+    sr, wav = scipy.io.wavfile.read(str(tmp_path / "o.wav"))
+    assert sr == 22050 and wav.dtype == np.int16 and wav.size % 256 == 0 and wav.size >= 11 * 256 and int(np.abs(wav).max()) >= 32000
+    durs = inf.model.infer(torch.tensor([[3, 4, 5]], device="cuda"), torch.randn(512, device="cuda"), 5, inf.decoder, durs_only=True)
+    assert durs.shape == (1, 1, 3) and bool((durs >= 1).all())
 
 
 def test_xvapitch_checkpoint_layout_is_the_references():

@@ -322,3 +322,28 @@ def test_oracle_dropout_sites_against_reference_train_mode_golden():
     for k in g.files:
         if k.startswith("sdp_grad/"):
             assert torch.allclose(sd[k[9:]].grad, t(k), rtol=1e-3, atol=1e-4), k
+
+
+def test_infer_oracle_matches_reference_infer_golden():
+    """oracle/xvapitch.py:infer (text encoder, duration predictor in reverse — inverse splines —, path expansion, pitch branch, flow in reverse,
+    waveform decoder) and rq_spline_inverse vs the vectors recorded from the reference's own xVAPitch.infer and
+    piecewise_rational_quadratic_transform(inverse=True) (oracle/gen_golden_xvapitch_infer.py): durations exact, waveform 1e-4."""
+    from oracle import hifigan as ohg, xvapitch as oxv
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xvapitch_infer.npz"))
+    c = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    K = 10
+    y, h = torch.from_numpy(g["spline/y"]), torch.from_numpy(g["spline/h"])
+    ws = float(g["spline/wh_scale"])
+    x = oxv.rq_spline_inverse(y, h[:, :K] * ws, h[:, K:2 * K] * ws, h[:, 2 * K:], float(g["spline/bound"]))
+    assert torch.allclose(x, torch.from_numpy(g["spline/x"]), rtol=1e-5, atol=1e-5)
+    fwd, _ = oxv.rq_spline(x, h[:, :K] * ws, h[:, K:2 * K] * ws, h[:, 2 * K:], float(g["spline/bound"]))
+    assert torch.allclose(fwd, y, atol=1e-4)                                       # the forward map undoes it
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    dl = ohg.init_vits_decoder_sd(int(g["dec_seed"]), c["latent"], c["dvec"])
+    for case in (1, 2):                                                            # case 0 (40 frames) is the GPU test's; these keep the CPU suite short
+        pre = "c%d/" % case
+        with torch.no_grad():
+            o = oxv.infer(sd, torch.from_numpy(g[pre + "tokens"]), torch.from_numpy(g[pre + "dvec"]), torch.from_numpy(g[pre + "lid"]),
+                          torch.from_numpy(g[pre + "noise"]), c, lambda z, gg: ohg.vits_decoder(dl, z, gg), pacing=float(g[pre + "pacing"]))
+        assert torch.equal(o["w_ceil"], torch.from_numpy(g[pre + "w_ceil"]))
+        assert torch.allclose(o["wav"], torch.from_numpy(g[pre + "wav"]), rtol=1e-4, atol=2e-5)

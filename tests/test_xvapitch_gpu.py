@@ -882,3 +882,49 @@ def test_vits_discriminator_short_segments(seg):
     assert _rel(d_wav.reshape(yhg.grad.shape), yhg.grad) < 2e-3
     worst = sorted(((_rel(v, leaves[k].grad), k) for k, v in D.grads().items()), reverse=True)
     assert worst[0][0] < 1e-2 and worst[len(worst) // 2][0] < 1e-3, worst[:4]
+
+
+def test_rq_spline_inverse_against_reference_golden(golden_dir):
+    """xva_rq_spline_inv (the duration predictor's sampling direction) against piecewise_rational_quadratic_transform(inverse=True,
+    tails="linear") of the reference (util.py:203-350) on values across both tails, the bin edges and the interior: 1e-5; and the forward kernel
+    undoes it."""
+    import ctypes as C
+    from xva_trainer_amd import _lib
+    from xva_trainer_amd.xvapitch import sdp
+    g = np.load(os.path.join(golden_dir, "xvapitch_infer.npz"))
+    y, h = torch.from_numpy(g["spline/y"]).cuda(), torch.from_numpy(g["spline/h"]).cuda().contiguous()
+    x = torch.empty_like(y)
+    _lib.check(_lib.lib.xva_rq_spline_inv(_lib.ptr(y), _lib.ptr(h), _lib.ptr(x), y.numel(), 10, float(g["spline/wh_scale"]), float(g["spline/bound"]),
+                                          _lib.stream_ptr()), "xva_rq_spline_inv")
+    assert torch.allclose(x.cpu(), torch.from_numpy(g["spline/x"]), rtol=1e-5, atol=1e-5), float((x.cpu() - torch.from_numpy(g["spline/x"])).abs().max())
+    back, _ = sdp.RqSpline.apply(x, h, 10, float(g["spline/wh_scale"]), float(g["spline/bound"]))
+    assert torch.allclose(back, y, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_infer_against_reference_infer_golden(golden_dir, case):
+    """AcousticTrainPath.infer + VitsDecoder against the reference's own `xVAPitch.infer` (model.py:417-599; recorded by
+    oracle/gen_golden_xvapitch_infer.py with the duration predictor's N(0, 1) draw): 19 / 7 / 1 symbols at pacing 2.2 / 3.7 / 1 — the ceil
+    durations bit-exact (and through durs_only), the latent before the decoder and the waveform at 1e-3."""
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
+    from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+    g = np.load(os.path.join(golden_dir, "xvapitch_infer.npz"))
+    c = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    ac = AcousticTrainPath(c["vocab"], c["langs"], latent_size=c["latent"], embedded_language_dim=c["lang_dim"], d_vector_dim=c["dvec"],
+                           hidden_channels_ffn=c["ffn"], num_heads=c["heads"], text_layers=c["te_layers"], posterior_layers=c["pe_layers"],
+                           flow_layers=c["flow_layers"], num_flows=c["num_flows"], spec_bins=c["spec_bins"], pitch=True, dropout_p=0.1, sdp_dropout_p=0.5)
+    ac.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")})
+    dec = VitsDecoder(c["latent"], c["dvec"])
+    dec.load_state_dict(ohg.init_vits_decoder_sd(int(g["dec_seed"]), c["latent"], c["dvec"]))
+    pre = "c%d/" % case
+    t = lambda k: torch.from_numpy(g[pre + k]).cuda()
+    kw = dict(pacing=float(g[pre + "pacing"]), noise=t("noise"))
+    w = ac.infer(t("tokens"), t("dvec"), t("lid"), dec, durs_only=True, **kw)
+    assert torch.equal(w.cpu(), torch.from_numpy(g[pre + "w_ceil"]))
+    wav = ac.infer(t("tokens"), t("dvec"), t("lid"), dec, **kw)
+    ref = torch.from_numpy(g[pre + "wav"])
+    assert wav.shape == ref.shape
+    assert _rel(ac.last_infer["z"], torch.from_numpy(g[pre + "z"])) < 1e-3
+    assert _rel(wav, ref) < 1e-3, _rel(wav, ref)
+    assert ac.training                                                              # infer leaves the training flag as it found it

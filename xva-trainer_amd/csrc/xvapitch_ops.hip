@@ -965,6 +965,27 @@ __global__ void rq_spline_fwd_kernel(const float* __restrict__ x, const float* _
     const float D = dl * dl * (dk1 * th * th + 2.f * dl * om + dk * (1.f - th) * (1.f - th));
     logdet[i] = logf(D) - 2.f * logf(den);
 }
+// The inverse direction (util.py:325-350, what ConvFlow runs with reverse=True when the duration predictor samples, sdp.py:311-321): the bin is
+// searched over the cumulative HEIGHTS, x is the root of the bin's quadratic a t^2 + b t + c = 0 taken as 2c / (-b - sqrt(b^2 - 4ac)).
+// No log|det| output: the sampling direction discards it (sdp.py:174-176).
+__global__ void rq_spline_inv_kernel(const float* __restrict__ y, const float* __restrict__ h, float* __restrict__ x, int64_t n, int K, float wh_scale,
+                                     float bound) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float yv = y[i];
+    if (!(yv >= -bound && yv <= bound)) { x[i] = yv; return; }
+    RqBins b;
+    rq_bins(h + i * (3 * K - 1), K, wh_scale, bound, b);
+    int k = -1;
+    for (int j = 0; j <= K; ++j) k += (yv >= (j == K ? b.ch[j] + 1e-6f : b.ch[j])) ? 1 : 0;     // searchsorted over cumheights (util.py:322)
+    k = min(max(k, 0), K - 1);
+    const float wk = b.cw[k + 1] - b.cw[k], hk = b.ch[k + 1] - b.ch[k], dk = b.dv[k], dk1 = b.dv[k + 1], dl = hk / wk;
+    const float dy = yv - b.ch[k], A = dk + dk1 - 2.f * dl;
+    const float qa = dy * A + hk * (dl - dk), qb = hk * dk - dy * A, qc = -dl * dy;
+    const float disc = fmaxf(qb * qb - 4.f * qa * qc, 0.f);
+    const float root = (2.f * qc) / (-qb - sqrtf(disc));
+    x[i] = root * wk + b.cw[k];
+}
 // dx and dh (n, 3K - 1) from dy (gradient of y) and dl (gradient of log|det|)
 __global__ void rq_spline_bwd_kernel(const float* __restrict__ x, const float* __restrict__ h, const float* __restrict__ gy_, const float* __restrict__ gl_,
                                      float* __restrict__ dx, float* __restrict__ dh, int64_t n, int K, float wh_scale, float bound) {
@@ -1022,6 +1043,12 @@ __global__ void rq_spline_bwd_kernel(const float* __restrict__ x, const float* _
 extern "C" int xva_rq_spline_fwd(const float* x, const float* h, float* y, float* logdet, int64_t n, int K, float wh_scale, float bound, void* stream) {
     XVA_CHECK_ARG(x && h && y && logdet && n >= 0 && K >= 2 && K <= RQ_MAXK && bound > 0.f, "rq_spline_fwd: bad args");
     if (n) hipLaunchKernelGGL(rq_spline_fwd_kernel, dim3((unsigned)xva_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, x, h, y, logdet, n, K, wh_scale, bound);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_rq_spline_inv(const float* y, const float* h, float* x, int64_t n, int K, float wh_scale, float bound, void* stream) {
+    XVA_CHECK_ARG(y && h && x && n >= 0 && K >= 2 && K <= RQ_MAXK && bound > 0.f, "rq_spline_inv: bad args");
+    if (n) hipLaunchKernelGGL(rq_spline_inv_kernel, dim3((unsigned)xva_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, y, h, x, n, K, wh_scale, bound);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }

@@ -1,8 +1,8 @@
 """ModelsManager — the registry entry points server.py uses for the trainers (python/models_manager.py:115-128,152-163).
 
 Served here: the trainer keys of the accelerated path ("fastpitch1_1", "hifigan", "xvapitch": python/models_manager.py:105-128) and the
-FastPitch / HiFi-GAN inference wrappers ("infer_fastpitch1_1", "infer_hifigan", :130-150); the 16 dataset tools and xVAPitch inference
-("infer_xvapitch") stay with the reference (`init_model` / `load_model` raise NotImplementedError for them here)."""
+FastPitch / HiFi-GAN / xVAPitch inference wrappers ("infer_fastpitch1_1", "infer_hifigan", "infer_xvapitch", :130-150); the 16 dataset tools stay
+with the reference (`init_model` raises NotImplementedError for them here)."""
 import os
 
 import torch
@@ -50,6 +50,9 @@ class ModelsManager(object):
             elif model_key == "infer_hifigan":
                 from .infer import HiFi_GAN
                 self.models_bank[model_key] = HiFi_GAN(self.logger, self.PROD, dev, self)
+            elif model_key == "infer_xvapitch":
+                from .xvapitch.xva_train import xVAPitchModel
+                self.models_bank[model_key] = xVAPitchModel(self.logger, self.PROD, dev, self)
             else:
                 raise NotImplementedError("inference model '%s' is not part of the accelerated path" % model_key)
         if not os.path.exists(ckpt_path):

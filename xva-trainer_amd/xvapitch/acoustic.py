@@ -226,6 +226,68 @@ class AcousticTrainPath:
                 for v in m.p.values():
                     v.grad = None
 
+    def _pitch_emb(self, pitch):
+        """pitch_emb = Conv1d(1, C, 3, padding 1) (model.py:176) as a GEMM over the three taps of each frame (a 4th zero column keeps rows 16 bytes
+        wide).  pitch (B, 1, Ty) -> (B, C, Ty)"""
+        p, Cc = self.p, self.C
+        B, _, Ty = pitch.shape
+        pp = F.pad(pitch.float().reshape(B, Ty), (1, 1))
+        cols = torch.stack([pp[:, 0:Ty], pp[:, 1:Ty + 1], pp[:, 2:Ty + 2], torch.zeros(B, Ty, device=pitch.device)], -1).contiguous()
+        w4 = torch.cat([p["pitch_emb.weight"].reshape(Cc, 3), torch.zeros(Cc, 1, device=pitch.device)], 1).reshape(Cc, 4, 1)
+        return Conv1x1.apply(cols, w4, p["pitch_emb.bias"]).transpose(1, 2)
+
+    # ---- model.py:417-599 ----
+    @torch.no_grad()
+    def infer(self, tokens, d_vector, language_id, decoder, pacing=1.0, durs_only=False, noise=None, noise_scale_dp=0.333, length_scale=1.0,
+              max_inference_len=None):
+        """`xVAPitch.infer` on the switches xVAPitchModel sets (xva_train.py:1424-1428: --pitch 1, pe_scaling 0.1, --energy / --ow_flow /
+        --expanded_flow 0; flc 0, lang_w 1) for ONE utterance: tokens (1, Tt) int64, d_vector (d_vector_dim,), language_id scalar tensor / int.
+        text encoder (:438-439) -> duration predictor sampled in reverse with noise_scale_dp (:443, model.py:73) -> w_ceil = ceil(exp(logw) *
+        length_scale * pacing) (:445-447; returned as is when durs_only) -> the prior means expanded along the path (:455-458) -> + pitch_emb(the
+        pitch prediction expanded by the durations) * pe_scaling (:498-515) -> z_p = m_p (the reference sets inference_noise_scale to 0, :549) ->
+        flow in reverse (:592) -> waveform decoder (:597).  noise (1, 2, Tt): the duration predictor's N(0, 1) draw (torch.randn when None).
+        Returns the waveform (1, 1, Ty * 256).  Runs in eval mode (no dropout) whatever the training flag says, as the reference's model.eval()."""
+        if not self.pitch:
+            raise ValueError("AcousticTrainPath.infer: built without the pitch branch (xVAPitchModel sets --pitch 1)")
+        _lib.require_cuda(tokens, d_vector)
+        p, Cc, L = self.p, self.C, self.L
+        B, Tt = tokens.shape
+        if B != 1:
+            raise ValueError("infer: one utterance at a time (the reference's infer unsqueezes ONE embedding, model.py:420)")
+        was = self.training
+        self.eval()
+        try:
+            dev = tokens.device
+            g = F.normalize(d_vector.float().reshape(1, -1)).unsqueeze(-1)                                  # _set_cond_input :918
+            lid = torch.as_tensor(language_id, device=dev).reshape(1).long()
+            lang = F.embedding(lid, p["emb_l.weight"])                                                      # (1, L) :431-432
+            x_emb = F.embedding(tokens, p["text_encoder.emb.weight"]) * math.sqrt(Cc)
+            x_in = torch.cat([x_emb, lang.unsqueeze(1).expand(B, Tt, L)], -1).transpose(1, 2)
+            x_mask = torch.ones(B, 1, Tt, device=dev)
+            x = self.encoder(x_in * x_mask, x_mask)                                                         # :438
+            stats = Conv1x1.apply(x.transpose(1, 2).contiguous(), p["text_encoder.proj.weight"], p["text_encoder.proj.bias"])   # (1, Tt, 2C) :439
+            logw = self.duration_predictor.infer(x, x_mask, g=g, lang_emb=lang.unsqueeze(-1), noise_scale=noise_scale_dp, noise=noise)   # :443
+            w_ceil = torch.ceil(torch.exp(logw) * x_mask * length_scale * pacing)                           # :445-447
+            if durs_only:
+                return w_ceil
+            reps = w_ceil.reshape(Tt).long()
+            Ty = max(int(reps.sum()), 1)                                                                    # :452
+            idx = torch.repeat_interleave(torch.arange(Tt, device=dev), reps)                               # generate_path + matmul :455-458 = a gather
+            m_p = torch.zeros(B, Cc, Ty, device=dev)
+            m_p[:, :, :idx.numel()] = stats[0, :, :Cc].index_select(0, idx).t().unsqueeze(0)
+            pin = torch.cat([x, g.expand(B, self.Dv, Tt)], 1)                                               # :498, model.py:1338-1340
+            pitch_pred = self.pitch_predictor(pin * x_mask, x_mask)                                         # (1, 1, Tt)
+            pitch_exp = torch.zeros(B, 1, Ty, device=dev)
+            pitch_exp[0, 0, :idx.numel()] = pitch_pred.reshape(Tt).index_select(0, idx)                     # expand_pitch_energy :935-958
+            m_p = m_p + self._pitch_emb(pitch_exp) * self.pe_scaling                                        # :511-515
+            y_mask = torch.ones(B, 1, Ty, device=dev)
+            z = self.flow(m_p.contiguous(), y_mask, g=g, reverse=True)                                      # :549-550, :592
+            z = (z * y_mask)[:, :, :max_inference_len]
+            self.last_infer = {"w_ceil": w_ceil, "z": z, "m_p": m_p, "logw": logw, "pitch_pred": pitch_pred}
+            return decoder(z.contiguous(), g)                                                               # :597
+        finally:
+            self.train(was)
+
     # ---- model.py:681-870 ----
     def __call__(self, tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps=None, noise=None, pitch_padded=None):
         """tokens (B, Tt) int64, y (B, spec_bins, Ty) linear spectrogram, d_vectors (B, d_vector_dim), language_ids (B,).  eps (B, C, Ty) / noise
@@ -253,11 +315,7 @@ class AcousticTrainPath:
         stats = Mask.apply(Conv1x1.apply(x.transpose(1, 2).contiguous(), p["text_encoder.proj.weight"], p["text_encoder.proj.bias"]), x_lens)   # :1148
         z_p = self.flow(z, y_mask, g=g)                                                                    # :723
         if self.pitch:                                                                                     # :752-755  z_p -= pitch_emb(pitch) * pe_scaling
-            # Conv1d(1, C, 3, padding 1) as a GEMM over the three taps of each frame (a 4th zero column keeps rows 16 bytes wide)
-            pp = F.pad(pitch_padded.float().reshape(B, Ty), (1, 1))
-            cols = torch.stack([pp[:, 0:Ty], pp[:, 1:Ty + 1], pp[:, 2:Ty + 2], torch.zeros(B, Ty, device=y.device)], -1).contiguous()
-            w4 = torch.cat([p["pitch_emb.weight"].reshape(Cc, 3), torch.zeros(Cc, 1, device=y.device)], 1).reshape(Cc, 4, 1)
-            z_p = z_p - Conv1x1.apply(cols, w4, p["pitch_emb.bias"]).transpose(1, 2) * self.pe_scaling
+            z_p = z_p - self._pitch_emb(pitch_padded) * self.pe_scaling
         with torch.no_grad():                                                                              # :763-776
             logp = prior_logp(stats.detach(), z_p.detach(), Cc)
             attn_mask = x_mask.squeeze(1).unsqueeze(-1) * y_mask.squeeze(1).unsqueeze(1)

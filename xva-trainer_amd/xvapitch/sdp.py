@@ -6,7 +6,7 @@ Same constructor arguments and state_dict keys / layouts as the reference module
 Every arithmetic step is a C call wrapped as ONE autograd primitive (depthwise dilated convolution, LayerNorm2, exact GELU, 1x1 convolution =
 xva_gemm, mask, add), so the blocks compose with torch autograd like the reference's; parameters are leaf tensors whose `.grad` autograd fills.
 Inside, tensors are fp32 time-major (B, T, C); splits / concatenations / flips of the 2-channel flow variable and the per-item sums of
-log-determinants are torch view / reduction glue.  StochasticDurationPredictor.forward (the training likelihood, :247-310) is assembled from these primitives; its reverse (sampling) direction is not built.
+log-determinants are torch view / reduction glue.  StochasticDurationPredictor.forward (the training likelihood, :247-310) is assembled from these primitives; its reverse (sampling) direction (:311-321) is StochasticDurationPredictor.infer.
 """
 import ctypes as C
 
@@ -37,6 +37,8 @@ lib.xva_fp_add_act.restype = i32
 lib.xva_fp_add_act.argtypes = [vp, vp, i32, i64, vp]
 lib.xva_hg_colsum.restype = i32
 lib.xva_hg_colsum.argtypes = [vp, i32, vp, i64, i32, f32, vp]
+lib.xva_rq_spline_inv.restype = i32
+lib.xva_rq_spline_inv.argtypes = [vp, vp, vp, i64, i32, f32, f32, vp]
 lib.xva_rq_spline_fwd.restype = i32
 lib.xva_rq_spline_fwd.argtypes = [vp, vp, vp, vp, i64, i32, f32, f32, vp]
 lib.xva_rq_spline_bwd.restype = i32
@@ -326,8 +328,8 @@ class ConvFlow(_Module):
         for k, v in self.convs.p.items():
             self.p["convs." + k] = v
 
-    def forward_btc(self, z, lens, g=None):
-        """z (B, T, 2), g (B, T, H) -> (B, T, 2), logdet (B)"""
+    def forward_btc(self, z, lens, g=None, reverse=False):
+        """z (B, T, 2), g (B, T, H) -> (B, T, 2), logdet (B) ; reverse=True: the inverse map, (B, T, 2) only"""
         p, H, NP = self.p, self.H, 3 * self.K - 1
         x0, x1 = z[..., 0:1], z[..., 1]
         # pre: Conv1d(1, H, 1) and proj: Conv1d(H, 3K - 1, 1) ride in GEMMs whose narrow dimension is zero-padded to a multiple of 4
@@ -339,6 +341,10 @@ class ConvFlow(_Module):
         wproj = torch.cat([p["proj.weight"].reshape(NP, H), torch.zeros(NPp - NP, H, device=z.device)], 0).reshape(NPp, H, 1)
         bproj = torch.cat([p["proj.bias"], torch.zeros(NPp - NP, device=z.device)])
         h = Mask.apply(Conv1x1.apply(h, wproj, bproj), lens)[..., :NP]
+        if reverse:                                                  # sdp.py:158-176 with inverse=True: x1 = spline^-1(y1); no log|det| (sampling path)
+            hc = h.contiguous(); y1 = x1.contiguous(); x1n = torch.empty_like(y1)
+            _lib.check(lib.xva_rq_spline_inv(P(y1), P(hc), P(x1n), y1.numel(), self.K, 1.0 / H ** 0.5, self.bound, ST()), "xva_rq_spline_inv")
+            return Mask.apply(torch.stack([x0[..., 0], x1n], -1), lens)
         y1, ld = RqSpline.apply(x1, h, self.K, 1.0 / H ** 0.5, self.bound)
         out = Mask.apply(torch.stack([x0[..., 0], y1], -1), lens)
         ldm = Mask.apply(ld.unsqueeze(-1), lens)
@@ -394,7 +400,9 @@ class ElementwiseAffine(_Module):
     def __init__(self, channels, device="cuda"):
         self.p = {"translation": _param(torch.zeros(channels, 1), device), "log_scale": _param(torch.zeros(channels, 1), device)}
 
-    def forward_btc(self, x, lens, g=None):
+    def forward_btc(self, x, lens, g=None, reverse=False):
+        if reverse:                                                  # sdp.py:112-113: (x - translation) * exp(-log_scale) * mask
+            return Mask.apply((x - self.p["translation"].reshape(1, 1, -1)) * torch.exp(-self.p["log_scale"].reshape(1, 1, -1)), lens)
         return Affine.apply(x, self.p["log_scale"], self.p["translation"], lens)
 
 
@@ -453,12 +461,9 @@ class StochasticDurationPredictor(_Module):
     def eval(self):
         return self.train(False)
 
-    def __call__(self, x, x_mask, dr, g=None, lang_emb=None, noise=None):
-        """x (B, C, T), x_mask (B, 1, T), dr (B, 1, T), g (B, Cg, 1), lang_emb (B, Cl, 1 or T), noise (B, 2, T) -> nll (B,)"""
-        _lib.require_cuda(x, dr)
-        import math
+    def _text_condition(self, x, lens, g, lang_emb):
+        """sdp.py:260-275: proj(convs(pre(x) + cond(g) + cond_lang(lang_emb))) * mask, time-major (B, T, H)"""
         p, H = self.p, self.H
-        lens = _lens_of(x, x_mask)
         B, _, T = x.shape
         tm = lambda t: t.float().transpose(1, 2).contiguous()
         xs = Conv1x1.apply(tm(x), p["pre.weight"], p["pre.bias"])
@@ -467,7 +472,37 @@ class StochasticDurationPredictor(_Module):
         if lang_emb is not None:
             xs = Add.apply(xs, Conv1x1.apply(tm(lang_emb), p["cond_lang.weight"], p["cond_lang.bias"]).expand(B, T, H).contiguous())
         xs = self.convs.forward_btc(xs, lens)
-        xs = Mask.apply(Conv1x1.apply(xs, p["proj.weight"], p["proj.bias"]), lens)
+        return Mask.apply(Conv1x1.apply(xs, p["proj.weight"], p["proj.bias"]), lens)
+
+    @torch.no_grad()
+    def infer(self, x, x_mask, g=None, lang_emb=None, noise_scale=1.0, noise=None):
+        """The sampling direction, `forward(..., reverse=True)` (sdp.py:311-321): z = noise * noise_scale runs BACKWARDS through the flows — the
+        list reversed, the second ConvFlow from the end of that list dropped ("a useless vflow"), a channel flip before every flow — and the
+        first channel is log w.  x (B, C, T), x_mask (B, 1, T), noise (B, 2, T) N(0, 1) (drawn with torch when None) -> logw (B, 1, T).
+        The caller runs it in eval mode (no dropout in `convs`)."""
+        _lib.require_cuda(x)
+        lens = _lens_of(x, x_mask)
+        B, _, T = x.shape
+        xs = self._text_condition(x, lens, g, lang_emb)
+        if noise is None:
+            noise = torch.randn(B, 2, T, device=x.device)
+        z = (noise.float() * noise_scale).transpose(1, 2).contiguous()
+        flows = list(reversed(self.flows))
+        flows = flows[:-2] + [flows[-1]]
+        for flow in flows:
+            z = torch.flip(z, [2]).contiguous()
+            z = flow.forward_btc(z, lens, xs, reverse=True)
+        return z[..., 0:1].transpose(1, 2).contiguous()
+
+    def __call__(self, x, x_mask, dr, g=None, lang_emb=None, noise=None):
+        """x (B, C, T), x_mask (B, 1, T), dr (B, 1, T), g (B, Cg, 1), lang_emb (B, Cl, 1 or T), noise (B, 2, T) -> nll (B,)"""
+        _lib.require_cuda(x, dr)
+        import math
+        p, H = self.p, self.H
+        lens = _lens_of(x, x_mask)
+        B, _, T = x.shape
+        tm = lambda t: t.float().transpose(1, 2).contiguous()
+        xs = self._text_condition(x, lens, g, lang_emb)
         # condition encoder of the durations: Conv1d(1, H, 1) as a GEMM over a 4-wide zero-padded input
         drs = tm(dr)
         wpp = torch.cat([p["post_pre.weight"].reshape(H, 1), torch.zeros(H, 3, device=x.device)], 1).reshape(H, 4, 1)

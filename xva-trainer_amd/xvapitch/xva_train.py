@@ -44,7 +44,11 @@ from .train_step import FlatGroupAdamW, XVAPitchStep
 N_SYMBOLS = 524          # len(ALL_SYMBOLS), python/xvapitch/text/ipa_to_xvaarpabet.py:103 (oracle/gen_xvapitch_checkpoint_layout.py evaluates it)
 N_LANGUAGES = 31         # len(lang_names), python/xvapitch/model.py:57
 LANGS = ["de", "en", "it", "fr", "ro", "jp", "es", "ru", "ar", "da", "el", "fi", "ha", "hi", "hu", "ko", "la", "nl", "pl", "pt", "sw", "sv", "tr", "uk",
-         "vi", "wo", "yo", "zh"]                                                       # xva_train.py:1163 (the language id is the index into lang_names' keys)
+         "vi", "wo", "yo", "zh"]                                                       # xva_train.py:1163: the languages of the priors datasets
+# the language id is the index into the SORTED keys of lang_names (python/xvapitch/text/__init__.py:5-37; dataset.py:123,425; xva_train.py:1415): "en" = 5
+LANG_CODES = sorted(["am", "ar", "da", "de", "el", "en", "es", "fi", "fr", "ha", "hi", "hu", "it", "jp", "ko", "la", "mn", "nl", "pl", "pt", "ro", "ru", "sw",
+                     "sv", "th", "tr", "uk", "vi", "wo", "yo", "zh"])
+assert len(LANG_CODES) == N_LANGUAGES
 
 
 def sort_xvap(x):
@@ -143,7 +147,7 @@ class XVAPitchFileLoader:
         self.items = read_metadata(dataset_path)
         if not self.items:
             raise FileNotFoundError("no usable lines in %s/metadata.csv (wavs/ missing?)" % dataset_path)
-        self.lang_id = LANGS.index(lang) if lang in LANGS else 1
+        self.lang_id = LANG_CODES.index(lang) if lang in LANG_CODES else LANG_CODES.index("en")
         self.enc = BasicTextEncoder()
         self.seed, self.rank, self.world, self.epoch = seed, rank, world, 0
         self.index = list(range(len(self.items))) * max(1, int(data_mult))
@@ -695,3 +699,69 @@ class xVAPitchTrainer(object):
         adld = checkpoint.get("avg_disc_loss_per_epoch_deltas", [[], []])
         self.training_stage = int(checkpoint.get("training_stage", 1))
         return 0, total_steps_done, adl, adld
+
+
+class xVAPitchModel(object):
+    """The inference wrapper `models_manager.load_model("infer_xvapitch", ckpt)` serves (python/xvapitch/xva_train.py:1396-1467): xVAPitch at the
+    switches that class sets (--big 1 defaults of its argparse, pitch 1, pe_scaling 0.1, energy / ow_flow / expanded_flow 0), `load_state_dict(ckpt_path,
+    ckpt)` (a training checkpoint's "state_dict" entry or a bare state_dict, strict=False), `infer(text, output, embedding)` -> a 22050 Hz int16 wav
+    normalised to its peak (:1457-1460).  The g2p text front end (python/xvapitch/text: 31 languages) is the reference's CPU preprocessing and is not
+    rebuilt: `text_to_sequence` is taken from the constructor, else from the reference package when this mirror runs inside the reference's tree;
+    `infer_symbols` takes the symbol ids directly."""
+
+    def __init__(self, logger, PROD, device, models_manager, compute="fp32", text_to_sequence=None, model_kwargs=None):
+        self.logger, self.PROD, self.models_manager = logger, PROD, models_manager
+        self.device = torch.device(device)
+        self.ckpt_path = None
+        self.language_id_mapping = {name: i for i, name in enumerate(LANG_CODES)}                         # :1415
+        kw = dict(n_vocab=N_SYMBOLS, num_languages=N_LANGUAGES, latent_size=256, embedded_language_dim=12, d_vector_dim=512, pitch=True, pe_scaling=0.1)
+        kw.update(model_kwargs or {})
+        self.model = AcousticTrainPath(device=self.device, compute=compute, **kw).eval()
+        self.decoder = VitsDecoder(self.model.C, self.model.Dv, compute=compute, device=self.device)
+        self._t2s = text_to_sequence
+        self.isReady = True
+
+    def load_state_dict(self, ckpt_path, ckpt, n_speakers=1):
+        self.ckpt_path = ckpt_path
+        if "state_dict" in ckpt:
+            ckpt = ckpt["state_dict"]
+        elif "model" in ckpt and isinstance(ckpt["model"], dict):                                         # an xVAPitch_{steps}.pt training checkpoint
+            ckpt = ckpt["model"]
+        own = self.model.state_dict()
+        self.model.load_state_dict({k: (ckpt[k].float() if k in ckpt and tuple(ckpt[k].shape) == tuple(v.shape) else v) for k, v in own.items()})
+        cur = self.decoder.state_dict()
+        pre = "waveform_decoder."
+        self.decoder.load_state_dict({k: (ckpt[pre + k].float() if pre + k in ckpt and tuple(ckpt[pre + k].shape) == tuple(v.shape) else v) for k, v in cur.items()})
+        self.model.eval()
+
+    def set_device(self, device):
+        if torch.device(device) != self.device:
+            raise RuntimeError("xVAPitchModel: built on %s; build a new wrapper for %s" % (self.device, device))
+
+    def _text_to_sequence(self, text):
+        if self._t2s is None:
+            try:                                                                                          # inside the reference's tree: its own front end
+                from python.xvapitch.text import get_text_preprocessor
+                base = ("./resources/app" if self.PROD else ".") + "/python/xvapitch/text"
+                self._t2s = get_text_preprocessor("en", base).text_to_sequence
+            except Exception as e:
+                raise RuntimeError("xVAPitchModel.infer(text): the g2p text front end (python/xvapitch/text) is the reference's CPU preprocessing — pass "
+                                   "text_to_sequence= to the constructor or call infer_symbols(ids, embedding)") from e
+        out = self._t2s(text)
+        return out[0] if isinstance(out, tuple) else out
+
+    @torch.no_grad()
+    def infer_symbols(self, symbol_ids, embedding, lang="en", pacing=1.0, noise=None):
+        """symbol ids (Tt,) -> waveform (samples,) float32 on the device (model.infer, model.py:417-599)"""
+        tokens = torch.as_tensor(symbol_ids, dtype=torch.int64, device=self.device).reshape(1, -1)
+        emb = torch.as_tensor(embedding, dtype=torch.float32, device=self.device).reshape(-1)
+        lid = torch.tensor(self.language_id_mapping[lang], device=self.device)
+        return self.model.infer(tokens, emb, lid, self.decoder, pacing=pacing, noise=noise).reshape(-1)
+
+    def infer(self, text, output, embedding):
+        import scipy.io.wavfile
+        wav = self.infer_symbols(self._text_to_sequence(text), embedding).cpu().numpy()
+        wav_norm = wav * (32767 / max(0.01, float(np.max(np.abs(wav)))))                                  # :1459
+        scipy.io.wavfile.write(output, 22050, wav_norm.astype(np.int16))
+        torch.cuda.empty_cache()
+        return ""
