@@ -51,8 +51,10 @@ typedef struct xva_mel_config {
 /* Number of frames T for clips of N samples, or -1 on bad arguments. */
 int xva_mel_num_frames(const xva_mel_config* cfg, int N);
 /* Diagnostics / test knob: 0 (default) = the windowed DFT of every frame is a 1024-point real FFT wherever n_fft == 1024 (all three reference
- * configurations); 1 = always the dense GEMM against the windowed DFT basis (the reference's own formulation; also env XVA_MEL_DFT=1).  Returns
- * the previous mode. */
+ * configurations) and the FORWARD mel (xva_mel_spectrogram, xva_mel_spectrogram_ragged) is one fused kernel — reflect-indexed frame, FFT,
+ * magnitude, mel filterbank, log — whose intermediates stay in LDS; 2 = the FFT inside the four-launch pipeline (pad, FFT, magnitude, filterbank
+ * GEMM; what the differentiable mel's backward always uses); 1 = always the dense GEMM against the windowed DFT basis (the reference's own
+ * formulation).  Also env XVA_MEL_DFT.  Returns the previous mode. */
 int xva_mel_set_dft(int mode);
 int64_t xva_mel_workspace_bytes(const xva_mel_config* cfg, int B, int N);
 /* wav:  (B, N) fp32 in [-1, 1], row stride ld_wav.

@@ -64,11 +64,13 @@ __global__ void xva_magnitude_kernel(const float* __restrict__ spec, float* __re
 // (cos(0) * w[n]); twiddles W_1024^m are computed once per workgroup into LDS (sincospif: 1 ulp).  Output: the DFT GEMM's layout,
 // spec[frame][re(0 .. nb - 1) | im(0 .. nb - 1)] with the GEMM's sign (im = -sum x w sin), so every consumer is unchanged.
 #define FFT_WAVES 4
-struct cf { float x, y; };
-__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ cf cmni(cf a) { return {a.y, -a.x}; }                 // a * (-i)
+// complex numbers as native 2-vectors: the adds / subtracts / multiplies of the butterflies map onto the packed fp32 instructions
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two floats per lane per issue) — the fused front-end kernel below is VALU-bound
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { const cf s = {-a.y, a.y}; return a.xx * b + s * b.yx; }   // (ax bx - ay by, ax by + ay bx)
+__device__ __forceinline__ cf cmni(cf a) { return (cf){a.y, -a.x}; }             // a * (-i)
 __device__ __forceinline__ void dft8(cf* a) {                                     // in place, natural order in and out, forward (e^{-2 pi i nk / 8})
     const float h = 0.70710678118654752440f;
     cf t0 = cadd(a[0], a[4]), t1 = csub(a[0], a[4]), t2 = cadd(a[2], a[6]), t3 = cmni(csub(a[2], a[6]));
@@ -142,7 +144,164 @@ __global__ __launch_bounds__(64 * FFT_WAVES) void xva_stft_fft1024_kernel(const 
         __syncthreads();
     }
 }
-// g_mel_dft: 1 = always the dense DFT GEMM (XVA_MEL_DFT=1 / xva_mel_set_dft); default the FFT wherever n_fft == 1024 (all three variants)
+// ---- the whole forward front end in ONE kernel: reflect-indexed frame -> windowed FFT -> magnitude -> mel filterbank -> log ----------------
+// The four-launch pipeline above writes and re-reads three intermediates per frame (padded clip, 1026-float spectrum, 544-float magnitude row:
+// 12.6 KB against 1.3 KB of algorithmic traffic, 9.4 x); only the differentiable mel's backward needs them.  Here a frame's spectrum never leaves
+// LDS: the wave that transformed it takes the 513 magnitudes and scatters them into the (at most two) triangular mel filters each bin belongs to
+// — a per-bin tap table built on the device from the caller's dense filterbank by a one-block pre-kernel, with a dense fallback for any bin
+// that has more than two non-zero weights — and writes log(max(., clamp)).  A workgroup (4 waves) walks 16 consecutive frames of one clip, so the
+// reference's (B, n_mel, T) layout is written in 64-byte row segments.  Frames are read straight from the caller's clip (float rows, or the ragged
+// int16 batch with / 32768) with torch's reflect index map applied per sample: no padded copy.
+struct MelTap { int m0; float w0; int m1; float w1; };           // m < 0: unused ; m0 == -2: more than two filters touch this bin (dense fallback)
+__global__ void xva_mel_taps_kernel(const float* __restrict__ mel_basis, int64_t ldm, int n_mel, int nb, MelTap* __restrict__ tab) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nb) return;
+    MelTap t = {-1, 0.f, -1, 0.f};
+    int cnt = 0;
+    for (int mb = 0; mb < n_mel; mb += 16) {                     // 16 independent loads in flight (a plain loop paid one L2 round trip per filter: 26 us)
+        float w[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w[q] = mb + q < n_mel ? mel_basis[(int64_t)(mb + q) * ldm + k] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (w[q] != 0.f) {
+                if (cnt == 0) { t.m0 = mb + q; t.w0 = w[q]; } else if (cnt == 1) { t.m1 = mb + q; t.w1 = w[q]; }
+                ++cnt;
+            }
+    }
+    if (cnt > 2 || (cnt == 2 && t.m1 != t.m0 + 1)) t.m0 = -2;       // the fast path assumes adjacent triangles (filters m, m + 1)
+    tab[k] = t;
+}
+#define MELF_FRAMES 16
+#define MELF_MAXMEL 96
+template <int SRC>      // 0: float clips, row stride ldx, N samples each ; 1: ragged int16 clips (flat + offsets[order[r]], lens) scaled by 1 / 32768
+__global__ __launch_bounds__(64 * FFT_WAVES) void xva_mel_fused_kernel(const void* __restrict__ src, int64_t ldx, const int64_t* __restrict__ offsets,
+                                                                       const int32_t* __restrict__ lens, const int32_t* __restrict__ order,
+                                                                       const float* __restrict__ window, const MelTap* __restrict__ tab,
+                                                                       const float* __restrict__ mel_basis, int64_t ldm, float* __restrict__ mel_out,
+                                                                       int32_t* __restrict__ n_frames_out, int B, int T, int N0, int pad, int hop, int nb,
+                                                                       int n_mel, float eps_add, float clamp_min, float log_clamp) {
+    __shared__ cf tw[1024];
+    __shared__ cf buf[FFT_WAVES][584];
+    __shared__ MelTap stab[584];                                                  // bin k at k + (k >> 3): a lane's 8 consecutive bins, conflict-free
+    __shared__ float macc[FFT_WAVES][MELF_MAXMEL];
+    __shared__ float melt[MELF_MAXMEL][MELF_FRAMES + 1];
+    for (int m = threadIdx.x; m < 1024; m += 64 * FFT_WAVES) { float sn, cs; sincospif(-(float)m * (1.0f / 512.0f), &sn, &cs); tw[m] = {cs, sn}; }
+    for (int k = threadIdx.x; k < nb; k += 64 * FFT_WAVES) stab[k + (k >> 3)] = tab[k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int m = lane; m < MELF_MAXMEL; m += 64) macc[wave][m] = 0.f;
+    cf* sb = buf[wave];
+    const int n2 = lane >> 3, n3 = lane & 7;
+    float2 w2[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) w2[n1] = *reinterpret_cast<const float2*>(window + 2 * (64 * n1 + lane));
+    __syncthreads();
+    const int gpc = (T + MELF_FRAMES - 1) / MELF_FRAMES;                          // frame groups per clip
+    for (int64_t grp = blockIdx.x; grp < (int64_t)B * gpc; grp += gridDim.x) {
+        const int b = (int)(grp / gpc), t0 = (int)(grp - (int64_t)b * gpc) * MELF_FRAMES;
+        int N = N0;
+        const float* xf = nullptr; const int16_t* xi = nullptr;
+        if constexpr (SRC == 0) xf = reinterpret_cast<const float*>(src) + (int64_t)b * ldx;
+        else {
+            const int i0 = order ? order[b] : b;
+            N = lens[i0];
+            xi = reinterpret_cast<const int16_t*>(src) + offsets[i0];
+            if (n_frames_out && t0 == 0 && threadIdx.x == 0) n_frames_out[b] = (N + 2 * pad - 1024) / hop + 1;
+        }
+        auto sample = [&](int i) -> float {                                      // x[reflect(i)], torch 'reflect' (no edge repeat); far-out frames of a
+            int sidx = i < 0 ? -i : i;                                           // ragged batch (zeroed later) are clamped into the clip
+            if (sidx >= N) sidx = 2 * (N - 1) - sidx;
+            sidx = min(max(sidx, 0), N - 1);
+            if constexpr (SRC == 0) return xf[sidx]; else return (float)xi[sidx] * (1.0f / 32768.0f);
+        };
+#pragma unroll 1
+        for (int it = 0; it < MELF_FRAMES / FFT_WAVES; ++it) {
+            const int fi = it * FFT_WAVES + wave, t = t0 + fi;
+            const bool live = t < T;
+            const int base = (live ? t : 0) * hop - pad;
+            cf a[8];
+            if (SRC == 0 && base >= 0 && base + 1024 <= N && ((ldx | hop | pad) & 1) == 0) {      // interior frame: 8-byte vector loads
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) {
+                    const float2 v = *reinterpret_cast<const float2*>(xf + base + 2 * (64 * n1 + lane));
+                    a[n1] = {v.x * w2[n1].x, v.y * w2[n1].y};
+                }
+            } else {
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) {
+                    const int i = base + 2 * (64 * n1 + lane);
+                    a[n1] = {sample(i) * w2[n1].x, sample(i + 1) * w2[n1].y};
+                }
+            }
+            dft8(a);
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1) sb[72 * k1 + lane] = k1 ? cmul(a[k1], tw[(16 * n2 * k1) & 1023]) : a[0];
+            __builtin_amdgcn_wave_barrier();                                      // the exchange buffer is the wave's own: LDS is in order within a wave
+            const int k1 = lane >> 3;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = sb[72 * k1 + 8 * q + n3];
+            dft8(a);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) sb[9 * (k1 + 8 * k2) + n3] = cmul(a[k2], tw[(2 * n3 * (k1 + 8 * k2)) & 1023]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = sb[9 * lane + q];
+            dft8(a);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k3 = 0; k3 < 8; ++k3) { const int k = lane + 64 * k3; sb[k + (k >> 3)] = a[k3]; }      // Z[k] at k + (k >> 3)
+            if (lane == 0) sb[512 + 64] = a[0];                                   // Z[512] = Z[0]
+            __builtin_amdgcn_wave_barrier();
+            // a lane takes 8 CONSECUTIVE bins (lane 63 also bin 512): consecutive bins share their one or two triangular filters, so a lane sums
+            // them in registers and issues a handful of LDS adds per frame (the bins of a wave instruction would otherwise collide on one address)
+            int cur = -1; float accA = 0.f, accB = 0.f;
+            auto flush = [&](int m, float v) { if (m >= 0 && m < n_mel && v != 0.f) unsafeAtomicAdd(&macc[wave][m], v); };
+#pragma unroll 1
+            for (int j = 0; j < 9; ++j) {
+                const int k = 8 * lane + j;
+                if (j == 8 && lane != 63) break;
+                if (k >= nb) break;
+                const int kc = 512 - k;
+                const cf zk = sb[k + (k >> 3)], zc = sb[kc + (kc >> 3)];
+                const cf e = {0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y)};
+                const cf d = {0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y)};
+                const cf o = cmul(cmni(d), tw[k]);
+                const float re = e.x + o.x, im = e.y + o.y;
+                float pw = re * re + im * im + eps_add;
+                if (clamp_min > 0.f) pw = fmaxf(pw, clamp_min);
+                const float mg = sqrtf(pw);
+                const MelTap tp = stab[k + (k >> 3)];
+                if (tp.m0 >= 0) {
+                    if (tp.m0 != cur) {
+                        flush(cur, accA);
+                        if (tp.m0 == cur + 1) { accA = accB; } else { flush(cur + 1, accB); accA = 0.f; }
+                        accB = 0.f; cur = tp.m0;
+                    }
+                    accA += tp.w0 * mg;
+                    if (tp.m1 >= 0) accB += tp.w1 * mg;
+                } else if (tp.m0 == -2) {
+                    for (int m = 0; m < n_mel; ++m) { const float w = mel_basis[(int64_t)m * ldm + k]; if (w != 0.f) unsafeAtomicAdd(&macc[wave][m], w * mg); }
+                }
+            }
+            flush(cur, accA); flush(cur + 1, accB);
+            __builtin_amdgcn_wave_barrier();
+            for (int m = lane; m < n_mel; m += 64) {
+                melt[m][fi] = logf(fmaxf(macc[wave][m], log_clamp));
+                macc[wave][m] = 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < n_mel * MELF_FRAMES; idx += 64 * FFT_WAVES) {
+            const int m = idx / MELF_FRAMES, f = idx - m * MELF_FRAMES, t = t0 + f;
+            if (t < T) mel_out[((int64_t)b * n_mel + m) * T + t] = melt[m][f];
+        }
+        __syncthreads();
+    }
+}
+// g_mel_dft: 0 (default) = the FFT wherever n_fft == 1024 (all three variants), and the forward mel as the one fused kernel above; 2 = the FFT with
+// the four-launch pipeline (pad, FFT, magnitude, filterbank GEMM); 1 = always the dense DFT GEMM (XVA_MEL_DFT / xva_mel_set_dft)
 static int g_mel_dft = [] { const char* e = getenv("XVA_MEL_DFT"); return e ? atoi(e) : 0; }();
 extern "C" int xva_mel_set_dft(int mode) { int old = g_mel_dft; g_mel_dft = mode; return old; }
 static inline int64_t al4(int64_t x) { return (x + 3) & ~(int64_t)3; }
@@ -173,7 +332,7 @@ static int mel_plan(const xva_mel_config* c, int B, int N, MelPlan* pl) {
 
 // spec[b][t][re | im] = windowed DFT of frame t of clip b: the 1024-point FFT kernel, or (other sizes, XVA_MEL_DFT=1) the overlapping-row GEMM
 static int stft_spec(const xva_mel_config* c, const MelPlan& pl, int B, const float* ypad, const float* dft_basis, float* spec, void* stream) {
-    if (c->n_fft == 1024 && !g_mel_dft && c->hop % 4 == 0) {
+    if (c->n_fft == 1024 && g_mel_dft != 1 && c->hop % 4 == 0) {
         const int64_t nframes = (int64_t)B * pl.T;
         int64_t grid = (nframes + FFT_WAVES - 1) / FFT_WAVES;
         if (grid > 256 * 8) grid = 256 * 8;
@@ -206,10 +365,25 @@ extern "C" int64_t xva_mel_workspace_bytes(const xva_mel_config* c, int B, int N
 
 static int mel_core(const xva_mel_config* c, const MelPlan& pl, int B, const float* dft_basis, const float* mel_basis_padded, float* mel_out,
                     float* workspace, void* stream);
+// the fused forward kernel: n_fft 1024 (its FFT), up to MELF_MAXMEL filters, the default front-end mode
+static bool mel_fused_ok(const xva_mel_config* c, const MelPlan& pl) {
+    return c->n_fft == 1024 && g_mel_dft == 0 && c->hop % 4 == 0 && c->n_mel <= MELF_MAXMEL && pl.nb <= 513;
+}
+static unsigned mel_fused_grid(int B, int T) {
+    const int64_t groups = (int64_t)B * ((T + MELF_FRAMES - 1) / MELF_FRAMES);
+    return (unsigned)(groups < 256 * 6 ? (groups < 1 ? 1 : groups) : 256 * 6);
+}
 
+static int mel_spectrogram_impl(const xva_mel_config* c, const float* wav, int B, int N, int64_t ld_wav, const float* dft_basis, const float* mel_basis_padded,
+                                float* mel_out, float* workspace, int64_t workspace_bytes, void* stream, bool keep_intermediates);
 extern "C" int xva_mel_spectrogram(const xva_mel_config* c, const float* wav, int B, int N, int64_t ld_wav,
                                    const float* dft_basis, const float* mel_basis_padded, float* mel_out,
                                    float* workspace, int64_t workspace_bytes, void* stream) {
+    return mel_spectrogram_impl(c, wav, B, N, ld_wav, dft_basis, mel_basis_padded, mel_out, workspace, workspace_bytes, stream, false);
+}
+// keep_intermediates: the differentiable mel's backward reads the spectrum and the magnitudes out of the workspace (four-launch pipeline)
+static int mel_spectrogram_impl(const xva_mel_config* c, const float* wav, int B, int N, int64_t ld_wav, const float* dft_basis, const float* mel_basis_padded,
+                                float* mel_out, float* workspace, int64_t workspace_bytes, void* stream, bool keep_intermediates) {
     XVA_CHECK_ARG(c && wav && dft_basis && mel_basis_padded && mel_out && workspace, "mel: null pointer");
     MelPlan pl;
     XVA_TRY(mel_plan(c, B, N, &pl));
@@ -217,6 +391,15 @@ extern "C" int xva_mel_spectrogram(const xva_mel_config* c, const float* wav, in
                   (long)workspace_bytes, (long)(pl.total * sizeof(float)));
     XVA_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "mel: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (!keep_intermediates && mel_fused_ok(c, pl)) {
+        MelTap* tab = reinterpret_cast<MelTap*>(workspace + pl.off_spec);
+        hipLaunchKernelGGL(xva_mel_taps_kernel, dim3(xva_cdiv(pl.nb, 64)), dim3(64), 0, st, mel_basis_padded, pl.ldm, c->n_mel, pl.nb, tab);
+        hipLaunchKernelGGL((xva_mel_fused_kernel<0>), dim3(mel_fused_grid(B, pl.T)), dim3(64 * FFT_WAVES), 0, st, wav, ld_wav, nullptr, nullptr, nullptr, dft_basis,
+                           tab, mel_basis_padded, pl.ldm, mel_out, nullptr, B, pl.T, N, c->pad, c->hop, pl.nb, c->n_mel, c->mag_eps_add, c->mag_clamp_min,
+                           c->log_clamp);
+        XVA_LAUNCH_CHECK();
+        return XVA_OK;
+    }
     float* ypad = workspace + pl.off_pad;
     {   // 1. reflect pad (plus zero the slack so over-reads of tail vectors are benign)
         int64_t total = (int64_t)B * pl.ldy;
@@ -258,6 +441,16 @@ extern "C" int xva_mel_spectrogram_ragged(const xva_mel_config* c, const int16_t
     XVA_TRY(mel_plan(c, B, Nmax, &pl));
     XVA_CHECK_ARG(workspace_bytes >= pl.total * (int64_t)sizeof(float), "mel_ragged: workspace too small");
     XVA_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "mel_ragged: workspace must be 16-byte aligned");
+    if (mel_fused_ok(c, pl)) {
+        hipStream_t st = (hipStream_t)stream;
+        MelTap* tab = reinterpret_cast<MelTap*>(workspace + pl.off_spec);
+        hipLaunchKernelGGL(xva_mel_taps_kernel, dim3(xva_cdiv(pl.nb, 64)), dim3(64), 0, st, mel_basis_padded, pl.ldm, c->n_mel, pl.nb, tab);
+        hipLaunchKernelGGL((xva_mel_fused_kernel<1>), dim3(mel_fused_grid(B, pl.T)), dim3(64 * FFT_WAVES), 0, st, flat, (int64_t)0, offsets, n_samples, order,
+                           dft_basis, tab, mel_basis_padded, pl.ldm, mel_out, n_frames_out, B, pl.T, Nmax, c->pad, c->hop, pl.nb, c->n_mel, c->mag_eps_add,
+                           c->mag_clamp_min, c->log_clamp);
+        XVA_LAUNCH_CHECK();
+        return xva_mel_finish_ragged(mel_out, n_frames_out, energy_out, B, c->n_mel, pl.T, energy_trunc, stream);
+    }
     hipLaunchKernelGGL(xva_reflect_pad_i16_ragged_kernel, dim3((unsigned)(pl.ldy / 256 < 1 ? 1 : (pl.ldy / 256 > 128 ? 128 : pl.ldy / 256)), B), dim3(256), 0,
                        (hipStream_t)stream, flat, offsets, n_samples, order, workspace + pl.off_pad, c->pad, pl.ldy, n_frames_out, c->n_fft, c->hop);
     XVA_LAUNCH_CHECK();
@@ -470,7 +663,7 @@ extern "C" int xva_mel_l1_loss_backward(const xva_mel_config* c, const float* wa
     XVA_TRY(mel_bwd_plan(c, B, N, &p));
     XVA_CHECK_ARG(workspace_bytes >= p.total * (int64_t)sizeof(float), "mel backward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    XVA_TRY(xva_mel_spectrogram(c, wav, B, N, ld_wav, dft_basis, mel_basis_padded, mel_out, workspace, workspace_bytes, stream));
+    XVA_TRY(mel_spectrogram_impl(c, wav, B, N, ld_wav, dft_basis, mel_basis_padded, mel_out, workspace, workspace_bytes, stream, true));
     const MelPlan& f = p.f;
     float* spec = workspace + f.off_spec;
     float* mag = workspace + f.off_mag;
