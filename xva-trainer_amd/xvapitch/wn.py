@@ -159,7 +159,7 @@ def conv_bwd_data(dy, w_eff, dx, k, d, compute, accumulate):
 def conv_bwd_weight(dy, x, dw, db, k, d, compute):
     """dw (Cout, k * Cin) fp32 += dy^T xcat ; db (Cout) += column sums of dy."""
     Cout, Cin = dy.C, x.C
-    key = (2, dy.B, dy.T, Cin, Cout, k, d, compute, dy.dt, x.dt, torch.cuda.current_stream(dw.device).cuda_stream)
+    key = (2, dy.B, dy.T, Cin, Cout, k, d, compute, dy.dt, x.dt, _lib.raw_stream(dw.device))
     def make():
         P = d * (k - 1) // 2
         return _lib.PreparedGemm(dy.store, x.store, dw, Cout, k * Cin, dy.rows, Cout, Cin, k * Cin, layout=_lib.GEMM_TN, compute=compute, accumulate=True, splitk=0,
