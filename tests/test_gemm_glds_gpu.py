@@ -326,3 +326,39 @@ def test_grouped_strided_conv_resident_input(mainloop, C, Cout, groups, k, s):
     xr = xv[:, PAD:PAD + T].double().transpose(1, 2).requires_grad_(True)
     F.conv1d(xr, W.double(), stride=s, padding=P_, groups=groups).backward(dyv[:, PAD:PAD + To].double().transpose(1, 2))
     assert _rel(dx.view(nseq, Hp, C)[:, PAD:PAD + T], xr.grad.transpose(1, 2)) < 3e-6
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+def test_splitk_with_the_full_epilogue_in_the_reduce_pass(layout):
+    """Forward / backward-data products with a long reduction and a small tile grid (FastPitch's encoder feed-forward: 4 864 rows x 384 columns
+    over K = 4 608) may be split along K when the caller passes splitk = 0 and slab scratch: the reduce pass applies the WHOLE epilogue (bias,
+    dropout, gate, residual, ReLU, row mask, bf16 store).  Against the unsplit product: the same values up to fp32 summation order (one bf16 ulp
+    on a bf16 C), identical dropout / mask pattern."""
+    L = _lib()
+    torch.manual_seed(5)
+    M, N, K, Tp = 4864, 384, 4608, 152
+    A, lda = _bf(M, K, scale=0.05)
+    if layout == "nt":
+        B, ldb = _bf(N, K)
+        kw = dict(layout=L.GEMM_NT)
+    else:
+        B, ldb = _bf(K, N)
+        kw = dict(layout=L.GEMM_NN)
+    bias = torch.randn(N, device="cuda")
+    R = torch.randn(M, N, device="cuda").bfloat16()
+    G = torch.randn(M, N, device="cuda").bfloat16()
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
+    common = dict(compute=1, bias=bias, relu=True, R=R, ldr=N, G=G, ldg=N, gate_slope=0.0, mask_mode=L.MASK_PAD, Tp=Tp, mask_pad=1, mask_len=Tp - 2,
+                  drop_p=0.1, drop_seed=77, drop_stream=3, **kw)
+    out = {}
+    for tag, extra in (("one", dict(splitk=1)), ("split", dict(splitk=0, sk_ws=ws))):
+        for cdt in (torch.bfloat16, torch.float32):
+            Cm = torch.full((M, N), 7.0, device="cuda", dtype=cdt)
+            L.gemm(A, B, Cm, M, N, K, lda, ldb, N, **common, **extra)
+            out[(tag, cdt)] = Cm.float()
+    for cdt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1.2e-2)):
+        a, b = out[("one", cdt)], out[("split", cdt)]
+        assert torch.equal(a == 0, b == 0) or ((a == 0) != (b == 0)).float().mean().item() < 1e-4      # same ReLU / dropout / mask zeros (up to ReLU gates at rounding)
+        assert ((a - b).abs().max() / a.abs().max()).item() < tol
+    pad_rows = torch.arange(M, device="cuda") % Tp
+    assert out[("split", torch.float32)][(pad_rows == 0) | (pad_rows == Tp - 1)].abs().max().item() == 0.0

@@ -284,6 +284,14 @@ static int linear_bwd_weight(Ctx& c, const void* dY, int64_t rows, int N, int64_
     g.sk_ws = c.W + (c.lane == 2 ? c.pl.skws3 : (c.lane ? c.pl.skws2 : c.pl.skws)); g.sk_ws_bytes = c.pl.skws_bytes;
     return xva_gemm(&g, c.st);
 }
+// Long reductions into narrow outputs (the encoder's 4 864 rows x 384 columns over K = 4 608): let xva_gemm split K through this lane's slab scratch
+// and apply the epilogue in the reduce pass (gemm.hip); it only does so when the tile grid would leave most of the chip idle.
+static void offer_split(const Ctx& c, xva_gemm_params& g) {
+    if (c.compute && g.K >= 2048 && !g.accumulate) {
+        g.splitk = 0;
+        g.sk_ws = c.W + (c.lane == 2 ? c.pl.skws3 : (c.lane ? c.pl.skws2 : c.pl.skws)); g.sk_ws_bytes = c.pl.skws_bytes;
+    }
+}
 // Conv1d(k=3, pad=1) over a padded token-major sequence: Y = act(Xcat Wt^T + b) [dropout] (+R), Wt tap-major [Cout][3*Cin]
 static int conv3_fwd(Ctx& c, const char* X, int64_t rows, int Cin, int64_t w_off, const float* bias, void* Y, int Cout,
                      int relu, const void* R, int mask, const int32_t* lens, int Tp, Drop dr = {0.f, 0}) {
@@ -292,6 +300,7 @@ static int conv3_fwd(Ctx& c, const char* X, int64_t rows, int Cin, int64_t w_off
     g.lda = Cin; g.ldb = 3 * Cin; g.ldc = Cout; g.bias = bias; g.act = relu ? XVA_ACT_RELU : XVA_ACT_NONE; g.R = R; g.ldr = Cout;
     g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
     g.drop_p = dr.p; g.drop_seed = c.seed; g.drop_stream = dr.stream;
+    offer_split(c, g);
     return xva_gemm(&g, c.st);
 }
 // dX[r] = sum_j dY[r-1+j] W[:, tap 2-j, :]  (gated by Gate > 0) (+R)
@@ -302,6 +311,7 @@ static int conv3_bwd_data(Ctx& c, const char* dY, int64_t rows, int Cout, int64_
     g.layout = XVA_GEMM_NN; g.A = dY - (int64_t)Cout * c.es; g.B = c.wt(w_off); g.C = dX; g.M = (int)rows; g.N = Cin; g.K = 3 * Cout;
     g.lda = Cout; g.ldb = 3 * Cin; g.ldc = Cin; g.seglen = Cout; g.seg0 = 2 * Cin; g.segstride = -Cin;
     g.R = R; g.ldr = Cin; g.G = Gate; g.ldg = Cin; g.mask_mode = mask; g.lens = lens; g.Tp = Tp; g.accumulate = accumulate;
+    offer_split(c, g);
     return xva_gemm(&g, c.st);
 }
 // dWt[Cout][3*Cin] += dY^T Xcat

@@ -123,6 +123,20 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
             }
             p.splitk = sk < 1 ? 1 : (int)sk;
         }
+        // Products with a NON-linear epilogue (forward / backward-data: bias, activation, gate, masks, dropout, bf16 output) whose grid leaves most
+        // of the chip idle while the reduction is long — FastPitch's encoder feed-forward products: 4 864 rows x 384 columns over K = 4 608 are 114
+        // tiles of 128 x 128 with 72 K tiles each — split along K as well when the caller offers slab scratch and asks for it (splitk = 0): the
+        // partial sums go through the slabs and xva_gemm_splitk_reduce applies the whole epilogue (the same epilogue4 the tiles use).
+        if (auto_sk && !can_split && p.sk_ws && p.layout != XVA_GEMM_TN && p.N % 4 == 0 && !p.C2 && glds_env < 0 && nkt >= 32 &&
+            ((uintptr_t)p.sk_ws % 16) == 0) {
+            const long t0 = ntiles(0);
+            static const long fs_num = [] { const char* e = getenv("XVA_GEMM_FSPLIT"); return e ? atol(e) : 520L; }();
+            long sk = t0 > 0 ? fs_num / t0 : 1;                    // ~one round of 128 x 128 tiles at two workgroups per CU (512 slots); swept 288 / 400 / 520 / 700 on the encoder products: 520 (4 splits) best
+            if (sk > nkt / 12) sk = nkt / 12;
+            const long fit = (long)(p.sk_ws_bytes / ((int64_t)p.M * p.N * 4 * nb));
+            if (sk > fit) sk = fit;
+            if (sk >= 2 && t0 <= 144) { glds_tile = 0; p.splitk = (int)sk; int bm0; xva_gemm_glds_tile_dims(0, &bm0, &bn); bn = bn * 1000 + bm0; }
+        }
         if (p.splitk > nkt) p.splitk = nkt;
     } else if (can_split) {
         const long tiles = (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2;

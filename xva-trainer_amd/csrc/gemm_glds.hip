@@ -2,8 +2,8 @@
 #include "gemm_glds.h"
 
 namespace xva_glds {
-// C (+)= alpha * (sum_s slab[s] + bias) + beta * R  for one batch item per blockIdx.y.
-// gridDim.z == 1: one pass with the full (linear) epilogue.  gridDim.z > 1 (many slabs of a small output; host-checked: pure fp32
+// C (+)= epilogue(sum_s slab[s])  for one batch item per blockIdx.y.
+// gridDim.z == 1: one pass with the full epilogue of the tile kernels (epilogue4).  gridDim.z > 1 (many slabs of a small output; host-checked: pure fp32
 // accumulation, no bias / residual): each z sums its share of the slabs and adds alpha * partial atomically.
 __global__ __launch_bounds__(256) void xva_gemm_splitk_reduce_kernel(xva_gemm_params p) {
     const int b2n = p.batch2 > 1 ? p.batch2 : 1;
@@ -15,6 +15,10 @@ __global__ __launch_bounds__(256) void xva_gemm_splitk_reduce_kernel(xva_gemm_pa
     const int per = (p.splitk + gridDim.z - 1) / gridDim.z;
     const int k0 = blockIdx.z * per, k1 = min(p.splitk, k0 + per);
     if (k0 >= k1) return;
+    xva_gemm_params q1 = p; q1.splitk = 1;          // the epilogue of an unsplit product (plain stores / read-modify-write accumulation)
+    auto al = [](const void* ptr, int by) { return ((uintptr_t)ptr % by) == 0; };
+    const bool misaligned = !al(p.C, p.c_dtype == XVA_BF16 ? 8 : 16) || (p.R && !al(p.R, p.r_dtype == XVA_BF16 ? 8 : 16)) ||
+                            (p.G && !al(p.G, p.g_dtype == XVA_BF16 ? 8 : 16)) || (p.C2 && !al(p.C2, p.c_dtype == XVA_BF16 ? 8 : 16));
     for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < MN; e += (int64_t)gridDim.x * 1024) {
         float4 s = *reinterpret_cast<const float4*>(slab + k0 * MN + e);
         for (int k = k0 + 1; k < k1; ++k) {
@@ -32,24 +36,22 @@ __global__ __launch_bounds__(256) void xva_gemm_splitk_reduce_kernel(xva_gemm_pa
             continue;
         }
         const int row = (int)(e / p.N), col = (int)(e - (int64_t)row * p.N);   // N % 4 == 0: the 4 values share a row
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float x = v[q];
-            if (p.bias) x += p.bias[(int64_t)z2 * p.sbias2 + col + q];
-            x *= p.alpha;
-            if (p.R) x += p.beta * ld_elem(p.R, roff + (int64_t)row * p.ldr + col + q, p.r_dtype);
-            const int64_t ci = coff + (p.c_trans ? (int64_t)(col + q) * p.ldc + row : (int64_t)row * p.ldc + col + q);
-            if (p.c_dtype == XVA_BF16) {
-                uint16_t* dst = reinterpret_cast<uint16_t*>(p.C) + ci;
-                if (p.accumulate) x += bf2f(*dst);
-                *dst = f2bf(x);
-            } else {
-                float* dst = reinterpret_cast<float*>(p.C) + ci;
-                if (p.accumulate == 2) atomicAdd(dst, x);
-                else if (p.accumulate) *dst += x;
-                else *dst = x;
-            }
+        // the FULL epilogue of the tile kernels (bias, alpha, dropout, gate, residual, activation, row mask, dtype, transposed store, accumulate), so
+        // that products with a non-linear epilogue can be split along K as well (xva_gemm: forward / backward-data products with a long reduction
+        // and a grid far below 256 workgroups)
+        bool live = true;
+        if (p.mask_mode != XVA_MASK_NONE) {
+            const int64_t rr = (int64_t)row * p.mask_mul + p.mask_add;
+            const int t = (int)(rr % p.Tp);
+            live = t >= p.mask_pad && t < p.mask_pad + p.mask_len;
+            if (live && p.mask_mode == XVA_MASK_LEN) live = (t - p.mask_pad) < p.lens[rr / p.Tp];
         }
+        const int64_t goff = (int64_t)z1 * p.sG + (int64_t)z2 * p.sG2;
+        const bool vec = p.c_trans == 0 && (p.ldc % 4 == 0) && (p.sC % 4 == 0) && (p.sC2 % 4 == 0) &&
+                         (!p.R || (p.ldr % 4 == 0 && p.sR % 4 == 0 && p.sR2 % 4 == 0)) && (!p.G || (p.ldg % 4 == 0 && p.sG % 4 == 0 && p.sG2 % 4 == 0)) && !misaligned;
+        const f32x4 a4 = {v[0], v[1], v[2], v[3]};
+        if (vec) epilogue4<true>(q1, a4, row, col, live, true, z2, coff, roff, goff);
+        else epilogue4<false>(q1, a4, row, col, live, true, z2, coff, roff, goff);
     }
 }
 
