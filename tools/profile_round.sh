@@ -23,7 +23,8 @@ XVA_C5_GEMM_PROFILE=1 python $R/tools/c5_step_time.py 16 100 400 bf16 bf16 2>/de
 rocprofv3 --kernel-trace --stats -d /tmp/p_c5 -o c -- python $R/tools/c5_step_time.py 16 100 400 bf16 bf16 > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/p_c5 -name "*.db" | head -1) $O/${RD}_xvapitch_c5_kernel_stats.csv
 # occupancy timelines of the three steps from the kernel traces above (GPU busy union, idle gaps, kernels in flight, who runs alone): tools/trace_gaps.py
-python $R/tools/trace_dump.py $(find /tmp/p_fp -name "*.db" | head -1) /tmp/fp_trace.csv > /dev/null && python $R/tools/trace_gaps.py /tmp/fp_trace.csv lamb_pass1 5 > $O/${RD}_fastpitch_timeline.txt 2>&1
+rocprofv3 --kernel-trace -d /tmp/p_fpt -o t -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-hifigan --no-xvapitch --no-fp32-parity --no-roofline > /dev/null 2>&1   # no roofline passes: their LAMB timing loops would be the last markers
+python $R/tools/trace_dump.py $(find /tmp/p_fpt -name "*.db" | head -1) /tmp/fp_trace.csv > /dev/null && python $R/tools/trace_gaps.py /tmp/fp_trace.csv lamb_pass1 5 > $O/${RD}_fastpitch_timeline.txt 2>&1
 python $R/tools/trace_dump.py $(find /tmp/p_hg -name "*.db" | head -1) /tmp/hg_trace.csv > /dev/null && python $R/tools/trace_gaps.py /tmp/hg_trace.csv adamw_kernel 6 > $O/${RD}_hifigan_timeline.txt 2>&1
 python $R/tools/trace_dump.py $(find /tmp/p_c5 -name "*.db" | head -1) /tmp/c5_trace.csv > /dev/null && python $R/tools/trace_gaps.py /tmp/c5_trace.csv adamw_kernel 4 > $O/${RD}_xvapitch_c5_timeline.txt 2>&1
 # the mel front end's kernels per mode (fused kernel / four-launch FFT pipeline / dense DFT)
