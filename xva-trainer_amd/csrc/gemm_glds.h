@@ -395,7 +395,7 @@ __device__ __forceinline__ void wave_lds_order() {
 
 template <int MI, int NJ>
 __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32x4 (&acc)[MI][NJ], XVA_LDS float* scr, int r0, int c0, int lane,
-                                                   int z1, int z2, int bz, int ks) {
+                                                   int z1, int z2, int bz, int ks, int nt_store = 0) {
     constexpr int WN = NJ * 16, PITCH = WN + 4, LPR = WN / 8, RPP = 64 / LPR, NPASS = 16 / RPP;
     constexpr int CH = MI < 2 ? MI : 2;                                   // 16-row blocks whose loads are in flight together
     const int rr = lane / LPR, col = c0 + (lane % LPR) * 8;
@@ -491,6 +491,11 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                 }
                 const int64_t ci = coff + (int64_t)row * p.ldc + col;
                 if (p.c_dtype == XVA_BF16) {
+                    if (nt_store) {      // a streamed output (larger than the L2s): do not evict the operand panels the next rounds re-read
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                        __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.C) + ci));
+                    } else
                     *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + ci) =
                         make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
                 } else {
@@ -529,7 +534,8 @@ constexpr int epi_scratch_bytes(int WN) { return 16 * (WN + 4) * 4; }
 // vec_epi: 1 = host-verified that N % 4 == 0 and C / R / G rows are 4-element aligned (vector epilogue allowed); 2 = 8-element
 // granularity as well (row-contiguous epilogue through LDS)
 template <int LAYOUT, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2 > 80 * 1024) ? 1 : (BM * BN >= 128 * 128 ? 2 : 3)) void xva_gemm_glds_kernel(xva_gemm_params p, int vec_epi) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2 > 80 * 1024) ? 1 : (BM * BN >= 128 * 128 ? 2 : 3)) void xva_gemm_glds_kernel(xva_gemm_params p, int vec_flags) {
+    const int vec_epi = vec_flags & 15, nt_store = vec_flags >> 4;     // bit 4: non-temporal C stores (gemm_glds.hip)
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
     constexpr int MI = WM / 16, NJ = WN / 16;
     constexpr int AK = LAYOUT == XVA_GEMM_TN ? IC : KC;
@@ -685,7 +691,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
 #pragma unroll
             for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(acc[i][j]));
     } else if (rows_epilogue_ok(p, vec_epi))
-        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks);
+        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
     else
         tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
     XVA_T(3);
@@ -766,7 +772,8 @@ struct KcReader32 {
 //   * tile t + 1 is first read in I(2t+3); every wave waits for its own tile t + 1 loads (vmcnt leaves tiles t + 2, t + 3 outstanding) in
 //     its read slot of tile t (I(2t+1) / I(2t+2)), i.e. before a barrier the first reader passes.
 template <int LAYOUT>
-__global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params p, int vec_epi) {
+__global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params p, int vec_flags) {
+    const int vec_epi = vec_flags & 15, nt_store = vec_flags >> 4;     // bit 4: non-temporal C stores (gemm_glds.hip)
     constexpr int BM = 256, BN = 256, WM = 128, WN = 64;
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
     constexpr int MI = WM / 16, NJ = WN / 16;
@@ -950,7 +957,7 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
 #undef XVA_BAR
     XVA_T(2);
     if (rows_epilogue_ok(p, vec_epi))
-        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks);
+        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
     else
         tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
     XVA_T(3);

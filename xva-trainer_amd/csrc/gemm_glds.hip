@@ -108,6 +108,12 @@ int xva_gemm_launch_glds(const xva_gemm_params& pin, int tile, hipStream_t st) {
     if (p.splitk <= 1 || !p.sk_ws || p.sk_ws_bytes < need || p.N % 4 != 0 || ((uintptr_t)p.sk_ws % 16) != 0) p.sk_ws = nullptr;
     int vec = vec_epilogue_ok(p);
     if (p.sk_ws && p.N % 8 == 0) vec = 2;        // slab stores are [M][N] fp32 rows whatever C looks like
+    // Non-temporal stores for outputs that cannot stay in the 8 x 4 MB of L2 anyway (FastPitch's 27 584 x 1 536 feed-forward intermediate: 85 MB):
+    // written the default way they evict the weight / activation panels the tile's next rounds (and the other lane's kernels) re-read.
+    // XVA_GEMM_NT_MB: threshold in MB (0 = never).
+    static const long nt_mb = [] { const char* e = getenv("XVA_GEMM_NT_MB"); return e ? atol(e) : 0L; }();
+    if (nt_mb > 0 && vec == 2 && !p.sk_ws && !p.accumulate && !p.C2 && !p.c_trans && p.c_dtype == XVA_BF16 &&
+        (int64_t)p.M * p.N * 2 * p.batch * p.batch2 >= nt_mb * (1L << 20)) vec |= 16;
     int rc = launch_tiles(p, tile, vec, st);
     if (rc == 0 && p.sk_ws) rc = xva_gemm_launch_splitk_reduce(p, st);
     return rc;
