@@ -772,7 +772,7 @@ struct KcReader32 {
 //   * tile t + 1 is first read in I(2t+3); every wave waits for its own tile t + 1 loads (vmcnt leaves tiles t + 2, t + 3 outstanding) in
 //     its read slot of tile t (I(2t+1) / I(2t+2)), i.e. before a barrier the first reader passes.
 template <int LAYOUT>
-__global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params p, int vec_flags, int total_blocks) {
+__global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params p, int vec_flags) {
     const int vec_epi = vec_flags & 15, nt_store = vec_flags >> 4;     // bit 4: non-temporal C stores (gemm_glds.hip)
     constexpr int BM = 256, BN = 256, WM = 128, WN = 64;
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
@@ -784,13 +784,9 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
     XVA_LDS uint8_t* smem = (XVA_LDS uint8_t*)smem_raw;
 
     const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
-    // total_blocks > gridDim.x: a PERSISTENT launch (XVA_GEMM_PERSIST8, gemm_glds.h launch_tile8) — workgroup b walks the virtual blocks b, b + gridDim.x, ...
-    // (gridDim.x a multiple of 8: a virtual block keeps its XCD), one barrier between the epilogue's LDS scratch and the next tile's DMA.
-#pragma unroll 1
-    for (unsigned vblock = blockIdx.x; vblock < (unsigned)total_blocks; vblock += gridDim.x) {
     int Lg;
     {
-        const unsigned total = (unsigned)total_blocks, id = vblock;
+        const unsigned total = gridDim.x, id = blockIdx.x;
         const unsigned xcd = id & 7u, slot = id >> 3, q = total >> 3, r = total & 7u;
         Lg = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot);
     }
@@ -965,11 +961,6 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
     else
         tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
     XVA_T(3);
-    if (vblock + gridDim.x < (unsigned)total_blocks) {           // persistent: every wave is done with its epilogue scratch before the ring is refilled
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
-    }
-    }
 }
 
 // ---- 256 x 128 tile, K tile 32, three LDS stages, TWO workgroups per CU ------------------------------------------------------------
@@ -1299,10 +1290,7 @@ inline int launch_tile8(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
         attr_set = true;
     }
     long nblocks = (long)xva_cdiv(p.N, 256) * xva_cdiv(p.M, 256) * p.batch * p.batch2 * p.splitk;
-    // persistent by default (XVA_GEMM_PERSIST8=0: one workgroup per tile): at most one workgroup per CU walks the tile list — no workgroup relaunch between a CU tiles; measured -1.0 ... -1.6 % on the FastPitch decoder products, -1 % / -0.6 % on the FastPitch / HiFi-GAN steps (the epilogue stores still drain before the next tile: on gfx950 they share vmcnt with the loads)
-    static const int persist = [] { const char* e = getenv("XVA_GEMM_PERSIST8"); return e ? atoi(e) : 1; }();
-    const long grid = (persist && nblocks > 256) ? 256 : nblocks;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, st, p, vec_epi, (int)nblocks);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(512), LDS, st, p, vec_epi);
     return 0;
 }
 
