@@ -121,6 +121,9 @@ int xva_gemm_set_mainloop(int mode);
  * 1 (default) = two wave groups one barrier apart over a ring of four 32-deep K tiles ({12 LDS reads + DMA | 32 MFMAs} phases), 2 = 1 for
  * the NT layout, 0 for NN / TN. Returns the previous mode. Same results up to fp32 summation order. */
 int xva_gemm_set_kloop(int mode);
+/* Diagnostics / test knob: K loop of the 384x128 direct-to-LDS tile (NT / NN). 1 (default) = the staggered loop above with {10 LDS reads + DMA |
+ * 24 MFMAs} phases, 0 = all waves in one phase. Returns the previous mode. Same results up to fp32 summation order. */
+int xva_gemm_set_kloop384(int mode);
 /* Diagnostics / test knob: 1 (default) = convolution weight gradients (TN, column segments, fp32 C accumulated through the caller's
  * split-K slabs) run on the resident-operand kernel (csrc/wgrad_res.h: the chunk's dY and X rows loaded once, all taps from LDS);
  * 0 = they stay on the general TN tiles.  Returns the previous mode.  Same results up to fp32 summation order. */

@@ -14,16 +14,20 @@ def _lib():
     return _lib
 
 
-# (mainloop mode, K loop of the 256x256 tile): 2/0 = two barriers per K tile, 2/1 = staggered wave groups; 8 = 256x128 tile with a 32-deep K tile
-@pytest.fixture(params=[(1, 1), (2, 1), (2, 0), (3, 1), (4, 1), (5, 1), (-1, 1), (6, 1), (7, 1), (8, 1)],
-                ids=["tile128", "tile256", "tile256_lockstep", "tile128x64", "tile64", "tile128x32", "auto", "auto_no_resident_conv", "tile384x128", "tile256x128k32"])
+# (mainloop mode, K loop of the 256x256 tile, K loop of the 384x128 tile): 2/0 = two barriers per K tile, 2/1 = staggered wave groups; 8 = 256x128 tile with a
+# 32-deep K tile; 7 = the 384x128 tile with the staggered (1) or the lock-step (0) loop
+@pytest.fixture(params=[(1, 1, 1), (2, 1, 1), (2, 0, 1), (3, 1, 1), (4, 1, 1), (5, 1, 1), (-1, 1, 1), (6, 1, 1), (7, 1, 1), (7, 1, 0), (8, 1, 1)],
+                ids=["tile128", "tile256", "tile256_lockstep", "tile128x64", "tile64", "tile128x32", "auto", "auto_no_resident_conv", "tile384x128",
+                     "tile384x128_lockstep", "tile256x128k32"])
 def mainloop(request):
     L = _lib()
     old = L.lib.xva_gemm_set_mainloop(request.param[0])
     oldk = L.lib.xva_gemm_set_kloop(request.param[1])
+    oldk3 = L.lib.xva_gemm_set_kloop384(request.param[2])
     yield request.param[0]
     L.lib.xva_gemm_set_mainloop(old)
     L.lib.xva_gemm_set_kloop(oldk)
+    L.lib.xva_gemm_set_kloop384(oldk3)
 
 
 def _bf(rows, cols, ld=None, scale=1.0):

@@ -771,11 +771,16 @@ struct KcReader32 {
 //     from I(2t+1) on: after a barrier every reader has passed;
 //   * tile t + 1 is first read in I(2t+3); every wave waits for its own tile t + 1 loads (vmcnt leaves tiles t + 2, t + 3 outstanding) in
 //     its read slot of tile t (I(2t+1) / I(2t+2)), i.e. before a barrier the first reader passes.
-template <int LAYOUT>
+// The same loop serves a 384 x 128 tile (BM = 384, BN = 128, 8 waves of 96 x 64: products with 256 < N <= 384 — FastPitch's d_model — NT / NN only, a
+// 384-wide index-contiguous image is not laid out): the ring slots have the same 32 KiB (24 + 8), a phase is 10 fragment reads | 24 MFMAs, and the
+// two groups are the waves 0 - 3 / 4 - 7 (row quarters 0, 1 / 2, 3) — what matters is that every SIMD holds one wave of either group.  Before, that
+// tile ran the lock-step loop of xva_gemm_glds_kernel (1.78 us per 64-deep K tile against an MFMA floor of 0.74).
+template <int LAYOUT, int BM = 256, int BN = 256, int WM = 128, int WN = 64>
 __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params p, int vec_flags) {
     const int vec_epi = vec_flags & 15, nt_store = vec_flags >> 4;     // bit 4: non-temporal C stores (gemm_glds.hip)
-    constexpr int BM = 256, BN = 256, WM = 128, WN = 64;
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
+    static_assert(NW == 8 && (BM + BN) == 512, "8 waves, 32 KiB ring slots");
+    static_assert(LAYOUT != XVA_GEMM_TN || BM == 256, "TN: A is an index-contiguous image (power-of-two widths only)");
     constexpr int MI = WM / 16, NJ = WN / 16;
     constexpr int AK = LAYOUT == XVA_GEMM_TN ? IC : KC;
     constexpr int BKD = LAYOUT == XVA_GEMM_NT ? KC : IC;
@@ -806,6 +811,7 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
+    const int grp = wave >> 2;                                   // wave group: waves g and g + 4 share a SIMD
     XVA_T(0);
 
     Loader32<AK, BM, NW> la;
@@ -896,7 +902,7 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
     if (NS > 4 && ntl > 3) __builtin_amdgcn_s_waitcnt(WAIT_VM3);
     else if (ntl > 2) __builtin_amdgcn_s_waitcnt(WAIT_VM2); else if (ntl > 1) __builtin_amdgcn_s_waitcnt(WAIT_VM1); else __builtin_amdgcn_s_waitcnt(WAIT_VM0);
     XVA_BAR();
-    if (wm == 1) XVA_BAR();                                      // group 1 runs one barrier behind group 0
+    if (grp == 1) XVA_BAR();                                     // group 1 runs one barrier behind group 0
     XVA_T(1);
     int slot = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -953,7 +959,7 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
         XVA_BAR();
         slot = slot == NS - 1 ? 0 : slot + 1;
     }
-    if (wm == 0) XVA_BAR();
+    if (grp == 0) XVA_BAR();
 #undef XVA_BAR
     XVA_T(2);
     if (rows_epilogue_ok(p, vec_epi))
@@ -1280,16 +1286,16 @@ inline int launch_tile3(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
     return 0;
 }
 
-template <int LAYOUT>
+template <int LAYOUT, int BM = 256, int BN = 256, int WM = 128, int WN = 64>
 inline int launch_tile8(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
-    constexpr int LDS = XVA_GLDS8_SLOTS * (256 + 256) * GK3 * 2;
-    auto kern = xva_gemm_glds8_kernel<LAYOUT>;
+    constexpr int LDS = XVA_GLDS8_SLOTS * (BM + BN) * GK3 * 2;
+    auto kern = xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
         attr_set = true;
     }
-    long nblocks = (long)xva_cdiv(p.N, 256) * xva_cdiv(p.M, 256) * p.batch * p.batch2 * p.splitk;
+    long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, BM) * p.batch * p.batch2 * p.splitk;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(512), LDS, st, p, vec_epi);
     return 0;
 }

@@ -97,6 +97,9 @@ int xva_gemm_launch_splitk_reduce(const xva_gemm_params& p, hipStream_t st) {
 // warm operands; inside the training steps (operands from HBM) FastPitch -0.8 %, HiFi-GAN -1.0 % step time.  env XVA_GEMM_KLOOP8
 static int g_kloop8 = [] { const char* e = getenv("XVA_GEMM_KLOOP8"); return e ? atoi(e) : 1; }();
 extern "C" int xva_gemm_set_kloop(int mode) { int old = g_kloop8; g_kloop8 = mode; return old; }
+// K loop of the 384 x 128 tile: 1 (default) = the staggered loop, 0 = the lock-step loop of xva_gemm_glds_kernel.  env XVA_GEMM_KLOOP384
+static int g_kloop384 = [] { const char* e = getenv("XVA_GEMM_KLOOP384"); return e ? atoi(e) : 1; }();
+extern "C" int xva_gemm_set_kloop384(int mode) { int old = g_kloop384; g_kloop384 = mode; return old; }
 static int vec_epilogue_ok(const xva_gemm_params& p);
 
 // tile: see launch_tiles
@@ -144,7 +147,12 @@ static int launch_tiles(const xva_gemm_params& p, int tile, int vec, hipStream_t
         case 2: return launch_layout<128, 64, 32, 64>(p, vec, st);
         case 3: return launch_layout<64, 64, 32, 32>(p, vec, st);
         case 4: return launch_layout<128, 32, 32, 32>(p, vec, st);       // N <= 32: no padded columns through the matrix pipe
-        case 5: return launch_layout<384, 128, 96, 64>(p, vec, st);      // 256 < N <= 384 (FastPitch d_model): no padded columns, one workgroup per CU
+        case 5:                                                          // 256 < N <= 384 (FastPitch d_model): no padded columns, one workgroup per CU
+            if (g_kloop384) {                                            // the staggered K loop (xva_gemm_glds8_kernel<.., 384, 128, 96, 64>)
+                if (p.layout == XVA_GEMM_NT) return xva_glds::launch_tile8<XVA_GEMM_NT, 384, 128, 96, 64>(p, vec, st);
+                if (p.layout == XVA_GEMM_NN) return xva_glds::launch_tile8<XVA_GEMM_NN, 384, 128, 96, 64>(p, vec, st);
+            }
+            return launch_layout<384, 128, 96, 64>(p, vec, st);
         case 6:                                                          // 256x128, K tile 32, two workgroups per CU
             switch (p.layout) {
                 case XVA_GEMM_NT: return xva_glds::launch_tile3<XVA_GEMM_NT, 256, 128>(p, vec, st);
