@@ -436,6 +436,26 @@ def fastpitch_fp32_leg(a, dev, steps=5, warm=2):
             grads.zero_()
             eng.fwd_loss_bwd(flat, grads, batch, a.stage)
         res["roofline"] = gemm_roofline(run_profiled, 1, "mfma", 157.3, "FastPitch fwd+bwd in the fp32 parity mode: 1 extra profiled pass")
+    # The same fp32-stored step with every product formed by three bf16 MFMAs on operands split into hi + lo bf16 while staged
+    # (csrc/gemm_core.h MODE 3, xva_gemm_set_fp32_products(1)): ~1e-5 per product; meets the same 1e-3 / 2e-3 bounds against the reference
+    # goldens (tests/test_fastpitch_gpu.py::test_against_reference_golden[*-fp32_split3]).
+    from xva_trainer_amd import _lib
+    old_mode = _lib.lib.xva_gemm_set_fp32_products(1)
+    try:
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+    finally:
+        _lib.lib.xva_gemm_set_fp32_products(old_mode)
+    res["split_products"] = {"ms_per_step": 1000.0 * dt3 / steps, "value": frames * steps / dt3, "unit": "mel-frames/s", "steps": steps,
+                             "final_loss": eng.slot("LOSSES", (8,)).cpu()[0].item(),
+                             "note": "fp32 storage, products as three bf16 MFMAs on hi + lo split operands (16 mantissa bits per operand, fp32 accumulation); "
+                                     "same parity bounds as the exact mode except the post-LAMB parameter norms (1e-4 instead of 1e-5)"}
     del eng, opt, grads, flat
     torch.cuda.empty_cache()
     return res

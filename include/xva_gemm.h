@@ -117,6 +117,11 @@ int xva_gemm(const xva_gemm_params* p, void* stream);
  * 1..5 direct-to-LDS 128x128 / 256x256 / 128x64 / 64x64 / 128x32 tiles wherever eligible, 6 automatic without the resident-input
  * convolution kernel, 7 the 384x128 tile (NT / NN). Returns the previous mode. Results are the same up to fp32 summation order. */
 int xva_gemm_set_mainloop(int mode);
+/* How products of fp32-stored operands with compute == 0 are formed: 0 (default) = the exact fp32 MFMA (k-ordered fmaf chain: the parity mode),
+ * 1 = every operand element split into two bf16 while staged (x = hi + lo, 16 mantissa bits) and three bf16 MFMAs per product with fp32
+ * accumulation (the lo * lo term, <= 2^-16 of the product, is dropped): ~1e-5 relative per product at a fraction of the matrix-pipe time.
+ * Returns the previous mode. */
+int xva_gemm_set_fp32_products(int mode);
 /* Diagnostics / test knob: K loop of the 256x256 direct-to-LDS tile. 0 = all waves in one phase (two barriers per 64-deep K tile),
  * 1 (default) = two wave groups one barrier apart over a ring of four 32-deep K tiles ({12 LDS reads + DMA | 32 MFMAs} phases), 2 = 1 for
  * the NT layout, 0 for NN / TN. Returns the previous mode. Same results up to fp32 summation order. */

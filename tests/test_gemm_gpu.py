@@ -10,7 +10,26 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOL = {0: 2e-5, 1: 2e-2}  # relative to max |ref|: fp32-exact MFMA vs bf16-input MFMA
+class _Tol(dict):
+    """relative to max |ref|: fp32-exact MFMA (or, under the fp32_products fixture, the bf16 hi + lo split: 16 mantissa bits per operand) vs bf16-input MFMA"""
+    split = False
+
+    def __getitem__(self, compute):
+        return {0: 6e-5 if self.split else 2e-5, 1: 2e-2}[compute]
+
+
+TOL = _Tol()
+
+
+@pytest.fixture(autouse=True, params=[0, 1], ids=["fp32_exact", "fp32_split3"])
+def fp32_products(request):
+    """every case twice: compute == 0 products by the exact fp32 MFMA and by three bf16 MFMAs on split operands (xva_gemm_set_fp32_products)"""
+    from xva_trainer_amd import _lib
+    old = _lib.lib.xva_gemm_set_fp32_products(request.param)
+    TOL.split = bool(request.param)
+    yield request.param
+    _lib.lib.xva_gemm_set_fp32_products(old)
+    TOL.split = False
 
 
 def _lib():
@@ -170,7 +189,7 @@ def test_epilogue_residual_gate_accumulate():
     L.gemm(A, B, Cm, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=0, R=R, ldr=N, G=G, ldg=N, accumulate=True, alpha=0.5)
     # epilogue order: alpha * acc -> gate -> + beta * R  (the residual path is not gated)
     ref = C0.double() + torch.where(G > 0, 0.5 * (A[:, :K].double() @ B[:, :K].double().t()), torch.zeros((), device="cuda", dtype=torch.float64)) + R.double()
-    assert _relerr(Cm, ref) < 2e-5
+    assert _relerr(Cm, ref) < TOL[0]
 
 
 def test_bad_arguments_fail_loudly():

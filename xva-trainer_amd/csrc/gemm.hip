@@ -6,6 +6,7 @@
 void xva_gemm_launch_fp32(const xva_gemm_params& p, int bn, unsigned nblocks, hipStream_t st);
 void xva_gemm_launch_bf16(const xva_gemm_params& p, int bn, unsigned nblocks, hipStream_t st);
 void xva_gemm_launch_mixed(const xva_gemm_params& p, int bn, unsigned nblocks, hipStream_t st);
+void xva_gemm_launch_split(const xva_gemm_params& p, int bn, unsigned nblocks, hipStream_t st);
 bool xva_gemm_glds_eligible(const xva_gemm_params& p);
 int xva_gemm_launch_glds(const xva_gemm_params& p, int tile, hipStream_t st);
 void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn);
@@ -22,6 +23,10 @@ void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn, double b
 // 128x128 / 256x256 / 128x64 / 64x64 wherever eligible.  A diagnostics / test knob, not part of the numerical contract.
 static int g_glds_mode = [] { const char* e = getenv("XVA_GEMM_GLDS"); return e ? atoi(e) : -1; }();
 extern "C" int xva_gemm_set_mainloop(int mode) { int old = g_glds_mode; g_glds_mode = mode; return old; }
+// Products of compute == 0 (fp32-stored operands): 0 (default) = the exact fp32 MFMA, 1 = each operand split into two bf16 (hi + lo) while staged and
+// three bf16 MFMAs per product (gemm_core.h MODE 3; ~1e-5 relative per product instead of 6e-8).  env XVA_GEMM_FP32_PRODUCTS
+static int g_fp32_products = [] { const char* e = getenv("XVA_GEMM_FP32_PRODUCTS"); return e ? atoi(e) : 0; }();
+extern "C" int xva_gemm_set_fp32_products(int mode) { int old = g_fp32_products; g_fp32_products = mode; return old; }
 
 extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     XVA_CHECK_ARG(pp != nullptr, "xva_gemm: null params");
@@ -149,9 +154,9 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     long nblocks = glds_tile >= 0 ? 1 : (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2 * p.splitk;
     XVA_CHECK_ARG(nblocks < (1L << 31), "xva_gemm: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    const int mode = p.compute == 0 ? 0 : (p.a_dtype == XVA_BF16 ? 1 : 2);
+    const int mode = p.compute == 0 ? (g_fp32_products == 1 ? 3 : 0) : (p.a_dtype == XVA_BF16 ? 1 : 2);
     const bool prof = xva_prof_is_on();
-    if (prof) { xva_prof_begin(st, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + mode); 
+    if (prof) { xva_prof_begin(st, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + (mode == 3 ? 0 : mode)); 
         // algorithmic bytes: each distinct element of A, B once (tap segments re-address the SAME rows/columns), C written (read too when
         // accumulating), residual and gate read
         const double es_ab = p.a_dtype == XVA_BF16 ? 2.0 : 4.0, es_c = p.c_dtype == XVA_BF16 ? 2.0 : 4.0, nbz = (double)p.batch * p.batch2;
@@ -167,6 +172,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (xva_gemm_launch_conv_res(p, res_dstep, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; }
     } else if (glds_tile >= 0) { if (xva_gemm_launch_glds(p, glds_tile, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; } }
     else if (mode == 0) xva_gemm_launch_fp32(p, bn, (unsigned)nblocks, st);
+    else if (mode == 3) xva_gemm_launch_split(p, bn, (unsigned)nblocks, st);
     else if (mode == 1) xva_gemm_launch_bf16(p, bn, (unsigned)nblocks, st);
     else xva_gemm_launch_mixed(p, bn, (unsigned)nblocks, st);
     if (prof) xva_prof_end(st);

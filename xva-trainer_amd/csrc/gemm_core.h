@@ -15,6 +15,9 @@
 // MODE 0: fp32 storage, fp32 LDS, v_mfma_f32_16x16x4_f32 (exact fp32 = k-ordered fmaf chain): the parity mode.
 // MODE 1: bf16 storage, bf16 LDS, v_mfma_f32_16x16x32_bf16.
 // MODE 2: fp32 storage rounded to bf16 while staged, bf16 LDS, v_mfma_f32_16x16x32_bf16.
+// MODE 3: fp32 storage SPLIT into two bf16 while staged (x = hi + lo, hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits), two bf16 LDS planes,
+//         three v_mfma_f32_16x16x32_bf16 per product (lo*hi + hi*lo + hi*hi, fp32 accumulation; lo*lo <= 2^-16 of the term is dropped): products good
+//         to ~1e-5 relative at a sixth of the matrix-pipe time of the exact fp32 MFMA (xva_gemm_set_fp32_products(1); the exact mode stays the default).
 #pragma once
 #include "xva_common.h"
 #include "../../include/xva_gemm.h"
@@ -36,6 +39,7 @@ template <int MODE> struct Cfg;
 template <> struct Cfg<0> { typedef float S; typedef float L; static constexpr int VE = 4, LD = BK + 4; static constexpr bool BF = false; };
 template <> struct Cfg<1> { typedef uint16_t S; typedef __bf16 L; static constexpr int VE = 8, LD = BK + 8; static constexpr bool BF = true; };
 template <> struct Cfg<2> { typedef float S; typedef __bf16 L; static constexpr int VE = 4, LD = BK + 8; static constexpr bool BF = true; };
+template <> struct Cfg<3> { typedef float S; typedef __bf16 L; static constexpr int VE = 4, LD = BK + 8; static constexpr bool BF = true; };
 
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ uint32_t pack_bf2(float a, float b);
@@ -51,10 +55,16 @@ __device__ __forceinline__ float ld_elem(const void* p, int64_t idx, int dtype) 
     return dtype == XVA_BF16 ? bf2f(reinterpret_cast<const uint16_t*>(p)[idx]) : reinterpret_cast<const float*>(p)[idx];
 }
 
+// x = hi + lo in bf16 pairs: (a, b) -> packed hi pair, packed lo pair
+__device__ __forceinline__ void split_bf2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf2(a, b);
+    lo = pack_bf2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
 // ---- a 16-byte staged vector and its LDS store ------------------------------------------------------------
 // fp32 storage: 4 k-consecutive floats.  bf16 storage: 8 k-consecutive bf16.
+// plane: elements between the hi and the lo image of an operand tile (MODE 3)
 template <int MODE, bool ACT>
-__device__ __forceinline__ void st_vec_k(typename Cfg<MODE>::L* dst, uint4 raw, float slope) {
+__device__ __forceinline__ void st_vec_k(typename Cfg<MODE>::L* dst, uint4 raw, float slope, int plane = 0) {
     if constexpr (MODE == 1) {
         if constexpr (ACT) {
             uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -71,6 +81,11 @@ __device__ __forceinline__ void st_vec_k(typename Cfg<MODE>::L* dst, uint4 raw, 
         if constexpr (ACT) { a = lrelu(a, slope); b = lrelu(b, slope); c = lrelu(c, slope); d = lrelu(d, slope); }
         if constexpr (MODE == 2) {
             *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2(a, b), pack_bf2(c, d));
+        } else if constexpr (MODE == 3) {
+            uint32_t h0, l0, h1, l1;
+            split_bf2(a, b, h0, l0); split_bf2(c, d, h1, l1);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(dst + plane) = make_uint2(l0, l1);
         } else {
             *reinterpret_cast<float4*>(dst) = make_float4(a, b, c, d);
         }
@@ -78,8 +93,13 @@ __device__ __forceinline__ void st_vec_k(typename Cfg<MODE>::L* dst, uint4 raw, 
 }
 // 4 k-consecutive values given as floats
 template <int MODE>
-__device__ __forceinline__ void st_quad(typename Cfg<MODE>::L* dst, float a, float b, float c, float d) {
-    if constexpr (Cfg<MODE>::BF) {
+__device__ __forceinline__ void st_quad(typename Cfg<MODE>::L* dst, float a, float b, float c, float d, int plane = 0) {
+    if constexpr (MODE == 3) {
+        uint32_t h0, l0, h1, l1;
+        split_bf2(a, b, h0, l0); split_bf2(c, d, h1, l1);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + plane) = make_uint2(l0, l1);
+    } else if constexpr (Cfg<MODE>::BF) {
         *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2(a, b), pack_bf2(c, d));
     } else {
         *reinterpret_cast<float4*>(dst) = make_float4(a, b, c, d);
@@ -145,7 +165,7 @@ struct KcStage {
             const int vid = t + it * NTHREADS;
             if (NV % NTHREADS != 0 && vid >= NV) continue;
             const int row = vid / VPR, kv = vid % VPR;
-            st_vec_k<MODE, ACT>(Xs + row * C::LD + kv * C::VE, v[it], slope);
+            st_vec_k<MODE, ACT>(Xs + row * C::LD + kv * C::VE, v[it], slope, ROWS * C::LD);
         }
     }
 };
@@ -230,7 +250,7 @@ struct IcStage {
                 for (int e = 0; e < 4; ++e) {
                     float a = f[0][e], b = f[1][e], c = f[2][e], dd = f[3][e];
                     if constexpr (ACT) { a = lrelu(a, slope); b = lrelu(b, slope); c = lrelu(c, slope); dd = lrelu(dd, slope); }
-                    st_quad<MODE>(d + e * C::LD, a, b, c, dd);
+                    st_quad<MODE>(d + e * C::LD, a, b, c, dd, ROWS * C::LD);
                 }
             }
         }
@@ -238,14 +258,15 @@ struct IcStage {
 };
 
 template <int LAYOUT, int MODE, int BN>
-__global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p) {
+__global__ __launch_bounds__(NTHREADS, (MODE == 3 && BN == 128) ? 2 : 3) void xva_gemm_kernel(xva_gemm_params p) {
     typedef Cfg<MODE> C;
     typedef typename C::S ST;
     typedef typename C::L LT;
     constexpr int LD = C::LD;
     constexpr int NTN = BN / 32;   // MFMA column tiles per wave
-    __shared__ __attribute__((aligned(16))) LT As[BM * LD];
-    __shared__ __attribute__((aligned(16))) LT Bs[BN * LD];
+    constexpr int PLANES = MODE == 3 ? 2 : 1;                       // MODE 3: hi image, then lo image
+    __shared__ __attribute__((aligned(16))) LT As[PLANES * BM * LD];
+    __shared__ __attribute__((aligned(16))) LT Bs[PLANES * BN * LD];
 
     // XCD-aware tile order: hardware places workgroup id on XCD id % 8 (each XCD has a private 4 MiB L2).  Give every XCD
     // a CONTIGUOUS run of logical tiles (n fastest, then m, then batch/split) so that the workgroups resident on one XCD
@@ -374,7 +395,35 @@ __global__ __launch_bounds__(NTHREADS, 3) void xva_gemm_kernel(xva_gemm_params p
 
         const LT* Aw = As + (wm * 64 + (lane & 15)) * LD;
         const LT* Bw = Bs + (wn * (BN / 2) + (lane & 15)) * LD;
-        if constexpr (C::BF) {
+        if constexpr (MODE == 3) {
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                bf16x8 ah[4], al[4], bh[NTN], bl[NTN];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(Aw + i * 16 * LD + kh * 32 + (lane >> 4) * 8);
+                    al[i] = *reinterpret_cast<const bf16x8*>(Aw + BM * LD + i * 16 * LD + kh * 32 + (lane >> 4) * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < NTN; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(Bw + j * 16 * LD + kh * 32 + (lane >> 4) * 8);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(Bw + BN * LD + j * 16 * LD + kh * 32 + (lane >> 4) * 8);
+                }
+                // term-major: the three MFMAs of one accumulator are 4 * NTN instructions apart (small terms first)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        } else if constexpr (C::BF) {
 #pragma unroll
             for (int kh = 0; kh < KH; ++kh) {
                 bf16x8 af[4], bfr[NTN];
