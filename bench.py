@@ -226,9 +226,8 @@ def pmc_traffic(family, pmc_csv):
         return None, "profiles/%s is stale (kernel sources changed since that PMC pass): not quoted" % pmc_csv
     m = re.match(r"xva_gemm_glds_kernel<(\d+)x(\d+)>", family)
     if m:
-        pat = re.compile(r"xva_gemm_glds_kernel<\d, %s, %s," % (m.group(1), m.group(2)))
-        if m.group(1) == "256" and m.group(2) == "256":     # both K loops of the 256x256 tile (the staggered one is its own kernel)
-            pat = re.compile(r"xva_gemm_glds_kernel<\d, 256, 256,|xva_gemm_glds8_kernel<\d>")
+        # both K loops of a tile: the lock-step kernel and the staggered one (xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN>: 256x256 and 384x128)
+        pat = re.compile(r"xva_gemm_glds8?_kernel<\d, %s, %s," % (m.group(1), m.group(2)))
     elif family.startswith("xva_conv_res_kernel<CIN="):
         pat = re.compile(r"xva_conv_res_kernel<\d, %s," % family[len("xva_conv_res_kernel<CIN="):-1])
     elif family.startswith("xva_wgrad_res_kernel"):
