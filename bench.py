@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--t-mel", type=int, default=860)
     ap.add_argument("--stage", type=int, default=3)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--hg-timeout", type=int, default=300, help="multi-rank runs: seconds after which the line is printed without the HiFi-GAN leg")
     ap.add_argument("--dropout", type=float, default=0.1, help="FastPitch dropout probability (reference trains with 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -44,6 +45,11 @@ def parse():
                     help="no GPU: run the multi-rank plumbing of this script (rank environment, process group, per-rank shards, the bucketed gradient "
                          "all-reduce over the engine's real bucket ranges, barrier + max-over-ranks timing, whole-job aggregation, the JSON line) on "
                          "CPU over gloo with a stand-in for the compute; the line carries \"dry_run\": true and is NOT a measurement")
+    ap.add_argument("--share-gpu-gloo", action="store_true",
+                    help="TEST ONLY (a box with one GPU): every rank uses cuda:0 and the process group is gloo instead of RCCL, so that the multi-rank "
+                         "path of this script — per-rank shards, event-driven bucket all-reduces on the side stream, barriers, MAX over ranks, the rank-0-only "
+                         "roofline passes next to the other ranks' collectives — executes end to end; the line carries \"shared_gpu_gloo\": true and its "
+                         "value is NOT a scaling measurement")
     ap.add_argument("--hg-batch", type=int, default=64)
     ap.add_argument("--hg-steps", type=int, default=0, help="timed HiFi-GAN steps (default: min(steps, 10))")
     return ap.parse_args()
@@ -372,7 +378,10 @@ def hifigan_leg(a, dev, rank, world):
            "config": {"workload": "HiFi-GAN v1 generator + MPD + MSD, batch %d/GPU x %d samples, D step + G step + 2 x fused AdamW" % (B, seg)},
            "loss_mel": float(out["loss_mel"].item()), "loss_disc_all": float(out["loss_disc_all"].item())}
     if rank == 0 and not a.no_roofline:
-        # the conv stack is priced against the HBM roofline (north_star): algorithmic bytes of every conv-as-GEMM launch / its time
+        # the conv stack is priced against the HBM roofline (north_star): algorithmic bytes of every conv-as-GEMM launch / its time.
+        # The extra profiled iteration runs on rank 0 ALONE: it must not contain a collective (the other ranks have left the leg and would never
+        # answer: the all-reduce — and with it this process — would hang), so the gradient exchange is switched off for it.
+        st.sync_d = st.sync_g = None
         res["roofline"] = gemm_roofline(lambda: st.train_step(x, y, y_mel), 1, "auto", 8000.0, "one extra profiled D+G iteration (stream lanes off)",
                                         pmc_csv="r03_hifigan_pmc_hbm_bytes.csv")
         # the HiFi-GAN conv stack is priced on HBM — ALGORITHMIC bytes of the whole iteration (every distinct operand /
@@ -466,7 +475,7 @@ def spawn_ranks(n):
     over RCCL).  Fails loudly when the node has fewer than N devices."""
     import socket
     have = torch.cuda.device_count()
-    if have < n and "--dry-run-gloo" not in sys.argv:
+    if have < n and "--dry-run-gloo" not in sys.argv and "--share-gpu-gloo" not in sys.argv:
         sys.exit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (n, have))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -657,13 +666,18 @@ def main():
         sys.exit("bench.py: --gpus %d does not match the launcher's WORLD_SIZE %d" % (a.gpus, world))
     if a.dry_run_gloo:
         return dry_run_gloo(a, rank, world)
+    if a.share_gpu_gloo:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         sys.exit("bench.py: rank %d needs cuda:%d but only %d GPU(s) are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.share_gpu_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == world
 
     from xva_trainer_amd import _lib, synthetic
@@ -735,6 +749,8 @@ def main():
                    "global_batch": a.batch * world, "per_gpu_frames_per_step": frames_per_step, "parallelism": "dp%d" % world,
                    "final_loss": loss},
     }
+    if a.share_gpu_gloo:
+        out["shared_gpu_gloo"] = True
     if rank == 0 and not a.no_roofline:
         def run_profiled():
             grads.zero_()
@@ -754,9 +770,30 @@ def main():
         del opt, grads
         eng._ws = None
         torch.cuda.empty_cache()
-        hg = hifigan_leg(a, dev, rank, world)
-        if rank == 0 and world == 1 and not a.no_cpu_baseline:
-            hg["cpu_baseline"] = hifigan_cpu_baseline()
+        if world > 1:
+            # The HiFi-GAN leg is an EXTRA object of the line; in a multi-rank run it contains collectives of its own.  It must never cost the
+            # contract line: if it has not finished after --hg-timeout seconds (a rank that died, a collective that never completes), rank 0
+            # prints the line it already has and every rank leaves.
+            import threading
+            hg_done = threading.Event()
+
+            def watchdog():
+                if not hg_done.wait(a.hg_timeout):
+                    if rank == 0:
+                        out["hifigan"] = {"error": "the multi-rank HiFi-GAN leg did not finish within %d s: line printed without it" % a.hg_timeout}
+                        print(json.dumps(out), flush=True)
+                    os._exit(0)
+            threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            hg = hifigan_leg(a, dev, rank, world)
+            if rank == 0 and world == 1 and not a.no_cpu_baseline:
+                hg["cpu_baseline"] = hifigan_cpu_baseline()
+        except Exception as e:
+            if world == 1:
+                raise
+            hg = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world > 1:
+            hg_done.set()
         out["hifigan"] = hg
     if rank == 0 and world == 1 and not a.no_xvapitch:
         try:

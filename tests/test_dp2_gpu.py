@@ -161,3 +161,30 @@ def test_hifigan_bucketsync_world2_equals_full_batch(tmp_path, backend):
             assert nb > 0 and ((res[key][b:e] - ref[b:e]).norm().item() / nb) < (1e-3 if which == HE.D else 2e-2), (key, i)
     assert ((res["fd"] - st.flat_d.cpu()).abs().max().item()) < 5e-4      # one AdamW step moves a weight by <= lr = 2e-4
     assert ((res["fg"] - st.flat_g.cpu()).abs().max().item()) < 5e-4
+
+
+@pytest.mark.timeout(1000)
+def test_bench_two_ranks_sharing_the_gpu_end_to_end():
+    """`python bench.py --gpus 2 --share-gpu-gloo`: the WHOLE multi-rank flow of the bench on the device path — the script re-executes itself under
+    torch.distributed.run, two ranks (both on cuda:0, gloo instead of RCCL) run the FastPitch step through GradSync (bucket events, side-stream
+    all-reduces, globally normalised losses) and the HiFi-GAN iteration through BucketSync, rank 0 alone runs its roofline passes next to the other
+    rank's collectives (an extra profiled HiFi-GAN iteration with its gradient exchange switched off: with it on, rank 0 hung in an all-reduce nobody
+    answered), and ONE contract line comes out with both legs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu-gloo", "--steps", "2", "--warmup", "1", "--hg-steps", "2",
+                        "--hg-timeout", "240"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["shared_gpu_gloo"] is True and out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 64
+    assert out["config"]["parallelism"] == "dp2" and out["value"] > 0 and "roofline" in out
+    hg = out["hifigan"]
+    assert "error" not in hg and hg["value"] > 0 and "roofline" in hg and "roofline_stack" in hg, hg
