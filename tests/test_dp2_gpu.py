@@ -179,12 +179,12 @@ def test_bench_two_ranks_sharing_the_gpu_end_to_end():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu-gloo", "--steps", "2", "--warmup", "1", "--hg-steps", "2",
-                        "--hg-timeout", "240"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+                        "--batch", "4", "--t-text", "40", "--t-mel", "200", "--hg-batch", "4", "--hg-timeout", "240"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["shared_gpu_gloo"] is True and out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 64
+    assert out["shared_gpu_gloo"] is True and out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 8
     assert out["config"]["parallelism"] == "dp2" and out["value"] > 0 and "roofline" in out
     hg = out["hifigan"]
     assert "error" not in hg and hg["value"] > 0 and "roofline" in hg and "roofline_stack" in hg, hg
