@@ -238,15 +238,27 @@ struct Ctx {
     int lane = 0;     // 0: the caller's stream, 1: the weight-gradient side stream, 2: the predictor side stream (own split-K slabs each)
     void* const* events = nullptr;  // optional hipEvent_t per gradient bucket (data-parallel overlap)
     int ev_base = 0;
-    int record(int i) {
-        if (events && events[i] && hipEventRecord((hipEvent_t)events[i], (hipStream_t)st) != hipSuccess) { xva_set_error("bucket event record failed"); return XVA_ERR_HIP; }
-        return XVA_OK;
-    }
+    int record(int i);
     char* A(int64_t off) const { return W + off; }                       // activation tensor at byte offset
     float* F(int64_t off) const { return (float*)(W + off); }            // fp32 tensor at byte offset
     const void* wt(int64_t elem_off) const { return Pw + elem_off * es; } // parameter tensor as a GEMM operand
     char* sh(char* p, int64_t elems) const { return p + elems * es; }     // shift an activation pointer by elements
 };
+
+// Bucket i's gradients are final on the lane this context issues to: record its event there and, when the data-parallel host has registered a
+// callback, call it NOW — while the host is still issuing backward.  The host enqueues the bucket's wait + all-reduce from inside it.  Measured
+// (tools/dp_overlap_probe.py): a hipStreamWaitEvent issued only after the whole backward had been issued resolved when the recording lane had DRAINED —
+// every bucket's exchange started at the end of backward, whatever the event flags; issued right behind the record it resolves at the record.
+typedef void (*xva_bucket_cb_t)(int bucket, void* user);
+static thread_local xva_bucket_cb_t g_bucket_cb = nullptr;
+static thread_local void* g_bucket_user = nullptr;
+extern "C" void xva_fp_set_bucket_callback(xva_bucket_cb_t cb, void* user) { g_bucket_cb = cb; g_bucket_user = user; }
+int Ctx::record(int i) {
+    if (!events || !events[i]) return XVA_OK;
+    if (hipEventRecord((hipEvent_t)events[i], (hipStream_t)st) != hipSuccess) { xva_set_error("bucket event record failed"); return XVA_ERR_HIP; }
+    if (g_bucket_cb) g_bucket_cb(i, g_bucket_user);
+    return XVA_OK;
+}
 
 static xva_gemm_params gp0(const Ctx& c) {
     xva_gemm_params g;

@@ -14,6 +14,7 @@ the minibatch; per optimizer step there are exactly two exchanges:
 With gradient accumulation only the last micro-batch synchronises (pass sync=False for the others).
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -28,6 +29,9 @@ lib.xva_fp_bucket_range.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C
 lib.xva_fp_backward_ex.restype = C.c_int32
 lib.xva_fp_backward_ex.argtypes = [C.POINTER(E.FpDims), C.c_void_p, C.c_void_p, C.POINTER(E.FpBatch), C.c_void_p, C.c_int64,
                                    C.POINTER(C.c_void_p), C.c_void_p]
+_BUCKET_CB = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)
+lib.xva_fp_set_bucket_callback.restype = None
+lib.xva_fp_set_bucket_callback.argtypes = [C.c_void_p, C.c_void_p]
 lib.xva_event_create.restype = C.c_void_p
 lib.xva_event_destroy.argtypes = [C.c_void_p]
 lib.xva_stream_wait_event.restype = C.c_int32
@@ -61,7 +65,7 @@ class GradSync:
         self.ranges = bucket_ranges()
         n = len(self.ranges)
         self.events = (C.c_void_p * n)(*[lib.xva_event_create() for _ in range(n)])
-        self.comm = torch.cuda.Stream(device=flat.device)
+        self.comm = torch.cuda.Stream(device=flat.device, priority=int(os.environ.get("XVA_DP_COMM_PRIO", "-1")))
         self._works = []
 
     def __del__(self):
@@ -87,13 +91,37 @@ class GradSync:
         with torch.cuda.stream(self.comm):
             wloss = dist.all_reduce(losses, group=self.group, async_op=True)   # reporting: SUM of the shares, under backward
         d = eng._prepare(batch.B, batch.Tt, batch.Tm, stage)
-        rc = lib.xva_fp_backward_ex(C.byref(d), _lib.ptr(self.flat), _lib.ptr(self.grads), C.byref(eng._abi), _lib.ptr(eng._ws),
-                                    eng._ws.numel(), self.events if sync else None, _lib.stream_ptr())
-        _lib.check(rc, "xva_fp_backward_ex")
+        self._works, self._cb_error = [], None
         if sync:
+            # The engine calls back right after it has recorded a bucket's event, while this thread is still inside xva_fp_backward_ex issuing the rest
+            # of backward: the bucket's wait + all-reduce go onto the exchange stream at that moment.  (Enqueued after the call had returned, every wait
+            # resolved when the recording lane had drained — the exchange ran after backward instead of under it: tools/dp_overlap_probe.py.)
             comm_ptr = C.c_void_p(self.comm.cuda_stream)
-            self._works = []
-            for i in buckets_for_stage(stage):
+            live = set(buckets_for_stage(stage))
+
+            def on_bucket(i, _user):
+                try:
+                    if i in live:
+                        b, e = self.ranges[i]
+                        _lib.check(lib.xva_stream_wait_event(comm_ptr, self.events[i]), "xva_stream_wait_event")
+                        with torch.cuda.stream(self.comm):
+                            self._works.append(dist.all_reduce(self.grads[b:e], group=self.group, async_op=True))
+                        live.discard(i)
+                except BaseException as ex:                         # never unwind through the C frames: re-raised below
+                    self._cb_error = ex
+            cb = _BUCKET_CB(on_bucket)
+            lib.xva_fp_set_bucket_callback(C.cast(cb, C.c_void_p), None)
+        try:
+            rc = lib.xva_fp_backward_ex(C.byref(d), _lib.ptr(self.flat), _lib.ptr(self.grads), C.byref(eng._abi), _lib.ptr(eng._ws),
+                                        eng._ws.numel(), self.events if sync else None, _lib.stream_ptr())
+        finally:
+            if sync:
+                lib.xva_fp_set_bucket_callback(None, None)
+        _lib.check(rc, "xva_fp_backward_ex")
+        if self._cb_error is not None:
+            raise self._cb_error
+        if sync:
+            for i in sorted(live):                                  # a bucket the engine did not announce (none today): exchange it after the call
                 b, e = self.ranges[i]
                 _lib.check(lib.xva_stream_wait_event(comm_ptr, self.events[i]), "xva_stream_wait_event")
                 with torch.cuda.stream(self.comm):
