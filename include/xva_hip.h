@@ -246,6 +246,8 @@ int xva_al_dk_fix(float* dk, const float* k, const float* colsum, int B, int Tt,
  * i.e. while the host is still issuing backward — so that the host can enqueue that bucket's wait + all-reduce on its exchange stream at once
  * (a wait issued after the whole backward has been issued resolves only when the recording lane has drained).  NULL unregisters. */
 void xva_fp_set_bucket_callback(void (*cb)(int bucket, void* user), void* user);
+/* the same for xva_hg_disc_backward_d_ex / xva_hg_generator_backward_ex (and their xVAPitch variants): bucket indices of the call in progress */
+void xva_hg_set_bucket_callback(void (*cb)(int bucket, void* user), void* user);
 /* Data-parallel overlap: gradient buckets (contiguous flat ranges, in backward completion order) and a backward
  * that records one hipEvent_t per bucket as it completes; the host starts that bucket's RCCL all-reduce on a side
  * stream (replaces nn.DataParallel's reduce_add_coalesced, python/fastpitch1_1/xva_train.py:48-53,465-466). */

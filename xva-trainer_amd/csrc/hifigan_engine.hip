@@ -653,9 +653,16 @@ int wn_backward(Ctx& c, const std::vector<Layer>& L, const float* P, float* G, c
     if (ds.empty()) return XVA_OK;
     return xva_hg_weight_norm_batch(ds.data(), (int)ds.size(), 1, c.st);
 }
+// Bucket i is final on the lane this context issues to: record its event and, when the data-parallel host has registered a callback, call it NOW — while
+// the host is still issuing the backward pass — so that the bucket's wait + all-reduce are enqueued at once (a wait issued after the whole pass had been
+// issued resolved when the recording lane had drained: tools/dp_overlap_probe.py, csrc/fastpitch_engine.hip Ctx::record).
+typedef void (*xva_bucket_cb_t)(int bucket, void* user);
+static thread_local xva_bucket_cb_t g_hg_bucket_cb = nullptr;
+static thread_local void* g_hg_bucket_user = nullptr;
 int record(const Ctx& c, void* const* events, int i) {
     if (!events || !events[i]) return XVA_OK;
     if (hipEventRecord((hipEvent_t)events[i], (hipStream_t)c.st) != hipSuccess) { xva_set_error("hifigan: hipEventRecord failed"); return XVA_ERR_HIP; }
+    if (g_hg_bucket_cb) g_hg_bucket_cb(i, g_hg_bucket_user);
     return XVA_OK;
 }
 int zero_dweff(Ctx& c, const std::vector<Layer>& L) {
@@ -1158,6 +1165,7 @@ extern "C" int xva_hg_generator_forward(const xva_hg_dims* d, const float* param
     XVA_CHECK_ARG(params_g && mel, "generator_forward: null");
     return gen_forward(c, params_g, mel, wav_out);
 }
+extern "C" void xva_hg_set_bucket_callback(void (*cb)(int, void*), void* user) { g_hg_bucket_cb = cb; g_hg_bucket_user = user; }
 extern "C" int xva_hg_generator_backward_ex(const xva_hg_dims* d, const float* params_g, float* grads_g, const float* d_wav, void* ws, int64_t ws_bytes,
                                             void* const* bucket_events, void* stream) {
     Ctx c;

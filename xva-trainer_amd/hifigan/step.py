@@ -86,6 +86,9 @@ def optimizer_orders(table=None):
     return tg, [t for t in td if t[0].startswith("msd.")] + [t for t in td if t[0].startswith("mpd.")]
 
 
+_BUCKET_CB = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)
+
+
 class BucketSync:
     """Bucketed mean all-reduce of one flat gradient buffer, overlapped with the backward that produces it."""
 
@@ -97,6 +100,8 @@ class BucketSync:
         lib.xva_event_destroy.argtypes = [C.c_void_p]
         lib.xva_stream_wait_event.restype = C.c_int32
         lib.xva_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
+        lib.xva_hg_set_bucket_callback.restype = None
+        lib.xva_hg_set_bucket_callback.argtypes = [C.c_void_p, C.c_void_p]
         self.events = (C.c_void_p * n)(*[lib.xva_event_create() for _ in range(n)])
         self.comm = torch.cuda.Stream(device=grads.device)
         self.world = torch.distributed.get_world_size(group)
@@ -109,18 +114,47 @@ class BucketSync:
         except Exception:
             pass
 
-    def reduce(self):
-        """Call right after the *_ex backward was enqueued with self.events: returns once the compute stream is ordered after
-        every bucket's all-reduce (no host sync)."""
+    def begin(self):
+        """Call right BEFORE the *_ex backward that records self.events: registers the engine's bucket callback, so that each bucket's wait + all-reduce
+        are enqueued on the exchange stream the moment its event has been recorded — while the host is still issuing the rest of the pass.  (Enqueued
+        after the call had returned, the waits resolved only when the recording lane had drained: the exchange ran after backward, not under it.)"""
         dist = torch.distributed
         comm_ptr = C.c_void_p(self.comm.cuda_stream)
-        works = []
-        for i, (b, e) in enumerate(self.ranges):
-            _lib.check(lib.xva_stream_wait_event(comm_ptr, self.events[i]), "xva_stream_wait_event")
-            with torch.cuda.stream(self.comm):
-                works.append(dist.all_reduce(self.grads[b:e], op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, group=self.group,
-                                             async_op=True))
-        for w in works:
+        self._works, self._left, self._err = [], set(range(len(self.ranges))), None
+
+        def on_bucket(i, _user):
+            try:
+                if i in self._left:
+                    self._left.discard(i)
+                    self._enqueue(i, comm_ptr, dist)
+            except BaseException as ex:                             # never unwind through the C frames: re-raised in reduce()
+                self._err = ex
+        self._cb = _BUCKET_CB(on_bucket)
+        lib.xva_hg_set_bucket_callback(C.cast(self._cb, C.c_void_p), None)
+
+    def _enqueue(self, i, comm_ptr, dist):
+        b, e = self.ranges[i]
+        _lib.check(lib.xva_stream_wait_event(comm_ptr, self.events[i]), "xva_stream_wait_event")
+        with torch.cuda.stream(self.comm):
+            self._works.append(dist.all_reduce(self.grads[b:e], op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, group=self.group,
+                                               async_op=True))
+
+    def reduce(self):
+        """Call right after that backward returned: returns once the compute stream is ordered after every bucket's all-reduce (no host sync)."""
+        dist = torch.distributed
+        started = getattr(self, "_cb", None) is not None
+        if started:
+            lib.xva_hg_set_bucket_callback(None, None)
+            self._cb = None
+            if self._err is not None:
+                raise self._err
+        else:
+            self._works, self._left = [], set(range(len(self.ranges)))
+        comm_ptr = C.c_void_p(self.comm.cuda_stream)
+        for i in sorted(self._left):                                # buckets the engine did not announce (or begin() was not called)
+            self._enqueue(i, comm_ptr, dist)
+        self._left = set()
+        for w in self._works:
             w.wait()
         if not self.avg:
             for b, e in self.ranges:
@@ -164,6 +198,8 @@ class HifiganStep:
         # ---- discriminator step
         ld = eng.disc_forward(self.flat_d, y_wav, y_g_hat, losses="d")
         self.grads_d.zero_()
+        if self.sync_d:
+            self.sync_d.begin()
         eng.disc_backward_d(self.flat_d, self.grads_d, self.sync_d.events if self.sync_d else None)
         if self.sync_d:
             self.sync_d.reduce()
@@ -173,6 +209,8 @@ class HifiganStep:
         d_wav = eng.disc_backward_g(self.flat_d)
         loss_mel, _ = pmel.mel_l1_loss_backward(y_g_hat, y_mel, d_wav, scale=45.0, accumulate=True)
         self.grads_g.zero_()
+        if self.sync_g:
+            self.sync_g.begin()
         eng.generator_backward(self.flat_g, self.grads_g, d_wav, self.sync_g.events if self.sync_g else None)
         if self.sync_g:
             self.sync_g.reduce()
