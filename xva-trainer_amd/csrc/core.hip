@@ -62,12 +62,9 @@ extern "C" int xva_prof_collect(double* out, int cap) {
 // ---- raw event / stream helpers for the data-parallel overlap (host code holds them as opaque pointers) ----
 extern "C" void* xva_event_create(void) {
     hipEvent_t e = nullptr;
-    // Timing-ENABLED on purpose (env XVA_EVENT_TIMING=0 restores hipEventDisableTiming): a record of such an event puts a marker with its own completion
-    // signal into the stream at record time.  A timing-disabled event only remembers the stream's last command; a hipStreamWaitEvent issued LATER — the
-    // data-parallel exchange waits for a bucket event after the host has issued the whole backward — then resolves through a marker appended at the
-    // stream's CURRENT tail, i.e. when the lane has drained: every bucket's exchange started when backward ended (tools/dp_overlap_probe.py).
-    static const int timing = [] { const char* v = getenv("XVA_EVENT_TIMING"); return v ? atoi(v) : 1; }();
-    if (hipEventCreateWithFlags(&e, timing ? hipEventDefault : hipEventDisableTiming) != hipSuccess) { xva_set_error("hipEventCreate failed"); return nullptr; }
+    // (timing-enabled events were tried for the data-parallel bucket events: no difference — a wait issued late resolves when the recording lane has
+    // drained whatever the flags; the fix is WHEN the wait is issued: xva_fp_set_bucket_callback)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { xva_set_error("hipEventCreate failed"); return nullptr; }
     return (void*)e;
 }
 extern "C" int xva_event_destroy(void* e) { return e && hipEventDestroy((hipEvent_t)e) == hipSuccess ? XVA_OK : XVA_ERR_HIP; }
