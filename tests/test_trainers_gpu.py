@@ -380,7 +380,7 @@ def test_xvapitch_trainer_runs_checkpoints_and_resumes(tmp_path):
     (model, both AdamW states, step count, stage), and handleTrainer drives the same thing through ModelsManager."""
     from xva_trainer_amd.data import write_synthetic_dataset
     from xva_trainer_amd.xvapitch import xva_train as XT
-    ds = write_synthetic_dataset(str(tmp_path / "in" / "voice_x"), n_items=6, seed=3, min_s=0.6, max_s=1.2, with_se_embs=True)
+    ds = write_synthetic_dataset(str(tmp_path / "in" / "voice_x"), n_items=6, seed=3, min_s=0.6, max_s=1.2, with_se_embs=True, min_words=3)
     data = {"dataset_path": ds, "output_path": str(tmp_path / "out"), "checkpoint": None, "num_workers": 0, "batch_size": 400, "lang": "en",
             "bkp_every_x": 2, "save_step": 4, "max_iterations": 9}
     mm, ws = _mm(), _WS()

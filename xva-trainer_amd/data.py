@@ -101,8 +101,9 @@ class BasicTextEncoder:
         return [self.space] + out + [self.space]           # TTSDataset.get_text: prepend / append the space symbol (:436-441)
 
 
-def read_metadata(dataset_path):
-    """[(name_without_ext, wav_path, text)] for the lines of metadata.csv whose wav exists (common/utils.py:78-140)."""
+def read_metadata(dataset_path, wav_dir="wavs"):
+    """[(name_without_ext, wav_path, text)] for the lines of metadata.csv whose wav exists (common/utils.py:78-140); wav_dir: the folder of the
+    clips (xVAPitch fine-tunes on `wavs_postprocessed/`, python/xvapitch/dataset.py:647)."""
     items = []
     with open(os.path.join(dataset_path, "metadata.csv"), encoding="utf-8") as f:
         for line in f.read().split("\n"):
@@ -112,7 +113,7 @@ def read_metadata(dataset_path):
             fname = parts[0].split("/")[-1]
             if not fname.endswith(".wav"):
                 fname += ".wav"
-            path = os.path.join(dataset_path, "wavs", fname)
+            path = os.path.join(dataset_path, wav_dir, fname)
             if os.path.exists(path):
                 items.append((fname[:-4], path, parts[1] if len(parts) > 1 else ""))
     return items
@@ -330,10 +331,10 @@ class HifiFileLoader:
             rng.shuffle(files)
             self.files += files
         self.batch_size, self.segment, self.device, self.rank, self.world = int(batch_size), int(segment), torch.device(device), rank, world
-        # Two streams: the epoch shuffle must be IDENTICAL on every rank (order[rank::world] is then a disjoint shard), so it gets its own
-        # Random(seed + epoch) like FastPitchFileLoader; the crop starts are per-rank draws and never touch it.
+        # The epoch shuffle must be IDENTICAL on every rank (order[rank::world] is then a disjoint shard): Random(seed + epoch) like
+        # FastPitchFileLoader.  The crop position of an item is a function of (seed, epoch, the item's place in the GLOBAL epoch order), drawn from a
+        # second stream: the union of the ranks' batches is the batch a single process with world x the batch size would build, crops included.
         self.seed, self.epoch = seed, 0
-        self.crop_rng = random.Random(seed * 7919 + 1 + rank)
         self._cache = _BoundedCache(5000)
 
     def __len__(self):
@@ -349,11 +350,15 @@ class HifiFileLoader:
     def __iter__(self):
         order = list(self.files)
         random.Random(self.seed + 1 + self.epoch).shuffle(order)
+        crop_rng = random.Random(self.seed * 7919 + 1 + self.epoch)
+        crop_u = [crop_rng.random() for _ in order]
         self.epoch += 1
-        order = order[self.rank::self.world]
+        order, crop_u = order[self.rank::self.world], crop_u[self.rank::self.world]
         for b in range(len(self)):
-            clips = [self.clip(p) for p in order[b * self.batch_size:(b + 1) * self.batch_size]]
-            starts = [self.crop_rng.randint(0, len(c) - self.segment) if len(c) >= self.segment else 0 for c in clips]   # meldataset.py:354-358
+            sl = slice(b * self.batch_size, (b + 1) * self.batch_size)
+            clips = [self.clip(p) for p in order[sl]]
+            # random.randint(0, len - segment) (meldataset.py:354-358), from the item's own uniform draw
+            starts = [min(len(c) - self.segment, int(u * (len(c) - self.segment + 1))) if len(c) >= self.segment else 0 for c, u in zip(clips, crop_u[sl])]
             yield prepare_segments(clips, starts, self.segment, self.device)
 
 
@@ -410,9 +415,10 @@ class SyntheticHifiLoader:
         return iter(self.items)
 
 
-def write_synthetic_dataset(path, n_items=8, seed=0, min_s=1.0, max_s=3.0, with_pitch=True, sr=22050, with_se_embs=False):
+def write_synthetic_dataset(path, n_items=8, seed=0, min_s=1.0, max_s=3.0, with_pitch=True, sr=22050, with_se_embs=False, min_words=2, fixed_text=None):
     """A reference-layout dataset directory of synthetic clips (tests / smoke): metadata.csv, wavs/*.wav (int16) and, with_pitch,
-    the `pitch/*.npy` cache in the reference's format ((1, n_frames) float32, zeros = unvoiced; data_function.py:525-560)."""
+    the `pitch/*.npy` cache in the reference's format ((1, n_frames) float32, zeros = unvoiced; data_function.py:525-560).  min_words: the shortest
+    line (xVAPitch drops lines under 15 characters); fixed_text: one text for every clip (equal token counts)."""
     rng = np.random.RandomState(seed)
     os.makedirs(os.path.join(path, "wavs"), exist_ok=True)
     if with_pitch:
@@ -424,7 +430,9 @@ def write_synthetic_dataset(path, n_items=8, seed=0, min_s=1.0, max_s=3.0, with_
         wav = np.round(synthetic.synth_wave(n, seed * 1000 + i) * 32768.0).astype(np.int16)
         name = "clip_%04d" % i
         write_wav_int16(os.path.join(path, "wavs", name + ".wav"), wav, sr)
-        text = " ".join(words[int(k)] for k in rng.randint(0, len(words), size=2 + i % 5)) + "."
+        text = " ".join(words[int(k)] for k in rng.randint(0, len(words), size=min_words + i % 5)) + "."
+        if fixed_text is not None:
+            text = fixed_text
         lines.append("%s|%s" % (name, text))
         if with_pitch:
             T = 1 + n // 256

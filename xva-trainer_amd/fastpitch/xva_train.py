@@ -28,6 +28,8 @@ import wave
 import numpy as np
 import torch
 
+from .. import dp_launch
+from ..dp_common import RankMixin, trainer_options
 from . import engine as E
 from . import params as P
 from .lamb import Lamb
@@ -90,7 +92,10 @@ def resolve_checkpoint(trainer, ckpt_fname, dataset_output):
 
 
 async def handleTrainer(models_manager, data, websocket, gpus, resume=False):
-    """python/fastpitch1_1/xva_train.py:57-176."""
+    """python/fastpitch1_1/xva_train.py:57-176.  gpus=[0, 1, ...] in the server process: dp_launch spawns one rank worker per GPU, each of which
+    runs this function with its own GPU (the reference wraps the model in nn.DataParallel instead, :465-466)."""
+    if dp_launch.wants_rank_group("fastpitch1_1", models_manager, gpus, resume):
+        return await dp_launch.handle_trainer("fastpitch1_1", models_manager, data, websocket, gpus, resume)
     gc.collect()
     torch.cuda.empty_cache()
     if not resume:
@@ -121,7 +126,7 @@ async def handleTrainer(models_manager, data, websocket, gpus, resume=False):
         torch.cuda.empty_cache()
         if _is_oom(e):                                                       # xva_train.py:131-145: retry with the base batch size - 3
             trainer.print_and_log("Out of VRAM")
-            if running and int(data["batch_size"]) > 3:
+            if running and int(data["batch_size"]) > 3 and trainer.world == 1:      # a rank worker reports it: the parent restarts the whole group
                 trainer.print_and_log("============= Reducing base batch size from %s to %s" % (data["batch_size"], int(data["batch_size"]) - 3),
                                       save_to_file=trainer.dataset_output)
                 data["batch_size"] = int(data["batch_size"]) - 3
@@ -150,7 +155,7 @@ async def handleTrainer(models_manager, data, websocket, gpus, resume=False):
         raise
 
 
-class FastPitchTrainer(object):
+class FastPitchTrainer(RankMixin):
     def __init__(self, logger, PROD, gpus, models_manager, websocket=None, compute="bf16", loader_factory=None):
         self.logger, self.PROD, self.gpus, self.models_manager, self.websocket = logger, PROD, gpus, models_manager, websocket
         self.compute = compute
@@ -164,8 +169,7 @@ class FastPitchTrainer(object):
         self.force_stage = None
         self.stage_finished = 0
         self.EPOCH_AVG_SPAN, self.target_delta = 20, 0.0
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self._rank_env()
         root = "./resources/app" if PROD else "."
         self.pretrained_ckpt_male = root + "/python/fastpitch1_1/pretrained_models/f4_nate_FastPitch_checkpoint_5760_67000.pt"
         self.pretrained_ckpt_female = root + "/python/fastpitch1_1/pretrained_models/f4_nora_FastPitch_checkpoint_4520_65550.pt"
@@ -198,7 +202,7 @@ class FastPitchTrainer(object):
                 json.dump(self.graphs_json, f)
 
     def pause(self, websocket=None):
-        self.running = False
+        self.request_stop()
 
     # ---- xva_train.py:675-755 ----
     async def start(self, data, gpus=None, resume=False):
@@ -219,12 +223,17 @@ class FastPitchTrainer(object):
             self.epochs_per_checkpoint = int(data.get("epochs_per_checkpoint", 1))
             self.max_iterations = data.get("max_iterations")          # benchmark / test hook (not in the reference)
             self.synthetic_data = bool(data.get("synthetic_data", False))   # explicit opt-in (bench / tests); never a silent fallback
+            opts = trainer_options(data)                                    # tests / bench (a rank worker cannot be handed Python objects)
+            self.compute = opts.get("compute", self.compute)
+            self.p_dropout = opts.get("p_dropout")
+            self.target_delta_override = opts.get("target_delta")
             self.learning_rate, self.weight_decay = 0.1, 1e-6
             self.dur_predictor_loss_scale = self.pitch_predictor_loss_scale = 0.1
             self.attn_loss_scale = 1.0                                 # xva_train.py:704
             self.warmup_steps, self.grad_clip_thresh = 1000, 1000
         while self.running and not self.JUST_FINISHED_STAGE and not self.END_OF_TRAINING:
             await self.iteration()
+            self._sync_stop()
 
     def get_target_delta(self, num_data_lines, stage):
         """xva_train.py:589-672 (target deltas; freezing is implemented by the engine's per-stage trainable ranges)."""
@@ -280,27 +289,6 @@ class FastPitchTrainer(object):
                            "keeping the checkpoint's pitch_mean / pitch_std.", save_to_file=self.dataset_output)
         return None, None
 
-    def _init_distributed(self):
-        """One process per GPU.  WORLD_SIZE > 1 without a process group is initialised here from the launcher's env (RANK,
-        LOCAL_RANK, MASTER_ADDR, MASTER_PORT); a multi-GPU request inside ONE process is refused (the reference would wrap the model
-        in nn.DataParallel, xva_train.py:465-466 — that single-process mode does not exist here)."""
-        import torch.distributed as dist
-        if self.world > 1:
-            if not dist.is_available():
-                raise RuntimeError("WORLD_SIZE=%d but torch.distributed is not available" % self.world)
-            if not dist.is_initialized():
-                for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-                    if k not in os.environ:
-                        raise RuntimeError("WORLD_SIZE=%d but %s is not set: launch under `python -m torch.distributed.run`" % (self.world, k))
-                dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
-            if dist.get_world_size() != self.world:
-                raise RuntimeError("process group size %d != WORLD_SIZE %d" % (dist.get_world_size(), self.world))
-            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-        if self.gpus is not None and len(self.gpus) > 1:
-            raise NotImplementedError("gpus=%s in one process: the MI355X path is one process per GPU — start the trainer under "
-                                      "`python -m torch.distributed.run --nproc-per-node %d` instead of nn.DataParallel" % (self.gpus, len(self.gpus)))
-        return torch.device("cuda", int(self.gpus[0]) if self.gpus else 0)
-
     def _make_loader(self, stage, dm):
         if self.loader_factory:
             loader = self.loader_factory(self)
@@ -342,6 +330,8 @@ class FastPitchTrainer(object):
         pitch_mean, pitch_std = self.get_or_calculate_pitch_stats()
 
         self.model = FastPitch(logger=self.logger, compute=self.compute).to(dev)
+        if getattr(self, "p_dropout", None) is not None:
+            self.model.p_dropout = float(self.p_dropout)
         self.model.seed = 1234 + self.rank                    # dropout masks differ across DP ranks (xva_train.py:294-295 seeds per rank)
         self.model.train()
         self.eng = self.model._get_engine()
@@ -407,6 +397,8 @@ class FastPitchTrainer(object):
         n_lines = getattr(self.train_loader, "actual_num_lines", None) or len(self.train_loader) * self.global_batch
         self.num_iters = max(1, len(self.train_loader) // self.gam)
         self.target_delta = self.get_target_delta(n_lines, stage)
+        if getattr(self, "target_delta_override", None) is not None:
+            self.target_delta = float(self.target_delta_override)
         self.target_patience, self.target_patience_count = 3, 0
         self.graphs_json["stages"][str(stage)]["target_delta"] = self.target_delta
         ranges = E.trainable_ranges(stage)
@@ -434,31 +426,6 @@ class FastPitchTrainer(object):
         self.iter_start_time = None
         self.iter_losses = []
         self.epoch_iter = 0
-
-    def _barrier(self):
-        if self.world > 1:
-            import torch.distributed as dist
-            if dist.is_initialized():
-                dist.barrier()
-
-    def _from_rank0(self, obj):
-        """rank 0's value of a small host object on every rank (decisions that must not differ between ranks: which checkpoint is the
-        newest, whether the durations still have to be extracted)."""
-        if self.world == 1:
-            return obj
-        import torch.distributed as dist
-        box = [obj]
-        dist.broadcast_object_list(box, src=0)
-        return box[0]
-
-    def _global_mean(self, value):
-        """mean over the DP ranks of a host scalar (keeps every rank's stopping / NaN decisions identical)."""
-        if self.world == 1:
-            return value
-        import torch.distributed as dist
-        t = torch.tensor([value], device=self.device, dtype=torch.float64)
-        dist.all_reduce(t)
-        return float(t.item()) / self.world
 
     # ---- xva_train.py:757-911 ----
     async def iteration(self):

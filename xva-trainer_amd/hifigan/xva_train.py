@@ -22,6 +22,8 @@ import time
 import numpy as np
 import torch
 
+from .. import dp_launch
+from ..dp_common import RankMixin, trainer_options
 from ..mel import mel_spectrogram
 from .step import HifiganStep
 
@@ -43,6 +45,9 @@ def scan_checkpoint(cp_dir, prefix):
 
 
 async def handleTrainer(models_manager, data, websocket, gpus, resume=False):
+    """python/hifigan/xva_train.py:50-128.  gpus=[0, 1, ...] in the server process: one rank worker per GPU (dp_launch)."""
+    if dp_launch.wants_rank_group("hifigan", models_manager, gpus, resume):
+        return await dp_launch.handle_trainer("hifigan", models_manager, data, websocket, gpus, resume)
     if not resume:
         models_manager.sync_init_model("hifigan", websocket=websocket, gpus=gpus)
         trainer = models_manager.models_bank["hifigan"]
@@ -66,7 +71,7 @@ async def handleTrainer(models_manager, data, websocket, gpus, resume=False):
     return None
 
 
-class HiFiTrainer(object):
+class HiFiTrainer(RankMixin):
     def __init__(self, logger, PROD, gpus, models_manager, websocket=None, compute="bf16", loader_factory=None):
         self.logger, self.PROD, self.gpus, self.models_manager, self.websocket = logger, PROD, gpus, models_manager, websocket
         self.compute, self.loader_factory = compute, loader_factory
@@ -76,8 +81,7 @@ class HiFiTrainer(object):
         self.training_log, self.training_log_live_line = [], ""
         self.h = dict(CONFIG_V1)
         self.EPOCH_AVG_SPAN, self.target_delta = 25, 1e-4
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self._rank_env()
         self.dataset_output = None
         self.allow_random_init = False              # tests / benchmarks only: the reference refuses to train from scratch (xva_train.py:276-277)
         root = "./resources/app" if PROD else "."
@@ -102,7 +106,7 @@ class HiFiTrainer(object):
             {"stages": {str(s): {"loss": [], "loss_delta": [], "target_delta": None} for s in range(1, 6)}}
 
     def pause(self, websocket=None):
-        self.running = False
+        self.request_stop()
 
     async def start(self, data, gpus=None, resume=False):
         if self.running:
@@ -121,24 +125,12 @@ class HiFiTrainer(object):
             self.epochs_per_checkpoint = int(data.get("epochs_per_checkpoint", 1))
             self.max_iterations = data.get("max_iterations")
             self.synthetic_data = bool(data.get("synthetic_data", False))      # explicit opt-in (bench / tests); never a silent fallback
+            opts = trainer_options(data)                                       # tests / bench (a rank worker cannot be handed Python objects)
+            self.compute = opts.get("compute", self.compute)
+            self.allow_random_init = bool(opts.get("allow_random_init", self.allow_random_init))
         while self.running and not self.END_OF_TRAINING:
             await self.iteration()
-
-    def _init_distributed(self):
-        import torch.distributed as dist
-        if self.world > 1:
-            if not dist.is_initialized():
-                for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-                    if k not in os.environ:
-                        raise RuntimeError("WORLD_SIZE=%d but %s is not set: launch under `python -m torch.distributed.run`" % (self.world, k))
-                dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
-            if dist.get_world_size() != self.world:
-                raise RuntimeError("process group size %d != WORLD_SIZE %d" % (dist.get_world_size(), self.world))
-            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-        if self.gpus is not None and len(self.gpus) > 1:
-            raise NotImplementedError("gpus=%s in one process: the MI355X path is one process per GPU — start the trainer under "
-                                      "`python -m torch.distributed.run --nproc-per-node %d`" % (self.gpus, len(self.gpus)))
-        return torch.device("cuda", int(self.gpus[0]) if self.gpus else 0)
+            self._sync_stop()
 
     async def init(self):
         dev = self._init_distributed()
@@ -157,7 +149,8 @@ class HiFiTrainer(object):
         self.avg_loss_per_epoch = []
         self.target_patience, self.target_patience_count = 3, 0
         self.graphs_json["stages"]["5"]["target_delta"] = self.target_delta
-        cp_g, cp_do = scan_checkpoint(checkpoint_path, "g_"), scan_checkpoint(checkpoint_path, "do_")
+        self._barrier()                    # one view of the output directory: every rank resumes from the pair rank 0 sees
+        cp_g, cp_do = self._from_rank0((scan_checkpoint(checkpoint_path, "g_"), scan_checkpoint(checkpoint_path, "do_")) if self.rank == 0 else None)
         if cp_g is None:                                                                    # xva_train.py:255-264
             self.print_and_log("No existing HiFi-GAN checkpoints for this voice.", save_to_file=self.dataset_output)
             src = {"[male]": self.pretrained_ckpt_male, "[female]": self.pretrained_ckpt_female}.get(self.hifigan_checkpoint, self.hifigan_checkpoint)
@@ -263,11 +256,7 @@ class HiFiTrainer(object):
         self.training_epoch += 1
         self.output_checkpoint()
         self.avg_loss_per_epoch[-1] /= max(1, self.epoch_iter)
-        if self.world > 1:                                                                # identical stopping decisions on every rank
-            import torch.distributed as dist
-            t = torch.tensor([self.avg_loss_per_epoch[-1]], device=self.device, dtype=torch.float64)
-            dist.all_reduce(t)
-            self.avg_loss_per_epoch[-1] = float(t.item()) / self.world
+        self.avg_loss_per_epoch[-1] = self._global_mean(self.avg_loss_per_epoch[-1])      # identical stopping decisions on every rank
         losses = self.avg_loss_per_epoch
         deltas = [(losses[i - 1] - losses[i]) / losses[i - 1] for i in range(1, len(losses)) if losses[i - 1]]
         self.graphs_json["stages"]["5"]["loss"].append([self.training_steps, losses[-1]])

@@ -33,8 +33,9 @@ import traceback
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, dp_launch
 from ..data import BasicTextEncoder, read_metadata, read_wav_int16
+from ..dp_common import RankMixin, trainer_options
 from .acoustic import AcousticTrainPath
 from .decoder import VitsDecoder
 from .discriminator import VitsDiscriminator
@@ -81,7 +82,10 @@ def _now():
 
 
 async def handleTrainer(models_manager, data, websocket, gpus, resume=False):
-    """python/xvapitch/xva_train.py:86-215."""
+    """python/xvapitch/xva_train.py:86-215.  gpus=[0, 1, ...] in the server process: one rank worker per GPU (dp_launch; the reference wraps the
+    model in nn.DataParallel, :427-428)."""
+    if dp_launch.wants_rank_group("xvapitch", models_manager, gpus, resume):
+        return await dp_launch.handle_trainer("xvapitch", models_manager, data, websocket, gpus, resume)
     torch.cuda.empty_cache()
     if not resume:
         models_manager.sync_init_model("xvapitch", websocket=websocket, gpus=[0] if gpus is None else gpus)
@@ -134,61 +138,144 @@ async def handleTrainer(models_manager, data, websocket, gpus, resume=False):
     return None
 
 
-class XVAPitchFileLoader:
-    """DataLoader(TTSDataset(read_datasets([dataset]))) of the reference (xva_train.py:1162-1260, dataset.py:223-527) for ONE dataset directory, the batch
-    built on the device.  Per item: wavs/{name}.wav (22050 Hz int16), the symbol ids (`tokens/{name}.npy` written by the reference's g2p front end, else
-    the basic character table of data.py — only meaningful for smoke tests), `se_embs/{name}.npy` (the 512-d speaker embedding; the dataset mean when an
-    item has none), `pitch/{name}.npy` ((1, frames) or (frames,), 0 = unvoiced; zeros when absent).  Yields dicts with xVAPitch.format_batch's keys
-    (model.py:221-269); `linear_input` / `waveform` come from GeneratorPass.batch_from_wav in the trainer (raw clips go to the device, not spectrograms).
-    Data-parallel: every rank shuffles the same epoch order and takes a disjoint stride of it."""
+def _reference_text_front_end(lang, PROD=False):
+    """The reference's g2p front end (python/xvapitch/text: 31 languages, CPU preprocessing outside this path) when this package runs inside the
+    reference's tree; None otherwise.  TTSDataset.get_text (dataset.py:292-314) calls exactly this; its prepend / append-space switches are off (:137-138)."""
+    try:
+        from python.xvapitch.text import get_text_preprocessor
+        base = ("./resources/app" if PROD else ".") + "/python/xvapitch/text"
+        return get_text_preprocessor(lang, base, override_useAnyG2P=False)
+    except Exception:
+        return None
 
-    def __init__(self, dataset_path, batch_size, device, lang="en", seed=1234, rank=0, world=1, data_mult=1, min_seq_len=15, log=None):
-        self.path, self.batch_size, self.device = dataset_path, int(batch_size), torch.device(device)
-        self.items = read_metadata(dataset_path)
+
+def priors_datasets(root, languages=LANGS):
+    """read_datasets' enumeration of a PRIORS download (dataset.py:607-621): the root itself when it holds a metadata.csv, plus every
+    `{lang}_{speaker}` sub-folder with one whose language prefix is wanted.  -> [(path, lang)]"""
+    out = []
+    if os.path.exists(os.path.join(root, "metadata.csv")):
+        out.append((root, None))
+    for fname in sorted(os.listdir(root)):
+        if "." not in fname and "_" in fname and fname.split("_")[0] in languages and os.path.exists(os.path.join(root, fname, "metadata.csv")):
+            out.append((os.path.join(root, fname), fname.split("_")[0]))
+    return out
+
+
+class XVAPitchFileLoader:
+    """DataLoader(TTSDataset(read_datasets(...))) of the reference (xva_train.py:1162-1260, dataset.py:223-527, 596-690), the batch built on the device.
+    `datasets`: one dataset directory or [(directory, lang)] (the PRIORS tree; an item's language id comes from its folder's prefix, dataset.py:621).
+    Per item: the wav — `wavs_postprocessed/` for the fine-tune set when that folder exists (is_ft, dataset.py:647: the normalised 22050 Hz audio the
+    speaker embeddings were computed from), else `wavs/` — 22050 Hz int16; the symbol ids: `tokens/{name}.npy` when a preprocessing run cached them,
+    else the reference's own text front end when this runs inside its tree (dataset.py:303), else an ERROR — ids from another table would silently
+    fine-tune the text encoder on garbage (`allow_basic_text=True`, tests only, falls back to data.py's character table); `se_embs/{name}.npy` (the 512-d
+    speaker embedding; read_datasets drops items without one, dataset.py:655-657); `pitch/{name}.npy` ((1, frames) or (frames,), 0 = unvoiced; zeros
+    when absent, counted).  Items whose text is shorter than `min_seq_len` characters (sort_and_filter_items, dataset.py:362-381) or whose clip has fewer
+    frames than one training segment (load_data re-draws those, dataset.py:253-255) are left out and counted.  Yields dicts with xVAPitch.format_batch's
+    keys (model.py:221-269); `linear_input` / `waveform` come from GeneratorPass.batch_from_wav in the trainer (raw clips go to the device, not
+    spectrograms).  Data-parallel: every rank shuffles the same epoch order and takes a disjoint stride of it."""
+
+    def __init__(self, datasets, batch_size, device, lang="en", seed=1234, rank=0, world=1, data_mult=1, min_seq_len=15, log=None, is_ft=True,
+                 segment_frames=32, allow_basic_text=False, PROD=False):
+        self.batch_size, self.device = int(batch_size), torch.device(device)
+        if isinstance(datasets, str):
+            datasets = [(datasets, None)]
+        self.path = datasets[0][0]
+        self.log = log or (lambda line: None)
+        self.allow_basic_text, self.PROD = allow_basic_text, PROD
+        self.enc, self._tp = BasicTextEncoder(), {}
+        self.items, self.ignored = [], {"short_text": 0, "short_clip": 0, "no_embedding": 0}
+        self.missing = {"tokens": 0, "pitch": 0}
+        self.languages = set()
+        embs = []
+        for path, dlang in datasets:
+            dlang = dlang or lang
+            sub = "wavs_postprocessed" if is_ft and os.path.isdir(os.path.join(path, "wavs_postprocessed")) else "wavs"
+            have_embs = os.path.isdir(os.path.join(path, "se_embs"))
+            for name, wpath, text in read_metadata(path, sub):
+                if len(text) < min_seq_len:
+                    self.ignored["short_text"] += 1
+                    continue
+                epath = os.path.join(path, "se_embs", name + ".npy")
+                if not os.path.exists(epath):
+                    if have_embs or not is_ft:
+                        self.ignored["no_embedding"] += 1
+                        continue
+                    epath = None
+                else:
+                    embs.append(epath)
+                self.items.append({"name": name, "wav": wpath, "text": text, "root": path, "lang": dlang, "emb": epath})
+                self.languages.add(dlang)
+        if not embs:
+            raise FileNotFoundError("%s/se_embs/*.npy not found: the speaker embeddings are extracted by the reference's preprocessing "
+                                    "(python/xvapitch/get_dataset_emb.py), outside the accelerated path" % self.path)
         if not self.items:
-            raise FileNotFoundError("no usable lines in %s/metadata.csv (wavs/ missing?)" % dataset_path)
-        self.lang_id = LANG_CODES.index(lang) if lang in LANG_CODES else LANG_CODES.index("en")
-        self.enc = BasicTextEncoder()
+            raise FileNotFoundError("no usable lines in %s/metadata.csv (wavs missing, or every line shorter than %d characters)" % (self.path, min_seq_len))
+        self.mean_emb = np.mean(np.stack([np.load(e).reshape(-1).astype(np.float32) for e in embs[:2000]]), 0)
+        # clips shorter than one training segment: rand_segments has no valid start for them (dataset.py:253-255 re-draws)
+        import wave
+        keep = []
+        for it in self.items:
+            try:
+                with wave.open(it["wav"], "rb") as w:
+                    frames = 1 + w.getnframes() // 256
+            except Exception:
+                frames = segment_frames + 1              # not a PCM wav the header reader understands: decided when it is loaded
+            if frames <= segment_frames:
+                self.ignored["short_clip"] += 1
+            else:
+                keep.append(it)
+        self.items = keep
+        if not self.items:
+            raise FileNotFoundError("every clip of %s is shorter than one %d-frame training segment" % (self.path, segment_frames))
+        self.log("Number of dataset samples ignored: %d text shorter than %d symbols, %d clips shorter than %d frames, %d without a speaker embedding | "
+                 "Final number of dataset lines: %d" % (self.ignored["short_text"], min_seq_len, self.ignored["short_clip"], segment_frames,
+                                                        self.ignored["no_embedding"], len(self.items)))
         self.seed, self.rank, self.world, self.epoch = seed, rank, world, 0
         self.index = list(range(len(self.items))) * max(1, int(data_mult))
         self.actual_num_lines = len(self.items)
         self._cache = {}
-        embs = [np.load(os.path.join(dataset_path, "se_embs", n + ".npy")).reshape(-1).astype(np.float32) for n, _, _ in self.items
-                if os.path.exists(os.path.join(dataset_path, "se_embs", n + ".npy"))]
-        if not embs:
-            raise FileNotFoundError("%s/se_embs/*.npy not found: the speaker embeddings are extracted by the reference's preprocessing "
-                                    "(python/xvapitch/get_dataset_emb.py), outside the accelerated path" % dataset_path)
-        self.mean_emb = np.mean(np.stack(embs), 0)
-        self.missing = {"tokens": 0, "pitch": 0}
-        self.log = log
+        self._reported = False
 
     def __len__(self):
         return (len(self.index) // self.world) // self.batch_size
 
+    def _tokens(self, it):
+        tpath = os.path.join(it["root"], "tokens", it["name"] + ".npy")
+        if os.path.exists(tpath):
+            return np.load(tpath).astype(np.int64).reshape(-1)
+        lang = it["lang"]
+        if lang not in self._tp:
+            self._tp[lang] = _reference_text_front_end(lang, self.PROD)
+        tp = self._tp[lang]
+        if tp is not None:
+            seq = tp.text_to_sequence(it["text"])
+            return np.asarray(seq[0] if isinstance(seq, tuple) else seq, dtype=np.int64).reshape(-1)
+        self.missing["tokens"] += 1
+        if not self.allow_basic_text:
+            raise RuntimeError("%s: no symbol ids for this line — neither %s (a cached g2p result) nor the reference's text front end "
+                               "(python/xvapitch/text, importable when the trainer runs inside the reference's tree) is available.  The xVAPitch text "
+                               "encoder is trained on ids of the 524-entry ALL_SYMBOLS table; ids from any other table would corrupt the voice." % (it["wav"], tpath))
+        return np.asarray(self.enc.encode(it["text"]), dtype=np.int64) + 1    # character ids (tests): never the pad id 0
+
     def item(self, i):
         it = self._cache.get(i)
         if it is None:
-            name, path, text = self.items[i]
-            wav, sr = read_wav_int16(path)
+            src = self.items[i]
+            wav, sr = read_wav_int16(src["wav"])
             if sr != 22050:
-                raise ValueError("%s SR doesn't match target 22050 SR" % path)
-            tpath = os.path.join(self.path, "tokens", name + ".npy")
-            if os.path.exists(tpath):
-                tok = np.load(tpath).astype(np.int64).reshape(-1)
-            else:
-                self.missing["tokens"] += 1
-                tok = np.asarray(self.enc.encode(text), dtype=np.int64) + 1           # character ids (smoke tests): never the pad id 0
-            epath = os.path.join(self.path, "se_embs", name + ".npy")
-            emb = np.load(epath).reshape(-1).astype(np.float32) if os.path.exists(epath) else self.mean_emb
+                raise RuntimeError("%s: sample rate %d, the trainer needs 22050 Hz mono int16 (the reference's audio preprocessing writes "
+                                   "wavs_postprocessed/ in that format)" % (src["wav"], sr))
+            emb = np.load(src["emb"]).reshape(-1).astype(np.float32) if src["emb"] else self.mean_emb
             frames = 1 + wav.shape[0] // 256
-            ppath = os.path.join(self.path, "pitch", name + ".npy")
+            ppath = os.path.join(src["root"], "pitch", src["name"] + ".npy")
             if os.path.exists(ppath):
                 pitch = np.load(ppath).astype(np.float32).reshape(-1)[:frames]
                 pitch = np.pad(pitch, (0, frames - pitch.shape[0]))
             else:
                 self.missing["pitch"] += 1
                 pitch = np.zeros(frames, dtype=np.float32)
-            it = {"name": path, "wav": wav.astype(np.float32) / 32768.0, "tokens": tok, "emb": emb, "pitch": pitch}
+            it = {"name": src["wav"], "wav": wav.astype(np.float32) / 32768.0, "tokens": self._tokens(src), "emb": emb, "pitch": pitch,
+                  "lang_id": LANG_CODES.index(src["lang"]) if src["lang"] in LANG_CODES else LANG_CODES.index("en")}
             if len(self._cache) < 5000:
                 self._cache[i] = it
         return it
@@ -215,10 +302,14 @@ class XVAPitchFileLoader:
             yield {"text_input": text.to(dev), "text_lengths": torch.tensor([len(it["tokens"]) for it in its], device=dev),
                    "wavs": wavs.to(dev), "wav_lengths": torch.tensor([len(it["wav"]) for it in its], device=dev), "pitch_padded": pitch.to(dev),
                    "d_vectors": torch.from_numpy(np.stack([it["emb"] for it in its])).to(dev),
-                   "language_ids": torch.full((B,), self.lang_id, dtype=torch.int64, device=dev), "wav_file_name": [it["name"] for it in its]}
+                   "language_ids": torch.tensor([it["lang_id"] for it in its], dtype=torch.int64, device=dev), "wav_file_name": [it["name"] for it in its]}
+        if not self._reported:               # once, after the first epoch has touched the items
+            self._reported = True
+            self.log("Dataset caches after the first epoch: %d items without symbol ids (character-table fallback), %d without a pitch file (zeros)"
+                     % (self.missing["tokens"], self.missing["pitch"]))
 
 
-class xVAPitchTrainer(object):
+class xVAPitchTrainer(RankMixin):
     def __init__(self, logger, PROD, gpus, models_manager, websocket=None, amp=None, cmd_training=False, compute="bf16", loader_factory=None, model_kwargs=None):
         self.logger, self.PROD, self.gpus, self.models_manager, self.websocket = logger, PROD, gpus, models_manager, websocket
         self.amp, self.cmd_training, self.compute, self.loader_factory = amp, cmd_training, compute, loader_factory
@@ -228,8 +319,8 @@ class xVAPitchTrainer(object):
         self.training_log, self.training_log_live_line = [], ""
         self.dataset_id = self.dataset_input = self.dataset_output = None
         self.batch_size = self.force_stage = self.workers = None
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self._rank_env()
+        self.world_invariant_noise = False
         self.pretrained_ckpt = ("./pretrained_models/xVAPitch_5820651.pt" if cmd_training else
                                 ("./resources/app" if PROD else ".") + "/python/xvapitch/pretrained_models/xVAPitch_5820651.pt")
         self.priors_languages_loaded = []
@@ -285,8 +376,9 @@ class xVAPitchTrainer(object):
         return [0.04, td * 0.2]
 
     def pause(self, websocket=None):
-        self.running = False
-        torch.cuda.empty_cache()
+        self.request_stop()
+        if self.world == 1:
+            torch.cuda.empty_cache()
 
     # ---- xva_train.py:534-577 ----
     async def start(self, data, gpus=None, resume=False):
@@ -311,9 +403,17 @@ class xVAPitchTrainer(object):
             self.max_iterations = data.get("max_iterations")            # benchmark / test hook (not in the reference)
             self.save_step = int(data.get("save_step", 50))              # the reference's constant (:310); tests shorten it
             self.priors_path = data.get("priors_path")
+            opts = trainer_options(data)                                # tests / bench (a rank worker cannot be handed Python objects)
+            self.compute = opts.get("compute", self.compute)
+            self.allow_random_init = bool(opts.get("allow_random_init", self.allow_random_init))
+            if "model_kwargs" in opts:
+                self.model_kwargs = dict(opts["model_kwargs"])
+            self.world_invariant_noise = bool(opts.get("world_invariant_noise", False))
+            self.target_delta_override = opts.get("target_delta")
         torch.cuda.empty_cache()
         while self.running and not self.JUST_FINISHED_STAGE and not self.END_OF_TRAINING:
             await self.iteration()
+            self._sync_stop()
 
     def start_new_epoch(self):
         self.keep_avg_train = {k: [] for k in ("step_time", "loss", "loss_gen", "loss_kl", "loss_feat", "loss_mel", "loss_mel_pred", "loss_duration",
@@ -321,20 +421,6 @@ class xVAPitchTrainer(object):
         self.steps_since_log = 0
         self.epoch_steps = 0
         self.finetune_it = True
-
-    def _device(self):
-        import torch.distributed as dist
-        if self.world > 1:
-            if not dist.is_initialized():
-                for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-                    if k not in os.environ:
-                        raise RuntimeError("WORLD_SIZE=%d but %s is not set: launch under `python -m torch.distributed.run`" % (self.world, k))
-                dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
-            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-        if self.gpus is not None and len(self.gpus) > 1:
-            raise NotImplementedError("gpus=%s in one process: the MI355X path is one process per GPU — start the trainer under "
-                                      "`python -m torch.distributed.run --nproc-per-node %d` instead of nn.DataParallel" % (self.gpus, len(self.gpus)))
-        return torch.device("cuda", int(self.gpus[0]) if self.gpus else 0)
 
     def init_model(self, device):
         """xVAPitch(args) at the trainer's switches (`--big 1 --pitch 1 --pe_scaling 0.2`, xva_train.py:1098-1132,1421-1425; model.py:40-215)."""
@@ -355,18 +441,32 @@ class xVAPitchTrainer(object):
         return sd
 
     def load_model_state_dict(self, sd):
-        """strict=False like the reference (:1038): keys this model does not hold are ignored, missing ones keep their values."""
+        """strict=False like the reference (:1038): keys this model does not hold are ignored, missing ones keep their values — but a key that
+        IS held with another shape raises, as torch's load_state_dict(strict=False) does (a checkpoint of another architecture must not load silently)."""
         ac, dec, disc = self.step.gen.acoustic, self.step.gen.decoder, self.step.disc
-        own = ac.state_dict()
-        ac.load_state_dict({k: sd[k] if k in sd and tuple(sd[k].shape) == tuple(v.shape) else v for k, v in own.items()})
+        bad, missing = [], []
+
+        def pick(key, cur):
+            if key not in sd:
+                missing.append(key)
+                return cur
+            if tuple(sd[key].shape) != tuple(cur.shape):
+                bad.append("%s: checkpoint %s, model %s" % (key, tuple(sd[key].shape), tuple(cur.shape)))
+                return cur
+            return sd[key]
+        ac.load_state_dict({k: pick(k, v) for k, v in ac.state_dict().items()})
         for pre, eng in (("waveform_decoder.", dec), ("disc.", disc)):
-            cur = eng.state_dict()
-            eng.load_state_dict({k: (sd[pre + k] if pre + k in sd and tuple(sd[pre + k].shape) == tuple(v.shape) else v) for k, v in cur.items()})
+            eng.load_state_dict({k: pick(pre + k, v) for k, v in eng.state_dict().items()})
+        if bad:
+            raise RuntimeError("Error(s) in loading state_dict for xVAPitch: size mismatch for " + "; ".join(bad[:8]) + (" ... (%d more)" % (len(bad) - 8) if len(bad) > 8 else ""))
+        if missing:
+            self.print_and_log("Checkpoint has no value for %d tensors (kept at their initial values): %s%s" % (
+                len(missing), ", ".join(missing[:6]), " ..." if len(missing) > 6 else ""), save_to_file=self.dataset_output)
 
     # ---- xva_train.py:277-466 ----
     async def init(self):
         self.FINETUNE_WEIGHT = 20
-        self.device = dev = self._device()
+        self.device = dev = self._init_distributed()
         torch.cuda.set_device(dev)
         np.random.seed(1234 + self.rank)
         torch.manual_seed(1234 + self.rank)
@@ -374,7 +474,8 @@ class xVAPitchTrainer(object):
         self.init_logs(dataset_output=self.dataset_output)
         self.print_and_log("Dataset: %s" % self.dataset_input, save_to_file=self.dataset_output)
         self.print_and_log("Language: %s" % self.lang, save_to_file=self.dataset_output)
-        ckpt_path = last_checkpoint(self.dataset_output)
+        self._barrier()                                        # every rank's writes to the output directory so far are done
+        ckpt_path = self._from_rank0(last_checkpoint(self.dataset_output) if self.rank == 0 else None)   # one view of "newest" for all ranks
         if ckpt_path is None:
             ckpt_path = self.checkpoint or self.pretrained_ckpt
             self.print_and_log("Checkpoint: %s" % ckpt_path, save_to_file=self.dataset_output)
@@ -422,6 +523,8 @@ class xVAPitchTrainer(object):
         self.finetune_loader, self.train_loader = self.setup_dataloaders(dev)
         ft_files = getattr(self.finetune_loader, "actual_num_lines", None) or len(self.finetune_loader) * self.batch_size
         self.target_deltas = self.get_target_delta(ft_files)
+        if getattr(self, "target_delta_override", None) is not None:
+            self.target_deltas = [float(v) for v in self.target_delta_override]
         self.ft_dataset_emb = [float(v) for v in getattr(self.finetune_loader, "mean_emb", np.zeros(512))]
         # ExponentialLR(gamma 0.999875), stepped per finished epoch (training_util.py:59-69, xva_train.py:919-920)
         self.gamma = 0.999875
@@ -450,15 +553,25 @@ class xVAPitchTrainer(object):
             pair = self.loader_factory(self)
             if pair is not None:
                 return pair
-        ft = XVAPitchFileLoader(self.dataset_input, self.per_rank_batch, dev, lang=self.lang, seed=1234, rank=self.rank, world=self.world, data_mult=10)
+        log = lambda line: self.print_and_log(line, save_to_file=self.dataset_output)
+        seg = int(self.model_kwargs.get("spec_segment_size", 32))
+        common = dict(rank=self.rank, world=self.world, segment_frames=seg, allow_basic_text=self.allow_random_init, PROD=self.PROD, log=log)
+        ft = XVAPitchFileLoader(self.dataset_input, self.per_rank_batch, dev, lang=self.lang, seed=1234, data_mult=10, is_ft=True,
+                                min_seq_len=15, **common)
         if 0 < len(ft.index) // self.world < self.per_rank_batch:
             ft.batch_size = max(1, len(ft.index) // self.world)
         self.print_and_log("Fine-tune dataset files: %d" % ft.actual_num_lines, save_to_file=self.dataset_output)
         root = self.priors_path or ("./PRIORS" if self.cmd_training else ("./resources/app" if self.PROD else ".") + "/python/xvapitch/PRIORS")
         priors = None
-        if os.path.isdir(root) and os.path.exists(os.path.join(root, "metadata.csv")):
-            priors = XVAPitchFileLoader(root, self.per_rank_batch, dev, lang=self.lang, seed=4321, rank=self.rank, world=self.world)
-            self.print_and_log("Priors datasets files: %d" % priors.actual_num_lines, save_to_file=self.dataset_output)
+        sets = priors_datasets(root) if os.path.isdir(root) else []
+        if sets:
+            # the PRIORS download is a tree of {lang}_{speaker}/metadata.csv folders, the language id from the prefix (dataset.py:607-621)
+            priors = XVAPitchFileLoader(sets, self.per_rank_batch, dev, lang=self.lang, seed=4321, is_ft=False, min_seq_len=15, **common)
+            if len(priors) == 0:
+                priors.batch_size = max(1, len(priors.index) // self.world)
+            self.priors_languages_loaded = sorted(priors.languages)
+            self.print_and_log("Priors datasets files: %d | languages: %s" % (priors.actual_num_lines, ",".join(self.priors_languages_loaded)),
+                               save_to_file=self.dataset_output)
         else:
             # the reference refuses to start without its PRIORS download (:372-374); here the fine-tune set alone trains (every iteration is a
             # fine-tune iteration) and the log says so
@@ -497,8 +610,9 @@ class xVAPitchTrainer(object):
         stepping = (self.accumulated_steps + 1) % self.gam == 0
         # ---- pass 0: generator (zero_grad at the start of each pass: :652-653) ----
         gp.zero_grad()
+        eps, noise, slice_ids = self._draws(batch["text_input"].size(1), Ty, y_lengths)
         out = step.generator_pass(batch["text_input"], batch["text_lengths"], y, y_lengths, waveform, batch["d_vectors"], batch["language_ids"],
-                                  pitch_padded=pitch)
+                                  pitch_padded=pitch, eps=eps, noise=noise, slice_ids=slice_ids)
         out["loss"].backward()
         if stepping and not use_ft:                                                    # priors iteration: the vocoder and posterior are not trained (:724-726)
             gp.acoustic.posterior_encoder.zero_grad()
@@ -568,6 +682,23 @@ class xVAPitchTrainer(object):
             if self.max_iterations and self.training_iters >= self.max_iterations:
                 self.running = False
 
+    def _draws(self, Tt, Ty, y_lengths):
+        """The iteration's random draws — the posterior encoder's eps (model.py:1472), the duration predictor's noise (sdp.py:281), the segment starts
+        (util.py:165-178).  Default: None, drawn where the reference draws them from this rank's stream (seed 1234 + rank).  `world_invariant_noise`
+        (tests): every rank draws the GLOBAL batch's values from one identically seeded generator and keeps its stride of them, so a 2-rank run sees
+        the values a single process with twice the batch sees (same clip lengths on both ranks assumed; otherwise the streams drift apart, harmlessly)."""
+        if not self.world_invariant_noise:
+            return None, None, None
+        if not hasattr(self, "_noise_gen"):
+            self._noise_gen = torch.Generator(device=self.device).manual_seed(1234)
+        g, W, r, B = self._noise_gen, self.world, self.rank, y_lengths.numel()
+        ac, S = self.step.gen.acoustic, self.step.gen.S
+        eps = torch.randn(B * W, ac.C, Ty, generator=g, device=self.device)[r::W].contiguous()
+        noise = torch.randn(B * W, 2, Tt, generator=g, device=self.device)[r::W].contiguous()
+        u = torch.rand(B * W, generator=g, device=self.device)[r::W]
+        slice_ids = (u * (y_lengths.to(self.device) - S + 1).float()).long()
+        return eps, noise, slice_ids
+
     async def _checkpoint_time(self, loss_delta, avg_loss, frames_per_second):
         """xva_train.py:796-865: every save_step optimiser steps — the stopping rule on the mean discriminator loss, then the checkpoint."""
         stage = self.training_stage
@@ -605,14 +736,6 @@ class xVAPitchTrainer(object):
             self.target_patience_count = 0
         if not has_saved:
             self.save_checkpoint(frames_s=frames_per_second, avg_loss=avg_loss, loss_delta=loss_delta, fpath=output_path, ckpt_time=ckpt_time)
-
-    def _global_mean(self, value):
-        if self.world == 1:
-            return value
-        import torch.distributed as dist
-        t = torch.tensor([value], device=self.device, dtype=torch.float64)
-        dist.all_reduce(t)
-        return float(t.item()) / self.world
 
     def finish_epoch(self):
         """xva_train.py:903-920: both schedulers step (ExponentialLR: lr *= gamma)."""
