@@ -57,11 +57,11 @@ def parse():
 
 def _thread_candidates():
     n = os.cpu_count() or 1
-    return sorted({t for t in (8, 32, 128) if t <= n} or {n})
+    return sorted({t for t in (8, 32) if t <= n} or {n})     # 128 threads took 5 - 25 s per probe step and never won
 
 
 def _best_of_threads(step, n_timed=3):
-    """Time `step()` (one full CPU training step) honestly: for each thread count in {8, 32, 128} (those the host has) one warm-up +
+    """Time `step()` (one full CPU training step) honestly: for each thread count in {8, 32} (those the host has) one warm-up +
     one timed step picks the best count (more threads is NOT faster for these small GEMMs), then n_timed steps are timed at it."""
     probe = {}
     for t in _thread_candidates():
@@ -141,18 +141,110 @@ def csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
+def git_head():
+    """HEAD of the tree this line was measured on (the GPU box gets a snapshot without .git: the builder's last `git rev-parse HEAD` travels in
+    profiles/HEAD, an untracked file the builder.s post-commit hook rewrites; None when neither is there — the csrc fingerprint next to it always is)."""
+    import subprocess
+    try:
+        r = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            return r.stdout.strip()
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, "profiles", "HEAD")).read().strip() or None
+    except Exception:
+        return None
+
+
+def rocprof_frac(family_regex, flops_per_launch, stats_csv, peak_tflops=2500.0):
+    """roofline fraction of a kernel family from the COMMITTED rocprofv3 --kernel-trace --stats summary of this workload (profiles/<stats_csv>, lanes
+    off): algorithmic FLOPs per launch / the trace's average duration.  The live `frac` next to it divides by a HIP-event pair per launch, which adds
+    ~10 us of event overhead to a 100 us kernel; the two bracket the truth.  None (with the reason) when the summary is missing or describes other
+    kernel sources (csrc fingerprint in the .meta.json next to it)."""
+    import csv
+    import re
+    path = os.path.join(ROOT, "profiles", stats_csv)
+    meta = path[:-4] + ".meta.json"
+    if not os.path.exists(path):
+        return None, "profiles/%s not committed" % stats_csv
+    if not os.path.exists(meta) or json.load(open(meta)).get("csrc") != csrc_fingerprint():
+        return None, "profiles/%s is stale (kernel sources changed since that trace): not quoted" % stats_csv
+    pat, calls, tot = re.compile(family_regex), 0, 0.0
+    for r in csv.DictReader(open(path)):
+        if pat.search(r["Name"]):
+            calls += int(r["Calls"])
+            tot += float(r["TotalDurationUs"]) if "TotalDurationUs" in r else float(r["TotalDurationNs"]) / 1e3
+    if not calls:
+        return None, "no launch of %s in profiles/%s" % (family_regex, stats_csv)
+    avg_us = tot / calls
+    return {"frac": flops_per_launch / avg_us / 1e6 / peak_tflops, "avg_launch_us": avg_us, "launches": calls,
+            "source": "profiles/%s @ %s" % (stats_csv, json.load(open(meta)).get("commit", "?"))}, None
+
+
+def golden_parity(leg, compute):
+    """`parity` object of a bench leg: the engine in the MODE BEING TIMED (`compute`) on the reference-recorded golden case of that leg
+    (tests/golden/*.npz: inputs, outputs and losses written by a run of the reference's own classes, oracle/gen_golden_*.py), dropout off — so the
+    line itself says what the timed mode does to the outputs north_star names (mel frames, waveforms, loss values; tolerance 1e-3).  CHECKER use of
+    oracle/: only its seeded weight generators (`init_state_dict`, `init_*_sd`: the goldens store a checksum of the weights, not the weights) are
+    called; nothing measured goes through it."""
+    import numpy as np
+    gdir = os.path.join(ROOT, "tests", "golden")
+    relmax = lambda a, b: float((a.double().cpu() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    rel2 = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    if leg == "fastpitch":
+        from oracle import fastpitch as ofp
+        from xva_trainer_amd.fastpitch import engine as E, params as P
+        g = np.load(os.path.join(gdir, "fp_stage3_small.npz"))
+        batch = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+        eng = E.FastPitchEngine("cuda", compute, p_dropout=0.0)
+        flat = torch.zeros(eng.total, device="cuda")
+        P.to_flat(ofp.init_state_dict(int(g["seed"])), eng.table, flat)
+        grads = torch.zeros_like(flat)
+        b = E.DeviceBatch.from_dict(batch, "cuda")
+        losses = eng.fwd_loss_bwd(flat, grads, b, 3).cpu()
+        o = eng.outputs(b, 3)
+        return {"case": "tests/golden/fp_stage3_small.npz (reference FastPitch + FastPitchLoss, stage 3, dropout off)", "mode": compute,
+                "mel_rel": relmax(o["mel_out"].float(), torch.from_numpy(g["mel_out"])), "mel_rel_l2": rel2(o["mel_out"].float(), torch.from_numpy(g["mel_out"])),
+                "pitch_pred_rel": relmax(o["pitch_pred"].float(), torch.from_numpy(g["pitch_pred"])),
+                "loss_rel": abs(float(losses[0]) - float(g["loss"])) / abs(float(g["loss"])), "tolerance_north_star": 1e-3,
+                "metric": "max |x - ref| / max |ref| (mel_rel, pitch_pred_rel), relative L2 (mel_rel_l2), relative scalar error (loss_rel)"}
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    g = np.load(os.path.join(gdir, "hg_step_b2.npz"))
+    seed = int(g["seed"])
+    st = HifiganStep("cuda", compute)
+    st.load_state_dicts(ohg.init_generator_sd(seed), ohg.init_mpd_sd(seed + 1), ohg.init_msd_sd(seed + 2))
+    out = st.train_step(torch.from_numpy(g["x_mel"]).cuda(), torch.from_numpy(g["y_wav"]).cuda(), torch.from_numpy(g["y_mel"]).cuda())
+    ref = dict(zip([str(k) for k in g["loss_names"]], (float(v) for v in g["losses"])))
+    mine = {"loss_disc_all": out["loss_disc_all"], "loss_mel": out["loss_mel"], "loss_gen": out["loss_gen"], "loss_fm": out["loss_fm"], "loss_gen_all": out["loss_gen_all"]}
+    want = {"loss_disc_all": ref["loss_disc_all"], "loss_mel": ref["loss_mel"], "loss_gen": ref["loss_gen_f"] + ref["loss_gen_s"],
+            "loss_fm": ref["loss_fm_f"] + ref["loss_fm_s"], "loss_gen_all": ref["loss_gen_all"]}
+    lr = {k: abs(float(mine[k]) - want[k]) / abs(want[k]) for k in want}
+    res = {"case": "tests/golden/hg_step_b2.npz (reference Generator + MPD + MSD + losses, one D+G iteration, B = 2)", "mode": compute,
+           "wave_rel": rel2(out["y_g_hat"].float(), torch.from_numpy(g["y_g_hat"]).squeeze(1)), "loss_rel": max(lr.values()), "loss_rel_by_name": lr,
+           "tolerance_north_star": 1e-3, "metric": "relative L2 of the generated waveform (wave_rel), worst relative error of the five reported losses (loss_rel)"}
+    del st
+    torch.cuda.empty_cache()
+    return res
+
+
 def timed_us(fn, iters=10, warm=2):
-    """Average duration of fn() in microseconds by a HIP event pair on torch's current stream (the stream every libxvahip launch of
-    this process goes to) around `iters` back-to-back calls."""
+    """Average duration of ONE fn() in microseconds: a HIP event pair around EACH call on torch's current stream (the stream every libxvahip launch
+    of this process goes to) — what the library's own xva_prof_* pairs do around a GEMM launch.  A pair around `iters` back-to-back calls (rounds
+    1 - 3) also timed the host's launch-to-launch gaps: LayerNorm 19 us against 13.6 us in the kernel trace."""
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
     torch.cuda.synchronize()
-    return 1000.0 * e0.elapsed_time(e1) / iters
+    pairs = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    return 1000.0 * sum(a.elapsed_time(b) for a, b in pairs) / iters
 
 
 def hbm_kernel_rooflines(dev, opt, grads, active, compute):
@@ -383,7 +475,7 @@ def hifigan_leg(a, dev, rank, world):
         # answer: the all-reduce — and with it this process — would hang), so the gradient exchange is switched off for it.
         st.sync_d = st.sync_g = None
         res["roofline"] = gemm_roofline(lambda: st.train_step(x, y, y_mel), 1, "auto", 8000.0, "one extra profiled D+G iteration (stream lanes off)",
-                                        pmc_csv="r03_hifigan_pmc_hbm_bytes.csv")
+                                        pmc_csv="r04_hifigan_pmc_hbm_bytes.csv")
         # the HiFi-GAN conv stack is priced on HBM — ALGORITHMIC bytes of the whole iteration (every distinct operand /
         # result element of every convolution launch once, forward + both backward products: the sum the profiled pass above recorded
         # per launch) over the TIMED iteration (stream lanes on, everything included: losses, reparametrisations, AdamW)
@@ -398,6 +490,49 @@ def hifigan_leg(a, dev, rank, world):
                                          "ridge (17 TFLOP : 55 GB = 313 flop/B), so the MFMA fraction of the same time is given beside it" % B}
     del st
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1:
+        try:
+            res["parity"] = golden_parity("hifigan", a.compute)
+        except Exception as e:                               # an extra measurement: never at the price of the contract line
+            res["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
+
+
+def hifigan_fp32_leg(a, dev, steps=3, warm=2):
+    """The same D+G iteration (B x 8192 samples of the `hifigan` object) in the PARITY mode: fp32 storage, exact-fp32 MFMA — the mode whose
+    waveform and nine losses meet north_star's 1e-3 against the reference's own classes (tests/test_hifigan_gpu.py::
+    test_full_step_against_reference_golden).  Priced against the 157.3 TFLOP/s fp32 matrix peak."""
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    st = HifiganStep(dev, "fp32")
+    init_hifigan_weights(st)
+    B, seg = a.hg_batch, 8192
+    x, y, y_mel = hifigan_inputs(B, 0, dev, seg)
+    for _ in range(warm):
+        out = st.train_step(x, y, y_mel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = st.train_step(x, y, y_mel)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"metric": "audio-samples/sec (HiFi-GAN v1 full D+G iteration, fp32 parity mode)", "value": B * seg * steps / dt, "unit": "audio-samples/s",
+           "ms_per_step": 1000.0 * dt / steps, "steps": steps, "dtype": "fp32",
+           "config": {"workload": "HiFi-GAN v1 generator + MPD + MSD, batch %d x %d samples, D step + G step + 2 x fused AdamW, fp32 storage + exact-fp32 MFMA" % (B, seg)},
+           "loss_mel": float(out["loss_mel"].item()), "loss_disc_all": float(out["loss_disc_all"].item()),
+           "tolerance": "waveform and all nine losses within 1e-3 (feature loss 2e-3) of the reference goldens (tests/test_hifigan_gpu.py)"}
+    if not a.no_roofline:
+        res["roofline"] = gemm_roofline(lambda: st.train_step(x, y, y_mel), 1, "mfma", 157.3, "one extra profiled D+G iteration in the fp32 parity mode (stream lanes off)")
+        ag = res["roofline"]["all_gemm"]
+        alg_tf = ag["tflops"] * ag["ms_per_step"] / 1e3
+        res["roofline_stack"] = {"bound": "mfma", "achieved": alg_tf / res["ms_per_step"] * 1e3, "peak": 157.3, "unit": "TFLOP/s",
+                                 "frac": alg_tf / res["ms_per_step"] * 1e3 / 157.3, "algorithmic_tflop_per_step": alg_tf,
+                                 "note": "whole iteration: algorithmic FLOPs of every convolution launch / timed ms_per_step, against the exact-fp32 MFMA peak"}
+    del st
+    torch.cuda.empty_cache()
+    try:
+        res["parity"] = golden_parity("hifigan", "fp32")
+    except Exception as e:
+        res["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
 
 
@@ -466,6 +601,10 @@ def fastpitch_fp32_leg(a, dev, steps=5, warm=2):
                                      "same parity bounds as the exact mode except the post-LAMB parameter norms (1e-4 instead of 1e-5)"}
     del eng, opt, grads, flat
     torch.cuda.empty_cache()
+    try:
+        res["parity"] = golden_parity("fastpitch", "fp32")
+    except Exception as e:
+        res["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
 
 
@@ -749,8 +888,14 @@ def main():
                    "global_batch": a.batch * world, "per_gpu_frames_per_step": frames_per_step, "parallelism": "dp%d" % world,
                    "final_loss": loss},
     }
+    out["provenance"] = {"git_head": git_head(), "csrc": csrc_fingerprint()}
     if a.share_gpu_gloo:
         out["shared_gpu_gloo"] = True
+    if rank == 0 and world == 1:
+        try:
+            out["parity"] = golden_parity("fastpitch", a.compute)
+        except Exception as e:                               # an extra measurement: never at the price of the contract line
+            out["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and not a.no_roofline:
         def run_profiled():
             grads.zero_()
@@ -758,7 +903,13 @@ def main():
         peak = 2500.0 if a.compute == "bf16" else 157.3
         out["roofline"] = gemm_roofline(run_profiled, 3, "mfma", peak,
                                         "FastPitch fwd+bwd: %d extra profiled passes after the timed region" % 3,
-                                        pmc_csv="r03_fastpitch_pmc_hbm_bytes.csv" if a.compute == "bf16" else None)
+                                        pmc_csv="r04_fastpitch_pmc_hbm_bytes.csv" if a.compute == "bf16" else None)
+        if a.compute == "bf16" and "256x256" in out["roofline"]["kernel"]:
+            # the same family's fraction from the committed rocprofv3 kernel trace (no event-pair overhead in the duration)
+            fr, why = rocprof_frac(r"xva_gemm_glds8_kernel<\d, 256, 256,", out["roofline"]["algorithmic_gflop_per_launch"] * 1e9,
+                                   "r04_fastpitch_only_serial_lanes_kernel_stats.csv")
+            out["roofline"]["frac_rocprof"] = fr["frac"] if fr else None
+            out["roofline"]["frac_rocprof_detail"] = fr if fr else why
     if rank == 0 and not a.no_roofline:
         out["hbm_kernels"] = hbm_kernel_rooflines(dev, opt, grads, active, a.compute)
     if rank == 0 and world == 1 and a.compute == "bf16" and not a.no_fp32_parity:
@@ -795,6 +946,11 @@ def main():
         if world > 1:
             hg_done.set()
         out["hifigan"] = hg
+        if rank == 0 and world == 1 and a.compute == "bf16" and not a.no_fp32_parity:
+            try:
+                out["hifigan_fp32_parity"] = hifigan_fp32_leg(a, dev)
+            except Exception as e:                           # an extra measurement: never at the price of the contract line
+                out["hifigan_fp32_parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not a.no_xvapitch:
         try:
             torch.cuda.empty_cache()

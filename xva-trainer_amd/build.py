@@ -30,11 +30,11 @@ def _headers_mtime():
     return m
 
 
-def _compile(src, verbose):
+def _compile(src, verbose, force=False):
     obj = os.path.join(CSRC, "build", src[:-4] + ".o")
     os.makedirs(os.path.dirname(obj), exist_ok=True)
     spath = os.path.join(CSRC, src)
-    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), _headers_mtime()):
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), _headers_mtime()):
         return obj, False
     cmd = ["hipcc"] + FLAGS + ["-I", INCLUDE, "-c", spath, "-o", obj]
     if verbose:
@@ -46,11 +46,12 @@ def _compile(src, verbose):
 
 
 def build(verbose=True, force=False):
+    """force: a from-source rebuild — every object is recompiled and the library relinked (`python xva-trainer_amd/build.py --force`)."""
     if force and os.path.exists(LIB):
         os.remove(LIB)
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        res = list(ex.map(lambda s: _compile(s, verbose), srcs))
+        res = list(ex.map(lambda s: _compile(s, verbose, force), srcs))
     objs = [o for o, _ in res]
     changed = any(c for _, c in res)
     if changed or not os.path.exists(LIB):

@@ -59,9 +59,17 @@ bool xva_gemm_wgrad_res_ok(const xva_gemm_params& p);   // wgrad_res.hip: does t
 inline int hg_conv_out_len(int T, const ConvW& w) { return (T + 2 * w.P - w.d * (w.k - 1) - 1) / w.s + 1; }
 
 enum { HG_MERGED = 0, HG_PERITEM = 1 };
-inline int hg_mode(const Seq& X, const Seq& Y, const ConvW& w) {
-    if (X.nseq == Y.nseq && X.Hp() == w.s * Y.Hp() && X.padF == w.s * Y.padF) return HG_MERGED;
-    return HG_PERITEM;
+inline bool hg_affine(const Seq& X, const Seq& Y, const ConvW& w) { return X.nseq == Y.nseq && X.Hp() == w.s * Y.Hp() && X.padF == w.s * Y.padF; }
+// XVA_HG_PERITEM (default 1): long stride-1 sequences whose length is a whole number of 128-row tiles run per item even where the merged form exists.
+// The merged form convolves (and masks) the pad rows and its tile count is whatever nseq * Hp / 128 gives: HiFi-GAN's 128-channel stage is
+// 64 x 2112 rows = 1056 tiles = 2.06 rounds of the 512 resident-input workgroups a chip holds (a third, nearly empty round), per item it is
+// 64 x 16 = 1024 tiles = exactly two; the 256-channel stage (T = 256, 32 + 32 pad rows) spends 20 % of its merged rows on pads.
+inline int hg_peritem_pref() { static const int v = [] { const char* e = getenv("XVA_HG_PERITEM"); return e ? atoi(e) : 1; }(); return v; }
+// Forward only: the merged form also re-zeroes the pad rows of its output, which backward relies on (gradient tensors share workspace slots).
+inline int hg_mode(const Seq& X, const Seq& Y, const ConvW& w, bool forward = false) {
+    if (!hg_affine(X, Y, w)) return HG_PERITEM;
+    if (forward && hg_peritem_pref() && w.s == 1 && Y.T % 128 == 0 && Y.T >= 256) return HG_PERITEM;
+    return HG_MERGED;
 }
 
 // ---- forward: Y = act(alpha * (conv(lrelu?(X)) + bias) + beta * R) ------------------------------------------------
@@ -80,7 +88,7 @@ inline int hg_conv_fwd(const Seq& X, const Seq& Y, const ConvW& w, const ConvEpi
     g.batch2 = w.groups; g.sA2 = Cig; g.sB2 = (int64_t)Cog * g.K; g.sC2 = Cog; g.sR2 = Cog;
     if (e.R) { XVA_CHECK_ARG(e.R->same_geom(Y) && e.R->C == Y.C, "conv_fwd: residual geometry"); g.ldr = Y.C; g.r_dtype = e.R->dt; }
     if (e.Y2) { XVA_CHECK_ARG(e.Y2->same_geom(Y) && e.Y2->C == Y.C && e.Y2->dt == Y.dt, "conv_fwd: second output geometry"); g.c2_slope = e.y2_slope; }
-    if (hg_mode(X, Y, w) == HG_MERGED) {
+    if (hg_mode(X, Y, w, true) == HG_MERGED) {
         g.A = (const char*)X.ptr() - (int64_t)w.P * X.C * X.es();
         g.C = Y.ptr(); g.M = (int)Y.rows();
         if (e.R) g.R = e.R->ptr();
@@ -159,7 +167,7 @@ inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x
     g.layout = XVA_GEMM_TN;
     g.C = w.dweff; g.c_dtype = XVA_F32; g.alpha = alpha;
     g.batch2 = w.groups; g.sC2 = (int64_t)Cog * w.k * Cig;
-    const bool merged = hg_mode(X, dY, w) == HG_MERGED;
+    const bool merged = hg_affine(X, dY, w);          // the reduction runs over all rows either way: pad rows are zeros
     const void* dy0 = merged ? dY.ptr() : dY.valid();
     const void* x0 = (const char*)(merged ? X.ptr() : X.valid()) - (int64_t)w.P * X.C * X.es();
     // The 128-row M tile wants the LARGER of (Cout_g, k*Cin_g) on M: for narrow layers (Cout_g <= 64) compute dW^T = Xcat^T dY

@@ -66,5 +66,6 @@ class GeneratorPass:
         with torch.no_grad():
             mel_tgt = self.stft(wav_seg)
         loss_mel = _MelL1.apply(o, mel_tgt, self.stft, self.alpha)                                        # losses.py:187-193
-        out.update({"model_outputs": o, "waveform_seg": wav_seg, "slice_ids": slice_ids, "loss_mel": loss_mel, "loss": out["loss"] + loss_mel})
+        out.update({"model_outputs": o, "waveform_seg": wav_seg, "slice_ids": slice_ids, "loss_mel": loss_mel, "loss": out["loss"] + loss_mel,
+                    "z_slice": z_slice})                          # the decoder's input: its gradient marks the end of the decoder's backward (BucketedSync.attach)
         return out

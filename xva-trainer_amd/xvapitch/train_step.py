@@ -228,6 +228,32 @@ class BucketedSync:
         self.step, self.group = step, group
         self.comm = torch.cuda.Stream()
         self.pending = {"gen": [], "disc": []}
+        self._early = set()
+
+    def attach(self, out):
+        """Exchange what is FINAL while the generator backward is still running (north_star: "overlapped with the backward pass").  The backward visits the
+        modules in reverse creation order — waveform decoder, pitch predictor, KL / expansion, duration predictor, flow, text encoder, posterior encoder —
+        so two buckets are complete long before it ends: the decoder's flat gradient (one engine call; the largest tensor of the generator group, 14 M
+        parameters in the reference's size) once d(loss) / d(z_slice) exists, and the flow's slice of the gradient arena once d(loss) / d(z) does.  A
+        tensor hook on those two activations enqueues the bucket's all-reduce on the exchange stream at that moment — the host is still inside
+        `loss.backward()` issuing the rest (the same reasoning as the engines' bucket callbacks, fastpitch/dp.py).  start_generator() sends the rest."""
+        self._early = set()
+        ac, dec = self.step.gen.acoustic, self.step.gen.decoder
+
+        def on_decoder(_grad):
+            if "waveform_decoder" not in self._early:
+                self._early.add("waveform_decoder")
+                self._launch("gen", [dec.grad])
+        out["z_slice"].register_hook(on_decoder)
+        flat, slices = getattr(ac, "_flat_g", None), getattr(ac, "_flat_buckets", None)
+        if flat is not None and slices and "flow" in slices and out["z"].requires_grad:
+            b, e = slices["flow"]
+
+            def on_flow(_grad):
+                if "flow" not in self._early:
+                    self._early.add("flow")
+                    self._launch("gen", [flat[b:e]])
+            out["z"].register_hook(on_flow)
 
     def _launch(self, which, tensors):
         import torch.distributed as dist
@@ -254,12 +280,15 @@ class BucketedSync:
         self.pending[which].append(ev)
 
     def start_generator(self):
+        """the buckets attach() has not already sent (all of them when it was not called)"""
         ac, dec = self.step.gen.acoustic, self.step.gen.decoder
-        self._launch("gen", [dec.grad])                                          # final first (the decoder is the head of the backward pass)
+        early, self._early = self._early, set()
+        if "waveform_decoder" not in early:
+            self._launch("gen", [dec.grad])                                      # final first (the decoder is the head of the backward pass)
         flat, slices = getattr(ac, "_flat_g", None), getattr(ac, "_flat_buckets", None)
         if flat is not None:                                                     # after the first optimiser step: a bucket is a slice of the gradient arena
             for name in list(BACKWARD_BUCKETS) + [n for n in slices if n not in BACKWARD_BUCKETS]:
-                if name in slices:
+                if name in slices and name not in early:
                     self._launch("gen", [flat[slices[name][0]:slices[name][1]]])
             return
         buckets = {}

@@ -613,6 +613,8 @@ class xVAPitchTrainer(RankMixin):
         eps, noise, slice_ids = self._draws(batch["text_input"].size(1), Ty, y_lengths)
         out = step.generator_pass(batch["text_input"], batch["text_lengths"], y, y_lengths, waveform, batch["d_vectors"], batch["language_ids"],
                                   pitch_padded=pitch, eps=eps, noise=noise, slice_ids=slice_ids)
+        if stepping and self.sync is not None and use_ft:
+            self.sync.attach(out)                                                      # the decoder's and the flow's buckets go out DURING this backward
         out["loss"].backward()
         if stepping and not use_ft:                                                    # priors iteration: the vocoder and posterior are not trained (:724-726)
             gp.acoustic.posterior_encoder.zero_grad()
