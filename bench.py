@@ -255,9 +255,13 @@ def hbm_kernel_rooflines(dev, opt, grads, active, compute):
     from xva_trainer_amd.mel import TacotronSTFT
     lib = _lib.lib
     out = {}
+    # what an event pair costs with nothing between its two records: the floor every per-launch duration below sits on
+    pair_us = timed_us(lambda: None, iters=20)
     def line(name, us, nbytes, note, flops=None, mfma_peak=None):
         gbs = nbytes / us / 1e3
+        net = max(us - pair_us, 1e-3)
         d = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None, "avg_launch_us": us,
+             "event_pair_overhead_us": pair_us, "frac_net_of_event_overhead": nbytes / net / 1e3 / 8000.0,
              "algorithmic_mbytes_per_launch": nbytes / 1e6, "note": note}
         if flops:
             d["tflops"] = flops / us / 1e6

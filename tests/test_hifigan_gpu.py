@@ -230,6 +230,37 @@ def test_full_step_against_reference_golden(golden_dir):
     assert _nrel(sd["msd"]["discriminators.0.convs.0.weight_u"], torch.from_numpy(g["msd_u0_after"])) < 1e-3
 
 
+def test_split_products_mode_meets_1e3_on_outputs_and_losses(golden_dir):
+    """fp32 storage with every product formed by three bf16 MFMAs on hi + lo split operands (xva_gemm_set_fp32_products(1), gemm_core.h MODE 3) against
+    the vectors recorded from the REFERENCE classes: what north_star names — the generated waveform and the loss values of one D + G iteration
+    (python/hifigan/xva_train.py:479-515, models.py:263-294) — at 1e-3 (feature loss 2e-3, like the exact mode).  The mode's GRADIENT elements are
+    looser than the exact mode's on this network (LeakyReLU gates through 78 layers: DESIGN.md section 4.4d) and are not asserted here."""
+    import os
+    from oracle import hifigan as ohg
+    from xva_trainer_amd import _lib
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    g = np.load(os.path.join(golden_dir, "hg_step_b2.npz"))
+    seed = int(g["seed"])
+    old = _lib.lib.xva_gemm_set_fp32_products(1)
+    try:
+        st = HifiganStep("cuda", "fp32")
+        st.load_state_dicts(ohg.init_generator_sd(seed), ohg.init_mpd_sd(seed + 1), ohg.init_msd_sd(seed + 2))
+        out = st.train_step(torch.from_numpy(g["x_mel"]).cuda(), torch.from_numpy(g["y_wav"]).cuda(), torch.from_numpy(g["y_mel"]).cuda())
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib.xva_gemm_set_fp32_products(old)
+    ref = dict(zip([str(k) for k in g["loss_names"]], g["losses"]))
+    wave = _nrel(out["y_g_hat"], torch.from_numpy(g["y_g_hat"]).squeeze(1))
+    errs = {"loss_disc_all": abs(out["loss_disc_all"].item() - ref["loss_disc_all"]) / ref["loss_disc_all"],
+            "loss_mel": abs(out["loss_mel"].item() - ref["loss_mel"]) / ref["loss_mel"],
+            "loss_gen": abs(out["loss_gen"].item() - (ref["loss_gen_f"] + ref["loss_gen_s"])) / (ref["loss_gen_f"] + ref["loss_gen_s"]),
+            "loss_fm": abs(out["loss_fm"].item() - (ref["loss_fm_f"] + ref["loss_fm_s"])) / (ref["loss_fm_f"] + ref["loss_fm_s"]),
+            "loss_gen_all": abs(out["loss_gen_all"].item() - ref["loss_gen_all"]) / ref["loss_gen_all"]}
+    print("split-products mode: waveform rel", wave, "losses", errs)
+    assert wave < 1e-3, wave
+    assert all(v < (2e-3 if k == "loss_fm" else 1e-3) for k, v in errs.items()), errs
+
+
 def test_adamw_kernel_matches_oracle():
     from oracle import hifigan as ohg
     from xva_trainer_amd.hifigan.step import FlatAdamW
