@@ -57,7 +57,7 @@ typedef struct xva_gemm_params {
     /* operand transforms applied while staging (LeakyReLU fused into the consumer): x -> x > 0 ? x : slope * x */
     int32_t a_lrelu, b_lrelu;
     float a_slope, b_slope;
-    /* epilogue: v = alpha * (acc + bias[col]) ; dropout ; v *= (G > 0 ? 1 : gate_slope) ; v += beta * R ; act ; row-mask ; store */
+    /* epilogue: v = alpha * (acc + bias[col]) ; dropout ; [v += fm_c * sign(G - F)] ; v *= (G > 0 ? 1 : gate_slope) ; v += beta * R ; act ; row-mask ; store */
     float alpha, beta;
     const float* bias;      /* [N] fp32 or NULL; second-level batch z2 reads bias + z2 * sbias2 */
     int64_t sbias2;
@@ -107,6 +107,12 @@ typedef struct xva_gemm_params {
      * strided convolution has lda = stride * a_rowpitch, a grouped one a_seglen < a_rowpitch.  0 = lda.  Only used to recognise
      * problems the resident-input kernel can take; the product it describes is the same. */
     int64_t a_rowpitch;
+    /* optional feature-matching term of a backward-data product (HiFi-GAN generator step: d/dx of 2 * mean|x_real - x_fake| through the fake
+     * feature map, python/hifigan/models.py:263-269, added to the gradient that arrives from the layer above BEFORE the LeakyReLU gate):
+     *     v = alpha * (acc + bias) ; dropout ; v += fm_c * sign(G - F) ; gate ; + beta * R ; act ; ...
+     * F (dtype g_dtype) is indexed exactly like G (ldg, sG, sG2) and needs G; NULL disables.  Direct-to-LDS kernels (bf16 operands) only. */
+    const void* F;
+    float fm_c;
 } xva_gemm_params;
 
 /* Launches on `stream` (a hipStream_t); returns 0 or a negative XVA_ERR_* code. */

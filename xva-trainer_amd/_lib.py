@@ -57,6 +57,7 @@ class GemmParams(C.Structure):
         ("sk_ws", C.c_void_p), ("sk_ws_bytes", i64),
         ("C2", vp), ("c2_slope", f32),
         ("a_rowpitch", i64),
+        ("F", vp), ("fm_c", f32),
     ]
 
 

@@ -63,6 +63,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     XVA_CHECK_ARG(p.accumulate != 2 || p.c_dtype == XVA_F32, "xva_gemm: atomic accumulation needs an fp32 C");
     XVA_CHECK_ARG(!p.C2 || (p.splitk == 1 && !p.accumulate && !p.c_trans && ((uintptr_t)p.C2 % 16) == ((uintptr_t)p.C % 16)),
                   "xva_gemm: a second output needs splitk == 1, plain (non-accumulating, non-transposed) stores and C's alignment");
+    XVA_CHECK_ARG(!p.F || (p.G && p.splitk == 1 && !auto_sk), "xva_gemm: the feature-matching term needs the gate tensor G and an unsplit product");
     XVA_CHECK_ARG(p.kb_len == 0 || (p.layout == XVA_GEMM_TN && p.kb_len > 0 && p.kb_sA % ve == 0 && p.kb_sB % ve == 0), "xva_gemm: bad K-block arguments");
     if (p.K == 0) p.splitk = 1;
     if (auto_sk && p.layout == XVA_GEMM_TN && p.seglen > 0 && p.sk_ws) {   // convolution weight gradient: resident-operand kernel (wgrad_res.h)
@@ -166,6 +167,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         double by = (ua + ub) * es_ab + (double)p.M * p.N * es_c * (p.accumulate ? 2.0 : 1.0);
         if (p.R) by += (double)p.M * p.N * (p.r_dtype == XVA_BF16 ? 2.0 : 4.0);
         if (p.G) by += (double)p.M * p.N * (p.g_dtype == XVA_BF16 ? 2.0 : 4.0);
+        if (p.F) by += (double)p.M * p.N * (p.g_dtype == XVA_BF16 ? 2.0 : 4.0);
         xva_prof_shape(p.M, p.N, p.K, p.batch * p.batch2, p.splitk, bn, by * nbz); }
     XVA_CHECK_ARG(!p.C2 || glds_tile >= 0, "xva_gemm: the second output is written by the direct-to-LDS kernels only (bf16 operands, K >= 64)");
     if (res_dstep != 0) {   // conv over 32 / 64 / 128 channels (per group), stride 1 / 2 / 4: resident input tile

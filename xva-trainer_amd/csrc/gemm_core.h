@@ -491,7 +491,11 @@ __global__ __launch_bounds__(NTHREADS, (MODE == 3 && BN == 128) ? 2 : 3) void xv
                 if ((p.splitk == 1 || first_split) && p.bias) v += p.bias[(int64_t)z2 * p.sbias2 + col];
                 v *= p.alpha;
                 if (p.drop_p > 0.f) v *= xva_dropout_scale(p.drop_p, p.drop_seed, p.drop_stream, (uint64_t)row * p.N + col);
-                if (p.G) v = (ld_elem(p.G, goff + (int64_t)row * p.ldg + col, p.g_dtype) > 0.f) ? v : v * p.gate_slope;
+                if (p.G) {
+                    const float gv = ld_elem(p.G, goff + (int64_t)row * p.ldg + col, p.g_dtype);
+                    if (p.F) { const float df = gv - ld_elem(p.F, goff + (int64_t)row * p.ldg + col, p.g_dtype); v += df > 0.f ? p.fm_c : (df < 0.f ? -p.fm_c : 0.f); }
+                    v = gv > 0.f ? v : v * p.gate_slope;
+                }
                 if ((p.splitk == 1 || first_split) && p.R) v += p.beta * ld_elem(p.R, roff + (int64_t)row * p.ldr + col, p.r_dtype);
                 switch (p.act) {
                     case XVA_ACT_RELU: v = fmaxf(v, 0.f); break;

@@ -230,6 +230,24 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (e < nv) g[e] = ld_elem(p.G, gi + e, p.g_dtype);
         }
+        if (p.F) {      // feature-matching term, before the gate: v += fm_c * sign(g - f)
+            float f[4] = {0.f, 0.f, 0.f, 0.f};
+            if (VEC) {
+                if (p.g_dtype == XVA_BF16) {
+                    uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.F) + gi);
+                    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+                    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+                } else {
+                    float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.F) + gi);
+                    f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nv) f[e] = ld_elem(p.F, gi + e, p.g_dtype);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float df = g[e] - f[e]; v[e] += df > 0.f ? p.fm_c : (df < 0.f ? -p.fm_c : 0.f); }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = g[e] > 0.f ? v[e] : v[e] * p.gate_slope;
     }
@@ -411,7 +429,7 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
         const float4 b0 = bq[0], b1 = bq[1];
         bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
     }
-    const bool want_r = !slab && p.R, want_g = !slab && p.G, want_c = !slab && p.accumulate;
+    const bool want_r = !slab && p.R, want_g = !slab && p.G, want_c = !slab && p.accumulate, want_f = want_g && p.F;
     const bool mask32 = (int64_t)p.M * p.mask_mul + p.mask_add < (1ll << 31) && p.mask_add >= 0 && p.mask_mul >= 0;   // mapped row indices fit 32 bits
     // The loop over groups of CH row blocks is a RUNTIME loop: unrolled, the epilogue of the 256x256 kernel alone was ~400 KB of
     // code (the instruction cache holds 64 KB) and took 21 us of a 50 us workgroup whatever the memory traffic.  Only the
@@ -419,13 +437,14 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
 #pragma unroll 1
     for (int ch = 0; ch < MI / CH; ++ch) {
         const int i0 = ch * CH;
-        uint4 rraw[CH * NPASS], graw[CH * NPASS], craw[CH * NPASS];
+        uint4 rraw[CH * NPASS], graw[CH * NPASS], craw[CH * NPASS], fraw[CH * NPASS];
         static_for<CH * NPASS>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             const int row = r0 + (i0 + q / NPASS) * 16 + (q % NPASS) * RPP + rr;
             if (row < p.M && col_ok) {
                 if (want_r) rraw[q] = load8(p.R, roff + (int64_t)row * p.ldr + col);
                 if (want_g) graw[q] = load8(p.G, goff + (int64_t)row * p.ldg + col);
+                if (want_f) fraw[q] = load8(p.F, goff + (int64_t)row * p.ldg + col);
                 if (want_c) craw[q] = load8(p.C, coff + (int64_t)row * p.ldc + col);
             }
         });
@@ -463,6 +482,11 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                 }
                 if (want_g) {
                     float g[8]; unpack8(graw[q], g);
+                    if (want_f) {      // feature-matching term, before the gate
+                        float f[8]; unpack8(fraw[q], f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float df = g[e] - f[e]; v[e] += df > 0.f ? p.fm_c : (df < 0.f ? -p.fm_c : 0.f); }
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = g[e] > 0.f ? v[e] : v[e] * p.gate_slope;
                 }

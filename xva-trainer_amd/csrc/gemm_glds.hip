@@ -174,6 +174,7 @@ static int vec_epilogue_ok(const xva_gemm_params& p) {
         int ok = (p.N % n == 0) && (p.ldc % n == 0) && (p.sC % n == 0) && (p.sC2 % n == 0) && al(p.C, p.c_dtype == XVA_BF16 ? ab : 16);
         if (p.R) ok = ok && (p.ldr % n == 0) && (p.sR % n == 0) && (p.sR2 % n == 0) && al(p.R, p.r_dtype == XVA_BF16 ? ab : 16);
         if (p.G) ok = ok && (p.ldg % n == 0) && (p.sG % n == 0) && (p.sG2 % n == 0) && al(p.G, p.g_dtype == XVA_BF16 ? ab : 16);
+        if (p.F) ok = ok && al(p.F, p.g_dtype == XVA_BF16 ? ab : 16);
         return ok;
     };
     if (!level(4)) return 0;

@@ -109,6 +109,7 @@ inline int hg_conv_fwd(const Seq& X, const Seq& Y, const ConvW& w, const ConvEpi
 // stride 1: one GEMM.  stride s: one GEMM per input phase psi (polyphase), each using the taps j = j0 + m*s.
 struct BwdEpi {
     const Seq* gate = nullptr; float gate_slope = 0.f;   // multiply by lrelu'(gate) (gate has dX's geometry)
+    const Seq* fm = nullptr; float fm_c = 0.f;           // before the gate: + fm_c * sign(gate - fm) (feature matching; fm has gate's geometry and dtype)
     const Seq* R = nullptr; float alpha = 1.f, beta = 1.f;
     int accumulate = 0;
 };
@@ -135,6 +136,7 @@ inline int hg_conv_bwd_data(const Seq& dY, const Seq& dX, const ConvW& w, const 
         g.batch2 = w.groups; g.sA2 = Cog; g.sB2 = (int64_t)Cog * w.k * Cig; g.sC2 = Cig; g.sR2 = Cig; g.sG2 = Cig;
         if (e.R) { g.ldr = (int64_t)w.s * dX.C; g.r_dtype = e.R->dt; }
         if (e.gate) { g.ldg = (int64_t)w.s * dX.C; g.g_dtype = e.gate->dt; g.gate_slope = e.gate_slope; }
+        if (e.fm) { XVA_CHECK_ARG(e.gate && e.fm->same_geom(*e.gate) && e.fm->C == e.gate->C && e.fm->dt == e.gate->dt, "conv_bwd_data: feature-map geometry"); g.fm_c = e.fm_c; }
         // stride 1: dX[t] = sum_j dY[t + P - j*d] W_j  -> c0 = P (row offset), taps step by d
         const int64_t a_row0 = (w.s == 1) ? (int64_t)w.P : (int64_t)c0;
         if (mode == HG_MERGED) {
@@ -143,6 +145,7 @@ inline int hg_conv_bwd_data(const Seq& dY, const Seq& dX, const ConvW& w, const 
             g.M = (int)dY.rows();
             if (e.R) g.R = (const char*)e.R->ptr() + (int64_t)psi * dX.C * e.R->es();
             if (e.gate) g.G = (const char*)e.gate->ptr() + (int64_t)psi * dX.C * e.gate->es();
+            if (e.fm) g.F = (const char*)e.fm->ptr() + (int64_t)psi * dX.C * e.fm->es();
             g.mask_mode = XVA_MASK_PAD; g.Tp = dX.Hp(); g.mask_pad = dX.padF; g.mask_len = dX.T; g.mask_mul = w.s; g.mask_add = psi;
         } else {
             const int Q = (dX.T - psi + w.s - 1) / w.s;
@@ -153,6 +156,7 @@ inline int hg_conv_bwd_data(const Seq& dY, const Seq& dX, const ConvW& w, const 
             g.M = Q;
             if (e.R) g.R = (const char*)e.R->valid() + (int64_t)psi * dX.C * e.R->es();
             if (e.gate) g.G = (const char*)e.gate->valid() + (int64_t)psi * dX.C * e.gate->es();
+            if (e.fm) g.F = (const char*)e.fm->valid() + (int64_t)psi * dX.C * e.fm->es();
         }
         XVA_TRY(xva_gemm(&g, st));
     }

@@ -931,12 +931,14 @@ int disc_backward_wave(Ctx& c, const float* Pd, const DiscRun& r, const SeqSpec*
         Seq x = c.S(r.t[i]).slice(f0, nf), xr = c.S(rt[i]).slice(r0, nf), dy = c.S(r.d[i + 1]).slice(f0, nf), dx = c.S(r.d[i]).slice(f0, nf);
         if (i == r.n - 1) {
             XVA_TRY(xva_hg_cout1_bwd_data(dy.ptr(), eff32(c, l, r.pass), x.ptr(), dx.ptr(), c.dt, x.rows(), x.C, l.k, 1, l.P, x.Hp(), x.padF, x.T, 0, 0.f, c.st));
+            XVA_TRY(xva_hg_seed_grad(xr.ptr(), x.ptr(), dx.ptr(), c.dt, nf, x.Hp(), x.padF, x.T, x.C, feat * 2.f / numel(i), 0.f, 0, 1, SLOPE, 0, c.st));
         } else {
-            BwdEpi b;
+            // + feature-matching gradient of this fmap, then LeakyReLU backward on the total — both in the product's epilogue (round 4; a separate
+            // read-modify-write pass over dx before: 46 launches and 3.9 GB of traffic per iteration at B = 64)
+            BwdEpi b; b.gate = &x; b.gate_slope = SLOPE;
+            if (feat != 0.f) { b.fm = &xr; b.fm_c = feat * 2.f / numel(i); }
             XVA_TRY(hg_conv_bwd_data(dy, dx, cw(c, l, Pd, r.pass), b, c.compute, c.st));
         }
-        // + feature-matching gradient of this fmap, then LeakyReLU backward on the total
-        XVA_TRY(xva_hg_seed_grad(xr.ptr(), x.ptr(), dx.ptr(), c.dt, nf, x.Hp(), x.padF, x.T, x.C, feat * 2.f / numel(i), 0.f, 0, 1, SLOPE, 0, c.st));
     }
     const Layer& l0 = L[r.li[0]];
     Seq d1 = c.S(r.d[1]).slice(f0, nf), dxc = c.S(r.xc[1]).slice(f0, nf);
