@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-end evidence on the GPU box: plain bench line, rocprofv3 kernel stats of the same command, and the two PMC passes
 # (FETCH_SIZE / WRITE_SIZE, separate runs as MI355X_MICROARCH.md prescribes) per leg.  Everything lands in gpurun_out/final/.
-# usage (from the build container):  gpurun -- 'XVA_COMMIT=<short sha> XVA_ROUND=r03 bash tools/profile_round.sh'
+# usage (from the build container):  gpurun -- 'XVA_COMMIT=<short sha> XVA_ROUND=r04 bash tools/profile_round.sh'
 R=${GRAFT_REPO_ROOT:-$PWD}
-RD=${XVA_ROUND:-r03}
+RD=${XVA_ROUND:-r04}
 O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o b -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_final_bench_under_rocprof.json
@@ -45,7 +45,9 @@ json.dump({"csrc": bench.csrc_fingerprint(), "commit": "${XVA_COMMIT:-unknown}",
           open("$O/${RD}_${leg}_pmc_hbm_bytes.meta.json", "w"))
 PY
 done
-# the plain bench line last: its roofline.traffic reads the PMC tables just measured (same sources: fingerprint checked)
-cp $O/${RD}_*_pmc_hbm_bytes.csv $O/${RD}_*_pmc_hbm_bytes.meta.json $R/profiles/
+# the lanes-off FastPitch kernel trace gets the same fingerprint: bench.py quotes roofline.frac_rocprof from it only while it describes the sources it runs
+cp $O/${RD}_fastpitch_pmc_hbm_bytes.meta.json $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.meta.json
+# the plain bench line last: its roofline.traffic / frac_rocprof read the tables just measured (same sources: fingerprint checked)
+cp $O/${RD}_*_pmc_hbm_bytes.csv $O/${RD}_*_pmc_hbm_bytes.meta.json $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.csv $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.meta.json $R/profiles/
 cd $R && python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/${RD}_final_bench.json
 ls -la $O

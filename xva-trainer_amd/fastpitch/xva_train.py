@@ -14,8 +14,8 @@ epoch-loss deltas <= target for 3 consecutive epochs, at least 20 epochs in stag
 re-written with training_stage + 1 and an empty loss history before the bare raise.
 Changed on purpose: the step is 3 C calls (no autograd graph, no GradScaler: bf16 needs no loss scaling); training.log is
 appended, not rewritten, each step; batches are built on the device from the dataset directory (xva-trainer_amd/data.py);
-multi-GPU is one process per GPU (dp.GradSync over RCCL) instead of single-process nn.DataParallel — launch the server /
-trainer under `python -m torch.distributed.run --nproc-per-node N`; rank 0 keeps the ws / log / checkpoint duties.
+multi-GPU is one process per GPU (dp.GradSync over RCCL) instead of single-process nn.DataParallel: handleTrainer(..., gpus=[0..N-1]) in the
+server process spawns and supervises the N rank workers (xva-trainer_amd/dp_launch.py); rank 0 keeps the ws / log / checkpoint duties.
 """
 import contextlib
 import gc

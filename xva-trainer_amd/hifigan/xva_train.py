@@ -13,7 +13,8 @@ ExponentialLR(last_epoch=epoch)'s initial step; like the reference the trainer n
 g_ / do_ pair; "[male]" / "[female]" resolve to the pretrained directories).
 Changed on purpose: crops, peak normalisation and both mels are computed on the GPU (xva-trainer_amd/data.py, HIP mel) instead of on
 the CPU in the dataset; one iteration is a fixed sequence of C calls (hifigan/step.py); multi-GPU is one process per GPU with
-bucketed, overlapped RCCL gradient exchange (the reference defines DataParallel here but never wraps, xva_train.py:40)."""
+bucketed, overlapped RCCL gradient exchange (the reference defines DataParallel here but never wraps, xva_train.py:40), started by
+handleTrainer(..., gpus=[0..N-1]) itself (xva-trainer_amd/dp_launch.py)."""
 import glob
 import json
 import os

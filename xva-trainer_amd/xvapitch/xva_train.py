@@ -19,9 +19,10 @@ Gradient accumulation, as the reference has it (:652-653): `optimizer.zero_grad(
 step after `gam` iterations applies the LAST micro-batch's gradients only; mirrored here (parity with the reference's training dynamics), not "fixed".
 
 Changed on purpose: no GradScaler (bf16 needs none; the checkpoint's "scaler" entry is an empty dict); spectrograms are computed on the GPU from the raw
-clips (GeneratorPass.batch_from_wav) instead of in DataLoader workers; multi-GPU is one process per GPU (train_step.BucketedSync over RCCL) instead of
-nn.DataParallel.  The text front end (g2p -> ALL_SYMBOLS ids), speaker-embedding extraction and pitch extraction are the reference's CPU preprocessing:
-this trainer reads their caches (`tokens/{name}.npy` int ids, `se_embs/{name}.npy` 512-d, `pitch/{name}.npy`), and says so when one is missing.
+clips (GeneratorPass.batch_from_wav) instead of in DataLoader workers; multi-GPU is one process per GPU (train_step.BucketedSync over RCCL; handleTrainer(..., gpus=[0..N-1]) spawns the rank workers,
+xva-trainer_amd/dp_launch.py) instead of nn.DataParallel.  The text front end (g2p -> ALL_SYMBOLS ids), speaker-embedding extraction and pitch extraction are the reference's CPU preprocessing:
+this trainer reads their caches (`tokens/{name}.npy` int ids — or the reference's own text front end when it is importable — `se_embs/{name}.npy` 512-d,
+`pitch/{name}.npy`); missing symbol ids are an error (ids of another table would corrupt the voice), missing pitch files are counted in training.log.
 """
 import datetime
 import json
