@@ -27,6 +27,9 @@ rocprofv3 --kernel-trace -d /tmp/p_fpt -o t -- python $R/bench.py --steps 6 --wa
 python $R/tools/trace_dump.py $(find /tmp/p_fpt -name "*.db" | head -1) /tmp/fp_trace.csv > /dev/null && python $R/tools/trace_gaps.py /tmp/fp_trace.csv lamb_pass1 5 > $O/${RD}_fastpitch_timeline.txt 2>&1
 python $R/tools/trace_dump.py $(find /tmp/p_hg -name "*.db" | head -1) /tmp/hg_trace.csv > /dev/null && python $R/tools/trace_gaps.py /tmp/hg_trace.csv adamw_kernel 6 > $O/${RD}_hifigan_timeline.txt 2>&1
 python $R/tools/trace_dump.py $(find /tmp/p_c5 -name "*.db" | head -1) /tmp/c5_trace.csv > /dev/null && python $R/tools/trace_gaps.py /tmp/c5_trace.csv adamw_kernel 4 > $O/${RD}_xvapitch_c5_timeline.txt 2>&1
+# when the xVAPitch generator group's buckets can start their exchange (one rank, marker kernels in place of the all-reduce)
+rocprofv3 --kernel-trace -d /tmp/p_c5dp -o d -- python $R/tools/dp_overlap_probe_c5.py > /dev/null 2>&1
+python $R/tools/trace_dump.py $(find /tmp/p_c5dp -name "*.db" | head -1) /tmp/c5dp_trace.csv > /dev/null && python $R/tools/dp_overlap_probe_c5.py --report /tmp/c5dp_trace.csv > $O/${RD}_dp_overlap_probe_c5.txt 2>&1
 # the mel front end's kernels per mode (fused kernel / four-launch FFT pipeline / dense DFT)
 rocprofv3 --kernel-trace --stats -d /tmp/p_mel -o m -- python $R/tools/mel_time.py > $O/${RD}_mel_front_end.txt 2>/dev/null
 python $R/tools/rocpd_summary.py $(find /tmp/p_mel -name "*.db" | head -1) /tmp/mel_stats.csv > /dev/null && grep -i "mel\|stft\|magnitude\|reflect\|gemm" /tmp/mel_stats.csv >> $O/${RD}_mel_front_end.txt
