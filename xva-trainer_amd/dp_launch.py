@@ -159,6 +159,10 @@ class RankGroup(object):
                 f.close()
             except Exception:
                 pass
+        tmp, self._tmp = getattr(self, "_tmp", None), None
+        if tmp:                                    # the workers' stderr files (quoted in the error when a rank dies without a message)
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
         self._logs, self.parked, self.running = [], False, False
 
     def __del__(self):
