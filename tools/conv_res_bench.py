@@ -22,7 +22,10 @@ def main():
     nseq, PAD = 64, 32
     ws = torch.zeros(96 << 18, device="cuda")
     print("%-22s %10s %10s %10s %10s %10s   (us ; TFLOP/s)" % ("shape", "fwd lrelu", "fwd plain", "bwd-data", "dW lrelu", "dW plain"))
-    for C, T in ((128, 2048), (64, 4096), (32, 8192)):
+    shapes = ((256, 256), (128, 2048), (64, 4096), (32, 8192))
+    if os.environ.get("XVA_BENCH_C"):
+        shapes = tuple(sh for sh in shapes if sh[0] == int(os.environ["XVA_BENCH_C"]))
+    for C, T in shapes:
         Hp = T + 2 * PAD
         rows = nseq * Hp
         xs = torch.zeros(rows + 2 * PAD + 64, C, device="cuda", dtype=torch.bfloat16)
