@@ -135,6 +135,10 @@ async def handleTrainer(models_manager, data, websocket, gpus, resume=False):
                 await trainer.websocket.send("Finished training\n")
             return None
         models_manager.models_bank.pop("xvapitch", None)
+        try:                                                                         # the UI reads training.log: say why the run stopped
+            trainer.print_and_log("ERROR: %s" % (str(e).splitlines()[0] if str(e) else type(e).__name__), save_to_file=trainer.dataset_output)
+        except Exception:
+            pass
         raise
     return None
 
