@@ -626,15 +626,17 @@ class xVAPitchTrainer(RankMixin):
             gp.decoder.zero_grad()
         if stepping and self.sync is not None:
             self.sync.start_generator()                                                # the exchange runs under the discriminator pass
-        loss_dict = {k: float(out[k].detach()) for k in ("loss", "loss_gen", "loss_kl", "loss_feat", "loss_mel", "loss_duration")}
-        if "loss_pitch" in out:
-            loss_dict["loss_pitch"] = float(out["loss_pitch"].detach())
+        loss_names = ["loss", "loss_gen", "loss_kl", "loss_feat", "loss_mel", "loss_duration"] + (["loss_pitch"] if "loss_pitch" in out else [])
+        loss_vals = [out[k].detach().reshape(()).float() for k in loss_names]
         # ---- pass 1: discriminator on the cached (generated.detach(), real) segments ----
         step.disc.zero_grad()
         loss_disc = step.discriminator_pass(out["model_outputs"].detach(), out["waveform_seg"])
         if stepping and self.sync is not None:
             self.sync.start_discriminator()                                            # ... and this one under the generator group's update
-        loss_dict["loss_disc"] = float(loss_disc)
+        # ONE device -> host transfer for the iteration's loss values, after both passes are enqueued (seven .item() syncs between the passes
+        # kept the host from issuing the discriminator pass while the generator backward was still running)
+        host = torch.stack(loss_vals + [torch.as_tensor(loss_disc, device=loss_vals[0].device).detach().reshape(()).float()]).cpu()
+        loss_dict = {k: float(v) for k, v in zip(loss_names + ["loss_disc"], host)}
         del out
         self.accumulated_steps += 1
         if self.accumulated_steps % self.gam == 0:
