@@ -53,6 +53,8 @@ lib.xva_sdp_dequant_bwd.restype = i32
 lib.xva_sdp_dequant_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
 P = _lib.ptr
 ST = _lib.stream_ptr
+# 1 (default): a DilatedDepthSeparableConv stack is one autograd node (DDSStack); 0: the per-primitive composition (XVA_SDP_FUSED=0, A/B and tests)
+_FUSED_DDS = int(__import__("os").environ.get("XVA_SDP_FUSED", "1"))
 
 
 
@@ -211,6 +213,96 @@ def _param(t, device):
     return t.to(device=device, dtype=torch.float32).requires_grad_(True)
 
 
+class DDSStack(torch.autograd.Function):
+    """DilatedDepthSeparableConv.forward (sdp.py:70-93) as ONE autograd node: the same kernels in the same order as the per-primitive composition
+    (DwConv -> LayerNormRows -> Gelu -> Conv1x1 -> LayerNormRows -> Gelu -> [Dropout] -> + x, L times, then the mask), issued back to back from one
+    forward / one backward instead of through 8 L + 2 autograd nodes — the duration predictor runs ten of these stacks per iteration on (16 x 100 x 192)
+    tensors and was bound by the host's per-node cost, not by the kernels.  Residual adds and the mask run in place on tensors the
+    node owns (no clone launches).  Inputs: x (B, T, C), g (B, T, C) or None, lens, cfg = (k, L, p_drop, seed, site0), then 8 parameters per layer
+    (convs_sep w, b; convs_1x1 w, b; norms_1 gamma, beta; norms_2 gamma, beta)."""
+
+    @staticmethod
+    def forward(ctx, x, g, lens, cfg, *params):
+        k, L, p_drop, seed, site0 = cfg
+        x = x.contiguous(); B, T, Cc = x.shape
+        rows, n = B * T, x.numel()
+        dev = x.device
+        if g is not None:
+            cur = torch.add(x, g)
+        else:
+            cur = x
+        saved = []
+        for i in range(L):
+            ws, bs, w1, b1, g1, be1, g2, be2 = params[8 * i:8 * i + 8]
+            wsc = ws.contiguous()
+            t1 = torch.empty_like(cur)
+            _lib.check(lib.xva_dwconv_fwd(P(cur), P(wsc), P(bs), P(t1), P(lens), B, T, Cc, k, k ** i, ST()), "xva_dwconv_fwd")
+            n1 = torch.empty_like(cur); m1 = torch.empty(rows, device=dev); r1 = torch.empty(rows, device=dev)
+            _lib.check(lib.xva_ln_rows_fwd(P(t1), P(g1), P(be1), P(n1), P(m1), P(r1), rows, Cc, 1e-5, ST()), "xva_ln_rows_fwd")
+            a1 = torch.empty_like(cur)
+            _lib.check(lib.xva_gelu_fwd(P(n1), P(a1), n, ST()), "xva_gelu_fwd")
+            w2 = w1.reshape(Cc, Cc).contiguous()
+            t2 = torch.empty_like(cur)
+            _prep((0, rows, Cc, Cc, True), lambda: _lib.PreparedGemm(a1, w2, t2, rows, Cc, Cc, Cc, Cc, Cc, layout=_lib.GEMM_NT, compute=0, bias=b1)).run(a1, w2, t2, bias=b1)
+            n2 = torch.empty_like(cur); m2 = torch.empty(rows, device=dev); r2 = torch.empty(rows, device=dev)
+            _lib.check(lib.xva_ln_rows_fwd(P(t2), P(g2), P(be2), P(n2), P(m2), P(r2), rows, Cc, 1e-5, ST()), "xva_ln_rows_fwd")
+            a2 = torch.empty_like(cur)
+            _lib.check(lib.xva_gelu_fwd(P(n2), P(a2), n, ST()), "xva_gelu_fwd")
+            if p_drop > 0:
+                nxt = torch.empty_like(cur)
+                _lib.check(lib.xva_dropout_apply(P(a2), P(nxt), 0, n, p_drop, seed, site0 + i, ST()), "xva_dropout_apply")
+            else:
+                nxt = a2
+            _lib.check(lib.xva_fp_add_act(P(nxt), P(cur), 0, n, ST()), "xva_fp_add_act")          # x = x + y, in place on the branch's own tensor
+            saved.append((cur, wsc, t1, m1, r1, g1, n1, a1, w2, t2, m2, r2, g2, n2))
+            cur = nxt
+        if L == 0 and g is None:
+            cur = cur.clone()
+        _lib.check(lib.xva_seq_mask(P(cur), 0, B, T, 0, Cc, P(lens), ST()), "xva_seq_mask")
+        ctx.saved, ctx.lens, ctx.cfg, ctx.params, ctx.has_g, ctx.dims = saved, lens, cfg, params, g is not None, (B, T, Cc)
+        return cur
+
+    @staticmethod
+    def backward(ctx, dy):
+        k, L, p_drop, seed, site0 = ctx.cfg
+        B, T, Cc = ctx.dims
+        rows, n, lens, params = B * T, B * T * Cc, ctx.lens, ctx.params
+        d = dy.contiguous().clone()
+        _lib.check(lib.xva_seq_mask(P(d), 0, B, T, 0, Cc, P(lens), ST()), "xva_seq_mask")
+        rets = [None] * (8 * L)
+        for i in reversed(range(L)):
+            cur, wsc, t1, m1, r1, g1, n1, a1, w2, t2, m2, r2, g2, n2 = ctx.saved[i]
+            ws, bs, w1, b1, _, be1, _, be2 = params[8 * i:8 * i + 8]
+            if p_drop > 0:
+                da2 = torch.empty_like(d)
+                _lib.check(lib.xva_dropout_apply(P(d), P(da2), 0, n, p_drop, seed, site0 + i, ST()), "xva_dropout_apply")
+            else:
+                da2 = d
+            dn2 = torch.empty_like(d)
+            _lib.check(lib.xva_gelu_bwd(P(n2), P(da2), P(dn2), n, ST()), "xva_gelu_bwd")
+            dt2 = torch.empty_like(d)
+            (dg2, rg2), (db2, rb2) = _gbuf(g2), _gbuf(be2)
+            _lib.check(lib.xva_ln_rows_bwd(P(dn2), P(t2), P(m2), P(r2), P(g2), P(dt2), P(dg2), P(db2), rows, Cc, ST()), "xva_ln_rows_bwd")
+            da1 = torch.empty_like(d)
+            _prep((1, rows, Cc, Cc), lambda: _lib.PreparedGemm(dt2, w2, da1, rows, Cc, Cc, Cc, Cc, Cc, layout=_lib.GEMM_NN, compute=0)).run(dt2, w2, da1)
+            (dw1, rw1), (dbb1, rb1) = _gbuf(w1), _gbuf(b1)
+            _prep((2, rows, Cc, Cc), lambda: _lib.PreparedGemm(dt2, a1, dw1, Cc, Cc, rows, Cc, Cc, Cc, layout=_lib.GEMM_TN, compute=0, accumulate=True,
+                                                                splitk=0)).run(dt2, a1, dw1)
+            _lib.check(lib.xva_hg_colsum(P(dt2), 0, P(dbb1), rows, Cc, 1.0, ST()), "xva_hg_colsum")
+            dn1 = torch.empty_like(d)
+            _lib.check(lib.xva_gelu_bwd(P(n1), P(da1), P(dn1), n, ST()), "xva_gelu_bwd")
+            dt1 = torch.empty_like(d)
+            (dg1, rg1), (db1, rbe1) = _gbuf(g1), _gbuf(be1)
+            _lib.check(lib.xva_ln_rows_bwd(P(dn1), P(t1), P(m1), P(r1), P(g1), P(dt1), P(dg1), P(db1), rows, Cc, ST()), "xva_ln_rows_bwd")
+            dxb = torch.empty_like(d)
+            (dws, rws), (dbs, rbs) = _gbuf(ws), _gbuf(bs)
+            _lib.check(lib.xva_dwconv_bwd(P(dt1), P(cur), P(wsc), P(dxb), P(dws), P(dbs), P(lens), B, T, Cc, k, k ** i, ST()), "xva_dwconv_bwd")
+            _lib.check(lib.xva_fp_add_act(P(dxb), P(d), 0, n, ST()), "xva_fp_add_act")             # d(x) = d(residual) + d(branch)
+            d = dxb
+            rets[8 * i:8 * i + 8] = [rws, rbs, (rw1.view(w1.shape) if rw1 is not None else None), rb1, rg1, rbe1, rg2, rb2]
+        return (d, d if ctx.has_g else None, None, None) + tuple(rets)
+
+
 class DilatedDepthSeparableConv:
     """sdp.py:40-93: per layer  y = GELU(LN(dwconv_{d = k^i}(x * x_mask))); y = GELU(LN(conv1x1(y))); x = x + y;  output x * x_mask."""
 
@@ -254,6 +346,13 @@ class DilatedDepthSeparableConv:
     def forward_btc(self, x, lens, g=None):
         """x, g: (B, T, C)"""
         p = self.p
+        if _FUSED_DDS:
+            ps = []
+            for i in range(self.L):
+                ps += [p["convs_sep.%d.weight" % i], p["convs_sep.%d.bias" % i], p["convs_1x1.%d.weight" % i], p["convs_1x1.%d.bias" % i],
+                       p["norms_1.%d.gamma" % i], p["norms_1.%d.beta" % i], p["norms_2.%d.gamma" % i], p["norms_2.%d.beta" % i]]
+            drop = self.dropout_p if self.training else 0.0
+            return DDSStack.apply(x, g, lens, (self.k, self.L, float(drop), int(self.drop_seed), int(self.site0)), *ps)
         if g is not None:
             x = Add.apply(x, g)
         for i in range(self.L):
