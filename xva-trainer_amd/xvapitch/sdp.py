@@ -213,94 +213,160 @@ def _param(t, device):
     return t.to(device=device, dtype=torch.float32).requires_grad_(True)
 
 
+def _dds_fwd(x, g, lens, cfg, params):
+    """The kernels of DilatedDepthSeparableConv.forward (sdp.py:70-93) back to back: (x [+ g]) -> L x {DwConv -> LayerNorm2 -> GELU -> Conv1x1 -> LayerNorm2 ->
+    GELU -> [Dropout] -> + x} -> mask.  Residual adds and the mask run in place on tensors this call owns.  Returns (out, what _dds_bwd needs)."""
+    k, L, p_drop, seed, site0 = cfg
+    x = x.contiguous(); B, T, Cc = x.shape
+    rows, n = B * T, x.numel()
+    dev = x.device
+    cur = torch.add(x, g) if g is not None else x
+    saved = []
+    for i in range(L):
+        ws, bs, w1, b1, g1, be1, g2, be2 = params[8 * i:8 * i + 8]
+        wsc = ws.contiguous()
+        t1 = torch.empty_like(cur)
+        _lib.check(lib.xva_dwconv_fwd(P(cur), P(wsc), P(bs), P(t1), P(lens), B, T, Cc, k, k ** i, ST()), "xva_dwconv_fwd")
+        n1 = torch.empty_like(cur); m1 = torch.empty(rows, device=dev); r1 = torch.empty(rows, device=dev)
+        _lib.check(lib.xva_ln_rows_fwd(P(t1), P(g1), P(be1), P(n1), P(m1), P(r1), rows, Cc, 1e-5, ST()), "xva_ln_rows_fwd")
+        a1 = torch.empty_like(cur)
+        _lib.check(lib.xva_gelu_fwd(P(n1), P(a1), n, ST()), "xva_gelu_fwd")
+        w2 = w1.reshape(Cc, Cc).contiguous()
+        t2 = torch.empty_like(cur)
+        _prep((0, rows, Cc, Cc, True), lambda: _lib.PreparedGemm(a1, w2, t2, rows, Cc, Cc, Cc, Cc, Cc, layout=_lib.GEMM_NT, compute=0, bias=b1)).run(a1, w2, t2, bias=b1)
+        n2 = torch.empty_like(cur); m2 = torch.empty(rows, device=dev); r2 = torch.empty(rows, device=dev)
+        _lib.check(lib.xva_ln_rows_fwd(P(t2), P(g2), P(be2), P(n2), P(m2), P(r2), rows, Cc, 1e-5, ST()), "xva_ln_rows_fwd")
+        a2 = torch.empty_like(cur)
+        _lib.check(lib.xva_gelu_fwd(P(n2), P(a2), n, ST()), "xva_gelu_fwd")
+        if p_drop > 0:
+            nxt = torch.empty_like(cur)
+            _lib.check(lib.xva_dropout_apply(P(a2), P(nxt), 0, n, p_drop, seed, site0 + i, ST()), "xva_dropout_apply")
+        else:
+            nxt = a2
+        _lib.check(lib.xva_fp_add_act(P(nxt), P(cur), 0, n, ST()), "xva_fp_add_act")          # x = x + y, in place on the branch's own tensor
+        saved.append((cur, wsc, t1, m1, r1, g1, n1, a1, w2, t2, m2, r2, g2, n2))
+        cur = nxt
+    if L == 0 and g is None:
+        cur = cur.clone()
+    _lib.check(lib.xva_seq_mask(P(cur), 0, B, T, 0, Cc, P(lens), ST()), "xva_seq_mask")
+    return cur, (saved, lens, cfg, params, (B, T, Cc))
+
+
+def _dds_bwd(state, dy):
+    """-> (d x [= d g], [8 L parameter-gradient returns: None where the sum went straight into the parameter's .grad])"""
+    saved, lens, cfg, params, (B, T, Cc) = state
+    k, L, p_drop, seed, site0 = cfg
+    rows, n = B * T, B * T * Cc
+    d = dy.contiguous().clone()
+    _lib.check(lib.xva_seq_mask(P(d), 0, B, T, 0, Cc, P(lens), ST()), "xva_seq_mask")
+    rets = [None] * (8 * L)
+    for i in reversed(range(L)):
+        cur, wsc, t1, m1, r1, g1, n1, a1, w2, t2, m2, r2, g2, n2 = saved[i]
+        ws, bs, w1, b1, _, be1, _, be2 = params[8 * i:8 * i + 8]
+        if p_drop > 0:
+            da2 = torch.empty_like(d)
+            _lib.check(lib.xva_dropout_apply(P(d), P(da2), 0, n, p_drop, seed, site0 + i, ST()), "xva_dropout_apply")
+        else:
+            da2 = d
+        dn2 = torch.empty_like(d)
+        _lib.check(lib.xva_gelu_bwd(P(n2), P(da2), P(dn2), n, ST()), "xva_gelu_bwd")
+        dt2 = torch.empty_like(d)
+        (dg2, rg2), (db2, rb2) = _gbuf(g2), _gbuf(be2)
+        _lib.check(lib.xva_ln_rows_bwd(P(dn2), P(t2), P(m2), P(r2), P(g2), P(dt2), P(dg2), P(db2), rows, Cc, ST()), "xva_ln_rows_bwd")
+        da1 = torch.empty_like(d)
+        _prep((1, rows, Cc, Cc), lambda: _lib.PreparedGemm(dt2, w2, da1, rows, Cc, Cc, Cc, Cc, Cc, layout=_lib.GEMM_NN, compute=0)).run(dt2, w2, da1)
+        (dw1, rw1), (dbb1, rb1) = _gbuf(w1), _gbuf(b1)
+        _prep((2, rows, Cc, Cc), lambda: _lib.PreparedGemm(dt2, a1, dw1, Cc, Cc, rows, Cc, Cc, Cc, layout=_lib.GEMM_TN, compute=0, accumulate=True,
+                                                            splitk=0)).run(dt2, a1, dw1)
+        _lib.check(lib.xva_hg_colsum(P(dt2), 0, P(dbb1), rows, Cc, 1.0, ST()), "xva_hg_colsum")
+        dn1 = torch.empty_like(d)
+        _lib.check(lib.xva_gelu_bwd(P(n1), P(da1), P(dn1), n, ST()), "xva_gelu_bwd")
+        dt1 = torch.empty_like(d)
+        (dg1, rg1), (db1, rbe1) = _gbuf(g1), _gbuf(be1)
+        _lib.check(lib.xva_ln_rows_bwd(P(dn1), P(t1), P(m1), P(r1), P(g1), P(dt1), P(dg1), P(db1), rows, Cc, ST()), "xva_ln_rows_bwd")
+        dxb = torch.empty_like(d)
+        (dws, rws), (dbs, rbs) = _gbuf(ws), _gbuf(bs)
+        _lib.check(lib.xva_dwconv_bwd(P(dt1), P(cur), P(wsc), P(dxb), P(dws), P(dbs), P(lens), B, T, Cc, k, k ** i, ST()), "xva_dwconv_bwd")
+        _lib.check(lib.xva_fp_add_act(P(dxb), P(d), 0, n, ST()), "xva_fp_add_act")             # d(x) = d(residual) + d(branch)
+        d = dxb
+        rets[8 * i:8 * i + 8] = [rws, rbs, (rw1.view(w1.shape) if rw1 is not None else None), rb1, rg1, rbe1, rg2, rb2]
+    return d, rets
+
+
 class DDSStack(torch.autograd.Function):
-    """DilatedDepthSeparableConv.forward (sdp.py:70-93) as ONE autograd node: the same kernels in the same order as the per-primitive composition
-    (DwConv -> LayerNormRows -> Gelu -> Conv1x1 -> LayerNormRows -> Gelu -> [Dropout] -> + x, L times, then the mask), issued back to back from one
-    forward / one backward instead of through 8 L + 2 autograd nodes — the duration predictor runs ten of these stacks per iteration on (16 x 100 x 192)
-    tensors and was bound by the host's per-node cost, not by the kernels.  Residual adds and the mask run in place on tensors the
-    node owns (no clone launches).  Inputs: x (B, T, C), g (B, T, C) or None, lens, cfg = (k, L, p_drop, seed, site0), then 8 parameters per layer
-    (convs_sep w, b; convs_1x1 w, b; norms_1 gamma, beta; norms_2 gamma, beta)."""
+    """DilatedDepthSeparableConv.forward (sdp.py:70-93) as ONE autograd node: the same kernels in the same order as the per-primitive composition, issued
+    back to back from one forward / one backward instead of through 8 L + 2 autograd nodes — the duration predictor runs ten of these stacks per
+    iteration on (16 x 100 x 192) tensors and was bound by the host's per-node cost, not by the kernels.  Inputs: x (B, T, C), g (B, T,
+    C) or None, lens, cfg = (k, L, p_drop, seed, site0), then 8 parameters per layer (convs_sep w, b; convs_1x1 w, b; norms_1 gamma, beta; norms_2
+    gamma, beta)."""
 
     @staticmethod
     def forward(ctx, x, g, lens, cfg, *params):
-        k, L, p_drop, seed, site0 = cfg
-        x = x.contiguous(); B, T, Cc = x.shape
-        rows, n = B * T, x.numel()
-        dev = x.device
-        if g is not None:
-            cur = torch.add(x, g)
-        else:
-            cur = x
-        saved = []
-        for i in range(L):
-            ws, bs, w1, b1, g1, be1, g2, be2 = params[8 * i:8 * i + 8]
-            wsc = ws.contiguous()
-            t1 = torch.empty_like(cur)
-            _lib.check(lib.xva_dwconv_fwd(P(cur), P(wsc), P(bs), P(t1), P(lens), B, T, Cc, k, k ** i, ST()), "xva_dwconv_fwd")
-            n1 = torch.empty_like(cur); m1 = torch.empty(rows, device=dev); r1 = torch.empty(rows, device=dev)
-            _lib.check(lib.xva_ln_rows_fwd(P(t1), P(g1), P(be1), P(n1), P(m1), P(r1), rows, Cc, 1e-5, ST()), "xva_ln_rows_fwd")
-            a1 = torch.empty_like(cur)
-            _lib.check(lib.xva_gelu_fwd(P(n1), P(a1), n, ST()), "xva_gelu_fwd")
-            w2 = w1.reshape(Cc, Cc).contiguous()
-            t2 = torch.empty_like(cur)
-            _prep((0, rows, Cc, Cc, True), lambda: _lib.PreparedGemm(a1, w2, t2, rows, Cc, Cc, Cc, Cc, Cc, layout=_lib.GEMM_NT, compute=0, bias=b1)).run(a1, w2, t2, bias=b1)
-            n2 = torch.empty_like(cur); m2 = torch.empty(rows, device=dev); r2 = torch.empty(rows, device=dev)
-            _lib.check(lib.xva_ln_rows_fwd(P(t2), P(g2), P(be2), P(n2), P(m2), P(r2), rows, Cc, 1e-5, ST()), "xva_ln_rows_fwd")
-            a2 = torch.empty_like(cur)
-            _lib.check(lib.xva_gelu_fwd(P(n2), P(a2), n, ST()), "xva_gelu_fwd")
-            if p_drop > 0:
-                nxt = torch.empty_like(cur)
-                _lib.check(lib.xva_dropout_apply(P(a2), P(nxt), 0, n, p_drop, seed, site0 + i, ST()), "xva_dropout_apply")
-            else:
-                nxt = a2
-            _lib.check(lib.xva_fp_add_act(P(nxt), P(cur), 0, n, ST()), "xva_fp_add_act")          # x = x + y, in place on the branch's own tensor
-            saved.append((cur, wsc, t1, m1, r1, g1, n1, a1, w2, t2, m2, r2, g2, n2))
-            cur = nxt
-        if L == 0 and g is None:
-            cur = cur.clone()
-        _lib.check(lib.xva_seq_mask(P(cur), 0, B, T, 0, Cc, P(lens), ST()), "xva_seq_mask")
-        ctx.saved, ctx.lens, ctx.cfg, ctx.params, ctx.has_g, ctx.dims = saved, lens, cfg, params, g is not None, (B, T, Cc)
-        return cur
+        out, ctx.state = _dds_fwd(x, g, lens, cfg, params)
+        ctx.has_g = g is not None
+        return out
 
     @staticmethod
     def backward(ctx, dy):
-        k, L, p_drop, seed, site0 = ctx.cfg
-        B, T, Cc = ctx.dims
-        rows, n, lens, params = B * T, B * T * Cc, ctx.lens, ctx.params
-        d = dy.contiguous().clone()
-        _lib.check(lib.xva_seq_mask(P(d), 0, B, T, 0, Cc, P(lens), ST()), "xva_seq_mask")
-        rets = [None] * (8 * L)
-        for i in reversed(range(L)):
-            cur, wsc, t1, m1, r1, g1, n1, a1, w2, t2, m2, r2, g2, n2 = ctx.saved[i]
-            ws, bs, w1, b1, _, be1, _, be2 = params[8 * i:8 * i + 8]
-            if p_drop > 0:
-                da2 = torch.empty_like(d)
-                _lib.check(lib.xva_dropout_apply(P(d), P(da2), 0, n, p_drop, seed, site0 + i, ST()), "xva_dropout_apply")
-            else:
-                da2 = d
-            dn2 = torch.empty_like(d)
-            _lib.check(lib.xva_gelu_bwd(P(n2), P(da2), P(dn2), n, ST()), "xva_gelu_bwd")
-            dt2 = torch.empty_like(d)
-            (dg2, rg2), (db2, rb2) = _gbuf(g2), _gbuf(be2)
-            _lib.check(lib.xva_ln_rows_bwd(P(dn2), P(t2), P(m2), P(r2), P(g2), P(dt2), P(dg2), P(db2), rows, Cc, ST()), "xva_ln_rows_bwd")
-            da1 = torch.empty_like(d)
-            _prep((1, rows, Cc, Cc), lambda: _lib.PreparedGemm(dt2, w2, da1, rows, Cc, Cc, Cc, Cc, Cc, layout=_lib.GEMM_NN, compute=0)).run(dt2, w2, da1)
-            (dw1, rw1), (dbb1, rb1) = _gbuf(w1), _gbuf(b1)
-            _prep((2, rows, Cc, Cc), lambda: _lib.PreparedGemm(dt2, a1, dw1, Cc, Cc, rows, Cc, Cc, Cc, layout=_lib.GEMM_TN, compute=0, accumulate=True,
-                                                                splitk=0)).run(dt2, a1, dw1)
-            _lib.check(lib.xva_hg_colsum(P(dt2), 0, P(dbb1), rows, Cc, 1.0, ST()), "xva_hg_colsum")
-            dn1 = torch.empty_like(d)
-            _lib.check(lib.xva_gelu_bwd(P(n1), P(da1), P(dn1), n, ST()), "xva_gelu_bwd")
-            dt1 = torch.empty_like(d)
-            (dg1, rg1), (db1, rbe1) = _gbuf(g1), _gbuf(be1)
-            _lib.check(lib.xva_ln_rows_bwd(P(dn1), P(t1), P(m1), P(r1), P(g1), P(dt1), P(dg1), P(db1), rows, Cc, ST()), "xva_ln_rows_bwd")
-            dxb = torch.empty_like(d)
-            (dws, rws), (dbs, rbs) = _gbuf(ws), _gbuf(bs)
-            _lib.check(lib.xva_dwconv_bwd(P(dt1), P(cur), P(wsc), P(dxb), P(dws), P(dbs), P(lens), B, T, Cc, k, k ** i, ST()), "xva_dwconv_bwd")
-            _lib.check(lib.xva_fp_add_act(P(dxb), P(d), 0, n, ST()), "xva_fp_add_act")             # d(x) = d(residual) + d(branch)
-            d = dxb
-            rets[8 * i:8 * i + 8] = [rws, rbs, (rw1.view(w1.shape) if rw1 is not None else None), rb1, rg1, rbe1, rg2, rb2]
+        d, rets = _dds_bwd(ctx.state, dy)
         return (d, d if ctx.has_g else None, None, None) + tuple(rets)
+
+
+class ConvFlowFn(torch.autograd.Function):
+    """ConvFlow.forward (sdp.py:147-176, the training direction) as ONE autograd node: x0 -> pre (Conv1d(1, H, 1): an outer product) -> the DDS stack conditioned
+    on g -> proj (H -> 3K - 1, zero-padded to a multiple of 4 columns for the GEMM) -> mask -> rational-quadratic spline of x1 -> (stack, mask, per-item
+    log-determinant).  Inputs: z (B, T, 2), g (B, T, H), lens, cfg = (dds cfg, K, bound, module), pre w, b, proj w, b, then the stack's 8 L parameters."""
+
+    @staticmethod
+    def forward(ctx, z, g, lens, cfg, pre_w, pre_b, proj_w, proj_b, *params):
+        dds_cfg, K, bound, mod = cfg
+        B, T, _ = z.shape
+        H, NP = pre_b.numel(), 3 * K - 1
+        NPp = (NP + 3) // 4 * 4
+        rows = B * T
+        zt = z.permute(2, 0, 1).contiguous()                                       # (2, B, T): x0 = zt[0], x1 = zt[1], both contiguous
+        x0, x1 = zt[0], zt[1]
+        h = torch.addcmul(pre_b.view(1, 1, H), x0.unsqueeze(-1), pre_w.view(1, 1, H))
+        h2, dds_state = _dds_fwd(h, g, lens, dds_cfg, params)
+        wp, bp = mod._proj_pad(proj_w, proj_b, NP, NPp, H)                          # persistent zero-padded copies (two small copies, no fills / cats)
+        hp = torch.empty(B, T, NPp, device=z.device)
+        _prep((0, rows, H, NPp, True), lambda: _lib.PreparedGemm(h2, wp, hp, rows, NPp, H, H, H, NPp, layout=_lib.GEMM_NT, compute=0, bias=bp)).run(h2, wp, hp, bias=bp)
+        _lib.check(lib.xva_seq_mask(P(hp), 0, B, T, 0, NPp, P(lens), ST()), "xva_seq_mask")
+        hs = hp[..., :NP].contiguous()
+        y1 = torch.empty_like(x1); ld = torch.empty_like(x1)
+        _lib.check(lib.xva_rq_spline_fwd(P(x1), P(hs), P(y1), P(ld), x1.numel(), K, 1.0 / H ** 0.5, bound, ST()), "xva_rq_spline_fwd")
+        out = torch.stack([x0, y1], -1)
+        _lib.check(lib.xva_seq_mask(P(out), 0, B, T, 0, 2, P(lens), ST()), "xva_seq_mask")
+        _lib.check(lib.xva_seq_mask(P(ld), 0, B, T, 0, 1, P(lens), ST()), "xva_seq_mask")
+        ctx.state = (dds_state, x0, x1, h2, wp, hs, lens, (B, T, H, K, NP, NPp, bound), (pre_w, pre_b, proj_w, proj_b))
+        return out, ld.sum(1)
+
+    @staticmethod
+    def backward(ctx, d_out, d_logdet):
+        dds_state, x0, x1, h2, wp, hs, lens, (B, T, H, K, NP, NPp, bound), (pre_w, pre_b, proj_w, proj_b) = ctx.state
+        rows = B * T
+        dev = x0.device
+        dm = d_out.permute(2, 0, 1).contiguous()                                    # (2, B, T)
+        _lib.check(lib.xva_seq_mask(P(dm), 0, 2 * B, T, 0, 1, P(torch.cat([lens, lens])), ST()), "xva_seq_mask")
+        d_ld = d_logdet.reshape(B, 1).expand(B, T).contiguous()
+        _lib.check(lib.xva_seq_mask(P(d_ld), 0, B, T, 0, 1, P(lens), ST()), "xva_seq_mask")
+        dx1 = torch.empty_like(x1); dhs = torch.empty_like(hs)
+        _lib.check(lib.xva_rq_spline_bwd(P(x1), P(hs), P(dm[1]), P(d_ld), P(dx1), P(dhs), x1.numel(), K, 1.0 / H ** 0.5, bound, ST()), "xva_rq_spline_bwd")
+        dhp = torch.nn.functional.pad(dhs, (0, NPp - NP))
+        _lib.check(lib.xva_seq_mask(P(dhp), 0, B, T, 0, NPp, P(lens), ST()), "xva_seq_mask")
+        dh2 = torch.empty(B, T, H, device=dev)
+        _prep((1, rows, H, NPp), lambda: _lib.PreparedGemm(dhp, wp, dh2, rows, H, NPp, NPp, H, H, layout=_lib.GEMM_NN, compute=0)).run(dhp, wp, dh2)
+        dwp = torch.zeros(NPp, H, device=dev)
+        _prep((2, rows, H, NPp), lambda: _lib.PreparedGemm(dhp, h2, dwp, NPp, H, rows, NPp, H, H, layout=_lib.GEMM_TN, compute=0, accumulate=True,
+                                                           splitk=0)).run(dhp, h2, dwp)
+        dbp = torch.zeros(NPp, device=dev)
+        _lib.check(lib.xva_hg_colsum(P(dhp), 0, P(dbp), rows, NPp, 1.0, ST()), "xva_hg_colsum")
+        dh, rets = _dds_bwd(dds_state, dh2)                                         # d(pre output) = d(conditioning g)
+        d_x0 = (dh * pre_w.view(1, 1, H)).sum(-1) + dm[0]
+        d_pre_w = (dh * x0.unsqueeze(-1)).sum((0, 1)).view(pre_w.shape)
+        d_pre_b = dh.sum((0, 1))
+        dz = torch.stack([d_x0, dx1], -1)
+        return (dz, dh, None, None, d_pre_w, d_pre_b, dwp[:NP].reshape(proj_w.shape), dbp[:NP]) + tuple(rets)
 
 
 class DilatedDepthSeparableConv:
@@ -427,9 +493,28 @@ class ConvFlow(_Module):
         for k, v in self.convs.p.items():
             self.p["convs." + k] = v
 
+    def _proj_pad(self, proj_w, proj_b, NP, NPp, H):
+        """proj's weight / bias zero-padded to NPp output columns in buffers that live with the module (the pad rows are written once)"""
+        buf = getattr(self, "_projp", None)
+        if buf is None or buf[0].device != proj_w.device:
+            buf = self._projp = (torch.zeros(NPp, H, device=proj_w.device), torch.zeros(NPp, device=proj_w.device))
+        with torch.no_grad():
+            buf[0][:NP].copy_(proj_w.detach().reshape(NP, H))
+            buf[1][:NP].copy_(proj_b.detach())
+        return buf
+
     def forward_btc(self, z, lens, g=None, reverse=False):
         """z (B, T, 2), g (B, T, H) -> (B, T, 2), logdet (B) ; reverse=True: the inverse map, (B, T, 2) only"""
         p, H, NP = self.p, self.H, 3 * self.K - 1
+        if _FUSED_DDS and not reverse and g is not None:
+            c = self.convs
+            ps = []
+            for i in range(c.L):
+                ps += [c.p["convs_sep.%d.weight" % i], c.p["convs_sep.%d.bias" % i], c.p["convs_1x1.%d.weight" % i], c.p["convs_1x1.%d.bias" % i],
+                       c.p["norms_1.%d.gamma" % i], c.p["norms_1.%d.beta" % i], c.p["norms_2.%d.gamma" % i], c.p["norms_2.%d.beta" % i]]
+            drop = c.dropout_p if c.training else 0.0
+            cfg = ((c.k, c.L, float(drop), int(c.drop_seed), int(c.site0)), self.K, self.bound, self)
+            return ConvFlowFn.apply(z, g, lens, cfg, p["pre.weight"], p["pre.bias"], p["proj.weight"], p["proj.bias"], *ps)
         x0, x1 = z[..., 0:1], z[..., 1]
         # pre: Conv1d(1, H, 1) and proj: Conv1d(H, 3K - 1, 1) ride in GEMMs whose narrow dimension is zero-padded to a multiple of 4
         x0p = torch.cat([x0, torch.zeros(*x0.shape[:-1], 3, device=z.device)], -1)
