@@ -282,7 +282,9 @@ class RelativePositionTransformer:
                 dy2 = mk(Co); dy2.store.copy_(ds2.store); _mask(dy2, lens)                       # y2 = dropout(conv_2(..) * x_mask)
                 if pd > 0:
                     _drop(dy2, dy2, pd, seed, site + 3)
-                dW2 = torch.zeros(Co, k * F, device=self.device)
+                # one zero fill for the layer's tap-major / concatenated weight-gradient scratch (dW2 | dW1 | dWqkv | dbqkv) instead of one per tensor
+                scr = torch.zeros(Co * k * F + F * k * Cc + 3 * Cc * Cc + 3 * Cc, device=self.device)
+                dW2 = scr[:Co * k * F].view(Co, k * F)
                 conv_bwd_weight(dy2, h, dW2, g["ffn.conv_2.bias"], k, 1, self.cmp)
                 g["ffn.conv_2.weight"] += dW2.view(Co, k, F).permute(0, 2, 1)
                 dh = mk(F)
@@ -291,7 +293,7 @@ class RelativePositionTransformer:
                 _lib.gemm(dy2.store, w2, dh.store, dy2.rows, F, k * Co, Co, k * F, F, layout=_lib.GEMM_NN, compute=self.cmp, a_offset=dy2.off(P_), c_offset=dh.off(),
                           a_seglen=Co if k > 1 else 0, a_segadj=-2 * Co if k > 1 else 0, seglen=Co if k > 1 else 0, seg0=0, segstride=F if k > 1 else 0,
                           G=h.view, ldg=F, gate_slope=0.0, mask_mode=_lib.MASK_PAD, Tp=dy2.Tp, mask_pad=PAD, mask_len=T, **dkw(2))
-                dW1 = torch.zeros(F, k * Cc, device=self.device)
+                dW1 = scr[Co * k * F:Co * k * F + F * k * Cc].view(F, k * Cc)
                 conv_bwd_weight(dh, x1m, dW1, g["ffn.conv_1.bias"], k, 1, self.cmp)
                 g["ffn.conv_1.weight"] += dW1.view(F, k, Cc).permute(0, 2, 1)
                 dx1m = mk(Cc)
@@ -306,9 +308,7 @@ class RelativePositionTransformer:
             dyo = ds1                                                                            # s1 = x + dropout(conv_o(att))
             if pd > 0:
                 dyo = mk(Cc); _drop(ds1, dyo, pd, seed, site + 1)
-            dWo = torch.zeros(Cc, Cc, device=self.device)
-            conv_bwd_weight(dyo, att, dWo, g["attn.conv_o.bias"], 1, 1, self.cmp)
-            g["attn.conv_o.weight"] += dWo.view(Cc, Cc, 1)
+            conv_bwd_weight(dyo, att, g["attn.conv_o.weight"].view(Cc, Cc), g["attn.conv_o.bias"], 1, 1, self.cmp)   # a 1x1 conv: the gradient buffer IS the GEMM's C
             datt = mk(Cc)
             conv_bwd_data(dyo, wo, datt, 1, 1, self.cmp, False)
             dqkv = mk(3 * Cc)
@@ -318,11 +318,12 @@ class RelativePositionTransformer:
                                            _lib.ptr(p["attn.emb_rel_v"]), _lib.ptr(lens), _lib.ptr(P), _lib.ptr(dS), _p(dqkv.view), _p(dqkv.view, Cc),
                                            _p(dqkv.view, 2 * Cc), 3 * Cc, _lib.ptr(demb_k), _lib.ptr(demb_v), B, T, H, dk, self.w, 1, dx.Tp, PAD,
                                            pd, seed, site, _lib.stream_ptr()), "xva_relattn_bwd")
-            dWqkv = torch.zeros(3 * Cc, Cc, device=self.device); dbqkv = torch.zeros(3 * Cc, device=self.device)
+            if last and Co == 1:
+                scr = torch.zeros(3 * Cc * Cc + 3 * Cc, device=self.device)
+            dWqkv = scr[scr.numel() - 3 * Cc * Cc - 3 * Cc:scr.numel() - 3 * Cc].view(3 * Cc, Cc); dbqkv = scr[scr.numel() - 3 * Cc:]
             conv_bwd_weight(dqkv, xm, dWqkv, dbqkv, 1, 1, self.cmp)
-            for j, n in enumerate("qkv"):
-                g["attn.conv_%s.weight" % n] += dWqkv[j * Cc:(j + 1) * Cc].view(Cc, Cc, 1)
-                g["attn.conv_%s.bias" % n] += dbqkv[j * Cc:(j + 1) * Cc]
+            torch._foreach_add_([g["attn.conv_%s.weight" % n] for n in "qkv"] + [g["attn.conv_%s.bias" % n] for n in "qkv"],
+                                [dWqkv[j * Cc:(j + 1) * Cc].view(Cc, Cc, 1) for j in range(3)] + [dbqkv[j * Cc:(j + 1) * Cc] for j in range(3)])   # one launch for the six
             dxm = mk(Cc)
             conv_bwd_data(dqkv, wqkv, dxm, 1, 1, self.cmp, False)
             dxm.store += ds1.store                                                               # residual x + y
