@@ -153,6 +153,46 @@ def test_rand_segments_draws_inside_the_clips():
         assert torch.equal(seg[i], x[i, :, int(idx[i]):int(idx[i]) + 32])
 
 
+def test_rand_segments_draws_what_the_reference_draws_and_defers_the_short_clip_check():
+    """util.py:165-178: `(torch.rand([B]).type_as(x) * max_idxs).long()` from the CPU generator; a clip shorter than the segment is an AssertionError —
+    raised here when the iteration's values are next read (ops.raise_deferred), with the start clamped so that the gather stays inside the tensor."""
+    from xva_trainer_amd.xvapitch import ops
+    ops.raise_deferred()
+    x = torch.randn(4, 3, 50).cuda()
+    lens = torch.tensor([50, 32, 40, 33], device="cuda")
+    torch.manual_seed(7)
+    _, idx = ops.rand_segments(x, lens, segment_size=32)
+    torch.manual_seed(7)
+    want = (torch.rand([4]) * (lens.cpu() - 32 + 1)).long()
+    assert torch.equal(idx.cpu(), want)
+    flags = ops.deferred_flags(x.device).cpu()
+    assert flags.tolist() == [0.0]
+    ops.raise_deferred(flags)                              # nothing set, list emptied
+    assert not ops.DEFERRED_CHECKS
+    seg, idx = ops.rand_segments(x, torch.tensor([50, 31, 40, 33], device="cuda"), segment_size=32)
+    assert seg.shape == (4, 3, 32) and int(idx[1]) == 0
+    with pytest.raises(AssertionError, match="shorter than the segment size"):
+        ops.raise_deferred()
+    assert not ops.DEFERRED_CHECKS
+
+
+def test_kl_loss_backward_takes_the_upstream_gradient_from_the_device():
+    """The loss weight (x upstream gradient) reaches xva_kl_loss_bwd without a host round trip; gradients against autograd on the formula."""
+    from xva_trainer_amd.xvapitch import ops
+    torch.manual_seed(1)
+    B, H, T = 3, 8, 37
+    t = [torch.randn(B, H, T, device="cuda").requires_grad_(True) for _ in range(4)]
+    mask = (torch.arange(T, device="cuda")[None, None, :] < torch.tensor([37, 20, 5], device="cuda")[:, None, None]).float()
+    l, _ = ops.kl_loss(t[0], t[1], t[2], t[3], mask)
+    (l * 2.5).backward()
+    got = [a.grad.clone() for a in t]
+    r = [a.detach().clone().requires_grad_(True) for a in t]
+    kl = r[3] - r[1] - 0.5 + 0.5 * (r[0] - r[2]) ** 2 * torch.exp(-2.0 * r[3])
+    ((kl * mask).sum() / mask.sum() * 2.5).backward()
+    for a, b in zip(got, r):
+        assert torch.allclose(a, b.grad, rtol=1e-5, atol=1e-7)
+
+
 def test_posterior_encoder_against_reference_golden(golden_dir):
     """PosteriorEncoder (model.py:1427-1475): conv1x1 -> conditioned WN -> conv1x1 -> z = (m + eps * exp(logs)) * mask with the reference's own
     N(0, 1) draw; z / m / logs and every gradient of a scalar over all three outputs."""

@@ -19,6 +19,7 @@ Every matrix product, convolution, normalisation, spline, MAS and KL step is a l
 transformer.py / sdp.py / ops.py, plus the two batched GEMM forms below); torch supplies the embedding gathers, the speaker-vector
 normalisation, concatenations / transposes and the elementwise preparation of the MAS operands."""
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -82,6 +83,35 @@ class _Expand(torch.autograd.Function):
         return d_stats, None
 
 
+def _cross(stream, *tensors):
+    """Tensors that were allocated on one stream and are about to be read on `stream`: tell the caching allocator, so that a block freed while that
+    stream's reader is still queued is not handed out again before it has run."""
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(stream)
+
+
+class _JoinStreams(torch.autograd.Function):
+    """Identity on the loss.  Its backward is the first node of the backward pass: it queues the end-of-pass join — the modules' backward passes run on the
+    streams of their forward passes and most of them write their parameter gradients themselves (no AccumulateGrad the engine would wait for), so the
+    caller's stream waits for every one of those streams when backward() returns."""
+    @staticmethod
+    def forward(ctx, loss, streams):
+        ctx.streams = streams
+        return loss.view_as(loss)
+
+    @staticmethod
+    def backward(ctx, g):
+        streams = ctx.streams
+
+        def join():
+            cur = torch.cuda.current_stream()
+            for s in streams:
+                cur.wait_stream(s)
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+        return g, None
+
+
 class AcousticTrainPath:
     """Constructor arguments follow model.py:55-135 (defaults = the reference's non-`big` model).  compute: "fp32" = exact-fp32 products everywhere
     (the parity mode) ; "bf16" = the throughput mode: WaveNet stacks (posterior encoder, flow) bf16-stored with bf16 MFMA, the two transformers' projections
@@ -120,6 +150,17 @@ class AcousticTrainPath:
             self._subs.append(("pitch_predictor.encoder.", self.pitch_predictor))
             self.p["pitch_emb.weight"] = _param((torch.rand(Cc, 1, 3, generator=gen) * 2 - 1) * 3 ** -0.5, self.device)
             self.p["pitch_emb.bias"] = _param((torch.rand(Cc, generator=gen) * 2 - 1) * 3 ** -0.5, self.device)
+
+    def _streams(self, device):
+        """(text encoder, duration predictor, pitch predictor) streams; XVA_C5_STREAMS=0: the current stream three times (one code path, no concurrency)."""
+        cur = torch.cuda.current_stream(device)
+        if os.environ.get("XVA_C5_STREAMS", "1") == "0":
+            return cur, cur, cur
+        key = torch.device(device).index or 0
+        pool = self.__dict__.setdefault("_stream_pool", {})
+        if key not in pool:
+            pool[key] = tuple(torch.cuda.Stream(device) for _ in range(3))
+        return pool[key]
 
     # ---- dropout (nn.Module.train / eval; the masks' seed) ----
     def _droppers(self):
@@ -289,9 +330,10 @@ class AcousticTrainPath:
             self.train(was)
 
     # ---- model.py:681-870 ----
-    def __call__(self, tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps=None, noise=None, pitch_padded=None):
+    def __call__(self, tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps=None, noise=None, pitch_padded=None, after_posterior=None):
         """tokens (B, Tt) int64, y (B, spec_bins, Ty) linear spectrogram, d_vectors (B, d_vector_dim), language_ids (B,).  eps (B, C, Ty) / noise
         (B, 2, Tt): the N(0, 1) draws of the posterior encoder (model.py:1472) and the duration predictor (sdp.py:281), drawn here when None.
+        after_posterior(z): called as soon as the posterior latent has been enqueued (generator_pass.py: the vocoder branch).
         pitch_padded (B, 1, Ty): frame-level pitch (0 = unvoiced), required when built with pitch=True.
         Returns the tensors train_step hands to the loss plus `attn`, `loss_kl`, `loss_duration` (`loss_pitch`, `pitch_tgt`, `pitch_pred`), `loss`."""
         if self.pitch and pitch_padded is None:
@@ -306,40 +348,81 @@ class AcousticTrainPath:
         Ty = y.size(2)
         g = F.normalize(d_vectors.float()).unsqueeze(-1)                                                  # _set_cond_input, model.py:918
         lang = F.embedding(language_ids, p["emb_l.weight"])                                               # (B, L) :695-696
+        # Four streams (see _streams): the text encoder needs neither the recording nor z, the two predictors read x DETACHED (their backward passes touch
+        # nothing but their own parameters) — each is a chain of hundreds of small launches that leaves most of the device idle when it runs alone.
+        main = torch.cuda.current_stream(y.device)
+        s_text, s_dur, s_pitch = self._streams(y.device)
+        forked = s_text != main
+        ev_in = main.record_event() if forked else None
         z, m_q, logs_q, y_mask = self.posterior_encoder(y, y_lengths, g=g, eps=eps)                        # :698
-        x_emb = F.embedding(tokens, p["text_encoder.emb.weight"]) * math.sqrt(Cc)                          # :1152
-        x_in = torch.cat([x_emb, lang.unsqueeze(1).expand(B, Tt, L)], -1).transpose(1, 2)                  # :1158-1163
-        x_lens = x_lengths.to(device=y.device, dtype=torch.int32).contiguous()
-        x_mask = (torch.arange(Tt, device=y.device)[None, :] < x_lens[:, None]).float().unsqueeze(1)
-        x = self.encoder(x_in * x_mask, x_mask)                                                            # (B, C + L, Tt) :1166
-        stats = Mask.apply(Conv1x1.apply(x.transpose(1, 2).contiguous(), p["text_encoder.proj.weight"], p["text_encoder.proj.bias"]), x_lens)   # :1148
+        if after_posterior is not None:          # the waveform decoder needs nothing but z: GeneratorPass starts it here, next to the rest of this path
+            after_posterior(z)
+        if forked:
+            s_text.wait_event(ev_in)
+            _cross(s_text, tokens, x_lengths, lang, g, pitch_padded)
+        with torch.cuda.stream(s_text):
+            x_emb = F.embedding(tokens, p["text_encoder.emb.weight"]) * math.sqrt(Cc)                      # :1152
+            x_in = torch.cat([x_emb, lang.unsqueeze(1).expand(B, Tt, L)], -1).transpose(1, 2)              # :1158-1163
+            x_lens = x_lengths.to(device=y.device, dtype=torch.int32).contiguous()
+            x_mask = (torch.arange(Tt, device=y.device)[None, :] < x_lens[:, None]).float().unsqueeze(1)
+            x = self.encoder(x_in * x_mask, x_mask)                                                        # (B, C + L, Tt) :1166
+            stats = Mask.apply(Conv1x1.apply(x.transpose(1, 2).contiguous(), p["text_encoder.proj.weight"], p["text_encoder.proj.bias"]), x_lens)   # :1148
+        if self.pitch:
+            if forked:
+                s_pitch.wait_stream(s_text)
+                s_pitch.wait_event(ev_in)
+                _cross(s_pitch, x, x_mask, g)
+            with torch.cuda.stream(s_pitch):
+                pin = torch.cat([x.detach(), g.expand(B, self.Dv, Tt)], 1)                                 # :836, model.py:1338-1340
+                pitch_pred = self.pitch_predictor(pin * x_mask, x_mask)                                    # (B, 1, Tt)
         z_p = self.flow(z, y_mask, g=g)                                                                    # :723
         if self.pitch:                                                                                     # :752-755  z_p -= pitch_emb(pitch) * pe_scaling
             z_p = z_p - self._pitch_emb(pitch_padded) * self.pe_scaling
+        if forked:
+            main.wait_stream(s_text)
+            _cross(main, x, x_mask, x_lens, stats)
         with torch.no_grad():                                                                              # :763-776
             logp = prior_logp(stats.detach(), z_p.detach(), Cc)
             attn_mask = x_mask.squeeze(1).unsqueeze(-1) * y_mask.squeeze(1).unsqueeze(1)
             attn = ops.maximum_path(logp, attn_mask)
             attn_pad = F.pad(attn, (0, _pad4(Ty) - Ty)).contiguous()
         dr = attn.sum(2).unsqueeze(1)                                                                      # :792
-        nll = self.duration_predictor(x.detach(), x_mask, dr, g=g, lang_emb=lang.detach().unsqueeze(-1), noise=noise)     # :795-803, :722
-        loss_duration = (nll / x_mask.sum()).sum()                                                         # :814, losses.py:220
+        if forked:
+            s_dur.wait_stream(main)
+            _cross(s_dur, x, x_mask, dr, g, lang)
+        with torch.cuda.stream(s_dur):
+            nll = self.duration_predictor(x.detach(), x_mask, dr, g=g, lang_emb=lang.detach().unsqueeze(-1), noise=noise)     # :795-803, :722
+            loss_duration = (nll / x_mask.sum()).sum()                                                     # :814, losses.py:220
         ex = _Expand.apply(stats, attn_pad)[:, :Ty].transpose(1, 2)                                        # (B, 2C, Ty) :846-847
         m_p, logs_p = ex[:, :Cc].contiguous(), ex[:, Cc:].contiguous()
         loss_kl, _ = ops.kl_loss(z_p, logs_q, m_p, logs_p, y_mask)                                          # losses.py:213
-        out = {"z": z, "m_q": m_q, "logs_q": logs_q, "x": x, "x_mask": x_mask, "y_mask": y_mask, "z_p": z_p, "m_p": m_p, "logs_p": logs_p, "attn": attn,
-               "loss_kl": loss_kl, "loss_duration": loss_duration, "loss": loss_kl + loss_duration}
         if self.pitch:
-            with torch.no_grad():                                                                          # :817-829 (ceil of a 0 / 1 path sum = the sum)
-                durs = (dr.squeeze(1) * x_mask.squeeze(1)).ceil().to(torch.int32).contiguous()
-                tgt_pad = torch.empty(B, Tt + 2, device=y.device)                                         # the kernel writes FastPitch's padded token rows: [0 | Tt values | 0]
-                _lib.check(_lib.lib.xva_fp_avg_pitch(_lib.ptr(pitch_padded.float().reshape(B, Ty).contiguous()), _lib.ptr(durs), _lib.ptr(tgt_pad), B, Tt, Ty, 0,
-                                                     _lib.stream_ptr()), "xva_fp_avg_pitch")
-                pitch_tgt = tgt_pad[:, 1:Tt + 1].contiguous()
-            pin = torch.cat([x.detach(), g.expand(B, self.Dv, Tt)], 1)                                     # :836, model.py:1338-1340
-            pitch_pred = self.pitch_predictor(pin * x_mask, x_mask)                                        # (B, 1, Tt)
-            # losses.py:224-241: the reference's mask broadcast makes the "masked mean" the plain sum of squared errors; / B, x 0.1 (:55)
-            err = pitch_pred.reshape(B, Tt) - pitch_tgt
-            loss_pitch = (err * err).sum() / B * 0.1
-            out.update({"pitch_tgt": pitch_tgt.unsqueeze(1), "pitch_pred": pitch_pred, "loss_pitch": loss_pitch, "loss": out["loss"] + loss_pitch})
+            if forked:
+                s_pitch.wait_stream(main)
+                _cross(s_pitch, dr, pitch_padded)
+            with torch.cuda.stream(s_pitch):
+                with torch.no_grad():                                                                      # :817-829 (ceil of a 0 / 1 path sum = the sum)
+                    durs = (dr.squeeze(1) * x_mask.squeeze(1)).ceil().to(torch.int32).contiguous()
+                    tgt_pad = torch.empty(B, Tt + 2, device=y.device)                                     # the kernel writes FastPitch's padded token rows: [0 | Tt values | 0]
+                    _lib.check(_lib.lib.xva_fp_avg_pitch(_lib.ptr(pitch_padded.float().reshape(B, Ty).contiguous()), _lib.ptr(durs), _lib.ptr(tgt_pad), B, Tt, Ty, 0,
+                                                         _lib.stream_ptr()), "xva_fp_avg_pitch")
+                    pitch_tgt = tgt_pad[:, 1:Tt + 1].contiguous()
+                # losses.py:224-241: the reference's mask broadcast makes the "masked mean" the plain sum of squared errors; / B, x 0.1 (:55)
+                err = pitch_pred.reshape(B, Tt) - pitch_tgt
+                loss_pitch = (err * err).sum() / B * 0.1
+        if forked:
+            main.wait_stream(s_dur)
+            _cross(main, loss_duration)
+            if self.pitch:
+                main.wait_stream(s_pitch)
+                _cross(main, loss_pitch, pitch_tgt, pitch_pred)
+        loss = loss_kl + loss_duration
+        if self.pitch:
+            loss = loss + loss_pitch
+        if forked and loss.requires_grad:
+            loss = _JoinStreams.apply(loss, (s_text, s_dur, s_pitch))
+        out = {"z": z, "m_q": m_q, "logs_q": logs_q, "x": x, "x_mask": x_mask, "y_mask": y_mask, "z_p": z_p, "m_p": m_p, "logs_p": logs_p, "attn": attn,
+               "loss_kl": loss_kl, "loss_duration": loss_duration, "loss": loss}
+        if self.pitch:
+            out.update({"pitch_tgt": pitch_tgt.unsqueeze(1), "pitch_pred": pitch_pred, "loss_pitch": loss_pitch})
         return out

@@ -9,6 +9,8 @@ The discriminator-side terms (generator / feature loss :195-196, the VitsDiscrim
     out = gp(tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=...)
     out["loss"].backward()        # gradients: gp.acoustic.grads(), gp.decoder.grads()
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -33,11 +35,46 @@ class _MelL1(torch.autograd.Function):
         return (d_wav * g).view(ctx.shape), None, None, None
 
 
+class _JoinBranch(torch.autograd.Function):
+    """loss = (the acoustic path's terms) + (the vocoder branch's terms), where the branch hangs off a DETACHED copy of z (GeneratorPass.__call__).
+    backward: the branch's whole backward pass is issued first, on the branch's stream, from inside this node (a nested autograd call) — it is the
+    GPU-heavy, host-cheap half (two engine calls), so the device works through it while the host issues the acoustic modules' backward on the main
+    stream; d loss / d z of the branch joins the main graph in a hook on z (event wait + add) right before the posterior encoder's backward."""
+    @staticmethod
+    def forward(ctx, main_loss, branch_value, state):
+        ctx.state = state
+        return main_loss + branch_value
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.state
+        side, cur = st["stream"], torch.cuda.current_stream()
+        side.wait_stream(cur)                                   # g
+        g.record_stream(side)
+        with torch.cuda.stream(side):                           # the caller's stream of the nested pass = the branch's: no join at its end
+            torch.autograd.backward(st["loss"], g)
+        st["event"] = side.record_event()
+        st["loss"] = None
+        if side != cur:                                         # whatever happens to z's hook, backward() returns with the branch joined
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream().wait_event(st["event"]))
+        return g, None, None
+
+
 class GeneratorPass:
     def __init__(self, acoustic, decoder, spec_segment_size=32, mel_loss_alpha=45.0):
         self.acoustic, self.decoder = acoustic, decoder
         self.S, self.alpha = int(spec_segment_size), float(mel_loss_alpha)                 # model.py:77, losses.py:27
         self.stft = xmel.TorchSTFTMel(1024, 256, 1024, sample_rate=22050, mel_fmin=0.0, mel_fmax=8000.0, n_mels=80)    # losses.py:29-46
+        self._side = {}
+
+    def branch_stream(self, device):
+        """The vocoder branch's stream (XVA_C5_BRANCH_STREAM=0: the current one — same code path, no concurrency)."""
+        if os.environ.get("XVA_C5_BRANCH_STREAM", "1") == "0":
+            return torch.cuda.current_stream(device)
+        key = torch.device(device).index or 0
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device)
+        return self._side[key]
 
     def zero_grad(self):
         self.acoustic.zero_grad()
@@ -52,20 +89,59 @@ class GeneratorPass:
         waveform = F.pad(wavs.float(), (0, Ty * 256 - wavs.size(1))).unsqueeze(1)
         return y, y_lengths, waveform
 
-    def __call__(self, tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=None, eps=None, noise=None, slice_ids=None):
-        """waveform (B, 1, Ty * 256).  slice_ids (B,): the segment starts (drawn like the reference's rand_segments when None)."""
-        out = self.acoustic(tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps=eps, noise=noise, pitch_padded=pitch_padded)
-        g = F.normalize(d_vectors.float()).unsqueeze(-1)
+    def __call__(self, tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=None, eps=None, noise=None, slice_ids=None, tail=None):
+        """waveform (B, 1, Ty * 256).  slice_ids (B,): the segment starts (drawn like the reference's rand_segments when None).
+        tail(model_outputs, waveform_seg) -> {name: loss}: further terms on the decoder's output (train_step: the adversarial ones), run inside the branch.
+
+        Two streams.  Everything after the posterior encoder splits into two independent halves: the vocoder branch (segment of z -> waveform decoder ->
+        mel / adversarial terms: a few engine calls, ~40 % of the iteration's device time, almost no host time) and the rest of the acoustic path (text
+        encoder, flow, alignment, duration / pitch predictors, KL: thousands of small launches, host-bound).  On one stream the device idles through the
+        second while the first waits its turn; here the branch runs on its own stream from the moment z exists, forward and backward (_JoinBranch)."""
+        dev = y.device
+        main, side = torch.cuda.current_stream(dev), self.branch_stream(dev)
+        st = {"stream": side}
         S = self.S
-        if slice_ids is None:
-            z_slice, slice_ids = ops.rand_segments(out["z"], y_lengths.to(out["z"].device), S)             # :850
+
+        def branch(z):
+            side.wait_stream(main)
+            zb = z.detach().requires_grad_(z.requires_grad)
+            for t in (z, waveform, d_vectors, y_lengths) + ((slice_ids,) if slice_ids is not None else ()):
+                if t.is_cuda:
+                    t.record_stream(side)
+            with torch.cuda.stream(side):
+                g = F.normalize(d_vectors.float()).unsqueeze(-1)
+                if slice_ids is None:
+                    z_slice, ids = ops.rand_segments(zb, y_lengths.to(zb.device), S)                          # :850
+                else:
+                    z_slice, ids = ops.segment(zb, slice_ids, S), slice_ids
+                o = self.decoder(z_slice, g)                                                                  # :852
+                wav_seg = ops.segment(waveform.float(), ids * 256, S * 256)                                   # :856-860
+                with torch.no_grad():
+                    mel_tgt = self.stft(wav_seg)
+                terms = {"loss_mel": _MelL1.apply(o, mel_tgt, self.stft, self.alpha)}                         # losses.py:187-193
+                if tail is not None:
+                    terms.update(tail(o, wav_seg))
+                total = sum(terms.values())
+            st.update(zb=zb, loss=total, terms=terms, o=o, wav_seg=wav_seg, ids=ids, z_slice=z_slice)
+
+        out = self.acoustic(tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps=eps, noise=noise, pitch_padded=pitch_padded, after_posterior=branch)
+        main.wait_stream(side)                                   # the caller reads the branch's tensors on its own stream
+        for t in [st["o"], st["wav_seg"], st["ids"], st["z_slice"], st["loss"]] + list(st["terms"].values()):
+            t.record_stream(main)
+        zb = st["zb"]
+        if zb.requires_grad:
+            def join(gz):                                        # d loss / d z = the flow's + the branch's
+                cur = torch.cuda.current_stream()
+                if st.get("event") is None or zb.grad is None:
+                    return gz
+                cur.wait_event(st["event"])
+                zb.grad.record_stream(cur)
+                return gz + zb.grad
+            out["z"].register_hook(join)
+            loss = _JoinBranch.apply(out["loss"], st["loss"].detach(), st)
         else:
-            z_slice = ops.segment(out["z"], slice_ids, S)
-        o = self.decoder(z_slice, g)                                                                      # :852
-        wav_seg = ops.segment(waveform.float(), slice_ids * 256, S * 256)                                 # :856-860
-        with torch.no_grad():
-            mel_tgt = self.stft(wav_seg)
-        loss_mel = _MelL1.apply(o, mel_tgt, self.stft, self.alpha)                                        # losses.py:187-193
-        out.update({"model_outputs": o, "waveform_seg": wav_seg, "slice_ids": slice_ids, "loss_mel": loss_mel, "loss": out["loss"] + loss_mel,
-                    "z_slice": z_slice})                          # the decoder's input: its gradient marks the end of the decoder's backward (BucketedSync.attach)
+            loss = out["loss"] + st["loss"]
+        out.update(st["terms"])
+        out.update({"model_outputs": st["o"], "waveform_seg": st["wav_seg"], "slice_ids": st["ids"], "loss": loss,
+                    "z_slice": st["z_slice"]})                    # the decoder's input: its gradient marks the end of the decoder's backward (BucketedSync.attach)
         return out

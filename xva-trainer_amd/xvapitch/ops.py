@@ -74,14 +74,44 @@ def segment(x, segment_indices, segment_size=4):
     return _Segment.apply(x, segment_indices, int(segment_size))
 
 
+DEFERRED_CHECKS = []          # (device bool scalar, message): conditions of this iteration that nobody has read yet — see raise_deferred()
+
+
+def raise_deferred(values=None):
+    """The reference asserts `(max_idxs > 0).all()` in the middle of the forward pass (util.py:165-178), which on a device tensor drains the queue.  Here
+    the condition stays on the device (the start index is clamped, so the gather stays inside the tensor either way) and whoever next moves values to the
+    host anyway — the trainer's one loss transfer per iteration — reads it with them: `flags()` gives the pending conditions as a float vector to append
+    to that transfer, `raise_deferred(host values)` raises the first one that is set.  Called without arguments it reads them itself (one sync)."""
+    pending, DEFERRED_CHECKS[:] = list(DEFERRED_CHECKS), []
+    if not pending:
+        return
+    if values is None:
+        values = torch.stack([c.float() for c, _ in pending]).cpu()
+    for v, (_, msg) in zip(values.tolist(), pending):
+        if v:
+            raise AssertionError(msg)
+
+
+def deferred_flags(device):
+    """The pending conditions as a float vector (empty when there are none); pass its host copy to raise_deferred()."""
+    if not DEFERRED_CHECKS:
+        return torch.zeros(0, device=device)
+    return torch.stack([c.float().reshape(()) for c, _ in DEFERRED_CHECKS])
+
+
 def rand_segments(x, x_lengths=None, segment_size=4):
-    """Random per-item start indices (torch.rand on x's device, as the reference draws them) + the device gather."""
+    """Random per-item start indices (torch.rand from the CPU generator, as the reference draws them: `torch.rand([B]).type_as(x)`) + the device gather.
+    No host round trip: the draw travels through pinned memory without waiting for the stream, the too-short check is deferred (raise_deferred)."""
     B, _, T = x.size()
     if x_lengths is None:
         x_lengths = torch.full((B,), T, device=x.device)
     max_idxs = x_lengths - segment_size + 1
-    assert bool((max_idxs > 0).all()), " [!] At least one sample is shorter than the segment size."
-    segment_indices = (torch.rand([B]).type_as(x) * max_idxs).long()
+    if len(DEFERRED_CHECKS) > 64:           # a caller that never reads them (a forward-only script): read now rather than grow without bound
+        raise_deferred()
+    DEFERRED_CHECKS.append(((max_idxs <= 0).any(), " [!] At least one sample is shorter than the segment size."))
+    u = torch.rand([B])
+    u = (u.pin_memory() if x.is_cuda else u).to(device=x.device, dtype=x.dtype, non_blocking=True)
+    segment_indices = (u * max_idxs.clamp_min(1)).long()
     return segment(x, segment_indices, segment_size), segment_indices
 
 
@@ -105,7 +135,10 @@ class _KlLoss(torch.autograd.Function):
         z_p, m_p, logs_p, mask, acc = ctx.saved_tensors
         B, H, T = z_p.shape
         outs = [torch.empty_like(z_p) for _ in range(4)]
-        _lib.check(lib.xva_kl_loss_bwd(_lib.ptr(z_p), _lib.ptr(m_p), _lib.ptr(logs_p), _lib.ptr(mask), _lib.ptr(acc), float(g_loss.item()),
+        # the upstream gradient stays on the device (a .item() here drained the whole queue in the middle of the backward pass — 6 ms of a host-bound
+        # iteration): the kernel scales by gscale * mask / acc[1], so the gradient is folded into a copy of the denominator
+        acc = torch.stack((acc[0], acc[1] / g_loss.float().reshape(())))
+        _lib.check(lib.xva_kl_loss_bwd(_lib.ptr(z_p), _lib.ptr(m_p), _lib.ptr(logs_p), _lib.ptr(mask), _lib.ptr(acc), 1.0,
                                        _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]), _lib.ptr(outs[3]), B, H, T, _lib.stream_ptr()),
                    "xva_kl_loss_bwd")
         return outs[0], outs[1], outs[2], outs[3], None

@@ -321,10 +321,11 @@ class XVAPitchStep:
                        train=False):
         from .wn import seq_arena_begin
         seq_arena_begin(y.device)          # a new iteration: the previous one's sequences are dead, their slab is zeroed in one memset and reused
-        out = self.gen(tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=pitch_padded, eps=eps, noise=noise, slice_ids=slice_ids)
-        loss_gen, loss_feat = _Adversarial.apply(out["model_outputs"], out["waveform_seg"], self.disc)          # model.py:313-315, losses.py:195-196
-        out.update({"loss_gen": loss_gen, "loss_feat": loss_feat, "loss": out["loss"] + loss_gen + loss_feat})  # losses.py:300
-        return out
+        def adversarial(o, wav_seg):                     # on the decoder's output, inside the vocoder branch (generator_pass.py)
+            loss_gen, loss_feat = _Adversarial.apply(o, wav_seg, self.disc)                                     # model.py:313-315, losses.py:195-196
+            return {"loss_gen": loss_gen, "loss_feat": loss_feat}                                               # losses.py:300: summed into "loss"
+        return self.gen(tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=pitch_padded, eps=eps, noise=noise, slice_ids=slice_ids,
+                        tail=adversarial)
 
     # ---- the two torch.optim.AdamW of python/xvapitch/training_util.py:56-57 (betas 0.8 / 0.99, eps 1e-9, weight decay 0.01; lr args.lr / 2e-4) ----
     def optimizer_step(self, lr=2e-4, lr_disc=2e-4, betas=(0.8, 0.99), eps=1e-9, weight_decay=0.01):

@@ -106,11 +106,30 @@ def _zeros(rows, Cc, device, dtype):
 class Seq:
     """Time-major sequence (B, PAD + T + PAD, C) with GUARD spare rows before / after (conv taps of the first / last item reach there)."""
 
+    _views = {}          # (slab address, byte offset, B, T, C, dtype) -> (store, view): an iteration carves the SAME sequences from the arena as the one before
+
     def __init__(self, B, T, Cc, device, dtype):
         self.B, self.T, self.C, self.Tp = B, T, Cc, T + 2 * PAD
-        self.store = _zeros(2 * GUARD + B * self.Tp, Cc, device, dtype)
-        self.view = self.store[GUARD:GUARD + B * self.Tp].view(B, self.Tp, Cc)
         self.dt = 1 if dtype == torch.bfloat16 else 0
+        a = _ARENA
+        rows = 2 * GUARD + B * self.Tp
+        n = (rows * Cc * (2 if self.dt else 4) + 255) // 256 * 256
+        if a.active and a.used + n <= a.cap and a.slab.device == _dev(device):
+            # the tensor objects of a slab slice are reused across iterations (creating the slice and its two views cost ~8 us of host time, 270 times
+            # an iteration); the memory itself was zeroed by seq_arena_begin()
+            key = (a.slab.data_ptr(), a.used, B, T, Cc, self.dt)
+            hit = Seq._views.get(key)
+            if hit is None:
+                if len(Seq._views) > 8192:
+                    Seq._views.clear()
+                store = a.slab[a.used:a.used + n].view(dtype)[:rows * Cc].view(rows, Cc)
+                hit = Seq._views[key] = (store, store[GUARD:GUARD + B * self.Tp].view(B, self.Tp, Cc))
+            a.want += n
+            a.used += n
+            self.store, self.view = hit
+            return
+        self.store = _zeros(rows, Cc, device, dtype)
+        self.view = self.store[GUARD:GUARD + B * self.Tp].view(B, self.Tp, Cc)
 
     @property
     def rows(self):

@@ -35,6 +35,7 @@ import numpy as np
 import torch
 
 from .. import _lib, dp_launch
+from . import ops as xops
 from ..data import BasicTextEncoder, read_metadata, read_wav_int16
 from ..dp_common import RankMixin, trainer_options
 from .acoustic import AcousticTrainPath
@@ -307,7 +308,8 @@ class XVAPitchFileLoader:
             yield {"text_input": text.to(dev), "text_lengths": torch.tensor([len(it["tokens"]) for it in its], device=dev),
                    "wavs": wavs.to(dev), "wav_lengths": torch.tensor([len(it["wav"]) for it in its], device=dev), "pitch_padded": pitch.to(dev),
                    "d_vectors": torch.from_numpy(np.stack([it["emb"] for it in its])).to(dev),
-                   "language_ids": torch.tensor([it["lang_id"] for it in its], dtype=torch.int64, device=dev), "wav_file_name": [it["name"] for it in its]}
+                   "language_ids": torch.tensor([it["lang_id"] for it in its], dtype=torch.int64, device=dev), "wav_file_name": [it["name"] for it in its],
+                   "num_frames": sum(1 + len(it["wav"]) // 256 for it in its)}
         if not self._reported:               # once, after the first epoch has touched the items
             self._reported = True
             self.log("Dataset caches after the first epoch: %d items without symbol ids (character-table fallback), %d without a pitch file (zeros)"
@@ -611,7 +613,8 @@ class xVAPitchTrainer(RankMixin):
         y, y_lengths, waveform = gp.batch_from_wav(batch["wavs"], batch["wav_lengths"])
         Ty = y.size(2)
         pitch = torch.nn.functional.pad(batch["pitch_padded"], (0, max(0, Ty - batch["pitch_padded"].size(2))))[..., :Ty].contiguous()
-        self.gam_num_frames += int(y_lengths.sum().item())
+        # frames of this batch from the host copy of the clip lengths when the loader kept one (no device round trip at the start of the iteration)
+        self.gam_num_frames += int(batch["num_frames"]) if "num_frames" in batch else int(y_lengths.sum().item())
         stepping = (self.accumulated_steps + 1) % self.gam == 0
         # ---- pass 0: generator (zero_grad at the start of each pass: :652-653) ----
         gp.zero_grad()
@@ -635,8 +638,12 @@ class xVAPitchTrainer(RankMixin):
             self.sync.start_discriminator()                                            # ... and this one under the generator group's update
         # ONE device -> host transfer for the iteration's loss values, after both passes are enqueued (seven .item() syncs between the passes
         # kept the host from issuing the discriminator pass while the generator backward was still running)
-        host = torch.stack(loss_vals + [torch.as_tensor(loss_disc, device=loss_vals[0].device).detach().reshape(()).float()]).cpu()
-        loss_dict = {k: float(v) for k, v in zip(loss_names + ["loss_disc"], host)}
+        # (the deferred conditions of the forward pass — a clip shorter than the segment — travel with them: ops.raise_deferred)
+        host = torch.cat([torch.stack(loss_vals + [torch.as_tensor(loss_disc, device=loss_vals[0].device).detach().reshape(()).float()]),
+                          xops.deferred_flags(loss_vals[0].device)]).cpu()
+        n = len(loss_names) + 1
+        xops.raise_deferred(host[n:])
+        loss_dict = {k: float(v) for k, v in zip(loss_names + ["loss_disc"], host[:n])}
         del out
         self.accumulated_steps += 1
         if self.accumulated_steps % self.gam == 0:
