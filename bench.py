@@ -665,7 +665,7 @@ def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2, roofline=True, c
     def iteration():
         step.gen.zero_grad(); D.zero_grad()
         y, yl, wav = step.gen.batch_from_wav(wavs, wav_lens)        # the posterior encoder's linear spectrograms from the raw clips, on the fly
-        o = step.generator_pass(tokens, xl, y, yl, wav, dvec, lids, pitch_padded=pitch)
+        o = step.generator_pass(tokens, xl, y, yl, wav, dvec, lids, pitch_padded=pitch, eager_disc=True)   # as the trainer calls it
         o["loss"].backward()
         ld = step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
         step.optimizer_step(lr=1e-6, lr_disc=1e-6)

@@ -624,7 +624,8 @@ def test_vits_discriminator_against_reference_golden(golden_dir, compute):
         assert el < 2e-2 and edw < 0.1 and nerr[0][0] < 0.1, (el, edw, nerr[:3])
 
 
-def test_c5_generator_and_discriminator_passes_against_reference_golden(golden_dir):
+@pytest.mark.parametrize("eager_disc", [False, True], ids=["reference order", "discriminator pass on the branch stream"])
+def test_c5_generator_and_discriminator_passes_against_reference_golden(golden_dir, eager_disc):
     """xvapitch/train_step.py:XVAPitchStep — BOTH passes of one xVAPitch iteration (BASELINE config C5) — against the vectors recorded from the
     reference's own code (oracle/gen_golden_xvapitch_c5.py: train_step + HifiganGenerator + VitsDiscriminator + the loss functions, assembled as
     model.py:272-384 / losses.py:187-300 do): the six generator-side losses, their total and loss_disc at 1e-3; d(total)/d(every generator
@@ -653,7 +654,8 @@ def test_c5_generator_and_discriminator_passes_against_reference_golden(golden_d
     t = lambda k: torch.from_numpy(g[k]).cuda()
     step.gen.zero_grad(); D.zero_grad()
     o = step.generator_pass(t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("wav"), t("dvec"), t("lids"), pitch_padded=t("pitch"), eps=t("eps"),
-                            noise=t("noise"), slice_ids=t("slice_ids"))
+                            noise=t("noise"), slice_ids=t("slice_ids"), eager_disc=eager_disc)
+    assert (step._eager is not None) == eager_disc          # the trainer's order: the discriminator pass has already run, inside the generator pass
     assert _rel(o["model_outputs"], torch.from_numpy(g5["model_outputs"])) < 1e-3
     for k in ("loss_mel", "loss_kl", "loss_duration", "loss_pitch", "loss_gen", "loss_feat", "loss"):
         assert abs(float(o[k]) - float(g5[k])) < 1e-3 * abs(float(g5[k])), (k, float(o[k]), float(g5[k]))

@@ -51,10 +51,13 @@ pitch = ((torch.rand(B, 1, Ty, generator=gen) * 3 - 1.2).clamp_min(0) * (torch.a
 x_lens, y_lens = x_lens.to(dev), y_lens.to(dev)
 
 
+EAGER = os.environ.get("XVA_C5_EAGER_DISC", "1") != "0"      # the trainer's order: the discriminator pass inside the generator pass, on the vocoder branch's stream
+
+
 def iteration():
     step.gen.zero_grad(); D.zero_grad()
     t0 = time.perf_counter()
-    o = step.generator_pass(tokens, x_lens, y, y_lens, wav, dvec, lids, pitch_padded=pitch)
+    o = step.generator_pass(tokens, x_lens, y, y_lens, wav, dvec, lids, pitch_padded=pitch, eager_disc=EAGER)
     o["loss"].backward()
     t1a = time.perf_counter()
     torch.cuda.synchronize(); t1 = time.perf_counter()

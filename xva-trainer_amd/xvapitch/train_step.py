@@ -318,14 +318,26 @@ class XVAPitchStep:
         self.gen, self.disc = generator_pass, discriminator
 
     def generator_pass(self, tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=None, eps=None, noise=None, slice_ids=None,
-                       train=False):
+                       train=False, eager_disc=False):
+        """eager_disc: also run the DISCRIMINATOR pass (model.py:366-384) here, on the vocoder branch's stream right after the adversarial terms — it needs
+        nothing but the decoder's detached output and the recording's segment, and the discriminator's parameters do not change before the optimiser steps
+        at the end of the iteration, so its result is the one the reference computes after the generator's backward pass.  The caller zeroes the
+        discriminator's gradients BEFORE this call (the reference zeroes them at the start of pass 1) and collects the loss with discriminator_pass()."""
         from .wn import seq_arena_begin
         seq_arena_begin(y.device)          # a new iteration: the previous one's sequences are dead, their slab is zeroed in one memset and reused
+        self._eager = None
+
         def adversarial(o, wav_seg):                     # on the decoder's output, inside the vocoder branch (generator_pass.py)
             loss_gen, loss_feat = _Adversarial.apply(o, wav_seg, self.disc)                                     # model.py:313-315, losses.py:195-196
+            if eager_disc:
+                with torch.no_grad():
+                    self._eager = (o, wav_seg, self.disc.d_pass(wav_seg, o.detach()))
             return {"loss_gen": loss_gen, "loss_feat": loss_feat}                                               # losses.py:300: summed into "loss"
-        return self.gen(tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=pitch_padded, eps=eps, noise=noise, slice_ids=slice_ids,
-                        tail=adversarial)
+        out = self.gen(tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=pitch_padded, eps=eps, noise=noise, slice_ids=slice_ids,
+                       tail=adversarial)
+        if self._eager is not None:
+            self._eager[2].record_stream(torch.cuda.current_stream(y.device))
+        return out
 
     # ---- the two torch.optim.AdamW of python/xvapitch/training_util.py:56-57 (betas 0.8 / 0.99, eps 1e-9, weight decay 0.01; lr args.lr / 2e-4) ----
     def optimizer_step(self, lr=2e-4, lr_disc=2e-4, betas=(0.8, 0.99), eps=1e-9, weight_decay=0.01):
@@ -348,4 +360,7 @@ class XVAPitchStep:
 
     def discriminator_pass(self, y_disc_cache, wav_seg_disc_cache):
         """model.py:366-384 + VitsDiscriminatorLoss (losses.py:331-351); the parameter gradients accumulate in self.disc.grads()."""
+        eager, self._eager = getattr(self, "_eager", None), None
+        if eager is not None and eager[0].data_ptr() == y_disc_cache.data_ptr() and eager[1].data_ptr() == wav_seg_disc_cache.data_ptr():
+            return eager[2]                              # generator_pass(eager_disc=True) has already run it on these two tensors
         return self.disc.d_pass(wav_seg_disc_cache, y_disc_cache)

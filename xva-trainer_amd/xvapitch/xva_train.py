@@ -618,9 +618,15 @@ class xVAPitchTrainer(RankMixin):
         stepping = (self.accumulated_steps + 1) % self.gam == 0
         # ---- pass 0: generator (zero_grad at the start of each pass: :652-653) ----
         gp.zero_grad()
+        step.disc.zero_grad()               # pass 1's zero_grad, early: the discriminator pass runs inside this call, on the vocoder branch's stream (eager_disc)
         eps, noise, slice_ids = self._draws(batch["text_input"].size(1), Ty, y_lengths)
         out = step.generator_pass(batch["text_input"], batch["text_lengths"], y, y_lengths, waveform, batch["d_vectors"], batch["language_ids"],
-                                  pitch_padded=pitch, eps=eps, noise=noise, slice_ids=slice_ids)
+                                  pitch_padded=pitch, eps=eps, noise=noise, slice_ids=slice_ids, eager_disc=True)
+        # ---- pass 1: discriminator on the (generated.detach(), real) segments: already enqueued; its gradients are final, so its exchange starts here and
+        # runs under the whole generator backward ----
+        loss_disc = step.discriminator_pass(out["model_outputs"].detach(), out["waveform_seg"])
+        if stepping and self.sync is not None:
+            self.sync.start_discriminator()
         if stepping and self.sync is not None and use_ft:
             self.sync.attach(out)                                                      # the decoder's and the flow's buckets go out DURING this backward
         out["loss"].backward()
@@ -628,14 +634,9 @@ class xVAPitchTrainer(RankMixin):
             gp.acoustic.posterior_encoder.zero_grad()
             gp.decoder.zero_grad()
         if stepping and self.sync is not None:
-            self.sync.start_generator()                                                # the exchange runs under the discriminator pass
+            self.sync.start_generator()                                                # the rest of the generator group, under its own tail
         loss_names = ["loss", "loss_gen", "loss_kl", "loss_feat", "loss_mel", "loss_duration"] + (["loss_pitch"] if "loss_pitch" in out else [])
         loss_vals = [out[k].detach().reshape(()).float() for k in loss_names]
-        # ---- pass 1: discriminator on the cached (generated.detach(), real) segments ----
-        step.disc.zero_grad()
-        loss_disc = step.discriminator_pass(out["model_outputs"].detach(), out["waveform_seg"])
-        if stepping and self.sync is not None:
-            self.sync.start_discriminator()                                            # ... and this one under the generator group's update
         # ONE device -> host transfer for the iteration's loss values, after both passes are enqueued (seven .item() syncs between the passes
         # kept the host from issuing the discriminator pass while the generator backward was still running)
         # (the deferred conditions of the forward pass — a clip shorter than the segment — travel with them: ops.raise_deferred)
