@@ -524,6 +524,34 @@ int xva_ln_rows_fwd(const float* x, const float* gamma, const float* beta, float
 int xva_ln_rows_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
                     int64_t rows, int C, void* stream);
 
+/* RelativePositionTransformer (python/xvapitch/glow_tts.py:59-485; the text encoder of model.py:1125-1136 and the pitch predictor of :1283-1305:
+ * layer_norm_type "2", relative window w, heads share the relative embeddings, in = hidden channels) as two engine calls over the primitives above.
+ * x / out / d_out / d_x: (B, C, T) / (B, Co, T) fp32 like the reference's tensors; lens (B,) = the rows of x_mask.  params / grads: host arrays of
+ * L * XVA_XVP_TR_PER_LAYER (+ 2 with has_proj: proj weight (Co, C, 1), bias) DEVICE pointers in the order, per layer, conv_q w, b, conv_k w, b, conv_v w, b,
+ * conv_o w, b (nn.Conv1d (C, C, 1)), emb_rel_k, emb_rel_v (1, 2w + 1, C / H), ffn conv_1 w (F, C, k), b, conv_2 w (Co_l, F, k), b, norm1 gamma, beta, norm2 gamma,
+ * beta — the reference's own layouts; gradients are ACCUMULATED into `grads`.  Co == 1 (has_proj): the stack returns proj(x) of the last layer's attention
+ * block (glow_tts.py:479-482); that layer's feed-forward network and second LayerNorm are not evaluated and get no gradient.  Dropout (p_drop > 0): the
+ * reference's four sites per layer, site0 + 4 * layer + {0, 1, 2, 3} under `seed` (same masks as the per-primitive path; backward takes the same values).
+ * workspace: xva_xvp_tr_workspace_bytes() bytes, 16-byte aligned, ZERO-FILLED before forward (structural pad rows) and handed unchanged to backward;
+ * sk_ws: split-K slab scratch of the weight-gradient products (64 MiB is plenty), contents irrelevant. */
+typedef struct xva_xvp_tr_dims {
+    int32_t B, T;
+    int32_t C, F, H, L;   /* hidden channels, feed-forward channels, heads, layers (<= 64) */
+    int32_t k, w;         /* feed-forward kernel size (odd), relative attention window */
+    int32_t Co;           /* out_channels: C without proj; 1 or a multiple of 4 with it */
+    int32_t has_proj;
+    int32_t compute;      /* 0 = exact fp32 products, 1 = bf16 MFMA on the fp32-stored operands of the projections / feed-forward convolutions */
+    float p_drop;
+    uint64_t seed;
+    uint32_t site0;
+} xva_xvp_tr_dims;
+#define XVA_XVP_TR_PER_LAYER 18
+int64_t xva_xvp_tr_workspace_bytes(const xva_xvp_tr_dims* d);
+int xva_xvp_tr_forward(const xva_xvp_tr_dims* d, const float* const* params, const float* x, const int32_t* lens, float* out, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+int xva_xvp_tr_backward(const xva_xvp_tr_dims* d, const float* const* params, float* const* grads, const float* d_out, const int32_t* lens, float* d_x,
+                        void* workspace, int64_t workspace_bytes, void* sk_ws, int64_t sk_ws_bytes, void* stream);
+
 /* Pieces of the stochastic duration predictor (python/xvapitch/sdp.py).  fp32, time-major (B, T, C) tensors without pad rows; `lens` = x_mask.
  * xva_dwconv_*: the depthwise dilated Conv1d of DilatedDepthSeparableConv (sdp.py:66-69,85) on x * x_mask with zero padding (k odd <= 7);
  * the backward writes dx and accumulates into dw (C, k) / db (C).  xva_gelu_*: torch's exact (erf) F.gelu (sdp.py:87,90). */

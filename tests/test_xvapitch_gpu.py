@@ -702,6 +702,45 @@ def test_rel_transformer_mixed_mode_against_reference_golden(golden_dir):
     assert 1e-6 < ey < 2e-2 and edx < 5e-2 and worst[0][0] < 0.1, (ey, edx, worst[:4])      # > 1e-6: the bf16 products really ran
 
 
+@pytest.mark.parametrize("cfg", [dict(C=196, Co=196, F=768, H=2, L=3, k=3, compute="fp32"), dict(C=196, Co=196, F=768, H=2, L=2, k=3, compute="mixed"),
+                                 dict(C=708, Co=1, F=768, H=2, L=3, k=3, compute="mixed"), dict(C=64, Co=32, F=128, H=4, L=2, k=1, compute="fp32")],
+                         ids=["text encoder fp32", "text encoder mixed", "pitch predictor (proj to 1 channel)", "proj to 32 channels, k 1"])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_transformer_engine_calls_equal_the_per_primitive_sequencing(cfg, p_drop):
+    """csrc/xvp_transformer.hip (xva_xvp_tr_forward / _backward: the whole stack as two C calls) against the Python sequencing of the same kernels
+    (transformer.py forward_seq / backward_seq, which the reference goldens pin): output, input gradient and every parameter gradient, with the
+    dropout masks of the same seed.  Same kernels, same summation order: equal to fp32 rounding of the few re-associated adds."""
+    from xva_trainer_amd.xvapitch import transformer as tmod
+    B, T = 3, 37
+    torch.manual_seed(5)
+    lens = torch.tensor([37, 20, 9])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1).cuda()
+    x0 = torch.randn(B, cfg["C"], T).cuda()
+    r = torch.randn(B, cfg["Co"], T).cuda()
+    res = {}
+    for engine in (False, True):
+        tr = tmod.RelativePositionTransformer(cfg["C"], cfg["Co"], cfg["C"], cfg["F"], cfg["H"], cfg["L"], kernel_size=cfg["k"], dropout_p=p_drop,
+                                              rel_attn_window_size=4, layer_norm_type="2", compute=cfg["compute"], seed=11, dropout_site_base=40)
+        tr.set_dropout_seed(777)
+        tr.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        old, tmod._ENGINE = tmod._ENGINE, engine
+        try:
+            y = tr(x, x_mask)
+            (y * r).sum().backward()
+        finally:
+            tmod._ENGINE = old
+        torch.cuda.synchronize()
+        res[engine] = (y.detach().clone(), x.grad.clone(), {k: v.clone() for k, v in tr.grads().items()})
+    (y0, dx0, g0), (y1, dx1, g1) = res[False], res[True]
+    assert float(y0.abs().max()) > 0 and float(dx0.abs().max()) > 0
+    assert _rel(y1, y0) < 1e-6 and _rel(dx1, dx0) < 1e-6, (_rel(y1, y0), _rel(dx1, dx0))
+    worst = sorted(((_rel(g1[k], g0[k]) if float(g0[k].abs().max()) > 0 else float(g1[k].abs().max()), k) for k in g0), reverse=True)
+    assert set(g0) == set(g1) and worst[0][0] < 1e-5, worst[:4]
+    dead = [k for k in g0 if float(g0[k].abs().max()) == 0]
+    assert all(float(g1[k].abs().max()) == 0 for k in dead)            # out_channels == 1: the last layer's feed-forward / norm2 get no gradient in either
+
+
 def test_c5_optimizer_step_matches_torch_adamw(golden_dir):
     """XVAPitchStep.optimizer_step (three flat xva_adamw_step launches) against torch.optim.AdamW — the class the reference trainer constructs
     (python/xvapitch/training_util.py:56-57: betas 0.8 / 0.99, eps 1e-9, weight decay 0.01) — run on the CPU over the same parameters and the

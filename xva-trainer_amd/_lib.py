@@ -179,6 +179,7 @@ def _fill_gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layout=GEMM_NT, compute=0, batc
 
 
 _SK_SCRATCH = {}
+PARAM_EPOCH = [0]        # bumped by whoever moves parameter / gradient tensors to new storage (train_step.FlatGroupAdamW._flatten): cached pointer tables check it
 
 
 def sk_scratch(device, nbytes=64 << 20):

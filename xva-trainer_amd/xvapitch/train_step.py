@@ -152,6 +152,7 @@ class FlatGroupAdamW:
                 off += al(c)
         self.named = [e[:4] for e in ent]
         self.offs, self.m, self.v, self.flat_p, self.flat_g, self.bucket_slices = offs, m, v, P, G, slices
+        _lib.PARAM_EPOCH[0] += 1                                                # pointer tables of the engine calls (transformer.py) are stale now
         if self.owner is not None:
             self.owner._flat_g, self.owner._flat_buckets = G, slices
 

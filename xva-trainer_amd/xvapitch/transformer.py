@@ -15,12 +15,13 @@ iteration), element index = position in the (B, H, T, T) weights / (row of the t
 False` switches it off (eval).  Not built: in_channels != hidden_channels, input_length, layer_norm type "1".
 """
 import ctypes as C
+import os
 
 import torch
 
 from .. import _lib
 from . import ops
-from .wn import PAD, Seq, conv_bwd_data, conv_bwd_weight, conv_fwd, _grad_hook, _lens_of
+from .wn import PAD, Seq, conv_bwd_data, conv_bwd_weight, conv_fwd, _grad_hook, _lens_of, _zeros
 
 lib = _lib.lib
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -34,6 +35,25 @@ lib.xva_ln_rows_fwd.restype = i32
 lib.xva_ln_rows_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]
 lib.xva_ln_rows_bwd.restype = i32
 lib.xva_ln_rows_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+
+
+class _TrDims(C.Structure):
+    """include/xva_hip.h xva_xvp_tr_dims"""
+    _fields_ = [("B", i32), ("T", i32), ("C", i32), ("F", i32), ("H", i32), ("L", i32), ("k", i32), ("w", i32), ("Co", i32), ("has_proj", i32), ("compute", i32),
+                ("p_drop", f32), ("seed", C.c_uint64), ("site0", C.c_uint32)]
+
+
+PER_LAYER = 18          # XVA_XVP_TR_PER_LAYER: the order of the engine's parameter table
+_ORDER = ("attn.conv_q.weight", "attn.conv_q.bias", "attn.conv_k.weight", "attn.conv_k.bias", "attn.conv_v.weight", "attn.conv_v.bias", "attn.conv_o.weight",
+          "attn.conv_o.bias", "attn.emb_rel_k", "attn.emb_rel_v", "ffn.conv_1.weight", "ffn.conv_1.bias", "ffn.conv_2.weight", "ffn.conv_2.bias", "norm1.gamma",
+          "norm1.beta", "norm2.gamma", "norm2.beta")
+lib.xva_xvp_tr_workspace_bytes.restype = i64
+lib.xva_xvp_tr_workspace_bytes.argtypes = [C.POINTER(_TrDims)]
+lib.xva_xvp_tr_forward.restype = i32
+lib.xva_xvp_tr_forward.argtypes = [C.POINTER(_TrDims), vp, vp, vp, vp, vp, i64, vp]
+lib.xva_xvp_tr_backward.restype = i32
+lib.xva_xvp_tr_backward.argtypes = [C.POINTER(_TrDims), vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]
+_ENGINE = os.environ.get("XVA_XVP_TR_ENGINE", "1") != "0"      # 0: the per-primitive Python sequencing below (same kernels; kept as the A / B and for the tests)
 
 
 def _p(t, elem_off=0):
@@ -164,6 +184,26 @@ class RelativePositionTransformer:
 
     def __call__(self, x, x_mask):
         return _TransformerFn.apply(x, self, _lens_of(x, x_mask), _grad_hook(x.device))
+
+    # ---- the engine calls (csrc/xvp_transformer.hip) ----
+    def _tables(self):
+        """(parameter, gradient) pointer tables in the engine's order; rebuilt when the tensors have moved (FlatGroupAdamW re-homes them into its arenas once)."""
+        first, lastp = self.layers[0].p[_ORDER[0]], self.layers[-1].p[_ORDER[-1]]
+        key = (first.data_ptr(), lastp.data_ptr(), self.layers[0].g[_ORDER[0]].data_ptr(), self.layers[-1].g[_ORDER[-1]].data_ptr(), _lib.PARAM_EPOCH[0])
+        if getattr(self, "_tab_key", None) != key:
+            ps = [l.p[n] for l in self.layers for n in _ORDER] + ([self.proj["weight"], self.proj["bias"]] if self.proj is not None else [])
+            gs = [l.g[n] for l in self.layers for n in _ORDER] + ([self.proj_g["weight"], self.proj_g["bias"]] if self.proj is not None else [])
+            for t in ps + gs:
+                if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                    raise _lib.XvaError("RelativePositionTransformer: parameters / gradients must be contiguous fp32 device tensors")
+            arr = C.c_void_p * len(ps)
+            self._tab = (arr(*[t.data_ptr() for t in ps]), arr(*[t.data_ptr() for t in gs]))
+            self._tab_key = key
+        return self._tab
+
+    def _dims(self, B, T):
+        pd = self.dropout_p if self.training else 0.0
+        return _TrDims(B, T, self.C, self.F, self.H, self.L, self.k, self.w, self.Co, int(self.proj is not None), self.cmp, pd, self.drop_seed, self.site0)
 
     # ---- sequences ----
     def _proj_padded(self):
@@ -337,6 +377,18 @@ class _TransformerFn(torch.autograd.Function):
     def forward(ctx, x, tr, lens, hook=None):
         _lib.require_cuda(x)
         B, Cc, T = x.shape
+        if _ENGINE:
+            d = tr._dims(B, T)
+            n = int(lib.xva_xvp_tr_workspace_bytes(C.byref(d)))
+            if n < 0:
+                raise _lib.XvaError("xva_xvp_tr_workspace_bytes: %s" % lib.xva_last_error().decode())
+            ws = _zeros((n + 3) // 4, 1, tr.device, torch.float32)          # zeroed: from the iteration's sequence arena when there is one
+            out = torch.empty(B, tr.Co, T, device=x.device)
+            prm, _ = tr._tables()
+            _lib.check(lib.xva_xvp_tr_forward(C.byref(d), prm, _lib.ptr(x.float().contiguous()), _lib.ptr(lens), _lib.ptr(out), C.c_void_p(ws.data_ptr()), n,
+                                              _lib.stream_ptr()), "xva_xvp_tr_forward")
+            ctx.tr, ctx.state = tr, (d, ws, n, lens)
+            return out
         xs = Seq(B, T, Cc, tr.device, torch.float32)
         _lib.check(ops.lib.xva_bct_to_seq(_lib.ptr(x.float().contiguous()), C.c_void_p(xs.view.data_ptr()), 0, B, Cc, T, PAD, None, _lib.stream_ptr()),
                    "xva_bct_to_seq")
@@ -347,6 +399,15 @@ class _TransformerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         tr = ctx.tr
+        if getattr(ctx, "state", None) is not None:
+            d, ws, n, lens = ctx.state
+            ctx.state = None
+            d_x = torch.empty(d.B, tr.C, d.T, device=d_out.device)
+            prm, grd = tr._tables()
+            sk = _lib.sk_scratch(d_out.device)
+            _lib.check(lib.xva_xvp_tr_backward(C.byref(d), prm, grd, _lib.ptr(d_out.float().contiguous()), _lib.ptr(lens), _lib.ptr(d_x), C.c_void_p(ws.data_ptr()),
+                                               n, C.c_void_p(sk.data_ptr()), sk.numel(), _lib.stream_ptr()), "xva_xvp_tr_backward")
+            return d_x, None, None, None
         B, Cc, T = ctx.dims
         ds = Seq(B, T, tr.Co, tr.device, torch.float32)
         _lib.check(ops.lib.xva_bct_to_seq(_lib.ptr(d_out.float().contiguous()), C.c_void_p(ds.view.data_ptr()), 0, B, tr.Co, T, PAD, None, _lib.stream_ptr()),
