@@ -561,6 +561,23 @@ int xva_dwconv_bwd(const float* dy, const float* x, const float* w, float* dx, f
 int xva_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int xva_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
 
+/* DilatedDepthSeparableConv.forward (python/xvapitch/sdp.py:70-93) and its backward as two engine calls over the primitives above: (x [+ g]) -> L x {depthwise
+ * conv (dilation k^i) -> LayerNorm2 -> GELU -> 1x1 conv -> LayerNorm2 -> GELU -> [Dropout, site0 + i under seed] -> + x} -> * x_mask.  x / g (may be NULL) / out / dy /
+ * dx: (B, T, C) fp32; params / grads: host arrays of 8 L device pointers — per layer convs_sep weight (C, 1, k), bias, convs_1x1 weight (C, C, 1), bias, norms_1
+ * gamma, beta, norms_2 gamma, beta; gradients are ACCUMULATED; dx = d x = d g.  workspace: xva_xvp_dds_workspace_bytes(), no initialisation needed, handed
+ * unchanged to the backward; sk_ws: split-K slab scratch of the 1x1 weight gradients. */
+typedef struct xva_xvp_dds_dims {
+    int32_t B, T, C, k, L;
+    float p_drop;
+    uint64_t seed;
+    uint32_t site0;
+} xva_xvp_dds_dims;
+int64_t xva_xvp_dds_workspace_bytes(const xva_xvp_dds_dims* d);
+int xva_xvp_dds_forward(const xva_xvp_dds_dims* d, const float* const* params, const float* x, const float* g, const int32_t* lens, float* out, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+int xva_xvp_dds_backward(const xva_xvp_dds_dims* d, const float* const* params, float* const* grads, const float* dy, const int32_t* lens, float* dx, void* workspace,
+                         int64_t workspace_bytes, void* sk_ws, int64_t sk_ws_bytes, void* stream);
+
 /* Rational-quadratic spline with linear tails, forward direction: piecewise_rational_quadratic_transform(inverse=False, tails="linear") of
  * python/xvapitch/util.py:203-391 as ConvFlow uses it (sdp.py:151-167).  x, y, logdet: n elements; h: (n, 3K - 1) raw parameters
  * [K widths | K heights | K - 1 derivatives], widths / heights multiplied by wh_scale (= 1 / sqrt(hidden)) before their softmax.  K <= 16.

@@ -341,6 +341,42 @@ def test_dds_conv_against_reference_golden(golden_dir):
     assert len(worst) == 8 * L and worst[0][0] < 1e-3, worst[:3]
 
 
+@pytest.mark.parametrize("with_g", [True, False], ids=["conditioned", "no conditioning"])
+@pytest.mark.parametrize("p_drop", [0.0, 0.5])
+def test_dds_engine_calls_equal_the_per_primitive_sequencing(with_g, p_drop):
+    """csrc/xvp_dds.hip (xva_xvp_dds_forward / _backward) against the Python sequencing of the same kernels (sdp.py _dds_fwd / _dds_bwd, which the reference golden
+    above pins): output, d x, d g and every parameter gradient, with the dropout masks of one seed.  Twice through the backward of the same module: the second
+    pass finds the parameters' .grad in place and accumulates into it directly (sdp._gbuf)."""
+    from xva_trainer_amd.xvapitch import sdp as smod
+    B, T, Cc, K, L = 3, 41, 192, 3, 3
+    torch.manual_seed(3)
+    lens = torch.tensor([41, 17, 30])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1).cuda()
+    x0, g0, r = torch.randn(B, Cc, T).cuda(), torch.randn(B, Cc, T).cuda(), torch.randn(B, Cc, T).cuda()
+    res = {}
+    for engine in (0, 1):
+        m = smod.DilatedDepthSeparableConv(Cc, K, L, dropout_p=p_drop, seed=4, dropout_site_base=7)
+        m.drop_seed = 991
+        old, smod._DDS_ENGINE = smod._DDS_ENGINE, engine
+        try:
+            for _ in range(2):
+                x = x0.clone().requires_grad_(True)
+                cond = g0.clone().requires_grad_(True) if with_g else None
+                y = m(x, x_mask, g=cond)
+                (y * r).sum().backward()
+        finally:
+            smod._DDS_ENGINE = old
+        torch.cuda.synchronize()
+        res[engine] = (y.detach().clone(), x.grad.clone(), cond.grad.clone() if with_g else None, {k: v.grad.clone() for k, v in m.p.items()})
+    (y0, dx0, dg0, gr0), (y1, dx1, dg1, gr1) = res[0], res[1]
+    assert float(y0.abs().max()) > 0 and _rel(y1, y0) < 1e-6 and _rel(dx1, dx0) < 1e-6
+    assert float((y1 * (1 - x_mask)).abs().max()) == 0.0
+    if with_g:
+        assert _rel(dg1, dg0) < 1e-6
+    worst = sorted(((_rel(gr1[k], gr0[k]), k) for k in gr0), reverse=True)
+    assert len(worst) == 8 * L and worst[0][0] < 1e-5, worst[:4]
+
+
 def test_conv_flow_against_reference_golden(golden_dir):
     """xvapitch/sdp.py:ConvFlow (pre, DDSConv with conditioning, proj, the rational-quadratic spline with linear tails — xva_rq_spline_fwd/bwd;
     python/xvapitch/sdp.py:116-176, util.py:203-391) vs the REFERENCE module on inputs that reach into the tails: transformed variable, per-item

@@ -1,0 +1,146 @@
+// xvp_dds.hip — DilatedDepthSeparableConv of xVAPitch's stochastic duration predictor (python/xvapitch/sdp.py:40-93) as two engine calls.
+//
+// The duration predictor runs ten of these stacks per training iteration (its own `convs` / `post_convs` and one inside each of the eight ConvFlows,
+// sdp.py:116-176,196-260) on (B, T, hidden) = (16, 100, 192) tensors: 3 layers x {depthwise dilated conv -> LayerNorm2 -> GELU -> 1x1 conv -> LayerNorm2 -> GELU ->
+// [Dropout] -> + x} and the mirror image backwards — ~660 launches of 3 - 15 us whose issue from Python (xva-trainer_amd/xvapitch/sdp.py _dds_fwd / _dds_bwd) cost
+// more host time than any other module of the iteration.  Same kernels, same order; the host side is this C++ loop.  Tensors are (B, T, C) fp32 without pad rows;
+// `lens` = the rows of x_mask.  The workspace needs no initialisation: every buffer is written before it is read.
+#include "xva_common.h"
+#include "xva_gemm.h"
+#include "xva_hip.h"
+
+namespace {
+struct Lay { float *cur, *t1, *m1, *r1, *n1, *a1, *t2, *m2, *r2, *n2, *a2, *nxt; };
+struct W {
+    float* x0;                                   // x [+ g]
+    Lay l[16];
+    float *d, *da2, *dn2, *dt2, *da1, *dn1, *dt1, *dxb[2];
+    int64_t floats;
+};
+struct Carver {
+    float* base; int64_t off;
+    float* take(int64_t n) { n = (n + 63) / 64 * 64; float* p = base ? base + off : nullptr; off += n; return p; }
+};
+void carve(const xva_xvp_dds_dims* d, float* base, W& w) {
+    Carver c{base, 0};
+    const int64_t rows = (int64_t)d->B * d->T, n = rows * d->C;
+    w.x0 = c.take(n);
+    for (int i = 0; i < d->L; i++) {
+        Lay& l = w.l[i];
+        l.t1 = c.take(n); l.m1 = c.take(rows); l.r1 = c.take(rows); l.n1 = c.take(n); l.a1 = c.take(n); l.t2 = c.take(n); l.m2 = c.take(rows); l.r2 = c.take(rows);
+        l.n2 = c.take(n); l.a2 = c.take(n);
+        l.nxt = d->p_drop > 0.f ? c.take(n) : l.a2;
+        l.cur = i == 0 ? w.x0 : w.l[i - 1].nxt;
+    }
+    w.d = c.take(n); w.da2 = c.take(n); w.dn2 = c.take(n); w.dt2 = c.take(n); w.da1 = c.take(n); w.dn1 = c.take(n); w.dt1 = c.take(n);
+    w.dxb[0] = c.take(n); w.dxb[1] = c.take(n);
+    w.floats = c.off;
+}
+int check_dims(const xva_xvp_dds_dims* d) {
+    XVA_CHECK_ARG(d && d->B > 0 && d->T > 0 && d->C > 0 && d->C % 4 == 0 && d->L >= 1 && d->L <= 16 && (d->k & 1) && d->k <= 7 && d->p_drop >= 0.f && d->p_drop < 1.f,
+                  "xvp_dds: B, T > 0; C a multiple of 4; 1 <= L <= 16; k odd <= 7; p_drop in [0, 1)");
+    return XVA_OK;
+}
+xva_gemm_params gemm_base() {
+    xva_gemm_params p;
+    memset(&p, 0, sizeof(p));
+    p.batch = 1; p.batch2 = 1; p.alpha = 1.f; p.beta = 1.f; p.splitk = 1; p.mask_mul = 1; p.mask_pad = 1;
+    return p;
+}
+__global__ void add2_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ o, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 x = a[i], y = b[i];
+    o[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+// dst = src * x_mask on (B, T, C) rows
+__global__ void copy_mask_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4, int C4, int T, const int32_t* __restrict__ lens) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int64_t r = i / C4;
+    const int b = (int)(r / T), t = (int)(r - (int64_t)b * T);
+    dst[i] = t < lens[b] ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+}  // namespace
+
+extern "C" int64_t xva_xvp_dds_workspace_bytes(const xva_xvp_dds_dims* d) {
+    if (check_dims(d) != XVA_OK) return -1;
+    W w;
+    carve(d, nullptr, w);
+    return w.floats * 4;
+}
+
+extern "C" int xva_xvp_dds_forward(const xva_xvp_dds_dims* d, const float* const* prm, const float* x, const float* g, const int32_t* lens, float* out, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    XVA_TRY(check_dims(d));
+    XVA_CHECK_ARG(prm && x && lens && out && workspace && ((uintptr_t)workspace % 16) == 0, "xvp_dds_forward: null / unaligned argument");
+    W w;
+    carve(d, (float*)workspace, w);
+    XVA_CHECK_ARG(workspace_bytes >= w.floats * 4, "xvp_dds_forward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = d->B, T = d->T, C = d->C, k = d->k;
+    const int64_t rows = (int64_t)B * T, n = rows * C;
+    if (g) {
+        hipLaunchKernelGGL(add2_kernel, dim3((unsigned)xva_cdiv(n / 4, 256)), dim3(256), 0, s, (const float4*)x, (const float4*)g, (float4*)w.x0, n / 4);
+        XVA_LAUNCH_CHECK();
+    } else if (hipMemcpyAsync(w.x0, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) { xva_set_error("xvp_dds_forward: copy failed"); return XVA_ERR_HIP; }
+    int dil = 1;
+    for (int i = 0; i < d->L; i++, dil *= k) {
+        const Lay& l = w.l[i];
+        const float* const* p = prm + 8 * i;                       // convs_sep w (C, 1, k), b ; convs_1x1 w (C, C, 1), b ; norms_1 gamma, beta ; norms_2 gamma, beta
+        XVA_TRY(xva_dwconv_fwd(l.cur, p[0], p[1], l.t1, lens, B, T, C, k, dil, stream));                            // sdp.py:85
+        XVA_TRY(xva_ln_rows_fwd(l.t1, p[4], p[5], l.n1, l.m1, l.r1, rows, C, 1e-5f, stream));                       // :86
+        XVA_TRY(xva_gelu_fwd(l.n1, l.a1, n, stream));                                                               // :87
+        xva_gemm_params q = gemm_base();                                                                            // :88
+        q.A = l.a1; q.B = p[2]; q.C = l.t2; q.M = (int32_t)rows; q.N = C; q.K = C; q.lda = C; q.ldb = C; q.ldc = C; q.layout = XVA_GEMM_NT; q.bias = p[3];
+        XVA_TRY(xva_gemm(&q, stream));
+        XVA_TRY(xva_ln_rows_fwd(l.t2, p[6], p[7], l.n2, l.m2, l.r2, rows, C, 1e-5f, stream));                       // :89
+        XVA_TRY(xva_gelu_fwd(l.n2, l.a2, n, stream));                                                               // :90
+        if (d->p_drop > 0.f) XVA_TRY(xva_dropout_apply(l.a2, l.nxt, 0, n, d->p_drop, d->seed, d->site0 + i, stream));   // :91
+        XVA_TRY(xva_fp_add_act(l.nxt, l.cur, 0, n, stream));                                                        // x = x + y (:92)
+    }
+    hipLaunchKernelGGL(copy_mask_kernel, dim3((unsigned)xva_cdiv(n / 4, 256)), dim3(256), 0, s, (const float4*)w.l[d->L - 1].nxt, (float4*)out, n / 4, C / 4, T, lens);   // :93
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
+extern "C" int xva_xvp_dds_backward(const xva_xvp_dds_dims* d, const float* const* prm, float* const* grd, const float* dy, const int32_t* lens, float* dx, void* workspace,
+                                    int64_t workspace_bytes, void* sk_ws, int64_t sk_ws_bytes, void* stream) {
+    XVA_TRY(check_dims(d));
+    XVA_CHECK_ARG(prm && grd && dy && lens && dx && workspace, "xvp_dds_backward: null argument");
+    W w;
+    carve(d, (float*)workspace, w);
+    XVA_CHECK_ARG(workspace_bytes >= w.floats * 4, "xvp_dds_backward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = d->B, T = d->T, C = d->C, k = d->k;
+    const int64_t rows = (int64_t)B * T, n = rows * C;
+    hipLaunchKernelGGL(copy_mask_kernel, dim3((unsigned)xva_cdiv(n / 4, 256)), dim3(256), 0, s, (const float4*)dy, (float4*)w.d, n / 4, C / 4, T, lens);
+    XVA_LAUNCH_CHECK();
+    float* dcur = w.d;
+    int dil = 1;
+    for (int i = 1; i < d->L; i++) dil *= k;
+    for (int i = d->L - 1; i >= 0; i--, dil /= k) {
+        const Lay& l = w.l[i];
+        const float* const* p = prm + 8 * i;
+        float* const* gr = grd + 8 * i;
+        const float* da2 = dcur;
+        if (d->p_drop > 0.f) { XVA_TRY(xva_dropout_apply(dcur, w.da2, 0, n, d->p_drop, d->seed, d->site0 + i, stream)); da2 = w.da2; }
+        XVA_TRY(xva_gelu_bwd(l.n2, da2, w.dn2, n, stream));
+        XVA_TRY(xva_ln_rows_bwd(w.dn2, l.t2, l.m2, l.r2, p[6], w.dt2, gr[6], gr[7], rows, C, stream));
+        xva_gemm_params q = gemm_base();                                                                            // d a1 = d t2 W
+        q.A = w.dt2; q.B = p[2]; q.C = w.da1; q.M = (int32_t)rows; q.N = C; q.K = C; q.lda = C; q.ldb = C; q.ldc = C; q.layout = XVA_GEMM_NN;
+        XVA_TRY(xva_gemm(&q, stream));
+        xva_gemm_params t = gemm_base();                                                                            // d W += d t2^T a1
+        t.A = w.dt2; t.B = l.a1; t.C = gr[2]; t.M = C; t.N = C; t.K = (int32_t)rows; t.lda = C; t.ldb = C; t.ldc = C; t.layout = XVA_GEMM_TN; t.accumulate = 1; t.splitk = 0;
+        t.sk_ws = sk_ws; t.sk_ws_bytes = sk_ws_bytes;
+        XVA_TRY(xva_gemm(&t, stream));
+        XVA_TRY(xva_hg_colsum(w.dt2, 0, gr[3], rows, C, 1.f, stream));
+        XVA_TRY(xva_gelu_bwd(l.n1, w.da1, w.dn1, n, stream));
+        XVA_TRY(xva_ln_rows_bwd(w.dn1, l.t1, l.m1, l.r1, p[4], w.dt1, gr[4], gr[5], rows, C, stream));
+        float* dxb = i == 0 ? dx : w.dxb[i & 1];
+        XVA_TRY(xva_dwconv_bwd(w.dt1, l.cur, p[0], dxb, gr[0], gr[1], lens, B, T, C, k, dil, stream));
+        XVA_TRY(xva_fp_add_act(dxb, dcur, 0, n, stream));                                                           // d(x) = d(residual) + d(branch)
+        dcur = dxb;
+    }
+    return XVA_OK;
+}

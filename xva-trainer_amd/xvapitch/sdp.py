@@ -213,9 +213,63 @@ def _param(t, device):
     return t.to(device=device, dtype=torch.float32).requires_grad_(True)
 
 
+class _DdsDims(C.Structure):
+    """include/xva_hip.h xva_xvp_dds_dims"""
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("k", C.c_int32), ("L", C.c_int32), ("p_drop", C.c_float), ("seed", C.c_uint64),
+                ("site0", C.c_uint32)]
+
+
+lib.xva_xvp_dds_workspace_bytes.restype = C.c_int64
+lib.xva_xvp_dds_workspace_bytes.argtypes = [C.POINTER(_DdsDims)]
+lib.xva_xvp_dds_forward.restype = C.c_int32
+lib.xva_xvp_dds_forward.argtypes = [C.POINTER(_DdsDims)] + [C.c_void_p] * 6 + [C.c_int64, C.c_void_p]
+lib.xva_xvp_dds_backward.restype = C.c_int32
+lib.xva_xvp_dds_backward.argtypes = [C.POINTER(_DdsDims)] + [C.c_void_p] * 6 + [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+_DDS_ENGINE = int(__import__("os").environ.get("XVA_XVP_DDS_ENGINE", "1"))      # 0: the per-primitive sequencing below (same kernels; the A / B and the tests' reference)
+_DDS_WS = {}
+
+
+def _dds_engine_ok(x, params):
+    return _DDS_ENGINE and x.size(-1) % 4 == 0 and 1 <= len(params) // 8 <= 16 and all(p.dtype == torch.float32 and p.is_contiguous() for p in params)
+
+
+def _dds_fwd_engine(x, g, lens, cfg, params):
+    k, L, p_drop, seed, site0 = cfg
+    x = x.contiguous(); B, T, Cc = x.shape
+    d = _DdsDims(B, T, Cc, k, L, p_drop, seed & 0xFFFFFFFFFFFFFFFF, site0)
+    key = (B, T, Cc, k, L, p_drop > 0)
+    n = _DDS_WS.get(key)
+    if n is None:
+        n = _DDS_WS[key] = int(lib.xva_xvp_dds_workspace_bytes(C.byref(d)))
+        if n < 0:
+            raise _lib.XvaError("xva_xvp_dds_workspace_bytes: %s" % lib.xva_last_error().decode())
+    ws = torch.empty(n, dtype=torch.uint8, device=x.device)
+    out = torch.empty_like(x)
+    prm = (C.c_void_p * (8 * L))(*[p.data_ptr() for p in params])
+    gc = g.contiguous() if g is not None else None
+    _lib.check(lib.xva_xvp_dds_forward(C.byref(d), prm, P(x), P(gc), P(lens), P(out), P(ws), n, ST()), "xva_xvp_dds_forward")
+    return out, ("engine", d, prm, ws, n, lens, params)
+
+
+def _dds_bwd_engine(state, dy):
+    _, d, prm, ws, n, lens, params = state
+    bufs = [_gbuf(p) for p in params]
+    grd = (C.c_void_p * len(params))(*[b.data_ptr() for b, _ in bufs])
+    dx = torch.empty(d.B, d.T, d.C, device=dy.device)
+    sk = _lib.sk_scratch(dy.device)
+    _lib.check(lib.xva_xvp_dds_backward(C.byref(d), prm, grd, P(dy.contiguous()), P(lens), P(dx), P(ws), n, P(sk), sk.numel(), ST()), "xva_xvp_dds_backward")
+    rets = [r for _, r in bufs]
+    for i in range(2, len(rets), 8):                       # the 1x1 convolution's weight: handed back in the parameter's own shape
+        if rets[i] is not None:
+            rets[i] = rets[i].view(params[i].shape)
+    return dx, rets
+
+
 def _dds_fwd(x, g, lens, cfg, params):
     """The kernels of DilatedDepthSeparableConv.forward (sdp.py:70-93) back to back: (x [+ g]) -> L x {DwConv -> LayerNorm2 -> GELU -> Conv1x1 -> LayerNorm2 ->
     GELU -> [Dropout] -> + x} -> mask.  Residual adds and the mask run in place on tensors this call owns.  Returns (out, what _dds_bwd needs)."""
+    if _dds_engine_ok(x, params):
+        return _dds_fwd_engine(x, g, lens, cfg, params)
     k, L, p_drop, seed, site0 = cfg
     x = x.contiguous(); B, T, Cc = x.shape
     rows, n = B * T, x.numel()
@@ -254,6 +308,8 @@ def _dds_fwd(x, g, lens, cfg, params):
 
 def _dds_bwd(state, dy):
     """-> (d x [= d g], [8 L parameter-gradient returns: None where the sum went straight into the parameter's .grad])"""
+    if state[0] == "engine":
+        return _dds_bwd_engine(state, dy)
     saved, lens, cfg, params, (B, T, Cc) = state
     k, L, p_drop, seed, site0 = cfg
     rows, n = B * T, B * T * Cc
