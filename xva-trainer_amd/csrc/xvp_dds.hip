@@ -61,6 +61,137 @@ __global__ void copy_mask_kernel(const float4* __restrict__ src, float4* __restr
     const int b = (int)(r / T), t = (int)(r - (int64_t)b * T);
     dst[i] = t < lens[b] ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_d(float v) { return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v); }
+
+// ---- fused row kernels (one wave per (b, t) row; the same per-lane summation orders as dwconv_fwd / ln_rows_fwd / gelu / dropout_apply / add, so the
+// results are the separate kernels' bit for bit) -------------------------------------------------------------------------------------------------
+// front half of a layer: t1 = depthwise dilated conv(cur * x_mask) ; n1 = LayerNorm2(t1) ; a1 = GELU(n1)
+__global__ void dds_front_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* __restrict__ t1, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ n1,
+                                 float* __restrict__ a1, const int32_t* __restrict__ lens, int64_t rows, int T, int C, int k, int d) {
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int b = (int)(row / T), t = (int)(row - (int64_t)b * T), len = lens[b], P = (k - 1) / 2;
+    float* tr = t1 + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float acc = bias[c];
+        for (int j = 0; j < k; ++j) {
+            const int tt = t + (j - P) * d;
+            if (tt >= 0 && tt < len) acc += w[c * k + j] * x[((int64_t)b * T + tt) * C + c];
+        }
+        tr[c] = acc; s += acc;
+    }
+    const float mu = xva_wave_sum(s) / C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float e = tr[c] - mu; q += e * e; }       // a lane re-reads only what it wrote
+    const float rs = rsqrtf(xva_wave_sum(q) / C + 1e-5f);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    for (int c = lane; c < C; c += 64) {
+        const float v = (tr[c] - mu) * rs * gamma[c] + beta[c];
+        n1[row * C + c] = v; a1[row * C + c] = gelu_f(v);
+    }
+}
+// back half: n2 = LayerNorm2(t2) ; nxt = Dropout(GELU(n2)) + cur
+__global__ void dds_back_kernel(const float* __restrict__ t2, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ cur,
+                                float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ n2, float* __restrict__ nxt, int64_t rows, int C, float p,
+                                uint64_t seed, uint32_t site) {
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = t2 + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mu = xva_wave_sum(s) / C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float e = xr[c] - mu; q += e * e; }
+    const float rs = rsqrtf(xva_wave_sum(q) / C + 1e-5f);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    for (int c = lane; c < C; c += 64) {
+        const int64_t i = row * C + c;
+        const float v = (xr[c] - mu) * rs * gamma[c] + beta[c];
+        n2[i] = v;
+        nxt[i] = gelu_f(v) * xva_dropout_scale(p, seed, site, (uint64_t)i) + cur[i];
+    }
+}
+// backward through [Dropout ->] GELU -> LayerNorm2 in one pass: g = dy * drop * gelu'(n), then dx = rstd (g gamma - mean(g gamma) - xhat mean(g gamma xhat)),
+// dgamma += sum_r g xhat, dbeta += sum_r g  (C <= 256: a lane holds its four columns; a wave walks `rpw` rows, a workgroup shares one atomic per column)
+__global__ void dds_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ nrm, const float* __restrict__ x, const float* __restrict__ mean,
+                                  const float* __restrict__ rstd, const float* __restrict__ gamma, float* __restrict__ dx, float* __restrict__ dgamma,
+                                  float* __restrict__ dbeta, int64_t rows, int C, int rpw, float p, uint64_t seed, uint32_t site) {
+    const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t r0 = wv * rpw, r1 = r0 + rpw < rows ? r0 + rpw : rows;
+    float gm[4], ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int c = u * 64 + lane; gm[u] = c < C ? gamma[c] : 0.f; }
+    for (int64_t r = r0; r < r1; ++r) {
+        const float mu = mean[r], rs = rstd[r];
+        float s1 = 0.f, s2 = 0.f, xh[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = u * 64 + lane;
+            float gy = 0.f; xh[u] = 0.f;
+            if (c < C) {
+                const int64_t i = r * C + c;
+                gy = dy[i] * xva_dropout_scale(p, seed, site, (uint64_t)i) * gelu_d(nrm[i]);
+                xh[u] = (x[i] - mu) * rs;
+            }
+            g[u] = gy * gm[u];
+            s1 += g[u]; s2 += g[u] * xh[u];
+            ag[u] += gy * xh[u]; ab[u] += gy;
+        }
+        s1 = xva_wave_sum(s1) / C; s2 = xva_wave_sum(s2) / C;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int c = u * 64 + lane; if (c < C) dx[r * C + c] = rs * (g[u] - s1 - xh[u] * s2); }
+    }
+    __shared__ float sh[2][4][256];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { sh[0][w][u * 64 + lane] = ag[u]; sh[1][w][u * 64 + lane] = ab[u]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a += sh[0][q][c]; b += sh[1][q][c]; }
+        atomicAdd(dgamma + c, a); atomicAdd(dbeta + c, b);
+    }
+}
+// d W (C, C) += dt^T a ; d b (C) += column sums of dt, for the 1x1 convolution of a layer (rows x C operands, C <= 256): 32 x 32 output tiles, the row range
+// split over blockIdx.z, fp32 FMAs, one atomic per output and split.  Replaces a split-K product + its slab reduce + the column-sum launch on a (16 x 100) x 192
+// problem where each of the three was launch latency.
+__global__ __launch_bounds__(256) void dds_wgrad_kernel(const float* __restrict__ dt, const float* __restrict__ a, float* __restrict__ dW, float* __restrict__ db,
+                                                        int64_t rows, int C, int rows_per_split) {
+    __shared__ float sd[32][33], sa[32][33];
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int64_t r0 = (int64_t)blockIdx.z * rows_per_split, r1 = r0 + rows_per_split < rows ? r0 + rows_per_split : rows;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                 // thread: outputs (m0 + ty + 8 i, n0 + tx), i < 4
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs = 0.f;
+    for (int64_t r = r0; r < r1; r += 32) {
+        for (int i = ty; i < 32; i += 8) {                                  // tile rows r .. r + 31, columns m0.. / n0..
+            const int64_t rr = r + i;
+            sd[i][tx] = (rr < r1 && m0 + tx < C) ? dt[rr * C + m0 + tx] : 0.f;
+            sa[i][tx] = (rr < r1 && n0 + tx < C) ? a[rr * C + n0 + tx] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) {
+            const float av = sa[q][tx];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += sd[q][ty + 8 * i] * av;
+        }
+        if (blockIdx.x == 0 && ty == 0) {
+#pragma unroll 8
+            for (int q = 0; q < 32; ++q) bs += sd[q][tx];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int m = m0 + ty + 8 * i, n = n0 + tx; if (m < C && n < C) atomicAdd(dW + (int64_t)m * C + n, acc[i]); }
+    if (blockIdx.x == 0 && ty == 0 && m0 + tx < C) atomicAdd(db + m0 + tx, bs);
+}
+const bool g_fused = [] { const char* e = getenv("XVA_XVP_DDS_FUSED"); return e ? atoi(e) != 0 : true; }();
 }  // namespace
 
 extern "C" int64_t xva_xvp_dds_workspace_bytes(const xva_xvp_dds_dims* d) {
@@ -88,16 +219,29 @@ extern "C" int xva_xvp_dds_forward(const xva_xvp_dds_dims* d, const float* const
     for (int i = 0; i < d->L; i++, dil *= k) {
         const Lay& l = w.l[i];
         const float* const* p = prm + 8 * i;                       // convs_sep w (C, 1, k), b ; convs_1x1 w (C, C, 1), b ; norms_1 gamma, beta ; norms_2 gamma, beta
-        XVA_TRY(xva_dwconv_fwd(l.cur, p[0], p[1], l.t1, lens, B, T, C, k, dil, stream));                            // sdp.py:85
-        XVA_TRY(xva_ln_rows_fwd(l.t1, p[4], p[5], l.n1, l.m1, l.r1, rows, C, 1e-5f, stream));                       // :86
-        XVA_TRY(xva_gelu_fwd(l.n1, l.a1, n, stream));                                                               // :87
+        const bool fused = g_fused;
+        if (fused) {
+            hipLaunchKernelGGL(dds_front_kernel, dim3((unsigned)xva_cdiv(rows, 4)), dim3(256), 0, s, l.cur, p[0], p[1], p[4], p[5], l.t1, l.m1, l.r1, l.n1, l.a1, lens, rows, T, C,
+                               k, dil);                                                                             // sdp.py:85-87
+            XVA_LAUNCH_CHECK();
+        } else {
+            XVA_TRY(xva_dwconv_fwd(l.cur, p[0], p[1], l.t1, lens, B, T, C, k, dil, stream));                        // sdp.py:85
+            XVA_TRY(xva_ln_rows_fwd(l.t1, p[4], p[5], l.n1, l.m1, l.r1, rows, C, 1e-5f, stream));                   // :86
+            XVA_TRY(xva_gelu_fwd(l.n1, l.a1, n, stream));                                                           // :87
+        }
         xva_gemm_params q = gemm_base();                                                                            // :88
         q.A = l.a1; q.B = p[2]; q.C = l.t2; q.M = (int32_t)rows; q.N = C; q.K = C; q.lda = C; q.ldb = C; q.ldc = C; q.layout = XVA_GEMM_NT; q.bias = p[3];
         XVA_TRY(xva_gemm(&q, stream));
-        XVA_TRY(xva_ln_rows_fwd(l.t2, p[6], p[7], l.n2, l.m2, l.r2, rows, C, 1e-5f, stream));                       // :89
-        XVA_TRY(xva_gelu_fwd(l.n2, l.a2, n, stream));                                                               // :90
-        if (d->p_drop > 0.f) XVA_TRY(xva_dropout_apply(l.a2, l.nxt, 0, n, d->p_drop, d->seed, d->site0 + i, stream));   // :91
-        XVA_TRY(xva_fp_add_act(l.nxt, l.cur, 0, n, stream));                                                        // x = x + y (:92)
+        if (fused) {
+            hipLaunchKernelGGL(dds_back_kernel, dim3((unsigned)xva_cdiv(rows, 4)), dim3(256), 0, s, l.t2, p[6], p[7], l.cur, l.m2, l.r2, l.n2, l.nxt, rows, C, d->p_drop, d->seed,
+                               d->site0 + i);                                                                       // :89-92
+            XVA_LAUNCH_CHECK();
+        } else {
+            XVA_TRY(xva_ln_rows_fwd(l.t2, p[6], p[7], l.n2, l.m2, l.r2, rows, C, 1e-5f, stream));                   // :89
+            XVA_TRY(xva_gelu_fwd(l.n2, l.a2, n, stream));                                                           // :90
+            if (d->p_drop > 0.f) XVA_TRY(xva_dropout_apply(l.a2, l.nxt, 0, n, d->p_drop, d->seed, d->site0 + i, stream));   // :91
+            XVA_TRY(xva_fp_add_act(l.nxt, l.cur, 0, n, stream));                                                    // x = x + y (:92)
+        }
     }
     hipLaunchKernelGGL(copy_mask_kernel, dim3((unsigned)xva_cdiv(n / 4, 256)), dim3(256), 0, s, (const float4*)w.l[d->L - 1].nxt, (float4*)out, n / 4, C / 4, T, lens);   // :93
     XVA_LAUNCH_CHECK();
@@ -123,20 +267,41 @@ extern "C" int xva_xvp_dds_backward(const xva_xvp_dds_dims* d, const float* cons
         const Lay& l = w.l[i];
         const float* const* p = prm + 8 * i;
         float* const* gr = grd + 8 * i;
-        const float* da2 = dcur;
-        if (d->p_drop > 0.f) { XVA_TRY(xva_dropout_apply(dcur, w.da2, 0, n, d->p_drop, d->seed, d->site0 + i, stream)); da2 = w.da2; }
-        XVA_TRY(xva_gelu_bwd(l.n2, da2, w.dn2, n, stream));
-        XVA_TRY(xva_ln_rows_bwd(w.dn2, l.t2, l.m2, l.r2, p[6], w.dt2, gr[6], gr[7], rows, C, stream));
+        const bool fused = g_fused && C <= 256;
+        int rpw = (int)xva_cdiv(rows, 2048); rpw = rpw < 2 ? 2 : (rpw > 16 ? 16 : rpw);
+        const unsigned lnb = (unsigned)xva_cdiv(xva_cdiv(rows, rpw), 4);
+        if (fused) {
+            hipLaunchKernelGGL(dds_ln_bwd_kernel, dim3(lnb), dim3(256), 0, s, dcur, l.n2, l.t2, l.m2, l.r2, p[6], w.dt2, gr[6], gr[7], rows, C, rpw, d->p_drop, d->seed,
+                               d->site0 + i);
+            XVA_LAUNCH_CHECK();
+        } else {
+            const float* da2 = dcur;
+            if (d->p_drop > 0.f) { XVA_TRY(xva_dropout_apply(dcur, w.da2, 0, n, d->p_drop, d->seed, d->site0 + i, stream)); da2 = w.da2; }
+            XVA_TRY(xva_gelu_bwd(l.n2, da2, w.dn2, n, stream));
+            XVA_TRY(xva_ln_rows_bwd(w.dn2, l.t2, l.m2, l.r2, p[6], w.dt2, gr[6], gr[7], rows, C, stream));
+        }
         xva_gemm_params q = gemm_base();                                                                            // d a1 = d t2 W
         q.A = w.dt2; q.B = p[2]; q.C = w.da1; q.M = (int32_t)rows; q.N = C; q.K = C; q.lda = C; q.ldb = C; q.ldc = C; q.layout = XVA_GEMM_NN;
         XVA_TRY(xva_gemm(&q, stream));
-        xva_gemm_params t = gemm_base();                                                                            // d W += d t2^T a1
-        t.A = w.dt2; t.B = l.a1; t.C = gr[2]; t.M = C; t.N = C; t.K = (int32_t)rows; t.lda = C; t.ldb = C; t.ldc = C; t.layout = XVA_GEMM_TN; t.accumulate = 1; t.splitk = 0;
-        t.sk_ws = sk_ws; t.sk_ws_bytes = sk_ws_bytes;
-        XVA_TRY(xva_gemm(&t, stream));
-        XVA_TRY(xva_hg_colsum(w.dt2, 0, gr[3], rows, C, 1.f, stream));
-        XVA_TRY(xva_gelu_bwd(l.n1, w.da1, w.dn1, n, stream));
-        XVA_TRY(xva_ln_rows_bwd(w.dn1, l.t1, l.m1, l.r1, p[4], w.dt1, gr[4], gr[5], rows, C, stream));
+        if (fused) {                                                                                                // d W += d t2^T a1 ; d b += colsum(d t2)
+            const int rps = 224;
+            hipLaunchKernelGGL(dds_wgrad_kernel, dim3((unsigned)xva_cdiv(C, 32), (unsigned)xva_cdiv(C, 32), (unsigned)xva_cdiv(rows, rps)), dim3(256), 0, s, w.dt2, l.a1, gr[2],
+                               gr[3], rows, C, rps);
+            XVA_LAUNCH_CHECK();
+        } else {
+            xva_gemm_params t = gemm_base();
+            t.A = w.dt2; t.B = l.a1; t.C = gr[2]; t.M = C; t.N = C; t.K = (int32_t)rows; t.lda = C; t.ldb = C; t.ldc = C; t.layout = XVA_GEMM_TN; t.accumulate = 1; t.splitk = 0;
+            t.sk_ws = sk_ws; t.sk_ws_bytes = sk_ws_bytes;
+            XVA_TRY(xva_gemm(&t, stream));
+            XVA_TRY(xva_hg_colsum(w.dt2, 0, gr[3], rows, C, 1.f, stream));
+        }
+        if (fused) {
+            hipLaunchKernelGGL(dds_ln_bwd_kernel, dim3(lnb), dim3(256), 0, s, w.da1, l.n1, l.t1, l.m1, l.r1, p[4], w.dt1, gr[4], gr[5], rows, C, rpw, 0.f, (uint64_t)0, 0u);
+            XVA_LAUNCH_CHECK();
+        } else {
+            XVA_TRY(xva_gelu_bwd(l.n1, w.da1, w.dn1, n, stream));
+            XVA_TRY(xva_ln_rows_bwd(w.dn1, l.t1, l.m1, l.r1, p[4], w.dt1, gr[4], gr[5], rows, C, stream));
+        }
         float* dxb = i == 0 ? dx : w.dxb[i & 1];
         XVA_TRY(xva_dwconv_bwd(w.dt1, l.cur, p[0], dxb, gr[0], gr[1], lens, B, T, C, k, dil, stream));
         XVA_TRY(xva_fp_add_act(dxb, dcur, 0, n, stream));                                                           // d(x) = d(residual) + d(branch)
