@@ -354,9 +354,7 @@ class AcousticTrainPath:
         s_text, s_dur, s_pitch = self._streams(y.device)
         forked = s_text != main
         ev_in = main.record_event() if forked else None
-        z, m_q, logs_q, y_mask = self.posterior_encoder(y, y_lengths, g=g, eps=eps)                        # :698
-        if after_posterior is not None:          # the waveform decoder needs nothing but z: GeneratorPass starts it here, next to the rest of this path
-            after_posterior(z)
+        # the text encoder first: the longest chain ahead of the alignment (13 transformer layers of small products), and it needs nothing but the tokens
         if forked:
             s_text.wait_event(ev_in)
             _cross(s_text, tokens, x_lengths, lang, g, pitch_padded)
@@ -367,6 +365,9 @@ class AcousticTrainPath:
             x_mask = (torch.arange(Tt, device=y.device)[None, :] < x_lens[:, None]).float().unsqueeze(1)
             x = self.encoder(x_in * x_mask, x_mask)                                                        # (B, C + L, Tt) :1166
             stats = Mask.apply(Conv1x1.apply(x.transpose(1, 2).contiguous(), p["text_encoder.proj.weight"], p["text_encoder.proj.bias"]), x_lens)   # :1148
+        z, m_q, logs_q, y_mask = self.posterior_encoder(y, y_lengths, g=g, eps=eps)                        # :698
+        if after_posterior is not None:          # the waveform decoder needs nothing but z: GeneratorPass starts it here, next to the rest of this path
+            after_posterior(z)
         if self.pitch:
             if forked:
                 s_pitch.wait_stream(s_text)
