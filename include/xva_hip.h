@@ -465,6 +465,25 @@ int xva_wn_res_skip_fwd(const void* rs, const void* x, void* x_next, void* out, 
                         void* stream);
 int xva_wn_res_skip_bwd(const void* d_x, const void* d_out, void* d_rs, int dt, int B, int Tp, int pad, int H, int last, const int32_t* lens,
                         void* stream);
+/* The layer loop of WN (python/xvapitch/wavenet.py:84-109) as two engine calls over xva_gemm and the four kernels above.  Sequences are the time-major stores of
+ * xva-trainer_amd/xvapitch/wn.py:Seq: (2 * 32 guard rows + B * (8 + T + 8)) x C elements of dtype dt, pad / guard rows zero.  x: the stack's (masked) input, H columns;
+ * out: H columns, ZERO on entry (the skip sum accumulates into it); gc: (B, 2 H L) fp32 = cond_layer(g) or NULL; tab: host array of L * XVA_XVP_WN_PER_LAYER device
+ * pointers — per layer the in_layer's EFFECTIVE weight (2H, k H) tap-major in dt, its bias (fp32), the res_skip layer's effective weight (2H | H for the last, H), bias,
+ * then the fp32 buffers the backward ACCUMULATES into: d(in weight) (2H, k H), d(in bias), d(res_skip weight), d(res_skip bias).  backward: d_out (H columns; rows
+ * t >= len may hold anything), d_x: ZERO on entry, returns d(input); d_gc (B, 2 H L) fp32 accumulated (with gc).  With XVA_XVP_WN_LANE=1 the weight-gradient products, their bias sums and
+ * the conditioning gradient run on an engine-owned side stream, joined to `stream` before the call returns (default: everything on `stream`).
+ * workspace: xva_xvp_wn_workspace_bytes(), ZERO-FILLED before forward, handed unchanged to backward. */
+typedef struct xva_xvp_wn_dims {
+    int32_t B, T, H, k, rate, L;   /* hidden channels, kernel size, dilation rate, layers (<= 32) */
+    int32_t dt;                    /* storage of the sequences and effective weights: 0 fp32, 1 bf16 */
+    int32_t compute;               /* 0 exact fp32 products, 1 bf16 MFMA */
+} xva_xvp_wn_dims;
+#define XVA_XVP_WN_PER_LAYER 8
+int64_t xva_xvp_wn_workspace_bytes(const xva_xvp_wn_dims* d);
+int xva_xvp_wn_forward(const xva_xvp_wn_dims* d, const void* const* tab, const void* x, void* out, const float* gc, const int32_t* lens, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+int xva_xvp_wn_backward(const xva_xvp_wn_dims* d, void* const* tab, const void* x, const void* d_out, void* d_x, const float* gc, float* d_gc, const int32_t* lens,
+                        void* workspace, int64_t workspace_bytes, void* sk_ws, int64_t sk_ws_bytes, void* stream);
 /* maximum_path (python/xvapitch/util.py:14-53): value (B, t_x, t_y) fp32, x_lens / y_lens (B) -> path (B, t_x, t_y) fp32 of 0 / 1,
  * on the device (the reference runs it in numpy on the CPU each step).  workspace: xva_maximum_path_workspace_bytes. */
 int64_t xva_maximum_path_workspace_bytes(int B, int t_x, int t_y);

@@ -53,6 +53,39 @@ def test_wn_against_reference_golden(golden_dir, compute, tol):
         assert float(dead.abs().max()) == 0.0                       # output * x_mask
 
 
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("cond", [True, False], ids=["conditioned", "no conditioning"])
+def test_wn_engine_calls_equal_the_per_primitive_sequencing(compute, cond):
+    """csrc/xvp_wn.hip (xva_xvp_wn_forward / _backward: the layer loop as two C calls, the weight gradients on the engine's side stream) against the Python
+    sequencing of the same kernels (wn.py forward_seq / backward_seq, which the reference golden above pins): output, d x, d g and every parameter gradient."""
+    from xva_trainer_amd.xvapitch import wn as wmod
+    B, H, T, CIN, L, K = 3, 192, 53, 64, 4, 5
+    torch.manual_seed(9)
+    lens = np.array([53, 20, 41])
+    x0, g0, r = torch.randn(B, H, T).cuda(), torch.randn(B, CIN, 1).cuda(), torch.randn(B, H, T).cuda()
+    res = {}
+    for engine in (0, 1):
+        wn = wmod.WN(H, H, K, 1, L, c_in_channels=CIN if cond else 0, compute=compute, seed=2)
+        wn.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        gg = g0.clone().requires_grad_(True) if cond else None
+        old, wmod._WN_ENGINE = wmod._WN_ENGINE, engine
+        try:
+            y = wn(x, _mask(lens, T, "cuda"), g=gg)
+            (y * r).sum().backward()
+        finally:
+            wmod._WN_ENGINE = old
+        torch.cuda.synchronize()
+        res[engine] = (y.detach().clone(), x.grad.clone(), gg.grad.clone() if cond else None, {k: v.clone() for k, v in wn.grads().items()})
+    (y0, dx0, dg0, gr0), (y1, dx1, dg1, gr1) = res[0], res[1]
+    tol = 1e-6 if compute == "fp32" else 1e-6          # same kernels, same operands: only atomically summed vectors (the conditioning gradient) may re-associate
+    assert float(y0.abs().max()) > 0 and _rel(y1, y0) < tol and _rel(dx1, dx0) < tol, (_rel(y1, y0), _rel(dx1, dx0))
+    if cond:
+        assert _rel(dg1, dg0) < 1e-5
+    worst = sorted(((_rel(gr1[k], gr0[k]), k) for k in gr0), reverse=True)
+    assert worst[0][0] < 1e-5, worst[:4]
+
+
 def test_coupling_against_reference_golden(golden_dir):
     from xva_trainer_amd.xvapitch.wn import ResidualCouplingBlock
     g = _g(golden_dir)

@@ -58,6 +58,20 @@ lib.xva_hg_colsum.argtypes = [vp, i32, vp, i64, i32, f32, vp]
 PAD, GUARD = 8, 32
 
 
+class _WnDims(C.Structure):
+    """include/xva_hip.h xva_xvp_wn_dims"""
+    _fields_ = [("B", i32), ("T", i32), ("H", i32), ("k", i32), ("rate", i32), ("L", i32), ("dt", i32), ("compute", i32)]
+
+
+lib.xva_xvp_wn_workspace_bytes.restype = i64
+lib.xva_xvp_wn_workspace_bytes.argtypes = [C.POINTER(_WnDims)]
+lib.xva_xvp_wn_forward.restype = i32
+lib.xva_xvp_wn_forward.argtypes = [C.POINTER(_WnDims), vp, vp, vp, vp, vp, vp, i64, vp]
+lib.xva_xvp_wn_backward.restype = i32
+lib.xva_xvp_wn_backward.argtypes = [C.POINTER(_WnDims), vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]
+_WN_ENGINE = int(__import__("os").environ.get("XVA_XVP_WN_ENGINE", "1"))        # 0: the per-primitive sequencing of forward_seq / backward_seq (same kernels, one stream)
+
+
 class _SeqArena:
     """One zeroed slab the sequences of a training iteration are carved from.  A Seq is born all-zero (structural pad rows, guard rows, the
     accumulators of the residual / skip paths rely on it); as torch.zeros each costs an allocation and a fill launch, ~500 per xVAPitch iteration.
@@ -239,6 +253,21 @@ class WN:
             off += (c.dweff.numel() + 63) // 64 * 64
         self._descs = None
 
+    def _table(self):
+        """the engine's pointer table (csrc/xvp_wn.hip); the bias tensors move once, when FlatGroupAdamW re-homes them into its arenas"""
+        b0, g0 = self.in_layers[0].p["bias"], self.res_skip_layers[-1].g["bias"]
+        key = (b0.data_ptr(), g0.data_ptr(), _lib.PARAM_EPOCH[0])
+        if getattr(self, "_tab_key", None) != key:
+            ptrs = []
+            for i in range(self.L):
+                a, r = self.in_layers[i], self.res_skip_layers[i]
+                ptrs += [a.eff, a.p["bias"], r.eff, r.p["bias"], a.dweff, a.g["bias"], r.dweff, r.g["bias"]]
+            for t in ptrs:
+                if not t.is_contiguous() or not t.is_cuda:
+                    raise _lib.XvaError("WN: parameters / gradients must be contiguous device tensors")
+            self._tab, self._tab_key = (C.c_void_p * len(ptrs))(*[t.data_ptr() for t in ptrs]), key
+        return self._tab
+
     def _wn_batch(self, backward):
         convs = [c for _, c in self._named()]
         key = tuple(t.data_ptr() for c in (convs[0], convs[-1]) for t in (c.p["weight_v"], c.g["weight_v"]))
@@ -297,6 +326,17 @@ class WN:
             self._g_in = gq
         out = Seq(B, x.T, H, self.device, self.dtype)
         self._x, self._a, self._acts, self._gc, self._lens = [x], [], [], gc, lens
+        if _WN_ENGINE and H % 8 == 0 and self.L <= 32:
+            d = _WnDims(B, x.T, H, self.k, self.rate, self.L, x.dt, self.compute)
+            n = int(lib.xva_xvp_wn_workspace_bytes(C.byref(d)))
+            if n < 0:
+                raise _lib.XvaError("xva_xvp_wn_workspace_bytes: %s" % lib.xva_last_error().decode())
+            ws = _zeros((n + 3) // 4, 1, self.device, torch.float32)            # zeroed: from the iteration's sequence arena when there is one
+            _lib.check(lib.xva_xvp_wn_forward(C.byref(d), self._table(), C.c_void_p(x.store.data_ptr()), C.c_void_p(out.store.data_ptr()), _lib.ptr(gc), _lib.ptr(lens),
+                                              C.c_void_p(ws.data_ptr()), n, _lib.stream_ptr()), "xva_xvp_wn_forward")
+            self._eng = (d, ws, n)
+            return out
+        self._eng = None
         cur = x
         for i in range(self.L):
             a = Seq(B, x.T, 2 * H, self.device, self.dtype)
@@ -330,7 +370,15 @@ class WN:
         dt = d_out.dt
         d_x = Seq(B, d_out.T, H, self.device, self.dtype)          # gradient w.r.t. the running residual stream (zero after the last layer)
         d_gc = torch.zeros(B, 2 * H * self.L, device=self.device) if self._gc is not None else None
-        for i in reversed(range(self.L)):
+        engine = getattr(self, "_eng", None) is not None
+        if engine:
+            d, ws, n = self._eng
+            self._eng = None
+            sk = _lib.sk_scratch(self.device)
+            _lib.check(lib.xva_xvp_wn_backward(C.byref(d), self._table(), C.c_void_p(self._x[0].store.data_ptr()), C.c_void_p(d_out.store.data_ptr()),
+                                               C.c_void_p(d_x.store.data_ptr()), _lib.ptr(self._gc), _lib.ptr(d_gc), _lib.ptr(lens), C.c_void_p(ws.data_ptr()), n,
+                                               C.c_void_p(sk.data_ptr()), sk.numel(), _lib.stream_ptr()), "xva_xvp_wn_backward")
+        for i in (() if engine else reversed(range(self.L))):
             last = i == self.L - 1
             d_rs = Seq(B, d_out.T, H if last else 2 * H, self.device, self.dtype)
             _lib.check(lib.xva_wn_res_skip_bwd(C.c_void_p(d_x.view.data_ptr()), C.c_void_p(d_out.view.data_ptr()), C.c_void_p(d_rs.view.data_ptr()), dt, B,
