@@ -1,6 +1,7 @@
 """The xVAPitch (C5) twin of tools/dp_overlap_probe.py: one rank, the real BucketedSync path of the trainer's iteration — attach() before the generator
 backward (tensor hooks on the decoder's input and the flow's input), start_generator() after it, start_discriminator() after the discriminator pass —
-with all_reduce replaced by a marker kernel on the stream it is called on.  Under `rocprofv3 --kernel-trace`: when can each bucket's exchange start,
+with all_reduce replaced by a marker kernel on the stream it is called on (since the five-stream iteration: the discriminator pass runs inside the generator pass
+and start_discriminator() comes right after the forward pass, as in the trainer).  Under `rocprofv3 --kernel-trace`: when can each bucket's exchange start,
 relative to the generator backward?
 
     rocprofv3 --kernel-trace -d /tmp/t -o d -- python tools/dp_overlap_probe_c5.py ; python tools/trace_dump.py <db> out.csv ; python tools/dp_overlap_probe_c5.py --report out.csv"""
@@ -21,7 +22,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--report":
         bounds = [us(r) for r in seg if "sign_kernel" in r["name"] and "<16" not in r["name"]]   # the fp32 one the host enqueues: forward done | generator backward done | discriminator pass done
         ad = [us(r) for r in seg if r["name"].startswith("adamw_kernel")]
         print("iteration of %d us: generator forward ends at %s us, generator backward at %s us, discriminator pass at %s us, AdamW at %s us; "
-              "exchange markers start at %s us" % (round((int(seg[-1]["end_ns"]) - t0) / 1e3), *(bounds + ["?"] * 3)[:3], ad, marks))
+              "exchange markers start at %s us (first: the discriminator's bucket)" % (round((int(seg[-1]["end_ns"]) - t0) / 1e3), *(bounds + ["?"] * 3)[:3], ad, marks))
     sys.exit(0)
 
 import socket
@@ -49,15 +50,17 @@ step = g["step"]
 sync = BucketedSync(step)
 for _ in range(4):
     step.gen.zero_grad(); g["D"].zero_grad()
-    o = step.generator_pass(g["tokens"], g["x_lens"], g["y"], g["y_lens"], g["wav"], g["dvec"], g["lids"], pitch_padded=g["pitch"])
-    _bound.sign_()
+    # the trainer's order (xvapitch/xva_train.py iteration): the discriminator pass runs INSIDE the generator pass on the vocoder branch's stream, its bucket
+    # goes out before the generator backward starts
+    o = step.generator_pass(g["tokens"], g["x_lens"], g["y"], g["y_lens"], g["wav"], g["dvec"], g["lids"], pitch_padded=g["pitch"], eager_disc=True)
+    _bound.sign_()                                       # forward (+ discriminator pass) issued; main has joined the branch
+    ld = step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
+    sync.start_discriminator()
     sync.attach(o)
     o["loss"].backward()
     _bound.sign_()
     sync.start_generator()
-    ld = step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
     _bound.sign_()
-    sync.start_discriminator()
     sync.finish("gen"); sync.finish("disc")
     step.optimizer_step(lr=1e-6, lr_disc=1e-6)
 torch.cuda.synchronize()
