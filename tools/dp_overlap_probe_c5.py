@@ -19,9 +19,9 @@ if len(sys.argv) > 2 and sys.argv[1] == "--report":
         t0 = int(seg[0]["start_ns"])
         us = lambda r: round((int(r["start_ns"]) - t0) / 1e3)
         marks = [us(r) for r in seg if "sign_kernel" in r["name"] and "<16" in r["name"]]         # the int8 marker (16 elements per vector)
-        bounds = [us(r) for r in seg if "sign_kernel" in r["name"] and "<16" not in r["name"]]   # the fp32 one the host enqueues: forward done | generator backward done | discriminator pass done
+        bounds = [us(r) for r in seg if "sign_kernel" in r["name"] and "<16" not in r["name"]]   # the fp32 one the host enqueues: forward (+ discriminator pass) done | generator backward done | start_generator() done
         ad = [us(r) for r in seg if r["name"].startswith("adamw_kernel")]
-        print("iteration of %d us: generator forward ends at %s us, generator backward at %s us, discriminator pass at %s us, AdamW at %s us; "
+        print("iteration of %d us: generator forward ends at %s us, generator backward at %s us, the last generator bucket is issued at %s us, AdamW at %s us; "
               "exchange markers start at %s us (first: the discriminator's bucket)" % (round((int(seg[-1]["end_ns"]) - t0) / 1e3), *(bounds + ["?"] * 3)[:3], ad, marks))
     sys.exit(0)
 
