@@ -210,6 +210,40 @@ def golden_parity(leg, compute):
                 "loss_rel": abs(float(losses[0]) - float(g["loss"])) / abs(float(g["loss"])), "tolerance_north_star": 1e-3,
                 "metric": "max |x - ref| / max |ref| (mel_rel, pitch_pred_rel), relative L2 (mel_rel_l2), relative scalar error (loss_rel)"}
     from oracle import hifigan as ohg
+    if leg == "xvapitch":
+        # the whole C5 iteration's forward on the case recorded from the reference's own xVAPitch.train_step + VitsGeneratorLoss / VitsDiscriminatorLoss
+        # (oracle/gen_golden_xvapitch_*.py), in the timed mode: WaveNet stacks bf16-stored, the transformers' products bf16 MFMA, decoder / discriminator bf16
+        from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
+        from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+        from xva_trainer_amd.xvapitch.discriminator import VitsDiscriminator
+        from xva_trainer_amd.xvapitch.generator_pass import GeneratorPass
+        from xva_trainer_amd.xvapitch.train_step import XVAPitchStep
+        g, g5 = np.load(os.path.join(gdir, "xvapitch_genpass.npz")), np.load(os.path.join(gdir, "xvapitch_c5.npz"))
+        c = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+        ac = AcousticTrainPath(c["vocab"], c["langs"], latent_size=c["latent"], embedded_language_dim=c["lang_dim"], d_vector_dim=c["dvec"], hidden_channels_ffn=c["ffn"],
+                               num_heads=c["heads"], text_layers=c["te_layers"], posterior_layers=c["pe_layers"], flow_layers=c["flow_layers"], num_flows=c["num_flows"],
+                               spec_bins=c["spec_bins"], pitch=True, compute=compute)
+        ac.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")})
+        dec = VitsDecoder(c["latent"], c["dvec"], compute=compute)
+        dec.load_state_dict(ohg.init_vits_decoder_sd(int(g["dec_seed"]), c["latent"], c["dvec"]))
+        D = VitsDiscriminator(compute=compute)
+        D.load_state_dict(ohg.init_vits_disc_sd(int(g5["disc_seed"])))
+        step = XVAPitchStep(GeneratorPass(ac, dec, spec_segment_size=int(g["seg"])), D)
+        t = lambda k: torch.from_numpy(g[k]).cuda()
+        step.gen.zero_grad(); D.zero_grad()
+        o = step.generator_pass(t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("wav"), t("dvec"), t("lids"), pitch_padded=t("pitch"), eps=t("eps"), noise=t("noise"),
+                                slice_ids=t("slice_ids"), eager_disc=True)
+        o["loss"].backward()
+        ld = step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
+        names = ("loss_mel", "loss_kl", "loss_duration", "loss_pitch", "loss_gen", "loss_feat", "loss")
+        lr = {k: abs(float(o[k]) - float(g5[k])) / abs(float(g5[k])) for k in names}
+        lr["loss_disc"] = abs(float(ld) - float(g5["loss_disc"])) / abs(float(g5["loss_disc"]))
+        res = {"case": "tests/golden/xvapitch_genpass.npz + xvapitch_c5.npz (reference xVAPitch.train_step + both loss classes, one iteration, the reference's draws)", "mode": compute,
+               "wave_rel": rel2(o["model_outputs"].float(), torch.from_numpy(g5["model_outputs"])), "loss_rel": max(lr.values()), "loss_rel_by_name": lr,
+               "tolerance_north_star": 1e-3, "metric": "relative L2 of the decoded segment (wave_rel), worst relative error of the eight reported losses (loss_rel)"}
+        del step, ac, dec, D
+        torch.cuda.empty_cache()
+        return res
     from xva_trainer_amd.hifigan.step import HifiganStep
     g = np.load(os.path.join(gdir, "hg_step_b2.npz"))
     seed = int(g["seed"])
@@ -697,6 +731,10 @@ def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2, roofline=True, c
                                   "a ratio above 100 %% is that overlap; the iteration is a dependent chain of ~3 000 small launches, bound by their latency, not by MFMA or HBM rate"
                                   % (100.0 * ag["ms_per_step"] / ms)}
         res["roofline"] = r
+    try:
+        res["parity"] = golden_parity("xvapitch", "bf16")
+    except Exception as e:          # the leg's numbers stand without it; say why it is missing
+        res["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if cpu_base:
         res["cpu_baseline"] = xvapitch_cpu_baseline(ac, dec, D, tokens, x_lens, y_lens, wavs, wav_lens, dvec, lids, pitch, SEG)
     return res
