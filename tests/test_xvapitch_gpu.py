@@ -725,6 +725,8 @@ def test_c5_generator_and_discriminator_passes_against_reference_golden(golden_d
     o = step.generator_pass(t("tokens"), t("x_lens"), t("y"), t("y_lens"), t("wav"), t("dvec"), t("lids"), pitch_padded=t("pitch"), eps=t("eps"),
                             noise=t("noise"), slice_ids=t("slice_ids"), eager_disc=eager_disc)
     assert (step._eager is not None) == eager_disc          # the trainer's order: the discriminator pass has already run, inside the generator pass
+    if eager_disc:
+        step.gen.join()                                     # values are read BEFORE the backward pass here: the branch's stream has not been joined yet (late_join)
     assert _rel(o["model_outputs"], torch.from_numpy(g5["model_outputs"])) < 1e-3
     for k in ("loss_mel", "loss_kl", "loss_duration", "loss_pitch", "loss_gen", "loss_feat", "loss"):
         assert abs(float(o[k]) - float(g5[k])) < 1e-3 * abs(float(g5[k])), (k, float(o[k]), float(g5[k]))

@@ -43,6 +43,8 @@ class _JoinBranch(torch.autograd.Function):
     @staticmethod
     def forward(ctx, main_loss, branch_value, state):
         ctx.state = state
+        if branch_value is None:                                # late_join: the VALUE is written on the branch's stream (GeneratorPass.__call__)
+            return torch.empty_like(main_loss)
         return main_loss + branch_value
 
     @staticmethod
@@ -76,6 +78,13 @@ class GeneratorPass:
             self._side[key] = torch.cuda.Stream(device)
         return self._side[key]
 
+    def join(self, device=None):
+        """the current stream waits for the vocoder branch (values of a late_join forward pass read before / without the backward pass)"""
+        cur = torch.cuda.current_stream(device)
+        side = self.branch_stream(cur.device)
+        if side != cur:
+            cur.wait_stream(side)
+
     def zero_grad(self):
         self.acoustic.zero_grad()
         self.decoder.zero_grad()
@@ -89,14 +98,19 @@ class GeneratorPass:
         waveform = F.pad(wavs.float(), (0, Ty * 256 - wavs.size(1))).unsqueeze(1)
         return y, y_lengths, waveform
 
-    def __call__(self, tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=None, eps=None, noise=None, slice_ids=None, tail=None):
+    def __call__(self, tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=None, eps=None, noise=None, slice_ids=None, tail=None,
+                 late_join=False):
         """waveform (B, 1, Ty * 256).  slice_ids (B,): the segment starts (drawn like the reference's rand_segments when None).
         tail(model_outputs, waveform_seg) -> {name: loss}: further terms on the decoder's output (train_step: the adversarial ones), run inside the branch.
 
         Two streams.  Everything after the posterior encoder splits into two independent halves: the vocoder branch (segment of z -> waveform decoder ->
         mel / adversarial terms: a few engine calls, ~40 % of the iteration's device time, almost no host time) and the rest of the acoustic path (text
         encoder, flow, alignment, duration / pitch predictors, KL: thousands of small launches, host-bound).  On one stream the device idles through the
-        second while the first waits its turn; here the branch runs on its own stream from the moment z exists, forward and backward (_JoinBranch)."""
+        second while the first waits its turn; here the branch runs on its own stream from the moment z exists, forward and backward (_JoinBranch).
+        late_join: the caller's stream does NOT wait for the branch when the forward pass ends (with the discriminator pass inside it the branch is the
+        longer half: the acoustic path's backward would wait 3 ms for tensors it never reads).  The branch's tensors in `out` — model_outputs, waveform_seg,
+        its loss terms — and the VALUE of out["loss"] (summed on the branch's stream) are then complete only after out["loss"].backward(), which returns
+        joined, or after join()."""
         dev = y.device
         main, side = torch.cuda.current_stream(dev), self.branch_stream(dev)
         st = {"stream": side}
@@ -125,7 +139,9 @@ class GeneratorPass:
             st.update(zb=zb, loss=total, terms=terms, o=o, wav_seg=wav_seg, ids=ids, z_slice=z_slice)
 
         out = self.acoustic(tokens, x_lengths, y, y_lengths, d_vectors, language_ids, eps=eps, noise=noise, pitch_padded=pitch_padded, after_posterior=branch)
-        main.wait_stream(side)                                   # the caller reads the branch's tensors on its own stream
+        late = bool(late_join) and side != main and st["zb"].requires_grad
+        if not late:
+            main.wait_stream(side)                               # the caller reads the branch's tensors on its own stream
         for t in [st["o"], st["wav_seg"], st["ids"], st["z_slice"], st["loss"]] + list(st["terms"].values()):
             t.record_stream(main)
         zb = st["zb"]
@@ -138,7 +154,15 @@ class GeneratorPass:
                 zb.grad.record_stream(cur)
                 return gz + zb.grad
             out["z"].register_hook(join)
-            loss = _JoinBranch.apply(out["loss"], st["loss"].detach(), st)
+            if late:
+                loss = _JoinBranch.apply(out["loss"], None, st)
+                ev = main.record_event()                         # the acoustic path's terms are on the caller's stream
+                side.wait_event(ev)
+                with torch.cuda.stream(side), torch.no_grad():
+                    loss.copy_(out["loss"].detach() + st["loss"].detach())
+                out["loss"].record_stream(side); loss.record_stream(side)
+            else:
+                loss = _JoinBranch.apply(out["loss"], st["loss"].detach(), st)
         else:
             loss = out["loss"] + st["loss"]
         out.update(st["terms"])

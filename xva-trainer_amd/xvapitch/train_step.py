@@ -17,6 +17,8 @@ gradient to the generator; only loss_gen sends a gradient through the discrimina
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from .. import _lib
@@ -302,6 +304,9 @@ class BucketedSync:
             self._launch("gen", rest)
 
     def start_discriminator(self):
+        side = self.step.gen.branch_stream(self.step.disc.grad.device)     # eager_disc: the discriminator pass ran on the vocoder branch's stream, which nobody has joined yet
+        if side != torch.cuda.current_stream():
+            self.comm.wait_stream(side)
         self._launch("disc", [self.step.disc.grad])
 
     def finish(self, which):
@@ -323,7 +328,9 @@ class XVAPitchStep:
         """eager_disc: also run the DISCRIMINATOR pass (model.py:366-384) here, on the vocoder branch's stream right after the adversarial terms — it needs
         nothing but the decoder's detached output and the recording's segment, and the discriminator's parameters do not change before the optimiser steps
         at the end of the iteration, so its result is the one the reference computes after the generator's backward pass.  The caller zeroes the
-        discriminator's gradients BEFORE this call (the reference zeroes them at the start of pass 1) and collects the loss with discriminator_pass()."""
+        discriminator's gradients BEFORE this call (the reference zeroes them at the start of pass 1) and collects the loss with discriminator_pass().
+        With it the pass also returns WITHOUT joining the branch's stream (GeneratorPass late_join): the branch's tensors and the loss VALUES in `out` are
+        complete after out["loss"].backward() (which returns joined) or after self.gen.join()."""
         from .wn import seq_arena_begin
         seq_arena_begin(y.device)          # a new iteration: the previous one's sequences are dead, their slab is zeroed in one memset and reused
         self._eager = None
@@ -335,7 +342,7 @@ class XVAPitchStep:
                     self._eager = (o, wav_seg, self.disc.d_pass(wav_seg, o.detach()))
             return {"loss_gen": loss_gen, "loss_feat": loss_feat}                                               # losses.py:300: summed into "loss"
         out = self.gen(tokens, x_lengths, y, y_lengths, waveform, d_vectors, language_ids, pitch_padded=pitch_padded, eps=eps, noise=noise, slice_ids=slice_ids,
-                       tail=adversarial)
+                       tail=adversarial, late_join=bool(eager_disc) and os.environ.get("XVA_C5_LATE_JOIN", "1") != "0")
         if self._eager is not None:
             self._eager[2].record_stream(torch.cuda.current_stream(y.device))
         return out
