@@ -363,11 +363,17 @@ class AcousticTrainPath:
             x_in = torch.cat([x_emb, lang.unsqueeze(1).expand(B, Tt, L)], -1).transpose(1, 2)              # :1158-1163
             x_lens = x_lengths.to(device=y.device, dtype=torch.int32).contiguous()
             x_mask = (torch.arange(Tt, device=y.device)[None, :] < x_lens[:, None]).float().unsqueeze(1)
-            x = self.encoder(x_in * x_mask, x_mask)                                                        # (B, C + L, Tt) :1166
-            stats = Mask.apply(Conv1x1.apply(x.transpose(1, 2).contiguous(), p["text_encoder.proj.weight"], p["text_encoder.proj.bias"]), x_lens)   # :1148
+            xin = x_in * x_mask
+            started = self.encoder.start(xin, x_mask)                                                      # forward issued here; its autograd node is created below, AFTER the flow's
         z, m_q, logs_q, y_mask = self.posterior_encoder(y, y_lengths, g=g, eps=eps)                        # :698
         if after_posterior is not None:          # the waveform decoder needs nothing but z: GeneratorPass starts it here, next to the rest of this path
             after_posterior(z)
+        z_p = self.flow(z, y_mask, g=g)                                                                    # :723
+        with torch.cuda.stream(s_text):
+            # autograd issues backward nodes in reverse order of creation: created here, the text encoder's backward (one engine call) is issued BEFORE the
+            # flow's and the posterior encoder's and runs next to them instead of after them
+            x = self.encoder.attach(xin, x_mask, started)                                                  # (B, C + L, Tt) :1166
+            stats = Mask.apply(Conv1x1.apply(x.transpose(1, 2).contiguous(), p["text_encoder.proj.weight"], p["text_encoder.proj.bias"]), x_lens)   # :1148
         if self.pitch:
             if forked:
                 s_pitch.wait_stream(s_text)
@@ -376,7 +382,6 @@ class AcousticTrainPath:
             with torch.cuda.stream(s_pitch):
                 pin = torch.cat([x.detach(), g.expand(B, self.Dv, Tt)], 1)                                 # :836, model.py:1338-1340
                 pitch_pred = self.pitch_predictor(pin * x_mask, x_mask)                                    # (B, 1, Tt)
-        z_p = self.flow(z, y_mask, g=g)                                                                    # :723
         if self.pitch:                                                                                     # :752-755  z_p -= pitch_emb(pitch) * pe_scaling
             z_p = z_p - self._pitch_emb(pitch_padded) * self.pe_scaling
         if forked:

@@ -185,6 +185,34 @@ class RelativePositionTransformer:
     def __call__(self, x, x_mask):
         return _TransformerFn.apply(x, self, _lens_of(x, x_mask), _grad_hook(x.device))
 
+    def start(self, x, x_mask):
+        """Issue the forward pass NOW without creating the autograd node; attach() creates it later.  autograd runs backward nodes in reverse order of
+        creation: a stack whose forward has to be issued first (the text encoder: the alignment waits for it) would otherwise have its backward issued last.
+        Returns a handle for attach(), or None when the engine path is off (attach() then runs the forward pass itself)."""
+        if not _ENGINE:
+            return None
+        lens = _lens_of(x, x_mask)
+        with torch.no_grad():
+            xd = x.detach().float().contiguous()
+            B, _, T = xd.shape
+            d = self._dims(B, T)
+            n = int(lib.xva_xvp_tr_workspace_bytes(C.byref(d)))
+            if n < 0:
+                raise _lib.XvaError("xva_xvp_tr_workspace_bytes: %s" % lib.xva_last_error().decode())
+            ws = _zeros((n + 3) // 4, 1, self.device, torch.float32)
+            out = torch.empty(B, self.Co, T, device=xd.device)
+            prm, _ = self._tables()
+            _lib.check(lib.xva_xvp_tr_forward(C.byref(d), prm, _lib.ptr(xd), _lib.ptr(lens), _lib.ptr(out), C.c_void_p(ws.data_ptr()), n, _lib.stream_ptr()),
+                       "xva_xvp_tr_forward")
+        return (out, (d, ws, n, lens), lens)
+
+    def attach(self, x, x_mask, handle):
+        """the autograd node of a forward pass start() issued (same x): call on the stream start() ran on"""
+        if handle is None:
+            return self(x, x_mask)
+        out, state, lens = handle
+        return _TransformerFn.apply(x, self, lens, _grad_hook(x.device), (out, state))
+
     # ---- the engine calls (csrc/xvp_transformer.hip) ----
     def _tables(self):
         """(parameter, gradient) pointer tables in the engine's order; rebuilt when the tensors have moved (FlatGroupAdamW re-homes them into its arenas once)."""
@@ -374,9 +402,13 @@ class RelativePositionTransformer:
 
 class _TransformerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, tr, lens, hook=None):
+    def forward(ctx, x, tr, lens, hook=None, started=None):
         _lib.require_cuda(x)
         B, Cc, T = x.shape
+        if started is not None:                      # RelativePositionTransformer.start() has already run the forward pass on this input
+            out, state = started
+            ctx.tr, ctx.state = tr, state
+            return out
         if _ENGINE:
             d = tr._dims(B, T)
             n = int(lib.xva_xvp_tr_workspace_bytes(C.byref(d)))
@@ -407,10 +439,10 @@ class _TransformerFn(torch.autograd.Function):
             sk = _lib.sk_scratch(d_out.device)
             _lib.check(lib.xva_xvp_tr_backward(C.byref(d), prm, grd, _lib.ptr(d_out.float().contiguous()), _lib.ptr(lens), _lib.ptr(d_x), C.c_void_p(ws.data_ptr()),
                                                n, C.c_void_p(sk.data_ptr()), sk.numel(), _lib.stream_ptr()), "xva_xvp_tr_backward")
-            return d_x, None, None, None
+            return d_x, None, None, None, None
         B, Cc, T = ctx.dims
         ds = Seq(B, T, tr.Co, tr.device, torch.float32)
         _lib.check(ops.lib.xva_bct_to_seq(_lib.ptr(d_out.float().contiguous()), C.c_void_p(ds.view.data_ptr()), 0, B, tr.Co, T, PAD, None, _lib.stream_ptr()),
                    "xva_bct_to_seq")
         d_x = tr.backward_seq(ds)
-        return ops.seq_to_bct(d_x.view, T, PAD), None, None, None
+        return ops.seq_to_bct(d_x.view, T, PAD), None, None, None, None
