@@ -805,9 +805,14 @@ def test_transformer_engine_calls_equal_the_per_primitive_sequencing(cfg, p_drop
         res[engine] = (y.detach().clone(), x.grad.clone(), {k: v.clone() for k, v in tr.grads().items()})
     (y0, dx0, g0), (y1, dx1, g1) = res[False], res[True]
     assert float(y0.abs().max()) > 0 and float(dx0.abs().max()) > 0
-    assert _rel(y1, y0) < 1e-6 and _rel(dx1, dx0) < 1e-6, (_rel(y1, y0), _rel(dx1, dx0))
-    worst = sorted(((_rel(g1[k], g0[k]) if float(g0[k].abs().max()) > 0 else float(g1[k].abs().max()), k) for k in g0), reverse=True)
-    assert set(g0) == set(g1) and worst[0][0] < 1e-5, worst[:4]
+    # The engine splits its long-K products along K (fp32 re-association, 3e-7 on the product).  In "mixed" mode every product rounds its operands to bf16:
+    # a last-bit difference upstream flips roundings downstream, so two correct evaluations agree to bf16 noise, not to fp32 noise.
+    ty, tg = (1e-5, 1e-5) if cfg["compute"] == "fp32" else (2e-3, 2e-2)
+    assert _rel(y1, y0) < ty and _rel(dx1, dx0) < tg, (_rel(y1, y0), _rel(dx1, dx0))
+    # conv_k.bias: the softmax does not see a bias of the keys — its gradient is rounding noise around zero (the reference golden test skips it too)
+    worst = sorted(((_rel(g1[k], g0[k]) if float(g0[k].abs().max()) > 0 else float(g1[k].abs().max()), k) for k in g0 if not k.endswith("conv_k.bias")), reverse=True)
+    assert set(g0) == set(g1) and worst[0][0] < tg, worst[:4]
+    assert all(float(g1[k].abs().max()) < 1e-3 * float(g1[k.replace("conv_k", "conv_q")].abs().max()) for k in g1 if k.endswith("conv_k.bias"))
     dead = [k for k in g0 if float(g0[k].abs().max()) == 0]
     assert all(float(g1[k].abs().max()) == 0 for k in dead)            # out_channels == 1: the last layer's feed-forward / norm2 get no gradient in either
 
