@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 RD=${XVA_ROUND:-r04}
 O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+export XVA_BENCH_C5_INPROCESS=1   # the rocprofv3 runs of bench.py keep the xVAPitch leg in the traced process (one database); the plain reference line below unsets it
 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o b -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_final_bench_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_stats -name "*.db" | head -1) $O/${RD}_final_bench_kernel_stats.csv
 # the same two legs with the engines' stream lanes off (XVA_*_STREAMS=1): kernels do not overlap, so the per-kernel average durations are the
@@ -52,5 +53,5 @@ done
 cp $O/${RD}_fastpitch_pmc_hbm_bytes.meta.json $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.meta.json
 # the plain bench line last: its roofline.traffic / frac_rocprof read the tables just measured (same sources: fingerprint checked)
 cp $O/${RD}_*_pmc_hbm_bytes.csv $O/${RD}_*_pmc_hbm_bytes.meta.json $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.csv $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.meta.json $R/profiles/
-cd $R && python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/${RD}_final_bench.json
+cd $R && XVA_BENCH_C5_INPROCESS=0 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/${RD}_final_bench.json
 ls -la $O
