@@ -86,6 +86,18 @@ def test_wn_engine_calls_equal_the_per_primitive_sequencing(compute, cond):
     assert worst[0][0] < 1e-5, worst[:4]
 
 
+def test_wn_engine_weight_gradient_lane_in_a_process_that_switches_it_on():
+    """XVA_XVP_WN_LANE=1 (csrc/xvp_wn.hip: the weight-gradient products of the backward loop on the engine's side stream, ordered by events) is decided once per
+    process: the engine-against-sequencing test above, re-run in a child process with the switch on."""
+    import subprocess, sys
+    if os.environ.get("XVA_XVP_WN_LANE") == "1":
+        pytest.skip("already inside the child process")
+    env = dict(os.environ, XVA_XVP_WN_LANE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "test_wn_engine_calls_equal", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
 def test_coupling_against_reference_golden(golden_dir):
     from xva_trainer_amd.xvapitch.wn import ResidualCouplingBlock
     g = _g(golden_dir)
