@@ -597,6 +597,13 @@ int xva_xvp_dds_forward(const xva_xvp_dds_dims* d, const float* const* params, c
 int xva_xvp_dds_backward(const xva_xvp_dds_dims* d, const float* const* params, float* const* grads, const float* dy, const int32_t* lens, float* dx, void* workspace,
                          int64_t workspace_bytes, void* sk_ws, int64_t sk_ws_bytes, void* stream);
 
+/* Two pieces of ConvFlow's backward (python/xvapitch/sdp.py:116-176).  xva_small_wgrad: d W (M, N) += dy^T x and d b (M) += column sums of dy for a 1x1 convolution
+ * with small M, N (dy (rows, M), x (rows, N), fp32 FMAs, atomics) — the `proj` layer's gradients in one launch.  xva_cf_pre_bwd: the backward of `pre`
+ * (Conv1d(1, H, 1) on x0) joined with the assembly of d z (rows, 2): d z[r] = (sum_c dh[r, c] w[c] + d_x0_pass[r], d_x1[r]); d_pre_w / d_pre_b (H) accumulated. H <= 256. */
+int xva_small_wgrad(const float* dy, const float* x, float* dW, float* db, int64_t rows, int M, int N, void* stream);
+int xva_cf_pre_bwd(const float* dh, const float* pre_w, const float* x0, const float* d_x0_pass, const float* d_x1, float* dz, float* d_pre_w, float* d_pre_b, int64_t rows,
+                   int H, void* stream);
+
 /* Rational-quadratic spline with linear tails, forward direction: piecewise_rational_quadratic_transform(inverse=False, tails="linear") of
  * python/xvapitch/util.py:203-391 as ConvFlow uses it (sdp.py:151-167).  x, y, logdet: n elements; h: (n, 3K - 1) raw parameters
  * [K widths | K heights | K - 1 derivatives], widths / heights multiplied by wh_scale (= 1 / sqrt(hidden)) before their softmax.  K <= 16.

@@ -7,7 +7,7 @@ sys.argv = [sys.argv[0], "16", "100", "400", "bf16", "bf16"]
 g = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "c5_step_time.py"), run_name="c5")
 import torch
 from xva_trainer_amd.xvapitch import sdp, transformer, wn
-SW = {"wn": (wn, "_WN_ENGINE"), "tr": (transformer, "_ENGINE"), "dds": (sdp, "_DDS_ENGINE")}
+SW = {"wn": (wn, "_WN_ENGINE"), "tr": (transformer, "_ENGINE"), "dds": (sdp, "_DDS_ENGINE"), "cf": (sdp, "_CF_FUSED")}
 names = sorted(opts)
 combos = list(itertools.product(*[[int(v) for v in opts[n].split(",")] for n in names]))
 step, D = g["step"], g["D"]

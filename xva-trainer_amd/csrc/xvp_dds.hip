@@ -158,11 +158,11 @@ __global__ void dds_ln_bwd_kernel(const float* __restrict__ dy, const float* __r
         atomicAdd(dgamma + c, a); atomicAdd(dbeta + c, b);
     }
 }
-// d W (C, C) += dt^T a ; d b (C) += column sums of dt, for the 1x1 convolution of a layer (rows x C operands, C <= 256): 32 x 32 output tiles, the row range
-// split over blockIdx.z, fp32 FMAs, one atomic per output and split.  Replaces a split-K product + its slab reduce + the column-sum launch on a (16 x 100) x 192
-// problem where each of the three was launch latency.
-__global__ __launch_bounds__(256) void dds_wgrad_kernel(const float* __restrict__ dt, const float* __restrict__ a, float* __restrict__ dW, float* __restrict__ db,
-                                                        int64_t rows, int C, int rows_per_split) {
+// d W (M, N) += dt^T a ; d b (M) += column sums of dt, for the 1x1 convolutions (rows x M and rows x N operands, M, N <= a few hundred): 32 x 32 output tiles,
+// the row range split over blockIdx.z, fp32 FMAs, one atomic per output and split.  Replaces a split-K product + its slab reduce + the column-sum launch on a
+// (16 x 100) x 192 problem where each of the three was launch latency.
+__global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ dt, const float* __restrict__ a, float* __restrict__ dW, float* __restrict__ db,
+                                                          int64_t rows, int M, int N, int rows_per_split) {
     __shared__ float sd[32][33], sa[32][33];
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int64_t r0 = (int64_t)blockIdx.z * rows_per_split, r1 = r0 + rows_per_split < rows ? r0 + rows_per_split : rows;
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void dds_wgrad_kernel(const float* __restrict_
     for (int64_t r = r0; r < r1; r += 32) {
         for (int i = ty; i < 32; i += 8) {                                  // tile rows r .. r + 31, columns m0.. / n0..
             const int64_t rr = r + i;
-            sd[i][tx] = (rr < r1 && m0 + tx < C) ? dt[rr * C + m0 + tx] : 0.f;
-            sa[i][tx] = (rr < r1 && n0 + tx < C) ? a[rr * C + n0 + tx] : 0.f;
+            sd[i][tx] = (rr < r1 && m0 + tx < M) ? dt[rr * M + m0 + tx] : 0.f;
+            sa[i][tx] = (rr < r1 && n0 + tx < N) ? a[rr * N + n0 + tx] : 0.f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -188,8 +188,41 @@ __global__ __launch_bounds__(256) void dds_wgrad_kernel(const float* __restrict_
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int m = m0 + ty + 8 * i, n = n0 + tx; if (m < C && n < C) atomicAdd(dW + (int64_t)m * C + n, acc[i]); }
-    if (blockIdx.x == 0 && ty == 0 && m0 + tx < C) atomicAdd(db + m0 + tx, bs);
+    for (int i = 0; i < 4; ++i) { const int m = m0 + ty + 8 * i, n = n0 + tx; if (m < M && n < N) atomicAdd(dW + (int64_t)m * N + n, acc[i]); }
+    if (blockIdx.x == 0 && ty == 0 && m0 + tx < M) atomicAdd(db + m0 + tx, bs);
+}
+// backward of ConvFlow's `pre` (Conv1d(1, H, 1): h[r, c] = b[c] + x0[r] w[c]) joined with the assembly of d z: d z[r] = (sum_c dh[r, c] w[c] + d x0'[r], d x1[r]),
+// d w[c] += sum_r dh[r, c] x0[r], d b[c] += sum_r dh[r, c]   (H <= 256: a lane holds its four columns; a wave walks `rpw` rows; one atomic per column and workgroup)
+__global__ void cf_pre_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ w, const float* __restrict__ x0, const float* __restrict__ dx0p,
+                                  const float* __restrict__ dx1, float* __restrict__ dz, float* __restrict__ dw, float* __restrict__ db, int64_t rows, int H, int rpw) {
+    const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wi = threadIdx.x >> 6;
+    const int64_t r0 = wv * rpw, r1 = r0 + rpw < rows ? r0 + rpw : rows;
+    float wv4[4], aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int c = u * 64 + lane; wv4[u] = c < H ? w[c] : 0.f; }
+    for (int64_t r = r0; r < r1; ++r) {
+        const float xr = x0[r];
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = u * 64 + lane;
+            const float d = c < H ? dh[r * H + c] : 0.f;
+            s += d * wv4[u]; aw[u] += d * xr; ab[u] += d;
+        }
+        s = xva_wave_sum(s);
+        if (lane == 0) { dz[2 * r] = s + dx0p[r]; dz[2 * r + 1] = dx1[r]; }
+    }
+    __shared__ float sh[2][4][256];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { sh[0][wi][u * 64 + lane] = aw[u]; sh[1][wi][u * 64 + lane] = ab[u]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a += sh[0][q][c]; b += sh[1][q][c]; }
+        atomicAdd(dw + c, a); atomicAdd(db + c, b);
+    }
 }
 const bool g_fused = [] { const char* e = getenv("XVA_XVP_DDS_FUSED"); return e ? atoi(e) != 0 : true; }();
 }  // namespace
@@ -285,8 +318,8 @@ extern "C" int xva_xvp_dds_backward(const xva_xvp_dds_dims* d, const float* cons
         XVA_TRY(xva_gemm(&q, stream));
         if (fused) {                                                                                                // d W += d t2^T a1 ; d b += colsum(d t2)
             const int rps = 224;
-            hipLaunchKernelGGL(dds_wgrad_kernel, dim3((unsigned)xva_cdiv(C, 32), (unsigned)xva_cdiv(C, 32), (unsigned)xva_cdiv(rows, rps)), dim3(256), 0, s, w.dt2, l.a1, gr[2],
-                               gr[3], rows, C, rps);
+            hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)xva_cdiv(C, 32), (unsigned)xva_cdiv(C, 32), (unsigned)xva_cdiv(rows, rps)), dim3(256), 0, s, w.dt2, l.a1, gr[2],
+                               gr[3], rows, C, C, rps);
             XVA_LAUNCH_CHECK();
         } else {
             xva_gemm_params t = gemm_base();
@@ -307,5 +340,26 @@ extern "C" int xva_xvp_dds_backward(const xva_xvp_dds_dims* d, const float* cons
         XVA_TRY(xva_fp_add_act(dxb, dcur, 0, n, stream));                                                           // d(x) = d(residual) + d(branch)
         dcur = dxb;
     }
+    return XVA_OK;
+}
+
+// ---- two pieces of ConvFlow's backward (python/xvapitch/sdp.py:116-176) that were seven and four launches of torch glue -----------------------------------------
+extern "C" int xva_small_wgrad(const float* dy, const float* x, float* dW, float* db, int64_t rows, int M, int N, void* stream) {
+    XVA_CHECK_ARG(dy && x && dW && db && rows >= 0 && M > 0 && N > 0, "small_wgrad: bad arguments");
+    if (rows == 0) return XVA_OK;
+    const int rps = 224;
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)xva_cdiv(N, 32), (unsigned)xva_cdiv(M, 32), (unsigned)xva_cdiv(rows, rps)), dim3(256), 0, (hipStream_t)stream, dy, x, dW, db,
+                       rows, M, N, rps);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_cf_pre_bwd(const float* dh, const float* pre_w, const float* x0, const float* d_x0_pass, const float* d_x1, float* dz, float* d_pre_w, float* d_pre_b,
+                              int64_t rows, int H, void* stream) {
+    XVA_CHECK_ARG(dh && pre_w && x0 && d_x0_pass && d_x1 && dz && d_pre_w && d_pre_b && rows >= 0 && H > 0 && H <= 256, "cf_pre_bwd: bad arguments (H <= 256)");
+    if (rows == 0) return XVA_OK;
+    int rpw = (int)xva_cdiv(rows, 2048); rpw = rpw < 2 ? 2 : (rpw > 16 ? 16 : rpw);
+    hipLaunchKernelGGL(cf_pre_bwd_kernel, dim3((unsigned)xva_cdiv(xva_cdiv(rows, rpw), 4)), dim3(256), 0, (hipStream_t)stream, dh, pre_w, x0, d_x0_pass, d_x1, dz, d_pre_w, d_pre_b, rows,
+                       H, rpw);
+    XVA_LAUNCH_CHECK();
     return XVA_OK;
 }

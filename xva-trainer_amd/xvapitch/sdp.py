@@ -227,6 +227,11 @@ lib.xva_xvp_dds_backward.restype = C.c_int32
 lib.xva_xvp_dds_backward.argtypes = [C.POINTER(_DdsDims)] + [C.c_void_p] * 6 + [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
 _DDS_ENGINE = int(__import__("os").environ.get("XVA_XVP_DDS_ENGINE", "1"))      # 0: the per-primitive sequencing below (same kernels; the A / B and the tests' reference)
 _DDS_WS = {}
+_CF_FUSED = int(__import__("os").environ.get("XVA_XVP_CF_FUSED", "1"))        # ConvFlow backward: proj gradients / the pre backward + d z as one launch each
+lib.xva_small_wgrad.restype = C.c_int32
+lib.xva_small_wgrad.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+lib.xva_cf_pre_bwd.restype = C.c_int32
+lib.xva_cf_pre_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_void_p]
 
 
 def _dds_engine_ok(x, params):
@@ -412,6 +417,16 @@ class ConvFlowFn(torch.autograd.Function):
         _lib.check(lib.xva_seq_mask(P(dhp), 0, B, T, 0, NPp, P(lens), ST()), "xva_seq_mask")
         dh2 = torch.empty(B, T, H, device=dev)
         _prep((1, rows, H, NPp), lambda: _lib.PreparedGemm(dhp, wp, dh2, rows, H, NPp, NPp, H, H, layout=_lib.GEMM_NN, compute=0)).run(dhp, wp, dh2)
+        if _CF_FUSED and H <= 256:
+            wb = torch.zeros(NPp * H + NPp, device=dev)                             # d(proj weight | bias), one fill
+            dwp, dbp = wb[:NPp * H].view(NPp, H), wb[NPp * H:]
+            _lib.check(lib.xva_small_wgrad(P(dhp), P(h2), P(dwp), P(dbp), rows, NPp, H, ST()), "xva_small_wgrad")
+            dh, rets = _dds_bwd(dds_state, dh2)                                     # d(pre output) = d(conditioning g)
+            dh = dh.contiguous()
+            (gw, rw), (gb, rb) = _gbuf(pre_w), _gbuf(pre_b)
+            dz = torch.empty(B, T, 2, device=dev)
+            _lib.check(lib.xva_cf_pre_bwd(P(dh), P(pre_w.contiguous()), P(x0), P(dm), P(dx1), P(dz), P(gw), P(gb), rows, H, ST()), "xva_cf_pre_bwd")   # dm = [d x0 | d x1'] : its first half
+            return (dz, dh, None, None, (rw.view(pre_w.shape) if rw is not None else None), rb, dwp[:NP].reshape(proj_w.shape), dbp[:NP]) + tuple(rets)
         dwp = torch.zeros(NPp, H, device=dev)
         _prep((2, rows, H, NPp), lambda: _lib.PreparedGemm(dhp, h2, dwp, NPp, H, rows, NPp, H, H, layout=_lib.GEMM_TN, compute=0, accumulate=True,
                                                            splitk=0)).run(dhp, h2, dwp)
