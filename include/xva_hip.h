@@ -600,6 +600,15 @@ int xva_xvp_dds_backward(const xva_xvp_dds_dims* d, const float* const* params, 
 /* Two pieces of ConvFlow's backward (python/xvapitch/sdp.py:116-176).  xva_small_wgrad: d W (M, N) += dy^T x and d b (M) += column sums of dy for a 1x1 convolution
  * with small M, N (dy (rows, M), x (rows, N), fp32 FMAs, atomics) — the `proj` layer's gradients in one launch.  xva_cf_pre_bwd: the backward of `pre`
  * (Conv1d(1, H, 1) on x0) joined with the assembly of d z (rows, 2): d z[r] = (sum_c dh[r, c] w[c] + d_x0_pass[r], d_x1[r]); d_pre_w / d_pre_b (H) accumulated. H <= 256. */
+/* The rest of ConvFlow's glue, one launch each (z / out / d_out / dz: (B, T, 2); x0, x1, y1, ld: (B, T); h: (B, T, H); hp: (B, T, NPp = 3K - 1 rounded up to 4) the
+ * proj output, hs (B, T, NP = 3K - 1) the spline's parameters; dm (2, B, T) = [d x0 passed through | d y1]; lens = the rows of x_mask):
+ * pre_fwd: x0, x1 = z[..., 0], z[..., 1]; h = b + x0 w (sdp.py:149-150).  mask_slice: hs = hp[..., :NP] * x_mask (:153-154).  post_fwd: out = [x0, y1] * x_mask,
+ * ld *= x_mask (in place), ldsum[b] = sum_t ld (:170-175).  bwd_head / pad_mask: the mirror images in the backward pass. */
+int xva_cf_pre_fwd(const float* z, const float* pre_w, const float* pre_b, float* x0, float* x1, float* h, int64_t rows, int H, void* stream);
+int xva_cf_mask_slice(const float* hp, float* hs, int B, int T, int NPp, int NP, const int32_t* lens, void* stream);
+int xva_cf_post_fwd(const float* x0, const float* y1, float* ld, float* out, float* ldsum, int B, int T, const int32_t* lens, void* stream);
+int xva_cf_bwd_head(const float* d_out, const float* d_logdet, float* dm, float* d_ld, int B, int T, const int32_t* lens, void* stream);
+int xva_cf_pad_mask(const float* dhs, float* dhp, int B, int T, int NPp, int NP, const int32_t* lens, void* stream);
 int xva_small_wgrad(const float* dy, const float* x, float* dW, float* db, int64_t rows, int M, int N, void* stream);
 int xva_cf_pre_bwd(const float* dh, const float* pre_w, const float* x0, const float* d_x0_pass, const float* d_x1, float* dz, float* d_pre_w, float* d_pre_b, int64_t rows,
                    int H, void* stream);

@@ -363,3 +363,82 @@ extern "C" int xva_cf_pre_bwd(const float* dh, const float* pre_w, const float* 
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
+
+// ---- the rest of ConvFlow's glue (sdp.py:147-176), one launch where torch needed two to five -----------------------------------------------------------------------
+namespace {
+// z (rows, 2) -> x0, x1 (rows) contiguous and h (rows, H) = b + x0 w   (the `pre` Conv1d(1, H, 1))
+__global__ void cf_pre_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ x0, float* __restrict__ x1,
+                                  float* __restrict__ h, int64_t rows, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * H) return;
+    const int64_t r = i / H; const int c = (int)(i - r * H);
+    const float a = z[2 * r];
+    h[i] = b[c] + a * w[c];
+    if (c == 0) { x0[r] = a; x1[r] = z[2 * r + 1]; }
+}
+// hs (rows, NP) = hp (rows, NPp)[:, :NP] * x_mask
+__global__ void cf_mask_slice_kernel(const float* __restrict__ hp, float* __restrict__ hs, int64_t rows, int NPp, int NP, int T, const int32_t* __restrict__ lens) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * NP) return;
+    const int64_t r = i / NP; const int c = (int)(i - r * NP);
+    const int b = (int)(r / T), t = (int)(r - (int64_t)b * T);
+    hs[i] = t < lens[b] ? hp[r * NPp + c] : 0.f;
+}
+// out (rows, 2) = [x0, y1] * x_mask ; ld *= x_mask ; ldsum[b] = sum_t ld[b, t]      (one workgroup per item)
+__global__ void cf_post_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ y1, float* __restrict__ ld, float* __restrict__ out, float* __restrict__ ldsum, int T,
+                                   const int32_t* __restrict__ lens) {
+    __shared__ float sh[16];
+    const int b = blockIdx.x, len = lens[b];
+    float s = 0.f;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const int64_t r = (int64_t)b * T + t;
+        const bool live = t < len;
+        const float l = live ? ld[r] : 0.f;
+        ld[r] = l; s += l;
+        out[2 * r] = live ? x0[r] : 0.f; out[2 * r + 1] = live ? y1[r] : 0.f;
+    }
+    s = xva_block_sum(s, sh);
+    if (threadIdx.x == 0) ldsum[b] = s;
+}
+// d_out (rows, 2), d_logdet (B) -> d x0' (rows), d y1 (rows), d ld (rows), all * x_mask
+__global__ void cf_bwd_head_kernel(const float* __restrict__ d_out, const float* __restrict__ d_logdet, float* __restrict__ dm, float* __restrict__ d_ld, int64_t rows, int T,
+                                   const int32_t* __restrict__ lens) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int b = (int)(r / T), t = (int)(r - (int64_t)b * T);
+    const bool live = t < lens[b];
+    dm[r] = live ? d_out[2 * r] : 0.f; dm[rows + r] = live ? d_out[2 * r + 1] : 0.f;
+    d_ld[r] = live ? d_logdet[b] : 0.f;
+}
+// dhp (rows, NPp) = [dhs (rows, NP) * x_mask | 0]
+__global__ void cf_pad_mask_kernel(const float* __restrict__ dhs, float* __restrict__ dhp, int64_t rows, int NPp, int NP, int T, const int32_t* __restrict__ lens) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * NPp) return;
+    const int64_t r = i / NPp; const int c = (int)(i - r * NPp);
+    const int b = (int)(r / T), t = (int)(r - (int64_t)b * T);
+    dhp[i] = (c < NP && t < lens[b]) ? dhs[r * NP + c] : 0.f;
+}
+}  // namespace
+#define CF_LAUNCH(kernel, n, ...) do { hipLaunchKernelGGL(kernel, dim3((unsigned)xva_cdiv((n), 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); XVA_LAUNCH_CHECK(); return XVA_OK; } while (0)
+extern "C" int xva_cf_pre_fwd(const float* z, const float* pre_w, const float* pre_b, float* x0, float* x1, float* h, int64_t rows, int H, void* stream) {
+    XVA_CHECK_ARG(z && pre_w && pre_b && x0 && x1 && h && rows > 0 && H > 0, "cf_pre_fwd: bad arguments");
+    CF_LAUNCH(cf_pre_fwd_kernel, rows * H, z, pre_w, pre_b, x0, x1, h, rows, H);
+}
+extern "C" int xva_cf_mask_slice(const float* hp, float* hs, int B, int T, int NPp, int NP, const int32_t* lens, void* stream) {
+    XVA_CHECK_ARG(hp && hs && lens && B > 0 && T > 0 && NP > 0 && NPp >= NP, "cf_mask_slice: bad arguments");
+    CF_LAUNCH(cf_mask_slice_kernel, (int64_t)B * T * NP, hp, hs, (int64_t)B * T, NPp, NP, T, lens);
+}
+extern "C" int xva_cf_post_fwd(const float* x0, const float* y1, float* ld, float* out, float* ldsum, int B, int T, const int32_t* lens, void* stream) {
+    XVA_CHECK_ARG(x0 && y1 && ld && out && ldsum && lens && B > 0 && T > 0, "cf_post_fwd: bad arguments");
+    hipLaunchKernelGGL(cf_post_fwd_kernel, dim3((unsigned)B), dim3(128), 0, (hipStream_t)stream, x0, y1, ld, out, ldsum, T, lens);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_cf_bwd_head(const float* d_out, const float* d_logdet, float* dm, float* d_ld, int B, int T, const int32_t* lens, void* stream) {
+    XVA_CHECK_ARG(d_out && d_logdet && dm && d_ld && lens && B > 0 && T > 0, "cf_bwd_head: bad arguments");
+    CF_LAUNCH(cf_bwd_head_kernel, (int64_t)B * T, d_out, d_logdet, dm, d_ld, (int64_t)B * T, T, lens);
+}
+extern "C" int xva_cf_pad_mask(const float* dhs, float* dhp, int B, int T, int NPp, int NP, const int32_t* lens, void* stream) {
+    XVA_CHECK_ARG(dhs && dhp && lens && B > 0 && T > 0 && NP > 0 && NPp >= NP, "cf_pad_mask: bad arguments");
+    CF_LAUNCH(cf_pad_mask_kernel, (int64_t)B * T * NPp, dhs, dhp, (int64_t)B * T, NPp, NP, T, lens);
+}

@@ -232,6 +232,14 @@ lib.xva_small_wgrad.restype = C.c_int32
 lib.xva_small_wgrad.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
 lib.xva_cf_pre_bwd.restype = C.c_int32
 lib.xva_cf_pre_bwd.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_void_p]
+lib.xva_cf_pre_fwd.restype = C.c_int32
+lib.xva_cf_pre_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_void_p]
+lib.xva_cf_mask_slice.restype = lib.xva_cf_pad_mask.restype = C.c_int32
+lib.xva_cf_mask_slice.argtypes = lib.xva_cf_pad_mask.argtypes = [C.c_void_p] * 2 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p]
+lib.xva_cf_post_fwd.restype = C.c_int32
+lib.xva_cf_post_fwd.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+lib.xva_cf_bwd_head.restype = C.c_int32
+lib.xva_cf_bwd_head.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
 
 
 def _dds_engine_ok(x, params):
@@ -385,21 +393,36 @@ class ConvFlowFn(torch.autograd.Function):
         H, NP = pre_b.numel(), 3 * K - 1
         NPp = (NP + 3) // 4 * 4
         rows = B * T
-        zt = z.permute(2, 0, 1).contiguous()                                       # (2, B, T): x0 = zt[0], x1 = zt[1], both contiguous
-        x0, x1 = zt[0], zt[1]
-        h = torch.addcmul(pre_b.view(1, 1, H), x0.unsqueeze(-1), pre_w.view(1, 1, H))
+        fused = _CF_FUSED and H <= 256
+        if fused:
+            zc = z.contiguous()
+            xs = torch.empty(2, B, T, device=z.device); x0, x1 = xs[0], xs[1]
+            h = torch.empty(B, T, H, device=z.device)
+            _lib.check(lib.xva_cf_pre_fwd(P(zc), P(pre_w.contiguous()), P(pre_b), P(x0), P(x1), P(h), rows, H, ST()), "xva_cf_pre_fwd")
+        else:
+            zt = z.permute(2, 0, 1).contiguous()                                   # (2, B, T): x0 = zt[0], x1 = zt[1], both contiguous
+            x0, x1 = zt[0], zt[1]
+            h = torch.addcmul(pre_b.view(1, 1, H), x0.unsqueeze(-1), pre_w.view(1, 1, H))
         h2, dds_state = _dds_fwd(h, g, lens, dds_cfg, params)
         wp, bp = mod._proj_pad(proj_w, proj_b, NP, NPp, H)                          # persistent zero-padded copies (two small copies, no fills / cats)
         hp = torch.empty(B, T, NPp, device=z.device)
         _prep((0, rows, H, NPp, True), lambda: _lib.PreparedGemm(h2, wp, hp, rows, NPp, H, H, H, NPp, layout=_lib.GEMM_NT, compute=0, bias=bp)).run(h2, wp, hp, bias=bp)
-        _lib.check(lib.xva_seq_mask(P(hp), 0, B, T, 0, NPp, P(lens), ST()), "xva_seq_mask")
-        hs = hp[..., :NP].contiguous()
+        if fused:
+            hs = torch.empty(B, T, NP, device=z.device)
+            _lib.check(lib.xva_cf_mask_slice(P(hp), P(hs), B, T, NPp, NP, P(lens), ST()), "xva_cf_mask_slice")
+        else:
+            _lib.check(lib.xva_seq_mask(P(hp), 0, B, T, 0, NPp, P(lens), ST()), "xva_seq_mask")
+            hs = hp[..., :NP].contiguous()
         y1 = torch.empty_like(x1); ld = torch.empty_like(x1)
         _lib.check(lib.xva_rq_spline_fwd(P(x1), P(hs), P(y1), P(ld), x1.numel(), K, 1.0 / H ** 0.5, bound, ST()), "xva_rq_spline_fwd")
+        ctx.state = (dds_state, x0, x1, h2, wp, hs, lens, (B, T, H, K, NP, NPp, bound), (pre_w, pre_b, proj_w, proj_b))
+        if fused:
+            out = torch.empty(B, T, 2, device=z.device); ldsum = torch.empty(B, device=z.device)
+            _lib.check(lib.xva_cf_post_fwd(P(x0), P(y1), P(ld), P(out), P(ldsum), B, T, P(lens), ST()), "xva_cf_post_fwd")
+            return out, ldsum
         out = torch.stack([x0, y1], -1)
         _lib.check(lib.xva_seq_mask(P(out), 0, B, T, 0, 2, P(lens), ST()), "xva_seq_mask")
         _lib.check(lib.xva_seq_mask(P(ld), 0, B, T, 0, 1, P(lens), ST()), "xva_seq_mask")
-        ctx.state = (dds_state, x0, x1, h2, wp, hs, lens, (B, T, H, K, NP, NPp, bound), (pre_w, pre_b, proj_w, proj_b))
         return out, ld.sum(1)
 
     @staticmethod
@@ -407,17 +430,26 @@ class ConvFlowFn(torch.autograd.Function):
         dds_state, x0, x1, h2, wp, hs, lens, (B, T, H, K, NP, NPp, bound), (pre_w, pre_b, proj_w, proj_b) = ctx.state
         rows = B * T
         dev = x0.device
-        dm = d_out.permute(2, 0, 1).contiguous()                                    # (2, B, T)
-        _lib.check(lib.xva_seq_mask(P(dm), 0, 2 * B, T, 0, 1, P(torch.cat([lens, lens])), ST()), "xva_seq_mask")
-        d_ld = d_logdet.reshape(B, 1).expand(B, T).contiguous()
-        _lib.check(lib.xva_seq_mask(P(d_ld), 0, B, T, 0, 1, P(lens), ST()), "xva_seq_mask")
+        fused = _CF_FUSED and H <= 256
+        if fused:
+            dm = torch.empty(2, B, T, device=dev); d_ld = torch.empty(B, T, device=dev)
+            _lib.check(lib.xva_cf_bwd_head(P(d_out.contiguous()), P(d_logdet.contiguous().float()), P(dm), P(d_ld), B, T, P(lens), ST()), "xva_cf_bwd_head")
+        else:
+            dm = d_out.permute(2, 0, 1).contiguous()                                # (2, B, T)
+            _lib.check(lib.xva_seq_mask(P(dm), 0, 2 * B, T, 0, 1, P(torch.cat([lens, lens])), ST()), "xva_seq_mask")
+            d_ld = d_logdet.reshape(B, 1).expand(B, T).contiguous()
+            _lib.check(lib.xva_seq_mask(P(d_ld), 0, B, T, 0, 1, P(lens), ST()), "xva_seq_mask")
         dx1 = torch.empty_like(x1); dhs = torch.empty_like(hs)
         _lib.check(lib.xva_rq_spline_bwd(P(x1), P(hs), P(dm[1]), P(d_ld), P(dx1), P(dhs), x1.numel(), K, 1.0 / H ** 0.5, bound, ST()), "xva_rq_spline_bwd")
-        dhp = torch.nn.functional.pad(dhs, (0, NPp - NP))
-        _lib.check(lib.xva_seq_mask(P(dhp), 0, B, T, 0, NPp, P(lens), ST()), "xva_seq_mask")
+        if fused:
+            dhp = torch.empty(B, T, NPp, device=dev)
+            _lib.check(lib.xva_cf_pad_mask(P(dhs), P(dhp), B, T, NPp, NP, P(lens), ST()), "xva_cf_pad_mask")
+        else:
+            dhp = torch.nn.functional.pad(dhs, (0, NPp - NP))
+            _lib.check(lib.xva_seq_mask(P(dhp), 0, B, T, 0, NPp, P(lens), ST()), "xva_seq_mask")
         dh2 = torch.empty(B, T, H, device=dev)
         _prep((1, rows, H, NPp), lambda: _lib.PreparedGemm(dhp, wp, dh2, rows, H, NPp, NPp, H, H, layout=_lib.GEMM_NN, compute=0)).run(dhp, wp, dh2)
-        if _CF_FUSED and H <= 256:
+        if fused:
             wb = torch.zeros(NPp * H + NPp, device=dev)                             # d(proj weight | bias), one fill
             dwp, dbp = wb[:NPp * H].view(NPp, H), wb[NPp * H:]
             _lib.check(lib.xva_small_wgrad(P(dhp), P(h2), P(dwp), P(dbp), rows, NPp, H, ST()), "xva_small_wgrad")
