@@ -690,7 +690,7 @@ def xvapitch_c5_fresh_process(a, dev):
     return res
 
 
-def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=5, warm=2, roofline=True, cpu_base=True):
+def xvapitch_c5_leg(dev, B=16, Tt=100, Ty=400, iters=20, warm=3, roofline=True, cpu_base=True):
     """One xVAPitch training iteration (BASELINE configs[4] on one GPU: linear spectrograms from the raw clips, generator pass fwd + bwd,
     discriminator pass fwd + bwd, the two AdamW updates;
     xva-trainer_amd/xvapitch/train_step.py) at the reference's model size (python/xvapitch/model.py:55-149) on a synthetic batch with random weights,
