@@ -164,3 +164,48 @@ def test_bench_two_rank_dry_run_over_gloo():
     # whole-job aggregate: both ranks' frames (their shards differ by seed, so within a few percent of 2 x rank 0's) over the max-over-ranks time
     total = out["value"] * out["ms_per_step"] / 1e3
     assert 1.8 * per_rank < total < 2.2 * per_rank, (total, per_rank)
+
+
+def _load_bench():
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec = importlib.util.spec_from_file_location("xva_bench_module", os.path.join(root, "bench.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod, root
+
+
+def test_bench_contract_line_is_compact_and_complete():
+    """the stdout line of bench.py is the contract keys + `roofline` + `cpu_baseline` + one small object per extra leg, at most
+    MAX_LINE_BYTES (6 kB; the round-4 line was 25 kB and the driver could not read it back).  Built here from the full measurement committed as
+    profiles/r04_final_bench.json — the same dictionary `emit` receives — so the reduction is checked without a GPU."""
+    import json
+    bench, root = _load_bench()
+    full = json.load(open(os.path.join(root, "profiles", "r04_final_bench.json")))
+    s = bench.compact_line(full)
+    assert "\n" not in s and len(s) <= bench.MAX_LINE_BYTES <= 8192, len(s)
+    line = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and line["config"]["workload"] == full["config"]["workload"]
+    rf = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "algorithmic_gflop_per_launch", "algorithmic_mbytes_per_launch"):
+        assert k in rf, k
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    cb = line["cpu_baseline"]
+    assert set(cb) >= {"value", "unit", "cores", "kind"} and cb["kind"] in ("port", "reference")
+    for leg in ("hifigan", "xvapitch_c5", "fastpitch_fp32_parity", "hifigan_fp32_parity"):
+        assert "ms_per_step" in line[leg] and "parity" in line[leg], leg
+    assert line["hifigan"]["roofline_stack"]["frac"] == pytest.approx(full["hifigan"]["roofline_stack"]["frac"], rel=1e-4)
+    # nothing long survives: no tables, notes, methods or samples
+    assert not any(k in s for k in ('"by_kernel"', '"note"', '"method"', '"sample"'))
+    # a pathological input still yields a line under the bound, contract keys intact
+    fat = dict(full, config=dict(full["config"]), hifigan=dict(full["hifigan"], value=1.0))
+    fat["hbm_kernels"] = {("k%d" % i): {"frac": 0.1, "achieved": 1.0, "avg_launch_us": 2.0} for i in range(400)}
+    s2 = bench.compact_line(fat)
+    assert len(s2) <= bench.MAX_LINE_BYTES and json.loads(s2)["roofline"]["frac"] == rf["frac"]

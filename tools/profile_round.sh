@@ -3,7 +3,7 @@
 # (FETCH_SIZE / WRITE_SIZE, separate runs as MI355X_MICROARCH.md prescribes) per leg.  Everything lands in gpurun_out/final/.
 # usage (from the build container):  gpurun -- 'XVA_COMMIT=<short sha> XVA_ROUND=r04 bash tools/profile_round.sh'
 R=${GRAFT_REPO_ROOT:-$PWD}
-RD=${XVA_ROUND:-r04}
+RD=${XVA_ROUND:-r05}
 O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export XVA_BENCH_C5_INPROCESS=1   # the rocprofv3 runs of bench.py keep the xVAPitch leg in the traced process (one database); the plain reference line below unsets it
@@ -54,4 +54,5 @@ cp $O/${RD}_fastpitch_pmc_hbm_bytes.meta.json $O/${RD}_fastpitch_only_serial_lan
 # the plain bench line last: its roofline.traffic / frac_rocprof read the tables just measured (same sources: fingerprint checked)
 cp $O/${RD}_*_pmc_hbm_bytes.csv $O/${RD}_*_pmc_hbm_bytes.meta.json $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.csv $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.meta.json $R/profiles/
 cd $R && XVA_BENCH_C5_INPROCESS=0 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/${RD}_final_bench.json
+cp $R/bench_detail.json $O/${RD}_final_bench_detail.json   # the tables / notes behind the compact line
 ls -la $O
