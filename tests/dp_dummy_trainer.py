@@ -23,6 +23,7 @@ class DummyTrainer(RankMixin):
         self.request_stop()
 
     async def start(self, data, gpus=None, resume=False):
+        self._begin_run()
         self.running = True
         if not resume:
             self.data = data

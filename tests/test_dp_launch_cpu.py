@@ -127,6 +127,52 @@ def test_out_of_memory_restarts_the_group_with_a_smaller_base_batch(env, tmp_pat
     assert r0 == r1 == [(3.0, 9.0)]                                                                # 8 -> 5 (< 7): the second group trained
 
 
+@pytest.mark.timeout(300)
+def test_second_start_while_training_leaves_the_group_alone_and_a_dead_socket_does_not_strand_it(env, tmp_path):
+    """a `startTraining` / `resume` that arrives while the ranks train must neither remove the live group from models_bank nor close it
+    (the reference's trainer.start() just returns); a websocket that raises is logged and dropped; a pause forwarded while the ranks are already
+    parked does not end the next run early."""
+    import dp_dummy_trainer as T
+    from xva_trainer_amd.dp_launch import RankGroup
+
+    class _DeadWS(_WS):
+        async def send(self, msg):
+            raise ConnectionError("socket closed")
+    mm, ws, data = _mm(), _DeadWS(), _data(tmp_path, iters=100000, sleep=0.01)
+    second = {}
+
+    def poke():
+        while not isinstance(mm.models_bank.get("dummy"), RankGroup) or not mm.models_bank["dummy"].running:
+            time.sleep(0.05)
+        time.sleep(1.0)
+        group = mm.models_bank["dummy"]
+        second["start"] = asyncio.run(T.handleTrainer(mm, data, _WS(), gpus=[0, 1]))                    # a second start ...
+        second["resume"] = asyncio.run(T.handleTrainer(mm, data, _WS(), gpus=[0, 1], resume=True))      # ... and a stray resume
+        second["same"] = mm.models_bank.get("dummy") is group and group.running and all(p.poll() is None for p in group.procs)
+        time.sleep(0.3)
+        group.pause()
+    th = threading.Thread(target=poke)
+    th.start()
+    assert asyncio.run(T.handleTrainer(mm, data, ws, gpus=[0, 1])) is None                              # the relay error did not end the run
+    th.join()
+    assert second == {"start": None, "resume": None, "same": True}
+    group = mm.models_bank["dummy"]
+    assert group.parked and all(p.poll() is None for p in group.procs)
+    n0 = _ranks(data)[0][0][0]
+    group.pause()                                                # a double click: pause while parked
+    time.sleep(0.3)
+    ws2 = _WS()
+    th = threading.Thread(target=lambda: (time.sleep(1.5), mm.models_bank["dummy"].pause()))
+    th.start()
+    assert asyncio.run(T.handleTrainer(mm, data, ws2, gpus=[0, 1], resume=True)) is None
+    th.join()
+    r0, r1 = _ranks(data)
+    assert r0 == r1 and r0[1][0] - n0 > 20, (r0, n0)            # ran for the 1.5 s, not for the two iterations a stale request would leave
+    assert mm.models_bank["dummy"].websocket is ws2             # the resumed run relays to the socket that asked for it
+    mm.models_bank["dummy"].close()
+    del mm.models_bank["dummy"]
+
+
 def test_single_gpu_and_rank_workers_do_not_fan_out(monkeypatch):
     from xva_trainer_amd import dp_launch
     mm = _mm()

@@ -62,6 +62,16 @@ class RankMixin:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self._stop_req, self._stop_work, self._stop_flag = False, None, None
 
+    def _begin_run(self):
+        """Top of start(): a stop request left over from the previous run (a pause forwarded while the ranks were already parked, or after the agreement
+        was reached) must not end the next run two iterations in; a pending agreement is waited for, never abandoned."""
+        if getattr(self, "_stop_work", None) is not None:
+            try:
+                self._stop_work.wait()
+            except Exception:
+                pass
+        self._stop_req, self._stop_work, self._stop_flag = False, None, None
+
     def _init_distributed(self):
         """One process per GPU.  WORLD_SIZE > 1: join (or create) the process group.  A gpus list with several entries in a process that is not
         a rank worker never reaches this point through handleTrainer (dp_launch spawns the ranks); a direct trainer.start(gpus=[0, 1]) is refused —

@@ -31,6 +31,7 @@ import subprocess
 import sys
 import tempfile
 import threading
+import time
 import traceback
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -77,6 +78,10 @@ def _read_messages(q, rank, fd):
     q.put((rank, {"t": "eof"}))
 
 
+class AlreadyRunning(Exception):
+    """start() on a group whose workers are training: the caller leaves models_bank alone (the reference's trainer.start() just returns)."""
+
+
 class RankGroup(object):
     """What `models_bank[key]` holds in the server process while N rank workers train: the trainer surface server.py touches (`pause`, `start`,
     `running`, deletion) mapped onto the workers."""
@@ -90,11 +95,13 @@ class RankGroup(object):
         self.isReady, self.ckpt_path, self.model = True, "None", None
         self.procs, self.q, self._readers, self._logs = [], queue.Queue(), [], []
         self.parked = False                  # workers alive and idle after a pause
+        self.closed = False                  # close() ran: a pump still waiting on the queue gives up
         self.dataset_output = None
 
     # ---- process management ----
     def _spawn(self, data):
         port = _free_port()
+        self.closed = False
         self._tmp = tempfile.mkdtemp(prefix="xva_dp_")
         cfg = json.dumps({"key": self.key, "module": self.worker_module, "data": data, "PROD": bool(self.PROD)})
         for rank, gpu in enumerate(self.gpus):
@@ -137,6 +144,7 @@ class RankGroup(object):
         """End the workers ("stop" in server.py deletes the trainer from models_bank; so does every terminal path here).  kill: a rank failed — its
         peers are stranded in a collective and will not answer a command."""
         procs, self.procs = self.procs, []
+        self.closed = True
         for p in procs:
             if p.poll() is None:
                 try:
@@ -179,7 +187,7 @@ class RankGroup(object):
         """Returns (result, parked): rank 0's handleTrainer value, and whether the workers stay alive (paused).  Raises RuntimeError carrying a
         worker's traceback."""
         if self.running:
-            return None, self.parked
+            raise AlreadyRunning(self.key)
         if resume:
             if not self.parked:
                 raise RuntimeError("resume: the rank workers of '%s' are gone" % self.key)
@@ -190,6 +198,11 @@ class RankGroup(object):
         self.running, self.parked = True, False
         try:
             return await self._pump()
+        except RuntimeError:
+            raise
+        except BaseException:                      # anything else leaving the pump (cancellation, a relay error): no stranded workers
+            self.close(kill=True)
+            raise
         finally:
             self.running = False
 
@@ -204,6 +217,8 @@ class RankGroup(object):
                 return None
         while len(results) < self.world:
             item = await loop.run_in_executor(None, get)
+            if self.closed:                        # close() from another task (stop, a replaced group): nothing more will arrive
+                raise RuntimeError("the rank workers of '%s' were closed while training" % self.key)
             if item is None:
                 for r, p in enumerate(self.procs):
                     if p.poll() is not None and r not in results and r in eof:
@@ -213,7 +228,14 @@ class RankGroup(object):
             kind = msg.get("t")
             if kind == "ws":
                 if rank == 0 and self.websocket is not None:
-                    await self.websocket.send(msg["m"])
+                    try:
+                        await self.websocket.send(msg["m"])
+                    except Exception as e:         # a closed / stale UI socket must not strand the workers: log, drop, keep pumping
+                        self.websocket = None
+                        try:
+                            self.logger.info("dp_launch: websocket relay failed (%s: %s); messages dropped until the next resume" % (type(e).__name__, e))
+                        except Exception:
+                            pass
             elif kind == "result":
                 results[rank] = msg
             elif kind == "error":
@@ -240,8 +262,12 @@ async def handle_trainer(key, models_manager, data, websocket, gpus, resume=Fals
     """The body of the three packages' handleTrainer when it runs in the server process with several GPUs (or resumes such a run).
     worker_module: the module whose handleTrainer the workers run (default: the package registered for `key`; tests pass a stand-in)."""
     bank = models_manager.models_bank
+    live = bank.get(key)
+    if isinstance(live, RankGroup) and live.running:
+        return None                                # a second start / resume while training: the reference's trainer.start() just returns
     if resume:
         group = bank[key]
+        group.websocket = websocket                # the UI may have reconnected since the pause
     else:
         old = bank.get(key)
         if isinstance(old, RankGroup):
@@ -250,6 +276,8 @@ async def handle_trainer(key, models_manager, data, websocket, gpus, resume=Fals
         bank[key] = group
     try:
         result, parked = await group.start(data, gpus=gpus, resume=resume)
+    except AlreadyRunning:
+        return None
     except RuntimeError as e:
         bank.pop(key, None)
         if getattr(e, "xva_oom", False) and key == "fastpitch1_1" and int(data.get("batch_size", 0)) > 3:      # python/fastpitch1_1/xva_train.py:131-145
@@ -291,8 +319,22 @@ def worker_main():
     def pause_trainer():
         mm = state["mm"]
         tr = mm.models_bank.get(key) if mm is not None else None
-        if tr is not None and hasattr(tr, "pause"):
+        if tr is not None and hasattr(tr, "pause") and getattr(tr, "running", True):
             tr.pause()
+        elif tr is None and not state.get("early"):
+            # a pause that beats the trainer into models_bank (the worker is still importing / building it) is remembered and applied once
+            # the trainer runs — dropped silently, the UI would show "paused" over ranks that keep training
+            state["early"] = True
+
+            def later():
+                for _ in range(3000):
+                    t = state["mm"].models_bank.get(key) if state["mm"] is not None else None
+                    if t is not None and hasattr(t, "pause") and getattr(t, "running", False):
+                        t.pause()
+                        break
+                    time.sleep(0.1)
+                state["early"] = False
+            threading.Thread(target=later, daemon=True).start()
 
     def reader():
         for line in sys.stdin:

@@ -208,6 +208,7 @@ class FastPitchTrainer(RankMixin):
     async def start(self, data, gpus=None, resume=False):
         if self.running:
             return
+        self._begin_run()
         self.running = True
         if not resume:
             if gpus is not None:

@@ -103,6 +103,8 @@ def rand_segments(x, x_lengths=None, segment_size=4):
     """Random per-item start indices (torch.rand from the CPU generator, as the reference draws them: `torch.rand([B]).type_as(x)`) + the device gather.
     No host round trip: the draw travels through pinned memory without waiting for the stream, the too-short check is deferred (raise_deferred)."""
     B, _, T = x.size()
+    if T < segment_size:                    # shapes are on the host: a gather of S > T rows would leave the tensor (the per-item lengths stay deferred)
+        raise AssertionError(" [!] At least one sample is shorter than the segment size.")
     if x_lengths is None:
         x_lengths = torch.full((B,), T, device=x.device)
     max_idxs = x_lengths - segment_size + 1

@@ -96,6 +96,7 @@ def seq_arena_begin(device):
     if a.slab is None or need > a.cap or a.slab.device != device:
         a.cap = int(need * 1.25) + (64 << 20)
         a.slab = torch.zeros(a.cap, device=device, dtype=torch.uint8)
+        Seq._views.clear()                   # the cached views pin the slab they were cut from: a regrown arena must not keep the old one alive
     elif a.used:
         a.slab[:a.used].zero_()
     a.used, a.want, a.active = 0, 0, True

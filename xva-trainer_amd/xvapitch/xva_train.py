@@ -391,6 +391,7 @@ class xVAPitchTrainer(RankMixin):
     async def start(self, data, gpus=None, resume=False):
         if self.running:
             return
+        self._begin_run()
         self.running = True
         if not resume:
             if gpus is not None:
