@@ -314,6 +314,10 @@ int xva_fp_rowscale_colsum(const void* X, int dt, const float* s, float* out, in
 int xva_fp_dur_from_log(const float* logd, float* out, int n, float max_dur, void* stream);
 int xva_cast_f32(const float* src, void* dst, int dt, int64_t n, void* stream);
 int xva_cast_to_f32(const void* src, int dt, float* dst, int64_t n, void* stream);
+/* Transposed bf16 shadow of n (<= 16) tap-major k = 3 convolution weights: src = params + src_off[i], fp32 [Cout][3][Cin]; dst = out + dst_off[i]
+ * (elements), bf16 [Cin][3][Cout] with dst[c][m][o] = src[o][2 - m][c] — the weight of the convolution that maps d(output) to d(input), so the
+ * backward-data product of python/fastpitch1_1/fastpitch/transformer.py:59-77 (autograd of CoreNet's second Conv1d) runs the NT main loop. */
+int xva_fp_wt_transpose3(const float* params, void* out, const int64_t* src_off, const int64_t* dst_off, int n, int Cout, int Cin, void* stream);
 /* dst += src over n (even) elements of the activation dtype: joins the gradient contributions that the temporal predictors' backward
  * (python/fastpitch1_1/fastpitch/model.py:394-418) produces on its own stream into d(encoder output) */
 int xva_fp_add_act(void* dst, const void* src, int dt, int64_t n, void* stream);
@@ -408,6 +412,10 @@ int xva_vits_disc_backward_g(const xva_hg_dims* d, float* params_d, const float*
  * env XVA_HG_STREAMS / XVA_FP_STREAMS = 1 do the same at start-up. */
 int xva_hg_set_streams(int n);
 int xva_fp_set_streams(int n);
+/* FastPitch bf16 mode, backward-data of the feed-forward's second Conv1d (python/fastpitch1_1/fastpitch/transformer.py:59-77 under autograd):
+ * 1 (default) = through a transposed, tap-reversed bf16 copy of the weight refreshed with the parameter shadow (NT main loop), 0 = on the weight as
+ * stored (NN main loop).  Changes the workspace plan: set it before xva_fp_workspace_bytes.  Returns the previous mode.  env XVA_FP_BWD_NT. */
+int xva_fp_set_bwd_nt(int mode);
 /* Test / diagnostics: byte offset (into the caller's workspace) and geometry {nseq, T, C, padF, padB} of an activation tensor the last
  * forward stored, time-major (nseq, padF + T + padB, C) in the activation dtype.  kind: 0 mel input, 1 conv_pre output, 2 u[i0] (ups
  * output), 3 lrelu(u[i0]), 4 xt1[resblock i0][m i1] (= lrelu(c1(lrelu(x))), models.py:43-45), 5 / 6 x after block m and its lrelu copy,

@@ -400,3 +400,28 @@ def test_bf16_engine_end_to_end_within_the_noise_floor_of_bf16_storage(stage):
     cos = (a @ r / (a.norm() * r.norm())).item()
     cos_floor = (r64 @ r / (r64.norm() * r.norm())).item()
     assert 1 - cos < 2 * (1 - cos_floor) + 1e-5, (cos, cos_floor)
+
+
+def test_backward_data_through_transposed_weights_equals_the_stored_weight_form():
+    """Round 5: in the bf16 mode the feed-forward's second Conv1d (transformer.py:59-77) is differentiated w.r.t. its input through a transposed,
+    tap-reversed bf16 copy of the weight and the NT main loop (xva_fp_set_bwd_nt(1), the default) instead of the NN loop on the weight as stored.
+    Same bf16 products in the same K order: every gradient must agree to fp32 summation noise (and the default mode is what every other bf16 case
+    of this file runs against the oracle)."""
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd import _lib
+    sd = ofp.init_state_dict(11)
+    batch = ofp.synth_batch(3, 41, 300, 5)
+    res = {}
+    for mode in (1, 0):
+        old = _lib.lib.xva_fp_set_bwd_nt(mode)
+        try:
+            eng, flat, grads = build_engine(sd, "bf16")
+            _, losses = _run(eng, flat, grads, batch, 3)
+            res[mode] = (grads.clone(), losses.clone())
+        finally:
+            _lib.lib.xva_fp_set_bwd_nt(old)
+    g1, g0 = res[1][0].double(), res[0][0].double()
+    assert torch.equal(res[1][1], res[0][1])                                  # the forward pass does not change
+    assert g0.abs().max().item() > 0
+    assert ((g1 - g0).norm() / g0.norm()).item() < 1e-6
+    assert ((g1 - g0).abs().max() / g0.abs().max()).item() < 1e-5

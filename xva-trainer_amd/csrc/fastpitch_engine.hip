@@ -152,8 +152,14 @@ struct Plan {
     int64_t skws, skws2, skws3, skws_bytes;   // split-K slab scratch of the weight-gradient GEMMs (main stream / weight-gradient lane / predictor lane)
     int64_t gX1, gX2;   // d(encoder output) contributions of the energy / pitch predictors (predictor lane)
     int64_t wshadow;    // activation-dtype copy of the flat parameters (bf16 mode); unused in fp32 mode
+    int64_t wt_c2;      // bf16 mode: transposed, tap-reversed copies of the 2 x NL conv2 weights ([DI][3][DM] each; encoder layers first) for the NT backward-data form
     int64_t total;
 };
+
+// Backward-data of the feed-forward's second convolution through a transposed weight copy and the NT main loop (1, default) or the NN loop on the
+// weight as stored (0).  env XVA_FP_BWD_NT; A/B and test switch (the results differ by fp32 summation order only: same products, same K order).
+static int g_bwd_nt = [] { const char* e = getenv("XVA_FP_BWD_NT"); return e ? atoi(e) : 1; }();
+extern "C" int xva_fp_set_bwd_nt(int mode) { int old = g_bwd_nt; g_bwd_nt = mode; return old; }
 
 int make_plan(const xva_fp_dims* d, Plan* p) {
     XVA_CHECK_ARG(d && d->B > 0 && d->Tt > 0 && d->Tm > 0, "fastpitch: bad dims");
@@ -219,6 +225,7 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     p->gBm2 = drop ? b.seq(Rm, DM, es) : p->gB2; p->gDm2 = drop ? b.seq(Rm, DM, es) : p->gD2;
     p->gH2 = b.seq(Rm, DI, es); p->gQKV2 = b.seq(Rm, DQKV, es);
     p->wshadow = d->compute ? b.take(table().total * es) : -1;
+    p->wt_c2 = (d->compute && g_bwd_nt) ? b.take((int64_t)2 * NL * DI * 3 * DM * 2) : -1;
     p->total = b.cur;
     return XVA_OK;
 }
@@ -243,8 +250,26 @@ struct Ctx {
     float* F(int64_t off) const { return (float*)(W + off); }            // fp32 tensor at byte offset
     const void* wt(int64_t elem_off) const { return Pw + elem_off * es; } // parameter tensor as a GEMM operand
     char* sh(char* p, int64_t elems) const { return p + elems * es; }     // shift an activation pointer by elements
+    const void* wt_c2(const struct LayerP* LP, int l) const;              // transposed conv2 weight of layer l of stack LP (null: not planned)
 };
 
+const void* Ctx::wt_c2(const LayerP* LP, int l) const {
+    if (pl.wt_c2 < 0 || !compute) return nullptr;
+    const ParamTable& T = table();
+    const int idx = LP == T.enc ? l : (LP == T.dec ? NL + l : -1);
+    return idx < 0 ? nullptr : W + pl.wt_c2 + (int64_t)idx * DI * 3 * DM * 2;
+}
+// the transposed conv2 weights of both stacks from the fp32 parameters (one launch; see xva_fp_wt_transpose3)
+static int refresh_wt_c2(const Ctx& c, const float* params, void* st) {
+    if (c.pl.wt_c2 < 0) return XVA_OK;
+    const ParamTable& T = table();
+    int64_t so[2 * NL], dof[2 * NL];
+    for (int l = 0; l < NL; ++l) {
+        so[l] = T.enc[l].c2_w; dof[l] = (int64_t)l * DI * 3 * DM;
+        so[NL + l] = T.dec[l].c2_w; dof[NL + l] = (int64_t)(NL + l) * DI * 3 * DM;
+    }
+    return xva_fp_wt_transpose3(params, c.W + c.pl.wt_c2, so, dof, 2 * NL, DM, DI, st);
+}
 // Bucket i's gradients are final on the lane this context issues to: record its event there and, when the data-parallel host has registered a
 // callback, call it NOW — while the host is still issuing backward.  The host enqueues the bucket's wait + all-reduce from inside it.  Measured
 // (tools/dp_overlap_probe.py): a hipStreamWaitEvent issued only after the whole backward had been issued resolved when the recording lane had DRAINED —
@@ -316,10 +341,19 @@ static int conv3_fwd(Ctx& c, const char* X, int64_t rows, int Cin, int64_t w_off
     return xva_gemm(&g, c.st);
 }
 // dX[r] = sum_j dY[r-1+j] W[:, tap 2-j, :]  (gated by Gate > 0) (+R)
+// wt: a transposed, tap-reversed bf16 copy of the weight ([Cin][3][Cout], xva_fp_wt_transpose3) — the product then runs as the forward form of
+// the transposed convolution (NT main loop: k-contiguous weight rows)
 static int conv3_bwd_data(Ctx& c, const char* dY, int64_t rows, int Cout, int64_t w_off, int Cin, void* dX, const void* R,
-                          const void* Gate, int mask, const int32_t* lens, int Tp, int accumulate, int c_dt = -1) {
+                          const void* Gate, int mask, const int32_t* lens, int Tp, int accumulate, int c_dt = -1, const void* wt = nullptr) {
     xva_gemm_params g = gp0(c);
     if (c_dt >= 0) g.c_dtype = c_dt;
+    if (wt) {
+        g.layout = XVA_GEMM_NT; g.A = dY - (int64_t)Cout * c.es; g.B = wt; g.C = dX; g.M = (int)rows; g.N = Cin; g.K = 3 * Cout;
+        g.lda = Cout; g.ldb = 3 * Cout; g.ldc = Cin;
+        g.R = R; g.ldr = Cin; g.G = Gate; g.ldg = Cin; g.mask_mode = mask; g.lens = lens; g.Tp = Tp; g.accumulate = accumulate;
+        offer_split(c, g);
+        return xva_gemm(&g, c.st);
+    }
     g.layout = XVA_GEMM_NN; g.A = dY - (int64_t)Cout * c.es; g.B = c.wt(w_off); g.C = dX; g.M = (int)rows; g.N = Cin; g.K = 3 * Cout;
     g.lda = Cout; g.ldb = 3 * Cin; g.ldc = Cin; g.seglen = Cout; g.seg0 = 2 * Cin; g.segstride = -Cin;
     g.R = R; g.ldr = Cin; g.G = Gate; g.ldg = Cin; g.mask_mode = mask; g.lens = lens; g.Tp = Tp; g.accumulate = accumulate;
@@ -453,7 +487,7 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         XVA_TRY(xva_fp_layernorm_bwd(gA, c.A(a.sum2), c.F(a.mean2), c.F(a.rstd2), c.P + p.ln2_g, gB, drop ? gBm : nullptr, c.dt, Gg + p.ln2_g,
                                      Gg + p.ln2_b, R, DM, XVA_MASK_LEN, lens, Tp, 0, 0.f, 0, 0, c.pd, c.seed, s0 + 2, nullptr, nullptr, c.st));
         // conv2 backward: gH = (gBm (*) W2) * [h > 0], structural rows zero
-        XVA_TRY(conv3_bwd_data(c, gBm, R, DM, p.c2_w, DI, gH, nullptr, c.A(a.h), XVA_MASK_PAD, lens, Tp, 0));
+        XVA_TRY(conv3_bwd_data(c, gBm, R, DM, p.c2_w, DI, gH, nullptr, c.A(a.h), XVA_MASK_PAD, lens, Tp, 0, -1, c.wt_c2(LP, l)));
         // conv1 backward + residual: gC = gB + gH (*) W1, LEN-masked (y1 was multiplied by mask)
         XVA_TRY(conv3_bwd_data(c, gH, R, DI, p.c1_w, DM, gC, gB, nullptr, XVA_MASK_LEN, lens, Tp, 0));
         // LN1 backward -> gD = d sum1 ; gDm = gD * dropmask (o_net branch)
@@ -663,7 +697,11 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
             XVA_HIP_TRY(hipStreamWaitEvent(wl0.sp, wl0.pfork, 0));
             XVA_TRY(xva_cast_f32(params + T.enc_end, c.W + pl.wshadow + T.enc_end * c.es, c.dt, T.total - T.enc_end, wl0.sp));
             XVA_HIP_TRY(hipEventRecord(wl0.pmid, wl0.sp));
-        } else XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
+            XVA_TRY(refresh_wt_c2(c, params, wl0.sp));                     // read by backward only: behind the shadow, off the forward's critical path
+        } else {
+            XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
+            XVA_TRY(refresh_wt_c2(c, params, c.st));
+        }
     }
     // encoder                                                              (model.py:346)
     XVA_TRY(xva_fp_embed_fwd(bt->text, c.P + T.word_emb, bt->pos_table, c.A(pl.enc_x[0]), c.dt, B, pl.Tt, DM, c.st));
