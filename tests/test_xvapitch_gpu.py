@@ -1097,3 +1097,95 @@ def test_infer_against_reference_infer_golden(golden_dir, case):
     assert _rel(ac.last_infer["z"], torch.from_numpy(g[pre + "z"])) < 1e-3
     assert _rel(wav, ref) < 1e-3, _rel(wav, ref)
     assert ac.training                                                              # infer leaves the training flag as it found it
+
+
+def test_c5_benchmarked_schedule_at_full_size_equals_one_stream_and_the_four_clip_batch():
+    """the schedule bench.py times — B = 16 x 100 symbols x 400 frames at the reference's model size, throughput mode, five streams,
+    the discriminator pass inside the generator pass (eager_disc), late_join — checked at ITS size:
+      (i) the same batch on ONE stream (XVA_C5_STREAMS=0, XVA_C5_BRANCH_STREAM=0, XVA_C5_LATE_JOIN=0, engine lanes off, the discriminator pass after the
+          backward pass, as python/xvapitch/model.py:272-384 orders it) gives the same losses and the same gradients: a missing event wait or a tensor
+          freed under a side stream shows up here and nowhere at B = 4;
+      (ii) the batch is 4 copies each of 4 clips with the random draws replicated: every loss of the reference is a masked mean (numerator and normaliser
+          both scale by 4), so every loss and every parameter gradient must equal the 4-clip batch's — tile shapes, split-K factors and launch grids
+          differ between the two, so the bound is bf16 summation-order noise (the bound tests/test_fullsize_gpu.py uses for HiFi-GAN)."""
+    from xva_trainer_amd import _lib
+    from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
+    from xva_trainer_amd.xvapitch.decoder import VitsDecoder
+    from xva_trainer_amd.xvapitch.discriminator import VitsDiscriminator
+    from xva_trainer_amd.xvapitch.generator_pass import GeneratorPass
+    from xva_trainer_amd.xvapitch.train_step import XVAPitchStep
+    dev = torch.device("cuda")
+    VOCAB, LANGS, SEG, Tt, Ty = 256, 31, 32, 100, 400
+    gen = torch.Generator().manual_seed(5)
+    ac = AcousticTrainPath(VOCAB, LANGS, pitch=True, compute="bf16", device=dev, dropout_p=0.1, sdp_dropout_p=0.5)
+    dec, D = VitsDecoder(192, 512, compute="bf16", device=dev), VitsDiscriminator(compute="bf16", device=dev)
+    for eng in (dec, D):
+        sd = {k: torch.randn(shape, generator=gen) * 0.02 for k, (off, numel, shape) in eng.table.items()}
+        for k in list(sd):
+            if k.endswith("weight_g"):
+                v = sd[k[:-1] + "v"]
+                sd[k] = v.reshape(v.size(0), -1).norm(dim=1).reshape(sd[k].shape)
+        eng.load_state_dict(sd)
+    step = XVAPitchStep(GeneratorPass(ac, dec, SEG), D)
+    x4 = torch.tensor([100, 77, 60, 51]); y4 = torch.tensor([400, 333, 251, 140])
+    tok4 = torch.randint(1, VOCAB, (4, Tt), generator=gen) * (torch.arange(Tt)[None, :] < x4[:, None])
+    wl4 = (y4 - 1) * 256 + torch.randint(0, 256, (4,), generator=gen)
+    wav4 = torch.rand(4, (Ty - 1) * 256 + 255, generator=gen) * 0.1 - 0.05
+    wav4 = wav4 * (torch.arange(wav4.size(1))[None, :] < wl4[:, None])
+    dv4, li4 = torch.randn(4, 512, generator=gen), torch.randint(0, LANGS, (4,), generator=gen)
+    pit4 = (torch.rand(4, 1, Ty, generator=gen) * 3 - 1.2).clamp_min(0) * (torch.arange(Ty)[None, None, :] < y4[:, None, None])
+    eps4, noi4 = torch.randn(4, 192, Ty, generator=gen), torch.randn(4, 2, Tt, generator=gen)
+    ids4 = (torch.rand(4, generator=gen) * (y4 - SEG + 1)).long()
+    rep = torch.arange(16) % 4                               # clip 0 first (the longest): the padded sizes are the same in both batches
+    LOSSES = ("loss", "loss_kl", "loss_duration", "loss_pitch", "loss_mel", "loss_gen", "loss_feat")
+
+    def run(idx, eager):
+        c = lambda t: t[idx].contiguous().to(dev)
+        step.gen.zero_grad(); D.zero_grad()
+        y, yl, wav = step.gen.batch_from_wav(c(wav4), c(wl4))
+        o = step.generator_pass(c(tok4), c(x4), y, yl, wav, c(dv4), c(li4), pitch_padded=c(pit4), eps=c(eps4), noise=c(noi4), slice_ids=c(ids4), eager_disc=eager)
+        o["loss"].backward()
+        ld = step.discriminator_pass(o["model_outputs"].detach(), o["waveform_seg"])
+        torch.cuda.synchronize()
+        from xva_trainer_amd.xvapitch import ops
+        ops.raise_deferred()
+        res = {k: float(o[k]) for k in LOSSES}
+        res["loss_disc"] = float(ld)
+        g = {"ac/" + k: v.detach().float().clone() for k, v in ac.grads().items() if v is not None}
+        g["dec"] = dec.grad.detach().float().clone(); g["disc"] = D.grad.detach().float().clone()
+        return res, g, o["model_outputs"].detach().float().clone()
+
+    def compare(a, b, ltol, gtol, what):
+        (la, ga, oa), (lb, gb, ob) = a, b
+        for k in la:
+            assert abs(la[k] - lb[k]) <= ltol * abs(lb[k]), (what, k, la[k], lb[k])
+        assert set(ga) == set(gb) and len(ga) > 400
+        worst = sorted(((float((ga[k].double() - gb[k].double()).norm() / gb[k].double().norm().clamp_min(1e-30)), k) for k in ga
+                        if float(gb[k].abs().max()) > 0), reverse=True)
+        print("C5 full size, %s: worst gradient tensors (relative L2) %s of %d" % (what, worst[:3], len(worst)))
+        assert worst[0][0] < gtol, (what, worst[:5])
+        return oa, ob
+
+    full = run(rep, eager=True)                              # the benchmarked schedule
+    assert full[2].shape[0] == 16 and all(np.isfinite(v) for v in full[0].values())
+    # (i) one stream, reference order of the two passes
+    env = {"XVA_C5_STREAMS": "0", "XVA_C5_BRANCH_STREAM": "0", "XVA_C5_LATE_JOIN": "0"}
+    old = {k: os.environ.get(k) for k in env}
+    old_lanes = _lib.lib.xva_hg_set_streams(1)
+    os.environ.update(env)
+    try:
+        serial = run(rep, eager=False)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        _lib.lib.xva_hg_set_streams(old_lanes)
+    oa, ob = compare(full, serial, 1e-5, 1e-5, "five streams / eager_disc / late_join vs one stream")
+    assert _rel(oa, ob) < 1e-6
+    # (ii) 4 copies of 4 clips = the 4-clip batch
+    four = run(torch.arange(4), eager=True)
+    oa, ob = compare(full, four, 2e-3, 1e-2, "16 = 4 x 4 clips vs the 4-clip batch")
+    for b in range(4):
+        assert _rel(oa[b], ob[b]) < 1e-2 and _rel(oa[b + 12], ob[b]) < 1e-2

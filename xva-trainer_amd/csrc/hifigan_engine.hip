@@ -839,6 +839,16 @@ int conv0_fwd(Ctx& c, const float* Pd, const DiscRun& r, int i0, int ni) {
     return hg_conv_fwd(xc, t1, cw0(c, l0, Pd, r.pass), e, c.compute, c.st);
 }
 
+// conv0 straight from the waveform (hg_ops.hip hg_cin1_fwd8_kernel): no im2col launch, no K = 8 / 16 product.  XVA_HG_CONV0_DIRECT=0 keeps the GEMM form
+// (the im2col of the waveform is then made here; with the direct form the D-step backward makes it, for the weight gradient — once per iteration, not twice)
+static const int g_conv0_direct = [] { const char* e = getenv("XVA_HG_CONV0_DIRECT"); return e ? atoi(e) : 1; }();
+int conv0_any(Ctx& c, const float* Pd, const DiscRun& r, const float* wav, int i0, int ni) {
+    if (!g_conv0_direct) { XVA_TRY(conv0_im2col(c, r, wav, i0, ni)); return conv0_fwd(c, Pd, r, i0, ni); }
+    const Layer& l0 = c.pl.dl[r.li[0]];
+    Seq t1 = c.S(r.t[1]).slice(i0, ni);
+    return xva_hg_cin1_fwd(wav, eff32(c, l0, r.pass), Pd + l0.bias, t1.ptr(), c.dt, ni / r.p, r.Tw, r.p, l0.k, l0.s, l0.P, l0.Cout, t1.Hp(), t1.padF, SLOPE, c.st);
+}
+
 int sn_prepare(Ctx& c, float* Pd, const DiscRun& r) {
     // one power iteration for every spectral-norm layer of the discriminator: 5 launches for all 8 layers (hg_wn.h: xva_sn_desc)
     xva_sn_desc ds[XVA_SN_BATCH];
@@ -871,8 +881,7 @@ int sn_prepare(Ctx& c, float* Pd, const DiscRun& r) {
 // forward of sequences [i0, i0 + ni) (ni = nb * p) fed from waveform `wav` (nb items)
 int disc_forward(Ctx& c, const float* Pd, const DiscRun& r, const float* wav, int i0, int ni) {
     const auto& L = c.pl.dl;
-    XVA_TRY(conv0_im2col(c, r, wav, i0, ni));
-    XVA_TRY(conv0_fwd(c, Pd, r, i0, ni));
+    XVA_TRY(conv0_any(c, Pd, r, wav, i0, ni));
     for (int i = 1; i < r.n; ++i) {
         Seq x = c.S(r.t[i]).slice(i0, ni), y = c.S(r.t[i + 1]).slice(i0, ni);
         ConvEpi e;
@@ -909,7 +918,10 @@ int disc_backward_params(Ctx& c, const float* Pd, float* Gd, const DiscRun& r, i
     }
     const Layer& l0 = L[r.li[0]];
     Seq d1 = c.S(r.d[1]).slice(i0, ni), xc = c.S(r.xc[0]).slice(i0, ni);
-    (void)wav_a; (void)nb_a; (void)wav_b;   // the im2col of both waveforms is already in xc (forward)
+    if (g_conv0_direct) {   // the weight gradient's operand: the im2col of the waveform(s) feeding this slice (the GEMM form's forward leaves it in xc)
+        XVA_TRY(conv0_im2col(c, r, wav_a, i0, nb_a * r.p));
+        if (wav_b) XVA_TRY(conv0_im2col(c, r, wav_b, i0 + nb_a * r.p, ni - nb_a * r.p));
+    }
     XVA_TRY(hg_conv_bwd_weight(d1, xc, cw0(c, l0, Pd, r.pass), 0, 0.f, 1.f, c.compute, c.st));
     defer_colsum(d1, Gd + l0.bias);
     return XVA_OK;
@@ -1035,9 +1047,14 @@ int discs_forward(Ctx& c0, float* Pd, const float* yr, const float* yg, float* l
         } else {
             // im2col per half (different waveforms), then every layer jointly over real + fake
             const auto& L = c.pl.dl;
-            XVA_TRY(conv0_im2col(c, s.run, s.wr, 0, s.nf));
-            XVA_TRY(conv0_im2col(c, s.run, s.wg, s.nf, s.nf));
-            XVA_TRY(conv0_fwd(c, Pd, s.run, 0, 2 * s.nf));
+            if (g_conv0_direct) {
+                XVA_TRY(conv0_any(c, Pd, s.run, s.wr, 0, s.nf));
+                XVA_TRY(conv0_any(c, Pd, s.run, s.wg, s.nf, s.nf));
+            } else {
+                XVA_TRY(conv0_im2col(c, s.run, s.wr, 0, s.nf));
+                XVA_TRY(conv0_im2col(c, s.run, s.wg, s.nf, s.nf));
+                XVA_TRY(conv0_fwd(c, Pd, s.run, 0, 2 * s.nf));
+            }
             for (int i = 1; i < s.run.n; ++i) {
                 Seq x = c.S(s.run.t[i]), y = c.S(s.run.t[i + 1]);
                 ConvEpi e;
