@@ -416,6 +416,9 @@ int xva_fp_set_streams(int n);
  * 1 (default) = through a transposed, tap-reversed bf16 copy of the weight refreshed with the parameter shadow (NT main loop), 0 = on the weight as
  * stored (NN main loop).  Changes the workspace plan: set it before xva_fp_workspace_bytes.  Returns the previous mode.  env XVA_FP_BWD_NT. */
 int xva_fp_set_bwd_nt(int mode);
+/* bf16 LayerNorm rows of 384 channels (python/fastpitch1_1/fastpitch/transformer.py:75,146): 1 (default) = the forward takes four rows per wavefront with 16-byte
+ * accesses, 0 = one row per wavefront (the backward always does).  Same arithmetic per row; the row sums are taken over a different lane order (fp32 rounding only).  env XVA_FP_LN4. */
+int xva_fp_set_ln4(int mode);
 /* Test / diagnostics: byte offset (into the caller's workspace) and geometry {nseq, T, C, padF, padB} of an activation tensor the last
  * forward stored, time-major (nseq, padF + T + padB, C) in the activation dtype.  kind: 0 mel input, 1 conv_pre output, 2 u[i0] (ups
  * output), 3 lrelu(u[i0]), 4 xt1[resblock i0][m i1] (= lrelu(c1(lrelu(x))), models.py:43-45), 5 / 6 x after block m and its lrelu copy,

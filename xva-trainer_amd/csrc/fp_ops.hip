@@ -357,11 +357,107 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const voi
     }
 }
 
+// ---- round 5: bf16 rows of 384 channels, FOUR rows per wave ------------------------------------------------------------------------------
+// A 384-channel bf16 row is 768 bytes: with one row per wave a lane moves 3 x 4 bytes and a wave instruction 256 bytes — 27 584 rows were 27 584
+// waves of {3 narrow loads -> two wave reductions -> 3 narrow stores}, 13 us for 42 MB (3.2 TB/s).  Four consecutive rows are 3 072 contiguous bytes =
+// 64 lanes x 3 x 16 bytes: lane l's chunk j holds elements (512 j + 8 l) ... + 7 of the group, i.e. row (512 j + 8 l) / 384 and columns
+// (512 j + 8 l) % 384 ... — the same columns for every group, so gamma / beta (and the backward's dgamma / dbeta sums) live in registers.  The four
+// row sums are masked wave reductions (the same two reductions per row as before); every load / store is a full 1 KB wave instruction.
+constexpr int LN4_C = 384;
+__device__ __forceinline__ void ln4_unpack(const uint4& r, float (&o)[8]) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(w[e] << 16); o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint32_t ln4_pack2(float a, float b) {
+    uint32_t x = __float_as_uint(a), y = __float_as_uint(b);
+    x += 0x7fffu + ((x >> 16) & 1u); y += 0x7fffu + ((y >> 16) & 1u);
+    return (x >> 16) | (y & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 ln4_pack(const float (&v)[8]) { return make_uint4(ln4_pack2(v[0], v[1]), ln4_pack2(v[2], v[3]), ln4_pack2(v[4], v[5]), ln4_pack2(v[6], v[7])); }
+// a[r] for a per-lane r in 0 .. 3 without indexing the register array dynamically (that would move it to scratch)
+__device__ __forceinline__ float ln4_sel(const float (&a)[4], int r) { return r == 0 ? a[0] : (r == 1 ? a[1] : (r == 2 ? a[2] : a[3])); }
+__device__ __forceinline__ bool ln4_selb(const bool (&a)[4], int r) { return r == 0 ? a[0] : (r == 1 ? a[1] : (r == 2 ? a[2] : a[3])); }
+// sums of a per-(chunk, lane) value over the lanes of each of the group's four rows: out[r]
+__device__ __forceinline__ void ln4_rowsums(const float (&part)[3], const int (&rw)[3], float (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t += rw[j] == r ? part[j] : 0.f;
+        out[r] = xva_wave_sum(t);
+    }
+}
+__global__ __launch_bounds__(256) void layernorm_fwd4_kernel(const uint16_t* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             uint16_t* __restrict__ Y, float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
+                                                             int mask_mode, const int* __restrict__ lens, int Tp, float eps) {
+    constexpr int C = LN4_C;
+    const int lane = threadIdx.x & 63;
+    const int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row0 = grp * 4;
+    if (row0 >= rows) return;
+    int rw[3], cl[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const int e = 512 * j + 8 * lane; rw[j] = e / C; cl[j] = e - rw[j] * C; }
+    float v[3][8];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (row0 + rw[j] < rows) raw = *reinterpret_cast<const uint4*>(X + row0 * C + 512 * j + 8 * lane);
+        ln4_unpack(raw, v[j]);
+    }
+    float part[3], mu4[4], var4[4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { part[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[j] += v[j][e]; }
+    ln4_rowsums(part, rw, mu4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mu4[r] *= (1.f / C);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const float mu = ln4_sel(mu4, rw[j]); part[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mu; part[j] += d * d; } }
+    ln4_rowsums(part, rw, var4);
+    float rs4[4]; bool live4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rs4[r] = rsqrtf(var4[r] * (1.f / C) + eps); live4[r] = row0 + r < rows && xva_row_live(mask_mode, lens, Tp, row0 + r); }
+    if (lane < 4 && row0 + lane < rows) { mean[row0 + lane] = mu4[lane]; rstd[row0 + lane] = rs4[lane]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (row0 + rw[j] >= rows) continue;
+        const float mu = ln4_sel(mu4, rw[j]), rs = ln4_sel(rs4, rw[j]);
+        const bool live = ln4_selb(live4, rw[j]);
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + cl[j]), g1 = *reinterpret_cast<const float4*>(gamma + cl[j] + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + cl[j]), b1 = *reinterpret_cast<const float4*>(beta + cl[j] + 4);
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = live ? (v[j][e] - mu) * rs * gm[e] + bt[e] : 0.f;
+        *reinterpret_cast<uint4*>(Y + row0 * C + 512 * j + 8 * lane) = ln4_pack(y);
+    }
+}
+
+// The BACKWARD stays on the one-row-per-wave kernel below (16 waves per workgroup, two packed rows in flight per wave: 28 us for the decoder rows).  Two
+// wider forms were built and measured in round 5 and are not kept: four rows per wave like the forward (24 + 24 dgamma / dbeta column sums per lane next to
+// the loads in flight: 250 VGPRs, two waves per SIMD — 58 us) and two rows per wave, one per half-wave with 12 fixed columns per lane and 8-byte accesses
+// (168 VGPRs, 12 waves per workgroup — 44 us).  The kernel is bound by rows in flight per CU, and the per-lane column sums are what limits those.
+// 1 (default): bf16 rows of 384 channels take the four-rows-per-wave forward kernel above; 0: one row per wave.  env XVA_FP_LN4 (A/B, tests)
+static int g_ln4 = [] { const char* e = getenv("XVA_FP_LN4"); return e ? atoi(e) : 1; }();
+extern "C" int xva_fp_set_ln4(int mode) { int old = g_ln4; g_ln4 = mode; return old; }
+
 extern "C" int xva_fp_layernorm_fwd(const void* X, const float* gamma, const float* beta, void* Y, int dt, float* mean, float* rstd,
                                     int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp, float p_drop, uint64_t seed,
                                     uint32_t stream_id, void* stream) {
     XVA_CHECK_ARG(X && gamma && beta && Y && mean && rstd, "layernorm_fwd: null");
     XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
+    if (g_ln4 && C == 384 && dt == XVA_BF16 && p_drop == 0.f && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+        ((uintptr_t)beta % 16) == 0) {
+        hipLaunchKernelGGL(layernorm_fwd4_kernel, dim3((unsigned)xva_cdiv(xva_cdiv(rows, 4), 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint16_t*>(X),
+                           gamma, beta, reinterpret_cast<uint16_t*>(Y), mean, rstd, rows, mask_mode, lens, Tp, 1e-5f);
+        XVA_LAUNCH_CHECK();
+        return XVA_OK;
+    }
     dim3 grid(xva_cdiv(rows, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
     if (C == 384)
         hipLaunchKernelGGL((layernorm_fwd_kernel<6>), grid, block, 0, (hipStream_t)stream, X, gamma, beta, Y, dt, mean, rstd, rows,
