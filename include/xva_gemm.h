@@ -7,7 +7,9 @@
  * Operands live in HBM as fp32 or bf16 (`a_dtype`, `b_dtype`, `c_dtype`; 0 = fp32, 1 = bf16), 16-byte aligned, leading
  * dimensions in ELEMENTS and multiples of 4 (fp32) / 8 (bf16).  `compute` selects the matrix pipe:
  *   0 = exact fp32 (v_mfma_f32_16x16x4_f32; operands must be stored fp32) — the parity mode;
- *   1 = bf16 inputs, fp32 accumulation (v_mfma_f32_16x16x32_bf16; fp32-stored operands are rounded while staged).
+ *   1 = bf16 inputs, fp32 accumulation (v_mfma_f32_16x16x32_bf16; fp32-stored operands are rounded while staged);
+ *   2 = fp32-stored operands, every element split into hi + lo bf16 while staged and three bf16 MFMAs per product (~1e-5 relative per product:
+ *       what xva_gemm_set_fp32_products(1) makes of compute 0, chosen per call).
  *
  * Convolution over a time-major (rows = time, columns = channels) activation is expressed by K SEGMENTS: the reduction
  * index kk = j * seglen + c (tap j, channel c) reads the A row shifted by tap j:
@@ -80,7 +82,7 @@ typedef struct xva_gemm_params {
                              * reduce into one C); fp32 C only for atomics */
     int32_t splitk;         /* >= 1; > 1 requires accumulate = 1 and a linear epilogue; 0 = let xva_gemm choose (it splits only
                              * when accumulate != 0, C is fp32 and the epilogue is linear) */
-    int32_t compute;        /* 0 fp32, 1 bf16 */
+    int32_t compute;        /* 0 fp32, 1 bf16, 2 split-bf16 products of fp32 operands */
     int32_t layout;         /* XVA_GEMM_* */
     int32_t a_dtype, b_dtype, c_dtype;
     int32_t c_trans;        /* 1: store C transposed: element (row, col) at C[col * ldc + row] */

@@ -41,7 +41,8 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     XVA_CHECK_ARG(p.layout >= 0 && p.layout <= 2, "xva_gemm: bad layout");
     XVA_CHECK_ARG(p.a_dtype == p.b_dtype, "xva_gemm: A and B must share a storage dtype");
     XVA_CHECK_ARG(p.a_dtype == XVA_F32 || p.a_dtype == XVA_BF16, "xva_gemm: bad operand dtype");
-    XVA_CHECK_ARG(!(p.compute == 0 && p.a_dtype != XVA_F32), "xva_gemm: the exact-fp32 pipe needs fp32-stored operands");
+    XVA_CHECK_ARG(p.compute >= 0 && p.compute <= 2, "xva_gemm: compute must be 0 (fp32), 1 (bf16) or 2 (split-bf16 products of fp32 operands)");
+    XVA_CHECK_ARG(!((p.compute == 0 || p.compute == 2) && p.a_dtype != XVA_F32), "xva_gemm: the fp32 pipes (exact, split products) need fp32-stored operands");
     const int ve = p.a_dtype == XVA_BF16 ? 8 : 4;
     XVA_CHECK_ARG(p.lda % ve == 0 && p.ldb % ve == 0, "xva_gemm: lda/ldb must be multiples of %d (lda=%ld ldb=%ld)", ve,
                   (long)p.lda, (long)p.ldb);
@@ -144,6 +145,10 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
             if (sk >= 2 && t0 <= 144) { glds_tile = 0; p.splitk = (int)sk; int bm0; xva_gemm_glds_tile_dims(0, &bm0, &bn); bn = bn * 1000 + bm0; }
         }
         if (p.splitk > nkt) p.splitk = nkt;
+        // Experiment knob (round 5): splits of at most XVA_GEMM_SK_ATOMIC_MAX parts skip the slabs + reduce launch and add their
+        // partial tiles to C with fp32 atomics (order-dependent sums; 0 = never, the default)
+        static const int sk_atomic_max = [] { const char* e = getenv("XVA_GEMM_SK_ATOMIC_MAX"); return e ? atoi(e) : 0; }();
+        if (can_split && p.splitk > 1 && p.splitk <= sk_atomic_max) p.sk_ws = nullptr;
     } else if (can_split) {
         const long tiles = (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2;
         long sk = (768 + tiles - 1) / tiles;
@@ -155,7 +160,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     long nblocks = glds_tile >= 0 ? 1 : (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2 * p.splitk;
     XVA_CHECK_ARG(nblocks < (1L << 31), "xva_gemm: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    const int mode = p.compute == 0 ? (g_fp32_products == 1 ? 3 : 0) : (p.a_dtype == XVA_BF16 ? 1 : 2);
+    const int mode = p.compute == 0 ? (g_fp32_products == 1 ? 3 : 0) : (p.compute == 2 ? 3 : (p.a_dtype == XVA_BF16 ? 1 : 2));
     const bool prof = xva_prof_is_on();
     if (prof) { xva_prof_begin(st, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + (mode == 3 ? 0 : mode)); 
         // algorithmic bytes: each distinct element of A, B once (tap segments re-address the SAME rows/columns), C written (read too when

@@ -31,7 +31,7 @@ int geo_of(const xva_xvp_tr_dims* d, Geo& g) {
     XVA_CHECK_ARG(g.B > 0 && g.T > 0 && g.L > 0 && g.C > 0 && g.C % 4 == 0 && g.F % 4 == 0 && g.H > 0 && g.C % g.H == 0 && (g.k & 1) && g.k / 2 <= PAD,
                   "xvp_tr: B, T, L > 0; C, F multiples of 4; C %% H == 0; k odd <= %d", 2 * PAD + 1);
     XVA_CHECK_ARG(g.proj ? (g.Co == 1 || g.Co % 4 == 0) : g.Co == g.C, "xvp_tr: out_channels must equal C (no proj) or be 1 / a multiple of 4 (proj)");
-    XVA_CHECK_ARG(g.pd >= 0.f && g.pd < 1.f && (g.cmp == 0 || g.cmp == 1), "xvp_tr: p_drop in [0, 1), compute 0 / 1");
+    XVA_CHECK_ARG(g.pd >= 0.f && g.pd < 1.f && (g.cmp >= 0 && g.cmp <= 2), "xvp_tr: p_drop in [0, 1), compute 0 / 1 / 2");
     g.rows = (int64_t)g.B * g.Tp; g.rtot = g.rows + 2 * GUARD;
     return XVA_OK;
 }

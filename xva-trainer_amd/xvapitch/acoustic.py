@@ -112,6 +112,17 @@ class _JoinStreams(torch.autograd.Function):
         return g, None
 
 
+def _sub_compute(compute, env):
+    """Throughput mode of the two RelativePositionTransformers (text encoder, pitch predictor): "split" — fp32 storage, every product three bf16 MFMAs on
+    hi + lo split operands (xva_gemm compute 2, ~1e-5 per product).  With plain bf16-rounded operands ("mixed", rounds 2 - 4) the pitch loss sat at 9.2e-4
+    of the reference's against the 1e-3 bound; measured on the reference golden in round 5 (bench.py xvapitch_c5.parity): text encoder split 5.9e-4, both
+    split 5.1e-6 (loss_kl 3.8e-4 -> 1.6e-4, loss_duration 5.5e-5 -> 2.4e-7) for +0.2 ms of a 24 ms iteration — both stacks run on side streams.
+    XVA_C5_TEXT_COMPUTE / XVA_C5_PITCH_COMPUTE = mixed | split | fp32 override."""
+    if compute != "bf16":
+        return "fp32"
+    return os.environ.get(env, "split")
+
+
 class AcousticTrainPath:
     """Constructor arguments follow model.py:55-135 (defaults = the reference's non-`big` model).  compute: "fp32" = exact-fp32 products everywhere
     (the parity mode) ; "bf16" = the throughput mode: WaveNet stacks (posterior encoder, flow) bf16-stored with bf16 MFMA, the two transformers' projections
@@ -131,7 +142,7 @@ class AcousticTrainPath:
                   "text_encoder.proj.bias": _param((torch.rand(2 * Cc, generator=gen) * 2 - 1) * (Cc + L) ** -0.5, self.device)}
         self.encoder = RelativePositionTransformer(Cc + L, Cc + L, Cc + L, hidden_channels_ffn, num_heads, text_layers, kernel_size=3, dropout_p=dropout_p,
                                                    layer_norm_type="2", rel_attn_window_size=4, device=device, seed=seed + 1,
-                                                   compute="mixed" if compute == "bf16" else "fp32", dropout_site_base=1000)
+                                                   compute=_sub_compute(compute, "XVA_C5_TEXT_COMPUTE"), dropout_site_base=1000)
         self.posterior_encoder = PosteriorEncoder(spec_bins, Cc, Cc, 5, 1, posterior_layers, cond_channels=d_vector_dim, device=device, compute=compute,
                                                   seed=seed + 2)
         self.flow = ResidualCouplingBlocks(Cc, Cc, 5, 1, flow_layers, num_flows=num_flows, cond_channels=d_vector_dim, device=device, compute=compute,
@@ -146,7 +157,7 @@ class AcousticTrainPath:
             hid = Cc + L + d_vector_dim                                                                                                   # model.py:1283-1284
             self.pitch_predictor = RelativePositionTransformer(hid, 1, hid, hidden_channels_ffn, num_heads, 3, kernel_size=3, dropout_p=dropout_p,
                                                                layer_norm_type="2", rel_attn_window_size=4, device=device, seed=seed + 5,
-                                                               compute="mixed" if compute == "bf16" else "fp32", dropout_site_base=2000)
+                                                               compute=_sub_compute(compute, "XVA_C5_PITCH_COMPUTE"), dropout_site_base=2000)
             self._subs.append(("pitch_predictor.encoder.", self.pitch_predictor))
             self.p["pitch_emb.weight"] = _param((torch.rand(Cc, 1, 3, generator=gen) * 2 - 1) * 3 ** -0.5, self.device)
             self.p["pitch_emb.bias"] = _param((torch.rand(Cc, generator=gen) * 2 - 1) * 3 ** -0.5, self.device)

@@ -119,9 +119,10 @@ class RelativePositionTransformer:
         self.Co = out_channels
         # "fp32": exact-fp32 MFMA products (the parity mode) ; "mixed": the same fp32-stored tensors, operands rounded to bf16 while staged
         # (bf16 MFMA, fp32 accumulation) — the throughput mode of the projections and feed-forward convolutions; attention / LayerNorm stay fp32
-        if compute not in ("fp32", "mixed"):
-            raise ValueError("RelativePositionTransformer: compute must be 'fp32' or 'mixed'")
-        self.cmp = 1 if compute == "mixed" else 0
+        # "split": fp32 storage, every product three bf16 MFMAs on hi + lo split operands (xva_gemm compute 2: ~1e-5 per product at 3 / 16 of the exact pipe's time)
+        if compute not in ("fp32", "mixed", "split"):
+            raise ValueError("RelativePositionTransformer: compute must be 'fp32', 'mixed' or 'split'")
+        self.cmp = {"fp32": 0, "mixed": 1, "split": 2}[compute]
         self.device = torch.device(device)
         gen = torch.Generator().manual_seed(seed)
         self.layers = [_Layer(self.C, self.F, self.H, self.k, self.w, self.device, gen, Co=out_channels if i == num_layers - 1 else None)
