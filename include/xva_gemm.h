@@ -115,6 +115,15 @@ typedef struct xva_gemm_params {
      * F (dtype g_dtype) is indexed exactly like G (ldg, sG, sG2) and needs G; NULL disables.  Direct-to-LDS kernels (bf16 operands) only. */
     const void* F;
     float fm_c;
+    /* SPLIT-bf16 PLANES (round 5; direct-to-LDS kernels, bf16 storage, no tap segments / K blocks, K a multiple of 32).  A value x that has to keep ~16
+     * mantissa bits through the bf16 matrix pipe is stored as two bf16 tensors of the same shape, hi = bf16(x) and lo = bf16(x - hi):
+     *   planes != 0: A and B are such pairs (hi plane at the given pointer, lo plane `a_plane` / `b_plane` ELEMENTS after it) and the product is
+     *                A_hi B_hi + A_hi B_lo + A_lo B_hi with fp32 accumulation (lo x lo, <= 2^-16 of the term, is dropped) — ONE launch whose K loop runs
+     *                three passes over the same tiles: the arithmetic of compute 2, with the split done once by the producer instead of at every staging;
+     *   c_plane != 0 (c_dtype bf16, splitk == 1, no accumulate / second output / transposed store): C is written as such a pair (lo plane c_plane elements
+     *                after C).  A gate tensor may be the hi plane of a pair (sign and zero-ness of x survive the rounding). */
+    int32_t planes;
+    int64_t a_plane, b_plane, c_plane;
 } xva_gemm_params;
 
 /* Launches on `stream` (a hipStream_t); returns 0 or a negative XVA_ERR_* code. */

@@ -318,6 +318,12 @@ int xva_cast_to_f32(const void* src, int dt, float* dst, int64_t n, void* stream
  * (elements), bf16 [Cin][3][Cout] with dst[c][m][o] = src[o][2 - m][c] — the weight of the convolution that maps d(output) to d(input), so the
  * backward-data product of python/fastpitch1_1/fastpitch/transformer.py:59-77 (autograd of CoreNet's second Conv1d) runs the NT main loop. */
 int xva_fp_wt_transpose3(const float* params, void* out, const int64_t* src_off, const int64_t* dst_off, int n, int Cout, int Cin, void* stream);
+/* the same, each copy written as a split-bf16 pair (hi plane, lo plane `plane` elements after it): the weight operand of the backward-data products of the
+ * fp32 mode's split-products feed-forward path (xva_gemm `planes`) */
+int xva_fp_wt_transpose3_planes(const float* params, void* out, const int64_t* src_off, const int64_t* dst_off, int n, int Cout, int Cin, int64_t plane, void* stream);
+/* fp32 tensor -> split-bf16 pair: dst[i] = bf16(src[i]), dst[plane + i] = bf16(src[i] - dst[i]) (n, plane multiples of 8): operands of xva_gemm's `planes`
+ * products, which keep ~16 mantissa bits through the bf16 matrix pipe (include/xva_gemm.h). */
+int xva_split_bf16(const float* src, void* dst, int64_t plane, int64_t n, void* stream);
 /* dst += src over n (even) elements of the activation dtype: joins the gradient contributions that the temporal predictors' backward
  * (python/fastpitch1_1/fastpitch/model.py:394-418) produces on its own stream into d(encoder output) */
 int xva_fp_add_act(void* dst, const void* src, int dt, int64_t n, void* stream);

@@ -46,3 +46,22 @@ print("phase net   launches   ms      TF/s   TB/s(alg)")
 for k in sorted(sec):
     v = sec[k]
     print("%5d %3d   %6d %8.3f %8.1f %7.2f" % (k[0], k[1], v[0], v[1], v[2] / v[1] if v[1] else 0, v[3] / v[1] / 1e3 if v[1] else 0))
+
+# the D-step backward (phase 3, the largest phase) taken apart launch by launch, per discriminator (MPD periods 2 / 3 / 5 / 7 / 11 =
+# net 0 - 4, MSD scales = net 5 - 7; within a discriminator the launches are in issue order: conv_post's gradients come from direct kernels, then per
+# layer {weight gradient TN | backward-data NN (one launch per input phase of a strided convolution)}, last the conv0 weight gradient)
+if "--phase3" in sys.argv or os.environ.get("XVA_HG_PHASE3"):
+    print("\nphase 3 (discs_backward_d) per launch; lanes off; ms from HIP-event pairs (incl. ~5 us of event overhead each)")
+    cur = None
+    for r in rows:
+        t = int(r.get("tag", 0))
+        if t // 1000 != 3:
+            continue
+        net = (t % 1000) // 10
+        if net != cur:
+            cur = net
+            v = sec[(3, net)]
+            print("-- net %d: %d launches, %.3f ms, %.0f TFLOP/s, %.2f TB/s algorithmic" % (net, v[0], v[1], v[2] / v[1], v[3] / v[1] / 1e3))
+        ms = float(r["ms"])
+        print("   %s M=%-7s N=%-5s K=%-7s batch=%-5s splitk=%-3s kernel=%-7s %7.3f ms %7.1f TFLOP/s %6.2f TB/s" %
+              (names[int(r["variant"]) // 3], r["M"], r["N"], r["K"], r["batch"], r["splitk"], r["bn"], ms, float(r["gflop"]) / ms, float(r["mbytes"]) / ms / 1e3))

@@ -58,6 +58,7 @@ class GemmParams(C.Structure):
         ("C2", vp), ("c2_slope", f32),
         ("a_rowpitch", i64),
         ("F", vp), ("fm_c", f32),
+        ("planes", i32), ("a_plane", i64), ("b_plane", i64), ("c_plane", i64),
     ]
 
 

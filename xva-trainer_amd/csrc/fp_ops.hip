@@ -1050,13 +1050,41 @@ extern "C" int xva_cast_f32(const float* src, void* dst, int dt, int64_t n, void
     return XVA_OK;
 }
 
+// fp32 tensor -> split-bf16 pair (hi = bf16(x) at dst[i], lo = bf16(x - hi) at dst[plane + i]): the operand format of xva_gemm's `planes` products
+// (include/xva_gemm.h).  8 elements per thread and iteration.
+__global__ void split_bf16x8_kernel(const float4* __restrict__ src, uint4* __restrict__ hi, uint4* __restrict__ lo, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = src[2 * i], b = src[2 * i + 1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h[e]) : "v"(v[2 * e]), "v"(v[2 * e + 1]));
+            const float r0 = v[2 * e] - __uint_as_float(h[e] << 16), r1 = v[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l[e]) : "v"(r0), "v"(r1));
+        }
+        hi[i] = make_uint4(h[0], h[1], h[2], h[3]);
+        lo[i] = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+extern "C" int xva_split_bf16(const float* src, void* dst, int64_t plane, int64_t n, void* stream) {
+    XVA_CHECK_ARG(src && dst && n >= 0 && n % 8 == 0 && plane % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "split_bf16: n and the plane offset must be multiples of 8, pointers 16-byte aligned");
+    if (n == 0) return XVA_OK;
+    const int64_t n8 = n / 8;
+    int g8 = (int)((n8 + 255) / 256); if (g8 > 8192) g8 = 8192;
+    hipLaunchKernelGGL(split_bf16x8_kernel, dim3(g8), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst),
+                       reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(dst) + plane), n8);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
 // Transposed bf16 shadow of tap-major convolution weights for the backward-data products (round 5): src fp32 [Cout][3][Cin] -> dst bf16
 // [Cin][3][Cout] with the taps reversed, dst[n][m][co] = src[co][2 - m][n] — the weight of the k = 3 convolution that maps d(output) to d(input),
 // so that backward-data runs the NT main loop (k-contiguous weight rows straight into LDS) instead of the NN one (transposing LDS reads of
 // row segments; measured 172 us against 138 us for FastPitch's conv2 backward-data, and 1.75x the algorithmic fetch).  One launch for up to 16
 // tensors; a 32 x 32 tile is transposed through LDS (coalesced 128-byte reads along Cin, 64-byte writes along Cout).
 struct xva_wt_batch { int64_t src[16]; int64_t dst[16]; int n; };
-__global__ __launch_bounds__(256) void wt_transpose3_kernel(const float* __restrict__ params, uint16_t* __restrict__ out, xva_wt_batch bt, int Cout, int Cin) {
+__global__ __launch_bounds__(256) void wt_transpose3_kernel(const float* __restrict__ params, uint16_t* __restrict__ out, xva_wt_batch bt, int Cout, int Cin, int64_t plane) {
     __shared__ float tile[32][33];
     const int which = blockIdx.z / 3, tap = blockIdx.z % 3;
     const float* src = params + bt.src[which];
@@ -1072,18 +1100,31 @@ __global__ __launch_bounds__(256) void wt_transpose3_kernel(const float* __restr
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const int n = n0 + r, co = c0 + tx;
-        if (n < Cin && co < Cout) a_st(dst, ((int64_t)n * 3 + (2 - tap)) * Cout + co, XVA_BF16, tile[tx][r]);
+        if (n < Cin && co < Cout) {
+            const int64_t o = ((int64_t)n * 3 + (2 - tap)) * Cout + co;
+            const float v = tile[tx][r];
+            a_st(dst, o, XVA_BF16, v);
+            if (plane) a_st(dst, o + plane, XVA_BF16, v - a_ld(dst, o, XVA_BF16));          // the lo plane of a split-bf16 pair
+        }
     }
 }
-extern "C" int xva_fp_wt_transpose3(const float* params, void* out, const int64_t* src_off, const int64_t* dst_off, int n, int Cout, int Cin, void* stream) {
+static int wt_transpose3(const float* params, void* out, const int64_t* src_off, const int64_t* dst_off, int n, int Cout, int Cin, int64_t plane, void* stream) {
     XVA_CHECK_ARG(params && out && src_off && dst_off && n >= 1 && n <= 16, "wt_transpose3: bad arguments");
     xva_wt_batch bt;
     bt.n = n;
     for (int i = 0; i < n; ++i) { bt.src[i] = src_off[i]; bt.dst[i] = dst_off[i]; }
     hipLaunchKernelGGL(wt_transpose3_kernel, dim3(xva_cdiv(Cin, 32), xva_cdiv(Cout, 32), 3 * n), dim3(256), 0, (hipStream_t)stream, params,
-                       reinterpret_cast<uint16_t*>(out), bt, Cout, Cin);
+                       reinterpret_cast<uint16_t*>(out), bt, Cout, Cin, plane);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
+}
+extern "C" int xva_fp_wt_transpose3(const float* params, void* out, const int64_t* src_off, const int64_t* dst_off, int n, int Cout, int Cin, void* stream) {
+    return wt_transpose3(params, out, src_off, dst_off, n, Cout, Cin, 0, stream);
+}
+// the same as a split-bf16 pair: the lo plane `plane` elements after the hi plane
+extern "C" int xva_fp_wt_transpose3_planes(const float* params, void* out, const int64_t* src_off, const int64_t* dst_off, int n, int Cout, int Cin, int64_t plane, void* stream) {
+    XVA_CHECK_ARG(plane > 0, "wt_transpose3_planes: plane offset");
+    return wt_transpose3(params, out, src_off, dst_off, n, Cout, Cin, plane, stream);
 }
 
 // activation-dtype tensor -> fp32 copy (the temporal predictors run on fp32-stored tensors: their gradients are sums of

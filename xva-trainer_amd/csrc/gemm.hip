@@ -66,6 +66,11 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
                   "xva_gemm: a second output needs splitk == 1, plain (non-accumulating, non-transposed) stores and C's alignment");
     XVA_CHECK_ARG(!p.F || (p.G && p.splitk == 1 && !auto_sk), "xva_gemm: the feature-matching term needs the gate tensor G and an unsplit product");
     XVA_CHECK_ARG(p.kb_len == 0 || (p.layout == XVA_GEMM_TN && p.kb_len > 0 && p.kb_sA % ve == 0 && p.kb_sB % ve == 0), "xva_gemm: bad K-block arguments");
+    XVA_CHECK_ARG(!p.planes || (p.compute == 1 && p.a_dtype == XVA_BF16 && p.a_seglen == 0 && p.a_segadj == 0 && p.seglen == 0 && p.kb_len == 0 &&
+                                p.a_plane % 8 == 0 && p.b_plane % 8 == 0 && !p.a_lrelu && !p.b_lrelu),
+                  "xva_gemm: split-bf16 planes need bf16 storage, compute 1, plain operands (no tap segments / K blocks / operand activation) and 8-element plane offsets");
+    XVA_CHECK_ARG(!p.c_plane || (p.c_dtype == XVA_BF16 && !p.accumulate && !p.C2 && !p.c_trans && p.c_plane % 8 == 0 && p.compute == 1 && p.a_dtype == XVA_BF16),
+                  "xva_gemm: a split-bf16 output pair needs a bf16 C without accumulation / second output / transposed store (direct-to-LDS kernels)");
     if (p.K == 0) p.splitk = 1;
     if (auto_sk && p.layout == XVA_GEMM_TN && p.seglen > 0 && p.sk_ws) {   // convolution weight gradient: resident-operand kernel (wgrad_res.h)
         const bool prof = xva_prof_is_on();
@@ -115,7 +120,8 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         else glds_tile = 3;
         if (glds_env >= 1 && glds_env <= 5) glds_tile = glds_env - 1;
         if (glds_env == 8) glds_tile = 6;                                // forced 256x128 (K tile 32, two workgroups per CU)
-        if (glds_env == 7 && p.layout != XVA_GEMM_TN) glds_tile = 5;     // forced 384x128 (NT / NN)   // forced: 1 -> 128x128, 2 -> 256x256, 3 -> 128x64, 4 -> 64x64, 5 -> 128x32
+        if (glds_env == 7 && p.layout != XVA_GEMM_TN) glds_tile = 5;
+        if (p.planes && glds_tile == 6) glds_tile = 0;                   // the 256x128 test tile has no plane passes     // forced 384x128 (NT / NN)   // forced: 1 -> 128x128, 2 -> 256x256, 3 -> 128x64, 4 -> 64x64, 5 -> 128x32
         int bm; xva_gemm_glds_tile_dims(glds_tile, &bm, &bn);
         bn = bn * 1000 + bm;   // profile tag
         if (can_split) {   // 256x256 tiles: at most one round of 256 workgroups; smaller tiles (2-3 per CU): ~1.7 rounds; >= 8 K tiles per split
@@ -175,6 +181,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (p.F) by += (double)p.M * p.N * (p.g_dtype == XVA_BF16 ? 2.0 : 4.0);
         xva_prof_shape(p.M, p.N, p.K, p.batch * p.batch2, p.splitk, bn, by * nbz); }
     XVA_CHECK_ARG(!p.C2 || glds_tile >= 0, "xva_gemm: the second output is written by the direct-to-LDS kernels only (bf16 operands, K >= 64)");
+    XVA_CHECK_ARG(!(p.planes || p.c_plane) || glds_tile >= 0, "xva_gemm: split-bf16 planes run on the direct-to-LDS kernels only (K >= 16, 8-element granularity)");
     if (res_dstep != 0) {   // conv over 32 / 64 / 128 channels (per group), stride 1 / 2 / 4: resident input tile
         if (xva_gemm_launch_conv_res(p, res_dstep, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; }
     } else if (glds_tile >= 0) { if (xva_gemm_launch_glds(p, glds_tile, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; } }

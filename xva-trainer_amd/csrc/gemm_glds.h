@@ -281,7 +281,13 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
                 v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
                 v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
             }
-            *dst = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            const uint2 hi = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            *dst = hi;
+            if (p.c_plane) {      // the lo plane of a split-bf16 pair: bf16(v - hi)
+                const float l0 = v[0] - __uint_as_float(hi.x << 16), l1 = v[1] - __uint_as_float(hi.x & 0xffff0000u);
+                const float l2 = v[2] - __uint_as_float(hi.y << 16), l3 = v[3] - __uint_as_float(hi.y & 0xffff0000u);
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + ci + p.c_plane) = make_uint2(pack_bf2(l0, l1), pack_bf2(l2, l3));
+            }
             if (p.C2) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C2) + ci) =
                 make_uint2(pack_bf2(lrelu(v[0], p.c2_slope), lrelu(v[1], p.c2_slope)), pack_bf2(lrelu(v[2], p.c2_slope), lrelu(v[3], p.c2_slope)));
         } else {
@@ -307,6 +313,7 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
                 float x = v[e];
                 if (p.accumulate) x += bf2f(*dst);
                 *dst = f2bf(x);
+                if (p.c_plane) dst[p.c_plane] = f2bf(x - bf2f(f2bf(x)));
                 if (p.C2) reinterpret_cast<uint16_t*>(p.C2)[ci] = f2bf(lrelu(x, p.c2_slope));
             } else {
                 float* dst = reinterpret_cast<float*>(p.C) + ci;
@@ -519,9 +526,16 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         const u32x4 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
                         __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.C) + ci));
-                    } else
-                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + ci) =
-                        make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                    } else {
+                        const uint4 hi = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + ci) = hi;
+                        if (p.c_plane) {      // the lo plane of a split-bf16 pair
+                            float hv[8]; unpack8(hi, hv);
+                            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + ci + p.c_plane) =
+                                make_uint4(pack_bf2(v[0] - hv[0], v[1] - hv[1]), pack_bf2(v[2] - hv[2], v[3] - hv[3]), pack_bf2(v[4] - hv[4], v[5] - hv[5]),
+                                           pack_bf2(v[6] - hv[6], v[7] - hv[7]));
+                        }
+                    }
                 } else {
                     float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + ci);
                     dst[0] = make_float4(v[0], v[1], v[2], v[3]); dst[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -584,7 +598,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
     const uint16_t* B = reinterpret_cast<const uint16_t*>(p.B) + (int64_t)z1 * p.sB + (int64_t)z2 * p.sB2;
 
     const int tpb = p.kb_len > 0 ? (p.kb_len + GK - 1) / GK : 1;                                  // K tiles per K block (TN)
-    const int nkt_total = p.kb_len > 0 ? (p.K / p.kb_len) * tpb : (p.K + GK - 1) / GK;
+    const int nkt1 = p.kb_len > 0 ? (p.K / p.kb_len) * tpb : (p.K + GK - 1) / GK;
+    const int nkt_total = p.planes ? 3 * nkt1 : nkt1;                                             // split-bf16 planes: three passes over the K tiles (hi hi, hi lo, lo hi)
     const int per = (nkt_total + p.splitk - 1) / p.splitk;
     const int kt_begin = ks * per;
     const int kt_end = min(nkt_total, kt_begin + per);
@@ -619,6 +634,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
                 lb.issue(B + (int64_t)blk * p.kb_sB + (int64_t)kl * p.ldb, kl, p.kb_len, smem + buf * BUF + A_BYTES, wave);
                 return;
             }
+        }
+        if (p.planes) {
+            const int pass = kt / nkt1, k0 = (kt - pass * nkt1) * GK;
+            la.issue(a_base(k0) + (pass == 2 ? p.a_plane : 0), k0, p.K, smem + buf * BUF, wave);
+            lb.issue(b_base(k0) + (pass == 1 ? p.b_plane : 0), k0, p.K, smem + buf * BUF + A_BYTES, wave);
+            return;
         }
         const int k0 = kt * GK;
         la.issue(a_base(k0), k0, p.K, smem + buf * BUF, wave);
@@ -828,7 +849,8 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
     const uint16_t* B = reinterpret_cast<const uint16_t*>(p.B) + (int64_t)z1 * p.sB + (int64_t)z2 * p.sB2;
 
     const int tpb = p.kb_len > 0 ? (p.kb_len + GK3 - 1) / GK3 : 1;
-    const int nkt_total = p.kb_len > 0 ? (p.K / p.kb_len) * tpb : (p.K + GK3 - 1) / GK3;
+    const int nkt1 = p.kb_len > 0 ? (p.K / p.kb_len) * tpb : (p.K + GK3 - 1) / GK3;
+    const int nkt_total = p.planes ? 3 * nkt1 : nkt1;            // split-bf16 planes: three passes over the K tiles (hi hi, hi lo, lo hi); host-checked: no segments / K blocks
     const int per = (nkt_total + p.splitk - 1) / p.splitk;
     const int kt_begin = ks * per;
     const int kt_end = min(nkt_total, kt_begin + per);
@@ -851,6 +873,8 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
     // other wave group's 32 MFMAs (512 cycles).
     const uint16_t* nA; const uint16_t* nB;      // bases of the next tile to issue
     int n_k0, n_akin = 0, n_bkin = 0;            // its first k (inside its K block for TN K blocks); position inside the A / B segment
+    int n_pass = 0;                              // split-bf16 planes: the pass the next tile belongs to
+    const uint16_t* const A0 = A; const uint16_t* const B0 = B;
     const bool kblocks = LAYOUT == XVA_GEMM_TN && p.kb_len > 0;
     const int Kb = kblocks ? p.kb_len : p.K;     // bound of the k index the loaders compare against
     {
@@ -860,8 +884,10 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
             nA = A + (int64_t)blk * p.kb_sA + (int64_t)kl * p.lda;
             nB = B + (int64_t)blk * p.kb_sB + (int64_t)kl * p.ldb;
         } else {
-            const int k0 = kt_begin * GK3;
+            n_pass = p.planes ? kt_begin / nkt1 : 0;
+            const int k0 = (kt_begin - n_pass * nkt1) * GK3;
             n_k0 = k0;
+            if (p.planes) { A += n_pass == 2 ? p.a_plane : 0; B += n_pass == 1 ? p.b_plane : 0; }
             if constexpr (AK == KC) {
                 nA = A + k0 + (p.a_seglen > 0 ? (int64_t)(k0 / p.a_seglen) * p.a_segadj : 0);
                 n_akin = p.a_seglen > 0 ? k0 % p.a_seglen : 0;
@@ -880,6 +906,17 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
         else { la.issue(nA, n_k0, Kb, st, wave); lb.issue(nB, n_k0, Kb, st + A_BYTES, wave); }
         // advance to the next tile
         n_k0 += GK3;
+        if (p.planes) {                           // plain operands (no segments): the next pass restarts at k = 0 on the other plane of A or B
+            if (n_k0 >= Kb) {
+                ++n_pass; n_k0 = 0;
+                nA = A0 + (n_pass == 2 ? p.a_plane : 0);
+                nB = B0 + (n_pass == 1 ? p.b_plane : 0);
+            } else {
+                if constexpr (AK == KC) nA += GK3; else nA += (int64_t)GK3 * p.lda;
+                if constexpr (BKD == KC) nB += GK3; else nB += (int64_t)GK3 * p.ldb;
+            }
+            return;
+        }
         if (kblocks) {
             if (n_k0 >= tpb * GK3) {              // next K block
                 nA += p.kb_sA - (int64_t)(n_k0 - GK3) * p.lda; nB += p.kb_sB - (int64_t)(n_k0 - GK3) * p.ldb; n_k0 = 0;
