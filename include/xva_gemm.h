@@ -139,6 +139,7 @@ int xva_gemm_set_mainloop(int mode);
  * accumulation (the lo * lo term, <= 2^-16 of the product, is dropped): ~1e-5 relative per product at a fraction of the matrix-pipe time.
  * Returns the previous mode. */
 int xva_gemm_set_fp32_products(int mode);
+int xva_gemm_get_fp32_products(void);
 /* Diagnostics / test knob: K loop of the 256x256 direct-to-LDS tile. 0 = all waves in one phase (two barriers per 64-deep K tile),
  * 1 (default) = two wave groups one barrier apart over a ring of four 32-deep K tiles ({12 LDS reads + DMA | 32 MFMAs} phases), 2 = 1 for
  * the NT layout, 0 for NN / TN. Returns the previous mode. Same results up to fp32 summation order. */

@@ -425,6 +425,11 @@ int xva_fp_set_bwd_nt(int mode);
 /* bf16 LayerNorm rows of 384 channels (python/fastpitch1_1/fastpitch/transformer.py:75,146): 1 (default) = the forward takes four rows per wavefront with 16-byte
  * accesses, 0 = one row per wavefront (the backward always does).  Same arithmetic per row; the row sums are taken over a different lane order (fp32 rounding only).  env XVA_FP_LN4. */
 int xva_fp_set_ln4(int mode);
+/* FastPitch fp32 mode with split-bf16 products (xva_gemm_set_fp32_products(1); outputs / losses within north_star's 1e-3): 1 (default) = the feed-forward
+ * convolutions (python/fastpitch1_1/fastpitch/transformer.py:59-77, 94 % of the FLOPs) run the direct-to-LDS kernels on split-bf16 pairs the producers
+ * write (include/xva_gemm.h `planes`), 0 = every product splits its operands while staging them (rounds 3 - 4).  Same arithmetic (hi hi + hi lo + lo hi);
+ * changes the workspace plan: set before xva_fp_workspace_bytes.  Returns the previous mode.  env XVA_FP_FFN_PLANES. */
+int xva_fp_set_ffn_planes(int mode);
 /* Test / diagnostics: byte offset (into the caller's workspace) and geometry {nseq, T, C, padF, padB} of an activation tensor the last
  * forward stored, time-major (nseq, padF + T + padB, C) in the activation dtype.  kind: 0 mel input, 1 conv_pre output, 2 u[i0] (ups
  * output), 3 lrelu(u[i0]), 4 xt1[resblock i0][m i1] (= lrelu(c1(lrelu(x))), models.py:43-45), 5 / 6 x after block m and its lrelu copy,

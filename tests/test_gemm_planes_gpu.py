@@ -20,7 +20,7 @@ def _ref(Ap, Bp, f):
 
 
 @pytest.mark.parametrize("layout,M,N,K", [("NT", 1024, 1536, 1152), ("NT", 777, 384, 4608), ("NT", 300, 192, 384), ("NN", 1024, 1536, 1152), ("NN", 515, 384, 4608),
-                                          ("TN", 1536, 1152, 4096), ("TN", 384, 1152, 5120), ("TN", 192, 384, 2048)])
+                                          ("TN", 1536, 1152, 4096), ("TN", 384, 1152, 5120), ("TN", 192, 384, 2048), ("TN", 384, 1152, 1726), ("TN", 1536, 1152, 35)])
 def test_planes_product_equals_the_three_term_sum(layout, M, N, K):
     from xva_trainer_amd import _lib
     g = torch.Generator().manual_seed(M + N + K)

@@ -15,6 +15,7 @@
 // hash masks regenerated in backward: nothing is stored for it except the dropped attention probabilities.
 #include "xva_common.h"
 #include "../../include/xva_hip.h"
+#include "../../include/xva_gemm.h"
 #include <string>
 #include <vector>
 
@@ -152,6 +153,10 @@ struct Plan {
     int64_t skws, skws2, skws3, skws_bytes;   // split-K slab scratch of the weight-gradient GEMMs (main stream / weight-gradient lane / predictor lane)
     int64_t gX1, gX2;   // d(encoder output) contributions of the energy / pitch predictors (predictor lane)
     int64_t wshadow;    // activation-dtype copy of the flat parameters (bf16 mode); unused in fp32 mode
+    // fp32 mode with split-bf16 products (xva_gemm_set_fp32_products(1)): the feed-forward convolutions (94 % of the FLOPs) run the direct-to-LDS kernels on
+    // split-bf16 PLANES (include/xva_gemm.h): the whole parameter table as a pair (wplanes; lo plane wplane_stride elements after hi), transposed tap-reversed
+    // pairs of both convolution weights of the 2 x NL layers (wtp_c1 / wtp_c2), and per layer parity a pair buffer for y1 and for d(sum2) (yp / gp; rows -1 .. R)
+    int64_t wplanes, wplane_stride, wtp_c1, wtp_c2, yp[2], gp[2];
     int64_t wt_c2;      // bf16 mode: transposed, tap-reversed copies of the 2 x NL conv2 weights ([DI][3][DM] each; encoder layers first) for the NT backward-data form
     int64_t total;
 };
@@ -160,6 +165,11 @@ struct Plan {
 // weight as stored (0).  env XVA_FP_BWD_NT; A/B and test switch (the results differ by fp32 summation order only: same products, same K order).
 static int g_bwd_nt = [] { const char* e = getenv("XVA_FP_BWD_NT"); return e ? atoi(e) : 1; }();
 extern "C" int xva_fp_set_bwd_nt(int mode) { int old = g_bwd_nt; g_bwd_nt = mode; return old; }
+
+// fp32 mode, split products: 1 (default) = the feed-forward convolutions through split-bf16 planes on the direct-to-LDS kernels (round 5), 0 = every product on
+// the register-staged kernel that splits while staging (rounds 3 - 4).  Changes the workspace plan: set before xva_fp_workspace_bytes.  env XVA_FP_FFN_PLANES
+static int g_ffn_planes = [] { const char* e = getenv("XVA_FP_FFN_PLANES"); return e ? atoi(e) : 1; }();
+extern "C" int xva_fp_set_ffn_planes(int mode) { int old = g_ffn_planes; g_ffn_planes = mode; return old; }
 
 int make_plan(const xva_fp_dims* d, Plan* p) {
     XVA_CHECK_ARG(d && d->B > 0 && d->Tt > 0 && d->Tm > 0, "fastpitch: bad dims");
@@ -226,6 +236,13 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     p->gH2 = b.seq(Rm, DI, es); p->gQKV2 = b.seq(Rm, DQKV, es);
     p->wshadow = d->compute ? b.take(table().total * es) : -1;
     p->wt_c2 = (d->compute && g_bwd_nt) ? b.take((int64_t)2 * NL * DI * 3 * DM * 2) : -1;
+    p->wplanes = p->wtp_c1 = p->wtp_c2 = p->yp[0] = p->yp[1] = p->gp[0] = p->gp[1] = -1;
+    p->wplane_stride = (table().total + 7) / 8 * 8;
+    if (!d->compute && g_ffn_planes) {
+        p->wplanes = b.take(2 * p->wplane_stride * 2);
+        p->wtp_c1 = b.take((int64_t)2 * (2 * NL) * DI * 3 * DM * 2); p->wtp_c2 = b.take((int64_t)2 * (2 * NL) * DI * 3 * DM * 2);
+        for (int q = 0; q < 2; ++q) { p->yp[q] = b.take(2 * (Rm + 2) * DM * 2); p->gp[q] = b.take(2 * (Rm + 2) * DM * 2); }
+    }
     p->total = b.cur;
     return XVA_OK;
 }
@@ -369,6 +386,88 @@ static int conv3_bwd_weight(Ctx& c, const void* dY, int64_t rows, int Cout, cons
     return xva_gemm(&g, c.st);
 }
 
+
+// ------------------------------------------------------------------ split-bf16 planes (fp32 mode, split products) ----
+// A sequence tensor as a split-bf16 pair (include/xva_gemm.h): hi plane rows -1 .. R (the guard rows are zeros), lo plane `plane` elements after it.
+struct PlaneT { char* base; int64_t plane; int C; };
+static inline char* prow(const PlaneT& t, int64_t row) { return t.base + (row + 1) * (int64_t)t.C * 2; }                  // hi plane, row `row`
+// the pair that lives IN an fp32 sequence slot of R rows x C channels (same bytes: 2 planes x (R + 2) rows x 2 B = (R + 2) rows x 4 B)
+static inline PlaneT planes_in_slot(char* row0_fp32, int64_t R, int C) { return PlaneT{row0_fp32 - (int64_t)C * 4, (R + 2) * (int64_t)C, C}; }
+static inline PlaneT planes_scratch(const Ctx& c, int64_t off, int64_t Rm) { return PlaneT{c.W + off, (Rm + 2) * (int64_t)DM, DM}; }
+static bool ffn_planes_on(const Ctx& c) { return !c.compute && c.pl.wplanes >= 0 && g_ffn_planes && xva_gemm_get_fp32_products() == 1; }
+// fp32 rows -1 .. R of a sequence tensor -> the pair
+static int split_rows(const Ctx& c, const char* row0_fp32, int64_t R, const PlaneT& dst, void* st) {
+    return xva_split_bf16(reinterpret_cast<const float*>(row0_fp32 - (int64_t)dst.C * 4), dst.base, dst.plane, (R + 2) * (int64_t)dst.C, st);
+}
+// the slot held fp32 rows before (exact mode on the same workspace): the two guard rows in the MIDDLE of the pair (hi row R, lo row -1) are then stale
+static int zero_mid_guards(const Ctx& c, const PlaneT& t, int64_t R, void* st) {
+    (void)c;
+    if (hipMemsetAsync(prow(t, R), 0, (size_t)t.C * 2, (hipStream_t)st) != hipSuccess ||
+        hipMemsetAsync(t.base + t.plane * 2, 0, (size_t)t.C * 2, (hipStream_t)st) != hipSuccess) { xva_set_error("fastpitch: memset failed"); return XVA_ERR_HIP; }
+    return XVA_OK;
+}
+static xva_gemm_params gpp(const Ctx& c) {
+    xva_gemm_params g = gp0(c);
+    g.compute = 1; g.a_dtype = g.b_dtype = XVA_BF16; g.planes = 1;
+    return g;
+}
+static const void* wplane(const Ctx& c, int64_t w_off) { return c.W + c.pl.wplanes + w_off * 2; }
+static const void* wtplane(const Ctx& c, int64_t buf, const LayerP* LP, int l) {
+    const ParamTable& T = table();
+    const int idx = LP == T.enc ? l : NL + l;
+    return c.W + buf + (int64_t)idx * DI * 3 * DM * 2;
+}
+constexpr int64_t WT_PLANE = (int64_t)2 * NL * DI * 3 * DM;           // elements between the hi and lo planes of the transposed weight sets
+// Y (pair or fp32) = act(Xcat Wt^T + b) [dropout] (+R): conv3_fwd on pairs.  Yp: pair output (fp32 Y == nullptr) or nullptr (fp32 output Y)
+static int conv3_fwd_p(Ctx& c, const PlaneT& X, int64_t rows, int Cin, int64_t w_off, const float* bias, const PlaneT* Yp, void* Y, int Cout, int relu,
+                       const void* R, int mask, const int32_t* lens, int Tp, Drop dr = {0.f, 0}) {
+    xva_gemm_params g = gpp(c);
+    g.layout = XVA_GEMM_NT; g.A = prow(X, -1); g.a_plane = X.plane; g.B = wplane(c, w_off); g.b_plane = c.pl.wplane_stride;
+    g.M = (int)rows; g.N = Cout; g.K = 3 * Cin; g.lda = Cin; g.ldb = 3 * Cin; g.ldc = Cout;
+    if (Yp) { g.C = prow(*Yp, 0); g.c_dtype = XVA_BF16; g.c_plane = Yp->plane; } else { g.C = Y; g.c_dtype = XVA_F32; }
+    g.bias = bias; g.act = relu ? XVA_ACT_RELU : XVA_ACT_NONE; g.R = R; g.ldr = Cout; g.r_dtype = XVA_F32;
+    g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
+    g.drop_p = dr.p; g.drop_seed = c.seed; g.drop_stream = dr.stream;
+    return xva_gemm(&g, c.st);
+}
+// dX = (dY (*) W^T through the transposed pair wt) [gate] (+R): dXp pair output or fp32 dX
+static int conv3_bwd_data_p(Ctx& c, const PlaneT& dY, int64_t rows, int Cout, const void* wt, int Cin, const PlaneT* dXp, void* dX, const void* R,
+                            const PlaneT* gate, int mask, const int32_t* lens, int Tp) {
+    xva_gemm_params g = gpp(c);
+    g.layout = XVA_GEMM_NT; g.A = prow(dY, -1); g.a_plane = dY.plane; g.B = wt; g.b_plane = WT_PLANE;
+    g.M = (int)rows; g.N = Cin; g.K = 3 * Cout; g.lda = Cout; g.ldb = 3 * Cout; g.ldc = Cin;
+    if (dXp) { g.C = prow(*dXp, 0); g.c_dtype = XVA_BF16; g.c_plane = dXp->plane; } else { g.C = dX; g.c_dtype = XVA_F32; }
+    g.R = R; g.ldr = Cin; g.r_dtype = XVA_F32;
+    if (gate) { g.G = prow(*gate, 0); g.ldg = Cin; g.g_dtype = XVA_BF16; }     // the hi plane: sign and zero-ness of the activation survive the rounding
+    g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
+    return xva_gemm(&g, c.st);
+}
+// dWt[Cout][3*Cin] += dY^T Xcat on pairs
+static int conv3_bwd_weight_p(Ctx& c, const PlaneT& dY, int64_t rows, int Cout, const PlaneT& X, int Cin, float* dWt) {
+    xva_gemm_params g = gpp(c);
+    g.layout = XVA_GEMM_TN; g.A = prow(dY, 0); g.a_plane = dY.plane; g.B = prow(X, -1); g.b_plane = X.plane; g.C = dWt; g.c_dtype = XVA_F32;
+    g.M = Cout; g.N = 3 * Cin; g.K = (int)rows; g.lda = Cout; g.ldb = Cin; g.ldc = 3 * Cin; g.accumulate = 1; g.splitk = 0;
+    g.sk_ws = c.W + (c.lane == 2 ? c.pl.skws3 : (c.lane ? c.pl.skws2 : c.pl.skws)); g.sk_ws_bytes = c.pl.skws_bytes;
+    return xva_gemm(&g, c.st);
+}
+// the parameter table and the transposed convolution weights as pairs (once per forward, like the bf16 mode's shadow)
+static int refresh_planes(const Ctx& c, const float* params, void* st) {
+    if (!ffn_planes_on(c)) return XVA_OK;
+    const ParamTable& T = table();
+    const int64_t n8 = T.total / 8 * 8;
+    XVA_TRY(xva_split_bf16(params, c.W + c.pl.wplanes, c.pl.wplane_stride, n8, st));
+    int64_t so[2 * NL], dof[2 * NL];
+    for (int which = 0; which < 2; ++which) {
+        for (int l = 0; l < NL; ++l) {
+            so[l] = which ? T.enc[l].c2_w : T.enc[l].c1_w; so[NL + l] = which ? T.dec[l].c2_w : T.dec[l].c1_w;
+            dof[l] = (int64_t)l * DI * 3 * DM; dof[NL + l] = (int64_t)(NL + l) * DI * 3 * DM;
+        }
+        // c1: [DI][3][DM] -> [DM][3][DI] ; c2: [DM][3][DI] -> [DI][3][DM]
+        XVA_TRY(xva_fp_wt_transpose3_planes(params, c.W + (which ? c.pl.wtp_c2 : c.pl.wtp_c1), so, dof, 2 * NL, which ? DM : DI, which ? DI : DM, WT_PLANE, st));
+    }
+    return XVA_OK;
+}
+
 // dropout sites: stream id = site_base + layer * 4 + {0 attention probs, 1 o_net output, 2 conv2 output}
 enum { DS_ENC = 0, DS_DEC = 100, DS_PRED = 200 };
 
@@ -408,8 +507,16 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         XVA_TRY(xva_fp_layernorm_fwd(c.A(a.sum1), c.P + p.ln1_g, c.P + p.ln1_b, c.A(a.y1), c.dt, c.F(a.mean1), c.F(a.rstd1), R, DM,
                                      XVA_MASK_LEN, lens, Tp, 0.f, 0, 0, c.st));
         // h = relu(conv1(y1)) ; sum2 = y1 + drop(conv2(h)) ; x' = LN(sum2) * mask  (transformer.py:59-77,168-170)
+        if (ffn_planes_on(c)) {     // fp32 mode, split products: both convolutions on split-bf16 pairs (h is stored as a pair in its fp32 slot)
+            const PlaneT yp = planes_scratch(c, c.pl.yp[0], c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re), hp = planes_in_slot(c.A(a.h), R, DI);
+            XVA_TRY(split_rows(c, c.A(a.y1), R, yp, c.st));
+            XVA_TRY(zero_mid_guards(c, hp, R, c.st));
+            XVA_TRY(conv3_fwd_p(c, yp, R, DM, p.c1_w, c.P + p.c1_b, &hp, nullptr, DI, 1, nullptr, XVA_MASK_PAD, lens, Tp));
+            XVA_TRY(conv3_fwd_p(c, hp, R, DI, p.c2_w, c.P + p.c2_b, nullptr, c.A(a.sum2), DM, 0, c.A(a.y1), XVA_MASK_NONE, nullptr, 0, Drop{c.pd, s0 + 2}));
+        } else {
         XVA_TRY(conv3_fwd(c, c.A(a.y1), R, DM, p.c1_w, c.P + p.c1_b, c.A(a.h), DI, 1, nullptr, XVA_MASK_PAD, lens, Tp));
         XVA_TRY(conv3_fwd(c, c.A(a.h), R, DI, p.c2_w, c.P + p.c2_b, c.A(a.sum2), DM, 0, c.A(a.y1), XVA_MASK_NONE, nullptr, 0, Drop{c.pd, s0 + 2}));
+        }
         XVA_TRY(xva_fp_layernorm_fwd(c.A(a.sum2), c.P + p.ln2_g, c.P + p.ln2_b, c.A(xo[l + 1]), c.dt, c.F(a.mean2), c.F(a.rstd2), R, DM,
                                      XVA_MASK_LEN, lens, Tp, 0.f, 0, 0, c.st));
     }
@@ -487,9 +594,21 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         XVA_TRY(xva_fp_layernorm_bwd(gA, c.A(a.sum2), c.F(a.mean2), c.F(a.rstd2), c.P + p.ln2_g, gB, drop ? gBm : nullptr, c.dt, Gg + p.ln2_g,
                                      Gg + p.ln2_b, R, DM, XVA_MASK_LEN, lens, Tp, 0, 0.f, 0, 0, c.pd, c.seed, s0 + 2, nullptr, nullptr, c.st));
         // conv2 backward: gH = (gBm (*) W2) * [h > 0], structural rows zero
+        const bool planes = ffn_planes_on(c);
+        const int64_t Rmax = c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re;
+        const PlaneT gBp = planes_scratch(c, c.pl.gp[planes ? par : 0], Rmax), y1p = planes_scratch(c, c.pl.yp[planes ? par : 0], Rmax);
+        const PlaneT gHp = planes_in_slot(gH, Rmax, DI), hp = planes_in_slot(c.A(a.h), R, DI);
+        if (planes) {               // fp32 mode, split products: d(sum2) and y1 as pairs; gH lives as a pair in its fp32 slot
+            XVA_TRY(split_rows(c, gBm, R, gBp, c.st));
+            XVA_TRY(split_rows(c, c.A(a.y1), R, y1p, c.st));
+            XVA_TRY(zero_mid_guards(c, gHp, Rmax, c.st));
+            XVA_TRY(conv3_bwd_data_p(c, gBp, R, DM, wtplane(c, c.pl.wtp_c2, LP, l), DI, &gHp, nullptr, nullptr, &hp, XVA_MASK_PAD, lens, Tp));
+            XVA_TRY(conv3_bwd_data_p(c, gHp, R, DI, wtplane(c, c.pl.wtp_c1, LP, l), DM, nullptr, gC, gB, nullptr, XVA_MASK_LEN, lens, Tp));
+        } else {
         XVA_TRY(conv3_bwd_data(c, gBm, R, DM, p.c2_w, DI, gH, nullptr, c.A(a.h), XVA_MASK_PAD, lens, Tp, 0, -1, c.wt_c2(LP, l)));
         // conv1 backward + residual: gC = gB + gH (*) W1, LEN-masked (y1 was multiplied by mask)
         XVA_TRY(conv3_bwd_data(c, gH, R, DI, p.c1_w, DM, gC, gB, nullptr, XVA_MASK_LEN, lens, Tp, 0));
+        }
         // LN1 backward -> gD = d sum1 ; gDm = gD * dropmask (o_net branch)
         XVA_TRY(xva_fp_layernorm_bwd(gC, c.A(a.sum1), c.F(a.mean1), c.F(a.rstd1), c.P + p.ln1_g, gD, drop ? gDm : nullptr, c.dt, Gg + p.ln1_g,
                                      Gg + p.ln1_b, R, DM, XVA_MASK_LEN, lens, Tp, 0, 0.f, 0, 0, c.pd, c.seed, s0 + 1, nullptr, nullptr, c.st));
@@ -532,10 +651,18 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
             XVA_HIP_TRY(hipEventRecord(wl.chain[l], (hipStream_t)c.st));
             XVA_HIP_TRY(hipStreamWaitEvent(wl.s, wl.chain[l], 0));
         }
+        if (planes) {
+            XVA_TRY(conv3_bwd_weight_p(cw, gBp, R, DM, hp, DI, Gg + p.c2_w));
+            XVA_TRY(xva_fp_colsum(gBm, c.dt, Gg + p.c2_b, R, DM, DM, cw.st));
+            XVA_TRY(conv3_bwd_weight_p(cw, gHp, R, DI, y1p, DM, Gg + p.c1_w));
+            XVA_TRY(xva_fp_colsum(prow(gHp, 0), XVA_BF16, Gg + p.c1_b, R, DI, DI, cw.st));                       // d b1 = column sums of hi + lo
+            XVA_TRY(xva_fp_colsum(prow(gHp, 0) + gHp.plane * 2, XVA_BF16, Gg + p.c1_b, R, DI, DI, cw.st));
+        } else {
         XVA_TRY(conv3_bwd_weight(cw, gBm, R, DM, c.A(a.h), DI, Gg + p.c2_w));
         XVA_TRY(xva_fp_colsum(gBm, c.dt, Gg + p.c2_b, R, DM, DM, cw.st));
         XVA_TRY(conv3_bwd_weight(cw, gH, R, DI, c.A(a.y1), DM, Gg + p.c1_w));
         XVA_TRY(xva_fp_colsum(gH, c.dt, Gg + p.c1_b, R, DI, DI, cw.st));
+        }
         XVA_TRY(linear_bwd_weight(cw, gDm, R, DM, DM, av, DH, DH, Gg + p.o_w));
         XVA_TRY(linear_bwd_weight(cw, gQKV, R, DQKV, DQKV, x, DM, DM, Gg + p.qkv_w));
         XVA_TRY(xva_fp_colsum(gQKV, c.dt, Gg + p.qkv_b, R, DQKV, DQKV, cw.st));
@@ -702,7 +829,7 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
             XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
             XVA_TRY(refresh_wt_c2(c, params, c.st));
         }
-    }
+    } else XVA_TRY(refresh_planes(c, params, c.st));
     // encoder                                                              (model.py:346)
     XVA_TRY(xva_fp_embed_fwd(bt->text, c.P + T.word_emb, bt->pos_table, c.A(pl.enc_x[0]), c.dt, B, pl.Tt, DM, c.st));
     XVA_TRY(layers_fwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, DS_ENC));
@@ -925,6 +1052,7 @@ extern "C" int xva_fp_infer_encode(const xva_fp_dims* d0, const float* params, c
     const ParamTable& T = table();
     const int B = pl.B;
     if (d.compute) XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
+    else XVA_TRY(refresh_planes(c, params, c.st));
     XVA_TRY(xva_fp_embed_fwd(bt->text, c.P + T.word_emb, bt->pos_table, c.A(pl.enc_x[0]), c.dt, B, pl.Tt, DM, c.st));
     XVA_TRY(layers_fwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, DS_ENC));
     char* enc_out = c.A(pl.enc_x[NL]);
@@ -956,6 +1084,7 @@ extern "C" int xva_fp_infer_decode(const xva_fp_dims* d0, const float* params, c
     const ParamTable& T = table();
     const int B = pl.B;
     if (d.compute) XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
+    else XVA_TRY(refresh_planes(c, params, c.st));
     int32_t* dec_lens = (int32_t*)c.A(pl.dec_lens);
     XVA_TRY(xva_fp_lenreg_map(durs, (int32_t*)c.A(pl.tok), (int32_t*)c.A(pl.tstart), dec_lens, B, pl.Tt, pl.Tm, 1.0f, c.st));   // :472-474
     XVA_TRY(xva_fp_lenreg_fwd(enc_cond, (int32_t*)c.A(pl.tok), dec_lens, pos_table, c.A(pl.dec_x[0]), c.dt, B, pl.Tt, pl.Tm, DM, c.st));

@@ -27,6 +27,7 @@ extern "C" int xva_gemm_set_mainloop(int mode) { int old = g_glds_mode; g_glds_m
 // three bf16 MFMAs per product (gemm_core.h MODE 3; ~1e-5 relative per product instead of 6e-8).  env XVA_GEMM_FP32_PRODUCTS
 static int g_fp32_products = [] { const char* e = getenv("XVA_GEMM_FP32_PRODUCTS"); return e ? atoi(e) : 0; }();
 extern "C" int xva_gemm_set_fp32_products(int mode) { int old = g_fp32_products; g_fp32_products = mode; return old; }
+extern "C" int xva_gemm_get_fp32_products(void) { return g_fp32_products; }
 
 extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     XVA_CHECK_ARG(pp != nullptr, "xva_gemm: null params");

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void xva_gemm_splitk_reduce_kernel(xva_gemm_pa
 // by the 64-deep K tile, K-block lengths that are multiples of it, 8-element granularity of every index-contiguous dimension.)
 bool xva_gemm_glds_eligible(const xva_gemm_params& p) {
     if (p.compute != 1 || p.a_dtype != XVA_BF16 || p.b_dtype != XVA_BF16) return false;
-    if (p.K % 8 != 0 || p.K < 8) return false;
+    // (TN: k indexes ROWS of both operands — rows past K come from the zero page lane by lane; taken for the split-bf16 pairs, whose products have no other kernel)
+    if ((p.K % 8 != 0 && !(p.planes && p.layout == XVA_GEMM_TN)) || p.K < 8) return false;
     if (p.layout == XVA_GEMM_TN) {
         if (p.M % 8 != 0 || p.N % 8 != 0 || p.M < 8 || p.N < 8) return false;
         if (p.kb_len > 0 && p.K % p.kb_len != 0) return false;
