@@ -645,14 +645,24 @@ def fastpitch_fp32_leg(a, dev, steps=5, warm=2):
         _lib.lib.xva_gemm_set_fp32_products(old_mode)
     res["split_products"] = {"ms_per_step": 1000.0 * dt3 / steps, "value": frames * steps / dt3, "unit": "mel-frames/s", "steps": steps,
                              "final_loss": eng.slot("LOSSES", (8,)).cpu()[0].item(),
-                             "note": "fp32 storage, products as three bf16 MFMAs on hi + lo split operands (16 mantissa bits per operand, fp32 accumulation); "
-                                     "same parity bounds as the exact mode except the post-LAMB parameter norms (1e-4 instead of 1e-5)"}
+                             "note": "fp32 storage, products as three bf16 MFMAs on hi + lo split operands (16 mantissa bits per operand, fp32 accumulation); the feed-forward "
+                                     "convolutions on split-bf16 pairs through the direct-to-LDS kernels (round 5), the attention chain / projections / predictors on the "
+                                     "register-staged kernel that splits while staging; same parity bounds as the exact mode except the post-LAMB parameter norms (1e-4 instead of 1e-5)"}
     del eng, opt, grads, flat
     torch.cuda.empty_cache()
     try:
         res["parity"] = golden_parity("fastpitch", "fp32")
     except Exception as e:
         res["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    old_mode = _lib.lib.xva_gemm_set_fp32_products(1)
+    try:
+        par = golden_parity("fastpitch", "fp32")
+        par["mode"] = "fp32 storage, split-bf16 products"
+        res["split_products"]["parity"] = par
+    except Exception as e:
+        res["split_products"]["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        _lib.lib.xva_gemm_set_fp32_products(old_mode)
     return res
 
 
@@ -1116,6 +1126,10 @@ def main():
     if rank == 0 and world == 1 and a.compute == "bf16" and not a.no_fp32_parity:
         try:
             out["fastpitch_fp32_parity"] = fastpitch_fp32_leg(a, dev)
+            sp = out["fastpitch_fp32_parity"].get("split_products")
+            if isinstance(sp, dict):     # the mode that meets north_star's 1e-3 on outputs and losses at a third of the exact mode's time: a leg of its own on the line
+                out["fastpitch_split"] = {"metric": "mel-frames/sec (FastPitch1.1 train step, fp32 storage + split-bf16 products)", "value": sp["value"], "unit": sp["unit"],
+                                          "ms_per_step": sp["ms_per_step"], "steps": sp["steps"], "dtype": "fp32 storage, bf16x3 products", "parity": sp.get("parity")}
         except Exception as e:                               # an extra measurement: never at the price of the contract line
             out["fastpitch_fp32_parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if not a.no_hifigan:

@@ -411,6 +411,13 @@ static xva_gemm_params gpp(const Ctx& c) {
     g.compute = 1; g.a_dtype = g.b_dtype = XVA_BF16; g.planes = 1;
     return g;
 }
+// the encoder's long reductions into few tiles (4 864 rows): let xva_gemm split K through this lane's slabs and apply the epilogue in the reduce pass (offer_split)
+static void offer_split_p(const Ctx& c, xva_gemm_params& g) {
+    if (g.K >= 1024 && !g.accumulate) {
+        g.splitk = 0;
+        g.sk_ws = c.W + (c.lane == 2 ? c.pl.skws3 : (c.lane ? c.pl.skws2 : c.pl.skws)); g.sk_ws_bytes = c.pl.skws_bytes;
+    }
+}
 static const void* wplane(const Ctx& c, int64_t w_off) { return c.W + c.pl.wplanes + w_off * 2; }
 static const void* wtplane(const Ctx& c, int64_t buf, const LayerP* LP, int l) {
     const ParamTable& T = table();
@@ -428,6 +435,7 @@ static int conv3_fwd_p(Ctx& c, const PlaneT& X, int64_t rows, int Cin, int64_t w
     g.bias = bias; g.act = relu ? XVA_ACT_RELU : XVA_ACT_NONE; g.R = R; g.ldr = Cout; g.r_dtype = XVA_F32;
     g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
     g.drop_p = dr.p; g.drop_seed = c.seed; g.drop_stream = dr.stream;
+    offer_split_p(c, g);
     return xva_gemm(&g, c.st);
 }
 // dX = (dY (*) W^T through the transposed pair wt) [gate] (+R): dXp pair output or fp32 dX
@@ -440,6 +448,7 @@ static int conv3_bwd_data_p(Ctx& c, const PlaneT& dY, int64_t rows, int Cout, co
     g.R = R; g.ldr = Cin; g.r_dtype = XVA_F32;
     if (gate) { g.G = prow(*gate, 0); g.ldg = Cin; g.g_dtype = XVA_BF16; }     // the hi plane: sign and zero-ness of the activation survive the rounding
     g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
+    offer_split_p(c, g);
     return xva_gemm(&g, c.st);
 }
 // dWt[Cout][3*Cin] += dY^T Xcat on pairs

@@ -105,6 +105,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     if (glds_env != 0 && p.K >= 16 && xva_gemm_glds_eligible(p)) {
         const long nb = (long)p.batch * p.batch2;
         nkt = p.kb_len > 0 ? (p.K / p.kb_len) * xva_cdiv(p.kb_len, 64) : xva_cdiv(p.K, 64);   // K blocks are tiled one by one
+        if (p.planes) nkt *= 3;                                                               // split-bf16 pairs: three passes over the K tiles
         auto ntiles = [&](int t) { int bm, bnn; xva_gemm_glds_tile_dims(t, &bm, &bnn); return (long)xva_cdiv(p.N, bnn) * xva_cdiv(p.M, bm) * nb; };
         const long t256 = ntiles(1);
         const double eff256 = (double)p.M * p.N * nb / ((double)t256 * 65536.0);
