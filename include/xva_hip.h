@@ -284,6 +284,12 @@ int xva_fp_softmax_fwd(void* S, void* P_dropped, int dt, const int32_t* lens, in
                        uint32_t stream_id, void* stream);
 int xva_fp_softmax_bwd(const void* P, void* dP, int dt, int B, int Tp, int64_t Ts, float scale, float p_drop, uint64_t seed,
                        uint32_t stream_id, void* stream);
+/* fp32 softmax rows with split-bf16 PAIR outputs (the operands of xva_gemm `planes`, fp32 mode with split products): forward writes P fp32 in place over S and
+ * the (dropped) copy as a pair (hi plane at Pd_pair, lo plane pair_plane elements after it); backward reads P / dP fp32 and writes dS as a pair. */
+int xva_fp_softmax_fwd_pairs(void* S, void* Pd_pair, int64_t pair_plane, const int32_t* lens, int B, int Tp, int64_t Ts, float p_drop, uint64_t seed,
+                             uint32_t stream_id, void* stream);
+int xva_fp_softmax_bwd_pairs(const void* P, const void* dP, void* dS_pair, int64_t pair_plane, int B, int Tp, int64_t Ts, float scale, float p_drop, uint64_t seed,
+                             uint32_t stream_id, void* stream);
 /* Fused single-head attention (d_head = 64) on bf16 tensors: qkv (B, Tp, 192) = [Q | K | V], keys 1..lens[b] valid.
  * Forward writes av (B, Tp, 64) and the per-row logsumexp; backward writes d_qkv (B, Tp, 192) (dscratch: B * Tp floats).
  * Same mathematics and dropout masks as the unfused xva_gemm + xva_fp_softmax_* chain (transformer.py:109-130). */

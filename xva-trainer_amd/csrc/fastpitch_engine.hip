@@ -135,6 +135,7 @@ struct Bump {
     int64_t seq(int64_t rows, int C, int es) { int64_t o = take((rows + 2) * (int64_t)C * es); return o + (int64_t)C * es; }
 };
 
+constexpr int QKV_SPARE = 8;
 struct LayerA { int64_t qkv, P, Pd, lse, av, sum1, mean1, rstd1, y1, h, sum2, mean2, rstd2; };
 struct PredA { int64_t c1, m1, r1, n1, c2, m2, r2, n2, out; };
 struct Plan {
@@ -157,6 +158,7 @@ struct Plan {
     // split-bf16 PLANES (include/xva_gemm.h): the whole parameter table as a pair (wplanes; lo plane wplane_stride elements after hi), transposed tap-reversed
     // pairs of both convolution weights of the 2 x NL layers (wtp_c1 / wtp_c2), and per layer parity a pair buffer for y1 and for d(sum2) (yp / gp; rows -1 .. R)
     int64_t wplanes, wplane_stride, wtp_c1, wtp_c2, yp[2], gp[2];
+    int64_t xp[2], dp[2], gPp;   // the same for the layer input x and d(sum1) (rows -1 .. R, DM channels), and d(scores) as a pair (B x Tp x Ts)
     int64_t wt_c2;      // bf16 mode: transposed, tap-reversed copies of the 2 x NL conv2 weights ([DI][3][DM] each; encoder layers first) for the NT backward-data form
     int64_t total;
 };
@@ -187,10 +189,12 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     auto plan_layers = [&](int64_t R, int Tp, int64_t Ts, int64_t* x, LayerA* L) {
         x[0] = b.seq(R, DM, es);
         for (int i = 0; i < NL; ++i) {
-            L[i].qkv = b.seq(R, DQKV, es);
+            // fp32 mode with the split-products planes path: QKV_SPARE spare rows — the products over the keys take K = Ts = round-up-8(Tp) and read up to 7 rows past the last item
+            L[i].qkv = b.seq(R + ((!fused && g_ffn_planes) ? QKV_SPARE : 0), DQKV, es);
             // bf16 mode runs the fused attention kernels (attention.hip): no (T x T) probability matrices, one logsumexp per row
             L[i].P = fused ? -1 : b.take((int64_t)p->B * Tp * Ts * es + 64);
-            L[i].Pd = fused ? -1 : (drop ? b.take((int64_t)p->B * Tp * Ts * es + 64) : L[i].P);
+            // (the split-products planes path keeps the dropped copy as a split-bf16 pair in the same bytes: it needs its own buffer without dropout too)
+            L[i].Pd = fused ? -1 : ((drop || g_ffn_planes) ? b.take((int64_t)p->B * Tp * Ts * es + 64) : L[i].P);
             L[i].lse = fused ? b.take(R * 4) : -1;
             L[i].av = b.seq(R, DH, es);
             L[i].sum1 = b.seq(R, DM, es);
@@ -236,14 +240,28 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     p->gH2 = b.seq(Rm, DI, es); p->gQKV2 = b.seq(Rm, DQKV, es);
     p->wshadow = d->compute ? b.take(table().total * es) : -1;
     p->wt_c2 = (d->compute && g_bwd_nt) ? b.take((int64_t)2 * NL * DI * 3 * DM * 2) : -1;
-    p->wplanes = p->wtp_c1 = p->wtp_c2 = p->yp[0] = p->yp[1] = p->gp[0] = p->gp[1] = -1;
+    p->wplanes = p->wtp_c1 = p->wtp_c2 = p->yp[0] = p->yp[1] = p->gp[0] = p->gp[1] = p->xp[0] = p->xp[1] = p->dp[0] = p->dp[1] = p->gPp = -1;
     p->wplane_stride = (table().total + 7) / 8 * 8;
     if (!d->compute && g_ffn_planes) {
         p->wplanes = b.take(2 * p->wplane_stride * 2);
         p->wtp_c1 = b.take((int64_t)2 * (2 * NL) * DI * 3 * DM * 2); p->wtp_c2 = b.take((int64_t)2 * (2 * NL) * DI * 3 * DM * 2);
-        for (int q = 0; q < 2; ++q) { p->yp[q] = b.take(2 * (Rm + 2) * DM * 2); p->gp[q] = b.take(2 * (Rm + 2) * DM * 2); }
+        for (int q = 0; q < 2; ++q) {
+            p->yp[q] = b.take(2 * (Rm + 2) * DM * 2); p->gp[q] = b.take(2 * (Rm + 2) * DM * 2);
+            p->xp[q] = b.take(2 * (Rm + 2) * DM * 2); p->dp[q] = b.take(2 * (Rm + 2) * DM * 2);
+        }
+        p->gPp = b.take((int64_t)p->B * Tpm * Tsm * 4 + 64);
     }
     p->total = b.cur;
+    static const bool dump = getenv("XVA_FP_DUMP_PLAN") != nullptr;      // debugging: the byte offsets of the plan's slots
+    if (dump) {
+        fprintf(stderr, "PLAN enc_x0 %ld", (long)p->enc_x[0]);
+        for (int i = 0; i < NL; ++i) fprintf(stderr, " | enc%d qkv %ld P %ld Pd %ld av %ld sum1 %ld y1 %ld h %ld sum2 %ld x %ld", i, (long)p->enc[i].qkv, (long)p->enc[i].P, (long)p->enc[i].Pd,
+                                             (long)p->enc[i].av, (long)p->enc[i].sum1, (long)p->enc[i].y1, (long)p->enc[i].h, (long)p->enc[i].sum2, (long)p->enc_x[i + 1]);
+        fprintf(stderr, " | dur.c1 %ld pitch.c1 %ld energy.c1 %ld energy.out %ld ptgt %ld etgt %ld enc_c1 %ld enc_c2 %ld tok %ld dec_x0 %ld dec0.qkv %ld mel_out %ld gA %ld gH %ld gAV %ld gP %ld gQKV %ld gE %ld pa %ld pb %ld skws %ld gX1 %ld gX2 %ld wplanes %ld total %ld\n",
+                (long)p->dur.c1, (long)p->pitch.c1, (long)p->energy.c1, (long)p->energy.out, (long)p->ptgt, (long)p->etgt, (long)p->enc_c1, (long)p->enc_c2, (long)p->tok, (long)p->dec_x[0],
+                (long)p->dec[0].qkv, (long)p->mel_out, (long)p->gA, (long)p->gH, (long)p->gAV, (long)p->gP, (long)p->gQKV, (long)p->gE, (long)p->pa, (long)p->pb, (long)p->skws, (long)p->gX1, (long)p->gX2,
+                (long)p->wplanes, (long)p->total);
+    }
     return XVA_OK;
 }
 
@@ -389,21 +407,28 @@ static int conv3_bwd_weight(Ctx& c, const void* dY, int64_t rows, int Cout, cons
 
 // ------------------------------------------------------------------ split-bf16 planes (fp32 mode, split products) ----
 // A sequence tensor as a split-bf16 pair (include/xva_gemm.h): hi plane rows -1 .. R (the guard rows are zeros), lo plane `plane` elements after it.
-struct PlaneT { char* base; int64_t plane; int C; };
+struct PlaneT { char* base; int64_t plane; int C; int extra = 0; };     // extra: spare rows after row R in each plane
 static inline char* prow(const PlaneT& t, int64_t row) { return t.base + (row + 1) * (int64_t)t.C * 2; }                  // hi plane, row `row`
 // the pair that lives IN an fp32 sequence slot of R rows x C channels (same bytes: 2 planes x (R + 2) rows x 2 B = (R + 2) rows x 4 B)
-static inline PlaneT planes_in_slot(char* row0_fp32, int64_t R, int C) { return PlaneT{row0_fp32 - (int64_t)C * 4, (R + 2) * (int64_t)C, C}; }
+static inline PlaneT planes_in_slot(char* row0_fp32, int64_t R, int C, int extra = 0) { return PlaneT{row0_fp32 - (int64_t)C * 4, (R + 2 + extra) * (int64_t)C, C, extra}; }
 static inline PlaneT planes_scratch(const Ctx& c, int64_t off, int64_t Rm) { return PlaneT{c.W + off, (Rm + 2) * (int64_t)DM, DM}; }
-static bool ffn_planes_on(const Ctx& c) { return !c.compute && c.pl.wplanes >= 0 && g_ffn_planes && xva_gemm_get_fp32_products() == 1; }
+static bool planes_mode(const Ctx& c) { return !c.compute && c.pl.wplanes >= 0 && g_ffn_planes && xva_gemm_get_fp32_products() == 1; }
+// per stack: the direct-to-LDS kernels want at least a K tile of rows / keys (toy sequences stay on the register-staged kernel)
+// XVA_FP_PLANES_MASK (A/B, debugging): bit 0 encoder stack, bit 1 decoder stack, bit 2 the attention block (clear: feed-forward only); default 7
+static const int g_planes_mask = [] { const char* e = getenv("XVA_FP_PLANES_MASK"); return e ? atoi(e) : 7; }();
+static bool ffn_planes_on(const Ctx& c, int64_t R, int Tp) {
+    const bool enc = R == c.pl.Re && Tp == c.pl.Ttp;
+    return planes_mode(c) && R >= 64 && Tp >= 16 && (g_planes_mask & (enc ? 1 : 2));
+}
+static bool att_planes_on(const Ctx& c, int64_t R, int Tp) { return ffn_planes_on(c, R, Tp) && (g_planes_mask & 4); }
 // fp32 rows -1 .. R of a sequence tensor -> the pair
 static int split_rows(const Ctx& c, const char* row0_fp32, int64_t R, const PlaneT& dst, void* st) {
     return xva_split_bf16(reinterpret_cast<const float*>(row0_fp32 - (int64_t)dst.C * 4), dst.base, dst.plane, (R + 2) * (int64_t)dst.C, st);
 }
 // the slot held fp32 rows before (exact mode on the same workspace): the two guard rows in the MIDDLE of the pair (hi row R, lo row -1) are then stale
 static int zero_mid_guards(const Ctx& c, const PlaneT& t, int64_t R, void* st) {
-    (void)c;
-    if (hipMemsetAsync(prow(t, R), 0, (size_t)t.C * 2, (hipStream_t)st) != hipSuccess ||
-        hipMemsetAsync(t.base + t.plane * 2, 0, (size_t)t.C * 2, (hipStream_t)st) != hipSuccess) { xva_set_error("fastpitch: memset failed"); return XVA_ERR_HIP; }
+    (void)c;                                               // hi rows R .. R + extra and lo row -1 are adjacent
+    if (hipMemsetAsync(prow(t, R), 0, (size_t)(2 + t.extra) * t.C * 2, (hipStream_t)st) != hipSuccess) { xva_set_error("fastpitch: memset failed"); return XVA_ERR_HIP; }
     return XVA_OK;
 }
 static xva_gemm_params gpp(const Ctx& c) {
@@ -461,7 +486,7 @@ static int conv3_bwd_weight_p(Ctx& c, const PlaneT& dY, int64_t rows, int Cout, 
 }
 // the parameter table and the transposed convolution weights as pairs (once per forward, like the bf16 mode's shadow)
 static int refresh_planes(const Ctx& c, const float* params, void* st) {
-    if (!ffn_planes_on(c)) return XVA_OK;
+    if (!planes_mode(c)) return XVA_OK;
     const ParamTable& T = table();
     const int64_t n8 = T.total / 8 * 8;
     XVA_TRY(xva_split_bf16(params, c.W + c.pl.wplanes, c.pl.wplane_stride, n8, st));
@@ -480,6 +505,127 @@ static int refresh_planes(const Ctx& c, const float* params, void* st) {
 // dropout sites: stream id = site_base + layer * 4 + {0 attention probs, 1 o_net output, 2 conv2 output}
 enum { DS_ENC = 0, DS_DEC = 100, DS_PRED = 200 };
 
+
+// ---- the attention block on split-bf16 pairs (fp32 mode, split products; transformer.py:100-152) -------------------------------------------------
+// Every product of MultiHeadAttn — qkv projection, Q K^T, P V, o_net and their backward forms — as ONE `planes` launch each on the direct-to-LDS kernels;
+// qkv, the dropped probabilities, A V and the gradients d(A V), d(scores), d(qkv) live as pairs in the bytes of their fp32 slots; the probabilities and
+// d(probabilities) stay fp32 for the softmax kernels, which emit the pairs the next products read.  Products over the keys take K = Ts (the row pitch,
+// a multiple of 8): columns Tp .. Ts - 1 of the probability rows are zeros.
+#define XVA_HIP_TRY(x) do { if ((x) != hipSuccess) { xva_set_error("fastpitch: stream / event call failed: " #x); return XVA_ERR_HIP; } } while (0)
+static void pgemm_common(xva_gemm_params& g, const PlaneT* A, const PlaneT* B, const PlaneT* Cp) {
+    if (A) g.a_plane = A->plane;
+    if (B) g.b_plane = B->plane;
+    if (Cp) { g.c_dtype = XVA_BF16; g.c_plane = Cp->plane; }
+}
+static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* x, int64_t R, int Tp, int64_t Ts, const int32_t* lens, uint32_t s0) {
+    const int B = c.pl.B;
+    const int64_t Rmax = c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re;
+    const PlaneT xp = planes_scratch(c, c.pl.xp[0], Rmax), qp = planes_in_slot(c.A(a.qkv), R, DQKV, QKV_SPARE), avp = planes_in_slot(c.A(a.av), R, DH);
+    const PlaneT wq{nullptr, c.pl.wplane_stride, 0};
+    const PlaneT pdp{c.A(a.Pd), (int64_t)B * Tp * Ts, 0};
+    XVA_TRY(split_rows(c, x, R, xp, c.st));
+    XVA_TRY(zero_mid_guards(c, qp, R, c.st));
+    XVA_TRY(zero_mid_guards(c, avp, R, c.st));
+    {   // qkv = x Wqkv^T + b, stored as a pair
+        xva_gemm_params g = gpp(c); pgemm_common(g, &xp, &wq, &qp);
+        g.layout = XVA_GEMM_NT; g.A = prow(xp, 0); g.B = wplane(c, p.qkv_w); g.C = prow(qp, 0); g.M = (int)R; g.N = DQKV; g.K = DM; g.lda = DM; g.ldb = DM; g.ldc = DQKV;
+        g.bias = c.P + p.qkv_b;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    {   // S = scale * Q K^T per item (fp32)
+        xva_gemm_params g = gpp(c); pgemm_common(g, &qp, &qp, nullptr);
+        g.layout = XVA_GEMM_NT; g.A = prow(qp, 0); g.B = prow(qp, 0) + DH * 2; g.C = c.A(a.P); g.c_dtype = XVA_F32; g.M = Tp; g.N = Tp; g.K = DH;
+        g.lda = DQKV; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DQKV; g.sB = g.sA; g.sC = (int64_t)Tp * Ts; g.alpha = 0.125f;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    XVA_TRY(xva_fp_softmax_fwd_pairs(c.A(a.P), pdp.base, pdp.plane, lens, B, Tp, Ts, c.pd, c.seed, s0 + 0, c.st));
+    {   // AV = dropatt(P) V, stored as a pair
+        xva_gemm_params g = gpp(c); pgemm_common(g, &pdp, &qp, &avp);
+        g.layout = XVA_GEMM_NN; g.A = pdp.base; g.B = prow(qp, 0) + 2 * DH * 2; g.C = prow(avp, 0); g.M = Tp; g.N = DH; g.K = (int)Ts;
+        g.lda = Ts; g.ldb = DQKV; g.ldc = DH; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DH;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    {   // sum1 = x + drop(AV Wo^T) (fp32)
+        xva_gemm_params g = gpp(c); pgemm_common(g, &avp, &wq, nullptr);
+        g.layout = XVA_GEMM_NT; g.A = prow(avp, 0); g.B = wplane(c, p.o_w); g.C = c.A(a.sum1); g.c_dtype = XVA_F32; g.M = (int)R; g.N = DM; g.K = DH; g.lda = DH; g.ldb = DH; g.ldc = DM;
+        g.R = x; g.ldr = DM; g.r_dtype = XVA_F32; g.drop_p = c.pd; g.drop_seed = c.seed; g.drop_stream = s0 + 1;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    return XVA_OK;
+}
+// backward of the same block: gDm = d(sum1) masked by o_net's dropout (fp32) -> gA = gD + d x through the block (fp32, LEN-masked).  Leaves the pairs the
+// weight gradients read (dp, xp of this layer parity; gQKV's slot) in place.
+static int attention_bwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* x, char* gDm, char* gD, char* gAV, char* gP, char* gQKV, char* gA, int par,
+                                int64_t R, int Tp, int64_t Ts, const int32_t* lens, uint32_t s0) {
+    const int B = c.pl.B;
+    const int64_t Rmax = c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re;
+    const PlaneT dpp = planes_scratch(c, c.pl.dp[par], Rmax), xp = planes_scratch(c, c.pl.xp[par], Rmax);
+    const PlaneT qp = planes_in_slot(c.A(a.qkv), R, DQKV, QKV_SPARE), avp = planes_in_slot(c.A(a.av), R, DH);
+    const PlaneT gavp = planes_in_slot(gAV, Rmax, DH), gqp = planes_in_slot(gQKV, Rmax, DQKV);
+    const PlaneT wq{nullptr, c.pl.wplane_stride, 0};
+    const PlaneT pdp{c.A(a.Pd), (int64_t)B * Tp * Ts, 0}, dsp{c.A(c.pl.gPp), (int64_t)B * Tp * Ts, 0};
+    XVA_TRY(split_rows(c, gDm, R, dpp, c.st));
+    XVA_TRY(split_rows(c, x, R, xp, c.st));
+    XVA_TRY(zero_mid_guards(c, gavp, Rmax, c.st));
+    XVA_TRY(zero_mid_guards(c, gqp, Rmax, c.st));
+    {   // gAV = gDm Wo
+        xva_gemm_params g = gpp(c); pgemm_common(g, &dpp, &wq, &gavp);
+        g.layout = XVA_GEMM_NN; g.A = prow(dpp, 0); g.B = wplane(c, p.o_w); g.C = prow(gavp, 0); g.M = (int)R; g.N = DH; g.K = DM; g.lda = DM; g.ldb = DH; g.ldc = DH;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    {   // dPd = gAV V^T (fp32)
+        xva_gemm_params g = gpp(c); pgemm_common(g, &gavp, &qp, nullptr);
+        g.layout = XVA_GEMM_NT; g.A = prow(gavp, 0); g.B = prow(qp, 0) + 2 * DH * 2; g.C = gP; g.c_dtype = XVA_F32; g.M = Tp; g.N = Tp; g.K = DH;
+        g.lda = DH; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DH; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * Ts;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    {   // dV = Pd^T gAV -> gQKV[:, 128:192]
+        xva_gemm_params g = gpp(c); pgemm_common(g, &pdp, &gavp, &gqp);
+        g.layout = XVA_GEMM_TN; g.A = pdp.base; g.B = prow(gavp, 0); g.C = prow(gqp, 0) + 2 * DH * 2; g.M = Tp; g.N = DH; g.K = Tp;
+        g.lda = Ts; g.ldb = DH; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DH; g.sC = (int64_t)Tp * DQKV;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    XVA_TRY(xva_fp_softmax_bwd_pairs(c.A(a.P), gP, dsp.base, dsp.plane, B, Tp, Ts, 0.125f, c.pd, c.seed, s0 + 0, c.st));      // dS (incl. 1/sqrt(d)) as a pair
+    {   // dQ = dS K -> gQKV[:, 0:64]
+        xva_gemm_params g = gpp(c); pgemm_common(g, &dsp, &qp, &gqp);
+        g.layout = XVA_GEMM_NN; g.A = dsp.base; g.B = prow(qp, 0) + DH * 2; g.C = prow(gqp, 0); g.M = Tp; g.N = DH; g.K = (int)Ts;
+        g.lda = Ts; g.ldb = DQKV; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DQKV;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    {   // dK = dS^T Q -> gQKV[:, 64:128]
+        xva_gemm_params g = gpp(c); pgemm_common(g, &dsp, &qp, &gqp);
+        g.layout = XVA_GEMM_TN; g.A = dsp.base; g.B = prow(qp, 0); g.C = prow(gqp, 0) + DH * 2; g.M = Tp; g.N = DH; g.K = Tp;
+        g.lda = Ts; g.ldb = DQKV; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DQKV;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    {   // d x = gD + gQKV Wqkv, LEN-masked -> gA (fp32)
+        xva_gemm_params g = gpp(c); pgemm_common(g, &gqp, &wq, nullptr);
+        g.layout = XVA_GEMM_NN; g.A = prow(gqp, 0); g.B = wplane(c, p.qkv_w); g.C = gA; g.c_dtype = XVA_F32; g.M = (int)R; g.N = DM; g.K = DQKV; g.lda = DQKV; g.ldb = DM; g.ldc = DM;
+        g.R = gD; g.ldr = DM; g.r_dtype = XVA_F32; g.mask_mode = XVA_MASK_LEN; g.lens = lens; g.Tp = Tp;
+        XVA_TRY(xva_gemm(&g, c.st));
+    }
+    return XVA_OK;
+}
+// the block's weight gradients and the qkv bias sums from the pairs attention_bwd_planes left (issued to cw's lane)
+static int attention_wgrad_planes(Ctx& cw, const LayerP& p, const LayerA& a, char* gQKV, int par, int64_t R, float* Gg) {
+    const Ctx& c = cw;
+    const int64_t Rmax = c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re;
+    const PlaneT dpp = planes_scratch(c, c.pl.dp[par], Rmax), xp = planes_scratch(c, c.pl.xp[par], Rmax);
+    const PlaneT avp = planes_in_slot(c.A(a.av), R, DH), gqp = planes_in_slot(gQKV, Rmax, DQKV);
+    auto wgrad = [&](const PlaneT& dY, int M, const PlaneT& X, int N, float* dW) {
+        xva_gemm_params g = gpp(cw); pgemm_common(g, &dY, &X, nullptr);
+        g.layout = XVA_GEMM_TN; g.A = prow(dY, 0); g.B = prow(X, 0); g.C = dW; g.c_dtype = XVA_F32; g.M = M; g.N = N; g.K = (int)R; g.lda = M; g.ldb = N; g.ldc = N;
+        g.accumulate = 1; g.splitk = 0;
+        g.sk_ws = cw.W + (cw.lane == 2 ? cw.pl.skws3 : (cw.lane ? cw.pl.skws2 : cw.pl.skws)); g.sk_ws_bytes = cw.pl.skws_bytes;
+        return xva_gemm(&g, cw.st);
+    };
+    XVA_TRY(wgrad(dpp, DM, avp, DH, Gg + p.o_w));
+    XVA_TRY(wgrad(gqp, DQKV, xp, DM, Gg + p.qkv_w));
+    XVA_TRY(xva_fp_colsum(prow(gqp, 0), XVA_BF16, Gg + p.qkv_b, R, DQKV, DQKV, cw.st));
+    XVA_TRY(xva_fp_colsum(prow(gqp, 0) + gqp.plane * 2, XVA_BF16, Gg + p.qkv_b, R, DQKV, DQKV, cw.st));
+    return XVA_OK;
+}
+
 // ------------------------------------------------------------------ transformer stack ----
 static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t* xo, int64_t R, int Tp, int64_t Ts,
                       const int32_t* lens, int site) {
@@ -490,12 +636,16 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         char* x = c.A(xo[l]);
         char* qkv = c.A(a.qkv); char* av = c.A(a.av);
         const uint32_t s0 = site + l * 4;
+        const bool att_planes = att_planes_on(c, R, Tp), ffn_planes = ffn_planes_on(c, R, Tp);
+        if (att_planes) {
+            XVA_TRY(attention_fwd_planes(c, p, a, x, R, Tp, Ts, lens, s0));
+        } else {
         // qkv = x Wqkv^T + b                                             (transformer.py:109)
         XVA_TRY(linear_fwd(c, x, R, DM, DM, p.qkv_w, c.P + p.qkv_b, qkv, DQKV, DQKV, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
         if (c.compute) {
             XVA_TRY(xva_fp_attention_fwd(qkv, lens, av, c.F(a.lse), B, Tp, 0.125f, c.pd, c.seed, s0 + 0, c.st));   // transformer.py:118-130
         } else {
-            char* Pm = c.A(a.P); char* Pdm = c.A(a.Pd);
+            char* Pm = c.A(a.P); char* Pdm = c.pd > 0.f ? c.A(a.Pd) : c.A(a.P);
             {   // S = scale * Q K^T per item                                  (transformer.py:118-119)
                 xva_gemm_params g = gp0(c);
                 g.layout = XVA_GEMM_NT; g.A = qkv; g.B = c.sh(qkv, DH); g.C = Pm; g.M = Tp; g.N = Tp; g.K = DH;
@@ -513,10 +663,11 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         }
         // sum1 = x + drop(AV Wo^T) ; y1 = LN(sum1) * mask                  (transformer.py:137-146,166-167)
         XVA_TRY(linear_fwd(c, av, R, DH, DH, p.o_w, nullptr, c.A(a.sum1), DM, DM, x, DM, XVA_MASK_NONE, nullptr, 0, Drop{c.pd, s0 + 1}));
+        }
         XVA_TRY(xva_fp_layernorm_fwd(c.A(a.sum1), c.P + p.ln1_g, c.P + p.ln1_b, c.A(a.y1), c.dt, c.F(a.mean1), c.F(a.rstd1), R, DM,
                                      XVA_MASK_LEN, lens, Tp, 0.f, 0, 0, c.st));
         // h = relu(conv1(y1)) ; sum2 = y1 + drop(conv2(h)) ; x' = LN(sum2) * mask  (transformer.py:59-77,168-170)
-        if (ffn_planes_on(c)) {     // fp32 mode, split products: both convolutions on split-bf16 pairs (h is stored as a pair in its fp32 slot)
+        if (ffn_planes) {     // fp32 mode, split products: both convolutions on split-bf16 pairs (h is stored as a pair in its fp32 slot)
             const PlaneT yp = planes_scratch(c, c.pl.yp[0], c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re), hp = planes_in_slot(c.A(a.h), R, DI);
             XVA_TRY(split_rows(c, c.A(a.y1), R, yp, c.st));
             XVA_TRY(zero_mid_guards(c, hp, R, c.st));
@@ -571,7 +722,6 @@ static WgLane& wg_lane() {
     return r;
 }
 static int g_fp_serial = 0;     // xva_fp_set_streams(1): everything on the caller's stream (per-kernel measurements)
-#define XVA_HIP_TRY(x) do { if ((x) != hipSuccess) { xva_set_error("fastpitch: stream / event call failed: " #x); return XVA_ERR_HIP; } } while (0)
 
 static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t* xo, int64_t R, int Tp, int64_t Ts,
                       const int32_t* lens, bool last_bucket_deferred, int site) {
@@ -603,7 +753,7 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         XVA_TRY(xva_fp_layernorm_bwd(gA, c.A(a.sum2), c.F(a.mean2), c.F(a.rstd2), c.P + p.ln2_g, gB, drop ? gBm : nullptr, c.dt, Gg + p.ln2_g,
                                      Gg + p.ln2_b, R, DM, XVA_MASK_LEN, lens, Tp, 0, 0.f, 0, 0, c.pd, c.seed, s0 + 2, nullptr, nullptr, c.st));
         // conv2 backward: gH = (gBm (*) W2) * [h > 0], structural rows zero
-        const bool planes = ffn_planes_on(c);
+        const bool planes = ffn_planes_on(c, R, Tp);
         const int64_t Rmax = c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re;
         const PlaneT gBp = planes_scratch(c, c.pl.gp[planes ? par : 0], Rmax), y1p = planes_scratch(c, c.pl.yp[planes ? par : 0], Rmax);
         const PlaneT gHp = planes_in_slot(gH, Rmax, DI), hp = planes_in_slot(c.A(a.h), R, DI);
@@ -621,12 +771,16 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         // LN1 backward -> gD = d sum1 ; gDm = gD * dropmask (o_net branch)
         XVA_TRY(xva_fp_layernorm_bwd(gC, c.A(a.sum1), c.F(a.mean1), c.F(a.rstd1), c.P + p.ln1_g, gD, drop ? gDm : nullptr, c.dt, Gg + p.ln1_g,
                                      Gg + p.ln1_b, R, DM, XVA_MASK_LEN, lens, Tp, 0, 0.f, 0, 0, c.pd, c.seed, s0 + 1, nullptr, nullptr, c.st));
+        const bool att_planes = att_planes_on(c, R, Tp);
+        if (att_planes) {           // the attention block on split-bf16 pairs (qkv, the dropped probabilities and A V are pairs since the forward pass)
+            XVA_TRY(attention_bwd_planes(c, p, a, x, gDm, gD, gAV, gP, gQKV, gA, par, R, Tp, Ts, lens, s0));
+        } else {
         // o_net backward
         XVA_TRY(linear_bwd_data(c, gDm, R, DM, DM, p.o_w, DH, gAV, DH, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
         if (c.compute) {
             XVA_TRY(xva_fp_attention_bwd(qkv, av, gAV, c.F(a.lse), (float*)gP, lens, gQKV, B, Tp, 0.125f, c.pd, c.seed, s0 + 0, c.st));
         } else {
-            char* Pm = c.A(a.P); char* Pdm = c.A(a.Pd);
+            char* Pm = c.A(a.P); char* Pdm = c.pd > 0.f ? c.A(a.Pd) : c.A(a.P);
             {   // dPd = dAV V^T
                 xva_gemm_params g = gp0(c);
                 g.layout = XVA_GEMM_NT; g.A = gAV; g.B = c.sh(qkv, 2 * DH); g.C = gP; g.M = Tp; g.N = Tp; g.K = DH;
@@ -655,6 +809,7 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         }
         // d x = gD + gQKV Wqkv, LEN-masked -> gA
         XVA_TRY(linear_bwd_data(c, gQKV, R, DQKV, DQKV, p.qkv_w, DM, gA, DM, gD, DM, XVA_MASK_LEN, lens, Tp));
+        }
         // weight gradients and bias sums of this layer (models' transformer.py:21-147 parameters), on the side lane when there is one
         if (two) {
             XVA_HIP_TRY(hipEventRecord(wl.chain[l], (hipStream_t)c.st));
@@ -672,9 +827,13 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         XVA_TRY(conv3_bwd_weight(cw, gH, R, DI, c.A(a.y1), DM, Gg + p.c1_w));
         XVA_TRY(xva_fp_colsum(gH, c.dt, Gg + p.c1_b, R, DI, DI, cw.st));
         }
+        if (att_planes) {
+            if (!(g_planes_mask & 8)) XVA_TRY(attention_wgrad_planes(cw, p, a, gQKV, par, R, Gg));
+        } else {
         XVA_TRY(linear_bwd_weight(cw, gDm, R, DM, DM, av, DH, DH, Gg + p.o_w));
         XVA_TRY(linear_bwd_weight(cw, gQKV, R, DQKV, DQKV, x, DM, DM, Gg + p.qkv_w));
         XVA_TRY(xva_fp_colsum(gQKV, c.dt, Gg + p.qkv_b, R, DQKV, DQKV, cw.st));
+        }
         if (two) XVA_HIP_TRY(hipEventRecord(wl.done[l], wl.s));
         if (l > 0 || !last_bucket_deferred) XVA_TRY(cw.record(c.ev_base + (NL - 1 - l)));
     }

@@ -99,8 +99,17 @@ extern "C" int xva_fp_embed_bwd(const int32_t* ids, const void* dX, int dt, floa
 #define SM_MAXPL 32  // up to 64*32 = 2048 keys per row
 // Writes the probabilities P in place over S; with attention dropout (dropatt, transformer.py:128) ALSO writes the dropped
 // copy Pd = P * m / (1 - p) that the P.V product consumes (backward needs the undropped P for the softmax Jacobian).
+// pair_plane > 0 (fp32 S): Pd is written as a split-bf16 pair (hi plane at Pd, lo plane pair_plane elements after it: the operand of xva_gemm `planes`)
+__device__ __forceinline__ void sm_store_pair(void* base, int64_t i, int64_t plane, float v) {
+    uint32_t u = __float_as_uint(v); u += 0x7fffu + ((u >> 16) & 1u);
+    const uint16_t h = (uint16_t)(u >> 16);
+    const float r = v - __uint_as_float((uint32_t)h << 16);
+    uint32_t w = __float_as_uint(r); w += 0x7fffu + ((w >> 16) & 1u);
+    reinterpret_cast<uint16_t*>(base)[i] = h;
+    reinterpret_cast<uint16_t*>(base)[i + plane] = (uint16_t)(w >> 16);
+}
 __global__ void softmax_fwd_kernel(void* __restrict__ S, void* __restrict__ Pd, int dt, const int* __restrict__ lens, int B, int Tp,
-                                   int64_t Ts, float p_drop, uint64_t seed, uint32_t stream_id) {
+                                   int64_t Ts, float p_drop, uint64_t seed, uint32_t stream_id, int64_t pair_plane) {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     if (row >= (int64_t)B * Tp) return;
@@ -130,13 +139,17 @@ __global__ void softmax_fwd_kernel(void* __restrict__ S, void* __restrict__ Pd, 
         if (j < Ts) {
             float pv = v[i] * inv;
             a_st(S, base + j, dt, pv);
-            if (Pd) a_st(Pd, base + j, dt, pv * xva_dropout_scale(p_drop, seed, stream_id, (uint64_t)row * Tp + j));
+            if (Pd) {
+                const float pd = pv * xva_dropout_scale(p_drop, seed, stream_id, (uint64_t)row * Tp + j);
+                if (pair_plane) sm_store_pair(Pd, base + j, pair_plane, pd); else a_st(Pd, base + j, dt, pd);
+            }
         }
     }
 }
 // dS = scale * P * (dP - sum_k dP_k P_k) in place over dP, where dP = dPd * m (attention-dropout mask regenerated).
+// dS_pair != nullptr (fp32 P / dP): dS goes there as a split-bf16 pair instead of in place
 __global__ void softmax_bwd_kernel(const void* __restrict__ P, void* __restrict__ dP, int dt, int B, int Tp, int64_t Ts, float scale,
-                                   float p_drop, uint64_t seed, uint32_t stream_id) {
+                                   float p_drop, uint64_t seed, uint32_t stream_id, void* __restrict__ dS_pair, int64_t pair_plane) {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     if (row >= (int64_t)B * Tp) return;
@@ -157,7 +170,10 @@ __global__ void softmax_bwd_kernel(const void* __restrict__ P, void* __restrict_
 #pragma unroll
     for (int i = 0; i < SM_MAXPL; ++i) {
         int j = lane + 64 * i;
-        if (j < Ts) a_st(dP, base + j, dt, (j < Tp) ? scale * pv[i] * (dv[i] - dot) : 0.f);
+        if (j < Ts) {
+            const float ds = (j < Tp) ? scale * pv[i] * (dv[i] - dot) : 0.f;
+            if (dS_pair) sm_store_pair(dS_pair, base + j, pair_plane, ds); else a_st(dP, base + j, dt, ds);
+        }
     }
 }
 
@@ -168,7 +184,16 @@ extern "C" int xva_fp_softmax_fwd(void* S, void* Pd, int dt, const int32_t* lens
     XVA_CHECK_ARG(p_drop == 0.f || Pd, "softmax_fwd: attention dropout needs the dropped-copy buffer");
     int64_t rows = (int64_t)B * Tp;
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3(xva_cdiv(rows, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
-                       (hipStream_t)stream, S, p_drop > 0.f ? Pd : (void*)nullptr, dt, lens, B, Tp, Ts, p_drop, seed, stream_id);
+                       (hipStream_t)stream, S, p_drop > 0.f ? Pd : (void*)nullptr, dt, lens, B, Tp, Ts, p_drop, seed, stream_id, (int64_t)0);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_fp_softmax_fwd_pairs(void* S, void* Pd_pair, int64_t pair_plane, const int32_t* lens, int B, int Tp, int64_t Ts, float p_drop, uint64_t seed,
+                                        uint32_t stream_id, void* stream) {
+    XVA_CHECK_ARG(S && Pd_pair && lens && pair_plane > 0 && Ts >= Tp && Ts <= 64 * SM_MAXPL, "softmax_fwd_pairs: bad args");
+    int64_t rows = (int64_t)B * Tp;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(xva_cdiv(rows, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
+                       (hipStream_t)stream, S, Pd_pair, XVA_F32, lens, B, Tp, Ts, p_drop, seed, stream_id, pair_plane);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
@@ -177,7 +202,16 @@ extern "C" int xva_fp_softmax_bwd(const void* P, void* dP, int dt, int B, int Tp
     XVA_CHECK_ARG(P && dP && Ts >= Tp && Ts <= 64 * SM_MAXPL, "softmax_bwd: bad args");
     int64_t rows = (int64_t)B * Tp;
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(xva_cdiv(rows, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
-                       (hipStream_t)stream, P, dP, dt, B, Tp, Ts, scale, p_drop, seed, stream_id);
+                       (hipStream_t)stream, P, dP, dt, B, Tp, Ts, scale, p_drop, seed, stream_id, (void*)nullptr, (int64_t)0);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_fp_softmax_bwd_pairs(const void* P, const void* dP, void* dS_pair, int64_t pair_plane, int B, int Tp, int64_t Ts, float scale, float p_drop,
+                                        uint64_t seed, uint32_t stream_id, void* stream) {
+    XVA_CHECK_ARG(P && dP && dS_pair && pair_plane > 0 && Ts >= Tp && Ts <= 64 * SM_MAXPL, "softmax_bwd_pairs: bad args");
+    int64_t rows = (int64_t)B * Tp;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(xva_cdiv(rows, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
+                       (hipStream_t)stream, P, const_cast<void*>(dP), XVA_F32, B, Tp, Ts, scale, p_drop, seed, stream_id, dS_pair, pair_plane);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }

@@ -611,7 +611,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
     Loader<AK, BM, NW> la;
     Loader<BKD, BN, NW> lb;
     if constexpr (AK == KC) la.init(lane, wave, m0, p.M, p.lda, 0, 0, 0, p.a_seglen, p.a_segadj);
-    else la.init(lane, wave, m0, p.M, p.lda, p.a_seglen, 0, p.a_segadj);          // TN: A column m -> m + (m / a_seglen) * a_segadj
+    else la.init(lane, wave, m0, (p.M + 7) & ~7, p.lda, p.a_seglen, 0, p.a_segadj);          // TN: A column m -> m + (m / a_seglen) * a_segadj; bound: see xva_gemm_glds_eligible
     if constexpr (BKD == KC) lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0);
     else if constexpr (LAYOUT == XVA_GEMM_TN) lb.init(lane, wave, n0, p.N, p.ldb, p.seglen, p.seg0, p.segstride);
     else lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0, p.seglen, p.segstride);      // NN: row segments (tile base carries the tile's first segment)
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
     Loader32<AK, BM, NW> la;
     Loader32<BKD, BN, NW> lb;
     if constexpr (AK == KC) la.init(lane, wave, m0, p.M, p.lda, 0, 0, 0, p.a_seglen, p.a_segadj);
-    else la.init(lane, wave, m0, p.M, p.lda, p.a_seglen, 0, p.a_segadj);
+    else la.init(lane, wave, m0, (p.M + 7) & ~7, p.lda, p.a_seglen, 0, p.a_segadj);
     if constexpr (BKD == KC) lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0);
     else if constexpr (LAYOUT == XVA_GEMM_TN) lb.init(lane, wave, n0, p.N, p.ldb, p.seglen, p.seg0, p.segstride);
     else lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0, p.seglen, p.segstride);
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void xva_gemm_glds3
     Loader32<AK, BM, NW> la;
     Loader32<BKD, BN, NW> lb;
     if constexpr (AK == KC) la.init(lane, wave, m0, p.M, p.lda, 0, 0, 0, p.a_seglen, p.a_segadj);
-    else la.init(lane, wave, m0, p.M, p.lda, p.a_seglen, 0, p.a_segadj);
+    else la.init(lane, wave, m0, (p.M + 7) & ~7, p.lda, p.a_seglen, 0, p.a_segadj);
     if constexpr (BKD == KC) lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0);
     else if constexpr (LAYOUT == XVA_GEMM_TN) lb.init(lane, wave, n0, p.N, p.ldb, p.seglen, p.seg0, p.segstride);
     else lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0, p.seglen, p.segstride);

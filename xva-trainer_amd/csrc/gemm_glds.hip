@@ -64,7 +64,10 @@ bool xva_gemm_glds_eligible(const xva_gemm_params& p) {
     // (TN: k indexes ROWS of both operands — rows past K come from the zero page lane by lane; taken for the split-bf16 pairs, whose products have no other kernel)
     if ((p.K % 8 != 0 && !(p.planes && p.layout == XVA_GEMM_TN)) || p.K < 8) return false;
     if (p.layout == XVA_GEMM_TN) {
-        if (p.M % 8 != 0 || p.N % 8 != 0 || p.M < 8 || p.N < 8) return false;
+        // split-bf16 pairs: M need not be a multiple of 8 when every k-row of A is readable up to the next multiple (lda covers it): the extra columns only
+        // reach C rows >= M, which are never stored (FastPitch's attention gradients: M = T + 2 keys, rows of Ts = round-up-8 elements)
+        const bool m_ok = p.M % 8 == 0 || (p.planes && p.a_seglen == 0 && p.lda >= ((p.M + 7) & ~7));
+        if (!m_ok || p.N % 8 != 0 || p.M < 8 || p.N < 8) return false;
         if (p.kb_len > 0 && p.K % p.kb_len != 0) return false;
     } else {
         auto seg_ok = [](int len) { return len <= 0 || len % xva_glds::GK == 0 || xva_glds::GK % len == 0; };   // a K tile maps onto whole segments
