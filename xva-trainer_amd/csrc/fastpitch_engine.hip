@@ -534,7 +534,8 @@ static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
     }
     {   // S = scale * Q K^T per item (fp32)
         xva_gemm_params g = gpp(c); pgemm_common(g, &qp, &qp, nullptr);
-        g.layout = XVA_GEMM_NT; g.A = prow(qp, 0); g.B = prow(qp, 0) + DH * 2; g.C = c.A(a.P); g.c_dtype = XVA_F32; g.M = Tp; g.N = Tp; g.K = DH;
+        // (N = Ts, the row pitch: the two to seven extra score columns — keys past the item, finite values the softmax never reads — buy 16-byte row stores)
+        g.layout = XVA_GEMM_NT; g.A = prow(qp, 0); g.B = prow(qp, 0) + DH * 2; g.C = c.A(a.P); g.c_dtype = XVA_F32; g.M = Tp; g.N = (int)Ts; g.K = DH;
         g.lda = DQKV; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DQKV; g.sB = g.sA; g.sC = (int64_t)Tp * Ts; g.alpha = 0.125f;
         XVA_TRY(xva_gemm(&g, c.st));
     }
@@ -575,7 +576,7 @@ static int attention_bwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
     }
     {   // dPd = gAV V^T (fp32)
         xva_gemm_params g = gpp(c); pgemm_common(g, &gavp, &qp, nullptr);
-        g.layout = XVA_GEMM_NT; g.A = prow(gavp, 0); g.B = prow(qp, 0) + 2 * DH * 2; g.C = gP; g.c_dtype = XVA_F32; g.M = Tp; g.N = Tp; g.K = DH;
+        g.layout = XVA_GEMM_NT; g.A = prow(gavp, 0); g.B = prow(qp, 0) + 2 * DH * 2; g.C = gP; g.c_dtype = XVA_F32; g.M = Tp; g.N = (int)Ts; g.K = DH;   // N = Ts: see the forward
         g.lda = DH; g.ldb = DQKV; g.ldc = Ts; g.batch = B; g.sA = (int64_t)Tp * DH; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * Ts;
         XVA_TRY(xva_gemm(&g, c.st));
     }
