@@ -389,6 +389,25 @@ def pmc_traffic(family, pmc_csv):
     return (by / n if n else None), "profiles/%s @ %s" % (pmc_csv, json.load(open(meta)).get("commit", "?"))
 
 
+def pmc_iteration_traffic(pmc_csv, per_iteration_kernel="adamw_kernel", launches_per_iteration=2):
+    """HBM bytes of ONE whole iteration from the committed PMC summary (every kernel: dispatches x (FETCH_SIZE x 2 + WRITE_SIZE), MI355X_MICROARCH.md's gfx950
+    correction), divided by the iterations the pass ran (counted by a kernel that runs a known number of times per iteration).  None when the file is missing
+    or describes other kernel sources."""
+    import csv
+    path = os.path.join(ROOT, "profiles", pmc_csv)
+    meta = path[:-4] + ".meta.json"
+    if not os.path.exists(path) or not os.path.exists(meta) or json.load(open(meta)).get("csrc") != csrc_fingerprint():
+        return None
+    tot, iters = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        d = int(r["Dispatches"])
+        tot += d * (float(r["FETCH_SIZE_KB_mean_raw"]) * 2.0 + float(r["WRITE_SIZE_KB_mean_raw"])) * 1000.0
+        if per_iteration_kernel in r["Kernel"]:
+            iters += d
+    iters //= launches_per_iteration
+    return tot / iters if iters else None
+
+
 def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
     """Live per-launch timing of the GEMM kernels (HIP event pair around every xva_gemm launch, on the launch stream, recorded by the
     library itself: xva_prof_* in csrc/core.hip).  The DOMINANT kernel = the (main loop, tile) family with the largest total time;
@@ -534,8 +553,12 @@ def hifigan_leg(a, dev, rank, world):
                                  "frac": alg_gb / res["ms_per_step"] * 1e3 / 8000.0, "algorithmic_gbytes_per_step": alg_gb,
                                  "algorithmic_tflop_per_step": alg_tf, "mfma_tflops": alg_tf / res["ms_per_step"] * 1e3,
                                  "mfma_frac": alg_tf / res["ms_per_step"] * 1e3 / 2500.0,
+                                 "traffic_gbytes_per_step": (lambda t: None if t is None else t / 1e9)(pmc_iteration_traffic(latest_profile("hifigan_pmc_hbm_bytes.csv"))),
                                  "note": "whole D+G iteration: algorithmic bytes of all convolution launches (B=%d) / timed ms_per_step; the workload sits on the "
                                          "ridge (17 TFLOP : 55 GB = 313 flop/B), so the MFMA fraction of the same time is given beside it" % B}
+    if isinstance(res.get("roofline_stack"), dict) and res["roofline_stack"].get("traffic_gbytes_per_step"):
+        rs = res["roofline_stack"]       # offline PMC passes over this workload (profiles/, csrc fingerprint checked): includes the set-up kernels of that run
+        rs["traffic_over_algorithmic"] = rs["traffic_gbytes_per_step"] / rs["algorithmic_gbytes_per_step"]
     del st
     torch.cuda.empty_cache()
     if rank == 0 and world == 1:

@@ -436,6 +436,12 @@ int xva_fp_set_ln4(int mode);
  * write (include/xva_gemm.h `planes`), 0 = every product splits its operands while staging them (rounds 3 - 4).  Same arithmetic (hi hi + hi lo + lo hi);
  * changes the workspace plan: set before xva_fp_workspace_bytes.  Returns the previous mode.  env XVA_FP_FFN_PLANES. */
 int xva_fp_set_ffn_planes(int mode);
+/* bf16 mode, the tail of MultiHeadAttn.forward (python/fastpitch1_1/fastpitch/transformer.py:132-147): sum1 = x + dropout(AV Wo^T), y1 = LayerNorm(sum1) * rowmask
+ * as ONE kernel (av (rows, 64), w_bf16 (384, 64), x / sum1 / y1 (rows, 384) bf16; mean / rstd fp32 per row; the dropout mask of the GEMM epilogue it replaces:
+ * hash(seed, stream_id, row * 384 + col)).  xva_fp_set_onet_fused(0) / env XVA_FP_ONET_FUSED=0 put the engine back on the GEMM + LayerNorm pair. */
+int xva_fp_onet_ln_fwd(const void* av, const void* w_bf16, const void* x, const float* gamma, const float* beta, void* sum1, void* y1, float* mean, float* rstd,
+                       int64_t rows, int mask_mode, const int32_t* lens, int Tp, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+int xva_fp_set_onet_fused(int mode);
 /* Test / diagnostics: byte offset (into the caller's workspace) and geometry {nseq, T, C, padF, padB} of an activation tensor the last
  * forward stored, time-major (nseq, padF + T + padB, C) in the activation dtype.  kind: 0 mel input, 1 conv_pre output, 2 u[i0] (ups
  * output), 3 lrelu(u[i0]), 4 xt1[resblock i0][m i1] (= lrelu(c1(lrelu(x))), models.py:43-45), 5 / 6 x after block m and its lrelu copy,

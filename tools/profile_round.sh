@@ -49,6 +49,16 @@ json.dump({"csrc": bench.csrc_fingerprint(), "commit": "${XVA_COMMIT:-unknown}",
           open("$O/${RD}_${leg}_pmc_hbm_bytes.meta.json", "w"))
 PY
 done
+# round 5 evidence: the D-step backward per launch, the resident-input convolution against the staggered general tiles on the generator's
+# 128 / 256-channel shapes (item 2b), LayerNorm forms, the split-products FastPitch step per kernel (item 4), split-K by atomics (item 2c)
+XVA_HG_PHASE3=1 python $R/tools/hg_gemm_profile.py 64 > $O/${RD}_hifigan_gemm_profile.txt 2>/dev/null
+for m in -1 7 6; do echo "== xva_gemm_set_mainloop($m): -1 automatic (resident-input kernel), 7 forced 384x128 staggered tile, 6 automatic without the resident-input kernel"; XVA_BENCH_C=128 python $R/tools/conv_res_bench.py $m 2>/dev/null | tail -6; done > $O/${RD}_conv_res_tile_modes.txt
+python $R/tools/ln_time.py > $O/${RD}_layernorm_timing.txt 2>/dev/null
+python $R/tools/fp_split_step.py 2>/dev/null | tail -1 > $O/${RD}_fastpitch_split_step.txt
+XVA_FP_FFN_PLANES=0 python $R/tools/fp_split_step.py 2>/dev/null | tail -1 >> $O/${RD}_fastpitch_split_step.txt
+XVA_SERIAL=1 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -o s -- python $R/tools/fp_split_step.py > /dev/null 2>&1
+python $R/tools/rocpd_summary.py $(find /tmp/p_sp -name "*.db" | head -1) $O/${RD}_fastpitch_split_kernel_stats.csv
+for m in 0 3; do echo "== XVA_GEMM_SK_ATOMIC_MAX=$m (splits of <= m parts add their partial tiles with fp32 atomics instead of slabs + reduce)"; XVA_GEMM_SK_ATOMIC_MAX=$m python $R/tools/hg_phase_timing.py 2>/dev/null | tail -11; done > $O/${RD}_splitk_atomics_ab.txt
 # the lanes-off FastPitch kernel trace gets the same fingerprint: bench.py quotes roofline.frac_rocprof from it only while it describes the sources it runs
 cp $O/${RD}_fastpitch_pmc_hbm_bytes.meta.json $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.meta.json
 # the plain bench line last: its roofline.traffic / frac_rocprof read the tables just measured (same sources: fingerprint checked)

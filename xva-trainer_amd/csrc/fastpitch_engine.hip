@@ -173,6 +173,10 @@ extern "C" int xva_fp_set_bwd_nt(int mode) { int old = g_bwd_nt; g_bwd_nt = mode
 static int g_ffn_planes = [] { const char* e = getenv("XVA_FP_FFN_PLANES"); return e ? atoi(e) : 1; }();
 extern "C" int xva_fp_set_ffn_planes(int mode) { int old = g_ffn_planes; g_ffn_planes = mode; return old; }
 
+// bf16 mode: 1 (default) = o_net + dropout + residual + LayerNorm of a transformer layer's attention block as one kernel (xva_fp_onet_ln_fwd), 0 = GEMM + LayerNorm
+static int g_onet_fused = [] { const char* e = getenv("XVA_FP_ONET_FUSED"); return e ? atoi(e) : 1; }();
+extern "C" int xva_fp_set_onet_fused(int mode) { int old = g_onet_fused; g_onet_fused = mode; return old; }
+
 int make_plan(const xva_fp_dims* d, Plan* p) {
     XVA_CHECK_ARG(d && d->B > 0 && d->Tt > 0 && d->Tm > 0, "fastpitch: bad dims");
     XVA_CHECK_ARG(d->stage >= 2 && d->stage <= 4, "fastpitch: stage must be 2, 3 or 4 (stage 1 aligner is not built yet)");
@@ -663,10 +667,16 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
             }
         }
         // sum1 = x + drop(AV Wo^T) ; y1 = LN(sum1) * mask                  (transformer.py:137-146,166-167)
+        if (c.compute && g_onet_fused) {   // bf16 mode: projection, dropout, residual and LayerNorm in one kernel (fp_fused.hip)
+            XVA_TRY(xva_fp_onet_ln_fwd(av, c.wt(p.o_w), x, c.P + p.ln1_g, c.P + p.ln1_b, c.A(a.sum1), c.A(a.y1), c.F(a.mean1), c.F(a.rstd1), R, XVA_MASK_LEN, lens, Tp,
+                                       c.pd, c.seed, s0 + 1, c.st));
+            goto ffn;
+        }
         XVA_TRY(linear_fwd(c, av, R, DH, DH, p.o_w, nullptr, c.A(a.sum1), DM, DM, x, DM, XVA_MASK_NONE, nullptr, 0, Drop{c.pd, s0 + 1}));
         }
         XVA_TRY(xva_fp_layernorm_fwd(c.A(a.sum1), c.P + p.ln1_g, c.P + p.ln1_b, c.A(a.y1), c.dt, c.F(a.mean1), c.F(a.rstd1), R, DM,
                                      XVA_MASK_LEN, lens, Tp, 0.f, 0, 0, c.st));
+    ffn:
         // h = relu(conv1(y1)) ; sum2 = y1 + drop(conv2(h)) ; x' = LN(sum2) * mask  (transformer.py:59-77,168-170)
         if (ffn_planes) {     // fp32 mode, split products: both convolutions on split-bf16 pairs (h is stored as a pair in its fp32 slot)
             const PlaneT yp = planes_scratch(c, c.pl.yp[0], c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re), hp = planes_in_slot(c.A(a.h), R, DI);
