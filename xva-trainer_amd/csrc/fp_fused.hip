@@ -32,6 +32,8 @@ __global__ __launch_bounds__(64 * OW) void onet_ln_fwd_kernel(const uint16_t* __
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(W + (int64_t)n * DH + c * 8);
         *reinterpret_cast<XVA_LDS bf16x8*>(wl + n * 128 + ((c ^ (n & 7)) << 4)) = v;
     }
+    XVA_LDS float* gl = (XVA_LDS float*)(wl + DM * 128);             // gamma | beta
+    for (int c = threadIdx.x; c < 2 * DM; c += 64 * OW) gl[c] = c < DM ? gamma[c] : beta[c - DM];
     __syncthreads();
     const int r16 = lane & 15, g = lane >> 4;
     const uint32_t bo0 = r16 * 128 + ((g ^ (r16 & 7)) << 4), bo1 = bo0 ^ 64;          // B fragment offsets inside a 16-row tile of the image, k half 0 / 1
@@ -43,6 +45,9 @@ __global__ __launch_bounds__(64 * OW) void onet_ln_fwd_kernel(const uint16_t* __
         // A fragments: row r16 of the block, k = kh * 32 + g * 8 ... + 7
         const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(AV + rowc * DH + g * 8);
         const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(AV + rowc * DH + 32 + g * 8);
+        uint2 xr[NJ];                                                  // the residual row pieces: all in flight before the products (one round trip, not six)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xr[j] = *reinterpret_cast<const uint2*>(X + rowc * DM + j * 16 + g * 4);
         f32x4 acc[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -57,20 +62,19 @@ __global__ __launch_bounds__(64 * OW) void onet_ln_fwd_kernel(const uint16_t* __
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int col = j * 16 + g * 4;
-            const uint2 xr = *reinterpret_cast<const uint2*>(X + rowc * DM + col);
             float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
             if (p_drop > 0.f) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= xva_dropout_scale(p_drop, seed, stream_id, (uint64_t)row * DM + col + e);
             }
-            v[0] += __uint_as_float(xr.x << 16); v[1] += __uint_as_float(xr.x & 0xffff0000u);
-            v[2] += __uint_as_float(xr.y << 16); v[3] += __uint_as_float(xr.y & 0xffff0000u);
+            v[0] += __uint_as_float(xr[j].x << 16); v[1] += __uint_as_float(xr[j].x & 0xffff0000u);
+            v[2] += __uint_as_float(xr[j].y << 16); v[3] += __uint_as_float(xr[j].y & 0xffff0000u);
             const uint2 pk = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             if (in) *reinterpret_cast<uint2*>(SUM1 + row * DM + col) = pk;
             acc[j][0] = __uint_as_float(pk.x << 16); acc[j][1] = __uint_as_float(pk.x & 0xffff0000u);
             acc[j][2] = __uint_as_float(pk.y << 16); acc[j][3] = __uint_as_float(pk.y & 0xffff0000u);
             s += (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
-            if ((j & 3) == 3) asm volatile("" ::: "memory");       // keep the compiler from hoisting all 24 residual loads / hashes above the loop (spills)
+            if ((j & 3) == 3) asm volatile("" ::: "memory");       // keep the compiler from forming all 96 dropout hashes at once (spills)
         }
         s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);                        // the four lanes that share row r16
         const float mu = s * (1.f / DM);
@@ -87,12 +91,12 @@ __global__ __launch_bounds__(64 * OW) void onet_ln_fwd_kernel(const uint16_t* __
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int col = j * 16 + g * 4;
-                const float4 gm = *reinterpret_cast<const float4*>(gamma + col), bt = *reinterpret_cast<const float4*>(beta + col);
+                const f32x4 gmv = *reinterpret_cast<const XVA_LDS f32x4*>(gl + col), btv = *reinterpret_cast<const XVA_LDS f32x4*>(gl + DM + col);
+                const float4 gm = make_float4(gmv[0], gmv[1], gmv[2], gmv[3]), bt = make_float4(btv[0], btv[1], btv[2], btv[3]);
                 float y[4];
                 y[0] = live ? (acc[j][0] - mu) * rs * gm.x + bt.x : 0.f; y[1] = live ? (acc[j][1] - mu) * rs * gm.y + bt.y : 0.f;
                 y[2] = live ? (acc[j][2] - mu) * rs * gm.z + bt.z : 0.f; y[3] = live ? (acc[j][3] - mu) * rs * gm.w + bt.w : 0.f;
                 *reinterpret_cast<uint2*>(Y1 + row * DM + col) = make_uint2(pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]));
-                if ((j & 3) == 3) asm volatile("" ::: "memory");   // likewise for the 24 x 8 gamma / beta values
             }
         }
     }
@@ -107,14 +111,14 @@ extern "C" int xva_fp_onet_ln_fwd(const void* av, const void* w_bf16, const void
     XVA_CHECK_ARG(al(av) && al(w_bf16) && al(x) && al(sum1) && al(y1) && al(gamma) && al(beta), "onet_ln_fwd: 16-byte alignment");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(onet_ln_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DM * 128) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(onet_ln_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DM * 128 + 2 * DM * 4) != hipSuccess) {
             xva_set_error("onet_ln_fwd: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP;
         }
         attr_set = true;
     }
     const int64_t nblk = (rows + 15) / 16;
     int grid = (int)((nblk + OW - 1) / OW); if (grid > 512) grid = 512;
-    hipLaunchKernelGGL(onet_ln_fwd_kernel, dim3(grid), dim3(64 * OW), DM * 128, (hipStream_t)stream, reinterpret_cast<const uint16_t*>(av),
+    hipLaunchKernelGGL(onet_ln_fwd_kernel, dim3(grid), dim3(64 * OW), DM * 128 + 2 * DM * 4, (hipStream_t)stream, reinterpret_cast<const uint16_t*>(av),
                        reinterpret_cast<const uint16_t*>(w_bf16), reinterpret_cast<const uint16_t*>(x), gamma, beta, reinterpret_cast<uint16_t*>(sum1),
                        reinterpret_cast<uint16_t*>(y1), mean, rstd, rows, mask_mode, lens, Tp, 1e-5f, p_drop, seed, stream_id);
     XVA_LAUNCH_CHECK();
