@@ -391,7 +391,8 @@ def pmc_traffic(family, pmc_csv):
 
 def pmc_iteration_traffic(pmc_csv, per_iteration_kernel="adamw_kernel", launches_per_iteration=2):
     """HBM bytes of ONE whole iteration from the committed PMC summary (every kernel: dispatches x (FETCH_SIZE x 2 + WRITE_SIZE), MI355X_MICROARCH.md's gfx950
-    correction), divided by the iterations the pass ran (counted by a kernel that runs a known number of times per iteration).  None when the file is missing
+    correction), divided by the iterations the pass ran (counted by a kernel that runs a known number of times per iteration); torch's own fill / copy kernels (workspace set-up of that
+    run) are left out.  None when the file is missing
     or describes other kernel sources."""
     import csv
     path = os.path.join(ROOT, "profiles", pmc_csv)
@@ -401,7 +402,8 @@ def pmc_iteration_traffic(pmc_csv, per_iteration_kernel="adamw_kernel", launches
     tot, iters = 0.0, 0
     for r in csv.DictReader(open(path)):
         d = int(r["Dispatches"])
-        tot += d * (float(r["FETCH_SIZE_KB_mean_raw"]) * 2.0 + float(r["WRITE_SIZE_KB_mean_raw"])) * 1000.0
+        if "at::native" not in r["Kernel"] and "__amd_rocclr" not in r["Kernel"]:      # torch's allocation fills / copies of that run's set-up are not the iteration's
+            tot += d * (float(r["FETCH_SIZE_KB_mean_raw"]) * 2.0 + float(r["WRITE_SIZE_KB_mean_raw"])) * 1000.0
         if per_iteration_kernel in r["Kernel"]:
             iters += d
     iters //= launches_per_iteration
