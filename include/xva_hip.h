@@ -284,6 +284,15 @@ int xva_fp_softmax_fwd(void* S, void* P_dropped, int dt, const int32_t* lens, in
                        uint32_t stream_id, void* stream);
 int xva_fp_softmax_bwd(const void* P, void* dP, int dt, int B, int Tp, int64_t Ts, float scale, float p_drop, uint64_t seed,
                        uint32_t stream_id, void* stream);
+/* LayerNorm on fp32 rows that ALSO leaves its output as a split-bf16 pair (hi plane at *_pair, lo plane pair_plane ELEMENTS after it; rows 0 .. rows - 1 of each
+ * plane — guard rows are the caller's): the operand of the next `planes` product without a split launch.  Backward: the pair is the gradient entering the
+ * dropout-ed branch (dX * m_out; dX itself when p_out == 0); dXm (fp32) may be null. */
+int xva_fp_layernorm_fwd_pair(const void* X, const float* gamma, const float* beta, void* Y, void* y_pair, int64_t pair_plane, float* mean, float* rstd,
+                              int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp, void* stream);
+int xva_fp_layernorm_bwd_pair(const void* dY, const void* X, const float* mean, const float* rstd, const float* gamma, void* dX, void* dXm, void* dx_pair,
+                              int64_t pair_plane, float* dgamma, float* dbeta, int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp, float p_out,
+                              uint64_t seed_out, uint32_t stream_out, void* stream);
+void xva_fp_set_ln_pairs(int on);
 /* fp32 softmax rows with split-bf16 PAIR outputs (the operands of xva_gemm `planes`, fp32 mode with split products): forward writes P fp32 in place over S and
  * the (dropped) copy as a pair (hi plane at Pd_pair, lo plane pair_plane elements after it); backward reads P / dP fp32 and writes dS as a pair. */
 int xva_fp_softmax_fwd_pairs(void* S, void* Pd_pair, int64_t pair_plane, const int32_t* lens, int B, int Tp, int64_t Ts, float p_drop, uint64_t seed,
@@ -297,6 +306,15 @@ int xva_fp_attention_fwd(const void* qkv, const int32_t* lens, void* av, float* 
                          uint64_t seed, uint32_t stream_id, void* stream);
 int xva_fp_attention_bwd(const void* qkv, const void* av, const void* d_av, const float* lse, float* dscratch, const int32_t* lens,
                          void* d_qkv, int B, int Tp, float scale, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+/* The same kernels on split-bf16 PAIRS (fp32 mode with split products; include/xva_gemm.h `planes`): qkv / av / d_av / d_qkv point at the hi planes, the lo planes
+ * sit `*_plane` ELEMENTS after them; every product is hi.hi + hi.lo + lo.hi in fp32 and the outputs leave as pairs.  Replaces the unfused scores -> softmax ->
+ * P V chain of that mode (two T x T fp32 tensors per layer and direction).  XVA_FP_ATT_FLASH / xva_fp_set_att_flash(0) restores the unfused chain. */
+int xva_fp_attention_fwd_pairs(const void* qkv, int64_t qkv_plane, const int32_t* lens, void* av, int64_t av_plane, float* lse, int B, int Tp, float scale,
+                               float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+int xva_fp_attention_bwd_pairs(const void* qkv, int64_t qkv_plane, const void* av, int64_t av_plane, const void* d_av, int64_t d_av_plane, const float* lse,
+                               float* dscratch, const int32_t* lens, void* d_qkv, int64_t d_qkv_plane, int B, int Tp, float scale, float p_drop, uint64_t seed,
+                               uint32_t stream_id, void* stream);
+void xva_fp_set_att_flash(int on);
 int xva_fp_layernorm_fwd(const void* X, const float* gamma, const float* beta, void* Y, int dt, float* mean, float* rstd, int64_t rows,
                          int C, int mask_mode, const int32_t* lens, int Tp, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
 int xva_fp_layernorm_bwd(const void* dY, const void* X, const float* mean, const float* rstd, const float* gamma, void* dX, void* dX_masked,

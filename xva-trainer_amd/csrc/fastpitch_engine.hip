@@ -136,7 +136,7 @@ struct Bump {
 };
 
 constexpr int QKV_SPARE = 8;
-struct LayerA { int64_t qkv, P, Pd, lse, av, sum1, mean1, rstd1, y1, h, sum2, mean2, rstd2; };
+struct LayerA { int64_t qkv, P, Pd, lse, av, sum1, mean1, rstd1, y1, h, sum2, mean2, rstd2, xp, yp; };   // xp / yp: the layer input and y1 as split-bf16 pairs (planes mode)
 struct PredA { int64_t c1, m1, r1, n1, c2, m2, r2, n2, out; };
 struct Plan {
     int B, Tt, Tm, Ttp, Tmp, es, dt;
@@ -157,8 +157,8 @@ struct Plan {
     // fp32 mode with split-bf16 products (xva_gemm_set_fp32_products(1)): the feed-forward convolutions (94 % of the FLOPs) run the direct-to-LDS kernels on
     // split-bf16 PLANES (include/xva_gemm.h): the whole parameter table as a pair (wplanes; lo plane wplane_stride elements after hi), transposed tap-reversed
     // pairs of both convolution weights of the 2 x NL layers (wtp_c1 / wtp_c2), and per layer parity a pair buffer for y1 and for d(sum2) (yp / gp; rows -1 .. R)
-    int64_t wplanes, wplane_stride, wtp_c1, wtp_c2, yp[2], gp[2];
-    int64_t xp[2], dp[2], gPp;   // the same for the layer input x and d(sum1) (rows -1 .. R, DM channels), and d(scores) as a pair (B x Tp x Ts)
+    int64_t wplanes, wplane_stride, wtp_c1, wtp_c2;
+    int64_t gp[2][2], dp[2][2], gPp;   // [stack: 0 encoder, 1 decoder][layer parity]   // the same for the layer input x and d(sum1) (rows -1 .. R, DM channels), and d(scores) as a pair (B x Tp x Ts)
     int64_t wt_c2;      // bf16 mode: transposed, tap-reversed copies of the 2 x NL conv2 weights ([DI][3][DM] each; encoder layers first) for the NT backward-data form
     int64_t total;
 };
@@ -176,6 +176,14 @@ extern "C" int xva_fp_set_ffn_planes(int mode) { int old = g_ffn_planes; g_ffn_p
 // bf16 mode: 1 (default) = o_net + dropout + residual + LayerNorm of a transformer layer's attention block as one kernel (xva_fp_onet_ln_fwd), 0 = GEMM + LayerNorm
 static int g_onet_fused = [] { const char* e = getenv("XVA_FP_ONET_FUSED"); return e ? atoi(e) : 1; }();
 extern "C" int xva_fp_set_onet_fused(int mode) { int old = g_onet_fused; g_onet_fused = mode; return old; }
+// fp32 mode, split products on pairs: 1 (default) = the attention core as the flash-style kernels on pairs (attention.hip: xva_fp_attention_*_pairs), 0 = scores ->
+// softmax -> P V through HBM (two T x T fp32 tensors per layer and direction)
+static int g_att_flash = [] { const char* e = getenv("XVA_FP_ATT_FLASH"); return e ? atoi(e) : 1; }();
+extern "C" void xva_fp_set_att_flash(int on) { g_att_flash = on; }
+// the same mode: 1 (default) = the LayerNorm kernels leave y1 / the next layer's input / d(sum) ALSO as split-bf16 pairs (xva_fp_layernorm_*_pair) and the
+// backward reads the forward's pairs, 0 = a split launch in front of every product that reads them (6 per layer)
+static int g_ln_pairs = [] { const char* e = getenv("XVA_FP_LN_PAIRS"); return e ? atoi(e) : 1; }();
+extern "C" void xva_fp_set_ln_pairs(int on) { g_ln_pairs = on; }
 
 int make_plan(const xva_fp_dims* d, Plan* p) {
     XVA_CHECK_ARG(d && d->B > 0 && d->Tt > 0 && d->Tm > 0, "fastpitch: bad dims");
@@ -208,6 +216,10 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
             L[i].sum2 = b.seq(R, DM, es);
             L[i].mean2 = b.take(R * 4); L[i].rstd2 = b.take(R * 4);
             x[i + 1] = b.seq(R, DM, es);
+            // fp32 mode, split products: the layer input and y1 ALSO as split-bf16 pairs, kept from the forward pass for the weight gradients (rows -1 .. R of
+            // two planes: the bytes of one fp32 sequence slot; guard rows are never written and stay zero)
+            L[i].xp = L[i].yp = -1;
+            if (!fused && g_ffn_planes) { L[i].xp = b.take(2 * (R + 2) * DM * 2); L[i].yp = b.take(2 * (R + 2) * DM * 2); }
         }
     };
     auto plan_pred = [&](PredA& A) {
@@ -244,15 +256,17 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     p->gH2 = b.seq(Rm, DI, es); p->gQKV2 = b.seq(Rm, DQKV, es);
     p->wshadow = d->compute ? b.take(table().total * es) : -1;
     p->wt_c2 = (d->compute && g_bwd_nt) ? b.take((int64_t)2 * NL * DI * 3 * DM * 2) : -1;
-    p->wplanes = p->wtp_c1 = p->wtp_c2 = p->yp[0] = p->yp[1] = p->gp[0] = p->gp[1] = p->xp[0] = p->xp[1] = p->dp[0] = p->dp[1] = p->gPp = -1;
+    p->wplanes = p->wtp_c1 = p->wtp_c2 = p->gPp = -1;
+    for (int st = 0; st < 2; ++st) for (int q = 0; q < 2; ++q) p->gp[st][q] = p->dp[st][q] = -1;
     p->wplane_stride = (table().total + 7) / 8 * 8;
     if (!d->compute && g_ffn_planes) {
         p->wplanes = b.take(2 * p->wplane_stride * 2);
         p->wtp_c1 = b.take((int64_t)2 * (2 * NL) * DI * 3 * DM * 2); p->wtp_c2 = b.take((int64_t)2 * (2 * NL) * DI * 3 * DM * 2);
-        for (int q = 0; q < 2; ++q) {
-            p->yp[q] = b.take(2 * (Rm + 2) * DM * 2); p->gp[q] = b.take(2 * (Rm + 2) * DM * 2);
-            p->xp[q] = b.take(2 * (Rm + 2) * DM * 2); p->dp[q] = b.take(2 * (Rm + 2) * DM * 2);
-        }
+        for (int st = 0; st < 2; ++st)           // d(sum2) / d(sum1) masked by their dropouts, as pairs: per stack (the guard rows sit at the stack's own R)
+            for (int q = 0; q < 2; ++q) {
+                const int64_t R = st ? p->Rd : p->Re;
+                p->gp[st][q] = b.take(2 * (R + 2) * DM * 2); p->dp[st][q] = b.take(2 * (R + 2) * DM * 2);
+            }
         p->gPp = b.take((int64_t)p->B * Tpm * Tsm * 4 + 64);
     }
     p->total = b.cur;
@@ -415,7 +429,7 @@ struct PlaneT { char* base; int64_t plane; int C; int extra = 0; };     // extra
 static inline char* prow(const PlaneT& t, int64_t row) { return t.base + (row + 1) * (int64_t)t.C * 2; }                  // hi plane, row `row`
 // the pair that lives IN an fp32 sequence slot of R rows x C channels (same bytes: 2 planes x (R + 2) rows x 2 B = (R + 2) rows x 4 B)
 static inline PlaneT planes_in_slot(char* row0_fp32, int64_t R, int C, int extra = 0) { return PlaneT{row0_fp32 - (int64_t)C * 4, (R + 2 + extra) * (int64_t)C, C, extra}; }
-static inline PlaneT planes_scratch(const Ctx& c, int64_t off, int64_t Rm) { return PlaneT{c.W + off, (Rm + 2) * (int64_t)DM, DM}; }
+static inline PlaneT planes_own(const Ctx& c, int64_t off, int64_t R) { return PlaneT{c.W + off, (R + 2) * (int64_t)DM, DM}; }      // a dedicated pair buffer of R rows x DM
 static bool planes_mode(const Ctx& c) { return !c.compute && c.pl.wplanes >= 0 && g_ffn_planes && xva_gemm_get_fp32_products() == 1; }
 // per stack: the direct-to-LDS kernels want at least a K tile of rows / keys (toy sequences stay on the register-staged kernel)
 // XVA_FP_PLANES_MASK (A/B, debugging): bit 0 encoder stack, bit 1 decoder stack, bit 2 the attention block (clear: feed-forward only); default 7
@@ -521,13 +535,12 @@ static void pgemm_common(xva_gemm_params& g, const PlaneT* A, const PlaneT* B, c
     if (B) g.b_plane = B->plane;
     if (Cp) { g.c_dtype = XVA_BF16; g.c_plane = Cp->plane; }
 }
-static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* x, int64_t R, int Tp, int64_t Ts, const int32_t* lens, uint32_t s0) {
+static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* x, bool x_is_split, int64_t R, int Tp, int64_t Ts, const int32_t* lens, uint32_t s0) {
     const int B = c.pl.B;
-    const int64_t Rmax = c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re;
-    const PlaneT xp = planes_scratch(c, c.pl.xp[0], Rmax), qp = planes_in_slot(c.A(a.qkv), R, DQKV, QKV_SPARE), avp = planes_in_slot(c.A(a.av), R, DH);
+    const PlaneT xp = planes_own(c, a.xp, R), qp = planes_in_slot(c.A(a.qkv), R, DQKV, QKV_SPARE), avp = planes_in_slot(c.A(a.av), R, DH);
     const PlaneT wq{nullptr, c.pl.wplane_stride, 0};
     const PlaneT pdp{c.A(a.Pd), (int64_t)B * Tp * Ts, 0};
-    XVA_TRY(split_rows(c, x, R, xp, c.st));
+    if (!x_is_split) XVA_TRY(split_rows(c, x, R, xp, c.st));       // (layers past the first: the previous layer's LayerNorm wrote the pair)
     XVA_TRY(zero_mid_guards(c, qp, R, c.st));
     XVA_TRY(zero_mid_guards(c, avp, R, c.st));
     {   // qkv = x Wqkv^T + b, stored as a pair
@@ -536,6 +549,10 @@ static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
         g.bias = c.P + p.qkv_b;
         XVA_TRY(xva_gemm(&g, c.st));
     }
+    if (g_att_flash) {   // softmax(scale Q K^T) V without the T x T tensors; the logsumexp rows sit at the start of the (unused) probability slot
+        XVA_TRY(xva_fp_attention_fwd_pairs(prow(qp, 0), qp.plane, lens, prow(avp, 0), avp.plane, reinterpret_cast<float*>(c.A(a.P)), B, Tp, 0.125f, c.pd, c.seed,
+                                           s0 + 0, c.st));
+    } else {
     {   // S = scale * Q K^T per item (fp32)
         xva_gemm_params g = gpp(c); pgemm_common(g, &qp, &qp, nullptr);
         // (N = Ts, the row pitch: the two to seven extra score columns — keys past the item, finite values the softmax never reads — buy 16-byte row stores)
@@ -550,6 +567,7 @@ static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
         g.lda = Ts; g.ldb = DQKV; g.ldc = DH; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DH;
         XVA_TRY(xva_gemm(&g, c.st));
     }
+    }
     {   // sum1 = x + drop(AV Wo^T) (fp32)
         xva_gemm_params g = gpp(c); pgemm_common(g, &avp, &wq, nullptr);
         g.layout = XVA_GEMM_NT; g.A = prow(avp, 0); g.B = wplane(c, p.o_w); g.C = c.A(a.sum1); g.c_dtype = XVA_F32; g.M = (int)R; g.N = DM; g.K = DH; g.lda = DH; g.ldb = DH; g.ldc = DM;
@@ -560,17 +578,16 @@ static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
 }
 // backward of the same block: gDm = d(sum1) masked by o_net's dropout (fp32) -> gA = gD + d x through the block (fp32, LEN-masked).  Leaves the pairs the
 // weight gradients read (dp, xp of this layer parity; gQKV's slot) in place.
-static int attention_bwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* x, char* gDm, char* gD, char* gAV, char* gP, char* gQKV, char* gA, int par,
-                                int64_t R, int Tp, int64_t Ts, const int32_t* lens, uint32_t s0) {
+static int attention_bwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* gDm, bool gDm_is_split, char* gD, char* gAV, char* gP, char* gQKV, char* gA, int stk,
+                                int par, int64_t R, int Tp, int64_t Ts, const int32_t* lens, uint32_t s0) {
     const int B = c.pl.B;
     const int64_t Rmax = c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re;
-    const PlaneT dpp = planes_scratch(c, c.pl.dp[par], Rmax), xp = planes_scratch(c, c.pl.xp[par], Rmax);
+    const PlaneT dpp = planes_own(c, c.pl.dp[stk][par], R);
     const PlaneT qp = planes_in_slot(c.A(a.qkv), R, DQKV, QKV_SPARE), avp = planes_in_slot(c.A(a.av), R, DH);
     const PlaneT gavp = planes_in_slot(gAV, Rmax, DH), gqp = planes_in_slot(gQKV, Rmax, DQKV);
     const PlaneT wq{nullptr, c.pl.wplane_stride, 0};
     const PlaneT pdp{c.A(a.Pd), (int64_t)B * Tp * Ts, 0}, dsp{c.A(c.pl.gPp), (int64_t)B * Tp * Ts, 0};
-    XVA_TRY(split_rows(c, gDm, R, dpp, c.st));
-    XVA_TRY(split_rows(c, x, R, xp, c.st));
+    if (!gDm_is_split) XVA_TRY(split_rows(c, gDm, R, dpp, c.st));
     XVA_TRY(zero_mid_guards(c, gavp, Rmax, c.st));
     XVA_TRY(zero_mid_guards(c, gqp, Rmax, c.st));
     {   // gAV = gDm Wo
@@ -578,6 +595,10 @@ static int attention_bwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
         g.layout = XVA_GEMM_NN; g.A = prow(dpp, 0); g.B = wplane(c, p.o_w); g.C = prow(gavp, 0); g.M = (int)R; g.N = DH; g.K = DM; g.lda = DM; g.ldb = DH; g.ldc = DH;
         XVA_TRY(xva_gemm(&g, c.st));
     }
+    if (g_att_flash) {   // d(qkv) pair from the pairs of qkv, A V, d(A V) and the saved logsumexp rows (D = rowsum(dO . O) in gP's bytes)
+        XVA_TRY(xva_fp_attention_bwd_pairs(prow(qp, 0), qp.plane, prow(avp, 0), avp.plane, prow(gavp, 0), gavp.plane, reinterpret_cast<const float*>(c.A(a.P)),
+                                           reinterpret_cast<float*>(gP), lens, prow(gqp, 0), gqp.plane, B, Tp, 0.125f, c.pd, c.seed, s0 + 0, c.st));
+    } else {
     {   // dPd = gAV V^T (fp32)
         xva_gemm_params g = gpp(c); pgemm_common(g, &gavp, &qp, nullptr);
         g.layout = XVA_GEMM_NT; g.A = prow(gavp, 0); g.B = prow(qp, 0) + 2 * DH * 2; g.C = gP; g.c_dtype = XVA_F32; g.M = Tp; g.N = (int)Ts; g.K = DH;   // N = Ts: see the forward
@@ -603,6 +624,7 @@ static int attention_bwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
         g.lda = Ts; g.ldb = DQKV; g.ldc = DQKV; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DQKV;
         XVA_TRY(xva_gemm(&g, c.st));
     }
+    }
     {   // d x = gD + gQKV Wqkv, LEN-masked -> gA (fp32)
         xva_gemm_params g = gpp(c); pgemm_common(g, &gqp, &wq, nullptr);
         g.layout = XVA_GEMM_NN; g.A = prow(gqp, 0); g.B = wplane(c, p.qkv_w); g.C = gA; g.c_dtype = XVA_F32; g.M = (int)R; g.N = DM; g.K = DQKV; g.lda = DQKV; g.ldb = DM; g.ldc = DM;
@@ -612,10 +634,10 @@ static int attention_bwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
     return XVA_OK;
 }
 // the block's weight gradients and the qkv bias sums from the pairs attention_bwd_planes left (issued to cw's lane)
-static int attention_wgrad_planes(Ctx& cw, const LayerP& p, const LayerA& a, char* gQKV, int par, int64_t R, float* Gg) {
+static int attention_wgrad_planes(Ctx& cw, const LayerP& p, const LayerA& a, char* gQKV, int stk, int par, int64_t R, float* Gg) {
     const Ctx& c = cw;
     const int64_t Rmax = c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re;
-    const PlaneT dpp = planes_scratch(c, c.pl.dp[par], Rmax), xp = planes_scratch(c, c.pl.xp[par], Rmax);
+    const PlaneT dpp = planes_own(c, c.pl.dp[stk][par], R), xp = planes_own(c, a.xp, R);      // xp: the forward's pair of the layer input
     const PlaneT avp = planes_in_slot(c.A(a.av), R, DH), gqp = planes_in_slot(gQKV, Rmax, DQKV);
     auto wgrad = [&](const PlaneT& dY, int M, const PlaneT& X, int N, float* dW) {
         xva_gemm_params g = gpp(cw); pgemm_common(g, &dY, &X, nullptr);
@@ -643,7 +665,7 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         const uint32_t s0 = site + l * 4;
         const bool att_planes = att_planes_on(c, R, Tp), ffn_planes = ffn_planes_on(c, R, Tp);
         if (att_planes) {
-            XVA_TRY(attention_fwd_planes(c, p, a, x, R, Tp, Ts, lens, s0));
+            XVA_TRY(attention_fwd_planes(c, p, a, x, g_ln_pairs && l > 0, R, Tp, Ts, lens, s0));
         } else {
         // qkv = x Wqkv^T + b                                             (transformer.py:109)
         XVA_TRY(linear_fwd(c, x, R, DM, DM, p.qkv_w, c.P + p.qkv_b, qkv, DQKV, DQKV, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
@@ -674,13 +696,18 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         }
         XVA_TRY(linear_fwd(c, av, R, DH, DH, p.o_w, nullptr, c.A(a.sum1), DM, DM, x, DM, XVA_MASK_NONE, nullptr, 0, Drop{c.pd, s0 + 1}));
         }
+        if (ffn_planes && g_ln_pairs) {        // y1 fp32 (the residual of conv2, LayerNorm backward) and as the pair conv1 reads
+            const PlaneT yp = planes_own(c, a.yp, R);
+            XVA_TRY(xva_fp_layernorm_fwd_pair(c.A(a.sum1), c.P + p.ln1_g, c.P + p.ln1_b, c.A(a.y1), prow(yp, 0), yp.plane, c.F(a.mean1), c.F(a.rstd1), R, DM,
+                                              XVA_MASK_LEN, lens, Tp, c.st));
+        } else
         XVA_TRY(xva_fp_layernorm_fwd(c.A(a.sum1), c.P + p.ln1_g, c.P + p.ln1_b, c.A(a.y1), c.dt, c.F(a.mean1), c.F(a.rstd1), R, DM,
                                      XVA_MASK_LEN, lens, Tp, 0.f, 0, 0, c.st));
     ffn:
         // h = relu(conv1(y1)) ; sum2 = y1 + drop(conv2(h)) ; x' = LN(sum2) * mask  (transformer.py:59-77,168-170)
         if (ffn_planes) {     // fp32 mode, split products: both convolutions on split-bf16 pairs (h is stored as a pair in its fp32 slot)
-            const PlaneT yp = planes_scratch(c, c.pl.yp[0], c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re), hp = planes_in_slot(c.A(a.h), R, DI);
-            XVA_TRY(split_rows(c, c.A(a.y1), R, yp, c.st));
+            const PlaneT yp = planes_own(c, a.yp, R), hp = planes_in_slot(c.A(a.h), R, DI);
+            if (!g_ln_pairs) XVA_TRY(split_rows(c, c.A(a.y1), R, yp, c.st));
             XVA_TRY(zero_mid_guards(c, hp, R, c.st));
             XVA_TRY(conv3_fwd_p(c, yp, R, DM, p.c1_w, c.P + p.c1_b, &hp, nullptr, DI, 1, nullptr, XVA_MASK_PAD, lens, Tp));
             XVA_TRY(conv3_fwd_p(c, hp, R, DI, p.c2_w, c.P + p.c2_b, nullptr, c.A(a.sum2), DM, 0, c.A(a.y1), XVA_MASK_NONE, nullptr, 0, Drop{c.pd, s0 + 2}));
@@ -688,6 +715,11 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         XVA_TRY(conv3_fwd(c, c.A(a.y1), R, DM, p.c1_w, c.P + p.c1_b, c.A(a.h), DI, 1, nullptr, XVA_MASK_PAD, lens, Tp));
         XVA_TRY(conv3_fwd(c, c.A(a.h), R, DI, p.c2_w, c.P + p.c2_b, c.A(a.sum2), DM, 0, c.A(a.y1), XVA_MASK_NONE, nullptr, 0, Drop{c.pd, s0 + 2}));
         }
+        if (att_planes && g_ln_pairs && l + 1 < NL) {       // the next layer's input, also as the pair its qkv projection (and that weight gradient) reads
+            const PlaneT xn = planes_own(c, LA[l + 1].xp, R);
+            XVA_TRY(xva_fp_layernorm_fwd_pair(c.A(a.sum2), c.P + p.ln2_g, c.P + p.ln2_b, c.A(xo[l + 1]), prow(xn, 0), xn.plane, c.F(a.mean2), c.F(a.rstd2), R, DM,
+                                              XVA_MASK_LEN, lens, Tp, c.st));
+        } else
         XVA_TRY(xva_fp_layernorm_fwd(c.A(a.sum2), c.P + p.ln2_g, c.P + p.ln2_b, c.A(xo[l + 1]), c.dt, c.F(a.mean2), c.F(a.rstd2), R, DM,
                                      XVA_MASK_LEN, lens, Tp, 0.f, 0, 0, c.st));
     }
@@ -758,19 +790,23 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         char* qkv = c.A(a.qkv); char* av = c.A(a.av);
         const uint32_t s0 = site + l * 4;
         const int par = two ? (l & 1) : 0;
+        const int stk = LP == table().enc ? 0 : 1;
         gB = setB[par]; gBm = setBm[par]; gD = setD[par]; gDm = setDm[par]; gH = setH[par]; gQKV = setQ[par];
         if (two && l + 2 < NL) XVA_HIP_TRY(hipStreamWaitEvent((hipStream_t)c.st, wl.done[l + 2], 0));   // this set's last readers
         // LN2 backward -> gB = d sum2 (residual path) ; gBm = gB * dropmask (conv2 branch)
+        const bool planes = ffn_planes_on(c, R, Tp), att_planes = att_planes_on(c, R, Tp);
+        const PlaneT gBp = planes_own(c, c.pl.gp[stk][par], R), y1p = planes_own(c, a.yp, R);        // (planes mode only)
+        if (planes && g_ln_pairs)
+            XVA_TRY(xva_fp_layernorm_bwd_pair(gA, c.A(a.sum2), c.F(a.mean2), c.F(a.rstd2), c.P + p.ln2_g, gB, drop ? gBm : nullptr, prow(gBp, 0), gBp.plane, Gg + p.ln2_g,
+                                              Gg + p.ln2_b, R, DM, XVA_MASK_LEN, lens, Tp, c.pd, c.seed, s0 + 2, c.st));
+        else
         XVA_TRY(xva_fp_layernorm_bwd(gA, c.A(a.sum2), c.F(a.mean2), c.F(a.rstd2), c.P + p.ln2_g, gB, drop ? gBm : nullptr, c.dt, Gg + p.ln2_g,
                                      Gg + p.ln2_b, R, DM, XVA_MASK_LEN, lens, Tp, 0, 0.f, 0, 0, c.pd, c.seed, s0 + 2, nullptr, nullptr, c.st));
         // conv2 backward: gH = (gBm (*) W2) * [h > 0], structural rows zero
-        const bool planes = ffn_planes_on(c, R, Tp);
         const int64_t Rmax = c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re;
-        const PlaneT gBp = planes_scratch(c, c.pl.gp[planes ? par : 0], Rmax), y1p = planes_scratch(c, c.pl.yp[planes ? par : 0], Rmax);
         const PlaneT gHp = planes_in_slot(gH, Rmax, DI), hp = planes_in_slot(c.A(a.h), R, DI);
         if (planes) {               // fp32 mode, split products: d(sum2) and y1 as pairs; gH lives as a pair in its fp32 slot
-            XVA_TRY(split_rows(c, gBm, R, gBp, c.st));
-            XVA_TRY(split_rows(c, c.A(a.y1), R, y1p, c.st));
+            if (!g_ln_pairs) XVA_TRY(split_rows(c, gBm, R, gBp, c.st));          // (y1p: the forward's pair)
             XVA_TRY(zero_mid_guards(c, gHp, Rmax, c.st));
             XVA_TRY(conv3_bwd_data_p(c, gBp, R, DM, wtplane(c, c.pl.wtp_c2, LP, l), DI, &gHp, nullptr, nullptr, &hp, XVA_MASK_PAD, lens, Tp));
             XVA_TRY(conv3_bwd_data_p(c, gHp, R, DI, wtplane(c, c.pl.wtp_c1, LP, l), DM, nullptr, gC, gB, nullptr, XVA_MASK_LEN, lens, Tp));
@@ -780,11 +816,15 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         XVA_TRY(conv3_bwd_data(c, gH, R, DI, p.c1_w, DM, gC, gB, nullptr, XVA_MASK_LEN, lens, Tp, 0));
         }
         // LN1 backward -> gD = d sum1 ; gDm = gD * dropmask (o_net branch)
+        if (att_planes && g_ln_pairs) {
+            const PlaneT dpp = planes_own(c, c.pl.dp[stk][par], R);
+            XVA_TRY(xva_fp_layernorm_bwd_pair(gC, c.A(a.sum1), c.F(a.mean1), c.F(a.rstd1), c.P + p.ln1_g, gD, drop ? gDm : nullptr, prow(dpp, 0), dpp.plane, Gg + p.ln1_g,
+                                              Gg + p.ln1_b, R, DM, XVA_MASK_LEN, lens, Tp, c.pd, c.seed, s0 + 1, c.st));
+        } else
         XVA_TRY(xva_fp_layernorm_bwd(gC, c.A(a.sum1), c.F(a.mean1), c.F(a.rstd1), c.P + p.ln1_g, gD, drop ? gDm : nullptr, c.dt, Gg + p.ln1_g,
                                      Gg + p.ln1_b, R, DM, XVA_MASK_LEN, lens, Tp, 0, 0.f, 0, 0, c.pd, c.seed, s0 + 1, nullptr, nullptr, c.st));
-        const bool att_planes = att_planes_on(c, R, Tp);
         if (att_planes) {           // the attention block on split-bf16 pairs (qkv, the dropped probabilities and A V are pairs since the forward pass)
-            XVA_TRY(attention_bwd_planes(c, p, a, x, gDm, gD, gAV, gP, gQKV, gA, par, R, Tp, Ts, lens, s0));
+            XVA_TRY(attention_bwd_planes(c, p, a, gDm, g_ln_pairs != 0, gD, gAV, gP, gQKV, gA, stk, par, R, Tp, Ts, lens, s0));
         } else {
         // o_net backward
         XVA_TRY(linear_bwd_data(c, gDm, R, DM, DM, p.o_w, DH, gAV, DH, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
@@ -839,7 +879,7 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         XVA_TRY(xva_fp_colsum(gH, c.dt, Gg + p.c1_b, R, DI, DI, cw.st));
         }
         if (att_planes) {
-            if (!(g_planes_mask & 8)) XVA_TRY(attention_wgrad_planes(cw, p, a, gQKV, par, R, Gg));
+            if (!(g_planes_mask & 8)) XVA_TRY(attention_wgrad_planes(cw, p, a, gQKV, stk, par, R, Gg));
         } else {
         XVA_TRY(linear_bwd_weight(cw, gDm, R, DM, DM, av, DH, DH, Gg + p.o_w));
         XVA_TRY(linear_bwd_weight(cw, gQKV, R, DQKV, DQKV, x, DM, DM, Gg + p.qkv_w));

@@ -216,6 +216,15 @@ extern "C" int xva_fp_softmax_bwd_pairs(const void* P, const void* dP, void* dS_
     return XVA_OK;
 }
 
+// two adjacent values as a split-bf16 pair: hi = bf16(v) at base[i], lo = bf16(v - hi) at base[i + plane] (the operand form of xva_gemm `planes`)
+__device__ __forceinline__ void st2_pair(uint16_t* base, int64_t i, int64_t plane, float x, float y) {
+    uint32_t hi, lo;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+    const float r0 = x - __uint_as_float(hi << 16), r1 = y - __uint_as_float(hi & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
+    *reinterpret_cast<uint32_t*>(base + i) = hi;
+    *reinterpret_cast<uint32_t*>(base + i + plane) = lo;
+}
 // =====================================================================================
 // LayerNorm over channels, one wave64 per row  (transformer.py:75,146 post-LN; common/layers.py:96)
 // Y = (LN(X) * gamma + beta) * rowmask [* dropout]; saves mean / rstd.  C = 64 * CPL.
@@ -225,7 +234,7 @@ template <int CPL>
 __global__ void layernorm_fwd_kernel(const void* __restrict__ X, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, void* __restrict__ Y, int dt, float* __restrict__ mean,
                                      float* __restrict__ rstd, int64_t rows, int mask_mode, const int* __restrict__ lens,
-                                     int Tp, float eps, float p_drop, uint64_t seed, uint32_t stream_id) {
+                                     int Tp, float eps, float p_drop, uint64_t seed, uint32_t stream_id, uint16_t* __restrict__ Ypair, int64_t pair_plane) {
     constexpr int C = 64 * CPL;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -253,6 +262,7 @@ __global__ void layernorm_fwd_kernel(const void* __restrict__ X, const float* __
             if (p_drop > 0.f) y[e] *= xva_dropout_scale(p_drop, seed, stream_id, (uint64_t)row * C + c + e);
         }
         a_st2(Y, row * C + c, dt, y[0], y[1]);
+        if (Ypair) st2_pair(Ypair, row * C + c, pair_plane, y[0], y[1]);
     }
 }
 
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const voi
                                      void* __restrict__ dXm, int dt, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
                                      int rows_per_block, int mask_mode, const int* __restrict__ lens, int Tp, int relu_gate, float p_in,
                                      uint64_t seed_in, uint32_t stream_in, float p_out, uint64_t seed_out, uint32_t stream_out,
-                                     const float* __restrict__ outer_d, const float* __restrict__ outer_w) {
+                                     const float* __restrict__ outer_d, const float* __restrict__ outer_w, uint16_t* __restrict__ dXpair, int64_t pair_plane) {
     constexpr int C = 64 * CPL;
     __shared__ float sh_g[LNB_WAVES][C];
     __shared__ float sh_b[LNB_WAVES][C];
@@ -324,6 +334,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const voi
             for (int h = 0; h < CPL / 2; ++h) {
                 a_st2(dX, row * C + 2 * lane + 128 * h, dt, 0.f, 0.f);
                 if (dXm) a_st2(dXm, row * C + 2 * lane + 128 * h, dt, 0.f, 0.f);
+                if (dXpair) st2_pair(dXpair, row * C + 2 * lane + 128 * h, pair_plane, 0.f, 0.f);
             }
             return;
         }
@@ -354,8 +365,12 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const voi
                 if (relu_gate && !(xval(cur, 2 * h + e) > 0.f)) v[e] = 0.f;
             }
             a_st2(dX, row * C + c, dt, v[0], v[1]);
-            if (dXm) a_st2(dXm, row * C + c, dt, v[0] * xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c),
-                           v[1] * xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c + 1));
+            if (dXm || (dXpair && p_out > 0.f)) {
+                v[0] *= xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c);
+                v[1] *= xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c + 1);
+            }
+            if (dXm) a_st2(dXm, row * C + c, dt, v[0], v[1]);
+            if (dXpair) st2_pair(dXpair, row * C + c, pair_plane, v[0], v[1]);     // the gradient entering the dropout-ed branch (= dX without dropout)
         }
     };
     if constexpr (BF) {
@@ -480,12 +495,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd4_kernel(const uint16_t* __r
 static int g_ln4 = [] { const char* e = getenv("XVA_FP_LN4"); return e ? atoi(e) : 1; }();
 extern "C" int xva_fp_set_ln4(int mode) { int old = g_ln4; g_ln4 = mode; return old; }
 
-extern "C" int xva_fp_layernorm_fwd(const void* X, const float* gamma, const float* beta, void* Y, int dt, float* mean, float* rstd,
+static int layernorm_fwd_impl(const void* X, const float* gamma, const float* beta, void* Y, int dt, float* mean, float* rstd,
                                     int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp, float p_drop, uint64_t seed,
-                                    uint32_t stream_id, void* stream) {
+                                    uint32_t stream_id, void* y_pair, int64_t pair_plane, void* stream) {
     XVA_CHECK_ARG(X && gamma && beta && Y && mean && rstd, "layernorm_fwd: null");
     XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
-    if (g_ln4 && C == 384 && dt == XVA_BF16 && p_drop == 0.f && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+    XVA_CHECK_ARG(!y_pair || (dt == XVA_F32 && pair_plane > 0 && pair_plane % 2 == 0 && ((uintptr_t)y_pair % 4) == 0), "layernorm_fwd: pair output wants fp32 rows");
+    uint16_t* yp = reinterpret_cast<uint16_t*>(y_pair);
+    if (g_ln4 && !y_pair && C == 384 && dt == XVA_BF16 && p_drop == 0.f && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
         ((uintptr_t)beta % 16) == 0) {
         hipLaunchKernelGGL(layernorm_fwd4_kernel, dim3((unsigned)xva_cdiv(xva_cdiv(rows, 4), 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint16_t*>(X),
                            gamma, beta, reinterpret_cast<uint16_t*>(Y), mean, rstd, rows, mask_mode, lens, Tp, 1e-5f);
@@ -495,10 +512,44 @@ extern "C" int xva_fp_layernorm_fwd(const void* X, const float* gamma, const flo
     dim3 grid(xva_cdiv(rows, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
     if (C == 384)
         hipLaunchKernelGGL((layernorm_fwd_kernel<6>), grid, block, 0, (hipStream_t)stream, X, gamma, beta, Y, dt, mean, rstd, rows,
-                           mask_mode, lens, Tp, 1e-5f, p_drop, seed, stream_id);
+                           mask_mode, lens, Tp, 1e-5f, p_drop, seed, stream_id, yp, pair_plane);
     else
         hipLaunchKernelGGL((layernorm_fwd_kernel<4>), grid, block, 0, (hipStream_t)stream, X, gamma, beta, Y, dt, mean, rstd, rows,
-                           mask_mode, lens, Tp, 1e-5f, p_drop, seed, stream_id);
+                           mask_mode, lens, Tp, 1e-5f, p_drop, seed, stream_id, yp, pair_plane);
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+extern "C" int xva_fp_layernorm_fwd(const void* X, const float* gamma, const float* beta, void* Y, int dt, float* mean, float* rstd,
+                                    int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp, float p_drop, uint64_t seed,
+                                    uint32_t stream_id, void* stream) {
+    return layernorm_fwd_impl(X, gamma, beta, Y, dt, mean, rstd, rows, C, mask_mode, lens, Tp, p_drop, seed, stream_id, nullptr, 0, stream);
+}
+// fp32 rows; ALSO writes Y as a split-bf16 pair (hi plane at y_pair, lo plane pair_plane elements after it) — the next product's operand without a split launch
+extern "C" int xva_fp_layernorm_fwd_pair(const void* X, const float* gamma, const float* beta, void* Y, void* y_pair, int64_t pair_plane, float* mean, float* rstd,
+                                         int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp, void* stream) {
+    XVA_CHECK_ARG(y_pair, "layernorm_fwd_pair: null");
+    return layernorm_fwd_impl(X, gamma, beta, Y, XVA_F32, mean, rstd, rows, C, mask_mode, lens, Tp, 0.f, 0, 0, y_pair, pair_plane, stream);
+}
+static int layernorm_bwd_impl(const void* dY, const void* X, const float* mean, const float* rstd, const float* gamma,
+                                    void* dX, void* dXm, int dt, float* dgamma, float* dbeta, int64_t rows, int C, int mask_mode,
+                                    const int32_t* lens, int Tp, int relu_gate, float p_in, uint64_t seed_in, uint32_t stream_in,
+                                    float p_out, uint64_t seed_out, uint32_t stream_out, const float* outer_d, const float* outer_w,
+                                    void* dx_pair, int64_t pair_plane, void* stream) {
+    XVA_CHECK_ARG((dY || (outer_d && outer_w)) && X && mean && rstd && gamma && dX, "layernorm_bwd: null");
+    XVA_CHECK_ARG(!dx_pair || (dt == XVA_F32 && pair_plane > 0 && pair_plane % 2 == 0 && ((uintptr_t)dx_pair % 4) == 0), "layernorm_bwd: pair output wants fp32 rows");
+    uint16_t* dxp = reinterpret_cast<uint16_t*>(dx_pair);
+    XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
+    XVA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both null");
+    int rpb = (int)xva_cdiv(rows, 256);          // <= 256 workgroups (one per CU)
+    rpb = (rpb + LNB_WAVES - 1) / LNB_WAVES * LNB_WAVES;
+    dim3 grid(xva_cdiv(rows, rpb)), block(64 * LNB_WAVES);
+    const bool bf = dt == XVA_BF16 && dY != nullptr && !outer_d;
+#define XVA_LNB(CPL, BFV) hipLaunchKernelGGL((layernorm_bwd_kernel<CPL, BFV>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma, \
+                                             dbeta, rows, rpb, mask_mode, lens, Tp, relu_gate, p_in, seed_in, stream_in, p_out, seed_out, stream_out, outer_d, outer_w, \
+                                             dxp, pair_plane)
+    if (C == 384) { if (bf) XVA_LNB(6, true); else XVA_LNB(6, false); }
+    else { if (bf) XVA_LNB(4, true); else XVA_LNB(4, false); }
+#undef XVA_LNB
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
@@ -507,20 +558,16 @@ extern "C" int xva_fp_layernorm_bwd(const void* dY, const void* X, const float* 
                                     const int32_t* lens, int Tp, int relu_gate, float p_in, uint64_t seed_in, uint32_t stream_in,
                                     float p_out, uint64_t seed_out, uint32_t stream_out, const float* outer_d, const float* outer_w,
                                     void* stream) {
-    XVA_CHECK_ARG((dY || (outer_d && outer_w)) && X && mean && rstd && gamma && dX, "layernorm_bwd: null");
-    XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
-    XVA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both null");
-    int rpb = (int)xva_cdiv(rows, 256);          // <= 256 workgroups (one per CU)
-    rpb = (rpb + LNB_WAVES - 1) / LNB_WAVES * LNB_WAVES;
-    dim3 grid(xva_cdiv(rows, rpb)), block(64 * LNB_WAVES);
-    const bool bf = dt == XVA_BF16 && dY != nullptr && !outer_d;
-#define XVA_LNB(CPL, BFV) hipLaunchKernelGGL((layernorm_bwd_kernel<CPL, BFV>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma, \
-                                             dbeta, rows, rpb, mask_mode, lens, Tp, relu_gate, p_in, seed_in, stream_in, p_out, seed_out, stream_out, outer_d, outer_w)
-    if (C == 384) { if (bf) XVA_LNB(6, true); else XVA_LNB(6, false); }
-    else { if (bf) XVA_LNB(4, true); else XVA_LNB(4, false); }
-#undef XVA_LNB
-    XVA_LAUNCH_CHECK();
-    return XVA_OK;
+    return layernorm_bwd_impl(dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma, dbeta, rows, C, mask_mode, lens, Tp, relu_gate, p_in, seed_in, stream_in, p_out,
+                              seed_out, stream_out, outer_d, outer_w, nullptr, 0, stream);
+}
+// fp32 rows; ALSO writes the gradient that enters the dropout-ed branch (dX * m_out; dX itself when p_out == 0) as a split-bf16 pair
+extern "C" int xva_fp_layernorm_bwd_pair(const void* dY, const void* X, const float* mean, const float* rstd, const float* gamma, void* dX, void* dXm, void* dx_pair,
+                                         int64_t pair_plane, float* dgamma, float* dbeta, int64_t rows, int C, int mask_mode, const int32_t* lens, int Tp, float p_out,
+                                         uint64_t seed_out, uint32_t stream_out, void* stream) {
+    XVA_CHECK_ARG(dx_pair, "layernorm_bwd_pair: null");
+    return layernorm_bwd_impl(dY, X, mean, rstd, gamma, dX, dXm, XVA_F32, dgamma, dbeta, rows, C, mask_mode, lens, Tp, 0, 0.f, 0, 0, p_out, seed_out, stream_out,
+                              nullptr, nullptr, dx_pair, pair_plane, stream);
 }
 
 // =====================================================================================
