@@ -348,6 +348,8 @@ int xva_fp_wt_transpose3_planes(const float* params, void* out, const int64_t* s
 /* fp32 tensor -> split-bf16 pair: dst[i] = bf16(src[i]), dst[plane + i] = bf16(src[i] - dst[i]) (n, plane multiples of 8): operands of xva_gemm's `planes`
  * products, which keep ~16 mantissa bits through the bf16 matrix pipe (include/xva_gemm.h). */
 int xva_split_bf16(const float* src, void* dst, int64_t plane, int64_t n, void* stream);
+/* zero n small byte spans (4-byte aligned, multiples of 4 bytes) in one launch per 40 spans: the guard rows of pairs that live in fp32 slots */
+int xva_zero_spans(void* const* ptrs, const int64_t* bytes, int n, void* stream);
 /* dst += src over n (even) elements of the activation dtype: joins the gradient contributions that the temporal predictors' backward
  * (python/fastpitch1_1/fastpitch/model.py:394-418) produces on its own stream into d(encoder output) */
 int xva_fp_add_act(void* dst, const void* src, int dt, int64_t n, void* stream);

@@ -5,7 +5,9 @@ import torch
 from xva_trainer_amd import _lib, synthetic
 from xva_trainer_amd.fastpitch import engine as E, params as P
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-eng = E.FastPitchEngine("cuda", "bf16", p_dropout=0.1)
+MODE = os.environ.get("XVA_FP_MODE", "bf16")     # bf16 | split (fp32 storage, split-bf16 products on pairs)
+if MODE == "split": _lib.lib.xva_gemm_set_fp32_products(1)
+eng = E.FastPitchEngine("cuda", "fp32" if MODE == "split" else "bf16", p_dropout=0.1)
 flat = torch.zeros(eng.total, device="cuda"); P.default_init_(flat, eng.table, seed=1234)
 grads = torch.zeros_like(flat)
 batch = E.DeviceBatch.from_dict(synthetic.fastpitch_batch(B, 150, 860, 1234), "cuda")
@@ -25,5 +27,5 @@ for r in rows:
 tot = sum(v[1] for v in agg.values())
 print("total GEMM ms", tot, "launches", len(rows))
 names = ["NT", "NN", "TN"]
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('XVA_TOP', '40'))]:
     print("%s m%d M=%-6s N=%-5s K=%-7s batch=%-5s sk=%-3s bn=%-3s n=%-3d ms=%8.3f  TF=%7.1f" % (names[int(k[0]) // 3], int(k[0]) % 3, k[1], k[2], k[3], k[4], k[5], k[6], v[0], v[1], v[2] / v[1] if v[1] else 0))

@@ -444,11 +444,12 @@ static int split_rows(const Ctx& c, const char* row0_fp32, int64_t R, const Plan
     return xva_split_bf16(reinterpret_cast<const float*>(row0_fp32 - (int64_t)dst.C * 4), dst.base, dst.plane, (R + 2) * (int64_t)dst.C, st);
 }
 // the slot held fp32 rows before (exact mode on the same workspace): the two guard rows in the MIDDLE of the pair (hi row R, lo row -1) are then stale
-static int zero_mid_guards(const Ctx& c, const PlaneT& t, int64_t R, void* st) {
-    (void)c;                                               // hi rows R .. R + extra and lo row -1 are adjacent
-    if (hipMemsetAsync(prow(t, R), 0, (size_t)(2 + t.extra) * t.C * 2, (hipStream_t)st) != hipSuccess) { xva_set_error("fastpitch: memset failed"); return XVA_ERR_HIP; }
-    return XVA_OK;
-}
+// (hi rows R .. R + extra and lo row -1 are adjacent.)  The pair outputs of the products never touch them: one batched launch per stack and pass.
+struct GuardSpans {
+    void* p[64]; int64_t n[64]; int cnt = 0;
+    void add(const PlaneT& t, int64_t R) { p[cnt] = prow(t, R); n[cnt] = (int64_t)(2 + t.extra) * t.C * 2; ++cnt; }
+    int zero(void* st) { return cnt ? xva_zero_spans(p, n, cnt, st) : XVA_OK; }
+};
 static xva_gemm_params gpp(const Ctx& c) {
     xva_gemm_params g = gp0(c);
     g.compute = 1; g.a_dtype = g.b_dtype = XVA_BF16; g.planes = 1;
@@ -503,11 +504,14 @@ static int conv3_bwd_weight_p(Ctx& c, const PlaneT& dY, int64_t rows, int Cout, 
     return xva_gemm(&g, c.st);
 }
 // the parameter table and the transposed convolution weights as pairs (once per forward, like the bf16 mode's shadow)
-static int refresh_planes(const Ctx& c, const float* params, void* st) {
-    if (!planes_mode(c)) return XVA_OK;
+// parameters [begin, end) of the table as a pair (begin a multiple of 8)
+static int refresh_planes_range(const Ctx& c, const float* params, int64_t begin, int64_t end, void* st) {
+    const int64_t n8 = (end - begin) / 8 * 8;
+    return xva_split_bf16(params + begin, c.W + c.pl.wplanes + begin * 2, c.pl.wplane_stride, n8, st);
+}
+// the transposed convolution weights (read by the backward-data products only)
+static int refresh_planes_wt(const Ctx& c, const float* params, void* st) {
     const ParamTable& T = table();
-    const int64_t n8 = T.total / 8 * 8;
-    XVA_TRY(xva_split_bf16(params, c.W + c.pl.wplanes, c.pl.wplane_stride, n8, st));
     int64_t so[2 * NL], dof[2 * NL];
     for (int which = 0; which < 2; ++which) {
         for (int l = 0; l < NL; ++l) {
@@ -518,6 +522,11 @@ static int refresh_planes(const Ctx& c, const float* params, void* st) {
         XVA_TRY(xva_fp_wt_transpose3_planes(params, c.W + (which ? c.pl.wtp_c2 : c.pl.wtp_c1), so, dof, 2 * NL, which ? DM : DI, which ? DI : DM, WT_PLANE, st));
     }
     return XVA_OK;
+}
+static int refresh_planes(const Ctx& c, const float* params, void* st) {
+    if (!planes_mode(c)) return XVA_OK;
+    XVA_TRY(refresh_planes_range(c, params, 0, table().total, st));
+    return refresh_planes_wt(c, params, st);
 }
 
 // dropout sites: stream id = site_base + layer * 4 + {0 attention probs, 1 o_net output, 2 conv2 output}
@@ -541,8 +550,6 @@ static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
     const PlaneT wq{nullptr, c.pl.wplane_stride, 0};
     const PlaneT pdp{c.A(a.Pd), (int64_t)B * Tp * Ts, 0};
     if (!x_is_split) XVA_TRY(split_rows(c, x, R, xp, c.st));       // (layers past the first: the previous layer's LayerNorm wrote the pair)
-    XVA_TRY(zero_mid_guards(c, qp, R, c.st));
-    XVA_TRY(zero_mid_guards(c, avp, R, c.st));
     {   // qkv = x Wqkv^T + b, stored as a pair
         xva_gemm_params g = gpp(c); pgemm_common(g, &xp, &wq, &qp);
         g.layout = XVA_GEMM_NT; g.A = prow(xp, 0); g.B = wplane(c, p.qkv_w); g.C = prow(qp, 0); g.M = (int)R; g.N = DQKV; g.K = DM; g.lda = DM; g.ldb = DM; g.ldc = DQKV;
@@ -588,8 +595,6 @@ static int attention_bwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
     const PlaneT wq{nullptr, c.pl.wplane_stride, 0};
     const PlaneT pdp{c.A(a.Pd), (int64_t)B * Tp * Ts, 0}, dsp{c.A(c.pl.gPp), (int64_t)B * Tp * Ts, 0};
     if (!gDm_is_split) XVA_TRY(split_rows(c, gDm, R, dpp, c.st));
-    XVA_TRY(zero_mid_guards(c, gavp, Rmax, c.st));
-    XVA_TRY(zero_mid_guards(c, gqp, Rmax, c.st));
     {   // gAV = gDm Wo
         xva_gemm_params g = gpp(c); pgemm_common(g, &dpp, &wq, &gavp);
         g.layout = XVA_GEMM_NN; g.A = prow(dpp, 0); g.B = wplane(c, p.o_w); g.C = prow(gavp, 0); g.M = (int)R; g.N = DH; g.K = DM; g.lda = DM; g.ldb = DH; g.ldc = DH;
@@ -657,13 +662,21 @@ static int attention_wgrad_planes(Ctx& cw, const LayerP& p, const LayerA& a, cha
 static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t* xo, int64_t R, int Tp, int64_t Ts,
                       const int32_t* lens, int site) {
     const int B = c.pl.B;
+    const bool att_planes = att_planes_on(c, R, Tp), ffn_planes = ffn_planes_on(c, R, Tp);
+    if (att_planes || ffn_planes) {      // the pairs of qkv, A V and h live in their fp32 slots: stale guard rows if the exact mode ran on this workspace
+        GuardSpans gs;
+        for (int l = 0; l < NL; ++l) {
+            if (att_planes) { gs.add(planes_in_slot(c.A(LA[l].qkv), R, DQKV, QKV_SPARE), R); gs.add(planes_in_slot(c.A(LA[l].av), R, DH), R); }
+            if (ffn_planes) gs.add(planes_in_slot(c.A(LA[l].h), R, DI), R);
+        }
+        XVA_TRY(gs.zero(c.st));
+    }
     for (int l = 0; l < NL; ++l) {
         const LayerP& p = LP[l];
         const LayerA& a = LA[l];
         char* x = c.A(xo[l]);
         char* qkv = c.A(a.qkv); char* av = c.A(a.av);
         const uint32_t s0 = site + l * 4;
-        const bool att_planes = att_planes_on(c, R, Tp), ffn_planes = ffn_planes_on(c, R, Tp);
         if (att_planes) {
             XVA_TRY(attention_fwd_planes(c, p, a, x, g_ln_pairs && l > 0, R, Tp, Ts, lens, s0));
         } else {
@@ -708,7 +721,6 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         if (ffn_planes) {     // fp32 mode, split products: both convolutions on split-bf16 pairs (h is stored as a pair in its fp32 slot)
             const PlaneT yp = planes_own(c, a.yp, R), hp = planes_in_slot(c.A(a.h), R, DI);
             if (!g_ln_pairs) XVA_TRY(split_rows(c, c.A(a.y1), R, yp, c.st));
-            XVA_TRY(zero_mid_guards(c, hp, R, c.st));
             XVA_TRY(conv3_fwd_p(c, yp, R, DM, p.c1_w, c.P + p.c1_b, &hp, nullptr, DI, 1, nullptr, XVA_MASK_PAD, lens, Tp));
             XVA_TRY(conv3_fwd_p(c, hp, R, DI, p.c2_w, c.P + p.c2_b, nullptr, c.A(a.sum2), DM, 0, c.A(a.y1), XVA_MASK_NONE, nullptr, 0, Drop{c.pd, s0 + 2}));
         } else {
@@ -783,6 +795,13 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
     }
     char* const setB[2] = {gB, c.A(c.pl.gB2)}; char* const setBm[2] = {gBm, c.A(c.pl.gBm2)}; char* const setD[2] = {gD, c.A(c.pl.gD2)};
     char* const setDm[2] = {gDm, c.A(c.pl.gDm2)}; char* const setH[2] = {gH, c.A(c.pl.gH2)}; char* const setQ[2] = {gQKV, c.A(c.pl.gQKV2)};
+    if (ffn_planes_on(c, R, Tp)) {       // d(h), d(A V), d(qkv) as pairs in their (shared, Rmax-row) fp32 slots: the guard rows, once per pass
+        const int64_t Rm = c.pl.Rd > c.pl.Re ? c.pl.Rd : c.pl.Re;
+        GuardSpans gs;
+        for (int q = 0; q < 2; ++q) { gs.add(planes_in_slot(setH[q], Rm, DI), Rm); gs.add(planes_in_slot(setQ[q], Rm, DQKV), Rm); }
+        gs.add(planes_in_slot(gAV, Rm, DH), Rm);
+        XVA_TRY(gs.zero(c.st));
+    }
     for (int l = NL - 1; l >= 0; --l) {
         const LayerP& p = LP[l];
         const LayerA& a = LA[l];
@@ -807,7 +826,6 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         const PlaneT gHp = planes_in_slot(gH, Rmax, DI), hp = planes_in_slot(c.A(a.h), R, DI);
         if (planes) {               // fp32 mode, split products: d(sum2) and y1 as pairs; gH lives as a pair in its fp32 slot
             if (!g_ln_pairs) XVA_TRY(split_rows(c, gBm, R, gBp, c.st));          // (y1p: the forward's pair)
-            XVA_TRY(zero_mid_guards(c, gHp, Rmax, c.st));
             XVA_TRY(conv3_bwd_data_p(c, gBp, R, DM, wtplane(c, c.pl.wtp_c2, LP, l), DI, &gHp, nullptr, nullptr, &hp, XVA_MASK_PAD, lens, Tp));
             XVA_TRY(conv3_bwd_data_p(c, gHp, R, DI, wtplane(c, c.pl.wtp_c1, LP, l), DM, nullptr, gC, gB, nullptr, XVA_MASK_LEN, lens, Tp));
         } else {
@@ -1035,6 +1053,7 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
     // bf16 shadow of the parameters: the encoder's slice first; the rest (predictors, embeddings, decoder, aligner: 5/6 of the bytes) on the
     // predictor lane under the encoder's forward
     WgLane& wl0 = wg_lane();
+    bool split_rest = false;
     const bool split_cast = d->compute && wl0.ok && !g_fp_serial && d->stage != 2 && T.enc_begin == 0 && T.enc_end % 8 == 0;
     if (d->compute) {
         if (split_cast) {
@@ -1048,11 +1067,20 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
             XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
             XVA_TRY(refresh_wt_c2(c, params, c.st));
         }
+    } else if (planes_mode(c) && wl0.ok && !g_fp_serial && d->stage != 2 && T.enc_begin == 0 && T.enc_end % 8 == 0) {
+        // split products: the parameter pairs the same way — the encoder's slice first, the rest and the transposed weights on the predictor lane
+        split_rest = true;
+        XVA_TRY(refresh_planes_range(c, params, 0, T.enc_end, c.st));
+        XVA_HIP_TRY(hipEventRecord(wl0.pfork, (hipStream_t)c.st));
+        XVA_HIP_TRY(hipStreamWaitEvent(wl0.sp, wl0.pfork, 0));
+        XVA_TRY(refresh_planes_range(c, params, T.enc_end, T.total, wl0.sp));
+        XVA_HIP_TRY(hipEventRecord(wl0.pmid, wl0.sp));
+        XVA_TRY(refresh_planes_wt(c, params, wl0.sp));
     } else XVA_TRY(refresh_planes(c, params, c.st));
     // encoder                                                              (model.py:346)
     XVA_TRY(xva_fp_embed_fwd(bt->text, c.P + T.word_emb, bt->pos_table, c.A(pl.enc_x[0]), c.dt, B, pl.Tt, DM, c.st));
     XVA_TRY(layers_fwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, DS_ENC));
-    if (split_cast) XVA_HIP_TRY(hipStreamWaitEvent((hipStream_t)c.st, wl0.pmid, 0));          // the rest of the shadow is in place
+    if (split_cast || split_rest) XVA_HIP_TRY(hipStreamWaitEvent((hipStream_t)c.st, wl0.pmid, 0));          // the rest of the shadow / pairs is in place
     char* enc_out = c.A(pl.enc_x[NL]);
     if (d->stage == 2) {                                                    // model.py:367-373
         XVA_TRY(pred_fwd(c, T.dur, pl.dur, enc_out, pl.pin_a, bt->in_lens, DS_PRED + 0));

@@ -1131,6 +1131,28 @@ extern "C" int xva_cast_f32(const float* src, void* dst, int dt, int64_t n, void
     return XVA_OK;
 }
 
+// Zero up to 40 small byte spans (multiples of 4, 4-byte aligned) in ONE launch: the guard rows of the split-bf16 pairs that live in fp32 slots (a memset per
+// span was 72 stream operations per FastPitch step).  One workgroup per span.
+struct xva_spans { void* p[40]; int32_t words[40]; };
+__global__ void zero_spans_kernel(xva_spans sp) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(sp.p[blockIdx.x]);
+    for (int i = threadIdx.x; i < sp.words[blockIdx.x]; i += blockDim.x) d[i] = 0u;
+}
+extern "C" int xva_zero_spans(void* const* ptrs, const int64_t* bytes, int n, void* stream) {
+    XVA_CHECK_ARG(n >= 0 && (n == 0 || (ptrs && bytes)), "zero_spans: bad args");
+    for (int i0 = 0; i0 < n; i0 += 40) {
+        xva_spans sp;
+        const int m = n - i0 < 40 ? n - i0 : 40;
+        for (int i = 0; i < m; ++i) {
+            XVA_CHECK_ARG(ptrs[i0 + i] && bytes[i0 + i] % 4 == 0 && bytes[i0 + i] < ((int64_t)1 << 32) && ((uintptr_t)ptrs[i0 + i] % 4) == 0, "zero_spans: spans are 4-byte aligned multiples of 4");
+            sp.p[i] = ptrs[i0 + i]; sp.words[i] = (int32_t)(bytes[i0 + i] / 4);
+        }
+        hipLaunchKernelGGL(zero_spans_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, sp);
+    }
+    XVA_LAUNCH_CHECK();
+    return XVA_OK;
+}
+
 // fp32 tensor -> split-bf16 pair (hi = bf16(x) at dst[i], lo = bf16(x - hi) at dst[plane + i]): the operand format of xva_gemm's `planes` products
 // (include/xva_gemm.h).  8 elements per thread and iteration.
 __global__ void split_bf16x8_kernel(const float4* __restrict__ src, uint4* __restrict__ hi, uint4* __restrict__ lo, int64_t n8) {

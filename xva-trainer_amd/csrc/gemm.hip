@@ -111,7 +111,8 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         const double eff256 = (double)p.M * p.N * nb / ((double)t256 * 65536.0);
         // 256x256 tiles (one workgroup per CU) when they fill the chip — by themselves or through split-K — without much padding;
         // narrow outputs take 64-column tiles; grids that would leave most CUs idle take 64x64 tiles
-        const long maxsk = can_split ? (nkt / 8 > 1 ? nkt / 8 : 1) : p.splitk;
+        const int min_kt = p.planes ? 24 : 8;          // K tiles per split at least (planes: 8 per pass — the slabs of a 144-way split were 84 MB of traffic for a 0.3 MB result)
+        const long maxsk = can_split ? (nkt / min_kt > 1 ? nkt / min_kt : 1) : p.splitk;
         if (p.N <= 32) glds_tile = 4;
         else if (p.N <= 64) glds_tile = 2;
         else if (nkt < 4) glds_tile = ntiles(0) >= 1024 ? 0 : 3;     // short reductions are prologue / epilogue bound: many small workgroups
@@ -130,7 +131,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
             const long tiles = ntiles(glds_tile);
             // small tiles are latency-bound per K tile (one DMA stage in flight): fill the chip with ~6 workgroups per CU
             long sk = glds_tile == 1 ? 256 / tiles : ((glds_tile == 0 ? 864 : 1536) + tiles / 2) / tiles;
-            if (sk > nkt / 8) sk = nkt / 8;
+            if (sk > nkt / min_kt) sk = nkt / min_kt;
             if (sk > 1024) sk = 1024;
             if (p.sk_ws && p.N % 4 == 0) {   // stay inside the caller's slab scratch (atomics are much slower)
                 const long fit = (long)(p.sk_ws_bytes / ((int64_t)p.M * p.N * 4 * nb));
