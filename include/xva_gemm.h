@@ -124,10 +124,17 @@ typedef struct xva_gemm_params {
      *                after C).  A gate tensor may be the hi plane of a pair (sign and zero-ness of x survive the rounding). */
     int32_t planes;
     int64_t a_plane, b_plane, c_plane;
+    /* Convolution weight gradients on the resident-operand kernel (TN with column segments, bf16 operands, fp32 C accumulated through the slabs: csrc/wgrad_res.h):
+     * colsum_out[z2 * M + m] += alpha * sum_k A[k][m] — the BIAS gradient of the same layer, from the dY tiles the kernel already holds in LDS (one extra MFMA
+     * against a fragment of ones per k-step in one wave of the first column group; fp32 atomics across the row-range splits).  xva_gemm refuses the field when
+     * another kernel would take the product: ask xva_gemm_takes_colsum first. */
+    float* colsum_out;
 } xva_gemm_params;
 
 /* Launches on `stream` (a hipStream_t); returns 0 or a negative XVA_ERR_* code. */
 int xva_gemm(const xva_gemm_params* p, void* stream);
+/* 1 when xva_gemm would run this product on the resident-operand weight-gradient kernel, i.e. honours colsum_out (p->colsum_out itself is not looked at). */
+int xva_gemm_takes_colsum(const xva_gemm_params* p);
 
 /* Diagnostics / test knob: main-loop selection for bf16-stored operands. -1 automatic (default), 0 general register-staged kernel, 8 the
  * 256x128 tile with a 32-deep K tile (two workgroups per CU),

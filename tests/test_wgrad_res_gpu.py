@@ -23,7 +23,7 @@ def _rel(out, ref):
     return ((out.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
 
 
-def _case(L, items, T_in, Cin, Cout, G, k, s, d, merged=False, seed=0, alpha=1.0, wgrad=1):
+def _case(L, items, T_in, Cin, Cout, G, k, s, d, merged=False, seed=0, alpha=1.0, wgrad=1, bias_grad=None):
     torch.manual_seed(seed)
     P = (k * d - d) // 2
     T_out = (T_in + 2 * P - d * (k - 1) - 1) // s + 1
@@ -48,6 +48,8 @@ def _case(L, items, T_in, Cin, Cout, G, k, s, d, merged=False, seed=0, alpha=1.0
     try:
         kw = dict(layout=L.GEMM_TN, compute=1, accumulate=True, splitk=0, sk_ws=ws, alpha=alpha, seglen=Cig, seg0=0, segstride=d * Cin - Cig,
                   batch2=G, sA2=Cog, sB2=Cig, sC2=Cog * k * Cig, a_rowpitch=Cin)
+        if bias_grad is not None:          # the layer's bias gradient from the same launch (xva_gemm colsum_out)
+            kw["colsum_out"] = bias_grad.data_ptr()
         if merged:
             L.gemm(dy, xbuf, dW, Cog, k * Cig, items * Hp, Cout, s * Cin, k * Cig, b_offset=(PAD - P) * Cin, **kw)
         else:
@@ -67,6 +69,8 @@ def _case(L, items, T_in, Cin, Cout, G, k, s, d, merged=False, seed=0, alpha=1.0
     assert y.shape[2] == T_out
     (y * dyv.double().transpose(1, 2)).sum().backward()
     ref = 0.5 + alpha * w.grad.permute(0, 2, 1).reshape(G, Cog, k * Cig)
+    if bias_grad is not None:
+        return dW, ref, alpha * dyv.double().sum(dim=(0, 1))
     return dW, ref
 
 
@@ -96,3 +100,22 @@ def test_scale_and_agreement_with_the_general_kernel():
     assert _rel(a, ref) < 3e-6 and _rel(b, ref) < 3e-6
     a2, _ = _case(L, 5, 900, 64, 64, 1, 11, 1, 3, seed=3, alpha=1.0 / 3, wgrad=1)
     assert torch.equal(a, a2)       # slabs + ordered reduction: bit-reproducible
+
+
+# the bias gradient of the same layer out of the weight-gradient launch (one MFMA against a fragment of ones per k-step, one wave of the first column group)
+@pytest.mark.parametrize("C,G,k,s,d,T,merged,alpha", [(32, 1, 11, 1, 5, 1024, False, 1.0), (64, 1, 3, 1, 3, 512, True, 1.0 / 3), (128, 1, 7, 1, 1, 300, True, 1.0),
+                                                       (128, 1, 3, 1, 1, 400, False, 0.5), (256, 16, 41, 1, 1, 600, False, 1.0), (128, 4, 41, 2, 1, 1024, False, 1.0)])
+def test_bias_gradient_from_the_weight_gradient_launch(C, G, k, s, d, T, merged, alpha):
+    L = _lib()
+    db = torch.full((C,), 0.25, device="cuda")
+    dW, ref, ref_b = _case(L, 6, T, C, C, G, k, s, d, merged=merged, seed=C + k + d + 1, alpha=alpha, bias_grad=db)
+    assert _rel(dW, ref) < 3e-6
+    assert _rel(db - 0.25, ref_b) < 2e-6
+
+
+def test_bias_gradient_field_is_refused_off_the_resident_kernel():
+    """colsum_out on a product another kernel would take is an error, not a silently missing gradient"""
+    L = _lib()
+    db = torch.zeros(32, device="cuda")
+    with pytest.raises(Exception, match="colsum_out"):
+        _case(L, 6, 512, 32, 32, 1, 3, 1, 1, wgrad=0, bias_grad=db)

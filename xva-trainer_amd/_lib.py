@@ -59,6 +59,7 @@ class GemmParams(C.Structure):
         ("a_rowpitch", i64),
         ("F", vp), ("fm_c", f32),
         ("planes", i32), ("a_plane", i64), ("b_plane", i64), ("c_plane", i64),
+        ("colsum_out", vp),
     ]
 
 

@@ -13,6 +13,7 @@ void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn);
 int xva_gemm_conv_res_plan(const xva_gemm_params& p, int* stride_out = nullptr, int64_t* rowpitch_out = nullptr);
 int xva_gemm_launch_conv_res(const xva_gemm_params& p, int dstep, hipStream_t st);
 int xva_gemm_launch_wgrad_res(const xva_gemm_params& p, hipStream_t st, int* splits_out);
+bool xva_gemm_wgrad_res_ok(const xva_gemm_params& p);
 bool xva_prof_is_on();
 void xva_prof_begin(hipStream_t st, double flops, int variant);
 void xva_prof_end(hipStream_t st);
@@ -29,6 +30,13 @@ static int g_fp32_products = [] { const char* e = getenv("XVA_GEMM_FP32_PRODUCTS
 extern "C" int xva_gemm_set_fp32_products(int mode) { int old = g_fp32_products; g_fp32_products = mode; return old; }
 extern "C" int xva_gemm_get_fp32_products(void) { return g_fp32_products; }
 
+extern "C" int xva_gemm_takes_colsum(const xva_gemm_params* pp) {
+    if (!pp) return 0;
+    xva_gemm_params p = *pp;
+    if (p.batch < 1) p.batch = 1;
+    if (p.batch2 < 1) p.batch2 = 1;
+    return (p.splitk == 0 && p.layout == XVA_GEMM_TN && p.seglen > 0 && p.sk_ws && p.M > 0 && p.N > 0 && p.K > 0 && xva_gemm_wgrad_res_ok(p)) ? 1 : 0;
+}
 extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     XVA_CHECK_ARG(pp != nullptr, "xva_gemm: null params");
     xva_gemm_params p = *pp;
@@ -73,6 +81,8 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     XVA_CHECK_ARG(!p.c_plane || (p.c_dtype == XVA_BF16 && !p.accumulate && !p.C2 && !p.c_trans && p.c_plane % 8 == 0 && p.compute == 1 && p.a_dtype == XVA_BF16),
                   "xva_gemm: a split-bf16 output pair needs a bf16 C without accumulation / second output / transposed store (direct-to-LDS kernels)");
     if (p.K == 0) p.splitk = 1;
+    XVA_CHECK_ARG(!p.colsum_out || (auto_sk && p.layout == XVA_GEMM_TN && p.seglen > 0 && p.sk_ws && xva_gemm_wgrad_res_ok(p)),
+                  "xva_gemm: colsum_out is honoured by the resident-operand weight-gradient kernel only (xva_gemm_takes_colsum)");
     if (auto_sk && p.layout == XVA_GEMM_TN && p.seglen > 0 && p.sk_ws) {   // convolution weight gradient: resident-operand kernel (wgrad_res.h)
         const bool prof = xva_prof_is_on();
         if (prof) xva_prof_begin((hipStream_t)stream, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + 1);

@@ -164,7 +164,10 @@ inline int hg_conv_bwd_data(const Seq& dY, const Seq& dX, const ConvW& w, const 
 }
 
 // ---- backward-weight: dWeff[g][co][(j, ci)] += alpha * sum_rows dY[r][co] * lrelu?(X)[s*r + j*d - P][ci] ----------
-inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x_lrelu, float x_slope, float alpha, int compute, void* st) {
+// db != nullptr: the layer's bias gradient db[c] += alpha * sum_rows dY[row][c] as well — inside the resident-operand kernel when it takes the product
+// (xva_gemm colsum_out), by the column-sum kernel otherwise
+extern "C" int xva_hg_colsum(const void* X, int dt, float* out, int64_t rows, int C, float scale, void* stream);
+inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x_lrelu, float x_slope, float alpha, int compute, void* st, float* db = nullptr) {
     XVA_CHECK_ARG(X.C == w.Cin && dY.C == w.Cout && X.nseq == dY.nseq && w.dweff, "conv_bwd_weight: mismatch");
     const int Cig = w.Cin / w.groups, Cog = w.Cout / w.groups;
     xva_gemm_params g = hg_gp(compute, dY.dt);
@@ -209,6 +212,11 @@ inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x
         g.K = (int)((int64_t)X.nseq * dY.T); g.kb_len = dY.T;
         if (!swap) { g.kb_sA = dY.item(); g.kb_sB = X.item(); } else { g.kb_sA = X.item(); g.kb_sB = dY.item(); }
         g.accumulate = 1; g.splitk = 0;   // xva_gemm sizes the split to its tile grid and the slab scratch
+    }
+    if (db) {
+        static const int fused = [] { const char* e = getenv("XVA_HG_BIAS_FUSED"); return e ? atoi(e) : 1; }();     // 0: always the column-sum kernel (A/B)
+        if (fused && !swap && xva_gemm_takes_colsum(&g)) g.colsum_out = db;
+        else XVA_TRY(xva_hg_colsum(dY.ptr(), dY.dt, db, dY.rows(), dY.C, alpha, st));
     }
     return xva_gemm(&g, st);
 }

@@ -741,10 +741,9 @@ int gen_backward(Ctx& c, const float* P, float* G, const float* d_wav, void* con
                     }
                 }
                 use_slabs(cw_);
-                XVA_TRY(hg_conv_bwd_weight(dcur, xt1, w2, 0, 0.f, sc, c.compute, cw_.st));
-                XVA_TRY(xva_hg_colsum(dcur.ptr(), c.dt, G + L[N.rc2[rb][m]].bias, dcur.rows(), C, sc, cw_.st));
-                XVA_TRY(hg_conv_bwd_weight(dt1, xin, w1, 0, 0.f, 1.f, c.compute, cw_.st));
-                XVA_TRY(xva_hg_colsum(dt1.ptr(), c.dt, G + L[N.rc1[rb][m]].bias, dt1.rows(), C, 1.f, cw_.st));
+                // (weight and bias gradient of a convolution in one launch where the resident-operand kernel takes it: hg_conv.h)
+                XVA_TRY(hg_conv_bwd_weight(dcur, xt1, w2, 0, 0.f, sc, c.compute, cw_.st, G + L[N.rc2[rb][m]].bias));
+                XVA_TRY(hg_conv_bwd_weight(dt1, xin, w1, 0, 0.f, 1.f, c.compute, cw_.st, G + L[N.rc1[rb][m]].bias));
                 use_slabs(c);
                 BwdEpi b1; b1.gate = &xin; b1.gate_slope = SLOPE; b1.R = &dcur; b1.beta = sc;
                 Seq dst = (m == 0) ? du : ((m == 2) ? da : db);

@@ -189,6 +189,14 @@ __global__ __launch_bounds__(512, (8 * NIW * D <= 80 && MI * NBW <= 12 && NBW <=
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // The bias gradient of the same layer (p.colsum_out): column sums of dY = dY^T x ones — one more MFMA per (k-step, 16-row tile) against a
+    // fragment of ones, in wave 0 of the FIRST column group only (each (output-row tile, row range, group) has exactly one).
+    const bool bias_wave = p.colsum_out != nullptr && cg == 0 && wave == 0;
+    f32x4 accb[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) accb[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
     const int ksteps = w.R / 32;
     constexpr int WAIT_N = (D - 2) * NIW;
@@ -218,6 +226,10 @@ __global__ __launch_bounds__(512, (8 * NIW * D <= 80 && MI * NBW <= 12 && NBW <=
             bf16x8 af[MI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) af[mi] = tr_value(fa[mi]);
+            if (bias_wave) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) accb[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[mi], accb[mi], 0, 0, 0);
+            }
             static_for<NBW>([&](auto nbc) {
                 constexpr int nb = decltype(nbc)::value;
                 if (nb < cnt) {
@@ -243,6 +255,10 @@ __global__ __launch_bounds__(512, (8 * NIW * D <= 80 && MI * NBW <= 12 && NBW <=
             }
         }
     });
+    if (bias_wave && g == 0) {       // every column of the ones product holds the sum: lanes 0 .. 15 own rows (output channels) i
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) atomicAdd(p.colsum_out + (int64_t)z2 * p.M + ct * CO_W + mi * 16 + i, p.alpha * accb[mi][0]);
+    }
 }
 
 }  // namespace xva_wgrad
