@@ -167,7 +167,9 @@ inline int hg_conv_bwd_data(const Seq& dY, const Seq& dX, const ConvW& w, const 
 // db != nullptr: the layer's bias gradient db[c] += alpha * sum_rows dY[row][c] as well — inside the resident-operand kernel when it takes the product
 // (xva_gemm colsum_out), by the column-sum kernel otherwise
 extern "C" int xva_hg_colsum(const void* X, int dt, float* out, int64_t rows, int C, float scale, void* stream);
-inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x_lrelu, float x_slope, float alpha, int compute, void* st, float* db = nullptr) {
+// db_deferred != nullptr: when the kernel does not take the bias gradient, leave it to the caller (*db_deferred = true: e.g. a batched column-sum launch later)
+inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x_lrelu, float x_slope, float alpha, int compute, void* st, float* db = nullptr,
+                              bool* db_deferred = nullptr) {
     XVA_CHECK_ARG(X.C == w.Cin && dY.C == w.Cout && X.nseq == dY.nseq && w.dweff, "conv_bwd_weight: mismatch");
     const int Cig = w.Cin / w.groups, Cog = w.Cout / w.groups;
     xva_gemm_params g = hg_gp(compute, dY.dt);
@@ -216,6 +218,7 @@ inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x
     if (db) {
         static const int fused = [] { const char* e = getenv("XVA_HG_BIAS_FUSED"); return e ? atoi(e) : 1; }();     // 0: always the column-sum kernel (A/B)
         if (fused && !swap && xva_gemm_takes_colsum(&g)) g.colsum_out = db;
+        else if (db_deferred) *db_deferred = true;
         else XVA_TRY(xva_hg_colsum(dY.ptr(), dY.dt, db, dY.rows(), dY.C, alpha, st));
     }
     return xva_gemm(&g, st);

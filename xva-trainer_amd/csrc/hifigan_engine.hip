@@ -909,8 +909,9 @@ int disc_backward_params(Ctx& c, const float* Pd, float* Gd, const DiscRun& r, i
                                           c.st));
         } else {
             ConvW w = cw(c, l, Pd, r.pass);
-            XVA_TRY(hg_conv_bwd_weight(dy, x, w, 0, 0.f, 1.f, c.compute, c.st));
-            defer_colsum(dy, Gd + l.bias);
+            bool later = false;          // (the grouped scale-discriminator layers: the bias gradient comes out of the weight-gradient launch)
+            XVA_TRY(hg_conv_bwd_weight(dy, x, w, 0, 0.f, 1.f, c.compute, c.st, Gd + l.bias, &later));
+            if (later) defer_colsum(dy, Gd + l.bias);
             BwdEpi b; b.gate = &x; b.gate_slope = SLOPE;
             XVA_TRY(hg_conv_bwd_data(dy, dx, w, b, c.compute, c.st));
         }
