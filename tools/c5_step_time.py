@@ -83,6 +83,20 @@ print("xVAPitch C5 iteration, B=%d x (%d symbols, %d spectrogram frames), segmen
 print("  generator pass fwd + bwd %.1f ms | discriminator pass fwd + bwd %.1f ms | 2 x AdamW %.1f ms | iteration %.1f ms = %.0f k segment-samples / s, %.0f spectrogram frames / s (losses %.3f / %.3f)"
       % (acc[0], acc[1], acc[2], tot, B * SEG * 256 / tot, float(y_lens.sum()) / tot * 1e3, lg, ld))
 
+if os.environ.get("XVA_C5_GLUE_SITES", "0") != "0":
+    # which Python lines of the package issue torch-native device work (memcpys, fills, elementwise glue): one iteration under torch.profiler with Python
+    # stacks, exported as a chrome trace; tools/c5_glue_sites.py attributes every runtime launch (hipMemcpy*, hipLaunchKernel of an at::native kernel,
+    # hipMemset*) to the innermost package frame that encloses it on its thread (the autograd thread's frames included)
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+                 experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
+        iteration(); torch.cuda.synchronize()
+    os.makedirs("gpurun_out", exist_ok=True)
+    prof.export_chrome_trace("gpurun_out/c5_trace.json.gz")
+    import subprocess
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "c5_glue_sites.py"), "gpurun_out/c5_trace.json.gz"])
+    sys.exit(0)
+
 if os.environ.get("XVA_C5_GEMM_PROFILE", "0") != "0":
     # every xva_gemm launch of one iteration with its own HIP event pair (csrc/core.hip xva_prof_*), by shape
     import collections, csv

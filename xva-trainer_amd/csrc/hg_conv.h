@@ -105,6 +105,38 @@ inline int hg_conv_fwd(const Seq& X, const Seq& Y, const ConvW& w, const ConvEpi
     return xva_gemm(&g, st);
 }
 
+// ---- forward of a ResBlock1 pair in one launch (conv_pair.hip): T1 = lrelu(conv1(Xin) + b1, slope1) ; Y = alpha * (conv2(T1) + b2) + beta * R  [; Y2 = lrelu(Y)]
+// Xin: the activated block input (x_raw = 0; e.R = the raw input as for hg_conv_fwd) or the raw one (x_raw = 1: LeakyReLU(x_slope) on the operand
+// fragments, the residual from the resident tile, e.R is ignored and alpha must equal beta; x_raw = 2: activated in place in LDS, e.R as given).  Returns 1 = launched, 0 = not taken (run the two
+// convolutions), < 0 = error.
+#include "conv_pair.h"
+inline int hg_conv_pair_fwd(const Seq& Xin, int x_raw, float x_slope, const Seq& T1, const Seq& Y, const ConvW& w1, const ConvW& w2, float slope1, const ConvEpi& e,
+                            int compute, void* st) {
+    const int C = Xin.C;
+    if (compute == 0 || Xin.dt != XVA_BF16 || !(C == 32 || C == 64)) return 0;
+    if (w1.Cin != C || w1.Cout != C || w2.Cin != C || w2.Cout != C || w1.groups != 1 || w2.groups != 1 || w1.s != 1 || w2.s != 1 || w2.d != 1) return 0;
+    const int h1 = w1.d * (w1.k - 1) / 2, h2 = (w2.k - 1) / 2;
+    if (!(w1.k & 1) || !(w2.k & 1) || w1.P != h1 || w2.P != h2 || Xin.padF < h1 + h2 || Xin.padB < h1 + h2) return 0;
+    if (!T1.same_geom(Xin) || !Y.same_geom(Xin) || T1.C != C || Y.C != C || T1.dt != Xin.dt || Y.dt != Xin.dt || e.a_lrelu || e.act != XVA_ACT_NONE) return 0;
+    if (x_raw == 1 && e.alpha != e.beta) return 0;
+    xva_gemm_params g = hg_gp(compute, Xin.dt);
+    g.layout = XVA_GEMM_NT;
+    g.N = C; g.K = w2.k * C; g.ldb = g.K; g.ldc = C; g.M = Y.T;
+    g.B = w2.eff; g.bias = w2.bias; g.sbias2 = C;
+    g.alpha = e.alpha; g.beta = e.beta; g.accumulate = e.accumulate;
+    g.batch = Xin.nseq; g.sC = Y.item(); g.sR = Y.item();
+    g.C = Y.valid();
+    if (x_raw != 1 && e.R) { if (!e.R->same_geom(Y) || e.R->C != C) return 0; g.R = e.R->valid(); g.ldr = C; g.r_dtype = e.R->dt; }
+    if (e.Y2) { if (!e.Y2->same_geom(Y) || e.Y2->C != C || e.Y2->dt != Y.dt) return 0; g.C2 = e.Y2->valid(); g.c2_slope = e.y2_slope; }
+    xva_conv_pair q;
+    memset(&q, 0, sizeof(q));
+    q.X = (const char*)Xin.valid() - (int64_t)(h1 + h2) * C * Xin.es(); q.sX = Xin.item(); q.ldx = C;
+    q.W1 = w1.eff; q.bias1 = w1.bias; q.k1 = w1.k; q.d1 = w1.d; q.slope1 = slope1;
+    q.T1 = T1.valid(); q.sT1 = T1.item(); q.ldt = C;
+    q.x_raw = x_raw; q.x_slope = x_slope;
+    return xva_conv_pair_fwd(&g, &q, st) == 0 ? 1 : 0;
+}
+
 // ---- backward-data: dX = gate(X) * sum_taps dY (*) W  (+ beta * R) -----------------------------------------------
 // stride 1: one GEMM.  stride s: one GEMM per input phase psi (polyphase), each using the taps j = j0 + m*s.
 struct BwdEpi {

@@ -47,6 +47,10 @@ int xva_hg_add_item_vec(void* seq, int dt, const float* vec, int B, int Hp, int 
 
 void xva_prof_tag(int tag);
 
+// forward of the 32 / 64-channel ResBlock pairs: see gen_forward.  env XVA_HG_PAIR; xva_hg_set_pair_mode for in-process A/B
+static int g_hg_pair = [] { const char* e = getenv("XVA_HG_PAIR"); return e ? atoi(e) : 1; }();
+extern "C" int xva_hg_set_pair_mode(int mode) { int old = g_hg_pair; g_hg_pair = mode; return old; }
+
 namespace {
 
 // profiling knob (tools/hg_disc_split.py): bit di set = discriminator di (MPD 0..4, MSD 5..7) runs; results are meaningless with bits cleared
@@ -608,18 +612,37 @@ int gen_forward(Ctx& c, const float* P, const float* mel, float* wav_out, const 
             for (int m = 0; m < 3; ++m) {                                                          // ResBlock1.forward (:41-48)
                 Seq xt1 = c.S(pl.xt1[rb][m]);
                 ConvEpi e1; e1.act = XVA_ACT_LRELU; e1.act_slope = SLOPE;                           // xt1 = lrelu(c1(lrelu(x)))
-                XVA_TRY(hg_conv_fwd(xact, xt1, cw(c, L[N.rc1[rb][m]], P), e1, c.compute, st));
                 ConvEpi e2; e2.R = &xcur;
+                // The 32 / 64-channel stages run a pair as ONE launch with the intermediate in LDS (conv_pair.hip).  XVA_HG_PAIR: 0 = two launches,
+                // 1 = fused, operand = the stored activated copy (bit-identical), 2 / 3 = fused from the raw block input (one pass less: LeakyReLU on the
+                // operand fragments + residual from the tile / tile activated in place + residual re-read)
+                const int pmode = dual ? g_hg_pair : 0;
+                auto pair = [&](const Seq& out) {
+                    return hg_conv_pair_fwd(pmode >= 2 ? xcur : xact, pmode - 1, SLOPE, xt1, out, cw(c, L[N.rc1[rb][m]], P), cw(c, L[N.rc2[rb][m]], P), SLOPE, e2, c.compute, st);
+                };
                 if (m < 2) {
                     Seq xn = c.S(pl.xr[rb][m]), xna = c.S(pl.xra[rb][m]);
                     if (dual) { e2.Y2 = &xna; e2.y2_slope = SLOPE; }
-                    XVA_TRY(hg_conv_fwd(xt1, xn, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, st));
+                    int fused = pmode ? pair(xn) : 0;
+                    if (fused < 0) return fused;
+                    if (!fused) {
+                        XVA_TRY(hg_conv_fwd(xact, xt1, cw(c, L[N.rc1[rb][m]], P), e1, c.compute, st));
+                        XVA_TRY(hg_conv_fwd(xt1, xn, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, st));
+                    }
                     if (!dual) XVA_TRY(xva_hg_lrelu_copy(xn.ptr(), xna.ptr(), c.dt, xn.rows() * xn.C, SLOPE, st));
                     xcur = xn; xact = xna;
                 } else {                                                                           // xs = sum_j resblock_j / 3  (:118-123)
                     e2.alpha = 1.f / 3; e2.beta = 1.f / 3; e2.accumulate = j > 0;
+                    // (the fused pair accumulates into xs in its epilogue: it has to wait for the previous resblock's BEFORE the launch)
+                    const bool try_pair = pmode && (xs.C == 32 || xs.C == 64);
+                    if (!try_pair) XVA_TRY(hg_conv_fwd(xact, xt1, cw(c, L[N.rc1[rb][m]], P), e1, c.compute, st));
                     if (lanes && j > 0 && hipStreamWaitEvent((hipStream_t)st, ss.pool[j - 1], 0) != hipSuccess) return fail();
-                    XVA_TRY(hg_conv_fwd(xt1, xs, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, st));
+                    int fused = try_pair ? pair(xs) : 0;
+                    if (fused < 0) return fused;
+                    if (!fused) {
+                        if (try_pair) XVA_TRY(hg_conv_fwd(xact, xt1, cw(c, L[N.rc1[rb][m]], P), e1, c.compute, st));
+                        XVA_TRY(hg_conv_fwd(xt1, xs, cw(c, L[N.rc2[rb][m]], P), e2, c.compute, st));
+                    }
                     if (lanes && hipEventRecord(ss.pool[j], (hipStream_t)st) != hipSuccess) return fail();
                 }
             }
