@@ -444,6 +444,10 @@ int xva_vits_disc_backward_g(const xva_hg_dims* d, float* params_d, const float*
  * env XVA_HG_STREAMS / XVA_FP_STREAMS = 1 do the same at start-up. */
 int xva_hg_set_streams(int n);
 int xva_fp_set_streams(int n);
+/* HiFi-GAN generator forward, bf16 mode: a ResBlock1 pair (python/hifigan/models.py:41-48) of the 32 / 64-channel stages as ONE launch (csrc/conv_pair.hip).
+ * 0 = two convolution launches; 1 (default) = fused, operand = the stored activated copy: bit-identical; 2 / 3 = fused from the raw block input (one tensor
+ * pass less; one rounding of the negative half differs: LeakyReLU applied to the bf16 value).  Returns the previous mode.  env XVA_HG_PAIR. */
+int xva_hg_set_pair_mode(int mode);
 /* FastPitch bf16 mode, backward-data of the feed-forward's second Conv1d (python/fastpitch1_1/fastpitch/transformer.py:59-77 under autograd):
  * 1 (default) = through a transposed, tap-reversed bf16 copy of the weight refreshed with the parameter shadow (NT main loop), 0 = on the weight as
  * stored (NN main loop).  Changes the workspace plan: set it before xva_fp_workspace_bytes.  Returns the previous mode.  env XVA_FP_BWD_NT. */
@@ -485,7 +489,9 @@ int xva_hg_disc_backward_d_ex(const xva_hg_dims* d, float* params_d, float* grad
 int xva_hg_disc_forward(const xva_hg_dims* d, float* params_d, const float* y_real, const float* y_fake, void* workspace,
                         int64_t workspace_bytes, float* losses, void* stream);
 /* Same with a loss selection: bit 0 = discriminator loss (all the D step needs, xva_train.py:488-493), bit 1 = generator LSGAN +
- * feature-matching losses (the G step, :506-512; the only part that reads every feature map).  Unselected entries stay 0. */
+ * feature-matching losses (the G step, :506-512; the only part that reads every feature map).  Unselected entries stay 0.
+ * Bit 2: the effective (weight-normalised, activation-dtype) weights in `workspace` were prepared from exactly these params_d by the previous forward on it
+ * (nothing wrote params_d since; the spectral-norm buffers do not count): the reparametrisation pass is skipped.  A wrong promise gives stale weights. */
 int xva_hg_disc_forward_ex(const xva_hg_dims* d, float* params_d, const float* y_real, const float* y_fake, void* workspace,
                            int64_t workspace_bytes, float* losses, int loss_mask, void* stream);
 /* D step (xva_train.py:494-495): accumulates d(loss_disc_s + loss_disc_f)/d(params_d) into grads_d. */

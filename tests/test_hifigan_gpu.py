@@ -509,3 +509,124 @@ def test_fused_resblock_pair_from_the_raw_input_stays_inside_bf16_noise(mode):
     e0, e2 = _nrel(w0, ref), _nrel(w2, ref)
     print("waveform vs the fp32 oracle: two launches", e0, "raw-input pair", e2)
     assert e2 < max(1.25 * e0, 5e-2)
+
+
+def test_d_step_forward_reuses_the_prepared_weights_only_when_nothing_wrote_them():
+    """The D-step forward of iteration i + 1 runs on the parameters the G-step forward of iteration i reparametrised (xva_hg_disc_forward_ex bit 2 behind
+    HifiganStep's token): three training iterations with the reuse equal three without it, and a parameter load in between drops the promise."""
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan.step import HifiganStep
+
+    def run(reuse, reload_at=None):
+        st = HifiganStep("cuda", "bf16")
+        st.load_state_dicts(ohg.init_generator_sd(11), ohg.init_mpd_sd(12), ohg.init_msd_sd(13))
+        if not reuse:
+            st._d_token = lambda: None
+        x, y, ym = ohg.synth_batch(2, 4324)
+        seen, losses = [], []
+        fwd = st.eng.disc_forward
+        def spy(flat_d, yr, yg, losses="all", weights_token=None):
+            out = fwd(flat_d, yr, yg, losses=losses, weights_token=weights_token)
+            seen.append(st.eng._d_eff_key is not None and bool(spy.last == st.eng._d_eff_key))
+            spy.last = st.eng._d_eff_key
+            return out
+        spy.last = None
+        st.eng.disc_forward = spy
+        for it in range(3):
+            if reload_at == it:
+                st.load_state_dicts(mpd=ohg.init_mpd_sd(22))
+            o = st.train_step(x.cuda(), y.cuda(), ym.cuda())
+            losses.append([float(o[k]) for k in ("loss_disc_all", "loss_gen_all", "loss_mel")])
+        torch.cuda.synchronize()
+        return st.flat_d.clone(), st.flat_g.clone(), losses, seen
+
+    d0, g0, l0, s0 = run(False)
+    d1, g1, l1, s1 = run(True)
+    assert s0 == [False] * 6 and s1 == [False, False, True, False, True, False], (s0, s1)     # D / G forward of each iteration: the D forward reuses from iteration 2 on
+    # two runs WITHOUT the reuse differ by the order of the backward's fp32 atomics (a near-zero gradient that changes sign moves its parameter by 2 lr in the
+    # first AdamW steps): that spread calibrates the comparison
+    d0b, g0b, l0b, _ = run(False)
+    noise_d, noise_g = _nrel(d0b, d0), _nrel(g0b, g0)
+    print("run-to-run spread without the reuse: D", noise_d, "G", noise_g, "; with the reuse: D", _nrel(d1, d0), "G", _nrel(g1, g0))
+    assert _nrel(d1, d0) <= max(5 * noise_d, 2e-3) and _nrel(g1, g0) <= max(5 * noise_g, 5e-3)
+    spread = max(abs(u - v) / abs(u) for a, b in zip(l0, l0b) for u, v in zip(a, b))
+    diff = max(abs(u - v) / abs(u) for a, b in zip(l0, l1) for u, v in zip(a, b))
+    print("losses: run-to-run spread without the reuse", spread, "; with the reuse", diff)
+    # (three GAN iterations from random weights amplify that spread chaotically: this is a sanity bound; the exact statement — same effective weights, bit-identical
+    # feature maps — is test_reused_discriminator_weights_equal_the_recomputed_ones)
+    assert diff <= max(5 * spread, 3e-2), (l0, l0b, l1)
+    d2, g2, l2, s2 = run(True, reload_at=1)
+    assert s2 == [False, False, False, False, True, False], s2                                 # the load before iteration 2 drops the promise
+
+
+def test_reused_discriminator_weights_equal_the_recomputed_ones():
+    """engine level: a forward that keeps the promise (same token, buffer, version, workspace) gives the losses of a forward that recomputes the weights; a torch
+    write to the parameter buffer drops it."""
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    st = HifiganStep("cuda", "bf16")
+    st.load_state_dicts(ohg.init_generator_sd(11), ohg.init_mpd_sd(12), ohg.init_msd_sd(13))
+    x, y, ym = ohg.synth_batch(2, 4324)
+    yg = st.eng.generator_forward(st.flat_g, x.cuda())
+    fmaps = lambda: [st.eng.slot("mpd", d, i).float().clone() for d in range(5) for i in range(1, 7)]   # the period discriminators' stored feature maps
+    a = st.eng.disc_forward(st.flat_d, y.cuda(), yg, losses="all", weights_token=7).clone()
+    assert st.eng._d_eff_key is not None
+    k = st.eng._d_eff_key
+    b = st.eng.disc_forward(st.flat_d, y.cuda(), yg, losses="all", weights_token=7).clone()          # reuses
+    fb = fmaps()
+    assert st.eng._d_eff_key == k
+    c = st.eng.disc_forward(st.flat_d, y.cuda(), yg, losses="all").clone()                           # recomputes
+    fc = fmaps()
+    assert st.eng._d_eff_key is None
+    for u, v in zip(fb, fc):
+        assert torch.equal(u, v)                                                                    # same effective weights: bit-identical activations
+    # (the spectral-norm discriminator advances its power iteration every pass: the summed losses move by its convergence, the same in both orders)
+    assert _nrel(b[:3], a[:3]) < 5e-2 and _nrel(c[:3], b[:3]) < 5e-2
+    st.flat_d[:8].mul_(1.0)                                                                         # a torch write: version counter moves
+    st.eng.disc_forward(st.flat_d, y.cuda(), yg, losses="all", weights_token=7)
+    assert st.eng._d_eff_key != k
+
+
+def test_discriminator_forward_on_the_stream_lanes_is_reproducible_and_conv0_matches_the_host():
+    """Six forwards of all eight discriminators on the default four stream lanes: every stored feature map of the five period discriminators and of the two
+    weight-normalised scale discriminators is bit-identical from run to run (the spectral-norm one advances its power iteration every pass), and the first layers
+    equal a host restatement of DiscriminatorP's conv0 (models.py:154-163) on bf16-rounded operands.  Round 5 found the packed-fp32 form of the direct conv0
+    kernel giving a few wrong even channels per run here — on the side lanes only, never alone (tools/hg_conv0_repro.py) — which end-to-end tolerances did not see."""
+    import torch.nn.functional as F
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    st = HifiganStep("cuda", "bf16")
+    mpd_sd = ohg.init_mpd_sd(12)
+    st.load_state_dicts(ohg.init_generator_sd(11), mpd_sd, ohg.init_msd_sd(13))
+    x, y, ym = ohg.synth_batch(2, 4324)
+    yg = st.eng.generator_forward(st.flat_g, x.cuda())
+    yr = y.cuda()
+    periods = [2, 3, 5, 7, 11]
+
+    def host_conv0(d, wavs):
+        p = periods[d]
+        pre = "discriminators.%d.convs.0." % d
+        w, b = ohg.wn_weight(mpd_sd, pre).float(), mpd_sd[pre + "bias"].float()
+        n, T = wavs.shape
+        xx = wavs.cpu().float()
+        if T % p:
+            xx = F.pad(xx.unsqueeze(1), (0, p - T % p), "reflect").squeeze(1)
+        o = F.leaky_relu(F.conv2d(ohg.bf16r(xx.view(n, 1, -1, p)).float(), ohg.bf16r(w).float(), b, stride=(3, 1), padding=(2, 0)), 0.1)
+        return o.permute(0, 3, 2, 1).reshape(n * p, o.size(2), 32)        # the engine's item order: (clip, phase)
+
+    refs = [torch.cat([host_conv0(d, yr), host_conv0(d, yg)], 0) for d in range(5)]
+    first = None
+    for run in range(6):
+        st.eng.disc_forward(st.flat_d, yr, yg, losses="all")
+        torch.cuda.synchronize()
+        maps = [st.eng.slot("mpd", d, i).float().cpu() for d in range(5) for i in range(1, 7)] + \
+               [st.eng.slot("msd", sc, 0, i).float().cpu() for sc in (1, 2) for i in range(1, 8)]
+        for d in range(5):
+            got, ref = maps[d * 6], refs[d]
+            assert float((got - ref).abs().max()) < 0.02 * float(ref.abs().max()), (run, d)       # a wrong tap moved elements by 5 ... 30 % of the range
+            assert _nrel(got, ref) < 3e-3, (run, d, _nrel(got, ref))
+        if first is None:
+            first = maps
+        else:
+            for k, (a, b) in enumerate(zip(maps, first)):
+                assert torch.equal(a, b), (run, k)

@@ -151,6 +151,68 @@ __global__ __launch_bounds__(256) void hg_cin1_fwd8_kernel(const float* __restri
         hg_st8(out, ((int64_t)seq * g.Hp + g.padF + h) * g.Cout + cg * 8, dt, v);
     }
 }
+// bf16 mode, Cout = 128, k <= 16 (DiscriminatorS conv0, models.py:207): the same forward on the matrix pipe WITHOUT an im2col in memory.  The v_pk_fma form above
+// is bound by VALU issue at this width (60 packed FMAs + 15 LDS reads per lane and 4 rows: 140 us per launch = 0.55 TB/s of stores); here a wave takes 16 rows at a
+// time: the lane's 4 consecutive taps of its row come straight from the staged waveform (LDS, already rounded to bf16: the operands of the GEMM form), eight
+// v_mfma_f32_16x16x16_bf16 (taps padded 15 -> 16 with a zero weight) give the 128 channels, and the weight rows are PERMUTED over the eight tiles so that a lane ends
+// up with 4 x 8 consecutive channels of its row: four 16-byte stores, 64 contiguous bytes per row and instruction.  Products are the GEMM form's (bf16 x bf16 exact in
+// fp32), the summation order is the matrix pipe's.
+typedef short hg_s4 __attribute__((ext_vector_type(4)));
+typedef float hg_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ short hg_bf16_bits(float v) { return (short)(__float_as_uint(hg_round_bf16(v)) >> 16); }
+constexpr int CIN1_MFMA_ROWS = 512;      // rows per workgroup (4 waves x 8 blocks of 16 rows)
+template <int NT>                        // Cout = 16 NT: 8 tiles (DiscriminatorS, 128 channels) or 2 (DiscriminatorP, 32 channels; k = 5: 11 zero taps — the matrix pipe is idle anyway)
+__global__ __launch_bounds__(256) void hg_cin1_fwd_mfma_kernel(const float* __restrict__ wav, const float* __restrict__ W, const float* __restrict__ bias,
+                                                               uint16_t* __restrict__ out, Cin1Geom g, float slope) {
+    constexpr int COUT = 16 * NT, NQ = NT / 2;                      // NQ 16-byte pieces per lane and row
+    extern __shared__ float sx[];                                   // samples s * h0 - P ... of this block's rows (+ 16 of slack: the zero-weight taps)
+    const int seq = blockIdx.y, b = seq / g.p, wf = seq % g.p;
+    const int h0 = blockIdx.x * CIN1_MFMA_ROWS;
+    const int nsmp = g.s * (CIN1_MFMA_ROWS - 1) + 16;
+    for (int i = threadIdx.x; i < nsmp; i += 256) sx[i] = hg_round_bf16(cin1_sample(wav, g, b, wf, g.s * h0 - g.P + i));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, gq = lane >> 4, k0 = gq * 4;
+    // tile j = 2 q + hh holds, as its row m = 4 gg + i, channel q * 32 + gg * 8 + hh * 4 + i: the lane with lane >> 4 == gg then owns channels q * 32 + gg * 8 .. + 7 of its row
+    hg_s4 wfr[NT];
+    float bs[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int q = j >> 1, hh = j & 1;
+        const int co = q * 32 + (m >> 2) * 8 + hh * 4 + (m & 3);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wfr[j][t] = (k0 + t < g.k) ? hg_bf16_bits(W[(int64_t)co * g.k + k0 + t]) : (short)0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bs[j][i] = bias[q * 32 + gq * 8 + hh * 4 + i];
+    }
+    __syncthreads();
+    for (int blk = wave; blk < CIN1_MFMA_ROWS / 16; blk += 4) {
+        const int n = blk * 16 + m, h = h0 + n;
+        if (h0 + blk * 16 >= g.Tout) break;
+        const float* xs = sx + g.s * n + k0;
+        hg_s4 xf;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xf[t] = (short)(__float_as_uint(xs[t]) >> 16);
+        hg_f4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wfr[j], xf, (hg_f4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (h < g.Tout) {
+            uint16_t* dst = out + ((int64_t)seq * g.Hp + g.padF + h) * COUT + gq * 8;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                uint32_t pk[4];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int j = 2 * q + hh;
+                    const float v0 = hg_lrelu(acc[j][0] + bs[j][0], slope), v1 = hg_lrelu(acc[j][1] + bs[j][1], slope);
+                    const float v2 = hg_lrelu(acc[j][2] + bs[j][2], slope), v3 = hg_lrelu(acc[j][3] + bs[j][3], slope);
+                    pk[2 * hh] = (__float_as_uint(hg_round_bf16(v0)) >> 16) | (__float_as_uint(hg_round_bf16(v1)) & 0xffff0000u);
+                    pk[2 * hh + 1] = (__float_as_uint(hg_round_bf16(v2)) >> 16) | (__float_as_uint(hg_round_bf16(v3)) & 0xffff0000u);
+                }
+                *reinterpret_cast<uint4*>(dst + q * 32) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+        }
+    }
+}
 // dW[co][j] += sum dY[seq][h][co] * x(seq, s*h + j - P) ; db[co] += sum dY   (dY = gradient w.r.t. the pre-activation)
 __global__ void hg_cin1_bwd_weight_kernel(const float* __restrict__ wav, const void* __restrict__ dY, int dt, float* __restrict__ dW,
                                           float* __restrict__ db, Cin1Geom g) {
@@ -208,7 +270,19 @@ extern "C" int xva_hg_cin1_fwd(const float* wav, const float* W, const float* bi
     Cin1Geom g;
     XVA_TRY(cin1_geom(&g, nb, Tw, p, k, s, P, Cout, Hp, padF));
     XVA_CHECK_ARG(wav && W && bias && out, "cin1_fwd: null");
-    if (Cout % 8 == 0 && 256 % (Cout / 8) == 0 && (k == 5 || k == 15) && (((uintptr_t)out) % 16) == 0 && ((int64_t)Hp * Cout) % 8 == 0) {
+    static const int mfma0 = [] { const char* e = getenv("XVA_HG_CONV0_MFMA"); return e ? atoi(e) : 1; }();     // 0: the v_pk_fma form (A/B)
+    if (mfma0 && dt == XVA_BF16 && (Cout == 128 || Cout == 32) && k <= 16 && (((uintptr_t)out) % 16) == 0 && ((int64_t)Hp * Cout) % 8 == 0) {
+        const size_t lds = (size_t)(s * (CIN1_MFMA_ROWS - 1) + 16) * sizeof(float);
+        const dim3 grid(xva_cdiv(g.Tout, CIN1_MFMA_ROWS), nb * p);
+        if (Cout == 128) hipLaunchKernelGGL(hg_cin1_fwd_mfma_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, wav, W, bias, (uint16_t*)out, g, slope);
+        else hipLaunchKernelGGL(hg_cin1_fwd_mfma_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, wav, W, bias, (uint16_t*)out, g, slope);
+        XVA_LAUNCH_CHECK();
+        return XVA_OK;
+    }
+    // the packed-fp32 form: OFF by default — inside the discriminator pass (four stream lanes) it gave sporadically wrong even channels for a few lanes of one
+    // instruction, on the side lanes only; bit-identical alone, on one stream and under tools/hg_conv0_repro.py's load.  XVA_HG_CONV0_PKFMA=1 brings it back for that hunt.
+    static const int pkfma = [] { const char* e = getenv("XVA_HG_CONV0_PKFMA"); return e ? atoi(e) : 0; }();
+    if (pkfma && Cout % 8 == 0 && 256 % (Cout / 8) == 0 && (k == 5 || k == 15) && (((uintptr_t)out) % 16) == 0 && ((int64_t)Hp * Cout) % 8 == 0) {
         constexpr int RPT = 16;
         const int rows_blk = 256 / (Cout / 8) * RPT;
         const size_t lds = (size_t)(s * (rows_blk - 1) + k) * sizeof(float);

@@ -864,8 +864,12 @@ int conv0_fwd(Ctx& c, const float* Pd, const DiscRun& r, int i0, int ni) {
 // conv0 straight from the waveform (hg_ops.hip hg_cin1_fwd8_kernel): no im2col launch, no K = 8 / 16 product.  XVA_HG_CONV0_DIRECT=0 keeps the GEMM form
 // (the im2col of the waveform is then made here; with the direct form the D-step backward makes it, for the weight gradient — once per iteration, not twice)
 static const int g_conv0_direct = [] { const char* e = getenv("XVA_HG_CONV0_DIRECT"); return e ? atoi(e) : 1; }();
+// bf16 mode only (hg_cin1_fwd_mfma_kernel).  The fp32 form of the direct kernel (hg_cin1_fwd8_kernel: packed-fp32 FMAs) gave sporadically wrong EVEN channels for a
+// few lanes of one instruction when it ran next to the other lanes' kernels (tools/hg_conv0_repro.py: bit-identical alone and on one stream): the exact-fp32 parity mode
+// keeps the GEMM form, and so does anything the matrix-pipe kernel does not take.
+static bool conv0_direct(const Ctx& c) { return g_conv0_direct && c.dt == XVA_BF16; }
 int conv0_any(Ctx& c, const float* Pd, const DiscRun& r, const float* wav, int i0, int ni) {
-    if (!g_conv0_direct) { XVA_TRY(conv0_im2col(c, r, wav, i0, ni)); return conv0_fwd(c, Pd, r, i0, ni); }
+    if (!conv0_direct(c)) { XVA_TRY(conv0_im2col(c, r, wav, i0, ni)); return conv0_fwd(c, Pd, r, i0, ni); }
     const Layer& l0 = c.pl.dl[r.li[0]];
     Seq t1 = c.S(r.t[1]).slice(i0, ni);
     return xva_hg_cin1_fwd(wav, eff32(c, l0, r.pass), Pd + l0.bias, t1.ptr(), c.dt, ni / r.p, r.Tw, r.p, l0.k, l0.s, l0.P, l0.Cout, t1.Hp(), t1.padF, SLOPE, c.st);
@@ -941,7 +945,7 @@ int disc_backward_params(Ctx& c, const float* Pd, float* Gd, const DiscRun& r, i
     }
     const Layer& l0 = L[r.li[0]];
     Seq d1 = c.S(r.d[1]).slice(i0, ni), xc = c.S(r.xc[0]).slice(i0, ni);
-    if (g_conv0_direct) {   // the weight gradient's operand: the im2col of the waveform(s) feeding this slice (the GEMM form's forward leaves it in xc)
+    if (conv0_direct(c)) {   // the weight gradient's operand: the im2col of the waveform(s) feeding this slice (the GEMM form's forward leaves it in xc)
         XVA_TRY(conv0_im2col(c, r, wav_a, i0, nb_a * r.p));
         if (wav_b) XVA_TRY(conv0_im2col(c, r, wav_b, i0 + nb_a * r.p, ni - nb_a * r.p));
     }
@@ -1046,7 +1050,9 @@ int pool_waves(Ctx& c, const float* yr, const float* yg) {
 
 // forward of all 8 discriminators on (real, fake); losses[0..2] = {disc loss, gen loss, feature loss}
 int discs_forward(Ctx& c0, float* Pd, const float* yr, const float* yg, float* losses, int loss_mask) {
-    XVA_TRY(prep_wn(c0, c0.pl.dl, Pd));
+    // bit 2 of loss_mask: the caller vouches that the effective weights in this workspace belong to these parameters (the D-step forward of iteration
+    // i + 1 runs on the parameters the G-step forward of iteration i prepared: 70 M parameters re-read and 140 MB re-written for nothing otherwise)
+    if (!(loss_mask & 4)) XVA_TRY(prep_wn(c0, c0.pl.dl, Pd));
     if (!c0.pl.dnetp->vits) XVA_TRY(pool_waves(c0, yr, yg));
     std::vector<DiscSet> sets; std::vector<DiscRun> snr;
     std::vector<xva_red_desc> reds[MAXL];      // per lane: a lane's loss reductions run on that lane as soon as its discriminators are through,
@@ -1070,7 +1076,7 @@ int discs_forward(Ctx& c0, float* Pd, const float* yr, const float* yg, float* l
         } else {
             // im2col per half (different waveforms), then every layer jointly over real + fake
             const auto& L = c.pl.dl;
-            if (g_conv0_direct) {
+            if (conv0_direct(c)) {
                 XVA_TRY(conv0_any(c, Pd, s.run, s.wr, 0, s.nf));
                 XVA_TRY(conv0_any(c, Pd, s.run, s.wg, s.nf, s.nf));
             } else {

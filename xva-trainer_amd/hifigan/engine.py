@@ -154,13 +154,19 @@ lib.xva_hg_disc_backward_g.restype = i32
 lib.xva_hg_disc_backward_g.argtypes = [C.POINTER(HgDims), vp, vp, vp, vp, vp, i64, vp]
 
 
-def _disc_forward(self, flat_d, y_real, y_fake, losses="all"):
+def _disc_forward(self, flat_d, y_real, y_fake, losses="all", weights_token=None):
     """MPD + MSD on (real, fake) (B, seg) fp32.  Returns a 4-float device tensor {loss_disc, loss_gen, loss_fm, -}.
-    losses: "all", "d" (discriminator loss only: the D step) or "g" (generator + feature-matching losses: the G step)."""
+    losses: "all", "d" (discriminator loss only: the D step) or "g" (generator + feature-matching losses: the G step).
+    weights_token: anything that changes whenever the caller's optimizer / checkpoint loader writes flat_d (None: no promise).  When it — and the buffer, its
+    torch version counter and the workspace — are those of the previous forward, the weight reparametrisation pass is skipped (xva_hg_disc_forward_ex bit 2)."""
     _lib.require_cuda(flat_d, y_real, y_fake)
     d = self._prepare(y_real.size(0), y_real.size(1))
     self._yr, self._yg = y_real.float().contiguous(), y_fake.float().contiguous()
     mask = {"all": 3, "d": 1, "g": 2}[losses]
+    key = None if weights_token is None else (weights_token, flat_d.data_ptr(), flat_d._version, self._ws.data_ptr(), self._key)
+    if key is not None and key == getattr(self, "_d_eff_key", None):
+        mask |= 4
+    self._d_eff_key = key
     out = torch.zeros(4, device=self.device)
     _lib.check(lib.xva_hg_disc_forward_ex(C.byref(d), _lib.ptr(flat_d), _lib.ptr(self._yr), _lib.ptr(self._yg), _lib.ptr(self._ws), self._ws.numel(),
                                           _lib.ptr(out), mask, _lib.stream_ptr()), "xva_hg_disc_forward_ex")

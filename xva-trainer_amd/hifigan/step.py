@@ -179,6 +179,7 @@ class HifiganStep:
 
     # ---- checkpoint tensors (python/hifigan/xva_train.py:570-601: {'generator': sd}, {'mpd': sd, 'msd': sd, ...}) ----
     def load_state_dicts(self, generator=None, mpd=None, msd=None):
+        self._loads = getattr(self, "_loads", 0) + 1
         if generator is not None:
             E.to_flat(generator, self.eng.table[E.G], self.flat_g)
         if mpd is not None:
@@ -190,13 +191,17 @@ class HifiganStep:
         return {"generator": E.from_flat(self.flat_g, self.eng.table[E.G]), "mpd": E.from_flat(self.flat_d, self.eng.table[E.D], "mpd."),
                 "msd": E.from_flat(self.flat_d, self.eng.table[E.D], "msd.")}
 
+    def _d_token(self):
+        return (self.optim_d.step_count, getattr(self, "_loads", 0))
+
     def train_step(self, x_mel, y_wav, y_mel):
         """x_mel (B, 80, T) input mel (fmax 8000), y_wav (B, T*256) target audio, y_mel (B, 80, T) loss mel (fmax None).
         Returns device tensors: dict(loss_disc_all, loss_gen_all, loss_mel, loss_fm, loss_gen, y_g_hat)."""
         eng = self.eng
         y_g_hat = eng.generator_forward(self.flat_g, x_mel)
         # ---- discriminator step
-        ld = eng.disc_forward(self.flat_d, y_wav, y_g_hat, losses="d")
+        # (the D step's forward runs on the parameters the previous iteration's G-step forward prepared: the token tells the engine nothing wrote them since)
+        ld = eng.disc_forward(self.flat_d, y_wav, y_g_hat, losses="d", weights_token=self._d_token())
         self.grads_d.zero_()
         if self.sync_d:
             self.sync_d.begin()
@@ -205,7 +210,7 @@ class HifiganStep:
             self.sync_d.reduce()
         self.optim_d.step(self.grads_d)
         # ---- generator step (updated discriminators)
-        lg = eng.disc_forward(self.flat_d, y_wav, y_g_hat, losses="g")
+        lg = eng.disc_forward(self.flat_d, y_wav, y_g_hat, losses="g", weights_token=self._d_token())
         d_wav = eng.disc_backward_g(self.flat_d)
         loss_mel, _ = pmel.mel_l1_loss_backward(y_g_hat, y_mel, d_wav, scale=45.0, accumulate=True)
         self.grads_g.zero_()
