@@ -66,3 +66,6 @@ cp $O/${RD}_*_pmc_hbm_bytes.csv $O/${RD}_*_pmc_hbm_bytes.meta.json $O/${RD}_fast
 cd $R && XVA_BENCH_C5_INPROCESS=0 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/${RD}_final_bench.json
 cp $R/bench_detail.json $O/${RD}_final_bench_detail.json   # the tables / notes behind the compact line
 ls -la $O
+# the fused ResBlock pair against the two launches (time, per-kernel, PMC traffic) and the run-to-run reproducibility of the three engines on their stream lanes
+bash $R/tools/pair_ab.sh; cp $R/gpurun_out/pair_ab.txt $O/${RD}_resblock_pair_ab_raw.txt
+python $R/tools/determinism_sweep.py 5 2>/dev/null | grep -v amdgpu.ids > $O/${RD}_determinism_sweep_raw.txt
