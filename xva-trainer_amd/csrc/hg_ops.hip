@@ -895,6 +895,19 @@ __device__ __forceinline__ void hg_weight_norm_fwd_body(const float* __restrict_
     float n = sqrtf(acc);
     if (threadIdx.x == 0) norm[o] = n;
     float sc = gparam ? gparam[o] / n : 1.f;          // gparam == null: a plain (not reparametrised) weight, re-laid out only
+    if (kind == 0 && dt == XVA_BF16 && (D1 & 7) == 0 && ((uintptr_t)eff & 15) == 0) {
+        // Conv weights in WRITE order: a thread owns 8 consecutive input channels of one tap = one 16-byte store; its 8 reads walk the row with stride k (the row
+        // was read for the norm a moment ago: L1 / L2).  The read-order loop below scatters 2-byte stores D1 elements apart: 0.8 TB/s on the 1024-channel layers.
+        uint16_t* eo = reinterpret_cast<uint16_t*>(eff) + (int64_t)o * inner;
+        for (int c = threadIdx.x; c < inner / 8; c += blockDim.x) {
+            const int t = c * 8, j = t / D1, i1 = t - j * D1;
+            uint32_t pk[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = hg_pack2(vo[(int64_t)(i1 + 2 * e) * k + j] * sc, vo[(int64_t)(i1 + 2 * e + 1) * k + j] * sc);
+            *reinterpret_cast<uint4*>(eo + t) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < inner; idx += blockDim.x) {
         int i1 = idx / k, j = idx % k;
         float w = vo[idx] * sc;
