@@ -33,7 +33,9 @@ def report(name, runs):
 
 
 # ---- FastPitch, every compute mode
-for compute in ("bf16", "fp32"):
+from xva_trainer_amd import _lib
+for compute, products in (("bf16", 0), ("fp32", 0), ("fp32", 1)):          # products 1: fp32 storage, split-bf16 products on planes (the mode that meets 1e-3 at speed)
+    old_products = _lib.lib.xva_gemm_set_fp32_products(products)
     eng = E.FastPitchEngine(dev, compute, p_dropout=0.1, seed=1234)
     flat = torch.zeros(eng.total, device=dev)
     P.default_init_(flat, eng.table, seed=1234)
@@ -50,7 +52,8 @@ for compute in ("bf16", "fp32"):
         for name, off, numel, shape in [(t[0], t[1], t[2], t[3]) for t in eng.table][:400]:
             d["grad:" + name] = grads[off:off + numel].clone()
         runs.append(d)
-    report("FastPitch %s step (B = 32 x 150 x 860, stage 3, dropout 0.1)" % compute, runs)
+    report("FastPitch %s%s step (B = 32 x 150 x 860, stage 3, dropout 0.1)" % (compute, " + split-bf16 products" if products else ""), runs)
+    _lib.lib.xva_gemm_set_fp32_products(old_products)
     del eng, flat, batch, runs
     torch.cuda.empty_cache()
 
@@ -58,46 +61,48 @@ for compute in ("bf16", "fp32"):
 from xva_trainer_amd.hifigan.step import HifiganStep
 from xva_trainer_amd.hifigan import engine as HE
 from xva_trainer_amd import mel as pmel
-st = HifiganStep(dev, "bf16")
-bench.init_hifigan_weights(st)
-x, y, y_mel = bench.hifigan_inputs(64, 0, dev)
-eng = st.eng
-runs = []
-pd0 = st.flat_d.clone()
-for r in range(R):
-    st.flat_d.copy_(pd0)                                    # the spectral-norm buffers advance every pass: start every run from the same ones
-    d = {}
-    yg = eng.generator_forward(st.flat_g, x)
-    d["waveform"] = yg.clone()
-    for rb in range(12):
-        for m in range(3):
-            d["xt1.%d.%d" % (rb, m)] = HE._slot(eng, "xt1", rb, m).float().clone()
-    for i in range(4):
-        d["xs.%d" % i] = HE._slot(eng, "xs", i).float().clone()
-    ld = eng.disc_forward(st.flat_d, y, yg, losses="d")
-    for dd in range(5):
-        for i in range(1, 7):
-            d["mpd.%d.%d" % (dd, i)] = HE._slot(eng, "mpd", dd, i).float().clone()
-    for sc in range(3):
-        for i in range(1, 8):
-            d["msd.%d.%d" % (sc, i)] = HE._slot(eng, "msd", sc, 0, i).float().clone()
-    gd = torch.zeros_like(st.flat_d)
-    eng.disc_backward_d(st.flat_d, gd)
-    d["loss_d"] = ld.clone(); d["grads_d"] = gd.clone()
-    lg = eng.disc_forward(st.flat_d, y, yg, losses="g")
-    dw = eng.disc_backward_g(st.flat_d)
-    d["d_wav (G step)"] = dw.clone(); d["loss_g"] = lg.clone()
-    pmel.mel_l1_loss_backward(yg, y_mel, dw, scale=45.0, accumulate=True)
-    gg = torch.zeros_like(st.flat_g)
-    eng.generator_backward(st.flat_g, gg, dw)
-    d["grads_g"] = gg.clone()
-    torch.cuda.synchronize()
-    runs.append(d)
-report("HiFi-GAN D + G passes (B = 64 x 8192, bf16)", runs)
+for hg_mode, hg_B in (("bf16", 64), ("fp32", 16)):
+    st = HifiganStep(dev, hg_mode)
+    bench.init_hifigan_weights(st)
+    x, y, y_mel = bench.hifigan_inputs(hg_B, 0, dev)
+    eng = st.eng
+    runs = []
+    pd0 = st.flat_d.clone()
+    for r in range(R):
+        st.flat_d.copy_(pd0)                                    # the spectral-norm buffers advance every pass: start every run from the same ones
+        d = {}
+        yg = eng.generator_forward(st.flat_g, x)
+        d["waveform"] = yg.clone()
+        for rb in range(12):
+            for m in range(3):
+                d["xt1.%d.%d" % (rb, m)] = HE._slot(eng, "xt1", rb, m).float().clone()
+        for i in range(4):
+            d["xs.%d" % i] = HE._slot(eng, "xs", i).float().clone()
+        ld = eng.disc_forward(st.flat_d, y, yg, losses="d")
+        for dd in range(5):
+            for i in range(1, 7):
+                d["mpd.%d.%d" % (dd, i)] = HE._slot(eng, "mpd", dd, i).float().clone()
+        for sc in range(3):
+            for i in range(1, 8):
+                d["msd.%d.%d" % (sc, i)] = HE._slot(eng, "msd", sc, 0, i).float().clone()
+        gd = torch.zeros_like(st.flat_d)
+        eng.disc_backward_d(st.flat_d, gd)
+        d["loss_d"] = ld.clone(); d["grads_d"] = gd.clone()
+        lg = eng.disc_forward(st.flat_d, y, yg, losses="g")
+        dw = eng.disc_backward_g(st.flat_d)
+        d["d_wav (G step)"] = dw.clone(); d["loss_g"] = lg.clone()
+        pmel.mel_l1_loss_backward(yg, y_mel, dw, scale=45.0, accumulate=True)
+        gg = torch.zeros_like(st.flat_g)
+        eng.generator_backward(st.flat_g, gg, dw)
+        d["grads_g"] = gg.clone()
+        torch.cuda.synchronize()
+        runs.append(d)
+    report("HiFi-GAN D + G passes (B = %d x 8192, %s)" % (hg_B, hg_mode), runs)
+    del st, eng, runs
+    torch.cuda.empty_cache()
+
 
 # ---- xVAPitch C5 iteration on its five streams (the benchmarked schedule: eager_disc, late_join), fixed random draws
-del st, eng, runs
-torch.cuda.empty_cache()
 from xva_trainer_amd.xvapitch.acoustic import AcousticTrainPath
 from xva_trainer_amd.xvapitch.decoder import VitsDecoder
 from xva_trainer_amd.xvapitch.discriminator import VitsDiscriminator
