@@ -440,6 +440,8 @@ def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
             key = "xva_conv_res_kernel<CIN=%d>" % (int(r["bn"]) - 900000)
         elif int(r["bn"]) >= 800000:
             key = "xva_wgrad_res_kernel<CIN=%d>" % (int(r["bn"]) - 800000)
+        elif int(r["bn"]) >= 700000:
+            key = "xva_conv_pair_kernel<C=%d>" % (int(r["bn"]) - 700000)
         else:
             key = ("xva_gemm_glds_kernel<%s>" % TILE_NAMES.get(r["bn"], r["bn"])) if glds else ("xva_gemm_kernel<BN=%s>" % r["bn"])
         f = fam[key]

@@ -222,6 +222,12 @@ static int launch_pair(const xva_gemm_params& p, const xva_conv_pair& e, hipStre
 
 }  // namespace xva_glds
 
+// per-launch profiling records of the GEMM entry point (core.hip): the pair registers itself with the algorithmic work of BOTH convolutions
+bool xva_prof_is_on();
+void xva_prof_begin(hipStream_t st, double flops, int variant);
+void xva_prof_end(hipStream_t st);
+void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn, double bytes);
+
 int xva_conv_pair_fwd(const xva_gemm_params* conv2, const xva_conv_pair* conv1, void* stream) {
     const xva_gemm_params& p = *conv2;
     const xva_conv_pair& e = *conv1;
@@ -240,5 +246,16 @@ int xva_conv_pair_fwd(const xva_gemm_params* conv2, const xva_conv_pair* conv1, 
     if (e.x_raw == 1 && (p.R || p.alpha != p.beta)) return -1;
     if (p.M < 1 || p.batch < 1) return -1;
     hipStream_t st = (hipStream_t)stream;
-    return C == 32 ? xva_glds::launch_pair<32>(p, e, st) : xva_glds::launch_pair<64>(p, e, st);
+    const bool prof = xva_prof_is_on();
+    if (prof) {
+        // algorithmic work: both products (no halo rows); bytes: the input once, both weights, the intermediate and the output written once (read too when
+        // accumulating), the residual when it comes from HBM — the intermediate is NOT re-read (tag 700000 + C; variant NT / bf16)
+        const double rows = (double)p.M * p.batch, Kt = (double)(e.k1 + k2) * C;
+        xva_prof_begin(st, 2.0 * rows * C * Kt, XVA_GEMM_NT * 3 + 1);
+        double by = rows * C * 2.0 * (3.0 + (p.accumulate ? 1.0 : 0.0) + (p.R ? 1.0 : 0.0)) + Kt * C * 2.0;
+        xva_prof_shape(p.M, C, (int)Kt, p.batch, 1, 700000 + C, by);
+    }
+    const int rc = C == 32 ? xva_glds::launch_pair<32>(p, e, st) : xva_glds::launch_pair<64>(p, e, st);
+    if (prof) xva_prof_end(st);
+    return rc;
 }
