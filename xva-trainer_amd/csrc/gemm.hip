@@ -140,7 +140,10 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (can_split) {   // 256x256 tiles: at most one round of 256 workgroups; smaller tiles (2-3 per CU): ~1.7 rounds; >= 8 K tiles per split
             const long tiles = ntiles(glds_tile);
             // small tiles are latency-bound per K tile (one DMA stage in flight): fill the chip with ~6 workgroups per CU
-            long sk = glds_tile == 1 ? 256 / tiles : ((glds_tile == 0 ? 864 : 1536) + tiles / 2) / tiles;
+            // XVA_GEMM_SK_FILL (per cent, default 100): scales the workgroup count a split aims at — inside the engines' stream lanes another lane's kernels fill what a
+            // product leaves idle, and every split less is a slab written, read and reduced less (A/B knob)
+            static const long fill = [] { const char* e = getenv("XVA_GEMM_SK_FILL"); long v = e ? atol(e) : 100L; return v < 10 ? 10L : v; }();
+            long sk = glds_tile == 1 ? (256 * fill / 100) / tiles : (((glds_tile == 0 ? 864 : 1536) * fill / 100) + tiles / 2) / tiles;
             if (sk > nkt / min_kt) sk = nkt / min_kt;
             if (sk > 1024) sk = 1024;
             if (p.sk_ws && p.N % 4 == 0) {   // stay inside the caller's slab scratch (atomics are much slower)
