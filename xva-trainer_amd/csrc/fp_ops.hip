@@ -273,9 +273,14 @@ __global__ void layernorm_fwd_kernel(const void* __restrict__ X, const float* __
 // 16 waves per workgroup and at most ~2 workgroups per CU: each gamma / beta address receives a few hundred atomics per launch
 // (one per workgroup) instead of one per 16 rows — same-address L2 atomics serialise.
 #define LNB_WAVES 16
+#ifndef XVA_LNB_ROWS
+#define XVA_LNB_ROWS 4        // rows in flight per wave in the FAST bf16 form (3: 128 VGPRs with 3 spills, 23.2 us; 4: 113 VGPRs, none)
+#endif
 // BF: bf16 operands (the throughput mode's transformer LayerNorms): the two rows in flight stay PACKED in registers (3 + 3 words per lane
 // instead of 6 + 6 floats), which is what lets a second prefetched row fit under 128 VGPRs without spilling
-template <int CPL, bool BF>
+// FAST: the transformer layers' common case fixed at compile time (no dropout on the incoming gradient, no ReLU gate, no pair output, no rank-1 dY): the generic
+// instantiation spilled 17 registers at its 128-VGPR budget (16 waves per workgroup); without the dead branches' live ranges the same loop keeps three rows in flight
+template <int CPL, bool BF, bool FAST>
 __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const void* __restrict__ dY, const void* __restrict__ X, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const float* __restrict__ gamma, void* __restrict__ dX,
                                      void* __restrict__ dXm, int dt, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const voi
             for (int h = 0; h < CPL / 2; ++h) {
                 a_st2(dX, row * C + 2 * lane + 128 * h, dt, 0.f, 0.f);
                 if (dXm) a_st2(dXm, row * C + 2 * lane + 128 * h, dt, 0.f, 0.f);
-                if (dXpair) st2_pair(dXpair, row * C + 2 * lane + 128 * h, pair_plane, 0.f, 0.f);
+                if (!FAST && dXpair) st2_pair(dXpair, row * C + 2 * lane + 128 * h, pair_plane, 0.f, 0.f);
             }
             return;
         }
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const voi
         for (int i = 0; i < CPL; ++i) {
             const int c = 2 * lane + 128 * (i >> 1) + (i & 1);
             float g = gval(cur, i);
-            if (p_in > 0.f) g *= xva_dropout_scale(p_in, seed_in, stream_in, (uint64_t)row * C + c);
+            if (!FAST && p_in > 0.f) g *= xva_dropout_scale(p_in, seed_in, stream_in, (uint64_t)row * C + c);
             xh[i] = (xval(cur, i) - mu) * rs;
             dh[i] = g * gm[i];
             s1 += dh[i];
@@ -362,18 +367,49 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const voi
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 v[e] = rs * (dh[2 * h + e] - s1 - xh[2 * h + e] * s2);
-                if (relu_gate && !(xval(cur, 2 * h + e) > 0.f)) v[e] = 0.f;
+                if (!FAST && relu_gate && !(xval(cur, 2 * h + e) > 0.f)) v[e] = 0.f;
             }
             a_st2(dX, row * C + c, dt, v[0], v[1]);
-            if (dXm || (dXpair && p_out > 0.f)) {
+            if (dXm || (!FAST && dXpair && p_out > 0.f)) {
                 v[0] *= xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c);
                 v[1] *= xva_dropout_scale(p_out, seed_out, stream_out, (uint64_t)row * C + c + 1);
             }
             if (dXm) a_st2(dXm, row * C + c, dt, v[0], v[1]);
-            if (dXpair) st2_pair(dXpair, row * C + c, pair_plane, v[0], v[1]);     // the gradient entering the dropout-ed branch (= dX without dropout)
+            if (!FAST && dXpair) st2_pair(dXpair, row * C + c, pair_plane, v[0], v[1]);     // the gradient entering the dropout-ed branch (= dX without dropout)
         }
     };
-    if constexpr (BF) {
+    if constexpr (BF && FAST) {
+#if XVA_LNB_ROWS == 4
+        RowIn ra, rb, rc, rd;
+        fetch(r0 + wave, ra);
+        fetch(r0 + wave + LNB_WAVES, rb);
+        fetch(r0 + wave + 2 * LNB_WAVES, rc);
+        fetch(r0 + wave + 3 * LNB_WAVES, rd);
+        for (int64_t row = r0 + wave; row < r1; row += 4 * LNB_WAVES) {
+            process(ra, row);
+            fetch(row + 4 * LNB_WAVES, ra);
+            if (row + LNB_WAVES < r1) process(rb, row + LNB_WAVES);
+            fetch(row + 5 * LNB_WAVES, rb);
+            if (row + 2 * LNB_WAVES < r1) process(rc, row + 2 * LNB_WAVES);
+            fetch(row + 6 * LNB_WAVES, rc);
+            if (row + 3 * LNB_WAVES < r1) process(rd, row + 3 * LNB_WAVES);
+            fetch(row + 7 * LNB_WAVES, rd);
+        }
+#else
+        RowIn ra, rb, rc;
+        fetch(r0 + wave, ra);
+        fetch(r0 + wave + LNB_WAVES, rb);
+        fetch(r0 + wave + 2 * LNB_WAVES, rc);
+        for (int64_t row = r0 + wave; row < r1; row += 3 * LNB_WAVES) {
+            process(ra, row);
+            fetch(row + 3 * LNB_WAVES, ra);
+            if (row + LNB_WAVES < r1) process(rb, row + LNB_WAVES);
+            fetch(row + 4 * LNB_WAVES, rb);
+            if (row + 2 * LNB_WAVES < r1) process(rc, row + 2 * LNB_WAVES);
+            fetch(row + 5 * LNB_WAVES, rc);
+        }
+#endif
+    } else if constexpr (BF) {
         RowIn ra, rb;
         fetch(r0 + wave, ra);
         fetch(r0 + wave + LNB_WAVES, rb);
@@ -396,6 +432,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const voi
 #pragma unroll
         for (int i = 0; i < CPL; ++i) { const int c = 2 * lane + 128 * (i >> 1) + (i & 1); sh_g[wave][c] = ag[i]; sh_b[wave][c] = ab[i]; }
         __syncthreads();
+        // (publishing the workgroups' column sums and letting the last of every 8 neighbours issue the atomics — 1 / 8 of them — was built and measured: 22.8 -> 21.7 us
+        // with agent-scope stores + counted waits, 114 us with a release fence, which writes the whole L2 back: not kept for 1 us)
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float g = 0.f, b = 0.f;
 #pragma unroll
@@ -544,10 +582,14 @@ static int layernorm_bwd_impl(const void* dY, const void* X, const float* mean, 
     rpb = (rpb + LNB_WAVES - 1) / LNB_WAVES * LNB_WAVES;
     dim3 grid(xva_cdiv(rows, rpb)), block(64 * LNB_WAVES);
     const bool bf = dt == XVA_BF16 && dY != nullptr && !outer_d;
-#define XVA_LNB(CPL, BFV) hipLaunchKernelGGL((layernorm_bwd_kernel<CPL, BFV>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma, \
+#define XVA_LNB(CPL, BFV) hipLaunchKernelGGL((layernorm_bwd_kernel<CPL, BFV, false>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma, \
                                              dbeta, rows, rpb, mask_mode, lens, Tp, relu_gate, p_in, seed_in, stream_in, p_out, seed_out, stream_out, outer_d, outer_w, \
                                              dxp, pair_plane)
-    if (C == 384) { if (bf) XVA_LNB(6, true); else XVA_LNB(6, false); }
+    static const int lnb_fast = [] { const char* e = getenv("XVA_FP_LNB_FAST"); return e ? atoi(e) : 1; }();     // 0: the generic kernel for every launch (A/B)
+    if (lnb_fast && C == 384 && bf && p_in <= 0.f && !relu_gate && !dxp) {
+        hipLaunchKernelGGL((layernorm_bwd_kernel<6, true, true>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma, dbeta, rows, rpb, mask_mode, lens,
+                           Tp, 0, 0.f, (uint64_t)0, 0u, p_out, seed_out, stream_out, (const float*)nullptr, (const float*)nullptr, (uint16_t*)nullptr, (int64_t)0);
+    } else if (C == 384) { if (bf) XVA_LNB(6, true); else XVA_LNB(6, false); }
     else { if (bf) XVA_LNB(4, true); else XVA_LNB(4, false); }
 #undef XVA_LNB
     XVA_LAUNCH_CHECK();
