@@ -4,10 +4,10 @@
  * Conv1d / ConvTranspose1d / Conv2d(k,1) / grouped Conv1d stacks of HiFi-GAN (python/hifigan/models.py:17-260)
  * in forward, backward-data and backward-weight form.
  *
- * Operands live in HBM as fp32 or bf16 (`a_dtype`, `b_dtype`, `c_dtype`; 0 = fp32, 1 = bf16), 16-byte aligned, leading
+ * Operands live in HBM as fp32, bf16 or IEEE half (`a_dtype`, `b_dtype`, `c_dtype`; 0 = fp32, 1 = bf16, 2 = fp16), 16-byte aligned, leading
  * dimensions in ELEMENTS and multiples of 4 (fp32) / 8 (bf16).  `compute` selects the matrix pipe:
  *   0 = exact fp32 (v_mfma_f32_16x16x4_f32; operands must be stored fp32) — the parity mode;
- *   1 = bf16 inputs, fp32 accumulation (v_mfma_f32_16x16x32_bf16; fp32-stored operands are rounded while staged);
+ *   1 = bf16 inputs, fp32 accumulation (v_mfma_f32_16x16x32_bf16; fp32-stored operands are rounded while staged); fp16-stored operands: v_mfma_f32_16x16x32_f16;
  *   2 = fp32-stored operands, every element split into hi + lo bf16 while staged and three bf16 MFMAs per product (~1e-5 relative per product:
  *       what xva_gemm_set_fp32_products(1) makes of compute 0, chosen per call).
  *
@@ -30,6 +30,10 @@ extern "C" {
 
 #define XVA_F32 0
 #define XVA_BF16 1
+#define XVA_F16 2  /* IEEE half (round 6): direct-to-LDS kernels only.  Wherever this header says "bf16 storage" a problem may use XVA_F16 instead — for ALL its
+                    * 16-bit tensors at once (A, B and whichever of C / R / G / F are not fp32): compute 1 then issues v_mfma_f32_16x16x32_f16 (the same rate, 11
+                    * mantissa bits instead of 8; the width the reference's own GPU path computes in under autocast, python/fastpitch1_1/xva_train.py:350,787).
+                    * No split planes (a pair of halves is pointless), no resident-operand weight-gradient kernel. */
 
 #define XVA_ACT_NONE 0
 #define XVA_ACT_RELU 1

@@ -40,32 +40,47 @@ N_SYMBOLS = 148
 #   gq(x)  the upstream gradient rounded on ITS way into the backward GEMMs of an fp32-stored tensor: backward only
 class _Round(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, fwd, bwd):
-        ctx.bwd = bwd
-        return x.to(torch.bfloat16).to(x.dtype) if fwd else x.clone()
+    def forward(ctx, x, fwd, bwd, dt=torch.bfloat16):
+        ctx.bwd, ctx.dt = bwd, dt
+        return x.to(dt).to(x.dtype) if fwd else x.clone()
 
     @staticmethod
     def backward(ctx, g):
-        return (g.to(torch.bfloat16).to(g.dtype) if ctx.bwd else g), None, None
+        return (g.to(ctx.dt).to(g.dtype) if ctx.bwd else g), None, None, None
 
 
 class Fp32Storage:
     name = "fp32"
-    s = q = gq = staticmethod(lambda x: x)
+    flash = False
+    resid32 = True
+    s = q = gq = r = o = staticmethod(lambda x: x)
 
 
-class Bf16Storage:
-    name = "bf16"
-    s = staticmethod(lambda x: _Round.apply(x, True, True))
-    q = staticmethod(lambda x: _Round.apply(x, True, False))
-    gq = staticmethod(lambda x: _Round.apply(x, False, True))
+def make_storage(name, dt, resid32=False):
+    """A 16-bit storage model.  s / q / gq as above, in dtype `dt` (bf16: 8 mantissa bits, the throughput mode; fp16: 11 bits, the width the
+    reference's own GPU path computes in under autocast — python/fastpitch1_1/xva_train.py:350,787).
+    resid32 = the RESIDUAL STREAM (embedding sums, o_net / FFN output + residual, LayerNorm inputs and outputs) stays fp32 and is rounded only
+    on its way into a product:  r(x) stores a residual-stream tensor (identity when resid32), o(x) reads one as a GEMM operand."""
+    s = staticmethod(lambda x: _Round.apply(x, True, True, dt))
+    q = staticmethod(lambda x: _Round.apply(x, True, False, dt))
+    gq = staticmethod(lambda x: _Round.apply(x, False, True, dt))
+    ident = staticmethod(lambda x: x)
+    return type(name, (), dict(name=name, flash=True, resid32=resid32, dtype=dt, s=s, q=q, gq=gq,
+                               r=ident if resid32 else s, o=q if resid32 else ident))
+
+
+Bf16Storage = make_storage("bf16", torch.bfloat16)
+F16Storage = make_storage("f16", torch.float16)
+Bf16Resid32Storage = make_storage("bf16_r32", torch.bfloat16, True)
+F16Resid32Storage = make_storage("f16_r32", torch.float16, True)
+_STORAGES = {"bf16": Bf16Storage, "f16": F16Storage, "bf16_r32": Bf16Resid32Storage, "f16_r32": F16Resid32Storage}
 
 
 def _storage(storage):
     if storage is None or storage == "fp32":
         return Fp32Storage
-    if storage == "bf16":
-        return Bf16Storage
+    if isinstance(storage, str):
+        return _STORAGES[storage]
     return storage
 
 
@@ -168,11 +183,11 @@ def _flash_pv(score, v, mult, st):
 
 
 def _mha(sd, pre, inp, key_pad_mask, drop=None, site=0, st=Fp32Storage):
-    qkv = st.s(F.linear(inp, st.q(sd[pre + "qkv_net.weight"]), sd[pre + "qkv_net.bias"]))
+    qkv = st.s(F.linear(st.o(inp), st.q(sd[pre + "qkv_net.weight"]), sd[pre + "qkv_net.bias"]))
     q, k, v = torch.chunk(qkv, 3, dim=2)
     score = st.gq(torch.bmm(q, k.transpose(1, 2)) * (1 / (D_HEAD ** 0.5)))   # dS is rounded on its way into the dQ / dK products
     score = score.masked_fill(key_pad_mask.unsqueeze(1), -float("inf"))
-    if st is Bf16Storage:                                     # the fused flash-style attention of the throughput mode
+    if st.flash:                                              # the fused flash-style attention of the throughput mode
         mult = drop.prob(site + 0, torch.ones_like(score)) if drop is not None else None
         vec = st.s(_flash_pv(score, v, mult, st))
     else:
@@ -183,18 +198,18 @@ def _mha(sd, pre, inp, key_pad_mask, drop=None, site=0, st=Fp32Storage):
     out = F.linear(vec, st.q(sd[pre + "o_net.weight"]))
     if drop is not None:
         out = drop.act(site + 1, out)                         # drop, transformer.py:139
-    return st.s(F.layer_norm(st.s(inp + out), (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"]))
+    return st.r(F.layer_norm(st.r(inp + out), (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"]))
 
 
 def _conv_ff(sd, pre, inp, drop=None, site=0, st=Fp32Storage):
-    core = inp.transpose(1, 2)
+    core = st.o(inp).transpose(1, 2)
     core = F.conv1d(core, st.q(sd[pre + "CoreNet.0.weight"]), sd[pre + "CoreNet.0.bias"], padding=1)
     core = st.s(F.relu(core))
     core = F.conv1d(core, st.q(sd[pre + "CoreNet.2.weight"]), sd[pre + "CoreNet.2.bias"], padding=1)
     core = core.transpose(1, 2)
     if drop is not None:
         core = drop.act(site + 2, core)                       # CoreNet's trailing nn.Dropout, transformer.py:51
-    return st.s(F.layer_norm(st.s(inp + core), (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"]))
+    return st.r(F.layer_norm(st.r(inp + core), (D_MODEL,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"]))
 
 
 def fft_transformer(sd, pre, dec_inp, seq_lens=None, embed=False, taps=None, drop=None, site=0, st=Fp32Storage):
@@ -205,7 +220,7 @@ def fft_transformer(sd, pre, dec_inp, seq_lens=None, embed=False, taps=None, dro
         inp = dec_inp
         mask = mask_from_lens(seq_lens, inp.size(1)).unsqueeze(2)
     pos = positional_embedding(inp.size(1), D_MODEL, inp.dtype) * mask
-    out = st.s(inp + pos)
+    out = st.r(inp + pos)
     if taps is not None:
         taps[pre + "in"] = out
     for i in range(N_LAYERS):
@@ -281,17 +296,17 @@ def forward(sd, batch, stage, taps=None, drop=None, storage=None):
     pitch_pred = temporal_predictor(sd, "pitch_predictor.", enc_out, enc_mask, drop, DS_PRED + 2, st).permute(0, 2, 1)
     pitch_tgt = average_pitch(batch["pitch"], dur_tgt)
     pitch_emb = F.conv1d(pitch_tgt, sd["pitch_emb.weight"], sd["pitch_emb.bias"], padding=1)
-    enc_out = st.s(enc_out + pitch_emb.transpose(1, 2))
+    enc_out = st.r(enc_out + pitch_emb.transpose(1, 2))
     energy_pred = temporal_predictor(sd, "energy_predictor.", enc_out, enc_mask, drop, DS_PRED + 4, st).squeeze(-1)
     energy_tgt = torch.log(1.0 + average_pitch(batch["energy"].unsqueeze(1), dur_tgt))
     energy_emb = F.conv1d(energy_tgt, sd["energy_emb.weight"], sd["energy_emb.bias"], padding=1)
     energy_tgt = energy_tgt.squeeze(1)
-    enc_out = st.s(enc_out + energy_emb.transpose(1, 2))
+    enc_out = st.r(enc_out + energy_emb.transpose(1, 2))
     if taps is not None:
         taps["enc_cond"] = enc_out
     len_regulated, dec_lens = regulate_len(dur_tgt, enc_out, 1.0, mel_max_len)
     dec_out, dec_mask = fft_transformer(sd, "decoder.", len_regulated, seq_lens=dec_lens, taps=taps, drop=drop, site=DS_DEC, st=st)
-    mel_out = st.s(F.linear(dec_out, st.q(sd["proj.weight"]), sd["proj.bias"]))
+    mel_out = st.r(F.linear(st.o(dec_out), st.q(sd["proj.weight"]), sd["proj.bias"]))
     return [mel_out, dec_mask, None, None, pitch_pred, pitch_tgt, energy_pred, energy_tgt, None, None, dur_tgt, None,
             batch["in_lens"]]
 

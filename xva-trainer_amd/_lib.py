@@ -133,6 +133,8 @@ def _dt(t):
         return 0
     if t.dtype == torch.bfloat16:
         return 1
+    if t.dtype == torch.float16:
+        return 2          # XVA_F16: direct-to-LDS kernels only (include/xva_gemm.h)
     raise XvaError("unsupported dtype %s" % t.dtype)
 
 

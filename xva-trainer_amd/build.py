@@ -30,11 +30,16 @@ def _headers_mtime():
     return m
 
 
+# translation units that #include another .hip (a second instantiation set of the same kernels)
+INCLUDES = {"gemm_glds_f16.hip": ["gemm_glds.hip"]}
+
+
 def _compile(src, verbose, force=False):
     obj = os.path.join(CSRC, "build", src[:-4] + ".o")
     os.makedirs(os.path.dirname(obj), exist_ok=True)
     spath = os.path.join(CSRC, src)
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), _headers_mtime()):
+    newest = max([os.path.getmtime(spath), _headers_mtime()] + [os.path.getmtime(os.path.join(CSRC, f)) for f in INCLUDES.get(src, [])])
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest:
         return obj, False
     cmd = ["hipcc"] + FLAGS + ["-I", INCLUDE, "-c", spath, "-o", obj]
     if verbose:

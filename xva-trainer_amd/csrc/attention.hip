@@ -64,19 +64,22 @@ struct Frag {
 };
 
 // two accumulator tiles (rows / keys 32t + g*4 + r and 32t + 16 + g*4 + r) -> one bf16 operand in the permuted k order
+// (F16: the 16-bit format of every tensor and MFMA operand of the kernel — false bf16, true IEEE half; gemm_glds.h)
+template <bool F16 = false>
 __device__ __forceinline__ bf16x8 pack_rows(f32x4 a, f32x4 b) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 v = {pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+    u32x4 v = {pack2<F16>(a[0], a[1]), pack2<F16>(a[2], a[3]), pack2<F16>(b[0], b[1]), pack2<F16>(b[2], b[3])};
     return __builtin_bit_cast(bf16x8, v);
 }
 __device__ __forceinline__ bf16x8 ld_frag(const uint16_t* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p)); }
+template <bool F16 = false>
 __device__ __forceinline__ void st4(uint16_t* dst, f32x4 v, float s) {
-    *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2(v[0] * s, v[1] * s), pack_bf2(v[2] * s, v[3] * s));
+    *reinterpret_cast<uint2*>(dst) = make_uint2(pack2<F16>(v[0] * s, v[1] * s), pack2<F16>(v[2] * s, v[3] * s));
 }
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MFMA(a, b, c) mma16<F16>(a, b, c)
 
 // ================================================================================ forward ====
-template <bool DROP>
+template <bool DROP, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int* __restrict__ lens,
                                                           uint16_t* __restrict__ av, float* __restrict__ lse, int Tp, float scale,
                                                           float pdrop, uint64_t seed, uint32_t stream_id) {
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         m = m_new;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const bf16x8 pf = pack_rows(s[2 * t], s[2 * t + 1]);
+            const bf16x8 pf = pack_rows<F16>(s[2 * t], s[2 * t + 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = MFMA(fr.read_tr(Vt, dt, t), pf, o[dt]);           // [d g*4+r][row lane&15]
         }
@@ -159,12 +162,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
         uint16_t* dst = av + ((int64_t)b * Tp + row) * 64 + g * 4;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) st4(dst + dt * 16, o[dt], inv);
+        for (int dt = 0; dt < 4; ++dt) st4<F16>(dst + dt * 16, o[dt], inv);
         if (g == 0) lse[(int64_t)b * Tp + row] = lsum > 0.f ? m + __logf(lsum) : INFINITY;
     }
 }
 
 // D[row] = sum_d dO[row][d] * O[row][d]   (8 lanes per row)
+template <bool F16 = false>
 __global__ void attn_bwd_prep_kernel(const uint16_t* __restrict__ O, const uint16_t* __restrict__ dO, float* __restrict__ D, int64_t rows) {
     const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     const int c = (threadIdx.x & 7) * 8;
@@ -173,15 +177,17 @@ __global__ void attn_bwd_prep_kernel(const uint16_t* __restrict__ O, const uint1
         uint4 a = *reinterpret_cast<const uint4*>(O + row * 64 + c), d = *reinterpret_cast<const uint4*>(dO + row * 64 + c);
         const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            s += __uint_as_float(aw[e] << 16) * __uint_as_float(dw[e] << 16) + __uint_as_float(aw[e] & 0xffff0000u) * __uint_as_float(dw[e] & 0xffff0000u);
+        for (int e = 0; e < 4; ++e) {
+            float a0, a1, d0, d1; unpack2<F16>(aw[e], a0, a1); unpack2<F16>(dw[e], d0, d1);
+            s += a0 * d0 + a1 * d1;
+        }
     }
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
     if (row < rows && (threadIdx.x & 7) == 0) D[row] = s;
 }
 
 // ================================================================================ backward: dK, dV ====
-template <bool DROP>
+template <bool DROP, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dO,
                                                               const float* __restrict__ lse, const float* __restrict__ Dv,
                                                               const int* __restrict__ lens, uint16_t* __restrict__ dqkv, int Tp,
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         if (key < Tp) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) { st4(outk + dt * 16, z, 1.f); st4(outk + 64 + dt * 16, z, 1.f); }
+            for (int dt = 0; dt < 4; ++dt) { st4<F16>(outk + dt * 16, z, 1.f); st4<F16>(outk + 64 + dt * 16, z, 1.f); }
         }
         return;
     }
@@ -267,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const bf16x8 pf = pack_rows(s[2 * t], s[2 * t + 1]);
-            const bf16x8 df = pack_rows(dp[2 * t], dp[2 * t + 1]);
+            const bf16x8 pf = pack_rows<F16>(s[2 * t], s[2 * t + 1]);
+            const bf16x8 df = pack_rows<F16>(dp[2 * t], dp[2 * t + 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 dv[dt] = MFMA(fr.read_tr(Ot, dt, t), pf, dv[dt]);            // dV[d][key] += dO[row][d] Pd[row][key]
@@ -279,12 +285,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     }
     if (key < Tp) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { st4(outk + dt * 16, dk[dt], 1.f); st4(outk + 64 + dt * 16, dv[dt], 1.f); }
+        for (int dt = 0; dt < 4; ++dt) { st4<F16>(outk + dt * 16, dk[dt], 1.f); st4<F16>(outk + 64 + dt * 16, dv[dt], 1.f); }
     }
 }
 
 // ================================================================================ backward: dQ ====
-template <bool DROP>
+template <bool DROP, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dO,
                                                              const float* __restrict__ lse, const float* __restrict__ Dv,
                                                              const int* __restrict__ lens, uint16_t* __restrict__ dqkv, int Tp,
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
             }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const bf16x8 df = pack_rows(dp[2 * t], dp[2 * t + 1]);
+            const bf16x8 df = pack_rows<F16>(dp[2 * t], dp[2 * t + 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = MFMA(fr.read_tr(Kt, dt, t), df, dq[dt]);   // dQ[d][row] += K[key][d] dS[row][key]
         }
@@ -353,9 +359,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     if (row < Tp) {
         uint16_t* dst = dqkv + ((int64_t)b * Tp + row) * 192 + g * 4;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) st4(dst + dt * 16, dq[dt], 1.f);
+        for (int dt = 0; dt < 4; ++dt) st4<F16>(dst + dt * 16, dq[dt], 1.f);
     }
 }
+#undef MFMA
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
 
 // ================================================================================ split-bf16 pairs (fp32 mode, split products) ====
@@ -716,23 +724,29 @@ static int raise_lds(K kernel, int bytes, bool& done) {
 }  // namespace
 
 // av (B, Tp, 64) = dropout(softmax(scale * Q K^T, keys 1..len)) V ; lse (B, Tp) fp32 = logsumexp of the masked scaled scores
-extern "C" int xva_fp_attention_fwd(const void* qkv, const int32_t* lens, void* av, float* lse, int B, int Tp, float scale,
-                                    float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+template <bool F16>
+static int attention_fwd_any(const void* qkv, const int32_t* lens, void* av, float* lse, int B, int Tp, float scale, float p_drop, uint64_t seed, uint32_t stream_id,
+                             void* stream) {
     XVA_CHECK_ARG(qkv && lens && av && lse && B > 0 && Tp > 0, "attention_fwd: bad args");
     XVA_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)av % 8) == 0, "attention_fwd: misaligned tensors");
     dim3 grid(xva_cdiv(Tp, 64), B), block(256);
     if (p_drop > 0.f)
-        hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)qkv, lens, (uint16_t*)av, lse, Tp,
+        hipLaunchKernelGGL((attn_fwd_kernel<true, F16>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)qkv, lens, (uint16_t*)av, lse, Tp,
                            scale, p_drop, seed, stream_id);
     else
-        hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)qkv, lens, (uint16_t*)av, lse, Tp,
+        hipLaunchKernelGGL((attn_fwd_kernel<false, F16>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)qkv, lens, (uint16_t*)av, lse, Tp,
                            scale, p_drop, seed, stream_id);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
+extern "C" int xva_fp_attention_fwd(const void* qkv, const int32_t* lens, void* av, float* lse, int B, int Tp, float scale,
+                                    float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+    return attention_fwd_any<false>(qkv, lens, av, lse, B, Tp, scale, p_drop, seed, stream_id, stream);
+}
 
 // d_qkv (B, Tp, 192) = gradients of Q | K | V given d_av; `dscratch` holds B * Tp floats
-extern "C" int xva_fp_attention_bwd(const void* qkv, const void* av, const void* d_av, const float* lse, float* dscratch,
+template <bool F16>
+static int attention_bwd_any(const void* qkv, const void* av, const void* d_av, const float* lse, float* dscratch,
                                     const int32_t* lens, void* d_qkv, int B, int Tp, float scale, float p_drop, uint64_t seed,
                                     uint32_t stream_id, void* stream) {
     XVA_CHECK_ARG(qkv && av && d_av && lse && dscratch && lens && d_qkv && B > 0 && Tp > 0, "attention_bwd: bad args");
@@ -740,27 +754,34 @@ extern "C" int xva_fp_attention_bwd(const void* qkv, const void* av, const void*
                   "attention_bwd: misaligned tensors");
     hipStream_t st = (hipStream_t)stream;
     const int64_t rows = (int64_t)B * Tp;
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)xva_cdiv(rows, 32)), dim3(256), 0, st, (const uint16_t*)av, (const uint16_t*)d_av,
+    hipLaunchKernelGGL((attn_bwd_prep_kernel<F16>), dim3((unsigned)xva_cdiv(rows, 32)), dim3(256), 0, st, (const uint16_t*)av, (const uint16_t*)d_av,
                        dscratch, rows);
     dim3 grid(xva_cdiv(Tp, 64), B), block(256);
     if (p_drop > 0.f) {
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, block, 0, st, (const uint16_t*)qkv, (const uint16_t*)d_av, lse, dscratch, lens,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, F16>), grid, block, 0, st, (const uint16_t*)qkv, (const uint16_t*)d_av, lse, dscratch, lens,
                            (uint16_t*)d_qkv, Tp, scale, p_drop, seed, stream_id);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, 0, st, (const uint16_t*)qkv, (const uint16_t*)d_av, lse, dscratch, lens,
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<true, F16>), grid, block, 0, st, (const uint16_t*)qkv, (const uint16_t*)d_av, lse, dscratch, lens,
                            (uint16_t*)d_qkv, Tp, scale, p_drop, seed, stream_id);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid, block, 0, st, (const uint16_t*)qkv, (const uint16_t*)d_av, lse, dscratch, lens,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, F16>), grid, block, 0, st, (const uint16_t*)qkv, (const uint16_t*)d_av, lse, dscratch, lens,
                            (uint16_t*)d_qkv, Tp, scale, p_drop, seed, stream_id);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, block, 0, st, (const uint16_t*)qkv, (const uint16_t*)d_av, lse, dscratch, lens,
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<false, F16>), grid, block, 0, st, (const uint16_t*)qkv, (const uint16_t*)d_av, lse, dscratch, lens,
                            (uint16_t*)d_qkv, Tp, scale, p_drop, seed, stream_id);
     }
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
+extern "C" int xva_fp_attention_bwd(const void* qkv, const void* av, const void* d_av, const float* lse, float* dscratch,
+                                    const int32_t* lens, void* d_qkv, int B, int Tp, float scale, float p_drop, uint64_t seed,
+                                    uint32_t stream_id, void* stream) {
+    return attention_bwd_any<false>(qkv, av, d_av, lse, dscratch, lens, d_qkv, B, Tp, scale, p_drop, seed, stream_id, stream);
+}
 
 // The same on split-bf16 pairs (fp32 mode with split products): qkv / av / d_av / d_qkv are the hi planes, their lo planes `*_plane` ELEMENTS after them.
+// Plane offsets of 0 (all of them): the tensors are single IEEE-half tensors (XVA_F16) — the fp16-operand mode of the same schedule (include/xva_hip.h).
 extern "C" int xva_fp_attention_fwd_pairs(const void* qkv, int64_t qkv_plane, const int32_t* lens, void* av, int64_t av_plane, float* lse, int B, int Tp,
                                           float scale, float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+    if (qkv_plane == 0 && av_plane == 0) return attention_fwd_any<true>(qkv, lens, av, lse, B, Tp, scale, p_drop, seed, stream_id, stream);
     XVA_CHECK_ARG(qkv && lens && av && lse && B > 0 && Tp > 0, "attention_fwd_pairs: bad args");
     XVA_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)av % 8) == 0 && qkv_plane % 8 == 0 && av_plane % 4 == 0, "attention_fwd_pairs: misaligned tensors");
     static bool a0 = false, a1 = false;
@@ -780,6 +801,8 @@ extern "C" int xva_fp_attention_fwd_pairs(const void* qkv, int64_t qkv_plane, co
 extern "C" int xva_fp_attention_bwd_pairs(const void* qkv, int64_t qkv_plane, const void* av, int64_t av_plane, const void* d_av, int64_t d_av_plane,
                                           const float* lse, float* dscratch, const int32_t* lens, void* d_qkv, int64_t d_qkv_plane, int B, int Tp, float scale,
                                           float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+    if (qkv_plane == 0 && av_plane == 0 && d_av_plane == 0 && d_qkv_plane == 0)
+        return attention_bwd_any<true>(qkv, av, d_av, lse, dscratch, lens, d_qkv, B, Tp, scale, p_drop, seed, stream_id, stream);
     XVA_CHECK_ARG(qkv && av && d_av && lse && dscratch && lens && d_qkv && B > 0 && Tp > 0, "attention_bwd_pairs: bad args");
     XVA_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)av % 16) == 0 && ((uintptr_t)d_av % 16) == 0 && ((uintptr_t)d_qkv % 8) == 0 && qkv_plane % 8 == 0 &&
                       av_plane % 8 == 0 && d_av_plane % 8 == 0 && d_qkv_plane % 4 == 0, "attention_bwd_pairs: misaligned tensors");

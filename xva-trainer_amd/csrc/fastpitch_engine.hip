@@ -191,10 +191,15 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     XVA_CHECK_ARG(d->Tm + 2 <= 2048 && d->Tt + 2 <= 2048, "fastpitch: sequence longer than 2046 unsupported");
     XVA_CHECK_ARG(d->p_dropout >= 0.f && d->p_dropout < 1.f, "fastpitch: bad dropout probability");
     p->B = d->B; p->Tt = d->Tt; p->Tm = d->Tm; p->Ttp = d->Tt + 2; p->Tmp = d->Tm + 2;
-    p->dt = d->compute ? XVA_BF16 : XVA_F32; p->es = d->compute ? 2 : 4;
+    XVA_CHECK_ARG(d->compute >= 0 && d->compute <= 2, "fastpitch: compute must be 0 (fp32), 1 (bf16) or 2 (fp16 operands, fp32 residual stream)");
+    // compute 2 (round 6): the storage plan of the fp32 mode with the planes path on — the residual stream, LayerNorm inputs / outputs and every gradient of them
+    // fp32, the MFMA operands (layer inputs, y1, qkv, A V, the feed-forward intermediate h and their gradients, all weights) single IEEE-half tensors where
+    // the split-products mode keeps bf16 pairs
+    const bool bf16s = d->compute == 1, h16 = d->compute == 2, planned_planes = h16 || (d->compute == 0 && g_ffn_planes);
+    p->dt = bf16s ? XVA_BF16 : XVA_F32; p->es = bf16s ? 2 : 4;
     const int es = p->es;
     const bool drop = d->p_dropout > 0.f;
-    const bool fused = d->compute != 0;
+    const bool fused = bf16s;
     p->Re = (int64_t)d->B * p->Ttp; p->Rd = (int64_t)d->B * p->Tmp;
     p->Tse = (p->Ttp + 7) & ~7; p->Tsd = (p->Tmp + 7) & ~7;
     Bump b;
@@ -202,11 +207,11 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
         x[0] = b.seq(R, DM, es);
         for (int i = 0; i < NL; ++i) {
             // fp32 mode with the split-products planes path: QKV_SPARE spare rows — the products over the keys take K = Ts = round-up-8(Tp) and read up to 7 rows past the last item
-            L[i].qkv = b.seq(R + ((!fused && g_ffn_planes) ? QKV_SPARE : 0), DQKV, es);
+            L[i].qkv = b.seq(R + (planned_planes ? QKV_SPARE : 0), DQKV, es);
             // bf16 mode runs the fused attention kernels (attention.hip): no (T x T) probability matrices, one logsumexp per row
             L[i].P = fused ? -1 : b.take((int64_t)p->B * Tp * Ts * es + 64);
             // (the split-products planes path keeps the dropped copy as a split-bf16 pair in the same bytes: it needs its own buffer without dropout too)
-            L[i].Pd = fused ? -1 : ((drop || g_ffn_planes) ? b.take((int64_t)p->B * Tp * Ts * es + 64) : L[i].P);
+            L[i].Pd = fused ? -1 : ((drop || planned_planes) ? b.take((int64_t)p->B * Tp * Ts * es + 64) : L[i].P);
             L[i].lse = fused ? b.take(R * 4) : -1;
             L[i].av = b.seq(R, DH, es);
             L[i].sum1 = b.seq(R, DM, es);
@@ -219,7 +224,7 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
             // fp32 mode, split products: the layer input and y1 ALSO as split-bf16 pairs, kept from the forward pass for the weight gradients (rows -1 .. R of
             // two planes: the bytes of one fp32 sequence slot; guard rows are never written and stay zero)
             L[i].xp = L[i].yp = -1;
-            if (!fused && g_ffn_planes) { L[i].xp = b.take(2 * (R + 2) * DM * 2); L[i].yp = b.take(2 * (R + 2) * DM * 2); }
+            if (planned_planes) { L[i].xp = b.take(2 * (R + 2) * DM * 2); L[i].yp = b.take(2 * (R + 2) * DM * 2); }
         }
     };
     auto plan_pred = [&](PredA& A) {
@@ -230,7 +235,7 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     };
     plan_layers(p->Re, p->Ttp, p->Tse, p->enc_x, p->enc);
     plan_pred(p->dur); plan_pred(p->pitch); plan_pred(p->energy);
-    p->pin_a = d->compute ? b.seq(p->Re, DM, 4) : -1; p->pin_b = d->compute ? b.seq(p->Re, DM, 4) : -1;
+    p->pin_a = bf16s ? b.seq(p->Re, DM, 4) : -1; p->pin_b = bf16s ? b.seq(p->Re, DM, 4) : -1;
     p->ptgt = b.take((p->Re + 8) * 4) + 16; p->etgt = b.take((p->Re + 8) * 4) + 16;
     p->enc_c1 = b.seq(p->Re, DM, es); p->enc_c2 = b.seq(p->Re, DM, es);
     p->tok = b.take((int64_t)p->B * p->Tm * 4); p->tstart = b.take((int64_t)p->B * (p->Tt + 1) * 4); p->dec_lens = b.take(p->B * 4);
@@ -254,12 +259,12 @@ int make_plan(const xva_fp_dims* d, Plan* p) {
     p->gB2 = b.seq(Rm, DM, es); p->gD2 = b.seq(Rm, DM, es);
     p->gBm2 = drop ? b.seq(Rm, DM, es) : p->gB2; p->gDm2 = drop ? b.seq(Rm, DM, es) : p->gD2;
     p->gH2 = b.seq(Rm, DI, es); p->gQKV2 = b.seq(Rm, DQKV, es);
-    p->wshadow = d->compute ? b.take(table().total * es) : -1;
-    p->wt_c2 = (d->compute && g_bwd_nt) ? b.take((int64_t)2 * NL * DI * 3 * DM * 2) : -1;
+    p->wshadow = bf16s ? b.take(table().total * es) : -1;
+    p->wt_c2 = (bf16s && g_bwd_nt) ? b.take((int64_t)2 * NL * DI * 3 * DM * 2) : -1;
     p->wplanes = p->wtp_c1 = p->wtp_c2 = p->gPp = -1;
     for (int st = 0; st < 2; ++st) for (int q = 0; q < 2; ++q) p->gp[st][q] = p->dp[st][q] = -1;
     p->wplane_stride = (table().total + 7) / 8 * 8;
-    if (!d->compute && g_ffn_planes) {
+    if (planned_planes) {
         p->wplanes = b.take(2 * p->wplane_stride * 2);
         p->wtp_c1 = b.take((int64_t)2 * (2 * NL) * DI * 3 * DM * 2); p->wtp_c2 = b.take((int64_t)2 * (2 * NL) * DI * 3 * DM * 2);
         for (int st = 0; st < 2; ++st)           // d(sum2) / d(sum1) masked by their dropouts, as pairs: per stack (the guard rows sit at the stack's own R)
@@ -292,7 +297,8 @@ struct Ctx {
     float* G;         // grads (may be null in forward)
     char* W;          // workspace
     void* st;
-    int compute, dt, es;
+    int compute, dt, es;   // compute: 1 = bf16 storage (the throughput mode), 0 = fp32 storage
+    bool h16 = false;      // fp32 storage, the planes schedule on single IEEE-half operand tensors (dims.compute == 2)
     float pd;         // dropout probability
     uint64_t seed;
     int lane = 0;     // 0: the caller's stream, 1: the weight-gradient side stream, 2: the predictor side stream (own split-K slabs each)
@@ -341,7 +347,9 @@ int Ctx::record(int i) {
 static xva_gemm_params gp0(const Ctx& c) {
     xva_gemm_params g;
     memset(&g, 0, sizeof(g));
-    g.batch = 1; g.batch2 = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.compute = c.compute; g.mask_pad = 1; g.mask_mul = 1;
+    // (fp16-operand mode: the products that stay on fp32-stored operands — temporal predictors, projection, toy sequences — take the split-bf16 products
+    // of the register-staged kernel, ~1e-5 per product, whatever xva_gemm_set_fp32_products says)
+    g.batch = 1; g.batch2 = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.compute = c.h16 ? 2 : c.compute; g.mask_pad = 1; g.mask_mul = 1;
     g.a_dtype = g.b_dtype = g.c_dtype = c.dt; g.r_dtype = g.g_dtype = c.dt;
     return g;
 }
@@ -425,20 +433,25 @@ static int conv3_bwd_weight(Ctx& c, const void* dY, int64_t rows, int Cout, cons
 
 // ------------------------------------------------------------------ split-bf16 planes (fp32 mode, split products) ----
 // A sequence tensor as a split-bf16 pair (include/xva_gemm.h): hi plane rows -1 .. R (the guard rows are zeros), lo plane `plane` elements after it.
+// fp16-operand mode (Ctx::h16): the same buffers and the same schedule with plane == 0 — ONE IEEE-half tensor where the pair's hi plane would be (the
+// lo plane's bytes stay unused); every consumer of a pair takes plane == 0 as "single XVA_F16 tensor" (include/xva_hip.h).
+static thread_local bool t_h16 = false;      // set by make_ctx: the helpers below build PlaneT descriptors without a context
 struct PlaneT { char* base; int64_t plane; int C; int extra = 0; };     // extra: spare rows after row R in each plane
 static inline char* prow(const PlaneT& t, int64_t row) { return t.base + (row + 1) * (int64_t)t.C * 2; }                  // hi plane, row `row`
 // the pair that lives IN an fp32 sequence slot of R rows x C channels (same bytes: 2 planes x (R + 2) rows x 2 B = (R + 2) rows x 4 B)
-static inline PlaneT planes_in_slot(char* row0_fp32, int64_t R, int C, int extra = 0) { return PlaneT{row0_fp32 - (int64_t)C * 4, (R + 2 + extra) * (int64_t)C, C, extra}; }
-static inline PlaneT planes_own(const Ctx& c, int64_t off, int64_t R) { return PlaneT{c.W + off, (R + 2) * (int64_t)DM, DM}; }      // a dedicated pair buffer of R rows x DM
-static bool planes_mode(const Ctx& c) { return !c.compute && c.pl.wplanes >= 0 && g_ffn_planes && xva_gemm_get_fp32_products() == 1; }
+static inline PlaneT planes_in_slot(char* row0_fp32, int64_t R, int C, int extra = 0) { return PlaneT{row0_fp32 - (int64_t)C * 4, t_h16 ? 0 : (R + 2 + extra) * (int64_t)C, C, extra}; }
+static inline PlaneT planes_own(const Ctx& c, int64_t off, int64_t R) { return PlaneT{c.W + off, c.h16 ? 0 : (R + 2) * (int64_t)DM, DM}; }      // a dedicated pair buffer of R rows x DM
+static bool planes_mode(const Ctx& c) { return !c.compute && c.pl.wplanes >= 0 && (c.h16 || (g_ffn_planes && xva_gemm_get_fp32_products() == 1)); }
+static inline int pair_dt(const Ctx& c) { return c.h16 ? XVA_F16 : XVA_BF16; }
+static inline int64_t wplane_off(const Ctx& c) { return c.h16 ? 0 : c.pl.wplane_stride; }
 // per stack: the direct-to-LDS kernels want at least a K tile of rows / keys (toy sequences stay on the register-staged kernel)
 // XVA_FP_PLANES_MASK (A/B, debugging): bit 0 encoder stack, bit 1 decoder stack, bit 2 the attention block (clear: feed-forward only); default 7
 static const int g_planes_mask = [] { const char* e = getenv("XVA_FP_PLANES_MASK"); return e ? atoi(e) : 7; }();
 static bool ffn_planes_on(const Ctx& c, int64_t R, int Tp) {
     const bool enc = R == c.pl.Re && Tp == c.pl.Ttp;
-    return planes_mode(c) && R >= 64 && Tp >= 16 && (g_planes_mask & (enc ? 1 : 2));
+    return planes_mode(c) && R >= 64 && Tp >= 16 && (c.h16 || (g_planes_mask & (enc ? 1 : 2)));
 }
-static bool att_planes_on(const Ctx& c, int64_t R, int Tp) { return ffn_planes_on(c, R, Tp) && (g_planes_mask & 4); }
+static bool att_planes_on(const Ctx& c, int64_t R, int Tp) { return ffn_planes_on(c, R, Tp) && (c.h16 || (g_planes_mask & 4)); }
 // fp32 rows -1 .. R of a sequence tensor -> the pair
 static int split_rows(const Ctx& c, const char* row0_fp32, int64_t R, const PlaneT& dst, void* st) {
     return xva_split_bf16(reinterpret_cast<const float*>(row0_fp32 - (int64_t)dst.C * 4), dst.base, dst.plane, (R + 2) * (int64_t)dst.C, st);
@@ -452,7 +465,8 @@ struct GuardSpans {
 };
 static xva_gemm_params gpp(const Ctx& c) {
     xva_gemm_params g = gp0(c);
-    g.compute = 1; g.a_dtype = g.b_dtype = XVA_BF16; g.planes = 1;
+    g.compute = 1; g.a_dtype = g.b_dtype = pair_dt(c); g.planes = c.h16 ? 0 : 1;
+    g.c_dtype = g.r_dtype = g.g_dtype = XVA_F32;
     return g;
 }
 // the encoder's long reductions into few tiles (4 864 rows): let xva_gemm split K through this lane's slabs and apply the epilogue in the reduce pass (offer_split)
@@ -473,9 +487,9 @@ constexpr int64_t WT_PLANE = (int64_t)2 * NL * DI * 3 * DM;           // element
 static int conv3_fwd_p(Ctx& c, const PlaneT& X, int64_t rows, int Cin, int64_t w_off, const float* bias, const PlaneT* Yp, void* Y, int Cout, int relu,
                        const void* R, int mask, const int32_t* lens, int Tp, Drop dr = {0.f, 0}) {
     xva_gemm_params g = gpp(c);
-    g.layout = XVA_GEMM_NT; g.A = prow(X, -1); g.a_plane = X.plane; g.B = wplane(c, w_off); g.b_plane = c.pl.wplane_stride;
+    g.layout = XVA_GEMM_NT; g.A = prow(X, -1); g.a_plane = X.plane; g.B = wplane(c, w_off); g.b_plane = wplane_off(c);
     g.M = (int)rows; g.N = Cout; g.K = 3 * Cin; g.lda = Cin; g.ldb = 3 * Cin; g.ldc = Cout;
-    if (Yp) { g.C = prow(*Yp, 0); g.c_dtype = XVA_BF16; g.c_plane = Yp->plane; } else { g.C = Y; g.c_dtype = XVA_F32; }
+    if (Yp) { g.C = prow(*Yp, 0); g.c_dtype = pair_dt(c); g.c_plane = Yp->plane; } else { g.C = Y; g.c_dtype = XVA_F32; }
     g.bias = bias; g.act = relu ? XVA_ACT_RELU : XVA_ACT_NONE; g.R = R; g.ldr = Cout; g.r_dtype = XVA_F32;
     g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
     g.drop_p = dr.p; g.drop_seed = c.seed; g.drop_stream = dr.stream;
@@ -486,11 +500,11 @@ static int conv3_fwd_p(Ctx& c, const PlaneT& X, int64_t rows, int Cin, int64_t w
 static int conv3_bwd_data_p(Ctx& c, const PlaneT& dY, int64_t rows, int Cout, const void* wt, int Cin, const PlaneT* dXp, void* dX, const void* R,
                             const PlaneT* gate, int mask, const int32_t* lens, int Tp) {
     xva_gemm_params g = gpp(c);
-    g.layout = XVA_GEMM_NT; g.A = prow(dY, -1); g.a_plane = dY.plane; g.B = wt; g.b_plane = WT_PLANE;
+    g.layout = XVA_GEMM_NT; g.A = prow(dY, -1); g.a_plane = dY.plane; g.B = wt; g.b_plane = c.h16 ? 0 : WT_PLANE;
     g.M = (int)rows; g.N = Cin; g.K = 3 * Cout; g.lda = Cout; g.ldb = 3 * Cout; g.ldc = Cin;
-    if (dXp) { g.C = prow(*dXp, 0); g.c_dtype = XVA_BF16; g.c_plane = dXp->plane; } else { g.C = dX; g.c_dtype = XVA_F32; }
+    if (dXp) { g.C = prow(*dXp, 0); g.c_dtype = pair_dt(c); g.c_plane = dXp->plane; } else { g.C = dX; g.c_dtype = XVA_F32; }
     g.R = R; g.ldr = Cin; g.r_dtype = XVA_F32;
-    if (gate) { g.G = prow(*gate, 0); g.ldg = Cin; g.g_dtype = XVA_BF16; }     // the hi plane: sign and zero-ness of the activation survive the rounding
+    if (gate) { g.G = prow(*gate, 0); g.ldg = Cin; g.g_dtype = pair_dt(c); }     // the hi plane: sign and zero-ness of the activation survive the rounding
     g.mask_mode = mask; g.lens = lens; g.Tp = Tp;
     offer_split_p(c, g);
     return xva_gemm(&g, c.st);
@@ -507,7 +521,7 @@ static int conv3_bwd_weight_p(Ctx& c, const PlaneT& dY, int64_t rows, int Cout, 
 // parameters [begin, end) of the table as a pair (begin a multiple of 8)
 static int refresh_planes_range(const Ctx& c, const float* params, int64_t begin, int64_t end, void* st) {
     const int64_t n8 = (end - begin) / 8 * 8;
-    return xva_split_bf16(params + begin, c.W + c.pl.wplanes + begin * 2, c.pl.wplane_stride, n8, st);
+    return xva_split_bf16(params + begin, c.W + c.pl.wplanes + begin * 2, wplane_off(c), n8, st);
 }
 // the transposed convolution weights (read by the backward-data products only)
 static int refresh_planes_wt(const Ctx& c, const float* params, void* st) {
@@ -519,7 +533,7 @@ static int refresh_planes_wt(const Ctx& c, const float* params, void* st) {
             dof[l] = (int64_t)l * DI * 3 * DM; dof[NL + l] = (int64_t)(NL + l) * DI * 3 * DM;
         }
         // c1: [DI][3][DM] -> [DM][3][DI] ; c2: [DM][3][DI] -> [DI][3][DM]
-        XVA_TRY(xva_fp_wt_transpose3_planes(params, c.W + (which ? c.pl.wtp_c2 : c.pl.wtp_c1), so, dof, 2 * NL, which ? DM : DI, which ? DI : DM, WT_PLANE, st));
+        XVA_TRY(xva_fp_wt_transpose3_planes(params, c.W + (which ? c.pl.wtp_c2 : c.pl.wtp_c1), so, dof, 2 * NL, which ? DM : DI, which ? DI : DM, c.h16 ? 0 : WT_PLANE, st));
     }
     return XVA_OK;
 }
@@ -542,13 +556,13 @@ enum { DS_ENC = 0, DS_DEC = 100, DS_PRED = 200 };
 static void pgemm_common(xva_gemm_params& g, const PlaneT* A, const PlaneT* B, const PlaneT* Cp) {
     if (A) g.a_plane = A->plane;
     if (B) g.b_plane = B->plane;
-    if (Cp) { g.c_dtype = XVA_BF16; g.c_plane = Cp->plane; }
+    if (Cp) { g.c_dtype = g.a_dtype; g.c_plane = Cp->plane; }      // (the operands' 16-bit format: bf16 pair / one half tensor)
 }
 static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* x, bool x_is_split, int64_t R, int Tp, int64_t Ts, const int32_t* lens, uint32_t s0) {
     const int B = c.pl.B;
     const PlaneT xp = planes_own(c, a.xp, R), qp = planes_in_slot(c.A(a.qkv), R, DQKV, QKV_SPARE), avp = planes_in_slot(c.A(a.av), R, DH);
-    const PlaneT wq{nullptr, c.pl.wplane_stride, 0};
-    const PlaneT pdp{c.A(a.Pd), (int64_t)B * Tp * Ts, 0};
+    const PlaneT wq{nullptr, wplane_off(c), 0};
+    const PlaneT pdp{c.A(a.Pd), c.h16 ? 0 : (int64_t)B * Tp * Ts, 0};
     if (!x_is_split) XVA_TRY(split_rows(c, x, R, xp, c.st));       // (layers past the first: the previous layer's LayerNorm wrote the pair)
     {   // qkv = x Wqkv^T + b, stored as a pair
         xva_gemm_params g = gpp(c); pgemm_common(g, &xp, &wq, &qp);
@@ -592,8 +606,8 @@ static int attention_bwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
     const PlaneT dpp = planes_own(c, c.pl.dp[stk][par], R);
     const PlaneT qp = planes_in_slot(c.A(a.qkv), R, DQKV, QKV_SPARE), avp = planes_in_slot(c.A(a.av), R, DH);
     const PlaneT gavp = planes_in_slot(gAV, Rmax, DH), gqp = planes_in_slot(gQKV, Rmax, DQKV);
-    const PlaneT wq{nullptr, c.pl.wplane_stride, 0};
-    const PlaneT pdp{c.A(a.Pd), (int64_t)B * Tp * Ts, 0}, dsp{c.A(c.pl.gPp), (int64_t)B * Tp * Ts, 0};
+    const PlaneT wq{nullptr, wplane_off(c), 0};
+    const PlaneT pdp{c.A(a.Pd), c.h16 ? 0 : (int64_t)B * Tp * Ts, 0}, dsp{c.A(c.pl.gPp), c.h16 ? 0 : (int64_t)B * Tp * Ts, 0};
     if (!gDm_is_split) XVA_TRY(split_rows(c, gDm, R, dpp, c.st));
     {   // gAV = gDm Wo
         xva_gemm_params g = gpp(c); pgemm_common(g, &dpp, &wq, &gavp);
@@ -653,8 +667,8 @@ static int attention_wgrad_planes(Ctx& cw, const LayerP& p, const LayerA& a, cha
     };
     XVA_TRY(wgrad(dpp, DM, avp, DH, Gg + p.o_w));
     XVA_TRY(wgrad(gqp, DQKV, xp, DM, Gg + p.qkv_w));
-    XVA_TRY(xva_fp_colsum(prow(gqp, 0), XVA_BF16, Gg + p.qkv_b, R, DQKV, DQKV, cw.st));
-    XVA_TRY(xva_fp_colsum(prow(gqp, 0) + gqp.plane * 2, XVA_BF16, Gg + p.qkv_b, R, DQKV, DQKV, cw.st));
+    XVA_TRY(xva_fp_colsum(prow(gqp, 0), pair_dt(c), Gg + p.qkv_b, R, DQKV, DQKV, cw.st));
+    if (!c.h16) XVA_TRY(xva_fp_colsum(prow(gqp, 0) + gqp.plane * 2, XVA_BF16, Gg + p.qkv_b, R, DQKV, DQKV, cw.st));
     return XVA_OK;
 }
 
@@ -888,8 +902,8 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
             XVA_TRY(conv3_bwd_weight_p(cw, gBp, R, DM, hp, DI, Gg + p.c2_w));
             XVA_TRY(xva_fp_colsum(gBm, c.dt, Gg + p.c2_b, R, DM, DM, cw.st));
             XVA_TRY(conv3_bwd_weight_p(cw, gHp, R, DI, y1p, DM, Gg + p.c1_w));
-            XVA_TRY(xva_fp_colsum(prow(gHp, 0), XVA_BF16, Gg + p.c1_b, R, DI, DI, cw.st));                       // d b1 = column sums of hi + lo
-            XVA_TRY(xva_fp_colsum(prow(gHp, 0) + gHp.plane * 2, XVA_BF16, Gg + p.c1_b, R, DI, DI, cw.st));
+            XVA_TRY(xva_fp_colsum(prow(gHp, 0), pair_dt(c), Gg + p.c1_b, R, DI, DI, cw.st));                       // d b1 = column sums of hi + lo
+            if (!c.h16) XVA_TRY(xva_fp_colsum(prow(gHp, 0) + gHp.plane * 2, XVA_BF16, Gg + p.c1_b, R, DI, DI, cw.st));
         } else {
         XVA_TRY(conv3_bwd_weight(cw, gBm, R, DM, c.A(a.h), DI, Gg + p.c2_w));
         XVA_TRY(xva_fp_colsum(gBm, c.dt, Gg + p.c2_b, R, DM, DM, cw.st));
@@ -963,9 +977,10 @@ static int make_ctx(Ctx& c, const xva_fp_dims* d, const float* params, float* gr
     XVA_CHECK_ARG(params && ws, "fastpitch: null params/workspace");
     XVA_CHECK_ARG(((uintptr_t)params % 16) == 0 && ((uintptr_t)ws % 256) == 0, "fastpitch: params must be 16-byte and workspace 256-byte aligned");
     XVA_CHECK_ARG(ws_bytes >= c.pl.total, "fastpitch: workspace too small (%ld < %ld bytes)", (long)ws_bytes, (long)c.pl.total);
-    c.d = d; c.P = params; c.G = grads; c.W = (char*)ws; c.st = st; c.compute = d->compute ? 1 : 0; c.dt = c.pl.dt; c.es = c.pl.es;
+    c.d = d; c.P = params; c.G = grads; c.W = (char*)ws; c.st = st; c.compute = d->compute == 1 ? 1 : 0; c.h16 = d->compute == 2; c.dt = c.pl.dt; c.es = c.pl.es;
     c.pd = d->p_dropout; c.seed = d->seed;
-    c.Pw = d->compute ? c.W + c.pl.wshadow : (const char*)params;
+    c.Pw = c.compute ? c.W + c.pl.wshadow : (const char*)params;
+    t_h16 = c.h16;
     return XVA_OK;
 }
 
@@ -1054,8 +1069,8 @@ extern "C" int xva_fp_forward(const xva_fp_dims* d, const float* params, const x
     // predictor lane under the encoder's forward
     WgLane& wl0 = wg_lane();
     bool split_rest = false;
-    const bool split_cast = d->compute && wl0.ok && !g_fp_serial && d->stage != 2 && T.enc_begin == 0 && T.enc_end % 8 == 0;
-    if (d->compute) {
+    const bool split_cast = c.compute && wl0.ok && !g_fp_serial && d->stage != 2 && T.enc_begin == 0 && T.enc_end % 8 == 0;
+    if (c.compute) {
         if (split_cast) {
             XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.enc_end, c.st));
             XVA_HIP_TRY(hipEventRecord(wl0.pfork, (hipStream_t)c.st));      // orders the side lane after whatever wrote `params` on the caller's stream
@@ -1191,7 +1206,7 @@ int make_actx(ACtx& c, const xva_fp_dims* d, const float* params, float* grads, 
     XVA_TRY(make_align_plan(d, &c.pl));
     XVA_CHECK_ARG(params && ws && ((uintptr_t)ws % 256) == 0 && ((uintptr_t)params % 16) == 0, "align: null / misaligned params or workspace");
     XVA_CHECK_ARG(ws_bytes >= c.pl.total, "align: workspace too small (%ld < %ld bytes)", (long)ws_bytes, (long)c.pl.total);
-    c.P = params; c.G = grads; c.W = (char*)ws; c.st = st; c.compute = d->compute ? 1 : 0;
+    c.P = params; c.G = grads; c.W = (char*)ws; c.st = st; c.compute = d->compute == 2 ? 2 : (d->compute ? 1 : 0);      // fp32-stored; 2: split-bf16 products
     return XVA_OK;
 }
 }  // namespace
@@ -1298,7 +1313,7 @@ extern "C" int xva_fp_infer_encode(const xva_fp_dims* d0, const float* params, c
     const Plan& pl = c.pl;
     const ParamTable& T = table();
     const int B = pl.B;
-    if (d.compute) XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
+    if (c.compute) XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
     else XVA_TRY(refresh_planes(c, params, c.st));
     XVA_TRY(xva_fp_embed_fwd(bt->text, c.P + T.word_emb, bt->pos_table, c.A(pl.enc_x[0]), c.dt, B, pl.Tt, DM, c.st));
     XVA_TRY(layers_fwd(c, T.enc, pl.enc, pl.enc_x, pl.Re, pl.Ttp, pl.Tse, bt->in_lens, DS_ENC));
@@ -1330,7 +1345,7 @@ extern "C" int xva_fp_infer_decode(const xva_fp_dims* d0, const float* params, c
     const Plan& pl = c.pl;
     const ParamTable& T = table();
     const int B = pl.B;
-    if (d.compute) XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
+    if (c.compute) XVA_TRY(xva_cast_f32(params, c.W + pl.wshadow, c.dt, T.total, c.st));
     else XVA_TRY(refresh_planes(c, params, c.st));
     int32_t* dec_lens = (int32_t*)c.A(pl.dec_lens);
     XVA_TRY(xva_fp_lenreg_map(durs, (int32_t*)c.A(pl.tok), (int32_t*)c.A(pl.tstart), dec_lens, B, pl.Tt, pl.Tm, 1.0f, c.st));   // :472-474

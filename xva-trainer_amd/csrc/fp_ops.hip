@@ -12,12 +12,17 @@
 
 #define WAVES_PER_BLOCK 4
 
-// activation element access: dt = XVA_F32 (parity mode) or XVA_BF16 (bf16 training mode); arithmetic is always fp32
+// activation element access: dt = XVA_F32 (parity mode), XVA_BF16 (bf16 training mode) or XVA_F16 (IEEE half: the single-plane operand copies of the
+// fp16-operand mode); arithmetic is always fp32
+typedef _Float16 xva_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_f16(float x, float y) { const xva_h2 h = {(_Float16)x, (_Float16)y}; return __builtin_bit_cast(uint32_t, h); }
 __device__ __forceinline__ float a_ld(const void* p, int64_t i, int dt) {
+    if (dt == XVA_F16) return (float)reinterpret_cast<const _Float16*>(p)[i];
     return dt == XVA_BF16 ? __uint_as_float(((uint32_t) reinterpret_cast<const uint16_t*>(p)[i]) << 16)
                           : reinterpret_cast<const float*>(p)[i];
 }
 __device__ __forceinline__ void a_st(void* p, int64_t i, int dt, float v) {
+    if (dt == XVA_F16) { reinterpret_cast<_Float16*>(p)[i] = (_Float16)v; return; }
     if (dt == XVA_BF16) {
         uint32_t u = __float_as_uint(v);
         u += 0x7fffu + ((u >> 16) & 1u);
@@ -29,7 +34,10 @@ __device__ __forceinline__ void a_st(void* p, int64_t i, int dt, float v) {
 
 // two adjacent elements (i even): one 4-byte (bf16) or 8-byte (fp32) access
 __device__ __forceinline__ void a_ld2(const void* p, int64_t i, int dt, float& x, float& y) {
-    if (dt == XVA_BF16) {
+    if (dt == XVA_F16) {
+        const xva_h2 h = *reinterpret_cast<const xva_h2*>(reinterpret_cast<const uint16_t*>(p) + i);
+        x = (float)h[0]; y = (float)h[1];
+    } else if (dt == XVA_BF16) {
         uint32_t u = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(p) + i);
         x = __uint_as_float(u << 16); y = __uint_as_float(u & 0xffff0000u);
     } else {
@@ -38,7 +46,9 @@ __device__ __forceinline__ void a_ld2(const void* p, int64_t i, int dt, float& x
     }
 }
 __device__ __forceinline__ void a_st2(void* p, int64_t i, int dt, float x, float y) {
-    if (dt == XVA_BF16) {
+    if (dt == XVA_F16) {
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(p) + i) = pk_f16(x, y);
+    } else if (dt == XVA_BF16) {
         uint32_t a = __float_as_uint(x), b = __float_as_uint(y);
         a += 0x7fffu + ((a >> 16) & 1u); b += 0x7fffu + ((b >> 16) & 1u);
         *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(p) + i) = (a >> 16) | (b & 0xffff0000u);
@@ -101,6 +111,7 @@ extern "C" int xva_fp_embed_bwd(const int32_t* ids, const void* dX, int dt, floa
 // copy Pd = P * m / (1 - p) that the P.V product consumes (backward needs the undropped P for the softmax Jacobian).
 // pair_plane > 0 (fp32 S): Pd is written as a split-bf16 pair (hi plane at Pd, lo plane pair_plane elements after it: the operand of xva_gemm `planes`)
 __device__ __forceinline__ void sm_store_pair(void* base, int64_t i, int64_t plane, float v) {
+    if (plane < 0) { reinterpret_cast<_Float16*>(base)[i] = (_Float16)v; return; }      // one IEEE-half tensor instead of a pair
     uint32_t u = __float_as_uint(v); u += 0x7fffu + ((u >> 16) & 1u);
     const uint16_t h = (uint16_t)(u >> 16);
     const float r = v - __uint_as_float((uint32_t)h << 16);
@@ -190,10 +201,10 @@ extern "C" int xva_fp_softmax_fwd(void* S, void* Pd, int dt, const int32_t* lens
 }
 extern "C" int xva_fp_softmax_fwd_pairs(void* S, void* Pd_pair, int64_t pair_plane, const int32_t* lens, int B, int Tp, int64_t Ts, float p_drop, uint64_t seed,
                                         uint32_t stream_id, void* stream) {
-    XVA_CHECK_ARG(S && Pd_pair && lens && pair_plane > 0 && Ts >= Tp && Ts <= 64 * SM_MAXPL, "softmax_fwd_pairs: bad args");
+    XVA_CHECK_ARG(S && Pd_pair && lens && pair_plane >= 0 && Ts >= Tp && Ts <= 64 * SM_MAXPL, "softmax_fwd_pairs: bad args");
     int64_t rows = (int64_t)B * Tp;
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3(xva_cdiv(rows, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
-                       (hipStream_t)stream, S, Pd_pair, XVA_F32, lens, B, Tp, Ts, p_drop, seed, stream_id, pair_plane);
+                       (hipStream_t)stream, S, Pd_pair, XVA_F32, lens, B, Tp, Ts, p_drop, seed, stream_id, pair_plane ? pair_plane : (int64_t)-1);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
@@ -208,16 +219,18 @@ extern "C" int xva_fp_softmax_bwd(const void* P, void* dP, int dt, int B, int Tp
 }
 extern "C" int xva_fp_softmax_bwd_pairs(const void* P, const void* dP, void* dS_pair, int64_t pair_plane, int B, int Tp, int64_t Ts, float scale, float p_drop,
                                         uint64_t seed, uint32_t stream_id, void* stream) {
-    XVA_CHECK_ARG(P && dP && dS_pair && pair_plane > 0 && Ts >= Tp && Ts <= 64 * SM_MAXPL, "softmax_bwd_pairs: bad args");
+    XVA_CHECK_ARG(P && dP && dS_pair && pair_plane >= 0 && Ts >= Tp && Ts <= 64 * SM_MAXPL, "softmax_bwd_pairs: bad args");
     int64_t rows = (int64_t)B * Tp;
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(xva_cdiv(rows, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
-                       (hipStream_t)stream, P, const_cast<void*>(dP), XVA_F32, B, Tp, Ts, scale, p_drop, seed, stream_id, dS_pair, pair_plane);
+                       (hipStream_t)stream, P, const_cast<void*>(dP), XVA_F32, B, Tp, Ts, scale, p_drop, seed, stream_id, dS_pair, pair_plane ? pair_plane : (int64_t)-1);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
 
 // two adjacent values as a split-bf16 pair: hi = bf16(v) at base[i], lo = bf16(v - hi) at base[i + plane] (the operand form of xva_gemm `planes`)
+// plane == 0: ONE IEEE-half tensor instead (the fp16-operand mode: same schedule, single-pass products on v_mfma_f32_16x16x32_f16)
 __device__ __forceinline__ void st2_pair(uint16_t* base, int64_t i, int64_t plane, float x, float y) {
+    if (plane == 0) { *reinterpret_cast<uint32_t*>(base + i) = pk_f16(x, y); return; }
     uint32_t hi, lo;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
     const float r0 = x - __uint_as_float(hi << 16), r1 = y - __uint_as_float(hi & 0xffff0000u);
@@ -538,7 +551,7 @@ static int layernorm_fwd_impl(const void* X, const float* gamma, const float* be
                                     uint32_t stream_id, void* y_pair, int64_t pair_plane, void* stream) {
     XVA_CHECK_ARG(X && gamma && beta && Y && mean && rstd, "layernorm_fwd: null");
     XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
-    XVA_CHECK_ARG(!y_pair || (dt == XVA_F32 && pair_plane > 0 && pair_plane % 2 == 0 && ((uintptr_t)y_pair % 4) == 0), "layernorm_fwd: pair output wants fp32 rows");
+    XVA_CHECK_ARG(!y_pair || (dt == XVA_F32 && pair_plane >= 0 && pair_plane % 2 == 0 && ((uintptr_t)y_pair % 4) == 0), "layernorm_fwd: pair output wants fp32 rows");
     uint16_t* yp = reinterpret_cast<uint16_t*>(y_pair);
     if (g_ln4 && !y_pair && C == 384 && dt == XVA_BF16 && p_drop == 0.f && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
         ((uintptr_t)beta % 16) == 0) {
@@ -574,7 +587,7 @@ static int layernorm_bwd_impl(const void* dY, const void* X, const float* mean, 
                                     float p_out, uint64_t seed_out, uint32_t stream_out, const float* outer_d, const float* outer_w,
                                     void* dx_pair, int64_t pair_plane, void* stream) {
     XVA_CHECK_ARG((dY || (outer_d && outer_w)) && X && mean && rstd && gamma && dX, "layernorm_bwd: null");
-    XVA_CHECK_ARG(!dx_pair || (dt == XVA_F32 && pair_plane > 0 && pair_plane % 2 == 0 && ((uintptr_t)dx_pair % 4) == 0), "layernorm_bwd: pair output wants fp32 rows");
+    XVA_CHECK_ARG(!dx_pair || (dt == XVA_F32 && pair_plane >= 0 && pair_plane % 2 == 0 && ((uintptr_t)dx_pair % 4) == 0), "layernorm_bwd: pair output wants fp32 rows");
     uint16_t* dxp = reinterpret_cast<uint16_t*>(dx_pair);
     XVA_CHECK_ARG(C == 384 || C == 256, "layernorm: C must be 384 or 256 (got %d)", C);
     XVA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both null");
@@ -637,7 +650,7 @@ __global__ void colsum2_kernel(const void* __restrict__ X, int dt, float* __rest
     const int c = blockIdx.x * 128 + 2 * lane;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    if (dt == XVA_BF16 && C % 8 == 0 && ld % 8 == 0 && ((uintptr_t)X % 16) == 0) {
+    if ((dt == XVA_BF16 || dt == XVA_F16) && C % 8 == 0 && ld % 8 == 0 && ((uintptr_t)X % 16) == 0) {
         // 16-byte loads: a lane owns 8 columns, 16 lanes the 128-column tile, a wave instruction 4 rows, 8 instructions in flight
         const int c8 = blockIdx.x * 128 + (lane & 15) * 8;
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -646,7 +659,10 @@ __global__ void colsum2_kernel(const void* __restrict__ X, int dt, float* __rest
             auto add = [&](const uint4& q) {
                 const uint32_t u[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { a[2 * e] += __uint_as_float(u[e] << 16); a[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+                for (int e = 0; e < 4; ++e) {
+                    if (dt == XVA_F16) { const xva_h2 h = __builtin_bit_cast(xva_h2, u[e]); a[2 * e] += (float)h[0]; a[2 * e + 1] += (float)h[1]; }
+                    else { a[2 * e] += __uint_as_float(u[e] << 16); a[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+                }
             };
             int64_t r = r0 + w * 4 + (lane >> 4);
             for (; r + 112 < r1; r += 128) {
@@ -1142,6 +1158,12 @@ __global__ void cast_bf16x8_kernel(const float4* __restrict__ src, uint4* __rest
         dst[i] = o;
     }
 }
+__global__ void cast_f16x8_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = src[2 * i], b = src[2 * i + 1];
+        dst[i] = make_uint4(pk_f16(a.x, a.y), pk_f16(a.z, a.w), pk_f16(b.x, b.y), pk_f16(b.z, b.w));
+    }
+}
 // dst += src (activation dtype, element pairs; n even)
 __global__ void add_act_kernel(void* __restrict__ dst, const void* __restrict__ src, int dt, int64_t npairs) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1160,10 +1182,10 @@ extern "C" int xva_fp_add_act(void* dst, const void* src, int dt, int64_t n, voi
 }
 extern "C" int xva_cast_f32(const float* src, void* dst, int dt, int64_t n, void* stream) {
     XVA_CHECK_ARG(src && dst, "cast: null");
-    if (dt == XVA_BF16 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 && n >= 8) {
+    if ((dt == XVA_BF16 || dt == XVA_F16) && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 && n >= 8) {
         const int64_t n8 = n / 8;
         int g8 = (int)((n8 + 255) / 256); if (g8 > 8192) g8 = 8192;
-        hipLaunchKernelGGL(cast_bf16x8_kernel, dim3(g8), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst), n8);
+        hipLaunchKernelGGL(dt == XVA_F16 ? cast_f16x8_kernel : cast_bf16x8_kernel, dim3(g8), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst), n8);
         if (n % 8 == 0) { XVA_LAUNCH_CHECK(); return XVA_OK; }
         src += n8 * 8; dst = reinterpret_cast<uint16_t*>(dst) + n8 * 8; n -= n8 * 8;
     }
@@ -1213,6 +1235,7 @@ __global__ void split_bf16x8_kernel(const float4* __restrict__ src, uint4* __res
     }
 }
 extern "C" int xva_split_bf16(const float* src, void* dst, int64_t plane, int64_t n, void* stream) {
+    if (plane == 0) return xva_cast_f32(src, dst, XVA_F16, n, stream);      // one IEEE-half tensor instead of a pair
     XVA_CHECK_ARG(src && dst && n >= 0 && n % 8 == 0 && plane % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "split_bf16: n and the plane offset must be multiples of 8, pointers 16-byte aligned");
     if (n == 0) return XVA_OK;
     const int64_t n8 = n / 8;
@@ -1229,7 +1252,7 @@ extern "C" int xva_split_bf16(const float* src, void* dst, int64_t plane, int64_
 // row segments; measured 172 us against 138 us for FastPitch's conv2 backward-data, and 1.75x the algorithmic fetch).  One launch for up to 16
 // tensors; a 32 x 32 tile is transposed through LDS (coalesced 128-byte reads along Cin, 64-byte writes along Cout).
 struct xva_wt_batch { int64_t src[16]; int64_t dst[16]; int n; };
-__global__ __launch_bounds__(256) void wt_transpose3_kernel(const float* __restrict__ params, uint16_t* __restrict__ out, xva_wt_batch bt, int Cout, int Cin, int64_t plane) {
+__global__ __launch_bounds__(256) void wt_transpose3_kernel(const float* __restrict__ params, uint16_t* __restrict__ out, xva_wt_batch bt, int Cout, int Cin, int64_t plane, int dt16) {
     __shared__ float tile[32][33];
     const int which = blockIdx.z / 3, tap = blockIdx.z % 3;
     const float* src = params + bt.src[which];
@@ -1248,18 +1271,18 @@ __global__ __launch_bounds__(256) void wt_transpose3_kernel(const float* __restr
         if (n < Cin && co < Cout) {
             const int64_t o = ((int64_t)n * 3 + (2 - tap)) * Cout + co;
             const float v = tile[tx][r];
-            a_st(dst, o, XVA_BF16, v);
+            a_st(dst, o, dt16, v);
             if (plane) a_st(dst, o + plane, XVA_BF16, v - a_ld(dst, o, XVA_BF16));          // the lo plane of a split-bf16 pair
         }
     }
 }
-static int wt_transpose3(const float* params, void* out, const int64_t* src_off, const int64_t* dst_off, int n, int Cout, int Cin, int64_t plane, void* stream) {
+static int wt_transpose3(const float* params, void* out, const int64_t* src_off, const int64_t* dst_off, int n, int Cout, int Cin, int64_t plane, void* stream, int dt16 = XVA_BF16) {
     XVA_CHECK_ARG(params && out && src_off && dst_off && n >= 1 && n <= 16, "wt_transpose3: bad arguments");
     xva_wt_batch bt;
     bt.n = n;
     for (int i = 0; i < n; ++i) { bt.src[i] = src_off[i]; bt.dst[i] = dst_off[i]; }
     hipLaunchKernelGGL(wt_transpose3_kernel, dim3(xva_cdiv(Cin, 32), xva_cdiv(Cout, 32), 3 * n), dim3(256), 0, (hipStream_t)stream, params,
-                       reinterpret_cast<uint16_t*>(out), bt, Cout, Cin, plane);
+                       reinterpret_cast<uint16_t*>(out), bt, Cout, Cin, plane, dt16);
     XVA_LAUNCH_CHECK();
     return XVA_OK;
 }
@@ -1268,7 +1291,8 @@ extern "C" int xva_fp_wt_transpose3(const float* params, void* out, const int64_
 }
 // the same as a split-bf16 pair: the lo plane `plane` elements after the hi plane
 extern "C" int xva_fp_wt_transpose3_planes(const float* params, void* out, const int64_t* src_off, const int64_t* dst_off, int n, int Cout, int Cin, int64_t plane, void* stream) {
-    XVA_CHECK_ARG(plane > 0, "wt_transpose3_planes: plane offset");
+    XVA_CHECK_ARG(plane >= 0, "wt_transpose3_planes: plane offset");
+    if (plane == 0) return wt_transpose3(params, out, src_off, dst_off, n, Cout, Cin, 0, stream, XVA_F16);      // one IEEE-half tensor instead of a pair
     return wt_transpose3(params, out, src_off, dst_off, n, Cout, Cin, plane, stream);
 }
 

@@ -9,6 +9,8 @@ void xva_gemm_launch_mixed(const xva_gemm_params& p, int bn, unsigned nblocks, h
 void xva_gemm_launch_split(const xva_gemm_params& p, int bn, unsigned nblocks, hipStream_t st);
 bool xva_gemm_glds_eligible(const xva_gemm_params& p);
 int xva_gemm_launch_glds(const xva_gemm_params& p, int tile, hipStream_t st);
+int xva_gemm_launch_glds_f16(const xva_gemm_params& p, int tile, hipStream_t st);
+int xva_gemm_launch_conv_res_f16(const xva_gemm_params& p, int dstep, hipStream_t st);
 void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn);
 int xva_gemm_conv_res_plan(const xva_gemm_params& p, int* stride_out = nullptr, int64_t* rowpitch_out = nullptr);
 int xva_gemm_launch_conv_res(const xva_gemm_params& p, int dstep, hipStream_t st);
@@ -49,10 +51,17 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     if (p.splitk < 1) p.splitk = 1;
     XVA_CHECK_ARG(p.layout >= 0 && p.layout <= 2, "xva_gemm: bad layout");
     XVA_CHECK_ARG(p.a_dtype == p.b_dtype, "xva_gemm: A and B must share a storage dtype");
-    XVA_CHECK_ARG(p.a_dtype == XVA_F32 || p.a_dtype == XVA_BF16, "xva_gemm: bad operand dtype");
+    XVA_CHECK_ARG(p.a_dtype == XVA_F32 || p.a_dtype == XVA_BF16 || p.a_dtype == XVA_F16, "xva_gemm: bad operand dtype");
+    {   // one 16-bit format per problem
+        const int h = p.a_dtype != XVA_F32 ? p.a_dtype : XVA_BF16;
+        auto ok16 = [&](int dt) { return dt == XVA_F32 || dt == h; };
+        XVA_CHECK_ARG(ok16(p.c_dtype) && (!p.R || ok16(p.r_dtype)) && (!p.G || ok16(p.g_dtype)) && (p.a_dtype != XVA_F32 || p.c_dtype != XVA_F16),
+                      "xva_gemm: the 16-bit tensors of one problem (A, B, C, R, G) must share a format (bf16 or fp16)");
+        XVA_CHECK_ARG(p.a_dtype != XVA_F16 || (!p.planes && !p.c_plane && !p.colsum_out), "xva_gemm: fp16 operands take no split planes / colsum_out");
+    }
     XVA_CHECK_ARG(p.compute >= 0 && p.compute <= 2, "xva_gemm: compute must be 0 (fp32), 1 (bf16) or 2 (split-bf16 products of fp32 operands)");
     XVA_CHECK_ARG(!((p.compute == 0 || p.compute == 2) && p.a_dtype != XVA_F32), "xva_gemm: the fp32 pipes (exact, split products) need fp32-stored operands");
-    const int ve = p.a_dtype == XVA_BF16 ? 8 : 4;
+    const int ve = p.a_dtype != XVA_F32 ? 8 : 4;
     XVA_CHECK_ARG(p.lda % ve == 0 && p.ldb % ve == 0, "xva_gemm: lda/ldb must be multiples of %d (lda=%ld ldb=%ld)", ve,
                   (long)p.lda, (long)p.ldb);
     XVA_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0, "xva_gemm: operands must be 16-byte aligned");
@@ -83,7 +92,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     if (p.K == 0) p.splitk = 1;
     XVA_CHECK_ARG(!p.colsum_out || (auto_sk && p.layout == XVA_GEMM_TN && p.seglen > 0 && p.sk_ws && xva_gemm_wgrad_res_ok(p)),
                   "xva_gemm: colsum_out is honoured by the resident-operand weight-gradient kernel only (xva_gemm_takes_colsum)");
-    if (auto_sk && p.layout == XVA_GEMM_TN && p.seglen > 0 && p.sk_ws) {   // convolution weight gradient: resident-operand kernel (wgrad_res.h)
+    if (auto_sk && p.layout == XVA_GEMM_TN && p.seglen > 0 && p.sk_ws && p.a_dtype != XVA_F16) {   // convolution weight gradient: resident-operand kernel (wgrad_res.h)
         const bool prof = xva_prof_is_on();
         if (prof) xva_prof_begin((hipStream_t)stream, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + 1);
         int splits = 1;
@@ -177,30 +186,31 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (sk > nkt / 8) sk = nkt / 8;
         p.splitk = sk < 1 ? 1 : (int)sk;
     }
+    XVA_CHECK_ARG(p.a_dtype != XVA_F16 || glds_tile >= 0, "xva_gemm: fp16 operands run on the direct-to-LDS kernels only (K >= 16, 8-element granularity; set XVA_GEMM_GLDS != 0)");
     const int res_dstep = (glds_tile >= 0 && glds_env != 6) ? xva_gemm_conv_res_plan(p) : 0;   // mode 6: resident-input kernel off
     if (res_dstep != 0) bn = 900000 + p.a_seglen;
     long nblocks = glds_tile >= 0 ? 1 : (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2 * p.splitk;
     XVA_CHECK_ARG(nblocks < (1L << 31), "xva_gemm: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    const int mode = p.compute == 0 ? (g_fp32_products == 1 ? 3 : 0) : (p.compute == 2 ? 3 : (p.a_dtype == XVA_BF16 ? 1 : 2));
+    const int mode = p.compute == 0 ? (g_fp32_products == 1 ? 3 : 0) : (p.compute == 2 ? 3 : (p.a_dtype != XVA_F32 ? 1 : 2));
     const bool prof = xva_prof_is_on();
     if (prof) { xva_prof_begin(st, 2.0 * p.M * (double)p.N * p.K * p.batch * p.batch2, p.layout * 3 + (mode == 3 ? 0 : mode)); 
         // algorithmic bytes: each distinct element of A, B once (tap segments re-address the SAME rows/columns), C written (read too when
         // accumulating), residual and gate read
-        const double es_ab = p.a_dtype == XVA_BF16 ? 2.0 : 4.0, es_c = p.c_dtype == XVA_BF16 ? 2.0 : 4.0, nbz = (double)p.batch * p.batch2;
+        const double es_ab = p.a_dtype != XVA_F32 ? 2.0 : 4.0, es_c = p.c_dtype != XVA_F32 ? 2.0 : 4.0, nbz = (double)p.batch * p.batch2;
         double ua, ub;
         if (p.layout == XVA_GEMM_TN) { ua = (double)p.K * (p.a_seglen > 0 ? p.a_seglen : p.M); ub = (double)p.K * (p.seglen > 0 ? p.seglen : p.N); }
         else { ua = (double)p.M * (p.a_seglen > 0 ? p.a_seglen : p.K); ub = (double)p.N * p.K; }
         double by = (ua + ub) * es_ab + (double)p.M * p.N * es_c * (p.accumulate ? 2.0 : 1.0);
-        if (p.R) by += (double)p.M * p.N * (p.r_dtype == XVA_BF16 ? 2.0 : 4.0);
-        if (p.G) by += (double)p.M * p.N * (p.g_dtype == XVA_BF16 ? 2.0 : 4.0);
-        if (p.F) by += (double)p.M * p.N * (p.g_dtype == XVA_BF16 ? 2.0 : 4.0);
+        if (p.R) by += (double)p.M * p.N * (p.r_dtype != XVA_F32 ? 2.0 : 4.0);
+        if (p.G) by += (double)p.M * p.N * (p.g_dtype != XVA_F32 ? 2.0 : 4.0);
+        if (p.F) by += (double)p.M * p.N * (p.g_dtype != XVA_F32 ? 2.0 : 4.0);
         xva_prof_shape(p.M, p.N, p.K, p.batch * p.batch2, p.splitk, bn, by * nbz); }
     XVA_CHECK_ARG(!p.C2 || glds_tile >= 0, "xva_gemm: the second output is written by the direct-to-LDS kernels only (bf16 operands, K >= 64)");
     XVA_CHECK_ARG(!(p.planes || p.c_plane) || glds_tile >= 0, "xva_gemm: split-bf16 planes run on the direct-to-LDS kernels only (K >= 16, 8-element granularity)");
     if (res_dstep != 0) {   // conv over 32 / 64 / 128 channels (per group), stride 1 / 2 / 4: resident input tile
-        if (xva_gemm_launch_conv_res(p, res_dstep, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; }
-    } else if (glds_tile >= 0) { if (xva_gemm_launch_glds(p, glds_tile, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; } }
+        if ((p.a_dtype == XVA_F16 ? xva_gemm_launch_conv_res_f16(p, res_dstep, st) : xva_gemm_launch_conv_res(p, res_dstep, st)) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; }
+    } else if (glds_tile >= 0) { if ((p.a_dtype == XVA_F16 ? xva_gemm_launch_glds_f16(p, glds_tile, st) : xva_gemm_launch_glds(p, glds_tile, st)) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; } }
     else if (mode == 0) xva_gemm_launch_fp32(p, bn, (unsigned)nblocks, st);
     else if (mode == 3) xva_gemm_launch_split(p, bn, (unsigned)nblocks, st);
     else if (mode == 1) xva_gemm_launch_bf16(p, bn, (unsigned)nblocks, st);

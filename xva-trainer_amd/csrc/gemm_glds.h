@@ -26,6 +26,37 @@ using xva_gemm_impl::ld_elem;
 using xva_gemm_impl::lrelu;
 using xva_gemm_impl::pack_bf2;
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// ---- the two 16-bit formats ------------------------------------------------------------------------------------------------------
+// Every kernel of this header exists in two flavours: bf16 (F16 = false: v_mfma_f32_16x16x32_bf16) and IEEE half (F16 = true:
+// v_mfma_f32_16x16x32_f16 — the same rate, the same LDS images and DMA; 11 mantissa bits instead of 8).  All 16-bit tensors of one
+// problem (A, B and whichever of C / R / G / F are not fp32) share the flavour; the LDS bytes are format-agnostic, so only the MFMA
+// opcode and the fp32 <-> 16-bit conversions of the epilogue differ.
+__device__ __forceinline__ bool is16(int dtype) { return dtype != XVA_F32; }
+template <bool F16> __device__ __forceinline__ void unpack2(uint32_t w, float& a, float& b) {
+    if constexpr (F16) { const f16x2 h = __builtin_bit_cast(f16x2, w); a = (float)h[0]; b = (float)h[1]; }
+    else { a = __uint_as_float(w << 16); b = __uint_as_float(w & 0xffff0000u); }
+}
+template <bool F16> __device__ __forceinline__ uint32_t pack2(float a, float b) {      // round-to-nearest-even pair
+    if constexpr (F16) { const f16x2 h = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(uint32_t, h); }
+    else return pack_bf2(a, b);
+}
+template <bool F16> __device__ __forceinline__ float ld16(const void* p, int64_t idx) {
+    const uint16_t u = reinterpret_cast<const uint16_t*>(p)[idx];
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, u); else return bf2f(u);
+}
+template <bool F16> __device__ __forceinline__ uint16_t cvt16(float v) {
+    if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)v); else return f2bf(v);
+}
+template <bool F16> __device__ __forceinline__ float ld_any(const void* p, int64_t idx, int dtype) {
+    return is16(dtype) ? ld16<F16>(p, idx) : reinterpret_cast<const float*>(p)[idx];
+}
+template <bool F16> __device__ __forceinline__ f32x4 mma16(bf16x8 x, bf16x8 y, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+}
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define XVA_LDS __attribute__((address_space(3)))
@@ -163,14 +194,15 @@ struct IcReader {
 
 // LeakyReLU of an operand fragment (x -> x > 0 ? x : slope * x), the "activation fused into the consumer" of HiFi-GAN's
 // generator (models.py:62-66,115-126): applied to the 8 bf16 values a lane feeds to one MFMA
+template <bool F16 = false>
 __device__ __forceinline__ bf16x8 lrelu_frag(bf16x8 f, float slope) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 w = __builtin_bit_cast(u32x4, f);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if (w[e] & 0x80008000u) {   // at least one negative value in the pair
-            const float lo = lrelu(__uint_as_float(w[e] << 16), slope), hi = lrelu(__uint_as_float(w[e] & 0xffff0000u), slope);
-            w[e] = pack_bf2(lo, hi);
+            float lo, hi; unpack2<F16>(w[e], lo, hi);
+            w[e] = pack2<F16>(lrelu(lo, slope), lrelu(hi, slope));
         }
     }
     return __builtin_bit_cast(bf16x8, w);
@@ -199,7 +231,7 @@ __device__ __forceinline__ void apply_act(const xva_gemm_params& p, float (&v)[N
 // ---- epilogue -------------------------------------------------------------------------------------------------------------
 // v[0..3]: columns col .. col + 3 of row `row` (all inside N when VEC).  Order (include/xva_gemm.h):
 // v = alpha * (acc + bias) ; dropout ; gate ; + beta * R ; act ; row mask ; store / accumulate.
-template <bool VEC>
+template <bool VEC, bool F16 = false>
 __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int row, int col, bool live, bool lin_first, int z2,
                                           int64_t coff, int64_t roff, int64_t goff) {
     float v[4] = {a[0], a[1], a[2], a[3]};
@@ -218,32 +250,30 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
         float g[4] = {1.f, 1.f, 1.f, 1.f};
         const int64_t gi = goff + (int64_t)row * p.ldg + col;
         if (VEC) {
-            if (p.g_dtype == XVA_BF16) {
+            if (is16(p.g_dtype)) {
                 uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.G) + gi);
-                g[0] = __uint_as_float(r.x << 16); g[1] = __uint_as_float(r.x & 0xffff0000u);
-                g[2] = __uint_as_float(r.y << 16); g[3] = __uint_as_float(r.y & 0xffff0000u);
+                unpack2<F16>(r.x, g[0], g[1]); unpack2<F16>(r.y, g[2], g[3]);
             } else {
                 float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.G) + gi);
                 g[0] = r.x; g[1] = r.y; g[2] = r.z; g[3] = r.w;
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < nv) g[e] = ld_elem(p.G, gi + e, p.g_dtype);
+            for (int e = 0; e < 4; ++e) if (e < nv) g[e] = ld_any<F16>(p.G, gi + e, p.g_dtype);
         }
         if (p.F) {      // feature-matching term, before the gate: v += fm_c * sign(g - f)
             float f[4] = {0.f, 0.f, 0.f, 0.f};
             if (VEC) {
-                if (p.g_dtype == XVA_BF16) {
+                if (is16(p.g_dtype)) {
                     uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.F) + gi);
-                    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
-                    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+                    unpack2<F16>(r.x, f[0], f[1]); unpack2<F16>(r.y, f[2], f[3]);
                 } else {
                     float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.F) + gi);
                     f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (e < nv) f[e] = ld_elem(p.F, gi + e, p.g_dtype);
+                for (int e = 0; e < 4; ++e) if (e < nv) f[e] = ld_any<F16>(p.F, gi + e, p.g_dtype);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float df = g[e] - f[e]; v[e] += df > 0.f ? p.fm_c : (df < 0.f ? -p.fm_c : 0.f); }
@@ -255,17 +285,16 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
         const int64_t ri = roff + (int64_t)row * p.ldr + col;
         float r4[4] = {0.f, 0.f, 0.f, 0.f};
         if (VEC) {
-            if (p.r_dtype == XVA_BF16) {
+            if (is16(p.r_dtype)) {
                 uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.R) + ri);
-                r4[0] = __uint_as_float(r.x << 16); r4[1] = __uint_as_float(r.x & 0xffff0000u);
-                r4[2] = __uint_as_float(r.y << 16); r4[3] = __uint_as_float(r.y & 0xffff0000u);
+                unpack2<F16>(r.x, r4[0], r4[1]); unpack2<F16>(r.y, r4[2], r4[3]);
             } else {
                 float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.R) + ri);
                 r4[0] = r.x; r4[1] = r.y; r4[2] = r.z; r4[3] = r.w;
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < nv) r4[e] = ld_elem(p.R, ri + e, p.r_dtype);
+            for (int e = 0; e < 4; ++e) if (e < nv) r4[e] = ld_any<F16>(p.R, ri + e, p.r_dtype);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += p.beta * r4[e];
@@ -274,22 +303,21 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
     if (!live) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
     if (VEC && !p.c_trans) {
         const int64_t ci = coff + (int64_t)row * p.ldc + col;
-        if (p.c_dtype == XVA_BF16) {
+        if (is16(p.c_dtype)) {
             uint2* dst = reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + ci);
             if (p.accumulate) {
                 uint2 o = *dst;
-                v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
-                v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
+                float o4[4]; unpack2<F16>(o.x, o4[0], o4[1]); unpack2<F16>(o.y, o4[2], o4[3]);
+                v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3];
             }
-            const uint2 hi = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            const uint2 hi = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
             *dst = hi;
             if (p.c_plane) {      // the lo plane of a split-bf16 pair: bf16(v - hi)
-                const float l0 = v[0] - __uint_as_float(hi.x << 16), l1 = v[1] - __uint_as_float(hi.x & 0xffff0000u);
-                const float l2 = v[2] - __uint_as_float(hi.y << 16), l3 = v[3] - __uint_as_float(hi.y & 0xffff0000u);
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + ci + p.c_plane) = make_uint2(pack_bf2(l0, l1), pack_bf2(l2, l3));
+                float h4[4]; unpack2<F16>(hi.x, h4[0], h4[1]); unpack2<F16>(hi.y, h4[2], h4[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + ci + p.c_plane) = make_uint2(pack2<F16>(v[0] - h4[0], v[1] - h4[1]), pack2<F16>(v[2] - h4[2], v[3] - h4[3]));
             }
             if (p.C2) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C2) + ci) =
-                make_uint2(pack_bf2(lrelu(v[0], p.c2_slope), lrelu(v[1], p.c2_slope)), pack_bf2(lrelu(v[2], p.c2_slope), lrelu(v[3], p.c2_slope)));
+                make_uint2(pack2<F16>(lrelu(v[0], p.c2_slope), lrelu(v[1], p.c2_slope)), pack2<F16>(lrelu(v[2], p.c2_slope), lrelu(v[3], p.c2_slope)));
         } else {
             float* dst = reinterpret_cast<float*>(p.C) + ci;
             if (p.splitk > 1 || p.accumulate == 2) {
@@ -308,13 +336,13 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
         for (int e = 0; e < 4; ++e) {
             if (e >= nv) break;
             const int64_t ci = coff + (p.c_trans ? (int64_t)(col + e) * p.ldc + row : (int64_t)row * p.ldc + col + e);
-            if (p.c_dtype == XVA_BF16) {
+            if (is16(p.c_dtype)) {
                 uint16_t* dst = reinterpret_cast<uint16_t*>(p.C) + ci;
                 float x = v[e];
-                if (p.accumulate) x += bf2f(*dst);
-                *dst = f2bf(x);
-                if (p.c_plane) dst[p.c_plane] = f2bf(x - bf2f(f2bf(x)));
-                if (p.C2) reinterpret_cast<uint16_t*>(p.C2)[ci] = f2bf(lrelu(x, p.c2_slope));
+                if (p.accumulate) x += ld16<F16>(dst, 0);
+                *dst = cvt16<F16>(x);
+                if (p.c_plane) dst[p.c_plane] = cvt16<F16>(x - ld16<F16>(dst, 0));
+                if (p.C2) reinterpret_cast<uint16_t*>(p.C2)[ci] = cvt16<F16>(lrelu(x, p.c2_slope));
             } else {
                 float* dst = reinterpret_cast<float*>(p.C) + ci;
                 if (p.splitk > 1 || p.accumulate == 2) atomicAdd(dst, v[e]);
@@ -331,7 +359,7 @@ __device__ __forceinline__ void epilogue4(const xva_gemm_params& p, f32x4 a, int
 
 // ---- epilogue of one wave tile: acc[i][j][e] = C[rbase + i*16][cbase + j*16 + e]  (rbase includes lane & 15, cbase (lane >> 4) * 4)
 // (compile-time indices: a rolled loop would index `acc` dynamically and push the accumulators to scratch)
-template <int MI, int NJ>
+template <int MI, int NJ, bool F16 = false>
 __device__ __forceinline__ void tile_epilogue(const xva_gemm_params& p, f32x4 (&acc)[MI][NJ], int vec_epi, int rbase, int cbase, int z1, int z2,
                                               int bz, int ks) {
     const int64_t coff = (int64_t)z1 * p.sC + (int64_t)z2 * p.sC2;
@@ -360,7 +388,7 @@ __device__ __forceinline__ void tile_epilogue(const xva_gemm_params& p, f32x4 (&
                 static_for<NJ>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     const int col = cbase + j * 16;
-                    if (col < p.N) epilogue4<VEC>(p, a[j], row, col, live, lin_first, z2, coff, roff, goff);
+                    if (col < p.N) epilogue4<VEC, F16>(p, a[j], row, col, live, lin_first, z2, coff, roff, goff);
                 });
             }
         }
@@ -402,10 +430,11 @@ __device__ __forceinline__ void tile_epilogue(const xva_gemm_params& p, f32x4 (&
 // 16-byte bf16 loads / stores, full 128-byte row segments per wave, and all loads of a group of row blocks issued before its
 // first store.  Same operation order as epilogue4.  Host-verified (vec_epi == 2): N % 8 == 0, 8-element row alignment of C / R / G.
 // (residual / gate / accumulated-into tensors are bf16 here: 8 values = one 16-byte load; fp32 ones take the 4-column epilogue)
+template <bool F16 = false>
 __device__ __forceinline__ void unpack8(const uint4& raw, float (&o)[8]) {
     const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(w[e] << 16); o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    for (int e = 0; e < 4; ++e) unpack2<F16>(w[e], o[2 * e], o[2 * e + 1]);
 }
 __device__ __forceinline__ uint4 load8(const void* base, int64_t idx) { return *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + idx); }
 
@@ -418,7 +447,7 @@ __device__ __forceinline__ void wave_lds_order() {
     asm volatile("" ::: "memory");
 }
 
-template <int MI, int NJ>
+template <int MI, int NJ, bool F16 = false>
 __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32x4 (&acc)[MI][NJ], XVA_LDS float* scr, int r0, int c0, int lane,
                                                    int z1, int z2, int bz, int ks, int nt_store = 0) {
     constexpr int WN = NJ * 16, PITCH = WN + 4, LPR = WN / 8, RPP = 64 / LPR, NPASS = 16 / RPP;
@@ -488,9 +517,9 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                     for (int e = 0; e < 8; ++e) v[e] *= xva_dropout_scale(p.drop_p, p.drop_seed, p.drop_stream, (uint64_t)row * p.N + col + e);
                 }
                 if (want_g) {
-                    float g[8]; unpack8(graw[q], g);
+                    float g[8]; unpack8<F16>(graw[q], g);
                     if (want_f) {      // feature-matching term, before the gate
-                        float f[8]; unpack8(fraw[q], f);
+                        float f[8]; unpack8<F16>(fraw[q], f);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { const float df = g[e] - f[e]; v[e] += df > 0.f ? p.fm_c : (df < 0.f ? -p.fm_c : 0.f); }
                     }
@@ -498,7 +527,7 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                     for (int e = 0; e < 8; ++e) v[e] = g[e] > 0.f ? v[e] : v[e] * p.gate_slope;
                 }
                 if (want_r) {
-                    float r8[8]; unpack8(rraw[q], r8);
+                    float r8[8]; unpack8<F16>(rraw[q], r8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += p.beta * r8[e];
                 }
@@ -516,24 +545,24 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                     }
                 }
                 if (want_c) {
-                    float o[8]; unpack8(craw[q], o);
+                    float o[8]; unpack8<F16>(craw[q], o);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += o[e];
                 }
                 const int64_t ci = coff + (int64_t)row * p.ldc + col;
-                if (p.c_dtype == XVA_BF16) {
+                if (is16(p.c_dtype)) {
                     if (nt_store) {      // a streamed output (larger than the L2s): do not evict the operand panels the next rounds re-read
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                        const u32x4 pk = {pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7])};
                         __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.C) + ci));
                     } else {
-                        const uint4 hi = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                        const uint4 hi = make_uint4(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7]));
                         *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + ci) = hi;
                         if (p.c_plane) {      // the lo plane of a split-bf16 pair
-                            float hv[8]; unpack8(hi, hv);
+                            float hv[8]; unpack8<F16>(hi, hv);
                             *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + ci + p.c_plane) =
-                                make_uint4(pack_bf2(v[0] - hv[0], v[1] - hv[1]), pack_bf2(v[2] - hv[2], v[3] - hv[3]), pack_bf2(v[4] - hv[4], v[5] - hv[5]),
-                                           pack_bf2(v[6] - hv[6], v[7] - hv[7]));
+                                make_uint4(pack2<F16>(v[0] - hv[0], v[1] - hv[1]), pack2<F16>(v[2] - hv[2], v[3] - hv[3]), pack2<F16>(v[4] - hv[4], v[5] - hv[5]),
+                                           pack2<F16>(v[6] - hv[6], v[7] - hv[7]));
                         }
                     }
                 } else {
@@ -543,9 +572,9 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                 if (p.C2) {   // the activated copy next to the raw one
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = lrelu(v[e], p.c2_slope);
-                    if (p.c_dtype == XVA_BF16) {
+                    if (is16(p.c_dtype)) {
                         *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C2) + ci) =
-                            make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                            make_uint4(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7]));
                     } else {
                         float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C2) + ci);
                         dst[0] = make_float4(v[0], v[1], v[2], v[3]); dst[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -563,7 +592,7 @@ __device__ __forceinline__ bool rows_epilogue_ok(const xva_gemm_params& p, int v
     if (p.c_trans) return false;
     if (!slab && p.c_dtype == XVA_F32 && (p.splitk > 1 || p.accumulate == 2)) return false;
     if (!slab && p.splitk > 1) return false;
-    if (!slab && ((p.R && p.r_dtype != XVA_BF16) || (p.G && p.g_dtype != XVA_BF16) || (p.accumulate && p.c_dtype != XVA_BF16))) return false;
+    if (!slab && ((p.R && !is16(p.r_dtype)) || (p.G && !is16(p.g_dtype)) || (p.accumulate && !is16(p.c_dtype)))) return false;
     return true;
 }
 constexpr int epi_scratch_bytes(int WN) { return 16 * (WN + 4) * 4; }
@@ -571,7 +600,7 @@ constexpr int epi_scratch_bytes(int WN) { return 16 * (WN + 4) * 4; }
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
 // vec_epi: 1 = host-verified that N % 4 == 0 and C / R / G rows are 4-element aligned (vector epilogue allowed); 2 = 8-element
 // granularity as well (row-contiguous epilogue through LDS)
-template <int LAYOUT, int BM, int BN, int WM, int WN>
+template <int LAYOUT, int BM, int BN, int WM, int WN, bool F16 = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2 > 80 * 1024) ? 1 : (BM * BN >= 128 * 128 ? 2 : 3)) void xva_gemm_glds_kernel(xva_gemm_params p, int vec_flags) {
     const int vec_epi = vec_flags & 15, nt_store = vec_flags >> 4;     // bit 4: non-temporal C stores (gemm_glds.hip)
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
@@ -687,11 +716,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
         for (int j = 0; j < NJ; ++j) bfr[j] = frag_value(bfrr[j]);
         if (p.a_lrelu) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
+            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag<F16>(af[i], p.a_slope);
         }
         if (p.b_lrelu) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag(bfr[j], p.b_slope);
+            for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag<F16>(bfr[j], p.b_slope);
         }
         if constexpr (XVA_GLDS_ABLATE & 1) {
 #pragma unroll
@@ -704,7 +733,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // swapped: lane = 4 columns of a row
+                acc[i][j] = mma16<F16>(bfr[j], af[i], acc[i][j]);   // swapped: lane = 4 columns of a row
     };
     if (kt_begin < kt_end) issue(kt_begin, 0);
     if (kt_begin + 1 < kt_end) { issue(kt_begin + 1, 1); __builtin_amdgcn_s_waitcnt(WAIT_YOUNGEST); }
@@ -736,9 +765,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
 #pragma unroll
             for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(acc[i][j]));
     } else if (rows_epilogue_ok(p, vec_epi))
-        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
+        tile_epilogue_rows<MI, NJ, F16>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
     else
-        tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
+        tile_epilogue<MI, NJ, F16>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
     XVA_T(3);
 }
 
@@ -820,7 +849,7 @@ struct KcReader32 {
 // 384-wide index-contiguous image is not laid out): the ring slots have the same 32 KiB (24 + 8), a phase is 10 fragment reads | 24 MFMAs, and the
 // two groups are the waves 0 - 3 / 4 - 7 (row quarters 0, 1 / 2, 3) — what matters is that every SIMD holds one wave of either group.  Before, that
 // tile ran the lock-step loop of xva_gemm_glds_kernel (1.78 us per 64-deep K tile against an MFMA floor of 0.74).
-template <int LAYOUT, int BM = 256, int BN = 256, int WM = 128, int WN = 64>
+template <int LAYOUT, int BM = 256, int BN = 256, int WM = 128, int WN = 64, bool F16 = false>
 __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params p, int vec_flags) {
     const int vec_epi = vec_flags & 15, nt_store = vec_flags >> 4;     // bit 4: non-temporal C stores (gemm_glds.hip)
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
@@ -995,11 +1024,11 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
         for (int j = 0; j < NJ; ++j) bfr[j] = frag_value(bfrr[j]);
         if (p.a_lrelu) {                                         // one uniform branch per read slot
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
+            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag<F16>(af[i], p.a_slope);
         }
         if (p.b_lrelu) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag(bfr[j], p.b_slope);
+            for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag<F16>(bfr[j], p.b_slope);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
         XVA_BAR();
@@ -1014,7 +1043,7 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma16<F16>(bfr[j], af[i], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
         }
         XVA_BAR();
@@ -1024,9 +1053,9 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
 #undef XVA_BAR
     XVA_T(2);
     if (rows_epilogue_ok(p, vec_epi))
-        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
+        tile_epilogue_rows<MI, NJ, F16>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
     else
-        tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
+        tile_epilogue<MI, NJ, F16>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
     XVA_T(3);
 }
 
@@ -1039,7 +1068,7 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
 // KC image: [ROWS][32 k] bf16 = 64-byte rows, 16-byte chunk c of row r at position c ^ f(r), f(r) = (4 - ((r >> 2) & 3)) & 3: the four
 // 16-lane groups of a ds_read_b128 fragment read ({rows v, 12 + v: chunk c}, {rows 4 + v, 8 + v: chunk c ^ 1}) each cover the 64 banks once.
 // IC image: the first 32 k-rows of the 64-deep image above (same swizzles, same transpose reads).
-template <int LAYOUT, int BM, int BN>
+template <int LAYOUT, int BM, int BN, bool F16 = false>
 __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void xva_gemm_glds3_kernel(xva_gemm_params p, int vec_epi) {
     constexpr int WM = 128, WN = 64;
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
@@ -1147,25 +1176,25 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void xva_gemm_glds3
         for (int j = 0; j < NJ; ++j) bfr[j] = frag_value(bfrr[j]);
         if (p.a_lrelu) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
+            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag<F16>(af[i], p.a_slope);
         }
         if (p.b_lrelu) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag(bfr[j], p.b_slope);
+            for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag<F16>(bfr[j], p.b_slope);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): the slot's fragments are in registers before this wave reaches the next barrier
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mma16<F16>(bfr[j], af[i], acc[i][j]);
         slot = slot == 2 ? 0 : slot + 1;
     }
     __builtin_amdgcn_s_barrier();               // the epilogue scratch overlays the ring
     if (rows_epilogue_ok(p, vec_epi))
-        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks);
+        tile_epilogue_rows<MI, NJ, F16>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks);
     else
-        tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
+        tile_epilogue<MI, NJ, F16>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
 }
 
 // ---- stride-1 convolution with a RESIDENT input tile ------------------------------------------------------------------------
@@ -1187,7 +1216,7 @@ template <int CIN> __device__ __forceinline__ int res_swz(int row) {
 #define XVA_CONV_RES_WAVES(BN) ((BN) <= 32 ? 5 : ((BN) <= 64 ? 3 : 2))
 #endif
 constexpr int res_a_bytes(int cin, int stride) { return (((stride * 128 + RES_HALO) * cin * 2) + 1023) & ~1023; }
-template <int LAYOUT, int CIN, int BN, int WM, int WN>
+template <int LAYOUT, int CIN, int BN, int WM, int WN, bool F16 = false>
 __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, XVA_CONV_RES_WAVES(BN)) void xva_conv_res_kernel(xva_gemm_params p, int vec_epi, int dstep, int stride,
                                                                                        int64_t rowpitch) {
     constexpr int BM = 128;
@@ -1272,7 +1301,7 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, XVA_CONV_RES_WAVES(BN)
         }
         if (p.a_lrelu) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag(af[i], p.a_slope);
+            for (int i = 0; i < MI; ++i) af[i] = lrelu_frag<F16>(af[i], p.a_slope);
         }
     };
     auto mfma_all = [&](const bf16x8 (&af)[MI], Frag<BKD> (&bfrr)[NJ]) {
@@ -1284,7 +1313,7 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, XVA_CONV_RES_WAVES(BN)
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mma16<F16>(bfr[j], af[i], acc[i][j]);
     };
     lb.issue(b_base(0), 0, p.K, smem + A_BYTES, wave);
     if (nkt > 1) { lb.issue(b_base(GK), GK, p.K, smem + A_BYTES + B_BYTES, wave); __builtin_amdgcn_s_waitcnt(WAIT_YOUNGEST); }
@@ -1310,19 +1339,19 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, XVA_CONV_RES_WAVES(BN)
     }
     XVA_T(2);
     if (rows_epilogue_ok(p, vec_epi))
-        tile_epilogue_rows<MI, NJ>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, z, 0);
+        tile_epilogue_rows<MI, NJ, F16>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, z, 0);
     else
-        tile_epilogue<MI, NJ>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, z, 0);
+        tile_epilogue<MI, NJ, F16>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, z, 0);
     XVA_T(3);
 }
 
-template <int LAYOUT, int CIN, int BN, int WM, int WN>
+template <int LAYOUT, int CIN, int BN, int WM, int WN, bool F16 = false>
 inline int launch_conv_res(const xva_gemm_params& p, int vec_epi, int dstep, int stride, int64_t rowpitch, hipStream_t st) {
     constexpr int LDS_FULL = res_a_bytes(CIN, 4) + 2 * BN * GK * 2;
     constexpr int LDS_MAX = LDS_FULL > 160 * 1024 ? 160 * 1024 : LDS_FULL;      // the plan never admits a (CIN, stride) pair beyond the 160 KiB of a CU
     if (res_a_bytes(CIN, stride) + 2 * BN * GK * 2 > LDS_MAX) return -1;
     const int LDS = res_a_bytes(CIN, stride) + 2 * BN * GK * 2;
-    auto kern = xva_conv_res_kernel<LAYOUT, CIN, BN, WM, WN>;
+    auto kern = xva_conv_res_kernel<LAYOUT, CIN, BN, WM, WN, F16>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess) return -1;
@@ -1333,10 +1362,10 @@ inline int launch_conv_res(const xva_gemm_params& p, int vec_epi, int dstep, int
     return 0;
 }
 
-template <int LAYOUT, int BM, int BN>
+template <int LAYOUT, int BM, int BN, bool F16 = false>
 inline int launch_tile3(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
     constexpr int LDS = 3 * (BM + BN) * GK3 * 2;
-    auto kern = xva_gemm_glds3_kernel<LAYOUT, BM, BN>;
+    auto kern = xva_gemm_glds3_kernel<LAYOUT, BM, BN, F16>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
@@ -1347,10 +1376,10 @@ inline int launch_tile3(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
     return 0;
 }
 
-template <int LAYOUT, int BM = 256, int BN = 256, int WM = 128, int WN = 64>
+template <int LAYOUT, int BM = 256, int BN = 256, int WM = 128, int WN = 64, bool F16 = false>
 inline int launch_tile8(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
     constexpr int LDS = XVA_GLDS8_SLOTS * (BM + BN) * GK3 * 2;
-    auto kern = xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN>;
+    auto kern = xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
@@ -1361,11 +1390,11 @@ inline int launch_tile8(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
     return 0;
 }
 
-template <int LAYOUT, int BM, int BN, int WM, int WN>
+template <int LAYOUT, int BM, int BN, int WM, int WN, bool F16 = false>
 inline int launch_tile(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int LDS = 2 * (BM + BN) * GK * 2;
-    auto kern = xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN>;
+    auto kern = xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN, F16>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;

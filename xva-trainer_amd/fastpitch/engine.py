@@ -62,7 +62,12 @@ lib.xva_fp_infer_encode.argtypes = [C.POINTER(FpDims), vp, C.POINTER(FpBatch), f
 lib.xva_fp_infer_decode.restype = i32
 lib.xva_fp_infer_decode.argtypes = [C.POINTER(FpDims), vp, vp, vp, vp, vp, i64, vp, vp]
 
-COMPUTE = {"fp32": 0, "bf16": 1, 0: 0, 1: 1}
+# "f16" (round 6): IEEE-half MFMA operands (v_mfma_f32_16x16x32_f16) over an fp32 residual stream — the storage plan of "fp32" with every operand copy a
+# single half tensor; the cheapest format found whose OUTPUTS stay within 1e-3 of the fp32 reference (profiles/r06_precision_probe.txt).  Its activation
+# gradients live in fp16 buffers too, so the loss gradient is multiplied by `FastPitchEngine.loss_scale` (a power of two, as the reference's GradScaler does
+# for its fp16 autocast path: python/fastpitch1_1/xva_train.py:350,856-859): flat_grads then hold loss_scale x gradient — pass `inv_scale = 1 / loss_scale`
+# to Lamb.step (which unscales before clipping) or read `unscaled(flat_grads)`.
+COMPUTE = {"fp32": 0, "bf16": 1, "f16": 2, 0: 0, 1: 1, 2: 2}
 ACT_SLOTS = {"MEL_OUT", "D_MEL", "ENC_OUT", "DEC_OUT", "ENC_COND"}   # stored in the activation dtype (bf16 when compute == bf16)
 
 
@@ -125,7 +130,10 @@ class FastPitchEngine:
         if self.device.type != "cuda":
             raise _lib.XvaError("FastPitchEngine needs a GPU device; the hot path has no CPU implementation")
         self.compute = COMPUTE[compute]
-        self.act_dtype = torch.bfloat16 if self.compute else torch.float32
+        self.act_dt = 1 if self.compute == 1 else 0          # XVA_BF16 / XVA_F32: the dtype of the workspace's activation slots
+        self.act_dtype = torch.bfloat16 if self.compute == 1 else torch.float32
+        self.loss_scale = 1.0                                 # "f16" only: see set_loss_scale / auto_loss_scale
+        self.auto_loss_scale = self.compute == 2
         self.p_dropout = float(p_dropout)
         self.seed = int(seed)
         self.step = 0
@@ -136,6 +144,29 @@ class FastPitchEngine:
         self._dims = None
         self._pos = None
         self._slot_off = {}
+
+    # -- loss scale of the fp16-operand mode -------------------------------------------------
+    def set_loss_scale(self, scale):
+        """Fix the loss scale (a power of two) and stop choosing it per batch."""
+        import math
+        m, _ = math.frexp(float(scale))
+        if m != 0.5 or scale <= 0:
+            raise ValueError("loss scale must be a positive power of two (exact in every format)")
+        self.loss_scale, self.auto_loss_scale = float(scale), False
+
+    def _choose_loss_scale(self, b):
+        """The scale that brings the mel loss's seed gradient 2 (mel_out - mel_tgt) / #(mel_tgt != 0) to O(1): the power of two next to the (upper bound of
+        the) denominator B * Tm * 80, from the batch geometry alone — no device read-back.  Measured on the oracle (profiles/r06_precision_probe.txt): stored
+        activation gradients then peak near 2^7 with the median near 2, against fp16's 2^-14 .. 2^16 normal range."""
+        import math
+        return float(2 ** max(0, int(round(math.log2(max(1, b.B * b.Tm * 80))))))
+
+    @property
+    def grad_inv_scale(self):
+        return 1.0 / self.loss_scale
+
+    def unscaled(self, flat_grads):
+        return flat_grads if self.loss_scale == 1.0 else flat_grads * (1.0 / self.loss_scale)
 
     # -- workspace ---------------------------------------------------------------------
     def _prepare(self, B, Tt, Tm, stage):
@@ -177,7 +208,7 @@ class FastPitchEngine:
         activation dtype without the two structural pad rows (slots 100 + l / 200 + l of xva_fp_slot_offset)."""
         off = i64()
         _lib.check(lib.xva_fp_slot_offset(C.byref(self._dims), (100 if stack == "encoder" else 200) + int(l), C.byref(off)), "xva_fp_slot_offset")
-        nb = B * (T + 2) * 384 * (2 if self.compute else 4)
+        nb = B * (T + 2) * 384 * (2 if self.compute == 1 else 4)
         return self._ws[off.value:off.value + nb].view(self.act_dtype).view(B, T + 2, 384)[:, 1:T + 1]
 
     def _abi_batch(self, b):
@@ -206,13 +237,15 @@ class FastPitchEngine:
 
     def loss_partials(self, b, stage):
         args, sp = self._loss_args(b)
-        _lib.check(lib.xva_fp_loss_partials(int(stage), self.compute, *args, sp("LOSS_ACC"), b.B, b.Tt, b.Tm, _lib.stream_ptr()), "xva_fp_loss_partials")
+        _lib.check(lib.xva_fp_loss_partials(int(stage), self.act_dt, *args, sp("LOSS_ACC"), b.B, b.Tt, b.Tm, _lib.stream_ptr()), "xva_fp_loss_partials")
         return self.slot("LOSS_ACC", (8,))
 
     def loss_grads(self, b, stage, grad_scale=1.0, dur_w=0.1, pitch_w=0.1, energy_w=0.1):
         args, sp = self._loss_args(b)
-        _lib.check(lib.xva_fp_loss_grads(int(stage), self.compute, *args, sp("LOSS_ACC"), sp("LOSSES"), sp("D_MEL"), sp("D_PITCH"), sp("D_ENERGY"),
-                                         sp("D_LOGDUR"), b.B, b.Tt, b.Tm, grad_scale, dur_w, pitch_w, energy_w, _lib.stream_ptr()),
+        if self.auto_loss_scale:
+            self.loss_scale = self._choose_loss_scale(b)
+        _lib.check(lib.xva_fp_loss_grads(int(stage), self.act_dt, *args, sp("LOSS_ACC"), sp("LOSSES"), sp("D_MEL"), sp("D_PITCH"), sp("D_ENERGY"),
+                                         sp("D_LOGDUR"), b.B, b.Tt, b.Tm, grad_scale * self.loss_scale, dur_w, pitch_w, energy_w, _lib.stream_ptr()),
                    "xva_fp_loss_grads")
         return self.slot("LOSSES", (8,))
 
