@@ -12,6 +12,7 @@ Extra objects: "roofline" (MFMA GEMM, per-launch average from HIP events in an e
 "cpu_baseline" (the CPU oracle = our port of the reference step, timed on a bounded sample on this host's cores).
 """
 import argparse
+import math
 import ctypes as C
 import json
 import os
@@ -33,7 +34,8 @@ def parse():
     ap.add_argument("--t-text", type=int, default=150)
     ap.add_argument("--t-mel", type=int, default=860)
     ap.add_argument("--stage", type=int, default=3)
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32", "f16"])
+    ap.add_argument("--no-f16", action="store_true", help="skip the fp16-operand FastPitch leg (the mode whose outputs meet north_star's 1e-3: `value_at_tolerance`)")
     ap.add_argument("--hg-timeout", type=int, default=300, help="multi-rank runs: seconds after which the line is printed without the HiFi-GAN leg")
     ap.add_argument("--dropout", type=float, default=0.1, help="FastPitch dropout probability (reference trains with 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -693,6 +695,62 @@ def fastpitch_fp32_leg(a, dev, steps=5, warm=2):
     return res
 
 
+def fastpitch_f16_leg(a, dev):
+    """The same FastPitch step (batch, lengths, dropout, LAMB, learning-rate schedule of the headline loop) in the fp16-OPERAND mode (round 6):
+    v_mfma_f32_16x16x32_f16 on IEEE-half operand copies, the residual stream / LayerNorm inputs and outputs and their gradients in fp32, a power-of-two loss
+    scale over the fp16 gradient buffers with the optimizer unscaling and skipping non-finite steps on the device (the reference's own GPU arithmetic:
+    fp16 autocast + GradScaler, python/fastpitch1_1/xva_train.py:350,787,856-859).  The cheapest format found whose outputs stay within north_star's 1e-3 of
+    the fp32 reference (profiles/r06_precision_probe.txt); `parity` is measured here, in this mode, on the reference-recorded golden case."""
+    from xva_trainer_amd import synthetic
+    from xva_trainer_amd.fastpitch import engine as E, params as P
+    from xva_trainer_amd.fastpitch.lamb import Lamb
+    eng = E.FastPitchEngine(dev, "f16", p_dropout=a.dropout, seed=1234)
+    flat = torch.zeros(eng.total, device=dev)
+    P.default_init_(flat, eng.table, seed=1234)
+    grads = torch.zeros_like(flat)
+    opt = Lamb(flat, eng.table, lr=0.1, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6)
+    ranges = E.trainable_ranges(a.stage)
+    active = {t[0] for t in eng.table if any(b <= t[1] < e for b, e in ranges)}
+    batch = E.DeviceBatch.from_dict(synthetic.fastpitch_batch(a.batch, a.t_text, a.t_mel, 1234), dev)
+    frames = int(batch.mel_lens.sum().item())
+    it = [50000]
+    skipped = torch.zeros((), device=dev)
+
+    def step():
+        it[0] += 1
+        opt.param_groups[0]["lr"] = 0.1 / it[0] ** 0.5
+        grads.zero_()
+        eng.fwd_loss_bwd(flat, grads, batch, a.stage, grad_scale=1.0)
+        opt.step(grads, active, max_grad_norm=1000.0, inv_scale=eng.grad_inv_scale)
+        skipped.add_(opt.skipped)
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"metric": "mel-frames/sec (FastPitch1.1 train step, fp16 operands + fp32 residual stream)", "value": frames * a.steps / dt, "unit": "mel-frames/s",
+           "ms_per_step": 1000.0 * dt / a.steps, "steps": a.steps, "dtype": "f16", "final_loss": eng.slot("LOSSES", (8,)).cpu()[0].item(),
+           "loss_scale": eng.loss_scale, "skipped_steps": int(skipped.item()),
+           "config": {"workload": "FastPitch1.1 stage-%d full train step, batch %d, %d tokens x %d mel frames, dropout p=%g, fp16 MFMA operands, fp32 residual stream, loss scale 2^%d"
+                                  % (a.stage, a.batch, a.t_text, a.t_mel, a.dropout, int(round(math.log2(eng.loss_scale))))},
+           "tolerance": "outputs / losses within 1e-3 of the reference goldens and of the oracle (tests/test_f16_gpu.py, tests/test_fullsize_gpu.py)"}
+    if not a.no_roofline:
+        def run_profiled():
+            grads.zero_()
+            eng.fwd_loss_bwd(flat, grads, batch, a.stage)
+        res["roofline"] = gemm_roofline(run_profiled, 3, "mfma", 2500.0, "FastPitch fwd+bwd in the fp16-operand mode: 3 extra profiled passes (dense fp16 MFMA peak = the bf16 one)")
+    del eng, opt, grads, flat
+    torch.cuda.empty_cache()
+    try:
+        res["parity"] = golden_parity("fastpitch", "f16")
+    except Exception as e:
+        res["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run, one rank per GPU
     (the reference's DP entry is single-process nn.DataParallel, python/fastpitch1_1/xva_train.py:465-466; here N processes
@@ -981,7 +1039,8 @@ def _compact_leg(leg):
 def compact_line(out):
     """The stdout line: the contract keys verbatim, `roofline` / `cpu_baseline` reduced to their numbers, one small object per extra leg."""
     line = {}
-    for k in ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"]:
+    for k in ["metric", "value", "value_at_tolerance", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_at_tolerance", "tolerance_mode", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data"]:
         if k in out:
             line[k] = out[k]
     line["config"] = dict(out.get("config", {}))
@@ -996,7 +1055,7 @@ def compact_line(out):
         line["cpu_baseline"] = _compact_cpu(out["cpu_baseline"])
     if isinstance(out.get("hbm_kernels"), dict):
         line["hbm_kernels"] = {k: _pick(v, ["frac", "achieved", "avg_launch_us"]) for k, v in out["hbm_kernels"].items() if isinstance(v, dict)}
-    for k in ["hifigan", "xvapitch_c5", "fastpitch_split", "fastpitch_fp32_parity", "hifigan_fp32_parity"]:
+    for k in ["fastpitch_f16", "hifigan", "xvapitch_c5", "fastpitch_split", "fastpitch_fp32_parity", "hifigan_fp32_parity"]:
         if k in out:
             line[k] = _compact_leg(out[k])
     line["detail"] = out.get("detail_file", "bench_detail.json")
@@ -1087,7 +1146,7 @@ def main():
             eng.fwd_loss_bwd(flat, grads, batch, stage, grad_scale=1.0)
         else:
             sync.fwd_loss_bwd(batch, stage, grad_scale=1.0)
-        opt.step(grads, active, max_grad_norm=1000.0)
+        opt.step(grads, active, max_grad_norm=1000.0, inv_scale=eng.grad_inv_scale)
 
     def barrier():
         if world > 1:
@@ -1122,7 +1181,7 @@ def main():
         "dtype": a.compute, "data": "synthetic",
         "config": {"workload": "FastPitch1.1 stage-%d full train step (fwd+loss+bwd%s+clip+fused LAMB), batch %d/GPU, %d tokens x %d mel frames, dropout p=%g, %s activations"
                                % (stage, "+RCCL grad all-reduce" if world > 1 else "", a.batch, a.t_text, a.t_mel, a.dropout,
-                                  "bf16" if a.compute == "bf16" else "fp32"),
+                                  {"bf16": "bf16", "fp32": "fp32", "f16": "fp32 residual stream + fp16 operand"}[a.compute]),
                    "global_batch": a.batch * world, "per_gpu_frames_per_step": frames_per_step, "parallelism": "dp%d" % world,
                    "final_loss": loss},
     }
@@ -1138,7 +1197,7 @@ def main():
         def run_profiled():
             grads.zero_()
             eng.fwd_loss_bwd(flat, grads, batch, stage)
-        peak = 2500.0 if a.compute == "bf16" else 157.3
+        peak = 157.3 if a.compute == "fp32" else 2500.0
         out["roofline"] = gemm_roofline(run_profiled, 3, "mfma", peak,
                                         "FastPitch fwd+bwd: %d extra profiled passes after the timed region" % 3,
                                         pmc_csv=latest_profile("fastpitch_pmc_hbm_bytes.csv") if a.compute == "bf16" else None)
@@ -1150,6 +1209,18 @@ def main():
             out["roofline"]["frac_rocprof_detail"] = fr if fr else why
     if rank == 0 and not a.no_roofline:
         out["hbm_kernels"] = hbm_kernel_rooflines(dev, opt, grads, active, a.compute)
+    if rank == 0 and world == 1 and a.compute == "bf16" and not a.no_f16:
+        try:
+            out["fastpitch_f16"] = fastpitch_f16_leg(a, dev)
+            par = out["fastpitch_f16"].get("parity", {})
+            # the throughput of the cheapest mode whose OUTPUTS meet north_star's 1e-3 on the reference-recorded case, next to `value` (the bf16 mode BASELINE
+            # configs[1] names, whose outputs sit at 1e-2): null if the in-run parity measurement does not confirm it
+            ok = all(isinstance(par.get(k), float) and par[k] <= 1e-3 for k in ("mel_rel", "pitch_pred_rel", "loss_rel"))
+            out["value_at_tolerance"] = out["fastpitch_f16"]["value"] if ok else None
+            out["ms_per_step_at_tolerance"] = out["fastpitch_f16"]["ms_per_step"] if ok else None
+            out["tolerance_mode"] = "fastpitch_f16 (fp16 operands, fp32 residual stream): outputs and losses within 1e-3 of the reference"
+        except Exception as e:                               # an extra measurement: never at the price of the contract line
+            out["fastpitch_f16"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and a.compute == "bf16" and not a.no_fp32_parity:
         try:
             out["fastpitch_fp32_parity"] = fastpitch_fp32_leg(a, dev)

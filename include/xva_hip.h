@@ -144,7 +144,13 @@ typedef struct xva_fp_dims {
     int32_t Tt;       /* padded text length  (max_inp_lengths[0]) */
     int32_t Tm;       /* padded mel length   (max_mel_lengths[0]) */
     int32_t stage;    /* training stage 2, 3 or 4 (model.training_stage) */
-    int32_t compute;  /* 0: fp32 activations + exact fp32 MFMA (parity mode); 1: bf16 activations + bf16-input MFMA (fp32 accumulate) */
+    int32_t compute;  /* 0: fp32 activations + exact fp32 MFMA (parity mode); 1: bf16 activations + bf16-input MFMA (fp32 accumulate);
+                       * 2 (round 6): fp16 OPERANDS over an fp32 residual stream — the storage plan and slots of mode 0 (fp32 activation slots), every MFMA operand
+                       * (layer inputs, LayerNorm outputs, qkv, attention output, the feed-forward intermediate, their gradients, all weights) a single IEEE-half copy,
+                       * products on v_mfma_f32_16x16x32_f16: the arithmetic width of the reference's own fp16 autocast path (python/fastpitch1_1/xva_train.py:350,787)
+                       * and the cheapest format whose OUTPUTS stay within 1e-3 of the fp32 reference (profiles/r06_precision_probe.txt).  The activation-gradient
+                       * buffers are fp16 too: pass a power-of-two loss scale through xva_fp_loss_grads' grad_scale and its inverse through xva_lamb_step's inv_scale
+                       * (the reference's GradScaler, xva_train.py:856-859). */
     float p_dropout;  /* 0.1 in the reference's training mode (model.py:149-174: dropout, dropatt, predictor dropout); 0 = eval */
     uint64_t seed;    /* dropout seed of this micro-batch (forward and backward must pass the same value) */
 } xva_fp_dims;
@@ -276,7 +282,7 @@ int xva_fp_loss_grads(int stage, int dt, const void* mel_out, const float* mel_t
                       float* d_logdur, int B, int Tt, int Tm, float grad_scale, float dur_w, float pitch_w, float energy_w,
                       void* stream);
 
-/* Individual kernels of the path.  Activation tensors are `void*` of dtype dt (XVA_F32 / XVA_BF16); parameters, statistics
+/* Individual kernels of the path.  Activation tensors are `void*` of dtype dt (XVA_F32 / XVA_BF16; the element-wise ones — cast, colsum, add — also XVA_F16); parameters, statistics
  * and token-level scalars are fp32.  Dropout masks are a pure function of (seed, stream_id, element index). */
 int xva_fp_embed_fwd(const int32_t* ids, const float* emb, const float* pos, void* out, int dt, int B, int T, int C, void* stream);
 int xva_fp_embed_bwd(const int32_t* ids, const void* dX, int dt, float* dEmb, int B, int T, int C, void* stream);
@@ -284,6 +290,9 @@ int xva_fp_softmax_fwd(void* S, void* P_dropped, int dt, const int32_t* lens, in
                        uint32_t stream_id, void* stream);
 int xva_fp_softmax_bwd(const void* P, void* dP, int dt, int B, int Tp, int64_t Ts, float scale, float p_drop, uint64_t seed,
                        uint32_t stream_id, void* stream);
+/* PAIR OUTPUTS AND THE fp16-OPERAND MODE (round 6).  Every `*_pair` / `*_pairs` / `*_planes` entry point below (and xva_split_bf16) takes the distance between
+ * the hi and the lo plane in ELEMENTS.  A distance of 0 selects the single-plane form: the tensor is ONE IEEE-half tensor (XVA_F16) at the hi plane's address and
+ * no lo plane is read or written — the operand format of FastPitch's compute mode 2, whose products are plain one-pass xva_gemm calls on XVA_F16 operands. */
 /* LayerNorm on fp32 rows that ALSO leaves its output as a split-bf16 pair (hi plane at *_pair, lo plane pair_plane ELEMENTS after it; rows 0 .. rows - 1 of each
  * plane — guard rows are the caller's): the operand of the next `planes` product without a split launch.  Backward: the pair is the gradient entering the
  * dropout-ed branch (dX * m_out; dX itself when p_out == 0); dXm (fp32) may be null. */
@@ -355,6 +364,8 @@ int xva_zero_spans(void* const* ptrs, const int64_t* bytes, int n, void* stream)
 int xva_fp_add_act(void* dst, const void* src, int dt, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------ optimizers ---- */
+/* (scal: >= 4 device floats: [1] the applied clip coefficient x inv_scale, [2] the pre-clip global gradient norm, [3] 1 when that norm was not finite and the step
+ * was SKIPPED on the device — moments and parameters untouched, as torch.cuda.amp.GradScaler.step does for the reference's fp16 path — else 0.) */
 /* Fused multi-tensor LAMB over the flat buffers = torch.nn.utils.clip_grad_norm_(.., max_grad_norm) followed by
  * Lamb.step (python/fastpitch1_1/lamb.py:40-106; call site xva_train.py:853-862).  Chunk descriptors come from
  * xva_opt_build_chunks (host) and list only the tensors that received a gradient this stage (Lamb skips

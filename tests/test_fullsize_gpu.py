@@ -208,9 +208,11 @@ def test_hifigan_full_size_bf16_step_is_the_weighted_sum_of_its_items():
                 assert ((full[key][b:e].double() - ref[b:e]).norm().item() / nb) < 1e-2, (key, b)
 
 
-@pytest.mark.parametrize("products", ["exact", "split_planes"])
+@pytest.mark.parametrize("products", ["exact", "split_planes", "f16"])
 def test_fastpitch_full_length_against_the_oracle(products):
-    """(split_planes, round 5: the same case with fp32 storage and split-bf16 products on the planes path — the feed-forward and attention products of every layer as
+    """(f16, round 6: the fp16-operand mode — the same schedule on single IEEE-half operand tensors and one-pass v_mfma_f32_16x16x32_f16 products, an fp32 residual
+    stream, loss-scaled fp16 gradient buffers: outputs and loss at north_star's 1e-3, the whole gradient at 5e-3.)
+    (split_planes, round 5: the same case with fp32 storage and split-bf16 products on the planes path — the feed-forward and attention products of every layer as
     three-pass `planes` launches at the full 862-row key count, the 1 724-row reductions of the weight gradients; outputs and loss at north_star's 1e-3, the whole
     gradient at 2e-3.)
     The CPU oracle AT FULL LENGTH: B = 2 clips of 150 tokens x 860 frames (BASELINE configs[1]'s sequence lengths: 14 key blocks in
@@ -235,11 +237,13 @@ def test_fastpitch_full_length_against_the_oracle(products):
     from xva_trainer_amd import _lib
     old_mode = _lib.lib.xva_gemm_set_fp32_products(1 if products == "split_planes" else 0)
     try:
-        eng, flat, grads = build_engine(sd, "fp32")
+        eng, flat, grads = build_engine(sd, "f16" if products == "f16" else "fp32")
         b = DeviceBatch.from_dict(batch, "cuda")
         grads.zero_()
         losses = eng.fwd_loss_bwd(flat, grads, b, stage).cpu()
         out = eng.outputs(b, stage)
+        if products == "f16":
+            grads.mul_(eng.grad_inv_scale)
     finally:
         _lib.lib.xva_gemm_set_fp32_products(old_mode)
     assert rel(out["mel_out"], out_ref[0]) < 1e-3
@@ -247,6 +251,15 @@ def test_fastpitch_full_length_against_the_oracle(products):
     assert rel(out["energy_pred"], out_ref[6]) < 1e-3
     assert torch.equal(out["dec_lens"].cpu().long(), batch["mel_lens"])
     assert abs(losses[0].item() - loss_ref.item()) < 1e-3 * abs(loss_ref.item())
+    if products == "f16":
+        from xva_trainer_amd.fastpitch import params as P
+        mine = P.from_flat(grads, eng.table)
+        a = torch.cat([mine[k].double().cpu().flatten() for k in ref_grads])
+        r = torch.cat([ref_grads[k].double().flatten() for k in ref_grads])
+        assert ((a - r).norm() / r.norm()).item() < 5e-3
+        bad, worst = grad_report(eng, grads, ref_grads, 4e-2)
+        assert not bad, bad[:10]
+        return
     if products == "split_planes":        # products carry ~1e-5 each: more gates within rounding of zero than in the exact mode (tests/test_fastpitch_gpu.py: 6e-3 on elements)
         from xva_trainer_amd.fastpitch import params as P
         mine = P.from_flat(grads, eng.table)

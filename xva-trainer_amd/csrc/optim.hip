@@ -41,6 +41,10 @@ __global__ void clip_coef_kernel(float* scal, float max_norm, float inv_scale) {
         float coef = max_norm / (norm + 1e-6f);
         scal[1] = (coef < 1.f ? coef : 1.f) * inv_scale;
         scal[2] = norm;
+        // a non-finite gradient (an overflow of the loss-scaled fp16 gradient buffers, a diverged batch): the step is SKIPPED on the device — moments
+        // and parameters untouched — as torch.cuda.amp.GradScaler.step does for the reference's fp16 path (xva_train.py:856-859); the host reads the
+        // flag when it reads the norm and backs the loss scale off
+        scal[3] = (norm == norm && norm <= 3.0e38f) ? 0.f : 1.f;
     }
 }
 
@@ -57,6 +61,7 @@ __global__ __launch_bounds__(OPT_THREADS) void lamb_pass1_kernel(const float* __
     int tid = ctid[c];
     int64_t s = cstart[c];
     int len = clen[c];
+    if (scal[3] != 0.f) return;      // skipped step (uniform)
     float gs = scal[1];
     float wn = 0.f, un = 0.f;
     const int len4 = len / 4;
@@ -98,7 +103,8 @@ __global__ __launch_bounds__(OPT_THREADS) void lamb_pass1_kernel(const float* __
 }
 __global__ __launch_bounds__(OPT_THREADS) void lamb_pass2_kernel(float* __restrict__ p, const float* __restrict__ m, const float* __restrict__ v,
                                   const int32_t* __restrict__ ctid, const int64_t* __restrict__ cstart,
-                                  const int32_t* __restrict__ clen, const float* __restrict__ norms, float lr, float eps, float wd) {
+                                  const int32_t* __restrict__ clen, const float* __restrict__ norms, const float* __restrict__ scal, float lr, float eps, float wd) {
+    if (scal[3] != 0.f) return;      // skipped step (uniform)
     int c = blockIdx.x;
     int tid = ctid[c];
     int64_t s = cstart[c];
@@ -155,7 +161,8 @@ extern "C" int64_t xva_opt_build_chunks(const int64_t* offsets, const int64_t* n
     return k;
 }
 
-// scal: >= 4 floats of device scratch; on return scal[2] = pre-clip global grad norm, scal[1] = applied coefficient.
+// scal: >= 4 floats of device scratch; on return scal[2] = pre-clip global grad norm, scal[1] = applied coefficient, scal[3] = 1 if the gradient was
+// non-finite and the step was skipped (nothing written), else 0.
 // norms: 2 * n_tensors floats of device scratch (per-tensor ||p||^2, ||u||^2; sqrt/clamp applied on use).
 // inv_scale: 1 / (loss scale * world averaging), folded into the gradient read (GradScaler.unscale_).
 // (Measured and not kept: running the two passes group by group over the chunk list so that a group's update pass finds its parameters and moments in
@@ -179,7 +186,7 @@ extern "C" int xva_lamb_step(float* params, const float* grads, float* exp_avg, 
         hipLaunchKernelGGL(lamb_pass1_kernel, dim3((unsigned)n_chunks), dim3(OPT_THREADS), 0, st, params, grads, exp_avg, exp_avg_sq,
                            ctid, cstart, clen, scal, norms, beta1, beta2, eps, weight_decay);
         hipLaunchKernelGGL(lamb_pass2_kernel, dim3((unsigned)n_chunks), dim3(OPT_THREADS), 0, st, params, exp_avg, exp_avg_sq, ctid,
-                           cstart, clen, norms, lr, eps, weight_decay);
+                           cstart, clen, norms, scal, lr, eps, weight_decay);
     }
     XVA_LAUNCH_CHECK();
     return XVA_OK;

@@ -65,6 +65,11 @@ class Lamb:
             self.steps[i] += 1
 
     @property
+    def skipped(self):
+        """1.0 if the last step met a non-finite gradient and was skipped on the device (moments and parameters untouched), else 0.0 (device scalar)."""
+        return self._scal[3]
+
+    @property
     def grad_norm(self):
         """Pre-clip global gradient norm of the last step (device scalar)."""
         return self._scal[2]

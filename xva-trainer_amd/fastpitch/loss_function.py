@@ -23,7 +23,7 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         eng, b, stage = ctx.h
-        s = g[0]
+        s = g[0] * eng.grad_inv_scale          # the slots hold loss_scale x seed ("f16" mode); autograd carries the plain gradient
         if stage == 2:
             d = eng.slot("D_LOGDUR", (b.B, b.Tt + 2))[:, 1:b.Tt + 1]
             return None, None, d * s

@@ -43,7 +43,7 @@ class _FastPitchFn(torch.autograd.Function):
             d = eng.slot(slot, shape)
             d.zero_()
             if g is not None:
-                d[sl] = g.reshape(d[sl].shape)
+                d[sl] = g.reshape(d[sl].shape) * eng.loss_scale      # ("f16": the fp16 gradient buffers want the loss-scaled seed; 1 otherwise)
 
         if stage == 2:
             put("D_LOGDUR", (b.B, b.Tt + 2), gouts[0], (slice(None), slice(1, b.Tt + 1)))
@@ -53,6 +53,8 @@ class _FastPitchFn(torch.autograd.Function):
             put("D_ENERGY", (b.B, b.Tt + 2), gouts[2], (slice(None), slice(1, b.Tt + 1)))
         g = torch.zeros_like(module.flat)
         eng.backward(module.flat.detach(), g, b, stage)
+        if eng.loss_scale != 1.0:
+            g.mul_(eng.grad_inv_scale)
         return g, None, None, None
 
 

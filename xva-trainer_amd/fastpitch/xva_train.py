@@ -448,6 +448,9 @@ class FastPitchTrainer(RankMixin):
             adjust_learning_rate(self.total_iter, self.optimizer, self.learning_rate, self.warmup_steps)
             self.grads.zero_()
         b = batch if isinstance(batch, E.DeviceBatch) else E.DeviceBatch.from_dict(batch, self.model.flat.device)
+        if self.eng.compute == 2 and self.eng.auto_loss_scale:      # one scale for all micro-batches of an accumulation: fixed from the first batch's geometry, then dynamic
+            self.eng.set_loss_scale(self.eng._choose_loss_scale(b))
+            self._loss_scale_cap = self.eng.loss_scale * 16
         flat = self.model.flat.data
         last = (self.accumulated_steps + 1) % self.gam == 0
         if stage == 1:
@@ -483,7 +486,9 @@ class FastPitchTrainer(RankMixin):
         self.iter_loss += reduced / self.gam
         self.iter_num_frames += int(b.mel_lens.sum().item()) if b.mel_lens is not None else 0
         if last:
-            self.optimizer.step(self.grads, self.active, max_grad_norm=self.grad_clip_thresh)
+            self.optimizer.step(self.grads, self.active, max_grad_norm=self.grad_clip_thresh, inv_scale=self.eng.grad_inv_scale if stage != 1 else 1.0)
+            if self.eng.compute == 2 and stage != 1:
+                self._update_loss_scale()
             iter_time = time.perf_counter() - self.iter_start_time
             fps = self.iter_num_frames * self.world / iter_time
             self.epoch_frames_per_sec[-1] += fps
@@ -497,6 +502,20 @@ class FastPitchTrainer(RankMixin):
             self.iter_start_time = time.perf_counter()
             if self.max_iterations and self.total_iter >= self.max_iterations:
                 self.running = False
+
+    # ---- torch.cuda.amp.GradScaler.update (xva_train.py:350,856-859) for the fp16-operand mode ----
+    def _update_loss_scale(self):
+        """The optimizer skipped a step with a non-finite gradient on the device (csrc/optim.hip): halve the scale; 2 000 good steps in a row: double it, up to
+        the geometry-derived ceiling.  One 4-byte read per optimizer step, in this mode only."""
+        if float(self.optimizer.skipped) != 0.0:
+            self.eng.set_loss_scale(max(1.0, self.eng.loss_scale / 2))
+            self._good_steps = 0
+            self.print_and_log("non-finite gradient: step skipped, loss scale -> %g" % self.eng.loss_scale, save_to_file=self.dataset_output)
+        else:
+            self._good_steps = getattr(self, "_good_steps", 0) + 1
+            if self._good_steps >= 2000 and self.eng.loss_scale < self._loss_scale_cap:
+                self.eng.set_loss_scale(self.eng.loss_scale * 2)
+                self._good_steps = 0
 
     # ---- xva_train.py:915-977 ----
     def finish_epoch(self):
