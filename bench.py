@@ -604,12 +604,39 @@ def hifigan_fp32_leg(a, dev, steps=3, warm=2):
         res["roofline_stack"] = {"bound": "mfma", "achieved": alg_tf / res["ms_per_step"] * 1e3, "peak": 157.3, "unit": "TFLOP/s",
                                  "frac": alg_tf / res["ms_per_step"] * 1e3 / 157.3, "algorithmic_tflop_per_step": alg_tf,
                                  "note": "whole iteration: algorithmic FLOPs of every convolution launch / timed ms_per_step, against the exact-fp32 MFMA peak"}
+    # The same fp32-stored iteration with every product formed by three bf16 MFMAs on operands split into hi + lo bf16 while staged (csrc/gemm_core.h MODE 3,
+    # xva_gemm_set_fp32_products(1)): the cheapest mode whose WAVEFORM meets 1e-3 — no single-pass 16-bit format does on the 78-layer generator
+    # (profiles/r06_hifigan_precision_probe.txt: bf16 1.3e-2, fp16 1.7e-3, either with an fp32 residual stream 1.1e-2 / 1.5e-3).
+    from xva_trainer_amd import _lib
+    old_mode = _lib.lib.xva_gemm_set_fp32_products(1)
+    try:
+        for _ in range(warm):
+            out = st.train_step(x, y, y_mel)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = st.train_step(x, y, y_mel)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+        res["split_products"] = {"ms_per_step": 1000.0 * dt3 / steps, "value": B * seg * steps / dt3, "unit": "audio-samples/s", "steps": steps,
+                                 "note": "fp32 storage, products as three bf16 MFMAs on hi + lo split operands (register-staged kernel)"}
+    finally:
+        _lib.lib.xva_gemm_set_fp32_products(old_mode)
     del st
     torch.cuda.empty_cache()
     try:
         res["parity"] = golden_parity("hifigan", "fp32")
     except Exception as e:
         res["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    old_mode = _lib.lib.xva_gemm_set_fp32_products(1)
+    try:
+        par = golden_parity("hifigan", "fp32")
+        par["mode"] = "fp32 storage, split-bf16 products"
+        res["split_products"]["parity"] = par
+    except Exception as e:
+        res["split_products"]["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        _lib.lib.xva_gemm_set_fp32_products(old_mode)
     return res
 
 
@@ -1018,7 +1045,7 @@ def _compact_leg(leg):
         return leg
     if "error" in leg:
         return {"error": str(leg["error"])[:200]}
-    o = _pick(leg, ["value", "unit", "ms_per_step", "steps", "dtype"])
+    o = _pick(leg, ["value", "value_at_tolerance", "unit", "ms_per_step", "ms_per_step_at_tolerance", "steps", "dtype"])
     if isinstance(leg.get("roofline_stack"), dict):
         o["roofline_stack"] = _pick(leg["roofline_stack"], ["bound", "frac", "achieved", "peak", "unit", "mfma_frac", "traffic_over_algorithmic"])
     if isinstance(leg.get("roofline"), dict):
@@ -1262,6 +1289,14 @@ def main():
         if rank == 0 and world == 1 and a.compute == "bf16" and not a.no_fp32_parity:
             try:
                 out["hifigan_fp32_parity"] = hifigan_fp32_leg(a, dev)
+                sp = out["hifigan_fp32_parity"].get("split_products", {})
+                par = sp.get("parity", {})
+                if isinstance(out.get("hifigan"), dict) and isinstance(par.get("wave_rel"), float):
+                    ok = par["wave_rel"] <= 1e-3 and par.get("loss_rel", 1.0) <= 2e-3
+                    out["hifigan"]["value_at_tolerance"] = sp["value"] if ok else None
+                    out["hifigan"]["ms_per_step_at_tolerance"] = sp["ms_per_step"] if ok else None
+                    out["hifigan"]["tolerance_mode"] = ("fp32 storage + split-bf16 products (three MFMA passes): no single-pass 16-bit format keeps the 78-layer generator's waveform "
+                                                        "within 1e-3 (profiles/r06_hifigan_precision_probe.txt: bf16 1.3e-2, fp16 1.7e-3)")
             except Exception as e:                           # an extra measurement: never at the price of the contract line
                 out["hifigan_fp32_parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not a.no_xvapitch:
