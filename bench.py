@@ -35,6 +35,10 @@ def parse():
     ap.add_argument("--t-mel", type=int, default=860)
     ap.add_argument("--stage", type=int, default=3)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32", "f16"])
+    ap.add_argument("--trainer-leg", action="store_true", help="run ONLY the trainer leg: FastPitchTrainer / HiFiTrainer through handleTrainer from a dataset directory of files, "
+                    "the trainer's OWN frames/s / samples/s meter next to the engine step on the same batch shape")
+    ap.add_argument("--no-trainer-leg", action="store_true", help="skip the trainer leg of the default run")
+    ap.add_argument("--trainer-iters", type=int, default=40, help="optimizer iterations of the trainer leg")
     ap.add_argument("--no-f16", action="store_true", help="skip the fp16-operand FastPitch leg (the mode whose outputs meet north_star's 1e-3: `value_at_tolerance`)")
     ap.add_argument("--hg-timeout", type=int, default=300, help="multi-rank runs: seconds after which the line is printed without the HiFi-GAN leg")
     ap.add_argument("--dropout", type=float, default=0.1, help="FastPitch dropout probability (reference trains with 0.1)")
@@ -778,6 +782,93 @@ def fastpitch_f16_leg(a, dev):
     return res
 
 
+class _BenchSocket:
+    def __init__(self):
+        self.sent = []
+
+    async def send(self, msg):
+        self.sent.append(msg)
+
+
+def trainer_leg(a, dev, compute="bf16"):
+    """What a user of the reference's trainer sees: `handleTrainer` -> FastPitchTrainer stage 3 / HiFiTrainer from a DATASET DIRECTORY
+    (metadata.csv + wavs/ + pitch/ written by data.write_synthetic_dataset: 256 clips of 9.8 s, int16 files; durations extracted by the trainer's own
+    stage-1 aligner pass), the loaders, the accumulation loop and the log lines in the loop — reported by the trainer's OWN meter (the reference's
+    python/fastpitch1_1/xva_train.py:864-867: frames of the optimizer step / wall time of the step; hifigan/xva_train.py:526-528) next to the engine-only
+    step on one of the same batches.  mel-frames/s and audio-samples/s as the headline line's metrics."""
+    import asyncio
+    import logging
+    import shutil
+    import tempfile
+    import numpy as np
+    from xva_trainer_amd import data as D
+    from xva_trainer_amd.models_manager import ModelsManager
+    from xva_trainer_amd.fastpitch import xva_train as FT
+    from xva_trainer_amd.hifigan import xva_train as HT
+    root = tempfile.mkdtemp(prefix="xva_trainer_leg_")
+    res = {}
+    try:
+        t0 = time.perf_counter()
+        n_samp = 844 * 256                                   # 845 mel frames (9.80 s): int(9 * 3.5 * 10 / 9.80) = 32 clips per micro-batch (xva_train.py:387-404)
+        text = ("the quick brown fox jumps over the lazy dog and keeps running through the quiet forest until the evening sun sets behind the distant hills of home ok")[:146] + "."
+        ds = D.write_synthetic_dataset(os.path.join(root, "in", "voice_bench"), n_items=256, seed=11, min_s=n_samp / 22050.0, max_s=n_samp / 22050.0, fixed_text=text)
+        json.dump({"mean": 180.0, "std": 40.0}, open(os.path.join(ds, "pitch_stats.json"), "w"))
+        res["dataset"] = {"clips": 256, "seconds_per_clip": n_samp / 22050.0, "write_s": time.perf_counter() - t0, "text_symbols": len(text) + 2}
+        out = os.path.join(root, "out")
+        mm = ModelsManager(logging.getLogger("bench"), False, str(dev))
+        # ---- FastPitch, stage 3
+        data = {"dataset_path": ds, "output_path": out, "checkpoint": None, "num_workers": 0, "batch_size": 9, "epochs_per_checkpoint": 100000, "force_stage": 3,
+                "max_iterations": 50000 + a.trainer_iters, "trainer_options": {"compute": compute, "allow_random_init": True}}
+        ws = _BenchSocket()
+        t0 = time.perf_counter()
+        asyncio.run(FT.handleTrainer(mm, data, ws, [dev.index or 0]))
+        wall = time.perf_counter() - t0
+        tr = mm.models_bank["fastpitch1_1"]
+        fps = list(getattr(tr, "all_frames_s", tr.avg_frames_s))
+        steady = fps[len(fps) // 4:] or fps                  # the first quarter carries the clip cache's cold file reads and the first-touch allocations
+        b = next(iter(tr.train_loader))
+        from xva_trainer_amd.fastpitch import engine as E
+        b = b if isinstance(b, E.DeviceBatch) else E.DeviceBatch.from_dict(b, dev)
+        frames = int(b.mel_lens.sum().item())
+        flat = tr.model.flat.data
+
+        def estep():
+            tr.grads.zero_()
+            tr.eng.fwd_loss_bwd(flat, tr.grads, b, 3, grad_scale=1.0)
+        for _ in range(3):
+            estep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(16):
+            estep()
+        tr.optimizer.step(tr.grads, tr.active, max_grad_norm=1000.0, inv_scale=tr.eng.grad_inv_scale)        # one LAMB step per gam micro-batches, as the trainer
+        torch.cuda.synchronize()
+        e_ms = (time.perf_counter() - t0) / 16 * 1e3
+        res["fastpitch"] = {"metric": "mel-frames/sec by the trainer's own meter (FastPitchTrainer stage 3 from files)", "value": float(np.mean(steady)), "unit": "mel-frames/s",
+                            "all_iterations_mean": float(np.mean(fps)), "iterations": len(fps), "micro_batch": tr.per_rank_batch, "gam": tr.gam, "compute": compute,
+                            "frames_per_micro_batch": frames, "t_text": int(b.Tt), "t_mel": int(b.Tm), "wall_s_incl_init_and_duration_extraction": wall,
+                            "engine_same_shape": {"value": frames / e_ms * 1e3, "ms_per_micro_batch": e_ms, "note": "fwd + loss + bwd of one of the trainer's batches, device-resident, "
+                                                  "one LAMB step per %d micro-batches amortised over 16" % tr.gam},
+                            "trainer_over_engine": float(np.mean(steady)) / (frames / e_ms * 1e3), "prefetch": bool(getattr(tr, "prefetch", False))}
+        del tr, b
+        mm.models_bank.pop("fastpitch1_1", None)
+        torch.cuda.empty_cache()
+        # ---- HiFi-GAN
+        hdata = {"dataset_path": ds, "output_path": out + "_hg", "checkpoint": None, "num_workers": 0, "batch_size": 46, "epochs_per_checkpoint": 100000,
+                 "max_iterations": a.trainer_iters, "trainer_options": {"compute": compute, "allow_random_init": True}}
+        t0 = time.perf_counter()
+        asyncio.run(HT.handleTrainer(mm, hdata, _BenchSocket(), [dev.index or 0]))
+        wall = time.perf_counter() - t0
+        th = mm.models_bank["hifigan"]
+        sps = [float(x) for x in getattr(th, "avg_samples_s", [])]
+        steady = sps[len(sps) // 4:] or sps
+        res["hifigan"] = {"metric": "audio-samples/sec by the trainer's own meter (HiFiTrainer from files)", "value": float(np.mean(steady)) if steady else None, "unit": "audio-samples/s",
+                          "iterations": len(sps), "batch": getattr(th, "per_rank_batch", None), "wall_s": wall, "prefetch": bool(getattr(th, "prefetch", False))}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return res
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run, one rank per GPU
     (the reference's DP entry is single-process nn.DataParallel, python/fastpitch1_1/xva_train.py:465-466; here N processes
@@ -1085,10 +1176,14 @@ def compact_line(out):
     for k in ["fastpitch_f16", "hifigan", "xvapitch_c5", "fastpitch_split", "fastpitch_fp32_parity", "hifigan_fp32_parity"]:
         if k in out:
             line[k] = _compact_leg(out[k])
+    if isinstance(out.get("trainer"), dict):
+        t = out["trainer"]
+        line["trainer"] = {"error": str(t["error"])[:200]} if "error" in t else {
+            k: _pick(t[k], ["value", "unit", "trainer_over_engine", "iterations", "prefetch"]) for k in ("fastpitch", "hifigan") if isinstance(t.get(k), dict)}
     line["detail"] = out.get("detail_file", "bench_detail.json")
     s = json.dumps(line, separators=(",", ":"))
     if len(s) > MAX_LINE_BYTES:                           # never at the price of the contract: drop the extras, largest first
-        for k in ["hbm_kernels", "hifigan_fp32_parity", "fastpitch_fp32_parity", "fastpitch_split", "xvapitch_c5", "hifigan", "parity"]:
+        for k in ["hbm_kernels", "hifigan_fp32_parity", "fastpitch_fp32_parity", "fastpitch_split", "trainer", "xvapitch_c5", "fastpitch_f16", "hifigan", "parity"]:
             line.pop(k, None)
             s = json.dumps(line, separators=(",", ":"))
             if len(s) <= MAX_LINE_BYTES:
@@ -1132,6 +1227,9 @@ def main():
         sys.exit("bench.py: rank %d needs cuda:%d but only %d GPU(s) are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if a.trainer_leg:
+        print(json.dumps(trainer_leg(a, dev, a.compute)), flush=True)
+        return
     if a.xvapitch_leg_only:                              # the child of xvapitch_c5_fresh_process: this leg alone, its object on stdout
         print(json.dumps(xvapitch_c5_leg(dev, roofline=not a.no_roofline, cpu_base=not a.no_cpu_baseline)), flush=True)
         return
@@ -1299,6 +1397,14 @@ def main():
                                                         "within 1e-3 (profiles/r06_hifigan_precision_probe.txt: bf16 1.3e-2, fp16 1.7e-3)")
             except Exception as e:                           # an extra measurement: never at the price of the contract line
                 out["hifigan_fp32_parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0 and world == 1 and not a.no_trainer_leg:
+        try:
+            torch.cuda.empty_cache()
+            out["trainer"] = trainer_leg(a, dev, a.compute)
+            if isinstance(out.get("hifigan"), dict) and out["hifigan"].get("value") and out["trainer"].get("hifigan", {}).get("value"):
+                out["trainer"]["hifigan"]["trainer_over_engine"] = out["trainer"]["hifigan"]["value"] / out["hifigan"]["value"]
+        except Exception as e:                               # an extra measurement: never at the price of the contract line
+            out["trainer"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not a.no_xvapitch:
         try:
             torch.cuda.empty_cache()

@@ -120,6 +120,131 @@ def read_metadata(dataset_path, wav_dir="wavs"):
 
 
 # ------------------------------------------------------------------------------------------------ device collate
+class _PinnedRing:
+    """Persistent pinned staging buffers: a ring of RING buffers per dtype, grown when a batch needs more, instead of one
+    cudaHostAlloc per field and batch.  A buffer is handed out again only after the H2D copy that read it last has run (its event)."""
+    RING = 4
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._bufs = {}          # dtype -> [[tensor, event or None], ...]
+        self._next = {}
+
+    def take(self, n, dtype):
+        if not torch.cuda.is_available():
+            return torch.empty(n, dtype=dtype), None
+        with self._lock:
+            ring = self._bufs.setdefault(dtype, [[None, None] for _ in range(self.RING)])
+            i = self._next.get(dtype, 0)
+            self._next[dtype] = (i + 1) % self.RING
+            slot = ring[i]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0] is None or slot[0].numel() < n:
+            slot[0] = torch.empty(max(n, 1) * 5 // 4 + 16, dtype=dtype).pin_memory()
+        slot[1] = torch.cuda.Event()
+        return slot[0][:n], slot[1]
+
+
+_PINNED = _PinnedRing()
+
+
+def _walk_tensors(obj, fn, depth=0):
+    if isinstance(obj, torch.Tensor):
+        fn(obj)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _walk_tensors(v, fn, depth + 1)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _walk_tensors(v, fn, depth + 1)
+    elif depth < 3 and hasattr(obj, "__dict__"):
+        for v in vars(obj).values():
+            _walk_tensors(v, fn, depth + 1)
+
+
+class Prefetcher:
+    """One background thread keeps `depth` batches ahead of the training loop (the reference's DataLoader(num_workers, pin_memory,
+    persistent_workers) — python/fastpitch1_1/xva_train.py:452, hifigan/xva_train.py:321): the file reads, the copy into the pinned ring, the H2D transfer
+    and the device-side collate / mel kernels of batch i + 1 run on a side stream while step i runs on the trainer's stream.  The consumer makes its
+    stream wait for the batch's event (no host synchronisation) and tells the caching allocator that its stream now uses the batch's tensors.
+    Same batches in the same order as iterating `loader` directly (the loaders draw from their own seeded generators)."""
+    _END = object()
+
+    def __init__(self, loader, device, depth=2):
+        self.loader, self.device, self.depth = loader, torch.device(device), int(depth)
+        self._side = None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __getattr__(self, name):                      # actual_num_lines, items, ...: the wrapped loader's attributes
+        return getattr(self.__dict__["loader"], name)
+
+    def __iter__(self):
+        import queue
+        import threading
+        if self.device.type != "cuda":
+            yield from self.loader
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        it = iter(self.loader)
+        q = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+        side, dev, END = self._side, self.device, self._END
+
+        def put(x):
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                while not stop.is_set():
+                    with torch.cuda.stream(side):
+                        try:
+                            b = next(it)
+                        except StopIteration:
+                            put(END)
+                            return
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    if not put((b, ev)):
+                        return
+            except BaseException as e:                 # surfaces in the training thread at the next()
+                put(e)
+
+        th = threading.Thread(target=work, name="xva-prefetch", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is END:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                b, ev = item
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(ev)
+                _walk_tensors(b, lambda t: t.record_stream(cur) if t.is_cuda else None)
+                yield b
+        finally:
+            stop.set()
+            try:
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=5.0)
+
+
 class _Ragged:
     """Ragged host arrays -> one pinned flat buffer + offsets / lengths, copied to the device asynchronously."""
 
@@ -130,7 +255,7 @@ class _Ragged:
         if len(arrays) > 1:
             off[1:] = np.cumsum(lens[:-1])
         total = int(sum(lens)) * inner
-        flat = torch.empty(max(total, 1), dtype=dtype).pin_memory() if torch.cuda.is_available() else torch.empty(max(total, 1), dtype=dtype)
+        flat, done = _PINNED.take(max(total, 1), dtype)
         np_flat = flat.numpy()
         pos = 0
         for a in arrays:
@@ -138,6 +263,8 @@ class _Ragged:
             np_flat[pos:pos + n] = np.ascontiguousarray(a).reshape(-1)
             pos += n
         self.flat = flat.to(device, non_blocking=True)
+        if done is not None:
+            done.record()                 # the staging buffer may be refilled once this copy has run
         self.offsets = torch.from_numpy(off).to(device, non_blocking=True)
         self.lens = torch.tensor(lens, dtype=torch.int32).to(device, non_blocking=True)
         self.inner = inner

@@ -139,10 +139,10 @@ class RankMixin:
 def trainer_options(data):
     """`data["trainer_options"]`: a JSON-able dict for tests and benchmarks (not in the reference; `max_iterations` / `synthetic_data` are its
     older siblings): compute ("bf16" | "fp32"), p_dropout, allow_random_init, model_kwargs, world_invariant_noise, target_delta (overrides the
-    stopping threshold(s) so that a test can reach a stage transition in a few epochs).  A rank worker cannot be handed
+    stopping threshold(s) so that a test can reach a stage transition in a few epochs), prefetch (false: the loaders run on the training thread).  A rank worker cannot be handed
     Python objects (loader factories, patched attributes), so everything a multi-rank test needs to set travels here."""
     opts = data.get("trainer_options") or {}
-    unknown = set(opts) - {"compute", "p_dropout", "allow_random_init", "model_kwargs", "world_invariant_noise", "target_delta"}
+    unknown = set(opts) - {"compute", "p_dropout", "allow_random_init", "model_kwargs", "world_invariant_noise", "target_delta", "prefetch"}
     if unknown:
         raise ValueError("unknown trainer_options: %s" % sorted(unknown))
     return opts

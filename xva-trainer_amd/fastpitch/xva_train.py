@@ -228,6 +228,7 @@ class FastPitchTrainer(RankMixin):
             self.compute = opts.get("compute", self.compute)
             self.p_dropout = opts.get("p_dropout")
             self.target_delta_override = opts.get("target_delta")
+            self.prefetch = bool(opts.get("prefetch", os.environ.get("XVA_PREFETCH", "1") != "0"))
             self.learning_rate, self.weight_decay = 0.1, 1e-6
             self.dur_predictor_loss_scale = self.pitch_predictor_loss_scale = 0.1
             self.attn_loss_scale = 1.0                                 # xva_train.py:704
@@ -235,6 +236,8 @@ class FastPitchTrainer(RankMixin):
         while self.running and not self.JUST_FINISHED_STAGE and not self.END_OF_TRAINING:
             await self.iteration()
             self._sync_stop()
+        if getattr(self, "is_init", False):
+            self._drain_pending()              # a pause lands between two iterations: the last micro-batch's report is still in flight
 
     def get_target_delta(self, num_data_lines, stage):
         """xva_train.py:589-672 (target deltas; freezing is implemented by the engine's per-stage trainable ranges)."""
@@ -308,7 +311,11 @@ class FastPitchTrainer(RankMixin):
             self.per_rank_batch = n_items
             self.global_batch = n_items * self.world
             self.gam = max(1, round(256 / self.global_batch))
-        return FastPitchFileLoader(self.dataset_input, self.per_rank_batch, stage, self.device, seed=1234, rank=self.rank, world=self.world, dm=dm)
+        ld = FastPitchFileLoader(self.dataset_input, self.per_rank_batch, stage, self.device, seed=1234, rank=self.rank, world=self.world, dm=dm)
+        if getattr(self, "prefetch", True):       # batch i + 1 is read, staged, uploaded and collated under step i (data.Prefetcher)
+            from ..data import Prefetcher
+            ld = Prefetcher(ld, self.device, depth=2)
+        return ld
 
     async def init(self):
         self.device = dev = self._init_distributed()
@@ -429,12 +436,16 @@ class FastPitchTrainer(RankMixin):
         self.epoch_iter = 0
 
     # ---- xva_train.py:757-911 ----
+    # The host never waits for the step it has just issued: the 9 floats a micro-batch reports (8 losses + its frame count) go to a pinned
+    # buffer behind an event and are READ after the next micro-batch has been enqueued — the reference's NaN check therefore acts one micro-batch late (it
+    # already acts after the fact, xva_train.py:825-832), and the parameters are protected meanwhile by the optimizer's on-device skip of non-finite steps.
     async def iteration(self):
         if not self.is_init:
             await self.init()
         try:
             batch = next(self.dataloader_iterator)
         except StopIteration:
+            self._drain_pending()
             self.finish_epoch()
             self.start_new_epoch()
             self.dataloader_iterator = iter(self.train_loader)
@@ -471,12 +482,51 @@ class FastPitchTrainer(RankMixin):
         else:
             losses = self.sync.fwd_loss_bwd(b, stage, grad_scale=1.0 / self.gam, sync=last)
         self.accumulated_steps += 1
-        host = losses.detach().cpu()                      # the one host sync per micro-batch (reference: 5 x .item())
+        rec = self._report_slot()
+        rec["dev"][:8].copy_(losses.detach()[:8])
+        rec["dev"][8] = b.mel_lens.sum() if b.mel_lens is not None else 0
+        rec.update(stage=stage, last=last, total_iter=self.total_iter, epoch=self.epoch)
+        if last:
+            self.optimizer.step(self.grads, self.active, max_grad_norm=self.grad_clip_thresh, inv_scale=self.eng.grad_inv_scale if stage != 1 else 1.0)
+            rec["dev"][9] = self.optimizer.skipped                                          # read with the losses, one micro-batch late
+            self.accumulated_steps = 0
+        rec["host"].copy_(rec["dev"], non_blocking=True)
+        rec["event"].record()                              # behind the optimizer step when there is one: the report's arrival is the step's completion
+        if last:
+            if self.max_iterations and self.total_iter >= self.max_iterations:
+                self.running = False
+        prev, self._pending = getattr(self, "_pending", None), rec
+        if prev is not None:
+            self._account(prev)
+        if not self.running or self.JUST_FINISHED_STAGE or self.END_OF_TRAINING:
+            self._drain_pending()
+
+    def _report_slot(self):
+        """two (device, pinned) pairs of 10 floats (8 losses, the frame count, the optimizer's skipped flag) used alternately: the micro-batch in flight and the one being read"""
+        if not getattr(self, "_slots", None):
+            dev = self.model.flat.device
+            self._slots = [{"dev": torch.zeros(10, device=dev), "host": torch.zeros(10).pin_memory(), "event": torch.cuda.Event()} for _ in range(2)]
+            self._slot_i = 0
+        self._slot_i ^= 1
+        return self._slots[self._slot_i]
+
+    def _drain_pending(self):
+        prev, self._pending = getattr(self, "_pending", None), None
+        if prev is not None:
+            self._account(prev)
+
+    def _account(self, rec):
+        """the bookkeeping of one micro-batch, from its (by now finished) 9-float report: xva_train.py:815-832 (the stage's stopping signal, the NaN skip),
+        :864-867 (frames / wall time of the optimizer step) and the log line"""
+        rec["event"].synchronize()
+        t_done = time.perf_counter()                      # the micro-batch (and its optimizer step) has finished by now: the meter's clock
+        host = rec["host"].clone()
+        stage = rec["stage"]
         mel_loss, dur_loss, pitch_loss = float(host[1]), float(host[2]), float(host[3])
         reduced = {1: float(host[0]), 2: float(host[0]), 3: pitch_loss * self.pitch_predictor_loss_scale, 4: mel_loss}[stage]
         if np.isnan(reduced):                             # xva_train.py:825-832 (the loss is global: every rank takes this branch together)
             self.print_and_log("loss is NaN", save_to_file=self.dataset_output)
-            self.grads.zero_()
+            self.grads.zero_()                            # whatever has been accumulated since (the optimizer skipped a step with these gradients on its own)
             self.accumulated_steps, self.iter_loss, self.iter_num_frames = 0, 0.0, 0
             self.nan_streak = getattr(self, "nan_streak", 0) + 1
             if self.nan_streak >= 100:              # the reference would skip micro-batches forever; a diverged model is reported instead
@@ -484,30 +534,28 @@ class FastPitchTrainer(RankMixin):
             return
         self.nan_streak = 0
         self.iter_loss += reduced / self.gam
-        self.iter_num_frames += int(b.mel_lens.sum().item()) if b.mel_lens is not None else 0
-        if last:
-            self.optimizer.step(self.grads, self.active, max_grad_norm=self.grad_clip_thresh, inv_scale=self.eng.grad_inv_scale if stage != 1 else 1.0)
+        self.iter_num_frames += int(host[8])
+        if rec["last"]:
             if self.eng.compute == 2 and stage != 1:
-                self._update_loss_scale()
-            iter_time = time.perf_counter() - self.iter_start_time
+                self._update_loss_scale(float(host[9]))
+            iter_time = t_done - self.iter_start_time
             fps = self.iter_num_frames * self.world / iter_time
             self.epoch_frames_per_sec[-1] += fps
             self.avg_frames_s.append(fps)
+            self.all_frames_s = getattr(self, "all_frames_s", []) + [fps]       # never reset (bench.py --trainer-leg)
             self.avg_loss_per_epoch[-1] += self.iter_loss
             self.iter_losses.append(self.iter_loss)
             self.training_log_live_line = "Stage: %d | Epoch: %d | iter: %d/%d -> %d | loss: %.6f | frames/s %d | Target: %.6f    " % (
-                stage, self.epoch, (self.total_iter + 1) % self.num_iters, self.num_iters, self.total_iter, self.iter_loss, int(fps), self.target_delta)
+                stage, rec["epoch"], (rec["total_iter"] + 1) % self.num_iters, self.num_iters, rec["total_iter"], self.iter_loss, int(fps), self.target_delta)
             self.print_and_log(save_to_file=self.dataset_output)
-            self.accumulated_steps, self.iter_loss, self.iter_num_frames = 0, 0.0, 0
-            self.iter_start_time = time.perf_counter()
-            if self.max_iterations and self.total_iter >= self.max_iterations:
-                self.running = False
+            self.iter_loss, self.iter_num_frames = 0.0, 0
+            self.iter_start_time = t_done
 
     # ---- torch.cuda.amp.GradScaler.update (xva_train.py:350,856-859) for the fp16-operand mode ----
-    def _update_loss_scale(self):
+    def _update_loss_scale(self, skipped):
         """The optimizer skipped a step with a non-finite gradient on the device (csrc/optim.hip): halve the scale; 2 000 good steps in a row: double it, up to
-        the geometry-derived ceiling.  One 4-byte read per optimizer step, in this mode only."""
-        if float(self.optimizer.skipped) != 0.0:
+        the geometry-derived ceiling.  `skipped` travels with the micro-batch's report (no extra synchronisation)."""
+        if skipped != 0.0:
             self.eng.set_loss_scale(max(1.0, self.eng.loss_scale / 2))
             self._good_steps = 0
             self.print_and_log("non-finite gradient: step skipped, loss scale -> %g" % self.eng.loss_scale, save_to_file=self.dataset_output)

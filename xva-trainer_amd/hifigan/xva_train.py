@@ -130,9 +130,12 @@ class HiFiTrainer(RankMixin):
             opts = trainer_options(data)                                       # tests / bench (a rank worker cannot be handed Python objects)
             self.compute = opts.get("compute", self.compute)
             self.allow_random_init = bool(opts.get("allow_random_init", self.allow_random_init))
+            self.prefetch = bool(opts.get("prefetch", os.environ.get("XVA_PREFETCH", "1") != "0"))
         while self.running and not self.END_OF_TRAINING:
             await self.iteration()
             self._sync_stop()
+        if getattr(self, "is_init", False):
+            self._drain_pending()              # a pause lands between two iterations: the last iteration's report is still in flight
 
     async def init(self):
         dev = self._init_distributed()
@@ -195,6 +198,9 @@ class HiFiTrainer(RankMixin):
         ld = HifiFileLoader(self.dataset_input, self.h["batch_size"], self.device, segment=self.h["segment_size"], seed=self.h["seed"],
                             rank=self.rank, world=self.world)
         self.print_and_log("Training items: %d" % len(ld.files), save_to_file=self.dataset_output)
+        if getattr(self, "prefetch", True):       # crops of batch i + 1 are read, staged, uploaded and normalised under step i (data.Prefetcher)
+            from ..data import Prefetcher
+            ld = Prefetcher(ld, self.device, depth=2)
         return ld
 
     def start_new_epoch(self):
@@ -203,11 +209,15 @@ class HiFiTrainer(RankMixin):
         self.epoch_iter = 0
 
     async def iteration(self):
+        """The host does not wait for the iteration it has just issued: the mel loss goes to a pinned float behind an event and is read —
+        with the log line and the its/s meter — after the NEXT iteration has been enqueued (the reference reads it with .item() in place,
+        python/hifigan/xva_train.py:517-528)."""
         if not self.is_init:
             await self.init()
         try:
             wav = next(self.dataloader_iterator)
         except StopIteration:
+            self._drain_pending()
             self.finish_epoch()
             self.start_new_epoch()
             self.dataloader_iterator = iter(self.train_loader)
@@ -218,18 +228,44 @@ class HiFiTrainer(RankMixin):
         x = mel_spectrogram(y, h["n_fft"], h["num_mels"], h["sampling_rate"], h["hop_size"], h["win_size"], h["fmin"], h["fmax"])
         y_mel = mel_spectrogram(y, h["n_fft"], h["num_mels"], h["sampling_rate"], h["hop_size"], h["win_size"], h["fmin"], h["fmax_for_loss"])
         out = self.core.train_step(x, y, y_mel)
-        mel_error = float(out["loss_mel"].item()) / 45.0                               # the one host sync per iteration
-        self.epoch_iter += 1
-        self.avg_loss_per_epoch[-1] += int(mel_error * 1000) / 1000
-        s_per_b = max(time.time() - start_b, 1e-9)
-        its_p_s = int(100 * h["batch_size"] * self.world / s_per_b) / 100
-        self.training_log_live_line = "Stage 5 | Epoch: %d | It: %d/%d (%d) | Mel loss: %.3f | its/s: %s " % (
-            self.training_epoch + 1, (self.training_steps + 1) % max(1, len(self.train_loader)), len(self.train_loader), self.training_steps + 1,
-            mel_error, its_p_s)
-        self.print_and_log(save_to_file=self.dataset_output)
+        if not getattr(self, "_slots", None):
+            self._slots = [{"host": torch.zeros(1).pin_memory(), "event": torch.cuda.Event()} for _ in range(2)]
+            self._slot_i = 0
+        self._slot_i ^= 1
+        rec = self._slots[self._slot_i]
+        rec["host"].copy_(out["loss_mel"].detach().reshape(1), non_blocking=True)
+        rec["event"].record()
+        rec.update(start_b=start_b, step=self.training_steps + 1, epoch=self.training_epoch + 1)
         self.training_steps += 1
         if self.max_iterations and self.training_steps >= self.max_iterations:
             self.running = False
+        prev, self._pending = getattr(self, "_pending", None), rec
+        if prev is not None:
+            self._account(prev)
+        if not self.running or self.END_OF_TRAINING:
+            self._drain_pending()
+
+    def _drain_pending(self):
+        prev, self._pending = getattr(self, "_pending", None), None
+        if prev is not None:
+            self._account(prev)
+
+    def _account(self, rec):
+        rec["event"].synchronize()
+        h = self.h
+        mel_error = float(rec["host"][0]) / 45.0
+        self.epoch_iter += 1
+        self.avg_loss_per_epoch[-1] += int(mel_error * 1000) / 1000
+        now = time.time()
+        last = getattr(self, "_last_account_t", None)
+        s_per_b = max(now - (last if last is not None and last > rec["start_b"] - 60.0 and self.epoch_iter > 1 else rec["start_b"]), 1e-9)   # wall time per iteration incl. the loader
+        self._last_account_t = now
+        its_p_s = int(100 * h["batch_size"] * self.world / s_per_b) / 100
+        self.avg_samples_s = getattr(self, "avg_samples_s", [])
+        self.avg_samples_s.append(h["batch_size"] * self.world * h["segment_size"] / s_per_b)
+        self.training_log_live_line = "Stage 5 | Epoch: %d | It: %d/%d (%d) | Mel loss: %.3f | its/s: %s " % (
+            rec["epoch"], rec["step"] % max(1, len(self.train_loader)), len(self.train_loader), rec["step"], mel_error, its_p_s)
+        self.print_and_log(save_to_file=self.dataset_output)
 
     def output_checkpoint(self):
         """xva_train.py:570-601.  Called BEFORE the epoch loss is normalised, like the reference: the log line divides the running sum."""
