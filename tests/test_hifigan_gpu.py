@@ -587,6 +587,24 @@ def test_reused_discriminator_weights_equal_the_recomputed_ones():
     assert st.eng._d_eff_key != k
 
 
+def test_reused_discriminator_weights_are_dropped_when_the_workspace_is_rebuilt():
+    """generator_forward of another geometry zeroes the workspace (and with it the prepared effective weights and norms); coming back to the first
+    geometry must NOT match the old reuse key — the discriminators would run on all-zero weights without any error."""
+    from oracle import hifigan as ohg
+    from xva_trainer_amd.hifigan.step import HifiganStep
+    st = HifiganStep("cuda", "bf16")
+    st.load_state_dicts(ohg.init_generator_sd(11), ohg.init_mpd_sd(12), ohg.init_msd_sd(13))
+    x, y, ym = ohg.synth_batch(2, 4324)
+    yg = st.eng.generator_forward(st.flat_g, x.cuda())
+    a = st.eng.disc_forward(st.flat_d, y.cuda(), yg, losses="all", weights_token=7).clone()
+    st.eng.generator_forward(st.flat_g, x[:, :, :16].cuda())         # shape B: the workspace is zeroed in place
+    yg2 = st.eng.generator_forward(st.flat_g, x.cuda())              # back to shape A: zeroed again
+    assert torch.equal(yg2, yg)
+    assert st.eng._d_eff_key is None
+    b = st.eng.disc_forward(st.flat_d, y.cuda(), yg2, losses="all", weights_token=7).clone()
+    assert float(b[:3].abs().sum()) > 0 and _nrel(b[:3], a[:3]) < 5e-2      # (the spectral-norm power iteration advances between the two)
+
+
 def test_discriminator_forward_on_the_stream_lanes_is_reproducible_and_conv0_matches_the_host():
     """Six forwards of all eight discriminators on the default four stream lanes: every stored feature map of the five period discriminators and of the two
     weight-normalised scale discriminators is bit-identical from run to run (the spectral-norm one advances its power iteration every pass), and the first layers

@@ -98,61 +98,11 @@ __global__ void hg_cin1_fwd_kernel(const float* __restrict__ wav, const float* _
         hg_st(out, ((int64_t)seq * g.Hp + g.padF + h) * g.Cout + co, dt, hg_lrelu(acc, slope));
     }
 }
-// Round 5: the same forward, store-bound instead of 3x that (it had become an im2col launch + an MFMA product with K = 8 / 16: 87 us for the
-// 135 MB that DiscriminatorS's first layer writes per 64 full-rate clips — 1.5 TB/s).  A thread owns 8 output channels (one 16-byte store per row)
-// and keeps their K x 8 weights in registers as float2 pairs (v_pk_fma_f32); a block of 256 threads = (Cout / 8) channel groups x row lanes covers
-// RPT rows per lane (interleaved: the lanes of a wave store consecutive rows); the block's span of the (folded, reflect-padded) waveform is staged in LDS once.  bf16 mode: the samples and weights
-// are rounded to bf16 first — the operands the GEMM form multiplied (im2col and padded weights in the activation dtype), so results agree with it
-// up to fp32 summation order.
-typedef float hg_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float hg_round_bf16(float v) { uint32_t u = __float_as_uint(v); u += 0x7fffu + ((u >> 16) & 1u); return __uint_as_float(u & 0xffff0000u); }
-template <int K, int RPT>
-__global__ __launch_bounds__(256) void hg_cin1_fwd8_kernel(const float* __restrict__ wav, const float* __restrict__ W, const float* __restrict__ bias,
-                                                           void* __restrict__ out, int dt, Cin1Geom g, float slope) {
-    extern __shared__ float sx[];                                   // samples s * h0 - P ... of this block's rows
-    const int ng = g.Cout >> 3, rl_n = 256 / ng;                    // channel groups, row lanes
-    const int cg = threadIdx.x % ng, rl = threadIdx.x / ng;
-    const int seq = blockIdx.y, b = seq / g.p, wf = seq % g.p;
-    const int rows_blk = rl_n * RPT, h0 = blockIdx.x * rows_blk;
-    const int nsmp = g.s * (rows_blk - 1) + K;
-    const bool rnd = dt == XVA_BF16;
-    for (int i = threadIdx.x; i < nsmp; i += 256) {
-        const float v = cin1_sample(wav, g, b, wf, g.s * h0 - g.P + i);
-        sx[i] = rnd ? hg_round_bf16(v) : v;
-    }
-    hg_f2 w2[4][K], b2[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int co = cg * 8 + e * 2;
-        b2[e] = (hg_f2){bias[co], bias[co + 1]};
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const float a = W[(int64_t)co * K + j], c = W[(int64_t)(co + 1) * K + j];
-            w2[e][j] = rnd ? (hg_f2){hg_round_bf16(a), hg_round_bf16(c)} : (hg_f2){a, c};
-        }
-    }
-    __syncthreads();
-#pragma unroll 2
-    for (int i = 0; i < RPT; ++i) {
-        const int hl = i * rl_n + rl, h = h0 + hl;                  // a wave's lanes cover consecutive rows: one contiguous store segment
-        if (h >= g.Tout) break;
-        hg_f2 acc[4] = {b2[0], b2[1], b2[2], b2[3]};
-        const float* xs = sx + g.s * hl;
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const float x = xs[j];
-            const hg_f2 xx = {x, x};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = __builtin_elementwise_fma(w2[e][j], xx, acc[e]);
-        }
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[2 * e] = hg_lrelu(acc[e][0], slope); v[2 * e + 1] = hg_lrelu(acc[e][1], slope); }
-        hg_st8(out, ((int64_t)seq * g.Hp + g.padF + h) * g.Cout + cg * 8, dt, v);
-    }
-}
-// bf16 mode, Cout = 128, k <= 16 (DiscriminatorS conv0, models.py:207): the same forward on the matrix pipe WITHOUT an im2col in memory.  The v_pk_fma form above
-// is bound by VALU issue at this width (60 packed FMAs + 15 LDS reads per lane and 4 rows: 140 us per launch = 0.55 TB/s of stores); here a wave takes 16 rows at a
+// bf16 mode, Cout = 128, k <= 16 (DiscriminatorS conv0, models.py:207): the same forward on the matrix pipe WITHOUT an im2col in memory.  (Round 5's first form
+// of this layer — a packed-fp32 VALU kernel — gave sporadically wrong even channels on the discriminators' side stream lanes and was bound by VALU issue anyway;
+// its cause was never isolated and the kernel is gone from the library, round 6; tests/test_lanes_gpu.py holds every engine's lanes-on results to its one-stream
+// results bit for bit instead.)  Here a wave takes 16 rows at a
 // time: the lane's 4 consecutive taps of its row come straight from the staged waveform (LDS, already rounded to bf16: the operands of the GEMM form), eight
 // v_mfma_f32_16x16x16_bf16 (taps padded 15 -> 16 with a zero weight) give the 128 channels, and the weight rows are PERMUTED over the eight tiles so that a lane ends
 // up with 4 x 8 consecutive channels of its row: four 16-byte stores, 64 contiguous bytes per row and instruction.  Products are the GEMM form's (bf16 x bf16 exact in
@@ -270,24 +220,11 @@ extern "C" int xva_hg_cin1_fwd(const float* wav, const float* W, const float* bi
     Cin1Geom g;
     XVA_TRY(cin1_geom(&g, nb, Tw, p, k, s, P, Cout, Hp, padF));
     XVA_CHECK_ARG(wav && W && bias && out, "cin1_fwd: null");
-    static const int mfma0 = [] { const char* e = getenv("XVA_HG_CONV0_MFMA"); return e ? atoi(e) : 1; }();     // 0: the v_pk_fma form (A/B)
-    if (mfma0 && dt == XVA_BF16 && (Cout == 128 || Cout == 32) && k <= 16 && (((uintptr_t)out) % 16) == 0 && ((int64_t)Hp * Cout) % 8 == 0) {
+    if (dt == XVA_BF16 && (Cout == 128 || Cout == 32) && k <= 16 && (((uintptr_t)out) % 16) == 0 && ((int64_t)Hp * Cout) % 8 == 0) {
         const size_t lds = (size_t)(s * (CIN1_MFMA_ROWS - 1) + 16) * sizeof(float);
         const dim3 grid(xva_cdiv(g.Tout, CIN1_MFMA_ROWS), nb * p);
         if (Cout == 128) hipLaunchKernelGGL(hg_cin1_fwd_mfma_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, wav, W, bias, (uint16_t*)out, g, slope);
         else hipLaunchKernelGGL(hg_cin1_fwd_mfma_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, wav, W, bias, (uint16_t*)out, g, slope);
-        XVA_LAUNCH_CHECK();
-        return XVA_OK;
-    }
-    // the packed-fp32 form: OFF by default — inside the discriminator pass (four stream lanes) it gave sporadically wrong even channels for a few lanes of one
-    // instruction, on the side lanes only; bit-identical alone, on one stream and under tools/hg_conv0_repro.py's load.  XVA_HG_CONV0_PKFMA=1 brings it back for that hunt.
-    static const int pkfma = [] { const char* e = getenv("XVA_HG_CONV0_PKFMA"); return e ? atoi(e) : 0; }();
-    if (pkfma && Cout % 8 == 0 && 256 % (Cout / 8) == 0 && (k == 5 || k == 15) && (((uintptr_t)out) % 16) == 0 && ((int64_t)Hp * Cout) % 8 == 0) {
-        constexpr int RPT = 16;
-        const int rows_blk = 256 / (Cout / 8) * RPT;
-        const size_t lds = (size_t)(s * (rows_blk - 1) + k) * sizeof(float);
-        if (k == 5) hipLaunchKernelGGL((hg_cin1_fwd8_kernel<5, RPT>), dim3(xva_cdiv(g.Tout, rows_blk), nb * p), dim3(256), lds, (hipStream_t)stream, wav, W, bias, out, dt, g, slope);
-        else hipLaunchKernelGGL((hg_cin1_fwd8_kernel<15, RPT>), dim3(xva_cdiv(g.Tout, rows_blk), nb * p), dim3(256), lds, (hipStream_t)stream, wav, W, bias, out, dt, g, slope);
         XVA_LAUNCH_CHECK();
         return XVA_OK;
     }

@@ -861,12 +861,12 @@ int conv0_fwd(Ctx& c, const float* Pd, const DiscRun& r, int i0, int ni) {
     return hg_conv_fwd(xc, t1, cw0(c, l0, Pd, r.pass), e, c.compute, c.st);
 }
 
-// conv0 straight from the waveform (hg_ops.hip hg_cin1_fwd8_kernel): no im2col launch, no K = 8 / 16 product.  XVA_HG_CONV0_DIRECT=0 keeps the GEMM form
+// conv0 straight from the waveform (hg_ops.hip hg_cin1_fwd_mfma_kernel): no im2col launch, no K = 8 / 16 product.  XVA_HG_CONV0_DIRECT=0 keeps the GEMM form
 // (the im2col of the waveform is then made here; with the direct form the D-step backward makes it, for the weight gradient — once per iteration, not twice)
 static const int g_conv0_direct = [] { const char* e = getenv("XVA_HG_CONV0_DIRECT"); return e ? atoi(e) : 1; }();
-// bf16 mode only (hg_cin1_fwd_mfma_kernel).  The fp32 form of the direct kernel (hg_cin1_fwd8_kernel: packed-fp32 FMAs) gave sporadically wrong EVEN channels for a
-// few lanes of one instruction when it ran next to the other lanes' kernels (tools/hg_conv0_repro.py: bit-identical alone and on one stream): the exact-fp32 parity mode
-// keeps the GEMM form, and so does anything the matrix-pipe kernel does not take.
+// bf16 mode only (hg_cin1_fwd_mfma_kernel); the exact-fp32 parity mode keeps the GEMM form, and so does anything the matrix-pipe kernel does not take.  (The
+// packed-fp32 direct kernel of round 5, found giving sporadically wrong values on the side stream lanes, was deleted in round 6 without a root cause:
+// tests/test_lanes_gpu.py compares every engine's lanes-on results with its one-stream results bit for bit.)
 static bool conv0_direct(const Ctx& c) { return g_conv0_direct && c.dt == XVA_BF16; }
 int conv0_any(Ctx& c, const float* Pd, const DiscRun& r, const float* wav, int i0, int ni) {
     if (!conv0_direct(c)) { XVA_TRY(conv0_im2col(c, r, wav, i0, ni)); return conv0_fwd(c, Pd, r, i0, ni); }

@@ -94,6 +94,8 @@ class HifiganEngine:
             else:
                 self._ws.zero_()
             self._dims, self._key = d, key
+            self._ws_gen = getattr(self, "_ws_gen", 0) + 1     # the prepared effective weights / norms in the workspace are gone: disc_forward must not skip
+            self._d_eff_key = None                             # its reparametrisation pass (A -> B -> A geometries would re-match the old key)
         return self._dims
 
     def generator_forward(self, flat_g, mel):
@@ -163,7 +165,7 @@ def _disc_forward(self, flat_d, y_real, y_fake, losses="all", weights_token=None
     d = self._prepare(y_real.size(0), y_real.size(1))
     self._yr, self._yg = y_real.float().contiguous(), y_fake.float().contiguous()
     mask = {"all": 3, "d": 1, "g": 2}[losses]
-    key = None if weights_token is None else (weights_token, flat_d.data_ptr(), flat_d._version, self._ws.data_ptr(), self._key)
+    key = None if weights_token is None else (weights_token, flat_d.data_ptr(), flat_d._version, self._ws.data_ptr(), self._key, self._ws_gen)
     if key is not None and key == getattr(self, "_d_eff_key", None):
         mask |= 4
     self._d_eff_key = key
