@@ -1050,12 +1050,18 @@ def dry_run_gloo(a, rank, world):
     grads = torch.zeros(total)
     expect = float(sum(r + 1 for r in range(world)))
 
+    stamps = {}
+
     def step():
         grads.zero_()
+        t_b = time.perf_counter()
         for b, e in ranges:
             grads[b:e] = rank + 1.0
+        stamps["bucket_start_ms"] = [1e3 * (time.perf_counter() - t_b)] * len(ranges)       # the stand-in "backward" finishes every bucket at once
+        t_e = time.perf_counter()
         if world > 1:
             allreduce_flat_buckets(grads, ranges)
+        stamps["backward_ms"], stamps["allreduce_ms_exposed"] = 1e3 * (t_e - t_b), 1e3 * (time.perf_counter() - t_e)
         for b, e in ranges:
             if e > b and not (grads[b].item() == expect and grads[e - 1].item() == expect):
                 sys.exit("bench.py --dry-run-gloo: rank %d bucket [%d, %d) reduced to %g / %g, expected %g" % (rank, b, e, grads[b], grads[e - 1], expect))
@@ -1081,6 +1087,7 @@ def dry_run_gloo(a, rank, world):
                           "value": total_frames * a.steps / dt, "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                           "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
                           "data": "synthetic", "dry_run": True,
+                          "dp": dict(stamps, rccl_ranks=dist.get_world_size() if world > 1 else 1, backend=dist.get_backend() if world > 1 else None, rccl_version=None),
                           "config": {"workload": "stand-in step: bucketed gloo all-reduce of the stage-%d gradient ranges" % a.stage,
                                      "global_batch": a.batch * world, "per_gpu_frames_per_step": frames_per_step, "parallelism": "dp%d" % world,
                                      "buckets": len(ranges), "bucket_floats": int(sum(e - b for b, e in ranges))}}), flush=True)
@@ -1165,6 +1172,9 @@ def compact_line(out):
     for k in ["provenance", "shared_gpu_gloo"]:
         if k in out:
             line[k] = out[k]
+    if isinstance(out.get("dp"), dict):
+        line["dp"] = {k: ([_r(x, 3) for x in v] if isinstance(v, list) else _r(v)) for k, v in out["dp"].items()
+                      if k in ("rccl_ranks", "rccl_version", "backend", "bucket_start_ms", "backward_ms", "allreduce_ms_exposed", "error")}
     if "parity" in out:
         line["parity"] = _compact_parity(out["parity"])
     if "roofline" in out:
@@ -1313,6 +1323,21 @@ def main():
     out["provenance"] = {"git_head": git_head(), "csrc": csrc_fingerprint()}
     if a.share_gpu_gloo:
         out["shared_gpu_gloo"] = True
+    if world > 1:
+        # the exchange explains itself: who took part, and one extra step with the buckets' timeline stamped
+        import torch.distributed as dist
+        dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": None}
+        try:
+            dp["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        try:
+            sync.diag = True
+            step()
+            dp.update(sync.diagnostics() or {})
+        except Exception as e:
+            dp["error"] = "%s: %s" % (type(e).__name__, e)
+        out["dp"] = dp
     if rank == 0 and world == 1:
         try:
             out["parity"] = golden_parity("fastpitch", a.compute)

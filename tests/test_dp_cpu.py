@@ -159,6 +159,9 @@ def test_bench_two_rank_dry_run_over_gloo():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["dry_run"] is True and out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    dp = out["dp"]            # the multi-rank line explains its exchange: the same keys the RCCL run fills from HIP events
+    assert dp["rccl_ranks"] == 2 and dp["backend"] == "gloo" and "rccl_version" in dp
+    assert len(dp["bucket_start_ms"]) == out["config"]["buckets"] and dp["allreduce_ms_exposed"] >= 0 and dp["backward_ms"] >= 0
     assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 64 and out["config"]["buckets"] >= 12
     per_rank = out["config"]["per_gpu_frames_per_step"]
     # whole-job aggregate: both ranks' frames (their shards differ by seed, so within a few percent of 2 x rank 0's) over the max-over-ranks time

@@ -830,7 +830,8 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         const bool planes = ffn_planes_on(c, R, Tp), att_planes = att_planes_on(c, R, Tp);
         const PlaneT gBp = planes_own(c, c.pl.gp[stk][par], R), y1p = planes_own(c, a.yp, R);        // (planes mode only)
         if (planes && g_ln_pairs)
-            XVA_TRY(xva_fp_layernorm_bwd_pair(gA, c.A(a.sum2), c.F(a.mean2), c.F(a.rstd2), c.P + p.ln2_g, gB, drop ? gBm : nullptr, prow(gBp, 0), gBp.plane, Gg + p.ln2_g,
+            // (fp16-operand mode: the dropout-masked copy exists as the half tensor only — its fp32 twin had one reader, the bias column sum, which reads the half tensor too)
+            XVA_TRY(xva_fp_layernorm_bwd_pair(gA, c.A(a.sum2), c.F(a.mean2), c.F(a.rstd2), c.P + p.ln2_g, gB, (drop && !c.h16) ? gBm : nullptr, prow(gBp, 0), gBp.plane, Gg + p.ln2_g,
                                               Gg + p.ln2_b, R, DM, XVA_MASK_LEN, lens, Tp, c.pd, c.seed, s0 + 2, c.st));
         else
         XVA_TRY(xva_fp_layernorm_bwd(gA, c.A(a.sum2), c.F(a.mean2), c.F(a.rstd2), c.P + p.ln2_g, gB, drop ? gBm : nullptr, c.dt, Gg + p.ln2_g,
@@ -850,7 +851,7 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         // LN1 backward -> gD = d sum1 ; gDm = gD * dropmask (o_net branch)
         if (att_planes && g_ln_pairs) {
             const PlaneT dpp = planes_own(c, c.pl.dp[stk][par], R);
-            XVA_TRY(xva_fp_layernorm_bwd_pair(gC, c.A(a.sum1), c.F(a.mean1), c.F(a.rstd1), c.P + p.ln1_g, gD, drop ? gDm : nullptr, prow(dpp, 0), dpp.plane, Gg + p.ln1_g,
+            XVA_TRY(xva_fp_layernorm_bwd_pair(gC, c.A(a.sum1), c.F(a.mean1), c.F(a.rstd1), c.P + p.ln1_g, gD, (drop && !c.h16) ? gDm : nullptr, prow(dpp, 0), dpp.plane, Gg + p.ln1_g,
                                               Gg + p.ln1_b, R, DM, XVA_MASK_LEN, lens, Tp, c.pd, c.seed, s0 + 1, c.st));
         } else
         XVA_TRY(xva_fp_layernorm_bwd(gC, c.A(a.sum1), c.F(a.mean1), c.F(a.rstd1), c.P + p.ln1_g, gD, drop ? gDm : nullptr, c.dt, Gg + p.ln1_g,
@@ -900,7 +901,8 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         }
         if (planes) {
             XVA_TRY(conv3_bwd_weight_p(cw, gBp, R, DM, hp, DI, Gg + p.c2_w));
-            XVA_TRY(xva_fp_colsum(gBm, c.dt, Gg + p.c2_b, R, DM, DM, cw.st));
+            if (c.h16 && g_ln_pairs) XVA_TRY(xva_fp_colsum(prow(gBp, 0), XVA_F16, Gg + p.c2_b, R, DM, DM, cw.st));
+            else XVA_TRY(xva_fp_colsum(gBm, c.dt, Gg + p.c2_b, R, DM, DM, cw.st));
             XVA_TRY(conv3_bwd_weight_p(cw, gHp, R, DI, y1p, DM, Gg + p.c1_w));
             XVA_TRY(xva_fp_colsum(prow(gHp, 0), pair_dt(c), Gg + p.c1_b, R, DI, DI, cw.st));                       // d b1 = column sums of hi + lo
             if (!c.h16) XVA_TRY(xva_fp_colsum(prow(gHp, 0) + gHp.plane * 2, XVA_BF16, Gg + p.c1_b, R, DI, DI, cw.st));
@@ -911,7 +913,7 @@ static int layers_bwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         XVA_TRY(xva_fp_colsum(gH, c.dt, Gg + p.c1_b, R, DI, DI, cw.st));
         }
         if (att_planes) {
-            if (!(g_planes_mask & 8)) XVA_TRY(attention_wgrad_planes(cw, p, a, gQKV, stk, par, R, Gg));
+            XVA_TRY(attention_wgrad_planes(cw, p, a, gQKV, stk, par, R, Gg));
         } else {
         XVA_TRY(linear_bwd_weight(cw, gDm, R, DM, DM, av, DH, DH, Gg + p.o_w));
         XVA_TRY(linear_bwd_weight(cw, gQKV, R, DQKV, DQKV, x, DM, DM, Gg + p.qkv_w));

@@ -149,10 +149,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (can_split) {   // 256x256 tiles: at most one round of 256 workgroups; smaller tiles (2-3 per CU): ~1.7 rounds; >= 8 K tiles per split
             const long tiles = ntiles(glds_tile);
             // small tiles are latency-bound per K tile (one DMA stage in flight): fill the chip with ~6 workgroups per CU
-            // XVA_GEMM_SK_FILL (per cent, default 100): scales the workgroup count a split aims at — inside the engines' stream lanes another lane's kernels fill what a
-            // product leaves idle, and every split less is a slab written, read and reduced less (A/B knob)
-            static const long fill = [] { const char* e = getenv("XVA_GEMM_SK_FILL"); long v = e ? atol(e) : 100L; return v < 10 ? 10L : v; }();
-            long sk = glds_tile == 1 ? (256 * fill / 100) / tiles : (((glds_tile == 0 ? 864 : 1536) * fill / 100) + tiles / 2) / tiles;
+            long sk = glds_tile == 1 ? 256 / tiles : ((glds_tile == 0 ? 864 : 1536) + tiles / 2) / tiles;
             if (sk > nkt / min_kt) sk = nkt / min_kt;
             if (sk > 1024) sk = 1024;
             if (p.sk_ws && p.N % 4 == 0) {   // stay inside the caller's slab scratch (atomics are much slower)
@@ -176,10 +173,6 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
             if (sk >= 2 && t0 <= 144) { glds_tile = 0; p.splitk = (int)sk; int bm0; xva_gemm_glds_tile_dims(0, &bm0, &bn); bn = bn * 1000 + bm0; }
         }
         if (p.splitk > nkt) p.splitk = nkt;
-        // Experiment knob (round 5): splits of at most XVA_GEMM_SK_ATOMIC_MAX parts skip the slabs + reduce launch and add their
-        // partial tiles to C with fp32 atomics (order-dependent sums; 0 = never, the default)
-        static const int sk_atomic_max = [] { const char* e = getenv("XVA_GEMM_SK_ATOMIC_MAX"); return e ? atoi(e) : 0; }();
-        if (can_split && p.splitk > 1 && p.splitk <= sk_atomic_max) p.sk_ws = nullptr;
     } else if (can_split) {
         const long tiles = (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * p.batch * p.batch2;
         long sk = (768 + tiles - 1) / tiles;

@@ -67,6 +67,8 @@ class GradSync:
         self.events = (C.c_void_p * n)(*[lib.xva_event_create() for _ in range(n)])
         self.comm = torch.cuda.Stream(device=flat.device, priority=int(os.environ.get("XVA_DP_COMM_PRIO", "-1")))
         self._works = []
+        self.diag = False          # True: the next fwd_loss_bwd(sync=True) stamps timing events (see diagnostics())
+        self._diag = None
 
     def __del__(self):
         try:
@@ -92,6 +94,10 @@ class GradSync:
             wloss = dist.all_reduce(losses, group=self.group, async_op=True)   # reporting: SUM of the shares, under backward
         d = eng._prepare(batch.B, batch.Tt, batch.Tm, stage)
         self._works, self._cb_error = [], None
+        tev = lambda: torch.cuda.Event(enable_timing=True)
+        diag = {"bwd_start": tev(), "bwd_end": tev(), "joined": tev(), "start": {}, "end": {}} if (self.diag and sync) else None
+        if diag is not None:
+            diag["bwd_start"].record(cur)
         if sync:
             # The engine calls back right after it has recorded a bucket's event, while this thread is still inside xva_fp_backward_ex issuing the rest
             # of backward: the bucket's wait + all-reduce go onto the exchange stream at that moment.  (Enqueued after the call had returned, every wait
@@ -105,7 +111,11 @@ class GradSync:
                         b, e = self.ranges[i]
                         _lib.check(lib.xva_stream_wait_event(comm_ptr, self.events[i]), "xva_stream_wait_event")
                         with torch.cuda.stream(self.comm):
+                            if diag is not None:
+                                diag["start"][i] = tev(); diag["start"][i].record(self.comm)      # the bucket's gradients are final: its exchange may start
                             self._works.append(dist.all_reduce(self.grads[b:e], group=self.group, async_op=True))
+                            if diag is not None:
+                                diag["end"][i] = tev(); diag["end"][i].record(self.comm)
                         live.discard(i)
                 except BaseException as ex:                         # never unwind through the C frames: re-raised below
                     self._cb_error = ex
@@ -126,10 +136,30 @@ class GradSync:
                 _lib.check(lib.xva_stream_wait_event(comm_ptr, self.events[i]), "xva_stream_wait_event")
                 with torch.cuda.stream(self.comm):
                     self._works.append(dist.all_reduce(self.grads[b:e], group=self.group, async_op=True))
+            if diag is not None:
+                diag["bwd_end"].record(cur)
             for w in self._works:
                 w.wait()                                            # the compute stream waits for the reduced buckets
+            if diag is not None:
+                diag["joined"].record(cur)
+                self._diag, self.diag = diag, False
         wloss.wait()
         return losses
+
+    def diagnostics(self):
+        """Timeline of the last fwd_loss_bwd that ran with `diag = True` (the first real multi-GPU run must explain itself):
+        bucket_start_ms[i] — when bucket i's exchange could start, relative to the start of backward (event on the exchange stream behind the bucket's event);
+        bucket_ms[i] — duration of its all-reduce; backward_ms; allreduce_ms_exposed — how long the compute stream waited for the exchange after backward's
+        last kernel (0 = fully overlapped)."""
+        g = self._diag
+        if g is None:
+            return None
+        torch.cuda.synchronize()
+        order = sorted(g["start"])
+        return {"buckets": order, "bucket_bytes": [4 * (self.ranges[i][1] - self.ranges[i][0]) for i in order],
+                "bucket_start_ms": [g["bwd_start"].elapsed_time(g["start"][i]) for i in order],
+                "bucket_ms": [g["start"][i].elapsed_time(g["end"][i]) for i in order],
+                "backward_ms": g["bwd_start"].elapsed_time(g["bwd_end"]), "allreduce_ms_exposed": g["bwd_end"].elapsed_time(g["joined"])}
 
 
 def allreduce_flat_buckets(grads, ranges, group=None):
