@@ -54,7 +54,7 @@ int xva_mel_num_frames(const xva_mel_config* cfg, int N);
  * configurations) and the FORWARD mel (xva_mel_spectrogram, xva_mel_spectrogram_ragged) is one fused kernel — reflect-indexed frame, FFT,
  * magnitude, mel filterbank, log — whose intermediates stay in LDS; 2 = the FFT inside the four-launch pipeline (pad, FFT, magnitude, filterbank
  * GEMM; what the differentiable mel's backward always uses); 1 = always the dense GEMM against the windowed DFT basis (the reference's own
- * formulation).  Also env XVA_MEL_DFT.  Returns the previous mode. */
+ * formulation).  Returns the previous mode. */
 int xva_mel_set_dft(int mode);
 int64_t xva_mel_workspace_bytes(const xva_mel_config* cfg, int B, int N);
 /* wav:  (B, N) fp32 in [-1, 1], row stride ld_wav.
@@ -317,7 +317,7 @@ int xva_fp_attention_bwd(const void* qkv, const void* av, const void* d_av, cons
                          void* d_qkv, int B, int Tp, float scale, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
 /* The same kernels on split-bf16 PAIRS (fp32 mode with split products; include/xva_gemm.h `planes`): qkv / av / d_av / d_qkv point at the hi planes, the lo planes
  * sit `*_plane` ELEMENTS after them; every product is hi.hi + hi.lo + lo.hi in fp32 and the outputs leave as pairs.  Replaces the unfused scores -> softmax ->
- * P V chain of that mode (two T x T fp32 tensors per layer and direction).  XVA_FP_ATT_FLASH / xva_fp_set_att_flash(0) restores the unfused chain. */
+ * P V chain of that mode (two T x T fp32 tensors per layer and direction).  xva_fp_set_att_flash(0) restores the unfused chain. */
 int xva_fp_attention_fwd_pairs(const void* qkv, int64_t qkv_plane, const int32_t* lens, void* av, int64_t av_plane, float* lse, int B, int Tp, float scale,
                                float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
 int xva_fp_attention_bwd_pairs(const void* qkv, int64_t qkv_plane, const void* av, int64_t av_plane, const void* d_av, int64_t d_av_plane, const float* lse,
@@ -461,7 +461,7 @@ int xva_fp_set_streams(int n);
 int xva_hg_set_pair_mode(int mode);
 /* FastPitch bf16 mode, backward-data of the feed-forward's second Conv1d (python/fastpitch1_1/fastpitch/transformer.py:59-77 under autograd):
  * 1 (default) = through a transposed, tap-reversed bf16 copy of the weight refreshed with the parameter shadow (NT main loop), 0 = on the weight as
- * stored (NN main loop).  Changes the workspace plan: set it before xva_fp_workspace_bytes.  Returns the previous mode.  env XVA_FP_BWD_NT. */
+ * stored (NN main loop).  Changes the workspace plan: set it before xva_fp_workspace_bytes.  Returns the previous mode.  */
 int xva_fp_set_bwd_nt(int mode);
 /* bf16 LayerNorm rows of 384 channels (python/fastpitch1_1/fastpitch/transformer.py:75,146): 1 (default) = the forward takes four rows per wavefront with 16-byte
  * accesses, 0 = one row per wavefront (the backward always does).  Same arithmetic per row; the row sums are taken over a different lane order (fp32 rounding only).  env XVA_FP_LN4. */

@@ -3,7 +3,7 @@
 # (FETCH_SIZE / WRITE_SIZE, separate runs as MI355X_MICROARCH.md prescribes) per leg.  Everything lands in gpurun_out/final/.
 # usage (from the build container):  gpurun -- 'XVA_COMMIT=<short sha> XVA_ROUND=r04 bash tools/profile_round.sh'
 R=${GRAFT_REPO_ROOT:-$PWD}
-RD=${XVA_ROUND:-r05}
+RD=${XVA_ROUND:-r06}
 O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export XVA_BENCH_C5_INPROCESS=1   # the rocprofv3 runs of bench.py keep the xVAPitch leg in the traced process (one database); the plain reference line below unsets it
@@ -58,7 +58,6 @@ python $R/tools/fp_split_step.py 2>/dev/null | tail -1 > $O/${RD}_fastpitch_spli
 XVA_FP_FFN_PLANES=0 python $R/tools/fp_split_step.py 2>/dev/null | tail -1 >> $O/${RD}_fastpitch_split_step.txt
 XVA_SERIAL=1 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -o s -- python $R/tools/fp_split_step.py > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/p_sp -name "*.db" | head -1) $O/${RD}_fastpitch_split_kernel_stats.csv
-for m in 0 3; do echo "== XVA_GEMM_SK_ATOMIC_MAX=$m (splits of <= m parts add their partial tiles with fp32 atomics instead of slabs + reduce)"; XVA_GEMM_SK_ATOMIC_MAX=$m python $R/tools/hg_phase_timing.py 2>/dev/null | tail -11; done > $O/${RD}_splitk_atomics_ab.txt
 # the lanes-off FastPitch kernel trace gets the same fingerprint: bench.py quotes roofline.frac_rocprof from it only while it describes the sources it runs
 cp $O/${RD}_fastpitch_pmc_hbm_bytes.meta.json $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.meta.json
 # the plain bench line last: its roofline.traffic / frac_rocprof read the tables just measured (same sources: fingerprint checked)
@@ -67,5 +66,13 @@ cd $R && XVA_BENCH_C5_INPROCESS=0 python bench.py --steps 20 --warmup 3 2>/dev/n
 cp $R/bench_detail.json $O/${RD}_final_bench_detail.json   # the tables / notes behind the compact line
 ls -la $O
 # the fused ResBlock pair against the two launches (time, per-kernel, PMC traffic) and the run-to-run reproducibility of the three engines on their stream lanes
-bash $R/tools/pair_ab.sh; cp $R/gpurun_out/pair_ab.txt $O/${RD}_resblock_pair_ab_raw.txt
 python $R/tools/determinism_sweep.py 5 2>/dev/null | grep -v amdgpu.ids > $O/${RD}_determinism_sweep_raw.txt
+# round 6 evidence: the vendor-GEMM yardstick, the fp16-operand FastPitch step per kernel with the lanes off (item 1), the trainers' own meters
+# from a dataset directory with and without the prefetcher (item 3), the 256 x 256 workgroup's phase timeline
+python $R/tools/gemm_yardstick.py 20 2>/dev/null > $O/${RD}_gemm_yardstick.txt
+XVA_FP_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/p_f16 -o s -- python $R/tools/fp_step_time.py 20 f16 > /dev/null 2>&1
+python $R/tools/rocpd_summary.py $(find /tmp/p_f16 -name "*.db" | head -1) $O/${RD}_fastpitch_f16_serial_lanes_kernel_stats.csv
+for m in bf16 f16; do python $R/tools/fp_step_time.py 30 $m 2>/dev/null | tail -1; done > $O/${RD}_fastpitch_step_times.txt
+cd $R && python bench.py --trainer-leg 2>/dev/null | tail -1 > $O/${RD}_trainer_leg_prefetch.json
+cd $R && XVA_PREFETCH=0 python bench.py --trainer-leg 2>/dev/null | tail -1 > $O/${RD}_trainer_leg_no_prefetch.json
+mkdir -p $R/build && hipcc --offload-arch=gfx950 -O3 -std=c++17 -DXVA_GLDS_TIMING -I$R/xva-trainer_amd/csrc -I$R/include $R/tools/glds_timing.hip $R/xva-trainer_amd/csrc/core.hip -o $R/build/glds_timing 2>/dev/null && $R/build/glds_timing 0 > $O/${RD}_glds_phase_timing.txt

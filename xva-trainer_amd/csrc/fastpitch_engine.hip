@@ -164,8 +164,8 @@ struct Plan {
 };
 
 // Backward-data of the feed-forward's second convolution through a transposed weight copy and the NT main loop (1, default) or the NN loop on the
-// weight as stored (0).  env XVA_FP_BWD_NT; A/B and test switch (the results differ by fp32 summation order only: same products, same K order).
-static int g_bwd_nt = [] { const char* e = getenv("XVA_FP_BWD_NT"); return e ? atoi(e) : 1; }();
+// weight as stored (0). A/B and test switch (the results differ by fp32 summation order only: same products, same K order).
+static int g_bwd_nt = 1;
 extern "C" int xva_fp_set_bwd_nt(int mode) { int old = g_bwd_nt; g_bwd_nt = mode; return old; }
 
 // fp32 mode, split products: 1 (default) = the feed-forward convolutions through split-bf16 planes on the direct-to-LDS kernels (round 5), 0 = every product on
@@ -178,11 +178,11 @@ static int g_onet_fused = [] { const char* e = getenv("XVA_FP_ONET_FUSED"); retu
 extern "C" int xva_fp_set_onet_fused(int mode) { int old = g_onet_fused; g_onet_fused = mode; return old; }
 // fp32 mode, split products on pairs: 1 (default) = the attention core as the flash-style kernels on pairs (attention.hip: xva_fp_attention_*_pairs), 0 = scores ->
 // softmax -> P V through HBM (two T x T fp32 tensors per layer and direction)
-static int g_att_flash = [] { const char* e = getenv("XVA_FP_ATT_FLASH"); return e ? atoi(e) : 1; }();
+static int g_att_flash = 1;
 extern "C" void xva_fp_set_att_flash(int on) { g_att_flash = on; }
 // the same mode: 1 (default) = the LayerNorm kernels leave y1 / the next layer's input / d(sum) ALSO as split-bf16 pairs (xva_fp_layernorm_*_pair) and the
 // backward reads the forward's pairs, 0 = a split launch in front of every product that reads them (6 per layer)
-static int g_ln_pairs = [] { const char* e = getenv("XVA_FP_LN_PAIRS"); return e ? atoi(e) : 1; }();
+static int g_ln_pairs = 1;
 extern "C" void xva_fp_set_ln_pairs(int on) { g_ln_pairs = on; }
 
 int make_plan(const xva_fp_dims* d, Plan* p) {
@@ -445,8 +445,8 @@ static bool planes_mode(const Ctx& c) { return !c.compute && c.pl.wplanes >= 0 &
 static inline int pair_dt(const Ctx& c) { return c.h16 ? XVA_F16 : XVA_BF16; }
 static inline int64_t wplane_off(const Ctx& c) { return c.h16 ? 0 : c.pl.wplane_stride; }
 // per stack: the direct-to-LDS kernels want at least a K tile of rows / keys (toy sequences stay on the register-staged kernel)
-// XVA_FP_PLANES_MASK (A/B, debugging): bit 0 encoder stack, bit 1 decoder stack, bit 2 the attention block (clear: feed-forward only); default 7
-static const int g_planes_mask = [] { const char* e = getenv("XVA_FP_PLANES_MASK"); return e ? atoi(e) : 7; }();
+// (former debugging mask, now fixed at 7) bit 0 encoder stack, bit 1 decoder stack, bit 2 the attention block (clear: feed-forward only); default 7
+static const int g_planes_mask = 7;
 static bool ffn_planes_on(const Ctx& c, int64_t R, int Tp) {
     const bool enc = R == c.pl.Re && Tp == c.pl.Ttp;
     return planes_mode(c) && R >= 64 && Tp >= 16 && (c.h16 || (g_planes_mask & (enc ? 1 : 2)));
@@ -764,10 +764,10 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
 // A second side stream carries the temporal predictors (model.py:394-418): in training the decoder is conditioned on the TARGET pitch /
 // energy, so neither its forward nor its backward depends on them; their small, latency-bound kernels run under the decoder's GEMMs.
 // env XVA_FP_STREAMS=1 keeps everything on the caller's stream.
-// Side-lane stream priority: env XVA_LANE_PRIO = 0 default priority (the default), 1 lowest, 2 highest.  Measured (FastPitch / HiFi-GAN ms
+// Side-lane stream priority (round 2 experiment, knob removed): default priority (kept), lowest, highest.  Measured (FastPitch / HiFi-GAN ms
 // per step): default 10.38 / 38.4, lowest 10.49 / 45.9 (the lanes starve: HiFi-GAN falls back to its one-stream time), highest 10.47 / 55.0 (the caller's chain starves).
 static hipError_t xva_create_lane_stream(hipStream_t* s) {
-    static const int mode = [] { const char* e = getenv("XVA_LANE_PRIO"); return e ? atoi(e) : 0; }();
+    static const int mode = 0;      // (measured in round 2: lowest / highest priority lanes starve one side; the knob is gone)
     int least = 0, greatest = 0;
     if (mode != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
         return hipStreamCreateWithPriority(s, hipStreamNonBlocking, mode == 1 ? least : greatest);

@@ -598,7 +598,7 @@ static int layernorm_bwd_impl(const void* dY, const void* X, const float* mean, 
 #define XVA_LNB(CPL, BFV) hipLaunchKernelGGL((layernorm_bwd_kernel<CPL, BFV, false>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma, \
                                              dbeta, rows, rpb, mask_mode, lens, Tp, relu_gate, p_in, seed_in, stream_in, p_out, seed_out, stream_out, outer_d, outer_w, \
                                              dxp, pair_plane)
-    static const int lnb_fast = [] { const char* e = getenv("XVA_FP_LNB_FAST"); return e ? atoi(e) : 1; }();     // 0: the generic kernel for every launch (A/B)
+    static const int lnb_fast = 1;
     if (lnb_fast && C == 384 && bf && p_in <= 0.f && !relu_gate && !dxp) {
         hipLaunchKernelGGL((layernorm_bwd_kernel<6, true, true>), grid, block, 0, (hipStream_t)stream, dY, X, mean, rstd, gamma, dX, dXm, dt, dgamma, dbeta, rows, rpb, mask_mode, lens,
                            Tp, 0, 0.f, (uint64_t)0, 0u, p_out, seed_out, stream_out, (const float*)nullptr, (const float*)nullptr, (uint16_t*)nullptr, (int64_t)0);

@@ -22,9 +22,9 @@ void xva_prof_end(hipStream_t st);
 void xva_prof_cancel();
 void xva_prof_shape(int M, int N, int K, int batch, int splitk, int bn, double bytes);
 
-// Main-loop selection: -1 automatic (default; env XVA_GEMM_GLDS overrides), 0 general kernel only, 1..4 force the direct-to-LDS tile
+// Main-loop selection: -1 automatic (default), 0 general kernel only, 1..4 force the direct-to-LDS tile
 // 128x128 / 256x256 / 128x64 / 64x64 wherever eligible.  A diagnostics / test knob, not part of the numerical contract.
-static int g_glds_mode = [] { const char* e = getenv("XVA_GEMM_GLDS"); return e ? atoi(e) : -1; }();
+static int g_glds_mode = -1;
 extern "C" int xva_gemm_set_mainloop(int mode) { int old = g_glds_mode; g_glds_mode = mode; return old; }
 // Products of compute == 0 (fp32-stored operands): 0 (default) = the exact fp32 MFMA, 1 = each operand split into two bf16 (hi + lo) while staged and
 // three bf16 MFMAs per product (gemm_core.h MODE 3; ~1e-5 relative per product instead of 6e-8).  env XVA_GEMM_FP32_PRODUCTS
@@ -116,7 +116,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         const long nb = (long)p.batch * p.batch2 * p.splitk;
         while (bn > 32 && (long)xva_cdiv(p.N, bn) * xva_cdiv(p.M, 128) * nb < 256) bn >>= 1;
     }
-    // direct-to-LDS main loop (gemm_glds.h) for bf16-stored operands; XVA_GEMM_GLDS=0 keeps everything on the general kernel,
+    // direct-to-LDS main loop (gemm_glds.h) for bf16-stored operands; xva_gemm_set_mainloop(0) keeps everything on the general kernel,
     // =1 forces the 128x128 tile, =2 forces 256x256 (A/B switches for profiling)
     const int glds_env = g_glds_mode;
     int glds_tile = -1;
@@ -165,7 +165,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         if (auto_sk && !can_split && p.sk_ws && p.layout != XVA_GEMM_TN && p.N % 4 == 0 && !p.C2 && glds_env < 0 && nkt >= 32 &&
             ((uintptr_t)p.sk_ws % 16) == 0) {
             const long t0 = ntiles(0);
-            static const long fs_num = [] { const char* e = getenv("XVA_GEMM_FSPLIT"); return e ? atol(e) : 520L; }();
+            static const long fs_num = 520L;
             long sk = t0 > 0 ? fs_num / t0 : 1;                    // ~one round of 128 x 128 tiles at two workgroups per CU (512 slots); swept 288 / 400 / 520 / 700 on the encoder products: 520 (4 splits) best
             if (sk > nkt / 12) sk = nkt / 12;
             const long fit = (long)(p.sk_ws_bytes / ((int64_t)p.M * p.N * 4 * nb));

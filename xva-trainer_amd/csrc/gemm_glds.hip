@@ -113,12 +113,12 @@ int xva_gemm_launch_splitk_reduce(const xva_gemm_params& p, hipStream_t st) {
 }
 // K loop of the 256 x 256 tile: 0 = all waves in one phase (two barriers per 64-deep K tile), 1 (default) = two wave groups one barrier
 // apart (xva_gemm_glds8_kernel), 2 = the latter for NT only.  Measured (tools/gemm_tile_ab.py): NT +5 ... +18 %, NN +2 ... +6 %, TN +-1 % on
-// warm operands; inside the training steps (operands from HBM) FastPitch -0.8 %, HiFi-GAN -1.0 % step time.  env XVA_GEMM_KLOOP8
-static int g_kloop8_v = [] { const char* e = getenv("XVA_GEMM_KLOOP8"); return e ? atoi(e) : 1; }();
+// warm operands; inside the training steps (operands from HBM) FastPitch -0.8 %, HiFi-GAN -1.0 % step time.
+static int g_kloop8_v = 1;
 extern "C" int xva_gemm_set_kloop(int mode) { int old = g_kloop8_v; g_kloop8_v = mode; return old; }
 int xva_gemm_glds_kloop8() { return g_kloop8_v; }
-// K loop of the 384 x 128 tile: 1 (default) = the staggered loop, 0 = the lock-step loop of xva_gemm_glds_kernel.  env XVA_GEMM_KLOOP384
-static int g_kloop384_v = [] { const char* e = getenv("XVA_GEMM_KLOOP384"); return e ? atoi(e) : 1; }();
+// K loop of the 384 x 128 tile: 1 (default) = the staggered loop, 0 = the lock-step loop of xva_gemm_glds_kernel.
+static int g_kloop384_v = 1;
 extern "C" int xva_gemm_set_kloop384(int mode) { int old = g_kloop384_v; g_kloop384_v = mode; return old; }
 int xva_gemm_glds_kloop384() { return g_kloop384_v; }
 #endif   // !XVA_GLDS_F16
@@ -142,8 +142,7 @@ int xva_gemm_launch_glds(const xva_gemm_params& pin, int tile, hipStream_t st) {
     if (p.sk_ws && p.N % 8 == 0) vec = 2;        // slab stores are [M][N] fp32 rows whatever C looks like
     // Non-temporal stores for outputs that cannot stay in the 8 x 4 MB of L2 anyway (FastPitch's 27 584 x 1 536 feed-forward intermediate: 85 MB):
     // written the default way they evict the weight / activation panels the tile's next rounds (and the other lane's kernels) re-read.
-    // XVA_GEMM_NT_MB: threshold in MB (0 = never).
-    static const long nt_mb = [] { const char* e = getenv("XVA_GEMM_NT_MB"); return e ? atol(e) : 0L; }();
+    static const long nt_mb = 0;      // (A/B at 12 / 30 / 60 MB thresholds, round 3: nothing outside the run-to-run band; off)
     if (nt_mb > 0 && vec == 2 && !p.sk_ws && !p.accumulate && !p.C2 && !p.c_trans && p.c_dtype != XVA_F32 &&
         (int64_t)p.M * p.N * 2 * p.batch * p.batch2 >= nt_mb * (1L << 20)) vec |= 16;
     int rc = launch_tiles(p, tile, vec, st);

@@ -433,10 +433,10 @@ struct Ctx {
 // chains fill each other's gaps.  The side stream and its two events are created once per host thread; nothing else is hidden: the
 // call still returns with all work ordered on the caller's stream.  env XVA_HG_STREAMS=n: number of lanes (1 = everything on the caller's
 // stream; default 2).
-// Side-lane stream priority: env XVA_LANE_PRIO = 0 default priority (the default), 1 lowest, 2 highest.  Measured (FastPitch / HiFi-GAN ms
+// Side-lane stream priority (round 2 experiment, knob removed): default priority (kept), lowest, highest.  Measured (FastPitch / HiFi-GAN ms
 // per step): default 10.38 / 38.4, lowest 10.49 / 45.9 (the lanes starve: HiFi-GAN falls back to its one-stream time), highest 10.47 / 55.0 (the caller's chain starves).
 static hipError_t xva_create_lane_stream(hipStream_t* s) {
-    static const int mode = [] { const char* e = getenv("XVA_LANE_PRIO"); return e ? atoi(e) : 0; }();
+    static const int mode = 0;      // (measured in round 2: lowest / highest priority lanes starve one side; the knob is gone)
     int least = 0, greatest = 0;
     if (mode != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
         return hipStreamCreateWithPriority(s, hipStreamNonBlocking, mode == 1 ? least : greatest);

@@ -9,7 +9,7 @@
 //
 // MI355X mapping: frames are never materialised — the reflect-padded waveform is read with OVERLAPPING rows (row pitch = hop), each sample
 // from HBM once, from L2 for its 4 overlapping frames.  The windowed DFT is a 1024-point real FFT, one wavefront per frame
-// (xva_stft_fft1024_kernel below: HBM-bound on the spectrum it writes); n_fft != 1024 or XVA_MEL_DFT=1 take the reference's own formulation,
+// (xva_stft_fft1024_kernel below: HBM-bound on the spectrum it writes); n_fft != 1024 or xva_mel_set_dft(1) take the reference's own formulation,
 // a GEMM against the windowed DFT basis on the exact-fp32 MFMA (bf16 would not hold the 1e-3 log-mel tolerance) — that GEMM is also what the
 // differentiable mel's backward uses.  Pipeline:  reflect-pad -> DFT (re | im) -> magnitude -> mel GEMM with
 // the log-clamp fused in its epilogue, written directly in the reference's (B, n_mel, T)
@@ -301,8 +301,8 @@ __global__ __launch_bounds__(64 * FFT_WAVES) void xva_mel_fused_kernel(const voi
     }
 }
 // g_mel_dft: 0 (default) = the FFT wherever n_fft == 1024 (all three variants), and the forward mel as the one fused kernel above; 2 = the FFT with
-// the four-launch pipeline (pad, FFT, magnitude, filterbank GEMM); 1 = always the dense DFT GEMM (XVA_MEL_DFT / xva_mel_set_dft)
-static int g_mel_dft = [] { const char* e = getenv("XVA_MEL_DFT"); return e ? atoi(e) : 0; }();
+// the four-launch pipeline (pad, FFT, magnitude, filterbank GEMM); 1 = always the dense DFT GEMM (xva_mel_set_dft)
+static int g_mel_dft = 0;
 extern "C" int xva_mel_set_dft(int mode) { int old = g_mel_dft; g_mel_dft = mode; return old; }
 static inline int64_t al4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 static inline int64_t al32(int64_t x) { return (x + 31) & ~(int64_t)31; }
@@ -330,7 +330,7 @@ static int mel_plan(const xva_mel_config* c, int B, int N, MelPlan* pl) {
     return XVA_OK;
 }
 
-// spec[b][t][re | im] = windowed DFT of frame t of clip b: the 1024-point FFT kernel, or (other sizes, XVA_MEL_DFT=1) the overlapping-row GEMM
+// spec[b][t][re | im] = windowed DFT of frame t of clip b: the 1024-point FFT kernel, or (other sizes, xva_mel_set_dft(1)) the overlapping-row GEMM
 static int stft_spec(const xva_mel_config* c, const MelPlan& pl, int B, const float* ypad, const float* dft_basis, float* spec, void* stream) {
     if (c->n_fft == 1024 && g_mel_dft != 1 && c->hop % 4 == 0) {
         const int64_t nframes = (int64_t)B * pl.T;

@@ -4,8 +4,8 @@
 namespace xva_glds { __global__ void xva_gemm_splitk_reduce_kernel(xva_gemm_params p); }
 int xva_gemm_launch_splitk_reduce(const xva_gemm_params& p, hipStream_t st);
 
-// env XVA_GEMM_WGRAD=0 / xva_gemm_set_wgrad(0): weight gradients stay on the general TN kernel (A/B switch, tests)
-static int g_wgrad_mode = [] { const char* e = getenv("XVA_GEMM_WGRAD"); return e ? atoi(e) : 1; }();
+// xva_gemm_set_wgrad(0): weight gradients stay on the general TN kernel (A/B switch, tests)
+static int g_wgrad_mode = 1;
 extern "C" int xva_gemm_set_wgrad(int mode) { int old = g_wgrad_mode; g_wgrad_mode = mode; return old; }
 // tuning overrides (tools/wgrad_bench.py): rows per chunk, DMA instructions per wave per chunk (2 / 4 / 6), workgroups in flight (0 = the plan's own)
 static int g_tune_r = 0, g_tune_niw = 0, g_tune_wgs = 0, g_tune_ablate = 0;
