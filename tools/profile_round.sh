@@ -6,16 +6,16 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 RD=${XVA_ROUND:-r06}
 O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export XVA_BENCH_C5_INPROCESS=1   # the rocprofv3 runs of bench.py keep the xVAPitch leg in the traced process (one database); the plain reference line below unsets it
-rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o b -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_final_bench_under_rocprof.json
+export XVA_BENCH_C5_INPROCESS=1   # the rocprofv3 runs of bench.py --no-f16 --no-trainer-leg keep the xVAPitch leg in the traced process (one database); the plain reference line below unsets it
+rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o b -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f16 --no-trainer-leg 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_final_bench_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_stats -name "*.db" | head -1) $O/${RD}_final_bench_kernel_stats.csv
 # the same two legs with the engines' stream lanes off (XVA_*_STREAMS=1): kernels do not overlap, so the per-kernel average durations are the
 # kernels' own — the numbers bench.py's roofline passes (lanes off as well) have to agree with
-XVA_FP_STREAMS=1 XVA_HG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/p_ser -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_serial_lanes_bench_under_rocprof.json
+XVA_FP_STREAMS=1 XVA_HG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/p_ser -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f16 --no-trainer-leg 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_serial_lanes_bench_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_ser -name "*.db" | head -1) $O/${RD}_serial_lanes_kernel_stats.csv
-XVA_FP_STREAMS=1 XVA_HG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/p_fps -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hifigan --no-xvapitch --no-fp32-parity 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_fastpitch_only_serial_lanes_under_rocprof.json
+XVA_FP_STREAMS=1 XVA_HG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/p_fps -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f16 --no-trainer-leg --no-hifigan --no-xvapitch --no-fp32-parity 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_fastpitch_only_serial_lanes_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_fps -name "*.db" | head -1) $O/${RD}_fastpitch_only_serial_lanes_kernel_stats.csv
-rocprofv3 --kernel-trace --stats -d /tmp/p_fp -o f -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hifigan --no-xvapitch --no-fp32-parity 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_fastpitch_only_under_rocprof.json
+rocprofv3 --kernel-trace --stats -d /tmp/p_fp -o f -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f16 --no-trainer-leg --no-hifigan --no-xvapitch --no-fp32-parity 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_fastpitch_only_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_fp -name "*.db" | head -1) $O/${RD}_fastpitch_only_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d /tmp/p_hg -o h -- python $R/tools/hg_phase_timing.py > $O/${RD}_hifigan_phase_timing.txt 2>/dev/null
 python $R/tools/rocpd_summary.py $(find /tmp/p_hg -name "*.db" | head -1) $O/${RD}_hifigan_only_kernel_stats.csv
@@ -24,7 +24,7 @@ XVA_C5_GEMM_PROFILE=1 python $R/tools/c5_step_time.py 16 100 400 bf16 bf16 2>/de
 rocprofv3 --kernel-trace --stats -d /tmp/p_c5 -o c -- python $R/tools/c5_step_time.py 16 100 400 bf16 bf16 > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/p_c5 -name "*.db" | head -1) $O/${RD}_xvapitch_c5_kernel_stats.csv
 # occupancy timelines of the three steps from the kernel traces above (GPU busy union, idle gaps, kernels in flight, who runs alone): tools/trace_gaps.py
-rocprofv3 --kernel-trace -d /tmp/p_fpt -o t -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-hifigan --no-xvapitch --no-fp32-parity --no-roofline > /dev/null 2>&1   # no roofline passes: their LAMB timing loops would be the last markers
+rocprofv3 --kernel-trace -d /tmp/p_fpt -o t -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-f16 --no-trainer-leg --no-hifigan --no-xvapitch --no-fp32-parity --no-roofline > /dev/null 2>&1   # no roofline passes: their LAMB timing loops would be the last markers
 python $R/tools/trace_dump.py $(find /tmp/p_fpt -name "*.db" | head -1) /tmp/fp_trace.csv > /dev/null && python $R/tools/trace_gaps.py /tmp/fp_trace.csv lamb_pass1 5 > $O/${RD}_fastpitch_timeline.txt 2>&1
 python $R/tools/trace_dump.py $(find /tmp/p_hg -name "*.db" | head -1) /tmp/hg_trace.csv > /dev/null && python $R/tools/trace_gaps.py /tmp/hg_trace.csv adamw_kernel 6 > $O/${RD}_hifigan_timeline.txt 2>&1
 python $R/tools/trace_dump.py $(find /tmp/p_c5 -name "*.db" | head -1) /tmp/c5_trace.csv > /dev/null && python $R/tools/trace_gaps.py /tmp/c5_trace.csv adamw_kernel 4 > $O/${RD}_xvapitch_c5_timeline.txt 2>&1
@@ -35,7 +35,7 @@ python $R/tools/trace_dump.py $(find /tmp/p_c5dp -name "*.db" | head -1) /tmp/c5
 rocprofv3 --kernel-trace --stats -d /tmp/p_mel -o m -- python $R/tools/mel_time.py > $O/${RD}_mel_front_end.txt 2>/dev/null
 python $R/tools/rocpd_summary.py $(find /tmp/p_mel -name "*.db" | head -1) /tmp/mel_stats.csv > /dev/null && grep -i "mel\|stft\|magnitude\|reflect\|gemm" /tmp/mel_stats.csv >> $O/${RD}_mel_front_end.txt
 for leg in fastpitch hifigan; do
-  if [ $leg = fastpitch ]; then CMD="python $R/bench.py --steps 2 --warmup 1 --no-hifigan --no-cpu-baseline --no-roofline --no-xvapitch --no-fp32-parity"; else CMD="python $R/tools/hg_gemm_profile.py 64"; fi
+  if [ $leg = fastpitch ]; then CMD="python $R/bench.py --steps 2 --warmup 1 --no-hifigan --no-cpu-baseline --no-f16 --no-trainer-leg --no-roofline --no-xvapitch --no-fp32-parity"; else CMD="python $R/tools/hg_gemm_profile.py 64"; fi
   for ctr in FETCH_SIZE WRITE_SIZE; do
     XVA_FP_STREAMS=1 XVA_HG_STREAMS=1 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/p_${leg}_$ctr -o c -- $CMD > /dev/null 2>&1
     python $R/tools/pmc_summary.py $(find /tmp/p_${leg}_$ctr -name "*.db" | head -1) /tmp/${leg}_$ctr.csv

@@ -60,11 +60,11 @@ inline int hg_conv_out_len(int T, const ConvW& w) { return (T + 2 * w.P - w.d * 
 
 enum { HG_MERGED = 0, HG_PERITEM = 1 };
 inline bool hg_affine(const Seq& X, const Seq& Y, const ConvW& w) { return X.nseq == Y.nseq && X.Hp() == w.s * Y.Hp() && X.padF == w.s * Y.padF; }
-// XVA_HG_PERITEM (default 1): long stride-1 sequences whose length is a whole number of 128-row tiles run per item even where the merged form exists.
+// (round-3 A/B, knob removed; kept on): long stride-1 sequences whose length is a whole number of 128-row tiles run per item even where the merged form exists.
 // The merged form convolves (and masks) the pad rows and its tile count is whatever nseq * Hp / 128 gives: HiFi-GAN's 128-channel stage is
 // 64 x 2112 rows = 1056 tiles = 2.06 rounds of the 512 resident-input workgroups a chip holds (a third, nearly empty round), per item it is
 // 64 x 16 = 1024 tiles = exactly two; the 256-channel stage (T = 256, 32 + 32 pad rows) spends 20 % of its merged rows on pads.
-inline int hg_peritem_pref() { static const int v = [] { const char* e = getenv("XVA_HG_PERITEM"); return e ? atoi(e) : 1; }(); return v; }
+inline int hg_peritem_pref() { return 1; }
 // Forward only: the merged form also re-zeroes the pad rows of its output, which backward relies on (gradient tensors share workspace slots).
 inline int hg_mode(const Seq& X, const Seq& Y, const ConvW& w, bool forward = false) {
     if (!hg_affine(X, Y, w)) return HG_PERITEM;
@@ -248,7 +248,7 @@ inline int hg_conv_bwd_weight(const Seq& dY, const Seq& X, const ConvW& w, int x
         g.accumulate = 1; g.splitk = 0;   // xva_gemm sizes the split to its tile grid and the slab scratch
     }
     if (db) {
-        static const int fused = [] { const char* e = getenv("XVA_HG_BIAS_FUSED"); return e ? atoi(e) : 1; }();     // 0: always the column-sum kernel (A/B)
+        static const int fused = 1;
         if (fused && !swap && xva_gemm_takes_colsum(&g)) g.colsum_out = db;
         else if (db_deferred) *db_deferred = true;
         else XVA_TRY(xva_hg_colsum(dY.ptr(), dY.dt, db, dY.rows(), dY.C, alpha, st));
