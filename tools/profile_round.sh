@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 RD=${XVA_ROUND:-r06}
 O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export XVA_BENCH_C5_INPROCESS=1   # the rocprofv3 runs of bench.py --no-f16 --no-trainer-leg keep the xVAPitch leg in the traced process (one database); the plain reference line below unsets it
+export XVA_BENCH_C5_INPROCESS=1   # the rocprofv3 runs of bench.py keep the xVAPitch leg in the traced process (one database); the plain reference line below unsets it
 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o b -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f16 --no-trainer-leg 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${RD}_final_bench_under_rocprof.json
 python $R/tools/rocpd_summary.py $(find /tmp/p_stats -name "*.db" | head -1) $O/${RD}_final_bench_kernel_stats.csv
 # the same two legs with the engines' stream lanes off (XVA_*_STREAMS=1): kernels do not overlap, so the per-kernel average durations are the
