@@ -25,7 +25,8 @@ def timed(fn, cold):
 
 SHAPES = [("conv1 fwd      NT", "NT", 27584, 1536, 1152), ("conv2 fwd      NT", "NT", 27584, 384, 4608), ("conv2 bwd-data NT", "NT", 27584, 1536, 1152),
           ("conv1 wgrad    TN", "TN", 1536, 1152, 27584), ("conv2 wgrad    TN", "TN", 384, 4608, 27584), ("conv1 bwd-data NN", "NN", 27584, 384, 4608),
-          ("square         NT", "NT", 8192, 8192, 4096)]
+          ("square         NT", "NT", 8192, 8192, 4096),
+          ("hifigan p11 fwd NT", "NT", 16896, 1024, 5120), ("hifigan p11 bwd NN", "NN", 16896, 1024, 5120), ("hifigan p7 fwd  NT", "NT", 15232, 1024, 5120)]
 print("%-20s %7s %6s %6s | %-6s %-5s | %10s %10s | %10s %10s | %s" % ("product", "M", "N", "K", "data", "cache", "vendor us", "TFLOP/s", "xva us", "TFLOP/s", "xva / vendor time"))
 for name, lay, M, N, K in SHAPES:
     for data in ("N(0,1)", "zeros"):

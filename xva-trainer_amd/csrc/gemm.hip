@@ -136,7 +136,18 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
         else if (p.N <= 64) glds_tile = 2;
         else if (nkt < 4) glds_tile = ntiles(0) >= 1024 ? 0 : 3;     // short reductions are prologue / epilogue bound: many small workgroups
         else if (p.layout != XVA_GEMM_TN && p.N > 256 && p.N <= 384 && ntiles(5) >= 160 && !can_split) glds_tile = 5;   // 384 x 128 tiles: no padded columns
-        else if (t256 * maxsk >= 192 && eff256 >= 0.7) glds_tile = 1;
+        else if (t256 * maxsk >= 192 && eff256 >= 0.7) {
+            glds_tile = 1;
+            // Round quantisation (round 6): a grid a few tiles over a whole number of rounds of the 256 CUs pays a whole extra round — HiFi-GAN's period-11
+            // discriminator (16 896 rows x 1 024 columns = 264 tiles of 256 x 256) ran its 1 024-channel layers at 0.52 round efficiency, 0.265 / 0.320 ms per
+            // launch against 0.14 / 0.17 for the other periods.  Cost model: rounds x tile area, the 384 x 128 tile's K loop priced 15 % dearer per flop
+            // (more LDS bytes per MFMA); NT / NN without split-K only (the 384-wide image has no TN form).
+            if (p.layout != XVA_GEMM_TN && !can_split && p.N % 128 == 0) {
+                const long t384 = ntiles(5);
+                const double c256 = (double)((t256 + 255) / 256) * 65536.0, c384 = (double)((t384 + 255) / 256) * 49152.0 * 1.15;
+                if (c384 < c256) glds_tile = 5;
+            }
+        }
         else if (p.layout != XVA_GEMM_TN && p.N % 128 == 0 && !can_split && ntiles(5) >= 176 && ntiles(5) <= 256) glds_tile = 5;   // one round of 384x128 tiles beats 1.x rounds of 128x128
         else if (ntiles(0) * maxsk >= 256) glds_tile = 0;
         else glds_tile = 3;
