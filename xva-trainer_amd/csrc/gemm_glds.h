@@ -33,7 +33,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // v_mfma_f32_16x16x32_f16 — the same rate, the same LDS images and DMA; 11 mantissa bits instead of 8).  All 16-bit tensors of one
 // problem (A, B and whichever of C / R / G / F are not fp32) share the flavour; the LDS bytes are format-agnostic, so only the MFMA
 // opcode and the fp32 <-> 16-bit conversions of the epilogue differ.
-__device__ __forceinline__ bool is16(int dtype) { return dtype != XVA_F32; }
+__host__ __device__ __forceinline__ bool is16(int dtype) { return dtype != XVA_F32; }
 template <bool F16> __device__ __forceinline__ void unpack2(uint32_t w, float& a, float& b) {
     if constexpr (F16) { const f16x2 h = __builtin_bit_cast(f16x2, w); a = (float)h[0]; b = (float)h[1]; }
     else { a = __uint_as_float(w << 16); b = __uint_as_float(w & 0xffff0000u); }
@@ -447,7 +447,12 @@ __device__ __forceinline__ void wave_lds_order() {
     asm volatile("" ::: "memory");
 }
 
-template <int MI, int NJ, bool F16 = false>
+// EPI (round 6): which optional epilogue features are COMPILED IN — bit 0: residual / gate / accumulate-into-C reads, bit 1: dropout, bit 2: the rest (feature-matching
+// term, second output, split-pair output, non-temporal stores).  The full epilogue is ~10 KB of code per pass and four passes per loop iteration: with everything
+// compiled in, a 256 x 256 workgroup spent 8.8 us in it whatever the problem used (6.4 us with the global stores removed: tools/glds_timing.hip -DXVA_GLDS_ABLATE=16),
+// 5.7 us with the unused paths compiled out.  The 256 x 256 / 384 x 128 kernels are instantiated for EPI 0, 1, 3 and 7 and the launcher picks the smallest that
+// covers the problem (epi_variant).
+template <int MI, int NJ, bool F16 = false, int EPI = 7>
 __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32x4 (&acc)[MI][NJ], XVA_LDS float* scr, int r0, int c0, int lane,
                                                    int z1, int z2, int bz, int ks, int nt_store = 0) {
     constexpr int WN = NJ * 16, PITCH = WN + 4, LPR = WN / 8, RPP = 64 / LPR, NPASS = 16 / RPP;
@@ -465,7 +470,8 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
         const float4 b0 = bq[0], b1 = bq[1];
         bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
     }
-    const bool want_r = !slab && p.R, want_g = !slab && p.G, want_c = !slab && p.accumulate, want_f = want_g && p.F;
+    constexpr bool E_RG = (EPI & 1) != 0, E_DROP = (EPI & 2) != 0, E_X = (EPI & 4) != 0;
+    const bool want_r = E_RG && !slab && p.R, want_g = E_RG && !slab && p.G, want_c = E_RG && !slab && p.accumulate, want_f = E_X && want_g && p.F;
     const bool mask32 = (int64_t)p.M * p.mask_mul + p.mask_add < (1ll << 31) && p.mask_add >= 0 && p.mask_mul >= 0;   // mapped row indices fit 32 bits
     // The loop over groups of CH row blocks is a RUNTIME loop: unrolled, the epilogue of the 256x256 kernel alone was ~400 KB of
     // code (the instruction cache holds 64 KB) and took 21 us of a 50 us workgroup whatever the memory traffic.  Only the
@@ -512,7 +518,7 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias[e]) * p.alpha;
-                if (p.drop_p > 0.f) {
+                if (E_DROP && p.drop_p > 0.f) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= xva_dropout_scale(p.drop_p, p.drop_seed, p.drop_stream, (uint64_t)row * p.N + col + e);
                 }
@@ -551,14 +557,14 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                 }
                 const int64_t ci = coff + (int64_t)row * p.ldc + col;
                 if (is16(p.c_dtype)) {
-                    if (nt_store) {      // a streamed output (larger than the L2s): do not evict the operand panels the next rounds re-read
+                    if (E_X && nt_store) {      // a streamed output (larger than the L2s): do not evict the operand panels the next rounds re-read
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         const u32x4 pk = {pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7])};
                         __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.C) + ci));
                     } else {
                         const uint4 hi = make_uint4(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]), pack2<F16>(v[4], v[5]), pack2<F16>(v[6], v[7]));
                         *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + ci) = hi;
-                        if (p.c_plane) {      // the lo plane of a split-bf16 pair
+                        if (E_X && p.c_plane) {      // the lo plane of a split-bf16 pair
                             float hv[8]; unpack8<F16>(hi, hv);
                             *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + ci + p.c_plane) =
                                 make_uint4(pack2<F16>(v[0] - hv[0], v[1] - hv[1]), pack2<F16>(v[2] - hv[2], v[3] - hv[3]), pack2<F16>(v[4] - hv[4], v[5] - hv[5]),
@@ -569,7 +575,7 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                     float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + ci);
                     dst[0] = make_float4(v[0], v[1], v[2], v[3]); dst[1] = make_float4(v[4], v[5], v[6], v[7]);
                 }
-                if (p.C2) {   // the activated copy next to the raw one
+                if (E_X && p.C2) {   // the activated copy next to the raw one
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = lrelu(v[e], p.c2_slope);
                     if (is16(p.c_dtype)) {
@@ -585,7 +591,7 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
     }
 }
 // can the row-contiguous epilogue serve this problem? (no transposed / atomic stores)
-__device__ __forceinline__ bool rows_epilogue_ok(const xva_gemm_params& p, int vec_epi) {
+__host__ __device__ __forceinline__ bool rows_epilogue_ok(const xva_gemm_params& p, int vec_epi) {
     if (vec_epi != 2) return false;
     const bool slab = p.splitk > 1 && p.sk_ws;
     if (slab) return true;                       // raw partial sums [split][M][N]: C's own layout (c_trans, strides) is the reduce kernel's business
@@ -596,11 +602,21 @@ __device__ __forceinline__ bool rows_epilogue_ok(const xva_gemm_params& p, int v
     return true;
 }
 constexpr int epi_scratch_bytes(int WN) { return 16 * (WN + 4) * 4; }
+// the smallest compiled epilogue variant (EPI of tile_epilogue_rows) that covers this launch; 7 = everything, incl. the 4-column fallback epilogue
+inline int epi_variant(const xva_gemm_params& p, int vec_flags) {
+    const int vec_epi = vec_flags & 15;
+    if (!rows_epilogue_ok(p, vec_epi)) return 7;
+    if (p.splitk > 1 && p.sk_ws) return 0;                              // raw partial sums into the slabs: no epilogue features at all
+    if (p.F || p.C2 || p.c_plane || (vec_flags >> 4)) return 7;
+    const bool rg = p.R || p.G || p.accumulate;
+    if (p.drop_p > 0.f) return 3;
+    return rg ? 1 : 0;
+}
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
 // vec_epi: 1 = host-verified that N % 4 == 0 and C / R / G rows are 4-element aligned (vector epilogue allowed); 2 = 8-element
 // granularity as well (row-contiguous epilogue through LDS)
-template <int LAYOUT, int BM, int BN, int WM, int WN, bool F16 = false>
+template <int LAYOUT, int BM, int BN, int WM, int WN, bool F16 = false, int EPI = 7>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2 > 80 * 1024) ? 1 : (BM * BN >= 128 * 128 ? 2 : 3)) void xva_gemm_glds_kernel(xva_gemm_params p, int vec_flags) {
     const int vec_epi = vec_flags & 15, nt_store = vec_flags >> 4;     // bit 4: non-temporal C stores (gemm_glds.hip)
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
@@ -764,7 +780,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(acc[i][j]));
-    } else if (rows_epilogue_ok(p, vec_epi))
+    } else if constexpr (EPI != 7)   // host-checked (epi_variant): see xva_gemm_glds8_kernel
+        tile_epilogue_rows<MI, NJ, F16, EPI>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
+    else if (rows_epilogue_ok(p, vec_epi))
         tile_epilogue_rows<MI, NJ, F16>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
     else
         tile_epilogue<MI, NJ, F16>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
@@ -849,7 +867,7 @@ struct KcReader32 {
 // 384-wide index-contiguous image is not laid out): the ring slots have the same 32 KiB (24 + 8), a phase is 10 fragment reads | 24 MFMAs, and the
 // two groups are the waves 0 - 3 / 4 - 7 (row quarters 0, 1 / 2, 3) — what matters is that every SIMD holds one wave of either group.  Before, that
 // tile ran the lock-step loop of xva_gemm_glds_kernel (1.78 us per 64-deep K tile against an MFMA floor of 0.74).
-template <int LAYOUT, int BM = 256, int BN = 256, int WM = 128, int WN = 64, bool F16 = false>
+template <int LAYOUT, int BM = 256, int BN = 256, int WM = 128, int WN = 64, bool F16 = false, int EPI = 7>
 __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params p, int vec_flags) {
     const int vec_epi = vec_flags & 15, nt_store = vec_flags >> 4;     // bit 4: non-temporal C stores (gemm_glds.hip)
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN;
@@ -1052,7 +1070,9 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
     if (grp == 0) XVA_BAR();
 #undef XVA_BAR
     XVA_T(2);
-    if (rows_epilogue_ok(p, vec_epi))
+    if constexpr (EPI != 7)         // host-checked (epi_variant): the row-contiguous epilogue serves this launch and needs no more than EPI's features
+        tile_epilogue_rows<MI, NJ, F16, EPI>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
+    else if (rows_epilogue_ok(p, vec_epi))
         tile_epilogue_rows<MI, NJ, F16>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
     else
         tile_epilogue<MI, NJ, F16>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
@@ -1379,30 +1399,47 @@ inline int launch_tile3(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
 template <int LAYOUT, int BM = 256, int BN = 256, int WM = 128, int WN = 64, bool F16 = false>
 inline int launch_tile8(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
     constexpr int LDS = XVA_GLDS8_SLOTS * (BM + BN) * GK3 * 2;
-    auto kern = xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
-        attr_set = true;
+    const long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, BM) * p.batch * p.batch2 * p.splitk;
+    auto go = [&](auto kern, bool& attr_set) {
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(512), LDS, st, p, vec_epi);
+        return 0;
+    };
+    static bool a0 = false, a1 = false, a3 = false, a7 = false;
+    switch (epi_variant(p, vec_epi)) {      // (vec_epi carries the flag bits of gemm_glds.hip: bit 4 = non-temporal stores)
+        case 0: return go(xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16, 0>, a0);
+        case 1: return go(xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16, 1>, a1);
+        case 3: return go(xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16, 3>, a3);
+        default: return go(xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16, 7>, a7);
     }
-    long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, BM) * p.batch * p.batch2 * p.splitk;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(512), LDS, st, p, vec_epi);
-    return 0;
 }
 
 template <int LAYOUT, int BM, int BN, int WM, int WN, bool F16 = false>
 inline int launch_tile(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int LDS = 2 * (BM + BN) * GK * 2;
-    auto kern = xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN, F16>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
-        attr_set = true;
+    const long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, BM) * p.batch * p.batch2 * p.splitk;
+    auto go = [&](auto kern, bool& attr_set) {
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT), LDS, st, p, vec_epi);
+        return 0;
+    };
+    static bool a0 = false, a1 = false, a3 = false, a7 = false;
+    if constexpr (BM == 128 && BN == 128) {      // the 128 x 128 tile gets the compiled-down epilogue variants too (the other small tiles keep the full one: build time)
+        switch (epi_variant(p, vec_epi)) {
+            case 0: return go(xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN, F16, 0>, a0);
+            case 1: return go(xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN, F16, 1>, a1);
+            case 3: return go(xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN, F16, 3>, a3);
+            default: break;
+        }
     }
-    long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, BM) * p.batch * p.batch2 * p.splitk;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT), LDS, st, p, vec_epi);
-    return 0;
+    return go(xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN, F16, 7>, a7);
 }
 
 }  // namespace xva_glds
