@@ -10,7 +10,6 @@ void xva_gemm_launch_split(const xva_gemm_params& p, int bn, unsigned nblocks, h
 bool xva_gemm_glds_eligible(const xva_gemm_params& p);
 int xva_gemm_launch_glds(const xva_gemm_params& p, int tile, hipStream_t st);
 int xva_gemm_launch_glds_f16(const xva_gemm_params& p, int tile, hipStream_t st);
-int xva_gemm_launch_conv_res_f16(const xva_gemm_params& p, int dstep, hipStream_t st);
 void xva_gemm_glds_tile_dims(int tile, int* bm, int* bn);
 int xva_gemm_conv_res_plan(const xva_gemm_params& p, int* stride_out = nullptr, int64_t* rowpitch_out = nullptr);
 int xva_gemm_launch_conv_res(const xva_gemm_params& p, int dstep, hipStream_t st);
@@ -213,7 +212,7 @@ extern "C" int xva_gemm(const xva_gemm_params* pp, void* stream) {
     XVA_CHECK_ARG(!p.C2 || glds_tile >= 0, "xva_gemm: the second output is written by the direct-to-LDS kernels only (bf16 operands, K >= 64)");
     XVA_CHECK_ARG(!(p.planes || p.c_plane) || glds_tile >= 0, "xva_gemm: split-bf16 planes run on the direct-to-LDS kernels only (K >= 16, 8-element granularity)");
     if (res_dstep != 0) {   // conv over 32 / 64 / 128 channels (per group), stride 1 / 2 / 4: resident input tile
-        if ((p.a_dtype == XVA_F16 ? xva_gemm_launch_conv_res_f16(p, res_dstep, st) : xva_gemm_launch_conv_res(p, res_dstep, st)) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; }
+        if (xva_gemm_launch_conv_res(p, res_dstep, st) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; }
     } else if (glds_tile >= 0) { if ((p.a_dtype == XVA_F16 ? xva_gemm_launch_glds_f16(p, glds_tile, st) : xva_gemm_launch_glds(p, glds_tile, st)) != 0) { xva_set_error("xva_gemm: cannot raise the dynamic LDS limit"); return XVA_ERR_HIP; } }
     else if (mode == 0) xva_gemm_launch_fp32(p, bn, (unsigned)nblocks, st);
     else if (mode == 3) xva_gemm_launch_split(p, bn, (unsigned)nblocks, st);

@@ -1236,7 +1236,7 @@ template <int CIN> __device__ __forceinline__ int res_swz(int row) {
 #define XVA_CONV_RES_WAVES(BN) ((BN) <= 32 ? 5 : ((BN) <= 64 ? 3 : 2))
 #endif
 constexpr int res_a_bytes(int cin, int stride) { return (((stride * 128 + RES_HALO) * cin * 2) + 1023) & ~1023; }
-template <int LAYOUT, int CIN, int BN, int WM, int WN, bool F16 = false>
+template <int LAYOUT, int CIN, int BN, int WM, int WN, bool F16 = false, int EPI = 7>
 __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, XVA_CONV_RES_WAVES(BN)) void xva_conv_res_kernel(xva_gemm_params p, int vec_epi, int dstep, int stride,
                                                                                        int64_t rowpitch) {
     constexpr int BM = 128;
@@ -1358,7 +1358,9 @@ __global__ __launch_bounds__((128 / WM) * (BN / WN) * 64, XVA_CONV_RES_WAVES(BN)
         __builtin_amdgcn_s_barrier();                            // B: tile kt + 1 has landed
     }
     XVA_T(2);
-    if (rows_epilogue_ok(p, vec_epi))
+    if constexpr (EPI != 7)          // host-checked (launch_conv_res): the row-contiguous epilogue serves this launch within EPI's features
+        tile_epilogue_rows<MI, NJ, F16, EPI>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, z, 0);
+    else if (rows_epilogue_ok(p, vec_epi))
         tile_epilogue_rows<MI, NJ, F16>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, z, 0);
     else
         tile_epilogue<MI, NJ, F16>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, z, 0);
@@ -1371,15 +1373,19 @@ inline int launch_conv_res(const xva_gemm_params& p, int vec_epi, int dstep, int
     constexpr int LDS_MAX = LDS_FULL > 160 * 1024 ? 160 * 1024 : LDS_FULL;      // the plan never admits a (CIN, stride) pair beyond the 160 KiB of a CU
     if (res_a_bytes(CIN, stride) + 2 * BN * GK * 2 > LDS_MAX) return -1;
     const int LDS = res_a_bytes(CIN, stride) + 2 * BN * GK * 2;
-    auto kern = xva_conv_res_kernel<LAYOUT, CIN, BN, WM, WN, F16>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess) return -1;
-        attr_set = true;
-    }
-    long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, 128) * p.batch * p.batch2;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, st, p, vec_epi, dstep, stride, rowpitch);
-    return 0;
+    const long nblocks = (long)xva_cdiv(p.N, BN) * xva_cdiv(p.M, 128) * p.batch * p.batch2;
+    auto go = [&](auto kern, bool& attr_set) {
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess) return -1;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, st, p, vec_epi, dstep, stride, rowpitch);
+        return 0;
+    };
+    static bool a5 = false, a7 = false;
+    // HiFi-GAN's convolutions never drop out: everything but the dropout hash (and the 4-column fallback epilogue) compiled in — EPI 5 — unless the launch needs them
+    if (p.drop_p <= 0.f && rows_epilogue_ok(p, vec_epi & 15)) return go(xva_conv_res_kernel<LAYOUT, CIN, BN, WM, WN, F16, 5>, a5);
+    return go(xva_conv_res_kernel<LAYOUT, CIN, BN, WM, WN, F16, 7>, a7);
 }
 
 template <int LAYOUT, int BM, int BN, bool F16 = false>

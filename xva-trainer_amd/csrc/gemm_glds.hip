@@ -215,6 +215,8 @@ int xva_gemm_vec_epilogue_ok(const xva_gemm_params& p) {
 #define vec_epilogue_ok xva_gemm_vec_epilogue_ok
 #endif   // !XVA_GLDS_F16
 // ---- convolutions over 8 / 16 / 32 / 64 / 128 input channels (per group), stride 1 / 2 / 4: resident-input kernel (gemm_glds.h) ----------
+// (bf16 only: no caller runs these layers on fp16 operands — xva_gemm_conv_res_plan declines them and the general tiles take the product)
+#if !XVA_GLDS_F16
 template <int LAYOUT, int CIN>
 static int conv_res_bn(const xva_gemm_params& p, int vec, int dstep, int stride, int64_t rp, hipStream_t st) {
     using namespace xva_glds;
@@ -226,9 +228,8 @@ static int conv_res_bn(const xva_gemm_params& p, int vec, int dstep, int stride,
 //   forward (NT): A(r, tap j, c) = X[(stride * r + j * d) * rowpitch + c]  ->  lda = stride * rowpitch, a_seglen + a_segadj = d * rowpitch
 //   backward-data (NN): the same over dY, taps walking backwards; one polyphase component of a strided conv is a stride-1 problem
 //   grouped: a_seglen = channels per group < rowpitch, the group index is the second batch level
-#if !XVA_GLDS_F16
 int xva_gemm_conv_res_plan(const xva_gemm_params& p, int* stride_out, int64_t* rowpitch_out) {
-    if (!xva_gemm_glds_eligible(p) || p.layout == XVA_GEMM_TN || p.splitk != 1) return 0;
+    if (!xva_gemm_glds_eligible(p) || p.layout == XVA_GEMM_TN || p.splitk != 1 || p.a_dtype != XVA_BF16) return 0;
     const int cin = p.a_seglen;
     const int64_t rp = p.a_rowpitch > 0 ? p.a_rowpitch : p.lda;
     if (!(cin == 8 || cin == 16 || cin == 32 || cin == 64 || cin == 128) || rp < cin || rp % 8 != 0 || p.lda % rp != 0 || p.K % cin != 0 || p.K / cin < 2) return 0;
@@ -248,7 +249,6 @@ int xva_gemm_conv_res_plan(const xva_gemm_params& p, int* stride_out, int64_t* r
     if (rowpitch_out) *rowpitch_out = rp;
     return dstep;
 }
-#endif   // !XVA_GLDS_F16
 template <int LAYOUT>
 static int conv_res_cin(const xva_gemm_params& p, int cin, int vec, int dstep, int stride, int64_t rp, hipStream_t st) {
     switch (cin) {
@@ -259,14 +259,11 @@ static int conv_res_cin(const xva_gemm_params& p, int cin, int vec, int dstep, i
         default: return conv_res_bn<LAYOUT, 128>(p, vec, dstep, stride, rp, st);
     }
 }
-#if XVA_GLDS_F16
-int xva_gemm_launch_conv_res_f16(const xva_gemm_params& p, int dstep, hipStream_t st) {
-#else
 int xva_gemm_launch_conv_res(const xva_gemm_params& p, int dstep, hipStream_t st) {
-#endif
     const int vec = vec_epilogue_ok(p);
     int stride = 1; int64_t rp = p.lda;
     if (xva_gemm_conv_res_plan(p, &stride, &rp) == 0) return -1;
     if (p.layout == XVA_GEMM_NT) return conv_res_cin<XVA_GEMM_NT>(p, p.a_seglen, vec, dstep, stride, rp, st);
     return conv_res_cin<XVA_GEMM_NN>(p, p.a_seglen, vec, dstep, stride, rp, st);
 }
+#endif   // !XVA_GLDS_F16
