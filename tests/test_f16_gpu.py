@@ -121,6 +121,19 @@ def test_gemm_f16_epilogue_fp32_residual_gate_and_mixed_outputs(mainloop):
     L.gemm(A, B, C16, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=1, G=G, ldg=N, gate_slope=0.0)
     ref = (A.double() @ B.double().t()) * (G.double() > 0)
     assert _rel(C16, ref) < 6e-4
+    # dropout + fp16 gate + fp32 residual -> fp32 C (the row-contiguous epilogue's fp32-residual variants on the 256-wide tiles): the mask is the
+    # one the residual-free launch draws, dropped elements carry the residual alone
+    Cn = torch.zeros(M, N, device="cuda")
+    L.gemm(A, B, Cn, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=1, bias=bias, G=G, ldg=N, gate_slope=0.0, drop_p=0.25, drop_seed=5, drop_stream=2)
+    Cr = torch.zeros(M, N, device="cuda")
+    L.gemm(A, B, Cr, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=1, bias=bias, G=G, ldg=N, gate_slope=0.0, drop_p=0.25, drop_seed=5, drop_stream=2,
+           R=R, ldr=N)
+    assert _rel(Cr, Cn.double() + R.double()) < 1e-6
+    kept = (Cn != 0).float().mean().item()
+    assert 0.3 < kept < 0.45                                 # 0.75 kept x about half through the gate
+    C16r = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+    L.gemm(A, B, C16r, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=1, bias=bias, R=R, ldr=N)
+    assert _rel(C16r, A.double() @ B.double().t() + bias.double() + R.double()) < 6e-4
 
 
 def test_gemm_rejects_mixed_16bit_formats_and_offpath_f16():

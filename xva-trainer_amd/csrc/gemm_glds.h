@@ -471,6 +471,7 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
         bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
     }
     constexpr bool E_RG = (EPI & 1) != 0, E_DROP = (EPI & 2) != 0, E_X = (EPI & 4) != 0;
+    constexpr bool E_R32 = (EPI & 8) != 0;      // the residual is an fp32 tensor (fp16-operand / split-products FastPitch: the fp32 residual stream): two 16-byte loads per piece
     const bool want_r = E_RG && !slab && p.R, want_g = E_RG && !slab && p.G, want_c = E_RG && !slab && p.accumulate, want_f = E_X && want_g && p.F;
     const bool mask32 = (int64_t)p.M * p.mask_mul + p.mask_add < (1ll << 31) && p.mask_add >= 0 && p.mask_mul >= 0;   // mapped row indices fit 32 bits
     // The loop over groups of CH row blocks is a RUNTIME loop: unrolled, the epilogue of the 256x256 kernel alone was ~400 KB of
@@ -479,12 +480,17 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
 #pragma unroll 1
     for (int ch = 0; ch < MI / CH; ++ch) {
         const int i0 = ch * CH;
-        uint4 rraw[CH * NPASS], graw[CH * NPASS], craw[CH * NPASS], fraw[CH * NPASS];
+        uint4 rraw[CH * NPASS], graw[CH * NPASS], craw[CH * NPASS], fraw[CH * NPASS], rraw2[E_R32 ? CH * NPASS : 1];
         static_for<CH * NPASS>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             const int row = r0 + (i0 + q / NPASS) * 16 + (q % NPASS) * RPP + rr;
             if (row < p.M && col_ok) {
-                if (want_r) rraw[q] = load8(p.R, roff + (int64_t)row * p.ldr + col);
+                if (want_r) {
+                    if constexpr (E_R32) {
+                        const float* rp = reinterpret_cast<const float*>(p.R) + roff + (int64_t)row * p.ldr + col;
+                        rraw[q] = *reinterpret_cast<const uint4*>(rp); rraw2[q] = *reinterpret_cast<const uint4*>(rp + 4);
+                    } else rraw[q] = load8(p.R, roff + (int64_t)row * p.ldr + col);
+                }
                 if (want_g) graw[q] = load8(p.G, goff + (int64_t)row * p.ldg + col);
                 if (want_f) fraw[q] = load8(p.F, goff + (int64_t)row * p.ldg + col);
                 if (want_c) craw[q] = load8(p.C, coff + (int64_t)row * p.ldc + col);
@@ -533,7 +539,11 @@ __device__ __forceinline__ void tile_epilogue_rows(const xva_gemm_params& p, f32
                     for (int e = 0; e < 8; ++e) v[e] = g[e] > 0.f ? v[e] : v[e] * p.gate_slope;
                 }
                 if (want_r) {
-                    float r8[8]; unpack8<F16>(rraw[q], r8);
+                    float r8[8];
+                    if constexpr (E_R32) {
+                        r8[0] = __uint_as_float(rraw[q].x); r8[1] = __uint_as_float(rraw[q].y); r8[2] = __uint_as_float(rraw[q].z); r8[3] = __uint_as_float(rraw[q].w);
+                        r8[4] = __uint_as_float(rraw2[q].x); r8[5] = __uint_as_float(rraw2[q].y); r8[6] = __uint_as_float(rraw2[q].z); r8[7] = __uint_as_float(rraw2[q].w);
+                    } else unpack8<F16>(rraw[q], r8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += p.beta * r8[e];
                 }
@@ -603,8 +613,11 @@ __host__ __device__ __forceinline__ bool rows_epilogue_ok(const xva_gemm_params&
 }
 constexpr int epi_scratch_bytes(int WN) { return 16 * (WN + 4) * 4; }
 // the smallest compiled epilogue variant (EPI of tile_epilogue_rows) that covers this launch; 7 = everything, incl. the 4-column fallback epilogue
-inline int epi_variant(const xva_gemm_params& p, int vec_flags) {
+inline int epi_variant(const xva_gemm_params& p, int vec_flags, bool r32_variants = false) {
     const int vec_epi = vec_flags & 15;
+    if (r32_variants && p.R && p.r_dtype == XVA_F32 && vec_epi == 2 && !p.c_trans && !(p.splitk > 1) && p.accumulate == 0 && (!p.G || is16(p.g_dtype)) &&
+        !p.F && !p.C2 && !p.c_plane && !(vec_flags >> 4) && p.ldr % 4 == 0 && p.sR % 4 == 0 && p.sR2 % 4 == 0 && ((uintptr_t)p.R % 16) == 0)
+        return (p.drop_p > 0.f ? 3 : 1) | 8;        // the row-contiguous epilogue with an fp32 residual (variants instantiated for the fp16 flavour)
     if (!rows_epilogue_ok(p, vec_epi)) return 7;
     if (p.splitk > 1 && p.sk_ws) return 0;                              // raw partial sums into the slabs: no epilogue features at all
     if (p.F || p.C2 || p.c_plane || (vec_flags >> 4)) return 7;
@@ -1415,7 +1428,13 @@ inline int launch_tile8(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
         return 0;
     };
     static bool a0 = false, a1 = false, a3 = false, a7 = false;
-    switch (epi_variant(p, vec_epi)) {      // (vec_epi carries the flag bits of gemm_glds.hip: bit 4 = non-temporal stores)
+    static bool a9 = false, a11 = false;
+    const int ev = epi_variant(p, vec_epi, F16);
+    if constexpr (F16) {
+        if (ev == 9) return go(xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16, 9>, a9);
+        if (ev == 11) return go(xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16, 11>, a11);
+    }
+    switch (ev) {      // (vec_epi carries the flag bits of gemm_glds.hip: bit 4 = non-temporal stores)
         case 0: return go(xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16, 0>, a0);
         case 1: return go(xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16, 1>, a1);
         case 3: return go(xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16, 3>, a3);
@@ -1438,7 +1457,13 @@ inline int launch_tile(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
     };
     static bool a0 = false, a1 = false, a3 = false, a7 = false;
     if constexpr (BM == 128 && BN == 128) {      // the 128 x 128 tile gets the compiled-down epilogue variants too (the other small tiles keep the full one: build time)
-        switch (epi_variant(p, vec_epi)) {
+        static bool a9 = false, a11 = false;
+        const int ev = epi_variant(p, vec_epi, F16);
+        if constexpr (F16) {
+            if (ev == 9) return go(xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN, F16, 9>, a9);
+            if (ev == 11) return go(xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN, F16, 11>, a11);
+        }
+        switch (ev) {
             case 0: return go(xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN, F16, 0>, a0);
             case 1: return go(xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN, F16, 1>, a1);
             case 3: return go(xva_gemm_glds_kernel<LAYOUT, BM, BN, WM, WN, F16, 3>, a3);
