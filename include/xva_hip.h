@@ -476,6 +476,10 @@ int xva_fp_set_ffn_planes(int mode);
  * hash(seed, stream_id, row * 384 + col)).  xva_fp_set_onet_fused(0) / env XVA_FP_ONET_FUSED=0 put the engine back on the GEMM + LayerNorm pair. */
 int xva_fp_onet_ln_fwd(const void* av, const void* w_bf16, const void* x, const float* gamma, const float* beta, void* sum1, void* y1, float* mean, float* rstd,
                        int64_t rows, int mask_mode, const int32_t* lens, int Tp, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+/* The same block in the fp16-operand mode (fp32 residual stream): av (rows, 64) and w (384, 64) IEEE half; x / sum1 / y1 (rows, 384) fp32, nothing rounded before the
+ * row statistics; y1_f16 = the half copy of y1 that conv1 reads (what xva_fp_layernorm_fwd_pair stores at plane distance 0).  Same dropout mask. */
+int xva_fp_onet_ln_fwd_f16(const void* av_f16, const void* w_f16, const float* x, const float* gamma, const float* beta, float* sum1, float* y1, void* y1_f16, float* mean,
+                           float* rstd, int64_t rows, int mask_mode, const int32_t* lens, int Tp, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
 int xva_fp_set_onet_fused(int mode);
 /* Test / diagnostics: byte offset (into the caller's workspace) and geometry {nseq, T, C, padF, padB} of an activation tensor the last
  * forward stored, time-major (nseq, padF + T + padB, C) in the activation dtype.  kind: 0 mel input, 1 conv_pre output, 2 u[i0] (ups

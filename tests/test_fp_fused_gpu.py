@@ -75,3 +75,76 @@ def test_engine_with_the_fused_tail_matches_the_unfused_engine():
     assert abs(res[1][1][0].item() - res[0][1][0].item()) < 2e-3 * abs(res[0][1][0].item())
     g1, g0 = res[1][0].double(), res[0][0].double()
     assert (g1 @ g0 / (g1.norm() * g0.norm())).item() > 0.999
+
+
+@pytest.mark.parametrize("B,T,p_drop", [(3, 37, 0.0), (2, 300, 0.1), (32, 860, 0.1), (1, 5, 0.1)])
+def test_fused_tail_f16_equals_gemm_plus_layernorm_pair(B, T, p_drop):
+    """round 6, the fp16-operand mode's flavour (xva_fp_onet_ln_fwd_f16): fp16 AV / Wo, fp32 x / sum1 / y1 + the half copy of y1, against the launches it replaces
+    (xva_gemm on XVA_F16 operands with an fp32 residual and the dropout epilogue, then xva_fp_layernorm_fwd_pair at plane distance 0)."""
+    from xva_trainer_amd import _lib
+    L = _lib.lib
+    Tp = T + 2
+    rows = B * Tp
+    g = torch.Generator().manual_seed(B * 11 + T)
+    av = torch.randn(rows, 64, generator=g).cuda().half()
+    x = torch.randn(rows, 384, generator=g).cuda()
+    W = (torch.randn(384, 64, generator=g) * 0.2).cuda().half()
+    gamma = (1 + 0.2 * torch.randn(384, generator=g)).cuda(); beta = (0.1 * torch.randn(384, generator=g)).cuda()
+    lens = torch.randint(max(1, T // 2), T + 1, (B,), generator=g).int().cuda()
+    seed, site = 0x1234567890ABCDEF, 41
+    s_ref = torch.zeros(rows, 384, device="cuda"); y_ref = torch.zeros_like(s_ref); h_ref = torch.zeros(rows, 384, device="cuda", dtype=torch.float16)
+    m_ref = torch.zeros(rows, device="cuda"); r_ref = torch.zeros(rows, device="cuda")
+    _lib.gemm(av, W, s_ref, rows, 384, 64, 64, 64, 384, layout=_lib.GEMM_NT, compute=1, R=x, ldr=384, drop_p=p_drop, drop_seed=seed, drop_stream=site)
+    assert L.xva_fp_layernorm_fwd_pair(_lib.ptr(s_ref), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y_ref), _lib.ptr(h_ref), C.c_int64(0), _lib.ptr(m_ref), _lib.ptr(r_ref),
+                                       C.c_int64(rows), 384, 2, _lib.ptr(lens), Tp, _lib.stream_ptr()) == 0, L.xva_last_error()
+    s = torch.full_like(s_ref, 3.0); y = torch.full_like(s_ref, 3.0); h = torch.full_like(h_ref, 3.0)
+    m = torch.zeros(rows, device="cuda"); r = torch.zeros(rows, device="cuda")
+    rc = L.xva_fp_onet_ln_fwd_f16(_lib.ptr(av), _lib.ptr(W), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(s), _lib.ptr(y), _lib.ptr(h), _lib.ptr(m), _lib.ptr(r),
+                                  C.c_int64(rows), 2, _lib.ptr(lens), Tp, C.c_float(p_drop), C.c_uint64(seed), site, _lib.stream_ptr())
+    assert rc == 0, L.xva_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(s == x, s_ref == x)                          # the same dropout mask (a dropped product leaves sum1 = x exactly)
+    assert ((s - s_ref).abs().max() / s_ref.abs().max()).item() < 1e-6          # fp32 sums of the same 64 products in another order
+    assert torch.allclose(m, m_ref, atol=2e-6, rtol=0) and torch.allclose(r, r_ref, rtol=1e-5, atol=0)
+    assert ((y - y_ref).abs().max() / y_ref.abs().max()).item() < 1e-5
+    assert torch.equal(h.float() != 0, y != 0) or ((h.float() != 0) != (y != 0)).float().mean().item() < 1e-3      # (half underflow of tiny y)
+    assert ((h.float() - y).abs() <= y.abs() * 2.0 ** -11 + 6e-8).all()           # the half copy is the rounding of the fp32 y1
+    # fp64 of the definition
+    sd = (x.double() + (av.double() @ W.double().t()) * ((s != x).double() / (1 - p_drop) if p_drop > 0 else 1.0)).cpu()
+    mu = sd.mean(1, keepdim=True); rs = (((sd - mu) ** 2).mean(1, keepdim=True) + 1e-5).rsqrt()
+    t = torch.arange(rows) % Tp
+    live = ((t > 0) & (t < Tp - 1) & (t <= lens.cpu()[torch.arange(rows) // Tp])).double()[:, None]
+    yd = ((sd - mu) * rs * gamma.double().cpu() + beta.double().cpu()) * live
+    assert ((y.double().cpu() - yd).abs().max() / yd.abs().max()).item() < 2e-5
+    if p_drop > 0:
+        assert 0.85 < (s != x).float().mean().item() < 0.95
+
+
+def test_f16_engine_with_the_fused_tail_matches_the_unfused_engine():
+    """the fp16-operand step with the fused tail (default) against xva_fp_set_onet_fused(0): the fp32 sums differ in their last bit, which moves a half rounding
+    (2^-11) of an operand here and there downstream — agreement inside the mode's own 1e-3"""
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd import _lib
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fp_util import build_engine
+    from xva_trainer_amd.fastpitch.engine import DeviceBatch
+    sd = ofp.init_state_dict(17)
+    batch = ofp.synth_batch(3, 41, 300, 8)
+    res = {}
+    for mode in (1, 0):
+        old = _lib.lib.xva_fp_set_onet_fused(mode)
+        try:
+            eng, flat, grads = build_engine(sd, "f16")
+            b = DeviceBatch.from_dict(batch, "cuda")
+            grads.zero_()
+            losses = eng.fwd_loss_bwd(flat, grads, b, 3).cpu()
+            torch.cuda.synchronize()
+            res[mode] = (grads.clone(), losses.clone(), eng.outputs(b, 3)["mel_out"].float().clone())
+        finally:
+            _lib.lib.xva_fp_set_onet_fused(old)
+    assert ((res[1][2] - res[0][2]).norm() / res[0][2].norm()).item() < 3e-4
+    assert ((res[1][2] - res[0][2]).abs().max() / res[0][2].abs().max()).item() < 1e-3
+    assert abs(res[1][1][0].item() - res[0][1][0].item()) < 1e-5 * abs(res[0][1][0].item())
+    g1, g0 = res[1][0].double(), res[0][0].double()
+    assert ((g1 - g0).norm() / g0.norm()).item() < 2e-3

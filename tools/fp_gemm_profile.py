@@ -5,9 +5,9 @@ import torch
 from xva_trainer_amd import _lib, synthetic
 from xva_trainer_amd.fastpitch import engine as E, params as P
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-MODE = os.environ.get("XVA_FP_MODE", "bf16")     # bf16 | split (fp32 storage, split-bf16 products on pairs)
+MODE = os.environ.get("XVA_FP_MODE", "bf16")     # bf16 | f16 (fp16 operands, fp32 residual stream) | split (fp32 storage, split-bf16 products on pairs)
 if MODE == "split": _lib.lib.xva_gemm_set_fp32_products(1)
-eng = E.FastPitchEngine("cuda", "fp32" if MODE == "split" else "bf16", p_dropout=0.1)
+eng = E.FastPitchEngine("cuda", {"split": "fp32", "f16": "f16"}.get(MODE, "bf16"), p_dropout=0.1)
 flat = torch.zeros(eng.total, device="cuda"); P.default_init_(flat, eng.table, seed=1234)
 grads = torch.zeros_like(flat)
 batch = E.DeviceBatch.from_dict(synthetic.fastpitch_batch(B, 150, 860, 1234), "cuda")

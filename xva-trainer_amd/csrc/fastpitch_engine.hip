@@ -558,7 +558,9 @@ static void pgemm_common(xva_gemm_params& g, const PlaneT* A, const PlaneT* B, c
     if (B) g.b_plane = B->plane;
     if (Cp) { g.c_dtype = g.a_dtype; g.c_plane = Cp->plane; }      // (the operands' 16-bit format: bf16 pair / one half tensor)
 }
-static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* x, bool x_is_split, int64_t R, int Tp, int64_t Ts, const int32_t* lens, uint32_t s0) {
+// fused_tail (fp16-operand mode): o_net, dropout, residual and the LayerNorm behind them as one kernel (fp_fused.hip) — the caller skips its LayerNorm launch
+static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* x, bool x_is_split, int64_t R, int Tp, int64_t Ts, const int32_t* lens, uint32_t s0,
+                                bool fused_tail = false) {
     const int B = c.pl.B;
     const PlaneT xp = planes_own(c, a.xp, R), qp = planes_in_slot(c.A(a.qkv), R, DQKV, QKV_SPARE), avp = planes_in_slot(c.A(a.av), R, DH);
     const PlaneT wq{nullptr, wplane_off(c), 0};
@@ -588,6 +590,11 @@ static int attention_fwd_planes(Ctx& c, const LayerP& p, const LayerA& a, char* 
         g.lda = Ts; g.ldb = DQKV; g.ldc = DH; g.batch = B; g.sA = (int64_t)Tp * Ts; g.sB = (int64_t)Tp * DQKV; g.sC = (int64_t)Tp * DH;
         XVA_TRY(xva_gemm(&g, c.st));
     }
+    }
+    if (fused_tail) {   // sum1 = x + drop(AV Wo^T) ; y1 = LN(sum1) * mask, fp32 and as the half copy conv1 reads
+        const PlaneT yp = planes_own(c, a.yp, R);
+        return xva_fp_onet_ln_fwd_f16(prow(avp, 0), wplane(c, p.o_w), reinterpret_cast<const float*>(x), c.P + p.ln1_g, c.P + p.ln1_b, reinterpret_cast<float*>(c.A(a.sum1)),
+                                      reinterpret_cast<float*>(c.A(a.y1)), prow(yp, 0), c.F(a.mean1), c.F(a.rstd1), R, XVA_MASK_LEN, lens, Tp, c.pd, c.seed, s0 + 1, c.st);
     }
     {   // sum1 = x + drop(AV Wo^T) (fp32)
         xva_gemm_params g = gpp(c); pgemm_common(g, &avp, &wq, nullptr);
@@ -691,8 +698,10 @@ static int layers_fwd(Ctx& c, const LayerP* LP, const LayerA* LA, const int64_t*
         char* x = c.A(xo[l]);
         char* qkv = c.A(a.qkv); char* av = c.A(a.av);
         const uint32_t s0 = site + l * 4;
+        const bool fused_tail = att_planes && ffn_planes && c.h16 && g_ln_pairs && g_onet_fused;
         if (att_planes) {
-            XVA_TRY(attention_fwd_planes(c, p, a, x, g_ln_pairs && l > 0, R, Tp, Ts, lens, s0));
+            XVA_TRY(attention_fwd_planes(c, p, a, x, g_ln_pairs && l > 0, R, Tp, Ts, lens, s0, fused_tail));
+            if (fused_tail) goto ffn;
         } else {
         // qkv = x Wqkv^T + b                                             (transformer.py:109)
         XVA_TRY(linear_fwd(c, x, R, DM, DM, p.qkv_w, c.P + p.qkv_b, qkv, DQKV, DQKV, nullptr, 0, XVA_MASK_NONE, nullptr, 0));
