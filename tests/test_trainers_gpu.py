@@ -124,6 +124,43 @@ def test_fastpitch_trainer_from_dataset_directory(tmp_path):
     assert len(l3) >= 2 and all(np.isfinite(l3))
 
 
+def test_fastpitch_trainer_fp16_operand_mode_skips_non_finite_steps_and_backs_the_loss_scale_off(tmp_path, monkeypatch):
+    """round 6, compute = "f16" through the trainer: the loss scale comes from the batch geometry, a step whose scaled gradients overflow fp16 is SKIPPED on
+    the device (csrc/optim.hip: clip_coef flags it, LAMB leaves weights and moments alone), the skip flag travels with the delayed loss report and the trainer
+    halves the scale — torch.cuda.amp.GradScaler's behaviour in the reference (xva_train.py:350,856-859).  Here the first scale is forced absurdly high."""
+    from xva_trainer_amd.data import SyntheticFastPitchLoader
+    from xva_trainer_amd.fastpitch import engine as E
+    real = E.FastPitchEngine._choose_loss_scale
+    chosen = []
+
+    def absurd(self, b):
+        chosen.append(real(self, b))
+        return 2.0 ** 40
+    monkeypatch.setattr(E.FastPitchEngine, "_choose_loss_scale", absurd)
+    mm, ws = _mm(), _WS()
+    n_it = 45
+    data = {"dataset_path": str(tmp_path / "in" / "voice_h"), "output_path": str(tmp_path / "out"), "checkpoint": None, "num_workers": 0,
+            "batch_size": 4, "epochs_per_checkpoint": 1, "force_stage": 3, "max_iterations": 50000 + n_it}
+    factory = lambda t: SyntheticFastPitchLoader(t.per_rank_batch, n_batches=4096, t_text=20, t_mel=90, seed=7)
+    tr = _fp_trainer(mm, ws, data["output_path"], "voice_h", compute="f16", factory=factory)
+    asyncio.run(tr.start(data, gpus=[0]))
+    assert tr.eng.compute == 2 and tr.total_iter == 50000 + n_it
+    assert len(chosen) == 1 and 2.0 ** 8 <= chosen[0] <= 2.0 ** 14                 # 14 x 90 x 80 frames-bins ~ 2^16.6, and 2^-4 of it
+    log = open(data["output_path"] + "/voice_h/training.log").read()
+    skips = len(re.findall(r"non-finite gradient: step skipped", log))
+    final = getattr(tr, "_next_loss_scale", None) or tr.eng.loss_scale
+    assert skips >= 10 and final == 2.0 ** 40 / 2.0 ** skips                       # one halving per skipped step, nothing else moved the scale
+    assert skips < n_it - 3                                                        # ... and the last steps were taken
+    assert float(tr.optimizer.skipped) == 0.0
+    losses = [float(x) for x in re.findall(r"Stage: 3 .*?loss: ([0-9.]+)", log)]
+    assert losses and all(np.isfinite(losses))
+    sd = tr.model.state_dict()
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
+    from xva_trainer_amd.fastpitch.model import FastPitch
+    fresh = FastPitch(compute="fp32").state_dict()
+    assert not torch.equal(sd["proj.weight"].cpu(), fresh["proj.weight"].cpu())    # taken steps moved the weights
+
+
 def test_stage_completion_rewrites_checkpoint_for_the_next_stage(tmp_path):
     """xva_train.py:954-970: patience of 3 on the avg-delta criterion; on completion training_stage + 1 and an EMPTY loss history go into
     the regular FastPitch_checkpoint_* (and Stage_N_DONE_*), so the next trainer starts stage N + 1 with a clean stopping history."""

@@ -458,6 +458,9 @@ class FastPitchTrainer(RankMixin):
                 self.iter_start_time = time.perf_counter()
             adjust_learning_rate(self.total_iter, self.optimizer, self.learning_rate, self.warmup_steps)
             self.grads.zero_()
+            if getattr(self, "_next_loss_scale", None):         # a new loss scale starts with an accumulation: never two scales inside one gradient sum
+                self.eng.set_loss_scale(self._next_loss_scale)
+                self._next_loss_scale = None
         b = batch if isinstance(batch, E.DeviceBatch) else E.DeviceBatch.from_dict(batch, self.model.flat.device)
         if self.eng.compute == 2 and self.eng.auto_loss_scale:      # one scale for all micro-batches of an accumulation: fixed from the first batch's geometry, then dynamic
             self.eng.set_loss_scale(self.eng._choose_loss_scale(b))
@@ -554,15 +557,17 @@ class FastPitchTrainer(RankMixin):
     # ---- torch.cuda.amp.GradScaler.update (xva_train.py:350,856-859) for the fp16-operand mode ----
     def _update_loss_scale(self, skipped):
         """The optimizer skipped a step with a non-finite gradient on the device (csrc/optim.hip): halve the scale; 2 000 good steps in a row: double it, up to
-        the geometry-derived ceiling.  `skipped` travels with the micro-batch's report (no extra synchronisation)."""
+        the geometry-derived ceiling.  `skipped` travels with the micro-batch's report (no extra synchronisation); the new scale takes effect with the next
+        accumulation that STARTS after the report (iteration()), so one gradient sum never mixes two scales."""
+        cur = getattr(self, "_next_loss_scale", None) or self.eng.loss_scale      # (the report is one micro-batch late: a change may already be pending)
         if skipped != 0.0:
-            self.eng.set_loss_scale(max(1.0, self.eng.loss_scale / 2))
+            self._next_loss_scale = max(1.0, cur / 2)
             self._good_steps = 0
-            self.print_and_log("non-finite gradient: step skipped, loss scale -> %g" % self.eng.loss_scale, save_to_file=self.dataset_output)
+            self.print_and_log("non-finite gradient: step skipped, loss scale -> %g" % self._next_loss_scale, save_to_file=self.dataset_output)
         else:
             self._good_steps = getattr(self, "_good_steps", 0) + 1
-            if self._good_steps >= 2000 and self.eng.loss_scale < self._loss_scale_cap:
-                self.eng.set_loss_scale(self.eng.loss_scale * 2)
+            if self._good_steps >= 2000 and cur < self._loss_scale_cap:
+                self._next_loss_scale = cur * 2
                 self._good_steps = 0
 
     # ---- xva_train.py:915-977 ----
