@@ -471,6 +471,9 @@ int xva_fp_set_ln4(int mode);
  * write (include/xva_gemm.h `planes`), 0 = every product splits its operands while staging them (rounds 3 - 4).  Same arithmetic (hi hi + hi lo + lo hi);
  * changes the workspace plan: set before xva_fp_workspace_bytes.  Returns the previous mode.  env XVA_FP_FFN_PLANES. */
 int xva_fp_set_ffn_planes(int mode);
+/* The plan-affecting switches (xva_fp_set_ffn_planes, xva_fp_set_bwd_nt) as one word.  xva_fp_workspace_bytes and xva_fp_slot_offset depend on them: a caller that
+ * caches either must re-query (and re-zero its workspace: the guard rows move) when this value changes. */
+int xva_fp_plan_knobs(void);
 /* bf16 mode, the tail of MultiHeadAttn.forward (python/fastpitch1_1/fastpitch/transformer.py:132-147): sum1 = x + dropout(AV Wo^T), y1 = LayerNorm(sum1) * rowmask
  * as ONE kernel (av (rows, 64), w_bf16 (384, 64), x / sum1 / y1 (rows, 384) bf16; mean / rstd fp32 per row; the dropout mask of the GEMM epilogue it replaces:
  * hash(seed, stream_id, row * 384 + col)).  xva_fp_set_onet_fused(0) / env XVA_FP_ONET_FUSED=0 put the engine back on the GEMM + LayerNorm pair. */

@@ -463,3 +463,34 @@ def test_split_products_feed_forward_on_planes_equals_splitting_while_staging():
     dec = [float((t1[k].double() - t0[k].double()).norm() / t0[k].double().norm()) for k in t0 if k.startswith(("decoder.", "proj.")) and float(t0[k].abs().max()) > 0]
     assert len(dec) > 60 and max(dec) < 2e-4, max(dec)
     assert ((g1 - g0).norm() / g0.norm()).item() < 5e-3
+
+
+def test_plan_switch_on_a_live_engine_rebuilds_the_workspace():
+    """the workspace plan depends on process-global switches (xva_fp_set_ffn_planes / _bwd_nt); an engine that already stepped must notice a switch
+    (xva_fp_plan_knobs is part of its workspace key): same results as a fresh engine in either setting, on ONE engine object switched back and forth."""
+    from oracle import fastpitch as ofp
+    from xva_trainer_amd import _lib
+    sd = ofp.init_state_dict(13)
+    batch = ofp.synth_batch(2, 23, 120, 6)
+    old_p = _lib.lib.xva_gemm_set_fp32_products(1)
+    try:
+        eng, flat, grads = build_engine(sd, "fp32")
+        seen = {}
+        for mode in (1, 0, 1, 0):
+            old = _lib.lib.xva_fp_set_ffn_planes(mode)
+            try:
+                eng.step = 5                                     # (the dropout masks follow the engine's step counter)
+                b, losses = _run(eng, flat, grads, batch, 3)
+                cur = (grads.clone(), losses.clone())
+                fresh_eng, fflat, fgrads = build_engine(sd, "fp32")
+                fresh_eng.step = 5
+                _, flosses = _run(fresh_eng, fflat, fgrads, batch, 3)
+                close = lambda x, y: ((x.double() - y.double()).norm() / y.double().norm()).item() < 1e-5     # (fp32 atomics in the embedding / bias sums: not bit-stable)
+                assert torch.equal(cur[1], flosses) and close(cur[0], fgrads), "mode %d: a switched engine differs from a fresh one" % mode
+                if mode in seen:
+                    assert close(seen[mode][0], cur[0]) and torch.equal(seen[mode][1], cur[1])
+                seen[mode] = cur
+            finally:
+                _lib.lib.xva_fp_set_ffn_planes(old)
+    finally:
+        _lib.lib.xva_gemm_set_fp32_products(old_p)

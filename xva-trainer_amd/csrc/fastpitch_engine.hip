@@ -172,6 +172,8 @@ extern "C" int xva_fp_set_bwd_nt(int mode) { int old = g_bwd_nt; g_bwd_nt = mode
 // the register-staged kernel that splits while staging (rounds 3 - 4).  Changes the workspace plan: set before xva_fp_workspace_bytes.  env XVA_FP_FFN_PLANES
 static int g_ffn_planes = [] { const char* e = getenv("XVA_FP_FFN_PLANES"); return e ? atoi(e) : 1; }();
 extern "C" int xva_fp_set_ffn_planes(int mode) { int old = g_ffn_planes; g_ffn_planes = mode; return old; }
+// the process-global switches the workspace plan depends on, as one word: a caller that caches xva_fp_workspace_bytes / xva_fp_slot_offset keys its cache on it
+extern "C" int xva_fp_plan_knobs(void) { return (g_ffn_planes ? 1 : 0) | (g_bwd_nt ? 2 : 0); }
 
 // bf16 mode: 1 (default) = o_net + dropout + residual + LayerNorm of a transformer layer's attention block as one kernel (xva_fp_onet_ln_fwd), 0 = GEMM + LayerNorm
 static int g_onet_fused = [] { const char* e = getenv("XVA_FP_ONET_FUSED"); return e ? atoi(e) : 1; }();

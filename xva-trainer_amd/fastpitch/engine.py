@@ -171,7 +171,7 @@ class FastPitchEngine:
 
     # -- workspace ---------------------------------------------------------------------
     def _prepare(self, B, Tt, Tm, stage):
-        key = (B, Tt, Tm, int(stage), self.compute, self.p_dropout)
+        key = (B, Tt, Tm, int(stage), self.compute, self.p_dropout, int(lib.xva_fp_plan_knobs()))     # (the plan also depends on two process-global switches)
         if key != self._ws_key:
             d = FpDims(B, Tt, Tm, int(stage), self.compute, self.p_dropout, self.seed)
             need = int(lib.xva_fp_workspace_bytes(C.byref(d)))
