@@ -71,6 +71,7 @@ class RankMixin:
             except Exception:
                 pass
         self._stop_req, self._stop_work, self._stop_flag = False, None, None
+        self._runs = getattr(self, "_runs", 0) + 1            # dp_launch: "exists, not running, never ran" = still starting (a pause must wait for it)
 
     def _init_distributed(self):
         """One process per GPU.  WORLD_SIZE > 1: join (or create) the process group.  A gpus list with several entries in a process that is not

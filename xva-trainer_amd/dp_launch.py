@@ -321,9 +321,11 @@ def worker_main():
         tr = mm.models_bank.get(key) if mm is not None else None
         if tr is not None and hasattr(tr, "pause") and getattr(tr, "running", True):
             tr.pause()
-        elif tr is None and not state.get("early"):
-            # a pause that beats the trainer into models_bank (the worker is still importing / building it) is remembered and applied once
-            # the trainer runs — dropped silently, the UI would show "paused" over ranks that keep training
+        elif (tr is None or getattr(tr, "_runs", 0) == 0) and not state.get("early"):
+            # a pause that beats the trainer into models_bank (the worker is still importing / building it), or that lands between its insertion and
+            # its first start() (RankMixin._begin_run counts the runs), is remembered and applied once the trainer runs — dropped silently, the UI
+            # would show "paused" over ranks that keep training.  A pause on a PARKED trainer (it has run before) stays a no-op: remembered, it would
+            # end the next resume two iterations in.
             state["early"] = True
 
             def later():
