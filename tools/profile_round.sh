@@ -76,3 +76,10 @@ for m in bf16 f16; do python $R/tools/fp_step_time.py 30 $m 2>/dev/null | tail -
 cd $R && python bench.py --trainer-leg 2>/dev/null | tail -1 > $O/${RD}_trainer_leg_prefetch.json
 cd $R && XVA_PREFETCH=0 python bench.py --trainer-leg 2>/dev/null | tail -1 > $O/${RD}_trainer_leg_no_prefetch.json
 mkdir -p $R/build && hipcc --offload-arch=gfx950 -O3 -std=c++17 -DXVA_GLDS_TIMING -I$R/xva-trainer_amd/csrc -I$R/include $R/tools/glds_timing.hip $R/xva-trainer_amd/csrc/core.hip -o $R/build/glds_timing 2>/dev/null && $R/build/glds_timing 0 > $O/${RD}_glds_phase_timing.txt
+# later round-6 probes: producer -> consumer through the Infinity Cache (item 2c), the attention block's K <= 192 products per tile, the fused fp16-mode tail,
+# every xva_gemm launch of one FastPitch fwd+bwd per shape in both modes (lanes off)
+python $R/tools/producer_consumer_probe.py 2>/dev/null > $O/${RD}_producer_consumer_probe_raw.txt
+python $R/tools/thin_gemm_ab.py 2>/dev/null > $O/${RD}_thin_gemm_tiles.txt
+python $R/tools/onet_f16_time.py 2>/dev/null > $O/${RD}_onet_f16_fused.txt
+cd $R && XVA_FP_STREAMS=1 XVA_TOP=60 python tools/fp_gemm_profile.py 2>/dev/null > $O/${RD}_fastpitch_gemm_profile_bf16.txt
+cd $R && XVA_FP_STREAMS=1 XVA_TOP=70 XVA_FP_MODE=f16 python tools/fp_gemm_profile.py 2>/dev/null > $O/${RD}_fastpitch_gemm_profile_f16.txt
