@@ -148,3 +148,19 @@ def test_f16_engine_with_the_fused_tail_matches_the_unfused_engine():
     assert abs(res[1][1][0].item() - res[0][1][0].item()) < 1e-5 * abs(res[0][1][0].item())
     g1, g0 = res[1][0].double(), res[0][0].double()
     assert ((g1 - g0).norm() / g0.norm()).item() < 2e-3
+
+
+def test_fused_tail_f16_rejects_bad_arguments():
+    """the C ABI's error behaviour: null / misaligned pointers come back as an error code with a message, nothing is launched"""
+    from xva_trainer_amd import _lib
+    L = _lib.lib
+    rows = 64
+    av = torch.zeros(rows, 64, device="cuda", dtype=torch.float16); W = torch.zeros(384, 64, device="cuda", dtype=torch.float16)
+    x = torch.zeros(rows * 384 + 8, device="cuda"); gamma = torch.ones(384, device="cuda"); beta = torch.zeros(384, device="cuda")
+    s = torch.zeros(rows, 384, device="cuda"); y = torch.zeros_like(s); h = torch.zeros(rows, 384, device="cuda", dtype=torch.float16)
+    m = torch.zeros(rows, device="cuda"); r = torch.zeros(rows, device="cuda"); lens = torch.full((1,), 62).int().cuda()
+    call = lambda xp, sp: L.xva_fp_onet_ln_fwd_f16(_lib.ptr(av), _lib.ptr(W), xp, _lib.ptr(gamma), _lib.ptr(beta), sp, _lib.ptr(y), _lib.ptr(h), _lib.ptr(m), _lib.ptr(r),
+                                                   C.c_int64(rows), 2, _lib.ptr(lens), 64, C.c_float(0.0), C.c_uint64(1), 0, _lib.stream_ptr())
+    assert call(_lib.ptr(x[1:]), _lib.ptr(s)) != 0 and b"alignment" in L.xva_last_error()          # x 4 bytes off a 16-byte boundary
+    assert call(_lib.ptr(x), None) != 0 and b"null" in L.xva_last_error()
+    assert call(_lib.ptr(x), _lib.ptr(s)) == 0
