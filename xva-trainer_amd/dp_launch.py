@@ -329,11 +329,19 @@ def worker_main():
             state["early"] = True
 
             def later():
+                # The request belongs to the trainer's FIRST run.  If that run has already ended when this thread looks (a peer rank's watcher asked first and
+                # the ranks agreed to stop within two iterations — the watchers poll 0.1 s apart), the request is spent: kept alive, it would stop the NEXT run
+                # (a resume) a few iterations in.
                 for _ in range(3000):
                     t = state["mm"].models_bank.get(key) if state["mm"] is not None else None
-                    if t is not None and hasattr(t, "pause") and getattr(t, "running", False):
-                        t.pause()
-                        break
+                    if t is not None and hasattr(t, "pause"):
+                        runs = getattr(t, "_runs", None)
+                        if getattr(t, "running", False):
+                            if runs is None or runs <= 1:
+                                t.pause()
+                            break
+                        if runs is not None and runs >= 1:
+                            break
                     time.sleep(0.1)
                 state["early"] = False
             threading.Thread(target=later, daemon=True).start()
