@@ -158,6 +158,9 @@ int xva_gemm_set_kloop(int mode);
 /* Diagnostics / test knob: K loop of the 384x128 direct-to-LDS tile (NT / NN). 1 (default) = the staggered loop above with {10 LDS reads + DMA |
  * 24 MFMAs} phases, 0 = all waves in one phase. Returns the previous mode. Same results up to fp32 summation order. */
 int xva_gemm_set_kloop384(int mode);
+/* NT products on the 256 x 256 tile (K % 64 == 0, tap segments a multiple of 64): 1 (default) = DMA pieces of 8 rows x 128 bytes (whole cache lines) into a ring of
+ * five 32 KiB operand units, 0 = the 16-row x 64-byte pieces of the 32-deep tiles.  Same products in the same order: results are bit-identical. */
+int xva_gemm_set_wholeline(int mode);
 /* Diagnostics / test knob: 1 (default) = convolution weight gradients (TN, column segments, fp32 C accumulated through the caller's
  * split-K slabs) run on the resident-operand kernel (csrc/wgrad_res.h: the chunk's dY and X rows loaded once, all taps from LDS);
  * 0 = they stay on the general TN tiles.  Returns the previous mode.  Same results up to fp32 summation order. */

@@ -366,3 +366,67 @@ def test_splitk_with_the_full_epilogue_in_the_reduce_pass(layout):
         assert ((a - b).abs().max() / a.abs().max()).item() < tol
     pad_rows = torch.arange(M, device="cuda") % Tp
     assert out[("split", torch.float32)][(pad_rows == 0) | (pad_rows == Tp - 1)].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_nt_wholeline_pieces_are_bit_identical_to_the_32_deep_tiles(dt):
+    """round 6: NT products on the 256 x 256 tile fetch their operands as 8-row x 128-byte DMA pieces into a ring of five operand units
+    (xva_gemm_glds8w_kernel) when K % 64 == 0 and the tap segments are multiples of 64.  The same 32-deep phases in the same order: every result is
+    bit-identical to the 16-row x 64-byte form (xva_gemm_set_wholeline(0)) — plain products, ragged edges, short and long K, the conv tap-segment form,
+    split-K slabs, two batch levels, the epilogue with gate + dropout + residual — and right against fp64."""
+    L = _lib()
+    L.lib.xva_gemm_set_wholeline.restype = int
+    old = L.lib.xva_gemm_set_mainloop(2)
+    oldk = L.lib.xva_gemm_set_kloop(1)
+    torch.manual_seed(3)
+    mk = lambda r, c, s=1.0: (torch.randn(r, c, device="cuda") * s).to(dt)
+    cdt = dt
+    cases = []
+    for M, N, K in [(700, 520, 64), (257, 264, 128), (1000, 1536, 1152), (300, 256, 4608), (64, 72, 192)]:
+        A, B = mk(M, K, 0.5), mk(N, K, 0.5)
+        cases.append(("plain %dx%dx%d" % (M, N, K), dict(args=(A, B, M, N, K, K, K), kw={}, ref=A.double() @ B.double().t())))
+    # conv k = 3 over 384 channels (FastPitch conv1): three tap segments of 384 = 6 x 64
+    T, Cin, Cout, PAD = 900, 384, 520, 8
+    xs = torch.zeros(T + 2 * PAD, Cin, device="cuda", dtype=dt); xs[PAD:PAD + T] = mk(T, Cin)
+    W = mk(Cout, Cin * 3, 0.05)
+    refc = sum(xs[PAD - 1 + j:PAD - 1 + j + T].double() @ W[:, j * Cin:(j + 1) * Cin].double().t() for j in range(3))
+    cases.append(("conv taps", dict(args=(xs, W, T, Cout, 3 * Cin, Cin, 3 * Cin), kw=dict(a_offset=(PAD - 1) * Cin, a_seglen=Cin, a_segadj=0), ref=refc)))
+    try:
+        for name, c in cases:
+            A, B, M, N, K, lda, ldb = c["args"]
+            outs = {}
+            G = (torch.randn(M, N, device="cuda") > 0).to(cdt); R = torch.randn(M, N, device="cuda").to(cdt); bias = torch.randn(N, device="cuda")
+            for mode in (1, 0):
+                L.lib.xva_gemm_set_wholeline(mode)
+                C32 = torch.full((M, N), 7.0, device="cuda")
+                L.gemm(A, B, C32, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=1, **c["kw"])
+                C16 = torch.full((M, N), 7.0, device="cuda", dtype=cdt)
+                L.gemm(A, B, C16, M, N, K, lda, ldb, N, layout=L.GEMM_NT, compute=1, bias=bias, G=G, ldg=N, gate_slope=0.0, R=R, ldr=N,
+                       drop_p=0.1, drop_seed=5, drop_stream=1, **c["kw"])
+                outs[mode] = (C32, C16)
+            assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1]), name
+            assert _rel(outs[1][0], c["ref"]) < 3e-6, name
+            kept = (outs[1][1].float() != R.float()).float().mean().item()       # a dropped or gated-off product leaves the residual alone
+            assert 0.35 < kept < 0.55, (name, kept)
+        # split-K through slabs (forward form with the epilogue in the reduce pass) and two batch levels
+        M, N, K = 520, 264, 4608
+        A, B = mk(M, K, 0.3), mk(N, K, 0.3)
+        ws = torch.empty(16 * M * N, device="cuda")
+        Ab, Bb = mk(6 * 300, 256, 0.5), mk(6 * 260, 256, 0.5)
+        res = {}
+        for mode in (1, 0):
+            L.lib.xva_gemm_set_wholeline(mode)
+            Cs = torch.zeros(M, N, device="cuda")
+            L.gemm(A, B, Cs, M, N, K, K, K, N, layout=L.GEMM_NT, compute=1, splitk=0, sk_ws=ws)
+            Cb = torch.zeros(6, 300, 260, device="cuda")
+            L.gemm(Ab, Bb, Cb, 300, 260, 256, 256, 256, 260, layout=L.GEMM_NT, compute=1, batch=3, batch2=2, sA=2 * 300 * 256, sA2=300 * 256, sB=2 * 260 * 256,
+                   sB2=260 * 256, sC=2 * 300 * 260, sC2=300 * 260)
+            res[mode] = (Cs, Cb)
+        assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1])
+        assert _rel(res[1][0], A.double() @ B.double().t()) < 3e-6
+        refb = torch.bmm(Ab.view(6, 300, 256).double(), Bb.view(6, 260, 256).double().transpose(1, 2))
+        assert _rel(res[1][1], refb) < 3e-6
+    finally:
+        L.lib.xva_gemm_set_wholeline(1)
+        L.lib.xva_gemm_set_mainloop(old)
+        L.lib.xva_gemm_set_kloop(oldk)

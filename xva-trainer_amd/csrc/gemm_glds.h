@@ -139,6 +139,12 @@ struct Loader {
             __builtin_amdgcn_global_load_lds((const XVA_GLB void*)src, (XVA_LDS void*)(tile + (q * NW + wave) * 1024), 16, 0, 0);
         }
     }
+    // the whole 64-deep tile lies inside K
+    __device__ __forceinline__ void issue_full(const uint16_t* base, XVA_LDS uint8_t* tile, int wave) const {
+#pragma unroll
+        for (int q = 0; q < NI; ++q)
+            __builtin_amdgcn_global_load_lds((const XVA_GLB void*)(base + off[q]), (XVA_LDS void*)(tile + (q * NW + wave) * 1024), 16, 0, 0);
+    }
 };
 
 // ---- MFMA operand fragments -----------------------------------------------------------------------------------------------------
@@ -804,6 +810,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (2 * (BM + BN) * GK * 2
 
 // ---- 32-deep K tiles -------------------------------------------------------------------------------------------------------------
 constexpr int GK3 = 32;
+#ifndef XVA_GLDS8_WHOLE
+#define XVA_GLDS8_WHOLE 1          // NT products on the 256 x 256 tile: the loop with whole-line DMA pieces (xva_gemm_glds8w_kernel) when the geometry allows
+#endif
+#ifdef XVA_GLDS_TIMING
+static inline int xva_gemm_glds_wholeline() { return XVA_GLDS8_WHOLE; }     // tools/glds_timing.hip: fixed at compile time
+#else
+int xva_gemm_glds_wholeline();                                              // gemm_glds.hip (xva_gemm_set_wholeline)
+#endif
 #ifndef XVA_GLDS8_SLOTS
 #define XVA_GLDS8_SLOTS 4          // ring slots of the staggered 256x256 K loop (4 or 5): 4 x 32 KiB, three tiles (96 k) in flight; 5 slots (all 160 KiB)
                                    // measured +2 % warm, nothing inside the training steps
@@ -1084,6 +1098,152 @@ __global__ __launch_bounds__(512, 1) void xva_gemm_glds8_kernel(xva_gemm_params 
 #undef XVA_BAR
     XVA_T(2);
     if constexpr (EPI != 7)         // host-checked (epi_variant): the row-contiguous epilogue serves this launch and needs no more than EPI's features
+        tile_epilogue_rows<MI, NJ, F16, EPI>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
+    else if (rows_epilogue_ok(p, vec_epi))
+        tile_epilogue_rows<MI, NJ, F16>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
+    else
+        tile_epilogue<MI, NJ, F16>(p, acc, vec_epi, m0 + wm * WM + (lane & 15), n0 + wn * WN + (lane >> 4) * 4, z1, z2, bz, ks);
+    XVA_T(3);
+}
+
+// ---- 256 x 256 tile, staggered wave groups, WHOLE-LINE DMA pieces (NT) -----------------------------------------------------------------------
+// The loop of xva_gemm_glds8_kernel for two K-contiguous operands (NT), with one change in how the operands reach the LDS.  There a DMA piece (one
+// global_load_lds_dwordx4 of a wave, 1 KiB) gathers 16 rows x 64 bytes — a 32-deep bf16 K tile — and the CU's address unit spends one cycle per 128-byte line a
+// piece touches: 16 per piece, 64 B/clk (tools/dma_issue_probe.hip: 130 ticks per piece with eight waves issuing, against 86 for 8 rows x 128 bytes).  Four waves of
+// a group issue their 16 pieces into one address unit, so the read slot of the staggered loop carried ~300 cycles of DMA issue (profiles/r06_kloop_ablation.txt) and
+// was longer than the other group's 32 MFMAs.  Here a piece is 8 rows x 128 bytes (whole lines, the 64-deep image of xva_gemm_glds_kernel: Loader / KcReader), the
+// ring holds FIVE 32 KiB units — one operand's 256 rows x 64 k each, in the order A(p), B(p), A(p + 1), ... — and a 32-deep phase reads one 64-byte half of its
+// pair's rows.  A pair is consumed over two tiles; the units of pair p - 1 are free from tile 2p on, so tile i issues unit i + 3 (even tiles a B unit — the
+// weights, warm in L2 — one tile-time before its first reader; odd tiles an A unit two tile-times ahead).  Host-checked (launch_tile8): NT, K % 64 == 0, tap
+// segments of A a multiple of 64 (or none), no planes, no K blocks.
+template <bool F16 = false, int EPI = 7>
+__global__ __launch_bounds__(512, 1) void xva_gemm_glds8w_kernel(xva_gemm_params p, int vec_flags) {
+    const int vec_epi = vec_flags & 15, nt_store = vec_flags >> 4;
+    constexpr int BM = 256, BN = 256, WM = 128, WN = 64;
+    constexpr int NWN = BN / WN, NW = 8;
+    constexpr int MI = WM / 16, NJ = WN / 16;
+    constexpr int UNIT = 256 * 128, NU = 5;                      // 32 KiB per operand pair-unit; five of them = all 160 KiB
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem_raw[];
+    XVA_LDS uint8_t* smem = (XVA_LDS uint8_t*)smem_raw;
+
+    const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
+    int Lg;
+    {
+        const unsigned total = gridDim.x, id = blockIdx.x;
+        const unsigned xcd = id & 7u, slot = id >> 3, q = total >> 3, r = total & 7u;
+        Lg = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot);
+    }
+    const int tn = Lg % nbx, tm = (Lg / nbx) % nby, z = Lg / (nbx * nby);
+    const int bz = z / p.splitk, ks = z - bz * p.splitk;
+    const int b2n = p.batch2 > 1 ? p.batch2 : 1;
+    const int z1 = bz / b2n, z2 = bz - z1 * b2n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + (int64_t)z1 * p.sA + (int64_t)z2 * p.sA2;
+    const uint16_t* B = reinterpret_cast<const uint16_t*>(p.B) + (int64_t)z1 * p.sB + (int64_t)z2 * p.sB2;
+
+    const int npair = p.K / 64;                                  // host-checked: K % 64 == 0
+    const int per = (npair + p.splitk - 1) / p.splitk;
+    const int pb = ks * per, pe = min(npair, pb + per);
+    const int ntl = pe > pb ? 2 * (pe - pb) : 0;                 // 32-deep tiles of this workgroup
+    const int nun = ntl;                                         // units (one A and one B per pair)
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int grp = wave >> 2;
+    XVA_T(0);
+
+    Loader<KC, BM, NW> la;
+    Loader<KC, BN, NW> lb;
+    la.init(lane, wave, m0, p.M, p.lda, 0, 0, 0, p.a_seglen, p.a_segadj);
+    lb.init(lane, wave, n0, p.N, p.ldb, 0, 0, 0);
+    // operand bases of the next A / B unit to issue
+    const int k0 = pb * 64;
+    const uint16_t* nA = A + k0 + (p.a_seglen > 0 ? (int64_t)(k0 / p.a_seglen) * p.a_segadj : 0);
+    const uint16_t* nB = B + k0;
+    int n_akin = p.a_seglen > 0 ? k0 % p.a_seglen : 0;
+    const int a_seg = p.a_seglen > 0 ? p.a_seglen : 0x7fffffff;
+    auto issue_unit = [&](int u) {                               // u: local unit index (even: A of pair u / 2, odd: B); slot u % 5
+        XVA_LDS uint8_t* st = smem + (u % NU) * UNIT;
+        if (u & 1) { lb.issue_full(nB, st, wave); nB += 64; }
+        else {
+            la.issue_full(nA, st, wave);
+            n_akin += 64;
+            const bool cross = n_akin >= a_seg;
+            n_akin = cross ? n_akin - a_seg : n_akin;
+            nA += 64 + (cross ? p.a_segadj : (int64_t)0);
+        }
+    };
+    KcReader kra, krb;
+    kra.init(lane); krb.init(lane);
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int UL = Loader<KC, BM, NW>::NI;                    // DMA pieces per wave per unit (4)
+    static_assert(UL == 4 && Loader<KC, BN, NW>::NI == 4, "vmcnt immediates below");
+#define XVA_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    {   // prologue: units 0 .. 4; units 0 and 1 (the first pair) have to land
+        const int n0u = nun < NU ? nun : NU;
+        for (int u = 0; u < n0u; ++u) issue_unit(u);
+        if (n0u >= 5) __builtin_amdgcn_s_waitcnt(0x0F70 | 12); else if (n0u == 4) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+        else if (n0u == 3) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    XVA_BAR();
+    if (grp == 1) XVA_BAR();                                     // group 1 runs one barrier behind group 0
+    XVA_T(1);
+    int ua = 0;                                                  // slot of the current pair's A unit (0 .. 4); its B unit sits in the next slot
+    for (int i = 0; i < ntl; ++i) {
+        const int h = i & 1;
+        const XVA_LDS uint8_t* At = smem + ua * UNIT;
+        const XVA_LDS uint8_t* Bt = smem + (ua == NU - 1 ? 0 : ua + 1) * UNIT;
+        Frag<KC> afr[MI], bfrr[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfrr[j] = krb.read(Bt, wn * WN + j * 16, h);
+#pragma unroll
+        for (int i2 = 0; i2 < MI; ++i2) afr[i2] = kra.read(At, wm * WM + i2 * 16, h);
+        // tile i >= 2 issues unit i + 3 (the slot of unit i - 2, whose pair every reader has left); an odd tile then waits for the next pair's units (<= i + 2)
+        const bool more = !(XVA_GLDS_ABLATE & 2) && i + 3 < nun;
+        if (i >= 2 && more) issue_unit(i + 3);
+        if (h) { if (more) __builtin_amdgcn_s_waitcnt(0x0F70 | UL); else __builtin_amdgcn_s_waitcnt(0x0F70); }
+        bf16x8 af[MI], bfr[NJ];
+#pragma unroll
+        for (int i2 = 0; i2 < MI; ++i2) af[i2] = frag_value(afr[i2]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = frag_value(bfrr[j]);
+        if (p.a_lrelu) {
+#pragma unroll
+            for (int i2 = 0; i2 < MI; ++i2) af[i2] = lrelu_frag<F16>(af[i2], p.a_slope);
+        }
+        if (p.b_lrelu) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[j] = lrelu_frag<F16>(bfr[j], p.b_slope);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+        XVA_BAR();
+        if constexpr (XVA_GLDS_ABLATE & 1) {
+#pragma unroll
+            for (int i2 = 0; i2 < MI; ++i2) asm volatile("" :: "v"(af[i2]));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(bfr[j]));
+        } else {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i2 = 0; i2 < MI; ++i2)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i2][j] = mma16<F16>(bfr[j], af[i2], acc[i2][j]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        XVA_BAR();
+        if (h) ua = ua + 2 >= NU ? ua + 2 - NU : ua + 2;
+    }
+    if (grp == 0) XVA_BAR();
+#undef XVA_BAR
+    XVA_T(2);
+    if constexpr (EPI != 7)
         tile_epilogue_rows<MI, NJ, F16, EPI>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
     else if (rows_epilogue_ok(p, vec_epi))
         tile_epilogue_rows<MI, NJ, F16>(p, acc, reinterpret_cast<XVA_LDS float*>(smem + wave * epi_scratch_bytes(WN)), m0 + wm * WM, n0 + wn * WN, lane, z1, z2, bz, ks, nt_store);
@@ -1430,6 +1590,31 @@ inline int launch_tile8(const xva_gemm_params& p, int vec_epi, hipStream_t st) {
     static bool a0 = false, a1 = false, a3 = false, a7 = false;
     static bool a9 = false, a11 = false;
     const int ev = epi_variant(p, vec_epi, F16);
+    if constexpr (LAYOUT == XVA_GEMM_NT && BM == 256 && BN == 256) {
+        // two K-contiguous operands: the loop with whole-line DMA pieces (xva_gemm_glds8w_kernel) whenever the geometry allows
+        if (xva_gemm_glds_wholeline() && p.K % 64 == 0 && !p.planes && p.kb_len == 0 && (p.a_seglen == 0 || p.a_seglen % 64 == 0)) {
+            constexpr int LDSW = 5 * 256 * 128;
+            auto gow = [&](auto kern, bool& attr_set) {
+                if (!attr_set) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW) != hipSuccess) return -1;
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(512), LDSW, st, p, vec_epi);
+                return 0;
+            };
+            static bool w0 = false, w1 = false, w3 = false, w7 = false, w9 = false, w11 = false;
+            if constexpr (F16) {
+                if (ev == 9) return gow(xva_gemm_glds8w_kernel<F16, 9>, w9);
+                if (ev == 11) return gow(xva_gemm_glds8w_kernel<F16, 11>, w11);
+            }
+            switch (ev) {
+                case 0: return gow(xva_gemm_glds8w_kernel<F16, 0>, w0);
+                case 1: return gow(xva_gemm_glds8w_kernel<F16, 1>, w1);
+                case 3: return gow(xva_gemm_glds8w_kernel<F16, 3>, w3);
+                default: return gow(xva_gemm_glds8w_kernel<F16, 7>, w7);
+            }
+        }
+    }
     if constexpr (F16) {
         if (ev == 9) return go(xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16, 9>, a9);
         if (ev == 11) return go(xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN, F16, 11>, a11);

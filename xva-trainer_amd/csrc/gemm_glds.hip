@@ -118,6 +118,11 @@ static int g_kloop8_v = 1;
 extern "C" int xva_gemm_set_kloop(int mode) { int old = g_kloop8_v; g_kloop8_v = mode; return old; }
 int xva_gemm_glds_kloop8() { return g_kloop8_v; }
 // K loop of the 384 x 128 tile: 1 (default) = the staggered loop, 0 = the lock-step loop of xva_gemm_glds_kernel.
+// NT products on the 256 x 256 tile: 1 (default) = whole-line DMA pieces over a ring of five operand units (xva_gemm_glds8w_kernel), 0 = the 32-deep tiles of
+// xva_gemm_glds8_kernel for every layout
+static int g_wholeline_v = XVA_GLDS8_WHOLE;
+extern "C" int xva_gemm_set_wholeline(int mode) { int old = g_wholeline_v; g_wholeline_v = mode; return old; }
+namespace xva_glds { int xva_gemm_glds_wholeline() { return g_wholeline_v; } }
 static int g_kloop384_v = 1;
 extern "C" int xva_gemm_set_kloop384(int mode) { int old = g_kloop384_v; g_kloop384_v = mode; return old; }
 int xva_gemm_glds_kloop384() { return g_kloop384_v; }
