@@ -379,7 +379,7 @@ def pmc_traffic(family, pmc_csv):
     m = re.match(r"xva_gemm_glds_kernel<(\d+)x(\d+)>", family)
     if m:
         # both K loops of a tile: the lock-step kernel and the staggered one (xva_gemm_glds8_kernel<LAYOUT, BM, BN, WM, WN>: 256x256 and 384x128)
-        pat = re.compile(r"xva_gemm_glds8?_kernel<\d, %s, %s," % (m.group(1), m.group(2)))
+        pat = re.compile(r"xva_gemm_glds8?_kernel<\d, %s, %s," % (m.group(1), m.group(2)) + (r"|xva_gemm_glds8w_kernel<" if m.group(1) == m.group(2) == "256" else ""))   # (8w: the NT 256x256 loop with whole-line DMA pieces)
     elif family.startswith("xva_conv_res_kernel<CIN="):
         pat = re.compile(r"xva_conv_res_kernel<\d, %s," % family[len("xva_conv_res_kernel<CIN="):-1])
     elif family.startswith("xva_wgrad_res_kernel"):
@@ -465,7 +465,7 @@ def gemm_roofline(run, nprof, bound, peak, note, pmc_csv=None):
     res = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
            "traffic_unit": ("HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE; offline passes over this workload: %s)" % traffic_src) if traffic
                            else traffic_src,
-           "kernel": name + (" (direct-to-LDS MFMA implicit-convolution GEMM, all layouts; 256x256: xva_gemm_glds8_kernel, the staggered K loop)" if "glds" in name else
+           "kernel": name + (" (direct-to-LDS MFMA implicit-convolution GEMM, all layouts; 256x256: xva_gemm_glds8_kernel / xva_gemm_glds8w_kernel, the staggered K loop)" if "glds" in name else
                              (" (resident-input MFMA convolution, forward + backward-data)" if "conv_res" in name else
                               (" (resident-operand MFMA convolution weight gradient)" if "wgrad_res" in name else ""))),
            "launches_per_step": f[0] / nprof, "avg_launch_us": 1e3 * f[1] / f[0], "kernel_ms_per_step": f[1] / nprof,
@@ -1353,7 +1353,7 @@ def main():
                                         pmc_csv=latest_profile("fastpitch_pmc_hbm_bytes.csv") if a.compute == "bf16" else None)
         if a.compute == "bf16" and "256x256" in out["roofline"]["kernel"]:
             # the same family's fraction from the committed rocprofv3 kernel trace (no event-pair overhead in the duration)
-            fr, why = rocprof_frac(r"xva_gemm_glds8_kernel<\d, 256, 256,", out["roofline"]["algorithmic_gflop_per_launch"] * 1e9,
+            fr, why = rocprof_frac(r"xva_gemm_glds8_kernel<\d, 256, 256,|xva_gemm_glds8w_kernel<", out["roofline"]["algorithmic_gflop_per_launch"] * 1e9,
                                    latest_profile("fastpitch_only_serial_lanes_kernel_stats.csv"))
             out["roofline"]["frac_rocprof"] = fr["frac"] if fr else None
             out["roofline"]["frac_rocprof_detail"] = fr if fr else why
