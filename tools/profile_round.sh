@@ -85,4 +85,5 @@ cd $R && XVA_FP_STREAMS=1 XVA_TOP=60 python tools/fp_gemm_profile.py 2>/dev/null
 cd $R && XVA_FP_STREAMS=1 XVA_TOP=70 XVA_FP_MODE=f16 python tools/fp_gemm_profile.py 2>/dev/null > $O/${RD}_fastpitch_gemm_profile_f16.txt
 # global -> LDS DMA by gather shape (half lines / whole lines / half-line pairs back to back), and the staggered K loop's ablations
 hipcc --offload-arch=gfx950 -O3 -w $R/tools/dma_pattern_probe.hip -o $R/build/dma_probe 2>/dev/null && $R/build/dma_probe > $O/${RD}_dma_pattern_probe.txt
+hipcc --offload-arch=gfx950 -O3 -w $R/tools/dma_issue_probe.hip -o $R/build/dma_issue 2>/dev/null && $R/build/dma_issue > $O/${RD}_dma_issue_probe.txt
 for a in 0 1 2 3 32; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DXVA_GLDS_TIMING -DXVA_GLDS_ABLATE=$a -I$R/xva-trainer_amd/csrc -I$R/include $R/tools/glds_timing.hip $R/xva-trainer_amd/csrc/core.hip -o $R/build/glds_timing_a 2>/dev/null && echo "XVA_GLDS_ABLATE=$a (1: no MFMAs, 2: no DMA, 32: vmcnt waits one tile looser)" && $R/build/glds_timing_a 0 | grep "staggered blocks   648"; done > $O/${RD}_kloop_ablation_raw.txt
